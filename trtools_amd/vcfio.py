@@ -1,0 +1,482 @@
+"""
+Host-side VCF text reader / writer.
+
+The reference delegates all VCF decoding to cyvcf2/htslib
+(trtools/utils/utils.py:19-67 ``LoadSingleReader`` -> ``cyvcf2.VCF``); what
+reaches the hot path is a handful of ``cyvcf2.Variant`` attributes
+(SURVEY.md section 1, section 8b).  This module decodes VCF 4.x text (plain,
+gzip or bgzip) into the same arrays with the same conventions, so that the
+batch packer and the TRRecord facade see what they would see from cyvcf2:
+
+* ``Variant.genotype.array()``  int16 ``[S, maxploidy+1]``; ``-1`` missing
+  haplotype, ``-2`` ploidy padding, last column = phased bit
+  (consumed at tr_harmonizer.py:860-862);
+* ``Variant.format(key)``  Integer -> int32 ``[S,k]`` (missing ``INT_MIN``,
+  short vectors padded with ``INT_MIN+1``), Float -> float32 (missing nan),
+  String -> ``<U`` array ``[S]``; ``KeyError`` when the key is not in FORMAT
+  (consumed through tr_harmonizer.py:561-588);
+* ``Variant.INFO`` typed per the header (Integer -> int, Float -> float32
+  rounded float, String -> str, multi-valued -> tuple, Flag -> True).
+
+It is host plumbing (a native block-parallel parser is SURVEY.md section 8f
+row 1), not part of the device hot path.
+"""
+import gzip
+import os
+import re
+
+import numpy as np
+
+INT_MISSING = -2147483648
+INT_VECTOR_END = -2147483647
+
+_HDR_RE = re.compile(r'^##(\w+)=<(.*)>\s*$')
+
+
+def _split_header_fields(body):
+    """Split ``ID=x,Number=1,Description="a, b"`` respecting quotes."""
+    out = {}
+    key, val, inq, cur = None, [], False, []
+    i = 0
+    n = len(body)
+    while i < n:
+        c = body[i]
+        if key is None:
+            if c == '=':
+                key = ''.join(cur).strip()
+                cur = []
+            else:
+                cur.append(c)
+        else:
+            if c == '"' and (i == 0 or body[i - 1] != '\\'):
+                inq = not inq
+            elif c == ',' and not inq:
+                out[key] = ''.join(cur)
+                key, cur = None, []
+            else:
+                cur.append(c)
+        i += 1
+    if key is not None:
+        out[key] = ''.join(cur)
+    return out
+
+
+class _Genotype:
+    """Stand-in for ``cyvcf2.Variant.genotype`` (array(), n_samples)."""
+
+    def __init__(self, arr):
+        self._arr = arr
+        self.n_samples = arr.shape[0]
+
+    def array(self):
+        return self._arr
+
+
+class _Info:
+    """dict-like INFO with cyvcf2's ``get`` / ``[]`` / ``[]=`` / iteration."""
+
+    def __init__(self, pairs):
+        self._d = dict(pairs)
+        self._order = [k for k, _ in pairs]
+
+    def get(self, key, default=None):
+        return self._d.get(key, default)
+
+    def __getitem__(self, key):
+        return self._d[key]
+
+    def __setitem__(self, key, value):
+        if key not in self._d:
+            self._order.append(key)
+        self._d[key] = value
+
+    def __contains__(self, key):
+        return key in self._d
+
+    def __iter__(self):
+        return iter([(k, self._d[k]) for k in self._order])
+
+    def keys(self):
+        return list(self._order)
+
+
+class Variant:
+    """One VCF record with the cyvcf2.Variant surface the hot path touches."""
+
+    __slots__ = ('_reader', '_fields', 'CHROM', 'POS', 'ID', 'REF', 'ALT', 'QUAL',
+                 '_filter', 'INFO', 'FORMAT', '_samples', '_cols', '_fmt_cache',
+                 '_gt', 'ploidy', '_set_formats', '_info_dirty')
+
+    def __init__(self, reader, line):
+        f = line.rstrip('\r\n').split('\t')
+        self._reader = reader
+        self._fields = f
+        self.CHROM = f[0]
+        self.POS = int(f[1])
+        self.ID = None if f[2] == '.' else f[2]
+        self.REF = f[3]
+        self.ALT = [] if f[4] == '.' else f[4].split(',')
+        self.QUAL = None if f[5] == '.' else float(f[5])
+        self._filter = None if f[6] in ('.', 'PASS') else f[6]
+        self.INFO = _Info(reader._parse_info(f[7]))
+        if len(f) > 8:
+            self.FORMAT = f[8].split(':')
+            self._samples = f[9:]
+        else:
+            self.FORMAT = []
+            self._samples = []
+        self._cols = None
+        self._fmt_cache = {}
+        self._set_formats = {}
+        self._gt = None
+        self.ploidy = 2
+        if reader.n_samples and 'GT' in self.FORMAT:
+            self._decode_gt()
+
+    # ---- FILTER (cyvcf2: None when PASS or '.') ----
+    @property
+    def FILTER(self):
+        return self._filter
+
+    @FILTER.setter
+    def FILTER(self, value):
+        self._filter = value
+
+    # ---- per-sample columns ----
+    def _columns(self):
+        if self._cols is None:
+            nf = len(self.FORMAT)
+            cols = [[] for _ in range(nf)]
+            for s in self._samples:
+                parts = s.split(':')
+                np_ = len(parts)
+                for i in range(nf):
+                    cols[i].append(parts[i] if i < np_ else '.')
+            self._cols = cols
+        return self._cols
+
+    def _decode_gt(self):
+        gi = self.FORMAT.index('GT')
+        if gi == 0:
+            raw = [s.split(':', 1)[0] for s in self._samples]
+        else:
+            raw = self._columns()[gi]
+        split = []
+        maxp = 1
+        for g in raw:
+            phased = '|' in g
+            al = g.replace('|', '/').split('/')
+            if len(al) > maxp:
+                maxp = len(al)
+            split.append((al, phased))
+        arr = np.full((len(raw), maxp + 1), -2, dtype=np.int16)
+        for i, (al, phased) in enumerate(split):
+            for j, a in enumerate(al):
+                arr[i, j] = -1 if a == '.' else int(a)
+            arr[i, maxp] = 1 if phased else 0
+        self._gt = arr
+        self.ploidy = maxp
+
+    @property
+    def genotype(self):
+        if self._gt is None:
+            return None
+        return _Genotype(self._gt)
+
+    @property
+    def genotypes(self):
+        """cyvcf2 ``Variant.genotypes``: list of [a0, a1, ..., phased]."""
+        if self._gt is None:
+            return []
+        p = self._gt.shape[1] - 1
+        return [[int(x) for x in row[:p]] + [bool(row[p])] for row in self._gt]
+
+    @genotypes.setter
+    def genotypes(self, value):
+        p = max(len(v) - 1 for v in value)
+        arr = np.full((len(value), p + 1), -2, dtype=np.int16)
+        for i, v in enumerate(value):
+            for j, a in enumerate(v[:-1]):
+                arr[i, j] = a
+            arr[i, p] = 1 if v[-1] else 0
+        self._gt = arr
+        self.ploidy = p
+
+    def set_gt_array(self, arr):
+        """Replace the genotype matrix (int16 [S, P+1], cyvcf2 layout)."""
+        self._gt = np.asarray(arr, dtype=np.int16)
+        self.ploidy = self._gt.shape[1] - 1
+
+    def format(self, key):
+        if key in self._set_formats:
+            return self._set_formats[key]
+        if key not in self.FORMAT:
+            raise KeyError(key)
+        if key in self._fmt_cache:
+            return self._fmt_cache[key]
+        col = self._columns()[self.FORMAT.index(key)]
+        typ = self._reader.format_types.get(key, ('String', '1'))[0]
+        if key == 'GT':
+            out = np.array(col)
+        elif typ == 'Integer':
+            out = self._numeric(col, np.int32, INT_MISSING, INT_VECTOR_END, int)
+        elif typ == 'Float':
+            out = self._numeric(col, np.float32, np.nan, np.nan, float)
+        else:
+            out = np.array(col) if len(col) else np.array([], dtype='<U1')
+        self._fmt_cache[key] = out
+        return out
+
+    @staticmethod
+    def _numeric(col, dtype, missing, pad, conv):
+        n = len(col)
+        simple = True
+        for v in col:
+            if ',' in v:
+                simple = False
+                break
+        if simple:
+            out = np.empty((n, 1), dtype=dtype)
+            for i, v in enumerate(col):
+                out[i, 0] = missing if v == '.' else conv(v)
+            return out
+        parts = [v.split(',') for v in col]
+        k = max(len(p) for p in parts)
+        out = np.full((n, k), pad, dtype=dtype)
+        for i, p in enumerate(parts):
+            for j, v in enumerate(p):
+                out[i, j] = missing if v == '.' else conv(v)
+        return out
+
+    def set_format(self, key, arr):
+        if key not in self.FORMAT:
+            self.FORMAT = list(self.FORMAT) + [key]
+        self._set_formats[key] = arr
+
+    # ---- text ----
+    def _format_value(self, key, i):
+        if key == 'GT':
+            row = self._gt[i]
+            p = len(row) - 1
+            sep = '|' if row[p] else '/'
+            toks = ['.' if a == -1 else str(int(a)) for a in row[:p] if a != -2]
+            return sep.join(toks) if toks else '.'
+        arr = self.format(key)
+        v = arr[i]
+        if arr.dtype.kind in 'US':
+            s = v.decode() if isinstance(v, bytes) else str(v)
+            return s if s != '' else '.'
+        toks = []
+        for x in np.atleast_1d(v):
+            if arr.dtype.kind == 'i':
+                if x == INT_VECTOR_END:
+                    break
+                toks.append('.' if x == INT_MISSING else str(int(x)))
+            else:
+                toks.append('.' if np.isnan(x) else _fmt_float(float(x)))
+        return ','.join(toks) if toks else '.'
+
+    def _info_text(self):
+        toks = []
+        for k, v in self.INFO:
+            if v is True:
+                toks.append(k)
+            elif isinstance(v, (tuple, list)):
+                toks.append(k + '=' + ','.join(_fmt_info(x) for x in v))
+            else:
+                toks.append(k + '=' + _fmt_info(v))
+        return ';'.join(toks) if toks else '.'
+
+    def __str__(self):
+        f = self._fields
+        filt = 'PASS' if self._filter is None and f[6] != '.' else (self._filter or f[6])
+        if self._filter is not None:
+            filt = self._filter
+        head = [self.CHROM, str(self.POS), self.ID or '.', self.REF,
+                ','.join(self.ALT) if self.ALT else '.', f[5], filt, self._info_text()]
+        if not self.FORMAT:
+            return '\t'.join(head) + '\n'
+        head.append(':'.join(self.FORMAT))
+        n = len(self._samples)
+        for i in range(n):
+            head.append(':'.join(self._format_value(k, i) for k in self.FORMAT))
+        return '\t'.join(head) + '\n'
+
+
+def _fmt_float(x):
+    s = '%g' % x
+    return s
+
+
+def _fmt_info(v):
+    if isinstance(v, float):
+        return _fmt_float(v)
+    return str(v)
+
+
+class VCFReader:
+    """Iterates ``Variant`` objects of a VCF file (plain / gzip / bgzip)."""
+
+    def __init__(self, path, lazy=False, samples=None):
+        if not os.path.exists(path) or os.path.isdir(path):
+            raise OSError("no such VCF: %s" % path)
+        self.path = path
+        with open(path, 'rb') as fh:
+            magic = fh.read(2)
+        if magic == b'\x1f\x8b':
+            self._fh = gzip.open(path, 'rt')
+        else:
+            self._fh = open(path, 'r')
+        self._header_lines = []
+        self.samples = []
+        self.info_types = {}
+        self.format_types = {}
+        self._pending = None
+        saw_chrom = False
+        for line in self._fh:
+            if line.startswith('##'):
+                self._header_lines.append(line.rstrip('\r\n'))
+                self._register(line)
+            elif line.startswith('#CHROM'):
+                cols = line.rstrip('\r\n').split('\t')
+                self.samples = cols[9:]
+                self._chrom_line = line.rstrip('\r\n')
+                saw_chrom = True
+                break
+            else:
+                break
+        if not saw_chrom:
+            raise OSError("%s does not look like a VCF (no #CHROM line)" % path)
+        self.n_samples = len(self.samples)
+        self._region = None
+
+    # -- header --
+    def _register(self, line):
+        m = _HDR_RE.match(line)
+        if not m:
+            return
+        kind, body = m.group(1), m.group(2)
+        d = _split_header_fields(body)
+        if kind == 'INFO':
+            self.info_types[d.get('ID')] = (d.get('Type'), d.get('Number'))
+        elif kind == 'FORMAT':
+            self.format_types[d.get('ID')] = (d.get('Type'), d.get('Number'))
+
+    @property
+    def raw_header(self):
+        return '\n'.join(self._header_lines + [self._chrom_line]) + '\n'
+
+    def header_iter(self):
+        for line in self._header_lines:
+            m = _HDR_RE.match(line)
+            if not m:
+                continue
+            d = _split_header_fields(m.group(2))
+            d['HeaderType'] = m.group(1) if m.group(1) in ('INFO', 'FORMAT', 'FILTER') \
+                else m.group(1)
+            if 'Description' in d:
+                d['Description'] = d['Description']
+            yield _HeaderRec(d)
+
+    def add_to_header(self, line):
+        self._header_lines.append(line.rstrip('\n'))
+        self._register(line)
+
+    def add_info_to_header(self, d):
+        self.add_to_header('##INFO=<ID={ID},Number={Number},Type={Type},'
+                           'Description="{Description}">'.format(**d))
+
+    def add_format_to_header(self, d):
+        self.add_to_header('##FORMAT=<ID={ID},Number={Number},Type={Type},'
+                           'Description="{Description}">'.format(**d))
+
+    def add_filter_to_header(self, d):
+        self.add_to_header('##FILTER=<ID={ID},Description="{Description}">'.format(**d))
+
+    # -- INFO parsing --
+    def _parse_info(self, text):
+        pairs = []
+        if text == '.' or text == '':
+            return pairs
+        for tok in text.split(';'):
+            if not tok:
+                continue
+            if '=' not in tok:
+                pairs.append((tok, True))
+                continue
+            k, v = tok.split('=', 1)
+            typ = self.info_types.get(k, ('String', '.'))[0]
+            if typ == 'Integer':
+                vals = [int(x) if x != '.' else None for x in v.split(',')]
+                pairs.append((k, vals[0] if len(vals) == 1 else tuple(vals)))
+            elif typ == 'Float':
+                vals = [float(np.float32(x)) if x != '.' else None for x in v.split(',')]
+                pairs.append((k, vals[0] if len(vals) == 1 else tuple(vals)))
+            elif typ == 'Flag':
+                pairs.append((k, True))
+            else:
+                pairs.append((k, v))
+        return pairs
+
+    # -- iteration --
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        while True:
+            line = self._fh.readline()
+            if not line:
+                raise StopIteration
+            if line.strip() == '':
+                continue
+            v = Variant(self, line)
+            if self._region is not None and not self._in_region(v):
+                continue
+            return v
+
+    def __call__(self, region):
+        """Region query ``chrom[:start-end]`` (linear scan; 1-based inclusive)."""
+        chrom, start, end = region, None, None
+        if ':' in region:
+            chrom, rng = region.split(':', 1)
+            a, b = rng.replace(',', '').split('-')
+            start, end = int(a), int(b)
+        self._region = (chrom, start, end)
+        return self
+
+    def _in_region(self, v):
+        chrom, start, end = self._region
+        if v.CHROM != chrom:
+            return False
+        if start is None:
+            return True
+        vend = v.POS + len(v.REF) - 1
+        return vend >= start and v.POS <= end
+
+    def close(self):
+        self._fh.close()
+
+
+class _HeaderRec(dict):
+    """``header_iter()`` element: dict with ``['HeaderType']`` etc. (cyvcf2 HREC)."""
+
+    def info(self):
+        return dict(self)
+
+
+class VCFWriter:
+    """Plain-text VCF writer (``cyvcf2.Writer`` stand-in: write_record, close)."""
+
+    def __init__(self, path, template):
+        self.path = path
+        if path.endswith('.gz'):
+            self._fh = gzip.open(path, 'wt')
+        else:
+            self._fh = open(path, 'w')
+        self._fh.write(template.raw_header)
+
+    def write_record(self, variant):
+        self._fh.write(str(variant))
+
+    def close(self):
+        self._fh.close()
