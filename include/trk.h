@@ -1,0 +1,313 @@
+/*
+ * trk.h -- C ABI of libtrk.so: the MI355X (gfx950) implementation of the
+ * TRTools per-locus hot path (tr_harmonizer.TRRecord reductions -> statSTR
+ * statistics / dumpSTR call filters, sample counters and locus filters).
+ *
+ * The reference (gymrek-lab/TRTools v6.1.0) is pure Python and has no FFI seam;
+ * its "operator API" for this path is the Python surface
+ *   trtools/utils/tr_harmonizer.py  TRRecord.Get{CalledSamples,CallRate,
+ *       AlleleCounts,AlleleFreqs,GenotypeCounts,MaxAllele}      (:864-1575)
+ *   trtools/utils/utils.py          Get{Heterozygosity,Entropy,Mean,Mode,
+ *       Variance,HardyWeinbergBinomialTest}                      (:118-338)
+ *   trtools/dumpSTR/filters.py      call-level Reason classes    (:327-867)
+ *                                   locus-level Filter_* classes (:35-217)
+ *   trtools/dumpSTR/dumpSTR.py      ApplyCallFilters :613-774, ApplyLocusFilters
+ *                                   :917-973, INFO recompute :1304-1336.
+ * Those methods are called once per VCF record; the entry points below are
+ * their batched equivalents (one call per batch of L loci) and are what a
+ * ctypes binding inside the reference would bind (INTEGRATION.md shows it).
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 (TRK_OK) or an
+ *     error code, the message is available from trk_last_error(); nothing
+ *     throws across the ABI.
+ *   - all array pointers in trk_batch / trk_*_out are DEVICE pointers obtained
+ *     from trk_dev_alloc (or any hipMalloc'ed memory of the same device),
+ *     16-byte aligned, C-contiguous.  Host staging is explicit through
+ *     trk_memcpy_h2d / trk_memcpy_d2h (PCIe cost is never hidden).
+ *   - one in-flight call per trk_ctx; calls are asynchronous on the context's
+ *     HIP stream, trk_sync() / trk_memcpy_d2h() synchronise.
+ *   - genotype sentinels are cyvcf2's: -1 missing haplotype, -2 ploidy padding
+ *     (tr_harmonizer.py:829-862).
+ */
+#ifndef TRK_H
+#define TRK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct trk_ctx trk_ctx;
+
+enum {
+    TRK_OK = 0,
+    TRK_ERR_HIP = 1,     /* a HIP runtime call failed                            */
+    TRK_ERR_ARG = 2,     /* invalid argument                                      */
+    TRK_ERR_NOMEM = 3,   /* device allocation failed                              */
+    TRK_ERR_RCCL = 4,    /* RCCL missing or a collective failed                   */
+    TRK_ERR_DATA = 5     /* the data violates a reference invariant (see docs)    */
+};
+
+/* ---- context ------------------------------------------------------------ */
+
+/* Create a context on HIP device `device` (one context per process per GPU). */
+int trk_init(int device, trk_ctx** out);
+void trk_free(trk_ctx* ctx);
+/* Last error message of this context (ctx may be NULL: last init error).     */
+const char* trk_last_error(trk_ctx* ctx);
+/* 1 = HIP/gfx950.  There is no CPU backend in this library.                  */
+int trk_backend(trk_ctx* ctx);
+int trk_device_count(int* n);
+int trk_device_info(trk_ctx* ctx, char* name, int name_len, int* n_cu,
+                    uint64_t* hbm_bytes, char* arch, int arch_len);
+
+/* ---- device memory / staging -------------------------------------------- */
+int trk_dev_alloc(trk_ctx* ctx, size_t bytes, void** dptr);
+int trk_dev_free(trk_ctx* ctx, void* dptr);
+int trk_memcpy_h2d(trk_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int trk_memcpy_d2h(trk_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int trk_memset(trk_ctx* ctx, void* dst_dev, int value, size_t bytes);
+int trk_sync(trk_ctx* ctx);
+
+/* ---- timing on the context's stream (HIP events) ------------------------ */
+/* Slots 0..TRK_N_TIMERS-1.  start/stop enqueue events on the compute stream;
+ * elapsed synchronises on the stop event and returns milliseconds.           */
+#define TRK_N_TIMERS 16
+int trk_timer_start(trk_ctx* ctx, int slot);
+int trk_timer_stop(trk_ctx* ctx, int slot);
+int trk_timer_elapsed_ms(trk_ctx* ctx, int slot, float* ms);
+
+/* Per-kernel profiling: when enabled every kernel launch is bracketed by HIP
+ * events on the compute stream; trk_profile_get drains them (synchronises).  */
+enum {
+    TRK_K_LOCUS_COUNT = 0,   /* genotype-matrix reduction (allele histograms)  */
+    TRK_K_LOCUS_FINALIZE = 1,
+    TRK_K_CALL_FILTER = 2,
+    TRK_K_LOCUS_FILTER = 3,
+    TRK_K_SYNTH = 4,
+    TRK_K_COUNT = 5
+};
+int trk_profile_enable(trk_ctx* ctx, int on);
+int trk_profile_get(trk_ctx* ctx, int kernel, int64_t* n_launches, double* total_ms);
+int trk_profile_reset(trk_ctx* ctx);
+
+/* ---- batch of loci -------------------------------------------------------
+ * Replaces, for L records at once, what TRRecord.__init__ precomputes per
+ * record (tr_harmonizer.py:693-773) plus cyvcf2's genotype.array():
+ *   gt            allele INDICES, [L, S, P] int16 (phase column dropped)
+ *   locus_ploidy  max ploidy of each record (vcfrecord.ploidy), <= P; columns
+ *                 >= locus_ploidy[l] are ignored.  NULL -> all loci have P.
+ *   allele_off    [L+1] prefix offsets into the per-allele tables
+ *                 (A_l = allele_off[l+1]-allele_off[l] = 1 + #ALT)
+ *   len_class     [sumA] rank of the allele's length among the locus's
+ *                 distinct lengths, ascending      (GetLengthGenotypes :1239)
+ *   str_class     [sumA] rank of the allele's (trimmed, upper-cased) sequence
+ *                 among the locus's distinct sequences, in numpy '<U' order
+ *                 (GetStringGenotypes :948-961)
+ *   len_class_value [sumA] length (repeat units, float64) of length-class c of
+ *                 locus l at allele_off[l]+c
+ *   max_alleles   max_l A_l if the caller knows it (picks the LDS histogram size), else 0
+ *   group_bits    [S] bit g set -> sample belongs to sample group g
+ *                 (statSTR --samples, statSTR.py:520-542); NULL -> one group
+ *                 holding every sample.  n_groups <= 8.
+ */
+typedef struct {
+    int32_t n_loci;
+    int32_t n_samples;
+    int32_t ploidy;
+    int32_t n_groups;
+    int64_t n_alleles_total;
+    int32_t max_alleles;   /* max A_l over the batch (sizes the LDS histogram); 0 = unknown */
+    int32_t reserved0;
+    const int16_t* gt;
+    const uint8_t* locus_ploidy;
+    const int32_t* allele_off;
+    const uint16_t* len_class;
+    const uint16_t* str_class;
+    const double* len_class_value;
+    const uint8_t* group_bits;
+} trk_batch;
+
+/* integer columns of trk_stats_out.locus_int ([G, L, TRK_LI_COLS] int32) */
+enum {
+    TRK_LI_N_CALLED = 0,     /* samples with no -1 haplotype (GetCalledSamples strict;
+                                == sum(GetGenotypeCounts().values()), statSTR.py:426) */
+    TRK_LI_N_LOWPLOIDY = 1,  /* of those, samples holding a -2 haplotype                */
+    TRK_LI_N_HOM_LEN = 2,    /* num_hom of utils.py:327-333, alleles by length          */
+    TRK_LI_N_HOM_STR = 3,    /* same, alleles by sequence                               */
+    TRK_LI_N_ALLELES = 4,    /* sum of allele counts (called haplotypes)                */
+    TRK_LI_N_BAD = 5,        /* haplotypes with index >= A_l (reference: IndexError)    */
+    TRK_LI_HWE_STATUS_LEN = 6,
+    TRK_LI_HWE_STATUS_STR = 7,
+    TRK_LI_N_SAMPLES = 8,    /* samples in the group                                    */
+    TRK_LI_NALLELES_LEN = 9, /* statSTR GetNAlleles, by length / by sequence            */
+    TRK_LI_NALLELES_STR = 10,
+    TRK_LI_COLS = 12
+};
+/* values of TRK_LI_HWE_STATUS_* */
+enum {
+    TRK_HWE_OK = 0,
+    TRK_HWE_NAN = 1,          /* utils.py:323-332 returned nan                          */
+    TRK_HWE_VALUE_ERROR = 2,  /* scipy binomtest would raise ValueError (n < 1)        */
+    TRK_HWE_INDEX_ERROR = 3   /* haploid locus: IndexError at utils.py:331              */
+};
+/* float columns of trk_stats_out.locus_f64 ([G, L, TRK_LF_COLS] float64) */
+enum {
+    TRK_LF_THRESH = 0,   /* GetMaxAllele                    tr_harmonizer.py:1542 */
+    TRK_LF_MEAN = 1,     /* utils.GetMean      (by length)  utils.py:215          */
+    TRK_LF_MODE = 2,     /* utils.GetMode      (by length)  utils.py:238          */
+    TRK_LF_VAR = 3,      /* utils.GetVariance  (by length)  utils.py:273          */
+    TRK_LF_HET_LEN = 4,  /* utils.GetHeterozygosity         utils.py:142          */
+    TRK_LF_HET_STR = 5,
+    TRK_LF_ENTROPY_LEN = 6, /* utils.GetEntropy             utils.py:178          */
+    TRK_LF_ENTROPY_STR = 7,
+    TRK_LF_HWEP_LEN = 8, /* utils.GetHardyWeinbergBinomialTest utils.py:298       */
+    TRK_LF_HWEP_STR = 9,
+    TRK_LF_CALLRATE = 10,/* GetCallRate                    tr_harmonizer.py:921  */
+    TRK_LF_COLS = 12
+};
+
+typedef struct {
+    double nalleles_thresh;   /* statSTR --nalleles-thresh (statSTR.py:207)        */
+    int32_t flags;            /* TRK_STATS_* */
+    int32_t reserved;
+} trk_stats_params;
+enum {
+    TRK_STATS_COUNT_ONLY = 1  /* skip the finaliser (allele_count + first 6 ints)  */
+};
+
+typedef struct {
+    int32_t* allele_count;  /* [G, sumA] counts per allele INDEX
+                               (GetAlleleCounts(index=True), :1420-1499)           */
+    int32_t* locus_int;     /* [G, L, TRK_LI_COLS]                                 */
+    double* locus_f64;      /* [G, L, TRK_LF_COLS]                                 */
+} trk_stats_out;
+
+/* (a3)(a5)-(a9) of SURVEY.md section 8: for every locus and sample group the
+ * allele histogram and every statSTR statistic.                                  */
+int trk_locus_stats(trk_ctx* ctx, const trk_batch* in, const trk_stats_params* prm,
+                    trk_stats_out* out);
+
+/* ---- dumpSTR call-level filters ------------------------------------------ */
+enum { TRK_DT_I32 = 0, TRK_DT_F32 = 1 };
+typedef struct {
+    const void* data;   /* device [L, S, ncol]                                     */
+    int32_t dtype;      /* TRK_DT_*; int32 missing = INT_MIN, float32 missing = nan */
+    int32_t ncol;
+} trk_plane;
+
+/* Filter opcodes: one per distinct arithmetic in dumpSTR/filters.py.           */
+enum {
+    TRK_F_LT = 1,          /* CallFilterMinValue :363-367  value < thr (in the plane's dtype) */
+    TRK_F_GT = 2,          /* CallFilterMaxValue :405-409                                    */
+    TRK_F_RATIO_GT = 3,    /* HipSTRCallFlankIndels/Stutter :444-449: a/b (float64) > thr     */
+    TRK_F_CALLED_LT = 4,   /* GangSTRCallExpansionProb{Hom,Het} :597-639, HipSTRCallMinSuppReads
+                              on a host pre-parsed plane: value < thr on called samples only  */
+    TRK_F_CALLED_SUM_LT = 5,/* GangSTRCallExpansionProbTotal :665-674: (a+b in dtype) < thr   */
+    TRK_F_CALLED_EQ = 6,   /* GangSTRCallSpanOnly :686-697: a == b on called samples          */
+    TRK_F_CALLED_SUM_EQ = 7,/* GangSTRCallSpanBoundOnly :711-722: a + a2 == b                 */
+    TRK_F_CALLED_OUTSIDE_CI = 8, /* GangSTRCallBadCI :739-757: plane a = REPCN [S,P],
+                              plane b = REPCI pre-parsed to [S,2P] (lo0,hi0,lo1,hi1,..)       */
+    TRK_F_AD_SUPPORT_LT = 9 /* PopSTRCallRequireSupport :858-867: AD[s, gt[s,j]] < thr       */
+};
+typedef struct {
+    int32_t op;
+    int32_t plane_a, col_a;
+    int32_t plane_b, col_b;
+    int32_t col_a2;
+    double thr;
+} trk_call_filter;
+
+#define TRK_MAX_FILTERS 24
+#define TRK_MAX_PLANES 16
+#define TRK_MASK_NOCALL 0x80000000u
+
+typedef struct {
+    int16_t* gt_out;          /* [L,S,P] genotypes with filtered calls set to -1
+                                 (dumpSTR.py:721-727); may be NULL                 */
+    uint32_t* filter_mask;    /* [L,S] bit k = filter k fired, bit 31 = sample was a
+                                 no-call (dumpSTR.py:651); 0 == 'PASS'; may be NULL */
+    int64_t* sample_counters; /* [(1+nf), S] += : row 0 numcalls (:686-687),
+                                 row 1+k sample_info[filter k] (:661)              */
+    int64_t* sample_totaldp;  /* [S] += DP of PASS calls with DP > 0 (:707-709)    */
+    int32_t* sample_dp_missing;/* [S] += PASS calls whose DP is missing (-> nan, :710) */
+    int32_t* error;           /* [4] error[0] != 0: a PASS call had negative DP
+                                 (ValueError :698-706); error[1]=locus, [2]=sample */
+} trk_call_out;
+
+/* (a11)-(a18): evaluate `n_filters` call-level filters on every call of the
+ * batch.  `dp_plane` = index of the DP (or LC) plane used for totaldp, -1 if
+ * the records carry neither (totaldp := nan, dumpSTR.py:712-713).               */
+int trk_call_filters(trk_ctx* ctx, const trk_batch* in, const trk_plane* planes,
+                     int n_planes, const trk_call_filter* filters, int n_filters,
+                     int dp_plane, trk_call_out* out);
+
+/* ---- dumpSTR locus-level filters ----------------------------------------- */
+enum {
+    TRK_LOCF_CALLRATE = 0,  /* filters.py:59-61   */
+    TRK_LOCF_HWE = 1,       /* filters.py:98-103  */
+    TRK_LOCF_HETLOW = 2,    /* filters.py:140-144 */
+    TRK_LOCF_HETHIGH = 3,   /* filters.py:181-185 */
+    TRK_LOCF_EXTERN0 = 4,   /* bits 4..27: host-evaluated filters (HRUN :190-217,
+                               BED regions :219-300) passed in extern_bits        */
+    TRK_LOCF_NO_CALLS = 31  /* dumpSTR.py:957-965 */
+};
+typedef struct {
+    double min_callrate, min_hwep, min_het, max_het; /* nan = filter disabled      */
+    int32_t use_length;        /* dumpSTR --use-length                             */
+    int32_t n_extern;          /* number of extern filter bits in use              */
+    const uint32_t* extern_bits; /* device [L] or NULL                            */
+} trk_locus_filter_spec;
+enum {
+    TRK_LC_TOTALCALLS = 0, TRK_LC_PASS = 1, TRK_LC_NO_CALLS = 2,
+    TRK_LC_FILTER0 = 3,      /* + bit index of the filter (0..27)                  */
+    TRK_LC_HWE_ERRORS = 31,  /* loci where the reference would raise in the HWE filter */
+    TRK_LC_COLS = 32
+};
+typedef struct {
+    uint32_t* locus_bits;    /* [L] bit per fired filter; 0 == PASS                */
+    int64_t* loc_counters;   /* [TRK_LC_COLS] += (loc_info of dumpSTR.py:1264-1268) */
+} trk_locus_out;
+/* (a19): locus filter decisions + loc_info counters from group 0 of `stats`.   */
+int trk_locus_filters(trk_ctx* ctx, int32_t n_loci, const trk_stats_out* stats,
+                      const trk_locus_filter_spec* spec, trk_locus_out* out);
+
+/* ---- multi-GPU (one process per GPU, RCCL over xGMI) --------------------- */
+/* 128-byte opaque id created by rank 0 and distributed by the launcher.       */
+int trk_comm_unique_id(uint8_t id[128]);
+int trk_comm_init(trk_ctx* ctx, int rank, int n_ranks, const uint8_t id[128]);
+/* in-place sum over ranks of int64 device counters (sample/locus counters).   */
+int trk_allreduce_sum_i64(trk_ctx* ctx, int64_t* dev, size_t count);
+/* gather `bytes_per_rank` bytes from every rank into recv (rank-major).       */
+int trk_allgather(trk_ctx* ctx, const void* send_dev, void* recv_dev, size_t bytes_per_rank);
+
+/* ---- scalar helpers (host, double) --------------------------------------- */
+/* Two-sided exact binomial test p-value == scipy.stats.binomtest(k, n, p).pvalue
+ * (third-party call at utils.py:334-338); same code as the device finaliser.  */
+double trk_binomtest_two_sided(int64_t k, int64_t n, double p);
+double trk_binom_pmf(int64_t k, int64_t n, double p);
+
+/* ---- synthetic many-sample VCF batches (bench / tests) ------------------- */
+typedef struct {
+    uint64_t seed;
+    int32_t n_loci, n_samples;           /* diploid                               */
+    const int32_t* allele_off;            /* device [L+1]                          */
+    const uint32_t* allele_cdf24;         /* device [sumA] cumulative allele probabilities, 24-bit */
+    const uint32_t* miss_thr16;           /* device [L] P(no-call) * 65536         */
+    const uint32_t* inbreed_thr16;        /* device [L] P(2nd allele := 1st) * 65536 */
+    int32_t locus_base;                   /* global index of locus 0 (sharding)    */
+    int32_t reserved;
+} trk_synth_spec;
+/* Fill gt [L,S,2] and (optional, may be NULL) FORMAT planes DP int32 [L,S],
+ * Q float32 [L,S], DSTUTTER / DFLANKINDEL int32 [L,S] with a counter-based
+ * generator that trtools_amd/synth.py reproduces bit-for-bit in numpy.         */
+int trk_synth_fill(trk_ctx* ctx, const trk_synth_spec* spec, int16_t* gt, int32_t* dp,
+                   float* q, int32_t* dstutter, int32_t* dflankindel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRK_H */

@@ -1,0 +1,60 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol that
+include/trk.h declares, its host scalar helpers match scipy, and the product
+refuses to run without a GPU (no CPU fallback).  No device compute here."""
+import os
+import re
+
+import pytest
+
+from helpers import load_golden, unjf, close
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    from trtools_amd import _lib as L
+    if not os.path.exists(L.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return L, L.load()
+
+
+def test_library_exports_every_declared_symbol():
+    L, lib = _lib()
+    hdr = open(os.path.join(ROOT, 'include', 'trk.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = sorted(set(re.findall(r'\b(trk_[a-z0-9_]+)\s*\(', hdr)))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), "libtrk.so does not export %s" % name
+    assert sorted(L.EXPORTS) == declared
+
+
+def test_binomtest_host_entry_matches_scipy_vectors():
+    L, lib = _lib()
+    for k, n, p, pv in load_golden('binomtest_vectors.json')['cases']:
+        got = lib.trk_binomtest_two_sided(k, n, p)
+        assert close(got, unjf(pv), 1e-9, 1e-300), (k, n, p, got, pv)
+
+
+def test_struct_sizes_match_header():
+    """ctypes mirrors of the ABI structs (64-bit Linux layout)."""
+    import ctypes as C
+    L, _ = _lib()
+    assert C.sizeof(L.Batch) == 4 * 4 + 8 + 8 + 7 * 8
+    assert C.sizeof(L.CallFilter) == 6 * 4 + 8
+    assert C.sizeof(L.Plane) == 16
+    assert C.sizeof(L.LocusFilterSpec) == 4 * 8 + 8 + 8
+    assert C.sizeof(L.SynthSpec) == 8 + 8 + 4 * 8 + 8
+
+
+def test_engine_fails_loudly_without_gpu():
+    import ctypes as C
+    L, lib = _lib()
+    n = C.c_int()
+    lib.trk_device_count(C.byref(n))
+    if n.value > 0:
+        pytest.skip("a GPU is present")
+    from trtools_amd.engine import Engine
+    with pytest.raises(L.TrkError):
+        Engine(0)

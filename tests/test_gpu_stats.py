@@ -1,0 +1,220 @@
+"""GPU parity: trk_locus_stats (HIP, through the C ABI) vs the reference's own
+outputs (tests/golden/trrecord_vectors.json) and vs the oracle on seeded
+synthetic batches.  Integers bit-exact, floats within 1e-9 (BASELINE.json)."""
+import math
+
+import numpy as np
+import pytest
+
+from helpers import load_golden, unjf, close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from trtools_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _fetch(res):
+    return res.allele_count.get(), res.locus_int.get(), res.locus_f64.get()
+
+
+def check_against_oracle(orc, L, cnt, li, lf, off, gt, lens, strs, groups, nalleles_thresh, loci=None):
+    """Compare device outputs of every (group, locus) with oracle.locus_stats."""
+    G = len(groups)
+    for l in (range(len(gt)) if loci is None else loci):
+        for g in range(G):
+            si = groups[g]
+            ol = orc.locus_stats(gt[l], lens[l], strs[l], si, use_length=True, nalleles_thresh=nalleles_thresh)
+            os_ = orc.locus_stats(gt[l], lens[l], strs[l], si, use_length=False, nalleles_thresh=nalleles_thresh)
+            a0, a1 = off[l], off[l + 1]
+            assert np.array_equal(cnt[g, a0:a1], ol['index_counts']), (l, g)
+            I, F = li[g, l], lf[g, l]
+            assert I[L.LI_N_CALLED] == ol['numcalled'] == ol['n_called'], (l, g)
+            assert I[L.LI_N_SAMPLES] == ol['n_samples']
+            assert I[L.LI_N_ALLELES] == int(ol['index_counts'].sum())
+            assert I[L.LI_N_BAD] == 0
+            assert I[L.LI_NALLELES_LEN] == ol['nalleles'], (l, g)
+            assert I[L.LI_NALLELES_STR] == os_['nalleles'], (l, g)
+            for col, o, key in ((L.LF_HET_LEN, ol, 'het'), (L.LF_HET_STR, os_, 'het'),
+                                (L.LF_ENTROPY_LEN, ol, 'entropy'), (L.LF_ENTROPY_STR, os_, 'entropy'),
+                                (L.LF_THRESH, ol, 'thresh'), (L.LF_MEAN, ol, 'mean'),
+                                (L.LF_MODE, ol, 'mode'), (L.LF_VAR, ol, 'var')):
+                assert close(F[col], o[key]), (l, g, key, F[col], o[key])
+            for scol, fcol, o in ((L.LI_HWE_STATUS_LEN, L.LF_HWEP_LEN, ol),
+                                  (L.LI_HWE_STATUS_STR, L.LF_HWEP_STR, os_)):
+                if o['hwep_status'] != orc.HWE_OK:
+                    assert I[scol] == o['hwep_status'], (l, g, I[scol], o['hwep_status'])
+                elif math.isnan(o['hwep']):
+                    assert I[scol] == L.HWE_NAN and math.isnan(F[fcol]), (l, g)
+                else:
+                    assert I[scol] == L.HWE_OK
+                    assert close(F[fcol], o['hwep'], 1e-9, 1e-300), (l, g, F[fcol], o['hwep'])
+
+
+def test_reference_golden_vectors(eng):
+    """Every case of trrecord_vectors.json (outputs of the REAL reference)."""
+    from trtools_amd import _lib as L
+    from trtools_amd.synth import pack_alleles
+    cases = load_golden('trrecord_vectors.json')['cases']
+    n_checked = 0
+    for c in cases:
+        gt = np.array(c['gt'], dtype=np.int16)[None, :, :]
+        strs = [c['ref']] + list(c['alts'])
+        lens = [unjf(x) for x in c['allele_lens']]
+        off, lc, sc, cv = pack_alleles([lens], [strs])
+        gb = None
+        if c['sample_index'] is not None:
+            gb = np.array(c['sample_index'], dtype=np.uint8)
+        b = eng.make_batch(gt, off, lc, sc, cv, group_bits=gb, n_groups=1)
+        res = eng.locus_stats(b, nalleles_thresh=0.1)
+        cnt, li, lf = _fetch(res)
+        st = c['statstr']
+        want_idx = np.zeros(len(lens), dtype=np.int64)
+        for k, v in c['counts_idx']:
+            want_idx[int(k)] = v
+        assert np.array_equal(cnt[0], want_idx), c['kind']
+        I, F = li[0, 0], lf[0, 0]
+        assert I[L.LI_N_CALLED] == st['numcalled']
+        assert I[L.LI_NALLELES_LEN] == st['nalleles_len']
+        assert I[L.LI_NALLELES_STR] == st['nalleles_str']
+        for col, key in ((L.LF_THRESH, 'thresh'), (L.LF_MEAN, 'mean'), (L.LF_MODE, 'mode'), (L.LF_VAR, 'var'),
+                         (L.LF_HET_LEN, 'het_len'), (L.LF_HET_STR, 'het_str'),
+                         (L.LF_ENTROPY_LEN, 'entropy_len'), (L.LF_ENTROPY_STR, 'entropy_str')):
+            assert close(F[col], unjf(st[key])), (c['kind'], key, F[col], st[key])
+        for scol, fcol, key in ((L.LI_HWE_STATUS_LEN, L.LF_HWEP_LEN, 'hwep_len'),
+                                (L.LI_HWE_STATUS_STR, L.LF_HWEP_STR, 'hwep_str')):
+            h = st[key]
+            if 'raises' in h:
+                want = L.HWE_VALUE_ERROR if h['raises'] == 'ValueError' else L.HWE_INDEX_ERROR
+                assert I[scol] == want, (c['kind'], c['ploidy'], key)
+            else:
+                v = unjf(h['ok'])
+                if math.isnan(v):
+                    assert I[scol] == L.HWE_NAN and math.isnan(F[fcol])
+                else:
+                    assert I[scol] == L.HWE_OK and close(F[fcol], v, 1e-9, 1e-300), (key, F[fcol], v)
+        if c['sample_index'] is None:
+            assert close(F[L.LF_CALLRATE], unjf(c['callrate']))
+        n_checked += 1
+        for a in b.arrays.values():
+            a.free()
+        for a in (res.allele_count, res.locus_int, res.locus_f64):
+            a.free()
+    assert n_checked == len(cases)
+
+
+@pytest.mark.parametrize("n_loci,n_samples", [(120, 1000), (40, 50), (30, 1003), (16, 4099)])
+def test_synth_batch_vs_oracle(eng, n_loci, n_samples):
+    from oracle import trtools_oracle as orc
+    from trtools_amd import _lib as L
+    from trtools_amd.synth import SynthBatch
+    sb = SynthBatch(eng, n_loci, n_samples, seed=20260928 + n_samples)
+    host = sb.host_rows(np.arange(n_loci))
+    # generator twin: device == numpy, bit for bit
+    assert np.array_equal(sb.dev['gt'].get(), host['gt'])
+    assert np.array_equal(sb.dev['dp'].get(), host['dp'])
+    assert np.array_equal(sb.dev['q'].get().view(np.uint32), host['q'].view(np.uint32))
+    res = eng.locus_stats(sb.batch, nalleles_thresh=0.01)
+    cnt, li, lf = _fetch(res)
+    off = sb.tables[0]
+    check_against_oracle(orc, L, cnt, li, lf, off, host['gt'], sb.loci.allele_lens, sb.loci.allele_strs,
+                         [None], 0.01)
+
+
+def _random_batch(rng, n_loci, n_samples, ploidy, max_alt, with_low=False):
+    from trtools_amd.synth import pack_alleles
+    lens, strs, gts, lp = [], [], [], []
+    for l in range(n_loci):
+        motif = ''.join(rng.choice(list('ACGT'), size=int(rng.integers(1, 5))))
+        A = 1 + int(rng.integers(0, max_alt + 1))
+        ss, seen = [], set()
+        while len(ss) < A:
+            s = motif * int(rng.integers(1, 3 * A + 4))
+            if rng.random() < 0.3:
+                s = s + 'N' * int(rng.integers(1, 3))
+            if rng.random() < 0.1 and ss:
+                s = ss[int(rng.integers(0, len(ss)))]     # duplicate sequence
+            elif s in seen:
+                continue
+            seen.add(s)
+            ss.append(s)
+        strs.append(ss)
+        lens.append([len(s) / len(motif) for s in ss])
+        pl = ploidy if not with_low else int(rng.integers(1, ploidy + 1))
+        lp.append(pl)
+        g = rng.integers(0, A, size=(n_samples, ploidy)).astype(np.int16)
+        g[rng.random(n_samples) < 0.1, :] = -1
+        g[rng.random(n_samples) < 0.05, int(rng.integers(0, ploidy))] = -1
+        if pl < ploidy:
+            g[:, pl:] = -2
+        elif ploidy > 1 and rng.random() < 0.5:
+            low = rng.random(n_samples) < 0.1
+            g[low, ploidy - 1] = -2
+        gts.append(g)
+    return np.stack(gts), lens, strs, np.array(lp, dtype=np.uint8), pack_alleles(lens, strs)
+
+
+@pytest.mark.parametrize("ploidy,n_groups", [(1, 1), (2, 3), (3, 1), (3, 2), (4, 8), (2, 1)])
+def test_general_ploidy_and_groups(eng, ploidy, n_groups):
+    from oracle import trtools_oracle as orc
+    from trtools_amd import _lib as L
+    rng = np.random.default_rng(100 * ploidy + n_groups)
+    n_loci, S = 25, 257
+    gt, lens, strs, lp, (off, lc, sc, cv) = _random_batch(rng, n_loci, S, ploidy, 12, with_low=True)
+    gb = rng.integers(0, 1 << n_groups, size=S).astype(np.uint8)
+    groups = [((gb >> g) & 1).astype(bool) for g in range(n_groups)]
+    b = eng.make_batch(gt, off, lc, sc, cv, locus_ploidy=lp, group_bits=gb, n_groups=n_groups)
+    res = eng.locus_stats(b, nalleles_thresh=0.05)
+    cnt, li, lf = _fetch(res)
+    # the oracle sees what the reference would see: only the locus's own ploidy columns
+    gt_view = [gt[l][:, :lp[l]] for l in range(n_loci)]
+    check_against_oracle(orc, L, cnt, li, lf, off, gt_view, lens, strs, groups, 0.05)
+
+
+def test_many_alleles_lds_and_direct_paths(eng):
+    """A > 255 (uint8 would overflow), A beyond the LDS histogram (global-atomic path)."""
+    from oracle import trtools_oracle as orc
+    from trtools_amd import _lib as L
+    from trtools_amd.synth import pack_alleles
+    rng = np.random.default_rng(5)
+    S = 3000
+    lens, strs, gts = [], [], []
+    for A in (300, 1500, 5000, 2):
+        ss = ['AC' * (i + 1) for i in range(A)]
+        strs.append(ss)
+        lens.append([len(s) / 2 for s in ss])
+        g = rng.integers(0, A, size=(S, 2)).astype(np.int16)
+        g[rng.random(S) < 0.05, :] = -1
+        gts.append(g)
+    gt = np.stack(gts)
+    off, lc, sc, cv = pack_alleles(lens, strs)
+    b = eng.make_batch(gt, off, lc, sc, cv)
+    res = eng.locus_stats(b)
+    cnt, li, lf = _fetch(res)
+    check_against_oracle(orc, L, cnt, li, lf, off, gt, lens, strs, [None], 0.01)
+
+
+def test_empty_and_tiny_batches(eng):
+    from trtools_amd import _lib as L
+    from trtools_amd.synth import pack_alleles
+    off, lc, sc, cv = pack_alleles([[3.0]], [['CAGCAGCAG']])
+    # one sample, no call (reference: get_nocall_record)
+    b = eng.make_batch(np.array([[[-1, -1]]], dtype=np.int16), off, lc, sc, cv)
+    cnt, li, lf = _fetch(eng.locus_stats(b))
+    assert cnt.tolist() == [[0]] and li[0, 0, L.LI_N_CALLED] == 0
+    assert math.isnan(lf[0, 0, L.LF_HET_LEN]) and math.isnan(lf[0, 0, L.LF_THRESH])
+    assert li[0, 0, L.LI_HWE_STATUS_LEN] == L.HWE_NAN
+    # zero loci
+    b0 = eng.make_batch(np.zeros((0, 5, 2), dtype=np.int16), np.zeros(1, dtype=np.int32),
+                        np.zeros(0, dtype=np.uint16), np.zeros(0, dtype=np.uint16), np.zeros(0))
+    res0 = eng.locus_stats(b0)
+    assert res0.locus_int.get().shape == (1, 0, L.TRK_LI_COLS)
+    # out-of-range allele index is reported, not counted (reference: IndexError :1242)
+    b2 = eng.make_batch(np.array([[[0, 7], [0, 0]]], dtype=np.int16), off, lc, sc, cv)
+    cnt, li, lf = _fetch(eng.locus_stats(b2))
+    assert li[0, 0, L.LI_N_BAD] == 1 and cnt.tolist() == [[3]]

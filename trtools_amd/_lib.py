@@ -1,0 +1,151 @@
+"""ctypes binding of libtrk.so (include/trk.h).  No torch, no fallback: if the
+HIP library is missing or no MI355X is visible this module raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libtrk.so')
+
+TRK_LI_COLS = 12
+TRK_LF_COLS = 12
+TRK_LC_COLS = 32
+TRK_MAX_FILTERS = 24
+TRK_MAX_PLANES = 16
+TRK_MASK_NOCALL = 0x80000000
+
+# locus_int columns
+LI_N_CALLED, LI_N_LOWPLOIDY, LI_N_HOM_LEN, LI_N_HOM_STR, LI_N_ALLELES, LI_N_BAD, \
+    LI_HWE_STATUS_LEN, LI_HWE_STATUS_STR, LI_N_SAMPLES, LI_NALLELES_LEN, LI_NALLELES_STR = range(11)
+HWE_OK, HWE_NAN, HWE_VALUE_ERROR, HWE_INDEX_ERROR = range(4)
+# locus_f64 columns
+LF_THRESH, LF_MEAN, LF_MODE, LF_VAR, LF_HET_LEN, LF_HET_STR, LF_ENTROPY_LEN, LF_ENTROPY_STR, \
+    LF_HWEP_LEN, LF_HWEP_STR, LF_CALLRATE = range(11)
+# kernels (profiling)
+K_LOCUS_COUNT, K_LOCUS_FINALIZE, K_CALL_FILTER, K_LOCUS_FILTER, K_SYNTH = range(5)
+KERNEL_NAMES = ['k_locus_count', 'k_locus_finalize', 'k_call_filter', 'k_locus_filter', 'k_synth']
+# filter ops
+F_LT, F_GT, F_RATIO_GT, F_CALLED_LT, F_CALLED_SUM_LT, F_CALLED_EQ, F_CALLED_SUM_EQ, \
+    F_CALLED_OUTSIDE_CI, F_AD_SUPPORT_LT = range(1, 10)
+DT_I32, DT_F32 = 0, 1
+# locus filter bits / counters
+LOCF_CALLRATE, LOCF_HWE, LOCF_HETLOW, LOCF_HETHIGH, LOCF_EXTERN0 = 0, 1, 2, 3, 4
+LOCF_NO_CALLS = 31
+LC_TOTALCALLS, LC_PASS, LC_NO_CALLS, LC_FILTER0 = 0, 1, 2, 3
+LC_HWE_ERRORS = 31
+STATS_COUNT_ONLY = 1
+
+
+class Batch(C.Structure):
+    _fields_ = [('n_loci', C.c_int32), ('n_samples', C.c_int32), ('ploidy', C.c_int32),
+                ('n_groups', C.c_int32), ('n_alleles_total', C.c_int64),
+                ('max_alleles', C.c_int32), ('reserved0', C.c_int32),
+                ('gt', C.c_void_p), ('locus_ploidy', C.c_void_p), ('allele_off', C.c_void_p),
+                ('len_class', C.c_void_p), ('str_class', C.c_void_p),
+                ('len_class_value', C.c_void_p), ('group_bits', C.c_void_p)]
+
+
+class StatsParams(C.Structure):
+    _fields_ = [('nalleles_thresh', C.c_double), ('flags', C.c_int32), ('reserved', C.c_int32)]
+
+
+class StatsOut(C.Structure):
+    _fields_ = [('allele_count', C.c_void_p), ('locus_int', C.c_void_p), ('locus_f64', C.c_void_p)]
+
+
+class Plane(C.Structure):
+    _fields_ = [('data', C.c_void_p), ('dtype', C.c_int32), ('ncol', C.c_int32)]
+
+
+class CallFilter(C.Structure):
+    _fields_ = [('op', C.c_int32), ('plane_a', C.c_int32), ('col_a', C.c_int32),
+                ('plane_b', C.c_int32), ('col_b', C.c_int32), ('col_a2', C.c_int32),
+                ('thr', C.c_double)]
+
+
+class CallOut(C.Structure):
+    _fields_ = [('gt_out', C.c_void_p), ('filter_mask', C.c_void_p),
+                ('sample_counters', C.c_void_p), ('sample_totaldp', C.c_void_p),
+                ('sample_dp_missing', C.c_void_p), ('error', C.c_void_p)]
+
+
+class LocusFilterSpec(C.Structure):
+    _fields_ = [('min_callrate', C.c_double), ('min_hwep', C.c_double), ('min_het', C.c_double),
+                ('max_het', C.c_double), ('use_length', C.c_int32), ('n_extern', C.c_int32),
+                ('extern_bits', C.c_void_p)]
+
+
+class LocusOut(C.Structure):
+    _fields_ = [('locus_bits', C.c_void_p), ('loc_counters', C.c_void_p)]
+
+
+class SynthSpec(C.Structure):
+    _fields_ = [('seed', C.c_uint64), ('n_loci', C.c_int32), ('n_samples', C.c_int32),
+                ('allele_off', C.c_void_p), ('allele_cdf24', C.c_void_p), ('miss_thr16', C.c_void_p),
+                ('inbreed_thr16', C.c_void_p), ('locus_base', C.c_int32), ('reserved', C.c_int32)]
+
+
+# every symbol include/trk.h declares (tests check that the library exports them)
+EXPORTS = [
+    'trk_init', 'trk_free', 'trk_last_error', 'trk_backend', 'trk_device_count', 'trk_device_info',
+    'trk_dev_alloc', 'trk_dev_free', 'trk_memcpy_h2d', 'trk_memcpy_d2h', 'trk_memset', 'trk_sync',
+    'trk_timer_start', 'trk_timer_stop', 'trk_timer_elapsed_ms',
+    'trk_profile_enable', 'trk_profile_get', 'trk_profile_reset',
+    'trk_locus_stats', 'trk_call_filters', 'trk_locus_filters',
+    'trk_comm_unique_id', 'trk_comm_init', 'trk_allreduce_sum_i64', 'trk_allgather',
+    'trk_binomtest_two_sided', 'trk_binom_pmf', 'trk_synth_fill',
+]
+
+_lib = None
+
+
+class TrkError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libtrk.so and declare signatures.  Raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TrkError("libtrk.so is not built (%s). Run `make -C trtools_amd/csrc` or "
+                       "`python -c 'import __graft_entry__ as g; g.build()'`. "
+                       "There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
+    P = C.POINTER
+    lib.trk_init.argtypes = [C.c_int, P(vp)]
+    lib.trk_free.argtypes = [vp]
+    lib.trk_free.restype = None
+    lib.trk_last_error.argtypes = [vp]
+    lib.trk_last_error.restype = C.c_char_p
+    lib.trk_backend.argtypes = [vp]
+    lib.trk_device_count.argtypes = [P(C.c_int)]
+    lib.trk_device_info.argtypes = [vp, C.c_char_p, C.c_int, P(C.c_int), P(u64), C.c_char_p, C.c_int]
+    lib.trk_dev_alloc.argtypes = [vp, C.c_size_t, P(vp)]
+    lib.trk_dev_free.argtypes = [vp, vp]
+    lib.trk_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.trk_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.trk_memset.argtypes = [vp, vp, C.c_int, C.c_size_t]
+    lib.trk_sync.argtypes = [vp]
+    lib.trk_timer_start.argtypes = [vp, C.c_int]
+    lib.trk_timer_stop.argtypes = [vp, C.c_int]
+    lib.trk_timer_elapsed_ms.argtypes = [vp, C.c_int, P(C.c_float)]
+    lib.trk_profile_enable.argtypes = [vp, C.c_int]
+    lib.trk_profile_get.argtypes = [vp, C.c_int, P(i64), P(dbl)]
+    lib.trk_profile_reset.argtypes = [vp]
+    lib.trk_locus_stats.argtypes = [vp, P(Batch), P(StatsParams), P(StatsOut)]
+    lib.trk_call_filters.argtypes = [vp, P(Batch), P(Plane), C.c_int, P(CallFilter), C.c_int, C.c_int,
+                                     P(CallOut)]
+    lib.trk_locus_filters.argtypes = [vp, i32, P(StatsOut), P(LocusFilterSpec), P(LocusOut)]
+    lib.trk_comm_unique_id.argtypes = [P(C.c_uint8)]
+    lib.trk_comm_init.argtypes = [vp, C.c_int, C.c_int, P(C.c_uint8)]
+    lib.trk_allreduce_sum_i64.argtypes = [vp, vp, C.c_size_t]
+    lib.trk_allgather.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.trk_binomtest_two_sided.argtypes = [i64, i64, dbl]
+    lib.trk_binomtest_two_sided.restype = dbl
+    lib.trk_binom_pmf.argtypes = [i64, i64, dbl]
+    lib.trk_binom_pmf.restype = dbl
+    lib.trk_synth_fill.argtypes = [vp, P(SynthSpec), vp, vp, vp, vp, vp]
+    _lib = lib
+    return lib

@@ -1,0 +1,483 @@
+// trk_api.hip -- host side of libtrk.so: the extern "C" entry points declared in
+// include/trk.h.  HIP runtime only (no torch); RCCL is bound lazily with dlopen
+// so that the library loads on machines without it.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "../../include/trk.h"
+#include "trk_binom.h"
+#include "trk_internal.h"
+
+// ---- RCCL (subset), resolved at run time --------------------------------------
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+enum { trkNcclUint8 = 1, trkNcclInt64 = 4 };
+enum { trkNcclSum = 0 };
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+static std::string g_init_error;
+
+static bool load_rccl(std::string& err) {
+    if (g_rccl.handle) return true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) {
+        err = std::string("cannot dlopen librccl: ") + (dlerror() ? dlerror() : "?");
+        return false;
+    }
+    RcclApi a;
+    a.handle = h;
+    a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
+    a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.AllGather) {
+        err = "librccl is missing required symbols";
+        return false;
+    }
+    g_rccl = a;
+    return true;
+}
+
+// ---- context ---------------------------------------------------------------------
+struct ProfRec {
+    int kernel;
+    hipEvent_t start, stop;
+};
+
+struct trk_ctx {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;
+    std::string err;
+    hipEvent_t t_start[TRK_N_TIMERS] = {};
+    hipEvent_t t_stop[TRK_N_TIMERS] = {};
+    bool profiling = false;
+    std::vector<ProfRec> prof_pending;
+    std::vector<hipEvent_t> event_pool;
+    int64_t prof_n[TRK_K_COUNT] = {};
+    double prof_ms[TRK_K_COUNT] = {};
+    int32_t* scratch = nullptr;  // finaliser class-count scratch
+    size_t scratch_bytes = 0;
+    ncclComm_t comm = nullptr;
+    int rank = 0, n_ranks = 1;
+};
+
+static int fail(trk_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_init_error = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                        \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail(ctx, TRK_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+static hipEvent_t get_event(trk_ctx* ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ProfScope {
+    trk_ctx* ctx;
+    ProfRec rec;
+    bool on;
+    ProfScope(trk_ctx* c, int kernel) : ctx(c), on(c->profiling) {
+        if (!on) return;
+        rec.kernel = kernel;
+        rec.start = get_event(c);
+        rec.stop = get_event(c);
+        (void)hipEventRecord(rec.start, c->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(rec.stop, ctx->stream);
+        ctx->prof_pending.push_back(rec);
+    }
+};
+
+static void drain_profile(trk_ctx* ctx) {
+    for (auto& r : ctx->prof_pending) {
+        (void)hipEventSynchronize(r.stop);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+            ctx->prof_n[r.kernel] += 1;
+            ctx->prof_ms[r.kernel] += ms;
+        }
+        ctx->event_pool.push_back(r.start);
+        ctx->event_pool.push_back(r.stop);
+    }
+    ctx->prof_pending.clear();
+}
+
+extern "C" {
+
+int trk_device_count(int* n) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *n = 0;
+        return fail(nullptr, TRK_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *n = c;
+    return TRK_OK;
+}
+
+int trk_init(int device, trk_ctx** out) {
+    if (!out) return fail(nullptr, TRK_ERR_ARG, "trk_init: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, TRK_ERR_HIP, "trk_init: no HIP device (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(nullptr, TRK_ERR_ARG, "trk_init: device %d out of range [0,%d)", device, n);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, TRK_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    trk_ctx* ctx = new trk_ctx();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, TRK_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    for (int i = 0; i < TRK_N_TIMERS; ++i) {
+        (void)hipEventCreate(&ctx->t_start[i]);
+        (void)hipEventCreate(&ctx->t_stop[i]);
+    }
+    *out = ctx;
+    return TRK_OK;
+}
+
+void trk_free(trk_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    drain_profile(ctx);
+    if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < TRK_N_TIMERS; ++i) {
+        (void)hipEventDestroy(ctx->t_start[i]);
+        (void)hipEventDestroy(ctx->t_stop[i]);
+    }
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* trk_last_error(trk_ctx* ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
+
+int trk_backend(trk_ctx*) { return 1; }
+
+int trk_device_info(trk_ctx* ctx, char* name, int name_len, int* n_cu, uint64_t* hbm_bytes, char* arch,
+                    int arch_len) {
+    if (!ctx) return TRK_ERR_ARG;
+    hipDeviceProp_t prop;
+    HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_len > 0) snprintf(name, name_len, "%s", prop.name);
+    if (arch && arch_len > 0) snprintf(arch, arch_len, "%s", prop.gcnArchName);
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)prop.totalGlobalMem;
+    return TRK_OK;
+}
+
+// ---- memory ----------------------------------------------------------------------
+int trk_dev_alloc(trk_ctx* ctx, size_t bytes, void** dptr) {
+    if (!ctx || !dptr) return TRK_ERR_ARG;
+    *dptr = nullptr;
+    if (bytes == 0) bytes = 16;
+    (void)hipSetDevice(ctx->device);
+    hipError_t e = hipMalloc(dptr, bytes);
+    if (e != hipSuccess) return fail(ctx, TRK_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return TRK_OK;
+}
+int trk_dev_free(trk_ctx* ctx, void* dptr) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (!dptr) return TRK_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipFree(dptr));
+    return TRK_OK;
+}
+int trk_memcpy_h2d(trk_ctx* ctx, void* d, const void* h, size_t n) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (n == 0) return TRK_OK;
+    HIPCHK(ctx, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return TRK_OK;
+}
+int trk_memcpy_d2h(trk_ctx* ctx, void* h, const void* d, size_t n) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (n == 0) return TRK_OK;
+    HIPCHK(ctx, hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return TRK_OK;
+}
+int trk_memset(trk_ctx* ctx, void* d, int v, size_t n) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (n == 0) return TRK_OK;
+    HIPCHK(ctx, hipMemsetAsync(d, v, n, ctx->stream));
+    return TRK_OK;
+}
+int trk_sync(trk_ctx* ctx) {
+    if (!ctx) return TRK_ERR_ARG;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return TRK_OK;
+}
+
+// ---- timers / profiling ----------------------------------------------------------
+int trk_timer_start(trk_ctx* ctx, int slot) {
+    if (!ctx || slot < 0 || slot >= TRK_N_TIMERS) return TRK_ERR_ARG;
+    HIPCHK(ctx, hipEventRecord(ctx->t_start[slot], ctx->stream));
+    return TRK_OK;
+}
+int trk_timer_stop(trk_ctx* ctx, int slot) {
+    if (!ctx || slot < 0 || slot >= TRK_N_TIMERS) return TRK_ERR_ARG;
+    HIPCHK(ctx, hipEventRecord(ctx->t_stop[slot], ctx->stream));
+    return TRK_OK;
+}
+int trk_timer_elapsed_ms(trk_ctx* ctx, int slot, float* ms) {
+    if (!ctx || slot < 0 || slot >= TRK_N_TIMERS || !ms) return TRK_ERR_ARG;
+    HIPCHK(ctx, hipEventSynchronize(ctx->t_stop[slot]));
+    HIPCHK(ctx, hipEventElapsedTime(ms, ctx->t_start[slot], ctx->t_stop[slot]));
+    return TRK_OK;
+}
+int trk_profile_enable(trk_ctx* ctx, int on) {
+    if (!ctx) return TRK_ERR_ARG;
+    ctx->profiling = on != 0;
+    return TRK_OK;
+}
+int trk_profile_get(trk_ctx* ctx, int kernel, int64_t* n, double* ms) {
+    if (!ctx || kernel < 0 || kernel >= TRK_K_COUNT) return TRK_ERR_ARG;
+    drain_profile(ctx);
+    if (n) *n = ctx->prof_n[kernel];
+    if (ms) *ms = ctx->prof_ms[kernel];
+    return TRK_OK;
+}
+int trk_profile_reset(trk_ctx* ctx) {
+    if (!ctx) return TRK_ERR_ARG;
+    drain_profile(ctx);
+    for (int i = 0; i < TRK_K_COUNT; ++i) {
+        ctx->prof_n[i] = 0;
+        ctx->prof_ms[i] = 0.0;
+    }
+    return TRK_OK;
+}
+
+// ---- the hot path ----------------------------------------------------------------
+static int check_batch(trk_ctx* ctx, const trk_batch* b) {
+    if (!b) return fail(ctx, TRK_ERR_ARG, "batch is NULL");
+    if (b->n_loci < 0 || b->n_samples < 0) return fail(ctx, TRK_ERR_ARG, "negative batch dimensions");
+    if (b->ploidy < 1 || b->ploidy > TRK_MAX_PLOIDY)
+        return fail(ctx, TRK_ERR_ARG, "ploidy %d outside [1,%d]", b->ploidy, TRK_MAX_PLOIDY);
+    if (b->n_loci > 0 && (!b->gt && b->n_samples > 0)) return fail(ctx, TRK_ERR_ARG, "gt is NULL");
+    if (b->n_loci > 0 && (!b->allele_off || !b->len_class || !b->str_class || !b->len_class_value))
+        return fail(ctx, TRK_ERR_ARG, "allele tables are NULL");
+    if (b->group_bits && (b->n_groups < 1 || b->n_groups > 8))
+        return fail(ctx, TRK_ERR_ARG, "n_groups %d outside [1,8]", b->n_groups);
+    if (((uintptr_t)b->gt & 15u) != 0) return fail(ctx, TRK_ERR_ARG, "gt must be 16-byte aligned");
+    return TRK_OK;
+}
+
+int trk_locus_stats(trk_ctx* ctx, const trk_batch* in, const trk_stats_params* prm, trk_stats_out* out) {
+    if (!ctx) return TRK_ERR_ARG;
+    int rc = check_batch(ctx, in);
+    if (rc) return rc;
+    if (!out || !out->allele_count || !out->locus_int) return fail(ctx, TRK_ERR_ARG, "stats outputs are NULL");
+    const bool count_only = prm && (prm->flags & TRK_STATS_COUNT_ONLY);
+    if (!count_only && !out->locus_f64) return fail(ctx, TRK_ERR_ARG, "locus_f64 is NULL");
+    if (in->n_loci == 0) return TRK_OK;
+    (void)hipSetDevice(ctx->device);
+    const int G = in->group_bits ? in->n_groups : 1;
+    const int64_t sumA = in->n_alleles_total;
+    HIPCHK(ctx, hipMemsetAsync(out->allele_count, 0, (size_t)G * sumA * sizeof(int32_t), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(out->locus_int, 0, (size_t)G * in->n_loci * TRK_LI_COLS * sizeof(int32_t),
+                               ctx->stream));
+    {
+        ProfScope ps(ctx, TRK_K_LOCUS_COUNT);
+        HIPCHK(ctx, trk::launch_locus_count(*in, in->max_alleles, out->allele_count, out->locus_int,
+                                            ctx->n_cu, ctx->stream));
+    }
+    if (count_only) return TRK_OK;
+    size_t need = (size_t)G * 2 * (size_t)sumA * sizeof(int32_t) + 16;
+    if (need > ctx->scratch_bytes) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch) (void)hipFree(ctx->scratch);
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        hipError_t e = hipMalloc((void**)&ctx->scratch, need);
+        if (e != hipSuccess) return fail(ctx, TRK_ERR_NOMEM, "scratch hipMalloc(%zu): %s", need, hipGetErrorString(e));
+        ctx->scratch_bytes = need;
+    }
+    {
+        ProfScope ps(ctx, TRK_K_LOCUS_FINALIZE);
+        HIPCHK(ctx, trk::launch_locus_finalize(*in, out->allele_count, out->locus_int, out->locus_f64, ctx->scratch,
+                                               prm ? prm->nalleles_thresh : 0.01, ctx->stream));
+    }
+    return TRK_OK;
+}
+
+int trk_call_filters(trk_ctx* ctx, const trk_batch* in, const trk_plane* planes, int n_planes,
+                     const trk_call_filter* filters, int n_filters, int dp_plane, trk_call_out* out) {
+    if (!ctx) return TRK_ERR_ARG;
+    int rc = check_batch(ctx, in);
+    if (rc) return rc;
+    if (n_planes < 0 || n_planes > TRK_MAX_PLANES) return fail(ctx, TRK_ERR_ARG, "n_planes %d > %d", n_planes, TRK_MAX_PLANES);
+    if (n_filters < 0 || n_filters > TRK_MAX_FILTERS)
+        return fail(ctx, TRK_ERR_ARG, "n_filters %d > %d", n_filters, TRK_MAX_FILTERS);
+    if (!out || !out->sample_counters || !out->sample_totaldp || !out->sample_dp_missing || !out->error)
+        return fail(ctx, TRK_ERR_ARG, "call-filter outputs are NULL");
+    if (dp_plane >= n_planes) return fail(ctx, TRK_ERR_ARG, "dp_plane out of range");
+    if (dp_plane >= 0 && planes[dp_plane].dtype != TRK_DT_I32)
+        return fail(ctx, TRK_ERR_ARG, "the DP/LC plane must be int32");
+    for (int i = 0; i < n_planes; ++i) {
+        if (!planes[i].data || planes[i].ncol < 1) return fail(ctx, TRK_ERR_ARG, "plane %d is empty", i);
+        if (planes[i].dtype != TRK_DT_I32 && planes[i].dtype != TRK_DT_F32)
+            return fail(ctx, TRK_ERR_ARG, "plane %d has unknown dtype", i);
+    }
+    for (int k = 0; k < n_filters; ++k) {
+        const trk_call_filter& f = filters[k];
+        if (f.op < TRK_F_LT || f.op > TRK_F_AD_SUPPORT_LT) return fail(ctx, TRK_ERR_ARG, "filter %d: unknown op %d", k, f.op);
+        if (f.plane_a < 0 || f.plane_a >= n_planes) return fail(ctx, TRK_ERR_ARG, "filter %d: plane_a out of range", k);
+        const bool needs_b = f.op == TRK_F_RATIO_GT || f.op == TRK_F_CALLED_EQ || f.op == TRK_F_CALLED_SUM_EQ ||
+                             f.op == TRK_F_CALLED_OUTSIDE_CI;
+        if (needs_b && (f.plane_b < 0 || f.plane_b >= n_planes))
+            return fail(ctx, TRK_ERR_ARG, "filter %d: plane_b out of range", k);
+        if (f.op != TRK_F_CALLED_OUTSIDE_CI && f.op != TRK_F_AD_SUPPORT_LT &&
+            (f.col_a < 0 || f.col_a >= planes[f.plane_a].ncol))
+            return fail(ctx, TRK_ERR_ARG, "filter %d: col_a out of range", k);
+        if ((f.op == TRK_F_CALLED_SUM_LT || f.op == TRK_F_CALLED_SUM_EQ) &&
+            (f.col_a2 < 0 || f.col_a2 >= planes[f.plane_a].ncol))
+            return fail(ctx, TRK_ERR_ARG, "filter %d: col_a2 out of range", k);
+        if (needs_b && f.op != TRK_F_CALLED_OUTSIDE_CI && (f.col_b < 0 || f.col_b >= planes[f.plane_b].ncol))
+            return fail(ctx, TRK_ERR_ARG, "filter %d: col_b out of range", k);
+        if (f.op == TRK_F_CALLED_OUTSIDE_CI && planes[f.plane_b].ncol < 2 * planes[f.plane_a].ncol)
+            return fail(ctx, TRK_ERR_ARG, "filter %d: REPCI plane needs 2 columns per REPCN column", k);
+        if ((f.op == TRK_F_CALLED_EQ || f.op == TRK_F_CALLED_SUM_EQ || f.op == TRK_F_CALLED_OUTSIDE_CI ||
+             f.op == TRK_F_AD_SUPPORT_LT) &&
+            planes[f.plane_a].dtype != TRK_DT_I32)
+            return fail(ctx, TRK_ERR_ARG, "filter %d: integer plane required", k);
+    }
+    if (in->n_loci == 0 || in->n_samples == 0) return TRK_OK;
+    (void)hipSetDevice(ctx->device);
+    ProfScope ps(ctx, TRK_K_CALL_FILTER);
+    HIPCHK(ctx, trk::launch_call_filter(*in, planes, n_planes, filters, n_filters, dp_plane, *out, ctx->n_cu,
+                                        ctx->stream));
+    return TRK_OK;
+}
+
+int trk_locus_filters(trk_ctx* ctx, int32_t n_loci, const trk_stats_out* stats, const trk_locus_filter_spec* spec,
+                      trk_locus_out* out) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (!stats || !spec || !out || !out->locus_bits || !out->loc_counters || !stats->locus_int || !stats->locus_f64)
+        return fail(ctx, TRK_ERR_ARG, "locus-filter arguments are NULL");
+    if (spec->n_extern < 0 || spec->n_extern > 24) return fail(ctx, TRK_ERR_ARG, "n_extern outside [0,24]");
+    if (n_loci <= 0) return TRK_OK;
+    (void)hipSetDevice(ctx->device);
+    ProfScope ps(ctx, TRK_K_LOCUS_FILTER);
+    HIPCHK(ctx, trk::launch_locus_filter(n_loci, stats->locus_int, stats->locus_f64, *spec, out->locus_bits,
+                                         out->loc_counters, ctx->stream));
+    return TRK_OK;
+}
+
+int trk_synth_fill(trk_ctx* ctx, const trk_synth_spec* spec, int16_t* gt, int32_t* dp, float* q, int32_t* dstutter,
+                   int32_t* dflankindel) {
+    if (!ctx || !spec || !gt) return fail(ctx, TRK_ERR_ARG, "synth arguments are NULL");
+    (void)hipSetDevice(ctx->device);
+    ProfScope ps(ctx, TRK_K_SYNTH);
+    HIPCHK(ctx, trk::launch_synth(*spec, gt, dp, q, dstutter, dflankindel, ctx->n_cu, ctx->stream));
+    return TRK_OK;
+}
+
+// ---- multi-GPU -------------------------------------------------------------------
+int trk_comm_unique_id(uint8_t id[128]) {
+    std::string err;
+    if (!load_rccl(err)) return fail(nullptr, TRK_ERR_RCCL, "%s", err.c_str());
+    ncclUniqueId uid;
+    ncclResult_t r = g_rccl.GetUniqueId(&uid);
+    if (r != 0) return fail(nullptr, TRK_ERR_RCCL, "ncclGetUniqueId failed (%d)", r);
+    memcpy(id, uid.internal, 128);
+    return TRK_OK;
+}
+
+int trk_comm_init(trk_ctx* ctx, int rank, int n_ranks, const uint8_t id[128]) {
+    if (!ctx) return TRK_ERR_ARG;
+    std::string err;
+    if (!load_rccl(err)) return fail(ctx, TRK_ERR_RCCL, "%s", err.c_str());
+    (void)hipSetDevice(ctx->device);
+    ncclUniqueId uid;
+    memcpy(uid.internal, id, 128);
+    ncclResult_t r = g_rccl.CommInitRank(&ctx->comm, n_ranks, uid, rank);
+    if (r != 0)
+        return fail(ctx, TRK_ERR_RCCL, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    ctx->rank = rank;
+    ctx->n_ranks = n_ranks;
+    return TRK_OK;
+}
+
+int trk_allreduce_sum_i64(trk_ctx* ctx, int64_t* dev, size_t count) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (ctx->n_ranks <= 1 && !ctx->comm) return TRK_OK;
+    if (!ctx->comm) return fail(ctx, TRK_ERR_RCCL, "communicator not initialised");
+    ncclResult_t r = g_rccl.AllReduce(dev, dev, count, trkNcclInt64, trkNcclSum, ctx->comm, ctx->stream);
+    if (r != 0) return fail(ctx, TRK_ERR_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    return TRK_OK;
+}
+
+int trk_allgather(trk_ctx* ctx, const void* send, void* recv, size_t bytes_per_rank) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (ctx->n_ranks <= 1 && !ctx->comm) {
+        if (send != recv) HIPCHK(ctx, hipMemcpyAsync(recv, send, bytes_per_rank, hipMemcpyDeviceToDevice, ctx->stream));
+        return TRK_OK;
+    }
+    if (!ctx->comm) return fail(ctx, TRK_ERR_RCCL, "communicator not initialised");
+    ncclResult_t r = g_rccl.AllGather(send, recv, bytes_per_rank, trkNcclUint8, ctx->comm, ctx->stream);
+    if (r != 0) return fail(ctx, TRK_ERR_RCCL, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    return TRK_OK;
+}
+
+// ---- scalar helpers --------------------------------------------------------------
+double trk_binomtest_two_sided(int64_t k, int64_t n, double p) {
+    if (n < 1 || k < 0 || k > n || !(p >= 0.0 && p <= 1.0)) return std::nan("");
+    return trkmath::binomtest_two_sided(k, n, p);
+}
+double trk_binom_pmf(int64_t k, int64_t n, double p) { return trkmath::binom_pmf(k, n, p); }
+
+}  // extern "C"

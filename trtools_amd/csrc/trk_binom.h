@@ -1,0 +1,188 @@
+// trk_binom.h -- float64 binomial pmf / tails / two-sided exact test, usable on
+// host and device.  Replaces the third-party call at the end of the reference's
+// HWE statistic (trtools/utils/utils.py:334-338):
+//     scipy.stats.binomtest(num_hom, n=total_samples, p=exp_hom_frac).pvalue
+// scipy (1.15.3, _binomtest.py, two-sided branch) does:
+//     d = pmf(k); rerr = 1 + 1e-7
+//     k == p*n            -> 1
+//     k <  p*n : ix = bsearch(-pmf, -d*rerr, ceil(p*n), n)
+//                y  = n - ix + (d*rerr == pmf(ix));  pval = cdf(k) + sf(n-y)
+//     k >  p*n : ix = bsearch(pmf, d*rerr, 0, floor(p*n))
+//                y  = ix + 1;                        pval = cdf(y-1) + sf(k-1)
+//     min(1, pval)
+// with `_binary_search_for_binom_tst` returning mid on equality, else lo or lo-1
+// by a final `a(lo) <= d` test.  The search bounds are floats in scipy (np.ceil /
+// np.floor of p*n); they hold integral values, so int64 reproduces them.
+//
+// pmf: Loader's saddle-point evaluation (C. Loader, "Fast and accurate
+// computation of binomial probabilities", 2000) -- relative error ~1e-15, the
+// same class of accuracy as the boost implementation behind scipy's binom.pmf.
+// Tails: every tail the test needs lies on the far side of the mean from the
+// mode, so the terms decay monotonically away from the starting point and are
+// summed directly with the pmf ratio recurrence until they no longer contribute.
+#ifndef TRK_BINOM_H
+#define TRK_BINOM_H
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define TRK_HD __host__ __device__
+#else
+#define TRK_HD
+#endif
+
+namespace trkmath {
+
+// Stirling series error  ln(n!) - [ (n+1/2) ln n - n + ln sqrt(2 pi) ]
+TRK_HD inline double stirlerr(double n) {
+    const double S0 = 0.083333333333333333333;        // 1/12
+    const double S1 = 0.00277777777777777777778;      // 1/360
+    const double S2 = 0.00079365079365079365079365;   // 1/1260
+    const double S3 = 0.000595238095238095238095238;  // 1/1680
+    const double S4 = 0.0008417508417508417508417508; // 1/1188
+    if (n <= 15.0) {
+        // exact values for integer n (only integers reach this function)
+        switch ((int)n) {
+            case 0: return 0.0;
+            case 1: return 0.0810614667953272610700921;
+            case 2: return 0.0413406959554092970354766;
+            case 3: return 0.0276779256849983383570457;
+            case 4: return 0.0207906721037650933647800;
+            case 5: return 0.0166446911898211931390978;
+            case 6: return 0.0138761288230707484359083;
+            case 7: return 0.0118967099458917695276039;
+            case 8: return 0.0104112652619720962021699;
+            case 9: return 0.0092554621827127328548279;
+            case 10: return 0.0083305634333628707927089;
+            case 11: return 0.0075736754879518405902949;
+            case 12: return 0.0069428401072095299179088;
+            case 13: return 0.0064089941880042071431500;
+            case 14: return 0.0059513701127588474956709;
+            default: return 0.0055547335519628010525039;
+        }
+    }
+    double nn = n * n;
+    if (n > 500.0) return (S0 - S1 / nn) / n;
+    if (n > 80.0) return (S0 - (S1 - S2 / nn) / nn) / n;
+    if (n > 35.0) return (S0 - (S1 - (S2 - S3 / nn) / nn) / nn) / n;
+    return (S0 - (S1 - (S2 - (S3 - S4 / nn) / nn) / nn) / nn) / n;
+}
+
+// deviance term  x ln(x/np) + np - x , accurate when x ~ np
+TRK_HD inline double bd0(double x, double np) {
+    if (fabs(x - np) < 0.1 * (x + np)) {
+        double v = (x - np) / (x + np);
+        double s = (x - np) * v;
+        double ej = 2.0 * x * v;
+        v = v * v;
+        for (int j = 1; j < 1000; ++j) {
+            ej *= v;
+            double s1 = s + ej / (double)(2 * j + 1);
+            if (s1 == s) return s1;
+            s = s1;
+        }
+        return s;
+    }
+    return x * log(x / np) + np - x;
+}
+
+TRK_HD inline double binom_pmf(int64_t ki, int64_t ni, double p) {
+    if (ki < 0 || ki > ni) return 0.0;
+    double k = (double)ki, n = (double)ni, q = 1.0 - p;
+    if (p <= 0.0) return ki == 0 ? 1.0 : 0.0;
+    if (q <= 0.0) return ki == ni ? 1.0 : 0.0;
+    if (ki == 0) {
+        if (ni == 0) return 1.0;
+        double lc = (p < 0.1) ? -bd0(n, n * q) - n * p : n * log(q);
+        return exp(lc);
+    }
+    if (ki == ni) {
+        double lc = (q < 0.1) ? -bd0(n, n * p) - n * q : n * log(p);
+        return exp(lc);
+    }
+    double lc = stirlerr(n) - stirlerr(k) - stirlerr(n - k) - bd0(k, n * p) - bd0(n - k, n * q);
+    // ln(2 pi k (n-k)/n)
+    double lf = 1.8378770664093455611265426 + log(k) + log1p(-k / n);
+    return exp(lc - 0.5 * lf);
+}
+
+// sum_{i=0..k} pmf(i); intended for k at or below the mean (terms shrink downwards)
+TRK_HD inline double binom_lower_tail(int64_t k, int64_t n, double p) {
+    if (k < 0) return 0.0;
+    if (k >= n) return 1.0;
+    double q = 1.0 - p;
+    if (p <= 0.0) return 1.0;
+    if (q <= 0.0) return 0.0;  // k < n
+    double t = binom_pmf(k, n, p);
+    double sum = t;
+    double r = q / p;
+    for (int64_t i = k; i > 0; --i) {
+        double ratio = ((double)i / (double)(n - i + 1)) * r;
+        t *= ratio;
+        sum += t;
+        if (ratio < 1.0 && t <= sum * 1e-18) break;
+    }
+    return sum;
+}
+
+// sum_{i=k+1..n} pmf(i) = sf(k); intended for k+1 at or above the mean
+TRK_HD inline double binom_upper_tail(int64_t k, int64_t n, double p) {
+    if (k >= n) return 0.0;
+    if (k < 0) return 1.0;
+    double q = 1.0 - p;
+    if (p <= 0.0) return 0.0;
+    if (q <= 0.0) return 1.0;  // k < n
+    double t = binom_pmf(k + 1, n, p);
+    double sum = t;
+    double r = p / q;
+    for (int64_t i = k + 1; i < n; ++i) {
+        double ratio = ((double)(n - i) / (double)(i + 1)) * r;
+        t *= ratio;
+        sum += t;
+        if (ratio < 1.0 && t <= sum * 1e-18) break;
+    }
+    return sum;
+}
+
+// scipy _binary_search_for_binom_tst on a(x) = sign * pmf(x)
+TRK_HD inline int64_t binom_bsearch(double sign, double d, int64_t lo, int64_t hi, int64_t n,
+                                    double p) {
+    while (lo < hi) {
+        int64_t mid = lo + (hi - lo) / 2;
+        double midval = sign * binom_pmf(mid, n, p);
+        if (midval < d) {
+            lo = mid + 1;
+        } else if (midval > d) {
+            hi = mid - 1;
+        } else {
+            return mid;
+        }
+    }
+    if (sign * binom_pmf(lo, n, p) <= d) return lo;
+    return lo - 1;
+}
+
+// scipy.stats.binomtest(k, n, p, alternative='two-sided').pvalue  (n >= 1, 0 <= k <= n)
+TRK_HD inline double binomtest_two_sided(int64_t k, int64_t n, double p) {
+    double d = binom_pmf(k, n, p);
+    const double rerr = 1.0 + 1e-7;
+    double pn = p * (double)n;
+    double kd = (double)k;
+    double pval;
+    if (kd == pn) {
+        pval = 1.0;
+    } else if (kd < pn) {
+        int64_t ix = binom_bsearch(-1.0, -d * rerr, (int64_t)ceil(pn), n, n, p);
+        int64_t y = n - ix + ((d * rerr == binom_pmf(ix, n, p)) ? 1 : 0);
+        pval = binom_lower_tail(k, n, p) + binom_upper_tail(n - y, n, p);
+    } else {
+        int64_t ix = binom_bsearch(1.0, d * rerr, 0, (int64_t)floor(pn), n, p);
+        int64_t y = ix + 1;
+        pval = binom_lower_tail(y - 1, n, p) + binom_upper_tail(k - 1, n, p);
+    }
+    return pval < 1.0 ? pval : 1.0;
+}
+
+}  // namespace trkmath
+#endif

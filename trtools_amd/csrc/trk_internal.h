@@ -1,0 +1,25 @@
+// trk_internal.h -- declarations shared by trk_kernels.hip and trk_api.hip
+#ifndef TRK_INTERNAL_H
+#define TRK_INTERNAL_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/trk.h"
+
+#define TRK_MAX_PLOIDY 8
+
+namespace trk {
+hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* allele_count, int32_t* locus_int,
+                              int n_cu, hipStream_t stream);
+hipError_t launch_locus_finalize(const trk_batch& b, const int32_t* allele_count, int32_t* locus_int,
+                                 double* locus_f64, int32_t* scratch, double nalleles_thresh, hipStream_t stream);
+hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n_planes,
+                              const trk_call_filter* filters, int n_filters, int dp_plane, const trk_call_out& out,
+                              int n_cu, hipStream_t stream);
+hipError_t launch_locus_filter(int L, const int32_t* locus_int, const double* locus_f64,
+                               const trk_locus_filter_spec& spec, uint32_t* bits, int64_t* counters,
+                               hipStream_t stream);
+hipError_t launch_synth(const trk_synth_spec& sp, int16_t* gt, int32_t* dp, float* q, int32_t* dstutter,
+                        int32_t* dflank, int n_cu, hipStream_t stream);
+}  // namespace trk
+#endif

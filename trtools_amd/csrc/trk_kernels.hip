@@ -1,0 +1,915 @@
+// trk_kernels.hip -- gfx950 (MI355X / CDNA4) device code of libtrk.
+//
+// The hot path is HBM-bound integer work: stream the [L, S, P] int16 genotype
+// tensor once, histogram allele indices per locus, fold a handful of per-row
+// predicates, and (dumpSTR) evaluate the call-level filter predicates on the
+// FORMAT planes.  No MFMA: nothing here is a contraction.  What matters on
+// CDNA4 is 16-byte-per-lane coalesced streaming, enough loads in flight per CU,
+// conflict-free LDS histogram updates and no atomics on the streaming path.
+//
+// Kernels
+//   k_locus_count      one 64-lane wavefront per locus row (no __syncthreads on
+//                      the streaming path; waves of a workgroup are independent).
+//                      Allele histogram in LDS with K bank-private copies:
+//                      lane i updates copy (i mod K) of bin b at word b*K + i%K,
+//                      so the 32 lanes of a ds_add_u32 lane group always hit 32
+//                      different banks no matter how skewed the allele
+//                      frequencies are (a plain histogram serialises ~32-way on
+//                      the major allele).
+//   k_locus_finalize   one thread per (group, locus): O(A) float64 statistics in
+//                      the reference's summation order + the exact binomial HWE
+//                      test (trk_binom.h).
+//   k_call_filter      column-owner tiling: a thread owns 4 consecutive samples
+//                      and walks a block of loci, so the per-sample counters
+//                      (dumpSTR sample_info) live in registers / thread-private
+//                      LDS slots and are flushed once per block.
+//   k_locus_filter     one thread per locus: filter bits + loc_info counters.
+//   k_synth            counter-based synthetic genotype / FORMAT generator.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/trk.h"
+#include "trk_binom.h"
+#include "trk_internal.h"
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int COUNT_WAVES_PER_WG = 4;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        int t = __shfl_xor(v, o, WAVE);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+// order LDS traffic of one wavefront (the hardware executes a wave's DS
+// operations in order; this stops the compiler from moving them)
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---------------------------------------------------------------------------
+// k_locus_count
+// ---------------------------------------------------------------------------
+// extra bins appended to each group's histogram in the grouped path
+enum { XB_CALLED = 0, XB_LOW = 1, XB_HOML = 2, XB_HOMS = 3, XB_NSAMP = 4, XB_BAD = 5, XB_N = 6 };
+
+struct RowCtx {
+    uint32_t* hist;      // LDS, this wave's histogram region
+    const uint32_t* lut; // LDS class LUT (lc | sc << 16) or nullptr
+    const uint16_t* lc_g;  // global class tables (already offset to this locus)
+    const uint16_t* sc_g;
+    int A;
+    int K;               // copies per bin (power of two)
+    int kslot;           // lane & (K-1)
+    int stride;          // bins per group = A + XB_N (grouped path)
+    bool dup_len, dup_str;
+    bool direct;         // histogram too large for LDS: global atomics
+    int32_t* cnt_g;      // allele_count + off (group 0)
+    int64_t sumA;        // group stride of allele_count
+    int pl;              // ploidy of this locus
+};
+
+__device__ __forceinline__ void class_of(const RowCtx& c, int a, int& lc, int& sc) {
+    if (c.lut) {
+        uint32_t v = c.lut[a];
+        lc = v & 0xffff;
+        sc = v >> 16;
+    } else {
+        lc = c.lc_g[a];
+        sc = c.sc_g[a];
+    }
+}
+
+// One diploid call (two haplotypes), no sample groups: histogram to LDS,
+// row predicates to registers.
+__device__ __forceinline__ void cell_p2(const RowCtx& c, uint32_t w, int& n_called, int& n_low,
+                                        int& n_hl, int& n_hs, int& n_bad) {
+    int a0 = (int16_t)(w & 0xffffu);
+    int a1 = (int16_t)(w >> 16);
+    if (c.pl < 2) a1 = -3;  // haploid locus inside a P=2 batch: second column ignored
+    bool miss = (a0 == -1) | (a1 == -1);
+    bool low = (a0 == -2) | (a1 == -2);
+    bool v0 = a0 >= 0, v1 = a1 >= 0;
+    bool b0 = v0 & (a0 >= c.A), b1 = v1 & (a1 >= c.A);
+    n_bad += (int)b0 + (int)b1;
+    v0 &= !b0;
+    v1 &= !b1;
+    if (!c.direct) {
+        if (v0 & v1 & (a0 == a1)) {
+            atomicAdd(&c.hist[a0 * c.K + c.kslot], 2u);
+        } else {
+            if (v0) atomicAdd(&c.hist[a0 * c.K + c.kslot], 1u);
+            if (v1) atomicAdd(&c.hist[a1 * c.K + c.kslot], 1u);
+        }
+    } else {
+        if (v0) atomicAdd(&c.cnt_g[a0], 1);
+        if (v1) atomicAdd(&c.cnt_g[a1], 1);
+    }
+    if (!miss) {
+        n_called++;
+        if (low) {
+            n_low++;
+        } else if (c.pl == 2 && v0 && v1) {
+            bool same = a0 == a1;
+            bool hl = same, hs = same;
+            if (!same && (c.dup_len | c.dup_str)) {
+                int l0, s0, l1, s1;
+                class_of(c, a0, l0, s0);
+                class_of(c, a1, l1, s1);
+                hl = l0 == l1;
+                hs = s0 == s1;
+            }
+            n_hl += hl;
+            n_hs += hs;
+        }
+    }
+}
+
+// General call: `P` haplotypes in vals[], optional group bits.  Everything goes
+// through the (LDS or global) bins; used for P != 2 and for stratified runs.
+template <int PMAX>
+__device__ __forceinline__ void cell_general(const RowCtx& c, const int* vals, int P, uint32_t gbits,
+                                             int G, int32_t* li_g, int64_t li_gstride) {
+    bool miss = false, low = false;
+    int nbad = 0;
+    int pl = c.pl;
+    for (int j = 0; j < pl; ++j) {
+        int a = vals[j];
+        miss |= a == -1;
+        low |= a == -2;
+        nbad += (a >= c.A);
+    }
+    bool hl = false, hs = false;
+    bool called = !miss;
+    if (called && !low && pl >= 2 && nbad == 0) {
+        // sorted genotype tuple: gt[0] == gt[1]  <=>  the smallest class occurs twice
+        int minl = 0x7fffffff, mins = 0x7fffffff, cl = 0, cs = 0;
+        for (int j = 0; j < pl; ++j) {
+            int l, s;
+            class_of(c, vals[j], l, s);
+            if (l < minl) { minl = l; cl = 1; } else if (l == minl) { cl++; }
+            if (s < mins) { mins = s; cs = 1; } else if (s == mins) { cs++; }
+        }
+        hl = cl >= 2;
+        hs = cs >= 2;
+    }
+    for (int g = 0; g < G; ++g) {
+        if (!((gbits >> g) & 1u)) continue;
+        if (!c.direct) {
+            uint32_t* h = c.hist + (size_t)g * c.stride * c.K;
+            for (int j = 0; j < pl; ++j) {
+                int a = vals[j];
+                if (a >= 0 && a < c.A) atomicAdd(&h[a * c.K + c.kslot], 1u);
+            }
+            uint32_t* x = h + c.A * c.K;
+            atomicAdd(&x[XB_NSAMP * c.K + c.kslot], 1u);
+            if (nbad) atomicAdd(&x[XB_BAD * c.K + c.kslot], (uint32_t)nbad);
+            if (called) {
+                atomicAdd(&x[XB_CALLED * c.K + c.kslot], 1u);
+                if (low) atomicAdd(&x[XB_LOW * c.K + c.kslot], 1u);
+                if (hl) atomicAdd(&x[XB_HOML * c.K + c.kslot], 1u);
+                if (hs) atomicAdd(&x[XB_HOMS * c.K + c.kslot], 1u);
+            }
+        } else {
+            int32_t* cg = c.cnt_g + (size_t)g * c.sumA;
+            for (int j = 0; j < pl; ++j) {
+                int a = vals[j];
+                if (a >= 0 && a < c.A) atomicAdd(&cg[a], 1);
+            }
+            int32_t* li = li_g + g * li_gstride;
+            atomicAdd(&li[TRK_LI_N_SAMPLES], 1);
+            if (nbad) atomicAdd(&li[TRK_LI_N_BAD], nbad);
+            if (called) {
+                atomicAdd(&li[TRK_LI_N_CALLED], 1);
+                if (low) atomicAdd(&li[TRK_LI_N_LOWPLOIDY], 1);
+                if (hl) atomicAdd(&li[TRK_LI_N_HOM_LEN], 1);
+                if (hs) atomicAdd(&li[TRK_LI_N_HOM_STR], 1);
+            }
+        }
+    }
+}
+
+template <bool FAST2>  // FAST2: P == 2 and no sample groups
+__global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count(
+    trk_batch b, int32_t* __restrict__ allele_count, int32_t* __restrict__ locus_int, int hist_entries,
+    int lut_entries) {
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wid = threadIdx.x >> 6;
+    uint32_t* hist = lds + (size_t)wid * (hist_entries + lut_entries);
+    uint32_t* lut = hist + hist_entries;
+    const int total_waves = gridDim.x * COUNT_WAVES_PER_WG;
+    const int L = b.n_loci, S = b.n_samples, P = b.ploidy;
+    const int G = b.group_bits ? b.n_groups : 1;
+    const int64_t sumA = b.n_alleles_total;
+
+    for (int l = blockIdx.x * COUNT_WAVES_PER_WG + wid; l < L; l += total_waves) {
+        const int off = b.allele_off[l];
+        const int A = b.allele_off[l + 1] - off;
+        RowCtx c;
+        c.A = A;
+        c.pl = b.locus_ploidy ? (int)b.locus_ploidy[l] : P;
+        if (c.pl > P) c.pl = P;
+        c.lc_g = b.len_class + off;
+        c.sc_g = b.str_class + off;
+        c.cnt_g = allele_count + off;
+        c.sumA = sumA;
+        c.hist = hist;
+        // class LUT + duplicate detection (classes are dense ranks: a duplicate
+        // exists iff max rank + 1 < A)
+        const bool lut_lds = A <= lut_entries;
+        int ml = 0, ms = 0;
+        for (int a = lane; a < A; a += WAVE) {
+            int lc = c.lc_g[a], sc = c.sc_g[a];
+            if (lut_lds) lut[a] = (uint32_t)lc | ((uint32_t)sc << 16);
+            ml = lc > ml ? lc : ml;
+            ms = sc > ms ? sc : ms;
+        }
+        ml = wave_max(ml);
+        ms = wave_max(ms);
+        c.dup_len = ml + 1 < A;
+        c.dup_str = ms + 1 < A;
+        c.lut = lut_lds ? lut : nullptr;
+        c.stride = FAST2 ? A : A + XB_N;
+        const int bins = G * c.stride;
+        int K = 32;
+        while (K > 1 && bins * K > hist_entries) K >>= 1;
+        c.direct = bins * K > hist_entries;
+        c.K = K;
+        c.kslot = lane & (K - 1);
+        if (!c.direct)
+            for (int i = lane; i < bins * K; i += WAVE) hist[i] = 0;
+        wave_lds_fence();
+
+        int n_called = 0, n_low = 0, n_hl = 0, n_hs = 0, n_bad = 0;
+        const int64_t row0 = (int64_t)l * S;
+        int32_t* li0 = locus_int + (int64_t)l * TRK_LI_COLS;
+        const int64_t li_gstride = (int64_t)L * TRK_LI_COLS;
+        if (FAST2) {
+            // cells are 4-byte (2 x int16); stream 16-byte chunks of the global cell
+            // array that cover [row0, row0 + S), masking cells outside the row
+            const u32x4* g4 = reinterpret_cast<const u32x4*>(b.gt);
+            const int64_t ch_first = row0 >> 2;
+            const int64_t ch_last = (row0 + S - 1) >> 2;
+            const int64_t row1 = row0 + S;
+            constexpr int U = 4;
+            for (int64_t ch = ch_first + lane; ch <= ch_last; ch += (int64_t)WAVE * U) {
+                u32x4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    int64_t cc = ch + (int64_t)u * WAVE;
+                    if (cc <= ch_last) v[u] = __builtin_nontemporal_load(&g4[cc]);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    int64_t cc = ch + (int64_t)u * WAVE;
+                    if (cc > ch_last) break;
+                    int64_t cell = cc << 2;
+                    uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    if (cell >= row0 && cell + 3 < row1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) cell_p2(c, w[j], n_called, n_low, n_hl, n_hs, n_bad);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (cell + j >= row0 && cell + j < row1)
+                                cell_p2(c, w[j], n_called, n_low, n_hl, n_hs, n_bad);
+                    }
+                }
+            }
+        } else {
+            for (int s = lane; s < S; s += WAVE) {
+                int vals[TRK_MAX_PLOIDY];
+                const int16_t* p = b.gt + (row0 + s) * P;
+                for (int j = 0; j < P && j < TRK_MAX_PLOIDY; ++j) vals[j] = p[j];
+                uint32_t gb = b.group_bits ? b.group_bits[s] : 1u;
+                cell_general<TRK_MAX_PLOIDY>(c, vals, P, gb, G, li0, li_gstride);
+            }
+        }
+        wave_lds_fence();
+
+        // fold the K copies of every bin; lane `bin` starts at copy (lane mod K) so
+        // that the 32 lanes of a ds_read lane group touch 32 different banks
+        if (!c.direct) {
+            for (int bin = lane; bin < bins; bin += WAVE) {
+                uint32_t s = 0;
+                for (int k = 0; k < K; ++k) s += hist[bin * K + ((k + lane) & (K - 1))];
+                int g = bin / c.stride;
+                int r = bin - g * c.stride;
+                if (r < A) {
+                    allele_count[(int64_t)g * sumA + off + r] = (int32_t)s;
+                } else {
+                    int x = r - A;
+                    int col = x == XB_CALLED ? TRK_LI_N_CALLED
+                              : x == XB_LOW  ? TRK_LI_N_LOWPLOIDY
+                              : x == XB_HOML ? TRK_LI_N_HOM_LEN
+                              : x == XB_HOMS ? TRK_LI_N_HOM_STR
+                              : x == XB_NSAMP ? TRK_LI_N_SAMPLES
+                                              : TRK_LI_N_BAD;
+                    li0[g * li_gstride + col] = (int32_t)s;
+                }
+            }
+        }
+        if (FAST2) {
+            n_called = wave_sum(n_called);
+            n_low = wave_sum(n_low);
+            n_hl = wave_sum(n_hl);
+            n_hs = wave_sum(n_hs);
+            n_bad = wave_sum(n_bad);
+            if (lane == 0) {
+                li0[TRK_LI_N_CALLED] = n_called;
+                li0[TRK_LI_N_LOWPLOIDY] = n_low;
+                li0[TRK_LI_N_HOM_LEN] = n_hl;
+                li0[TRK_LI_N_HOM_STR] = n_hs;
+                li0[TRK_LI_N_BAD] = n_bad;
+                li0[TRK_LI_N_SAMPLES] = S;
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_locus_finalize : one thread per (group, locus)
+// ---------------------------------------------------------------------------
+struct ModeStats {
+    double het, entropy, hwep;
+    int nalleles, status;
+};
+
+// class counts are in cc[0..ncls), ascending class order == the dict order the
+// reference iterates in (np.unique sorts keys; tr_harmonizer.py:1495-1499)
+__device__ void mode_stats(const int32_t* cc, int ncls, int64_t total, double nalleles_thresh,
+                           int n_called, int n_low, int n_hom, int pl, ModeStats& o) {
+    const double nan = __builtin_nan("");
+    o.het = o.entropy = o.hwep = nan;
+    o.nalleles = 0;
+    o.status = TRK_HWE_NAN;
+    if (total <= 0) return;  // ValidateAlleleFreqs: empty dict  (utils.py:139)
+    const double ft = (double)total;  // float(sum(counts))   (tr_harmonizer.py:1539)
+    double fsum = 0.0, sq = 0.0;
+    int na = 0;
+    for (int c = 0; c < ncls; ++c) {
+        int n = cc[c];
+        if (n == 0) continue;
+        double f = (double)n / ft;
+        fsum += f;
+        sq += f * f;
+        na += f >= nalleles_thresh;
+    }
+    o.nalleles = na;  // statSTR.py:207 (no validity check there)
+    if (!(fabs(1.0 - fsum) <= 0.001)) return;  // utils.py:140
+    o.het = 1.0 - sq;                          // utils.py:175
+    // scipy.stats.entropy(pk, base=2): pk /= sum(pk); -sum(pk ln pk) / ln 2
+    double ent = 0.0;
+    for (int c = 0; c < ncls; ++c) {
+        int n = cc[c];
+        if (n == 0) continue;
+        double pk = ((double)n / ft) / fsum;
+        ent -= pk * log(pk);
+    }
+    ent /= 0.693147180559945309417232;
+    o.entropy = ent == 0.0 ? 0.0 : ent;  // normalise -0.0
+    // GetHardyWeinbergBinomialTest utils.py:325-338
+    if (n_called == 0) {
+        o.status = TRK_HWE_VALUE_ERROR;  // binomtest(0, n=0): ValueError
+    } else if (pl < 2) {
+        o.status = TRK_HWE_INDEX_ERROR;  // gt[1] on a 1-tuple
+    } else if (n_low > 0) {
+        o.status = TRK_HWE_NAN;  // a -2 / ',' haplotype is not in allele_freqs
+    } else {
+        o.status = TRK_HWE_OK;
+        o.hwep = trkmath::binomtest_two_sided(n_hom, n_called, sq);
+    }
+}
+
+__global__ __launch_bounds__(128) void k_locus_finalize(trk_batch b, const int32_t* __restrict__ allele_count,
+                                                       int32_t* __restrict__ locus_int,
+                                                       double* __restrict__ locus_f64,
+                                                       int32_t* __restrict__ scratch, double nalleles_thresh) {
+    const int L = b.n_loci;
+    const int G = b.group_bits ? b.n_groups : 1;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)G * L) return;
+    const int g = (int)(t / L);
+    const int l = (int)(t - (int64_t)g * L);
+    const int off = b.allele_off[l];
+    const int A = b.allele_off[l + 1] - off;
+    const int64_t sumA = b.n_alleles_total;
+    const int32_t* cnt = allele_count + (int64_t)g * sumA + off;
+    int32_t* ccl = scratch + ((int64_t)g * 2 + 0) * sumA + off;
+    int32_t* ccs = scratch + ((int64_t)g * 2 + 1) * sumA + off;
+    int32_t* li = locus_int + ((int64_t)g * L + l) * TRK_LI_COLS;
+    double* lf = locus_f64 + ((int64_t)g * L + l) * TRK_LF_COLS;
+    const double nan = __builtin_nan("");
+
+    for (int a = 0; a < A; ++a) {
+        ccl[a] = 0;
+        ccs[a] = 0;
+    }
+    int64_t total = 0;
+    for (int a = 0; a < A; ++a) {
+        int n = cnt[a];
+        ccl[b.len_class[off + a]] += n;
+        ccs[b.str_class[off + a]] += n;
+        total += n;
+    }
+    li[TRK_LI_N_ALLELES] = (int32_t)total;
+    const int n_called = li[TRK_LI_N_CALLED];
+    const int n_low = li[TRK_LI_N_LOWPLOIDY];
+    int pl = b.locus_ploidy ? (int)b.locus_ploidy[l] : b.ploidy;
+
+    ModeStats ml, ms;
+    mode_stats(ccl, A, total, nalleles_thresh, n_called, n_low, li[TRK_LI_N_HOM_LEN], pl, ml);
+    mode_stats(ccs, A, total, nalleles_thresh, n_called, n_low, li[TRK_LI_N_HOM_STR], pl, ms);
+    li[TRK_LI_HWE_STATUS_LEN] = ml.status;
+    li[TRK_LI_HWE_STATUS_STR] = ms.status;
+    li[TRK_LI_NALLELES_LEN] = ml.nalleles;
+    li[TRK_LI_NALLELES_STR] = ms.nalleles;
+    lf[TRK_LF_HET_LEN] = ml.het;
+    lf[TRK_LF_HET_STR] = ms.het;
+    lf[TRK_LF_ENTROPY_LEN] = ml.entropy;
+    lf[TRK_LF_ENTROPY_STR] = ms.entropy;
+    lf[TRK_LF_HWEP_LEN] = ml.hwep;
+    lf[TRK_LF_HWEP_STR] = ms.hwep;
+
+    // always-by-length statistics (statSTR.py:126,347,375,402)
+    double thresh = nan, mean = nan, mode = nan, var = nan;
+    if (total > 0) {
+        const double* cv = b.len_class_value + off;
+        const double ft = (double)total;
+        double fsum = 0.0;
+        int best = -1, bestn = 0;
+        for (int c = 0; c < A; ++c) {
+            int n = ccl[c];
+            if (n == 0) continue;
+            fsum += (double)n / ft;
+            thresh = cv[c];  // ascending classes: the last non-empty one is the max
+            if (n > bestn) {  // first maximum == min over ties (utils.py:263-271)
+                bestn = n;
+                best = c;
+            }
+        }
+        if (fabs(1.0 - fsum) <= 0.001) {
+            double m = 0.0;
+            for (int c = 0; c < A; ++c) {
+                int n = ccl[c];
+                if (n == 0) continue;
+                m += cv[c] * ((double)n / ft);  // utils.py:236
+            }
+            double v = 0.0;
+            for (int c = 0; c < A; ++c) {
+                int n = ccl[c];
+                if (n == 0) continue;
+                double d = cv[c] - m;
+                v += ((double)n / ft) * (d * d);  // utils.py:296
+            }
+            mean = m;
+            var = v;
+            mode = cv[best];
+        }
+    }
+    lf[TRK_LF_THRESH] = thresh;
+    lf[TRK_LF_MEAN] = mean;
+    lf[TRK_LF_MODE] = mode;
+    lf[TRK_LF_VAR] = var;
+    int ns = li[TRK_LI_N_SAMPLES];
+    lf[TRK_LF_CALLRATE] = ns > 0 ? (double)n_called / (double)ns : nan;  // tr_harmonizer.py:946
+    lf[11] = 0.0;
+}
+
+// ---------------------------------------------------------------------------
+// k_call_filter : dumpSTR call-level filters, column-owner tiling
+// ---------------------------------------------------------------------------
+constexpr int CF_THREADS = 256;
+constexpr int CF_V = 4;  // samples per thread
+
+__device__ __forceinline__ double plane_val(const trk_plane& p, int64_t cell, int col) {
+    if (p.dtype == TRK_DT_I32) return (double)reinterpret_cast<const int32_t*>(p.data)[cell * p.ncol + col];
+    return (double)reinterpret_cast<const float*>(p.data)[cell * p.ncol + col];
+}
+
+// evaluate one filter on one call; returns true when the filter fires
+__device__ __forceinline__ bool eval_filter(const trk_call_filter& f, const trk_plane* planes, int64_t cell,
+                                            bool called, const int* gtv, int P, int pl) {
+    const trk_plane& pa = planes[f.plane_a];
+    switch (f.op) {
+        case TRK_F_LT:
+        case TRK_F_CALLED_LT: {
+            if (f.op == TRK_F_CALLED_LT && !called) return false;
+            if (pa.dtype == TRK_DT_F32) {
+                float v = reinterpret_cast<const float*>(pa.data)[cell * pa.ncol + f.col_a];
+                return v < (float)f.thr;  // numpy compares float32 arrays in float32
+            }
+            int32_t v = reinterpret_cast<const int32_t*>(pa.data)[cell * pa.ncol + f.col_a];
+            return (double)v < f.thr;
+        }
+        case TRK_F_GT: {
+            if (pa.dtype == TRK_DT_F32) {
+                float v = reinterpret_cast<const float*>(pa.data)[cell * pa.ncol + f.col_a];
+                return v > (float)f.thr;
+            }
+            int32_t v = reinterpret_cast<const int32_t*>(pa.data)[cell * pa.ncol + f.col_a];
+            return (double)v > f.thr;
+        }
+        case TRK_F_RATIO_GT: {
+            double a = plane_val(pa, cell, f.col_a);
+            double bb = plane_val(planes[f.plane_b], cell, f.col_b);
+            return (a / bb) > f.thr;  // int32/int32 -> float64 true division
+        }
+        case TRK_F_CALLED_SUM_LT: {
+            if (!called) return false;
+            if (pa.dtype == TRK_DT_F32) {
+                const float* d = reinterpret_cast<const float*>(pa.data) + cell * pa.ncol;
+                float s = d[f.col_a] + d[f.col_a2];
+                return s < (float)f.thr;
+            }
+            const int32_t* d = reinterpret_cast<const int32_t*>(pa.data) + cell * pa.ncol;
+            return (double)((int64_t)d[f.col_a] + (int64_t)d[f.col_a2]) < f.thr;
+        }
+        case TRK_F_CALLED_EQ: {
+            if (!called) return false;
+            const int32_t* d = reinterpret_cast<const int32_t*>(pa.data) + cell * pa.ncol;
+            const trk_plane& pb = planes[f.plane_b];
+            int32_t bb = reinterpret_cast<const int32_t*>(pb.data)[cell * pb.ncol + f.col_b];
+            return d[f.col_a] == bb;
+        }
+        case TRK_F_CALLED_SUM_EQ: {
+            if (!called) return false;
+            const int32_t* d = reinterpret_cast<const int32_t*>(pa.data) + cell * pa.ncol;
+            const trk_plane& pb = planes[f.plane_b];
+            int32_t bb = reinterpret_cast<const int32_t*>(pb.data)[cell * pb.ncol + f.col_b];
+            return (int64_t)d[f.col_a] + (int64_t)d[f.col_a2] == (int64_t)bb;
+        }
+        case TRK_F_CALLED_OUTSIDE_CI: {
+            if (!called) return false;
+            const int32_t* ml = reinterpret_cast<const int32_t*>(pa.data) + cell * pa.ncol;
+            const trk_plane& pb = planes[f.plane_b];
+            const int32_t* ci = reinterpret_cast<const int32_t*>(pb.data) + cell * pb.ncol;
+            bool hit = false;
+            for (int j = 0; j < pa.ncol; ++j) hit |= (ml[j] < ci[2 * j]) | (ci[2 * j + 1] < ml[j]);
+            return hit;
+        }
+        case TRK_F_AD_SUPPORT_LT: {
+            // read_support[sample, gt_idx] with numpy negative indexing (filters.py:865)
+            const int32_t* ad = reinterpret_cast<const int32_t*>(pa.data) + cell * pa.ncol;
+            bool hit = false;
+            for (int j = 0; j < pl; ++j) {
+                int a = gtv[j];
+                if (a < 0) a += pa.ncol;
+                if (a < 0 || a >= pa.ncol) continue;
+                hit |= (double)ad[a] < f.thr;
+            }
+            return hit;
+        }
+        default:
+            return false;
+    }
+}
+
+struct CallArgs {
+    trk_batch b;
+    trk_plane planes[TRK_MAX_PLANES];
+    trk_call_filter filters[TRK_MAX_FILTERS];
+    int n_planes, n_filters, dp_plane, loci_per_block;
+    trk_call_out out;
+};
+
+template <bool VEC>  // VEC: P == 2 and S % 4 == 0 -> every thread's 4 cells are one aligned 16-byte chunk
+__global__ __launch_bounds__(CF_THREADS) void k_call_filter(const CallArgs a) {
+    extern __shared__ uint32_t fcount[];  // [n_filters][CF_THREADS * CF_V]
+    const int tid = threadIdx.x;
+    const int S = a.b.n_samples, L = a.b.n_loci, P = a.b.ploidy;
+    const int nf = a.n_filters;
+    const int64_t s0 = ((int64_t)blockIdx.x * CF_THREADS + tid) * CF_V;
+    const int l_begin = blockIdx.y * a.loci_per_block;
+    const int l_end = min(L, l_begin + a.loci_per_block);
+    for (int k = 0; k < nf; ++k)
+#pragma unroll
+        for (int j = 0; j < CF_V; ++j) fcount[(k * CF_THREADS + tid) * CF_V + j] = 0;
+    uint32_t numcalls[CF_V] = {0, 0, 0, 0};
+    uint32_t dpmiss[CF_V] = {0, 0, 0, 0};
+    int64_t totaldp[CF_V] = {0, 0, 0, 0};
+    if (s0 < S) {
+        const int nvalid = (int)min((int64_t)CF_V, (int64_t)S - s0);
+        for (int l = l_begin; l < l_end; ++l) {
+            const int64_t cell0 = (int64_t)l * S + s0;
+            const int pl = a.b.locus_ploidy ? min((int)a.b.locus_ploidy[l], P) : P;
+            uint32_t w[CF_V];
+            if (VEC) {
+                u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.b.gt) + (cell0 >> 2));
+                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+            }
+            uint32_t mask[CF_V];
+#pragma unroll
+            for (int j = 0; j < CF_V; ++j) {
+                mask[j] = 0;
+                if (j >= nvalid) continue;
+                const int64_t cell = cell0 + j;
+                int gtv[TRK_MAX_PLOIDY];
+                if (VEC) {
+                    gtv[0] = (int16_t)(w[j] & 0xffffu);
+                    gtv[1] = (int16_t)(w[j] >> 16);
+                } else {
+                    for (int q = 0; q < P && q < TRK_MAX_PLOIDY; ++q) gtv[q] = a.b.gt[cell * P + q];
+                }
+                bool miss = false;
+                for (int q = 0; q < pl; ++q) miss |= gtv[q] == -1;
+                const bool called = !miss;  // GetCalledSamples (dumpSTR.py:651)
+                uint32_t m = 0;
+                for (int k = 0; k < nf; ++k) {
+                    if (eval_filter(a.filters[k], a.planes, cell, called, gtv, P, pl)) {
+                        m |= 1u << k;
+                        if (called) fcount[(k * CF_THREADS + tid) * CF_V + j]++;  // dumpSTR.py:661
+                    }
+                }
+                if (!called) m |= TRK_MASK_NOCALL;
+                mask[j] = m;
+                if (m == 0) {  // 'PASS'  (dumpSTR.py:686-713)
+                    numcalls[j]++;
+                    if (a.dp_plane >= 0) {
+                        const trk_plane& dp = a.planes[a.dp_plane];
+                        int32_t d = reinterpret_cast<const int32_t*>(dp.data)[cell * dp.ncol];
+                        if (d == INT32_MIN) {
+                            dpmiss[j]++;
+                        } else if (d < 0) {
+                            if (atomicCAS(&a.out.error[0], 0, 1) == 0) {
+                                a.out.error[1] = l;
+                                a.out.error[2] = (int32_t)(s0 + j);
+                            }
+                        } else {
+                            totaldp[j] += d;
+                        }
+                    }
+                } else if (called) {  // filtered call: genotype := no-call (dumpSTR.py:721-727)
+                    if (VEC) {
+                        w[j] = 0xffffffffu;
+                    } else if (a.out.gt_out) {
+                        for (int q = 0; q < pl; ++q) gtv[q] = -1;
+                    }
+                }
+                if (!VEC && a.out.gt_out)
+                    for (int q = 0; q < P; ++q) a.out.gt_out[cell * P + q] = (int16_t)gtv[q];
+            }
+            if (VEC) {
+                if (a.out.gt_out)
+                    __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]},
+                                                reinterpret_cast<u32x4*>(a.out.gt_out) + (cell0 >> 2));
+                if (a.out.filter_mask)
+                    __builtin_nontemporal_store(u32x4{mask[0], mask[1], mask[2], mask[3]},
+                                                reinterpret_cast<u32x4*>(a.out.filter_mask) + (cell0 >> 2));
+            } else if (a.out.filter_mask) {
+                for (int j = 0; j < nvalid; ++j) a.out.filter_mask[cell0 + j] = mask[j];
+            }
+        }
+        // flush the per-sample counters of this block of loci
+        for (int j = 0; j < nvalid; ++j) {
+            const int64_t s = s0 + j;
+            if (numcalls[j])
+                atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_counters + s),
+                          (unsigned long long)numcalls[j]);
+            if (totaldp[j])
+                atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_totaldp + s),
+                          (unsigned long long)totaldp[j]);
+            if (dpmiss[j]) atomicAdd(a.out.sample_dp_missing + s, (int)dpmiss[j]);
+            for (int k = 0; k < nf; ++k) {
+                uint32_t c = fcount[(k * CF_THREADS + tid) * CF_V + j];
+                if (c)
+                    atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_counters + (int64_t)(1 + k) * S + s),
+                              (unsigned long long)c);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_locus_filter : one thread per locus
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_locus_filter(int L, const int32_t* __restrict__ locus_int,
+                                                     const double* __restrict__ locus_f64,
+                                                     trk_locus_filter_spec spec, uint32_t* __restrict__ bits_out,
+                                                     unsigned long long* __restrict__ counters) {
+    int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    const int32_t* li = locus_int + (int64_t)l * TRK_LI_COLS;
+    const double* lf = locus_f64 + (int64_t)l * TRK_LF_COLS;
+    uint32_t bits = 0;
+    // nan thresholds disable a filter; nan statistics never fire (x < nan == false)
+    if (spec.min_callrate == spec.min_callrate && lf[TRK_LF_CALLRATE] < spec.min_callrate)
+        bits |= 1u << TRK_LOCF_CALLRATE;  // filters.py:60
+    if (spec.min_hwep == spec.min_hwep) {
+        int st = li[spec.use_length ? TRK_LI_HWE_STATUS_LEN : TRK_LI_HWE_STATUS_STR];
+        if (st == TRK_HWE_VALUE_ERROR || st == TRK_HWE_INDEX_ERROR) atomicAdd(&counters[TRK_LC_HWE_ERRORS], 1ull);
+        double hw = lf[spec.use_length ? TRK_LF_HWEP_LEN : TRK_LF_HWEP_STR];
+        if (hw < spec.min_hwep) bits |= 1u << TRK_LOCF_HWE;  // filters.py:102
+    }
+    double het = lf[spec.use_length ? TRK_LF_HET_LEN : TRK_LF_HET_STR];
+    if (spec.min_het == spec.min_het && het < spec.min_het) bits |= 1u << TRK_LOCF_HETLOW;   // filters.py:142
+    if (spec.max_het == spec.max_het && het > spec.max_het) bits |= 1u << TRK_LOCF_HETHIGH;  // filters.py:183
+    if (spec.extern_bits) bits |= (spec.extern_bits[l] & ((1u << spec.n_extern) - 1u)) << TRK_LOCF_EXTERN0;
+    for (int k = 0; k < 28; ++k)
+        if ((bits >> k) & 1u) atomicAdd(&counters[TRK_LC_FILTER0 + k], 1ull);  // dumpSTR.py:949
+    const int n_called = li[TRK_LI_N_CALLED];
+    if (n_called == 0) {  // dumpSTR.py:957-965
+        bits |= 1u << TRK_LOCF_NO_CALLS;
+        atomicAdd(&counters[TRK_LC_NO_CALLS], 1ull);
+    }
+    if (bits == 0) {  // dumpSTR.py:967-971
+        atomicAdd(&counters[TRK_LC_PASS], 1ull);
+        atomicAdd(&counters[TRK_LC_TOTALCALLS], (unsigned long long)n_called);
+    }
+    bits_out[l] = bits;
+}
+
+// ---------------------------------------------------------------------------
+// k_synth : synthetic diploid genotypes + HipSTR-shaped FORMAT planes
+// (bit-for-bit twin: trtools_amd/synth.py::cells_numpy)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z ^= z >> 30;
+    z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27;
+    z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+
+__global__ __launch_bounds__(256) void k_synth(trk_synth_spec sp, int16_t* __restrict__ gt, int32_t* __restrict__ dp,
+                                              float* __restrict__ q, int32_t* __restrict__ dstutter,
+                                              int32_t* __restrict__ dflank) {
+    const int64_t n = (int64_t)sp.n_loci * sp.n_samples;
+    for (int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; cell < n;
+         cell += (int64_t)gridDim.x * blockDim.x) {
+        const int l = (int)(cell / sp.n_samples);
+        const int s = (int)(cell - (int64_t)l * sp.n_samples);
+        const uint64_t gidx = (uint64_t)(sp.locus_base + l) * (uint64_t)sp.n_samples + (uint64_t)s;
+        const uint64_t x = sp.seed + 0x9E3779B97F4A7C15ull * (gidx + 1ull);
+        const uint64_t h1 = mix64(x);
+        const uint64_t h2 = mix64(x + 0x632BE59BD9B4E019ull);
+        const uint64_t h3 = mix64(x + 0xD1B54A32D192ED03ull);
+        const uint32_t u0 = (uint32_t)(h1 & 0xffffffu);
+        const uint32_t u1 = (uint32_t)((h1 >> 24) & 0xffffffu);
+        const uint32_t um = (uint32_t)((h1 >> 48) & 0xffffu);
+        const uint32_t ui = (uint32_t)(h2 & 0xffffu);
+        const int off = sp.allele_off[l];
+        const int A = sp.allele_off[l + 1] - off;
+        const uint32_t* cdf = sp.allele_cdf24 + off;
+        int a0 = 0, a1 = 0;
+        while (a0 < A - 1 && u0 >= cdf[a0]) ++a0;
+        while (a1 < A - 1 && u1 >= cdf[a1]) ++a1;
+        if (ui < sp.inbreed_thr16[l]) a1 = a0;
+        const uint32_t mt = sp.miss_thr16[l];
+        const bool nocall = um < mt;
+        const bool partial = !nocall && um < mt + 328u;  // ~0.5% '0/.' calls
+        int16_t g0 = (int16_t)a0, g1 = (int16_t)a1;
+        if (nocall) {
+            g0 = -1;
+            g1 = -1;
+        } else if (partial) {
+            g1 = -1;
+        }
+        gt[cell * 2 + 0] = g0;
+        gt[cell * 2 + 1] = g1;
+        // DP: Irwin-Hall(4 bytes) scaled to mean 30, sd 12, floor at 0
+        uint32_t bsum = (uint32_t)((h2 >> 16) & 0xff) + (uint32_t)((h2 >> 24) & 0xff) +
+                        (uint32_t)((h2 >> 32) & 0xff) + (uint32_t)((h2 >> 40) & 0xff);
+        uint32_t v = bsum * 12u;
+        int32_t d = v >= 1680u ? (int32_t)((v - 1680u) / 148u) : 0;
+        // Q: 1 - (2*clz32 + bit)/100, float32
+        uint32_t r = (uint32_t)(h3 & 0xffffffffu);
+        int lz = r ? __clz(r) : 32;
+        int qi = 100 - (2 * lz + (int)((h3 >> 32) & 1u));
+        if (qi < 0) qi = 0;
+        int32_t st = __popc((uint32_t)((h3 >> 33) & 0xffu)) >> 1;
+        int32_t fl = __popc((uint32_t)((h3 >> 41) & 0xfu)) >> 1;
+        if (st > d) st = d;
+        if (fl > d) fl = d;
+        if (nocall) {
+            if (dp) dp[cell] = INT32_MIN;
+            if (q) q[cell] = __builtin_nanf("");
+            if (dstutter) dstutter[cell] = INT32_MIN;
+            if (dflank) dflank[cell] = INT32_MIN;
+        } else {
+            if (dp) dp[cell] = d;
+            if (q) q[cell] = (float)qi / 100.0f;
+            if (dstutter) dstutter[cell] = st;
+            if (dflank) dflank[cell] = fl;
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// launchers (called from trk_api.hip)
+// ---------------------------------------------------------------------------
+namespace trk {
+
+static int next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* allele_count, int32_t* locus_int,
+                              int n_cu, hipStream_t stream) {
+    const int G = b.group_bits ? b.n_groups : 1;
+    const bool fast2 = (b.ploidy == 2) && !b.group_bits;
+    int maxA = max_alleles > 0 ? max_alleles : 64;
+    int bins = G * (maxA + (fast2 ? 0 : XB_N));
+    int hist_entries = next_pow2(bins * 32);
+    if (hist_entries < 256) hist_entries = 256;
+    if (hist_entries > 4096) hist_entries = 4096;
+    int lut_entries = next_pow2(maxA);
+    if (lut_entries < 64) lut_entries = 64;
+    if (lut_entries > 2048) lut_entries = 2048;
+    size_t lds = (size_t)COUNT_WAVES_PER_WG * (hist_entries + lut_entries) * sizeof(uint32_t);
+    int wgs = (b.n_loci + COUNT_WAVES_PER_WG - 1) / COUNT_WAVES_PER_WG;
+    int max_wgs = n_cu * 8;
+    if (wgs > max_wgs) wgs = max_wgs;
+    if (wgs < 1) wgs = 1;
+    if (fast2)
+        hipLaunchKernelGGL(k_locus_count<true>, dim3(wgs), dim3(WAVE * COUNT_WAVES_PER_WG), lds, stream, b,
+                           allele_count, locus_int, hist_entries, lut_entries);
+    else
+        hipLaunchKernelGGL(k_locus_count<false>, dim3(wgs), dim3(WAVE * COUNT_WAVES_PER_WG), lds, stream, b,
+                           allele_count, locus_int, hist_entries, lut_entries);
+    return hipGetLastError();
+}
+
+hipError_t launch_locus_finalize(const trk_batch& b, const int32_t* allele_count, int32_t* locus_int,
+                                 double* locus_f64, int32_t* scratch, double nalleles_thresh, hipStream_t stream) {
+    const int G = b.group_bits ? b.n_groups : 1;
+    int64_t n = (int64_t)G * b.n_loci;
+    if (n == 0) return hipSuccess;
+    int blocks = (int)((n + 127) / 128);
+    hipLaunchKernelGGL(k_locus_finalize, dim3(blocks), dim3(128), 0, stream, b, allele_count, locus_int, locus_f64,
+                       scratch, nalleles_thresh);
+    return hipGetLastError();
+}
+
+hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n_planes,
+                              const trk_call_filter* filters, int n_filters, int dp_plane, const trk_call_out& out,
+                              int n_cu, hipStream_t stream) {
+    CallArgs a;
+    a.b = b;
+    for (int i = 0; i < n_planes; ++i) a.planes[i] = planes[i];
+    for (int i = 0; i < n_filters; ++i) a.filters[i] = filters[i];
+    a.n_planes = n_planes;
+    a.n_filters = n_filters;
+    a.dp_plane = dp_plane;
+    a.out = out;
+    const int S = b.n_samples, L = b.n_loci;
+    if (S == 0 || L == 0) return hipSuccess;
+    int gx = (S + CF_THREADS * CF_V - 1) / (CF_THREADS * CF_V);
+    // enough blocks to fill the chip (>= 8 per CU) while keeping the per-block
+    // counter flush (one atomic per sample per counter) small next to the stream
+    int want_blocks = n_cu * 16;
+    int gy = (want_blocks + gx - 1) / gx;
+    if (gy > L) gy = L;
+    if (gy < 1) gy = 1;
+    int lpb = (L + gy - 1) / gy;
+    if (lpb > 4096) lpb = 4096;
+    gy = (L + lpb - 1) / lpb;
+    a.loci_per_block = lpb;
+    size_t lds = (size_t)n_filters * CF_THREADS * CF_V * sizeof(uint32_t);
+    const bool vec = (b.ploidy == 2) && (S % 4 == 0);
+    if (vec)
+        hipLaunchKernelGGL(k_call_filter<true>, dim3(gx, gy), dim3(CF_THREADS), lds, stream, a);
+    else
+        hipLaunchKernelGGL(k_call_filter<false>, dim3(gx, gy), dim3(CF_THREADS), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_locus_filter(int L, const int32_t* locus_int, const double* locus_f64,
+                               const trk_locus_filter_spec& spec, uint32_t* bits, int64_t* counters,
+                               hipStream_t stream) {
+    if (L == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_locus_filter, dim3((L + 255) / 256), dim3(256), 0, stream, L, locus_int, locus_f64, spec,
+                       bits, reinterpret_cast<unsigned long long*>(counters));
+    return hipGetLastError();
+}
+
+hipError_t launch_synth(const trk_synth_spec& sp, int16_t* gt, int32_t* dp, float* q, int32_t* dstutter,
+                        int32_t* dflank, int n_cu, hipStream_t stream) {
+    int64_t n = (int64_t)sp.n_loci * sp.n_samples;
+    if (n == 0) return hipSuccess;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > (int64_t)n_cu * 32) blocks = (int64_t)n_cu * 32;
+    hipLaunchKernelGGL(k_synth, dim3((int)blocks), dim3(256), 0, stream, sp, gt, dp, q, dstutter, dflank);
+    return hipGetLastError();
+}
+
+}  // namespace trk

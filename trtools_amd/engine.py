@@ -1,0 +1,327 @@
+"""Engine: thin Python object over the libtrk C ABI (one per process per GPU).
+
+Host code stays Python (BASELINE.json north_star); all per-sample arithmetic
+runs in the HIP kernels of libtrk.so.  Arrays handed to the engine are numpy
+arrays with the documented dtypes; ``upload`` makes the PCIe copy explicit and
+returns a ``DeviceArray``; results stay on the device until ``.get()``.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class DeviceArray:
+    """A typed view of device memory owned by an Engine."""
+
+    def __init__(self, eng, shape, dtype):
+        self.eng = eng
+        self.shape = tuple(int(x) for x in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        ptr = C.c_void_p()
+        eng._chk(eng.lib.trk_dev_alloc(eng.ctx, max(self.nbytes, 16), C.byref(ptr)))
+        self.ptr = ptr.value
+        eng._live.add(self)
+
+    def get(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        if self.nbytes:
+            self.eng._chk(self.eng.lib.trk_memcpy_d2h(self.eng.ctx, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def set(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=self.dtype)
+        if arr.shape != self.shape:
+            raise ValueError("shape mismatch %s vs %s" % (arr.shape, self.shape))
+        if self.nbytes:
+            self.eng._chk(self.eng.lib.trk_memcpy_h2d(self.eng.ctx, self.ptr, arr.ctypes.data, self.nbytes))
+        return self
+
+    def zero(self):
+        if self.nbytes:
+            self.eng._chk(self.eng.lib.trk_memset(self.eng.ctx, self.ptr, 0, self.nbytes))
+        return self
+
+    def free(self):
+        if self.ptr is not None and self.eng.ctx is not None:
+            self.eng.lib.trk_dev_free(self.eng.ctx, self.ptr)
+        self.ptr = None
+        self.eng._live.discard(self)
+
+
+class DeviceBatch:
+    """trk_batch + the DeviceArrays that back it."""
+
+    def __init__(self, struct, arrays, n_groups, sum_alleles):
+        self.struct = struct
+        self.arrays = arrays
+        self.n_loci = struct.n_loci
+        self.n_samples = struct.n_samples
+        self.ploidy = struct.ploidy
+        self.n_groups = n_groups
+        self.sum_alleles = sum_alleles
+
+    def with_gt(self, gt_dev):
+        """Same allele tables, different genotype tensor (e.g. dumpSTR's masked GT)."""
+        s = L.Batch()
+        C.memmove(C.byref(s), C.byref(self.struct), C.sizeof(L.Batch))
+        s.gt = gt_dev.ptr
+        arrays = dict(self.arrays)
+        arrays['gt'] = gt_dev
+        return DeviceBatch(s, arrays, self.n_groups, self.sum_alleles)
+
+
+class StatsResult:
+    def __init__(self, allele_count, locus_int, locus_f64):
+        self.allele_count = allele_count
+        self.locus_int = locus_int
+        self.locus_f64 = locus_f64
+        self.struct = L.StatsOut(allele_count.ptr, locus_int.ptr, locus_f64.ptr if locus_f64 else None)
+
+
+class CallResult:
+    def __init__(self, gt_out, filter_mask, sample_counters, sample_totaldp, sample_dp_missing, error):
+        self.gt_out = gt_out
+        self.filter_mask = filter_mask
+        self.sample_counters = sample_counters
+        self.sample_totaldp = sample_totaldp
+        self.sample_dp_missing = sample_dp_missing
+        self.error = error
+        self.struct = L.CallOut(gt_out.ptr if gt_out else None, filter_mask.ptr if filter_mask else None,
+                                sample_counters.ptr, sample_totaldp.ptr, sample_dp_missing.ptr, error.ptr)
+
+
+class Engine:
+    def __init__(self, device=0):
+        self.lib = L.load()
+        self.ctx = None
+        self._live = set()
+        ctx = C.c_void_p()
+        rc = self.lib.trk_init(int(device), C.byref(ctx))
+        if rc != 0:
+            msg = self.lib.trk_last_error(None)
+            raise L.TrkError("trk_init(device=%d) failed [%d]: %s -- this package needs an MI355X; "
+                             "there is no CPU fallback" % (device, rc, msg.decode() if msg else '?'))
+        self.ctx = ctx
+        name = C.create_string_buffer(256)
+        arch = C.create_string_buffer(64)
+        ncu = C.c_int()
+        hbm = C.c_uint64()
+        self._chk(self.lib.trk_device_info(self.ctx, name, 256, C.byref(ncu), C.byref(hbm), arch, 64))
+        self.device_name = name.value.decode()
+        self.arch = arch.value.decode()
+        self.n_cu = ncu.value
+        self.hbm_bytes = hbm.value
+
+    # ---- plumbing ----
+    def _chk(self, rc):
+        if rc != 0:
+            msg = self.lib.trk_last_error(self.ctx)
+            raise L.TrkError("libtrk error %d: %s" % (rc, msg.decode() if msg else '?'))
+
+    def close(self):
+        if self.ctx is not None:
+            for a in list(self._live):
+                a.free()
+            self.lib.trk_free(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def empty(self, shape, dtype):
+        return DeviceArray(self, shape, dtype)
+
+    def zeros(self, shape, dtype):
+        return DeviceArray(self, shape, dtype).zero()
+
+    def upload(self, arr, dtype=None):
+        arr = np.ascontiguousarray(arr, dtype=dtype)
+        return DeviceArray(self, arr.shape, arr.dtype).set(arr)
+
+    def sync(self):
+        self._chk(self.lib.trk_sync(self.ctx))
+
+    def timer_start(self, slot=0):
+        self._chk(self.lib.trk_timer_start(self.ctx, slot))
+
+    def timer_stop(self, slot=0):
+        self._chk(self.lib.trk_timer_stop(self.ctx, slot))
+
+    def timer_ms(self, slot=0):
+        ms = C.c_float()
+        self._chk(self.lib.trk_timer_elapsed_ms(self.ctx, slot, C.byref(ms)))
+        return ms.value
+
+    def profile(self, on=True):
+        self._chk(self.lib.trk_profile_enable(self.ctx, 1 if on else 0))
+
+    def profile_reset(self):
+        self._chk(self.lib.trk_profile_reset(self.ctx))
+
+    def profile_get(self):
+        out = {}
+        for k, name in enumerate(L.KERNEL_NAMES):
+            n = C.c_int64()
+            ms = C.c_double()
+            self._chk(self.lib.trk_profile_get(self.ctx, k, C.byref(n), C.byref(ms)))
+            out[name] = (n.value, ms.value)
+        return out
+
+    # ---- batches ----
+    def make_batch(self, gt, allele_off, len_class, str_class, len_class_value,
+                   locus_ploidy=None, group_bits=None, n_groups=1, max_alleles=None):
+        """Upload host arrays (numpy) or accept DeviceArrays; returns a DeviceBatch."""
+        def dev(x, dt):
+            return x if isinstance(x, DeviceArray) else self.upload(x, dt)
+        gt_d = dev(gt, np.int16)
+        if len(gt_d.shape) != 3:
+            raise ValueError("gt must be [L, S, P]")
+        Lc, S, P = gt_d.shape
+        off_host = None
+        if not isinstance(allele_off, DeviceArray):
+            off_host = np.ascontiguousarray(allele_off, dtype=np.int32)
+            if off_host.shape != (Lc + 1,):
+                raise ValueError("allele_off must have L+1 entries")
+        off_d = dev(allele_off, np.int32)
+        lc_d = dev(len_class, np.uint16)
+        sc_d = dev(str_class, np.uint16)
+        cv_d = dev(len_class_value, np.float64)
+        sumA = lc_d.shape[0]
+        if off_host is not None:
+            if int(off_host[-1]) != sumA:
+                raise ValueError("allele_off[-1] != len(len_class)")
+            if max_alleles is None:
+                max_alleles = int(np.max(np.diff(off_host))) if Lc else 0
+        arrays = dict(gt=gt_d, allele_off=off_d, len_class=lc_d, str_class=sc_d, len_class_value=cv_d)
+        s = L.Batch()
+        s.n_loci, s.n_samples, s.ploidy = Lc, S, P
+        s.n_groups = int(n_groups)
+        s.n_alleles_total = sumA
+        s.max_alleles = int(max_alleles or 0)
+        s.gt, s.allele_off = gt_d.ptr, off_d.ptr
+        s.len_class, s.str_class, s.len_class_value = lc_d.ptr, sc_d.ptr, cv_d.ptr
+        if locus_ploidy is not None:
+            arrays['locus_ploidy'] = dev(locus_ploidy, np.uint8)
+            s.locus_ploidy = arrays['locus_ploidy'].ptr
+        if group_bits is not None:
+            arrays['group_bits'] = dev(group_bits, np.uint8)
+            s.group_bits = arrays['group_bits'].ptr
+        else:
+            n_groups = 1
+        return DeviceBatch(s, arrays, int(n_groups), sumA)
+
+    # ---- hot path ----
+    def alloc_stats(self, batch):
+        G = batch.n_groups
+        return StatsResult(self.empty((G, batch.sum_alleles), np.int32),
+                           self.empty((G, batch.n_loci, L.TRK_LI_COLS), np.int32),
+                           self.empty((G, batch.n_loci, L.TRK_LF_COLS), np.float64))
+
+    def locus_stats(self, batch, nalleles_thresh=0.01, out=None, count_only=False):
+        if out is None:
+            out = self.alloc_stats(batch)
+        prm = L.StatsParams(float(nalleles_thresh), L.STATS_COUNT_ONLY if count_only else 0, 0)
+        self._chk(self.lib.trk_locus_stats(self.ctx, C.byref(batch.struct), C.byref(prm), C.byref(out.struct)))
+        return out
+
+    def alloc_call_out(self, batch, n_filters, want_gt=True, want_mask=True):
+        S = batch.n_samples
+        return CallResult(
+            self.empty((batch.n_loci, S, batch.ploidy), np.int16) if want_gt else None,
+            self.empty((batch.n_loci, S), np.uint32) if want_mask else None,
+            self.zeros((1 + n_filters, S), np.int64), self.zeros((S,), np.int64),
+            self.zeros((S,), np.int32), self.zeros((4,), np.int32))
+
+    def call_filters(self, batch, planes, filters, dp_plane=-1, out=None):
+        """planes: list of DeviceArray ([L,S] or [L,S,k], int32/float32);
+        filters: list of dicts(op, plane_a, col_a=0, plane_b=-1, col_b=0, col_a2=0, thr=0.0)."""
+        np_ = len(planes)
+        nf = len(filters)
+        if np_ > L.TRK_MAX_PLANES or nf > L.TRK_MAX_FILTERS:
+            raise ValueError("too many planes/filters")
+        parr = (L.Plane * max(np_, 1))()
+        for i, p in enumerate(planes):
+            if p.shape[:2] != (batch.n_loci, batch.n_samples):
+                raise ValueError("plane %d has shape %s" % (i, p.shape))
+            ncol = 1 if len(p.shape) == 2 else p.shape[2]
+            if p.dtype == np.int32:
+                dt = L.DT_I32
+            elif p.dtype == np.float32:
+                dt = L.DT_F32
+            else:
+                raise ValueError("plane %d dtype %s not supported" % (i, p.dtype))
+            parr[i] = L.Plane(p.ptr, dt, ncol)
+        farr = (L.CallFilter * max(nf, 1))()
+        for k, f in enumerate(filters):
+            farr[k] = L.CallFilter(int(f['op']), int(f['plane_a']), int(f.get('col_a', 0)),
+                                   int(f.get('plane_b', -1)), int(f.get('col_b', 0)),
+                                   int(f.get('col_a2', 0)), float(f.get('thr', 0.0)))
+        if out is None:
+            out = self.alloc_call_out(batch, nf)
+        self._chk(self.lib.trk_call_filters(self.ctx, C.byref(batch.struct), parr, np_, farr, nf,
+                                            int(dp_plane), C.byref(out.struct)))
+        return out
+
+    def locus_filters(self, n_loci, stats, min_callrate=None, min_hwep=None, min_het=None, max_het=None,
+                      use_length=False, extern_bits=None, n_extern=0, bits_out=None, counters=None):
+        nan = float('nan')
+        spec = L.LocusFilterSpec(
+            nan if min_callrate is None else float(min_callrate),
+            nan if min_hwep is None else float(min_hwep),
+            nan if min_het is None else float(min_het),
+            nan if max_het is None else float(max_het),
+            1 if use_length else 0, int(n_extern), extern_bits.ptr if extern_bits is not None else None)
+        if bits_out is None:
+            bits_out = self.empty((n_loci,), np.uint32)
+        if counters is None:
+            counters = self.zeros((L.TRK_LC_COLS,), np.int64)
+        out = L.LocusOut(bits_out.ptr, counters.ptr)
+        self._chk(self.lib.trk_locus_filters(self.ctx, int(n_loci), C.byref(stats.struct), C.byref(spec),
+                                             C.byref(out)))
+        return bits_out, counters
+
+    # ---- scalar helpers ----
+    def binomtest(self, k, n, p):
+        return self.lib.trk_binomtest_two_sided(int(k), int(n), float(p))
+
+    # ---- multi-GPU ----
+    def comm_unique_id(self):
+        buf = (C.c_uint8 * 128)()
+        rc = self.lib.trk_comm_unique_id(buf)
+        if rc != 0:
+            raise L.TrkError("trk_comm_unique_id: %s" % self.lib.trk_last_error(None).decode())
+        return bytes(buf)
+
+    def comm_init(self, rank, n_ranks, uid):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self._chk(self.lib.trk_comm_init(self.ctx, int(rank), int(n_ranks), buf))
+
+    def allreduce_sum_i64(self, arr):
+        self._chk(self.lib.trk_allreduce_sum_i64(self.ctx, arr.ptr, int(np.prod(arr.shape))))
+
+    def allgather(self, send, recv):
+        self._chk(self.lib.trk_allgather(self.ctx, send.ptr, recv.ptr, send.nbytes))
+
+    # ---- synthetic batches ----
+    def synth_fill(self, seed, n_loci, n_samples, allele_off_d, cdf_d, miss_d, inb_d, locus_base=0,
+                   planes=('dp', 'q')):
+        gt = self.empty((n_loci, n_samples, 2), np.int16)
+        out = {'gt': gt}
+        ptrs = {}
+        for nm, dt in (('dp', np.int32), ('q', np.float32), ('dstutter', np.int32), ('dflankindel', np.int32)):
+            if nm in planes:
+                out[nm] = self.empty((n_loci, n_samples), dt)
+                ptrs[nm] = out[nm].ptr
+            else:
+                ptrs[nm] = None
+        spec = L.SynthSpec(int(seed), int(n_loci), int(n_samples), allele_off_d.ptr, cdf_d.ptr, miss_d.ptr,
+                           inb_d.ptr, int(locus_base), 0)
+        self._chk(self.lib.trk_synth_fill(self.ctx, C.byref(spec), gt.ptr, ptrs['dp'], ptrs['q'],
+                                          ptrs['dstutter'], ptrs['dflankindel']))
+        return out

@@ -1,0 +1,261 @@
+"""Synthetic many-sample TR call sets (bench + tests).
+
+Two halves:
+
+* ``make_loci``  -- seeded numpy generation of the per-locus tables: motif,
+  allele sequences / lengths (HipSTR-shape: unit and non-unit alleles, same
+  length / different sequence alleles, flank-trim duplicates), allele
+  frequencies, missingness, inbreeding.  Small (O(L * A)), always on the host.
+* ``cells_numpy`` -- the per-call generator (genotypes + DP/Q/DSTUTTER/
+  DFLANKINDEL) as a counter-based hash of (seed, locus, sample).  It is the
+  bit-for-bit numpy twin of the HIP kernel ``k_synth`` (csrc/trk_kernels.hip),
+  so a full-size batch generated on the device can be spot-checked on the CPU
+  row by row without ever materialising it on the host.
+
+``pack_alleles`` turns per-locus allele (length, sequence) lists into the
+class tables of ``trk_batch`` (include/trk.h).
+"""
+import numpy as np
+
+M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+INT_MISSING = -2147483648
+
+
+# ---------------------------------------------------------------------------
+# allele tables -> trk_batch class arrays
+# ---------------------------------------------------------------------------
+
+def pack_alleles(allele_lens, allele_strs):
+    """Per-locus lists -> (allele_off, len_class, str_class, len_class_value).
+
+    ``allele_lens[l]``: floats, length in repeat units of every allele index
+    (TRRecord.ref_allele_length + alt_allele_lengths, tr_harmonizer.py:740-759).
+    ``allele_strs[l]``: the trimmed upper-case sequences (ref_allele + alt_alleles).
+    len_class = dense rank of the length (ascending, the key order of
+    GetAlleleCounts(uselength=True)); str_class = dense rank of the sequence in
+    numpy '<U' / python str order (the key order of GetAlleleCounts(uselength=False)).
+    """
+    n = len(allele_lens)
+    off = np.zeros(n + 1, dtype=np.int32)
+    for i in range(n):
+        off[i + 1] = off[i] + len(allele_lens[i])
+    total = int(off[-1])
+    lc = np.zeros(total, dtype=np.uint16)
+    sc = np.zeros(total, dtype=np.uint16)
+    cv = np.zeros(total, dtype=np.float64)
+    for i in range(n):
+        lens = [float(x) for x in allele_lens[i]]
+        if len(lens) > 65535:
+            raise ValueError("more than 65535 alleles at one locus")
+        o = int(off[i])
+        ul = sorted(set(lens))
+        rank = {v: r for r, v in enumerate(ul)}
+        for a, v in enumerate(lens):
+            lc[o + a] = rank[v]
+        cv[o:o + len(ul)] = ul
+        strs = list(allele_strs[i]) if allele_strs is not None else None
+        if strs is None:
+            sc[o:o + len(lens)] = lc[o:o + len(lens)]
+        else:
+            us = sorted(set(strs))
+            srank = {v: r for r, v in enumerate(us)}
+            for a, v in enumerate(strs):
+                sc[o + a] = srank[v]
+    return off, lc, sc, cv
+
+
+# ---------------------------------------------------------------------------
+# per-locus tables
+# ---------------------------------------------------------------------------
+
+class Loci:
+    """Per-locus synthetic tables (host)."""
+
+    def __init__(self):
+        self.motifs = []
+        self.allele_strs = []
+        self.allele_lens = []
+        self.allele_off = None
+        self.cdf24 = None
+        self.miss_thr16 = None
+        self.inbreed_thr16 = None
+
+
+def make_loci(n_loci, n_samples, seed, max_alleles=None, all_missing_frac=0.01, inbred_frac=0.10,
+              miss_rate=0.03, pure_repeats=False):
+    """HipSTR-shape loci. ``pure_repeats`` -> GangSTR-shape."""
+    rng = np.random.default_rng(seed)
+    if max_alleles is None:
+        max_alleles = int(min(64, max(4, 4 * np.log2(max(n_samples, 2)))))
+    lam = max(1.0, 0.9 * np.log2(max(n_samples, 2)))
+    out = Loci()
+    off = [0]
+    cdfs = []
+    period_w = np.array([0.30, 0.35, 0.12, 0.13, 0.06, 0.04])
+    bases = np.array(list('ACGT'))
+    for _ in range(n_loci):
+        period = int(rng.choice(6, p=period_w)) + 1
+        motif = ''.join(rng.choice(bases, size=period))
+        if period > 1 and len(set(motif)) == 1:
+            motif = motif[:-1] + ('C' if motif[0] != 'C' else 'G')
+        ref_copies = int(rng.integers(8, 31))
+        ref = motif * ref_copies
+        n_alt = int(min(max_alleles - 1, 1 + rng.poisson(lam)))
+        strs = [ref]
+        seen = {ref}
+        tries = 0
+        while len(strs) < 1 + n_alt and tries < 8 * n_alt + 16:
+            tries += 1
+            k = int(rng.integers(-6, 9))
+            copies = max(1, ref_copies + k)
+            s = motif * copies
+            u = rng.random()
+            if not pure_repeats:
+                if u < 0.10 and period > 1:      # non-unit (fractional) allele
+                    s = s + motif[: int(rng.integers(1, period))]
+                elif u < 0.15:                   # same length, different sequence
+                    p = int(rng.integers(0, len(s)))
+                    c = 'A' if s[p] != 'A' else 'T'
+                    s = s[:p] + c + s[p + 1:]
+            if u >= 0.985 and not pure_repeats:
+                s = strs[int(rng.integers(0, len(strs)))]   # duplicate after flank trimming
+            elif s in seen:
+                continue
+            seen.add(s)
+            strs.append(s)
+        A = len(strs)
+        w = rng.dirichlet(np.full(A, 0.5))
+        w[0] += 0.5
+        w /= w.sum()
+        c = np.floor(np.cumsum(w) * (1 << 24)).astype(np.int64)
+        c = np.minimum(c, (1 << 24))
+        c[-1] = 1 << 24
+        cdfs.append(c.astype(np.uint32))
+        out.motifs.append(motif)
+        out.allele_strs.append(strs)
+        out.allele_lens.append([len(s) / len(motif) for s in strs])
+        off.append(off[-1] + A)
+    out.allele_off = np.array(off, dtype=np.int32)
+    out.cdf24 = np.concatenate(cdfs) if cdfs else np.zeros(0, dtype=np.uint32)
+    miss = np.full(n_loci, int(round(miss_rate * 65536)), dtype=np.uint32)
+    miss[rng.random(n_loci) < all_missing_frac] = 65536
+    out.miss_thr16 = miss
+    inb = np.zeros(n_loci, dtype=np.uint32)
+    inb[rng.random(n_loci) < inbred_frac] = int(round(0.3 * 65536))
+    out.inbreed_thr16 = inb
+    return out
+
+
+# ---------------------------------------------------------------------------
+# per-call generator (numpy twin of k_synth)
+# ---------------------------------------------------------------------------
+
+def _mix64(z):
+    z = z.copy()
+    z ^= z >> np.uint64(30)
+    z *= np.uint64(0xBF58476D1CE4E5B9)
+    z ^= z >> np.uint64(27)
+    z *= np.uint64(0x94D049BB133111EB)
+    z ^= z >> np.uint64(31)
+    return z
+
+
+def _popcount(x):
+    x = x.astype(np.uint64)
+    c = np.zeros(x.shape, dtype=np.int32)
+    for b in range(8):
+        c += ((x >> np.uint64(b)) & np.uint64(1)).astype(np.int32)
+    return c
+
+
+def cells_numpy(seed, loci, locus_idx, n_samples, locus_base=0):
+    """Generate the calls of loci ``locus_idx`` (indices into ``loci``) for all samples.
+
+    Returns dict(gt int16 [n,S,2], dp int32 [n,S], q float32 [n,S],
+    dstutter int32, dflankindel int32).  ``locus_base + locus_idx`` is the
+    global locus number fed to the hash (so shards of a larger call set agree).
+    """
+    locus_idx = np.asarray(locus_idx, dtype=np.int64)
+    n = locus_idx.shape[0]
+    S = int(n_samples)
+    old = np.seterr(over='ignore')
+    try:
+        gl = (locus_idx + int(locus_base)).astype(np.uint64)[:, None]
+        s = np.arange(S, dtype=np.uint64)[None, :]
+        gidx = gl * np.uint64(S) + s
+        x = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (gidx + np.uint64(1))
+        h1 = _mix64(x)
+        h2 = _mix64(x + np.uint64(0x632BE59BD9B4E019))
+        h3 = _mix64(x + np.uint64(0xD1B54A32D192ED03))
+    finally:
+        np.seterr(**old)
+    u0 = (h1 & np.uint64(0xffffff)).astype(np.uint32)
+    u1 = ((h1 >> np.uint64(24)) & np.uint64(0xffffff)).astype(np.uint32)
+    um = ((h1 >> np.uint64(48)) & np.uint64(0xffff)).astype(np.uint32)
+    ui = (h2 & np.uint64(0xffff)).astype(np.uint32)
+    a0 = np.zeros((n, S), dtype=np.int32)
+    a1 = np.zeros((n, S), dtype=np.int32)
+    for r, li in enumerate(locus_idx):
+        o, e = int(loci.allele_off[li]), int(loci.allele_off[li + 1])
+        cdf = loci.cdf24[o:e]
+        A = e - o
+        a0[r] = np.minimum(np.searchsorted(cdf, u0[r], side='right'), A - 1)
+        a1[r] = np.minimum(np.searchsorted(cdf, u1[r], side='right'), A - 1)
+    inb = loci.inbreed_thr16[locus_idx][:, None]
+    a1 = np.where(ui < inb, a0, a1)
+    mt = loci.miss_thr16[locus_idx][:, None]
+    nocall = um < mt
+    partial = (~nocall) & (um < mt + np.uint32(328))
+    g0 = np.where(nocall, -1, a0).astype(np.int16)
+    g1 = np.where(nocall | partial, -1, a1).astype(np.int16)
+    gt = np.stack([g0, g1], axis=2)
+    bsum = (((h2 >> np.uint64(16)) & np.uint64(0xff)) + ((h2 >> np.uint64(24)) & np.uint64(0xff)) +
+            ((h2 >> np.uint64(32)) & np.uint64(0xff)) + ((h2 >> np.uint64(40)) & np.uint64(0xff))).astype(np.int64)
+    v = bsum * 12
+    d = np.where(v >= 1680, (v - 1680) // 148, 0).astype(np.int32)
+    r32 = (h3 & np.uint64(0xffffffff)).astype(np.uint64)
+    # clz32 via frexp (exact for < 2**53)
+    _, ex = np.frexp(r32.astype(np.float64))
+    lz = np.where(r32 == 0, 32, 32 - ex).astype(np.int32)
+    qi = 100 - (2 * lz + ((h3 >> np.uint64(32)) & np.uint64(1)).astype(np.int32))
+    qi = np.maximum(qi, 0)
+    st = _popcount((h3 >> np.uint64(33)) & np.uint64(0xff)) >> 1
+    fl = _popcount((h3 >> np.uint64(41)) & np.uint64(0xf)) >> 1
+    st = np.minimum(st, d)
+    fl = np.minimum(fl, d)
+    q = (qi.astype(np.float32) / np.float32(100.0)).astype(np.float32)
+    dp = np.where(nocall, INT_MISSING, d).astype(np.int32)
+    q = np.where(nocall, np.float32(np.nan), q).astype(np.float32)
+    st = np.where(nocall, INT_MISSING, st).astype(np.int32)
+    fl = np.where(nocall, INT_MISSING, fl).astype(np.int32)
+    return dict(gt=gt, dp=dp, q=q, dstutter=st, dflankindel=fl)
+
+
+class SynthBatch:
+    """A synthetic call set resident on the device (see Engine.synth_fill)."""
+
+    def __init__(self, eng, n_loci, n_samples, seed, planes=('dp', 'q'), locus_base=0, loci=None,
+                 pure_repeats=False):
+        self.eng = eng
+        self.n_loci, self.n_samples, self.seed = n_loci, n_samples, seed
+        self.locus_base = locus_base
+        self.loci = loci if loci is not None else make_loci(n_loci, n_samples, seed,
+                                                            pure_repeats=pure_repeats)
+        lo = self.loci
+        off, lc, sc, cv = pack_alleles(lo.allele_lens, lo.allele_strs)
+        self.tables = (off, lc, sc, cv)
+        self.d_off = eng.upload(off, np.int32)
+        d_cdf = eng.upload(lo.cdf24, np.uint32)
+        d_miss = eng.upload(lo.miss_thr16, np.uint32)
+        d_inb = eng.upload(lo.inbreed_thr16, np.uint32)
+        self.dev = eng.synth_fill(seed, n_loci, n_samples, self.d_off, d_cdf, d_miss, d_inb,
+                                  locus_base=locus_base, planes=planes)
+        eng.sync()
+        for t in (d_cdf, d_miss, d_inb):
+            t.free()
+        self.batch = eng.make_batch(self.dev['gt'], self.d_off, lc, sc, cv,
+                                    max_alleles=int(np.max(np.diff(off))) if n_loci else 0)
+
+    def host_rows(self, locus_idx):
+        """CPU regeneration of selected loci (for spot-check parity at full size)."""
+        return cells_numpy(self.seed, self.loci, locus_idx, self.n_samples, self.locus_base)
