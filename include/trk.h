@@ -139,7 +139,7 @@ enum {
     TRK_LI_N_HOM_LEN = 2,    /* num_hom of utils.py:327-333, alleles by length          */
     TRK_LI_N_HOM_STR = 3,    /* same, alleles by sequence                               */
     TRK_LI_N_ALLELES = 4,    /* sum of allele counts (called haplotypes)                */
-    TRK_LI_N_BAD = 5,        /* haplotypes with index >= A_l (reference: IndexError)    */
+    TRK_LI_N_BAD = 5,        /* calls holding an allele index >= A_l (reference: IndexError) */
     TRK_LI_HWE_STATUS_LEN = 6,
     TRK_LI_HWE_STATUS_STR = 7,
     TRK_LI_N_SAMPLES = 8,    /* samples in the group                                    */

@@ -103,7 +103,7 @@ __device__ __forceinline__ void cell_p2(const RowCtx& c, uint32_t w, int& n_call
     bool low = (a0 == -2) | (a1 == -2);
     bool v0 = a0 >= 0, v1 = a1 >= 0;
     bool b0 = v0 & (a0 >= c.A), b1 = v1 & (a1 >= c.A);
-    n_bad += (int)b0 + (int)b1;
+    n_bad += (int)(b0 | b1);
     v0 &= !b0;
     v1 &= !b1;
     if (!c.direct) {
@@ -149,7 +149,7 @@ __device__ __forceinline__ void cell_general(const RowCtx& c, const int* vals, i
         int a = vals[j];
         miss |= a == -1;
         low |= a == -2;
-        nbad += (a >= c.A);
+        nbad |= (a >= c.A);
     }
     bool hl = false, hs = false;
     bool called = !miss;
@@ -338,6 +338,137 @@ __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count(
             }
         }
         wave_lds_fence();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_locus_count_fast : the streaming fast path (P == 2, one sample group,
+// rows 16-byte aligned, max_alleles known and small enough for LDS).
+// Branch-free per call: invalid haplotypes (-1, -2, out of range) are steered
+// into a trash bin instead of being predicated away, row predicates are folded
+// into per-lane counters with add-with-carry.
+// ---------------------------------------------------------------------------
+template <bool DUP>
+__device__ __forceinline__ void fast_cell(uint32_t w, int A, uint32_t* hist, const uint32_t* lut, int kshift,
+                                          int kslot, int& n_miss, int& n_low, int& n_hom, int& n_hl, int& n_hs,
+                                          int& n_bad) {
+    const int a0 = (int)(int16_t)(w & 0xffffu);
+    const int a1 = (int)w >> 16;
+    const bool v0 = (unsigned)a0 < (unsigned)A;
+    const bool v1 = (unsigned)a1 < (unsigned)A;
+    const int i0 = v0 ? a0 : A;
+    const int i1 = v1 ? a1 : A;
+    atomicAdd(&hist[(i0 << kshift) + kslot], 1u);
+    atomicAdd(&hist[(i1 << kshift) + kslot], 1u);
+    const bool m = (a0 == -1) | (a1 == -1);
+    const bool lo = ((a0 == -2) | (a1 == -2)) & !m;
+    n_miss += m;
+    n_low += lo;
+    n_bad += (a0 > a1 ? a0 : a1) >= A;
+    n_hom += (a0 == a1) & v0;
+    if (DUP) {
+        const uint32_t x = lut[i0] ^ lut[i1];  // lut[A] is a class no allele has
+        const bool both = v0 & v1;
+        n_hl += both & ((x & 0xffffu) == 0u);
+        n_hs += both & ((x >> 16) == 0u);
+    }
+}
+
+template <bool DUP, int U>
+__device__ __forceinline__ void fast_row(const u32x4* __restrict__ row, int nchunks, int lane, int A,
+                                         uint32_t* hist, const uint32_t* lut, int kshift, int kslot,
+                                         uint32_t hap1_fix, int& n_miss, int& n_low, int& n_hom, int& n_hl,
+                                         int& n_hs, int& n_bad) {
+    int c = lane;
+    // full groups of U chunks per lane
+    for (; c + (U - 1) * WAVE < nchunks; c += U * WAVE) {
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(&row[c + u * WAVE]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                fast_cell<DUP>(v[u][j] | hap1_fix, A, hist, lut, kshift, kslot, n_miss, n_low, n_hom, n_hl, n_hs,
+                               n_bad);
+        }
+    }
+    for (; c < nchunks; c += WAVE) {
+        u32x4 v = __builtin_nontemporal_load(&row[c]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            fast_cell<DUP>(v[j] | hap1_fix, A, hist, lut, kshift, kslot, n_miss, n_low, n_hom, n_hl, n_hs, n_bad);
+    }
+}
+
+template <int U>
+__global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_fast(
+    trk_batch b, int32_t* __restrict__ allele_count, int32_t* __restrict__ locus_int, int kshift,
+    int wave_lds_words) {
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wid = threadIdx.x >> 6;
+    const int l = blockIdx.x * COUNT_WAVES_PER_WG + wid;
+    if (l >= b.n_loci) return;  // waves are independent: no workgroup barrier anywhere
+    const int S = b.n_samples;
+    const int off = b.allele_off[l];
+    const int A = b.allele_off[l + 1] - off;
+    const int K = 1 << kshift;
+    const int kslot = lane & (K - 1);
+    uint32_t* hist = lds + (size_t)wid * wave_lds_words;
+    uint32_t* lut = hist + ((A + 1) << kshift);
+    int pl = b.locus_ploidy ? (int)b.locus_ploidy[l] : 2;
+    // a haploid record inside a diploid batch: the second column is not part of the
+    // record; force it to -3 (neither a no-call nor padding, never counted)
+    const uint32_t hap1_fix = pl < 2 ? 0xfffd0000u : 0u;
+    // dense class ranks: a duplicate (two indices, one class) exists iff max rank + 1 < A
+    int ml = 0, ms = 0;
+    for (int a = lane; a < A; a += WAVE) {
+        int lc = b.len_class[off + a], sc = b.str_class[off + a];
+        lut[a] = (uint32_t)lc | ((uint32_t)sc << 16);
+        ml = lc > ml ? lc : ml;
+        ms = sc > ms ? sc : ms;
+    }
+    if (lane == 0) lut[A] = 0xffffffffu;
+    ml = wave_max(ml);
+    ms = wave_max(ms);
+    const bool dup = (ml + 1 < A) | (ms + 1 < A);
+    for (int i = lane; i < ((A + 1) << kshift); i += WAVE) hist[i] = 0;
+    wave_lds_fence();
+
+    int n_miss = 0, n_low = 0, n_hom = 0, n_hl = 0, n_hs = 0, n_bad = 0;
+    const u32x4* row = reinterpret_cast<const u32x4*>(b.gt) + (((int64_t)l * S) >> 2);
+    const int nchunks = S >> 2;
+    if (dup)
+        fast_row<true, U>(row, nchunks, lane, A, hist, lut, kshift, kslot, hap1_fix, n_miss, n_low, n_hom, n_hl, n_hs,
+                          n_bad);
+    else
+        fast_row<false, U>(row, nchunks, lane, A, hist, lut, kshift, kslot, hap1_fix, n_miss, n_low, n_hom, n_hl,
+                           n_hs, n_bad);
+    wave_lds_fence();
+    for (int bin = lane; bin < A; bin += WAVE) {
+        uint32_t s = 0;
+        for (int k = 0; k < K; ++k) s += hist[(bin << kshift) + ((k + lane) & (K - 1))];
+        allele_count[off + bin] = (int32_t)s;
+    }
+    n_miss = wave_sum(n_miss);
+    n_low = wave_sum(n_low);
+    n_hom = wave_sum(n_hom);
+    n_bad = wave_sum(n_bad);
+    if (dup) {
+        n_hl = wave_sum(n_hl);
+        n_hs = wave_sum(n_hs);
+    } else {
+        n_hl = n_hs = n_hom;
+    }
+    if (lane == 0) {
+        int32_t* li0 = locus_int + (int64_t)l * TRK_LI_COLS;
+        li0[TRK_LI_N_CALLED] = S - n_miss;
+        li0[TRK_LI_N_LOWPLOIDY] = n_low;
+        li0[TRK_LI_N_HOM_LEN] = pl == 2 ? n_hl : 0;
+        li0[TRK_LI_N_HOM_STR] = pl == 2 ? n_hs : 0;
+        li0[TRK_LI_N_BAD] = n_bad;
+        li0[TRK_LI_N_SAMPLES] = S;
     }
 }
 
@@ -827,6 +958,20 @@ hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* alle
                               int n_cu, hipStream_t stream) {
     const int G = b.group_bits ? b.n_groups : 1;
     const bool fast2 = (b.ploidy == 2) && !b.group_bits;
+    if (fast2 && max_alleles > 0 && (b.n_samples % 4) == 0 && b.n_samples > 0) {
+        // words per wave: (A+1) bins x K copies + (A+1) LUT words, K = 32 while it fits in 16 KiB
+        int kshift = 5;
+        while (kshift > 0 && ((max_alleles + 1) << kshift) + max_alleles + 1 > 4096) --kshift;
+        int words = ((max_alleles + 1) << kshift) + max_alleles + 1;
+        if (words <= 4096) {
+            words = (words + 3) & ~3;
+            size_t lds_fast = (size_t)COUNT_WAVES_PER_WG * words * sizeof(uint32_t);
+            int wgs_fast = (b.n_loci + COUNT_WAVES_PER_WG - 1) / COUNT_WAVES_PER_WG;
+            hipLaunchKernelGGL(k_locus_count_fast<4>, dim3(wgs_fast), dim3(WAVE * COUNT_WAVES_PER_WG), lds_fast,
+                               stream, b, allele_count, locus_int, kshift, words);
+            return hipGetLastError();
+        }
+    }
     int maxA = max_alleles > 0 ? max_alleles : 64;
     int bins = G * (maxA + (fast2 ? 0 : XB_N));
     int hist_entries = next_pow2(bins * 32);
