@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""bench.py -- statSTR + dumpSTR hot path on synthetic many-sample call sets.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N ...`
+  (one rank per GPU).  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json metric / configs[3]): statSTR full statistics + dumpSTR
+call- and locus-level filters on a HipSTR-shape call set of 100 000 loci x
+10 000 samples per GPU, inputs resident in HBM before the timed region
+(generated on the device by k_synth; its numpy twin regenerates rows on the
+host for the parity spot-check and the CPU baseline).
+
+One step =
+  statSTR : trk_locus_stats(GT)                  (k_locus_count + k_locus_finalize)
+  dumpSTR : trk_call_filters(GT, DP, Q)          (k_call_filter: min-DP, max-DP, min-Q ->
+                                                  masked GT', filter mask, sample counters)
+            trk_locus_stats(GT')                 (k_locus_count + k_locus_finalize)
+            trk_locus_filters(callrate, HWE, het low/high)  (k_locus_filter)
+  N > 1   : loci are sharded by rank (weak scaling: every rank owns 100k loci of an
+            N x 100k-locus cohort); per step an RCCL all-reduce sums the per-sample /
+            per-filter counters and an RCCL all-gather collects the per-locus result
+            rows (issued on a second HIP stream, overlapped with the next step).
+torch is imported only for N > 1 (rendezvous, barrier, max-over-ranks), never for compute.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+BYTES_PER_CELL_CALL_FILTER = 20  # read GT 4 + DP 4 + Q 4, write GT' 4 + mask 4
+BYTES_PER_CELL_COUNT = 4         # read GT 4
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--loci', type=int, default=100000)
+    ap.add_argument('--samples', type=int, default=10000)
+    ap.add_argument('--seed', type=int, default=20260928 + 3)
+    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of the CPU baseline sample')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-check', action='store_true')
+    return ap.parse_args()
+
+
+class Workload:
+    """Device-resident buffers + one step of the hot path."""
+
+    def __init__(self, eng, args, rank, world):
+        from trtools_amd.synth import SynthBatch
+        from trtools_amd import _lib as L
+        self.L = L
+        self.eng = eng
+        self.rank, self.world = rank, world
+        self.n_loci, self.n_samples = args.loci, args.samples
+        self.sb = SynthBatch(eng, args.loci, args.samples, seed=args.seed, planes=('dp', 'q'),
+                             locus_base=rank * args.loci)
+        self.planes = [self.sb.dev['dp'], self.sb.dev['q']]
+        # dumpSTR --hipstr-min-call-DP 10 --hipstr-max-call-DP 1000 --hipstr-min-call-Q 0.9
+        self.filters = [dict(op=L.F_LT, plane_a=0, thr=10), dict(op=L.F_GT, plane_a=0, thr=1000),
+                        dict(op=L.F_LT, plane_a=1, thr=0.9)]
+        self.locus_args = dict(min_callrate=0.8, min_hwep=1e-4, min_het=0.05, max_het=0.95, use_length=False)
+        b = self.sb.batch
+        self.stats_a = [eng.alloc_stats(b) for _ in range(2)]     # statSTR rows (double buffered for the gather)
+        self.stats_b = [eng.alloc_stats(b) for _ in range(2)]     # dumpSTR rows
+        self.call_out = eng.alloc_call_out(b, len(self.filters))
+        self.batch2 = b.with_gt(self.call_out.gt_out)
+        self.bits = eng.empty((self.n_loci,), np.uint32)
+        self.loc_counters = eng.zeros((L.TRK_LC_COLS,), np.int64)
+        self.gather = None
+        if world > 1:
+            row_bytes = self.stats_a[0].locus_f64.nbytes
+            self.gather = eng.empty((world, row_bytes), np.uint8)
+        self.step_no = 0
+
+    def step(self):
+        eng = self.eng
+        i = self.step_no & 1
+        self.step_no += 1
+        b = self.sb.batch
+        # counters are per step (each step is a complete statSTR + dumpSTR run)
+        self.call_out.sample_counters.zero()
+        self.call_out.sample_totaldp.zero()
+        self.call_out.sample_dp_missing.zero()
+        self.loc_counters.zero()
+        eng.locus_stats(b, out=self.stats_a[i])
+        eng.call_filters(b, self.planes, self.filters, dp_plane=0, out=self.call_out)
+        eng.locus_stats(self.batch2, out=self.stats_b[i])
+        eng.locus_filters(self.n_loci, self.stats_b[i], bits_out=self.bits, counters=self.loc_counters,
+                          **self.locus_args)
+        if self.world > 1:
+            eng.allreduce_sum_i64(self.call_out.sample_counters)
+            eng.allreduce_sum_i64(self.call_out.sample_totaldp)
+            eng.allreduce_sum_i64(self.loc_counters)
+            eng.allgather(self.stats_b[i].locus_f64, self.gather)
+
+
+def parity_spot_check(wl, n_check=6):
+    """Full-size run vs the oracle on a few regenerated rows + size-independent invariants."""
+    from oracle import trtools_oracle as orc
+    L = wl.L
+    eng = wl.eng
+    rng = np.random.default_rng(1)
+    idx = np.sort(rng.choice(wl.n_loci, size=min(n_check, wl.n_loci), replace=False))
+    host = wl.sb.host_rows(idx)
+    i = (wl.step_no - 1) & 1
+    cnt = wl.stats_a[i].allele_count.get()[0]
+    li = wl.stats_a[i].locus_int.get()[0]
+    lf = wl.stats_a[i].locus_f64.get()[0]
+    off = wl.sb.tables[0]
+    for r, l in enumerate(idx):
+        o = orc.locus_stats(host['gt'][r], wl.sb.loci.allele_lens[l], wl.sb.loci.allele_strs[l], None,
+                            use_length=False)
+        assert np.array_equal(cnt[off[l]:off[l + 1]], o['index_counts']), ("allele counts", l)
+        assert li[l, L.LI_N_CALLED] == o['numcalled'], ("numcalled", l)
+        for col, key in ((L.LF_HET_STR, 'het'), (L.LF_MEAN, 'mean'), (L.LF_VAR, 'var'), (L.LF_HWEP_STR, 'hwep')):
+            a, bb = lf[l, col], o[key]
+            assert (np.isnan(a) and np.isnan(bb)) or abs(a - bb) <= 1e-9 * max(1.0, abs(bb)), (key, l, a, bb)
+    # invariants over the whole shard
+    nall = li[:, L.LI_N_ALLELES].astype(np.int64)
+    seg = np.add.reduceat(cnt.astype(np.int64), off[:-1]) if wl.n_loci else np.zeros(0)
+    assert np.array_equal(seg, nall), "sum of allele counts != N_ALLELES"
+    assert np.all(li[:, L.LI_N_CALLED] <= wl.n_samples) and np.all(li[:, L.LI_N_BAD] == 0)
+    cnts = wl.call_out.sample_counters.get()
+    if wl.world == 1:
+        lib = wl.stats_b[i].locus_int.get()[0]
+        # every PASS call is a called sample of the masked matrix and vice versa
+        assert int(cnts[0].sum()) == int(lib[:, L.LI_N_CALLED].sum()), "numcalls != called after masking"
+        lc = wl.loc_counters.get()
+        bits = wl.bits.get()
+        assert lc[L.LC_PASS] == int(np.sum(bits == 0))
+        assert lc[L.LC_TOTALCALLS] == int(lib[bits == 0, L.LI_N_CALLED].sum())
+    return len(idx)
+
+
+def cpu_baseline(wl, budget_s):
+    """The oracle (numpy/scipy port of the reference's per-locus algorithm) on a bounded
+    sample of the same workload, one host core."""
+    import collections
+    from oracle import trtools_oracle as orc
+    rng = np.random.default_rng(2)
+    S = wl.n_samples
+    done = 0
+    t0 = time.perf_counter()
+    info = collections.OrderedDict([('numcalls', np.zeros(S, dtype=int)), ('totaldp', np.zeros(S)),
+                                    ('mindp', np.zeros(S, dtype=int)), ('maxdp', np.zeros(S, dtype=int)),
+                                    ('minq', np.zeros(S, dtype=int))])
+    loc = collections.defaultdict(int)
+    gen_time = 0.0
+    while True:
+        l = int(rng.integers(0, wl.n_loci))
+        tg = time.perf_counter()
+        h = wl.sb.host_rows(np.array([l]))
+        gen_time += time.perf_counter() - tg
+        gt, dp, q = h['gt'][0], h['dp'][0].reshape(-1, 1), h['q'][0].reshape(-1, 1)
+        lens, strs = wl.sb.loci.allele_lens[l], wl.sb.loci.allele_strs[l]
+        orc.locus_stats(gt, lens, strs, None, use_length=False)            # statSTR, all 11 stats
+        outs = [('mindp', orc.filt_min_value(dp, 10)), ('maxdp', orc.filt_max_value(dp, 1000)),
+                ('minq', orc.filt_min_value(q, 0.9))]
+        g2, _ = orc.apply_call_filters(gt, outs, info, dp=dp)              # dumpSTR call filters
+        try:
+            orc.apply_locus_filters(g2, lens, strs, loc, use_length=False, min_callrate=0.8, min_hwep=1e-4,
+                                    min_het=0.05, max_het=0.95)
+            orc.locus_info_fields(g2, lens, strs, False)
+        except ValueError:
+            pass
+        done += 1
+        if time.perf_counter() - t0 - gen_time >= budget_s:
+            break
+    el = time.perf_counter() - t0 - gen_time
+    return dict(value=done / el, unit="loci/s", cores=1, kind="port",
+                sample="%d random loci x %d samples of the same synthetic call set, statSTR (11 stats, "
+                       "string alleles) + dumpSTR (3 call filters, 4 locus filters, INFO recompute) through "
+                       "oracle/trtools_oracle.py (numpy+scipy, per-locus like the reference), %.1f s"
+                       % (done, S, el),
+                cells_per_s=done * S / el)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # rendezvous / barrier only
+        dist.init_process_group(backend='gloo')
+    from trtools_amd.engine import Engine
+    eng = Engine(local_rank)
+    if world > 1:
+        uid = [eng.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        eng.comm_init(rank, world, uid[0])
+    wl = Workload(eng, args, rank, world)
+
+    def barrier():
+        eng.sync()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        wl.step()
+    barrier()
+    eng.profile(True)
+    eng.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    eng.sync()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+        dist.barrier()
+    prof = eng.profile_get()
+    eng.profile(False)
+
+    n_checked = 0
+    if not args.no_check:
+        n_checked = parity_spot_check(wl)
+    if rank == 0:
+        cells = wl.n_loci * wl.n_samples
+        ms_step = elapsed / args.steps * 1e3
+        loci_s = world * wl.n_loci * args.steps / elapsed
+        kn, kms = prof['k_call_filter']
+        cn, cms = prof['k_locus_count']
+        fn_, fms = prof['k_locus_finalize']
+        avg_cf = kms / max(kn, 1)
+        avg_cnt = cms / max(cn, 1)
+        achieved = cells * BYTES_PER_CELL_CALL_FILTER / (avg_cf * 1e-3) / 1e9 if kn else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get('k_call_filter_bytes_per_launch')
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "loci/sec (and genotype-cells/sec) statSTR+dumpSTR, 100k loci x 10k samples",
+            "value": loci_s, "unit": "loci/s",
+            "cells_per_sec": loci_s * wl.n_samples,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "i16", "data": "synthetic",
+            "config": {"workload": "statSTR (11 stats) + dumpSTR (min-DP/max-DP/min-Q call filters, "
+                                   "callrate/HWE/het-low/het-high locus filters) combined, HipSTR-shape, "
+                                   "%d loci x %d samples per GPU (BASELINE configs[3])" % (wl.n_loci, wl.n_samples),
+                       "n_loci_per_gpu": wl.n_loci, "n_samples": wl.n_samples, "ploidy": 2,
+                       "max_alleles": int(np.max(np.diff(wl.sb.tables[0]))),
+                       "sharding": "loci by rank; RCCL all-reduce of sample/locus counters + all-gather of locus rows"
+                       if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "k_call_filter", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "bytes_per_cell": BYTES_PER_CELL_CALL_FILTER, "avg_launch_ms": avg_cf,
+                         "launches": kn},
+            "kernels_ms": {k: (v[1] / v[0] if v[0] else None) for k, v in prof.items()},
+            "k_locus_count_roofline": {"achieved": cells * BYTES_PER_CELL_COUNT / (avg_cnt * 1e-3) / 1e9 if cn else 0.0,
+                                       "unit": "GB/s", "bytes_per_cell": BYTES_PER_CELL_COUNT,
+                                       "frac": (cells * BYTES_PER_CELL_COUNT / (avg_cnt * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                                       if cn else 0.0},
+            "parity_rows_checked": n_checked,
+            "device": eng.arch,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == '__main__':
+    main()

@@ -233,7 +233,7 @@ typedef struct {
     int64_t* sample_counters; /* [(1+nf), S] += : row 0 numcalls (:686-687),
                                  row 1+k sample_info[filter k] (:661)              */
     int64_t* sample_totaldp;  /* [S] += DP of PASS calls with DP > 0 (:707-709)    */
-    int32_t* sample_dp_missing;/* [S] += PASS calls whose DP is missing (-> nan, :710) */
+    int64_t* sample_dp_missing;/* [S] += PASS calls whose DP is missing (-> nan, :710) */
     int32_t* error;           /* [4] error[0] != 0: a PASS call had negative DP
                                  (ValueError :698-706); error[1]=locus, [2]=sample */
 } trk_call_out;

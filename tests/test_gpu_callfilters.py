@@ -1,0 +1,260 @@
+"""GPU parity: trk_call_filters / trk_locus_filters (HIP through the C ABI) vs
+the oracle restatement of dumpSTR.ApplyCallFilters / ApplyLocusFilters
+(dumpSTR.py:613-973, filters.py).  Integer outputs bit-exact."""
+import collections
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+INT_MIN = -2147483648
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from trtools_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _oracle_run(orc, gt, filt_fn, names, dp, locus_ploidy=None):
+    """Loop the oracle over loci; returns sample_info, masked gt, mask bits."""
+    Lc, S, P = gt.shape
+    info = collections.OrderedDict()
+    info['numcalls'] = np.zeros(S, dtype=int)
+    info['totaldp'] = np.zeros(S, dtype=float)
+    for n in names:
+        info[n] = np.zeros(S, dtype=int)
+    gout = np.empty_like(gt)
+    mask = np.zeros((Lc, S), dtype=np.uint32)
+    for l in range(Lc):
+        pl = P if locus_ploidy is None else int(locus_ploidy[l])
+        g = gt[l][:, :pl]
+        outs = filt_fn(l, g)
+        for k, (_, o) in enumerate(outs):
+            mask[l] |= (~np.isnan(o)).astype(np.uint32) << np.uint32(k)
+        mask[l] |= (~orc.get_called_samples(g)).astype(np.uint32) << np.uint32(31)
+        mg, _ = orc.apply_call_filters(g, outs, info, dp=None if dp is None else dp[l].reshape(-1, 1))
+        gout[l] = gt[l]
+        gout[l][:, :pl] = mg
+    return info, gout, mask
+
+
+def _compare(info, gout, mask, res, names, S):
+    cnt = res.sample_counters.get()
+    assert np.array_equal(cnt[0], info['numcalls'])
+    for k, n in enumerate(names):
+        assert np.array_equal(cnt[1 + k], info[n]), n
+    tot = res.sample_totaldp.get().astype(float)
+    tot[res.sample_dp_missing.get() > 0] = np.nan
+    assert np.array_equal(np.isnan(tot), np.isnan(info['totaldp']))
+    ok = ~np.isnan(tot)
+    assert np.array_equal(tot[ok], info['totaldp'][ok])
+    assert np.array_equal(res.gt_out.get(), gout)
+    assert np.array_equal(res.filter_mask.get(), mask)
+    assert res.error.get()[0] == 0
+
+
+@pytest.mark.parametrize("n_loci,n_samples", [(150, 1000), (33, 52), (20, 1003)])
+def test_hipstr_shape_filters(eng, n_loci, n_samples):
+    from oracle import trtools_oracle as orc
+    from trtools_amd import _lib as L
+    from trtools_amd.synth import SynthBatch
+    sb = SynthBatch(eng, n_loci, n_samples, seed=77 + n_samples, planes=('dp', 'q', 'dstutter', 'dflankindel'))
+    h = sb.host_rows(np.arange(n_loci))
+    planes = [sb.dev['dp'], sb.dev['q'], sb.dev['dstutter'], sb.dev['dflankindel']]
+    # BuildCallFilters order (dumpSTR.py:792-804): flank indel, stutter, min DP, max DP, min Q
+    filters = [dict(op=L.F_RATIO_GT, plane_a=3, plane_b=0, thr=0.15),
+               dict(op=L.F_RATIO_GT, plane_a=2, plane_b=0, thr=0.15),
+               dict(op=L.F_LT, plane_a=0, thr=10), dict(op=L.F_GT, plane_a=0, thr=55),
+               dict(op=L.F_LT, plane_a=1, thr=0.9)]
+    names = ['flank', 'stutter', 'mindp', 'maxdp', 'minq']
+
+    def filt(l, g):
+        dp = h['dp'][l].reshape(-1, 1)
+        return [('flank', orc.filt_ratio_gt(h['dflankindel'][l].reshape(-1, 1), dp, 0.15)),
+                ('stutter', orc.filt_ratio_gt(h['dstutter'][l].reshape(-1, 1), dp, 0.15)),
+                ('mindp', orc.filt_min_value(dp, 10)), ('maxdp', orc.filt_max_value(dp, 55)),
+                ('minq', orc.filt_min_value(h['q'][l].reshape(-1, 1), 0.9))]
+    info, gout, mask = _oracle_run(orc, h['gt'], filt, names, h['dp'])
+    res = eng.call_filters(sb.batch, planes, filters, dp_plane=0)
+    _compare(info, gout, mask, res, names, n_samples)
+    assert info['mindp'].sum() > 0 and info['minq'].sum() > 0 and info['stutter'].sum() > 0
+
+    # locus filters on the masked genotypes (dumpSTR.py:917-973)
+    b2 = sb.batch.with_gt(res.gt_out)
+    st = eng.locus_stats(b2)
+    for use_length in (False, True):
+        bits, counters = eng.locus_filters(n_loci, st, min_callrate=0.9, min_hwep=0.01, min_het=0.1,
+                                           max_het=0.8, use_length=use_length)
+        loc = collections.OrderedDict((k, 0) for k in ['totalcalls', 'PASS', 'NO_CALLS_REMAINING',
+                                                       'CALLRATE0.9', 'HWE0.01', 'HETLOW0.1', 'HETHIGH0.8'])
+        want_bits = np.zeros(n_loci, dtype=np.uint32)
+        bitof = {'CALLRATE0.9': 0, 'HWE0.01': 1, 'HETLOW0.1': 2, 'HETHIGH0.8': 3, 'NO_CALLS_REMAINING': 31}
+        n_raise = 0
+        for l in range(n_loci):
+            try:
+                _, nm = orc.apply_locus_filters(gout[l], sb.loci.allele_lens[l], sb.loci.allele_strs[l], loc,
+                                                use_length=use_length, min_callrate=0.9, min_hwep=0.01,
+                                                min_het=0.1, max_het=0.8)
+            except ValueError:
+                n_raise += 1   # the reference would crash here; the device reports it
+                continue
+            for x in nm:
+                want_bits[l] |= np.uint32(1) << np.uint32(bitof[x])
+        c = counters.get()
+        if n_raise == 0:
+            assert np.array_equal(bits.get(), want_bits)
+            assert c[L.LC_TOTALCALLS] == loc['totalcalls'] and c[L.LC_PASS] == loc['PASS']
+            assert c[L.LC_NO_CALLS] == loc['NO_CALLS_REMAINING']
+            for nm, b in (('CALLRATE0.9', 0), ('HWE0.01', 1), ('HETLOW0.1', 2), ('HETHIGH0.8', 3)):
+                assert c[L.LC_FILTER0 + b] == loc[nm], nm
+        assert c[L.LC_HWE_ERRORS] == n_raise
+
+
+def test_gangstr_and_popstr_shape_filters(eng):
+    """QEXP / RC / REPCN+REPCI / AD filters (filters.py:573-867) incl. ploidy 1-3."""
+    from oracle import trtools_oracle as orc
+    from trtools_amd import _lib as L
+    from trtools_amd.synth import pack_alleles
+    rng = np.random.default_rng(11)
+    Lc, S, P = 40, 96, 2
+    A = 5
+    gt = rng.integers(0, A, size=(Lc, S, P)).astype(np.int16)
+    gt[rng.random((Lc, S)) < 0.1] = -1
+    gt[rng.random((Lc, S)) < 0.03, 1] = -1
+    gt[3] = -1                                   # a locus without any call
+    lens = [[float(i + 2) for i in range(A)]] * Lc
+    strs = [['AC' * (i + 2) for i in range(A)]] * Lc
+    off, lc, sc, cv = pack_alleles(lens, strs)
+    dp = rng.integers(0, 40, size=(Lc, S)).astype(np.int32)
+    qexp = rng.dirichlet(np.ones(3), size=(Lc, S)).astype(np.float32)
+    qexp[rng.random((Lc, S)) < 0.1] = -1
+    rc = np.zeros((Lc, S, 4), dtype=np.int32)
+    rem = dp.copy()
+    for j in range(3):
+        x = (rng.random((Lc, S)) * (rem + 1)).astype(np.int32)
+        x[rng.random((Lc, S)) < 0.2] = 0
+        rc[:, :, j] = np.minimum(x, rem)
+        rem = rem - rc[:, :, j]
+    rc[:, :, 3] = rem
+    perm = rng.permuted(np.tile(np.arange(4), (Lc, S, 1)), axis=2)
+    rc = np.take_along_axis(rc, perm, axis=2)
+    repcn = rng.integers(2, 12, size=(Lc, S, 2)).astype(np.int32)
+    lo = repcn - rng.integers(-1, 3, size=(Lc, S, 2))
+    hi = repcn + rng.integers(-1, 3, size=(Lc, S, 2))
+    repci = np.stack([lo[:, :, 0], hi[:, :, 0], lo[:, :, 1], hi[:, :, 1]], axis=2).astype(np.int32)
+    ad = rng.integers(0, 8, size=(Lc, S, A)).astype(np.int32)
+    nocall = np.any(gt == -1, axis=2)
+    dp[nocall & (rng.random((Lc, S)) < 0.8)] = INT_MIN
+    b = eng.make_batch(gt, off, lc, sc, cv)
+    planes = [eng.upload(dp), eng.upload(qexp), eng.upload(rc), eng.upload(repcn), eng.upload(repci),
+              eng.upload(ad)]
+    # BuildCallFilters order (dumpSTR.py:819-836, 867-872)
+    filters = [dict(op=L.F_LT, plane_a=0, thr=5), dict(op=L.F_GT, plane_a=0, thr=35),
+               dict(op=L.F_CALLED_LT, plane_a=1, col_a=1, thr=0.2),
+               dict(op=L.F_CALLED_LT, plane_a=1, col_a=2, thr=0.2),
+               dict(op=L.F_CALLED_SUM_LT, plane_a=1, col_a=1, col_a2=2, thr=0.5),
+               dict(op=L.F_CALLED_EQ, plane_a=2, col_a=1, plane_b=0, col_b=0),
+               dict(op=L.F_CALLED_SUM_EQ, plane_a=2, col_a=1, col_a2=3, plane_b=0, col_b=0),
+               dict(op=L.F_CALLED_OUTSIDE_CI, plane_a=3, plane_b=4),
+               dict(op=L.F_AD_SUPPORT_LT, plane_a=5, thr=2)]
+    names = ['mindp', 'maxdp', 'het', 'hom', 'total', 'span', 'spanbound', 'badci', 'support']
+
+    def filt(l, g):
+        d = dp[l].reshape(-1, 1)
+        rcs = np.array([','.join(map(str, r)) for r in rc[l]])
+        cis = np.array(['%d-%d,%d-%d' % tuple(r) for r in repci[l]])
+        return [('mindp', orc.filt_min_value(d, 5)), ('maxdp', orc.filt_max_value(d, 35)),
+                ('het', orc.filt_gangstr_qexp(g, qexp[l], 0.2, 'het')),
+                ('hom', orc.filt_gangstr_qexp(g, qexp[l], 0.2, 'hom')),
+                ('total', orc.filt_gangstr_qexp(g, qexp[l], 0.5, 'total')),
+                ('span', orc.filt_gangstr_span_only(g, rcs, d)),
+                ('spanbound', orc.filt_gangstr_spanbound_only(g, rcs, d)),
+                ('badci', orc.filt_gangstr_bad_ci(g, repcn[l], cis)),
+                ('support', orc.filt_popstr_require_support(g, ad[l], 2))]
+    info, gout, mask = _oracle_run(orc, gt, filt, names, dp)
+    res = eng.call_filters(b, planes, filters, dp_plane=0)
+    _compare(info, gout, mask, res, names, S)
+    for n in names:
+        assert info[n].sum() > 0, n
+
+
+def test_general_ploidy_call_filters(eng):
+    from oracle import trtools_oracle as orc
+    from trtools_amd import _lib as L
+    from trtools_amd.synth import pack_alleles
+    rng = np.random.default_rng(12)
+    Lc, S, P, A = 17, 61, 3, 4
+    gt = rng.integers(0, A, size=(Lc, S, P)).astype(np.int16)
+    lp = rng.integers(1, P + 1, size=Lc).astype(np.uint8)
+    for l in range(Lc):
+        gt[l][:, lp[l]:] = -2
+    gt[rng.random((Lc, S)) < 0.1, 0] = -1
+    dp = rng.integers(0, 40, size=(Lc, S)).astype(np.int32)
+    q = rng.random((Lc, S)).astype(np.float32)
+    off, lc, sc, cv = pack_alleles([[1.0, 2.0, 3.0, 4.5]] * Lc, [['A', 'AA', 'AAA', 'AAAAC']] * Lc)
+    b = eng.make_batch(gt, off, lc, sc, cv, locus_ploidy=lp)
+    filters = [dict(op=L.F_LT, plane_a=0, thr=10), dict(op=L.F_LT, plane_a=1, thr=0.5)]
+
+    def filt(l, g):
+        return [('mindp', orc.filt_min_value(dp[l].reshape(-1, 1), 10)),
+                ('minq', orc.filt_min_value(q[l].reshape(-1, 1), 0.5))]
+    info, gout, mask = _oracle_run(orc, gt, filt, ['mindp', 'minq'], dp, locus_ploidy=lp)
+    res = eng.call_filters(b, [eng.upload(dp), eng.upload(q)], filters, dp_plane=0)
+    _compare(info, gout, mask, res, ['mindp', 'minq'], S)
+
+
+def test_negative_dp_is_reported(eng):
+    """dumpSTR.py:698-706: a PASS call with negative DP is a ValueError."""
+    from trtools_amd import _lib as L
+    from trtools_amd.synth import pack_alleles
+    gt = np.zeros((2, 8, 2), dtype=np.int16)
+    dp = np.full((2, 8), 20, dtype=np.int32)
+    dp[1, 5] = -3
+    off, lc, sc, cv = pack_alleles([[1.0]] * 2, [['A']] * 2)
+    b = eng.make_batch(gt, off, lc, sc, cv)
+    res = eng.call_filters(b, [eng.upload(dp)], [dict(op=L.F_GT, plane_a=0, thr=100)], dp_plane=0)
+    err = res.error.get()
+    assert err[0] == 1 and err[1] == 1 and err[2] == 5
+
+
+def test_float32_threshold_semantics(eng):
+    """numpy compares a float32 FORMAT array with the threshold in float32:
+    float32(0.9) < 0.9 is False there but True in float64."""
+    from trtools_amd import _lib as L
+    from trtools_amd.synth import pack_alleles
+    gt = np.zeros((1, 4, 2), dtype=np.int16)
+    q = np.array([[0.9, 0.89999, 0.90001, np.nan]], dtype=np.float32)
+    off, lc, sc, cv = pack_alleles([[1.0]], [['A']])
+    b = eng.make_batch(gt, off, lc, sc, cv)
+    res = eng.call_filters(b, [eng.upload(q)], [dict(op=L.F_LT, plane_a=0, thr=0.9)], dp_plane=-1)
+    assert (res.filter_mask.get()[0] & 1).tolist() == [0, 1, 0, 0]
+    assert (q[0] < 0.9).tolist() == [False, True, False, False]
+
+
+def test_missing_dp_poisons_totaldp(eng):
+    """dumpSTR.py:710-711: a PASS call whose DP is missing turns the sample's totaldp into nan."""
+    from oracle import trtools_oracle as orc
+    from trtools_amd import _lib as L
+    from trtools_amd.synth import pack_alleles
+    rng = np.random.default_rng(3)
+    Lc, S = 12, 40
+    gt = rng.integers(0, 2, size=(Lc, S, 2)).astype(np.int16)
+    gt[rng.random((Lc, S)) < 0.1] = -1
+    dp = rng.integers(1, 40, size=(Lc, S)).astype(np.int32)
+    dp[rng.random((Lc, S)) < 0.05] = INT_MIN
+    dp[rng.random((Lc, S)) < 0.05] = 0
+    q = rng.random((Lc, S)).astype(np.float32)
+    off, lc, sc, cv = pack_alleles([[1.0, 2.0]] * Lc, [['A', 'AA']] * Lc)
+    b = eng.make_batch(gt, off, lc, sc, cv)
+
+    def filt(l, g):
+        return [('minq', orc.filt_min_value(q[l].reshape(-1, 1), 0.3))]
+    info, gout, mask = _oracle_run(orc, gt, filt, ['minq'], dp)
+    res = eng.call_filters(b, [eng.upload(dp), eng.upload(q)], [dict(op=L.F_LT, plane_a=1, thr=0.3)], dp_plane=0)
+    _compare(info, gout, mask, res, ['minq'], S)
+    assert np.isnan(info['totaldp']).any() and (~np.isnan(info['totaldp'])).any()

@@ -218,3 +218,17 @@ def test_empty_and_tiny_batches(eng):
     b2 = eng.make_batch(np.array([[[0, 7], [0, 0]]], dtype=np.int16), off, lc, sc, cv)
     cnt, li, lf = _fetch(eng.locus_stats(b2))
     assert li[0, 0, L.LI_N_BAD] == 1 and cnt.tolist() == [[3]]
+
+
+def test_rccl_single_rank_collectives(eng):
+    """The RCCL path (dlopen'ed librccl, ncclCommInitRank) on a 1-rank communicator."""
+    uid = eng.comm_unique_id()
+    assert len(uid) == 128
+    eng.comm_init(0, 1, uid)
+    a = eng.upload(np.arange(1000, dtype=np.int64))
+    eng.allreduce_sum_i64(a)
+    assert np.array_equal(a.get(), np.arange(1000, dtype=np.int64))
+    src = eng.upload(np.arange(256, dtype=np.uint8))
+    dst = eng.zeros((1, 256), np.uint8)
+    eng.allgather(src, dst)
+    assert np.array_equal(dst.get()[0], np.arange(256, dtype=np.uint8))

@@ -482,8 +482,9 @@ struct ModeStats {
 
 // class counts are in cc[0..ncls), ascending class order == the dict order the
 // reference iterates in (np.unique sorts keys; tr_harmonizer.py:1495-1499)
-__device__ void mode_stats(const int32_t* cc, int ncls, int64_t total, double nalleles_thresh,
-                           int n_called, int n_low, int n_hom, int pl, ModeStats& o) {
+__device__ __forceinline__ void mode_stats(const int32_t* cc, int cstride, int ncls, int64_t total,
+                                           double nalleles_thresh, int n_called, int n_low, int n_hom, int pl,
+                                           ModeStats& o) {
     const double nan = __builtin_nan("");
     o.het = o.entropy = o.hwep = nan;
     o.nalleles = 0;
@@ -493,7 +494,7 @@ __device__ void mode_stats(const int32_t* cc, int ncls, int64_t total, double na
     double fsum = 0.0, sq = 0.0;
     int na = 0;
     for (int c = 0; c < ncls; ++c) {
-        int n = cc[c];
+        int n = cc[c * cstride];
         if (n == 0) continue;
         double f = (double)n / ft;
         fsum += f;
@@ -506,7 +507,7 @@ __device__ void mode_stats(const int32_t* cc, int ncls, int64_t total, double na
     // scipy.stats.entropy(pk, base=2): pk /= sum(pk); -sum(pk ln pk) / ln 2
     double ent = 0.0;
     for (int c = 0; c < ncls; ++c) {
-        int n = cc[c];
+        int n = cc[c * cstride];
         if (n == 0) continue;
         double pk = ((double)n / ft) / fsum;
         ent -= pk * log(pk);
@@ -526,10 +527,16 @@ __device__ void mode_stats(const int32_t* cc, int ncls, int64_t total, double na
     }
 }
 
-__global__ __launch_bounds__(128) void k_locus_finalize(trk_batch b, const int32_t* __restrict__ allele_count,
-                                                       int32_t* __restrict__ locus_int,
-                                                       double* __restrict__ locus_f64,
-                                                       int32_t* __restrict__ scratch, double nalleles_thresh) {
+constexpr int FIN_THREADS = 64;
+// LDS_CC: class counts live in thread-private LDS columns ([class][thread], so a
+// wave's accesses are bank-conflict free); otherwise in a global scratch segment.
+template <bool LDS_CC>
+__global__ __launch_bounds__(FIN_THREADS) void k_locus_finalize(trk_batch b, const int32_t* __restrict__ allele_count,
+                                                               int32_t* __restrict__ locus_int,
+                                                               double* __restrict__ locus_f64,
+                                                               int32_t* __restrict__ scratch,
+                                                               double nalleles_thresh, int max_alleles) {
+    extern __shared__ uint32_t fin_lds[];
     const int L = b.n_loci;
     const int G = b.group_bits ? b.n_groups : 1;
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -540,21 +547,31 @@ __global__ __launch_bounds__(128) void k_locus_finalize(trk_batch b, const int32
     const int A = b.allele_off[l + 1] - off;
     const int64_t sumA = b.n_alleles_total;
     const int32_t* cnt = allele_count + (int64_t)g * sumA + off;
-    int32_t* ccl = scratch + ((int64_t)g * 2 + 0) * sumA + off;
-    int32_t* ccs = scratch + ((int64_t)g * 2 + 1) * sumA + off;
+    int32_t* ccl;
+    int32_t* ccs;
+    int cs;
+    if (LDS_CC) {
+        ccl = reinterpret_cast<int32_t*>(fin_lds) + threadIdx.x;
+        ccs = ccl + max_alleles * FIN_THREADS;
+        cs = FIN_THREADS;
+    } else {
+        ccl = scratch + ((int64_t)g * 2 + 0) * sumA + off;
+        ccs = scratch + ((int64_t)g * 2 + 1) * sumA + off;
+        cs = 1;
+    }
     int32_t* li = locus_int + ((int64_t)g * L + l) * TRK_LI_COLS;
     double* lf = locus_f64 + ((int64_t)g * L + l) * TRK_LF_COLS;
     const double nan = __builtin_nan("");
 
     for (int a = 0; a < A; ++a) {
-        ccl[a] = 0;
-        ccs[a] = 0;
+        ccl[a * cs] = 0;
+        ccs[a * cs] = 0;
     }
     int64_t total = 0;
     for (int a = 0; a < A; ++a) {
         int n = cnt[a];
-        ccl[b.len_class[off + a]] += n;
-        ccs[b.str_class[off + a]] += n;
+        ccl[b.len_class[off + a] * cs] += n;
+        ccs[b.str_class[off + a] * cs] += n;
         total += n;
     }
     li[TRK_LI_N_ALLELES] = (int32_t)total;
@@ -563,8 +580,15 @@ __global__ __launch_bounds__(128) void k_locus_finalize(trk_batch b, const int32
     int pl = b.locus_ploidy ? (int)b.locus_ploidy[l] : b.ploidy;
 
     ModeStats ml, ms;
-    mode_stats(ccl, A, total, nalleles_thresh, n_called, n_low, li[TRK_LI_N_HOM_LEN], pl, ml);
-    mode_stats(ccs, A, total, nalleles_thresh, n_called, n_low, li[TRK_LI_N_HOM_STR], pl, ms);
+    mode_stats(ccl, cs, A, total, nalleles_thresh, n_called, n_low, li[TRK_LI_N_HOM_LEN], pl, ml);
+    // identical partitions of the allele indices (the common case: no two alleles
+    // share a length or a sequence) give identical class counts in both modes
+    bool same = li[TRK_LI_N_HOM_LEN] == li[TRK_LI_N_HOM_STR];
+    for (int a = 0; a < A && same; ++a) same = ccl[a * cs] == ccs[a * cs];
+    if (same)
+        ms = ml;
+    else
+        mode_stats(ccs, cs, A, total, nalleles_thresh, n_called, n_low, li[TRK_LI_N_HOM_STR], pl, ms);
     li[TRK_LI_HWE_STATUS_LEN] = ml.status;
     li[TRK_LI_HWE_STATUS_STR] = ms.status;
     li[TRK_LI_NALLELES_LEN] = ml.nalleles;
@@ -584,7 +608,7 @@ __global__ __launch_bounds__(128) void k_locus_finalize(trk_batch b, const int32
         double fsum = 0.0;
         int best = -1, bestn = 0;
         for (int c = 0; c < A; ++c) {
-            int n = ccl[c];
+            int n = ccl[c * cs];
             if (n == 0) continue;
             fsum += (double)n / ft;
             thresh = cv[c];  // ascending classes: the last non-empty one is the max
@@ -596,13 +620,13 @@ __global__ __launch_bounds__(128) void k_locus_finalize(trk_batch b, const int32
         if (fabs(1.0 - fsum) <= 0.001) {
             double m = 0.0;
             for (int c = 0; c < A; ++c) {
-                int n = ccl[c];
+                int n = ccl[c * cs];
                 if (n == 0) continue;
                 m += cv[c] * ((double)n / ft);  // utils.py:236
             }
             double v = 0.0;
             for (int c = 0; c < A; ++c) {
-                int n = ccl[c];
+                int n = ccl[c * cs];
                 if (n == 0) continue;
                 double d = cv[c] - m;
                 v += ((double)n / ft) * (d * d);  // utils.py:296
@@ -715,6 +739,10 @@ struct CallArgs {
     trk_plane planes[TRK_MAX_PLANES];
     trk_call_filter filters[TRK_MAX_FILTERS];
     int n_planes, n_filters, dp_plane, loci_per_block;
+    uint32_t fast_plane_mask;   // planes 0..3 with one column (fetched as 16-byte vectors)
+    uint32_t fast_filter_mask;  // LT / GT / CALLED_LT filters on a fast plane
+    uint32_t slow_filter_mask;  // everything else
+    uint32_t pad0;
     trk_call_out out;
 };
 
@@ -814,13 +842,183 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter(const CallArgs a) {
             if (totaldp[j])
                 atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_totaldp + s),
                           (unsigned long long)totaldp[j]);
-            if (dpmiss[j]) atomicAdd(a.out.sample_dp_missing + s, (int)dpmiss[j]);
+            if (dpmiss[j])
+                atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_dp_missing + s),
+                          (unsigned long long)dpmiss[j]);
             for (int k = 0; k < nf; ++k) {
                 uint32_t c = fcount[(k * CF_THREADS + tid) * CF_V + j];
                 if (c)
                     atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_counters + (int64_t)(1 + k) * S + s),
                               (unsigned long long)c);
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_call_filter_fast : P == 2, S % 4 == 0.  Plane-major evaluation: the (up to
+// four) single-column FORMAT planes are fetched once per locus as 16-byte
+// vectors, then every simple threshold filter that reads plane p is evaluated
+// on the registers.  Filters that need two planes or multi-column planes take
+// the per-call path (eval_filter).  U loci are in flight per thread.
+// ---------------------------------------------------------------------------
+constexpr int CF_FASTP = 4;
+
+struct CfLocus {
+    u32x4 gt;
+    u32x4 pv[CF_FASTP];
+};
+
+__device__ __forceinline__ void cf_load(const CallArgs& a, int64_t cell0, CfLocus& d) {
+    d.gt = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.b.gt) + (cell0 >> 2));
+#pragma unroll
+    for (int p = 0; p < CF_FASTP; ++p)
+        if ((a.fast_plane_mask >> p) & 1u)
+            d.pv[p] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.planes[p].data) + (cell0 >> 2));
+}
+
+__device__ __forceinline__ void cf_process(const CallArgs& a, int l, int64_t cell0, int64_t s0, int tid,
+                                           const CfLocus& d, uint32_t* fcount, uint32_t* numcalls,
+                                           int64_t* totaldp, uint32_t* dpmiss) {
+    const int nf = a.n_filters;
+    const int pl = a.b.locus_ploidy ? min((int)a.b.locus_ploidy[l], 2) : 2;
+    uint32_t w[CF_V] = {d.gt[0], d.gt[1], d.gt[2], d.gt[3]};
+    uint32_t mask[CF_V];
+    bool called[CF_V];
+#pragma unroll
+    for (int j = 0; j < CF_V; ++j) {
+        const bool m0 = (w[j] & 0xffffu) == 0xffffu;
+        const bool m1 = (pl > 1) & ((w[j] >> 16) == 0xffffu);
+        called[j] = !(m0 | m1);
+        mask[j] = called[j] ? 0u : TRK_MASK_NOCALL;
+    }
+#pragma unroll
+    for (int p = 0; p < CF_FASTP; ++p) {
+        if (!((a.fast_plane_mask >> p) & 1u)) continue;
+        const bool isf = a.planes[p].dtype == TRK_DT_F32;
+        for (int k = 0; k < nf; ++k) {
+            if (!((a.fast_filter_mask >> k) & 1u)) continue;
+            const trk_call_filter& f = a.filters[k];
+            if (f.plane_a != p) continue;
+            const bool gt_op = f.op == TRK_F_GT;
+            const bool need_called = f.op == TRK_F_CALLED_LT;
+            const float thrf = (float)f.thr;
+#pragma unroll
+            for (int j = 0; j < CF_V; ++j) {
+                bool hit;
+                if (isf) {
+                    const float v = __uint_as_float(d.pv[p][j]);
+                    hit = gt_op ? (v > thrf) : (v < thrf);
+                } else {
+                    const double v = (double)(int32_t)d.pv[p][j];
+                    hit = gt_op ? (v > f.thr) : (v < f.thr);
+                }
+                hit &= called[j] | !need_called;
+                mask[j] |= hit ? (1u << k) : 0u;
+                if (hit & called[j]) atomicAdd(&fcount[(k * CF_THREADS + tid) * CF_V + j], 1u);
+            }
+        }
+    }
+    if (a.slow_filter_mask) {
+        for (int k = 0; k < nf; ++k) {
+            if (!((a.slow_filter_mask >> k) & 1u)) continue;
+#pragma unroll
+            for (int j = 0; j < CF_V; ++j) {
+                int gtv[2] = {(int)(int16_t)(w[j] & 0xffffu), (int)(int16_t)(w[j] >> 16)};
+                if (eval_filter(a.filters[k], a.planes, cell0 + j, called[j], gtv, 2, pl)) {
+                    mask[j] |= 1u << k;
+                    if (called[j]) atomicAdd(&fcount[(k * CF_THREADS + tid) * CF_V + j], 1u);
+                }
+            }
+        }
+    }
+    const bool dp_fast = a.dp_plane >= 0 && a.dp_plane < CF_FASTP && ((a.fast_plane_mask >> a.dp_plane) & 1u);
+#pragma unroll
+    for (int j = 0; j < CF_V; ++j) {
+        if (mask[j] == 0) {
+            numcalls[j]++;
+            if (a.dp_plane >= 0) {
+                int32_t dv;
+                if (dp_fast) {
+                    // static indexing only: pick the DP vector with a uniform select chain
+                    uint32_t raw = d.pv[0][j];
+#pragma unroll
+                    for (int p = 1; p < CF_FASTP; ++p) raw = a.dp_plane == p ? d.pv[p][j] : raw;
+                    dv = (int32_t)raw;
+                } else {
+                    const trk_plane& dp = a.planes[a.dp_plane];
+                    dv = reinterpret_cast<const int32_t*>(dp.data)[(cell0 + j) * dp.ncol];
+                }
+                if (dv == INT32_MIN) {
+                    dpmiss[j]++;
+                } else if (dv < 0) {
+                    if (atomicCAS(&a.out.error[0], 0, 1) == 0) {
+                        a.out.error[1] = l;
+                        a.out.error[2] = (int32_t)(s0 + j);
+                    }
+                } else {
+                    totaldp[j] += dv;
+                }
+            }
+        } else if (called[j]) {
+            w[j] = pl > 1 ? 0xffffffffu : (w[j] | 0xffffu);
+        }
+    }
+    if (a.out.gt_out)
+        __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]},
+                                    reinterpret_cast<u32x4*>(a.out.gt_out) + (cell0 >> 2));
+    if (a.out.filter_mask)
+        __builtin_nontemporal_store(u32x4{mask[0], mask[1], mask[2], mask[3]},
+                                    reinterpret_cast<u32x4*>(a.out.filter_mask) + (cell0 >> 2));
+}
+
+template <int U>
+__global__ __launch_bounds__(CF_THREADS) void k_call_filter_fast(const CallArgs a) {
+    extern __shared__ uint32_t fcount[];  // [n_filters][CF_THREADS * CF_V]
+    const int tid = threadIdx.x;
+    const int S = a.b.n_samples, L = a.b.n_loci;
+    const int nf = a.n_filters;
+    const int64_t s0 = ((int64_t)blockIdx.x * CF_THREADS + tid) * CF_V;
+    const int l_begin = blockIdx.y * a.loci_per_block;
+    const int l_end = min(L, l_begin + a.loci_per_block);
+    for (int k = 0; k < nf; ++k)
+#pragma unroll
+        for (int j = 0; j < CF_V; ++j) fcount[(k * CF_THREADS + tid) * CF_V + j] = 0;
+    if (s0 >= S) return;  // S % 4 == 0: a thread's 4 samples are all in range or all out
+    uint32_t numcalls[CF_V] = {0, 0, 0, 0};
+    uint32_t dpmiss[CF_V] = {0, 0, 0, 0};
+    int64_t totaldp[CF_V] = {0, 0, 0, 0};
+    int l = l_begin;
+    for (; l + U <= l_end; l += U) {
+        CfLocus d[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) cf_load(a, (int64_t)(l + u) * S + s0, d[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            cf_process(a, l + u, (int64_t)(l + u) * S + s0, s0, tid, d[u], fcount, numcalls, totaldp, dpmiss);
+    }
+    for (; l < l_end; ++l) {
+        CfLocus d;
+        cf_load(a, (int64_t)l * S + s0, d);
+        cf_process(a, l, (int64_t)l * S + s0, s0, tid, d, fcount, numcalls, totaldp, dpmiss);
+    }
+#pragma unroll
+    for (int j = 0; j < CF_V; ++j) {
+        const int64_t s = s0 + j;
+        if (numcalls[j])
+            atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_counters + s),
+                      (unsigned long long)numcalls[j]);
+        if (totaldp[j])
+            atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_totaldp + s),
+                      (unsigned long long)totaldp[j]);
+        if (dpmiss[j])
+                atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_dp_missing + s),
+                          (unsigned long long)dpmiss[j]);
+        for (int k = 0; k < nf; ++k) {
+            uint32_t c = fcount[(k * CF_THREADS + tid) * CF_V + j];
+            if (c)
+                atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_counters + (int64_t)(1 + k) * S + s),
+                          (unsigned long long)c);
         }
     }
 }
@@ -999,9 +1197,16 @@ hipError_t launch_locus_finalize(const trk_batch& b, const int32_t* allele_count
     const int G = b.group_bits ? b.n_groups : 1;
     int64_t n = (int64_t)G * b.n_loci;
     if (n == 0) return hipSuccess;
-    int blocks = (int)((n + 127) / 128);
-    hipLaunchKernelGGL(k_locus_finalize, dim3(blocks), dim3(128), 0, stream, b, allele_count, locus_int, locus_f64,
-                       scratch, nalleles_thresh);
+    int blocks = (int)((n + FIN_THREADS - 1) / FIN_THREADS);
+    const int maxA = b.max_alleles;
+    if (maxA > 0 && maxA <= 96) {
+        size_t lds = (size_t)2 * maxA * FIN_THREADS * sizeof(int32_t);
+        hipLaunchKernelGGL(k_locus_finalize<true>, dim3(blocks), dim3(FIN_THREADS), lds, stream, b, allele_count,
+                           locus_int, locus_f64, scratch, nalleles_thresh, maxA);
+    } else {
+        hipLaunchKernelGGL(k_locus_finalize<false>, dim3(blocks), dim3(FIN_THREADS), 0, stream, b, allele_count,
+                           locus_int, locus_f64, scratch, nalleles_thresh, maxA);
+    }
     return hipGetLastError();
 }
 
@@ -1021,20 +1226,33 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
     int gx = (S + CF_THREADS * CF_V - 1) / (CF_THREADS * CF_V);
     // enough blocks to fill the chip (>= 8 per CU) while keeping the per-block
     // counter flush (one atomic per sample per counter) small next to the stream
-    int want_blocks = n_cu * 16;
+    int want_blocks = n_cu * 64;
     int gy = (want_blocks + gx - 1) / gx;
     if (gy > L) gy = L;
     if (gy < 1) gy = 1;
     int lpb = (L + gy - 1) / gy;
+    if (lpb < 32) lpb = L < 32 ? L : 32;
     if (lpb > 4096) lpb = 4096;
     gy = (L + lpb - 1) / lpb;
     a.loci_per_block = lpb;
     size_t lds = (size_t)n_filters * CF_THREADS * CF_V * sizeof(uint32_t);
     const bool vec = (b.ploidy == 2) && (S % 4 == 0);
-    if (vec)
-        hipLaunchKernelGGL(k_call_filter<true>, dim3(gx, gy), dim3(CF_THREADS), lds, stream, a);
-    else
+    a.fast_plane_mask = a.fast_filter_mask = a.slow_filter_mask = a.pad0 = 0;
+    if (vec) {
+        for (int p = 0; p < n_planes && p < CF_FASTP; ++p)
+            if (planes[p].ncol == 1 && ((uintptr_t)planes[p].data & 15u) == 0) a.fast_plane_mask |= 1u << p;
+        for (int k = 0; k < n_filters; ++k) {
+            const trk_call_filter& f = filters[k];
+            const bool simple = f.op == TRK_F_LT || f.op == TRK_F_GT || f.op == TRK_F_CALLED_LT;
+            if (simple && f.plane_a < CF_FASTP && ((a.fast_plane_mask >> f.plane_a) & 1u))
+                a.fast_filter_mask |= 1u << k;
+            else
+                a.slow_filter_mask |= 1u << k;
+        }
+        hipLaunchKernelGGL(k_call_filter_fast<2>, dim3(gx, gy), dim3(CF_THREADS), lds, stream, a);
+    } else {
         hipLaunchKernelGGL(k_call_filter<false>, dim3(gx, gy), dim3(CF_THREADS), lds, stream, a);
+    }
     return hipGetLastError();
 }
 

@@ -236,7 +236,7 @@ class Engine:
             self.empty((batch.n_loci, S, batch.ploidy), np.int16) if want_gt else None,
             self.empty((batch.n_loci, S), np.uint32) if want_mask else None,
             self.zeros((1 + n_filters, S), np.int64), self.zeros((S,), np.int64),
-            self.zeros((S,), np.int32), self.zeros((4,), np.int32))
+            self.zeros((S,), np.int64), self.zeros((4,), np.int32))
 
     def call_filters(self, batch, planes, filters, dp_plane=-1, out=None):
         """planes: list of DeviceArray ([L,S] or [L,S,k], int32/float32);
