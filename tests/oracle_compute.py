@@ -1,0 +1,173 @@
+"""Oracle-backed stand-in for trtools_amd.compute.DeviceCompute (TESTS ONLY).
+
+Same methods, results computed one locus at a time by oracle/trtools_oracle.py.
+It lets the CPU test-suite drive the host layer (VCF decoding, harmonisation,
+batch packing, text formatting, counters/log writing) end to end against the
+reference's golden files on a machine without a GPU, and it is the checker the
+GPU tests compare DeviceCompute against.  Never imported by the product."""
+import collections
+import math
+
+import numpy as np
+
+from oracle import trtools_oracle as orc
+from trtools_amd import _lib as L
+from trtools_amd.compute import StatsHost, CallHost
+
+
+def _groups(hb):
+    if hb.group_bits is None:
+        return [None]
+    return [((hb.group_bits >> g) & 1).astype(bool) for g in range(hb.n_groups)]
+
+
+def stats_of(hb, gt, nalleles_thresh):
+    groups = _groups(hb)
+    G, Lc = len(groups), hb.n_loci
+    cnt = np.zeros((G, int(hb.allele_off[-1])), dtype=np.int32)
+    li = np.zeros((G, Lc, L.TRK_LI_COLS), dtype=np.int32)
+    lf = np.full((G, Lc, L.TRK_LF_COLS), np.nan)
+    for l in range(Lc):
+        pl = int(hb.locus_ploidy[l])
+        g = gt[l][:, :pl]
+        o, e = int(hb.allele_off[l]), int(hb.allele_off[l + 1])
+        for gi, si in enumerate(groups):
+            ol = orc.locus_stats(g, hb.allele_lens[l], hb.allele_strs[l], si, True, nalleles_thresh)
+            os_ = orc.locus_stats(g, hb.allele_lens[l], hb.allele_strs[l], si, False, nalleles_thresh)
+            cnt[gi, o:e] = ol['index_counts']
+            I, F = li[gi, l], lf[gi, l]
+            I[L.LI_N_CALLED] = ol['n_called']
+            I[L.LI_N_SAMPLES] = ol['n_samples']
+            I[L.LI_N_ALLELES] = int(ol['index_counts'].sum())
+            I[L.LI_NALLELES_LEN], I[L.LI_NALLELES_STR] = ol['nalleles'], os_['nalleles']
+            for scol, fcol, o_ in ((L.LI_HWE_STATUS_LEN, L.LF_HWEP_LEN, ol), (L.LI_HWE_STATUS_STR, L.LF_HWEP_STR, os_)):
+                if o_['hwep_status'] != orc.HWE_OK:
+                    I[scol] = o_['hwep_status']
+                elif math.isnan(o_['hwep']):
+                    I[scol] = L.HWE_NAN
+                else:
+                    I[scol] = L.HWE_OK
+                    F[fcol] = o_['hwep']
+            F[L.LF_THRESH], F[L.LF_MEAN], F[L.LF_MODE], F[L.LF_VAR] = ol['thresh'], ol['mean'], ol['mode'], ol['var']
+            F[L.LF_HET_LEN], F[L.LF_HET_STR] = ol['het'], os_['het']
+            F[L.LF_ENTROPY_LEN], F[L.LF_ENTROPY_STR] = ol['entropy'], os_['entropy']
+            F[L.LF_CALLRATE] = ol['n_called'] / ol['n_samples'] if ol['n_samples'] else np.nan
+    return StatsHost(cnt, li, lf)
+
+
+def _eval_filter(f, planes, l, g):
+    """One trk_call_filter spec on locus l through the oracle's filt_* functions."""
+    op = f['op']
+    pa = planes[f['plane_a']][l]
+    pa = pa.reshape(pa.shape[0], -1)
+    ca = f.get('col_a', 0)
+    thr = f.get('thr', 0.0)
+    if pa.dtype == np.int32 and float(thr) == int(thr):
+        thr = int(thr)
+    S = pa.shape[0]
+    called = orc.get_called_samples(g)
+    if op == L.F_LT:
+        return orc.filt_min_value(pa[:, ca:ca + 1], thr)
+    if op == L.F_GT:
+        return orc.filt_max_value(pa[:, ca:ca + 1], thr)
+    if op == L.F_RATIO_GT:
+        pb = planes[f['plane_b']][l].reshape(S, -1)
+        cb = f.get('col_b', 0)
+        return orc.filt_ratio_gt(pa[:, ca:ca + 1], pb[:, cb:cb + 1], thr)
+    out = np.full(S, np.nan)
+    if not np.any(called):
+        return out
+    if op == L.F_CALLED_LT:
+        v = pa[called, ca]
+        out[np.nonzero(called)[0][v < thr]] = v[v < thr]
+        return out
+    if op == L.F_CALLED_SUM_LT:
+        v = pa[called, ca] + pa[called, f['col_a2']]
+        out[np.nonzero(called)[0][v < thr]] = v[v < thr]
+        return out
+    pb = planes[f['plane_b']][l].reshape(S, -1) if f.get('plane_b', -1) >= 0 else None
+    if op == L.F_CALLED_EQ:
+        v = pa[called, ca].astype(np.int64)
+        hit = v == pb[called, f.get('col_b', 0)]
+        out[np.nonzero(called)[0][hit]] = v[hit]
+        return out
+    if op == L.F_CALLED_SUM_EQ:
+        v = pa[called, ca].astype(np.int64) + pa[called, f['col_a2']]
+        hit = v == pb[called, f.get('col_b', 0)]
+        out[np.nonzero(called)[0][hit]] = v[hit]
+        return out
+    if op == L.F_CALLED_OUTSIDE_CI:
+        cis = np.array(['%d-%d,%d-%d' % tuple(r[:4]) for r in pb])
+        return orc.filt_gangstr_bad_ci(g, pa, cis)
+    if op == L.F_AD_SUPPORT_LT:
+        return orc.filt_popstr_require_support(g, pa, thr)
+    raise ValueError("unknown op %r" % op)
+
+
+class OracleCompute:
+    def locus_stats(self, hb, nalleles_thresh=0.01):
+        return stats_of(hb, hb.gt, nalleles_thresh)
+
+    def dumpstr_batch(self, hb, planes, filters, dp_plane, locus_spec, nalleles_thresh=0.01):
+        Lc, S = hb.n_loci, hb.n_samples
+        nf = len(filters)
+        info = collections.OrderedDict()
+        info['numcalls'] = np.zeros(S, dtype=np.int64)
+        info['totaldp'] = np.zeros(S, dtype=float)
+        names = ['f%d' % k for k in range(nf)]
+        for n in names:
+            info[n] = np.zeros(S, dtype=np.int64)
+        gout = hb.gt.copy()
+        mask = np.zeros((Lc, S), dtype=np.uint32)
+        dp_missing = np.zeros(S, dtype=np.int64)
+        for l in range(Lc):
+            pl = int(hb.locus_ploidy[l])
+            g = hb.gt[l][:, :pl]
+            outs = [(names[k], _eval_filter(filters[k], planes, l, g)) for k in range(nf)]
+            for k, (_, o) in enumerate(outs):
+                mask[l] |= (~np.isnan(o)).astype(np.uint32) << np.uint32(k)
+            mask[l] |= (~orc.get_called_samples(g)).astype(np.uint32) << np.uint32(31)
+            dp = None if dp_plane < 0 else planes[dp_plane][l].reshape(S, -1)[:, :1]
+            mg, _ = orc.apply_call_filters(g, outs, info, dp=dp)
+            gout[l][:, :pl] = mg
+        totaldp = info['totaldp'].copy()
+        dp_missing[np.isnan(totaldp)] = 1
+        totaldp[np.isnan(totaldp)] = 0
+        counters = np.stack([info['numcalls']] + [info[n] for n in names]).astype(np.int64)
+        ch = CallHost(gout, mask, counters, totaldp.astype(np.int64), dp_missing, np.zeros(4, dtype=np.int32))
+        st = stats_of(hb, gout, nalleles_thresh)
+        # locus filters (dumpSTR.py:917-973) from the same statistics
+        spec = dict(locus_spec)
+        ext = spec.pop('extern_bits', None)
+        n_ext = spec.pop('n_extern', 0)
+        ul = spec.get('use_length', False)
+        bits = np.zeros(Lc, dtype=np.uint32)
+        lc = np.zeros(L.TRK_LC_COLS, dtype=np.int64)
+        for l in range(Lc):
+            I, F = st.locus_int[0, l], st.locus_f64[0, l]
+            b = 0
+            if spec.get('min_callrate') is not None and F[L.LF_CALLRATE] < spec['min_callrate']:
+                b |= 1 << L.LOCF_CALLRATE
+            if spec.get('min_hwep') is not None:
+                if I[L.LI_HWE_STATUS_LEN if ul else L.LI_HWE_STATUS_STR] in (L.HWE_VALUE_ERROR, L.HWE_INDEX_ERROR):
+                    lc[L.LC_HWE_ERRORS] += 1
+                if F[L.LF_HWEP_LEN if ul else L.LF_HWEP_STR] < spec['min_hwep']:
+                    b |= 1 << L.LOCF_HWE
+            het = F[L.LF_HET_LEN if ul else L.LF_HET_STR]
+            if spec.get('min_het') is not None and het < spec['min_het']:
+                b |= 1 << L.LOCF_HETLOW
+            if spec.get('max_het') is not None and het > spec['max_het']:
+                b |= 1 << L.LOCF_HETHIGH
+            if ext is not None:
+                b |= (int(ext[l]) & ((1 << n_ext) - 1)) << L.LOCF_EXTERN0
+            for k in range(28):
+                if (b >> k) & 1:
+                    lc[L.LC_FILTER0 + k] += 1
+            if I[L.LI_N_CALLED] == 0:
+                b |= 1 << L.LOCF_NO_CALLS
+                lc[L.LC_NO_CALLS] += 1
+            if b == 0:
+                lc[L.LC_PASS] += 1
+                lc[L.LC_TOTALCALLS] += int(I[L.LI_N_CALLED])
+            bits[l] = b
+        return ch, st, bits, lc

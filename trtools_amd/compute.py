@@ -1,0 +1,81 @@
+"""The compute seam between the Python host layer and libtrk.
+
+``DeviceCompute`` uploads a HostBatch, runs the HIP kernels through the C ABI
+and brings the (small) per-locus / per-sample results back as numpy arrays.
+The host layer (tr_harmonizer / statSTR / dumpSTR mirrors) only talks to this
+interface; the tests substitute an oracle-backed object with the same methods
+to exercise the host logic on machines without a GPU -- the product itself has
+no CPU implementation."""
+import numpy as np
+
+
+class StatsHost:
+    """Host copies of trk_stats_out."""
+
+    def __init__(self, allele_count, locus_int, locus_f64):
+        self.allele_count = allele_count   # [G, sumA] int32
+        self.locus_int = locus_int         # [G, L, TRK_LI_COLS] int32
+        self.locus_f64 = locus_f64         # [G, L, TRK_LF_COLS] float64
+
+
+class CallHost:
+    def __init__(self, gt_out, mask, sample_counters, totaldp, dp_missing, error):
+        self.gt_out = gt_out
+        self.mask = mask
+        self.sample_counters = sample_counters
+        self.totaldp = totaldp
+        self.dp_missing = dp_missing
+        self.error = error
+
+
+class DeviceCompute:
+    def __init__(self, engine=None, device=0):
+        from .engine import Engine
+        self.eng = engine if engine is not None else Engine(device)
+
+    def _upload(self, hb):
+        return self.eng.make_batch(hb.gt, hb.allele_off, hb.len_class, hb.str_class, hb.len_class_value,
+                                   locus_ploidy=hb.locus_ploidy, group_bits=hb.group_bits,
+                                   n_groups=hb.n_groups, max_alleles=hb.max_alleles)
+
+    @staticmethod
+    def _free(*objs):
+        for o in objs:
+            if o is None:
+                continue
+            if hasattr(o, 'arrays'):
+                for a in o.arrays.values():
+                    a.free()
+            elif hasattr(o, 'free'):
+                o.free()
+
+    def locus_stats(self, hb, nalleles_thresh=0.01):
+        b = self._upload(hb)
+        res = self.eng.locus_stats(b, nalleles_thresh=nalleles_thresh)
+        out = StatsHost(res.allele_count.get(), res.locus_int.get(), res.locus_f64.get())
+        self._free(b, res.allele_count, res.locus_int, res.locus_f64)
+        return out
+
+    def dumpstr_batch(self, hb, planes, filters, dp_plane, locus_spec, nalleles_thresh=0.01):
+        """Call filters -> masked genotypes -> locus statistics -> locus filters, all on the device.
+        Returns (CallHost, StatsHost, locus_bits uint32[L], loc_counters int64[32])."""
+        eng = self.eng
+        b = self._upload(hb)
+        dplanes = [eng.upload(p) for p in planes]
+        call = eng.call_filters(b, dplanes, filters, dp_plane=dp_plane)
+        b2 = b.with_gt(call.gt_out)
+        st = eng.locus_stats(b2, nalleles_thresh=nalleles_thresh)
+        ext = None
+        spec = dict(locus_spec)
+        ext_host = spec.pop('extern_bits', None)
+        if ext_host is not None:
+            ext = eng.upload(np.ascontiguousarray(ext_host, dtype=np.uint32))
+        bits, counters = eng.locus_filters(hb.n_loci, st, extern_bits=ext, **spec)
+        ch = CallHost(call.gt_out.get(), call.filter_mask.get(), call.sample_counters.get(),
+                      call.sample_totaldp.get(), call.sample_dp_missing.get(), call.error.get())
+        sh = StatsHost(st.allele_count.get(), st.locus_int.get(), st.locus_f64.get())
+        out = (ch, sh, bits.get(), counters.get())
+        self._free(b, *dplanes, call.gt_out, call.filter_mask, call.sample_counters, call.sample_totaldp,
+                   call.sample_dp_missing, call.error, st.allele_count, st.locus_int, st.locus_f64,
+                   bits, counters, ext)
+        return out

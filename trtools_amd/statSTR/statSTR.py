@@ -1,0 +1,287 @@
+"""statSTR: per-locus statistics of a TR VCF -- same command line, same
+``main(args) -> int`` and same ``<out>.tab`` as the reference
+(trtools/statSTR/statSTR.py), with the per-locus loop (statSTR.py:575-639)
+replaced by batches of loci reduced on the GPU (trk_locus_stats).
+
+Host Python parses / harmonises records and formats text; every statistic in
+the table comes from the device (allele histograms + finaliser), for all sample
+groups of a batch in one kernel pass.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+from .. import __version__
+from .. import _lib as L
+from ..batch import pack_records
+from ..utils import common, utils
+from ..utils import tr_harmonizer as trh
+
+BATCH_CELLS = 1 << 24     # loci x samples per device batch
+MAX_GROUPS_PER_PASS = 8   # sample groups evaluated per kernel pass (trk.h)
+
+
+def GetHeader(header, sample_prefixes):
+    """Column names of one statistic (statSTR.py:82-102)."""
+    if len(sample_prefixes) == 0:
+        return [header]
+    return [header + "-" + sp for sp in sample_prefixes]
+
+
+def format_nan_precision(precision_format, val):
+    """statSTR.py:490-494."""
+    if np.isnan(val):
+        return "\tnan"
+    return precision_format.format(val)
+
+
+def getargs():  # pragma: no cover
+    parser = argparse.ArgumentParser(__doc__, formatter_class=utils.ArgumentDefaultsHelpFormatter)
+    io = parser.add_argument_group("Input/output")
+    io.add_argument("--vcf", help="Input STR VCF file", type=str, required=True)
+    io.add_argument("--out", help="Output file prefix. Use stdout to print file to standard output. In "
+                    "addition, if not stdout then timing diagnostics are print to stdout.", type=str,
+                    required=True)
+    io.add_argument("--vcftype", help="Options=%s" % [str(i) for i in trh.VcfTypes.__members__], type=str,
+                    default="auto")
+    io.add_argument("--precision", help="How much precision to use when printing decimals", type=int, default=3)
+    fg = parser.add_argument_group("Filtering group")
+    fg.add_argument("--samples", help="File containing list of samples to include. Or a comma-separated list "
+                    "of files to compute stats separate for each group of samples", type=str)
+    fg.add_argument("--sample-prefixes", help="Prefixes to name output for each samples group. By default "
+                    "uses 1,2,3 etc.", type=str)
+    fg.add_argument("--region", help="Restrict to the region chrom:start-end. Requires file to bgzipped and "
+                    "tabix indexed.", type=str)
+    fg.add_argument("--only-passing", help="Only process records  where FILTER==PASS", action="store_true")
+    name = "Stats group"
+    sg = parser.add_argument_group(name)
+    sg.add_argument("--thresh", help="Output threshold field (max allele size, used for GangSTR strinfo).",
+                    action="store_true")
+    sg.add_argument("--afreq", help="Output allele frequencies", action="store_true")
+    sg.add_argument("--acount", help="Output allele counts", action="store_true")
+    sg.add_argument("--nalleles", help="Output number of alleles with frequency exceeding a specified "
+                    "threshold", action="store_true")
+    sg.add_argument("--nalleles-thresh", help="The threshold for nalleles", type=float, default=0.01)
+    sg.add_argument("--hwep", help="Output HWE p-values per loci.", action="store_true")
+    sg.add_argument("--het", help="Output the heterozygosity of each locus.", action="store_true")
+    sg.add_argument("--entropy", help="Output the entropy of each locus.", action="store_true")
+    sg.add_argument("--mean", help="Output mean of the allele frequencies.", action="store_true")
+    sg.add_argument("--mode", help="Output mode of the allele frequencies.", action="store_true")
+    sg.add_argument("--var", help="Output variance of the allele frequencies.", action="store_true")
+    sg.add_argument("--numcalled", help="Output number of samples called.", action="store_true")
+    sg.add_argument("--use-length", help="Calculate per-locus stats (het, HWE) collapsing alleles by length. "
+                    "This is implicitly true for genotypers which only emit length based genotypes.",
+                    action="store_true")
+    pg = parser.add_argument_group("Plotting group")
+    pg.add_argument("--plot-afreq", help="Output allele frequency plot. Will only do for a maximum of 10 TRs.",
+                    action="store_true")
+    vg = parser.add_argument_group("Version")
+    vg.add_argument("--version", action="version", version='{version}'.format(version=__version__))
+    args = parser.parse_args()
+    chosen = {}
+    for grp in parser._action_groups:
+        if grp.title == name:
+            chosen = {a.dest: getattr(args, a.dest, None) for a in grp._group_actions}
+    if not any(chosen.values()):
+        common.WARNING("Error: Please use at least one of the flags in the Stats group. See statSTR --help "
+                       "for options.")
+        return None
+    return args
+
+
+class _RowFormatter:
+    """Text of one output row from the device results of one batch."""
+
+    def __init__(self, args, n_groups):
+        self.args = args
+        self.n_groups = n_groups
+        self.pfmt = "\t{:." + str(args.precision) + "}"
+
+    def afreq_text(self, hb, cnt, l, count):
+        """statSTR.py:158-172: 'allele:freq' joined in sorted key order."""
+        keys, ranks = hb.class_keys(l, self.args.use_length)
+        o, e = int(hb.allele_off[l]), int(hb.allele_off[l + 1])
+        cc = np.zeros(len(keys), dtype=np.int64)
+        np.add.at(cc, ranks, cnt[o:e])
+        present = [c for c in range(len(keys)) if cc[c]]
+        if not present:
+            return "."
+        if count:
+            return ",".join("%s:%i" % (keys[c], cc[c]) for c in present)
+        total = float(cc.sum())
+        return ",".join("%s:%.3f" % (keys[c], cc[c] / total) for c in present)
+
+    def row(self, hb, st, l, rec, trrec):
+        a = self.args
+        ul = a.use_length
+        G = self.n_groups
+        I, F = st.locus_int, st.locus_f64
+        out = [str(rec.CHROM), "\t", str(rec.POS), "\t", str(rec.POS + len(trrec.ref_allele))]
+        if a.thresh:
+            for g in range(G):
+                out.append(format_nan_precision(self.pfmt, F[g, l, L.LF_THRESH]))
+        if a.afreq:
+            for g in range(G):
+                out.append("\t" + self.afreq_text(hb, st.allele_count[g], l, False))
+        if a.acount:
+            for g in range(G):
+                out.append("\t" + self.afreq_text(hb, st.allele_count[g], l, True))
+        if a.nalleles:
+            for g in range(G):
+                out.append("\t" + str(int(I[g, l, L.LI_NALLELES_LEN if ul else L.LI_NALLELES_STR])))
+        if a.hwep:
+            for g in range(G):
+                status = I[g, l, L.LI_HWE_STATUS_LEN if ul else L.LI_HWE_STATUS_STR]
+                if status == L.HWE_VALUE_ERROR:
+                    raise ValueError("binomtest: n must be a positive integer (no fully called genotype at "
+                                     "{}:{})".format(rec.CHROM, rec.POS))
+                if status == L.HWE_INDEX_ERROR:
+                    raise IndexError("tuple index out of range (haploid genotypes at {}:{} have no HWE test)"
+                                     .format(rec.CHROM, rec.POS))
+                out.append(format_nan_precision(self.pfmt, F[g, l, L.LF_HWEP_LEN if ul else L.LF_HWEP_STR]))
+        if a.het:
+            for g in range(G):
+                out.append(format_nan_precision(self.pfmt, F[g, l, L.LF_HET_LEN if ul else L.LF_HET_STR]))
+        if a.entropy:
+            for g in range(G):
+                out.append(format_nan_precision(self.pfmt, F[g, l, L.LF_ENTROPY_LEN if ul else L.LF_ENTROPY_STR]))
+        for flag, col in ((a.mean, L.LF_MEAN), (a.mode, L.LF_MODE), (a.var, L.LF_VAR)):
+            if flag:
+                for g in range(G):
+                    out.append(format_nan_precision(self.pfmt, F[g, l, col]))
+        if a.numcalled:
+            for g in range(G):
+                out.append("\t" + str(int(I[g, l, L.LI_N_CALLED])))
+        out.append("\n")
+        return "".join(out)
+
+
+def _flush(batch, group_masks, fmt, outf, nalleles_thresh):
+    """Reduce one batch of (variant, TRRecord) pairs on the device and write its rows."""
+    from .. import runtime
+    if not batch:
+        return
+    recs = [t for _, t in batch]
+    compute = runtime.get_compute()
+    masks = group_masks if group_masks[0] is not None else None
+    if masks is None or len(masks) <= MAX_GROUPS_PER_PASS:
+        hb = pack_records(recs, masks)
+        st = compute.locus_stats(hb, nalleles_thresh=nalleles_thresh)
+    else:
+        # more than 8 strata: several passes over the same genotype tensor
+        parts = []
+        for i in range(0, len(masks), MAX_GROUPS_PER_PASS):
+            hb = pack_records(recs, masks[i:i + MAX_GROUPS_PER_PASS])
+            parts.append(compute.locus_stats(hb, nalleles_thresh=nalleles_thresh))
+        from ..compute import StatsHost
+        st = StatsHost(np.concatenate([p.allele_count for p in parts]),
+                       np.concatenate([p.locus_int for p in parts]),
+                       np.concatenate([p.locus_f64 for p in parts]))
+    if np.any(st.locus_int[:, :, L.LI_N_BAD]):
+        l = int(np.argwhere(st.locus_int[:, :, L.LI_N_BAD])[0][1])
+        raise IndexError("genotype index out of range at {}:{}".format(batch[l][0].CHROM, batch[l][0].POS))
+    for l, (rec, trrec) in enumerate(batch):
+        outf.write(fmt.row(hb, st, l, rec, trrec))
+
+
+def main(args):
+    if not os.path.exists(args.vcf):
+        common.WARNING("Error: %s does not exist" % args.vcf)
+        return 1
+    if not os.path.exists(os.path.dirname(os.path.abspath(args.out))):
+        common.WARNING("Error: The directory which contains the output location {} does"
+                       " not exist".format(args.out))
+        return 1
+    if os.path.isdir(args.out) and args.out.endswith(os.sep):
+        common.WARNING("Error: The output location {} is a directory".format(args.out))
+        return 1
+
+    invcf = utils.LoadSingleReader(args.vcf, checkgz=args.region is not None)
+    if invcf is None:
+        return 1
+    vcftype = trh.VcfTypes[args.vcftype] if args.vcftype != 'auto' else trh.InferVCFType(invcf)
+
+    # sample groups (statSTR.py:520-542)
+    sample_prefixes, group_masks = [], [None]
+    if args.samples:
+        all_samples = np.array(invcf.samples)
+        sfiles = args.samples.split(",")
+        sample_prefixes = args.sample_prefixes.split(",") if args.sample_prefixes \
+            else [str(i) for i in range(1, len(sfiles) + 1)]
+        if len(sfiles) != len(sample_prefixes):
+            common.WARNING("--sample-prefixes must be same length as --samples")
+            return 1
+        group_masks = []
+        for sf in sfiles:
+            with open(sf, "r") as fh:
+                wanted = np.array([line.strip() for line in fh.readlines()])
+            mask = np.isin(all_samples, wanted)
+            if not np.any(mask):
+                common.WARNING("No samples from {} found in the VCF file".format(sf))
+                return 1
+            group_masks.append(mask)
+
+    header = ["chrom", "start", "end"]
+    for flag, name in ((args.thresh, "thresh"), (args.afreq, "afreq"), (args.acount, "acount"),
+                       (args.nalleles, "nalleles"), (args.hwep, "hwep"), (args.het, "het"),
+                       (args.entropy, "entropy"), (args.mean, "mean"), (args.mode, "mode"),
+                       (args.var, "var"), (args.numcalled, "numcalled")):
+        if flag:
+            header.extend(GetHeader(name, sample_prefixes))
+
+    fmt = _RowFormatter(args, len(group_masks))
+    outf = None
+    try:
+        if args.out == "stdout":
+            if args.plot_afreq:
+                common.WARNING("Cannot use --out stdout when generating plots")
+                return 1
+            outf = sys.stdout
+        else:
+            outf = open(args.out + ".tab", "w")
+        outf.write("\t".join(header) + "\n")
+        region = invcf(args.region) if args.region else invcf
+        n_samples = max(len(invcf.samples), 1)
+        batch_loci = max(1, min(4096, BATCH_CELLS // n_samples))
+        start_time = time.time()
+        nrecords = 0
+        num_plotted = 0
+        batch = []
+        for record in region:
+            nrecords += 1
+            trrecord = trh.HarmonizeRecord(vcftype, record)
+            if args.only_passing and record.FILTER is not None:
+                continue
+            if args.plot_afreq and num_plotted <= 10:
+                from .plots import PlotAlleleFreqs
+                PlotAlleleFreqs(trrecord, args.out, sample_indexes=group_masks, sampleprefixes=sample_prefixes)
+                num_plotted += 1
+            batch.append((record, trrecord))
+            if len(batch) >= batch_loci:
+                _flush(batch, group_masks, fmt, outf, args.nalleles_thresh)
+                batch = []
+                outf.flush()
+                if args.out != "stdout":
+                    print("Finished {} records, time/record={:.5}sec".format(
+                        nrecords, (time.time() - start_time) / nrecords), flush=True, end="\r")
+        _flush(batch, group_masks, fmt, outf, args.nalleles_thresh)
+    finally:
+        if outf is not None and args.out != "stdout":
+            outf.close()
+    if args.out != "stdout":
+        print("\nDone", flush=True)
+    return 0
+
+
+def run():  # pragma: no cover
+    args = getargs()
+    if args is None:
+        sys.exit(1)
+    sys.exit(main(args))
+
+
+if __name__ == "__main__":  # pragma: no cover
+    run()
