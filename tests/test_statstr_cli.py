@@ -34,9 +34,16 @@ def _run(tmp_path, compute, golden, **kw):
         assert statSTR.main(_args(out, **kw)) == 0
     finally:
         runtime.set_compute(old)
-    got = open(out + '.tab').read()
-    want = open(os.path.join(DATA, golden)).read()
-    assert got == want
+    got = open(out + '.tab').read().split('\n')
+    want = open(os.path.join(DATA, golden)).read().split('\n')
+    diffs = [(i, g, w) for i, (g, w) in enumerate(zip(got, want)) if g != w]
+    msg = ''
+    if diffs:
+        i, g, w = diffs[0]
+        gc, wc = g.split('\t'), w.split('\t')
+        cols = [(j, a, b) for j, (a, b) in enumerate(zip(gc, wc)) if a != b]
+        msg = "%d differing lines; first at line %d, columns %s" % (len(diffs), i, cols[:4])
+    assert not diffs and len(got) == len(want), msg
 
 
 def _strat():
