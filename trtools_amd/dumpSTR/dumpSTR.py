@@ -1,0 +1,680 @@
+"""dumpSTR: call-level and locus-level filtering of TR VCFs -- same command line,
+``main(args) -> int``, ``.vcf`` / ``.samplog.tab`` / ``.loclog.tab`` outputs as
+the reference (trtools/dumpSTR/dumpSTR.py), with the per-record loop
+(dumpSTR.py:1270-1338) replaced by batches of loci processed on the GPU:
+
+  k_call_filter   every call-level predicate, the FORMAT/FILTER bit mask, the masked
+                  genotypes and the per-sample counters of ``sample_info``
+  k_locus_count / k_locus_finalize   allele histograms + statistics of the masked genotypes
+  k_locus_filter  locus filter decisions and the ``loc_info`` counters
+
+Host Python parses / harmonises records, pre-parses string FORMAT fields,
+evaluates the string-only locus filters (HRUN, BED regions) and writes text.
+"""
+import argparse
+import collections
+import itertools
+import os
+import subprocess as sp
+import sys
+
+import numpy as np
+
+from .. import __version__
+from .. import _lib as L
+from .. import vcfio
+from ..batch import pack_records, stack_plane
+from ..utils import common, utils
+from ..utils import tr_harmonizer as trh
+from . import filters
+
+_NOCALL_INT_FORMAT_VAL = -2147483648
+BATCH_CELLS = 1 << 23
+
+
+def MakeWriter(outfile, invcf, command):
+    """VCF writer whose header records the dumpSTR command (dumpSTR.py:24-46)."""
+    invcf.add_to_header("##command-DumpSTR=" + command)
+    return vcfio.VCFWriter(outfile, invcf)
+
+
+# ---------------------------------------------------------------------------
+# argument validation (dumpSTR.py:48-521), table driven
+# ---------------------------------------------------------------------------
+# (argument, rule, needed FORMAT fields); rule: '01' value in [0,1], '>=0' non-negative
+_CALLER_RULES = collections.OrderedDict([
+    ('hipstr', (trh.VcfTypes.hipstr, "HipSTR", [
+        ('hipstr_max_call_flank_indel', '01', ('DP', 'DFLANKINDEL')), ('hipstr_max_call_stutter', '01', ('DP', 'DSTUTTER')),
+        ('hipstr_min_supp_reads', '>=0', ('ALLREADS', 'GB')), ('hipstr_min_call_DP', '>=0', ('DP',)),
+        ('hipstr_max_call_DP', '>=0', ('DP',)), ('hipstr_min_call_Q', '01', ('Q',))],
+        [('hipstr_min_call_DP', 'hipstr_max_call_DP')])),
+    ('longtr', (trh.VcfTypes.longtr, "LongTR", [
+        ('longtr_max_call_flank_indel', '01', ('DP', 'DFLANKINDEL')), ('longtr_min_supp_reads', '>=0', ('ALLREADS', 'GB')),
+        ('longtr_min_call_DP', '>=0', ('DP',)), ('longtr_max_call_DP', '>=0', ('DP',)),
+        ('longtr_min_call_Q', '01', ('Q',))],
+        [('longtr_min_call_DP', 'longtr_max_call_DP')])),
+    ('gangstr', (trh.VcfTypes.gangstr, "GangSTR", [
+        ('gangstr_min_call_DP', '>=0', ('DP',)), ('gangstr_max_call_DP', '>=0', ('DP',)),
+        ('gangstr_min_call_Q', '01', ('Q',)), ('gangstr_expansion_prob_het', '01', ('QEXP',)),
+        ('gangstr_expansion_prob_hom', '01', ('QEXP',)), ('gangstr_expansion_prob_total', '01', ('QEXP',))],
+        [('gangstr_min_call_DP', 'gangstr_max_call_DP')])),
+    ('advntr', (trh.VcfTypes.advntr, "adVNTR", [
+        ('advntr_min_call_DP', '>=0', ('DP',)), ('advntr_max_call_DP', '>=0', ('DP',)),
+        ('advntr_min_spanning', '>=0 ', ('SR',)), ('advntr_min_flanking', '>=0 ', ('FR',)),
+        ('advntr_min_ML', '>=0', ('ML',))],
+        [('advntr_min_call_DP', 'advntr_max_call_DP')])),
+    ('eh', (trh.VcfTypes.eh, "ExpansionHunter", [
+        ('eh_min_ADFL', '>=0', ('ADFL',)), ('eh_min_ADIR', '>=0', ('ADIR',)), ('eh_min_ADSP', '>=0', ('ADSP',)),
+        ('eh_min_call_LC', '>=0', ('LC',)), ('eh_max_call_LC', '>=0', ('LC',))],
+        [('eh_min_call_LC', 'eh_max_call_LC')])),
+    ('popstr', (trh.VcfTypes.popstr, "popSTR", [
+        ('popstr_min_call_DP', '>=0', ('DP',)), ('popstr_max_call_DP', '>=0', ('DP',)),
+        ('popstr_require_support', '>=0', ('AD',))],
+        [('popstr_min_call_DP', 'popstr_max_call_DP')])),
+])
+_GANGSTR_FLAGS = ('gangstr_filter_span_only', 'gangstr_filter_spanbound_only', 'gangstr_filter_badCI')
+_BEAGLE_NAMES = {"adVNTR": "AdVNTR"}
+
+
+def _flag(arg):
+    """argparse destination -> command-line spelling (case of DP/Q/... preserved)."""
+    return "--" + arg.replace("_", "-")
+
+
+def CheckLocusFilters(args, vcftype, is_beagle):
+    """dumpSTR.py:48-99."""
+    if args.min_locus_callrate is not None and is_beagle:
+        common.WARNING("--min-locus-callrate cannot be applied to Beagle imputed files at the moment "
+                       "as there are currently no call level Beagle filters")
+        return False
+    for arg in ('min_locus_hwep', 'min_locus_het', 'max_locus_het'):
+        v = getattr(args, arg)
+        if v is not None and (v < 0 or v > 1):
+            common.WARNING("Invalid {}. Must be between 0 and 1".format(_flag(arg)))
+            return False
+    if args.min_locus_het is not None and args.max_locus_het is not None \
+            and args.max_locus_het < args.min_locus_het:
+        common.WARNING("Cannot have --max-locus-het less than --min-locus-het")
+        return False
+    hip_like = vcftype in (trh.VcfTypes.hipstr, trh.VcfTypes.longtr)
+    if args.use_length and not hip_like:
+        common.WARNING("--use-length is only meaningful for HipSTR or LongTR, which report sequence level "
+                       "differences.")
+    if args.filter_hrun and not hip_like:
+        common.WARNING("--filter-hrun only relevant to HipSTR or LongTR files. This filter will have no effect.")
+    if args.filter_regions is not None and args.filter_regions_names is not None:
+        if len(args.filter_regions_names.split(",")) != len(args.filter_regions.split(",")):
+            common.WARNING("Length of --filter-regions-names must match --filter-regions.")
+            return False
+    return True
+
+
+def _check_caller(format_fields, args, rules, pairs):
+    for arg, rule, fields in rules:
+        v = getattr(args, arg, None)
+        if v is None:
+            continue
+        if rule == '01' and (v < 0 or v > 1):
+            common.WARNING("{} must be between 0 and 1".format(_flag(arg)))
+            return False
+        if rule.startswith('>=0') and v < 0:
+            common.WARNING("{} must be {}".format(_flag(arg), ">=0" if rule.endswith(' ') else ">= 0"))
+            return False
+        for f in fields:
+            assert f in format_fields
+    for lo, hi in pairs:
+        a, b = getattr(args, lo, None), getattr(args, hi, None)
+        if a is not None and b is not None and b < a:
+            common.WARNING("{} must be >= {}".format(_flag(hi), _flag(lo)))
+            return False
+    return True
+
+
+def CheckFilters(format_fields, args, vcftype, is_beagle):
+    """Validate the user's filters against the VCF's caller (dumpSTR.py:396-521)."""
+    if not CheckLocusFilters(args, vcftype, is_beagle):
+        return False
+    for _, (vt, label, rules, pairs) in _CALLER_RULES.items():
+        used = any(getattr(args, arg, None) is not None for arg, _, _ in rules)
+        if label == "GangSTR":
+            used = used or any(getattr(args, f, False) for f in _GANGSTR_FLAGS)
+        if not used:
+            continue
+        if vcftype != vt:
+            common.WARNING("{} options can only be applied to {} VCFs".format(label, label))
+            return False
+        if is_beagle and label != "popSTR":
+            common.WARNING("{} call level filters cannot be applied to Beagle VCFs".format(
+                _BEAGLE_NAMES.get(label, label)))
+            return False
+        if not _check_caller(format_fields, args, rules, pairs):
+            return False
+    return True
+
+
+# ---------------------------------------------------------------------------
+# logs (dumpSTR.py:523-588)
+# ---------------------------------------------------------------------------
+
+def WriteLocLog(loc_info, fname):
+    keys = list(loc_info.keys())
+    assert "totalcalls" in keys and "PASS" in keys
+    keys.remove("totalcalls")
+    callrate = 0 if loc_info["PASS"] == 0 else float(loc_info["totalcalls"]) / loc_info["PASS"]
+    with open(fname, "w") as f:
+        f.write("MeanSamplesPerPassingSTR\t%s\n" % callrate)
+        for k in keys:
+            f.write("FILTER:%s\t%s\n" % (k, loc_info[k]))
+    return True
+
+
+def WriteSampLog(sample_info, sample_names, fname):
+    header = ["sample"] + list(sample_info.keys())
+    header[header.index('totaldp')] = 'meanDP'
+    with open(fname, "w") as f:
+        f.write("\t".join(header) + "\n")
+        for i, s in enumerate(sample_names):
+            numcalls = sample_info["numcalls"][i]
+            cols = [s, str(numcalls)]
+            cols.append(str(sample_info["totaldp"][i] * 1.0 / numcalls) if numcalls > 0 else "0")
+            for counts in itertools.islice(sample_info.values(), 2, None):
+                cols.append(str(counts[i]))
+            f.write("\t".join(cols) + "\n")
+
+
+def GetAllCallFilters(call_filters):
+    return [f.name for f in call_filters]
+
+
+# ---------------------------------------------------------------------------
+# filter lists (dumpSTR.py:777-915)
+# ---------------------------------------------------------------------------
+
+def BuildCallFilters(args):
+    """Call filters in the reference's fixed order (= samplog column order)."""
+    F = filters
+    out = []
+
+    def add(arg, make):
+        v = getattr(args, arg, None)
+        if v is not None and v is not False:
+            out.append(make(v))
+    add('hipstr_max_call_flank_indel', lambda v: F.HipSTRCallFlankIndels(v))
+    add('hipstr_max_call_stutter', lambda v: F.HipSTRCallStutter(v))
+    add('hipstr_min_supp_reads', lambda v: F.HipSTRCallMinSuppReads(v))
+    add('hipstr_min_call_DP', lambda v: F.CallFilterMinValue("HipSTRCallMinDepth", "DP", v))
+    add('hipstr_max_call_DP', lambda v: F.CallFilterMaxValue("HipSTRCallMaxDepth", "DP", v))
+    add('hipstr_min_call_Q', lambda v: F.CallFilterMinValue("HipSTRCallMinQ", "Q", v))
+    add('longtr_max_call_flank_indel', lambda v: F.HipSTRCallFlankIndels(v, rename="LongTRCallFlankIndels"))
+    add('longtr_min_supp_reads', lambda v: F.HipSTRCallMinSuppReads(v, rename="LongTRMinSuppReads"))
+    add('longtr_min_call_DP', lambda v: F.CallFilterMinValue("LongTRCallMinDepth", "DP", v))
+    add('longtr_max_call_DP', lambda v: F.CallFilterMaxValue("LongTRCallMaxDepth", "DP", v))
+    add('longtr_min_call_Q', lambda v: F.CallFilterMinValue("LongTRCallMinQ", "Q", v))
+    add('gangstr_min_call_DP', lambda v: F.CallFilterMinValue("GangSTRCallMinDepth", "DP", v))
+    add('gangstr_max_call_DP', lambda v: F.CallFilterMaxValue("GangSTRCallMaxDepth", "DP", v))
+    add('gangstr_min_call_Q', lambda v: F.CallFilterMinValue("GangSTRCallMinQ", "Q", v))
+    add('gangstr_expansion_prob_het', lambda v: F.GangSTRCallExpansionProbHet(v))
+    add('gangstr_expansion_prob_hom', lambda v: F.GangSTRCallExpansionProbHom(v))
+    add('gangstr_expansion_prob_total', lambda v: F.GangSTRCallExpansionProbTotal(v))
+    add('gangstr_filter_span_only', lambda v: F.GangSTRCallSpanOnly())
+    add('gangstr_filter_spanbound_only', lambda v: F.GangSTRCallSpanBoundOnly())
+    add('gangstr_filter_badCI', lambda v: F.GangSTRCallBadCI())
+    add('advntr_min_call_DP', lambda v: F.CallFilterMinValue("AdVNTRCallMinDepth", "DP", v))
+    add('advntr_max_call_DP', lambda v: F.CallFilterMaxValue("AdVNTRCallMaxDepth", "DP", v))
+    add('advntr_min_spanning', lambda v: F.CallFilterMinValue("AdVNTRCallMinSpanning", "SR", v))
+    add('advntr_min_flanking', lambda v: F.CallFilterMinValue("AdVNTRCallMinFlanking", "FR", v))
+    add('advntr_min_ML', lambda v: F.CallFilterMinValue("AdVNTRCallMinML", "ML", v))
+    add('eh_min_call_LC', lambda v: F.CallFilterMinValue("EHCallMinDepth", "LC", v))
+    add('eh_max_call_LC', lambda v: F.CallFilterMaxValue("EHCallMaxDepth", "LC", v))
+    add('eh_min_ADFL', lambda v: F.CallFilterMinValue("EHCallMinADFL", "ADFL", v))
+    add('eh_min_ADIR', lambda v: F.CallFilterMinValue("EHCallMinADFL", "ADIR", v))
+    add('eh_min_ADSP', lambda v: F.CallFilterMinValue("EHCallMinADSP", "ADSP", v))
+    add('popstr_min_call_DP', lambda v: F.CallFilterMinValue("PopSTRMinCallDepth", "DP", v))
+    add('popstr_max_call_DP', lambda v: F.CallFilterMaxValue("PopSTRMaxCallDepth", "DP", v))
+    add('popstr_require_support', lambda v: F.PopSTRCallRequireSupport(v))
+    return out
+
+
+def BuildLocusFilters(args):
+    """Locus filters in the reference's order (dumpSTR.py:875-915)."""
+    out = []
+    if args.min_locus_callrate is not None:
+        out.append(filters.Filter_MinLocusCallrate(args.min_locus_callrate))
+    if args.min_locus_hwep is not None:
+        out.append(filters.Filter_MinLocusHWEP(args.min_locus_hwep, args.use_length))
+    if args.min_locus_het is not None:
+        out.append(filters.Filter_MinLocusHet(args.min_locus_het, args.use_length))
+    if args.max_locus_het is not None:
+        out.append(filters.Filter_MaxLocusHet(args.max_locus_het, args.use_length))
+    if args.filter_hrun:
+        out.append(filters.Filter_LocusHrun())
+    if args.filter_regions is not None:
+        files = args.filter_regions.split(",")
+        names = args.filter_regions_names.split(",") if args.filter_regions_names is not None \
+            else ['FILTER' + str(i) for i in range(len(files))]
+        for nm, fn in zip(names, files):
+            rf = filters.create_region_filter(nm, fn)
+            if rf is None:
+                raise ValueError('Could not load regions file: {}'.format(fn))
+            out.append(rf)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# batch evaluation
+# ---------------------------------------------------------------------------
+
+class _Planes:
+    """FORMAT planes a set of call filters needs, stacked over a batch of records."""
+
+    def __init__(self, records, call_filters, want_dp=True):
+        self.keys, builders = [], {}
+        for f in call_filters:
+            for key, build in f.planes():
+                if key not in builders:
+                    builders[key] = build
+                    self.keys.append(key)
+        self.dp_key = None
+        if want_dp and records:
+            fmt = records[0].format
+            for cand in ('DP', 'LC'):          # dumpSTR.py:688-695
+                if cand in fmt:
+                    self.dp_key = cand
+                    if cand not in builders:
+                        builders[cand] = filters._field(cand)[1]
+                        self.keys.append(cand)
+                    break
+        self.index = {k: i for i, k in enumerate(self.keys)}
+        self.arrays = []
+        for k in self.keys:
+            per = [np.asarray(builders[k](r)) for r in records]
+            per = [a.reshape(a.shape[0], -1) for a in per]
+            kind = per[0].dtype.kind if per else 'i'
+            if kind == 'f':
+                self.arrays.append(stack_plane([a.astype(np.float32) for a in per], np.float32))
+            elif kind in 'iu':
+                self.arrays.append(stack_plane([a.astype(np.int32) for a in per], np.int32))
+            else:
+                raise ValueError("Found an unexpected format dtype for format field " + k)
+        if self.dp_key is not None and self.arrays[self.index[self.dp_key]].dtype != np.int32:
+            raise NotImplementedError("non-integer DP/LC FORMAT fields are not supported by the device path")
+
+    def get(self, key):
+        return self.arrays[self.index[key]]
+
+    @property
+    def dp_plane(self):
+        return -1 if self.dp_key is None else self.index[self.dp_key]
+
+
+def _filter_values(f, planes, hb, l):
+    """float64[S]: what the reference writes after '<filter name>_' for a fired call."""
+    if isinstance(f, filters.PopSTRCallRequireSupport):
+        ad = planes.get('AD')[l]
+        out = np.full(ad.shape[0], np.nan)
+        rows = np.arange(ad.shape[0])
+        for j in range(int(hb.locus_ploidy[l])):          # last offending haplotype wins
+            idx = hb.gt[l][:, j].astype(int)
+            idx = np.where(idx < 0, idx + ad.shape[1], idx)
+            ok = (idx >= 0) & (idx < ad.shape[1])
+            v = np.where(ok, ad[rows, np.clip(idx, 0, ad.shape[1] - 1)], f.threshold)
+            hit = ok & (v < f.threshold)
+            out[hit] = v[hit]
+        return out
+    return f.value(planes.get, l)
+
+
+def evaluate_call_filters(records, call_filters):
+    """Device evaluation of call filters on records; returns (mask [L,S], values[k][l] float64[S])."""
+    from .. import runtime
+    hb = pack_records(records)
+    planes = _Planes(records, call_filters, want_dp=False)
+    specs = [f.spec(planes.index) for f in call_filters]
+    ch, _, _, _ = runtime.get_compute().dumpstr_batch(hb, planes.arrays, specs, -1, {})
+    values = [[_filter_values(f, planes, hb, l) for l in range(hb.n_loci)] for f in call_filters]
+    return ch.mask, values
+
+
+def _call_filter_text(mask_row, names, values_l):
+    """FORMAT/FILTER strings of one record (dumpSTR.py:648-683)."""
+    out = []
+    for s, m in enumerate(mask_row):
+        m = int(m)
+        if m & L.TRK_MASK_NOCALL:
+            out.append('NOCALL')
+        elif m == 0:
+            out.append('PASS')
+        else:
+            out.append(','.join('%s_%s' % (names[k], '%g' % values_l[k][s])
+                                for k in range(len(names)) if (m >> k) & 1))
+    return out
+
+
+def _null_filtered(vcfrecord, filtered, ploidy):
+    """Mask the genotype and every other FORMAT field of filtered calls (dumpSTR.py:721-746)."""
+    g = np.array(vcfrecord.genotype.array())
+    g[filtered, :ploidy] = -1
+    g[filtered, -1] = 0
+    vcfrecord.set_gt_array(g)
+    for field in list(vcfrecord.FORMAT):
+        if field in ('GT', 'FILTER'):
+            continue
+        vals = np.array(vcfrecord.format(field))
+        kind = vals.dtype.kind
+        if kind in 'US':
+            vals = vals.astype(object)
+            vals[filtered] = '.'
+            vals = np.array([str(v) for v in vals])
+        elif kind == 'f':
+            vals[filtered] = np.nan
+        elif kind == 'i':
+            vals[filtered] = _NOCALL_INT_FORMAT_VAL
+        else:
+            raise ValueError("Found an unexpected format dtype for format field " + field)
+        vcfrecord.set_format(field, vals)
+
+
+class _Run:
+    """State of one dumpSTR run: filters, counters, writer."""
+
+    def __init__(self, args, invcf, call_filters, locus_filters, outvcf):
+        self.args, self.invcf, self.outvcf = args, invcf, outvcf
+        self.call_filters, self.locus_filters = call_filters, locus_filters
+        n = len(invcf.samples)
+        self.sample_names = np.array(invcf.samples)
+        self.sample_info = collections.OrderedDict()
+        self.sample_info['numcalls'] = np.zeros(n, dtype=int)
+        self.sample_info['totaldp'] = np.zeros(n, dtype=float)
+        for nm in GetAllCallFilters(call_filters):
+            self.sample_info[nm] = np.zeros(n, dtype=int)
+        self.loc_info = collections.OrderedDict([("totalcalls", 0), ("PASS", 0), ("NO_CALLS_REMAINING", 0)])
+        for f in locus_filters:
+            self.loc_info[f.filter_name()] = 0
+        # device bit of every locus filter: fixed bits for the statistic filters,
+        # extern bits (in order) for the string filters
+        self.host_filters = [f for f in locus_filters if f.bit is None]
+        self.bit_of = {}
+        for f in locus_filters:
+            self.bit_of[id(f)] = f.bit if f.bit is not None \
+                else L.LOCF_EXTERN0 + self.host_filters.index(f)
+        self.spec = dict(min_callrate=args.min_locus_callrate, min_hwep=args.min_locus_hwep,
+                         min_het=args.min_locus_het, max_het=args.max_locus_het,
+                         use_length=bool(args.use_length), n_extern=len(self.host_filters))
+
+    def process(self, records):
+        from .. import runtime
+        if not records:
+            return
+        args = self.args
+        hb = pack_records(records)
+        planes = _Planes(records, self.call_filters)
+        specs = [f.spec(planes.index) for f in self.call_filters]
+        ext = None
+        if self.host_filters:
+            ext = np.zeros(len(records), dtype=np.uint32)
+            for l, r in enumerate(records):
+                for j, f in enumerate(self.host_filters):
+                    if f(r) is not None:
+                        ext[l] |= np.uint32(1 << j)
+        spec = dict(self.spec, extern_bits=ext)
+        ch, st, bits, lc = runtime.get_compute().dumpstr_batch(hb, planes.arrays, specs, planes.dp_plane, spec)
+        if ch.error[0]:
+            l, s = int(ch.error[1]), int(ch.error[2])
+            bad = np.zeros(len(self.sample_names), dtype=bool)
+            bad[s] = True
+            raise ValueError("The following samples have calls but negative DP values at chromosome {} pos {}: {}"
+                             .format(records[l].chrom, records[l].pos, str(self.sample_names[bad])))
+        if lc[L.LC_HWE_ERRORS]:
+            raise ValueError("binomtest: n must be a positive integer (a locus has allele calls but no fully "
+                             "called genotype; the HWE filter cannot be evaluated)")
+        if np.any(st.locus_int[0, :, L.LI_N_BAD]):
+            raise IndexError("genotype index out of range for the alleles of a record")
+        # ---- counters (dumpSTR.py:661,686-713 and 946-971) ----
+        si = self.sample_info
+        si['numcalls'] += ch.sample_counters[0]
+        for k, f in enumerate(self.call_filters):
+            si[f.name] += ch.sample_counters[1 + k]
+        if planes.dp_plane >= 0:
+            si['totaldp'] += ch.totaldp
+            si['totaldp'][ch.dp_missing > 0] = np.nan
+        else:
+            si['totaldp'][:] = np.nan
+        li = self.loc_info
+        li['totalcalls'] += int(lc[L.LC_TOTALCALLS])
+        li['PASS'] += int(lc[L.LC_PASS])
+        li['NO_CALLS_REMAINING'] += int(lc[L.LC_NO_CALLS])
+        for f in self.locus_filters:
+            li[f.filter_name()] += int(lc[L.LC_FILTER0 + self.bit_of[id(f)]])
+        # ---- per-record text (host) ----
+        names = [f.name for f in self.call_filters]
+        ul = bool(args.use_length)
+        for l, r in enumerate(records):
+            v = r.vcfrecord
+            mrow = ch.mask[l]
+            fired = (mrow & np.uint32(0x7fffffff)) != 0
+            vals = [_filter_values(f, planes, hb, l) if np.any((mrow >> np.uint32(k)) & 1) else None
+                    for k, f in enumerate(self.call_filters)]
+            v.set_format('FILTER', np.array(_call_filter_text(mrow, names, vals)))
+            filtered = fired & ((mrow & np.uint32(L.TRK_MASK_NOCALL)) == 0)
+            if np.any(filtered):
+                _null_filtered(v, filtered, r.GetMaxPloidy())
+            b = int(bits[l])
+            fired_names = [f.filter_name() for f in self.locus_filters if (b >> self.bit_of[id(f)]) & 1]
+            if (b >> L.LOCF_NO_CALLS) & 1:
+                fired_names.append('NO_CALLS_REMAINING')
+            if not args.drop_filtered:
+                v.FILTER = ';'.join(fired_names) if fired_names else 'PASS'
+            if args.drop_filtered and fired_names:
+                continue
+            # INFO recompute (dumpSTR.py:1304-1336)
+            seq = r.full_alleles[0] if r.HasFullStringGenotypes() else r.ref_allele
+            v.INFO['HRUN'] = utils.GetHomopolymerRun(seq)
+            I, Fv = st.locus_int[0, l], st.locus_f64[0, l]
+            n_alt = len(r.alt_alleles)
+            if I[L.LI_N_CALLED] > 0:
+                status = I[L.LI_HWE_STATUS_LEN if ul else L.LI_HWE_STATUS_STR]
+                if status == L.HWE_INDEX_ERROR:
+                    raise IndexError("tuple index out of range (haploid genotypes have no HWE test)")
+                v.INFO['HET'] = float(Fv[L.LF_HET_LEN if ul else L.LF_HET_STR])
+                v.INFO['HWEP'] = float(Fv[L.LF_HWEP_LEN if ul else L.LF_HWEP_STR])
+                o = int(hb.allele_off[l])
+                ac = st.allele_count[0, o:o + n_alt + 1]
+                v.INFO['AC'] = 0 if n_alt == 0 else ",".join(str(int(x)) for x in ac[1:])
+                v.INFO['REFAC'] = int(ac[0])
+            else:
+                v.INFO['HET'] = -1
+                v.INFO['HWEP'] = -1
+                v.INFO['AC'] = 0 if n_alt == 0 else ','.join(['0'] * n_alt)
+                v.INFO['REFAC'] = 0
+            self.outvcf.write_record(v)
+
+
+def getargs():  # pragma: no cover
+    parser = argparse.ArgumentParser(__doc__, formatter_class=utils.ArgumentDefaultsHelpFormatter)
+    io = parser.add_argument_group("Input/output")
+    io.add_argument("--vcf", help="Input STR VCF file", type=str, required=True)
+    io.add_argument("--out", help="Prefix for output files", type=str, required=True)
+    io.add_argument("--zip", help="Produce a bgzipped and tabix indexed output VCF", action="store_true")
+    io.add_argument("--vcftype", help="Options=%s" % [str(i) for i in trh.VcfTypes.__members__], type=str,
+                    default="auto")
+    lg = parser.add_argument_group("Locus-level filters (tool agnostic)")
+    lg.add_argument("--min-locus-callrate", help="Minimum locus call rate", type=float)
+    lg.add_argument("--min-locus-hwep", help="Filter loci failing HWE at this p-value threshold", type=float)
+    lg.add_argument("--min-locus-het", help="Minimum locus heterozygosity", type=float)
+    lg.add_argument("--max-locus-het", help="Maximum locus heterozygosity", type=float)
+    lg.add_argument("--use-length", help="Calculate per-locus stats (het, HWE) collapsing alleles by length",
+                    action="store_true")
+    lg.add_argument("--filter-regions", help="Comma-separated list of BED files of regions to filter. Must be "
+                    "bgzipped and tabix indexed", type=str)
+    lg.add_argument("--filter-regions-names", help="Comma-separated list of filter names for each BED filter "
+                    "file", type=str)
+    lg.add_argument("--filter-hrun", help="Filter STRs with long homopolymer runs.", action="store_true")
+    lg.add_argument("--drop-filtered", help="Drop filtered records from output", action="store_true")
+    typed = {'01': float, '>=0': int, '>=0 ': int}
+    helps = {'max_call_flank_indel': "Maximum call flank indel rate", 'max_call_stutter': "Maximum call stutter rate",
+             'min_supp_reads': "Minimum supporting reads for each allele", 'min_call_DP': "Minimum call coverage",
+             'max_call_DP': "Maximum call coverage", 'min_call_Q': "Minimum call quality score",
+             'min_call_LC': "Minimum call coverage", 'max_call_LC': "Maximum call coverage"}
+    for key, (_, label, rules, _) in _CALLER_RULES.items():
+        grp = parser.add_argument_group("Call-level filters specific to %s output" % label)
+        for arg, rule, _ in rules:
+            t = float if arg.endswith('_ML') else typed[rule]
+            grp.add_argument(_flag(arg), help=helps.get(arg.split('_', 1)[1], arg.replace('_', ' ')), type=t)
+        if key == 'gangstr':
+            grp.add_argument("--gangstr-filter-span-only", help="Filter out all calls that only have spanning read "
+                             "support", action="store_true")
+            grp.add_argument("--gangstr-filter-spanbound-only", help="Filter out all reads except spanning and "
+                             "bounding", action="store_true")
+            grp.add_argument("--gangstr-filter-badCI", help="Filter regions where the ML estimate is not in the CI",
+                             action="store_true")
+    dg = parser.add_argument_group("Debugging parameters")
+    dg.add_argument("--num-records", help="Only process this many records", type=int)
+    dg.add_argument("--die-on-warning", help="Quit if a record can't be parsed", action="store_true")
+    dg.add_argument("--verbose", help="Print out extra info", action="store_true")
+    vg = parser.add_argument_group("Version")
+    vg.add_argument("--version", action="version", version='{version}'.format(version=__version__))
+    return parser.parse_args()
+
+
+_INFO_FIELDS = [  # (ID, Description, Type, Number)  dumpSTR.py:1130-1208
+    ('AC', 'Alternate allele counts', 'Integer', 'A'),
+    ('REFAC', 'Reference allele count', 'Integer', 1),
+    ('HET', 'Heterozygosity', 'Float', 1),
+    ('HWEP', 'HWE p-value for obs. vs. exp het rate', 'Float', 1),
+    ('HRUN', 'Length of longest homopolymer run', 'Integer', 1),
+]
+_FIELD_ISSUE = (
+    "Error: The {} field '{}' is present in the input VCF and doesn't have the expected Type and Number "
+    "so it can't be worked with. Please use 'bcftools annotate --rename-annots' or another equivalent tool to "
+    "rename or remove the field and then rerun dumpSTR. (--rename-annots is a flag available in the development "
+    "version of bcftools which can be installed from https://samtools.github.io/bcftools/) (You can pipe the "
+    "output of that command into dumpSTR if you wish to avoid writing another file to disk)")
+
+
+def main(args):
+    invcf = utils.LoadSingleReader(args.vcf, checkgz=False)
+    if invcf is None:
+        return 1
+    if not os.path.exists(os.path.dirname(os.path.abspath(args.out))):
+        common.WARNING("Error: The directory which contains the output location {} does"
+                       " not exist".format(args.out))
+        return 1
+    if os.path.isdir(args.out + ".vcf"):
+        common.WARNING("Error: The output location {} is a directory".format(args.out))
+        return 1
+    if args.out[-1] in {'.', '/'}:
+        common.WARNING("Output prefix must not end in '/' or '.'")
+        return 1
+
+    harmonizer = trh.TRRecordHarmonizer(invcf, args.vcftype)
+    is_beagle = harmonizer.IsBeagleVCF()
+    vcftype = harmonizer.vcftype
+
+    format_fields, info_fields, old_filters = {}, {}, {}
+    for h in invcf.header_iter():
+        kind = h['HeaderType']
+        if kind == 'INFO':
+            info_fields[h['ID']] = h
+        elif kind == 'FORMAT':
+            format_fields[h['ID']] = h
+        elif kind == 'FILTER':
+            old_filters[h['ID']] = h
+    if not CheckFilters(format_fields, args, vcftype, is_beagle):
+        return 1
+
+    issues = False
+    if 'FILTER' not in format_fields:
+        invcf.add_format_to_header({'ID': 'FILTER', 'Description': 'call-level filters that have been applied',
+                                    'Type': 'String', 'Number': 1})
+    elif format_fields['FILTER']['Type'] != 'String' or format_fields['FILTER']['Number'] != '1':
+        issues = True
+        common.WARNING(_FIELD_ISSUE.format('format', 'FILTER'))
+    for fid, desc, typ, num in _INFO_FIELDS:
+        if fid not in info_fields:
+            invcf.add_info_to_header({'ID': fid, 'Description': desc, 'Type': typ, 'Number': num})
+        elif info_fields[fid]['Type'] != typ or info_fields[fid]['Number'] != str(num):
+            issues = True
+            common.WARNING(_FIELD_ISSUE.format('info', fid))
+        elif info_fields[fid]['Description'] != desc:
+            common.WARNING("Overwriting the preexisting info {} field".format(fid))
+    if issues:
+        return 1
+
+    invcf.add_filter_to_header({
+        "ID": "NO_CALLS_REMAINING",
+        "Description": "All calls at this locus were already nocalls or were individually "
+                       "filtered before the locus level filters were applied."})
+    try:
+        locus_filters = BuildLocusFilters(args)
+    except ValueError:
+        return 1
+    for f in locus_filters:
+        if f.filter_name() not in old_filters:
+            invcf.add_filter_to_header({"ID": f.filter_name(), "Description": f.description()})
+        elif old_filters[f.filter_name()]['Description'] != f.description():
+            common.WARNING("Using locus level filter " + f.filter_name() + "which has the same name as a FILTER "
+                           "field that already exists in the input VCF. The filters DumpSTR writes to the output "
+                           "with this name will possibly have different meanings than the filters with the name "
+                           "that are already present.")
+    call_filters = BuildCallFilters(args)
+
+    suffix = '.vcf.gz' if args.zip else '.vcf'
+    outvcf = MakeWriter(args.out + suffix, invcf, " ".join(sys.argv))
+    if outvcf is None:
+        return 1
+    run = _Run(args, invcf, call_filters, locus_filters, outvcf)
+
+    n_samples = max(len(invcf.samples), 1)
+    batch_loci = max(1, min(2048, BATCH_CELLS // n_samples))
+    record_counter = 0
+    batch = []
+    while True:
+        try:
+            record = next(harmonizer)
+        except StopIteration:
+            break
+        except TypeError as te:
+            message = te.args[0]
+            if 'missing' in message and 'mandatory' in message:
+                common.WARNING("Could not parse VCF.\n" + message)
+                return 1
+            raise te
+        except ValueError as ve:
+            message = ve.args[0]
+            if 'properly formatted' in message:
+                common.WARNING("Could not parse VCF.\n" + message)
+                return 1
+            raise ve
+        if args.verbose:
+            common.MSG("Processing %s:%s" % (record.chrom, record.pos))
+        record_counter += 1
+        if args.num_records is not None and record_counter > args.num_records:
+            break
+        batch.append(record)
+        if len(batch) >= batch_loci:
+            run.process(batch)
+            batch = []
+    run.process(batch)
+
+    invcf.close()
+    outvcf.close()
+    WriteSampLog(run.sample_info, invcf.samples, args.out + ".samplog.tab")
+    WriteLocLog(run.loc_info, args.out + ".loclog.tab")
+    if args.zip:
+        try:
+            proc = sp.run(["tabix", args.out + suffix])
+            rc = proc.returncode
+        except FileNotFoundError:
+            rc = 127
+        if rc != 0:
+            common.WARNING("Tabix failed with returncode " + str(rc))
+            return 1
+    return 0
+
+
+def run():  # pragma: no cover
+    sys.exit(main(getargs()))
+
+
+if __name__ == "__main__":  # pragma: no cover
+    run()
