@@ -1,0 +1,215 @@
+/*
+ * ORACLE (C half) -- TEST INFRASTRUCTURE ONLY; never linked into libtrk.so.
+ *
+ * Plain-C restatement of the integer reductions of the TRTools per-locus hot
+ * path, written for speed on one host core so that the GPU results can be
+ * checked at sizes the numpy oracle cannot reach and so that bench.py has a
+ * compiled CPU baseline next to the numpy port.  Each function cites the
+ * reference lines (gymrek-lab/TRTools v6.1.0) whose arithmetic it follows.
+ * It is itself pinned against oracle/trtools_oracle.py (which is pinned against
+ * the real reference) by tests/test_oracle_c.py.
+ *
+ * Independent of csrc/: own histogram code, own binomial pmf (lgamma based) and
+ * tail summation.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* One locus.  gt: [S, P] allele indices (-1 missing, -2 padding); only the first
+ * `pl` columns belong to the record.  lc/sc: class rank of every allele index.
+ * cnt[A]  <- GetAlleleCounts(index=True)              tr_harmonizer.py:1420-1499
+ * out[0]  <- sum(GetGenotypeCounts().values())        tr_harmonizer.py:1326-1418 (rows without -1)
+ * out[1]  <- rows without -1 that hold a -2
+ * out[2]  <- num_hom by length class, out[3] by sequence class   utils.py:327-333
+ * out[4]  <- rows holding an index >= A                                               */
+void orc_locus_counts(const int16_t* gt, int S, int P, int pl, int A, const uint16_t* lc, const uint16_t* sc,
+                      int32_t* cnt, int32_t* out) {
+    memset(cnt, 0, sizeof(int32_t) * (size_t)A);
+    int32_t n_called = 0, n_low = 0, n_hl = 0, n_hs = 0, n_bad = 0;
+    for (int s = 0; s < S; ++s) {
+        const int16_t* row = gt + (size_t)s * P;
+        int miss = 0, low = 0, bad = 0;
+        for (int j = 0; j < pl; ++j) {
+            int a = row[j];
+            if (a == -1) miss = 1;
+            else if (a == -2) low = 1;
+            else if (a >= A) bad = 1;
+            else if (a >= 0) cnt[a]++;
+        }
+        n_bad += bad;
+        if (miss) continue;
+        n_called++;
+        if (low) { n_low++; continue; }
+        if (pl < 2 || bad) continue;
+        /* sorted tuple: gt[0] == gt[1]  <=>  the smallest class occurs at least twice */
+        int minl = 1 << 30, mins = 1 << 30, cl = 0, cs = 0;
+        for (int j = 0; j < pl; ++j) {
+            int l = lc[row[j]], q = sc[row[j]];
+            if (l < minl) { minl = l; cl = 1; } else if (l == minl) cl++;
+            if (q < mins) { mins = q; cs = 1; } else if (q == mins) cs++;
+        }
+        n_hl += cl >= 2;
+        n_hs += cs >= 2;
+    }
+    out[0] = n_called; out[1] = n_low; out[2] = n_hl; out[3] = n_hs; out[4] = n_bad;
+}
+
+static double orc_binom_pmf(int64_t k, int64_t n, double p) {
+    if (k < 0 || k > n) return 0.0;
+    if (p <= 0.0) return k == 0 ? 1.0 : 0.0;
+    if (p >= 1.0) return k == n ? 1.0 : 0.0;
+    double lg = lgamma((double)n + 1.0) - lgamma((double)k + 1.0) - lgamma((double)(n - k) + 1.0);
+    return exp(lg + (double)k * log(p) + (double)(n - k) * log1p(-p));
+}
+static double orc_lower(int64_t k, int64_t n, double p) {
+    if (k < 0) return 0.0;
+    double s = 0.0;
+    for (int64_t i = k; i >= 0; --i) {
+        double t = orc_binom_pmf(i, n, p);
+        s += t;
+        if (t <= s * 1e-17 && (double)i < p * (double)n) break;
+    }
+    return s;
+}
+static double orc_upper(int64_t k, int64_t n, double p) { /* sf(k) */
+    double s = 0.0;
+    for (int64_t i = k + 1; i <= n; ++i) {
+        double t = orc_binom_pmf(i, n, p);
+        s += t;
+        if (t <= s * 1e-17 && (double)i > p * (double)n) break;
+    }
+    return s;
+}
+static int64_t orc_bsearch(double sign, double d, int64_t lo, int64_t hi, int64_t n, double p) {
+    while (lo < hi) {
+        int64_t mid = lo + (hi - lo) / 2;
+        double v = sign * orc_binom_pmf(mid, n, p);
+        if (v < d) lo = mid + 1; else if (v > d) hi = mid - 1; else return mid;
+    }
+    return (sign * orc_binom_pmf(lo, n, p) <= d) ? lo : lo - 1;
+}
+/* scipy.stats.binomtest(k, n, p).pvalue, two-sided (call site utils.py:334-338).  lgamma-based pmf:
+ * ~1e-11 relative at n = 1e4, inside the 1e-9 bar. */
+double orc_binomtest(int64_t k, int64_t n, double p) {
+    double d = orc_binom_pmf(k, n, p), rerr = 1.0 + 1e-7, pn = p * (double)n, pv;
+    if ((double)k == pn) return 1.0;
+    if ((double)k < pn) {
+        int64_t ix = orc_bsearch(-1.0, -d * rerr, (int64_t)ceil(pn), n, n, p);
+        int64_t y = n - ix + (d * rerr == orc_binom_pmf(ix, n, p));
+        pv = orc_lower(k, n, p) + orc_upper(n - y, n, p);
+    } else {
+        int64_t ix = orc_bsearch(1.0, d * rerr, 0, (int64_t)floor(pn), n, p);
+        pv = orc_lower(ix, n, p) + orc_upper(k - 1, n, p);
+    }
+    return pv < 1.0 ? pv : 1.0;
+}
+
+/* Scalars of one allele-class mode from class counts cc[ncls] (ascending class = dict order).
+ * res: het, entropy, hwep (nan when undefined), status (0 ok, 1 nan, 2 ValueError, 3 IndexError).
+ * utils.py:118-212, 298-338 */
+void orc_mode_stats(const int32_t* cc, int ncls, int n_called, int n_low, int n_hom, int pl, double* res) {
+    double nanv = nan("");
+    res[0] = res[1] = res[2] = nanv; res[3] = 1;
+    int64_t total = 0;
+    for (int c = 0; c < ncls; ++c) total += cc[c];
+    if (total <= 0) return;
+    double ft = (double)total, fsum = 0.0, sq = 0.0;
+    for (int c = 0; c < ncls; ++c) { if (!cc[c]) continue; double f = cc[c] / ft; fsum += f; sq += f * f; }
+    if (!(fabs(1.0 - fsum) <= 0.001)) return;
+    res[0] = 1.0 - sq;
+    double ent = 0.0;
+    for (int c = 0; c < ncls; ++c) { if (!cc[c]) continue; double pk = (cc[c] / ft) / fsum; ent -= pk * log(pk); }
+    res[1] = ent / log(2.0) + 0.0;
+    if (n_called == 0) { res[3] = 2; return; }
+    if (pl < 2) { res[3] = 3; return; }
+    if (n_low > 0) { res[3] = 1; return; }
+    res[3] = 0;
+    res[2] = orc_binomtest(n_hom, n_called, sq);
+}
+
+/* mean / mode / variance / max by length (utils.py:215-296, tr_harmonizer.py:1542-1575) */
+void orc_length_stats(const int32_t* ccl, const double* cv, int ncls, double* res) {
+    double nanv = nan("");
+    res[0] = res[1] = res[2] = res[3] = nanv; /* thresh, mean, mode, var */
+    int64_t total = 0;
+    for (int c = 0; c < ncls; ++c) total += ccl[c];
+    if (total <= 0) return;
+    double ft = (double)total, fsum = 0.0;
+    int best = -1, bestn = 0;
+    for (int c = 0; c < ncls; ++c) {
+        if (!ccl[c]) continue;
+        fsum += ccl[c] / ft;
+        res[0] = cv[c];
+        if (ccl[c] > bestn) { bestn = ccl[c]; best = c; }
+    }
+    if (!(fabs(1.0 - fsum) <= 0.001)) return;
+    double m = 0.0, v = 0.0;
+    for (int c = 0; c < ncls; ++c) if (ccl[c]) m += cv[c] * (ccl[c] / ft);
+    for (int c = 0; c < ncls; ++c) if (ccl[c]) { double d = cv[c] - m; v += (ccl[c] / ft) * (d * d); }
+    res[1] = m; res[2] = cv[best]; res[3] = v;
+}
+
+/* Whole batch, P == 2 layout [L,S,P]: statSTR statistics of every locus (one group).
+ * out_i[l*8 ..]: n_called, n_low, hom_len, hom_str, n_bad, status_len, status_str, n_alleles
+ * out_f[l*10..]: thresh, mean, mode, var, het_len, het_str, ent_len, ent_str, hwep_len, hwep_str */
+void orc_batch_stats(const int16_t* gt, int L, int S, int P, const uint8_t* locus_ploidy, const int32_t* off,
+                     const uint16_t* lc, const uint16_t* sc, const double* cv, int32_t* cnt, int32_t* out_i,
+                     double* out_f) {
+    int maxA = 0;
+    for (int l = 0; l < L; ++l) if (off[l + 1] - off[l] > maxA) maxA = off[l + 1] - off[l];
+    int32_t* ccl = (int32_t*)malloc(sizeof(int32_t) * (size_t)(maxA + 1));
+    int32_t* ccs = (int32_t*)malloc(sizeof(int32_t) * (size_t)(maxA + 1));
+    for (int l = 0; l < L; ++l) {
+        int o = off[l], A = off[l + 1] - o, pl = locus_ploidy ? locus_ploidy[l] : P;
+        int32_t r[5];
+        orc_locus_counts(gt + (size_t)l * S * P, S, P, pl, A, lc + o, sc + o, cnt + o, r);
+        memset(ccl, 0, sizeof(int32_t) * (size_t)A);
+        memset(ccs, 0, sizeof(int32_t) * (size_t)A);
+        int64_t tot = 0;
+        for (int a = 0; a < A; ++a) { ccl[lc[o + a]] += cnt[o + a]; ccs[sc[o + a]] += cnt[o + a]; tot += cnt[o + a]; }
+        double ml[4], ms[4], ln[4];
+        orc_mode_stats(ccl, A, r[0], r[1], r[2], pl, ml);
+        orc_mode_stats(ccs, A, r[0], r[1], r[3], pl, ms);
+        orc_length_stats(ccl, cv + o, A, ln);
+        int32_t* oi = out_i + (size_t)l * 8;
+        oi[0] = r[0]; oi[1] = r[1]; oi[2] = r[2]; oi[3] = r[3]; oi[4] = r[4];
+        oi[5] = (int32_t)ml[3]; oi[6] = (int32_t)ms[3]; oi[7] = (int32_t)tot;
+        double* of = out_f + (size_t)l * 10;
+        of[0] = ln[0]; of[1] = ln[1]; of[2] = ln[2]; of[3] = ln[3];
+        of[4] = ml[0]; of[5] = ms[0]; of[6] = ml[1]; of[7] = ms[1]; of[8] = ml[2]; of[9] = ms[2];
+    }
+    free(ccl); free(ccs);
+}
+
+/* dumpSTR ApplyCallFilters (dumpSTR.py:613-774) for the threshold filters min-DP / max-DP / min-Q
+ * (CallFilterMinValue/MaxValue, filters.py:363-409) on a [L,S,2] batch.  thr_q is compared in float32.
+ * counters: [4][S] int64 numcalls, minDP, maxDP, minQ;  totaldp [S] int64;  dpmiss [S] int64 */
+void orc_call_filters_dpq(const int16_t* gt, const int32_t* dp, const float* q, int L, int S, double min_dp,
+                          double max_dp, double min_q, int16_t* gt_out, uint32_t* mask, int64_t* counters,
+                          int64_t* totaldp, int64_t* dpmiss) {
+    float tq = (float)min_q;
+    for (int l = 0; l < L; ++l)
+        for (int s = 0; s < S; ++s) {
+            size_t c = (size_t)l * S + s;
+            int a0 = gt[c * 2], a1 = gt[c * 2 + 1];
+            int called = !(a0 == -1 || a1 == -1);
+            uint32_t m = 0;
+            if ((double)dp[c] < min_dp) m |= 1u;
+            if ((double)dp[c] > max_dp) m |= 2u;
+            if (q[c] < tq) m |= 4u;
+            if (called) {
+                if (m & 1u) counters[1 * (size_t)S + s]++;
+                if (m & 2u) counters[2 * (size_t)S + s]++;
+                if (m & 4u) counters[3 * (size_t)S + s]++;
+            } else m |= 0x80000000u;
+            mask[c] = m;
+            gt_out[c * 2] = (int16_t)a0; gt_out[c * 2 + 1] = (int16_t)a1;
+            if (m == 0) {
+                counters[s]++;
+                if (dp[c] == INT32_MIN) dpmiss[s]++;
+                else if (dp[c] > 0) totaldp[s] += dp[c];
+            } else if (called) { gt_out[c * 2] = -1; gt_out[c * 2 + 1] = -1; }
+        }
+}

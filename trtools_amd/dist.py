@@ -1,0 +1,113 @@
+"""Multi-GPU sharding of the locus axis (one process per GPU).
+
+Loci are independent, so the call set is cut into contiguous locus shards, one
+per rank, and every rank runs the unchanged single-GPU path on its shard.  The
+only data that crosses ranks:
+
+* dumpSTR's ``sample_info`` (per-sample numcalls / totaldp / per-filter counts)
+  and ``loc_info`` counters are sums over ALL loci  -> all-reduce (sum);
+* the per-locus result rows (statSTR table rows, locus filter bits) are needed by
+  the rank that writes the output                          -> all-gather in rank order.
+
+``RcclComm`` runs both on device buffers through libtrk (RCCL over xGMI);
+``TorchComm`` does the same on host arrays through an initialised
+``torch.distributed`` group (gloo on CPU in the tests)."""
+import numpy as np
+
+
+def locus_shard(n_loci, rank, world):
+    """Contiguous, balanced shard [start, stop) of rank ``rank`` (output order = input order)."""
+    base, rem = divmod(int(n_loci), int(world))
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+class TorchComm:
+    """Host-array collectives over torch.distributed (any backend that handles CPU tensors)."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def allreduce_sum_i64(self, arr):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64).copy())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.numpy()
+
+    def allgather_bytes(self, arr):
+        """Gather variable-length uint8 payloads; returns the list in rank order."""
+        import torch
+        n = torch.tensor([arr.size], dtype=torch.int64)
+        sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
+        self.dist.all_gather(sizes, n)
+        m = int(max(int(s[0]) for s in sizes))
+        buf = torch.zeros(m, dtype=torch.uint8)
+        buf[:arr.size] = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint8).reshape(-1))
+        outs = [torch.zeros(m, dtype=torch.uint8) for _ in range(self.world)]
+        self.dist.all_gather(outs, buf)
+        return [o.numpy()[:int(s[0])] for o, s in zip(outs, sizes)]
+
+
+class RcclComm:
+    """Collectives on DeviceArrays through libtrk (trk_allreduce_sum_i64 / trk_allgather)."""
+
+    def __init__(self, engine, rank, world):
+        self.eng, self.rank, self.world = engine, rank, world
+
+    def allreduce_sum_i64(self, arr):
+        d = self.eng.upload(np.ascontiguousarray(arr, dtype=np.int64))
+        self.eng.allreduce_sum_i64(d)
+        out = d.get()
+        d.free()
+        return out
+
+    def allgather_bytes(self, arr):
+        sizes = self.allreduce_sum_i64(np.eye(self.world, dtype=np.int64)[self.rank] * arr.size)
+        m = int(sizes.max())
+        pad = np.zeros(m, dtype=np.uint8)
+        pad[:arr.size] = np.ascontiguousarray(arr, dtype=np.uint8).reshape(-1)
+        send = self.eng.upload(pad)
+        recv = self.eng.empty((self.world, m), np.uint8)
+        self.eng.allgather(send, recv)
+        out = recv.get()
+        send.free()
+        recv.free()
+        return [out[r, :int(sizes[r])] for r in range(self.world)]
+
+
+def reduce_sample_info(sample_info, comm):
+    """Cohort-wide ``sample_info`` from per-shard ones (dumpSTR.py:1251-1259 semantics:
+    integer counters add; totaldp adds and stays nan once any shard poisoned it)."""
+    keys = list(sample_info.keys())
+    ints = np.stack([np.asarray(sample_info[k], dtype=np.int64) for k in keys if k != 'totaldp'])
+    td = np.asarray(sample_info['totaldp'], dtype=float)
+    poisoned = np.isnan(td)
+    extra = np.stack([np.where(poisoned, 0, td).astype(np.int64), poisoned.astype(np.int64)])
+    red = comm.allreduce_sum_i64(np.concatenate([ints, extra]))
+    out = type(sample_info)()
+    it = iter(red[:len(keys) - 1])
+    for k in keys:
+        if k == 'totaldp':
+            v = red[-2].astype(float)
+            v[red[-1] > 0] = np.nan
+            out[k] = v
+        else:
+            out[k] = next(it)
+    return out
+
+
+def reduce_loc_info(loc_info, comm):
+    keys = list(loc_info.keys())
+    red = comm.allreduce_sum_i64(np.array([int(loc_info[k]) for k in keys], dtype=np.int64))
+    out = type(loc_info)()
+    for k, v in zip(keys, red):
+        out[k] = int(v)
+    return out
+
+
+def gather_rows(rows_bytes, comm):
+    """Concatenate per-shard output (bytes) in rank order == locus order."""
+    parts = comm.allgather_bytes(np.frombuffer(rows_bytes, dtype=np.uint8))
+    return b''.join(p.tobytes() for p in parts)
