@@ -81,6 +81,8 @@ struct trk_ctx {
     double prof_ms[TRK_K_COUNT] = {};
     int32_t* scratch = nullptr;  // finaliser class-count scratch
     size_t scratch_bytes = 0;
+    void* worklist = nullptr;    // deferred HWE tests (count + items)
+    size_t worklist_bytes = 0;
     ncclComm_t comm = nullptr;
     int rank = 0, n_ranks = 1;
 };
@@ -199,6 +201,7 @@ void trk_free(trk_ctx* ctx) {
         (void)hipEventDestroy(ctx->t_stop[i]);
     }
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->worklist) (void)hipFree(ctx->worklist);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -346,10 +349,20 @@ int trk_locus_stats(trk_ctx* ctx, const trk_batch* in, const trk_stats_params* p
         if (e != hipSuccess) return fail(ctx, TRK_ERR_NOMEM, "scratch hipMalloc(%zu): %s", need, hipGetErrorString(e));
         ctx->scratch_bytes = need;
     }
+    size_t wneed = trk::finalize_worklist_bytes((int64_t)G * in->n_loci);
+    if (wneed > ctx->worklist_bytes) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->worklist) (void)hipFree(ctx->worklist);
+        ctx->worklist = nullptr;
+        ctx->worklist_bytes = 0;
+        hipError_t e = hipMalloc(&ctx->worklist, wneed);
+        if (e != hipSuccess) return fail(ctx, TRK_ERR_NOMEM, "worklist hipMalloc(%zu): %s", wneed, hipGetErrorString(e));
+        ctx->worklist_bytes = wneed;
+    }
     {
         ProfScope ps(ctx, TRK_K_LOCUS_FINALIZE);
         HIPCHK(ctx, trk::launch_locus_finalize(*in, out->allele_count, out->locus_int, out->locus_f64, ctx->scratch,
-                                               prm ? prm->nalleles_thresh : 0.01, ctx->stream));
+                                               ctx->worklist, prm ? prm->nalleles_thresh : 0.01, ctx->stream));
     }
     return TRK_OK;
 }

@@ -182,24 +182,74 @@ TRK_HD inline int64_t binom_bsearch(double sign, double d, int64_t lo, int64_t h
     return lo - 1;
 }
 
-// scipy.stats.binomtest(k, n, p, alternative='two-sided').pvalue  (n >= 1, 0 <= k <= n)
-TRK_HD inline double binomtest_two_sided(int64_t k, int64_t n, double p) {
-    double d = binom_pmf(k, n, p);
-    const double rerr = 1.0 + 1e-7;
-    double pn = p * (double)n;
-    double kd = (double)k;
-    double pval;
-    if (kd == pn) {
-        pval = 1.0;
-    } else if (kd < pn) {
-        int64_t ix = binom_bsearch(-1.0, -d * rerr, (int64_t)ceil(pn), n, n, p);
-        int64_t y = n - ix + ((d * rerr == binom_pmf(ix, n, p)) ? 1 : 0);
-        pval = binom_lower_tail(k, n, p) + binom_upper_tail(n - y, n, p);
-    } else {
-        int64_t ix = binom_bsearch(1.0, d * rerr, 0, (int64_t)floor(pn), n, p);
-        int64_t y = ix + 1;
-        pval = binom_lower_tail(y - 1, n, p) + binom_upper_tail(k - 1, n, p);
+// sum_{i<=kl} pmf(i) + sum_{i>ku} pmf(i): both far tails advanced in ONE loop (two
+// independent recurrences per iteration: twice the ILP, half the trip count, and --
+// on the GPU -- one code path for every lane whatever side of the mean k lies on).
+TRK_HD inline double binom_two_tails(int64_t kl, int64_t ku, int64_t n, double p) {
+    const double q = 1.0 - p;
+    double sum_l = 0.0, sum_u = 0.0, t_l = 0.0, t_u = 0.0;
+    bool run_l = false, run_u = false;
+    // lower tail: edge cases of binom_lower_tail
+    if (kl >= n) sum_l = 1.0;
+    else if (kl >= 0) {
+        if (p <= 0.0) sum_l = 1.0;
+        else if (q > 0.0) { t_l = binom_pmf(kl, n, p); sum_l = t_l; run_l = kl > 0; }
     }
+    // upper tail: edge cases of binom_upper_tail
+    if (ku < 0) sum_u = 1.0;
+    else if (ku < n) {
+        if (q <= 0.0) sum_u = 1.0;
+        else if (p > 0.0) { t_u = binom_pmf(ku + 1, n, p); sum_u = t_u; run_u = ku + 1 < n; }
+    }
+    const double r_l = (p > 0.0) ? q / p : 0.0;
+    const double r_u = (q > 0.0) ? p / q : 0.0;
+    double di = (double)kl, ddl = (double)(n - kl + 1);
+    double dn = (double)(n - ku - 1), ddu = (double)(ku + 2);
+    while (run_l | run_u) {
+        if (run_l) {
+            const double ratio = di * fast_rcp(ddl) * r_l;
+            t_l *= ratio;
+            sum_l += t_l;
+            di -= 1.0;
+            ddl += 1.0;
+            run_l = !((ratio < 1.0 && t_l <= sum_l * 1e-18) || di <= 0.0);
+        }
+        if (run_u) {
+            const double ratio = dn * fast_rcp(ddu) * r_u;
+            t_u *= ratio;
+            sum_u += t_u;
+            dn -= 1.0;
+            ddu += 1.0;
+            run_u = !((ratio < 1.0 && t_u <= sum_u * 1e-18) || dn <= 0.0);
+        }
+    }
+    return sum_l + sum_u;
+}
+
+// scipy.stats.binomtest(k, n, p, alternative='two-sided').pvalue  (n >= 1, 0 <= k <= n)
+// One code path for k below and above the mean (the branch only selects the search
+// range, the sign of the searched function and which two tails are summed).
+TRK_HD inline double binomtest_two_sided(int64_t k, int64_t n, double p) {
+    const double d = binom_pmf(k, n, p);
+    const double rerr = 1.0 + 1e-7;
+    const double pn = p * (double)n;
+    const double kd = (double)k;
+    if (kd == pn) return 1.0;
+    const bool below = kd < pn;
+    const double sign = below ? -1.0 : 1.0;
+    const int64_t lo = below ? (int64_t)ceil(pn) : 0;
+    const int64_t hi = below ? n : (int64_t)floor(pn);
+    const int64_t ix = binom_bsearch(sign, sign * d * rerr, lo, hi, n, p);
+    int64_t kl, ku;
+    if (below) {
+        const int64_t y = n - ix + ((d * rerr == binom_pmf(ix, n, p)) ? 1 : 0);
+        kl = k;          // cdf(k)
+        ku = n - y;      // sf(n - y)
+    } else {
+        kl = ix;         // cdf(y - 1), y = ix + 1
+        ku = k - 1;      // sf(k - 1)
+    }
+    const double pval = binom_two_tails(kl, ku, n, p);
     return pval < 1.0 ? pval : 1.0;
 }
 

@@ -12,7 +12,9 @@ namespace trk {
 hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* allele_count, int32_t* locus_int,
                               int n_cu, hipStream_t stream);
 hipError_t launch_locus_finalize(const trk_batch& b, const int32_t* allele_count, int32_t* locus_int,
-                                 double* locus_f64, int32_t* scratch, double nalleles_thresh, hipStream_t stream);
+                                 double* locus_f64, int32_t* scratch, void* worklist, double nalleles_thresh,
+                                 hipStream_t stream);
+size_t finalize_worklist_bytes(int64_t n_group_loci);
 hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n_planes,
                               const trk_call_filter* filters, int n_filters, int dp_plane, const trk_call_out& out,
                               int n_cu, hipStream_t stream);

@@ -27,6 +27,7 @@
 //   k_synth            counter-based synthetic genotype / FORMAT generator.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/trk.h"
 #include "trk_binom.h"
@@ -476,8 +477,18 @@ __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_fast(
 // k_locus_finalize : one thread per (group, locus)
 // ---------------------------------------------------------------------------
 struct ModeStats {
-    double het, entropy, hwep;
+    double het, entropy, hwep, sq;
     int nalleles, status;
+};
+
+// one deferred HWE test (k_hwe_test): homogeneous work items, so the lanes of a wave
+// differ only in loop trip counts, and loci whose two allele partitions coincide are
+// tested once
+struct HweItem {
+    int32_t slot;   // g * L + l
+    int32_t modes;  // bit 0: write HWEP_LEN, bit 1: write HWEP_STR
+    int32_t k, n;
+    double p;
 };
 
 // class counts are in cc[0..ncls), ascending class order == the dict order the
@@ -487,6 +498,7 @@ __device__ __forceinline__ void mode_stats(const int32_t* cc, int cstride, int n
                                            ModeStats& o) {
     const double nan = __builtin_nan("");
     o.het = o.entropy = o.hwep = nan;
+    o.sq = 0.0;
     o.nalleles = 0;
     o.status = TRK_HWE_NAN;
     if (total <= 0) return;  // ValidateAlleleFreqs: empty dict  (utils.py:139)
@@ -522,8 +534,8 @@ __device__ __forceinline__ void mode_stats(const int32_t* cc, int cstride, int n
     } else if (n_low > 0) {
         o.status = TRK_HWE_NAN;  // a -2 / ',' haplotype is not in allele_freqs
     } else {
-        o.status = TRK_HWE_OK;
-        o.hwep = trkmath::binomtest_two_sided(n_hom, n_called, sq);
+        o.status = TRK_HWE_OK;  // p-value computed by k_hwe_test
+        o.sq = sq;
     }
 }
 
@@ -535,7 +547,9 @@ __global__ __launch_bounds__(FIN_THREADS) void k_locus_finalize(trk_batch b, con
                                                                int32_t* __restrict__ locus_int,
                                                                double* __restrict__ locus_f64,
                                                                int32_t* __restrict__ scratch,
-                                                               double nalleles_thresh, int max_alleles) {
+                                                               double nalleles_thresh, int max_alleles,
+                                                               unsigned int* __restrict__ hwe_count,
+                                                               HweItem* __restrict__ hwe_items) {
     extern __shared__ uint32_t fin_lds[];
     const int L = b.n_loci;
     const int G = b.group_bits ? b.n_groups : 1;
@@ -589,6 +603,17 @@ __global__ __launch_bounds__(FIN_THREADS) void k_locus_finalize(trk_batch b, con
         ms = ml;
     else
         mode_stats(ccs, cs, A, total, nalleles_thresh, n_called, n_low, li[TRK_LI_N_HOM_STR], pl, ms);
+    {
+        const int32_t slot = (int32_t)((int64_t)g * L + l);
+        if (ml.status == TRK_HWE_OK) {
+            HweItem it = {slot, same ? 3 : 1, li[TRK_LI_N_HOM_LEN], n_called, ml.sq};
+            hwe_items[atomicAdd(hwe_count, 1u)] = it;
+        }
+        if (!same && ms.status == TRK_HWE_OK) {
+            HweItem it = {slot, 2, li[TRK_LI_N_HOM_STR], n_called, ms.sq};
+            hwe_items[atomicAdd(hwe_count, 1u)] = it;
+        }
+    }
     li[TRK_LI_HWE_STATUS_LEN] = ml.status;
     li[TRK_LI_HWE_STATUS_STR] = ms.status;
     li[TRK_LI_NALLELES_LEN] = ml.nalleles;
@@ -643,6 +668,18 @@ __global__ __launch_bounds__(FIN_THREADS) void k_locus_finalize(trk_batch b, con
     int ns = li[TRK_LI_N_SAMPLES];
     lf[TRK_LF_CALLRATE] = ns > 0 ? (double)n_called / (double)ns : nan;  // tr_harmonizer.py:946
     lf[11] = 0.0;
+}
+
+__global__ __launch_bounds__(FIN_THREADS) void k_hwe_test(const unsigned int* __restrict__ hwe_count,
+                                                         const HweItem* __restrict__ items,
+                                                         double* __restrict__ locus_f64) {
+    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= *hwe_count) return;
+    const HweItem it = items[t];
+    const double pv = trkmath::binomtest_two_sided(it.k, it.n, it.p);  // utils.py:334-338
+    double* lf = locus_f64 + (int64_t)it.slot * TRK_LF_COLS;
+    if (it.modes & 1) lf[TRK_LF_HWEP_LEN] = pv;
+    if (it.modes & 2) lf[TRK_LF_HWEP_STR] = pv;
 }
 
 // ---------------------------------------------------------------------------
@@ -1193,22 +1230,33 @@ hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* alle
 }
 
 hipError_t launch_locus_finalize(const trk_batch& b, const int32_t* allele_count, int32_t* locus_int,
-                                 double* locus_f64, int32_t* scratch, double nalleles_thresh, hipStream_t stream) {
+                                 double* locus_f64, int32_t* scratch, void* worklist, double nalleles_thresh,
+                                 hipStream_t stream) {
     const int G = b.group_bits ? b.n_groups : 1;
     int64_t n = (int64_t)G * b.n_loci;
     if (n == 0) return hipSuccess;
     int blocks = (int)((n + FIN_THREADS - 1) / FIN_THREADS);
     const int maxA = b.max_alleles;
+    unsigned int* count = reinterpret_cast<unsigned int*>(worklist);
+    HweItem* items = reinterpret_cast<HweItem*>(reinterpret_cast<char*>(worklist) + 16);
+    hipError_t e = hipMemsetAsync(count, 0, 16, stream);
+    if (e != hipSuccess) return e;
     if (maxA > 0 && maxA <= 96) {
         size_t lds = (size_t)2 * maxA * FIN_THREADS * sizeof(int32_t);
         hipLaunchKernelGGL(k_locus_finalize<true>, dim3(blocks), dim3(FIN_THREADS), lds, stream, b, allele_count,
-                           locus_int, locus_f64, scratch, nalleles_thresh, maxA);
+                           locus_int, locus_f64, scratch, nalleles_thresh, maxA, count, items);
     } else {
         hipLaunchKernelGGL(k_locus_finalize<false>, dim3(blocks), dim3(FIN_THREADS), 0, stream, b, allele_count,
-                           locus_int, locus_f64, scratch, nalleles_thresh, maxA);
+                           locus_int, locus_f64, scratch, nalleles_thresh, maxA, count, items);
     }
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    int tblocks = (int)((2 * n + FIN_THREADS - 1) / FIN_THREADS);
+    hipLaunchKernelGGL(k_hwe_test, dim3(tblocks), dim3(FIN_THREADS), 0, stream, count, items, locus_f64);
     return hipGetLastError();
 }
+
+size_t finalize_worklist_bytes(int64_t n_group_loci) { return 16 + (size_t)(2 * n_group_loci) * sizeof(HweItem); }
 
 hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n_planes,
                               const trk_call_filter* filters, int n_filters, int dp_plane, const trk_call_out& out,
