@@ -307,6 +307,14 @@ typedef struct {
 int trk_synth_fill(trk_ctx* ctx, const trk_synth_spec* spec, int16_t* gt, int32_t* dp,
                    float* q, int32_t* dstutter, int32_t* dflankindel);
 
+/* GangSTR-shaped FORMAT planes for an already generated (gt, dp) pair: QEXP float32 [L,S,3],
+ * REPCN int32 [L,S,2], RC int32 [L,S,4] (enclosing, spanning, FRR, bounding; sums to DP) and
+ * REPCI int32 [L,S,4] (lo0,hi0,lo1,hi1).  allele_repcn: device [sumA] integer repeat count
+ * of every allele.  numpy twin: trtools_amd/synth.py::gangstr_planes_numpy.               */
+int trk_synth_fill_gangstr(trk_ctx* ctx, const trk_synth_spec* spec, const int16_t* gt, const int32_t* dp,
+                           const int32_t* allele_repcn, float* qexp, int32_t* repcn, int32_t* rc,
+                           int32_t* repci);
+
 #ifdef __cplusplus
 }
 #endif

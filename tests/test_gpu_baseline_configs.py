@@ -1,0 +1,168 @@
+"""GPU parity at the BASELINE.json configuration sizes.
+
+configs[1]  statSTR full stats, synthetic HipSTR-shape, 10k loci x 1k samples:
+            EVERY locus against the C half of the oracle + the fast kernel against the
+            general kernel (two independent device code paths) + sampled loci against the
+            numpy oracle.
+configs[2]  dumpSTR call + locus filters, synthetic GangSTR-shape, 50k loci x 5k samples:
+            size-independent invariants over the whole batch + sampled loci against the
+            numpy oracle (rows regenerated on the host by the generator's numpy twin).
+configs[3]  (100k x 10k) is what bench.py runs, with the same spot checks.
+"""
+import collections
+import math
+
+import numpy as np
+import pytest
+
+from helpers import close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from trtools_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def test_config1_statstr_10k_x_1k(eng):
+    from oracle import oracle_c, trtools_oracle as orc
+    from trtools_amd import _lib as L
+    from trtools_amd.synth import SynthBatch
+    Lc, S = 10000, 1000
+    sb = SynthBatch(eng, Lc, S, seed=20260928 + 1, planes=())
+    res = eng.locus_stats(sb.batch, nalleles_thresh=0.01)
+    cnt, li, lf = res.allele_count.get()[0], res.locus_int.get()[0], res.locus_f64.get()[0]
+    off, lc, sc, cv = sb.tables
+    gt = sb.dev['gt'].get()
+    # (1) every locus vs the C oracle
+    ccnt, oi, of = oracle_c.batch_stats(gt, None, off, lc, sc, cv)
+    assert np.array_equal(cnt, ccnt)
+    assert np.array_equal(li[:, L.LI_N_CALLED], oi[:, 0]) and np.array_equal(li[:, L.LI_N_LOWPLOIDY], oi[:, 1])
+    assert np.array_equal(li[:, L.LI_N_HOM_LEN], oi[:, 2]) and np.array_equal(li[:, L.LI_N_HOM_STR], oi[:, 3])
+    assert np.array_equal(li[:, L.LI_N_ALLELES], oi[:, 7]) and not li[:, L.LI_N_BAD].any()
+    assert np.array_equal(li[:, L.LI_HWE_STATUS_LEN], oi[:, 5]) and np.array_equal(li[:, L.LI_HWE_STATUS_STR], oi[:, 6])
+    cols = [L.LF_THRESH, L.LF_MEAN, L.LF_MODE, L.LF_VAR, L.LF_HET_LEN, L.LF_HET_STR, L.LF_ENTROPY_LEN,
+            L.LF_ENTROPY_STR, L.LF_HWEP_LEN, L.LF_HWEP_STR]
+    for j, c in enumerate(cols):
+        a, b = lf[:, c], of[:, j]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), c
+        ok = ~np.isnan(a)
+        assert np.all(np.abs(a[ok] - b[ok]) <= 1e-9 * np.maximum(1.0, np.abs(b[ok])) + 1e-300), c
+    # (2) fast kernel vs general kernel (one all-samples group forces the general path)
+    b2 = eng.make_batch(sb.dev['gt'], sb.d_off, lc, sc, cv, group_bits=np.ones(S, dtype=np.uint8), n_groups=1,
+                        max_alleles=int(np.max(np.diff(off))))
+    res2 = eng.locus_stats(b2, nalleles_thresh=0.01)
+    assert np.array_equal(res2.allele_count.get()[0], cnt)
+    li2 = res2.locus_int.get()[0]
+    assert np.array_equal(li2, li)
+    lf2 = res2.locus_f64.get()[0]
+    assert np.array_equal(np.nan_to_num(lf2, nan=-7.0), np.nan_to_num(lf, nan=-7.0))
+    # (3) sampled loci vs the numpy oracle (incl. nalleles, call rate)
+    for l in np.random.default_rng(0).choice(Lc, size=60, replace=False):
+        o = orc.locus_stats(gt[l], sb.loci.allele_lens[l], sb.loci.allele_strs[l], None, use_length=False)
+        assert li[l, L.LI_NALLELES_STR] == o['nalleles']
+        assert close(lf[l, L.LF_CALLRATE], orc.get_call_rate(gt[l]))
+        assert close(lf[l, L.LF_HET_STR], o['het']) and close(lf[l, L.LF_ENTROPY_STR], o['entropy'])
+        if o['hwep_status'] == orc.HWE_OK and not math.isnan(o['hwep']):
+            assert close(lf[l, L.LF_HWEP_STR], o['hwep'], 1e-9, 1e-300)
+
+
+def test_config2_dumpstr_gangstr_50k_x_5k(eng):
+    from oracle import trtools_oracle as orc
+    from trtools_amd import _lib as L
+    from trtools_amd.synth import SynthBatch
+    Lc, S = 50000, 5000
+    sb = SynthBatch(eng, Lc, S, seed=20260928 + 2, planes=('dp', 'q'), pure_repeats=True)
+    sb.add_gangstr_planes()
+    planes = [sb.dev['dp'], sb.dev['q'], sb.dev['qexp'], sb.dev['rc'], sb.dev['repcn'], sb.dev['repci']]
+    # BuildCallFilters order for GangSTR (dumpSTR.py:819-836)
+    filters = [dict(op=L.F_LT, plane_a=0, thr=10), dict(op=L.F_GT, plane_a=0, thr=60),
+               dict(op=L.F_LT, plane_a=1, thr=0.9),
+               dict(op=L.F_CALLED_LT, plane_a=2, col_a=1, thr=0.05),
+               dict(op=L.F_CALLED_LT, plane_a=2, col_a=2, thr=0.05),
+               dict(op=L.F_CALLED_SUM_LT, plane_a=2, col_a=1, col_a2=2, thr=0.2),
+               dict(op=L.F_CALLED_EQ, plane_a=3, col_a=1, plane_b=0, col_b=0),
+               dict(op=L.F_CALLED_SUM_EQ, plane_a=3, col_a=1, col_a2=3, plane_b=0, col_b=0),
+               dict(op=L.F_CALLED_OUTSIDE_CI, plane_a=4, plane_b=5)]
+    names = ['mindp', 'maxdp', 'minq', 'het', 'hom', 'total', 'span', 'spanbound', 'badci']
+    res = eng.call_filters(sb.batch, planes, filters, dp_plane=0)
+    b2 = sb.batch.with_gt(res.gt_out)
+    st = eng.locus_stats(b2)
+    bits, counters = eng.locus_filters(Lc, st, min_callrate=0.8, min_hwep=1e-3, min_het=0.05, max_het=0.9)
+    assert res.error.get()[0] == 0
+    cnts = res.sample_counters.get()
+    li = st.locus_int.get()[0]
+    lf = st.locus_f64.get()[0]
+    lc = counters.get()
+    bits_h = bits.get()
+    # ---- invariants over the whole batch ----
+    mask = res.filter_mask.get()
+    nocall = (mask >> np.uint32(31)).astype(bool)
+    assert int(cnts[0].sum()) == int((mask == 0).sum()) == int(li[:, L.LI_N_CALLED].sum())
+    assert np.array_equal(cnts[0], (mask == 0).sum(axis=0))
+    for k in range(len(filters)):
+        fired = ((mask >> np.uint32(k)) & np.uint32(1)).astype(bool) & ~nocall
+        assert np.array_equal(cnts[1 + k], fired.sum(axis=0)), names[k]
+        assert fired.any(), names[k]
+    del nocall
+    assert lc[L.LC_PASS] == int((bits_h == 0).sum())
+    assert lc[L.LC_TOTALCALLS] == int(li[bits_h == 0, L.LI_N_CALLED].sum())
+    assert lc[L.LC_NO_CALLS] == int((li[:, L.LI_N_CALLED] == 0).sum())
+    for b in range(4):
+        assert lc[L.LC_FILTER0 + b] == int(((bits_h >> np.uint32(b)) & 1).sum())
+    cnt = st.allele_count.get()[0]
+    off = sb.tables[0]
+    assert np.array_equal(np.add.reduceat(cnt.astype(np.int64), off[:-1]), li[:, L.LI_N_ALLELES])
+    # ---- sampled loci against the numpy oracle ----
+    idx = np.sort(np.random.default_rng(1).choice(Lc, size=24, replace=False))
+    h = sb.host_rows(idx)
+    g = sb.host_gangstr_rows(idx, h)
+    for r, l in enumerate(idx):
+        l = int(l)
+        gt = h['gt'][r]
+        d = h['dp'][r].reshape(-1, 1)
+        assert np.array_equal(sb.dev['gt'].get_rows(l, l + 1)[0], gt)
+        for key in ('qexp', 'rc', 'repcn', 'repci'):
+            dev_row = sb.dev[key].get_rows(l, l + 1)[0]
+            if key == 'qexp':
+                assert np.array_equal(dev_row.view(np.uint32), g[key][r].view(np.uint32)), key
+            else:
+                assert np.array_equal(dev_row, g[key][r]), key
+        rcs = np.array([','.join(map(str, x)) for x in g['rc'][r]])
+        cis = np.array(['%d-%d,%d-%d' % tuple(x) for x in g['repci'][r]])
+        outs = [('mindp', orc.filt_min_value(d, 10)), ('maxdp', orc.filt_max_value(d, 60)),
+                ('minq', orc.filt_min_value(h['q'][r].reshape(-1, 1), 0.9)),
+                ('het', orc.filt_gangstr_qexp(gt, g['qexp'][r], 0.05, 'het')),
+                ('hom', orc.filt_gangstr_qexp(gt, g['qexp'][r], 0.05, 'hom')),
+                ('total', orc.filt_gangstr_qexp(gt, g['qexp'][r], 0.2, 'total')),
+                ('span', orc.filt_gangstr_span_only(gt, rcs, d)),
+                ('spanbound', orc.filt_gangstr_spanbound_only(gt, rcs, d)),
+                ('badci', orc.filt_gangstr_bad_ci(gt, g['repcn'][r], cis))]
+        want_mask = np.zeros(S, dtype=np.uint32)
+        for k, (_, o) in enumerate(outs):
+            want_mask |= (~np.isnan(o)).astype(np.uint32) << np.uint32(k)
+        want_mask |= (~orc.get_called_samples(gt)).astype(np.uint32) << np.uint32(31)
+        assert np.array_equal(mask[l], want_mask), l
+        info = collections.OrderedDict([('numcalls', np.zeros(S, dtype=int)), ('totaldp', np.zeros(S))] +
+                                       [(n, np.zeros(S, dtype=int)) for n in names])
+        g2, _ = orc.apply_call_filters(gt, outs, info, dp=d)
+        assert np.array_equal(res.gt_out.get_rows(l, l + 1)[0], g2), l
+        lens, strs = sb.loci.allele_lens[l], sb.loci.allele_strs[l]
+        loc = collections.defaultdict(int)
+        try:
+            _, nm = orc.apply_locus_filters(g2, lens, strs, loc, use_length=False, min_callrate=0.8,
+                                            min_hwep=1e-3, min_het=0.05, max_het=0.9)
+        except ValueError:
+            continue
+        bitof = {'CALLRATE0.8': 0, 'HWE0.001': 1, 'HETLOW0.05': 2, 'HETHIGH0.9': 3, 'NO_CALLS_REMAINING': 31}
+        want = 0
+        for x in nm:
+            want |= 1 << bitof[x]
+        assert int(bits_h[l]) == want, (l, nm)
+        o = orc.locus_stats(g2, lens, strs, None, use_length=False)
+        assert np.array_equal(cnt[off[l]:off[l + 1]], o['index_counts'])
+        assert close(lf[l, L.LF_HET_STR], o['het'])

@@ -92,7 +92,7 @@ EXPORTS = [
     'trk_profile_enable', 'trk_profile_get', 'trk_profile_reset',
     'trk_locus_stats', 'trk_call_filters', 'trk_locus_filters',
     'trk_comm_unique_id', 'trk_comm_init', 'trk_allreduce_sum_i64', 'trk_allgather',
-    'trk_binomtest_two_sided', 'trk_binom_pmf', 'trk_synth_fill',
+    'trk_binomtest_two_sided', 'trk_binom_pmf', 'trk_synth_fill', 'trk_synth_fill_gangstr',
 ]
 
 _lib = None
@@ -147,5 +147,6 @@ def load():
     lib.trk_binom_pmf.argtypes = [i64, i64, dbl]
     lib.trk_binom_pmf.restype = dbl
     lib.trk_synth_fill.argtypes = [vp, P(SynthSpec), vp, vp, vp, vp, vp]
+    lib.trk_synth_fill_gangstr.argtypes = [vp, P(SynthSpec), vp, vp, vp, vp, vp, vp, vp]
     _lib = lib
     return lib

@@ -439,6 +439,16 @@ int trk_synth_fill(trk_ctx* ctx, const trk_synth_spec* spec, int16_t* gt, int32_
     return TRK_OK;
 }
 
+int trk_synth_fill_gangstr(trk_ctx* ctx, const trk_synth_spec* spec, const int16_t* gt, const int32_t* dp,
+                           const int32_t* allele_repcn, float* qexp, int32_t* repcn, int32_t* rc, int32_t* repci) {
+    if (!ctx || !spec || !gt || !dp || !allele_repcn || !qexp || !repcn || !rc || !repci)
+        return fail(ctx, TRK_ERR_ARG, "synth (gangstr) arguments are NULL");
+    (void)hipSetDevice(ctx->device);
+    ProfScope ps(ctx, TRK_K_SYNTH);
+    HIPCHK(ctx, trk::launch_synth_gangstr(*spec, gt, dp, allele_repcn, qexp, repcn, rc, repci, ctx->n_cu, ctx->stream));
+    return TRK_OK;
+}
+
 // ---- multi-GPU -------------------------------------------------------------------
 int trk_comm_unique_id(uint8_t id[128]) {
     std::string err;

@@ -23,5 +23,8 @@ hipError_t launch_locus_filter(int L, const int32_t* locus_int, const double* lo
                                hipStream_t stream);
 hipError_t launch_synth(const trk_synth_spec& sp, int16_t* gt, int32_t* dp, float* q, int32_t* dstutter,
                         int32_t* dflank, int n_cu, hipStream_t stream);
+hipError_t launch_synth_gangstr(const trk_synth_spec& sp, const int16_t* gt, const int32_t* dp,
+                                const int32_t* allele_repcn, float* qexp, int32_t* repcn, int32_t* rc,
+                                int32_t* repci, int n_cu, hipStream_t stream);
 }  // namespace trk
 #endif

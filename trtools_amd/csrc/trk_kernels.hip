@@ -1176,6 +1176,81 @@ __global__ __launch_bounds__(256) void k_synth(trk_synth_spec sp, int16_t* __res
     }
 }
 
+__global__ __launch_bounds__(256) void k_synth_gangstr(trk_synth_spec sp, const int16_t* __restrict__ gt,
+                                                      const int32_t* __restrict__ dp,
+                                                      const int32_t* __restrict__ allele_repcn,
+                                                      float* __restrict__ qexp, int32_t* __restrict__ repcn,
+                                                      int32_t* __restrict__ rc, int32_t* __restrict__ repci) {
+    const int64_t n = (int64_t)sp.n_loci * sp.n_samples;
+    for (int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; cell < n;
+         cell += (int64_t)gridDim.x * blockDim.x) {
+        const int l = (int)(cell / sp.n_samples);
+        const int s = (int)(cell - (int64_t)l * sp.n_samples);
+        const uint64_t gidx = (uint64_t)(sp.locus_base + l) * (uint64_t)sp.n_samples + (uint64_t)s;
+        const uint64_t x = sp.seed + 0x9E3779B97F4A7C15ull * (gidx + 1ull);
+        const uint64_t h4 = mix64(x + 0xA0761D6478BD642Full);
+        const uint64_t h5 = mix64(x + 0xE7037ED1A0B428DBull);
+        const int g0 = gt[cell * 2], g1 = gt[cell * 2 + 1];
+        const int off = sp.allele_off[l];
+        const bool nocall = g0 < 0 && g1 < 0;
+        if (nocall) {
+            for (int j = 0; j < 3; ++j) qexp[cell * 3 + j] = __builtin_nanf("");
+            for (int j = 0; j < 2; ++j) repcn[cell * 2 + j] = INT32_MIN;
+            for (int j = 0; j < 4; ++j) {
+                rc[cell * 4 + j] = INT32_MIN;
+                repci[cell * 4 + j] = INT32_MIN;
+            }
+            continue;
+        }
+        const int32_t d = dp[cell] < 0 ? 0 : dp[cell];
+        // QEXP: thousandths summing to 1000, or the -1 sentinel (1 in 16)
+        const uint32_t b0 = (uint32_t)(h4 & 0xff), b1 = (uint32_t)((h4 >> 8) & 0xff);
+        const int p0 = (int)(b0 * 1000u / 255u);
+        const int p1 = (int)(((uint32_t)(1000 - p0) * b1) >> 8);
+        const int p2 = 1000 - p0 - p1;
+        if (((h4 >> 16) & 0xf) == 0) {
+            for (int j = 0; j < 3; ++j) qexp[cell * 3 + j] = -1.0f;
+        } else {
+            qexp[cell * 3 + 0] = (float)p0 / 1000.0f;
+            qexp[cell * 3 + 1] = (float)p1 / 1000.0f;
+            qexp[cell * 3 + 2] = (float)p2 / 1000.0f;
+        }
+        // REPCN / REPCI
+        const uint32_t e = (uint32_t)((h4 >> 20) & 0xffff);
+        for (int j = 0; j < 2; ++j) {
+            const int g = j == 0 ? g0 : g1;
+            const int32_t r = g >= 0 ? allele_repcn[off + g] : INT32_MIN;
+            repcn[cell * 2 + j] = r;
+            if (g < 0) {
+                repci[cell * 4 + 2 * j] = INT32_MIN;
+                repci[cell * 4 + 2 * j + 1] = INT32_MIN;
+                continue;
+            }
+            const int lo_w = (int)((e >> (4 * j)) & 3u), hi_w = (int)((e >> (4 * j + 2)) & 3u);
+            int lo = r - lo_w, hi = r + hi_w;
+            if (lo < 0) lo = 0;  // 'lo-hi' text cannot carry a negative bound
+            if (((e >> (8 + j)) & 0x1f) == 0) lo = r + 1, hi = r + 2;  // ML estimate outside the CI (~3%)
+            repci[cell * 4 + 2 * j] = lo;
+            repci[cell * 4 + 2 * j + 1] = hi;
+        }
+        // RC: enclosing, spanning, FRR, bounding; sums to DP
+        const uint32_t c0 = (uint32_t)(h5 & 0xff), c1 = (uint32_t)((h5 >> 8) & 0xff), c2 = (uint32_t)((h5 >> 16) & 0xff);
+        int32_t encl = (int32_t)((c0 * (uint32_t)(d + 1)) >> 8);
+        int32_t rem = d - encl;
+        int32_t span = (int32_t)((c1 * (uint32_t)(rem + 1)) >> 8);
+        rem -= span;
+        int32_t frr = (int32_t)((c2 * (uint32_t)(rem + 1)) >> 8);
+        int32_t bound = rem - frr;
+        const uint32_t mode = (uint32_t)((h5 >> 24) & 0x3f);
+        if (mode == 0) { encl = 0; span = d; frr = 0; bound = 0; }            // spanning reads only
+        else if (mode == 1) { encl = 0; frr = 0; span = d / 2; bound = d - span; }  // spanning + bounding only
+        rc[cell * 4 + 0] = encl;
+        rc[cell * 4 + 1] = span;
+        rc[cell * 4 + 2] = frr;
+        rc[cell * 4 + 3] = bound;
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -1202,8 +1277,17 @@ hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* alle
             words = (words + 3) & ~3;
             size_t lds_fast = (size_t)COUNT_WAVES_PER_WG * words * sizeof(uint32_t);
             int wgs_fast = (b.n_loci + COUNT_WAVES_PER_WG - 1) / COUNT_WAVES_PER_WG;
-            hipLaunchKernelGGL(k_locus_count_fast<4>, dim3(wgs_fast), dim3(WAVE * COUNT_WAVES_PER_WG), lds_fast,
-                               stream, b, allele_count, locus_int, kshift, words);
+            int cnt_u = 4;
+            if (const char* e = getenv("TRK_CNT_U")) cnt_u = atoi(e);
+            if (cnt_u == 2)
+                hipLaunchKernelGGL(k_locus_count_fast<2>, dim3(wgs_fast), dim3(WAVE * COUNT_WAVES_PER_WG), lds_fast,
+                                   stream, b, allele_count, locus_int, kshift, words);
+            else if (cnt_u == 8)
+                hipLaunchKernelGGL(k_locus_count_fast<8>, dim3(wgs_fast), dim3(WAVE * COUNT_WAVES_PER_WG), lds_fast,
+                                   stream, b, allele_count, locus_int, kshift, words);
+            else
+                hipLaunchKernelGGL(k_locus_count_fast<4>, dim3(wgs_fast), dim3(WAVE * COUNT_WAVES_PER_WG), lds_fast,
+                                   stream, b, allele_count, locus_int, kshift, words);
             return hipGetLastError();
         }
     }
@@ -1297,7 +1381,22 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             else
                 a.slow_filter_mask |= 1u << k;
         }
-        hipLaunchKernelGGL(k_call_filter_fast<2>, dim3(gx, gy), dim3(CF_THREADS), lds, stream, a);
+        // experiment knobs (tools/perf_sweep.py): TRK_CF_LPB = loci per block, TRK_CF_U = loci in flight
+        if (const char* e = getenv("TRK_CF_LPB")) {
+            int v = atoi(e);
+            if (v > 0) {
+                a.loci_per_block = v;
+                gy = (L + v - 1) / v;
+            }
+        }
+        int cf_u = 2;
+        if (const char* e = getenv("TRK_CF_U")) cf_u = atoi(e);
+        if (cf_u == 1)
+            hipLaunchKernelGGL(k_call_filter_fast<1>, dim3(gx, gy), dim3(CF_THREADS), lds, stream, a);
+        else if (cf_u == 4)
+            hipLaunchKernelGGL(k_call_filter_fast<4>, dim3(gx, gy), dim3(CF_THREADS), lds, stream, a);
+        else
+            hipLaunchKernelGGL(k_call_filter_fast<2>, dim3(gx, gy), dim3(CF_THREADS), lds, stream, a);
     } else {
         hipLaunchKernelGGL(k_call_filter<false>, dim3(gx, gy), dim3(CF_THREADS), lds, stream, a);
     }
@@ -1320,6 +1419,18 @@ hipError_t launch_synth(const trk_synth_spec& sp, int16_t* gt, int32_t* dp, floa
     int64_t blocks = (n + 255) / 256;
     if (blocks > (int64_t)n_cu * 32) blocks = (int64_t)n_cu * 32;
     hipLaunchKernelGGL(k_synth, dim3((int)blocks), dim3(256), 0, stream, sp, gt, dp, q, dstutter, dflank);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth_gangstr(const trk_synth_spec& sp, const int16_t* gt, const int32_t* dp,
+                                const int32_t* allele_repcn, float* qexp, int32_t* repcn, int32_t* rc,
+                                int32_t* repci, int n_cu, hipStream_t stream) {
+    int64_t n = (int64_t)sp.n_loci * sp.n_samples;
+    if (n == 0) return hipSuccess;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > (int64_t)n_cu * 32) blocks = (int64_t)n_cu * 32;
+    hipLaunchKernelGGL(k_synth_gangstr, dim3((int)blocks), dim3(256), 0, stream, sp, gt, dp, allele_repcn, qexp,
+                       repcn, rc, repci);
     return hipGetLastError();
 }
 

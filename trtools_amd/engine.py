@@ -31,6 +31,15 @@ class DeviceArray:
             self.eng._chk(self.eng.lib.trk_memcpy_d2h(self.eng.ctx, out.ctypes.data, self.ptr, self.nbytes))
         return out
 
+    def get_rows(self, lo, hi):
+        """Copy rows [lo, hi) of the leading axis to the host (partial D2H)."""
+        row = int(np.prod(self.shape[1:], dtype=np.int64)) * self.dtype.itemsize
+        out = np.empty((hi - lo,) + self.shape[1:], dtype=self.dtype)
+        if hi > lo and row:
+            self.eng._chk(self.eng.lib.trk_memcpy_d2h(self.eng.ctx, out.ctypes.data, self.ptr + lo * row,
+                                                      (hi - lo) * row))
+        return out
+
     def set(self, arr):
         arr = np.ascontiguousarray(arr, dtype=self.dtype)
         if arr.shape != self.shape:
@@ -324,4 +333,16 @@ class Engine:
                            inb_d.ptr, int(locus_base), 0)
         self._chk(self.lib.trk_synth_fill(self.ctx, C.byref(spec), gt.ptr, ptrs['dp'], ptrs['q'],
                                           ptrs['dstutter'], ptrs['dflankindel']))
+        return out
+
+    def synth_fill_gangstr(self, seed, n_loci, n_samples, allele_off_d, gt, dp, allele_repcn_d, locus_base=0):
+        out = {'qexp': self.empty((n_loci, n_samples, 3), np.float32),
+               'repcn': self.empty((n_loci, n_samples, 2), np.int32),
+               'rc': self.empty((n_loci, n_samples, 4), np.int32),
+               'repci': self.empty((n_loci, n_samples, 4), np.int32)}
+        spec = L.SynthSpec(int(seed), int(n_loci), int(n_samples), allele_off_d.ptr, None, None, None,
+                           int(locus_base), 0)
+        self._chk(self.lib.trk_synth_fill_gangstr(self.ctx, C.byref(spec), gt.ptr, dp.ptr, allele_repcn_d.ptr,
+                                                  out['qexp'].ptr, out['repcn'].ptr, out['rc'].ptr,
+                                                  out['repci'].ptr))
         return out

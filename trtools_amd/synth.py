@@ -231,6 +231,78 @@ def cells_numpy(seed, loci, locus_idx, n_samples, locus_base=0):
     return dict(gt=gt, dp=dp, q=q, dstutter=st, dflankindel=fl)
 
 
+def allele_repcn(loci):
+    """Integer repeat count of every allele (GangSTR REPCN), concatenated in allele_off order."""
+    out = []
+    for lens in loci.allele_lens:
+        out.extend(int(round(x)) for x in lens)
+    return np.array(out, dtype=np.int32)
+
+
+def gangstr_planes_numpy(seed, loci, locus_idx, n_samples, gt, dp, locus_base=0):
+    """numpy twin of k_synth_gangstr: QEXP [n,S,3] f32, REPCN [n,S,2], RC [n,S,4], REPCI [n,S,4] int32."""
+    locus_idx = np.asarray(locus_idx, dtype=np.int64)
+    n, S = locus_idx.shape[0], int(n_samples)
+    old = np.seterr(over='ignore')
+    try:
+        gl = (locus_idx + int(locus_base)).astype(np.uint64)[:, None]
+        s = np.arange(S, dtype=np.uint64)[None, :]
+        x = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (gl * np.uint64(S) + s + np.uint64(1))
+        h4 = _mix64(x + np.uint64(0xA0761D6478BD642F))
+        h5 = _mix64(x + np.uint64(0xE7037ED1A0B428DB))
+    finally:
+        np.seterr(**old)
+    g = gt.astype(np.int64)
+    nocall = (g[:, :, 0] < 0) & (g[:, :, 1] < 0)
+    d = np.where(dp < 0, 0, dp).astype(np.int64)
+    rep_all = allele_repcn(loci)
+    b0 = (h4 & np.uint64(0xff)).astype(np.int64)
+    b1 = ((h4 >> np.uint64(8)) & np.uint64(0xff)).astype(np.int64)
+    p0 = b0 * 1000 // 255
+    p1 = ((1000 - p0) * b1) >> 8
+    p2 = 1000 - p0 - p1
+    qexp = np.stack([p0, p1, p2], axis=2).astype(np.float32) / np.float32(1000.0)
+    sent = ((h4 >> np.uint64(16)) & np.uint64(0xf)) == 0
+    qexp[sent] = np.float32(-1.0)
+    qexp[nocall] = np.float32(np.nan)
+    e = ((h4 >> np.uint64(20)) & np.uint64(0xffff)).astype(np.int64)
+    repcn = np.full((n, S, 2), INT_MISSING, dtype=np.int64)
+    repci = np.full((n, S, 4), INT_MISSING, dtype=np.int64)
+    offs = loci.allele_off[locus_idx].astype(np.int64)[:, None]
+    for j in range(2):
+        gj = g[:, :, j]
+        ok = gj >= 0
+        r = np.where(ok, rep_all[np.clip(offs + gj, 0, len(rep_all) - 1)], INT_MISSING)
+        repcn[:, :, j] = r
+        lo = np.maximum(r - ((e >> (4 * j)) & 3), 0)
+        hi = r + ((e >> (4 * j + 2)) & 3)
+        bad = ((e >> (8 + j)) & 0x1f) == 0
+        lo = np.where(bad, r + 1, lo)
+        hi = np.where(bad, r + 2, hi)
+        repci[:, :, 2 * j] = np.where(ok, lo, INT_MISSING)
+        repci[:, :, 2 * j + 1] = np.where(ok, hi, INT_MISSING)
+    c0 = (h5 & np.uint64(0xff)).astype(np.int64)
+    c1 = ((h5 >> np.uint64(8)) & np.uint64(0xff)).astype(np.int64)
+    c2 = ((h5 >> np.uint64(16)) & np.uint64(0xff)).astype(np.int64)
+    encl = (c0 * (d + 1)) >> 8
+    rem = d - encl
+    span = (c1 * (rem + 1)) >> 8
+    rem = rem - span
+    frr = (c2 * (rem + 1)) >> 8
+    bound = rem - frr
+    mode = ((h5 >> np.uint64(24)) & np.uint64(0x3f)).astype(np.int64)
+    m0, m1 = mode == 0, mode == 1
+    encl = np.where(m0 | m1, 0, encl)
+    frr = np.where(m0 | m1, 0, frr)
+    span = np.where(m0, d, np.where(m1, d // 2, span))
+    bound = np.where(m0, 0, np.where(m1, d - d // 2, bound))
+    rc = np.stack([encl, span, frr, bound], axis=2)
+    rc[nocall] = INT_MISSING
+    repcn[nocall] = INT_MISSING
+    repci[nocall] = INT_MISSING
+    return dict(qexp=qexp, repcn=repcn.astype(np.int32), rc=rc.astype(np.int32), repci=repci.astype(np.int32))
+
+
 class SynthBatch:
     """A synthetic call set resident on the device (see Engine.synth_fill)."""
 
@@ -259,3 +331,18 @@ class SynthBatch:
     def host_rows(self, locus_idx):
         """CPU regeneration of selected loci (for spot-check parity at full size)."""
         return cells_numpy(self.seed, self.loci, locus_idx, self.n_samples, self.locus_base)
+
+    def add_gangstr_planes(self):
+        """Generate QEXP / REPCN / RC / REPCI on the device for this call set (GangSTR shape)."""
+        d_rep = self.eng.upload(allele_repcn(self.loci), np.int32)
+        out = self.eng.synth_fill_gangstr(self.seed, self.n_loci, self.n_samples, self.d_off, self.dev['gt'],
+                                          self.dev['dp'], d_rep, locus_base=self.locus_base)
+        self.eng.sync()
+        d_rep.free()
+        self.dev.update(out)
+        return out
+
+    def host_gangstr_rows(self, locus_idx, base_rows=None):
+        h = base_rows if base_rows is not None else self.host_rows(locus_idx)
+        return gangstr_planes_numpy(self.seed, self.loci, locus_idx, self.n_samples, h['gt'], h['dp'],
+                                    self.locus_base)
