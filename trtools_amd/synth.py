@@ -346,3 +346,84 @@ class SynthBatch:
         h = base_rows if base_rows is not None else self.host_rows(locus_idx)
         return gangstr_planes_numpy(self.seed, self.loci, locus_idx, self.n_samples, h['gt'], h['dp'],
                                     self.locus_base)
+
+
+# ---------------------------------------------------------------------------
+# text rendering (small scale: parse -> pack plumbing and CLI parity tests)
+# ---------------------------------------------------------------------------
+
+def _fmt_f32(x):
+    return '.' if np.isnan(x) else '%g' % float(x)
+
+
+def _fmt_i32(x):
+    return '.' if int(x) == INT_MISSING else str(int(x))
+
+
+def render_vcf(path, loci, rows, caller='hipstr', n_samples=None, extra=None, chrom='chr1'):
+    """Write the call set ``rows`` (output of cells_numpy for all loci of ``loci``) as VCF text.
+
+    caller='hipstr': flanked alleles (one base on each side, removed again by the START/END
+    trimming of the harmoniser), FORMAT GT:GB:Q:DP:DSTUTTER:DFLANKINDEL:ALLREADS.
+    caller='gangstr': FORMAT GT:DP:Q:REPCN:REPCI:RC:QEXP, ``extra`` = gangstr_planes_numpy output."""
+    gt = rows['gt']
+    n, S = gt.shape[0], gt.shape[1]
+    names = ['S%04d' % i for i in range(S)]
+    with open(path, 'w') as fh:
+        fh.write('##fileformat=VCFv4.1\n')
+        if caller == 'hipstr':
+            fh.write('##command=HipSTR-v0.6.2 --synthetic\n')
+            for k, t, d in (('START', 'Integer', 'start'), ('END', 'Integer', 'end'), ('PERIOD', 'Integer', 'period')):
+                fh.write('##INFO=<ID=%s,Number=1,Type=%s,Description="%s">\n' % (k, t, d))
+            fmts = (('GT', 'String'), ('GB', 'String'), ('Q', 'Float'), ('DP', 'Integer'), ('DSTUTTER', 'Integer'),
+                    ('DFLANKINDEL', 'Integer'), ('ALLREADS', 'String'))
+        else:
+            fh.write('##command=GangSTR-2.4 --synthetic\n')
+            fh.write('##INFO=<ID=RU,Number=1,Type=String,Description="motif">\n')
+            fmts = (('GT', 'String'), ('DP', 'Integer'), ('Q', 'Float'), ('REPCN', 'Integer', '2'), ('REPCI', 'String'),
+                    ('RC', 'String'), ('QEXP', 'Float', '3'))
+        for f in fmts:
+            num = f[2] if len(f) > 2 else '1'
+            fh.write('##FORMAT=<ID=%s,Number=%s,Type=%s,Description="%s">\n' % (f[0], num, f[1], f[0]))
+        fh.write('##contig=<ID=%s>\n' % chrom)
+        fh.write('#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t' + '\t'.join(names) + '\n')
+        for l in range(n):
+            strs = loci.allele_strs[l]
+            pos = 1000 + 500 * l
+            if caller == 'hipstr':
+                ref = 'G' + strs[0] + 'T'
+                alts = ['G' + a + 'T' for a in strs[1:]]
+                info = 'START=%d;END=%d;PERIOD=%d' % (pos + 1, pos + len(strs[0]), len(loci.motifs[l]))
+                fkeys = 'GT:GB:Q:DP:DSTUTTER:DFLANKINDEL:ALLREADS'
+            else:
+                ref, alts = strs[0], list(strs[1:])
+                info = 'RU=%s' % loci.motifs[l].lower()
+                fkeys = 'GT:DP:Q:REPCN:REPCI:RC:QEXP'
+            cols = [chrom, str(pos), 'STR_%d' % l, ref, ','.join(alts) if alts else '.', '.', '.', info, fkeys]
+            for s in range(S):
+                a0, a1 = int(gt[l, s, 0]), int(gt[l, s, 1])
+                g = '%s|%s' % ('.' if a0 < 0 else a0, '.' if a1 < 0 else a1)
+                if a0 < 0 and a1 < 0:
+                    cols.append(':'.join([g] + ['.'] * (len(fkeys.split(':')) - 1)))
+                    continue
+                dp, q = rows['dp'][l, s], rows['q'][l, s]
+                if caller == 'hipstr':
+                    diffs = [(len(strs[a]) - len(strs[0])) if a >= 0 else 0 for a in (a0, a1)]
+                    gb = '%d|%d' % tuple(diffs)
+                    half = int(dp) // 2
+                    reads = {}
+                    reads[diffs[0]] = reads.get(diffs[0], 0) + half
+                    reads[diffs[1]] = reads.get(diffs[1], 0) + (int(dp) - half) // (1 + (s % 3 == 0))
+                    ar = ';'.join('%d|%d' % kv for kv in sorted(reads.items()) if kv[1] > 0) or '.'
+                    cols.append(':'.join([g, gb, _fmt_f32(q), _fmt_i32(dp), _fmt_i32(rows['dstutter'][l, s]),
+                                          _fmt_i32(rows['dflankindel'][l, s]), ar]))
+                else:
+                    e = extra
+                    rep = ','.join(_fmt_i32(x) for x in e['repcn'][l, s])
+                    ci = e['repci'][l, s]
+                    rci = ','.join('%s-%s' % (_fmt_i32(ci[2 * j]), _fmt_i32(ci[2 * j + 1])) for j in range(2))
+                    rc = ','.join(_fmt_i32(x) for x in e['rc'][l, s])
+                    qx = ','.join(_fmt_f32(x) for x in e['qexp'][l, s])
+                    cols.append(':'.join([g, _fmt_i32(dp), _fmt_f32(q), rep, rci, rc, qx]))
+            fh.write('\t'.join(cols) + '\n')
+    return names

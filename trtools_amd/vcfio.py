@@ -105,7 +105,7 @@ class Variant:
 
     __slots__ = ('_reader', '_fields', 'CHROM', 'POS', 'ID', 'REF', 'ALT', 'QUAL',
                  '_filter', 'INFO', 'FORMAT', '_samples', '_cols', '_fmt_cache',
-                 '_gt', 'ploidy', '_set_formats', '_info_dirty')
+                 '_gt', '_gtlist', 'ploidy', '_set_formats', '_info_dirty')
 
     def __init__(self, reader, line):
         f = line.rstrip('\r\n').split('\t')
@@ -129,6 +129,7 @@ class Variant:
         self._fmt_cache = {}
         self._set_formats = {}
         self._gt = None
+        self._gtlist = None
         self.ploidy = 2
         if reader.n_samples and 'GT' in self.FORMAT:
             self._decode_gt()
@@ -185,11 +186,14 @@ class Variant:
 
     @property
     def genotypes(self):
-        """cyvcf2 ``Variant.genotypes``: list of [a0, a1, ..., phased]."""
+        """cyvcf2 ``Variant.genotypes``: list of [a0, a1, ..., phased].  Like cyvcf2 the list
+        is cached, so ``v.genotypes[i] = ...; v.genotypes = v.genotypes`` updates the record."""
         if self._gt is None:
             return []
-        p = self._gt.shape[1] - 1
-        return [[int(x) for x in row[:p]] + [bool(row[p])] for row in self._gt]
+        if self._gtlist is None:
+            p = self._gt.shape[1] - 1
+            self._gtlist = [[int(x) for x in row[:p]] + [bool(row[p])] for row in self._gt]
+        return self._gtlist
 
     @genotypes.setter
     def genotypes(self, value):
@@ -200,11 +204,13 @@ class Variant:
                 arr[i, j] = a
             arr[i, p] = 1 if v[-1] else 0
         self._gt = arr
+        self._gtlist = None
         self.ploidy = p
 
     def set_gt_array(self, arr):
         """Replace the genotype matrix (int16 [S, P+1], cyvcf2 layout)."""
         self._gt = np.asarray(arr, dtype=np.int16)
+        self._gtlist = None
         self.ploidy = self._gt.shape[1] - 1
 
     def format(self, key):
