@@ -232,3 +232,25 @@ def test_rccl_single_rank_collectives(eng):
     dst = eng.zeros((1, 256), np.uint8)
     eng.allgather(src, dst)
     assert np.array_equal(dst.get()[0], np.arange(256, dtype=np.uint8))
+
+
+def test_sentinel_mixes_on_the_streaming_kernel(eng):
+    """Diploid batch without a ploidy table (the streaming kernel): haploid calls (a,-2),
+    partial calls (a,-1), (-1,-2) / (-2,-1) / (-2,-2) / (-1,-1) rows, duplicate classes."""
+    from oracle import trtools_oracle as orc
+    from trtools_amd import _lib as L
+    rng = np.random.default_rng(21)
+    n_loci, S = 40, 512
+    gt, lens, strs, _, (off, lc, sc, cv) = _random_batch(rng, n_loci, S, 2, 9)
+    for l in range(n_loci):
+        r = rng.random(S)
+        gt[l][r < 0.06, 1] = -2
+        gt[l][(r >= 0.06) & (r < 0.09), 0] = -2
+        gt[l][(r >= 0.09) & (r < 0.11)] = -2
+        gt[l][(r >= 0.11) & (r < 0.13)] = (-1, -2)
+        gt[l][(r >= 0.13) & (r < 0.15)] = (-2, -1)
+    gt[5] = -1
+    gt[6] = -2
+    b = eng.make_batch(gt, off, lc, sc, cv)
+    cnt, li, lf = _fetch(eng.locus_stats(b, nalleles_thresh=0.02))
+    check_against_oracle(orc, L, cnt, li, lf, off, gt, lens, strs, [None], 0.02)

@@ -402,6 +402,145 @@ __device__ __forceinline__ void fast_row(const u32x4* __restrict__ row, int nchu
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_locus_count_v2 : same mapping as k_locus_count_fast with the per-call work cut to
+// ~10 VALU + 2 LDS atomics.  The sentinels are histogrammed like alleles
+// (packed 16-bit math: +2 then min with A+2 gives bin 0 = '-2', bin 1 = '-1',
+// bins 2..A+1 = alleles, bin A+2 = out of range) and every row predicate is derived
+// after the stream from those totals plus three cheap per-call facts:
+//   eq    rows whose two bins are equal            (one compare)
+//   c_xy  rows whose two haplotypes are BOTH sentinels, by combination (rare path)
+// so that
+//   rows with a '-1'      = hap(-1) - c(-1,-1)                    -> n_called = S - that
+//   low-ploidy rows       = hap(-2) - c(-2,-2) - c(-1,-2) - c(-2,-1)
+//   homozygous (by index) = eq - c(-1,-1) - c(-2,-2)
+// ---------------------------------------------------------------------------
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+template <bool DUP>
+__device__ __forceinline__ void v2_cell(uint32_t w, uint32_t amax2, uint32_t* hist, const uint32_t* lut,
+                                        int kshift, int kslot, int combo_bin0, int& n_eq, int& n_hl, int& n_hs) {
+    u16x2 u = __builtin_bit_cast(u16x2, w) + (u16x2){2, 2};
+    u16x2 t2 = __builtin_elementwise_min(u, __builtin_bit_cast(u16x2, amax2));
+    const uint32_t t = __builtin_bit_cast(uint32_t, t2);
+    const uint32_t lo = t & 0xffffu, hi = t >> 16;
+    atomicAdd(&hist[(lo << kshift) + kslot], 1u);
+    atomicAdd(&hist[(hi << kshift) + kslot], 1u);
+    n_eq += lo == hi;
+    if ((t & 0xfffefffeu) == 0u)  // both haplotypes are sentinels (a no-call): ~3 % of the rows
+        atomicAdd(&hist[((combo_bin0 + (int)(lo + 2u * hi)) << kshift) + kslot], 1u);
+    if (DUP) {
+        const uint32_t x = lut[lo] ^ lut[hi];
+        n_hl += (x & 0xffffu) == 0u;
+        n_hs += (x >> 16) == 0u;
+    }
+}
+
+template <bool DUP, int U>
+__device__ __forceinline__ void v2_row(const u32x4* __restrict__ row, int nchunks, int lane, uint32_t amax2,
+                                       uint32_t* hist, const uint32_t* lut, int kshift, int kslot, int combo_bin0,
+                                       int& n_eq, int& n_hl, int& n_hs) {
+    int c = lane;
+    for (; c + (U - 1) * WAVE < nchunks; c += U * WAVE) {
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(&row[c + u * WAVE]);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                v2_cell<DUP>(v[u][j], amax2, hist, lut, kshift, kslot, combo_bin0, n_eq, n_hl, n_hs);
+    }
+    for (; c < nchunks; c += WAVE) {
+        u32x4 v = __builtin_nontemporal_load(&row[c]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v2_cell<DUP>(v[j], amax2, hist, lut, kshift, kslot, combo_bin0, n_eq, n_hl, n_hs);
+    }
+}
+
+// bins: 0 '-2', 1 '-1', 2..A+1 alleles, A+2 out of range, A+3.. A+6 sentinel pairs (lo + 2*hi)
+template <int U>
+__global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v2(
+    trk_batch b, int32_t* __restrict__ allele_count, int32_t* __restrict__ locus_int, int kshift,
+    int wave_lds_words) {
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wid = threadIdx.x >> 6;
+    const int l = blockIdx.x * COUNT_WAVES_PER_WG + wid;
+    if (l >= b.n_loci) return;  // waves are independent: no workgroup barrier anywhere
+    const int S = b.n_samples;
+    const int off = b.allele_off[l];
+    const int A = b.allele_off[l + 1] - off;
+    const int K = 1 << kshift;
+    const int kslot = lane & (K - 1);
+    const int nbins = A + 7;
+    uint32_t* hist = lds + (size_t)wid * wave_lds_words;
+    uint32_t* lut = hist + (nbins << kshift);  // indexed by BIN
+    int ml = 0, ms = 0;
+    for (int a = lane; a < A; a += WAVE) {
+        int lc = b.len_class[off + a], sc = b.str_class[off + a];
+        lut[a + 2] = (uint32_t)lc | ((uint32_t)sc << 16);
+        ml = lc > ml ? lc : ml;
+        ms = sc > ms ? sc : ms;
+    }
+    if (lane == 0) {  // sentinel bins: classes no allele has, distinct from each other
+        lut[0] = 0xffffffffu;
+        lut[1] = 0xfffefffeu;
+        lut[A + 2] = 0xfffdfffdu;
+    }
+    ml = wave_max(ml);
+    ms = wave_max(ms);
+    const bool dup = (ml + 1 < A) | (ms + 1 < A);
+    for (int i = lane; i < (nbins << kshift); i += WAVE) hist[i] = 0;
+    wave_lds_fence();
+
+    int n_eq = 0, n_hl = 0, n_hs = 0;
+    const u32x4* row = reinterpret_cast<const u32x4*>(b.gt) + (((int64_t)l * S) >> 2);
+    const int nchunks = S >> 2;
+    const uint32_t amax2 = (uint32_t)(A + 2) * 0x00010001u;
+    if (dup)
+        v2_row<true, U>(row, nchunks, lane, amax2, hist, lut, kshift, kslot, A + 3, n_eq, n_hl, n_hs);
+    else
+        v2_row<false, U>(row, nchunks, lane, amax2, hist, lut, kshift, kslot, A + 3, n_eq, n_hl, n_hs);
+    wave_lds_fence();
+    // fold the K copies of every bin (rotated start: conflict-free), keep the totals of the
+    // special bins in registers of the lanes that own them
+    int special = 0;  // this lane's total if it owns one of the special bins, gathered below
+    for (int bin = lane; bin < nbins; bin += WAVE) {
+        uint32_t s = 0;
+        for (int k = 0; k < K; ++k) s += hist[(bin << kshift) + ((k + lane) & (K - 1))];
+        if (bin >= 2 && bin < A + 2) allele_count[off + bin - 2] = (int32_t)s;
+        // stash special totals in LDS words that are no longer needed (copy 0 of the bin)
+        hist[bin << kshift] = s;
+    }
+    (void)special;
+    wave_lds_fence();
+    n_eq = wave_sum(n_eq);
+    if (dup) {
+        n_hl = wave_sum(n_hl);
+        n_hs = wave_sum(n_hs);
+    }
+    if (lane == 0) {
+        const int h_m2 = (int)hist[0 << kshift], h_m1 = (int)hist[1 << kshift];
+        const int n_bad = (int)hist[(A + 2) << kshift];
+        const int c00 = (int)hist[(A + 3) << kshift];  // (-2,-2)
+        const int c10 = (int)hist[(A + 4) << kshift];  // lo = -1, hi = -2
+        const int c01 = (int)hist[(A + 5) << kshift];  // lo = -2, hi = -1
+        const int c11 = (int)hist[(A + 6) << kshift];  // (-1,-1)
+        const int miss_rows = h_m1 - c11;
+        const int low_rows = h_m2 - c00 - c10 - c01;
+        const int hom_idx = n_eq - c11 - c00;
+        int32_t* li0 = locus_int + (int64_t)l * TRK_LI_COLS;
+        li0[TRK_LI_N_CALLED] = S - miss_rows;
+        li0[TRK_LI_N_LOWPLOIDY] = low_rows;
+        li0[TRK_LI_N_HOM_LEN] = dup ? n_hl - c11 - c00 : hom_idx;
+        li0[TRK_LI_N_HOM_STR] = dup ? n_hs - c11 - c00 : hom_idx;
+        li0[TRK_LI_N_BAD] = n_bad;
+        li0[TRK_LI_N_SAMPLES] = S;
+    }
+    wave_lds_fence();
+}
+
 template <int U>
 __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_fast(
     trk_batch b, int32_t* __restrict__ allele_count, int32_t* __restrict__ locus_int, int kshift,
@@ -1010,7 +1149,7 @@ __device__ __forceinline__ void cf_process(const CallArgs& a, int l, int64_t cel
 }
 
 template <int U>
-__global__ __launch_bounds__(CF_THREADS) void k_call_filter_fast(const CallArgs a) {
+__global__ __launch_bounds__(CF_THREADS) void k_call_filter_fast(const CallArgs a) {  // U: loci in flight per thread
     extern __shared__ uint32_t fcount[];  // [n_filters][CF_THREADS * CF_V]
     const int tid = threadIdx.x;
     const int S = a.b.n_samples, L = a.b.n_loci;
@@ -1269,25 +1408,38 @@ hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* alle
     const int G = b.group_bits ? b.n_groups : 1;
     const bool fast2 = (b.ploidy == 2) && !b.group_bits;
     if (fast2 && max_alleles > 0 && (b.n_samples % 4) == 0 && b.n_samples > 0) {
-        // words per wave: (A+1) bins x K copies + (A+1) LUT words, K = 32 while it fits in 16 KiB
+        const char* ver_env = getenv("TRK_CNT_VER");
+        const bool use_v2 = !b.locus_ploidy && max_alleles + 2 < 65535 && !(ver_env && atoi(ver_env) == 1);
+        const int extra = use_v2 ? 7 : 1;  // bins besides the alleles
+        // words per wave: bins x K copies + one LUT word per bin, K = 32 while it fits in 16 KiB
         int kshift = 5;
-        while (kshift > 0 && ((max_alleles + 1) << kshift) + max_alleles + 1 > 4096) --kshift;
-        int words = ((max_alleles + 1) << kshift) + max_alleles + 1;
+        while (kshift > 0 && ((max_alleles + extra) << kshift) + max_alleles + extra > 4096) --kshift;
+        int words = ((max_alleles + extra) << kshift) + max_alleles + extra;
         if (words <= 4096) {
             words = (words + 3) & ~3;
             size_t lds_fast = (size_t)COUNT_WAVES_PER_WG * words * sizeof(uint32_t);
             int wgs_fast = (b.n_loci + COUNT_WAVES_PER_WG - 1) / COUNT_WAVES_PER_WG;
-            int cnt_u = 4;
+            int cnt_u = 2;
             if (const char* e = getenv("TRK_CNT_U")) cnt_u = atoi(e);
-            if (cnt_u == 2)
-                hipLaunchKernelGGL(k_locus_count_fast<2>, dim3(wgs_fast), dim3(WAVE * COUNT_WAVES_PER_WG), lds_fast,
-                                   stream, b, allele_count, locus_int, kshift, words);
-            else if (cnt_u == 8)
-                hipLaunchKernelGGL(k_locus_count_fast<8>, dim3(wgs_fast), dim3(WAVE * COUNT_WAVES_PER_WG), lds_fast,
-                                   stream, b, allele_count, locus_int, kshift, words);
-            else
-                hipLaunchKernelGGL(k_locus_count_fast<4>, dim3(wgs_fast), dim3(WAVE * COUNT_WAVES_PER_WG), lds_fast,
-                                   stream, b, allele_count, locus_int, kshift, words);
+            dim3 grid(wgs_fast), block(WAVE * COUNT_WAVES_PER_WG);
+            if (use_v2) {
+                if (cnt_u == 4)
+                    hipLaunchKernelGGL(k_locus_count_v2<4>, grid, block, lds_fast, stream, b, allele_count, locus_int,
+                                       kshift, words);
+                else if (cnt_u == 1)
+                    hipLaunchKernelGGL(k_locus_count_v2<1>, grid, block, lds_fast, stream, b, allele_count, locus_int,
+                                       kshift, words);
+                else
+                    hipLaunchKernelGGL(k_locus_count_v2<2>, grid, block, lds_fast, stream, b, allele_count, locus_int,
+                                       kshift, words);
+            } else {
+                if (cnt_u == 4)
+                    hipLaunchKernelGGL(k_locus_count_fast<4>, grid, block, lds_fast, stream, b, allele_count,
+                                       locus_int, kshift, words);
+                else
+                    hipLaunchKernelGGL(k_locus_count_fast<2>, grid, block, lds_fast, stream, b, allele_count,
+                                       locus_int, kshift, words);
+            }
             return hipGetLastError();
         }
     }
@@ -1358,12 +1510,12 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
     int gx = (S + CF_THREADS * CF_V - 1) / (CF_THREADS * CF_V);
     // enough blocks to fill the chip (>= 8 per CU) while keeping the per-block
     // counter flush (one atomic per sample per counter) small next to the stream
-    int want_blocks = n_cu * 64;
+    int want_blocks = n_cu * 32;
     int gy = (want_blocks + gx - 1) / gx;
     if (gy > L) gy = L;
     if (gy < 1) gy = 1;
     int lpb = (L + gy - 1) / gy;
-    if (lpb < 32) lpb = L < 32 ? L : 32;
+    if (lpb < 128) lpb = L < 128 ? L : 128;
     if (lpb > 4096) lpb = 4096;
     gy = (L + lpb - 1) / lpb;
     a.loci_per_block = lpb;
@@ -1389,7 +1541,7 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
                 gy = (L + v - 1) / v;
             }
         }
-        int cf_u = 2;
+        int cf_u = 1;  // measured: U=1 == U=2 (3.8 ms), U=4 spills (profiles/r01_notes.md)
         if (const char* e = getenv("TRK_CF_U")) cf_u = atoi(e);
         if (cf_u == 1)
             hipLaunchKernelGGL(k_call_filter_fast<1>, dim3(gx, gy), dim3(CF_THREADS), lds, stream, a);
