@@ -12,10 +12,14 @@ call- and locus-level filters on a HipSTR-shape call set of 100 000 loci x
 host for the parity spot-check and the CPU baseline).
 
 One step =
-  statSTR : trk_locus_stats(GT)                  (k_locus_count + k_locus_finalize)
-  dumpSTR : trk_call_filters(GT, DP, Q)          (k_call_filter: min-DP, max-DP, min-Q ->
-                                                  masked GT', filter mask, sample counters)
-            trk_locus_stats(GT')                 (k_locus_count + k_locus_finalize)
+  statSTR : trk_locus_stats(GT)                  (k_locus_count + k_locus_finalize + k_hwe_test)
+  dumpSTR : trk_call_filters(GT, DP, Q)          (k_call_filter: min-DP, max-DP, min-Q -> masked GT',
+                                                  filter mask, sample counters, and -- via the delta
+                                                  outputs -- the allele/genotype counts of GT' obtained by
+                                                  subtracting the masked calls from the counts of GT that
+                                                  the statSTR half of the step already produced: no second
+                                                  pass over the genotype tensor)
+            trk_locus_finalize(counts of GT')    (k_locus_finalize + k_hwe_test)
             trk_locus_filters(callrate, HWE, het low/high)  (k_locus_filter)
   N > 1   : loci are sharded by rank (weak scaling: every rank owns 100k loci of an
             N x 100k-locus cohort); per step an RCCL all-reduce sums the per-sample /
@@ -94,8 +98,10 @@ class Workload:
         self.call_out.sample_dp_missing.zero()
         self.loc_counters.zero()
         eng.locus_stats(b, out=self.stats_a[i])
-        eng.call_filters(b, self.planes, self.filters, dp_plane=0, out=self.call_out)
-        eng.locus_stats(self.batch2, out=self.stats_b[i])
+        self.stats_b[i].allele_count.copy_from(self.stats_a[i].allele_count)
+        self.stats_b[i].locus_int.copy_from(self.stats_a[i].locus_int)
+        eng.call_filters(b, self.planes, self.filters, dp_plane=0, out=self.call_out, delta_stats=self.stats_b[i])
+        eng.locus_finalize(b, self.stats_b[i])
         eng.locus_filters(self.n_loci, self.stats_b[i], bits_out=self.bits, counters=self.loc_counters,
                           **self.locus_args)
         if self.world > 1:
@@ -126,6 +132,15 @@ def parity_spot_check(wl, n_check=6):
         for col, key in ((L.LF_HET_STR, 'het'), (L.LF_MEAN, 'mean'), (L.LF_VAR, 'var'), (L.LF_HWEP_STR, 'hwep')):
             a, bb = lf[l, col], o[key]
             assert (np.isnan(a) and np.isnan(bb)) or abs(a - bb) <= 1e-9 * max(1.0, abs(bb)), (key, l, a, bb)
+    # dumpSTR half: the delta-corrected counts must equal a recount of the masked genotypes
+    lib_ = wl.stats_b[i].locus_int.get()[0]
+    cntb = wl.stats_b[i].allele_count.get()[0]
+    for r, l in enumerate(idx):
+        l = int(l)
+        g2 = wl.call_out.gt_out.get_rows(l, l + 1)[0]
+        o2 = orc.locus_stats(g2, wl.sb.loci.allele_lens[l], wl.sb.loci.allele_strs[l], None, use_length=False)
+        assert np.array_equal(cntb[off[l]:off[l + 1]], o2['index_counts']), ("masked allele counts", l)
+        assert lib_[l, L.LI_N_CALLED] == o2['numcalled'], ("masked numcalled", l)
     # invariants over the whole shard
     nall = li[:, L.LI_N_ALLELES].astype(np.int64)
     seg = np.add.reduceat(cnt.astype(np.int64), off[:-1]) if wl.n_loci else np.zeros(0)

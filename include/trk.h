@@ -69,6 +69,7 @@ int trk_dev_alloc(trk_ctx* ctx, size_t bytes, void** dptr);
 int trk_dev_free(trk_ctx* ctx, void* dptr);
 int trk_memcpy_h2d(trk_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int trk_memcpy_d2h(trk_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int trk_memcpy_d2d(trk_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes); /* async on the stream */
 int trk_memset(trk_ctx* ctx, void* dst_dev, int value, size_t bytes);
 int trk_sync(trk_ctx* ctx);
 
@@ -191,6 +192,12 @@ typedef struct {
 int trk_locus_stats(trk_ctx* ctx, const trk_batch* in, const trk_stats_params* prm,
                     trk_stats_out* out);
 
+/* The finaliser alone: float statistics + HWE test from allele_count / the first six
+ * locus_int columns already present in `out` (after trk_locus_stats(COUNT_ONLY), possibly
+ * corrected by trk_call_filters' delta outputs).                                        */
+int trk_locus_finalize(trk_ctx* ctx, const trk_batch* in, const trk_stats_params* prm,
+                       trk_stats_out* out);
+
 /* ---- dumpSTR call-level filters ------------------------------------------ */
 enum { TRK_DT_I32 = 0, TRK_DT_F32 = 1 };
 typedef struct {
@@ -236,6 +243,13 @@ typedef struct {
     int64_t* sample_dp_missing;/* [S] += PASS calls whose DP is missing (-> nan, :710) */
     int32_t* error;           /* [4] error[0] != 0: a PASS call had negative DP
                                  (ValueError :698-706); error[1]=locus, [2]=sample */
+    /* Optional (both or neither): allele_count [sumA] and locus_int [L, TRK_LI_COLS] of the
+     * UNFILTERED genotypes (group 0 of a trk_locus_stats(TRK_STATS_COUNT_ONLY) run on the same
+     * batch).  The kernel subtracts what every filtered call contributed, so on return they are
+     * the counts of gt_out -- the rebuilt record of dumpSTR.py:748-774 -- without a second pass
+     * over the genotype tensor.  Follow with trk_locus_finalize.                            */
+    int32_t* delta_allele_count;
+    int32_t* delta_locus_int;
 } trk_call_out;
 
 /* (a11)-(a18): evaluate `n_filters` call-level filters on every call of the

@@ -258,3 +258,23 @@ def test_missing_dp_poisons_totaldp(eng):
     res = eng.call_filters(b, [eng.upload(dp), eng.upload(q)], [dict(op=L.F_LT, plane_a=1, thr=0.3)], dp_plane=0)
     _compare(info, gout, mask, res, ['minq'], S)
     assert np.isnan(info['totaldp']).any() and (~np.isnan(info['totaldp'])).any()
+
+
+@pytest.mark.parametrize("n_samples", [1000, 1003])
+def test_delta_counts_equal_recount(eng, n_samples):
+    """trk_call_out.delta_*: counts(GT) minus the filtered calls == counts(GT') recomputed from gt_out
+    (streaming kernel with the LDS delta table for S % 4 == 0, per-call kernel otherwise)."""
+    from trtools_amd import _lib as L
+    from trtools_amd.synth import SynthBatch
+    sb = SynthBatch(eng, 300, n_samples, seed=5 + n_samples)
+    planes = [sb.dev['dp'], sb.dev['q']]
+    filters = [dict(op=L.F_LT, plane_a=0, thr=25), dict(op=L.F_LT, plane_a=1, thr=0.95)]
+    st = eng.locus_stats(sb.batch, count_only=True)
+    res = eng.call_filters(sb.batch, planes, filters, dp_plane=0, delta_stats=st)
+    eng.locus_finalize(sb.batch, st)
+    ref = eng.locus_stats(sb.batch.with_gt(res.gt_out))
+    assert np.array_equal(st.allele_count.get(), ref.allele_count.get())
+    assert np.array_equal(st.locus_int.get(), ref.locus_int.get())
+    a, b = st.locus_f64.get(), ref.locus_f64.get()
+    assert np.array_equal(np.nan_to_num(a, nan=-7.0), np.nan_to_num(b, nan=-7.0))
+    assert (res.filter_mask.get() & np.uint32(3)).any()

@@ -65,7 +65,8 @@ class CallFilter(C.Structure):
 class CallOut(C.Structure):
     _fields_ = [('gt_out', C.c_void_p), ('filter_mask', C.c_void_p),
                 ('sample_counters', C.c_void_p), ('sample_totaldp', C.c_void_p),
-                ('sample_dp_missing', C.c_void_p), ('error', C.c_void_p)]
+                ('sample_dp_missing', C.c_void_p), ('error', C.c_void_p),
+                ('delta_allele_count', C.c_void_p), ('delta_locus_int', C.c_void_p)]
 
 
 class LocusFilterSpec(C.Structure):
@@ -87,10 +88,10 @@ class SynthSpec(C.Structure):
 # every symbol include/trk.h declares (tests check that the library exports them)
 EXPORTS = [
     'trk_init', 'trk_free', 'trk_last_error', 'trk_backend', 'trk_device_count', 'trk_device_info',
-    'trk_dev_alloc', 'trk_dev_free', 'trk_memcpy_h2d', 'trk_memcpy_d2h', 'trk_memset', 'trk_sync',
+    'trk_dev_alloc', 'trk_dev_free', 'trk_memcpy_h2d', 'trk_memcpy_d2h', 'trk_memcpy_d2d', 'trk_memset', 'trk_sync',
     'trk_timer_start', 'trk_timer_stop', 'trk_timer_elapsed_ms',
     'trk_profile_enable', 'trk_profile_get', 'trk_profile_reset',
-    'trk_locus_stats', 'trk_call_filters', 'trk_locus_filters',
+    'trk_locus_stats', 'trk_locus_finalize', 'trk_call_filters', 'trk_locus_filters',
     'trk_comm_unique_id', 'trk_comm_init', 'trk_allreduce_sum_i64', 'trk_allgather',
     'trk_binomtest_two_sided', 'trk_binom_pmf', 'trk_synth_fill', 'trk_synth_fill_gangstr',
 ]
@@ -126,6 +127,7 @@ def load():
     lib.trk_dev_free.argtypes = [vp, vp]
     lib.trk_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
     lib.trk_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.trk_memcpy_d2d.argtypes = [vp, vp, vp, C.c_size_t]
     lib.trk_memset.argtypes = [vp, vp, C.c_int, C.c_size_t]
     lib.trk_sync.argtypes = [vp]
     lib.trk_timer_start.argtypes = [vp, C.c_int]
@@ -135,6 +137,7 @@ def load():
     lib.trk_profile_get.argtypes = [vp, C.c_int, P(i64), P(dbl)]
     lib.trk_profile_reset.argtypes = [vp]
     lib.trk_locus_stats.argtypes = [vp, P(Batch), P(StatsParams), P(StatsOut)]
+    lib.trk_locus_finalize.argtypes = [vp, P(Batch), P(StatsParams), P(StatsOut)]
     lib.trk_call_filters.argtypes = [vp, P(Batch), P(Plane), C.c_int, P(CallFilter), C.c_int, C.c_int,
                                      P(CallOut)]
     lib.trk_locus_filters.argtypes = [vp, i32, P(StatsOut), P(LocusFilterSpec), P(LocusOut)]

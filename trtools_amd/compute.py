@@ -62,9 +62,12 @@ class DeviceCompute:
         eng = self.eng
         b = self._upload(hb)
         dplanes = [eng.upload(p) for p in planes]
-        call = eng.call_filters(b, dplanes, filters, dp_plane=dp_plane)
-        b2 = b.with_gt(call.gt_out)
-        st = eng.locus_stats(b2, nalleles_thresh=nalleles_thresh)
+        # counts of the unfiltered genotypes, corrected by the call-filter kernel for every call it
+        # masks (dumpSTR.py:721-774 rebuilds the record; here no second pass over the tensor), then
+        # the finaliser
+        st = eng.locus_stats(b, nalleles_thresh=nalleles_thresh, count_only=True)
+        call = eng.call_filters(b, dplanes, filters, dp_plane=dp_plane, delta_stats=st)
+        eng.locus_finalize(b, st, nalleles_thresh=nalleles_thresh)
         ext = None
         spec = dict(locus_spec)
         ext_host = spec.pop('extern_bits', None)

@@ -253,6 +253,12 @@ int trk_memcpy_d2h(trk_ctx* ctx, void* h, const void* d, size_t n) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return TRK_OK;
 }
+int trk_memcpy_d2d(trk_ctx* ctx, void* d, const void* s, size_t n) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (n == 0) return TRK_OK;
+    HIPCHK(ctx, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, ctx->stream));
+    return TRK_OK;
+}
 int trk_memset(trk_ctx* ctx, void* d, int v, size_t n) {
     if (!ctx) return TRK_ERR_ARG;
     if (n == 0) return TRK_OK;
@@ -319,6 +325,8 @@ static int check_batch(trk_ctx* ctx, const trk_batch* b) {
     return TRK_OK;
 }
 
+static int ensure_fin_buffers(trk_ctx* ctx, int G, int64_t sumA, int n_loci);
+
 int trk_locus_stats(trk_ctx* ctx, const trk_batch* in, const trk_stats_params* prm, trk_stats_out* out) {
     if (!ctx) return TRK_ERR_ARG;
     int rc = check_batch(ctx, in);
@@ -339,6 +347,17 @@ int trk_locus_stats(trk_ctx* ctx, const trk_batch* in, const trk_stats_params* p
                                             ctx->n_cu, ctx->stream));
     }
     if (count_only) return TRK_OK;
+    rc = ensure_fin_buffers(ctx, G, sumA, in->n_loci);
+    if (rc) return rc;
+    {
+        ProfScope ps(ctx, TRK_K_LOCUS_FINALIZE);
+        HIPCHK(ctx, trk::launch_locus_finalize(*in, out->allele_count, out->locus_int, out->locus_f64, ctx->scratch,
+                                               ctx->worklist, prm ? prm->nalleles_thresh : 0.01, ctx->stream));
+    }
+    return TRK_OK;
+}
+
+static int ensure_fin_buffers(trk_ctx* ctx, int G, int64_t sumA, int n_loci) {
     size_t need = (size_t)G * 2 * (size_t)sumA * sizeof(int32_t) + 16;
     if (need > ctx->scratch_bytes) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -349,7 +368,7 @@ int trk_locus_stats(trk_ctx* ctx, const trk_batch* in, const trk_stats_params* p
         if (e != hipSuccess) return fail(ctx, TRK_ERR_NOMEM, "scratch hipMalloc(%zu): %s", need, hipGetErrorString(e));
         ctx->scratch_bytes = need;
     }
-    size_t wneed = trk::finalize_worklist_bytes((int64_t)G * in->n_loci);
+    size_t wneed = trk::finalize_worklist_bytes((int64_t)G * n_loci);
     if (wneed > ctx->worklist_bytes) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->worklist) (void)hipFree(ctx->worklist);
@@ -359,11 +378,23 @@ int trk_locus_stats(trk_ctx* ctx, const trk_batch* in, const trk_stats_params* p
         if (e != hipSuccess) return fail(ctx, TRK_ERR_NOMEM, "worklist hipMalloc(%zu): %s", wneed, hipGetErrorString(e));
         ctx->worklist_bytes = wneed;
     }
-    {
-        ProfScope ps(ctx, TRK_K_LOCUS_FINALIZE);
-        HIPCHK(ctx, trk::launch_locus_finalize(*in, out->allele_count, out->locus_int, out->locus_f64, ctx->scratch,
-                                               ctx->worklist, prm ? prm->nalleles_thresh : 0.01, ctx->stream));
-    }
+    return TRK_OK;
+}
+
+int trk_locus_finalize(trk_ctx* ctx, const trk_batch* in, const trk_stats_params* prm, trk_stats_out* out) {
+    if (!ctx) return TRK_ERR_ARG;
+    int rc = check_batch(ctx, in);
+    if (rc) return rc;
+    if (!out || !out->allele_count || !out->locus_int || !out->locus_f64)
+        return fail(ctx, TRK_ERR_ARG, "stats outputs are NULL");
+    if (in->n_loci == 0) return TRK_OK;
+    (void)hipSetDevice(ctx->device);
+    const int G = in->group_bits ? in->n_groups : 1;
+    rc = ensure_fin_buffers(ctx, G, in->n_alleles_total, in->n_loci);
+    if (rc) return rc;
+    ProfScope ps(ctx, TRK_K_LOCUS_FINALIZE);
+    HIPCHK(ctx, trk::launch_locus_finalize(*in, out->allele_count, out->locus_int, out->locus_f64, ctx->scratch,
+                                           ctx->worklist, prm ? prm->nalleles_thresh : 0.01, ctx->stream));
     return TRK_OK;
 }
 
@@ -378,6 +409,10 @@ int trk_call_filters(trk_ctx* ctx, const trk_batch* in, const trk_plane* planes,
     if (!out || !out->sample_counters || !out->sample_totaldp || !out->sample_dp_missing || !out->error)
         return fail(ctx, TRK_ERR_ARG, "call-filter outputs are NULL");
     if (dp_plane >= n_planes) return fail(ctx, TRK_ERR_ARG, "dp_plane out of range");
+    if ((out->delta_allele_count == nullptr) != (out->delta_locus_int == nullptr))
+        return fail(ctx, TRK_ERR_ARG, "delta_allele_count and delta_locus_int must be given together");
+    if (out->delta_allele_count && in->group_bits)
+        return fail(ctx, TRK_ERR_ARG, "delta outputs are defined for ungrouped batches only");
     if (dp_plane >= 0 && planes[dp_plane].dtype != TRK_DT_I32)
         return fail(ctx, TRK_ERR_ARG, "the DP/LC plane must be int32");
     for (int i = 0; i < n_planes; ++i) {

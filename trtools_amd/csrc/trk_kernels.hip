@@ -918,9 +918,54 @@ struct CallArgs {
     uint32_t fast_plane_mask;   // planes 0..3 with one column (fetched as 16-byte vectors)
     uint32_t fast_filter_mask;  // LT / GT / CALLED_LT filters on a fast plane
     uint32_t slow_filter_mask;  // everything else
-    uint32_t pad0;
+    int32_t delta_stride;       // LDS words per locus of the delta table (max_alleles + 4), 0 = no delta
+    int32_t dbg;
     trk_call_out out;
 };
+
+// what one filtered call (called, now masked to no-call) removes from the locus counts
+enum { DX_CALLED = 0, DX_LOW = 1, DX_HOML = 2, DX_HOMS = 3, DX_N = 4 };
+
+// gtv: the call's haplotypes; tab: this locus's delta table (LDS) or nullptr -> global atomics
+__device__ __forceinline__ void delta_filtered_call(const CallArgs& a, int l, const int* gtv, int pl, int32_t* tab,
+                                                    int tab_alleles) {
+    const int off = a.b.allele_off[l];
+    const int A = a.b.allele_off[l + 1] - off;
+    bool low = false, bad = false;
+    for (int j = 0; j < pl; ++j) {
+        const int v = gtv[j];
+        low |= v == -2;
+        bad |= v >= A;
+        if (v >= 0 && v < A) {
+            if (tab) atomicAdd(&tab[v], 1);
+            else atomicSub(&a.out.delta_allele_count[off + v], 1);
+        }
+    }
+    bool hl = false, hs = false;
+    if (!low && !bad && pl >= 2) {
+        int minl = 0x7fffffff, mins = 0x7fffffff, cl = 0, cs = 0;
+        for (int j = 0; j < pl; ++j) {
+            const int lc = a.b.len_class[off + gtv[j]], sc = a.b.str_class[off + gtv[j]];
+            if (lc < minl) { minl = lc; cl = 1; } else if (lc == minl) { cl++; }
+            if (sc < mins) { mins = sc; cs = 1; } else if (sc == mins) { cs++; }
+        }
+        hl = cl >= 2;
+        hs = cs >= 2;
+    }
+    if (tab) {
+        int32_t* x = tab + tab_alleles;
+        atomicAdd(&x[DX_CALLED], 1);
+        if (low) atomicAdd(&x[DX_LOW], 1);
+        if (hl) atomicAdd(&x[DX_HOML], 1);
+        if (hs) atomicAdd(&x[DX_HOMS], 1);
+    } else {
+        int32_t* li = a.out.delta_locus_int + (int64_t)l * TRK_LI_COLS;
+        atomicSub(&li[TRK_LI_N_CALLED], 1);
+        if (low) atomicSub(&li[TRK_LI_N_LOWPLOIDY], 1);
+        if (hl) atomicSub(&li[TRK_LI_N_HOM_LEN], 1);
+        if (hs) atomicSub(&li[TRK_LI_N_HOM_STR], 1);
+    }
+}
 
 template <bool VEC>  // VEC: P == 2 and S % 4 == 0 -> every thread's 4 cells are one aligned 16-byte chunk
 __global__ __launch_bounds__(CF_THREADS) void k_call_filter(const CallArgs a) {
@@ -989,6 +1034,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter(const CallArgs a) {
                         }
                     }
                 } else if (called) {  // filtered call: genotype := no-call (dumpSTR.py:721-727)
+                    if (a.out.delta_allele_count) delta_filtered_call(a, l, gtv, pl, nullptr, 0);
                     if (VEC) {
                         w[j] = 0xffffffffu;
                     } else if (a.out.gt_out) {
@@ -1053,9 +1099,40 @@ __device__ __forceinline__ void cf_load(const CallArgs& a, int64_t cell0, CfLocu
             d.pv[p] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.planes[p].data) + (cell0 >> 2));
 }
 
+// per-locus delta context of the streaming call-filter kernel (all in LDS, filled at block start)
+struct CfDelta {
+    int32_t* tab;         // [max_alleles + DX_N] counts removed from this locus
+    const uint32_t* lut;  // [max_alleles] lc | sc << 16
+    int A;                // alleles of this locus
+    int nal;              // max_alleles (offset of the DX_* entries)
+    bool dup;             // some alleles share a class: homozygosity needs the LUT
+};
+
+__device__ __forceinline__ void cf_delta_call(const CfDelta& c, uint32_t w, int pl) {
+    const int a0 = (int)(int16_t)(w & 0xffffu);
+    const int a1 = pl > 1 ? (int)(int16_t)(w >> 16) : -3;
+    const bool v0 = (unsigned)a0 < (unsigned)c.A, v1 = (unsigned)a1 < (unsigned)c.A;
+    if (v0) atomicAdd(&c.tab[a0], 1);
+    if (v1) atomicAdd(&c.tab[a1], 1);
+    int32_t* x = c.tab + c.nal;
+    atomicAdd(&x[DX_CALLED], 1);
+    if ((a0 == -2) | (a1 == -2)) {
+        atomicAdd(&x[DX_LOW], 1);
+    } else if (v0 & v1) {
+        bool hl = a0 == a1, hs = hl;
+        if (c.dup & !hl) {
+            const uint32_t q = c.lut[a0] ^ c.lut[a1];
+            hl = (q & 0xffffu) == 0u;
+            hs = (q >> 16) == 0u;
+        }
+        if (hl) atomicAdd(&x[DX_HOML], 1);
+        if (hs) atomicAdd(&x[DX_HOMS], 1);
+    }
+}
+
 __device__ __forceinline__ void cf_process(const CallArgs& a, int l, int64_t cell0, int64_t s0, int tid,
                                            const CfLocus& d, uint32_t* fcount, uint32_t* numcalls,
-                                           int64_t* totaldp, uint32_t* dpmiss) {
+                                           int64_t* totaldp, uint32_t* dpmiss, const CfDelta* dc) {
     const int nf = a.n_filters;
     const int pl = a.b.locus_ploidy ? min((int)a.b.locus_ploidy[l], 2) : 2;
     uint32_t w[CF_V] = {d.gt[0], d.gt[1], d.gt[2], d.gt[3]};
@@ -1137,6 +1214,7 @@ __device__ __forceinline__ void cf_process(const CallArgs& a, int l, int64_t cel
                 }
             }
         } else if (called[j]) {
+            if (dc && !(a.dbg & 1)) cf_delta_call(*dc, w[j], pl);
             w[j] = pl > 1 ? 0xffffffffu : (w[j] | 0xffffu);
         }
     }
@@ -1150,7 +1228,7 @@ __device__ __forceinline__ void cf_process(const CallArgs& a, int l, int64_t cel
 
 template <int U>
 __global__ __launch_bounds__(CF_THREADS) void k_call_filter_fast(const CallArgs a) {  // U: loci in flight per thread
-    extern __shared__ uint32_t fcount[];  // [n_filters][CF_THREADS * CF_V]
+    extern __shared__ uint32_t fcount[];  // [n_filters][CF_THREADS * CF_V], then the delta table
     const int tid = threadIdx.x;
     const int S = a.b.n_samples, L = a.b.n_loci;
     const int nf = a.n_filters;
@@ -1160,41 +1238,281 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_fast(const CallArgs 
     for (int k = 0; k < nf; ++k)
 #pragma unroll
         for (int j = 0; j < CF_V; ++j) fcount[(k * CF_THREADS + tid) * CF_V + j] = 0;
-    if (s0 >= S) return;  // S % 4 == 0: a thread's 4 samples are all in range or all out
-    uint32_t numcalls[CF_V] = {0, 0, 0, 0};
-    uint32_t dpmiss[CF_V] = {0, 0, 0, 0};
-    int64_t totaldp[CF_V] = {0, 0, 0, 0};
-    int l = l_begin;
-    for (; l + U <= l_end; l += U) {
-        CfLocus d[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) cf_load(a, (int64_t)(l + u) * S + s0, d[u]);
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            cf_process(a, l + u, (int64_t)(l + u) * S + s0, s0, tid, d[u], fcount, numcalls, totaldp, dpmiss);
+    // delta context in LDS: table [loci][max_alleles + 4], class LUT [loci][max_alleles], per-locus (A, dup)
+    int32_t* dbase = nullptr;
+    uint32_t* lutb = nullptr;
+    int32_t* linfo = nullptr;
+    const int dstride = a.delta_stride;
+    const int nal = dstride - DX_N;
+    const int nl = l_end - l_begin;
+    if (dstride) {
+        dbase = reinterpret_cast<int32_t*>(fcount + (size_t)nf * CF_THREADS * CF_V);
+        lutb = reinterpret_cast<uint32_t*>(dbase + (size_t)a.loci_per_block * dstride);
+        linfo = reinterpret_cast<int32_t*>(lutb + (size_t)a.loci_per_block * nal);
+        for (int i = tid; i < nl * dstride; i += CF_THREADS) dbase[i] = 0;
+        for (int li = tid; li < nl; li += CF_THREADS) {
+            const int off = a.b.allele_off[l_begin + li];
+            const int A = a.b.allele_off[l_begin + li + 1] - off;
+            int ml = 0, ms = 0;
+            for (int q = 0; q < A && q < nal; ++q) {
+                const int lc = a.b.len_class[off + q], sc = a.b.str_class[off + q];
+                lutb[li * nal + q] = (uint32_t)lc | ((uint32_t)sc << 16);
+                ml = lc > ml ? lc : ml;
+                ms = sc > ms ? sc : ms;
+            }
+            linfo[2 * li] = A;
+            linfo[2 * li + 1] = ((ml + 1 < A) | (ms + 1 < A)) ? 1 : 0;
+        }
+        __syncthreads();
     }
-    for (; l < l_end; ++l) {
-        CfLocus d;
-        cf_load(a, (int64_t)l * S + s0, d);
-        cf_process(a, l, (int64_t)l * S + s0, s0, tid, d, fcount, numcalls, totaldp, dpmiss);
-    }
+    if (s0 < S) {  // S % 4 == 0: a thread's 4 samples are all in range or all out
+        uint32_t numcalls[CF_V] = {0, 0, 0, 0};
+        uint32_t dpmiss[CF_V] = {0, 0, 0, 0};
+        int64_t totaldp[CF_V] = {0, 0, 0, 0};
+        for (int l = l_begin; l < l_end; l += U) {
+            CfLocus d[U];
 #pragma unroll
-    for (int j = 0; j < CF_V; ++j) {
-        const int64_t s = s0 + j;
-        if (numcalls[j])
-            atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_counters + s),
-                      (unsigned long long)numcalls[j]);
-        if (totaldp[j])
-            atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_totaldp + s),
-                      (unsigned long long)totaldp[j]);
-        if (dpmiss[j])
+            for (int u = 0; u < U; ++u)
+                if (l + u < l_end) cf_load(a, (int64_t)(l + u) * S + s0, d[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (l + u >= l_end) break;
+                CfDelta dc;
+                if (dstride) {
+                    const int li = l + u - l_begin;
+                    dc.tab = dbase + li * dstride;
+                    dc.lut = lutb + li * nal;
+                    dc.A = linfo[2 * li];
+                    dc.dup = linfo[2 * li + 1] != 0;
+                    dc.nal = nal;
+                }
+                cf_process(a, l + u, (int64_t)(l + u) * S + s0, s0, tid, d[u], fcount, numcalls, totaldp, dpmiss,
+                           dstride ? &dc : nullptr);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CF_V; ++j) {
+            const int64_t s = s0 + j;
+            if (numcalls[j])
+                atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_counters + s),
+                          (unsigned long long)numcalls[j]);
+            if (totaldp[j])
+                atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_totaldp + s),
+                          (unsigned long long)totaldp[j]);
+            if (dpmiss[j])
                 atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_dp_missing + s),
                           (unsigned long long)dpmiss[j]);
-        for (int k = 0; k < nf; ++k) {
-            uint32_t c = fcount[(k * CF_THREADS + tid) * CF_V + j];
-            if (c)
-                atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_counters + (int64_t)(1 + k) * S + s),
-                          (unsigned long long)c);
+            for (int k = 0; k < nf; ++k) {
+                uint32_t c = fcount[(k * CF_THREADS + tid) * CF_V + j];
+                if (c)
+                    atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_counters + (int64_t)(1 + k) * S + s),
+                              (unsigned long long)c);
+            }
+        }
+    }
+    if (dstride && !(a.dbg & 2)) {  // flush the block's delta table: one global atomic per non-zero entry
+        __syncthreads();
+        for (int i = tid; i < nl * dstride; i += CF_THREADS) {
+            const int v = dbase[i];
+            if (!v) continue;
+            const int l = l_begin + i / dstride;
+            const int r = i - (l - l_begin) * dstride;
+            if (r < nal) {
+                atomicSub(&a.out.delta_allele_count[a.b.allele_off[l] + r], v);
+            } else {
+                const int x = r - nal;
+                const int col = x == DX_CALLED ? TRK_LI_N_CALLED
+                                : x == DX_LOW  ? TRK_LI_N_LOWPLOIDY
+                                : x == DX_HOML ? TRK_LI_N_HOM_LEN
+                                               : TRK_LI_N_HOM_STR;
+                atomicSub(&a.out.delta_locus_int[(int64_t)l * TRK_LI_COLS + col], v);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_call_filter_v2 : the issue-lean streaming kernel for the common dumpSTR filter
+// sets (every filter a plain threshold on a single-column plane: min/max DP, min Q,
+// pre-parsed min supporting reads ...), diploid records, S % 4 == 0.
+// Profiling showed the generic streaming kernel to be instruction-issue bound
+// (~2300 issue cycles per wave per locus), not HBM bound.  Here
+//   * integer planes compare against pre-rounded int32 thresholds (one v_cmp),
+//     float planes against the float32 threshold (numpy's semantics);
+//   * per-sample filter counters live in registers (NF x 4, add-with-carry);
+//   * the only data-dependent branch is "this call is filtered" (a few %), whose
+//     body is four LDS atomics into the block's delta table (alleles to their bin
+//     or a trash slot, {called, low-ploidy} and {hom-by-length, hom-by-sequence}
+//     as two packed 16+16-bit words).
+// ---------------------------------------------------------------------------
+struct V2Filter {
+    const void* plane;    // [L,S] int32 or float32
+    int32_t kind;         // 0: int LT, 1: int GT, 2: float LT, 3: float GT
+    int32_t need_called;  // TRK_F_CALLED_LT
+    int32_t ithr;
+    float fthr;
+    int32_t bit;          // bit of this filter in the mask / row of sample_counters - 1
+    int32_t pad;
+};
+struct V2Args {
+    trk_batch b;
+    V2Filter f[4];
+    const int32_t* dp;    // DP/LC plane or nullptr
+    int loci_per_block;
+    int delta_nal;        // max_alleles when the delta outputs are requested, else 0
+    trk_call_out out;
+};
+enum { V2_TRASH = 0, V2_W0 = 1, V2_W1 = 2, V2_EXTRA = 3 };  // after the allele bins
+
+template <int NF, bool DELTA>
+__global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
+    extern __shared__ uint32_t v2lds[];
+    const int tid = threadIdx.x;
+    const int S = a.b.n_samples, L = a.b.n_loci;
+    const int64_t s0 = ((int64_t)blockIdx.x * CF_THREADS + tid) * CF_V;
+    const int l_begin = blockIdx.y * a.loci_per_block;
+    const int l_end = min(L, l_begin + a.loci_per_block);
+    const int nl = l_end - l_begin;
+    const int nal = a.delta_nal;
+    const int dstride = nal + V2_EXTRA;
+    uint32_t* dtab = v2lds;                                        // [loci][nal + 3]
+    uint32_t* lutb = dtab + (size_t)a.loci_per_block * dstride;    // [loci][nal]
+    int32_t* linfo = reinterpret_cast<int32_t*>(lutb + (size_t)a.loci_per_block * nal);  // [loci][2]
+    if (DELTA) {
+        for (int i = tid; i < nl * dstride; i += CF_THREADS) dtab[i] = 0;
+        for (int li = tid; li < nl; li += CF_THREADS) {
+            const int off = a.b.allele_off[l_begin + li];
+            const int A = a.b.allele_off[l_begin + li + 1] - off;
+            int ml = 0, ms = 0;
+            for (int q = 0; q < A && q < nal; ++q) {
+                const int lc = a.b.len_class[off + q], sc = a.b.str_class[off + q];
+                lutb[li * nal + q] = (uint32_t)lc | ((uint32_t)sc << 16);
+                ml = lc > ml ? lc : ml;
+                ms = sc > ms ? sc : ms;
+            }
+            linfo[2 * li] = A;
+            linfo[2 * li + 1] = ((ml + 1 < A) | (ms + 1 < A)) ? 1 : 0;
+        }
+        __syncthreads();
+    }
+    if (s0 < S) {
+        uint32_t numcalls[CF_V] = {0, 0, 0, 0}, dpmiss[CF_V] = {0, 0, 0, 0};
+        uint32_t fc[NF][CF_V];
+        int64_t totaldp[CF_V] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < NF; ++k)
+#pragma unroll
+            for (int j = 0; j < CF_V; ++j) fc[k][j] = 0;
+        for (int l = l_begin; l < l_end; ++l) {
+            const int64_t c4 = ((int64_t)l * S + s0) >> 2;
+            const u32x4 g = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.b.gt) + c4);
+            u32x4 pv[NF];
+#pragma unroll
+            for (int k = 0; k < NF; ++k)
+                pv[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.f[k].plane) + c4);
+            u32x4 dv = {0, 0, 0, 0};
+            if (a.dp) dv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.dp) + c4);
+            u32x4 wout, mout;
+#pragma unroll
+            for (int j = 0; j < CF_V; ++j) {
+                const uint32_t w = g[j];
+                const bool called = ((w & 0xffffu) != 0xffffu) & ((w >> 16) != 0xffffu);
+                uint32_t m = called ? 0u : TRK_MASK_NOCALL;
+#pragma unroll
+                for (int k = 0; k < NF; ++k) {
+                    const V2Filter& f = a.f[k];
+                    bool hit;
+                    if (f.kind & 2) {
+                        const float v = __uint_as_float(pv[k][j]);
+                        hit = (f.kind & 1) ? (v > f.fthr) : (v < f.fthr);
+                    } else {
+                        const int32_t v = (int32_t)pv[k][j];
+                        hit = (f.kind & 1) ? (v > f.ithr) : (v < f.ithr);
+                    }
+                    hit &= called | (f.need_called == 0);
+                    m |= hit ? (1u << f.bit) : 0u;
+                    fc[k][j] += hit & called;  // dumpSTR.py:661
+                }
+                const bool pass = m == 0u;  // dumpSTR.py:686
+                numcalls[j] += pass;
+                if (a.dp) {
+                    const int32_t d = (int32_t)dv[j];
+                    dpmiss[j] += pass & (d == INT32_MIN);
+                    totaldp[j] += (pass & (d > 0)) ? d : 0;
+                    if (pass & (d < 0) & (d != INT32_MIN)) {  // dumpSTR.py:698-706
+                        if (atomicCAS(&a.out.error[0], 0, 1) == 0) {
+                            a.out.error[1] = l;
+                            a.out.error[2] = (int32_t)(s0 + j);
+                        }
+                    }
+                }
+                const bool filtered = called & !pass;  // dumpSTR.py:715-727
+                if (DELTA) {
+                    if (filtered) {
+                        const int li = l - l_begin;
+                        uint32_t* tab = dtab + li * dstride;
+                        const int A = linfo[2 * li];
+                        const int a0 = (int)(int16_t)(w & 0xffffu), a1 = (int)(int16_t)(w >> 16);
+                        const bool v0 = (unsigned)a0 < (unsigned)A, v1 = (unsigned)a1 < (unsigned)A;
+                        atomicAdd(&tab[v0 ? a0 : nal + V2_TRASH], 1u);
+                        atomicAdd(&tab[v1 ? a1 : nal + V2_TRASH], 1u);
+                        const bool low = (a0 == -2) | (a1 == -2);
+                        bool hl = (a0 == a1) & v0, hs = hl;
+                        if (linfo[2 * li + 1] && v0 && v1 && !hl) {
+                            const uint32_t q = lutb[li * nal + a0] ^ lutb[li * nal + a1];
+                            hl = (q & 0xffffu) == 0u;
+                            hs = (q >> 16) == 0u;
+                        }
+                        atomicAdd(&tab[nal + V2_W0], 1u + (low ? 0x10000u : 0u));
+                        const uint32_t w1 = (hl ? 1u : 0u) + (hs ? 0x10000u : 0u);
+                        if (w1) atomicAdd(&tab[nal + V2_W1], w1);
+                    }
+                }
+                wout[j] = filtered ? 0xffffffffu : w;
+                mout[j] = m;
+            }
+            if (a.out.gt_out) __builtin_nontemporal_store(wout, reinterpret_cast<u32x4*>(a.out.gt_out) + c4);
+            if (a.out.filter_mask) __builtin_nontemporal_store(mout, reinterpret_cast<u32x4*>(a.out.filter_mask) + c4);
+        }
+#pragma unroll
+        for (int j = 0; j < CF_V; ++j) {
+            const int64_t s = s0 + j;
+            if (numcalls[j])
+                atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_counters + s),
+                          (unsigned long long)numcalls[j]);
+            if (totaldp[j])
+                atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_totaldp + s),
+                          (unsigned long long)totaldp[j]);
+            if (dpmiss[j])
+                atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_dp_missing + s),
+                          (unsigned long long)dpmiss[j]);
+#pragma unroll
+            for (int k = 0; k < NF; ++k)
+                if (fc[k][j])
+                    atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_counters +
+                                                                    (int64_t)(1 + a.f[k].bit) * S + s),
+                              (unsigned long long)fc[k][j]);
+        }
+    }
+    if (DELTA) {  // one global atomic per non-zero entry of the block's delta table
+        __syncthreads();
+        for (int i = tid; i < nl * dstride; i += CF_THREADS) {
+            const uint32_t v = dtab[i];
+            if (!v) continue;
+            const int li = i / dstride;
+            const int r = i - li * dstride;
+            const int l = l_begin + li;
+            if (r < nal) {
+                atomicSub(&a.out.delta_allele_count[a.b.allele_off[l] + r], (int)v);
+            } else if (r == nal + V2_W0) {
+                int32_t* li_ = a.out.delta_locus_int + (int64_t)l * TRK_LI_COLS;
+                atomicSub(&li_[TRK_LI_N_CALLED], (int)(v & 0xffffu));
+                if (v >> 16) atomicSub(&li_[TRK_LI_N_LOWPLOIDY], (int)(v >> 16));
+            } else if (r == nal + V2_W1) {
+                int32_t* li_ = a.out.delta_locus_int + (int64_t)l * TRK_LI_COLS;
+                if (v & 0xffffu) atomicSub(&li_[TRK_LI_N_HOM_LEN], (int)(v & 0xffffu));
+                if (v >> 16) atomicSub(&li_[TRK_LI_N_HOM_STR], (int)(v >> 16));
+            }
         }
     }
 }
@@ -1521,7 +1839,91 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
     a.loci_per_block = lpb;
     size_t lds = (size_t)n_filters * CF_THREADS * CF_V * sizeof(uint32_t);
     const bool vec = (b.ploidy == 2) && (S % 4 == 0);
-    a.fast_plane_mask = a.fast_filter_mask = a.slow_filter_mask = a.pad0 = 0;
+    a.fast_plane_mask = a.fast_filter_mask = a.slow_filter_mask = 0;
+    a.delta_stride = 0;
+    a.dbg = getenv("TRK_CF_DBG") ? atoi(getenv("TRK_CF_DBG")) : 0;
+    bool lds_delta = false;
+    if (out.delta_allele_count && vec && b.max_alleles > 0) {
+        // the delta table must fit next to the filter counters: shrink the locus block if needed
+        const int stride = b.max_alleles + DX_N;
+        const size_t per_locus = ((size_t)stride + b.max_alleles + 2) * sizeof(int32_t);  // table + LUT + info
+        const size_t budget = 24 * 1024;
+        if (per_locus * 8 <= budget) {
+            int max_lpb = (int)(budget / per_locus);
+            if (lpb > max_lpb) {
+                lpb = max_lpb;
+                gy = (L + lpb - 1) / lpb;
+                a.loci_per_block = lpb;
+            }
+            lds_delta = true;
+            a.delta_stride = stride;
+        }
+    }
+    // ---- issue-lean kernel: every filter a plain threshold on a single-column plane ----
+    if (vec && !b.locus_ploidy && n_filters >= 1 && n_filters <= 4 && !getenv("TRK_CF_GENERIC")) {
+        V2Args v;
+        bool ok = true;
+        for (int k = 0; k < n_filters && ok; ++k) {
+            const trk_call_filter& f = filters[k];
+            const trk_plane& pl = planes[f.plane_a];
+            ok = (f.op == TRK_F_LT || f.op == TRK_F_GT || f.op == TRK_F_CALLED_LT) && pl.ncol == 1 &&
+                 ((uintptr_t)pl.data & 15u) == 0 && f.thr == f.thr;
+            if (!ok) break;
+            V2Filter& o = v.f[k];
+            o.plane = pl.data;
+            o.need_called = f.op == TRK_F_CALLED_LT;
+            o.bit = k;
+            o.pad = 0;
+            o.ithr = 0;
+            o.fthr = 0.f;
+            const bool gt_op = f.op == TRK_F_GT;
+            if (pl.dtype == TRK_DT_F32) {
+                o.kind = 2 | (gt_op ? 1 : 0);
+                o.fthr = (float)f.thr;
+            } else {
+                // (double)v < thr  <=>  v < ceil(thr);   (double)v > thr  <=>  v > floor(thr)
+                const double t = gt_op ? floor(f.thr) : ceil(f.thr);
+                if (!(t > -2147483647.0 && t < 2147483647.0)) ok = false;
+                o.kind = gt_op ? 1 : 0;
+                o.ithr = (int32_t)t;
+            }
+        }
+        if (ok && dp_plane >= 0 && (planes[dp_plane].ncol != 1 || ((uintptr_t)planes[dp_plane].data & 15u))) ok = false;
+        const bool delta = out.delta_allele_count != nullptr;
+        if (ok && delta && !(b.max_alleles > 0 && b.max_alleles <= 120)) ok = false;
+        if (ok) {
+            v.b = b;
+            v.dp = dp_plane >= 0 ? reinterpret_cast<const int32_t*>(planes[dp_plane].data) : nullptr;
+            v.out = out;
+            v.delta_nal = delta ? b.max_alleles : 0;
+            size_t lds2 = 0;
+            if (delta) {
+                const size_t per_locus = ((size_t)2 * b.max_alleles + V2_EXTRA + 2) * sizeof(uint32_t);
+                int max_lpb = (int)((32 * 1024) / per_locus);
+                if (lpb > max_lpb) lpb = max_lpb;
+                lds2 = (size_t)lpb * per_locus;
+            }
+            if (const char* e = getenv("TRK_CF_LPB")) {
+                int q = atoi(e);
+                if (q > 0 && (!delta || q <= lpb)) lpb = q;
+                if (delta) lds2 = (size_t)lpb * ((size_t)2 * b.max_alleles + V2_EXTRA + 2) * sizeof(uint32_t);
+            }
+            gy = (L + lpb - 1) / lpb;
+            v.loci_per_block = lpb;
+            dim3 grid(gx, gy), block(CF_THREADS);
+#define TRK_V2(NFV)                                                                                   \
+    if (delta)                                                                                        \
+        hipLaunchKernelGGL((k_call_filter_v2<NFV, true>), grid, block, lds2, stream, v);               \
+    else                                                                                              \
+        hipLaunchKernelGGL((k_call_filter_v2<NFV, false>), grid, block, 0, stream, v)
+            if (n_filters == 1) { TRK_V2(1); }
+            else if (n_filters == 2) { TRK_V2(2); }
+            else if (n_filters == 3) { TRK_V2(3); }
+            else { TRK_V2(4); }
+#undef TRK_V2
+            return hipGetLastError();
+        }
+    }
     if (vec) {
         for (int p = 0; p < n_planes && p < CF_FASTP; ++p)
             if (planes[p].ncol == 1 && ((uintptr_t)planes[p].data & 15u) == 0) a.fast_plane_mask |= 1u << p;
@@ -1536,11 +1938,18 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
         // experiment knobs (tools/perf_sweep.py): TRK_CF_LPB = loci per block, TRK_CF_U = loci in flight
         if (const char* e = getenv("TRK_CF_LPB")) {
             int v = atoi(e);
-            if (v > 0) {
+            if (v > 0 && !lds_delta) {
                 a.loci_per_block = v;
                 gy = (L + v - 1) / v;
             }
         }
+        if (out.delta_allele_count && !lds_delta) {
+            // no room for an LDS table (huge allele sets): per-call evaluation with global atomics
+            hipLaunchKernelGGL(k_call_filter<false>, dim3(gx, gy), dim3(CF_THREADS), lds, stream, a);
+            return hipGetLastError();
+        }
+        if (lds_delta)
+            lds += (size_t)a.loci_per_block * ((size_t)a.delta_stride + b.max_alleles + 2) * sizeof(int32_t);
         int cf_u = 1;  // measured: U=1 == U=2 (3.8 ms), U=4 spills (profiles/r01_notes.md)
         if (const char* e = getenv("TRK_CF_U")) cf_u = atoi(e);
         if (cf_u == 1)

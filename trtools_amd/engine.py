@@ -48,6 +48,14 @@ class DeviceArray:
             self.eng._chk(self.eng.lib.trk_memcpy_h2d(self.eng.ctx, self.ptr, arr.ctypes.data, self.nbytes))
         return self
 
+    def copy_from(self, other):
+        """Device-to-device copy (async on the engine's stream)."""
+        if other.nbytes != self.nbytes:
+            raise ValueError("size mismatch")
+        if self.nbytes:
+            self.eng._chk(self.eng.lib.trk_memcpy_d2d(self.eng.ctx, self.ptr, other.ptr, self.nbytes))
+        return self
+
     def zero(self):
         if self.nbytes:
             self.eng._chk(self.eng.lib.trk_memset(self.eng.ctx, self.ptr, 0, self.nbytes))
@@ -99,7 +107,16 @@ class CallResult:
         self.sample_dp_missing = sample_dp_missing
         self.error = error
         self.struct = L.CallOut(gt_out.ptr if gt_out else None, filter_mask.ptr if filter_mask else None,
-                                sample_counters.ptr, sample_totaldp.ptr, sample_dp_missing.ptr, error.ptr)
+                                sample_counters.ptr, sample_totaldp.ptr, sample_dp_missing.ptr, error.ptr,
+                                None, None)
+
+    def with_delta(self, stats):
+        """trk_call_out whose delta outputs point at ``stats`` (counts of the unfiltered genotypes)."""
+        s = L.CallOut()
+        C.memmove(C.byref(s), C.byref(self.struct), C.sizeof(L.CallOut))
+        s.delta_allele_count = stats.allele_count.ptr
+        s.delta_locus_int = stats.locus_int.ptr
+        return s
 
 
 class Engine:
@@ -247,9 +264,17 @@ class Engine:
             self.zeros((1 + n_filters, S), np.int64), self.zeros((S,), np.int64),
             self.zeros((S,), np.int64), self.zeros((4,), np.int32))
 
-    def call_filters(self, batch, planes, filters, dp_plane=-1, out=None):
+    def locus_finalize(self, batch, stats, nalleles_thresh=0.01):
+        """Float statistics + HWE test from counts already in ``stats`` (trk_locus_finalize)."""
+        prm = L.StatsParams(float(nalleles_thresh), 0, 0)
+        self._chk(self.lib.trk_locus_finalize(self.ctx, C.byref(batch.struct), C.byref(prm), C.byref(stats.struct)))
+        return stats
+
+    def call_filters(self, batch, planes, filters, dp_plane=-1, out=None, delta_stats=None):
         """planes: list of DeviceArray ([L,S] or [L,S,k], int32/float32);
-        filters: list of dicts(op, plane_a, col_a=0, plane_b=-1, col_b=0, col_a2=0, thr=0.0)."""
+        filters: list of dicts(op, plane_a, col_a=0, plane_b=-1, col_b=0, col_a2=0, thr=0.0);
+        delta_stats: StatsResult holding the counts of the unfiltered genotypes, corrected in place
+        to the counts of the masked genotypes (no second pass over the tensor)."""
         np_ = len(planes)
         nf = len(filters)
         if np_ > L.TRK_MAX_PLANES or nf > L.TRK_MAX_FILTERS:
@@ -273,8 +298,9 @@ class Engine:
                                    int(f.get('col_a2', 0)), float(f.get('thr', 0.0)))
         if out is None:
             out = self.alloc_call_out(batch, nf)
+        ostruct = out.struct if delta_stats is None else out.with_delta(delta_stats)
         self._chk(self.lib.trk_call_filters(self.ctx, C.byref(batch.struct), parr, np_, farr, nf,
-                                            int(dp_plane), C.byref(out.struct)))
+                                            int(dp_plane), C.byref(ostruct)))
         return out
 
     def locus_filters(self, n_loci, stats, min_callrate=None, min_hwep=None, min_het=None, max_het=None,
