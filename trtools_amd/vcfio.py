@@ -315,6 +315,8 @@ def _fmt_float(x):
 
 
 def _fmt_info(v):
+    if v is None:
+        return '.'
     if isinstance(v, float):
         return _fmt_float(v)
     return str(v)
@@ -337,6 +339,9 @@ class VCFReader:
         self.samples = []
         self.info_types = {}
         self.format_types = {}
+        self.contigs_declared = set()
+        self.contigs_seen = []      # CHROMs of parsed records that the header does not declare
+        self.has_pass_filter = False
         self._pending = None
         saw_chrom = False
         for line in self._fh:
@@ -367,6 +372,10 @@ class VCFReader:
             self.info_types[d.get('ID')] = (d.get('Type'), d.get('Number'))
         elif kind == 'FORMAT':
             self.format_types[d.get('ID')] = (d.get('Type'), d.get('Number'))
+        elif kind == 'contig':
+            self.contigs_declared.add(d.get('ID'))
+        elif kind == 'FILTER' and d.get('ID') == 'PASS':
+            self.has_pass_filter = True
 
     @property
     def raw_header(self):
@@ -436,6 +445,8 @@ class VCFReader:
             if line.strip() == '':
                 continue
             v = Variant(self, line)
+            if v.CHROM not in self.contigs_declared and v.CHROM not in self.contigs_seen:
+                self.contigs_seen.append(v.CHROM)   # htslib adds a dummy ##contig line for these
             if self._region is not None and not self._in_region(v):
                 continue
             return v
@@ -471,18 +482,38 @@ class _HeaderRec(dict):
 
 
 class VCFWriter:
-    """Plain-text VCF writer (``cyvcf2.Writer`` stand-in: write_record, close)."""
+    """Plain-text VCF writer (``cyvcf2.Writer`` stand-in: write_record, close).
+
+    Like htslib the header is emitted with the first record (or on close) and completed with
+    what htslib adds on its own: ``##FILTER=<ID=PASS,...>`` after the fileformat line and a bare
+    ``##contig=<ID=...>`` line for every contig the records used without declaring it."""
 
     def __init__(self, path, template):
         self.path = path
+        self._tmpl = template
+        self._wrote_header = False
         if path.endswith('.gz'):
             self._fh = gzip.open(path, 'wt')
         else:
             self._fh = open(path, 'w')
-        self._fh.write(template.raw_header)
+
+    def _header(self):
+        t = self._tmpl
+        lines = list(t._header_lines)
+        if not t.has_pass_filter:
+            at = 1 if lines and lines[0].startswith('##fileformat') else 0
+            lines.insert(at, '##FILTER=<ID=PASS,Description="All filters passed">')
+        for c in t.contigs_seen:
+            lines.append('##contig=<ID=%s>' % c)
+        self._fh.write('\n'.join(lines + [t._chrom_line]) + '\n')
+        self._wrote_header = True
 
     def write_record(self, variant):
+        if not self._wrote_header:
+            self._header()
         self._fh.write(str(variant))
 
     def close(self):
+        if not self._wrote_header:
+            self._header()
         self._fh.close()
