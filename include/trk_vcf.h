@@ -1,0 +1,74 @@
+/*
+ * trk_vcf.h -- C ABI of the native VCF / BGZF reader in libtrk.so.
+ *
+ * it replaces, for the hot path, what the reference gets from
+ * cyvcf2/htslib (trtools/utils/utils.py:19-67 LoadSingleReader -> cyvcf2.VCF;
+ * Variant.genotype.array() consumed at tr_harmonizer.py:860-862; Variant.format(key) consumed
+ * through tr_harmonizer.py:561-588) -- decoding straight into the packed batch layout of
+ * trk_batch (include/trk.h) instead of one Python object per sample field:
+ *
+ *   gt      int16 [n, S, P]   allele indices, -1 missing haplotype, -2 ploidy padding
+ *   phased  uint8 [n, S]      cyvcf2's phase column ('|' seen in the GT)
+ *   planes  int32 / float32 [n, S, ncol]   selected FORMAT fields, cyvcf2 conventions:
+ *           Integer missing = INT_MIN, short vectors padded with INT_MIN + 1, Float missing = NaN
+ *           (floats go text -> double -> float, as htslib does)
+ *
+ * BGZF blocks are inflated and records are parsed by a pool of host threads.  Host code only.
+ */
+#ifndef TRK_VCF_H
+#define TRK_VCF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct trk_vcf trk_vcf;
+
+enum {
+    TRK_VCF_INT = 0,        /* comma separated integers                                      */
+    TRK_VCF_FLOAT = 1,      /* comma separated floats                                        */
+    TRK_VCF_INT_RANGES = 2, /* integers separated by ',' or '-'  (GangSTR REPCI 'lo-hi,lo-hi') */
+    TRK_VCF_MINSUPP = 3     /* HipSTR: min over the GB alleles of the ALLREADS read count
+                               ('len|count;...'), 0 when ALLREADS is missing; 1 column
+                               (reference dumpSTR/filters.py:519-567)                        */
+};
+
+/* Open a plain / gzip / bgzip VCF and read its header.  n_threads <= 0: all cores. */
+int trk_vcf_open(const char* path, int n_threads, trk_vcf** out);
+void trk_vcf_close(trk_vcf* v);
+const char* trk_vcf_last_error(trk_vcf* v);  /* v may be NULL: last open error */
+/* header text ('##...' lines and the '#CHROM' line, '\n' separated) */
+const char* trk_vcf_header(trk_vcf* v, size_t* len);
+int trk_vcf_n_samples(trk_vcf* v);
+const char* trk_vcf_sample_name(trk_vcf* v, int i);
+
+/* Ask for a FORMAT field to be decoded into a plane; returns the plane index (>= 0) or < 0. */
+int trk_vcf_select_format(trk_vcf* v, const char* key, int kind, int ncol);
+
+typedef struct {
+    int32_t n_records;       /* records decoded by this call (0 = end of file)              */
+    int32_t max_ploidy;      /* P of the gt tensor                                          */
+    int16_t* gt;             /* [max_records, S, P]  caller-owned                            */
+    uint8_t* phased;         /* [max_records, S]     caller-owned, may be NULL              */
+    uint8_t* locus_ploidy;   /* [max_records]        caller-owned                            */
+    void** planes;           /* [n_selected] caller-owned buffers [max_records, S, ncol]    */
+    /* the record lines themselves (for the fixed columns and anything not decoded above):
+     * text[line_off[i] .. line_end[i]) is record i (no newline);
+     * field_off[i*10 + k] is the offset inside the line of column k (k = 0..8: CHROM..FORMAT,
+     * k = 9: first sample column).  Owned by the reader, valid until the next call.        */
+    const char* text;
+    const int64_t* line_off;
+    const int64_t* line_end;
+    const int32_t* field_off;
+} trk_vcf_batch;
+
+/* Decode up to max_records records.  Returns 0, or a non-zero code with trk_vcf_last_error(). */
+int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batch* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,570 @@
+// trk_vcf.cpp -- native VCF / BGZF reader (host C++17, zlib): decodes records straight into
+// the packed batch layout of include/trk.h.  See include/trk_vcf.h for the contract and the
+// reference call sites it stands in for (cyvcf2 behind trtools/utils/utils.py:19-67).
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <charconv>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/trk_vcf.h"
+
+namespace {
+
+constexpr int32_t INT_MISSING = INT32_MIN;
+constexpr int32_t INT_VECTOR_END = INT32_MIN + 1;
+std::string g_open_error;
+
+// ---------------------------------------------------------------------------------------
+// input: plain text, gzip stream, or BGZF (block-parallel inflate)
+// ---------------------------------------------------------------------------------------
+struct Source {
+    FILE* fp = nullptr;
+    gzFile gz = nullptr;
+    bool bgzf = false, plain = false, eof = false;
+    int n_threads = 1;
+    std::vector<unsigned char> cbuf;  // compressed bytes not yet consumed (BGZF)
+    size_t cpos = 0;
+
+    bool open(const char* path, int threads, std::string& err) {
+        n_threads = threads;
+        fp = fopen(path, "rb");
+        if (!fp) {
+            err = std::string("cannot open ") + path;
+            return false;
+        }
+        unsigned char h[18];
+        size_t n = fread(h, 1, sizeof h, fp);
+        rewind(fp);
+        if (n >= 2 && h[0] == 0x1f && h[1] == 0x8b) {
+            // BGZF: FEXTRA set, extra subfield 'B','C' of length 2
+            bgzf = n >= 18 && (h[3] & 4) && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0;
+            if (!bgzf) {
+                fclose(fp);
+                fp = nullptr;
+                gz = gzopen(path, "rb");
+                if (!gz) {
+                    err = std::string("gzopen failed for ") + path;
+                    return false;
+                }
+                gzbuffer(gz, 1 << 20);
+            }
+        } else {
+            plain = true;
+        }
+        return true;
+    }
+    void close() {
+        if (fp) fclose(fp);
+        if (gz) gzclose(gz);
+        fp = nullptr;
+        gz = nullptr;
+    }
+
+    // append at least `want` decompressed bytes to out (fewer only at end of file)
+    bool fill(std::string& out, size_t want, std::string& err) {
+        size_t start = out.size();
+        while (!eof && out.size() - start < want) {
+            if (plain || gz) {
+                size_t chunk = std::max<size_t>(want, 1 << 22);
+                size_t old = out.size();
+                out.resize(old + chunk);
+                long got = plain ? (long)fread(&out[old], 1, chunk, fp) : (long)gzread(gz, &out[old], (unsigned)chunk);
+                if (got < 0) {
+                    err = "read error";
+                    return false;
+                }
+                out.resize(old + (size_t)got);
+                if ((size_t)got < chunk) eof = true;
+            } else {
+                if (!fill_bgzf(out, want, err)) return false;
+            }
+        }
+        return true;
+    }
+
+    bool fill_bgzf(std::string& out, size_t want, std::string& err) {
+        // top up the compressed buffer
+        if (cpos > 0 && cpos == cbuf.size()) {
+            cbuf.clear();
+            cpos = 0;
+        }
+        size_t target = std::max<size_t>(want / 3, 8u << 20);
+        if (cbuf.size() - cpos < target) {
+            if (cpos > 0) {
+                cbuf.erase(cbuf.begin(), cbuf.begin() + (long)cpos);
+                cpos = 0;
+            }
+            size_t old = cbuf.size();
+            cbuf.resize(old + target);
+            size_t got = fread(cbuf.data() + old, 1, target, fp);
+            cbuf.resize(old + got);
+        }
+        // index complete blocks
+        struct Blk { size_t off, csize, isize, dst; };
+        std::vector<Blk> blks;
+        size_t p = cpos, total = 0;
+        while (p + 18 <= cbuf.size()) {
+            const unsigned char* h = cbuf.data() + p;
+            if (h[0] != 0x1f || h[1] != 0x8b) {
+                err = "corrupt BGZF block header";
+                return false;
+            }
+            size_t bsize = ((size_t)h[16] | ((size_t)h[17] << 8)) + 1;
+            if (p + bsize > cbuf.size()) break;
+            size_t isize = (size_t)h[bsize - 4] | ((size_t)h[bsize - 3] << 8) | ((size_t)h[bsize - 2] << 16) |
+                           ((size_t)h[bsize - 1] << 24);
+            blks.push_back({p, bsize, isize, total});
+            total += isize;
+            p += bsize;
+        }
+        if (blks.empty()) {
+            if (cbuf.size() - cpos == 0 || feof(fp)) {
+                eof = true;
+                return true;
+            }
+            err = "truncated BGZF block";
+            return false;
+        }
+        size_t base = out.size();
+        out.resize(base + total);
+        std::atomic<size_t> next{0};
+        std::atomic<bool> bad{false};
+        auto work = [&]() {
+            for (;;) {
+                size_t i = next.fetch_add(1);
+                if (i >= blks.size()) break;
+                const Blk& b = blks[i];
+                if (b.isize == 0) continue;
+                z_stream zs;
+                memset(&zs, 0, sizeof zs);
+                if (inflateInit2(&zs, -15) != Z_OK) {
+                    bad = true;
+                    return;
+                }
+                const unsigned char* h = cbuf.data() + b.off;
+                size_t xlen = (size_t)h[10] | ((size_t)h[11] << 8);
+                zs.next_in = const_cast<unsigned char*>(h + 12 + xlen);
+                zs.avail_in = (unsigned)(b.csize - 12 - xlen - 8);
+                zs.next_out = reinterpret_cast<unsigned char*>(&out[base + b.dst]);
+                zs.avail_out = (unsigned)b.isize;
+                int rc = inflate(&zs, Z_FINISH);
+                inflateEnd(&zs);
+                if (rc != Z_STREAM_END) bad = true;
+            }
+        };
+        int nt = std::max(1, std::min<int>(n_threads, (int)blks.size()));
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work);
+        work();
+        for (auto& t : th) t.join();
+        if (bad) {
+            err = "BGZF inflate failed";
+            return false;
+        }
+        cpos = p;
+        if (cpos == cbuf.size() && feof(fp)) eof = true;
+        return true;
+    }
+};
+
+struct PlaneSel {
+    std::string key;
+    int kind, ncol;
+};
+
+}  // namespace
+
+struct trk_vcf {
+    Source src;
+    std::string err;
+    std::string header;
+    std::vector<std::string> samples;
+    std::vector<PlaneSel> planes;
+    std::string buf;     // decompressed text: [consumed .. pending)
+    size_t pos = 0;      // start of unconsumed text in buf
+    std::vector<int64_t> line_off, line_end;
+    std::vector<int32_t> field_off;
+    int n_threads = 1;
+};
+
+namespace {
+
+inline const char* find_ch(const char* p, const char* e, char c) {
+    const void* r = memchr(p, c, (size_t)(e - p));
+    return r ? static_cast<const char*>(r) : e;
+}
+
+inline int32_t parse_int(const char* p, const char* e) {
+    if (p == e || (e - p == 1 && *p == '.')) return INT_MISSING;
+    long long v = 0;
+    auto r = std::from_chars(p, e, v);
+    if (r.ec != std::errc()) return INT_MISSING;
+    return (int32_t)v;
+}
+
+inline float parse_float(const char* p, const char* e) {
+    if (p == e || (e - p == 1 && *p == '.')) return NAN;
+    double d = 0;
+    auto r = std::from_chars(p, e, d);  // text -> double -> float (htslib / python float() path)
+    if (r.ec != std::errc()) {
+        std::string s(p, e);
+        d = strtod(s.c_str(), nullptr);  // nan / inf spellings
+    }
+    return (float)d;
+}
+
+// one subfield -> ncol values
+inline void parse_list(const char* p, const char* e, int kind, int ncol, void* dst) {
+    if (kind == TRK_VCF_FLOAT) {
+        float* o = static_cast<float*>(dst);
+        int j = 0;
+        while (j < ncol) {
+            const char* q = find_ch(p, e, ',');
+            o[j++] = parse_float(p, q);
+            if (q == e) break;
+            p = q + 1;
+        }
+        for (; j < ncol; ++j) o[j] = NAN;
+    } else {
+        int32_t* o = static_cast<int32_t*>(dst);
+        int j = 0;
+        if (e - p == 1 && *p == '.') {
+            o[0] = INT_MISSING;
+            j = 1;
+        } else {
+            while (j < ncol) {
+                const char* q = p;
+                // a leading '-' belongs to the number; later '-' separate ranges when asked to
+                if (q < e && *q == '-') ++q;
+                while (q < e && *q != ',' && !(kind == TRK_VCF_INT_RANGES && *q == '-')) ++q;
+                o[j++] = parse_int(p, q);
+                if (q == e) break;
+                p = q + 1;
+            }
+        }
+        for (; j < ncol; ++j) o[j] = (j == 0) ? INT_MISSING : INT_VECTOR_END;
+    }
+}
+
+// HipSTR minimum supporting reads of one call (filters.py:519-567 pre-parse)
+inline int32_t min_supp(const char* gb, const char* gbe, const char* ar, const char* are) {
+    if (!ar || ar == are || (are - ar == 1 && *ar == '.')) return 0;
+    if (!gb || gb == gbe) return 0;
+    int32_t best = INT32_MAX;
+    const char* p = gb;
+    while (p <= gbe) {
+        const char* q = p;
+        if (q < gbe && *q == '-') ++q;
+        while (q < gbe && *q != '|' && *q != '/') ++q;
+        int32_t allele = parse_int(p, q);
+        int32_t count = 0;
+        const char* a = ar;
+        while (a < are) {
+            const char* semi = find_ch(a, are, ';');
+            const char* bar = find_ch(a, semi, '|');
+            if (bar < semi && parse_int(a, bar) == allele) {
+                count = parse_int(bar + 1, semi);
+                break;
+            }
+            a = semi + 1;
+        }
+        best = std::min(best, count);
+        if (q >= gbe) break;
+        p = q + 1;
+    }
+    return best == INT32_MAX ? 0 : best;
+}
+
+struct RecordJob {
+    trk_vcf* v;
+    const char* text;
+    int S, P;
+    trk_vcf_batch* out;
+    std::atomic<int> error{0};
+};
+
+void parse_record(RecordJob& job, int rec) {
+    trk_vcf* v = job.v;
+    const int S = job.S, P = job.P;
+    const char* line = job.text + v->line_off[rec];
+    const char* end = job.text + v->line_end[rec];
+    int32_t* foff = &v->field_off[(size_t)rec * 10];
+    const char* p = line;
+    for (int k = 0; k < 10; ++k) {
+        foff[k] = (int32_t)(p - line);
+        if (k == 9) break;
+        const char* t = find_ch(p, end, '\t');
+        if (t == end) {
+            for (int kk = k + 1; kk < 10; ++kk) foff[kk] = (int32_t)(end - line);
+            break;
+        }
+        p = t + 1;
+    }
+    int16_t* gt = job.out->gt + (size_t)rec * S * P;
+    uint8_t* ph = job.out->phased ? job.out->phased + (size_t)rec * S : nullptr;
+    for (size_t i = 0; i < (size_t)S * P; ++i) gt[i] = -2;
+    if (ph) memset(ph, 0, (size_t)S);
+    const int np = (int)v->planes.size();
+    // FORMAT keys -> subfield index of GT and of every selected plane's inputs
+    const char* fmt = line + foff[8];
+    const char* fmt_end = (foff[9] > foff[8]) ? line + foff[9] - 1 : end;
+    int gt_idx = -1;
+    std::vector<int> pidx(np, -1), pidx2(np, -1);
+    {
+        int k = 0;
+        const char* a = fmt;
+        while (a <= fmt_end && a < end) {
+            const char* b = find_ch(a, fmt_end, ':');
+            size_t n = (size_t)(b - a);
+            if (n == 2 && a[0] == 'G' && a[1] == 'T') gt_idx = k;
+            for (int i = 0; i < np; ++i) {
+                const PlaneSel& ps = v->planes[i];
+                if (ps.kind == TRK_VCF_MINSUPP) {
+                    if (n == 2 && a[0] == 'G' && a[1] == 'B') pidx[i] = k;
+                    if (n == 8 && memcmp(a, "ALLREADS", 8) == 0) pidx2[i] = k;
+                } else if (ps.key.size() == n && memcmp(ps.key.data(), a, n) == 0) {
+                    pidx[i] = k;
+                }
+            }
+            ++k;
+            if (b >= fmt_end) break;
+            a = b + 1;
+        }
+    }
+    int max_needed = gt_idx;
+    for (int i = 0; i < np; ++i) max_needed = std::max(max_needed, std::max(pidx[i], pidx2[i]));
+    int maxpl = 1;
+    const char* sp = line + foff[9];
+    std::vector<const char*> sub_b((size_t)max_needed + 2), sub_e((size_t)max_needed + 2);
+    for (int s = 0; s < S; ++s) {
+        const char* se = find_ch(sp, end, '\t');
+        // subfield boundaries up to the last one we need
+        int nsub = 0;
+        {
+            const char* a = sp;
+            while (nsub <= max_needed) {
+                const char* b = find_ch(a, se, ':');
+                sub_b[nsub] = a;
+                sub_e[nsub] = b;
+                ++nsub;
+                if (b == se) break;
+                a = b + 1;
+            }
+        }
+        if (gt_idx >= 0 && gt_idx < nsub) {
+            const char* a = sub_b[gt_idx];
+            const char* e = sub_e[gt_idx];
+            int j = 0;
+            bool phased = false;
+            while (a <= e) {
+                const char* b = a;
+                while (b < e && *b != '/' && *b != '|') ++b;
+                if (j >= P) {
+                    job.error = 2;  // ploidy above the tensor's P
+                    break;
+                }
+                gt[(size_t)s * P + j] = (b - a == 1 && *a == '.') || b == a ? (int16_t)-1 : (int16_t)parse_int(a, b);
+                ++j;
+                if (b >= e) break;
+                if (*b == '|') phased = true;
+                a = b + 1;
+            }
+            if (ph) ph[s] = phased ? 1 : 0;
+            maxpl = std::max(maxpl, j);
+        }
+        for (int i = 0; i < np; ++i) {
+            const PlaneSel& ps = v->planes[i];
+            char* base = static_cast<char*>(job.out->planes[i]);
+            if (ps.kind == TRK_VCF_MINSUPP) {
+                int32_t* o = reinterpret_cast<int32_t*>(base) + ((size_t)rec * S + s);
+                const bool have_gb = pidx[i] >= 0 && pidx[i] < nsub;
+                const bool have_ar = pidx2[i] >= 0 && pidx2[i] < nsub;
+                *o = (have_gb && have_ar) ? min_supp(sub_b[pidx[i]], sub_e[pidx[i]], sub_b[pidx2[i]], sub_e[pidx2[i]]) : 0;
+                continue;
+            }
+            const size_t esz = 4;
+            void* o = base + ((size_t)rec * S + s) * ps.ncol * esz;
+            if (pidx[i] >= 0 && pidx[i] < nsub) {
+                parse_list(sub_b[pidx[i]], sub_e[pidx[i]], ps.kind, ps.ncol, o);
+            } else {  // field absent from FORMAT or dropped at the end of the sample column: missing
+                static const char dot = '.';
+                parse_list(&dot, &dot + 1, ps.kind, ps.ncol, o);
+            }
+        }
+        if (se == end) {
+            if (s + 1 < S) job.error = 3;  // fewer sample columns than the header announces
+            break;
+        }
+        sp = se + 1;
+    }
+    job.out->locus_ploidy[rec] = (uint8_t)maxpl;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* trk_vcf_last_error(trk_vcf* v) { return v ? v->err.c_str() : g_open_error.c_str(); }
+
+int trk_vcf_open(const char* path, int n_threads, trk_vcf** out) {
+    if (!out || !path) return 2;
+    *out = nullptr;
+    trk_vcf* v = new trk_vcf();
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads < 1) n_threads = 1;
+    v->n_threads = n_threads;
+    if (!v->src.open(path, n_threads, g_open_error)) {
+        delete v;
+        return 1;
+    }
+    // header: everything up to and including the #CHROM line
+    for (;;) {
+        size_t scan = v->pos;
+        bool done = false;
+        while (scan < v->buf.size()) {
+            size_t nl = v->buf.find('\n', scan);
+            if (nl == std::string::npos) break;
+            if (v->buf[scan] != '#') {
+                done = true;
+                break;
+            }
+            bool chrom = v->buf.compare(scan, 6, "#CHROM") == 0;
+            v->header.append(v->buf, scan, nl - scan + 1);
+            if (chrom) {
+                std::string line = v->buf.substr(scan, nl - scan);
+                if (!line.empty() && line.back() == '\r') line.pop_back();
+                size_t a = 0;
+                int col = 0;
+                while (a <= line.size()) {
+                    size_t b = line.find('\t', a);
+                    if (b == std::string::npos) b = line.size();
+                    if (col >= 9) v->samples.push_back(line.substr(a, b - a));
+                    ++col;
+                    a = b + 1;
+                }
+                scan = nl + 1;
+                v->pos = scan;
+                done = true;
+                break;
+            }
+            scan = nl + 1;
+            v->pos = scan;
+        }
+        if (done) break;
+        if (v->src.eof) break;
+        if (!v->src.fill(v->buf, 1 << 20, g_open_error)) {
+            v->src.close();
+            delete v;
+            return 1;
+        }
+    }
+    if (v->header.find("#CHROM") == std::string::npos) {
+        g_open_error = std::string(path) + " does not look like a VCF (no #CHROM line)";
+        v->src.close();
+        delete v;
+        return 1;
+    }
+    *out = v;
+    return 0;
+}
+
+void trk_vcf_close(trk_vcf* v) {
+    if (!v) return;
+    v->src.close();
+    delete v;
+}
+
+const char* trk_vcf_header(trk_vcf* v, size_t* len) {
+    if (len) *len = v->header.size();
+    return v->header.c_str();
+}
+int trk_vcf_n_samples(trk_vcf* v) { return (int)v->samples.size(); }
+const char* trk_vcf_sample_name(trk_vcf* v, int i) {
+    return (i >= 0 && i < (int)v->samples.size()) ? v->samples[(size_t)i].c_str() : "";
+}
+
+int trk_vcf_select_format(trk_vcf* v, const char* key, int kind, int ncol) {
+    if (!v || !key || ncol < 1 || kind < 0 || kind > TRK_VCF_MINSUPP) return -1;
+    if (kind == TRK_VCF_MINSUPP) ncol = 1;
+    v->planes.push_back({key, kind, ncol});
+    return (int)v->planes.size() - 1;
+}
+
+int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batch* out) {
+    if (!v || !out || max_records < 1 || max_ploidy < 1) return 2;
+    const int S = (int)v->samples.size();
+    out->n_records = 0;
+    out->max_ploidy = max_ploidy;
+    // drop what the previous call handed out
+    if (v->pos > 0) {
+        v->buf.erase(0, v->pos);
+        v->pos = 0;
+    }
+    v->line_off.clear();
+    v->line_end.clear();
+    size_t scan = 0;
+    while ((int)v->line_off.size() < max_records) {
+        size_t nl = v->buf.find('\n', scan);
+        if (nl == std::string::npos) {
+            if (v->src.eof) {
+                if (scan < v->buf.size()) {  // last line without a newline
+                    v->buf.push_back('\n');
+                    continue;
+                }
+                break;
+            }
+            if (!v->src.fill(v->buf, 16u << 20, v->err)) return 1;
+            continue;
+        }
+        size_t e = nl;
+        if (e > scan && v->buf[e - 1] == '\r') --e;
+        if (e > scan) {  // skip blank lines
+            v->line_off.push_back((int64_t)scan);
+            v->line_end.push_back((int64_t)e);
+        }
+        scan = nl + 1;
+    }
+    const int n = (int)v->line_off.size();
+    v->pos = scan;
+    v->field_off.assign((size_t)n * 10, 0);
+    RecordJob job;
+    job.v = v;
+    job.text = v->buf.data();
+    job.S = S;
+    job.P = max_ploidy;
+    job.out = out;
+    std::atomic<int> next{0};
+    auto runner = [&]() {
+        for (;;) {
+            int i = next.fetch_add(1);
+            if (i >= n) break;
+            parse_record(job, i);
+        }
+    };
+    int nt = std::max(1, std::min(v->n_threads, n));
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(runner);
+    runner();
+    for (auto& t : th) t.join();
+    if (job.error) {
+        v->err = job.error == 2 ? "a genotype has more haplotypes than max_ploidy"
+                                : "a record has fewer sample columns than the header";
+        return 5;
+    }
+    out->n_records = n;
+    out->text = v->buf.data();
+    out->line_off = v->line_off.data();
+    out->line_end = v->line_end.data();
+    out->field_off = v->field_off.data();
+    return 0;
+}
+
+}  // extern "C"

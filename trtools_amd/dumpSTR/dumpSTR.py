@@ -618,6 +618,27 @@ def main(args):
                            "that are already present.")
     call_filters = BuildCallFilters(args)
 
+    # let the native reader decode what the call filters read (GT is always decoded)
+    if hasattr(invcf, 'select_format'):
+        from .. import vcfnative
+        wanted = []
+        for f in call_filters:
+            wanted.extend(k for k, _ in f.planes())
+        for cand in ('DP', 'LC'):
+            if cand in format_fields:
+                wanted.append(cand)
+                break
+        for key in dict.fromkeys(wanted):
+            if key == '__minsupp':
+                invcf.select_format('ALLREADS', vcfnative.KIND_MINSUPP, 1, alias='__minsupp')
+            elif key == '__rc':
+                invcf.select_format('RC', vcfnative.KIND_INT, 4, alias='__rc')
+            elif key == '__repci':
+                invcf.select_format('REPCI', vcfnative.KIND_INT_RANGES, 4, alias='__repci')
+            elif key in format_fields and format_fields[key]['Type'] in ('Integer', 'Float') \
+                    and format_fields[key]['Number'].isdigit():
+                invcf.select_format(key, ncol=int(format_fields[key]['Number']))
+
     suffix = '.vcf.gz' if args.zip else '.vcf'
     outvcf = MakeWriter(args.out + suffix, invcf, " ".join(sys.argv))
     if outvcf is None:

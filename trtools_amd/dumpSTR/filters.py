@@ -310,6 +310,9 @@ def _min_supp_reads(record):
     supporting read count, 0 when ALLREADS is absent/missing for the sample
     (filters.py:519-567).  int32 [S, 1]."""
     n = record.GetNumSamples()
+    native = getattr(record.vcfrecord, '_fmt_cache', {}).get('__minsupp')
+    if native is not None:           # decoded by the native reader (trk_vcf.h TRK_VCF_MINSUPP)
+        return native
     out = np.zeros((n, 1), dtype=np.int32)
     if "ALLREADS" not in record.format:
         return out
@@ -416,8 +419,13 @@ def _split_ints(arr, ncol, seps):
     return out
 
 
+def _native(record, key):
+    return getattr(record.vcfrecord, '_fmt_cache', {}).get(key)
+
+
 def _rc_plane(record):
-    return _split_ints(record.format['RC'], 4, [','])
+    native = _native(record, '__rc')
+    return native if native is not None else _split_ints(record.format['RC'], 4, [','])
 
 
 class GangSTRCallSpanOnly(Reason):
@@ -456,6 +464,9 @@ class GangSTRCallSpanBoundOnly(Reason):
 
 
 def _repci_plane(record):
+    native = _native(record, '__repci')
+    if native is not None:
+        return native
     ncol = 2 * record.format['REPCN'].shape[1]
     return _split_ints(record.format['REPCI'], ncol, [',', '-'])
 

@@ -40,6 +40,9 @@ def LoadSingleReader(vcf_loc, checkgz=True, lazy=False, samples=None):
             common.WARNING("Samples cannot be loaded in a particular order. Order will be ignored")
         samples = list(samples)
     try:
+        if os.environ.get('TRK_NATIVE_VCF', '1') != '0':
+            from .. import vcfnative
+            return vcfnative.NativeVCFReader(vcf_loc, lazy=lazy, samples=samples)
         return vcfio.VCFReader(vcf_loc, lazy=lazy, samples=samples)
     except OSError:
         common.WARNING("Could not open VCF file %s. Is it really VCF?" % vcf_loc)

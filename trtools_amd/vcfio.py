@@ -104,11 +104,14 @@ class Variant:
     """One VCF record with the cyvcf2.Variant surface the hot path touches."""
 
     __slots__ = ('_reader', '_fields', 'CHROM', 'POS', 'ID', 'REF', 'ALT', 'QUAL',
-                 '_filter', 'INFO', 'FORMAT', '_samples', '_cols', '_fmt_cache',
+                 '_filter', 'INFO', 'FORMAT', '_tail', '_samples_list', '_cols', '_fmt_cache',
                  '_gt', '_gtlist', 'ploidy', '_set_formats', '_info_dirty')
 
-    def __init__(self, reader, line):
-        f = line.rstrip('\r\n').split('\t')
+    def __init__(self, reader, line, gt=None, native=None):
+        """``gt`` (int16 [S, P+1], cyvcf2 layout) and ``native`` ({FORMAT key: array [S, k]}) are
+        supplied by the native reader (trtools_amd.vcfnative); the sample columns are then only
+        split in Python if a field that was not decoded natively is asked for."""
+        f = line.rstrip('\r\n').split('\t', 9)
         self._reader = reader
         self._fields = f
         self.CHROM = f[0]
@@ -121,18 +124,28 @@ class Variant:
         self.INFO = _Info(reader._parse_info(f[7]))
         if len(f) > 8:
             self.FORMAT = f[8].split(':')
-            self._samples = f[9:]
+            self._tail = f[9] if len(f) > 9 else ''
         else:
             self.FORMAT = []
-            self._samples = []
+            self._tail = ''
+        self._samples_list = None
         self._cols = None
-        self._fmt_cache = {}
+        self._fmt_cache = dict(native) if native else {}
         self._set_formats = {}
         self._gt = None
         self._gtlist = None
         self.ploidy = 2
-        if reader.n_samples and 'GT' in self.FORMAT:
+        if gt is not None:
+            self._gt = gt
+            self.ploidy = gt.shape[1] - 1
+        elif reader.n_samples and 'GT' in self.FORMAT:
             self._decode_gt()
+
+    @property
+    def _samples(self):
+        if self._samples_list is None:
+            self._samples_list = self._tail.split('\t') if self._tail else []
+        return self._samples_list
 
     # ---- FILTER (cyvcf2: None when PASS or '.') ----
     @property
@@ -216,6 +229,8 @@ class Variant:
     def format(self, key):
         if key in self._set_formats:
             return self._set_formats[key]
+        if key.startswith('__') and key in self._fmt_cache:   # pre-parsed plane of the native reader
+            return self._fmt_cache[key]
         if key not in self.FORMAT:
             raise KeyError(key)
         if key in self._fmt_cache:
@@ -273,6 +288,8 @@ class Variant:
             s = v.decode() if isinstance(v, bytes) else str(v)
             return s if s != '' else '.'
         toks = []
+        if arr.dtype.kind == 'f' and np.all(np.isnan(np.atleast_1d(v))):
+            return '.'          # a fully missing vector is a single '.' (htslib)
         for x in np.atleast_1d(v):
             if arr.dtype.kind == 'i':
                 if x == INT_VECTOR_END:
