@@ -102,6 +102,9 @@ def test_string_field_preparse_kinds():
                 assert np.array_equal(want[called], got[called]), (path, vpy.POS)
             else:
                 called = rec.GetCalledSamples()     # the GangSTR filters only look at called samples
+                if not called.any():
+                    n += 1
+                    continue
                 assert np.array_equal(filters._rc_plane(rec)[called], vnat.format('__rc')[called]), (path, vpy.POS)
                 assert np.array_equal(filters._repci_plane(rec)[called], vnat.format('__repci')[called]), (path, vpy.POS)
             n += 1
