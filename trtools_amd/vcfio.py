@@ -510,7 +510,8 @@ class VCFWriter:
         self._tmpl = template
         self._wrote_header = False
         if path.endswith('.gz'):
-            self._fh = gzip.open(path, 'wt')
+            from .bgzf import BgzfWriter
+            self._fh = BgzfWriter(path)      # --zip output is real bgzip (dumpSTR.py:1241-1245)
         else:
             self._fh = open(path, 'w')
 
