@@ -22,9 +22,11 @@ One step =
             trk_locus_finalize(counts of GT')    (k_locus_finalize + k_hwe_test)
             trk_locus_filters(callrate, HWE, het low/high)  (k_locus_filter)
   N > 1   : loci are sharded by rank (weak scaling: every rank owns 100k loci of an
-            N x 100k-locus cohort); per step an RCCL all-reduce sums the per-sample /
-            per-filter counters and an RCCL all-gather collects the per-locus result
-            rows (issued on a second HIP stream, overlapped with the next step).
+            N x 100k-locus cohort).  The one real exchange of the path: dumpSTR's per-sample /
+            per-filter counters and loc_info are sums over ALL loci -> RCCL all-reduce (< 1 MB);
+            the per-locus filter decisions are all-gathered (RCCL, 0.4 MB per rank) for the rank
+            that writes the cohort's FILTER column.  Statistic rows stay with the rank that owns
+            the loci (each rank writes its slice of the table; rank order == locus order).
 torch is imported only for N > 1 (rendezvous, barrier, max-over-ranks), never for compute.
 """
 import argparse
@@ -82,9 +84,8 @@ class Workload:
         self.bits = eng.empty((self.n_loci,), np.uint32)
         self.loc_counters = eng.zeros((L.TRK_LC_COLS,), np.int64)
         self.gather = None
-        if world > 1:
-            row_bytes = self.stats_a[0].locus_f64.nbytes
-            self.gather = eng.empty((world, row_bytes), np.uint8)
+        if world > 1 or os.environ.get('TRK_FORCE_DIST'):
+            self.gather = eng.empty((world, self.n_loci), np.uint32)
         self.step_no = 0
 
     def step(self):
@@ -104,11 +105,12 @@ class Workload:
         eng.locus_finalize(b, self.stats_b[i])
         eng.locus_filters(self.n_loci, self.stats_b[i], bits_out=self.bits, counters=self.loc_counters,
                           **self.locus_args)
-        if self.world > 1:
+        if self.gather is not None:
             eng.allreduce_sum_i64(self.call_out.sample_counters)
             eng.allreduce_sum_i64(self.call_out.sample_totaldp)
+            eng.allreduce_sum_i64(self.call_out.sample_dp_missing)
             eng.allreduce_sum_i64(self.loc_counters)
-            eng.allgather(self.stats_b[i].locus_f64, self.gather)
+            eng.allgather(self.bits, self.gather)
 
 
 def parity_spot_check(wl, n_check=6):
@@ -207,12 +209,13 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     dist = None
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get('TRK_FORCE_DIST'))   # TRK_FORCE_DIST: exercise the
+    if use_dist:                                                      # collective path on one rank
         import torch.distributed as dist  # rendezvous / barrier only
         dist.init_process_group(backend='gloo')
     from trtools_amd.engine import Engine
     eng = Engine(local_rank)
-    if world > 1:
+    if use_dist:
         uid = [eng.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         eng.comm_init(rank, world, uid[0])
@@ -275,8 +278,8 @@ def main():
                                    "%d loci x %d samples per GPU (BASELINE configs[3])" % (wl.n_loci, wl.n_samples),
                        "n_loci_per_gpu": wl.n_loci, "n_samples": wl.n_samples, "ploidy": 2,
                        "max_alleles": int(np.max(np.diff(wl.sb.tables[0]))),
-                       "sharding": "loci by rank; RCCL all-reduce of sample/locus counters + all-gather of locus rows"
-                       if world > 1 else "single GPU"},
+                       "sharding": "loci by rank; RCCL all-reduce of sample/locus counters + all-gather of the "
+                                   "per-locus filter decisions" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_call_filter", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_cell": BYTES_PER_CELL_CALL_FILTER, "avg_launch_ms": avg_cf,
