@@ -1,0 +1,85 @@
+"""(1) The harmoniser mirror (trtools_amd/utils/tr_harmonizer.py) against what the IMPORTED
+reference produced for the records of every fixture VCF (tests/golden/harmonized_records.json.gz,
+tools/gen_golden_dumpstr.py::gen_harmonized; reference tr_harmonizer.py:264-550, 693-773);
+(2) statSTR flag combinations (use-length, region, precision, only-passing) against tables the
+imported reference wrote (tests/golden/statstr_flags/)."""
+import gzip
+import json
+import os
+import sys
+
+import pytest
+
+from helpers import GOLDEN
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+DATA = os.path.join(GOLDEN, 'data')
+
+
+def test_harmonized_records_match_reference():
+    from trtools_amd.utils import tr_harmonizer as trh, utils
+    gold = json.load(gzip.open(os.path.join(GOLDEN, 'harmonized_records.json.gz'), 'rt'))['files']
+    total = 0
+    for rel, g in gold.items():
+        reader = utils.LoadSingleReader(os.path.join(DATA, rel), checkgz=False)
+        vt = g['vcftype']
+        assert trh.InferVCFType(reader, vt).name == vt
+        want = iter(g['records'])
+        for i, r in enumerate(trh.TRRecordHarmonizer(reader, vt)):
+            if i % 7 and i > 40:
+                continue
+            got = [r.chrom, int(r.pos), int(r.end_pos), int(r.full_alleles_pos), int(r.full_alleles_end_pos),
+                   r.record_id, r.motif, r.ref_allele, list(r.alt_alleles), float(r.ref_allele_length),
+                   [float(x) for x in r.alt_allele_lengths], r.full_alleles is not None, r.quality_field,
+                   str(r)[:200]]
+            assert got == next(want), (rel, i)
+            total += 1
+    assert total > 5000
+
+
+def test_type_inference_and_wrong_type_errors():
+    """tr_harmonizer.py:180-244 and the mandatory-field checks :316-324, 349-354, 424-427."""
+    from trtools_amd.utils import tr_harmonizer as trh, utils
+    hip = utils.LoadSingleReader(os.path.join(DATA, 'many_samples.vcf.gz'), checkgz=False)
+    assert trh.InferVCFType(hip) == trh.VcfTypes.hipstr
+    with pytest.raises(TypeError):
+        trh.InferVCFType(hip, 'gangstr')
+    with pytest.raises(ValueError):
+        trh._ToVCFType('nonsense')
+    gang = utils.LoadSingleReader(os.path.join(DATA, 'dumpSTR', 'test_gangstr.vcf.gz'), checkgz=False)
+    rec = next(gang)
+    with pytest.raises(TypeError):
+        trh.HarmonizeRecord('hipstr', rec)      # START/END/PERIOD missing
+    with pytest.raises(TypeError):
+        trh.HarmonizeRecord('advntr', rec)      # VID missing
+    assert trh.MayHaveImpureRepeats('hipstr') and not trh.MayHaveImpureRepeats('gangstr')
+    assert trh.HasLengthRefGenotype('eh') and trh.HasLengthAltGenotypes('popstr')
+
+
+def _run_stat(tmp_path, compute, name):
+    import gen_golden_dumpstr as gg
+    from trtools_amd import runtime
+    from trtools_amd.statSTR import statSTR
+    old = runtime.set_compute(compute)
+    try:
+        out = str(tmp_path / name)
+        assert statSTR.main(gg.stat_args(out, os.path.join(DATA, 'many_samples.vcf.gz'), **gg.STAT_CASES[name])) == 0
+    finally:
+        runtime.set_compute(old)
+    got = open(out + '.tab').read()
+    want = open(os.path.join(GOLDEN, 'statstr_flags', name + '.tab')).read()
+    assert got == want, name
+    assert got.count('\n') > 5
+
+
+@pytest.mark.parametrize("name", ['uselength', 'region', 'precision7_few', 'only_passing'])
+def test_statstr_flag_combinations_cpu(tmp_path, name):
+    from oracle_compute import OracleCompute
+    _run_stat(tmp_path, OracleCompute(), name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ['uselength', 'region', 'precision7_few', 'only_passing'])
+def test_statstr_flag_combinations_gpu(tmp_path, name):
+    from trtools_amd.compute import DeviceCompute
+    _run_stat(tmp_path, DeviceCompute(), name)

@@ -75,3 +75,66 @@ def gen_dumpstr_synth():
 
 
 GENERATORS = {'dumpstr_synth': gen_dumpstr_synth}
+
+
+# ---------------------------------------------------------------------------------------
+# harmonised records of every fixture VCF (tr_harmonizer.py:264-550, 693-773) and extra
+# statSTR flag combinations (use-length, region, only-passing, precision) from the reference
+# ---------------------------------------------------------------------------------------
+def gen_harmonized():
+    import json
+    import trtools.utils.tr_harmonizer as trh
+    import trtools.utils.utils as rutils
+    data = os.path.join(REPO, 'tests', 'golden', 'data')
+    files = [('many_samples.vcf.gz', 'hipstr'), ('dumpSTR/trio_chr21_hipstr.sorted.vcf.gz', 'hipstr'),
+             ('dumpSTR/trio_chr21_gangstr.sorted.vcf.gz', 'gangstr'), ('dumpSTR/test_gangstr.vcf.gz', 'gangstr'),
+             ('dumpSTR/NA12878_chr21_advntr.sorted.vcf.gz', 'advntr'), ('dumpSTR/NA12878_chr21_popstr.sorted.vcf.gz', 'popstr'),
+             ('dumpSTR/longtr_testfile.vcf.gz', 'longtr')]
+    out = {}
+    for rel, vt in files:
+        reader = rutils.LoadSingleReader(os.path.join(data, rel), checkgz=False)
+        assert trh.InferVCFType(reader, vt).name == vt
+        recs = []
+        for i, r in enumerate(trh.TRRecordHarmonizer(reader, vt)):
+            if i % 7 and i > 40:
+                continue            # every 7th record after the first 40
+            recs.append([r.chrom, int(r.pos), int(r.end_pos), int(r.full_alleles_pos), int(r.full_alleles_end_pos),
+                         r.record_id, r.motif, r.ref_allele, list(r.alt_alleles), float(r.ref_allele_length),
+                         [float(x) for x in r.alt_allele_lengths], r.full_alleles is not None, r.quality_field,
+                         str(r)[:200]])
+        out[rel] = {'vcftype': vt, 'records': recs}
+        print("harmonized %s: %d records" % (rel, len(recs)))
+    with open(os.path.join(REPO, 'tests', 'golden', 'harmonized_records.json'), 'w') as fh:
+        json.dump({'generator': 'tools/gen_golden_dumpstr.py gen_harmonized', 'files': out}, fh)
+
+
+STAT_CASES = {
+    'uselength': dict(use_length=True),
+    'region': dict(region='1:1000000-2000000', afreq=True, mean=True),
+    'precision7_few': dict(precision=7, thresh=False, acount=False, nalleles=False, entropy=False, mode=False),
+    'only_passing': dict(only_passing=True, hwep=False),
+}
+
+
+def stat_args(out, vcf, **kw):
+    ns = argparse.Namespace(vcf=vcf, out=out, vcftype='hipstr', samples=None, sample_prefixes=None, plot_afreq=False,
+                            region=None, thresh=True, afreq=True, acount=True, hwep=True, het=True, entropy=True,
+                            mean=True, mode=True, var=True, numcalled=True, use_length=False, precision=4,
+                            nalleles=True, nalleles_thresh=0.1, only_passing=False)
+    for k, v in kw.items():
+        setattr(ns, k, v)
+    return ns
+
+
+def gen_statstr_flags():
+    import trtools.statSTR.statSTR as rstat
+    d = os.path.join(REPO, 'tests', 'golden', 'statstr_flags')
+    os.makedirs(d, exist_ok=True)
+    vcf = os.path.join(REPO, 'tests', 'golden', 'data', 'many_samples.vcf.gz')
+    for name, kw in STAT_CASES.items():
+        assert rstat.main(stat_args(os.path.join(d, name), vcf, **kw)) == 0
+        print("statstr_flags/%s: ok" % name)
+
+
+GENERATORS['harmonized'] = gen_harmonized
+GENERATORS['statstr_flags'] = gen_statstr_flags
