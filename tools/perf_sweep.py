@@ -13,12 +13,13 @@ F3 = [dict(op=L.F_LT, plane_a=0, thr=10), dict(op=L.F_GT, plane_a=0, thr=1000), 
 st = eng.locus_stats(sb.batch, count_only=True)
 eng.profile(True)
 out = eng.alloc_call_out(sb.batch, 3)
-def t_cf(delta):
+def t_cf(delta=True):
     eng.profile_reset()
-    for _ in range(3): eng.call_filters(sb.batch, planes, F3, dp_plane=0, out=out, delta_stats=st if delta else None)
+    for _ in range(4): eng.call_filters(sb.batch, planes, F3, dp_plane=0, out=out, delta_stats=st if delta else None)
     eng.sync(); n, ms = eng.profile_get()['k_call_filter']; return ms / n
-for lpb in (128, 256, 512, 1024):
-    for sub in (32, 64, 90):
-        os.environ['TRK_CF_LPB'] = str(lpb); os.environ['TRK_CF_SUB'] = str(sub)
-        t = t_cf(True)
-        print("delta lpb=%4d sub=%3d: %.3f ms  %.0f GB/s(20B)" % (lpb, sub, t, cells * 20 / t / 1e6))
+print("dedupe on, nt ld/st : %.3f ms" % t_cf())
+os.environ['TRK_CF_NODEDUPE'] = '1'; print("dedupe off          : %.3f ms" % t_cf()); os.environ.pop('TRK_CF_NODEDUPE')
+for mm in (1, 2, 3):
+    os.environ['TRK_CF_MEM'] = str(mm); print("mem_mode=%d (1 plain ld, 2 plain st): %.3f ms" % (mm, t_cf()))
+os.environ.pop('TRK_CF_MEM')
+print("no delta            : %.3f ms" % t_cf(False))
