@@ -78,4 +78,7 @@ def test_bad_inputs_return_1(tmp_path):
     assert statSTR.main(_args(str(tmp_path / 'o'), vcf=str(tmp_path / 'missing.vcf'))) == 1
     assert statSTR.main(_args(str(tmp_path / 'nodir' / 'o'))) == 1
     # a region query needs a bgzipped + indexed file (statSTR.py:511-514)
-    assert statSTR.main(_args(str(tmp_path / 'o'), region='chr1:1-10')) == 1
+    import shutil
+    noidx = str(tmp_path / 'noindex.vcf.gz')
+    shutil.copy(os.path.join(DATA, 'many_samples.vcf.gz'), noidx)
+    assert statSTR.main(_args(str(tmp_path / 'o'), vcf=noidx, region='chr1:1-10')) == 1

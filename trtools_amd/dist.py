@@ -44,7 +44,7 @@ class TorchComm:
         self.dist.all_gather(sizes, n)
         m = int(max(int(s[0]) for s in sizes))
         buf = torch.zeros(m, dtype=torch.uint8)
-        buf[:arr.size] = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint8).reshape(-1))
+        buf[:arr.size] = torch.from_numpy(np.array(arr, dtype=np.uint8).reshape(-1))
         outs = [torch.zeros(m, dtype=torch.uint8) for _ in range(self.world)]
         self.dist.all_gather(outs, buf)
         return [o.numpy()[:int(s[0])] for o, s in zip(outs, sizes)]
@@ -111,3 +111,85 @@ def gather_rows(rows_bytes, comm):
     """Concatenate per-shard output (bytes) in rank order == locus order."""
     parts = comm.allgather_bytes(np.frombuffer(rows_bytes, dtype=np.uint8))
     return b''.join(p.tobytes() for p in parts)
+
+
+# ---------------------------------------------------------------------------------------
+# locus-sharded command-line runs (statSTR / dumpSTR under a one-process-per-GPU launcher)
+# ---------------------------------------------------------------------------------------
+_comm = None
+
+
+def set_comm(comm):
+    """Install the communicator the sharded CLIs use (tests: TorchComm over gloo)."""
+    global _comm
+    old = _comm
+    _comm = comm
+    return old
+
+
+def _exchange_id(uid, rank, world, addr, port):
+    """Rank 0 hands the 128-byte RCCL id to every other rank over plain TCP (no torch needed)."""
+    import socket
+    import time
+    if rank == 0:
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((addr, port))
+        srv.listen(world)
+        for _ in range(world - 1):
+            c, _a = srv.accept()
+            c.sendall(uid)
+            c.close()
+        srv.close()
+        return uid
+    deadline = time.time() + 300
+    while True:
+        try:
+            c = socket.create_connection((addr, port), timeout=10)
+            break
+        except OSError:
+            if time.time() > deadline:
+                raise
+            time.sleep(0.2)
+    buf = b''
+    while len(buf) < 128:
+        chunk = c.recv(128 - len(buf))
+        if not chunk:
+            raise OSError("rendezvous closed early")
+        buf += chunk
+    c.close()
+    return buf
+
+
+def get_comm():
+    """(rank, world, comm).  world == 1 -> comm is None.  With WORLD_SIZE > 1 in the environment
+    (torchrun / any launcher exporting RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT) an RCCL
+    communicator is created inside libtrk on this process's GPU."""
+    import os
+    global _comm
+    if _comm is not None:
+        return _comm.rank, _comm.world, _comm
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world <= 1:
+        return 0, 1, None
+    from . import runtime
+    eng = runtime.get_compute().eng
+    addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
+    port = int(os.environ.get('MASTER_PORT', '29500')) + 17
+    uid = _exchange_id(eng.comm_unique_id() if rank == 0 else None, rank, world, addr, port)
+    eng.comm_init(rank, world, uid)
+    _comm = RcclComm(eng, rank, world)
+    return rank, world, _comm
+
+
+def merge_parts(parts, comm):
+    """``parts``: this rank's list of (batch_index, bytes).  Returns, on every rank, the
+    concatenation of all ranks' parts in batch order (== record order of the input)."""
+    import pickle
+    blobs = comm.allgather_bytes(np.frombuffer(pickle.dumps(parts), dtype=np.uint8))
+    allparts = []
+    for b in blobs:
+        allparts.extend(pickle.loads(b.tobytes()))
+    allparts.sort(key=lambda t: t[0])
+    return b''.join(p for _, p in allparts)

@@ -400,11 +400,47 @@ class _Run:
         self.spec = dict(min_callrate=args.min_locus_callrate, min_hwep=args.min_locus_hwep,
                          min_het=args.min_locus_het, max_het=args.max_locus_het,
                          use_length=bool(args.use_length), n_extern=len(self.host_filters))
+        # locus sharding (one process per GPU): batch b belongs to rank b mod WORLD_SIZE
+        from .. import dist
+        self.rank, self.world, self.comm = dist.get_comm()
+        self.batch_no = -1
+        self.parts = []
+        self.no_dp = False
+
+    def emit(self, variant):
+        if self.world == 1:
+            self.outvcf.write_record(variant)
+        else:
+            self._cur.append(str(variant))
+
+    def finish(self):
+        """Cohort-wide counters and the merged record stream (rank 0 writes)."""
+        if self.world == 1:
+            return
+        from .. import dist
+        flag = self.comm.allreduce_sum_i64(np.array([1 if self.no_dp else 0], dtype=np.int64))
+        self.sample_info = dist.reduce_sample_info(self.sample_info, self.comm)
+        if flag[0] > 0:
+            self.sample_info['totaldp'][:] = np.nan
+        self.loc_info = dist.reduce_loc_info(self.loc_info, self.comm)
+        merged = dist.merge_parts(self.parts, self.comm)
+        if self.rank == 0:
+            self.outvcf.write_text(merged.decode())
 
     def process(self, records):
         from .. import runtime
         if not records:
             return
+        self.batch_no += 1
+        if self.world > 1 and self.batch_no % self.world != self.rank:
+            return
+        self._cur = []
+        self._process(records)
+        if self.world > 1:
+            self.parts.append((self.batch_no, ''.join(self._cur).encode()))
+
+    def _process(self, records):
+        from .. import runtime
         args = self.args
         hb = pack_records(records)
         planes = _Planes(records, self.call_filters)
@@ -439,6 +475,7 @@ class _Run:
             si['totaldp'][ch.dp_missing > 0] = np.nan
         else:
             si['totaldp'][:] = np.nan
+            self.no_dp = True
         li = self.loc_info
         li['totalcalls'] += int(lc[L.LC_TOTALCALLS])
         li['PASS'] += int(lc[L.LC_PASS])
@@ -486,7 +523,7 @@ class _Run:
                 v.INFO['HWEP'] = -1
                 v.INFO['AC'] = 0 if n_alt == 0 else ','.join(['0'] * n_alt)
                 v.INFO['REFAC'] = 0
-            self.outvcf.write_record(v)
+            self.emit(v)
 
 
 def getargs():  # pragma: no cover
@@ -640,7 +677,11 @@ def main(args):
                 invcf.select_format(key, ncol=int(format_fields[key]['Number']))
 
     suffix = '.vcf.gz' if args.zip else '.vcf'
-    outvcf = MakeWriter(args.out + suffix, invcf, " ".join(sys.argv))
+    from .. import dist
+    rank = dist.get_comm()[0]
+    # in a sharded run only rank 0 writes the outputs; the other ranks get a scratch writer
+    vcf_path = args.out + suffix if rank == 0 else args.out + '.rank%d.tmp' % rank + suffix
+    outvcf = MakeWriter(vcf_path, invcf, " ".join(sys.argv))
     if outvcf is None:
         return 1
     run = _Run(args, invcf, call_filters, locus_filters, outvcf)
@@ -676,9 +717,13 @@ def main(args):
             run.process(batch)
             batch = []
     run.process(batch)
+    run.finish()
 
     invcf.close()
     outvcf.close()
+    if run.rank != 0:
+        os.remove(vcf_path)               # only rank 0's file holds the merged records
+        return 0
     WriteSampLog(run.sample_info, invcf.samples, args.out + ".samplog.tab")
     WriteLocLog(run.loc_info, args.out + ".loclog.tab")
     if args.zip:

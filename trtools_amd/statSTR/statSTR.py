@@ -159,6 +159,44 @@ class _RowFormatter:
         return "".join(out)
 
 
+class _ShardedOut:
+    """Under a one-process-per-GPU launcher (WORLD_SIZE > 1) batch b of the input belongs to rank
+    b mod WORLD_SIZE; every rank keeps the text of its batches and rank 0 writes the merged table
+    (batch order == record order).  With one process it is a pass-through to the output file."""
+
+    def __init__(self, outf):
+        from .. import dist
+        self.rank, self.world, self.comm = dist.get_comm()
+        self.outf = outf
+        self.parts = []
+        self.batch_no = -1
+        self._cur = None
+
+    def next_batch(self):
+        self.batch_no += 1
+        mine = self.world == 1 or self.batch_no % self.world == self.rank
+        self._cur = [] if (mine and self.world > 1) else None
+        return mine
+
+    def write(self, text):
+        if self._cur is None:
+            self.outf.write(text)
+        else:
+            self._cur.append(text)
+
+    def end_batch(self):
+        if self._cur is not None:
+            self.parts.append((self.batch_no, ''.join(self._cur).encode()))
+            self._cur = None
+
+    def finish(self):
+        if self.world > 1:
+            from .. import dist
+            merged = dist.merge_parts(self.parts, self.comm)
+            if self.rank == 0:
+                self.outf.write(merged.decode())
+
+
 def _flush(batch, group_masks, fmt, outf, nalleles_thresh):
     """Reduce one batch of (variant, TRRecord) pairs on the device and write its rows."""
     from .. import runtime
@@ -242,7 +280,9 @@ def main(args):
             outf = sys.stdout
         else:
             outf = open(args.out + ".tab", "w")
-        outf.write("\t".join(header) + "\n")
+        shard = _ShardedOut(outf)
+        if shard.rank == 0:
+            outf.write("\t".join(header) + "\n")
         region = invcf(args.region) if args.region else invcf
         n_samples = max(len(invcf.samples), 1)
         batch_loci = max(1, min(4096, BATCH_CELLS // n_samples))
@@ -261,13 +301,18 @@ def main(args):
                 num_plotted += 1
             batch.append((record, trrecord))
             if len(batch) >= batch_loci:
-                _flush(batch, group_masks, fmt, outf, args.nalleles_thresh)
+                if shard.next_batch():
+                    _flush(batch, group_masks, fmt, shard, args.nalleles_thresh)
+                    shard.end_batch()
                 batch = []
                 outf.flush()
-                if args.out != "stdout":
+                if args.out != "stdout" and shard.rank == 0:
                     print("Finished {} records, time/record={:.5}sec".format(
                         nrecords, (time.time() - start_time) / nrecords), flush=True, end="\r")
-        _flush(batch, group_masks, fmt, outf, args.nalleles_thresh)
+        if batch and shard.next_batch():
+            _flush(batch, group_masks, fmt, shard, args.nalleles_thresh)
+            shard.end_batch()
+        shard.finish()
     finally:
         if outf is not None and args.out != "stdout":
             outf.close()

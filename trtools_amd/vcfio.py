@@ -531,6 +531,12 @@ class VCFWriter:
             self._header()
         self._fh.write(str(variant))
 
+    def write_text(self, text):
+        """Already formatted record lines (merged shards of a multi-process run)."""
+        if not self._wrote_header:
+            self._header()
+        self._fh.write(text)
+
     def close(self):
         if not self._wrote_header:
             self._header()
