@@ -89,7 +89,9 @@ enum {
     TRK_K_CALL_FILTER = 2,
     TRK_K_LOCUS_FILTER = 3,
     TRK_K_SYNTH = 4,
-    TRK_K_COUNT = 5
+    TRK_K_ASSOC_SCAN = 5,    /* associaTR: genotype x trait cross-products per locus */
+    TRK_K_ASSOC_FINALIZE = 6,
+    TRK_K_COUNT = 7
 };
 int trk_profile_enable(trk_ctx* ctx, int on);
 int trk_profile_get(trk_ctx* ctx, int kernel, int64_t* n_launches, double* total_ms);
@@ -288,6 +290,81 @@ typedef struct {
 /* (a19): locus filter decisions + loc_info counters from group 0 of `stats`.   */
 int trk_locus_filters(trk_ctx* ctx, int32_t n_loci, const trk_stats_out* stats,
                       const trk_locus_filter_spec* spec, trk_locus_out* out);
+
+/* ---- associaTR linear-regression scan --------
+ * For every locus of a batch, what one iteration of load_trs
+ * (associaTR/load_and_filter_genotypes.py:157-259) plus the regression block of
+ * perform_gwas_helper (associaTR/associaTR.py:246-291) compute:
+ *   curr_samples   = sample_in & GetCalledSamples()                       (:167-169)
+ *   allele counts of those samples' genotypes (GetAlleleFreqs(curr_samples), :177)
+ *   the locus filter: no called samples / one (rounded) length allele / non-major
+ *   allele count < cutoff (:229-239), then 'n covars >= n samples' (associaTR.py:257)
+ *   summed length genotype per sample, standardised over curr_samples (:266-273)
+ *   OLS of the outcome on [genotype, 1, covariates] over curr_samples: p-value,
+ *   coefficient, standard error of the genotype term and the centred R^2 (:277-289,
+ *   statsmodels OLS.fit(); here by normal equations in float64: cross-products in one
+ *   pass over the genotype tensor, a Cholesky factorisation per locus, Student-t tail).
+ * The outcome / covariates are the caller's standardised columns (associaTR.py:198-202),
+ * row-major by VECTOR: vec[0] = outcome, vec[1..] = covariates, each [S] (entries of
+ * samples with sample_in == 0 are ignored).  The intercept is implicit.
+ */
+#define TRK_ASSOC_MAX_VEC 16
+typedef struct {
+    int32_t n_vec;              /* M >= 1: outcome + (M-1) covariates                        */
+    int32_t flags;              /* 0                                                         */
+    const double* vec;          /* device [M, S]                                             */
+    const uint8_t* sample_in;   /* device [S], NULL = every sample                           */
+    const double* allele_len;   /* device [sumA] length in repeat units per allele INDEX
+                                   (the LUT of GetLengthGenotypes, tr_harmonizer.py:1239)    */
+    const uint16_t* rlen_class; /* device [sumA]: for length class c of locus l (entry
+                                   allele_off[l]+c, classes as trk_batch.len_class) the rank of
+                                   its ROUNDED length among the locus's distinct rounded lengths
+                                   (clean_len_alleles, load_and_filter_genotypes.py:37-45)   */
+    double non_major_cutoff;    /* --non-major-cutoff                                        */
+} trk_assoc_params;
+
+/* trk_assoc_out.locus_int columns ([L, TRK_AI_COLS] int32) */
+enum {
+    TRK_AI_N_TESTED = 0,   /* samples in curr_samples                                        */
+    TRK_AI_STATUS = 1,     /* TRK_AS_*                                                       */
+    TRK_AI_N_RALLELES = 2, /* distinct rounded length alleles among curr_samples             */
+    TRK_AI_RANK = 3,       /* rank of the design (df_resid = n - rank)                       */
+    TRK_AI_N_BAD = 4,      /* calls with an allele index >= A_l                               */
+    TRK_AI_N_HAPS = 5,     /* called haplotypes among curr_samples (denominator of the AFs)  */
+    TRK_AI_COLS = 8
+};
+enum {
+    TRK_AS_OK = 0,
+    TRK_AS_NO_CALLED = 1,      /* 'No called samples'                                        */
+    TRK_AS_ONE_ALLELE = 2,     /* 'Only one called allele'                                   */
+    TRK_AS_NON_MAJOR = 3,      /* 'non-major allele count<cutoff'                            */
+    TRK_AS_N_COVARS = 4,       /* 'n covars >= n samples'                                    */
+    TRK_AS_ZERO_VARIANCE = 5,  /* summed genotype constant over curr_samples (reference: 0/0) */
+    TRK_AS_COLLINEAR = 6       /* genotype in the span of the covariates                     */
+};
+/* trk_assoc_out.locus_f64 columns ([L, TRK_AF_COLS] float64); nan where not tested */
+enum {
+    TRK_AF_PVAL = 0,
+    TRK_AF_COEF = 1,      /* coefficient of the STANDARDISED genotype (params[0])           */
+    TRK_AF_SE = 2,        /* its standard error (bse[0])                                    */
+    TRK_AF_RSQUARED = 3,
+    TRK_AF_GT_STD = 4,    /* np.std of the summed genotypes (associaTR.py:272)              */
+    TRK_AF_GT_MEAN = 5,
+    TRK_AF_TVALUE = 6,
+    TRK_AF_DF_RESID = 7,
+    TRK_AF_NONMAJOR = 8,  /* np.sum(af)*n_samples*2 of load_and_filter_genotypes.py:236     */
+    TRK_AF_COLS = 10
+};
+typedef struct {
+    int32_t* locus_int;     /* device [L, TRK_AI_COLS]                                       */
+    double* locus_f64;      /* device [L, TRK_AF_COLS]                                       */
+    int32_t* allele_count;  /* device [sumA] counts per allele INDEX over curr_samples       */
+} trk_assoc_out;
+int trk_assoc_scan(trk_ctx* ctx, const trk_batch* in, const trk_assoc_params* prm, trk_assoc_out* out);
+
+/* Two-sided Student-t tail 2*sf(|t|, df) == scipy.stats.t.sf(|t|, df)*2 (the third-party call
+ * behind statsmodels' pvalues); host double, same code as the device finaliser.              */
+double trk_student_t_two_sided(double t, double df);
 
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) --------------------- */
 /* 128-byte opaque id created by rank 0 and distributed by the launcher.       */

@@ -1,0 +1,163 @@
+"""GPU parity: trk_assoc_scan (HIP, through the C ABI) vs the associaTR oracle on seeded synthetic
+batches.  Integers / filter decisions bit-exact, floats within 1e-9 (p-values: 1e-9 relative)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from trtools_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def make_case(seed, L, S, P=2, M=1, subset=False, max_alleles=12, miss=0.04, frac_len=True, locus_ploidy=False):
+    """Random loci: lengths with duplicates (same length, different sequence) and rounding collisions,
+    missing / partial calls, an all-missing locus, a monomorphic locus, an all-heterozygous locus."""
+    rng = np.random.default_rng(seed)
+    lens, gts = [], []
+    for l in range(L):
+        A = int(rng.integers(1, max_alleles + 1))
+        base = float(rng.integers(5, 30))
+        ll = [base]
+        for a in range(1, A):
+            r = rng.random()
+            if r < 0.15:
+                ll.append(ll[int(rng.integers(0, len(ll)))])                 # same length again
+            elif r < 0.3 and frac_len:
+                ll.append(base + float(rng.integers(-3, 4)) + 0.001 * float(rng.integers(1, 4)))  # rounds onto a neighbour
+            elif frac_len and r < 0.5:
+                ll.append(base + float(rng.integers(-8, 9)) / 3.0)
+            else:
+                ll.append(base + float(rng.integers(-4, 8)))
+        lens.append(ll)
+        p = rng.dirichlet(np.full(A, 0.6))
+        g = rng.choice(A, size=(S, P), p=p).astype(np.int16)
+        m = rng.random((S, P)) < miss * 0.3
+        g[m] = -1
+        g[rng.random(S) < miss] = -1
+        if P > 1 and l % 7 == 3:
+            g[rng.random(S) < 0.1, P - 1] = -2                               # lower-ploidy samples
+        if l == 1:
+            g[:] = -1
+        if l == 2:
+            g[:] = 0
+        if l == 3 and A > 1 and P == 2:
+            g[:, 0], g[:, 1] = 0, 1
+        gts.append(g)
+    gt = np.stack(gts)
+    lp = None
+    if locus_ploidy:
+        lp = rng.integers(1, P + 1, size=L).astype(np.uint8)
+        for l in range(L):
+            gt[l, :, lp[l]:] = -2
+    traits = rng.normal(size=(S, M))
+    traits[:, 0] += 0.05 * gt[min(5, L - 1), :, 0]
+    if subset:
+        traits[rng.random(S) < 0.05, 0] = np.nan
+        keep = rng.random(S) < 0.8
+    else:
+        keep = None
+    return lens, gt, lp, traits, keep
+
+
+def run_case(eng, seed, L, S, P=2, M=1, subset=False, cutoff=3.0, precision=2, **kw):
+    from oracle import associatr_oracle as ao
+    from trtools_amd import synth
+    from trtools_amd import _lib as TL
+    lens, gt, lp, traits, keep = make_case(seed, L, S, P, M, subset, **kw)
+    names = ['s%d' % i for i in range(S)]
+    sub = [n for n, k in zip(names, keep) if k] if keep is not None else None
+    sf, covars, outcome, pheno_std = ao.prepare_design(names, [traits], True, sub)
+    # device inputs
+    off, lc, sc, cv = synth.pack_alleles(lens, None)
+    alen, rcls = synth.pack_assoc_tables(lens, precision)
+    vec = np.zeros((M, S))
+    vec[0, sf] = outcome
+    for k in range(1, M):
+        vec[k, sf] = covars[:, 1 + k]
+    batch = eng.make_batch(gt, off, lc, sc, cv, locus_ploidy=lp)
+    res = eng.assoc_scan(batch, vec, alen, rcls, sample_in=None if sf.all() else sf.astype(np.uint8),
+                         non_major_cutoff=cutoff)
+    li, lf, cnt = res.locus_int.get(), res.locus_f64.get(), res.allele_count.get()
+    status_of = {None: TL.AS_OK, 'No called samples': TL.AS_NO_CALLED, 'Only one called allele': TL.AS_ONE_ALLELE,
+                 'n covars >= n samples': TL.AS_N_COVARS}
+    n_ok = 0
+    for l in range(L):
+        g = gt[l] if lp is None else gt[l][:, :lp[l]]
+        gi = ao.locus_genotypes(g, lens[l], sf, cutoff, precision)
+        reason = gi['locus_filtered']
+        n_tested = int(np.sum(gi['called_samples_filter']))
+        if not reason and covars.shape[1] >= n_tested:
+            reason = 'n covars >= n samples'
+        want = status_of.get(reason, TL.AS_NON_MAJOR)
+        assert li[l, TL.AI_N_TESTED] == n_tested, (l, li[l], n_tested)
+        # allele counts by index over the tested samples
+        curr = sf & ~np.any(g == -1, axis=1)
+        sel = g[curr]
+        exp_cnt = np.bincount(sel[sel >= 0].astype(int), minlength=len(lens[l]))
+        assert np.array_equal(cnt[off[l]:off[l + 1]], exp_cnt), (l, cnt[off[l]:off[l + 1]], exp_cnt)
+        assert li[l, TL.AI_N_RALLELES] == len(gi['allele_frequency']), l
+        if want == TL.AS_OK:
+            summed = np.sum(gi['gts'], axis=1)
+            if np.std(summed) <= 1e-9 * max(1.0, abs(np.mean(summed))):
+                assert li[l, TL.AI_STATUS] == TL.AS_ZERO_VARIANCE, (l, li[l])
+                continue
+        assert li[l, TL.AI_STATUS] == want, (l, li[l], reason)
+        if want != TL.AS_OK:
+            assert np.isnan(lf[l, TL.AF_PVAL])
+            continue
+        r = ao.locus_regression(gi['gts'], gi['called_samples_filter'], covars, outcome, pheno_std)
+        for col, key, tol in ((TL.AF_COEF, 'coef_std', 1e-9), (TL.AF_SE, 'se_std', 1e-9), (TL.AF_RSQUARED, 'rsquared', 1e-9),
+                              (TL.AF_GT_STD, 'std', 1e-12), (TL.AF_TVALUE, 'tvalue', 1e-9), (TL.AF_PVAL, 'pval', 1e-9)):
+            a, b = lf[l, col], r[key]
+            assert abs(a - b) <= tol * max(abs(b), 1e-300) + (1e-12 if key in ('coef_std', 'tvalue', 'rsquared') else 0), \
+                (l, key, a, b)
+        assert lf[l, TL.AF_DF_RESID] == r['df_resid'], l
+        assert abs(lf[l, TL.AF_GT_MEAN] - np.mean(np.sum(gi['gts'], axis=1))) < 1e-9
+        n_ok += 1
+    return n_ok
+
+
+def test_fast_path_single_trait(eng):
+    assert run_case(eng, 1, 120, 512, M=1) > 60
+
+
+def test_fast_path_covariates_and_subset(eng):
+    assert run_case(eng, 2, 90, 1000, M=4, subset=True) > 40
+    assert run_case(eng, 3, 60, 768, M=10, subset=True, cutoff=0.0) > 30
+
+
+def test_fast_path_sample_chunks(eng):
+    # 16 vectors x 4096 samples do not fit one LDS chunk -> partial records over several chunks
+    assert run_case(eng, 4, 40, 4096, M=16, subset=True, miss=0.02) > 20
+
+
+def test_many_alleles_and_rounding(eng):
+    assert run_case(eng, 5, 50, 640, M=2, max_alleles=60) > 25
+    assert run_case(eng, 6, 30, 512, M=1, max_alleles=400, precision=10) > 10   # generic path (LUT too big)
+
+
+def test_generic_path_ploidy_and_alignment(eng):
+    assert run_case(eng, 7, 40, 333, P=2, M=3, subset=True) > 15      # S % 4 != 0
+    assert run_case(eng, 8, 40, 200, P=3, M=2) > 15
+    assert run_case(eng, 9, 40, 200, P=1, M=1, cutoff=0.0) > 15
+    assert run_case(eng, 10, 40, 256, P=3, M=2, locus_ploidy=True, cutoff=0.0) > 10
+
+
+def test_n_covars_rule_and_empty(eng):
+    assert run_case(eng, 11, 30, 12, M=12, cutoff=0.0, miss=0.0) == 0   # 13 columns >= 12 samples
+    from trtools_amd import synth
+    off, lc, sc, cv = synth.pack_alleles([], None)
+    b = eng.make_batch(np.zeros((0, 8, 2), np.int16), off, lc, sc, cv)
+    r = eng.assoc_scan(b, np.zeros((1, 8)), np.zeros(0), np.zeros(0, np.uint16))
+    assert r.locus_int.get().shape == (0, 8)

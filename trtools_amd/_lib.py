@@ -22,7 +22,8 @@ LF_THRESH, LF_MEAN, LF_MODE, LF_VAR, LF_HET_LEN, LF_HET_STR, LF_ENTROPY_LEN, LF_
     LF_HWEP_LEN, LF_HWEP_STR, LF_CALLRATE = range(11)
 # kernels (profiling)
 K_LOCUS_COUNT, K_LOCUS_FINALIZE, K_CALL_FILTER, K_LOCUS_FILTER, K_SYNTH = range(5)
-KERNEL_NAMES = ['k_locus_count', 'k_locus_finalize', 'k_call_filter', 'k_locus_filter', 'k_synth']
+KERNEL_NAMES = ['k_locus_count', 'k_locus_finalize', 'k_call_filter', 'k_locus_filter', 'k_synth',
+                'k_assoc_scan', 'k_assoc_finalize']
 # filter ops
 F_LT, F_GT, F_RATIO_GT, F_CALLED_LT, F_CALLED_SUM_LT, F_CALLED_EQ, F_CALLED_SUM_EQ, \
     F_CALLED_OUTSIDE_CI, F_AD_SUPPORT_LT = range(1, 10)
@@ -79,6 +80,23 @@ class LocusOut(C.Structure):
     _fields_ = [('locus_bits', C.c_void_p), ('loc_counters', C.c_void_p)]
 
 
+class AssocParams(C.Structure):
+    _fields_ = [('n_vec', C.c_int32), ('flags', C.c_int32), ('vec', C.c_void_p), ('sample_in', C.c_void_p),
+                ('allele_len', C.c_void_p), ('rlen_class', C.c_void_p), ('non_major_cutoff', C.c_double)]
+
+
+class AssocOut(C.Structure):
+    _fields_ = [('locus_int', C.c_void_p), ('locus_f64', C.c_void_p), ('allele_count', C.c_void_p)]
+
+
+# associaTR scan: trk_assoc_out columns / status codes (include/trk.h)
+ASSOC_MAX_VEC = 16
+AI_N_TESTED, AI_STATUS, AI_N_RALLELES, AI_RANK, AI_N_BAD, AI_N_HAPS, AI_COLS = 0, 1, 2, 3, 4, 5, 8
+(AF_PVAL, AF_COEF, AF_SE, AF_RSQUARED, AF_GT_STD, AF_GT_MEAN, AF_TVALUE, AF_DF_RESID, AF_NONMAJOR) = range(9)
+AF_COLS = 10
+(AS_OK, AS_NO_CALLED, AS_ONE_ALLELE, AS_NON_MAJOR, AS_N_COVARS, AS_ZERO_VARIANCE, AS_COLLINEAR) = range(7)
+
+
 class SynthSpec(C.Structure):
     _fields_ = [('seed', C.c_uint64), ('n_loci', C.c_int32), ('n_samples', C.c_int32),
                 ('allele_off', C.c_void_p), ('allele_cdf24', C.c_void_p), ('miss_thr16', C.c_void_p),
@@ -94,6 +112,7 @@ EXPORTS = [
     'trk_locus_stats', 'trk_locus_finalize', 'trk_call_filters', 'trk_locus_filters',
     'trk_comm_unique_id', 'trk_comm_init', 'trk_allreduce_sum_i64', 'trk_allgather',
     'trk_binomtest_two_sided', 'trk_binom_pmf', 'trk_synth_fill', 'trk_synth_fill_gangstr',
+    'trk_assoc_scan', 'trk_student_t_two_sided',
 ]
 
 _lib = None
@@ -149,6 +168,9 @@ def load():
     lib.trk_binomtest_two_sided.restype = dbl
     lib.trk_binom_pmf.argtypes = [i64, i64, dbl]
     lib.trk_binom_pmf.restype = dbl
+    lib.trk_assoc_scan.argtypes = [vp, P(Batch), P(AssocParams), P(AssocOut)]
+    lib.trk_student_t_two_sided.argtypes = [dbl, dbl]
+    lib.trk_student_t_two_sided.restype = dbl
     lib.trk_synth_fill.argtypes = [vp, P(SynthSpec), vp, vp, vp, vp, vp]
     lib.trk_synth_fill_gangstr.argtypes = [vp, P(SynthSpec), vp, vp, vp, vp, vp, vp, vp]
     _lib = lib

@@ -13,6 +13,7 @@
 
 #include "../../include/trk.h"
 #include "trk_binom.h"
+#include "trk_student.h"
 #include "trk_internal.h"
 
 // ---- RCCL (subset), resolved at run time --------------------------------------
@@ -83,6 +84,8 @@ struct trk_ctx {
     size_t scratch_bytes = 0;
     void* worklist = nullptr;    // deferred HWE tests (count + items)
     size_t worklist_bytes = 0;
+    void* assoc_ws = nullptr;    // associaTR scan workspace (Gram, partial records, class counts)
+    size_t assoc_ws_bytes = 0;
     ncclComm_t comm = nullptr;
     int rank = 0, n_ranks = 1;
 };
@@ -202,6 +205,7 @@ void trk_free(trk_ctx* ctx) {
     }
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->worklist) (void)hipFree(ctx->worklist);
+    if (ctx->assoc_ws) (void)hipFree(ctx->assoc_ws);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -532,6 +536,44 @@ int trk_allgather(trk_ctx* ctx, const void* send, void* recv, size_t bytes_per_r
 }
 
 // ---- scalar helpers --------------------------------------------------------------
+// ---- associaTR scan -----------------------------------------------------------------------
+int trk_assoc_scan(trk_ctx* ctx, const trk_batch* in, const trk_assoc_params* prm, trk_assoc_out* out) {
+    if (!ctx) return TRK_ERR_ARG;
+    int rc = check_batch(ctx, in);
+    if (rc) return rc;
+    if (!prm || !out) return fail(ctx, TRK_ERR_ARG, "assoc params/outputs are NULL");
+    if (prm->n_vec < 1 || prm->n_vec > TRK_ASSOC_MAX_VEC)
+        return fail(ctx, TRK_ERR_ARG, "n_vec %d outside [1,%d]", prm->n_vec, TRK_ASSOC_MAX_VEC);
+    if (in->group_bits) return fail(ctx, TRK_ERR_ARG, "sample groups are not used by the association scan");
+    if (in->n_loci == 0) return TRK_OK;
+    if (!prm->vec || !prm->allele_len || !prm->rlen_class) return fail(ctx, TRK_ERR_ARG, "assoc inputs are NULL");
+    if (!out->locus_int || !out->locus_f64 || !out->allele_count)
+        return fail(ctx, TRK_ERR_ARG, "assoc outputs are NULL");
+    (void)hipSetDevice(ctx->device);
+    const size_t need = trk::assoc_workspace_bytes(*in, prm->n_vec);
+    if (need > ctx->assoc_ws_bytes) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->assoc_ws) (void)hipFree(ctx->assoc_ws);
+        ctx->assoc_ws = nullptr;
+        ctx->assoc_ws_bytes = 0;
+        hipError_t e = hipMalloc(&ctx->assoc_ws, need);
+        if (e != hipSuccess) return fail(ctx, TRK_ERR_NOMEM, "assoc workspace hipMalloc(%zu): %s", need, hipGetErrorString(e));
+        ctx->assoc_ws_bytes = need;
+    }
+    HIPCHK(ctx, trk::launch_assoc_prepare(*in, *prm, *out, ctx->assoc_ws, ctx->stream));
+    {
+        ProfScope ps(ctx, TRK_K_ASSOC_SCAN);
+        HIPCHK(ctx, trk::launch_assoc_scan(*in, *prm, *out, ctx->assoc_ws, ctx->stream));
+    }
+    {
+        ProfScope ps(ctx, TRK_K_ASSOC_FINALIZE);
+        HIPCHK(ctx, trk::launch_assoc_finalize(*in, *prm, *out, ctx->assoc_ws, ctx->stream));
+    }
+    return TRK_OK;
+}
+
+double trk_student_t_two_sided(double t, double df) { return trkmath::student_t_two_sided(t, df); }
+
 double trk_binomtest_two_sided(int64_t k, int64_t n, double p) {
     if (n < 1 || k < 0 || k > n || !(p >= 0.0 && p <= 1.0)) return std::nan("");
     return trkmath::binomtest_two_sided(k, n, p);

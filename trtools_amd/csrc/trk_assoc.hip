@@ -1,0 +1,799 @@
+// trk_assoc.hip -- associaTR linear-regression scan for gfx950.
+//
+// Reference loop (one Python iteration + one statsmodels OLS fit per locus):
+//   trtools/associaTR/load_and_filter_genotypes.py:157-259, trtools/associaTR/associaTR.py:246-291.
+// Here: ONE pass over the genotype tensor produces, per locus, the cross-products the
+// regression needs (float64) and the allele histogram of the tested samples; a second,
+// thread-per-locus kernel applies the locus filters, solves the normal equations by
+// Cholesky and evaluates the Student-t tail.
+//
+//   k_assoc_gram      Gram matrix of [outcome, covariates, 1] over the regression sample set
+//                     (once per call; per-locus Grams are this minus the rows of samples whose
+//                     call is missing at the locus).
+//   k_assoc_scan<MV>  HBM-bound streaming kernel.  Workgroup = 16 waves sharing one chunk of
+//                     the sample vectors in LDS (float64, masked); each WAVE streams the
+//                     genotype row segment of one locus (16 B nontemporal loads per lane), looks
+//                     the two allele lengths up in a per-wave LDS table, and accumulates
+//                         n, sum g, sum g^2, sum g*vec_k        (g = summed length, pivoted)
+//                     in registers, the allele histogram in K bank-private LDS copies (as
+//                     k_locus_count_v2), and -- on the rare lanes whose call is missing -- the
+//                     Gram correction, one matrix entry per lane.  4 B of HBM traffic per call.
+//   k_assoc_scan_any  any ploidy / alignment / allele count (correctness path).
+//   k_assoc_finalize  thread per locus: filters (numpy's pairwise summation order restated so
+//                     that the cutoff comparison is bit-exact), Cholesky with the genotype
+//                     column last (beta = z_p / L_pp, var = scale / L_pp^2, ssr = y'y - |z|^2),
+//                     two-sided t tail (trk_student.h).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "../../include/trk.h"
+#include "trk_internal.h"
+#include "trk_student.h"
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int AS_WAVES = 16;                 // waves per workgroup of the scan kernel
+constexpr int AS_THREADS = WAVE * AS_WAVES;  // 1024
+constexpr int AS_MAXV = TRK_ASSOC_MAX_VEC;   // 16
+constexpr int AS_MAXNC = (AS_MAXV + 1) * (AS_MAXV + 2) / 2;  // 153 Gram entries of [vec..., 1]
+constexpr int AS_E = (AS_MAXNC + WAVE - 1) / WAVE;           // Gram entries per lane (3)
+constexpr int FIN_T = 64;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+// columns of the per-(chunk, locus) partial record (float64):
+//   0 n | 1 sum g | 2 sum g^2 | 3..3+M-1 sum g*vec_k | 3+M.. Gram correction (NC) | last: n_bad
+struct AssocArgs {
+    trk_batch b;
+    const double* vec;         // [M, S]
+    const uint8_t* sample_in;  // [S] or null
+    const double* allele_len;  // [sumA]
+    double* partial;           // [nchunks, L, NS]
+    int32_t* allele_count;     // [sumA]
+    int M, NS, NC;
+    int chunk;                 // samples per chunk (multiple of 256)
+    int nchunks;
+    int loci_per_wg;
+    int wave_bytes;            // LDS bytes of one wave's private area (LUT + histogram)
+    int kshift;
+    uint8_t pa[AS_MAXNC], pb[AS_MAXNC];  // Gram entry e = row pa[e] x row pb[e]; row M = ones
+};
+
+// -------------------------------------------------------------------------------------------
+// Gram matrix of the sample vectors (+ ones) over the regression set: one thread per entry
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_assoc_gram(AssocArgs a, double* __restrict__ full) {
+    const int e = blockIdx.x;
+    const int S = a.b.n_samples;
+    const int ra = a.pa[e], rb = a.pb[e];
+    double acc = 0.0;
+    for (int s = threadIdx.x; s < S; s += 256) {
+        if (a.sample_in && !a.sample_in[s]) continue;
+        const double x = ra == a.M ? 1.0 : a.vec[(size_t)ra * S + s];
+        const double y = rb == a.M ? 1.0 : a.vec[(size_t)rb * S + s];
+        acc += x * y;
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) full[e] = red[0];
+}
+
+// -------------------------------------------------------------------------------------------
+// streaming scan, diploid fast path
+// -------------------------------------------------------------------------------------------
+template <int MV>
+struct Acc {
+    int n = 0;
+    double sg = 0.0, sgg = 0.0;
+    double sgv[MV];
+    double corr[AS_E];
+};
+
+template <int MV>
+__global__ __launch_bounds__(AS_THREADS) void k_assoc_scan(const AssocArgs a) {
+    extern __shared__ double lds_d[];
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wid = tid >> 6;
+    const int S = a.b.n_samples, M = a.M, Sc = a.chunk;
+    const int s_begin = blockIdx.y * Sc;
+    const int ns = min(S - s_begin, Sc);  // multiple of 4
+    double* vec = lds_d;                                              // [M][Sc]
+    uint32_t* maskw = reinterpret_cast<uint32_t*>(vec + (size_t)M * Sc);  // [Sc/4] one byte per sample
+    unsigned char* wave_area = reinterpret_cast<unsigned char*>(maskw + Sc / 4) + (size_t)wid * a.wave_bytes;
+
+    // stage this chunk of the sample vectors (zero for samples outside the regression set)
+    for (int i = tid; i < ns; i += AS_THREADS) {
+        const bool in = !a.sample_in || a.sample_in[s_begin + i];
+        reinterpret_cast<unsigned char*>(maskw)[i] = in ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < MV; ++k)
+            if (k < M) vec[(size_t)k * Sc + i] = in ? a.vec[(size_t)k * S + s_begin + i] : 0.0;
+    }
+    __syncthreads();
+
+    // this lane's Gram entries (rare path)
+    int pa[AS_E], pb[AS_E];
+#pragma unroll
+    for (int e = 0; e < AS_E; ++e) {
+        const int idx = lane + e * WAVE;
+        pa[e] = idx < a.NC ? a.pa[idx] : -1;
+        pb[e] = idx < a.NC ? a.pb[idx] : -1;
+    }
+    const int K = 1 << a.kshift, kslot = lane & (K - 1);
+    const int nch = ns >> 2;
+    const int l0 = blockIdx.x * a.loci_per_wg;
+    const int l1 = min(a.b.n_loci, l0 + a.loci_per_wg);
+
+    for (int l = l0 + wid; l < l1; l += AS_WAVES) {  // waves are independent from here on
+        const int off = a.b.allele_off[l];
+        const int A = a.b.allele_off[l + 1] - off;
+        // bins: 0 '-2' (and every call that is not tested), 1 '-1', 2..A+1 alleles, A+2 out of range
+        double* lut = reinterpret_cast<double*>(wave_area);           // [A+3] pivoted lengths by BIN
+        uint32_t* hist = reinterpret_cast<uint32_t*>(lut + (A + 3));  // [(A+3) << kshift]
+        const double pivot = a.allele_len[off];
+        for (int i = lane; i < A; i += WAVE) lut[i + 2] = a.allele_len[off + i] - pivot;
+        if (lane == 0) {
+            lut[0] = -2.0 - pivot;  // GetLengthGenotypes maps the padding index -2 to the length -2
+            lut[1] = 0.0;
+            lut[A + 2] = 0.0;
+        }
+        for (int i = lane; i < ((A + 3) << a.kshift); i += WAVE) hist[i] = 0;
+        wave_fence();
+
+        Acc<MV> acc;
+#pragma unroll
+        for (int k = 0; k < MV; ++k) acc.sgv[k] = 0.0;
+#pragma unroll
+        for (int e = 0; e < AS_E; ++e) acc.corr[e] = 0.0;
+        const u32x4* row = reinterpret_cast<const u32x4*>(a.b.gt + ((int64_t)l * S + s_begin) * 2);
+        const uint32_t amax2 = (uint32_t)(A + 2) * 0x00010001u;
+
+        for (int c0 = 0; c0 < nch; c0 += WAVE) {
+            const int c = c0 + lane;
+            const bool live = c < nch;
+            u32x4 v = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            uint32_t mk = 0;
+            if (live) {
+                v = __builtin_nontemporal_load(&row[c]);
+                mk = maskw[c];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t w = v[j];
+                const bool in = (mk >> (8 * j)) & 1u;
+                u16x2 u = __builtin_bit_cast(u16x2, w) + (u16x2){2, 2};
+                u16x2 t2 = __builtin_elementwise_min(u, __builtin_bit_cast(u16x2, amax2));
+                const uint32_t t = __builtin_bit_cast(uint32_t, t2);
+                const uint32_t lo = t & 0xffffu, hi = t >> 16;
+                const bool miss = (lo == 1u) | (hi == 1u);
+                const bool ok = in & !miss;
+                double g = lut[lo] + lut[hi];
+                g = ok ? g : 0.0;
+                acc.n += ok;
+                acc.sg += g;
+                acc.sgg = __builtin_fma(g, g, acc.sgg);
+                const int s = c * 4 + j;
+#pragma unroll
+                for (int k = 0; k < MV; ++k)
+                    if (k < M) acc.sgv[k] = __builtin_fma(g, live ? vec[(size_t)k * Sc + s] : 0.0, acc.sgv[k]);
+                atomicAdd(&hist[((ok ? lo : 0u) << a.kshift) + kslot], 1u);
+                atomicAdd(&hist[((ok ? hi : 0u) << a.kshift) + kslot], 1u);
+                // samples of the regression set whose call is missing here leave the locus's
+                // Gram matrix: a few % of the calls; the wave walks them one at a time and each
+                // lane updates the matrix entries it owns
+                uint64_t mm = __ballot(in & miss);
+                while (mm) {
+                    const int src = __ffsll((long long)mm) - 1;
+                    mm &= mm - 1;
+                    const int sm = (c0 + src) * 4 + j;
+#pragma unroll
+                    for (int e = 0; e < AS_E; ++e) {
+                        if (pa[e] < 0) continue;
+                        const double x = pa[e] == M ? 1.0 : vec[(size_t)pa[e] * Sc + sm];
+                        const double y = pb[e] == M ? 1.0 : vec[(size_t)pb[e] * Sc + sm];
+                        acc.corr[e] += x * y;
+                    }
+                }
+            }
+        }
+        wave_fence();
+        // ---- reduce and write this (chunk, locus) record --------------------------------------
+        double* rec = a.partial + ((size_t)blockIdx.y * a.b.n_loci + l) * a.NS;
+        const int n = wave_sum_i32(acc.n);
+        const double sg = wave_sum_f64(acc.sg), sgg = wave_sum_f64(acc.sgg);
+        if (lane == 0) {
+            rec[0] = (double)n;
+            rec[1] = sg;
+            rec[2] = sgg;
+        }
+#pragma unroll
+        for (int k = 0; k < MV; ++k)
+            if (k < M) {
+                const double t = wave_sum_f64(acc.sgv[k]);
+                if (lane == 0) rec[3 + k] = t;
+            }
+#pragma unroll
+        for (int e = 0; e < AS_E; ++e)
+            if (pa[e] >= 0) rec[3 + M + lane + e * WAVE] = acc.corr[e];
+        for (int bin = lane; bin < A + 3; bin += WAVE) {
+            uint32_t sum = 0;
+            for (int k = 0; k < K; ++k) sum += hist[(bin << a.kshift) + ((k + lane) & (K - 1))];
+            if (bin >= 2 && bin < A + 2) {
+                if (a.nchunks == 1)
+                    a.allele_count[off + bin - 2] = (int32_t)sum;
+                else if (sum)
+                    atomicAdd(&a.allele_count[off + bin - 2], (int32_t)sum);
+            }
+            if (bin == A + 2) rec[a.NS - 1] = (double)sum;
+        }
+        wave_fence();
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// streaming scan, any ploidy / alignment / allele count: wave per locus, operands from global
+// memory, histogram by global atomics (allele_count zeroed by the launcher)
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_assoc_scan_any(const AssocArgs a) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int l = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (l >= a.b.n_loci) return;
+    const int S = a.b.n_samples, P = a.b.ploidy, M = a.M;
+    const int pl = a.b.locus_ploidy ? a.b.locus_ploidy[l] : P;
+    const int off = a.b.allele_off[l];
+    const int A = a.b.allele_off[l + 1] - off;
+    const double pivot = a.allele_len[off];
+    int n = 0, n_bad = 0;
+    double sg = 0.0, sgg = 0.0, sgv[AS_MAXV], corr[AS_E];
+    for (int k = 0; k < AS_MAXV; ++k) sgv[k] = 0.0;
+    for (int e = 0; e < AS_E; ++e) corr[e] = 0.0;
+    for (int s0 = 0; s0 < S; s0 += WAVE) {
+        const int s = s0 + lane;
+        bool in = false, miss = false;
+        double g = 0.0;
+        if (s < S) {
+            in = !a.sample_in || a.sample_in[s];
+            const int16_t* cell = a.b.gt + ((int64_t)l * S + s) * P;
+            for (int p = 0; p < pl; ++p) miss |= cell[p] == -1;
+            if (in && !miss) {
+                for (int p = 0; p < pl; ++p) {
+                    const int al = cell[p];
+                    if (al == -2) {
+                        g += -2.0 - pivot;
+                    } else if (al >= 0 && al < A) {
+                        g += a.allele_len[off + al] - pivot;
+                        atomicAdd(&a.allele_count[off + al], 1);
+                    } else {
+                        ++n_bad;
+                    }
+                }
+                ++n;
+                sg += g;
+                sgg = __builtin_fma(g, g, sgg);
+                for (int k = 0; k < M; ++k) sgv[k] = __builtin_fma(g, a.vec[(size_t)k * S + s], sgv[k]);
+            }
+        }
+        uint64_t mm = __ballot(in & miss);
+        while (mm) {
+            const int src = __ffsll((long long)mm) - 1;
+            mm &= mm - 1;
+            const int sm = s0 + src;
+            for (int e = 0; e < AS_E; ++e) {
+                const int idx = lane + e * WAVE;
+                if (idx >= a.NC) continue;
+                const double x = a.pa[idx] == M ? 1.0 : a.vec[(size_t)a.pa[idx] * S + sm];
+                const double y = a.pb[idx] == M ? 1.0 : a.vec[(size_t)a.pb[idx] * S + sm];
+                corr[e] += x * y;
+            }
+        }
+    }
+    double* rec = a.partial + (size_t)l * a.NS;
+    n = wave_sum_i32(n);
+    n_bad = wave_sum_i32(n_bad);
+    sg = wave_sum_f64(sg);
+    sgg = wave_sum_f64(sgg);
+    if (lane == 0) {
+        rec[0] = (double)n;
+        rec[1] = sg;
+        rec[2] = sgg;
+        rec[a.NS - 1] = (double)n_bad;
+    }
+    for (int k = 0; k < M; ++k) {
+        const double t = wave_sum_f64(sgv[k]);
+        if (lane == 0) rec[3 + k] = t;
+    }
+    for (int e = 0; e < AS_E; ++e) {
+        const int idx = lane + e * WAVE;
+        if (idx < a.NC) rec[3 + M + idx] = corr[e];
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// finaliser
+// -------------------------------------------------------------------------------------------
+// The frequencies of the ROUNDED length alleles in ascending order, one at a time
+// (load_and_filter_genotypes.py:37-45 on top of GetAlleleFreqs, tr_harmonizer.py:1501-1540):
+// classes of equal length were merged as integer counts; classes whose rounded lengths
+// coincide are merged as float frequencies, added in ascending order.
+struct AfStream {
+    const int32_t* cc;          // class counts of this locus
+    const uint16_t* rcls;       // rounded class of each length class
+    int ncls, c;
+    double total;
+    __device__ void reset() { c = 0; }
+    __device__ bool next(double& f) {
+        while (c < ncls && cc[c] == 0) ++c;
+        if (c >= ncls) return false;
+        const int r = rcls[c];
+        f = (double)cc[c] / total;
+        ++c;
+        while (c < ncls) {
+            if (cc[c] == 0) {
+                ++c;
+                continue;
+            }
+            if (rcls[c] != r) break;
+            f += (double)cc[c] / total;
+            ++c;
+        }
+        return true;
+    }
+};
+
+// numpy's pairwise summation (np.add.reduce on a contiguous float64 vector: blocks of 8
+// accumulators up to 128 elements, recursive halving above) over the stream with element
+// `skip` removed; elements are consumed strictly in order, so the recursion only needs the sizes
+struct PwSum {
+    AfStream* st;
+    int idx, skip;
+    __device__ double take() {
+        double f = 0.0;
+        for (;;) {
+            st->next(f);
+            if (idx++ != skip) return f;
+        }
+    }
+    __device__ double leaf(int n) {
+        if (n < 8) {
+            double res = 0.0;
+            for (int i = 0; i < n; ++i) res += take();
+            return res;
+        }
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = take();
+        int i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += take();
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += take();
+        return res;
+    }
+    __device__ double sum(int n) {
+        int fn[24], stage[24];
+        double left[24];
+        int sp = 0;
+        fn[0] = n;
+        stage[0] = 0;
+        double ret = 0.0;
+        while (sp >= 0) {
+            const int m = fn[sp];
+            if (m <= 128) {
+                ret = leaf(m);
+                --sp;
+                continue;
+            }
+            int n2 = m / 2;
+            n2 -= n2 % 8;
+            if (stage[sp] == 0) {
+                stage[sp] = 1;
+                fn[sp + 1] = n2;
+                stage[sp + 1] = 0;
+                ++sp;
+            } else if (stage[sp] == 1) {
+                left[sp] = ret;
+                stage[sp] = 2;
+                fn[sp + 1] = m - n2;
+                stage[sp + 1] = 0;
+                ++sp;
+            } else {
+                ret = left[sp] + ret;
+                --sp;
+            }
+        }
+        return ret;
+    }
+};
+
+struct FinArgs {
+    trk_batch b;
+    const double* partial;
+    const double* full;          // [NC]
+    const int32_t* allele_count;
+    int32_t* cc;                 // [sumA] scratch, zeroed
+    const uint16_t* rlen_class;
+    const double* allele_len;
+    int32_t* locus_int;
+    double* locus_f64;
+    double cutoff;
+    int M, NS, NC, nchunks;
+};
+
+// index of Gram entry (r, c), r <= c, rows 0..M (row M = ones), row-major upper triangle
+__device__ __forceinline__ int gidx(int r, int c, int M) { return r * (M + 1) - r * (r - 1) / 2 + (c - r); }
+
+__global__ __launch_bounds__(FIN_T) void k_assoc_finalize(const FinArgs a) {
+    extern __shared__ double fin_lds[];  // [entries][FIN_T], one column per thread
+    const int l = blockIdx.x * FIN_T + threadIdx.x;
+    if (l >= a.b.n_loci) return;
+    const int M = a.M, L = a.b.n_loci;
+    const int P = M + 1;  // design columns: ones, covariates 1..M-1, genotype (last)
+#define LW(e) fin_lds[(size_t)(e) * FIN_T + threadIdx.x]
+    int32_t* li = a.locus_int + (size_t)l * TRK_AI_COLS;
+    double* lf = a.locus_f64 + (size_t)l * TRK_AF_COLS;
+    for (int i = 0; i < TRK_AI_COLS; ++i) li[i] = 0;
+    for (int i = 0; i < TRK_AF_COLS; ++i) lf[i] = NAN;
+
+    // ---- partial records of the sample chunks, in chunk order --------------------------------
+    double n_d = 0.0, sg = 0.0, sgg = 0.0, n_bad = 0.0;
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+        const double* rec = a.partial + ((size_t)ch * L + l) * a.NS;
+        n_d += rec[0];
+        sg += rec[1];
+        sgg += rec[2];
+        n_bad += rec[a.NS - 1];
+    }
+    const int n = (int)n_d;
+    li[TRK_AI_N_TESTED] = n;
+    li[TRK_AI_N_BAD] = (int)n_bad;
+
+    // ---- allele frequencies and the locus filters --------------------------------------------
+    const int off = a.b.allele_off[l];
+    const int A = a.b.allele_off[l + 1] - off;
+    int32_t* cc = a.cc + off;
+    int64_t total = 0;
+    for (int i = 0; i < A; ++i) {
+        const int cnt = a.allele_count[off + i];
+        if (cnt) {
+            cc[a.b.len_class[off + i]] += cnt;
+            total += cnt;
+        }
+    }
+    li[TRK_AI_N_HAPS] = (int)total;
+    AfStream st{cc, a.rlen_class + off, A, 0, (double)total};
+    int R = 0, argmax = 0;
+    double fmax = -1.0, f;
+    st.reset();
+    while (st.next(f)) {
+        if (f > fmax) {
+            fmax = f;
+            argmax = R;
+        }
+        ++R;
+    }
+    li[TRK_AI_N_RALLELES] = R;
+    int status = TRK_AS_OK;
+    if (R == 0) {
+        status = TRK_AS_NO_CALLED;
+    } else if (R == 1) {
+        status = TRK_AS_ONE_ALLELE;
+    } else {
+        st.reset();
+        PwSum pw{&st, 0, argmax};
+        const double s_af = 0.0 + pw.sum(R - 1);
+        const double nonmajor = s_af * (double)n * 2.0;
+        lf[TRK_AF_NONMAJOR] = nonmajor;
+        if (nonmajor < a.cutoff)
+            status = TRK_AS_NON_MAJOR;
+        else if (M + 1 >= n)
+            status = TRK_AS_N_COVARS;
+    }
+    if (status != TRK_AS_OK) {
+        li[TRK_AI_STATUS] = status;
+        return;
+    }
+
+    // ---- standardised genotype ---------------------------------------------------------------
+    const double mean = sg / n_d;
+    const double var = (sgg - sg * mean) / n_d;
+    const int plv = a.b.locus_ploidy ? a.b.locus_ploidy[l] : a.b.ploidy;
+    lf[TRK_AF_GT_MEAN] = mean + (double)plv * a.allele_len[off];  // undo the pivot (len(ref) per haplotype)
+    if (!(var > 1e-12 * (sgg / n_d))) {  // constant up to rounding of the running sums
+        li[TRK_AI_STATUS] = TRK_AS_ZERO_VARIANCE;
+        return;
+    }
+    const double sd = sqrt(var);
+    lf[TRK_AF_GT_STD] = sd;
+
+    // ---- Gram matrix of the called samples: full - correction --------------------------------
+    // LDS column: packed lower triangle of the P x P normal matrix (row-major), then rhs [P]
+    const int ntri = P * (P + 1) / 2;
+    auto G = [&](int r, int c) {  // Gram entry of vec rows r <= c (row M = ones)
+        const int e = gidx(r, c, M);
+        double v = a.full[e];
+        for (int ch = 0; ch < a.nchunks; ++ch) v -= a.partial[((size_t)ch * L + l) * a.NS + 3 + M + e];
+        return v;
+    };
+    auto row_of = [&](int j) { return j == 0 ? M : j; };  // design column j < M -> vec row
+    for (int i = 0; i < M; ++i)
+        for (int j = 0; j <= i; ++j) {
+            int r = row_of(i), c = row_of(j);
+            if (r > c) {
+                int t = r;
+                r = c;
+                c = t;
+            }
+            LW(i * (i + 1) / 2 + j) = G(r, c);
+        }
+    const double sy = G(0, M), yy = G(0, 0);
+    for (int j = 0; j < M; ++j) {
+        // genotype row: sum g~ * column_j = (sum g*col_j - mean * sum col_j) / sd
+        double sgc, sc;
+        if (j == 0) {
+            sgc = sg;
+            sc = n_d;
+        } else {
+            sgc = 0.0;
+            for (int ch = 0; ch < a.nchunks; ++ch) sgc += a.partial[((size_t)ch * L + l) * a.NS + 3 + j];
+            sc = G(j, M);
+        }
+        LW(M * (M + 1) / 2 + j) = (sgc - mean * sc) / sd;
+        LW(ntri + j) = j == 0 ? sy : G(0, j);  // rhs: column_j ' y
+    }
+    LW(M * (M + 1) / 2 + M) = n_d;  // g~ ' g~
+    {
+        double sgy = 0.0;
+        for (int ch = 0; ch < a.nchunks; ++ch) sgy += a.partial[((size_t)ch * L + l) * a.NS + 3];
+        LW(ntri + M) = (sgy - mean * sy) / sd;
+    }
+
+    // ---- Cholesky with forward substitution; dependent columns are dropped (pinv semantics) ---
+    int rank = 0;
+    double zz = 0.0, lpp = 0.0, zp = 0.0;
+    bool last_dependent = false;
+    for (int j = 0; j < P; ++j) {
+        const double ajj = LW(j * (j + 1) / 2 + j);
+        double d = ajj;
+        for (int k = 0; k < j; ++k) {
+            const double v = LW(j * (j + 1) / 2 + k);
+            d -= v * v;
+        }
+        if (!(d > 1e-11 * ajj)) {  // column in the span of the previous ones
+            for (int i = j; i < P; ++i) LW(i * (i + 1) / 2 + j) = 0.0;
+            LW(ntri + j) = 0.0;
+            if (j == P - 1) last_dependent = true;
+            continue;
+        }
+        const double ljj = sqrt(d);
+        LW(j * (j + 1) / 2 + j) = ljj;
+        for (int i = j + 1; i < P; ++i) {
+            double v = LW(i * (i + 1) / 2 + j);
+            for (int k = 0; k < j; ++k) v -= LW(i * (i + 1) / 2 + k) * LW(j * (j + 1) / 2 + k);
+            LW(i * (i + 1) / 2 + j) = v / ljj;
+        }
+        double z = LW(ntri + j);
+        for (int k = 0; k < j; ++k) z -= LW(j * (j + 1) / 2 + k) * LW(ntri + k);
+        z /= ljj;
+        LW(ntri + j) = z;
+        zz += z * z;
+        ++rank;
+        if (j == P - 1) {
+            lpp = ljj;
+            zp = z;
+        }
+    }
+    li[TRK_AI_RANK] = rank;
+    if (last_dependent) {
+        li[TRK_AI_STATUS] = TRK_AS_COLLINEAR;
+        return;
+    }
+    const double df = n_d - (double)rank;
+    const double ssr = yy - zz;
+    const double scale = ssr / df;
+    const double coef = zp / lpp;
+    const double se = sqrt(scale) / lpp;
+    const double tval = coef / se;
+    const double tss = yy - sy * sy / n_d;
+    lf[TRK_AF_COEF] = coef;
+    lf[TRK_AF_SE] = se;
+    lf[TRK_AF_TVALUE] = tval;
+    lf[TRK_AF_DF_RESID] = df;
+    lf[TRK_AF_RSQUARED] = 1.0 - ssr / tss;
+    lf[TRK_AF_PVAL] = trkmath::student_t_two_sided(tval, df);
+    li[TRK_AI_STATUS] = TRK_AS_OK;
+#undef LW
+}
+
+}  // namespace
+
+namespace trk {
+
+struct AssocPlan {
+    bool fast;
+    int chunk, nchunks, wave_bytes, kshift, loci_per_wg, mv;
+    size_t lds_bytes;
+};
+
+static AssocPlan assoc_plan(const trk_batch& b, int M) {
+    AssocPlan p{};
+    p.nchunks = 1;
+    const int S = b.n_samples, Amax = b.max_alleles;
+    p.mv = M <= 1 ? 1 : M <= 2 ? 2 : M <= 4 ? 4 : M <= 8 ? 8 : 16;
+    if (getenv("TRK_AS_GENERIC")) return p;
+    if (b.ploidy != 2 || b.locus_ploidy || S <= 0 || (S % 4) != 0 || Amax <= 0 || Amax + 3 >= 65535 ||
+        (reinterpret_cast<uintptr_t>(b.gt) & 15))
+        return p;
+    // one wave's private area: LUT (A+3 doubles) + histogram (A+3 bins x K copies), at most 4 KiB
+    int kshift = 4;
+    while (kshift >= 0 && (Amax + 3) * (8 + (4 << kshift)) > 4096) --kshift;
+    if (kshift < 0) return p;
+    p.kshift = kshift;
+    p.wave_bytes = ((Amax + 3) * (8 + (4 << kshift)) + 15) & ~15;
+    const size_t lds_total = 160 * 1024;
+    const size_t rem = lds_total - (size_t)AS_WAVES * p.wave_bytes - 64;
+    int chunk = (int)(rem / (8 * (size_t)M + 1));
+    chunk &= ~255;
+    if (chunk < 256) return p;
+    const int s_pad = (S + 255) & ~255;
+    if (chunk >= s_pad) {
+        p.chunk = s_pad;
+        p.nchunks = 1;
+    } else {
+        p.nchunks = (S + chunk - 1) / chunk;
+        p.chunk = (((S + p.nchunks - 1) / p.nchunks) + 255) & ~255;  // balanced
+    }
+    p.lds_bytes = (size_t)M * p.chunk * 8 + p.chunk + (size_t)AS_WAVES * p.wave_bytes;
+    p.loci_per_wg = 48;
+    if (const char* e = getenv("TRK_AS_LB")) p.loci_per_wg = atoi(e) > 0 ? atoi(e) : 48;
+    p.fast = true;
+    return p;
+}
+
+size_t assoc_workspace_bytes(const trk_batch& b, int M) {
+    const AssocPlan p = assoc_plan(b, M);
+    const int NC = (M + 1) * (M + 2) / 2, NS = 3 + M + NC + 1;
+    size_t bytes = (size_t)NC * 8;                                    // full Gram
+    bytes += (size_t)p.nchunks * b.n_loci * NS * 8;                   // partial records
+    bytes += ((size_t)b.n_alleles_total * 4 + 7) & ~(size_t)7;        // class counts
+    return bytes + 64;
+}
+
+template <int MV>
+static hipError_t launch_scan_t(const AssocArgs& a, const AssocPlan& p, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assoc_scan<MV>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    if (e != hipSuccess) return e;
+    dim3 grid((a.b.n_loci + p.loci_per_wg - 1) / p.loci_per_wg, p.nchunks), block(AS_THREADS);
+    hipLaunchKernelGGL(k_assoc_scan<MV>, grid, block, p.lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+static void assoc_build(const trk_batch& b, const trk_assoc_params& prm, const trk_assoc_out& out, void* workspace,
+                        AssocPlan& p, AssocArgs& a, FinArgs& f, double*& full) {
+    const int M = prm.n_vec;
+    p = assoc_plan(b, M);
+    a = AssocArgs{};
+    a.b = b;
+    a.vec = prm.vec;
+    a.sample_in = prm.sample_in;
+    a.allele_len = prm.allele_len;
+    a.M = M;
+    a.NC = (M + 1) * (M + 2) / 2;
+    a.NS = 3 + M + a.NC + 1;
+    a.chunk = p.chunk;
+    a.nchunks = p.nchunks;
+    a.loci_per_wg = p.loci_per_wg;
+    a.wave_bytes = p.wave_bytes;
+    a.kshift = p.kshift;
+    int e = 0;
+    for (int r = 0; r <= M; ++r)
+        for (int c = r; c <= M; ++c) {
+            a.pa[e] = (uint8_t)r;
+            a.pb[e] = (uint8_t)c;
+            ++e;
+        }
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    full = reinterpret_cast<double*>(ws);
+    a.partial = reinterpret_cast<double*>(ws + (size_t)a.NC * 8);
+    a.allele_count = out.allele_count;
+    f = FinArgs{};
+    f.b = b;
+    f.partial = a.partial;
+    f.full = full;
+    f.allele_count = out.allele_count;
+    f.cc = reinterpret_cast<int32_t*>(ws + (size_t)a.NC * 8 + (size_t)p.nchunks * b.n_loci * a.NS * 8);
+    f.rlen_class = prm.rlen_class;
+    f.allele_len = prm.allele_len;
+    f.locus_int = out.locus_int;
+    f.locus_f64 = out.locus_f64;
+    f.cutoff = prm.non_major_cutoff;
+    f.M = M;
+    f.NS = a.NS;
+    f.NC = a.NC;
+    f.nchunks = p.nchunks;
+}
+
+// step 1 (cheap): zero the scratch, Gram matrix of the regression set
+hipError_t launch_assoc_prepare(const trk_batch& b, const trk_assoc_params& prm, const trk_assoc_out& out,
+                                void* workspace, hipStream_t stream) {
+    AssocPlan p;
+    AssocArgs a;
+    FinArgs f;
+    double* full;
+    assoc_build(b, prm, out, workspace, p, a, f, full);
+    hipError_t err;
+    if (b.n_alleles_total > 0) {
+        if ((err = hipMemsetAsync(f.cc, 0, (size_t)b.n_alleles_total * 4, stream)) != hipSuccess) return err;
+        if (!p.fast || p.nchunks > 1)
+            if ((err = hipMemsetAsync(out.allele_count, 0, (size_t)b.n_alleles_total * 4, stream)) != hipSuccess)
+                return err;
+    }
+    hipLaunchKernelGGL(k_assoc_gram, dim3(a.NC), dim3(256), 0, stream, a, full);
+    return hipGetLastError();
+}
+
+// step 2: the streaming pass over the genotype tensor
+hipError_t launch_assoc_scan(const trk_batch& b, const trk_assoc_params& prm, const trk_assoc_out& out,
+                             void* workspace, hipStream_t stream) {
+    AssocPlan p;
+    AssocArgs a;
+    FinArgs f;
+    double* full;
+    assoc_build(b, prm, out, workspace, p, a, f, full);
+    if (b.n_loci == 0) return hipSuccess;
+    if (p.fast) {
+        switch (p.mv) {
+            case 1: return launch_scan_t<1>(a, p, stream);
+            case 2: return launch_scan_t<2>(a, p, stream);
+            case 4: return launch_scan_t<4>(a, p, stream);
+            case 8: return launch_scan_t<8>(a, p, stream);
+            default: return launch_scan_t<16>(a, p, stream);
+        }
+    }
+    hipLaunchKernelGGL(k_assoc_scan_any, dim3((b.n_loci + 3) / 4), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// step 3: filters + regression per locus
+hipError_t launch_assoc_finalize(const trk_batch& b, const trk_assoc_params& prm, const trk_assoc_out& out,
+                                 void* workspace, hipStream_t stream) {
+    AssocPlan p;
+    AssocArgs a;
+    FinArgs f;
+    double* full;
+    assoc_build(b, prm, out, workspace, p, a, f, full);
+    if (b.n_loci == 0) return hipSuccess;
+    const int P = prm.n_vec + 1;
+    const size_t fin_lds = (size_t)(P * (P + 1) / 2 + P) * FIN_T * 8;
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assoc_finalize),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(k_assoc_finalize, dim3((b.n_loci + FIN_T - 1) / FIN_T), dim3(FIN_T), fin_lds, stream, f);
+    return hipGetLastError();
+}
+
+}  // namespace trk

@@ -26,5 +26,13 @@ hipError_t launch_synth(const trk_synth_spec& sp, int16_t* gt, int32_t* dp, floa
 hipError_t launch_synth_gangstr(const trk_synth_spec& sp, const int16_t* gt, const int32_t* dp,
                                 const int32_t* allele_repcn, float* qexp, int32_t* repcn, int32_t* rc,
                                 int32_t* repci, int n_cu, hipStream_t stream);
+// associaTR scan (trk_assoc.hip): prepare -> scan -> finalize on the same stream and workspace
+size_t assoc_workspace_bytes(const trk_batch& b, int n_vec);
+hipError_t launch_assoc_prepare(const trk_batch& b, const trk_assoc_params& prm, const trk_assoc_out& out,
+                                void* workspace, hipStream_t stream);
+hipError_t launch_assoc_scan(const trk_batch& b, const trk_assoc_params& prm, const trk_assoc_out& out,
+                             void* workspace, hipStream_t stream);
+hipError_t launch_assoc_finalize(const trk_batch& b, const trk_assoc_params& prm, const trk_assoc_out& out,
+                                 void* workspace, hipStream_t stream);
 }  // namespace trk
 #endif

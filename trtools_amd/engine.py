@@ -98,6 +98,12 @@ class StatsResult:
         self.struct = L.StatsOut(allele_count.ptr, locus_int.ptr, locus_f64.ptr if locus_f64 else None)
 
 
+class AssocResult:
+    def __init__(self, locus_int, locus_f64, allele_count):
+        self.locus_int, self.locus_f64, self.allele_count = locus_int, locus_f64, allele_count
+        self.struct = L.AssocOut(locus_int.ptr, locus_f64.ptr, allele_count.ptr)
+
+
 class CallResult:
     def __init__(self, gt_out, filter_mask, sample_counters, sample_totaldp, sample_dp_missing, error):
         self.gt_out = gt_out
@@ -322,6 +328,34 @@ class Engine:
         return bits_out, counters
 
     # ---- scalar helpers ----
+    # ---- associaTR scan ----
+    def assoc_scan(self, batch, vec, allele_len, rlen_class, sample_in=None, non_major_cutoff=20.0, out=None):
+        """trk_assoc_scan: vec [M, S] float64 (row 0 the standardised outcome, rows 1.. covariates),
+        allele_len [sumA] float64, rlen_class [sumA] uint16, sample_in [S] uint8 or None.
+        Returns AssocResult (device arrays locus_int [L, AI_COLS], locus_f64 [L, AF_COLS], allele_count [sumA])."""
+        def dev(x, dt):
+            return x if isinstance(x, DeviceArray) else self.upload(x, dt)
+        vec_d = dev(vec, np.float64)
+        if len(vec_d.shape) != 2 or vec_d.shape[1] != batch.n_samples:
+            raise ValueError("vec must be [M, S]")
+        len_d, rc_d = dev(allele_len, np.float64), dev(rlen_class, np.uint16)
+        in_d = dev(sample_in, np.uint8) if sample_in is not None else None
+        if out is None:
+            out = AssocResult(self.empty((batch.n_loci, L.AI_COLS), np.int32),
+                              self.empty((batch.n_loci, L.AF_COLS), np.float64),
+                              self.empty((batch.sum_alleles,), np.int32))
+        prm = L.AssocParams()
+        prm.n_vec, prm.flags = vec_d.shape[0], 0
+        prm.vec, prm.allele_len, prm.rlen_class = vec_d.ptr, len_d.ptr, rc_d.ptr
+        prm.sample_in = in_d.ptr if in_d is not None else None
+        prm.non_major_cutoff = float(non_major_cutoff)
+        out._keep = (vec_d, len_d, rc_d, in_d)
+        self._chk(self.lib.trk_assoc_scan(self.ctx, C.byref(batch.struct), C.byref(prm), C.byref(out.struct)))
+        return out
+
+    def student_t_two_sided(self, t, df):
+        return float(self.lib.trk_student_t_two_sided(float(t), float(df)))
+
     def binomtest(self, k, n, p):
         return self.lib.trk_binomtest_two_sided(int(k), int(n), float(p))
 

@@ -64,6 +64,30 @@ def pack_alleles(allele_lens, allele_strs):
     return off, lc, sc, cv
 
 
+def pack_assoc_tables(allele_lens, precision=2):
+    """Per-locus length lists -> (allele_len [sumA] float64, rlen_class [sumA] uint16) of
+    ``trk_assoc_params`` (include/trk.h).  allele_len is the LUT of GetLengthGenotypes
+    (tr_harmonizer.py:1239) by allele index; rlen_class[allele_off[l] + c] is, for length class c
+    (classes as in pack_alleles), the dense rank of ``round(np.float64(length), precision)`` --
+    the key clean_len_alleles builds (associaTR/load_and_filter_genotypes.py:37-45; the keys are
+    numpy scalars there, so numpy's rounding applies)."""
+    total = sum(len(x) for x in allele_lens)
+    alen = np.zeros(total, dtype=np.float64)
+    rcls = np.zeros(total, dtype=np.uint16)
+    o = 0
+    for lens in allele_lens:
+        lens = [float(x) for x in lens]
+        alen[o:o + len(lens)] = lens
+        ul = sorted(set(lens))
+        rk = [round(np.float64(v), precision) for v in ul]
+        ur = sorted(set(rk))
+        rank = {v: r for r, v in enumerate(ur)}
+        for c, v in enumerate(rk):
+            rcls[o + c] = rank[v]
+        o += len(lens)
+    return alen, rcls
+
+
 # ---------------------------------------------------------------------------
 # per-locus tables
 # ---------------------------------------------------------------------------
