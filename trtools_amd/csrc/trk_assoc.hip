@@ -75,6 +75,7 @@ struct AssocArgs {
     int loci_per_wg;
     int wave_bytes;            // LDS bytes of one wave's private area (LUT + histogram)
     int kshift;
+    int dbg;                   // TRK_AS_DBG ablation bits (1: no rare path, 2: no histogram, 4: no LUT)
     uint8_t pa[AS_MAXNC], pb[AS_MAXNC];  // Gram entry e = row pa[e] x row pb[e]; row M = ones
 };
 
@@ -107,127 +108,298 @@ __global__ __launch_bounds__(256) void k_assoc_gram(AssocArgs a, double* __restr
 // -------------------------------------------------------------------------------------------
 template <int MV>
 struct Acc {
-    int n = 0;
+    static constexpr int E = ((MV + 1) * (MV + 2) / 2 + WAVE - 1) / WAVE;  // Gram entries per lane
     double sg = 0.0, sgg = 0.0;
     double sgv[MV];
-    double corr[AS_E];
+    double corr[E];
 };
 
+struct ScanCtx {
+    const double* lut;   // LDS, by BIN: 0 '-2', 1 '-1' (NaN), 2..A+1 alleles, A+2 out of range
+    uint32_t* hist;      // LDS, (A+3) bins x K copies
+    const double* vec;   // LDS [M][Sc]
+    int Sc, M, kshift, kslot;
+    uint32_t amax2;
+    int dbg;
+};
+
+// One chunk = 4 consecutive samples of one lane.  `mk`: their regression-set bytes (MASK only).
+// Returns the 4-bit set of samples that are in the regression set but not called here.
+template <int MV, bool MASK, bool TAIL>
+__device__ __forceinline__ uint32_t scan_chunk(const ScanCtx& x, const u32x4 v, uint32_t mk, int s0, bool live,
+                                               Acc<MV>& acc) {
+    // few vectors: fetch the four samples of every vector up front (two 16-byte LDS reads each);
+    // many vectors: read inside the loop, the accumulators need the registers
+    constexpr bool PRE = MV <= 2;
+    double y[PRE ? MV : 1][4];
+    if (PRE) {
+#pragma unroll
+        for (int k = 0; k < MV; ++k)
+            if (k < x.M) {
+                if (!TAIL || live) {
+                    const double2 a0 = *reinterpret_cast<const double2*>(&x.vec[(size_t)k * x.Sc + s0]);
+                    const double2 a1 = *reinterpret_cast<const double2*>(&x.vec[(size_t)k * x.Sc + s0 + 2]);
+                    y[k][0] = a0.x; y[k][1] = a0.y; y[k][2] = a1.x; y[k][3] = a1.y;
+                } else {
+                    y[k][0] = y[k][1] = y[k][2] = y[k][3] = 0.0;
+                }
+            }
+    }
+    uint32_t rare = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t w = v[j];
+        u16x2 u = __builtin_bit_cast(u16x2, w) + (u16x2){2, 2};
+        u16x2 t2 = __builtin_elementwise_min(u, __builtin_bit_cast(u16x2, x.amax2));
+        const uint32_t t = __builtin_bit_cast(uint32_t, t2);
+        const uint32_t lo = t & 0xffffu, hi = t >> 16;
+        double g = (x.dbg & 4) ? (double)(lo + hi) : x.lut[lo] + x.lut[hi];   // NaN when either haplotype is '-1'
+        const bool called = g == g;
+        bool ok = called;
+        if (MASK) {
+            const bool in = (mk >> (8 * j)) & 1u;
+            ok = called & in;
+            rare |= (uint32_t)(in & !called) << j;
+        } else {
+            rare |= (uint32_t)(!called) << j;
+        }
+        if (TAIL) {
+            ok &= live;
+        }
+        g = ok ? g : 0.0;
+        acc.sg += g;
+        acc.sgg = __builtin_fma(g, g, acc.sgg);
+#pragma unroll
+        for (int k = 0; k < MV; ++k)
+            if (k < x.M) {
+                const double yv = PRE ? y[k][j] : ((!TAIL || live) ? x.vec[(size_t)k * x.Sc + s0 + j] : 0.0);
+                acc.sgv[k] = __builtin_fma(g, yv, acc.sgv[k]);
+            }
+        // calls that are not tested are counted in bin 1 (2 per call): n = calls - bin1 / 2
+        if ((!TAIL || live) && !(x.dbg & 2)) {
+            atomicAdd(&x.hist[((ok ? lo : 1u) << x.kshift) + x.kslot], 1u);
+            atomicAdd(&x.hist[((ok ? hi : 1u) << x.kshift) + x.kslot], 1u);
+        }
+    }
+    if (TAIL && !live) rare = 0;
+    return rare;
+}
+
+// Samples of the regression set whose call is missing at this locus leave its Gram matrix
+// (a few % of the calls).  Doing that work where the call is met serialises the wave on LDS
+// latency (measured: 5.4 of 6.6 ms), so the main loop only QUEUES them -- one record per
+// 4-sample chunk that holds any: (chunk << 4 | 4-bit set), appended with ballot/mbcnt, order
+// deterministic -- and the queue is drained in bulk, when nearly full and at the end of the row.
+constexpr int AS_QCAP = 256;  // records per wave
+
+__device__ __forceinline__ void queue_push(uint32_t* q, int& qlen, uint32_t rare, int c) {
+    const uint64_t mm = __ballot(rare != 0);
+    if (mm) {
+        const int pos = qlen + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+        if (rare) q[pos] = ((uint32_t)c << 4) | rare;
+        qlen += __popcll(mm);
+    }
+}
+
+// few vectors: lane = queued sample; every lane keeps the whole (small) Gram triangle of its
+// samples in registers -- rows 0..MV-1 the vectors (zero beyond M), row MV the ones
 template <int MV>
+__device__ __forceinline__ void drain_by_sample(const ScanCtx& x, const uint32_t* q, int qlen, int lane, double* cs) {
+    wave_fence();
+    for (int base = 0; base < qlen; base += WAVE) {
+        const uint32_t rec = base + lane < qlen ? q[base + lane] : 0u;
+        uint32_t bits = rec & 15u;
+        const int c = (int)(rec >> 4);
+        while (bits) {
+            const int j = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            const int s = c * 4 + j;
+            double z[MV + 1];
+#pragma unroll
+            for (int k = 0; k < MV; ++k) z[k] = k < x.M ? x.vec[(size_t)k * x.Sc + s] : 0.0;
+            z[MV] = 1.0;
+            int e = 0;
+#pragma unroll
+            for (int r = 0; r <= MV; ++r)
+#pragma unroll
+                for (int cc = r; cc <= MV; ++cc) cs[e++] += z[r] * z[cc];
+        }
+    }
+    wave_fence();
+}
+
+// many vectors: lane = Gram entry (row pa x row pb, row M = ones); the queued samples are
+// walked four at a time so that eight LDS reads are in flight
+template <int MV>
+__device__ __forceinline__ void drain_by_entry(const ScanCtx& x, const uint32_t* q, int qlen, int lane,
+                                               const int* pa, const int* pb, double* corr) {
+    constexpr int E = Acc<MV>::E;
+    wave_fence();
+    auto one = [&](int s) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (pa[e] < 0) continue;
+            const double xa = pa[e] == x.M ? 1.0 : x.vec[(size_t)pa[e] * x.Sc + s];
+            const double xb = pb[e] == x.M ? 1.0 : x.vec[(size_t)pb[e] * x.Sc + s];
+            corr[e] += xa * xb;
+        }
+    };
+    for (int base = 0; base < qlen; base += WAVE) {
+        const int cnt = min(WAVE, qlen - base);
+        const uint32_t rec = lane < cnt ? q[base + lane] : 0u;
+        int i = 0;
+        for (; i + 4 <= cnt; i += 4) {  // lowest sample of four records at a time
+            int s4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)rec, i + k);
+                s4[k] = (int)(r >> 4) * 4 + __ffs((int)(r & 15u)) - 1;
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (pa[e] < 0) continue;
+                double xa[4], xb[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    xa[k] = pa[e] == x.M ? 1.0 : x.vec[(size_t)pa[e] * x.Sc + s4[k]];
+                    xb[k] = pb[e] == x.M ? 1.0 : x.vec[(size_t)pb[e] * x.Sc + s4[k]];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) corr[e] += xa[k] * xb[k];
+            }
+        }
+        for (; i < cnt; ++i) {
+            const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)rec, i);
+            one((int)(r >> 4) * 4 + __ffs((int)(r & 15u)) - 1);
+        }
+        // records that hold more than one sample (under 1 % of the chunks): the rest, one at a time
+        const uint32_t b0 = rec & 15u;
+        uint32_t rest = b0 & (b0 - 1u);
+        uint64_t mm = __ballot(rest != 0);
+        while (mm) {
+            const int src = __ffsll((long long)mm) - 1;
+            mm &= mm - 1;
+            const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)rec, src);
+            uint32_t bits = (r & 15u) & ((r & 15u) - 1u);
+            while (bits) {
+                const int j = __ffs((int)bits) - 1;
+                bits &= bits - 1;
+                one((int)(r >> 4) * 4 + j);
+            }
+        }
+    }
+    wave_fence();
+}
+
+template <int MV, bool MASK>
 __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan(const AssocArgs a) {
     extern __shared__ double lds_d[];
+    constexpr int E = Acc<MV>::E;
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wid = tid >> 6;
     const int S = a.b.n_samples, M = a.M, Sc = a.chunk;
     const int s_begin = blockIdx.y * Sc;
     const int ns = min(S - s_begin, Sc);  // multiple of 4
-    double* vec = lds_d;                                              // [M][Sc]
-    uint32_t* maskw = reinterpret_cast<uint32_t*>(vec + (size_t)M * Sc);  // [Sc/4] one byte per sample
+    double* vec = lds_d;                                                   // [M][Sc]
+    uint32_t* maskw = reinterpret_cast<uint32_t*>(vec + (size_t)M * Sc);   // [Sc/4] one byte per sample
     unsigned char* wave_area = reinterpret_cast<unsigned char*>(maskw + Sc / 4) + (size_t)wid * a.wave_bytes;
+    uint32_t* queue = reinterpret_cast<uint32_t*>(wave_area);  // [AS_QCAP] missing-call records
+    wave_area += AS_QCAP * sizeof(uint32_t);
+    constexpr bool BY_SAMPLE = MV <= 4;
+    constexpr int NCS = BY_SAMPLE ? (MV + 1) * (MV + 2) / 2 : 1;
 
     // stage this chunk of the sample vectors (zero for samples outside the regression set)
     for (int i = tid; i < ns; i += AS_THREADS) {
-        const bool in = !a.sample_in || a.sample_in[s_begin + i];
-        reinterpret_cast<unsigned char*>(maskw)[i] = in ? 1 : 0;
+        const bool in = !MASK || a.sample_in[s_begin + i];
+        if (MASK) reinterpret_cast<unsigned char*>(maskw)[i] = in ? 1 : 0;
 #pragma unroll
         for (int k = 0; k < MV; ++k)
             if (k < M) vec[(size_t)k * Sc + i] = in ? a.vec[(size_t)k * S + s_begin + i] : 0.0;
     }
     __syncthreads();
 
-    // this lane's Gram entries (rare path)
-    int pa[AS_E], pb[AS_E];
+    int pa[E], pb[E];
 #pragma unroll
-    for (int e = 0; e < AS_E; ++e) {
+    for (int e = 0; e < E; ++e) {
         const int idx = lane + e * WAVE;
         pa[e] = idx < a.NC ? a.pa[idx] : -1;
         pb[e] = idx < a.NC ? a.pb[idx] : -1;
     }
-    const int K = 1 << a.kshift, kslot = lane & (K - 1);
+    const int K = 1 << a.kshift;
     const int nch = ns >> 2;
+    const int nfull = nch & ~(2 * WAVE - 1);  // chunks covered by full two-deep iterations
     const int l0 = blockIdx.x * a.loci_per_wg;
     const int l1 = min(a.b.n_loci, l0 + a.loci_per_wg);
 
     for (int l = l0 + wid; l < l1; l += AS_WAVES) {  // waves are independent from here on
         const int off = a.b.allele_off[l];
         const int A = a.b.allele_off[l + 1] - off;
-        // bins: 0 '-2' (and every call that is not tested), 1 '-1', 2..A+1 alleles, A+2 out of range
-        double* lut = reinterpret_cast<double*>(wave_area);           // [A+3] pivoted lengths by BIN
+        double* lut = reinterpret_cast<double*>(wave_area);           // [A+3]
         uint32_t* hist = reinterpret_cast<uint32_t*>(lut + (A + 3));  // [(A+3) << kshift]
         const double pivot = a.allele_len[off];
         for (int i = lane; i < A; i += WAVE) lut[i + 2] = a.allele_len[off + i] - pivot;
         if (lane == 0) {
             lut[0] = -2.0 - pivot;  // GetLengthGenotypes maps the padding index -2 to the length -2
-            lut[1] = 0.0;
+            lut[1] = __builtin_nan("");
             lut[A + 2] = 0.0;
         }
         for (int i = lane; i < ((A + 3) << a.kshift); i += WAVE) hist[i] = 0;
         wave_fence();
 
+        ScanCtx x{lut, hist, vec, Sc, M, a.kshift, lane & (K - 1), (uint32_t)(A + 2) * 0x00010001u, a.dbg};
         Acc<MV> acc;
 #pragma unroll
         for (int k = 0; k < MV; ++k) acc.sgv[k] = 0.0;
 #pragma unroll
-        for (int e = 0; e < AS_E; ++e) acc.corr[e] = 0.0;
+        for (int e = 0; e < E; ++e) acc.corr[e] = 0.0;
+        double cs[NCS];
+#pragma unroll
+        for (int e = 0; e < NCS; ++e) cs[e] = 0.0;
+        int qlen = 0;
+        auto drain = [&]() {
+            if (a.dbg & 1) {
+            } else if (BY_SAMPLE) {
+                drain_by_sample<MV>(x, queue, qlen, lane, cs);
+            } else {
+                drain_by_entry<MV>(x, queue, qlen, lane, pa, pb, acc.corr);
+            }
+            qlen = 0;
+        };
         const u32x4* row = reinterpret_cast<const u32x4*>(a.b.gt + ((int64_t)l * S + s_begin) * 2);
-        const uint32_t amax2 = (uint32_t)(A + 2) * 0x00010001u;
 
-        for (int c0 = 0; c0 < nch; c0 += WAVE) {
+        int c0 = 0;
+        for (; c0 < nfull; c0 += 2 * WAVE) {
+            const int ca = c0 + lane, cb = c0 + WAVE + lane;
+            const u32x4 va = __builtin_nontemporal_load(&row[ca]);
+            const u32x4 vb = __builtin_nontemporal_load(&row[cb]);
+            const uint32_t ma = MASK ? maskw[ca] : 0u, mb = MASK ? maskw[cb] : 0u;
+            const uint32_t ra = scan_chunk<MV, MASK, false>(x, va, ma, ca * 4, true, acc);
+            const uint32_t rb = scan_chunk<MV, MASK, false>(x, vb, mb, cb * 4, true, acc);
+            queue_push(queue, qlen, ra, ca);
+            queue_push(queue, qlen, rb, cb);
+            if (qlen > AS_QCAP - 2 * WAVE) drain();
+        }
+        for (; c0 < nch; c0 += WAVE) {
             const int c = c0 + lane;
             const bool live = c < nch;
-            u32x4 v = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            u32x4 v = {0u, 0u, 0u, 0u};
             uint32_t mk = 0;
             if (live) {
                 v = __builtin_nontemporal_load(&row[c]);
-                mk = maskw[c];
+                if (MASK) mk = maskw[c];
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t w = v[j];
-                const bool in = (mk >> (8 * j)) & 1u;
-                u16x2 u = __builtin_bit_cast(u16x2, w) + (u16x2){2, 2};
-                u16x2 t2 = __builtin_elementwise_min(u, __builtin_bit_cast(u16x2, amax2));
-                const uint32_t t = __builtin_bit_cast(uint32_t, t2);
-                const uint32_t lo = t & 0xffffu, hi = t >> 16;
-                const bool miss = (lo == 1u) | (hi == 1u);
-                const bool ok = in & !miss;
-                double g = lut[lo] + lut[hi];
-                g = ok ? g : 0.0;
-                acc.n += ok;
-                acc.sg += g;
-                acc.sgg = __builtin_fma(g, g, acc.sgg);
-                const int s = c * 4 + j;
-#pragma unroll
-                for (int k = 0; k < MV; ++k)
-                    if (k < M) acc.sgv[k] = __builtin_fma(g, live ? vec[(size_t)k * Sc + s] : 0.0, acc.sgv[k]);
-                atomicAdd(&hist[((ok ? lo : 0u) << a.kshift) + kslot], 1u);
-                atomicAdd(&hist[((ok ? hi : 0u) << a.kshift) + kslot], 1u);
-                // samples of the regression set whose call is missing here leave the locus's
-                // Gram matrix: a few % of the calls; the wave walks them one at a time and each
-                // lane updates the matrix entries it owns
-                uint64_t mm = __ballot(in & miss);
-                while (mm) {
-                    const int src = __ffsll((long long)mm) - 1;
-                    mm &= mm - 1;
-                    const int sm = (c0 + src) * 4 + j;
-#pragma unroll
-                    for (int e = 0; e < AS_E; ++e) {
-                        if (pa[e] < 0) continue;
-                        const double x = pa[e] == M ? 1.0 : vec[(size_t)pa[e] * Sc + sm];
-                        const double y = pb[e] == M ? 1.0 : vec[(size_t)pb[e] * Sc + sm];
-                        acc.corr[e] += x * y;
-                    }
-                }
-            }
+            const uint32_t r = scan_chunk<MV, MASK, true>(x, v, mk, c * 4, live, acc);
+            queue_push(queue, qlen, r, c);
+            if (qlen > AS_QCAP - 2 * WAVE) drain();
         }
+        drain();
         wave_fence();
         // ---- reduce and write this (chunk, locus) record --------------------------------------
         double* rec = a.partial + ((size_t)blockIdx.y * a.b.n_loci + l) * a.NS;
-        const int n = wave_sum_i32(acc.n);
         const double sg = wave_sum_f64(acc.sg), sgg = wave_sum_f64(acc.sgg);
         if (lane == 0) {
-            rec[0] = (double)n;
             rec[1] = sg;
             rec[2] = sgg;
         }
@@ -237,9 +409,23 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan(const AssocArgs a) {
                 const double t = wave_sum_f64(acc.sgv[k]);
                 if (lane == 0) rec[3 + k] = t;
             }
+        if (BY_SAMPLE) {
+            int e = 0;
 #pragma unroll
-        for (int e = 0; e < AS_E; ++e)
-            if (pa[e] >= 0) rec[3 + M + lane + e * WAVE] = acc.corr[e];
+            for (int r = 0; r <= MV; ++r)
+#pragma unroll
+                for (int cc = r; cc <= MV; ++cc) {
+                    const double t = wave_sum_f64(cs[e++]);
+                    // static rows -> this call's rows: vectors beyond M do not exist, ones = row M
+                    const int rr = r == MV ? M : r, rc = cc == MV ? M : cc;
+                    if (lane == 0 && (r == MV || r < M) && (cc == MV || cc < M))
+                        rec[3 + M + rr * (M + 1) - rr * (rr - 1) / 2 + (rc - rr)] = t;
+                }
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if (pa[e] >= 0) rec[3 + M + lane + e * WAVE] = acc.corr[e];
+        }
         for (int bin = lane; bin < A + 3; bin += WAVE) {
             uint32_t sum = 0;
             for (int k = 0; k < K; ++k) sum += hist[(bin << a.kshift) + ((k + lane) & (K - 1))];
@@ -249,6 +435,7 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan(const AssocArgs a) {
                 else if (sum)
                     atomicAdd(&a.allele_count[off + bin - 2], (int32_t)sum);
             }
+            if (bin == 1) rec[0] = (double)(ns - (int)(sum >> 1));  // tested samples of this chunk
             if (bin == A + 2) rec[a.NS - 1] = (double)sum;
         }
         wave_fence();
@@ -647,12 +834,13 @@ static AssocPlan assoc_plan(const trk_batch& b, int M) {
     if (b.ploidy != 2 || b.locus_ploidy || S <= 0 || (S % 4) != 0 || Amax <= 0 || Amax + 3 >= 65535 ||
         (reinterpret_cast<uintptr_t>(b.gt) & 15))
         return p;
-    // one wave's private area: LUT (A+3 doubles) + histogram (A+3 bins x K copies), at most 4 KiB
+    // one wave's private area: missing-call queue (1 KiB) + LUT (A+3 doubles) + histogram
+    // (A+3 bins x K copies), the latter two within 3 KiB
     int kshift = 4;
-    while (kshift >= 0 && (Amax + 3) * (8 + (4 << kshift)) > 4096) --kshift;
+    while (kshift >= 0 && (Amax + 3) * (8 + (4 << kshift)) > 3072) --kshift;
     if (kshift < 0) return p;
     p.kshift = kshift;
-    p.wave_bytes = ((Amax + 3) * (8 + (4 << kshift)) + 15) & ~15;
+    p.wave_bytes = AS_QCAP * 4 + (((Amax + 3) * (8 + (4 << kshift)) + 15) & ~15);
     const size_t lds_total = 160 * 1024;
     const size_t rem = lds_total - (size_t)AS_WAVES * p.wave_bytes - 64;
     int chunk = (int)(rem / (8 * (size_t)M + 1));
@@ -682,14 +870,18 @@ size_t assoc_workspace_bytes(const trk_batch& b, int M) {
     return bytes + 64;
 }
 
-template <int MV>
-static hipError_t launch_scan_t(const AssocArgs& a, const AssocPlan& p, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assoc_scan<MV>),
+template <int MV, bool MASK>
+static hipError_t launch_scan_tm(const AssocArgs& a, const AssocPlan& p, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assoc_scan<MV, MASK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     if (e != hipSuccess) return e;
     dim3 grid((a.b.n_loci + p.loci_per_wg - 1) / p.loci_per_wg, p.nchunks), block(AS_THREADS);
-    hipLaunchKernelGGL(k_assoc_scan<MV>, grid, block, p.lds_bytes, stream, a);
+    hipLaunchKernelGGL((k_assoc_scan<MV, MASK>), grid, block, p.lds_bytes, stream, a);
     return hipGetLastError();
+}
+template <int MV>
+static hipError_t launch_scan_t(const AssocArgs& a, const AssocPlan& p, hipStream_t stream) {
+    return a.sample_in ? launch_scan_tm<MV, true>(a, p, stream) : launch_scan_tm<MV, false>(a, p, stream);
 }
 
 static void assoc_build(const trk_batch& b, const trk_assoc_params& prm, const trk_assoc_out& out, void* workspace,
@@ -709,6 +901,7 @@ static void assoc_build(const trk_batch& b, const trk_assoc_params& prm, const t
     a.loci_per_wg = p.loci_per_wg;
     a.wave_bytes = p.wave_bytes;
     a.kshift = p.kshift;
+    a.dbg = getenv("TRK_AS_DBG") ? atoi(getenv("TRK_AS_DBG")) : 0;
     int e = 0;
     for (int r = 0; r <= M; ++r)
         for (int c = r; c <= M; ++c) {
