@@ -171,3 +171,45 @@ class OracleCompute:
                 lc[L.LC_TOTALCALLS] += int(I[L.LI_N_CALLED])
             bits[l] = b
         return ch, st, bits, lc
+
+    def assoc_batch(self, hb, vec, sample_in, non_major_cutoff, precision=2):
+        """trk_assoc_scan through oracle/associatr_oracle.py (one locus at a time)."""
+        from oracle import associatr_oracle as ao
+        from trtools_amd.compute import AssocHost
+        S, M = hb.n_samples, vec.shape[0]
+        sf = np.ones(S, dtype=bool) if sample_in is None else np.asarray(sample_in, dtype=bool)
+        covars = np.ones((int(sf.sum()), M + 1))
+        outcome = vec[0, sf]
+        for k in range(1, M):
+            covars[:, 1 + k] = vec[k, sf]
+        li = np.zeros((hb.n_loci, L.AI_COLS), dtype=np.int32)
+        lf = np.full((hb.n_loci, L.AF_COLS), np.nan)
+        cnt = np.zeros(int(hb.allele_off[-1]), dtype=np.int32)
+        code = {'No called samples': L.AS_NO_CALLED, 'Only one called allele': L.AS_ONE_ALLELE}
+        for l in range(hb.n_loci):
+            g = hb.gt[l][:, :int(hb.locus_ploidy[l])]
+            gi = ao.locus_genotypes(g, hb.allele_lens[l], sf, non_major_cutoff, precision)
+            n = int(np.sum(gi['called_samples_filter']))
+            li[l, L.AI_N_TESTED] = n
+            li[l, L.AI_N_RALLELES] = len(gi['allele_frequency'])
+            curr = sf & ~np.any(g == -1, axis=1)
+            sel = g[curr]
+            o, e = int(hb.allele_off[l]), int(hb.allele_off[l + 1])
+            cnt[o:e] = np.bincount(sel[sel >= 0].astype(int), minlength=e - o)
+            li[l, L.AI_N_HAPS] = int(cnt[o:e].sum())
+            reason = gi['locus_filtered']
+            if reason:
+                li[l, L.AI_STATUS] = code.get(reason, L.AS_NON_MAJOR)
+                continue
+            if M + 1 >= n:
+                li[l, L.AI_STATUS] = L.AS_N_COVARS
+                continue
+            summed = np.sum(gi['gts'], axis=1)
+            if np.std(summed) <= 1e-9 * max(1.0, abs(np.mean(summed))):
+                li[l, L.AI_STATUS] = L.AS_ZERO_VARIANCE
+                continue
+            r = ao.locus_regression(gi['gts'], gi['called_samples_filter'], covars, outcome, 1.0)
+            lf[l, L.AF_PVAL], lf[l, L.AF_COEF], lf[l, L.AF_SE] = r['pval'], r['coef_std'], r['se_std']
+            lf[l, L.AF_RSQUARED], lf[l, L.AF_GT_STD], lf[l, L.AF_TVALUE] = r['rsquared'], r['std'], r['tvalue']
+            lf[l, L.AF_DF_RESID], lf[l, L.AF_GT_MEAN] = r['df_resid'], np.mean(summed)
+        return AssocHost(li, lf, cnt)

@@ -1,0 +1,90 @@
+"""associaTR command line (trtools_amd.associaTR.associaTR.main) against the tables the REAL reference
+wrote for the same arguments (tests/golden/associatr, tools/gen_golden_associatr.py) and against the
+reference's plink2 fixtures under its own acceptance rule.
+
+CPU: the host layer (covariate joins, harmonisation, packing, text) with the oracle-backed compute
+stand-in.  GPU: the same with the device (trk_assoc_scan through the C ABI)."""
+import contextlib
+import io
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import assoc_cases                                            # noqa: E402
+from assoc_compare import compare_tables, compare_to_plink    # noqa: E402
+
+GOLD = os.path.join(ROOT, 'tests', 'golden', 'associatr')
+GT_CASES = sorted(n for n, (kw, _, _) in assoc_cases.CASES.items() if not kw.get('beagle_dosages'))
+
+
+def run_cli(out, kw, len_precision, p_precision):
+    from trtools_amd.associaTR import associaTR as at
+    old = (at.load_and_filter_genotypes.allele_len_precision, at.pval_precision)
+    at.load_and_filter_genotypes.allele_len_precision, at.pval_precision = len_precision, p_precision
+    try:
+        with contextlib.redirect_stdout(io.StringIO()) as log:
+            at.main(assoc_cases.make_args(out, **kw))
+    finally:
+        at.load_and_filter_genotypes.allele_len_precision, at.pval_precision = old
+    return log.getvalue()
+
+
+def check_case(name, tmp_path):
+    kw, plink, skip = assoc_cases.CASES[name]
+    out = str(tmp_path / 'a.tsv')
+    log = run_cli(out, kw, 10, 15)
+    assert 'samples in the VCF' in log and 'Done.' in log
+    compare_tables(out, os.path.join(GOLD, name + '.precise.tsv'), rtol=1e-9)
+    if plink:
+        assert compare_to_plink(out, os.path.join(assoc_cases.DATA, plink), 'test_pheno', skip_filtered=skip) > 100
+    run_cli(out, kw, 2, 2)
+    compare_tables(out, os.path.join(GOLD, name + '.tsv'), rtol=1e-9, p_rtol=0.0)
+    assert not os.path.exists(out + '.temp')
+
+
+@pytest.fixture
+def oracle_compute():
+    from trtools_amd import runtime
+    from oracle_compute import OracleCompute
+    old = runtime.set_compute(OracleCompute())
+    yield
+    runtime.set_compute(old)
+
+
+@pytest.mark.parametrize('name', GT_CASES)
+def test_cli_host_layer_with_oracle_compute(name, tmp_path, oracle_compute):
+    check_case(name, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', GT_CASES)
+def test_cli_on_device(name, tmp_path):
+    from trtools_amd import runtime
+    runtime.set_compute(None)
+    check_case(name, tmp_path)
+
+
+def test_refused_options(tmp_path, oracle_compute):
+    from trtools_amd.associaTR import associaTR as at
+    kw = dict(assoc_cases.CASES['dosages'][0])
+    with pytest.raises(NotImplementedError):
+        at.main(assoc_cases.make_args(str(tmp_path / 'x.tsv'), **kw))
+    with pytest.raises(NotImplementedError):
+        at.main(assoc_cases.make_args(str(tmp_path / 'x.tsv'), same_samples=True, plotting_phenotype='p.npy'))
+
+
+def test_region_is_a_slice_of_the_full_run(tmp_path, oracle_compute):
+    """associaTR/tests/test_associaTR.py:113-133."""
+    full, part, none = (str(tmp_path / n) for n in ('f.tsv', 'p.tsv', 'n.tsv'))
+    run_cli(full, dict(same_samples=True), 2, 2)
+    run_cli(part, dict(same_samples=True, region='1:993134-3781638'), 2, 2)
+    run_cli(none, dict(same_samples=True, region='2:993134-3781638'), 2, 2)
+    lines = open(full).readlines()
+    got = open(part).readlines()
+    assert got[0] == lines[0] and got[1:] == lines[77:77 + len(got) - 1] and len(got) - 1 == 366 - 77 + 1
+    assert len(open(none).readlines()) == 1

@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""associaTR: association of TR length with a phenotype -- same command line, same
+``main(args)`` / ``perform_gwas(...)`` and the same output table as the reference
+(trtools/associaTR/associaTR.py), with the per-locus loop (associaTR.py:246-291: numpy
+standardisation + one statsmodels OLS fit per locus) replaced by batches of loci scanned on
+the GPU (``trk_assoc_scan``: genotype x trait cross-products in one pass over the genotype
+tensor, a Cholesky solve and a Student-t tail per locus).
+
+Host Python assembles the covariates (associaTR.py:138-204), parses / harmonises records and
+formats text.  Not provided (and refused loudly, there is no CPU path in this package):
+``--beagle-dosages`` (regression on AP1/AP2 dosages) and the reference's hidden, unfinished
+``--plotting-phenotype`` family of options.
+"""
+import argparse
+import datetime
+import shutil
+import sys
+import time
+
+import numpy as np
+
+from .. import __version__
+from .. import _lib as L
+from .. import runtime
+from ..batch import pack_records
+from ..utils import tr_harmonizer as trh
+from ..utils import utils
+from . import load_and_filter_genotypes
+
+pval_precision = 2
+BATCH_CELLS = 1 << 24     # loci x samples per device batch
+
+_REASONS = {L.AS_NO_CALLED: 'No called samples', L.AS_ONE_ALLELE: 'Only one called allele',
+            L.AS_N_COVARS: 'n covars >= n samples'}
+
+
+def _merge_arrays(a, b):
+    """``a`` left-outer-joined with ``b`` on the first (id) column (associaTR.py:22-54)."""
+    assert len(a.shape) == 2 and len(b.shape) == 2
+    assert len(set(a[:, 0]).intersection(b[:, 0])) > 0
+    assert len(set(a[:, 0])) == a.shape[0]
+    assert len(set(b[:, 0])) == b.shape[0]
+    where = {key: row for row, key in enumerate(b[:, 0])}
+    extra = np.full((a.shape[0], b.shape[1] - 1), np.nan)
+    for row, key in enumerate(a[:, 0]):
+        hit = where.get(key)
+        if hit is not None:
+            extra[row, :] = b[hit, 1:]
+    return np.concatenate((a, extra), axis=1)
+
+
+def _weighted_binom_conf(weights, successes, confidence):
+    """Weighted Wilson interval (associaTR.py:56-103; kept for API compatibility, unused by the scan)."""
+    import scipy.stats
+    assert weights.shape == successes.shape
+    assert len(weights.shape) == 1
+    t = np.sum(weights)
+    phat = np.dot(weights, successes) / t
+    z = scipy.stats.norm.ppf(1 - confidence / 2)
+    c = z * np.sqrt(np.dot(weights, weights))
+    divisor = 2 + 2 * c ** 2 / t ** 2
+    center = (2 * phat + c ** 2 / t ** 2) / divisor
+    half = c / t * np.sqrt(4 * phat * (1 - phat) + c ** 2 / t ** 2) / divisor
+    return (phat, center - half, center + half)
+
+
+def _load_design(all_samples, trait_fnames, same_samples, sample_fname):
+    """Covariate assembly of perform_gwas_helper (associaTR.py:138-204), messages included.
+    Returns (sample_filter bool[S], covars [Sf, 1+T] with column 0 reserved for the genotype and
+    column 1 the intercept, outcome [Sf], pheno_std)."""
+    print('{} samples in the VCF'.format(len(all_samples)), flush=True)
+    if not same_samples:
+        covars = np.load(trait_fnames[0])
+        if np.sum(np.isin(np.array(all_samples, dtype=float), covars[:, 0])) < 3:
+            print(all_samples, covars[:, 0])
+            print('Less than 3 samples matched between the covars array and the VCF. '
+                  'Prehaps you meant to run with --same-samples? '
+                  'Erroring out.')
+            sys.exit(1)
+        for trait_fname in trait_fnames[1:]:
+            covars = _merge_arrays(covars, np.load(trait_fname))
+        covars = _merge_arrays(np.array(all_samples, dtype=float).reshape(-1, 1), covars)
+    else:
+        arrays = []
+        for trait_fname in trait_fnames:
+            arrays.append(np.load(trait_fname))
+            if not arrays[-1].shape[0] == len(all_samples):
+                print("different number of samples in covariates file {trait_fname} than VCF, "
+                      "and --same-samples was specified. Erroring out.")
+                sys.exit(1)
+        covars = np.hstack([np.full((arrays[0].shape[0], 1), -1), *arrays])
+
+    if sample_fname:
+        with open(sample_fname) as sample_file:
+            sample_subset = [line.strip() for line in sample_file.readlines()]
+        sample_filter = np.isin(all_samples, sample_subset)
+        print(('{} samples remain after subsetting to samples '
+               'from the file {}.\n'
+               '{} samples from the sample file '
+               'were not present in the VCF and were discarded.'
+               ).format(np.sum(sample_filter), sample_fname, len(sample_subset) - np.sum(sample_filter)))
+    else:
+        sample_filter = np.array([True] * len(all_samples))
+
+    before = sum(sample_filter)
+    sample_filter = sample_filter & ~np.any(np.isnan(covars), axis=1)
+    after = sum(sample_filter)
+    print(('Removing {} samples which had missing '
+           'phenotypes or covariates.\n'
+           'Using {} for the regression.\n'
+           'The number of samples used in each variant\'s regression will only be lower '
+           'if that variant has missing calls.\n'
+           ).format(before - after, after))
+
+    covars = covars[sample_filter, :]
+    pheno_std = np.std(covars[:, 1])
+    covars = (covars - np.mean(covars, axis=0)) / np.std(covars, axis=0)
+    outcome = covars[:, 1].copy()
+    covars[:, 1] = 1
+    return sample_filter, covars, outcome, pheno_std
+
+
+def _device_vectors(sample_filter, covars, outcome):
+    """[M, S] float64 for trk_assoc_params.vec: row 0 the outcome, rows 1.. the covariates; samples
+    outside the regression set hold zeros (ignored on the device)."""
+    S, M = len(sample_filter), covars.shape[1] - 1
+    if M > L.ASSOC_MAX_VEC:
+        raise ValueError("associaTR: %d trait columns (phenotype + covariates); this build scans at most %d"
+                         % (M, L.ASSOC_MAX_VEC))
+    vec = np.zeros((M, S), dtype=np.float64)
+    vec[0, sample_filter] = outcome
+    for k in range(1, M):
+        vec[k, sample_filter] = covars[:, 1 + k]
+    return vec
+
+
+def _flush(records, outfile, vec, sample_filter, pheno_std, non_major_cutoff):
+    """One device batch -> output rows (associaTR.py:246-293)."""
+    if not records:
+        return
+    lf_mod = load_and_filter_genotypes
+    hb = pack_records(records)
+    res = runtime.get_compute().assoc_batch(hb, vec, sample_filter, non_major_cutoff,
+                                            precision=lf_mod.allele_len_precision)
+    fmt = "{:." + str(pval_precision) + "e}\t{}\t{}\t{}\t"
+    for l, rec in enumerate(records):
+        li, lf = res.locus_int[l], res.locus_f64[l]
+        o, e = int(hb.allele_off[l]), int(hb.allele_off[l + 1])
+        allele_frequency = lf_mod.allele_frequency_from_counts(res.allele_count[o:e], hb.allele_lens[l])
+        details = lf_mod.locus_details(rec, allele_frequency)
+        unique_alleles = np.unique(lf_mod.rounded_allele_lengths(rec))
+        outfile.write("{}\t{}\t{}\t{}\t".format(rec.chrom, rec.pos, ','.join(list(unique_alleles.astype(str))),
+                                                int(li[L.AI_N_TESTED])))
+        status = int(li[L.AI_STATUS])
+        if status == L.AS_OK:
+            std = lf[L.AF_GT_STD]
+            outfile.write('False\t')
+            outfile.write(fmt.format(lf[L.AF_PVAL], lf[L.AF_COEF] / std * pheno_std, lf[L.AF_SE] / std * pheno_std,
+                                     lf[L.AF_RSQUARED]))
+            outfile.write('\t'.join(details))
+            outfile.write('\n')
+        else:
+            if status == L.AS_NON_MAJOR:
+                reason = 'non-major allele count<{}'.format(non_major_cutoff)
+            elif status in _REASONS:
+                reason = _REASONS[status]
+            elif status == L.AS_ZERO_VARIANCE:
+                # the reference divides 0/0 here and statsmodels raises on the empty design
+                raise ValueError("locus %s:%s: the summed genotype is constant over the tested samples"
+                                 % (rec.chrom, rec.pos))
+            else:
+                raise ValueError("locus %s:%s: genotype collinear with the covariates" % (rec.chrom, rec.pos))
+            outfile.write('{}\tnan\tnan\tnan\tnan\t'.format(reason))
+            outfile.write('\t'.join(details))
+            outfile.write('\n')
+    outfile.flush()
+
+
+def perform_gwas_helper(outfile, all_samples, record_iter, phenotype_name, trait_fnames, same_samples, sample_fname,
+                        non_major_cutoff):
+    """Header, covariates, batched scan (associaTR.py:117-372 without the plotting statistics)."""
+    outfile.write("chrom\tpos\talleles\tn_samples_tested\tlocus_filtered\tp_{}\tcoeff_{}\t".format(
+        phenotype_name, phenotype_name))
+    outfile.write('se_{}\tregression_R^2\t'.format(phenotype_name))
+    outfile.flush()
+    sample_filter, covars, outcome, pheno_std = _load_design(all_samples, trait_fnames, same_samples, sample_fname)
+    vec = _device_vectors(sample_filter, covars, outcome)
+    outfile.write('\t'.join(load_and_filter_genotypes.DETAIL_FIELDS) + '\n')
+
+    batch_loci = max(1, min(4096, BATCH_CELLS // max(1, len(all_samples))))
+    n_loci, start_time = 0, time.time()
+    records = []
+    for trrecord in record_iter:
+        records.append(trrecord)
+        n_loci += 1
+        if len(records) >= batch_loci:
+            _flush(records, outfile, vec, sample_filter, pheno_std, non_major_cutoff)
+            records = []
+    _flush(records, outfile, vec, sample_filter, pheno_std, non_major_cutoff)
+    total_time = time.time() - start_time
+    if n_loci > 0:
+        print("Done.\nTotal loci: {}\nTotal time: {}s\ntime/locus: {}s\n".format(
+            n_loci, total_time, total_time / n_loci), flush=True)
+    else:
+        print("No variants found in the region being looked at\n", flush=True)
+
+
+def perform_gwas(outfname, tr_vcf, phenotype_name, traits_fnames, vcftype, same_samples, sample_fname, region,
+                 non_major_cutoff, beagle_dosages, plotting_phenotype_fname, paired_genotype_plot,
+                 plot_phenotype_residuals, plotting_ci_alphas, imputed_ukb_strs_paper_period_check):
+    """Signature of the reference (associaTR.py:432-482)."""
+    if beagle_dosages:
+        raise NotImplementedError("--beagle-dosages: the dosage regression is not part of this build "
+                                  "(only the GT-based scan runs on the device; there is no CPU path)")
+    if plotting_phenotype_fname or paired_genotype_plot or plot_phenotype_residuals or plotting_ci_alphas:
+        raise NotImplementedError("the hidden --plotting-phenotype options of the reference are not provided")
+    reader = utils.LoadSingleReader(tr_vcf, checkgz=False)
+    if reader is None:
+        raise ValueError("could not open %s" % tr_vcf)
+    all_samples = reader.samples
+    record_iter = load_and_filter_genotypes.iter_records(
+        tr_vcf, region, vcftype, False, imputed_ukb_strs_paper_period_check)
+    print("Writing output to {}.temp".format(outfname), flush=True)
+    with open(outfname + '.temp', 'w') as outfile:
+        perform_gwas_helper(outfile, all_samples, record_iter, phenotype_name, traits_fnames, same_samples,
+                            sample_fname, non_major_cutoff)
+    print("Moving {}.temp to {}".format(outfname, outfname), flush=True)
+    shutil.move(outfname + '.temp', outfname)
+    print("Done.", flush=True)
+
+
+def getargs():  # pragma: no cover
+    parser = argparse.ArgumentParser(__doc__, formatter_class=utils.ArgumentDefaultsHelpFormatter)
+    parser.add_argument('outfile')
+    parser.add_argument('tr_vcf')
+    parser.add_argument('phenotype_name', help='name of the phenotype being regressed against')
+    parser.add_argument('traits', nargs='+',
+                        help='At least one .npy 2d float array file of trait values per sample. The first trait of '
+                             'the first file is the phenotype, every other column of every file a covariate. Without '
+                             '--same-samples the first column of each file is the numeric sample ID and files are '
+                             'joined on it; with --same-samples every array has one row per VCF sample, in VCF order, '
+                             'and no ID column. Traits are standardised before the regression; coefficients and '
+                             'standard errors are reported on the original scale.')
+    parser.add_argument('--vcftype', choices=[str(item) for item in trh.VcfTypes.__members__],
+                        help="Specify which caller produced the TR VCF, useful when the VCF is ambiguous "
+                             "and the caller cannot be automatically inferred.")
+    parser.add_argument('--same-samples', default=False, action='store_true', help='see the traits help string')
+    parser.add_argument('--sample-list', help="File containing list of samples to use, one sample ID per line. "
+                                              "If not specified, all samples are used.")
+    parser.add_argument('--region', help="Restrict to \"chr:start-end\"")
+    parser.add_argument('--non-major-cutoff', type=float, default=20,
+                        help='Filter loci whose non-major-allele count (alleles coalesced by length) is below this '
+                             'cutoff. Set to 0 to disable this filter.')
+    parser.add_argument('--beagle-dosages', action='store_true', default=False,
+                        help="regress against Beagle dosages from the AP{1,2} fields (not available in this build)")
+    parser.add_argument('--plotting-phenotype', help=argparse.SUPPRESS)
+    parser.add_argument('--paired-genotype-plot', action='store_true', default=False, help=argparse.SUPPRESS)
+    parser.add_argument('--plot-phenotype-residuals', action='store_true', default=False, help=argparse.SUPPRESS)
+    parser.add_argument('--plotting-ci-alphas', type=float, nargs='*', default=[], help=argparse.SUPPRESS)
+    parser.add_argument('--imputed-ukb-strs-paper-period-check', default=False, action='store_true',
+                        help=argparse.SUPPRESS)
+    parser.add_argument("--version", action="version", version='{}'.format(__version__))
+    return parser.parse_args()
+
+
+def main(args):
+    today = datetime.datetime.now().strftime("%Y_%m_%d")
+    print('-------Running AssociaTR (trtools v{}) ----------'.format(__version__))
+    print("Run date: {}".format(today))
+    print(args, flush=True)
+    perform_gwas(args.outfile, args.tr_vcf, args.phenotype_name, args.traits, args.vcftype, args.same_samples,
+                 args.sample_list, args.region, args.non_major_cutoff, args.beagle_dosages, args.plotting_phenotype,
+                 args.paired_genotype_plot, args.plot_phenotype_residuals, args.plotting_ci_alphas,
+                 args.imputed_ukb_strs_paper_period_check)
+
+
+def run():  # pragma: no cover
+    main(getargs())
+
+
+if __name__ == '__main__':  # pragma: no cover
+    run()

@@ -28,14 +28,28 @@ class CallHost:
         self.error = error
 
 
+class AssocHost:
+    """Host copies of trk_assoc_out."""
+
+    def __init__(self, locus_int, locus_f64, allele_count):
+        self.locus_int = locus_int         # [L, AI_COLS] int32
+        self.locus_f64 = locus_f64         # [L, AF_COLS] float64
+        self.allele_count = allele_count   # [sumA] int32, tested samples only
+
+
 class DeviceCompute:
     def __init__(self, engine=None, device=0):
         from .engine import Engine
         self.eng = engine if engine is not None else Engine(device)
 
     def _upload(self, hb):
+        # a per-locus ploidy table only when some locus really is of lower ploidy than the tensor
+        # (the kernels' streaming paths need every column to be live)
+        lp = hb.locus_ploidy
+        if lp is not None and (hb.n_loci == 0 or bool(np.all(np.asarray(lp) == hb.ploidy))):
+            lp = None
         return self.eng.make_batch(hb.gt, hb.allele_off, hb.len_class, hb.str_class, hb.len_class_value,
-                                   locus_ploidy=hb.locus_ploidy, group_bits=hb.group_bits,
+                                   locus_ploidy=lp, group_bits=hb.group_bits,
                                    n_groups=hb.n_groups, max_alleles=hb.max_alleles)
 
     @staticmethod
@@ -81,4 +95,26 @@ class DeviceCompute:
         self._free(b, *dplanes, call.gt_out, call.filter_mask, call.sample_counters, call.sample_totaldp,
                    call.sample_dp_missing, call.error, st.allele_count, st.locus_int, st.locus_f64,
                    bits, counters, ext)
+        return out
+
+    def assoc_batch(self, hb, vec, sample_in, non_major_cutoff, precision=2):
+        """associaTR scan of one batch (trk_assoc_scan): vec [M, S] float64 (outcome, covariates),
+        sample_in bool[S] or None.  Returns AssocHost."""
+        from .synth import pack_assoc_tables
+        eng = self.eng
+        b = self._upload(hb)
+        alen, rcls = pack_assoc_tables(hb.allele_lens, precision)
+        sin = None
+        if sample_in is not None and not bool(np.all(sample_in)):
+            sin = np.ascontiguousarray(sample_in, dtype=np.uint8)
+        if not hasattr(self, '_assoc_vec') or self._assoc_vec[0] is not vec:
+            if hasattr(self, '_assoc_vec'):
+                self._free(self._assoc_vec[1], self._assoc_vec[2])
+            self._assoc_vec = (vec, eng.upload(np.ascontiguousarray(vec, dtype=np.float64)),
+                               eng.upload(sin) if sin is not None else None)
+        _, vec_d, sin_d = self._assoc_vec
+        alen_d, rcls_d = eng.upload(alen), eng.upload(rcls)
+        res = eng.assoc_scan(b, vec_d, alen_d, rcls_d, sample_in=sin_d, non_major_cutoff=non_major_cutoff)
+        out = AssocHost(res.locus_int.get(), res.locus_f64.get(), res.allele_count.get())
+        self._free(b, alen_d, rcls_d, res.locus_int, res.locus_f64, res.allele_count)
         return out

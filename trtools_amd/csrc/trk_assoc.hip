@@ -117,8 +117,8 @@ struct Acc {
 struct ScanCtx {
     const double* lut;   // LDS, by BIN: 0 '-2', 1 '-1' (NaN), 2..A+1 alleles, A+2 out of range
     uint32_t* hist;      // LDS, (A+3) bins x K copies
-    const double* vec;   // LDS [M][Sc]
-    int Sc, M, kshift, kslot;
+    const double* vec;   // LDS [M][Sr]
+    int Sr, M, kshift, kslot;   // Sr: row stride of vec (chunk, +1 when lanes read different rows)
     uint32_t amax2;
     int dbg;
 };
@@ -137,8 +137,8 @@ __device__ __forceinline__ uint32_t scan_chunk(const ScanCtx& x, const u32x4 v, 
         for (int k = 0; k < MV; ++k)
             if (k < x.M) {
                 if (!TAIL || live) {
-                    const double2 a0 = *reinterpret_cast<const double2*>(&x.vec[(size_t)k * x.Sc + s0]);
-                    const double2 a1 = *reinterpret_cast<const double2*>(&x.vec[(size_t)k * x.Sc + s0 + 2]);
+                    const double2 a0 = *reinterpret_cast<const double2*>(&x.vec[(size_t)k * x.Sr + s0]);
+                    const double2 a1 = *reinterpret_cast<const double2*>(&x.vec[(size_t)k * x.Sr + s0 + 2]);
                     y[k][0] = a0.x; y[k][1] = a0.y; y[k][2] = a1.x; y[k][3] = a1.y;
                 } else {
                     y[k][0] = y[k][1] = y[k][2] = y[k][3] = 0.0;
@@ -172,7 +172,7 @@ __device__ __forceinline__ uint32_t scan_chunk(const ScanCtx& x, const u32x4 v, 
 #pragma unroll
         for (int k = 0; k < MV; ++k)
             if (k < x.M) {
-                const double yv = PRE ? y[k][j] : ((!TAIL || live) ? x.vec[(size_t)k * x.Sc + s0 + j] : 0.0);
+                const double yv = PRE ? y[k][j] : ((!TAIL || live) ? x.vec[(size_t)k * x.Sr + s0 + j] : 0.0);
                 acc.sgv[k] = __builtin_fma(g, yv, acc.sgv[k]);
             }
         // calls that are not tested are counted in bin 1 (2 per call): n = calls - bin1 / 2
@@ -190,14 +190,14 @@ __device__ __forceinline__ uint32_t scan_chunk(const ScanCtx& x, const u32x4 v, 
 // latency (measured: 5.4 of 6.6 ms), so the main loop only QUEUES them -- one record per
 // 4-sample chunk that holds any: (chunk << 4 | 4-bit set), appended with ballot/mbcnt, order
 // deterministic -- and the queue is drained in bulk, when nearly full and at the end of the row.
-constexpr int AS_QCAP = 256;  // records per wave
+constexpr int AS_QCAP = 512;  // records per wave (uint16: 12-bit chunk index, 4-bit set)
 
-__device__ __forceinline__ void queue_push(uint32_t* q, int& qlen, uint32_t rare, int c) {
+__device__ __forceinline__ void queue_push(uint16_t* q, int& qlen, uint32_t rare, int c) {
     const uint64_t mm = __ballot(rare != 0);
     if (mm) {
         const int pos = qlen + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32),
                                                              __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-        if (rare) q[pos] = ((uint32_t)c << 4) | rare;
+        if (rare) q[pos] = (uint16_t)(((uint32_t)c << 4) | rare);
         qlen += __popcll(mm);
     }
 }
@@ -205,7 +205,7 @@ __device__ __forceinline__ void queue_push(uint32_t* q, int& qlen, uint32_t rare
 // few vectors: lane = queued sample; every lane keeps the whole (small) Gram triangle of its
 // samples in registers -- rows 0..MV-1 the vectors (zero beyond M), row MV the ones
 template <int MV>
-__device__ __forceinline__ void drain_by_sample(const ScanCtx& x, const uint32_t* q, int qlen, int lane, double* cs) {
+__device__ __forceinline__ void drain_by_sample(const ScanCtx& x, const uint16_t* q, int qlen, int lane, double* cs) {
     wave_fence();
     for (int base = 0; base < qlen; base += WAVE) {
         const uint32_t rec = base + lane < qlen ? q[base + lane] : 0u;
@@ -217,7 +217,7 @@ __device__ __forceinline__ void drain_by_sample(const ScanCtx& x, const uint32_t
             const int s = c * 4 + j;
             double z[MV + 1];
 #pragma unroll
-            for (int k = 0; k < MV; ++k) z[k] = k < x.M ? x.vec[(size_t)k * x.Sc + s] : 0.0;
+            for (int k = 0; k < MV; ++k) z[k] = k < x.M ? x.vec[(size_t)k * x.Sr + s] : 0.0;
             z[MV] = 1.0;
             int e = 0;
 #pragma unroll
@@ -232,7 +232,7 @@ __device__ __forceinline__ void drain_by_sample(const ScanCtx& x, const uint32_t
 // many vectors: lane = Gram entry (row pa x row pb, row M = ones); the queued samples are
 // walked four at a time so that eight LDS reads are in flight
 template <int MV>
-__device__ __forceinline__ void drain_by_entry(const ScanCtx& x, const uint32_t* q, int qlen, int lane,
+__device__ __forceinline__ void drain_by_entry(const ScanCtx& x, const uint16_t* q, int qlen, int lane,
                                                const int* pa, const int* pb, double* corr) {
     constexpr int E = Acc<MV>::E;
     wave_fence();
@@ -240,8 +240,8 @@ __device__ __forceinline__ void drain_by_entry(const ScanCtx& x, const uint32_t*
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             if (pa[e] < 0) continue;
-            const double xa = pa[e] == x.M ? 1.0 : x.vec[(size_t)pa[e] * x.Sc + s];
-            const double xb = pb[e] == x.M ? 1.0 : x.vec[(size_t)pb[e] * x.Sc + s];
+            const double xa = pa[e] == x.M ? 1.0 : x.vec[(size_t)pa[e] * x.Sr + s];
+            const double xb = pb[e] == x.M ? 1.0 : x.vec[(size_t)pb[e] * x.Sr + s];
             corr[e] += xa * xb;
         }
     };
@@ -262,8 +262,8 @@ __device__ __forceinline__ void drain_by_entry(const ScanCtx& x, const uint32_t*
                 double xa[4], xb[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    xa[k] = pa[e] == x.M ? 1.0 : x.vec[(size_t)pa[e] * x.Sc + s4[k]];
-                    xb[k] = pb[e] == x.M ? 1.0 : x.vec[(size_t)pb[e] * x.Sc + s4[k]];
+                    xa[k] = pa[e] == x.M ? 1.0 : x.vec[(size_t)pa[e] * x.Sr + s4[k]];
+                    xb[k] = pb[e] == x.M ? 1.0 : x.vec[(size_t)pb[e] * x.Sr + s4[k]];
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) corr[e] += xa[k] * xb[k];
@@ -302,11 +302,15 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan(const AssocArgs a) {
     const int S = a.b.n_samples, M = a.M, Sc = a.chunk;
     const int s_begin = blockIdx.y * Sc;
     const int ns = min(S - s_begin, Sc);  // multiple of 4
-    double* vec = lds_d;                                                   // [M][Sc]
-    uint32_t* maskw = reinterpret_cast<uint32_t*>(vec + (size_t)M * Sc);   // [Sc/4] one byte per sample
+    // row stride: the by-entry drain reads one sample of MANY rows at once; a stride that is a
+    // multiple of 32 banks would put them all on one bank pair
+    const int Sr = Sc + (MV > 4 ? 1 : 0);
+    double* vec = lds_d;                                                   // [M][Sr]
+    uint32_t* maskw = reinterpret_cast<uint32_t*>(vec + (size_t)M * Sr);   // [Sc/4] one byte per sample
     unsigned char* wave_area = reinterpret_cast<unsigned char*>(maskw + Sc / 4) + (size_t)wid * a.wave_bytes;
-    uint32_t* queue = reinterpret_cast<uint32_t*>(wave_area);  // [AS_QCAP] missing-call records
-    wave_area += AS_QCAP * sizeof(uint32_t);
+    uint16_t* queue = reinterpret_cast<uint16_t*>(wave_area);  // [AS_QCAP] missing-call records
+    wave_area += AS_QCAP * sizeof(uint16_t);
+    constexpr int U = MV == 1 ? 4 : 2;  // 16-byte loads in flight per lane
     constexpr bool BY_SAMPLE = MV <= 4;
     constexpr int NCS = BY_SAMPLE ? (MV + 1) * (MV + 2) / 2 : 1;
 
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan(const AssocArgs a) {
         if (MASK) reinterpret_cast<unsigned char*>(maskw)[i] = in ? 1 : 0;
 #pragma unroll
         for (int k = 0; k < MV; ++k)
-            if (k < M) vec[(size_t)k * Sc + i] = in ? a.vec[(size_t)k * S + s_begin + i] : 0.0;
+            if (k < M) vec[(size_t)k * Sr + i] = in ? a.vec[(size_t)k * S + s_begin + i] : 0.0;
     }
     __syncthreads();
 
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan(const AssocArgs a) {
     }
     const int K = 1 << a.kshift;
     const int nch = ns >> 2;
-    const int nfull = nch & ~(2 * WAVE - 1);  // chunks covered by full two-deep iterations
+    const int nfull = nch - nch % (U * WAVE);  // chunks covered by full U-deep iterations
     const int l0 = blockIdx.x * a.loci_per_wg;
     const int l1 = min(a.b.n_loci, l0 + a.loci_per_wg);
 
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan(const AssocArgs a) {
         for (int i = lane; i < ((A + 3) << a.kshift); i += WAVE) hist[i] = 0;
         wave_fence();
 
-        ScanCtx x{lut, hist, vec, Sc, M, a.kshift, lane & (K - 1), (uint32_t)(A + 2) * 0x00010001u, a.dbg};
+        ScanCtx x{lut, hist, vec, Sr, M, a.kshift, lane & (K - 1), (uint32_t)(A + 2) * 0x00010001u, a.dbg};
         Acc<MV> acc;
 #pragma unroll
         for (int k = 0; k < MV; ++k) acc.sgv[k] = 0.0;
@@ -370,16 +374,20 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan(const AssocArgs a) {
         const u32x4* row = reinterpret_cast<const u32x4*>(a.b.gt + ((int64_t)l * S + s_begin) * 2);
 
         int c0 = 0;
-        for (; c0 < nfull; c0 += 2 * WAVE) {
-            const int ca = c0 + lane, cb = c0 + WAVE + lane;
-            const u32x4 va = __builtin_nontemporal_load(&row[ca]);
-            const u32x4 vb = __builtin_nontemporal_load(&row[cb]);
-            const uint32_t ma = MASK ? maskw[ca] : 0u, mb = MASK ? maskw[cb] : 0u;
-            const uint32_t ra = scan_chunk<MV, MASK, false>(x, va, ma, ca * 4, true, acc);
-            const uint32_t rb = scan_chunk<MV, MASK, false>(x, vb, mb, cb * 4, true, acc);
-            queue_push(queue, qlen, ra, ca);
-            queue_push(queue, qlen, rb, cb);
-            if (qlen > AS_QCAP - 2 * WAVE) drain();
+        for (; c0 < nfull; c0 += U * WAVE) {
+            u32x4 v[U];
+            uint32_t mk[U], rr[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                v[u] = __builtin_nontemporal_load(&row[c0 + u * WAVE + lane]);
+                mk[u] = MASK ? maskw[c0 + u * WAVE + lane] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                rr[u] = scan_chunk<MV, MASK, false>(x, v[u], mk[u], (c0 + u * WAVE + lane) * 4, true, acc);
+#pragma unroll
+            for (int u = 0; u < U; ++u) queue_push(queue, qlen, rr[u], c0 + u * WAVE + lane);
+            if (qlen > AS_QCAP - U * WAVE) drain();
         }
         for (; c0 < nch; c0 += WAVE) {
             const int c = c0 + lane;
@@ -392,7 +400,7 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan(const AssocArgs a) {
             }
             const uint32_t r = scan_chunk<MV, MASK, true>(x, v, mk, c * 4, live, acc);
             queue_push(queue, qlen, r, c);
-            if (qlen > AS_QCAP - 2 * WAVE) drain();
+            if (qlen > AS_QCAP - U * WAVE) drain();
         }
         drain();
         wave_fence();
@@ -840,11 +848,12 @@ static AssocPlan assoc_plan(const trk_batch& b, int M) {
     while (kshift >= 0 && (Amax + 3) * (8 + (4 << kshift)) > 3072) --kshift;
     if (kshift < 0) return p;
     p.kshift = kshift;
-    p.wave_bytes = AS_QCAP * 4 + (((Amax + 3) * (8 + (4 << kshift)) + 15) & ~15);
+    p.wave_bytes = AS_QCAP * 2 + (((Amax + 3) * (8 + (4 << kshift)) + 15) & ~15);
     const size_t lds_total = 160 * 1024;
-    const size_t rem = lds_total - (size_t)AS_WAVES * p.wave_bytes - 64;
+    const size_t rem = lds_total - (size_t)AS_WAVES * p.wave_bytes - 64 - 8 * (size_t)M;
     int chunk = (int)(rem / (8 * (size_t)M + 1));
     chunk &= ~255;
+    if (chunk > 16384) chunk = 16384;  // 12-bit chunk index in the queue records
     if (chunk < 256) return p;
     const int s_pad = (S + 255) & ~255;
     if (chunk >= s_pad) {
@@ -854,9 +863,17 @@ static AssocPlan assoc_plan(const trk_batch& b, int M) {
         p.nchunks = (S + chunk - 1) / chunk;
         p.chunk = (((S + p.nchunks - 1) / p.nchunks) + 255) & ~255;  // balanced
     }
-    p.lds_bytes = (size_t)M * p.chunk * 8 + p.chunk + (size_t)AS_WAVES * p.wave_bytes;
-    p.loci_per_wg = 48;
-    if (const char* e = getenv("TRK_AS_LB")) p.loci_per_wg = atoi(e) > 0 ? atoi(e) : 48;
+    p.lds_bytes = (size_t)M * (p.chunk + 1) * 8 + p.chunk + (size_t)AS_WAVES * p.wave_bytes;
+    // one workgroup per CU at a time (LDS): size the locus blocks so that the grid is a whole
+    // number of rounds over the 256 CUs, ~48 loci (3 per wave) each
+    {
+        const int per_round = 256 / (p.nchunks < 256 ? p.nchunks : 256) > 0 ? 256 / p.nchunks : 1;
+        int rounds = (b.n_loci + per_round * 48 - 1) / (per_round * 48);
+        if (rounds < 1) rounds = 1;
+        p.loci_per_wg = (b.n_loci + per_round * rounds - 1) / (per_round * rounds);
+        if (p.loci_per_wg < 1) p.loci_per_wg = 1;
+    }
+    if (const char* e = getenv("TRK_AS_LB")) p.loci_per_wg = atoi(e) > 0 ? atoi(e) : p.loci_per_wg;
     p.fast = true;
     return p;
 }
