@@ -56,6 +56,7 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of the CPU baseline sample')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-check', action='store_true')
+    ap.add_argument('--no-assoc', action='store_true', help='skip the associaTR scan timing (the "associatr_scan" extra)')
     return ap.parse_args()
 
 
@@ -158,6 +159,68 @@ def parity_spot_check(wl, n_check=6):
         assert lc[L.LC_PASS] == int(np.sum(bits == 0))
         assert lc[L.LC_TOTALCALLS] == int(lib[bits == 0, L.LI_N_CALLED].sum())
     return len(idx)
+
+
+def assoc_extra(wl, args, iters=5):
+    """SURVEY section 8 row f3 / BASELINE configs[4] on ONE GPU, outside the timed region of the headline
+    metric: the associaTR scan (trk_assoc_scan) over this rank's resident genotype tensor, one seeded
+    standard-normal trait, every sample in the regression set.  4 algorithmic bytes per call (the GT read).
+    A handful of loci is checked against the associaTR oracle."""
+    from trtools_amd.synth import pack_assoc_tables
+    eng = wl.eng
+    n_loci, n_samples = wl.n_loci, wl.n_samples
+    alen, rcls = pack_assoc_tables(wl.sb.loci.allele_lens, 2)
+    alen_d, rcls_d = eng.upload(alen, np.float64), eng.upload(rcls, np.uint16)
+    rng = np.random.default_rng(args.seed + 77)
+    y = rng.normal(size=n_samples)
+    y = (y - y.mean()) / y.std()
+    vec_d = eng.upload(y[None, :].copy(), np.float64)
+    res = None
+    eng.profile(True)
+    for it in range(iters + 1):
+        if it == 1:
+            eng.sync()
+            eng.profile_reset()
+            t0 = time.perf_counter()
+        res = eng.assoc_scan(wl.sb.batch, vec_d, alen_d, rcls_d, non_major_cutoff=20.0, out=res)
+    eng.sync()
+    wall = (time.perf_counter() - t0) / iters
+    prof = eng.profile_get()
+    eng.profile(False)
+    n, ms = prof['k_assoc_scan']
+    nf, msf = prof['k_assoc_finalize']
+    scan_ms = ms / max(n, 1)
+    cells = n_loci * n_samples
+    out = {"workload": "associaTR linear-regression scan, %d loci x %d samples x 1 trait (BASELINE configs[4] on one GPU)"
+                       % (n_loci, n_samples),
+           "loci_per_s": n_loci / wall, "ms_per_pass": wall * 1e3,
+           "kernels_ms": {"k_assoc_scan": scan_ms, "k_assoc_finalize": msf / max(nf, 1)},
+           "roofline": {"bound": "hbm", "kernel": "k_assoc_scan", "bytes_per_cell": 4,
+                        "achieved": cells * 4 / (scan_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": cells * 4 / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+    if not args.no_check:
+        from oracle import associatr_oracle as ao
+        li, lf = res.locus_int.get(), res.locus_f64.get()
+        idx = np.unique(np.linspace(0, n_loci - 1, 5).astype(int))
+        rows = wl.sb.host_rows(idx)
+        sf = np.ones(n_samples, dtype=bool)
+        covars = np.ones((n_samples, 2))
+        checked = 0
+        for k, l in enumerate(idx):
+            r = ao.scan_locus(rows['gt'][k], wl.sb.loci.allele_lens[l], sf, covars, y, 1.0, 20.0, 2)
+            assert li[l, 0] == r['n_tested'], (l, li[l], r['n_tested'])
+            if r['locus_filtered']:
+                assert li[l, 1] != 0, (l, r['locus_filtered'])
+                continue
+            assert li[l, 1] == 0, (l, li[l])
+            for col, key in ((0, 'pval'), (1, 'coef_std'), (2, 'se_std'), (3, 'rsquared')):
+                assert abs(lf[l, col] - r[key]) <= 1e-9 * abs(r[key]) + 1e-12, (l, key, lf[l, col], r[key])
+            checked += 1
+        out["parity_loci_checked"] = int(len(idx))
+        out["parity_loci_regressed"] = checked
+    for d in (alen_d, rcls_d, vec_d, res.locus_int, res.locus_f64, res.allele_count):
+        d.free()
+    return out
 
 
 def cpu_baseline(wl, budget_s):
@@ -292,6 +355,8 @@ def main():
             "parity_rows_checked": n_checked,
             "device": eng.arch,
         }
+        if not args.no_assoc and world == 1:
+            out["extras"] = {"associatr_scan": assoc_extra(wl, args)}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
         print(json.dumps(out), flush=True)
