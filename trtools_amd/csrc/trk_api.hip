@@ -563,7 +563,7 @@ int trk_assoc_scan(trk_ctx* ctx, const trk_batch* in, const trk_assoc_params* pr
     HIPCHK(ctx, trk::launch_assoc_prepare(*in, *prm, *out, ctx->assoc_ws, ctx->stream));
     {
         ProfScope ps(ctx, TRK_K_ASSOC_SCAN);
-        HIPCHK(ctx, trk::launch_assoc_scan(*in, *prm, *out, ctx->assoc_ws, ctx->stream));
+        HIPCHK(ctx, trk::launch_assoc_scan(*in, *prm, *out, ctx->assoc_ws, ctx->n_cu, ctx->stream));
     }
     {
         ProfScope ps(ctx, TRK_K_ASSOC_FINALIZE);

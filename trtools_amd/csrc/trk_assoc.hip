@@ -72,9 +72,11 @@ struct AssocArgs {
     int M, NS, NC;
     int chunk;                 // samples per chunk (multiple of 256)
     int nchunks;
-    int loci_per_wg;
+    int loci_per_wg;           // 0: persistent workgroups, waves take loci from work_counter
+    int* work_counter;         // [nchunks] next locus of each sample chunk (zeroed by the launcher)
     int wave_bytes;            // LDS bytes of one wave's private area (LUT + histogram)
     int kshift;
+    int n_cu;
     int dbg;                   // TRK_AS_DBG ablation bits (1: no rare path, 2: no histogram, 4: no LUT)
     uint8_t pa[AS_MAXNC], pb[AS_MAXNC];  // Gram entry e = row pa[e] x row pb[e]; row M = ones
 };
@@ -334,10 +336,29 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan(const AssocArgs a) {
     const int K = 1 << a.kshift;
     const int nch = ns >> 2;
     const int nfull = nch - nch % (U * WAVE);  // chunks covered by full U-deep iterations
-    const int l0 = blockIdx.x * a.loci_per_wg;
-    const int l1 = min(a.b.n_loci, l0 + a.loci_per_wg);
-
-    for (int l = l0 + wid; l < l1; l += AS_WAVES) {  // waves are independent from here on
+    // waves are independent from here on.  Persistent workgroups (one per CU, the LDS admits no
+    // more; the trait vectors are staged once per CU).  Each wave first walks its static share of
+    // the first 7/8 of the loci, then takes single loci of the rest from a global counter so that
+    // no wave idles at the end (all loci through the counter would saturate same-address atomics:
+    // ~10 ns each, 1 ms for 100k loci).
+    const int n_waves = gridDim.x * AS_WAVES;
+    const int l_dyn0 = a.loci_per_wg ? 0 : (int)(((int64_t)a.b.n_loci * 7 / 8) / n_waves) * n_waves;
+    int l_static = a.loci_per_wg ? blockIdx.x * a.loci_per_wg + wid : blockIdx.x * AS_WAVES + wid;
+    const int l_end = a.loci_per_wg ? min(a.b.n_loci, (int)(blockIdx.x + 1) * a.loci_per_wg) : a.b.n_loci;
+    for (;;) {
+        int l;
+        if (a.loci_per_wg) {
+            l = l_static;
+            l_static += AS_WAVES;
+        } else if (l_static < l_dyn0) {
+            l = l_static;
+            l_static += n_waves;
+        } else {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(&a.work_counter[blockIdx.y], 1);
+            l = l_dyn0 + __builtin_amdgcn_readfirstlane(t);
+        }
+        if (l >= l_end) break;
         const int off = a.b.allele_off[l];
         const int A = a.b.allele_off[l + 1] - off;
         double* lut = reinterpret_cast<double*>(wave_area);           // [A+3]
@@ -873,7 +894,8 @@ static AssocPlan assoc_plan(const trk_batch& b, int M) {
         p.loci_per_wg = (b.n_loci + per_round * rounds - 1) / (per_round * rounds);
         if (p.loci_per_wg < 1) p.loci_per_wg = 1;
     }
-    if (const char* e = getenv("TRK_AS_LB")) p.loci_per_wg = atoi(e) > 0 ? atoi(e) : p.loci_per_wg;
+    p.loci_per_wg = 0;  // persistent workgroups by default; TRK_AS_LB=n restores static blocks of n loci
+    if (const char* e = getenv("TRK_AS_LB")) p.loci_per_wg = atoi(e) > 0 ? atoi(e) : 0;
     p.fast = true;
     return p;
 }
@@ -881,7 +903,7 @@ static AssocPlan assoc_plan(const trk_batch& b, int M) {
 size_t assoc_workspace_bytes(const trk_batch& b, int M) {
     const AssocPlan p = assoc_plan(b, M);
     const int NC = (M + 1) * (M + 2) / 2, NS = 3 + M + NC + 1;
-    size_t bytes = (size_t)NC * 8;                                    // full Gram
+    size_t bytes = 1024 + (size_t)NC * 8;                             // work counters, full Gram
     bytes += (size_t)p.nchunks * b.n_loci * NS * 8;                   // partial records
     bytes += ((size_t)b.n_alleles_total * 4 + 7) & ~(size_t)7;        // class counts
     return bytes + 64;
@@ -892,7 +914,16 @@ static hipError_t launch_scan_tm(const AssocArgs& a, const AssocPlan& p, hipStre
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assoc_scan<MV, MASK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     if (e != hipSuccess) return e;
-    dim3 grid((a.b.n_loci + p.loci_per_wg - 1) / p.loci_per_wg, p.nchunks), block(AS_THREADS);
+    int gx;
+    if (p.loci_per_wg) {
+        gx = (a.b.n_loci + p.loci_per_wg - 1) / p.loci_per_wg;
+    } else {
+        gx = (a.n_cu + p.nchunks - 1) / p.nchunks;  // ~one workgroup per CU over all chunks
+        const int max_useful = (a.b.n_loci + AS_WAVES - 1) / AS_WAVES;
+        if (gx > max_useful) gx = max_useful;
+        if (gx < 1) gx = 1;
+    }
+    dim3 grid(gx, p.nchunks), block(AS_THREADS);
     hipLaunchKernelGGL((k_assoc_scan<MV, MASK>), grid, block, p.lds_bytes, stream, a);
     return hipGetLastError();
 }
@@ -927,6 +958,8 @@ static void assoc_build(const trk_batch& b, const trk_assoc_params& prm, const t
             ++e;
         }
     unsigned char* ws = static_cast<unsigned char*>(workspace);
+    a.work_counter = reinterpret_cast<int*>(ws);
+    ws += 1024;
     full = reinterpret_cast<double*>(ws);
     a.partial = reinterpret_cast<double*>(ws + (size_t)a.NC * 8);
     a.allele_count = out.allele_count;
@@ -956,6 +989,7 @@ hipError_t launch_assoc_prepare(const trk_batch& b, const trk_assoc_params& prm,
     double* full;
     assoc_build(b, prm, out, workspace, p, a, f, full);
     hipError_t err;
+    if ((err = hipMemsetAsync(a.work_counter, 0, 1024, stream)) != hipSuccess) return err;
     if (b.n_alleles_total > 0) {
         if ((err = hipMemsetAsync(f.cc, 0, (size_t)b.n_alleles_total * 4, stream)) != hipSuccess) return err;
         if (!p.fast || p.nchunks > 1)
@@ -968,12 +1002,13 @@ hipError_t launch_assoc_prepare(const trk_batch& b, const trk_assoc_params& prm,
 
 // step 2: the streaming pass over the genotype tensor
 hipError_t launch_assoc_scan(const trk_batch& b, const trk_assoc_params& prm, const trk_assoc_out& out,
-                             void* workspace, hipStream_t stream) {
+                             void* workspace, int n_cu, hipStream_t stream) {
     AssocPlan p;
     AssocArgs a;
     FinArgs f;
     double* full;
     assoc_build(b, prm, out, workspace, p, a, f, full);
+    a.n_cu = n_cu > 0 ? n_cu : 256;
     if (b.n_loci == 0) return hipSuccess;
     if (p.fast) {
         switch (p.mv) {

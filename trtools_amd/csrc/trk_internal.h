@@ -31,7 +31,7 @@ size_t assoc_workspace_bytes(const trk_batch& b, int n_vec);
 hipError_t launch_assoc_prepare(const trk_batch& b, const trk_assoc_params& prm, const trk_assoc_out& out,
                                 void* workspace, hipStream_t stream);
 hipError_t launch_assoc_scan(const trk_batch& b, const trk_assoc_params& prm, const trk_assoc_out& out,
-                             void* workspace, hipStream_t stream);
+                             void* workspace, int n_cu, hipStream_t stream);
 hipError_t launch_assoc_finalize(const trk_batch& b, const trk_assoc_params& prm, const trk_assoc_out& out,
                                  void* workspace, hipStream_t stream);
 }  // namespace trk
