@@ -77,7 +77,6 @@ struct AssocArgs {
     int wave_bytes;            // LDS bytes of one wave's private area (LUT + histogram)
     int kshift;
     int n_cu;
-    int dbg;                   // TRK_AS_DBG ablation bits (1: no rare path, 2: no histogram, 4: no LUT)
     uint8_t pa[AS_MAXNC], pb[AS_MAXNC];  // Gram entry e = row pa[e] x row pb[e]; row M = ones
 };
 
@@ -122,7 +121,6 @@ struct ScanCtx {
     const double* vec;   // LDS [M][Sr]
     int Sr, M, kshift, kslot;   // Sr: row stride of vec (chunk, +1 when lanes read different rows)
     uint32_t amax2;
-    int dbg;
 };
 
 // One chunk = 4 consecutive samples of one lane.  `mk`: their regression-set bytes (MASK only).
@@ -136,8 +134,7 @@ __device__ __forceinline__ uint32_t scan_chunk(const ScanCtx& x, const u32x4 v, 
     double y[PRE ? MV : 1][4];
     if (PRE) {
 #pragma unroll
-        for (int k = 0; k < MV; ++k)
-            if (k < x.M) {
+        for (int k = 0; k < MV; ++k) {
                 if (!TAIL || live) {
                     const double2 a0 = *reinterpret_cast<const double2*>(&x.vec[(size_t)k * x.Sr + s0]);
                     const double2 a1 = *reinterpret_cast<const double2*>(&x.vec[(size_t)k * x.Sr + s0 + 2]);
@@ -155,7 +152,7 @@ __device__ __forceinline__ uint32_t scan_chunk(const ScanCtx& x, const u32x4 v, 
         u16x2 t2 = __builtin_elementwise_min(u, __builtin_bit_cast(u16x2, x.amax2));
         const uint32_t t = __builtin_bit_cast(uint32_t, t2);
         const uint32_t lo = t & 0xffffu, hi = t >> 16;
-        double g = (x.dbg & 4) ? (double)(lo + hi) : x.lut[lo] + x.lut[hi];   // NaN when either haplotype is '-1'
+        double g = x.lut[lo] + x.lut[hi];   // NaN when either haplotype is '-1'
         const bool called = g == g;
         bool ok = called;
         if (MASK) {
@@ -172,13 +169,15 @@ __device__ __forceinline__ uint32_t scan_chunk(const ScanCtx& x, const u32x4 v, 
         acc.sg += g;
         acc.sgg = __builtin_fma(g, g, acc.sgg);
 #pragma unroll
-        for (int k = 0; k < MV; ++k)
-            if (k < x.M) {
-                const double yv = PRE ? y[k][j] : ((!TAIL || live) ? x.vec[(size_t)k * x.Sr + s0 + j] : 0.0);
-                acc.sgv[k] = __builtin_fma(g, yv, acc.sgv[k]);
-            }
+        for (int k = 0; k < MV; ++k) {
+            // few vectors: M == MV.  Many: the (uniform) guard also keeps the compiler from
+            // hoisting MV x 4 x U LDS reads to the top of the loop, which spills
+            if (!PRE && k >= x.M) continue;
+            const double yv = PRE ? y[k][j] : ((!TAIL || live) ? x.vec[(size_t)k * x.Sr + s0 + j] : 0.0);
+            acc.sgv[k] = __builtin_fma(g, yv, acc.sgv[k]);
+        }
         // calls that are not tested are counted in bin 1 (2 per call): n = calls - bin1 / 2
-        if ((!TAIL || live) && !(x.dbg & 2)) {
+        if (!TAIL || live) {
             atomicAdd(&x.hist[((ok ? lo : 1u) << x.kshift) + x.kslot], 1u);
             atomicAdd(&x.hist[((ok ? hi : 1u) << x.kshift) + x.kslot], 1u);
         }
@@ -219,7 +218,7 @@ __device__ __forceinline__ void drain_by_sample(const ScanCtx& x, const uint16_t
             const int s = c * 4 + j;
             double z[MV + 1];
 #pragma unroll
-            for (int k = 0; k < MV; ++k) z[k] = k < x.M ? x.vec[(size_t)k * x.Sr + s] : 0.0;
+            for (int k = 0; k < MV; ++k) z[k] = x.vec[(size_t)k * x.Sr + s];
             z[MV] = 1.0;
             int e = 0;
 #pragma unroll
@@ -307,8 +306,8 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan(const AssocArgs a) {
     // row stride: the by-entry drain reads one sample of MANY rows at once; a stride that is a
     // multiple of 32 banks would put them all on one bank pair
     const int Sr = Sc + (MV > 4 ? 1 : 0);
-    double* vec = lds_d;                                                   // [M][Sr]
-    uint32_t* maskw = reinterpret_cast<uint32_t*>(vec + (size_t)M * Sr);   // [Sc/4] one byte per sample
+    double* vec = lds_d;                                                   // [MV][Sr], rows >= M zero
+    uint32_t* maskw = reinterpret_cast<uint32_t*>(vec + (size_t)MV * Sr);  // [Sc/4] one byte per sample
     unsigned char* wave_area = reinterpret_cast<unsigned char*>(maskw + Sc / 4) + (size_t)wid * a.wave_bytes;
     uint16_t* queue = reinterpret_cast<uint16_t*>(wave_area);  // [AS_QCAP] missing-call records
     wave_area += AS_QCAP * sizeof(uint16_t);
@@ -321,8 +320,7 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan(const AssocArgs a) {
         const bool in = !MASK || a.sample_in[s_begin + i];
         if (MASK) reinterpret_cast<unsigned char*>(maskw)[i] = in ? 1 : 0;
 #pragma unroll
-        for (int k = 0; k < MV; ++k)
-            if (k < M) vec[(size_t)k * Sr + i] = in ? a.vec[(size_t)k * S + s_begin + i] : 0.0;
+        for (int k = 0; k < MV; ++k) vec[(size_t)k * Sr + i] = (in && k < M) ? a.vec[(size_t)k * S + s_begin + i] : 0.0;
     }
     __syncthreads();
 
@@ -373,7 +371,7 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan(const AssocArgs a) {
         for (int i = lane; i < ((A + 3) << a.kshift); i += WAVE) hist[i] = 0;
         wave_fence();
 
-        ScanCtx x{lut, hist, vec, Sr, M, a.kshift, lane & (K - 1), (uint32_t)(A + 2) * 0x00010001u, a.dbg};
+        ScanCtx x{lut, hist, vec, Sr, M, a.kshift, lane & (K - 1), (uint32_t)(A + 2) * 0x00010001u};
         Acc<MV> acc;
 #pragma unroll
         for (int k = 0; k < MV; ++k) acc.sgv[k] = 0.0;
@@ -384,8 +382,7 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan(const AssocArgs a) {
         for (int e = 0; e < NCS; ++e) cs[e] = 0.0;
         int qlen = 0;
         auto drain = [&]() {
-            if (a.dbg & 1) {
-            } else if (BY_SAMPLE) {
+            if (BY_SAMPLE) {
                 drain_by_sample<MV>(x, queue, qlen, lane, cs);
             } else {
                 drain_by_entry<MV>(x, queue, qlen, lane, pa, pb, acc.corr);
@@ -871,8 +868,8 @@ static AssocPlan assoc_plan(const trk_batch& b, int M) {
     p.kshift = kshift;
     p.wave_bytes = AS_QCAP * 2 + (((Amax + 3) * (8 + (4 << kshift)) + 15) & ~15);
     const size_t lds_total = 160 * 1024;
-    const size_t rem = lds_total - (size_t)AS_WAVES * p.wave_bytes - 64 - 8 * (size_t)M;
-    int chunk = (int)(rem / (8 * (size_t)M + 1));
+    const size_t rem = lds_total - (size_t)AS_WAVES * p.wave_bytes - 64 - 8 * (size_t)p.mv;
+    int chunk = (int)(rem / (8 * (size_t)p.mv + 1));
     chunk &= ~255;
     if (chunk > 16384) chunk = 16384;  // 12-bit chunk index in the queue records
     if (chunk < 256) return p;
@@ -884,7 +881,7 @@ static AssocPlan assoc_plan(const trk_batch& b, int M) {
         p.nchunks = (S + chunk - 1) / chunk;
         p.chunk = (((S + p.nchunks - 1) / p.nchunks) + 255) & ~255;  // balanced
     }
-    p.lds_bytes = (size_t)M * (p.chunk + 1) * 8 + p.chunk + (size_t)AS_WAVES * p.wave_bytes;
+    p.lds_bytes = (size_t)p.mv * (p.chunk + 1) * 8 + p.chunk + (size_t)AS_WAVES * p.wave_bytes;
     // one workgroup per CU at a time (LDS): size the locus blocks so that the grid is a whole
     // number of rounds over the 256 CUs, ~48 loci (3 per wave) each
     {
@@ -949,7 +946,6 @@ static void assoc_build(const trk_batch& b, const trk_assoc_params& prm, const t
     a.loci_per_wg = p.loci_per_wg;
     a.wave_bytes = p.wave_bytes;
     a.kshift = p.kshift;
-    a.dbg = getenv("TRK_AS_DBG") ? atoi(getenv("TRK_AS_DBG")) : 0;
     int e = 0;
     for (int r = 0; r <= M; ++r)
         for (int c = r; c <= M; ++c) {
