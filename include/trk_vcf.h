@@ -45,6 +45,11 @@ const char* trk_vcf_header(trk_vcf* v, size_t* len);
 int trk_vcf_n_samples(trk_vcf* v);
 const char* trk_vcf_sample_name(trk_vcf* v, int i);
 
+/* Continue reading at a BGZF virtual offset (compressed block offset << 16 | offset inside the
+ * inflated block) -- the positions a tabix index (.tbi) holds; what cyvcf2's vcf(region) does
+ * through htslib (statSTR.py:568-570, load_and_filter_genotypes.py:126-128).  BGZF files only. */
+int trk_vcf_seek(trk_vcf* v, uint64_t voffset);
+
 /* Ask for a FORMAT field to be decoded into a plane; returns the plane index (>= 0) or < 0. */
 int trk_vcf_select_format(trk_vcf* v, const char* key, int kind, int ncol);
 

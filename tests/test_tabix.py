@@ -1,0 +1,118 @@
+"""Tabix indexes without htslib tools (trtools_amd/tabix.py) and the native reader's index seek.
+Pinned by the .tbi files htslib wrote for the reference's fixture VCFs."""
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+DATA = os.path.join(ROOT, 'tests', 'golden', 'data')
+FIXTURES = sorted(f for f in glob.glob(DATA + '/**/*.vcf.gz', recursive=True) if os.path.exists(f + '.tbi'))
+
+
+@pytest.mark.parametrize('vcf', FIXTURES, ids=[os.path.basename(f) for f in FIXTURES])
+def test_built_index_agrees_with_htslib(vcf, tmp_path):
+    from trtools_amd import tabix
+    ref = tabix.TabixIndex.load(vcf + '.tbi')
+    out = str(tmp_path / 'x.tbi')
+    mine = tabix.build(vcf, out)
+    back = tabix.TabixIndex.load(out)
+    assert back.names == mine.names == ref.names
+    assert back.linear == mine.linear and back.bins == mine.bins          # write/read round trip
+    assert ref.meta == back.meta
+    for r in range(len(ref.names)):
+        # htslib's meta bin: first/last virtual offset of the sequence and its record count
+        assert mine.bins[r][tabix.META_BIN] == ref.bins[r][tabix.META_BIN]
+        a, b = ref.linear[r], mine.linear[r]
+        assert len(a) == len(b)
+        # windows in which a record STARTS carry the same offset in any htslib version; empty windows are
+        # filled from a neighbour (which one changed between htslib versions): both fills must be covered
+        fwd = all(x == y for x, y in zip(a, b))
+        filled = set(a)
+        assert fwd or all(y in filled for y in b)
+        starts = set()
+        for s, e, line in tabix._lines(vcf):
+            if line and line[:1] != b'#':
+                starts.add(s)
+        assert set(b) <= starts and set(a) <= starts
+        # every chunk of the binning index starts at a record and the bins are the records' bins
+        for bin_id, chunks in mine.bins[r].items():
+            if bin_id != tabix.META_BIN:
+                assert all(c[0] in starts and c[1] > c[0] for c in chunks)
+
+
+def _records(reader, region=None):
+    it = reader(region) if region else reader
+    return [(v.CHROM, v.POS, v.ID) for v in it]
+
+
+def test_region_seek_returns_what_the_full_scan_returns(tmp_path):
+    from trtools_amd import vcfnative, vcfio
+    vcf = os.path.join(DATA, 'many_samples.vcf.gz')
+    rng = np.random.default_rng(3)
+    allpos = [p for _, p, _ in _records(vcfnative.NativeVCFReader(vcf))]
+    regions = ['1:1000000-2000000', '1:1-20000', '1:%d-%d' % (allpos[-1], allpos[-1] + 10), '1:9000000-9999999', '2:1-100', '1']
+    for _ in range(12):
+        a = int(rng.integers(1, allpos[-1]))
+        regions.append('1:%d-%d' % (a, a + int(rng.integers(1, 400000))))
+    for reg in regions:
+        seek = vcfnative.NativeVCFReader(vcf)
+        got = _records(seek, reg)
+        want = _records(vcfio.VCFReader(vcf), reg)              # python decoder: always a linear scan
+        assert got == want, reg
+        if ':' in reg and got:
+            assert seek._indexed_region
+    os.environ['TRK_TABIX'] = '0'
+    try:
+        r = vcfnative.NativeVCFReader(vcf)
+        assert _records(r, regions[0]) == _records(vcfio.VCFReader(vcf), regions[0]) and not r._indexed_region
+    finally:
+        del os.environ['TRK_TABIX']
+
+
+def test_seek_reads_fewer_bytes(tmp_path):
+    """A large bgzipped file: a region near the end is served without inflating the whole file."""
+    from trtools_amd import bgzf, tabix, vcfnative
+    path = str(tmp_path / 'big.vcf.gz')
+    with bgzf.BgzfWriter(path) as fh:
+        fh.write('##fileformat=VCFv4.2\n##contig=<ID=chr1>\n##FORMAT=<ID=GT,Number=1,Type=String,Description="g">\n')
+        fh.write('#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t' + '\t'.join('s%d' % i for i in range(200)) + '\n')
+        gts = '\t'.join(['0/1'] * 200)
+        for i in range(6000):
+            fh.write('chr1\t%d\tr%d\tACAC\tAC\t.\t.\t.\tGT\t%s\n' % (1000 + 37 * i, i, gts))
+    idx = tabix.build(path)
+    assert len(idx.linear[0]) == (1000 + 37 * 5999 + 3) // 16384 + 1
+    r = vcfnative.NativeVCFReader(path)
+    got = [v.POS for v in r('chr1:200000-200100')]
+    assert got == [p for p in range(1000, 1000 + 37 * 6000, 37) if p + 3 >= 200000 and p <= 200100]
+    assert r._indexed_region
+
+
+def test_dumpstr_zip_writes_an_index(tmp_path):
+    from trtools_amd import tabix
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    from trtools_amd import runtime
+    from trtools_amd.dumpSTR import dumpSTR
+    from oracle_compute import OracleCompute
+    import gen_golden_dumpstr as gg
+    old = runtime.set_compute(OracleCompute())
+    try:
+        caller, kw = gg.CASES['hipstr_all']
+        args = gg.make_args(str(tmp_path / 'z'), os.path.join(ROOT, 'tests', 'golden', 'dumpstr_synth', 'synth_hipstr.vcf'),
+                            caller, **kw)
+        args.zip = True
+        argv, sys.argv = sys.argv, ['dumpSTR']
+        try:
+            assert dumpSTR.main(args) == 0
+        finally:
+            sys.argv = argv
+    finally:
+        runtime.set_compute(old)
+    out = str(tmp_path / 'z.vcf.gz')
+    idx = tabix.TabixIndex.load(out + '.tbi')
+    n = sum(1 for s, e, l in tabix._lines(out) if l and l[:1] != b'#')
+    assert sum(idx.bins[r][tabix.META_BIN][1][0] for r in range(len(idx.names))) == n > 0

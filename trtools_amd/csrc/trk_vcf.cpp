@@ -476,6 +476,36 @@ int trk_vcf_open(const char* path, int n_threads, trk_vcf** out) {
     return 0;
 }
 
+int trk_vcf_seek(trk_vcf* v, uint64_t voffset) {
+    if (!v) return 2;
+    if (!v->src.bgzf || !v->src.fp) {
+        v->err = "seek needs a BGZF (bgzip) file";
+        return 1;
+    }
+    const uint64_t coff = voffset >> 16;
+    const size_t uoff = (size_t)(voffset & 0xffffu);
+    if (fseeko(v->src.fp, (off_t)coff, SEEK_SET) != 0) {
+        v->err = "fseek failed";
+        return 1;
+    }
+    v->src.cbuf.clear();
+    v->src.cpos = 0;
+    v->src.eof = false;
+    v->buf.clear();
+    v->pos = 0;
+    v->line_off.clear();
+    v->line_end.clear();
+    // the first block must be inflated before the in-block offset can be applied
+    while (v->buf.size() < uoff && !v->src.eof)
+        if (!v->src.fill(v->buf, 1 << 16, v->err)) return 1;
+    if (v->buf.size() < uoff) {
+        v->err = "virtual offset beyond the end of its block";
+        return 1;
+    }
+    v->pos = uoff;
+    return 0;
+}
+
 void trk_vcf_close(trk_vcf* v) {
     if (!v) return;
     v->src.close();

@@ -727,13 +727,12 @@ def main(args):
     WriteSampLog(run.sample_info, invcf.samples, args.out + ".samplog.tab")
     WriteLocLog(run.loc_info, args.out + ".loclog.tab")
     if args.zip:
+        # the reference shells out to `tabix` (dumpSTR.py:1347-1352); the index is written here
+        from .. import tabix
         try:
-            proc = sp.run(["tabix", args.out + suffix])
-            rc = proc.returncode
-        except FileNotFoundError:
-            rc = 127
-        if rc != 0:
-            common.WARNING("Tabix failed with returncode " + str(rc))
+            tabix.build(args.out + suffix)
+        except (OSError, ValueError) as e:
+            common.WARNING("Tabix failed with returncode 1 (%s)" % e)
             return 1
     return 0
 

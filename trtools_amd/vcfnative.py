@@ -9,6 +9,8 @@ available (decoded lazily in Python from the record text)."""
 import ctypes as C
 import os
 
+from struct import error as struct_error
+
 import numpy as np
 
 from . import _lib
@@ -41,6 +43,7 @@ def _api():
         lib.trk_vcf_sample_name.restype = C.c_char_p
         lib.trk_vcf_select_format.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
         lib.trk_vcf_read_batch.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_Batch)]
+        lib.trk_vcf_seek.argtypes = [vp, C.c_uint64]
         lib._vcf_ready = True
     return lib
 
@@ -77,6 +80,7 @@ class NativeVCFReader(vcfio.VCFReader):
                 self.samples = line.split('\t')[9:]
         self.n_samples = len(self.samples)
         self._region = None
+        self._indexed_region = False
         self._selected = []          # (key, kind, ncol, dtype)
         self._max_ploidy = max_ploidy
         self._batch_records = batch_records
@@ -152,8 +156,40 @@ class NativeVCFReader(vcfio.VCFReader):
             if v.CHROM not in self.contigs_declared and v.CHROM not in self.contigs_seen:
                 self.contigs_seen.append(v.CHROM)
             if self._region is not None and not self._in_region(v):
+                if self._indexed_region and self._past_region(v):
+                    self._eof, self._rows = True, []     # sorted file: nothing further can overlap
+                    raise StopIteration
                 continue
             return v
+
+    def __call__(self, region):
+        """Region query ``chrom[:start-end]``.  With a tabix index next to a bgzipped file the reader
+        seeks to the first 16 kb window the region touches (the index's linear table) and stops at
+        the first record past the region; without one it scans the whole file."""
+        vcfio.VCFReader.__call__(self, region)
+        self._indexed_region = False
+        tbi = self.path + '.tbi'
+        if os.path.isfile(tbi) and os.environ.get('TRK_TABIX', '1') != '0':
+            from . import tabix
+            try:
+                idx = tabix.TabixIndex.load(tbi)
+            except (OSError, ValueError, struct_error):
+                return self
+            chrom, start, _ = self._region
+            off = idx.start_offset(chrom, start)
+            if off is None or off < 0:
+                self._eof, self._rows, self._row_i = True, [], 0   # sequence absent / region past its end
+                return self
+            if self._lib.trk_vcf_seek(self._h, off) == 0:
+                self._rows, self._row_i, self._eof = [], 0, False
+                self._indexed_region = True
+        return self
+
+    def _past_region(self, v):
+        chrom, start, end = self._region
+        if v.CHROM != chrom:
+            return True
+        return end is not None and v.POS > end
 
     def close(self):
         if self._h is not None:
