@@ -308,7 +308,7 @@ int trk_locus_filters(trk_ctx* ctx, int32_t n_loci, const trk_stats_out* stats,
  * row-major by VECTOR: vec[0] = outcome, vec[1..] = covariates, each [S] (entries of
  * samples with sample_in == 0 are ignored).  The intercept is implicit.
  */
-#define TRK_ASSOC_MAX_VEC 16
+#define TRK_ASSOC_MAX_VEC 31
 typedef struct {
     int32_t n_vec;              /* M >= 1: outcome + (M-1) covariates                        */
     int32_t flags;              /* 0                                                         */

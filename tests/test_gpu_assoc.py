@@ -142,6 +142,25 @@ def test_fast_path_sample_chunks(eng):
     assert run_case(eng, 4, 40, 4096, M=16, subset=True, miss=0.02) > 20
 
 
+def test_mfma_path_many_covariates(eng):
+    # M >= 3 goes through k_assoc_scan_mfma (16 loci x 16/32 vector rows per MFMA tile)
+    assert run_case(eng, 21, 70, 1000, M=3, subset=True) > 30
+    assert run_case(eng, 22, 50, 2048, M=15) > 25              # 16 rows with the ones row: one tile
+    assert run_case(eng, 23, 50, 1500, M=16, subset=True, miss=0.08) > 25   # two tiles
+    assert run_case(eng, 24, 37, 772, M=31, subset=True) > 15  # loci not a multiple of 16, S not of 256
+    assert run_case(eng, 25, 20, 516, M=20, cutoff=0.0, miss=0.5) > 3      # half the calls missing
+
+
+def test_lds_resident_kernels_for_more_than_two_vectors(eng):
+    os.environ['TRK_AS_MFMA_MIN'] = '99'
+    try:
+        assert run_case(eng, 2, 90, 1000, M=4, subset=True) > 40
+        assert run_case(eng, 3, 60, 768, M=10, subset=True, cutoff=0.0) > 30
+        assert run_case(eng, 4, 40, 4096, M=16, subset=True, miss=0.02) > 20
+    finally:
+        del os.environ['TRK_AS_MFMA_MIN']
+
+
 def test_many_alleles_and_rounding(eng):
     assert run_case(eng, 5, 50, 640, M=2, max_alleles=60) > 25
     assert run_case(eng, 6, 30, 512, M=1, max_alleles=400, precision=10) > 10   # generic path (LUT too big)

@@ -37,10 +37,10 @@ namespace {
 constexpr int WAVE = 64;
 constexpr int AS_WAVES = 16;                 // waves per workgroup of the scan kernel
 constexpr int AS_THREADS = WAVE * AS_WAVES;  // 1024
-constexpr int AS_MAXV = TRK_ASSOC_MAX_VEC;   // 16
-constexpr int AS_MAXNC = (AS_MAXV + 1) * (AS_MAXV + 2) / 2;  // 153 Gram entries of [vec..., 1]
-constexpr int AS_E = (AS_MAXNC + WAVE - 1) / WAVE;           // Gram entries per lane (3)
-constexpr int FIN_T = 64;
+constexpr int AS_MAXV = TRK_ASSOC_MAX_VEC;   // 31
+constexpr int AS_MAXNC = (AS_MAXV + 1) * (AS_MAXV + 2) / 2;  // 528 Gram entries of [vec..., 1]
+constexpr int AS_E = (AS_MAXNC + WAVE - 1) / WAVE;           // Gram entries per lane, generic kernel (9)
+constexpr int FIN_T = 64;                    // finaliser threads per block (fewer when the normal matrix is large)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
@@ -469,6 +469,250 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan(const AssocArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------
+// streaming scan, many covariates: the cross-products  sum_s g[l][s] * v_k[s]  of SIXTEEN loci
+// and up to 16*RT vector rows are a GEMM tile, done with v_mfma_f64_16x16x4_f64.
+//   workgroup = 16 waves = 16 loci; the row is walked in steps of 256 samples:
+//     * all threads stage the step's block of the vectors (+ a row of ones, + zero rows up to
+//       16*RT) into LDS -- loaded a step ahead into registers, as is each wave's genotype chunk;
+//     * every wave decodes ITS locus as in the one-trait kernel (NaN LUT, sum g^2, histogram,
+//       tested-sample count from the '-1' bin) and writes the 256 summed lengths to its row of
+//       the G tile in LDS;                                               -- barrier --
+//     * MFMA: wave w multiplies columns [16w, 16w+16) of the G tile (A: 16 loci x 4 samples) with
+//       the same columns of the vector block (B: 4 samples x 16 rows), accumulating C[16 x 16*RT];
+//     * missing calls: each wave gathers the vector columns of ITS locus's missing samples (still
+//       resident) four at a time and accumulates their Gram matrix, A = B = Z (16 rows x 4
+//       samples) per tile pair;                                           -- barrier --
+//   Inside a step the 256 samples sit in LDS in the order (cell j of the 16-byte chunk, lane):
+//   column j*64 + lane holds sample 4*lane + j, for the G tile and the vector block alike, so
+//   that a wave's 64 lanes write consecutive doubles (sample order would be a 16-way conflict).
+//   end of row: the 16 partial C tiles are summed through LDS in wave order (deterministic).
+// MFMA lane layout (probed on gfx950, tools/mfma_probe): A lane i = A[i%16][i/16],
+// B lane i = B[i/16][i%16], D lane i reg r = D[4r + i/16][i%16].
+// -------------------------------------------------------------------------------------------
+constexpr int MF_SB = 256;    // samples per step
+constexpr int MF_SBR = 257;   // LDS row stride (odd: 16 rows of one column fall on 16 bank pairs);
+                              // column MF_SB is a zero column (padding of the missing-sample batches)
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+template <int RT, bool MASK>
+__global__ __launch_bounds__(AS_THREADS) void k_assoc_scan_mfma(const AssocArgs a) {
+    extern __shared__ double lds_d[];
+    constexpr int ROWS = 16 * RT;
+    constexpr int NP = RT * (RT + 1) / 2;  // tile pairs of the symmetric Gram matrix
+    __shared__ int tile_sh;
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wid = tid >> 6;
+    const int S = a.b.n_samples, M = a.M, L = a.b.n_loci;
+    double* Vb = lds_d;                 // [ROWS][MF_SBR]  rows 0..M-1 vectors, row M ones, rest zero
+    double* Gt = Vb + ROWS * MF_SBR;    // [16][MF_SBR]    summed lengths of the 16 loci (0 where not tested)
+    unsigned char* wave_area = reinterpret_cast<unsigned char*>(Gt + 16 * MF_SBR) + (size_t)wid * a.wave_bytes;
+    uint16_t* xs = reinterpret_cast<uint16_t*>(wave_area);  // [MF_SB + 8] missing samples of this step
+    wave_area += (MF_SB + 8) * sizeof(uint16_t);
+    const int K = 1 << a.kshift;
+    const int nsteps = (S + MF_SB - 1) / MF_SB;
+    // staging role of this thread: row vr (+16 per tile), 4 consecutive samples at column vc
+    const int vr = tid >> 6, vc = (tid & 63) * 4;
+    for (int r = tid; r < ROWS; r += AS_THREADS) Vb[r * MF_SBR + MF_SB] = 0.0;
+
+    auto load_v = [&](int step, double (*out)[4]) {
+        const int s = step * MF_SB + vc;
+        uint32_t mk = 0x01010101u;
+        if (MASK && s < S) mk = *reinterpret_cast<const uint32_t*>(a.sample_in + s);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int r = vr + 16 * t;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool in = s < S && ((mk >> (8 * j)) & 0xffu) != 0;   // S % 4 == 0: all four or none
+                double x = 0.0;
+                if (in) x = r < M ? a.vec[(size_t)r * S + s + j] : (r == M ? 1.0 : 0.0);
+                out[t][j] = x;
+            }
+        }
+    };
+
+    for (;;) {
+        if (tid == 0) tile_sh = atomicAdd(&a.work_counter[0], 1);
+        __syncthreads();
+        const int tile = tile_sh;
+        __syncthreads();
+        if (tile * 16 >= L) break;
+        const int l = tile * 16 + wid;
+        const bool has = l < L;
+        const int off = has ? a.b.allele_off[l] : 0;
+        const int A = has ? a.b.allele_off[l + 1] - off : 1;
+        double* lut = reinterpret_cast<double*>(wave_area);
+        uint32_t* hist = reinterpret_cast<uint32_t*>(lut + (A + 3));
+        if (has) {
+            const double pivot = a.allele_len[off];
+            for (int i = lane; i < A; i += WAVE) lut[i + 2] = a.allele_len[off + i] - pivot;
+            if (lane == 0) {
+                lut[0] = -2.0 - pivot;
+                lut[1] = __builtin_nan("");
+                lut[A + 2] = 0.0;
+            }
+            for (int i = lane; i < ((A + 3) << a.kshift); i += WAVE) hist[i] = 0;
+        }
+        wave_fence();
+        const uint32_t amax2 = (uint32_t)(A + 2) * 0x00010001u;
+        const int kslot = lane & (K - 1);
+        const u32x4* row = reinterpret_cast<const u32x4*>(a.b.gt + (int64_t)(has ? l : 0) * S * 2);
+
+        d4 C[RT], Gc[NP];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) C[t] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int p = 0; p < NP; ++p) Gc[p] = (d4){0.0, 0.0, 0.0, 0.0};
+        double sgg = 0.0;
+
+        const u32x4 dead = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        u32x4 vnext = dead;
+        uint32_t mnext = 0x01010101u;
+        double vbn[RT][4];
+        if (has && 4 * lane < S) {
+            vnext = __builtin_nontemporal_load(&row[lane]);
+            if (MASK) mnext = *reinterpret_cast<const uint32_t*>(a.sample_in + 4 * lane);
+        }
+        load_v(0, vbn);
+
+        for (int step = 0; step < nsteps; ++step) {
+            const int s0 = step * MF_SB;
+            // ---- this step's vector block -> LDS; this wave's genotype chunk -> G tile -----------
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Vb[(vr + 16 * t) * MF_SBR + j * 64 + (tid & 63)] = vbn[t][j];
+            const u32x4 v = vnext;
+            const uint32_t mk = mnext;
+            const bool live = has && s0 + 4 * lane < S;
+            uint32_t rare = 0;
+            double g4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t w = v[j];
+                u16x2 u = __builtin_bit_cast(u16x2, w) + (u16x2){2, 2};
+                u16x2 t2 = __builtin_elementwise_min(u, __builtin_bit_cast(u16x2, amax2));
+                const uint32_t t = __builtin_bit_cast(uint32_t, t2);
+                const uint32_t lo = t & 0xffffu, hi = t >> 16;
+                double g = lut[lo] + lut[hi];
+                const bool called = g == g;
+                const bool in = !MASK || ((mk >> (8 * j)) & 0xffu) != 0;
+                const bool ok = called & in & live;
+                rare |= (uint32_t)(in & !called & live) << j;
+                g = ok ? g : 0.0;
+                g4[j] = g;
+                sgg = __builtin_fma(g, g, sgg);
+                if (live) {
+                    atomicAdd(&hist[((ok ? lo : 1u) << a.kshift) + kslot], 1u);
+                    atomicAdd(&hist[((ok ? hi : 1u) << a.kshift) + kslot], 1u);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Gt[wid * MF_SBR + j * 64 + lane] = g4[j];
+            // ---- next step's operands into registers (they arrive during the MFMA phase) ---------
+            vnext = dead;
+            mnext = 0x01010101u;
+            if (step + 1 < nsteps) {
+                const int sn = s0 + MF_SB + 4 * lane;
+                if (has && sn < S) {
+                    vnext = __builtin_nontemporal_load(&row[(sn >> 2)]);
+                    if (MASK) mnext = *reinterpret_cast<const uint32_t*>(a.sample_in + sn);
+                }
+                load_v(step + 1, vbn);
+            }
+            // ---- this wave's missing samples of the step, compacted (order: cell, then lane) ------
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool bit = (rare >> j) & 1u;
+                const uint64_t mm = __ballot(bit);
+                if (mm) {
+                    const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32),
+                                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+                    if (bit) xs[pos] = (uint16_t)(j * 64 + lane);
+                    cnt += __popcll(mm);
+                }
+            }
+            if (lane < 4) xs[cnt + lane] = (uint16_t)MF_SB;  // pad the last batch with the zero column
+            __syncthreads();
+            // ---- MFMA: columns [16 wid, 16 wid + 16) of the step ---------------------------------
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int col = 16 * wid + 4 * ks + (lane >> 4);
+                const double av = Gt[(lane & 15) * MF_SBR + col];
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    const double bv = Vb[(16 * t + (lane & 15)) * MF_SBR + col];
+                    C[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, C[t], 0, 0, 0);
+                }
+            }
+            // ---- Gram matrix of this locus's missing samples, four at a time ---------------------
+            for (int b0 = 0; b0 < cnt; b0 += 4) {
+                const int sx = xs[b0 + (lane >> 4)];
+                double z[RT];
+#pragma unroll
+                for (int t = 0; t < RT; ++t) z[t] = Vb[(16 * t + (lane & 15)) * MF_SBR + sx];
+                int p = 0;
+#pragma unroll
+                for (int ti = 0; ti < RT; ++ti)
+#pragma unroll
+                    for (int tj = ti; tj < RT; ++tj) {
+                        Gc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(z[ti], z[tj], Gc[p], 0, 0, 0);
+                        ++p;
+                    }
+            }
+            __syncthreads();
+        }
+
+        // ---- end of the row --------------------------------------------------------------------
+        double* rec = a.partial + (size_t)(has ? l : 0) * a.NS;
+        double* red = Gt;  // [16 waves][256]
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wid * 256 + lane * 4 + r] = C[t][r];
+            __syncthreads();
+            if (lane < 16) {
+                // locus wid = 4*reg + lane/16  ->  reg = wid / 4, lane group wid % 4; vector row 16 t + lane
+                double sum = 0.0;
+                for (int w2 = 0; w2 < AS_WAVES; ++w2) sum += red[w2 * 256 + (16 * (wid & 3) + lane) * 4 + (wid >> 2)];
+                const int vrow = 16 * t + lane;
+                if (has) {
+                    if (vrow < M) rec[3 + vrow] = sum;
+                    else if (vrow == M) rec[1] = sum;   // the row of ones: sum g
+                }
+            }
+            __syncthreads();
+        }
+        const double sgg_w = wave_sum_f64(sgg);
+        if (has) {
+            if (lane == 0) rec[2] = sgg_w;
+            int p = 0;
+#pragma unroll
+            for (int ti = 0; ti < RT; ++ti)
+#pragma unroll
+                for (int tj = ti; tj < RT; ++tj) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ra = 16 * ti + 4 * r + (lane >> 4), rb = 16 * tj + (lane & 15);
+                        if (ra <= rb && rb <= M) rec[3 + M + ra * (M + 1) - ra * (ra - 1) / 2 + (rb - ra)] = Gc[p][r];
+                    }
+                    ++p;
+                }
+            for (int bin = lane; bin < A + 3; bin += WAVE) {
+                uint32_t sum = 0;
+                for (int k = 0; k < K; ++k) sum += hist[(bin << a.kshift) + ((k + lane) & (K - 1))];
+                if (bin >= 2 && bin < A + 2) a.allele_count[off + bin - 2] = (int32_t)sum;
+                if (bin == 1) rec[0] = (double)(S - (int)(sum >> 1));
+                if (bin == A + 2) rec[a.NS - 1] = (double)sum;
+            }
+        }
+        wave_fence();
+    }
+}
+
+// -------------------------------------------------------------------------------------------
 // streaming scan, any ploidy / alignment / allele count: wave per locus, operands from global
 // memory, histogram by global atomics (allele_count zeroed by the launcher)
 // -------------------------------------------------------------------------------------------
@@ -660,12 +904,12 @@ struct FinArgs {
 __device__ __forceinline__ int gidx(int r, int c, int M) { return r * (M + 1) - r * (r - 1) / 2 + (c - r); }
 
 __global__ __launch_bounds__(FIN_T) void k_assoc_finalize(const FinArgs a) {
-    extern __shared__ double fin_lds[];  // [entries][FIN_T], one column per thread
-    const int l = blockIdx.x * FIN_T + threadIdx.x;
+    extern __shared__ double fin_lds[];  // [entries][blockDim.x], one column per thread
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= a.b.n_loci) return;
     const int M = a.M, L = a.b.n_loci;
     const int P = M + 1;  // design columns: ones, covariates 1..M-1, genotype (last)
-#define LW(e) fin_lds[(size_t)(e) * FIN_T + threadIdx.x]
+#define LW(e) fin_lds[(size_t)(e) * blockDim.x + threadIdx.x]
     int32_t* li = a.locus_int + (size_t)l * TRK_AI_COLS;
     double* lf = a.locus_f64 + (size_t)l * TRK_AF_COLS;
     for (int i = 0; i < TRK_AI_COLS; ++i) li[i] = 0;
@@ -847,6 +1091,7 @@ namespace trk {
 
 struct AssocPlan {
     bool fast;
+    int mfma_rt;   // 0: not the MFMA kernel; 1/2: 16-row tiles of the vector block
     int chunk, nchunks, wave_bytes, kshift, loci_per_wg, mv;
     size_t lds_bytes;
 };
@@ -866,6 +1111,22 @@ static AssocPlan assoc_plan(const trk_batch& b, int M) {
     while (kshift >= 0 && (Amax + 3) * (8 + (4 << kshift)) > 3072) --kshift;
     if (kshift < 0) return p;
     p.kshift = kshift;
+    // many covariates: the MFMA kernel (16 loci per workgroup step); TRK_AS_MFMA_MIN moves the threshold
+    {
+        int mfma_min = 5;
+        if (const char* e = getenv("TRK_AS_MFMA_MIN")) mfma_min = atoi(e);
+        if (M >= mfma_min && M + 1 <= 32) {
+            p.mfma_rt = M + 1 <= 16 ? 1 : 2;
+            p.wave_bytes = (((MF_SB + 8) * 2 + 15) & ~15) + (((Amax + 3) * (8 + (4 << kshift)) + 15) & ~15);
+            p.lds_bytes = (size_t)(16 * p.mfma_rt + 16) * MF_SBR * 8 + (size_t)AS_WAVES * p.wave_bytes;
+            p.nchunks = 1;
+            p.chunk = 0;
+            p.loci_per_wg = 0;
+            p.fast = true;
+            return p;
+        }
+    }
+    if (M > 16) return p;  // the LDS-resident kernels are instantiated up to 16 vectors
     p.wave_bytes = AS_QCAP * 2 + (((Amax + 3) * (8 + (4 << kshift)) + 15) & ~15);
     const size_t lds_total = 160 * 1024;
     const size_t rem = lds_total - (size_t)AS_WAVES * p.wave_bytes - 64 - 8 * (size_t)p.mv;
@@ -1006,6 +1267,24 @@ hipError_t launch_assoc_scan(const trk_batch& b, const trk_assoc_params& prm, co
     assoc_build(b, prm, out, workspace, p, a, f, full);
     a.n_cu = n_cu > 0 ? n_cu : 256;
     if (b.n_loci == 0) return hipSuccess;
+    if (p.fast && p.mfma_rt) {
+        int gx = a.n_cu;
+        const int tiles = (b.n_loci + 15) / 16;
+        if (gx > tiles) gx = tiles;
+        hipError_t e;
+#define TRK_MFMA_LAUNCH(RT_, MASK_)                                                                              \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assoc_scan_mfma<RT_, MASK_>),                       \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);                       \
+    if (e != hipSuccess) return e;                                                                               \
+    hipLaunchKernelGGL((k_assoc_scan_mfma<RT_, MASK_>), dim3(gx), dim3(AS_THREADS), p.lds_bytes, stream, a);
+        if (p.mfma_rt == 1) {
+            if (a.sample_in) { TRK_MFMA_LAUNCH(1, true) } else { TRK_MFMA_LAUNCH(1, false) }
+        } else {
+            if (a.sample_in) { TRK_MFMA_LAUNCH(2, true) } else { TRK_MFMA_LAUNCH(2, false) }
+        }
+#undef TRK_MFMA_LAUNCH
+        return hipGetLastError();
+    }
     if (p.fast) {
         switch (p.mv) {
             case 1: return launch_scan_t<1>(a, p, stream);
@@ -1029,11 +1308,13 @@ hipError_t launch_assoc_finalize(const trk_batch& b, const trk_assoc_params& prm
     assoc_build(b, prm, out, workspace, p, a, f, full);
     if (b.n_loci == 0) return hipSuccess;
     const int P = prm.n_vec + 1;
-    const size_t fin_lds = (size_t)(P * (P + 1) / 2 + P) * FIN_T * 8;
+    int fin_t = FIN_T;
+    while (fin_t > 8 && (size_t)(P * (P + 1) / 2 + P) * fin_t * 8 > 150 * 1024) fin_t >>= 1;
+    const size_t fin_lds = (size_t)(P * (P + 1) / 2 + P) * fin_t * 8;
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assoc_finalize),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(k_assoc_finalize, dim3((b.n_loci + FIN_T - 1) / FIN_T), dim3(FIN_T), fin_lds, stream, f);
+    hipLaunchKernelGGL(k_assoc_finalize, dim3((b.n_loci + fin_t - 1) / fin_t), dim3(fin_t), fin_lds, stream, f);
     return hipGetLastError();
 }
 
