@@ -565,6 +565,11 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan_mfma(const AssocArgs 
 #pragma unroll
         for (int p = 0; p < NP; ++p) Gc[p] = (d4){0.0, 0.0, 0.0, 0.0};
         double sgg = 0.0;
+        double a_def[4] = {0.0, 0.0, 0.0, 0.0}, b_def[RT][4];
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b_def[t][j] = 0.0;
 
         const u32x4 dead = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
         u32x4 vnext = dead;
@@ -590,6 +595,10 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan_mfma(const AssocArgs 
             double g4[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                // the PREVIOUS step's tile product, from registers: the matrix pipe works while this
+                // wave (and its three SIMD mates) decode the next calls
+#pragma unroll
+                for (int t = 0; t < RT; ++t) C[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_def[j], b_def[t][j], C[t], 0, 0, 0);
                 const uint32_t w = v[j];
                 u16x2 u = __builtin_bit_cast(u16x2, w) + (u16x2){2, 2};
                 u16x2 t2 = __builtin_elementwise_min(u, __builtin_bit_cast(u16x2, amax2));
@@ -636,16 +645,14 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan_mfma(const AssocArgs 
             }
             if (lane < 4) xs[cnt + lane] = (uint16_t)MF_SB;  // pad the last batch with the zero column
             __syncthreads();
-            // ---- MFMA: columns [16 wid, 16 wid + 16) of the step ---------------------------------
+            // ---- operands of this wave's share of the tile product, columns [16 wid, 16 wid + 16):
+            //      into registers now, multiplied during the next step's decode ---------------------
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int col = 16 * wid + 4 * ks + (lane >> 4);
-                const double av = Gt[(lane & 15) * MF_SBR + col];
+                a_def[ks] = Gt[(lane & 15) * MF_SBR + col];
 #pragma unroll
-                for (int t = 0; t < RT; ++t) {
-                    const double bv = Vb[(16 * t + (lane & 15)) * MF_SBR + col];
-                    C[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, C[t], 0, 0, 0);
-                }
+                for (int t = 0; t < RT; ++t) b_def[t][ks] = Vb[(16 * t + (lane & 15)) * MF_SBR + col];
             }
             // ---- Gram matrix of this locus's missing samples, four at a time ---------------------
             for (int b0 = 0; b0 < cnt; b0 += 4) {
@@ -666,6 +673,10 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan_mfma(const AssocArgs 
         }
 
         // ---- end of the row --------------------------------------------------------------------
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)  // the last step's tile product
+#pragma unroll
+            for (int t = 0; t < RT; ++t) C[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_def[ks], b_def[t][ks], C[t], 0, 0, 0);
         double* rec = a.partial + (size_t)(has ? l : 0) * a.NS;
         double* red = Gt;  // [16 waves][256]
 #pragma unroll
