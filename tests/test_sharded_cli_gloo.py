@@ -42,6 +42,14 @@ def _worker(rank, world, port, outdir):
     caller, kw = gg.CASES['hipstr_all']
     rc2 = dumpSTR.main(gg.make_args(os.path.join(outdir, 'dump'), os.path.join(GOLD, 'dumpstr_synth', 'synth_hipstr.vcf'),
                                     caller, **kw))
+    # associaTR: many small batches as well
+    import contextlib
+    import io
+    import assoc_cases
+    from trtools_amd.associaTR import associaTR as at
+    at.BATCH_CELLS = 30 * 50
+    with contextlib.redirect_stdout(io.StringIO()):
+        at.main(assoc_cases.make_args(os.path.join(outdir, 'assoc.tsv'), **assoc_cases.CASES['two_trait_files'][0]))
     with open(os.path.join(outdir, 'rc%d' % rank), 'w') as fh:
         fh.write('%d %d' % (rc1, rc2))
     dist.barrier()
@@ -61,5 +69,9 @@ def test_two_rank_cli_outputs_equal_single_process(tmp_path):
         assert open(os.path.join(out, 'dump' + ext)).read() == \
             open(os.path.join(GOLD, 'dumpstr_synth', 'hipstr_all' + ext)).read(), ext
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from assoc_compare import compare_tables
+    assert compare_tables(os.path.join(out, 'assoc.tsv'), os.path.join(GOLD, 'associatr', 'two_trait_files.tsv'),
+                          rtol=1e-9, p_rtol=0.0) > 900
+    assert not [f for f in os.listdir(out) if f.endswith('.temp')]
     from vcf_compare import compare_vcfs
     assert compare_vcfs(os.path.join(out, 'dump.vcf'), os.path.join(GOLD, 'dumpstr_synth', 'hipstr_all.vcf')) == []

@@ -173,30 +173,46 @@ def _flush(records, outfile, vec, sample_filter, pheno_std, non_major_cutoff):
             outfile.write('{}\tnan\tnan\tnan\tnan\t'.format(reason))
             outfile.write('\t'.join(details))
             outfile.write('\n')
-    outfile.flush()
+    if hasattr(outfile, 'flush'):
+        outfile.flush()
 
 
 def perform_gwas_helper(outfile, all_samples, record_iter, phenotype_name, trait_fnames, same_samples, sample_fname,
                         non_major_cutoff):
     """Header, covariates, batched scan (associaTR.py:117-372 without the plotting statistics)."""
-    outfile.write("chrom\tpos\talleles\tn_samples_tested\tlocus_filtered\tp_{}\tcoeff_{}\t".format(
-        phenotype_name, phenotype_name))
-    outfile.write('se_{}\tregression_R^2\t'.format(phenotype_name))
-    outfile.flush()
+    from .. import dist
+    rank = dist.get_comm()[0]
+    if rank == 0:
+        outfile.write("chrom\tpos\talleles\tn_samples_tested\tlocus_filtered\tp_{}\tcoeff_{}\t".format(
+            phenotype_name, phenotype_name))
+        outfile.write('se_{}\tregression_R^2\t'.format(phenotype_name))
+        outfile.flush()
     sample_filter, covars, outcome, pheno_std = _load_design(all_samples, trait_fnames, same_samples, sample_fname)
     vec = _device_vectors(sample_filter, covars, outcome)
-    outfile.write('\t'.join(load_and_filter_genotypes.DETAIL_FIELDS) + '\n')
+    if rank == 0:
+        outfile.write('\t'.join(load_and_filter_genotypes.DETAIL_FIELDS) + '\n')
 
+    # one process per GPU (WORLD_SIZE > 1): batch b of the input belongs to rank b mod WORLD_SIZE,
+    # rank 0 writes the merged table (statSTR._ShardedOut); one process: a pass-through
+    from ..statSTR.statSTR import _ShardedOut
+    shard = _ShardedOut(outfile)
     batch_loci = max(1, min(4096, BATCH_CELLS // max(1, len(all_samples))))
     n_loci, start_time = 0, time.time()
     records = []
+
+    def emit(recs):
+        if recs and shard.next_batch():
+            _flush(recs, shard, vec, sample_filter, pheno_std, non_major_cutoff)
+            shard.end_batch()
+
     for trrecord in record_iter:
         records.append(trrecord)
         n_loci += 1
         if len(records) >= batch_loci:
-            _flush(records, outfile, vec, sample_filter, pheno_std, non_major_cutoff)
+            emit(records)
             records = []
-    _flush(records, outfile, vec, sample_filter, pheno_std, non_major_cutoff)
+    emit(records)
+    shard.finish()
     total_time = time.time() - start_time
     if n_loci > 0:
         print("Done.\nTotal loci: {}\nTotal time: {}s\ntime/locus: {}s\n".format(
@@ -220,10 +236,17 @@ def perform_gwas(outfname, tr_vcf, phenotype_name, traits_fnames, vcftype, same_
     all_samples = reader.samples
     record_iter = load_and_filter_genotypes.iter_records(
         tr_vcf, region, vcftype, False, imputed_ukb_strs_paper_period_check)
+    from .. import dist
+    rank = dist.get_comm()[0]
+    temp = outfname + '.temp' if rank == 0 else outfname + '.rank%d.temp' % rank
     print("Writing output to {}.temp".format(outfname), flush=True)
-    with open(outfname + '.temp', 'w') as outfile:
+    with open(temp, 'w') as outfile:
         perform_gwas_helper(outfile, all_samples, record_iter, phenotype_name, traits_fnames, same_samples,
                             sample_fname, non_major_cutoff)
+    if rank != 0:
+        import os
+        os.remove(temp)               # only rank 0's file holds the merged table
+        return
     print("Moving {}.temp to {}".format(outfname, outfname), flush=True)
     shutil.move(outfname + '.temp', outfname)
     print("Done.", flush=True)
