@@ -362,6 +362,36 @@ typedef struct {
 } trk_assoc_out;
 int trk_assoc_scan(trk_ctx* ctx, const trk_batch* in, const trk_assoc_params* prm, trk_assoc_out* out);
 
+/* associaTR --beagle-dosages (load_and_filter_genotypes.py:179-215, associaTR.py:266-273): the
+ * regressor is the expected summed length from the Beagle AP1/AP2 allele probabilities,
+ *     g_s = sum over rounded-length classes u (ascending) of len_u * (d_u,1 + d_u,2),
+ *     d_u,p = sum over the alleles of class u (index order, reference allele first) of AP_p,
+ *     AP_p(ref) = max(0, 1 - sum_i AP_p[i])   (float32, numpy's summation order),
+ * over curr_samples = sample_in & called (by GT).  Same regression outputs as trk_assoc_scan
+ * (locus filters that depend on the allele frequencies are left to the caller: status is one of
+ * OK / N_COVARS / ZERO_VARIANCE / COLLINEAR); in addition per class the sums behind
+ * allele_frequency and the per-allele dosage r^2, and per locus those behind the length r^2.   */
+typedef struct {
+    const float* ap1;            /* device [L, S, n_alt_cols] float32 (cyvcf2 format('AP1'))           */
+    const float* ap2;
+    int32_t n_alt_cols;          /* >= max_l (A_l - 1); columns beyond A_l - 1 are not read             */
+    int32_t reserved;
+    const int32_t* perm;         /* device [sumA] allele indices of each locus ordered by (class, index) */
+    const uint16_t* dclass;      /* device [sumA] by allele INDEX: rank of round(length, precision) among
+                                    the locus's distinct rounded lengths (np.unique(len_alleles))        */
+    const double* dclass_value;  /* device [sumA] rounded length of class u at allele_off[l] + u         */
+    const uint16_t* best_class;  /* device [sumA] by allele INDEX: the class whose value equals
+                                    np.around(length, precision) (best-guess calls, :199-202), 0xffff none */
+} trk_assoc_dosage;
+/* class_sums [sumA, TRK_ADC_COLS] (row allele_off[l] + u): sum d, sum d^2, sum x, sum x*d over the
+ * 2n haplotype entries (x = best-guess call equals the class); locus_sums [L, TRK_ADL_COLS]: sum x,
+ * sum x^2, sum y, sum y^2, sum x*y, 2n, min x, max x with x = best-guess length, y = expected length per
+ * haplotype (min == max: numpy's corrcoef of a constant vector is decided by rounding -- the caller handles it) */
+#define TRK_ADC_COLS 4
+#define TRK_ADL_COLS 8
+int trk_assoc_scan_dosage(trk_ctx* ctx, const trk_batch* in, const trk_assoc_params* prm,
+                          const trk_assoc_dosage* dos, trk_assoc_out* out, double* class_sums, double* locus_sums);
+
 /* Two-sided Student-t tail 2*sf(|t|, df) == scipy.stats.t.sf(|t|, df)*2 (the third-party call
  * behind statsmodels' pvalues); host double, same code as the device finaliser.              */
 double trk_student_t_two_sided(double t, double df);

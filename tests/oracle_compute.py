@@ -213,3 +213,59 @@ class OracleCompute:
             lf[l, L.AF_RSQUARED], lf[l, L.AF_GT_STD], lf[l, L.AF_TVALUE] = r['rsquared'], r['std'], r['tvalue']
             lf[l, L.AF_DF_RESID], lf[l, L.AF_GT_MEAN] = r['df_resid'], np.mean(summed)
         return AssocHost(li, lf, cnt)
+
+    def assoc_dosage_batch(self, hb, vec, sample_in, ap1, ap2, precision=2):
+        """trk_assoc_scan_dosage through oracle/associatr_oracle.py."""
+        from oracle import associatr_oracle as ao
+        from trtools_amd.compute import AssocHost
+        from trtools_amd.synth import pack_dosage_tables
+        S, M = hb.n_samples, vec.shape[0]
+        sf = np.ones(S, dtype=bool) if sample_in is None else np.asarray(sample_in, dtype=bool)
+        covars = np.ones((int(sf.sum()), M + 1))
+        outcome = vec[0, sf]
+        for k in range(1, M):
+            covars[:, 1 + k] = vec[k, sf]
+        tabs = pack_dosage_tables(hb.allele_lens, precision)
+        li = np.zeros((hb.n_loci, L.AI_COLS), dtype=np.int32)
+        lf = np.full((hb.n_loci, L.AF_COLS), np.nan)
+        cs = np.zeros((int(hb.allele_off[-1]), L.ADC_COLS))
+        ls = np.zeros((hb.n_loci, L.ADL_COLS))
+        for l in range(hb.n_loci):
+            g = hb.gt[l][:, :int(hb.locus_ploidy[l])]
+            A = len(hb.allele_lens[l])
+            gi = ao.locus_genotypes(g, hb.allele_lens[l], sf, 0.0, precision, ap1[l][:, :A - 1], ap2[l][:, :A - 1])
+            n = int(np.sum(gi['called_samples_filter']))
+            li[l, L.AI_N_TESTED] = n
+            curr = sf & ~np.any(g == -1, axis=1)
+            # the sums the device reports, recomputed from the oracle's per-length dosage matrices
+            lens = [round(float(x), precision) for x in hb.allele_lens[l]]
+            uniq = np.unique(lens)
+            gts = {u: np.zeros((n, 2)) for u in uniq}
+            for p_, ap in ((0, ap1[l]), (1, ap2[l])):
+                gts[lens[0]][:, p_] += np.maximum(0, 1 - np.sum(ap[curr, :A - 1], axis=1))
+                for i in range(A - 1):
+                    gts[lens[i + 1]][:, p_] += ap[curr, i]
+            lut = np.array([*[float(x) for x in hb.allele_lens[l]], -2, -1])
+            best = lut[g.astype(int)][curr, :]
+            rbest = np.around(best, precision)
+            o = int(hb.allele_off[l])
+            for k, u in enumerate(uniq):
+                d = gts[u].reshape(-1)
+                x = (rbest == u).reshape(-1).astype(float)
+                cs[o + k] = [d.sum(), (d * d).sum(), x.sum(), (x * d).sum()]
+            y = np.add.reduce([u * gts[u] for u in uniq]).reshape(-1) if n else np.zeros(0)
+            x = best.reshape(-1)
+            ls[l] = [x.sum(), (x * x).sum(), y.sum(), (y * y).sum(), (x * y).sum(), 2 * n,
+                     x.min() if n else np.inf, x.max() if n else -np.inf]
+            if M + 1 >= n:
+                li[l, L.AI_STATUS] = L.AS_N_COVARS
+                continue
+            summed = np.sum([u * np.sum(gts[u], axis=1) for u in uniq], axis=0)
+            if np.std(summed) <= 1e-12 * max(1.0, abs(np.mean(summed))):
+                li[l, L.AI_STATUS] = L.AS_ZERO_VARIANCE
+                continue
+            r = ao.locus_regression(gts, gi['called_samples_filter'], covars, outcome, 1.0, dosages=True)
+            lf[l, L.AF_PVAL], lf[l, L.AF_COEF], lf[l, L.AF_SE] = r['pval'], r['coef_std'], r['se_std']
+            lf[l, L.AF_RSQUARED], lf[l, L.AF_GT_STD], lf[l, L.AF_TVALUE] = r['rsquared'], r['std'], r['tvalue']
+            lf[l, L.AF_DF_RESID] = r['df_resid']
+        return AssocHost(li, lf, np.zeros(int(hb.allele_off[-1]), dtype=np.int32)), cs, ls, tabs

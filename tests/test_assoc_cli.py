@@ -19,7 +19,7 @@ import assoc_cases                                            # noqa: E402
 from assoc_compare import compare_tables, compare_to_plink    # noqa: E402
 
 GOLD = os.path.join(ROOT, 'tests', 'golden', 'associatr')
-GT_CASES = sorted(n for n, (kw, _, _) in assoc_cases.CASES.items() if not kw.get('beagle_dosages'))
+GT_CASES = sorted(assoc_cases.CASES)     # GT-based and --beagle-dosages runs alike
 
 
 def run_cli(out, kw, len_precision, p_precision):
@@ -71,9 +71,6 @@ def test_cli_on_device(name, tmp_path):
 
 def test_refused_options(tmp_path, oracle_compute):
     from trtools_amd.associaTR import associaTR as at
-    kw = dict(assoc_cases.CASES['dosages'][0])
-    with pytest.raises(NotImplementedError):
-        at.main(assoc_cases.make_args(str(tmp_path / 'x.tsv'), **kw))
     with pytest.raises(NotImplementedError):
         at.main(assoc_cases.make_args(str(tmp_path / 'x.tsv'), same_samples=True, plotting_phenotype='p.npy'))
 

@@ -85,6 +85,14 @@ class AssocParams(C.Structure):
                 ('allele_len', C.c_void_p), ('rlen_class', C.c_void_p), ('non_major_cutoff', C.c_double)]
 
 
+class AssocDosage(C.Structure):
+    _fields_ = [('ap1', C.c_void_p), ('ap2', C.c_void_p), ('n_alt_cols', C.c_int32), ('reserved', C.c_int32),
+                ('perm', C.c_void_p), ('dclass', C.c_void_p), ('dclass_value', C.c_void_p), ('best_class', C.c_void_p)]
+
+
+ADC_COLS, ADL_COLS = 4, 8
+
+
 class AssocOut(C.Structure):
     _fields_ = [('locus_int', C.c_void_p), ('locus_f64', C.c_void_p), ('allele_count', C.c_void_p)]
 
@@ -112,7 +120,7 @@ EXPORTS = [
     'trk_locus_stats', 'trk_locus_finalize', 'trk_call_filters', 'trk_locus_filters',
     'trk_comm_unique_id', 'trk_comm_init', 'trk_allreduce_sum_i64', 'trk_allgather',
     'trk_binomtest_two_sided', 'trk_binom_pmf', 'trk_synth_fill', 'trk_synth_fill_gangstr',
-    'trk_assoc_scan', 'trk_student_t_two_sided',
+    'trk_assoc_scan', 'trk_assoc_scan_dosage', 'trk_student_t_two_sided',
 ]
 
 _lib = None
@@ -169,6 +177,7 @@ def load():
     lib.trk_binom_pmf.argtypes = [i64, i64, dbl]
     lib.trk_binom_pmf.restype = dbl
     lib.trk_assoc_scan.argtypes = [vp, P(Batch), P(AssocParams), P(AssocOut)]
+    lib.trk_assoc_scan_dosage.argtypes = [vp, P(Batch), P(AssocParams), P(AssocDosage), P(AssocOut), vp, vp]
     lib.trk_student_t_two_sided.argtypes = [dbl, dbl]
     lib.trk_student_t_two_sided.restype = dbl
     lib.trk_synth_fill.argtypes = [vp, P(SynthSpec), vp, vp, vp, vp, vp]

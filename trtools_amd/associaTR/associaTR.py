@@ -7,8 +7,8 @@ the GPU (``trk_assoc_scan``: genotype x trait cross-products in one pass over th
 tensor, a Cholesky solve and a Student-t tail per locus).
 
 Host Python assembles the covariates (associaTR.py:138-204), parses / harmonises records and
-formats text.  Not provided (and refused loudly, there is no CPU path in this package):
-``--beagle-dosages`` (regression on AP1/AP2 dosages) and the reference's hidden, unfinished
+formats text; ``--beagle-dosages`` regresses on the expected length from the AP1/AP2 fields
+(``trk_assoc_scan_dosage``).  Not provided (refused loudly): the reference's hidden, unfinished
 ``--plotting-phenotype`` family of options.
 """
 import argparse
@@ -134,24 +134,74 @@ def _device_vectors(sample_filter, covars, outcome):
     return vec
 
 
-def _flush(records, outfile, vec, sample_filter, pheno_std, non_major_cutoff):
+def _r2(n2, sx, sxx, sy, syy, sxy):
+    """np.corrcoef(x, y)[0, 1] ** 2 from the sums over n2 entries (nan when either side is constant)."""
+    with np.errstate(all='ignore'):
+        num = np.float64(n2) * sxy - np.float64(sx) * sy
+        den = (np.float64(n2) * sxx - np.float64(sx) * sx) * (np.float64(n2) * syy - np.float64(sy) * sy)
+        return np.float64(num * num) / den if den > 0 else np.float64(np.nan)
+
+
+def _dosage_details(rec, n, cs, ls):
+    """allele_frequency and the two imputation-quality columns of load_trs's dosage branch
+    (load_and_filter_genotypes.py:179-227) from the device's per-class / per-locus sums."""
+    lf_mod = load_and_filter_genotypes
+    len_alleles = lf_mod.rounded_allele_lengths(rec)
+    uniq = np.unique(len_alleles)
+    with np.errstate(all='ignore'):
+        allele_frequency = {u: np.float64(cs[k, 0]) / (2 * n) for k, u in enumerate(uniq)}
+    rank = {float(u): k for k, u in enumerate(uniq)}
+    r2 = {}
+    for length in len_alleles:
+        if length in r2:
+            continue
+        k = rank[float(length)]
+        r2[length] = _r2(2 * n, cs[k, 2], cs[k, 2], cs[k, 0], cs[k, 1], cs[k, 3])
+    if n > 0 and ls[6] == ls[7]:
+        # every best-guess length is the same number x: np.corrcoef centres it with numpy's pairwise mean, which
+        # differs from x by a rounding error unless x sums exactly -- the result is 0 (to ~1e-30) or nan
+        x = np.float64(ls[6])
+        length_r2 = np.float64(np.nan) if np.mean(np.full(2 * n, x)) == x else np.float64(0.0)
+    else:
+        length_r2 = _r2(ls[5], ls[0], ls[1], ls[2], ls[3], ls[4])
+    extra = (lf_mod.dict_str(lf_mod.round_vals(r2, lf_mod.r2_precision)), str(round(length_r2, lf_mod.r2_precision)))
+    return allele_frequency, extra
+
+
+def _flush(records, outfile, vec, sample_filter, pheno_std, non_major_cutoff, beagle_dosages=False):
     """One device batch -> output rows (associaTR.py:246-293)."""
     if not records:
         return
     lf_mod = load_and_filter_genotypes
     hb = pack_records(records)
-    res = runtime.get_compute().assoc_batch(hb, vec, sample_filter, non_major_cutoff,
-                                            precision=lf_mod.allele_len_precision)
+    if beagle_dosages:
+        from ..batch import stack_plane
+        ap1 = stack_plane([np.asarray(r.format['AP1'], dtype=np.float32) for r in records], np.float32)
+        ap2 = stack_plane([np.asarray(r.format['AP2'], dtype=np.float32) for r in records], np.float32)
+        res, class_sums, locus_sums, _ = runtime.get_compute().assoc_dosage_batch(
+            hb, vec, sample_filter, ap1, ap2, precision=lf_mod.allele_len_precision)
+    else:
+        res = runtime.get_compute().assoc_batch(hb, vec, sample_filter, non_major_cutoff,
+                                                precision=lf_mod.allele_len_precision)
     fmt = "{:." + str(pval_precision) + "e}\t{}\t{}\t{}\t"
     for l, rec in enumerate(records):
         li, lf = res.locus_int[l], res.locus_f64[l]
         o, e = int(hb.allele_off[l]), int(hb.allele_off[l + 1])
-        allele_frequency = lf_mod.allele_frequency_from_counts(res.allele_count[o:e], hb.allele_lens[l])
-        details = lf_mod.locus_details(rec, allele_frequency)
+        status = int(li[L.AI_STATUS])
+        if beagle_dosages:
+            n = int(li[L.AI_N_TESTED])
+            allele_frequency, extra = _dosage_details(rec, n, class_sums[o:e], locus_sums[l])
+            details = lf_mod.locus_details(rec, allele_frequency, extra)
+            reason = lf_mod.filter_reason(allele_frequency, n, non_major_cutoff, True)
+            if reason:                       # load_trs's filters come before the regression's own
+                status = -1
+        else:
+            allele_frequency = lf_mod.allele_frequency_from_counts(res.allele_count[o:e], hb.allele_lens[l])
+            details = lf_mod.locus_details(rec, allele_frequency)
+            reason = None
         unique_alleles = np.unique(lf_mod.rounded_allele_lengths(rec))
         outfile.write("{}\t{}\t{}\t{}\t".format(rec.chrom, rec.pos, ','.join(list(unique_alleles.astype(str))),
                                                 int(li[L.AI_N_TESTED])))
-        status = int(li[L.AI_STATUS])
         if status == L.AS_OK:
             std = lf[L.AF_GT_STD]
             outfile.write('False\t')
@@ -160,7 +210,9 @@ def _flush(records, outfile, vec, sample_filter, pheno_std, non_major_cutoff):
             outfile.write('\t'.join(details))
             outfile.write('\n')
         else:
-            if status == L.AS_NON_MAJOR:
+            if status == -1:
+                pass
+            elif status == L.AS_NON_MAJOR:
                 reason = 'non-major allele count<{}'.format(non_major_cutoff)
             elif status in _REASONS:
                 reason = _REASONS[status]
@@ -178,7 +230,7 @@ def _flush(records, outfile, vec, sample_filter, pheno_std, non_major_cutoff):
 
 
 def perform_gwas_helper(outfile, all_samples, record_iter, phenotype_name, trait_fnames, same_samples, sample_fname,
-                        non_major_cutoff):
+                        non_major_cutoff, beagle_dosages=False):
     """Header, covariates, batched scan (associaTR.py:117-372 without the plotting statistics)."""
     from .. import dist
     rank = dist.get_comm()[0]
@@ -190,7 +242,10 @@ def perform_gwas_helper(outfile, all_samples, record_iter, phenotype_name, trait
     sample_filter, covars, outcome, pheno_std = _load_design(all_samples, trait_fnames, same_samples, sample_fname)
     vec = _device_vectors(sample_filter, covars, outcome)
     if rank == 0:
-        outfile.write('\t'.join(load_and_filter_genotypes.DETAIL_FIELDS) + '\n')
+        fields = list(load_and_filter_genotypes.DETAIL_FIELDS)
+        if beagle_dosages:
+            fields.extend(load_and_filter_genotypes.DOSAGE_DETAIL_FIELDS)
+        outfile.write('\t'.join(fields) + '\n')
 
     # one process per GPU (WORLD_SIZE > 1): batch b of the input belongs to rank b mod WORLD_SIZE,
     # rank 0 writes the merged table (statSTR._ShardedOut); one process: a pass-through
@@ -202,7 +257,7 @@ def perform_gwas_helper(outfile, all_samples, record_iter, phenotype_name, trait
 
     def emit(recs):
         if recs and shard.next_batch():
-            _flush(recs, shard, vec, sample_filter, pheno_std, non_major_cutoff)
+            _flush(recs, shard, vec, sample_filter, pheno_std, non_major_cutoff, beagle_dosages)
             shard.end_batch()
 
     for trrecord in record_iter:
@@ -225,9 +280,6 @@ def perform_gwas(outfname, tr_vcf, phenotype_name, traits_fnames, vcftype, same_
                  non_major_cutoff, beagle_dosages, plotting_phenotype_fname, paired_genotype_plot,
                  plot_phenotype_residuals, plotting_ci_alphas, imputed_ukb_strs_paper_period_check):
     """Signature of the reference (associaTR.py:432-482)."""
-    if beagle_dosages:
-        raise NotImplementedError("--beagle-dosages: the dosage regression is not part of this build "
-                                  "(only the GT-based scan runs on the device; there is no CPU path)")
     if plotting_phenotype_fname or paired_genotype_plot or plot_phenotype_residuals or plotting_ci_alphas:
         raise NotImplementedError("the hidden --plotting-phenotype options of the reference are not provided")
     reader = utils.LoadSingleReader(tr_vcf, checkgz=False)
@@ -235,14 +287,14 @@ def perform_gwas(outfname, tr_vcf, phenotype_name, traits_fnames, vcftype, same_
         raise ValueError("could not open %s" % tr_vcf)
     all_samples = reader.samples
     record_iter = load_and_filter_genotypes.iter_records(
-        tr_vcf, region, vcftype, False, imputed_ukb_strs_paper_period_check)
+        tr_vcf, region, vcftype, beagle_dosages, imputed_ukb_strs_paper_period_check)
     from .. import dist
     rank = dist.get_comm()[0]
     temp = outfname + '.temp' if rank == 0 else outfname + '.rank%d.temp' % rank
     print("Writing output to {}.temp".format(outfname), flush=True)
     with open(temp, 'w') as outfile:
         perform_gwas_helper(outfile, all_samples, record_iter, phenotype_name, traits_fnames, same_samples,
-                            sample_fname, non_major_cutoff)
+                            sample_fname, non_major_cutoff, beagle_dosages)
     if rank != 0:
         import os
         os.remove(temp)               # only rank 0's file holds the merged table
@@ -275,7 +327,8 @@ def getargs():  # pragma: no cover
                         help='Filter loci whose non-major-allele count (alleles coalesced by length) is below this '
                              'cutoff. Set to 0 to disable this filter.')
     parser.add_argument('--beagle-dosages', action='store_true', default=False,
-                        help="regress against Beagle dosages from the AP{1,2} fields (not available in this build)")
+                        help="regress against Beagle dosages from the AP{1,2} fields instead of from the GT field. "
+                             "(The GP field is not supported)")
     parser.add_argument('--plotting-phenotype', help=argparse.SUPPRESS)
     parser.add_argument('--paired-genotype-plot', action='store_true', default=False, help=argparse.SUPPRESS)
     parser.add_argument('--plot-phenotype-residuals', action='store_true', default=False, help=argparse.SUPPRESS)

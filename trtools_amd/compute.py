@@ -118,3 +118,21 @@ class DeviceCompute:
         out = AssocHost(res.locus_int.get(), res.locus_f64.get(), res.allele_count.get())
         self._free(b, alen_d, rcls_d, res.locus_int, res.locus_f64, res.allele_count)
         return out
+
+    def assoc_dosage_batch(self, hb, vec, sample_in, ap1, ap2, precision=2):
+        """associaTR --beagle-dosages scan of one batch (trk_assoc_scan_dosage): ap1/ap2 [L, S, K] float32.
+        Returns (AssocHost, class_sums [sumA, 4], locus_sums [L, 6], (perm, dclass, dclass_value, best_class))."""
+        from .synth import pack_assoc_tables, pack_dosage_tables
+        eng = self.eng
+        b = self._upload(hb)
+        alen, rcls = pack_assoc_tables(hb.allele_lens, precision)
+        tabs = pack_dosage_tables(hb.allele_lens, precision)
+        sin = None
+        if sample_in is not None and not bool(np.all(sample_in)):
+            sin = np.ascontiguousarray(sample_in, dtype=np.uint8)
+        res, cs, ls = eng.assoc_scan_dosage(b, np.ascontiguousarray(vec, dtype=np.float64), alen, rcls,
+                                            np.ascontiguousarray(ap1, dtype=np.float32),
+                                            np.ascontiguousarray(ap2, dtype=np.float32), *tabs, sample_in=sin)
+        out = (AssocHost(res.locus_int.get(), res.locus_f64.get(), res.allele_count.get()), cs.get(), ls.get(), tabs)
+        self._free(b, res.locus_int, res.locus_f64, res.allele_count, cs, ls, *[x for x in res._keep if x is not None])
+        return out

@@ -572,6 +572,39 @@ int trk_assoc_scan(trk_ctx* ctx, const trk_batch* in, const trk_assoc_params* pr
     return TRK_OK;
 }
 
+int trk_assoc_scan_dosage(trk_ctx* ctx, const trk_batch* in, const trk_assoc_params* prm, const trk_assoc_dosage* dos,
+                          trk_assoc_out* out, double* class_sums, double* locus_sums) {
+    if (!ctx) return TRK_ERR_ARG;
+    int rc = check_batch(ctx, in);
+    if (rc) return rc;
+    if (!prm || !out || !dos) return fail(ctx, TRK_ERR_ARG, "assoc params/outputs are NULL");
+    if (prm->n_vec < 1 || prm->n_vec > TRK_ASSOC_MAX_VEC)
+        return fail(ctx, TRK_ERR_ARG, "n_vec %d outside [1,%d]", prm->n_vec, TRK_ASSOC_MAX_VEC);
+    if (in->n_loci == 0) return TRK_OK;
+    if (!prm->vec || !prm->allele_len || !prm->rlen_class) return fail(ctx, TRK_ERR_ARG, "assoc inputs are NULL");
+    if (!dos->ap1 || !dos->ap2 || !dos->perm || !dos->dclass || !dos->dclass_value || !dos->best_class)
+        return fail(ctx, TRK_ERR_ARG, "dosage inputs are NULL");
+    if (!out->locus_int || !out->locus_f64 || !out->allele_count || !class_sums || !locus_sums)
+        return fail(ctx, TRK_ERR_ARG, "assoc outputs are NULL");
+    if (in->ploidy < 1) return fail(ctx, TRK_ERR_ARG, "ploidy");
+    (void)hipSetDevice(ctx->device);
+    trk_batch bb = *in;
+    bb.max_alleles = 0;
+    const size_t need = trk::assoc_workspace_bytes(bb, prm->n_vec);
+    if (need > ctx->assoc_ws_bytes) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->assoc_ws) (void)hipFree(ctx->assoc_ws);
+        ctx->assoc_ws = nullptr;
+        ctx->assoc_ws_bytes = 0;
+        hipError_t e = hipMalloc(&ctx->assoc_ws, need);
+        if (e != hipSuccess) return fail(ctx, TRK_ERR_NOMEM, "assoc workspace hipMalloc(%zu): %s", need, hipGetErrorString(e));
+        ctx->assoc_ws_bytes = need;
+    }
+    ProfScope ps(ctx, TRK_K_ASSOC_SCAN);
+    HIPCHK(ctx, trk::launch_assoc_dosage(*in, *prm, *dos, *out, class_sums, locus_sums, ctx->assoc_ws, ctx->stream));
+    return TRK_OK;
+}
+
 double trk_student_t_two_sided(double t, double df) { return trkmath::student_t_two_sided(t, df); }
 
 double trk_binomtest_two_sided(int64_t k, int64_t n, double p) {

@@ -802,6 +802,220 @@ __global__ __launch_bounds__(256) void k_assoc_scan_any(const AssocArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------
+// --beagle-dosages: the regressor is the expected summed length from the AP1/AP2 allele
+// probabilities (see trk_assoc_dosage in trk.h).  Wave per locus; two passes over the locus's
+// samples: sample-major for the regression sums, class-major for the per-class sums.
+// -------------------------------------------------------------------------------------------
+struct DosArgs {
+    trk_assoc_dosage d;
+    double* class_sums;
+    double* locus_sums;
+};
+
+// numpy's float32 pairwise sum of x[0..n) (np.sum(ap[curr, :], axis=1), contiguous rows)
+__device__ float np_sum_f32(const float* x, int n) {
+    int lo_[12], n_[12], stage[12];
+    float left[12];
+    int sp = 0;
+    lo_[0] = 0;
+    n_[0] = n;
+    stage[0] = 0;
+    float ret = 0.f;
+    while (sp >= 0) {
+        const int m = n_[sp], lo = lo_[sp];
+        if (m <= 128) {
+            if (m < 8) {
+                float res = 0.f;
+                for (int i = 0; i < m; ++i) res += x[lo + i];
+                ret = res;
+            } else {
+                float r[8];
+                for (int j = 0; j < 8; ++j) r[j] = x[lo + j];
+                int i = 8;
+                for (; i < m - (m % 8); i += 8)
+                    for (int j = 0; j < 8; ++j) r[j] += x[lo + i + j];
+                float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+                for (; i < m; ++i) res += x[lo + i];
+                ret = res;
+            }
+            --sp;
+            continue;
+        }
+        int n2 = m / 2;
+        n2 -= n2 % 8;
+        if (stage[sp] == 0) {
+            stage[sp] = 1;
+            lo_[sp + 1] = lo;
+            n_[sp + 1] = n2;
+            stage[sp + 1] = 0;
+            ++sp;
+        } else if (stage[sp] == 1) {
+            left[sp] = ret;
+            stage[sp] = 2;
+            lo_[sp + 1] = lo + n2;
+            n_[sp + 1] = m - n2;
+            stage[sp + 1] = 0;
+            ++sp;
+        } else {
+            ret = left[sp] + ret;
+            --sp;
+        }
+    }
+    return 0.f + ret;
+}
+
+__global__ __launch_bounds__(256) void k_assoc_dosage(const AssocArgs a, const DosArgs q) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int l = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (l >= a.b.n_loci) return;
+    const int S = a.b.n_samples, P = a.b.ploidy, M = a.M, Kc = q.d.n_alt_cols;
+    const int pl = a.b.locus_ploidy ? a.b.locus_ploidy[l] : P;
+    const int off = a.b.allele_off[l];
+    const int A = a.b.allele_off[l + 1] - off;
+    const int32_t* perm = q.d.perm + off;
+    const uint16_t* dcl = q.d.dclass + off;
+    const double* dval = q.d.dclass_value + off;
+    const uint16_t* bcl = q.d.best_class + off;
+    const double pivot = 2.0 * dval[dcl[0]];  // any constant: the variance is shift invariant
+    int ncls = 0;
+    for (int i = 0; i < A; ++i) ncls = max(ncls, (int)dcl[i] + 1);
+
+    // ---- pass 1: sample-major -----------------------------------------------------------------
+    int n = 0;
+    double sg = 0.0, sgg = 0.0, sgv[AS_MAXV], corr[AS_E];
+    double rx = 0.0, rxx = 0.0, ry = 0.0, ryy = 0.0, rxy = 0.0, xmin = INFINITY, xmax = -INFINITY;
+    for (int k = 0; k < AS_MAXV; ++k) sgv[k] = 0.0;
+    for (int e = 0; e < AS_E; ++e) corr[e] = 0.0;
+    for (int s0 = 0; s0 < S; s0 += WAVE) {
+        const int s = s0 + lane;
+        bool in = false, miss = false;
+        if (s < S) {
+            in = !a.sample_in || a.sample_in[s];
+            const int16_t* cell = a.b.gt + ((int64_t)l * S + s) * P;
+            for (int p = 0; p < pl; ++p) miss |= cell[p] == -1;
+            if (in && !miss) {
+                const float* ap[2] = {q.d.ap1 + ((int64_t)l * S + s) * Kc, q.d.ap2 + ((int64_t)l * S + s) * Kc};
+                float ref[2];
+                for (int p = 0; p < 2; ++p) ref[p] = fmaxf(0.f, 1.f - np_sum_f32(ap[p], A - 1));
+                double g = 0.0, y[2] = {0.0, 0.0};
+                int u = dcl[perm[0]];
+                double d[2] = {0.0, 0.0};
+                for (int i = 0; i <= A; ++i) {
+                    const int al = i < A ? perm[i] : -1;
+                    const int u2 = i < A ? (int)dcl[al] : -1;
+                    if (u2 != u) {  // class u complete
+                        g += dval[u] * (d[0] + d[1]);
+                        y[0] += dval[u] * d[0];
+                        y[1] += dval[u] * d[1];
+                        u = u2;
+                        d[0] = d[1] = 0.0;
+                    }
+                    if (i < A)
+                        for (int p = 0; p < 2; ++p) d[p] += (double)(al == 0 ? ref[p] : ap[p][al - 1]);
+                }
+                // best-guess length per haplotype (GetLengthGenotypes: -2 stays -2)
+                for (int p = 0; p < 2 && p < pl; ++p) {
+                    const int al = cell[p];
+                    const double x = al == -2 ? -2.0 : (al >= 0 && al < A ? a.allele_len[off + al] : 0.0);
+                    xmin = fmin(xmin, x);
+                    xmax = fmax(xmax, x);
+                    rx += x;
+                    rxx += x * x;
+                    ry += y[p];
+                    ryy += y[p] * y[p];
+                    rxy += x * y[p];
+                }
+                g -= pivot;
+                ++n;
+                sg += g;
+                sgg = __builtin_fma(g, g, sgg);
+                for (int k = 0; k < M; ++k) sgv[k] = __builtin_fma(g, a.vec[(size_t)k * S + s], sgv[k]);
+            }
+        }
+        uint64_t mm = __ballot(in & miss);
+        while (mm) {
+            const int src = __ffsll((long long)mm) - 1;
+            mm &= mm - 1;
+            const int sm = s0 + src;
+            for (int e = 0; e < AS_E; ++e) {
+                const int idx = lane + e * WAVE;
+                if (idx >= a.NC) continue;
+                const double xa = a.pa[idx] == M ? 1.0 : a.vec[(size_t)a.pa[idx] * S + sm];
+                const double xb = a.pb[idx] == M ? 1.0 : a.vec[(size_t)a.pb[idx] * S + sm];
+                corr[e] += xa * xb;
+            }
+        }
+    }
+    double* rec = a.partial + (size_t)l * a.NS;
+    n = wave_sum_i32(n);
+    sg = wave_sum_f64(sg);
+    sgg = wave_sum_f64(sgg);
+    rx = wave_sum_f64(rx);
+    rxx = wave_sum_f64(rxx);
+    ry = wave_sum_f64(ry);
+    ryy = wave_sum_f64(ryy);
+    rxy = wave_sum_f64(rxy);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        xmin = fmin(xmin, __shfl_xor(xmin, o, WAVE));
+        xmax = fmax(xmax, __shfl_xor(xmax, o, WAVE));
+    }
+    if (lane == 0) {
+        rec[0] = (double)n;
+        rec[1] = sg;
+        rec[2] = sgg;
+        rec[a.NS - 1] = 0.0;
+        double* ls = q.locus_sums + (size_t)l * TRK_ADL_COLS;
+        ls[0] = rx; ls[1] = rxx; ls[2] = ry; ls[3] = ryy; ls[4] = rxy; ls[5] = 2.0 * n; ls[6] = xmin; ls[7] = xmax;
+    }
+    for (int k = 0; k < M; ++k) {
+        const double t = wave_sum_f64(sgv[k]);
+        if (lane == 0) rec[3 + k] = t;
+    }
+    for (int e = 0; e < AS_E; ++e) {
+        const int idx = lane + e * WAVE;
+        if (idx < a.NC) rec[3 + M + idx] = corr[e];
+    }
+    // ---- pass 2: class-major --------------------------------------------------------------------
+    int first = 0;
+    for (int u = 0; u < ncls; ++u) {
+        int last = first;
+        while (last < A && dcl[perm[last]] == u) ++last;
+        double sd = 0.0, sdd = 0.0, sx = 0.0, sxd = 0.0;
+        for (int s = lane; s < S; s += WAVE) {
+            if (a.sample_in && !a.sample_in[s]) continue;
+            const int16_t* cell = a.b.gt + ((int64_t)l * S + s) * P;
+            bool miss = false;
+            for (int p = 0; p < pl; ++p) miss |= cell[p] == -1;
+            if (miss) continue;
+            const float* ap[2] = {q.d.ap1 + ((int64_t)l * S + s) * Kc, q.d.ap2 + ((int64_t)l * S + s) * Kc};
+            for (int p = 0; p < 2; ++p) {
+                double d = 0.0;
+                for (int i = first; i < last; ++i) {
+                    const int al = perm[i];
+                    d += (double)(al == 0 ? fmaxf(0.f, 1.f - np_sum_f32(ap[p], A - 1)) : ap[p][al - 1]);
+                }
+                const int al = p < pl ? cell[p] : -2;
+                const double x = (al >= 0 && al < A && bcl[al] == u) ? 1.0 : 0.0;
+                sd += d;
+                sdd += d * d;
+                sx += x;
+                sxd += x * d;
+            }
+        }
+        sd = wave_sum_f64(sd);
+        sdd = wave_sum_f64(sdd);
+        sx = wave_sum_f64(sx);
+        sxd = wave_sum_f64(sxd);
+        if (lane == 0) {
+            double* cs = q.class_sums + (size_t)(off + u) * TRK_ADC_COLS;
+            cs[0] = sd; cs[1] = sdd; cs[2] = sx; cs[3] = sxd;
+        }
+        first = last;
+    }
+}
+
+// -------------------------------------------------------------------------------------------
 // finaliser
 // -------------------------------------------------------------------------------------------
 // The frequencies of the ROUNDED length alleles in ascending order, one at a time
@@ -909,6 +1123,7 @@ struct FinArgs {
     double* locus_f64;
     double cutoff;
     int M, NS, NC, nchunks;
+    int dosage;                  // 1: no allele-frequency filters here (the caller applies them)
 };
 
 // index of Gram entry (r, c), r <= c, rows 0..M (row M = ones), row-major upper triangle
@@ -965,7 +1180,9 @@ __global__ __launch_bounds__(FIN_T) void k_assoc_finalize(const FinArgs a) {
     }
     li[TRK_AI_N_RALLELES] = R;
     int status = TRK_AS_OK;
-    if (R == 0) {
+    if (a.dosage) {
+        if (M + 1 >= n) status = TRK_AS_N_COVARS;
+    } else if (R == 0) {
         status = TRK_AS_NO_CALLED;
     } else if (R == 1) {
         status = TRK_AS_ONE_ALLELE;
@@ -1325,6 +1542,43 @@ hipError_t launch_assoc_finalize(const trk_batch& b, const trk_assoc_params& prm
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assoc_finalize),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds);
     if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(k_assoc_finalize, dim3((b.n_loci + fin_t - 1) / fin_t), dim3(fin_t), fin_lds, stream, f);
+    return hipGetLastError();
+}
+
+hipError_t launch_assoc_dosage(const trk_batch& b, const trk_assoc_params& prm, const trk_assoc_dosage& dos,
+                               const trk_assoc_out& out, double* class_sums, double* locus_sums, void* workspace,
+                               hipStream_t stream) {
+    AssocPlan p;
+    AssocArgs a;
+    FinArgs f;
+    double* full;
+    trk_batch bb = b;
+    bb.max_alleles = 0;  // plan: the generic record layout (one chunk, no LDS-resident vectors)
+    assoc_build(bb, prm, out, workspace, p, a, f, full);
+    a.b = b;
+    f.b = b;
+    hipError_t err;
+    if ((err = hipMemsetAsync(a.work_counter, 0, 1024, stream)) != hipSuccess) return err;
+    if (b.n_alleles_total > 0) {
+        if ((err = hipMemsetAsync(f.cc, 0, (size_t)b.n_alleles_total * 4, stream)) != hipSuccess) return err;
+        if ((err = hipMemsetAsync(out.allele_count, 0, (size_t)b.n_alleles_total * 4, stream)) != hipSuccess) return err;
+        if ((err = hipMemsetAsync(class_sums, 0, (size_t)b.n_alleles_total * TRK_ADC_COLS * 8, stream)) != hipSuccess)
+            return err;
+    }
+    if (b.n_loci == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_assoc_gram, dim3(a.NC), dim3(256), 0, stream, a, full);
+    DosArgs q{dos, class_sums, locus_sums};
+    hipLaunchKernelGGL(k_assoc_dosage, dim3((b.n_loci + 3) / 4), dim3(256), 0, stream, a, q);
+    if ((err = hipGetLastError()) != hipSuccess) return err;
+    f.dosage = 1;
+    const int P = prm.n_vec + 1;
+    int fin_t = FIN_T;
+    while (fin_t > 8 && (size_t)(P * (P + 1) / 2 + P) * fin_t * 8 > 150 * 1024) fin_t >>= 1;
+    const size_t fin_lds = (size_t)(P * (P + 1) / 2 + P) * fin_t * 8;
+    if ((err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assoc_finalize),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds)) != hipSuccess)
+        return err;
     hipLaunchKernelGGL(k_assoc_finalize, dim3((b.n_loci + fin_t - 1) / fin_t), dim3(fin_t), fin_lds, stream, f);
     return hipGetLastError();
 }

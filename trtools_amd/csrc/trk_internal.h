@@ -34,5 +34,8 @@ hipError_t launch_assoc_scan(const trk_batch& b, const trk_assoc_params& prm, co
                              void* workspace, int n_cu, hipStream_t stream);
 hipError_t launch_assoc_finalize(const trk_batch& b, const trk_assoc_params& prm, const trk_assoc_out& out,
                                  void* workspace, hipStream_t stream);
+hipError_t launch_assoc_dosage(const trk_batch& b, const trk_assoc_params& prm, const trk_assoc_dosage& dos,
+                               const trk_assoc_out& out, double* class_sums, double* locus_sums, void* workspace,
+                               hipStream_t stream);
 }  // namespace trk
 #endif

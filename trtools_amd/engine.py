@@ -353,6 +353,37 @@ class Engine:
         self._chk(self.lib.trk_assoc_scan(self.ctx, C.byref(batch.struct), C.byref(prm), C.byref(out.struct)))
         return out
 
+    def assoc_scan_dosage(self, batch, vec, allele_len, rlen_class, ap1, ap2, perm, dclass, dclass_value, best_class,
+                          sample_in=None):
+        """trk_assoc_scan_dosage.  ap1/ap2 [L, S, K] float32; perm int32 / dclass uint16 / dclass_value float64 /
+        best_class uint16, all [sumA].  Returns (AssocResult, class_sums [sumA, 4], locus_sums [L, 6]) on the device."""
+        def dev(x, dt):
+            return x if isinstance(x, DeviceArray) else self.upload(x, dt)
+        vec_d = dev(vec, np.float64)
+        len_d, rc_d = dev(allele_len, np.float64), dev(rlen_class, np.uint16)
+        in_d = dev(sample_in, np.uint8) if sample_in is not None else None
+        a1, a2 = dev(ap1, np.float32), dev(ap2, np.float32)
+        if a1.shape != a2.shape or len(a1.shape) != 3 or a1.shape[:2] != (batch.n_loci, batch.n_samples):
+            raise ValueError("ap1/ap2 must be [L, S, K]")
+        pm, dc, dv, bc = dev(perm, np.int32), dev(dclass, np.uint16), dev(dclass_value, np.float64), dev(best_class, np.uint16)
+        out = AssocResult(self.empty((batch.n_loci, L.AI_COLS), np.int32),
+                          self.empty((batch.n_loci, L.AF_COLS), np.float64),
+                          self.empty((batch.sum_alleles,), np.int32))
+        cs = self.empty((batch.sum_alleles, L.ADC_COLS), np.float64)
+        ls = self.empty((batch.n_loci, L.ADL_COLS), np.float64)
+        prm = L.AssocParams()
+        prm.n_vec, prm.flags = vec_d.shape[0], 0
+        prm.vec, prm.allele_len, prm.rlen_class = vec_d.ptr, len_d.ptr, rc_d.ptr
+        prm.sample_in = in_d.ptr if in_d is not None else None
+        prm.non_major_cutoff = 0.0
+        dos = L.AssocDosage()
+        dos.ap1, dos.ap2, dos.n_alt_cols = a1.ptr, a2.ptr, a1.shape[2]
+        dos.perm, dos.dclass, dos.dclass_value, dos.best_class = pm.ptr, dc.ptr, dv.ptr, bc.ptr
+        out._keep = (vec_d, len_d, rc_d, in_d, a1, a2, pm, dc, dv, bc)
+        self._chk(self.lib.trk_assoc_scan_dosage(self.ctx, C.byref(batch.struct), C.byref(prm), C.byref(dos),
+                                                 C.byref(out.struct), cs.ptr, ls.ptr))
+        return out, cs, ls
+
     def student_t_two_sided(self, t, df):
         return float(self.lib.trk_student_t_two_sided(float(t), float(df)))
 

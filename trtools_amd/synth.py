@@ -88,6 +88,35 @@ def pack_assoc_tables(allele_lens, precision=2):
     return alen, rcls
 
 
+def pack_dosage_tables(allele_lens, precision=2):
+    """Per-locus length lists -> the per-allele tables of ``trk_assoc_dosage`` (include/trk.h):
+    perm int32 (allele indices ordered by (class, index)), dclass uint16 (by allele index: rank of
+    ``round(length, precision)`` -- python floats, python round, as ``len_alleles`` in
+    load_and_filter_genotypes.py:171-172 -- among the locus's distinct rounded lengths),
+    dclass_value float64 (by class) and best_class uint16 (by allele index: the class whose value
+    equals ``np.around(length, precision)``, the best-guess call of :199-202; 0xffff when none)."""
+    total = sum(len(x) for x in allele_lens)
+    perm = np.zeros(total, dtype=np.int32)
+    dcls = np.zeros(total, dtype=np.uint16)
+    dval = np.zeros(total, dtype=np.float64)
+    best = np.full(total, 0xffff, dtype=np.uint16)
+    o = 0
+    for lens in allele_lens:
+        lens = [float(x) for x in lens]
+        rl = [round(x, precision) for x in lens]
+        uniq = sorted(set(rl))
+        rank = {v: r for r, v in enumerate(uniq)}
+        n = len(lens)
+        for a in range(n):
+            dcls[o + a] = rank[rl[a]]
+            around = float(np.around(lens[a], precision))
+            best[o + a] = rank.get(around, 0xffff)
+        dval[o:o + len(uniq)] = uniq
+        perm[o:o + n] = sorted(range(n), key=lambda a: (rank[rl[a]], a))
+        o += n
+    return perm, dcls, dval, best
+
+
 # ---------------------------------------------------------------------------
 # per-locus tables
 # ---------------------------------------------------------------------------
