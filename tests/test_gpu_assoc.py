@@ -151,6 +151,15 @@ def test_mfma_path_many_covariates(eng):
     assert run_case(eng, 25, 20, 516, M=20, cutoff=0.0, miss=0.5) > 3      # half the calls missing
 
 
+def test_wave_parallel_regression_for_narrow_designs_too(eng):
+    os.environ['TRK_AS_WAVE_REGRESS_MIN'] = '2'
+    try:
+        assert run_case(eng, 31, 60, 512, M=2, subset=True) > 25
+        assert run_case(eng, 32, 40, 640, M=9, subset=True) > 15
+    finally:
+        del os.environ['TRK_AS_WAVE_REGRESS_MIN']
+
+
 def test_lds_resident_kernels_for_more_than_two_vectors(eng):
     os.environ['TRK_AS_MFMA_MIN'] = '99'
     try:

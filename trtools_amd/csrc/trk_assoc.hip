@@ -1124,6 +1124,7 @@ struct FinArgs {
     double cutoff;
     int M, NS, NC, nchunks;
     int dosage;                  // 1: no allele-frequency filters here (the caller applies them)
+    int wave_regress;            // 1: the regression is left to k_assoc_regress_wave (wide designs)
 };
 
 // index of Gram entry (r, c), r <= c, rows 0..M (row M = ones), row-major upper triangle
@@ -1213,6 +1214,12 @@ __global__ __launch_bounds__(FIN_T) void k_assoc_finalize(const FinArgs a) {
     }
     const double sd = sqrt(var);
     lf[TRK_AF_GT_STD] = sd;
+    if (a.wave_regress) {
+        lf[TRK_AF_COLS - 1] = mean;          // pivoted mean, for k_assoc_regress_wave
+        li[TRK_AI_STATUS] = TRK_AS_OK;
+        li[TRK_AI_RANK] = -1;                // "regression pending"
+        return;
+    }
 
     // ---- Gram matrix of the called samples: full - correction --------------------------------
     // LDS column: packed lower triangle of the P x P normal matrix (row-major), then rhs [P]
@@ -1311,6 +1318,109 @@ __global__ __launch_bounds__(FIN_T) void k_assoc_finalize(const FinArgs a) {
     lf[TRK_AF_PVAL] = trkmath::student_t_two_sided(tval, df);
     li[TRK_AI_STATUS] = TRK_AS_OK;
 #undef LW
+}
+
+// -------------------------------------------------------------------------------------------
+// regression of one locus per WAVE (wide designs: a 32 x 32 Cholesky per thread costs 6.5 ms per
+// 100k loci).  Lane i owns row i of the normal matrix [ones, covariates 1..M-1, genotype] in an
+// LDS tile; lane P carries the right-hand side as one more row (L_Pj = z_j, forward
+// substitution for free).  Left-looking: column j needs row j (broadcast reads) and each lane's
+// own row.  Same arithmetic and the same dropped-column rule as the thread-per-locus finaliser.
+// -------------------------------------------------------------------------------------------
+constexpr int RW_WAVES = 4;
+__global__ __launch_bounds__(WAVE* RW_WAVES) void k_assoc_regress_wave(const FinArgs a) {
+    extern __shared__ double rw_lds[];
+    const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x >> 6;
+    const int l = blockIdx.x * RW_WAVES + wid;
+    if (l >= a.b.n_loci) return;
+    int32_t* li = a.locus_int + (size_t)l * TRK_AI_COLS;
+    double* lf = a.locus_f64 + (size_t)l * TRK_AF_COLS;
+    if (li[TRK_AI_STATUS] != TRK_AS_OK || li[TRK_AI_RANK] != -1) return;  // filtered, or already regressed
+    const int M = a.M, L = a.b.n_loci, P = M + 1;
+    const int ld = P + 1;                       // row stride (odd or even, rows are lane-private)
+    double* A = rw_lds + (size_t)wid * (P + 1) * ld;   // rows 0..P-1 matrix, row P rhs
+    const double* rec0 = a.partial + (size_t)l * a.NS;
+    auto psum = [&](int col) {
+        double v = 0.0;
+        for (int ch = 0; ch < a.nchunks; ++ch) v += a.partial[((size_t)ch * L + l) * a.NS + col];
+        return v;
+    };
+    (void)rec0;
+    auto G = [&](int r, int c) {
+        if (r > c) { const int t = r; r = c; c = t; }
+        const int e = gidx(r, c, M);
+        return a.full[e] - psum(3 + M + e);
+    };
+    auto row_of = [&](int j) { return j == 0 ? M : j; };
+    const double n_d = (double)li[TRK_AI_N_TESTED];
+    const double mean = lf[TRK_AF_COLS - 1], sd = lf[TRK_AF_GT_STD];
+    const double sg = psum(1);
+    const double sy = G(0, M), yy = G(0, 0);
+    // ---- build: lane i < M row of Z'Z, lane M the genotype row, lane P the right-hand side ------
+    if (lane < M) {
+        for (int j = 0; j <= lane; ++j) A[lane * ld + j] = G(row_of(lane), row_of(j));
+    } else if (lane == M) {
+        for (int j = 0; j < M; ++j) {
+            const double sgc = j == 0 ? sg : psum(3 + j);
+            const double sc = j == 0 ? n_d : G(j, M);
+            A[M * ld + j] = (sgc - mean * sc) / sd;
+        }
+        A[M * ld + M] = n_d;
+    } else if (lane == P) {
+        for (int j = 0; j < M; ++j) A[P * ld + j] = j == 0 ? sy : G(0, j);
+        A[P * ld + M] = (psum(3) - mean * sy) / sd;
+    }
+    wave_fence();
+    // ---- left-looking Cholesky; rows j..P (row P = rhs) are updated for column j ---------------
+    int rank = 0;
+    bool last_dependent = false;
+    double zz = 0.0;
+    for (int j = 0; j < P; ++j) {
+        double v = 0.0;
+        if (lane >= j && lane <= P) {
+            v = A[lane * ld + j];
+            for (int k = 0; k < j; ++k) v -= A[lane * ld + k] * A[j * ld + k];
+        }
+        const double ajj = A[j * ld + j];  // still the original diagonal entry
+        const double d = __shfl(v, j, WAVE);
+        wave_fence();
+        if (!(d > 1e-11 * ajj)) {  // column in the span of the previous ones: dropped (pinv semantics)
+            if (lane >= j && lane <= P) A[lane * ld + j] = 0.0;
+            if (j == P - 1) last_dependent = true;
+        } else {
+            const double ljj = sqrt(d);
+            if (lane == j) A[lane * ld + j] = ljj;
+            else if (lane > j && lane <= P) A[lane * ld + j] = v / ljj;
+            ++rank;
+        }
+        wave_fence();
+    }
+    if (lane == 0) {
+        li[TRK_AI_RANK] = rank;
+        if (last_dependent) {
+            li[TRK_AI_STATUS] = TRK_AS_COLLINEAR;
+        } else {
+            for (int j = 0; j < P; ++j) {
+                const double z = A[P * ld + j];
+                zz += z * z;
+            }
+            const double lpp = A[M * ld + M], zp = A[P * ld + M];
+            const double df = n_d - (double)rank;
+            const double ssr = yy - zz;
+            const double scale = ssr / df;
+            const double coef = zp / lpp;
+            const double se = sqrt(scale) / lpp;
+            const double tval = coef / se;
+            const double tss = yy - sy * sy / n_d;
+            lf[TRK_AF_COEF] = coef;
+            lf[TRK_AF_SE] = se;
+            lf[TRK_AF_TVALUE] = tval;
+            lf[TRK_AF_DF_RESID] = df;
+            lf[TRK_AF_RSQUARED] = 1.0 - ssr / tss;
+            lf[TRK_AF_PVAL] = trkmath::student_t_two_sided(tval, df);
+        }
+        lf[TRK_AF_COLS - 1] = NAN;
+    }
 }
 
 }  // namespace
@@ -1418,6 +1528,23 @@ static hipError_t launch_scan_t(const AssocArgs& a, const AssocPlan& p, hipStrea
     return a.sample_in ? launch_scan_tm<MV, true>(a, p, stream) : launch_scan_tm<MV, false>(a, p, stream);
 }
 
+static bool use_wave_regress(int M) {
+    int min_m = 22;  // below, 64 thread-private LDS columns fit and the thread-per-locus solve is faster
+    if (const char* e = getenv("TRK_AS_WAVE_REGRESS_MIN")) min_m = atoi(e);
+    return M >= min_m && M + 2 <= WAVE;
+}
+
+static hipError_t launch_regress_wave(const FinArgs& f, hipStream_t stream) {
+    const int P = f.M + 1;
+    const size_t lds = (size_t)RW_WAVES * (P + 1) * (P + 1) * 8;
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assoc_regress_wave),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(k_assoc_regress_wave, dim3((f.b.n_loci + RW_WAVES - 1) / RW_WAVES), dim3(WAVE * RW_WAVES), lds,
+                       stream, f);
+    return hipGetLastError();
+}
+
 static void assoc_build(const trk_batch& b, const trk_assoc_params& prm, const trk_assoc_out& out, void* workspace,
                         AssocPlan& p, AssocArgs& a, FinArgs& f, double*& full) {
     const int M = prm.n_vec;
@@ -1463,6 +1590,7 @@ static void assoc_build(const trk_batch& b, const trk_assoc_params& prm, const t
     f.NS = a.NS;
     f.NC = a.NC;
     f.nchunks = p.nchunks;
+    f.wave_regress = use_wave_regress(M) ? 1 : 0;
 }
 
 // step 1 (cheap): zero the scratch, Gram matrix of the regression set
@@ -1543,7 +1671,8 @@ hipError_t launch_assoc_finalize(const trk_batch& b, const trk_assoc_params& prm
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds);
     if (err != hipSuccess) return err;
     hipLaunchKernelGGL(k_assoc_finalize, dim3((b.n_loci + fin_t - 1) / fin_t), dim3(fin_t), fin_lds, stream, f);
-    return hipGetLastError();
+    if ((err = hipGetLastError()) != hipSuccess) return err;
+    return f.wave_regress ? launch_regress_wave(f, stream) : hipSuccess;
 }
 
 hipError_t launch_assoc_dosage(const trk_batch& b, const trk_assoc_params& prm, const trk_assoc_dosage& dos,
@@ -1580,7 +1709,8 @@ hipError_t launch_assoc_dosage(const trk_batch& b, const trk_assoc_params& prm, 
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds)) != hipSuccess)
         return err;
     hipLaunchKernelGGL(k_assoc_finalize, dim3((b.n_loci + fin_t - 1) / fin_t), dim3(fin_t), fin_lds, stream, f);
-    return hipGetLastError();
+    if ((err = hipGetLastError()) != hipSuccess) return err;
+    return f.wave_regress ? launch_regress_wave(f, stream) : hipSuccess;
 }
 
 }  // namespace trk
