@@ -218,6 +218,22 @@ def assoc_extra(wl, args, iters=5):
             checked += 1
         out["parity_loci_checked"] = int(len(idx))
         out["parity_loci_regressed"] = checked
+        if not args.no_cpu_baseline:
+            # the same scan through the oracle port (numpy + scipy, one locus and one OLS fit at a time like the
+            # reference), 1 core, on a bounded sample of loci regenerated by the generator's numpy twin
+            t0 = time.perf_counter()
+            done = 0
+            rng2 = np.random.default_rng(args.seed + 78)
+            while time.perf_counter() - t0 < 3.0:
+                pick = np.sort(rng2.choice(n_loci, size=8, replace=False))
+                rows2 = wl.sb.host_rows(pick)
+                for k, l in enumerate(pick):
+                    ao.scan_locus(rows2['gt'][k], wl.sb.loci.allele_lens[l], sf, covars, y, 1.0, 20.0, 2)
+                done += len(pick)
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": done / dt, "unit": "loci/s", "cores": 1, "kind": "port",
+                                   "sample": "%d random loci x %d samples through oracle/associatr_oracle.py "
+                                             "(incl. regenerating the rows), %.1f s" % (done, n_samples, dt)}
     for d in (alen_d, rcls_d, vec_d, res.locus_int, res.locus_f64, res.allele_count):
         d.free()
     return out

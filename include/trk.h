@@ -392,6 +392,19 @@ typedef struct {
 int trk_assoc_scan_dosage(trk_ctx* ctx, const trk_batch* in, const trk_assoc_params* prm,
                           const trk_assoc_dosage* dos, trk_assoc_out* out, double* class_sums, double* locus_sums);
 
+/* ---- per-sample dosages ----------------------------------------
+ * TRRecord.GetDosages (tr_harmonizer.py:1098-1208) for every (locus, sample) of a batch:
+ *   BESTGUESS       sum of the called alleles' lengths ('-1' / '-2' count 0)
+ *   BESTGUESS_NORM  the same with any '-1' / '-2' -> nan, then (d - 2 min) / (max - min) clipped to [0, 2]
+ *   BEAGLEAP        sum over both haplotypes of clip(AP_p . alt_lengths, 0, max alt) + clip(1 - sum AP_p, 0, 1) * ref
+ *   BEAGLEAP_NORM   normalised the same way
+ * float32 out [L, S] (the reference returns float32).  locus_err [L]: bit 0 an AP row sums to more
+ * than 1.1, bit 1 a negative AP value, bit 2 a normalised dosage >= 2.1 or <= -0.1 -- the conditions
+ * under which the reference raises ValueError (strict) or returns nan for the whole record.       */
+enum { TRK_DOS_BESTGUESS = 0, TRK_DOS_BEAGLEAP = 1, TRK_DOS_BESTGUESS_NORM = 2, TRK_DOS_BEAGLEAP_NORM = 3 };
+int trk_dosages(trk_ctx* ctx, const trk_batch* in, const double* allele_len, int dosage_type, const float* ap1,
+                const float* ap2, int n_alt_cols, float* out, int32_t* locus_err);
+
 /* Two-sided Student-t tail 2*sf(|t|, df) == scipy.stats.t.sf(|t|, df)*2 (the third-party call
  * behind statsmodels' pvalues); host double, same code as the device finaliser.              */
 double trk_student_t_two_sided(double t, double df);

@@ -597,3 +597,49 @@ def loclog_rows(loc_info):
     for k in keys:
         rows.append("FILTER:%s\t%s" % (k, loc_info[k]))
     return rows
+
+
+# ----------------------------------------------------------------------------
+# per-sample dosages (tr_harmonizer.py:1098-1208)
+# ----------------------------------------------------------------------------
+
+def get_dosages(gt, allele_lens, dosagetype='bestguess', ap1=None, ap2=None):
+    """TRRecord.GetDosages(dosagetype, strict=False) on arrays: gt [S, P] allele indices, allele_lens
+    [ref, alts...], ap1/ap2 float32 [S, A-1].  Returns float32 [S] (a row of nan where the reference
+    warns and gives up)."""
+    gt = np.asarray(gt).astype(int)
+    n = gt.shape[0]
+    lens = [float(x) for x in allele_lens]
+    ref_len, alt_lens = lens[0], lens[1:]
+    norm = dosagetype.endswith('_norm')
+    if dosagetype.startswith('bestguess'):
+        lut = np.array([*lens, -2, -1])                       # tr_harmonizer.py:1239
+        lengts = lut[gt]
+        fill = np.nan if norm else 0
+        lengts[gt == -1] = fill
+        lengts[gt == -2] = fill
+        unnorm = lengts.sum(axis=1).astype(np.float32)
+    else:
+        ref1 = np.clip(1 - np.sum(ap1, axis=1), 0, 1)
+        ref2 = np.clip(1 - np.sum(ap2, axis=1), 0, 1)
+        if np.any(np.sum(ap1, axis=1) > 1.1) or np.any(np.sum(ap2, axis=1) > 1.1):
+            return np.array([np.nan] * n, dtype=np.float32)
+        if np.any(ap1 < 0) or np.any(ap2 < 0):
+            return np.array([np.nan] * n, dtype=np.float32)
+        if len(alt_lens) > 0:
+            cap = max(alt_lens)
+            h1 = np.clip(np.dot(ap1, alt_lens), 0, cap)
+            h2 = np.clip(np.dot(ap2, alt_lens), 0, cap)
+        else:
+            h1 = h2 = 0
+        unnorm = (h1 + h2 + ref1 * ref_len + ref2 * ref_len).astype(np.float32)
+    if not norm:
+        return unnorm
+    lo, hi = min(lens), max(lens)
+    if lo == hi:
+        return np.zeros(n, dtype=np.float32)
+    dos = (unnorm - 2 * lo) / (hi - lo)
+    with np.errstate(invalid='ignore'):
+        if np.any(dos >= 2.1) or np.any(dos <= -0.1):
+            return np.array([np.nan] * n, dtype=np.float32)
+    return np.clip(dos, 0, 2)

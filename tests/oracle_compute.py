@@ -269,3 +269,25 @@ class OracleCompute:
             lf[l, L.AF_RSQUARED], lf[l, L.AF_GT_STD], lf[l, L.AF_TVALUE] = r['rsquared'], r['std'], r['tvalue']
             lf[l, L.AF_DF_RESID] = r['df_resid']
         return AssocHost(li, lf, np.zeros(int(hb.allele_off[-1]), dtype=np.int32)), cs, ls, tabs
+
+    def dosages_batch(self, hb, dosage_type, ap1=None, ap2=None):
+        """trk_dosages through oracle.get_dosages; error bits recomputed from the inputs."""
+        out = np.full((hb.n_loci, hb.n_samples), np.nan, dtype=np.float32)
+        err = np.zeros(hb.n_loci, dtype=np.int32)
+        for l in range(hb.n_loci):
+            g = hb.gt[l][:, :int(hb.locus_ploidy[l])]
+            A = len(hb.allele_lens[l])
+            a1 = None if ap1 is None else ap1[l][:, :A - 1]
+            a2 = None if ap2 is None else ap2[l][:, :A - 1]
+            if a1 is not None:
+                if np.any(np.sum(a1, axis=1) > 1.1) or np.any(np.sum(a2, axis=1) > 1.1):
+                    err[l] |= 1
+                if np.any(a1 < 0) or np.any(a2 < 0):
+                    err[l] |= 2
+            if err[l]:
+                continue
+            d = orc.get_dosages(g, hb.allele_lens[l], dosage_type, a1, a2)
+            if dosage_type.endswith('_norm') and np.all(np.isnan(d)) and not np.all(np.any(g < 0, axis=1)):
+                err[l] |= 4
+            out[l] = d
+        return out, err

@@ -91,6 +91,7 @@ class AssocDosage(C.Structure):
 
 
 ADC_COLS, ADL_COLS = 4, 8
+DOS_TYPES = {'bestguess': 0, 'beagleap': 1, 'bestguess_norm': 2, 'beagleap_norm': 3}
 
 
 class AssocOut(C.Structure):
@@ -120,7 +121,7 @@ EXPORTS = [
     'trk_locus_stats', 'trk_locus_finalize', 'trk_call_filters', 'trk_locus_filters',
     'trk_comm_unique_id', 'trk_comm_init', 'trk_allreduce_sum_i64', 'trk_allgather',
     'trk_binomtest_two_sided', 'trk_binom_pmf', 'trk_synth_fill', 'trk_synth_fill_gangstr',
-    'trk_assoc_scan', 'trk_assoc_scan_dosage', 'trk_student_t_two_sided',
+    'trk_assoc_scan', 'trk_assoc_scan_dosage', 'trk_student_t_two_sided', 'trk_dosages',
 ]
 
 _lib = None
@@ -178,6 +179,7 @@ def load():
     lib.trk_binom_pmf.restype = dbl
     lib.trk_assoc_scan.argtypes = [vp, P(Batch), P(AssocParams), P(AssocOut)]
     lib.trk_assoc_scan_dosage.argtypes = [vp, P(Batch), P(AssocParams), P(AssocDosage), P(AssocOut), vp, vp]
+    lib.trk_dosages.argtypes = [vp, P(Batch), vp, C.c_int, vp, vp, C.c_int, vp, vp]
     lib.trk_student_t_two_sided.argtypes = [dbl, dbl]
     lib.trk_student_t_two_sided.restype = dbl
     lib.trk_synth_fill.argtypes = [vp, P(SynthSpec), vp, vp, vp, vp, vp]

@@ -136,3 +136,16 @@ class DeviceCompute:
         out = (AssocHost(res.locus_int.get(), res.locus_f64.get(), res.allele_count.get()), cs.get(), ls.get(), tabs)
         self._free(b, res.locus_int, res.locus_f64, res.allele_count, cs, ls, *[x for x in res._keep if x is not None])
         return out
+
+    def dosages_batch(self, hb, dosage_type, ap1=None, ap2=None):
+        """TRRecord.GetDosages for every record of a batch (trk_dosages): (float32 [L, S], int32 [L] error bits)."""
+        from .synth import pack_assoc_tables
+        eng = self.eng
+        b = self._upload(hb)
+        alen, _ = pack_assoc_tables(hb.allele_lens, 2)
+        out, err = eng.dosages(b, alen, dosage_type,
+                               None if ap1 is None else np.ascontiguousarray(ap1, dtype=np.float32),
+                               None if ap2 is None else np.ascontiguousarray(ap2, dtype=np.float32))
+        res = (out.get(), err.get())
+        self._free(b, out, err, *[x for x in out._keep if x is not None])
+        return res

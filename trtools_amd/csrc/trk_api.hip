@@ -605,6 +605,22 @@ int trk_assoc_scan_dosage(trk_ctx* ctx, const trk_batch* in, const trk_assoc_par
     return TRK_OK;
 }
 
+int trk_dosages(trk_ctx* ctx, const trk_batch* in, const double* allele_len, int dosage_type, const float* ap1,
+                const float* ap2, int n_alt_cols, float* out, int32_t* locus_err) {
+    if (!ctx) return TRK_ERR_ARG;
+    int rc = check_batch(ctx, in);
+    if (rc) return rc;
+    if (dosage_type < 0 || dosage_type > 3) return fail(ctx, TRK_ERR_ARG, "dosage type %d", dosage_type);
+    if (in->n_loci == 0) return TRK_OK;
+    const bool beagle = dosage_type == TRK_DOS_BEAGLEAP || dosage_type == TRK_DOS_BEAGLEAP_NORM;
+    if (!allele_len || !out || !locus_err || (beagle && (!ap1 || !ap2)))
+        return fail(ctx, TRK_ERR_ARG, "dosage inputs/outputs are NULL");
+    if (in->n_loci > 65535) return fail(ctx, TRK_ERR_ARG, "at most 65535 loci per dosage call");
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, trk::launch_dosages(*in, allele_len, dosage_type, ap1, ap2, n_alt_cols, out, locus_err, ctx->stream));
+    return TRK_OK;
+}
+
 double trk_student_t_two_sided(double t, double df) { return trkmath::student_t_two_sided(t, df); }
 
 double trk_binomtest_two_sided(int64_t k, int64_t n, double p) {

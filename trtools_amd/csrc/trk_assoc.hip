@@ -1016,6 +1016,76 @@ __global__ __launch_bounds__(256) void k_assoc_dosage(const AssocArgs a, const D
 }
 
 // -------------------------------------------------------------------------------------------
+// per-sample dosages (TRRecord.GetDosages, tr_harmonizer.py:1098-1208): one thread per call
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dosages(trk_batch b, const double* __restrict__ allele_len, int type,
+                                                 const float* __restrict__ ap1, const float* __restrict__ ap2, int Kc,
+                                                 float* __restrict__ out, int32_t* __restrict__ locus_err) {
+    const int l = blockIdx.y;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int S = b.n_samples, P = b.ploidy;
+    if (s >= S) return;
+    const int pl = b.locus_ploidy ? b.locus_ploidy[l] : P;
+    const int off = b.allele_off[l];
+    const int A = b.allele_off[l + 1] - off;
+    double lmin = allele_len[off], lmax = allele_len[off], amax = -INFINITY;
+    for (int i = 1; i < A; ++i) {
+        const double v = allele_len[off + i];
+        lmin = fmin(lmin, v);
+        lmax = fmax(lmax, v);
+        amax = fmax(amax, v);
+    }
+    const bool norm = type == TRK_DOS_BESTGUESS_NORM || type == TRK_DOS_BEAGLEAP_NORM;
+    int err = 0;
+    float unnorm;
+    if (type == TRK_DOS_BESTGUESS || type == TRK_DOS_BESTGUESS_NORM) {
+        const int16_t* cell = b.gt + ((int64_t)l * S + s) * P;
+        double d = 0.0;
+        for (int p = 0; p < pl; ++p) {
+            const int al = cell[p];
+            double v;
+            if (al < 0) v = norm ? (double)NAN : 0.0;
+            else v = al < A ? allele_len[off + al] : (double)NAN;
+            d = p == 0 ? v : d + v;
+        }
+        unnorm = (float)d;
+    } else {
+        const float* ap[2] = {ap1 + ((int64_t)l * S + s) * Kc, ap2 + ((int64_t)l * S + s) * Kc};
+        double h[2] = {0.0, 0.0};
+        float refd[2];
+        for (int p = 0; p < 2; ++p) {
+            const float sum = np_sum_f32(ap[p], A - 1);
+            if (sum > 1.1f) err |= 1;
+            double dot = 0.0;
+            for (int i = 0; i < A - 1; ++i) {
+                if (ap[p][i] < 0.f) err |= 2;
+                dot += (double)ap[p][i] * allele_len[off + 1 + i];
+            }
+            if (A > 1) h[p] = dot == dot ? fmin(fmax(dot, 0.0), amax) : dot;   // np.clip keeps nan
+            const float om = 1.f - sum;
+            const float ref = om == om ? fminf(fmaxf(om, 0.f), 1.f) : om;
+            refd[p] = ref * (float)allele_len[off];
+        }
+        if (A > 1)
+            unnorm = (float)(((h[0] + h[1]) + (double)refd[0]) + (double)refd[1]);
+        else
+            unnorm = refd[0] + refd[1];
+    }
+    float res = unnorm;
+    if (norm) {
+        if (lmin == lmax) {
+            res = 0.f;
+        } else {
+            res = (unnorm - (float)(2.0 * lmin)) / (float)(lmax - lmin);
+            if (res >= 2.1f || res <= -0.1f) err |= 4;
+            if (res == res) res = fminf(fmaxf(res, 0.f), 2.f);   // nan stays nan (np.clip)
+        }
+    }
+    out[(int64_t)l * S + s] = res;
+    if (err) atomicOr(&locus_err[l], err);
+}
+
+// -------------------------------------------------------------------------------------------
 // finaliser
 // -------------------------------------------------------------------------------------------
 // The frequencies of the ROUNDED length alleles in ascending order, one at a time
@@ -1711,6 +1781,15 @@ hipError_t launch_assoc_dosage(const trk_batch& b, const trk_assoc_params& prm, 
     hipLaunchKernelGGL(k_assoc_finalize, dim3((b.n_loci + fin_t - 1) / fin_t), dim3(fin_t), fin_lds, stream, f);
     if ((err = hipGetLastError()) != hipSuccess) return err;
     return f.wave_regress ? launch_regress_wave(f, stream) : hipSuccess;
+}
+
+hipError_t launch_dosages(const trk_batch& b, const double* allele_len, int type, const float* ap1, const float* ap2,
+                          int n_alt_cols, float* out, int32_t* locus_err, hipStream_t stream) {
+    hipError_t err = hipMemsetAsync(locus_err, 0, (size_t)b.n_loci * 4, stream);
+    if (err != hipSuccess || b.n_loci == 0 || b.n_samples == 0) return err;
+    hipLaunchKernelGGL(k_dosages, dim3((b.n_samples + 255) / 256, b.n_loci), dim3(256), 0, stream, b, allele_len, type,
+                       ap1, ap2, n_alt_cols, out, locus_err);
+    return hipGetLastError();
 }
 
 }  // namespace trk

@@ -37,5 +37,7 @@ hipError_t launch_assoc_finalize(const trk_batch& b, const trk_assoc_params& prm
 hipError_t launch_assoc_dosage(const trk_batch& b, const trk_assoc_params& prm, const trk_assoc_dosage& dos,
                                const trk_assoc_out& out, double* class_sums, double* locus_sums, void* workspace,
                                hipStream_t stream);
+hipError_t launch_dosages(const trk_batch& b, const double* allele_len, int type, const float* ap1, const float* ap2,
+                          int n_alt_cols, float* out, int32_t* locus_err, hipStream_t stream);
 }  // namespace trk
 #endif

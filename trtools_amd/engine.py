@@ -384,6 +384,22 @@ class Engine:
                                                  C.byref(out.struct), cs.ptr, ls.ptr))
         return out, cs, ls
 
+    def dosages(self, batch, allele_len, dosage_type, ap1=None, ap2=None):
+        """trk_dosages -> (float32 [L, S] device array, int32 [L] error bits device array)."""
+        def dev(x, dt):
+            return x if isinstance(x, DeviceArray) else self.upload(x, dt)
+        t = L.DOS_TYPES[dosage_type] if isinstance(dosage_type, str) else int(dosage_type)
+        len_d = dev(allele_len, np.float64)
+        a1 = dev(ap1, np.float32) if ap1 is not None else None
+        a2 = dev(ap2, np.float32) if ap2 is not None else None
+        out = self.empty((batch.n_loci, batch.n_samples), np.float32)
+        err = self.empty((batch.n_loci,), np.int32)
+        out._keep = (len_d, a1, a2)
+        self._chk(self.lib.trk_dosages(self.ctx, C.byref(batch.struct), len_d.ptr, t, a1.ptr if a1 is not None else None,
+                                       a2.ptr if a2 is not None else None, a1.shape[2] if a1 is not None else 0,
+                                       out.ptr, err.ptr))
+        return out, err
+
     def student_t_two_sided(self, t, df):
         return float(self.lib.trk_student_t_two_sided(float(t), float(df)))
 

@@ -649,3 +649,54 @@ class TRRecordHarmonizer:
             raise ValueError("Unable to parse the " + str(self._record_idx) + "th tandem repeat in the "
                              "provided VCF. Check that it is properly formatted.")
         return HarmonizeRecord(self.vcftype, record)
+
+
+def GetDosagesBatch(records, dosagetype=TRDosageTypes.bestguess, strict=True):
+    """``TRRecord.GetDosages`` (reference tr_harmonizer.py:1098-1208) for a list of records of one
+    sample set in one device call (``trk_dosages``).  Returns a float32
+    array ``[len(records), n_samples]``; errors follow the reference record by record: ValueError
+    with its message when ``strict``, otherwise a warning and a row of nan."""
+    from .. import runtime
+    from ..batch import pack_records, stack_plane
+    if not records:
+        return np.zeros((0, 0), dtype=np.float32)
+    beagle = dosagetype in (TRDosageTypes.beagleap, TRDosageTypes.beagleap_norm)
+    norm = dosagetype in (TRDosageTypes.bestguess_norm, TRDosageTypes.beagleap_norm)
+    n = records[0].GetNumSamples()
+    ok = list(range(len(records)))
+    out = np.full((len(records), n), np.nan, dtype=np.float32)
+
+    def problem(i, msg, raise_msg=None):
+        if strict:
+            raise ValueError(raise_msg or msg)
+        common.WARNING(msg)
+        ok.remove(i)
+
+    ap1 = ap2 = None
+    if beagle:
+        for i, r in enumerate(records):
+            fmt = r.vcfrecord.FORMAT
+            if "AP1" not in fmt or "AP2" not in fmt or r.vcfrecord.format("AP1") is None \
+                    or r.vcfrecord.format("AP2") is None:
+                problem(i, "Requested Beagle dosages for record at {}:{} but AP1/AP2 fields not found."
+                        .format(r.chrom, r.pos))
+        if not ok:
+            return out
+    recs = [records[i] for i in ok]
+    hb = pack_records(recs)
+    if beagle:
+        ap1 = stack_plane([np.asarray(r.vcfrecord.format("AP1"), dtype=np.float32) for r in recs], np.float32)
+        ap2 = stack_plane([np.asarray(r.vcfrecord.format("AP2"), dtype=np.float32) for r in recs], np.float32)
+    dos, err = runtime.get_compute().dosages_batch(hb, dosagetype.name, ap1, ap2)
+    for k, i in enumerate(list(ok)):
+        r, e = records[i], int(err[k])
+        if e & 1:
+            problem(i, "{}:{} AP1 or AP2 field summing to more than 1 detected".format(r.chrom, r.pos))
+        elif e & 2:
+            problem(i, "{}:{} Negative AP1 or AP2 fields detected".format(r.chrom, r.pos),
+                    "Negative AP1 or AP2 fields detected")
+        elif norm and (e & 4):
+            problem(i, "{}:{} Error normalizing dosages: value >=2.1 or <=-0.1 detected".format(r.chrom, r.pos))
+        else:
+            out[i] = dos[k]
+    return out
