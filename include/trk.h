@@ -252,6 +252,8 @@ typedef struct {
      * over the genotype tensor.  Follow with trk_locus_finalize.                            */
     int32_t* delta_allele_count;
     int32_t* delta_locus_int;
+    double* sample_totaldp_f64; /* [S] += the depth of PASS calls when the DP/LC plane is Float (ExpansionHunter's
+                                   LC); sample_totaldp stays 0 then.  Required only for a Float depth plane.   */
 } trk_call_out;
 
 /* (a11)-(a18): evaluate `n_filters` call-level filters on every call of the

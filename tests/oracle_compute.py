@@ -134,7 +134,9 @@ class OracleCompute:
         dp_missing[np.isnan(totaldp)] = 1
         totaldp[np.isnan(totaldp)] = 0
         counters = np.stack([info['numcalls']] + [info[n] for n in names]).astype(np.int64)
-        ch = CallHost(gout, mask, counters, totaldp.astype(np.int64), dp_missing, np.zeros(4, dtype=np.int32))
+        if np.all(totaldp == np.floor(totaldp)):
+            totaldp = totaldp.astype(np.int64)
+        ch = CallHost(gout, mask, counters, totaldp, dp_missing, np.zeros(4, dtype=np.int32))
         st = stats_of(hb, gout, nalleles_thresh)
         # locus filters (dumpSTR.py:917-973) from the same statistics
         spec = dict(locus_spec)

@@ -88,11 +88,15 @@ class DeviceCompute:
         if ext_host is not None:
             ext = eng.upload(np.ascontiguousarray(ext_host, dtype=np.uint32))
         bits, counters = eng.locus_filters(hb.n_loci, st, extern_bits=ext, **spec)
+        totaldp = call.sample_totaldp.get()
+        if dp_plane >= 0 and np.asarray(planes[dp_plane]).dtype.kind == 'f':
+            totaldp = call.sample_totaldp_f64.get()      # Float depth plane (ExpansionHunter's LC)
         ch = CallHost(call.gt_out.get(), call.filter_mask.get(), call.sample_counters.get(),
-                      call.sample_totaldp.get(), call.sample_dp_missing.get(), call.error.get())
+                      totaldp, call.sample_dp_missing.get(), call.error.get())
         sh = StatsHost(st.allele_count.get(), st.locus_int.get(), st.locus_f64.get())
         out = (ch, sh, bits.get(), counters.get())
         self._free(b, *dplanes, call.gt_out, call.filter_mask, call.sample_counters, call.sample_totaldp,
+                   call.sample_totaldp_f64,
                    call.sample_dp_missing, call.error, st.allele_count, st.locus_int, st.locus_f64,
                    bits, counters, ext)
         return out

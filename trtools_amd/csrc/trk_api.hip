@@ -410,6 +410,9 @@ int trk_call_filters(trk_ctx* ctx, const trk_batch* in, const trk_plane* planes,
     if (n_planes < 0 || n_planes > TRK_MAX_PLANES) return fail(ctx, TRK_ERR_ARG, "n_planes %d > %d", n_planes, TRK_MAX_PLANES);
     if (n_filters < 0 || n_filters > TRK_MAX_FILTERS)
         return fail(ctx, TRK_ERR_ARG, "n_filters %d > %d", n_filters, TRK_MAX_FILTERS);
+    if (dp_plane >= 0 && dp_plane < n_planes && planes && planes[dp_plane].dtype == TRK_DT_F32 && out &&
+        !out->sample_totaldp_f64)
+        return fail(ctx, TRK_ERR_ARG, "a Float depth plane needs sample_totaldp_f64");
     if (!out || !out->sample_counters || !out->sample_totaldp || !out->sample_dp_missing || !out->error)
         return fail(ctx, TRK_ERR_ARG, "call-filter outputs are NULL");
     if (dp_plane >= n_planes) return fail(ctx, TRK_ERR_ARG, "dp_plane out of range");
@@ -417,8 +420,6 @@ int trk_call_filters(trk_ctx* ctx, const trk_batch* in, const trk_plane* planes,
         return fail(ctx, TRK_ERR_ARG, "delta_allele_count and delta_locus_int must be given together");
     if (out->delta_allele_count && in->group_bits)
         return fail(ctx, TRK_ERR_ARG, "delta outputs are defined for ungrouped batches only");
-    if (dp_plane >= 0 && planes[dp_plane].dtype != TRK_DT_I32)
-        return fail(ctx, TRK_ERR_ARG, "the DP/LC plane must be int32");
     for (int i = 0; i < n_planes; ++i) {
         if (!planes[i].data || planes[i].ncol < 1) return fail(ctx, TRK_ERR_ARG, "plane %d is empty", i);
         if (planes[i].dtype != TRK_DT_I32 && planes[i].dtype != TRK_DT_F32)

@@ -1019,7 +1019,21 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter(const CallArgs a) {
                 mask[j] = m;
                 if (m == 0) {  // 'PASS'  (dumpSTR.py:686-713)
                     numcalls[j]++;
-                    if (a.dp_plane >= 0) {
+                    if (a.dp_plane >= 0 && a.planes[a.dp_plane].dtype == TRK_DT_F32) {
+                        // Float depth (dumpSTR.py:688-713 on a float32 array): nan is neither negative nor
+                        // positive; sums of float32 values are exact in float64 at these magnitudes, so the
+                        // order of the atomics does not show
+                        const trk_plane& dp = a.planes[a.dp_plane];
+                        const float d = reinterpret_cast<const float*>(dp.data)[cell * dp.ncol];
+                        if (d < 0.f) {
+                            if (atomicCAS(&a.out.error[0], 0, 1) == 0) {
+                                a.out.error[1] = l;
+                                a.out.error[2] = (int32_t)(s0 + j);
+                            }
+                        } else if (d > 0.f) {
+                            atomicAdd(a.out.sample_totaldp_f64 + s0 + j, (double)d);
+                        }
+                    } else if (a.dp_plane >= 0) {
                         const trk_plane& dp = a.planes[a.dp_plane];
                         int32_t d = reinterpret_cast<const int32_t*>(dp.data)[cell * dp.ncol];
                         if (d == INT32_MIN) {
@@ -1838,7 +1852,9 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
     gy = (L + lpb - 1) / lpb;
     a.loci_per_block = lpb;
     size_t lds = (size_t)n_filters * CF_THREADS * CF_V * sizeof(uint32_t);
-    const bool vec = (b.ploidy == 2) && (S % 4 == 0);
+    // a Float depth plane (ExpansionHunter's LC) is summed in float64 by the per-call kernel only
+    const bool float_dp = dp_plane >= 0 && planes[dp_plane].dtype == TRK_DT_F32;
+    const bool vec = (b.ploidy == 2) && (S % 4 == 0) && !float_dp;
     a.fast_plane_mask = a.fast_filter_mask = a.slow_filter_mask = 0;
     a.delta_stride = 0;
     a.dbg = getenv("TRK_CF_DBG") ? atoi(getenv("TRK_CF_DBG")) : 0;

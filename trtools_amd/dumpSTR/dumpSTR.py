@@ -296,8 +296,6 @@ class _Planes:
                 self.arrays.append(stack_plane([a.astype(np.int32) for a in per], np.int32))
             else:
                 raise ValueError("Found an unexpected format dtype for format field " + k)
-        if self.dp_key is not None and self.arrays[self.index[self.dp_key]].dtype != np.int32:
-            raise NotImplementedError("non-integer DP/LC FORMAT fields are not supported by the device path")
 
     def get(self, key):
         return self.arrays[self.index[key]]

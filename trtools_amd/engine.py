@@ -105,7 +105,9 @@ class AssocResult:
 
 
 class CallResult:
-    def __init__(self, gt_out, filter_mask, sample_counters, sample_totaldp, sample_dp_missing, error):
+    def __init__(self, gt_out, filter_mask, sample_counters, sample_totaldp, sample_dp_missing, error,
+                 sample_totaldp_f64=None):
+        self.sample_totaldp_f64 = sample_totaldp_f64
         self.gt_out = gt_out
         self.filter_mask = filter_mask
         self.sample_counters = sample_counters
@@ -114,7 +116,7 @@ class CallResult:
         self.error = error
         self.struct = L.CallOut(gt_out.ptr if gt_out else None, filter_mask.ptr if filter_mask else None,
                                 sample_counters.ptr, sample_totaldp.ptr, sample_dp_missing.ptr, error.ptr,
-                                None, None)
+                                None, None, sample_totaldp_f64.ptr if sample_totaldp_f64 is not None else None)
 
     def with_delta(self, stats):
         """trk_call_out whose delta outputs point at ``stats`` (counts of the unfiltered genotypes)."""
@@ -268,7 +270,7 @@ class Engine:
             self.empty((batch.n_loci, S, batch.ploidy), np.int16) if want_gt else None,
             self.empty((batch.n_loci, S), np.uint32) if want_mask else None,
             self.zeros((1 + n_filters, S), np.int64), self.zeros((S,), np.int64),
-            self.zeros((S,), np.int64), self.zeros((4,), np.int32))
+            self.zeros((S,), np.int64), self.zeros((4,), np.int32), self.zeros((S,), np.float64))
 
     def locus_finalize(self, batch, stats, nalleles_thresh=0.01):
         """Float statistics + HWE test from counts already in ``stats`` (trk_locus_finalize)."""
