@@ -8,6 +8,11 @@ configs[2]  dumpSTR call + locus filters, synthetic GangSTR-shape, 50k loci x 5k
             size-independent invariants over the whole batch + sampled loci against the
             numpy oracle (rows regenerated on the host by the generator's numpy twin).
 configs[3]  (100k x 10k) is what bench.py runs, with the same spot checks.
+configs[4]  associaTR linear-regression scan, 100k loci x 10k samples x 1 trait (one GPU's share and more):
+            size-independent properties over the whole batch (invariance of p / R^2 / counts under an affine
+            change of the trait with the coefficient scaling along, sample masking == dropping the samples'
+            contribution, the one-trait kernel == the MFMA kernel == the per-call kernel on the same input,
+            sum of allele counts == 2 x tested samples - padding) + sampled loci against the associaTR oracle.
 """
 import collections
 import math
@@ -166,3 +171,82 @@ def test_config2_dumpstr_gangstr_50k_x_5k(eng):
         o = orc.locus_stats(g2, lens, strs, None, use_length=False)
         assert np.array_equal(cnt[off[l]:off[l + 1]], o['index_counts'])
         assert close(lf[l, L.LF_HET_STR], o['het'])
+
+
+def test_config4_associatr_100k_x_10k(eng):
+    import os
+    from oracle import associatr_oracle as ao
+    from trtools_amd.synth import SynthBatch, pack_assoc_tables
+    from trtools_amd import _lib as TL
+    Lc, S = 100000, 10000
+    sb = SynthBatch(eng, Lc, S, seed=20260928 + 4, planes=())
+    alen, rcls = pack_assoc_tables(sb.loci.allele_lens, 2)
+    alen_d, rcls_d = eng.upload(alen, np.float64), eng.upload(rcls, np.uint16)
+    rng = np.random.default_rng(44)
+    y = rng.normal(size=S)
+    y = (y - y.mean()) / y.std()
+
+    def scan(vec, sample_in=None, env=None):
+        old = {}
+        for k, v in (env or {}).items():
+            old[k] = os.environ.get(k)
+            os.environ[k] = v
+        try:
+            r = eng.assoc_scan(sb.batch, np.ascontiguousarray(vec), alen_d, rcls_d, sample_in=sample_in,
+                               non_major_cutoff=20.0)
+            out = (r.locus_int.get(), r.locus_f64.get(), r.allele_count.get())
+            for d in (r.locus_int, r.locus_f64, r.allele_count):
+                d.free()
+            return out
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+
+    li, lf, cnt = scan(y[None, :])
+    ok = li[:, TL.AI_STATUS] == TL.AS_OK
+    assert ok.sum() > 0.8 * Lc
+    # counts: every tested sample contributes its two haplotypes (the generator has no ploidy padding)
+    off = sb.tables[0].astype(np.int64)
+    per_locus = np.add.reduceat(cnt, off[:-1])
+    assert np.array_equal(per_locus, 2 * li[:, TL.AI_N_TESTED].astype(np.int64))
+    assert np.array_equal(per_locus, li[:, TL.AI_N_HAPS])
+    p = lf[ok, TL.AF_PVAL]
+    assert np.all((p >= 0) & (p <= 1)) and np.all(lf[ok, TL.AF_SE] > 0)
+    assert np.all(lf[ok, TL.AF_DF_RESID] == li[ok, TL.AI_N_TESTED] - 2)
+    t2 = lf[ok, TL.AF_TVALUE] ** 2
+    df = lf[ok, TL.AF_DF_RESID]
+    assert np.allclose(lf[ok, TL.AF_RSQUARED], t2 / (t2 + df), rtol=1e-9, atol=1e-13)   # one regressor + intercept
+    # affine change of the trait: same statistics, coefficient and standard error scale
+    li2, lf2, _ = scan((3.5 * y - 2.0)[None, :])
+    assert np.array_equal(li2, li)
+    for col, factor in ((TL.AF_PVAL, 1.0), (TL.AF_RSQUARED, 1.0), (TL.AF_COEF, 3.5), (TL.AF_SE, 3.5), (TL.AF_GT_STD, 1.0)):
+        assert np.allclose(lf2[ok, col], factor * lf[ok, col], rtol=1e-8, atol=1e-12 if col == TL.AF_RSQUARED else 1e-300), col
+    # three device code paths on the same input: one-trait kernel (above), MFMA kernel, per-call kernel
+    for env in ({'TRK_AS_MFMA_MIN': '1'}, {'TRK_AS_GENERIC': '1'}):
+        li3, lf3, cnt3 = scan(y[None, :], env=env)
+        assert np.array_equal(li3, li) and np.array_equal(cnt3, cnt), env
+        for col in (TL.AF_PVAL, TL.AF_COEF, TL.AF_SE, TL.AF_RSQUARED, TL.AF_GT_STD):
+            assert np.allclose(lf3[ok, col], lf[ok, col], rtol=1e-9, atol=1e-13 if col == TL.AF_RSQUARED else 1e-300), (env, col)
+    # a sample mask: masked samples count for nothing (compare with zeroing nothing else)
+    mask = (rng.random(S) < 0.9).astype(np.uint8)
+    ym = y.copy()
+    m = mask.astype(bool)
+    ym[m] = (y[m] - y[m].mean()) / y[m].std()
+    lim, lfm, cntm = scan(ym[None, :], sample_in=mask)
+    assert np.all(lim[:, TL.AI_N_TESTED] <= li[:, TL.AI_N_TESTED]) and lim[:, TL.AI_N_TESTED].max() <= m.sum()
+    # sampled loci against the oracle (rows regenerated by the generator's numpy twin), full and masked runs
+    idx = np.unique(np.linspace(0, Lc - 1, 9).astype(int))
+    rows = sb.host_rows(idx)
+    for k, l in enumerate(idx):
+        for (I, F, sf, yy) in ((li, lf, np.ones(S, dtype=bool), y), (lim, lfm, m, ym[m])):
+            cov = np.ones((int(sf.sum()), 2))
+            r = ao.scan_locus(rows['gt'][k], sb.loci.allele_lens[l], sf, cov, yy, 1.0, 20.0, 2)
+            assert I[l, TL.AI_N_TESTED] == r['n_tested'], l
+            assert (I[l, TL.AI_STATUS] == TL.AS_OK) == (not r['locus_filtered']), (l, r['locus_filtered'])
+            if not r['locus_filtered']:
+                for col, key in ((TL.AF_PVAL, 'pval'), (TL.AF_COEF, 'coef_std'), (TL.AF_SE, 'se_std'),
+                                 (TL.AF_RSQUARED, 'rsquared')):
+                    assert abs(F[l, col] - r[key]) <= 1e-9 * abs(r[key]) + 1e-13, (l, key)
