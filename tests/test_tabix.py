@@ -24,11 +24,11 @@ def test_built_index_agrees_with_htslib(vcf, tmp_path):
     assert back.linear == mine.linear and back.bins == mine.bins          # write/read round trip
     assert ref.meta == back.meta
     for r in range(len(ref.names)):
-            # htslib's meta bin: first virtual offset of the sequence and its record count.  The END offset is where
-            # the writing htslib version's bgzf_tell stood after the last record (older versions: the start of its
-            # block): not compared beyond ordering
-            mm, rm = mine.bins[r][tabix.META_BIN], ref.bins[r][tabix.META_BIN]
-            assert mm[0][0] == rm[0][0] and mm[1] == rm[1] and mm[0][1] >= rm[0][1] > mm[0][0]
+        # htslib's meta bin: first virtual offset of the sequence and its record count.  The END offset is where
+        # the writing htslib version's bgzf_tell stood after the last record (older versions: the start of its
+        # block): not compared beyond ordering
+        mm, rm = mine.bins[r][tabix.META_BIN], ref.bins[r][tabix.META_BIN]
+        assert mm[0][0] == rm[0][0] and mm[1] == rm[1] and mm[0][1] >= rm[0][1] > mm[0][0]
         a, b = ref.linear[r], mine.linear[r]
         assert len(a) == len(b)
         # windows in which a record STARTS carry the same offset in any htslib version; empty windows are
