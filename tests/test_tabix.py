@@ -122,3 +122,14 @@ def test_dumpstr_zip_writes_an_index(tmp_path):
     idx = tabix.TabixIndex.load(out + '.tbi')
     n = sum(1 for s, e, l in tabix._lines(out) if l and l[:1] != b'#')
     assert sum(idx.bins[r][tabix.META_BIN][1][0] for r in range(len(idx.names))) == n > 0
+
+
+def test_stale_index_falls_back_to_a_scan():
+    """trio_chr21_hipstr's fixture index was written for another compression of the file: the seek is refused and
+    the region is served by the linear scan."""
+    from trtools_amd import vcfnative, vcfio
+    vcf = os.path.join(DATA, 'dumpSTR', 'trio_chr21_hipstr.sorted.vcf.gz')
+    r = vcfnative.NativeVCFReader(vcf)
+    got = _records(r, 'chr21:15000000-15500000')
+    assert not r._indexed_region and len(got) > 10
+    assert got == _records(vcfio.VCFReader(vcf), 'chr21:15000000-15500000')

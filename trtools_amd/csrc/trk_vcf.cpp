@@ -484,6 +484,18 @@ int trk_vcf_seek(trk_vcf* v, uint64_t voffset) {
     }
     const uint64_t coff = voffset >> 16;
     const size_t uoff = (size_t)(voffset & 0xffffu);
+    // the offset must be the start of a BGZF block of THIS file (a stale .tbi points elsewhere):
+    // checked before any reader state is touched, so that the caller can fall back to a scan
+    const off_t here = ftello(v->src.fp);
+    unsigned char h[18];
+    const bool ok = fseeko(v->src.fp, (off_t)coff, SEEK_SET) == 0 && fread(h, 1, sizeof h, v->src.fp) == sizeof h &&
+                    h[0] == 0x1f && h[1] == 0x8b && (h[3] & 4) && h[12] == 'B' && h[13] == 'C' &&
+                    uoff <= 0xff00u;
+    if (!ok) {
+        (void)fseeko(v->src.fp, here, SEEK_SET);
+        v->err = "virtual offset does not point at a BGZF block (stale index?)";
+        return 1;
+    }
     if (fseeko(v->src.fp, (off_t)coff, SEEK_SET) != 0) {
         v->err = "fseek failed";
         return 1;
