@@ -12,7 +12,15 @@ ALL = dict(thresh=True, afreq=True, acount=True, hwep=True, het=True, entropy=Tr
            numcalled=True, nalleles=True)
 NONE = {k: False for k in ALL}
 
+GROUPS = os.path.join(DATA, 'statSTR', 'groups')     # ten sample lists of many_samples.vcf.gz (five samples each)
+TEN = ','.join(os.path.join(GROUPS, 'g%d.txt' % i) for i in range(10))
+
 CASES = [
+    # more sample groups than one kernel pass takes (8): two passes over the batch
+    ('ten_groups', os.path.join(DATA, 'many_samples.vcf.gz'), 'hipstr',
+     dict(ALL, samples=TEN, sample_prefixes=','.join('grp%d' % i for i in range(10)), region='1:3000000-6000000')),
+    ('ten_groups_uselength', os.path.join(DATA, 'many_samples.vcf.gz'), 'hipstr',
+     dict(ALL, use_length=True, samples=TEN, sample_prefixes=','.join('grp%d' % i for i in range(10)), region='1:1-3000000')),
     ('ceu_only_passing', os.path.join(S, 'CEU_test.vcf.gz'), 'auto', dict(NONE, only_passing=True)),
     ('ceu_all', os.path.join(S, 'CEU_test.vcf.gz'), 'auto', dict(ALL)),
     ('few_all', os.path.join(S, 'few_samples_few_loci.vcf.gz'), 'auto', dict(ALL)),

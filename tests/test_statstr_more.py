@@ -36,7 +36,7 @@ def run_and_check(outdir):
             raise AssertionError((name, first, gl[first][:300] if first < len(gl) else None,
                                   wl[first][:300] if first < len(wl) else None))
         n += 1
-    assert n == 21
+    assert n == 23
 
 
 def test_more_reference_cases_host_layer_cpu(tmp_path):
