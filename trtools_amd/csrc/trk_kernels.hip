@@ -1384,14 +1384,25 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
     const int tid = threadIdx.x;
     const int S = a.b.n_samples, L = a.b.n_loci;
     const int64_t s0 = ((int64_t)blockIdx.x * CF_THREADS + tid) * CF_V;
-    const int l_begin = blockIdx.y * a.loci_per_block;
-    const int l_end = min(L, l_begin + a.loci_per_block);
-    const int nl = l_end - l_begin;
     const int nal = a.delta_nal;
     const int dstride = nal + V2_EXTRA;
     uint32_t* dtab = v2lds;                                        // [loci][nal + 3]
     uint32_t* lutb = dtab + (size_t)a.loci_per_block * dstride;    // [loci][nal]
     int32_t* linfo = reinterpret_cast<int32_t*>(lutb + (size_t)a.loci_per_block * nal);  // [loci][2]
+    // per-sample counters live in registers across ALL the locus blocks this workgroup walks
+    // (blockIdx.y, + gridDim.y, ...) and are flushed once
+    uint32_t numcalls[CF_V] = {0, 0, 0, 0}, dpmiss[CF_V] = {0, 0, 0, 0};
+    uint32_t fc[NF][CF_V];
+    int64_t totaldp[CF_V] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < NF; ++k)
+#pragma unroll
+        for (int j = 0; j < CF_V; ++j) fc[k][j] = 0;
+    const int n_blocks = (L + a.loci_per_block - 1) / a.loci_per_block;
+    for (int by = blockIdx.y; by < n_blocks; by += gridDim.y) {
+    const int l_begin = by * a.loci_per_block;
+    const int l_end = min(L, l_begin + a.loci_per_block);
+    const int nl = l_end - l_begin;
     if (DELTA) {
         for (int i = tid; i < nl * dstride; i += CF_THREADS) dtab[i] = 0;
         for (int li = tid; li < nl; li += CF_THREADS) {
@@ -1410,13 +1421,6 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
         __syncthreads();
     }
     if (s0 < S) {
-        uint32_t numcalls[CF_V] = {0, 0, 0, 0}, dpmiss[CF_V] = {0, 0, 0, 0};
-        uint32_t fc[NF][CF_V];
-        int64_t totaldp[CF_V] = {0, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < NF; ++k)
-#pragma unroll
-            for (int j = 0; j < CF_V; ++j) fc[k][j] = 0;
         for (int l = l_begin; l < l_end; ++l) {
             const int64_t c4 = ((int64_t)l * S + s0) >> 2;
             const u32x4 g = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.b.gt) + c4);
@@ -1488,25 +1492,6 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
             if (a.out.gt_out) __builtin_nontemporal_store(wout, reinterpret_cast<u32x4*>(a.out.gt_out) + c4);
             if (a.out.filter_mask) __builtin_nontemporal_store(mout, reinterpret_cast<u32x4*>(a.out.filter_mask) + c4);
         }
-#pragma unroll
-        for (int j = 0; j < CF_V; ++j) {
-            const int64_t s = s0 + j;
-            if (numcalls[j])
-                atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_counters + s),
-                          (unsigned long long)numcalls[j]);
-            if (totaldp[j])
-                atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_totaldp + s),
-                          (unsigned long long)totaldp[j]);
-            if (dpmiss[j])
-                atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_dp_missing + s),
-                          (unsigned long long)dpmiss[j]);
-#pragma unroll
-            for (int k = 0; k < NF; ++k)
-                if (fc[k][j])
-                    atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_counters +
-                                                                    (int64_t)(1 + a.f[k].bit) * S + s),
-                              (unsigned long long)fc[k][j]);
-        }
     }
     if (DELTA) {  // one global atomic per non-zero entry of the block's delta table
         __syncthreads();
@@ -1528,7 +1513,31 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
                 if (v >> 16) atomicSub(&li_[TRK_LI_N_HOM_STR], (int)(v >> 16));
             }
         }
+        __syncthreads();   // the table is re-initialised for the next block
     }
+    }  // locus blocks of this workgroup
+    if (s0 < S) {
+#pragma unroll
+        for (int j = 0; j < CF_V; ++j) {
+            const int64_t s = s0 + j;
+            if (numcalls[j])
+                atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_counters + s),
+                          (unsigned long long)numcalls[j]);
+            if (totaldp[j])
+                atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_totaldp + s),
+                          (unsigned long long)totaldp[j]);
+            if (dpmiss[j])
+                atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_dp_missing + s),
+                          (unsigned long long)dpmiss[j]);
+#pragma unroll
+            for (int k = 0; k < NF; ++k)
+                if (fc[k][j])
+                    atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_counters +
+                                                                    (int64_t)(1 + a.f[k].bit) * S + s),
+                              (unsigned long long)fc[k][j]);
+        }
+    }
+
 }
 
 // ---------------------------------------------------------------------------
@@ -1926,6 +1935,12 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             }
             gy = (L + lpb - 1) / lpb;
             v.loci_per_block = lpb;
+            // workgroups walk blocks blockIdx.y, + gridDim.y, ... with the per-sample counters in registers;
+            // TRK_CF_GY caps gridDim.y (default: one block per workgroup)
+            if (const char* e = getenv("TRK_CF_GY")) {
+                int q = atoi(e);
+                if (q > 0 && q < gy) gy = q;
+            }
             dim3 grid(gx, gy), block(CF_THREADS);
 #define TRK_V2(NFV)                                                                                   \
     if (delta)                                                                                        \
