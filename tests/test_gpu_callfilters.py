@@ -278,3 +278,25 @@ def test_delta_counts_equal_recount(eng, n_samples):
     a, b = st.locus_f64.get(), ref.locus_f64.get()
     assert np.array_equal(np.nan_to_num(a, nan=-7.0), np.nan_to_num(b, nan=-7.0))
     assert (res.filter_mask.get() & np.uint32(3)).any()
+
+
+def test_no_filters_gives_per_sample_call_counts_and_float_depth(eng):
+    """n_filters == 0: sample_counters[0] is the per-sample number of calls (qcSTR's sample_calls), the genotypes
+    pass through; a Float depth plane (ExpansionHunter's LC) is summed in float64 (sample_totaldp_f64)."""
+    from trtools_amd import synth
+    rng = np.random.default_rng(9)
+    Lc, S = 37, 130
+    lens = [[10.0, 11.0, 12.0]] * Lc
+    off, lc, sc, cv = synth.pack_alleles(lens, None)
+    gt = rng.integers(-1, 3, size=(Lc, S, 2)).astype(np.int16)
+    lcov = rng.uniform(0, 60, size=(Lc, S, 1)).astype(np.float32)
+    lcov[rng.random((Lc, S, 1)) < 0.05] = np.nan
+    b = eng.make_batch(gt, off, lc, sc, cv)
+    res = eng.call_filters(b, [eng.upload(lcov)], [], dp_plane=0)
+    called = ~np.any(gt == -1, axis=2)
+    assert np.array_equal(res.sample_counters.get()[0], called.sum(axis=0))
+    assert np.array_equal(res.gt_out.get(), gt)
+    assert np.array_equal(res.filter_mask.get() >> 31, (~called).astype(np.uint32))
+    want = np.where(called & (lcov[:, :, 0] > 0), lcov[:, :, 0].astype(np.float64), 0.0).sum(axis=0)
+    assert np.allclose(res.sample_totaldp_f64.get(), want, rtol=1e-14, atol=0)
+    assert not res.sample_totaldp.get().any()
