@@ -864,6 +864,194 @@ __device__ float np_sum_f32(const float* x, int n) {
     return 0.f + ret;
 }
 
+// Single pass for loci with few alleles (A <= DQ_A): the locus's tables sit in LDS, the row sums
+// are numpy's plain left-to-right float32 sums (fewer than 8 terms), and the per-class sums are
+// kept in lane-private LDS columns (sized by the batch's largest allele set), so that nothing is
+// read twice.  4 waves per workgroup, one locus per wave; the next 64 samples' operands are
+// loaded while the current ones are processed.  Same arithmetic as k_assoc_dosage.
+constexpr int DQ_A = 8;    // alleles (ref + 7 alternates: numpy sums fewer than 8 floats sequentially)
+__global__ __launch_bounds__(256) void k_assoc_dosage_small(const AssocArgs a, const DosArgs q, int cmax) {
+    extern __shared__ double dq_lds[];               // [4 waves][cmax * 4][64 lanes] class accumulators
+    __shared__ int tab_perm[4][DQ_A], tab_cls[4][DQ_A], tab_best[4][DQ_A];
+    __shared__ double tab_val[4][DQ_A], tab_len[4][DQ_A];
+    const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x >> 6;
+    const int l = blockIdx.x * 4 + wid;
+    if (l >= a.b.n_loci) return;
+    double (*cls_acc)[WAVE] = reinterpret_cast<double (*)[WAVE]>(dq_lds + (size_t)wid * cmax * 4 * WAVE);
+    const int S = a.b.n_samples, M = a.M, Kc = q.d.n_alt_cols;
+    const int off = a.b.allele_off[l];
+    const int A = a.b.allele_off[l + 1] - off;
+    if (lane < A) {
+        tab_perm[wid][lane] = q.d.perm[off + lane];
+        tab_cls[wid][lane] = q.d.dclass[off + lane];
+        tab_best[wid][lane] = q.d.best_class[off + lane];
+        tab_val[wid][lane] = q.d.dclass_value[off + lane];
+        tab_len[wid][lane] = a.allele_len[off + lane];
+    }
+    for (int i = 0; i < cmax * 4; ++i) cls_acc[i][lane] = 0.0;
+    wave_fence();
+    int ncls = 0;
+    for (int i = 0; i < A; ++i) ncls = max(ncls, tab_cls[wid][i] + 1);
+    const double pivot = 2.0 * tab_val[wid][tab_cls[wid][0]];
+
+    int n = 0;
+    double sg = 0.0, sgg = 0.0, sgv[AS_MAXV], corr[AS_E];
+    double rx = 0.0, rxx = 0.0, ry = 0.0, ryy = 0.0, rxy = 0.0, xmin = INFINITY, xmax = -INFINITY;
+    for (int k = 0; k < AS_MAXV; ++k) sgv[k] = 0.0;
+    for (int e = 0; e < AS_E; ++e) corr[e] = 0.0;
+    // operands of the next 64 samples, in flight while the current ones are processed
+    uint32_t w_n = 0xffffffffu;
+    float ap_n[2][DQ_A - 1];
+    bool in_n = false;
+    auto fetch = [&](int s) {
+        w_n = 0xffffffffu;
+        in_n = false;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int i = 0; i < DQ_A - 1; ++i) ap_n[p][i] = 0.f;
+        if (s < S) {
+            in_n = !a.sample_in || a.sample_in[s];
+            w_n = reinterpret_cast<const uint32_t*>(a.b.gt)[(int64_t)l * S + s];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const float* ap = (p ? q.d.ap2 : q.d.ap1) + ((int64_t)l * S + s) * Kc;
+#pragma unroll
+                for (int i = 0; i < DQ_A - 1; ++i)
+                    if (i < A - 1) ap_n[p][i] = ap[i];
+            }
+        }
+    };
+    fetch(lane);
+    for (int s0 = 0; s0 < S; s0 += WAVE) {
+        const int s = s0 + lane;
+        const uint32_t w = w_n;
+        float apv[2][DQ_A - 1];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int i = 0; i < DQ_A - 1; ++i) apv[p][i] = ap_n[p][i];
+        bool in = in_n, miss = false;
+        fetch(s + WAVE);
+        if (s < S) {
+            const int a0 = (int)(int16_t)(w & 0xffffu), a1 = (int)(int16_t)(w >> 16);
+            miss = (a0 == -1) | (a1 == -1);
+            if (in && !miss) {
+                float x[2][DQ_A];   // x[p][allele]: AP value of every allele (the reference allele derived)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int i = 1; i < DQ_A; ++i) {
+                        const float v = apv[p][i - 1];
+                        x[p][i] = v;
+                        if (i < A) sum += v;
+                    }
+                    x[p][0] = fmaxf(0.f, 1.f - sum);
+                }
+                double g = 0.0, y[2] = {0.0, 0.0}, d[2] = {0.0, 0.0};
+                int u = tab_cls[wid][tab_perm[wid][0]];
+                const int b0 = (a0 >= 0 && a0 < A) ? tab_best[wid][a0] : 0xffff;
+                const int b1 = (a1 >= 0 && a1 < A) ? tab_best[wid][a1] : 0xffff;
+                for (int i = 0; i <= A; ++i) {
+                    const int al = i < A ? tab_perm[wid][i] : -1;
+                    const int u2 = i < A ? tab_cls[wid][al] : -1;
+                    if (u2 != u) {  // class u complete
+                        const double lv = tab_val[wid][u];
+                        g += lv * (d[0] + d[1]);
+                        y[0] += lv * d[0];
+                        y[1] += lv * d[1];
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            const double xi = ((p ? b1 : b0) == u) ? 1.0 : 0.0;
+                            cls_acc[u * 4 + 0][lane] += d[p];
+                            cls_acc[u * 4 + 1][lane] += d[p] * d[p];
+                            cls_acc[u * 4 + 2][lane] += xi;
+                            cls_acc[u * 4 + 3][lane] += xi * d[p];
+                        }
+                        u = u2;
+                        d[0] = d[1] = 0.0;
+                    }
+                    if (i < A) {
+                        float v0 = x[0][0], v1 = x[1][0];
+#pragma unroll
+                        for (int t = 1; t < DQ_A; ++t) {   // static register indexing
+                            v0 = al == t ? x[0][t] : v0;
+                            v1 = al == t ? x[1][t] : v1;
+                        }
+                        d[0] += (double)v0;
+                        d[1] += (double)v1;
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int al = p ? a1 : a0;
+                    const double xv = al == -2 ? -2.0 : (al >= 0 && al < A ? tab_len[wid][al] : 0.0);
+                    xmin = fmin(xmin, xv);
+                    xmax = fmax(xmax, xv);
+                    rx += xv;
+                    rxx += xv * xv;
+                    ry += y[p];
+                    ryy += y[p] * y[p];
+                    rxy += xv * y[p];
+                }
+                g -= pivot;
+                ++n;
+                sg += g;
+                sgg = __builtin_fma(g, g, sgg);
+                for (int k = 0; k < M; ++k) sgv[k] = __builtin_fma(g, a.vec[(size_t)k * S + s], sgv[k]);
+            }
+        }
+        uint64_t mm = __ballot(in & miss);
+        while (mm) {
+            const int src = __ffsll((long long)mm) - 1;
+            mm &= mm - 1;
+            const int sm = s0 + src;
+            for (int e = 0; e < AS_E; ++e) {
+                const int idx = lane + e * WAVE;
+                if (idx >= a.NC) continue;
+                const double xa = a.pa[idx] == M ? 1.0 : a.vec[(size_t)a.pa[idx] * S + sm];
+                const double xb = a.pb[idx] == M ? 1.0 : a.vec[(size_t)a.pb[idx] * S + sm];
+                corr[e] += xa * xb;
+            }
+        }
+    }
+    double* rec = a.partial + (size_t)l * a.NS;
+    n = wave_sum_i32(n);
+    sg = wave_sum_f64(sg);
+    sgg = wave_sum_f64(sgg);
+    rx = wave_sum_f64(rx);
+    rxx = wave_sum_f64(rxx);
+    ry = wave_sum_f64(ry);
+    ryy = wave_sum_f64(ryy);
+    rxy = wave_sum_f64(rxy);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        xmin = fmin(xmin, __shfl_xor(xmin, o, WAVE));
+        xmax = fmax(xmax, __shfl_xor(xmax, o, WAVE));
+    }
+    if (lane == 0) {
+        rec[0] = (double)n;
+        rec[1] = sg;
+        rec[2] = sgg;
+        rec[a.NS - 1] = 0.0;
+        double* ls = q.locus_sums + (size_t)l * TRK_ADL_COLS;
+        ls[0] = rx; ls[1] = rxx; ls[2] = ry; ls[3] = ryy; ls[4] = rxy; ls[5] = 2.0 * n; ls[6] = xmin; ls[7] = xmax;
+    }
+    for (int k = 0; k < M; ++k) {
+        const double t = wave_sum_f64(sgv[k]);
+        if (lane == 0) rec[3 + k] = t;
+    }
+    for (int e = 0; e < AS_E; ++e) {
+        const int idx = lane + e * WAVE;
+        if (idx < a.NC) rec[3 + M + idx] = corr[e];
+    }
+    for (int i = 0; i < ncls * 4; ++i) {
+        const double t = wave_sum_f64(cls_acc[i][lane]);
+        if (lane == 0) q.class_sums[(size_t)(off + (i >> 2)) * TRK_ADC_COLS + (i & 3)] = t;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_assoc_dosage(const AssocArgs a, const DosArgs q) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int l = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1768,7 +1956,15 @@ hipError_t launch_assoc_dosage(const trk_batch& b, const trk_assoc_params& prm, 
     if (b.n_loci == 0) return hipSuccess;
     hipLaunchKernelGGL(k_assoc_gram, dim3(a.NC), dim3(256), 0, stream, a, full);
     DosArgs q{dos, class_sums, locus_sums};
-    hipLaunchKernelGGL(k_assoc_dosage, dim3((b.n_loci + 3) / 4), dim3(256), 0, stream, a, q);
+    // few alleles everywhere (and diploid, which Beagle output is): the single-pass kernel
+    if (b.max_alleles > 0 && b.max_alleles <= DQ_A && b.ploidy == 2 && !b.locus_ploidy && !getenv("TRK_AS_DOSAGE_GENERIC"))
+    {
+        const int cmax = b.max_alleles;   // classes <= alleles
+        hipLaunchKernelGGL(k_assoc_dosage_small, dim3((b.n_loci + 3) / 4), dim3(256), (size_t)4 * cmax * 4 * WAVE * 8, stream, a,
+                           q, cmax);
+    }
+    else
+        hipLaunchKernelGGL(k_assoc_dosage, dim3((b.n_loci + 3) / 4), dim3(256), 0, stream, a, q);
     if ((err = hipGetLastError()) != hipSuccess) return err;
     f.dosage = 1;
     const int P = prm.n_vec + 1;
