@@ -107,11 +107,15 @@ class Variant:
                  '_filter', 'INFO', 'FORMAT', '_tail', '_samples_list', '_cols', '_fmt_cache',
                  '_gt', '_gtlist', 'ploidy', '_set_formats', '_info_dirty')
 
-    def __init__(self, reader, line, gt=None, native=None):
+    def __init__(self, reader, line, gt=None, native=None, tail=None):
         """``gt`` (int16 [S, P+1], cyvcf2 layout) and ``native`` ({FORMAT key: array [S, k]}) are
         supplied by the native reader (trtools_amd.vcfnative); the sample columns are then only
-        split in Python if a field that was not decoded natively is asked for."""
+        split in Python if a field that was not decoded natively is asked for.  With ``tail``
+        (bytes of the sample columns) ``line`` holds the nine fixed columns only and the sample text
+        is decoded on first use."""
         f = line.rstrip('\r\n').split('\t', 9)
+        if tail is not None:
+            f = f[:9] + [tail]
         self._reader = reader
         self._fields = f
         self.CHROM = f[0]
@@ -144,6 +148,8 @@ class Variant:
     @property
     def _samples(self):
         if self._samples_list is None:
+            if isinstance(self._tail, bytes):
+                self._tail = self._tail.decode().rstrip('\r\n')
             self._samples_list = self._tail.split('\t') if self._tail else []
         return self._samples_list
 

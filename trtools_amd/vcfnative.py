@@ -130,13 +130,21 @@ class NativeVCFReader(vcfio.VCFReader):
         m = b.n_records
         rows = []
         for i in range(m):
-            line = C.string_at(b.text + b.line_off[i], b.line_end[i] - b.line_off[i]).decode()
+            # the nine fixed columns as text now; the sample columns (most of the line) stay bytes until a field
+            # that was not decoded natively is asked for
+            f9 = int(b.field_off[i * 10 + 9])
+            n_line = b.line_end[i] - b.line_off[i]
+            if 0 < f9 < n_line:
+                line = C.string_at(b.text + b.line_off[i], f9 - 1).decode()
+                tail = C.string_at(b.text + b.line_off[i] + f9, n_line - f9)
+            else:
+                line, tail = C.string_at(b.text + b.line_off[i], n_line).decode(), None
             pl = int(lp[i])
             g = np.empty((S, pl + 1), dtype=np.int16)
             g[:, :pl] = gt[i, :, :pl]
             g[:, pl] = ph[i]
             native = {k: planes[j][i] for j, (k, _, _, _) in enumerate(self._selected)}
-            rows.append((line, g, native))
+            rows.append((line, g, native, tail))
         self._rows, self._row_i = rows, 0
         self._eof = m == 0
         self.last_batch = dict(gt=gt[:m], phased=ph[:m], locus_ploidy=lp[:m],
@@ -150,9 +158,9 @@ class NativeVCFReader(vcfio.VCFReader):
                 self._next_batch()
                 if self._eof:
                     raise StopIteration
-            line, g, native = self._rows[self._row_i]
+            line, g, native, tail = self._rows[self._row_i]
             self._row_i += 1
-            v = vcfio.Variant(self, line, gt=g if self.n_samples else None, native=native)
+            v = vcfio.Variant(self, line, gt=g if self.n_samples else None, native=native, tail=tail)
             if v.CHROM not in self.contigs_declared and v.CHROM not in self.contigs_seen:
                 self.contigs_seen.append(v.CHROM)
             if self._region is not None and not self._in_region(v):
