@@ -201,12 +201,18 @@ int trk_locus_finalize(trk_ctx* ctx, const trk_batch* in, const trk_stats_params
                        trk_stats_out* out);
 
 /* ---- dumpSTR call-level filters ------------------------------------------ */
-enum { TRK_DT_I32 = 0, TRK_DT_F32 = 1 };
+enum { TRK_DT_I32 = 0, TRK_DT_F32 = 1,
+       TRK_DT_PLANAR = 0x100 /* or'ed in: data is [ncol, L, S] -- one contiguous [L, S] array per column.  Every
+                                column then streams as 16-byte vectors like a single-column plane (GangSTR's
+                                QEXP / RC / REPCN / REPCI: 1.7 -> TB/s of the per-call path otherwise)          */ };
 typedef struct {
-    const void* data;   /* device [L, S, ncol]                                     */
-    int32_t dtype;      /* TRK_DT_*; int32 missing = INT_MIN, float32 missing = nan */
+    const void* data;   /* device [L, S, ncol], or [ncol, L, S] with TRK_DT_PLANAR    */
+    int32_t dtype;      /* TRK_DT_I32 / TRK_DT_F32 (| TRK_DT_PLANAR); int32 missing = INT_MIN, float32 missing = nan */
     int32_t ncol;
 } trk_plane;
+/* [n_cells, ncol] -> [ncol, n_cells] for 4-byte elements (device to device; a helper for callers whose FORMAT
+ * planes are produced interleaved).                                                                           */
+int trk_planarize(trk_ctx* ctx, const void* src, void* dst, int64_t n_cells, int32_t ncol);
 
 /* Filter opcodes: one per distinct arithmetic in dumpSTR/filters.py.           */
 enum {

@@ -115,13 +115,17 @@ def test_hipstr_shape_filters(eng, n_loci, n_samples):
         assert c[L.LC_HWE_ERRORS] == n_raise
 
 
-def test_gangstr_and_popstr_shape_filters(eng):
-    """QEXP / RC / REPCN+REPCI / AD filters (filters.py:573-867) incl. ploidy 1-3."""
+@pytest.mark.parametrize("layout,S", [('interleaved', 96), ('planar', 96), ('interleaved', 1000), ('planar', 1000),
+                                      ('planarize', 1003)])
+def test_gangstr_and_popstr_shape_filters(eng, layout, S):
+    """QEXP / RC / REPCN+REPCI / AD filters (filters.py:573-867) incl. ploidy 1-3.  Multi-column planes in
+    both device layouts: interleaved [L, S, k] and planar [k, L, S] (TRK_DT_PLANAR; uploaded that way or
+    transposed on the device by trk_planarize)."""
     from oracle import trtools_oracle as orc
     from trtools_amd import _lib as L
     from trtools_amd.synth import pack_alleles
     rng = np.random.default_rng(11)
-    Lc, S, P = 40, 96, 2
+    Lc, P = 40, 2
     A = 5
     gt = rng.integers(0, A, size=(Lc, S, P)).astype(np.int16)
     gt[rng.random((Lc, S)) < 0.1] = -1
@@ -151,8 +155,14 @@ def test_gangstr_and_popstr_shape_filters(eng):
     nocall = np.any(gt == -1, axis=2)
     dp[nocall & (rng.random((Lc, S)) < 0.8)] = INT_MIN
     b = eng.make_batch(gt, off, lc, sc, cv)
-    planes = [eng.upload(dp), eng.upload(qexp), eng.upload(rc), eng.upload(repcn), eng.upload(repci),
-              eng.upload(ad)]
+    if layout == 'planar':
+        up = eng.upload_plane
+    elif layout == 'planarize':
+        up = lambda a: eng.planarize(eng.upload(a))
+    else:
+        up = eng.upload
+    planes = [up(dp), up(qexp), up(rc), up(repcn), up(repci), up(ad)]
+    assert getattr(planes[2], 'planar', False) == (layout != 'interleaved')
     # BuildCallFilters order (dumpSTR.py:819-836, 867-872)
     filters = [dict(op=L.F_LT, plane_a=0, thr=5), dict(op=L.F_GT, plane_a=0, thr=35),
                dict(op=L.F_CALLED_LT, plane_a=1, col_a=1, thr=0.2),

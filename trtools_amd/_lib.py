@@ -28,6 +28,7 @@ KERNEL_NAMES = ['k_locus_count', 'k_locus_finalize', 'k_call_filter', 'k_locus_f
 F_LT, F_GT, F_RATIO_GT, F_CALLED_LT, F_CALLED_SUM_LT, F_CALLED_EQ, F_CALLED_SUM_EQ, \
     F_CALLED_OUTSIDE_CI, F_AD_SUPPORT_LT = range(1, 10)
 DT_I32, DT_F32 = 0, 1
+DT_PLANAR = 0x100
 # locus filter bits / counters
 LOCF_CALLRATE, LOCF_HWE, LOCF_HETLOW, LOCF_HETHIGH, LOCF_EXTERN0 = 0, 1, 2, 3, 4
 LOCF_NO_CALLS = 31
@@ -122,7 +123,7 @@ EXPORTS = [
     'trk_locus_stats', 'trk_locus_finalize', 'trk_call_filters', 'trk_locus_filters',
     'trk_comm_unique_id', 'trk_comm_init', 'trk_allreduce_sum_i64', 'trk_allgather',
     'trk_binomtest_two_sided', 'trk_binom_pmf', 'trk_synth_fill', 'trk_synth_fill_gangstr',
-    'trk_assoc_scan', 'trk_assoc_scan_dosage', 'trk_student_t_two_sided', 'trk_dosages',
+    'trk_assoc_scan', 'trk_assoc_scan_dosage', 'trk_student_t_two_sided', 'trk_dosages', 'trk_planarize',
 ]
 
 _lib = None
@@ -180,6 +181,7 @@ def load():
     lib.trk_binom_pmf.restype = dbl
     lib.trk_assoc_scan.argtypes = [vp, P(Batch), P(AssocParams), P(AssocOut)]
     lib.trk_assoc_scan_dosage.argtypes = [vp, P(Batch), P(AssocParams), P(AssocDosage), P(AssocOut), vp, vp]
+    lib.trk_planarize.argtypes = [vp, vp, vp, i64, C.c_int32]
     lib.trk_dosages.argtypes = [vp, P(Batch), vp, C.c_int, vp, vp, C.c_int, vp, vp]
     lib.trk_student_t_two_sided.argtypes = [dbl, dbl]
     lib.trk_student_t_two_sided.restype = dbl

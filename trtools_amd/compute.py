@@ -75,7 +75,7 @@ class DeviceCompute:
         Returns (CallHost, StatsHost, locus_bits uint32[L], loc_counters int64[32])."""
         eng = self.eng
         b = self._upload(hb)
-        dplanes = [eng.upload(p) for p in planes]
+        dplanes = [eng.upload_plane(p) for p in planes]
         # counts of the unfiltered genotypes, corrected by the call-filter kernel for every call it
         # masks (dumpSTR.py:721-774 rebuilds the record; here no second pass over the tensor), then
         # the finaliser

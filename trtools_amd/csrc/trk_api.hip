@@ -410,7 +410,7 @@ int trk_call_filters(trk_ctx* ctx, const trk_batch* in, const trk_plane* planes,
     if (n_planes < 0 || n_planes > TRK_MAX_PLANES) return fail(ctx, TRK_ERR_ARG, "n_planes %d > %d", n_planes, TRK_MAX_PLANES);
     if (n_filters < 0 || n_filters > TRK_MAX_FILTERS)
         return fail(ctx, TRK_ERR_ARG, "n_filters %d > %d", n_filters, TRK_MAX_FILTERS);
-    if (dp_plane >= 0 && dp_plane < n_planes && planes && planes[dp_plane].dtype == TRK_DT_F32 && out &&
+    if (dp_plane >= 0 && dp_plane < n_planes && planes && (planes[dp_plane].dtype & 0xff) == TRK_DT_F32 && out &&
         !out->sample_totaldp_f64)
         return fail(ctx, TRK_ERR_ARG, "a Float depth plane needs sample_totaldp_f64");
     if (!out || !out->sample_counters || !out->sample_totaldp || !out->sample_dp_missing || !out->error)
@@ -422,7 +422,7 @@ int trk_call_filters(trk_ctx* ctx, const trk_batch* in, const trk_plane* planes,
         return fail(ctx, TRK_ERR_ARG, "delta outputs are defined for ungrouped batches only");
     for (int i = 0; i < n_planes; ++i) {
         if (!planes[i].data || planes[i].ncol < 1) return fail(ctx, TRK_ERR_ARG, "plane %d is empty", i);
-        if (planes[i].dtype != TRK_DT_I32 && planes[i].dtype != TRK_DT_F32)
+        if ((planes[i].dtype & ~TRK_DT_PLANAR) != TRK_DT_I32 && (planes[i].dtype & ~TRK_DT_PLANAR) != TRK_DT_F32)
             return fail(ctx, TRK_ERR_ARG, "plane %d has unknown dtype", i);
     }
     for (int k = 0; k < n_filters; ++k) {
@@ -445,7 +445,7 @@ int trk_call_filters(trk_ctx* ctx, const trk_batch* in, const trk_plane* planes,
             return fail(ctx, TRK_ERR_ARG, "filter %d: REPCI plane needs 2 columns per REPCN column", k);
         if ((f.op == TRK_F_CALLED_EQ || f.op == TRK_F_CALLED_SUM_EQ || f.op == TRK_F_CALLED_OUTSIDE_CI ||
              f.op == TRK_F_AD_SUPPORT_LT) &&
-            planes[f.plane_a].dtype != TRK_DT_I32)
+            (planes[f.plane_a].dtype & 0xff) != TRK_DT_I32)
             return fail(ctx, TRK_ERR_ARG, "filter %d: integer plane required", k);
     }
     if (in->n_loci == 0 || in->n_samples == 0) return TRK_OK;
@@ -619,6 +619,15 @@ int trk_dosages(trk_ctx* ctx, const trk_batch* in, const double* allele_len, int
     if (in->n_loci > 65535) return fail(ctx, TRK_ERR_ARG, "at most 65535 loci per dosage call");
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, trk::launch_dosages(*in, allele_len, dosage_type, ap1, ap2, n_alt_cols, out, locus_err, ctx->stream));
+    return TRK_OK;
+}
+
+int trk_planarize(trk_ctx* ctx, const void* src, void* dst, int64_t n_cells, int32_t ncol) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (!src || !dst || n_cells < 0 || ncol < 1) return fail(ctx, TRK_ERR_ARG, "planarize arguments");
+    if (n_cells == 0) return TRK_OK;
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, trk::launch_planarize(src, dst, n_cells, ncol, ctx->stream));
     return TRK_OK;
 }
 

@@ -827,81 +827,77 @@ __global__ __launch_bounds__(FIN_THREADS) void k_hwe_test(const unsigned int* __
 constexpr int CF_THREADS = 256;
 constexpr int CF_V = 4;  // samples per thread
 
-__device__ __forceinline__ double plane_val(const trk_plane& p, int64_t cell, int col) {
-    if (p.dtype == TRK_DT_I32) return (double)reinterpret_cast<const int32_t*>(p.data)[cell * p.ncol + col];
-    return (double)reinterpret_cast<const float*>(p.data)[cell * p.ncol + col];
+// element (cell, col) of a plane: [L*S, ncol] interleaved, or -- TRK_DT_PLANAR -- [ncol, L*S]
+__device__ __forceinline__ int64_t pidx(const trk_plane& p, int64_t cell, int col, int64_t nc) {
+    return (p.dtype & TRK_DT_PLANAR) ? (int64_t)col * nc + cell : cell * p.ncol + col;
+}
+__device__ __forceinline__ bool p_is_f32(const trk_plane& p) { return (p.dtype & 0xff) == TRK_DT_F32; }
+__device__ __forceinline__ int32_t p_i32(const trk_plane& p, int64_t cell, int col, int64_t nc) {
+    return reinterpret_cast<const int32_t*>(p.data)[pidx(p, cell, col, nc)];
+}
+__device__ __forceinline__ float p_f32(const trk_plane& p, int64_t cell, int col, int64_t nc) {
+    return reinterpret_cast<const float*>(p.data)[pidx(p, cell, col, nc)];
+}
+__device__ __forceinline__ double plane_val(const trk_plane& p, int64_t cell, int col, int64_t nc) {
+    if (!p_is_f32(p)) return (double)p_i32(p, cell, col, nc);
+    return (double)p_f32(p, cell, col, nc);
 }
 
-// evaluate one filter on one call; returns true when the filter fires
+// evaluate one filter on one call; returns true when the filter fires (nc = L * S)
 __device__ __forceinline__ bool eval_filter(const trk_call_filter& f, const trk_plane* planes, int64_t cell,
-                                            bool called, const int* gtv, int P, int pl) {
+                                            bool called, const int* gtv, int P, int pl, int64_t nc) {
     const trk_plane& pa = planes[f.plane_a];
     switch (f.op) {
         case TRK_F_LT:
         case TRK_F_CALLED_LT: {
             if (f.op == TRK_F_CALLED_LT && !called) return false;
-            if (pa.dtype == TRK_DT_F32) {
-                float v = reinterpret_cast<const float*>(pa.data)[cell * pa.ncol + f.col_a];
-                return v < (float)f.thr;  // numpy compares float32 arrays in float32
-            }
-            int32_t v = reinterpret_cast<const int32_t*>(pa.data)[cell * pa.ncol + f.col_a];
-            return (double)v < f.thr;
+            if (p_is_f32(pa)) return p_f32(pa, cell, f.col_a, nc) < (float)f.thr;  // numpy compares float32 arrays in float32
+            return (double)p_i32(pa, cell, f.col_a, nc) < f.thr;
         }
         case TRK_F_GT: {
-            if (pa.dtype == TRK_DT_F32) {
-                float v = reinterpret_cast<const float*>(pa.data)[cell * pa.ncol + f.col_a];
-                return v > (float)f.thr;
-            }
-            int32_t v = reinterpret_cast<const int32_t*>(pa.data)[cell * pa.ncol + f.col_a];
-            return (double)v > f.thr;
+            if (p_is_f32(pa)) return p_f32(pa, cell, f.col_a, nc) > (float)f.thr;
+            return (double)p_i32(pa, cell, f.col_a, nc) > f.thr;
         }
         case TRK_F_RATIO_GT: {
-            double a = plane_val(pa, cell, f.col_a);
-            double bb = plane_val(planes[f.plane_b], cell, f.col_b);
+            double a = plane_val(pa, cell, f.col_a, nc);
+            double bb = plane_val(planes[f.plane_b], cell, f.col_b, nc);
             return (a / bb) > f.thr;  // int32/int32 -> float64 true division
         }
         case TRK_F_CALLED_SUM_LT: {
             if (!called) return false;
-            if (pa.dtype == TRK_DT_F32) {
-                const float* d = reinterpret_cast<const float*>(pa.data) + cell * pa.ncol;
-                float s = d[f.col_a] + d[f.col_a2];
+            if (p_is_f32(pa)) {
+                float s = p_f32(pa, cell, f.col_a, nc) + p_f32(pa, cell, f.col_a2, nc);
                 return s < (float)f.thr;
             }
-            const int32_t* d = reinterpret_cast<const int32_t*>(pa.data) + cell * pa.ncol;
-            return (double)((int64_t)d[f.col_a] + (int64_t)d[f.col_a2]) < f.thr;
+            return (double)((int64_t)p_i32(pa, cell, f.col_a, nc) + (int64_t)p_i32(pa, cell, f.col_a2, nc)) < f.thr;
         }
         case TRK_F_CALLED_EQ: {
             if (!called) return false;
-            const int32_t* d = reinterpret_cast<const int32_t*>(pa.data) + cell * pa.ncol;
-            const trk_plane& pb = planes[f.plane_b];
-            int32_t bb = reinterpret_cast<const int32_t*>(pb.data)[cell * pb.ncol + f.col_b];
-            return d[f.col_a] == bb;
+            return p_i32(pa, cell, f.col_a, nc) == p_i32(planes[f.plane_b], cell, f.col_b, nc);
         }
         case TRK_F_CALLED_SUM_EQ: {
             if (!called) return false;
-            const int32_t* d = reinterpret_cast<const int32_t*>(pa.data) + cell * pa.ncol;
-            const trk_plane& pb = planes[f.plane_b];
-            int32_t bb = reinterpret_cast<const int32_t*>(pb.data)[cell * pb.ncol + f.col_b];
-            return (int64_t)d[f.col_a] + (int64_t)d[f.col_a2] == (int64_t)bb;
+            return (int64_t)p_i32(pa, cell, f.col_a, nc) + (int64_t)p_i32(pa, cell, f.col_a2, nc) ==
+                   (int64_t)p_i32(planes[f.plane_b], cell, f.col_b, nc);
         }
         case TRK_F_CALLED_OUTSIDE_CI: {
             if (!called) return false;
-            const int32_t* ml = reinterpret_cast<const int32_t*>(pa.data) + cell * pa.ncol;
             const trk_plane& pb = planes[f.plane_b];
-            const int32_t* ci = reinterpret_cast<const int32_t*>(pb.data) + cell * pb.ncol;
             bool hit = false;
-            for (int j = 0; j < pa.ncol; ++j) hit |= (ml[j] < ci[2 * j]) | (ci[2 * j + 1] < ml[j]);
+            for (int j = 0; j < pa.ncol; ++j) {
+                const int32_t ml = p_i32(pa, cell, j, nc);
+                hit = hit || ml < p_i32(pb, cell, 2 * j, nc) || p_i32(pb, cell, 2 * j + 1, nc) < ml;
+            }
             return hit;
         }
         case TRK_F_AD_SUPPORT_LT: {
             // read_support[sample, gt_idx] with numpy negative indexing (filters.py:865)
-            const int32_t* ad = reinterpret_cast<const int32_t*>(pa.data) + cell * pa.ncol;
             bool hit = false;
             for (int j = 0; j < pl; ++j) {
                 int a = gtv[j];
                 if (a < 0) a += pa.ncol;
                 if (a < 0 || a >= pa.ncol) continue;
-                hit |= (double)ad[a] < f.thr;
+                hit |= (double)p_i32(pa, cell, a, nc) < f.thr;
             }
             return hit;
         }
@@ -915,9 +911,20 @@ struct CallArgs {
     trk_plane planes[TRK_MAX_PLANES];
     trk_call_filter filters[TRK_MAX_FILTERS];
     int n_planes, n_filters, dp_plane, loci_per_block;
-    uint32_t fast_plane_mask;   // planes 0..3 with one column (fetched as 16-byte vectors)
-    uint32_t fast_filter_mask;  // LT / GT / CALLED_LT filters on a fast plane
-    uint32_t slow_filter_mask;  // everything else
+    int loci_per_wg;            // streaming kernel: loci of one workgroup, walked in sub-blocks of loci_per_block
+    int64_t n_cells;            // L * S (column stride of planar planes)
+    // vector sources of the streaming kernel: single-column planes and single columns of planar planes,
+    // each a [L*S] array of 4-byte elements fetched as one 16-byte vector per thread and locus
+    const void* src_ptr[16];
+    uint32_t src_f32_mask;      // source holds float32
+    int32_t n_src;
+    int8_t f_src_a[TRK_MAX_FILTERS], f_src_a2[TRK_MAX_FILTERS], f_src_b[TRK_MAX_FILTERS];  // operands of filter k
+    int8_t f_ci[TRK_MAX_FILTERS][6];  // OUTSIDE_CI: sources of ml_j, lo_j, hi_j (j < f_ci_n <= 2)
+    int8_t f_ci_n[TRK_MAX_FILTERS];
+    int8_t dp_src;              // source of the DP/LC plane, -1: read per call
+    uint32_t reg_filter_mask;   // filters all of whose operands are sources: evaluated on the registers
+    uint32_t int_thr_mask;      // LT/GT on an int32 source with the threshold folded to an integer (f_ithr)
+    int32_t f_ithr[TRK_MAX_FILTERS];
     int32_t delta_stride;       // LDS words per locus of the delta table (max_alleles + 4), 0 = no delta
     int32_t dbg;
     trk_call_out out;
@@ -1010,7 +1017,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter(const CallArgs a) {
                 const bool called = !miss;  // GetCalledSamples (dumpSTR.py:651)
                 uint32_t m = 0;
                 for (int k = 0; k < nf; ++k) {
-                    if (eval_filter(a.filters[k], a.planes, cell, called, gtv, P, pl)) {
+                    if (eval_filter(a.filters[k], a.planes, cell, called, gtv, P, pl, a.n_cells)) {
                         m |= 1u << k;
                         if (called) fcount[(k * CF_THREADS + tid) * CF_V + j]++;  // dumpSTR.py:661
                     }
@@ -1019,12 +1026,12 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter(const CallArgs a) {
                 mask[j] = m;
                 if (m == 0) {  // 'PASS'  (dumpSTR.py:686-713)
                     numcalls[j]++;
-                    if (a.dp_plane >= 0 && a.planes[a.dp_plane].dtype == TRK_DT_F32) {
+                    if (a.dp_plane >= 0 && p_is_f32(a.planes[a.dp_plane])) {
                         // Float depth (dumpSTR.py:688-713 on a float32 array): nan is neither negative nor
                         // positive; sums of float32 values are exact in float64 at these magnitudes, so the
                         // order of the atomics does not show
                         const trk_plane& dp = a.planes[a.dp_plane];
-                        const float d = reinterpret_cast<const float*>(dp.data)[cell * dp.ncol];
+                        const float d = p_f32(dp, cell, 0, a.n_cells);
                         if (d < 0.f) {
                             if (atomicCAS(&a.out.error[0], 0, 1) == 0) {
                                 a.out.error[1] = l;
@@ -1035,7 +1042,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter(const CallArgs a) {
                         }
                     } else if (a.dp_plane >= 0) {
                         const trk_plane& dp = a.planes[a.dp_plane];
-                        int32_t d = reinterpret_cast<const int32_t*>(dp.data)[cell * dp.ncol];
+                        int32_t d = p_i32(dp, cell, 0, a.n_cells);
                         if (d == INT32_MIN) {
                             dpmiss[j]++;
                         } else if (d < 0) {
@@ -1098,20 +1105,65 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter(const CallArgs a) {
 // on the registers.  Filters that need two planes or multi-column planes take
 // the per-call path (eval_filter).  U loci are in flight per thread.
 // ---------------------------------------------------------------------------
-constexpr int CF_FASTP = 4;
+constexpr int CF_NSRC = 16;  // most vector sources of one launch; the kernel is built for 4, 8, 12 and 16
 
+template <int NS>
 struct CfLocus {
     u32x4 gt;
-    u32x4 pv[CF_FASTP];
+    u32x4 sv[NS];
 };
 
-__device__ __forceinline__ void cf_load(const CallArgs& a, int64_t cell0, CfLocus& d) {
+template <int NS>
+__device__ __forceinline__ void cf_load(const CallArgs& a, int64_t cell0, CfLocus<NS>& d) {
     d.gt = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.b.gt) + (cell0 >> 2));
 #pragma unroll
-    for (int p = 0; p < CF_FASTP; ++p)
-        if ((a.fast_plane_mask >> p) & 1u)
-            d.pv[p] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.planes[p].data) + (cell0 >> 2));
+    for (int q = 0; q < NS; ++q)
+        if (q < a.n_src)
+            d.sv[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.src_ptr[q]) + (cell0 >> 2));
 }
+
+// the four values of source `idx` (uniform across the wave): static register indexing behind uniform guards
+template <int NS>
+__device__ __forceinline__ void cf_gather(const CfLocus<NS>& d, int idx, uint32_t* out) {
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+        if (q == idx) {
+            out[0] = d.sv[q][0];
+            out[1] = d.sv[q][1];
+            out[2] = d.sv[q][2];
+            out[3] = d.sv[q][3];
+        }
+}
+
+// Class LUT of a locus block in LDS, built by the whole workgroup: lutb[li][q] = len_class | str_class << 16 of
+// allele q, linfo[li] = {A, flag, scratch}; flag: some alleles share a class (max class + 1 < A), so that the
+// homozygosity of a filtered call needs the LUT.  Ends with a barrier.
+constexpr int CF_LINFO = 3;
+__device__ __forceinline__ void cf_build_lut(const trk_batch& b, int l_begin, int nl, int nal, int tid,
+                                             uint32_t* lutb, int32_t* linfo) {
+    for (int li = tid; li < nl; li += CF_THREADS) {
+        linfo[CF_LINFO * li] = b.allele_off[l_begin + li + 1] - b.allele_off[l_begin + li];
+        linfo[CF_LINFO * li + 1] = 0;
+        linfo[CF_LINFO * li + 2] = 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < nl * nal; i += CF_THREADS) {
+        const int li = i / nal, q = i - li * nal;
+        if (q >= linfo[CF_LINFO * li]) continue;
+        const int off = b.allele_off[l_begin + li];
+        const int lc = b.len_class[off + q], sc = b.str_class[off + q];
+        lutb[i] = (uint32_t)lc | ((uint32_t)sc << 16);
+        atomicMax(&linfo[CF_LINFO * li + 1], lc);
+        atomicMax(&linfo[CF_LINFO * li + 2], sc);
+    }
+    __syncthreads();
+    for (int li = tid; li < nl; li += CF_THREADS) {
+        const int A = linfo[CF_LINFO * li];
+        linfo[CF_LINFO * li + 1] = ((linfo[CF_LINFO * li + 1] + 1 < A) | (linfo[CF_LINFO * li + 2] + 1 < A)) ? 1 : 0;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ bool cf_lut_needed(const int32_t* linfo, int li) { return linfo[CF_LINFO * li + 1] != 0; }
 
 // per-locus delta context of the streaming call-filter kernel (all in LDS, filled at block start)
 struct CfDelta {
@@ -1122,6 +1174,12 @@ struct CfDelta {
     bool dup;             // some alleles share a class: homozygosity needs the LUT
 };
 
+// words after the allele bins of a locus's delta table: a bin for indices outside the locus's alleles,
+// W0 = filtered calls | low-ploidy calls << 16, W1 = length-homozygous | sequence-homozygous << 16
+enum { V2_TRASH = 0, V2_W0 = 1, V2_W1 = 2, V2_EXTRA = 3 };
+
+// a called genotype that a filter masks to no-call: what it removes from the locus counts.  (The packed,
+// branch-free form of k_call_filter_v2 costs this kernel five more VGPRs and a wave of occupancy.)
 __device__ __forceinline__ void cf_delta_call(const CfDelta& c, uint32_t w, int pl) {
     const int a0 = (int)(int16_t)(w & 0xffffu);
     const int a1 = pl > 1 ? (int)(int16_t)(w >> 16) : -3;
@@ -1144,9 +1202,11 @@ __device__ __forceinline__ void cf_delta_call(const CfDelta& c, uint32_t w, int 
     }
 }
 
+template <int NS, bool ALLREG>
 __device__ __forceinline__ void cf_process(const CallArgs& a, int l, int64_t cell0, int64_t s0, int tid,
-                                           const CfLocus& d, uint32_t* fcount, uint32_t* numcalls,
-                                           int64_t* totaldp, uint32_t* dpmiss, const CfDelta* dc) {
+                                           const CfLocus<NS>& d, uint32_t* fcount, uint32_t* numcalls,
+                                           int64_t* totaldp, uint32_t* dpmiss, const CfDelta dc,
+                                           const bool has_delta) {
     const int nf = a.n_filters;
     const int pl = a.b.locus_ploidy ? min((int)a.b.locus_ploidy[l], 2) : 2;
     uint32_t w[CF_V] = {d.gt[0], d.gt[1], d.gt[2], d.gt[3]};
@@ -1159,66 +1219,120 @@ __device__ __forceinline__ void cf_process(const CallArgs& a, int l, int64_t cel
         called[j] = !(m0 | m1);
         mask[j] = called[j] ? 0u : TRK_MASK_NOCALL;
     }
-#pragma unroll
-    for (int p = 0; p < CF_FASTP; ++p) {
-        if (!((a.fast_plane_mask >> p) & 1u)) continue;
-        const bool isf = a.planes[p].dtype == TRK_DT_F32;
-        for (int k = 0; k < nf; ++k) {
-            if (!((a.fast_filter_mask >> k) & 1u)) continue;
-            const trk_call_filter& f = a.filters[k];
-            if (f.plane_a != p) continue;
-            const bool gt_op = f.op == TRK_F_GT;
-            const bool need_called = f.op == TRK_F_CALLED_LT;
+    for (int k = 0; k < nf; ++k) {
+        const trk_call_filter& f = a.filters[k];
+        bool hit[CF_V];
+        if (ALLREG || ((a.reg_filter_mask >> k) & 1u)) {
+            // every operand is a vector source already in registers
+            const bool af = (a.src_f32_mask >> a.f_src_a[k]) & 1u;
+            uint32_t oa[CF_V] = {0, 0, 0, 0}, oa2[CF_V] = {0, 0, 0, 0}, ob[CF_V] = {0, 0, 0, 0};
+            if (a.f_src_a[k] >= 0) cf_gather(d, a.f_src_a[k], oa);
+            if (a.f_src_a2[k] >= 0) cf_gather(d, a.f_src_a2[k], oa2);
+            if (a.f_src_b[k] >= 0) cf_gather(d, a.f_src_b[k], ob);
             const float thrf = (float)f.thr;
+            switch (f.op) {
+                case TRK_F_LT:
+                case TRK_F_CALLED_LT:
+                case TRK_F_GT: {
+                    const bool gt_op = f.op == TRK_F_GT, need = f.op == TRK_F_CALLED_LT;
+                    const bool ithr_ok = (a.int_thr_mask >> k) & 1u;
+                    const int32_t ithr = a.f_ithr[k];
 #pragma unroll
-            for (int j = 0; j < CF_V; ++j) {
-                bool hit;
-                if (isf) {
-                    const float v = __uint_as_float(d.pv[p][j]);
-                    hit = gt_op ? (v > thrf) : (v < thrf);
-                } else {
-                    const double v = (double)(int32_t)d.pv[p][j];
-                    hit = gt_op ? (v > f.thr) : (v < f.thr);
+                    for (int j = 0; j < CF_V; ++j) {
+                        bool h;
+                        if (ithr_ok) {
+                            const int32_t v = (int32_t)oa[j];
+                            h = gt_op ? (v > ithr) : (v < ithr);
+                        } else if (af) {
+                            const float v = __uint_as_float(oa[j]);
+                            h = gt_op ? (v > thrf) : (v < thrf);   // numpy compares float32 arrays in float32
+                        } else {
+                            const double v = (double)(int32_t)oa[j];
+                            h = gt_op ? (v > f.thr) : (v < f.thr);
+                        }
+                        hit[j] = h & (called[j] | !need);
+                    }
+                    break;
                 }
-                hit &= called[j] | !need_called;
-                mask[j] |= hit ? (1u << k) : 0u;
-                if (hit & called[j]) atomicAdd(&fcount[(k * CF_THREADS + tid) * CF_V + j], 1u);
+                case TRK_F_RATIO_GT: {
+                    const bool bf = (a.src_f32_mask >> a.f_src_b[k]) & 1u;
+#pragma unroll
+                    for (int j = 0; j < CF_V; ++j) {
+                        const double x = af ? (double)__uint_as_float(oa[j]) : (double)(int32_t)oa[j];
+                        const double y = bf ? (double)__uint_as_float(ob[j]) : (double)(int32_t)ob[j];
+                        hit[j] = (x / y) > f.thr;
+                    }
+                    break;
+                }
+                case TRK_F_CALLED_SUM_LT: {
+#pragma unroll
+                    for (int j = 0; j < CF_V; ++j) {
+                        bool h;
+                        if (af) {
+                            const float sum = __uint_as_float(oa[j]) + __uint_as_float(oa2[j]);
+                            h = sum < thrf;
+                        } else {
+                            h = (double)((int64_t)(int32_t)oa[j] + (int64_t)(int32_t)oa2[j]) < f.thr;
+                        }
+                        hit[j] = h & called[j];
+                    }
+                    break;
+                }
+                case TRK_F_CALLED_EQ: {
+#pragma unroll
+                    for (int j = 0; j < CF_V; ++j) hit[j] = called[j] & ((int32_t)oa[j] == (int32_t)ob[j]);
+                    break;
+                }
+                case TRK_F_CALLED_SUM_EQ: {
+#pragma unroll
+                    for (int j = 0; j < CF_V; ++j)
+                        hit[j] = called[j] & ((int64_t)(int32_t)oa[j] + (int64_t)(int32_t)oa2[j] == (int64_t)(int32_t)ob[j]);
+                    break;
+                }
+                case TRK_F_CALLED_OUTSIDE_CI: {
+#pragma unroll
+                    for (int j = 0; j < CF_V; ++j) hit[j] = false;
+                    for (int c = 0; c < a.f_ci_n[k]; ++c) {
+                        uint32_t ml[CF_V] = {0, 0, 0, 0}, lo[CF_V] = {0, 0, 0, 0}, hi[CF_V] = {0, 0, 0, 0};
+                        cf_gather(d, a.f_ci[k][3 * c], ml);
+                        cf_gather(d, a.f_ci[k][3 * c + 1], lo);
+                        cf_gather(d, a.f_ci[k][3 * c + 2], hi);
+#pragma unroll
+                        for (int j = 0; j < CF_V; ++j)
+                            hit[j] |= called[j] & (((int32_t)ml[j] < (int32_t)lo[j]) | ((int32_t)hi[j] < (int32_t)ml[j]));
+                    }
+                    break;
+                }
+                default:
+#pragma unroll
+                    for (int j = 0; j < CF_V; ++j) hit[j] = false;
             }
-        }
-    }
-    if (a.slow_filter_mask) {
-        for (int k = 0; k < nf; ++k) {
-            if (!((a.slow_filter_mask >> k) & 1u)) continue;
+        } else {
 #pragma unroll
             for (int j = 0; j < CF_V; ++j) {
                 int gtv[2] = {(int)(int16_t)(w[j] & 0xffffu), (int)(int16_t)(w[j] >> 16)};
-                if (eval_filter(a.filters[k], a.planes, cell0 + j, called[j], gtv, 2, pl)) {
-                    mask[j] |= 1u << k;
-                    if (called[j]) atomicAdd(&fcount[(k * CF_THREADS + tid) * CF_V + j], 1u);
-                }
+                hit[j] = eval_filter(f, a.planes, cell0 + j, called[j], gtv, 2, pl, a.n_cells);
             }
         }
+#pragma unroll
+        for (int j = 0; j < CF_V; ++j) mask[j] |= hit[j] ? (1u << k) : 0u;
+        // per-thread counters, two samples per LDS word (a block holds <= 4096 loci: 16 bits are enough)
+        uint32_t* fc = fcount + (k * CF_THREADS + tid) * 2;
+        atomicAdd(&fc[0], (uint32_t)(hit[0] & called[0]) | ((uint32_t)(hit[1] & called[1]) << 16));
+        atomicAdd(&fc[1], (uint32_t)(hit[2] & called[2]) | ((uint32_t)(hit[3] & called[3]) << 16));
     }
-    const bool dp_fast = a.dp_plane >= 0 && a.dp_plane < CF_FASTP && ((a.fast_plane_mask >> a.dp_plane) & 1u);
+    uint32_t dpv[CF_V] = {0, 0, 0, 0};
+    if (a.dp_src >= 0) cf_gather(d, a.dp_src, dpv);
 #pragma unroll
     for (int j = 0; j < CF_V; ++j) {
-        if (mask[j] == 0) {
+        if (mask[j] == 0) {  // dumpSTR.py:686
             numcalls[j]++;
             if (a.dp_plane >= 0) {
-                int32_t dv;
-                if (dp_fast) {
-                    // static indexing only: pick the DP vector with a uniform select chain
-                    uint32_t raw = d.pv[0][j];
-#pragma unroll
-                    for (int p = 1; p < CF_FASTP; ++p) raw = a.dp_plane == p ? d.pv[p][j] : raw;
-                    dv = (int32_t)raw;
-                } else {
-                    const trk_plane& dp = a.planes[a.dp_plane];
-                    dv = reinterpret_cast<const int32_t*>(dp.data)[(cell0 + j) * dp.ncol];
-                }
+                const int32_t dv = (ALLREG || a.dp_src >= 0) ? (int32_t)dpv[j]
+                                                             : p_i32(a.planes[a.dp_plane], cell0 + j, 0, a.n_cells);
                 if (dv == INT32_MIN) {
                     dpmiss[j]++;
-                } else if (dv < 0) {
+                } else if (dv < 0) {  // dumpSTR.py:698-706
                     if (atomicCAS(&a.out.error[0], 0, 1) == 0) {
                         a.out.error[1] = l;
                         a.out.error[2] = (int32_t)(s0 + j);
@@ -1227,8 +1341,8 @@ __device__ __forceinline__ void cf_process(const CallArgs& a, int l, int64_t cel
                     totaldp[j] += dv;
                 }
             }
-        } else if (called[j]) {
-            if (dc && !(a.dbg & 1)) cf_delta_call(*dc, w[j], pl);
+        } else if (called[j]) {  // dumpSTR.py:715-727
+            if (has_delta && !(a.dbg & 1)) cf_delta_call(dc, w[j], pl);
             w[j] = pl > 1 ? 0xffffffffu : (w[j] | 0xffffu);
         }
     }
@@ -1240,70 +1354,95 @@ __device__ __forceinline__ void cf_process(const CallArgs& a, int l, int64_t cel
                                     reinterpret_cast<u32x4*>(a.out.filter_mask) + (cell0 >> 2));
 }
 
-template <int U>
-__global__ __launch_bounds__(CF_THREADS) void k_call_filter_fast(const CallArgs a) {  // U: loci in flight per thread
-    extern __shared__ uint32_t fcount[];  // [n_filters][CF_THREADS * CF_V], then the delta table
+// PF: the next locus's vectors are in flight while the current one is evaluated (two register sets).
+// ALLREG: every filter and the depth plane read vector sources only (the per-call path is compiled out).
+// A workgroup owns loci [y * loci_per_wg, ...) and walks them in sub-blocks of loci_per_block, the unit of the
+// LDS delta table; the per-sample counters live across sub-blocks and are flushed once.
+// (the instantiation that sits one register above 128 VGPRs is held to four waves per SIMD)
+template <bool PF, int NS, bool ALLREG>
+__global__ __launch_bounds__(CF_THREADS, (!PF && NS == 12 && ALLREG) ? 4 : 1) void k_call_filter_fast(const CallArgs a) {
+    extern __shared__ uint32_t fcount[];  // [n_filters][CF_THREADS][2] (16-bit pairs), then the delta table
     const int tid = threadIdx.x;
     const int S = a.b.n_samples, L = a.b.n_loci;
     const int nf = a.n_filters;
     const int64_t s0 = ((int64_t)blockIdx.x * CF_THREADS + tid) * CF_V;
-    const int l_begin = blockIdx.y * a.loci_per_block;
-    const int l_end = min(L, l_begin + a.loci_per_block);
-    for (int k = 0; k < nf; ++k)
-#pragma unroll
-        for (int j = 0; j < CF_V; ++j) fcount[(k * CF_THREADS + tid) * CF_V + j] = 0;
+    const bool live = s0 < S;  // S % 4 == 0: a thread's 4 samples are all in range or all out
+    const int wg_begin = blockIdx.y * a.loci_per_wg;
+    const int wg_end = min(L, wg_begin + a.loci_per_wg);
+    for (int k = 0; k < nf; ++k) fcount[(k * CF_THREADS + tid) * 2] = fcount[(k * CF_THREADS + tid) * 2 + 1] = 0;
     // delta context in LDS: table [loci][max_alleles + 4], class LUT [loci][max_alleles], per-locus (A, dup)
-    int32_t* dbase = nullptr;
-    uint32_t* lutb = nullptr;
-    int32_t* linfo = nullptr;
     const int dstride = a.delta_stride;
     const int nal = dstride - DX_N;
-    const int nl = l_end - l_begin;
-    if (dstride) {
-        dbase = reinterpret_cast<int32_t*>(fcount + (size_t)nf * CF_THREADS * CF_V);
-        lutb = reinterpret_cast<uint32_t*>(dbase + (size_t)a.loci_per_block * dstride);
-        linfo = reinterpret_cast<int32_t*>(lutb + (size_t)a.loci_per_block * nal);
-        for (int i = tid; i < nl * dstride; i += CF_THREADS) dbase[i] = 0;
-        for (int li = tid; li < nl; li += CF_THREADS) {
-            const int off = a.b.allele_off[l_begin + li];
-            const int A = a.b.allele_off[l_begin + li + 1] - off;
-            int ml = 0, ms = 0;
-            for (int q = 0; q < A && q < nal; ++q) {
-                const int lc = a.b.len_class[off + q], sc = a.b.str_class[off + q];
-                lutb[li * nal + q] = (uint32_t)lc | ((uint32_t)sc << 16);
-                ml = lc > ml ? lc : ml;
-                ms = sc > ms ? sc : ms;
-            }
-            linfo[2 * li] = A;
-            linfo[2 * li + 1] = ((ml + 1 < A) | (ms + 1 < A)) ? 1 : 0;
+    int32_t* const dbase = reinterpret_cast<int32_t*>(fcount + (size_t)nf * CF_THREADS * 2);
+    uint32_t* const lutb = reinterpret_cast<uint32_t*>(dbase + (size_t)a.loci_per_block * dstride);
+    int32_t* const linfo = reinterpret_cast<int32_t*>(lutb + (size_t)a.loci_per_block * nal);
+    uint32_t numcalls[CF_V] = {0, 0, 0, 0};
+    uint32_t dpmiss[CF_V] = {0, 0, 0, 0};
+    int64_t totaldp[CF_V] = {0, 0, 0, 0};
+    for (int l_begin = wg_begin; l_begin < wg_end; l_begin += a.loci_per_block) {
+        const int l_end = min(wg_end, l_begin + a.loci_per_block);
+        const int nl = l_end - l_begin;
+        if (dstride) {
+            for (int i = tid; i < nl * dstride; i += CF_THREADS) dbase[i] = 0;
+            cf_build_lut(a.b, l_begin, nl, nal, tid, lutb, linfo);
         }
-        __syncthreads();
-    }
-    if (s0 < S) {  // S % 4 == 0: a thread's 4 samples are all in range or all out
-        uint32_t numcalls[CF_V] = {0, 0, 0, 0};
-        uint32_t dpmiss[CF_V] = {0, 0, 0, 0};
-        int64_t totaldp[CF_V] = {0, 0, 0, 0};
-        for (int l = l_begin; l < l_end; l += U) {
-            CfLocus d[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (l + u < l_end) cf_load(a, (int64_t)(l + u) * S + s0, d[u]);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (l + u >= l_end) break;
-                CfDelta dc;
+        if (live) {
+            auto run = [&](int l, const CfLocus<NS>& d) {
+                CfDelta dc = {nullptr, nullptr, 0, 0, false};
                 if (dstride) {
-                    const int li = l + u - l_begin;
+                    const int li = l - l_begin;
                     dc.tab = dbase + li * dstride;
                     dc.lut = lutb + li * nal;
-                    dc.A = linfo[2 * li];
-                    dc.dup = linfo[2 * li + 1] != 0;
+                    dc.A = linfo[CF_LINFO * li];
+                    dc.dup = cf_lut_needed(linfo, li);
                     dc.nal = nal;
                 }
-                cf_process(a, l + u, (int64_t)(l + u) * S + s0, s0, tid, d[u], fcount, numcalls, totaldp, dpmiss,
-                           dstride ? &dc : nullptr);
+                cf_process<NS, ALLREG>(a, l, (int64_t)l * S + s0, s0, tid, d, fcount, numcalls, totaldp, dpmiss, dc,
+                                       dstride != 0);
+            };
+            if (PF) {
+                CfLocus<NS> d0, d1;
+                cf_load(a, (int64_t)l_begin * S + s0, d0);
+                for (int l = l_begin; l < l_end; l += 2) {
+                    const bool more = l + 1 < l_end;
+                    if (more) cf_load(a, (int64_t)(l + 1) * S + s0, d1);
+                    run(l, d0);
+                    if (more) {
+                        if (l + 2 < l_end) cf_load(a, (int64_t)(l + 2) * S + s0, d0);
+                        run(l + 1, d1);
+                    }
+                }
+            } else {
+                for (int l = l_begin; l < l_end; ++l) {
+                    CfLocus<NS> d;
+                    cf_load(a, (int64_t)l * S + s0, d);
+                    run(l, d);
+                }
             }
         }
+        if (dstride) {  // flush the sub-block's delta table: one global atomic per non-zero entry
+            __syncthreads();
+            if (!(a.dbg & 2))
+                for (int i = tid; i < nl * dstride; i += CF_THREADS) {
+                    const int v = dbase[i];
+                    if (!v) continue;
+                    const int l = l_begin + i / dstride;
+                    const int r = i - (l - l_begin) * dstride;
+                    if (r < nal) {
+                        atomicSub(&a.out.delta_allele_count[a.b.allele_off[l] + r], v);
+                    } else {
+                        const int x = r - nal;
+                        const int col = x == DX_CALLED ? TRK_LI_N_CALLED
+                                        : x == DX_LOW  ? TRK_LI_N_LOWPLOIDY
+                                        : x == DX_HOML ? TRK_LI_N_HOM_LEN
+                                                       : TRK_LI_N_HOM_STR;
+                        atomicSub(&a.out.delta_locus_int[(int64_t)l * TRK_LI_COLS + col], v);
+                    }
+                }
+            __syncthreads();
+        }
+    }
+    if (live) {
 #pragma unroll
         for (int j = 0; j < CF_V; ++j) {
             const int64_t s = s0 + j;
@@ -1317,29 +1456,10 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_fast(const CallArgs 
                 atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_dp_missing + s),
                           (unsigned long long)dpmiss[j]);
             for (int k = 0; k < nf; ++k) {
-                uint32_t c = fcount[(k * CF_THREADS + tid) * CF_V + j];
+                const uint32_t c = (fcount[(k * CF_THREADS + tid) * 2 + (j >> 1)] >> (16 * (j & 1))) & 0xffffu;
                 if (c)
                     atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_counters + (int64_t)(1 + k) * S + s),
                               (unsigned long long)c);
-            }
-        }
-    }
-    if (dstride && !(a.dbg & 2)) {  // flush the block's delta table: one global atomic per non-zero entry
-        __syncthreads();
-        for (int i = tid; i < nl * dstride; i += CF_THREADS) {
-            const int v = dbase[i];
-            if (!v) continue;
-            const int l = l_begin + i / dstride;
-            const int r = i - (l - l_begin) * dstride;
-            if (r < nal) {
-                atomicSub(&a.out.delta_allele_count[a.b.allele_off[l] + r], v);
-            } else {
-                const int x = r - nal;
-                const int col = x == DX_CALLED ? TRK_LI_N_CALLED
-                                : x == DX_LOW  ? TRK_LI_N_LOWPLOIDY
-                                : x == DX_HOML ? TRK_LI_N_HOM_LEN
-                                               : TRK_LI_N_HOM_STR;
-                atomicSub(&a.out.delta_locus_int[(int64_t)l * TRK_LI_COLS + col], v);
             }
         }
     }
@@ -1361,24 +1481,26 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_fast(const CallArgs 
 // ---------------------------------------------------------------------------
 struct V2Filter {
     const void* plane;    // [L,S] int32 or float32
-    int32_t kind;         // 0: int LT, 1: int GT, 2: float LT, 3: float GT
+    int32_t kind;         // 0: int LT, 1: int GT, 2: float LT, 3: float GT, 4: int / depth > dthr (RATIO_GT)
     int32_t need_called;  // TRK_F_CALLED_LT
     int32_t ithr;
     float fthr;
     int32_t bit;          // bit of this filter in the mask / row of sample_counters - 1
     int32_t pad;
+    double dthr;
 };
+constexpr int V2_MAX_FILTERS = 6;
 struct V2Args {
     trk_batch b;
-    V2Filter f[4];
+    V2Filter f[V2_MAX_FILTERS];
     const int32_t* dp;    // DP/LC plane or nullptr
     int loci_per_block;
     int delta_nal;        // max_alleles when the delta outputs are requested, else 0
     trk_call_out out;
 };
-enum { V2_TRASH = 0, V2_W0 = 1, V2_W1 = 2, V2_EXTRA = 3 };  // after the allele bins
 
-template <int NF, bool DELTA>
+// RATIO: some filter is a HipSTR-style ratio over the depth plane (float64 division, filters.py:415-484)
+template <int NF, bool DELTA, bool RATIO>
 __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
     extern __shared__ uint32_t v2lds[];
     const int tid = threadIdx.x;
@@ -1405,20 +1527,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
     const int nl = l_end - l_begin;
     if (DELTA) {
         for (int i = tid; i < nl * dstride; i += CF_THREADS) dtab[i] = 0;
-        for (int li = tid; li < nl; li += CF_THREADS) {
-            const int off = a.b.allele_off[l_begin + li];
-            const int A = a.b.allele_off[l_begin + li + 1] - off;
-            int ml = 0, ms = 0;
-            for (int q = 0; q < A && q < nal; ++q) {
-                const int lc = a.b.len_class[off + q], sc = a.b.str_class[off + q];
-                lutb[li * nal + q] = (uint32_t)lc | ((uint32_t)sc << 16);
-                ml = lc > ml ? lc : ml;
-                ms = sc > ms ? sc : ms;
-            }
-            linfo[2 * li] = A;
-            linfo[2 * li + 1] = ((ml + 1 < A) | (ms + 1 < A)) ? 1 : 0;
-        }
-        __syncthreads();
+        cf_build_lut(a.b, l_begin, nl, nal, tid, lutb, linfo);
     }
     if (s0 < S) {
         for (int l = l_begin; l < l_end; ++l) {
@@ -1440,7 +1549,9 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
                 for (int k = 0; k < NF; ++k) {
                     const V2Filter& f = a.f[k];
                     bool hit;
-                    if (f.kind & 2) {
+                    if (RATIO && f.kind == 4) {
+                        hit = ((double)(int32_t)pv[k][j] / (double)(int32_t)dv[j]) > f.dthr;
+                    } else if (f.kind & 2) {
                         const float v = __uint_as_float(pv[k][j]);
                         hit = (f.kind & 1) ? (v > f.fthr) : (v < f.fthr);
                     } else {
@@ -1469,14 +1580,14 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
                     if (filtered) {
                         const int li = l - l_begin;
                         uint32_t* tab = dtab + li * dstride;
-                        const int A = linfo[2 * li];
+                        const int A = linfo[CF_LINFO * li];
                         const int a0 = (int)(int16_t)(w & 0xffffu), a1 = (int)(int16_t)(w >> 16);
                         const bool v0 = (unsigned)a0 < (unsigned)A, v1 = (unsigned)a1 < (unsigned)A;
                         atomicAdd(&tab[v0 ? a0 : nal + V2_TRASH], 1u);
                         atomicAdd(&tab[v1 ? a1 : nal + V2_TRASH], 1u);
                         const bool low = (a0 == -2) | (a1 == -2);
                         bool hl = (a0 == a1) & v0, hs = hl;
-                        if (linfo[2 * li + 1] && v0 && v1 && !hl) {
+                        if (v0 && v1 && !hl && cf_lut_needed(linfo, li)) {
                             const uint32_t q = lutb[li * nal + a0] ^ lutb[li * nal + a1];
                             hl = (q & 0xffffu) == 0u;
                             hs = (q >> 16) == 0u;
@@ -1731,6 +1842,14 @@ __global__ __launch_bounds__(256) void k_synth_gangstr(trk_synth_spec sp, const 
     }
 }
 
+// [n_cells, ncol] -> [ncol, n_cells], 4-byte elements
+__global__ __launch_bounds__(256) void k_planarize(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                  int64_t n_cells, int ncol) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_cells; c += stride)
+        for (int k = 0; k < ncol; ++k) dst[(int64_t)k * n_cells + c] = src[c * ncol + k];
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -1862,16 +1981,90 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
     a.loci_per_block = lpb;
     size_t lds = (size_t)n_filters * CF_THREADS * CF_V * sizeof(uint32_t);
     // a Float depth plane (ExpansionHunter's LC) is summed in float64 by the per-call kernel only
-    const bool float_dp = dp_plane >= 0 && planes[dp_plane].dtype == TRK_DT_F32;
+    const bool float_dp = dp_plane >= 0 && (planes[dp_plane].dtype & 0xff) == TRK_DT_F32;
     const bool vec = (b.ploidy == 2) && (S % 4 == 0) && !float_dp;
-    a.fast_plane_mask = a.fast_filter_mask = a.slow_filter_mask = 0;
+    a.n_cells = (int64_t)L * S;
+    // ---- vector sources: one [L*S] array per (plane, column) that can be fetched as 16-byte vectors --------
+    a.n_src = 0;
+    a.src_f32_mask = 0;
+    a.reg_filter_mask = 0;
+    a.int_thr_mask = 0;
+    a.dp_src = -1;
+    for (int k = 0; k < TRK_MAX_FILTERS; ++k) {
+        a.f_src_a[k] = a.f_src_a2[k] = a.f_src_b[k] = -1;
+        a.f_ci_n[k] = 0;
+    }
+    auto source_of = [&](int p, int col) -> int {
+        if (!vec || p < 0 || p >= n_planes || getenv("TRK_CF_NOSRC")) return -1;
+        const trk_plane& pl = planes[p];
+        const bool planar = (pl.dtype & TRK_DT_PLANAR) != 0;
+        if (!(pl.ncol == 1 || planar) || col < 0 || col >= pl.ncol) return -1;
+        const char* ptr = static_cast<const char*>(pl.data) + (planar ? (size_t)col * a.n_cells * 4 : 0);
+        if ((uintptr_t)ptr & 15u) return -1;
+        for (int q = 0; q < a.n_src; ++q)
+            if (a.src_ptr[q] == ptr) return q;
+        if (a.n_src >= CF_NSRC) return -1;
+        a.src_ptr[a.n_src] = ptr;
+        if ((pl.dtype & 0xff) == TRK_DT_F32) a.src_f32_mask |= 1u << a.n_src;
+        return a.n_src++;
+    };
+    if (vec) {
+        if (dp_plane >= 0) a.dp_src = (int8_t)source_of(dp_plane, 0);
+        for (int k = 0; k < n_filters; ++k) {
+            const trk_call_filter& f = filters[k];
+            bool ok = true;
+            switch (f.op) {
+                case TRK_F_LT: case TRK_F_GT: case TRK_F_CALLED_LT:
+                    ok = (a.f_src_a[k] = (int8_t)source_of(f.plane_a, f.col_a)) >= 0;
+                    if (ok && !((a.src_f32_mask >> a.f_src_a[k]) & 1u) && f.thr == f.thr) {
+                        // (double)v < thr  <=>  v < ceil(thr);   (double)v > thr  <=>  v > floor(thr)
+                        const double t = f.op == TRK_F_GT ? floor(f.thr) : ceil(f.thr);
+                        if (t > -2147483647.0 && t < 2147483647.0) {
+                            a.f_ithr[k] = (int32_t)t;
+                            a.int_thr_mask |= 1u << k;
+                        }
+                    }
+                    break;
+                case TRK_F_RATIO_GT: case TRK_F_CALLED_EQ:
+                    ok = (a.f_src_a[k] = (int8_t)source_of(f.plane_a, f.col_a)) >= 0 &&
+                         (a.f_src_b[k] = (int8_t)source_of(f.plane_b, f.col_b)) >= 0;
+                    break;
+                case TRK_F_CALLED_SUM_LT:
+                    ok = (a.f_src_a[k] = (int8_t)source_of(f.plane_a, f.col_a)) >= 0 &&
+                         (a.f_src_a2[k] = (int8_t)source_of(f.plane_a, f.col_a2)) >= 0;
+                    break;
+                case TRK_F_CALLED_SUM_EQ:
+                    ok = (a.f_src_a[k] = (int8_t)source_of(f.plane_a, f.col_a)) >= 0 &&
+                         (a.f_src_a2[k] = (int8_t)source_of(f.plane_a, f.col_a2)) >= 0 &&
+                         (a.f_src_b[k] = (int8_t)source_of(f.plane_b, f.col_b)) >= 0;
+                    break;
+                case TRK_F_CALLED_OUTSIDE_CI: {
+                    const int nc = planes[f.plane_a].ncol;
+                    ok = nc >= 1 && nc <= 2;
+                    for (int c = 0; c < nc && ok; ++c) {
+                        const int ml = source_of(f.plane_a, c), lo = source_of(f.plane_b, 2 * c),
+                                  hi = source_of(f.plane_b, 2 * c + 1);
+                        ok = ml >= 0 && lo >= 0 && hi >= 0;
+                        a.f_ci[k][3 * c] = (int8_t)ml;
+                        a.f_ci[k][3 * c + 1] = (int8_t)lo;
+                        a.f_ci[k][3 * c + 2] = (int8_t)hi;
+                    }
+                    a.f_ci_n[k] = ok ? (int8_t)nc : 0;
+                    break;
+                }
+                default:
+                    ok = false;
+            }
+            if (ok) a.reg_filter_mask |= 1u << k;
+        }
+    }
     a.delta_stride = 0;
     a.dbg = getenv("TRK_CF_DBG") ? atoi(getenv("TRK_CF_DBG")) : 0;
     bool lds_delta = false;
     if (out.delta_allele_count && vec && b.max_alleles > 0) {
         // the delta table must fit next to the filter counters: shrink the locus block if needed
         const int stride = b.max_alleles + DX_N;
-        const size_t per_locus = ((size_t)stride + b.max_alleles + 2) * sizeof(int32_t);  // table + LUT + info
+        const size_t per_locus = ((size_t)stride + b.max_alleles + CF_LINFO) * sizeof(int32_t);  // table + LUT + info
         const size_t budget = 24 * 1024;
         if (per_locus * 8 <= budget) {
             int max_lpb = (int)(budget / per_locus);
@@ -1885,24 +2078,35 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
         }
     }
     // ---- issue-lean kernel: every filter a plain threshold on a single-column plane ----
-    if (vec && !b.locus_ploidy && n_filters >= 1 && n_filters <= 4 && !getenv("TRK_CF_GENERIC")) {
+    if (vec && !b.locus_ploidy && n_filters >= 1 && n_filters <= V2_MAX_FILTERS && !getenv("TRK_CF_GENERIC")) {
         V2Args v;
-        bool ok = true;
+        bool ok = true, ratio = false;
         for (int k = 0; k < n_filters && ok; ++k) {
             const trk_call_filter& f = filters[k];
             const trk_plane& pl = planes[f.plane_a];
-            ok = (f.op == TRK_F_LT || f.op == TRK_F_GT || f.op == TRK_F_CALLED_LT) && pl.ncol == 1 &&
-                 ((uintptr_t)pl.data & 15u) == 0 && f.thr == f.thr;
-            if (!ok) break;
             V2Filter& o = v.f[k];
-            o.plane = pl.data;
             o.need_called = f.op == TRK_F_CALLED_LT;
             o.bit = k;
             o.pad = 0;
             o.ithr = 0;
             o.fthr = 0.f;
+            o.dthr = f.thr;
+            if (f.op == TRK_F_RATIO_GT) {
+                // numerator an int32 source, denominator the depth vector the kernel loads anyway
+                ok = a.f_src_a[k] >= 0 && a.dp_src >= 0 && a.f_src_b[k] == a.dp_src &&
+                     !((a.src_f32_mask >> a.f_src_a[k]) & 1u) && !((a.src_f32_mask >> a.dp_src) & 1u);
+                if (!ok) break;
+                o.plane = a.src_ptr[a.f_src_a[k]];
+                o.kind = 4;
+                ratio = true;
+                continue;
+            }
+            ok = (f.op == TRK_F_LT || f.op == TRK_F_GT || f.op == TRK_F_CALLED_LT) && a.f_src_a[k] >= 0 &&
+                 f.thr == f.thr;
+            if (!ok) break;
+            o.plane = a.src_ptr[a.f_src_a[k]];
             const bool gt_op = f.op == TRK_F_GT;
-            if (pl.dtype == TRK_DT_F32) {
+            if ((pl.dtype & 0xff) == TRK_DT_F32) {
                 o.kind = 2 | (gt_op ? 1 : 0);
                 o.fthr = (float)f.thr;
             } else {
@@ -1913,17 +2117,17 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
                 o.ithr = (int32_t)t;
             }
         }
-        if (ok && dp_plane >= 0 && (planes[dp_plane].ncol != 1 || ((uintptr_t)planes[dp_plane].data & 15u))) ok = false;
+        if (ok && dp_plane >= 0 && a.dp_src < 0) ok = false;
         const bool delta = out.delta_allele_count != nullptr;
         if (ok && delta && !(b.max_alleles > 0 && b.max_alleles <= 120)) ok = false;
         if (ok) {
             v.b = b;
-            v.dp = dp_plane >= 0 ? reinterpret_cast<const int32_t*>(planes[dp_plane].data) : nullptr;
+            v.dp = dp_plane >= 0 ? reinterpret_cast<const int32_t*>(a.src_ptr[a.dp_src]) : nullptr;
             v.out = out;
             v.delta_nal = delta ? b.max_alleles : 0;
             size_t lds2 = 0;
             if (delta) {
-                const size_t per_locus = ((size_t)2 * b.max_alleles + V2_EXTRA + 2) * sizeof(uint32_t);
+                const size_t per_locus = ((size_t)2 * b.max_alleles + V2_EXTRA + CF_LINFO) * sizeof(uint32_t);
                 int max_lpb = (int)((32 * 1024) / per_locus);
                 if (lpb > max_lpb) lpb = max_lpb;
                 lds2 = (size_t)lpb * per_locus;
@@ -1931,7 +2135,7 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             if (const char* e = getenv("TRK_CF_LPB")) {
                 int q = atoi(e);
                 if (q > 0 && (!delta || q <= lpb)) lpb = q;
-                if (delta) lds2 = (size_t)lpb * ((size_t)2 * b.max_alleles + V2_EXTRA + 2) * sizeof(uint32_t);
+                if (delta) lds2 = (size_t)lpb * ((size_t)2 * b.max_alleles + V2_EXTRA + CF_LINFO) * sizeof(uint32_t);
             }
             gy = (L + lpb - 1) / lpb;
             v.loci_per_block = lpb;
@@ -1943,52 +2147,81 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             }
             dim3 grid(gx, gy), block(CF_THREADS);
 #define TRK_V2(NFV)                                                                                   \
-    if (delta)                                                                                        \
-        hipLaunchKernelGGL((k_call_filter_v2<NFV, true>), grid, block, lds2, stream, v);               \
+    if (delta && ratio)                                                                               \
+        hipLaunchKernelGGL((k_call_filter_v2<NFV, true, true>), grid, block, lds2, stream, v);         \
+    else if (delta)                                                                                   \
+        hipLaunchKernelGGL((k_call_filter_v2<NFV, true, false>), grid, block, lds2, stream, v);        \
+    else if (ratio)                                                                                   \
+        hipLaunchKernelGGL((k_call_filter_v2<NFV, false, true>), grid, block, 0, stream, v);           \
     else                                                                                              \
-        hipLaunchKernelGGL((k_call_filter_v2<NFV, false>), grid, block, 0, stream, v)
+        hipLaunchKernelGGL((k_call_filter_v2<NFV, false, false>), grid, block, 0, stream, v)
             if (n_filters == 1) { TRK_V2(1); }
             else if (n_filters == 2) { TRK_V2(2); }
             else if (n_filters == 3) { TRK_V2(3); }
-            else { TRK_V2(4); }
+            else if (n_filters == 4) { TRK_V2(4); }
+            else if (n_filters == 5) { TRK_V2(5); }
+            else { TRK_V2(6); }
 #undef TRK_V2
             return hipGetLastError();
         }
     }
     if (vec) {
-        for (int p = 0; p < n_planes && p < CF_FASTP; ++p)
-            if (planes[p].ncol == 1 && ((uintptr_t)planes[p].data & 15u) == 0) a.fast_plane_mask |= 1u << p;
-        for (int k = 0; k < n_filters; ++k) {
-            const trk_call_filter& f = filters[k];
-            const bool simple = f.op == TRK_F_LT || f.op == TRK_F_GT || f.op == TRK_F_CALLED_LT;
-            if (simple && f.plane_a < CF_FASTP && ((a.fast_plane_mask >> f.plane_a) & 1u))
-                a.fast_filter_mask |= 1u << k;
-            else
-                a.slow_filter_mask |= 1u << k;
-        }
-        // experiment knobs (tools/perf_sweep.py): TRK_CF_LPB = loci per block, TRK_CF_U = loci in flight
-        if (const char* e = getenv("TRK_CF_LPB")) {
-            int v = atoi(e);
-            if (v > 0 && !lds_delta) {
-                a.loci_per_block = v;
-                gy = (L + v - 1) / v;
-            }
-        }
         if (out.delta_allele_count && !lds_delta) {
             // no room for an LDS table (huge allele sets): per-call evaluation with global atomics
             hipLaunchKernelGGL(k_call_filter<false>, dim3(gx, gy), dim3(CF_THREADS), lds, stream, a);
             return hipGetLastError();
         }
-        if (lds_delta)
-            lds += (size_t)a.loci_per_block * ((size_t)a.delta_stride + b.max_alleles + 2) * sizeof(int32_t);
-        int cf_u = 1;  // measured: U=1 == U=2 (3.8 ms), U=4 spills (profiles/r01_notes.md)
-        if (const char* e = getenv("TRK_CF_U")) cf_u = atoi(e);
-        if (cf_u == 1)
-            hipLaunchKernelGGL(k_call_filter_fast<1>, dim3(gx, gy), dim3(CF_THREADS), lds, stream, a);
-        else if (cf_u == 4)
-            hipLaunchKernelGGL(k_call_filter_fast<4>, dim3(gx, gy), dim3(CF_THREADS), lds, stream, a);
-        else
-            hipLaunchKernelGGL(k_call_filter_fast<2>, dim3(gx, gy), dim3(CF_THREADS), lds, stream, a);
+        // knobs for tools/perf_sweep.py: TRK_CF_ROUNDS / TRK_CF_WPC workgroups per CU, TRK_CF_DELTA_KB table
+        // budget, TRK_CF_PF=1 prefetch
+        int rounds = 1, wpc = 0, delta_kb = 8, pf = 0;
+        if (const char* e = getenv("TRK_CF_ROUNDS")) rounds = atoi(e) > 0 ? atoi(e) : rounds;
+        if (const char* e = getenv("TRK_CF_WPC")) wpc = atoi(e);
+        if (const char* e = getenv("TRK_CF_DELTA_KB")) delta_kb = atoi(e) > 0 ? atoi(e) : delta_kb;
+        if (const char* e = getenv("TRK_CF_PF")) pf = atoi(e);
+        const bool allreg = a.reg_filter_mask == (n_filters >= 32 ? ~0u : (1u << n_filters) - 1u) &&
+                            (dp_plane < 0 || a.dp_src >= 0) && !getenv("TRK_CF_NOALLREG");
+        void (*kfn)(CallArgs) = nullptr;
+#define TRK_FAST(NS)                                             \
+    kfn = (allreg && pf) ? k_call_filter_fast<true, NS, true>    \
+          : allreg       ? k_call_filter_fast<false, NS, true>   \
+                         : k_call_filter_fast<false, NS, false>
+        if (a.n_src <= 4) { TRK_FAST(4); }
+        else if (a.n_src <= 8) { TRK_FAST(8); }
+        else if (a.n_src <= 12) { TRK_FAST(12); }
+        else { TRK_FAST(16); }
+#undef TRK_FAST
+        // geometry: every workgroup owns one contiguous locus range (<= 61440 loci: the 16-bit per-thread
+        // counters) and all of them are resident at once -- the grid is the kernel's occupancy x CUs, so no
+        // partial second round of workgroups trails the first -- and walks it in sub-blocks sized by the
+        // LDS delta table.
+        const size_t lds_counters = (size_t)n_filters * CF_THREADS * 2 * sizeof(uint32_t);
+        const size_t per_locus = ((size_t)a.delta_stride + b.max_alleles + CF_LINFO) * sizeof(int32_t);
+        int max_sub = lds_delta ? (int)((size_t)delta_kb * 1024 / per_locus) : 0;
+        if (lds_delta && max_sub < 8) max_sub = 8;
+        if (wpc <= 0) {
+            int occ = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, CF_THREADS,
+                                                             lds_counters + (size_t)max_sub * per_locus) != hipSuccess ||
+                occ < 1)
+                occ = 3;
+            wpc = occ * rounds;
+        }
+        int gyf = (n_cu * wpc) / gx;   // round down: never more workgroups than slots
+        if (gyf > L) gyf = L;
+        if (gyf < 1) gyf = 1;
+        int lpw = (L + gyf - 1) / gyf;
+        if (lpw > 61440) lpw = 61440;
+        gyf = (L + lpw - 1) / lpw;
+        int sub = lpw;
+        lds = lds_counters;
+        if (lds_delta) {
+            const int nsub = (lpw + max_sub - 1) / max_sub;
+            sub = (lpw + nsub - 1) / nsub;
+            lds += (size_t)sub * per_locus;
+        }
+        a.loci_per_wg = lpw;
+        a.loci_per_block = sub;
+        hipLaunchKernelGGL(kfn, dim3(gx, gyf), dim3(CF_THREADS), lds, stream, a);
     } else {
         hipLaunchKernelGGL(k_call_filter<false>, dim3(gx, gy), dim3(CF_THREADS), lds, stream, a);
     }
@@ -2023,6 +2256,14 @@ hipError_t launch_synth_gangstr(const trk_synth_spec& sp, const int16_t* gt, con
     if (blocks > (int64_t)n_cu * 32) blocks = (int64_t)n_cu * 32;
     hipLaunchKernelGGL(k_synth_gangstr, dim3((int)blocks), dim3(256), 0, stream, sp, gt, dp, allele_repcn, qexp,
                        repcn, rc, repci);
+    return hipGetLastError();
+}
+
+hipError_t launch_planarize(const void* src, void* dst, int64_t n_cells, int ncol, hipStream_t stream) {
+    int64_t blocks = (n_cells + 255) / 256;
+    if (blocks > 65535 * 16) blocks = 65535 * 16;
+    hipLaunchKernelGGL(k_planarize, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<const uint32_t*>(src),
+                       static_cast<uint32_t*>(dst), n_cells, ncol);
     return hipGetLastError();
 }
 

@@ -6,6 +6,7 @@ arrays with the documented dtypes; ``upload`` makes the PCIe copy explicit and
 returns a ``DeviceArray``; results stay on the device until ``.get()``.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -289,16 +290,17 @@ class Engine:
             raise ValueError("too many planes/filters")
         parr = (L.Plane * max(np_, 1))()
         for i, p in enumerate(planes):
-            if p.shape[:2] != (batch.n_loci, batch.n_samples):
+            planar = getattr(p, 'planar', False)      # [k, L, S]: one contiguous array per column
+            if (p.shape[1:] if planar else p.shape[:2]) != (batch.n_loci, batch.n_samples):
                 raise ValueError("plane %d has shape %s" % (i, p.shape))
-            ncol = 1 if len(p.shape) == 2 else p.shape[2]
+            ncol = p.shape[0] if planar else (1 if len(p.shape) == 2 else p.shape[2])
             if p.dtype == np.int32:
                 dt = L.DT_I32
             elif p.dtype == np.float32:
                 dt = L.DT_F32
             else:
                 raise ValueError("plane %d dtype %s not supported" % (i, p.dtype))
-            parr[i] = L.Plane(p.ptr, dt, ncol)
+            parr[i] = L.Plane(p.ptr, dt | (L.DT_PLANAR if planar else 0), ncol)
         farr = (L.CallFilter * max(nf, 1))()
         for k, f in enumerate(filters):
             farr[k] = L.CallFilter(int(f['op']), int(f['plane_a']), int(f.get('col_a', 0)),
@@ -309,6 +311,26 @@ class Engine:
         ostruct = out.struct if delta_stats is None else out.with_delta(delta_stats)
         self._chk(self.lib.trk_call_filters(self.ctx, C.byref(batch.struct), parr, np_, farr, nf,
                                             int(dp_plane), C.byref(ostruct)))
+        return out
+
+    def upload_plane(self, arr):
+        """Upload a FORMAT plane [L, S] or [L, S, k] (int32 / float32).  Multi-column planes go up planar
+        ([k, L, S], TRK_DT_PLANAR) so that every column streams as 16-byte vectors."""
+        arr = np.asarray(arr)
+        if arr.ndim == 3 and arr.shape[2] > 1 and os.environ.get('TRK_CF_INTERLEAVED', '0') == '0':
+            d = self.upload(np.ascontiguousarray(arr.transpose(2, 0, 1)))
+            d.planar = True
+            return d
+        return self.upload(np.ascontiguousarray(arr))
+
+    def planarize(self, plane):
+        """Device [L, S, k] -> new device array [k, L, S] marked planar (trk_planarize)."""
+        if len(plane.shape) != 3 or plane.shape[2] == 1:
+            return plane
+        Lc, S, k = plane.shape
+        out = self.empty((k, Lc, S), plane.dtype)
+        self._chk(self.lib.trk_planarize(self.ctx, plane.ptr, out.ptr, Lc * S, k))
+        out.planar = True
         return out
 
     def locus_filters(self, n_loci, stats, min_callrate=None, min_hwep=None, min_het=None, max_het=None,
