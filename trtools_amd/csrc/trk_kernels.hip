@@ -1490,6 +1490,11 @@ struct V2Filter {
     double dthr;
 };
 constexpr int V2_MAX_FILTERS = 6;
+// -DTRK_V2_WRED=0 builds the per-lane form for A/B runs (profiles/r01_notes.md: 4.35 -> 4.19 ms)
+#ifndef TRK_V2_WRED
+#define TRK_V2_WRED 1
+#endif
+constexpr bool V2_WRED = TRK_V2_WRED != 0;
 struct V2Args {
     trk_batch b;
     V2Filter f[V2_MAX_FILTERS];
@@ -1530,6 +1535,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
         cf_build_lut(a.b, l_begin, nl, nal, tid, lutb, linfo);
     }
     if (s0 < S) {
+        const bool leader = (tid & 63) == __ffsll((unsigned long long)__ballot(1)) - 1;  // first live lane of the wave
         for (int l = l_begin; l < l_end; ++l) {
             const int64_t c4 = ((int64_t)l * S + s0) >> 2;
             const u32x4 g = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.b.gt) + c4);
@@ -1540,6 +1546,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
             u32x4 dv = {0, 0, 0, 0};
             if (a.dp) dv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.dp) + c4);
             u32x4 wout, mout;
+            uint32_t w0acc = 0, w1acc = 0;
 #pragma unroll
             for (int j = 0; j < CF_V; ++j) {
                 const uint32_t w = g[j];
@@ -1576,7 +1583,27 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
                     }
                 }
                 const bool filtered = called & !pass;  // dumpSTR.py:715-727
-                if (DELTA) {
+                if (DELTA && V2_WRED) {
+                    // the per-locus words are sums of lane flags: count them with ballots, one LDS atomic per wave
+                    const int li = l - l_begin;
+                    uint32_t* tab = dtab + li * dstride;
+                    const int A = linfo[CF_LINFO * li];
+                    const int a0 = (int)(int16_t)(w & 0xffffu), a1 = (int)(int16_t)(w >> 16);
+                    const bool v0 = (unsigned)a0 < (unsigned)A, v1 = (unsigned)a1 < (unsigned)A;
+                    const bool low = filtered & ((a0 == -2) | (a1 == -2));
+                    bool hl = filtered & (a0 == a1) & v0, hs = hl;
+                    if (filtered) {
+                        atomicAdd(&tab[v0 ? a0 : nal + V2_TRASH], 1u);
+                        atomicAdd(&tab[v1 ? a1 : nal + V2_TRASH], 1u);
+                        if (v0 && v1 && a0 != a1 && cf_lut_needed(linfo, li)) {
+                            const uint32_t q = lutb[li * nal + a0] ^ lutb[li * nal + a1];
+                            hl = (q & 0xffffu) == 0u;
+                            hs = (q >> 16) == 0u;
+                        }
+                    }
+                    w0acc += (uint32_t)__popcll(__ballot(filtered)) + ((uint32_t)__popcll(__ballot(low)) << 16);
+                    w1acc += (uint32_t)__popcll(__ballot(hl)) + ((uint32_t)__popcll(__ballot(hs)) << 16);
+                } else if (DELTA) {
                     if (filtered) {
                         const int li = l - l_begin;
                         uint32_t* tab = dtab + li * dstride;
@@ -1599,6 +1626,11 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
                 }
                 wout[j] = filtered ? 0xffffffffu : w;
                 mout[j] = m;
+            }
+            if (DELTA && V2_WRED && leader) {
+                uint32_t* tab = dtab + (l - l_begin) * dstride;
+                if (w0acc) atomicAdd(&tab[nal + V2_W0], w0acc);
+                if (w1acc) atomicAdd(&tab[nal + V2_W1], w1acc);
             }
             if (a.out.gt_out) __builtin_nontemporal_store(wout, reinterpret_cast<u32x4*>(a.out.gt_out) + c4);
             if (a.out.filter_mask) __builtin_nontemporal_store(mout, reinterpret_cast<u32x4*>(a.out.filter_mask) + c4);
