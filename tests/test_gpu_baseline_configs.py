@@ -122,6 +122,22 @@ def test_config2_dumpstr_gangstr_50k_x_5k(eng):
     cnt = st.allele_count.get()[0]
     off = sb.tables[0]
     assert np.array_equal(np.add.reduceat(cnt.astype(np.int64), off[:-1]), li[:, L.LI_N_ALLELES])
+    # ---- the same planes planar ([k, L, S], every filter evaluated on register-resident vector sources), with
+    # the delta outputs: bit-identical masks / genotypes / counters, and counts(GT') = counts(GT) - delta ----
+    pl_planes = [eng.planarize(p) for p in planes]
+    assert pl_planes[2].planar and pl_planes[2].shape == (3, Lc, S)
+    st0 = eng.locus_stats(sb.batch, count_only=True)
+    res_p = eng.call_filters(sb.batch, pl_planes, filters, dp_plane=0, delta_stats=st0)
+    assert np.array_equal(res_p.filter_mask.get(), mask)
+    assert np.array_equal(res_p.sample_counters.get(), cnts)
+    assert np.array_equal(res_p.sample_totaldp.get(), res.sample_totaldp.get())
+    assert np.array_equal(res_p.sample_dp_missing.get(), res.sample_dp_missing.get())
+    assert np.array_equal(res_p.gt_out.get_rows(0, 64), res.gt_out.get_rows(0, 64))
+    assert np.array_equal(res_p.gt_out.get_rows(Lc - 64, Lc), res.gt_out.get_rows(Lc - 64, Lc))
+    assert np.array_equal(st0.allele_count.get()[0], cnt)
+    for col in (L.LI_N_CALLED, L.LI_N_LOWPLOIDY, L.LI_N_HOM_LEN, L.LI_N_HOM_STR):
+        assert np.array_equal(st0.locus_int.get()[0][:, col], li[:, col])
+    del pl_planes, res_p, st0
     # ---- sampled loci against the numpy oracle ----
     idx = np.sort(np.random.default_rng(1).choice(Lc, size=24, replace=False))
     h = sb.host_rows(idx)
