@@ -73,6 +73,38 @@ typedef struct {
 /* Decode up to max_records records.  Returns 0, or a non-zero code with trk_vcf_last_error(). */
 int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batch* out);
 
+/* ---- record serialisation ---------------------------------------------------------------
+ * what the reference gets from cyvcf2.Writer.write_record (htslib's
+ * vcf_format) for the records dumpSTR rewrites (dumpSTR.py:684, 721-746, 1338).  The per-sample
+ * columns of ONE record are serialised from the typed FORMAT arrays cyvcf2 hands out
+ * (Variant.genotype.array(), Variant.format(key)):
+ *   GT     int16 [S, P+1]  -1 -> '.', -2 (ploidy padding) skipped, last column = phased ('|' or '/')
+ *   INT    int32 [S, k]    INT_MIN -> '.', INT_MIN+1 ends the vector; an empty vector is '.'
+ *   FLOAT  float32 [S, k]  NaN -> '.', a vector of NaNs is a single '.'; others as printf("%g")
+ *   BYTES / UCS4  fixed-width strings (numpy 'S<n>' / '<U<n>'), NUL padded; empty -> '.'
+ *   CALLFILTER    dumpSTR's FORMAT/FILTER text built from the call-filter mask (dumpSTR.py:648-683): 'NOCALL' when
+ *          bit 31 is set, 'PASS' for 0, else '<name k>_<%g of values[k][s]>' of every set bit k, comma joined
+ * Output: for every sample '\t' + the columns joined by ':' (no newline).  Returns the number of
+ * bytes written, or -(bytes needed) when cap is too small, or INT64_MIN for a bad argument.     */
+enum { TRK_VCF_COL_GT = 0, TRK_VCF_COL_INT = 1, TRK_VCF_COL_FLOAT = 2, TRK_VCF_COL_BYTES = 3, TRK_VCF_COL_UCS4 = 4,
+       TRK_VCF_COL_CALLFILTER = 5 };
+typedef struct {
+    const uint32_t* mask;           /* [S] trk_call_out.filter_mask row of the record                 */
+    int32_t n_filters;
+    int32_t reserved;
+    const char* const* names;       /* [n_filters] filter names                                        */
+    const double* const* values;    /* [n_filters] -> [S] offending values; NULL rows for unfired bits */
+} trk_vcf_callfilter;
+typedef struct {
+    int32_t kind;
+    int32_t ncol;      /* values per sample (GT: P + 1); strings: 1                       */
+    int32_t itemsize;  /* strings: bytes per sample                                       */
+    int32_t reserved;
+    const void* data;  /* [S, ncol] C-contiguous; CALLFILTER: a trk_vcf_callfilter        */
+} trk_vcf_column;
+int64_t trk_vcf_format_samples(int32_t n_samples, int32_t n_columns, const trk_vcf_column* cols, char* out,
+                               int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,102 @@
+"""Native record serialiser (trk_vcf_format_samples, include/trk_vcf.h) against the
+Python formatting loop of vcfio.Variant -- which the dumpSTR golden VCFs pin to the reference's cyvcf2/htslib output
+(tests/test_dumpstr_cli.py, tests/test_dumpstr_more.py) -- on every record of every fixture VCF, untouched and after
+the edits dumpSTR makes (FILTER column added, filtered calls nulled)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from trtools_amd import vcfio
+
+DATA = os.path.join(os.path.dirname(__file__), 'golden', 'data')
+FILES = sorted(glob.glob(os.path.join(DATA, '**', '*.vcf'), recursive=True) +
+               glob.glob(os.path.join(DATA, '**', '*.vcf.gz'), recursive=True))
+
+
+def _readers(path):
+    yield vcfio.VCFReader(path)
+    from trtools_amd import vcfnative
+    try:
+        yield vcfnative.NativeVCFReader(path)
+    except (OSError, ValueError):
+        return
+
+
+@pytest.mark.parametrize('path', FILES, ids=[os.path.relpath(p, DATA) for p in FILES])
+def test_native_text_equals_python_text(path):
+    assert vcfio._serializer() is not None, "libtrk.so is not built"
+    from trtools_amd.dumpSTR import dumpSTR as D
+    rng = np.random.default_rng(7)
+    n_checked = 0
+    for rd in _readers(path):
+        try:
+            it = iter(rd)
+            first = next(it, None)
+        except (ValueError, KeyError, IndexError):
+            continue        # fixtures that are malformed on purpose
+        k = 0
+        v = first
+        while v is not None and k < 60:
+            assert v.to_text(native=True) == v.to_text(native=False)
+            S = v.n_samples_hint()
+            if S and v.genotype is not None and 'GT' in v.FORMAT:
+                # what dumpSTR does to a record (dumpSTR.py:684, 721-746)
+                mask = np.zeros(S, dtype=np.uint32)
+                mask[rng.random(S) < 0.3] |= np.uint32(1)
+                mask[rng.random(S) < 0.2] |= np.uint32(4)
+                mask[np.any(np.asarray(v.genotype.array())[:, :-1] == -1, axis=1)] = np.uint32(0x80000000)
+                filtered = (mask & np.uint32(0x7fffffff)) != 0
+                vals = [np.round(rng.random(S) * 50, 2), None, rng.integers(0, 1000, S).astype(float) / 7]
+                col = vcfio.CallFilterColumn(mask, ['MinDP', 'unused', 'Q0.9'], vals)
+                if k % 2:
+                    v.set_format('FILTER', col)                  # written from the mask by the native serialiser
+                else:
+                    v.set_format('FILTER', col.to_array())       # the text array the reference builds
+                try:
+                    D._null_filtered(v, filtered, v.ploidy)
+                except ValueError:
+                    pass
+                assert v.to_text(native=True) == v.to_text(native=False)
+                assert v._samples_text_native() is not None or any(
+                    v.format(key).dtype.kind not in 'ifUS' for key in v.FORMAT if key != 'GT')
+            n_checked += 1
+            k += 1
+            try:
+                v = next(it, None)
+            except (ValueError, KeyError, IndexError):
+                break
+    assert n_checked or os.path.getsize(path) < 4096
+
+
+def test_value_forms():
+    """Missing / vector-end / NaN conventions and unicode strings."""
+    api = vcfio._serializer()
+    assert api is not None
+    lib, Column = api
+    import ctypes
+    gt = np.array([[0, 1, 1], [-1, -1, 0], [2, -2, 0], [-2, -2, 0], [-1, 3, 1]], dtype=np.int16)
+    iv = np.array([[5, -2147483647, -2147483647], [-2147483648, 7, -2147483647], [-2147483647, 1, 1],
+                   [1, 2, 3], [-2147483648, -2147483648, -2147483648]], dtype=np.int32)
+    fv = np.array([[0.5, np.nan], [np.nan, np.nan], [1e-7, 3.0], [np.nan, 1.25], [123456789.0, -0.0]], dtype=np.float32)
+    sv = np.array(['a', '', 'x|y', 'é', 'PASS'])
+    bv = np.array([b'', b'q', b'longer', b'.', b'z'])
+    cols = (Column * 5)(Column(0, 3, 0, 0, gt.ctypes.data), Column(1, 3, 0, 0, iv.ctypes.data),
+                        Column(2, 2, 0, 0, fv.ctypes.data), Column(4, 1, sv.dtype.itemsize, 0, sv.ctypes.data),
+                        Column(3, 1, bv.dtype.itemsize, 0, bv.ctypes.data))
+    buf = ctypes.create_string_buffer(1024)
+    n = lib.trk_vcf_format_samples(5, 5, cols, buf, 1024)
+    assert n > 0
+    want = ('\t0|1:5:0.5,.:a:.' '\t./.:.,7:.:.:q' '\t2:.:1e-07,3:x|y:longer' '\t.:1,2,3:.,1.25:é:.'
+            '\t.|3:.,.,.:1.23457e+08,-0:PASS:z')
+    assert buf.raw[:n].decode() == want
+    for x in (0.1, 1e-5, 123456.0, 1234567.0, 0.30000001192092896, 2.5e-10, 1e16, 100.0, 0.95, 3.4028234663852886e38):
+        f1 = np.array([[x]], dtype=np.float32)
+        c1 = (Column * 1)(Column(2, 1, 0, 0, f1.ctypes.data))
+        n1 = lib.trk_vcf_format_samples(1, 1, c1, buf, 1024)
+        assert buf.raw[:n1].decode() == '\t' + '%g' % float(f1[0, 0]), x
+    # too small a buffer: the size comes back negated, nothing is written past the end
+    small = ctypes.create_string_buffer(8)
+    assert lib.trk_vcf_format_samples(5, 5, cols, small, 8) == -n
+    assert lib.trk_vcf_format_samples(-1, 5, cols, small, 8) < -10**15

@@ -1,3 +1,8 @@
+#!/bin/bash
+# A/B of two library builds on ONE GPU box (box-to-box variance is +-5 %): build the variant next to the product
+# library, e.g.
+#   hipcc ... -DTRK_V2_WRED=0 -c trk_kernels.hip -o /tmp/k.o && hipcc -shared ... -o trtools_amd/libtrk_w0.so
+# then `gpurun -- bash tools/ab_bench.sh`: three alternating bench runs (ms/step, call-filter ms, roofline fraction).
 for r in 1 2 3; do
 for v in w1 w0; do
   if [ $v = w0 ]; then cp trtools_amd/libtrk.so /tmp/keep.so; cp trtools_amd/libtrk_w0.so trtools_amd/libtrk.so; fi

@@ -58,3 +58,19 @@ if not a.no_gpu:
                        nalleles=True, nalleles_thresh=0.01, only_passing=False)
     t = time.time(); rc = statSTR.main(ns); t4 = time.time() - t
     print("statSTR CLI end to end (11 stats): rc=%d %6.2fs  %.0f loci/s  %.2e cells/s" % (rc, t4, a.loci / t4, cells / t4))
+    # dumpSTR end to end: the same file through call filters + locus filters to an output VCF and the two logs
+    from trtools_amd.dumpSTR import dumpSTR
+    old = sys.argv
+    sys.argv = ['dumpSTR', '--vcf', path, '--out', os.path.join(a.out, 'dump'), '--vcftype', 'hipstr',
+                '--hipstr-min-call-DP', '10', '--hipstr-max-call-DP', '55', '--hipstr-min-call-Q', '0.9',
+                '--min-locus-callrate', '0.8', '--min-locus-hwep', '0.001', '--min-locus-het', '0.05',
+                '--max-locus-het', '0.9']
+    dargs = dumpSTR.getargs()
+    sys.argv = old
+    t = time.time(); rc = dumpSTR.main(dargs); t5 = time.time() - t
+    print("dumpSTR CLI end to end (3 call + 4 locus filters, VCF out %.0f MB): rc=%d %6.2fs  %.0f loci/s  %.2e cells/s" % (
+        os.path.getsize(os.path.join(a.out, 'dump.vcf')) / 1e6, rc, t5, a.loci / t5, cells / t5))
+    if os.environ.get('E2E_PROFILE'):
+        import cProfile, pstats
+        pr = cProfile.Profile(); pr.enable(); dumpSTR.main(dargs); pr.disable()
+        pstats.Stats(pr).sort_stats('tottime').print_stats(18)

@@ -1354,13 +1354,12 @@ __device__ __forceinline__ void cf_process(const CallArgs& a, int l, int64_t cel
                                     reinterpret_cast<u32x4*>(a.out.filter_mask) + (cell0 >> 2));
 }
 
-// PF: the next locus's vectors are in flight while the current one is evaluated (two register sets).
 // ALLREG: every filter and the depth plane read vector sources only (the per-call path is compiled out).
 // A workgroup owns loci [y * loci_per_wg, ...) and walks them in sub-blocks of loci_per_block, the unit of the
 // LDS delta table; the per-sample counters live across sub-blocks and are flushed once.
 // (the instantiation that sits one register above 128 VGPRs is held to four waves per SIMD)
-template <bool PF, int NS, bool ALLREG>
-__global__ __launch_bounds__(CF_THREADS, (!PF && NS == 12 && ALLREG) ? 4 : 1) void k_call_filter_fast(const CallArgs a) {
+template <int NS, bool ALLREG>
+__global__ __launch_bounds__(CF_THREADS, (NS == 12 && ALLREG) ? 4 : 1) void k_call_filter_fast(const CallArgs a) {
     extern __shared__ uint32_t fcount[];  // [n_filters][CF_THREADS][2] (16-bit pairs), then the delta table
     const int tid = threadIdx.x;
     const int S = a.b.n_samples, L = a.b.n_loci;
@@ -1400,24 +1399,12 @@ __global__ __launch_bounds__(CF_THREADS, (!PF && NS == 12 && ALLREG) ? 4 : 1) vo
                 cf_process<NS, ALLREG>(a, l, (int64_t)l * S + s0, s0, tid, d, fcount, numcalls, totaldp, dpmiss, dc,
                                        dstride != 0);
             };
-            if (PF) {
-                CfLocus<NS> d0, d1;
-                cf_load(a, (int64_t)l_begin * S + s0, d0);
-                for (int l = l_begin; l < l_end; l += 2) {
-                    const bool more = l + 1 < l_end;
-                    if (more) cf_load(a, (int64_t)(l + 1) * S + s0, d1);
-                    run(l, d0);
-                    if (more) {
-                        if (l + 2 < l_end) cf_load(a, (int64_t)(l + 2) * S + s0, d0);
-                        run(l + 1, d1);
-                    }
-                }
-            } else {
-                for (int l = l_begin; l < l_end; ++l) {
-                    CfLocus<NS> d;
-                    cf_load(a, (int64_t)l * S + s0, d);
-                    run(l, d);
-                }
+            // (loading locus l + 1 into a second register set while l is evaluated was measured: the registers
+            // cost more occupancy than the overlap buys, profiles/r01_notes.md)
+            for (int l = l_begin; l < l_end; ++l) {
+                CfLocus<NS> d;
+                cf_load(a, (int64_t)l * S + s0, d);
+                run(l, d);
             }
         }
         if (dstride) {  // flush the sub-block's delta table: one global atomic per non-zero entry
@@ -2203,20 +2190,15 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             hipLaunchKernelGGL(k_call_filter<false>, dim3(gx, gy), dim3(CF_THREADS), lds, stream, a);
             return hipGetLastError();
         }
-        // knobs for tools/perf_sweep.py: TRK_CF_ROUNDS / TRK_CF_WPC workgroups per CU, TRK_CF_DELTA_KB table
-        // budget, TRK_CF_PF=1 prefetch
-        int rounds = 1, wpc = 0, delta_kb = 8, pf = 0;
+        // knobs for tools/perf_sweep.py: TRK_CF_ROUNDS / TRK_CF_WPC workgroups per CU, TRK_CF_DELTA_KB table budget
+        int rounds = 1, wpc = 0, delta_kb = 8;
         if (const char* e = getenv("TRK_CF_ROUNDS")) rounds = atoi(e) > 0 ? atoi(e) : rounds;
         if (const char* e = getenv("TRK_CF_WPC")) wpc = atoi(e);
         if (const char* e = getenv("TRK_CF_DELTA_KB")) delta_kb = atoi(e) > 0 ? atoi(e) : delta_kb;
-        if (const char* e = getenv("TRK_CF_PF")) pf = atoi(e);
         const bool allreg = a.reg_filter_mask == (n_filters >= 32 ? ~0u : (1u << n_filters) - 1u) &&
                             (dp_plane < 0 || a.dp_src >= 0) && !getenv("TRK_CF_NOALLREG");
         void (*kfn)(CallArgs) = nullptr;
-#define TRK_FAST(NS)                                             \
-    kfn = (allreg && pf) ? k_call_filter_fast<true, NS, true>    \
-          : allreg       ? k_call_filter_fast<false, NS, true>   \
-                         : k_call_filter_fast<false, NS, false>
+#define TRK_FAST(NS) kfn = allreg ? k_call_filter_fast<NS, true> : k_call_filter_fast<NS, false>
         if (a.n_src <= 4) { TRK_FAST(4); }
         else if (a.n_src <= 8) { TRK_FAST(8); }
         else if (a.n_src <= 12) { TRK_FAST(12); }

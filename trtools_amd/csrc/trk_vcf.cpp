@@ -609,4 +609,150 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
     return 0;
 }
 
+// ---- record serialisation (trk_vcf.h) ------------------------------------------------------
+namespace {
+struct OutBuf {
+    char* p;
+    int64_t cap, n;
+    inline void put(char c) {
+        if (n < cap) p[n] = c;
+        ++n;
+    }
+    inline void put(const char* s, size_t len) {
+        if (n + (int64_t)len <= cap) memcpy(p + n, s, len);
+        n += (int64_t)len;
+    }
+    inline void put_int(long v) {
+        char tmp[24];
+        auto r = std::to_chars(tmp, tmp + sizeof tmp, v);
+        put(tmp, (size_t)(r.ptr - tmp));
+    }
+};
+
+inline void put_utf8(OutBuf& o, uint32_t c) {
+    if (c < 0x80) {
+        o.put((char)c);
+    } else if (c < 0x800) {
+        o.put((char)(0xc0 | (c >> 6)));
+        o.put((char)(0x80 | (c & 0x3f)));
+    } else if (c < 0x10000) {
+        o.put((char)(0xe0 | (c >> 12)));
+        o.put((char)(0x80 | ((c >> 6) & 0x3f)));
+        o.put((char)(0x80 | (c & 0x3f)));
+    } else {
+        o.put((char)(0xf0 | (c >> 18)));
+        o.put((char)(0x80 | ((c >> 12) & 0x3f)));
+        o.put((char)(0x80 | ((c >> 6) & 0x3f)));
+        o.put((char)(0x80 | (c & 0x3f)));
+    }
+}
+}  // namespace
+
+int64_t trk_vcf_format_samples(int32_t n_samples, int32_t n_columns, const trk_vcf_column* cols, char* out,
+                               int64_t cap) {
+    if (n_samples < 0 || n_columns < 0 || (n_columns && !cols) || cap < 0 || (cap && !out)) return INT64_MIN;
+    for (int c = 0; c < n_columns; ++c)
+        if (cols[c].kind < TRK_VCF_COL_GT || cols[c].kind > TRK_VCF_COL_CALLFILTER || cols[c].ncol < 1 ||
+            !cols[c].data || ((cols[c].kind >= TRK_VCF_COL_BYTES) && cols[c].itemsize < 0))
+            return INT64_MIN;
+    OutBuf o{out, cap, 0};
+    char tmp[48];
+    for (int64_t s = 0; s < n_samples; ++s) {
+        o.put('\t');
+        for (int c = 0; c < n_columns; ++c) {
+            const trk_vcf_column& f = cols[c];
+            if (c) o.put(':');
+            const int k = f.ncol;
+            switch (f.kind) {
+                case TRK_VCF_COL_GT: {
+                    const int16_t* g = static_cast<const int16_t*>(f.data) + s * k;
+                    const char sep = g[k - 1] ? '|' : '/';
+                    int n = 0;
+                    for (int j = 0; j < k - 1; ++j) {
+                        if (g[j] == -2) continue;
+                        if (n++) o.put(sep);
+                        if (g[j] == -1) o.put('.');
+                        else o.put_int(g[j]);
+                    }
+                    if (!n) o.put('.');
+                    break;
+                }
+                case TRK_VCF_COL_INT: {
+                    const int32_t* v = static_cast<const int32_t*>(f.data) + s * k;
+                    int n = 0;
+                    for (int j = 0; j < k; ++j) {
+                        if (v[j] == INT32_MIN + 1) break;
+                        if (n++) o.put(',');
+                        if (v[j] == INT32_MIN) o.put('.');
+                        else o.put_int(v[j]);
+                    }
+                    if (!n) o.put('.');
+                    break;
+                }
+                case TRK_VCF_COL_FLOAT: {
+                    const float* v = static_cast<const float*>(f.data) + s * k;
+                    bool any = false;
+                    for (int j = 0; j < k; ++j) any |= !std::isnan(v[j]);
+                    if (!any) {
+                        o.put('.');
+                        break;
+                    }
+                    for (int j = 0; j < k; ++j) {
+                        if (j) o.put(',');
+                        if (std::isnan(v[j])) {
+                            o.put('.');
+                        } else {
+                            // printf("%g"): to_chars with a precision is specified to give the same digits
+                            auto r = std::to_chars(tmp, tmp + sizeof tmp, (double)v[j], std::chars_format::general, 6);
+                            o.put(tmp, (size_t)(r.ptr - tmp));
+                        }
+                    }
+                    break;
+                }
+                case TRK_VCF_COL_BYTES: {
+                    const char* v = static_cast<const char*>(f.data) + s * (int64_t)f.itemsize;
+                    size_t len = (size_t)f.itemsize;
+                    while (len && v[len - 1] == 0) --len;
+                    if (!len) o.put('.');
+                    else o.put(v, len);
+                    break;
+                }
+                case TRK_VCF_COL_CALLFILTER: {
+                    const trk_vcf_callfilter* cf = static_cast<const trk_vcf_callfilter*>(f.data);
+                    const uint32_t m = cf->mask[s];
+                    if (m & 0x80000000u) {
+                        o.put("NOCALL", 6);
+                    } else if (m == 0) {
+                        o.put("PASS", 4);
+                    } else {
+                        int n = 0;
+                        for (int b = 0; b < cf->n_filters && b < 31; ++b) {
+                            if (!((m >> b) & 1u)) continue;
+                            if (n++) o.put(',');
+                            o.put(cf->names[b], strlen(cf->names[b]));
+                            o.put('_');
+                            const double x = cf->values[b] ? cf->values[b][s] : NAN;
+                            const int len = snprintf(tmp, sizeof tmp, "%g", x);
+                            o.put(tmp, (size_t)len);
+                        }
+                        if (!n) o.put('.');
+                    }
+                    break;
+                }
+                default: {  // TRK_VCF_COL_UCS4
+                    const int nch = f.itemsize / 4;
+                    const uint32_t* v = reinterpret_cast<const uint32_t*>(static_cast<const char*>(f.data) +
+                                                                          s * (int64_t)f.itemsize);
+                    int len = nch;
+                    while (len && v[len - 1] == 0) --len;
+                    if (!len) o.put('.');
+                    for (int j = 0; j < len; ++j) put_utf8(o, v[j]);
+                    break;
+                }
+            }
+        }
+    }
+    return o.n <= cap ? o.n : -o.n;
+}
+
 }  // extern "C"

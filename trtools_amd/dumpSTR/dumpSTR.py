@@ -335,17 +335,7 @@ def evaluate_call_filters(records, call_filters):
 
 def _call_filter_text(mask_row, names, values_l):
     """FORMAT/FILTER strings of one record (dumpSTR.py:648-683)."""
-    out = []
-    for s, m in enumerate(mask_row):
-        m = int(m)
-        if m & L.TRK_MASK_NOCALL:
-            out.append('NOCALL')
-        elif m == 0:
-            out.append('PASS')
-        else:
-            out.append(','.join('%s_%s' % (names[k], '%g' % values_l[k][s])
-                                for k in range(len(names)) if (m >> k) & 1))
-    return out
+    return vcfio.CallFilterColumn(mask_row, names, values_l).to_list()
 
 
 def _null_filtered(vcfrecord, filtered, ploidy):
@@ -489,7 +479,7 @@ class _Run:
             fired = (mrow & np.uint32(0x7fffffff)) != 0
             vals = [_filter_values(f, planes, hb, l) if np.any((mrow >> np.uint32(k)) & 1) else None
                     for k, f in enumerate(self.call_filters)]
-            v.set_format('FILTER', np.array(_call_filter_text(mrow, names, vals)))
+            v.set_format('FILTER', vcfio.CallFilterColumn(mrow, names, vals))
             filtered = fired & ((mrow & np.uint32(L.TRK_MASK_NOCALL)) == 0)
             if np.any(filtered):
                 _null_filtered(v, filtered, r.GetMaxPloidy())

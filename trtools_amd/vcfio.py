@@ -21,6 +21,7 @@ batch packer and the TRRecord facade see what they would see from cyvcf2:
 It is host plumbing (a native block-parallel parser is SURVEY.md section 8f
 row 1), not part of the device hot path.
 """
+import ctypes
 import gzip
 import os
 import re
@@ -99,6 +100,72 @@ class _Info:
     def keys(self):
         return list(self._order)
 
+
+
+
+class CallFilterColumn:
+    """dumpSTR's FORMAT/FILTER column of one record, kept as the call-filter mask until the record is written
+    (dumpSTR.py:648-683): ``NOCALL`` (bit 31), ``PASS`` (0) or ``<name>_<%g value>`` of every fired filter, comma
+    joined.  ``to_array()`` is the text as a numpy string array; the native serialiser writes it from the mask."""
+
+    def __init__(self, mask, names, values):
+        self.mask = np.ascontiguousarray(mask, dtype=np.uint32)
+        self.names = list(names)
+        self.values = [None if v is None else np.ascontiguousarray(v, dtype=np.float64) for v in values]
+
+    def to_list(self):
+        m = self.mask
+        nocall = (m & np.uint32(0x80000000)) != 0
+        out = np.full(len(m), 'PASS', dtype=object)
+        out[nocall] = 'NOCALL'
+        nk = len(self.names)
+        for s in np.nonzero(~nocall & (m != 0))[0]:
+            ms = int(m[s])
+            out[s] = ','.join('%s_%s' % (self.names[k], '%g' % (np.nan if self.values[k] is None else self.values[k][s]))
+                              for k in range(nk) if (ms >> k) & 1)
+        return out.tolist()
+
+    def to_array(self):
+        return np.array(self.to_list()) if len(self.mask) else np.array([], dtype='<U1')
+
+    def max_text(self):
+        return max(8, sum(len(n.encode()) + 26 for n in self.names))
+
+    def native_struct(self):
+        nk = len(self.names)
+
+        class CallFilter(ctypes.Structure):
+            _fields_ = [('mask', ctypes.c_void_p), ('n_filters', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                        ('names', ctypes.POINTER(ctypes.c_char_p)), ('values', ctypes.POINTER(ctypes.c_void_p))]
+        names = (ctypes.c_char_p * max(nk, 1))(*[n.encode() for n in self.names])
+        vals = (ctypes.c_void_p * max(nk, 1))(*[None if v is None else v.ctypes.data for v in self.values])
+        st = CallFilter(self.mask.ctypes.data, nk, 0, names, vals)
+        return [st, names, vals, self]      # element 0 is the struct; the rest keeps its pointers alive
+
+_SERIALIZER = False
+
+
+def _serializer():
+    """(lib, Column struct) of the native record serialiser, or None when libtrk.so is not built -- text
+    formatting is host IO, not the compute path, and falls back to the Python loop."""
+    global _SERIALIZER
+    if _SERIALIZER is False:
+        _SERIALIZER = None
+        if os.environ.get('TRK_NATIVE_WRITER', '1') != '0':
+            try:
+                from . import _lib
+                lib = _lib.load()
+
+                class Column(ctypes.Structure):
+                    _fields_ = [('kind', ctypes.c_int32), ('ncol', ctypes.c_int32), ('itemsize', ctypes.c_int32),
+                                ('reserved', ctypes.c_int32), ('data', ctypes.c_void_p)]
+                lib.trk_vcf_format_samples.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(Column),
+                                                       ctypes.c_char_p, ctypes.c_int64]
+                lib.trk_vcf_format_samples.restype = ctypes.c_int64
+                _SERIALIZER = (lib, Column)
+            except (OSError, AttributeError, RuntimeError):
+                _SERIALIZER = None
+    return _SERIALIZER
 
 class Variant:
     """One VCF record with the cyvcf2.Variant surface the hot path touches."""
@@ -234,7 +301,10 @@ class Variant:
 
     def format(self, key):
         if key in self._set_formats:
-            return self._set_formats[key]
+            v = self._set_formats[key]
+            if isinstance(v, CallFilterColumn):
+                v = self._set_formats[key] = v.to_array()
+            return v
         if key.startswith('__') and key in self._fmt_cache:   # pre-parsed plane of the native reader
             return self._fmt_cache[key]
         if key not in self.FORMAT:
@@ -317,6 +387,11 @@ class Variant:
         return ';'.join(toks) if toks else '.'
 
     def __str__(self):
+        return self.to_text()
+
+    def to_text(self, native=True):
+        """The record line.  native=False: format the sample columns with the Python loop (the definition the
+        native serialiser is tested against)."""
         f = self._fields
         filt = 'PASS' if self._filter is None and f[6] != '.' else (self._filter or f[6])
         if self._filter is not None:
@@ -326,10 +401,75 @@ class Variant:
         if not self.FORMAT:
             return '\t'.join(head) + '\n'
         head.append(':'.join(self.FORMAT))
+        body = self._samples_text_native() if native else None
+        if body is not None:
+            return '\t'.join(head) + body + '\n'
         n = len(self._samples)
         for i in range(n):
             head.append(':'.join(self._format_value(k, i) for k in self.FORMAT))
         return '\t'.join(head) + '\n'
+
+    def _samples_text_native(self):
+        """The per-sample columns ('\\t' + fields joined by ':' for every sample) from the typed FORMAT arrays,
+        serialised by libtrk (trk_vcf_format_samples, include/trk_vcf.h) -- the same text the loop over
+        ``_format_value`` builds.  None when a column is not a plain int32 / float32 / fixed-width string array
+        (object arrays, other integer widths): the caller then formats in Python."""
+        api = _serializer()
+        if api is None or self._gt is None and 'GT' in self.FORMAT:
+            return None
+        lib, Column = api
+        n = self.n_samples_hint()
+        if n == 0:
+            return None
+        cols = (Column * len(self.FORMAT))()
+        keep = []
+        cap = 0
+        for i, key in enumerate(self.FORMAT):
+            lazy = self._set_formats.get(key)
+            if key == 'GT':
+                arr = np.ascontiguousarray(self._gt, dtype=np.int16)
+                kind, ncol, item = 0, arr.shape[1], 0
+                cap += n * (7 * ncol + 1)
+            elif isinstance(lazy, CallFilterColumn):
+                if len(lazy.mask) != n:
+                    return None
+                arr = lazy.native_struct()
+                keep.append(arr)
+                cols[i] = Column(5, 1, 0, 0, ctypes.addressof(arr[0]))
+                cap += n * lazy.max_text()
+                continue
+            else:
+                arr = self.format(key)
+                if not isinstance(arr, np.ndarray) or arr.shape[:1] != (n,) or arr.ndim > 2:
+                    return None
+                dk = arr.dtype.kind
+                if dk in 'if':
+                    if arr.dtype != (np.int32 if dk == 'i' else np.float32):
+                        return None
+                    arr = np.ascontiguousarray(arr.reshape(n, -1))
+                    if arr.shape[1] < 1:
+                        return None
+                    kind, ncol, item = (1 if dk == 'i' else 2), arr.shape[1], 0
+                    cap += n * (17 * ncol + 1)
+                elif dk in 'US' and arr.ndim == 1 and arr.dtype.itemsize > 0 and arr.dtype.isnative:
+                    arr = np.ascontiguousarray(arr)
+                    kind, ncol, item = (4 if dk == 'U' else 3), 1, arr.dtype.itemsize
+                    cap += n * (item + 2)
+                else:
+                    return None
+            keep.append(arr)
+            cols[i] = Column(kind, ncol, item, 0, arr.ctypes.data)
+        cap += n + 16
+        buf = ctypes.create_string_buffer(cap)
+        got = lib.trk_vcf_format_samples(n, len(self.FORMAT), cols, buf, cap)
+        if got < 0:
+            return None
+        return buf.raw[:got].decode()
+
+    def n_samples_hint(self):
+        if self._gt is not None:
+            return int(self._gt.shape[0])
+        return len(self._samples)
 
 
 def _fmt_float(x):
