@@ -105,6 +105,26 @@ typedef struct {
 int64_t trk_vcf_format_samples(int32_t n_samples, int32_t n_columns, const trk_vcf_column* cols, char* out,
                                int64_t cap);
 
+/* ---- typed decode of every FORMAT field of one record ----------------------------------
+ * What cyvcf2's Variant.format(key) returns for the fields the batch reader was not asked to
+ * select (dumpSTR touches ALL of them when it nulls a filtered call, dumpSTR.py:730-746):
+ *   INT    int32  [S, k]  '.' -> INT_MIN, short vectors padded with INT_MIN + 1, k = longest vector
+ *   FLOAT  float32 [S, k] '.' and padding -> NaN (text -> double -> float)
+ *   UCS4   [S] strings of ncol code points, NUL padded (numpy '<U<ncol>'); ncol >= 1
+ * `samples` is the tab separated sample columns of the record line (text[field_off[9] ..]);
+ * a sample with fewer fields than FORMAT reads as '.' for the rest.  Two calls: pass 0 fills
+ * `ncol` of every field whose kind is INT / FLOAT / UCS4 (other kinds are skipped), the caller
+ * allocates `out`, pass 1 fills the arrays.  Returns 0; 1 when the number of sample columns is
+ * not n_samples; 2 for a token that is not a number (the caller falls back to its own parser
+ * for the error text); -1 for bad arguments.                                                  */
+typedef struct {
+    int32_t kind;
+    int32_t ncol;
+    void* out;
+} trk_vcf_decode;
+int trk_vcf_decode_formats(const char* samples, int64_t len, int32_t n_samples, int32_t n_fields,
+                           trk_vcf_decode* fields, int32_t pass);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,3 +100,50 @@ def test_value_forms():
     small = ctypes.create_string_buffer(8)
     assert lib.trk_vcf_format_samples(5, 5, cols, small, 8) == -n
     assert lib.trk_vcf_format_samples(-1, 5, cols, small, 8) < -10**15
+
+
+@pytest.mark.parametrize('path', FILES, ids=[os.path.relpath(p, DATA) for p in FILES])
+def test_native_format_decode_equals_python_decode(path, monkeypatch):
+    """trk_vcf_decode_formats against the Python field decoder (Variant._numeric / np.array(col)), every FORMAT
+    field of every record: same dtype, shape and values (NaN == NaN)."""
+    assert vcfio._serializer() is not None, "libtrk.so is not built"
+
+    def decode_all(limit=80):
+        out = []
+        try:
+            for k, v in enumerate(vcfio.VCFReader(path)):
+                if k >= limit:
+                    break
+                rec = {}
+                for key in v.FORMAT:
+                    if key == 'GT':
+                        continue
+                    try:
+                        rec[key] = v.format(key)
+                    except (ValueError, KeyError) as e:
+                        rec[key] = type(e).__name__
+                out.append((rec, v._cols is None))
+        except (ValueError, KeyError, IndexError):
+            pass
+        return out
+
+    nat = decode_all()
+    monkeypatch.setattr(vcfio, '_SERIALIZER', None)
+    py = decode_all()
+    assert len(nat) == len(py)
+    n_native = 0
+    for (a, a_native), (b, _) in zip(nat, py):
+        n_native += bool(a_native)
+        assert a.keys() == b.keys()
+        for key in a:
+            x, y = a[key], b[key]
+            if isinstance(y, str):
+                assert x == y, key
+                continue
+            assert x.dtype == y.dtype and x.shape == y.shape, (key, x.dtype, y.dtype, x.shape, y.shape)
+            if x.dtype.kind == 'f':
+                assert np.array_equal(x, y, equal_nan=True), key
+            else:
+                assert np.array_equal(x, y), key
+    if nat and any(len(r) for r, _ in nat):
+        assert n_native > 0, "the native decoder was never used"

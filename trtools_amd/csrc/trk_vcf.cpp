@@ -755,4 +755,121 @@ int64_t trk_vcf_format_samples(int32_t n_samples, int32_t n_columns, const trk_v
     return o.n <= cap ? o.n : -o.n;
 }
 
+// ---- typed decode of all FORMAT fields of one record (trk_vcf.h) -----------------------------
+namespace {
+inline int utf8_len(const char* p, const char* e) {   // code points in [p, e)
+    int n = 0;
+    for (; p < e; ++p) n += ((unsigned char)*p & 0xc0) != 0x80;
+    return n;
+}
+inline void utf8_to_ucs4(const char* p, const char* e, uint32_t* out) {
+    while (p < e) {
+        const unsigned char c = (unsigned char)*p;
+        uint32_t cp;
+        int extra;
+        if (c < 0x80) { cp = c; extra = 0; }
+        else if ((c & 0xe0) == 0xc0) { cp = c & 0x1f; extra = 1; }
+        else if ((c & 0xf0) == 0xe0) { cp = c & 0x0f; extra = 2; }
+        else { cp = c & 0x07; extra = 3; }
+        ++p;
+        for (int i = 0; i < extra && p < e; ++i, ++p) cp = (cp << 6) | ((unsigned char)*p & 0x3f);
+        *out++ = cp;
+    }
+}
+}  // namespace
+
+int trk_vcf_decode_formats(const char* samples, int64_t len, int32_t n_samples, int32_t n_fields,
+                           trk_vcf_decode* fields, int32_t pass) {
+    if (!samples || len < 0 || n_samples < 0 || n_fields < 0 || (n_fields && !fields)) return -1;
+    const char* p = samples;
+    const char* end = samples + len;
+    while (end > p && (end[-1] == '\n' || end[-1] == '\r')) --end;
+    if (pass == 0)
+        for (int f = 0; f < n_fields; ++f) fields[f].ncol = 1;
+    int64_t s = 0;
+    if (p == end) return n_samples == 0 ? 0 : 1;
+    static const char dot[] = ".";
+    while (true) {
+        if (s >= n_samples) return 1;
+        const char* se = static_cast<const char*>(memchr(p, '\t', (size_t)(end - p)));
+        if (!se) se = end;
+        const char* q = p;
+        bool exhausted = false;
+        for (int f = 0; f < n_fields; ++f) {
+            const char* tb;
+            const char* te;
+            if (exhausted) {
+                tb = dot;
+                te = dot + 1;
+            } else {
+                tb = q;
+                te = static_cast<const char*>(memchr(q, ':', (size_t)(se - q)));
+                if (!te) {
+                    te = se;
+                    exhausted = true;
+                } else {
+                    q = te + 1;
+                }
+            }
+            trk_vcf_decode& d = fields[f];
+            if (d.kind == TRK_VCF_COL_UCS4) {
+                if (pass == 0) {
+                    const int n = utf8_len(tb, te);
+                    if (n > d.ncol) d.ncol = n;
+                } else {
+                    uint32_t* o = static_cast<uint32_t*>(d.out) + s * d.ncol;
+                    utf8_to_ucs4(tb, te, o);   // the caller zero-filled the array
+                }
+            } else if (d.kind == TRK_VCF_COL_INT || d.kind == TRK_VCF_COL_FLOAT) {
+                if (pass == 0) {
+                    int n = 1;
+                    for (const char* c = tb; c < te; ++c) n += *c == ',';
+                    if (n > d.ncol) d.ncol = n;
+                } else {
+                    int j = 0;
+                    const char* c = tb;
+                    while (true) {
+                        const char* ce = static_cast<const char*>(memchr(c, ',', (size_t)(te - c)));
+                        if (!ce) ce = te;
+                        if (j >= d.ncol) return -1;
+                        const bool missing = ce - c == 1 && *c == '.';
+                        if (d.kind == TRK_VCF_COL_INT) {
+                            int32_t v = INT32_MIN;
+                            if (!missing) {
+                                auto r = std::from_chars(c, ce, v);
+                                if (r.ec != std::errc() || r.ptr != ce) return 2;
+                            }
+                            static_cast<int32_t*>(d.out)[s * d.ncol + j] = v;
+                        } else {
+                            float v = NAN;
+                            if (!missing) {
+                                double x;
+                                auto r = std::from_chars(c, ce, x);
+                                if (r.ec == std::errc::result_out_of_range && r.ptr == ce) {
+                                    x = strtod(std::string(c, ce).c_str(), nullptr);   // inf / denormal as Python's float()
+                                } else if (r.ec != std::errc() || r.ptr != ce) {
+                                    return 2;
+                                }
+                                v = (float)x;
+                            }
+                            static_cast<float*>(d.out)[s * d.ncol + j] = v;
+                        }
+                        ++j;
+                        if (ce == te) break;
+                        c = ce + 1;
+                    }
+                    if (d.kind == TRK_VCF_COL_INT)
+                        for (; j < d.ncol; ++j) static_cast<int32_t*>(d.out)[s * d.ncol + j] = INT32_MIN + 1;
+                    else
+                        for (; j < d.ncol; ++j) static_cast<float*>(d.out)[s * d.ncol + j] = NAN;
+                }
+            }
+        }
+        ++s;
+        if (se == end) break;
+        p = se + 1;
+    }
+    return s == n_samples ? 0 : 1;
+}
+
 }  // extern "C"

@@ -350,9 +350,7 @@ def _null_filtered(vcfrecord, filtered, ploidy):
         vals = np.array(vcfrecord.format(field))
         kind = vals.dtype.kind
         if kind in 'US':
-            vals = vals.astype(object)
-            vals[filtered] = '.'
-            vals = np.array([str(v) for v in vals])
+            vals[filtered] = '.'      # fixed-width arrays hold at least one character
         elif kind == 'f':
             vals[filtered] = np.nan
         elif kind == 'i':

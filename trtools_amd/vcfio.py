@@ -142,6 +142,10 @@ class CallFilterColumn:
         st = CallFilter(self.mask.ctypes.data, nk, 0, names, vals)
         return [st, names, vals, self]      # element 0 is the struct; the rest keeps its pointers alive
 
+class _Decode(ctypes.Structure):
+    _fields_ = [('kind', ctypes.c_int32), ('ncol', ctypes.c_int32), ('out', ctypes.c_void_p)]
+
+
 _SERIALIZER = False
 
 
@@ -162,6 +166,8 @@ def _serializer():
                 lib.trk_vcf_format_samples.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(Column),
                                                        ctypes.c_char_p, ctypes.c_int64]
                 lib.trk_vcf_format_samples.restype = ctypes.c_int64
+                lib.trk_vcf_decode_formats.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                                       ctypes.POINTER(_Decode), ctypes.c_int32]
                 _SERIALIZER = (lib, Column)
             except (OSError, AttributeError, RuntimeError):
                 _SERIALIZER = None
@@ -311,6 +317,8 @@ class Variant:
             raise KeyError(key)
         if key in self._fmt_cache:
             return self._fmt_cache[key]
+        if key != 'GT' and self._cols is None and self._decode_formats_native() and key in self._fmt_cache:
+            return self._fmt_cache[key]
         col = self._columns()[self.FORMAT.index(key)]
         typ = self._reader.format_types.get(key, ('String', '1'))[0]
         if key == 'GT':
@@ -323,6 +331,51 @@ class Variant:
             out = np.array(col) if len(col) else np.array([], dtype='<U1')
         self._fmt_cache[key] = out
         return out
+
+    def _decode_formats_native(self):
+        """Decode every not yet cached Integer / Float / String FORMAT field of the record in one native pass over
+        the sample columns (trk_vcf_decode_formats, include/trk_vcf.h) -- the arrays ``_numeric`` / ``np.array(col)``
+        below build.  False when libtrk.so is not built or the text does not parse (the Python decoder then raises
+        the error the reference's reader would)."""
+        api = _serializer()
+        if api is None:
+            return False
+        lib = api[0]
+        tail = self._tail
+        if self._samples_list is not None:
+            tail = '\t'.join(self._samples_list)
+        raw = tail if isinstance(tail, bytes) else tail.encode()
+        n = self._reader.n_samples if self._gt is None else int(self._gt.shape[0])
+        nf = len(self.FORMAT)
+        if n == 0 or nf == 0:
+            return False
+        fields = (_Decode * nf)()
+        want = []
+        for i, key in enumerate(self.FORMAT):
+            kind = -1
+            if key != 'GT' and key not in self._fmt_cache:
+                typ = self._reader.format_types.get(key, ('String', '1'))[0]
+                kind = 1 if typ == 'Integer' else 2 if typ == 'Float' else 4
+                want.append(i)
+            fields[i].kind = kind
+        if not want:
+            return False
+        if lib.trk_vcf_decode_formats(raw, len(raw), n, nf, fields, 0) != 0:
+            return False
+        outs = {}
+        for i in want:
+            k = fields[i].ncol
+            if fields[i].kind == 4:
+                arr = np.zeros(n, dtype='<U%d' % k)
+            else:
+                arr = np.empty((n, k), dtype=np.int32 if fields[i].kind == 1 else np.float32)
+            outs[i] = arr
+            fields[i].out = arr.ctypes.data
+        if lib.trk_vcf_decode_formats(raw, len(raw), n, nf, fields, 1) != 0:
+            return False
+        for i in want:
+            self._fmt_cache[self.FORMAT[i]] = outs[i]
+        return True
 
     @staticmethod
     def _numeric(col, dtype, missing, pad, conv):
