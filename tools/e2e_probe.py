@@ -58,6 +58,10 @@ if not a.no_gpu:
                        nalleles=True, nalleles_thresh=0.01, only_passing=False)
     t = time.time(); rc = statSTR.main(ns); t4 = time.time() - t
     print("statSTR CLI end to end (11 stats): rc=%d %6.2fs  %.0f loci/s  %.2e cells/s" % (rc, t4, a.loci / t4, cells / t4))
+    if os.environ.get('E2E_PROFILE'):
+        import cProfile, pstats
+        pr = cProfile.Profile(); pr.enable(); statSTR.main(ns); pr.disable()
+        pstats.Stats(pr).sort_stats('tottime').print_stats(16)
     # dumpSTR end to end: the same file through call filters + locus filters to an output VCF and the two logs
     from trtools_amd.dumpSTR import dumpSTR
     old = sys.argv
