@@ -88,6 +88,7 @@ class Workload:
         if world > 1 or os.environ.get('TRK_FORCE_DIST'):
             self.gather = eng.empty((world, self.n_loci), np.uint32)
         self.step_no = 0
+        self.overlap = os.environ.get('TRK_BENCH_OVERLAP', '1') != '0'
 
     def step(self):
         eng = self.eng
@@ -99,13 +100,23 @@ class Workload:
         self.call_out.sample_totaldp.zero()
         self.call_out.sample_dp_missing.zero()
         self.loc_counters.zero()
-        eng.locus_stats(b, out=self.stats_a[i])
+        # statSTR: count (queue 0), then its finaliser on queue 1 -- latency-bound, it runs beside the HBM-bound
+        # call-filter pass of dumpSTR instead of in front of it (TRK_BENCH_OVERLAP=0: everything on queue 0)
+        eng.locus_stats(b, out=self.stats_a[i], count_only=True)
         self.stats_b[i].allele_count.copy_from(self.stats_a[i].allele_count)
         self.stats_b[i].locus_int.copy_from(self.stats_a[i].locus_int)
+        if self.overlap:
+            eng.queue_wait(1, 0)
+            with eng.on_queue(1):
+                eng.locus_finalize(b, self.stats_a[i])
+        else:
+            eng.locus_finalize(b, self.stats_a[i])
         eng.call_filters(b, self.planes, self.filters, dp_plane=0, out=self.call_out, delta_stats=self.stats_b[i])
         eng.locus_finalize(b, self.stats_b[i])
         eng.locus_filters(self.n_loci, self.stats_b[i], bits_out=self.bits, counters=self.loc_counters,
                           **self.locus_args)
+        if self.overlap:
+            eng.queue_wait(0, 1)
         if self.gather is not None:
             eng.allreduce_sum_i64(self.call_out.sample_counters)
             eng.allreduce_sum_i64(self.call_out.sample_totaldp)

@@ -72,6 +72,15 @@ int trk_memcpy_d2h(trk_ctx* ctx, void* dst_host, const void* src_dev, size_t byt
 int trk_memcpy_d2d(trk_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes); /* async on the stream */
 int trk_memset(trk_ctx* ctx, void* dst_dev, int value, size_t bytes);
 int trk_sync(trk_ctx* ctx);
+/* A context owns TRK_N_STREAMS in-order queues (HIP streams).  Every entry point enqueues on the selected
+ * one (queue 0 after trk_init); trk_stream_wait makes `waiter` wait for what has been enqueued on `signal`
+ * so far; trk_sync waits for all of them.  Each queue has its own finaliser scratch, so independent work
+ * can overlap -- bench.py runs statSTR's finaliser (k_locus_finalize + k_hwe_test, latency bound) on
+ * queue 1 beside dumpSTR's call-filter pass (HBM bound) on queue 0.  The associaTR entry points share one
+ * workspace: use them from one queue at a time.                                                        */
+#define TRK_N_STREAMS 2
+int trk_stream_select(trk_ctx* ctx, int queue);
+int trk_stream_wait(trk_ctx* ctx, int waiter, int signal);
 
 /* ---- timing on the context's stream (HIP events) ------------------------ */
 /* Slots 0..TRK_N_TIMERS-1.  start/stop enqueue events on the compute stream;

@@ -254,3 +254,36 @@ def test_sentinel_mixes_on_the_streaming_kernel(eng):
     b = eng.make_batch(gt, off, lc, sc, cv)
     cnt, li, lf = _fetch(eng.locus_stats(b, nalleles_thresh=0.02))
     check_against_oracle(orc, L, cnt, li, lf, off, gt, lens, strs, [None], 0.02)
+
+
+def test_two_queues_give_the_same_statistics(eng):
+    """trk_stream_select / trk_stream_wait: the finaliser on queue 1 beside a call-filter pass on queue 0 (what
+    bench.py overlaps) returns what the single-queue sequence returns."""
+    from trtools_amd import _lib as L
+    from trtools_amd.synth import SynthBatch
+    sb = SynthBatch(eng, 300, 2000, seed=99, planes=('dp', 'q'))
+    want = eng.locus_stats(sb.batch)
+    filters = [dict(op=L.F_LT, plane_a=0, thr=10), dict(op=L.F_LT, plane_a=1, thr=0.9)]
+    planes = [sb.dev['dp'], sb.dev['q']]
+    ref_b = eng.locus_stats(sb.batch, count_only=True)
+    ref_call = eng.call_filters(sb.batch, planes, filters, dp_plane=0, delta_stats=ref_b)
+    eng.locus_finalize(sb.batch, ref_b)
+    for _ in range(3):
+        a = eng.locus_stats(sb.batch, count_only=True)
+        b = eng.alloc_stats(sb.batch)
+        b.allele_count.copy_from(a.allele_count)
+        b.locus_int.copy_from(a.locus_int)
+        eng.queue_wait(1, 0)
+        with eng.on_queue(1):
+            eng.locus_finalize(sb.batch, a)
+        res = eng.call_filters(sb.batch, planes, filters, dp_plane=0, delta_stats=b)
+        eng.locus_finalize(sb.batch, b)
+        eng.queue_wait(0, 1)
+        eng.sync()
+        assert np.array_equal(a.locus_int.get(), want.locus_int.get())
+        assert np.array_equal(a.locus_f64.get(), want.locus_f64.get(), equal_nan=True)
+        assert np.array_equal(b.locus_int.get(), ref_b.locus_int.get())
+        assert np.array_equal(b.locus_f64.get(), ref_b.locus_f64.get(), equal_nan=True)
+        assert np.array_equal(res.filter_mask.get(), ref_call.filter_mask.get())
+    with pytest.raises(Exception):
+        eng.queue_wait(0, 7)

@@ -123,7 +123,7 @@ EXPORTS = [
     'trk_locus_stats', 'trk_locus_finalize', 'trk_call_filters', 'trk_locus_filters',
     'trk_comm_unique_id', 'trk_comm_init', 'trk_allreduce_sum_i64', 'trk_allgather',
     'trk_binomtest_two_sided', 'trk_binom_pmf', 'trk_synth_fill', 'trk_synth_fill_gangstr',
-    'trk_assoc_scan', 'trk_assoc_scan_dosage', 'trk_student_t_two_sided', 'trk_dosages', 'trk_planarize',
+    'trk_assoc_scan', 'trk_assoc_scan_dosage', 'trk_student_t_two_sided', 'trk_dosages', 'trk_planarize', 'trk_stream_select', 'trk_stream_wait',
 ]
 
 _lib = None
@@ -182,6 +182,8 @@ def load():
     lib.trk_assoc_scan.argtypes = [vp, P(Batch), P(AssocParams), P(AssocOut)]
     lib.trk_assoc_scan_dosage.argtypes = [vp, P(Batch), P(AssocParams), P(AssocDosage), P(AssocOut), vp, vp]
     lib.trk_planarize.argtypes = [vp, vp, vp, i64, C.c_int32]
+    lib.trk_stream_select.argtypes = [vp, C.c_int]
+    lib.trk_stream_wait.argtypes = [vp, C.c_int, C.c_int]
     lib.trk_dosages.argtypes = [vp, P(Batch), vp, C.c_int, vp, vp, C.c_int, vp, vp]
     lib.trk_student_t_two_sided.argtypes = [dbl, dbl]
     lib.trk_student_t_two_sided.restype = dbl

@@ -71,7 +71,12 @@ struct ProfRec {
 struct trk_ctx {
     int device = 0;
     int n_cu = 256;
-    hipStream_t stream = nullptr;
+    // two in-order queues (trk_stream_select / trk_stream_wait): entry points enqueue on the selected one, and
+    // each has its own finaliser scratch, so that e.g. statSTR's finaliser can run beside dumpSTR's call-filter pass
+    hipStream_t streams[TRK_N_STREAMS] = {};
+    hipEvent_t join_event[TRK_N_STREAMS] = {};
+    int cur = 0;
+    hipStream_t s() const { return streams[cur]; }
     std::string err;
     hipEvent_t t_start[TRK_N_TIMERS] = {};
     hipEvent_t t_stop[TRK_N_TIMERS] = {};
@@ -80,10 +85,10 @@ struct trk_ctx {
     std::vector<hipEvent_t> event_pool;
     int64_t prof_n[TRK_K_COUNT] = {};
     double prof_ms[TRK_K_COUNT] = {};
-    int32_t* scratch = nullptr;  // finaliser class-count scratch
-    size_t scratch_bytes = 0;
-    void* worklist = nullptr;    // deferred HWE tests (count + items)
-    size_t worklist_bytes = 0;
+    int32_t* scratch_[TRK_N_STREAMS] = {};  // finaliser class-count scratch (per queue)
+    size_t scratch_bytes_[TRK_N_STREAMS] = {};
+    void* worklist_[TRK_N_STREAMS] = {};    // deferred HWE tests (count + items)
+    size_t worklist_bytes_[TRK_N_STREAMS] = {};
     void* assoc_ws = nullptr;    // associaTR scan workspace (Gram, partial records, class counts)
     size_t assoc_ws_bytes = 0;
     ncclComm_t comm = nullptr;
@@ -124,16 +129,18 @@ struct ProfScope {
     trk_ctx* ctx;
     ProfRec rec;
     bool on;
+    hipStream_t st = nullptr;
     ProfScope(trk_ctx* c, int kernel) : ctx(c), on(c->profiling) {
         if (!on) return;
         rec.kernel = kernel;
         rec.start = get_event(c);
         rec.stop = get_event(c);
-        (void)hipEventRecord(rec.start, c->stream);
+        st = c->s();
+        (void)hipEventRecord(rec.start, st);
     }
     ~ProfScope() {
         if (!on) return;
-        (void)hipEventRecord(rec.stop, ctx->stream);
+        (void)hipEventRecord(rec.stop, st);
         ctx->prof_pending.push_back(rec);
     }
 };
@@ -179,10 +186,13 @@ int trk_init(int device, trk_ctx** out) {
     ctx->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
-    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) {
-        delete ctx;
-        return fail(nullptr, TRK_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    for (int i = 0; i < TRK_N_STREAMS; ++i) {
+        e = hipStreamCreateWithFlags(&ctx->streams[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_event[i], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            delete ctx;
+            return fail(nullptr, TRK_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        }
     }
     for (int i = 0; i < TRK_N_TIMERS; ++i) {
         (void)hipEventCreate(&ctx->t_start[i]);
@@ -195,7 +205,7 @@ int trk_init(int device, trk_ctx** out) {
 void trk_free(trk_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < TRK_N_STREAMS; ++i) (void)hipStreamSynchronize(ctx->streams[i]);
     drain_profile(ctx);
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -203,10 +213,13 @@ void trk_free(trk_ctx* ctx) {
         (void)hipEventDestroy(ctx->t_start[i]);
         (void)hipEventDestroy(ctx->t_stop[i]);
     }
-    if (ctx->scratch) (void)hipFree(ctx->scratch);
-    if (ctx->worklist) (void)hipFree(ctx->worklist);
+    for (int i = 0; i < TRK_N_STREAMS; ++i) {
+        if (ctx->scratch_[i]) (void)hipFree(ctx->scratch_[i]);
+        if (ctx->worklist_[i]) (void)hipFree(ctx->worklist_[i]);
+        if (ctx->join_event[i]) (void)hipEventDestroy(ctx->join_event[i]);
+        if (ctx->streams[i]) (void)hipStreamDestroy(ctx->streams[i]);
+    }
     if (ctx->assoc_ws) (void)hipFree(ctx->assoc_ws);
-    (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -239,51 +252,67 @@ int trk_dev_alloc(trk_ctx* ctx, size_t bytes, void** dptr) {
 int trk_dev_free(trk_ctx* ctx, void* dptr) {
     if (!ctx) return TRK_ERR_ARG;
     if (!dptr) return TRK_OK;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < TRK_N_STREAMS; ++i) HIPCHK(ctx, hipStreamSynchronize(ctx->streams[i]));
     HIPCHK(ctx, hipFree(dptr));
     return TRK_OK;
 }
 int trk_memcpy_h2d(trk_ctx* ctx, void* d, const void* h, size_t n) {
     if (!ctx) return TRK_ERR_ARG;
     if (n == 0) return TRK_OK;
-    HIPCHK(ctx, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, ctx->s()));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->s()));
     return TRK_OK;
 }
 int trk_memcpy_d2h(trk_ctx* ctx, void* h, const void* d, size_t n) {
     if (!ctx) return TRK_ERR_ARG;
     if (n == 0) return TRK_OK;
-    HIPCHK(ctx, hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, ctx->s()));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->s()));
     return TRK_OK;
 }
 int trk_memcpy_d2d(trk_ctx* ctx, void* d, const void* s, size_t n) {
     if (!ctx) return TRK_ERR_ARG;
     if (n == 0) return TRK_OK;
-    HIPCHK(ctx, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, ctx->s()));
     return TRK_OK;
 }
 int trk_memset(trk_ctx* ctx, void* d, int v, size_t n) {
     if (!ctx) return TRK_ERR_ARG;
     if (n == 0) return TRK_OK;
-    HIPCHK(ctx, hipMemsetAsync(d, v, n, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(d, v, n, ctx->s()));
     return TRK_OK;
 }
 int trk_sync(trk_ctx* ctx) {
     if (!ctx) return TRK_ERR_ARG;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < TRK_N_STREAMS; ++i) HIPCHK(ctx, hipStreamSynchronize(ctx->streams[i]));
+    return TRK_OK;
+}
+int trk_stream_select(trk_ctx* ctx, int queue) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (queue < 0 || queue >= TRK_N_STREAMS) return fail(ctx, TRK_ERR_ARG, "queue %d outside [0, %d)", queue, TRK_N_STREAMS);
+    ctx->cur = queue;
+    return TRK_OK;
+}
+int trk_stream_wait(trk_ctx* ctx, int waiter, int signal) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (waiter < 0 || waiter >= TRK_N_STREAMS || signal < 0 || signal >= TRK_N_STREAMS)
+        return fail(ctx, TRK_ERR_ARG, "queue outside [0, %d)", TRK_N_STREAMS);
+    if (waiter == signal) return TRK_OK;
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipEventRecord(ctx->join_event[signal], ctx->streams[signal]));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->streams[waiter], ctx->join_event[signal], 0));
     return TRK_OK;
 }
 
 // ---- timers / profiling ----------------------------------------------------------
 int trk_timer_start(trk_ctx* ctx, int slot) {
     if (!ctx || slot < 0 || slot >= TRK_N_TIMERS) return TRK_ERR_ARG;
-    HIPCHK(ctx, hipEventRecord(ctx->t_start[slot], ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->t_start[slot], ctx->s()));
     return TRK_OK;
 }
 int trk_timer_stop(trk_ctx* ctx, int slot) {
     if (!ctx || slot < 0 || slot >= TRK_N_TIMERS) return TRK_ERR_ARG;
-    HIPCHK(ctx, hipEventRecord(ctx->t_stop[slot], ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->t_stop[slot], ctx->s()));
     return TRK_OK;
 }
 int trk_timer_elapsed_ms(trk_ctx* ctx, int slot, float* ms) {
@@ -342,45 +371,45 @@ int trk_locus_stats(trk_ctx* ctx, const trk_batch* in, const trk_stats_params* p
     (void)hipSetDevice(ctx->device);
     const int G = in->group_bits ? in->n_groups : 1;
     const int64_t sumA = in->n_alleles_total;
-    HIPCHK(ctx, hipMemsetAsync(out->allele_count, 0, (size_t)G * sumA * sizeof(int32_t), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(out->allele_count, 0, (size_t)G * sumA * sizeof(int32_t), ctx->s()));
     HIPCHK(ctx, hipMemsetAsync(out->locus_int, 0, (size_t)G * in->n_loci * TRK_LI_COLS * sizeof(int32_t),
-                               ctx->stream));
+                               ctx->s()));
     {
         ProfScope ps(ctx, TRK_K_LOCUS_COUNT);
         HIPCHK(ctx, trk::launch_locus_count(*in, in->max_alleles, out->allele_count, out->locus_int,
-                                            ctx->n_cu, ctx->stream));
+                                            ctx->n_cu, ctx->s()));
     }
     if (count_only) return TRK_OK;
     rc = ensure_fin_buffers(ctx, G, sumA, in->n_loci);
     if (rc) return rc;
     {
         ProfScope ps(ctx, TRK_K_LOCUS_FINALIZE);
-        HIPCHK(ctx, trk::launch_locus_finalize(*in, out->allele_count, out->locus_int, out->locus_f64, ctx->scratch,
-                                               ctx->worklist, prm ? prm->nalleles_thresh : 0.01, ctx->stream));
+        HIPCHK(ctx, trk::launch_locus_finalize(*in, out->allele_count, out->locus_int, out->locus_f64, ctx->scratch_[ctx->cur],
+                                               ctx->worklist_[ctx->cur], prm ? prm->nalleles_thresh : 0.01, ctx->s()));
     }
     return TRK_OK;
 }
 
 static int ensure_fin_buffers(trk_ctx* ctx, int G, int64_t sumA, int n_loci) {
     size_t need = (size_t)G * 2 * (size_t)sumA * sizeof(int32_t) + 16;
-    if (need > ctx->scratch_bytes) {
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->scratch) (void)hipFree(ctx->scratch);
-        ctx->scratch = nullptr;
-        ctx->scratch_bytes = 0;
-        hipError_t e = hipMalloc((void**)&ctx->scratch, need);
+    if (need > ctx->scratch_bytes_[ctx->cur]) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->s()));
+        if (ctx->scratch_[ctx->cur]) (void)hipFree(ctx->scratch_[ctx->cur]);
+        ctx->scratch_[ctx->cur] = nullptr;
+        ctx->scratch_bytes_[ctx->cur] = 0;
+        hipError_t e = hipMalloc((void**)&ctx->scratch_[ctx->cur], need);
         if (e != hipSuccess) return fail(ctx, TRK_ERR_NOMEM, "scratch hipMalloc(%zu): %s", need, hipGetErrorString(e));
-        ctx->scratch_bytes = need;
+        ctx->scratch_bytes_[ctx->cur] = need;
     }
     size_t wneed = trk::finalize_worklist_bytes((int64_t)G * n_loci);
-    if (wneed > ctx->worklist_bytes) {
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->worklist) (void)hipFree(ctx->worklist);
-        ctx->worklist = nullptr;
-        ctx->worklist_bytes = 0;
-        hipError_t e = hipMalloc(&ctx->worklist, wneed);
+    if (wneed > ctx->worklist_bytes_[ctx->cur]) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->s()));
+        if (ctx->worklist_[ctx->cur]) (void)hipFree(ctx->worklist_[ctx->cur]);
+        ctx->worklist_[ctx->cur] = nullptr;
+        ctx->worklist_bytes_[ctx->cur] = 0;
+        hipError_t e = hipMalloc(&ctx->worklist_[ctx->cur], wneed);
         if (e != hipSuccess) return fail(ctx, TRK_ERR_NOMEM, "worklist hipMalloc(%zu): %s", wneed, hipGetErrorString(e));
-        ctx->worklist_bytes = wneed;
+        ctx->worklist_bytes_[ctx->cur] = wneed;
     }
     return TRK_OK;
 }
@@ -397,8 +426,8 @@ int trk_locus_finalize(trk_ctx* ctx, const trk_batch* in, const trk_stats_params
     rc = ensure_fin_buffers(ctx, G, in->n_alleles_total, in->n_loci);
     if (rc) return rc;
     ProfScope ps(ctx, TRK_K_LOCUS_FINALIZE);
-    HIPCHK(ctx, trk::launch_locus_finalize(*in, out->allele_count, out->locus_int, out->locus_f64, ctx->scratch,
-                                           ctx->worklist, prm ? prm->nalleles_thresh : 0.01, ctx->stream));
+    HIPCHK(ctx, trk::launch_locus_finalize(*in, out->allele_count, out->locus_int, out->locus_f64, ctx->scratch_[ctx->cur],
+                                           ctx->worklist_[ctx->cur], prm ? prm->nalleles_thresh : 0.01, ctx->s()));
     return TRK_OK;
 }
 
@@ -452,7 +481,7 @@ int trk_call_filters(trk_ctx* ctx, const trk_batch* in, const trk_plane* planes,
     (void)hipSetDevice(ctx->device);
     ProfScope ps(ctx, TRK_K_CALL_FILTER);
     HIPCHK(ctx, trk::launch_call_filter(*in, planes, n_planes, filters, n_filters, dp_plane, *out, ctx->n_cu,
-                                        ctx->stream));
+                                        ctx->s()));
     return TRK_OK;
 }
 
@@ -466,7 +495,7 @@ int trk_locus_filters(trk_ctx* ctx, int32_t n_loci, const trk_stats_out* stats, 
     (void)hipSetDevice(ctx->device);
     ProfScope ps(ctx, TRK_K_LOCUS_FILTER);
     HIPCHK(ctx, trk::launch_locus_filter(n_loci, stats->locus_int, stats->locus_f64, *spec, out->locus_bits,
-                                         out->loc_counters, ctx->stream));
+                                         out->loc_counters, ctx->s()));
     return TRK_OK;
 }
 
@@ -475,7 +504,7 @@ int trk_synth_fill(trk_ctx* ctx, const trk_synth_spec* spec, int16_t* gt, int32_
     if (!ctx || !spec || !gt) return fail(ctx, TRK_ERR_ARG, "synth arguments are NULL");
     (void)hipSetDevice(ctx->device);
     ProfScope ps(ctx, TRK_K_SYNTH);
-    HIPCHK(ctx, trk::launch_synth(*spec, gt, dp, q, dstutter, dflankindel, ctx->n_cu, ctx->stream));
+    HIPCHK(ctx, trk::launch_synth(*spec, gt, dp, q, dstutter, dflankindel, ctx->n_cu, ctx->s()));
     return TRK_OK;
 }
 
@@ -485,7 +514,7 @@ int trk_synth_fill_gangstr(trk_ctx* ctx, const trk_synth_spec* spec, const int16
         return fail(ctx, TRK_ERR_ARG, "synth (gangstr) arguments are NULL");
     (void)hipSetDevice(ctx->device);
     ProfScope ps(ctx, TRK_K_SYNTH);
-    HIPCHK(ctx, trk::launch_synth_gangstr(*spec, gt, dp, allele_repcn, qexp, repcn, rc, repci, ctx->n_cu, ctx->stream));
+    HIPCHK(ctx, trk::launch_synth_gangstr(*spec, gt, dp, allele_repcn, qexp, repcn, rc, repci, ctx->n_cu, ctx->s()));
     return TRK_OK;
 }
 
@@ -519,7 +548,7 @@ int trk_allreduce_sum_i64(trk_ctx* ctx, int64_t* dev, size_t count) {
     if (!ctx) return TRK_ERR_ARG;
     if (ctx->n_ranks <= 1 && !ctx->comm) return TRK_OK;
     if (!ctx->comm) return fail(ctx, TRK_ERR_RCCL, "communicator not initialised");
-    ncclResult_t r = g_rccl.AllReduce(dev, dev, count, trkNcclInt64, trkNcclSum, ctx->comm, ctx->stream);
+    ncclResult_t r = g_rccl.AllReduce(dev, dev, count, trkNcclInt64, trkNcclSum, ctx->comm, ctx->s());
     if (r != 0) return fail(ctx, TRK_ERR_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     return TRK_OK;
 }
@@ -527,11 +556,11 @@ int trk_allreduce_sum_i64(trk_ctx* ctx, int64_t* dev, size_t count) {
 int trk_allgather(trk_ctx* ctx, const void* send, void* recv, size_t bytes_per_rank) {
     if (!ctx) return TRK_ERR_ARG;
     if (ctx->n_ranks <= 1 && !ctx->comm) {
-        if (send != recv) HIPCHK(ctx, hipMemcpyAsync(recv, send, bytes_per_rank, hipMemcpyDeviceToDevice, ctx->stream));
+        if (send != recv) HIPCHK(ctx, hipMemcpyAsync(recv, send, bytes_per_rank, hipMemcpyDeviceToDevice, ctx->s()));
         return TRK_OK;
     }
     if (!ctx->comm) return fail(ctx, TRK_ERR_RCCL, "communicator not initialised");
-    ncclResult_t r = g_rccl.AllGather(send, recv, bytes_per_rank, trkNcclUint8, ctx->comm, ctx->stream);
+    ncclResult_t r = g_rccl.AllGather(send, recv, bytes_per_rank, trkNcclUint8, ctx->comm, ctx->s());
     if (r != 0) return fail(ctx, TRK_ERR_RCCL, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     return TRK_OK;
 }
@@ -553,7 +582,7 @@ int trk_assoc_scan(trk_ctx* ctx, const trk_batch* in, const trk_assoc_params* pr
     (void)hipSetDevice(ctx->device);
     const size_t need = trk::assoc_workspace_bytes(*in, prm->n_vec);
     if (need > ctx->assoc_ws_bytes) {
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->s()));
         if (ctx->assoc_ws) (void)hipFree(ctx->assoc_ws);
         ctx->assoc_ws = nullptr;
         ctx->assoc_ws_bytes = 0;
@@ -561,14 +590,14 @@ int trk_assoc_scan(trk_ctx* ctx, const trk_batch* in, const trk_assoc_params* pr
         if (e != hipSuccess) return fail(ctx, TRK_ERR_NOMEM, "assoc workspace hipMalloc(%zu): %s", need, hipGetErrorString(e));
         ctx->assoc_ws_bytes = need;
     }
-    HIPCHK(ctx, trk::launch_assoc_prepare(*in, *prm, *out, ctx->assoc_ws, ctx->stream));
+    HIPCHK(ctx, trk::launch_assoc_prepare(*in, *prm, *out, ctx->assoc_ws, ctx->s()));
     {
         ProfScope ps(ctx, TRK_K_ASSOC_SCAN);
-        HIPCHK(ctx, trk::launch_assoc_scan(*in, *prm, *out, ctx->assoc_ws, ctx->n_cu, ctx->stream));
+        HIPCHK(ctx, trk::launch_assoc_scan(*in, *prm, *out, ctx->assoc_ws, ctx->n_cu, ctx->s()));
     }
     {
         ProfScope ps(ctx, TRK_K_ASSOC_FINALIZE);
-        HIPCHK(ctx, trk::launch_assoc_finalize(*in, *prm, *out, ctx->assoc_ws, ctx->stream));
+        HIPCHK(ctx, trk::launch_assoc_finalize(*in, *prm, *out, ctx->assoc_ws, ctx->s()));
     }
     return TRK_OK;
 }
@@ -593,7 +622,7 @@ int trk_assoc_scan_dosage(trk_ctx* ctx, const trk_batch* in, const trk_assoc_par
     bb.max_alleles = 0;
     const size_t need = trk::assoc_workspace_bytes(bb, prm->n_vec);
     if (need > ctx->assoc_ws_bytes) {
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->s()));
         if (ctx->assoc_ws) (void)hipFree(ctx->assoc_ws);
         ctx->assoc_ws = nullptr;
         ctx->assoc_ws_bytes = 0;
@@ -602,7 +631,7 @@ int trk_assoc_scan_dosage(trk_ctx* ctx, const trk_batch* in, const trk_assoc_par
         ctx->assoc_ws_bytes = need;
     }
     ProfScope ps(ctx, TRK_K_ASSOC_SCAN);
-    HIPCHK(ctx, trk::launch_assoc_dosage(*in, *prm, *dos, *out, class_sums, locus_sums, ctx->assoc_ws, ctx->stream));
+    HIPCHK(ctx, trk::launch_assoc_dosage(*in, *prm, *dos, *out, class_sums, locus_sums, ctx->assoc_ws, ctx->s()));
     return TRK_OK;
 }
 
@@ -618,7 +647,7 @@ int trk_dosages(trk_ctx* ctx, const trk_batch* in, const double* allele_len, int
         return fail(ctx, TRK_ERR_ARG, "dosage inputs/outputs are NULL");
     if (in->n_loci > 65535) return fail(ctx, TRK_ERR_ARG, "at most 65535 loci per dosage call");
     (void)hipSetDevice(ctx->device);
-    HIPCHK(ctx, trk::launch_dosages(*in, allele_len, dosage_type, ap1, ap2, n_alt_cols, out, locus_err, ctx->stream));
+    HIPCHK(ctx, trk::launch_dosages(*in, allele_len, dosage_type, ap1, ap2, n_alt_cols, out, locus_err, ctx->s()));
     return TRK_OK;
 }
 
@@ -627,7 +656,7 @@ int trk_planarize(trk_ctx* ctx, const void* src, void* dst, int64_t n_cells, int
     if (!src || !dst || n_cells < 0 || ncol < 1) return fail(ctx, TRK_ERR_ARG, "planarize arguments");
     if (n_cells == 0) return TRK_OK;
     (void)hipSetDevice(ctx->device);
-    HIPCHK(ctx, trk::launch_planarize(src, dst, n_cells, ncol, ctx->stream));
+    HIPCHK(ctx, trk::launch_planarize(src, dst, n_cells, ncol, ctx->s()));
     return TRK_OK;
 }
 

@@ -128,6 +128,19 @@ class CallResult:
         return s
 
 
+class _QueueScope:
+    def __init__(self, eng, queue):
+        self.eng, self.queue = eng, int(queue)
+
+    def __enter__(self):
+        self.eng._chk(self.eng.lib.trk_stream_select(self.eng.ctx, self.queue))
+        return self
+
+    def __exit__(self, *exc):
+        self.eng._chk(self.eng.lib.trk_stream_select(self.eng.ctx, 0))
+        return False
+
+
 class Engine:
     def __init__(self, device=0):
         self.lib = L.load()
@@ -312,6 +325,15 @@ class Engine:
         self._chk(self.lib.trk_call_filters(self.ctx, C.byref(batch.struct), parr, np_, farr, nf,
                                             int(dp_plane), C.byref(ostruct)))
         return out
+
+    def on_queue(self, queue):
+        """``with eng.on_queue(1): ...``: the calls inside enqueue on the context's queue ``queue`` (HIP stream);
+        pair with ``queue_wait`` for the ordering against queue 0 (trk_stream_select / trk_stream_wait)."""
+        return _QueueScope(self, queue)
+
+    def queue_wait(self, waiter, signal):
+        """Queue ``waiter`` waits for everything enqueued so far on queue ``signal``."""
+        self._chk(self.lib.trk_stream_wait(self.ctx, int(waiter), int(signal)))
 
     def upload_plane(self, arr):
         """Upload a FORMAT plane [L, S] or [L, S, k] (int32 / float32).  Multi-column planes go up planar
