@@ -80,49 +80,63 @@ class Workload:
         b = self.sb.batch
         self.stats_a = [eng.alloc_stats(b) for _ in range(2)]     # statSTR rows (double buffered for the gather)
         self.stats_b = [eng.alloc_stats(b) for _ in range(2)]     # dumpSTR rows
-        self.call_out = eng.alloc_call_out(b, len(self.filters))
-        self.batch2 = b.with_gt(self.call_out.gt_out)
-        self.bits = eng.empty((self.n_loci,), np.uint32)
-        self.loc_counters = eng.zeros((L.TRK_LC_COLS,), np.int64)
+        # everything a step hands to the next stage is double buffered (the tail of step n runs beside the head of
+        # step n + 1); the masked genotypes and the mask are written and consumed on queue 0 only: one copy
+        from trtools_amd.engine import CallResult
+        co = eng.alloc_call_out(b, len(self.filters))
+        S = self.n_samples
+        self.call_outs = [co, CallResult(co.gt_out, co.filter_mask, eng.zeros((1 + len(self.filters), S), np.int64),
+                                         eng.zeros((S,), np.int64), eng.zeros((S,), np.int64),
+                                         eng.zeros((4,), np.int32), eng.zeros((S,), np.float64))]
+        self.bits_ = [eng.empty((self.n_loci,), np.uint32) for _ in range(2)]
+        self.loc_counters_ = [eng.zeros((L.TRK_LC_COLS,), np.int64) for _ in range(2)]
         self.gather = None
         if world > 1 or os.environ.get('TRK_FORCE_DIST'):
             self.gather = eng.empty((world, self.n_loci), np.uint32)
         self.step_no = 0
         self.overlap = os.environ.get('TRK_BENCH_OVERLAP', '1') != '0'
 
+    # the buffers of the last completed step
+    call_out = property(lambda self: self.call_outs[(self.step_no - 1) & 1])
+    bits = property(lambda self: self.bits_[(self.step_no - 1) & 1])
+    loc_counters = property(lambda self: self.loc_counters_[(self.step_no - 1) & 1])
+
     def step(self):
+        """One statSTR + dumpSTR pass over the batch.  Queue 0 carries the HBM-bound stream kernels (count, call
+        filters), queue 1 the latency-bound rest: statSTR's finaliser runs beside the call-filter pass, dumpSTR's
+        finaliser + locus filters (+ the RCCL exchange) beside the next step's count.  TRK_BENCH_OVERLAP=0 puts
+        everything on queue 0."""
         eng = self.eng
         i = self.step_no & 1
         self.step_no += 1
         b = self.sb.batch
+        out, bits, loc = self.call_outs[i], self.bits_[i], self.loc_counters_[i]
+        q1 = 1 if self.overlap else 0
         # counters are per step (each step is a complete statSTR + dumpSTR run)
-        self.call_out.sample_counters.zero()
-        self.call_out.sample_totaldp.zero()
-        self.call_out.sample_dp_missing.zero()
-        self.loc_counters.zero()
-        # statSTR: count (queue 0), then its finaliser on queue 1 -- latency-bound, it runs beside the HBM-bound
-        # call-filter pass of dumpSTR instead of in front of it (TRK_BENCH_OVERLAP=0: everything on queue 0)
-        eng.locus_stats(b, out=self.stats_a[i], count_only=True)
+        out.sample_counters.zero()
+        out.sample_totaldp.zero()
+        out.sample_dp_missing.zero()
+        eng.locus_stats(b, out=self.stats_a[i], count_only=True)                    # statSTR: count
         self.stats_b[i].allele_count.copy_from(self.stats_a[i].allele_count)
         self.stats_b[i].locus_int.copy_from(self.stats_a[i].locus_int)
-        if self.overlap:
-            eng.queue_wait(1, 0)
-            with eng.on_queue(1):
-                eng.locus_finalize(b, self.stats_a[i])
-        else:
-            eng.locus_finalize(b, self.stats_a[i])
-        eng.call_filters(b, self.planes, self.filters, dp_plane=0, out=self.call_out, delta_stats=self.stats_b[i])
-        eng.locus_finalize(b, self.stats_b[i])
-        eng.locus_filters(self.n_loci, self.stats_b[i], bits_out=self.bits, counters=self.loc_counters,
-                          **self.locus_args)
-        if self.overlap:
-            eng.queue_wait(0, 1)
-        if self.gather is not None:
-            eng.allreduce_sum_i64(self.call_out.sample_counters)
-            eng.allreduce_sum_i64(self.call_out.sample_totaldp)
-            eng.allreduce_sum_i64(self.call_out.sample_dp_missing)
-            eng.allreduce_sum_i64(self.loc_counters)
-            eng.allgather(self.bits, self.gather)
+        eng.queue_wait(q1, 0)
+        with eng.on_queue(q1):
+            eng.locus_finalize(b, self.stats_a[i])                                 # statSTR: 11 statistics per locus
+        eng.call_filters(b, self.planes, self.filters, dp_plane=0, out=out, delta_stats=self.stats_b[i])
+        # queue 0 may start the next step once statSTR's finaliser and the PREVIOUS tail are done (they own the
+        # other buffer set); this step's tail is enqueued behind that point and overlaps the next count
+        eng.queue_wait(0, q1)
+        eng.queue_wait(q1, 0)
+        with eng.on_queue(q1):
+            loc.zero()
+            eng.locus_finalize(b, self.stats_b[i])
+            eng.locus_filters(self.n_loci, self.stats_b[i], bits_out=bits, counters=loc, **self.locus_args)
+            if self.gather is not None:
+                eng.allreduce_sum_i64(out.sample_counters)
+                eng.allreduce_sum_i64(out.sample_totaldp)
+                eng.allreduce_sum_i64(out.sample_dp_missing)
+                eng.allreduce_sum_i64(loc)
+                eng.allgather(bits, self.gather)
 
 
 def parity_spot_check(wl, n_check=6):
