@@ -287,3 +287,46 @@ def test_two_queues_give_the_same_statistics(eng):
         assert np.array_equal(res.filter_mask.get(), ref_call.filter_mask.get())
     with pytest.raises(Exception):
         eng.queue_wait(0, 7)
+
+
+@pytest.mark.parametrize("n_groups,S,layout", [(1, 1000, 'subset'), (2, 1000, 'disjoint'), (2, 1004, 'overlap'),
+                                                (3, 2000, 'overlap'), (3, 64, 'disjoint')])
+def test_sample_groups_on_the_streaming_kernel(eng, n_groups, S, layout):
+    """statSTR --samples (statSTR.py:520-542): diploid batches with S % 4 == 0 take k_locus_count_v2g (one histogram
+    per class of group bits).  Groups may overlap, samples may be in no group; sentinel mixes, out-of-class
+    duplicates and an all-missing locus included."""
+    from oracle import trtools_oracle as orc
+    from trtools_amd import _lib as L
+    rng = np.random.default_rng(1000 * n_groups + S)
+    n_loci = 30
+    gt, lens, strs, lp, (off, lc, sc, cv) = _random_batch(rng, n_loci, S, 2, 12)
+    gt[3] = -1                       # no call at all
+    gt[4, :, 1] = -2                 # haploid calls in a diploid tensor
+    gt[5, : S // 2] = [-1, -2]
+    gt[6, : S // 3] = [-2, -1]
+    gt[7, : S // 4] = [-2, -2]
+    if layout == 'subset':
+        gb = (rng.random(S) < 0.6).astype(np.uint8)
+    elif layout == 'disjoint':
+        gb = (np.uint8(1) << rng.integers(0, n_groups, size=S).astype(np.uint8)).astype(np.uint8)
+        gb[rng.random(S) < 0.1] = 0
+    else:
+        gb = rng.integers(0, 1 << n_groups, size=S).astype(np.uint8)
+    gb |= (rng.integers(0, 2, size=S).astype(np.uint8) << np.uint8(7))      # bits above n_groups are ignored
+    groups = [((gb >> g) & 1).astype(bool) for g in range(n_groups)]
+    b = eng.make_batch(gt, off, lc, sc, cv, group_bits=gb, n_groups=n_groups)
+    res = eng.locus_stats(b, nalleles_thresh=0.05)
+    cnt, li, lf = _fetch(res)
+    check_against_oracle(orc, L, cnt, li, lf, off, [gt[l] for l in range(n_loci)], lens, strs, groups, 0.05)
+    for g in range(n_groups):
+        assert np.all(li[g][:, L.LI_N_SAMPLES] == int(groups[g].sum()))
+    # the per-call kernel (TRK_CNT_NOGROUPFAST) gives the same integers
+    import os
+    os.environ['TRK_CNT_NOGROUPFAST'] = '1'
+    try:
+        ref = eng.locus_stats(b, nalleles_thresh=0.05)
+    finally:
+        del os.environ['TRK_CNT_NOGROUPFAST']
+    cols = [L.LI_N_CALLED, L.LI_N_LOWPLOIDY, L.LI_N_HOM_LEN, L.LI_N_HOM_STR, L.LI_N_SAMPLES]
+    assert np.array_equal(ref.allele_count.get(), res.allele_count.get())
+    assert np.array_equal(ref.locus_int.get()[:, :, cols], res.locus_int.get()[:, :, cols])

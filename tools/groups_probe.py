@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""statSTR --samples a,b (sample groups, SURVEY 8d "stratified variant") at 100k x 10k: time of the count and
+finalise kernels with G = 1, 2, 3 group masks (2: disjoint 40 % / 60 %; 3: the reference's layout for two sample
+lists = the two lists plus everything)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from trtools_amd.engine import Engine
+from trtools_amd.synth import SynthBatch
+eng = Engine(0)
+eng.profile(True)
+Lc, S = int(os.environ.get('L', 100000)), int(os.environ.get('S', 10000))
+sb = SynthBatch(eng, Lc, S, seed=20260928 + 3, planes=())
+rng = np.random.default_rng(3)
+a = rng.random(S) < 0.4
+for G, gb in ((1, None), (2, (a * 1 + (~a) * 2).astype(np.uint8)), (3, (a * 1 + (~a) * 2 + 4).astype(np.uint8))):
+    b = sb.batch if gb is None else sb.batch.with_groups(eng, gb, G)
+    res = eng.alloc_stats(b)
+    for it in range(6):
+        if it == 1:
+            eng.sync(); eng.profile_reset(); t0 = time.perf_counter()
+        eng.locus_stats(b, out=res)
+    eng.sync(); w = (time.perf_counter() - t0) / 5
+    pg = eng.profile_get()
+    c = pg['k_locus_count'][1] / pg['k_locus_count'][0]
+    f = pg['k_locus_finalize'][1] / pg['k_locus_finalize'][0]
+    print("G=%d: %.3f ms/pass = %.2e loci/s; count %.3f ms = %.0f GB/s, finalize+hwe %.3f ms" % (
+        G, w * 1e3, Lc / w, c, Lc * S * 4 / (c * 1e-3) / 1e9, f))

@@ -541,6 +541,158 @@ __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v2(
     wave_lds_fence();
 }
 
+// ---------------------------------------------------------------------------
+// k_locus_count_v2g : k_locus_count_v2 for sample groups (statSTR --samples a,b,...: statSTR.py:520-542).
+// A sample's group bits (<= 3 groups here) are its CLASS; every class has its own histogram (all bins of
+// k_locus_count_v2 plus "both bins equal" / "same length class" / "same sequence class" rows), so the stream
+// does the same work per call as the ungrouped kernel plus one byte of group bits per sample, and a group's
+// totals are the sums over the classes that contain it -- taken once per locus after the stream.
+// bins per class: 0 '-2', 1 '-1', 2..A+1 alleles, A+2 out of range, A+3..A+6 sentinel pairs, A+7 eq, A+8 hl, A+9 hs
+// ---------------------------------------------------------------------------
+constexpr int V2G_EXTRA = 10;
+
+template <bool DUP>
+__device__ __forceinline__ void v2g_cell(uint32_t w, uint32_t cls, uint32_t amax2, uint32_t* hist,
+                                         const uint32_t* lut, int kshift, int kslot, int cstride, int A) {
+    u16x2 u = __builtin_bit_cast(u16x2, w) + (u16x2){2, 2};
+    u16x2 t2 = __builtin_elementwise_min(u, __builtin_bit_cast(u16x2, amax2));
+    const uint32_t t = __builtin_bit_cast(uint32_t, t2);
+    const uint32_t lo = t & 0xffffu, hi = t >> 16;
+    uint32_t* h = hist + cls * cstride + kslot;
+    atomicAdd(&h[lo << kshift], 1u);
+    atomicAdd(&h[hi << kshift], 1u);
+    if ((t & 0xfffefffeu) == 0u) atomicAdd(&h[(A + 3 + (int)(lo + 2u * hi)) << kshift], 1u);
+    if (DUP) {
+        const uint32_t x = lut[lo] ^ lut[hi];
+        if ((x & 0xffffu) == 0u) atomicAdd(&h[(A + 8) << kshift], 1u);
+        if ((x >> 16) == 0u) atomicAdd(&h[(A + 9) << kshift], 1u);
+    } else if (lo == hi) {
+        atomicAdd(&h[(A + 7) << kshift], 1u);
+    }
+}
+
+template <bool DUP>
+__device__ __forceinline__ void v2g_row(const u32x4* __restrict__ row, const uint32_t* __restrict__ gbits4,
+                                        int nchunks, int lane, uint32_t amax2, uint32_t* hist, const uint32_t* lut,
+                                        int kshift, int kslot, int cstride, int A, uint32_t cmask) {
+    constexpr int U = 2;
+    int c = lane;
+    for (; c + (U - 1) * WAVE < nchunks; c += U * WAVE) {
+        u32x4 v[U];
+        uint32_t gb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v[u] = __builtin_nontemporal_load(&row[c + u * WAVE]);
+            gb[u] = gbits4[c + u * WAVE];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                v2g_cell<DUP>(v[u][j], (gb[u] >> (8 * j)) & cmask, amax2, hist, lut, kshift, kslot, cstride, A);
+    }
+    for (; c < nchunks; c += WAVE) {
+        const u32x4 v = __builtin_nontemporal_load(&row[c]);
+        const uint32_t gb = gbits4[c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            v2g_cell<DUP>(v[j], (gb >> (8 * j)) & cmask, amax2, hist, lut, kshift, kslot, cstride, A);
+    }
+}
+
+__global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v2g(
+    trk_batch b, int32_t* __restrict__ allele_count, int32_t* __restrict__ locus_int, int kshift,
+    int wave_lds_words) {
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wid = threadIdx.x >> 6;
+    const int l = blockIdx.x * COUNT_WAVES_PER_WG + wid;
+    if (l >= b.n_loci) return;  // waves are independent: no workgroup barrier anywhere
+    const int S = b.n_samples, G = b.n_groups;
+    const int ncls = 1 << G;
+    const int off = b.allele_off[l];
+    const int A = b.allele_off[l + 1] - off;
+    const int K = 1 << kshift;
+    const int kslot = lane & (K - 1);
+    const int nbins = A + V2G_EXTRA;
+    const int cstride = nbins << kshift;
+    uint32_t* hist = lds + (size_t)wid * wave_lds_words;
+    uint32_t* lut = hist + ncls * cstride;  // indexed by BIN
+    int ml = 0, ms = 0;
+    for (int a = lane; a < A; a += WAVE) {
+        int lc = b.len_class[off + a], sc = b.str_class[off + a];
+        lut[a + 2] = (uint32_t)lc | ((uint32_t)sc << 16);
+        ml = lc > ml ? lc : ml;
+        ms = sc > ms ? sc : ms;
+    }
+    if (lane == 0) {  // sentinel bins: classes no allele has, distinct from each other
+        lut[0] = 0xffffffffu;
+        lut[1] = 0xfffefffeu;
+        lut[A + 2] = 0xfffdfffdu;
+    }
+    ml = wave_max(ml);
+    ms = wave_max(ms);
+    const bool dup = (ml + 1 < A) | (ms + 1 < A);
+    for (int i = lane; i < ncls * cstride; i += WAVE) hist[i] = 0;
+    wave_lds_fence();
+
+    const u32x4* row = reinterpret_cast<const u32x4*>(b.gt) + (((int64_t)l * S) >> 2);
+    const uint32_t* gbits4 = reinterpret_cast<const uint32_t*>(b.group_bits);
+    const uint32_t amax2 = (uint32_t)(A + 2) * 0x00010001u;
+    if (dup)
+        v2g_row<true>(row, gbits4, S >> 2, lane, amax2, hist, lut, kshift, kslot, cstride, A, (uint32_t)ncls - 1u);
+    else
+        v2g_row<false>(row, gbits4, S >> 2, lane, amax2, hist, lut, kshift, kslot, cstride, A, (uint32_t)ncls - 1u);
+    wave_lds_fence();
+    // fold: per bin the K copies of every class, then per group the classes that contain it.  Group g's total of
+    // a bin is parked in copy 0 of class g's bin (only this lane touches the bin's words).
+    int hap[3] = {0, 0, 0};   // haplotypes (alleles + sentinels + out of range) of the group: 2 per sample
+    for (int bin = lane; bin < nbins; bin += WAVE) {
+        uint32_t cs[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            cs[c] = 0;
+            if (c < ncls)
+                for (int k = 0; k < K; ++k) cs[c] += hist[c * cstride + (bin << kshift) + ((k + lane) & (K - 1))];
+        }
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            if (g >= G) break;
+            uint32_t tot = 0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if ((c >> g) & 1) tot += cs[c];
+            if (bin >= 2 && bin < A + 2) allele_count[(int64_t)g * b.n_alleles_total + off + bin - 2] = (int32_t)tot;
+            if (bin <= A + 2) hap[g] += (int)tot;
+            hist[g * cstride + (bin << kshift)] = tot;
+        }
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        if (g >= G) break;
+        const int n_samp = wave_sum(hap[g]) >> 1;
+        if (lane == 0) {
+            const uint32_t* h = hist + g * cstride;
+            const int h_m2 = (int)h[0 << kshift], h_m1 = (int)h[1 << kshift];
+            const int n_bad = (int)h[(A + 2) << kshift];
+            const int c00 = (int)h[(A + 3) << kshift];  // (-2,-2)
+            const int c10 = (int)h[(A + 4) << kshift];  // lo = -1, hi = -2
+            const int c01 = (int)h[(A + 5) << kshift];  // lo = -2, hi = -1
+            const int c11 = (int)h[(A + 6) << kshift];  // (-1,-1)
+            const int hom_idx = (int)h[(A + 7) << kshift] - c11 - c00;
+            int32_t* li0 = locus_int + ((int64_t)g * b.n_loci + l) * TRK_LI_COLS;
+            li0[TRK_LI_N_CALLED] = n_samp - (h_m1 - c11);
+            li0[TRK_LI_N_LOWPLOIDY] = h_m2 - c00 - c10 - c01;
+            li0[TRK_LI_N_HOM_LEN] = dup ? (int)h[(A + 8) << kshift] - c11 - c00 : hom_idx;
+            li0[TRK_LI_N_HOM_STR] = dup ? (int)h[(A + 9) << kshift] - c11 - c00 : hom_idx;
+            li0[TRK_LI_N_BAD] = n_bad;
+            li0[TRK_LI_N_SAMPLES] = n_samp;
+        }
+    }
+    wave_lds_fence();
+}
+
 template <int U>
 __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_fast(
     trk_batch b, int32_t* __restrict__ allele_count, int32_t* __restrict__ locus_int, int kshift,
@@ -1919,6 +2071,23 @@ hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* alle
                     hipLaunchKernelGGL(k_locus_count_fast<2>, grid, block, lds_fast, stream, b, allele_count,
                                        locus_int, kshift, words);
             }
+            return hipGetLastError();
+        }
+    }
+    // sample groups (statSTR --samples): the streaming kernel with one histogram per class of group bits
+    if (b.group_bits && G >= 1 && G <= 3 && b.ploidy == 2 && !b.locus_ploidy && max_alleles > 0 &&
+        max_alleles + 2 < 65535 && b.n_samples > 0 && (b.n_samples % 4) == 0 &&
+        ((uintptr_t)b.group_bits & 3u) == 0 && !getenv("TRK_CNT_NOGROUPFAST")) {
+        const int ncls = 1 << G, nb = max_alleles + V2G_EXTRA;
+        int kshift = 5;
+        while (kshift > 2 && ncls * (nb << kshift) + nb > 3072) --kshift;   // <= 12 KiB per wave
+        int words = ncls * (nb << kshift) + nb;
+        if (words <= 3072) {
+            words = (words + 3) & ~3;
+            const size_t lds_g = (size_t)COUNT_WAVES_PER_WG * words * sizeof(uint32_t);
+            const int wgs_g = (b.n_loci + COUNT_WAVES_PER_WG - 1) / COUNT_WAVES_PER_WG;
+            hipLaunchKernelGGL(k_locus_count_v2g, dim3(wgs_g), dim3(WAVE * COUNT_WAVES_PER_WG), lds_g, stream, b,
+                               allele_count, locus_int, kshift, words);
             return hipGetLastError();
         }
     }

@@ -90,6 +90,17 @@ class DeviceBatch:
         arrays['gt'] = gt_dev
         return DeviceBatch(s, arrays, self.n_groups, self.sum_alleles)
 
+    def with_groups(self, eng, group_bits, n_groups):
+        """Same tensors, sample groups attached (bit g of group_bits[s]: sample s is in group g)."""
+        s = L.Batch()
+        C.memmove(C.byref(s), C.byref(self.struct), C.sizeof(L.Batch))
+        gb = eng.upload(np.ascontiguousarray(group_bits, dtype=np.uint8))
+        s.group_bits = gb.ptr
+        s.n_groups = int(n_groups)
+        arrays = dict(self.arrays)
+        arrays['group_bits'] = gb
+        return DeviceBatch(s, arrays, int(n_groups), self.sum_alleles)
+
 
 class StatsResult:
     def __init__(self, allele_count, locus_int, locus_f64):
