@@ -103,6 +103,16 @@ class _Info:
 
 
 
+class _CallFilterStruct(ctypes.Structure):
+    _fields_ = [('mask', ctypes.c_void_p), ('n_filters', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('names', ctypes.POINTER(ctypes.c_char_p)), ('values', ctypes.POINTER(ctypes.c_void_p))]
+
+
+def _addr(arr):
+    """Address of a numpy array's buffer (cheaper than ``arr.ctypes.data``)."""
+    return arr.__array_interface__['data'][0]
+
+
 class CallFilterColumn:
     """dumpSTR's FORMAT/FILTER column of one record, kept as the call-filter mask until the record is written
     (dumpSTR.py:648-683): ``NOCALL`` (bit 31), ``PASS`` (0) or ``<name>_<%g value>`` of every fired filter, comma
@@ -133,13 +143,10 @@ class CallFilterColumn:
 
     def native_struct(self):
         nk = len(self.names)
-
-        class CallFilter(ctypes.Structure):
-            _fields_ = [('mask', ctypes.c_void_p), ('n_filters', ctypes.c_int32), ('reserved', ctypes.c_int32),
-                        ('names', ctypes.POINTER(ctypes.c_char_p)), ('values', ctypes.POINTER(ctypes.c_void_p))]
+        CallFilter = _CallFilterStruct
         names = (ctypes.c_char_p * max(nk, 1))(*[n.encode() for n in self.names])
-        vals = (ctypes.c_void_p * max(nk, 1))(*[None if v is None else v.ctypes.data for v in self.values])
-        st = CallFilter(self.mask.ctypes.data, nk, 0, names, vals)
+        vals = (ctypes.c_void_p * max(nk, 1))(*[None if v is None else _addr(v) for v in self.values])
+        st = CallFilter(_addr(self.mask), nk, 0, names, vals)
         return [st, names, vals, self]      # element 0 is the struct; the rest keeps its pointers alive
 
 class _Decode(ctypes.Structure):
@@ -370,7 +377,7 @@ class Variant:
             else:
                 arr = np.empty((n, k), dtype=np.int32 if fields[i].kind == 1 else np.float32)
             outs[i] = arr
-            fields[i].out = arr.ctypes.data
+            fields[i].out = _addr(arr)
         if lib.trk_vcf_decode_formats(raw, len(raw), n, nf, fields, 1) != 0:
             return False
         for i in want:
@@ -511,7 +518,7 @@ class Variant:
                 else:
                     return None
             keep.append(arr)
-            cols[i] = Column(kind, ncol, item, 0, arr.ctypes.data)
+            cols[i] = Column(kind, ncol, item, 0, _addr(arr))
         cap += n + 16
         buf = ctypes.create_string_buffer(cap)
         got = lib.trk_vcf_format_samples(n, len(self.FORMAT), cols, buf, cap)
