@@ -147,3 +147,43 @@ def test_native_format_decode_equals_python_decode(path, monkeypatch):
                 assert np.array_equal(x, y), key
     if nat and any(len(r) for r, _ in nat):
         assert n_native > 0, "the native decoder was never used"
+
+
+def test_large_records_are_formatted_in_parallel_with_the_same_text():
+    """Records with many samples are split by sample range over a thread pool: the text must be the serial text."""
+    api = vcfio._serializer()
+    assert api is not None
+    lib, Column = api
+    import ctypes
+    rng = np.random.default_rng(3)
+    S = 6007
+    gt = rng.integers(-2, 40, size=(S, 3)).astype(np.int16)
+    gt[:, 2] = rng.integers(0, 2, size=S)
+    iv = rng.integers(-5, 100000, size=(S, 2)).astype(np.int32)
+    iv[rng.random(S) < 0.1, 0] = -2147483648
+    iv[rng.random(S) < 0.3, 1] = -2147483647
+    fv = (rng.random((S, 1)) * 10.0 ** rng.integers(-6, 7, size=(S, 1))).astype(np.float32)
+    fv[rng.random(S) < 0.1] = np.nan
+    sv = np.array(['x' * int(n) for n in rng.integers(0, 40, size=S)])
+    mask = rng.integers(0, 8, size=S).astype(np.uint32)
+    mask[rng.random(S) < 0.1] = 0x80000000
+    cf = vcfio.CallFilterColumn(mask, ['a', 'bb', 'ccc'], [rng.random(S), None, rng.random(S) * 100])
+
+    def text(lo, hi):
+        st = vcfio.CallFilterColumn(mask[lo:hi], cf.names, [None if v is None else v[lo:hi] for v in cf.values])
+        keep = [np.ascontiguousarray(gt[lo:hi]), np.ascontiguousarray(iv[lo:hi]), np.ascontiguousarray(fv[lo:hi]),
+                np.ascontiguousarray(sv[lo:hi]), st.native_struct()]
+        cols = (Column * 5)(Column(0, 3, 0, 0, keep[0].ctypes.data), Column(1, 2, 0, 0, keep[1].ctypes.data),
+                            Column(2, 1, 0, 0, keep[2].ctypes.data),
+                            Column(4, 1, sv.dtype.itemsize, 0, keep[3].ctypes.data),
+                            Column(5, 1, 0, 0, ctypes.addressof(keep[4][0])))
+        cap = (hi - lo) * 400
+        buf = ctypes.create_string_buffer(cap)
+        n = lib.trk_vcf_format_samples(hi - lo, 5, cols, buf, cap)
+        assert n > 0
+        return buf.raw[:n]
+
+    whole = text(0, S)
+    pieces = b''.join(text(lo, min(S, lo + 500)) for lo in range(0, S, 500))   # 500 x 5 fields: the serial path
+    assert whole == pieces
+    assert text(0, S) == whole

@@ -6,6 +6,9 @@
 #include <algorithm>
 #include <atomic>
 #include <charconv>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -648,16 +651,13 @@ inline void put_utf8(OutBuf& o, uint32_t c) {
 }
 }  // namespace
 
-int64_t trk_vcf_format_samples(int32_t n_samples, int32_t n_columns, const trk_vcf_column* cols, char* out,
-                               int64_t cap) {
-    if (n_samples < 0 || n_columns < 0 || (n_columns && !cols) || cap < 0 || (cap && !out)) return INT64_MIN;
-    for (int c = 0; c < n_columns; ++c)
-        if (cols[c].kind < TRK_VCF_COL_GT || cols[c].kind > TRK_VCF_COL_CALLFILTER || cols[c].ncol < 1 ||
-            !cols[c].data || ((cols[c].kind >= TRK_VCF_COL_BYTES) && cols[c].itemsize < 0))
-            return INT64_MIN;
-    OutBuf o{out, cap, 0};
+}  // extern "C"  (helpers below have C++ linkage)
+
+namespace {
+// samples [s0, s1) of the record into o
+void format_range(int64_t s0, int64_t s1, int32_t n_columns, const trk_vcf_column* cols, OutBuf& o) {
     char tmp[48];
-    for (int64_t s = 0; s < n_samples; ++s) {
+    for (int64_t s = s0; s < s1; ++s) {
         o.put('\t');
         for (int c = 0; c < n_columns; ++c) {
             const trk_vcf_column& f = cols[c];
@@ -752,6 +752,113 @@ int64_t trk_vcf_format_samples(int32_t n_samples, int32_t n_columns, const trk_v
             }
         }
     }
+}
+
+// A small fork-join pool for the serialiser: records of thousands of samples are split by sample range.
+class FmtPool {
+   public:
+    static FmtPool& get() {
+        static FmtPool* p = new FmtPool;   // never destroyed: its workers outlive static destruction
+        return *p;
+    }
+    int size() const { return (int)workers_.size() + 1; }
+    // run fn(task) for task in [0, n) on the workers and the calling thread
+    template <class F>
+    void run(int n, F&& fn) {
+        std::unique_lock<std::mutex> call_lock(call_mu_);   // one record at a time
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            fn_ = [&](int t) { fn(t); };
+            n_tasks_ = n;
+            next_.store(0);
+            pending_ = n;
+            ++gen_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> g(mu_);
+        done_cv_.wait(g, [&] { return pending_ == 0; });
+    }
+
+   private:
+    FmtPool() {
+        int n = (int)std::thread::hardware_concurrency();
+        if (const char* e = getenv("TRK_FMT_THREADS")) n = atoi(e);
+        if (n > 8) n = 8;
+        for (int i = 1; i < n; ++i) workers_.emplace_back([this] { loop(); });
+        for (auto& w : workers_) w.detach();
+    }
+    void work() {
+        while (true) {
+            const int t = next_.fetch_add(1);
+            if (t >= n_tasks_) break;
+            fn_(t);
+            std::lock_guard<std::mutex> g(mu_);
+            if (--pending_ == 0) done_cv_.notify_all();
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        while (true) {
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return gen_ != seen; });
+                seen = gen_;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_, call_mu_;
+    std::condition_variable cv_, done_cv_;
+    std::function<void(int)> fn_;
+    int n_tasks_ = 0, pending_ = 0;
+    std::atomic<int> next_{0};
+    uint64_t gen_ = 0;
+};
+}  // namespace
+
+extern "C" {
+
+int64_t trk_vcf_format_samples(int32_t n_samples, int32_t n_columns, const trk_vcf_column* cols, char* out,
+                               int64_t cap) {
+    if (n_samples < 0 || n_columns < 0 || (n_columns && !cols) || cap < 0 || (cap && !out)) return INT64_MIN;
+    for (int c = 0; c < n_columns; ++c)
+        if (cols[c].kind < TRK_VCF_COL_GT || cols[c].kind > TRK_VCF_COL_CALLFILTER || cols[c].ncol < 1 ||
+            !cols[c].data || ((cols[c].kind >= TRK_VCF_COL_BYTES) && cols[c].itemsize < 0))
+            return INT64_MIN;
+    // large records: sample ranges formatted in parallel into private buffers, then laid end to end
+    const int64_t work = (int64_t)n_samples * n_columns;
+    FmtPool* pool = work >= 8192 ? &FmtPool::get() : nullptr;
+    if (pool && pool->size() > 1) {
+        const int T = (int)std::min<int64_t>(pool->size() * 2, n_samples / 256 + 1);
+        std::vector<std::vector<char>> bufs((size_t)T);
+        std::vector<int64_t> used((size_t)T, 0);
+        pool->run(T, [&](int t) {
+            const int64_t s0 = (int64_t)n_samples * t / T, s1 = (int64_t)n_samples * (t + 1) / T;
+            std::vector<char>& b = bufs[(size_t)t];
+            b.resize((size_t)((s1 - s0) * n_columns * 12 + 64));
+            OutBuf o{b.data(), (int64_t)b.size(), 0};
+            format_range(s0, s1, n_columns, cols, o);
+            if (o.n > o.cap) {   // the guess was short: the count is exact now
+                b.resize((size_t)o.n);
+                o = OutBuf{b.data(), (int64_t)b.size(), 0};
+                format_range(s0, s1, n_columns, cols, o);
+            }
+            used[(size_t)t] = o.n;
+        });
+        int64_t total = 0;
+        for (int t = 0; t < T; ++t) total += used[(size_t)t];
+        if (total > cap) return -total;
+        int64_t at = 0;
+        for (int t = 0; t < T; ++t) {
+            memcpy(out + at, bufs[(size_t)t].data(), (size_t)used[(size_t)t]);
+            at += used[(size_t)t];
+        }
+        return total;
+    }
+    OutBuf o{out, cap, 0};
+    format_range(0, n_samples, n_columns, cols, o);
     return o.n <= cap ? o.n : -o.n;
 }
 
