@@ -213,7 +213,7 @@ int trk_locus_finalize(trk_ctx* ctx, const trk_batch* in, const trk_stats_params
 enum { TRK_DT_I32 = 0, TRK_DT_F32 = 1,
        TRK_DT_PLANAR = 0x100 /* or'ed in: data is [ncol, L, S] -- one contiguous [L, S] array per column.  Every
                                 column then streams as 16-byte vectors like a single-column plane (GangSTR's
-                                QEXP / RC / REPCN / REPCI: 4.2 ms instead of 9.3 ms for the nine-filter set at
+                                QEXP / RC / REPCN / REPCI: 4.3 ms instead of 7.5 ms for the nine-filter set at
                                 50k x 5k, profiles/r01_notes.md)                                                */ };
 typedef struct {
     const void* data;   /* device [L, S, ncol], or [ncol, L, S] with TRK_DT_PLANAR    */

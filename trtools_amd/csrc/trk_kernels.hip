@@ -1058,6 +1058,7 @@ __device__ __forceinline__ bool eval_filter(const trk_call_filter& f, const trk_
     }
 }
 
+constexpr int CF_MAX_GROUPS = 6;
 struct CallArgs {
     trk_batch b;
     trk_plane planes[TRK_MAX_PLANES];
@@ -1070,6 +1071,11 @@ struct CallArgs {
     const void* src_ptr[16];
     uint32_t src_f32_mask;      // source holds float32
     int32_t n_src;
+    // interleaved planes [L*S, k] (k = 2..4): the k vectors of a thread's four calls are fetched together and
+    // de-interleaved into k consecutive sources (their src_ptr is NULL)
+    const void* grp_ptr[CF_MAX_GROUPS];
+    int8_t grp_base[CF_MAX_GROUPS], grp_k[CF_MAX_GROUPS];
+    int32_t grp_n;
     int8_t f_src_a[TRK_MAX_FILTERS], f_src_a2[TRK_MAX_FILTERS], f_src_b[TRK_MAX_FILTERS];  // operands of filter k
     int8_t f_ci[TRK_MAX_FILTERS][6];  // OUTSIDE_CI: sources of ml_j, lo_j, hi_j (j < f_ci_n <= 2)
     int8_t f_ci_n[TRK_MAX_FILTERS];
@@ -1265,13 +1271,44 @@ struct CfLocus {
     u32x4 sv[NS];
 };
 
+// K vectors = 4 calls x K interleaved columns -> sources Q .. Q+K-1 (column c of call j is word j*K + c).
+// Every register index is a template constant, so the sources stay in VGPRs.
+template <int K, int NS, int Q>
+__device__ __forceinline__ void cf_deinterleave(const u32x4* __restrict__ p, CfLocus<NS>& d) {
+    if constexpr (Q + K <= NS) {
+        u32x4 r[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) r[i] = __builtin_nontemporal_load(p + i);
+#pragma unroll
+        for (int c = 0; c < K; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d.sv[Q + c][j] = r[(j * K + c) / 4][(j * K + c) % 4];
+    }
+}
+// uniform dispatch of (first slot, k) to the static form
+template <int NS, int Q>
+__device__ __forceinline__ void cf_load_group(const u32x4* __restrict__ p, CfLocus<NS>& d, int base, int k) {
+    if constexpr (Q < NS) {
+        if (base == Q) {
+            if (k == 2) cf_deinterleave<2, NS, Q>(p, d);
+            else if (k == 3) cf_deinterleave<3, NS, Q>(p, d);
+            else cf_deinterleave<4, NS, Q>(p, d);
+        } else {
+            cf_load_group<NS, Q + 1>(p, d, base, k);
+        }
+    }
+}
+
 template <int NS>
 __device__ __forceinline__ void cf_load(const CallArgs& a, int64_t cell0, CfLocus<NS>& d) {
     d.gt = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.b.gt) + (cell0 >> 2));
 #pragma unroll
     for (int q = 0; q < NS; ++q)
-        if (q < a.n_src)
+        if (q < a.n_src && a.src_ptr[q])
             d.sv[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.src_ptr[q]) + (cell0 >> 2));
+    for (int g = 0; g < a.grp_n; ++g)   // interleaved planes
+        cf_load_group<NS, 0>(reinterpret_cast<const u32x4*>(a.grp_ptr[g]) + (cell0 >> 2) * a.grp_k[g], d,
+                             a.grp_base[g], a.grp_k[g]);
 }
 
 // the four values of source `idx` (uniform across the wave): static register indexing behind uniform guards
@@ -2174,6 +2211,8 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
     a.n_cells = (int64_t)L * S;
     // ---- vector sources: one [L*S] array per (plane, column) that can be fetched as 16-byte vectors --------
     a.n_src = 0;
+    a.grp_n = 0;
+    int grp_plane[CF_MAX_GROUPS];
     a.src_f32_mask = 0;
     a.reg_filter_mask = 0;
     a.int_thr_mask = 0;
@@ -2186,7 +2225,24 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
         if (!vec || p < 0 || p >= n_planes || getenv("TRK_CF_NOSRC")) return -1;
         const trk_plane& pl = planes[p];
         const bool planar = (pl.dtype & TRK_DT_PLANAR) != 0;
-        if (!(pl.ncol == 1 || planar) || col < 0 || col >= pl.ncol) return -1;
+        if (col < 0 || col >= pl.ncol) return -1;
+        if (pl.ncol > 1 && !planar) {   // interleaved: all k columns become sources together
+            if (pl.ncol > 4 || ((uintptr_t)pl.data & 15u) || getenv("TRK_CF_NOGROUPS")) return -1;
+            for (int g = 0; g < a.grp_n; ++g)
+                if (grp_plane[g] == p) return a.grp_base[g] + col;
+            if (a.grp_n >= CF_MAX_GROUPS || a.n_src + pl.ncol > CF_NSRC) return -1;
+            const int g = a.grp_n++;
+            grp_plane[g] = p;
+            a.grp_ptr[g] = pl.data;
+            a.grp_base[g] = (int8_t)a.n_src;
+            a.grp_k[g] = (int8_t)pl.ncol;
+            for (int c = 0; c < pl.ncol; ++c) {
+                a.src_ptr[a.n_src] = nullptr;
+                if ((pl.dtype & 0xff) == TRK_DT_F32) a.src_f32_mask |= 1u << a.n_src;
+                ++a.n_src;
+            }
+            return a.grp_base[g] + col;
+        }
         const char* ptr = static_cast<const char*>(pl.data) + (planar ? (size_t)col * a.n_cells * 4 : 0);
         if ((uintptr_t)ptr & 15u) return -1;
         for (int q = 0; q < a.n_src; ++q)
@@ -2281,7 +2337,7 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             o.dthr = f.thr;
             if (f.op == TRK_F_RATIO_GT) {
                 // numerator an int32 source, denominator the depth vector the kernel loads anyway
-                ok = a.f_src_a[k] >= 0 && a.dp_src >= 0 && a.f_src_b[k] == a.dp_src &&
+                ok = a.f_src_a[k] >= 0 && a.src_ptr[a.f_src_a[k]] && a.dp_src >= 0 && a.f_src_b[k] == a.dp_src &&
                      !((a.src_f32_mask >> a.f_src_a[k]) & 1u) && !((a.src_f32_mask >> a.dp_src) & 1u);
                 if (!ok) break;
                 o.plane = a.src_ptr[a.f_src_a[k]];
@@ -2290,7 +2346,7 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
                 continue;
             }
             ok = (f.op == TRK_F_LT || f.op == TRK_F_GT || f.op == TRK_F_CALLED_LT) && a.f_src_a[k] >= 0 &&
-                 f.thr == f.thr;
+                 a.src_ptr[a.f_src_a[k]] && f.thr == f.thr;   // (a column of an interleaved plane has no array of its own)
             if (!ok) break;
             o.plane = a.src_ptr[a.f_src_a[k]];
             const bool gt_op = f.op == TRK_F_GT;
