@@ -393,6 +393,9 @@ def main():
                                        "unit": "GB/s", "bytes_per_cell": BYTES_PER_CELL_COUNT,
                                        "frac": (cells * BYTES_PER_CELL_COUNT / (avg_cnt * 1e-3) / 1e9 / HBM_PEAK_GBS)
                                        if cn else 0.0},
+            "queues": ("2: stream kernels on queue 0, finalisers / locus filters / RCCL exchange on queue 1 and "
+                       "overlapped with them -- kernels_ms are per-launch averages under that contention "
+                       "(k_locus_count alone: 0.70 ms)") if wl.overlap else "1",
             "parity_rows_checked": n_checked,
             "device": eng.arch,
         }
