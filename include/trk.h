@@ -133,7 +133,11 @@ typedef struct {
     int32_t n_groups;
     int64_t n_alleles_total;
     int32_t max_alleles;   /* max A_l over the batch (sizes the LDS histogram); 0 = unknown */
-    int32_t reserved0;
+    int32_t n_pad_samples; /* the last n_pad_samples samples of every row are padding: their genotypes MUST be -1
+                              (no call) and they are left out of TRK_LI_N_SAMPLES.  Rows of a multiple of four
+                              samples are 16-byte aligned, which the streaming kernels need: a cohort of 10001
+                              samples is handed over as 10004 with n_pad_samples = 3 (compute.py does this; the
+                              unpadded layout runs the per-call kernels, 4-6x slower) */
     const int16_t* gt;
     const uint8_t* locus_ploidy;
     const int32_t* allele_off;

@@ -40,7 +40,7 @@ STATS_COUNT_ONLY = 1
 class Batch(C.Structure):
     _fields_ = [('n_loci', C.c_int32), ('n_samples', C.c_int32), ('ploidy', C.c_int32),
                 ('n_groups', C.c_int32), ('n_alleles_total', C.c_int64),
-                ('max_alleles', C.c_int32), ('reserved0', C.c_int32),
+                ('max_alleles', C.c_int32), ('n_pad_samples', C.c_int32),
                 ('gt', C.c_void_p), ('locus_ploidy', C.c_void_p), ('allele_off', C.c_void_p),
                 ('len_class', C.c_void_p), ('str_class', C.c_void_p),
                 ('len_class_value', C.c_void_p), ('group_bits', C.c_void_p)]

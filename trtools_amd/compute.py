@@ -6,6 +6,8 @@ The host layer (tr_harmonizer / statSTR / dumpSTR mirrors) only talks to this
 interface; the tests substitute an oracle-backed object with the same methods
 to exercise the host logic on machines without a GPU -- the product itself has
 no CPU implementation."""
+import os
+
 import numpy as np
 
 
@@ -42,15 +44,35 @@ class DeviceCompute:
         from .engine import Engine
         self.eng = engine if engine is not None else Engine(device)
 
-    def _upload(self, hb):
+    @staticmethod
+    def _n_pad(hb):
+        """Samples to append so that a diploid row is a multiple of four samples = 16-byte aligned: the streaming
+        kernels need that (a cohort of 10001 samples otherwise runs the per-call kernels, 4-6x slower)."""
+        S = hb.gt.shape[1]
+        return (-S) % 4 if (hb.gt.shape[2] == 2 and S > 0 and os.environ.get('TRK_PAD_SAMPLES', '1') != '0') else 0
+
+    @staticmethod
+    def _pad(arr, n_pad, axis, value):
+        if not n_pad:
+            return arr
+        arr = np.asarray(arr)
+        shape = list(arr.shape)
+        shape[axis] = n_pad
+        return np.concatenate([arr, np.full(shape, value, dtype=arr.dtype)], axis=axis)
+
+    def _upload(self, hb, pad=True):
         # a per-locus ploidy table only when some locus really is of lower ploidy than the tensor
         # (the kernels' streaming paths need every column to be live)
         lp = hb.locus_ploidy
         if lp is not None and (hb.n_loci == 0 or bool(np.all(np.asarray(lp) == hb.ploidy))):
             lp = None
-        return self.eng.make_batch(hb.gt, hb.allele_off, hb.len_class, hb.str_class, hb.len_class_value,
-                                   locus_ploidy=lp, group_bits=hb.group_bits,
-                                   n_groups=hb.n_groups, max_alleles=hb.max_alleles)
+        n_pad = self._n_pad(hb) if pad else 0
+        gb = hb.group_bits
+        if n_pad and gb is not None:
+            gb = self._pad(gb, n_pad, 0, 0)          # padding samples belong to no group
+        return self.eng.make_batch(self._pad(hb.gt, n_pad, 1, -1), hb.allele_off, hb.len_class, hb.str_class,
+                                   hb.len_class_value, locus_ploidy=lp, group_bits=gb,
+                                   n_groups=hb.n_groups, max_alleles=hb.max_alleles, n_pad=n_pad)
 
     @staticmethod
     def _free(*objs):
@@ -75,6 +97,10 @@ class DeviceCompute:
         Returns (CallHost, StatsHost, locus_bits uint32[L], loc_counters int64[32])."""
         eng = self.eng
         b = self._upload(hb)
+        n_pad, S = self._n_pad(hb), hb.gt.shape[1]
+        if n_pad:   # the padding samples' FORMAT values are missing like their genotypes
+            planes = [self._pad(p, n_pad, 1, np.nan if np.asarray(p).dtype.kind == 'f' else np.iinfo(np.int32).min)
+                      for p in planes]
         dplanes = [eng.upload_plane(p) for p in planes]
         # counts of the unfiltered genotypes, corrected by the call-filter kernel for every call it
         # masks (dumpSTR.py:721-774 rebuilds the record; here no second pass over the tensor), then
@@ -91,8 +117,8 @@ class DeviceCompute:
         totaldp = call.sample_totaldp.get()
         if dp_plane >= 0 and np.asarray(planes[dp_plane]).dtype.kind == 'f':
             totaldp = call.sample_totaldp_f64.get()      # Float depth plane (ExpansionHunter's LC)
-        ch = CallHost(call.gt_out.get(), call.filter_mask.get(), call.sample_counters.get(),
-                      totaldp, call.sample_dp_missing.get(), call.error.get())
+        ch = CallHost(call.gt_out.get()[:, :S], call.filter_mask.get()[:, :S], call.sample_counters.get()[:, :S],
+                      totaldp[:S], call.sample_dp_missing.get()[:S], call.error.get())
         sh = StatsHost(st.allele_count.get(), st.locus_int.get(), st.locus_f64.get())
         out = (ch, sh, bits.get(), counters.get())
         self._free(b, *dplanes, call.gt_out, call.filter_mask, call.sample_counters, call.sample_totaldp,
@@ -111,10 +137,13 @@ class DeviceCompute:
         sin = None
         if sample_in is not None and not bool(np.all(sample_in)):
             sin = np.ascontiguousarray(sample_in, dtype=np.uint8)
+        n_pad = self._n_pad(hb)
+        if n_pad:   # padding samples are outside the regression set and carry zeros in every vector
+            sin = self._pad(np.ones(hb.gt.shape[1], dtype=np.uint8) if sin is None else sin, n_pad, 0, 0)
         if not hasattr(self, '_assoc_vec') or self._assoc_vec[0] is not vec:
             if hasattr(self, '_assoc_vec'):
                 self._free(self._assoc_vec[1], self._assoc_vec[2])
-            self._assoc_vec = (vec, eng.upload(np.ascontiguousarray(vec, dtype=np.float64)),
+            self._assoc_vec = (vec, eng.upload(np.ascontiguousarray(self._pad(vec, n_pad, 1, 0.0), dtype=np.float64)),
                                eng.upload(sin) if sin is not None else None)
         _, vec_d, sin_d = self._assoc_vec
         alen_d, rcls_d = eng.upload(alen), eng.upload(rcls)
@@ -128,7 +157,7 @@ class DeviceCompute:
         Returns (AssocHost, class_sums [sumA, 4], locus_sums [L, 6], (perm, dclass, dclass_value, best_class))."""
         from .synth import pack_assoc_tables, pack_dosage_tables
         eng = self.eng
-        b = self._upload(hb)
+        b = self._upload(hb, pad=False)     # the AP planes come as they are: per-call kernels, any row length
         alen, rcls = pack_assoc_tables(hb.allele_lens, precision)
         tabs = pack_dosage_tables(hb.allele_lens, precision)
         sin = None
@@ -145,7 +174,7 @@ class DeviceCompute:
         """TRRecord.GetDosages for every record of a batch (trk_dosages): (float32 [L, S], int32 [L] error bits)."""
         from .synth import pack_assoc_tables
         eng = self.eng
-        b = self._upload(hb)
+        b = self._upload(hb, pad=False)     # the AP planes come as they are: per-call kernels, any row length
         alen, _ = pack_assoc_tables(hb.allele_lens, 2)
         out, err = eng.dosages(b, alen, dosage_type,
                                None if ap1 is None else np.ascontiguousarray(ap1, dtype=np.float32),

@@ -355,6 +355,8 @@ static int check_batch(trk_ctx* ctx, const trk_batch* b) {
     if (b->group_bits && (b->n_groups < 1 || b->n_groups > 8))
         return fail(ctx, TRK_ERR_ARG, "n_groups %d outside [1,8]", b->n_groups);
     if (((uintptr_t)b->gt & 15u) != 0) return fail(ctx, TRK_ERR_ARG, "gt must be 16-byte aligned");
+    if (b->n_pad_samples < 0 || (b->n_pad_samples > 0 && b->n_pad_samples >= b->n_samples))
+        return fail(ctx, TRK_ERR_ARG, "n_pad_samples %d outside [0, n_samples)", b->n_pad_samples);
     return TRK_OK;
 }
 

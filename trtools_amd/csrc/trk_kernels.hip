@@ -335,7 +335,7 @@ __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count(
                 li0[TRK_LI_N_HOM_LEN] = n_hl;
                 li0[TRK_LI_N_HOM_STR] = n_hs;
                 li0[TRK_LI_N_BAD] = n_bad;
-                li0[TRK_LI_N_SAMPLES] = S;
+                li0[TRK_LI_N_SAMPLES] = S - b.n_pad_samples;
             }
         }
         wave_lds_fence();
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v2(
         li0[TRK_LI_N_HOM_LEN] = dup ? n_hl - c11 - c00 : hom_idx;
         li0[TRK_LI_N_HOM_STR] = dup ? n_hs - c11 - c00 : hom_idx;
         li0[TRK_LI_N_BAD] = n_bad;
-        li0[TRK_LI_N_SAMPLES] = S;
+        li0[TRK_LI_N_SAMPLES] = S - b.n_pad_samples;
     }
     wave_lds_fence();
 }
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_fast(
         li0[TRK_LI_N_HOM_LEN] = pl == 2 ? n_hl : 0;
         li0[TRK_LI_N_HOM_STR] = pl == 2 ? n_hs : 0;
         li0[TRK_LI_N_BAD] = n_bad;
-        li0[TRK_LI_N_SAMPLES] = S;
+        li0[TRK_LI_N_SAMPLES] = S - b.n_pad_samples;
     }
 }
 

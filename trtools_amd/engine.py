@@ -234,8 +234,9 @@ class Engine:
 
     # ---- batches ----
     def make_batch(self, gt, allele_off, len_class, str_class, len_class_value,
-                   locus_ploidy=None, group_bits=None, n_groups=1, max_alleles=None):
-        """Upload host arrays (numpy) or accept DeviceArrays; returns a DeviceBatch."""
+                   locus_ploidy=None, group_bits=None, n_groups=1, max_alleles=None, n_pad=0):
+        """Upload host arrays (numpy) or accept DeviceArrays; returns a DeviceBatch.  n_pad: the last n_pad samples
+        of every row are padding (genotype -1), see trk_batch.n_pad_samples."""
         def dev(x, dt):
             return x if isinstance(x, DeviceArray) else self.upload(x, dt)
         gt_d = dev(gt, np.int16)
@@ -261,6 +262,7 @@ class Engine:
         s = L.Batch()
         s.n_loci, s.n_samples, s.ploidy = Lc, S, P
         s.n_groups = int(n_groups)
+        s.n_pad_samples = int(n_pad)
         s.n_alleles_total = sumA
         s.max_alleles = int(max_alleles or 0)
         s.gt, s.allele_off = gt_d.ptr, off_d.ptr
