@@ -310,3 +310,35 @@ def test_no_filters_gives_per_sample_call_counts_and_float_depth(eng):
     want = np.where(called & (lcov[:, :, 0] > 0), lcov[:, :, 0].astype(np.float64), 0.0).sum(axis=0)
     assert np.allclose(res.sample_totaldp_f64.get(), want, rtol=1e-14, atol=0)
     assert not res.sample_totaldp.get().any()
+
+
+def test_ratio_filters_decide_like_the_float64_division(eng):
+    """HipSTR flank-indel / stutter filters (filters.py:415-484: DSTUTTER / DP > thr in float64) on the lean
+    streaming kernel: exact ties (3/20 vs 0.15), zero and missing depths, missing numerators, negative values and odd
+    thresholds must all come out as numpy has them."""
+    from trtools_amd import _lib as L
+    from trtools_amd.synth import pack_alleles
+    rng = np.random.default_rng(5)
+    Lc, S = 24, 4096
+    gt = rng.integers(0, 2, size=(Lc, S, 2)).astype(np.int16)
+    off, lc, sc, cv = pack_alleles([[2.0, 3.0]] * Lc, [['ACAC', 'ACACAC']] * Lc)
+    b = eng.make_batch(gt, off, lc, sc, cv)
+    for thr in (0.15, 0.2, 1.0 / 3.0, 0.0, -0.5, 1.0, 1e-300, 3.0, float('inf'), 0.15000000000000002):
+        dp = rng.integers(1, 200, size=(Lc, S)).astype(np.int32)
+        num = rng.integers(0, 40, size=(Lc, S)).astype(np.int32)
+        # exact ties and near ties of the threshold
+        k = rng.integers(1, 9, size=(Lc, S))
+        tie = rng.random((Lc, S)) < 0.3
+        dp[tie] = (20 * k)[tie]
+        num[tie] = (3 * k)[tie]
+        dp[rng.random((Lc, S)) < 0.02] = 0
+        dp[rng.random((Lc, S)) < 0.02] = INT_MIN
+        num[rng.random((Lc, S)) < 0.02] = INT_MIN
+        num[rng.random((Lc, S)) < 0.02] *= -1
+        dp[rng.random((Lc, S)) < 0.01] *= -1
+        with np.errstate(divide='ignore', invalid='ignore'):
+            want = (num.astype(np.float64) / dp.astype(np.float64)) > thr
+        filters = [dict(op=L.F_RATIO_GT, plane_a=1, plane_b=0, thr=thr), dict(op=L.F_LT, plane_a=0, thr=-1e9)]
+        res = eng.call_filters(b, [eng.upload(dp), eng.upload(num)], filters, dp_plane=0)
+        got = (res.filter_mask.get() & np.uint32(1)).astype(bool)
+        assert np.array_equal(got, want), thr
