@@ -94,6 +94,7 @@ class Workload:
         if world > 1 or os.environ.get('TRK_FORCE_DIST'):
             self.gather = eng.empty((world, self.n_loci), np.uint32)
         self.step_no = 0
+        self._pending = None
         self.overlap = os.environ.get('TRK_BENCH_OVERLAP', '1') != '0'
 
     # the buffers of the last completed step
@@ -103,14 +104,15 @@ class Workload:
 
     def step(self):
         """One statSTR + dumpSTR pass over the batch.  Queue 0 carries the HBM-bound stream kernels (count, call
-        filters), queue 1 the latency-bound rest: statSTR's finaliser runs beside the call-filter pass, dumpSTR's
-        finaliser + locus filters (+ the RCCL exchange) beside the next step's count.  TRK_BENCH_OVERLAP=0 puts
-        everything on queue 0."""
+        filters), queue 1 the latency-bound rest, placed beside the long call-filter kernel: statSTR's finaliser of
+        this step and dumpSTR's finaliser + locus filters (+ the RCCL exchange) of the PREVIOUS step (its outputs
+        are double buffered; ``flush`` runs the last one).  TRK_BENCH_OVERLAP=0 puts everything on queue 0, in
+        step order."""
         eng = self.eng
         i = self.step_no & 1
         self.step_no += 1
         b = self.sb.batch
-        out, bits, loc = self.call_outs[i], self.bits_[i], self.loc_counters_[i]
+        out = self.call_outs[i]
         q1 = 1 if self.overlap else 0
         # counters are per step (each step is a complete statSTR + dumpSTR run)
         out.sample_counters.zero()
@@ -121,22 +123,38 @@ class Workload:
         self.stats_b[i].locus_int.copy_from(self.stats_a[i].locus_int)
         eng.queue_wait(q1, 0)
         with eng.on_queue(q1):
+            self._tail()                                                           # dumpSTR tail of the previous step
             eng.locus_finalize(b, self.stats_a[i])                                 # statSTR: 11 statistics per locus
         eng.call_filters(b, self.planes, self.filters, dp_plane=0, out=out, delta_stats=self.stats_b[i])
-        # queue 0 may start the next step once statSTR's finaliser and the PREVIOUS tail are done (they own the
-        # other buffer set); this step's tail is enqueued behind that point and overlaps the next count
+        # queue 0 goes on to the next step once queue 1 is through with what it holds now (the other buffer set)
         eng.queue_wait(0, q1)
-        eng.queue_wait(q1, 0)
-        with eng.on_queue(q1):
-            loc.zero()
-            eng.locus_finalize(b, self.stats_b[i])
-            eng.locus_filters(self.n_loci, self.stats_b[i], bits_out=bits, counters=loc, **self.locus_args)
-            if self.gather is not None:
-                eng.allreduce_sum_i64(out.sample_counters)
-                eng.allreduce_sum_i64(out.sample_totaldp)
-                eng.allreduce_sum_i64(out.sample_dp_missing)
-                eng.allreduce_sum_i64(loc)
-                eng.allgather(bits, self.gather)
+        self._pending = i
+        if not self.overlap:
+            self._tail()
+
+    def _tail(self):
+        """dumpSTR after the call filters: statistics of the masked genotypes, locus filters, cohort-wide sums."""
+        if self._pending is None:
+            return
+        eng, i = self.eng, self._pending
+        self._pending = None
+        out, bits, loc = self.call_outs[i], self.bits_[i], self.loc_counters_[i]
+        loc.zero()
+        eng.locus_finalize(self.sb.batch, self.stats_b[i])
+        eng.locus_filters(self.n_loci, self.stats_b[i], bits_out=bits, counters=loc, **self.locus_args)
+        if self.gather is not None:
+            eng.allreduce_sum_i64(out.sample_counters)
+            eng.allreduce_sum_i64(out.sample_totaldp)
+            eng.allreduce_sum_i64(out.sample_dp_missing)
+            eng.allreduce_sum_i64(loc)
+            eng.allgather(bits, self.gather)
+
+    def flush(self):
+        """Enqueue the tail of the last step (call before the final synchronisation)."""
+        q1 = 1 if self.overlap else 0
+        self.eng.queue_wait(q1, 0)
+        with self.eng.on_queue(q1):
+            self._tail()
 
 
 def parity_spot_check(wl, n_check=6):
@@ -332,12 +350,14 @@ def main():
 
     for _ in range(args.warmup):
         wl.step()
+    wl.flush()
     barrier()
     eng.profile(True)
     eng.profile_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wl.step()
+    wl.flush()
     eng.sync()
     t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -395,7 +415,7 @@ def main():
                                        if cn else 0.0},
             "queues": ("2: stream kernels on queue 0, finalisers / locus filters / RCCL exchange on queue 1 and "
                        "overlapped with them -- kernels_ms are per-launch averages under that contention "
-                       "(k_locus_count alone: 0.70 ms)") if wl.overlap else "1",
+                       "(queue 1 work runs beside k_call_filter)") if wl.overlap else "1",
             "parity_rows_checked": n_checked,
             "device": eng.arch,
         }
