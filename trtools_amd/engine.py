@@ -349,14 +349,16 @@ class Engine:
         self._chk(self.lib.trk_stream_wait(self.ctx, int(waiter), int(signal)))
 
     def upload_plane(self, arr):
-        """Upload a FORMAT plane [L, S] or [L, S, k] (int32 / float32).  Multi-column planes go up planar
-        ([k, L, S], TRK_DT_PLANAR) so that every column streams as 16-byte vectors."""
+        """Upload a FORMAT plane [L, S] or [L, S, k] (int32 / float32).  Multi-column planes end up planar
+        ([k, L, S], TRK_DT_PLANAR) so that every column streams as 16-byte vectors: uploaded as they are and
+        transposed on the device (a host transpose of a 160 MB plane costs ~0.3 s)."""
         arr = np.asarray(arr)
+        d = self.upload(np.ascontiguousarray(arr))
         if arr.ndim == 3 and arr.shape[2] > 1 and os.environ.get('TRK_CF_INTERLEAVED', '0') == '0':
-            d = self.upload(np.ascontiguousarray(arr.transpose(2, 0, 1)))
-            d.planar = True
-            return d
-        return self.upload(np.ascontiguousarray(arr))
+            p = self.planarize(d)
+            d.free()
+            return p
+        return d
 
     def planarize(self, plane):
         """Device [L, S, k] -> new device array [k, L, S] marked planar (trk_planarize)."""
