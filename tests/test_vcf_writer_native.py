@@ -187,3 +187,53 @@ def test_large_records_are_formatted_in_parallel_with_the_same_text():
     pieces = b''.join(text(lo, min(S, lo + 500)) for lo in range(0, S, 500))   # 500 x 5 fields: the serial path
     assert whole == pieces
     assert text(0, S) == whole
+
+
+def test_decode_edge_cases(tmp_path):
+    """Short sample columns (trailing fields dropped), vectors of unequal length, '.', CRLF line ends, unicode strings,
+    a non-numeric token in an Integer field (-> the Python decoder's ValueError)."""
+    p = tmp_path / 'edge.vcf'
+    lines = ['##fileformat=VCFv4.2',
+             '##FORMAT=<ID=GT,Number=1,Type=String,Description="g">',
+             '##FORMAT=<ID=DP,Number=1,Type=Integer,Description="d">',
+             '##FORMAT=<ID=AD,Number=.,Type=Integer,Description="a">',
+             '##FORMAT=<ID=PL,Number=.,Type=Float,Description="p">',
+             '##FORMAT=<ID=TX,Number=1,Type=String,Description="t">',
+             '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tA\tB\tC\tD',
+             'c\t1\t.\tAC\tACAC\t.\t.\t.\tGT:DP:AD:PL:TX\t0/1:7:3,4:0.5,1e-3,nan:é\t1|1\t.:.:.:.:.\t0/0:-3:1,2,3:.,2:x y',
+             'c\t2\t.\tAC\tACAC\t.\t.\t.\tGT:DP\t0/1:5\t1/1:6\t./.:.\t0/0:7',
+             'c\t3\t.\tAC\tACAC\t.\t.\t.\tGT:DP\t0/1:5\t1/1:oops\t./.:.\t0/0:7']
+    p.write_bytes(('\r\n'.join(lines) + '\r\n').encode())
+
+    def decode(native):
+        old = vcfio._SERIALIZER
+        if not native:
+            vcfio._SERIALIZER = None
+        try:
+            out = []
+            for v in vcfio.VCFReader(str(p)):
+                rec = {}
+                for key in v.FORMAT[1:]:
+                    try:
+                        rec[key] = v.format(key)
+                    except ValueError as e:
+                        rec[key] = 'ValueError'
+                bad = any(isinstance(x, str) for x in rec.values())
+                out.append((rec, None if bad else v.to_text(native=native)))
+            return out
+        finally:
+            vcfio._SERIALIZER = old
+    assert vcfio._serializer() is not None
+    nat, py = decode(True), decode(False)
+    assert len(nat) == len(py) == 3
+    for (a, ta), (b, tb) in zip(nat, py):
+        assert ta == tb
+        for key in b:
+            if isinstance(b[key], str):
+                assert a[key] == b[key]
+            else:
+                assert a[key].dtype == b[key].dtype and a[key].shape == b[key].shape, key
+                assert np.array_equal(a[key], b[key], equal_nan=(a[key].dtype.kind == 'f')), key
+    assert nat[0][0]['AD'].shape == (4, 3) and nat[0][0]['AD'][1, 0] == -2147483648 and nat[0][0]['AD'][0, 2] == -2147483647
+    assert nat[0][0]['TX'][0] == 'é' and nat[0][0]['TX'][1] == '.'
+    assert nat[2][0]['DP'] == 'ValueError'
