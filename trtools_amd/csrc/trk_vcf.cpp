@@ -1,6 +1,7 @@
 // trk_vcf.cpp -- native VCF / BGZF reader (host C++17, zlib): decodes records straight into
 // the packed batch layout of include/trk.h.  See include/trk_vcf.h for the contract and the
 // reference call sites it stands in for (cyvcf2 behind trtools/utils/utils.py:19-67).
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -761,7 +762,8 @@ class FmtPool {
         static FmtPool* p = new FmtPool;   // never destroyed: its workers outlive static destruction
         return *p;
     }
-    int size() const { return (int)workers_.size() + 1; }
+    // (a forked child inherits the object but not its threads: it formats serially)
+    int size() const { return getpid() == pid_ ? (int)workers_.size() + 1 : 1; }
     // run fn(task) for task in [0, n) on the workers and the calling thread
     template <class F>
     void run(int n, F&& fn) {
@@ -809,6 +811,7 @@ class FmtPool {
         }
     }
     std::vector<std::thread> workers_;
+    pid_t pid_ = getpid();
     std::mutex mu_, call_mu_;
     std::condition_variable cv_, done_cv_;
     std::function<void(int)> fn_;
