@@ -266,3 +266,47 @@ def test_config4_associatr_100k_x_10k(eng):
                 for col, key in ((TL.AF_PVAL, 'pval'), (TL.AF_COEF, 'coef_std'), (TL.AF_SE, 'se_std'),
                                  (TL.AF_RSQUARED, 'rsquared')):
                     assert abs(F[l, col] - r[key]) <= 1e-9 * abs(r[key]) + 1e-13, (l, key)
+
+
+def test_config3_combined_100k_x_10k_two_queue_pipeline(eng):
+    """configs[3] exactly as bench.py runs it (statSTR + dumpSTR on 100k x 10k, finalisers and locus filters on the
+    second queue, the dumpSTR tail one step behind): three pipelined steps give the same outputs as one step with
+    everything in order on queue 0, and the oracle spot checks hold."""
+    import argparse
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    args = argparse.Namespace(loci=100000, samples=10000, seed=20260928 + 3)
+    os.environ['TRK_BENCH_OVERLAP'] = '0'
+    try:
+        ref = bench.Workload(eng, args, 0, 1)
+    finally:
+        del os.environ['TRK_BENCH_OVERLAP']
+    ref.step()
+    ref.flush()
+    eng.sync()
+    want = dict(bits=ref.bits.get(), loc=ref.loc_counters.get(), cnt=ref.call_out.sample_counters.get(),
+                li_a=ref.stats_a[0].locus_int.get(), lf_a=ref.stats_a[0].locus_f64.get(),
+                li_b=ref.stats_b[0].locus_int.get(), lf_b=ref.stats_b[0].locus_f64.get(),
+                mask_head=ref.call_out.filter_mask.get_rows(0, 32))
+    # free the big buffers of the reference run before the second workload allocates its own
+    for arr in list(eng._live):
+        if arr.nbytes > (1 << 28) and arr not in ref.sb.dev.values():
+            arr.free()
+    wl = bench.Workload(eng, args, 0, 1)
+    assert wl.overlap
+    for _ in range(3):
+        wl.step()
+    wl.flush()
+    eng.sync()
+    i = (wl.step_no - 1) & 1
+    assert np.array_equal(wl.bits.get(), want['bits'])
+    assert np.array_equal(wl.loc_counters.get(), want['loc'])
+    assert np.array_equal(wl.call_out.sample_counters.get(), want['cnt'])
+    assert np.array_equal(wl.stats_a[i].locus_int.get(), want['li_a'])
+    assert np.array_equal(wl.stats_a[i].locus_f64.get(), want['lf_a'], equal_nan=True)
+    assert np.array_equal(wl.stats_b[i].locus_int.get(), want['li_b'])
+    assert np.array_equal(wl.stats_b[i].locus_f64.get(), want['lf_b'], equal_nan=True)
+    assert np.array_equal(wl.call_out.filter_mask.get_rows(0, 32), want['mask_head'])
+    assert bench.parity_spot_check(wl, n_check=8) == 8
