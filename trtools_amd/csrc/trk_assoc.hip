@@ -1787,7 +1787,7 @@ static hipError_t launch_scan_t(const AssocArgs& a, const AssocPlan& p, hipStrea
 }
 
 static bool use_wave_regress(int M) {
-    int min_m = 22;  // below, 64 thread-private LDS columns fit and the thread-per-locus solve is faster
+    int min_m = 18;  // below, the thread-per-locus solve is faster (M = 16: 1.05 vs 1.12 ms; M = 20: 1.62 vs 1.31 ms)
     if (const char* e = getenv("TRK_AS_WAVE_REGRESS_MIN")) min_m = atoi(e);
     return M >= min_m && M + 2 <= WAVE;
 }
