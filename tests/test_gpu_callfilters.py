@@ -342,3 +342,37 @@ def test_ratio_filters_decide_like_the_float64_division(eng):
         res = eng.call_filters(b, [eng.upload(dp), eng.upload(num)], filters, dp_plane=0)
         got = (res.filter_mask.get() & np.uint32(1)).astype(bool)
         assert np.array_equal(got, want), thr
+
+
+@pytest.mark.parametrize("max_alt,S", [(130, 512), (900, 256), (3000, 64)])
+def test_delta_outputs_with_very_large_allele_sets(eng, max_alt, S):
+    """Loci with hundreds / thousands of alleles: the LDS delta tables of the streaming kernels do not fit, the
+    interpreter with smaller blocks or the per-call kernel with global atomics takes over -- delta-corrected counts
+    must still equal a recount of the masked genotypes."""
+    from trtools_amd import _lib as L
+    from trtools_amd.synth import pack_alleles
+    rng = np.random.default_rng(max_alt)
+    Lc = 12
+    lens, strs, gts = [], [], []
+    for l in range(Lc):
+        A = max_alt + 1 if l % 3 == 0 else int(rng.integers(1, 6))
+        strs.append(['AC' * (i + 1) for i in range(A)])
+        lens.append([float(i + 1) for i in range(A)])
+        g = rng.integers(0, A, size=(S, 2)).astype(np.int16)
+        g[rng.random(S) < 0.1] = -1
+        gts.append(g)
+    gt = np.stack(gts)
+    off, lc, sc, cv = pack_alleles(lens, strs)
+    b = eng.make_batch(gt, off, lc, sc, cv)
+    dp = rng.integers(0, 50, size=(Lc, S)).astype(np.int32)
+    q = rng.random((Lc, S)).astype(np.float32)
+    filters = [dict(op=L.F_LT, plane_a=0, thr=15), dict(op=L.F_LT, plane_a=1, thr=0.4)]
+    st = eng.locus_stats(b, count_only=True)
+    res = eng.call_filters(b, [eng.upload(dp), eng.upload(q)], filters, dp_plane=0, delta_stats=st)
+    recount = eng.locus_stats(b.with_gt(res.gt_out), count_only=True)
+    assert np.array_equal(st.allele_count.get(), recount.allele_count.get())
+    cols = [L.LI_N_CALLED, L.LI_N_LOWPLOIDY, L.LI_N_HOM_LEN, L.LI_N_HOM_STR]
+    assert np.array_equal(st.locus_int.get()[0][:, cols], recount.locus_int.get()[0][:, cols])
+    want_mask = ((dp < 15).astype(np.uint32) | ((q < np.float32(0.4)).astype(np.uint32) << 1))
+    want_mask |= np.any(gt == -1, axis=2).astype(np.uint32) << np.uint32(31)
+    assert np.array_equal(res.filter_mask.get(), want_mask)
