@@ -27,6 +27,10 @@ One step =
             the per-locus filter decisions are all-gathered (RCCL, 0.4 MB per rank) for the rank
             that writes the cohort's FILTER column.  Statistic rows stay with the rank that owns
             the loci (each rank writes its slice of the table; rank order == locus order).
+Queues: the two HBM-bound stream kernels (k_locus_count, k_call_filter) run on the context's queue 0; the
+latency-bound rest (both finalisers, the locus filters, the RCCL exchange) on queue 1 beside the call-filter
+kernel -- statSTR's finaliser of the step and dumpSTR's tail of the PREVIOUS step, whose outputs are double
+buffered (Workload.step / flush).  All work of the K steps ends inside the timed region (flush + trk_sync).
 torch is imported only for N > 1 (rendezvous, barrier, max-over-ranks), never for compute.
 """
 import argparse
