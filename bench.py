@@ -329,6 +329,44 @@ def cpu_baseline(wl, budget_s):
                 cells_per_s=done * S / el)
 
 
+def cpu_baseline_c(wl, n_loci=3072, max_threads=32):
+    """The C half of the oracle (oracle/oracle_c.c: counts, statistics, exact HWE test, the three threshold call
+    filters, recount of the masked genotypes) on a bounded sample of the same call set: one core, then all cores
+    with the loci split over threads ('single core and all cores').  A compiled, per-locus CPU
+    implementation of the same step -- a stronger baseline than the numpy port, still only a reported number."""
+    import threading
+    from oracle import oracle_c
+    n_loci = min(n_loci, wl.n_loci)
+    idx = np.arange(n_loci)
+    h = wl.sb.host_rows(idx)
+    off_all = wl.sb.tables[0]
+    off = (off_all[:n_loci + 1] - off_all[0]).astype(np.int32)
+    lc, sc, cv = (np.ascontiguousarray(t[off_all[0]:off_all[n_loci]]) for t in wl.sb.tables[1:4])
+
+    def work(lo, hi):
+        o = (off[lo:hi + 1] - off[lo]).astype(np.int32)
+        sl = slice(int(off[lo]), int(off[hi]))
+        oracle_c.batch_stats(h['gt'][lo:hi], None, o, lc[sl], sc[sl], cv[sl])                      # statSTR
+        g2 = oracle_c.call_filters_dpq(h['gt'][lo:hi], h['dp'][lo:hi], h['q'][lo:hi], 10, 1000, 0.9)[0]
+        oracle_c.batch_stats(g2, None, o, lc[sl], sc[sl], cv[sl])                                  # dumpSTR on GT'
+
+    oracle_c.load()
+    out = {}
+    for label, nt in (('one_core', 1), ('all_cores', max(1, min(max_threads, os.cpu_count() or 1, n_loci // 8)))):
+        bounds = np.linspace(0, n_loci, nt + 1).astype(int)
+        th = [threading.Thread(target=work, args=(int(bounds[i]), int(bounds[i + 1]))) for i in range(nt)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        el = time.perf_counter() - t0
+        out[label] = dict(value=n_loci / el, unit="loci/s", cores=nt, cells_per_s=n_loci * wl.n_samples / el)
+    out['kind'] = "port (C restatement, oracle/oracle_c.c)"
+    out['sample'] = "%d loci x %d samples of the same synthetic call set" % (n_loci, wl.n_samples)
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', '0'))
@@ -427,6 +465,11 @@ def main():
             out["extras"] = {"associatr_scan": assoc_extra(wl, args)}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
+            if world == 1:
+                try:
+                    out.setdefault("extras", {})["cpu_baseline_c"] = cpu_baseline_c(wl)
+                except Exception as e:      # the checker's C half is optional equipment of the box
+                    out.setdefault("extras", {})["cpu_baseline_c"] = {"error": str(e)[:200]}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
