@@ -1,0 +1,135 @@
+"""Property-based GPU parity (hypothesis): random small batches -- any sample count (rows aligned or not), ploidy 1-3,
+1-9 alleles with duplicate length / sequence classes, arbitrary mixes of missing (-1) and padding (-2) haplotypes,
+optional sample groups -- against the numpy oracle for the statistics, and random threshold filter sets against the
+oracle's call-filter restatement for masks, masked genotypes and per-sample counters."""
+import collections
+
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from test_gpu_stats import check_against_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from trtools_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _batch(rng, n_loci, S, P, with_low):
+    from trtools_amd.synth import pack_alleles
+    lens, strs, gts, lp = [], [], [], []
+    for l in range(n_loci):
+        motif = ''.join(rng.choice(list('ACGT'), size=int(rng.integers(1, 4))))
+        A = 1 + int(rng.integers(0, 9))
+        ss = []
+        while len(ss) < A:
+            s = motif * int(rng.integers(1, 12))
+            if rng.random() < 0.3:
+                s += 'N' * int(rng.integers(1, 3))          # same motif count, different length class
+            if s in ss and rng.random() < 0.7:
+                continue
+            ss.append(s)                                   # now and then a duplicate sequence
+        strs.append(ss)
+        lens.append([len(s) / len(motif) for s in ss])
+        pl = P if not with_low else int(rng.integers(1, P + 1))
+        lp.append(pl)
+        g = rng.integers(0, A, size=(S, P)).astype(np.int16)
+        g[rng.random(S) < rng.random() * 0.4] = -1
+        g[rng.random(S) < 0.05, int(rng.integers(0, P))] = -1
+        if pl < P:
+            g[:, pl:] = -2
+        elif P > 1 and rng.random() < 0.5:
+            g[rng.random(S) < 0.15, P - 1] = -2
+        if rng.random() < 0.1:
+            g[:] = -1
+        gts.append(g)
+    return np.stack(gts), lens, strs, np.array(lp, dtype=np.uint8), pack_alleles(lens, strs)
+
+
+@settings(max_examples=200, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(0, 2**31 - 1), n_loci=st.integers(1, 10), S=st.integers(1, 260), P=st.integers(1, 3),
+       with_low=st.booleans(), n_groups=st.integers(0, 3))
+def test_statistics_match_the_oracle(eng, seed, n_loci, S, P, with_low, n_groups):
+    from oracle import trtools_oracle as orc
+    from trtools_amd import _lib as L
+    rng = np.random.default_rng(seed)
+    gt, lens, strs, lp, (off, lc, sc, cv) = _batch(rng, n_loci, S, P, with_low)
+    gb, groups = None, [None]
+    if n_groups:
+        gb = rng.integers(0, 1 << n_groups, size=S).astype(np.uint8)
+        groups = [((gb >> g) & 1).astype(bool) for g in range(n_groups)]
+    b = eng.make_batch(gt, off, lc, sc, cv, locus_ploidy=lp if with_low else None, group_bits=gb,
+                       n_groups=max(n_groups, 1))
+    res = eng.locus_stats(b, nalleles_thresh=0.05)
+    gt_view = [gt[l][:, :lp[l]] for l in range(n_loci)]
+    check_against_oracle(orc, L, res.allele_count.get(), res.locus_int.get(), res.locus_f64.get(), off, gt_view, lens,
+                         strs, groups, 0.05)
+    for a in list(b.arrays.values()) + [res.allele_count, res.locus_int, res.locus_f64]:
+        a.free()
+
+
+@settings(max_examples=200, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(0, 2**31 - 1), n_loci=st.integers(1, 8), S=st.integers(1, 300), n_filters=st.integers(0, 7),
+       delta=st.booleans(), with_low=st.booleans())
+def test_threshold_call_filters_match_the_oracle(eng, seed, n_loci, S, n_filters, delta, with_low):
+    from oracle import trtools_oracle as orc
+    from trtools_amd import _lib as L
+    rng = np.random.default_rng(seed)
+    gt, lens, strs, lp, (off, lc, sc, cv) = _batch(rng, n_loci, S, 2, with_low)
+    dp = rng.integers(0, 40, size=(n_loci, S)).astype(np.int32)
+    dp[rng.random((n_loci, S)) < 0.05] = -2147483648
+    nocall = np.stack([np.any(gt[l][:, :lp[l]] == -1, axis=1) for l in range(n_loci)])
+    dp[nocall & (rng.random((n_loci, S)) < 0.5)] = -2147483648
+    q = np.round(rng.random((n_loci, S)), 2).astype(np.float32)
+    q[rng.random((n_loci, S)) < 0.05] = np.nan
+    filters, fns = [], []
+    for k in range(n_filters):
+        plane = int(rng.integers(0, 2))
+        gt_op = bool(rng.integers(0, 2))
+        thr = float(rng.integers(0, 40)) if plane == 0 else float(np.round(rng.random(), 2))
+        filters.append(dict(op=L.F_GT if gt_op else L.F_LT, plane_a=plane, thr=thr))
+        fns.append((plane, gt_op, thr))
+    b = eng.make_batch(gt, off, lc, sc, cv, locus_ploidy=lp if with_low else None)
+    st_ = eng.locus_stats(b, count_only=True) if delta else None
+    res = eng.call_filters(b, [eng.upload(dp), eng.upload(q)], filters, dp_plane=0, delta_stats=st_)
+    names = ['f%d' % k for k in range(n_filters)]
+    info = collections.OrderedDict([('numcalls', np.zeros(S, dtype=int)), ('totaldp', np.zeros(S))] +
+                                   [(n, np.zeros(S, dtype=int)) for n in names])
+    gout = np.empty_like(gt)
+    mask = np.zeros((n_loci, S), dtype=np.uint32)
+    for l in range(n_loci):
+        outs = []
+        for k, (plane, gt_op, thr) in enumerate(fns):
+            field = (dp if plane == 0 else q)[l].reshape(-1, 1)
+            outs.append((names[k], orc.filt_max_value(field, thr) if gt_op else orc.filt_min_value(field, thr)))
+        for k, (_, o) in enumerate(outs):
+            mask[l] |= (~np.isnan(o)).astype(np.uint32) << np.uint32(k)
+        g = gt[l][:, :lp[l]]                # the reference sees the record's own ploidy columns
+        mask[l] |= (~orc.get_called_samples(g)).astype(np.uint32) << np.uint32(31)
+        try:
+            gout[l] = gt[l]
+            gout[l][:, :lp[l]], _ = orc.apply_call_filters(g, outs, info, dp=dp[l].reshape(-1, 1))
+        except ValueError:      # a passing call with negative depth: the device reports it in `error`
+            assert res.error.get()[0] != 0
+            return
+    assert res.error.get()[0] == 0
+    assert np.array_equal(res.filter_mask.get(), mask)
+    assert np.array_equal(res.gt_out.get(), gout)
+    cnt = res.sample_counters.get()
+    assert np.array_equal(cnt[0], info['numcalls'])
+    for k, n in enumerate(names):
+        assert np.array_equal(cnt[1 + k], info[n])
+    tot = res.sample_totaldp.get().astype(float)
+    tot[res.sample_dp_missing.get() > 0] = np.nan
+    assert np.array_equal(tot, info['totaldp'], equal_nan=True)
+    if delta:
+        recount = eng.locus_stats(b.with_gt(res.gt_out), count_only=True)
+        assert np.array_equal(st_.allele_count.get(), recount.allele_count.get())
+        cols = [L.LI_N_CALLED, L.LI_N_LOWPLOIDY, L.LI_N_HOM_LEN, L.LI_N_HOM_STR]
+        assert np.array_equal(st_.locus_int.get()[0][:, cols], recount.locus_int.get()[0][:, cols])

@@ -159,16 +159,19 @@ def _random_batch(rng, n_loci, n_samples, ploidy, max_alt, with_low=False):
     return np.stack(gts), lens, strs, np.array(lp, dtype=np.uint8), pack_alleles(lens, strs)
 
 
-@pytest.mark.parametrize("ploidy,n_groups", [(1, 1), (2, 3), (3, 1), (3, 2), (4, 8), (2, 1)])
-def test_general_ploidy_and_groups(eng, ploidy, n_groups):
+@pytest.mark.parametrize("S", [257, 256])     # 256: aligned rows, the streaming kernels with a per-locus ploidy table
+@pytest.mark.parametrize("ploidy,n_groups", [(1, 1), (2, 3), (3, 1), (3, 2), (4, 8), (2, 1), (2, 0)])
+def test_general_ploidy_and_groups(eng, ploidy, n_groups, S):
     from oracle import trtools_oracle as orc
     from trtools_amd import _lib as L
     rng = np.random.default_rng(100 * ploidy + n_groups)
-    n_loci, S = 25, 257
+    n_loci = 25
     gt, lens, strs, lp, (off, lc, sc, cv) = _random_batch(rng, n_loci, S, ploidy, 12, with_low=True)
-    gb = rng.integers(0, 1 << n_groups, size=S).astype(np.uint8)
-    groups = [((gb >> g) & 1).astype(bool) for g in range(n_groups)]
-    b = eng.make_batch(gt, off, lc, sc, cv, locus_ploidy=lp, group_bits=gb, n_groups=n_groups)
+    gb, groups = None, [None]
+    if n_groups:
+        gb = rng.integers(0, 1 << n_groups, size=S).astype(np.uint8)
+        groups = [((gb >> g) & 1).astype(bool) for g in range(n_groups)]
+    b = eng.make_batch(gt, off, lc, sc, cv, locus_ploidy=lp, group_bits=gb, n_groups=max(n_groups, 1))
     res = eng.locus_stats(b, nalleles_thresh=0.05)
     cnt, li, lf = _fetch(res)
     # the oracle sees what the reference would see: only the locus's own ploidy columns

@@ -390,7 +390,7 @@ __device__ __forceinline__ void fast_row(const u32x4* __restrict__ row, int nchu
         for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                fast_cell<DUP>(v[u][j] | hap1_fix, A, hist, lut, kshift, kslot, n_miss, n_low, n_hom, n_hl, n_hs,
+                fast_cell<DUP>(hap1_fix ? (v[u][j] & 0xffffu) | hap1_fix : v[u][j], A, hist, lut, kshift, kslot, n_miss, n_low, n_hom, n_hl, n_hs,
                                n_bad);
         }
     }
@@ -398,7 +398,7 @@ __device__ __forceinline__ void fast_row(const u32x4* __restrict__ row, int nchu
         u32x4 v = __builtin_nontemporal_load(&row[c]);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            fast_cell<DUP>(v[j] | hap1_fix, A, hist, lut, kshift, kslot, n_miss, n_low, n_hom, n_hl, n_hs, n_bad);
+            fast_cell<DUP>(hap1_fix ? (v[j] & 0xffffu) | hap1_fix : v[j], A, hist, lut, kshift, kslot, n_miss, n_low, n_hom, n_hl, n_hs, n_bad);
     }
 }
 
@@ -710,8 +710,9 @@ __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_fast(
     uint32_t* hist = lds + (size_t)wid * wave_lds_words;
     uint32_t* lut = hist + ((A + 1) << kshift);
     int pl = b.locus_ploidy ? (int)b.locus_ploidy[l] : 2;
-    // a haploid record inside a diploid batch: the second column is not part of the
-    // record; force it to -3 (neither a no-call nor padding, never counted)
+    // a haploid record inside a diploid batch: the second column is not part of the record (it holds the -2
+    // padding): REPLACE it by -3 (neither a no-call nor padding, never counted).  [OR-ing -3 over the -2 gave -1,
+    // i.e. every call of such a record read as missing -- found by tests/test_gpu_property.py]
     const uint32_t hap1_fix = pl < 2 ? 0xfffd0000u : 0u;
     // dense class ranks: a duplicate (two indices, one class) exists iff max rank + 1 < A
     int ml = 0, ms = 0;
