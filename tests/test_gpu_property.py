@@ -133,3 +133,14 @@ def test_threshold_call_filters_match_the_oracle(eng, seed, n_loci, S, n_filters
         assert np.array_equal(st_.allele_count.get(), recount.allele_count.get())
         cols = [L.LI_N_CALLED, L.LI_N_LOWPLOIDY, L.LI_N_HOM_LEN, L.LI_N_HOM_STR]
         assert np.array_equal(st_.locus_int.get()[0][:, cols], recount.locus_int.get()[0][:, cols])
+
+
+@settings(max_examples=120, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(0, 2**31 - 1), n_loci=st.integers(6, 14), S=st.integers(40, 700), P=st.integers(1, 3),
+       M=st.integers(1, 9), subset=st.booleans(), locus_ploidy=st.booleans(), miss=st.sampled_from([0.0, 0.04, 0.3]))
+def test_association_scan_matches_the_oracle(eng, seed, n_loci, S, P, M, subset, locus_ploidy, miss):
+    """trk_assoc_scan on random shapes (aligned and unaligned rows, ploidy 1-3 with and without a per-locus ploidy
+    table, 1-9 trait columns -> one-trait / LDS-resident / MFMA / per-call kernels, sample subsets, missing rates)
+    against the associaTR oracle, with the tolerances of tests/test_gpu_assoc.py."""
+    from test_gpu_assoc import run_case
+    run_case(eng, seed, n_loci, S, P=P, M=M, subset=subset, locus_ploidy=locus_ploidy and P > 1, miss=miss)
