@@ -23,10 +23,10 @@ def _same(a, b):
     return np.array_equal(a, b)
 
 
-def _compare(path, batch_records=None):
+def _compare(path, batch_records=None, max_ploidy=2):
     from trtools_amd import vcfio, vcfnative
     py = list(vcfio.VCFReader(path))
-    r = vcfnative.NativeVCFReader(path, batch_records=batch_records)
+    r = vcfnative.NativeVCFReader(path, batch_records=batch_records, max_ploidy=max_ploidy)
     num = [k for k, (t, n) in r.format_types.items() if t in ('Integer', 'Float') and k != 'GT']
     ncols = {}
     for v in py:
