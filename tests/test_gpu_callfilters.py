@@ -115,22 +115,19 @@ def test_hipstr_shape_filters(eng, n_loci, n_samples):
         assert c[L.LC_HWE_ERRORS] == n_raise
 
 
-@pytest.mark.parametrize("layout,S", [('interleaved', 96), ('planar', 96), ('interleaved', 1000), ('planar', 1000),
-                                      ('planarize', 1003)])
-def test_gangstr_and_popstr_shape_filters(eng, layout, S):
-    """QEXP / RC / REPCN+REPCI / AD filters (filters.py:573-867) incl. ploidy 1-3.  Multi-column planes in
-    both device layouts: interleaved [L, S, k] and planar [k, L, S] (TRK_DT_PLANAR; uploaded that way or
-    transposed on the device by trk_planarize)."""
+def run_gangstr_popstr_case(eng, seed, Lc, S, layout, keep=None, thr=None, delta=False, require_hits=False):
+    """QEXP / RC / REPCN+REPCI / AD filters (filters.py:573-867) on a random diploid batch against the oracle.
+    keep: which of the nine filters to apply (order kept); thr: (mindp, maxdp, het, hom, total, support)."""
     from oracle import trtools_oracle as orc
     from trtools_amd import _lib as L
     from trtools_amd.synth import pack_alleles
-    rng = np.random.default_rng(11)
-    Lc, P = 40, 2
-    A = 5
+    rng = np.random.default_rng(seed)
+    P, A = 2, 5
+    t_mindp, t_maxdp, t_het, t_hom, t_total, t_supp = thr if thr is not None else (5, 35, 0.2, 0.2, 0.5, 2)
     gt = rng.integers(0, A, size=(Lc, S, P)).astype(np.int16)
     gt[rng.random((Lc, S)) < 0.1] = -1
     gt[rng.random((Lc, S)) < 0.03, 1] = -1
-    gt[3] = -1                                   # a locus without any call
+    gt[min(3, Lc - 1)] = -1                      # a locus without any call
     lens = [[float(i + 2) for i in range(A)]] * Lc
     strs = [['AC' * (i + 2) for i in range(A)]] * Lc
     off, lc, sc, cv = pack_alleles(lens, strs)
@@ -164,33 +161,53 @@ def test_gangstr_and_popstr_shape_filters(eng, layout, S):
     planes = [up(dp), up(qexp), up(rc), up(repcn), up(repci), up(ad)]
     assert getattr(planes[2], 'planar', False) == (layout != 'interleaved')
     # BuildCallFilters order (dumpSTR.py:819-836, 867-872)
-    filters = [dict(op=L.F_LT, plane_a=0, thr=5), dict(op=L.F_GT, plane_a=0, thr=35),
-               dict(op=L.F_CALLED_LT, plane_a=1, col_a=1, thr=0.2),
-               dict(op=L.F_CALLED_LT, plane_a=1, col_a=2, thr=0.2),
-               dict(op=L.F_CALLED_SUM_LT, plane_a=1, col_a=1, col_a2=2, thr=0.5),
+    filters = [dict(op=L.F_LT, plane_a=0, thr=t_mindp), dict(op=L.F_GT, plane_a=0, thr=t_maxdp),
+               dict(op=L.F_CALLED_LT, plane_a=1, col_a=1, thr=t_het),
+               dict(op=L.F_CALLED_LT, plane_a=1, col_a=2, thr=t_hom),
+               dict(op=L.F_CALLED_SUM_LT, plane_a=1, col_a=1, col_a2=2, thr=t_total),
                dict(op=L.F_CALLED_EQ, plane_a=2, col_a=1, plane_b=0, col_b=0),
                dict(op=L.F_CALLED_SUM_EQ, plane_a=2, col_a=1, col_a2=3, plane_b=0, col_b=0),
                dict(op=L.F_CALLED_OUTSIDE_CI, plane_a=3, plane_b=4),
-               dict(op=L.F_AD_SUPPORT_LT, plane_a=5, thr=2)]
+               dict(op=L.F_AD_SUPPORT_LT, plane_a=5, thr=t_supp)]
     names = ['mindp', 'maxdp', 'het', 'hom', 'total', 'span', 'spanbound', 'badci', 'support']
+    keep = list(range(9)) if keep is None else sorted(keep)
+    filters = [filters[k] for k in keep]
+    names = [names[k] for k in keep]
 
     def filt(l, g):
         d = dp[l].reshape(-1, 1)
         rcs = np.array([','.join(map(str, r)) for r in rc[l]])
         cis = np.array(['%d-%d,%d-%d' % tuple(r) for r in repci[l]])
-        return [('mindp', orc.filt_min_value(d, 5)), ('maxdp', orc.filt_max_value(d, 35)),
-                ('het', orc.filt_gangstr_qexp(g, qexp[l], 0.2, 'het')),
-                ('hom', orc.filt_gangstr_qexp(g, qexp[l], 0.2, 'hom')),
-                ('total', orc.filt_gangstr_qexp(g, qexp[l], 0.5, 'total')),
-                ('span', orc.filt_gangstr_span_only(g, rcs, d)),
-                ('spanbound', orc.filt_gangstr_spanbound_only(g, rcs, d)),
-                ('badci', orc.filt_gangstr_bad_ci(g, repcn[l], cis)),
-                ('support', orc.filt_popstr_require_support(g, ad[l], 2))]
+        allf = [('mindp', lambda: orc.filt_min_value(d, t_mindp)), ('maxdp', lambda: orc.filt_max_value(d, t_maxdp)),
+                ('het', lambda: orc.filt_gangstr_qexp(g, qexp[l], t_het, 'het')),
+                ('hom', lambda: orc.filt_gangstr_qexp(g, qexp[l], t_hom, 'hom')),
+                ('total', lambda: orc.filt_gangstr_qexp(g, qexp[l], t_total, 'total')),
+                ('span', lambda: orc.filt_gangstr_span_only(g, rcs, d)),
+                ('spanbound', lambda: orc.filt_gangstr_spanbound_only(g, rcs, d)),
+                ('badci', lambda: orc.filt_gangstr_bad_ci(g, repcn[l], cis)),
+                ('support', lambda: orc.filt_popstr_require_support(g, ad[l], t_supp))]
+        return [(allf[k][0], allf[k][1]()) for k in keep]
     info, gout, mask = _oracle_run(orc, gt, filt, names, dp)
-    res = eng.call_filters(b, planes, filters, dp_plane=0)
+    st = eng.locus_stats(b, count_only=True) if delta else None
+    res = eng.call_filters(b, planes, filters, dp_plane=0, delta_stats=st)
     _compare(info, gout, mask, res, names, S)
-    for n in names:
-        assert info[n].sum() > 0, n
+    if delta:
+        recount = eng.locus_stats(b.with_gt(res.gt_out), count_only=True)
+        assert np.array_equal(st.allele_count.get(), recount.allele_count.get())
+        cols = [L.LI_N_CALLED, L.LI_N_LOWPLOIDY, L.LI_N_HOM_LEN, L.LI_N_HOM_STR]
+        assert np.array_equal(st.locus_int.get()[0][:, cols], recount.locus_int.get()[0][:, cols])
+    if require_hits:
+        for n in names:
+            assert info[n].sum() > 0, n
+
+
+@pytest.mark.parametrize("layout,S", [('interleaved', 96), ('planar', 96), ('interleaved', 1000), ('planar', 1000),
+                                      ('planarize', 1003)])
+def test_gangstr_and_popstr_shape_filters(eng, layout, S):
+    """QEXP / RC / REPCN+REPCI / AD filters (filters.py:573-867).  Multi-column planes in both device layouts:
+    interleaved [L, S, k] and planar [k, L, S] (TRK_DT_PLANAR; uploaded that way or transposed on the device by
+    trk_planarize)."""
+    run_gangstr_popstr_case(eng, 11, 40, S, layout, require_hits=True)
 
 
 def test_general_ploidy_call_filters(eng):

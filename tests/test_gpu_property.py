@@ -144,3 +144,16 @@ def test_association_scan_matches_the_oracle(eng, seed, n_loci, S, P, M, subset,
     against the associaTR oracle, with the tolerances of tests/test_gpu_assoc.py."""
     from test_gpu_assoc import run_case
     run_case(eng, seed, n_loci, S, P=P, M=M, subset=subset, locus_ploidy=locus_ploidy and P > 1, miss=miss)
+
+
+@settings(max_examples=100, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(0, 2**31 - 1), n_loci=st.integers(1, 9), S=st.integers(1, 520),
+       layout=st.sampled_from(['interleaved', 'planar', 'planarize']),
+       keep=st.sets(st.integers(0, 8), min_size=1), delta=st.booleans(),
+       thr=st.tuples(st.integers(0, 20), st.integers(10, 45), st.sampled_from([0.0, 0.1, 0.35]),
+                     st.sampled_from([0.05, 0.2, 0.5]), st.sampled_from([0.2, 0.6, 1.0]), st.integers(0, 6)))
+def test_gangstr_and_popstr_filters_match_the_oracle(eng, seed, n_loci, S, layout, keep, delta, thr):
+    """Random subsets of the GangSTR / PopSTR call filters, random thresholds, any sample count, all three plane
+    layouts, with and without the delta outputs (register interpreter, per-call path and their mixtures)."""
+    from test_gpu_callfilters import run_gangstr_popstr_case
+    run_gangstr_popstr_case(eng, seed, n_loci, S, layout, keep=keep, thr=thr, delta=delta)
