@@ -88,16 +88,22 @@ def test_threshold_call_filters_match_the_oracle(eng, seed, n_loci, S, n_filters
     dp[nocall & (rng.random((n_loci, S)) < 0.5)] = -2147483648
     q = np.round(rng.random((n_loci, S)), 2).astype(np.float32)
     q[rng.random((n_loci, S)) < 0.05] = np.nan
+    num = rng.integers(0, 12, size=(n_loci, S)).astype(np.int32)       # DSTUTTER / DFLANKINDEL-like counts
+    num[rng.random((n_loci, S)) < 0.05] = -2147483648
     filters, fns = [], []
     for k in range(n_filters):
-        plane = int(rng.integers(0, 2))
+        plane = int(rng.integers(0, 3))
         gt_op = bool(rng.integers(0, 2))
-        thr = float(rng.integers(0, 40)) if plane == 0 else float(np.round(rng.random(), 2))
-        filters.append(dict(op=L.F_GT if gt_op else L.F_LT, plane_a=plane, thr=thr))
+        if plane == 2:      # HipSTR's ratio over the depth (filters.py:415-484)
+            thr = float(rng.choice([0.15, 0.1, 0.25, 1.0 / 3.0, 0.0]))
+            filters.append(dict(op=L.F_RATIO_GT, plane_a=2, plane_b=0, thr=thr))
+        else:
+            thr = float(rng.integers(0, 40)) if plane == 0 else float(np.round(rng.random(), 2))
+            filters.append(dict(op=L.F_GT if gt_op else L.F_LT, plane_a=plane, thr=thr))
         fns.append((plane, gt_op, thr))
     b = eng.make_batch(gt, off, lc, sc, cv, locus_ploidy=lp if with_low else None)
     st_ = eng.locus_stats(b, count_only=True) if delta else None
-    res = eng.call_filters(b, [eng.upload(dp), eng.upload(q)], filters, dp_plane=0, delta_stats=st_)
+    res = eng.call_filters(b, [eng.upload(dp), eng.upload(q), eng.upload(num)], filters, dp_plane=0, delta_stats=st_)
     names = ['f%d' % k for k in range(n_filters)]
     info = collections.OrderedDict([('numcalls', np.zeros(S, dtype=int)), ('totaldp', np.zeros(S))] +
                                    [(n, np.zeros(S, dtype=int)) for n in names])
@@ -106,6 +112,10 @@ def test_threshold_call_filters_match_the_oracle(eng, seed, n_loci, S, n_filters
     for l in range(n_loci):
         outs = []
         for k, (plane, gt_op, thr) in enumerate(fns):
+            if plane == 2:
+                with np.errstate(divide='ignore', invalid='ignore'):
+                    outs.append((names[k], orc.filt_ratio_gt(num[l].reshape(-1, 1), dp[l].reshape(-1, 1), thr)))
+                continue
             field = (dp if plane == 0 else q)[l].reshape(-1, 1)
             outs.append((names[k], orc.filt_max_value(field, thr) if gt_op else orc.filt_min_value(field, thr)))
         for k, (_, o) in enumerate(outs):
