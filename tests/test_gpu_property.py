@@ -167,3 +167,75 @@ def test_gangstr_and_popstr_filters_match_the_oracle(eng, seed, n_loci, S, layou
     layouts, with and without the delta outputs (register interpreter, per-call path and their mixtures)."""
     from test_gpu_callfilters import run_gangstr_popstr_case
     run_gangstr_popstr_case(eng, seed, n_loci, S, layout, keep=keep, thr=thr, delta=delta)
+
+
+@pytest.fixture(scope='module')
+def comp(eng):
+    from trtools_amd.compute import DeviceCompute
+    return DeviceCompute(engine=eng)
+
+
+@settings(max_examples=150, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(0, 2**31 - 1), n_loci=st.integers(1, 9), S=st.integers(1, 130), P=st.integers(1, 3),
+       with_low=st.booleans(), n_groups=st.integers(0, 2), n_filters=st.integers(0, 5))
+def test_compute_seam_matches_the_oracle_seam(comp, seed, n_loci, S, P, with_low, n_groups, n_filters):
+    """What the CLIs call (compute.DeviceCompute: row padding, per-locus ploidy tables, planar planes, delta
+    outputs, finaliser, locus filters) against the oracle-backed object the CPU tests substitute for it
+    (tests/oracle_compute.py), on random host batches."""
+    from oracle_compute import OracleCompute
+    from trtools_amd import _lib as L
+    from trtools_amd.batch import HostBatch
+    rng = np.random.default_rng(seed)
+    gt, lens, strs, lp, _ = _batch(rng, n_loci, S, P, with_low)
+    gb = None
+    if n_groups:
+        gb = rng.integers(0, 1 << n_groups, size=S).astype(np.uint8)
+    hb = HostBatch(gt, lp, lens, strs, group_bits=gb, n_groups=max(n_groups, 1))
+    orc_c = OracleCompute()
+    a, b = comp.locus_stats(hb, nalleles_thresh=0.05), orc_c.locus_stats(hb, nalleles_thresh=0.05)
+    # (the integer columns the host layer reads; the oracle-backed object fills no others)
+    cols = [L.LI_N_CALLED, L.LI_N_SAMPLES, L.LI_N_ALLELES, L.LI_NALLELES_LEN, L.LI_NALLELES_STR, L.LI_HWE_STATUS_LEN,
+            L.LI_HWE_STATUS_STR]
+    assert np.array_equal(a.allele_count, b.allele_count)
+    assert np.array_equal(a.locus_int[:, :, cols], b.locus_int[:, :, cols])
+    nf = L.LF_CALLRATE + 1          # the named float columns (the last one of the 12 is spare)
+    assert np.allclose(a.locus_f64[..., :nf], b.locus_f64[..., :nf], rtol=1e-9, atol=1e-12, equal_nan=True)
+    if n_groups:
+        return                      # the dumpSTR pass is defined for one sample group
+    dp = rng.integers(0, 40, size=(n_loci, S)).astype(np.int32)
+    dp[rng.random((n_loci, S)) < 0.05] = -2147483648
+    q = np.round(rng.random((n_loci, S)), 2).astype(np.float32)
+    qexp = rng.random((n_loci, S, 3)).astype(np.float32)
+    filters = []
+    for k in range(n_filters):
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            filters.append(dict(op=L.F_LT, plane_a=0, thr=float(rng.integers(0, 30))))
+        elif kind == 1:
+            filters.append(dict(op=L.F_GT, plane_a=0, thr=float(rng.integers(10, 40))))
+        elif kind == 2:
+            filters.append(dict(op=L.F_LT, plane_a=1, thr=float(np.round(rng.random(), 2))))
+        else:
+            filters.append(dict(op=L.F_CALLED_SUM_LT, plane_a=2, col_a=1, col_a2=2, thr=float(np.round(rng.random() * 1.5, 2))))
+    spec = dict(min_callrate=float(rng.choice([0.0, 0.5, 0.9])), min_het=0.05, max_het=0.9)
+    # (the HWE locus filter needs every tested locus to have a fully called genotype; both seams agree on the
+    # error count, compared below through the counters)
+    if rng.random() < 0.5:
+        spec['min_hwep'] = 0.01
+    (ca, sa, ba, la) = comp.dumpstr_batch(hb, [dp, q, qexp], filters, 0, spec, nalleles_thresh=0.05)
+    (cb, sb, bb, lb) = orc_c.dumpstr_batch(hb, [dp, q, qexp], filters, 0, spec, nalleles_thresh=0.05)
+    if ca.error[0]:
+        return                      # a passing call with negative depth: the reference raises here
+    assert np.array_equal(ca.mask, cb.mask)
+    assert np.array_equal(ca.gt_out, cb.gt_out)
+    assert np.array_equal(ca.sample_counters, cb.sample_counters)
+    tot_a = ca.totaldp.astype(float)
+    tot_a[ca.dp_missing > 0] = np.nan
+    tot_b = np.asarray(cb.totaldp, dtype=float)
+    tot_b[cb.dp_missing > 0] = np.nan
+    assert np.array_equal(tot_a, tot_b, equal_nan=True)
+    assert np.array_equal(sa.allele_count, sb.allele_count)
+    assert np.array_equal(sa.locus_int[:, :, cols], sb.locus_int[:, :, cols])
+    assert np.allclose(sa.locus_f64[..., :nf], sb.locus_f64[..., :nf], rtol=1e-9, atol=1e-12, equal_nan=True)
+    assert np.array_equal(ba, bb)
+    assert np.array_equal(la, lb)
