@@ -239,3 +239,13 @@ def test_compute_seam_matches_the_oracle_seam(comp, seed, n_loci, S, P, with_low
     assert np.allclose(sa.locus_f64[..., :nf], sb.locus_f64[..., :nf], rtol=1e-9, atol=1e-12, equal_nan=True)
     assert np.array_equal(ba, bb)
     assert np.array_equal(la, lb)
+
+
+@settings(max_examples=60, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(0, 10**6), n_loci=st.integers(6, 16), S=st.integers(60, 420), M=st.integers(1, 8),
+       amax=st.integers(1, 12))
+def test_dosage_scan_matches_the_oracle(eng, seed, n_loci, S, M, amax):
+    """trk_assoc_scan_dosage (--beagle-dosages) on random shapes: allele sets of 1..12 (both the single-pass and the
+    two-pass kernel), 1-8 trait columns, sample subsets, missing calls."""
+    from test_gpu_assoc import run_dosage_case
+    run_dosage_case(eng, seed, n_loci, S, M, amax)
