@@ -53,7 +53,8 @@ def _batch(rng, n_loci, S, P, with_low):
 
 
 @settings(max_examples=200, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
-@given(seed=st.integers(0, 2**31 - 1), n_loci=st.integers(1, 10), S=st.integers(1, 260), P=st.integers(1, 3),
+@given(seed=st.integers(0, 2**31 - 1), n_loci=st.integers(1, 10),
+       S=st.one_of(st.integers(1, 260), st.sampled_from([1020, 1024, 1028, 2049, 4100])), P=st.integers(1, 3),
        with_low=st.booleans(), n_groups=st.integers(0, 3))
 def test_statistics_match_the_oracle(eng, seed, n_loci, S, P, with_low, n_groups):
     from oracle import trtools_oracle as orc
@@ -75,7 +76,8 @@ def test_statistics_match_the_oracle(eng, seed, n_loci, S, P, with_low, n_groups
 
 
 @settings(max_examples=200, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
-@given(seed=st.integers(0, 2**31 - 1), n_loci=st.integers(1, 8), S=st.integers(1, 300), n_filters=st.integers(0, 7),
+@given(seed=st.integers(0, 2**31 - 1), n_loci=st.integers(1, 8),
+       S=st.one_of(st.integers(1, 300), st.sampled_from([1020, 1024, 1028, 2052, 4100])), n_filters=st.integers(0, 7),
        delta=st.booleans(), with_low=st.booleans())
 def test_threshold_call_filters_match_the_oracle(eng, seed, n_loci, S, n_filters, delta, with_low):
     from oracle import trtools_oracle as orc
