@@ -237,3 +237,110 @@ def test_decode_edge_cases(tmp_path):
     assert nat[0][0]['AD'].shape == (4, 3) and nat[0][0]['AD'][1, 0] == -2147483648 and nat[0][0]['AD'][0, 2] == -2147483647
     assert nat[0][0]['TX'][0] == 'é' and nat[0][0]['TX'][1] == '.'
     assert nat[2][0]['DP'] == 'ValueError'
+
+
+# ---- randomised: native serialiser / decoder against the Python definitions --------------------------------------
+from hypothesis import HealthCheck, given, settings, strategies as st   # noqa: E402
+
+_FLOATS = [0.0, -0.0, 1.0, 0.1, 0.95, 1e-5, 1e-4, 123456.0, 1234567.0, 1e16, 3.4e38, 1.17549435e-38, 1e-45, float('inf'),
+           float('-inf'), 0.30000001192092896, 2.5, 99999.95, 999999.5, 1e-7]
+
+
+@settings(max_examples=150, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(0, 2**31 - 1), S=st.integers(1, 60), ploidy=st.integers(1, 3), ki=st.integers(1, 4), kf=st.integers(1, 3))
+def test_random_arrays_native_text_equals_python_text(seed, S, ploidy, ki, kf):
+    """Variant.to_text(native=True) == to_text(native=False) on records whose FORMAT arrays are random: genotype
+    sentinels and phasing, INT_MIN / vector-end patterns, float specials and values at the %g format switches, ASCII
+    and non-ASCII strings, the call-filter column."""
+    rng = np.random.default_rng(seed)
+    header = ['##fileformat=VCFv4.2', '##FORMAT=<ID=GT,Number=1,Type=String,Description="g">',
+              '##FORMAT=<ID=IV,Number=.,Type=Integer,Description="i">', '##FORMAT=<ID=FV,Number=.,Type=Float,Description="f">',
+              '##FORMAT=<ID=SV,Number=1,Type=String,Description="s">',
+              '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t' + '\t'.join('s%d' % i for i in range(S))]
+    line = 'c\t10\t.\tAC\tACAC\t.\t.\t.\tGT:IV:FV:SV\t' + '\t'.join(['0/0:1:1:x'] * S)
+    import io
+    import tempfile
+    with tempfile.NamedTemporaryFile('w', suffix='.vcf', delete=False) as fh:
+        fh.write('\n'.join(header + [line]) + '\n')
+        path = fh.name
+    try:
+        v = next(iter(vcfio.VCFReader(path)))
+    finally:
+        os.remove(path)
+    gt = rng.integers(-2, 12, size=(S, ploidy + 1)).astype(np.int16)
+    gt[:, ploidy] = rng.integers(0, 2, size=S)
+    v.set_gt_array(gt)
+    iv = rng.integers(-1000, 100000, size=(S, ki)).astype(np.int32)
+    iv[rng.random((S, ki)) < 0.2] = -2147483648
+    for s in range(S):                       # vector ends only at the tail of a row
+        n_end = int(rng.integers(0, ki + 1)) if rng.random() < 0.3 else 0
+        if n_end:
+            iv[s, ki - n_end:] = -2147483647
+    fv = rng.choice(np.array(_FLOATS + list(rng.normal(size=8) * 10.0 ** rng.integers(-8, 9, size=8))), size=(S, kf)).astype(np.float32)
+    fv[rng.random((S, kf)) < 0.2] = np.nan
+    sv = np.array([rng.choice(['', '.', 'PASS', 'a|b', 'é', 'x' * int(rng.integers(1, 30)), '名前']) for _ in range(S)])
+    v.set_format('IV', iv)
+    v.set_format('FV', fv)
+    v.set_format('SV', sv)
+    mask = rng.integers(0, 16, size=S).astype(np.uint32)
+    mask[rng.random(S) < 0.2] = 0x80000000
+    mask[rng.random(S) < 0.3] = 0
+    vals = [rng.choice(np.array(_FLOATS[:14]), size=S), None, rng.integers(0, 100, size=S).astype(float), rng.random(S)]
+    v.set_format('FILTER', vcfio.CallFilterColumn(mask, ['A', 'unused', 'Cc', 'd_d'], vals))
+    a = v.to_text(native=True)
+    b = v.to_text(native=False)
+    assert a == b
+
+
+@settings(max_examples=150, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(0, 2**31 - 1), S=st.integers(1, 50), n_rec=st.integers(1, 4))
+def test_random_text_native_decode_equals_python_decode(seed, S, n_rec):
+    """trk_vcf_decode_formats == Variant._numeric / np.array(col) on random sample columns."""
+    rng = np.random.default_rng(seed)
+
+    def tok_i():
+        return '.' if rng.random() < 0.15 else str(int(rng.integers(-10**6, 10**6)))
+
+    def tok_f():
+        if rng.random() < 0.15:
+            return '.'
+        x = float(rng.choice(_FLOATS[:-1] + [float(rng.normal()) * 10.0 ** int(rng.integers(-30, 30))]))
+        return rng.choice(['%g' % x, '%e' % x, repr(x), '%.3f' % x if abs(x) < 1e6 else '%g' % x])
+
+    header = ['##fileformat=VCFv4.2', '##FORMAT=<ID=GT,Number=1,Type=String,Description="g">',
+              '##FORMAT=<ID=IV,Number=.,Type=Integer,Description="i">', '##FORMAT=<ID=FV,Number=.,Type=Float,Description="f">',
+              '##FORMAT=<ID=SV,Number=1,Type=String,Description="s">', '##FORMAT=<ID=UN,Number=1,Type=Character,Description="u">',
+              '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t' + '\t'.join('s%d' % i for i in range(S))]
+    lines = []
+    for r in range(n_rec):
+        cols = []
+        for s in range(S):
+            toks = ['0/1', ','.join(tok_i() for _ in range(int(rng.integers(1, 4)))),
+                    ','.join(tok_f() for _ in range(int(rng.integers(1, 4)))),
+                    rng.choice(['.', 'x', 'a|b;c', 'é', 'long' * int(rng.integers(1, 6))]), rng.choice(['.', 'q'])]
+            if rng.random() < 0.2:
+                toks = toks[:int(rng.integers(1, 5))]
+            cols.append(':'.join(toks))
+        lines.append('c\t%d\t.\tAC\tACAC\t.\t.\t.\tGT:IV:FV:SV:UN\t' % (10 + r) + '\t'.join(cols))
+    import tempfile
+    with tempfile.NamedTemporaryFile('w', suffix='.vcf', delete=False, encoding='utf-8') as fh:
+        fh.write('\n'.join(header + lines) + '\n')
+        path = fh.name
+
+    def decode(native):
+        old = vcfio._SERIALIZER
+        if not native:
+            vcfio._SERIALIZER = None
+        try:
+            return [{k: v.format(k) for k in ('IV', 'FV', 'SV', 'UN')} for v in vcfio.VCFReader(path)]
+        finally:
+            vcfio._SERIALIZER = old
+    try:
+        assert vcfio._serializer() is not None
+        nat, py = decode(True), decode(False)
+    finally:
+        os.remove(path)
+    for a, b in zip(nat, py):
+        for k in b:
+            assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape, (k, a[k].dtype, b[k].dtype, a[k].shape, b[k].shape)
+            assert np.array_equal(a[k], b[k], equal_nan=(a[k].dtype.kind == 'f')), k
