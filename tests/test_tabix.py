@@ -133,3 +133,49 @@ def test_stale_index_falls_back_to_a_scan():
     got = _records(r, 'chr21:15000000-15500000')
     assert not r._indexed_region and len(got) > 10
     assert got == _records(vcfio.VCFReader(vcf), 'chr21:15000000-15500000')
+
+
+from hypothesis import HealthCheck, given, settings, strategies as st   # noqa: E402
+
+
+@settings(max_examples=60, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(0, 2**31 - 1), n_rec=st.integers(1, 400), n_chrom=st.integers(1, 3), S=st.integers(1, 30),
+       spread=st.sampled_from([50, 5000, 200000]))
+def test_random_files_index_seek_equals_scan(tmp_path_factory, seed, n_rec, n_chrom, S, spread):
+    """Random position-sorted bgzip VCFs (several contigs, dense and sparse positions, long reference alleles that
+    span 16 kb windows, many BGZF blocks): tabix.build + index-driven region reads return exactly what a linear scan
+    with the Python decoder returns, for random regions including empty ones and regions past the last record."""
+    from trtools_amd import tabix, vcfio, vcfnative
+    from trtools_amd.bgzf import BgzfWriter
+    rng = np.random.default_rng(seed)
+    d = tmp_path_factory.mktemp('tbx')
+    path = str(d / 'r.vcf.gz')
+    chroms = ['chr%d' % (c + 1) for c in range(n_chrom)]
+    per = np.sort(rng.integers(0, n_chrom, size=n_rec))
+    lines = ['##fileformat=VCFv4.2', '##command=HipSTR-v0.6.2 fuzz', '##INFO=<ID=END,Number=1,Type=Integer,Description="e">',
+             '##FORMAT=<ID=GT,Number=1,Type=String,Description="g">',
+             '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t' + '\t'.join('s%d' % i for i in range(S))]
+    last = {}
+    recs = []
+    for r in range(n_rec):
+        c = chroms[per[r]]
+        pos = last.get(c, 0) + int(rng.integers(0, spread)) + (1 if c not in last else 0)
+        pos = max(pos, 1)
+        last[c] = pos
+        ref = 'AC' * int(rng.integers(1, 40)) if rng.random() < 0.9 else 'A' * int(rng.integers(1, 30000))
+        recs.append((c, pos))
+        lines.append('\t'.join([c, str(pos), 'r%d' % r, ref, 'ACAC', '.', '.', '.', 'GT'] + ['0/1'] * S))
+    with BgzfWriter(path, threads=1) as fh:
+        fh.write('\n'.join(lines) + '\n')
+    tabix.build(path)
+    regions = []
+    for _ in range(8):
+        c = chroms[int(rng.integers(0, n_chrom))]
+        hi = last.get(c, 1000)
+        a = int(rng.integers(1, hi + 2000))
+        regions.append('%s:%d-%d' % (c, a, a + int(rng.integers(0, max(2, spread * 3)))))
+    regions += [chroms[0], '%s:%d-%d' % (chroms[-1], last.get(chroms[-1], 1) + 10, last.get(chroms[-1], 1) + 500), 'chrNone:1-10']
+    for reg in regions:
+        got = _records(vcfnative.NativeVCFReader(path), reg)
+        want = _records(vcfio.VCFReader(path), reg)
+        assert got == want, reg
