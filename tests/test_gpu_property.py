@@ -251,3 +251,48 @@ def test_dosage_scan_matches_the_oracle(eng, seed, n_loci, S, M, amax):
     two-pass kernel), 1-8 trait columns, sample subsets, missing calls."""
     from test_gpu_assoc import run_dosage_case
     run_dosage_case(eng, seed, n_loci, S, M, amax)
+
+
+@settings(max_examples=100, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(0, 2**31 - 1), n_loci=st.integers(1, 8), S=st.integers(1, 200),
+       dtype_=st.sampled_from(['bestguess', 'bestguess_norm', 'beagleap', 'beagleap_norm']), amax=st.integers(1, 12))
+def test_dosages_match_the_oracle(comp, seed, n_loci, S, dtype_, amax):
+    """TRRecord.GetDosages for a batch (trk_dosages) against the oracle: four dosage types, 1-12 alleles (numpy's
+    blocked float32 row sums above 8 terms), missing calls, AP rows that do not sum to one, the error conditions."""
+    from oracle_compute import OracleCompute
+    from test_dosages import close32
+    from trtools_amd.batch import HostBatch
+    rng = np.random.default_rng(seed)
+    lens, strs, gts = [], [], []
+    for l in range(n_loci):
+        A = int(rng.integers(1, amax + 1))
+        strs.append(['AC' * (i + 1) for i in range(A)])
+        lens.append([float(i + 1) + (0.5 if rng.random() < 0.2 else 0.0) for i in range(A)])
+        g = rng.integers(0, A, size=(S, 2)).astype(np.int16)
+        g[rng.random(S) < 0.1] = -1
+        if rng.random() < 0.1:
+            g[:] = -1
+        gts.append(g)
+    hb = HostBatch(np.stack(gts), np.full(n_loci, 2, dtype=np.uint8), lens, strs)
+    ap1 = ap2 = None
+    if dtype_.startswith('beagle'):
+        K = max(len(x) for x in lens) - 1
+        aps = []
+        for _ in range(2):
+            a = np.zeros((n_loci, S, max(K, 1)), dtype=np.float32)
+            for l in range(n_loci):
+                k = len(lens[l]) - 1
+                if k:
+                    p = rng.dirichlet(np.full(k + 1, 0.5), size=S)
+                    a[l, :, :k] = (p[:, 1:] * rng.uniform(0.85, 1.15, size=(S, 1))).astype(np.float32)
+                if rng.random() < 0.05:
+                    a[l, int(rng.integers(0, S)), 0] = -0.25      # negative probability -> error bit
+                if rng.random() < 0.05 and k:
+                    a[l, int(rng.integers(0, S)), :k] = 1.0       # row sum above 1.1 -> error bit
+            aps.append(a)
+        ap1, ap2 = aps
+    got, gerr = comp.dosages_batch(hb, dtype_, ap1, ap2)
+    want, werr = OracleCompute().dosages_batch(hb, dtype_, ap1, ap2)
+    assert np.array_equal(gerr, werr)
+    ok = werr == 0
+    assert close32(got[ok], want[ok])
