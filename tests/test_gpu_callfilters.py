@@ -115,7 +115,8 @@ def test_hipstr_shape_filters(eng, n_loci, n_samples):
         assert c[L.LC_HWE_ERRORS] == n_raise
 
 
-def run_gangstr_popstr_case(eng, seed, Lc, S, layout, keep=None, thr=None, delta=False, require_hits=False):
+def run_gangstr_popstr_case(eng, seed, Lc, S, layout, keep=None, thr=None, delta=False, require_hits=False,
+                            with_low=False):
     """QEXP / RC / REPCN+REPCI / AD filters (filters.py:573-867) on a random diploid batch against the oracle.
     keep: which of the nine filters to apply (order kept); thr: (mindp, maxdp, het, hom, total, support)."""
     from oracle import trtools_oracle as orc
@@ -128,6 +129,10 @@ def run_gangstr_popstr_case(eng, seed, Lc, S, layout, keep=None, thr=None, delta
     gt[rng.random((Lc, S)) < 0.1] = -1
     gt[rng.random((Lc, S)) < 0.03, 1] = -1
     gt[min(3, Lc - 1)] = -1                      # a locus without any call
+    lp = None
+    if with_low:                                 # haploid records inside the diploid batch
+        lp = rng.integers(1, 3, size=Lc).astype(np.uint8)
+        gt[lp == 1, :, 1] = -2
     lens = [[float(i + 2) for i in range(A)]] * Lc
     strs = [['AC' * (i + 2) for i in range(A)]] * Lc
     off, lc, sc, cv = pack_alleles(lens, strs)
@@ -151,7 +156,7 @@ def run_gangstr_popstr_case(eng, seed, Lc, S, layout, keep=None, thr=None, delta
     ad = rng.integers(0, 8, size=(Lc, S, A)).astype(np.int32)
     nocall = np.any(gt == -1, axis=2)
     dp[nocall & (rng.random((Lc, S)) < 0.8)] = INT_MIN
-    b = eng.make_batch(gt, off, lc, sc, cv)
+    b = eng.make_batch(gt, off, lc, sc, cv, locus_ploidy=lp)
     if layout == 'planar':
         up = eng.upload_plane
     elif layout == 'planarize':
@@ -187,7 +192,7 @@ def run_gangstr_popstr_case(eng, seed, Lc, S, layout, keep=None, thr=None, delta
                 ('badci', lambda: orc.filt_gangstr_bad_ci(g, repcn[l], cis)),
                 ('support', lambda: orc.filt_popstr_require_support(g, ad[l], t_supp))]
         return [(allf[k][0], allf[k][1]()) for k in keep]
-    info, gout, mask = _oracle_run(orc, gt, filt, names, dp)
+    info, gout, mask = _oracle_run(orc, gt, filt, names, dp, locus_ploidy=lp)
     st = eng.locus_stats(b, count_only=True) if delta else None
     res = eng.call_filters(b, planes, filters, dp_plane=0, delta_stats=st)
     _compare(info, gout, mask, res, names, S)

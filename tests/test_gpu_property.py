@@ -161,14 +161,14 @@ def test_association_scan_matches_the_oracle(eng, seed, n_loci, S, P, M, subset,
 @settings(max_examples=100, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
 @given(seed=st.integers(0, 2**31 - 1), n_loci=st.integers(1, 9), S=st.integers(1, 520),
        layout=st.sampled_from(['interleaved', 'planar', 'planarize']),
-       keep=st.sets(st.integers(0, 8), min_size=1), delta=st.booleans(),
+       keep=st.sets(st.integers(0, 8), min_size=1), delta=st.booleans(), with_low=st.booleans(),
        thr=st.tuples(st.integers(0, 20), st.integers(10, 45), st.sampled_from([0.0, 0.1, 0.35]),
                      st.sampled_from([0.05, 0.2, 0.5]), st.sampled_from([0.2, 0.6, 1.0]), st.integers(0, 6)))
-def test_gangstr_and_popstr_filters_match_the_oracle(eng, seed, n_loci, S, layout, keep, delta, thr):
+def test_gangstr_and_popstr_filters_match_the_oracle(eng, seed, n_loci, S, layout, keep, delta, thr, with_low):
     """Random subsets of the GangSTR / PopSTR call filters, random thresholds, any sample count, all three plane
     layouts, with and without the delta outputs (register interpreter, per-call path and their mixtures)."""
     from test_gpu_callfilters import run_gangstr_popstr_case
-    run_gangstr_popstr_case(eng, seed, n_loci, S, layout, keep=keep, thr=thr, delta=delta)
+    run_gangstr_popstr_case(eng, seed, n_loci, S, layout, keep=keep, thr=thr, delta=delta, with_low=with_low)
 
 
 @pytest.fixture(scope='module')
