@@ -1,0 +1,97 @@
+"""Randomised end-to-end runs: a random synthetic HipSTR / GangSTR VCF (any sample count) through the statSTR and
+dumpSTR command-line mirrors, once with the device behind the compute seam and once with the oracle-backed seam the CPU
+tests use -- the statistics table, the output VCF and both dumpSTR logs must be byte-identical."""
+import os
+
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from test_dumpstr_cli import make_args as dump_args
+from test_statstr_cli import _args as stat_args
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def computes():
+    from oracle_compute import OracleCompute
+    from trtools_amd.compute import DeviceCompute
+    return DeviceCompute(), OracleCompute()
+
+
+def _both(computes, run):
+    from trtools_amd import runtime
+    outs = []
+    for c in computes:
+        old = runtime.set_compute(c)
+        try:
+            outs.append(run())
+        finally:
+            runtime.set_compute(old)
+    return outs
+
+
+@settings(max_examples=12, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(0, 10**6), n_loci=st.integers(3, 40), S=st.integers(1, 70), caller=st.sampled_from(['hipstr', 'gangstr']),
+       use_length=st.booleans(), groups=st.booleans())
+def test_clis_device_equals_oracle_seam(tmp_path_factory, computes, seed, n_loci, S, caller, use_length, groups):
+    from trtools_amd import synth
+    from trtools_amd.dumpSTR import dumpSTR
+    from trtools_amd.statSTR import statSTR
+    rng = np.random.default_rng(seed)
+    d = tmp_path_factory.mktemp('cli')
+    vcf = str(d / 'in.vcf')
+    loci = synth.make_loci(n_loci, S, seed=seed, pure_repeats=(caller == 'gangstr'))
+    idx = np.arange(n_loci)
+    rows = synth.cells_numpy(seed, loci, idx, S)
+    extra = synth.gangstr_planes_numpy(seed, loci, idx, S, rows['gt'], rows['dp'], 0) if caller == 'gangstr' else None
+    names = synth.render_vcf(vcf, loci, rows, caller=caller, extra=extra)
+    # ---- statSTR ----
+    kw = dict(vcf=vcf, vcftype=caller, use_length=use_length, nalleles_thresh=0.05)
+    if groups and S >= 2:
+        files = []
+        for g in range(2):
+            f = str(d / ('grp%d.txt' % g))
+            pick = [n for n in names if rng.random() < 0.6] or [names[0]]
+            open(f, 'w').write('\n'.join(pick) + '\n')
+            files.append(f)
+        kw['samples'] = ','.join(files)
+        kw['sample_prefixes'] = 'a,b'
+
+    def run_stat():
+        out = str(d / 'stat')
+        try:
+            rc = statSTR.main(stat_args(out, **kw))
+        except (ValueError, IndexError) as e:       # the reference's own failures (HWE test without a full genotype)
+            return type(e).__name__ + ': ' + str(e), None
+        return rc, open(out + '.tab').read() if rc == 0 else None
+    (rc_a, tab_a), (rc_b, tab_b) = _both(computes, run_stat)
+    assert rc_a == rc_b and tab_a == tab_b
+    # ---- dumpSTR ----
+    if caller == 'hipstr':
+        f = dict(hipstr_min_call_DP=int(rng.integers(5, 25)), hipstr_max_call_DP=int(rng.integers(40, 200)),
+                 hipstr_min_call_Q=float(rng.choice([0.8, 0.9, 0.95])), hipstr_max_call_stutter=0.15,
+                 hipstr_max_call_flank_indel=0.15)
+        if rng.random() < 0.5:
+            f['hipstr_min_supp_reads'] = int(rng.integers(1, 12))
+    else:
+        f = dict(gangstr_min_call_DP=int(rng.integers(5, 25)), gangstr_max_call_DP=int(rng.integers(40, 200)),
+                 gangstr_min_call_Q=0.9, gangstr_expansion_prob_het=0.05, gangstr_expansion_prob_total=0.2,
+                 gangstr_filter_span_only=bool(rng.integers(0, 2)), gangstr_filter_spanbound_only=bool(rng.integers(0, 2)),
+                 gangstr_filter_badCI=bool(rng.integers(0, 2)))
+    f.update(vcftype=caller, use_length=use_length, min_locus_callrate=float(rng.choice([0.0, 0.5, 0.8])),
+             min_locus_het=0.05, max_locus_het=0.9, drop_filtered=bool(rng.integers(0, 2)))
+    if rng.random() < 0.5:
+        f['filter_hrun'] = True
+
+    def run_dump():
+        out = str(d / 'dump')
+        try:
+            rc = dumpSTR.main(dump_args(out, vcf, **f))
+        except (ValueError, IndexError) as e:       # e.g. the HWE filter on a locus without a full genotype
+            return type(e).__name__, None
+        return rc, tuple(open(out + ext).read() for ext in ('.vcf', '.samplog.tab', '.loclog.tab')) if rc == 0 else None
+    (rc_a, out_a), (rc_b, out_b) = _both(computes, run_dump)
+    assert rc_a == rc_b
+    assert out_a == out_b
