@@ -95,3 +95,51 @@ def test_clis_device_equals_oracle_seam(tmp_path_factory, computes, seed, n_loci
     (rc_a, out_a), (rc_b, out_b) = _both(computes, run_dump)
     assert rc_a == rc_b
     assert out_a == out_b
+
+
+@settings(max_examples=15, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(0, 10**6), n_loci=st.integers(2, 30), S=st.integers(1, 50), use_length=st.booleans())
+def test_statstr_mixed_ploidy_device_equals_oracle_seam(tmp_path_factory, computes, seed, n_loci, S, use_length):
+    """Haploid records and haploid samples (chrX-like) in one file: batches padded with -2, per-locus ploidy tables,
+    row padding -- the statSTR table of the device seam equals the oracle-backed seam's."""
+    from trtools_amd.statSTR import statSTR
+    rng = np.random.default_rng(seed)
+    d = tmp_path_factory.mktemp('mp')
+    vcf = str(d / 'in.vcf')
+    lines = ['##fileformat=VCFv4.1', '##command=HipSTR-v0.6.2 fuzz', '##INFO=<ID=START,Number=1,Type=Integer,Description="s">',
+             '##INFO=<ID=END,Number=1,Type=Integer,Description="e">', '##INFO=<ID=PERIOD,Number=1,Type=Integer,Description="p">',
+             '##FORMAT=<ID=GT,Number=1,Type=String,Description="g">', '##contig=<ID=chrX>',
+             '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t' + '\t'.join('s%d' % i for i in range(S))]
+    for l in range(n_loci):
+        pos = 1000 + 200 * l
+        n_alt = int(rng.integers(0, 5))
+        ref = 'AC' * int(rng.integers(3, 9))
+        alts = ['AC' * int(rng.integers(1, 14)) + ('A' if rng.random() < 0.2 else '') for _ in range(n_alt)]
+        alts = [a for a in dict.fromkeys(alts) if a != ref]
+        A = 1 + len(alts)
+        haploid_record = rng.random() < 0.35
+        cols = []
+        for s in range(S):
+            if rng.random() < 0.1:
+                cols.append('.' if haploid_record or rng.random() < 0.5 else './.')
+            elif haploid_record or rng.random() < 0.2:
+                cols.append(str(int(rng.integers(0, A))))
+            else:
+                a, b = int(rng.integers(0, A)), int(rng.integers(0, A))
+                cols.append('%s|%s' % (a, '.' if rng.random() < 0.05 else b))
+        lines.append('\t'.join(['chrX', str(pos), '.', ref, ','.join(alts) or '.', '.', '.',
+                                'START=%d;END=%d;PERIOD=2' % (pos, pos + len(ref) - 1), 'GT'] + cols))
+    open(vcf, 'w').write('\n'.join(lines) + '\n')
+
+    def run_stat(hwep):
+        out = str(d / 'stat')
+        try:
+            rc = statSTR.main(stat_args(out, vcf=vcf, vcftype='hipstr', use_length=use_length, hwep=hwep, nalleles_thresh=0.05))
+        except (ValueError, IndexError) as e:
+            return type(e).__name__ + ': ' + str(e), None
+        return rc, open(out + '.tab').read() if rc == 0 else None
+    for hwep in (False, True):      # with --hwep haploid records make the reference raise: same error from both seams
+        (rc_a, tab_a), (rc_b, tab_b) = _both(computes, lambda: run_stat(hwep))
+        assert rc_a == rc_b and tab_a == tab_b
+        if hwep is False:
+            assert rc_a == 0
