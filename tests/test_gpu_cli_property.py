@@ -98,17 +98,21 @@ def test_clis_device_equals_oracle_seam(tmp_path_factory, computes, seed, n_loci
 
 
 @settings(max_examples=15, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
-@given(seed=st.integers(0, 10**6), n_loci=st.integers(2, 30), S=st.integers(1, 50), use_length=st.booleans())
-def test_statstr_mixed_ploidy_device_equals_oracle_seam(tmp_path_factory, computes, seed, n_loci, S, use_length):
+@given(seed=st.integers(0, 10**6), n_loci=st.integers(2, 30), S=st.integers(1, 50), use_length=st.booleans(),
+       haploid_records=st.booleans())
+def test_mixed_ploidy_device_equals_oracle_seam(tmp_path_factory, computes, seed, n_loci, S, use_length,
+                                                haploid_records):
     """Haploid records and haploid samples (chrX-like) in one file: batches padded with -2, per-locus ploidy tables,
-    row padding -- the statSTR table of the device seam equals the oracle-backed seam's."""
+    row padding -- the statSTR table and the dumpSTR outputs (VCF, both logs) of the device seam equal the
+    oracle-backed seam's."""
     from trtools_amd.statSTR import statSTR
     rng = np.random.default_rng(seed)
     d = tmp_path_factory.mktemp('mp')
     vcf = str(d / 'in.vcf')
     lines = ['##fileformat=VCFv4.1', '##command=HipSTR-v0.6.2 fuzz', '##INFO=<ID=START,Number=1,Type=Integer,Description="s">',
              '##INFO=<ID=END,Number=1,Type=Integer,Description="e">', '##INFO=<ID=PERIOD,Number=1,Type=Integer,Description="p">',
-             '##FORMAT=<ID=GT,Number=1,Type=String,Description="g">', '##contig=<ID=chrX>',
+             '##FORMAT=<ID=GT,Number=1,Type=String,Description="g">', '##FORMAT=<ID=DP,Number=1,Type=Integer,Description="d">',
+             '##FORMAT=<ID=Q,Number=1,Type=Float,Description="q">', '##contig=<ID=chrX>',
              '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t' + '\t'.join('s%d' % i for i in range(S))]
     for l in range(n_loci):
         pos = 1000 + 200 * l
@@ -117,18 +121,19 @@ def test_statstr_mixed_ploidy_device_equals_oracle_seam(tmp_path_factory, comput
         alts = ['AC' * int(rng.integers(1, 14)) + ('A' if rng.random() < 0.2 else '') for _ in range(n_alt)]
         alts = [a for a in dict.fromkeys(alts) if a != ref]
         A = 1 + len(alts)
-        haploid_record = rng.random() < 0.35
+        haploid_record = haploid_records and rng.random() < 0.35
         cols = []
         for s in range(S):
+            fmt = ':%d:%.2f' % (int(rng.integers(1, 60)), rng.random())
             if rng.random() < 0.1:
-                cols.append('.' if haploid_record or rng.random() < 0.5 else './.')
+                cols.append(('.' if haploid_record or rng.random() < 0.5 else './.') + ':.:.')
             elif haploid_record or rng.random() < 0.2:
-                cols.append(str(int(rng.integers(0, A))))
+                cols.append(str(int(rng.integers(0, A))) + fmt)
             else:
                 a, b = int(rng.integers(0, A)), int(rng.integers(0, A))
-                cols.append('%s|%s' % (a, '.' if rng.random() < 0.05 else b))
+                cols.append('%s|%s' % (a, '.' if rng.random() < 0.05 else b) + fmt)
         lines.append('\t'.join(['chrX', str(pos), '.', ref, ','.join(alts) or '.', '.', '.',
-                                'START=%d;END=%d;PERIOD=2' % (pos, pos + len(ref) - 1), 'GT'] + cols))
+                                'START=%d;END=%d;PERIOD=2' % (pos, pos + len(ref) - 1), 'GT:DP:Q'] + cols))
     open(vcf, 'w').write('\n'.join(lines) + '\n')
 
     def run_stat(hwep):
@@ -143,3 +148,21 @@ def test_statstr_mixed_ploidy_device_equals_oracle_seam(tmp_path_factory, comput
         assert rc_a == rc_b and tab_a == tab_b
         if hwep is False:
             assert rc_a == 0
+
+    from trtools_amd.dumpSTR import dumpSTR
+    f = dict(vcftype='hipstr', use_length=use_length, hipstr_min_call_DP=int(rng.integers(5, 30)),
+             hipstr_max_call_DP=int(rng.integers(35, 60)), hipstr_min_call_Q=float(rng.choice([0.3, 0.6, 0.9])),
+             min_locus_callrate=float(rng.choice([0.0, 0.5])), min_locus_het=0.05, max_locus_het=0.95)
+
+    def run_dump():
+        out = str(d / 'dump')
+        try:
+            rc = dumpSTR.main(dump_args(out, vcf, **f))
+        except (ValueError, IndexError) as e:
+            return type(e).__name__ + ': ' + str(e), None
+        return rc, tuple(open(out + ext).read() for ext in ('.vcf', '.samplog.tab', '.loclog.tab')) if rc == 0 else None
+    # (dumpSTR recomputes HWEP for INFO: a haploid record makes the reference -- and both seams -- raise IndexError)
+    (rc_a, out_a), (rc_b, out_b) = _both(computes, run_dump)
+    assert rc_a == rc_b and out_a == out_b
+    if not haploid_records and S >= 16:     # (a record all of whose samples came out haploid is a haploid record)
+        assert rc_a == 0
