@@ -772,7 +772,7 @@ class FmtPool {
             std::lock_guard<std::mutex> g(mu_);
             fn_ = [&](int t) { fn(t); };
             n_tasks_ = n;
-            next_.store(0);
+            next_ = 0;
             pending_ = n;
             ++gen_;
         }
@@ -790,11 +790,19 @@ class FmtPool {
         for (int i = 1; i < n; ++i) workers_.emplace_back([this] { loop(); });
         for (auto& w : workers_) w.detach();
     }
+    // tasks are handed out under the mutex (a dozen per record): a worker that is late leaving the previous
+    // record's loop sees either the old, exhausted state or the new one whole -- never a mixture
     void work() {
         while (true) {
-            const int t = next_.fetch_add(1);
-            if (t >= n_tasks_) break;
-            fn_(t);
+            std::function<void(int)> f;
+            int t;
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                if (next_ >= n_tasks_) break;
+                t = next_++;
+                f = fn_;
+            }
+            f(t);
             std::lock_guard<std::mutex> g(mu_);
             if (--pending_ == 0) done_cv_.notify_all();
         }
@@ -816,7 +824,7 @@ class FmtPool {
     std::condition_variable cv_, done_cv_;
     std::function<void(int)> fn_;
     int n_tasks_ = 0, pending_ = 0;
-    std::atomic<int> next_{0};
+    int next_ = 0;
     uint64_t gen_ = 0;
 };
 }  // namespace
