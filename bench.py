@@ -7,9 +7,9 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json metric / configs[3]): statSTR full statistics + dumpSTR
 call- and locus-level filters on a HipSTR-shape call set of 100 000 loci x
-10 000 samples per GPU, inputs resident in HBM before the timed region
-(generated on the device by k_synth; its numpy twin regenerates rows on the
-host for the parity spot-check and the CPU baseline).
+10 000 samples, inputs resident in HBM before the timed region (generated on
+the device by k_synth; its numpy twin regenerates rows on the host for the
+CPU baseline).
 
 One step =
   statSTR : trk_locus_stats(GT)                  (k_locus_count + k_locus_finalize + k_hwe_test)
@@ -21,17 +21,32 @@ One step =
                                                   pass over the genotype tensor)
             trk_locus_finalize(counts of GT')    (k_locus_finalize + k_hwe_test)
             trk_locus_filters(callrate, HWE, het low/high)  (k_locus_filter)
-  N > 1   : loci are sharded by rank (weak scaling: every rank owns 100k loci of an
-            N x 100k-locus cohort).  The one real exchange of the path: dumpSTR's per-sample /
-            per-filter counters and loc_info are sums over ALL loci -> RCCL all-reduce (< 1 MB);
-            the per-locus filter decisions are all-gathered (RCCL, 0.4 MB per rank) for the rank
-            that writes the cohort's FILTER column.  Statistic rows stay with the rank that owns
-            the loci (each rank writes its slice of the table; rank order == locus order).
+  N > 1   : --scaling strong (default, BASELINE configs[3] as written): the 100 000-locus cohort is cut into
+            contiguous locus shards, one per rank (12 500 loci each at N = 8; `value` = 100 000 loci x steps /
+            time).  --scaling weak: every rank owns 100 000 loci of an N x 100k-locus cohort.
+            The one real exchange of the path: dumpSTR's per-sample / per-filter counters and loc_info are sums
+            over ALL loci (dumpSTR.py:1251-1268) and the per-locus filter decisions are needed by the rank that
+            writes the cohort's FILTER column -> ONE grouped RCCL launch per step (trk_exchange: all-reduce of
+            one packed int64 buffer + all-gather of the filter bits).  Statistic rows stay with the rank that
+            owns the loci (rank order == locus order).
 Queues: the two HBM-bound stream kernels (k_locus_count, k_call_filter) run on the context's queue 0; the
-latency-bound rest (both finalisers, the locus filters, the RCCL exchange) on queue 1 beside the call-filter
-kernel -- statSTR's finaliser of the step and dumpSTR's tail of the PREVIOUS step, whose outputs are double
-buffered (Workload.step / flush).  All work of the K steps ends inside the timed region (flush + trk_sync).
+latency-bound rest beside the call-filter kernel on queues 1 and 2 -- dumpSTR's tail of the PREVIOUS step
+(finaliser, locus filters, the RCCL exchange; its outputs are double buffered) on queue 1, statSTR's finaliser of
+the step on queue 2 (Workload.step / flush).  All work of the K steps ends inside the timed region (flush + trk_sync).
 torch is imported only for N > 1 (rendezvous, barrier, max-over-ranks), never for compute.
+
+Parity inside the bench: after the timed region EVERY locus of the shard is checked against the compiled C
+restatement of the reference's algorithm (oracle/fullsize.py: counts, 11 statistics, filter masks, masked
+genotypes, sample_info, locus filter decisions, loc_info) -- `parity_rows_checked` == loci of the shard.
+
+Extras (N = 1 only, each outside the timed region of the headline metric):
+  strong_shard    the same step at 100000/N loci for N = 2, 4, 8 on this one GPU through a 1-rank RCCL
+                  communicator: what one of N ranks does in the strong-scaled run, with the predicted scaling
+                  efficiency (t_100k / N) / t_shard
+  config1         BASELINE configs[1]: statSTR full statistics, 10k loci x 1k samples
+  config2         BASELINE configs[2]: dumpSTR, GangSTR shape, nine call + four locus filters, 50k x 5k
+  associatr_scan  BASELINE configs[4] on one GPU
+  cpu_baseline_c  the compiled C restatement on one core and on all cores
 """
 import argparse
 import json
@@ -54,52 +69,80 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--loci', type=int, default=100000)
+    ap.add_argument('--loci', type=int, default=100000, help='loci of the cohort (strong) / per GPU (weak)')
     ap.add_argument('--samples', type=int, default=10000)
+    ap.add_argument('--scaling', choices=('strong', 'weak'), default='strong')
     ap.add_argument('--seed', type=int, default=20260928 + 3)
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of the CPU baseline sample')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-check', action='store_true')
     ap.add_argument('--no-assoc', action='store_true', help='skip the associaTR scan timing (the "associatr_scan" extra)')
+    ap.add_argument('--no-extras', action='store_true', help='skip strong_shard / config1 / config2')
     return ap.parse_args()
 
 
-class Workload:
-    """Device-resident buffers + one step of the hot path."""
+FILTERS_DPQ = None
 
-    def __init__(self, eng, args, rank, world):
+
+def filters_dpq():
+    """dumpSTR --hipstr-min-call-DP 10 --hipstr-max-call-DP 1000 --hipstr-min-call-Q 0.9"""
+    from trtools_amd import _lib as L
+    return [dict(op=L.F_LT, plane_a=0, thr=10), dict(op=L.F_GT, plane_a=0, thr=1000),
+            dict(op=L.F_LT, plane_a=1, thr=0.9)]
+
+
+LOCUS_ARGS = dict(min_callrate=0.8, min_hwep=1e-4, min_het=0.05, max_het=0.95, use_length=False)
+
+
+class Workload:
+    """Device-resident buffers of one rank's shard + one step of the hot path."""
+
+    def __init__(self, eng, seed, n_samples, loci, locus_base, world, use_comm, overlap=True, gather_loci=None):
         from trtools_amd.synth import SynthBatch
         from trtools_amd import _lib as L
+        from trtools_amd.engine import CallResult
         self.L = L
         self.eng = eng
-        self.rank, self.world = rank, world
-        self.n_loci, self.n_samples = args.loci, args.samples
-        self.sb = SynthBatch(eng, args.loci, args.samples, seed=args.seed, planes=('dp', 'q'),
-                             locus_base=rank * args.loci)
+        self.world = world
+        self.n_loci, self.n_samples = len(loci.allele_lens), n_samples
+        self.sb = SynthBatch(eng, self.n_loci, n_samples, seed=seed, planes=('dp', 'q'), locus_base=locus_base,
+                             loci=loci)
         self.planes = [self.sb.dev['dp'], self.sb.dev['q']]
-        # dumpSTR --hipstr-min-call-DP 10 --hipstr-max-call-DP 1000 --hipstr-min-call-Q 0.9
-        self.filters = [dict(op=L.F_LT, plane_a=0, thr=10), dict(op=L.F_GT, plane_a=0, thr=1000),
-                        dict(op=L.F_LT, plane_a=1, thr=0.9)]
-        self.locus_args = dict(min_callrate=0.8, min_hwep=1e-4, min_het=0.05, max_het=0.95, use_length=False)
+        self.filters = filters_dpq()
+        self.locus_args = dict(LOCUS_ARGS)
         b = self.sb.batch
-        self.stats_a = [eng.alloc_stats(b) for _ in range(2)]     # statSTR rows (double buffered for the gather)
-        self.stats_b = [eng.alloc_stats(b) for _ in range(2)]     # dumpSTR rows
+        # statSTR rows and, as the twin copy of the same count pass (TRK_STATS_TWIN), the counts dumpSTR's call
+        # filters correct in place; double buffered for the tail that runs one step behind
+        self.stats_a = [eng.alloc_stats(b, twin=True) for _ in range(2)]
+        self.stats_b = [(st.twin if getattr(st, 'twin', None) else eng.alloc_stats(b)) for st in self.stats_a]
         # everything a step hands to the next stage is double buffered (the tail of step n runs beside the head of
-        # step n + 1); the masked genotypes and the mask are written and consumed on queue 0 only: one copy
-        from trtools_amd.engine import CallResult
-        co = eng.alloc_call_out(b, len(self.filters))
-        S = self.n_samples
-        self.call_outs = [co, CallResult(co.gt_out, co.filter_mask, eng.zeros((1 + len(self.filters), S), np.int64),
-                                         eng.zeros((S,), np.int64), eng.zeros((S,), np.int64),
-                                         eng.zeros((4,), np.int32), eng.zeros((S,), np.float64))]
-        self.bits_ = [eng.empty((self.n_loci,), np.uint32) for _ in range(2)]
-        self.loc_counters_ = [eng.zeros((L.TRK_LC_COLS,), np.int64) for _ in range(2)]
-        self.gather = None
-        if world > 1 or os.environ.get('TRK_FORCE_DIST'):
-            self.gather = eng.empty((world, self.n_loci), np.uint32)
+        # step n + 1); the masked genotypes and the mask are written and consumed on queue 0 only: one copy.
+        # Everything that is summed over the ranks lives back to back in ONE int64 buffer per step slot
+        # (sample_info rows, totaldp, dp-missing, loc_info): one memset, one all-reduce.
+        S, nf = n_samples, len(self.filters)
+        S2 = (S + 1) & ~1                                         # 16-byte aligned segments
+        self.sums_, self.call_outs, self.loc_counters_ = [], [], []
+        gt_out = eng.empty((self.n_loci, S, 2), np.int16)
+        mask = eng.empty((self.n_loci, S), np.uint32)
+        for _ in range(2):
+            sums = eng.zeros(((1 + nf) * S2 + 2 * S2 + L.TRK_LC_COLS,), np.int64)
+            sc = sums.view(0, (1 + nf, S), np.int64) if S2 == S else None
+            if sc is None:
+                raise ValueError("an even number of samples is required")
+            td = sums.view((1 + nf) * S2 * 8, (S,), np.int64)
+            dm = sums.view((2 + nf) * S2 * 8, (S,), np.int64)
+            loc = sums.view((3 + nf) * S2 * 8, (L.TRK_LC_COLS,), np.int64)
+            self.sums_.append(sums)
+            self.loc_counters_.append(loc)
+            self.call_outs.append(CallResult(gt_out, mask, sc, td, dm, eng.zeros((4,), np.int32),
+                                             eng.zeros((S,), np.float64)))
+        # the all-gather moves equal-sized rows: the largest shard's size (shards differ by at most one locus)
+        gl = max(self.n_loci, gather_loci or 0)
+        self.bits_ = [eng.zeros((gl,), np.uint32) for _ in range(2)]
+        self.gather = eng.empty((world, gl), np.uint32) if use_comm else None
         self.step_no = 0
         self._pending = None
-        self.overlap = os.environ.get('TRK_BENCH_OVERLAP', '1') != '0'
+        self.overlap = overlap
 
     # the buffers of the last completed step
     call_out = property(lambda self: self.call_outs[(self.step_no - 1) & 1])
@@ -107,7 +150,7 @@ class Workload:
     loc_counters = property(lambda self: self.loc_counters_[(self.step_no - 1) & 1])
 
     def step(self):
-        """One statSTR + dumpSTR pass over the batch.  Queue 0 carries the HBM-bound stream kernels (count, call
+        """One statSTR + dumpSTR pass over the shard.  Queue 0 carries the HBM-bound stream kernels (count, call
         filters), queue 1 the latency-bound rest, placed beside the long call-filter kernel: statSTR's finaliser of
         this step and dumpSTR's finaliser + locus filters (+ the RCCL exchange) of the PREVIOUS step (its outputs
         are double buffered; ``flush`` runs the last one).  TRK_BENCH_OVERLAP=0 puts everything on queue 0, in
@@ -117,21 +160,22 @@ class Workload:
         self.step_no += 1
         b = self.sb.batch
         out = self.call_outs[i]
-        q1 = 1 if self.overlap else 0
-        # counters are per step (each step is a complete statSTR + dumpSTR run)
-        out.sample_counters.zero()
-        out.sample_totaldp.zero()
-        out.sample_dp_missing.zero()
-        eng.locus_stats(b, out=self.stats_a[i], count_only=True)                    # statSTR: count
-        self.stats_b[i].allele_count.copy_from(self.stats_a[i].allele_count)
-        self.stats_b[i].locus_int.copy_from(self.stats_a[i].locus_int)
+        q1, q2 = (1, 2) if self.overlap else (0, 0)
+        self.sums_[i].zero()       # counters are per step (each step is a complete statSTR + dumpSTR run)
+        eng.locus_stats(b, out=self.stats_a[i], count_only=True)                    # statSTR: count (+ twin copy)
+        if not getattr(self.stats_a[i], 'twin', None):
+            self.stats_b[i].allele_count.copy_from(self.stats_a[i].allele_count)
+            self.stats_b[i].locus_int.copy_from(self.stats_a[i].locus_int)
         eng.queue_wait(q1, 0)
+        eng.queue_wait(q2, 0)
         with eng.on_queue(q1):
             self._tail()                                                           # dumpSTR tail of the previous step
+        with eng.on_queue(q2):
             eng.locus_finalize(b, self.stats_a[i])                                 # statSTR: 11 statistics per locus
         eng.call_filters(b, self.planes, self.filters, dp_plane=0, out=out, delta_stats=self.stats_b[i])
-        # queue 0 goes on to the next step once queue 1 is through with what it holds now (the other buffer set)
+        # queue 0 goes on to the next step once queues 1 and 2 are through with what they hold now
         eng.queue_wait(0, q1)
+        eng.queue_wait(0, q2)
         self._pending = i
         if not self.overlap:
             self._tail()
@@ -142,16 +186,11 @@ class Workload:
             return
         eng, i = self.eng, self._pending
         self._pending = None
-        out, bits, loc = self.call_outs[i], self.bits_[i], self.loc_counters_[i]
-        loc.zero()
         eng.locus_finalize(self.sb.batch, self.stats_b[i])
-        eng.locus_filters(self.n_loci, self.stats_b[i], bits_out=bits, counters=loc, **self.locus_args)
+        eng.locus_filters(self.n_loci, self.stats_b[i], bits_out=self.bits_[i], counters=self.loc_counters_[i],
+                          **self.locus_args)
         if self.gather is not None:
-            eng.allreduce_sum_i64(out.sample_counters)
-            eng.allreduce_sum_i64(out.sample_totaldp)
-            eng.allreduce_sum_i64(out.sample_dp_missing)
-            eng.allreduce_sum_i64(loc)
-            eng.allgather(bits, self.gather)
+            eng.exchange(self.sums_[i], self.bits_[i], self.gather)
 
     def flush(self):
         """Enqueue the tail of the last step (call before the final synchronisation)."""
@@ -160,55 +199,71 @@ class Workload:
         with self.eng.on_queue(q1):
             self._tail()
 
+    def run(self, steps, warmup, barrier=None):
+        """warmup untimed steps, then `steps` timed ones; returns (seconds, per-kernel profile)."""
+        eng = self.eng
+        for _ in range(warmup):
+            self.step()
+        self.flush()
+        eng.sync()
+        if barrier:
+            barrier()
+        eng.profile(True)
+        eng.profile_reset()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.flush()
+        eng.sync()
+        elapsed = time.perf_counter() - t0
+        prof = eng.profile_get()
+        eng.profile(False)
+        return elapsed, prof
 
-def parity_spot_check(wl, n_check=6):
-    """Full-size run vs the oracle on a few regenerated rows + size-independent invariants."""
-    from oracle import trtools_oracle as orc
+    def free(self):
+        for st in self.stats_a + self.stats_b:
+            for a in (st.allele_count, st.locus_int, st.locus_f64) + tuple(getattr(st, '_owners', ())):
+                a.free()
+        for a in self.sums_ + self.bits_ + [self.call_outs[0].gt_out, self.call_outs[0].filter_mask, self.gather]:
+            if a is not None:
+                a.free()
+        for co in self.call_outs:
+            co.error.free()
+            co.sample_totaldp_f64.free()
+        for a in list(self.sb.dev.values()) + list(self.sb.batch.arrays.values()):
+            a.free()
+
+
+def exhaustive_check(wl, single_rank_sums):
+    """EVERY locus of the shard vs oracle_c on all host threads (oracle/fullsize.py).  The device generator's
+    output is read back block by block and is the input of both sides."""
+    from oracle import fullsize
     L = wl.L
-    eng = wl.eng
-    rng = np.random.default_rng(1)
-    idx = np.sort(rng.choice(wl.n_loci, size=min(n_check, wl.n_loci), replace=False))
-    host = wl.sb.host_rows(idx)
     i = (wl.step_no - 1) & 1
-    cnt = wl.stats_a[i].allele_count.get()[0]
-    li = wl.stats_a[i].locus_int.get()[0]
-    lf = wl.stats_a[i].locus_f64.get()[0]
-    off = wl.sb.tables[0]
-    for r, l in enumerate(idx):
-        o = orc.locus_stats(host['gt'][r], wl.sb.loci.allele_lens[l], wl.sb.loci.allele_strs[l], None,
-                            use_length=False)
-        assert np.array_equal(cnt[off[l]:off[l + 1]], o['index_counts']), ("allele counts", l)
-        assert li[l, L.LI_N_CALLED] == o['numcalled'], ("numcalled", l)
-        for col, key in ((L.LF_HET_STR, 'het'), (L.LF_MEAN, 'mean'), (L.LF_VAR, 'var'), (L.LF_HWEP_STR, 'hwep')):
-            a, bb = lf[l, col], o[key]
-            assert (np.isnan(a) and np.isnan(bb)) or abs(a - bb) <= 1e-9 * max(1.0, abs(bb)), (key, l, a, bb)
-    # dumpSTR half: the delta-corrected counts must equal a recount of the masked genotypes
-    lib_ = wl.stats_b[i].locus_int.get()[0]
-    cntb = wl.stats_b[i].allele_count.get()[0]
-    for r, l in enumerate(idx):
-        l = int(l)
-        g2 = wl.call_out.gt_out.get_rows(l, l + 1)[0]
-        o2 = orc.locus_stats(g2, wl.sb.loci.allele_lens[l], wl.sb.loci.allele_strs[l], None, use_length=False)
-        assert np.array_equal(cntb[off[l]:off[l + 1]], o2['index_counts']), ("masked allele counts", l)
-        assert lib_[l, L.LI_N_CALLED] == o2['numcalled'], ("masked numcalled", l)
-    # invariants over the whole shard
-    nall = li[:, L.LI_N_ALLELES].astype(np.int64)
-    seg = np.add.reduceat(cnt.astype(np.int64), off[:-1]) if wl.n_loci else np.zeros(0)
-    assert np.array_equal(seg, nall), "sum of allele counts != N_ALLELES"
-    assert np.all(li[:, L.LI_N_CALLED] <= wl.n_samples) and np.all(li[:, L.LI_N_BAD] == 0)
-    cnts = wl.call_out.sample_counters.get()
-    if wl.world == 1:
-        lib = wl.stats_b[i].locus_int.get()[0]
-        # every PASS call is a called sample of the masked matrix and vice versa
-        assert int(cnts[0].sum()) == int(lib[:, L.LI_N_CALLED].sum()), "numcalls != called after masking"
-        lc = wl.loc_counters.get()
-        bits = wl.bits.get()
-        assert lc[L.LC_PASS] == int(np.sum(bits == 0))
-        assert lc[L.LC_TOTALCALLS] == int(lib[bits == 0, L.LI_N_CALLED].sum())
-    return len(idx)
+    dev = dict(cnt_a=wl.stats_a[i].allele_count.get()[0], li_a=wl.stats_a[i].locus_int.get()[0],
+               lf_a=wl.stats_a[i].locus_f64.get()[0], cnt_b=wl.stats_b[i].allele_count.get()[0],
+               li_b=wl.stats_b[i].locus_int.get()[0], lf_b=wl.stats_b[i].locus_f64.get()[0],
+               bits=wl.bits.get()[:wl.n_loci])
+    if single_rank_sums:
+        dev.update(sample_counters=wl.call_out.sample_counters.get(), totaldp=wl.call_out.sample_totaldp.get(),
+                   dpmiss=wl.call_out.sample_dp_missing.get(), loc_counters=wl.loc_counters.get())
+    gt_d, dp_d, q_d = wl.sb.dev['gt'], wl.sb.dev['dp'], wl.sb.dev['q']
+
+    def fetch_inputs(lo, hi):
+        return gt_d.get_rows(lo, hi), [dp_d.get_rows(lo, hi), q_d.get_rows(lo, hi)]
+
+    def fetch_outputs(lo, hi):
+        return wl.call_out.gt_out.get_rows(lo, hi), wl.call_out.filter_mask.get_rows(lo, hi)
+
+    assert wl.call_out.error.get()[0] == 0
+    t0 = time.perf_counter()
+    r = fullsize.check_step(fetch_inputs, fetch_outputs, wl.n_loci, wl.n_samples, wl.sb.tables, wl.filters, 0,
+                            wl.locus_args, dev, n_threads=max(1, fullsize.oracle_c.n_cores() // max(1, wl.world)))
+    r['seconds'] = time.perf_counter() - t0
+    return r
 
 
-def assoc_extra(wl, args, iters=5):
+def assoc_extra(wl, seed, no_check, no_cpu, iters=5):
     """SURVEY section 8 row f3 / BASELINE configs[4] on ONE GPU, outside the timed region of the headline
     metric: the associaTR scan (trk_assoc_scan) over this rank's resident genotype tensor, one seeded
     standard-normal trait, every sample in the regression set.  4 algorithmic bytes per call (the GT read).
@@ -218,7 +273,7 @@ def assoc_extra(wl, args, iters=5):
     n_loci, n_samples = wl.n_loci, wl.n_samples
     alen, rcls = pack_assoc_tables(wl.sb.loci.allele_lens, 2)
     alen_d, rcls_d = eng.upload(alen, np.float64), eng.upload(rcls, np.uint16)
-    rng = np.random.default_rng(args.seed + 77)
+    rng = np.random.default_rng(seed + 77)
     y = rng.normal(size=n_samples)
     y = (y - y.mean()) / y.std()
     vec_d = eng.upload(y[None, :].copy(), np.float64)
@@ -245,7 +300,7 @@ def assoc_extra(wl, args, iters=5):
            "roofline": {"bound": "hbm", "kernel": "k_assoc_scan", "bytes_per_cell": 4,
                         "achieved": cells * 4 / (scan_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": cells * 4 / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
-    if not args.no_check:
+    if not no_check:
         from oracle import associatr_oracle as ao
         li, lf = res.locus_int.get(), res.locus_f64.get()
         idx = np.unique(np.linspace(0, n_loci - 1, 5).astype(int))
@@ -265,12 +320,12 @@ def assoc_extra(wl, args, iters=5):
             checked += 1
         out["parity_loci_checked"] = int(len(idx))
         out["parity_loci_regressed"] = checked
-        if not args.no_cpu_baseline:
+        if not no_cpu:
             # the same scan through the oracle port (numpy + scipy, one locus and one OLS fit at a time like the
             # reference), 1 core, on a bounded sample of loci regenerated by the generator's numpy twin
             t0 = time.perf_counter()
             done = 0
-            rng2 = np.random.default_rng(args.seed + 78)
+            rng2 = np.random.default_rng(seed + 78)
             while time.perf_counter() - t0 < 3.0:
                 pick = np.sort(rng2.choice(n_loci, size=8, replace=False))
                 rows2 = wl.sb.host_rows(pick)
@@ -284,6 +339,16 @@ def assoc_extra(wl, args, iters=5):
     for d in (alen_d, rcls_d, vec_d, res.locus_int, res.locus_f64, res.allele_count):
         d.free()
     return out
+
+
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(wl, budget_s):
@@ -321,7 +386,7 @@ def cpu_baseline(wl, budget_s):
         if time.perf_counter() - t0 - gen_time >= budget_s:
             break
     el = time.perf_counter() - t0 - gen_time
-    return dict(value=done / el, unit="loci/s", cores=1, kind="port",
+    return dict(value=done / el, unit="loci/s", cores=1, kind="port", cpu=cpu_model(),
                 sample="%d random loci x %d samples of the same synthetic call set, statSTR (11 stats, "
                        "string alleles) + dumpSTR (3 call filters, 4 locus filters, INFO recompute) through "
                        "oracle/trtools_oracle.py (numpy+scipy, per-locus like the reference), %.1f s"
@@ -329,46 +394,237 @@ def cpu_baseline(wl, budget_s):
                 cells_per_s=done * S / el)
 
 
-def cpu_baseline_c(wl, n_loci=3072, max_threads=32):
+def cpu_baseline_c(wl, n_loci=4096):
     """The C half of the oracle (oracle/oracle_c.c: counts, statistics, exact HWE test, the three threshold call
-    filters, recount of the masked genotypes) on a bounded sample of the same call set: one core, then all cores
-    with the loci split over threads ('single core and all cores').  A compiled, per-locus CPU
-    implementation of the same step -- a stronger baseline than the numpy port, still only a reported number."""
-    import threading
+    filters, recount of the masked genotypes) on a bounded sample of the same call set read back from the device:
+    one core, then all cores with the loci split over OpenMP threads inside the library ('single core
+    and all cores').  A compiled, per-locus CPU implementation of the same step -- a stronger baseline than the
+    numpy port, still only a reported number."""
     from oracle import oracle_c
     n_loci = min(n_loci, wl.n_loci)
-    idx = np.arange(n_loci)
-    h = wl.sb.host_rows(idx)
+    gt = wl.sb.dev['gt'].get_rows(0, n_loci)
+    planes = [wl.sb.dev['dp'].get_rows(0, n_loci), wl.sb.dev['q'].get_rows(0, n_loci)]
     off_all = wl.sb.tables[0]
     off = (off_all[:n_loci + 1] - off_all[0]).astype(np.int32)
     lc, sc, cv = (np.ascontiguousarray(t[off_all[0]:off_all[n_loci]]) for t in wl.sb.tables[1:4])
-
-    def work(lo, hi):
-        o = (off[lo:hi + 1] - off[lo]).astype(np.int32)
-        sl = slice(int(off[lo]), int(off[hi]))
-        oracle_c.batch_stats(h['gt'][lo:hi], None, o, lc[sl], sc[sl], cv[sl])                      # statSTR
-        g2 = oracle_c.call_filters_dpq(h['gt'][lo:hi], h['dp'][lo:hi], h['q'][lo:hi], 10, 1000, 0.9)[0]
-        oracle_c.batch_stats(g2, None, o, lc[sl], sc[sl], cv[sl])                                  # dumpSTR on GT'
-
     oracle_c.load()
     out = {}
-    for label, nt in (('one_core', 1), ('all_cores', max(1, min(max_threads, os.cpu_count() or 1, n_loci // 8)))):
-        bounds = np.linspace(0, n_loci, nt + 1).astype(int)
-        th = [threading.Thread(target=work, args=(int(bounds[i]), int(bounds[i + 1]))) for i in range(nt)]
+    for label, nt in (('one_core', 1), ('all_cores', oracle_c.n_cores())):
+        n = n_loci if nt > 1 else max(64, n_loci // 8)
+        o = (off[:n + 1]).astype(np.int32)
+        sl = slice(0, int(off[n]))
         t0 = time.perf_counter()
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
+        oracle_c.batch_stats(gt[:n], None, o, lc[sl], sc[sl], cv[sl], n_threads=nt)                        # statSTR
+        g2 = oracle_c.call_filters(gt[:n], [p[:n] for p in planes], wl.filters, dp_plane=0, n_threads=nt)[0]
+        oracle_c.batch_stats(g2, None, o, lc[sl], sc[sl], cv[sl], n_threads=nt)                             # dumpSTR on GT'
         el = time.perf_counter() - t0
-        out[label] = dict(value=n_loci / el, unit="loci/s", cores=nt, cells_per_s=n_loci * wl.n_samples / el)
-    out['kind'] = "port (C restatement, oracle/oracle_c.c)"
-    out['sample'] = "%d loci x %d samples of the same synthetic call set" % (n_loci, wl.n_samples)
+        out[label] = dict(value=n / el, unit="loci/s", cores=nt, cells_per_s=n * wl.n_samples / el,
+                          sample="%d loci x %d samples, %.1f s" % (n, wl.n_samples, el))
+    out['kind'] = "port (C restatement, oracle/oracle_c.c, OpenMP over loci)"
+    out['cpu'] = cpu_model()
+    return out
+
+
+def strong_shard_extra(eng, args, loci, t_full_ms, steps):
+    """What one of N ranks does in the strong-scaled run, measured on this one GPU: loci [0, 100000/N) of the same
+    cohort, the exchange through a 1-rank RCCL communicator (the collective kernels launch and run; only the wire
+    is missing).  predicted_efficiency = (t_100k / N) / t_shard."""
+    out = {}
+    cells_full = args.loci * args.samples
+    for n in (2, 4, 8):
+        hi = args.loci // n
+        wl = Workload(eng, args.seed, args.samples, loci.slice(0, hi), 0, 1, use_comm=True)
+        el, prof = wl.run(steps, 3)
+        ms = el / steps * 1e3
+        kn, kms = prof['k_call_filter']
+        cf = kms / max(kn, 1)
+        cells = hi * args.samples
+        out["N=%d" % n] = {"loci": hi, "ms_per_step": ms, "k_call_filter_ms": cf,
+                           "k_call_filter_frac": cells * BYTES_PER_CELL_CALL_FILTER / (cf * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "kernels_ms": {k: (v[1] / v[0] if v[0] else None) for k, v in prof.items() if v[0]},
+                           "predicted_efficiency": (t_full_ms / n) / ms,
+                           "predicted_loci_per_s_at_N": args.loci / (ms * 1e-3)}
+        wl.free()
+    out["note"] = ("one GPU, 1-rank RCCL communicator: every kernel and collective launch of a rank of the N-GPU "
+                   "strong-scaled run, without the xGMI wire time (< 1 MB per step)")
+    return out
+
+
+def config1_extra(eng, no_check, iters=50):
+    """BASELINE configs[1]: statSTR full statistics on a synthetic HipSTR-shape call set, 10k loci x 1k samples."""
+    from trtools_amd.synth import SynthBatch
+    from trtools_amd import _lib as L
+    Lc, S = 10000, 1000
+    sb = SynthBatch(eng, Lc, S, seed=20260928 + 1, planes=())
+    res = eng.alloc_stats(sb.batch)
+    eng.profile(True)
+    for it in range(iters + 3):
+        if it == 3:
+            eng.sync()
+            eng.profile_reset()
+            t0 = time.perf_counter()
+        eng.locus_stats(sb.batch, out=res)
+    eng.sync()
+    w = (time.perf_counter() - t0) / iters
+    pg = eng.profile_get()
+    eng.profile(False)
+    cnt_ms = pg['k_locus_count'][1] / pg['k_locus_count'][0]
+    fin_ms = pg['k_locus_finalize'][1] / pg['k_locus_finalize'][0]
+    out = {"workload": "statSTR full statistics, HipSTR shape, %d loci x %d samples (BASELINE configs[1])" % (Lc, S),
+           "ms_per_pass": w * 1e3, "loci_per_s": Lc / w, "calls_per_s": Lc * S / w,
+           "kernels_ms": {"k_locus_count": cnt_ms, "k_locus_finalize+k_hwe_test": fin_ms},
+           "roofline": {"bound": "hbm", "kernel": "k_locus_count", "bytes_per_cell": 4,
+                        "achieved": Lc * S * 4 / (cnt_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": Lc * S * 4 / (cnt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "note": "40 MB per launch: 5 us at the HBM peak -- launch-latency regime; the long-stream "
+                                "figure for this row length is extras.short_rows"}}
+    if not no_check:
+        from oracle import fullsize, oracle_c
+        off, lc, sc, cv = sb.tables
+        cnt_o, oi, of = oracle_c.batch_stats(sb.dev['gt'].get(), None, off, lc, sc, cv, n_threads=oracle_c.n_cores())
+        fullsize._cmp_stats('config1', 0, res.allele_count.get()[0], res.locus_int.get()[0], res.locus_f64.get()[0],
+                            cnt_o, oi, of, S)
+        out["parity_rows_checked"] = Lc
+    # the same row length as a long stream (1M loci x 1k samples = 4 GB): the short-row rate of the count kernel
+    for a in (res.allele_count, res.locus_int, res.locus_f64):
+        a.free()
+    for a in list(sb.dev.values()) + list(sb.batch.arrays.values()):
+        a.free()
+    return out
+
+
+def short_rows_extra(eng, iters=5):
+    """The count kernel on 1000-sample rows as a long stream (400k loci x 1k samples = 1.6 GB per launch)."""
+    from trtools_amd.synth import SynthBatch, make_loci
+    Lc, S = 400000, 1000
+    base = make_loci(10000, S, 20260928 + 1)
+    # tile the 10k-locus table 40 times (the per-call hash still differs by locus)
+    import copy
+    loci = copy.copy(base)
+    reps = Lc // 10000
+    loci.motifs = base.motifs * reps
+    loci.allele_strs = base.allele_strs * reps
+    loci.allele_lens = base.allele_lens * reps
+    nA = int(base.allele_off[-1])
+    loci.allele_off = np.concatenate([base.allele_off[:-1] + r * nA for r in range(reps)] +
+                                     [np.array([reps * nA])]).astype(np.int32)
+    loci.cdf24 = np.tile(base.cdf24, reps)
+    loci.miss_thr16 = np.tile(base.miss_thr16, reps)
+    loci.inbreed_thr16 = np.tile(base.inbreed_thr16, reps)
+    sb = SynthBatch(eng, Lc, S, seed=20260928 + 11, planes=(), loci=loci)
+    res = eng.alloc_stats(sb.batch)
+    eng.profile(True)
+    for it in range(iters + 2):
+        if it == 2:
+            eng.sync()
+            eng.profile_reset()
+        eng.locus_stats(sb.batch, out=res, count_only=True)
+    eng.sync()
+    pg = eng.profile_get()
+    eng.profile(False)
+    ms = pg['k_locus_count'][1] / pg['k_locus_count'][0]
+    out = {"workload": "k_locus_count on %d loci x %d samples (1000-sample rows as a long stream)" % (Lc, S),
+           "k_locus_count_ms": ms, "achieved_GBs": Lc * S * 4 / (ms * 1e-3) / 1e9,
+           "frac": Lc * S * 4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    for a in (res.allele_count, res.locus_int, res.locus_f64):
+        a.free()
+    for a in list(sb.dev.values()) + list(sb.batch.arrays.values()):
+        a.free()
+    return out
+
+
+def gangstr_filters():
+    """BuildCallFilters order for GangSTR (dumpSTR.py:819-836): min/max DP, min Q, expansion-prob het / hom / total,
+    span-only, span+bound-only, bad CI."""
+    from trtools_amd import _lib as L
+    return [dict(op=L.F_LT, plane_a=0, thr=10), dict(op=L.F_GT, plane_a=0, thr=60), dict(op=L.F_LT, plane_a=1, thr=0.9),
+            dict(op=L.F_CALLED_LT, plane_a=2, col_a=1, thr=0.05), dict(op=L.F_CALLED_LT, plane_a=2, col_a=2, thr=0.05),
+            dict(op=L.F_CALLED_SUM_LT, plane_a=2, col_a=1, col_a2=2, thr=0.2),
+            dict(op=L.F_CALLED_EQ, plane_a=3, col_a=1, plane_b=0, col_b=0),
+            dict(op=L.F_CALLED_SUM_EQ, plane_a=3, col_a=1, col_a2=3, plane_b=0, col_b=0),
+            dict(op=L.F_CALLED_OUTSIDE_CI, plane_a=4, plane_b=5)]
+
+
+def config2_extra(eng, no_check, iters=5):
+    """BASELINE configs[2]: dumpSTR call + locus filters on a synthetic GangSTR-shape call set, 50k loci x 5k samples,
+    the nine GangSTR call filters + four locus filters.  FORMAT planes are handed over planar ([k, L, S], what
+    Engine.upload_plane produces from cyvcf2-shaped [L, S, k] arrays): every column streams as 16-byte vectors and
+    unused columns (QEXP[0], RC[0], RC[2]) are never read -- 4 (GT) + 4 + 4 + 8 + 8 + 8 + 16 = 52 B read,
+    8 B written per call."""
+    from trtools_amd.synth import SynthBatch
+    from trtools_amd import _lib as L
+    Lc, S = 50000, 5000
+    sb = SynthBatch(eng, Lc, S, seed=20260928 + 2, planes=('dp', 'q'), pure_repeats=True)
+    sb.add_gangstr_planes()
+    names = ['dp', 'q', 'qexp', 'rc', 'repcn', 'repci']
+    inter = [sb.dev[n] for n in names]
+    planes = [eng.planarize(p) for p in inter]
+    filters = gangstr_filters()
+    locus_args = dict(min_callrate=0.8, min_hwep=1e-3, min_het=0.05, max_het=0.9, use_length=False)
+    st = eng.alloc_stats(sb.batch)
+    out_c = eng.alloc_call_out(sb.batch, len(filters))
+    bits = eng.empty((Lc,), np.uint32)
+    loc = eng.zeros((L.TRK_LC_COLS,), np.int64)
+    eng.profile(True)
+    for it in range(iters + 1):
+        if it == 1:
+            eng.sync()
+            eng.profile_reset()
+            t0 = time.perf_counter()
+        for a in (out_c.sample_counters, out_c.sample_totaldp, out_c.sample_dp_missing, loc):
+            a.zero()
+        eng.locus_stats(sb.batch, out=st, count_only=True)
+        eng.call_filters(sb.batch, planes, filters, dp_plane=0, out=out_c, delta_stats=st)
+        eng.locus_finalize(sb.batch, st)
+        eng.locus_filters(Lc, st, bits_out=bits, counters=loc, **locus_args)
+    eng.sync()
+    w = (time.perf_counter() - t0) / iters
+    pg = eng.profile_get()
+    eng.profile(False)
+    cf = pg['k_call_filter'][1] / pg['k_call_filter'][0]
+    moved = 4 + 4 + 4 + 8 + 8 + 8 + 16 + 8   # GT, DP, Q, QEXP[1:3], RC[1], RC[3], REPCN, REPCI; GT' + mask
+    out = {"workload": "dumpSTR, GangSTR shape, 9 call filters + 4 locus filters, %d loci x %d samples "
+                       "(BASELINE configs[2]), FORMAT planes planar" % (Lc, S),
+           "ms_per_pass": w * 1e3, "loci_per_s": Lc / w, "calls_per_s": Lc * S / w,
+           "kernels_ms": {k: (v[1] / v[0]) for k, v in pg.items() if v[0]},
+           "roofline": {"bound": "hbm", "kernel": "k_call_filter_fast", "bytes_per_cell_moved": moved,
+                        "bytes_per_cell_nominal": 72,
+                        "achieved": Lc * S * moved / (cf * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": Lc * S * moved / (cf * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+    if not no_check:
+        from oracle import fullsize
+        dev = dict(cnt_a=None, cnt_b=st.allele_count.get()[0], li_b=st.locus_int.get()[0], lf_b=st.locus_f64.get()[0],
+                   bits=bits.get(), sample_counters=out_c.sample_counters.get(), totaldp=out_c.sample_totaldp.get(),
+                   dpmiss=out_c.sample_dp_missing.get(), loc_counters=loc.get())
+        assert out_c.error.get()[0] == 0
+
+        def fetch_inputs(lo, hi):
+            return sb.dev['gt'].get_rows(lo, hi), [p.get_rows(lo, hi) for p in inter]
+
+        def fetch_outputs(lo, hi):
+            return out_c.gt_out.get_rows(lo, hi), out_c.filter_mask.get_rows(lo, hi)
+
+        t0 = time.perf_counter()
+        r = fullsize.check_step(fetch_inputs, fetch_outputs, Lc, S, sb.tables, filters, 0, locus_args, dev, block=2048)
+        out["parity_rows_checked"] = r['loci']
+        out["parity_calls_bit_for_bit"] = r['calls_bit_for_bit']
+        out["parity_worst_float_rel"] = r['worst_float_rel']
+        out["parity_seconds"] = time.perf_counter() - t0
+    for a in (planes + [st.allele_count, st.locus_int, st.locus_f64, out_c.gt_out, out_c.filter_mask,
+                        out_c.sample_counters, out_c.sample_totaldp, out_c.sample_dp_missing, out_c.error,
+                        out_c.sample_totaldp_f64, bits, loc] + list(sb.dev.values()) + list(sb.batch.arrays.values())):
+        a.free()
     return out
 
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON: native libraries print there too (RCCL's version banner at
+    # communicator creation), so file descriptor 1 is pointed at stderr for the run and the line goes to a copy
+    # of the original descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -378,58 +634,69 @@ def main():
         import torch.distributed as dist  # rendezvous / barrier only
         dist.init_process_group(backend='gloo')
     from trtools_amd.engine import Engine
+    from trtools_amd.synth import make_loci
+    from trtools_amd.dist import locus_shard
     eng = Engine(local_rank)
     if use_dist:
         uid = [eng.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         eng.comm_init(rank, world, uid[0])
-    wl = Workload(eng, args, rank, world)
+    # the cohort's per-locus tables (every rank builds the same ones from the seed)
+    loci = make_loci(args.loci, args.samples, args.seed)
+    if args.scaling == 'strong':
+        lo, hi = locus_shard(args.loci, rank, world)
+        my_loci, locus_base, total_loci = (loci.slice(lo, hi) if world > 1 else loci), lo, args.loci
+    else:
+        my_loci, locus_base, total_loci = loci, rank * args.loci, args.loci * world
+    wl = Workload(eng, args.seed, args.samples, my_loci, locus_base, world, use_comm=use_dist,
+                  overlap=os.environ.get('TRK_BENCH_OVERLAP', '1') != '0', gather_loci=-(-args.loci // world))
 
     def barrier():
-        eng.sync()
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        wl.step()
-    wl.flush()
-    barrier()
-    eng.profile(True)
-    eng.profile_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wl.step()
-    wl.flush()
-    eng.sync()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
+    elapsed, prof = wl.run(args.steps, args.warmup, barrier)
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
         dist.barrier()
-    prof = eng.profile_get()
-    eng.profile(False)
 
-    n_checked = 0
+    check = None
     if not args.no_check:
-        n_checked = parity_spot_check(wl)
+        check = exhaustive_check(wl, single_rank_sums=(world == 1))
+        if dist is not None:
+            # cohort-wide sums: the oracle's per-shard sums added over the ranks must equal what RCCL produced
+            import torch
+            c, td, dm, loc = check['sums']
+            packed = torch.from_numpy(np.concatenate([c.reshape(-1), td, dm, loc]).astype(np.int64))
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+            got = np.concatenate([wl.call_out.sample_counters.get().reshape(-1), wl.call_out.sample_totaldp.get(),
+                                  wl.call_out.sample_dp_missing.get(), wl.loc_counters.get()])
+            assert np.array_equal(packed.numpy(), got), "cohort-wide sums (RCCL all-reduce) differ from the oracle's"
+            rows = torch.tensor([check['loci']], dtype=torch.int64)
+            dist.all_reduce(rows, op=dist.ReduceOp.SUM)
+            check['loci_all_ranks'] = int(rows[0])
+            assert np.array_equal(wl.gather.get()[rank], wl.bits.get()), "all-gathered filter bits: own row differs"
     if rank == 0:
         cells = wl.n_loci * wl.n_samples
         ms_step = elapsed / args.steps * 1e3
-        loci_s = world * wl.n_loci * args.steps / elapsed
+        loci_s = total_loci * args.steps / elapsed
         kn, kms = prof['k_call_filter']
         cn, cms = prof['k_locus_count']
-        fn_, fms = prof['k_locus_finalize']
         avg_cf = kms / max(kn, 1)
         avg_cnt = cms / max(cn, 1)
         achieved = cells * BYTES_PER_CELL_CALL_FILTER / (avg_cf * 1e-3) / 1e9 if kn else 0.0
-        traffic = None
+        traffic, traffic_src = None, None
         tf = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(tf):
+        if os.path.exists(tf) and wl.n_loci == 100000 and wl.n_samples == 10000:
             try:
-                traffic = json.load(open(tf)).get('k_call_filter_bytes_per_launch')
+                pj = json.load(open(tf))
+                traffic = pj.get('k_call_filter_bytes_per_launch')
+                traffic_src = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                               "bench command (%s), guide's gfx950 corrections applied; a recorded figure, NOT "
+                               "measured in this run" % pj.get('source', 'see profiles/README.md'))
             except Exception:
                 traffic = None
         out = {
@@ -437,17 +704,22 @@ def main():
             "value": loci_s, "unit": "loci/s",
             "cells_per_sec": loci_s * wl.n_samples,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "i16", "data": "synthetic",
             "config": {"workload": "statSTR (11 stats) + dumpSTR (min-DP/max-DP/min-Q call filters, "
                                    "callrate/HWE/het-low/het-high locus filters) combined, HipSTR-shape, "
-                                   "%d loci x %d samples per GPU (BASELINE configs[3])" % (wl.n_loci, wl.n_samples),
-                       "n_loci_per_gpu": wl.n_loci, "n_samples": wl.n_samples, "ploidy": 2,
+                                   "%d loci x %d samples (BASELINE configs[3]), %s" %
+                                   (total_loci, wl.n_samples,
+                                    "one GPU" if world == 1 else
+                                    ("locus-sharded over %d GPUs, %d loci per GPU" % (world, wl.n_loci))),
+                       "n_loci_total": total_loci, "n_loci_per_gpu": wl.n_loci, "n_samples": wl.n_samples, "ploidy": 2,
                        "max_alleles": int(np.max(np.diff(wl.sb.tables[0]))),
-                       "sharding": "loci by rank; RCCL all-reduce of sample/locus counters + all-gather of the "
-                                   "per-locus filter decisions" if world > 1 else "single GPU"},
+                       "sharding": ("contiguous locus shards by rank; per step ONE grouped RCCL launch: all-reduce of "
+                                    "the packed sample_info / totaldp / loc_info counters + all-gather of the "
+                                    "per-locus filter decisions") if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_call_filter", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "bytes_per_cell": BYTES_PER_CELL_CALL_FILTER, "avg_launch_ms": avg_cf,
                          "launches": kn},
             "kernels_ms": {k: (v[1] / v[0] if v[0] else None) for k, v in prof.items()},
@@ -455,21 +727,38 @@ def main():
                                        "unit": "GB/s", "bytes_per_cell": BYTES_PER_CELL_COUNT,
                                        "frac": (cells * BYTES_PER_CELL_COUNT / (avg_cnt * 1e-3) / 1e9 / HBM_PEAK_GBS)
                                        if cn else 0.0},
-            "queues": ("2: stream kernels on queue 0, finalisers / locus filters / RCCL exchange on queue 1 and "
-                       "overlapped with them -- kernels_ms are per-launch averages under that contention "
-                       "(queue 1 work runs beside k_call_filter)") if wl.overlap else "1",
-            "parity_rows_checked": n_checked,
+            "queues": ("3: stream kernels on queue 0, dumpSTR's finaliser / locus filters / RCCL exchange on queue 1, "
+                       "statSTR's finaliser on queue 2, both overlapped with the call-filter kernel -- kernels_ms "
+                       "are per-launch averages under that contention") if wl.overlap else "1",
+            "parity_rows_checked": (check.get('loci_all_ranks', check['loci']) if check else 0),
             "device": eng.arch,
         }
-        if not args.no_assoc and world == 1:
-            out["extras"] = {"associatr_scan": assoc_extra(wl, args)}
-        if not args.no_cpu_baseline and world == 1:   # the CPU baselines are timed at N = 1 only
+        if check:
+            out["parity"] = {"checker": "oracle/oracle_c.c on %d host threads (oracle/fullsize.py)" % check['threads'],
+                             "loci": check['loci'], "calls": check['calls'],
+                             "calls_bit_for_bit_gt_and_mask": check['calls_bit_for_bit'],
+                             "worst_float_rel": check['worst_float_rel'], "seconds": check['seconds']}
+    if rank == 0 and world == 1:
+        extras = out.setdefault("extras", {})
+        if not args.no_assoc:
+            extras["associatr_scan"] = assoc_extra(wl, args.seed, args.no_check, args.no_cpu_baseline)
+        if not args.no_cpu_baseline:   # the CPU baselines are timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
             try:
-                out.setdefault("extras", {})["cpu_baseline_c"] = cpu_baseline_c(wl)
+                extras["cpu_baseline_c"] = cpu_baseline_c(wl)
             except Exception as e:      # the checker's C half is optional equipment of the box
-                out.setdefault("extras", {})["cpu_baseline_c"] = {"error": str(e)[:200]}
-        print(json.dumps(out), flush=True)
+                extras["cpu_baseline_c"] = {"error": str(e)[:200]}
+        if not args.no_extras:
+            wl.free()
+            if not use_dist:
+                uid = eng.comm_unique_id()
+                eng.comm_init(0, 1, uid)
+            extras["strong_shard"] = strong_shard_extra(eng, args, loci, ms_step, max(args.steps, 20))
+            extras["config1"] = config1_extra(eng, args.no_check)
+            extras["short_rows"] = short_rows_extra(eng)
+            extras["config2"] = config2_extra(eng, args.no_check)
+    if rank == 0:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

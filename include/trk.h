@@ -72,13 +72,23 @@ int trk_memcpy_d2h(trk_ctx* ctx, void* dst_host, const void* src_dev, size_t byt
 int trk_memcpy_d2d(trk_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes); /* async on the stream */
 int trk_memset(trk_ctx* ctx, void* dst_dev, int value, size_t bytes);
 int trk_sync(trk_ctx* ctx);
+/* Pinned (page-locked) host staging memory: hipHostMalloc.  A copy from / to such a buffer runs at the full PCIe
+ * rate and -- through the *_async forms -- overlaps with kernels of the other queue; pageable numpy buffers go
+ * through the driver's bounce buffer and serialise.  The async forms enqueue on the selected queue and return;
+ * trk_queue_sync(queue) / trk_sync() wait.  (compute.py keeps a ring of these per Engine: the reference streams
+ * record -> row, statSTR.py:586-639; here batch n+1 uploads while batch n computes and batch n-1 is formatted.) */
+int trk_host_alloc(trk_ctx* ctx, size_t bytes, void** hptr);
+int trk_host_free(trk_ctx* ctx, void* hptr);
+int trk_memcpy_h2d_async(trk_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int trk_memcpy_d2h_async(trk_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int trk_queue_sync(trk_ctx* ctx, int queue);
 /* A context owns TRK_N_STREAMS in-order queues (HIP streams).  Every entry point enqueues on the selected
  * one (queue 0 after trk_init); trk_stream_wait makes `waiter` wait for what has been enqueued on `signal`
  * so far; trk_sync waits for all of them.  Each queue has its own finaliser scratch, so independent work
  * can overlap -- bench.py runs statSTR's finaliser (k_locus_finalize + k_hwe_test, latency bound) on
  * queue 1 beside dumpSTR's call-filter pass (HBM bound) on queue 0.  The associaTR entry points share one
  * workspace: use them from one queue at a time.                                                        */
-#define TRK_N_STREAMS 2
+#define TRK_N_STREAMS 3
 int trk_stream_select(trk_ctx* ctx, int queue);
 int trk_stream_wait(trk_ctx* ctx, int waiter, int signal);
 
@@ -192,7 +202,12 @@ typedef struct {
     int32_t reserved;
 } trk_stats_params;
 enum {
-    TRK_STATS_COUNT_ONLY = 1  /* skip the finaliser (allele_count + first 6 ints)  */
+    TRK_STATS_COUNT_ONLY = 1, /* skip the finaliser (allele_count + first 6 ints)  */
+    TRK_STATS_TWIN = 2        /* out->allele_count is [2][G, sumA] and out->locus_int [2][G, L, TRK_LI_COLS]: the counts
+                                 are stored twice, back to back, in the one pass over the tensor.  For the caller that lets
+                                 trk_call_filters correct one copy in place (delta outputs, dumpSTR) and keeps the other
+                                 for statSTR's own rows: no device-to-device copies between the two halves of a step.
+                                 The finaliser (and locus_f64) see the first copy only.                              */
 };
 
 typedef struct {
@@ -439,6 +454,12 @@ int trk_comm_init(trk_ctx* ctx, int rank, int n_ranks, const uint8_t id[128]);
 int trk_allreduce_sum_i64(trk_ctx* ctx, int64_t* dev, size_t count);
 /* gather `bytes_per_rank` bytes from every rank into recv (rank-major).       */
 int trk_allgather(trk_ctx* ctx, const void* send_dev, void* recv_dev, size_t bytes_per_rank);
+/* The whole exchange of one dumpSTR pass as ONE grouped RCCL launch (ncclGroupStart/End): the in-place sum of
+ * `n_sums` packed int64 counters (sample_info rows, totaldp, loc_info: dumpSTR.py:1251-1268 -- the caller lays them
+ * out back to back in one buffer) and the rank-major gather of every rank's per-locus filter bits.  Either half may
+ * be empty (NULL / 0).                                                                                            */
+int trk_exchange(trk_ctx* ctx, int64_t* sums_dev, size_t n_sums, const void* send_dev, void* recv_dev,
+                 size_t bytes_per_rank);
 
 /* ---- scalar helpers (host, double) --------------------------------------- */
 /* Two-sided exact binomial test p-value == scipy.stats.binomtest(k, n, p).pvalue

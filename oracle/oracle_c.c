@@ -12,6 +12,7 @@
  * Independent of csrc/: own histogram code, own binomial pmf (lgamma based) and
  * tail summation.
  */
+#define _DEFAULT_SOURCE   /* lgamma_r */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -60,7 +61,10 @@ static double orc_binom_pmf(int64_t k, int64_t n, double p) {
     if (k < 0 || k > n) return 0.0;
     if (p <= 0.0) return k == 0 ? 1.0 : 0.0;
     if (p >= 1.0) return k == n ? 1.0 : 0.0;
-    double lg = lgamma((double)n + 1.0) - lgamma((double)k + 1.0) - lgamma((double)(n - k) + 1.0);
+    /* lgamma_r: plain lgamma() writes the global `signgam` on every call -- with the loci split over threads
+     * that one cache line bounces between all cores (measured: 256 threads slower than one) */
+    int sg;
+    double lg = lgamma_r((double)n + 1.0, &sg) - lgamma_r((double)k + 1.0, &sg) - lgamma_r((double)(n - k) + 1.0, &sg);
     return exp(lg + (double)k * log(p) + (double)(n - k) * log1p(-p));
 }
 static double orc_lower(int64_t k, int64_t n, double p) {
@@ -151,6 +155,10 @@ void orc_length_stats(const int32_t* ccl, const double* cv, int ncls, double* re
     res[1] = m; res[2] = cv[best]; res[3] = v;
 }
 
+static void orc_locus_all(const int16_t* gt, int l, int S, int P, const uint8_t* locus_ploidy, const int32_t* off,
+                          const uint16_t* lc, const uint16_t* sc, const double* cv, int32_t* cnt, int32_t* out_i,
+                          double* out_f, int32_t* ccl, int32_t* ccs);
+
 /* Whole batch, P == 2 layout [L,S,P]: statSTR statistics of every locus (one group).
  * out_i[l*8 ..]: n_called, n_low, hom_len, hom_str, n_bad, status_len, status_str, n_alleles
  * out_f[l*10..]: thresh, mean, mode, var, het_len, het_str, ent_len, ent_str, hwep_len, hwep_str */
@@ -161,7 +169,32 @@ void orc_batch_stats(const int16_t* gt, int L, int S, int P, const uint8_t* locu
     for (int l = 0; l < L; ++l) if (off[l + 1] - off[l] > maxA) maxA = off[l + 1] - off[l];
     int32_t* ccl = (int32_t*)malloc(sizeof(int32_t) * (size_t)(maxA + 1));
     int32_t* ccs = (int32_t*)malloc(sizeof(int32_t) * (size_t)(maxA + 1));
-    for (int l = 0; l < L; ++l) {
+    for (int l = 0; l < L; ++l) orc_locus_all(gt, l, S, P, locus_ploidy, off, lc, sc, cv, cnt, out_i, out_f, ccl, ccs);
+    free(ccl); free(ccs);
+}
+
+/* the same, loci split over `n_threads` host threads (OpenMP): the all-cores CPU baseline of bench.py and the
+ * checker of the full-size parity runs (every locus of a 100k x 10k call set in seconds) */
+void orc_batch_stats_mt(const int16_t* gt, int L, int S, int P, const uint8_t* locus_ploidy, const int32_t* off,
+                        const uint16_t* lc, const uint16_t* sc, const double* cv, int32_t* cnt, int32_t* out_i,
+                        double* out_f, int n_threads) {
+    int maxA = 0;
+    for (int l = 0; l < L; ++l) if (off[l + 1] - off[l] > maxA) maxA = off[l + 1] - off[l];
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel num_threads(n_threads)
+    {
+        int32_t* ccl = (int32_t*)malloc(sizeof(int32_t) * (size_t)(maxA + 1));
+        int32_t* ccs = (int32_t*)malloc(sizeof(int32_t) * (size_t)(maxA + 1));
+#pragma omp for schedule(dynamic, 8)
+        for (int l = 0; l < L; ++l) orc_locus_all(gt, l, S, P, locus_ploidy, off, lc, sc, cv, cnt, out_i, out_f, ccl, ccs);
+        free(ccl); free(ccs);
+    }
+}
+
+static void orc_locus_all(const int16_t* gt, int l, int S, int P, const uint8_t* locus_ploidy, const int32_t* off,
+                          const uint16_t* lc, const uint16_t* sc, const double* cv, int32_t* cnt, int32_t* out_i,
+                          double* out_f, int32_t* ccl, int32_t* ccs) {
+    {
         int o = off[l], A = off[l + 1] - o, pl = locus_ploidy ? locus_ploidy[l] : P;
         int32_t r[5];
         orc_locus_counts(gt + (size_t)l * S * P, S, P, pl, A, lc + o, sc + o, cnt + o, r);
@@ -180,7 +213,6 @@ void orc_batch_stats(const int16_t* gt, int L, int S, int P, const uint8_t* locu
         of[0] = ln[0]; of[1] = ln[1]; of[2] = ln[2]; of[3] = ln[3];
         of[4] = ml[0]; of[5] = ms[0]; of[6] = ml[1]; of[7] = ms[1]; of[8] = ml[2]; of[9] = ms[2];
     }
-    free(ccl); free(ccs);
 }
 
 /* dumpSTR ApplyCallFilters (dumpSTR.py:613-774) for the threshold filters min-DP / max-DP / min-Q
@@ -212,4 +244,118 @@ void orc_call_filters_dpq(const int16_t* gt, const int32_t* dp, const float* q, 
                 else if (dp[c] > 0) totaldp[s] += dp[c];
             } else if (called) { gt_out[c * 2] = -1; gt_out[c * 2 + 1] = -1; }
         }
+}
+
+/* ---- any dumpSTR call-filter set -------------------------------------------------------------------------
+ * filters.py:327-867 as (op, operands) records -- the numbering of include/trk.h's TRK_F_* so that a test can hand the
+ * same spec to both sides -- evaluated one call at a time, then dumpSTR.py:613-774 (ApplyCallFilters):
+ *   1 LT            CallFilterMinValue :363-367      value < thr (float32 planes compare in float32, as numpy does)
+ *   2 GT            CallFilterMaxValue :405-409
+ *   3 RATIO_GT      HipSTRCallFlankIndels / Stutter :444-449, :479-484   a / b in float64 > thr
+ *   4 CALLED_LT     GangSTRCallExpansionProb{Hom,Het} :597-639, min supporting reads on a pre-parsed plane
+ *   5 CALLED_SUM_LT GangSTRCallExpansionProbTotal :665-674   (a + a2 in the plane's dtype) < thr
+ *   6 CALLED_EQ     GangSTRCallSpanOnly :686-697             a == b
+ *   7 CALLED_SUM_EQ GangSTRCallSpanBoundOnly :711-722        a + a2 == b
+ *   8 OUTSIDE_CI    GangSTRCallBadCI :739-757                REPCN_j outside [lo_j, hi_j]
+ *   9 AD_SUPPORT_LT PopSTRCallRequireSupport :858-867        AD[s, gt[s, j]] < thr (numpy negative indexing)
+ * planes are interleaved [L, S, ncol] int32 (missing INT_MIN) or float32 (missing nan).
+ * mask bit k: filter k's output is not nan; bit 31: the sample is a no-call (:651).  counters [(1+nf), S]:
+ * row 0 numcalls (:686-687), row 1+k sample_info[filter k] (:661).  err[0] != 0: negative DP on a PASS call (:698-706). */
+typedef struct { int32_t op, plane_a, col_a, plane_b, col_b, col_a2; double thr; } orc_filter;
+typedef struct { const void* data; int32_t is_f32; int32_t ncol; } orc_plane;
+
+static inline int32_t pl_i(const orc_plane* p, size_t c, int col) { return ((const int32_t*)p->data)[c * (size_t)p->ncol + col]; }
+static inline float pl_f(const orc_plane* p, size_t c, int col) { return ((const float*)p->data)[c * (size_t)p->ncol + col]; }
+static inline double pl_d(const orc_plane* p, size_t c, int col) { return p->is_f32 ? (double)pl_f(p, c, col) : (double)pl_i(p, c, col); }
+
+static int orc_eval(const orc_filter* f, const orc_plane* planes, size_t c, int called, const int16_t* g, int pl) {
+    const orc_plane* a = planes + f->plane_a;
+    switch (f->op) {
+        case 4: if (!called) return 0; /* fall through */
+        case 1: return a->is_f32 ? pl_f(a, c, f->col_a) < (float)f->thr : (double)pl_i(a, c, f->col_a) < f->thr;
+        case 2: return a->is_f32 ? pl_f(a, c, f->col_a) > (float)f->thr : (double)pl_i(a, c, f->col_a) > f->thr;
+        case 3: return pl_d(a, c, f->col_a) / pl_d(planes + f->plane_b, c, f->col_b) > f->thr;
+        case 5:
+            if (!called) return 0;
+            if (a->is_f32) { volatile float s = pl_f(a, c, f->col_a) + pl_f(a, c, f->col_a2); return s < (float)f->thr; }
+            return (double)((int64_t)pl_i(a, c, f->col_a) + (int64_t)pl_i(a, c, f->col_a2)) < f->thr;
+        case 6: return called && pl_i(a, c, f->col_a) == pl_i(planes + f->plane_b, c, f->col_b);
+        case 7: return called && (int64_t)pl_i(a, c, f->col_a) + (int64_t)pl_i(a, c, f->col_a2) ==
+                                     (int64_t)pl_i(planes + f->plane_b, c, f->col_b);
+        case 8: {
+            if (!called) return 0;
+            const orc_plane* b = planes + f->plane_b;
+            for (int j = 0; j < a->ncol; ++j) {
+                int32_t ml = pl_i(a, c, j);
+                if (ml < pl_i(b, c, 2 * j) || pl_i(b, c, 2 * j + 1) < ml) return 1;
+            }
+            return 0;
+        }
+        case 9: {
+            int hit = 0;
+            for (int j = 0; j < pl; ++j) {
+                int q = g[j];
+                if (q < 0) q += a->ncol;
+                if (q < 0 || q >= a->ncol) continue;
+                hit |= (double)pl_i(a, c, q) < f->thr;
+            }
+            return hit;
+        }
+    }
+    return 0;
+}
+
+void orc_call_filters(const int16_t* gt, int L, int S, int P, const uint8_t* locus_ploidy, const orc_plane* planes,
+                      int n_planes, const orc_filter* filters, int nf, int dp_plane, int16_t* gt_out, uint32_t* mask,
+                      int64_t* counters, int64_t* totaldp, int64_t* dpmiss, int32_t* err, int n_threads) {
+    (void)n_planes;
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel num_threads(n_threads)
+    {
+        int64_t* cn = (int64_t*)calloc((size_t)(nf + 3) * (size_t)S, sizeof(int64_t));  /* thread-private, summed below */
+        int64_t* td = cn + (size_t)(nf + 1) * S;
+        int64_t* dm = td + S;
+#pragma omp for schedule(dynamic, 8)
+        for (int l = 0; l < L; ++l) {
+            const int pl = locus_ploidy ? (locus_ploidy[l] < P ? locus_ploidy[l] : P) : P;
+            for (int s = 0; s < S; ++s) {
+                const size_t c = (size_t)l * S + s;
+                const int16_t* g = gt + c * P;
+                int called = 1;
+                for (int j = 0; j < pl; ++j) called &= g[j] != -1;
+                uint32_t m = 0;
+                for (int k = 0; k < nf; ++k)
+                    if (orc_eval(filters + k, planes, c, called, g, pl)) {
+                        m |= 1u << k;
+                        if (called) cn[(size_t)(1 + k) * S + s]++;
+                    }
+                if (!called) m |= 0x80000000u;
+                if (mask) mask[c] = m;
+                int filtered = 0;
+                if (m == 0) {
+                    cn[s]++;
+                    if (dp_plane >= 0) {
+                        const orc_plane* d = planes + dp_plane;
+                        if (d->is_f32) {   /* Float depth (ExpansionHunter LC): not summed here */
+                        } else {
+                            int32_t v = pl_i(d, c, 0);
+                            if (v == INT32_MIN) dm[s]++;
+                            else if (v < 0) { if (err) err[0] = 1; }
+                            else td[s] += v;
+                        }
+                    }
+                } else if (called) filtered = 1;
+                if (gt_out) {
+                    int16_t* o = gt_out + c * P;
+                    for (int j = 0; j < P; ++j) o[j] = (filtered && j < pl) ? (int16_t)-1 : g[j];
+                }
+            }
+        }
+#pragma omp critical
+        {
+            for (size_t i = 0; i < (size_t)(nf + 1) * S; ++i) counters[i] += cn[i];
+            for (int s = 0; s < S; ++s) { totaldp[s] += td[s]; dpmiss[s] += dm[s]; }
+        }
+        free(cn);
+    }
 }

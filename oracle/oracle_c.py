@@ -25,7 +25,20 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def batch_stats(gt, locus_ploidy, off, lc, sc, cv):
+class _Plane(C.Structure):
+    _fields_ = [('data', C.c_void_p), ('is_f32', C.c_int32), ('ncol', C.c_int32)]
+
+
+class _Filter(C.Structure):
+    _fields_ = [('op', C.c_int32), ('plane_a', C.c_int32), ('col_a', C.c_int32), ('plane_b', C.c_int32),
+                ('col_b', C.c_int32), ('col_a2', C.c_int32), ('thr', C.c_double)]
+
+
+def n_cores():
+    return max(1, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
+
+
+def batch_stats(gt, locus_ploidy, off, lc, sc, cv, n_threads=1):
     lib = load()
     gt = np.ascontiguousarray(gt, dtype=np.int16)
     Lc, S, P = gt.shape
@@ -37,9 +50,46 @@ def batch_stats(gt, locus_ploidy, off, lc, sc, cv):
     cnt = np.zeros(int(off[-1]), dtype=np.int32)
     oi = np.zeros((Lc, 8), dtype=np.int32)
     of = np.zeros((Lc, 10), dtype=np.float64)
-    lib.orc_batch_stats(_p(gt), Lc, S, P, None if lp is None else _p(lp), _p(off), _p(lc), _p(sc), _p(cv),
-                        _p(cnt), _p(oi), _p(of))
+    if n_threads > 1:
+        lib.orc_batch_stats_mt(_p(gt), Lc, S, P, None if lp is None else _p(lp), _p(off), _p(lc), _p(sc), _p(cv),
+                               _p(cnt), _p(oi), _p(of), int(n_threads))
+    else:
+        lib.orc_batch_stats(_p(gt), Lc, S, P, None if lp is None else _p(lp), _p(off), _p(lc), _p(sc), _p(cv),
+                            _p(cnt), _p(oi), _p(of))
     return cnt, oi, of
+
+
+def call_filters(gt, planes, filters, dp_plane=-1, locus_ploidy=None, n_threads=1, want_gt=True, want_mask=True):
+    """orc_call_filters: ``planes`` interleaved [L, S] / [L, S, k] int32 or float32 arrays, ``filters`` dicts with the
+    keys of Engine.call_filters (op numbered as TRK_F_*).  Returns (gt_out | None, mask | None, counters [(1+nf), S],
+    totaldp [S], dpmiss [S], err [4])."""
+    lib = load()
+    gt = np.ascontiguousarray(gt, dtype=np.int16)
+    Lc, S, P = gt.shape
+    keep = []
+    parr = (_Plane * max(len(planes), 1))()
+    for i, pl in enumerate(planes):
+        pl = np.ascontiguousarray(pl)
+        if pl.dtype not in (np.int32, np.float32):
+            raise ValueError("plane dtype %s" % pl.dtype)
+        keep.append(pl)
+        parr[i] = _Plane(pl.ctypes.data, 1 if pl.dtype == np.float32 else 0, 1 if pl.ndim == 2 else pl.shape[2])
+    nf = len(filters)
+    farr = (_Filter * max(nf, 1))()
+    for k, f in enumerate(filters):
+        farr[k] = _Filter(int(f['op']), int(f['plane_a']), int(f.get('col_a', 0)), int(f.get('plane_b', -1)),
+                          int(f.get('col_b', 0)), int(f.get('col_a2', 0)), float(f.get('thr', 0.0)))
+    lp = None if locus_ploidy is None else np.ascontiguousarray(locus_ploidy, dtype=np.uint8)
+    gout = np.empty_like(gt) if want_gt else None
+    mask = np.zeros((Lc, S), dtype=np.uint32) if want_mask else None
+    counters = np.zeros((1 + nf, S), dtype=np.int64)
+    totaldp = np.zeros(S, dtype=np.int64)
+    dpmiss = np.zeros(S, dtype=np.int64)
+    err = np.zeros(4, dtype=np.int32)
+    lib.orc_call_filters(_p(gt), Lc, S, P, None if lp is None else _p(lp), parr, len(planes), farr, nf, int(dp_plane),
+                         None if gout is None else _p(gout), None if mask is None else _p(mask), _p(counters),
+                         _p(totaldp), _p(dpmiss), _p(err), int(n_threads))
+    return gout, mask, counters, totaldp, dpmiss, err
 
 
 def call_filters_dpq(gt, dp, q, min_dp, max_dp, min_q):

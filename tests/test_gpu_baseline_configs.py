@@ -138,6 +138,18 @@ def test_config2_dumpstr_gangstr_50k_x_5k(eng):
     for col in (L.LI_N_CALLED, L.LI_N_LOWPLOIDY, L.LI_N_HOM_LEN, L.LI_N_HOM_STR):
         assert np.array_equal(st0.locus_int.get()[0][:, col], li[:, col])
     del pl_planes, res_p, st0
+    # ---- EVERY locus against the compiled oracle's generic call-filter interpreter (pinned to the numpy oracle by
+    # tests/test_fullsize_checker.py): masks / masked genotypes bit for bit on the first 10k+ loci, statistics,
+    # locus filter decisions, sample_info and loc_info over all 50k ----
+    from oracle import fullsize
+    dev = dict(cnt_a=None, cnt_b=cnt, li_b=li, lf_b=lf, bits=bits_h, sample_counters=cnts,
+               totaldp=res.sample_totaldp.get(), dpmiss=res.sample_dp_missing.get(), loc_counters=lc)
+    r = fullsize.check_step(lambda lo, hi: (sb.dev['gt'].get_rows(lo, hi), [p.get_rows(lo, hi) for p in planes]),
+                            lambda lo, hi: (res.gt_out.get_rows(lo, hi), res.filter_mask.get_rows(lo, hi)),
+                            Lc, S, sb.tables, filters, 0,
+                            dict(min_callrate=0.8, min_hwep=1e-3, min_het=0.05, max_het=0.9, use_length=False), dev,
+                            block=2048)
+    assert r['loci'] == Lc and r['calls_bit_for_bit'] >= 10000 * S and r['worst_float_rel'] <= 1e-9
     # ---- sampled loci against the numpy oracle ----
     idx = np.sort(np.random.default_rng(1).choice(Lc, size=24, replace=False))
     h = sb.host_rows(idx)
@@ -272,17 +284,14 @@ def test_config3_combined_100k_x_10k_two_queue_pipeline(eng):
     """configs[3] exactly as bench.py runs it (statSTR + dumpSTR on 100k x 10k, finalisers and locus filters on the
     second queue, the dumpSTR tail one step behind): three pipelined steps give the same outputs as one step with
     everything in order on queue 0, and the oracle spot checks hold."""
-    import argparse
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
-    args = argparse.Namespace(loci=100000, samples=10000, seed=20260928 + 3)
-    os.environ['TRK_BENCH_OVERLAP'] = '0'
-    try:
-        ref = bench.Workload(eng, args, 0, 1)
-    finally:
-        del os.environ['TRK_BENCH_OVERLAP']
+    from trtools_amd.synth import make_loci
+    seed, S = 20260928 + 3, 10000
+    loci = make_loci(100000, S, seed)
+    ref = bench.Workload(eng, seed, S, loci, 0, 1, use_comm=False, overlap=False)
     ref.step()
     ref.flush()
     eng.sync()
@@ -294,7 +303,7 @@ def test_config3_combined_100k_x_10k_two_queue_pipeline(eng):
     for arr in list(eng._live):
         if arr.nbytes > (1 << 28) and arr not in ref.sb.dev.values():
             arr.free()
-    wl = bench.Workload(eng, args, 0, 1)
+    wl = bench.Workload(eng, seed, S, loci, 0, 1, use_comm=False)
     assert wl.overlap
     for _ in range(3):
         wl.step()
@@ -309,4 +318,50 @@ def test_config3_combined_100k_x_10k_two_queue_pipeline(eng):
     assert np.array_equal(wl.stats_b[i].locus_int.get(), want['li_b'])
     assert np.array_equal(wl.stats_b[i].locus_f64.get(), want['lf_b'], equal_nan=True)
     assert np.array_equal(wl.call_out.filter_mask.get_rows(0, 32), want['mask_head'])
-    assert bench.parity_spot_check(wl, n_check=8) == 8
+    # EVERY locus of the 100k x 10k call set against the compiled oracle (statistics before and after masking, locus
+    # filter decisions, sample_info, loc_info; masks and masked genotypes bit for bit on the first 10 000+ loci)
+    r = bench.exhaustive_check(wl, single_rank_sums=True)
+    assert r['loci'] == 100000 and r['calls_bit_for_bit'] >= 10000 * S and r['worst_float_rel'] <= 1e-9
+
+
+def test_config3_locus_shards_add_up_to_the_cohort(eng):
+    """BASELINE configs[3] as the multi-GPU run cuts it: contiguous locus shards of ONE cohort (dist.locus_shard).  Two
+    shards run one after the other on this GPU give, put together, exactly what the unsharded run gives: per-locus
+    rows concatenate in rank order, sample_info / loc_info add up (the sums RCCL forms over xGMI)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from trtools_amd.dist import locus_shard
+    from trtools_amd.synth import make_loci
+    seed, S, Lc = 20260928 + 3, 2000, 9001
+    loci = make_loci(Lc, S, seed)
+    eng.comm_init(0, 1, eng.comm_unique_id())      # 1-rank RCCL communicator: the exchange kernels really launch
+
+    def run(lo, hi, world):
+        wl = bench.Workload(eng, seed, S, loci.slice(lo, hi), lo, 1, use_comm=True, gather_loci=-(-Lc // world))
+        for _ in range(2):
+            wl.step()
+        wl.flush()
+        eng.sync()
+        i = (wl.step_no - 1) & 1
+        out = dict(bits=wl.bits.get()[:hi - lo], gathered=wl.gather.get()[0][:hi - lo], loc=wl.loc_counters.get(),
+                   cnt=wl.call_out.sample_counters.get(), td=wl.call_out.sample_totaldp.get(),
+                   li_a=wl.stats_a[i].locus_int.get()[0], lf_a=wl.stats_a[i].locus_f64.get()[0],
+                   li_b=wl.stats_b[i].locus_int.get()[0], lf_b=wl.stats_b[i].locus_f64.get()[0],
+                   cnt_b=wl.stats_b[i].allele_count.get()[0])
+        r = bench.exhaustive_check(wl, single_rank_sums=True)
+        assert r['loci'] == hi - lo
+        wl.free()
+        return out
+
+    whole = run(0, Lc, 1)
+    assert np.array_equal(whole['bits'], whole['gathered'])
+    for world in (2, 3):
+        parts = [run(*locus_shard(Lc, r, world), world) for r in range(world)]
+        for key in ('bits', 'li_a', 'li_b', 'cnt_b'):
+            assert np.array_equal(np.concatenate([p[key] for p in parts]), whole[key]), (world, key)
+        for key in ('lf_a', 'lf_b'):
+            assert np.array_equal(np.concatenate([p[key] for p in parts]), whole[key], equal_nan=True), (world, key)
+        for key in ('loc', 'cnt', 'td'):
+            assert np.array_equal(sum(p[key] for p in parts), whole[key]), (world, key)

@@ -259,6 +259,62 @@ def test_sentinel_mixes_on_the_streaming_kernel(eng):
     check_against_oracle(orc, L, cnt, li, lf, off, gt, lens, strs, [None], 0.02)
 
 
+@pytest.mark.parametrize("S", [4, 60, 64, 68, 252, 1000, 2048, 4096, 5000])
+def test_loci_per_wave_variants_agree(eng, S):
+    """k_locus_count_v2 (one locus per wave) vs k_locus_count_v3<2> / <4> (two / four loci side by side in a wave,
+    the short-row kernel): identical counts and row predicates on rows with every sentinel mix, duplicate classes,
+    a locus count that leaves the last wave partly empty, and allele counts that differ inside a wave; the
+    one-locus-per-wave result is checked against the oracle."""
+    import os
+    from oracle import trtools_oracle as orc
+    from trtools_amd import _lib as L
+    rng = np.random.default_rng(100 + S)
+    n_loci = 23
+    gt, lens, strs, _, (off, lc, sc, cv) = _random_batch(rng, n_loci, S, 2, 14)
+    for l in range(n_loci):
+        r = rng.random(S)
+        gt[l][r < 0.05, 1] = -2
+        gt[l][(r >= 0.05) & (r < 0.08)] = (-1, -2)
+        gt[l][(r >= 0.08) & (r < 0.10)] = (-2, -1)
+        gt[l][(r >= 0.10) & (r < 0.12)] = -2
+        gt[l][(r >= 0.12) & (r < 0.16)] = -1
+        gt[l][(r >= 0.16) & (r < 0.19), 1] = -1
+    gt[3] = -1
+    gt[4] = -2
+    b = eng.make_batch(gt, off, lc, sc, cv)
+    got = {}
+    for rr in ('1', '2', '4'):
+        os.environ['TRK_CNT_R'] = rr
+        try:
+            got[rr] = _fetch(eng.locus_stats(b, nalleles_thresh=0.02))
+        finally:
+            del os.environ['TRK_CNT_R']
+    check_against_oracle(orc, L, *got['1'], off, gt, lens, strs, [None], 0.02)
+    for rr in ('2', '4'):
+        assert np.array_equal(got[rr][0], got['1'][0]), rr
+        assert np.array_equal(got[rr][1], got['1'][1]), rr
+        assert np.array_equal(got[rr][2], got['1'][2], equal_nan=True), rr
+
+
+@pytest.mark.parametrize("S,ploidy,groups", [(1000, 2, 0), (8000, 2, 0), (1003, 2, 0), (512, 3, 0), (1000, 2, 2)])
+def test_twin_count_outputs(eng, S, ploidy, groups):
+    """TRK_STATS_TWIN: the second copy of allele_count / locus_int equals the first on the streaming kernels (which
+    store it in the same pass) and on the general paths (copied after the kernel)."""
+    rng = np.random.default_rng(S + ploidy)
+    gt, lens, strs, _, (off, lc, sc, cv) = _random_batch(rng, 37, S, ploidy, 9)
+    gb = None
+    if groups:
+        gb = rng.integers(0, 1 << groups, size=S).astype(np.uint8)
+    b = eng.make_batch(gt, off, lc, sc, cv, group_bits=gb, n_groups=max(groups, 1))
+    plain = eng.locus_stats(b, count_only=True)
+    out = eng.alloc_stats(b, twin=True)
+    eng.locus_stats(b, out=out, count_only=True)
+    for res in (out, out.twin):
+        assert np.array_equal(res.allele_count.get(), plain.allele_count.get())
+        assert np.array_equal(res.locus_int.get()[..., :6], plain.locus_int.get()[..., :6])
+        assert np.array_equal(res.locus_int.get()[..., 8], plain.locus_int.get()[..., 8])
+
+
 def test_two_queues_give_the_same_statistics(eng):
     """trk_stream_select / trk_stream_wait: the finaliser on queue 1 beside a call-filter pass on queue 0 (what
     bench.py overlaps) returns what the single-queue sequence returns."""

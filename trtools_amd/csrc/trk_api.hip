@@ -29,6 +29,8 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 static RcclApi g_rccl;
@@ -54,6 +56,8 @@ static bool load_rccl(std::string& err) {
     a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
     a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+    a.GroupStart = (decltype(a.GroupStart))dlsym(h, "ncclGroupStart");
+    a.GroupEnd = (decltype(a.GroupEnd))dlsym(h, "ncclGroupEnd");
     if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.AllGather) {
         err = "librccl is missing required symbols";
         return false;
@@ -287,6 +291,39 @@ int trk_sync(trk_ctx* ctx) {
     for (int i = 0; i < TRK_N_STREAMS; ++i) HIPCHK(ctx, hipStreamSynchronize(ctx->streams[i]));
     return TRK_OK;
 }
+int trk_host_alloc(trk_ctx* ctx, size_t bytes, void** hptr) {
+    if (!ctx || !hptr) return TRK_ERR_ARG;
+    *hptr = nullptr;
+    if (bytes == 0) bytes = 16;
+    (void)hipSetDevice(ctx->device);
+    hipError_t e = hipHostMalloc(hptr, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(ctx, TRK_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return TRK_OK;
+}
+int trk_host_free(trk_ctx* ctx, void* hptr) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (!hptr) return TRK_OK;
+    HIPCHK(ctx, hipHostFree(hptr));
+    return TRK_OK;
+}
+int trk_memcpy_h2d_async(trk_ctx* ctx, void* d, const void* h, size_t n) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (n == 0) return TRK_OK;
+    HIPCHK(ctx, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, ctx->s()));
+    return TRK_OK;
+}
+int trk_memcpy_d2h_async(trk_ctx* ctx, void* h, const void* d, size_t n) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (n == 0) return TRK_OK;
+    HIPCHK(ctx, hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, ctx->s()));
+    return TRK_OK;
+}
+int trk_queue_sync(trk_ctx* ctx, int queue) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (queue < 0 || queue >= TRK_N_STREAMS) return fail(ctx, TRK_ERR_ARG, "queue %d outside [0, %d)", queue, TRK_N_STREAMS);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->streams[queue]));
+    return TRK_OK;
+}
 int trk_stream_select(trk_ctx* ctx, int queue) {
     if (!ctx) return TRK_ERR_ARG;
     if (queue < 0 || queue >= TRK_N_STREAMS) return fail(ctx, TRK_ERR_ARG, "queue %d outside [0, %d)", queue, TRK_N_STREAMS);
@@ -373,13 +410,10 @@ int trk_locus_stats(trk_ctx* ctx, const trk_batch* in, const trk_stats_params* p
     (void)hipSetDevice(ctx->device);
     const int G = in->group_bits ? in->n_groups : 1;
     const int64_t sumA = in->n_alleles_total;
-    HIPCHK(ctx, hipMemsetAsync(out->allele_count, 0, (size_t)G * sumA * sizeof(int32_t), ctx->s()));
-    HIPCHK(ctx, hipMemsetAsync(out->locus_int, 0, (size_t)G * in->n_loci * TRK_LI_COLS * sizeof(int32_t),
-                               ctx->s()));
     {
         ProfScope ps(ctx, TRK_K_LOCUS_COUNT);
         HIPCHK(ctx, trk::launch_locus_count(*in, in->max_alleles, out->allele_count, out->locus_int,
-                                            ctx->n_cu, ctx->s()));
+                                            ctx->n_cu, ctx->s(), prm && (prm->flags & TRK_STATS_TWIN)));
     }
     if (count_only) return TRK_OK;
     rc = ensure_fin_buffers(ctx, G, sumA, in->n_loci);
@@ -564,6 +598,28 @@ int trk_allgather(trk_ctx* ctx, const void* send, void* recv, size_t bytes_per_r
     if (!ctx->comm) return fail(ctx, TRK_ERR_RCCL, "communicator not initialised");
     ncclResult_t r = g_rccl.AllGather(send, recv, bytes_per_rank, trkNcclUint8, ctx->comm, ctx->s());
     if (r != 0) return fail(ctx, TRK_ERR_RCCL, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    return TRK_OK;
+}
+
+int trk_exchange(trk_ctx* ctx, int64_t* sums, size_t n_sums, const void* send, void* recv, size_t bytes_per_rank) {
+    if (!ctx) return TRK_ERR_ARG;
+    const bool do_sum = sums && n_sums > 0, do_gather = send && recv && bytes_per_rank > 0;
+    if (ctx->n_ranks <= 1 && !ctx->comm) {
+        if (do_gather && send != recv)
+            HIPCHK(ctx, hipMemcpyAsync(recv, send, bytes_per_rank, hipMemcpyDeviceToDevice, ctx->s()));
+        return TRK_OK;
+    }
+    if (!ctx->comm) return fail(ctx, TRK_ERR_RCCL, "communicator not initialised");
+    const bool group = do_sum && do_gather && g_rccl.GroupStart && g_rccl.GroupEnd;
+    ncclResult_t r = 0;
+    if (group) r = g_rccl.GroupStart();
+    if (r == 0 && do_sum) r = g_rccl.AllReduce(sums, sums, n_sums, trkNcclInt64, trkNcclSum, ctx->comm, ctx->s());
+    if (r == 0 && do_gather) r = g_rccl.AllGather(send, recv, bytes_per_rank, trkNcclUint8, ctx->comm, ctx->s());
+    if (group) {
+        const ncclResult_t r2 = g_rccl.GroupEnd();
+        if (r == 0) r = r2;
+    }
+    if (r != 0) return fail(ctx, TRK_ERR_RCCL, "trk_exchange: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     return TRK_OK;
 }
 

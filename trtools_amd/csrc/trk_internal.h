@@ -10,7 +10,7 @@
 
 namespace trk {
 hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* allele_count, int32_t* locus_int,
-                              int n_cu, hipStream_t stream);
+                              int n_cu, hipStream_t stream, bool twin);
 hipError_t launch_locus_finalize(const trk_batch& b, const int32_t* allele_count, int32_t* locus_int,
                                  double* locus_f64, int32_t* scratch, void* worklist, double nalleles_thresh,
                                  hipStream_t stream);

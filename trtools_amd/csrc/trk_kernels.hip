@@ -417,6 +417,45 @@ __device__ __forceinline__ void fast_row(const u32x4* __restrict__ row, int nchu
 // ---------------------------------------------------------------------------
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
+// Row streamer of the count kernels: U 16-byte chunks per lane in flight, the NEXT U already requested while the
+// current ones are histogrammed (two register sets), and the first set requested by the caller at the very top of
+// the kernel -- before the class LUT is built and the histogram zeroed -- so that the row's first bytes travel
+// while the wave does its per-locus bookkeeping.  (Without this a wave alternates between waiting for its loads
+// and issuing ALU/LDS work; on 1000-sample rows the whole row is 4 chunks per lane and the wait is most of the
+// wave's life.)  Chunk indices past the row are clamped for the load and skipped by the consumer.
+template <int LPL, int U>
+__device__ __forceinline__ void row_fetch(const u32x4* __restrict__ row, int base, int sl, int last, u32x4 (&v)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int c = base + sl + u * LPL;
+        v[u] = __builtin_nontemporal_load(&row[c < last ? c : last]);
+    }
+}
+template <int LPL, int U, typename Cell>
+__device__ __forceinline__ void row_stream(const u32x4* __restrict__ row, int nchunks, int sl, u32x4 (&cur)[U],
+                                           Cell&& cell) {
+    const int last = nchunks > 0 ? nchunks - 1 : 0;
+    for (int base = 0; base < nchunks; base += U * LPL) {
+        u32x4 nxt[U];
+        const bool more = base + U * LPL < nchunks;          // uniform over the wave
+        if (more) row_fetch<LPL, U>(row, base + U * LPL, sl, last, nxt);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (base + sl + u * LPL < nchunks) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t w = cur[u][j];
+                    cell(w);
+                }
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        }
+    }
+}
+
 template <bool DUP>
 __device__ __forceinline__ void v2_cell(uint32_t w, uint32_t amax2, uint32_t* hist, const uint32_t* lut,
                                         int kshift, int kslot, int combo_bin0, int& n_eq, int& n_hl, int& n_hs) {
@@ -436,39 +475,22 @@ __device__ __forceinline__ void v2_cell(uint32_t w, uint32_t amax2, uint32_t* hi
     }
 }
 
-template <bool DUP, int U>
-__device__ __forceinline__ void v2_row(const u32x4* __restrict__ row, int nchunks, int lane, uint32_t amax2,
-                                       uint32_t* hist, const uint32_t* lut, int kshift, int kslot, int combo_bin0,
-                                       int& n_eq, int& n_hl, int& n_hs) {
-    int c = lane;
-    for (; c + (U - 1) * WAVE < nchunks; c += U * WAVE) {
-        u32x4 v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(&row[c + u * WAVE]);
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                v2_cell<DUP>(v[u][j], amax2, hist, lut, kshift, kslot, combo_bin0, n_eq, n_hl, n_hs);
-    }
-    for (; c < nchunks; c += WAVE) {
-        u32x4 v = __builtin_nontemporal_load(&row[c]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v2_cell<DUP>(v[j], amax2, hist, lut, kshift, kslot, combo_bin0, n_eq, n_hl, n_hs);
-    }
-}
-
 // bins: 0 '-2', 1 '-1', 2..A+1 alleles, A+2 out of range, A+3.. A+6 sentinel pairs (lo + 2*hi)
+// twin_delta != 0 (TRK_STATS_TWIN): every count is stored a second time, twin_ac / twin_li elements further on
 template <int U>
 __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v2(
     trk_batch b, int32_t* __restrict__ allele_count, int32_t* __restrict__ locus_int, int kshift,
-    int wave_lds_words) {
+    int wave_lds_words, int64_t twin_ac, int64_t twin_li) {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wid = threadIdx.x >> 6;
     const int l = blockIdx.x * COUNT_WAVES_PER_WG + wid;
     if (l >= b.n_loci) return;  // waves are independent: no workgroup barrier anywhere
     const int S = b.n_samples;
+    const u32x4* row = reinterpret_cast<const u32x4*>(b.gt) + (((int64_t)l * S) >> 2);
+    const int nchunks = S >> 2;
+    u32x4 cur[U];
+    row_fetch<WAVE, U>(row, 0, lane, nchunks - 1, cur);   // the row's first chunks travel during the prologue
     const int off = b.allele_off[l];
     const int A = b.allele_off[l + 1] - off;
     const int K = 1 << kshift;
@@ -495,13 +517,15 @@ __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v2(
     wave_lds_fence();
 
     int n_eq = 0, n_hl = 0, n_hs = 0;
-    const u32x4* row = reinterpret_cast<const u32x4*>(b.gt) + (((int64_t)l * S) >> 2);
-    const int nchunks = S >> 2;
     const uint32_t amax2 = (uint32_t)(A + 2) * 0x00010001u;
     if (dup)
-        v2_row<true, U>(row, nchunks, lane, amax2, hist, lut, kshift, kslot, A + 3, n_eq, n_hl, n_hs);
+        row_stream<WAVE, U>(row, nchunks, lane, cur, [&](uint32_t w) {
+            v2_cell<true>(w, amax2, hist, lut, kshift, kslot, A + 3, n_eq, n_hl, n_hs);
+        });
     else
-        v2_row<false, U>(row, nchunks, lane, amax2, hist, lut, kshift, kslot, A + 3, n_eq, n_hl, n_hs);
+        row_stream<WAVE, U>(row, nchunks, lane, cur, [&](uint32_t w) {
+            v2_cell<false>(w, amax2, hist, lut, kshift, kslot, A + 3, n_eq, n_hl, n_hs);
+        });
     wave_lds_fence();
     // fold the K copies of every bin (rotated start: conflict-free), keep the totals of the
     // special bins in registers of the lanes that own them
@@ -509,7 +533,10 @@ __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v2(
     for (int bin = lane; bin < nbins; bin += WAVE) {
         uint32_t s = 0;
         for (int k = 0; k < K; ++k) s += hist[(bin << kshift) + ((k + lane) & (K - 1))];
-        if (bin >= 2 && bin < A + 2) allele_count[off + bin - 2] = (int32_t)s;
+        if (bin >= 2 && bin < A + 2) {
+            allele_count[off + bin - 2] = (int32_t)s;
+            if (twin_ac) allele_count[twin_ac + off + bin - 2] = (int32_t)s;
+        }
         // stash special totals in LDS words that are no longer needed (copy 0 of the bin)
         hist[bin << kshift] = s;
     }
@@ -530,13 +557,167 @@ __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v2(
         const int miss_rows = h_m1 - c11;
         const int low_rows = h_m2 - c00 - c10 - c01;
         const int hom_idx = n_eq - c11 - c00;
-        int32_t* li0 = locus_int + (int64_t)l * TRK_LI_COLS;
-        li0[TRK_LI_N_CALLED] = S - miss_rows;
-        li0[TRK_LI_N_LOWPLOIDY] = low_rows;
-        li0[TRK_LI_N_HOM_LEN] = dup ? n_hl - c11 - c00 : hom_idx;
-        li0[TRK_LI_N_HOM_STR] = dup ? n_hs - c11 - c00 : hom_idx;
-        li0[TRK_LI_N_BAD] = n_bad;
-        li0[TRK_LI_N_SAMPLES] = S - b.n_pad_samples;
+        // the whole 48-byte row (the finaliser's columns zeroed): three 16-byte stores, no memset before the launch
+        static_assert(TRK_LI_COLS == 12 && TRK_LI_N_CALLED == 0 && TRK_LI_N_HOM_STR == 3 && TRK_LI_N_BAD == 5 &&
+                      TRK_LI_N_SAMPLES == 8, "row layout");
+        const u32x4 r0 = {(uint32_t)(S - miss_rows), (uint32_t)low_rows, (uint32_t)(dup ? n_hl - c11 - c00 : hom_idx),
+                          (uint32_t)(dup ? n_hs - c11 - c00 : hom_idx)};
+        const u32x4 r1 = {0u, (uint32_t)n_bad, 0u, 0u};
+        const u32x4 r2 = {(uint32_t)(S - b.n_pad_samples), 0u, 0u, 0u};
+        for (int64_t tw = 0;; tw = twin_li) {
+            u32x4* li0 = reinterpret_cast<u32x4*>(locus_int + tw + (int64_t)l * TRK_LI_COLS);
+            li0[0] = r0;
+            li0[1] = r1;
+            li0[2] = r2;
+            if (tw == twin_li) break;
+        }
+    }
+    wave_lds_fence();
+}
+
+// ---------------------------------------------------------------------------
+// k_locus_count_v3<R> : k_locus_count_v2 for SHORT rows -- R = 2 or 4 loci per wavefront, 64 / R lanes each.
+// A 1000-sample row is 250 16-byte chunks: four loads per lane of a whole wave, against ~500 instructions of
+// per-locus work that do not depend on the row length (class LUT, histogram zeroing and fold, reductions, the
+// result row).  The v2 kernel is instruction-issue bound there (400k x 1k: 2.9 TB/s, 0.36 of the HBM peak;
+// 100k x 10k: 5.8 TB/s).  With R loci side by side in one wave every one of those instructions serves R loci.
+// Histogram rows stay bank-conflict free without more LDS per locus: a bin is one 32-word row, lane i adds at
+// column i mod 32 -- with R = 2 each 32-lane group (= one locus) has its own rows, with R = 4 the two loci of a
+// 32-lane group share rows and own 16 columns each (a ds_add_u32 is served in lane groups {0-31}, {32-63}).
+// bins as in v2: 0 '-2', 1 '-1', 2..A+1 alleles, A+2 out of range, A+3..A+6 sentinel pairs.
+// ---------------------------------------------------------------------------
+template <int LPL>
+__device__ __forceinline__ int seg_sum(int v) {
+#pragma unroll
+    for (int o = LPL / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+template <int LPL>
+__device__ __forceinline__ int seg_max(int v) {
+#pragma unroll
+    for (int o = LPL / 2; o > 0; o >>= 1) {
+        const int t = __shfl_xor(v, o, WAVE);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+template <bool DUP>
+__device__ __forceinline__ void v3_cell(uint32_t w, uint32_t amax2, uint32_t* hcol, const uint32_t* lut,
+                                        int combo_bin0, int& n_eq, int& n_hl, int& n_hs) {
+    u16x2 u = __builtin_bit_cast(u16x2, w) + (u16x2){2, 2};
+    u16x2 t2 = __builtin_elementwise_min(u, __builtin_bit_cast(u16x2, amax2));
+    const uint32_t t = __builtin_bit_cast(uint32_t, t2);
+    const uint32_t lo = t & 0xffffu, hi = t >> 16;
+    atomicAdd(&hcol[lo << 5], 1u);
+    atomicAdd(&hcol[hi << 5], 1u);
+    n_eq += lo == hi;
+    if ((t & 0xfffefffeu) == 0u) atomicAdd(&hcol[(combo_bin0 + (int)(lo + 2u * hi)) << 5], 1u);
+    if (DUP) {
+        const uint32_t x = lut[lo] ^ lut[hi];
+        n_hl += (x & 0xffffu) == 0u;
+        n_hs += (x >> 16) == 0u;
+    }
+}
+
+template <int R, int U>
+__global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v3(
+    trk_batch b, int32_t* __restrict__ allele_count, int32_t* __restrict__ locus_int, int nbmax,
+    int wave_lds_words, int64_t twin_ac, int64_t twin_li) {
+    static_assert(R == 2 || R == 4, "loci per wave");
+    constexpr int LPL = WAVE / R;                 // lanes per locus
+    constexpr int KC = R == 4 ? 16 : 32;          // histogram columns of one locus
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wid = threadIdx.x >> 6;
+    const int sub = lane / LPL, sl = lane % LPL;
+    const int l_raw = (blockIdx.x * COUNT_WAVES_PER_WG + wid) * R + sub;
+    if ((blockIdx.x * COUNT_WAVES_PER_WG + wid) * R >= b.n_loci) return;   // whole wave beyond the batch
+    const bool live = l_raw < b.n_loci;
+    const int l = live ? l_raw : b.n_loci - 1;
+    const int S = b.n_samples;
+    const u32x4* row = reinterpret_cast<const u32x4*>(b.gt) + (((int64_t)l * S) >> 2);
+    const int nchunks = live ? (S >> 2) : 0;
+    u32x4 cur[U];
+    row_fetch<LPL, U>(row, 0, sl, (S >> 2) - 1, cur);     // the row's first chunks travel during the prologue
+    const int off = b.allele_off[l];
+    const int A = b.allele_off[l + 1] - off;
+    const int nbins = A + 7;
+    uint32_t* wbase = lds + (size_t)wid * wave_lds_words;
+    const int cbase = R == 4 ? (sub & 1) * 16 : 0;
+    uint32_t* hrow = wbase + (size_t)(lane >> 5) * nbmax * 32;            // this 32-lane group's rows
+    uint32_t* hcol = hrow + (lane & 31);
+    uint32_t* lut = wbase + (size_t)2 * nbmax * 32 + (size_t)sub * nbmax;  // indexed by BIN
+    int ml = 0, ms = 0;
+    for (int a = sl; a < A; a += LPL) {
+        const int lc = b.len_class[off + a], sc = b.str_class[off + a];
+        lut[a + 2] = (uint32_t)lc | ((uint32_t)sc << 16);
+        ml = lc > ml ? lc : ml;
+        ms = sc > ms ? sc : ms;
+    }
+    if (sl == 0) {  // sentinel bins: classes no allele has, distinct from each other
+        lut[0] = 0xffffffffu;
+        lut[1] = 0xfffefffeu;
+        lut[A + 2] = 0xfffdfffdu;
+    }
+    ml = seg_max<LPL>(ml);
+    ms = seg_max<LPL>(ms);
+    const bool dup = (ml + 1 < A) | (ms + 1 < A);
+    const bool any_dup = __ballot(dup) != 0ull;
+    for (int i = lane; i < 2 * nbmax * 32; i += WAVE) wbase[i] = 0;
+    wave_lds_fence();
+
+    int n_eq = 0, n_hl = 0, n_hs = 0;
+    const uint32_t amax2 = (uint32_t)(A + 2) * 0x00010001u;
+    // (every locus of the batch has S samples: the loop count is uniform over the wave; a wave's dead tail loci
+    // -- nchunks == 0 -- only skip the consumer)
+    if (any_dup)
+        row_stream<LPL, U>(row, S >> 2, sl, cur, [&](uint32_t w) {
+            if (nchunks) v3_cell<true>(w, amax2, hcol, lut, A + 3, n_eq, n_hl, n_hs);
+        });
+    else
+        row_stream<LPL, U>(row, S >> 2, sl, cur, [&](uint32_t w) {
+            if (nchunks) v3_cell<false>(w, amax2, hcol, lut, A + 3, n_eq, n_hl, n_hs);
+        });
+    wave_lds_fence();
+    // fold this locus's KC columns of every bin (rotated start: conflict-free); the total is parked in the locus's
+    // first column of the row (only this lane touches the bin's half row)
+    for (int bin = sl; bin < nbins; bin += LPL) {
+        uint32_t s = 0;
+#pragma unroll 8
+        for (int k = 0; k < KC; ++k) s += hrow[(bin << 5) + cbase + ((k + sl) & (KC - 1))];
+        if (live && bin >= 2 && bin < A + 2) {
+            allele_count[off + bin - 2] = (int32_t)s;
+            if (twin_ac) allele_count[twin_ac + off + bin - 2] = (int32_t)s;
+        }
+        hrow[(bin << 5) + cbase] = s;
+    }
+    wave_lds_fence();
+    n_eq = seg_sum<LPL>(n_eq);
+    if (any_dup) {
+        n_hl = seg_sum<LPL>(n_hl);
+        n_hs = seg_sum<LPL>(n_hs);
+    }
+    if (sl == 0 && live) {
+        const uint32_t* h = hrow + cbase;
+        const int h_m2 = (int)h[0 << 5], h_m1 = (int)h[1 << 5];
+        const int n_bad = (int)h[(A + 2) << 5];
+        const int c00 = (int)h[(A + 3) << 5];  // (-2,-2)
+        const int c10 = (int)h[(A + 4) << 5];  // lo = -1, hi = -2
+        const int c01 = (int)h[(A + 5) << 5];  // lo = -2, hi = -1
+        const int c11 = (int)h[(A + 6) << 5];  // (-1,-1)
+        const int hom_idx = n_eq - c11 - c00;
+        const u32x4 r0 = {(uint32_t)(S - (h_m1 - c11)), (uint32_t)(h_m2 - c00 - c10 - c01),
+                          (uint32_t)(dup ? n_hl - c11 - c00 : hom_idx), (uint32_t)(dup ? n_hs - c11 - c00 : hom_idx)};
+        const u32x4 r1 = {0u, (uint32_t)n_bad, 0u, 0u};
+        const u32x4 r2 = {(uint32_t)(S - b.n_pad_samples), 0u, 0u, 0u};
+        for (int64_t tw = 0;; tw = twin_li) {   // the whole 48-byte row, as in k_locus_count_v2
+            u32x4* li0 = reinterpret_cast<u32x4*>(locus_int + tw + (int64_t)l * TRK_LI_COLS);
+            li0[0] = r0;
+            li0[1] = r1;
+            li0[2] = r2;
+            if (tw == twin_li) break;
+        }
     }
     wave_lds_fence();
 }
@@ -1326,30 +1507,76 @@ __device__ __forceinline__ void cf_gather(const CfLocus<NS>& d, int idx, uint32_
 }
 
 // Class LUT of a locus block in LDS, built by the whole workgroup: lutb[li][q] = len_class | str_class << 16 of
-// allele q, linfo[li] = {A, flag, scratch}; flag: some alleles share a class (max class + 1 < A), so that the
+// allele q, linfo[li] = {A, flag, allele_off}; flag: some alleles share a class (max class + 1 < A), so that the
 // homozygosity of a filtered call needs the LUT.  Ends with a barrier.
+// Two global round trips per block whatever its size: (1) the block's allele offsets, (2) every class entry -- all
+// of a thread's entries are fetched before the first is used, the duplicate test is a packed 16-bit max over the
+// aligned lane group that owns a locus (no LDS atomics).  [The first form -- a loop over entries with the offset
+// and the two class loads dependent inside every iteration plus two ds_max per entry -- cost a workgroup ~50 us:
+// nothing at 100k loci, where other workgroups stream meanwhile, but at a strong-scaling shard of 12.5k loci
+// every workgroup of the single round sits in its prologue at the same time: 0.76 ms against 0.54 ms without the
+// delta outputs, profiles/r02_notes.md]
 constexpr int CF_LINFO = 3;
+constexpr int CF_LUT_UNROLL = 8;
 __device__ __forceinline__ void cf_build_lut(const trk_batch& b, int l_begin, int nl, int nal, int tid,
                                              uint32_t* lutb, int32_t* linfo) {
     for (int li = tid; li < nl; li += CF_THREADS) {
-        linfo[CF_LINFO * li] = b.allele_off[l_begin + li + 1] - b.allele_off[l_begin + li];
+        const int o0 = b.allele_off[l_begin + li], o1 = b.allele_off[l_begin + li + 1];
+        linfo[CF_LINFO * li] = o1 - o0;
         linfo[CF_LINFO * li + 1] = 0;
-        linfo[CF_LINFO * li + 2] = 0;
+        linfo[CF_LINFO * li + 2] = o0;
     }
     __syncthreads();
-    for (int i = tid; i < nl * nal; i += CF_THREADS) {
+    int gshift = 0;                       // lane group of a locus: the power of two >= nal
+    while ((1 << gshift) < nal) ++gshift;
+    if (gshift <= 6) {
+        const int gsz = 1 << gshift, q = tid & (gsz - 1), lpp = CF_THREADS >> gshift;   // loci per pass
+        for (int li0 = tid >> gshift; li0 < nl; li0 += lpp * CF_LUT_UNROLL) {
+            uint32_t cls[CF_LUT_UNROLL];
+#pragma unroll
+            for (int u = 0; u < CF_LUT_UNROLL; ++u) {
+                const int li = li0 + u * lpp;
+                cls[u] = 0;
+                if (li < nl && q < linfo[CF_LINFO * li]) {
+                    const int e = linfo[CF_LINFO * li + 2] + q;
+                    cls[u] = (uint32_t)b.len_class[e] | ((uint32_t)b.str_class[e] << 16);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CF_LUT_UNROLL; ++u) {
+                const int li = li0 + u * lpp;
+                // uniform over the lane group, and a group never straddles a wave: the shuffles below are safe
+                if (li >= nl) break;
+                const int A = linfo[CF_LINFO * li];
+                if (q < nal) lutb[li * nal + q] = cls[u];
+                u16x2 m = __builtin_bit_cast(u16x2, cls[u]);
+                for (int o = gsz >> 1; o > 0; o >>= 1) {
+                    const uint32_t t = (uint32_t)__shfl_xor((int)__builtin_bit_cast(uint32_t, m), o, WAVE);
+                    m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2, t));
+                }
+                if (q == 0) linfo[CF_LINFO * li + 1] = (((int)m.x + 1 < A) | ((int)m.y + 1 < A)) ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        return;
+    }
+    for (int i = tid; i < nl * nal; i += CF_THREADS) {     // allele sets beyond a wave: one entry at a time
         const int li = i / nal, q = i - li * nal;
         if (q >= linfo[CF_LINFO * li]) continue;
-        const int off = b.allele_off[l_begin + li];
-        const int lc = b.len_class[off + q], sc = b.str_class[off + q];
-        lutb[i] = (uint32_t)lc | ((uint32_t)sc << 16);
-        atomicMax(&linfo[CF_LINFO * li + 1], lc);
-        atomicMax(&linfo[CF_LINFO * li + 2], sc);
+        const int e = linfo[CF_LINFO * li + 2] + q;
+        lutb[i] = (uint32_t)b.len_class[e] | ((uint32_t)b.str_class[e] << 16);
     }
     __syncthreads();
+    // dense ranks: a duplicate exists iff the largest rank + 1 < A, i.e. iff no allele has rank A - 1
     for (int li = tid; li < nl; li += CF_THREADS) {
         const int A = linfo[CF_LINFO * li];
-        linfo[CF_LINFO * li + 1] = ((linfo[CF_LINFO * li + 1] + 1 < A) | (linfo[CF_LINFO * li + 2] + 1 < A)) ? 1 : 0;
+        bool top_l = false, top_s = false;
+        for (int q = 0; q < A; ++q) {
+            const uint32_t v = lutb[li * nal + q];
+            top_l |= (int)(v & 0xffffu) == A - 1;
+            top_s |= (int)(v >> 16) == A - 1;
+        }
+        linfo[CF_LINFO * li + 1] = (A > 0 && !(top_l && top_s)) ? 1 : 0;
     }
     __syncthreads();
 }
@@ -1603,10 +1830,11 @@ __global__ __launch_bounds__(CF_THREADS, (NS == 12 && ALLREG) ? 4 : 1) void k_ca
                 for (int i = tid; i < nl * dstride; i += CF_THREADS) {
                     const int v = dbase[i];
                     if (!v) continue;
-                    const int l = l_begin + i / dstride;
-                    const int r = i - (l - l_begin) * dstride;
+                    const int li_f = i / dstride;
+                    const int l = l_begin + li_f;
+                    const int r = i - li_f * dstride;
                     if (r < nal) {
-                        atomicSub(&a.out.delta_allele_count[a.b.allele_off[l] + r], v);
+                        atomicSub(&a.out.delta_allele_count[linfo[CF_LINFO * li_f + 2] + r], v);
                     } else {
                         const int x = r - nal;
                         const int col = x == DX_CALLED ? TRK_LI_N_CALLED
@@ -1817,14 +2045,15 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
     }
     if (DELTA) {  // one global atomic per non-zero entry of the block's delta table
         __syncthreads();
+        const uint32_t rcp = (uint32_t)((0x100000000ull + (uint32_t)dstride - 1u) / (uint32_t)dstride);  // i / dstride
         for (int i = tid; i < nl * dstride; i += CF_THREADS) {
             const uint32_t v = dtab[i];
             if (!v) continue;
-            const int li = i / dstride;
+            const int li = (int)__umulhi((uint32_t)i, rcp);
             const int r = i - li * dstride;
             const int l = l_begin + li;
             if (r < nal) {
-                atomicSub(&a.out.delta_allele_count[a.b.allele_off[l] + r], (int)v);
+                atomicSub(&a.out.delta_allele_count[linfo[CF_LINFO * li + 2] + r], (int)v);
             } else if (r == nal + V2_W0) {
                 int32_t* li_ = a.out.delta_locus_int + (int64_t)l * TRK_LI_COLS;
                 atomicSub(&li_[TRK_LI_N_CALLED], (int)(v & 0xffffu));
@@ -2074,10 +2303,28 @@ static int next_pow2(int v) {
     return p;
 }
 
+// twin (TRK_STATS_TWIN): allele_count is [2][G, sumA] and locus_int [2][G, L, COLS]; both copies receive the counts.
+// The streaming kernels write every output element themselves (and the twin copy in the same pass); the general
+// paths accumulate with atomics into zeroed arrays and are followed by two device-to-device copies.
 hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* allele_count, int32_t* locus_int,
-                              int n_cu, hipStream_t stream) {
+                              int n_cu, hipStream_t stream, bool twin) {
     const int G = b.group_bits ? b.n_groups : 1;
     const bool fast2 = (b.ploidy == 2) && !b.group_bits;
+    const size_t ac_elems = (size_t)G * (size_t)b.n_alleles_total, li_elems = (size_t)G * b.n_loci * TRK_LI_COLS;
+    const int64_t twin_ac = twin ? (int64_t)ac_elems : 0, twin_li = twin ? (int64_t)li_elems : 0;
+    auto zero_outputs = [&]() -> hipError_t {
+        hipError_t e = hipMemsetAsync(allele_count, 0, ac_elems * sizeof(int32_t), stream);
+        if (e != hipSuccess) return e;
+        return hipMemsetAsync(locus_int, 0, li_elems * sizeof(int32_t), stream);
+    };
+    auto copy_twin = [&]() -> hipError_t {
+        if (!twin) return hipGetLastError();
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        e = hipMemcpyAsync(allele_count + ac_elems, allele_count, ac_elems * sizeof(int32_t), hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return e;
+        return hipMemcpyAsync(locus_int + li_elems, locus_int, li_elems * sizeof(int32_t), hipMemcpyDeviceToDevice, stream);
+    };
     if (fast2 && max_alleles > 0 && (b.n_samples % 4) == 0 && b.n_samples > 0) {
         const char* ver_env = getenv("TRK_CNT_VER");
         const bool use_v2 = !b.locus_ploidy && max_alleles + 2 < 65535 && !(ver_env && atoi(ver_env) == 1);
@@ -2090,20 +2337,44 @@ hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* alle
             words = (words + 3) & ~3;
             size_t lds_fast = (size_t)COUNT_WAVES_PER_WG * words * sizeof(uint32_t);
             int wgs_fast = (b.n_loci + COUNT_WAVES_PER_WG - 1) / COUNT_WAVES_PER_WG;
-            int cnt_u = 2;
+            int cnt_u = 4;   // with the double-buffered streamer four chunks in flight beat two (tools/count_probe.py)
             if (const char* e = getenv("TRK_CNT_U")) cnt_u = atoi(e);
             dim3 grid(wgs_fast), block(WAVE * COUNT_WAVES_PER_WG);
+            // short rows: R loci per wave (k_locus_count_v3) while the wider per-wave histogram still lets >= 2
+            // workgroups share a CU.  TRK_CNT_R = 1 / 2 / 4 overrides the row-length rule (tools/perf_sweep.py).
+            int rr = b.n_samples <= 4096 ? 4 : 2;
+            if (const char* e = getenv("TRK_CNT_R")) rr = atoi(e);
+            const int nbmax = max_alleles + 7;
+            const int words3 = (2 * nbmax * 32 + 4 * nbmax + 3) & ~3;
+            if (use_v2 && (rr == 2 || rr == 4) && (size_t)COUNT_WAVES_PER_WG * words3 * 4 <= 72 * 1024) {
+                const int per_wg = COUNT_WAVES_PER_WG * rr;
+                dim3 g3((b.n_loci + per_wg - 1) / per_wg);
+                const size_t lds3 = (size_t)COUNT_WAVES_PER_WG * words3 * sizeof(uint32_t);
+                if (rr == 4 && cnt_u == 4)
+                    hipLaunchKernelGGL((k_locus_count_v3<4, 4>), g3, block, lds3, stream, b, allele_count, locus_int, nbmax, words3, twin_ac, twin_li);
+                else if (rr == 4)
+                    hipLaunchKernelGGL((k_locus_count_v3<4, 2>), g3, block, lds3, stream, b, allele_count, locus_int, nbmax, words3, twin_ac, twin_li);
+                else if (cnt_u == 4)
+                    hipLaunchKernelGGL((k_locus_count_v3<2, 4>), g3, block, lds3, stream, b, allele_count, locus_int, nbmax, words3, twin_ac, twin_li);
+                else
+                    hipLaunchKernelGGL((k_locus_count_v3<2, 2>), g3, block, lds3, stream, b, allele_count, locus_int, nbmax, words3, twin_ac, twin_li);
+                // (only N_ALLELES / HWE status / NALLELES columns, written by the finaliser, are left untouched)
+                return hipGetLastError();
+            }
             if (use_v2) {
                 if (cnt_u == 4)
                     hipLaunchKernelGGL(k_locus_count_v2<4>, grid, block, lds_fast, stream, b, allele_count, locus_int,
-                                       kshift, words);
+                                       kshift, words, twin_ac, twin_li);
                 else if (cnt_u == 1)
                     hipLaunchKernelGGL(k_locus_count_v2<1>, grid, block, lds_fast, stream, b, allele_count, locus_int,
-                                       kshift, words);
+                                       kshift, words, twin_ac, twin_li);
                 else
                     hipLaunchKernelGGL(k_locus_count_v2<2>, grid, block, lds_fast, stream, b, allele_count, locus_int,
-                                       kshift, words);
+                                       kshift, words, twin_ac, twin_li);
+                return hipGetLastError();
             } else {
+                hipError_t ez = zero_outputs();
+                if (ez != hipSuccess) return ez;
                 if (cnt_u == 4)
                     hipLaunchKernelGGL(k_locus_count_fast<4>, grid, block, lds_fast, stream, b, allele_count,
                                        locus_int, kshift, words);
@@ -2111,7 +2382,7 @@ hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* alle
                     hipLaunchKernelGGL(k_locus_count_fast<2>, grid, block, lds_fast, stream, b, allele_count,
                                        locus_int, kshift, words);
             }
-            return hipGetLastError();
+            return copy_twin();
         }
     }
     // sample groups (statSTR --samples): the streaming kernel with one histogram per class of group bits
@@ -2126,9 +2397,11 @@ hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* alle
             words = (words + 3) & ~3;
             const size_t lds_g = (size_t)COUNT_WAVES_PER_WG * words * sizeof(uint32_t);
             const int wgs_g = (b.n_loci + COUNT_WAVES_PER_WG - 1) / COUNT_WAVES_PER_WG;
+            hipError_t ez = zero_outputs();
+            if (ez != hipSuccess) return ez;
             hipLaunchKernelGGL(k_locus_count_v2g, dim3(wgs_g), dim3(WAVE * COUNT_WAVES_PER_WG), lds_g, stream, b,
                                allele_count, locus_int, kshift, words);
-            return hipGetLastError();
+            return copy_twin();
         }
     }
     int maxA = max_alleles > 0 ? max_alleles : 64;
@@ -2144,13 +2417,15 @@ hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* alle
     int max_wgs = n_cu * 8;
     if (wgs > max_wgs) wgs = max_wgs;
     if (wgs < 1) wgs = 1;
+    hipError_t ez = zero_outputs();
+    if (ez != hipSuccess) return ez;
     if (fast2)
         hipLaunchKernelGGL(k_locus_count<true>, dim3(wgs), dim3(WAVE * COUNT_WAVES_PER_WG), lds, stream, b,
                            allele_count, locus_int, hist_entries, lut_entries);
     else
         hipLaunchKernelGGL(k_locus_count<false>, dim3(wgs), dim3(WAVE * COUNT_WAVES_PER_WG), lds, stream, b,
                            allele_count, locus_int, hist_entries, lut_entries);
-    return hipGetLastError();
+    return copy_twin();
 }
 
 hipError_t launch_locus_finalize(const trk_batch& b, const int32_t* allele_count, int32_t* locus_int,
@@ -2384,6 +2659,43 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
                 if (q > 0 && (!delta || q <= lpb)) lpb = q;
                 if (delta) lds2 = (size_t)lpb * ((size_t)2 * b.max_alleles + V2_EXTRA + CF_LINFO) * sizeof(uint32_t);
             }
+            void (*kv2)(V2Args) = nullptr;
+#define TRK_V2(NFV)                                                                                   \
+    kv2 = (delta && ratio) ? k_call_filter_v2<NFV, true, true>                                        \
+          : delta          ? k_call_filter_v2<NFV, true, false>                                       \
+          : ratio          ? k_call_filter_v2<NFV, false, true>                                       \
+                           : k_call_filter_v2<NFV, false, false>
+            if (n_filters == 1) { TRK_V2(1); }
+            else if (n_filters == 2) { TRK_V2(2); }
+            else if (n_filters == 3) { TRK_V2(3); }
+            else if (n_filters == 4) { TRK_V2(4); }
+            else if (n_filters == 5) { TRK_V2(5); }
+            else { TRK_V2(6); }
+            // Grid: whole rounds of resident workgroups, and at least TRK_CF_MIN_ROUNDS (2) of them.  All workgroups
+            // of ONE round run their prologue (class LUT), their stream and their flush at the same time, so the
+            // memory system idles twice; from two rounds on the phases of different workgroups overlap.  Matters
+            // for a strong-scaling shard (12.5k loci x 10k samples: 1070 workgroups of 117 loci = 0.84 rounds
+            // 0.77 ms; 2560 of 49 loci 0.63 ms); at 100k loci the rule changes 6.7 rounds into 7.
+            if (!getenv("TRK_CF_LPB")) {
+                int occ = 0;
+                const size_t lds_max = delta ? (size_t)lpb * ((size_t)2 * b.max_alleles + V2_EXTRA + CF_LINFO) * 4 : 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kv2, CF_THREADS, lds_max) != hipSuccess || occ < 1)
+                    occ = 4;
+                int min_rounds = 2;
+                if (const char* e = getenv("TRK_CF_MIN_ROUNDS")) min_rounds = atoi(e) > 0 ? atoi(e) : 2;
+                const long slots = (long)n_cu * occ;
+                const long min_wgs = (long)gx * ((L + lpb - 1) / lpb);
+                long k = (min_wgs + slots - 1) / slots;
+                if (k < min_rounds) k = min_rounds;
+                long gyr = (k * slots) / gx;
+                if (gyr > L) gyr = L;
+                if (gyr >= 1) {
+                    int lpb2 = (int)((L + gyr - 1) / gyr);
+                    if (lpb2 < 8) lpb2 = L < 8 ? L : 8;      // a block's fixed cost needs some loci to spread over
+                    if (lpb2 < lpb) lpb = lpb2;
+                }
+                if (delta) lds2 = (size_t)lpb * ((size_t)2 * b.max_alleles + V2_EXTRA + CF_LINFO) * sizeof(uint32_t);
+            }
             gy = (L + lpb - 1) / lpb;
             v.loci_per_block = lpb;
             // workgroups walk blocks blockIdx.y, + gridDim.y, ... with the per-sample counters in registers;
@@ -2393,21 +2705,7 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
                 if (q > 0 && q < gy) gy = q;
             }
             dim3 grid(gx, gy), block(CF_THREADS);
-#define TRK_V2(NFV)                                                                                   \
-    if (delta && ratio)                                                                               \
-        hipLaunchKernelGGL((k_call_filter_v2<NFV, true, true>), grid, block, lds2, stream, v);         \
-    else if (delta)                                                                                   \
-        hipLaunchKernelGGL((k_call_filter_v2<NFV, true, false>), grid, block, lds2, stream, v);        \
-    else if (ratio)                                                                                   \
-        hipLaunchKernelGGL((k_call_filter_v2<NFV, false, true>), grid, block, 0, stream, v);           \
-    else                                                                                              \
-        hipLaunchKernelGGL((k_call_filter_v2<NFV, false, false>), grid, block, 0, stream, v)
-            if (n_filters == 1) { TRK_V2(1); }
-            else if (n_filters == 2) { TRK_V2(2); }
-            else if (n_filters == 3) { TRK_V2(3); }
-            else if (n_filters == 4) { TRK_V2(4); }
-            else if (n_filters == 5) { TRK_V2(5); }
-            else { TRK_V2(6); }
+            hipLaunchKernelGGL(kv2, grid, block, lds2, stream, v);
 #undef TRK_V2
             return hipGetLastError();
         }

@@ -16,15 +16,27 @@ from . import _lib as L
 class DeviceArray:
     """A typed view of device memory owned by an Engine."""
 
-    def __init__(self, eng, shape, dtype):
+    def __init__(self, eng, shape, dtype, _ptr=None, _parent=None):
         self.eng = eng
         self.shape = tuple(int(x) for x in shape)
         self.dtype = np.dtype(dtype)
         self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self.parent = _parent
+        if _parent is not None:          # a window of another array's memory (not owned)
+            self.ptr = int(_ptr)
+            return
         ptr = C.c_void_p()
         eng._chk(eng.lib.trk_dev_alloc(eng.ctx, max(self.nbytes, 16), C.byref(ptr)))
         self.ptr = ptr.value
         eng._live.add(self)
+
+    def view(self, offset_bytes, shape, dtype):
+        """A typed window [offset_bytes, ...) of this array's memory; the parent keeps ownership.  Lets a caller lay
+        several result arrays out back to back in one allocation (one RCCL all-reduce over all of them)."""
+        v = DeviceArray(self.eng, shape, dtype, _ptr=self.ptr + int(offset_bytes), _parent=self)
+        if offset_bytes < 0 or offset_bytes + v.nbytes > self.nbytes or (self.ptr + offset_bytes) % v.dtype.itemsize:
+            raise ValueError("view outside its parent or misaligned")
+        return v
 
     def get(self):
         out = np.empty(self.shape, dtype=self.dtype)
@@ -63,7 +75,7 @@ class DeviceArray:
         return self
 
     def free(self):
-        if self.ptr is not None and self.eng.ctx is not None:
+        if self.parent is None and self.ptr is not None and self.eng.ctx is not None:
             self.eng.lib.trk_dev_free(self.eng.ctx, self.ptr)
         self.ptr = None
         self.eng._live.discard(self)
@@ -278,16 +290,31 @@ class Engine:
         return DeviceBatch(s, arrays, int(n_groups), sumA)
 
     # ---- hot path ----
-    def alloc_stats(self, batch):
+    def alloc_stats(self, batch, twin=False):
+        """Result arrays of trk_locus_stats.  ``twin``: the count arrays hold two copies back to back
+        (TRK_STATS_TWIN); ``.twin`` is a StatsResult over the second copy with its own float columns."""
         G = batch.n_groups
-        return StatsResult(self.empty((G, batch.sum_alleles), np.int32),
-                           self.empty((G, batch.n_loci, L.TRK_LI_COLS), np.int32),
-                           self.empty((G, batch.n_loci, L.TRK_LF_COLS), np.float64))
+        if not twin:
+            return StatsResult(self.empty((G, batch.sum_alleles), np.int32),
+                               self.empty((G, batch.n_loci, L.TRK_LI_COLS), np.int32),
+                               self.empty((G, batch.n_loci, L.TRK_LF_COLS), np.float64))
+        n_ac, n_li = G * batch.sum_alleles, G * batch.n_loci * L.TRK_LI_COLS
+        ac = self.empty((2, G, batch.sum_alleles), np.int32)
+        li = self.empty((2, G, batch.n_loci, L.TRK_LI_COLS), np.int32)
+        first = StatsResult(ac.view(0, (G, batch.sum_alleles), np.int32),
+                            li.view(0, (G, batch.n_loci, L.TRK_LI_COLS), np.int32),
+                            self.empty((G, batch.n_loci, L.TRK_LF_COLS), np.float64))
+        first.twin = StatsResult(ac.view(n_ac * 4, (G, batch.sum_alleles), np.int32),
+                                 li.view(n_li * 4, (G, batch.n_loci, L.TRK_LI_COLS), np.int32),
+                                 self.empty((G, batch.n_loci, L.TRK_LF_COLS), np.float64))
+        first._owners = (ac, li)
+        return first
 
     def locus_stats(self, batch, nalleles_thresh=0.01, out=None, count_only=False):
         if out is None:
             out = self.alloc_stats(batch)
-        prm = L.StatsParams(float(nalleles_thresh), L.STATS_COUNT_ONLY if count_only else 0, 0)
+        flags = (L.STATS_COUNT_ONLY if count_only else 0) | (L.STATS_TWIN if getattr(out, 'twin', None) else 0)
+        prm = L.StatsParams(float(nalleles_thresh), flags, 0)
         self._chk(self.lib.trk_locus_stats(self.ctx, C.byref(batch.struct), C.byref(prm), C.byref(out.struct)))
         return out
 
@@ -484,6 +511,15 @@ class Engine:
 
     def allgather(self, send, recv):
         self._chk(self.lib.trk_allgather(self.ctx, send.ptr, recv.ptr, send.nbytes))
+
+    def exchange(self, sums, send=None, recv=None):
+        """trk_exchange: one grouped RCCL launch -- in-place int64 sum of ``sums`` over the ranks and the rank-major
+        gather of ``send`` into ``recv``."""
+        self._chk(self.lib.trk_exchange(self.ctx, sums.ptr if sums is not None else None,
+                                        int(np.prod(sums.shape)) if sums is not None else 0,
+                                        send.ptr if send is not None else None,
+                                        recv.ptr if recv is not None else None,
+                                        send.nbytes if send is not None else 0))
 
     # ---- synthetic batches ----
     def synth_fill(self, seed, n_loci, n_samples, allele_off_d, cdf_d, miss_d, inb_d, locus_base=0,

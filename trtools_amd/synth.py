@@ -133,6 +133,19 @@ class Loci:
         self.miss_thr16 = None
         self.inbreed_thr16 = None
 
+    def slice(self, lo, hi):
+        """Tables of loci [lo, hi): one rank's contiguous shard of a cohort-wide table."""
+        out = Loci()
+        out.motifs = self.motifs[lo:hi]
+        out.allele_strs = self.allele_strs[lo:hi]
+        out.allele_lens = self.allele_lens[lo:hi]
+        a0, a1 = int(self.allele_off[lo]), int(self.allele_off[hi])
+        out.allele_off = (self.allele_off[lo:hi + 1] - a0).astype(np.int32)
+        out.cdf24 = self.cdf24[a0:a1]
+        out.miss_thr16 = self.miss_thr16[lo:hi]
+        out.inbreed_thr16 = self.inbreed_thr16[lo:hi]
+        return out
+
 
 def make_loci(n_loci, n_samples, seed, max_alleles=None, all_missing_frac=0.01, inbred_frac=0.10,
               miss_rate=0.03, pure_repeats=False):
