@@ -97,7 +97,8 @@ LOCUS_ARGS = dict(min_callrate=0.8, min_hwep=1e-4, min_het=0.05, max_het=0.95, u
 class Workload:
     """Device-resident buffers of one rank's shard + one step of the hot path."""
 
-    def __init__(self, eng, seed, n_samples, loci, locus_base, world, use_comm, overlap=True, gather_loci=None):
+    def __init__(self, eng, seed, n_samples, loci, locus_base, world, use_comm, overlap=True, gather_loci=None,
+                 pipeline_count=False):
         from trtools_amd.synth import SynthBatch
         from trtools_amd import _lib as L
         from trtools_amd.engine import CallResult
@@ -143,60 +144,76 @@ class Workload:
         self.step_no = 0
         self._pending = None
         self.overlap = overlap
+        self.pipeline_count = pipeline_count
 
     # the buffers of the last completed step
     call_out = property(lambda self: self.call_outs[(self.step_no - 1) & 1])
     bits = property(lambda self: self.bits_[(self.step_no - 1) & 1])
     loc_counters = property(lambda self: self.loc_counters_[(self.step_no - 1) & 1])
 
+    # ordering points (trk_event_*), one per buffer set i = step & 1
+    EV_COUNT, EV_CF, EV_TAIL, EV_FINA = 0, 2, 4, 6
+
     def step(self):
-        """One statSTR + dumpSTR pass over the shard.  Queue 0 carries the HBM-bound stream kernels (count, call
-        filters), queue 1 the latency-bound rest, placed beside the long call-filter kernel: statSTR's finaliser of
-        this step and dumpSTR's finaliser + locus filters (+ the RCCL exchange) of the PREVIOUS step (its outputs
-        are double buffered; ``flush`` runs the last one).  TRK_BENCH_OVERLAP=0 puts everything on queue 0, in
-        step order."""
+        """One statSTR + dumpSTR pass over the shard.
+        queue 0  the call-filter pass (k_call_filter + k_cf_reduce), HBM bound
+        queue 1  dumpSTR's tail of the PREVIOUS step: finaliser, locus filters, the RCCL exchange
+        queue 2  statSTR's finaliser of this step
+        queue 3  the count pass of this step when ``pipeline_count`` (N > 1 shards: the count of step n runs beside
+                 the end of the call filters of step n - 1 -- it does not depend on them -- so that the ramp and the
+                 tail of the two short stream kernels overlap); otherwise queue 0, in order before the call filters
+        Every output a step hands on is double buffered; a queue that recycles a buffer set waits for the marks its
+        consumers recorded two steps ago (long past), never for work enqueued in this step, so queue 0 runs its
+        stream kernels back to back.  TRK_BENCH_OVERLAP=0 puts everything on queue 0, in step order."""
         eng = self.eng
         i = self.step_no & 1
         self.step_no += 1
         b = self.sb.batch
         out = self.call_outs[i]
-        q1, q2 = (1, 2) if self.overlap else (0, 0)
-        self.sums_[i].zero()       # counters are per step (each step is a complete statSTR + dumpSTR run)
-        eng.locus_stats(b, out=self.stats_a[i], count_only=True)                    # statSTR: count (+ twin copy)
-        if not getattr(self.stats_a[i], 'twin', None):
-            self.stats_b[i].allele_count.copy_from(self.stats_a[i].allele_count)
-            self.stats_b[i].locus_int.copy_from(self.stats_a[i].locus_int)
-        eng.queue_wait(q1, 0)
-        eng.queue_wait(q2, 0)
+        q1, q2, qc = (1, 2, 3 if self.pipeline_count else 0) if self.overlap else (0, 0, 0)
+        with eng.on_queue(qc):
+            eng.event_wait(self.EV_TAIL + i)       # tail(n - 2) has consumed sums / stats_b of this buffer set
+            eng.event_wait(self.EV_FINA + i)       # fin_a(n - 2) has consumed stats_a of this buffer set
+            self.sums_[i].zero()                   # counters are per step (each step is a complete run)
+            eng.locus_stats(b, out=self.stats_a[i], count_only=True)                # statSTR: count (+ twin copy)
+            if not getattr(self.stats_a[i], 'twin', None):
+                self.stats_b[i].allele_count.copy_from(self.stats_a[i].allele_count)
+                self.stats_b[i].locus_int.copy_from(self.stats_a[i].locus_int)
+            eng.event_record(self.EV_COUNT + i)
         with eng.on_queue(q1):
+            # beside this step's call filters, not beside its count pass (the latency-bound finalisers cost the
+            # short count kernel a third of its time, the long call-filter kernel ~3 %)
+            eng.event_wait(self.EV_COUNT + i)
             self._tail()                                                           # dumpSTR tail of the previous step
         with eng.on_queue(q2):
+            eng.event_wait(self.EV_COUNT + i)
             eng.locus_finalize(b, self.stats_a[i])                                 # statSTR: 11 statistics per locus
+            eng.event_record(self.EV_FINA + i)
+        eng.event_wait(self.EV_COUNT + i)
         eng.call_filters(b, self.planes, self.filters, dp_plane=0, out=out, delta_stats=self.stats_b[i])
-        # queue 0 goes on to the next step once queues 1 and 2 are through with what they hold now
-        eng.queue_wait(0, q1)
-        eng.queue_wait(0, q2)
+        eng.event_record(self.EV_CF + i)
         self._pending = i
         if not self.overlap:
             self._tail()
 
     def _tail(self):
-        """dumpSTR after the call filters: statistics of the masked genotypes, locus filters, cohort-wide sums."""
+        """dumpSTR after the call filters: statistics of the masked genotypes, locus filters, cohort-wide sums
+        (enqueued on the selected queue)."""
         if self._pending is None:
             return
         eng, i = self.eng, self._pending
         self._pending = None
+        eng.event_wait(self.EV_CF + i)
         eng.locus_finalize(self.sb.batch, self.stats_b[i])
         eng.locus_filters(self.n_loci, self.stats_b[i], bits_out=self.bits_[i], counters=self.loc_counters_[i],
                           **self.locus_args)
         if self.gather is not None:
             eng.exchange(self.sums_[i], self.bits_[i], self.gather)
+        eng.event_record(self.EV_TAIL + i)
 
     def flush(self):
         """Enqueue the tail of the last step (call before the final synchronisation)."""
-        q1 = 1 if self.overlap else 0
-        self.eng.queue_wait(q1, 0)
-        with self.eng.on_queue(q1):
+        with self.eng.on_queue(1 if self.overlap else 0):
             self._tail()
 
     def run(self, steps, warmup, barrier=None):
@@ -433,7 +450,7 @@ def strong_shard_extra(eng, args, loci, t_full_ms, steps):
     cells_full = args.loci * args.samples
     for n in (2, 4, 8):
         hi = args.loci // n
-        wl = Workload(eng, args.seed, args.samples, loci.slice(0, hi), 0, 1, use_comm=True)
+        wl = Workload(eng, args.seed, args.samples, loci.slice(0, hi), 0, 1, use_comm=True, pipeline_count=True)
         el, prof = wl.run(steps, 3)
         ms = el / steps * 1e3
         kn, kms = prof['k_call_filter']
@@ -649,7 +666,8 @@ def main():
     else:
         my_loci, locus_base, total_loci = loci, rank * args.loci, args.loci * world
     wl = Workload(eng, args.seed, args.samples, my_loci, locus_base, world, use_comm=use_dist,
-                  overlap=os.environ.get('TRK_BENCH_OVERLAP', '1') != '0', gather_loci=-(-args.loci // world))
+                  overlap=os.environ.get('TRK_BENCH_OVERLAP', '1') != '0', gather_loci=-(-args.loci // world),
+                  pipeline_count=(world > 1) or bool(os.environ.get('TRK_BENCH_PIPE_COUNT')))
 
     def barrier():
         if dist is not None:

@@ -88,9 +88,16 @@ int trk_queue_sync(trk_ctx* ctx, int queue);
  * can overlap -- bench.py runs statSTR's finaliser (k_locus_finalize + k_hwe_test, latency bound) on
  * queue 1 beside dumpSTR's call-filter pass (HBM bound) on queue 0.  The associaTR entry points share one
  * workspace: use them from one queue at a time.                                                        */
-#define TRK_N_STREAMS 3
+#define TRK_N_STREAMS 4
 int trk_stream_select(trk_ctx* ctx, int queue);
 int trk_stream_wait(trk_ctx* ctx, int waiter, int signal);
+/* Named ordering points for pipelines that run several batches deep: trk_event_record marks "everything enqueued so
+ * far on the SELECTED queue"; trk_event_wait makes the selected queue wait for the mark of `slot` as last recorded
+ * (never recorded: no wait).  Unlike trk_stream_wait the mark can be an old one -- a queue that recycles a double
+ * buffer waits for the consumer of two batches ago, which has long finished, instead of the one just enqueued.    */
+#define TRK_N_EVENTS 16
+int trk_event_record(trk_ctx* ctx, int slot);
+int trk_event_wait(trk_ctx* ctx, int slot);
 
 /* ---- timing on the context's stream (HIP events) ------------------------ */
 /* Slots 0..TRK_N_TIMERS-1.  start/stop enqueue events on the compute stream;

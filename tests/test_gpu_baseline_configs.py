@@ -339,8 +339,11 @@ def test_config3_locus_shards_add_up_to_the_cohort(eng):
     eng.comm_init(0, 1, eng.comm_unique_id())      # 1-rank RCCL communicator: the exchange kernels really launch
 
     def run(lo, hi, world):
-        wl = bench.Workload(eng, seed, S, loci.slice(lo, hi), lo, 1, use_comm=True, gather_loci=-(-Lc // world))
-        for _ in range(2):
+        # the shards run as a rank of the multi-GPU job does: the count pass of a step on its own queue, beside the
+        # end of the previous step's call filters (pipeline_count)
+        wl = bench.Workload(eng, seed, S, loci.slice(lo, hi), lo, 1, use_comm=True, gather_loci=-(-Lc // world),
+                            pipeline_count=world > 1)
+        for _ in range(4):
             wl.step()
         wl.flush()
         eng.sync()

@@ -22,6 +22,28 @@ def tiled(base, reps):
 
 
 eng = Engine(0)
+if '--bench-data' in sys.argv:      # the bench's own cohort (100k x 10k, seed 20260931) and its 12.5k-locus shard
+    loci = make_loci(100000, 10000, 20260931)
+    for n in (100000, 12500):
+        sb = SynthBatch(eng, n, 10000, seed=20260931, planes=(), loci=loci.slice(0, n))
+        for twin in (False, True):
+            res = eng.alloc_stats(sb.batch, twin=twin)
+            for R in ('1', '2', '4'):
+                for U in ('1', '2', '4'):
+                    os.environ['TRK_CNT_R'], os.environ['TRK_CNT_U'] = R, U
+                    eng.profile(True)
+                    for it in range(13):
+                        if it == 3:
+                            eng.sync(); eng.profile_reset()
+                        eng.locus_stats(sb.batch, out=res, count_only=True)
+                    eng.sync()
+                    k, ms = eng.profile_get()['k_locus_count']
+                    eng.profile(False)
+                    print("bench data %6d x 10000 twin=%d R=%s U=%s  %.4f ms (%.2f of peak)" % (
+                        n, twin, R, U, ms / k, n * 1e4 * 4 / (ms / k * 1e-3) / 8e12), flush=True)
+        for a in list(sb.dev.values()) + list(sb.batch.arrays.values()):
+            a.free()
+    sys.exit(0)
 shapes = [(10000, 1000, 1), (400000, 1000, 40), (1600000, 252, 160), (200000, 2000, 20), (100000, 4000, 10), (50000, 5000, 5),
           (100000, 10000, 10)]
 if len(sys.argv) > 1:

@@ -20,10 +20,12 @@ eng.comm_init(0, 1, eng.comm_unique_id())
 loci = make_loci(max(a.loci), a.samples, 20260931)
 for n in a.loci:
     wl = bench.Workload(eng, 20260931, a.samples, loci.slice(0, n), 0, 1, use_comm=True)
+    wl.pipeline_count = bool(os.environ.get('PIPE'))
     for knob in a.knobs:
         kv = [k.split('=') for k in knob.split(',') if k]
         for k, v in kv:
             os.environ[k] = v
+        wl.pipeline_count = bool(os.environ.get('PIPE'))
         el, prof = wl.run(a.steps, 3)
         for k, v in kv:
             del os.environ[k]

@@ -36,7 +36,7 @@ LC_TOTALCALLS, LC_PASS, LC_NO_CALLS, LC_FILTER0 = 0, 1, 2, 3
 LC_HWE_ERRORS = 31
 STATS_COUNT_ONLY = 1
 STATS_TWIN = 2
-TRK_N_STREAMS = 3
+TRK_N_STREAMS = 4
 
 
 class Batch(C.Structure):
@@ -126,7 +126,7 @@ EXPORTS = [
     'trk_comm_unique_id', 'trk_comm_init', 'trk_allreduce_sum_i64', 'trk_allgather',
     'trk_binomtest_two_sided', 'trk_binom_pmf', 'trk_synth_fill', 'trk_synth_fill_gangstr',
     'trk_assoc_scan', 'trk_assoc_scan_dosage', 'trk_student_t_two_sided', 'trk_dosages', 'trk_planarize', 'trk_stream_select', 'trk_stream_wait',
-    'trk_host_alloc', 'trk_host_free', 'trk_memcpy_h2d_async', 'trk_memcpy_d2h_async', 'trk_queue_sync', 'trk_exchange',
+    'trk_host_alloc', 'trk_host_free', 'trk_memcpy_h2d_async', 'trk_memcpy_d2h_async', 'trk_queue_sync', 'trk_exchange', 'trk_event_record', 'trk_event_wait',
 ]
 
 _lib = None
@@ -184,6 +184,8 @@ def load():
     lib.trk_memcpy_h2d_async.argtypes = [vp, vp, vp, C.c_size_t]
     lib.trk_memcpy_d2h_async.argtypes = [vp, vp, vp, C.c_size_t]
     lib.trk_queue_sync.argtypes = [vp, C.c_int]
+    lib.trk_event_record.argtypes = [vp, C.c_int]
+    lib.trk_event_wait.argtypes = [vp, C.c_int]
     lib.trk_binomtest_two_sided.argtypes = [i64, i64, dbl]
     lib.trk_binomtest_two_sided.restype = dbl
     lib.trk_binom_pmf.argtypes = [i64, i64, dbl]

@@ -79,6 +79,8 @@ struct trk_ctx {
     // each has its own finaliser scratch, so that e.g. statSTR's finaliser can run beside dumpSTR's call-filter pass
     hipStream_t streams[TRK_N_STREAMS] = {};
     hipEvent_t join_event[TRK_N_STREAMS] = {};
+    hipEvent_t user_event[TRK_N_EVENTS] = {};
+    bool user_event_set[TRK_N_EVENTS] = {};
     int cur = 0;
     hipStream_t s() const { return streams[cur]; }
     std::string err;
@@ -93,6 +95,8 @@ struct trk_ctx {
     size_t scratch_bytes_[TRK_N_STREAMS] = {};
     void* worklist_[TRK_N_STREAMS] = {};    // deferred HWE tests (count + items)
     size_t worklist_bytes_[TRK_N_STREAMS] = {};
+    void* cf_ws_[TRK_N_STREAMS] = {};       // call-filter partial sample counters (per queue)
+    size_t cf_ws_bytes_[TRK_N_STREAMS] = {};
     void* assoc_ws = nullptr;    // associaTR scan workspace (Gram, partial records, class counts)
     size_t assoc_ws_bytes = 0;
     ncclComm_t comm = nullptr;
@@ -202,6 +206,7 @@ int trk_init(int device, trk_ctx** out) {
         (void)hipEventCreate(&ctx->t_start[i]);
         (void)hipEventCreate(&ctx->t_stop[i]);
     }
+    for (int i = 0; i < TRK_N_EVENTS; ++i) (void)hipEventCreateWithFlags(&ctx->user_event[i], hipEventDisableTiming);
     *out = ctx;
     return TRK_OK;
 }
@@ -217,9 +222,12 @@ void trk_free(trk_ctx* ctx) {
         (void)hipEventDestroy(ctx->t_start[i]);
         (void)hipEventDestroy(ctx->t_stop[i]);
     }
+    for (int i = 0; i < TRK_N_EVENTS; ++i)
+        if (ctx->user_event[i]) (void)hipEventDestroy(ctx->user_event[i]);
     for (int i = 0; i < TRK_N_STREAMS; ++i) {
         if (ctx->scratch_[i]) (void)hipFree(ctx->scratch_[i]);
         if (ctx->worklist_[i]) (void)hipFree(ctx->worklist_[i]);
+        if (ctx->cf_ws_[i]) (void)hipFree(ctx->cf_ws_[i]);
         if (ctx->join_event[i]) (void)hipEventDestroy(ctx->join_event[i]);
         if (ctx->streams[i]) (void)hipStreamDestroy(ctx->streams[i]);
     }
@@ -338,6 +346,21 @@ int trk_stream_wait(trk_ctx* ctx, int waiter, int signal) {
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipEventRecord(ctx->join_event[signal], ctx->streams[signal]));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->streams[waiter], ctx->join_event[signal], 0));
+    return TRK_OK;
+}
+
+int trk_event_record(trk_ctx* ctx, int slot) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (slot < 0 || slot >= TRK_N_EVENTS) return fail(ctx, TRK_ERR_ARG, "event slot %d outside [0, %d)", slot, TRK_N_EVENTS);
+    HIPCHK(ctx, hipEventRecord(ctx->user_event[slot], ctx->s()));
+    ctx->user_event_set[slot] = true;
+    return TRK_OK;
+}
+int trk_event_wait(trk_ctx* ctx, int slot) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (slot < 0 || slot >= TRK_N_EVENTS) return fail(ctx, TRK_ERR_ARG, "event slot %d outside [0, %d)", slot, TRK_N_EVENTS);
+    if (!ctx->user_event_set[slot]) return TRK_OK;
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->s(), ctx->user_event[slot], 0));
     return TRK_OK;
 }
 
@@ -515,9 +538,27 @@ int trk_call_filters(trk_ctx* ctx, const trk_batch* in, const trk_plane* planes,
     }
     if (in->n_loci == 0 || in->n_samples == 0) return TRK_OK;
     (void)hipSetDevice(ctx->device);
+    // grown outside the profiling bracket and before the launch (a growth synchronises this queue)
+    trk::Scratch sc{ctx, [](void* user, size_t bytes) -> void* {
+                        trk_ctx* c = static_cast<trk_ctx*>(user);
+                        const int q = c->cur;
+                        if (bytes > c->cf_ws_bytes_[q]) {
+                            if (hipStreamSynchronize(c->streams[q]) != hipSuccess) return nullptr;
+                            if (c->cf_ws_[q]) (void)hipFree(c->cf_ws_[q]);
+                            c->cf_ws_[q] = nullptr;
+                            c->cf_ws_bytes_[q] = 0;
+                            const size_t want = bytes + bytes / 4;
+                            if (hipMalloc(&c->cf_ws_[q], want) != hipSuccess) {
+                                (void)hipGetLastError();
+                                return nullptr;   // the kernel falls back to atomics
+                            }
+                            c->cf_ws_bytes_[q] = want;
+                        }
+                        return c->cf_ws_[q];
+                    }};
     ProfScope ps(ctx, TRK_K_CALL_FILTER);
     HIPCHK(ctx, trk::launch_call_filter(*in, planes, n_planes, filters, n_filters, dp_plane, *out, ctx->n_cu,
-                                        ctx->s()));
+                                        ctx->s(), sc));
     return TRK_OK;
 }
 

@@ -15,9 +15,14 @@ hipError_t launch_locus_finalize(const trk_batch& b, const int32_t* allele_count
                                  double* locus_f64, int32_t* scratch, void* worklist, double nalleles_thresh,
                                  hipStream_t stream);
 size_t finalize_worklist_bytes(int64_t n_group_loci);
+// device scratch owned by the context, handed out (and grown) on request; nullptr when it cannot be had
+struct Scratch {
+    void* user;
+    void* (*get)(void* user, size_t bytes);
+};
 hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n_planes,
                               const trk_call_filter* filters, int n_filters, int dp_plane, const trk_call_out& out,
-                              int n_cu, hipStream_t stream);
+                              int n_cu, hipStream_t stream, const Scratch& scratch);
 hipError_t launch_locus_filter(int L, const int32_t* locus_int, const double* locus_f64,
                                const trk_locus_filter_spec& spec, uint32_t* bits, int64_t* counters,
                                hipStream_t stream);

@@ -1906,6 +1906,11 @@ struct V2Args {
     const int32_t* dp;    // DP/LC plane or nullptr
     int loci_per_block;
     int delta_nal;        // max_alleles when the delta outputs are requested, else 0
+    int dbg;              // TRK_CF_DBG (timing experiments only): 1 no per-sample counter flush, 2 no delta flush
+    // per-workgroup partial sample counters (plain coalesced stores, summed by k_cf_reduce) instead of one
+    // device-scope atomic per counter, sample and workgroup; nullptr: atomics
+    uint16_t* part16;     // [gridDim.y][2 + NF][S]: numcalls, dp-missing, filter k
+    unsigned long long* part64;  // [gridDim.y][S]: totaldp
     trk_call_out out;
 };
 
@@ -2048,7 +2053,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
         const uint32_t rcp = (uint32_t)((0x100000000ull + (uint32_t)dstride - 1u) / (uint32_t)dstride);  // i / dstride
         for (int i = tid; i < nl * dstride; i += CF_THREADS) {
             const uint32_t v = dtab[i];
-            if (!v) continue;
+            if (!v || (a.dbg & 2)) continue;
             const int li = (int)__umulhi((uint32_t)i, rcp);
             const int r = i - li * dstride;
             const int l = l_begin + li;
@@ -2067,7 +2072,24 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
         __syncthreads();   // the table is re-initialised for the next block
     }
     }  // locus blocks of this workgroup
-    if (s0 < S) {
+    if (s0 < S && a.part16 && !(a.dbg & 1)) {
+        // this workgroup's counters of its 4 samples: one 8-byte store per counter row, 32 bytes of depth sums
+        typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        u16x4* p16 = reinterpret_cast<u16x4*>(a.part16 + ((size_t)blockIdx.y * (2 + NF)) * S + s0);
+        const size_t rs = (size_t)S / 4;   // row stride in u16x4
+        p16[0] = (u16x4){(unsigned short)numcalls[0], (unsigned short)numcalls[1], (unsigned short)numcalls[2],
+                         (unsigned short)numcalls[3]};
+        p16[rs] = (u16x4){(unsigned short)dpmiss[0], (unsigned short)dpmiss[1], (unsigned short)dpmiss[2],
+                          (unsigned short)dpmiss[3]};
+#pragma unroll
+        for (int k = 0; k < NF; ++k)
+            p16[(2 + k) * rs] = (u16x4){(unsigned short)fc[k][0], (unsigned short)fc[k][1], (unsigned short)fc[k][2],
+                                        (unsigned short)fc[k][3]};
+        u64x2* p64 = reinterpret_cast<u64x2*>(a.part64 + (size_t)blockIdx.y * S + s0);
+        p64[0] = (u64x2){(unsigned long long)totaldp[0], (unsigned long long)totaldp[1]};
+        p64[1] = (u64x2){(unsigned long long)totaldp[2], (unsigned long long)totaldp[3]};
+    } else if (s0 < S && !(a.dbg & 1)) {
 #pragma unroll
         for (int j = 0; j < CF_V; ++j) {
             const int64_t s = s0 + j;
@@ -2089,6 +2111,90 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
         }
     }
 
+}
+
+// ---------------------------------------------------------------------------
+// k_cf_reduce : sums the per-workgroup partial sample counters of k_call_filter_v2 into the int64 outputs.
+// Thread (quad of 4 samples, slice): walks the locus blocks by = slice, slice + NSL, ...; the NSL slices of a quad are
+// added up through LDS and one thread per quad does the (non-atomic) += on the outputs.  12.5k loci x 10k samples:
+// 1280 workgroups x 60k counters = 7.7 M device-scope atomics (58 us, all at the end of the single round of
+// workgroups) become 18 MB of plain stores + this kernel; at 100k loci 75 M atomics (0.11 ms) become 125 MB.
+// ---------------------------------------------------------------------------
+constexpr int CFR_NSL = 16, CFR_QPB = 16;   // slices per quad, quads per workgroup (256 threads)
+constexpr int CFR_ROWS = 2 + V2_MAX_FILTERS, CFR_UNR = 4;
+__global__ __launch_bounds__(CFR_NSL* CFR_QPB) void k_cf_reduce(const uint16_t* __restrict__ part16,
+                                                               const unsigned long long* __restrict__ part64,
+                                                               int gy, int S, int nrow16, V2Filter f0, V2Filter f1,
+                                                               V2Filter f2, V2Filter f3, V2Filter f4, V2Filter f5,
+                                                               trk_call_out out) {
+    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    __shared__ uint32_t red32[CFR_NSL][CFR_ROWS][CFR_QPB * 4];
+    __shared__ unsigned long long red64[CFR_NSL][CFR_QPB * 4];
+    const int ql = threadIdx.x % CFR_QPB, slice = threadIdx.x / CFR_QPB;
+    const int quad = blockIdx.x * CFR_QPB + ql;
+    const bool live = quad * 4 < S;
+    const size_t rs = (size_t)S / 4;
+    uint32_t acc[CFR_ROWS][4];
+    unsigned long long accd[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < CFR_ROWS; ++r) acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0;
+    if (live) {
+        const u16x4* p16 = reinterpret_cast<const u16x4*>(part16) + quad;
+        const u64x2* p64 = reinterpret_cast<const u64x2*>(part64) + (size_t)quad * 2;
+        // every row of CFR_UNR locus blocks requested before the first is added: a handful of round trips in all
+        for (int by0 = slice; by0 < gy; by0 += CFR_NSL * CFR_UNR) {
+            u16x4 v[CFR_UNR][CFR_ROWS];
+            u64x2 da[CFR_UNR], db[CFR_UNR];
+#pragma unroll
+            for (int u = 0; u < CFR_UNR; ++u) {
+                const int by = by0 + u * CFR_NSL;
+                const bool ok = by < gy;
+                const size_t byc = ok ? by : 0;
+#pragma unroll
+                for (int r = 0; r < CFR_ROWS; ++r)
+                    v[u][r] = (ok && r < nrow16) ? p16[(byc * nrow16 + r) * rs] : (u16x4){0, 0, 0, 0};
+                da[u] = ok ? p64[byc * rs * 2] : (u64x2){0, 0};
+                db[u] = ok ? p64[byc * rs * 2 + 1] : (u64x2){0, 0};
+            }
+#pragma unroll
+            for (int u = 0; u < CFR_UNR; ++u) {
+#pragma unroll
+                for (int r = 0; r < CFR_ROWS; ++r) {
+                    acc[r][0] += v[u][r].x; acc[r][1] += v[u][r].y; acc[r][2] += v[u][r].z; acc[r][3] += v[u][r].w;
+                }
+                accd[0] += da[u].x; accd[1] += da[u].y; accd[2] += db[u].x; accd[3] += db[u].y;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < CFR_ROWS; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red32[slice][r][ql * 4 + j] = acc[r][j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red64[slice][ql * 4 + j] = accd[j];
+    __syncthreads();
+    const int bits[6] = {f0.bit, f1.bit, f2.bit, f3.bit, f4.bit, f5.bit};
+    // outputs of this workgroup: (nrow16 + 1) rows x 64 samples, one thread each (non-atomic +=: nobody else writes
+    // these counters while the call-filter pass runs)
+    for (int o = threadIdx.x; o < (nrow16 + 1) * CFR_QPB * 4; o += CFR_NSL * CFR_QPB) {
+        const int r = o / (CFR_QPB * 4), c = o % (CFR_QPB * 4);
+        const int64_t smp = (int64_t)blockIdx.x * CFR_QPB * 4 + c;
+        if (smp >= S) continue;
+        unsigned long long t = 0;
+        if (r < nrow16) {
+#pragma unroll
+            for (int k = 0; k < CFR_NSL; ++k) t += red32[k][r][c];
+        } else {
+#pragma unroll
+            for (int k = 0; k < CFR_NSL; ++k) t += red64[k][c];
+        }
+        int64_t* dst = r == 0       ? out.sample_counters + smp
+                       : r == 1     ? out.sample_dp_missing + smp
+                       : r < nrow16 ? out.sample_counters + (int64_t)(1 + bits[r - 2]) * S + smp
+                                    : out.sample_totaldp + smp;
+        if (t) *dst += (int64_t)t;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2342,7 +2448,7 @@ hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* alle
             dim3 grid(wgs_fast), block(WAVE * COUNT_WAVES_PER_WG);
             // short rows: R loci per wave (k_locus_count_v3) while the wider per-wave histogram still lets >= 2
             // workgroups share a CU.  TRK_CNT_R = 1 / 2 / 4 overrides the row-length rule (tools/perf_sweep.py).
-            int rr = b.n_samples <= 4096 ? 4 : 2;
+            int rr = b.n_samples <= 4096 ? 4 : 1;   // (bench data, 10k-sample rows: R = 1 0.69 ms, R = 2 0.77, R = 4 0.76)
             if (const char* e = getenv("TRK_CNT_R")) rr = atoi(e);
             const int nbmax = max_alleles + 7;
             const int words3 = (2 * nbmax * 32 + 4 * nbmax + 3) & ~3;
@@ -2459,7 +2565,7 @@ size_t finalize_worklist_bytes(int64_t n_group_loci) { return 16 + (size_t)(2 * 
 
 hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n_planes,
                               const trk_call_filter* filters, int n_filters, int dp_plane, const trk_call_out& out,
-                              int n_cu, hipStream_t stream) {
+                              int n_cu, hipStream_t stream, const Scratch& scratch) {
     CallArgs a;
     a.b = b;
     for (int i = 0; i < n_planes; ++i) a.planes[i] = planes[i];
@@ -2647,6 +2753,7 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             v.dp = dp_plane >= 0 ? reinterpret_cast<const int32_t*>(a.src_ptr[a.dp_src]) : nullptr;
             v.out = out;
             v.delta_nal = delta ? b.max_alleles : 0;
+            v.dbg = a.dbg;
             size_t lds2 = 0;
             if (delta) {
                 const size_t per_locus = ((size_t)2 * b.max_alleles + V2_EXTRA + CF_LINFO) * sizeof(uint32_t);
@@ -2704,8 +2811,29 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
                 int q = atoi(e);
                 if (q > 0 && q < gy) gy = q;
             }
+            // per-workgroup partial counters + k_cf_reduce instead of atomics (u16 partials: a workgroup's loci
+            // must stay below 65536; TRK_CF_ATOMICS=1 keeps the atomics for A/B runs)
+            v.part16 = nullptr;
+            v.part64 = nullptr;
+            const long walks = ((L + lpb - 1) / lpb + gy - 1) / gy;
+            if (walks * lpb < 65536 && !getenv("TRK_CF_ATOMICS")) {
+                const size_t b16 = (((size_t)gy * (2 + n_filters) * S * sizeof(uint16_t)) + 255) & ~(size_t)255;
+                const size_t b64 = (size_t)gy * S * sizeof(unsigned long long);
+                if (void* ws = scratch.get(scratch.user, b16 + b64)) {
+                    v.part16 = static_cast<uint16_t*>(ws);
+                    v.part64 = reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + b16);
+                }
+            }
             dim3 grid(gx, gy), block(CF_THREADS);
             hipLaunchKernelGGL(kv2, grid, block, lds2, stream, v);
+            if (v.part16) {
+                hipError_t e1 = hipGetLastError();
+                if (e1 != hipSuccess) return e1;
+                const int quads = S / 4;
+                hipLaunchKernelGGL(k_cf_reduce, dim3((quads + CFR_QPB - 1) / CFR_QPB), dim3(CFR_NSL * CFR_QPB), 0, stream,
+                                   v.part16, v.part64, gy, S, 2 + n_filters, v.f[0], v.f[1], v.f[2], v.f[3], v.f[4],
+                                   v.f[5], out);
+            }
 #undef TRK_V2
             return hipGetLastError();
         }

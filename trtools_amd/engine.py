@@ -375,6 +375,14 @@ class Engine:
         """Queue ``waiter`` waits for everything enqueued so far on queue ``signal``."""
         self._chk(self.lib.trk_stream_wait(self.ctx, int(waiter), int(signal)))
 
+    def event_record(self, slot):
+        """Mark "everything enqueued so far on the selected queue" under ``slot`` (trk_event_record)."""
+        self._chk(self.lib.trk_event_record(self.ctx, int(slot)))
+
+    def event_wait(self, slot):
+        """The selected queue waits for the mark last recorded under ``slot`` (trk_event_wait)."""
+        self._chk(self.lib.trk_event_wait(self.ctx, int(slot)))
+
     def upload_plane(self, arr):
         """Upload a FORMAT plane [L, S] or [L, S, k] (int32 / float32).  Multi-column planes end up planar
         ([k, L, S], TRK_DT_PLANAR) so that every column streams as 16-byte vectors: uploaded as they are and
