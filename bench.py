@@ -275,7 +275,7 @@ def exhaustive_check(wl, single_rank_sums):
     assert wl.call_out.error.get()[0] == 0
     t0 = time.perf_counter()
     r = fullsize.check_step(fetch_inputs, fetch_outputs, wl.n_loci, wl.n_samples, wl.sb.tables, wl.filters, 0,
-                            wl.locus_args, dev, n_threads=max(1, fullsize.oracle_c.n_cores() // max(1, wl.world)))
+                            wl.locus_args, dev, n_threads=max(1, fullsize.oracle_c.tuned_threads() // max(1, wl.world)))
     r['seconds'] = time.perf_counter() - t0
     return r
 
@@ -411,7 +411,7 @@ def cpu_baseline(wl, budget_s):
                 cells_per_s=done * S / el)
 
 
-def cpu_baseline_c(wl, n_loci=4096):
+def cpu_baseline_c(wl, n_loci=16384):
     """The C half of the oracle (oracle/oracle_c.c: counts, statistics, exact HWE test, the three threshold call
     filters, recount of the masked genotypes) on a bounded sample of the same call set read back from the device:
     one core, then all cores with the loci split over OpenMP threads inside the library ('single core
@@ -426,19 +426,29 @@ def cpu_baseline_c(wl, n_loci=4096):
     lc, sc, cv = (np.ascontiguousarray(t[off_all[0]:off_all[n_loci]]) for t in wl.sb.tables[1:4])
     oracle_c.load()
     out = {}
-    for label, nt in (('one_core', 1), ('all_cores', oracle_c.n_cores())):
-        n = n_loci if nt > 1 else max(64, n_loci // 8)
+    for label, nt in (('one_core', 1), ('all_cores', oracle_c.tuned_threads())):
+        n = n_loci if nt > 1 else max(64, n_loci // 16)
         o = (off[:n + 1]).astype(np.int32)
         sl = slice(0, int(off[n]))
-        t0 = time.perf_counter()
-        oracle_c.batch_stats(gt[:n], None, o, lc[sl], sc[sl], cv[sl], n_threads=nt)                        # statSTR
-        g2 = oracle_c.call_filters(gt[:n], [p[:n] for p in planes], wl.filters, dp_plane=0, n_threads=nt)[0]
-        oracle_c.batch_stats(g2, None, o, lc[sl], sc[sl], cv[sl], n_threads=nt)                             # dumpSTR on GT'
-        el = time.perf_counter() - t0
-        out[label] = dict(value=n / el, unit="loci/s", cores=nt, cells_per_s=n * wl.n_samples / el,
-                          sample="%d loci x %d samples, %.1f s" % (n, wl.n_samples, el))
-    out['kind'] = "port (C restatement, oracle/oracle_c.c, OpenMP over loci)"
+        g, pl = np.ascontiguousarray(gt[:n]), [np.ascontiguousarray(p[:n]) for p in planes]
+        # outputs allocated (and touched) before the clock starts: the region times the C code, not numpy's page faults
+        st = (np.zeros(int(off[n]), dtype=np.int32), np.zeros((n, 8), dtype=np.int32), np.zeros((n, 10)))
+        co = (np.zeros_like(g), np.zeros((n, wl.n_samples), dtype=np.uint32))
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            oracle_c.batch_stats(g, None, o, lc[sl], sc[sl], cv[sl], n_threads=nt, out=st)                  # statSTR
+            g2 = oracle_c.call_filters(g, pl, wl.filters, dp_plane=0, n_threads=nt, out=co)[0]
+            oracle_c.batch_stats(g2, None, o, lc[sl], sc[sl], cv[sl], n_threads=nt, out=st)                 # dumpSTR on GT'
+            el = time.perf_counter() - t0
+            best = el if best is None else min(best, el)
+        out[label] = dict(value=n / best, unit="loci/s", cores=nt, cells_per_s=n * wl.n_samples / best,
+                          sample="%d loci x %d samples, %.2f s (best of 2)" % (n, wl.n_samples, best))
+    out['kind'] = "port (C restatement, oracle/oracle_c.c, OpenMP over loci inside the library)"
     out['cpu'] = cpu_model()
+    out['cores_visible'] = oracle_c.n_cores()
+    out['note'] = ("all_cores uses the OpenMP team size that a calibration run found fastest on this host "
+                   "(oracle_c.tuned_threads), not necessarily every visible hardware thread")
     return out
 
 

@@ -98,7 +98,7 @@ def check_step(fetch_inputs, fetch_outputs, n_loci, n_samples, tables, filters, 
         sample_counters [(1+nf), S], totaldp [S], dpmiss [S], bits [L], loc_counters [32]
     Returns a dict of what was covered (loci, calls compared bit for bit, worst float deviation)."""
     off, lc, sc, cv = tables
-    nt = n_threads or oracle_c.n_cores()
+    nt = n_threads or oracle_c.tuned_threads()
     S = n_samples
     nf = len(filters)
     counters = np.zeros((1 + nf, S), dtype=np.int64)

@@ -12,7 +12,6 @@
  * Independent of csrc/: own histogram code, own binomial pmf (lgamma based) and
  * tail summation.
  */
-#define _DEFAULT_SOURCE   /* lgamma_r */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -57,14 +56,22 @@ void orc_locus_counts(const int16_t* gt, int S, int P, int pl, int A, const uint
     out[0] = n_called; out[1] = n_low; out[2] = n_hl; out[3] = n_hs; out[4] = n_bad;
 }
 
+/* ln Gamma(x), x >= 1: Stirling's series above 15 (next term 691 / (360360 x^11) < 1e-17), the recurrence below */
+static double orc_lgamma(double x) {
+    double shift = 0.0;
+    while (x < 15.0) { shift += log(x); x += 1.0; }
+    const double xi = 1.0 / x, x2 = xi * xi;
+    const double ser = xi * (1.0 / 12.0 - x2 * (1.0 / 360.0 - x2 * (1.0 / 1260.0 - x2 * (1.0 / 1680.0 - x2 * (1.0 / 1188.0)))));
+    return (x - 0.5) * log(x) - x + 0.91893853320467274178 + ser - shift;
+}
+
 static double orc_binom_pmf(int64_t k, int64_t n, double p) {
     if (k < 0 || k > n) return 0.0;
     if (p <= 0.0) return k == 0 ? 1.0 : 0.0;
     if (p >= 1.0) return k == n ? 1.0 : 0.0;
-    /* lgamma_r: plain lgamma() writes the global `signgam` on every call -- with the loci split over threads
-     * that one cache line bounces between all cores (measured: 256 threads slower than one) */
-    int sg;
-    double lg = lgamma_r((double)n + 1.0, &sg) - lgamma_r((double)k + 1.0, &sg) - lgamma_r((double)(n - k) + 1.0, &sg);
+    /* own log-gamma: libm's lgamma() writes the global `signgam` on every call (one cache line bouncing between
+     * all cores once the loci are split over threads) and lgamma_r() scaled even worse on the hosts tried */
+    double lg = orc_lgamma((double)n + 1.0) - orc_lgamma((double)k + 1.0) - orc_lgamma((double)(n - k) + 1.0);
     return exp(lg + (double)k * log(p) + (double)(n - k) * log1p(-p));
 }
 static double orc_lower(int64_t k, int64_t n, double p) {

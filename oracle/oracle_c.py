@@ -38,7 +38,40 @@ def n_cores():
     return max(1, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
 
 
-def batch_stats(gt, locus_ploidy, off, lc, sc, cv, n_threads=1):
+_tuned = None
+
+
+def tuned_threads():
+    """The OpenMP team size at which the per-locus work runs fastest on this host (calibrated once on a small random
+    call set): the visible core count is an upper bound only -- containers cap CPU time below it, and hyper-threads
+    or far memory can make a full team slower than a partial one."""
+    global _tuned
+    if _tuned is None:
+        import time
+        rng = np.random.default_rng(0)
+        Lc, S, A = 2048, 2000, 8
+        gt = rng.integers(-1, A, size=(Lc, S, 2)).astype(np.int16)
+        off = (np.arange(Lc + 1) * A).astype(np.int32)
+        lc = np.tile(np.arange(A, dtype=np.uint16), Lc)
+        cv = np.tile(np.arange(A, dtype=np.float64), Lc)
+        cands = sorted({n for n in (1, 2, 4, 8, 16, 32, 48, 64, 96, 128, 192, 256, n_cores()) if n <= n_cores()})
+        best, best_t = 1, None
+        for nt in cands:
+            t = []
+            outb = (np.zeros(Lc * A, dtype=np.int32), np.zeros((Lc, 8), dtype=np.int32), np.zeros((Lc, 10)))
+            for _ in range(3):
+                t0 = time.perf_counter()
+                batch_stats(gt, None, off, lc, lc, cv, n_threads=nt, out=outb)
+                t.append(time.perf_counter() - t0)
+            if best_t is None or min(t) < best_t:
+                best, best_t = nt, min(t)
+        _tuned = best
+    return _tuned
+
+
+def batch_stats(gt, locus_ploidy, off, lc, sc, cv, n_threads=1, out=None):
+    """``out``: optional preallocated (cnt int32 [sumA], oi int32 [L, 8], of float64 [L, 10]) -- the timing legs of
+    bench.py keep numpy's allocation and page faults out of the measured region with it."""
     lib = load()
     gt = np.ascontiguousarray(gt, dtype=np.int16)
     Lc, S, P = gt.shape
@@ -47,9 +80,12 @@ def batch_stats(gt, locus_ploidy, off, lc, sc, cv, n_threads=1):
     sc = np.ascontiguousarray(sc, dtype=np.uint16)
     cv = np.ascontiguousarray(cv, dtype=np.float64)
     lp = None if locus_ploidy is None else np.ascontiguousarray(locus_ploidy, dtype=np.uint8)
-    cnt = np.zeros(int(off[-1]), dtype=np.int32)
-    oi = np.zeros((Lc, 8), dtype=np.int32)
-    of = np.zeros((Lc, 10), dtype=np.float64)
+    if out is not None:
+        cnt, oi, of = out
+    else:
+        cnt = np.zeros(int(off[-1]), dtype=np.int32)
+        oi = np.zeros((Lc, 8), dtype=np.int32)
+        of = np.zeros((Lc, 10), dtype=np.float64)
     if n_threads > 1:
         lib.orc_batch_stats_mt(_p(gt), Lc, S, P, None if lp is None else _p(lp), _p(off), _p(lc), _p(sc), _p(cv),
                                _p(cnt), _p(oi), _p(of), int(n_threads))
@@ -59,7 +95,8 @@ def batch_stats(gt, locus_ploidy, off, lc, sc, cv, n_threads=1):
     return cnt, oi, of
 
 
-def call_filters(gt, planes, filters, dp_plane=-1, locus_ploidy=None, n_threads=1, want_gt=True, want_mask=True):
+def call_filters(gt, planes, filters, dp_plane=-1, locus_ploidy=None, n_threads=1, want_gt=True, want_mask=True,
+                 out=None):
     """orc_call_filters: ``planes`` interleaved [L, S] / [L, S, k] int32 or float32 arrays, ``filters`` dicts with the
     keys of Engine.call_filters (op numbered as TRK_F_*).  Returns (gt_out | None, mask | None, counters [(1+nf), S],
     totaldp [S], dpmiss [S], err [4])."""
@@ -80,8 +117,11 @@ def call_filters(gt, planes, filters, dp_plane=-1, locus_ploidy=None, n_threads=
         farr[k] = _Filter(int(f['op']), int(f['plane_a']), int(f.get('col_a', 0)), int(f.get('plane_b', -1)),
                           int(f.get('col_b', 0)), int(f.get('col_a2', 0)), float(f.get('thr', 0.0)))
     lp = None if locus_ploidy is None else np.ascontiguousarray(locus_ploidy, dtype=np.uint8)
-    gout = np.empty_like(gt) if want_gt else None
-    mask = np.zeros((Lc, S), dtype=np.uint32) if want_mask else None
+    if out is not None:          # preallocated (gt_out, mask)
+        gout, mask = out
+    else:
+        gout = np.empty_like(gt) if want_gt else None
+        mask = np.zeros((Lc, S), dtype=np.uint32) if want_mask else None
     counters = np.zeros((1 + nf, S), dtype=np.int64)
     totaldp = np.zeros(S, dtype=np.int64)
     dpmiss = np.zeros(S, dtype=np.int64)

@@ -30,6 +30,16 @@ def test_library_exports_every_declared_symbol():
     assert sorted(L.EXPORTS) == declared
 
 
+def test_shipped_library_is_built_from_the_sources_next_to_it():
+    """The build leaves the SHA-256 of every source file next to libtrk.so; load() refuses (or rebuilds) a binary
+    whose digest differs, so a stale prebuilt library cannot be what the GPU tests exercise."""
+    L, _ = _lib()
+    assert open(L.LIB_PATH + '.srchash').read().strip() == L.source_digest()
+    mk = open(os.path.join(ROOT, 'trtools_amd', 'csrc', 'Makefile')).read()
+    listed = re.search(r'^SRCS = (.*?)\n\n', mk, flags=re.S | re.M).group(1).replace('\\\n', ' ').split()
+    assert [os.path.normpath(os.path.join('csrc', f)) for f in listed] == [os.path.normpath(f) for f in L._SOURCES]
+
+
 def test_binomtest_host_entry_matches_scipy_vectors():
     L, lib = _lib()
     for k, n, p, pv in load_golden('binomtest_vectors.json')['cases']:

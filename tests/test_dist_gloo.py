@@ -96,3 +96,34 @@ def test_two_rank_sharded_dumpstr_matches_single_process(tmp_path):
         a, b = np.asarray(info1[k], dtype=float), np.asarray(info2[k], dtype=float)
         assert np.array_equal(np.isnan(a), np.isnan(b)), k
         assert np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)]), k
+
+
+def _float_worker(rank, world, port, outfile):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from trtools_amd import dist as tdist
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    info = collections.OrderedDict()
+    info['numcalls'] = np.array([3, 4, 5, 0]) * (rank + 1)
+    # ExpansionHunter's LC is a Float field: per-shard depth sums carry fractions (and one sample is poisoned on rank 1)
+    info['totaldp'] = np.array([10.25, 0.5, 7.125, 0.0]) + rank * np.array([0.5, 0.25, np.nan if rank else 0.0, 0.0])
+    info['f0'] = np.array([1, 0, 2, 0])
+    red = tdist.reduce_sample_info(info, tdist.TorchComm())
+    if rank == 0:
+        with open(outfile, 'wb') as fh:
+            pickle.dump(dict(red), fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_float_depth_sums_keep_their_fraction_across_ranks(tmp_path):
+    """reduce_sample_info cast every rank's float totaldp to int64 before the all-reduce, so a
+    multi-rank dumpSTR run on ExpansionHunter input printed a different meanDP than the single-process run."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'f.pkl')
+    mp.spawn(_float_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    red = pickle.load(open(out, 'rb'))
+    assert red['numcalls'].tolist() == [9, 12, 15, 0] and red['f0'].tolist() == [2, 0, 4, 0]
+    td = red['totaldp']
+    assert td[0] == 10.25 + 10.75 and td[1] == 0.5 + 0.75 and np.isnan(td[2]) and td[3] == 0.0

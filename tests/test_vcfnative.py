@@ -113,13 +113,116 @@ def test_string_field_preparse_kinds():
         assert n > 0
 
 
-def test_ploidy_above_tensor_is_an_error(tmp_path):
-    from trtools_amd import vcfnative
-    p = tmp_path / 't.vcf'
-    p.write_text('##fileformat=VCFv4.1\n##FORMAT=<ID=GT,Number=1,Type=String,Description="g">\n'
-                 '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tA\tB\n'
-                 '1\t5\t.\tA\tAA\t.\t.\t.\tGT\t0/1/1\t0\n')
-    with pytest.raises(ValueError):
-        list(vcfnative.NativeVCFReader(str(p), max_ploidy=2))
-    v = list(vcfnative.NativeVCFReader(str(p), max_ploidy=3))[0]
-    assert v.genotype.array().tolist() == [[0, 1, 1, 0], [0, -2, -2, 0]] and v.ploidy == 3
+def _triploid_vcf(path, n_records=9, n_samples=7, seed=4):
+    """A small GangSTR-style VCF in which diploid, haploid and triploid genotypes mix (record 3 onwards hold 0/1/1)."""
+    rng = np.random.default_rng(seed)
+    with open(path, 'w') as fh:
+        fh.write('##fileformat=VCFv4.1\n##command=GangSTR-2.4 --synthetic\n'
+                 '##INFO=<ID=RU,Number=1,Type=String,Description="motif">\n'
+                 '##INFO=<ID=END,Number=1,Type=Integer,Description="end">\n'
+                 '##INFO=<ID=PERIOD,Number=1,Type=Integer,Description="period">\n'
+                 '##INFO=<ID=REF,Number=1,Type=Float,Description="ref copies">\n'
+                 '##FORMAT=<ID=GT,Number=1,Type=String,Description="g">\n'
+                 '##FORMAT=<ID=DP,Number=1,Type=Integer,Description="d">\n##contig=<ID=chr1>\n'
+                 '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t' +
+                 '\t'.join('S%d' % i for i in range(n_samples)) + '\n')
+        for r in range(n_records):
+            ref = 'ac' * (5 + r)
+            alts = ['ac' * (6 + r), 'ac' * (3 + r)]
+            cols = []
+            for s_ in range(n_samples):
+                pl = 2 if r < 3 else int(rng.choice([1, 2, 3]))
+                g = [str(x) if x >= 0 else '.' for x in rng.integers(-1, 3, size=pl)]
+                cols.append('/'.join(g) + ':%d' % rng.integers(1, 40))
+            fh.write('chr1\t%d\t.\t%s\t%s\t.\t.\tRU=ac;END=%d;PERIOD=2;REF=%d\tGT:DP\t%s\n' % (
+                100 + 50 * r, ref, ','.join(alts), 100 + 50 * r + len(ref) - 1, 5 + r, '\t'.join(cols)))
+
+
+def test_ploidy_above_tensor_is_retried_with_a_wider_one(tmp_path):
+    """A genotype with more haplotypes than the batch tensor has columns: the reader reports it WITHOUT consuming
+    the lines and the wrapper decodes them again with twice the columns (the reference's cyvcf2 sizes the genotype
+    array per record) -- whatever the batch size, i.e. wherever in a batch the first wide record falls."""
+    from trtools_amd import vcfio, vcfnative
+    p = str(tmp_path / 't.vcf')
+    _triploid_vcf(p)
+    py = list(vcfio.VCFReader(p))
+    assert max(v.ploidy for v in py) == 3
+    for br in (None, 1, 2, 4):
+        nat = list(vcfnative.NativeVCFReader(p, batch_records=br))      # default max_ploidy = 2
+        assert len(nat) == len(py)
+        for x, y in zip(py, nat):
+            assert np.array_equal(x.genotype.array(), y.genotype.array()) and x.ploidy == y.ploidy
+            assert np.array_equal(x.format('DP'), y.format('DP')) and str(x) == str(y)
+    one = tmp_path / 'one.vcf'
+    one.write_text('##fileformat=VCFv4.1\n##FORMAT=<ID=GT,Number=1,Type=String,Description="g">\n'
+                   '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tA\tB\n'
+                   '1\t5\t.\tA\tAA\t.\t.\t.\tGT\t0/1/1/0/1\t0\n')
+    v = list(vcfnative.NativeVCFReader(str(one)))[0]          # 2 -> 4 -> 8 columns
+    assert v.genotype.array().tolist() == [[0, 1, 1, 0, 1, 0], [0, -2, -2, -2, -2, 0]] and v.ploidy == 5
+
+
+def test_triploid_records_through_the_statstr_cli(tmp_path):
+    """with the native reader as the default, a VCF holding 0/1/1 genotypes made statSTR abort.  The
+    CLI (oracle-backed compute seam on CPU) now gives the same table with either reader."""
+    import argparse
+    import oracle_compute
+    from trtools_amd import runtime
+    from trtools_amd.statSTR import statSTR
+    p = str(tmp_path / 't.vcf')
+    _triploid_vcf(p)
+    outs = {}
+    old = runtime.set_compute(oracle_compute.OracleCompute())
+    try:
+        for native in ('1', '0'):
+            os.environ['TRK_NATIVE_VCF'] = native
+            out = str(tmp_path / ('o' + native))
+            args = argparse.Namespace(
+                vcf=p, out=out, vcftype='gangstr', samples=None, sample_prefixes=None, plot_afreq=False, region=None,
+                thresh=True, afreq=True, acount=True, hwep=False, het=True, entropy=True, mean=True, mode=True,
+                var=True, numcalled=True, use_length=False, precision=4, nalleles=True, nalleles_thresh=0.1,
+                only_passing=False)
+            assert statSTR.main(args) == 0
+            outs[native] = open(out + '.tab').read()
+    finally:
+        os.environ.pop('TRK_NATIVE_VCF', None)
+        runtime.set_compute(old)
+    assert outs['1'] == outs['0'] and outs['1'].count('\n') == 10
+
+
+def test_corrupt_bgzf_blocks_are_refused(tmp_path):
+    """A BGZF header is not trusted: impossible block sizes, a missing BC subfield and inflated sizes above 64 KiB
+    are reported as corrupt instead of being used as lengths."""
+    import struct
+    from trtools_amd import bgzf, tabix, vcfnative
+    src = os.path.join(GOLDEN, 'dumpstr_synth', 'synth_hipstr.vcf')
+    good = str(tmp_path / 'good.vcf.gz')
+    text = open(src, 'rb').read()
+    with bgzf.BgzfWriter(good, threads=1) as w:      # small blocks: the file has several
+        for i in range(0, len(text), 9000):
+            w.write(text[i:i + 9000])
+            w._pending.append(bytes(w._buf))
+            w._buf = bytearray()
+    raw = bytearray(open(good, 'rb').read())
+    assert len(list(vcfnative.NativeVCFReader(good))) == 40 and len(list(tabix._blocks(good))) >= 5
+    b2 = struct.unpack_from('<H', raw, 16)[0] + 1            # offset of the second block (the first one decides
+    bsize2 = struct.unpack_from('<H', raw, b2 + 16)[0] + 1   # between BGZF and plain gzip when the file is opened)
+
+    def broken(name, edit):
+        b = bytearray(raw)
+        edit(b)
+        path = str(tmp_path / name)
+        open(path, 'wb').write(bytes(b))
+        return path
+
+    cases = {
+        'tiny_bsize.vcf.gz': lambda b: struct.pack_into('<H', b, b2 + 16, 5),     # BSIZE smaller than its own header
+        'no_bc.vcf.gz': lambda b: b.__setitem__(slice(b2 + 12, b2 + 14), b'XY'),   # extra field without BC
+        'huge_isize.vcf.gz': lambda b: struct.pack_into('<I', b, b2 + bsize2 - 4, 1 << 30),
+        'not_gzip.vcf.gz': lambda b: b.__setitem__(b2 + 1, 0),
+    }
+    for name, edit in cases.items():
+        path = broken(name, edit)
+        with pytest.raises((OSError, ValueError)):
+            list(vcfnative.NativeVCFReader(path))
+        with pytest.raises(ValueError):
+            list(tabix._blocks(path))

@@ -136,6 +136,55 @@ class TrkError(RuntimeError):
     pass
 
 
+# the sources libtrk.so is built from, in the order csrc/Makefile hashes them
+_SOURCES = ['csrc/trk_api.hip', 'csrc/trk_assoc.hip', 'csrc/trk_binom.h', 'csrc/trk_internal.h', 'csrc/trk_kernels.hip',
+            'csrc/trk_student.h', 'csrc/trk_vcf.cpp', '../include/trk.h', '../include/trk_vcf.h']
+
+
+def source_digest():
+    import hashlib
+    h = hashlib.sha256()
+    for rel in _SOURCES:
+        with open(os.path.join(_HERE, rel), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _ensure_current():
+    """A prebuilt libtrk.so must come from the sources next to it: the build leaves their SHA-256 in
+    libtrk.so.srchash.  On a mismatch the library is rebuilt (hipcc cross-compiles anywhere); if that is not
+    possible this raises rather than run a stale binary.  TRK_SKIP_STALE_CHECK=1 skips the check."""
+    if os.environ.get('TRK_SKIP_STALE_CHECK'):
+        return
+    try:
+        want = source_digest()
+    except OSError:
+        return                      # a binary-only install: nothing to compare against
+    try:
+        have = open(LIB_PATH + '.srchash').read().strip()
+    except OSError:
+        have = None
+    if have == want:
+        return
+    import fcntl
+    import shutil
+    import subprocess
+    if shutil.which('hipcc') is None or shutil.which('make') is None:
+        raise TrkError("libtrk.so is older than its sources (digest %s, sources %s) and cannot be rebuilt here "
+                       "(no hipcc/make)" % (have, want))
+    with open(os.path.join(_HERE, 'csrc', '.build.lock'), 'w') as lock:     # one builder among parallel ranks
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            have = open(LIB_PATH + '.srchash').read().strip()
+        except OSError:
+            have = None
+        if have != want:
+            r = subprocess.run(['make', '-C', os.path.join(_HERE, 'csrc'), '-j4'], stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT)
+            if r.returncode != 0:
+                raise TrkError("libtrk.so is stale and the rebuild failed:\n%s" % r.stdout.decode()[-2000:])
+
+
 def load():
     """dlopen libtrk.so and declare signatures.  Raises if it was not built."""
     global _lib
@@ -145,6 +194,7 @@ def load():
         raise TrkError("libtrk.so is not built (%s). Run `make -C trtools_amd/csrc` or "
                        "`python -c 'import __graft_entry__ as g; g.build()'`. "
                        "There is no CPU fallback." % LIB_PATH)
+    _ensure_current()
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, u64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
     P = C.POINTER

@@ -140,17 +140,29 @@ class DeviceCompute:
         n_pad = self._n_pad(hb)
         if n_pad:   # padding samples are outside the regression set and carry zeros in every vector
             sin = self._pad(np.ones(hb.gt.shape[1], dtype=np.uint8) if sin is None else sin, n_pad, 0, 0)
-        if not hasattr(self, '_assoc_vec') or self._assoc_vec[0] is not vec:
-            if hasattr(self, '_assoc_vec'):
-                self._free(self._assoc_vec[1], self._assoc_vec[2])
-            self._assoc_vec = (vec, eng.upload(np.ascontiguousarray(self._pad(vec, n_pad, 1, 0.0), dtype=np.float64)),
-                               eng.upload(sin) if sin is not None else None)
-        _, vec_d, sin_d = self._assoc_vec
+        # the trait vectors are the same for every batch of a run: uploaded once and kept, keyed on their CONTENT
+        # (shape + checksum -- an array reused with other values, or edited in place, is uploaded again); the small
+        # sample mask travels with every call
+        import zlib
+        vec = np.ascontiguousarray(vec, dtype=np.float64)
+        key = (vec.shape, n_pad, zlib.crc32(vec.view(np.uint8).reshape(-1)))
+        if getattr(self, '_assoc_vec', (None, None))[0] != key:
+            if getattr(self, '_assoc_vec', None) is not None:
+                self._free(self._assoc_vec[1])
+            self._assoc_vec = (key, eng.upload(np.ascontiguousarray(self._pad(vec, n_pad, 1, 0.0), dtype=np.float64)))
+        vec_d = self._assoc_vec[1]
+        sin_d = eng.upload(sin) if sin is not None else None
         alen_d, rcls_d = eng.upload(alen), eng.upload(rcls)
         res = eng.assoc_scan(b, vec_d, alen_d, rcls_d, sample_in=sin_d, non_major_cutoff=non_major_cutoff)
         out = AssocHost(res.locus_int.get(), res.locus_f64.get(), res.allele_count.get())
-        self._free(b, alen_d, rcls_d, res.locus_int, res.locus_f64, res.allele_count)
+        self._free(b, alen_d, rcls_d, sin_d, res.locus_int, res.locus_f64, res.allele_count)
         return out
+
+    def close(self):
+        """Release what the object keeps on the device between calls."""
+        if getattr(self, '_assoc_vec', None) is not None:
+            self._free(self._assoc_vec[1])
+            self._assoc_vec = None
 
     def assoc_dosage_batch(self, hb, vec, sample_in, ap1, ap2, precision=2):
         """associaTR --beagle-dosages scan of one batch (trk_assoc_scan_dosage): ap1/ap2 [L, S, K] float32.

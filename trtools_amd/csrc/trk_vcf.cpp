@@ -117,14 +117,42 @@ struct Source {
         size_t p = cpos, total = 0;
         while (p + 18 <= cbuf.size()) {
             const unsigned char* h = cbuf.data() + p;
-            if (h[0] != 0x1f || h[1] != 0x8b) {
+            // gzip member with an extra field that holds the 'BC' subfield (BSIZE).  Nothing of the header is
+            // trusted: a block must have room for its own header, extra field, a deflate stream and the trailer,
+            // and inflates to at most 64 KiB (the BGZF limit) -- a corrupt or hostile file must not turn into an
+            // out-of-bounds read of cbuf or a multi-gigabyte allocation.
+            if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) {
                 err = "corrupt BGZF block header";
                 return false;
             }
-            size_t bsize = ((size_t)h[16] | ((size_t)h[17] << 8)) + 1;
+            const size_t xlen = (size_t)h[10] | ((size_t)h[11] << 8);
+            if (p + 12 + xlen > cbuf.size()) {
+                if (xlen > 1024) {   // htslib writes 6; anything this long is not BGZF
+                    err = "corrupt BGZF block (extra field)";
+                    return false;
+                }
+                break;               // the rest of the header is not in the buffer yet
+            }
+            size_t bsize = 0;
+            for (size_t q = 12; q + 4 <= 12 + xlen;) {
+                const size_t slen = (size_t)h[q + 2] | ((size_t)h[q + 3] << 8);
+                if (h[q] == 'B' && h[q + 1] == 'C' && slen == 2 && q + 6 <= 12 + xlen) {
+                    bsize = ((size_t)h[q + 4] | ((size_t)h[q + 5] << 8)) + 1;
+                    break;
+                }
+                q += 4 + slen;
+            }
+            if (bsize == 0 || bsize < 12 + xlen + 2 + 8) {
+                err = "corrupt BGZF block (no BC subfield / impossible block size)";
+                return false;
+            }
             if (p + bsize > cbuf.size()) break;
             size_t isize = (size_t)h[bsize - 4] | ((size_t)h[bsize - 3] << 8) | ((size_t)h[bsize - 2] << 16) |
                            ((size_t)h[bsize - 1] << 24);
+            if (isize > 65536) {
+                err = "corrupt BGZF block (inflated size above 64 KiB)";
+                return false;
+            }
             blks.push_back({p, bsize, isize, total});
             total += isize;
             p += bsize;
@@ -579,7 +607,6 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
         scan = nl + 1;
     }
     const int n = (int)v->line_off.size();
-    v->pos = scan;
     v->field_off.assign((size_t)n * 10, 0);
     RecordJob job;
     job.v = v;
@@ -601,10 +628,13 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
     runner();
     for (auto& t : th) t.join();
     if (job.error) {
+        // nothing is consumed: the same lines are decoded again by the next call (the caller retries a ploidy
+        // overflow with a wider genotype tensor, vcfnative.py)
         v->err = job.error == 2 ? "a genotype has more haplotypes than max_ploidy"
                                 : "a record has fewer sample columns than the header";
         return 5;
     }
+    v->pos = scan;
     out->n_records = n;
     out->text = v->buf.data();
     out->line_off = v->line_off.data();

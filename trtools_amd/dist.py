@@ -79,20 +79,24 @@ class RcclComm:
 
 def reduce_sample_info(sample_info, comm):
     """Cohort-wide ``sample_info`` from per-shard ones (dumpSTR.py:1251-1259 semantics:
-    integer counters add; totaldp adds and stays nan once any shard poisoned it)."""
+    integer counters add; totaldp adds and stays nan once any shard poisoned it).  totaldp is a float sum
+    (ExpansionHunter's LC depth is a Float field): every rank's float64 partial sums are gathered and added on the
+    host in rank order -- the order the single-process run meets the records in -- never cast to integers."""
     keys = list(sample_info.keys())
     ints = np.stack([np.asarray(sample_info[k], dtype=np.int64) for k in keys if k != 'totaldp'])
-    td = np.asarray(sample_info['totaldp'], dtype=float)
+    td = np.asarray(sample_info['totaldp'], dtype=np.float64)
     poisoned = np.isnan(td)
-    extra = np.stack([np.where(poisoned, 0, td).astype(np.int64), poisoned.astype(np.int64)])
-    red = comm.allreduce_sum_i64(np.concatenate([ints, extra]))
+    red = comm.allreduce_sum_i64(np.concatenate([ints, poisoned.astype(np.int64)[None, :]]))
+    parts = comm.allgather_bytes(np.frombuffer(np.where(poisoned, 0.0, td).astype(np.float64).tobytes(), dtype=np.uint8))
+    total = np.zeros(td.shape[0], dtype=np.float64)
+    for p in parts:
+        total = total + np.frombuffer(p.tobytes(), dtype=np.float64)
     out = type(sample_info)()
     it = iter(red[:len(keys) - 1])
     for k in keys:
         if k == 'totaldp':
-            v = red[-2].astype(float)
-            v[red[-1] > 0] = np.nan
-            out[k] = v
+            total[red[-1] > 0] = np.nan
+            out[k] = total
         else:
             out[k] = next(it)
     return out

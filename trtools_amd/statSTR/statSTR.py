@@ -279,7 +279,10 @@ def main(args):
                 return 1
             outf = sys.stdout
         else:
-            outf = open(args.out + ".tab", "w")
+            # only rank 0 writes the table: the other ranks of a sharded run must not even open it (mode "w" would
+            # truncate what rank 0 has flushed by then)
+            from .. import dist as _dist
+            outf = open(args.out + ".tab" if _dist.get_comm()[0] == 0 else os.devnull, "w")
         shard = _ShardedOut(outf)
         if shard.rank == 0:
             outf.write("\t".join(header) + "\n")

@@ -118,14 +118,28 @@ def _blocks(path):
     with open(path, 'rb') as fh:
         coff = 0
         while True:
-            hdr = fh.read(18)
-            if len(hdr) < 18:
+            hdr = fh.read(12)
+            if len(hdr) < 12:
                 return
-            if hdr[:2] != b'\x1f\x8b' or hdr[12:14] != b'BC':
+            if hdr[:3] != b'\x1f\x8b\x08' or not hdr[3] & 4:
                 raise ValueError("%s is not BGZF" % path)
-            bsize = struct.unpack_from('<H', hdr, 16)[0] + 1
-            body = fh.read(bsize - 18)
-            data = zlib.decompress(body[:-8], -15) if len(body) > 8 else b''
+            xlen = struct.unpack_from('<H', hdr, 10)[0]
+            extra = fh.read(xlen)
+            bsize, q = 0, 0
+            while q + 4 <= len(extra):          # the 'BC' subfield need not be the first one
+                slen = struct.unpack_from('<H', extra, q + 2)[0]
+                if extra[q:q + 2] == b'BC' and slen == 2 and q + 6 <= len(extra):
+                    bsize = struct.unpack_from('<H', extra, q + 4)[0] + 1
+                    break
+                q += 4 + slen
+            if len(extra) < xlen or bsize < 12 + xlen + 2 + 8:
+                raise ValueError("%s: corrupt BGZF block at offset %d" % (path, coff))
+            body = fh.read(bsize - 12 - xlen)
+            if len(body) < bsize - 12 - xlen:
+                raise ValueError("%s: truncated BGZF block at offset %d" % (path, coff))
+            if struct.unpack_from('<I', body, len(body) - 4)[0] > 65536:
+                raise ValueError("%s: corrupt BGZF block at offset %d (inflated size)" % (path, coff))
+            data = zlib.decompress(body[:-8], -15)
             yield coff, bsize, data
             coff += bsize
 

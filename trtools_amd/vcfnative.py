@@ -122,8 +122,13 @@ class NativeVCFReader(vcfio.VCFReader):
             b.planes = C.cast(parr, C.POINTER(C.c_void_p))
             rc = self._lib.trk_vcf_read_batch(self._h, n, P, C.byref(b))
             if rc == 5 and b'haplotypes' in self._lib.trk_vcf_last_error(self._h):
-                raise ValueError("a record of %s has ploidy above %d: reopen with a larger max_ploidy"
-                                 % (self.path, P))
+                # a genotype with more haplotypes than the tensor has columns (0/1/1 in a file read as diploid):
+                # the reader has consumed nothing, decode the same lines again with a wider tensor (cyvcf2 sizes
+                # its genotype array per record; the kernels take any ploidy up to 8)
+                if P >= 64:
+                    raise ValueError("a record of %s has more than 64 haplotypes per genotype" % self.path)
+                P = self._max_ploidy = 2 * P
+                continue
             if rc != 0:
                 raise ValueError(self._lib.trk_vcf_last_error(self._h).decode())
             break
