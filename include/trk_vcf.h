@@ -125,6 +125,58 @@ typedef struct {
 int trk_vcf_decode_formats(const char* samples, int64_t len, int32_t n_samples, int32_t n_fields,
                            trk_vcf_decode* fields, int32_t pass);
 
+/* ---- batch harmonisation + statSTR rows -------------------------------------------------------
+ * The host side of the per-locus hot path without one Python object per record ("one call per batch
+ * of loci").  For the records of a batch as trk_vcf_read_batch left them:
+ *
+ * trk_vcf_harmonize  what the reference derives per record in _HarmonizeHipSTRRecord / _HarmonizeGangSTRRecord /
+ *   _HarmonizeAdVNTRRecord and TRRecord.__init__ (tr_harmonizer.py:303-408, 693-773): upper-cased alleles, HipSTR's
+ *   flank trim REF[START-POS : END-POS+1-len(REF)] (Python slice semantics), allele lengths len(allele) / len(motif)
+ *   (HipSTR: PERIOD, GangSTR / adVNTR: len(RU)) -- and from them the class tables of trk_batch (include/trk.h:
+ *   allele_off, len_class, str_class, len_class_value) plus the sorted distinct sequences (the keys of
+ *   GetAlleleCounts, tr_harmonizer.py:1495-1499).  Records it does not cover (a missing mandatory INFO field,
+ *   symbolic alleles, PopSTR / ExpansionHunter input) get status 1 and n_python counts them: the caller then runs the
+ *   batch through the Python harmoniser, which raises the reference's errors.
+ * trk_vcf_statstr_rows  the text of statSTR's output rows (statSTR.py:586-629) from the device results of the batch:
+ *   chrom, POS, POS + len(ref allele), then per enabled statistic and sample group the columns in the reference's
+ *   order and formats ('{:.<precision>}' floats, 'nan', 'key:%.3f' / 'key:%i' lists in sorted key order, keys being
+ *   sequences or str(numpy.float64) lengths).  err_kind: 1 / 2 the reference raises ValueError / IndexError in the
+ *   HWE test of locus err_locus, 3 a genotype index beyond the record's alleles.
+ * All returned pointers are owned by the reader and stay valid until its next trk_vcf_read_batch / harmonize call. */
+enum { TRK_VT_GANGSTR = 0, TRK_VT_HIPSTR = 1, TRK_VT_ADVNTR = 2 };
+typedef struct {
+    int32_t n_records;
+    int32_t n_python;              /* records with status != 0                                            */
+    int64_t n_alleles_total;
+    const int32_t* allele_off;     /* [n + 1]                                                             */
+    const uint16_t* len_class;     /* [sumA]                                                              */
+    const uint16_t* str_class;     /* [sumA]                                                              */
+    const double* len_class_value; /* [sumA] length of length-class c of locus l at allele_off[l] + c     */
+    const double* allele_len;      /* [sumA] length by allele INDEX (GetLengthGenotypes' LUT)             */
+    const int64_t* pos;            /* [n] VCF POS                                                         */
+    const int64_t* end;            /* [n] POS + len(ref allele)                                           */
+    const uint8_t* passing;        /* [n] FILTER is '.' or 'PASS'                                          */
+    const uint8_t* status;         /* [n] 0 harmonised here, 1 needs the Python harmoniser                */
+    const char* keys;              /* distinct upper-cased sequences, locus by locus in sorted order      */
+    const int64_t* key_off;        /* [sumA + 1] key c of locus l: keys[key_off[allele_off[l] + c] .. +1)  */
+    const int32_t* n_str_classes;  /* [n]                                                                 */
+    const int32_t* n_len_classes;  /* [n]                                                                 */
+} trk_vcf_harmonized;
+int trk_vcf_harmonize(trk_vcf* v, const trk_vcf_batch* b, int vcftype, trk_vcf_harmonized* out);
+
+enum { TRK_SS_THRESH = 1, TRK_SS_AFREQ = 2, TRK_SS_ACOUNT = 4, TRK_SS_NALLELES = 8, TRK_SS_HWEP = 16, TRK_SS_HET = 32,
+       TRK_SS_ENTROPY = 64, TRK_SS_MEAN = 128, TRK_SS_MODE = 256, TRK_SS_VAR = 512, TRK_SS_NUMCALLED = 1024 };
+typedef struct {
+    int32_t n_groups, precision, use_length, flags;
+    const int32_t* allele_count;   /* host copies of trk_stats_out: [G, sumA]                              */
+    const int32_t* locus_int;      /* [G, n, 12]                                                           */
+    const double* locus_f64;       /* [G, n, 12]                                                           */
+} trk_vcf_statstr;
+/* Returns the number of bytes written, -(bytes needed) when cap is too small, INT64_MIN for bad arguments.  `skip`
+ * ([n], may be NULL): records left out (--only-passing).                                                       */
+int64_t trk_vcf_statstr_rows(const trk_vcf_batch* b, const trk_vcf_harmonized* h, const trk_vcf_statstr* in,
+                             const uint8_t* skip, char* out, int64_t cap, int32_t* err_locus, int32_t* err_kind);
+
 #ifdef __cplusplus
 }
 #endif

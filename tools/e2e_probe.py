@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 ap = argparse.ArgumentParser()
 ap.add_argument('--loci', type=int, default=2000)
-ap.add_argument('--samples', type=int, default=2000)
+ap.add_argument('--samples', type=int, default=5000)
 ap.add_argument('--out', default='/tmp/e2e')
 ap.add_argument('--no-gpu', action='store_true')
 a = ap.parse_args()
@@ -56,8 +56,18 @@ if not a.no_gpu:
                        plot_afreq=False, region=None, thresh=True, afreq=True, acount=True, hwep=True, het=True,
                        entropy=True, mean=True, mode=True, var=True, numcalled=True, use_length=False, precision=4,
                        nalleles=True, nalleles_thresh=0.01, only_passing=False)
-    t = time.time(); rc = statSTR.main(ns); t4 = time.time() - t
-    print("statSTR CLI end to end (11 stats): rc=%d %6.2fs  %.0f loci/s  %.2e cells/s" % (rc, t4, a.loci / t4, cells / t4))
+    for mode in ('1', '1', '0'):
+        os.environ['TRK_STATSTR_BATCH'] = mode
+        t = time.time(); rc = statSTR.main(ns); t4 = time.time() - t
+        print("statSTR CLI end to end (11 stats, %s path): rc=%d %6.3fs  %.0f loci/s  %.2e cells/s" % (
+            'batch' if mode == '1' else 'per-record', rc, t4, a.loci / t4, cells / t4))
+        if mode == '1':
+            os.replace(ns.out + '.tab', ns.out + '.batch.tab')
+    print("batch path table == per-record table:", open(ns.out + '.batch.tab').read() == open(ns.out + '.tab').read())
+    os.environ['TRK_STATSTR_BATCH'] = '1'
+    os.environ['TRK_VCF_TIMING'] = '1'
+    statSTR.main(ns)
+    del os.environ['TRK_VCF_TIMING']
     if os.environ.get('E2E_PROFILE'):
         import cProfile, pstats
         pr = cProfile.Profile(); pr.enable(); statSTR.main(ns); pr.disable()

@@ -19,13 +19,35 @@ class HostBatch:
         self.gt = np.ascontiguousarray(gt, dtype=np.int16)
         self.n_loci, self.n_samples, self.ploidy = self.gt.shape
         self.locus_ploidy = np.ascontiguousarray(locus_ploidy, dtype=np.uint8)
-        self.allele_lens = allele_lens
-        self.allele_strs = allele_strs
+        self._lens, self._strs, self._lists = allele_lens, allele_strs, None
         self.allele_off, self.len_class, self.str_class, self.len_class_value = \
             pack_alleles(allele_lens, allele_strs)
         self.max_alleles = int(np.max(np.diff(self.allele_off))) if self.n_loci else 0
         self.group_bits = None if group_bits is None else np.ascontiguousarray(group_bits, dtype=np.uint8)
         self.n_groups = n_groups if group_bits is not None else 1
+
+    @classmethod
+    def from_tables(cls, gt, locus_ploidy, allele_off, len_class, str_class, len_class_value, group_bits=None,
+                    n_groups=1, lists=None):
+        """A HostBatch whose class tables were computed elsewhere (the native batch harmoniser,
+        vcfnative.RawBatch.harmonize): no per-locus Python work.  ``lists``: a callable returning
+        (allele_lens, allele_strs) for the few users that want the per-locus Python lists (the oracle-backed
+        compute stand-in of the tests)."""
+        hb = cls.__new__(cls)
+        hb.gt = gt if (gt.dtype == np.int16 and gt.flags['C_CONTIGUOUS']) else np.ascontiguousarray(gt, dtype=np.int16)
+        hb.n_loci, hb.n_samples, hb.ploidy = hb.gt.shape
+        hb.locus_ploidy = np.ascontiguousarray(locus_ploidy, dtype=np.uint8)
+        hb.allele_off, hb.len_class, hb.str_class, hb.len_class_value = allele_off, len_class, str_class, len_class_value
+        hb.max_alleles = int(np.max(np.diff(allele_off))) if hb.n_loci else 0
+        hb.group_bits = None if group_bits is None else np.ascontiguousarray(group_bits, dtype=np.uint8)
+        hb.n_groups = n_groups if group_bits is not None else 1
+        hb._lists = lists
+        hb._lens = hb._strs = None
+        return hb
+
+    def _materialise(self):
+        if self._lens is None:
+            self._lens, self._strs = self._lists()
 
     def class_keys(self, l, use_length):
         """Sorted distinct allele representations of locus ``l`` and the class of every index."""
@@ -37,6 +59,20 @@ class HostBatch:
         ranks = self.str_class[o:e]
         keys = sorted(set(self.allele_strs[l]))
         return [np.str_(k) for k in keys], ranks
+
+
+def _lists_property(name):
+    def get(self):
+        self._materialise() if getattr(self, '_lists', None) is not None else None
+        return getattr(self, name)
+
+    def set_(self, value):
+        setattr(self, name, value)
+    return property(get, set_)
+
+
+HostBatch.allele_lens = _lists_property('_lens')
+HostBatch.allele_strs = _lists_property('_strs')
 
 
 def genotype_matrix(vcfrecord):

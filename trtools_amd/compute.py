@@ -44,6 +44,10 @@ class DeviceCompute:
         from .engine import Engine
         self.eng = engine if engine is not None else Engine(device)
 
+    def host_buffer(self, nbytes):
+        """Pinned staging memory for the native reader's batch arrays (Engine.host_buffer)."""
+        return self.eng.host_buffer(nbytes)
+
     @staticmethod
     def _n_pad(hb):
         """Samples to append so that a diploid row is a multiple of four samples = 16-byte aligned: the streaming

@@ -3,10 +3,13 @@
 // reference call sites it stands in for (cyvcf2 behind trtools/utils/utils.py:19-67).
 #include <unistd.h>
 #include <zlib.h>
+#include <dlfcn.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <atomic>
 #include <charconv>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -25,6 +28,91 @@ namespace {
 constexpr int32_t INT_MISSING = INT32_MIN;
 constexpr int32_t INT_VECTOR_END = INT32_MIN + 1;
 std::string g_open_error;
+
+// ---------------------------------------------------------------------------------------
+// The decompressed text: a growable byte buffer WITHOUT value initialisation (std::string::resize zero-fills,
+// i.e. touches every new page on one thread before the inflate workers get to write it) that grows by realloc
+// (glibc remaps large blocks instead of copying them) and asks for huge pages.  At 120 MB of text per batch the
+// zero-fill, the page faults and the doubling copies of a std::string were most of the reader's time.
+// ---------------------------------------------------------------------------------------
+class TextBuf {
+    char* p_ = nullptr;
+    size_t n_ = 0, cap_ = 0;
+
+public:
+    static constexpr size_t npos = std::string::npos;
+    TextBuf() = default;
+    TextBuf(const TextBuf&) = delete;
+    TextBuf& operator=(const TextBuf&) = delete;
+    ~TextBuf() { free(p_); }
+    size_t size() const { return n_; }
+    const char* data() const { return p_; }
+    char* data() { return p_; }
+    char& operator[](size_t i) { return p_[i]; }
+    const char& operator[](size_t i) const { return p_[i]; }
+    void reserve(size_t c) {
+        if (c <= cap_) return;
+        size_t nc = std::max<size_t>(c, cap_ + cap_ / 2);
+        nc = (nc + ((size_t)1 << 21) - 1) & ~(((size_t)1 << 21) - 1);
+        char* q = static_cast<char*>(realloc(p_, nc));
+        if (!q) throw std::bad_alloc();
+        p_ = q;
+        cap_ = nc;
+#ifdef MADV_HUGEPAGE
+        (void)madvise(p_, cap_, MADV_HUGEPAGE);
+#endif
+    }
+    void resize(size_t n) {   // new bytes are NOT initialised
+        reserve(n);
+        n_ = n;
+    }
+    void clear() { n_ = 0; }
+    void push_back(char c) {
+        reserve(n_ + 1);
+        p_[n_++] = c;
+    }
+    void erase(size_t pos, size_t n) {   // only ever used on the consumed front
+        if (pos != 0 || n == 0) return;
+        n = std::min(n, n_);
+        memmove(p_, p_ + n, n_ - n);
+        n_ -= n;
+    }
+    size_t find(char c, size_t from) const {
+        if (from >= n_) return npos;
+        const void* r = memchr(p_ + from, c, n_ - from);
+        return r ? (size_t)(static_cast<const char*>(r) - p_) : npos;
+    }
+    int compare(size_t pos, size_t n, const char* s) const {
+        const size_t m = strlen(s);
+        const size_t have = pos < n_ ? std::min(n, n_ - pos) : 0;
+        const int c = memcmp(p_ + pos, s, std::min(have, m));
+        return c ? c : (have < m ? -1 : (have > m ? 1 : 0));
+    }
+    std::string substr(size_t pos, size_t n) const { return std::string(p_ + pos, std::min(n, n_ - pos)); }
+};
+
+// libdeflate (2-3x zlib's inflate rate) is in the image as a runtime library without its header: bound by hand at
+// run time, zlib when it is absent.
+struct Deflater {
+    void* handle = nullptr;
+    void* (*alloc)() = nullptr;
+    int (*decompress)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+    void (*release)(void*) = nullptr;
+    Deflater() {
+        if (getenv("TRK_VCF_ZLIB")) return;
+        handle = dlopen("libdeflate.so.0", RTLD_NOW);
+        if (!handle) return;
+        alloc = reinterpret_cast<void* (*)()>(dlsym(handle, "libdeflate_alloc_decompressor"));
+        decompress = reinterpret_cast<int (*)(void*, const void*, size_t, void*, size_t, size_t*)>(
+            dlsym(handle, "libdeflate_deflate_decompress"));
+        release = reinterpret_cast<void (*)(void*)>(dlsym(handle, "libdeflate_free_decompressor"));
+        if (!alloc || !decompress || !release) decompress = nullptr;
+    }
+};
+const Deflater& deflater() {
+    static Deflater d;
+    return d;
+}
 
 // ---------------------------------------------------------------------------------------
 // input: plain text, gzip stream, or BGZF (block-parallel inflate)
@@ -73,7 +161,7 @@ struct Source {
     }
 
     // append at least `want` decompressed bytes to out (fewer only at end of file)
-    bool fill(std::string& out, size_t want, std::string& err) {
+    bool fill(TextBuf& out, size_t want, std::string& err) {
         size_t start = out.size();
         while (!eof && out.size() - start < want) {
             if (plain || gz) {
@@ -94,7 +182,7 @@ struct Source {
         return true;
     }
 
-    bool fill_bgzf(std::string& out, size_t want, std::string& err) {
+    bool fill_bgzf(TextBuf& out, size_t want, std::string& err) {
         // top up the compressed buffer
         if (cpos > 0 && cpos == cbuf.size()) {
             cbuf.clear();
@@ -170,11 +258,25 @@ struct Source {
         std::atomic<size_t> next{0};
         std::atomic<bool> bad{false};
         auto work = [&]() {
+            void* ld = deflater().decompress ? deflater().alloc() : nullptr;   // one decompressor per worker
+            struct Rel {
+                void* p;
+                ~Rel() { if (p) deflater().release(p); }
+            } rel{ld};
             for (;;) {
                 size_t i = next.fetch_add(1);
                 if (i >= blks.size()) break;
                 const Blk& b = blks[i];
                 if (b.isize == 0) continue;
+                if (ld) {
+                    const unsigned char* h = cbuf.data() + b.off;
+                    const size_t xlen = (size_t)h[10] | ((size_t)h[11] << 8);
+                    size_t got = 0;
+                    if (deflater().decompress(ld, h + 12 + xlen, b.csize - 12 - xlen - 8, &out[base + b.dst], b.isize,
+                                              &got) != 0 || got != b.isize)
+                        bad = true;
+                    continue;
+                }
                 z_stream zs;
                 memset(&zs, 0, sizeof zs);
                 if (inflateInit2(&zs, -15) != Z_OK) {
@@ -212,15 +314,26 @@ struct PlaneSel {
     int kind, ncol;
 };
 
+// results of trk_vcf_harmonize, owned by the reader (valid until the next call)
+struct HzStore {
+    std::vector<int32_t> allele_off, n_str_classes, n_len_classes;
+    std::vector<uint16_t> len_class, str_class;
+    std::vector<double> len_class_value, allele_len;
+    std::vector<int64_t> pos, end, key_off;
+    std::vector<uint8_t> passing, status;
+    std::string keys;
+};
+
 }  // namespace
 
 struct trk_vcf {
     Source src;
+    HzStore hz;
     std::string err;
     std::string header;
     std::vector<std::string> samples;
     std::vector<PlaneSel> planes;
-    std::string buf;     // decompressed text: [consumed .. pending)
+    TextBuf buf;         // decompressed text: [consumed .. pending)
     size_t pos = 0;      // start of unconsumed text in buf
     std::vector<int64_t> line_off, line_end;
     std::vector<int32_t> field_off;
@@ -450,7 +563,9 @@ int trk_vcf_open(const char* path, int n_threads, trk_vcf** out) {
     if (!out || !path) return 2;
     *out = nullptr;
     trk_vcf* v = new trk_vcf();
-    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    // all cores, but not more than 64 threads: the workers are started per batch, and beyond that their start-up
+    // costs more than the extra hands bring (a 50 MB batch parses in ~3 ms on 64 threads)
+    if (n_threads <= 0) n_threads = std::min(64, (int)std::thread::hardware_concurrency());
     if (n_threads < 1) n_threads = 1;
     v->n_threads = n_threads;
     if (!v->src.open(path, n_threads, g_open_error)) {
@@ -469,7 +584,7 @@ int trk_vcf_open(const char* path, int n_threads, trk_vcf** out) {
                 break;
             }
             bool chrom = v->buf.compare(scan, 6, "#CHROM") == 0;
-            v->header.append(v->buf, scan, nl - scan + 1);
+            v->header.append(v->buf.data() + scan, nl - scan + 1);
             if (chrom) {
                 std::string line = v->buf.substr(scan, nl - scan);
                 if (!line.empty() && line.back() == '\r') line.pop_back();
@@ -585,6 +700,10 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
     v->line_off.clear();
     v->line_end.clear();
     size_t scan = 0;
+    const bool timing = getenv("TRK_VCF_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = timing ? now() : 0.0;
+    double t_fill = 0.0;
     while ((int)v->line_off.size() < max_records) {
         size_t nl = v->buf.find('\n', scan);
         if (nl == std::string::npos) {
@@ -595,7 +714,9 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
                 }
                 break;
             }
+            const double tf = timing ? now() : 0.0;
             if (!v->src.fill(v->buf, 16u << 20, v->err)) return 1;
+            if (timing) t_fill += now() - tf;
             continue;
         }
         size_t e = nl;
@@ -607,6 +728,7 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
         scan = nl + 1;
     }
     const int n = (int)v->line_off.size();
+    const double t1 = timing ? now() : 0.0;
     v->field_off.assign((size_t)n * 10, 0);
     RecordJob job;
     job.v = v;
@@ -634,6 +756,9 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
                                 : "a record has fewer sample columns than the header";
         return 5;
     }
+    if (timing)
+        fprintf(stderr, "[trk_vcf] batch of %d records: scan %.1f ms (of which inflate/read %.1f), parse %.1f ms, %d threads\n", n,
+                (t1 - t0) * 1e3, t_fill * 1e3, (now() - t1) * 1e3, nt);
     v->pos = scan;
     out->n_records = n;
     out->text = v->buf.data();
@@ -1018,6 +1143,406 @@ int trk_vcf_decode_formats(const char* samples, int64_t len, int32_t n_samples, 
         p = se + 1;
     }
     return s == n_samples ? 0 : 1;
+}
+
+}  // extern "C"
+
+// =====================================================================================================
+// Batch harmonisation + statSTR rows: the host pipeline of the per-locus hot path without one Python object per
+// record (SURVEY.md 8(b) "one call per batch of loci"; the reference streams record -> row, statSTR.py:575-639).
+// =====================================================================================================
+namespace {
+
+// a[start:stop] of a Python sequence of length n (stop absent when !has_stop) -> [b, e)
+inline void py_slice(long n, long start, bool has_stop, long stop, long& b, long& e) {
+    b = start < 0 ? std::max(n + start, 0L) : std::min(start, n);
+    e = !has_stop ? n : (stop < 0 ? std::max(n + stop, 0L) : std::min(stop, n));
+    if (e < b) e = b;
+}
+
+// value of `key` in an INFO column "k=v;k2;k3=v3": false when absent
+inline bool info_get(const char* s, const char* e, const char* key, size_t klen, const char*& vb, const char*& ve,
+                     bool& has_value) {
+    const char* p = s;
+    while (p < e) {
+        const char* t = static_cast<const char*>(memchr(p, ';', (size_t)(e - p)));
+        if (!t) t = e;
+        if ((size_t)(t - p) >= klen && memcmp(p, key, klen) == 0 && (p + klen == t || p[klen] == '=')) {
+            has_value = p + klen < t;
+            vb = has_value ? p + klen + 1 : t;
+            ve = t;
+            return true;
+        }
+        p = t + 1;
+    }
+    return false;
+}
+
+inline bool parse_long(const char* b, const char* e, long& out) {
+    if (b == e) return false;
+    auto r = std::from_chars(b, e, out);
+    return r.ec == std::errc() && r.ptr == e;
+}
+
+struct HzRecord {  // one record's harmonised alleles (views into the line; upper-casing happens on copy)
+    std::vector<std::pair<const char*, long>> alleles;  // trimmed [ptr, len)
+    double unit = 1.0;                                   // len(motif)
+    int64_t pos = 0, end = 0;
+    bool ok = false, passing = false;
+};
+
+// What _HarmonizeHipSTRRecord / _HarmonizeGangSTRRecord / _HarmonizeAdVNTRRecord + TRRecord.__init__ derive per record
+// (reference tr_harmonizer.py:303-408, 693-773): the trimmed alleles and the motif LENGTH (lengths are
+// len(allele) / len(motif); the motif's letters do not enter any statistic).  Anything unusual -- a missing mandatory
+// INFO field, a symbolic allele, a value that is not an integer -- leaves ok = false: the caller runs that batch
+// through the Python harmoniser, which raises the reference's errors.
+void harmonize_one(const char* line, const int32_t* fo, int64_t line_len, int vcftype, HzRecord& r) {
+    const char* col[9];
+    const char* cole[9];
+    for (int k = 0; k < 8; ++k) {
+        col[k] = line + fo[k];
+        cole[k] = line + fo[k + 1] - 1;
+    }
+    if (fo[8] == 0 && fo[9] == 0) cole[7] = line + line_len;   // no FORMAT column
+    if (fo[8] != 0) cole[7] = line + fo[8] - 1;
+    r.ok = false;
+    long pos;
+    if (!parse_long(col[1], cole[1], pos)) return;
+    r.pos = pos;
+    const char* ref = col[3];
+    const long ref_len = (long)(cole[3] - col[3]);
+    const char* flt = col[6];
+    const long fl = (long)(cole[6] - col[6]);
+    r.passing = (fl == 1 && flt[0] == '.') || (fl == 4 && memcmp(flt, "PASS", 4) == 0);
+    // alleles: REF then ALT (comma separated, '.' = none)
+    std::vector<std::pair<const char*, long>> raw;
+    raw.emplace_back(ref, ref_len);
+    const char* a = col[4];
+    const char* ae = cole[4];
+    if (!(ae - a == 1 && a[0] == '.')) {
+        while (a <= ae) {
+            const char* t = static_cast<const char*>(memchr(a, ',', (size_t)(ae - a)));
+            if (!t) t = ae;
+            raw.emplace_back(a, (long)(t - a));
+            a = t + 1;
+            if (t == ae) break;
+        }
+    }
+    for (auto& al : raw)
+        for (long i = 0; i < al.second; ++i)
+            if (al.first[i] == '<' || al.first[i] == '[' || al.first[i] == ']' || al.first[i] == '*') return;  // symbolic
+    const char* info = col[7];
+    const char* infoe = cole[7];
+    const char *vb, *ve;
+    bool hv;
+    if (vcftype == TRK_VT_HIPSTR) {
+        long start, endv, period;
+        if (!info_get(info, infoe, "START", 5, vb, ve, hv) || !hv || !parse_long(vb, ve, start)) return;
+        if (!info_get(info, infoe, "END", 3, vb, ve, hv) || !hv || !parse_long(vb, ve, endv)) return;
+        if (!info_get(info, infoe, "PERIOD", 6, vb, ve, hv) || !hv || !parse_long(vb, ve, period)) return;
+        if (period <= 0) return;
+        const long lead = start - pos;
+        const long tail = endv - pos + 1 - ref_len;
+        r.alleles.clear();
+        for (auto& al : raw) {
+            long b, e;
+            py_slice(al.second, lead, tail != 0, tail, b, e);   // a[lead:stop], stop = None when tail == 0
+            r.alleles.emplace_back(al.first + b, e - b);
+        }
+        r.unit = (double)period;
+    } else {
+        if (!info_get(info, infoe, "RU", 2, vb, ve, hv) || !hv || ve == vb) return;
+        const long rul = (long)(ve - vb);
+        const char *xb, *xe;
+        const bool has_vid = info_get(info, infoe, "VID", 3, xb, xe, hv);
+        const bool has_varid = info_get(info, infoe, "VARID", 5, xb, xe, hv);
+        if (vcftype == TRK_VT_GANGSTR && (has_vid || has_varid)) return;
+        if (vcftype == TRK_VT_ADVNTR && !has_vid) return;
+        r.alleles = raw;
+        r.unit = (double)rul;
+    }
+    r.end = pos + r.alleles[0].second;   // rec.POS + len(trrec.ref_allele), statSTR.py:590
+    r.ok = true;
+}
+
+// Python's '{:.<p>}'.format(float): '%.<p>g' plus '.0' when the result looks like an integer
+inline void put_py_float(std::string& o, double v, int prec) {
+    char tmp[64];
+    int n = snprintf(tmp, sizeof tmp, "%.*g", prec, v);
+    o.append(tmp, (size_t)n);
+    bool plain = true;
+    for (int i = 0; i < n; ++i)
+        if (tmp[i] == '.' || tmp[i] == 'e' || tmp[i] == 'n' || tmp[i] == 'i') plain = false;   // nan / inf keep their text
+    if (plain) o.append(".0");
+}
+
+// str(numpy.float64): shortest digits that round-trip, positional for 1e-4 <= |x| < 1e16, always with a '.'
+inline void put_np_float(std::string& o, double v) {
+    char tmp[64];
+    const double av = std::fabs(v);
+    if (v != v) { o.append("nan"); return; }
+    if (std::isinf(v)) { o.append(v < 0 ? "-inf" : "inf"); return; }
+    if (av != 0.0 && (av < 1e-4 || av >= 1e16)) {
+        auto r = std::to_chars(tmp, tmp + sizeof tmp, v, std::chars_format::scientific);
+        std::string s(tmp, r.ptr);           // d.ddde+XX: numpy prints at least two exponent digits, like to_chars
+        o.append(s);
+        return;
+    }
+    auto r = std::to_chars(tmp, tmp + sizeof tmp, v, std::chars_format::fixed);
+    size_t n = (size_t)(r.ptr - tmp);
+    o.append(tmp, n);
+    if (!memchr(tmp, '.', n)) o.append(".0");
+}
+
+}  // namespace
+
+extern "C" {
+
+int trk_vcf_harmonize(trk_vcf* v, const trk_vcf_batch* b, int vcftype, trk_vcf_harmonized* out) {
+    if (!v || !b || !out || vcftype < 0 || vcftype > TRK_VT_ADVNTR) return 2;
+    HzStore& st = v->hz;
+    const int n = b->n_records;
+    std::vector<HzRecord> recs((size_t)n);
+    {
+        std::atomic<int> next{0};
+        auto runner = [&]() {
+            for (;;) {
+                const int i0 = next.fetch_add(64);
+                if (i0 >= n) break;
+                for (int i = i0; i < std::min(n, i0 + 64); ++i)
+                    harmonize_one(b->text + b->line_off[i], b->field_off + (size_t)i * 10, b->line_end[i] - b->line_off[i],
+                                  vcftype, recs[(size_t)i]);
+            }
+        };
+        const int nt = std::max(1, std::min({v->n_threads, 16, (n + 63) / 64}));
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(runner);
+        runner();
+        for (auto& t : th) t.join();
+    }
+    st.allele_off.assign((size_t)n + 1, 0);
+    st.pos.assign((size_t)n, 0);
+    st.end.assign((size_t)n, 0);
+    st.passing.assign((size_t)n, 0);
+    st.status.assign((size_t)n, 0);
+    st.n_str_classes.assign((size_t)n, 0);
+    st.n_len_classes.assign((size_t)n, 0);
+    int n_python = 0;
+    for (int i = 0; i < n; ++i) {
+        const HzRecord& r = recs[(size_t)i];
+        st.status[(size_t)i] = r.ok ? 0 : 1;
+        n_python += !r.ok;
+        st.pos[(size_t)i] = r.pos;
+        st.end[(size_t)i] = r.end;
+        st.passing[(size_t)i] = r.passing;
+        const size_t A = r.ok ? r.alleles.size() : 1;
+        if (A > 65535) { st.status[(size_t)i] = 1; ++n_python; }
+        st.allele_off[(size_t)i + 1] = st.allele_off[(size_t)i] + (int32_t)(A > 65535 ? 1 : A);
+    }
+    const size_t sumA = (size_t)st.allele_off[(size_t)n];
+    st.len_class.assign(sumA, 0);
+    st.str_class.assign(sumA, 0);
+    st.len_class_value.assign(sumA, 0.0);
+    st.allele_len.assign(sumA, 0.0);
+    st.key_off.assign(sumA + 1, 0);
+    st.keys.clear();
+    std::vector<int> order;
+    std::vector<std::string> up;
+    for (int i = 0; i < n; ++i) {
+        const size_t o = (size_t)st.allele_off[(size_t)i];
+        const size_t A = (size_t)st.allele_off[(size_t)i + 1] - o;
+        if (st.status[(size_t)i]) {
+            for (size_t q = 0; q <= A; ++q) st.key_off[o + q] = (int64_t)st.keys.size();
+            continue;
+        }
+        const HzRecord& r = recs[(size_t)i];
+        up.resize(A);
+        for (size_t q = 0; q < A; ++q) {
+            up[q].assign(r.alleles[q].first, (size_t)r.alleles[q].second);
+            for (auto& c : up[q])
+                if (c >= 'a' && c <= 'z') c = (char)(c - 32);
+            st.allele_len[o + q] = (double)r.alleles[q].second / r.unit;   // len(allele) / len(motif)
+        }
+        // sequence classes: dense rank in sorted order of the distinct sequences (python str order == byte order)
+        order.resize(A);
+        for (size_t q = 0; q < A; ++q) order[q] = (int)q;
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return up[(size_t)x] < up[(size_t)y]; });
+        int rank = -1;
+        for (size_t k = 0; k < A; ++k) {
+            if (k == 0 || up[(size_t)order[k]] != up[(size_t)order[k - 1]]) {
+                ++rank;
+                st.key_off[o + (size_t)rank] = (int64_t)st.keys.size();
+                st.keys.append(up[(size_t)order[k]]);
+            }
+            st.str_class[o + (size_t)order[k]] = (uint16_t)rank;
+        }
+        st.n_str_classes[(size_t)i] = rank + 1;
+        for (size_t q = (size_t)rank + 1; q <= A; ++q) st.key_off[o + q] = (int64_t)st.keys.size();
+        // length classes: dense rank of the distinct lengths, ascending
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return st.allele_len[o + (size_t)x] < st.allele_len[o + (size_t)y]; });
+        rank = -1;
+        for (size_t k = 0; k < A; ++k) {
+            const double lv = st.allele_len[o + (size_t)order[k]];
+            if (k == 0 || lv != st.allele_len[o + (size_t)order[k - 1]]) {
+                ++rank;
+                st.len_class_value[o + (size_t)rank] = lv;
+            }
+            st.len_class[o + (size_t)order[k]] = (uint16_t)rank;
+        }
+        st.n_len_classes[(size_t)i] = rank + 1;
+    }
+    st.key_off[sumA] = (int64_t)st.keys.size();
+    out->n_records = n;
+    out->n_python = n_python;
+    out->n_alleles_total = (int64_t)sumA;
+    out->allele_off = st.allele_off.data();
+    out->len_class = st.len_class.data();
+    out->str_class = st.str_class.data();
+    out->len_class_value = st.len_class_value.data();
+    out->allele_len = st.allele_len.data();
+    out->pos = st.pos.data();
+    out->end = st.end.data();
+    out->passing = st.passing.data();
+    out->status = st.status.data();
+    out->keys = st.keys.data();
+    out->key_off = st.key_off.data();
+    out->n_str_classes = st.n_str_classes.data();
+    out->n_len_classes = st.n_len_classes.data();
+    return 0;
+}
+
+int64_t trk_vcf_statstr_rows(const trk_vcf_batch* b, const trk_vcf_harmonized* h, const trk_vcf_statstr* in,
+                             const uint8_t* skip, char* out, int64_t cap, int32_t* err_locus, int32_t* err_kind) {
+    if (!b || !h || !in || !in->locus_int || !in->locus_f64 || !in->allele_count) return INT64_MIN;
+    const int n = h->n_records, G = in->n_groups;
+    const int64_t sumA = h->n_alleles_total;
+    if (err_locus) *err_locus = -1;
+    if (err_kind) *err_kind = 0;
+    // columns of trk_stats_out (include/trk.h)
+    enum { LI_N_CALLED = 0, LI_N_BAD = 5, LI_HWE_LEN = 6, LI_HWE_STR = 7, LI_NALL_LEN = 9, LI_NALL_STR = 10, LI_COLS = 12 };
+    enum { LF_THRESH = 0, LF_MEAN = 1, LF_MODE = 2, LF_VAR = 3, LF_HET_LEN = 4, LF_HET_STR = 5, LF_ENT_LEN = 6,
+           LF_ENT_STR = 7, LF_HWEP_LEN = 8, LF_HWEP_STR = 9, LF_COLS = 12 };
+    const bool ul = in->use_length != 0;
+    const int prec = in->precision;
+    // rows are independent: formatted by a few threads into per-chunk strings, concatenated in order
+    const int chunk = 256;
+    const int n_chunks = (n + chunk - 1) / chunk;
+    std::vector<std::string> parts((size_t)n_chunks);
+    std::atomic<int> next{0};
+    std::atomic<int> bad_locus{INT32_MAX};
+    std::atomic<int> bad_kind{0};
+    auto fmt_float = [&](std::string& o, double v) {
+        o.push_back('\t');
+        if (v != v) o.append("nan");
+        else put_py_float(o, v, prec);
+    };
+    auto runner = [&]() {
+        std::vector<int64_t> cc;
+        char tmp[64];
+        for (;;) {
+            const int c = next.fetch_add(1);
+            if (c >= n_chunks) break;
+            std::string& o = parts[(size_t)c];
+            o.reserve((size_t)chunk * 160);
+            for (int l = c * chunk; l < std::min(n, (c + 1) * chunk); ++l) {
+                if (skip && skip[l]) continue;
+                const int64_t off = h->allele_off[l], A = h->allele_off[l + 1] - off;
+                const char* line = b->text + b->line_off[l];
+                const int32_t* fo = b->field_off + (size_t)l * 10;
+                o.append(line + fo[0], (size_t)(fo[1] - 1 - fo[0]));   // str(rec.CHROM)
+                o.push_back('\t');
+                auto r = std::to_chars(tmp, tmp + sizeof tmp, (long long)h->pos[l]);
+                o.append(tmp, (size_t)(r.ptr - tmp));
+                o.push_back('\t');
+                r = std::to_chars(tmp, tmp + sizeof tmp, (long long)h->end[l]);
+                o.append(tmp, (size_t)(r.ptr - tmp));
+                auto I = [&](int g, int col) { return in->locus_int[((int64_t)g * n + l) * LI_COLS + col]; };
+                auto F = [&](int g, int col) { return in->locus_f64[((int64_t)g * n + l) * LF_COLS + col]; };
+                for (int g = 0; g < G; ++g)
+                    if (I(g, LI_N_BAD)) {
+                        int cur = bad_locus.load();
+                        while (l < cur && !bad_locus.compare_exchange_weak(cur, l)) {}
+                        if (l <= bad_locus.load()) bad_kind = 3;
+                    }
+                auto afreq = [&](int g, bool count) {
+                    // statSTR.py:158-172: 'key:value' of every class with a non-zero count, in sorted key order
+                    const int ncls = ul ? h->n_len_classes[l] : h->n_str_classes[l];
+                    const uint16_t* cls = (ul ? h->len_class : h->str_class) + off;
+                    cc.assign((size_t)ncls, 0);
+                    const int32_t* cnt = in->allele_count + (int64_t)g * sumA + off;
+                    int64_t total = 0;
+                    for (int64_t q = 0; q < A; ++q) {
+                        cc[cls[q]] += cnt[q];
+                        total += cnt[q];
+                    }
+                    o.push_back('\t');
+                    bool any = false;
+                    for (int k = 0; k < ncls; ++k) {
+                        if (!cc[(size_t)k]) continue;
+                        if (any) o.push_back(',');
+                        any = true;
+                        if (ul) put_np_float(o, h->len_class_value[off + k]);
+                        else o.append(h->keys + h->key_off[off + k], (size_t)(h->key_off[off + k + 1] - h->key_off[off + k]));
+                        o.push_back(':');
+                        int m;
+                        if (count) m = snprintf(tmp, sizeof tmp, "%lld", (long long)cc[(size_t)k]);
+                        else m = snprintf(tmp, sizeof tmp, "%.3f", (double)cc[(size_t)k] / (double)total);
+                        o.append(tmp, (size_t)m);
+                    }
+                    if (!any) o.push_back('.');
+                };
+                if (in->flags & TRK_SS_THRESH) for (int g = 0; g < G; ++g) fmt_float(o, F(g, LF_THRESH));
+                if (in->flags & TRK_SS_AFREQ) for (int g = 0; g < G; ++g) afreq(g, false);
+                if (in->flags & TRK_SS_ACOUNT) for (int g = 0; g < G; ++g) afreq(g, true);
+                if (in->flags & TRK_SS_NALLELES)
+                    for (int g = 0; g < G; ++g) {
+                        o.push_back('\t');
+                        r = std::to_chars(tmp, tmp + sizeof tmp, (int)I(g, ul ? LI_NALL_LEN : LI_NALL_STR));
+                        o.append(tmp, (size_t)(r.ptr - tmp));
+                    }
+                if (in->flags & TRK_SS_HWEP)
+                    for (int g = 0; g < G; ++g) {
+                        const int stt = I(g, ul ? LI_HWE_LEN : LI_HWE_STR);
+                        if (stt == 2 || stt == 3) {   // the reference raises here (ValueError / IndexError)
+                            int cur = bad_locus.load();
+                            while (l < cur && !bad_locus.compare_exchange_weak(cur, l)) {}
+                            if (l <= bad_locus.load()) bad_kind = stt == 2 ? 1 : 2;
+                        }
+                        fmt_float(o, F(g, ul ? LF_HWEP_LEN : LF_HWEP_STR));
+                    }
+                if (in->flags & TRK_SS_HET) for (int g = 0; g < G; ++g) fmt_float(o, F(g, ul ? LF_HET_LEN : LF_HET_STR));
+                if (in->flags & TRK_SS_ENTROPY) for (int g = 0; g < G; ++g) fmt_float(o, F(g, ul ? LF_ENT_LEN : LF_ENT_STR));
+                if (in->flags & TRK_SS_MEAN) for (int g = 0; g < G; ++g) fmt_float(o, F(g, LF_MEAN));
+                if (in->flags & TRK_SS_MODE) for (int g = 0; g < G; ++g) fmt_float(o, F(g, LF_MODE));
+                if (in->flags & TRK_SS_VAR) for (int g = 0; g < G; ++g) fmt_float(o, F(g, LF_VAR));
+                if (in->flags & TRK_SS_NUMCALLED)
+                    for (int g = 0; g < G; ++g) {
+                        o.push_back('\t');
+                        r = std::to_chars(tmp, tmp + sizeof tmp, (int)I(g, LI_N_CALLED));
+                        o.append(tmp, (size_t)(r.ptr - tmp));
+                    }
+                o.push_back('\n');
+            }
+        }
+    };
+    const int nt = std::max(1, std::min(8, n_chunks));
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(runner);
+    runner();
+    for (auto& t : th) t.join();
+    if (bad_locus.load() != INT32_MAX) {
+        if (err_locus) *err_locus = bad_locus.load();
+        if (err_kind) *err_kind = bad_kind.load();
+    }
+    int64_t total = 0;
+    for (auto& p : parts) total += (int64_t)p.size();
+    if (total > cap || !out) return -total;
+    int64_t w = 0;
+    for (auto& p : parts) {
+        memcpy(out + w, p.data(), p.size());
+        w += (int64_t)p.size();
+    }
+    return total;
 }
 
 }  // extern "C"

@@ -25,9 +25,12 @@ class DeviceArray:
         if _parent is not None:          # a window of another array's memory (not owned)
             self.ptr = int(_ptr)
             return
-        ptr = C.c_void_p()
-        eng._chk(eng.lib.trk_dev_alloc(eng.ctx, max(self.nbytes, 16), C.byref(ptr)))
-        self.ptr = ptr.value
+        self.cap = eng._size_class(max(self.nbytes, 16))
+        self.ptr = eng._pool_take(self.cap)
+        if self.ptr is None:
+            ptr = C.c_void_p()
+            eng._chk(eng.lib.trk_dev_alloc(eng.ctx, self.cap, C.byref(ptr)))
+            self.ptr = ptr.value
         eng._live.add(self)
 
     def view(self, offset_bytes, shape, dtype):
@@ -75,8 +78,12 @@ class DeviceArray:
         return self
 
     def free(self):
+        """Give the memory back: to the engine's pool of device buffers (reused by the next array of the same size
+        class -- a CLI run allocates the same dozen buffers for every batch, and hipMalloc / hipFree each
+        synchronise the device), or to the driver when pooling is off or the pool is full."""
         if self.parent is None and self.ptr is not None and self.eng.ctx is not None:
-            self.eng.lib.trk_dev_free(self.eng.ctx, self.ptr)
+            if not self.eng._pool_give(self.cap, self.ptr):
+                self.eng.lib.trk_dev_free(self.eng.ctx, self.ptr)
         self.ptr = None
         self.eng._live.discard(self)
 
@@ -169,6 +176,10 @@ class Engine:
         self.lib = L.load()
         self.ctx = None
         self._live = set()
+        self._pool = {}              # size class -> [device pointers]
+        self._pool_bytes = 0
+        self._pool_limit = int(float(os.environ.get('TRK_POOL_GB', '16')) * (1 << 30))
+        self._pinned = []            # (pointer, bytes) of hipHostMalloc'ed staging buffers
         ctx = C.c_void_p()
         rc = self.lib.trk_init(int(device), C.byref(ctx))
         if rc != 0:
@@ -192,10 +203,53 @@ class Engine:
             msg = self.lib.trk_last_error(self.ctx)
             raise L.TrkError("libtrk error %d: %s" % (rc, msg.decode() if msg else '?'))
 
+    # ---- device buffer pool / pinned staging ----
+    @staticmethod
+    def _size_class(nbytes):
+        """Sizes are rounded up to 1/8 steps of a power of two (<= 12.5 % waste) so that the slightly smaller last
+        batch of a file reuses the buffers of the full ones."""
+        if nbytes <= 4096:
+            return 4096
+        step = 1 << (int(nbytes - 1).bit_length() - 3)
+        return (nbytes + step - 1) // step * step
+
+    def _pool_take(self, cap):
+        lst = self._pool.get(cap)
+        if lst:
+            self._pool_bytes -= cap
+            return lst.pop()
+        return None
+
+    def _pool_give(self, cap, ptr):
+        if self._pool_limit <= 0 or self._pool_bytes + cap > self._pool_limit:
+            return False
+        self._pool.setdefault(cap, []).append(ptr)
+        self._pool_bytes += cap
+        return True
+
+    def trim(self):
+        """Return every pooled device buffer to the driver."""
+        for lst in self._pool.values():
+            for ptr in lst:
+                self.lib.trk_dev_free(self.ctx, ptr)
+        self._pool, self._pool_bytes = {}, 0
+
+    def host_buffer(self, nbytes):
+        """A pinned (page-locked, hipHostMalloc) host buffer as a numpy uint8 array: a copy from / to it runs at the
+        full PCIe rate and its pages never fault.  Lives until the engine is closed."""
+        ptr = C.c_void_p()
+        self._chk(self.lib.trk_host_alloc(self.ctx, max(int(nbytes), 16), C.byref(ptr)))
+        self._pinned.append(ptr.value)
+        return np.ctypeslib.as_array(C.cast(ptr.value, C.POINTER(C.c_uint8)), shape=(max(int(nbytes), 16),))
+
     def close(self):
         if self.ctx is not None:
             for a in list(self._live):
                 a.free()
+            self.trim()
+            for ptr in self._pinned:
+                self.lib.trk_host_free(self.ctx, ptr)
+            self._pinned = []
             self.lib.trk_free(self.ctx)
             self.ctx = None
 

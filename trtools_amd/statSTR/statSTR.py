@@ -225,6 +225,79 @@ def _flush(batch, group_masks, fmt, outf, nalleles_thresh):
         outf.write(fmt.row(hb, st, l, rec, trrec))
 
 
+def _batch_path_ok(args, invcf, vcftype):
+    """The batch pipeline (native reader -> native batch harmoniser -> device -> native row formatter: no Python
+    object per record) covers the callers whose records carry allele SEQUENCES; everything else, region queries and
+    plots take the per-record loop below.  TRK_STATSTR_BATCH=0 forces the per-record loop."""
+    from ..vcfnative import NativeVCFReader, VT_CODES
+    return (isinstance(invcf, NativeVCFReader) and vcftype.name in VT_CODES and not args.region and
+            not args.plot_afreq and len(invcf.samples) > 0 and os.environ.get('TRK_STATSTR_BATCH', '1') != '0')
+
+
+def _run_batches(args, invcf, vcftype, group_masks, fmt, shard, batch_loci, start_time):
+    """statSTR.py:575-639 a batch at a time.  Returns the number of records read."""
+    from .. import runtime
+    from ..batch import HostBatch
+    from ..vcfnative import SS_FLAGS
+    compute = runtime.get_compute()
+    flags = 0
+    for name, bit in SS_FLAGS.items():
+        if getattr(args, name):
+            flags |= bit
+    masks = group_masks if group_masks[0] is not None else None
+    gb, ng = None, 1
+    if masks is not None:
+        if len(masks) > MAX_GROUPS_PER_PASS:
+            return None                      # more strata than one device pass takes: per-record loop
+        ng = len(masks)
+        gb = np.zeros(len(invcf.samples), dtype=np.uint8)
+        for g, m in enumerate(masks):
+            gb |= (np.asarray(m, dtype=bool).astype(np.uint8) << g)
+    invcf.use_buffers(getattr(compute, 'host_buffer', None), ring=2)
+    nrecords = 0
+    while True:
+        rb = invcf.read_raw_batch(batch_loci)
+        if rb.n == 0:
+            break
+        nrecords += rb.n
+        hz = rb.harmonize(vcftype.name)
+        if hz.n_python:
+            # something the native harmoniser does not cover: this batch goes through the Python objects (and
+            # raises the reference's errors where the reference does)
+            batch = []
+            for record in rb.records():
+                trrecord = trh.HarmonizeRecord(vcftype, record)
+                if args.only_passing and record.FILTER is not None:
+                    continue
+                batch.append((record, trrecord))
+            if shard.next_batch():
+                _flush(batch, group_masks, fmt, shard, args.nalleles_thresh)
+                shard.end_batch()
+            continue
+        if not shard.next_batch():
+            continue
+        hb = HostBatch.from_tables(rb.gt, rb.locus_ploidy, hz.allele_off, hz.len_class, hz.str_class,
+                                   hz.len_class_value, gb, ng, lists=hz.lists)
+        st = compute.locus_stats(hb, nalleles_thresh=args.nalleles_thresh)
+        skip = (hz.passing == 0) if args.only_passing else None
+        text, el, ek = rb.statstr_rows(st, flags, args.precision, args.use_length, skip)
+        if ek:
+            chrom, pos = rb.chrom_pos(el)
+            if ek == 1:
+                raise ValueError("binomtest: n must be a positive integer (no fully called genotype at "
+                                 "{}:{})".format(chrom, pos))
+            if ek == 2:
+                raise IndexError("tuple index out of range (haploid genotypes at {}:{} have no HWE test)"
+                                 .format(chrom, pos))
+            raise IndexError("genotype index out of range at {}:{}".format(chrom, pos))
+        shard.write(text.decode())
+        shard.end_batch()
+        if args.out != "stdout" and shard.rank == 0:
+            print("Finished {} records, time/record={:.5}sec".format(
+                nrecords, (time.time() - start_time) / nrecords), flush=True, end="\r")
+    return nrecords
+
+
 def main(args):
     if not os.path.exists(args.vcf):
         common.WARNING("Error: %s does not exist" % args.vcf)
@@ -293,6 +366,9 @@ def main(args):
         nrecords = 0
         num_plotted = 0
         batch = []
+        if _batch_path_ok(args, invcf, vcftype) and \
+                _run_batches(args, invcf, vcftype, group_masks, fmt, shard, batch_loci, start_time) is not None:
+            region = ()
         for record in region:
             nrecords += 1
             trrecord = trh.HarmonizeRecord(vcftype, record)

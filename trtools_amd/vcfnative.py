@@ -27,6 +27,111 @@ class _Batch(C.Structure):
                 ('field_off', C.POINTER(C.c_int32))]
 
 
+class _Harmonized(C.Structure):
+    _fields_ = [('n_records', C.c_int32), ('n_python', C.c_int32), ('n_alleles_total', C.c_int64),
+                ('allele_off', C.POINTER(C.c_int32)), ('len_class', C.POINTER(C.c_uint16)),
+                ('str_class', C.POINTER(C.c_uint16)), ('len_class_value', C.POINTER(C.c_double)),
+                ('allele_len', C.POINTER(C.c_double)), ('pos', C.POINTER(C.c_int64)), ('end', C.POINTER(C.c_int64)),
+                ('passing', C.POINTER(C.c_uint8)), ('status', C.POINTER(C.c_uint8)), ('keys', C.c_void_p),
+                ('key_off', C.POINTER(C.c_int64)), ('n_str_classes', C.POINTER(C.c_int32)),
+                ('n_len_classes', C.POINTER(C.c_int32))]
+
+
+class _StatRows(C.Structure):
+    _fields_ = [('n_groups', C.c_int32), ('precision', C.c_int32), ('use_length', C.c_int32), ('flags', C.c_int32),
+                ('allele_count', C.c_void_p), ('locus_int', C.c_void_p), ('locus_f64', C.c_void_p)]
+
+
+VT_CODES = {'gangstr': 0, 'hipstr': 1, 'longtr': 1, 'advntr': 2}
+SS_FLAGS = dict(thresh=1, afreq=2, acount=4, nalleles=8, hwep=16, het=32, entropy=64, mean=128, mode=256, var=512,
+                numcalled=1024)
+
+
+def _np(ptr, n, dtype):
+    """numpy view of n elements behind a ctypes pointer (memory owned by the reader)."""
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype)
+
+
+class HarmonizedBatch:
+    """trk_vcf_harmonize's tables as numpy views (valid until the reader's next batch)."""
+
+    def __init__(self, hz):
+        n, sa = hz.n_records, hz.n_alleles_total
+        self.struct = hz
+        self.n, self.n_python = n, hz.n_python
+        self.allele_off = _np(hz.allele_off, n + 1, np.int32)
+        self.len_class = _np(hz.len_class, sa, np.uint16)
+        self.str_class = _np(hz.str_class, sa, np.uint16)
+        self.len_class_value = _np(hz.len_class_value, sa, np.float64)
+        self.allele_len = _np(hz.allele_len, sa, np.float64)
+        self.pos = _np(hz.pos, n, np.int64)
+        self.passing = _np(hz.passing, n, np.uint8)
+        self.key_off = _np(hz.key_off, sa + 1, np.int64)
+
+    def lists(self):
+        """(allele_lens, allele_strs) per locus as Python lists (tests' oracle stand-in only)."""
+        keys = C.string_at(self.struct.keys, int(self.key_off[-1])) if len(self.key_off) else b''
+        lens, strs = [], []
+        for l in range(self.n):
+            o, e = int(self.allele_off[l]), int(self.allele_off[l + 1])
+            lens.append([float(x) for x in self.allele_len[o:e]])
+            strs.append([keys[self.key_off[o + c]:self.key_off[o + c + 1]].decode() for c in self.str_class[o:e]])
+        return lens, strs
+
+
+class RawBatch:
+    """One batch of records as the native reader decoded it: the genotype tensor and FORMAT planes as arrays, the
+    record text still inside the reader.  No Python object per record unless ``records()`` is asked for."""
+
+    def __init__(self, reader, b, gt, ph, lp, planes):
+        self.reader, self.b = reader, b
+        self.n = b.n_records
+        self.gt, self.phased, self.locus_ploidy = gt[:self.n], ph[:self.n], lp[:self.n]
+        self.planes = {k: planes[j][:self.n] for j, (k, _, _, _) in enumerate(reader._selected)}
+        self._hz = None
+
+    def harmonize(self, vcftype):
+        hz = _Harmonized()
+        rc = self.reader._lib.trk_vcf_harmonize(self.reader._h, C.byref(self.b), VT_CODES[vcftype], C.byref(hz))
+        if rc != 0:
+            raise ValueError("trk_vcf_harmonize failed (%d)" % rc)
+        self._hz = HarmonizedBatch(hz)
+        return self._hz
+
+    def chrom_pos(self, l):
+        f0, f1 = int(self.b.field_off[l * 10]), int(self.b.field_off[l * 10 + 1])
+        return C.string_at(self.b.text + self.b.line_off[l] + f0, f1 - 1 - f0).decode(), int(self._hz.pos[l])
+
+    def statstr_rows(self, st, flags, precision, use_length, skip=None):
+        """statSTR's rows for this batch from the host copies of the device results (trk_vcf_statstr_rows)."""
+        ac = np.ascontiguousarray(st.allele_count, dtype=np.int32)
+        li = np.ascontiguousarray(st.locus_int, dtype=np.int32)
+        lf = np.ascontiguousarray(st.locus_f64, dtype=np.float64)
+        prm = _StatRows(ac.shape[0], int(precision), 1 if use_length else 0, int(flags), ac.ctypes.data,
+                        li.ctypes.data, lf.ctypes.data)
+        sk = None if skip is None else np.ascontiguousarray(skip, dtype=np.uint8)
+        el, ek = C.c_int32(), C.c_int32()
+        cap = max(1 << 16, self.n * 256)
+        lib = self.reader._lib
+        while True:
+            buf = C.create_string_buffer(cap)
+            n = lib.trk_vcf_statstr_rows(C.byref(self.b), C.byref(self._hz.struct), C.byref(prm),
+                                         None if sk is None else sk.ctypes.data, buf, cap, C.byref(el), C.byref(ek))
+            if n >= 0:
+                break
+            if n == -(1 << 63):
+                raise ValueError("trk_vcf_statstr_rows: bad arguments")
+            cap = -n + 64
+        return buf.raw[:n], el.value, ek.value
+
+    def records(self):
+        """vcfio.Variant objects of the batch (the per-record path)."""
+        return [vcfio.Variant(self.reader, line, gt=g if self.reader.n_samples else None, native=native, tail=tail)
+                for line, g, native, tail in self.reader._rows_of(self)]
+
+
 def _api():
     lib = _lib.load()
     if not getattr(lib, '_vcf_ready', False):
@@ -44,6 +149,10 @@ def _api():
         lib.trk_vcf_select_format.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
         lib.trk_vcf_read_batch.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_Batch)]
         lib.trk_vcf_seek.argtypes = [vp, C.c_uint64]
+        lib.trk_vcf_harmonize.argtypes = [vp, C.POINTER(_Batch), C.c_int, C.POINTER(_Harmonized)]
+        lib.trk_vcf_statstr_rows.argtypes = [C.POINTER(_Batch), C.POINTER(_Harmonized), C.POINTER(_StatRows), vp,
+                                             C.c_char_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        lib.trk_vcf_statstr_rows.restype = C.c_int64
         lib._vcf_ready = True
     return lib
 
@@ -107,15 +216,13 @@ class NativeVCFReader(vcfio.VCFReader):
             raise ValueError("cannot select FORMAT field %s" % key)
         self._selected.append((name, kind, ncol, np.float32 if kind == KIND_FLOAT else np.int32))
 
-    def _next_batch(self):
+    def read_raw_batch(self, n_records=None):
+        """Decode the next batch of records into arrays (RawBatch); ``.n == 0`` at the end of the file."""
         S = self.n_samples
         P = self._max_ploidy
-        n = self._batch_records or max(1, min(4096, (1 << 22) // max(S, 1)))
+        n = n_records or self._batch_records or max(1, min(4096, (1 << 22) // max(S, 1)))
         while True:
-            gt = np.empty((n, S, P), dtype=np.int16)
-            ph = np.empty((n, S), dtype=np.uint8)
-            lp = np.empty(n, dtype=np.uint8)
-            planes = [np.empty((n, S, nc), dtype=dt) for _, _, nc, dt in self._selected]
+            gt, ph, lp, planes = self._arrays(n, S, P)
             parr = (C.c_void_p * max(len(planes), 1))(*[p.ctypes.data for p in planes])
             b = _Batch()
             b.gt, b.phased, b.locus_ploidy = gt.ctypes.data, ph.ctypes.data, lp.ctypes.data
@@ -132,9 +239,47 @@ class NativeVCFReader(vcfio.VCFReader):
             if rc != 0:
                 raise ValueError(self._lib.trk_vcf_last_error(self._h).decode())
             break
-        m = b.n_records
+        rb = RawBatch(self, b, gt, ph, lp, planes)
+        rb._keep = parr
+        return rb
+
+    def use_buffers(self, allocator=None, ring=2):
+        """Decode batches into a ring of ``ring`` preallocated array sets instead of fresh numpy arrays (a batch then
+        stays valid until ``ring`` further batches have been read).  Fresh arrays cost a page fault per 4 KB inside
+        the parser threads, which serialise in the kernel -- the reader ran at a fifth of its rate because of it.
+        ``allocator(nbytes) -> uint8 array``: where the memory comes from (DeviceCompute.host_buffer: pinned pages,
+        so that the upload is a plain DMA)."""
+        self._ring, self._ring_i, self._ring_n, self._alloc = [], 0, int(ring), allocator
+
+    def _arrays(self, n, S, P):
+        if getattr(self, '_ring_n', 0) <= 0:
+            return (np.empty((n, S, P), dtype=np.int16), np.empty((n, S), dtype=np.uint8), np.empty(n, dtype=np.uint8),
+                    [np.empty((n, S, nc), dtype=dt) for _, _, nc, dt in self._selected])
+        key = (n, S, P, tuple((nc, np.dtype(dt).str) for _, _, nc, dt in self._selected))
+        if len(self._ring) < self._ring_n or self._ring[self._ring_i % self._ring_n][0] != key:
+            def take(shape, dt):
+                nb = int(np.prod(shape, dtype=np.int64)) * np.dtype(dt).itemsize
+                if self._alloc is not None:
+                    raw = self._alloc(nb)
+                else:
+                    raw = np.empty(max(nb, 16), dtype=np.uint8)
+                    raw[:] = 0                                   # touch the pages now, not in the parser threads
+                return raw[:nb].view(dt).reshape(shape)
+            slot = (key, (take((n, S, P), np.int16), take((n, S), np.uint8), take((n,), np.uint8),
+                          [take((n, S, nc), dt) for _, _, nc, dt in self._selected]))
+            if len(self._ring) < self._ring_n:
+                self._ring.append(slot)
+                self._ring_i = len(self._ring) - 1
+            else:
+                self._ring[self._ring_i % self._ring_n] = slot
+        arrs = self._ring[self._ring_i % self._ring_n][1]
+        self._ring_i += 1
+        return arrs
+
+    def _rows_of(self, rb):
+        b, S = rb.b, self.n_samples
         rows = []
-        for i in range(m):
+        for i in range(rb.n):
             # the nine fixed columns as text now; the sample columns (most of the line) stay bytes until a field
             # that was not decoded natively is asked for
             f9 = int(b.field_off[i * 10 + 9])
@@ -144,16 +289,19 @@ class NativeVCFReader(vcfio.VCFReader):
                 tail = C.string_at(b.text + b.line_off[i] + f9, n_line - f9)
             else:
                 line, tail = C.string_at(b.text + b.line_off[i], n_line).decode(), None
-            pl = int(lp[i])
+            pl = int(rb.locus_ploidy[i])
             g = np.empty((S, pl + 1), dtype=np.int16)
-            g[:, :pl] = gt[i, :, :pl]
-            g[:, pl] = ph[i]
-            native = {k: planes[j][i] for j, (k, _, _, _) in enumerate(self._selected)}
+            g[:, :pl] = rb.gt[i, :, :pl]
+            g[:, pl] = rb.phased[i]
+            native = {k: p[i] for k, p in rb.planes.items()}
             rows.append((line, g, native, tail))
-        self._rows, self._row_i = rows, 0
-        self._eof = m == 0
-        self.last_batch = dict(gt=gt[:m], phased=ph[:m], locus_ploidy=lp[:m],
-                               planes={k: planes[j][:m] for j, (k, _, _, _) in enumerate(self._selected)})
+        return rows
+
+    def _next_batch(self):
+        rb = self.read_raw_batch()
+        self._rows, self._row_i = self._rows_of(rb), 0
+        self._eof = rb.n == 0
+        self.last_batch = dict(gt=rb.gt, phased=rb.phased, locus_ploidy=rb.locus_ploidy, planes=rb.planes)
 
     def __next__(self):
         while True:
