@@ -45,6 +45,9 @@ Extras (N = 1 only, each outside the timed region of the headline metric):
                   efficiency (t_100k / N) / t_shard
   config1         BASELINE configs[1]: statSTR full statistics, 10k loci x 1k samples
   config2         BASELINE configs[2]: dumpSTR, GangSTR shape, nine call + four locus filters, 50k x 5k
+  compact_outputs the call-filter pass with the opt-in one-byte mask and no masked-genotype plane (13 B per call)
+  end_to_end      statSTR's command line from a bgzipped text VCF to its table; a packed host batch through
+                  upload + kernels + download (PCIe included)
   associatr_scan  BASELINE configs[4] on one GPU
   cpu_baseline_c  the compiled C restatement on one core and on all cores
 """
@@ -477,6 +480,48 @@ def strong_shard_extra(eng, args, loci, t_full_ms, steps):
     return out
 
 
+def compact_outputs_extra(wl, iters=8):
+    """The opt-in output set for callers that rebuild their records from the mask (this repository's dumpSTR): a
+    one-byte mask per call, no masked-genotype plane (trk_call_out.filter_mask8, gt_out = NULL) -- 12 B read + 1 B
+    written per call instead of 12 + 8.  Same filters, same counters and delta outputs; NOT the headline contract
+    (SURVEY.md 8d prices the path at 20 B per call), reported beside it."""
+    eng = wl.eng
+    b = wl.sb.batch
+    i = (wl.step_no - 1) & 1
+    ref_mask = wl.call_out.filter_mask.get_rows(0, 2048)
+    ref_counters = wl.call_out.sample_counters.get()
+    out = eng.alloc_call_out(b, len(wl.filters), want_gt=False, want_mask=False, want_mask8=True)
+    st = eng.alloc_stats(b)
+    eng.profile(True)
+    for it in range(iters + 2):
+        if it == 2:
+            eng.sync()
+            eng.profile_reset()
+        for a in (out.sample_counters, out.sample_totaldp, out.sample_dp_missing):
+            a.zero()
+        st.allele_count.copy_from(wl.stats_a[i].allele_count)
+        st.locus_int.copy_from(wl.stats_a[i].locus_int)
+        eng.call_filters(b, wl.planes, wl.filters, dp_plane=0, out=out, delta_stats=st)
+    eng.sync()
+    n, ms = eng.profile_get()['k_call_filter']
+    eng.profile(False)
+    ms /= n
+    m8 = out.filter_mask8.get_rows(0, 2048)
+    want = ((ref_mask & np.uint32(0x7f)) | ((ref_mask >> np.uint32(24)) & np.uint32(0x80))).astype(np.uint8)
+    assert np.array_equal(m8, want), "compact mask differs from the 32-bit mask"
+    assert np.array_equal(out.sample_counters.get(), ref_counters), "counters differ with the compact outputs"
+    assert np.array_equal(st.allele_count.get(), wl.stats_b[i].allele_count.get())
+    cells = wl.n_loci * wl.n_samples
+    res = {"workload": "the call-filter pass of the headline step with trk_call_out.filter_mask8 only (no gt_out, no "
+                       "32-bit mask): 13 B per call", "k_call_filter_ms": ms, "bytes_per_cell": 13,
+           "achieved_GBs": cells * 13 / (ms * 1e-3) / 1e9, "frac": cells * 13 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "checked": "mask bytes of 2048 loci, every sample counter and every allele count equal the 20 B run's"}
+    for a in (out.filter_mask8, out.sample_counters, out.sample_totaldp, out.sample_dp_missing, out.error,
+              out.sample_totaldp_f64, st.allele_count, st.locus_int, st.locus_f64):
+        a.free()
+    return res
+
+
 def config1_extra(eng, no_check, iters=50):
     """BASELINE configs[1]: statSTR full statistics on a synthetic HipSTR-shape call set, 10k loci x 1k samples."""
     from trtools_amd.synth import SynthBatch
@@ -644,6 +689,98 @@ def config2_extra(eng, no_check, iters=5):
     return out
 
 
+def end_to_end_extra(eng, seed):
+    """SURVEY.md 8(d) "report both kernel-only and end-to-end": (a) statSTR's command line from a bgzipped text VCF
+    (2000 loci x 5000 samples, GT:DP:Q, written here) to its table of 11 statistics -- native reader, native batch
+    harmoniser, upload from pinned staging, kernels, download, native row formatter; (b) a packed host batch
+    (4096 loci x 10000 samples) through upload + statistics + download, i.e. the device path with PCIe included,
+    from pageable and from pinned host memory.  Never part of `value`."""
+    import tempfile
+    from trtools_amd import runtime, synth
+    from trtools_amd.batch import HostBatch
+    from trtools_amd.bgzf import BgzfWriter
+    from trtools_amd.compute import DeviceCompute
+    from trtools_amd.statSTR import statSTR
+    out = {}
+    comp = DeviceCompute(engine=eng)
+    old = runtime.set_compute(comp)
+    try:
+        Lc, S = 2000, 5000
+        tmp = tempfile.mkdtemp(prefix='trk_e2e_')
+        path = os.path.join(tmp, 'synth.vcf.gz')
+        loci = synth.make_loci(Lc, S, seed=5)
+        with BgzfWriter(path, level=1) as fh:
+            fh.write('##fileformat=VCFv4.1\n##command=HipSTR-v0.6.2 --synthetic\n')
+            for k in ('START', 'END', 'PERIOD'):
+                fh.write('##INFO=<ID=%s,Number=1,Type=Integer,Description="%s">\n' % (k, k))
+            for k, t in (('GT', 'String'), ('DP', 'Integer'), ('Q', 'Float')):
+                fh.write('##FORMAT=<ID=%s,Number=1,Type=%s,Description="%s">\n' % (k, t, k))
+            fh.write('#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t' + '\t'.join('S%05d' % i for i in range(S)) + '\n')
+            for l0 in range(0, Lc, 64):
+                idx = np.arange(l0, min(Lc, l0 + 64))
+                rows = synth.cells_numpy(5, loci, idx, S)
+                for r, l in enumerate(idx):
+                    strs = loci.allele_strs[l]
+                    pos = 1000 + 500 * int(l)
+                    g0 = np.where(rows['gt'][r, :, 0] < 0, '.', rows['gt'][r, :, 0].astype(str))
+                    g1 = np.where(rows['gt'][r, :, 1] < 0, '.', rows['gt'][r, :, 1].astype(str))
+                    dp = np.where(rows['dp'][r] == -2147483648, '.', rows['dp'][r].astype(str))
+                    q = np.where(np.isnan(rows['q'][r]), '.', np.char.mod('%g', rows['q'][r]))
+                    cols = np.char.add(np.char.add(np.char.add(np.char.add(g0, '|'), g1), ':'),
+                                       np.char.add(np.char.add(dp, ':'), q))
+                    fh.write('\t'.join(['chr1', str(pos), 'STR_%d' % l, strs[0], ','.join(strs[1:]) or '.', '.', '.',
+                                        'START=%d;END=%d;PERIOD=%d' % (pos, pos + len(strs[0]) - 1, len(loci.motifs[l])),
+                                        'GT:DP:Q']) + '\t' + '\t'.join(cols) + '\n')
+        ns = argparse.Namespace(vcf=path, out=os.path.join(tmp, 'stat'), vcftype='hipstr', samples=None,
+                                sample_prefixes=None, plot_afreq=False, region=None, thresh=True, afreq=True,
+                                acount=True, hwep=True, het=True, entropy=True, mean=True, mode=True, var=True,
+                                numcalled=True, use_length=False, precision=4, nalleles=True, nalleles_thresh=0.01,
+                                only_passing=False)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rc = statSTR.main(ns)
+            el = time.perf_counter() - t0
+            assert rc == 0
+            best = el if best is None else min(best, el)
+        out["statstr_cli_text_vcf_to_table"] = {
+            "workload": "statSTR (11 statistics) on a bgzipped text VCF, %d loci x %d samples, GT:DP:Q (%.0f MB "
+                        "compressed), to its .tab file" % (Lc, S, os.path.getsize(path) / 1e6),
+            "seconds": best, "loci_per_s": Lc / best, "calls_per_s": Lc * S / best,
+            "rows": sum(1 for _ in open(ns.out + '.tab')) - 1}
+        for f in os.listdir(tmp):
+            os.remove(os.path.join(tmp, f))
+        os.rmdir(tmp)
+        # (b) packed batch -> results, PCIe included
+        Lb, Sb = 4096, 10000
+        lo2 = synth.make_loci(Lb, Sb, seed + 9)
+        rows = synth.cells_numpy(seed + 9, lo2, np.arange(Lb), Sb)
+        off, lc, sc, cv = synth.pack_alleles(lo2.allele_lens, lo2.allele_strs)
+        res = {}
+        for kind in ('pageable', 'pinned'):
+            if kind == 'pinned':
+                gt = eng.host_buffer(rows['gt'].nbytes)[:rows['gt'].nbytes].view(np.int16).reshape(rows['gt'].shape)
+                gt[...] = rows['gt']
+            else:
+                gt = rows['gt']
+            hb = HostBatch.from_tables(gt, np.full(Lb, 2, dtype=np.uint8), off, lc, sc, cv)
+            comp.locus_stats(hb)
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                comp.locus_stats(hb)
+                el = time.perf_counter() - t0
+                best = el if best is None else min(best, el)
+            res[kind] = {"seconds": best, "loci_per_s": Lb / best, "calls_per_s": Lb * Sb / best,
+                         "host_to_device_GBs": rows['gt'].nbytes / best / 1e9}
+        res["workload"] = ("statSTR statistics of one packed host batch, %d loci x %d samples (%.0f MB of genotypes): "
+                           "upload + kernels + download of the per-locus results" % (Lb, Sb, rows['gt'].nbytes / 1e6))
+        out["packed_batch_incl_pcie"] = res
+    finally:
+        runtime.set_compute(old)
+    return out
+
+
 def main():
     args = parse()
     # stdout carries exactly ONE line, the JSON: native libraries print there too (RCCL's version banner at
@@ -777,6 +914,7 @@ def main():
             except Exception as e:      # the checker's C half is optional equipment of the box
                 extras["cpu_baseline_c"] = {"error": str(e)[:200]}
         if not args.no_extras:
+            extras["compact_outputs"] = compact_outputs_extra(wl)
             wl.free()
             if not use_dist:
                 uid = eng.comm_unique_id()
@@ -785,6 +923,7 @@ def main():
             extras["config1"] = config1_extra(eng, args.no_check)
             extras["short_rows"] = short_rows_extra(eng)
             extras["config2"] = config2_extra(eng, args.no_check)
+            extras["end_to_end"] = end_to_end_extra(eng, args.seed)
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:

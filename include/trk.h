@@ -296,7 +296,14 @@ typedef struct {
     int32_t* delta_locus_int;
     double* sample_totaldp_f64; /* [S] += the depth of PASS calls when the DP/LC plane is Float (ExpansionHunter's
                                    LC); sample_totaldp stays 0 then.  Required only for a Float depth plane.   */
+    uint8_t* filter_mask8;      /* optional [L,S]: the mask in one byte per call for at most 7 filters -- bit k = filter
+                                   k fired, bit 7 = the sample was a no-call (TRK_MASK8_NOCALL); 0 == 'PASS'.  A caller
+                                   that rebuilds its records from the mask (as this repository's dumpSTR does: a
+                                   filtered call's genotype is '.') asks for this and neither gt_out nor filter_mask:
+                                   12 B read + 1 B written per call instead of 12 + 8 (the per-sample counters and the
+                                   delta outputs are unchanged).  NULL, or more than 7 filters: not written.        */
 } trk_call_out;
+#define TRK_MASK8_NOCALL 0x80u
 
 /* (a11)-(a18): evaluate `n_filters` call-level filters on every call of the
  * batch.  `dp_plane` = index of the DP (or LC) plane used for totaldp, -1 if

@@ -398,3 +398,37 @@ def test_delta_outputs_with_very_large_allele_sets(eng, max_alt, S):
     want_mask = ((dp < 15).astype(np.uint32) | ((q < np.float32(0.4)).astype(np.uint32) << 1))
     want_mask |= np.any(gt == -1, axis=2).astype(np.uint32) << np.uint32(31)
     assert np.array_equal(res.filter_mask.get(), want_mask)
+
+
+@pytest.mark.parametrize("n_samples,n_filters", [(1000, 3), (1000, 7), (1003, 2), (1000, 9)])
+def test_compact_mask_output(eng, n_samples, n_filters):
+    """trk_call_out.filter_mask8: one byte per call (bit k = filter k, bit 7 = no-call) next to -- or instead of -- the
+    32-bit mask and the masked genotypes, on the threshold kernel, the interpreter kernel (a GangSTR-style filter in
+    the set) and the per-call kernel (unaligned rows); counters and delta outputs do not depend on which outputs are
+    asked for.  More than 7 filters: the byte mask is not written."""
+    from trtools_amd import _lib as L
+    from trtools_amd.synth import SynthBatch
+    sb = SynthBatch(eng, 200, n_samples, seed=77 + n_samples + n_filters, planes=('dp', 'q', 'dstutter'))
+    planes = [sb.dev['dp'], sb.dev['q'], sb.dev['dstutter']]
+    pool = [dict(op=L.F_LT, plane_a=0, thr=12), dict(op=L.F_GT, plane_a=0, thr=50), dict(op=L.F_LT, plane_a=1, thr=0.93),
+            dict(op=L.F_CALLED_LT, plane_a=2, thr=1), dict(op=L.F_GT, plane_a=2, thr=2),
+            dict(op=L.F_CALLED_EQ, plane_a=2, plane_b=0), dict(op=L.F_LT, plane_a=0, thr=20),
+            dict(op=L.F_GT, plane_a=1, thr=0.99), dict(op=L.F_LT, plane_a=2, thr=1)]
+    filters = pool[:n_filters]
+    st = eng.locus_stats(sb.batch, count_only=True)
+    full = eng.call_filters(sb.batch, planes, filters, dp_plane=0, delta_stats=st)
+    mask = full.filter_mask.get()
+    st2 = eng.locus_stats(sb.batch, count_only=True)
+    out = eng.alloc_call_out(sb.batch, n_filters, want_gt=False, want_mask=False, want_mask8=True)
+    out.filter_mask8.set(np.full((200, n_samples), 0x55, dtype=np.uint8))
+    eng.call_filters(sb.batch, planes, filters, dp_plane=0, out=out, delta_stats=st2)
+    m8 = out.filter_mask8.get()
+    if n_filters <= 7:
+        want = ((mask & np.uint32(0x7f)) | ((mask >> np.uint32(24)) & np.uint32(0x80))).astype(np.uint8)
+        assert np.array_equal(m8, want) and (m8 & 0x80).any() and (m8 & 0x7f).any()
+    else:
+        assert np.all(m8 == 0x55)
+    assert np.array_equal(out.sample_counters.get(), full.sample_counters.get())
+    assert np.array_equal(out.sample_totaldp.get(), full.sample_totaldp.get())
+    assert np.array_equal(st2.allele_count.get(), st.allele_count.get())
+    assert np.array_equal(st2.locus_int.get()[..., :6], st.locus_int.get()[..., :6])

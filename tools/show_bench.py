@@ -11,6 +11,6 @@ print('cpu', {k: v for k, v in d.get('cpu_baseline', {}).items() if k != 'sample
 for k, v in ex.get('strong_shard', {}).items():
     if k != 'note':
         print(' shard', k, 'ms %.3f eff %.3f' % (v['ms_per_step'], v['predicted_efficiency']), {a: round(b, 3) for a, b in v['kernels_ms'].items()})
-for name in ('config1', 'short_rows', 'config2', 'associatr_scan', 'cpu_baseline_c', 'end_to_end'):
+for name in ('compact_outputs', 'config1', 'short_rows', 'config2', 'associatr_scan', 'cpu_baseline_c', 'end_to_end'):
     if name in ex:
         print(name, json.dumps(ex[name])[:900])

@@ -12,6 +12,7 @@ TRK_LC_COLS = 32
 TRK_MAX_FILTERS = 24
 TRK_MAX_PLANES = 16
 TRK_MASK_NOCALL = 0x80000000
+TRK_MASK8_NOCALL = 0x80
 
 # locus_int columns
 LI_N_CALLED, LI_N_LOWPLOIDY, LI_N_HOM_LEN, LI_N_HOM_STR, LI_N_ALLELES, LI_N_BAD, \
@@ -71,7 +72,7 @@ class CallOut(C.Structure):
                 ('sample_counters', C.c_void_p), ('sample_totaldp', C.c_void_p),
                 ('sample_dp_missing', C.c_void_p), ('error', C.c_void_p),
                 ('delta_allele_count', C.c_void_p), ('delta_locus_int', C.c_void_p),
-                ('sample_totaldp_f64', C.c_void_p)]
+                ('sample_totaldp_f64', C.c_void_p), ('filter_mask8', C.c_void_p)]
 
 
 class LocusFilterSpec(C.Structure):

@@ -423,12 +423,17 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 // while the wave does its per-locus bookkeeping.  (Without this a wave alternates between waiting for its loads
 // and issuing ALU/LDS work; on 1000-sample rows the whole row is 4 chunks per lane and the wait is most of the
 // wave's life.)  Chunk indices past the row are clamped for the load and skipped by the consumer.
+// g_gt_temporal (TRK_GT_TEMPORAL=1, experiments): genotype loads without the nontemporal hint, so that the tensor may
+// stay in the 256 MiB Infinity Cache for a second reader that follows closely (count pass beside call-filter pass)
+__device__ int g_gt_temporal = 0;
 template <int LPL, int U>
 __device__ __forceinline__ void row_fetch(const u32x4* __restrict__ row, int base, int sl, int last, u32x4 (&v)[U]) {
+    const bool tmp = g_gt_temporal != 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int c = base + sl + u * LPL;
-        v[u] = __builtin_nontemporal_load(&row[c < last ? c : last]);
+        const u32x4* p = &row[c < last ? c : last];
+        v[u] = tmp ? *p : __builtin_nontemporal_load(p);
     }
 }
 template <int LPL, int U, typename Cell>
@@ -1415,6 +1420,9 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter(const CallArgs a) {
             } else if (a.out.filter_mask) {
                 for (int j = 0; j < nvalid; ++j) a.out.filter_mask[cell0 + j] = mask[j];
             }
+            if (a.out.filter_mask8)
+                for (int j = 0; j < nvalid; ++j)
+                    a.out.filter_mask8[cell0 + j] = (uint8_t)((mask[j] & 0x7fu) | ((mask[j] >> 24) & 0x80u));
         }
         // flush the per-sample counters of this block of loci
         for (int j = 0; j < nvalid; ++j) {
@@ -1769,6 +1777,12 @@ __device__ __forceinline__ void cf_process(const CallArgs& a, int l, int64_t cel
     if (a.out.filter_mask)
         __builtin_nontemporal_store(u32x4{mask[0], mask[1], mask[2], mask[3]},
                                     reinterpret_cast<u32x4*>(a.out.filter_mask) + (cell0 >> 2));
+    if (a.out.filter_mask8) {
+        uint32_t m8 = 0;
+#pragma unroll
+        for (int j = 0; j < CF_V; ++j) m8 |= ((mask[j] & 0x7fu) | ((mask[j] >> 24) & 0x80u)) << (8 * j);
+        __builtin_nontemporal_store(m8, reinterpret_cast<uint32_t*>(a.out.filter_mask8) + (cell0 >> 2));
+    }
 }
 
 // ALLREG: every filter and the depth plane read vector sources only (the per-call path is compiled out).
@@ -1948,7 +1962,8 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
         const bool leader = (tid & 63) == __ffsll((unsigned long long)__ballot(1)) - 1;  // first live lane of the wave
         for (int l = l_begin; l < l_end; ++l) {
             const int64_t c4 = ((int64_t)l * S + s0) >> 2;
-            const u32x4 g = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.b.gt) + c4);
+            const u32x4* gp = reinterpret_cast<const u32x4*>(a.b.gt) + c4;
+            const u32x4 g = g_gt_temporal ? *gp : __builtin_nontemporal_load(gp);
             u32x4 pv[NF];
 #pragma unroll
             for (int k = 0; k < NF; ++k)
@@ -2046,6 +2061,12 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
             }
             if (a.out.gt_out) __builtin_nontemporal_store(wout, reinterpret_cast<u32x4*>(a.out.gt_out) + c4);
             if (a.out.filter_mask) __builtin_nontemporal_store(mout, reinterpret_cast<u32x4*>(a.out.filter_mask) + c4);
+            if (a.out.filter_mask8) {   // one byte per call: bit 7 = no-call
+                uint32_t m8 = 0;
+#pragma unroll
+                for (int j = 0; j < CF_V; ++j) m8 |= ((mout[j] & 0x7fu) | ((mout[j] >> 24) & 0x80u)) << (8 * j);
+                __builtin_nontemporal_store(m8, reinterpret_cast<uint32_t*>(a.out.filter_mask8) + c4);
+            }
         }
     }
     if (DELTA) {  // one global atomic per non-zero entry of the block's delta table
@@ -2412,8 +2433,18 @@ static int next_pow2(int v) {
 // twin (TRK_STATS_TWIN): allele_count is [2][G, sumA] and locus_int [2][G, L, COLS]; both copies receive the counts.
 // The streaming kernels write every output element themselves (and the twin copy in the same pass); the general
 // paths accumulate with atomics into zeroed arrays and are followed by two device-to-device copies.
+static void sync_gt_temporal() {
+    static int last = -1;
+    const int want = getenv("TRK_GT_TEMPORAL") ? atoi(getenv("TRK_GT_TEMPORAL")) : 0;
+    if (want != last) {
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gt_temporal), &want, sizeof want);
+        last = want;
+    }
+}
+
 hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* allele_count, int32_t* locus_int,
                               int n_cu, hipStream_t stream, bool twin) {
+    sync_gt_temporal();
     const int G = b.group_bits ? b.n_groups : 1;
     const bool fast2 = (b.ploidy == 2) && !b.group_bits;
     const size_t ac_elems = (size_t)G * (size_t)b.n_alleles_total, li_elems = (size_t)G * b.n_loci * TRK_LI_COLS;
@@ -2574,6 +2605,7 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
     a.n_filters = n_filters;
     a.dp_plane = dp_plane;
     a.out = out;
+    if (n_filters > 7) a.out.filter_mask8 = nullptr;
     const int S = b.n_samples, L = b.n_loci;
     if (S == 0 || L == 0) return hipSuccess;
     int gx = (S + CF_THREADS * CF_V - 1) / (CF_THREADS * CF_V);
@@ -2751,7 +2783,7 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
         if (ok) {
             v.b = b;
             v.dp = dp_plane >= 0 ? reinterpret_cast<const int32_t*>(a.src_ptr[a.dp_src]) : nullptr;
-            v.out = out;
+            v.out = a.out;
             v.delta_nal = delta ? b.max_alleles : 0;
             v.dbg = a.dbg;
             size_t lds2 = 0;

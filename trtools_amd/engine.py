@@ -137,8 +137,9 @@ class AssocResult:
 
 class CallResult:
     def __init__(self, gt_out, filter_mask, sample_counters, sample_totaldp, sample_dp_missing, error,
-                 sample_totaldp_f64=None):
+                 sample_totaldp_f64=None, filter_mask8=None):
         self.sample_totaldp_f64 = sample_totaldp_f64
+        self.filter_mask8 = filter_mask8
         self.gt_out = gt_out
         self.filter_mask = filter_mask
         self.sample_counters = sample_counters
@@ -147,7 +148,8 @@ class CallResult:
         self.error = error
         self.struct = L.CallOut(gt_out.ptr if gt_out else None, filter_mask.ptr if filter_mask else None,
                                 sample_counters.ptr, sample_totaldp.ptr, sample_dp_missing.ptr, error.ptr,
-                                None, None, sample_totaldp_f64.ptr if sample_totaldp_f64 is not None else None)
+                                None, None, sample_totaldp_f64.ptr if sample_totaldp_f64 is not None else None,
+                                filter_mask8.ptr if filter_mask8 is not None else None)
 
     def with_delta(self, stats):
         """trk_call_out whose delta outputs point at ``stats`` (counts of the unfiltered genotypes)."""
@@ -372,13 +374,14 @@ class Engine:
         self._chk(self.lib.trk_locus_stats(self.ctx, C.byref(batch.struct), C.byref(prm), C.byref(out.struct)))
         return out
 
-    def alloc_call_out(self, batch, n_filters, want_gt=True, want_mask=True):
+    def alloc_call_out(self, batch, n_filters, want_gt=True, want_mask=True, want_mask8=False):
         S = batch.n_samples
         return CallResult(
             self.empty((batch.n_loci, S, batch.ploidy), np.int16) if want_gt else None,
             self.empty((batch.n_loci, S), np.uint32) if want_mask else None,
             self.zeros((1 + n_filters, S), np.int64), self.zeros((S,), np.int64),
-            self.zeros((S,), np.int64), self.zeros((4,), np.int32), self.zeros((S,), np.float64))
+            self.zeros((S,), np.int64), self.zeros((4,), np.int32), self.zeros((S,), np.float64),
+            self.empty((batch.n_loci, S), np.uint8) if want_mask8 else None)
 
     def locus_finalize(self, batch, stats, nalleles_thresh=0.01):
         """Float statistics + HWE test from counts already in ``stats`` (trk_locus_finalize)."""
