@@ -161,6 +161,7 @@ typedef struct {
     const int64_t* key_off;        /* [sumA + 1] key c of locus l: keys[key_off[allele_off[l] + c] .. +1)  */
     const int32_t* n_str_classes;  /* [n]                                                                 */
     const int32_t* n_len_classes;  /* [n]                                                                 */
+    const int32_t* hrun;           /* [n] longest homopolymer run of REF (utils.GetHomopolymerRun)        */
 } trk_vcf_harmonized;
 int trk_vcf_harmonize(trk_vcf* v, const trk_vcf_batch* b, int vcftype, trk_vcf_harmonized* out);
 
@@ -176,6 +177,46 @@ typedef struct {
  * ([n], may be NULL): records left out (--only-passing).                                                       */
 int64_t trk_vcf_statstr_rows(const trk_vcf_batch* b, const trk_vcf_harmonized* h, const trk_vcf_statstr* in,
                              const uint8_t* skip, char* out, int64_t cap, int32_t* err_locus, int32_t* err_kind);
+
+/* ---- dumpSTR's output records, a batch at a time ------------------------------------------------
+ * For every record of the batch (as trk_vcf_read_batch left it) whose head is not NULL: the caller's head text (the
+ * nine leading columns of the OUTPUT line: FILTER and INFO rewritten, FORMAT with ':FILTER' appended -- dumpSTR.py:
+ * 917-973, 1304-1336) followed by the per-sample columns re-serialised from the typed FORMAT arrays exactly as the
+ * per-record path does (trk_vcf_decode_formats -> nulling of filtered calls, dumpSTR.py:721-746 -> trk_vcf_format_samples
+ * with the FORMAT/FILTER column built from the call-filter mask, dumpSTR.py:648-683), and a newline.  Records are
+ * independent: one per host-thread task, output in record order.
+ *   mask8 / mask32     [n, S] trk_call_out.filter_mask8 / filter_mask of the batch (one of them)
+ *   gt, phased, locus_ploidy  the batch's genotype tensor [n, S, ploidy], phase bytes [n, S], per-record ploidy
+ *   filters[k]         name of call filter k and where the number behind '<name>_<value>' comes from: kind 0 the value
+ *                      of column col_a of plane_a ([n, S, ncol_a], dtype 0 int32 / 1 float32) as a double, kind 1 that
+ *                      value divided by plane_b's (HipSTR flank-indel / stutter ratios, filters.py:444-449)
+ *   format_keys/kinds  the header's FORMAT IDs and how each is decoded (TRK_VCF_COL_INT / _FLOAT / _UCS4); IDs not
+ *                      listed decode as strings
+ * Returns the bytes written; -(bytes needed) when cap is too small; INT64_MIN for bad arguments; INT64_MIN + 1 when
+ * a record is outside what this path covers (*err_record: a FORMAT/FILTER field already present, no GT, a token that
+ * is not a number ...): the caller then takes the per-record path for the batch.                                  */
+typedef struct {
+    const char* name;
+    int32_t kind, reserved;
+    const void* plane_a;
+    int32_t dtype_a, ncol_a, col_a, pad_a;
+    const void* plane_b;
+    int32_t dtype_b, ncol_b, col_b, pad_b;
+} trk_vcf_cf_value;
+typedef struct {
+    int32_t n_samples, ploidy, n_filters, n_format_keys, n_threads, reserved;
+    const int16_t* gt;
+    const uint8_t* phased;
+    const uint8_t* locus_ploidy;
+    const uint8_t* mask8;
+    const uint32_t* mask32;
+    const trk_vcf_cf_value* filters;
+    const char* const* heads;        /* [n] NUL-terminated; NULL = the record is not written */
+    const char* const* format_keys;
+    const int32_t* format_kinds;
+} trk_vcf_dumpstr;
+int64_t trk_vcf_dumpstr_lines(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, char* out, int64_t cap,
+                              int32_t* err_record);
 
 #ifdef __cplusplus
 }

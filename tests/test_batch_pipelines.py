@@ -1,0 +1,184 @@
+"""The batch pipelines of the two command lines (native reader -> native batch harmoniser -> compute seam -> native
+row / record writer, no Python object per record) against the per-record loops they replace: byte-identical outputs
+on the reference's fixture VCFs and on the synthetic HipSTR / GangSTR files, for several argument sets each.  The
+per-record loops are what the golden-file tests pin (tests/test_statstr_cli.py, test_dumpstr_cli.py, ...); this file
+pins the batch pipelines to them.  CPU: oracle-backed compute stand-in; the GPU legs run the same comparison through
+libtrk."""
+import argparse
+import os
+
+import pytest
+
+from helpers import GOLDEN
+from test_dumpstr_cli import make_args as dump_args
+
+D = os.path.join(GOLDEN, 'data')
+DD = os.path.join(D, 'dumpSTR')
+SYN = os.path.join(GOLDEN, 'dumpstr_synth')
+
+STAT_FILES = [
+    (os.path.join(D, 'many_samples.vcf.gz'), 'hipstr'),
+    (os.path.join(DD, 'trio_chr21_hipstr.sorted.vcf.gz'), 'hipstr'),
+    (os.path.join(DD, 'trio_chr21_gangstr.sorted.vcf.gz'), 'gangstr'),
+    (os.path.join(DD, 'test_gangstr.vcf.gz'), 'gangstr'),
+    (os.path.join(DD, 'NA12878_chr21_advntr.sorted.vcf.gz'), 'advntr'),
+    (os.path.join(DD, 'longtr_testfile.vcf.gz'), 'longtr'),
+    (os.path.join(SYN, 'synth_hipstr.vcf'), 'hipstr'),
+    (os.path.join(SYN, 'synth_gangstr.vcf'), 'gangstr'),
+]
+
+
+def _stat_args(vcf, out, vcftype, **kw):
+    ns = argparse.Namespace(vcf=vcf, out=out, vcftype=vcftype, samples=None, sample_prefixes=None, plot_afreq=False,
+                            region=None, thresh=True, afreq=True, acount=True, hwep=False, het=True, entropy=True,
+                            mean=True, mode=True, var=True, numcalled=True, use_length=False, precision=4, nalleles=True,
+                            nalleles_thresh=0.05, only_passing=False)
+    for k, v in kw.items():
+        setattr(ns, k, v)
+    return ns
+
+
+def _both(fn, env):
+    outs = []
+    for mode in ('1', '0'):
+        os.environ[env] = mode
+        try:
+            outs.append(fn(mode))
+        finally:
+            del os.environ[env]
+    return outs
+
+
+def _run_stat(tmp_path, compute, path, vcftype, **kw):
+    from trtools_amd import runtime
+    from trtools_amd.statSTR import statSTR
+    taken = []
+    orig = statSTR._run_batches
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        taken.append(r)
+        return r
+    statSTR._run_batches = spy
+    old = runtime.set_compute(compute)
+    try:
+        def go(mode):
+            out = str(tmp_path / ('s' + mode))
+            assert statSTR.main(_stat_args(path, out, vcftype, **kw)) == 0
+            return open(out + '.tab').read()
+        a, b = _both(go, 'TRK_STATSTR_BATCH')
+    finally:
+        runtime.set_compute(old)
+        statSTR._run_batches = orig
+    assert taken and taken[0] is not None and taken[0] > 0, "the batch pipeline did not run"
+    assert a == b
+    return a
+
+
+# the oracle-backed stand-in takes a second per hundred records: the CPU legs use the small inputs, the GPU legs all
+SMALL_STAT = [f for f in STAT_FILES if 'trio' not in f[0] and 'many_samples' not in f[0]]
+
+
+@pytest.mark.parametrize('path,vcftype', SMALL_STAT, ids=[os.path.basename(p) for p, _ in SMALL_STAT])
+def test_statstr_batch_pipeline_equals_per_record_loop(tmp_path, path, vcftype):
+    from oracle_compute import OracleCompute
+    hwep = vcftype in ('hipstr',) and 'trio' not in path
+    t = _run_stat(tmp_path, OracleCompute(), path, vcftype, hwep=hwep)
+    assert t.count('\n') > 5
+    _run_stat(tmp_path, OracleCompute(), path, vcftype, use_length=True, precision=6, only_passing=True, acount=False)
+
+
+def test_statstr_batch_pipeline_with_sample_groups(tmp_path):
+    from oracle_compute import OracleCompute
+    from trtools_amd import vcfio
+    names = vcfio.VCFReader(os.path.join(SYN, 'synth_hipstr.vcf')).samples
+    for i, sel in enumerate((names[::2], names[1::3])):
+        (tmp_path / ('g%d.txt' % i)).write_text('\n'.join(sel) + '\n')
+    _run_stat(tmp_path, OracleCompute(), os.path.join(SYN, 'synth_hipstr.vcf'), 'hipstr', hwep=True,
+              samples=str(tmp_path / 'g0.txt') + ',' + str(tmp_path / 'g1.txt'), sample_prefixes='a,b')
+
+
+DUMP_CASES = {
+    'synth_hipstr_all': (os.path.join(SYN, 'synth_hipstr.vcf'),
+                         dict(vcftype='hipstr', hipstr_max_call_flank_indel=0.05, hipstr_max_call_stutter=0.3,
+                              hipstr_min_supp_reads=10, hipstr_min_call_DP=20, hipstr_max_call_DP=50,
+                              hipstr_min_call_Q=0.9, use_length=True, min_locus_hwep=0.01, min_locus_callrate=0.5)),
+    'hipstr_thresholds': (os.path.join(DD, 'trio_chr21_hipstr.sorted.vcf.gz'),
+                          dict(vcftype='hipstr', hipstr_min_call_DP=20, hipstr_max_call_DP=60, hipstr_min_call_Q=0.9,
+                               min_locus_callrate=0.7, min_locus_het=0.05, max_locus_het=0.6, num_records=None)),
+    'hipstr_ratios_minsupp': (os.path.join(DD, 'trio_chr21_hipstr.sorted.vcf.gz'),
+                              dict(vcftype='hipstr', hipstr_max_call_flank_indel=0.05, hipstr_max_call_stutter=0.3,
+                                   hipstr_min_supp_reads=10, hipstr_min_call_DP=30, use_length=True,
+                                   min_locus_hwep=0.01)),
+    'hipstr_drop_filtered': (os.path.join(SYN, 'synth_hipstr.vcf'),
+                             dict(vcftype='hipstr', hipstr_min_call_DP=25, hipstr_min_call_Q=0.95,
+                                  min_locus_callrate=0.9, drop_filtered=True)),
+    'gangstr_thresholds': (os.path.join(DD, 'trio_chr21_gangstr.sorted.vcf.gz'),
+                           dict(vcftype='gangstr', gangstr_min_call_DP=10, gangstr_max_call_DP=100,
+                                gangstr_min_call_Q=0.9, min_locus_callrate=0.6)),
+    'synth_gangstr': (os.path.join(SYN, 'synth_gangstr.vcf'),
+                      dict(vcftype='gangstr', gangstr_min_call_DP=15, gangstr_min_call_Q=0.92, max_locus_het=0.7)),
+    'no_call_filters': (os.path.join(SYN, 'synth_hipstr.vcf'), dict(vcftype='hipstr', min_locus_callrate=0.95)),
+    'longtr': (os.path.join(DD, 'longtr_testfile.vcf.gz'),
+               dict(vcftype='longtr', longtr_min_call_DP=30, longtr_max_call_DP=200, longtr_min_call_Q=0.9,
+                    use_length=True, min_locus_het=0.05)),
+}
+
+
+# inputs the native pieces decline (records without the mandatory INFO fields, a FORMAT/FILTER field from an earlier
+# dumpSTR round): the batch goes through the record objects -- same outputs, just not through the batch pipeline
+FALLBACK_CASES = {'longtr'}
+BIG_CASES = {'hipstr_thresholds', 'hipstr_ratios_minsupp', 'gangstr_thresholds'}     # trio files: GPU legs only
+
+
+def _run_dump(tmp_path, compute, name):
+    from trtools_amd import runtime
+    from trtools_amd.dumpSTR import dumpSTR
+    path, kw = DUMP_CASES[name]
+    taken = []
+    orig = dumpSTR._Run.process_raw
+
+    def spy(self, *a, **k):
+        r = orig(self, *a, **k)
+        taken.append(r)
+        return r
+    dumpSTR._Run.process_raw = spy
+    old = runtime.set_compute(compute)
+    try:
+        def go(mode):
+            out = str(tmp_path / ('d' + mode))
+            assert dumpSTR.main(dump_args(out, path, **kw)) == 0
+            return tuple(open(out + ext).read() for ext in ('.vcf', '.samplog.tab', '.loclog.tab'))
+        a, b = _both(go, 'TRK_DUMPSTR_BATCH')
+    finally:
+        runtime.set_compute(old)
+        dumpSTR._Run.process_raw = orig
+    if name not in FALLBACK_CASES:
+        assert taken and all(taken), "the batch pipeline did not handle every batch"
+    for x, y, what in zip(a, b, ('vcf', 'samplog', 'loclog')):
+        if x != y:
+            la, lb = x.split('\n'), y.split('\n')
+            i = next(i for i, (p, q) in enumerate(zip(la, lb)) if p != q)
+            raise AssertionError("%s: %s differs at line %d:\n%s\n%s" % (name, what, i, la[i][:400], lb[i][:400]))
+    return a
+
+
+@pytest.mark.parametrize('name', sorted(set(DUMP_CASES) - BIG_CASES))
+def test_dumpstr_batch_pipeline_equals_per_record_loop(tmp_path, name):
+    from oracle_compute import OracleCompute
+    vcf, _, loclog = _run_dump(tmp_path, OracleCompute(), name)
+    assert vcf.count('\n') > 20 and 'PASS' in loclog
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', sorted(DUMP_CASES))
+def test_dumpstr_batch_pipeline_gpu(tmp_path, name):
+    from trtools_amd import runtime
+    _run_dump(tmp_path, runtime.get_compute(), name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('path,vcftype', STAT_FILES, ids=[os.path.basename(p) for p, _ in STAT_FILES])
+def test_statstr_batch_pipeline_gpu(tmp_path, path, vcftype):
+    from trtools_amd import runtime
+    _run_stat(tmp_path, runtime.get_compute(), path, vcftype, hwep=('many_samples' in path or 'synth_hipstr' in path))

@@ -96,10 +96,15 @@ class DeviceCompute:
         self._free(b, res.allele_count, res.locus_int, res.locus_f64)
         return out
 
-    def dumpstr_batch(self, hb, planes, filters, dp_plane, locus_spec, nalleles_thresh=0.01):
+    supports_compact = True
+
+    def dumpstr_batch(self, hb, planes, filters, dp_plane, locus_spec, nalleles_thresh=0.01, compact=False):
         """Call filters -> masked genotypes -> locus statistics -> locus filters, all on the device.
-        Returns (CallHost, StatsHost, locus_bits uint32[L], loc_counters int64[32])."""
+        Returns (CallHost, StatsHost, locus_bits uint32[L], loc_counters int64[32]).  ``compact``: the caller
+        rebuilds its records from the mask -- only the one-byte mask comes back (trk_call_out.filter_mask8; CallHost.mask
+        is uint8 then, gt_out None), not the masked genotype tensor and the 32-bit mask."""
         eng = self.eng
+        compact = compact and len(filters) <= 7
         b = self._upload(hb)
         n_pad, S = self._n_pad(hb), hb.gt.shape[1]
         if n_pad:   # the padding samples' FORMAT values are missing like their genotypes
@@ -110,7 +115,8 @@ class DeviceCompute:
         # masks (dumpSTR.py:721-774 rebuilds the record; here no second pass over the tensor), then
         # the finaliser
         st = eng.locus_stats(b, nalleles_thresh=nalleles_thresh, count_only=True)
-        call = eng.call_filters(b, dplanes, filters, dp_plane=dp_plane, delta_stats=st)
+        cout = eng.alloc_call_out(b, len(filters), want_gt=not compact, want_mask=not compact, want_mask8=compact)
+        call = eng.call_filters(b, dplanes, filters, dp_plane=dp_plane, out=cout, delta_stats=st)
         eng.locus_finalize(b, st, nalleles_thresh=nalleles_thresh)
         ext = None
         spec = dict(locus_spec)
@@ -121,11 +127,12 @@ class DeviceCompute:
         totaldp = call.sample_totaldp.get()
         if dp_plane >= 0 and np.asarray(planes[dp_plane]).dtype.kind == 'f':
             totaldp = call.sample_totaldp_f64.get()      # Float depth plane (ExpansionHunter's LC)
-        ch = CallHost(call.gt_out.get()[:, :S], call.filter_mask.get()[:, :S], call.sample_counters.get()[:, :S],
-                      totaldp[:S], call.sample_dp_missing.get()[:S], call.error.get())
+        ch = CallHost(None if compact else call.gt_out.get()[:, :S],
+                      call.filter_mask8.get()[:, :S] if compact else call.filter_mask.get()[:, :S],
+                      call.sample_counters.get()[:, :S], totaldp[:S], call.sample_dp_missing.get()[:S], call.error.get())
         sh = StatsHost(st.allele_count.get(), st.locus_int.get(), st.locus_f64.get())
         out = (ch, sh, bits.get(), counters.get())
-        self._free(b, *dplanes, call.gt_out, call.filter_mask, call.sample_counters, call.sample_totaldp,
+        self._free(b, *dplanes, call.gt_out, call.filter_mask, call.filter_mask8, call.sample_counters, call.sample_totaldp,
                    call.sample_totaldp_f64,
                    call.sample_dp_missing, call.error, st.allele_count, st.locus_int, st.locus_f64,
                    bits, counters, ext)

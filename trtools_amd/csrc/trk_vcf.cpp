@@ -316,7 +316,7 @@ struct PlaneSel {
 
 // results of trk_vcf_harmonize, owned by the reader (valid until the next call)
 struct HzStore {
-    std::vector<int32_t> allele_off, n_str_classes, n_len_classes;
+    std::vector<int32_t> allele_off, n_str_classes, n_len_classes, hrun;
     std::vector<uint16_t> len_class, str_class;
     std::vector<double> len_class_value, allele_len;
     std::vector<int64_t> pos, end, key_off;
@@ -1188,6 +1188,7 @@ struct HzRecord {  // one record's harmonised alleles (views into the line; uppe
     std::vector<std::pair<const char*, long>> alleles;  // trimmed [ptr, len)
     double unit = 1.0;                                   // len(motif)
     int64_t pos = 0, end = 0;
+    int32_t hrun = 0;
     bool ok = false, passing = false;
 };
 
@@ -1214,6 +1215,14 @@ void harmonize_one(const char* line, const int32_t* fo, int64_t line_len, int vc
     const char* flt = col[6];
     const long fl = (long)(cole[6] - col[6]);
     r.passing = (fl == 1 && flt[0] == '.') || (fl == 4 && memcmp(flt, "PASS", 4) == 0);
+    {   // utils.GetHomopolymerRun(REF): longest run of one letter, case-insensitive (dumpSTR.py:1304-1306)
+        int best = ref_len > 0 ? 1 : 0, run = 1;
+        for (long i = 1; i < ref_len; ++i) {
+            run = ((ref[i] | 32) == (ref[i - 1] | 32)) ? run + 1 : 1;
+            if (run > best) best = run;
+        }
+        r.hrun = best;
+    }
     // alleles: REF then ALT (comma separated, '.' = none)
     std::vector<std::pair<const char*, long>> raw;
     raw.emplace_back(ref, ref_len);
@@ -1327,6 +1336,7 @@ int trk_vcf_harmonize(trk_vcf* v, const trk_vcf_batch* b, int vcftype, trk_vcf_h
     st.status.assign((size_t)n, 0);
     st.n_str_classes.assign((size_t)n, 0);
     st.n_len_classes.assign((size_t)n, 0);
+    st.hrun.assign((size_t)n, 0);
     int n_python = 0;
     for (int i = 0; i < n; ++i) {
         const HzRecord& r = recs[(size_t)i];
@@ -1335,6 +1345,7 @@ int trk_vcf_harmonize(trk_vcf* v, const trk_vcf_batch* b, int vcftype, trk_vcf_h
         st.pos[(size_t)i] = r.pos;
         st.end[(size_t)i] = r.end;
         st.passing[(size_t)i] = r.passing;
+        st.hrun[(size_t)i] = r.hrun;
         const size_t A = r.ok ? r.alleles.size() : 1;
         if (A > 65535) { st.status[(size_t)i] = 1; ++n_python; }
         st.allele_off[(size_t)i + 1] = st.allele_off[(size_t)i] + (int32_t)(A > 65535 ? 1 : A);
@@ -1408,6 +1419,7 @@ int trk_vcf_harmonize(trk_vcf* v, const trk_vcf_batch* b, int vcftype, trk_vcf_h
     out->key_off = st.key_off.data();
     out->n_str_classes = st.n_str_classes.data();
     out->n_len_classes = st.n_len_classes.data();
+    out->hrun = st.hrun.data();
     return 0;
 }
 
@@ -1541,6 +1553,201 @@ int64_t trk_vcf_statstr_rows(const trk_vcf_batch* b, const trk_vcf_harmonized* h
     for (auto& p : parts) {
         memcpy(out + w, p.data(), p.size());
         w += (int64_t)p.size();
+    }
+    return total;
+}
+
+}  // extern "C"
+
+// =====================================================================================================
+// dumpSTR records of a whole batch: what the reference does per record in ApplyCallFilters (dumpSTR.py:613-774: the
+// FORMAT/FILTER column, genotypes and every other FORMAT field of filtered calls nulled) and cyvcf2.Writer.write_record
+// (dumpSTR.py:1338) -- decode every FORMAT field of the record to its typed array, null the filtered samples,
+// serialise -- for all records of a batch on host threads, one record per task.  The caller supplies the nine leading
+// columns of every output line (FILTER and INFO rewritten, FORMAT with ':FILTER' appended).
+// =====================================================================================================
+extern "C" {
+
+int64_t trk_vcf_dumpstr_lines(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, char* out, int64_t cap,
+                              int32_t* err_record) {
+    if (!b || !in || !in->heads || !in->gt || !in->locus_ploidy || (!in->mask8 && !in->mask32)) return INT64_MIN;
+    const int n = b->n_records, S = in->n_samples, P = in->ploidy;
+    if (err_record) *err_record = -1;
+    std::vector<std::string> lines((size_t)n);
+    std::atomic<int> next{0};
+    std::atomic<int> bad{INT32_MAX};
+    auto fail = [&](int l) {
+        int cur = bad.load();
+        while (l < cur && !bad.compare_exchange_weak(cur, l)) {}
+    };
+    auto runner = [&]() {
+        std::vector<trk_vcf_decode> dec;
+        std::vector<std::vector<char>> store;
+        std::vector<trk_vcf_column> cols;
+        std::vector<int16_t> gtrow;
+        std::vector<uint32_t> m32((size_t)S);
+        std::vector<uint8_t> filtered((size_t)S);
+        std::vector<std::vector<double>> vals((size_t)in->n_filters);
+        std::vector<const double*> vptr((size_t)std::max(in->n_filters, 1));
+        std::vector<const char*> names((size_t)std::max(in->n_filters, 1));
+        for (int k = 0; k < in->n_filters; ++k) names[(size_t)k] = in->filters[k].name;
+        for (;;) {
+            const int l = next.fetch_add(1);
+            if (l >= n) break;
+            if (!in->heads[l]) continue;     // record dropped by the caller (--drop-filtered)
+            const char* line = b->text + b->line_off[l];
+            const int32_t* fo = b->field_off + (size_t)l * 10;
+            const int64_t line_len = b->line_end[l] - b->line_off[l];
+            if (fo[9] <= fo[8] || fo[9] >= line_len) { fail(l); continue; }
+            // FORMAT keys of the record -> decode kinds from the header table
+            const char* f = line + fo[8];
+            const char* fe = line + fo[9] - 1;
+            dec.clear();
+            int gt_idx = -1;
+            bool ok = true;
+            for (const char* a = f; a <= fe;) {
+                const char* c = find_ch(a, fe, ':');
+                const size_t kl = (size_t)(c - a);
+                int kind = TRK_VCF_COL_UCS4;
+                if (kl == 2 && a[0] == 'G' && a[1] == 'T') {
+                    gt_idx = (int)dec.size();
+                    kind = -1;
+                } else if (kl == 6 && memcmp(a, "FILTER", 6) == 0) {
+                    ok = false;              // a second dumpSTR round: the per-record path knows what to do
+                } else {
+                    for (int t = 0; t < in->n_format_keys; ++t)
+                        if (strlen(in->format_keys[t]) == kl && memcmp(in->format_keys[t], a, kl) == 0) {
+                            kind = in->format_kinds[t];
+                            break;
+                        }
+                }
+                dec.push_back({kind, 0, nullptr});
+                if (c >= fe) break;
+                a = c + 1;
+            }
+            if (!ok || gt_idx < 0) { fail(l); continue; }
+            const int nf = (int)dec.size();
+            const char* smp = line + fo[9];
+            const int64_t smp_len = line_len - fo[9];
+            if (trk_vcf_decode_formats(smp, smp_len, S, nf, dec.data(), 0) != 0) { fail(l); continue; }
+            store.resize((size_t)nf);
+            for (int i = 0; i < nf; ++i) {
+                if (dec[(size_t)i].kind < 0) continue;
+                const size_t bytes = (size_t)S * (size_t)std::max(dec[(size_t)i].ncol, 1) * 4;
+                store[(size_t)i].assign(bytes, 0);
+                dec[(size_t)i].out = store[(size_t)i].data();
+            }
+            if (trk_vcf_decode_formats(smp, smp_len, S, nf, dec.data(), 1) != 0) { fail(l); continue; }
+            // the mask of this record as 32 bits; filtered = some filter fired on a called sample (dumpSTR.py:715-717)
+            uint32_t any_bits = 0;
+            for (int s = 0; s < S; ++s) {
+                uint32_t m;
+                if (in->mask8) {
+                    const uint8_t x = in->mask8[(size_t)l * S + s];
+                    m = (uint32_t)(x & 0x7f) | ((x & 0x80) ? 0x80000000u : 0u);
+                } else {
+                    m = in->mask32[(size_t)l * S + s];
+                }
+                m32[(size_t)s] = m;
+                filtered[(size_t)s] = (m & 0x7fffffffu) != 0 && !(m & 0x80000000u);
+                any_bits |= m & 0x7fffffffu;
+            }
+            // genotypes: [S, pl + 1] with the phase column; a filtered call is all '.' and unphased (:721-727)
+            const int pl = in->locus_ploidy[l];
+            gtrow.assign((size_t)S * (pl + 1), 0);
+            for (int s = 0; s < S; ++s) {
+                int16_t* g = &gtrow[(size_t)s * (pl + 1)];
+                const int16_t* src = in->gt + ((size_t)l * S + s) * P;
+                if (filtered[(size_t)s]) {
+                    for (int j = 0; j < pl; ++j) g[j] = -1;
+                    g[pl] = 0;
+                } else {
+                    for (int j = 0; j < pl; ++j) g[j] = src[j];
+                    g[pl] = in->phased ? in->phased[(size_t)l * S + s] : 0;
+                }
+            }
+            // every other field of a filtered call is missing (:730-746)
+            for (int i = 0; i < nf; ++i) {
+                const trk_vcf_decode& d = dec[(size_t)i];
+                if (d.kind < 0) continue;
+                for (int s = 0; s < S; ++s) {
+                    if (!filtered[(size_t)s]) continue;
+                    if (d.kind == TRK_VCF_COL_INT) {
+                        int32_t* o = static_cast<int32_t*>(d.out) + (size_t)s * d.ncol;
+                        for (int j = 0; j < d.ncol; ++j) o[j] = INT_MISSING;
+                    } else if (d.kind == TRK_VCF_COL_FLOAT) {
+                        float* o = static_cast<float*>(d.out) + (size_t)s * d.ncol;
+                        for (int j = 0; j < d.ncol; ++j) o[j] = NAN;
+                    } else {
+                        uint32_t* o = static_cast<uint32_t*>(d.out) + (size_t)s * d.ncol;
+                        o[0] = '.';
+                        for (int j = 1; j < d.ncol; ++j) o[j] = 0;
+                    }
+                }
+            }
+            // the numbers behind '<filter name>_<value>' of the filters that fired somewhere in this record
+            for (int k = 0; k < in->n_filters; ++k) {
+                vptr[(size_t)k] = nullptr;
+                if (!((any_bits >> k) & 1u)) continue;
+                const trk_vcf_cf_value& fv = in->filters[k];
+                std::vector<double>& v = vals[(size_t)k];
+                v.resize((size_t)S);
+                auto elem = [&](const void* plane, int dtype, int ncol, int col, int s) -> double {
+                    const size_t i = ((size_t)l * S + s) * ncol + col;
+                    return dtype == 1 ? (double)static_cast<const float*>(plane)[i] : (double)static_cast<const int32_t*>(plane)[i];
+                };
+                for (int s = 0; s < S; ++s) {
+                    const double a = elem(fv.plane_a, fv.dtype_a, fv.ncol_a, fv.col_a, s);
+                    v[(size_t)s] = fv.kind == 1 ? a / elem(fv.plane_b, fv.dtype_b, fv.ncol_b, fv.col_b, s) : a;
+                }
+                vptr[(size_t)k] = v.data();
+            }
+            trk_vcf_callfilter cf{m32.data(), in->n_filters, 0, names.data(), vptr.data()};
+            cols.clear();
+            int64_t need = 0;
+            for (int i = 0; i < nf; ++i) {
+                const trk_vcf_decode& d = dec[(size_t)i];
+                if (d.kind < 0) {
+                    cols.push_back({TRK_VCF_COL_GT, pl + 1, 0, 0, gtrow.data()});
+                    need += (int64_t)S * (7 * (pl + 1) + 1);
+                } else if (d.kind == TRK_VCF_COL_UCS4) {
+                    cols.push_back({TRK_VCF_COL_UCS4, 1, d.ncol * 4, 0, d.out});
+                    need += (int64_t)S * (d.ncol * 4 + 2);
+                } else {
+                    cols.push_back({d.kind, d.ncol, 0, 0, d.out});
+                    need += (int64_t)S * (17 * d.ncol + 1);
+                }
+            }
+            cols.push_back({TRK_VCF_COL_CALLFILTER, 1, 0, 0, &cf});
+            int64_t cfw = 8;
+            for (int k = 0; k < in->n_filters; ++k) cfw += (int64_t)strlen(names[(size_t)k]) + 26;
+            need += (int64_t)S * cfw;
+            std::string& o = lines[(size_t)l];
+            const size_t hl = strlen(in->heads[l]);
+            o.resize(hl + (size_t)need + 2);
+            memcpy(&o[0], in->heads[l], hl);
+            const int64_t w = trk_vcf_format_samples(S, (int)cols.size(), cols.data(), &o[hl], need);
+            if (w < 0) { fail(l); o.clear(); continue; }
+            o.resize(hl + (size_t)w);
+            o.push_back('\n');
+        }
+    };
+    const int nt = std::max(1, std::min({in->n_threads > 0 ? in->n_threads : 32, 64, n}));
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(runner);
+    runner();
+    for (auto& t : th) t.join();
+    if (bad.load() != INT32_MAX) {
+        if (err_record) *err_record = bad.load();
+        return INT64_MIN + 1;
+    }
+    int64_t total = 0;
+    for (auto& s : lines) total += (int64_t)s.size();
+    if (!out || total > cap) return -total;
+    int64_t w = 0;
+    for (auto& s : lines) {
+        memcpy(out + w, s.data(), s.size());
+        w += (int64_t)s.size();
     }
     return total;
 }

@@ -425,6 +425,151 @@ class _Run:
         if self.world > 1:
             self.parts.append((self.batch_no, ''.join(self._cur).encode()))
 
+    # ---- the batch pipeline: no Python object per record -------------------------------------------------------
+    _SIMPLE_VALUES = (filters.CallFilterMinValue, filters._HipSTRRatio, filters.HipSTRCallMinSuppReads)
+
+    def batch_path_ok(self, vcftype):
+        """The batch pipeline (native reader -> native batch harmoniser -> device -> native record writer) covers
+        callers whose records carry allele sequences, call filters whose reported value is a FORMAT number or a
+        ratio of two, and the statistic locus filters; everything else takes the per-record loop.
+        TRK_DUMPSTR_BATCH=0 forces the per-record loop."""
+        from ..vcfnative import NativeVCFReader, VT_CODES
+        a = self.args
+        return (isinstance(self.invcf, NativeVCFReader) and vcftype.name in VT_CODES and not self.host_filters and
+                all(isinstance(f, self._SIMPLE_VALUES) for f in self.call_filters) and
+                a.num_records is None and not a.verbose and len(self.invcf.samples) > 0 and
+                os.environ.get('TRK_DUMPSTR_BATCH', '1') != '0')
+
+    def process_raw(self, rb, hz, format_kinds):
+        """One batch through the batch pipeline.  False: a record is outside what it covers (nothing has been
+        written or counted): the caller runs the batch through ``process``."""
+        from .. import runtime
+        from ..batch import HostBatch
+        args = self.args
+        # FORMAT planes the filters read, as the native reader decoded them
+        keys = []
+        for f in self.call_filters:
+            for key, _ in f.planes():
+                if key not in keys:
+                    keys.append(key)
+        fmt0 = rb.head_fields(0)[8].split(':') if rb.n else []
+        dp_key = None
+        for cand in ('DP', 'LC'):                     # dumpSTR.py:688-695, judged on the batch's first record
+            if cand in fmt0:
+                dp_key = cand
+                if cand not in keys:
+                    keys.append(cand)
+                break
+        if any(k not in rb.planes for k in keys):
+            return False
+        index = {k: i for i, k in enumerate(keys)}
+        arrays = [rb.planes[k] for k in keys]
+        specs = [f.spec(index) for f in self.call_filters]
+        self.batch_no += 1
+        if self.world > 1 and self.batch_no % self.world != self.rank:
+            return True
+        hb = HostBatch.from_tables(rb.gt, rb.locus_ploidy, hz.allele_off, hz.len_class, hz.str_class,
+                                   hz.len_class_value, lists=hz.lists)
+        compute = runtime.get_compute()
+        kw = dict(compact=True) if getattr(compute, 'supports_compact', False) else {}
+        ch, st, bits, lc = compute.dumpstr_batch(hb, arrays, specs, -1 if dp_key is None else index[dp_key],
+                                                 dict(self.spec, extern_bits=None), **kw)
+        # the native writer first: if it declines, the batch has left no trace
+        names = [f.name for f in self.call_filters]
+        cfv = []
+        for f in self.call_filters:
+            if isinstance(f, filters._HipSTRRatio):
+                cfv.append((f.name, 1, (rb.planes[f.numerator], 0), (rb.planes['DP'], 0)))
+            else:
+                key = f.planes()[0][0]
+                cfv.append((f.name, 0, (rb.planes[key], 0), None))
+        ul = bool(args.use_length)
+        heads = []
+        for l in range(rb.n):
+            b = int(bits[l])
+            fired_names = [f.filter_name() for f in self.locus_filters if (b >> self.bit_of[id(f)]) & 1]
+            if (b >> L.LOCF_NO_CALLS) & 1:
+                fired_names.append('NO_CALLS_REMAINING')
+            if args.drop_filtered and fired_names:
+                heads.append(None)
+                continue
+            f = rb.head_fields(l)
+            if len(f) < 9:
+                return self._undo_batch()
+            if not args.drop_filtered:
+                f[6] = ';'.join(fired_names) if fired_names else 'PASS'
+            elif f[6] == '.':
+                pass                      # an unset FILTER stays '.', 'PASS' stays 'PASS' (Variant.to_text)
+            info = vcfio._Info(self.invcf._parse_info(f[7]))
+            info['HRUN'] = int(hz.hrun[l])
+            I, Fv = st.locus_int[0, l], st.locus_f64[0, l]
+            o = int(hz.allele_off[l])
+            n_alt = int(hz.allele_off[l + 1]) - o - 1
+            if I[L.LI_N_CALLED] > 0:
+                status = I[L.LI_HWE_STATUS_LEN if ul else L.LI_HWE_STATUS_STR]
+                if status == L.HWE_INDEX_ERROR:
+                    raise IndexError("tuple index out of range (haploid genotypes have no HWE test)")
+                info['HET'] = float(Fv[L.LF_HET_LEN if ul else L.LF_HET_STR])
+                info['HWEP'] = float(Fv[L.LF_HWEP_LEN if ul else L.LF_HWEP_STR])
+                ac = st.allele_count[0, o:o + n_alt + 1]
+                info['AC'] = 0 if n_alt == 0 else ",".join(str(int(x)) for x in ac[1:])
+                info['REFAC'] = int(ac[0])
+            else:
+                info['HET'] = -1
+                info['HWEP'] = -1
+                info['AC'] = 0 if n_alt == 0 else ','.join(['0'] * n_alt)
+                info['REFAC'] = 0
+            f[7] = vcfio.info_text(info)
+            f[8] = f[8] + ':FILTER'
+            chrom = f[0]
+            if chrom not in self.invcf.contigs_declared and chrom not in self.invcf.contigs_seen:
+                self.invcf.contigs_seen.append(chrom)
+            heads.append('\t'.join(f))
+        text = rb.dumpstr_lines(heads, ch.mask, cfv, format_kinds)
+        if text is None:
+            return self._undo_batch()
+        if ch.error[0]:
+            l, s = int(ch.error[1]), int(ch.error[2])
+            bad = np.zeros(len(self.sample_names), dtype=bool)
+            bad[s] = True
+            chrom, pos = rb.chrom_pos(l)
+            raise ValueError("The following samples have calls but negative DP values at chromosome {} pos {}: {}"
+                             .format(chrom, pos, str(self.sample_names[bad])))
+        if lc[L.LC_HWE_ERRORS]:
+            raise ValueError("binomtest: n must be a positive integer (a locus has allele calls but no fully "
+                             "called genotype; the HWE filter cannot be evaluated)")
+        if np.any(st.locus_int[0, :, L.LI_N_BAD]):
+            raise IndexError("genotype index out of range for the alleles of a record")
+        self._count(ch, lc, dp_key is not None)
+        if self.world == 1:
+            self.outvcf.write_text(text.decode())
+        else:
+            self.parts.append((self.batch_no, text))
+        return True
+
+    def _undo_batch(self):
+        self.batch_no -= 1
+        return False
+
+    def _count(self, ch, lc, have_dp):
+        """sample_info / loc_info of one batch (dumpSTR.py:661, 686-713 and 946-971)."""
+        si = self.sample_info
+        si['numcalls'] += ch.sample_counters[0]
+        for k, f in enumerate(self.call_filters):
+            si[f.name] += ch.sample_counters[1 + k]
+        if have_dp:
+            si['totaldp'] += ch.totaldp
+            si['totaldp'][ch.dp_missing > 0] = np.nan
+        else:
+            si['totaldp'][:] = np.nan
+            self.no_dp = True
+        li = self.loc_info
+        li['totalcalls'] += int(lc[L.LC_TOTALCALLS])
+        li['PASS'] += int(lc[L.LC_PASS])
+        li['NO_CALLS_REMAINING'] += int(lc[L.LC_NO_CALLS])
+        for f in self.locus_filters:
+            li[f.filter_name()] += int(lc[L.LC_FILTER0 + self.bit_of[id(f)]])
+
     def _process(self, records):
         from .. import runtime
         args = self.args
@@ -676,7 +821,33 @@ def main(args):
     batch_loci = max(1, min(2048, BATCH_CELLS // n_samples))
     record_counter = 0
     batch = []
-    while True:
+    use_batches = run.batch_path_ok(vcftype)
+    if use_batches:
+        from .. import runtime
+        kinds = {k: (1 if h['Type'] == 'Integer' else 2 if h['Type'] == 'Float' else 4) for k, h in format_fields.items()}
+        invcf.use_buffers(getattr(runtime.get_compute(), 'host_buffer', None), ring=2)
+    while use_batches:
+        rb = invcf.read_raw_batch(batch_loci)
+        if rb.n == 0:
+            break
+        hz = rb.harmonize(vcftype.name)
+        if hz.n_python == 0 and run.process_raw(rb, hz, kinds):
+            continue
+        # a batch the native pieces do not cover: through the record objects, with the per-record loop's handling
+        # of unparsable records
+        try:
+            run.process([trh.HarmonizeRecord(vcftype, v) for v in rb.records()])
+        except TypeError as te:
+            if 'missing' in te.args[0] and 'mandatory' in te.args[0]:
+                common.WARNING("Could not parse VCF.\n" + te.args[0])
+                return 1
+            raise te
+        except ValueError as ve:
+            if 'properly formatted' in ve.args[0]:
+                common.WARNING("Could not parse VCF.\n" + ve.args[0])
+                return 1
+            raise ve
+    while not use_batches:
         try:
             record = next(harmonizer)
         except StopIteration:

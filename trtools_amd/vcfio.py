@@ -436,6 +436,9 @@ class Variant:
         return ','.join(toks) if toks else '.'
 
     def _info_text(self):
+        return info_text(self.INFO)
+
+    def _info_text_old(self):
         toks = []
         for k, v in self.INFO:
             if v is True:
@@ -535,6 +538,19 @@ class Variant:
 def _fmt_float(x):
     s = '%g' % x
     return s
+
+
+def info_text(info):
+    """The INFO column from an ``_Info`` (typed values re-serialised the way htslib writes them)."""
+    toks = []
+    for k, v in info:
+        if v is True:
+            toks.append(k)
+        elif isinstance(v, (tuple, list)):
+            toks.append(k + '=' + ','.join(_fmt_info(x) for x in v))
+        else:
+            toks.append(k + '=' + _fmt_info(v))
+    return ';'.join(toks) if toks else '.'
 
 
 def _fmt_info(v):

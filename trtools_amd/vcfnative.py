@@ -34,7 +34,7 @@ class _Harmonized(C.Structure):
                 ('allele_len', C.POINTER(C.c_double)), ('pos', C.POINTER(C.c_int64)), ('end', C.POINTER(C.c_int64)),
                 ('passing', C.POINTER(C.c_uint8)), ('status', C.POINTER(C.c_uint8)), ('keys', C.c_void_p),
                 ('key_off', C.POINTER(C.c_int64)), ('n_str_classes', C.POINTER(C.c_int32)),
-                ('n_len_classes', C.POINTER(C.c_int32))]
+                ('n_len_classes', C.POINTER(C.c_int32)), ('hrun', C.POINTER(C.c_int32))]
 
 
 class _StatRows(C.Structure):
@@ -69,6 +69,8 @@ class HarmonizedBatch:
         self.pos = _np(hz.pos, n, np.int64)
         self.passing = _np(hz.passing, n, np.uint8)
         self.key_off = _np(hz.key_off, sa + 1, np.int64)
+        self.hrun = _np(hz.hrun, n, np.int32)
+        self.status = _np(hz.status, n, np.uint8)
 
     def lists(self):
         """(allele_lens, allele_strs) per locus as Python lists (tests' oracle stand-in only)."""
@@ -79,6 +81,21 @@ class HarmonizedBatch:
             lens.append([float(x) for x in self.allele_len[o:e]])
             strs.append([keys[self.key_off[o + c]:self.key_off[o + c + 1]].decode() for c in self.str_class[o:e]])
         return lens, strs
+
+
+class _CfValue(C.Structure):
+    _fields_ = [('name', C.c_char_p), ('kind', C.c_int32), ('reserved', C.c_int32), ('plane_a', C.c_void_p),
+                ('dtype_a', C.c_int32), ('ncol_a', C.c_int32), ('col_a', C.c_int32), ('pad_a', C.c_int32),
+                ('plane_b', C.c_void_p), ('dtype_b', C.c_int32), ('ncol_b', C.c_int32), ('col_b', C.c_int32),
+                ('pad_b', C.c_int32)]
+
+
+class _DumpLines(C.Structure):
+    _fields_ = [('n_samples', C.c_int32), ('ploidy', C.c_int32), ('n_filters', C.c_int32), ('n_format_keys', C.c_int32),
+                ('n_threads', C.c_int32), ('reserved', C.c_int32), ('gt', C.c_void_p), ('phased', C.c_void_p),
+                ('locus_ploidy', C.c_void_p), ('mask8', C.c_void_p), ('mask32', C.c_void_p),
+                ('filters', C.POINTER(_CfValue)), ('heads', C.POINTER(C.c_char_p)),
+                ('format_keys', C.POINTER(C.c_char_p)), ('format_kinds', C.POINTER(C.c_int32))]
 
 
 class RawBatch:
@@ -126,10 +143,64 @@ class RawBatch:
             cap = -n + 64
         return buf.raw[:n], el.value, ek.value
 
+    def head_fields(self, l):
+        """The eight leading columns and the FORMAT column of record l as text."""
+        b = self.b
+        f9 = int(b.field_off[l * 10 + 9])
+        n_line = b.line_end[l] - b.line_off[l]
+        end = f9 - 1 if 0 < f9 < n_line else n_line
+        return C.string_at(b.text + b.line_off[l], end).decode().split('\t')
+
+    def dumpstr_lines(self, heads, mask, cf_values, format_kinds, n_threads=0):
+        """trk_vcf_dumpstr_lines: the output records of the batch.  heads: list of str / None; mask: uint8 or uint32
+        [n, S]; cf_values: list of (name, kind, (plane, col), (plane, col) | None); format_kinds: {FORMAT ID: 1 int /
+        2 float / 4 string}.  Returns bytes, or None when a record is outside what the native writer covers."""
+        S, P = self.gt.shape[1], self.gt.shape[2]
+        gt = np.ascontiguousarray(self.gt)
+        ph = np.ascontiguousarray(self.phased)
+        lp = np.ascontiguousarray(self.locus_ploidy)
+        mask = np.ascontiguousarray(mask)
+        keep = [gt, ph, lp, mask]
+        fv = (_CfValue * max(len(cf_values), 1))()
+        for k, (name, kind, a, bsrc) in enumerate(cf_values):
+            pa = np.ascontiguousarray(a[0])
+            keep.append(pa)
+            fv[k].name, fv[k].kind = name.encode(), int(kind)
+            fv[k].plane_a, fv[k].dtype_a = pa.ctypes.data, 1 if pa.dtype == np.float32 else 0
+            fv[k].ncol_a, fv[k].col_a = (pa.shape[2] if pa.ndim == 3 else 1), int(a[1])
+            if bsrc is not None:
+                pb = np.ascontiguousarray(bsrc[0])
+                keep.append(pb)
+                fv[k].plane_b, fv[k].dtype_b = pb.ctypes.data, 1 if pb.dtype == np.float32 else 0
+                fv[k].ncol_b, fv[k].col_b = (pb.shape[2] if pb.ndim == 3 else 1), int(bsrc[1])
+        harr = (C.c_char_p * max(self.n, 1))(*[None if h is None else h.encode() for h in heads])
+        fk = list(format_kinds.items())
+        karr = (C.c_char_p * max(len(fk), 1))(*[k.encode() for k, _ in fk])
+        kk = (C.c_int32 * max(len(fk), 1))(*[int(v) for _, v in fk])
+        prm = _DumpLines(S, P, len(cf_values), len(fk), int(n_threads), 0, gt.ctypes.data, ph.ctypes.data,
+                         lp.ctypes.data, mask.ctypes.data if mask.dtype == np.uint8 else None,
+                         mask.ctypes.data if mask.dtype == np.uint32 else None, fv, harr, karr, kk)
+        lib = self.reader._lib
+        err = C.c_int32()
+        cap = int(sum(self.b.line_end[i] - self.b.line_off[i] for i in range(self.n)) * 1.3) + (1 << 16)
+        while True:
+            buf = (C.c_char * cap)()
+            n = lib.trk_vcf_dumpstr_lines(C.byref(self.b), C.byref(prm), buf, cap, C.byref(err))
+            if n >= 0:
+                return C.string_at(buf, n)
+            if n <= -(1 << 63) + 1:
+                return None
+            cap = -n + 64
+
     def records(self):
         """vcfio.Variant objects of the batch (the per-record path)."""
-        return [vcfio.Variant(self.reader, line, gt=g if self.reader.n_samples else None, native=native, tail=tail)
-                for line, g, native, tail in self.reader._rows_of(self)]
+        out = [vcfio.Variant(self.reader, line, gt=g if self.reader.n_samples else None, native=native, tail=tail)
+               for line, g, native, tail in self.reader._rows_of(self)]
+        r = self.reader
+        for v in out:          # contigs the file uses without declaring them (the writer adds their header lines)
+            if v.CHROM not in r.contigs_declared and v.CHROM not in r.contigs_seen:
+                r.contigs_seen.append(v.CHROM)
+        return out
 
 
 def _api():
@@ -153,6 +224,9 @@ def _api():
         lib.trk_vcf_statstr_rows.argtypes = [C.POINTER(_Batch), C.POINTER(_Harmonized), C.POINTER(_StatRows), vp,
                                              C.c_char_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         lib.trk_vcf_statstr_rows.restype = C.c_int64
+        lib.trk_vcf_dumpstr_lines.argtypes = [C.POINTER(_Batch), C.POINTER(_DumpLines), vp, C.c_int64,
+                                              C.POINTER(C.c_int32)]
+        lib.trk_vcf_dumpstr_lines.restype = C.c_int64
         lib._vcf_ready = True
     return lib
 
