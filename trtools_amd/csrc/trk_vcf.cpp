@@ -12,6 +12,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <climits>
 #include <cmath>
@@ -1591,6 +1592,8 @@ int64_t trk_vcf_dumpstr_lines(const trk_vcf_batch* b, const trk_vcf_dumpstr* in,
         std::vector<const double*> vptr((size_t)std::max(in->n_filters, 1));
         std::vector<const char*> names((size_t)std::max(in->n_filters, 1));
         for (int k = 0; k < in->n_filters; ++k) names[(size_t)k] = in->filters[k].name;
+        std::unique_ptr<char[]> scratch;
+        size_t scratch_cap = 0;
         for (;;) {
             const int l = next.fetch_add(1);
             if (l >= n) break;
@@ -1634,7 +1637,8 @@ int64_t trk_vcf_dumpstr_lines(const trk_vcf_batch* b, const trk_vcf_dumpstr* in,
             for (int i = 0; i < nf; ++i) {
                 if (dec[(size_t)i].kind < 0) continue;
                 const size_t bytes = (size_t)S * (size_t)std::max(dec[(size_t)i].ncol, 1) * 4;
-                store[(size_t)i].assign(bytes, 0);
+                if (store[(size_t)i].size() < bytes) store[(size_t)i].resize(bytes);
+                if (dec[(size_t)i].kind == TRK_VCF_COL_UCS4) memset(store[(size_t)i].data(), 0, bytes);   // NUL padded
                 dec[(size_t)i].out = store[(size_t)i].data();
             }
             if (trk_vcf_decode_formats(smp, smp_len, S, nf, dec.data(), 1) != 0) { fail(l); continue; }
@@ -1722,13 +1726,23 @@ int64_t trk_vcf_dumpstr_lines(const trk_vcf_batch* b, const trk_vcf_dumpstr* in,
             int64_t cfw = 8;
             for (int k = 0; k < in->n_filters; ++k) cfw += (int64_t)strlen(names[(size_t)k]) + 26;
             need += (int64_t)S * cfw;
+            // formatted into this thread's scratch (sized by a generous bound, never value-initialised), then
+            // copied at its real length
+            if ((int64_t)scratch_cap < need) {
+                scratch.reset(new char[(size_t)need]);
+                scratch_cap = (size_t)need;
+            }
+            // (format_range directly: trk_vcf_format_samples would hand the record to its sample-range thread pool,
+            // and thirty-two callers queueing on that one pool serialise -- here the records are the parallel axis)
+            OutBuf ob{scratch.get(), need, 0};
+            format_range(0, S, (int)cols.size(), cols.data(), ob);
+            const int64_t w = ob.n;
+            if (w > need) { fail(l); continue; }
             std::string& o = lines[(size_t)l];
             const size_t hl = strlen(in->heads[l]);
-            o.resize(hl + (size_t)need + 2);
-            memcpy(&o[0], in->heads[l], hl);
-            const int64_t w = trk_vcf_format_samples(S, (int)cols.size(), cols.data(), &o[hl], need);
-            if (w < 0) { fail(l); o.clear(); continue; }
-            o.resize(hl + (size_t)w);
+            o.reserve(hl + (size_t)w + 1);
+            o.assign(in->heads[l], hl);
+            o.append(scratch.get(), (size_t)w);
             o.push_back('\n');
         }
     };
@@ -1744,10 +1758,22 @@ int64_t trk_vcf_dumpstr_lines(const trk_vcf_batch* b, const trk_vcf_dumpstr* in,
     int64_t total = 0;
     for (auto& s : lines) total += (int64_t)s.size();
     if (!out || total > cap) return -total;
-    int64_t w = 0;
-    for (auto& s : lines) {
-        memcpy(out + w, s.data(), s.size());
-        w += (int64_t)s.size();
+    {   // the lines land at their prefix offsets, copied by the same number of threads
+        std::vector<int64_t> at((size_t)n + 1, 0);
+        for (int i = 0; i < n; ++i) at[(size_t)i + 1] = at[(size_t)i] + (int64_t)lines[(size_t)i].size();
+        std::atomic<int> nx{0};
+        auto copier = [&]() {
+            for (;;) {
+                const int i0 = nx.fetch_add(16);
+                if (i0 >= n) break;
+                for (int i = i0; i < std::min(n, i0 + 16); ++i)
+                    memcpy(out + at[(size_t)i], lines[(size_t)i].data(), lines[(size_t)i].size());
+            }
+        };
+        std::vector<std::thread> tc;
+        for (int t = 1; t < nt; ++t) tc.emplace_back(copier);
+        copier();
+        for (auto& t : tc) t.join();
     }
     return total;
 }

@@ -542,9 +542,9 @@ class _Run:
             raise IndexError("genotype index out of range for the alleles of a record")
         self._count(ch, lc, dp_key is not None)
         if self.world == 1:
-            self.outvcf.write_text(text.decode())
+            self.outvcf.write_bytes(text)
         else:
-            self.parts.append((self.batch_no, text))
+            self.parts.append((self.batch_no, bytes(text)))
         return True
 
     def _undo_batch(self):

@@ -759,6 +759,18 @@ class VCFWriter:
             self._header()
         self._fh.write(text)
 
+    def write_bytes(self, data):
+        """Already formatted record lines as bytes / a memoryview (the batch record writer): no decode - encode
+        round trip through the text layer."""
+        if not self._wrote_header:
+            self._header()
+        raw = getattr(self._fh, 'buffer', None)
+        if raw is not None:                      # text file: flush what the text layer holds, then the raw bytes
+            self._fh.flush()
+            raw.write(data)
+        else:
+            self._fh.write(bytes(data))          # BgzfWriter takes bytes
+
     def close(self):
         if not self._wrote_header:
             self._header()

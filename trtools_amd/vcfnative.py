@@ -182,12 +182,12 @@ class RawBatch:
                          mask.ctypes.data if mask.dtype == np.uint32 else None, fv, harr, karr, kk)
         lib = self.reader._lib
         err = C.c_int32()
-        cap = int(sum(self.b.line_end[i] - self.b.line_off[i] for i in range(self.n)) * 1.3) + (1 << 16)
+        cap = int((int(self.b.line_end[self.n - 1]) - int(self.b.line_off[0])) * 1.3) + (1 << 16) if self.n else 16
         while True:
-            buf = (C.c_char * cap)()
-            n = lib.trk_vcf_dumpstr_lines(C.byref(self.b), C.byref(prm), buf, cap, C.byref(err))
+            buf = np.empty(cap, dtype=np.uint8)          # not zero-filled; handed to the writer as a memoryview
+            n = lib.trk_vcf_dumpstr_lines(C.byref(self.b), C.byref(prm), buf.ctypes.data, cap, C.byref(err))
             if n >= 0:
-                return C.string_at(buf, n)
+                return memoryview(buf)[:n]
             if n <= -(1 << 63) + 1:
                 return None
             cap = -n + 64
