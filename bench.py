@@ -748,6 +748,28 @@ def end_to_end_extra(eng, seed):
                         "compressed), to its .tab file" % (Lc, S, os.path.getsize(path) / 1e6),
             "seconds": best, "loci_per_s": Lc / best, "calls_per_s": Lc * S / best,
             "rows": sum(1 for _ in open(ns.out + '.tab')) - 1}
+        # dumpSTR on the same file: three call filters + four locus filters, output VCF (~180 MB) and the two logs
+        from trtools_amd.dumpSTR import dumpSTR
+        argv = sys.argv
+        sys.argv = ['dumpSTR', '--vcf', path, '--out', os.path.join(tmp, 'dump'), '--vcftype', 'hipstr',
+                    '--hipstr-min-call-DP', '10', '--hipstr-max-call-DP', '55', '--hipstr-min-call-Q', '0.9',
+                    '--min-locus-callrate', '0.8', '--min-locus-hwep', '0.001', '--min-locus-het', '0.05',
+                    '--max-locus-het', '0.9']
+        try:
+            dargs = dumpSTR.getargs()
+        finally:
+            sys.argv = argv
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rc = dumpSTR.main(dargs)
+            el = time.perf_counter() - t0
+            assert rc == 0
+            best = el if best is None else min(best, el)
+        out["dumpstr_cli_text_vcf_to_vcf"] = {
+            "workload": "dumpSTR (min/max call DP, min call Q; call rate, HWE, het low/high) on the same file, to an "
+                        "output VCF of %.0f MB + sample and locus logs" % (os.path.getsize(os.path.join(tmp, 'dump.vcf')) / 1e6),
+            "seconds": best, "loci_per_s": Lc / best, "calls_per_s": Lc * S / best}
         for f in os.listdir(tmp):
             os.remove(os.path.join(tmp, f))
         os.rmdir(tmp)

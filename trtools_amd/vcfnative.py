@@ -331,14 +331,23 @@ class NativeVCFReader(vcfio.VCFReader):
                     [np.empty((n, S, nc), dtype=dt) for _, _, nc, dt in self._selected])
         key = (n, S, P, tuple((nc, np.dtype(dt).str) for _, _, nc, dt in self._selected))
         if len(self._ring) < self._ring_n or self._ring[self._ring_i % self._ring_n][0] != key:
+            # one slab per ring slot (a pinned allocation costs milliseconds whatever its size), carved 64-byte aligned
+            shapes = [((n, S, P), np.int16), ((n, S), np.uint8), ((n,), np.uint8)] + \
+                     [((n, S, nc), dt) for _, _, nc, dt in self._selected]
+            sizes = [(int(np.prod(sh, dtype=np.int64)) * np.dtype(dt).itemsize + 63) & ~63 for sh, dt in shapes]
+            total = max(sum(sizes), 64)
+            if self._alloc is not None:
+                slab = self._alloc(total)
+            else:
+                slab = np.empty(total, dtype=np.uint8)
+                slab[:] = 0                                      # touch the pages now, not in the parser threads
+            cursor = [0]
+
             def take(shape, dt):
                 nb = int(np.prod(shape, dtype=np.int64)) * np.dtype(dt).itemsize
-                if self._alloc is not None:
-                    raw = self._alloc(nb)
-                else:
-                    raw = np.empty(max(nb, 16), dtype=np.uint8)
-                    raw[:] = 0                                   # touch the pages now, not in the parser threads
-                return raw[:nb].view(dt).reshape(shape)
+                a = slab[cursor[0]:cursor[0] + nb].view(dt).reshape(shape)
+                cursor[0] += (nb + 63) & ~63
+                return a
             slot = (key, (take((n, S, P), np.int16), take((n, S), np.uint8), take((n,), np.uint8),
                           [take((n, S, nc), dt) for _, _, nc, dt in self._selected]))
             if len(self._ring) < self._ring_n:
