@@ -1,21 +1,29 @@
 #!/bin/bash
-# The three rocprofv3 passes behind profiles/<tag>_*: kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in their own
-# runs (never combined with another trace domain), all around the same bench command.  Run on the GPU box:
-#   gpurun -- bash tools/profile_round.sh r01e
+# The rocprofv3 passes behind profiles/<tag>_*: kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in their own runs
+# (never combined with another trace domain), around (a) the bench command -- headline step + the associaTR extra --
+# and (b) tools/config_probe.py (BASELINE configs[1] and configs[2], HipSTR five-filter set).  Run on the GPU box:
+#   gpurun -- bash tools/profile_round.sh r02
 set -u
-tag=${1:-r01e}
+tag=${1:-r02}
 repo=$(pwd)
 out=$repo/gpurun_out/$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-cmd="python $repo/bench.py --steps 5 --warmup 2"
-rocprofv3 --kernel-trace --stats -d "$out/stats" -o stats -- $cmd > "$out/bench_under_rocprof.log" 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/fetch" -o fetch -- $cmd --steps 2 > "$out/pmc_fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/write" -o write -- $cmd --steps 2 > "$out/pmc_write.log" 2>&1
-cd "$repo"
 db() { find "$out/$1" -name '*.db' | head -1; }
-python tools/rocprof_summary.py stats "$(db stats)" > "$out/${tag}_kernel_stats.csv"
-python tools/rocprof_summary.py pmc "$(db fetch)" "$(db write)" > "$out/${tag}_pmc_fetch_write.csv"
-tail -1 "$out/bench_under_rocprof.log" | cut -c1-400
-head -12 "$out/${tag}_kernel_stats.csv"
-grep -i "call_filter\|locus_count\|assoc_scan\|k_synth" "$out/${tag}_pmc_fetch_write.csv" | head -20
+run3() {   # name, command...: stats pass + two PMC passes of the same command
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats -d "$out/${name}_stats" -o stats -- "$@" > "$out/${name}_under_rocprof.log" 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/${name}_fetch" -o fetch -- "$@" > "$out/${name}_pmc_fetch.log" 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/${name}_write" -o write -- "$@" > "$out/${name}_pmc_write.log" 2>&1
+  ( cd "$repo" && python tools/rocprof_summary.py stats "$(db ${name}_stats)" > "$out/${tag}_${name}_kernel_stats.csv" \
+    && python tools/rocprof_summary.py pmc "$(db ${name}_fetch)" "$(db ${name}_write)" > "$out/${tag}_${name}_pmc_fetch_write.csv" )
+}
+run3 bench python "$repo/bench.py" --steps 5 --warmup 2 --no-check --no-cpu-baseline --no-extras
+run3 configs python "$repo/tools/config_probe.py"
+cd "$repo"
+python tools/pmc_traffic.py "$out/${tag}_bench_pmc_fetch_write.csv" "$out/${tag}_configs_pmc_fetch_write.csv" "$tag" > "$out/${tag}_pmc_traffic.json"
+grep -h "^{" "$out/bench_under_rocprof.log" | tail -1 | cut -c1-300
+head -14 "$out/${tag}_bench_kernel_stats.csv"
+head -12 "$out/${tag}_configs_kernel_stats.csv"
+grep "configs\|HipSTR" "$out/configs_under_rocprof.log" | cut -c1-260
+cat "$out/${tag}_pmc_traffic.json" | head -40
