@@ -83,3 +83,61 @@ def test_statstr_flag_combinations_cpu(tmp_path, name):
 def test_statstr_flag_combinations_gpu(tmp_path, name):
     from trtools_amd.compute import DeviceCompute
     _run_stat(tmp_path, DeviceCompute(), name)
+
+
+def _api_checks(compute):
+    """TRRecord.GetAlleleCounts / GetAlleleFreqs / GetMaxAllele with every kind of ``sample_index`` numpy accepts as a
+    row index (reference tr_harmonizer.py:1400-1401, 1488-1489: ``gts[sample_index, :]``) against the oracle, and the
+    per-record cache: the three getters of one (record, sample_index) cost ONE pass through the compute seam."""
+    import numpy as np
+    from oracle import trtools_oracle as orc
+    from trtools_amd import runtime
+    from trtools_amd.utils import tr_harmonizer as trh, utils
+
+    class Counting:
+        def __init__(self, inner):
+            self.inner, self.calls = inner, 0
+
+        def locus_stats(self, hb, nalleles_thresh=0.01):
+            self.calls += 1
+            return self.inner.locus_stats(hb, nalleles_thresh=nalleles_thresh)
+
+    seam = Counting(compute)
+    old = runtime.set_compute(seam)
+    try:
+        reader = utils.LoadSingleReader(os.path.join(GOLDEN, 'dumpstr_synth', 'synth_hipstr.vcf'), checkgz=False)
+        rng = np.random.default_rng(8)
+        n_checked = 0
+        for i, rec in enumerate(trh.TRRecordHarmonizer(reader, 'hipstr')):
+            if i % 9:
+                continue
+            S = rec.GetNumSamples()
+            gt = rec.vcfrecord.genotype.array()[:, :-1]
+            lens = [rec.ref_allele_length] + list(rec.alt_allele_lengths)
+            for si in (None, rng.random(S) < 0.6, rng.permutation(S)[:S // 2], rng.integers(0, S, size=S + 7),
+                       np.array([-1, 0, 0, 0, -2, 3]), [2, 2, 2]):
+                before = seam.calls
+                got = rec.GetAlleleCounts(sample_index=si)
+                want = orc.get_allele_counts(gt, lens, None if si is None else np.asarray(si))
+                assert {float(k): int(v) for k, v in got.items()} == {float(k): int(v) for k, v in want.items()}, (i, si)
+                fr = rec.GetAlleleFreqs(sample_index=si)
+                assert abs(sum(fr.values()) - 1.0) < 1e-12 or not fr
+                mx = rec.GetMaxAllele(sample_index=si)
+                wmx = orc.get_max_allele(gt, lens, None if si is None else np.asarray(si))
+                assert (np.isnan(mx) and np.isnan(wmx)) or mx == wmx
+                assert seam.calls == before + 1, "three getters of one (record, sample_index): one pass"
+                n_checked += 1
+        assert n_checked >= 24
+    finally:
+        runtime.set_compute(old)
+
+
+def test_sample_index_kinds_and_stats_cache_cpu():
+    from oracle_compute import OracleCompute
+    _api_checks(OracleCompute())
+
+
+@pytest.mark.gpu
+def test_sample_index_kinds_and_stats_cache_gpu():
+    from trtools_amd.compute import DeviceCompute
+    _api_checks(DeviceCompute())

@@ -430,21 +430,48 @@ class TRRecord:
 
     # ---- reductions over samples: GPU ----------------------------------------------------
     def _device_stats(self, sample_index=None):
-        """One-locus batch through trk_locus_stats; ``sample_index`` as one sample group."""
+        """One-locus batch through trk_locus_stats; ``sample_index`` as one sample group.
+
+        The result is kept per (genotype array, sample_index): GetAlleleCounts, GetAlleleFreqs and GetMaxAllele of one
+        record cost one upload and one launch together, not one each (the reference recomputes per call,
+        tr_harmonizer.py:1420-1575).  ``sample_index`` may be anything numpy takes as a row index (:1400-1401,
+        :1488-1489): a boolean mask or unique indices become a sample group on the device; an index that repeats
+        samples is expanded on the host first (the repeated rows are uploaded as samples of their own), so that a
+        sample counts as often as it is named."""
         from .. import runtime
         from ..batch import pack_records
-        masks = None
+        gt_obj = self.vcfrecord._gt if hasattr(self.vcfrecord, '_gt') else None
+        key = None
         if sample_index is not None:
             si = np.asarray(sample_index)
-            if si.dtype != bool and len(np.unique(si)) != len(si):
-                raise NotImplementedError("repeated sample indices are not supported by the device path")
-            m = np.zeros(self.GetNumSamples(), dtype=bool)
-            m[si] = True
-            masks = [m]
+            key = (si.dtype.str, si.shape, si.tobytes())
+        cache = getattr(self, '_stats_cache', None)
+        if cache is not None and cache[0] is gt_obj and gt_obj is not None and key in cache[1]:
+            return cache[1][key]
+        masks, expand = None, None
+        if sample_index is not None:
+            if si.dtype == bool:
+                masks = [si]
+            else:
+                idx = np.arange(self.GetNumSamples())[si]          # numpy's own index semantics (negatives, slices)
+                if len(np.unique(idx)) == len(idx):
+                    m = np.zeros(self.GetNumSamples(), dtype=bool)
+                    m[idx] = True
+                    masks = [m]
+                else:
+                    expand = idx
         hb = pack_records([self], masks)
+        if expand is not None:
+            hb.gt = np.ascontiguousarray(hb.gt[:, expand, :])
+            hb.n_samples = hb.gt.shape[1]
         st = runtime.get_compute().locus_stats(hb)
         if st.locus_int[0, 0, L.LI_N_BAD]:
             raise IndexError("genotype index out of range for the alleles of record {}".format(str(self)))
+        if gt_obj is not None:
+            if cache is None or cache[0] is not gt_obj:
+                self._stats_cache = cache = (gt_obj, {})
+            if len(cache[1]) < 16:
+                cache[1][key] = (st, hb)
         return st, hb
 
     def GetAlleleCounts(self, sample_index=None, *, uselength=True, index=False, fullgenotypes=False):
