@@ -195,8 +195,12 @@ def load():
         raise TrkError("libtrk.so is not built (%s). Run `make -C trtools_amd/csrc` or "
                        "`python -c 'import __graft_entry__ as g; g.build()'`. "
                        "There is no CPU fallback." % LIB_PATH)
-    _ensure_current()
-    lib = C.CDLL(LIB_PATH)
+    alt = os.environ.get('TRK_LIBTRK')          # A/B runs of two builds on one box (tools/ab_bench.sh)
+    if alt:
+        lib = C.CDLL(alt)
+    else:
+        _ensure_current()
+        lib = C.CDLL(LIB_PATH)
     vp, i32, i64, u64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
     P = C.POINTER
     lib.trk_init.argtypes = [C.c_int, P(vp)]
