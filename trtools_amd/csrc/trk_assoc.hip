@@ -469,6 +469,361 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan(const AssocArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------
+// streaming scan, ONE or TWO trait vectors (associaTR's default: the outcome alone, or with one covariate).
+// Same layout and results as k_assoc_scan; rewritten around what the counters say of it at 100k x 10k
+// (SQ_ACTIVE_INST_VALU = 86 % of the wave-cycles of a SIMD, 22 VALU instructions per 64 calls of which 7 are per-locus
+// work): the kernel is bound by vector instruction issue, not by LDS or HBM.  So:
+//   * the four calls of a 16-byte chunk are a batch: their eight LUT reads and the trait values are issued back to
+//     back ahead of the chunk's histogram atomics (reads cannot pass atomics, so the per-call version met the LDS
+//     latency once per call);
+//   * LDS byte addresses straight from the packed 16-bit bins with v_mad_u32_u16 (op_sel picks the high half): one
+//     instruction per address instead of and/shift + shift-add; the not-tested select is made once on the packed
+//     pair (-> bins 1, 1); without a sample mask the summed length of a missing call is NaN with a zero low word,
+//     so clearing its HIGH word alone makes it +0.0;
+//   * sum g is not accumulated per call: it follows from the histogram (sum over bins of count x length);
+//   * histogram copies per LOCUS: as many as its bins leave room for in the wave's 3 KiB (32 = one per bank of a
+//     32-lane group, conflict free), folded by bins x parts lanes with 16-byte reads;
+//   * the next U chunks of the row are requested while the current ones are processed, the first ones before the
+//     locus's tables are built;
+//   * missing calls are queued once per U chunks (one 32-bit record: first chunk, 4U-bit set) instead of per chunk;
+//   * the per-locus wave reductions (sum g^2, sum g v, the Gram corrections) go through LDS, eight values at a
+//     time (column sums by 8 lanes each + three shuffle steps), instead of six shuffle steps per value.
+// 100k x 10k, 1 trait: 1.05 -> ... ms (profiles/r02_notes.md section 7).
+// -------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) const double* lds_cf64;
+typedef __attribute__((address_space(3))) uint32_t* lds_u32;
+__device__ __forceinline__ uint32_t mad16_lo(uint32_t t, uint32_t k, uint32_t b) {
+    uint32_t r;
+    asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(t), "v"(k), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t mad16_hi(uint32_t t, uint32_t k, uint32_t b) {
+    uint32_t r;
+    asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(t), "v"(k), "v"(b));
+    return r;
+}
+struct QuadCtx {
+    const double* vec;  // LDS [MV][Sr]
+    int Sr;
+    uint32_t lut_b;     // LDS byte address of the length LUT (by bin)
+    uint32_t hist_b;    // LDS byte address of this lane's histogram column
+    uint32_t kbytes;    // bytes between two bins of the histogram (4 << kshift)
+    uint32_t eight;
+    uint32_t amax2;
+};
+template <int MV>
+struct FewAcc {
+    double sgg = 0.0;
+    double sgv[MV];
+};
+// The four calls of one 16-byte chunk; `mk`: their regression-set bytes (MASK only).  Returns the 4-bit set of
+// samples that are in the regression set but not called here.
+template <int MV, bool MASK>
+__device__ __forceinline__ uint32_t scan_quad(const QuadCtx& q, const u32x4 v, uint32_t mk, int s0, FewAcc<MV>& acc) {
+    uint32_t t[4];
+    double gl[4], gh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t w = v[j];   // (a bit_cast of the vector element itself reads element 0)
+        u16x2 u = __builtin_bit_cast(u16x2, w) + (u16x2){2, 2};
+        u16x2 t2 = __builtin_elementwise_min(u, __builtin_bit_cast(u16x2, q.amax2));
+        t[j] = __builtin_bit_cast(uint32_t, t2);
+        gl[j] = *(lds_cf64)(uintptr_t)mad16_lo(t[j], q.eight, q.lut_b);
+        gh[j] = *(lds_cf64)(uintptr_t)mad16_hi(t[j], q.eight, q.lut_b);
+    }
+    double y[MV][4];
+#pragma unroll
+    for (int k = 0; k < MV; ++k) {
+        const double2 a0 = *reinterpret_cast<const double2*>(&q.vec[(size_t)k * q.Sr + s0]);
+        const double2 a1 = *reinterpret_cast<const double2*>(&q.vec[(size_t)k * q.Sr + s0 + 2]);
+        y[k][0] = a0.x; y[k][1] = a0.y; y[k][2] = a1.x; y[k][3] = a1.y;
+    }
+    uint32_t rare = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double g = gl[j] + gh[j];   // NaN when either haplotype is '-1'
+        const bool called = g == g;
+        bool ok = called;
+        if (MASK) {
+            const bool in = (mk >> (8 * j)) & 1u;
+            ok = called & in;
+            rare |= (in & !called) ? (1u << j) : 0u;
+            g = ok ? g : 0.0;
+        } else {
+            rare |= called ? 0u : (1u << j);
+            // the NaN is the LUT's (payload 0, and NaN + x keeps it): without its high word it is +0.0
+            const uint64_t gb = __builtin_bit_cast(uint64_t, g);
+            const uint32_t hi = called ? (uint32_t)(gb >> 32) : 0u;
+            g = __builtin_bit_cast(double, ((uint64_t)hi << 32) | (uint32_t)gb);
+        }
+        // calls that are not tested are counted in bin 1 (2 per call): n = calls - bin1 / 2
+        const uint32_t tb = ok ? t[j] : 0x00010001u;
+        __hip_atomic_fetch_add((lds_u32)(uintptr_t)mad16_lo(tb, q.kbytes, q.hist_b), 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add((lds_u32)(uintptr_t)mad16_hi(tb, q.kbytes, q.hist_b), 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+        acc.sgg = __builtin_fma(g, g, acc.sgg);
+#pragma unroll
+        for (int k = 0; k < MV; ++k) acc.sgv[k] = __builtin_fma(g, y[k][j], acc.sgv[k]);
+    }
+    return rare;
+}
+
+// U 16-byte chunks of a genotype row per lane, chunk indices past `last` clamped (the consumer skips them)
+template <int U>
+__device__ __forceinline__ void scan_fetch(const u32x4* __restrict__ row, int lane, int last, u32x4 (&v)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int c = lane + u * WAVE;
+        v[u] = __builtin_nontemporal_load(&row[c < last ? c : (last > 0 ? last : 0)]);
+    }
+}
+
+constexpr int AF_QCAP = 256;  // 32-bit records per wave: first chunk of the lane's iteration << 16 | 4U-bit set
+constexpr int AF_AREA = 3072; // histogram + LUT of the wave's current locus
+
+// lane = queued record; every lane keeps the (small) Gram triangle of its samples in registers -- rows 0..MV-1 the
+// vectors (zero beyond M), row MV the ones
+template <int MV>
+__device__ __forceinline__ void drain_few(const QuadCtx& q, const uint32_t* queue, int qlen, int lane, double* cs) {
+    wave_fence();
+    for (int b0 = 0; b0 < qlen; b0 += WAVE) {
+        const uint32_t rec = b0 + lane < qlen ? queue[b0 + lane] : 0u;
+        uint32_t bits = rec & 0xffffu;
+        const int c0 = (int)(rec >> 16);
+        while (bits) {
+            const int b = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            const int s = ((c0 + (b >> 2) * WAVE) << 2) + (b & 3);
+            double z[MV + 1];
+#pragma unroll
+            for (int k = 0; k < MV; ++k) z[k] = q.vec[(size_t)k * q.Sr + s];
+            z[MV] = 1.0;
+            int e = 0;
+#pragma unroll
+            for (int r = 0; r <= MV; ++r)
+#pragma unroll
+                for (int cc = r; cc <= MV; ++cc) cs[e++] += z[r] * z[cc];
+        }
+    }
+    wave_fence();
+}
+
+template <int MV, bool MASK>
+__global__ __launch_bounds__(AS_THREADS) void k_assoc_scan_few(const AssocArgs a) {
+    static_assert(MV == 1 || MV == 2, "trait vectors");
+    extern __shared__ double lds_d[];
+    constexpr int U = MV == 1 ? 4 : 2;             // 16-byte chunks per lane and iteration
+    constexpr int NCS = (MV + 1) * (MV + 2) / 2;   // Gram triangle of [vec..., 1]
+    constexpr int NV = 2 + MV + NCS;               // per-locus wave sums: g^2, g, g v_k, corrections
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wid = tid >> 6;
+    const int S = a.b.n_samples, M = a.M, Sc = a.chunk;
+    const int s_begin = blockIdx.y * Sc;
+    const int ns = min(S - s_begin, Sc);  // multiple of 4
+    const int Sr = Sc;
+    double* vec = lds_d;                                                   // [MV][Sr], rows >= M zero
+    uint32_t* maskw = reinterpret_cast<uint32_t*>(vec + (size_t)MV * Sr);  // [Sc/4] one byte per sample
+    unsigned char* wave_base = reinterpret_cast<unsigned char*>(maskw + Sc / 4) + (size_t)wid * a.wave_bytes;
+    uint32_t* queue = reinterpret_cast<uint32_t*>(wave_base);              // [AF_QCAP] missing-call records
+    unsigned char* area_p = wave_base + AF_QCAP * sizeof(uint32_t);        // [AF_AREA]
+    double* red = reinterpret_cast<double*>(wave_base);                    // [8][WAVE], end of a locus
+
+    // stage this chunk of the sample vectors (zero for samples outside the regression set)
+    for (int i = tid; i < ns; i += AS_THREADS) {
+        const bool in = !MASK || a.sample_in[s_begin + i];
+        if (MASK) reinterpret_cast<unsigned char*>(maskw)[i] = in ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < MV; ++k) vec[(size_t)k * Sr + i] = (in && k < M) ? a.vec[(size_t)k * S + s_begin + i] : 0.0;
+    }
+    __syncthreads();
+
+    const int nch = ns >> 2;
+    // waves are independent from here on; loci are handed out as in k_assoc_scan
+    const int n_waves = gridDim.x * AS_WAVES;
+    const int l_dyn0 = a.loci_per_wg ? 0 : (int)(((int64_t)a.b.n_loci * 7 / 8) / n_waves) * n_waves;
+    int l_static = a.loci_per_wg ? blockIdx.x * a.loci_per_wg + wid : blockIdx.x * AS_WAVES + wid;
+    const int l_end = a.loci_per_wg ? min(a.b.n_loci, (int)(blockIdx.x + 1) * a.loci_per_wg) : a.b.n_loci;
+    for (;;) {
+        int l;
+        if (a.loci_per_wg) {
+            l = l_static;
+            l_static += AS_WAVES;
+        } else if (l_static < l_dyn0) {
+            l = l_static;
+            l_static += n_waves;
+        } else {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(&a.work_counter[blockIdx.y], 1);
+            l = l_dyn0 + __builtin_amdgcn_readfirstlane(t);
+        }
+        if (l >= l_end) break;
+        // the row's first chunks travel while the wave builds the locus's tables
+        const u32x4* row = reinterpret_cast<const u32x4*>(a.b.gt + ((int64_t)l * S + s_begin) * 2);
+        u32x4 cur[U];
+        scan_fetch<U>(row, lane, nch - 1, cur);
+        const int off = a.b.allele_off[l];
+        const int A = a.b.allele_off[l + 1] - off;
+        const int nb = A + 3;   // bins: 0 '-2', 1 '-1' / not tested, 2..A+1 alleles, A+2 out of range
+        int kshift = 5;
+        while (kshift > 0 && nb * (8 + (4 << kshift)) + 8 > AF_AREA) --kshift;
+        const int K = 1 << kshift;
+        uint32_t* hist = reinterpret_cast<uint32_t*>(area_p);                                   // [nb << kshift]
+        double* lut = reinterpret_cast<double*>(area_p + (((nb << kshift) * 4 + 7) & ~7));      // [nb]
+        const double pivot = a.allele_len[off];
+        for (int i = lane; i < A; i += WAVE) lut[i + 2] = a.allele_len[off + i] - pivot;
+        if (lane == 0) {
+            lut[0] = -2.0 - pivot;  // GetLengthGenotypes maps the padding index -2 to the length -2
+            lut[1] = __builtin_nan("");
+            lut[A + 2] = 0.0;
+        }
+        if (kshift >= 2) {
+            const u32x4 z4 = {0u, 0u, 0u, 0u};
+            for (int i = lane; i < (nb << (kshift - 2)); i += WAVE) reinterpret_cast<u32x4*>(hist)[i] = z4;
+        } else {
+            for (int i = lane; i < (nb << kshift); i += WAVE) hist[i] = 0;
+        }
+        wave_fence();
+
+        const QuadCtx qc{vec, Sr, (uint32_t)(uintptr_t)(lds_cf64)lut,
+                         (uint32_t)(uintptr_t)(lds_u32)hist + 4u * (uint32_t)(lane & (K - 1)), 4u << kshift, 8u,
+                         (uint32_t)(A + 2) * 0x00010001u};
+        FewAcc<MV> acc;
+#pragma unroll
+        for (int k = 0; k < MV; ++k) acc.sgv[k] = 0.0;
+        double cs[NCS];
+#pragma unroll
+        for (int e = 0; e < NCS; ++e) cs[e] = 0.0;
+        int qlen = 0;
+        for (int base = 0; base < nch; base += U * WAVE) {
+            u32x4 nxt[U];
+            const bool more = base + U * WAVE < nch;   // uniform over the wave
+            if (more) scan_fetch<U>(row + base + U * WAVE, lane, nch - 1 - (base + U * WAVE), nxt);
+            uint32_t set = 0;
+            if (base + U * WAVE <= nch) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int c = base + u * WAVE + lane;
+                    set |= scan_quad<MV, MASK>(qc, cur[u], MASK ? maskw[c] : 0u, c * 4, acc) << (4 * u);
+                }
+            } else {   // the row's last, partial iteration: lanes past the end sit out
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int c = base + u * WAVE + lane;
+                    if (c < nch) set |= scan_quad<MV, MASK>(qc, cur[u], MASK ? maskw[c] : 0u, c * 4, acc) << (4 * u);
+                }
+            }
+            {   // queue the lanes that met missing calls (ballot + mbcnt: deterministic order)
+                const uint64_t mm = __ballot(set != 0);
+                if (mm) {
+                    const int pos = qlen + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32),
+                                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+                    if (set) queue[pos] = ((uint32_t)(base + lane) << 16) | set;
+                    qlen += __popcll(mm);
+                }
+            }
+            if (qlen > AF_QCAP - WAVE) {
+                drain_few<MV>(qc, queue, qlen, lane, cs);
+                qlen = 0;
+            }
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+            }
+        }
+        drain_few<MV>(qc, queue, qlen, lane, cs);
+        // ---- fold the histogram: lanes = bins x parts, every part adds K / parts copies read 16 bytes at a time ----
+        double* rec = a.partial + ((size_t)blockIdx.y * a.b.n_loci + l) * a.NS;
+        double sg_h = 0.0;   // sum g of the tested calls = sum over their haplotypes' bins of count x length
+        auto bin_done = [&](int bin, uint32_t sum) {
+            if (bin != 1) sg_h += (double)sum * lut[bin];
+            if (bin >= 2 && bin < A + 2) {
+                if (a.nchunks == 1)
+                    a.allele_count[off + bin - 2] = (int32_t)sum;
+                else if (sum)
+                    atomicAdd(&a.allele_count[off + bin - 2], (int32_t)sum);
+            }
+            if (bin == 1) rec[0] = (double)(ns - (int)(sum >> 1));  // tested samples of this chunk
+            if (bin == A + 2) rec[a.NS - 1] = (double)sum;
+        };
+        if (kshift >= 2) {
+            int pshift = kshift - 2;
+            while (pshift > 0 && (nb << pshift) > WAVE) --pshift;
+            const int part = lane & ((1 << pshift) - 1);
+            const int per4 = K >> (pshift + 2);   // 16-byte reads per part
+            for (int bin0 = 0; bin0 < nb; bin0 += WAVE >> pshift) {
+                const int bin = bin0 + (lane >> pshift);
+                uint32_t sum = 0;
+                if (bin < nb) {
+                    const u32x4* hp = reinterpret_cast<const u32x4*>(hist + (bin << kshift)) + part * per4;
+                    for (int i = 0; i < per4; ++i) {
+                        const u32x4 h = hp[i];
+                        sum += (h.x + h.y) + (h.z + h.w);
+                    }
+                }
+                for (int o = (1 << pshift) >> 1; o > 0; o >>= 1) sum += (uint32_t)__shfl_xor((int)sum, o, WAVE);
+                if (bin < nb && part == 0) bin_done(bin, sum);
+            }
+        } else {
+            for (int bin = lane; bin < nb; bin += WAVE) {
+                uint32_t sum = 0;
+                for (int k = 0; k < K; ++k) sum += hist[(bin << kshift) + k];
+                bin_done(bin, sum);
+            }
+        }
+        wave_fence();
+        // ---- the per-lane sums, eight values at a time through the wave's LDS (queue and tables are done with) ----
+        double vals[NV];
+        vals[0] = acc.sgg;
+        vals[1] = sg_h;
+#pragma unroll
+        for (int k = 0; k < MV; ++k) vals[2 + k] = acc.sgv[k];
+#pragma unroll
+        for (int e = 0; e < NCS; ++e) vals[2 + MV + e] = cs[e];
+#pragma unroll
+        for (int v0 = 0; v0 < NV; v0 += 8) {
+#pragma unroll
+            for (int v = v0; v < NV && v < v0 + 8; ++v) red[(v - v0) * WAVE + lane] = vals[v];
+            wave_fence();
+            const int vi = v0 + (lane >> 3), p8 = lane & 7;
+            double sum = 0.0;
+            if (vi < NV) {
+                const double2* rp = reinterpret_cast<const double2*>(red + (vi - v0) * WAVE + p8 * 8);
+                const double2 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+                sum = ((r0.x + r0.y) + (r1.x + r1.y)) + ((r2.x + r2.y) + (r3.x + r3.y));
+            }
+            sum += __shfl_xor(sum, 1, WAVE);
+            sum += __shfl_xor(sum, 2, WAVE);
+            sum += __shfl_xor(sum, 4, WAVE);
+            if (vi < NV && p8 == 0) {
+                int tgt = -1;   // column of the partial record (static rows -> this call's rows: vectors beyond M
+                if (vi == 0) {  // do not exist, the ones are row M)
+                    tgt = 2;
+                } else if (vi == 1) {
+                    tgt = 1;
+                } else if (vi < 2 + MV) {
+                    if (vi - 2 < M) tgt = 3 + (vi - 2);
+                } else {
+                    int e = vi - 2 - MV, r = 0;
+                    while (e >= MV + 1 - r) {
+                        e -= MV + 1 - r;
+                        ++r;
+                    }
+                    const int cc = r + e;
+                    if ((r == MV || r < M) && (cc == MV || cc < M)) {
+                        const int rr = r == MV ? M : r, rc = cc == MV ? M : cc;
+                        tgt = 3 + M + rr * (M + 1) - rr * (rr - 1) / 2 + (rc - rr);
+                    }
+                }
+                if (tgt >= 0) rec[tgt] = sum;
+            }
+            wave_fence();
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
 // streaming scan, many covariates: the cross-products  sum_s g[l][s] * v_k[s]  of SIXTEEN loci
 // and up to 16*RT vector rows are a GEMM tile, done with v_mfma_f64_16x16x4_f64.
 //   workgroup = 16 waves = 16 loci; the row is walked in steps of 256 samples:
@@ -1724,6 +2079,10 @@ static AssocPlan assoc_plan(const trk_batch& b, int M) {
     }
     if (M > 16) return p;  // the LDS-resident kernels are instantiated up to 16 vectors
     p.wave_bytes = AS_QCAP * 2 + (((Amax + 3) * (8 + (4 << kshift)) + 15) & ~15);
+    if (p.mv <= 2) {   // k_assoc_scan_few: queue + 3 KiB of tables per wave, copies per locus; one copy must fit
+        if ((Amax + 3) * 12 + 8 > AF_AREA) return p;
+        p.wave_bytes = AF_QCAP * 4 + AF_AREA;
+    }
     const size_t lds_total = 160 * 1024;
     const size_t rem = lds_total - (size_t)AS_WAVES * p.wave_bytes - 64 - 8 * (size_t)p.mv;
     int chunk = (int)(rem / (8 * (size_t)p.mv + 1));
@@ -1765,7 +2124,12 @@ size_t assoc_workspace_bytes(const trk_batch& b, int M) {
 
 template <int MV, bool MASK>
 static hipError_t launch_scan_tm(const AssocArgs& a, const AssocPlan& p, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assoc_scan<MV, MASK>),
+    void (*kern)(const AssocArgs) = &k_assoc_scan<MV, MASK>;
+    if constexpr (MV <= 2) {   // TRK_AS_OLD_SCAN=1: the per-call kernel, for A/B timing
+        static const bool old_scan = getenv("TRK_AS_OLD_SCAN") != nullptr;
+        if (!old_scan) kern = &k_assoc_scan_few<MV, MASK>;
+    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     if (e != hipSuccess) return e;
     int gx;
@@ -1778,7 +2142,7 @@ static hipError_t launch_scan_tm(const AssocArgs& a, const AssocPlan& p, hipStre
         if (gx < 1) gx = 1;
     }
     dim3 grid(gx, p.nchunks), block(AS_THREADS);
-    hipLaunchKernelGGL((k_assoc_scan<MV, MASK>), grid, block, p.lds_bytes, stream, a);
+    hipLaunchKernelGGL(kern, grid, block, p.lds_bytes, stream, a);
     return hipGetLastError();
 }
 template <int MV>
