@@ -1928,6 +1928,12 @@ struct V2Args {
     trk_call_out out;
 };
 
+// x += (this lane's bit of the wave-wide mask): the mask goes in as the carry of an add-with-carry (one instruction;
+// written as a select and an add the compiler emits two)
+__device__ __forceinline__ void add_mask(uint32_t& x, uint64_t mask) {
+    asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(x) : "s"(mask) : "vcc");
+}
+
 // RATIO: some filter is a HipSTR-style ratio over the depth plane (float64 division, filters.py:415-484)
 template <int NF, bool DELTA, bool RATIO>
 __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
@@ -1949,6 +1955,13 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
     for (int k = 0; k < NF; ++k)
 #pragma unroll
         for (int j = 0; j < CF_V; ++j) fc[k][j] = 0;
+    uint64_t nn[NF];      // all lanes when the filter also applies to calls that are not made
+    uint32_t bitv[NF];    // the filter's bit of the mask word
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+        nn[k] = a.f[k].need_called == 0 ? ~0ull : 0ull;
+        bitv[k] = 1u << a.f[k].bit;
+    }
     const int n_blocks = (L + a.loci_per_block - 1) / a.loci_per_block;
     for (int by = blockIdx.y; by < n_blocks; by += gridDim.y) {
     const int l_begin = by * a.loci_per_block;
@@ -1972,77 +1985,131 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
             if (a.dp) dv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.dp) + c4);
             u32x4 wout, mout;
             uint32_t w0acc = 0, w1acc = 0;
+            // The decisions are kept as wave-wide 64-bit lane masks in scalar registers (ballots) and combined by
+            // scalar instructions; the vector side only compares, builds the mask word, and bumps the counters with
+            // the mask as carry-in.  The filter's kind is tested ONCE per filter and locus (four plain compares per
+            // arm).  (Written call-major with per-lane booleans and the kind tested inside, the compiler emitted the
+            // four-way test per call and filter, merged the booleans with three scalar instructions each and ran out
+            // of scalar registers -- SGPR spills are v_readlane / v_writelane, vector instructions: 98 VALU + 100
+            // SALU instructions per call, the SIMDs 67 % VALU-busy; profiles/r02_notes.md section 8.)
+            uint64_t hm[NF][CF_V];
+#pragma unroll
+            for (int k = 0; k < NF; ++k) {
+                const V2Filter& f = a.f[k];
+                if (RATIO && f.kind == 4) {
+                    // (deciding from x - thr * y and dividing only near ties was measured: 7.41 vs 7.19 ms, the
+                    // kernel has the issue slots for the division; profiles/r01_notes.md)
+#pragma unroll
+                    for (int j = 0; j < CF_V; ++j)
+                        hm[k][j] = __ballot(((double)(int32_t)pv[k][j] / (double)(int32_t)dv[j]) > f.dthr);
+                } else if (f.kind == 0) {
+#pragma unroll
+                    for (int j = 0; j < CF_V; ++j) hm[k][j] = __ballot((int32_t)pv[k][j] < f.ithr);
+                } else if (f.kind == 1) {
+#pragma unroll
+                    for (int j = 0; j < CF_V; ++j) hm[k][j] = __ballot((int32_t)pv[k][j] > f.ithr);
+                } else if (f.kind == 2) {
+#pragma unroll
+                    for (int j = 0; j < CF_V; ++j) hm[k][j] = __ballot(__uint_as_float(pv[k][j]) < f.fthr);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < CF_V; ++j) hm[k][j] = __ballot(__uint_as_float(pv[k][j]) > f.fthr);
+                }
+            }
+            uint64_t passm[CF_V], filtm[CF_V];
 #pragma unroll
             for (int j = 0; j < CF_V; ++j) {
                 const uint32_t w = g[j];
-                const bool called = ((w & 0xffffu) != 0xffffu) & ((w >> 16) != 0xffffu);
-                uint32_t m = called ? 0u : TRK_MASK_NOCALL;
+                // (one ballot per compare: the ballot of a combined condition goes through a 0/1 register)
+                const uint64_t calledm = __ballot((w & 0xffffu) != 0xffffu) & __ballot(w < 0xffff0000u);
+                uint32_t m = __builtin_amdgcn_inverse_ballot_w64(calledm) ? 0u : TRK_MASK_NOCALL;
+                uint64_t anyhit = 0;
 #pragma unroll
                 for (int k = 0; k < NF; ++k) {
-                    const V2Filter& f = a.f[k];
-                    bool hit;
-                    if (RATIO && f.kind == 4) {
-                        // (deciding from x - thr * y and dividing only near ties was measured: 7.41 vs 7.19 ms, the
-                        // kernel has the issue slots for the division; profiles/r01_notes.md)
-                        hit = ((double)(int32_t)pv[k][j] / (double)(int32_t)dv[j]) > f.dthr;
-                    } else if (f.kind & 2) {
-                        const float v = __uint_as_float(pv[k][j]);
-                        hit = (f.kind & 1) ? (v > f.fthr) : (v < f.fthr);
-                    } else {
-                        const int32_t v = (int32_t)pv[k][j];
-                        hit = (f.kind & 1) ? (v > f.ithr) : (v < f.ithr);
-                    }
-                    hit &= called | (f.need_called == 0);
-                    m |= hit ? (1u << f.bit) : 0u;
-                    fc[k][j] += hit & called;  // dumpSTR.py:661
+                    const uint64_t h = hm[k][j] & (calledm | nn[k]);
+                    m |= __builtin_amdgcn_inverse_ballot_w64(h) ? bitv[k] : 0u;
+                    add_mask(fc[k][j], h & calledm);  // dumpSTR.py:661
+                    anyhit |= h;
                 }
-                const bool pass = m == 0u;  // dumpSTR.py:686
-                numcalls[j] += pass;
-                if (a.dp) {
+                passm[j] = calledm & ~anyhit;   // mask word == 0: dumpSTR.py:686
+                filtm[j] = calledm & anyhit;    // called and not passing: dumpSTR.py:715-727
+                add_mask(numcalls[j], passm[j]);
+                wout[j] = __builtin_amdgcn_inverse_ballot_w64(filtm[j]) ? 0xffffffffu : w;
+                mout[j] = m;
+            }
+            if (a.dp) {
+                uint64_t bad = 0;
+#pragma unroll
+                for (int j = 0; j < CF_V; ++j) {
                     const int32_t d = (int32_t)dv[j];
-                    dpmiss[j] += pass & (d == INT32_MIN);
-                    totaldp[j] += (pass & (d > 0)) ? d : 0;
-                    if (pass & (d < 0) & (d != INT32_MIN)) {  // dumpSTR.py:698-706
-                        if (atomicCAS(&a.out.error[0], 0, 1) == 0) {
-                            a.out.error[1] = l;
-                            a.out.error[2] = (int32_t)(s0 + j);
+                    add_mask(dpmiss[j], passm[j] & __ballot(d == INT32_MIN));
+                    const int32_t dpos = d > 0 ? d : 0;
+                    totaldp[j] += __builtin_amdgcn_inverse_ballot_w64(passm[j]) ? dpos : 0;
+                    bad |= passm[j] & __ballot((uint32_t)d > 0x80000000u);   // negative, not the missing marker
+                }
+                if (bad) {   // a negative depth on a call that passes (cold): dumpSTR.py:698-706
+#pragma unroll
+                    for (int j = CF_V - 1; j >= 0; --j) {
+                        const int32_t d = (int32_t)dv[j];
+                        if ((mout[j] == 0u) & (d < 0) & (d != INT32_MIN)) {
+                            if (atomicCAS(&a.out.error[0], 0, 1) == 0) {
+                                a.out.error[1] = l;
+                                a.out.error[2] = (int32_t)(s0 + j);
+                            }
                         }
                     }
                 }
-                const bool filtered = called & !pass;  // dumpSTR.py:715-727
-                if (DELTA && V2_WRED) {
-                    // the per-locus words are sums of lane flags: count them with ballots, one LDS atomic per wave
-                    const int li = l - l_begin;
-                    uint32_t* tab = dtab + li * dstride;
-                    const int A = linfo[CF_LINFO * li];
-                    const int a0 = (int)(int16_t)(w & 0xffffu), a1 = (int)(int16_t)(w >> 16);
-                    const bool v0 = (unsigned)a0 < (unsigned)A, v1 = (unsigned)a1 < (unsigned)A;
-                    const bool low = filtered & ((a0 == -2) | (a1 == -2));
-                    bool hl = filtered & (a0 == a1) & v0, hs = hl;
+            }
+            uint32_t* tab = dtab;
+            if (DELTA && V2_WRED) {
+                // the per-locus words are sums of lane flags: count them from the masks, one LDS atomic per wave
+                const int li = l - l_begin;
+                tab = dtab + li * dstride;
+                const uint32_t A = (uint32_t)linfo[CF_LINFO * li];
+                const bool lut_needed = cf_lut_needed(linfo, li);
+                const uint32_t* lutl = lutb + li * nal;
+#pragma unroll
+                for (int j = 0; j < CF_V; ++j) {
+                    const uint32_t w = g[j];
+                    const uint32_t a0 = w & 0xffffu, a1 = w >> 16;   // unsigned halves: -1 = 0xffff, -2 = 0xfffe
+                    const bool filtered = __builtin_amdgcn_inverse_ballot_w64(filtm[j]);
+                    const bool v0 = a0 < A, v1 = a1 < A;             // (-2 / out of range: not below A)
+                    const uint64_t lowm = filtm[j] & (__ballot(a0 == 0xfffeu) | __ballot(a1 == 0xfffeu));
+                    // homozygous by index (same allele twice); by length / sequence class only where the locus has
+                    // alleles that share a class (uniform per locus, rare): then the LUT decides for a0 != a1
+                    uint64_t hlm = filtm[j] & __ballot(a0 == a1) & __ballot(v0), hsm = hlm;
                     if (filtered) {
-                        atomicAdd(&tab[v0 ? a0 : nal + V2_TRASH], 1u);
-                        atomicAdd(&tab[v1 ? a1 : nal + V2_TRASH], 1u);
-                        if (v0 && v1 && a0 != a1 && cf_lut_needed(linfo, li)) {
-                            const uint32_t q = lutb[li * nal + a0] ^ lutb[li * nal + a1];
-                            hl = (q & 0xffffu) == 0u;
-                            hs = (q >> 16) == 0u;
-                        }
+                        atomicAdd(&tab[v0 ? (int)a0 : nal + V2_TRASH], 1u);
+                        atomicAdd(&tab[v1 ? (int)a1 : nal + V2_TRASH], 1u);
                     }
-                    w0acc += (uint32_t)__popcll(__ballot(filtered)) + ((uint32_t)__popcll(__ballot(low)) << 16);
-                    w1acc += (uint32_t)__popcll(__ballot(hl)) + ((uint32_t)__popcll(__ballot(hs)) << 16);
-                } else if (DELTA) {
-                    if (filtered) {
-                        const int li = l - l_begin;
-                        uint32_t* tab = dtab + li * dstride;
-                        const int A = linfo[CF_LINFO * li];
-                        const int a0 = (int)(int16_t)(w & 0xffffu), a1 = (int)(int16_t)(w >> 16);
-                        const bool v0 = (unsigned)a0 < (unsigned)A, v1 = (unsigned)a1 < (unsigned)A;
-                        atomicAdd(&tab[v0 ? a0 : nal + V2_TRASH], 1u);
-                        atomicAdd(&tab[v1 ? a1 : nal + V2_TRASH], 1u);
-                        const bool low = (a0 == -2) | (a1 == -2);
-                        bool hl = (a0 == a1) & v0, hs = hl;
-                        if (v0 && v1 && !hl && cf_lut_needed(linfo, li)) {
-                            const uint32_t q = lutb[li * nal + a0] ^ lutb[li * nal + a1];
+                    if (lut_needed) {
+                        const bool need = filtered & v0 & v1 & (a0 != a1);
+                        uint32_t q = 0xffffffffu;
+                        if (need) q = lutl[a0] ^ lutl[a1];
+                        hlm |= __ballot((q & 0xffffu) == 0u);
+                        hsm |= __ballot((q >> 16) == 0u);
+                    }
+                    w0acc += (uint32_t)__popcll(filtm[j]) + ((uint32_t)__popcll(lowm) << 16);
+                    w1acc += (uint32_t)__popcll(hlm) + ((uint32_t)__popcll(hsm) << 16);
+                }
+            } else if (DELTA) {
+                const int li = l - l_begin;
+                tab = dtab + li * dstride;
+                const int A = linfo[CF_LINFO * li];
+                const bool lut_needed = cf_lut_needed(linfo, li);
+#pragma unroll
+                for (int j = 0; j < CF_V; ++j) {
+                    if (__builtin_amdgcn_inverse_ballot_w64(filtm[j])) {
+                        const uint32_t w = g[j];
+                        const int sa0 = (int)(int16_t)(w & 0xffffu), sa1 = (int)(int16_t)(w >> 16);
+                        const bool v0 = (unsigned)sa0 < (unsigned)A, v1 = (unsigned)sa1 < (unsigned)A;
+                        atomicAdd(&tab[v0 ? sa0 : nal + V2_TRASH], 1u);
+                        atomicAdd(&tab[v1 ? sa1 : nal + V2_TRASH], 1u);
+                        const bool low = (sa0 == -2) | (sa1 == -2);
+                        bool hl = (sa0 == sa1) & v0, hs = hl;
+                        if (v0 && v1 && !hl && lut_needed) {
+                            const uint32_t* lutl = lutb + li * nal;
+                            const uint32_t q = lutl[sa0] ^ lutl[sa1];
                             hl = (q & 0xffffu) == 0u;
                             hs = (q >> 16) == 0u;
                         }
@@ -2051,11 +2118,8 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
                         if (w1) atomicAdd(&tab[nal + V2_W1], w1);
                     }
                 }
-                wout[j] = filtered ? 0xffffffffu : w;
-                mout[j] = m;
             }
             if (DELTA && V2_WRED && leader) {
-                uint32_t* tab = dtab + (l - l_begin) * dstride;
                 if (w0acc) atomicAdd(&tab[nal + V2_W0], w0acc);
                 if (w1acc) atomicAdd(&tab[nal + V2_W1], w1acc);
             }
