@@ -1627,6 +1627,271 @@ __device__ __forceinline__ void cf_delta_call(const CfDelta& c, uint32_t w, int 
     }
 }
 
+// x += (this lane's bit of the wave-wide mask): the mask goes in as the carry of an add-with-carry (one instruction;
+// written as a select and an add the compiler emits two)
+__device__ __forceinline__ void add_mask(uint32_t& x, uint64_t mask) {
+    asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(x) : "s"(mask) : "vcc");
+}
+
+// ---- every operand in registers (ALLREG): sources as four vectors, decisions as lane masks -------------------------
+// The sources of a thread's four calls are held as four NS-element vectors (c[j][q] = source q of call j): a filter
+// picks its operands with a wave-uniform DYNAMIC index, which the compiler turns into one indexed v_mov each
+// (s_set_gpr_idx).  The select chain of cf_gather costs 4 x NS instructions per operand; with nine filters the
+// GangSTR set spent ~250 vector instructions per call on 60 bytes (SQ counters, profiles/r02_notes.md section 8).
+// Decisions are wave-wide lane masks in scalar registers as in k_call_filter_v2.
+template <int NS>
+struct CfRegs {
+    static constexpr int NLO = (NS < 8 ? NS : 8) * 4, NHI = (NS > 8 ? NS - 8 : 1) * 4;
+    typedef uint32_t lo_t __attribute__((ext_vector_type(NLO)));
+    typedef uint32_t hi_t __attribute__((ext_vector_type(NHI)));
+    u32x4 gt;
+    lo_t lo;   // element 4 q + j: source q (< 8) of call j -- a 16-byte load lands in four consecutive elements
+    hi_t hi;   // sources 8 ..
+    // the four values of source `idx` (uniform across the wave)
+    __device__ __forceinline__ void get(int idx, uint32_t (&v)[CF_V]) const {
+        if (NS <= 8 || idx < 8) {
+#pragma unroll
+            for (int j = 0; j < CF_V; ++j) v[j] = lo[4 * idx + j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < CF_V; ++j) v[j] = hi[4 * (idx - 8) + j];
+        }
+    }
+};
+// Planar sources only (every source its own [L*S] array).  Every slot is loaded unconditionally -- a conditional
+// insert makes the whole vector a phi and the register allocator copies it; slots past n_src re-read the genotype
+// row (an L2 hit).
+template <int NS>
+__device__ __forceinline__ void cf_load_r(const CallArgs& a, int64_t cell0, CfRegs<NS>& d) {
+    d.gt = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.b.gt) + (cell0 >> 2));
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        const void* sp = q < a.n_src ? a.src_ptr[q] : static_cast<const void*>(a.b.gt);
+        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sp) + (cell0 >> 2));
+#pragma unroll
+        for (int j = 0; j < CF_V; ++j) {
+            if (q < 8) d.lo[4 * q + j] = t[j];
+            else d.hi[4 * (q - 8) + j] = t[j];
+        }
+    }
+}
+
+template <int NS>
+__device__ __forceinline__ void cf_process_r(const CallArgs& a, int l, int64_t cell0, int64_t s0, int tid, bool leader,
+                                             const CfRegs<NS>& d, uint32_t* fcount, uint32_t* numcalls,
+                                             int64_t* totaldp, uint32_t* dpmiss, const CfDelta dc,
+                                             const bool has_delta) {
+    const int nf = a.n_filters;
+    const int pl = a.b.locus_ploidy ? min((int)a.b.locus_ploidy[l], 2) : 2;
+    const uint64_t livem = __ballot(1);
+    uint32_t w[CF_V] = {d.gt[0], d.gt[1], d.gt[2], d.gt[3]};
+    uint32_t mask[CF_V];
+    uint64_t calledm[CF_V], anyhit[CF_V];
+#pragma unroll
+    for (int j = 0; j < CF_V; ++j) {
+        uint64_t miss = __ballot((w[j] & 0xffffu) == 0xffffu);
+        if (pl > 1) miss |= __ballot(w[j] >= 0xffff0000u);
+        calledm[j] = livem & ~miss;
+        mask[j] = __builtin_amdgcn_inverse_ballot_w64(calledm[j]) ? 0u : TRK_MASK_NOCALL;
+        anyhit[j] = 0;
+    }
+    for (int k = 0; k < nf; ++k) {
+        const trk_call_filter& f = a.filters[k];
+        const int ia = a.f_src_a[k], ia2 = a.f_src_a2[k], ib = a.f_src_b[k];
+        const bool af = ia >= 0 && ((a.src_f32_mask >> ia) & 1u);
+        const float thrf = (float)f.thr;
+        uint64_t hm[CF_V] = {0, 0, 0, 0};
+        uint32_t oa[CF_V] = {0, 0, 0, 0}, oa2[CF_V] = {0, 0, 0, 0}, ob[CF_V] = {0, 0, 0, 0};
+        if (ia >= 0) d.get(ia, oa);
+        if (ia2 >= 0) d.get(ia2, oa2);
+        if (ib >= 0) d.get(ib, ob);
+        switch (f.op) {
+            case TRK_F_LT:
+            case TRK_F_CALLED_LT:
+            case TRK_F_GT: {
+                const bool gt_op = f.op == TRK_F_GT;
+                if ((a.int_thr_mask >> k) & 1u) {
+                    const int32_t ithr = a.f_ithr[k];
+                    if (gt_op) {
+#pragma unroll
+                        for (int j = 0; j < CF_V; ++j) hm[j] = __ballot((int32_t)oa[j] > ithr);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < CF_V; ++j) hm[j] = __ballot((int32_t)oa[j] < ithr);
+                    }
+                } else if (af) {   // numpy compares float32 arrays in float32
+                    if (gt_op) {
+#pragma unroll
+                        for (int j = 0; j < CF_V; ++j) hm[j] = __ballot(__uint_as_float(oa[j]) > thrf);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < CF_V; ++j) hm[j] = __ballot(__uint_as_float(oa[j]) < thrf);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < CF_V; ++j) {
+                        const double v = (double)(int32_t)oa[j];
+                        hm[j] = gt_op ? __ballot(v > f.thr) : __ballot(v < f.thr);
+                    }
+                }
+                if (f.op == TRK_F_CALLED_LT) {
+#pragma unroll
+                    for (int j = 0; j < CF_V; ++j) hm[j] &= calledm[j];
+                }
+                break;
+            }
+            case TRK_F_RATIO_GT: {
+                const bool bf = (a.src_f32_mask >> ib) & 1u;
+#pragma unroll
+                for (int j = 0; j < CF_V; ++j) {
+                    const uint32_t xa = oa[j], xb = ob[j];
+                    const double x = af ? (double)__uint_as_float(xa) : (double)(int32_t)xa;
+                    const double y = bf ? (double)__uint_as_float(xb) : (double)(int32_t)xb;
+                    hm[j] = __ballot((x / y) > f.thr);
+                }
+                break;
+            }
+            case TRK_F_CALLED_SUM_LT: {
+#pragma unroll
+                for (int j = 0; j < CF_V; ++j) {
+                    const uint32_t xa = oa[j], xa2 = oa2[j];
+                    if (af)
+                        hm[j] = __ballot(__uint_as_float(xa) + __uint_as_float(xa2) < thrf);
+                    else
+                        hm[j] = __ballot((double)((int64_t)(int32_t)xa + (int64_t)(int32_t)xa2) < f.thr);
+                    hm[j] &= calledm[j];
+                }
+                break;
+            }
+            case TRK_F_CALLED_EQ: {
+#pragma unroll
+                for (int j = 0; j < CF_V; ++j)
+                    hm[j] = calledm[j] & __ballot((int32_t)oa[j] == (int32_t)ob[j]);
+                break;
+            }
+            case TRK_F_CALLED_SUM_EQ: {
+#pragma unroll
+                for (int j = 0; j < CF_V; ++j)
+                    hm[j] = calledm[j] & __ballot((int64_t)(int32_t)oa[j] + (int64_t)(int32_t)oa2[j] ==
+                                                  (int64_t)(int32_t)ob[j]);
+                break;
+            }
+            case TRK_F_CALLED_OUTSIDE_CI: {
+                for (int c = 0; c < a.f_ci_n[k]; ++c) {
+                    uint32_t vm[CF_V], vl[CF_V], vh[CF_V];
+                    d.get(a.f_ci[k][3 * c], vm);
+                    d.get(a.f_ci[k][3 * c + 1], vl);
+                    d.get(a.f_ci[k][3 * c + 2], vh);
+#pragma unroll
+                    for (int j = 0; j < CF_V; ++j) {
+                        const int32_t ml = (int32_t)vm[j];
+                        hm[j] |= calledm[j] & (__ballot(ml < (int32_t)vl[j]) | __ballot((int32_t)vh[j] < ml));
+                    }
+                }
+                break;
+            }
+            default:
+                break;
+        }
+        const uint32_t bit = 1u << k;
+        uint32_t inc[2] = {0, 0};
+#pragma unroll
+        for (int j = 0; j < CF_V; ++j) {
+            mask[j] |= __builtin_amdgcn_inverse_ballot_w64(hm[j]) ? bit : 0u;
+            anyhit[j] |= hm[j];
+            inc[j >> 1] |= __builtin_amdgcn_inverse_ballot_w64(hm[j] & calledm[j]) ? (1u << (16 * (j & 1))) : 0u;
+        }
+        // per-thread counters, two samples per LDS word (a block holds <= 4096 loci: 16 bits are enough)
+        uint32_t* fc = fcount + (k * CF_THREADS + tid) * 2;
+        atomicAdd(&fc[0], inc[0]);
+        atomicAdd(&fc[1], inc[1]);
+    }
+    uint64_t passm[CF_V], filtm[CF_V];
+#pragma unroll
+    for (int j = 0; j < CF_V; ++j) {
+        passm[j] = calledm[j] & ~anyhit[j];  // mask word == 0: dumpSTR.py:686
+        filtm[j] = calledm[j] & anyhit[j];   // dumpSTR.py:715-727
+        add_mask(numcalls[j], passm[j]);
+    }
+    if (a.dp_plane >= 0) {
+        uint64_t bad = 0;
+        uint32_t dpv[CF_V];
+        d.get(a.dp_src, dpv);
+#pragma unroll
+        for (int j = 0; j < CF_V; ++j) {
+            const int32_t dv = (int32_t)dpv[j];
+            add_mask(dpmiss[j], passm[j] & __ballot(dv == INT32_MIN));
+            const int32_t dpos = dv > 0 ? dv : 0;
+            totaldp[j] += __builtin_amdgcn_inverse_ballot_w64(passm[j]) ? dpos : 0;
+            bad |= passm[j] & __ballot((uint32_t)dv > 0x80000000u);   // negative, not the missing marker
+        }
+        if (bad) {  // a negative depth on a call that passes (cold): dumpSTR.py:698-706
+#pragma unroll
+            for (int j = CF_V - 1; j >= 0; --j) {
+                const int32_t dv = (int32_t)dpv[j];
+                if ((mask[j] == 0u) & (dv < 0) & (dv != INT32_MIN)) {
+                    if (atomicCAS(&a.out.error[0], 0, 1) == 0) {
+                        a.out.error[1] = l;
+                        a.out.error[2] = (int32_t)(s0 + j);
+                    }
+                }
+            }
+        }
+    }
+    if (has_delta && !(a.dbg & 1)) {
+        // what the filtered calls remove from the locus counts: allele bins per call, the four per-locus counters
+        // from the masks -- one LDS atomic each per wave and locus
+        uint32_t n_filt = 0, n_low = 0, n_hl = 0, n_hs = 0;
+        const uint32_t A = (uint32_t)dc.A;
+#pragma unroll
+        for (int j = 0; j < CF_V; ++j) {
+            const uint32_t a0 = w[j] & 0xffffu, a1 = pl > 1 ? (w[j] >> 16) : 0xfffdu;   // unsigned halves: -2 = 0xfffe
+            const bool filtered = __builtin_amdgcn_inverse_ballot_w64(filtm[j]);
+            const bool v0 = a0 < A, v1 = a1 < A;
+            if (filtered) {
+                if (v0) atomicAdd(&dc.tab[a0], 1);
+                if (v1) atomicAdd(&dc.tab[a1], 1);
+            }
+            const uint64_t lowm = filtm[j] & (__ballot(a0 == 0xfffeu) | __ballot(a1 == 0xfffeu));
+            const uint64_t bothm = filtm[j] & ~lowm & __ballot(v0) & __ballot(v1);
+            uint64_t hlm = bothm & __ballot(a0 == a1), hsm = hlm;
+            if (dc.dup) {   // alleles that share a class (uniform per locus, rare): the LUT decides for a0 != a1
+                const bool need = __builtin_amdgcn_inverse_ballot_w64(bothm & ~hlm);
+                uint32_t q = 0xffffffffu;
+                if (need) q = dc.lut[a0] ^ dc.lut[a1];
+                hlm |= __ballot((q & 0xffffu) == 0u);
+                hsm |= __ballot((q >> 16) == 0u);
+            }
+            n_filt += (uint32_t)__popcll(filtm[j]);
+            n_low += (uint32_t)__popcll(lowm);
+            n_hl += (uint32_t)__popcll(hlm);
+            n_hs += (uint32_t)__popcll(hsm);
+        }
+        if (leader) {
+            int32_t* x = dc.tab + dc.nal;
+            if (n_filt) atomicAdd(&x[DX_CALLED], (int32_t)n_filt);
+            if (n_low) atomicAdd(&x[DX_LOW], (int32_t)n_low);
+            if (n_hl) atomicAdd(&x[DX_HOML], (int32_t)n_hl);
+            if (n_hs) atomicAdd(&x[DX_HOMS], (int32_t)n_hs);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CF_V; ++j)
+        if (__builtin_amdgcn_inverse_ballot_w64(filtm[j])) w[j] = pl > 1 ? 0xffffffffu : (w[j] | 0xffffu);
+    if (a.out.gt_out)
+        __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]},
+                                    reinterpret_cast<u32x4*>(a.out.gt_out) + (cell0 >> 2));
+    if (a.out.filter_mask)
+        __builtin_nontemporal_store(u32x4{mask[0], mask[1], mask[2], mask[3]},
+                                    reinterpret_cast<u32x4*>(a.out.filter_mask) + (cell0 >> 2));
+    if (a.out.filter_mask8) {
+        uint32_t m8 = 0;
+#pragma unroll
+        for (int j = 0; j < CF_V; ++j) m8 |= ((mask[j] & 0x7fu) | ((mask[j] >> 24) & 0x80u)) << (8 * j);
+        __builtin_nontemporal_store(m8, reinterpret_cast<uint32_t*>(a.out.filter_mask8) + (cell0 >> 2));
+    }
+}
+
 template <int NS, bool ALLREG>
 __device__ __forceinline__ void cf_process(const CallArgs& a, int l, int64_t cell0, int64_t s0, int tid,
                                            const CfLocus<NS>& d, uint32_t* fcount, uint32_t* numcalls,
@@ -1789,7 +2054,8 @@ __device__ __forceinline__ void cf_process(const CallArgs& a, int l, int64_t cel
 // A workgroup owns loci [y * loci_per_wg, ...) and walks them in sub-blocks of loci_per_block, the unit of the
 // LDS delta table; the per-sample counters live across sub-blocks and are flushed once.
 // (the instantiation that sits one register above 128 VGPRs is held to four waves per SIMD)
-template <int NS, bool ALLREG>
+// PLANAR (with ALLREG): no interleaved planes either -- the sources sit in indexable vectors, cf_process_r.
+template <int NS, bool ALLREG, bool PLANAR>
 __global__ __launch_bounds__(CF_THREADS, (NS == 12 && ALLREG) ? 4 : 1) void k_call_filter_fast(const CallArgs a) {
     extern __shared__ uint32_t fcount[];  // [n_filters][CF_THREADS][2] (16-bit pairs), then the delta table
     const int tid = threadIdx.x;
@@ -1817,7 +2083,7 @@ __global__ __launch_bounds__(CF_THREADS, (NS == 12 && ALLREG) ? 4 : 1) void k_ca
             cf_build_lut(a.b, l_begin, nl, nal, tid, lutb, linfo);
         }
         if (live) {
-            auto run = [&](int l, const CfLocus<NS>& d) {
+            auto delta_of = [&](int l) {
                 CfDelta dc = {nullptr, nullptr, 0, 0, false};
                 if (dstride) {
                     const int li = l - l_begin;
@@ -1827,15 +2093,25 @@ __global__ __launch_bounds__(CF_THREADS, (NS == 12 && ALLREG) ? 4 : 1) void k_ca
                     dc.dup = cf_lut_needed(linfo, li);
                     dc.nal = nal;
                 }
-                cf_process<NS, ALLREG>(a, l, (int64_t)l * S + s0, s0, tid, d, fcount, numcalls, totaldp, dpmiss, dc,
-                                       dstride != 0);
+                return dc;
             };
             // (loading locus l + 1 into a second register set while l is evaluated was measured: the registers
             // cost more occupancy than the overlap buys, profiles/r01_notes.md)
-            for (int l = l_begin; l < l_end; ++l) {
-                CfLocus<NS> d;
-                cf_load(a, (int64_t)l * S + s0, d);
-                run(l, d);
+            if constexpr (ALLREG && PLANAR) {
+                const bool leader = (tid & 63) == __ffsll((unsigned long long)__ballot(1)) - 1;  // first live lane
+                for (int l = l_begin; l < l_end; ++l) {
+                    CfRegs<NS> d;
+                    cf_load_r(a, (int64_t)l * S + s0, d);
+                    cf_process_r<NS>(a, l, (int64_t)l * S + s0, s0, tid, leader, d, fcount, numcalls, totaldp, dpmiss,
+                                     delta_of(l), dstride != 0);
+                }
+            } else {
+                for (int l = l_begin; l < l_end; ++l) {
+                    CfLocus<NS> d;
+                    cf_load(a, (int64_t)l * S + s0, d);
+                    cf_process<NS, ALLREG>(a, l, (int64_t)l * S + s0, s0, tid, d, fcount, numcalls, totaldp, dpmiss,
+                                           delta_of(l), dstride != 0);
+                }
             }
         }
         if (dstride) {  // flush the sub-block's delta table: one global atomic per non-zero entry
@@ -1927,12 +2203,6 @@ struct V2Args {
     unsigned long long* part64;  // [gridDim.y][S]: totaldp
     trk_call_out out;
 };
-
-// x += (this lane's bit of the wave-wide mask): the mask goes in as the carry of an add-with-carry (one instruction;
-// written as a select and an add the compiler emits two)
-__device__ __forceinline__ void add_mask(uint32_t& x, uint64_t mask) {
-    asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(x) : "s"(mask) : "vcc");
-}
 
 // RATIO: some filter is a HipSTR-style ratio over the depth plane (float64 division, filters.py:415-484)
 template <int NF, bool DELTA, bool RATIO>
@@ -2948,7 +3218,11 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
         const bool allreg = a.reg_filter_mask == (n_filters >= 32 ? ~0u : (1u << n_filters) - 1u) &&
                             (dp_plane < 0 || a.dp_src >= 0) && !getenv("TRK_CF_NOALLREG");
         void (*kfn)(CallArgs) = nullptr;
-#define TRK_FAST(NS) kfn = allreg ? k_call_filter_fast<NS, true> : k_call_filter_fast<NS, false>
+        // TRK_CF_NOREGVEC=1: the select-chain form also for planar sources (A/B timing)
+        const bool planar = allreg && a.grp_n == 0 && !getenv("TRK_CF_NOREGVEC");
+#define TRK_FAST(NS)                                                                 \
+    kfn = planar ? k_call_filter_fast<NS, true, true>                                \
+                 : allreg ? k_call_filter_fast<NS, true, false> : k_call_filter_fast<NS, false, false>
         if (a.n_src <= 4) { TRK_FAST(4); }
         else if (a.n_src <= 8) { TRK_FAST(8); }
         else if (a.n_src <= 12) { TRK_FAST(12); }
