@@ -456,6 +456,35 @@ enum { TRK_DOS_BESTGUESS = 0, TRK_DOS_BEAGLEAP = 1, TRK_DOS_BESTGUESS_NORM = 2, 
 int trk_dosages(trk_ctx* ctx, const trk_batch* in, const double* allele_len, int dosage_type, const float* ap1,
                 const float* ap2, int n_alt_cols, float* out, int32_t* locus_err);
 
+/* ---- qcSTR's reductions (trtools/qcSTR/qcSTR.py:529-561, 619-621) ----------------
+ * One pass over the genotype tensor and (optionally) the FORMAT quality plane of a batch:
+ *   a sample's entry at a locus is a CALL unless every haplotype index of the record is -1 (qcSTR.py:533-535 --
+ *   note: not dumpSTR's rule, a half-missing call counts here);
+ *   sample_calls[s] = calls of sample s over the batch's loci (qcSTR.py:536), locus_calls[l] = calls at locus l
+ *   (summed per chromosome by the caller, qcSTR.py:537);
+ *   quality: the score of a no-call becomes nan (qcSTR.py:540); then
+ *     ignore_no_call == 0: nan -> 0 and every selected sample enters (543): sample_qual_sum[s] += q (548),
+ *                          locus mean = locus_qual_sum[l] / locus_qual_n[l] with n = selected samples (554);
+ *     ignore_no_call != 0: only the non-nan entries enter sums and counts (551, 556).
+ *   sample_in [S] (qcSTR --samples, qcSTR.py:463-470): entries of samples outside the set count nowhere.
+ * Sums are float64 in a fixed order (the reference adds float32 scores into a float64 total per sample and takes a
+ * float32 pairwise mean per locus: agreement is to float32 rounding, not bit for bit).  The counts are exact.   */
+typedef struct {
+    const uint8_t* sample_in; /* [S] or NULL                                                    */
+    const float* quality;     /* [L*S] float32 (nan = missing) or NULL: call counts only        */
+    int32_t ignore_no_call;   /* qcSTR --quality-ignore-no-call                                 */
+    int32_t pad;
+} trk_qc_params;
+typedef struct {
+    int64_t* sample_calls;    /* [S]                                                            */
+    int64_t* locus_calls;     /* [L]                                                            */
+    double* sample_qual_sum;  /* [S] or NULL (required with a quality plane)                    */
+    int64_t* sample_qual_n;   /* [S] or NULL: entries summed per sample                         */
+    double* locus_qual_sum;   /* [L] or NULL (required with a quality plane)                    */
+    int64_t* locus_qual_n;    /* [L] or NULL: entries summed per locus                          */
+} trk_qc_out;
+int trk_qc_reduce(trk_ctx* ctx, const trk_batch* in, const trk_qc_params* prm, trk_qc_out* out);
+
 /* Two-sided Student-t tail 2*sf(|t|, df) == scipy.stats.t.sf(|t|, df)*2 (the third-party call
  * behind statsmodels' pvalues); host double, same code as the device finaliser.              */
 double trk_student_t_two_sided(double t, double df);

@@ -36,6 +36,7 @@ Third-party arithmetic on the path (not under /root/reference):
   (utils.py:212,334-338); numpy.unique / sort -- called directly.
 """
 import ast
+import warnings
 import collections
 
 import numpy as np
@@ -643,3 +644,63 @@ def get_dosages(gt, allele_lens, dosagetype='bestguess', ap1=None, ap2=None):
         if np.any(dos >= 2.1) or np.any(dos <= -0.1):
             return np.array([np.nan] * n, dtype=np.float32)
     return np.clip(dos, 0, 2)
+
+
+# ----------------------------------------------------------------------------
+# qcSTR's per-record reductions (qcSTR/qcSTR.py:529-561)
+# ----------------------------------------------------------------------------
+
+def qc_record(gt, quality=None, sample_index=None, ignore_no_call=False):
+    """One iteration of qcSTR's main loop on arrays: gt [S, P] allele indices of the record's own ploidy columns,
+    quality float32 [S, 1] (GetQualityScores) or None, sample_index boolean [S] or None.
+    Returns (calls bool [S'], q float32 [S', 1] after the nan handling or None, per-locus mean or None) where S' are
+    the selected samples -- exactly the values qcSTR.py:533-556 computes."""
+    gt = np.asarray(gt)
+    if sample_index is None:
+        sample_index = np.ones(gt.shape[0], dtype=bool)
+    idx_gts = gt[sample_index, :]                                   # qcSTR.py:533
+    nocall = np.full((1, idx_gts.shape[1]), -1)
+    calls = ~np.all(idx_gts == nocall, axis=1)                      # 534-535
+    if quality is None:
+        return calls, None, None
+    q = np.array(quality, dtype=np.float32)[sample_index, :]       # 539 (a copy: the reference writes into it)
+    q[~calls] = np.nan                                              # 540
+    if not ignore_no_call:
+        q[np.isnan(q)] = 0                                          # 541-542
+        mean = np.mean(q)                                           # 553-554
+    else:
+        idxs = ~np.isnan(q)                                         # 543-544
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            mean = np.mean(q[idxs])                                 # 555-556 (nan, with a warning, when none)
+    return calls, q, mean
+
+
+def qc_accumulate(records, sample_index=None, ignore_no_call=False):
+    """qcSTR's accumulators over a list of (chrom, gt [S, P], quality [S, 1] or None): sample_calls (536),
+    chrom_calls (537), per-sample quality totals (546-551) and the per-locus means (552-556), plus the per-sample
+    means as qcSTR.py:619-621 takes them."""
+    sample_calls = None
+    chrom_calls = {}
+    totals = None
+    per_locus = []
+    n = 0
+    for chrom, gt, quality in records:
+        calls, q, mean = qc_record(gt, quality, sample_index, ignore_no_call)
+        if sample_calls is None:
+            sample_calls = np.zeros(len(calls))
+            totals = np.zeros(len(calls))
+        sample_calls += calls
+        chrom_calls[chrom] = chrom_calls.get(chrom, 0) + np.sum(calls)
+        if q is not None:
+            if not ignore_no_call:
+                totals += q.reshape(-1)
+            else:
+                idxs = ~np.isnan(q)
+                totals[idxs.reshape(-1)] += q[idxs].reshape(-1)
+            per_locus.append(mean)
+        n += 1
+    with np.errstate(invalid='ignore', divide='ignore'):
+        per_sample = None if totals is None else (totals / n if not ignore_no_call else totals / sample_calls)
+    return dict(sample_calls=sample_calls, chrom_calls=chrom_calls, per_sample_total=totals,
+                per_sample_quality=per_sample, per_locus_quality=per_locus, numrecords=n)

@@ -99,6 +99,15 @@ ADC_COLS, ADL_COLS = 4, 8
 DOS_TYPES = {'bestguess': 0, 'beagleap': 1, 'bestguess_norm': 2, 'beagleap_norm': 3}
 
 
+class QcParams(C.Structure):
+    _fields_ = [('sample_in', C.c_void_p), ('quality', C.c_void_p), ('ignore_no_call', C.c_int32), ('pad', C.c_int32)]
+
+
+class QcOut(C.Structure):
+    _fields_ = [('sample_calls', C.c_void_p), ('locus_calls', C.c_void_p), ('sample_qual_sum', C.c_void_p),
+                ('sample_qual_n', C.c_void_p), ('locus_qual_sum', C.c_void_p), ('locus_qual_n', C.c_void_p)]
+
+
 class AssocOut(C.Structure):
     _fields_ = [('locus_int', C.c_void_p), ('locus_f64', C.c_void_p), ('allele_count', C.c_void_p)]
 
@@ -126,7 +135,7 @@ EXPORTS = [
     'trk_locus_stats', 'trk_locus_finalize', 'trk_call_filters', 'trk_locus_filters',
     'trk_comm_unique_id', 'trk_comm_init', 'trk_allreduce_sum_i64', 'trk_allgather',
     'trk_binomtest_two_sided', 'trk_binom_pmf', 'trk_synth_fill', 'trk_synth_fill_gangstr',
-    'trk_assoc_scan', 'trk_assoc_scan_dosage', 'trk_student_t_two_sided', 'trk_dosages', 'trk_planarize', 'trk_stream_select', 'trk_stream_wait',
+    'trk_assoc_scan', 'trk_assoc_scan_dosage', 'trk_student_t_two_sided', 'trk_dosages', 'trk_qc_reduce', 'trk_planarize', 'trk_stream_select', 'trk_stream_wait',
     'trk_host_alloc', 'trk_host_free', 'trk_memcpy_h2d_async', 'trk_memcpy_d2h_async', 'trk_queue_sync', 'trk_exchange', 'trk_event_record', 'trk_event_wait',
 ]
 
@@ -139,7 +148,7 @@ class TrkError(RuntimeError):
 
 # the sources libtrk.so is built from, in the order csrc/Makefile hashes them
 _SOURCES = ['csrc/trk_api.hip', 'csrc/trk_assoc.hip', 'csrc/trk_binom.h', 'csrc/trk_internal.h', 'csrc/trk_kernels.hip',
-            'csrc/trk_student.h', 'csrc/trk_vcf.cpp', '../include/trk.h', '../include/trk_vcf.h']
+            'csrc/trk_qc.hip', 'csrc/trk_student.h', 'csrc/trk_vcf.cpp', '../include/trk.h', '../include/trk_vcf.h']
 
 
 def source_digest():
@@ -251,6 +260,7 @@ def load():
     lib.trk_stream_select.argtypes = [vp, C.c_int]
     lib.trk_stream_wait.argtypes = [vp, C.c_int, C.c_int]
     lib.trk_dosages.argtypes = [vp, P(Batch), vp, C.c_int, vp, vp, C.c_int, vp, vp]
+    lib.trk_qc_reduce.argtypes = [vp, P(Batch), P(QcParams), P(QcOut)]
     lib.trk_student_t_two_sided.argtypes = [dbl, dbl]
     lib.trk_student_t_two_sided.restype = dbl
     lib.trk_synth_fill.argtypes = [vp, P(SynthSpec), vp, vp, vp, vp, vp]

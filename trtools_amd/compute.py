@@ -193,6 +193,22 @@ class DeviceCompute:
         self._free(b, res.locus_int, res.locus_f64, res.allele_count, cs, ls, *[x for x in res._keep if x is not None])
         return out
 
+    def qc_batch(self, hb, quality=None, sample_index=None, ignore_no_call=False):
+        """qcSTR's per-record loop (trtools/qcSTR/qcSTR.py:529-561) for a whole batch in one device pass
+        (trk_qc_reduce): ``quality`` float32 [L, S] (GetQualityScores of every record, nan = missing),
+        ``sample_index`` the boolean sample selection of qcSTR --samples.  Returns a dict of host arrays over ALL
+        samples / loci of the batch: sample_calls, locus_calls and, with a plane, sample_qual_sum, sample_qual_n,
+        locus_qual_sum, locus_qual_n (the reference's means are sum / n; rows of unselected samples are 0)."""
+        eng = self.eng
+        b = self._upload(hb, pad=False)
+        sin = None if sample_index is None else np.ascontiguousarray(sample_index, dtype=bool).astype(np.uint8)
+        res = eng.qc_reduce(b, None if quality is None else np.ascontiguousarray(quality, dtype=np.float32), sin,
+                            ignore_no_call)
+        keep = res.pop('_keep')
+        out = {k: v.get() for k, v in res.items()}
+        self._free(b, *res.values(), *[x for x in keep if x is not None])
+        return out
+
     def dosages_batch(self, hb, dosage_type, ap1=None, ap2=None):
         """TRRecord.GetDosages for every record of a batch (trk_dosages): (float32 [L, S], int32 [L] error bits)."""
         from .synth import pack_assoc_tables

@@ -404,6 +404,25 @@ int trk_profile_reset(trk_ctx* ctx) {
 }
 
 // ---- the hot path ----------------------------------------------------------------
+// Device scratch of the selected queue (partial counters of the call-filter and qc passes), grown on demand: a growth
+// synchronises that queue, so it happens before the launch and outside the profiling bracket.
+static void* workspace_for_queue(trk_ctx* c, size_t bytes) {
+    const int q = c->cur;
+    if (bytes > c->cf_ws_bytes_[q]) {
+        if (hipStreamSynchronize(c->streams[q]) != hipSuccess) return nullptr;
+        if (c->cf_ws_[q]) (void)hipFree(c->cf_ws_[q]);
+        c->cf_ws_[q] = nullptr;
+        c->cf_ws_bytes_[q] = 0;
+        const size_t want = bytes + bytes / 4;
+        if (hipMalloc(&c->cf_ws_[q], want) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        c->cf_ws_bytes_[q] = want;
+    }
+    return c->cf_ws_[q];
+}
+
 static int check_batch(trk_ctx* ctx, const trk_batch* b) {
     if (!b) return fail(ctx, TRK_ERR_ARG, "batch is NULL");
     if (b->n_loci < 0 || b->n_samples < 0) return fail(ctx, TRK_ERR_ARG, "negative batch dimensions");
@@ -540,21 +559,7 @@ int trk_call_filters(trk_ctx* ctx, const trk_batch* in, const trk_plane* planes,
     (void)hipSetDevice(ctx->device);
     // grown outside the profiling bracket and before the launch (a growth synchronises this queue)
     trk::Scratch sc{ctx, [](void* user, size_t bytes) -> void* {
-                        trk_ctx* c = static_cast<trk_ctx*>(user);
-                        const int q = c->cur;
-                        if (bytes > c->cf_ws_bytes_[q]) {
-                            if (hipStreamSynchronize(c->streams[q]) != hipSuccess) return nullptr;
-                            if (c->cf_ws_[q]) (void)hipFree(c->cf_ws_[q]);
-                            c->cf_ws_[q] = nullptr;
-                            c->cf_ws_bytes_[q] = 0;
-                            const size_t want = bytes + bytes / 4;
-                            if (hipMalloc(&c->cf_ws_[q], want) != hipSuccess) {
-                                (void)hipGetLastError();
-                                return nullptr;   // the kernel falls back to atomics
-                            }
-                            c->cf_ws_bytes_[q] = want;
-                        }
-                        return c->cf_ws_[q];
+                        return workspace_for_queue(static_cast<trk_ctx*>(user), bytes);   // null: atomics instead
                     }};
     ProfScope ps(ctx, TRK_K_CALL_FILTER);
     HIPCHK(ctx, trk::launch_call_filter(*in, planes, n_planes, filters, n_filters, dp_plane, *out, ctx->n_cu,
@@ -747,6 +752,32 @@ int trk_dosages(trk_ctx* ctx, const trk_batch* in, const double* allele_len, int
     if (in->n_loci > 65535) return fail(ctx, TRK_ERR_ARG, "at most 65535 loci per dosage call");
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, trk::launch_dosages(*in, allele_len, dosage_type, ap1, ap2, n_alt_cols, out, locus_err, ctx->s()));
+    return TRK_OK;
+}
+
+int trk_qc_reduce(trk_ctx* ctx, const trk_batch* in, const trk_qc_params* prm, trk_qc_out* out) {
+    if (!ctx) return TRK_ERR_ARG;
+    int rc = check_batch(ctx, in);
+    if (rc) return rc;
+    if (!prm || !out || !out->sample_calls || !out->locus_calls)
+        return fail(ctx, TRK_ERR_ARG, "qc reduce: parameters / call-count outputs are NULL");
+    if (prm->quality && (!out->sample_qual_sum || !out->locus_qual_sum))
+        return fail(ctx, TRK_ERR_ARG, "qc reduce: a quality plane needs sample_qual_sum and locus_qual_sum");
+    (void)hipSetDevice(ctx->device);
+    if (in->n_loci == 0 || in->n_samples == 0) {
+        if (in->n_samples > 0) {
+            HIPCHK(ctx, hipMemsetAsync(out->sample_calls, 0, (size_t)in->n_samples * 8, ctx->s()));
+            if (prm->quality) {
+                HIPCHK(ctx, hipMemsetAsync(out->sample_qual_sum, 0, (size_t)in->n_samples * 8, ctx->s()));
+                if (out->sample_qual_n)
+                    HIPCHK(ctx, hipMemsetAsync(out->sample_qual_n, 0, (size_t)in->n_samples * 8, ctx->s()));
+            }
+        }
+        return TRK_OK;
+    }
+    void* ws = workspace_for_queue(ctx, trk::qc_workspace_bytes(*in, prm->quality, ctx->n_cu));
+    if (!ws) return fail(ctx, TRK_ERR_HIP, "qc reduce: workspace allocation failed");
+    HIPCHK(ctx, trk::launch_qc_reduce(*in, *prm, *out, ws, ctx->n_cu, ctx->s()));
     return TRK_OK;
 }
 

@@ -553,6 +553,29 @@ class Engine:
                                        out.ptr, err.ptr))
         return out, err
 
+    def qc_reduce(self, batch, quality=None, sample_in=None, ignore_no_call=False):
+        """trk_qc_reduce (qcSTR's reductions, include/trk.h): per-sample and per-locus call counts, and with a
+        quality plane (float32 [L, S], host or device) the quality sums and the numbers of entries summed.
+        Returns a dict of device arrays: sample_calls, locus_calls (int64) and, with a plane, sample_qual_sum,
+        locus_qual_sum (float64), sample_qual_n, locus_qual_n (int64)."""
+        def dev(x, dt):
+            return x if isinstance(x, DeviceArray) else self.upload(np.ascontiguousarray(x, dtype=dt), dt)
+        nl, ns = batch.n_loci, batch.n_samples
+        q = dev(quality, np.float32) if quality is not None else None
+        sin = dev(sample_in, np.uint8) if sample_in is not None else None
+        res = dict(sample_calls=self.empty((ns,), np.int64), locus_calls=self.empty((nl,), np.int64))
+        if q is not None:
+            res.update(sample_qual_sum=self.empty((ns,), np.float64), sample_qual_n=self.empty((ns,), np.int64),
+                       locus_qual_sum=self.empty((nl,), np.float64), locus_qual_n=self.empty((nl,), np.int64))
+        prm = L.QcParams(sin.ptr if sin is not None else None, q.ptr if q is not None else None,
+                         1 if ignore_no_call else 0, 0)
+        out = L.QcOut(*[res[k].ptr if k in res else None
+                        for k in ('sample_calls', 'locus_calls', 'sample_qual_sum', 'sample_qual_n', 'locus_qual_sum',
+                                  'locus_qual_n')])
+        res['_keep'] = (q, sin)
+        self._chk(self.lib.trk_qc_reduce(self.ctx, C.byref(batch.struct), C.byref(prm), C.byref(out)))
+        return res
+
     def student_t_two_sided(self, t, df):
         return float(self.lib.trk_student_t_two_sided(float(t), float(df)))
 

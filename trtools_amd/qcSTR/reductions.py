@@ -1,0 +1,95 @@
+"""The numbers behind qcSTR's plots, computed a batch at a time on the device.
+
+Mirrors the accumulation of the reference's main loop (trtools/qcSTR/qcSTR.py:441-575, 613-660): what it passes to
+``OutputSampleCallrate`` / ``OutputChromCallrate`` / ``OutputQualityPerSample`` / ``OutputQualityPerLocus`` /
+``OutputDiffRefHistogram`` / ``OutputDiffRefBias``.  Per record the reference does a handful of numpy reductions
+over the samples; here a batch of records goes through ONE device pass (``trk_qc_reduce`` for calls and quality,
+``trk_locus_stats`` for the allele counts by length) and the host only adds up batch results."""
+import numpy as np
+
+from ..utils import common
+from ..utils import tr_harmonizer as trh
+from ..utils import utils
+
+
+def _flush(compute, batch, sample_index, use_q, ignore, acc):
+    from ..batch import pack_records
+    recs = [r for _, r in batch]
+    subset = not bool(np.all(sample_index))
+    hb = pack_records(recs, group_masks=[sample_index] if subset else None)
+    q = None
+    if use_q:
+        q = np.stack([np.asarray(r.GetQualityScores(), dtype=np.float32).reshape(-1) for r in recs])
+    res = compute.qc_batch(hb, q, sample_index if subset else None, ignore)
+    acc['sample_calls'] += res['sample_calls'][sample_index]
+    for (chrom, _), c in zip(batch, res['locus_calls']):
+        acc['chrom_calls'][chrom] = acc['chrom_calls'].get(chrom, 0) + int(c)
+    if use_q:
+        acc['per_sample_total'] += res['sample_qual_sum'][sample_index]
+        with np.errstate(invalid='ignore', divide='ignore'):
+            acc['per_locus'].extend((res['locus_qual_sum'] / res['locus_qual_n']).tolist())
+    # allele counts by length over the selected samples (qcSTR.py:529-530, 563-568)
+    st = compute.locus_stats(hb)
+    cnt = st.allele_count[0]
+    for l, r in enumerate(recs):
+        lo, hi = int(hb.allele_off[l]), int(hb.allele_off[l + 1])
+        lens = np.asarray([r.ref_allele_length] + list(r.alt_allele_lengths), dtype=np.float64)
+        c = cnt[lo:hi].astype(np.int64)
+        period = len(r.motif)
+        diff_unit = lens - r.ref_allele_length
+        acc['n_alleles'] += int(c.sum())
+        acc['sum_diff_unit'] += float((diff_unit * c).sum())
+        acc['sum_diff_bp'] += float((diff_unit * period * c).sum())
+        acc['sum_reflen_bp'] += float(r.ref_allele_length * period * c.sum())
+
+
+def qc_reductions(vcf, vcftype='auto', samples=None, period=None, quality=(), quality_ignore_no_call=False,
+                  numrecords=None, batch_loci=1024):
+    """Returns a dict: samples (the selected names), sample_calls, chrom_calls, numrecords, per_sample_quality and
+    per_locus_quality (None without a quality request), and the sums behind the two diff-from-reference plots
+    (n_alleles, sum_diff_unit, sum_diff_bp, sum_reflen_bp).  Arguments as the reference's command line
+    (qcSTR.py:343-419); returns None where the reference returns 1."""
+    from .. import runtime
+    compute = runtime.get_compute()
+    invcf = utils.LoadSingleReader(vcf, checkgz=False)
+    if invcf is None:
+        return None
+    harmonizer = trh.TRRecordHarmonizer(invcf, vcftype) if vcftype != 'auto' else trh.TRRecordHarmonizer(invcf)
+    quality = list(quality)
+    if len(quality) > 0 and not harmonizer.HasQualityScore():
+        common.WARNING("Requested a quality plot, but the input vcf doesn't have quality scores!")
+        return None
+    if samples:
+        wanted = [item.strip() for item in open(samples, "r").readlines()]
+        sample_index = np.isin(np.array(invcf.samples), wanted)
+        sample_list = list(np.array(invcf.samples)[sample_index])
+    else:
+        sample_list = list(invcf.samples)
+        sample_index = np.ones(len(sample_list), dtype=bool)
+    if len(quality) == 0 and harmonizer.HasQualityScore():   # the default quality plot (qcSTR.py:472-479)
+        quality = ['sample-stratified'] if len(sample_list) <= 5 else ['per-locus']
+    use_q = len(quality) != 0
+    acc = dict(sample_calls=np.zeros(len(sample_list)), chrom_calls={}, per_sample_total=np.zeros(len(sample_list)),
+               per_locus=[], n_alleles=0, sum_diff_unit=0.0, sum_diff_bp=0.0, sum_reflen_bp=0.0)
+    batch, n = [], 0
+    for trrecord in harmonizer:
+        if numrecords is not None and n >= numrecords:
+            break
+        if period is not None and len(trrecord.motif) != period:
+            continue
+        acc['chrom_calls'].setdefault(trrecord.chrom, 0)
+        batch.append((trrecord.chrom, trrecord))
+        n += 1
+        if len(batch) >= batch_loci:
+            _flush(compute, batch, sample_index, use_q, quality_ignore_no_call, acc)
+            batch = []
+    if batch:
+        _flush(compute, batch, sample_index, use_q, quality_ignore_no_call, acc)
+    per_sample = None
+    if use_q:
+        with np.errstate(invalid='ignore', divide='ignore'):
+            per_sample = acc['per_sample_total'] / (acc['sample_calls'] if quality_ignore_no_call else n)
+    return dict(samples=sample_list, sample_calls=acc['sample_calls'], chrom_calls=acc['chrom_calls'], numrecords=n,
+                per_sample_quality=per_sample, per_locus_quality=acc['per_locus'] if use_q else None,
+                n_alleles=acc['n_alleles'], sum_diff_unit=acc['sum_diff_unit'], sum_diff_bp=acc['sum_diff_bp'],
+                sum_reflen_bp=acc['sum_reflen_bp'])
