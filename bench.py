@@ -522,6 +522,44 @@ def compact_outputs_extra(wl, iters=8):
     return res
 
 
+def qc_reduce_extra(wl, no_check, iters=8):
+    """qcSTR's per-sample / per-locus call counts and quality sums of the headline cohort in one
+    pass (trk_qc_reduce: genotypes + the Q plane, 8 B per call; three launches: scan + two small finishers)."""
+    eng = wl.eng
+    b = wl.sb.batch
+    q = wl.sb.dev['q']
+    res = eng.qc_reduce(b, q)
+    eng.sync()
+    eng.timer_start(0)
+    for _ in range(iters):
+        for k, v in res.items():
+            if k != '_keep':
+                v.free()
+        res = eng.qc_reduce(b, q)
+    eng.timer_stop(0)
+    ms = eng.timer_ms(0) / iters
+    cells = wl.n_loci * wl.n_samples
+    out = {"workload": "qcSTR reductions (calls + quality sums per sample and per locus), %d loci x %d samples"
+                       % (wl.n_loci, wl.n_samples), "ms_per_pass": ms, "bytes_per_cell": 8,
+           "achieved_GBs": cells * 8 / (ms * 1e-3) / 1e9, "frac": cells * 8 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if not no_check:
+        from oracle import trtools_oracle as orc
+        n = 64
+        gt = wl.sb.dev['gt'].get_rows(0, n).reshape(n, wl.n_samples, 2)
+        qh = q.get_rows(0, n).reshape(n, wl.n_samples)
+        lc, ls, ln = res['locus_calls'].get()[:n], res['locus_qual_sum'].get()[:n], res['locus_qual_n'].get()[:n]
+        for l in range(n):
+            calls, qq, _ = orc.qc_record(gt[l], qh[l].reshape(-1, 1))
+            assert int(calls.sum()) == int(lc[l]) and int(ln[l]) == wl.n_samples, "qc reduce: locus %d counts" % l
+            assert abs(float(qq.astype(np.float64).sum()) - float(ls[l])) <= 1e-9 * max(1.0, abs(float(ls[l])))
+        assert int(res['sample_calls'].get().sum()) == int(res['locus_calls'].get().sum())
+        out["parity"] = "%d loci against oracle/trtools_oracle.qc_record; sum over samples == sum over loci" % n
+    for k, v in res.items():
+        if k != '_keep':
+            v.free()
+    return out
+
+
 def config1_extra(eng, no_check, iters=50):
     """BASELINE configs[1]: statSTR full statistics on a synthetic HipSTR-shape call set, 10k loci x 1k samples."""
     from trtools_amd.synth import SynthBatch
@@ -937,6 +975,7 @@ def main():
                 extras["cpu_baseline_c"] = {"error": str(e)[:200]}
         if not args.no_extras:
             extras["compact_outputs"] = compact_outputs_extra(wl)
+            extras["qc_reduce"] = qc_reduce_extra(wl, args.no_check)
             wl.free()
             if not use_dist:
                 uid = eng.comm_unique_id()
