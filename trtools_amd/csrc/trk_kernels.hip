@@ -39,19 +39,33 @@ constexpr int WAVE = 64;
 constexpr int COUNT_WAVES_PER_WG = 4;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// Whole-wave reductions with DPP row operations (six vector instructions, no LDS round trips; the shuffle form costs
+// six ds_bpermute + their latencies).  Every lane must be active.  xor 1, xor 2, half-row mirror and row mirror leave
+// the 16-lane row's result in each of its lanes; row_bcast:15 folds rows 0 -> 1 and 2 -> 3, row_bcast:31 rows 1 -> 3:
+// lane 63 holds the wave's result.
+#define TRK_DPP_STEP(op_, v_, ctrl_, rmask_, ident_) \
+    v_ = op_(v_, __builtin_amdgcn_update_dpp(ident_, v_, ctrl_, rmask_, 0xf, false))
+__device__ __forceinline__ int dpp_add(int a, int b) { return a + b; }
+__device__ __forceinline__ int dpp_max(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
+    TRK_DPP_STEP(dpp_add, v, 0xB1, 0xf, 0);    // quad_perm [1,0,3,2]
+    TRK_DPP_STEP(dpp_add, v, 0x4E, 0xf, 0);    // quad_perm [2,3,0,1]
+    TRK_DPP_STEP(dpp_add, v, 0x141, 0xf, 0);   // row_half_mirror
+    TRK_DPP_STEP(dpp_add, v, 0x140, 0xf, 0);   // row_mirror
+    TRK_DPP_STEP(dpp_add, v, 0x142, 0xa, 0);   // row_bcast:15 into rows 1 and 3
+    TRK_DPP_STEP(dpp_add, v, 0x143, 0xc, 0);   // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        int t = __shfl_xor(v, o, WAVE);
-        v = t > v ? t : v;
-    }
-    return v;
+    TRK_DPP_STEP(dpp_max, v, 0xB1, 0xf, v);
+    TRK_DPP_STEP(dpp_max, v, 0x4E, 0xf, v);
+    TRK_DPP_STEP(dpp_max, v, 0x141, 0xf, v);
+    TRK_DPP_STEP(dpp_max, v, 0x140, 0xf, v);
+    TRK_DPP_STEP(dpp_max, v, 0x142, 0xa, v);
+    TRK_DPP_STEP(dpp_max, v, 0x143, 0xc, v);
+    return __builtin_amdgcn_readlane(v, 63);
 }
+#undef TRK_DPP_STEP
 // order LDS traffic of one wavefront (the hardware executes a wave's DS
 // operations in order; this stops the compiler from moving them)
 __device__ __forceinline__ void wave_lds_fence() {
@@ -461,6 +475,62 @@ __device__ __forceinline__ void row_stream(const u32x4* __restrict__ row, int nc
     }
 }
 
+// Whole-wave row streamer of k_locus_count_v2: full iterations (every lane live, no clamping) run two at a time with
+// the two register sets swapping roles -- no copy of the prefetched set, one 64-bit address per iteration with the U
+// loads at immediate offsets, no per-chunk liveness test; the row's last (partial) iterations go through the guarded
+// form.  `cur` holds the row's first U chunks on entry (row_fetch at the top of the kernel).
+template <int U, typename Cell>
+__device__ __forceinline__ void row_stream_wave(const u32x4* __restrict__ row, int nchunks, int lane, u32x4 (&cur)[U],
+                                                Cell&& cell) {
+    constexpr int STEP = U * WAVE;
+    const int nfull = nchunks / STEP;
+    const u32x4* p = row + lane;
+    int it = 0;
+    for (; it + 3 <= nfull; it += 2) {   // iterations it, it + 1 and it + 2 are full
+        u32x4 alt[U];
+        const u32x4* p1 = p + (size_t)(it + 1) * STEP;
+#pragma unroll
+        for (int u = 0; u < U; ++u) alt[u] = __builtin_nontemporal_load(p1 + u * WAVE);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t w = cur[u][j];
+                cell(w);
+            }
+        const u32x4* p2 = p + (size_t)(it + 2) * STEP;
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = __builtin_nontemporal_load(p2 + u * WAVE);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t w = alt[u][j];
+                cell(w);
+            }
+    }
+    const int last = nchunks > 0 ? nchunks - 1 : 0;
+    for (int base = it * STEP; base < nchunks; base += STEP) {
+        u32x4 nxt[U];
+        const bool more = base + STEP < nchunks;          // uniform over the wave
+        if (more) row_fetch<WAVE, U>(row, base + STEP, lane, last, nxt);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (base + lane + u * WAVE < nchunks) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t w = cur[u][j];
+                    cell(w);
+                }
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        }
+    }
+}
+
 template <bool DUP>
 __device__ __forceinline__ void v2_cell(uint32_t w, uint32_t amax2, uint32_t* hist, const uint32_t* lut,
                                         int kshift, int kslot, int combo_bin0, int& n_eq, int& n_hl, int& n_hs) {
@@ -477,6 +547,57 @@ __device__ __forceinline__ void v2_cell(uint32_t w, uint32_t amax2, uint32_t* hi
         const uint32_t x = lut[lo] ^ lut[hi];
         n_hl += (x & 0xffffu) == 0u;
         n_hs += (x >> 16) == 0u;
+    }
+}
+
+// ---- the wave-per-locus cell in mask form (k_locus_count_v2) ----------------------------------------------------
+// The SQ counters put k_locus_count_v2 at ~100 % VALU-busy with 27 vector instructions per 64 calls
+// (profiles/r02_notes.md section 7): the kernel is bound by vector issue at 5.7 TB/s.  Per call it needs only the two
+// histogram atomics per lane; everything else is a COUNT over the wave and can be a popcount of a lane mask, which
+// costs one vector compare and scalar instructions:  equal bins (homozygous by index), the four sentinel pairs
+// (t is one of four constants then), and with duplicate classes the LUT tests.  LDS byte addresses come straight from
+// the packed 16-bit bins (v_mad_u32_u16, op_sel for the high half).
+typedef __attribute__((address_space(3))) uint32_t* lds_u32p;
+typedef __attribute__((address_space(3))) const uint32_t* lds_cu32p;
+__device__ __forceinline__ uint32_t mad16_lo(uint32_t t, uint32_t k, uint32_t b) {
+    uint32_t r;
+    asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(t), "v"(k), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t mad16_hi(uint32_t t, uint32_t k, uint32_t b) {
+    uint32_t r;
+    asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(t), "v"(k), "v"(b));
+    return r;
+}
+// lanes whose two 16-bit halves are equal
+__device__ __forceinline__ uint64_t halves_equal(uint32_t t) {
+    uint64_t m;
+    asm("v_cmp_eq_u16_sdwa %0, %1, %1 src0_sel:WORD_0 src1_sel:WORD_1" : "=s"(m) : "v"(t));
+    return m;
+}
+struct CountAcc {   // wave-uniform counters of one locus
+    uint32_t n_eq = 0, c00 = 0, c10 = 0, c01 = 0, c11 = 0, n_hl = 0, n_hs = 0;
+};
+template <bool DUP>
+__device__ __forceinline__ void v2m_cell(uint32_t w, uint32_t amax2, uint32_t hist_b, uint32_t kbytes, uint32_t lut_b,
+                                         uint32_t four, CountAcc& c) {
+    u16x2 u = __builtin_bit_cast(u16x2, w) + (u16x2){2, 2};
+    u16x2 t2 = __builtin_elementwise_min(u, __builtin_bit_cast(u16x2, amax2));
+    const uint32_t t = __builtin_bit_cast(uint32_t, t2);
+    __hip_atomic_fetch_add((lds_u32p)(uintptr_t)mad16_lo(t, kbytes, hist_b), 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add((lds_u32p)(uintptr_t)mad16_hi(t, kbytes, hist_b), 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+    c.n_eq += (uint32_t)__popcll(halves_equal(t));
+    // both haplotypes sentinels (bins 0 / 1): the four pairs, (-2,-2), lo -1 hi -2, lo -2 hi -1, (-1,-1)
+    c.c00 += (uint32_t)__popcll(__ballot(t == 0x00000000u));
+    c.c10 += (uint32_t)__popcll(__ballot(t == 0x00000001u));
+    c.c01 += (uint32_t)__popcll(__ballot(t == 0x00010000u));
+    c.c11 += (uint32_t)__popcll(__ballot(t == 0x00010001u));
+    if (DUP) {
+        const uint32_t x = *(lds_cu32p)(uintptr_t)mad16_lo(t, four, lut_b) ^ *(lds_cu32p)(uintptr_t)mad16_hi(t, four, lut_b);
+        c.n_hl += (uint32_t)__popcll(__ballot((x & 0xffffu) == 0u));
+        c.n_hs += (uint32_t)__popcll(__ballot(x < 0x10000u));
     }
 }
 
@@ -518,56 +639,84 @@ __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v2(
     ml = wave_max(ml);
     ms = wave_max(ms);
     const bool dup = (ml + 1 < A) | (ms + 1 < A);
-    for (int i = lane; i < (nbins << kshift); i += WAVE) hist[i] = 0;
+    if (kshift >= 2) {
+        const u32x4 z4 = {0u, 0u, 0u, 0u};
+        for (int i = lane; i < ((A + 3) << (kshift - 2)); i += WAVE) reinterpret_cast<u32x4*>(hist)[i] = z4;
+    } else {
+        for (int i = lane; i < ((A + 3) << kshift); i += WAVE) hist[i] = 0;
+    }
     wave_lds_fence();
 
-    int n_eq = 0, n_hl = 0, n_hs = 0;
+    CountAcc c;
     const uint32_t amax2 = (uint32_t)(A + 2) * 0x00010001u;
+    const uint32_t hist_b = (uint32_t)(uintptr_t)(lds_u32p)hist + 4u * (uint32_t)kslot, kbytes = 4u << kshift;
+    const uint32_t lut_b = (uint32_t)(uintptr_t)(lds_u32p)lut, four = 4u;
     if (dup)
-        row_stream<WAVE, U>(row, nchunks, lane, cur, [&](uint32_t w) {
-            v2_cell<true>(w, amax2, hist, lut, kshift, kslot, A + 3, n_eq, n_hl, n_hs);
+        row_stream_wave<U>(row, nchunks, lane, cur, [&](uint32_t w) {
+            v2m_cell<true>(w, amax2, hist_b, kbytes, lut_b, four, c);
         });
     else
-        row_stream<WAVE, U>(row, nchunks, lane, cur, [&](uint32_t w) {
-            v2_cell<false>(w, amax2, hist, lut, kshift, kslot, A + 3, n_eq, n_hl, n_hs);
+        row_stream_wave<U>(row, nchunks, lane, cur, [&](uint32_t w) {
+            v2m_cell<false>(w, amax2, hist_b, kbytes, lut_b, four, c);
         });
     wave_lds_fence();
-    // fold the K copies of every bin (rotated start: conflict-free), keep the totals of the
-    // special bins in registers of the lanes that own them
-    int special = 0;  // this lane's total if it owns one of the special bins, gathered below
-    for (int bin = lane; bin < nbins; bin += WAVE) {
-        uint32_t s = 0;
-        for (int k = 0; k < K; ++k) s += hist[(bin << kshift) + ((k + lane) & (K - 1))];
-        if (bin >= 2 && bin < A + 2) {
-            allele_count[off + bin - 2] = (int32_t)s;
-            if (twin_ac) allele_count[twin_ac + off + bin - 2] = (int32_t)s;
+    // fold the K copies of every bin: lanes = bins x parts, every part adds K / parts copies read 16 bytes at a time,
+    // the parts of a bin are adjacent lanes
+    uint32_t h_m2 = 0, h_m1 = 0, n_bad = 0;   // totals of the special bins, broadcast below
+    if (kshift >= 2) {
+        int pshift = kshift - 2;
+        while (pshift > 0 && (nbins << pshift) > WAVE) --pshift;
+        const int part = lane & ((1 << pshift) - 1);
+        const int per4 = K >> (pshift + 2);   // 16-byte reads per part
+        for (int bin0 = 0; bin0 < nbins; bin0 += WAVE >> pshift) {
+            const int bin = bin0 + (lane >> pshift);
+            uint32_t sum = 0;
+            if (bin < A + 3) {                // (the sentinel-pair bins are not used by this kernel)
+                const u32x4* hp = reinterpret_cast<const u32x4*>(hist + (bin << kshift)) + part * per4;
+                for (int i = 0; i < per4; ++i) {
+                    const u32x4 h = hp[i];
+                    sum += (h.x + h.y) + (h.z + h.w);
+                }
+            }
+            for (int o = (1 << pshift) >> 1; o > 0; o >>= 1) sum += (uint32_t)__shfl_xor((int)sum, o, WAVE);
+            if (part == 0 && bin >= 2 && bin < A + 2) {
+                allele_count[off + bin - 2] = (int32_t)sum;
+                if (twin_ac) allele_count[twin_ac + off + bin - 2] = (int32_t)sum;
+            }
+            if (bin0 == 0) {                  // bins 0 and 1 sit in the first pass, at lanes 0 and 1 << pshift
+                h_m2 = (uint32_t)__builtin_amdgcn_readlane((int)sum, 0);
+                h_m1 = (uint32_t)__shfl((int)sum, 1 << pshift, WAVE);
+            }
+            const int lb = (A + 2 - bin0) << pshift;   // lane that holds the out-of-range bin in this pass
+            if (lb >= 0 && lb < WAVE) n_bad = (uint32_t)__shfl((int)sum, lb, WAVE);
         }
-        // stash special totals in LDS words that are no longer needed (copy 0 of the bin)
-        hist[bin << kshift] = s;
-    }
-    (void)special;
-    wave_lds_fence();
-    n_eq = wave_sum(n_eq);
-    if (dup) {
-        n_hl = wave_sum(n_hl);
-        n_hs = wave_sum(n_hs);
+    } else {
+        for (int bin = lane; bin < A + 3; bin += WAVE) {
+            uint32_t sum = 0;
+            for (int k = 0; k < K; ++k) sum += hist[(bin << kshift) + k];
+            if (bin >= 2 && bin < A + 2) {
+                allele_count[off + bin - 2] = (int32_t)sum;
+                if (twin_ac) allele_count[twin_ac + off + bin - 2] = (int32_t)sum;
+            }
+            hist[bin << kshift] = sum;
+        }
+        wave_lds_fence();
+        h_m2 = hist[0 << kshift];
+        h_m1 = hist[1 << kshift];
+        n_bad = hist[(A + 2) << kshift];
     }
     if (lane == 0) {
-        const int h_m2 = (int)hist[0 << kshift], h_m1 = (int)hist[1 << kshift];
-        const int n_bad = (int)hist[(A + 2) << kshift];
-        const int c00 = (int)hist[(A + 3) << kshift];  // (-2,-2)
-        const int c10 = (int)hist[(A + 4) << kshift];  // lo = -1, hi = -2
-        const int c01 = (int)hist[(A + 5) << kshift];  // lo = -2, hi = -1
-        const int c11 = (int)hist[(A + 6) << kshift];  // (-1,-1)
-        const int miss_rows = h_m1 - c11;
-        const int low_rows = h_m2 - c00 - c10 - c01;
-        const int hom_idx = n_eq - c11 - c00;
+        const int c00 = (int)c.c00, c10 = (int)c.c10, c01 = (int)c.c01, c11 = (int)c.c11;
+        const int miss_rows = (int)h_m1 - c11;
+        const int low_rows = (int)h_m2 - c00 - c10 - c01;
+        const int hom_idx = (int)c.n_eq - c11 - c00;
         // the whole 48-byte row (the finaliser's columns zeroed): three 16-byte stores, no memset before the launch
         static_assert(TRK_LI_COLS == 12 && TRK_LI_N_CALLED == 0 && TRK_LI_N_HOM_STR == 3 && TRK_LI_N_BAD == 5 &&
                       TRK_LI_N_SAMPLES == 8, "row layout");
-        const u32x4 r0 = {(uint32_t)(S - miss_rows), (uint32_t)low_rows, (uint32_t)(dup ? n_hl - c11 - c00 : hom_idx),
-                          (uint32_t)(dup ? n_hs - c11 - c00 : hom_idx)};
-        const u32x4 r1 = {0u, (uint32_t)n_bad, 0u, 0u};
+        const u32x4 r0 = {(uint32_t)(S - miss_rows), (uint32_t)low_rows,
+                          (uint32_t)(dup ? (int)c.n_hl - c11 - c00 : hom_idx),
+                          (uint32_t)(dup ? (int)c.n_hs - c11 - c00 : hom_idx)};
+        const u32x4 r1 = {0u, n_bad, 0u, 0u};
         const u32x4 r2 = {(uint32_t)(S - b.n_pad_samples), 0u, 0u, 0u};
         for (int64_t tw = 0;; tw = twin_li) {
             u32x4* li0 = reinterpret_cast<u32x4*>(locus_int + tw + (int64_t)l * TRK_LI_COLS);
@@ -2833,10 +2982,13 @@ hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* alle
                 return hipGetLastError();
             }
             if (use_v2) {
-                if (cnt_u == 4)
+                // wave-per-locus kernel: two chunks per register set (83 VGPRs, five waves per SIMD) beat four (100
+                // VGPRs, four waves) since the streamer swaps its two sets instead of copying: 0.70 vs 0.79 ms
+                const int v2_u = getenv("TRK_CNT_U") ? cnt_u : 2;
+                if (v2_u == 4)
                     hipLaunchKernelGGL(k_locus_count_v2<4>, grid, block, lds_fast, stream, b, allele_count, locus_int,
                                        kshift, words, twin_ac, twin_li);
-                else if (cnt_u == 1)
+                else if (v2_u == 1)
                     hipLaunchKernelGGL(k_locus_count_v2<1>, grid, block, lds_fast, stream, b, allele_count, locus_int,
                                        kshift, words, twin_ac, twin_li);
                 else
