@@ -46,9 +46,9 @@ def main():
     res["k_call_filter"] = entry(bench, 'k_call_filter_v2<3, true, false>', 20.0e9)
     res["k_cf_reduce"] = entry(bench, 'k_cf_reduce', None)
     res["k_locus_count"] = entry(bench, 'k_locus_count_v2<', 4.0e9)
-    res["k_assoc_scan"] = entry(bench, 'k_assoc_scan<1, false>', 4.0e9)
+    res["k_assoc_scan"] = entry(bench, 'k_assoc_scan_few<1, false>', 4.0e9) or entry(bench, 'k_assoc_scan<1, false>', 4.0e9)
     res["config1_k_locus_count"] = entry(configs, 'k_locus_count_v3<4', 4.0e7)
-    res["config2_k_call_filter_fast"] = entry(configs, 'k_call_filter_fast<12, true>', 50000 * 5000 * 60.0)
+    res["config2_k_call_filter_fast"] = entry(configs, 'k_call_filter_fast<12, true, true>', 50000 * 5000 * 60.0) or entry(configs, 'k_call_filter_fast<12, true>', 50000 * 5000 * 60.0)
     if res["k_call_filter"]:
         res["k_call_filter_bytes_per_launch"] = res["k_call_filter"]["bytes_per_launch"]
     print(json.dumps(res, indent=1))

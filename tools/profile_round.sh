@@ -1,7 +1,7 @@
 #!/bin/bash
 # The rocprofv3 passes behind profiles/<tag>_*: kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in their own runs
 # (never combined with another trace domain), around (a) the bench command -- headline step + the associaTR extra --
-# and (b) tools/config_probe.py (BASELINE configs[1] and configs[2], HipSTR five-filter set).  Run on the GPU box:
+# (b) tools/config_probe.py (BASELINE configs[1] and configs[2], HipSTR five-filter set) and (c) tools/qc_probe.py.  Run on the GPU box:
 #   gpurun -- bash tools/profile_round.sh r02
 set -u
 tag=${1:-r02}
@@ -20,6 +20,7 @@ run3() {   # name, command...: stats pass + two PMC passes of the same command
 }
 run3 bench python "$repo/bench.py" --steps 5 --warmup 2 --no-check --no-cpu-baseline --no-extras
 run3 configs python "$repo/tools/config_probe.py"
+run3 qc python "$repo/tools/qc_probe.py" --iters 3
 cd "$repo"
 python tools/pmc_traffic.py "$out/${tag}_bench_pmc_fetch_write.csv" "$out/${tag}_configs_pmc_fetch_write.csv" "$tag" > "$out/${tag}_pmc_traffic.json"
 grep -h "^{" "$out/bench_under_rocprof.log" | tail -1 | cut -c1-300
