@@ -173,6 +173,11 @@ def test_lds_resident_kernels_for_more_than_two_vectors(eng):
 def test_many_alleles_and_rounding(eng):
     assert run_case(eng, 5, 50, 640, M=2, max_alleles=60) > 25
     assert run_case(eng, 6, 30, 512, M=1, max_alleles=400, precision=10) > 10   # generic path (LUT too big)
+    # the one / two-vector kernel with so many bins that fewer than four histogram copies fit the wave's table area
+    # (scalar zeroing and fold), with and without a sample subset
+    assert run_case(eng, 11, 40, 2048, M=1, max_alleles=200) > 20
+    assert run_case(eng, 12, 40, 1024, M=2, max_alleles=240, subset=True) > 20
+    assert run_case(eng, 13, 40, 1024, M=1, max_alleles=130, subset=True, miss=0.3) > 15
 
 
 def test_generic_path_ploidy_and_alignment(eng):
