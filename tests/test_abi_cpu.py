@@ -68,3 +68,29 @@ def test_engine_fails_loudly_without_gpu():
     from trtools_amd.engine import Engine
     with pytest.raises(L.TrkError):
         Engine(0)
+
+
+def test_binomtest_host_entry_random_cases_match_scipy():
+    """The exact two-sided test behind the HWE column (utils.py:334-338) against scipy itself on a sweep of n, p and k
+    (edges, the mean and its neighbours, random draws around the mean): the guided search for the far-side crossing
+    (trk_binom.h binom_boundary) must land where scipy's bisection does."""
+    import numpy as np
+    import scipy.stats as st
+    from trtools_amd import _lib as L
+    lib = L.load()
+    rng = np.random.default_rng(3)
+    cases = []
+    for n in [1, 2, 3, 5, 10, 37, 100, 999, 2000, 10000]:
+        for p in [1e-6, 0.003, 0.05, 0.25, 0.5, 0.5000001, 0.77, 0.97, 0.999999]:
+            ks = set([0, 1, n // 2, n - 1, n, int(n * p), int(n * p) + 1, max(0, int(n * p) - 1)] +
+                     [int(x) for x in rng.integers(0, n + 1, size=6)])
+            cases += [(k, n, p) for k in ks if 0 <= k <= n]
+    for _ in range(800):
+        n = int(rng.integers(1, 20001))
+        p = float(rng.random())
+        k = int(np.clip(rng.normal(n * p, 3 * np.sqrt(n * p * (1 - p)) + 1), 0, n))
+        cases.append((k, n, p))
+    for k, n, p in cases:
+        got = lib.trk_binomtest_two_sided(k, n, p)
+        want = st.binomtest(k, n, p).pvalue
+        assert abs(got - want) <= 1e-9 * max(want, 1e-300) or abs(got - want) < 1e-300, (k, n, p, got, want)

@@ -182,6 +182,63 @@ TRK_HD inline int64_t binom_bsearch(double sign, double d, int64_t lo, int64_t h
     return lo - 1;
 }
 
+// The index scipy's bisection returns -- the largest i in [lo, hi] with sign * pmf(i) <= d, lo - 1 if there is none
+// (sign * pmf is increasing over the range: it lies on one side of the mode) -- found from a GUESS instead: one pmf
+// evaluation at the guess, a walk along the pmf ratio recurrence to the crossing, and two direct evaluations that
+// confirm it (pmf(ix) is returned: the caller compares it with d).  The bisection costs ~log2(range) + 1 evaluations
+// of ~400 instructions each; the guess (k mirrored at the mean) is a few steps off.  Falls back to the bisection
+// when the walk does not arrive.
+TRK_HD inline int64_t binom_boundary(double sign, double d, int64_t lo, int64_t hi, int64_t n, double p, int64_t guess,
+                                     double* pmf_ix) {
+    if (lo > hi) {                       // (the bisection's final test alone)
+        const int64_t ix = sign * binom_pmf(lo, n, p) <= d ? lo : lo - 1;
+        *pmf_ix = binom_pmf(ix, n, p);
+        return ix;
+    }
+    const double q = 1.0 - p;
+    int64_t i = guess < lo ? lo : (guess > hi ? hi : guess);
+    double t = binom_pmf(i, n, p);
+    const double up = p / q, down = q / p;   // pmf(i+1) = pmf(i) (n-i)/(i+1) p/q ; pmf(i-1) = pmf(i) i/(n-i+1) q/p
+    bool ok = p > 0.0 && q > 0.0;
+    if (ok) {
+        int steps = 0;
+        if (sign * t <= d) {             // inside: move right while the next one is inside too
+            while (i < hi && steps < 96) {
+                const double tn = t * ((double)(n - i) * fast_rcp((double)(i + 1)) * up);
+                if (!(sign * tn <= d)) break;
+                t = tn;
+                ++i;
+                ++steps;
+            }
+        } else {                         // outside: move left until inside (or past lo)
+            while (i >= lo && steps < 96) {
+                if (i == lo) { i = lo - 1; break; }
+                t = t * ((double)i * fast_rcp((double)(n - i + 1)) * down);
+                --i;
+                ++steps;
+                if (sign * t <= d) break;
+            }
+        }
+        ok = steps < 96;
+    }
+    if (ok) {
+        // confirm with the direct evaluation (the walk's values carry the recurrence's rounding): i inside, i + 1 not
+        for (int fix = 0; fix < 4 && ok; ++fix) {
+            const double ti = i >= lo ? binom_pmf(i, n, p) : 0.0;
+            if (i >= lo && !(sign * ti <= d)) { --i; continue; }
+            if (i < hi) {
+                const double tn = binom_pmf(i + 1, n, p);
+                if (sign * tn <= d) { ++i; continue; }
+            }
+            *pmf_ix = i >= lo ? ti : binom_pmf(i, n, p);
+            return i;
+        }
+    }
+    const int64_t ix = binom_bsearch(sign, d, lo, hi, n, p);
+    *pmf_ix = binom_pmf(ix, n, p);
+    return ix;
+}
+
 // sum_{i<=kl} pmf(i) + sum_{i>ku} pmf(i): both far tails advanced in ONE loop (two
 // independent recurrences per iteration: twice the ILP, half the trip count, and --
 // on the GPU -- one code path for every lane whatever side of the mean k lies on).
@@ -239,10 +296,12 @@ TRK_HD inline double binomtest_two_sided(int64_t k, int64_t n, double p) {
     const double sign = below ? -1.0 : 1.0;
     const int64_t lo = below ? (int64_t)ceil(pn) : 0;
     const int64_t hi = below ? n : (int64_t)floor(pn);
-    const int64_t ix = binom_bsearch(sign, sign * d * rerr, lo, hi, n, p);
+    // (the mirror image of k at the mean is where a symmetric pmf would cross; skew moves the crossing a few steps)
+    double pmf_ix;
+    const int64_t ix = binom_boundary(sign, sign * d * rerr, lo, hi, n, p, (int64_t)floor(2.0 * pn - kd + 0.5), &pmf_ix);
     int64_t kl, ku;
     if (below) {
-        const int64_t y = n - ix + ((d * rerr == binom_pmf(ix, n, p)) ? 1 : 0);
+        const int64_t y = n - ix + ((d * rerr == pmf_ix) ? 1 : 0);
         kl = k;          // cdf(k)
         ku = n - y;      // sf(n - y)
     } else {
