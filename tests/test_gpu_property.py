@@ -12,6 +12,16 @@ from test_gpu_stats import check_against_oracle
 
 pytestmark = pytest.mark.gpu
 
+# TRK_PROPERTY_SCALE=k: one-off campaigns on the GPU box -- k times the examples, fresh random seeds (the suite itself
+# runs the derandomised set)
+import os
+_SCALE = int(os.environ.get('TRK_PROPERTY_SCALE', '0'))
+
+
+def _cfg(n):
+    return settings(max_examples=n * max(_SCALE, 1), deadline=None, derandomize=_SCALE == 0, database=None,
+                    suppress_health_check=list(HealthCheck))
+
 
 @pytest.fixture(scope='module')
 def eng():
@@ -52,7 +62,7 @@ def _batch(rng, n_loci, S, P, with_low):
     return np.stack(gts), lens, strs, np.array(lp, dtype=np.uint8), pack_alleles(lens, strs)
 
 
-@settings(max_examples=200, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+@_cfg(200)
 @given(seed=st.integers(0, 2**31 - 1), n_loci=st.integers(1, 10),
        S=st.one_of(st.integers(1, 260), st.sampled_from([1020, 1024, 1028, 2049, 4100])), P=st.integers(1, 3),
        with_low=st.booleans(), n_groups=st.integers(0, 3))
@@ -75,7 +85,7 @@ def test_statistics_match_the_oracle(eng, seed, n_loci, S, P, with_low, n_groups
         a.free()
 
 
-@settings(max_examples=200, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+@_cfg(200)
 @given(seed=st.integers(0, 2**31 - 1), n_loci=st.integers(1, 8),
        S=st.one_of(st.integers(1, 300), st.sampled_from([1020, 1024, 1028, 2052, 4100])), n_filters=st.integers(0, 7),
        delta=st.booleans(), with_low=st.booleans())
@@ -147,7 +157,7 @@ def test_threshold_call_filters_match_the_oracle(eng, seed, n_loci, S, n_filters
         assert np.array_equal(st_.locus_int.get()[0][:, cols], recount.locus_int.get()[0][:, cols])
 
 
-@settings(max_examples=120, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+@_cfg(120)
 @given(seed=st.integers(0, 2**31 - 1), n_loci=st.integers(6, 14), S=st.integers(40, 700), P=st.integers(1, 3),
        M=st.integers(1, 9), subset=st.booleans(), locus_ploidy=st.booleans(), miss=st.sampled_from([0.0, 0.04, 0.3]))
 def test_association_scan_matches_the_oracle(eng, seed, n_loci, S, P, M, subset, locus_ploidy, miss):
@@ -158,7 +168,7 @@ def test_association_scan_matches_the_oracle(eng, seed, n_loci, S, P, M, subset,
     run_case(eng, seed, n_loci, S, P=P, M=M, subset=subset, locus_ploidy=locus_ploidy and P > 1, miss=miss)
 
 
-@settings(max_examples=100, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+@_cfg(100)
 @given(seed=st.integers(0, 2**31 - 1), n_loci=st.integers(1, 9), S=st.integers(1, 520),
        layout=st.sampled_from(['interleaved', 'planar', 'planarize']),
        keep=st.sets(st.integers(0, 8), min_size=1), delta=st.booleans(), with_low=st.booleans(),
@@ -177,7 +187,7 @@ def comp(eng):
     return DeviceCompute(engine=eng)
 
 
-@settings(max_examples=150, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+@_cfg(150)
 @given(seed=st.integers(0, 2**31 - 1), n_loci=st.integers(1, 9), S=st.integers(1, 130), P=st.integers(1, 3),
        with_low=st.booleans(), n_groups=st.integers(0, 2), n_filters=st.integers(0, 5))
 def test_compute_seam_matches_the_oracle_seam(comp, seed, n_loci, S, P, with_low, n_groups, n_filters):
@@ -243,7 +253,7 @@ def test_compute_seam_matches_the_oracle_seam(comp, seed, n_loci, S, P, with_low
     assert np.array_equal(la, lb)
 
 
-@settings(max_examples=60, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+@_cfg(60)
 @given(seed=st.integers(0, 10**6), n_loci=st.integers(6, 16), S=st.integers(60, 420), M=st.integers(1, 8),
        amax=st.integers(1, 12))
 def test_dosage_scan_matches_the_oracle(eng, seed, n_loci, S, M, amax):
@@ -253,7 +263,7 @@ def test_dosage_scan_matches_the_oracle(eng, seed, n_loci, S, M, amax):
     run_dosage_case(eng, seed, n_loci, S, M, amax)
 
 
-@settings(max_examples=100, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+@_cfg(100)
 @given(seed=st.integers(0, 2**31 - 1), n_loci=st.integers(1, 8), S=st.integers(1, 200),
        dtype_=st.sampled_from(['bestguess', 'bestguess_norm', 'beagleap', 'beagleap_norm']), amax=st.integers(1, 12))
 def test_dosages_match_the_oracle(comp, seed, n_loci, S, dtype_, amax):
