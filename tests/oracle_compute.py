@@ -293,3 +293,27 @@ class OracleCompute:
                 err[l] |= 4
             out[l] = d
         return out, err
+
+    def qc_batch(self, hb, quality=None, sample_index=None, ignore_no_call=False):
+        """trk_qc_reduce through oracle.qc_record, one record at a time (the arrays DeviceCompute.qc_batch returns)."""
+        L_, S = hb.n_loci, hb.n_samples
+        sel = np.ones(S, dtype=bool) if sample_index is None else np.asarray(sample_index, dtype=bool)
+        idx = np.flatnonzero(sel)
+        out = dict(sample_calls=np.zeros(S, dtype=np.int64), locus_calls=np.zeros(L_, dtype=np.int64))
+        if quality is not None:
+            out.update(sample_qual_sum=np.zeros(S), sample_qual_n=np.zeros(S, dtype=np.int64),
+                       locus_qual_sum=np.zeros(L_), locus_qual_n=np.zeros(L_, dtype=np.int64))
+        for l in range(L_):
+            g = hb.gt[l][:, :int(hb.locus_ploidy[l])]
+            calls, q, _ = orc.qc_record(g, None if quality is None else np.asarray(quality[l]).reshape(-1, 1), sel,
+                                        ignore_no_call)
+            out['sample_calls'][idx] += calls
+            out['locus_calls'][l] = calls.sum()
+            if q is not None:
+                v = q.reshape(-1).astype(np.float64)
+                ok = ~np.isnan(v)
+                out['sample_qual_sum'][idx[ok]] += v[ok]
+                out['sample_qual_n'][idx[ok]] += 1
+                out['locus_qual_sum'][l] = v[ok].sum()
+                out['locus_qual_n'][l] = ok.sum()
+        return out

@@ -72,3 +72,27 @@ def test_half_missing_call_counts_and_all_missing_does_not():
     sel = np.array([True, False, True, False, True])
     calls, q2, mean2 = orc.qc_record(gt, q, sel)
     assert calls.tolist() == [True, False, True] and mean2 == np.float32(1.5 / 3)
+
+
+@pytest.mark.parametrize('case', [c for c in CASES if c['name'] in ('many_samples_subset_ignore', 'multi_chrom', 'gangstr',
+                                                                     'popstr_no_quality')],
+                         ids=lambda c: c['name'])
+def test_product_host_logic_with_the_oracle_behind_the_compute_seam(case):
+    """trtools_amd.qcSTR.qc_reductions (reader, harmoniser, batching, accumulation) with OracleCompute standing in
+    for the device: the host logic alone must reproduce the reference's accumulators."""
+    from oracle_compute import OracleCompute
+    from trtools_amd import runtime
+    from trtools_amd.qcSTR import qc_reductions
+    old = runtime.set_compute(OracleCompute())
+    try:
+        got = qc_reductions(os.path.join(GOLD, case['vcf']), vcftype=case['vcftype'],
+                            samples=os.path.join(GOLD, case['samples']) if case['samples'] else None,
+                            quality=case['quality'], quality_ignore_no_call=case['ignore_no_call'], batch_loci=257)
+    finally:
+        runtime.set_compute(old)
+    assert got is not None
+    check_against_golden(case, got, got['samples'], float_tol=2e-6)
+    want = case['recorded']
+    assert got['n_alleles'] == want['diffref_hist']['n']
+    np.testing.assert_allclose(got['sum_diff_unit'], want['diffref_hist']['sum'], rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(got['sum_diff_bp'], want['diffref_bias']['sum_diffs'], rtol=1e-9, atol=1e-6)
