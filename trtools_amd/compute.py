@@ -48,6 +48,11 @@ class DeviceCompute:
         """Pinned staging memory for the native reader's batch arrays (Engine.host_buffer)."""
         return self.eng.host_buffer(nbytes)
 
+    def host_release(self, arr):
+        """Give a ``host_buffer`` back (the reader does when it is closed): the next reader reuses it."""
+        self.eng.sync()                      # uploads from the buffer may still be queued
+        self.eng.host_buffer_release(arr)
+
     @staticmethod
     def _n_pad(hb):
         """Samples to append so that a diploid row is a multiple of four samples = 16-byte aligned: the streaming

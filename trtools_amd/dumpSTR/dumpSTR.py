@@ -825,7 +825,8 @@ def main(args):
     if use_batches:
         from .. import runtime
         kinds = {k: (1 if h['Type'] == 'Integer' else 2 if h['Type'] == 'Float' else 4) for k, h in format_fields.items()}
-        invcf.use_buffers(getattr(runtime.get_compute(), 'host_buffer', None), ring=2)
+        invcf.use_buffers(getattr(runtime.get_compute(), 'host_buffer', None), ring=2,
+                          release=getattr(runtime.get_compute(), 'host_release', None))
     while use_batches:
         rb = invcf.read_raw_batch(batch_loci)
         if rb.n == 0:

@@ -181,7 +181,9 @@ class Engine:
         self._pool = {}              # size class -> [device pointers]
         self._pool_bytes = 0
         self._pool_limit = int(float(os.environ.get('TRK_POOL_GB', '16')) * (1 << 30))
-        self._pinned = []            # (pointer, bytes) of hipHostMalloc'ed staging buffers
+        self._pinned = []            # pointers of hipHostMalloc'ed staging buffers
+        self._pinned_cls = {}        # pointer -> size class of the buffers handed out
+        self._pinned_free = {}       # size class -> released pointers
         ctx = C.c_void_p()
         rc = self.lib.trk_init(int(device), C.byref(ctx))
         if rc != 0:
@@ -238,11 +240,32 @@ class Engine:
 
     def host_buffer(self, nbytes):
         """A pinned (page-locked, hipHostMalloc) host buffer as a numpy uint8 array: a copy from / to it runs at the
-        full PCIe rate and its pages never fault.  Lives until the engine is closed."""
-        ptr = C.c_void_p()
-        self._chk(self.lib.trk_host_alloc(self.ctx, max(int(nbytes), 16), C.byref(ptr)))
-        self._pinned.append(ptr.value)
-        return np.ctypeslib.as_array(C.cast(ptr.value, C.POINTER(C.c_uint8)), shape=(max(int(nbytes), 16),))
+        full PCIe rate and its pages never fault.  Taken from the engine's pool of released buffers when one of the
+        same size class is free (an allocation costs ~15 ms whatever its size); lives until ``host_buffer_release``
+        or the end of the engine."""
+        want = max(int(nbytes), 16)
+        cls = self._size_class(want)
+        free = self._pinned_free.get(cls)
+        if free:
+            ptr = free.pop()
+        else:
+            p = C.c_void_p()
+            self._chk(self.lib.trk_host_alloc(self.ctx, cls, C.byref(p)))
+            ptr = p.value
+            self._pinned.append(ptr)
+        self._pinned_cls[ptr] = cls
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(cls,))[:want]
+
+    def host_buffer_release(self, arr):
+        """Hand a ``host_buffer`` array back to the pool (the caller must not touch it afterwards, and no copy from or
+        to it may still be in flight)."""
+        base = arr
+        while getattr(base, 'base', None) is not None and isinstance(base.base, np.ndarray):
+            base = base.base
+        ptr = base.ctypes.data
+        cls = self._pinned_cls.pop(ptr, None)
+        if cls is not None:
+            self._pinned_free.setdefault(cls, []).append(ptr)
 
     def close(self):
         if self.ctx is not None:
@@ -251,7 +274,7 @@ class Engine:
             self.trim()
             for ptr in self._pinned:
                 self.lib.trk_host_free(self.ctx, ptr)
-            self._pinned = []
+            self._pinned, self._pinned_cls, self._pinned_free = [], {}, {}
             self.lib.trk_free(self.ctx)
             self.ctx = None
 

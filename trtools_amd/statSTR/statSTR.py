@@ -253,7 +253,7 @@ def _run_batches(args, invcf, vcftype, group_masks, fmt, shard, batch_loci, star
         gb = np.zeros(len(invcf.samples), dtype=np.uint8)
         for g, m in enumerate(masks):
             gb |= (np.asarray(m, dtype=bool).astype(np.uint8) << g)
-    invcf.use_buffers(getattr(compute, 'host_buffer', None), ring=2)
+    invcf.use_buffers(getattr(compute, 'host_buffer', None), ring=2, release=getattr(compute, 'host_release', None))
     nrecords = 0
     while True:
         rb = invcf.read_raw_batch(batch_loci)
@@ -395,6 +395,8 @@ def main(args):
     finally:
         if outf is not None and args.out != "stdout":
             outf.close()
+        if hasattr(invcf, 'close'):
+            invcf.close()            # hands the reader's pinned staging buffers back to the pool
     if args.out != "stdout":
         print("\nDone", flush=True)
     return 0

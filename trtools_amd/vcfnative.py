@@ -317,13 +317,14 @@ class NativeVCFReader(vcfio.VCFReader):
         rb._keep = parr
         return rb
 
-    def use_buffers(self, allocator=None, ring=2):
+    def use_buffers(self, allocator=None, ring=2, release=None):
         """Decode batches into a ring of ``ring`` preallocated array sets instead of fresh numpy arrays (a batch then
         stays valid until ``ring`` further batches have been read).  Fresh arrays cost a page fault per 4 KB inside
         the parser threads, which serialise in the kernel -- the reader ran at a fifth of its rate because of it.
         ``allocator(nbytes) -> uint8 array``: where the memory comes from (DeviceCompute.host_buffer: pinned pages,
         so that the upload is a plain DMA)."""
         self._ring, self._ring_i, self._ring_n, self._alloc = [], 0, int(ring), allocator
+        self._release, self._slabs = release, []     # ``release(slab)``: called for every slab when the reader closes
 
     def _arrays(self, n, S, P):
         if getattr(self, '_ring_n', 0) <= 0:
@@ -338,6 +339,7 @@ class NativeVCFReader(vcfio.VCFReader):
             total = max(sum(sizes), 64)
             if self._alloc is not None:
                 slab = self._alloc(total)
+                self._slabs.append(slab)
             else:
                 slab = np.empty(total, dtype=np.uint8)
                 slab[:] = 0                                      # touch the pages now, not in the parser threads
@@ -439,6 +441,11 @@ class NativeVCFReader(vcfio.VCFReader):
         if self._h is not None:
             self._lib.trk_vcf_close(self._h)
             self._h = None
+        slabs, self._slabs, self._ring = getattr(self, '_slabs', []), [], []
+        rel = getattr(self, '_release', None)
+        if rel is not None:
+            for slab in slabs:
+                rel(slab)
 
     def __del__(self):
         try:
