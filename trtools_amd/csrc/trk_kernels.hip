@@ -1412,6 +1412,13 @@ struct CallArgs {
     const void* grp_ptr[CF_MAX_GROUPS];
     int8_t grp_base[CF_MAX_GROUPS], grp_k[CF_MAX_GROUPS];
     int32_t grp_n;
+    // the same sources as LOAD SLOTS of the register-vector path (cf_load_r): slot s is one 16-byte vector per thread
+    // at  slot_ptr[s] + ((cell0 / 4) * slot_mult[s] + slot_chunk[s]) * 16  (a planar source: mult 1, chunk 0; chunk i of
+    // an interleaved plane with k columns: mult k, chunk i), landing in elements 4 s .. 4 s + 3 of the vector; the value
+    // of logical source q for call j is element  src_off[q] + j * src_stride[q]  (planar: 4 q + j; column c of an
+    // interleaved plane whose first slot is b: 4 b + c + j k)
+    const void* slot_ptr[16];
+    int8_t slot_mult[16], slot_chunk[16], src_off[16], src_stride[16];
     int8_t f_src_a[TRK_MAX_FILTERS], f_src_a2[TRK_MAX_FILTERS], f_src_b[TRK_MAX_FILTERS];  // operands of filter k
     int8_t f_ci[TRK_MAX_FILTERS][6];  // OUTSIDE_CI: sources of ml_j, lo_j, hi_j (j < f_ci_n <= 2)
     int8_t f_ci_n[TRK_MAX_FILTERS];
@@ -1788,7 +1795,7 @@ __device__ __forceinline__ void add_mask(uint32_t& x, uint64_t mask) {
 // (s_set_gpr_idx).  The select chain of cf_gather costs 4 x NS instructions per operand; with nine filters the
 // GangSTR set spent ~250 vector instructions per call on 60 bytes (SQ counters, profiles/r02_notes.md section 8).
 // Decisions are wave-wide lane masks in scalar registers as in k_call_filter_v2.
-template <int NS>
+template <int NS, bool GEN>
 struct CfRegs {
     static constexpr int NLO = (NS < 8 ? NS : 8) * 4, NHI = (NS > 8 ? NS - 8 : 1) * 4;
     typedef uint32_t lo_t __attribute__((ext_vector_type(NLO)));
@@ -1796,9 +1803,20 @@ struct CfRegs {
     u32x4 gt;
     lo_t lo;   // element 4 q + j: source q (< 8) of call j -- a 16-byte load lands in four consecutive elements
     hi_t hi;   // sources 8 ..
-    // the four values of source `idx` (uniform across the wave)
-    __device__ __forceinline__ void get(int idx, uint32_t (&v)[CF_V]) const {
-        if (NS <= 8 || idx < 8) {
+    // element e of the (lo, hi) pair, e uniform across the wave: one indexed move
+    __device__ __forceinline__ uint32_t elem(int e) const {
+        if (NS <= 8 || e < NLO) return lo[e];
+        return hi[e - NLO];
+    }
+    // the four values of logical source `idx` (uniform across the wave)
+    // GEN: interleaved planes among the sources (element offset and stride from the tables); else every source is
+    // planar and sits in elements 4 idx .. 4 idx + 3
+    __device__ __forceinline__ void get(const CallArgs& a, int idx, uint32_t (&v)[CF_V]) const {
+        if constexpr (GEN) {
+            const int off = a.src_off[idx], st = a.src_stride[idx];
+#pragma unroll
+            for (int j = 0; j < CF_V; ++j) v[j] = elem(off + j * st);
+        } else if (NS <= 8 || idx < 8) {
 #pragma unroll
             for (int j = 0; j < CF_V; ++j) v[j] = lo[4 * idx + j];
         } else {
@@ -1807,16 +1825,22 @@ struct CfRegs {
         }
     }
 };
-// Planar sources only (every source its own [L*S] array).  Every slot is loaded unconditionally -- a conditional
-// insert makes the whole vector a phi and the register allocator copies it; slots past n_src re-read the genotype
-// row (an L2 hit).
-template <int NS>
-__device__ __forceinline__ void cf_load_r(const CallArgs& a, int64_t cell0, CfRegs<NS>& d) {
-    d.gt = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.b.gt) + (cell0 >> 2));
+// Every slot is loaded unconditionally -- a conditional insert makes the whole vector a phi and the register
+// allocator copies it; slots past the last one re-read the genotype row (an L2 hit).
+template <int NS, bool GEN>
+__device__ __forceinline__ void cf_load_r(const CallArgs& a, int64_t cell0, CfRegs<NS, GEN>& d) {
+    const int64_t c4 = cell0 >> 2;
+    d.gt = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.b.gt) + c4);
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
-        const void* sp = q < a.n_src ? a.src_ptr[q] : static_cast<const void*>(a.b.gt);
-        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sp) + (cell0 >> 2));
+        const u32x4* sp = reinterpret_cast<const u32x4*>(a.b.gt) + c4;
+        if (q < a.n_src) {
+            if constexpr (GEN)
+                sp = reinterpret_cast<const u32x4*>(a.slot_ptr[q]) + (c4 * a.slot_mult[q] + a.slot_chunk[q]);
+            else
+                sp = reinterpret_cast<const u32x4*>(a.slot_ptr[q]) + c4;
+        }
+        const u32x4 t = __builtin_nontemporal_load(sp);
 #pragma unroll
         for (int j = 0; j < CF_V; ++j) {
             if (q < 8) d.lo[4 * q + j] = t[j];
@@ -1825,9 +1849,9 @@ __device__ __forceinline__ void cf_load_r(const CallArgs& a, int64_t cell0, CfRe
     }
 }
 
-template <int NS>
+template <int NS, bool GEN>
 __device__ __forceinline__ void cf_process_r(const CallArgs& a, int l, int64_t cell0, int64_t s0, int tid, bool leader,
-                                             const CfRegs<NS>& d, uint32_t* fcount, uint32_t* numcalls,
+                                             const CfRegs<NS, GEN>& d, uint32_t* fcount, uint32_t* numcalls,
                                              int64_t* totaldp, uint32_t* dpmiss, const CfDelta dc,
                                              const bool has_delta) {
     const int nf = a.n_filters;
@@ -1851,9 +1875,9 @@ __device__ __forceinline__ void cf_process_r(const CallArgs& a, int l, int64_t c
         const float thrf = (float)f.thr;
         uint64_t hm[CF_V] = {0, 0, 0, 0};
         uint32_t oa[CF_V] = {0, 0, 0, 0}, oa2[CF_V] = {0, 0, 0, 0}, ob[CF_V] = {0, 0, 0, 0};
-        if (ia >= 0) d.get(ia, oa);
-        if (ia2 >= 0) d.get(ia2, oa2);
-        if (ib >= 0) d.get(ib, ob);
+        if (ia >= 0) d.get(a, ia, oa);
+        if (ia2 >= 0) d.get(a, ia2, oa2);
+        if (ib >= 0) d.get(a, ib, ob);
         switch (f.op) {
             case TRK_F_LT:
             case TRK_F_CALLED_LT:
@@ -1928,9 +1952,9 @@ __device__ __forceinline__ void cf_process_r(const CallArgs& a, int l, int64_t c
             case TRK_F_CALLED_OUTSIDE_CI: {
                 for (int c = 0; c < a.f_ci_n[k]; ++c) {
                     uint32_t vm[CF_V], vl[CF_V], vh[CF_V];
-                    d.get(a.f_ci[k][3 * c], vm);
-                    d.get(a.f_ci[k][3 * c + 1], vl);
-                    d.get(a.f_ci[k][3 * c + 2], vh);
+                    d.get(a, a.f_ci[k][3 * c], vm);
+                    d.get(a, a.f_ci[k][3 * c + 1], vl);
+                    d.get(a, a.f_ci[k][3 * c + 2], vh);
 #pragma unroll
                     for (int j = 0; j < CF_V; ++j) {
                         const int32_t ml = (int32_t)vm[j];
@@ -1965,7 +1989,7 @@ __device__ __forceinline__ void cf_process_r(const CallArgs& a, int l, int64_t c
     if (a.dp_plane >= 0) {
         uint64_t bad = 0;
         uint32_t dpv[CF_V];
-        d.get(a.dp_src, dpv);
+        d.get(a, a.dp_src, dpv);
 #pragma unroll
         for (int j = 0; j < CF_V; ++j) {
             const int32_t dv = (int32_t)dpv[j];
@@ -2203,8 +2227,9 @@ __device__ __forceinline__ void cf_process(const CallArgs& a, int l, int64_t cel
 // A workgroup owns loci [y * loci_per_wg, ...) and walks them in sub-blocks of loci_per_block, the unit of the
 // LDS delta table; the per-sample counters live across sub-blocks and are flushed once.
 // (the instantiation that sits one register above 128 VGPRs is held to four waves per SIMD)
-// PLANAR (with ALLREG): no interleaved planes either -- the sources sit in indexable vectors, cf_process_r.
-template <int NS, bool ALLREG, bool PLANAR>
+// VEC (with ALLREG): the sources sit in indexable register vectors, cf_process_r -- 1: every source planar, 2: interleaved
+// planes among them (offsets and strides from tables); 0: the select-chain form.
+template <int NS, bool ALLREG, int VEC>
 __global__ __launch_bounds__(CF_THREADS, (NS == 12 && ALLREG) ? 4 : 1) void k_call_filter_fast(const CallArgs a) {
     extern __shared__ uint32_t fcount[];  // [n_filters][CF_THREADS][2] (16-bit pairs), then the delta table
     const int tid = threadIdx.x;
@@ -2246,12 +2271,12 @@ __global__ __launch_bounds__(CF_THREADS, (NS == 12 && ALLREG) ? 4 : 1) void k_ca
             };
             // (loading locus l + 1 into a second register set while l is evaluated was measured: the registers
             // cost more occupancy than the overlap buys, profiles/r01_notes.md)
-            if constexpr (ALLREG && PLANAR) {
+            if constexpr (ALLREG && VEC != 0) {
                 const bool leader = (tid & 63) == __ffsll((unsigned long long)__ballot(1)) - 1;  // first live lane
                 for (int l = l_begin; l < l_end; ++l) {
-                    CfRegs<NS> d;
+                    CfRegs<NS, VEC == 2> d;
                     cf_load_r(a, (int64_t)l * S + s0, d);
-                    cf_process_r<NS>(a, l, (int64_t)l * S + s0, s0, tid, leader, d, fcount, numcalls, totaldp, dpmiss,
+                    cf_process_r<NS, VEC == 2>(a, l, (int64_t)l * S + s0, s0, tid, leader, d, fcount, numcalls, totaldp, dpmiss,
                                      delta_of(l), dstride != 0);
                 }
             } else {
@@ -3367,14 +3392,33 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
         if (const char* e = getenv("TRK_CF_ROUNDS")) rounds = atoi(e) > 0 ? atoi(e) : rounds;
         if (const char* e = getenv("TRK_CF_WPC")) wpc = atoi(e);
         if (const char* e = getenv("TRK_CF_DELTA_KB")) delta_kb = atoi(e) > 0 ? atoi(e) : delta_kb;
+        // load slots / element offsets of the register-vector path (CallArgs: slot_*, src_off, src_stride)
+        for (int q = 0; q < 16; ++q) {
+            a.slot_ptr[q] = b.gt;
+            a.slot_mult[q] = 1;
+            a.slot_chunk[q] = 0;
+            a.src_off[q] = (int8_t)(4 * q);
+            a.src_stride[q] = 1;
+        }
+        for (int q = 0; q < a.n_src && q < 16; ++q)
+            if (a.src_ptr[q]) a.slot_ptr[q] = a.src_ptr[q];
+        for (int g = 0; g < a.grp_n; ++g)
+            for (int c = 0; c < a.grp_k[g]; ++c) {
+                const int q = a.grp_base[g] + c;
+                a.slot_ptr[q] = a.grp_ptr[g];
+                a.slot_mult[q] = a.grp_k[g];
+                a.slot_chunk[q] = (int8_t)c;
+                a.src_off[q] = (int8_t)(4 * a.grp_base[g] + c);
+                a.src_stride[q] = a.grp_k[g];
+            }
         const bool allreg = a.reg_filter_mask == (n_filters >= 32 ? ~0u : (1u << n_filters) - 1u) &&
                             (dp_plane < 0 || a.dp_src >= 0) && !getenv("TRK_CF_NOALLREG");
         void (*kfn)(CallArgs) = nullptr;
         // TRK_CF_NOREGVEC=1: the select-chain form also for planar sources (A/B timing)
-        const bool planar = allreg && a.grp_n == 0 && !getenv("TRK_CF_NOREGVEC");
-#define TRK_FAST(NS)                                                                 \
-    kfn = planar ? k_call_filter_fast<NS, true, true>                                \
-                 : allreg ? k_call_filter_fast<NS, true, false> : k_call_filter_fast<NS, false, false>
+        const bool regvec = allreg && !getenv("TRK_CF_NOREGVEC");
+#define TRK_FAST(NS)                                                                                          \
+    kfn = regvec ? (a.grp_n == 0 ? k_call_filter_fast<NS, true, 1> : k_call_filter_fast<NS, true, 2>)         \
+                 : allreg ? k_call_filter_fast<NS, true, 0> : k_call_filter_fast<NS, false, 0>
         if (a.n_src <= 4) { TRK_FAST(4); }
         else if (a.n_src <= 8) { TRK_FAST(8); }
         else if (a.n_src <= 12) { TRK_FAST(12); }
