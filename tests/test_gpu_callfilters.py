@@ -4,6 +4,8 @@ the oracle restatement of dumpSTR.ApplyCallFilters / ApplyLocusFilters
 import collections
 import math
 
+import os
+
 import numpy as np
 import pytest
 
@@ -158,7 +160,12 @@ def run_gangstr_popstr_case(eng, seed, Lc, S, layout, keep=None, thr=None, delta
     dp[nocall & (rng.random((Lc, S)) < 0.8)] = INT_MIN
     b = eng.make_batch(gt, off, lc, sc, cv, locus_ploidy=lp)
     if layout == 'planar':
-        up = eng.upload_plane
+        def up(a):   # Engine.upload_plane with the transposition forced (by default planes of <= 4 columns stay as they are)
+            os.environ['TRK_CF_PLANARIZE'] = '1'
+            try:
+                return eng.upload_plane(a)
+            finally:
+                del os.environ['TRK_CF_PLANARIZE']
     elif layout == 'planarize':
         up = lambda a: eng.planarize(eng.upload(a))
     else:

@@ -464,15 +464,20 @@ class Engine:
         self._chk(self.lib.trk_event_wait(self.ctx, int(slot)))
 
     def upload_plane(self, arr):
-        """Upload a FORMAT plane [L, S] or [L, S, k] (int32 / float32).  Multi-column planes end up planar
-        ([k, L, S], TRK_DT_PLANAR) so that every column streams as 16-byte vectors: uploaded as they are and
-        transposed on the device (a host transpose of a 160 MB plane costs ~0.3 s)."""
+        """Upload a FORMAT plane [L, S] or [L, S, k] (int32 / float32) as it is.  Planes of up to four columns stay
+        interleaved, as cyvcf2 hands them: the call-filter kernel fetches a thread's k 16-byte chunks and picks the
+        columns out of its registers (5.45 against 3.8 ms on the GangSTR nine-filter set at 50k x 5k), which is
+        cheaper than transposing them first (the transposition moves every byte twice: 5.5 ms for the same planes).
+        Wider planes are made planar on the device ([k, L, S], TRK_DT_PLANAR: every column streams as 16-byte
+        vectors; a host transpose of a 160 MB plane costs ~0.3 s).  TRK_CF_PLANARIZE=1 / 0 forces either."""
         arr = np.asarray(arr)
         d = self.upload(np.ascontiguousarray(arr))
-        if arr.ndim == 3 and arr.shape[2] > 1 and os.environ.get('TRK_CF_INTERLEAVED', '0') == '0':
-            p = self.planarize(d)
-            d.free()
-            return p
+        if arr.ndim == 3 and arr.shape[2] > 1:
+            force = os.environ.get('TRK_CF_PLANARIZE')
+            if force == '1' or (force is None and arr.shape[2] > 4):
+                p = self.planarize(d)
+                d.free()
+                return p
         return d
 
     def planarize(self, plane):
