@@ -199,7 +199,7 @@ typedef struct {
     const char* name;
     int32_t kind, reserved;
     const void* plane_a;
-    int32_t dtype_a, ncol_a, col_a, pad_a;
+    int32_t dtype_a, ncol_a, col_a, col_a2;   /* col_a2: the second column of kind 2 */
     const void* plane_b;
     int32_t dtype_b, ncol_b, col_b, pad_b;
 } trk_vcf_cf_value;

@@ -118,6 +118,17 @@ DUMP_CASES = {
                                 gangstr_min_call_Q=0.9, min_locus_callrate=0.6)),
     'synth_gangstr': (os.path.join(SYN, 'synth_gangstr.vcf'),
                       dict(vcftype='gangstr', gangstr_min_call_DP=15, gangstr_min_call_Q=0.92, max_locus_het=0.7)),
+    # every GangSTR call filter (dumpSTR.py:819-836): expansion probabilities (single column and the float32 sum of two),
+    # span-only / span+bound-only on the pre-parsed RC field, the confidence-interval filter on REPCN / REPCI
+    'synth_gangstr_all': (os.path.join(SYN, 'synth_gangstr.vcf'),
+                          dict(vcftype='gangstr', gangstr_min_call_DP=10, gangstr_max_call_DP=60, gangstr_min_call_Q=0.9,
+                               gangstr_expansion_prob_het=0.3, gangstr_expansion_prob_hom=0.3,
+                               gangstr_expansion_prob_total=0.6, gangstr_filter_span_only=True,
+                               gangstr_filter_spanbound_only=True, gangstr_filter_badCI=True, min_locus_callrate=0.3)),
+    'gangstr_all_trio': (os.path.join(DD, 'trio_chr21_gangstr.sorted.vcf.gz'),
+                         dict(vcftype='gangstr', gangstr_expansion_prob_het=0.1, gangstr_expansion_prob_hom=0.1,
+                              gangstr_expansion_prob_total=0.3, gangstr_filter_span_only=True,
+                              gangstr_filter_spanbound_only=True, gangstr_filter_badCI=True, gangstr_min_call_DP=15)),
     'no_call_filters': (os.path.join(SYN, 'synth_hipstr.vcf'), dict(vcftype='hipstr', min_locus_callrate=0.95)),
     'longtr': (os.path.join(DD, 'longtr_testfile.vcf.gz'),
                dict(vcftype='longtr', longtr_min_call_DP=30, longtr_max_call_DP=200, longtr_min_call_Q=0.9,
@@ -128,7 +139,7 @@ DUMP_CASES = {
 # inputs the native pieces decline (records without the mandatory INFO fields, a FORMAT/FILTER field from an earlier
 # dumpSTR round): the batch goes through the record objects -- same outputs, just not through the batch pipeline
 FALLBACK_CASES = {'longtr'}
-BIG_CASES = {'hipstr_thresholds', 'hipstr_ratios_minsupp', 'gangstr_thresholds'}     # trio files: GPU legs only
+BIG_CASES = {'hipstr_thresholds', 'hipstr_ratios_minsupp', 'gangstr_thresholds', 'gangstr_all_trio'}     # trio files: GPU legs only
 
 
 def _run_dump(tmp_path, compute, name):

@@ -1700,9 +1700,39 @@ int64_t trk_vcf_dumpstr_lines(const trk_vcf_batch* b, const trk_vcf_dumpstr* in,
                     const size_t i = ((size_t)l * S + s) * ncol + col;
                     return dtype == 1 ? (double)static_cast<const float*>(plane)[i] : (double)static_cast<const int32_t*>(plane)[i];
                 };
-                for (int s = 0; s < S; ++s) {
-                    const double a = elem(fv.plane_a, fv.dtype_a, fv.ncol_a, fv.col_a, s);
-                    v[(size_t)s] = fv.kind == 1 ? a / elem(fv.plane_b, fv.dtype_b, fv.ncol_b, fv.col_b, s) : a;
+                if (fv.kind == 2) {
+                    // sum of two columns of one plane: GangSTR's QEXP[1] + QEXP[2] (a float32 sum, as numpy adds two
+                    // float32 arrays) and RC[1] + RC[3] (integers)
+                    for (int s = 0; s < S; ++s) {
+                        const size_t i = ((size_t)l * S + s) * fv.ncol_a;
+                        if (fv.dtype_a == 1) {
+                            const float* pa = static_cast<const float*>(fv.plane_a) + i;
+                            const volatile float f = pa[fv.col_a] + pa[fv.col_a2];
+                            v[(size_t)s] = (double)f;
+                        } else {
+                            const int32_t* pa = static_cast<const int32_t*>(fv.plane_a) + i;
+                            v[(size_t)s] = (double)((int64_t)pa[fv.col_a] + (int64_t)pa[fv.col_a2]);
+                        }
+                    }
+                } else if (fv.kind == 3) {
+                    // GangSTR's bad confidence interval: the maximum-likelihood copy number (plane a, one column per
+                    // haplotype) of the FIRST haplotype whose interval (plane b: lo, hi per haplotype) excludes it
+                    for (int s = 0; s < S; ++s) {
+                        const int32_t* ml = static_cast<const int32_t*>(fv.plane_a) + ((size_t)l * S + s) * fv.ncol_a;
+                        const int32_t* ci = static_cast<const int32_t*>(fv.plane_b) + ((size_t)l * S + s) * fv.ncol_b;
+                        double x = NAN;
+                        for (int j = 0; j < fv.ncol_a && 2 * j + 1 < fv.ncol_b; ++j)
+                            if (ml[j] < ci[2 * j] || ci[2 * j + 1] < ml[j]) {
+                                x = (double)ml[j];
+                                break;
+                            }
+                        v[(size_t)s] = x;
+                    }
+                } else {
+                    for (int s = 0; s < S; ++s) {
+                        const double a = elem(fv.plane_a, fv.dtype_a, fv.ncol_a, fv.col_a, s);
+                        v[(size_t)s] = fv.kind == 1 ? a / elem(fv.plane_b, fv.dtype_b, fv.ncol_b, fv.col_b, s) : a;
+                    }
                 }
                 vptr[(size_t)k] = v.data();
             }

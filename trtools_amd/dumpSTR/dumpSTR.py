@@ -426,7 +426,9 @@ class _Run:
             self.parts.append((self.batch_no, ''.join(self._cur).encode()))
 
     # ---- the batch pipeline: no Python object per record -------------------------------------------------------
-    _SIMPLE_VALUES = (filters.CallFilterMinValue, filters._HipSTRRatio, filters.HipSTRCallMinSuppReads)
+    _SIMPLE_VALUES = (filters.CallFilterMinValue, filters._HipSTRRatio, filters.HipSTRCallMinSuppReads,
+                      filters._GangSTRQexp, filters.GangSTRCallSpanOnly, filters.GangSTRCallSpanBoundOnly,
+                      filters.GangSTRCallBadCI)
 
     def batch_path_ok(self, vcftype):
         """The batch pipeline (native reader -> native batch harmoniser -> device -> native record writer) covers
@@ -480,6 +482,17 @@ class _Run:
         for f in self.call_filters:
             if isinstance(f, filters._HipSTRRatio):
                 cfv.append((f.name, 1, (rb.planes[f.numerator], 0), (rb.planes['DP'], 0)))
+            elif isinstance(f, filters._GangSTRQexp):
+                if len(f.cols) == 1:
+                    cfv.append((f.name, 0, (rb.planes['QEXP'], f.cols[0]), None))
+                else:
+                    cfv.append((f.name, 2, (rb.planes['QEXP'], f.cols[0], f.cols[1]), None))
+            elif isinstance(f, filters.GangSTRCallSpanOnly):
+                cfv.append((f.name, 0, (rb.planes['__rc'], 1), None))
+            elif isinstance(f, filters.GangSTRCallSpanBoundOnly):
+                cfv.append((f.name, 2, (rb.planes['__rc'], 1, 3), None))
+            elif isinstance(f, filters.GangSTRCallBadCI):
+                cfv.append((f.name, 3, (rb.planes['REPCN'], 0), (rb.planes['__repci'], 0)))
             else:
                 key = f.planes()[0][0]
                 cfv.append((f.name, 0, (rb.planes[key], 0), None))

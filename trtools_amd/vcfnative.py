@@ -85,7 +85,7 @@ class HarmonizedBatch:
 
 class _CfValue(C.Structure):
     _fields_ = [('name', C.c_char_p), ('kind', C.c_int32), ('reserved', C.c_int32), ('plane_a', C.c_void_p),
-                ('dtype_a', C.c_int32), ('ncol_a', C.c_int32), ('col_a', C.c_int32), ('pad_a', C.c_int32),
+                ('dtype_a', C.c_int32), ('ncol_a', C.c_int32), ('col_a', C.c_int32), ('col_a2', C.c_int32),
                 ('plane_b', C.c_void_p), ('dtype_b', C.c_int32), ('ncol_b', C.c_int32), ('col_b', C.c_int32),
                 ('pad_b', C.c_int32)]
 
@@ -163,11 +163,14 @@ class RawBatch:
         keep = [gt, ph, lp, mask]
         fv = (_CfValue * max(len(cf_values), 1))()
         for k, (name, kind, a, bsrc) in enumerate(cf_values):
+            # kind 0: plane a, column a[1]; 1: a / b; 2: columns a[1] + a[2] of plane a; 3: GangSTR bad CI (a = REPCN,
+            # b = the pre-parsed REPCI)
             pa = np.ascontiguousarray(a[0])
             keep.append(pa)
             fv[k].name, fv[k].kind = name.encode(), int(kind)
             fv[k].plane_a, fv[k].dtype_a = pa.ctypes.data, 1 if pa.dtype == np.float32 else 0
             fv[k].ncol_a, fv[k].col_a = (pa.shape[2] if pa.ndim == 3 else 1), int(a[1])
+            fv[k].col_a2 = int(a[2]) if len(a) > 2 else 0
             if bsrc is not None:
                 pb = np.ascontiguousarray(bsrc[0])
                 keep.append(pb)
