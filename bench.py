@@ -808,6 +808,37 @@ def end_to_end_extra(eng, seed):
             "workload": "dumpSTR (min/max call DP, min call Q; call rate, HWE, het low/high) on the same file, to an "
                         "output VCF of %.0f MB + sample and locus logs" % (os.path.getsize(os.path.join(tmp, 'dump.vcf')) / 1e6),
             "seconds": best, "loci_per_s": Lc / best, "calls_per_s": Lc * S / best}
+        # BASELINE configs[2] through text at reduced scale: a GangSTR-shape file (GT:DP:Q:REPCN:REPCI:RC:QEXP), the
+        # nine GangSTR call filters + four locus filters, output VCF + logs
+        Lg, Sg = 400, 2000
+        gpath = os.path.join(tmp, 'gangstr.vcf')
+        gl = synth.make_loci(Lg, Sg, seed=7, pure_repeats=True)
+        gidx = np.arange(Lg)
+        grows = synth.cells_numpy(7, gl, gidx, Sg)
+        synth.render_vcf(gpath, gl, grows, caller='gangstr',
+                         extra=synth.gangstr_planes_numpy(7, gl, gidx, Sg, grows['gt'], grows['dp'], 0))
+        sys.argv = ['dumpSTR', '--vcf', gpath, '--out', os.path.join(tmp, 'gdump'), '--vcftype', 'gangstr',
+                    '--gangstr-min-call-DP', '10', '--gangstr-max-call-DP', '60', '--gangstr-min-call-Q', '0.9',
+                    '--gangstr-expansion-prob-het', '0.05', '--gangstr-expansion-prob-hom', '0.05',
+                    '--gangstr-expansion-prob-total', '0.2', '--gangstr-filter-span-only',
+                    '--gangstr-filter-spanbound-only', '--gangstr-filter-badCI', '--min-locus-callrate', '0.8',
+                    '--min-locus-hwep', '0.001', '--min-locus-het', '0.05', '--max-locus-het', '0.9']
+        try:
+            gargs = dumpSTR.getargs()
+        finally:
+            sys.argv = argv
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rc = dumpSTR.main(gargs)
+            el = time.perf_counter() - t0
+            assert rc == 0
+            best = el if best is None else min(best, el)
+        out["dumpstr_cli_gangstr_nine_filters"] = {
+            "workload": "dumpSTR with the nine GangSTR call filters + four locus filters (BASELINE configs[2] at reduced "
+                        "scale) on a GangSTR-shape text VCF, %d loci x %d samples (%.0f MB), to an output VCF + logs"
+                        % (Lg, Sg, os.path.getsize(gpath) / 1e6),
+            "seconds": best, "loci_per_s": Lg / best, "calls_per_s": Lg * Sg / best}
         for f in os.listdir(tmp):
             os.remove(os.path.join(tmp, f))
         os.rmdir(tmp)
