@@ -189,7 +189,11 @@ int64_t trk_vcf_statstr_rows(const trk_vcf_batch* b, const trk_vcf_harmonized* h
  *   gt, phased, locus_ploidy  the batch's genotype tensor [n, S, ploidy], phase bytes [n, S], per-record ploidy
  *   filters[k]         name of call filter k and where the number behind '<name>_<value>' comes from: kind 0 the value
  *                      of column col_a of plane_a ([n, S, ncol_a], dtype 0 int32 / 1 float32) as a double, kind 1 that
- *                      value divided by plane_b's (HipSTR flank-indel / stutter ratios, filters.py:444-449)
+ *                      value divided by plane_b's (HipSTR flank-indel / stutter ratios, filters.py:444-449), kind 2
+ *                      columns col_a + col_a2 of plane_a (GangSTR QEXP[1] + QEXP[2] as a float32 sum, filters.py:668-
+ *                      672; RC[1] + RC[3], filters.py:717-721), kind 3 GangSTR's bad confidence interval: plane_a the
+ *                      REPCN columns, plane_b the pre-parsed REPCI (lo, hi per haplotype), the value is REPCN of the
+ *                      first haplotype whose interval excludes it (filters.py:744-756)
  *   format_keys/kinds  the header's FORMAT IDs and how each is decoded (TRK_VCF_COL_INT / _FLOAT / _UCS4); IDs not
  *                      listed decode as strings
  * Returns the bytes written; -(bytes needed) when cap is too small; INT64_MIN for bad arguments; INT64_MIN + 1 when
