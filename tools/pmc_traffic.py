@@ -48,7 +48,11 @@ def main():
     res["k_locus_count"] = entry(bench, 'k_locus_count_v2<', 4.0e9)
     res["k_assoc_scan"] = entry(bench, 'k_assoc_scan_few<1, false>', 4.0e9) or entry(bench, 'k_assoc_scan<1, false>', 4.0e9)
     res["config1_k_locus_count"] = entry(configs, 'k_locus_count_v3<4', 4.0e7)
-    res["config2_k_call_filter_fast"] = entry(configs, 'k_call_filter_fast<12, true, true>', 50000 * 5000 * 60.0) or entry(configs, 'k_call_filter_fast<12, true>', 50000 * 5000 * 60.0)
+    res["config2_k_call_filter_fast"] = (entry(configs, 'k_call_filter_fast<12, true, 1>', 50000 * 5000 * 60.0) or
+                                         entry(configs, 'k_call_filter_fast<12, true, true>', 50000 * 5000 * 60.0) or
+                                         entry(configs, 'k_call_filter_fast<12, true>', 50000 * 5000 * 60.0))
+    # the same filters on planes left interleaved (as cyvcf2 hands them): every column of a plane is fetched
+    res["config2_interleaved_k_call_filter_fast"] = entry(configs, 'k_call_filter_fast<16, true, 2>', 50000 * 5000 * 72.0)
     if res["k_call_filter"]:
         res["k_call_filter_bytes_per_launch"] = res["k_call_filter"]["bytes_per_launch"]
     print(json.dumps(res, indent=1))
