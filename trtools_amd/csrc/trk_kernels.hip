@@ -1808,12 +1808,16 @@ struct CfRegs {
         if (NS <= 8 || e < NLO) return lo[e];
         return hi[e - NLO];
     }
-    // the four values of logical source `idx` (uniform across the wave)
+    // The four values of logical source `idx`.  idx is the same in every lane, but where it comes out of a byte
+    // table of the kernel arguments the compiler fetches it with a vector load and then wraps every indexed move in
+    // a loop over the distinct values of the lanes -- readfirstlane tells it there is one.
     // GEN: interleaved planes among the sources (element offset and stride from the tables); else every source is
     // planar and sits in elements 4 idx .. 4 idx + 3
-    __device__ __forceinline__ void get(const CallArgs& a, int idx, uint32_t (&v)[CF_V]) const {
+    __device__ __forceinline__ void get(const CallArgs& a, int idx_, uint32_t (&v)[CF_V]) const {
+        const int idx = __builtin_amdgcn_readfirstlane(idx_);
         if constexpr (GEN) {
-            const int off = a.src_off[idx], st = a.src_stride[idx];
+            const int off = __builtin_amdgcn_readfirstlane((int)a.src_off[idx]);
+            const int st = __builtin_amdgcn_readfirstlane((int)a.src_stride[idx]);
 #pragma unroll
             for (int j = 0; j < CF_V; ++j) v[j] = elem(off + j * st);
         } else if (NS <= 8 || idx < 8) {
