@@ -575,6 +575,12 @@ __device__ __forceinline__ uint64_t halves_equal(uint32_t t) {
     asm("v_cmp_eq_u16_sdwa %0, %1, %1 src0_sel:WORD_0 src1_sel:WORD_1" : "=s"(m) : "v"(t));
     return m;
 }
+// x += (this lane's bit of the wave-wide mask): the mask goes in as the carry of an add-with-carry (one instruction;
+// written as a select and an add the compiler emits two)
+__device__ __forceinline__ void add_mask(uint32_t& x, uint64_t mask) {
+    asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(x) : "s"(mask) : "vcc");
+}
+
 struct CountAcc {   // wave-uniform counters of one locus
     uint32_t n_eq = 0, c00 = 0, c10 = 0, c01 = 0, c11 = 0, n_hl = 0, n_hs = 0;
 };
@@ -756,21 +762,27 @@ __device__ __forceinline__ int seg_max(int v) {
     return v;
 }
 
+// hcol_b: LDS byte address of this lane's histogram column (bins are 128 bytes apart), lut_b: of the locus's class LUT.
+// Addresses straight from the packed bins (v_mad_u32_u16); per-lane counters (a wave holds R loci: no wave-wide counts).
 template <bool DUP>
-__device__ __forceinline__ void v3_cell(uint32_t w, uint32_t amax2, uint32_t* hcol, const uint32_t* lut,
-                                        int combo_bin0, int& n_eq, int& n_hl, int& n_hs) {
+__device__ __forceinline__ void v3_cell(uint32_t w, uint32_t amax2, uint32_t hcol_b, uint32_t lut_b, uint32_t c128,
+                                        uint32_t c4, uint32_t combo_b, uint32_t& n_eq, uint32_t& n_hl,
+                                        uint32_t& n_hs) {
     u16x2 u = __builtin_bit_cast(u16x2, w) + (u16x2){2, 2};
     u16x2 t2 = __builtin_elementwise_min(u, __builtin_bit_cast(u16x2, amax2));
     const uint32_t t = __builtin_bit_cast(uint32_t, t2);
-    const uint32_t lo = t & 0xffffu, hi = t >> 16;
-    atomicAdd(&hcol[lo << 5], 1u);
-    atomicAdd(&hcol[hi << 5], 1u);
-    n_eq += lo == hi;
-    if ((t & 0xfffefffeu) == 0u) atomicAdd(&hcol[(combo_bin0 + (int)(lo + 2u * hi)) << 5], 1u);
+    __hip_atomic_fetch_add((lds_u32p)(uintptr_t)mad16_lo(t, c128, hcol_b), 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add((lds_u32p)(uintptr_t)mad16_hi(t, c128, hcol_b), 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+    add_mask(n_eq, halves_equal(t));
+    if ((t & 0xfffefffeu) == 0u)   // both haplotypes sentinels: bin A + 3 + lo + 2 hi
+        __hip_atomic_fetch_add((lds_u32p)(uintptr_t)(combo_b + (((t | (t >> 15)) & 3u) << 7)), 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
     if (DUP) {
-        const uint32_t x = lut[lo] ^ lut[hi];
-        n_hl += (x & 0xffffu) == 0u;
-        n_hs += (x >> 16) == 0u;
+        const uint32_t x = *(lds_cu32p)(uintptr_t)mad16_lo(t, c4, lut_b) ^ *(lds_cu32p)(uintptr_t)mad16_hi(t, c4, lut_b);
+        add_mask(n_hl, __ballot((x & 0xffffu) == 0u));
+        add_mask(n_hs, __ballot(x < 0x10000u));
     }
 }
 
@@ -818,28 +830,37 @@ __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v3(
     ms = seg_max<LPL>(ms);
     const bool dup = (ml + 1 < A) | (ms + 1 < A);
     const bool any_dup = __ballot(dup) != 0ull;
-    for (int i = lane; i < 2 * nbmax * 32; i += WAVE) wbase[i] = 0;
+    {   // (2 * nbmax * 32 words: a multiple of four, 16-byte aligned)
+        const u32x4 z4 = {0u, 0u, 0u, 0u};
+        for (int i = lane; i < 2 * nbmax * 8; i += WAVE) reinterpret_cast<u32x4*>(wbase)[i] = z4;
+    }
     wave_lds_fence();
 
-    int n_eq = 0, n_hl = 0, n_hs = 0;
+    uint32_t n_eq = 0, n_hl = 0, n_hs = 0;
     const uint32_t amax2 = (uint32_t)(A + 2) * 0x00010001u;
+    const uint32_t hcol_b = (uint32_t)(uintptr_t)(lds_u32p)hcol, lut_b = (uint32_t)(uintptr_t)(lds_u32p)lut;
+    const uint32_t c128 = 128u, c4 = 4u, combo_b = hcol_b + ((uint32_t)(A + 3) << 7);
     // (every locus of the batch has S samples: the loop count is uniform over the wave; a wave's dead tail loci
     // -- nchunks == 0 -- only skip the consumer)
     if (any_dup)
         row_stream<LPL, U>(row, S >> 2, sl, cur, [&](uint32_t w) {
-            if (nchunks) v3_cell<true>(w, amax2, hcol, lut, A + 3, n_eq, n_hl, n_hs);
+            if (nchunks) v3_cell<true>(w, amax2, hcol_b, lut_b, c128, c4, combo_b, n_eq, n_hl, n_hs);
         });
     else
         row_stream<LPL, U>(row, S >> 2, sl, cur, [&](uint32_t w) {
-            if (nchunks) v3_cell<false>(w, amax2, hcol, lut, A + 3, n_eq, n_hl, n_hs);
+            if (nchunks) v3_cell<false>(w, amax2, hcol_b, lut_b, c128, c4, combo_b, n_eq, n_hl, n_hs);
         });
     wave_lds_fence();
     // fold this locus's KC columns of every bin (rotated start: conflict-free); the total is parked in the locus's
     // first column of the row (only this lane touches the bin's half row)
     for (int bin = sl; bin < nbins; bin += LPL) {
         uint32_t s = 0;
-#pragma unroll 8
-        for (int k = 0; k < KC; ++k) s += hrow[(bin << 5) + cbase + ((k + sl) & (KC - 1))];
+        const u32x4* hp = reinterpret_cast<const u32x4*>(hrow + (bin << 5) + cbase);
+#pragma unroll
+        for (int k = 0; k < KC / 4; ++k) {    // 16-byte reads, the start rotated by lane (fewer lanes on one bank group)
+            const u32x4 h = hp[(k + sl) & (KC / 4 - 1)];
+            s += (h.x + h.y) + (h.z + h.w);
+        }
         if (live && bin >= 2 && bin < A + 2) {
             allele_count[off + bin - 2] = (int32_t)s;
             if (twin_ac) allele_count[twin_ac + off + bin - 2] = (int32_t)s;
@@ -847,10 +868,10 @@ __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v3(
         hrow[(bin << 5) + cbase] = s;
     }
     wave_lds_fence();
-    n_eq = seg_sum<LPL>(n_eq);
+    n_eq = (uint32_t)seg_sum<LPL>((int)n_eq);
     if (any_dup) {
-        n_hl = seg_sum<LPL>(n_hl);
-        n_hs = seg_sum<LPL>(n_hs);
+        n_hl = (uint32_t)seg_sum<LPL>((int)n_hl);
+        n_hs = (uint32_t)seg_sum<LPL>((int)n_hs);
     }
     if (sl == 0 && live) {
         const uint32_t* h = hrow + cbase;
@@ -860,9 +881,10 @@ __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v3(
         const int c10 = (int)h[(A + 4) << 5];  // lo = -1, hi = -2
         const int c01 = (int)h[(A + 5) << 5];  // lo = -2, hi = -1
         const int c11 = (int)h[(A + 6) << 5];  // (-1,-1)
-        const int hom_idx = n_eq - c11 - c00;
+        const int hom_idx = (int)n_eq - c11 - c00;
         const u32x4 r0 = {(uint32_t)(S - (h_m1 - c11)), (uint32_t)(h_m2 - c00 - c10 - c01),
-                          (uint32_t)(dup ? n_hl - c11 - c00 : hom_idx), (uint32_t)(dup ? n_hs - c11 - c00 : hom_idx)};
+                          (uint32_t)(dup ? (int)n_hl - c11 - c00 : hom_idx),
+                          (uint32_t)(dup ? (int)n_hs - c11 - c00 : hom_idx)};
         const u32x4 r1 = {0u, (uint32_t)n_bad, 0u, 0u};
         const u32x4 r2 = {(uint32_t)(S - b.n_pad_samples), 0u, 0u, 0u};
         for (int64_t tw = 0;; tw = twin_li) {   // the whole 48-byte row, as in k_locus_count_v2
@@ -1781,12 +1803,6 @@ __device__ __forceinline__ void cf_delta_call(const CfDelta& c, uint32_t w, int 
         if (hl) atomicAdd(&x[DX_HOML], 1);
         if (hs) atomicAdd(&x[DX_HOMS], 1);
     }
-}
-
-// x += (this lane's bit of the wave-wide mask): the mask goes in as the carry of an add-with-carry (one instruction;
-// written as a select and an add the compiler emits two)
-__device__ __forceinline__ void add_mask(uint32_t& x, uint64_t mask) {
-    asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(x) : "s"(mask) : "vcc");
 }
 
 // ---- every operand in registers (ALLREG): sources as four vectors, decisions as lane masks -------------------------
@@ -2991,7 +3007,9 @@ hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* alle
             dim3 grid(wgs_fast), block(WAVE * COUNT_WAVES_PER_WG);
             // short rows: R loci per wave (k_locus_count_v3) while the wider per-wave histogram still lets >= 2
             // workgroups share a CU.  TRK_CNT_R = 1 / 2 / 4 overrides the row-length rule (tools/perf_sweep.py).
-            int rr = b.n_samples <= 4096 ? 4 : 1;   // (bench data, 10k-sample rows: R = 1 0.69 ms, R = 2 0.77, R = 4 0.76)
+            // four loci per wave for rows of up to 2048 samples (400k x 1k: R = 4 0.38 ms, R = 1 0.46; 200k x 2k: 0.37 / 0.37;
+            // 100k x 4k: 0.37 / 0.29; 100k x 10k: 0.76 / 0.62)
+            int rr = b.n_samples <= 2048 ? 4 : 1;
             if (const char* e = getenv("TRK_CNT_R")) rr = atoi(e);
             const int nbmax = max_alleles + 7;
             const int words3 = (2 * nbmax * 32 + 4 * nbmax + 3) & ~3;
