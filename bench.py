@@ -31,7 +31,7 @@ One step =
             owns the loci (rank order == locus order).
 Queues: the two HBM-bound stream kernels (k_locus_count, k_call_filter) run on the context's queue 0; the
 latency-bound rest beside the call-filter kernel on queues 1 and 2 -- dumpSTR's tail of the PREVIOUS step
-(finaliser, locus filters, the RCCL exchange; its outputs are double buffered) on queue 1, statSTR's finaliser of
+(finaliser, locus filters, the RCCL exchange; its outputs are double -- for N > 1 triple -- buffered) on queue 1, statSTR's finaliser of
 the step on queue 2 (Workload.step / flush).  All work of the K steps ends inside the timed region (flush + trk_sync).
 torch is imported only for N > 1 (rendezvous, barrier, max-over-ranks), never for compute.
 
@@ -101,7 +101,7 @@ class Workload:
     """Device-resident buffers of one rank's shard + one step of the hot path."""
 
     def __init__(self, eng, seed, n_samples, loci, locus_base, world, use_comm, overlap=True, gather_loci=None,
-                 pipeline_count=False):
+                 pipeline_count=False, n_sets=None, ev_base=0):
         from trtools_amd.synth import SynthBatch
         from trtools_amd import _lib as L
         from trtools_amd.engine import CallResult
@@ -116,10 +116,17 @@ class Workload:
         self.locus_args = dict(LOCUS_ARGS)
         b = self.sb.batch
         # statSTR rows and, as the twin copy of the same count pass (TRK_STATS_TWIN), the counts dumpSTR's call
-        # filters correct in place; double buffered for the tail that runs one step behind
-        self.stats_a = [eng.alloc_stats(b, twin=True) for _ in range(2)]
+        # filters correct in place; one per buffer set (the tail runs one step behind)
+        # Buffer sets of what a step hands on (small per-locus / per-sample arrays).  Two when the count pass runs in
+        # order before the call filters; THREE when it is pipelined beside the previous step's call filters: with
+        # two, count(n + 1) must wait for tail(n - 1) -- which runs beside call_filters(n) and, slowed by it, takes
+        # as long -- so it started only when call_filters(n) ended (kernel timeline of the 12.5k-locus shard,
+        # tools/timeline_probe.py: 125-148 us between two call-filter kernels, now the reduction kernel's ~20)
+        self.NB = NB = int(n_sets or os.environ.get('TRK_BENCH_NSETS') or (3 if pipeline_count else 2))
+        self.EV_COUNT, self.EV_CF, self.EV_TAIL, self.EV_FINA = (ev_base + k * NB for k in range(4))
+        self.stats_a = [eng.alloc_stats(b, twin=True) for _ in range(NB)]
         self.stats_b = [(st.twin if getattr(st, 'twin', None) else eng.alloc_stats(b)) for st in self.stats_a]
-        # everything a step hands to the next stage is double buffered (the tail of step n runs beside the head of
+        # everything a step hands to the next stage exists once per buffer set (the tail of step n runs beside the head of
         # step n + 1); the masked genotypes and the mask are written and consumed on queue 0 only: one copy.
         # Everything that is summed over the ranks lives back to back in ONE int64 buffer per step slot
         # (sample_info rows, totaldp, dp-missing, loc_info): one memset, one all-reduce.
@@ -128,7 +135,7 @@ class Workload:
         self.sums_, self.call_outs, self.loc_counters_ = [], [], []
         gt_out = eng.empty((self.n_loci, S, 2), np.int16)
         mask = eng.empty((self.n_loci, S), np.uint32)
-        for _ in range(2):
+        for _ in range(NB):
             sums = eng.zeros(((1 + nf) * S2 + 2 * S2 + L.TRK_LC_COLS,), np.int64)
             sc = sums.view(0, (1 + nf, S), np.int64) if S2 == S else None
             if sc is None:
@@ -142,7 +149,7 @@ class Workload:
                                              eng.zeros((S,), np.float64)))
         # the all-gather moves equal-sized rows: the largest shard's size (shards differ by at most one locus)
         gl = max(self.n_loci, gather_loci or 0)
-        self.bits_ = [eng.zeros((gl,), np.uint32) for _ in range(2)]
+        self.bits_ = [eng.zeros((gl,), np.uint32) for _ in range(NB)]
         self.gather = eng.empty((world, gl), np.uint32) if use_comm else None
         self.step_no = 0
         self._pending = None
@@ -150,12 +157,11 @@ class Workload:
         self.pipeline_count = pipeline_count
 
     # the buffers of the last completed step
-    call_out = property(lambda self: self.call_outs[(self.step_no - 1) & 1])
-    bits = property(lambda self: self.bits_[(self.step_no - 1) & 1])
-    loc_counters = property(lambda self: self.loc_counters_[(self.step_no - 1) & 1])
-
-    # ordering points (trk_event_*), one per buffer set i = step & 1
-    EV_COUNT, EV_CF, EV_TAIL, EV_FINA = 0, 2, 4, 6
+    last = property(lambda self: (self.step_no - 1) % self.NB)     # buffer set of the last completed step
+    call_out = property(lambda self: self.call_outs[self.last])
+    bits = property(lambda self: self.bits_[self.last])
+    loc_counters = property(lambda self: self.loc_counters_[self.last])
+    # ordering points (trk_event_*): EV_COUNT / EV_CF / EV_TAIL / EV_FINA + i, one per buffer set i = step mod NB
 
     def step(self):
         """One statSTR + dumpSTR pass over the shard.
@@ -165,18 +171,18 @@ class Workload:
         queue 3  the count pass of this step when ``pipeline_count`` (N > 1 shards: the count of step n runs beside
                  the end of the call filters of step n - 1 -- it does not depend on them -- so that the ramp and the
                  tail of the two short stream kernels overlap); otherwise queue 0, in order before the call filters
-        Every output a step hands on is double buffered; a queue that recycles a buffer set waits for the marks its
-        consumers recorded two steps ago (long past), never for work enqueued in this step, so queue 0 runs its
+        Every output a step hands on exists NB times; a queue that recycles a buffer set waits for the marks its
+        consumers recorded NB steps ago (long past), never for work enqueued in this step, so queue 0 runs its
         stream kernels back to back.  TRK_BENCH_OVERLAP=0 puts everything on queue 0, in step order."""
         eng = self.eng
-        i = self.step_no & 1
+        i = self.step_no % self.NB
         self.step_no += 1
         b = self.sb.batch
         out = self.call_outs[i]
         q1, q2, qc = (1, 2, 3 if self.pipeline_count else 0) if self.overlap else (0, 0, 0)
         with eng.on_queue(qc):
-            eng.event_wait(self.EV_TAIL + i)       # tail(n - 2) has consumed sums / stats_b of this buffer set
-            eng.event_wait(self.EV_FINA + i)       # fin_a(n - 2) has consumed stats_a of this buffer set
+            eng.event_wait(self.EV_TAIL + i)       # tail(n - NB) has consumed sums / stats_b of this buffer set
+            eng.event_wait(self.EV_FINA + i)       # fin_a(n - NB) has consumed stats_a of this buffer set
             self.sums_[i].zero()                   # counters are per step (each step is a complete run)
             eng.locus_stats(b, out=self.stats_a[i], count_only=True)                # statSTR: count (+ twin copy)
             if not getattr(self.stats_a[i], 'twin', None):
@@ -259,7 +265,7 @@ def exhaustive_check(wl, single_rank_sums):
     output is read back block by block and is the input of both sides."""
     from oracle import fullsize
     L = wl.L
-    i = (wl.step_no - 1) & 1
+    i = wl.last
     dev = dict(cnt_a=wl.stats_a[i].allele_count.get()[0], li_a=wl.stats_a[i].locus_int.get()[0],
                lf_a=wl.stats_a[i].locus_f64.get()[0], cnt_b=wl.stats_b[i].allele_count.get()[0],
                li_b=wl.stats_b[i].locus_int.get()[0], lf_b=wl.stats_b[i].locus_f64.get()[0],
@@ -487,7 +493,7 @@ def compact_outputs_extra(wl, iters=8):
     (SURVEY.md 8d prices the path at 20 B per call), reported beside it."""
     eng = wl.eng
     b = wl.sb.batch
-    i = (wl.step_no - 1) & 1
+    i = wl.last
     ref_mask = wl.call_out.filter_mask.get_rows(0, 2048)
     ref_counters = wl.call_out.sample_counters.get()
     out = eng.alloc_call_out(b, len(wl.filters), want_gt=False, want_mask=False, want_mask8=True)

@@ -309,7 +309,7 @@ def test_config3_combined_100k_x_10k_two_queue_pipeline(eng):
         wl.step()
     wl.flush()
     eng.sync()
-    i = (wl.step_no - 1) & 1
+    i = wl.last
     assert np.array_equal(wl.bits.get(), want['bits'])
     assert np.array_equal(wl.loc_counters.get(), want['loc'])
     assert np.array_equal(wl.call_out.sample_counters.get(), want['cnt'])
@@ -347,7 +347,7 @@ def test_config3_locus_shards_add_up_to_the_cohort(eng):
             wl.step()
         wl.flush()
         eng.sync()
-        i = (wl.step_no - 1) & 1
+        i = wl.last
         out = dict(bits=wl.bits.get()[:hi - lo], gathered=wl.gather.get()[0][:hi - lo], loc=wl.loc_counters.get(),
                    cnt=wl.call_out.sample_counters.get(), td=wl.call_out.sample_totaldp.get(),
                    li_a=wl.stats_a[i].locus_int.get()[0], lf_a=wl.stats_a[i].locus_f64.get()[0],

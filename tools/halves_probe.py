@@ -28,9 +28,8 @@ if os.environ.get('MODE', 'halves') == 'halves':
     per = 100000 // parts
     wls = []
     for h in range(parts):
-        w = bench.Workload(eng, 20260931, 10000, loci.slice(h * per, (h + 1) * per), h * per, 1, use_comm=False, pipeline_count=True)
-        base = 8 * (h & 1)
-        w.EV_COUNT, w.EV_CF, w.EV_TAIL, w.EV_FINA = base, base + 2, base + 4, base + 6
+        w = bench.Workload(eng, 20260931, 10000, loci.slice(h * per, (h + 1) * per), h * per, 1, use_comm=False,
+                           pipeline_count=True, n_sets=2, ev_base=8 * (h & 1))
         wls.append(w)
     dt, p = timed(wls)
     print("%d parts alternating: %.3f ms per 100k loci  %s" % (parts, dt * 1e3, p))
