@@ -171,15 +171,23 @@ def WriteLocLog(loc_info, fname):
 def WriteSampLog(sample_info, sample_names, fname):
     header = ["sample"] + list(sample_info.keys())
     header[header.index('totaldp')] = 'meanDP'
+    # (columns as Python lists first: str() of a Python int / float prints what str() of the numpy scalar prints, at a
+    # fifth of the cost -- 5000 samples x 6 columns were 12 ms of a 0.22 s run)
+    def plain(col):
+        a = np.asarray(col)
+        # (only 64-bit columns print alike as Python numbers; anything else keeps its numpy scalars)
+        return a.tolist() if a.dtype in (np.int64, np.float64) else list(a)
+    numcalls_l = plain(sample_info["numcalls"])
+    totaldp_l = plain(sample_info["totaldp"])
+    rest = [plain(c) for c in itertools.islice(sample_info.values(), 2, None)]
+    lines = ["\t".join(header)]
+    for i, s in enumerate(sample_names):
+        numcalls = numcalls_l[i]
+        cols = [s, str(numcalls), str(totaldp_l[i] * 1.0 / numcalls) if numcalls > 0 else "0"]
+        cols.extend(str(c[i]) for c in rest)
+        lines.append("\t".join(cols))
     with open(fname, "w") as f:
-        f.write("\t".join(header) + "\n")
-        for i, s in enumerate(sample_names):
-            numcalls = sample_info["numcalls"][i]
-            cols = [s, str(numcalls)]
-            cols.append(str(sample_info["totaldp"][i] * 1.0 / numcalls) if numcalls > 0 else "0")
-            for counts in itertools.islice(sample_info.values(), 2, None):
-                cols.append(str(counts[i]))
-            f.write("\t".join(cols) + "\n")
+        f.write("\n".join(lines) + "\n")
 
 
 def GetAllCallFilters(call_filters):
