@@ -344,3 +344,45 @@ def test_random_text_native_decode_equals_python_decode(seed, S, n_rec):
         for k in b:
             assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape, (k, a[k].dtype, b[k].dtype, a[k].shape, b[k].shape)
             assert np.array_equal(a[k], b[k], equal_nan=(a[k].dtype.kind == 'f')), k
+
+
+def test_rewrite_info_equals_parse_assign_format():
+    from helpers import GOLDEN
+    """vcfio.rewrite_info (the dumpSTR batch path's INFO column: tokens that already read the way they would be
+    written back pass through untouched) against the general path -- parse into typed values, assign, re-serialise --
+    on every record of the fixture files and on strings that must NOT take the shortcut."""
+    import glob
+    from trtools_amd import vcfio, vcfnative
+    files = glob.glob(os.path.join(GOLDEN, 'data', 'dumpSTR', '*.vcf.gz')) + \
+        glob.glob(os.path.join(GOLDEN, 'dumpstr_synth', '*.vcf')) + [os.path.join(GOLDEN, 'data', 'many_samples.vcf.gz')]
+    upd = [('HRUN', 3), ('HET', 0.123456789), ('HWEP', 1e-12), ('AC', "1,2"), ('REFAC', 5)]
+    n = 0
+    for p in files:
+        r = vcfnative.NativeVCFReader(p)
+        while True:
+            rb = r.read_raw_batch(500)
+            if rb.n == 0:
+                break
+            for l in range(0, rb.n, 3):
+                f = rb.head_fields(l)
+                if len(f) >= 8:
+                    assert vcfio.rewrite_info(r, f[7], upd) == vcfio._rewrite_info_general(r, f[7], upd), (p, f[7])
+                    n += 1
+        r.close()
+    assert n > 5000
+
+    class Hdr:
+        info_types = {'A': ('Integer', '1'), 'F': ('Float', '1'), 'G': ('Flag', '0'), 'S': ('String', '1'),
+                      'HET': ('Float', '1'), 'AC': ('Integer', 'A')}
+        _parse_info = vcfio.VCFReader._parse_info
+    h = Hdr()
+    for t in ['.', '', 'A=1', 'A=007', 'A=+5', 'A=-5', 'A=-05', 'A=1,2,.', 'A=.', 'F=0.123456789;A=3', 'G', 'G=1',
+              'S=x;S=y', 'X;Y=2;A=0', 'HET=0.5;A=1;AC=3,4', 'A=1;;S=q', 'A=-0', 'A=1e3', 'A=', 'S=', 'A=1,,2']:
+        for u in (upd, []):
+            res = []
+            for fn in (vcfio._rewrite_info_general, vcfio.rewrite_info):
+                try:
+                    res.append(fn(h, t, u))
+                except Exception as e:      # noqa: BLE001 -- the same failure is the same behaviour
+                    res.append(('raises', type(e).__name__))
+            assert res[0] == res[1], (t, u, res)

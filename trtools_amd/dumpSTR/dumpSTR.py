@@ -521,8 +521,7 @@ class _Run:
                 f[6] = ';'.join(fired_names) if fired_names else 'PASS'
             elif f[6] == '.':
                 pass                      # an unset FILTER stays '.', 'PASS' stays 'PASS' (Variant.to_text)
-            info = vcfio._Info(self.invcf._parse_info(f[7]))
-            info['HRUN'] = int(hz.hrun[l])
+            upd = [('HRUN', int(hz.hrun[l]))]
             I, Fv = st.locus_int[0, l], st.locus_f64[0, l]
             o = int(hz.allele_off[l])
             n_alt = int(hz.allele_off[l + 1]) - o - 1
@@ -530,17 +529,13 @@ class _Run:
                 status = I[L.LI_HWE_STATUS_LEN if ul else L.LI_HWE_STATUS_STR]
                 if status == L.HWE_INDEX_ERROR:
                     raise IndexError("tuple index out of range (haploid genotypes have no HWE test)")
-                info['HET'] = float(Fv[L.LF_HET_LEN if ul else L.LF_HET_STR])
-                info['HWEP'] = float(Fv[L.LF_HWEP_LEN if ul else L.LF_HWEP_STR])
-                ac = st.allele_count[0, o:o + n_alt + 1]
-                info['AC'] = 0 if n_alt == 0 else ",".join(str(int(x)) for x in ac[1:])
-                info['REFAC'] = int(ac[0])
+                ac = st.allele_count[0, o:o + n_alt + 1].tolist()
+                upd += [('HET', float(Fv[L.LF_HET_LEN if ul else L.LF_HET_STR])),
+                        ('HWEP', float(Fv[L.LF_HWEP_LEN if ul else L.LF_HWEP_STR])),
+                        ('AC', 0 if n_alt == 0 else ",".join(str(x) for x in ac[1:])), ('REFAC', ac[0])]
             else:
-                info['HET'] = -1
-                info['HWEP'] = -1
-                info['AC'] = 0 if n_alt == 0 else ','.join(['0'] * n_alt)
-                info['REFAC'] = 0
-            f[7] = vcfio.info_text(info)
+                upd += [('HET', -1), ('HWEP', -1), ('AC', 0 if n_alt == 0 else ','.join(['0'] * n_alt)), ('REFAC', 0)]
+            f[7] = vcfio.rewrite_info(self.invcf, f[7], upd)
             f[8] = f[8] + ':FILTER'
             chrom = f[0]
             if chrom not in self.invcf.contigs_declared and chrom not in self.invcf.contigs_seen:

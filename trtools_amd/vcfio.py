@@ -553,6 +553,67 @@ def info_text(info):
     return ';'.join(toks) if toks else '.'
 
 
+def rewrite_info(reader, text, updates):
+    """``info_text`` of the record's INFO column after ``info[k] = v`` for every (k, v) of ``updates`` -- what
+    ``_Info(reader._parse_info(text))`` + the assignments + ``info_text`` give, without building the typed objects
+    when the text already reads the way it would be written back: String values, bare flags and integers in canonical
+    form pass through as they are.  Anything else (Float values, which htslib re-serialises from float32; '+5' or
+    '007'; a key that occurs twice; a Flag with a value) takes the general path."""
+    if text == '.' or text == '':
+        return info_text(updates) if updates else '.'
+    toks = text.split(';')
+    types = reader.info_types
+    upd = dict(updates)
+    seen = set()
+    out = []
+    for tok in toks:
+        if not tok:
+            continue
+        eq = tok.find('=')
+        k = tok if eq < 0 else tok[:eq]
+        if k in seen:
+            return _rewrite_info_general(reader, text, updates)
+        seen.add(k)
+        if k in upd:
+            out.append(k + '=' + _fmt_one(upd[k]))
+            continue
+        if eq < 0:
+            out.append(tok)
+            continue
+        typ = types.get(k, ('String', '.'))[0]
+        if typ == 'Integer':
+            v = tok[eq + 1:]
+            for x in (v.split(',') if ',' in v else (v,)):
+                if not ((x.isdigit() and (x[0] != '0' or x == '0')) or
+                        (x[:1] == '-' and x[1:].isdigit() and x[1:2] != '0') or x == '.'):
+                    return _rewrite_info_general(reader, text, updates)
+            out.append(tok)
+        elif typ == 'Float' or typ == 'Flag':
+            return _rewrite_info_general(reader, text, updates)
+        else:
+            out.append(tok)
+    for k, v in updates:
+        if k not in seen:
+            seen.add(k)
+            out.append(k + '=' + _fmt_one(upd[k]))
+    return ';'.join(out) if out else '.'
+
+
+def _fmt_one(v):
+    if v is True:
+        raise ValueError("flags are not set through rewrite_info")
+    if isinstance(v, (tuple, list)):
+        return ','.join(_fmt_info(x) for x in v)
+    return _fmt_info(v)
+
+
+def _rewrite_info_general(reader, text, updates):
+    info = _Info(reader._parse_info(text))
+    for k, v in updates:
+        info[k] = v
+    return info_text(info)
+
+
 def _fmt_info(v):
     if v is None:
         return '.'
