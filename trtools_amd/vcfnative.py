@@ -130,7 +130,7 @@ class RawBatch:
                         li.ctypes.data, lf.ctypes.data)
         sk = None if skip is None else np.ascontiguousarray(skip, dtype=np.uint8)
         el, ek = C.c_int32(), C.c_int32()
-        cap = max(1 << 16, self.n * 256)
+        cap = max(1 << 16, self.n * 1024)     # (a row with many alleles runs to several hundred bytes)
         lib = self.reader._lib
         while True:
             buf = C.create_string_buffer(cap)
@@ -185,7 +185,12 @@ class RawBatch:
                          mask.ctypes.data if mask.dtype == np.uint32 else None, fv, harr, karr, kk)
         lib = self.reader._lib
         err = C.c_int32()
-        cap = int((int(self.b.line_end[self.n - 1]) - int(self.b.line_off[0])) * 1.3) + (1 << 16) if self.n else 16
+        # output bound: the input text, a third more for re-serialised numbers, and per call the FILTER column this
+        # pass appends (':PASS' / ':NOCALL'; the longer '<name>_<value>' strings of the few filtered calls fit in
+        # the slack).  The buffer is not touched beyond what is written, so a generous bound costs nothing -- a
+        # tight one (x 1.3 alone) made the writer run twice on every batch whose calls mostly pass.
+        cap = (int((int(self.b.line_end[self.n - 1]) - int(self.b.line_off[0])) * 1.35) + self.n * S * 12 + (1 << 16)
+               if self.n else 16)
         while True:
             buf = np.empty(cap, dtype=np.uint8)          # not zero-filled; handed to the writer as a memoryview
             n = lib.trk_vcf_dumpstr_lines(C.byref(self.b), C.byref(prm), buf.ctypes.data, cap, C.byref(err))
