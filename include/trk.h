@@ -358,8 +358,13 @@ int trk_locus_filters(trk_ctx* ctx, int32_t n_loci, const trk_stats_out* stats,
  * The outcome / covariates are the caller's standardised columns (associaTR.py:198-202),
  * row-major by VECTOR: vec[0] = outcome, vec[1..] = covariates, each [S] (entries of
  * samples with sample_in == 0 are ignored).  The intercept is implicit.
+ * Up to TRK_ASSOC_MAX_VEC rows are scanned in ONE pass over the genotype tensor; trk_assoc_scan
+ * takes up to TRK_ASSOC_MAX_VEC_WIDE rows (associaTR.py:138-204 has no bound: any number of
+ * --same-file-covars / .npy columns) by scanning every pair of 15-row groups as a design of its
+ * own -- g(g-1)/2 passes for g = ceil(M / 15) groups -- and solving the whole design per locus.
  */
 #define TRK_ASSOC_MAX_VEC 31
+#define TRK_ASSOC_MAX_VEC_WIDE 62
 typedef struct {
     int32_t n_vec;              /* M >= 1: outcome + (M-1) covariates                        */
     int32_t flags;              /* 0                                                         */

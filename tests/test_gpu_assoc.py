@@ -151,6 +151,19 @@ def test_mfma_path_many_covariates(eng):
     assert run_case(eng, 25, 20, 516, M=20, cutoff=0.0, miss=0.5) > 3      # half the calls missing
 
 
+def test_wide_designs_pairs_of_row_groups(eng):
+    """More than 31 trait columns (the reference has no bound, associaTR.py:138-204): pairs of 15-row groups
+    through the same scan kernels, the whole design solved by a wave per locus.  Up to 62 rows."""
+    assert run_case(eng, 41, 50, 1024, M=32, subset=True) > 20               # groups of 15, 15, 2
+    assert run_case(eng, 42, 37, 772, M=45, subset=True, miss=0.1) > 15      # three full groups; loci % 16, S % 256
+    assert run_case(eng, 43, 40, 1280, M=62, cutoff=0.0, miss=0.3) > 15      # five groups, ten pairs, 64 lanes
+    assert run_case(eng, 44, 30, 333, P=2, M=40, subset=True) > 10           # S % 4 != 0: the generic scan kernel
+    assert run_case(eng, 45, 30, 300, P=3, M=33) > 10                        # triploid: the generic scan kernel
+    from trtools_amd._lib import TrkError
+    with pytest.raises(TrkError):
+        run_case(eng, 46, 10, 256, M=63)
+
+
 def test_wave_parallel_regression_for_narrow_designs_too(eng):
     os.environ['TRK_AS_WAVE_REGRESS_MIN'] = '2'
     try:

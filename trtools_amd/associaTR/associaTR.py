@@ -120,13 +120,15 @@ def _load_design(all_samples, trait_fnames, same_samples, sample_fname):
     return sample_filter, covars, outcome, pheno_std
 
 
-def _device_vectors(sample_filter, covars, outcome):
+def _device_vectors(sample_filter, covars, outcome, beagle_dosages=False):
     """[M, S] float64 for trk_assoc_params.vec: row 0 the outcome, rows 1.. the covariates; samples
-    outside the regression set hold zeros (ignored on the device)."""
+    outside the regression set hold zeros (ignored on the device).  Up to 31 rows are scanned in one
+    pass, up to 62 as pairs of row groups (trk.h TRK_ASSOC_MAX_VEC_WIDE); --beagle-dosages: 31."""
     S, M = len(sample_filter), covars.shape[1] - 1
-    if M > L.ASSOC_MAX_VEC:
+    limit = L.ASSOC_MAX_VEC if beagle_dosages else L.ASSOC_MAX_VEC_WIDE
+    if M > limit:
         raise ValueError("associaTR: %d trait columns (phenotype + covariates); this build scans at most %d"
-                         % (M, L.ASSOC_MAX_VEC))
+                         % (M, limit))
     vec = np.zeros((M, S), dtype=np.float64)
     vec[0, sample_filter] = outcome
     for k in range(1, M):
@@ -240,7 +242,7 @@ def perform_gwas_helper(outfile, all_samples, record_iter, phenotype_name, trait
         outfile.write('se_{}\tregression_R^2\t'.format(phenotype_name))
         outfile.flush()
     sample_filter, covars, outcome, pheno_std = _load_design(all_samples, trait_fnames, same_samples, sample_fname)
-    vec = _device_vectors(sample_filter, covars, outcome)
+    vec = _device_vectors(sample_filter, covars, outcome, beagle_dosages)
     if rank == 0:
         fields = list(load_and_filter_genotypes.DETAIL_FIELDS)
         if beagle_dosages:

@@ -2036,6 +2036,52 @@ __global__ __launch_bounds__(WAVE* RW_WAVES) void k_assoc_regress_wave(const Fin
     }
 }
 
+
+// -------------------------------------------------------------------------------------------
+// wide designs (32..62 vector rows): the rows are cut into groups of <= 15 and every PAIR of groups
+// is scanned as a design of <= 30 rows by the kernels above; this kernel moves one pair's records
+// (chunks summed) and its full Gram matrix to their places in the records of the whole design.
+// Block l < L: locus l; block L: the full Gram matrix.
+// -------------------------------------------------------------------------------------------
+struct WideArgs {
+    const double* sub_partial;  // [nchunks, L, ns]
+    const double* sub_full;     // [nc]
+    double* partial;            // [L, NS] records of the whole design (one chunk)
+    double* full;               // [NC]
+    int L, m, ns, nc, nchunks;  // the pair's design
+    int M, NS;                  // the whole design
+    int first;                  // 1: this pair also carries n, sum g, sum g^2, n_bad
+    uint8_t row[AS_MAXV + 1];   // row of the whole design behind row r of the pair; row[m] = M (ones)
+    uint8_t pa[AS_MAXNC], pb[AS_MAXNC];
+};
+__global__ __launch_bounds__(256) void k_assoc_wide_gather(const WideArgs a) {
+    const int l = blockIdx.x;
+    if (l == a.L) {
+        for (int e = threadIdx.x; e < a.nc; e += blockDim.x)
+            a.full[gidx(a.row[a.pa[e]], a.row[a.pb[e]], a.M)] = a.sub_full[e];
+        return;
+    }
+    double* dst = a.partial + (size_t)l * a.NS;
+    for (int e = threadIdx.x; e < a.ns; e += blockDim.x) {
+        int d;
+        if (e < 3) {
+            if (!a.first) continue;
+            d = e;
+        } else if (e < 3 + a.m) {
+            d = 3 + a.row[e - 3];
+        } else if (e < 3 + a.m + a.nc) {
+            const int g = e - 3 - a.m;
+            d = 3 + a.M + gidx(a.row[a.pa[g]], a.row[a.pb[g]], a.M);
+        } else {
+            if (!a.first) continue;
+            d = a.NS - 1;
+        }
+        double v = 0.0;
+        for (int ch = 0; ch < a.nchunks; ++ch) v += a.sub_partial[((size_t)ch * a.L + l) * a.ns + e];
+        dst[d] = v;
+    }
+}
+
 }  // namespace
 
 namespace trk {
@@ -2113,7 +2159,19 @@ static AssocPlan assoc_plan(const trk_batch& b, int M) {
     return p;
 }
 
+constexpr int AW_GROUP = 15;   // rows per group of a wide design: a pair of groups + the ones row fits two MFMA tiles
+static size_t assoc_ws_one(const trk_batch& b, int M);
+static size_t wide_vec_bytes(const trk_batch& b) { return ((size_t)2 * AW_GROUP * b.n_samples * 8 + 255) & ~(size_t)255; }
+static size_t wide_cnt_bytes(const trk_batch& b) { return ((size_t)b.n_alleles_total * 4 + 255) & ~(size_t)255; }
+
 size_t assoc_workspace_bytes(const trk_batch& b, int M) {
+    size_t bytes = (assoc_ws_one(b, M) + 255) & ~(size_t)255;
+    if (M > TRK_ASSOC_MAX_VEC)   // + one pair's workspace, its vector block, a scratch histogram
+        bytes += ((assoc_ws_one(b, 2 * AW_GROUP) + 255) & ~(size_t)255) + wide_vec_bytes(b) + wide_cnt_bytes(b);
+    return bytes;
+}
+
+static size_t assoc_ws_one(const trk_batch& b, int M) {
     const AssocPlan p = assoc_plan(b, M);
     const int NC = (M + 1) * (M + 2) / 2, NS = 3 + M + NC + 1;
     size_t bytes = 1024 + (size_t)NC * 8;                             // work counters, full Gram
@@ -2185,7 +2243,7 @@ static void assoc_build(const trk_batch& b, const trk_assoc_params& prm, const t
     a.wave_bytes = p.wave_bytes;
     a.kshift = p.kshift;
     int e = 0;
-    for (int r = 0; r <= M; ++r)
+    for (int r = 0; r <= M && M <= AS_MAXV; ++r)
         for (int c = r; c <= M; ++c) {
             a.pa[e] = (uint8_t)r;
             a.pb[e] = (uint8_t)c;
@@ -2212,7 +2270,7 @@ static void assoc_build(const trk_batch& b, const trk_assoc_params& prm, const t
     f.NS = a.NS;
     f.NC = a.NC;
     f.nchunks = p.nchunks;
-    f.wave_regress = use_wave_regress(M) ? 1 : 0;
+    f.wave_regress = (use_wave_regress(M) || M > AS_MAXV) ? 1 : 0;   // wide designs: always a wave per locus
 }
 
 // step 1 (cheap): zero the scratch, Gram matrix of the regression set
@@ -2227,12 +2285,80 @@ hipError_t launch_assoc_prepare(const trk_batch& b, const trk_assoc_params& prm,
     if ((err = hipMemsetAsync(a.work_counter, 0, 1024, stream)) != hipSuccess) return err;
     if (b.n_alleles_total > 0) {
         if ((err = hipMemsetAsync(f.cc, 0, (size_t)b.n_alleles_total * 4, stream)) != hipSuccess) return err;
+        if (prm.n_vec > AS_MAXV) return hipSuccess;   // wide design: the pair scans prepare themselves
         if (!p.fast || p.nchunks > 1)
             if ((err = hipMemsetAsync(out.allele_count, 0, (size_t)b.n_alleles_total * 4, stream)) != hipSuccess)
                 return err;
     }
+    if (prm.n_vec > AS_MAXV) return hipSuccess;
     hipLaunchKernelGGL(k_assoc_gram, dim3(a.NC), dim3(256), 0, stream, a, full);
     return hipGetLastError();
+}
+
+// wide designs: every pair of row groups through prepare + scan as a design of its own, gathered
+// into the records of the whole design
+static hipError_t launch_assoc_scan_wide(const trk_batch& b, const trk_assoc_params& prm, const trk_assoc_out& out,
+                                         void* workspace, int n_cu, hipStream_t stream) {
+    const int M = prm.n_vec, S = b.n_samples;
+    AssocPlan p;
+    AssocArgs a;
+    FinArgs f;
+    double* full;
+    assoc_build(b, prm, out, workspace, p, a, f, full);
+    unsigned char* sub_ws = static_cast<unsigned char*>(workspace) + ((assoc_ws_one(b, M) + 255) & ~(size_t)255);
+    double* sub_vec = reinterpret_cast<double*>(sub_ws + ((assoc_ws_one(b, 2 * AW_GROUP) + 255) & ~(size_t)255));
+    int32_t* sub_cnt = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(sub_vec) + wide_vec_bytes(b));
+    const int ng = (M + AW_GROUP - 1) / AW_GROUP;
+    hipError_t err;
+    bool first = true;
+    for (int ga = 0; ga < ng; ++ga)
+        for (int gb = ga + 1; gb < ng; ++gb) {
+            const int a0 = ga * AW_GROUP, na = AW_GROUP;
+            const int b0 = gb * AW_GROUP, nb = (M - b0 < AW_GROUP) ? M - b0 : AW_GROUP;
+            const int m = na + nb;
+            if ((err = hipMemcpyAsync(sub_vec, prm.vec + (size_t)a0 * S, (size_t)na * S * 8, hipMemcpyDeviceToDevice,
+                                      stream)) != hipSuccess)
+                return err;
+            if ((err = hipMemcpyAsync(sub_vec + (size_t)na * S, prm.vec + (size_t)b0 * S, (size_t)nb * S * 8,
+                                      hipMemcpyDeviceToDevice, stream)) != hipSuccess)
+                return err;
+            trk_assoc_params sp = prm;
+            sp.n_vec = m;
+            sp.vec = sub_vec;
+            trk_assoc_out so = out;
+            if (!first) so.allele_count = sub_cnt;   // the histogram is the same in every pass: kept from the first
+            if ((err = launch_assoc_prepare(b, sp, so, sub_ws, stream)) != hipSuccess) return err;
+            if ((err = launch_assoc_scan(b, sp, so, sub_ws, n_cu, stream)) != hipSuccess) return err;
+            AssocPlan q;
+            AssocArgs sa;
+            FinArgs sf;
+            double* sfull;
+            assoc_build(b, sp, so, sub_ws, q, sa, sf, sfull);
+            WideArgs w{};
+            w.sub_partial = sa.partial;
+            w.sub_full = sfull;
+            w.partial = a.partial;
+            w.full = full;
+            w.L = b.n_loci;
+            w.m = m;
+            w.ns = sa.NS;
+            w.nc = sa.NC;
+            w.nchunks = q.nchunks;
+            w.M = M;
+            w.NS = a.NS;
+            w.first = first ? 1 : 0;
+            for (int r = 0; r < na; ++r) w.row[r] = (uint8_t)(a0 + r);
+            for (int r = 0; r < nb; ++r) w.row[na + r] = (uint8_t)(b0 + r);
+            w.row[m] = (uint8_t)M;
+            for (int e = 0; e < sa.NC; ++e) {
+                w.pa[e] = sa.pa[e];
+                w.pb[e] = sa.pb[e];
+            }
+            hipLaunchKernelGGL(k_assoc_wide_gather, dim3(b.n_loci + 1), dim3(256), 0, stream, w);
+            if ((err = hipGetLastError()) != hipSuccess) return err;
+            first = false;
+        }
+    return hipSuccess;
 }
 
 // step 2: the streaming pass over the genotype tensor
@@ -2242,6 +2368,7 @@ hipError_t launch_assoc_scan(const trk_batch& b, const trk_assoc_params& prm, co
     AssocArgs a;
     FinArgs f;
     double* full;
+    if (prm.n_vec > AS_MAXV) return b.n_loci ? launch_assoc_scan_wide(b, prm, out, workspace, n_cu, stream) : hipSuccess;
     assoc_build(b, prm, out, workspace, p, a, f, full);
     a.n_cu = n_cu > 0 ? n_cu : 256;
     if (b.n_loci == 0) return hipSuccess;
@@ -2287,8 +2414,8 @@ hipError_t launch_assoc_finalize(const trk_batch& b, const trk_assoc_params& prm
     if (b.n_loci == 0) return hipSuccess;
     const int P = prm.n_vec + 1;
     int fin_t = FIN_T;
-    while (fin_t > 8 && (size_t)(P * (P + 1) / 2 + P) * fin_t * 8 > 150 * 1024) fin_t >>= 1;
-    const size_t fin_lds = (size_t)(P * (P + 1) / 2 + P) * fin_t * 8;
+    while (fin_t > 8 && !f.wave_regress && (size_t)(P * (P + 1) / 2 + P) * fin_t * 8 > 150 * 1024) fin_t >>= 1;
+    const size_t fin_lds = f.wave_regress ? 0 : (size_t)(P * (P + 1) / 2 + P) * fin_t * 8;   // the normal matrix lives in k_assoc_regress_wave
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assoc_finalize),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds);
     if (err != hipSuccess) return err;
