@@ -85,3 +85,44 @@ def test_region_is_a_slice_of_the_full_run(tmp_path, oracle_compute):
     got = open(part).readlines()
     assert got[0] == lines[0] and got[1:] == lines[77:77 + len(got) - 1] and len(got) - 1 == 366 - 77 + 1
     assert len(open(none).readlines()) == 1
+
+
+def _wide_traits(tmp_path, n_cols, seed=9):
+    """Seeded trait file for the 50-sample HipSTR fixture: sample index, outcome, n_cols - 1 covariates."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    t = rng.normal(size=(50, n_cols))
+    f = str(tmp_path / ('traits_%d.npy' % n_cols))
+    np.save(f, t)
+    return f
+
+
+def test_wide_design_limits_of_the_host_layer(tmp_path, oracle_compute):
+    """More than 31 trait columns (no bound in the reference, associaTR.py:138-204): accepted up to 62 for the
+    GT-based scan, refused above, and above 31 with --beagle-dosages."""
+    out = str(tmp_path / 'w.tsv')
+    run_cli(out, dict(same_samples=True, tr_vcf=assoc_cases.HIPSTR, traits=[_wide_traits(tmp_path, 40)]), 2, 2)
+    rows = open(out).readlines()
+    assert len(rows) > 10 and sum('n covars >= n samples' not in r for r in rows[1:]) > 5
+    with pytest.raises(ValueError):
+        run_cli(out, dict(same_samples=True, tr_vcf=assoc_cases.HIPSTR, traits=[_wide_traits(tmp_path, 63)]), 2, 2)
+    with pytest.raises(ValueError):
+        run_cli(out, dict(same_samples=True, beagle_dosages=True, traits=[_wide_traits(tmp_path, 32)]), 2, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n_cols', [32, 36, 40])
+def test_wide_design_cli_on_device_equals_oracle_compute(n_cols, tmp_path):
+    """The whole CLI with 32-40 trait columns on the device against the same run through the oracle-backed seam."""
+    from trtools_amd import runtime
+    from oracle_compute import OracleCompute
+    kw = dict(same_samples=True, tr_vcf=assoc_cases.HIPSTR, traits=[_wide_traits(tmp_path, n_cols)])
+    dev, ora = str(tmp_path / 'd.tsv'), str(tmp_path / 'o.tsv')
+    runtime.set_compute(None)
+    run_cli(dev, kw, 10, 15)
+    old = runtime.set_compute(OracleCompute())
+    try:
+        run_cli(ora, kw, 10, 15)
+    finally:
+        runtime.set_compute(old)
+    assert compare_tables(dev, ora, rtol=1e-7) > 50
