@@ -514,6 +514,12 @@ int trk_exchange(trk_ctx* ctx, int64_t* sums_dev, size_t n_sums, const void* sen
  * (third-party call at utils.py:334-338); same code as the device finaliser.  */
 double trk_binomtest_two_sided(int64_t k, int64_t n, double p);
 double trk_binom_pmf(int64_t k, int64_t n, double p);
+/* The same test for `count` triples ON THE DEVICE: lanes = 2, the lane-pair routine statSTR's / dumpSTR's deferred
+ * HWE tests use (k_hwe_test); lanes = 1, the serial routine in one lane (the two agree bit for bit).  k, n, p, out
+ * are HOST arrays (copied in and out; a test / diagnostic entry, synchronous).  Triples outside n >= 1,
+ * 0 <= k <= n, 0 <= p <= 1 give nan.                                                                          */
+int trk_binomtest_batch(trk_ctx* ctx, const int64_t* k, const int64_t* n, const double* p, int64_t count, double* out,
+                        int32_t lanes);
 
 /* ---- synthetic many-sample VCF batches (bench / tests) ------------------- */
 typedef struct {

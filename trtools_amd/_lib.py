@@ -135,7 +135,7 @@ EXPORTS = [
     'trk_profile_enable', 'trk_profile_get', 'trk_profile_reset',
     'trk_locus_stats', 'trk_locus_finalize', 'trk_call_filters', 'trk_locus_filters',
     'trk_comm_unique_id', 'trk_comm_init', 'trk_allreduce_sum_i64', 'trk_allgather',
-    'trk_binomtest_two_sided', 'trk_binom_pmf', 'trk_synth_fill', 'trk_synth_fill_gangstr',
+    'trk_binomtest_two_sided', 'trk_binom_pmf', 'trk_binomtest_batch', 'trk_synth_fill', 'trk_synth_fill_gangstr',
     'trk_assoc_scan', 'trk_assoc_scan_dosage', 'trk_student_t_two_sided', 'trk_dosages', 'trk_qc_reduce', 'trk_planarize', 'trk_stream_select', 'trk_stream_wait',
     'trk_host_alloc', 'trk_host_free', 'trk_memcpy_h2d_async', 'trk_memcpy_d2h_async', 'trk_queue_sync', 'trk_exchange', 'trk_event_record', 'trk_event_wait',
 ]
@@ -253,6 +253,7 @@ def load():
     lib.trk_event_wait.argtypes = [vp, C.c_int]
     lib.trk_binomtest_two_sided.argtypes = [i64, i64, dbl]
     lib.trk_binomtest_two_sided.restype = dbl
+    lib.trk_binomtest_batch.argtypes = [vp, vp, vp, vp, i64, vp, C.c_int32]
     lib.trk_binom_pmf.argtypes = [i64, i64, dbl]
     lib.trk_binom_pmf.restype = dbl
     lib.trk_assoc_scan.argtypes = [vp, P(Batch), P(AssocParams), P(AssocOut)]

@@ -798,4 +798,29 @@ double trk_binomtest_two_sided(int64_t k, int64_t n, double p) {
 }
 double trk_binom_pmf(int64_t k, int64_t n, double p) { return trkmath::binom_pmf(k, n, p); }
 
+int trk_binomtest_batch(trk_ctx* ctx, const int64_t* k, const int64_t* n, const double* p, int64_t count, double* out,
+                        int32_t lanes) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (count < 0 || (count > 0 && (!k || !n || !p || !out)) || (lanes != 1 && lanes != 2))
+        return fail(ctx, TRK_ERR_ARG, "binomtest arguments");
+    if (count == 0) return TRK_OK;
+    (void)hipSetDevice(ctx->device);
+    const size_t col = (size_t)count * 8;
+    unsigned char* dev = nullptr;
+    hipError_t e = hipMalloc(&dev, 4 * col);
+    if (e != hipSuccess) return fail(ctx, TRK_ERR_NOMEM, "binomtest hipMalloc(%zu): %s", 4 * col, hipGetErrorString(e));
+    int rc = TRK_OK;
+    if ((e = hipMemcpyAsync(dev, k, col, hipMemcpyHostToDevice, ctx->s())) == hipSuccess &&
+        (e = hipMemcpyAsync(dev + col, n, col, hipMemcpyHostToDevice, ctx->s())) == hipSuccess &&
+        (e = hipMemcpyAsync(dev + 2 * col, p, col, hipMemcpyHostToDevice, ctx->s())) == hipSuccess &&
+        (e = trk::launch_binomtest_batch(reinterpret_cast<int64_t*>(dev), reinterpret_cast<int64_t*>(dev + col),
+                                         reinterpret_cast<double*>(dev + 2 * col), count,
+                                         reinterpret_cast<double*>(dev + 3 * col), lanes, ctx->s())) == hipSuccess &&
+        (e = hipMemcpyAsync(out, dev + 3 * col, col, hipMemcpyDeviceToHost, ctx->s())) == hipSuccess)
+        e = hipStreamSynchronize(ctx->s());
+    if (e != hipSuccess) rc = fail(ctx, TRK_ERR_HIP, "trk_binomtest_batch: %s", hipGetErrorString(e));
+    (void)hipFree(dev);
+    return rc;
+}
+
 }  // extern "C"

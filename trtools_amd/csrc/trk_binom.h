@@ -31,13 +31,24 @@
 #else
 #define TRK_HD
 #endif
+// On the device a test is a handful of pmf evaluations (~400 instructions each).  The evaluations every test makes
+// are inlined at their few call sites; the rare ones (fallbacks, edge shapes) share ONE out-of-line copy, so that the
+// kernel neither pays the call sequence (register save / restore through scratch) on its hot path nor grows past the
+// instruction cache.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TRK_HOT __attribute__((always_inline))
+#define TRK_COLD __attribute__((noinline))
+#else
+#define TRK_HOT
+#define TRK_COLD
+#endif
 
 namespace trkmath {
 
 // 1/x: on the device v_rcp_f64 refined by one Newton step (relative error
 // ~1e-16, an order of magnitude cheaper than the IEEE division sequence; the
 // statistic's parity bar is 1e-9); plain division on the host.
-TRK_HD inline double fast_rcp(double x) {
+TRK_HD TRK_HOT inline double fast_rcp(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     double y = __builtin_amdgcn_rcp(x);
     y = fma(fma(-x, y, 1.0), y, y);
@@ -48,7 +59,7 @@ TRK_HD inline double fast_rcp(double x) {
 }
 
 // Stirling series error  ln(n!) - [ (n+1/2) ln n - n + ln sqrt(2 pi) ]
-TRK_HD inline double stirlerr(double n) {
+TRK_HD TRK_HOT inline double stirlerr(double n) {
     const double S0 = 0.083333333333333333333;        // 1/12
     const double S1 = 0.00277777777777777777778;      // 1/360
     const double S2 = 0.00079365079365079365079365;   // 1/1260
@@ -83,7 +94,7 @@ TRK_HD inline double stirlerr(double n) {
 }
 
 // deviance term  x ln(x/np) + np - x , accurate when x ~ np
-TRK_HD inline double bd0(double x, double np) {
+TRK_HD TRK_HOT inline double bd0(double x, double np) {
     if (fabs(x - np) < 0.1 * (x + np)) {
         double v = (x - np) / (x + np);
         double s = (x - np) * v;
@@ -100,7 +111,7 @@ TRK_HD inline double bd0(double x, double np) {
     return x * log(x / np) + np - x;
 }
 
-TRK_HD inline double binom_pmf(int64_t ki, int64_t ni, double p) {
+TRK_HD TRK_HOT inline double binom_pmf(int64_t ki, int64_t ni, double p) {
     if (ki < 0 || ki > ni) return 0.0;
     double k = (double)ki, n = (double)ni, q = 1.0 - p;
     if (p <= 0.0) return ki == 0 ? 1.0 : 0.0;
@@ -120,6 +131,9 @@ TRK_HD inline double binom_pmf(int64_t ki, int64_t ni, double p) {
     return exp(lc - 0.5 * lf);
 }
 
+// the out-of-line copy for the rare call sites
+TRK_HD TRK_COLD inline double binom_pmf_cold(int64_t k, int64_t n, double p) { return binom_pmf(k, n, p); }
+
 // sum_{i=0..k} pmf(i); intended for k at or below the mean (terms shrink downwards)
 TRK_HD inline double binom_lower_tail(int64_t k, int64_t n, double p) {
     if (k < 0) return 0.0;
@@ -127,7 +141,7 @@ TRK_HD inline double binom_lower_tail(int64_t k, int64_t n, double p) {
     double q = 1.0 - p;
     if (p <= 0.0) return 1.0;
     if (q <= 0.0) return 0.0;  // k < n
-    double t = binom_pmf(k, n, p);
+    double t = binom_pmf_cold(k, n, p);
     double sum = t;
     const double r = q / p;
     double di = (double)k, dd = (double)(n - k + 1);
@@ -149,7 +163,7 @@ TRK_HD inline double binom_upper_tail(int64_t k, int64_t n, double p) {
     double q = 1.0 - p;
     if (p <= 0.0) return 0.0;
     if (q <= 0.0) return 1.0;  // k < n
-    double t = binom_pmf(k + 1, n, p);
+    double t = binom_pmf_cold(k + 1, n, p);
     double sum = t;
     const double r = p / q;
     double dn = (double)(n - k - 1), dd = (double)(k + 2);
@@ -165,11 +179,11 @@ TRK_HD inline double binom_upper_tail(int64_t k, int64_t n, double p) {
 }
 
 // scipy _binary_search_for_binom_tst on a(x) = sign * pmf(x)
-TRK_HD inline int64_t binom_bsearch(double sign, double d, int64_t lo, int64_t hi, int64_t n,
+TRK_HD TRK_COLD inline int64_t binom_bsearch(double sign, double d, int64_t lo, int64_t hi, int64_t n,
                                     double p) {
     while (lo < hi) {
         int64_t mid = lo + (hi - lo) / 2;
-        double midval = sign * binom_pmf(mid, n, p);
+        double midval = sign * binom_pmf_cold(mid, n, p);
         if (midval < d) {
             lo = mid + 1;
         } else if (midval > d) {
@@ -178,7 +192,7 @@ TRK_HD inline int64_t binom_bsearch(double sign, double d, int64_t lo, int64_t h
             return mid;
         }
     }
-    if (sign * binom_pmf(lo, n, p) <= d) return lo;
+    if (sign * binom_pmf_cold(lo, n, p) <= d) return lo;
     return lo - 1;
 }
 
@@ -188,11 +202,14 @@ TRK_HD inline int64_t binom_bsearch(double sign, double d, int64_t lo, int64_t h
 // confirm it (pmf(ix) is returned: the caller compares it with d).  The bisection costs ~log2(range) + 1 evaluations
 // of ~400 instructions each; the guess (k mirrored at the mean) is a few steps off.  Falls back to the bisection
 // when the walk does not arrive.
+// *pmf_next = pmf(ix + 1) when ix < hi: both values start a tail sum of the test, which therefore needs no further
+// evaluation.
 TRK_HD inline int64_t binom_boundary(double sign, double d, int64_t lo, int64_t hi, int64_t n, double p, int64_t guess,
-                                     double* pmf_ix) {
+                                     double* pmf_ix, double* pmf_next) {
     if (lo > hi) {                       // (the bisection's final test alone)
-        const int64_t ix = sign * binom_pmf(lo, n, p) <= d ? lo : lo - 1;
-        *pmf_ix = binom_pmf(ix, n, p);
+        const int64_t ix = sign * binom_pmf_cold(lo, n, p) <= d ? lo : lo - 1;
+        *pmf_ix = binom_pmf_cold(ix, n, p);
+        *pmf_next = binom_pmf_cold(ix + 1, n, p);
         return ix;
     }
     const double q = 1.0 - p;
@@ -226,23 +243,28 @@ TRK_HD inline int64_t binom_boundary(double sign, double d, int64_t lo, int64_t 
         for (int fix = 0; fix < 4 && ok; ++fix) {
             const double ti = i >= lo ? binom_pmf(i, n, p) : 0.0;
             if (i >= lo && !(sign * ti <= d)) { --i; continue; }
+            double tn_last = 0.0;
             if (i < hi) {
-                const double tn = binom_pmf(i + 1, n, p);
-                if (sign * tn <= d) { ++i; continue; }
+                tn_last = binom_pmf(i + 1, n, p);
+                if (sign * tn_last <= d) { ++i; continue; }
             }
-            *pmf_ix = i >= lo ? ti : binom_pmf(i, n, p);
+            *pmf_ix = i >= lo ? ti : binom_pmf_cold(i, n, p);
+            *pmf_next = tn_last;   // (0 when ix == hi: no caller starts a tail there)
             return i;
         }
     }
     const int64_t ix = binom_bsearch(sign, d, lo, hi, n, p);
-    *pmf_ix = binom_pmf(ix, n, p);
+    *pmf_ix = binom_pmf_cold(ix, n, p);
+    *pmf_next = binom_pmf_cold(ix + 1, n, p);
     return ix;
 }
 
 // sum_{i<=kl} pmf(i) + sum_{i>ku} pmf(i): both far tails advanced in ONE loop (two
 // independent recurrences per iteration: twice the ILP, half the trip count, and --
 // on the GPU -- one code path for every lane whatever side of the mean k lies on).
-TRK_HD inline double binom_two_tails(int64_t kl, int64_t ku, int64_t n, double p) {
+// t_l0 = pmf(kl), t_u0 = pmf(ku + 1) when the caller already holds them (nan: evaluated here).
+TRK_HD inline double binom_two_tails(int64_t kl, int64_t ku, int64_t n, double p, double t_l0 = __builtin_nan(""),
+                                     double t_u0 = __builtin_nan("")) {
     const double q = 1.0 - p;
     double sum_l = 0.0, sum_u = 0.0, t_l = 0.0, t_u = 0.0;
     bool run_l = false, run_u = false;
@@ -250,13 +272,13 @@ TRK_HD inline double binom_two_tails(int64_t kl, int64_t ku, int64_t n, double p
     if (kl >= n) sum_l = 1.0;
     else if (kl >= 0) {
         if (p <= 0.0) sum_l = 1.0;
-        else if (q > 0.0) { t_l = binom_pmf(kl, n, p); sum_l = t_l; run_l = kl > 0; }
+        else if (q > 0.0) { t_l = t_l0 == t_l0 ? t_l0 : binom_pmf_cold(kl, n, p); sum_l = t_l; run_l = kl > 0; }
     }
     // upper tail: edge cases of binom_upper_tail
     if (ku < 0) sum_u = 1.0;
     else if (ku < n) {
         if (q <= 0.0) sum_u = 1.0;
-        else if (p > 0.0) { t_u = binom_pmf(ku + 1, n, p); sum_u = t_u; run_u = ku + 1 < n; }
+        else if (p > 0.0) { t_u = t_u0 == t_u0 ? t_u0 : binom_pmf_cold(ku + 1, n, p); sum_u = t_u; run_u = ku + 1 < n; }
     }
     const double r_l = (p > 0.0) ? q / p : 0.0;
     const double r_u = (q > 0.0) ? p / q : 0.0;
@@ -297,20 +319,142 @@ TRK_HD inline double binomtest_two_sided(int64_t k, int64_t n, double p) {
     const int64_t lo = below ? (int64_t)ceil(pn) : 0;
     const int64_t hi = below ? n : (int64_t)floor(pn);
     // (the mirror image of k at the mean is where a symmetric pmf would cross; skew moves the crossing a few steps)
-    double pmf_ix;
-    const int64_t ix = binom_boundary(sign, sign * d * rerr, lo, hi, n, p, (int64_t)floor(2.0 * pn - kd + 0.5), &pmf_ix);
+    double pmf_ix, pmf_next;
+    const int64_t ix = binom_boundary(sign, sign * d * rerr, lo, hi, n, p, (int64_t)floor(2.0 * pn - kd + 0.5), &pmf_ix,
+                                      &pmf_next);
+    // the four terms the two tails start from are pmf(k), pmf(ix) and pmf(ix + 1): all evaluated above
     int64_t kl, ku;
+    double t_l0, t_u0;
     if (below) {
-        const int64_t y = n - ix + ((d * rerr == pmf_ix) ? 1 : 0);
+        const bool eq = d * rerr == pmf_ix;
+        const int64_t y = n - ix + (eq ? 1 : 0);
         kl = k;          // cdf(k)
-        ku = n - y;      // sf(n - y)
+        ku = n - y;      // sf(n - y): starts at pmf(ix + 1 - eq)
+        t_l0 = d;
+        t_u0 = eq ? pmf_ix : pmf_next;
     } else {
         kl = ix;         // cdf(y - 1), y = ix + 1
         ku = k - 1;      // sf(k - 1)
+        t_l0 = pmf_ix;
+        t_u0 = d;
     }
-    const double pval = binom_two_tails(kl, ku, n, p);
+    const double pval = binom_two_tails(kl, ku, n, p, t_l0, t_u0);
     return pval < 1.0 ? pval : 1.0;
 }
+
+#if defined(__HIPCC__)
+__device__ TRK_COLD inline double binomtest_two_sided_cold(int64_t k, int64_t n, double p) { return binomtest_two_sided(k, n, p); }
+
+// The same test by TWO neighbouring lanes (h = 0 / 1, both holding k, n, p): the pmf evaluations -- the cost of a
+// test, ~400 dependent instructions each -- go two at a time (pmf(k) beside pmf(guess), pmf(i) beside pmf(i + 1)),
+// and each lane sums one tail.  Every decision and every sum is the serial function's, term for term.
+__device__ TRK_HOT inline double binomtest_two_sided_pair(int64_t k, int64_t n, double p, int h, bool* ok);
+// the pair routine with the serial one behind it (out of line), for callers that are not short of registers
+__device__ inline double binomtest_two_sided_pair_or_serial(int64_t k, int64_t n, double p, int h) {
+    bool ok;
+    const double pv = binomtest_two_sided_pair(k, n, p, h, &ok);
+    return ok ? pv : binomtest_two_sided_cold(k, n, p);
+}
+
+// *ok = false (both lanes): a shape the pair does not handle -- p at 0 or 1, or the walk from the guess did not arrive
+// -- and the caller runs the serial routine instead (k_hwe_test: through its overflow list, so that the hot kernel
+// holds no call and no second copy of the test).
+__device__ TRK_HOT inline double binomtest_two_sided_pair(int64_t k, int64_t n, double p, int h, bool* ok) {
+    *ok = true;
+    const double rerr = 1.0 + 1e-7;
+    const double pn = p * (double)n;
+    const double kd = (double)k;
+    const double q = 1.0 - p;
+    const bool below = kd < pn;
+    const double sign = below ? -1.0 : 1.0;
+    const int64_t lo = below ? (int64_t)ceil(pn) : 0;
+    const int64_t hi = below ? n : (int64_t)floor(pn);
+    if (kd == pn) return 1.0;
+    if (lo > hi || !(p > 0.0) || !(q > 0.0)) { *ok = false; return 0.0; }   // (the pair agrees)
+    const int64_t guess = (int64_t)floor(2.0 * pn - kd + 0.5);
+    int64_t i = guess < lo ? lo : (guess > hi ? hi : guess);
+    const double v = binom_pmf(h ? i : k, n, p);
+    const double vo = __shfl_xor(v, 1);
+    const double d = h ? vo : v;       // pmf(k)
+    double t = h ? v : vo;             // pmf(i)
+    const double thr = sign * d * rerr;
+    const double up = p / q, down = q / p;
+    int steps = 0;
+    if (sign * t <= thr) {
+        while (i < hi && steps < 96) {
+            const double tn = t * ((double)(n - i) * fast_rcp((double)(i + 1)) * up);
+            if (!(sign * tn <= thr)) break;
+            t = tn;
+            ++i;
+            ++steps;
+        }
+    } else {
+        while (i >= lo && steps < 96) {
+            if (i == lo) { i = lo - 1; break; }
+            t = t * ((double)i * fast_rcp((double)(n - i + 1)) * down);
+            --i;
+            ++steps;
+            if (sign * t <= thr) break;
+        }
+    }
+    bool found = false;
+    double pmf_ix = 0.0, pmf_next = 0.0;
+    for (int fix = 0; fix < 4 && steps < 96; ++fix) {
+        // (i == lo - 1, nothing inside the range -- k is the mode: pmf(lo - 1) is still wanted, as pmf_ix)
+        const bool need = h ? i < hi : i >= lo - 1;
+        const double e = need ? binom_pmf(i + h, n, p) : 0.0;
+        const double eo = __shfl_xor(e, 1);
+        const double ti = h ? eo : e, tn = h ? e : eo;
+        if (i >= lo && !(sign * ti <= thr)) { --i; continue; }
+        if (i < hi && sign * tn <= thr) { ++i; continue; }
+        pmf_ix = ti;
+        pmf_next = tn;
+        found = true;
+        break;
+    }
+    if (!found) { *ok = false; return 0.0; }   // the walk did not arrive: the serial path (bisection)
+    // lane 0: sum_{j <= kl} pmf(j) downwards from t_l0; lane 1: sum_{j > ku} pmf(j) upwards from t_u0
+    int64_t kl, ku;
+    double t_l0, t_u0;
+    if (below) {
+        const bool eq = d * rerr == pmf_ix;
+        kl = k;
+        ku = i - (eq ? 1 : 0);
+        t_l0 = d;
+        t_u0 = eq ? pmf_ix : pmf_next;
+    } else {
+        kl = i;
+        ku = k - 1;
+        t_l0 = pmf_ix;
+        t_u0 = d;
+    }
+    double sum = 0.0, tt = 0.0, num, den;
+    bool run = false;
+    if (h == 0) {
+        if (kl >= n) sum = 1.0;
+        else if (kl >= 0) { tt = t_l0; sum = tt; run = kl > 0; }
+        num = (double)kl;
+        den = (double)(n - kl + 1);
+    } else {
+        if (ku < 0) sum = 1.0;
+        else if (ku < n) { tt = t_u0; sum = tt; run = ku + 1 < n; }
+        num = (double)(n - ku - 1);
+        den = (double)(ku + 2);
+    }
+    const double r = h ? up : down;
+    while (run) {
+        const double ratio = num * fast_rcp(den) * r;
+        tt *= ratio;
+        sum += tt;
+        num -= 1.0;
+        den += 1.0;
+        run = !((ratio < 1.0 && tt <= sum * 1e-18) || num <= 0.0);
+    }
+    const double so = __shfl_xor(sum, 1);
+    const double pval = h ? so + sum : sum + so;   // sum_l + sum_u
+    return pval < 1.0 ? pval : 1.0;
+}
+#endif
 
 }  // namespace trkmath
 #endif

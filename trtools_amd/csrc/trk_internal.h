@@ -32,6 +32,8 @@ hipError_t launch_synth_gangstr(const trk_synth_spec& sp, const int16_t* gt, con
                                 const int32_t* allele_repcn, float* qexp, int32_t* repcn, int32_t* rc,
                                 int32_t* repci, int n_cu, hipStream_t stream);
 // associaTR scan (trk_assoc.hip): prepare -> scan -> finalize on the same stream and workspace
+hipError_t launch_binomtest_batch(const int64_t* k, const int64_t* n, const double* p, int64_t count, double* out,
+                                  int lanes, hipStream_t stream);
 size_t assoc_workspace_bytes(const trk_batch& b, int n_vec);
 hipError_t launch_assoc_prepare(const trk_batch& b, const trk_assoc_params& prm, const trk_assoc_out& out,
                                 void* workspace, hipStream_t stream);

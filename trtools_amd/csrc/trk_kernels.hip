@@ -1319,16 +1319,62 @@ __global__ __launch_bounds__(FIN_THREADS) void k_locus_finalize(trk_batch b, con
     lf[11] = 0.0;
 }
 
-__global__ __launch_bounds__(FIN_THREADS) void k_hwe_test(const unsigned int* __restrict__ hwe_count,
+// Two neighbouring lanes per test: the kernel lasts as long as its slowest test, and a test is a chain of pmf
+// evaluations that go two at a time this way (trk_binom.h).  The kernel runs beside the call-filter kernel of the
+// step, in the registers that one leaves free: it holds the pair routine alone -- the few tests the pair hands back
+// (worklist header word 1 counts them) are done by k_hwe_test_serial right after.
+template <int WAVES>   // waves per SIMD the kernel is compiled for: 7 -> 72 registers, what five call-filter waves leave free
+__global__ __launch_bounds__(FIN_THREADS, WAVES) void k_hwe_test(unsigned int* __restrict__ hwe_count,
                                                          const HweItem* __restrict__ items,
-                                                         double* __restrict__ locus_f64) {
-    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= *hwe_count) return;
+                                                         double* __restrict__ locus_f64,
+                                                         unsigned int* __restrict__ overflow) {
+    const unsigned int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned int t = tid >> 1;
+    if (t >= hwe_count[0]) return;
     const HweItem it = items[t];
-    const double pv = trkmath::binomtest_two_sided(it.k, it.n, it.p);  // utils.py:334-338
+    bool ok;
+    const double pv = trkmath::binomtest_two_sided_pair(it.k, it.n, it.p, (int)(tid & 1), &ok);  // utils.py:334-338
+    if (tid & 1) return;
+    if (!ok) {
+        overflow[atomicAdd(&hwe_count[1], 1u)] = t;
+        return;
+    }
     double* lf = locus_f64 + (int64_t)it.slot * TRK_LF_COLS;
     if (it.modes & 1) lf[TRK_LF_HWEP_LEN] = pv;
     if (it.modes & 2) lf[TRK_LF_HWEP_STR] = pv;
+}
+
+// one lane per test: the items of `list` (header word 1 entries), or every item (list == nullptr, TRK_HWE_SERIAL=1)
+// (compiled for the registers the call-filter waves leave free, like the pair kernel: a launch that needs more waits
+// for the whole call-filter kernel to retire, with nothing to do)
+__global__ __launch_bounds__(FIN_THREADS, 7) void k_hwe_test_serial(const unsigned int* __restrict__ hwe_count,
+                                                                const HweItem* __restrict__ items,
+                                                                double* __restrict__ locus_f64,
+                                                                const unsigned int* __restrict__ list) {
+    const unsigned int total = list ? hwe_count[1] : hwe_count[0];
+    for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const HweItem it = items[list ? list[t] : t];
+        double pv;
+        [[clang::always_inline]] pv = trkmath::binomtest_two_sided(it.k, it.n, it.p);
+        double* lf = locus_f64 + (int64_t)it.slot * TRK_LF_COLS;
+        if (it.modes & 1) lf[TRK_LF_HWEP_LEN] = pv;
+        if (it.modes & 2) lf[TRK_LF_HWEP_STR] = pv;
+    }
+}
+
+// the lane-pair test on caller-supplied triples (trk_binomtest_batch: parity tests of the routine itself)
+__global__ __launch_bounds__(FIN_THREADS) void k_binomtest_batch(const int64_t* __restrict__ k, const int64_t* __restrict__ n,
+                                                                const double* __restrict__ p, int64_t count,
+                                                                double* __restrict__ out, int lanes) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t t = lanes == 2 ? tid >> 1 : tid;
+    if (t >= count) return;
+    const int64_t kk = k[t], nn = n[t];
+    const double pp = p[t];
+    const bool valid = nn >= 1 && kk >= 0 && kk <= nn && pp >= 0.0 && pp <= 1.0;
+    double pv = __builtin_nan("");
+    if (valid) pv = lanes == 2 ? trkmath::binomtest_two_sided_pair_or_serial(kk, nn, pp, (int)(tid & 1)) : trkmath::binomtest_two_sided(kk, nn, pp);
+    if (lanes != 2 || !(tid & 1)) out[t] = pv;
 }
 
 // ---------------------------------------------------------------------------
@@ -3120,12 +3166,40 @@ hipError_t launch_locus_finalize(const trk_batch& b, const int32_t* allele_count
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    int tblocks = (int)((2 * n + FIN_THREADS - 1) / FIN_THREADS);
-    hipLaunchKernelGGL(k_hwe_test, dim3(tblocks), dim3(FIN_THREADS), 0, stream, count, items, locus_f64);
+    unsigned int* overflow = reinterpret_cast<unsigned int*>(items + 2 * n);
+    static const int hwe_serial = getenv("TRK_HWE_SERIAL") ? 1 : 0;   // one lane per test, for A/B timing
+    if (hwe_serial) {
+        hipLaunchKernelGGL(k_hwe_test_serial, dim3((unsigned)((2 * n + FIN_THREADS - 1) / FIN_THREADS)), dim3(FIN_THREADS), 0,
+                           stream, count, items, locus_f64, (const unsigned int*)nullptr);
+        return hipGetLastError();
+    }
+    int tblocks = (int)((4 * n + FIN_THREADS - 1) / FIN_THREADS);   // up to two tests per locus, two lanes per test
+    // small batches are a latency chain (configs[1]: count 18 us, finaliser 29, these tests 20): the uncapped build,
+    // 155 registers and no scratch; large ones run beside the call filters: the 72-register build.  TRK_HWE_WIDE=1/0
+    // forces one or the other.
+    static const char* hwe_env = getenv("TRK_HWE_WIDE");
+    const bool hwe_wide = hwe_env ? atoi(hwe_env) != 0 : n <= 32768;
+    if (hwe_wide)
+        hipLaunchKernelGGL(k_hwe_test<1>, dim3(tblocks), dim3(FIN_THREADS), 0, stream, count, items, locus_f64, overflow);
+    else
+        hipLaunchKernelGGL(k_hwe_test<7>, dim3(tblocks), dim3(FIN_THREADS), 0, stream, count, items, locus_f64, overflow);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_hwe_test_serial, dim3(16), dim3(FIN_THREADS), 0, stream, count, items, locus_f64,
+                       (const unsigned int*)overflow);
     return hipGetLastError();
 }
 
-size_t finalize_worklist_bytes(int64_t n_group_loci) { return 16 + (size_t)(2 * n_group_loci) * sizeof(HweItem); }
+hipError_t launch_binomtest_batch(const int64_t* k, const int64_t* n, const double* p, int64_t count, double* out,
+                                  int lanes, hipStream_t stream) {
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_binomtest_batch, dim3((unsigned)((lanes * count + FIN_THREADS - 1) / FIN_THREADS)), dim3(FIN_THREADS), 0,
+                       stream, k, n, p, count, out, lanes);
+    return hipGetLastError();
+}
+
+size_t finalize_worklist_bytes(int64_t n_group_loci) {
+    return 16 + (size_t)(2 * n_group_loci) * (sizeof(HweItem) + 4);   // header, items, overflow list
+}
 
 hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n_planes,
                               const trk_call_filter* filters, int n_filters, int dp_plane, const trk_call_out& out,

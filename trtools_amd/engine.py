@@ -610,6 +610,18 @@ class Engine:
     def binomtest(self, k, n, p):
         return self.lib.trk_binomtest_two_sided(int(k), int(n), float(p))
 
+    def binomtest_batch(self, k, n, p, lanes=2):
+        """scipy.stats.binomtest(k, n, p).pvalue for arrays of triples, on the device by the routine the deferred HWE
+        tests use (trk_binomtest_batch; lanes=1: the serial routine in one lane)."""
+        k = np.ascontiguousarray(k, dtype=np.int64)
+        n = np.ascontiguousarray(n, dtype=np.int64)
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        assert k.shape == n.shape == p.shape and k.ndim == 1
+        out = np.empty(k.shape, dtype=np.float64)
+        self._chk(self.lib.trk_binomtest_batch(self.ctx, k.ctypes.data, n.ctypes.data, p.ctypes.data, k.size,
+                                               out.ctypes.data, lanes))
+        return out
+
     # ---- multi-GPU ----
     def comm_unique_id(self):
         buf = (C.c_uint8 * 128)()
