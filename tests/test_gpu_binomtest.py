@@ -36,6 +36,8 @@ def triples(seed, count):
     k = np.where(shape == 3, np.floor(n * p).astype(np.int64) + rng.integers(-1, 3, count), k)   # at / beside the mean
     k = np.where(shape == 4, rng.integers(0, 2, count) * n, k)              # 0 or n
     k = np.where(shape == 5, rng.integers(0, 20000, count) % (n + 1), k)    # anywhere
+    far = np.rint(n * p + rng.choice([-1, 1], count) * rng.uniform(20, 120, count) * sd).astype(np.int64)
+    k = np.where(shape == 6, far, k)                                        # 20-120 sd out: Newton steps before the walk
     return np.clip(k, 0, n), n, p
 
 

@@ -6,7 +6,7 @@ from trtools_amd.engine import Engine
 from trtools_amd.synth import SynthBatch
 eng = Engine(0)
 eng.profile(True)
-for L_, S in ((10000, 1000), (12500, 10000)):
+for L_, S in ((10000, 1000), (12500, 10000), (100000, 10000)):
     sb = SynthBatch(eng, L_, S, seed=20260928 + 1, planes=())
     res = eng.alloc_stats(sb.batch)
     for it in range(41):

@@ -45,6 +45,23 @@
 
 namespace trkmath {
 
+// steps the boundary search walks from its guess before it gives up (a step costs a hundredth of a pmf evaluation,
+// the bisection behind it a dozen evaluations)
+#define TRK_BINOM_WALK 192
+
+// Where the pmf on the far side of the mean falls to pmf(k): k mirrored at the mean, moved by the skew.  With
+// z = (k - np) / sigma, ln pmf ~ -z^2/2 + g (z^3 - 3z)/6, g = (1 - 2p)/sigma, and equal values at -z1 and z1 + delta
+// give delta = g z1^2 / 3, i.e. (1 - 2p) z^2 / 3 counts -- 13 at z = 10, p = 0.3; more than a hundred at z = 30,
+// which call sets far from equilibrium do reach.  Only the cost of the search depends on the guess.
+TRK_HD inline int64_t binom_mirror_guess(double kd, double pn, double p) {
+    const double q = 1.0 - p;
+    const double var = pn * q;
+    const double dz = kd - pn;
+    const double skew = var > 0.0 ? (1.0 - 2.0 * p) * (dz * dz) / (3.0 * var) : 0.0;
+    const double g = 2.0 * pn - kd + skew + 0.5;
+    return (int64_t)floor(g < -1.0 ? -1.0 : (g > 4.0e18 ? 4.0e18 : g));
+}
+
 // 1/x: on the device v_rcp_f64 refined by one Newton step (relative error
 // ~1e-16, an order of magnitude cheaper than the IEEE division sequence; the
 // statistic's parity bar is 1e-9); plain division on the host.
@@ -220,7 +237,7 @@ TRK_HD inline int64_t binom_boundary(double sign, double d, int64_t lo, int64_t 
     if (ok) {
         int steps = 0;
         if (sign * t <= d) {             // inside: move right while the next one is inside too
-            while (i < hi && steps < 96) {
+            while (i < hi && steps < TRK_BINOM_WALK) {
                 const double tn = t * ((double)(n - i) * fast_rcp((double)(i + 1)) * up);
                 if (!(sign * tn <= d)) break;
                 t = tn;
@@ -228,7 +245,7 @@ TRK_HD inline int64_t binom_boundary(double sign, double d, int64_t lo, int64_t 
                 ++steps;
             }
         } else {                         // outside: move left until inside (or past lo)
-            while (i >= lo && steps < 96) {
+            while (i >= lo && steps < TRK_BINOM_WALK) {
                 if (i == lo) { i = lo - 1; break; }
                 t = t * ((double)i * fast_rcp((double)(n - i + 1)) * down);
                 --i;
@@ -236,7 +253,7 @@ TRK_HD inline int64_t binom_boundary(double sign, double d, int64_t lo, int64_t 
                 if (sign * t <= d) break;
             }
         }
-        ok = steps < 96;
+        ok = steps < TRK_BINOM_WALK;
     }
     if (ok) {
         // confirm with the direct evaluation (the walk's values carry the recurrence's rounding): i inside, i + 1 not
@@ -320,7 +337,7 @@ TRK_HD inline double binomtest_two_sided(int64_t k, int64_t n, double p) {
     const int64_t hi = below ? n : (int64_t)floor(pn);
     // (the mirror image of k at the mean is where a symmetric pmf would cross; skew moves the crossing a few steps)
     double pmf_ix, pmf_next;
-    const int64_t ix = binom_boundary(sign, sign * d * rerr, lo, hi, n, p, (int64_t)floor(2.0 * pn - kd + 0.5), &pmf_ix,
+    const int64_t ix = binom_boundary(sign, sign * d * rerr, lo, hi, n, p, binom_mirror_guess(kd, pn, p), &pmf_ix,
                                       &pmf_next);
     // the four terms the two tails start from are pmf(k), pmf(ix) and pmf(ix + 1): all evaluated above
     int64_t kl, ku;
@@ -371,17 +388,17 @@ __device__ TRK_HOT inline double binomtest_two_sided_pair(int64_t k, int64_t n, 
     const int64_t hi = below ? n : (int64_t)floor(pn);
     if (kd == pn) return 1.0;
     if (lo > hi || !(p > 0.0) || !(q > 0.0)) { *ok = false; return 0.0; }   // (the pair agrees)
-    const int64_t guess = (int64_t)floor(2.0 * pn - kd + 0.5);
+    const int64_t guess = binom_mirror_guess(kd, pn, p);
     int64_t i = guess < lo ? lo : (guess > hi ? hi : guess);
     const double v = binom_pmf(h ? i : k, n, p);
     const double vo = __shfl_xor(v, 1);
     const double d = h ? vo : v;       // pmf(k)
     double t = h ? v : vo;             // pmf(i)
-    const double thr = sign * d * rerr;
     const double up = p / q, down = q / p;
+    const double thr = sign * d * rerr;
     int steps = 0;
     if (sign * t <= thr) {
-        while (i < hi && steps < 96) {
+        while (i < hi && steps < TRK_BINOM_WALK) {
             const double tn = t * ((double)(n - i) * fast_rcp((double)(i + 1)) * up);
             if (!(sign * tn <= thr)) break;
             t = tn;
@@ -389,7 +406,7 @@ __device__ TRK_HOT inline double binomtest_two_sided_pair(int64_t k, int64_t n, 
             ++steps;
         }
     } else {
-        while (i >= lo && steps < 96) {
+        while (i >= lo && steps < TRK_BINOM_WALK) {
             if (i == lo) { i = lo - 1; break; }
             t = t * ((double)i * fast_rcp((double)(n - i + 1)) * down);
             --i;
@@ -399,7 +416,7 @@ __device__ TRK_HOT inline double binomtest_two_sided_pair(int64_t k, int64_t n, 
     }
     bool found = false;
     double pmf_ix = 0.0, pmf_next = 0.0;
-    for (int fix = 0; fix < 4 && steps < 96; ++fix) {
+    for (int fix = 0; fix < 4 && steps < TRK_BINOM_WALK; ++fix) {
         // (i == lo - 1, nothing inside the range -- k is the mode: pmf(lo - 1) is still wanted, as pmf_ix)
         const bool need = h ? i < hi : i >= lo - 1;
         const double e = need ? binom_pmf(i + h, n, p) : 0.0;

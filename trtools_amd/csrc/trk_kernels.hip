@@ -3184,7 +3184,7 @@ hipError_t launch_locus_finalize(const trk_batch& b, const int32_t* allele_count
     else
         hipLaunchKernelGGL(k_hwe_test<7>, dim3(tblocks), dim3(FIN_THREADS), 0, stream, count, items, locus_f64, overflow);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_hwe_test_serial, dim3(16), dim3(FIN_THREADS), 0, stream, count, items, locus_f64,
+    hipLaunchKernelGGL(k_hwe_test_serial, dim3(256), dim3(FIN_THREADS), 0, stream, count, items, locus_f64,
                        (const unsigned int*)overflow);
     return hipGetLastError();
 }
