@@ -331,6 +331,9 @@ TRK_HD inline double binomtest_two_sided(int64_t k, int64_t n, double p) {
     const double pn = p * (double)n;
     const double kd = (double)k;
     if (kd == pn) return 1.0;
+    // pmf(k) underflows (|z| beyond ~38): every term of both tails is at most pmf(k), the sums below come out 0.0 --
+    // after a search over indices whose values are all 0, which no guess shortens
+    if (d == 0.0) return 0.0;
     const bool below = kd < pn;
     const double sign = below ? -1.0 : 1.0;
     const int64_t lo = below ? (int64_t)ceil(pn) : 0;
@@ -394,6 +397,7 @@ __device__ TRK_HOT inline double binomtest_two_sided_pair(int64_t k, int64_t n, 
     const double vo = __shfl_xor(v, 1);
     const double d = h ? vo : v;       // pmf(k)
     double t = h ? v : vo;             // pmf(i)
+    if (d == 0.0) return 0.0;          // (as the serial routine)
     const double up = p / q, down = q / p;
     const double thr = sign * d * rerr;
     int steps = 0;
