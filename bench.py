@@ -101,7 +101,7 @@ class Workload:
     """Device-resident buffers of one rank's shard + one step of the hot path."""
 
     def __init__(self, eng, seed, n_samples, loci, locus_base, world, use_comm, overlap=True, gather_loci=None,
-                 pipeline_count=False, n_sets=None, ev_base=0):
+                 pipeline_count=False, n_sets=None, ev_base=0, host_group=None):
         from trtools_amd.synth import SynthBatch
         from trtools_amd import _lib as L
         from trtools_amd.engine import CallResult
@@ -155,6 +155,9 @@ class Workload:
         self._pending = None
         self.overlap = overlap
         self.pipeline_count = pipeline_count
+        # TRK_BENCH_COMM=host (rehearsal of the N > 1 control flow with several ranks on ONE device, where RCCL
+        # refuses to build a communicator): the step's exchange goes through host copies over the socket group
+        self.host_group = host_group
 
     # the buffers of the last completed step
     last = property(lambda self: (self.step_no - 1) % self.NB)     # buffer set of the last completed step
@@ -216,7 +219,12 @@ class Workload:
         eng.locus_finalize(self.sb.batch, self.stats_b[i])
         eng.locus_filters(self.n_loci, self.stats_b[i], bits_out=self.bits_[i], counters=self.loc_counters_[i],
                           **self.locus_args)
-        if self.gather is not None:
+        if self.gather is not None and self.host_group is not None:
+            eng.sync()
+            self.sums_[i].set(self.host_group.allreduce_sum_i64(self.sums_[i].get()))
+            parts = self.host_group.allgather_bytes(self.bits_[i].get().view(np.uint8))
+            self.gather.set(np.stack([np.frombuffer(p.tobytes(), dtype=np.uint32) for p in parts]))
+        elif self.gather is not None:
             eng.exchange(self.sums_[i], self.bits_[i], self.gather)
         eng.event_record(self.EV_TAIL + i)
 
@@ -289,11 +297,13 @@ def exhaustive_check(wl, single_rank_sums):
     return r
 
 
-def assoc_extra(wl, seed, no_check, no_cpu, iters=5):
-    """SURVEY section 8 row f3 / BASELINE configs[4] on ONE GPU, outside the timed region of the headline
+def assoc_extra(wl, seed, no_check, no_cpu, iters=5, group=None, total_loci=None):
+    """SURVEY section 8 row f3 / BASELINE configs[4], outside the timed region of the headline
     metric: the associaTR scan (trk_assoc_scan) over this rank's resident genotype tensor, one seeded
     standard-normal trait, every sample in the regression set.  4 algorithmic bytes per call (the GT read).
-    A handful of loci is checked against the associaTR oracle."""
+    A handful of loci is checked against the associaTR oracle.  With N > 1 every rank scans its locus shard
+    (the scan has no exchange step: result rows stay with the rank that owns the loci, as the sharded associaTR
+    command line writes them in rank order); barrier, `iters` timed passes, max over the ranks."""
     from trtools_amd.synth import pack_assoc_tables
     eng = wl.eng
     n_loci, n_samples = wl.n_loci, wl.n_samples
@@ -308,20 +318,27 @@ def assoc_extra(wl, seed, no_check, no_cpu, iters=5):
     for it in range(iters + 1):
         if it == 1:
             eng.sync()
+            if group is not None:
+                group.barrier()
             eng.profile_reset()
             t0 = time.perf_counter()
         res = eng.assoc_scan(wl.sb.batch, vec_d, alen_d, rcls_d, non_major_cutoff=20.0, out=res)
     eng.sync()
     wall = (time.perf_counter() - t0) / iters
+    world = group.world if group is not None else 1
+    if group is not None:
+        wall = float(group.allreduce_max_f64(np.array([wall]))[0])
+    total_loci = total_loci or n_loci
     prof = eng.profile_get()
     eng.profile(False)
     n, ms = prof['k_assoc_scan']
     nf, msf = prof['k_assoc_finalize']
     scan_ms = ms / max(n, 1)
     cells = n_loci * n_samples
-    out = {"workload": "associaTR linear-regression scan, %d loci x %d samples x 1 trait (BASELINE configs[4] on one GPU)"
-                       % (n_loci, n_samples),
-           "loci_per_s": n_loci / wall, "ms_per_pass": wall * 1e3,
+    out = {"workload": "associaTR linear-regression scan, %d loci x %d samples x 1 trait (BASELINE configs[4] on %s)"
+                       % (total_loci, n_samples,
+                          "one GPU" if world == 1 else "%d GPUs, %d loci per GPU, no exchange step" % (world, n_loci)),
+           "n_gpus": world, "loci_per_s": total_loci / wall, "ms_per_pass": wall * 1e3,
            "kernels_ms": {"k_assoc_scan": scan_ms, "k_assoc_finalize": msf / max(nf, 1)},
            "roofline": {"bound": "hbm", "kernel": "k_assoc_scan", "bytes_per_cell": 4,
                         "achieved": cells * 4 / (scan_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -889,19 +906,23 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    dist = None
+    group = None
     use_dist = world > 1 or bool(os.environ.get('TRK_FORCE_DIST'))   # TRK_FORCE_DIST: exercise the
-    if use_dist:                                                      # collective path on one rank
-        import torch.distributed as dist  # rendezvous / barrier only
-        dist.init_process_group(backend='gloo')
+    # collective path on one rank.  TRK_BENCH_COMM=host: the step's exchange through host copies over the socket
+    # group instead of RCCL; TRK_BENCH_SHARE_DEVICE=1: every rank on device 0 -- together they rehearse the whole
+    # N > 1 control flow (sharding, barrier, max-over-ranks, per-rank every-locus check, cohort-sum assertion) with
+    # several processes on the ONE GPU a builder can reach (RCCL refuses two ranks of one communicator on a device)
+    comm_mode = os.environ.get('TRK_BENCH_COMM', 'rccl')
+    share_device = bool(os.environ.get('TRK_BENCH_SHARE_DEVICE'))
     from trtools_amd.engine import Engine
     from trtools_amd.synth import make_loci
-    from trtools_amd.dist import locus_shard
-    eng = Engine(local_rank)
+    from trtools_amd.dist import locus_shard, SocketGroup
     if use_dist:
-        uid = [eng.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        eng.comm_init(rank, world, uid[0])
+        group = SocketGroup(rank, world)     # rendezvous / barrier / small host reductions over TCP: no torch
+    eng = Engine(0 if share_device else local_rank)
+    if use_dist and comm_mode != 'host':
+        uid = group.broadcast_bytes(eng.comm_unique_id() if rank == 0 else b'')
+        eng.comm_init(rank, world, uid)
     # the cohort's per-locus tables (every rank builds the same ones from the seed)
     loci = make_loci(args.loci, args.samples, args.seed)
     if args.scaling == 'strong':
@@ -911,36 +932,41 @@ def main():
         my_loci, locus_base, total_loci = loci, rank * args.loci, args.loci * world
     wl = Workload(eng, args.seed, args.samples, my_loci, locus_base, world, use_comm=use_dist,
                   overlap=os.environ.get('TRK_BENCH_OVERLAP', '1') != '0', gather_loci=-(-args.loci // world),
-                  pipeline_count=(world > 1) or bool(os.environ.get('TRK_BENCH_PIPE_COUNT')))
+                  pipeline_count=(world > 1) or bool(os.environ.get('TRK_BENCH_PIPE_COUNT')),
+                  host_group=group if (use_dist and comm_mode == 'host') else None)
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        if group is not None:
+            group.barrier()
 
     elapsed, prof = wl.run(args.steps, args.warmup, barrier)
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-        dist.barrier()
+    if group is not None:
+        elapsed = float(group.allreduce_max_f64(np.array([elapsed]))[0])
+        group.barrier()
 
     check = None
     if not args.no_check:
         check = exhaustive_check(wl, single_rank_sums=(world == 1))
-        if dist is not None:
-            # cohort-wide sums: the oracle's per-shard sums added over the ranks must equal what RCCL produced
-            import torch
+        if group is not None:
+            # cohort-wide sums: the oracle's per-shard sums added over the ranks must equal what the exchange produced
             c, td, dm, loc = check['sums']
-            packed = torch.from_numpy(np.concatenate([c.reshape(-1), td, dm, loc]).astype(np.int64))
-            dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+            packed = group.allreduce_sum_i64(np.concatenate([c.reshape(-1), td, dm, loc]).astype(np.int64))
             got = np.concatenate([wl.call_out.sample_counters.get().reshape(-1), wl.call_out.sample_totaldp.get(),
                                   wl.call_out.sample_dp_missing.get(), wl.loc_counters.get()])
-            assert np.array_equal(packed.numpy(), got), "cohort-wide sums (RCCL all-reduce) differ from the oracle's"
-            rows = torch.tensor([check['loci']], dtype=torch.int64)
-            dist.all_reduce(rows, op=dist.ReduceOp.SUM)
-            check['loci_all_ranks'] = int(rows[0])
-            assert np.array_equal(wl.gather.get()[rank], wl.bits.get()), "all-gathered filter bits: own row differs"
+            assert np.array_equal(packed, got), "cohort-wide sums (all-reduce over the ranks) differ from the oracle's"
+            check['loci_all_ranks'] = int(group.allreduce_sum_i64(np.array([check['loci']]))[0])
+            # every rank's filter decisions arrived, in rank order == locus order
+            gathered = wl.gather.get()
+            assert np.array_equal(gathered[rank][:wl.n_loci], wl.bits.get()[:wl.n_loci]), \
+                "all-gathered filter bits: own row differs"
+            mine = np.zeros(gathered.shape[1], dtype=np.uint32)
+            mine[:wl.n_loci] = wl.bits.get()[:wl.n_loci]
+            rows_all = group.allgather_bytes(mine.view(np.uint8))
+            for r in range(world):
+                nr = locus_shard(args.loci, r, world)
+                nr = (nr[1] - nr[0]) if args.scaling == 'strong' else args.loci
+                assert np.array_equal(np.frombuffer(rows_all[r].tobytes(), dtype=np.uint32)[:nr], gathered[r][:nr]), \
+                    "all-gathered filter bits: row of rank %d differs from what that rank computed" % r
     if rank == 0:
         cells = wl.n_loci * wl.n_samples
         ms_step = elapsed / args.steps * 1e3
@@ -1000,6 +1026,11 @@ def main():
                              "loci": check['loci'], "calls": check['calls'],
                              "calls_bit_for_bit_gt_and_mask": check['calls_bit_for_bit'],
                              "worst_float_rel": check['worst_float_rel'], "seconds": check['seconds']}
+    if world > 1 and not args.no_assoc:
+        # BASELINE configs[4] ("associaTR ... 8 x MI355X"): every rank scans its shard, max over the ranks
+        a = assoc_extra(wl, args.seed, args.no_check, True, group=group, total_loci=total_loci)
+        if rank == 0:
+            out.setdefault("extras", {})["associatr_scan"] = a
     if rank == 0 and world == 1:
         extras = out.setdefault("extras", {})
         if not args.no_assoc:
@@ -1024,9 +1055,9 @@ def main():
             extras["end_to_end"] = end_to_end_extra(eng, args.seed)
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if group is not None:
+        group.barrier()
+        group.close()
     eng.close()
 
 

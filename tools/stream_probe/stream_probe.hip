@@ -1,0 +1,313 @@
+// stream_probe.hip -- what does the memory system of an MI355X give a kernel with the call-filter pass's exact
+// stream shape and NO arithmetic?  ("next round" item 1.i)
+//
+// The dumpSTR call-filter pass (k_call_filter_v2<3,true,false>) reads three [L,S] 4-byte planes (GT, DP, Q) and
+// writes two (GT', mask): 12 B in + 8 B out per call, every access a 16-byte nontemporal vector, column-owner
+// tiling (a thread owns 4 consecutive samples and walks a block of loci; grid = (S/1024, L/lpb)).
+// This program times that shape, bare, next to the variations that could explain a gap:
+//   cf<U>     column-owner tiling, U loci in flight per thread (the product kernel: U = 1)
+//   cf+occ    the same with resident workgroups capped to 5 per CU by dynamic LDS (the product kernel's occupancy)
+//   row       one wave per locus row (the count kernel's mapping), same five streams
+//   flat      flat index space: thread i moves chunk i of every stream (a classic "triad")
+//   read3 / write2 / copy   the read-only, write-only and 1:1 mixes at the same tiling
+//   plain     ordinary loads / stores instead of nontemporal ones
+// Build: hipcc --offload-arch=gfx950 -O3 -o stream_probe stream_probe.hip ; run: ./stream_probe [L] [S] [reps]
+// Output: one line per variant (min / avg ms over the repetitions, TB/s of the bytes the variant moves).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+struct Streams {
+    const u32x4* in[3];
+    u32x4* out[2];
+};
+
+template <bool NT>
+__device__ __forceinline__ u32x4 ld(const u32x4* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT>
+__device__ __forceinline__ void st(u32x4* p, u32x4 v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+
+// column-owner tiling: thread = one 16-byte chunk column (4 samples), walks the loci of its block
+// persistent + strided: workgroup y takes loci y*U .. y*U+U-1, then + gridDim.y*U, ...: all resident workgroups march
+// through the tensor together (a window of gridDim.y*U rows per stream)
+template <int U, int NIN, int NOUT, bool NT>
+__global__ __launch_bounds__(256) void k_cfs(Streams s, int L, int S4, uint32_t* sink) {
+    extern __shared__ uint32_t dummy[];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= S4) return;
+    u32x4 acc = {0, 0, 0, 0};
+    for (int l = blockIdx.y * U; l < L; l += gridDim.y * U) {
+        u32x4 v[U][NIN > 0 ? NIN : 1];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < NIN; ++k)
+                if (l + u < L) v[u][k] = ld<NT>(s.in[k] + (size_t)(l + u) * S4 + c);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (l + u >= L) break;
+            u32x4 r = {(uint32_t)l, 1u, 2u, 3u};
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) r |= v[u][k];
+            if (NOUT == 0) acc ^= r;
+#pragma unroll
+            for (int k = 0; k < NOUT; ++k) st<NT>(s.out[k] + (size_t)(l + u) * S4 + c, r + (uint32_t)k);
+        }
+    }
+    if (NOUT == 0 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[0] = 1;
+    if (dummy && L < 0) dummy[threadIdx.x] = 0;
+}
+
+template <int U, int NIN, int NOUT, bool NT>
+__global__ __launch_bounds__(256) void k_cf(Streams s, int L, int S4, int lpb, uint32_t* sink) {
+    extern __shared__ uint32_t dummy[];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= S4) return;
+    const int l0 = blockIdx.y * lpb, l1 = min(L, l0 + lpb);
+    u32x4 acc = {0, 0, 0, 0};
+    int l = l0;
+    for (; l + U <= l1; l += U) {
+        u32x4 v[U][NIN > 0 ? NIN : 1];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) v[u][k] = ld<NT>(s.in[k] + (size_t)(l + u) * S4 + c);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            u32x4 r = {(uint32_t)l, 1u, 2u, 3u};
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) r |= v[u][k];
+            if (NOUT == 0) acc ^= r;
+#pragma unroll
+            for (int k = 0; k < NOUT; ++k) st<NT>(s.out[k] + (size_t)(l + u) * S4 + c, r + (uint32_t)k);
+        }
+    }
+    for (; l < l1; ++l) {
+        u32x4 r = {(uint32_t)l, 1u, 2u, 3u};
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) r |= ld<NT>(s.in[k] + (size_t)l * S4 + c);
+        if (NOUT == 0) acc ^= r;
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) st<NT>(s.out[k] + (size_t)l * S4 + c, r + (uint32_t)k);
+    }
+    if (NOUT == 0 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[0] = 1;
+    if (dummy && lpb < 0) dummy[threadIdx.x] = 0;
+}
+
+// one wave per locus row, 4 waves per workgroup, U chunks in flight per lane
+template <int U, int NIN, int NOUT, bool NT>
+__global__ __launch_bounds__(256) void k_row(Streams s, int L, int S4, uint32_t* sink) {
+    const int l = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (l >= L) return;
+    const int lane = threadIdx.x & 63;
+    u32x4 acc = {0, 0, 0, 0};
+    const size_t base = (size_t)l * S4;
+    for (int c0 = lane; c0 < S4; c0 += 64 * U) {
+        u32x4 v[U][NIN > 0 ? NIN : 1];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + 64 * u;
+#pragma unroll
+            for (int k = 0; k < NIN; ++k)
+                if (c < S4) v[u][k] = ld<NT>(s.in[k] + base + c);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + 64 * u;
+            if (c >= S4) break;
+            u32x4 r = {(uint32_t)l, 1u, 2u, 3u};
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) r |= v[u][k];
+            if (NOUT == 0) acc ^= r;
+#pragma unroll
+            for (int k = 0; k < NOUT; ++k) st<NT>(s.out[k] + base + c, r + (uint32_t)k);
+        }
+    }
+    if (NOUT == 0 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[0] = 1;
+}
+
+// flat: grid-stride over all chunks
+template <int NIN, int NOUT, bool NT>
+__global__ __launch_bounds__(256) void k_flat(Streams s, size_t n, uint32_t* sink) {
+    u32x4 acc = {0, 0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        u32x4 r = {(uint32_t)i, 1u, 2u, 3u};
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) r |= ld<NT>(s.in[k] + i);
+        if (NOUT == 0) acc ^= r;
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) st<NT>(s.out[k] + i, r + (uint32_t)k);
+    }
+    if (NOUT == 0 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[0] = 1;
+}
+
+struct Result { std::string name; double mn, avg, bytes; };
+static std::vector<Result> results;
+static hipEvent_t e0, e1;
+static int reps = 7;
+
+template <typename F>
+static void run(const char* name, double bytes, F launch) {
+    launch();   // warm-up
+    CK(hipDeviceSynchronize());
+    double mn = 1e30, sum = 0;
+    for (int r = 0; r < reps; ++r) {
+        CK(hipEventRecord(e0, 0));
+        launch();
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        mn = std::min(mn, (double)ms);
+        sum += ms;
+    }
+    CK(hipGetLastError());
+    results.push_back({name, mn, sum / reps, bytes});
+    printf("%-44s min %7.3f ms  avg %7.3f ms  %6.2f TB/s (avg)  %5.3f of 8 TB/s\n", name, mn, sum / reps,
+           bytes / (sum / reps) * 1e-9, bytes / (sum / reps) * 1e-9 / 8.0);
+    fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+    int L = argc > 1 ? atoi(argv[1]) : 100000, S = argc > 2 ? atoi(argv[2]) : 10000;
+    if (argc > 3) reps = atoi(argv[3]);
+    const int S4 = S / 4;
+    const size_t n = (size_t)L * S4, plane = n * 16;
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    int mclk = 0, sclk = 0;
+    hipDeviceGetAttribute(&mclk, hipDeviceAttributeMemoryClockRate, 0);
+    hipDeviceGetAttribute(&sclk, hipDeviceAttributeClockRate, 0);
+    printf("# device %s, %d CUs, sclk %d kHz, mclk %d kHz; L = %d, S = %d, plane = %.2f GB, reps = %d\n", prop.name,
+           prop.multiProcessorCount, sclk, mclk, L, S, plane * 1e-9, reps);
+    Streams s;
+    void* buf[5];
+    for (int k = 0; k < 5; ++k) {
+        CK(hipMalloc(&buf[k], plane));
+        CK(hipMemset(buf[k], k + 1, plane));
+    }
+    for (int k = 0; k < 3; ++k) s.in[k] = (const u32x4*)buf[k];
+    s.out[0] = (u32x4*)buf[3];
+    s.out[1] = (u32x4*)buf[4];
+    uint32_t* sink;
+    CK(hipMalloc(&sink, 64));
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipDeviceSynchronize());
+    const int ncu = prop.multiProcessorCount;
+    const int gx = (S4 + 255) / 256;
+    // the product kernel's grid rule: whole rounds of (occupancy x CUs) workgroups
+    auto lpb_for = [&](int occ) {
+        const long slots = (long)ncu * occ;
+        int lpb = 117;
+        const long min_wgs = (long)gx * ((L + lpb - 1) / lpb);
+        long k = (min_wgs + slots - 1) / slots;
+        if (k < 2) k = 2;
+        long gyr = k * slots / gx;
+        int lpb2 = (int)((L + gyr - 1) / gyr);
+        return lpb2 < lpb ? lpb2 : lpb;
+    };
+    const double b5 = 5.0 * plane, b3 = 3.0 * plane, b2 = 2.0 * plane;
+    if (argc > 4 && !strcmp(argv[4], "sweep")) {
+        // resident workgroups per CU (capped by dynamic LDS) x loci in flight x locus assignment, grid = exactly the
+        // resident set (persistent workgroups)
+        for (int wgcu : {2, 3, 4, 5, 6, 8}) {
+            const size_t lds = wgcu >= 8 ? 0 : std::min<size_t>(64 * 1024, (size_t)(160 * 1024 / wgcu - 2048));
+            const int gy = std::max(1, wgcu * ncu / gx);
+            const int lpb = (L + gy - 1) / gy;
+            char nm[128];
+#define SW(UU)                                                                                                      \
+            snprintf(nm, sizeof nm, "sweep cf<%d> block   %d WG/CU persistent (gy %d, %d loci/WG)", UU, wgcu, gy, lpb); \
+            run(nm, b5, [&] { hipLaunchKernelGGL((k_cf<UU, 3, 2, true>), dim3(gx, gy), dim3(256), lds, 0, s, L, S4, lpb, sink); }); \
+            snprintf(nm, sizeof nm, "sweep cf<%d> strided %d WG/CU persistent (gy %d)", UU, wgcu, gy);             \
+            run(nm, b5, [&] { hipLaunchKernelGGL((k_cfs<UU, 3, 2, true>), dim3(gx, gy), dim3(256), lds, 0, s, L, S4, sink); });
+            SW(1) SW(2) SW(4)
+#undef SW
+        }
+        // the product grid rule (whole rounds) with strided-in-round assignment is the same as block for one round;
+        // non-persistent strided: gy = L / lpb workgroups each taking lpb loci gy apart
+        for (int lpb : {16, 112}) {
+            const int gy = (L + lpb - 1) / lpb;
+            char nm[128];
+            snprintf(nm, sizeof nm, "sweep cf<1> strided, %d loci per WG (gy %d), 5 WG/CU", lpb, gy);
+            run(nm, b5, [&] { hipLaunchKernelGGL((k_cfs<1, 3, 2, true>), dim3(gx, gy), dim3(256), 30 * 1024, 0, s, L, S4, sink); });
+        }
+        printf("JSON [");
+        for (size_t i = 0; i < results.size(); ++i)
+            printf("%s{\"name\": \"%s\", \"min_ms\": %.4f, \"avg_ms\": %.4f, \"tbps\": %.3f}", i ? ", " : "",
+                   results[i].name.c_str(), results[i].mn, results[i].avg, results[i].bytes / results[i].avg * 1e-9);
+        printf("]\n");
+        return 0;
+    }
+    {
+        const int lpb = lpb_for(5), gy = (L + lpb - 1) / lpb;
+        printf("# column-owner grid (%d, %d), %d loci per block\n", gx, gy, lpb);
+        const size_t lds5 = 30 * 1024;   // 160 KiB / 5 > 30 KiB > 160 KiB / 6: five workgroups per CU
+        run("cf<1> 3in/2out nt, 5 WG/CU (product shape)", b5, [&] { hipLaunchKernelGGL((k_cf<1, 3, 2, true>), dim3(gx, gy), dim3(256), lds5, 0, s, L, S4, lpb, sink); });
+        run("cf<1> 3in/2out nt, 8 WG/CU", b5, [&] { hipLaunchKernelGGL((k_cf<1, 3, 2, true>), dim3(gx, gy), dim3(256), 0, 0, s, L, S4, lpb, sink); });
+        run("cf<2> 3in/2out nt, 5 WG/CU", b5, [&] { hipLaunchKernelGGL((k_cf<2, 3, 2, true>), dim3(gx, gy), dim3(256), lds5, 0, s, L, S4, lpb, sink); });
+        run("cf<2> 3in/2out nt, 8 WG/CU", b5, [&] { hipLaunchKernelGGL((k_cf<2, 3, 2, true>), dim3(gx, gy), dim3(256), 0, 0, s, L, S4, lpb, sink); });
+        run("cf<4> 3in/2out nt, 5 WG/CU", b5, [&] { hipLaunchKernelGGL((k_cf<4, 3, 2, true>), dim3(gx, gy), dim3(256), lds5, 0, s, L, S4, lpb, sink); });
+        run("cf<4> 3in/2out nt, 8 WG/CU", b5, [&] { hipLaunchKernelGGL((k_cf<4, 3, 2, true>), dim3(gx, gy), dim3(256), 0, 0, s, L, S4, lpb, sink); });
+        const size_t lds3 = 50 * 1024, lds2 = 70 * 1024;
+        run("cf<1> 3in/2out nt, 3 WG/CU", b5, [&] { hipLaunchKernelGGL((k_cf<1, 3, 2, true>), dim3(gx, gy), dim3(256), lds3, 0, s, L, S4, lpb, sink); });
+        run("cf<4> 3in/2out nt, 2 WG/CU", b5, [&] { hipLaunchKernelGGL((k_cf<4, 3, 2, true>), dim3(gx, gy), dim3(256), lds2, 0, s, L, S4, lpb, sink); });
+        run("cf<1> 3in/2out plain ld/st, 5 WG/CU", b5, [&] { hipLaunchKernelGGL((k_cf<1, 3, 2, false>), dim3(gx, gy), dim3(256), lds5, 0, s, L, S4, lpb, sink); });
+        run("cf<2> 3in/2out plain ld/st, 8 WG/CU", b5, [&] { hipLaunchKernelGGL((k_cf<2, 3, 2, false>), dim3(gx, gy), dim3(256), 0, 0, s, L, S4, lpb, sink); });
+        run("cf<1> 3in/0out nt (read only), 5 WG/CU", b3, [&] { hipLaunchKernelGGL((k_cf<1, 3, 0, true>), dim3(gx, gy), dim3(256), lds5, 0, s, L, S4, lpb, sink); });
+        run("cf<2> 3in/0out nt (read only), 8 WG/CU", b3, [&] { hipLaunchKernelGGL((k_cf<2, 3, 0, true>), dim3(gx, gy), dim3(256), 0, 0, s, L, S4, lpb, sink); });
+        run("cf<1> 0in/2out nt (write only), 5 WG/CU", b2, [&] { hipLaunchKernelGGL((k_cf<1, 0, 2, true>), dim3(gx, gy), dim3(256), lds5, 0, s, L, S4, lpb, sink); });
+        run("cf<1> 1in/1out nt (copy), 5 WG/CU", b2, [&] { hipLaunchKernelGGL((k_cf<1, 1, 1, true>), dim3(gx, gy), dim3(256), lds5, 0, s, L, S4, lpb, sink); });
+        run("cf<2> 1in/1out nt (copy), 8 WG/CU", b2, [&] { hipLaunchKernelGGL((k_cf<2, 1, 1, true>), dim3(gx, gy), dim3(256), 0, 0, s, L, S4, lpb, sink); });
+        run("cf<1> 3in/1out nt (16 B/call), 5 WG/CU", 4.0 * plane, [&] { hipLaunchKernelGGL((k_cf<1, 3, 1, true>), dim3(gx, gy), dim3(256), lds5, 0, s, L, S4, lpb, sink); });
+        run("cf<1> 2in/2out nt (fused-count analogue)", 4.0 * plane, [&] { hipLaunchKernelGGL((k_cf<1, 2, 2, true>), dim3(gx, gy), dim3(256), lds5, 0, s, L, S4, lpb, sink); });
+        // other block sizes of the same tiling
+        for (int q : {16, 49, 400, 2000}) {
+            const int gy2 = (L + q - 1) / q;
+            char nm[96];
+            snprintf(nm, sizeof nm, "cf<1> 3in/2out nt, 5 WG/CU, %d loci/block", q);
+            run(nm, b5, [&] { hipLaunchKernelGGL((k_cf<1, 3, 2, true>), dim3(gx, gy2), dim3(256), lds5, 0, s, L, S4, q, sink); });
+        }
+    }
+    {
+        const int g = (L + 3) / 4;
+        run("row<1> 3in/2out nt (wave per locus row)", b5, [&] { hipLaunchKernelGGL((k_row<1, 3, 2, true>), dim3(g), dim3(256), 0, 0, s, L, S4, sink); });
+        run("row<2> 3in/2out nt", b5, [&] { hipLaunchKernelGGL((k_row<2, 3, 2, true>), dim3(g), dim3(256), 0, 0, s, L, S4, sink); });
+        run("row<4> 3in/2out nt", b5, [&] { hipLaunchKernelGGL((k_row<4, 3, 2, true>), dim3(g), dim3(256), 0, 0, s, L, S4, sink); });
+        run("row<2> 3in/2out plain", b5, [&] { hipLaunchKernelGGL((k_row<2, 3, 2, false>), dim3(g), dim3(256), 0, 0, s, L, S4, sink); });
+        run("row<2> 1in/0out nt (count kernel's stream)", 1.0 * plane, [&] { hipLaunchKernelGGL((k_row<2, 1, 0, true>), dim3(g), dim3(256), 0, 0, s, L, S4, sink); });
+        run("row<4> 1in/0out nt", 1.0 * plane, [&] { hipLaunchKernelGGL((k_row<4, 1, 0, true>), dim3(g), dim3(256), 0, 0, s, L, S4, sink); });
+        run("row<2> 3in/0out nt", b3, [&] { hipLaunchKernelGGL((k_row<2, 3, 0, true>), dim3(g), dim3(256), 0, 0, s, L, S4, sink); });
+        run("row<2> 1in/1out nt (copy)", b2, [&] { hipLaunchKernelGGL((k_row<2, 1, 1, true>), dim3(g), dim3(256), 0, 0, s, L, S4, sink); });
+    }
+    {
+        for (int wpc : {8, 16, 32}) {
+            char nm[96];
+            snprintf(nm, sizeof nm, "flat 3in/2out nt, grid %d x CUs", wpc);
+            run(nm, b5, [&] { hipLaunchKernelGGL((k_flat<3, 2, true>), dim3(ncu * wpc), dim3(256), 0, 0, s, n, sink); });
+        }
+        run("flat 3in/2out nt, one chunk per thread", b5, [&] { hipLaunchKernelGGL((k_flat<3, 2, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, s, n, sink); });
+        run("flat 3in/2out plain, grid 16 x CUs", b5, [&] { hipLaunchKernelGGL((k_flat<3, 2, false>), dim3(ncu * 16), dim3(256), 0, 0, s, n, sink); });
+        run("flat 1in/1out plain (float4 copy), 16 x CUs", b2, [&] { hipLaunchKernelGGL((k_flat<1, 1, false>), dim3(ncu * 16), dim3(256), 0, 0, s, n, sink); });
+        run("flat 1in/1out nt (copy), 16 x CUs", b2, [&] { hipLaunchKernelGGL((k_flat<1, 1, true>), dim3(ncu * 16), dim3(256), 0, 0, s, n, sink); });
+        run("flat 1in/0out nt (read), 16 x CUs", 1.0 * plane, [&] { hipLaunchKernelGGL((k_flat<1, 0, true>), dim3(ncu * 16), dim3(256), 0, 0, s, n, sink); });
+        run("flat 3in/0out nt (read), 16 x CUs", b3, [&] { hipLaunchKernelGGL((k_flat<3, 0, true>), dim3(ncu * 16), dim3(256), 0, 0, s, n, sink); });
+        run("flat 0in/2out nt (write), 16 x CUs", b2, [&] { hipLaunchKernelGGL((k_flat<0, 2, true>), dim3(ncu * 16), dim3(256), 0, 0, s, n, sink); });
+        run("hipMemcpyAsync D2D (one plane)", b2, [&] { CK(hipMemcpyAsync(buf[3], buf[0], plane, hipMemcpyDeviceToDevice, 0)); });
+    }
+    // machine-readable tail
+    printf("JSON [");
+    for (size_t i = 0; i < results.size(); ++i)
+        printf("%s{\"name\": \"%s\", \"min_ms\": %.4f, \"avg_ms\": %.4f, \"tbps\": %.3f}", i ? ", " : "", results[i].name.c_str(),
+               results[i].mn, results[i].avg, results[i].bytes / results[i].avg * 1e-9);
+    printf("]\n");
+    return 0;
+}

@@ -2445,7 +2445,11 @@ struct V2Args {
 };
 
 // RATIO: some filter is a HipSTR-style ratio over the depth plane (float64 division, filters.py:415-484)
-template <int NF, bool DELTA, bool RATIO>
+// ALIAS: static sharing of plane registers -- bit 0: the depth statistics read filter 0's plane (a.dp == f[0].plane),
+//        bit k (k >= 1): filter k reads the plane of filter k - 1 (the host orders the filters so; min-DP / max-DP /
+//        depth sums are ONE 16-byte load per locus instead of three)
+// PF:    the planes of locus l + 1 are requested before locus l is evaluated (second register set)
+template <int NF, bool DELTA, bool RATIO, int ALIAS = 0, int PF = 0>
 __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
     extern __shared__ uint32_t v2lds[];
     const int tid = threadIdx.x;
@@ -2483,16 +2487,37 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
     }
     if (s0 < S) {
         const bool leader = (tid & 63) == __ffsll((unsigned long long)__ballot(1)) - 1;  // first live lane of the wave
-        for (int l = l_begin; l < l_end; ++l) {
+        struct Set { u32x4 g; u32x4 pv[NF]; u32x4 dv; };
+        auto load_set = [&](Set& d, int l) {
             const int64_t c4 = ((int64_t)l * S + s0) >> 2;
             const u32x4* gp = reinterpret_cast<const u32x4*>(a.b.gt) + c4;
-            const u32x4 g = g_gt_temporal ? *gp : __builtin_nontemporal_load(gp);
+            if (ALIAS == 0 && PF == 0) d.g = g_gt_temporal ? *gp : __builtin_nontemporal_load(gp);
+            else d.g = __builtin_nontemporal_load(gp);
+#pragma unroll
+            for (int k = 0; k < NF; ++k) {
+                if (k > 0 && ((ALIAS >> k) & 1)) d.pv[k] = d.pv[k - 1];
+                else d.pv[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.f[k].plane) + c4);
+            }
+            d.dv = (u32x4){0, 0, 0, 0};
+            if (ALIAS & 1) d.dv = d.pv[0];
+            else if (a.dp) d.dv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.dp) + c4);
+        };
+        Set cur;
+        if (PF) load_set(cur, l_begin);
+        for (int l = l_begin; l < l_end; ++l) {
+            const int64_t c4 = ((int64_t)l * S + s0) >> 2;
+            Set nxt;
+            if (PF) {
+                if (l + 1 < l_end) load_set(nxt, l + 1);
+                else nxt = cur;
+            } else {
+                load_set(cur, l);
+            }
+            const u32x4 g = cur.g;
             u32x4 pv[NF];
 #pragma unroll
-            for (int k = 0; k < NF; ++k)
-                pv[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.f[k].plane) + c4);
-            u32x4 dv = {0, 0, 0, 0};
-            if (a.dp) dv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.dp) + c4);
+            for (int k = 0; k < NF; ++k) pv[k] = cur.pv[k];
+            const u32x4 dv = cur.dv;
             u32x4 wout, mout;
             uint32_t w0acc = 0, w1acc = 0;
             // The decisions are kept as wave-wide 64-bit lane masks in scalar registers (ballots) and combined by
@@ -2547,7 +2572,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
                 wout[j] = __builtin_amdgcn_inverse_ballot_w64(filtm[j]) ? 0xffffffffu : w;
                 mout[j] = m;
             }
-            if (a.dp) {
+            if ((ALIAS & 1) || a.dp) {
                 uint64_t bad = 0;
 #pragma unroll
                 for (int j = 0; j < CF_V; ++j) {
@@ -2641,6 +2666,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
                 for (int j = 0; j < CF_V; ++j) m8 |= ((mout[j] & 0x7fu) | ((mout[j] >> 24) & 0x80u)) << (8 * j);
                 __builtin_nontemporal_store(m8, reinterpret_cast<uint32_t*>(a.out.filter_mask8) + c4);
             }
+            if (PF) cur = nxt;
         }
     }
     if (DELTA) {  // one global atomic per non-zero entry of the block's delta table
@@ -3417,6 +3443,32 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             else if (n_filters == 4) { TRK_V2(4); }
             else if (n_filters == 5) { TRK_V2(5); }
             else { TRK_V2(6); }
+            // EXPERIMENT (TRK_V2_MODE bit 0: static plane aliasing, bit 1: next-locus prefetch)
+            {
+                const int mode = getenv("TRK_V2_MODE") ? atoi(getenv("TRK_V2_MODE")) : 0;
+                if (mode && n_filters == 3 && delta && !ratio) {
+                    // filters of one plane next to each other, the depth plane's first (stable)
+                    V2Filter tmp[V2_MAX_FILTERS];
+                    int n = 0;
+                    bool used[V2_MAX_FILTERS] = {false};
+                    for (int pass = 0; pass < 2; ++pass)
+                        for (int k = 0; k < n_filters; ++k) {
+                            if (used[k]) continue;
+                            if (pass == 0 && v.f[k].plane != (const void*)v.dp) continue;
+                            const void* pl = v.f[k].plane;
+                            for (int q = k; q < n_filters; ++q)
+                                if (!used[q] && v.f[q].plane == pl) { tmp[n++] = v.f[q]; used[q] = true; }
+                        }
+                    for (int k = 0; k < n_filters; ++k) v.f[k] = tmp[k];
+                    int alias = (v.dp && v.f[0].plane == (const void*)v.dp) ? 1 : 0;
+                    for (int k = 1; k < n_filters; ++k)
+                        if (v.f[k].plane == v.f[k - 1].plane) alias |= 1 << k;
+                    if (alias == 3 && (mode & 1))
+                        kv2 = (mode & 2) ? k_call_filter_v2<3, true, false, 3, 1> : k_call_filter_v2<3, true, false, 3, 0>;
+                    else if (mode & 2)
+                        kv2 = k_call_filter_v2<3, true, false, 0, 1>;
+                }
+            }
             // Grid: whole rounds of resident workgroups, and at least TRK_CF_MIN_ROUNDS (2) of them.  All workgroups
             // of ONE round run their prologue (class LUT), their stream and their flush at the same time, so the
             // memory system idles twice; from two rounds on the phases of different workgroups overlap.  Matters

@@ -50,6 +50,133 @@ class TorchComm:
         return [o.numpy()[:int(s[0])] for o, s in zip(outs, sizes)]
 
 
+class SocketGroup:
+    """Process group over plain TCP sockets -- rendezvous, barrier and small host-array collectives without torch.
+    Rank 0 listens on (addr, port) and is the hub: a collective is a gather of every rank's payload to rank 0 and a
+    broadcast of the result.  What crosses it is small (the 128-byte RCCL id, a few timings, dumpSTR's per-sample
+    counters: < 1 MB); bulk data goes through RCCL (``RcclComm``).  Same surface as ``TorchComm`` so the sharded
+    command lines and the tests can run on either."""
+
+    def __init__(self, rank=None, world=None, addr=None, port=None, timeout=300.0):
+        import os
+        import socket
+        import struct
+        import time
+        self.rank = int(os.environ.get('RANK', '0')) if rank is None else int(rank)
+        self.world = int(os.environ.get('WORLD_SIZE', '1')) if world is None else int(world)
+        addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
+        port = int(port) if port is not None else int(os.environ.get('MASTER_PORT', '29500')) + 17
+        self._struct = struct
+        self._peers = {}          # rank 0: rank -> socket
+        self._hub = None          # other ranks: socket to rank 0
+        if self.world <= 1:
+            return
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(self.world)
+            srv.settimeout(timeout)
+            while len(self._peers) < self.world - 1:
+                c, _a = srv.accept()
+                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                c.settimeout(None)
+                r = struct.unpack('<q', self._recv_exact(c, 8))[0]
+                if not (0 < r < self.world) or r in self._peers:
+                    c.close()
+                    raise OSError("rendezvous: unexpected rank %d" % r)
+                self._peers[r] = c
+            srv.close()
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    c = socket.create_connection((addr, port), timeout=10)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.1)
+            c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            c.settimeout(None)
+            c.sendall(struct.pack('<q', self.rank))
+            self._hub = c
+
+    @staticmethod
+    def _recv_exact(c, n):
+        buf = bytearray()
+        while len(buf) < n:
+            chunk = c.recv(min(n - len(buf), 1 << 20))
+            if not chunk:
+                raise OSError("peer closed the connection")
+            buf += chunk
+        return bytes(buf)
+
+    def _send(self, c, payload):
+        c.sendall(self._struct.pack('<q', len(payload)) + payload)
+
+    def _recv(self, c):
+        n = self._struct.unpack('<q', self._recv_exact(c, 8))[0]
+        return self._recv_exact(c, n)
+
+    def _gather(self, payload):
+        """rank 0: list of every rank's payload in rank order; other ranks: None (payload sent)."""
+        if self.world <= 1:
+            return [payload]
+        if self.rank == 0:
+            return [payload] + [self._recv(self._peers[r]) for r in range(1, self.world)]
+        self._send(self._hub, payload)
+        return None
+
+    def _bcast(self, payload):
+        if self.world <= 1:
+            return payload
+        if self.rank == 0:
+            for r in range(1, self.world):
+                self._send(self._peers[r], payload)
+            return payload
+        return self._recv(self._hub)
+
+    def broadcast_bytes(self, payload):
+        """``payload`` of rank 0 on every rank."""
+        return self._bcast(payload if self.rank == 0 else b'')
+
+    def barrier(self):
+        self._gather(b'')
+        self._bcast(b'')
+
+    def allgather_bytes(self, arr):
+        import pickle
+        mine = np.ascontiguousarray(arr, dtype=np.uint8).reshape(-1).tobytes()
+        parts = self._gather(mine)
+        blob = self._bcast(pickle.dumps(parts) if parts is not None else b'')
+        return [np.frombuffer(p, dtype=np.uint8) for p in pickle.loads(blob)]
+
+    def _allreduce(self, arr, dtype, fold):
+        a = np.ascontiguousarray(arr, dtype=dtype)
+        parts = self._gather(a.tobytes())
+        if parts is not None:
+            acc = np.frombuffer(parts[0], dtype=dtype).copy()
+            for p in parts[1:]:
+                acc = fold(acc, np.frombuffer(p, dtype=dtype))
+            parts = acc.tobytes()
+        return np.frombuffer(self._bcast(parts or b''), dtype=dtype).reshape(a.shape).copy()
+
+    def allreduce_sum_i64(self, arr):
+        return self._allreduce(arr, np.int64, np.add)
+
+    def allreduce_max_f64(self, arr):
+        return self._allreduce(arr, np.float64, np.maximum)
+
+    def close(self):
+        for c in list(self._peers.values()) + ([self._hub] if self._hub else []):
+            try:
+                c.close()
+            except OSError:
+                pass
+        self._peers, self._hub = {}, None
+
+
 class RcclComm:
     """Collectives on DeviceArrays through libtrk (trk_allreduce_sum_i64 / trk_allgather)."""
 
@@ -133,36 +260,11 @@ def set_comm(comm):
 
 def _exchange_id(uid, rank, world, addr, port):
     """Rank 0 hands the 128-byte RCCL id to every other rank over plain TCP (no torch needed)."""
-    import socket
-    import time
-    if rank == 0:
-        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        srv.bind((addr, port))
-        srv.listen(world)
-        for _ in range(world - 1):
-            c, _a = srv.accept()
-            c.sendall(uid)
-            c.close()
-        srv.close()
-        return uid
-    deadline = time.time() + 300
-    while True:
-        try:
-            c = socket.create_connection((addr, port), timeout=10)
-            break
-        except OSError:
-            if time.time() > deadline:
-                raise
-            time.sleep(0.2)
-    buf = b''
-    while len(buf) < 128:
-        chunk = c.recv(128 - len(buf))
-        if not chunk:
-            raise OSError("rendezvous closed early")
-        buf += chunk
-    c.close()
-    return buf
+    g = SocketGroup(rank, world, addr, port)
+    try:
+        return g.broadcast_bytes(uid if rank == 0 else b'')
+    finally:
+        g.close()
 
 
 def get_comm():
