@@ -250,6 +250,16 @@ typedef struct {
  * planes are produced interleaved).                                                                           */
 int trk_planarize(trk_ctx* ctx, const void* src, void* dst, int64_t n_cells, int32_t ncol);
 
+/* Measurement aids (bench.py; no counterpart in the reference).
+ * trk_stream_probe: the call-filter pass's stream shape with no arithmetic -- three [n_loci, n_samples] 4-byte planes
+ * read, two written, 16 bytes per lane, the pass's tiling and grid -- `reps` launches timed with HIP events on the
+ * selected queue; *avg_ms = average launch time.  out0 / out1 are overwritten.  What THIS box's memory system gives
+ * a 12 B-in / 8 B-out stream (boxes of one pool differ by 15 %: profiles/r03_notes.md).
+ * trk_device_clocks: the device's reported peak engine / memory clocks (kHz) and memory bus width (bits). */
+int trk_stream_probe(trk_ctx* ctx, const void* in0, const void* in1, const void* in2, void* out0, void* out1,
+                     int64_t n_loci, int64_t n_samples, int32_t reps, float* avg_ms);
+int trk_device_clocks(trk_ctx* ctx, int32_t* sclk_khz, int32_t* mclk_khz, int32_t* mem_bus_bits);
+
 /* Filter opcodes: one per distinct arithmetic in dumpSTR/filters.py.           */
 enum {
     TRK_F_LT = 1,          /* CallFilterMinValue :363-367  value < thr (in the plane's dtype) */

@@ -193,3 +193,76 @@ def test_dumpstr_batch_pipeline_gpu(tmp_path, name):
 def test_statstr_batch_pipeline_gpu(tmp_path, path, vcftype):
     from trtools_amd import runtime
     _run_stat(tmp_path, runtime.get_compute(), path, vcftype, hwep=('many_samples' in path or 'synth_hipstr' in path))
+
+
+def _strip_format_key(src, dst, key, which):
+    """Copy of the text VCF ``src`` in which the records ``which`` (0-based indices) lose FORMAT key ``key``."""
+    import gzip
+    op = gzip.open if src.endswith('.gz') else open
+    n = -1
+    with op(src, 'rt') as fin, open(dst, 'w') as fout:
+        for line in fin:
+            if line.startswith('#'):
+                fout.write(line)
+                continue
+            n += 1
+            if n in which:
+                f = line.rstrip('\n').split('\t')
+                keys = f[8].split(':')
+                i = keys.index(key)
+                f[8] = ':'.join(k for k in keys if k != key)
+                f[9:] = [':'.join(v for j, v in enumerate(s.split(':')) if j != i) if ':' in s else s for s in f[9:]]
+                line = '\t'.join(f) + '\n'
+            fout.write(line)
+
+
+@pytest.mark.parametrize('which', [{0}, {7}], ids=['first_record', 'later_record'])
+def test_dumpstr_record_without_a_filtered_format_key_fails_as_the_reference_does(tmp_path, which):
+    """a HipSTR record without DP under --hipstr-min-call-DP.  The reference raises KeyError at
+    `record.format[self.field]` (filters.py:327-409); the batch pipeline used to fill the plane with the missing marker,
+    null every call and flag the locus NO_CALLS_REMAINING.  It must decline the batch, and the per-record loop must
+    then fail exactly as with TRK_DUMPSTR_BATCH=0."""
+    from oracle_compute import OracleCompute
+    from trtools_amd import runtime
+    from trtools_amd.dumpSTR import dumpSTR
+    src = os.path.join(SYN, 'synth_hipstr.vcf')
+    vcf = str(tmp_path / 'nodp.vcf')
+    _strip_format_key(src, vcf, 'DP', which)
+    old = runtime.set_compute(OracleCompute())
+    try:
+        outcomes = []
+        for mode in ('1', '0'):
+            os.environ['TRK_DUMPSTR_BATCH'] = mode
+            try:
+                rc = dumpSTR.main(dump_args(str(tmp_path / ('o' + mode)), vcf, vcftype='hipstr', hipstr_min_call_DP=20))
+                outcomes.append(('rc', rc))
+            except Exception as e:      # noqa: BLE001 -- the two modes must fail the same way
+                outcomes.append((type(e).__name__, str(e)))
+            finally:
+                del os.environ['TRK_DUMPSTR_BATCH']
+    finally:
+        runtime.set_compute(old)
+    assert outcomes[0] == outcomes[1], outcomes
+    assert outcomes[0][0] == 'KeyError' and 'DP' in outcomes[0][1], outcomes
+
+
+def test_dumpstr_depth_field_is_judged_per_record(tmp_path):
+    """dumpSTR.py:688-695 looks for DP (else LC) in EVERY record: a file in which some records lack DP and no filter
+    reads it gives the same logs through the batch pipeline (which hands such a batch to the per-record loop) and
+    through the loop itself."""
+    from oracle_compute import OracleCompute
+    from trtools_amd import runtime
+    from trtools_amd.dumpSTR import dumpSTR
+    src = os.path.join(SYN, 'synth_hipstr.vcf')
+    vcf = str(tmp_path / 'somedp.vcf')
+    _strip_format_key(src, vcf, 'DP', {3, 4, 11})
+    old = runtime.set_compute(OracleCompute())
+    try:
+        def go(mode):
+            out = str(tmp_path / ('p' + mode))
+            assert dumpSTR.main(dump_args(out, vcf, vcftype='hipstr', hipstr_min_call_Q=0.9)) == 0
+            return tuple(open(out + ext).read() for ext in ('.vcf', '.samplog.tab', '.loclog.tab'))
+        a, b = _both(go, 'TRK_DUMPSTR_BATCH')
+    finally:
+        runtime.set_compute(old)
+    assert a == b

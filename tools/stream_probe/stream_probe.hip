@@ -102,6 +102,59 @@ __global__ __launch_bounds__(256) void k_cf(Streams s, int L, int S4, int lpb, u
     if (dummy && lpb < 0) dummy[threadIdx.x] = 0;
 }
 
+// the product shape with data of the product's kind.  MODE 0: outputs = constants derived from the loop counter;
+// 1: out0 = in0 (the masked genotypes are the genotypes), out1 = sparse word (a few % non-zero, like the filter mask);
+// 2: out0 = in0, out1 = in1 ^ in2 (dense random words); 3: both outputs dense random
+template <int MODE>
+__global__ __launch_bounds__(256) void k_cf_data(Streams s, int L, int S4, int lpb, uint32_t thr) {
+    extern __shared__ uint32_t dummy[];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= S4) return;
+    const int l0 = blockIdx.y * lpb, l1 = min(L, l0 + lpb);
+    for (int l = l0; l < l1; ++l) {
+        const size_t o = (size_t)l * S4 + c;
+        const u32x4 a = __builtin_nontemporal_load(s.in[0] + o), b = __builtin_nontemporal_load(s.in[1] + o),
+                    d = __builtin_nontemporal_load(s.in[2] + o);
+        u32x4 r0, r1;
+        if (MODE == 0) {
+            r0 = (u32x4){(uint32_t)l, 1u, 2u, 3u};
+            r1 = r0 + 1u;
+            if ((a.x ^ b.x ^ d.x) == 0x12345u && (a.y ^ b.y ^ d.y) == 0x54321u) r1.x = 7u;   // keep the loads
+        } else if (MODE == 1) {
+            r0 = a;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool hit = (b[j] & 0xffffu) < thr;
+                r1[j] = hit ? 5u : ((d[j] & 0xffu) == 0u ? 0x80000000u : 0u);
+                if (hit) r0[j] = 0xffffffffu;
+            }
+        } else if (MODE == 2) {
+            r0 = a;
+            r1 = b ^ d;
+        } else {
+            r0 = a ^ b;
+            r1 = b ^ d;
+        }
+        __builtin_nontemporal_store(r0, s.out[0] + o);
+        __builtin_nontemporal_store(r1, s.out[1] + o);
+    }
+    if (dummy && lpb < 0) dummy[threadIdx.x] = 0;
+}
+
+__global__ void k_fill(uint32_t* p, size_t n, uint32_t seed, int kind) {
+    // kind 0: uniform random words; 1: small-integer pairs in 16-bit halves (genotype-like); 2: small ints (depth-like)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t z = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        uint32_t v = (uint32_t)z;
+        if (kind == 1) v = ((v & 7u) | (((v >> 8) & 7u) << 16));
+        else if (kind == 2) v = 10u + (v & 63u);
+        p[i] = v;
+    }
+}
+
 // one wave per locus row, 4 waves per workgroup, U chunks in flight per lane
 template <int U, int NIN, int NOUT, bool NT>
 __global__ __launch_bounds__(256) void k_row(Streams s, int L, int S4, uint32_t* sink) {
@@ -216,6 +269,39 @@ int main(int argc, char** argv) {
         return lpb2 < lpb ? lpb2 : lpb;
     };
     const double b5 = 5.0 * plane, b3 = 3.0 * plane, b2 = 2.0 * plane;
+    if (argc > 4 && !strcmp(argv[4], "data")) {
+        // does the DATA matter?  product shape, product grid; inputs constant bytes / realistic / random
+        const int lpb = lpb_for(5), gy = (L + lpb - 1) / lpb;
+        const size_t lds5 = 30 * 1024;
+        const char* fills[3] = {"inputs memset bytes", "inputs genotype-/depth-like small integers", "inputs uniform random words"};
+        for (int f = 0; f < 3; ++f) {
+            if (f > 0)
+                for (int k = 0; k < 3; ++k) {
+                    hipLaunchKernelGGL(k_fill, dim3(ncu * 16), dim3(256), 0, 0, (uint32_t*)buf[k], n * 4, 77u + k,
+                                       f == 2 ? 0 : (k == 0 ? 1 : 2));
+                }
+            CK(hipDeviceSynchronize());
+            char nm[160];
+            snprintf(nm, sizeof nm, "data: %s; outputs constants", fills[f]);
+            run(nm, b5, [&] { hipLaunchKernelGGL((k_cf_data<0>), dim3(gx, gy), dim3(256), lds5, 0, s, L, S4, lpb, 2000u); });
+            snprintf(nm, sizeof nm, "data: %s; out0 = in0, out1 sparse (3 %% set)", fills[f]);
+            run(nm, b5, [&] { hipLaunchKernelGGL((k_cf_data<1>), dim3(gx, gy), dim3(256), lds5, 0, s, L, S4, lpb, f == 1 ? 12u : 2000u); });
+            snprintf(nm, sizeof nm, "data: %s; out0 = in0, out1 = in1 ^ in2", fills[f]);
+            run(nm, b5, [&] { hipLaunchKernelGGL((k_cf_data<2>), dim3(gx, gy), dim3(256), lds5, 0, s, L, S4, lpb, 0u); });
+            snprintf(nm, sizeof nm, "data: %s; both outputs xor of inputs", fills[f]);
+            run(nm, b5, [&] { hipLaunchKernelGGL((k_cf_data<3>), dim3(gx, gy), dim3(256), lds5, 0, s, L, S4, lpb, 0u); });
+        }
+        // the plain copy / read figures on random data
+        run("random data: flat 1in/1out nt (copy), 16 x CUs", b2, [&] { hipLaunchKernelGGL((k_flat<1, 1, true>), dim3(ncu * 16), dim3(256), 0, 0, s, n, sink); });
+        run("random data: flat 3in/0out nt (read), 16 x CUs", b3, [&] { hipLaunchKernelGGL((k_flat<3, 0, true>), dim3(ncu * 16), dim3(256), 0, 0, s, n, sink); });
+        run("random data: row<2> 1in/0out nt (count kernel's stream)", 1.0 * plane, [&] { hipLaunchKernelGGL((k_row<2, 1, 0, true>), dim3((L + 3) / 4), dim3(256), 0, 0, s, L, S4, sink); });
+        printf("JSON [");
+        for (size_t i = 0; i < results.size(); ++i)
+            printf("%s{\"name\": \"%s\", \"min_ms\": %.4f, \"avg_ms\": %.4f, \"tbps\": %.3f}", i ? ", " : "",
+                   results[i].name.c_str(), results[i].mn, results[i].avg, results[i].bytes / results[i].avg * 1e-9);
+        printf("]\n");
+        return 0;
+    }
     if (argc > 4 && !strcmp(argv[4], "sweep")) {
         // resident workgroups per CU (capped by dynamic LDS) x loci in flight x locus assignment, grid = exactly the
         // resident set (persistent workgroups)

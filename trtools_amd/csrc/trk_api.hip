@@ -790,6 +790,41 @@ int trk_planarize(trk_ctx* ctx, const void* src, void* dst, int64_t n_cells, int
     return TRK_OK;
 }
 
+int trk_stream_probe(trk_ctx* ctx, const void* in0, const void* in1, const void* in2, void* out0, void* out1,
+                     int64_t n_loci, int64_t n_samples, int32_t reps, float* avg_ms) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (!in0 || !in1 || !in2 || !out0 || !out1 || !avg_ms || n_loci < 1 || n_samples < 4 || n_samples % 4 || reps < 1)
+        return fail(ctx, TRK_ERR_ARG, "stream probe arguments");
+    (void)hipSetDevice(ctx->device);
+    const void* in[3] = {in0, in1, in2};
+    void* out[2] = {out0, out1};
+    hipEvent_t e0, e1;
+    HIPCHK(ctx, hipEventCreate(&e0));
+    HIPCHK(ctx, hipEventCreate(&e1));
+    hipError_t e = trk::launch_stream_probe(in, 3, out, 2, n_loci, n_samples, ctx->n_cu, ctx->s());   // warm-up
+    if (e == hipSuccess) e = hipEventRecord(e0, ctx->s());
+    for (int r = 0; r < reps && e == hipSuccess; ++r)
+        e = trk::launch_stream_probe(in, 3, out, 2, n_loci, n_samples, ctx->n_cu, ctx->s());
+    if (e == hipSuccess) e = hipEventRecord(e1, ctx->s());
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return fail(ctx, TRK_ERR_HIP, "trk_stream_probe: %s", hipGetErrorString(e));
+    *avg_ms = ms / (float)reps;
+    return TRK_OK;
+}
+
+int trk_device_clocks(trk_ctx* ctx, int32_t* sclk_khz, int32_t* mclk_khz, int32_t* mem_bus_bits) {
+    if (!ctx) return TRK_ERR_ARG;
+    int v = 0;
+    if (sclk_khz) { HIPCHK(ctx, hipDeviceGetAttribute(&v, hipDeviceAttributeClockRate, ctx->device)); *sclk_khz = v; }
+    if (mclk_khz) { HIPCHK(ctx, hipDeviceGetAttribute(&v, hipDeviceAttributeMemoryClockRate, ctx->device)); *mclk_khz = v; }
+    if (mem_bus_bits) { HIPCHK(ctx, hipDeviceGetAttribute(&v, hipDeviceAttributeMemoryBusWidth, ctx->device)); *mem_bus_bits = v; }
+    return TRK_OK;
+}
+
 double trk_student_t_two_sided(double t, double df) { return trkmath::student_t_two_sided(t, df); }
 
 double trk_binomtest_two_sided(int64_t k, int64_t n, double p) {

@@ -2430,6 +2430,20 @@ constexpr int V2_MAX_FILTERS = 6;
 #define TRK_V2_WRED 1
 #endif
 constexpr bool V2_WRED = TRK_V2_WRED != 0;
+// -DTRK_V2_ABL=<bits>: timing-only ablation builds of k_call_filter_v2 (wrong results; tools/v2_ablation.sh):
+// 1 no filter compares, 2 no per-sample counter adds, 4 no depth statistics, 8 no per-locus delta block,
+// 16 no decision logic at all (outputs are copies of the inputs), 32 no block prologue / delta flush,
+// 64 everything is computed but the stored words do not depend on it (GT' = GT, mask = 0)
+#ifndef TRK_V2_ABL
+#define TRK_V2_ABL 0
+#endif
+constexpr int V2_ABL = TRK_V2_ABL;
+// -DTRK_V2_HIST=<K>: TIMING EXPERIMENT -- the call-filter pass also histograms every call (K bank-spread copies per
+// bin, the count kernel's sentinel / equal-halves popcounts) into a scratch LDS table that nobody reads
+#ifndef TRK_V2_HIST
+#define TRK_V2_HIST 0
+#endif
+constexpr int V2_HIST = TRK_V2_HIST;
 struct V2Args {
     trk_batch b;
     V2Filter f[V2_MAX_FILTERS];
@@ -2460,6 +2474,8 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
     uint32_t* dtab = v2lds;                                        // [loci][nal + 3]
     uint32_t* lutb = dtab + (size_t)a.loci_per_block * dstride;    // [loci][nal]
     int32_t* linfo = reinterpret_cast<int32_t*>(lutb + (size_t)a.loci_per_block * nal);  // [loci][2]
+    uint32_t* hist = reinterpret_cast<uint32_t*>(linfo + (size_t)a.loci_per_block * CF_LINFO);  // V2_HIST: [loci][(nal + 3) * K]
+    const int hstride = (nal + 3) * V2_HIST;
     // per-sample counters live in registers across ALL the locus blocks this workgroup walks
     // (blockIdx.y, + gridDim.y, ...) and are flushed once
     uint32_t numcalls[CF_V] = {0, 0, 0, 0}, dpmiss[CF_V] = {0, 0, 0, 0};
@@ -2481,7 +2497,9 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
     const int l_begin = by * a.loci_per_block;
     const int l_end = min(L, l_begin + a.loci_per_block);
     const int nl = l_end - l_begin;
-    if (DELTA) {
+    if (DELTA && !(V2_ABL & 32)) {
+        if (V2_HIST)
+            for (int i = tid; i < nl * hstride; i += CF_THREADS) hist[i] = 0;
         for (int i = tid; i < nl * dstride; i += CF_THREADS) dtab[i] = 0;
         cf_build_lut(a.b, l_begin, nl, nal, tid, lutb, linfo);
     }
@@ -2531,7 +2549,10 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
 #pragma unroll
             for (int k = 0; k < NF; ++k) {
                 const V2Filter& f = a.f[k];
-                if (RATIO && f.kind == 4) {
+                if (V2_ABL & 1) {
+#pragma unroll
+                    for (int j = 0; j < CF_V; ++j) hm[k][j] = 0;
+                } else if (RATIO && f.kind == 4) {
                     // (deciding from x - thr * y and dividing only near ties was measured: 7.41 vs 7.19 ms, the
                     // kernel has the issue slots for the division; profiles/r01_notes.md)
 #pragma unroll
@@ -2563,16 +2584,20 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
                 for (int k = 0; k < NF; ++k) {
                     const uint64_t h = hm[k][j] & (calledm | nn[k]);
                     m |= __builtin_amdgcn_inverse_ballot_w64(h) ? bitv[k] : 0u;
-                    add_mask(fc[k][j], h & calledm);  // dumpSTR.py:661
+                    if (!(V2_ABL & 2)) add_mask(fc[k][j], h & calledm);  // dumpSTR.py:661
                     anyhit |= h;
                 }
                 passm[j] = calledm & ~anyhit;   // mask word == 0: dumpSTR.py:686
                 filtm[j] = calledm & anyhit;    // called and not passing: dumpSTR.py:715-727
-                add_mask(numcalls[j], passm[j]);
+                if (!(V2_ABL & 2)) add_mask(numcalls[j], passm[j]);
                 wout[j] = __builtin_amdgcn_inverse_ballot_w64(filtm[j]) ? 0xffffffffu : w;
                 mout[j] = m;
             }
-            if ((ALIAS & 1) || a.dp) {
+            if (V2_ABL & 16) {
+#pragma unroll
+                for (int j = 0; j < CF_V; ++j) { wout[j] = g[j]; mout[j] = pv[0][j] ^ pv[NF - 1][j]; }
+            }
+            if (!(V2_ABL & 4) && ((ALIAS & 1) || a.dp)) {
                 uint64_t bad = 0;
 #pragma unroll
                 for (int j = 0; j < CF_V; ++j) {
@@ -2595,8 +2620,36 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
                     }
                 }
             }
+            if (V2_HIST && DELTA) {
+                const int li = l - l_begin;
+                const uint32_t A2 = (uint32_t)linfo[CF_LINFO * li] + 2u;
+                const uint32_t amax2 = A2 | (A2 << 16);
+                const uint32_t hb = (uint32_t)(uintptr_t)(lds_u32p)(hist + li * hstride + (tid & (V2_HIST - 1)));
+                const uint32_t kbytes = 4u * V2_HIST;
+                uint32_t e0 = 0, e1 = 0, e2 = 0;
+#pragma unroll
+                for (int j = 0; j < CF_V; ++j) {
+                    u16x2 u = __builtin_bit_cast(u16x2, g[j]) + (u16x2){2, 2};
+                    u16x2 t2 = __builtin_elementwise_min(u, __builtin_bit_cast(u16x2, amax2));
+                    const uint32_t t = __builtin_bit_cast(uint32_t, t2);
+                    __hip_atomic_fetch_add((lds_u32p)(uintptr_t)mad16_lo(t, kbytes, hb), 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add((lds_u32p)(uintptr_t)mad16_hi(t, kbytes, hb), 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                    e0 += (uint32_t)__popcll(halves_equal(t)) + ((uint32_t)__popcll(__ballot(t == 0x00000000u)) << 16);
+                    e1 += (uint32_t)__popcll(__ballot(t == 0x00000001u)) + ((uint32_t)__popcll(__ballot(t == 0x00010000u)) << 16);
+                    e2 += (uint32_t)__popcll(__ballot(t == 0x00010001u));
+                }
+                if (leader) {
+                    uint32_t* tl = hist + li * hstride + (nal + 2) * V2_HIST;
+                    atomicAdd(&tl[0], e0);
+                    atomicAdd(&tl[1], e1);
+                    atomicAdd(&tl[2], e2);
+                }
+            }
             uint32_t* tab = dtab;
-            if (DELTA && V2_WRED) {
+            if (V2_ABL & 8) {
+            } else if (DELTA && V2_WRED) {
                 // the per-locus words are sums of lane flags: count them from the masks, one LDS atomic per wave
                 const int li = l - l_begin;
                 tab = dtab + li * dstride;
@@ -2654,9 +2707,17 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
                     }
                 }
             }
-            if (DELTA && V2_WRED && leader) {
+            if (DELTA && V2_WRED && leader && !(V2_ABL & 8)) {
                 if (w0acc) atomicAdd(&tab[nal + V2_W0], w0acc);
                 if (w1acc) atomicAdd(&tab[nal + V2_W1], w1acc);
+            }
+            if (V2_ABL & 64) {   // the decisions are made (they feed the counters), but what is stored does not depend on them
+#pragma unroll
+                for (int j = 0; j < CF_V; ++j) {
+                    numcalls[j] += (wout[j] != g[j]) + (mout[j] != 0u);
+                    wout[j] = g[j];
+                    mout[j] = 0u;
+                }
             }
             if (a.out.gt_out) __builtin_nontemporal_store(wout, reinterpret_cast<u32x4*>(a.out.gt_out) + c4);
             if (a.out.filter_mask) __builtin_nontemporal_store(mout, reinterpret_cast<u32x4*>(a.out.filter_mask) + c4);
@@ -2669,7 +2730,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
             if (PF) cur = nxt;
         }
     }
-    if (DELTA) {  // one global atomic per non-zero entry of the block's delta table
+    if (DELTA && !(V2_ABL & 32)) {  // one global atomic per non-zero entry of the block's delta table
         __syncthreads();
         const uint32_t rcp = (uint32_t)((0x100000000ull + (uint32_t)dstride - 1u) / (uint32_t)dstride);  // i / dstride
         for (int i = tid; i < nl * dstride; i += CF_THREADS) {
@@ -2860,6 +2921,33 @@ __global__ __launch_bounds__(256) void k_locus_filter(int L, const int32_t* __re
 // ---------------------------------------------------------------------------
 // k_synth : synthetic diploid genotypes + HipSTR-shaped FORMAT planes
 // (bit-for-bit twin: trtools_amd/synth.py::cells_numpy)
+// ---------------------------------------------------------------------------
+// k_stream_probe : the call-filter pass's stream shape with no arithmetic -- column-owner tiling (thread = one
+// 16-byte chunk column, workgroup = 1024 samples x a block of loci), n_in nontemporal 16-byte input streams OR-ed
+// together, n_out output streams.  What the memory system of THIS box gives a 12 B-in / 8 B-out stream is the
+// yardstick the bench prints next to k_call_filter (boxes differ by 15 %; profiles/r03_notes.md section 1).
+// ---------------------------------------------------------------------------
+struct ProbeArgs {
+    const u32x4* in[4];
+    u32x4* out[4];
+};
+template <int NIN, int NOUT>
+__global__ __launch_bounds__(256) void k_stream_probe(ProbeArgs s, int L, int S4, int lpb) {
+    extern __shared__ uint32_t probe_lds[];   // sized by the launcher to cap the resident workgroups per CU
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= S4) return;
+    const int l0 = blockIdx.y * lpb, l1 = min(L, l0 + lpb);
+    for (int l = l0; l < l1; ++l) {
+        const size_t o = (size_t)l * S4 + c;
+        u32x4 r = {(uint32_t)l, 1u, 2u, 3u};
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) r |= __builtin_nontemporal_load(s.in[k] + o);
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) __builtin_nontemporal_store(r + (uint32_t)k, s.out[k] + o);
+    }
+    if (lpb < 0) probe_lds[threadIdx.x] = 0;
+}
+
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     z ^= z >> 30;
@@ -3421,15 +3509,15 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             v.dbg = a.dbg;
             size_t lds2 = 0;
             if (delta) {
-                const size_t per_locus = ((size_t)2 * b.max_alleles + V2_EXTRA + CF_LINFO) * sizeof(uint32_t);
-                int max_lpb = (int)((32 * 1024) / per_locus);
+                const size_t per_locus = ((size_t)2 * b.max_alleles + V2_EXTRA + CF_LINFO + (size_t)(b.max_alleles + 3) * V2_HIST) * sizeof(uint32_t);
+                int max_lpb = (int)(((V2_HIST ? 30 : 32) * 1024) / per_locus);
                 if (lpb > max_lpb) lpb = max_lpb;
                 lds2 = (size_t)lpb * per_locus;
             }
             if (const char* e = getenv("TRK_CF_LPB")) {
                 int q = atoi(e);
                 if (q > 0 && (!delta || q <= lpb)) lpb = q;
-                if (delta) lds2 = (size_t)lpb * ((size_t)2 * b.max_alleles + V2_EXTRA + CF_LINFO) * sizeof(uint32_t);
+                if (delta) lds2 = (size_t)lpb * ((size_t)2 * b.max_alleles + V2_EXTRA + CF_LINFO + (size_t)(b.max_alleles + 3) * V2_HIST) * sizeof(uint32_t);
             }
             void (*kv2)(V2Args) = nullptr;
 #define TRK_V2(NFV)                                                                                   \
@@ -3443,11 +3531,14 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             else if (n_filters == 4) { TRK_V2(4); }
             else if (n_filters == 5) { TRK_V2(5); }
             else { TRK_V2(6); }
-            // EXPERIMENT (TRK_V2_MODE bit 0: static plane aliasing, bit 1: next-locus prefetch)
+            // Static plane sharing (template ALIAS): the filters of one plane are made neighbours, the depth plane's
+            // first, and the instantiation whose alias pattern matches reads each plane ONCE per locus (min-DP /
+            // max-DP / depth sums: one 16-byte load instead of three; same-box A/B 3.85 -> 3.70 ms on a fast box,
+            // 4.34 -> 4.28 on a slow one, profiles/r03_notes.md).  TRK_V2_MODE=0 keeps one load per filter;
+            // bit 1 of TRK_V2_MODE adds the next-locus prefetch (measured: no gain, kept for A/B runs at NF = 3).
             {
-                const int mode = getenv("TRK_V2_MODE") ? atoi(getenv("TRK_V2_MODE")) : 0;
-                if (mode && n_filters == 3 && delta && !ratio) {
-                    // filters of one plane next to each other, the depth plane's first (stable)
+                const int mode = getenv("TRK_V2_MODE") ? atoi(getenv("TRK_V2_MODE")) : 1;
+                if (mode && delta) {
                     V2Filter tmp[V2_MAX_FILTERS];
                     int n = 0;
                     bool used[V2_MAX_FILTERS] = {false};
@@ -3459,14 +3550,32 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
                             for (int q = k; q < n_filters; ++q)
                                 if (!used[q] && v.f[q].plane == pl) { tmp[n++] = v.f[q]; used[q] = true; }
                         }
-                    for (int k = 0; k < n_filters; ++k) v.f[k] = tmp[k];
-                    int alias = (v.dp && v.f[0].plane == (const void*)v.dp) ? 1 : 0;
-                    for (int k = 1; k < n_filters; ++k)
-                        if (v.f[k].plane == v.f[k - 1].plane) alias |= 1 << k;
-                    if (alias == 3 && (mode & 1))
-                        kv2 = (mode & 2) ? k_call_filter_v2<3, true, false, 3, 1> : k_call_filter_v2<3, true, false, 3, 0>;
-                    else if (mode & 2)
-                        kv2 = k_call_filter_v2<3, true, false, 0, 1>;
+                    int alias = (v.dp && tmp[0].plane == (const void*)v.dp) ? 1 : 0;
+                    if (n_filters >= 2 && tmp[1].plane == tmp[0].plane) alias |= 2;
+                    // (further pairs of one plane keep their own loads: only bit 0 / bit 1 patterns are instantiated)
+                    void (*ka)(V2Args) = nullptr;
+#define TRK_V2A(NFV, RT)                                                                          \
+    ka = alias == 3 ? (NFV >= 2 ? k_call_filter_v2<NFV, true, RT, (NFV >= 2 ? 3 : 1), 0> : nullptr) \
+       : alias == 1 ? k_call_filter_v2<NFV, true, RT, 1, 0> : nullptr
+                    if (!ratio) {
+                        if (n_filters == 1) { TRK_V2A(1, false); }
+                        else if (n_filters == 2) { TRK_V2A(2, false); }
+                        else if (n_filters == 3) { TRK_V2A(3, false); }
+                        else if (n_filters == 4) { TRK_V2A(4, false); }
+                    } else {
+                        if (n_filters == 3) { TRK_V2A(3, true); }
+                        else if (n_filters == 4) { TRK_V2A(4, true); }
+                        else if (n_filters == 5) { TRK_V2A(5, true); }
+                        else if (n_filters == 6) { TRK_V2A(6, true); }
+                    }
+#undef TRK_V2A
+                    if ((mode & 2) && n_filters == 3 && !ratio)
+                        ka = alias == 3 ? k_call_filter_v2<3, true, false, 3, 1> : k_call_filter_v2<3, true, false, 0, 1>;
+                    if (ka) {
+                        if (!((mode & 2) && alias != 3))
+                            for (int k = 0; k < n_filters; ++k) v.f[k] = tmp[k];
+                        kv2 = ka;
+                    }
                 }
             }
             // Grid: whole rounds of resident workgroups, and at least TRK_CF_MIN_ROUNDS (2) of them.  All workgroups
@@ -3476,7 +3585,7 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             // 0.77 ms; 2560 of 49 loci 0.63 ms); at 100k loci the rule changes 6.7 rounds into 7.
             if (!getenv("TRK_CF_LPB")) {
                 int occ = 0;
-                const size_t lds_max = delta ? (size_t)lpb * ((size_t)2 * b.max_alleles + V2_EXTRA + CF_LINFO) * 4 : 0;
+                const size_t lds_max = delta ? (size_t)lpb * ((size_t)2 * b.max_alleles + V2_EXTRA + CF_LINFO + (size_t)(b.max_alleles + 3) * V2_HIST) * 4 : 0;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kv2, CF_THREADS, lds_max) != hipSuccess || occ < 1)
                     occ = 4;
                 int min_rounds = 2;
@@ -3492,7 +3601,7 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
                     if (lpb2 < 8) lpb2 = L < 8 ? L : 8;      // a block's fixed cost needs some loci to spread over
                     if (lpb2 < lpb) lpb = lpb2;
                 }
-                if (delta) lds2 = (size_t)lpb * ((size_t)2 * b.max_alleles + V2_EXTRA + CF_LINFO) * sizeof(uint32_t);
+                if (delta) lds2 = (size_t)lpb * ((size_t)2 * b.max_alleles + V2_EXTRA + CF_LINFO + (size_t)(b.max_alleles + 3) * V2_HIST) * sizeof(uint32_t);
             }
             gy = (L + lpb - 1) / lpb;
             v.loci_per_block = lpb;
@@ -3638,6 +3747,28 @@ hipError_t launch_synth_gangstr(const trk_synth_spec& sp, const int16_t* gt, con
     if (blocks > (int64_t)n_cu * 32) blocks = (int64_t)n_cu * 32;
     hipLaunchKernelGGL(k_synth_gangstr, dim3((int)blocks), dim3(256), 0, stream, sp, gt, dp, allele_repcn, qexp,
                        repcn, rc, repci);
+    return hipGetLastError();
+}
+
+hipError_t launch_stream_probe(const void* const* in, int n_in, void* const* out, int n_out, int64_t n_loci,
+                               int64_t n_samples, int n_cu, hipStream_t stream) {
+    if (n_in != 3 || n_out != 2 || n_samples % 4) return hipErrorInvalidValue;
+    ProbeArgs a = {};
+    for (int k = 0; k < n_in; ++k) a.in[k] = static_cast<const u32x4*>(in[k]);
+    for (int k = 0; k < n_out; ++k) a.out[k] = static_cast<u32x4*>(out[k]);
+    const int S4 = (int)(n_samples / 4), L = (int)n_loci;
+    const int gx = (S4 + 255) / 256;
+    // the call-filter pass's geometry: 5 workgroups per CU (capped here by 30 KiB of dynamic LDS), whole rounds
+    const long slots = (long)n_cu * 5;
+    int lpb = 117;
+    long rounds = ((long)gx * ((L + lpb - 1) / lpb) + slots - 1) / slots;
+    if (rounds < 2) rounds = 2;
+    long gyr = rounds * slots / gx;
+    if (gyr < 1) gyr = 1;
+    const int lpb2 = (int)((L + gyr - 1) / gyr);
+    if (lpb2 >= 1 && lpb2 < lpb) lpb = lpb2;
+    const int gy = (L + lpb - 1) / lpb;
+    hipLaunchKernelGGL((k_stream_probe<3, 2>), dim3(gx, gy), dim3(256), 30 * 1024, stream, a, L, S4, lpb);
     return hipGetLastError();
 }
 

@@ -429,7 +429,18 @@ class _Run:
         if self.world > 1 and self.batch_no % self.world != self.rank:
             return
         self._cur = []
-        self._process(records)
+        # the depth field (DP, else LC, else none) is looked up in EVERY record (dumpSTR.py:688-695): a chunk is cut
+        # into runs of records that agree on it, each run one device batch (normally the whole chunk)
+        def dp_key_of(r):
+            fmt = r.format
+            return 'DP' if 'DP' in fmt else 'LC' if 'LC' in fmt else None
+        lo = 0
+        k0 = dp_key_of(records[0])
+        for i in range(1, len(records) + 1):
+            k = dp_key_of(records[i]) if i < len(records) else object()
+            if k != k0:
+                self._process(records[lo:i])
+                lo, k0 = i, k
         if self.world > 1:
             self.parts.append((self.batch_no, ''.join(self._cur).encode()))
 
@@ -462,14 +473,23 @@ class _Run:
             for key, _ in f.planes():
                 if key not in keys:
                     keys.append(key)
-        fmt0 = rb.head_fields(0)[8].split(':') if rb.n else []
-        dp_key = None
-        for cand in ('DP', 'LC'):                     # dumpSTR.py:688-695, judged on the batch's first record
-            if cand in fmt0:
-                dp_key = cand
-                if cand not in keys:
-                    keys.append(cand)
-                break
+        # Every record must carry every FORMAT key a filter reads (the reference raises KeyError at
+        # `record.format[self.field]`, filters.py:327-409; a plane of the native reader holds missing values where
+        # a record lacks the key) and all records must agree on the depth field (DP, else LC: dumpSTR.py:688-695 is
+        # judged per record) -- otherwise the per-record loop takes the batch and behaves as the reference does.
+        formats = rb.format_columns()
+        real = {'__minsupp': ('ALLREADS', 'GB'), '__rc': ('RC',), '__repci': ('REPCI',)}
+        dp_keys = set()
+        for fmt in formats:
+            for k in keys:
+                if any(r not in fmt for r in real.get(k, (k,))):
+                    return False
+            dp_keys.add('DP' if 'DP' in fmt else 'LC' if 'LC' in fmt else None)
+        if len(dp_keys) > 1:
+            return False
+        dp_key = dp_keys.pop() if dp_keys else None
+        if dp_key is not None and dp_key not in keys:
+            keys.append(dp_key)
         if any(k not in rb.planes for k in keys):
             return False
         index = {k: i for i, k in enumerate(keys)}

@@ -622,6 +622,21 @@ class Engine:
                                                out.ctypes.data, lanes))
         return out
 
+    # ---- measurement aids ----
+    def stream_probe(self, in0, in1, in2, out0, out1, n_loci, n_samples, reps=5):
+        """Average launch time (ms) of the call-filter pass's bare stream shape on these planes (trk_stream_probe);
+        out0 / out1 are overwritten."""
+        ms = C.c_float()
+        self._chk(self.lib.trk_stream_probe(self.ctx, in0.ptr, in1.ptr, in2.ptr, out0.ptr, out1.ptr, int(n_loci),
+                                            int(n_samples), int(reps), C.byref(ms)))
+        return float(ms.value)
+
+    def device_clocks(self):
+        """{'sclk_khz', 'mclk_khz', 'mem_bus_bits'} as the runtime reports them (peak values, not the live clocks)."""
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self._chk(self.lib.trk_device_clocks(self.ctx, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(sclk_khz=a.value, mclk_khz=b.value, mem_bus_bits=c.value)
+
     # ---- multi-GPU ----
     def comm_unique_id(self):
         buf = (C.c_uint8 * 128)()

@@ -143,6 +143,36 @@ class RawBatch:
             cap = -n + 64
         return buf.raw[:n], el.value, ek.value
 
+    def format_columns(self):
+        """The distinct FORMAT columns of the batch's records, as lists of keys (normally one).  Vectorised: records
+        whose FORMAT bytes equal the first record's are recognised without touching Python strings."""
+        b, n = self.b, self.n
+        if n == 0:
+            return []
+        fo = np.ctypeslib.as_array(b.field_off, shape=(n * 10,)).reshape(n, 10)
+        lo = np.ctypeslib.as_array(b.line_off, shape=(n,))
+        le = np.ctypeslib.as_array(b.line_end, shape=(n,))
+        start = lo + fo[:, 8]
+        # field_off[9] is one past the tab that ends FORMAT (parse_record's own rule for the column's end)
+        end = np.where(fo[:, 9] > fo[:, 8], lo + fo[:, 9] - 1, le)
+        ln = np.maximum(end - start, 0)
+        first = C.string_at(b.text + int(start[0]), int(ln[0])) if ln[0] > 0 else b''
+        same = ln == ln[0]
+        if ln[0] > 0 and same.any():
+            text = np.ctypeslib.as_array(C.cast(b.text, C.POINTER(C.c_uint8)), shape=(int(le.max()),))
+            ref = np.frombuffer(first, dtype=np.uint8)
+            idx = np.flatnonzero(same)
+            eq = (text[start[idx, None] + np.arange(ref.size)[None, :]] == ref[None, :]).all(axis=1)
+            same[idx] = eq
+        out = [first.decode().split(':') if first else []]
+        seen = {first}
+        for l in np.flatnonzero(~same):
+            t = C.string_at(b.text + int(start[l]), int(ln[l])) if ln[l] > 0 else b''
+            if t not in seen:
+                seen.add(t)
+                out.append(t.decode().split(':') if t else [])
+        return out
+
     def head_fields(self, l):
         """The eight leading columns and the FORMAT column of record l as text."""
         b = self.b
