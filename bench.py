@@ -1021,7 +1021,9 @@ def main():
                        "sharding": ("contiguous locus shards by rank; per step ONE grouped RCCL launch: all-reduce of "
                                     "the packed sample_info / totaldp / loc_info counters + all-gather of the "
                                     "per-locus filter decisions") if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "k_call_filter", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_call_filter_v2 (HIP events around that kernel alone; the 0.06 ms "
+                                                   "k_cf_reduce that follows it is kernels_ms.k_cf_reduce)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "bytes_per_cell": BYTES_PER_CELL_CALL_FILTER, "avg_launch_ms": avg_cf,

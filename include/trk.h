@@ -117,7 +117,8 @@ enum {
     TRK_K_SYNTH = 4,
     TRK_K_ASSOC_SCAN = 5,    /* associaTR: genotype x trait cross-products per locus */
     TRK_K_ASSOC_FINALIZE = 6,
-    TRK_K_COUNT = 7
+    TRK_K_CF_REDUCE = 7,     /* k_cf_reduce: sums the call-filter pass's per-workgroup partial sample counters */
+    TRK_K_COUNT = 8
 };
 int trk_profile_enable(trk_ctx* ctx, int on);
 int trk_profile_get(trk_ctx* ctx, int kernel, int64_t* n_launches, double* total_ms);

@@ -24,7 +24,7 @@ LF_THRESH, LF_MEAN, LF_MODE, LF_VAR, LF_HET_LEN, LF_HET_STR, LF_ENTROPY_LEN, LF_
 # kernels (profiling)
 K_LOCUS_COUNT, K_LOCUS_FINALIZE, K_CALL_FILTER, K_LOCUS_FILTER, K_SYNTH = range(5)
 KERNEL_NAMES = ['k_locus_count', 'k_locus_finalize', 'k_call_filter', 'k_locus_filter', 'k_synth',
-                'k_assoc_scan', 'k_assoc_finalize']
+                'k_assoc_scan', 'k_assoc_finalize', 'k_cf_reduce']
 # filter ops
 F_LT, F_GT, F_RATIO_GT, F_CALLED_LT, F_CALLED_SUM_LT, F_CALLED_EQ, F_CALLED_SUM_EQ, \
     F_CALLED_OUTSIDE_CI, F_AD_SUPPORT_LT = range(1, 10)

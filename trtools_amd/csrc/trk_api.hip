@@ -151,6 +151,16 @@ struct ProfScope {
         (void)hipEventRecord(rec.stop, st);
         ctx->prof_pending.push_back(rec);
     }
+    // ends the bracket of the first kernel of a launch sequence here and opens one for the next kernel
+    void split(int kernel2) {
+        if (!on) return;
+        (void)hipEventRecord(rec.stop, st);
+        ctx->prof_pending.push_back(rec);
+        rec.kernel = kernel2;
+        rec.start = get_event(ctx);
+        rec.stop = get_event(ctx);
+        (void)hipEventRecord(rec.start, st);
+    }
 };
 
 static void drain_profile(trk_ctx* ctx) {
@@ -558,10 +568,15 @@ int trk_call_filters(trk_ctx* ctx, const trk_batch* in, const trk_plane* planes,
     if (in->n_loci == 0 || in->n_samples == 0) return TRK_OK;
     (void)hipSetDevice(ctx->device);
     // grown outside the profiling bracket and before the launch (a growth synchronises this queue)
-    trk::Scratch sc{ctx, [](void* user, size_t bytes) -> void* {
-                        return workspace_for_queue(static_cast<trk_ctx*>(user), bytes);   // null: atomics instead
-                    }};
+    // TRK_K_CALL_FILTER brackets the streaming kernel alone; the reduction of the per-workgroup partial counters that
+    // follows it (k_cf_reduce) is TRK_K_CF_REDUCE
     ProfScope ps(ctx, TRK_K_CALL_FILTER);
+    struct Hook { trk_ctx* ctx; ProfScope* ps; } hook{ctx, &ps};
+    trk::Scratch sc{&hook,
+                    [](void* user, size_t bytes) -> void* {
+                        return workspace_for_queue(static_cast<Hook*>(user)->ctx, bytes);   // null: atomics instead
+                    },
+                    [](void* user) { static_cast<Hook*>(user)->ps->split(TRK_K_CF_REDUCE); }};
     HIPCHK(ctx, trk::launch_call_filter(*in, planes, n_planes, filters, n_filters, dp_plane, *out, ctx->n_cu,
                                         ctx->s(), sc));
     return TRK_OK;

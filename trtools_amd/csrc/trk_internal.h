@@ -19,6 +19,7 @@ size_t finalize_worklist_bytes(int64_t n_group_loci);
 struct Scratch {
     void* user;
     void* (*get)(void* user, size_t bytes);
+    void (*next_kernel)(void* user);   // called between the streaming kernel and its reduction kernel (profiling bracket)
 };
 hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n_planes,
                               const trk_call_filter* filters, int n_filters, int dp_plane, const trk_call_out& out,

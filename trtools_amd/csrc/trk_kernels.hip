@@ -3629,6 +3629,7 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             if (v.part16) {
                 hipError_t e1 = hipGetLastError();
                 if (e1 != hipSuccess) return e1;
+                if (scratch.next_kernel) scratch.next_kernel(scratch.user);
                 const int quads = S / 4;
                 hipLaunchKernelGGL(k_cf_reduce, dim3((quads + CFR_QPB - 1) / CFR_QPB), dim3(CFR_NSL * CFR_QPB), 0, stream,
                                    v.part16, v.part64, gy, S, 2 + n_filters, v.f[0], v.f[1], v.f[2], v.f[3], v.f[4],
