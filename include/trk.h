@@ -143,6 +143,19 @@ int trk_profile_reset(trk_ctx* ctx);
  *   group_bits    [S] bit g set -> sample belongs to sample group g
  *                 (statSTR --samples, statSTR.py:520-542); NULL -> one group
  *                 holding every sample.  n_groups <= 8.
+ *   row_stride    samples from the start of one row of gt to the start of the next; 0 = n_samples.  With gt
+ *                 pointing at column c0 of a wider tensor the batch is a VIEW of the column range
+ *                 [c0, c0 + n_samples) (trk_locus_stats' streaming count kernels only; every other entry wants 0).
+ *   class_runs    sample groups without a per-call group lookup.  Group membership belongs to the SAMPLE, the same
+ *                 for every locus: when the caller lays the sample columns out ordered by group-bit pattern
+ *                 ("class"), every class is a contiguous column range, the ungrouped streaming kernel counts each
+ *                 range (a view, row_stride) and the classes are added into their groups per locus afterwards --
+ *                 any number of overlapping groups at the ungrouped kernel's rate.  HOST array
+ *                 int32[4 * n_class_runs]: {first column, columns, real samples, group bits} per run; `first column`
+ *                 and `columns` are multiples of four (16-byte rows), the columns beyond `real samples` are padding
+ *                 whose genotypes MUST be -1.  group_bits (the same bits per column, 0 for padding) stays mandatory:
+ *                 the kernels for batches outside the streaming path read it.  Engine.make_batch / compute.py
+ *                 build this layout (trk_permute_columns does the gather on the device).
  */
 typedef struct {
     int32_t n_loci;
@@ -163,6 +176,9 @@ typedef struct {
     const uint16_t* str_class;
     const double* len_class_value;
     const uint8_t* group_bits;
+    int32_t row_stride;        /* 0 = n_samples */
+    int32_t n_class_runs;      /* 0 = columns are not ordered by class */
+    const int32_t* class_runs; /* HOST memory, int32[4 * n_class_runs] */
 } trk_batch;
 
 /* integer columns of trk_stats_out.locus_int ([G, L, TRK_LI_COLS] int32) */
@@ -250,6 +266,12 @@ typedef struct {
 /* [n_cells, ncol] -> [ncol, n_cells] for 4-byte elements (device to device; a helper for callers whose FORMAT
  * planes are produced interleaved).                                                                           */
 int trk_planarize(trk_ctx* ctx, const void* src, void* dst, int64_t n_cells, int32_t ncol);
+
+/* Column gather of a genotype tensor (device to device): dst[l, j, :] = src[l, col[j], :] for j < n_dst, a column of
+ * no-calls (-1) where col[j] < 0.  src [n_loci, n_src, ploidy] int16, dst [n_loci, n_dst, ploidy] int16, col DEVICE
+ * int32[n_dst].  Lays a cohort out by sample class for trk_batch.class_runs. */
+int trk_permute_columns(trk_ctx* ctx, const int16_t* src, int16_t* dst, const int32_t* col, int64_t n_loci,
+                        int32_t n_src, int32_t n_dst, int32_t ploidy);
 
 /* Measurement aids (bench.py; no counterpart in the reference).
  * trk_stream_probe: the call-filter pass's stream shape with no arithmetic -- three [n_loci, n_samples] 4-byte planes

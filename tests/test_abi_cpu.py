@@ -51,7 +51,7 @@ def test_struct_sizes_match_header():
     """ctypes mirrors of the ABI structs (64-bit Linux layout)."""
     import ctypes as C
     L, _ = _lib()
-    assert C.sizeof(L.Batch) == 4 * 4 + 8 + 8 + 7 * 8
+    assert C.sizeof(L.Batch) == 4 * 4 + 8 + 8 + 7 * 8 + 2 * 4 + 8
     assert C.sizeof(L.CallFilter) == 6 * 4 + 8
     assert C.sizeof(L.Plane) == 16
     assert C.sizeof(L.LocusFilterSpec) == 4 * 8 + 8 + 8

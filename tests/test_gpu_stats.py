@@ -389,3 +389,78 @@ def test_sample_groups_on_the_streaming_kernel(eng, n_groups, S, layout):
     cols = [L.LI_N_CALLED, L.LI_N_LOWPLOIDY, L.LI_N_HOM_LEN, L.LI_N_HOM_STR, L.LI_N_SAMPLES]
     assert np.array_equal(ref.allele_count.get(), res.allele_count.get())
     assert np.array_equal(ref.locus_int.get()[:, :, cols], res.locus_int.get()[:, :, cols])
+
+
+@pytest.mark.parametrize("n_groups,S,layout", [(1, 1000, 'subset'), (2, 1003, 'overlap'), (3, 64, 'disjoint'),
+                                                (5, 2501, 'overlap'), (8, 4000, 'disjoint'), (8, 997, 'overlap'),
+                                                (4, 37, 'empty_group')])
+def test_sample_groups_as_class_column_ranges(eng, n_groups, S, layout):
+    """trk_batch.class_runs (DeviceBatch.sorted_by_class): the columns gathered into class order on the device, each
+    class counted by the ungrouped streaming kernel through a column-range view, classes added into groups.  Any
+    sample count, up to 8 overlapping groups, samples in no group, a group without samples; against the oracle and
+    bit for bit against the per-call group kernel on the unsorted batch (incl. the float columns: same finaliser)."""
+    from oracle import trtools_oracle as orc
+    from trtools_amd import _lib as L
+    rng = np.random.default_rng(77 * n_groups + S)
+    n_loci = 26
+    gt, lens, strs, lp, (off, lc, sc, cv) = _random_batch(rng, n_loci, S, 2, 12)
+    gt[3] = -1
+    gt[4, :, 1] = -2
+    gt[5, : S // 2] = [-1, -2]
+    gt[6, : S // 3] = [-2, -1]
+    gt[7, : S // 4] = [-2, -2]
+    if layout == 'subset':
+        gb = (rng.random(S) < 0.6).astype(np.uint8)
+    elif layout == 'disjoint':
+        gb = (np.uint8(1) << rng.integers(0, n_groups, size=S).astype(np.uint8)).astype(np.uint8)
+        gb[rng.random(S) < 0.1] = 0
+    elif layout == 'empty_group':
+        gb = rng.integers(0, 1 << n_groups, size=S).astype(np.uint8) & np.uint8(0b1011)   # group 2 has nobody
+    else:
+        gb = rng.integers(0, 1 << n_groups, size=S).astype(np.uint8)
+    groups = [((gb >> g) & 1).astype(bool) for g in range(n_groups)]
+    plain = eng.make_batch(gt, off, lc, sc, cv)
+    b = plain.sorted_by_class(eng, gb, n_groups)
+    assert getattr(b, 'class_sorted', False) and b.struct.n_class_runs >= 1
+    res = eng.locus_stats(b, nalleles_thresh=0.05)
+    cnt, li, lf = _fetch(res)
+    if layout != 'empty_group':      # (the oracle raises for a group without samples as the reference does)
+        check_against_oracle(orc, L, cnt, li, lf, off, [gt[l] for l in range(n_loci)], lens, strs, groups, 0.05)
+    for g in range(n_groups):
+        assert np.all(li[g][:, L.LI_N_SAMPLES] == int(groups[g].sum()))
+    ref = eng.locus_stats(plain.with_groups(eng, gb, n_groups), nalleles_thresh=0.05)
+    assert np.array_equal(ref.allele_count.get(), cnt)
+    assert np.array_equal(ref.locus_int.get(), li)
+    assert np.array_equal(ref.locus_f64.get(), lf, equal_nan=True)
+    # twin outputs (dumpSTR's copy of the counts) come out of the combine step too
+    tw = eng.alloc_stats(b, twin=True)
+    eng.locus_stats(b, out=tw, count_only=True)
+    cols = [L.LI_N_CALLED, L.LI_N_LOWPLOIDY, L.LI_N_HOM_LEN, L.LI_N_HOM_STR, L.LI_N_BAD, L.LI_N_SAMPLES]
+    assert np.array_equal(tw.allele_count.get(), cnt) and np.array_equal(tw.twin.allele_count.get(), cnt)
+    assert np.array_equal(tw.twin.locus_int.get()[:, :, cols], li[:, :, cols])
+
+
+def test_column_range_view_is_rejected_outside_the_count_entry(eng):
+    """trk_batch.row_stride is honoured by trk_locus_stats' streaming kernels only; the other entries refuse it."""
+    from trtools_amd import _lib as L
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    gt, lens, strs, lp, (off, lc, sc, cv) = _random_batch(rng, 8, 64, 2, 6)
+    b = eng.make_batch(gt, off, lc, sc, cv)
+    # a view of columns 16..47: equal to the statistics of the sliced tensor
+    s = L.Batch()
+    C.memmove(C.byref(s), C.byref(b.struct), C.sizeof(L.Batch))
+    s.gt = b.arrays['gt'].ptr + 16 * 2 * 2
+    s.n_samples, s.row_stride = 32, 64
+    from trtools_amd.engine import DeviceBatch
+    view = DeviceBatch(s, b.arrays, 1, b.sum_alleles)
+    res = eng.locus_stats(view, nalleles_thresh=0.05)
+    ref = eng.locus_stats(eng.make_batch(np.ascontiguousarray(gt[:, 16:48]), off, lc, sc, cv), nalleles_thresh=0.05)
+    assert np.array_equal(res.allele_count.get(), ref.allele_count.get())
+    assert np.array_equal(res.locus_int.get(), ref.locus_int.get())
+    assert np.array_equal(res.locus_f64.get(), ref.locus_f64.get(), equal_nan=True)
+    with pytest.raises(L.TrkError):
+        eng.call_filters(view, [], [])
+    s.row_stride = 62
+    with pytest.raises(L.TrkError):
+        eng.locus_stats(DeviceBatch(s, b.arrays, 1, b.sum_alleles))

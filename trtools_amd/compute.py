@@ -77,6 +77,20 @@ class DeviceCompute:
             lp = None
         n_pad = self._n_pad(hb) if pad else 0
         gb = hb.group_bits
+        # Sample groups: with four or more groups per pass (TRK_CLASS_SORT=1: always, =0: never) the columns are
+        # gathered on the device into class order and counted range by range with the ungrouped streaming kernel
+        # (DeviceBatch.sorted_by_class; the per-call group kernel takes 19-23 ms at 100k x 10k where this takes ~2).
+        # Up to three groups keep the one-pass grouped kernel (k_locus_count_v2g), which needs no gather.
+        mode = os.environ.get('TRK_CLASS_SORT', '')
+        class_sort = (gb is not None and hb.gt.shape[2] == 2 and lp is None and hb.n_loci > 0 and mode != '0' and
+                      (hb.n_groups >= 4 or mode == '1'))
+        if class_sort:
+            base = self.eng.make_batch(hb.gt, hb.allele_off, hb.len_class, hb.str_class, hb.len_class_value,
+                                       max_alleles=hb.max_alleles)
+            b = base.sorted_by_class(self.eng, gb, hb.n_groups)
+            if b.arrays['gt'] is not base.arrays['gt']:
+                base.arrays['gt'].free()
+            return b
         if n_pad and gb is not None:
             gb = self._pad(gb, n_pad, 0, 0)          # padding samples belong to no group
         return self.eng.make_batch(self._pad(hb.gt, n_pad, 1, -1), hb.allele_off, hb.len_class, hb.str_class,

@@ -433,8 +433,13 @@ static void* workspace_for_queue(trk_ctx* c, size_t bytes) {
     return c->cf_ws_[q];
 }
 
-static int check_batch(trk_ctx* ctx, const trk_batch* b) {
+static int check_batch(trk_ctx* ctx, const trk_batch* b, bool count_entry = false) {
     if (!b) return fail(ctx, TRK_ERR_ARG, "batch is NULL");
+    if (b->row_stride != 0 && (!count_entry || b->row_stride < b->n_samples || (b->row_stride & 3)))
+        return fail(ctx, TRK_ERR_ARG, "row_stride %d: column-range views are for trk_locus_stats, rows a multiple of "
+                                      "four samples apart and at least n_samples long", b->row_stride);
+    if (b->n_class_runs < 0 || (b->n_class_runs > 0 && (!b->class_runs || !b->group_bits)))
+        return fail(ctx, TRK_ERR_ARG, "class_runs needs the run table and group_bits");
     if (b->n_loci < 0 || b->n_samples < 0) return fail(ctx, TRK_ERR_ARG, "negative batch dimensions");
     if (b->ploidy < 1 || b->ploidy > TRK_MAX_PLOIDY)
         return fail(ctx, TRK_ERR_ARG, "ploidy %d outside [1,%d]", b->ploidy, TRK_MAX_PLOIDY);
@@ -453,7 +458,7 @@ static int ensure_fin_buffers(trk_ctx* ctx, int G, int64_t sumA, int n_loci);
 
 int trk_locus_stats(trk_ctx* ctx, const trk_batch* in, const trk_stats_params* prm, trk_stats_out* out) {
     if (!ctx) return TRK_ERR_ARG;
-    int rc = check_batch(ctx, in);
+    int rc = check_batch(ctx, in, true);
     if (rc) return rc;
     if (!out || !out->allele_count || !out->locus_int) return fail(ctx, TRK_ERR_ARG, "stats outputs are NULL");
     const bool count_only = prm && (prm->flags & TRK_STATS_COUNT_ONLY);
@@ -462,10 +467,14 @@ int trk_locus_stats(trk_ctx* ctx, const trk_batch* in, const trk_stats_params* p
     (void)hipSetDevice(ctx->device);
     const int G = in->group_bits ? in->n_groups : 1;
     const int64_t sumA = in->n_alleles_total;
+    int32_t* class_ws = nullptr;
+    if (in->n_class_runs > 0)   // (grown before the bracket: a growth synchronises this queue; null -> per-call kernels)
+        class_ws = static_cast<int32_t*>(workspace_for_queue(
+            ctx, (size_t)in->n_class_runs * ((size_t)sumA + (size_t)in->n_loci * TRK_LI_COLS) * sizeof(int32_t)));
     {
         ProfScope ps(ctx, TRK_K_LOCUS_COUNT);
         HIPCHK(ctx, trk::launch_locus_count(*in, in->max_alleles, out->allele_count, out->locus_int,
-                                            ctx->n_cu, ctx->s(), prm && (prm->flags & TRK_STATS_TWIN)));
+                                            ctx->n_cu, ctx->s(), prm && (prm->flags & TRK_STATS_TWIN), class_ws));
     }
     if (count_only) return TRK_OK;
     rc = ensure_fin_buffers(ctx, G, sumA, in->n_loci);
@@ -802,6 +811,18 @@ int trk_planarize(trk_ctx* ctx, const void* src, void* dst, int64_t n_cells, int
     if (n_cells == 0) return TRK_OK;
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, trk::launch_planarize(src, dst, n_cells, ncol, ctx->s()));
+    return TRK_OK;
+}
+
+int trk_permute_columns(trk_ctx* ctx, const int16_t* src, int16_t* dst, const int32_t* col, int64_t n_loci,
+                        int32_t n_src, int32_t n_dst, int32_t ploidy) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (n_loci < 0 || n_src < 0 || n_dst < 0 || ploidy < 1 || ploidy > TRK_MAX_PLOIDY)
+        return fail(ctx, TRK_ERR_ARG, "permute_columns arguments");
+    if (n_loci == 0 || n_dst == 0) return TRK_OK;
+    if (!src || !dst || !col) return fail(ctx, TRK_ERR_ARG, "permute_columns: NULL array");
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, trk::launch_permute_columns(src, dst, col, n_loci, n_src, n_dst, ploidy, ctx->n_cu, ctx->s()));
     return TRK_OK;
 }
 

@@ -9,8 +9,12 @@
 #define TRK_MAX_PLOIDY 8
 
 namespace trk {
+// class_ws: device scratch of n_class_runs x (sumA + L x TRK_LI_COLS) int32 for the class passes of a batch whose
+// columns are ordered by sample class (trk_batch.class_runs); nullptr: the per-call group kernels
 hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* allele_count, int32_t* locus_int,
-                              int n_cu, hipStream_t stream, bool twin);
+                              int n_cu, hipStream_t stream, bool twin, int32_t* class_ws);
+hipError_t launch_permute_columns(const int16_t* src, int16_t* dst, const int32_t* col, int64_t n_loci, int n_src,
+                                  int n_dst, int ploidy, int n_cu, hipStream_t stream);
 hipError_t launch_locus_finalize(const trk_batch& b, const int32_t* allele_count, int32_t* locus_int,
                                  double* locus_f64, int32_t* scratch, void* worklist, double nalleles_thresh,
                                  hipStream_t stream);

@@ -619,7 +619,8 @@ __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v2(
     const int l = blockIdx.x * COUNT_WAVES_PER_WG + wid;
     if (l >= b.n_loci) return;  // waves are independent: no workgroup barrier anywhere
     const int S = b.n_samples;
-    const u32x4* row = reinterpret_cast<const u32x4*>(b.gt) + (((int64_t)l * S) >> 2);
+    const int64_t RS = b.row_stride ? b.row_stride : S;     // a column-range view: rows are RS samples apart
+    const u32x4* row = reinterpret_cast<const u32x4*>(b.gt) + (((int64_t)l * RS) >> 2);
     const int nchunks = S >> 2;
     u32x4 cur[U];
     row_fetch<WAVE, U>(row, 0, lane, nchunks - 1, cur);   // the row's first chunks travel during the prologue
@@ -802,7 +803,8 @@ __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v3(
     const bool live = l_raw < b.n_loci;
     const int l = live ? l_raw : b.n_loci - 1;
     const int S = b.n_samples;
-    const u32x4* row = reinterpret_cast<const u32x4*>(b.gt) + (((int64_t)l * S) >> 2);
+    const int64_t RS = b.row_stride ? b.row_stride : S;     // a column-range view: rows are RS samples apart
+    const u32x4* row = reinterpret_cast<const u32x4*>(b.gt) + (((int64_t)l * RS) >> 2);
     const int nchunks = live ? (S >> 2) : 0;
     u32x4 cur[U];
     row_fetch<LPL, U>(row, 0, sl, (S >> 2) - 1, cur);     // the row's first chunks travel during the prologue
@@ -2922,6 +2924,78 @@ __global__ __launch_bounds__(256) void k_locus_filter(int L, const int32_t* __re
 // k_synth : synthetic diploid genotypes + HipSTR-shaped FORMAT planes
 // (bit-for-bit twin: trtools_amd/synth.py::cells_numpy)
 // ---------------------------------------------------------------------------
+// k_class_combine : group totals from the per-class counts of the class passes (trk_batch.class_runs): a group's
+// allele counts and its additive locus_int columns are the sums over the classes whose bits contain the group.
+// ws: per used class [sumA allele counts | L x TRK_LI_COLS rows], back to back.  Thread = one output element of
+// group 0's arrays, looping over the groups.
+// ---------------------------------------------------------------------------
+struct ClassRuns {
+    int n;
+    uint8_t bits[256];
+};
+__global__ __launch_bounds__(256) void k_class_combine(ClassRuns cr, const int32_t* __restrict__ ws, int64_t n_ac,
+                                                      int64_t n_li, int G, int32_t* __restrict__ allele_count,
+                                                      int32_t* __restrict__ locus_int, int64_t twin_ac, int64_t twin_li) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_ac + n_li) return;
+    const int64_t per = n_ac + n_li;
+    int32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool additive = true;
+    if (i >= n_ac) {
+        const int col = (int)((i - n_ac) % TRK_LI_COLS);
+        additive = col == TRK_LI_N_CALLED || col == TRK_LI_N_LOWPLOIDY || col == TRK_LI_N_HOM_LEN ||
+                   col == TRK_LI_N_HOM_STR || col == TRK_LI_N_BAD || col == TRK_LI_N_SAMPLES;
+    }
+    if (additive)
+        for (int r = 0; r < cr.n; ++r) {
+            const int32_t v = ws[(int64_t)r * per + i];
+            const uint32_t bits = cr.bits[r];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) acc[g] += ((bits >> g) & 1u) ? v : 0;
+        }
+    for (int g = 0; g < G; ++g) {
+        if (i < n_ac) {
+            allele_count[(int64_t)g * n_ac + i] = acc[g];
+            if (twin_ac) allele_count[twin_ac + (int64_t)g * n_ac + i] = acc[g];
+        } else {
+            locus_int[(int64_t)g * n_li + (i - n_ac)] = acc[g];
+            if (twin_li) locus_int[twin_li + (int64_t)g * n_li + (i - n_ac)] = acc[g];
+        }
+    }
+}
+
+// dst[l, j, :] = src[l, col[j], :] (col[j] < 0: a no-call column).  Diploid, n_dst % 4 == 0: one workgroup per row at a
+// time (the row's 4 n_src bytes are fetched by ONE XCD and then served from its L2 however scattered col[] is; with
+// the rows' chunks spread over workgroups every XCD pulled most of every row: 3.4 ms instead of ~1.6 for 100k x
+// 10k), a thread stores 16 bytes = four gathered calls.  Any other shape: element-wise.
+__global__ __launch_bounds__(256) void k_permute_columns(const int16_t* __restrict__ src, int16_t* __restrict__ dst,
+                                                        const int32_t* __restrict__ col, int64_t n_loci, int n_src,
+                                                        int n_dst, int ploidy) {
+    if (ploidy == 2 && (n_dst & 3) == 0) {
+        const int q4 = n_dst >> 2;
+        for (int64_t l = blockIdx.x; l < n_loci; l += gridDim.x) {
+            const uint32_t* srow = reinterpret_cast<const uint32_t*>(src) + l * n_src;
+            u32x4* drow = reinterpret_cast<u32x4*>(dst) + l * q4;
+            for (int j4 = threadIdx.x; j4 < q4; j4 += 256) {
+                const int4 c = reinterpret_cast<const int4*>(col)[j4];
+                u32x4 o;
+                o[0] = c.x >= 0 ? srow[c.x] : 0xffffffffu;
+                o[1] = c.y >= 0 ? srow[c.y] : 0xffffffffu;
+                o[2] = c.z >= 0 ? srow[c.z] : 0xffffffffu;
+                o[3] = c.w >= 0 ? srow[c.w] : 0xffffffffu;
+                __builtin_nontemporal_store(o, drow + j4);
+            }
+        }
+        return;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_loci * n_dst; i += (int64_t)gridDim.x * 256) {
+        const int64_t l = i / n_dst;
+        const int c = col[(int)(i - l * n_dst)];
+        for (int p = 0; p < ploidy; ++p) dst[i * ploidy + p] = c >= 0 ? src[(l * n_src + c) * ploidy + p] : (int16_t)-1;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_stream_probe : the call-filter pass's stream shape with no arithmetic -- column-owner tiling (thread = one
 // 16-byte chunk column, workgroup = 1024 samples x a block of loci), n_in nontemporal 16-byte input streams OR-ed
 // together, n_out output streams.  What the memory system of THIS box gives a 12 B-in / 8 B-out stream is the
@@ -3130,12 +3204,11 @@ static void sync_gt_temporal() {
     }
 }
 
-hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* allele_count, int32_t* locus_int,
-                              int n_cu, hipStream_t stream, bool twin) {
-    sync_gt_temporal();
-    const int G = b.group_bits ? b.n_groups : 1;
+// The ungrouped diploid streaming kernels (k_locus_count_v3 / _v2 / _fast) on one batch -- or on a column-range VIEW of
+// one (trk_batch.row_stride; the class passes of launch_locus_count).  false: the batch is outside what they cover.
+static bool launch_count_streaming(const trk_batch& b, int max_alleles, int32_t* allele_count, int32_t* locus_int,
+                                   hipStream_t stream, bool twin, size_t ac_elems, size_t li_elems, hipError_t* err) {
     const bool fast2 = (b.ploidy == 2) && !b.group_bits;
-    const size_t ac_elems = (size_t)G * (size_t)b.n_alleles_total, li_elems = (size_t)G * b.n_loci * TRK_LI_COLS;
     const int64_t twin_ac = twin ? (int64_t)ac_elems : 0, twin_li = twin ? (int64_t)li_elems : 0;
     auto zero_outputs = [&]() -> hipError_t {
         hipError_t e = hipMemsetAsync(allele_count, 0, ac_elems * sizeof(int32_t), stream);
@@ -3153,6 +3226,7 @@ hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* alle
     if (fast2 && max_alleles > 0 && (b.n_samples % 4) == 0 && b.n_samples > 0) {
         const char* ver_env = getenv("TRK_CNT_VER");
         const bool use_v2 = !b.locus_ploidy && max_alleles + 2 < 65535 && !(ver_env && atoi(ver_env) == 1);
+        if (!use_v2 && b.row_stride) return false;   // (the older kernel knows no views)
         const int extra = use_v2 ? 7 : 1;  // bins besides the alleles
         // words per wave: bins x K copies + one LUT word per bin, K = 32 while it fits in 16 KiB
         int kshift = 5;
@@ -3186,7 +3260,7 @@ hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* alle
                 else
                     hipLaunchKernelGGL((k_locus_count_v3<2, 2>), g3, block, lds3, stream, b, allele_count, locus_int, nbmax, words3, twin_ac, twin_li);
                 // (only N_ALLELES / HWE status / NALLELES columns, written by the finaliser, are left untouched)
-                return hipGetLastError();
+                { *err = hipGetLastError(); return true; }
             }
             if (use_v2) {
                 // wave-per-locus kernel: two chunks per register set (83 VGPRs, five waves per SIMD) beat four (100
@@ -3201,10 +3275,10 @@ hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* alle
                 else
                     hipLaunchKernelGGL(k_locus_count_v2<2>, grid, block, lds_fast, stream, b, allele_count, locus_int,
                                        kshift, words, twin_ac, twin_li);
-                return hipGetLastError();
+                { *err = hipGetLastError(); return true; }
             } else {
                 hipError_t ez = zero_outputs();
-                if (ez != hipSuccess) return ez;
+                if (ez != hipSuccess) { *err = ez; return true; }
                 if (cnt_u == 4)
                     hipLaunchKernelGGL(k_locus_count_fast<4>, grid, block, lds_fast, stream, b, allele_count,
                                        locus_int, kshift, words);
@@ -3212,9 +3286,82 @@ hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* alle
                     hipLaunchKernelGGL(k_locus_count_fast<2>, grid, block, lds_fast, stream, b, allele_count,
                                        locus_int, kshift, words);
             }
-            return copy_twin();
+            { *err = copy_twin(); return true; }
         }
     }
+    return false;
+}
+
+hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* allele_count, int32_t* locus_int,
+                              int n_cu, hipStream_t stream, bool twin, int32_t* class_ws) {
+    sync_gt_temporal();
+    const int G = b.group_bits ? b.n_groups : 1;
+    const bool fast2 = (b.ploidy == 2) && !b.group_bits;
+    const size_t ac_elems = (size_t)G * (size_t)b.n_alleles_total, li_elems = (size_t)G * b.n_loci * TRK_LI_COLS;
+    const int64_t twin_ac = twin ? (int64_t)ac_elems : 0, twin_li = twin ? (int64_t)li_elems : 0;
+    auto zero_outputs = [&]() -> hipError_t {
+        hipError_t e = hipMemsetAsync(allele_count, 0, ac_elems * sizeof(int32_t), stream);
+        if (e != hipSuccess) return e;
+        return hipMemsetAsync(locus_int, 0, li_elems * sizeof(int32_t), stream);
+    };
+    auto copy_twin = [&]() -> hipError_t {
+        if (!twin) return hipGetLastError();
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        e = hipMemcpyAsync(allele_count + ac_elems, allele_count, ac_elems * sizeof(int32_t), hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return e;
+        return hipMemcpyAsync(locus_int + li_elems, locus_int, li_elems * sizeof(int32_t), hipMemcpyDeviceToDevice, stream);
+    };
+    if (!b.n_class_runs) {
+        hipError_t es = hipSuccess;
+        if (launch_count_streaming(b, max_alleles, allele_count, locus_int, stream, twin, ac_elems, li_elems, &es)) return es;
+    }
+    // sample classes laid out as column ranges (trk_batch.class_runs): the ungrouped streaming kernel per range,
+    // then the classes added into their groups (k_class_combine).  Any number of (overlapping) groups.
+    if (b.n_class_runs > 0 && b.class_runs && class_ws && b.group_bits && b.ploidy == 2 && !b.locus_ploidy &&
+        max_alleles > 0 && !b.row_stride) {
+        const int NR = b.n_class_runs;
+        const size_t ac1 = (size_t)b.n_alleles_total, li1 = (size_t)b.n_loci * TRK_LI_COLS;
+        bool ok = NR <= 256;
+        for (int r = 0; r < NR && ok; ++r) {
+            const int32_t* q = b.class_runs + 4 * r;
+            ok = q[0] >= 0 && q[1] > 0 && (q[0] & 3) == 0 && (q[1] & 3) == 0 && q[2] >= 0 && q[2] <= q[1] &&
+                 q[0] + q[1] <= b.n_samples;
+        }
+        if (ok) {
+            ClassRuns cr = {};
+            int n_used = 0;
+            for (int r = 0; r < NR; ++r) {
+                const int32_t* q = b.class_runs + 4 * r;
+                if ((q[3] & ((1 << G) - 1)) == 0 || q[2] == 0) continue;   // samples in no group are never read
+                trk_batch v = b;
+                v.gt = b.gt + (size_t)q[0] * 2;
+                v.n_samples = q[1];
+                v.n_pad_samples = q[1] - q[2];
+                v.row_stride = b.n_samples;
+                v.group_bits = nullptr;
+                v.n_groups = 1;
+                v.n_class_runs = 0;
+                v.class_runs = nullptr;
+                int32_t* ac = class_ws + (size_t)n_used * (ac1 + li1);
+                hipError_t es = hipSuccess;
+                if (!launch_count_streaming(v, max_alleles, ac, ac + ac1, stream, false, ac1, li1, &es)) { ok = false; break; }
+                if (es != hipSuccess) return es;
+                if (n_used < 256) cr.bits[n_used] = (uint8_t)q[3];
+                ++n_used;
+            }
+            if (ok) {
+                cr.n = n_used;
+                const int64_t n_ac = (int64_t)ac1, n_li = (int64_t)li1;
+                const int64_t total = n_ac + n_li;
+                hipLaunchKernelGGL(k_class_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, cr, class_ws,
+                                   n_ac, n_li, G, allele_count, locus_int, twin ? (int64_t)ac_elems : 0,
+                                   twin ? (int64_t)li_elems : 0);
+                return hipGetLastError();
+            }
+        }
+    }
+    if (b.row_stride) return hipErrorInvalidValue;   // a view outside the streaming kernels
     // sample groups (statSTR --samples): the streaming kernel with one histogram per class of group bits
     if (b.group_bits && G >= 1 && G <= 3 && b.ploidy == 2 && !b.locus_ploidy && max_alleles > 0 &&
         max_alleles + 2 < 65535 && b.n_samples > 0 && (b.n_samples % 4) == 0 &&
@@ -3748,6 +3895,17 @@ hipError_t launch_synth_gangstr(const trk_synth_spec& sp, const int16_t* gt, con
     if (blocks > (int64_t)n_cu * 32) blocks = (int64_t)n_cu * 32;
     hipLaunchKernelGGL(k_synth_gangstr, dim3((int)blocks), dim3(256), 0, stream, sp, gt, dp, allele_repcn, qexp,
                        repcn, rc, repci);
+    return hipGetLastError();
+}
+
+hipError_t launch_permute_columns(const int16_t* src, int16_t* dst, const int32_t* col, int64_t n_loci, int n_src,
+                                  int n_dst, int ploidy, int n_cu, hipStream_t stream) {
+    if (n_loci <= 0 || n_dst <= 0) return hipSuccess;
+    int64_t wgs = (ploidy == 2 && (n_dst & 3) == 0) ? n_loci : (n_loci * n_dst + 255) / 256;
+    const int64_t cap = (int64_t)n_cu * 32;
+    if (wgs > cap) wgs = cap;
+    hipLaunchKernelGGL(k_permute_columns, dim3((unsigned)wgs), dim3(256), 0, stream, src, dst, col, n_loci, n_src, n_dst,
+                       ploidy);
     return hipGetLastError();
 }
 

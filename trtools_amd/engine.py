@@ -121,6 +121,53 @@ class DeviceBatch:
         return DeviceBatch(s, arrays, int(n_groups), self.sum_alleles)
 
 
+    def sorted_by_class(self, eng, group_bits, n_groups):
+        """Sample groups at the ungrouped streaming kernel's rate (trk_batch.class_runs): the genotype columns are
+        gathered on the device so that the samples of one class (one pattern of group bits) are neighbours -- every
+        class a 16-byte aligned column range, padded with no-call columns, samples in no group dropped -- and the
+        batch carries the run table; trk_locus_stats then counts each range with the ungrouped kernel and adds the
+        classes into their groups.  ``group_bits``: host uint8[S] of THIS batch's columns (padding columns 0).
+        Returns a new DeviceBatch that owns the gathered tensor (free its arrays['gt'] / ['group_bits'] when done);
+        diploid batches only -- others get ``with_groups``."""
+        gb = np.ascontiguousarray(group_bits, dtype=np.uint8) & np.uint8((1 << int(n_groups)) - 1)
+        S = self.n_samples
+        if gb.shape != (S,):
+            raise ValueError("group_bits must have one entry per sample column")
+        if self.ploidy != 2 or self.n_loci == 0:
+            return self.with_groups(eng, gb, n_groups)
+        cols, bits, runs, at = [], [], [], 0
+        for c in np.unique(gb):
+            if c == 0:
+                continue
+            idx = np.flatnonzero(gb == c).astype(np.int32)
+            pad = (-idx.size) % 4
+            runs.append((at, idx.size + pad, idx.size, int(c)))
+            at += idx.size + pad
+            cols.append(np.concatenate([idx, np.full(pad, -1, dtype=np.int32)]))
+            bits.append(np.concatenate([np.full(idx.size, c, dtype=np.uint8), np.zeros(pad, dtype=np.uint8)]))
+        if not runs:
+            return self.with_groups(eng, gb, n_groups)
+        col = np.concatenate(cols)
+        S2 = int(col.size)
+        col_d = eng.upload(col)
+        gt2 = eng.empty((self.n_loci, S2, 2), np.int16)
+        eng._chk(eng.lib.trk_permute_columns(eng.ctx, self.arrays['gt'].ptr, gt2.ptr, col_d.ptr, self.n_loci, S, S2, 2))
+        col_d.free()
+        s = L.Batch()
+        C.memmove(C.byref(s), C.byref(self.struct), C.sizeof(L.Batch))
+        gbd = eng.upload(np.concatenate(bits))
+        table = np.ascontiguousarray(np.array(runs, dtype=np.int32).reshape(-1))
+        s.gt, s.n_samples, s.n_pad_samples = gt2.ptr, S2, 0
+        s.group_bits, s.n_groups = gbd.ptr, int(n_groups)
+        s.n_class_runs, s.class_runs = len(runs), table.ctypes.data
+        arrays = dict(self.arrays)
+        arrays['gt'], arrays['group_bits'] = gt2, gbd
+        out = DeviceBatch(s, arrays, int(n_groups), self.sum_alleles)
+        out._class_runs = table          # host memory the struct points at
+        out.class_sorted = True
+        return out
+
+
 class StatsResult:
     def __init__(self, allele_count, locus_int, locus_f64):
         self.allele_count = allele_count
