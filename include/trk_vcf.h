@@ -50,6 +50,17 @@ const char* trk_vcf_sample_name(trk_vcf* v, int i);
  * through htslib (statSTR.py:568-570, load_and_filter_genotypes.py:126-128).  BGZF files only. */
 int trk_vcf_seek(trk_vcf* v, uint64_t voffset);
 
+/* Contiguous shard of the records for one of `world` readers of the same file (one process per GPU; SURVEY 8(e):
+ * "contiguous locus ranges per rank").  The compressed file is cut at the BGZF block boundaries nearest to
+ * rank / world of its size (a plain-text file at those byte offsets); a record belongs to the rank in whose range
+ * its line STARTS, so the ranks' batches, concatenated in rank order, are the records of the file in file order, and
+ * each rank inflates its own range plus at most the block or two in which its last line ends.  The header stays as
+ * read by trk_vcf_open.  Call once, before the first trk_vcf_read_batch.  *begin_off / *end_off: the file offsets of
+ * the range.  Returns non-zero (and changes nothing) for inputs that cannot be cut (plain gzip).
+ * trk_vcf_counters: {inflated bytes, compressed bytes, BGZF blocks} consumed since the shard was set. */
+int trk_vcf_shard(trk_vcf* v, int rank, int world, uint64_t* begin_off, uint64_t* end_off);
+void trk_vcf_counters(trk_vcf* v, uint64_t out[3]);
+
 /* Ask for a FORMAT field to be decoded into a plane; returns the plane index (>= 0) or < 0. */
 int trk_vcf_select_format(trk_vcf* v, const char* key, int kind, int ncol);
 

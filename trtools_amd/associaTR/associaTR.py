@@ -232,7 +232,7 @@ def _flush(records, outfile, vec, sample_filter, pheno_std, non_major_cutoff, be
 
 
 def perform_gwas_helper(outfile, all_samples, record_iter, phenotype_name, trait_fnames, same_samples, sample_fname,
-                        non_major_cutoff, beagle_dosages=False):
+                        non_major_cutoff, beagle_dosages=False, attach=None):
     """Header, covariates, batched scan (associaTR.py:117-372 without the plotting statistics)."""
     from .. import dist
     rank = dist.get_comm()[0]
@@ -249,10 +249,12 @@ def perform_gwas_helper(outfile, all_samples, record_iter, phenotype_name, trait
             fields.extend(load_and_filter_genotypes.DOSAGE_DETAIL_FIELDS)
         outfile.write('\t'.join(fields) + '\n')
 
-    # one process per GPU (WORLD_SIZE > 1): batch b of the input belongs to rank b mod WORLD_SIZE,
-    # rank 0 writes the merged table (statSTR._ShardedOut); one process: a pass-through
+    # one process per GPU (WORLD_SIZE > 1): every rank scans its contiguous share of the records (or, where the input
+    # cannot be cut, batch b mod WORLD_SIZE); rank 0 writes the merged table (statSTR._ShardedOut)
     from ..statSTR.statSTR import _ShardedOut
     shard = _ShardedOut(outfile)
+    if attach is not None:
+        attach['shard'] = shard        # iter_records cuts the reader into contiguous shards when it starts
     batch_loci = max(1, min(4096, BATCH_CELLS // max(1, len(all_samples))))
     n_loci, start_time = 0, time.time()
     records = []
@@ -288,15 +290,16 @@ def perform_gwas(outfname, tr_vcf, phenotype_name, traits_fnames, vcftype, same_
     if reader is None:
         raise ValueError("could not open %s" % tr_vcf)
     all_samples = reader.samples
+    attach = {}
     record_iter = load_and_filter_genotypes.iter_records(
-        tr_vcf, region, vcftype, beagle_dosages, imputed_ukb_strs_paper_period_check)
+        tr_vcf, region, vcftype, beagle_dosages, imputed_ukb_strs_paper_period_check, attach=attach)
     from .. import dist
     rank = dist.get_comm()[0]
     temp = outfname + '.temp' if rank == 0 else outfname + '.rank%d.temp' % rank
     print("Writing output to {}.temp".format(outfname), flush=True)
     with open(temp, 'w') as outfile:
         perform_gwas_helper(outfile, all_samples, record_iter, phenotype_name, traits_fnames, same_samples,
-                            sample_fname, non_major_cutoff, beagle_dosages)
+                            sample_fname, non_major_cutoff, beagle_dosages, attach=attach)
     if rank != 0:
         import os
         os.remove(temp)               # only rank 0's file holds the merged table

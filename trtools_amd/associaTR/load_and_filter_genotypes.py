@@ -121,7 +121,7 @@ def beagle_dosage_genotypes(trrecord, curr_samples, len_alleles):
 
 
 def iter_records(vcf_fname, region=None, vcftype=None, beagle_dosages=False,
-                 _imputed_ukb_strs_paper_period_check=False):
+                 _imputed_ukb_strs_paper_period_check=False, attach=None):
     """Harmonised records of the file in the order / with the skipping rules of load_trs
     (reference :113-155): region restriction, records starting before the region, the PERIOD check."""
     vcf = utils.LoadSingleReader(vcf_fname, checkgz=False)
@@ -132,6 +132,9 @@ def iter_records(vcf_fname, region=None, vcftype=None, beagle_dosages=False,
     if region is not None:
         region_start = int(region.split(':')[1].split('-')[0])
         vcf = vcf(region)
+    elif attach is not None and attach.get('shard') is not None:
+        # one process per GPU: this rank reads its contiguous share of the records only (statSTR._ShardedOut.attach)
+        attach['shard'].attach(vcf)
     first = True
     for record in vcf:
         if first and beagle_dosages and "AP1" not in record.FORMAT:

@@ -125,6 +125,13 @@ struct Source {
     int n_threads = 1;
     std::vector<unsigned char> cbuf;  // compressed bytes not yet consumed (BGZF)
     size_t cpos = 0;
+    // contiguous shards (trk_vcf_shard): the blocks from file offset end_coff on belong to the next rank.  The first of
+    // them is still inflated (the last line this rank owns may end in it), one more per call after that; limit_pos is
+    // the index in the text buffer where the foreign data begins (SIZE_MAX: not met yet).
+    uint64_t cbuf_foff = 0;           // file offset of cbuf[0]
+    uint64_t end_coff = UINT64_MAX;
+    size_t limit_pos = SIZE_MAX;
+    uint64_t n_inflated = 0, n_compressed = 0, n_blocks = 0;   // counters: bytes out / in, blocks
 
     bool open(const char* path, int threads, std::string& err) {
         n_threads = threads;
@@ -164,7 +171,9 @@ struct Source {
     // append at least `want` decompressed bytes to out (fewer only at end of file)
     bool fill(TextBuf& out, size_t want, std::string& err) {
         size_t start = out.size();
-        while (!eof && out.size() - start < want) {
+        // (a shard that has reached the next rank's blocks takes one block per call: the caller only needs the end of
+        // its last line)
+        while (!eof && out.size() - start < want && !(limit_pos != SIZE_MAX && out.size() > start)) {
             if (plain || gz) {
                 size_t chunk = std::max<size_t>(want, 1 << 22);
                 size_t old = out.size();
@@ -186,13 +195,22 @@ struct Source {
     bool fill_bgzf(TextBuf& out, size_t want, std::string& err) {
         // top up the compressed buffer
         if (cpos > 0 && cpos == cbuf.size()) {
+            cbuf_foff += cbuf.size();
             cbuf.clear();
             cpos = 0;
         }
         size_t target = std::max<size_t>(want / 3, 8u << 20);
+        if (end_coff != UINT64_MAX) {
+            // a shard reads up to its end plus one block; once there, one more block's worth per call
+            const uint64_t have_to = cbuf_foff + cbuf.size();
+            const uint64_t stop = end_coff + 2 * 65536;
+            target = have_to < stop ? (size_t)std::min<uint64_t>(target, stop - have_to) : (size_t)65536 + 64;
+            if (target < 65536 + 64) target = 65536 + 64;   // always room for one whole block
+        }
         if (cbuf.size() - cpos < target) {
             if (cpos > 0) {
                 cbuf.erase(cbuf.begin(), cbuf.begin() + (long)cpos);
+                cbuf_foff += cpos;
                 cpos = 0;
             }
             size_t old = cbuf.size();
@@ -204,7 +222,12 @@ struct Source {
         struct Blk { size_t off, csize, isize, dst; };
         std::vector<Blk> blks;
         size_t p = cpos, total = 0;
+        int beyond = 0;                   // blocks of the next shard taken by this call
         while (p + 18 <= cbuf.size()) {
+            if (cbuf_foff + p >= end_coff) {
+                if (limit_pos == SIZE_MAX) limit_pos = out.size() + total;
+                if (beyond++ >= 1) break;
+            }
             const unsigned char* h = cbuf.data() + p;
             // gzip member with an extra field that holds the 'BC' subfield (BSIZE).  Nothing of the header is
             // trusted: a block must have room for its own header, extra field, a deflate stream and the trailer,
@@ -244,6 +267,9 @@ struct Source {
             }
             blks.push_back({p, bsize, isize, total});
             total += isize;
+            n_inflated += isize;
+            n_compressed += bsize;
+            ++n_blocks;
             p += bsize;
         }
         if (blks.empty()) {
@@ -339,6 +365,9 @@ struct trk_vcf {
     std::vector<int64_t> line_off, line_end;
     std::vector<int32_t> field_off;
     int n_threads = 1;
+    // contiguous shard of the file (trk_vcf_shard)
+    bool sharded = false, skip_partial = false, shard_done = false;
+    uint64_t plain_end = UINT64_MAX;   // plain text: file offset where the next rank's lines begin
 };
 
 namespace {
@@ -650,6 +679,10 @@ int trk_vcf_seek(trk_vcf* v, uint64_t voffset) {
     }
     v->src.cbuf.clear();
     v->src.cpos = 0;
+    v->src.cbuf_foff = coff;
+    v->src.end_coff = UINT64_MAX;
+    v->src.limit_pos = SIZE_MAX;
+    v->sharded = v->skip_partial = v->shard_done = false;
     v->src.eof = false;
     v->buf.clear();
     v->pos = 0;
@@ -664,6 +697,146 @@ int trk_vcf_seek(trk_vcf* v, uint64_t voffset) {
     }
     v->pos = uoff;
     return 0;
+}
+
+// ---- contiguous shards --------------------------------------------------------------------
+namespace {
+struct BlockHdr { size_t bsize, isize, xlen; };
+// a BGZF block header at p[0..n): sizes, or false
+bool bgzf_header(const unsigned char* p, size_t n, BlockHdr& h) {
+    if (n < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return false;
+    h.xlen = (size_t)p[10] | ((size_t)p[11] << 8);
+    if (h.xlen > 1024 || 12 + h.xlen > n) return false;
+    h.bsize = 0;
+    for (size_t q = 12; q + 4 <= 12 + h.xlen;) {
+        const size_t slen = (size_t)p[q + 2] | ((size_t)p[q + 3] << 8);
+        if (p[q] == 'B' && p[q + 1] == 'C' && slen == 2 && q + 6 <= 12 + h.xlen) {
+            h.bsize = ((size_t)p[q + 4] | ((size_t)p[q + 5] << 8)) + 1;
+            break;
+        }
+        q += 4 + slen;
+    }
+    return h.bsize >= 12 + h.xlen + 2 + 8;
+}
+// the first BGZF block that starts at or after file offset c: a candidate header whose BSIZE chain reaches two more
+// valid headers (or the end of the file).  fsize when there is none.
+uint64_t next_block(FILE* fp, uint64_t c, uint64_t fsize) {
+    if (c >= fsize) return fsize;
+    std::vector<unsigned char> w((size_t)std::min<uint64_t>(fsize - c, 4 * 65536 + 4096));
+    if (fseeko(fp, (off_t)c, SEEK_SET) != 0 || fread(w.data(), 1, w.size(), fp) != w.size()) return fsize;
+    for (size_t p = 0; p + 18 <= w.size() && p <= 65536 + 64; ++p) {
+        size_t q = p;
+        int ok = 0;
+        while (ok < 3) {
+            BlockHdr h;
+            if (c + q == fsize) { ok = 3; break; }
+            if (q + 18 > w.size()) { ok = ok >= 1 ? 3 : 0; break; }   // ran out of window after >= 1 full block
+            if (!bgzf_header(w.data() + q, w.size() - q, h) || c + q + h.bsize > fsize) { ok = 0; break; }
+            q += h.bsize;
+            ++ok;
+        }
+        if (ok >= 3) return c + p;
+    }
+    return fsize;
+}
+// last byte of the uncompressed data that precedes file offset b (the block(s) ending exactly at b); -1: nothing before
+int last_byte_before(FILE* fp, uint64_t b) {
+    while (b > 0) {
+        const uint64_t lo = b > 65536 + 1024 ? b - (65536 + 1024) : 0;
+        std::vector<unsigned char> w((size_t)(b - lo));
+        if (fseeko(fp, (off_t)lo, SEEK_SET) != 0 || fread(w.data(), 1, w.size(), fp) != w.size()) return -1;
+        bool found = false;
+        for (size_t back = 28; back <= w.size(); ++back) {     // (an empty block is 28 bytes)
+            const size_t p = w.size() - back;
+            BlockHdr h;
+            if (!bgzf_header(w.data() + p, back, h) || h.bsize != back) continue;
+            const size_t isize = (size_t)w[p + back - 4] | ((size_t)w[p + back - 3] << 8) | ((size_t)w[p + back - 2] << 16) |
+                                 ((size_t)w[p + back - 1] << 24);
+            if (isize > 65536) continue;
+            if (isize == 0) {          // empty block: look further back
+                b = lo + p;
+                found = true;
+                break;
+            }
+            std::vector<unsigned char> o(isize);
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) return -1;
+            zs.next_in = w.data() + p + 12 + h.xlen;
+            zs.avail_in = (unsigned)(back - 12 - h.xlen - 8);
+            zs.next_out = o.data();
+            zs.avail_out = (unsigned)isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END) continue;
+            return o[isize - 1];
+        }
+        if (!found) return -1;
+    }
+    return -1;
+}
+}  // namespace
+
+extern "C" int trk_vcf_shard(trk_vcf* v, int rank, int world, uint64_t* begin_off, uint64_t* end_off) {
+    if (!v || world < 1 || rank < 0 || rank >= world) return 2;
+    if (world == 1) return 0;
+    if (!v->src.fp || !(v->src.bgzf || v->src.plain)) {
+        v->err = "contiguous shards need a BGZF (bgzip) or plain-text file";
+        return 1;
+    }
+    FILE* fp = v->src.fp;
+    if (fseeko(fp, 0, SEEK_END) != 0) { v->err = "fseek failed"; return 1; }
+    const uint64_t fsize = (uint64_t)ftello(fp);
+    auto cut = [&](int r) -> uint64_t {
+        if (r <= 0) return 0;
+        if (r >= world) return fsize;
+        const uint64_t c = (uint64_t)((unsigned __int128)fsize * (unsigned)r / (unsigned)world);
+        return v->src.bgzf ? next_block(fp, c, fsize) : c;
+    };
+    const uint64_t b0 = cut(rank), b1 = cut(rank + 1);
+    // a line belongs to the rank in whose range it STARTS: the shard begins inside a foreign line unless the byte
+    // before it is a newline
+    bool partial = false;
+    if (b0 > 0) {
+        int last;
+        if (v->src.bgzf) {
+            last = last_byte_before(fp, b0);
+        } else {
+            unsigned char ch = 0;
+            last = (fseeko(fp, (off_t)(b0 - 1), SEEK_SET) == 0 && fread(&ch, 1, 1, fp) == 1) ? ch : -1;
+        }
+        partial = last >= 0 && last != '\n';
+    }
+    if (fseeko(fp, (off_t)b0, SEEK_SET) != 0) { v->err = "fseek failed"; return 1; }
+    v->src.cbuf.clear();
+    v->src.cpos = 0;
+    v->src.cbuf_foff = b0;
+    v->src.eof = false;
+    v->src.limit_pos = SIZE_MAX;
+    v->src.n_inflated = v->src.n_compressed = v->src.n_blocks = 0;
+    v->buf.clear();
+    v->pos = 0;
+    v->line_off.clear();
+    v->line_end.clear();
+    v->sharded = true;
+    v->shard_done = b0 >= b1;
+    v->skip_partial = partial;
+    if (v->src.bgzf) {
+        v->src.end_coff = rank + 1 < world ? b1 : UINT64_MAX;
+    } else {
+        v->src.end_coff = UINT64_MAX;
+        if (rank + 1 < world) v->src.limit_pos = (size_t)(b1 - b0);
+    }
+    if (begin_off) *begin_off = b0;
+    if (end_off) *end_off = b1;
+    return 0;
+}
+
+extern "C" void trk_vcf_counters(trk_vcf* v, uint64_t out[3]) {
+    if (!v || !out) return;
+    out[0] = v->src.n_inflated;
+    out[1] = v->src.n_compressed;
+    out[2] = v->src.n_blocks;
 }
 
 void trk_vcf_close(trk_vcf* v) {
@@ -696,16 +869,38 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
     // drop what the previous call handed out
     if (v->pos > 0) {
         v->buf.erase(0, v->pos);
+        if (v->src.limit_pos != SIZE_MAX) v->src.limit_pos = v->src.limit_pos > v->pos ? v->src.limit_pos - v->pos : 0;
         v->pos = 0;
     }
     v->line_off.clear();
     v->line_end.clear();
     size_t scan = 0;
+    if (v->shard_done) return 0;
+    if (v->skip_partial) {
+        // the shard begins inside a line the previous rank owns: drop up to and including its newline
+        for (;;) {
+            size_t nl = v->buf.find('\n', 0);
+            if (nl != std::string::npos) {
+                scan = nl + 1;
+                break;
+            }
+            if (v->src.eof) {
+                scan = v->buf.size();
+                break;
+            }
+            if (!v->src.fill(v->buf, 1u << 16, v->err)) return 1;
+        }
+        v->skip_partial = false;
+    }
     const bool timing = getenv("TRK_VCF_TIMING") != nullptr;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = timing ? now() : 0.0;
     double t_fill = 0.0;
     while ((int)v->line_off.size() < max_records) {
+        if (scan >= v->src.limit_pos) {   // the next line starts in the next rank's blocks
+            v->shard_done = true;
+            break;
+        }
         size_t nl = v->buf.find('\n', scan);
         if (nl == std::string::npos) {
             if (v->src.eof) {
@@ -722,7 +917,7 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
         }
         size_t e = nl;
         if (e > scan && v->buf[e - 1] == '\r') --e;
-        if (e > scan) {  // skip blank lines
+        if (e > scan && !(v->sharded && v->buf[scan] == '#')) {  // skip blank lines (and, in a shard, the header)
             v->line_off.push_back((int64_t)scan);
             v->line_end.push_back((int64_t)e);
         }

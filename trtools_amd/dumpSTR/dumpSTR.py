@@ -394,12 +394,24 @@ class _Run:
         self.spec = dict(min_callrate=args.min_locus_callrate, min_hwep=args.min_locus_hwep,
                          min_het=args.min_locus_het, max_het=args.max_locus_het,
                          use_length=bool(args.use_length), n_extern=len(self.host_filters))
-        # locus sharding (one process per GPU): batch b belongs to rank b mod WORLD_SIZE
+        # locus sharding (one process per GPU): each rank reads its contiguous share of the records where the reader
+        # can be cut (native reader on a bgzipped / plain-text file: trk_vcf_shard), else batch b belongs to rank
+        # b mod WORLD_SIZE
         from .. import dist
         self.rank, self.world, self.comm = dist.get_comm()
         self.batch_no = -1
         self.parts = []
         self.no_dp = False
+        self.contiguous = False
+        if self.world > 1 and args.num_records is None:
+            fn = getattr(invcf, 'shard', None)
+            self.contiguous = bool(fn and fn(self.rank, self.world))
+
+    def _mine(self):
+        return self.world == 1 or self.contiguous or self.batch_no % self.world == self.rank
+
+    def _key(self):
+        return (self.rank << 40) + self.batch_no if self.contiguous else self.batch_no
 
     def emit(self, variant):
         if self.world == 1:
@@ -417,6 +429,14 @@ class _Run:
         if flag[0] > 0:
             self.sample_info['totaldp'][:] = np.nan
         self.loc_info = dist.reduce_loc_info(self.loc_info, self.comm)
+        # contigs the header does not declare: every rank's, in rank order (== file order for contiguous shards)
+        import pickle
+        seen = []
+        for blob in self.comm.allgather_bytes(np.frombuffer(pickle.dumps(list(self.invcf.contigs_seen)), dtype=np.uint8)):
+            for c in pickle.loads(blob.tobytes()):
+                if c not in seen:
+                    seen.append(c)
+        self.invcf.contigs_seen[:] = seen
         merged = dist.merge_parts(self.parts, self.comm)
         if self.rank == 0:
             self.outvcf.write_text(merged.decode())
@@ -426,7 +446,7 @@ class _Run:
         if not records:
             return
         self.batch_no += 1
-        if self.world > 1 and self.batch_no % self.world != self.rank:
+        if not self._mine():
             return
         self._cur = []
         # the depth field (DP, else LC, else none) is looked up in EVERY record (dumpSTR.py:688-695): a chunk is cut
@@ -442,7 +462,7 @@ class _Run:
                 self._process(records[lo:i])
                 lo, k0 = i, k
         if self.world > 1:
-            self.parts.append((self.batch_no, ''.join(self._cur).encode()))
+            self.parts.append((self._key(), ''.join(self._cur).encode()))
 
     # ---- the batch pipeline: no Python object per record -------------------------------------------------------
     _SIMPLE_VALUES = (filters.CallFilterMinValue, filters._HipSTRRatio, filters.HipSTRCallMinSuppReads,
@@ -496,7 +516,12 @@ class _Run:
         arrays = [rb.planes[k] for k in keys]
         specs = [f.spec(index) for f in self.call_filters]
         self.batch_no += 1
-        if self.world > 1 and self.batch_no % self.world != self.rank:
+        # contigs the header does not declare are registered for EVERY record of the batch, on every rank, before the
+        # ownership and --drop-filtered decisions (the per-record reader registers them as it parses)
+        for chrom in rb.chroms():
+            if chrom not in self.invcf.contigs_declared and chrom not in self.invcf.contigs_seen:
+                self.invcf.contigs_seen.append(chrom)
+        if not self._mine():
             return True
         hb = HostBatch.from_tables(rb.gt, rb.locus_ploidy, hz.allele_off, hz.len_class, hz.str_class,
                                    hz.len_class_value, lists=hz.lists)
@@ -557,9 +582,6 @@ class _Run:
                 upd += [('HET', -1), ('HWEP', -1), ('AC', 0 if n_alt == 0 else ','.join(['0'] * n_alt)), ('REFAC', 0)]
             f[7] = vcfio.rewrite_info(self.invcf, f[7], upd)
             f[8] = f[8] + ':FILTER'
-            chrom = f[0]
-            if chrom not in self.invcf.contigs_declared and chrom not in self.invcf.contigs_seen:
-                self.invcf.contigs_seen.append(chrom)
             heads.append('\t'.join(f))
         text = rb.dumpstr_lines(heads, ch.mask, cfv, format_kinds)
         if text is None:
@@ -580,7 +602,7 @@ class _Run:
         if self.world == 1:
             self.outvcf.write_bytes(text)
         else:
-            self.parts.append((self.batch_no, bytes(text)))
+            self.parts.append((self._key(), bytes(text)))
         return True
 
     def _undo_batch(self):

@@ -160,9 +160,12 @@ class _RowFormatter:
 
 
 class _ShardedOut:
-    """Under a one-process-per-GPU launcher (WORLD_SIZE > 1) batch b of the input belongs to rank
-    b mod WORLD_SIZE; every rank keeps the text of its batches and rank 0 writes the merged table
-    (batch order == record order).  With one process it is a pass-through to the output file."""
+    """Under a one-process-per-GPU launcher (WORLD_SIZE > 1) every rank keeps the text of its batches and rank 0
+    writes the merged table.  Who owns what: when the reader can be cut (``attach``: the native reader on a bgzipped
+    or plain-text file, no region query) each rank reads ONLY its contiguous share of the records -- SURVEY 8(e)'s
+    contiguous locus ranges: a rank inflates and parses 1 / WORLD_SIZE of the file -- and every batch it reads is
+    its own; otherwise every rank reads everything and batch b belongs to rank b mod WORLD_SIZE.  Either way the
+    parts are merged in record order.  With one process it is a pass-through to the output file."""
 
     def __init__(self, outf):
         from .. import dist
@@ -171,10 +174,18 @@ class _ShardedOut:
         self.parts = []
         self.batch_no = -1
         self._cur = None
+        self.contiguous = False
+
+    def attach(self, reader, region=None):
+        """Cut the input into contiguous shards if the reader allows it (call before the first read)."""
+        if self.world > 1 and not region:
+            fn = getattr(reader, 'shard', None)
+            self.contiguous = bool(fn and fn(self.rank, self.world))
+        return self.contiguous
 
     def next_batch(self):
         self.batch_no += 1
-        mine = self.world == 1 or self.batch_no % self.world == self.rank
+        mine = self.world == 1 or self.contiguous or self.batch_no % self.world == self.rank
         self._cur = [] if (mine and self.world > 1) else None
         return mine
 
@@ -186,7 +197,8 @@ class _ShardedOut:
 
     def end_batch(self):
         if self._cur is not None:
-            self.parts.append((self.batch_no, ''.join(self._cur).encode()))
+            key = (self.rank << 40) + self.batch_no if self.contiguous else self.batch_no
+            self.parts.append((key, ''.join(self._cur).encode()))
             self._cur = None
 
     def finish(self):
@@ -359,6 +371,8 @@ def main(args):
         shard = _ShardedOut(outf)
         if shard.rank == 0:
             outf.write("\t".join(header) + "\n")
+        if not args.plot_afreq:
+            shard.attach(invcf, args.region)
         region = invcf(args.region) if args.region else invcf
         n_samples = max(len(invcf.samples), 1)
         batch_loci = max(1, min(4096, BATCH_CELLS // n_samples))

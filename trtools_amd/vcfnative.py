@@ -143,6 +143,19 @@ class RawBatch:
             cap = -n + 64
         return buf.raw[:n], el.value, ek.value
 
+    def chroms(self):
+        """The distinct CHROM values of the batch, in order of first appearance."""
+        out, last = [], None
+        for l in range(self.n):
+            f0, f1 = int(self.b.field_off[l * 10]), int(self.b.field_off[l * 10 + 1])
+            c = C.string_at(self.b.text + self.b.line_off[l] + f0, f1 - 1 - f0)
+            if c != last:
+                last = c
+                d = c.decode()
+                if d not in out:
+                    out.append(d)
+        return out
+
     def format_columns(self):
         """The distinct FORMAT columns of the batch's records, as lists of keys (normally one).  Vectorised: records
         whose FORMAT bytes equal the first record's are recognised without touching Python strings."""
@@ -258,6 +271,9 @@ def _api():
         lib.trk_vcf_select_format.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
         lib.trk_vcf_read_batch.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_Batch)]
         lib.trk_vcf_seek.argtypes = [vp, C.c_uint64]
+        lib.trk_vcf_shard.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        lib.trk_vcf_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
+        lib.trk_vcf_counters.restype = None
         lib.trk_vcf_harmonize.argtypes = [vp, C.POINTER(_Batch), C.c_int, C.POINTER(_Harmonized)]
         lib.trk_vcf_statstr_rows.argtypes = [C.POINTER(_Batch), C.POINTER(_Harmonized), C.POINTER(_StatRows), vp,
                                              C.c_char_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -354,6 +370,26 @@ class NativeVCFReader(vcfio.VCFReader):
         rb = RawBatch(self, b, gt, ph, lp, planes)
         rb._keep = parr
         return rb
+
+    def shard(self, rank, world):
+        """Keep only this rank's contiguous share of the records (trk_vcf_shard: the compressed file cut at BGZF block
+        boundaries, a record belongs to the rank in whose range its line starts).  Call before the first read.
+        True when the file could be cut; False leaves the reader untouched (plain gzip: every rank reads everything
+        and the callers deal batches out round-robin)."""
+        if world <= 1:
+            return True
+        b, e = C.c_uint64(), C.c_uint64()
+        if self._lib.trk_vcf_shard(self._h, int(rank), int(world), C.byref(b), C.byref(e)) != 0:
+            return False
+        self.shard_range = (b.value, e.value)
+        self._rows, self._row_i, self._eof = [], 0, False
+        return True
+
+    def counters(self):
+        """{inflated bytes, compressed bytes, BGZF blocks} read since ``shard`` (trk_vcf_counters)."""
+        out = (C.c_uint64 * 3)()
+        self._lib.trk_vcf_counters(self._h, out)
+        return dict(inflated=int(out[0]), compressed=int(out[1]), blocks=int(out[2]))
 
     def use_buffers(self, allocator=None, ring=2, release=None):
         """Decode batches into a ring of ``ring`` preallocated array sets instead of fresh numpy arrays (a batch then
