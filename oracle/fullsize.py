@@ -25,6 +25,7 @@ LC_TOTALCALLS, LC_PASS, LC_NO_CALLS, LC_FILTER0, LC_HWE_ERRORS = 0, 1, 2, 3, 31
 FLOAT_COLS = [LF_THRESH, LF_MEAN, LF_MODE, LF_VAR, LF_HET_LEN, LF_HET_STR, LF_ENTROPY_LEN, LF_ENTROPY_STR,
               LF_HWEP_LEN, LF_HWEP_STR]
 RTOL = 1e-9
+P_TINY = 1e-280      # p-values are compared relative to themselves down to here
 
 
 def _cmp_stats(tag, lo, cnt_d, li_d, lf_d, cnt_o, oi, of, n_samples):
@@ -48,10 +49,20 @@ def _cmp_stats(tag, lo, cnt_d, li_d, lf_d, cnt_o, oi, of, n_samples):
         if bad.any():
             raise AssertionError("%s: float column %d nan pattern differs at locus %d" % (tag, c, first(bad)))
         ok = ~np.isnan(a)
-        err = np.abs(a[ok] - b[ok]) / np.maximum(1.0, np.abs(b[ok]))
-        # p-values far below 1 are compared relative to themselves
-        small = np.abs(b[ok]) < 1.0
-        err[small] = np.minimum(err[small], np.abs(a[ok][small] - b[ok][small]) / np.maximum(np.abs(b[ok][small]), 1e-300))
+        aa, bb = a[ok], b[ok]
+        if c in (LF_HWEP_LEN, LF_HWEP_STR):
+            # p-values: RELATIVE to themselves all the way down (1e-200 against 1.1e-200 is a 10 % error, not an
+            # absolute 1e-201), except where float64 runs out: below P_TINY both sides only have to be that small
+            # (the exact test's pmf(k) underflows there; the device returns 0, an incomplete-beta tail may return a
+            # denormal-range value -- tests/test_gpu_binomtest.py documents that boundary against scipy)
+            tiny = np.abs(bb) < P_TINY
+            err = np.abs(aa - bb) / np.maximum(np.abs(bb), P_TINY)
+            err[tiny] = np.where(np.abs(aa[tiny]) < 10 * P_TINY, 0.0, np.inf)
+        else:
+            err = np.abs(aa - bb) / np.maximum(1.0, np.abs(bb))
+            # values below 1 relative to themselves too, down to the rounding noise of a sum of ~1 terms
+            small = np.abs(bb) < 1.0
+            err[small] = np.minimum(err[small] * 1e3, np.abs(aa[small] - bb[small]) / np.maximum(np.abs(bb[small]), 1e-300))
         if err.size and err.max() > RTOL:
             i = np.flatnonzero(ok)[int(np.argmax(err))]
             raise AssertionError("%s: float column %d off by %.3g (rel) at locus %d: %r vs %r" %
@@ -63,6 +74,28 @@ def _cmp_stats(tag, lo, cnt_d, li_d, lf_d, cnt_o, oi, of, n_samples):
     if bad.any():
         raise AssertionError("%s: call rate differs at locus %d" % (tag, first(bad)))
     return worst
+
+
+def check_group_stats(fetch_inputs, n_loci, n_samples, tables, group_masks, dev, block=4096, n_threads=None):
+    """statSTR --samples at full size: EVERY locus of every sample group against oracle_c on the group's columns
+    (statSTR.py:520-542: a group's statistics are the statistics of the record restricted to its samples).
+    dev: cnt [G, sumA], li [G, L, cols], lf [G, L, cols] as the device wrote them."""
+    off, lc, sc, cv = tables
+    nt = n_threads or oracle_c.tuned_threads()
+    worst = 0.0
+    for lo in range(0, n_loci, block):
+        hi = min(n_loci, lo + block)
+        gt, _ = fetch_inputs(lo, hi)
+        o = (off[lo:hi + 1] - off[lo]).astype(np.int32)
+        sl = slice(int(off[lo]), int(off[hi]))
+        for g, m in enumerate(group_masks):
+            sub = np.ascontiguousarray(gt[:, np.asarray(m, dtype=bool)])
+            cnt_o, oi, of = oracle_c.batch_stats(sub, None, o, lc[sl], sc[sl], cv[sl], n_threads=nt)
+            worst = max(worst, _cmp_stats('statSTR group %d' % g, lo, dev['cnt'][g][sl], dev['li'][g][lo:hi],
+                                          dev['lf'][g][lo:hi], cnt_o, oi, of, int(np.sum(m))))
+            if not np.all(dev['li'][g][lo:hi, LI_N_SAMPLES] == int(np.sum(m))):
+                raise AssertionError("group %d: n_samples column differs in block %d" % (g, lo))
+    return dict(loci=int(n_loci), groups=len(group_masks), worst_float_rel=worst, threads=nt)
 
 
 def locus_filter_bits(oi, of, n_samples, min_callrate=None, min_hwep=None, min_het=None, max_het=None,
@@ -161,3 +194,49 @@ def check_step(fetch_inputs, fetch_outputs, n_loci, n_samples, tables, filters, 
             raise AssertionError("loc_info counters differ: %r vs %r" % (dev['loc_counters'][:8], loc[:8]))
     return dict(loci=int(n_loci), calls=int(n_loci) * int(S), calls_bit_for_bit=int(full_calls),
                 worst_float_rel=worst, threads=nt, sums=(counters, totaldp, dpmiss, loc))
+
+
+def check_assoc(fetch_gt, n_loci, n_samples, tables_off, allele_len, x, y, dev_int, dev_f64, sample_in=None,
+                non_major_cutoff=20.0, block=4096, n_threads=None):
+    """associaTR scan (SURVEY 8 row f3 / BASELINE configs[4]) at full size: EVERY locus against oracle_c's
+    orc_assoc_locus (pinned to oracle/associatr_oracle.py by tests/test_oracle_c.py).
+
+    fetch_gt(lo, hi) -> int16 [n, S, 2]; x [S, M] design (column 0 reserved, column 1 ones, covariates), y [S];
+    dev_int [L, >= 2] (n_tested, status), dev_f64 [L, >= 4] (p, coef_std, se_std, R^2) as the device wrote them.
+    Tested-sample counts and the filter decision of every locus exactly; the four statistics to 1e-9 relative
+    (R^2 near 0: 1e-13 absolute).  Returns dict(loci, regressed, worst_rel)."""
+    nt = n_threads or oracle_c.tuned_threads()
+    off = np.asarray(tables_off)
+    worst, regressed = 0.0, 0
+    for lo in range(0, n_loci, block):
+        hi = min(n_loci, lo + block)
+        gt = fetch_gt(lo, hi)
+        o = (off[lo:hi + 1] - off[lo]).astype(np.int32)
+        oi, of = oracle_c.assoc_scan(gt, o, allele_len[int(off[lo]):int(off[hi])], x, y, sample_in=sample_in,
+                                     non_major_cutoff=non_major_cutoff, n_threads=nt)
+        di, df = dev_int[lo:hi], dev_f64[lo:hi]
+        bad = di[:, 0] != oi[:, 0]
+        if bad.any():
+            i = int(np.flatnonzero(bad)[0])
+            raise AssertionError("assoc: n_tested differs at locus %d: %d vs %d" % (lo + i, di[i, 0], oi[i, 0]))
+        # statuses 0-4 are the reference's decisions; 5 (oracle: degenerate) / 5-6 (device) carry no statistics
+        o_ok, d_ok = oi[:, 1] == 0, di[:, 1] == 0
+        degenerate = (oi[:, 1] == 5) | (di[:, 1] >= 5)
+        bad = (oi[:, 1] != np.minimum(di[:, 1], 5)) & ~degenerate
+        if bad.any():
+            i = int(np.flatnonzero(bad)[0])
+            raise AssertionError("assoc: filter decision differs at locus %d: %d vs %d" % (lo + i, di[i, 1], oi[i, 1]))
+        both = o_ok & d_ok
+        regressed += int(both.sum())
+        for col in range(4):
+            a, b = df[both, col], of[both, col]
+            err = np.abs(a - b) / np.maximum(np.abs(b), 1e-300)
+            if col == 3:
+                err = np.where(np.abs(a - b) <= 1e-13, 0.0, err)
+            if err.size and not (err.max() <= RTOL):
+                i = int(np.flatnonzero(both)[int(np.nanargmax(err))])
+                raise AssertionError("assoc: column %d off by %.3g (rel) at locus %d: %r vs %r" %
+                                     (col, np.nanmax(err), lo + i, df[i, col], of[i, col]))
+            if err.size:
+                worst = max(worst, float(err.max()))
+    return dict(loci=int(n_loci), regressed=regressed, worst_rel=worst, threads=nt)

@@ -366,3 +366,251 @@ void orc_call_filters(const int16_t* gt, int L, int S, int P, const uint8_t* loc
         free(cn);
     }
 }
+
+/* ======================================================================================
+ * associaTR linear-regression scan, one locus at a time, restated from
+ *   associaTR/load_and_filter_genotypes.py:157-259  (called samples, length allele frequencies rounded to two
+ *                                                    decimals, the non-major-allele filter)
+ *   associaTR/associaTR.py:246-291                  (summed length standardised over the tested samples, OLS of the
+ *                                                    outcome on [genotype, 1, covariates], p / coefficient / se / R^2)
+ * and from statsmodels' published OLS.fit() for a full-rank design (normal equations here, in long double; the
+ * numpy restatement oracle/associatr_oracle.py does the SVD pseudo-inverse -- tests/test_oracle_c.py pins this
+ * function to it on random loci and on the golden cases' designs).  Diploid tensors.
+ * ====================================================================================== */
+#include <stdio.h>
+
+/* Python's round(x, 2) (correctly rounded decimal, half to even on the exact binary value) */
+static double orc_round2(double x) {
+    char buf[64];
+    snprintf(buf, sizeof buf, "%.2f", x);
+    return strtod(buf, NULL);
+}
+
+/* numpy's add.reduce over a contiguous float64 array of n <= 128 elements (pairwise_sum, numpy/core/src/umath/
+ * loops_utils.h.src): a plain loop below 8 elements, eight accumulators above */
+static double orc_np_sum(const double* a, int n) {
+    if (n < 8) {
+        double r = 0.0;           /* (numpy starts from -0.0; the sign of an empty or all-zero sum does not matter here) */
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+/* regularised incomplete beta I_x(a, b) by the continued fraction (modified Lentz), for the Student-t tail */
+static double orc_betacf(double a, double b, double x) {
+    const double tiny = 1e-300;
+    double qab = a + b, qap = a + 1.0, qam = a - 1.0, c = 1.0, d = 1.0 - qab * x / qap;
+    if (fabs(d) < tiny) d = tiny;
+    d = 1.0 / d;
+    double h = d;
+    for (int m = 1; m <= 100000; ++m) {
+        int m2 = 2 * m;
+        double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+        d = 1.0 + aa * d; if (fabs(d) < tiny) d = tiny;
+        c = 1.0 + aa / c; if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d; h *= d * c;
+        aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+        d = 1.0 + aa * d; if (fabs(d) < tiny) d = tiny;
+        c = 1.0 + aa / c; if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        double del = d * c;
+        h *= del;
+        if (fabs(del - 1.0) < 1e-16) break;
+    }
+    return h;
+}
+/* I_x(a, b) with xc = 1 - x handed in separately (either may be tiny; neither is formed by subtraction here) */
+static double orc_betainc(double a, double b, double x, double xc) {
+    if (x <= 0.0) return 0.0;
+    if (xc <= 0.0) return 1.0;
+    /* (long double log-gammas: at df ~ 1e5 the three terms are ~1e6 each and their difference is wanted to 1e-12) */
+    double lbt = (double)(lgammal((long double)a + b) - lgammal((long double)a) - lgammal((long double)b)) + a * log(x) + b * log(xc);
+    if (x < (a + 1.0) / (a + b + 2.0)) return exp(lbt) * orc_betacf(a, b, x) / a;
+    return 1.0 - exp(lbt) * orc_betacf(b, a, xc) / b;
+}
+/* 2 * scipy.stats.t.sf(|t|, df) = I_{df / (df + t^2)}(df / 2, 1 / 2) */
+double orc_t_two_sided(double t, double df) {
+    if (t != t || df != df) return NAN;
+    const double t2 = t * t;
+    const double x = df / (df + t2), xc = t2 / (df + t2);
+    /* |t| < 1: the p-value is of order 1 and x rounds towards 1 -- the complementary form keeps the digits */
+    if (t2 < 1.0) return 1.0 - orc_betainc(0.5, 0.5 * df, xc, x);
+    return orc_betainc(0.5 * df, 0.5, x, xc);
+}
+
+/* One locus.  x: design [S][M] in sample order, column 0 reserved for the genotype, column 1 the intercept, the rest
+ * standardised covariates; y: outcome [S]; sample_in: uint8[S] or NULL.  out_i: {n_tested, status}; status 0 tested,
+ * 1 no called samples, 2 only one called allele, 3 non-major allele count below the cutoff, 4 n covars >= n samples,
+ * 5 degenerate (constant genotype / singular design: not compared).  out_f: {p, coef_std, se_std, R^2}. */
+void orc_assoc_locus(const int16_t* gt, int S, int A, const double* alen, const uint8_t* sample_in, const double* x,
+                     int M, const double* y, double non_major_cutoff, int32_t* out_i, double* out_f) {
+    out_f[0] = out_f[1] = out_f[2] = out_f[3] = NAN;
+    /* allele frequencies by rounded length, ascending */
+    double* rl = (double*)malloc(sizeof(double) * (size_t)(A > 0 ? A : 1));
+    int* cls = (int*)malloc(sizeof(int) * (size_t)(A > 0 ? A : 1));
+    double* ukey = (double*)malloc(sizeof(double) * (size_t)(A > 0 ? A : 1));
+    int nu = 0;
+    for (int a = 0; a < A; ++a) rl[a] = orc_round2(alen[a]);
+    for (int a = 0; a < A; ++a) {           /* distinct rounded lengths, ascending */
+        int found = 0;
+        for (int u = 0; u < nu; ++u) found |= ukey[u] == rl[a];
+        if (!found) ukey[nu++] = rl[a];
+    }
+    for (int i = 1; i < nu; ++i) {          /* insertion sort */
+        double k = ukey[i]; int j = i - 1;
+        while (j >= 0 && ukey[j] > k) { ukey[j + 1] = ukey[j]; --j; }
+        ukey[j + 1] = k;
+    }
+    for (int a = 0; a < A; ++a) for (int u = 0; u < nu; ++u) if (ukey[u] == rl[a]) cls[a] = u;
+    /* counts by EXACT length first (np.unique over the called alleles' lengths), then merged by rounded key in
+     * ascending order (clean_len_alleles): frequency of a rounded class = sum of c / total over its exact lengths in
+     * ascending exact-length order */
+    int64_t* cnt = (int64_t*)calloc((size_t)(A > 0 ? A : 1), sizeof(int64_t));
+    int n = 0;
+    long double sg = 0.0L, sgg = 0.0L;
+    double* g = (double*)malloc(sizeof(double) * (size_t)(S > 0 ? S : 1));
+    int* idx = (int*)malloc(sizeof(int) * (size_t)(S > 0 ? S : 1));
+    int64_t total = 0;
+    for (int s = 0; s < S; ++s) {
+        int a0 = gt[2 * (size_t)s], a1 = gt[2 * (size_t)s + 1];
+        if (a0 == -1 || a1 == -1) continue;
+        if (sample_in && !sample_in[s]) continue;
+        double v = 0.0;
+        int ok = 1;
+        for (int j = 0; j < 2; ++j) {
+            int a = j ? a1 : a0;
+            if (a == -2) v += -2.0;                     /* lut = [*lengths, -2, -1] (tr_harmonizer.py:1239) */
+            else if (a >= 0 && a < A) { v += alen[a]; cnt[a]++; total++; }
+            else ok = 0;
+        }
+        if (!ok) continue;
+        g[n] = v; idx[n] = s; ++n;
+        sg += v;
+    }
+    out_i[0] = n;
+    /* distinct exact lengths among the counted alleles, ascending; their frequencies merged by rounded class */
+    double* fr = (double*)calloc((size_t)(nu > 0 ? nu : 1), sizeof(double));
+    int* seen = (int*)calloc((size_t)(nu > 0 ? nu : 1), sizeof(int));
+    {
+        /* order allele indices by exact length (stable), merge equal exact lengths first */
+        int* ord = (int*)malloc(sizeof(int) * (size_t)(A > 0 ? A : 1));
+        for (int a = 0; a < A; ++a) ord[a] = a;
+        for (int i = 1; i < A; ++i) {
+            int k = ord[i], j = i - 1;
+            while (j >= 0 && alen[ord[j]] > alen[k]) { ord[j + 1] = ord[j]; --j; }
+            ord[j + 1] = k;
+        }
+        int i = 0;
+        while (i < A) {
+            int j = i;
+            int64_t c = 0;
+            while (j < A && alen[ord[j]] == alen[ord[i]]) c += cnt[ord[j++]];
+            if (c > 0) {
+                int u = cls[ord[i]];
+                double f = (double)c / (double)total;
+                if (!seen[u]) { fr[u] = f; seen[u] = 1; } else fr[u] += f;
+            }
+            i = j;
+        }
+        free(ord);
+    }
+    int nfr = 0;
+    double* af = (double*)malloc(sizeof(double) * (size_t)(nu > 0 ? nu : 1));
+    for (int u = 0; u < nu; ++u) if (seen[u]) af[nfr++] = fr[u];
+    int status = 0;
+    if (nfr == 0) status = 1;
+    else if (nfr == 1) status = 2;
+    else {
+        int am = 0;
+        for (int u = 1; u < nfr; ++u) if (af[u] > af[am]) am = u;       /* np.argmax: first maximum */
+        for (int u = am; u + 1 < nfr; ++u) af[u] = af[u + 1];
+        if (orc_np_sum(af, nfr - 1) * n * 2 < non_major_cutoff) status = 3;
+    }
+    if (!status && M >= n) status = 4;
+    if (!status) {
+        const long double mean = sg / n;
+        for (int i = 0; i < n; ++i) { long double d = g[i] - mean; sgg += d * d; }
+        const long double sd = sqrtl(sgg / n);
+        if (!(sd > 0.0L)) status = 5;
+        else {
+            /* normal equations of [g_std, x_1..x_{M-1}] in long double, Gauss-Jordan with partial pivoting */
+            long double* N = (long double*)calloc((size_t)M * (M + 1), sizeof(long double));
+            long double yy = 0.0L, ysum = 0.0L;
+            long double* row = (long double*)malloc(sizeof(long double) * (size_t)M);
+            for (int i = 0; i < n; ++i) {
+                const int s = idx[i];
+                row[0] = (g[i] - mean) / sd;
+                for (int k = 1; k < M; ++k) row[k] = x[(size_t)s * M + k];
+                for (int a = 0; a < M; ++a) {
+                    for (int b = 0; b < M; ++b) N[a * (M + 1) + b] += row[a] * row[b];
+                    N[a * (M + 1) + M] += row[a] * y[s];
+                }
+                yy += (long double)y[s] * y[s];
+                ysum += y[s];
+            }
+            /* inverse of the normal matrix alongside: solve for beta and the (0,0) entry of the inverse */
+            long double* W = (long double*)calloc((size_t)M * 2 * M, sizeof(long double));
+            for (int a = 0; a < M; ++a) {
+                for (int b = 0; b < M; ++b) W[a * 2 * M + b] = N[a * (M + 1) + b];
+                W[a * 2 * M + M + a] = 1.0L;
+            }
+            int singular = 0;
+            for (int c = 0; c < M && !singular; ++c) {
+                int piv = c;
+                for (int r = c + 1; r < M; ++r) if (fabsl(W[r * 2 * M + c]) > fabsl(W[piv * 2 * M + c])) piv = r;
+                if (fabsl(W[piv * 2 * M + c]) < 1e-12L * n) { singular = 1; break; }
+                if (piv != c) for (int k = 0; k < 2 * M; ++k) { long double t = W[c * 2 * M + k]; W[c * 2 * M + k] = W[piv * 2 * M + k]; W[piv * 2 * M + k] = t; }
+                long double pv = W[c * 2 * M + c];
+                for (int k = 0; k < 2 * M; ++k) W[c * 2 * M + k] /= pv;
+                for (int r = 0; r < M; ++r) if (r != c) {
+                    long double f = W[r * 2 * M + c];
+                    if (f != 0.0L) for (int k = 0; k < 2 * M; ++k) W[r * 2 * M + k] -= f * W[c * 2 * M + k];
+                }
+            }
+            if (singular) status = 5;
+            else {
+                long double* beta = (long double*)calloc((size_t)M, sizeof(long double));
+                for (int a = 0; a < M; ++a) for (int b = 0; b < M; ++b) beta[a] += W[a * 2 * M + M + b] * N[b * (M + 1) + M];
+                /* ssr from the residuals (second pass), as the reference does */
+                long double ssr = 0.0L;
+                for (int i = 0; i < n; ++i) {
+                    const int s = idx[i];
+                    long double fit = beta[0] * ((g[i] - mean) / sd);
+                    for (int k = 1; k < M; ++k) fit += beta[k] * x[(size_t)s * M + k];
+                    long double r = y[s] - fit;
+                    ssr += r * r;
+                }
+                const long double df = (long double)n - M;
+                const long double scale = ssr / df;
+                const long double se = sqrtl(W[0 * 2 * M + M + 0] * scale);
+                const long double ym = ysum / n;
+                const long double sst = yy - n * ym * ym;
+                out_f[0] = orc_t_two_sided((double)(beta[0] / se), (double)df);
+                out_f[1] = (double)beta[0];
+                out_f[2] = (double)se;
+                out_f[3] = (double)(1.0L - ssr / sst);
+                free(beta);
+            }
+            free(W); free(row); free(N);
+        }
+    }
+    out_i[1] = status;
+    free(af); free(seen); free(fr); free(idx); free(g); free(cnt); free(ukey); free(cls); free(rl);
+}
+
+void orc_assoc_scan_mt(const int16_t* gt, int L, int S, const int32_t* off, const double* alen, const uint8_t* sample_in,
+                       const double* x, int M, const double* y, double non_major_cutoff, int32_t* out_i, double* out_f,
+                       int n_threads) {
+#pragma omp parallel for schedule(dynamic, 16) num_threads(n_threads)
+    for (int l = 0; l < L; ++l)
+        orc_assoc_locus(gt + (size_t)l * S * 2, S, off[l + 1] - off[l], alen + off[l], sample_in, x, M, y, non_major_cutoff,
+                        out_i + 2 * (size_t)l, out_f + 4 * (size_t)l);
+}

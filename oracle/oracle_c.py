@@ -146,3 +146,25 @@ def call_filters_dpq(gt, dp, q, min_dp, max_dp, min_q):
     lib.orc_call_filters_dpq(_p(gt), _p(dp), _p(q), Lc, S, C.c_double(min_dp), C.c_double(max_dp),
                              C.c_double(min_q), _p(gout), _p(mask), _p(counters), _p(totaldp), _p(dpmiss))
     return gout, mask, counters, totaldp, dpmiss
+
+
+def assoc_scan(gt, off, allele_len, x, y, sample_in=None, non_major_cutoff=20.0, n_threads=1):
+    """orc_assoc_scan_mt: the associaTR scan of a diploid batch.  x: design [S, M] (column 0 reserved for the genotype,
+    column 1 the intercept, then standardised covariates), y: outcome [S].  Returns (out_i [L, 2] = n_tested, status;
+    out_f [L, 4] = p, coef_std, se_std, R^2)."""
+    lib = load()
+    gt = np.ascontiguousarray(gt, dtype=np.int16)
+    Lc, S, P = gt.shape
+    assert P == 2
+    off = np.ascontiguousarray(off, dtype=np.int32)
+    al = np.ascontiguousarray(allele_len, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    assert x.shape[0] == S and y.shape == (S,)
+    si = None if sample_in is None else np.ascontiguousarray(sample_in, dtype=np.uint8)
+    oi = np.zeros((Lc, 2), dtype=np.int32)
+    of = np.full((Lc, 4), np.nan)
+    lib.orc_assoc_scan_mt.restype = None
+    lib.orc_assoc_scan_mt(_p(gt), C.c_int(Lc), C.c_int(S), _p(off), _p(al), None if si is None else _p(si), _p(x),
+                          C.c_int(x.shape[1]), _p(y), C.c_double(non_major_cutoff), _p(oi), _p(of), C.c_int(n_threads))
+    return oi, of

@@ -265,7 +265,20 @@ def test_config4_associatr_100k_x_10k(eng):
     ym[m] = (y[m] - y[m].mean()) / y[m].std()
     lim, lfm, cntm = scan(ym[None, :], sample_in=mask)
     assert np.all(lim[:, TL.AI_N_TESTED] <= li[:, TL.AI_N_TESTED]) and lim[:, TL.AI_N_TESTED].max() <= m.sum()
-    # sampled loci against the oracle (rows regenerated by the generator's numpy twin), full and masked runs
+    # EVERY locus of both runs against the compiled restatement of the scan (oracle_c.c orc_assoc_locus, pinned to the
+    # numpy oracle by tests/test_oracle_c.py): tested samples, filter decisions, p / coefficient / se / R^2
+    from oracle import fullsize
+    gt_d = sb.dev['gt']
+    x1 = np.zeros((S, 2))
+    x1[:, 1] = 1.0
+    r_all = fullsize.check_assoc(lambda lo, hi: gt_d.get_rows(lo, hi), Lc, S, sb.tables[0], alen, x1, y, li, lf)
+    assert r_all['loci'] == Lc and r_all['regressed'] > 0.8 * Lc and r_all['worst_rel'] <= 1e-9
+    ym_full = np.zeros(S)
+    ym_full[m] = ym[m]
+    r_m = fullsize.check_assoc(lambda lo, hi: gt_d.get_rows(lo, hi), Lc, S, sb.tables[0], alen, x1, ym_full, lim, lfm,
+                               sample_in=mask)
+    assert r_m['loci'] == Lc and r_m['worst_rel'] <= 1e-9
+    # sampled loci against the numpy oracle (rows regenerated by the generator's numpy twin), full and masked runs
     idx = np.unique(np.linspace(0, Lc - 1, 9).astype(int))
     rows = sb.host_rows(idx)
     for k, l in enumerate(idx):
@@ -368,3 +381,70 @@ def test_config3_locus_shards_add_up_to_the_cohort(eng):
             assert np.array_equal(np.concatenate([p[key] for p in parts]), whole[key], equal_nan=True), (world, key)
         for key in ('loc', 'cnt', 'td'):
             assert np.array_equal(sum(p[key] for p in parts), whole[key]), (world, key)
+
+
+def test_config3_use_length_every_locus(eng):
+    """The combined step with --use-length locus filters (length alleles: HWE / heterozygosity by repeat length), a
+    40 000 x 4 000 cohort, every locus against the compiled oracle (the full-size checks ran
+    use_length = False only)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from trtools_amd.synth import make_loci
+    seed, S, Lc = 20260928 + 13, 4000, 40000
+    loci = make_loci(Lc, S, seed)
+    wl = bench.Workload(eng, seed, S, loci, 0, 1, use_comm=False)
+    wl.locus_args = dict(bench.LOCUS_ARGS, use_length=True, min_hwep=1e-6, min_het=0.3)
+    for _ in range(2):
+        wl.step()
+    wl.flush()
+    eng.sync()
+    r = bench.exhaustive_check(wl, single_rank_sums=True)
+    assert r['loci'] == Lc and r['worst_float_rel'] <= 1e-9
+    # the two allele notions really decide differently on this cohort (else the test would prove nothing)
+    wl2 = bench.Workload(eng, seed, S, loci, 0, 1, use_comm=False)
+    wl2.locus_args = dict(wl.locus_args, use_length=False)
+    wl2.step()
+    wl2.flush()
+    eng.sync()
+    assert not np.array_equal(wl.bits.get(), wl2.bits.get())
+    wl.free()
+    wl2.free()
+
+
+@pytest.mark.parametrize('layout', ['two_disjoint', 'five_overlapping'])
+def test_statstr_sample_groups_every_locus(eng, layout):
+    """statSTR --samples at 50 000 x 5 000: every locus of every group against the compiled oracle on the group's
+    columns -- the one-pass grouped kernel (<= 3 groups), the class-column-range path (trk_batch.class_runs) and,
+    for the two-group layout, both against each other bit for bit."""
+    from oracle import fullsize
+    from trtools_amd.synth import SynthBatch
+    Lc, S = 50000, 5000
+    sb = SynthBatch(eng, Lc, S, seed=20260928 + 21, planes=())
+    rng = np.random.default_rng(21)
+    if layout == 'two_disjoint':
+        a = rng.random(S) < 0.4
+        gb, G = (a * 1 + (~a) * 2).astype(np.uint8), 2
+    else:
+        gb, G = rng.integers(0, 32, size=S).astype(np.uint8), 5
+    masks = [((gb >> g) & 1).astype(bool) for g in range(G)]
+    gt_d = sb.dev['gt']
+
+    def fetch(lo, hi):
+        return gt_d.get_rows(lo, hi), []
+    results = []
+    for path in (('sorted',) if G > 3 else ('grouped', 'sorted')):
+        b = sb.batch.sorted_by_class(eng, gb, G) if path == 'sorted' else sb.batch.with_groups(eng, gb, G)
+        res = eng.locus_stats(b, nalleles_thresh=0.01)
+        dev = dict(cnt=res.allele_count.get(), li=res.locus_int.get(), lf=res.locus_f64.get())
+        r = fullsize.check_group_stats(fetch, Lc, S, sb.tables, masks, dev)
+        assert r['loci'] == Lc and r['worst_float_rel'] <= 1e-9
+        results.append(dev)
+        for x in (res.allele_count, res.locus_int, res.locus_f64):
+            x.free()
+        if path == 'sorted':
+            b.arrays['gt'].free()
+    if len(results) == 2:
+        for k in ('cnt', 'li', 'lf'):
+            assert np.array_equal(results[0][k], results[1][k], equal_nan=True), k

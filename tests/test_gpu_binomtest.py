@@ -69,3 +69,36 @@ def test_invalid_triples_and_empty(eng):
     out = eng.binomtest_batch([3, -1, 5, 2], [0, 5, 4, 5], [0.5, 0.5, 0.5, 1.5])
     assert np.all(np.isnan(out))
     assert eng.binomtest_batch([], [], []).shape == (0,)
+
+
+def test_p_values_down_to_the_underflow_boundary_against_scipy(eng):
+    """What a statSTR `hwep` cell holds for very unlikely loci.  Along one family of triples
+    (n = 20 000, p = 0.5, k moving away from the mean) the exact p-value falls from 1e-5 to below the smallest
+    float64:
+      * down to 1e-280 the device agrees with scipy RELATIVE to the value (1e-9), not merely to an absolute 1e-9;
+      * where pmf(k) itself underflows (below ~1e-308: |z| beyond ~37.6) both tails are sums of zeros: the device
+        returns exactly 0.0 -- scipy returns 0.0 there too, or a denormal-range number out of the incomplete-beta
+        tail (< 1e-300).  statSTR's '{:.p}'-formatted cell reads '0.0' on the device side where the reference may
+        print e.g. '1e-310' -- inside north_star's 1e-9, and the boundary is this test's to document;
+      * in between (1e-308 ... 1e-280: denormal intermediate sums) both sides are only required to be that small."""
+    from scipy.stats import binomtest
+    n, p = 20000, 0.5
+    ks = np.unique(np.concatenate([np.arange(10320, 13000, 37), np.arange(12600, 12760)])).astype(np.int64)
+    dev = eng.binomtest_batch(ks, np.full(ks.size, n, dtype=np.int64), np.full(ks.size, p))
+    seen_rel = seen_zero = 0
+    last = 1.0
+    for k, d in zip(ks, dev):
+        want = binomtest(int(k), n, p).pvalue
+        assert d <= last * (1 + 1e-12)          # monotone in the distance from the mean
+        last = max(d, 0.0)
+        if want >= 1e-280:
+            assert abs(d - want) <= 1e-9 * want, (k, d, want)
+            seen_rel += 1
+        elif want >= 1e-300:
+            assert d < 1e-270, (k, d, want)
+        else:
+            assert d < 1e-290, (k, d, want)
+            seen_zero += d == 0.0
+    assert seen_rel > 40 and seen_zero > 20
+    # the statistic's formatting at the boundary: what the table shows
+    assert '{:.4}'.format(float(dev[-1])) == '0.0'

@@ -4,6 +4,7 @@ import collections
 import math
 
 import numpy as np
+import pytest
 
 from oracle import trtools_oracle as orc
 from oracle import oracle_c
@@ -59,3 +60,85 @@ def test_c_call_filters_match_numpy_oracle():
     tot[dpmiss > 0] = np.nan
     assert np.array_equal(np.isnan(tot), np.isnan(info['totaldp']))
     assert np.array_equal(tot[~np.isnan(tot)], info['totaldp'][~np.isnan(tot)])
+
+
+def _assoc_case(seed, S, n_cov, subset):
+    rng = np.random.default_rng(seed)
+    Lc = 60
+    lens, rows = [], []
+    for l in range(Lc):
+        A = int(rng.integers(1, 9))
+        base = float(rng.integers(5, 30))
+        al = [base] + [base + float(rng.integers(-6, 7)) + float(rng.choice([0.0, 0.0, 0.5, 0.004, 0.001, 0.25]))
+                       for _ in range(A - 1)]
+        lens.append(al)
+        p = rng.dirichlet(np.full(A, 0.4))
+        if l % 11 == 3:
+            p = np.eye(A)[0] * 0.999 + 0.001 / A           # nearly monomorphic: the non-major-allele filter
+            p /= p.sum()
+        g = rng.choice(A, size=(S, 2), p=p).astype(np.int16)
+        g[rng.random(S) < 0.05] = -1
+        g[rng.random(S) < 0.01, 1] = -1                    # half-missing calls are not called
+        if l % 17 == 5:
+            g[:] = -1
+        rows.append(g)
+    gt = np.stack(rows)
+    off = np.concatenate([[0], np.cumsum([len(a) for a in lens])]).astype(np.int32)
+    alen = np.concatenate([np.array(a) for a in lens])
+    cov = rng.normal(size=(S, n_cov))
+    y = rng.normal(size=S) + 0.1 * gt[7, :, 0]
+    sample_in = (rng.random(S) < 0.7) if subset else np.ones(S, dtype=bool)
+    # standardisation over the regression set, as associaTR.py:192-204 does
+    full = np.concatenate([y[:, None], cov], axis=1)[sample_in]
+    full = (full - full.mean(axis=0)) / full.std(axis=0)
+    x = np.zeros((S, 2 + n_cov))
+    x[:, 1] = 1.0
+    x[sample_in, 2:] = full[:, 1:]
+    yy = np.zeros(S)
+    yy[sample_in] = full[:, 0]
+    return gt, off, alen, lens, x, yy, sample_in
+
+
+@pytest.mark.parametrize('S,n_cov,subset,cutoff', [(300, 0, False, 20.0), (257, 2, True, 5.0), (64, 3, False, 1.0),
+                                                   (1500, 1, True, 40.0)])
+def test_c_association_scan_equals_the_numpy_oracle(S, n_cov, subset, cutoff):
+    """oracle_c.c's orc_assoc_locus against oracle/associatr_oracle.py (itself pinned to the reference-generated
+    tables and the plink fixtures): tested-sample counts and filter reasons exactly, p / coefficient / se / R^2 to
+    1e-10 -- so that the GPU scan can be checked at EVERY locus of BASELINE configs[4]."""
+    from oracle import associatr_oracle as ao
+    gt, off, alen, lens, x, y, sample_in = _assoc_case(1000 + S + n_cov, S, n_cov, subset)
+    oi, of = oracle_c.assoc_scan(gt, off, alen, x, y, sample_in=None if not subset else sample_in,
+                                 non_major_cutoff=cutoff, n_threads=2)
+    covars = x[sample_in]
+    outcome = y[sample_in]
+    reasons = {None: 0, 'No called samples': 1, 'Only one called allele': 2, 'n covars >= n samples': 4}
+    n_reg = 0
+    for l in range(gt.shape[0]):
+        r = ao.scan_locus(gt[l], lens[l], sample_in, covars, outcome, 1.0, cutoff, 2)
+        assert oi[l, 0] == r['n_tested'], l
+        why = r['locus_filtered']
+        want = 3 if (why and why.startswith('non-major')) else reasons[why]
+        if oi[l, 1] == 5:
+            continue                       # constant genotype over the tested samples: nothing to compare
+        assert oi[l, 1] == want, (l, oi[l], why)
+        if want == 0:
+            n_reg += 1
+            for j, key in enumerate(('pval', 'coef_std', 'se_std', 'rsquared')):
+                # (R^2 = 1 - ssr / sst cancels near 0: float64 noise of the numpy side, 1e-15 absolute)
+                assert abs(of[l, j] - r[key]) <= 1e-10 * abs(r[key]) + (1e-13 if key == 'rsquared' else 1e-300), \
+                    (l, key, of[l, j], r[key])
+    assert n_reg >= 20
+
+
+def test_c_student_t_tail_against_scipy():
+    import ctypes as C
+    from scipy.stats import t as student
+    lib = oracle_c.load()
+    lib.orc_t_two_sided.restype = C.c_double
+    lib.orc_t_two_sided.argtypes = [C.c_double, C.c_double]
+    rng = np.random.default_rng(4)
+    for df in (1, 2, 5, 30, 997, 9998, 250000):
+        for tv in np.concatenate([[0.0, 1e-9, 0.3, 1.0, 2.5, 8.0, 20.0, 37.0], rng.uniform(0, 40, 20)]):
+            want = 2 * student.sf(tv, df)
+            got = lib.orc_t_two_sided(float(tv), float(df))
+            assert abs(got - want) <= 2e-11 * want + 1e-300, (df, tv, got, want)
