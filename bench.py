@@ -361,8 +361,20 @@ def assoc_extra(wl, seed, no_check, no_cpu, iters=5, group=None, total_loci=None
             for col, key in ((0, 'pval'), (1, 'coef_std'), (2, 'se_std'), (3, 'rsquared')):
                 assert abs(lf[l, col] - r[key]) <= 1e-9 * abs(r[key]) + 1e-12, (l, key, lf[l, col], r[key])
             checked += 1
-        out["parity_loci_checked"] = int(len(idx))
-        out["parity_loci_regressed"] = checked
+        # ... and EVERY locus of the shard against the compiled restatement (oracle_c.c orc_assoc_locus)
+        from oracle import fullsize
+        gt_d = wl.sb.dev['gt']
+        x1 = np.zeros((n_samples, 2))
+        x1[:, 1] = 1.0
+        t0 = time.perf_counter()
+        ra = fullsize.check_assoc(lambda lo, hi: gt_d.get_rows(lo, hi), n_loci, n_samples, wl.sb.tables[0], alen, x1, y,
+                                  li, lf, non_major_cutoff=20.0,
+                                  n_threads=max(1, fullsize.oracle_c.tuned_threads() // max(1, world)))
+        out["parity_loci_checked"] = int(ra['loci'])
+        out["parity_loci_regressed"] = int(ra['regressed'])
+        out["parity"] = {"checker": "oracle/oracle_c.c orc_assoc_locus on %d host threads, every locus; %d loci also "
+                                    "against oracle/associatr_oracle.py" % (ra['threads'], len(idx)),
+                         "worst_rel": ra['worst_rel'], "seconds": time.perf_counter() - t0}
         if not no_cpu:
             # the same scan through the oracle port (numpy + scipy, one locus and one OLS fit at a time like the
             # reference), 1 core, on a bounded sample of loci regenerated by the generator's numpy twin

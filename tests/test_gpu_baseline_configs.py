@@ -448,3 +448,33 @@ def test_statstr_sample_groups_every_locus(eng, layout):
     if len(results) == 2:
         for k in ('cnt', 'li', 'lf'):
             assert np.array_equal(results[0][k], results[1][k], equal_nan=True), k
+
+
+@pytest.mark.parametrize('n_cov,subset', [(2, False), (6, True)])
+def test_associatr_with_covariates_every_locus(eng, n_cov, subset):
+    """The scan with covariates (the LDS-resident and the MFMA kernels: 3 / 7 trait vectors) on 30 000 x 4 000, with
+    and without a sample subset: every locus against the compiled restatement."""
+    from oracle import fullsize
+    from trtools_amd.synth import SynthBatch, pack_assoc_tables
+    Lc, S = 30000, 4000
+    sb = SynthBatch(eng, Lc, S, seed=20260928 + 31 + n_cov, planes=())
+    alen, rcls = pack_assoc_tables(sb.loci.allele_lens, 2)
+    rng = np.random.default_rng(31 + n_cov)
+    keep = (rng.random(S) < 0.85) if subset else np.ones(S, dtype=bool)
+    raw = rng.normal(size=(S, 1 + n_cov))
+    raw[:, 1] += 0.3 * raw[:, 0]                          # correlated covariate
+    z = (raw[keep] - raw[keep].mean(axis=0)) / raw[keep].std(axis=0)
+    vec = np.zeros((1 + n_cov, S))
+    vec[:, keep] = z.T
+    res = eng.assoc_scan(sb.batch, vec, alen, rcls, sample_in=keep.astype(np.uint8) if subset else None,
+                         non_major_cutoff=20.0)
+    li, lf = res.locus_int.get(), res.locus_f64.get()
+    x = np.zeros((S, 2 + n_cov))
+    x[:, 1] = 1.0
+    x[:, 2:] = vec[1:].T
+    gt_d = sb.dev['gt']
+    r = fullsize.check_assoc(lambda lo, hi: gt_d.get_rows(lo, hi), Lc, S, sb.tables[0], alen, x, vec[0], li, lf,
+                             sample_in=keep.astype(np.uint8) if subset else None)
+    assert r['loci'] == Lc and r['regressed'] > 0.7 * Lc and r['worst_rel'] <= 1e-9
+    for d in (res.locus_int, res.locus_f64, res.allele_count):
+        d.free()
