@@ -2798,6 +2798,284 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
 }
 
 // ---------------------------------------------------------------------------
+// k_call_filter_gs : dumpSTR's CLOSED list of GangSTR call filters (dumpSTR.py:819-836, filters.py:327-409 and
+// 573-757) with static operand slots -- no interpreter loop, no indexed register moves, no scratch.  The nine
+// predicates in a fixed role order, each switched on or off by a wave-uniform flag:
+//   0 min DP   DP < t                 (every call)          5 QEXP total  QEXP[1] + QEXP[2] < t (float32 sum; called)
+//   1 max DP   DP > t                 (every call)          6 span only   RC[1] == DP                     (called)
+//   2 min Q    Q < t (float32)        (every call)          7 span+bound  RC[1] + RC[3] == DP (int64 sum; called)
+//   3 QEXP het QEXP[1] < t            (called)              8 bad CI      REPCN[j] outside REPCI[2j .. 2j+1], j = 0, 1
+//   4 QEXP hom QEXP[2] < t            (called)
+// Same tiling, counters, delta table and outputs as k_call_filter_v2 (column-owner: thread = 4 samples x the loci of
+// its workgroup).  PLANAR: every column its own [L, S] array (13 16-byte loads per locus, unused columns never
+// read); otherwise the planes as cyvcf2 / Engine.upload_plane hands them, [L, S, k]: the k vectors of a thread's
+// four calls are loaded whole and the columns picked out of the registers with compile-time indices (16 loads).
+// ---------------------------------------------------------------------------
+constexpr int GS_NF = 9;
+#ifndef TRK_GS_NT_INTERLEAVED
+#define TRK_GS_NT_INTERLEAVED 0
+#endif
+constexpr bool GS_NT_INTERLEAVED = TRK_GS_NT_INTERLEAVED != 0;
+struct GsFilter {
+    int32_t on, bit, ithr;
+    float fthr;
+};
+struct GsArgs {
+    trk_batch b;
+    GsFilter f[GS_NF];
+    // PLANAR: dp, q, qexp[1], qexp[2], rc[1], rc[3], repcn[0], repcn[1], repci[0..3]; interleaved: dp, q, then the
+    // bases of QEXP [.,3], RC [.,4], REPCN [.,2], REPCI [.,4] in slots 2..5
+    const void* p[12];
+    int use_qexp, use_rc, use_ci, has_dp;
+    int loci_per_block, delta_nal;
+    uint16_t* part16;            // [gridDim.y][2 + GS_NF][S]
+    unsigned long long* part64;  // [gridDim.y][S]
+    trk_call_out out;
+};
+
+// MASK >= 0: the enabled roles are a compile-time set and filter `role` owns mask bit / counter row
+// popcount(MASK & ((1 << role) - 1)) -- the order dumpSTR builds its GangSTR list in (dumpSTR.py:819-836); no flag
+// or bit registers, no branches.  MASK < 0: flags and bits from the arguments.
+template <bool PLANAR, bool DELTA, int MASK>
+__global__ __launch_bounds__(CF_THREADS) void k_call_filter_gs(const GsArgs a) {
+    extern __shared__ uint32_t v2lds[];
+    const int tid = threadIdx.x;
+    const int S = a.b.n_samples, L = a.b.n_loci;
+    const int64_t s0 = ((int64_t)blockIdx.x * CF_THREADS + tid) * CF_V;
+    const int nal = a.delta_nal;
+    const int dstride = nal + V2_EXTRA;
+    uint32_t* dtab = v2lds;
+    uint32_t* lutb = dtab + (size_t)a.loci_per_block * dstride;
+    int32_t* linfo = reinterpret_cast<int32_t*>(lutb + (size_t)a.loci_per_block * nal);
+    // per-sample counters as 16-bit pairs (samples 2 i and 2 i + 1 share a register: a workgroup's loci stay below
+    // 65536): half the registers of one counter per sample -- 22 instead of 44 VGPRs, the difference between three
+    // and four waves per SIMD.  The low half takes the mask as the carry of an add, the high half through the SDWA
+    // form of the same instruction (carry in vcc).
+    uint32_t numcalls[2] = {0, 0}, dpmiss[2] = {0, 0};
+    uint32_t fc[GS_NF][2];
+    int64_t totaldp[CF_V] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < GS_NF; ++k) fc[k][0] = fc[k][1] = 0;
+    uint32_t vzero = 0;
+    asm volatile("" : "+v"(vzero));     // (a register that holds 0: SDWA takes no inline constants)
+    auto add16 = [&](uint32_t (&c)[2], int j, uint64_t mask) {
+        if (j & 1)
+            asm("s_mov_b64 vcc, %2\n\tv_addc_co_u32_sdwa %0, vcc, %1, %0, vcc dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE "
+                "src0_sel:DWORD src1_sel:WORD_1"
+                : "+v"(c[j >> 1]) : "v"(vzero), "s"(mask) : "vcc");
+        else
+            add_mask(c[j >> 1], mask);
+    };
+    const int n_blocks = (L + a.loci_per_block - 1) / a.loci_per_block;
+    for (int by = blockIdx.y; by < n_blocks; by += gridDim.y) {
+    const int l_begin = by * a.loci_per_block;
+    const int l_end = min(L, l_begin + a.loci_per_block);
+    const int nl = l_end - l_begin;
+    if (DELTA) {
+        for (int i = tid; i < nl * dstride; i += CF_THREADS) dtab[i] = 0;
+        cf_build_lut(a.b, l_begin, nl, nal, tid, lutb, linfo);
+    }
+    if (s0 < S) {
+        const bool leader = (tid & 63) == __ffsll((unsigned long long)__ballot(1)) - 1;
+        for (int l = l_begin; l < l_end; ++l) {
+            const int64_t c4 = ((int64_t)l * S + s0) >> 2;
+            // (interleaved planes: a lane's k vectors are k x 16 consecutive bytes, so every load instruction of the
+            // group touches every cache line of the wave's 64 k x 16 bytes -- plain loads, which the L1 may keep
+            // between them, instead of the streaming hint; TRK_GS_NT_INTERLEAVED for A/B runs)
+            auto ld = [&](int slot, int64_t idx) {
+                const u32x4* q = reinterpret_cast<const u32x4*>(a.p[slot]) + idx;
+                return (PLANAR || slot < 2 || GS_NT_INTERLEAVED) ? __builtin_nontemporal_load(q) : *q;
+            };
+            const u32x4 g = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.b.gt) + c4);
+            u32x4 dv = {0, 0, 0, 0}, qv = {0, 0, 0, 0};
+            const bool use_q = MASK >= 0 ? ((MASK >> 2) & 1) != 0 : a.f[2].on != 0;
+            const bool use_qexp = MASK >= 0 ? (MASK & 0x38) != 0 : a.use_qexp != 0;
+            const bool use_rc = MASK >= 0 ? (MASK & 0xc0) != 0 : a.use_rc != 0;
+            const bool use_ci = MASK >= 0 ? (MASK & 0x100) != 0 : a.use_ci != 0;
+            const bool has_dp = MASK >= 0 ? true : a.has_dp != 0;
+            if (has_dp) dv = ld(0, c4);
+            if (use_q) qv = ld(1, c4);
+            // operands by call j: e1 / e2 = QEXP[1] / QEXP[2], r1 / r3 = RC[1] / RC[3], cn / lo / hi by haplotype
+            u32x4 e1 = {0, 0, 0, 0}, e2 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0}, r3 = {0, 0, 0, 0};
+            u32x4 cn0 = {0, 0, 0, 0}, cn1 = {0, 0, 0, 0}, lo0 = {0, 0, 0, 0}, hi0 = {0, 0, 0, 0}, lo1 = {0, 0, 0, 0},
+                  hi1 = {0, 0, 0, 0};
+            if (PLANAR) {
+                if (use_qexp) { e1 = ld(2, c4); e2 = ld(3, c4); }
+                if (use_rc) { r1 = ld(4, c4); r3 = ld(5, c4); }
+                if (use_ci) { cn0 = ld(6, c4); cn1 = ld(7, c4); lo0 = ld(8, c4); hi0 = ld(9, c4); lo1 = ld(10, c4); hi1 = ld(11, c4); }
+            } else {
+                if (use_qexp) {           // 4 calls x 3 floats = 3 vectors: element 3 j + c of the 12
+                    const u32x4 x0 = ld(2, c4 * 3), x1 = ld(2, c4 * 3 + 1), x2 = ld(2, c4 * 3 + 2);
+                    e1 = (u32x4){x0[1], x1[0], x1[3], x2[2]};
+                    e2 = (u32x4){x0[2], x1[1], x2[0], x2[3]};
+                }
+                if (use_rc) {             // call j = vector j: {enclosing, spanning, flanking, bound}
+                    const u32x4 x0 = ld(3, c4 * 4), x1 = ld(3, c4 * 4 + 1), x2 = ld(3, c4 * 4 + 2), x3 = ld(3, c4 * 4 + 3);
+                    r1 = (u32x4){x0[1], x1[1], x2[1], x3[1]};
+                    r3 = (u32x4){x0[3], x1[3], x2[3], x3[3]};
+                }
+                if (use_ci) {
+                    const u32x4 n0 = ld(4, c4 * 2), n1 = ld(4, c4 * 2 + 1);
+                    cn0 = (u32x4){n0[0], n0[2], n1[0], n1[2]};
+                    cn1 = (u32x4){n0[1], n0[3], n1[1], n1[3]};
+                    const u32x4 x0 = ld(5, c4 * 4), x1 = ld(5, c4 * 4 + 1), x2 = ld(5, c4 * 4 + 2), x3 = ld(5, c4 * 4 + 3);
+                    lo0 = (u32x4){x0[0], x1[0], x2[0], x3[0]};
+                    hi0 = (u32x4){x0[1], x1[1], x2[1], x3[1]};
+                    lo1 = (u32x4){x0[2], x1[2], x2[2], x3[2]};
+                    hi1 = (u32x4){x0[3], x1[3], x2[3], x3[3]};
+                }
+            }
+            uint64_t calledm[CF_V], anyhit[CF_V];
+            u32x4 mout;
+#pragma unroll
+            for (int j = 0; j < CF_V; ++j) {
+                const uint32_t w = g[j];
+                calledm[j] = __ballot((w & 0xffffu) != 0xffffu) & __ballot(w < 0xffff0000u);
+                mout[j] = __builtin_amdgcn_inverse_ballot_w64(calledm[j]) ? 0u : TRK_MASK_NOCALL;
+                anyhit[j] = 0;
+            }
+            // one predicate: the lane mask of the calls it fires on (`hit`), its bit into the mask word, its per-sample
+            // counter bumped where the call is made (dumpSTR.py:661), the union for the pass / filtered decision
+#define TRK_GS_FILTER(K, CALLED_ONLY, EXPR)                                                   \
+            if (MASK >= 0 ? ((MASK >> K) & 1) != 0 : a.f[K].on != 0) {                        \
+                const uint32_t bitv = MASK >= 0 ? 1u << __builtin_popcount(MASK & ((1 << K) - 1)) : 1u << a.f[K].bit; \
+                _Pragma("unroll") for (int j = 0; j < CF_V; ++j) {                            \
+                    uint64_t hit = __ballot(EXPR);                                            \
+                    if (CALLED_ONLY) hit &= calledm[j];                                       \
+                    mout[j] |= __builtin_amdgcn_inverse_ballot_w64(hit) ? bitv : 0u;          \
+                    add16(fc[K], j, CALLED_ONLY ? hit : (hit & calledm[j]));                  \
+                    anyhit[j] |= hit;                                                         \
+                }                                                                             \
+            }
+            TRK_GS_FILTER(0, false, (int32_t)dv[j] < a.f[0].ithr)
+            TRK_GS_FILTER(1, false, (int32_t)dv[j] > a.f[1].ithr)
+            TRK_GS_FILTER(2, false, __uint_as_float(qv[j]) < a.f[2].fthr)
+            TRK_GS_FILTER(3, true, __uint_as_float(e1[j]) < a.f[3].fthr)
+            TRK_GS_FILTER(4, true, __uint_as_float(e2[j]) < a.f[4].fthr)
+            TRK_GS_FILTER(5, true, (__uint_as_float(e1[j]) + __uint_as_float(e2[j])) < a.f[5].fthr)
+            TRK_GS_FILTER(6, true, (int32_t)r1[j] == (int32_t)dv[j])
+            TRK_GS_FILTER(7, true, ((int64_t)(int32_t)r1[j] + (int64_t)(int32_t)r3[j]) == (int64_t)(int32_t)dv[j])
+            TRK_GS_FILTER(8, true, ((int32_t)cn0[j] < (int32_t)lo0[j]) | ((int32_t)hi0[j] < (int32_t)cn0[j]) |
+                                       ((int32_t)cn1[j] < (int32_t)lo1[j]) | ((int32_t)hi1[j] < (int32_t)cn1[j]))
+#undef TRK_GS_FILTER
+            uint64_t passm[CF_V], filtm[CF_V];
+            u32x4 wout;
+#pragma unroll
+            for (int j = 0; j < CF_V; ++j) {
+                passm[j] = calledm[j] & ~anyhit[j];   // dumpSTR.py:686
+                filtm[j] = calledm[j] & anyhit[j];    // dumpSTR.py:715-727
+                add16(numcalls, j, passm[j]);
+                wout[j] = __builtin_amdgcn_inverse_ballot_w64(filtm[j]) ? 0xffffffffu : g[j];
+            }
+            if (has_dp) {
+                uint64_t bad = 0;
+#pragma unroll
+                for (int j = 0; j < CF_V; ++j) {
+                    const int32_t d = (int32_t)dv[j];
+                    add16(dpmiss, j, passm[j] & __ballot(d == INT32_MIN));
+                    const int32_t dpos = d > 0 ? d : 0;
+                    totaldp[j] += __builtin_amdgcn_inverse_ballot_w64(passm[j]) ? dpos : 0;
+                    bad |= passm[j] & __ballot((uint32_t)d > 0x80000000u);
+                }
+                if (bad) {   // a negative depth on a call that passes (cold): dumpSTR.py:698-706
+#pragma unroll
+                    for (int j = CF_V - 1; j >= 0; --j) {
+                        const int32_t d = (int32_t)dv[j];
+                        if ((mout[j] == 0u) & (d < 0) & (d != INT32_MIN)) {
+                            if (atomicCAS(&a.out.error[0], 0, 1) == 0) {
+                                a.out.error[1] = l;
+                                a.out.error[2] = (int32_t)(s0 + j);
+                            }
+                        }
+                    }
+                }
+            }
+            if (DELTA) {    // what the filtered calls remove from the locus counts (as k_call_filter_v2)
+                const int li = l - l_begin;
+                uint32_t* tab = dtab + li * dstride;
+                const uint32_t A = (uint32_t)linfo[CF_LINFO * li];
+                const bool lut_needed = cf_lut_needed(linfo, li);
+                const uint32_t* lutl = lutb + li * nal;
+                uint32_t w0acc = 0, w1acc = 0;
+#pragma unroll
+                for (int j = 0; j < CF_V; ++j) {
+                    const uint32_t w = g[j];
+                    const uint32_t a0 = w & 0xffffu, a1 = w >> 16;
+                    const bool filtered = __builtin_amdgcn_inverse_ballot_w64(filtm[j]);
+                    const bool v0 = a0 < A, v1 = a1 < A;
+                    const uint64_t lowm = filtm[j] & (__ballot(a0 == 0xfffeu) | __ballot(a1 == 0xfffeu));
+                    uint64_t hlm = filtm[j] & __ballot(a0 == a1) & __ballot(v0), hsm = hlm;
+                    if (filtered) {
+                        atomicAdd(&tab[v0 ? (int)a0 : nal + V2_TRASH], 1u);
+                        atomicAdd(&tab[v1 ? (int)a1 : nal + V2_TRASH], 1u);
+                    }
+                    if (lut_needed) {
+                        const bool need = filtered & v0 & v1 & (a0 != a1);
+                        uint32_t q = 0xffffffffu;
+                        if (need) q = lutl[a0] ^ lutl[a1];
+                        hlm |= __ballot((q & 0xffffu) == 0u);
+                        hsm |= __ballot((q >> 16) == 0u);
+                    }
+                    w0acc += (uint32_t)__popcll(filtm[j]) + ((uint32_t)__popcll(lowm) << 16);
+                    w1acc += (uint32_t)__popcll(hlm) + ((uint32_t)__popcll(hsm) << 16);
+                }
+                if (leader) {
+                    if (w0acc) atomicAdd(&tab[nal + V2_W0], w0acc);
+                    if (w1acc) atomicAdd(&tab[nal + V2_W1], w1acc);
+                }
+            }
+            if (a.out.gt_out) __builtin_nontemporal_store(wout, reinterpret_cast<u32x4*>(a.out.gt_out) + c4);
+            if (a.out.filter_mask) __builtin_nontemporal_store(mout, reinterpret_cast<u32x4*>(a.out.filter_mask) + c4);
+            if (a.out.filter_mask8) {
+                uint32_t m8 = 0;
+#pragma unroll
+                for (int j = 0; j < CF_V; ++j) m8 |= ((mout[j] & 0x7fu) | ((mout[j] >> 24) & 0x80u)) << (8 * j);
+                __builtin_nontemporal_store(m8, reinterpret_cast<uint32_t*>(a.out.filter_mask8) + c4);
+            }
+        }
+    }
+    if (DELTA) {
+        __syncthreads();
+        const uint32_t rcp = (uint32_t)((0x100000000ull + (uint32_t)dstride - 1u) / (uint32_t)dstride);
+        for (int i = tid; i < nl * dstride; i += CF_THREADS) {
+            const uint32_t v = dtab[i];
+            if (!v) continue;
+            const int li = (int)__umulhi((uint32_t)i, rcp);
+            const int r = i - li * dstride;
+            const int l = l_begin + li;
+            if (r < nal) {
+                atomicSub(&a.out.delta_allele_count[linfo[CF_LINFO * li + 2] + r], (int)v);
+            } else if (r == nal + V2_W0) {
+                int32_t* li_ = a.out.delta_locus_int + (int64_t)l * TRK_LI_COLS;
+                atomicSub(&li_[TRK_LI_N_CALLED], (int)(v & 0xffffu));
+                if (v >> 16) atomicSub(&li_[TRK_LI_N_LOWPLOIDY], (int)(v >> 16));
+            } else if (r == nal + V2_W1) {
+                int32_t* li_ = a.out.delta_locus_int + (int64_t)l * TRK_LI_COLS;
+                if (v & 0xffffu) atomicSub(&li_[TRK_LI_N_HOM_LEN], (int)(v & 0xffffu));
+                if (v >> 16) atomicSub(&li_[TRK_LI_N_HOM_STR], (int)(v >> 16));
+            }
+        }
+        __syncthreads();
+    }
+    }  // locus blocks of this workgroup
+    if (s0 < S) {
+        typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        u16x4* p16 = reinterpret_cast<u16x4*>(a.part16 + ((size_t)blockIdx.y * (2 + GS_NF)) * S + s0);
+        const size_t rs = (size_t)S / 4;
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        // (the pairs are already in the partial rows' layout: four 16-bit counters = two registers = one 8-byte store)
+        reinterpret_cast<u32x2*>(p16)[0] = (u32x2){numcalls[0], numcalls[1]};
+        reinterpret_cast<u32x2*>(p16 + rs)[0] = (u32x2){dpmiss[0], dpmiss[1]};
+#pragma unroll
+        for (int k = 0; k < GS_NF; ++k) reinterpret_cast<u32x2*>(p16 + (2 + k) * rs)[0] = (u32x2){fc[k][0], fc[k][1]};
+        u64x2* p64 = reinterpret_cast<u64x2*>(a.part64 + (size_t)blockIdx.y * S + s0);
+        p64[0] = (u64x2){(unsigned long long)totaldp[0], (unsigned long long)totaldp[1]};
+        p64[1] = (u64x2){(unsigned long long)totaldp[2], (unsigned long long)totaldp[3]};
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_cf_reduce : sums the per-workgroup partial sample counters of k_call_filter_v2 into the int64 outputs.
 // Thread (quad of 4 samples, slice): walks the locus blocks by = slice, slice + NSL, ...; the NSL slices of a quad are
 // added up through LDS and one thread per quad does the (non-atomic) += on the outputs.  12.5k loci x 10k samples:
@@ -2805,12 +3083,12 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
 // workgroups) become 18 MB of plain stores + this kernel; at 100k loci 75 M atomics (0.11 ms) become 125 MB.
 // ---------------------------------------------------------------------------
 constexpr int CFR_NSL = 16, CFR_QPB = 16;   // slices per quad, quads per workgroup (256 threads)
-constexpr int CFR_ROWS = 2 + V2_MAX_FILTERS, CFR_UNR = 4;
+constexpr int CFR_MAX_FILTERS = 9;            // (the closed GangSTR list of k_call_filter_gs)
+constexpr int CFR_ROWS = 2 + CFR_MAX_FILTERS, CFR_UNR = 4;
+struct CfrBits { int32_t bit[CFR_MAX_FILTERS]; };   // counter row of filter k = 1 + bit[k]
 __global__ __launch_bounds__(CFR_NSL* CFR_QPB) void k_cf_reduce(const uint16_t* __restrict__ part16,
                                                                const unsigned long long* __restrict__ part64,
-                                                               int gy, int S, int nrow16, V2Filter f0, V2Filter f1,
-                                                               V2Filter f2, V2Filter f3, V2Filter f4, V2Filter f5,
-                                                               trk_call_out out) {
+                                                               int gy, int S, int nrow16, CfrBits fb, trk_call_out out) {
     typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     __shared__ uint32_t red32[CFR_NSL][CFR_ROWS][CFR_QPB * 4];
@@ -2858,7 +3136,7 @@ __global__ __launch_bounds__(CFR_NSL* CFR_QPB) void k_cf_reduce(const uint16_t* 
 #pragma unroll
     for (int j = 0; j < 4; ++j) red64[slice][ql * 4 + j] = accd[j];
     __syncthreads();
-    const int bits[6] = {f0.bit, f1.bit, f2.bit, f3.bit, f4.bit, f5.bit};
+    const int* bits = fb.bit;
     // outputs of this workgroup: (nrow16 + 1) rows x 64 samples, one thread each (non-atomic +=: nobody else writes
     // these counters while the call-filter pass runs)
     for (int o = threadIdx.x; o < (nrow16 + 1) * CFR_QPB * 4; o += CFR_NSL * CFR_QPB) {
@@ -3778,12 +4056,180 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
                 if (e1 != hipSuccess) return e1;
                 if (scratch.next_kernel) scratch.next_kernel(scratch.user);
                 const int quads = S / 4;
+                CfrBits fb = {};
+                for (int k = 0; k < n_filters; ++k) fb.bit[k] = v.f[k].bit;
                 hipLaunchKernelGGL(k_cf_reduce, dim3((quads + CFR_QPB - 1) / CFR_QPB), dim3(CFR_NSL * CFR_QPB), 0, stream,
-                                   v.part16, v.part64, gy, S, 2 + n_filters, v.f[0], v.f[1], v.f[2], v.f[3], v.f[4],
-                                   v.f[5], out);
+                                   v.part16, v.part64, gy, S, 2 + n_filters, fb, out);
             }
 #undef TRK_V2
             return hipGetLastError();
+        }
+    }
+    // ---- dumpSTR's closed GangSTR list (k_call_filter_gs): every filter one of the nine roles, the depth plane the
+    // DP operand, multi-column planes all planar or all interleaved.  TRK_CF_NOGS=1: the interpreter kernel. ----
+    if (vec && !b.locus_ploidy && n_filters >= 1 && n_filters <= GS_NF && !getenv("TRK_CF_NOGS") &&
+        !getenv("TRK_CF_GENERIC") && (!out.delta_allele_count || (b.max_alleles > 0 && b.max_alleles <= 120))) {
+        GsArgs g = {};
+        bool ok = true;
+        int qexp_pl = -1, rc_pl = -1, cn_pl = -1, ci_pl = -1, q_pl = -1;
+        auto is_i32 = [&](int p) { return (planes[p].dtype & 0xff) == TRK_DT_I32; };
+        auto is_f32 = [&](int p) { return (planes[p].dtype & 0xff) == TRK_DT_F32; };
+        auto same = [&](int& slot, int p) { if (slot < 0) slot = p; return slot == p; };
+        auto int_thr = [&](double thr, bool gt_op, int32_t& o) {
+            const double t = gt_op ? floor(thr) : ceil(thr);   // (double)v < thr <=> v < ceil(thr); > <=> v > floor(thr)
+            if (!(thr == thr) || !(t > -2147483647.0 && t < 2147483647.0)) return false;
+            o = (int32_t)t;
+            return true;
+        };
+        for (int k = 0; k < n_filters && ok; ++k) {
+            const trk_call_filter& f = filters[k];
+            int role = -1;
+            switch (f.op) {
+                case TRK_F_LT:
+                    if (f.plane_a == dp_plane && is_i32(f.plane_a) && planes[f.plane_a].ncol == 1) {
+                        role = 0;
+                        ok = int_thr(f.thr, false, g.f[0].ithr);
+                    } else if (is_f32(f.plane_a) && planes[f.plane_a].ncol == 1 && f.thr == f.thr) {
+                        role = 2;
+                        ok = same(q_pl, f.plane_a);
+                        g.f[2].fthr = (float)f.thr;
+                    }
+                    break;
+                case TRK_F_GT:
+                    if (f.plane_a == dp_plane && is_i32(f.plane_a) && planes[f.plane_a].ncol == 1) {
+                        role = 1;
+                        ok = int_thr(f.thr, true, g.f[1].ithr);
+                    }
+                    break;
+                case TRK_F_CALLED_LT:
+                    if (is_f32(f.plane_a) && planes[f.plane_a].ncol == 3 && (f.col_a == 1 || f.col_a == 2) && f.thr == f.thr) {
+                        role = f.col_a == 1 ? 3 : 4;
+                        ok = same(qexp_pl, f.plane_a);
+                        g.f[role].fthr = (float)f.thr;
+                    }
+                    break;
+                case TRK_F_CALLED_SUM_LT:
+                    if (is_f32(f.plane_a) && planes[f.plane_a].ncol == 3 && f.thr == f.thr &&
+                        ((f.col_a == 1 && f.col_a2 == 2) || (f.col_a == 2 && f.col_a2 == 1))) {
+                        role = 5;
+                        ok = same(qexp_pl, f.plane_a);
+                        g.f[5].fthr = (float)f.thr;
+                    }
+                    break;
+                case TRK_F_CALLED_EQ:
+                    if (is_i32(f.plane_a) && planes[f.plane_a].ncol == 4 && f.col_a == 1 && f.plane_b == dp_plane &&
+                        dp_plane >= 0 && is_i32(dp_plane) && planes[dp_plane].ncol == 1 && f.col_b == 0) {
+                        role = 6;
+                        ok = same(rc_pl, f.plane_a);
+                    }
+                    break;
+                case TRK_F_CALLED_SUM_EQ:
+                    if (is_i32(f.plane_a) && planes[f.plane_a].ncol == 4 && f.plane_b == dp_plane && dp_plane >= 0 &&
+                        is_i32(dp_plane) && planes[dp_plane].ncol == 1 && f.col_b == 0 &&
+                        ((f.col_a == 1 && f.col_a2 == 3) || (f.col_a == 3 && f.col_a2 == 1))) {
+                        role = 7;
+                        ok = same(rc_pl, f.plane_a);
+                    }
+                    break;
+                case TRK_F_CALLED_OUTSIDE_CI:
+                    if (is_i32(f.plane_a) && planes[f.plane_a].ncol == 2 && is_i32(f.plane_b) && planes[f.plane_b].ncol == 4) {
+                        role = 8;
+                        ok = same(cn_pl, f.plane_a) && same(ci_pl, f.plane_b);
+                    }
+                    break;
+                default:
+                    break;
+            }
+            if (role < 0 || g.f[role].on) ok = false;    // not one of the nine, or a role twice
+            if (ok) {
+                g.f[role].on = 1;
+                g.f[role].bit = k;
+            }
+        }
+        for (int r = 0; r < GS_NF; ++r)
+            if (!g.f[r].on) g.f[r].bit = -1;             // (its counter row is all zero and lands nowhere)
+        if (ok && dp_plane >= 0 && !(is_i32(dp_plane) && planes[dp_plane].ncol == 1)) ok = false;
+        // multi-column planes: all planar or all interleaved
+        int n_planar = 0, n_inter = 0;
+        for (int p : {qexp_pl, rc_pl, cn_pl, ci_pl})
+            if (p >= 0) ((planes[p].dtype & TRK_DT_PLANAR) ? n_planar : n_inter)++;
+        if (ok && n_planar && n_inter) ok = false;
+        if (ok) {
+            const bool planar = n_planar > 0 || n_inter == 0;
+            const size_t colb = (size_t)L * S * 4;        // bytes of one planar column
+            auto colp = [&](int p, int c) { return static_cast<const void*>(static_cast<const char*>(planes[p].data) + colb * c); };
+            g.b = b;
+            g.has_dp = dp_plane >= 0;
+            g.use_qexp = qexp_pl >= 0;
+            g.use_rc = rc_pl >= 0;
+            g.use_ci = cn_pl >= 0;
+            g.p[0] = dp_plane >= 0 ? planes[dp_plane].data : nullptr;
+            g.p[1] = q_pl >= 0 ? planes[q_pl].data : nullptr;
+            if (planar) {
+                if (qexp_pl >= 0) { g.p[2] = colp(qexp_pl, 1); g.p[3] = colp(qexp_pl, 2); }
+                if (rc_pl >= 0) { g.p[4] = colp(rc_pl, 1); g.p[5] = colp(rc_pl, 3); }
+                if (cn_pl >= 0) {
+                    g.p[6] = colp(cn_pl, 0); g.p[7] = colp(cn_pl, 1);
+                    for (int c = 0; c < 4; ++c) g.p[8 + c] = colp(ci_pl, c);
+                }
+            } else {
+                g.p[2] = qexp_pl >= 0 ? planes[qexp_pl].data : nullptr;
+                g.p[3] = rc_pl >= 0 ? planes[rc_pl].data : nullptr;
+                g.p[4] = cn_pl >= 0 ? planes[cn_pl].data : nullptr;
+                g.p[5] = ci_pl >= 0 ? planes[ci_pl].data : nullptr;
+            }
+            const bool delta = out.delta_allele_count != nullptr;
+            g.out = a.out;
+            g.delta_nal = delta ? b.max_alleles : 0;
+            // the whole list in dumpSTR's own order: the instantiation with the compile-time role set
+            bool canonical = dp_plane >= 0;
+            for (int r = 0; r < GS_NF; ++r) canonical = canonical && g.f[r].on && g.f[r].bit == r;
+            // (interleaved planes: the build with run-time flags is the faster one -- 3.44 against 3.6-3.8 ms at 50k x
+            // 5k on one box, profiles/r03_notes.md -- so the compile-time set serves the planar layout only)
+            canonical = canonical && planar && !getenv("TRK_GS_RUNTIME_FLAGS");
+            void (*kg)(GsArgs) =
+                canonical ? (delta ? k_call_filter_gs<true, true, 0x1ff> : k_call_filter_gs<true, false, 0x1ff>)
+                          : (planar ? (delta ? k_call_filter_gs<true, true, -1> : k_call_filter_gs<true, false, -1>)
+                                    : (delta ? k_call_filter_gs<false, true, -1> : k_call_filter_gs<false, false, -1>));
+            // geometry as for k_call_filter_v2: whole rounds of resident workgroups, the delta table within 32 KiB
+            const size_t per_locus = delta ? ((size_t)2 * b.max_alleles + V2_EXTRA + CF_LINFO) * sizeof(uint32_t) : 0;
+            int lpb2 = lpb;
+            if (delta) lpb2 = std::min<int>(lpb2, (int)((32 * 1024) / per_locus));
+            int occ = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kg, CF_THREADS, (size_t)lpb2 * per_locus) != hipSuccess || occ < 1)
+                occ = 3;
+            const long slots = (long)n_cu * occ;
+            long rounds = ((long)gx * ((L + lpb2 - 1) / lpb2) + slots - 1) / slots;
+            if (rounds < 2) rounds = 2;
+            long gyr = rounds * slots / gx;
+            if (gyr > L) gyr = L;
+            if (gyr >= 1) {
+                int q = (int)((L + gyr - 1) / gyr);
+                if (q < 8) q = L < 8 ? L : 8;
+                if (q < lpb2) lpb2 = q;
+            }
+            if (const char* e = getenv("TRK_CF_LPB")) {
+                const int q = atoi(e);
+                if (q > 0 && q <= lpb2) lpb2 = q;
+            }
+            const int gy2 = (L + lpb2 - 1) / lpb2;
+            g.loci_per_block = lpb2;
+            const size_t b16 = (((size_t)gy2 * (2 + GS_NF) * S * sizeof(uint16_t)) + 255) & ~(size_t)255;
+            const size_t b64 = (size_t)gy2 * S * sizeof(unsigned long long);
+            void* ws = lpb2 < 65536 ? scratch.get(scratch.user, b16 + b64) : nullptr;
+            if (ws) {
+                g.part16 = static_cast<uint16_t*>(ws);
+                g.part64 = reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + b16);
+                hipLaunchKernelGGL(kg, dim3(gx, gy2), dim3(CF_THREADS), (size_t)lpb2 * per_locus, stream, g);
+                hipError_t e1 = hipGetLastError();
+                if (e1 != hipSuccess) return e1;
+                if (scratch.next_kernel) scratch.next_kernel(scratch.user);
+                CfrBits fb = {};
+                for (int r = 0; r < GS_NF; ++r) fb.bit[r] = g.f[r].bit;
+                hipLaunchKernelGGL(k_cf_reduce, dim3((S / 4 + CFR_QPB - 1) / CFR_QPB), dim3(CFR_NSL * CFR_QPB), 0, stream,
+                                   g.part16, g.part64, gy2, S, 2 + GS_NF, fb, out);
+                return hipGetLastError();
+            }
         }
     }
     if (vec) {
