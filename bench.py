@@ -907,6 +907,25 @@ def end_to_end_extra(eng, seed):
     return out
 
 
+def box_stream_probe(eng, wl):
+    """The box's own yardstick (it overwrites GT' / mask: call it after everything that reads them): the bare 12 B-in /
+    8 B-out stream of the call-filter pass's shape on the same planes (trk_stream_probe), and the clocks the runtime
+    reports."""
+    try:
+        pms = eng.stream_probe(wl.sb.dev['gt'], wl.sb.dev['dp'], wl.sb.dev['q'], wl.call_out.gt_out,
+                               wl.call_out.filter_mask, wl.n_loci, wl.n_samples, reps=5)
+        box_probe = {"what": "k_stream_probe<3,2>: three 16 B/lane nontemporal input streams, two output streams, "
+                             "the call-filter pass's tiling and grid rule, no arithmetic (profiles/r03_notes.md)",
+                     "avg_launch_ms": pms,
+                     "achieved": wl.n_loci * wl.n_samples * BYTES_PER_CELL_CALL_FILTER / (pms * 1e-3) / 1e9,
+                     "unit": "GB/s"}
+        box_probe["frac"] = box_probe["achieved"] / HBM_PEAK_GBS
+        box_probe.update(eng.device_clocks())
+    except Exception as e:      # an aid, never a reason to lose the line
+        box_probe = {"error": str(e)[:200]}
+    return box_probe
+
+
 def main():
     args = parse()
     # stdout carries exactly ONE line, the JSON: native libraries print there too (RCCL's version banner at
@@ -956,7 +975,7 @@ def main():
         elapsed = float(group.allreduce_max_f64(np.array([elapsed]))[0])
         group.barrier()
 
-    check = None
+    check, probe = None, None
     if not args.no_check:
         check = exhaustive_check(wl, single_rank_sums=(world == 1))
         if group is not None:
@@ -979,22 +998,6 @@ def main():
                 nr = (nr[1] - nr[0]) if args.scaling == 'strong' else args.loci
                 assert np.array_equal(np.frombuffer(rows_all[r].tobytes(), dtype=np.uint32)[:nr], gathered[r][:nr]), \
                     "all-gathered filter bits: row of rank %d differs from what that rank computed" % r
-    # the box's own yardstick, after the check (it overwrites GT' / mask): the bare 12 B-in / 8 B-out stream of the
-    # call-filter pass's shape on the same planes (trk_stream_probe), and the clocks the runtime reports
-    box_probe = None
-    if rank == 0:
-        try:
-            pms = eng.stream_probe(wl.sb.dev['gt'], wl.sb.dev['dp'], wl.sb.dev['q'], wl.call_out.gt_out,
-                                   wl.call_out.filter_mask, wl.n_loci, wl.n_samples, reps=5)
-            box_probe = {"what": "k_stream_probe<3,2>: three 16 B/lane nontemporal input streams, two output streams, "
-                                 "the call-filter pass's tiling and grid rule, no arithmetic (profiles/r03_notes.md)",
-                         "avg_launch_ms": pms,
-                         "achieved": wl.n_loci * wl.n_samples * BYTES_PER_CELL_CALL_FILTER / (pms * 1e-3) / 1e9,
-                         "unit": "GB/s"}
-            box_probe["frac"] = box_probe["achieved"] / HBM_PEAK_GBS
-            box_probe.update(eng.device_clocks())
-        except Exception as e:      # an aid, never a reason to lose the line
-            box_probe = {"error": str(e)[:200]}
     if rank == 0:
         cells = wl.n_loci * wl.n_samples
         ms_step = elapsed / args.steps * 1e3
@@ -1039,9 +1042,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "bytes_per_cell": BYTES_PER_CELL_CALL_FILTER, "avg_launch_ms": avg_cf,
-                         "launches": kn, "box_stream_probe": box_probe,
-                         "frac_of_box_stream": (achieved / box_probe["achieved"])
-                         if box_probe and box_probe.get("achieved") else None},
+                         "launches": kn, "box_stream_probe": None, "frac_of_box_stream": None},
             "kernels_ms": {k: (v[1] / v[0] if v[0] else None) for k, v in prof.items()},
             "k_locus_count_roofline": {"achieved": cells * BYTES_PER_CELL_COUNT / (avg_cnt * 1e-3) / 1e9 if cn else 0.0,
                                        "unit": "GB/s", "bytes_per_cell": BYTES_PER_CELL_COUNT,
@@ -1076,6 +1077,7 @@ def main():
         if not args.no_extras:
             extras["compact_outputs"] = compact_outputs_extra(wl)
             extras["qc_reduce"] = qc_reduce_extra(wl, args.no_check)
+            probe = box_stream_probe(eng, wl)
             wl.free()
             if not use_dist:
                 uid = eng.comm_unique_id()
@@ -1086,6 +1088,11 @@ def main():
             extras["config2"] = config2_extra(eng, args.no_check)
             extras["end_to_end"] = end_to_end_extra(eng, args.seed)
     if rank == 0:
+        if probe is None:
+            probe = box_stream_probe(eng, wl)
+        out["roofline"]["box_stream_probe"] = probe
+        if probe.get("achieved"):
+            out["roofline"]["frac_of_box_stream"] = out["roofline"]["achieved"] / probe["achieved"]
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if group is not None:
         group.barrier()
