@@ -43,11 +43,14 @@ def main():
         return {"kernel": k, "fetch_kib_raw": v['FETCH_SIZE'][0], "write_kib_raw": v.get('WRITE_SIZE', (0.0,))[0],
                 "fetch_bytes": f, "write_bytes": w, "bytes_per_launch": f + w, "algorithmic_bytes_per_launch": algo,
                 "ratio": (f + w) / algo if algo else None}
-    res["k_call_filter"] = entry(bench, 'k_call_filter_v2<3, true, false>', 20.0e9)
+    res["k_call_filter"] = entry(bench, 'k_call_filter_v2<3, true, false', 20.0e9)
+    res["k_stream_probe"] = entry(bench, 'k_stream_probe<3, 2>', 20.0e9)
     res["k_cf_reduce"] = entry(bench, 'k_cf_reduce', None)
     res["k_locus_count"] = entry(bench, 'k_locus_count_v2<', 4.0e9)
     res["k_assoc_scan"] = entry(bench, 'k_assoc_scan_few<1, false>', 4.0e9) or entry(bench, 'k_assoc_scan<1, false>', 4.0e9)
     res["config1_k_locus_count"] = entry(configs, 'k_locus_count_v3<4', 4.0e7)
+    res["config2_k_call_filter_gs_planar"] = entry(configs, 'k_call_filter_gs<true, true', 50000 * 5000 * 60.0)
+    res["config2_k_call_filter_gs_interleaved"] = entry(configs, 'k_call_filter_gs<false, true', 50000 * 5000 * 72.0)
     res["config2_k_call_filter_fast"] = (entry(configs, 'k_call_filter_fast<12, true, 1>', 50000 * 5000 * 60.0) or
                                          entry(configs, 'k_call_filter_fast<12, true, true>', 50000 * 5000 * 60.0) or
                                          entry(configs, 'k_call_filter_fast<12, true>', 50000 * 5000 * 60.0))

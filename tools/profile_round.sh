@@ -2,9 +2,9 @@
 # The rocprofv3 passes behind profiles/<tag>_*: kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in their own runs
 # (never combined with another trace domain), around (a) the bench command -- headline step + the associaTR extra --
 # (b) tools/config_probe.py (BASELINE configs[1] and configs[2], HipSTR five-filter set) and (c) tools/qc_probe.py.  Run on the GPU box:
-#   gpurun -- bash tools/profile_round.sh r02
+#   gpurun -- bash tools/profile_round.sh r03
 set -u
-tag=${1:-r02}
+tag=${1:-r03}
 repo=$(pwd)
 out=$repo/gpurun_out/$tag
 mkdir -p "$out"
@@ -21,6 +21,9 @@ run3() {   # name, command...: stats pass + two PMC passes of the same command
 run3 bench python "$repo/bench.py" --steps 5 --warmup 2 --no-check --no-cpu-baseline --no-extras
 run3 configs python "$repo/tools/config_probe.py"
 run3 qc python "$repo/tools/qc_probe.py" --iters 3
+# statSTR --samples (sample groups): kernel trace only
+rocprofv3 --kernel-trace --stats -d "$out/groups_stats" -o stats -- python "$repo/tools/groups_probe.py" > "$out/groups_under_rocprof.log" 2>&1
+( cd "$repo" && python tools/rocprof_summary.py stats "$(db groups_stats)" > "$out/${tag}_groups_kernel_stats.csv" )
 cd "$repo"
 python tools/pmc_traffic.py "$out/${tag}_bench_pmc_fetch_write.csv" "$out/${tag}_configs_pmc_fetch_write.csv" "$tag" > "$out/${tag}_pmc_traffic.json"
 grep -h "^{" "$out/bench_under_rocprof.log" | tail -1 | cut -c1-300
