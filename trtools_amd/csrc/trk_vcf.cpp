@@ -343,7 +343,7 @@ struct PlaneSel {
 
 // results of trk_vcf_harmonize, owned by the reader (valid until the next call)
 struct HzStore {
-    std::vector<int32_t> allele_off, n_str_classes, n_len_classes, hrun;
+    std::vector<int32_t> allele_off, n_str_classes, n_len_classes, hrun, period;
     std::vector<uint16_t> len_class, str_class;
     std::vector<double> len_class_value, allele_len;
     std::vector<int64_t> pos, end, key_off;
@@ -1385,6 +1385,7 @@ struct HzRecord {  // one record's harmonised alleles (views into the line; uppe
     double unit = 1.0;                                   // len(motif)
     int64_t pos = 0, end = 0;
     int32_t hrun = 0;
+    int32_t period = INT32_MIN;                          // INFO PERIOD (an integer), INT32_MIN when absent
     bool ok = false, passing = false;
 };
 
@@ -1440,6 +1441,11 @@ void harmonize_one(const char* line, const int32_t* fo, int64_t line_len, int vc
     const char* infoe = cole[7];
     const char *vb, *ve;
     bool hv;
+    {   // INFO PERIOD where the record has one (the HRUN locus filter, filters.py:211-213)
+        long pv;
+        if (info_get(info, infoe, "PERIOD", 6, vb, ve, hv) && hv && parse_long(vb, ve, pv) && pv > INT32_MIN && pv <= INT32_MAX)
+            r.period = (int32_t)pv;
+    }
     if (vcftype == TRK_VT_HIPSTR) {
         long start, endv, period;
         if (!info_get(info, infoe, "START", 5, vb, ve, hv) || !hv || !parse_long(vb, ve, start)) return;
@@ -1533,6 +1539,7 @@ int trk_vcf_harmonize(trk_vcf* v, const trk_vcf_batch* b, int vcftype, trk_vcf_h
     st.n_str_classes.assign((size_t)n, 0);
     st.n_len_classes.assign((size_t)n, 0);
     st.hrun.assign((size_t)n, 0);
+    st.period.assign((size_t)n, INT32_MIN);
     int n_python = 0;
     for (int i = 0; i < n; ++i) {
         const HzRecord& r = recs[(size_t)i];
@@ -1542,6 +1549,7 @@ int trk_vcf_harmonize(trk_vcf* v, const trk_vcf_batch* b, int vcftype, trk_vcf_h
         st.end[(size_t)i] = r.end;
         st.passing[(size_t)i] = r.passing;
         st.hrun[(size_t)i] = r.hrun;
+        st.period[(size_t)i] = r.period;
         const size_t A = r.ok ? r.alleles.size() : 1;
         if (A > 65535) { st.status[(size_t)i] = 1; ++n_python; }
         st.allele_off[(size_t)i + 1] = st.allele_off[(size_t)i] + (int32_t)(A > 65535 ? 1 : A);
@@ -1616,6 +1624,7 @@ int trk_vcf_harmonize(trk_vcf* v, const trk_vcf_batch* b, int vcftype, trk_vcf_h
     out->n_str_classes = st.n_str_classes.data();
     out->n_len_classes = st.n_len_classes.data();
     out->hrun = st.hrun.data();
+    out->period = st.period.data();
     return 0;
 }
 

@@ -272,6 +272,11 @@ def BuildLocusFilters(args):
 # batch evaluation
 # ---------------------------------------------------------------------------
 
+# what the last main() call ran through: 'batch' (every batch through the batch pipeline), 'mixed' (some batches
+# through the record objects), 'per-record' (the loop); read by bench.py's end-to-end extra and the tests
+LAST_RUN = {}
+
+
 class _Planes:
     """FORMAT planes a set of call filters needs, stacked over a batch of records."""
 
@@ -476,9 +481,9 @@ class _Run:
         TRK_DUMPSTR_BATCH=0 forces the per-record loop."""
         from ..vcfnative import NativeVCFReader, VT_CODES
         a = self.args
-        return (isinstance(self.invcf, NativeVCFReader) and vcftype.name in VT_CODES and not self.host_filters and
+        return (isinstance(self.invcf, NativeVCFReader) and vcftype.name in VT_CODES and
                 all(isinstance(f, self._SIMPLE_VALUES) for f in self.call_filters) and
-                a.num_records is None and not a.verbose and len(self.invcf.samples) > 0 and
+                len(self.invcf.samples) > 0 and
                 os.environ.get('TRK_DUMPSTR_BATCH', '1') != '0')
 
     def process_raw(self, rb, hz, format_kinds):
@@ -527,8 +532,24 @@ class _Run:
                                    hz.len_class_value, lists=hz.lists)
         compute = runtime.get_compute()
         kw = dict(compact=True) if getattr(compute, 'supports_compact', False) else {}
+        # the string-only locus filters (HRUN, BED regions: filters.py:190-300) for the whole batch at once, from the
+        # harmoniser's per-record tables: extern bits of the locus-filter kernel
+        ext = None
+        if self.host_filters:
+            ext = np.zeros(rb.n, dtype=np.uint32)
+            chroms = None
+            for j, f in enumerate(self.host_filters):
+                if isinstance(f, filters.Filter_LocusHrun):
+                    per = hz.period
+                    fire = ((per == 5) | (per == 6)) & (hz.hrun >= per)
+                else:
+                    if chroms is None:
+                        chroms = rb.chrom_column()
+                    ref_len = hz.allele_len[hz.allele_off[:-1]]          # record.ref_allele_length (repeat units)
+                    fire = f.overlaps_batch(chroms, hz.pos, hz.pos + ref_len)
+                ext |= fire.astype(np.uint32) << np.uint32(j)
         ch, st, bits, lc = compute.dumpstr_batch(hb, arrays, specs, -1 if dp_key is None else index[dp_key],
-                                                 dict(self.spec, extern_bits=None), **kw)
+                                                 dict(self.spec, extern_bits=ext), **kw)
         # the native writer first: if it declines, the batch has left no trace
         names = [f.name for f in self.call_filters]
         cfv = []
@@ -885,17 +906,42 @@ def main(args):
         kinds = {k: (1 if h['Type'] == 'Integer' else 2 if h['Type'] == 'Float' else 4) for k, h in format_fields.items()}
         invcf.use_buffers(getattr(runtime.get_compute(), 'host_buffer', None), ring=2,
                           release=getattr(runtime.get_compute(), 'host_release', None))
+    LAST_RUN.clear()
+    LAST_RUN.update(path='batch' if use_batches else 'per-record', batches=0, fallback_batches=0)
     while use_batches:
-        rb = invcf.read_raw_batch(batch_loci)
+        want = batch_loci
+        if args.num_records is not None:          # dumpSTR.py:1292-1293: the first num_records records
+            want = min(batch_loci, args.num_records - record_counter)
+            if want <= 0:
+                break
+        rb = invcf.read_raw_batch(want)
         if rb.n == 0:
             break
+        record_counter += rb.n
         hz = rb.harmonize(vcftype.name)
+        if args.verbose:
+            for l in range(rb.n):
+                common.MSG("Processing %s:%s" % rb.chrom_pos(l))
+        LAST_RUN['batches'] += 1
         if hz.n_python == 0 and run.process_raw(rb, hz, kinds):
             continue
+        LAST_RUN['fallback_batches'] += 1
+        LAST_RUN['path'] = 'mixed'
         # a batch the native pieces do not cover: through the record objects, with the per-record loop's handling
         # of unparsable records
         try:
-            run.process([trh.HarmonizeRecord(vcftype, v) for v in rb.records()])
+            recs, it, k = [], rb.iter_variants(), 0
+            while True:
+                try:
+                    v = next(it)
+                except StopIteration:
+                    break
+                except Exception:        # a line that does not parse: TRRecordHarmonizer.__next__'s message
+                    raise ValueError("Unable to parse the " + str(record_counter - rb.n + k + 2) + "th tandem repeat in "
+                                     "the provided VCF. Check that it is properly formatted.")
+                recs.append(trh.HarmonizeRecord(vcftype, v))
+                k += 1
+            run.process(recs)
         except TypeError as te:
             if 'missing' in te.args[0] and 'mandatory' in te.args[0]:
                 common.WARNING("Could not parse VCF.\n" + te.args[0])

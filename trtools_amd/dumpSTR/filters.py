@@ -165,6 +165,30 @@ class _BedIndex:
         beg0, end0 = int(float(start1)) - 1, int(float(end1))
         return any(s < end0 and e > beg0 for s, e in self.by_chrom[chrom])
 
+    def overlaps_many(self, chrom, start1, end1):
+        """``overlaps`` for arrays of regions on one chromosome: some interval has s < end0 and e > beg0 <=> the
+        largest end among the intervals that start before end0 lies beyond beg0 (starts sorted, running maximum of
+        the ends)."""
+        import numpy as np
+        out = np.zeros(len(start1), dtype=bool)
+        iv = self.by_chrom.get(chrom)
+        if not iv:
+            return out
+        tab = self._arrays.get(chrom) if hasattr(self, '_arrays') else None
+        if tab is None:
+            if not hasattr(self, '_arrays'):
+                self._arrays = {}
+            starts = np.array([s for s, _ in iv], dtype=np.int64)
+            ends = np.maximum.accumulate(np.array([e for _, e in iv], dtype=np.int64))
+            tab = self._arrays[chrom] = (starts, ends)
+        starts, ends = tab
+        beg0 = np.trunc(np.asarray(start1, dtype=np.float64)).astype(np.int64) - 1
+        end0 = np.trunc(np.asarray(end1, dtype=np.float64)).astype(np.int64)
+        k = np.searchsorted(starts, end0, side='left')
+        has = k > 0
+        out[has] = ends[k[has] - 1] > beg0[has]
+        return out
+
 
 def create_region_filter(name, filename):
     """Locus filter flagging records that overlap a BED file (filters.py:219-300).
@@ -203,6 +227,20 @@ def create_region_filter(name, filename):
                 if self.regions.overlaps(c, record.pos, end):
                     return self.name
             return None
+
+        def overlaps_batch(self, chroms, pos, end):
+            """``__call__`` for a batch: chroms list of str, pos / end arrays (end = pos + ref_allele_length)."""
+            import numpy as np
+            out = np.zeros(len(chroms), dtype=bool)
+            if self.regions is None:
+                return out
+            chroms = np.asarray(chroms, dtype=object)
+            for c in set(chroms.tolist()):
+                idx = np.flatnonzero(chroms == c)
+                other = c.replace("chr", "") if "chr" in c else "chr" + c
+                for cc in (c, other):
+                    out[idx] |= self.regions.overlaps_many(cc, pos[idx], end[idx])
+            return out
 
         def filter_name(self):
             return self.name

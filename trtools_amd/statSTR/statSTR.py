@@ -239,11 +239,17 @@ def _flush(batch, group_masks, fmt, outf, nalleles_thresh):
 
 def _batch_path_ok(args, invcf, vcftype):
     """The batch pipeline (native reader -> native batch harmoniser -> device -> native row formatter: no Python
-    object per record) covers the callers whose records carry allele SEQUENCES; everything else, region queries and
-    plots take the per-record loop below.  TRK_STATSTR_BATCH=0 forces the per-record loop."""
+    object per record) covers the callers whose records carry allele SEQUENCES, with or without a --region query
+    (index seek, then batches cut at the region's end); everything else and plots take the per-record loop below.
+    TRK_STATSTR_BATCH=0 forces the per-record loop."""
     from ..vcfnative import NativeVCFReader, VT_CODES
-    return (isinstance(invcf, NativeVCFReader) and vcftype.name in VT_CODES and not args.region and
+    return (isinstance(invcf, NativeVCFReader) and vcftype.name in VT_CODES and
             not args.plot_afreq and len(invcf.samples) > 0 and os.environ.get('TRK_STATSTR_BATCH', '1') != '0')
+
+
+# what the last main() call ran through (bench.py's end-to-end extra and the tests read it): 'batch' = the batch
+# pipeline for every batch, 'mixed' = some batches went through the record objects, 'per-record' = the loop
+LAST_RUN = {}
 
 
 def _run_batches(args, invcf, vcftype, group_masks, fmt, shard, batch_loci, start_time):
@@ -267,17 +273,31 @@ def _run_batches(args, invcf, vcftype, group_masks, fmt, shard, batch_loci, star
             gb |= (np.asarray(m, dtype=bool).astype(np.uint8) << g)
     invcf.use_buffers(getattr(compute, 'host_buffer', None), ring=2, release=getattr(compute, 'host_release', None))
     nrecords = 0
-    while True:
+    region_done = False
+    LAST_RUN.update(path='batch', batches=0, fallback_batches=0)
+    if args.region:
+        invcf(args.region)                   # statSTR.py:568-570: seek to the region's first index window
+    while not region_done:
         rb = invcf.read_raw_batch(batch_loci)
         if rb.n == 0:
             break
-        nrecords += rb.n
         hz = rb.harmonize(vcftype.name)
+        keep = None
+        if args.region:
+            keep, region_done = invcf.region_keep(rb, hz)
+            if not keep.any():
+                continue
+        nrecords += rb.n if keep is None else int(keep.sum())
+        LAST_RUN['batches'] += 1
         if hz.n_python:
+            LAST_RUN['fallback_batches'] += 1
+            LAST_RUN['path'] = 'mixed'
             # something the native harmoniser does not cover: this batch goes through the Python objects (and
             # raises the reference's errors where the reference does)
             batch = []
-            for record in rb.records():
+            for l, record in enumerate(rb.records()):
+                if keep is not None and not keep[l]:
+                    continue
                 trrecord = trh.HarmonizeRecord(vcftype, record)
                 if args.only_passing and record.FILTER is not None:
                     continue
@@ -292,6 +312,8 @@ def _run_batches(args, invcf, vcftype, group_masks, fmt, shard, batch_loci, star
                                    hz.len_class_value, gb, ng, lists=hz.lists)
         st = compute.locus_stats(hb, nalleles_thresh=args.nalleles_thresh)
         skip = (hz.passing == 0) if args.only_passing else None
+        if keep is not None:
+            skip = ~keep if skip is None else (skip | ~keep)
         text, el, ek = rb.statstr_rows(st, flags, args.precision, args.use_length, skip)
         if ek:
             chrom, pos = rb.chrom_pos(el)
@@ -380,9 +402,13 @@ def main(args):
         nrecords = 0
         num_plotted = 0
         batch = []
+        LAST_RUN.clear()
+        LAST_RUN.update(path='per-record', batches=0, fallback_batches=0)
         if _batch_path_ok(args, invcf, vcftype) and \
                 _run_batches(args, invcf, vcftype, group_masks, fmt, shard, batch_loci, start_time) is not None:
             region = ()
+        else:
+            LAST_RUN['path'] = 'per-record'
         for record in region:
             nrecords += 1
             trrecord = trh.HarmonizeRecord(vcftype, record)

@@ -34,7 +34,8 @@ class _Harmonized(C.Structure):
                 ('allele_len', C.POINTER(C.c_double)), ('pos', C.POINTER(C.c_int64)), ('end', C.POINTER(C.c_int64)),
                 ('passing', C.POINTER(C.c_uint8)), ('status', C.POINTER(C.c_uint8)), ('keys', C.c_void_p),
                 ('key_off', C.POINTER(C.c_int64)), ('n_str_classes', C.POINTER(C.c_int32)),
-                ('n_len_classes', C.POINTER(C.c_int32)), ('hrun', C.POINTER(C.c_int32))]
+                ('n_len_classes', C.POINTER(C.c_int32)), ('hrun', C.POINTER(C.c_int32)),
+                ('period', C.POINTER(C.c_int32))]
 
 
 class _StatRows(C.Structure):
@@ -70,6 +71,7 @@ class HarmonizedBatch:
         self.passing = _np(hz.passing, n, np.uint8)
         self.key_off = _np(hz.key_off, sa + 1, np.int64)
         self.hrun = _np(hz.hrun, n, np.int32)
+        self.period = _np(hz.period, n, np.int32)
         self.status = _np(hz.status, n, np.uint8)
 
     def lists(self):
@@ -154,6 +156,17 @@ class RawBatch:
                 d = c.decode()
                 if d not in out:
                     out.append(d)
+        return out
+
+    def chrom_column(self):
+        """CHROM of every record of the batch (list of str)."""
+        out, last, lastd = [], None, None
+        for l in range(self.n):
+            f0, f1 = int(self.b.field_off[l * 10]), int(self.b.field_off[l * 10 + 1])
+            c = C.string_at(self.b.text + self.b.line_off[l] + f0, f1 - 1 - f0)
+            if c != last:
+                last, lastd = c, c.decode()
+            out.append(lastd)
         return out
 
     def format_columns(self):
@@ -242,6 +255,16 @@ class RawBatch:
             if n <= -(1 << 63) + 1:
                 return None
             cap = -n + 64
+
+    def iter_variants(self):
+        """The batch's vcfio.Variant objects one at a time (a malformed line raises at ITS turn, as the per-record
+        reader does)."""
+        r = self.reader
+        for line, g, native, tail in r._rows_of(self):
+            v = vcfio.Variant(r, line, gt=g if r.n_samples else None, native=native, tail=tail)
+            if v.CHROM not in r.contigs_declared and v.CHROM not in r.contigs_seen:
+                r.contigs_seen.append(v.CHROM)
+            yield v
 
     def records(self):
         """vcfio.Variant objects of the batch (the per-record path)."""
@@ -504,6 +527,32 @@ class NativeVCFReader(vcfio.VCFReader):
                 self._rows, self._row_i, self._eof = [], 0, False
                 self._indexed_region = True
         return self
+
+    def region_keep(self, rb, hz):
+        """The region query of ``__call__`` applied to a raw batch: (keep bool[n], done).  A record is in the region
+        when its CHROM matches and [POS, POS + len(REF) - 1] meets [start, end] (``_in_region``); with an index the
+        first record past the region ends the query (``done``; the records after it are dropped too)."""
+        n = rb.n
+        if self._region is None or n == 0:
+            return np.ones(n, dtype=bool), False
+        chrom, start, end = self._region
+        same = np.array([c == chrom for c in rb.chrom_column()], dtype=bool)
+        pos = hz.pos
+        keep = same.copy()
+        if start is not None:
+            fo = np.ctypeslib.as_array(rb.b.field_off, shape=(n * 10,)).reshape(n, 10)
+            ref_len = (fo[:, 4] - fo[:, 3] - 1).astype(np.int64)
+            keep &= (pos + ref_len - 1 >= start) & (pos <= end)
+        done = False
+        if self._indexed_region:
+            past = ~same
+            if end is not None:
+                past |= pos > end
+            past &= ~keep
+            if past.any():
+                keep[int(np.flatnonzero(past)[0]):] = False
+                done = True
+        return keep, done
 
     def _past_region(self, v):
         chrom, start, end = self._region
