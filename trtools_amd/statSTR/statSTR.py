@@ -263,14 +263,15 @@ def _run_batches(args, invcf, vcftype, group_masks, fmt, shard, batch_loci, star
         if getattr(args, name):
             flags |= bit
     masks = group_masks if group_masks[0] is not None else None
-    gb, ng = None, 1
+    passes = [(None, 1)]                     # (group bits, groups) per device pass: up to eight strata each
     if masks is not None:
-        if len(masks) > MAX_GROUPS_PER_PASS:
-            return None                      # more strata than one device pass takes: per-record loop
-        ng = len(masks)
-        gb = np.zeros(len(invcf.samples), dtype=np.uint8)
-        for g, m in enumerate(masks):
-            gb |= (np.asarray(m, dtype=bool).astype(np.uint8) << g)
+        passes = []
+        for i in range(0, len(masks), MAX_GROUPS_PER_PASS):
+            part = masks[i:i + MAX_GROUPS_PER_PASS]
+            gb = np.zeros(len(invcf.samples), dtype=np.uint8)
+            for g, m in enumerate(part):
+                gb |= (np.asarray(m, dtype=bool).astype(np.uint8) << g)
+            passes.append((gb, len(part)))
     invcf.use_buffers(getattr(compute, 'host_buffer', None), ring=2, release=getattr(compute, 'host_release', None))
     nrecords = 0
     region_done = False
@@ -308,9 +309,17 @@ def _run_batches(args, invcf, vcftype, group_masks, fmt, shard, batch_loci, star
             continue
         if not shard.next_batch():
             continue
-        hb = HostBatch.from_tables(rb.gt, rb.locus_ploidy, hz.allele_off, hz.len_class, hz.str_class,
-                                   hz.len_class_value, gb, ng, lists=hz.lists)
-        st = compute.locus_stats(hb, nalleles_thresh=args.nalleles_thresh)
+        parts = []
+        for gb, ng in passes:
+            hb = HostBatch.from_tables(rb.gt, rb.locus_ploidy, hz.allele_off, hz.len_class, hz.str_class,
+                                       hz.len_class_value, gb, ng, lists=hz.lists)
+            parts.append(compute.locus_stats(hb, nalleles_thresh=args.nalleles_thresh))
+        st = parts[0]
+        if len(parts) > 1:                   # more than eight strata: the passes' rows side by side
+            from ..compute import StatsHost
+            st = StatsHost(np.concatenate([p.allele_count for p in parts]),
+                           np.concatenate([p.locus_int for p in parts]),
+                           np.concatenate([p.locus_f64 for p in parts]))
         skip = (hz.passing == 0) if args.only_passing else None
         if keep is not None:
             skip = ~keep if skip is None else (skip | ~keep)
