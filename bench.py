@@ -820,7 +820,7 @@ def end_to_end_extra(eng, seed):
             "workload": "statSTR (11 statistics) on a bgzipped text VCF, %d loci x %d samples, GT:DP:Q (%.0f MB "
                         "compressed), to its .tab file" % (Lc, S, os.path.getsize(path) / 1e6),
             "seconds": best, "loci_per_s": Lc / best, "calls_per_s": Lc * S / best,
-            "rows": sum(1 for _ in open(ns.out + '.tab')) - 1}
+            "rows": sum(1 for _ in open(ns.out + '.tab')) - 1, "path": dict(statSTR.LAST_RUN)}
         # dumpSTR on the same file: three call filters + four locus filters, output VCF (~180 MB) and the two logs
         from trtools_amd.dumpSTR import dumpSTR
         argv = sys.argv
@@ -842,7 +842,7 @@ def end_to_end_extra(eng, seed):
         out["dumpstr_cli_text_vcf_to_vcf"] = {
             "workload": "dumpSTR (min/max call DP, min call Q; call rate, HWE, het low/high) on the same file, to an "
                         "output VCF of %.0f MB + sample and locus logs" % (os.path.getsize(os.path.join(tmp, 'dump.vcf')) / 1e6),
-            "seconds": best, "loci_per_s": Lc / best, "calls_per_s": Lc * S / best}
+            "seconds": best, "loci_per_s": Lc / best, "calls_per_s": Lc * S / best, "path": dict(dumpSTR.LAST_RUN)}
         # BASELINE configs[2] through text at reduced scale: a GangSTR-shape file (GT:DP:Q:REPCN:REPCI:RC:QEXP), the
         # nine GangSTR call filters + four locus filters, output VCF + logs
         Lg, Sg = 400, 2000
@@ -873,7 +873,7 @@ def end_to_end_extra(eng, seed):
             "workload": "dumpSTR with the nine GangSTR call filters + four locus filters (BASELINE configs[2] at reduced "
                         "scale) on a GangSTR-shape text VCF, %d loci x %d samples (%.0f MB), to an output VCF + logs"
                         % (Lg, Sg, os.path.getsize(gpath) / 1e6),
-            "seconds": best, "loci_per_s": Lg / best, "calls_per_s": Lg * Sg / best}
+            "seconds": best, "loci_per_s": Lg / best, "calls_per_s": Lg * Sg / best, "path": dict(dumpSTR.LAST_RUN)}
         for f in os.listdir(tmp):
             os.remove(os.path.join(tmp, f))
         os.rmdir(tmp)

@@ -15,6 +15,7 @@ import argparse
 import collections
 import itertools
 import os
+import time
 import subprocess as sp
 import sys
 
@@ -275,6 +276,12 @@ def BuildLocusFilters(args):
 # what the last main() call ran through: 'batch' (every batch through the batch pipeline), 'mixed' (some batches
 # through the record objects), 'per-record' (the loop); read by bench.py's end-to-end extra and the tests
 LAST_RUN = {}
+
+
+def _tick(phase, seconds):
+    """Wall time of the batch pipeline's phases, summed over the batches of a run (LAST_RUN['seconds'])."""
+    d = LAST_RUN.setdefault('seconds', {})
+    d[phase] = d.get(phase, 0.0) + seconds
 
 
 class _Planes:
@@ -548,8 +555,11 @@ class _Run:
                     ref_len = hz.allele_len[hz.allele_off[:-1]]          # record.ref_allele_length (repeat units)
                     fire = f.overlaps_batch(chroms, hz.pos, hz.pos + ref_len)
                 ext |= fire.astype(np.uint32) << np.uint32(j)
+        t_dev = time.perf_counter()
         ch, st, bits, lc = compute.dumpstr_batch(hb, arrays, specs, -1 if dp_key is None else index[dp_key],
                                                  dict(self.spec, extern_bits=ext), **kw)
+        t_heads = time.perf_counter()
+        _tick('upload_kernels_download', t_heads - t_dev)
         # the native writer first: if it declines, the batch has left no trace
         names = [f.name for f in self.call_filters]
         cfv = []
@@ -604,7 +614,10 @@ class _Run:
             f[7] = vcfio.rewrite_info(self.invcf, f[7], upd)
             f[8] = f[8] + ':FILTER'
             heads.append('\t'.join(f))
+        t_lines = time.perf_counter()
+        _tick('record_heads_python', t_lines - t_heads)
         text = rb.dumpstr_lines(heads, ch.mask, cfv, format_kinds)
+        _tick('record_text_native', time.perf_counter() - t_lines)
         if text is None:
             return self._undo_batch()
         if ch.error[0]:
@@ -620,8 +633,10 @@ class _Run:
         if np.any(st.locus_int[0, :, L.LI_N_BAD]):
             raise IndexError("genotype index out of range for the alleles of a record")
         self._count(ch, lc, dp_key is not None)
+        t_w = time.perf_counter()
         if self.world == 1:
             self.outvcf.write_bytes(text)
+            _tick('write_output', time.perf_counter() - t_w)
         else:
             self.parts.append((self._key(), bytes(text)))
         return True
@@ -914,11 +929,15 @@ def main(args):
             want = min(batch_loci, args.num_records - record_counter)
             if want <= 0:
                 break
+        t0 = time.perf_counter()
         rb = invcf.read_raw_batch(want)
+        t1 = time.perf_counter()
+        _tick('read_parse', t1 - t0)
         if rb.n == 0:
             break
         record_counter += rb.n
         hz = rb.harmonize(vcftype.name)
+        _tick('harmonize', time.perf_counter() - t1)
         if args.verbose:
             for l in range(rb.n):
                 common.MSG("Processing %s:%s" % rb.chrom_pos(l))
