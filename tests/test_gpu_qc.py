@@ -105,3 +105,12 @@ def test_product_reductions_equal_reference_goldens(case):
     np.testing.assert_allclose(got['sum_diff_unit'], want['diffref_hist']['sum'], rtol=1e-9, atol=1e-6)
     np.testing.assert_allclose(got['sum_diff_bp'], want['diffref_bias']['sum_diffs'], rtol=1e-9, atol=1e-6)
     np.testing.assert_allclose(got['sum_reflen_bp'], want['diffref_bias']['sum_reflens'], rtol=1e-9, atol=1e-6)
+    # the joint (reference length, period, difference) distribution reproduces the recorded sums exactly: it is the
+    # data of both diff-from-reference plots (four scalars could not rebuild the per-bin medians)
+    h = got['diff_ref_histogram']
+    assert sum(h.values()) == got['n_alleles']
+    np.testing.assert_allclose(sum(d * k for (_, _, d), k in h.items()), want['diffref_hist']['sum'], rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(sum(d * p * k for (_, p, d), k in h.items()), want['diffref_bias']['sum_diffs'],
+                               rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(sum(r * k for (r, _, _), k in h.items()), want['diffref_bias']['sum_reflens'],
+                               rtol=1e-9, atol=1e-6)

@@ -226,3 +226,31 @@ def test_corrupt_bgzf_blocks_are_refused(tmp_path):
             list(vcfnative.NativeVCFReader(path))
         with pytest.raises(ValueError):
             list(tabix._blocks(path))
+
+
+def test_wide_genotypes_widen_one_batch_only_and_nine_haplotypes_are_named(tmp_path):
+    """one 0/1/1 genotype used to double the tensor width for every later batch of the file, and a
+    genotype beyond the device's ploidy limit surfaced late as an opaque libtrk error.  Now only the batch that
+    holds the wide record is decoded wider, and more than 8 haplotypes are refused with the file and the record."""
+    from trtools_amd import vcfnative
+    p = tmp_path / 'w.vcf'
+    head = ('##fileformat=VCFv4.1\n##FORMAT=<ID=GT,Number=1,Type=String,Description="g">\n'
+            '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tA\tB\n')
+    recs = ['1\t%d\t.\tA\tAA\t.\t.\t.\tGT\t%s\t0/1\n' % (10 + i, '0/1/1' if i == 1 else '0/0') for i in range(8)]
+    p.write_text(head + ''.join(recs))
+    r = vcfnative.NativeVCFReader(str(p))
+    widths = []
+    while True:
+        rb = r.read_raw_batch(2)
+        if rb.n == 0:
+            break
+        widths.append(rb.gt.shape[2])
+    r.close()
+    assert widths == [4, 2, 2, 2]
+    bad = tmp_path / 'nine.vcf'
+    bad.write_text(head + '7\t123\t.\tA\tAA\t.\t.\t.\tGT\t0/1/1/0/1/0/0/1/1\t0\n')
+    r = vcfnative.NativeVCFReader(str(bad))
+    with pytest.raises(ValueError) as ei:
+        r.read_raw_batch(4)
+    r.close()
+    assert 'nine.vcf' in str(ei.value) and '7:123' in str(ei.value) and '8 haplotypes' in str(ei.value)

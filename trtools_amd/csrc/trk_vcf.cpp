@@ -464,6 +464,7 @@ struct RecordJob {
     int S, P;
     trk_vcf_batch* out;
     std::atomic<int> error{0};
+    std::atomic<int> error_rec{-1};   // a record the error was met in
 };
 
 void parse_record(RecordJob& job, int rec) {
@@ -544,6 +545,7 @@ void parse_record(RecordJob& job, int rec) {
                 while (b < e && *b != '/' && *b != '|') ++b;
                 if (j >= P) {
                     job.error = 2;  // ploidy above the tensor's P
+                    job.error_rec = rec;
                     break;
                 }
                 gt[(size_t)s * P + j] = (b - a == 1 && *a == '.') || b == a ? (int16_t)-1 : (int16_t)parse_int(a, b);
@@ -575,7 +577,7 @@ void parse_record(RecordJob& job, int rec) {
             }
         }
         if (se == end) {
-            if (s + 1 < S) job.error = 3;  // fewer sample columns than the header announces
+            if (s + 1 < S) { job.error = 3; job.error_rec = rec; }  // fewer sample columns than the header announces
             break;
         }
         sp = se + 1;
@@ -950,6 +952,15 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
         // overflow with a wider genotype tensor, vcfnative.py)
         v->err = job.error == 2 ? "a genotype has more haplotypes than max_ploidy"
                                 : "a record has fewer sample columns than the header";
+        const int er = job.error_rec.load();
+        if (er >= 0 && er < n) {            // name the record: CHROM:POS
+            const char* line = v->buf.data() + v->line_off[(size_t)er];
+            const char* lend = v->buf.data() + v->line_end[(size_t)er];
+            const char* t1p = find_ch(line, lend, '\t');
+            const char* t2p = t1p < lend ? find_ch(t1p + 1, lend, '\t') : lend;
+            v->err += " (record " + std::string(line, (size_t)(t1p - line)) + ":" +
+                      (t1p < lend ? std::string(t1p + 1, (size_t)(t2p - t1p - 1)) : std::string("?")) + ")";
+        }
         return 5;
     }
     if (timing)

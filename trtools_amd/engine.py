@@ -213,10 +213,14 @@ class _QueueScope:
 
     def __enter__(self):
         self.eng._chk(self.eng.lib.trk_stream_select(self.eng.ctx, self.queue))
+        self.eng._queue = self.queue
+        if self.queue != 0:
+            self.eng._multi_queue = True
         return self
 
     def __exit__(self, *exc):
         self.eng._chk(self.eng.lib.trk_stream_select(self.eng.ctx, 0))
+        self.eng._queue = 0
         return False
 
 
@@ -225,9 +229,12 @@ class Engine:
         self.lib = L.load()
         self.ctx = None
         self._live = set()
-        self._pool = {}              # size class -> [device pointers]
+        self._pool = {}              # size class -> [(device pointer, idle: no queue can still be using it)]
         self._pool_bytes = 0
-        self._pool_limit = int(float(os.environ.get('TRK_POOL_GB', '16')) * (1 << 30))
+        self._queue = 0              # the selected queue (on_queue)
+        self._multi_queue = False    # another queue than 0 has been used since the last full synchronisation
+        # the pool holds at most TRK_POOL_GB of freed buffers until close() / trim() (0 = no pooling)
+        self._pool_limit = int(float(os.environ.get('TRK_POOL_GB', '8')) * (1 << 30))
         self._pinned = []            # pointers of hipHostMalloc'ed staging buffers
         self._pinned_cls = {}        # pointer -> size class of the buffers handed out
         self._pinned_free = {}       # size class -> released pointers
@@ -265,23 +272,34 @@ class Engine:
         return (nbytes + step - 1) // step * step
 
     def _pool_take(self, cap):
+        """A pooled buffer of this size class.  free() is NOT a synchronisation point (hipFree was): work enqueued
+        earlier may still read or write a freed buffer.  Queues are in-order, so while only queue 0 is in use a
+        buffer can be handed straight back out; once other queues have been used (bench.py's pipelined step) nobody
+        knows which queue touched a buffer last, and the first reuse waits for the whole device (trk_sync) -- after
+        which every pooled buffer is idle again."""
         lst = self._pool.get(cap)
-        if lst:
-            self._pool_bytes -= cap
-            return lst.pop()
-        return None
+        if not lst:
+            return None
+        ptr, safe = lst.pop()
+        self._pool_bytes -= cap
+        if not safe:
+            self.sync()
+            self._multi_queue = False
+            for rest in self._pool.values():
+                rest[:] = [(p, True) for p, _ in rest]
+        return ptr
 
     def _pool_give(self, cap, ptr):
         if self._pool_limit <= 0 or self._pool_bytes + cap > self._pool_limit:
             return False
-        self._pool.setdefault(cap, []).append(ptr)
+        self._pool.setdefault(cap, []).append((ptr, not self._multi_queue))
         self._pool_bytes += cap
         return True
 
     def trim(self):
         """Return every pooled device buffer to the driver."""
         for lst in self._pool.values():
-            for ptr in lst:
+            for ptr, _ in lst:
                 self.lib.trk_dev_free(self.ctx, ptr)
         self._pool, self._pool_bytes = {}, 0
 

@@ -37,6 +37,16 @@ def _flush(compute, batch, sample_index, use_q, ignore, acc):
         c = cnt[lo:hi].astype(np.int64)
         period = len(r.motif)
         diff_unit = lens - r.ref_allele_length
+        # the joint distribution the two diff-from-reference plots are drawn from (qcSTR.py:238-327: the histogram of
+        # diff_unit; per reference-length bin the mean / median of diff_bp, bins with fewer than mingts calls
+        # dropped): (reference length in bp, period, difference in repeat units) -> allele calls.  Small (a few
+        # entries per locus) and enough to rebuild either plot's data exactly.
+        hist = acc['diff_hist']
+        reflen_bp = float(r.ref_allele_length * period)
+        for d, k in zip(diff_unit.tolist(), c.tolist()):
+            if k:
+                key = (reflen_bp, period, d)
+                hist[key] = hist.get(key, 0) + k
         acc['n_alleles'] += int(c.sum())
         acc['sum_diff_unit'] += float((diff_unit * c).sum())
         acc['sum_diff_bp'] += float((diff_unit * period * c).sum())
@@ -46,8 +56,13 @@ def _flush(compute, batch, sample_index, use_q, ignore, acc):
 def qc_reductions(vcf, vcftype='auto', samples=None, period=None, quality=(), quality_ignore_no_call=False,
                   numrecords=None, batch_loci=1024):
     """Returns a dict: samples (the selected names), sample_calls, chrom_calls, numrecords, per_sample_quality and
-    per_locus_quality (None without a quality request), and the sums behind the two diff-from-reference plots
-    (n_alleles, sum_diff_unit, sum_diff_bp, sum_reflen_bp).  Arguments as the reference's command line
+    per_locus_quality (None without a quality request), the sums behind the two diff-from-reference plots
+    (n_alleles, sum_diff_unit, sum_diff_bp, sum_reflen_bp) and ``diff_ref_histogram``: {(reference length in bp,
+    period, difference from the reference in repeat units): allele calls} -- the joint distribution from which
+    OutputDiffRefHistogram's histogram and OutputDiffRefBias's per-bin mean / median (with its mingts rule) can be
+    rebuilt; the per-call quality matrix of the sample-stratified / per-call plots is not kept (plotting is out of
+    scope).  Per-locus quality means are float64 sums / n here where the reference takes
+    np.mean over float32: equal to float32 rounding (stated in tests/test_gpu_qc.py).  Arguments as the reference's command line
     (qcSTR.py:343-419); returns None where the reference returns 1."""
     from .. import runtime
     compute = runtime.get_compute()
@@ -70,7 +85,7 @@ def qc_reductions(vcf, vcftype='auto', samples=None, period=None, quality=(), qu
         quality = ['sample-stratified'] if len(sample_list) <= 5 else ['per-locus']
     use_q = len(quality) != 0
     acc = dict(sample_calls=np.zeros(len(sample_list)), chrom_calls={}, per_sample_total=np.zeros(len(sample_list)),
-               per_locus=[], n_alleles=0, sum_diff_unit=0.0, sum_diff_bp=0.0, sum_reflen_bp=0.0)
+               per_locus=[], n_alleles=0, sum_diff_unit=0.0, sum_diff_bp=0.0, sum_reflen_bp=0.0, diff_hist={})
     batch, n = [], 0
     for trrecord in harmonizer:
         if numrecords is not None and n >= numrecords:
@@ -92,4 +107,4 @@ def qc_reductions(vcf, vcftype='auto', samples=None, period=None, quality=(), qu
     return dict(samples=sample_list, sample_calls=acc['sample_calls'], chrom_calls=acc['chrom_calls'], numrecords=n,
                 per_sample_quality=per_sample, per_locus_quality=acc['per_locus'] if use_q else None,
                 n_alleles=acc['n_alleles'], sum_diff_unit=acc['sum_diff_unit'], sum_diff_bp=acc['sum_diff_bp'],
-                sum_reflen_bp=acc['sum_reflen_bp'])
+                sum_reflen_bp=acc['sum_reflen_bp'], diff_ref_histogram=acc['diff_hist'])

@@ -373,7 +373,8 @@ class NativeVCFReader(vcfio.VCFReader):
         P = self._max_ploidy
         n = n_records or self._batch_records or max(1, min(4096, (1 << 22) // max(S, 1)))
         while True:
-            gt, ph, lp, planes = self._arrays(n, S, P)
+            # (a batch retried with a wider tensor gets arrays of its own: the ring keeps the file's usual shape)
+            gt, ph, lp, planes = self._arrays(n, S, P, ring=(P == self._max_ploidy))
             parr = (C.c_void_p * max(len(planes), 1))(*[p.ctypes.data for p in planes])
             b = _Batch()
             b.gt, b.phased, b.locus_ploidy = gt.ctypes.data, ph.ctypes.data, lp.ctypes.data
@@ -383,9 +384,12 @@ class NativeVCFReader(vcfio.VCFReader):
                 # a genotype with more haplotypes than the tensor has columns (0/1/1 in a file read as diploid):
                 # the reader has consumed nothing, decode the same lines again with a wider tensor (cyvcf2 sizes
                 # its genotype array per record; the kernels take any ploidy up to 8)
-                if P >= 64:
-                    raise ValueError("a record of %s has more than 64 haplotypes per genotype" % self.path)
-                P = self._max_ploidy = 2 * P
+                # Only THIS batch is decoded wider: one 0/1/1 genotype must not make every later batch of the file
+                # twice as wide.  The device takes ploidy <= 8 (TRK_MAX_PLOIDY).
+                if P >= 8:
+                    raise ValueError("%s: %s -- more than 8 haplotypes per genotype are not supported"
+                                     % (self.path, self._lib.trk_vcf_last_error(self._h).decode()))
+                P = min(8, 2 * P)
                 continue
             if rc != 0:
                 raise ValueError(self._lib.trk_vcf_last_error(self._h).decode())
@@ -423,8 +427,8 @@ class NativeVCFReader(vcfio.VCFReader):
         self._ring, self._ring_i, self._ring_n, self._alloc = [], 0, int(ring), allocator
         self._release, self._slabs = release, []     # ``release(slab)``: called for every slab when the reader closes
 
-    def _arrays(self, n, S, P):
-        if getattr(self, '_ring_n', 0) <= 0:
+    def _arrays(self, n, S, P, ring=True):
+        if getattr(self, '_ring_n', 0) <= 0 or not ring:
             return (np.empty((n, S, P), dtype=np.int16), np.empty((n, S), dtype=np.uint8), np.empty(n, dtype=np.uint8),
                     [np.empty((n, S, nc), dtype=dt) for _, _, nc, dt in self._selected])
         key = (n, S, P, tuple((nc, np.dtype(dt).str) for _, _, nc, dt in self._selected))
