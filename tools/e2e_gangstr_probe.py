@@ -31,7 +31,9 @@ old = sys.argv; sys.argv = argv; args = dumpSTR.getargs(); sys.argv = old
 cells = a.loci * a.samples
 for rep in range(2):
     t = time.time(); rc = dumpSTR.main(args); dt = time.time() - t
-    print("dumpSTR CLI, GangSTR nine call + four locus filters: rc=%d %.2fs  %.0f loci/s  %.2e cells/s" % (rc, dt, a.loci / dt, cells / dt))
+    print("dumpSTR CLI, GangSTR nine call + four locus filters: rc=%d %.3fs  %.0f loci/s  %.2e cells/s" % (rc, dt, a.loci / dt, cells / dt))
+    print("   path / phases:", {k: (v if not isinstance(v, dict) else {p: round(x, 4) for p, x in v.items()})
+                                for k, v in dumpSTR.LAST_RUN.items()})
 if os.environ.get('E2E_PROFILE'):
     import cProfile, pstats
     pr = cProfile.Profile(); pr.enable(); dumpSTR.main(args); pr.disable()

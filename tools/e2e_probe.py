@@ -84,6 +84,10 @@ if not a.no_gpu:
     t = time.time(); rc = dumpSTR.main(dargs); t5 = time.time() - t
     print("dumpSTR CLI end to end (3 call + 4 locus filters, VCF out %.0f MB): rc=%d %6.2fs  %.0f loci/s  %.2e cells/s" % (
         os.path.getsize(os.path.join(a.out, 'dump.vcf')) / 1e6, rc, t5, a.loci / t5, cells / t5))
+    print("dumpSTR path / phases:", {k: (v if not isinstance(v, dict) else {p: round(x, 3) for p, x in v.items()})
+                                     for k, v in dumpSTR.LAST_RUN.items()})
+    t = time.time(); rc = dumpSTR.main(dargs); t5 = time.time() - t
+    print("dumpSTR CLI second run: %6.2fs  %.2e cells/s" % (t5, cells / t5))
     if os.environ.get('E2E_PROFILE'):
         import cProfile, pstats
         pr = cProfile.Profile(); pr.enable(); dumpSTR.main(dargs); pr.disable()
