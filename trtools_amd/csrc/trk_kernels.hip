@@ -3248,12 +3248,36 @@ __global__ __launch_bounds__(256) void k_class_combine(ClassRuns cr, const int32
 // 10k), a thread stores 16 bytes = four gathered calls.  Any other shape: element-wise.
 __global__ __launch_bounds__(256) void k_permute_columns(const int16_t* __restrict__ src, int16_t* __restrict__ dst,
                                                         const int32_t* __restrict__ col, int64_t n_loci, int n_src,
-                                                        int n_dst, int ploidy) {
+                                                        int n_dst, int ploidy, int use_lds) {
+    extern __shared__ uint32_t perm_lds[];
     if (ploidy == 2 && (n_dst & 3) == 0) {
         const int q4 = n_dst >> 2;
         for (int64_t l = blockIdx.x; l < n_loci; l += gridDim.x) {
             const uint32_t* srow = reinterpret_cast<const uint32_t*>(src) + l * n_src;
             u32x4* drow = reinterpret_cast<u32x4*>(dst) + l * q4;
+            if (use_lds) {
+                // the row into LDS with coalesced loads (16 bytes per lane where the row start is aligned), the gather
+                // out of LDS: scattered 4-byte reads cost LDS bank conflicts, not a cache line per lane
+                if ((n_src & 3) == 0) {
+                    const u32x4* s4 = reinterpret_cast<const u32x4*>(srow);
+                    for (int i = threadIdx.x; i < (n_src >> 2); i += 256)
+                        reinterpret_cast<u32x4*>(perm_lds)[i] = __builtin_nontemporal_load(s4 + i);
+                } else {
+                    for (int i = threadIdx.x; i < n_src; i += 256) perm_lds[i] = srow[i];
+                }
+                __syncthreads();
+                for (int j4 = threadIdx.x; j4 < q4; j4 += 256) {
+                    const int4 c = reinterpret_cast<const int4*>(col)[j4];
+                    u32x4 o;
+                    o[0] = c.x >= 0 ? perm_lds[c.x] : 0xffffffffu;
+                    o[1] = c.y >= 0 ? perm_lds[c.y] : 0xffffffffu;
+                    o[2] = c.z >= 0 ? perm_lds[c.z] : 0xffffffffu;
+                    o[3] = c.w >= 0 ? perm_lds[c.w] : 0xffffffffu;
+                    __builtin_nontemporal_store(o, drow + j4);
+                }
+                __syncthreads();
+                continue;
+            }
             for (int j4 = threadIdx.x; j4 < q4; j4 += 256) {
                 const int4 c = reinterpret_cast<const int4*>(col)[j4];
                 u32x4 o;
@@ -4350,8 +4374,10 @@ hipError_t launch_permute_columns(const int16_t* src, int16_t* dst, const int32_
     int64_t wgs = (ploidy == 2 && (n_dst & 3) == 0) ? n_loci : (n_loci * n_dst + 255) / 256;
     const int64_t cap = (int64_t)n_cu * 32;
     if (wgs > cap) wgs = cap;
-    hipLaunchKernelGGL(k_permute_columns, dim3((unsigned)wgs), dim3(256), 0, stream, src, dst, col, n_loci, n_src, n_dst,
-                       ploidy);
+    // rows of up to 16k diploid samples are staged in LDS (64 KiB); longer ones are gathered from global memory
+    const bool lds_ok = ploidy == 2 && (n_dst & 3) == 0 && (size_t)n_src * 4 <= 64 * 1024 && !getenv("TRK_PERMUTE_NOLDS");
+    hipLaunchKernelGGL(k_permute_columns, dim3((unsigned)wgs), dim3(256), lds_ok ? (size_t)n_src * 4 : 0, stream, src, dst, col,
+                       n_loci, n_src, n_dst, ploidy, lds_ok ? 1 : 0);
     return hipGetLastError();
 }
 
