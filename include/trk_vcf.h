@@ -146,7 +146,7 @@ int trk_vcf_decode_formats(const char* samples, int64_t len, int32_t n_samples, 
  *   (HipSTR: PERIOD, GangSTR / adVNTR: len(RU)) -- and from them the class tables of trk_batch (include/trk.h:
  *   allele_off, len_class, str_class, len_class_value) plus the sorted distinct sequences (the keys of
  *   GetAlleleCounts, tr_harmonizer.py:1495-1499).  Records it does not cover (a missing mandatory INFO field,
- *   symbolic alleles, PopSTR / ExpansionHunter input) get status 1 and n_python counts them: the caller then runs the
+ *   symbolic alleles) get status 1 and n_python counts them: the caller then runs the
  *   batch through the Python harmoniser, which raises the reference's errors.
  * trk_vcf_statstr_rows  the text of statSTR's output rows (statSTR.py:586-629) from the device results of the batch:
  *   chrom, POS, POS + len(ref allele), then per enabled statistic and sample group the columns in the reference's
@@ -154,7 +154,7 @@ int trk_vcf_decode_formats(const char* samples, int64_t len, int32_t n_samples, 
  *   sequences or str(numpy.float64) lengths).  err_kind: 1 / 2 the reference raises ValueError / IndexError in the
  *   HWE test of locus err_locus, 3 a genotype index beyond the record's alleles.
  * All returned pointers are owned by the reader and stay valid until its next trk_vcf_read_batch / harmonize call. */
-enum { TRK_VT_GANGSTR = 0, TRK_VT_HIPSTR = 1, TRK_VT_ADVNTR = 2 };
+enum { TRK_VT_GANGSTR = 0, TRK_VT_HIPSTR = 1, TRK_VT_ADVNTR = 2, TRK_VT_EH = 3, TRK_VT_POPSTR = 4 };
 typedef struct {
     int32_t n_records;
     int32_t n_python;              /* records with status != 0                                            */

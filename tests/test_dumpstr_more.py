@@ -23,9 +23,7 @@ WANT = json.load(open(os.path.join(OUT, 'results.json')))['rc']
 PATHS = {}
 # the argument sets that may leave the batch pipeline, and why; every other successful run must go through it for
 # every batch (the fallbacks used to be silent)
-PER_RECORD_OK = {'eh_file': 'ExpansionHunter records carry no allele sequences: Python harmoniser',
-                 'beagle_allowed_eh': 'ExpansionHunter input',
-                 'round_two': 'input is dumpSTR output: a FORMAT/FILTER field is already there'}
+PER_RECORD_OK = {'round_two': 'input is dumpSTR output: a FORMAT/FILTER field is already there'}
 
 
 def run_all(outdir):

@@ -141,3 +141,55 @@ def test_sample_index_kinds_and_stats_cache_cpu():
 def test_sample_index_kinds_and_stats_cache_gpu():
     from trtools_amd.compute import DeviceCompute
     _api_checks(DeviceCompute())
+
+
+def _fixture_files():
+    import os
+    from helpers import GOLDEN
+    D = os.path.join(GOLDEN, 'data')
+    DD = os.path.join(D, 'dumpSTR')
+    return [(os.path.join(DD, 'trio_chr21_hipstr.sorted.vcf.gz'), 'hipstr'),
+            (os.path.join(DD, 'trio_chr21_gangstr.sorted.vcf.gz'), 'gangstr'),
+            (os.path.join(DD, 'NA12878_chr21_advntr.sorted.vcf.gz'), 'advntr'),
+            (os.path.join(DD, 'NA12878_chr21_eh.sorted.vcf.gz'), 'eh'),
+            (os.path.join(DD, 'NA12878_chr21_popstr.sorted.vcf.gz'), 'popstr'),
+            (os.path.join(DD, 'longtr_testfile.vcf.gz'), 'longtr')]
+
+
+@pytest.mark.parametrize('path,vcftype', _fixture_files(), ids=[v for _, v in _fixture_files()])
+def test_native_batch_harmoniser_equals_the_python_harmoniser(path, vcftype):
+    """trk_vcf_harmonize (all six callers since round 3: ExpansionHunter / PopSTR alleles are fabricated from the
+    motif as utils.FabricateAllele does) against the Python harmoniser record by record: allele lengths, the
+    upper-cased sequences in class order, positions, the homopolymer run of the (possibly fabricated) reference
+    allele, INFO PERIOD.  Records the native one declines (symbolic <DEL> alleles of LongTR) are skipped."""
+    import os
+    import numpy as np
+    from trtools_amd import vcfnative
+    from trtools_amd.utils import tr_harmonizer as trh, utils
+    if not os.path.exists(path):
+        pytest.skip("fixture absent")
+    r = vcfnative.NativeVCFReader(path)
+    vt = trh.VcfTypes[vcftype]
+    n_checked = 0
+    while n_checked < 600:
+        rb = r.read_raw_batch(200)
+        if rb.n == 0:
+            break
+        hz = rb.harmonize(vcftype)
+        lens, strs = hz.lists()
+        for l, rec in enumerate(rb.records()):
+            if hz.status[l]:
+                continue
+            t = trh.HarmonizeRecord(vt, rec)
+            want_len = [t.ref_allele_length] + list(t.alt_allele_lengths)
+            want_str = [t.ref_allele] + list(t.alt_alleles)
+            assert lens[l] == [float(x) for x in want_len], (l, lens[l], want_len)
+            assert strs[l] == [str(x) for x in want_str], (l, strs[l][:3], want_str[:3])
+            assert int(hz.pos[l]) == rec.POS
+            seq = t.full_alleles[0] if t.HasFullStringGenotypes() else t.ref_allele
+            assert int(hz.hrun[l]) == utils.GetHomopolymerRun(seq), l
+            per = rec.INFO.get('PERIOD')
+            assert (int(hz.period[l]) == per) if per is not None else (int(hz.period[l]) == -2147483648)
+            n_checked += 1
+    r.close()
+    assert n_checked > 20

@@ -1398,7 +1398,23 @@ struct HzRecord {  // one record's harmonised alleles (views into the line; uppe
     int32_t hrun = 0;
     int32_t period = INT32_MIN;                          // INFO PERIOD (an integer), INT32_MIN when absent
     bool ok = false, passing = false;
+    // ExpansionHunter / PopSTR: alleles given by LENGTH (<STRn>, <n>) are fabricated from the motif (utils.py:566-602);
+    // `lengths` then holds the stated lengths (len(fabricated) / len(motif) differs for fractional ones)
+    std::vector<std::string> owned;
+    std::vector<double> lengths;
 };
+
+// utils.FabricateAllele(motif, length): floor(length) copies, then leading bases of the motif while one more base
+// stays below `length` copies
+inline std::string fabricate_allele(const std::string& motif, double length) {
+    std::string fab;
+    const double fl = std::floor(length);
+    if (fl > 0)
+        for (long k = 0; k < (long)fl; ++k) fab += motif;
+    size_t i = 0;
+    while (((double)(fab.size() + 1)) / (double)motif.size() < length && i < motif.size()) fab += motif[i++];
+    return fab;
+}
 
 // What _HarmonizeHipSTRRecord / _HarmonizeGangSTRRecord / _HarmonizeAdVNTRRecord + TRRecord.__init__ derive per record
 // (reference tr_harmonizer.py:303-408, 693-773): the trimmed alleles and the motif LENGTH (lengths are
@@ -1445,9 +1461,11 @@ void harmonize_one(const char* line, const int32_t* fo, int64_t line_len, int vc
             if (t == ae) break;
         }
     }
-    for (auto& al : raw)
-        for (long i = 0; i < al.second; ++i)
-            if (al.first[i] == '<' || al.first[i] == '[' || al.first[i] == ']' || al.first[i] == '*') return;  // symbolic
+    const bool by_length = vcftype == TRK_VT_EH || vcftype == TRK_VT_POPSTR;
+    if (!by_length)
+        for (auto& al : raw)
+            for (long i = 0; i < al.second; ++i)
+                if (al.first[i] == '<' || al.first[i] == '[' || al.first[i] == ']' || al.first[i] == '*') return;  // symbolic
     const char* info = col[7];
     const char* infoe = cole[7];
     const char *vb, *ve;
@@ -1457,7 +1475,66 @@ void harmonize_one(const char* line, const int32_t* fo, int64_t line_len, int vc
         if (info_get(info, infoe, "PERIOD", 6, vb, ve, hv) && hv && parse_long(vb, ve, pv) && pv > INT32_MIN && pv <= INT32_MAX)
             r.period = (int32_t)pv;
     }
-    if (vcftype == TRK_VT_HIPSTR) {
+    if (by_length) {
+        // _HarmonizeEHRecord / _HarmonizePopSTRRecord (tr_harmonizer.py:473-550): the alt alleles are '<STRn>' / '<n>',
+        // n a float; EH's reference length is RL / len(RU), PopSTR's the REF string
+        std::string motif;
+        const char* prefix;
+        size_t plen;
+        if (vcftype == TRK_VT_EH) {
+            const char *xb, *xe;
+            if (!info_get(info, infoe, "VARID", 5, xb, xe, hv) || !hv) return;
+            if (!info_get(info, infoe, "RU", 2, vb, ve, hv) || !hv || ve == vb) return;
+            motif.assign(vb, (size_t)(ve - vb));
+            prefix = "<STR";
+            plen = 4;
+        } else {
+            if (!info_get(info, infoe, "Motif", 5, vb, ve, hv) || !hv || ve == vb) return;
+            motif.assign(vb, (size_t)(ve - vb));
+            prefix = "<";
+            plen = 1;
+        }
+        for (auto& c : motif)
+            if (c >= 'a' && c <= 'z') c = (char)(c - 32);
+        r.unit = (double)motif.size();
+        r.owned.clear();
+        r.lengths.clear();
+        if (vcftype == TRK_VT_EH) {
+            long rl;
+            if (!info_get(info, infoe, "RL", 2, vb, ve, hv) || !hv || !parse_long(vb, ve, rl) || rl < 0) return;
+            const double ref_units = (double)rl / r.unit;
+            r.owned.push_back(fabricate_allele(motif, ref_units));
+            r.lengths.push_back(ref_units);
+        } else {
+            r.owned.emplace_back(ref, (size_t)ref_len);
+            r.lengths.push_back((double)ref_len / r.unit);
+        }
+        for (size_t q = 1; q < raw.size(); ++q) {
+            const char* ab = raw[q].first;
+            const long al = raw[q].second;
+            if (al < (long)plen + 2 || memcmp(ab, prefix, plen) != 0 || ab[al - 1] != '>') return;   // Python: TypeError
+            std::string num(ab + plen, (size_t)(al - (long)plen - 1));
+            char* endp = nullptr;
+            const double nrep = strtod(num.c_str(), &endp);
+            if (endp == num.c_str() || *endp != 0 || !(nrep >= 0.0) || !std::isfinite(nrep)) return;
+            // (characters Python's float() takes and strtod does not, or the reverse: leave those to Python)
+            for (char ch : num)
+                if (!((ch >= '0' && ch <= '9') || ch == '.' || ch == 'e' || ch == 'E' || ch == '+' || ch == '-')) return;
+            r.owned.push_back(fabricate_allele(motif, nrep));
+            r.lengths.push_back(nrep);
+        }
+        r.alleles.clear();
+        for (auto& o : r.owned) r.alleles.emplace_back(o.data(), (long)o.size());
+        {   // HRUN is taken on trrecord.ref_allele (dumpSTR.py:1307-1312): for ExpansionHunter the FABRICATED reference
+            const std::string& ra = r.owned[0];
+            int best = ra.empty() ? 0 : 1, run = 1;
+            for (size_t i = 1; i < ra.size(); ++i) {
+                run = ((ra[i] | 32) == (ra[i - 1] | 32)) ? run + 1 : 1;
+                if (run > best) best = run;
+            }
+            r.hrun = best;
+        }
+    } else if (vcftype == TRK_VT_HIPSTR) {
         long start, endv, period;
         if (!info_get(info, infoe, "START", 5, vb, ve, hv) || !hv || !parse_long(vb, ve, start)) return;
         if (!info_get(info, infoe, "END", 3, vb, ve, hv) || !hv || !parse_long(vb, ve, endv)) return;
@@ -1521,7 +1598,7 @@ inline void put_np_float(std::string& o, double v) {
 extern "C" {
 
 int trk_vcf_harmonize(trk_vcf* v, const trk_vcf_batch* b, int vcftype, trk_vcf_harmonized* out) {
-    if (!v || !b || !out || vcftype < 0 || vcftype > TRK_VT_ADVNTR) return 2;
+    if (!v || !b || !out || vcftype < 0 || vcftype > TRK_VT_POPSTR) return 2;
     HzStore& st = v->hz;
     const int n = b->n_records;
     std::vector<HzRecord> recs((size_t)n);
@@ -1587,7 +1664,8 @@ int trk_vcf_harmonize(trk_vcf* v, const trk_vcf_batch* b, int vcftype, trk_vcf_h
             up[q].assign(r.alleles[q].first, (size_t)r.alleles[q].second);
             for (auto& c : up[q])
                 if (c >= 'a' && c <= 'z') c = (char)(c - 32);
-            st.allele_len[o + q] = (double)r.alleles[q].second / r.unit;   // len(allele) / len(motif)
+            st.allele_len[o + q] = r.lengths.empty() ? (double)r.alleles[q].second / r.unit   // len(allele) / len(motif)
+                                                     : r.lengths[q];                          // the stated length
         }
         // sequence classes: dense rank in sorted order of the distinct sequences (python str order == byte order)
         order.resize(A);

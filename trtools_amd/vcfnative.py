@@ -43,7 +43,7 @@ class _StatRows(C.Structure):
                 ('allele_count', C.c_void_p), ('locus_int', C.c_void_p), ('locus_f64', C.c_void_p)]
 
 
-VT_CODES = {'gangstr': 0, 'hipstr': 1, 'longtr': 1, 'advntr': 2}
+VT_CODES = {'gangstr': 0, 'hipstr': 1, 'longtr': 1, 'advntr': 2, 'eh': 3, 'popstr': 4}
 SS_FLAGS = dict(thresh=1, afreq=2, acount=4, nalleles=8, hwep=16, het=32, entropy=64, mean=128, mode=256, var=512,
                 numcalled=1024)
 
