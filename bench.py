@@ -623,6 +623,27 @@ def config1_extra(eng, no_check, iters=50):
                         "frac": Lc * S * 4 / (cnt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "note": "40 MB per launch: 5 us at the HBM peak -- launch-latency regime; the long-stream "
                                 "figure for this row length is extras.short_rows"}}
+    # THROUGHPUT of the same pass when a command line keeps several batches in flight: the pass is a chain of three
+    # short latency-bound kernels (count 18 us, finaliser 29, HWE tests 20-28) that leave most of the chip idle;
+    # four independent batches round-robin over the context's four in-order queues overlap them
+    NQ = 4
+    sets = [res] + [eng.alloc_stats(sb.batch) for _ in range(NQ - 1)]
+    for it in range(iters + NQ):
+        if it == NQ:
+            eng.sync()
+            t0 = time.perf_counter()
+        with eng.on_queue(it % NQ):
+            eng.locus_stats(sb.batch, out=sets[it % NQ])
+    eng.sync()
+    wq = (time.perf_counter() - t0) / iters
+    out["four_queues"] = {"what": "the same pass, four batches in flight on the context's four queues (throughput, not "
+                                  "latency)", "ms_per_pass": wq * 1e3, "loci_per_s": Lc / wq}
+    for st in sets[1:]:
+        if not no_check:
+            assert np.array_equal(st.locus_f64.get(), res.locus_f64.get(), equal_nan=True)
+            assert np.array_equal(st.allele_count.get(), res.allele_count.get())
+        for a in (st.allele_count, st.locus_int, st.locus_f64):
+            a.free()
     if not no_check:
         from oracle import fullsize, oracle_c
         off, lc, sc, cv = sb.tables
