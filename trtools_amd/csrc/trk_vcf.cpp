@@ -741,8 +741,53 @@ uint64_t next_block(FILE* fp, uint64_t c, uint64_t fsize) {
     }
     return fsize;
 }
+// start of the block that ends exactly at file offset b, found by WALKING the block chain forward from a validated
+// block start a few blocks earlier (no guessing from bytes that merely look like a header); UINT64_MAX: not found
+uint64_t block_before(FILE* fp, uint64_t b, uint64_t fsize) {
+    if (b == 0) return UINT64_MAX;
+    uint64_t p = next_block(fp, b > 3 * 65536 + 4096 ? b - (3 * 65536 + 4096) : 0, fsize);
+    unsigned char h[18 + 1024];
+    while (p < b) {
+        const size_t want = (size_t)std::min<uint64_t>(sizeof h, fsize - p);
+        if (fseeko(fp, (off_t)p, SEEK_SET) != 0 || fread(h, 1, want, fp) != want) return UINT64_MAX;
+        BlockHdr hd;
+        if (!bgzf_header(h, want, hd)) return UINT64_MAX;
+        if (p + hd.bsize == b) return p;
+        p += hd.bsize;
+    }
+    return UINT64_MAX;
+}
+
 // last byte of the uncompressed data that precedes file offset b (the block(s) ending exactly at b); -1: nothing before
-int last_byte_before(FILE* fp, uint64_t b) {
+int last_byte_before(FILE* fp, uint64_t b, uint64_t fsize) {
+    // first by the block chain (exact); the backward scan below only if the chain does not land on b
+    for (uint64_t e = b; e > 0;) {
+        const uint64_t q = block_before(fp, e, fsize);
+        if (q == UINT64_MAX) break;
+        std::vector<unsigned char> w((size_t)(e - q));
+        if (fseeko(fp, (off_t)q, SEEK_SET) != 0 || fread(w.data(), 1, w.size(), fp) != w.size()) break;
+        BlockHdr h;
+        if (!bgzf_header(w.data(), w.size(), h) || h.bsize != w.size()) break;
+        const size_t isize = (size_t)w[w.size() - 4] | ((size_t)w[w.size() - 3] << 8) | ((size_t)w[w.size() - 2] << 16) |
+                             ((size_t)w[w.size() - 1] << 24);
+        if (isize > 65536) break;
+        if (isize == 0) {          // an empty block: the data before it decides
+            e = q;
+            continue;
+        }
+        std::vector<unsigned char> o(isize);
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) break;
+        zs.next_in = w.data() + 12 + h.xlen;
+        zs.avail_in = (unsigned)(w.size() - 12 - h.xlen - 8);
+        zs.next_out = o.data();
+        zs.avail_out = (unsigned)isize;
+        const int rc = inflate(&zs, Z_FINISH);
+        inflateEnd(&zs);
+        if (rc != Z_STREAM_END) break;
+        return o[isize - 1];
+    }
     while (b > 0) {
         const uint64_t lo = b > 65536 + 1024 ? b - (65536 + 1024) : 0;
         std::vector<unsigned char> w((size_t)(b - lo));
@@ -802,7 +847,7 @@ extern "C" int trk_vcf_shard(trk_vcf* v, int rank, int world, uint64_t* begin_of
     if (b0 > 0) {
         int last;
         if (v->src.bgzf) {
-            last = last_byte_before(fp, b0);
+            last = last_byte_before(fp, b0, fsize);
         } else {
             unsigned char ch = 0;
             last = (fseeko(fp, (off_t)(b0 - 1), SEEK_SET) == 0 && fread(&ch, 1, 1, fp) == 1) ? ch : -1;
