@@ -108,9 +108,14 @@ class Workload:
         self.L = L
         self.eng = eng
         self.world = world
-        self.n_loci, self.n_samples = len(loci.allele_lens), n_samples
+        self.n_loci, self.n_real = len(loci.allele_lens), n_samples
         self.sb = SynthBatch(eng, self.n_loci, n_samples, seed=seed, planes=('dp', 'q'), locus_base=locus_base,
                              loci=loci)
+        # Rows padded to a multiple of 32 samples (128 bytes) with no-call samples, as compute.DeviceCompute uploads
+        # any cohort (trk_batch.n_pad_samples, trk_pad_rows): n_real = the cohort's samples (what every reported rate
+        # counts), n_samples = the row length of every device array.  TRK_ROW_ALIGN=4: the dense layout.
+        self.sb.pad_rows(max(4, int(os.environ.get('TRK_ROW_ALIGN', '32')) & ~3))
+        self.n_samples = n_samples = self.sb.n_dev
         self.planes = [self.sb.dev['dp'], self.sb.dev['q']]
         self.filters = filters_dpq()
         self.locus_args = dict(LOCUS_ARGS)
@@ -292,7 +297,8 @@ def exhaustive_check(wl, single_rank_sums):
     assert wl.call_out.error.get()[0] == 0
     t0 = time.perf_counter()
     r = fullsize.check_step(fetch_inputs, fetch_outputs, wl.n_loci, wl.n_samples, wl.sb.tables, wl.filters, 0,
-                            wl.locus_args, dev, n_threads=max(1, fullsize.oracle_c.tuned_threads() // max(1, wl.world)))
+                            wl.locus_args, dev, n_threads=max(1, fullsize.oracle_c.tuned_threads() // max(1, wl.world)),
+                            n_pad=wl.sb.n_pad)
     r['seconds'] = time.perf_counter() - t0
     return r
 
@@ -334,7 +340,7 @@ def assoc_extra(wl, seed, no_check, no_cpu, iters=5, group=None, total_loci=None
     n, ms = prof['k_assoc_scan']
     nf, msf = prof['k_assoc_finalize']
     scan_ms = ms / max(n, 1)
-    cells = n_loci * n_samples
+    cells = n_loci * wl.n_real
     out = {"workload": "associaTR linear-regression scan, %d loci x %d samples x 1 trait (BASELINE configs[4] on %s)"
                        % (total_loci, n_samples,
                           "one GPU" if world == 1 else "%d GPUs, %d loci per GPU, no exchange step" % (world, n_loci)),
@@ -480,8 +486,8 @@ def cpu_baseline_c(wl, n_loci=16384):
             oracle_c.batch_stats(g2, None, o, lc[sl], sc[sl], cv[sl], n_threads=nt, out=st)                 # dumpSTR on GT'
             el = time.perf_counter() - t0
             best = el if best is None else min(best, el)
-        out[label] = dict(value=n / best, unit="loci/s", cores=nt, cells_per_s=n * wl.n_samples / best,
-                          sample="%d loci x %d samples, %.2f s (best of 2)" % (n, wl.n_samples, best))
+        out[label] = dict(value=n / best, unit="loci/s", cores=nt, cells_per_s=n * wl.n_real / best,
+                          sample="%d loci x %d samples, %.2f s (best of 2)" % (n, wl.n_real, best))
     out['kind'] = "port (C restatement, oracle/oracle_c.c, OpenMP over loci inside the library)"
     out['cpu'] = cpu_model()
     out['cores_visible'] = oracle_c.n_cores()
@@ -546,7 +552,7 @@ def compact_outputs_extra(wl, iters=8):
     assert np.array_equal(m8, want), "compact mask differs from the 32-bit mask"
     assert np.array_equal(out.sample_counters.get(), ref_counters), "counters differ with the compact outputs"
     assert np.array_equal(st.allele_count.get(), wl.stats_b[i].allele_count.get())
-    cells = wl.n_loci * wl.n_samples
+    cells = wl.n_loci * wl.n_real
     res = {"workload": "the call-filter pass of the headline step with trk_call_out.filter_mask8 only (no gt_out, no "
                        "32-bit mask): 13 B per call", "k_call_filter_ms": ms, "bytes_per_cell": 13,
            "achieved_GBs": cells * 13 / (ms * 1e-3) / 1e9, "frac": cells * 13 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -573,9 +579,9 @@ def qc_reduce_extra(wl, no_check, iters=8):
         res = eng.qc_reduce(b, q)
     eng.timer_stop(0)
     ms = eng.timer_ms(0) / iters
-    cells = wl.n_loci * wl.n_samples
+    cells = wl.n_loci * wl.n_real
     out = {"workload": "qcSTR reductions (calls + quality sums per sample and per locus), %d loci x %d samples"
-                       % (wl.n_loci, wl.n_samples), "ms_per_pass": ms, "bytes_per_cell": 8,
+                       % (wl.n_loci, wl.n_real), "ms_per_pass": ms, "bytes_per_cell": 8,
            "achieved_GBs": cells * 8 / (ms * 1e-3) / 1e9, "frac": cells * 8 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if not no_check:
         from oracle import trtools_oracle as orc
@@ -938,7 +944,7 @@ def box_stream_probe(eng, wl):
         box_probe = {"what": "k_stream_probe<3,2>: three 16 B/lane nontemporal input streams, two output streams, "
                              "the call-filter pass's tiling and grid rule, no arithmetic (profiles/r03_notes.md)",
                      "avg_launch_ms": pms,
-                     "achieved": wl.n_loci * wl.n_samples * BYTES_PER_CELL_CALL_FILTER / (pms * 1e-3) / 1e9,
+                     "achieved": wl.n_loci * wl.n_real * BYTES_PER_CELL_CALL_FILTER / (pms * 1e-3) / 1e9,
                      "unit": "GB/s"}
         box_probe["frac"] = box_probe["achieved"] / HBM_PEAK_GBS
         box_probe.update(eng.device_clocks())
@@ -1020,7 +1026,7 @@ def main():
                 assert np.array_equal(np.frombuffer(rows_all[r].tobytes(), dtype=np.uint32)[:nr], gathered[r][:nr]), \
                     "all-gathered filter bits: row of rank %d differs from what that rank computed" % r
     if rank == 0:
-        cells = wl.n_loci * wl.n_samples
+        cells = wl.n_loci * wl.n_real
         ms_step = elapsed / args.steps * 1e3
         loci_s = total_loci * args.steps / elapsed
         kn, kms = prof['k_call_filter']
@@ -1030,7 +1036,7 @@ def main():
         achieved = cells * BYTES_PER_CELL_CALL_FILTER / (avg_cf * 1e-3) / 1e9 if kn else 0.0
         traffic, traffic_src = None, None
         tf = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(tf) and wl.n_loci == 100000 and wl.n_samples == 10000:
+        if os.path.exists(tf) and wl.n_loci == 100000 and wl.n_real == 10000:
             try:
                 pj = json.load(open(tf))
                 traffic = pj.get('k_call_filter_bytes_per_launch')
@@ -1042,17 +1048,20 @@ def main():
         out = {
             "metric": "loci/sec (and genotype-cells/sec) statSTR+dumpSTR, 100k loci x 10k samples",
             "value": loci_s, "unit": "loci/s",
-            "cells_per_sec": loci_s * wl.n_samples,
+            "cells_per_sec": loci_s * wl.n_real,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "i16", "data": "synthetic",
             "config": {"workload": "statSTR (11 stats) + dumpSTR (min-DP/max-DP/min-Q call filters, "
                                    "callrate/HWE/het-low/het-high locus filters) combined, HipSTR-shape, "
                                    "%d loci x %d samples (BASELINE configs[3]), %s" %
-                                   (total_loci, wl.n_samples,
+                                   (total_loci, wl.n_real,
                                     "one GPU" if world == 1 else
                                     ("locus-sharded over %d GPUs, %d loci per GPU" % (world, wl.n_loci))),
-                       "n_loci_total": total_loci, "n_loci_per_gpu": wl.n_loci, "n_samples": wl.n_samples, "ploidy": 2,
+                       "n_loci_total": total_loci, "n_loci_per_gpu": wl.n_loci, "n_samples": wl.n_real, "ploidy": 2,
+                       "row_layout": ("%d samples per device row: %d no-call padding samples so that every row starts "
+                                      "on a 128-byte boundary (trk_batch.n_pad_samples; rates count the %d real samples)"
+                                      % (wl.n_samples, wl.sb.n_pad, wl.n_real)) if wl.sb.n_pad else "dense",
                        "max_alleles": int(np.max(np.diff(wl.sb.tables[0]))),
                        "sharding": ("contiguous locus shards by rank; per step ONE grouped RCCL launch: all-reduce of "
                                     "the packed sample_info / totaldp / loc_info counters + all-gather of the "

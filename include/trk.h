@@ -266,6 +266,15 @@ typedef struct {
 /* [n_cells, ncol] -> [ncol, n_cells] for 4-byte elements (device to device; a helper for callers whose FORMAT
  * planes are produced interleaved).                                                                           */
 int trk_planarize(trk_ctx* ctx, const void* src, void* dst, int64_t n_cells, int32_t ncol);
+/* Rows of row_words 4-byte words -> rows of row_words + pad_words words, the pad filled with `fill` (device to device,
+ * src != dst).  The padding samples of trk_batch.n_pad_samples are appended this way after a dense upload: a diploid
+ * genotype row or a FORMAT plane row is padded to a multiple of 32 samples so that EVERY row of the tensor starts on a
+ * 128-byte boundary -- 10 000 samples are 40 000 bytes, every second row starts in the middle of a cache line and the
+ * call-filter stream runs 3-4 % slower (profiles/r03_notes.md section 10).  fill: 0xffffffff for genotypes (two -1),
+ * 0x80000000 for an int32 plane, a quiet nan (0x7fc00000) for a float32 plane.  The reference has no counterpart (its
+ * rows are numpy arrays built per record, tr_harmonizer.py:1046-1090).                                              */
+int trk_pad_rows(trk_ctx* ctx, const void* src, void* dst, int64_t n_rows, int32_t row_words, int32_t pad_words,
+                 uint32_t fill);
 
 /* Column gather of a genotype tensor (device to device): dst[l, j, :] = src[l, col[j], :] for j < n_dst, a column of
  * no-calls (-1) where col[j] < 0.  src [n_loci, n_src, ploidy] int16, dst [n_loci, n_dst, ploidy] int16, col DEVICE

@@ -107,3 +107,61 @@ def test_association_scan(comp, S, subset):
     assert np.array_equal(a.locus_int, b.locus_int)
     assert np.array_equal(a.allele_count, b.allele_count)
     assert np.allclose(a.locus_f64, b.locus_f64, rtol=1e-11, atol=1e-13, equal_nan=True)
+
+
+def test_pad_rows_entry(comp):
+    """trk_pad_rows: the padding samples are appended on the device (no host copy of the tensor); genotypes get -1,
+    int32 planes the missing value, float32 planes nan, multi-column planes whole padding samples."""
+    eng = comp.eng
+    rng = np.random.default_rng(5)
+    gt = rng.integers(-1, 5, size=(37, 1000, 2)).astype(np.int16)
+    dp = rng.integers(0, 99, size=(37, 1000)).astype(np.int32)
+    q3 = rng.random((37, 1000, 3)).astype(np.float32)
+    for arr, fill in ((gt, -1), (dp, np.iinfo(np.int32).min), (q3, np.nan)):
+        d = eng.pad_samples(eng.upload(arr), 24)
+        got = d.get()
+        d.free()
+        assert got.shape == (37, 1024) + arr.shape[2:]
+        assert np.array_equal(got[:, :1000], arr)
+        pad = got[:, 1000:]
+        assert np.all(np.isnan(pad)) if fill is np.nan else np.all(pad == fill)
+    d = eng.upload(dp)
+    assert eng.pad_samples(d, 0) is d
+    d.free()
+
+
+@pytest.mark.parametrize('S', [1000, 2500])
+def test_rows_on_cache_line_boundaries(comp, S):
+    """From 512 samples on the statSTR / dumpSTR passes pad every row to a multiple of 32 samples (128 bytes;
+    TRK_ROW_ALIGN): same results as the dense layout, bit for bit, and nothing of the padding comes back."""
+    from trtools_amd import _lib as L
+    hb, rng = _host_batch(S, seed=77 + S)
+    assert comp._n_pad(hb, rows=True) == (-S) % 32 and comp._n_pad(hb) == 0
+    dp = rng.integers(0, 60, size=(hb.n_loci, S)).astype(np.int32)
+    q = rng.random((hb.n_loci, S)).astype(np.float32)
+    filters = [dict(op=L.F_LT, plane_a=0, thr=10), dict(op=L.F_GT, plane_a=0, thr=50), dict(op=L.F_LT, plane_a=1, thr=0.3)]
+    spec = dict(min_callrate=0.8, min_hwep=0.01, min_het=0.05, max_het=0.9)
+
+    def both(fn):
+        old = os.environ.get('TRK_ROW_ALIGN')
+        try:
+            os.environ['TRK_ROW_ALIGN'] = '32'
+            a = fn()
+            os.environ['TRK_ROW_ALIGN'] = '4'
+            b = fn()
+        finally:
+            os.environ.pop('TRK_ROW_ALIGN', None)
+            if old is not None:
+                os.environ['TRK_ROW_ALIGN'] = old
+        return a, b
+    (ca, sa, ba, la), (cb, sb, bb, lb) = both(lambda: comp.dumpstr_batch(hb, [dp, q], filters, 0, spec))
+    for name in ('gt_out', 'mask', 'sample_counters', 'totaldp', 'dp_missing'):
+        x, y = getattr(ca, name), getattr(cb, name)
+        assert x.shape == y.shape and np.array_equal(x, y), name
+    assert ca.gt_out.shape[1] == S and ca.sample_counters.shape[1] == S
+    assert np.array_equal(sa.locus_int, sb.locus_int) and np.array_equal(sa.locus_f64, sb.locus_f64, equal_nan=True)
+    assert np.array_equal(ba, bb) and np.array_equal(la, lb)
+    assert np.all(sa.locus_int[0][:, L.LI_N_SAMPLES] == S)
+    a, b = both(lambda: comp.locus_stats(hb))
+    assert np.array_equal(a.locus_int, b.locus_int) and np.array_equal(a.locus_f64, b.locus_f64, equal_nan=True)
+    assert np.array_equal(a.allele_count, b.allele_count)

@@ -155,6 +155,54 @@ __global__ void k_fill(uint32_t* p, size_t n, uint32_t seed, int kind) {
     }
 }
 
+// column-owner tiling, generalised: TPB threads per workgroup, V adjacent 16-byte chunks per thread (a wave covers
+// V KB contiguous per stream and locus), XY = 1: blockIdx.x walks the locus blocks and blockIdx.y the column tiles
+// (workgroups launched together are neighbours in LOCI instead of in columns)
+template <int TPB, int V, int XY>
+__global__ __launch_bounds__(TPB) void k_cfg(Streams s, int L, int S4, int lpb) {
+    extern __shared__ uint32_t dummy[];
+    const int bx = XY ? blockIdx.y : blockIdx.x, by = XY ? blockIdx.x : blockIdx.y;
+    const int c0 = (bx * TPB + threadIdx.x) * V;
+    if (c0 >= S4) return;
+    const int l0 = by * lpb, l1 = min(L, l0 + lpb);
+    for (int l = l0; l < l1; ++l) {
+        u32x4 a[V][3];
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (c0 + v < S4) a[v][k] = __builtin_nontemporal_load(s.in[k] + (size_t)l * S4 + c0 + v);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            if (c0 + v >= S4) break;
+            u32x4 r = {(uint32_t)l, 1u, 2u, 3u};
+            r |= a[v][0] | a[v][1] | a[v][2];
+            __builtin_nontemporal_store(r, s.out[0] + (size_t)l * S4 + c0 + v);
+            __builtin_nontemporal_store(r + 1u, s.out[1] + (size_t)l * S4 + c0 + v);
+        }
+    }
+    if (dummy && lpb < 0) dummy[threadIdx.x] = 0;
+}
+
+// the column-owner walk over rows that are RS4 chunks apart while only C4 chunks of each are used (a padded row
+// stride: the pad is never touched)
+template <int XY>
+__global__ __launch_bounds__(256) void k_cfr(Streams s, int L, int C4, int RS4, int lpb) {
+    extern __shared__ uint32_t dummy[];
+    const int bx = XY ? blockIdx.y : blockIdx.x, by = XY ? blockIdx.x : blockIdx.y;
+    const int c = bx * 256 + threadIdx.x;
+    if (c >= C4) return;
+    const int l0 = by * lpb, l1 = min(L, l0 + lpb);
+    for (int l = l0; l < l1; ++l) {
+        const size_t o = (size_t)l * RS4 + c;
+        u32x4 r = {(uint32_t)l, 1u, 2u, 3u};
+        r |= __builtin_nontemporal_load(s.in[0] + o) | __builtin_nontemporal_load(s.in[1] + o) | __builtin_nontemporal_load(s.in[2] + o);
+        __builtin_nontemporal_store(r, s.out[0] + o);
+        __builtin_nontemporal_store(r + 1u, s.out[1] + o);
+    }
+    if (dummy && lpb < 0) dummy[threadIdx.x] = 0;
+}
+
 // one wave per locus row, 4 waves per workgroup, U chunks in flight per lane
 template <int U, int NIN, int NOUT, bool NT>
 __global__ __launch_bounds__(256) void k_row(Streams s, int L, int S4, uint32_t* sink) {
@@ -200,6 +248,37 @@ __global__ __launch_bounds__(256) void k_flat(Streams s, size_t n, uint32_t* sin
         for (int k = 0; k < NOUT; ++k) st<NT>(s.out[k] + i, r + (uint32_t)k);
     }
     if (NOUT == 0 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[0] = 1;
+}
+
+// flat, PER consecutive 4 KB blocks per workgroup (a thread's chunks are 4 KB apart); ALL: every load first, then
+// every store (one wait), else load/store block by block
+template <int PER, bool ALL>
+__global__ __launch_bounds__(256) void k_flat_adj(Streams s, size_t n) {
+    const size_t i0 = (size_t)blockIdx.x * 256 * PER + threadIdx.x;
+    if (ALL) {
+        u32x4 r[PER];
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            const size_t i = i0 + (size_t)p * 256;
+            r[p] = (u32x4){(uint32_t)i, 1u, 2u, 3u};
+            if (i < n) r[p] |= ld<true>(s.in[0] + i) | ld<true>(s.in[1] + i) | ld<true>(s.in[2] + i);
+        }
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            const size_t i = i0 + (size_t)p * 256;
+            if (i < n) { st<true>(s.out[0] + i, r[p]); st<true>(s.out[1] + i, r[p] + 1u); }
+        }
+    } else {
+#pragma unroll 1
+        for (int p = 0; p < PER; ++p) {
+            const size_t i = i0 + (size_t)p * 256;
+            if (i >= n) break;
+            u32x4 r = {(uint32_t)i, 1u, 2u, 3u};
+            r |= ld<true>(s.in[0] + i) | ld<true>(s.in[1] + i) | ld<true>(s.in[2] + i);
+            st<true>(s.out[0] + i, r);
+            st<true>(s.out[1] + i, r + 1u);
+        }
+    }
 }
 
 struct Result { std::string name; double mn, avg, bytes; };
@@ -300,6 +379,86 @@ int main(int argc, char** argv) {
             printf("%s{\"name\": \"%s\", \"min_ms\": %.4f, \"avg_ms\": %.4f, \"tbps\": %.3f}", i ? ", " : "",
                    results[i].name.c_str(), results[i].mn, results[i].avg, results[i].bytes / results[i].avg * 1e-9);
         printf("]\n");
+        return 0;
+    }
+    if (argc > 4 && !strcmp(argv[4], "stride")) {
+        // S (argv[2]) is the allocation's row length; COLS of each row are used, rows STRIDE samples apart for a list
+        // of strides: which alignment of the row start does the column-owner walk need?
+        const int cols = getenv("COLS") ? atoi(getenv("COLS")) : 10000;
+        const int C4 = cols / 4, gxc = (C4 + 255) / 256;
+        const double bytes = 20.0 * L * cols;
+        const int lpb = lpb_for(5), gy = (L + lpb - 1) / lpb;
+        for (int stride : {10000, 10016, 10048, 10112, 10240, 10496, 10752, 11264, 12288}) {
+            if (stride > S || stride < cols) continue;
+            char nm[160];
+            snprintf(nm, sizeof nm, "stride %5d samples (%6d B, aligned to %4d B): %d loci/block column-major", stride, stride * 4,
+                     (stride * 4) & -(stride * 4), lpb);
+            run(nm, bytes, [&] { hipLaunchKernelGGL((k_cfr<0>), dim3(gxc, gy), dim3(256), 30 * 1024, 0, s, L, C4, stride / 4, lpb); });
+            snprintf(nm, sizeof nm, "stride %5d samples (%6d B, aligned to %4d B): %d loci/block locus-major", stride, stride * 4,
+                     (stride * 4) & -(stride * 4), lpb);
+            run(nm, bytes, [&] { hipLaunchKernelGGL((k_cfr<1>), dim3(gy, gxc), dim3(256), 30 * 1024, 0, s, L, C4, stride / 4, lpb); });
+            const int gy32 = (L + 31) / 32;
+            snprintf(nm, sizeof nm, "stride %5d samples (%6d B, aligned to %4d B): 32 loci/block locus-major", stride, stride * 4,
+                     (stride * 4) & -(stride * 4));
+            run(nm, bytes, [&] { hipLaunchKernelGGL((k_cfr<1>), dim3(gy32, gxc), dim3(256), 30 * 1024, 0, s, L, C4, stride / 4, 32); });
+        }
+        return 0;
+    }
+    if (argc > 4 && !strcmp(argv[4], "short")) {
+        // how short-lived must a workgroup be to stream like the one-chunk-per-thread kernel?  loci per block 1..32 of
+        // the column-owner walk (both launch orders), and flat grid-stride kernels with 2..8 chunks per thread
+        for (int lpb : {1, 2, 3, 4, 8, 16, 32}) {
+            const int gyy = (L + lpb - 1) / lpb;
+            char nm[128];
+            snprintf(nm, sizeof nm, "short: column-owner, %d loci/block, column-major launch", lpb);
+            run(nm, b5, [&] { hipLaunchKernelGGL((k_cfg<256, 1, 0>), dim3(gx, gyy), dim3(256), 0, 0, s, L, S4, lpb); });
+            snprintf(nm, sizeof nm, "short: column-owner, %d loci/block, locus-major launch", lpb);
+            run(nm, b5, [&] { hipLaunchKernelGGL((k_cfg<256, 1, 1>), dim3(gyy, gx), dim3(256), 0, 0, s, L, S4, lpb); });
+        }
+        for (int per : {1, 2, 4, 8, 16}) {
+            const unsigned g = (unsigned)((n + 256ull * per - 1) / (256ull * per));
+            char nm[128];
+            snprintf(nm, sizeof nm, "short: flat grid-stride, %d chunks per thread (grid %u)", per, g);
+            run(nm, b5, [&] { hipLaunchKernelGGL((k_flat<3, 2, true>), dim3(g), dim3(256), 0, 0, s, n, sink); });
+        }
+#define FA(PER, ALL)                                                                                              \
+        {                                                                                                         \
+            const unsigned g = (unsigned)((n + 256ull * PER - 1) / (256ull * PER));                               \
+            char nm[128];                                                                                         \
+            snprintf(nm, sizeof nm, "short: flat, %d adjacent 4 KB blocks per workgroup, %s", PER,                \
+                     ALL ? "all loads then all stores" : "block by block");                                       \
+            run(nm, b5, [&] { hipLaunchKernelGGL((k_flat_adj<PER, ALL>), dim3(g), dim3(256), 0, 0, s, n); });     \
+        }
+        FA(2, false) FA(2, true) FA(4, false) FA(4, true) FA(8, false) FA(16, false)
+#undef FA
+        for (int lpb : {49, 112, 400}) {
+            const int gyy = (L + lpb - 1) / lpb;
+            char nm[128];
+            snprintf(nm, sizeof nm, "short: column-owner, %d loci/block, column-major launch", lpb);
+            run(nm, b5, [&] { hipLaunchKernelGGL((k_cfg<256, 1, 0>), dim3(gx, gyy), dim3(256), 0, 0, s, L, S4, lpb); });
+        }
+        return 0;
+    }
+    if (argc > 4 && !strcmp(argv[4], "tiles")) {
+        // workgroup width / chunks per thread / launch order of the column-owner tiling (5 workgroups' worth of
+        // waves per CU kept by dynamic LDS where the workgroup is 256 threads)
+        const int lpb = lpb_for(5);
+        const size_t lds5 = 30 * 1024;
+#define TL(TPB, V, XY, LDS, LPB)                                                                                  \
+        {                                                                                                         \
+            const int gxx = (S4 + TPB * V - 1) / (TPB * V), gyy = (L + (LPB) - 1) / (LPB);                          \
+            char nm[128];                                                                                         \
+            snprintf(nm, sizeof nm, "tiles: %d threads x %d chunks, %s-major launch, %d loci/block", TPB, V,       \
+                     XY ? "locus" : "column", LPB);                                                                \
+            run(nm, b5, [&] { hipLaunchKernelGGL((k_cfg<TPB, V, XY>), XY ? dim3(gyy, gxx) : dim3(gxx, gyy), dim3(TPB), LDS, 0, s, L, S4, LPB); }); \
+        }
+        TL(256, 1, 0, lds5, lpb) TL(256, 1, 1, lds5, lpb) TL(256, 2, 0, lds5, lpb) TL(256, 2, 1, lds5, lpb)
+        TL(256, 4, 0, lds5, lpb) TL(512, 1, 0, 60 * 1024, lpb) TL(1024, 1, 0, 0, lpb) TL(1024, 1, 1, 0, lpb)
+        TL(128, 1, 0, 15 * 1024, lpb) TL(64, 1, 0, 7 * 1024, lpb) TL(64, 1, 1, 7 * 1024, lpb)
+        TL(256, 1, 0, lds5, 16) TL(256, 1, 1, lds5, 16) TL(256, 2, 1, lds5, 16) TL(64, 1, 1, 7 * 1024, 16)
+        TL(256, 1, 1, lds5, 4) TL(64, 4, 1, 7 * 1024, 8)
+#undef TL
+        run("flat 3in/2out nt, one chunk per thread", b5, [&] { hipLaunchKernelGGL((k_flat<3, 2, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, s, n, sink); });
         return 0;
     }
     if (argc > 4 && !strcmp(argv[4], "sweep")) {

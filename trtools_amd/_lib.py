@@ -137,7 +137,7 @@ EXPORTS = [
     'trk_locus_stats', 'trk_locus_finalize', 'trk_call_filters', 'trk_locus_filters',
     'trk_comm_unique_id', 'trk_comm_init', 'trk_allreduce_sum_i64', 'trk_allgather',
     'trk_binomtest_two_sided', 'trk_binom_pmf', 'trk_binomtest_batch', 'trk_synth_fill', 'trk_synth_fill_gangstr',
-    'trk_assoc_scan', 'trk_assoc_scan_dosage', 'trk_student_t_two_sided', 'trk_dosages', 'trk_qc_reduce', 'trk_planarize', 'trk_permute_columns', 'trk_stream_probe', 'trk_device_clocks', 'trk_stream_select', 'trk_stream_wait',
+    'trk_assoc_scan', 'trk_assoc_scan_dosage', 'trk_student_t_two_sided', 'trk_dosages', 'trk_qc_reduce', 'trk_planarize', 'trk_pad_rows', 'trk_permute_columns', 'trk_stream_probe', 'trk_device_clocks', 'trk_stream_select', 'trk_stream_wait',
     'trk_host_alloc', 'trk_host_free', 'trk_memcpy_h2d_async', 'trk_memcpy_d2h_async', 'trk_queue_sync', 'trk_exchange', 'trk_event_record', 'trk_event_wait',
 ]
 
@@ -260,6 +260,7 @@ def load():
     lib.trk_assoc_scan.argtypes = [vp, P(Batch), P(AssocParams), P(AssocOut)]
     lib.trk_assoc_scan_dosage.argtypes = [vp, P(Batch), P(AssocParams), P(AssocDosage), P(AssocOut), vp, vp]
     lib.trk_planarize.argtypes = [vp, vp, vp, i64, C.c_int32]
+    lib.trk_pad_rows.argtypes = [vp, vp, vp, i64, C.c_int32, C.c_int32, C.c_uint32]
     lib.trk_permute_columns.argtypes = [vp, vp, vp, vp, i64, C.c_int32, C.c_int32, C.c_int32]
     lib.trk_stream_probe.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, C.c_int32, P(C.c_float)]
     lib.trk_device_clocks.argtypes = [vp, P(C.c_int32), P(C.c_int32), P(C.c_int32)]

@@ -54,11 +54,18 @@ class DeviceCompute:
         self.eng.host_buffer_release(arr)
 
     @staticmethod
-    def _n_pad(hb):
-        """Samples to append so that a diploid row is a multiple of four samples = 16-byte aligned: the streaming
-        kernels need that (a cohort of 10001 samples otherwise runs the per-call kernels, 4-6x slower)."""
+    def _n_pad(hb, rows=False):
+        """Padding samples appended to every row (trk_batch.n_pad_samples): to a multiple of 4 so that the diploid
+        rows are whole 16-byte chunks; ``rows`` (the statSTR / dumpSTR passes): to a multiple of TRK_ROW_ALIGN
+        samples (default 32 = 128 bytes) from 512 samples on, so that every row of the tensor and of the FORMAT
+        planes starts on a cache-line boundary (include/trk.h, trk_pad_rows: 3-4 % of the call-filter pass)."""
         S = hb.gt.shape[1]
-        return (-S) % 4 if (hb.gt.shape[2] == 2 and S > 0 and os.environ.get('TRK_PAD_SAMPLES', '1') != '0') else 0
+        if not (hb.gt.shape[2] == 2 and S > 0 and os.environ.get('TRK_PAD_SAMPLES', '1') != '0'):
+            return 0
+        align = 4
+        if rows and S >= 512:
+            align = max(4, int(os.environ.get('TRK_ROW_ALIGN', '32')) & ~3)
+        return (-S) % align
 
     @staticmethod
     def _pad(arr, n_pad, axis, value):
@@ -69,13 +76,13 @@ class DeviceCompute:
         shape[axis] = n_pad
         return np.concatenate([arr, np.full(shape, value, dtype=arr.dtype)], axis=axis)
 
-    def _upload(self, hb, pad=True):
+    def _upload(self, hb, pad=True, rows=False):
         # a per-locus ploidy table only when some locus really is of lower ploidy than the tensor
         # (the kernels' streaming paths need every column to be live)
         lp = hb.locus_ploidy
         if lp is not None and (hb.n_loci == 0 or bool(np.all(np.asarray(lp) == hb.ploidy))):
             lp = None
-        n_pad = self._n_pad(hb) if pad else 0
+        n_pad = self._n_pad(hb, rows) if pad else 0
         gb = hb.group_bits
         # Sample groups: with four or more groups per pass (TRK_CLASS_SORT=1: always, =0: never) the columns are
         # gathered on the device into class order and counted range by range with the ungrouped streaming kernel
@@ -93,7 +100,9 @@ class DeviceCompute:
             return b
         if n_pad and gb is not None:
             gb = self._pad(gb, n_pad, 0, 0)          # padding samples belong to no group
-        return self.eng.make_batch(self._pad(hb.gt, n_pad, 1, -1), hb.allele_off, hb.len_class, hb.str_class,
+        # (the padding columns are appended on the device: no host copy of the tensor)
+        gt_d = self.eng.pad_samples(self.eng.upload(hb.gt, np.int16), n_pad)
+        return self.eng.make_batch(gt_d, hb.allele_off, hb.len_class, hb.str_class,
                                    hb.len_class_value, locus_ploidy=lp, group_bits=gb,
                                    n_groups=hb.n_groups, max_alleles=hb.max_alleles, n_pad=n_pad)
 
@@ -109,7 +118,7 @@ class DeviceCompute:
                 o.free()
 
     def locus_stats(self, hb, nalleles_thresh=0.01):
-        b = self._upload(hb)
+        b = self._upload(hb, rows=True)
         res = self.eng.locus_stats(b, nalleles_thresh=nalleles_thresh)
         out = StatsHost(res.allele_count.get(), res.locus_int.get(), res.locus_f64.get())
         self._free(b, res.allele_count, res.locus_int, res.locus_f64)
@@ -124,12 +133,10 @@ class DeviceCompute:
         is uint8 then, gt_out None), not the masked genotype tensor and the 32-bit mask."""
         eng = self.eng
         compact = compact and len(filters) <= 7
-        b = self._upload(hb)
-        n_pad, S = self._n_pad(hb), hb.gt.shape[1]
-        if n_pad:   # the padding samples' FORMAT values are missing like their genotypes
-            planes = [self._pad(p, n_pad, 1, np.nan if np.asarray(p).dtype.kind == 'f' else np.iinfo(np.int32).min)
-                      for p in planes]
-        dplanes = [eng.upload_plane(p) for p in planes]
+        b = self._upload(hb, rows=True)
+        S = hb.gt.shape[1]
+        n_pad = b.struct.n_samples - S      # the padding samples' FORMAT values are missing like their genotypes
+        dplanes = [eng.upload_plane(p, n_pad=n_pad) for p in planes]
         # counts of the unfiltered genotypes, corrected by the call-filter kernel for every call it
         # masks (dumpSTR.py:721-774 rebuilds the record; here no second pass over the tensor), then
         # the finaliser

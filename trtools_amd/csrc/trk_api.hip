@@ -814,6 +814,17 @@ int trk_planarize(trk_ctx* ctx, const void* src, void* dst, int64_t n_cells, int
     return TRK_OK;
 }
 
+int trk_pad_rows(trk_ctx* ctx, const void* src, void* dst, int64_t n_rows, int32_t row_words, int32_t pad_words,
+                 uint32_t fill) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (n_rows < 0 || row_words < 0 || pad_words < 0) return fail(ctx, TRK_ERR_ARG, "pad_rows arguments");
+    if (n_rows == 0 || row_words + pad_words == 0) return TRK_OK;
+    if (!src || !dst || src == dst) return fail(ctx, TRK_ERR_ARG, "pad_rows: NULL or aliased arrays");
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, trk::launch_pad_rows(src, dst, n_rows, row_words, pad_words, fill, ctx->n_cu, ctx->s()));
+    return TRK_OK;
+}
+
 int trk_permute_columns(trk_ctx* ctx, const int16_t* src, int16_t* dst, const int32_t* col, int64_t n_loci,
                         int32_t n_src, int32_t n_dst, int32_t ploidy) {
     if (!ctx) return TRK_ERR_ARG;

@@ -51,6 +51,8 @@ hipError_t launch_assoc_dosage(const trk_batch& b, const trk_assoc_params& prm, 
                                hipStream_t stream);
 hipError_t launch_dosages(const trk_batch& b, const double* allele_len, int type, const float* ap1, const float* ap2,
                           int n_alt_cols, float* out, int32_t* locus_err, hipStream_t stream);
+hipError_t launch_pad_rows(const void* src, void* dst, int64_t n_rows, int row_words, int pad_words, uint32_t fill,
+                           int n_cu, hipStream_t stream);
 hipError_t launch_planarize(const void* src, void* dst, int64_t n_cells, int ncol, hipStream_t stream);
 hipError_t launch_stream_probe(const void* const* in, int n_in, void* const* out, int n_out, int64_t n_loci,
                                int64_t n_samples, int n_cu, hipStream_t stream);

@@ -2453,6 +2453,7 @@ struct V2Args {
     int loci_per_block;
     int delta_nal;        // max_alleles when the delta outputs are requested, else 0
     int dbg;              // TRK_CF_DBG (timing experiments only): 1 no per-sample counter flush, 2 no delta flush
+    int xy;               // 1: launched locus-major (blockIdx.x walks the locus blocks, blockIdx.y the column tiles)
     // per-workgroup partial sample counters (plain coalesced stores, summed by k_cf_reduce) instead of one
     // device-scope atomic per counter, sample and workgroup; nullptr: atomics
     uint16_t* part16;     // [gridDim.y][2 + NF][S]: numcalls, dp-missing, filter k
@@ -2470,7 +2471,9 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
     extern __shared__ uint32_t v2lds[];
     const int tid = threadIdx.x;
     const int S = a.b.n_samples, L = a.b.n_loci;
-    const int64_t s0 = ((int64_t)blockIdx.x * CF_THREADS + tid) * CF_V;
+    const int bix = a.xy ? blockIdx.y : blockIdx.x, biy = a.xy ? blockIdx.x : blockIdx.y;
+    const int gdy = a.xy ? gridDim.x : gridDim.y;
+    const int64_t s0 = ((int64_t)bix * CF_THREADS + tid) * CF_V;
     const int nal = a.delta_nal;
     const int dstride = nal + V2_EXTRA;
     uint32_t* dtab = v2lds;                                        // [loci][nal + 3]
@@ -2495,7 +2498,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
         bitv[k] = 1u << a.f[k].bit;
     }
     const int n_blocks = (L + a.loci_per_block - 1) / a.loci_per_block;
-    for (int by = blockIdx.y; by < n_blocks; by += gridDim.y) {
+    for (int by = biy; by < n_blocks; by += gdy) {
     const int l_begin = by * a.loci_per_block;
     const int l_end = min(L, l_begin + a.loci_per_block);
     const int nl = l_end - l_begin;
@@ -2760,7 +2763,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
         // this workgroup's counters of its 4 samples: one 8-byte store per counter row, 32 bytes of depth sums
         typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
         typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-        u16x4* p16 = reinterpret_cast<u16x4*>(a.part16 + ((size_t)blockIdx.y * (2 + NF)) * S + s0);
+        u16x4* p16 = reinterpret_cast<u16x4*>(a.part16 + ((size_t)biy * (2 + NF)) * S + s0);
         const size_t rs = (size_t)S / 4;   // row stride in u16x4
         p16[0] = (u16x4){(unsigned short)numcalls[0], (unsigned short)numcalls[1], (unsigned short)numcalls[2],
                          (unsigned short)numcalls[3]};
@@ -2770,7 +2773,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
         for (int k = 0; k < NF; ++k)
             p16[(2 + k) * rs] = (u16x4){(unsigned short)fc[k][0], (unsigned short)fc[k][1], (unsigned short)fc[k][2],
                                         (unsigned short)fc[k][3]};
-        u64x2* p64 = reinterpret_cast<u64x2*>(a.part64 + (size_t)blockIdx.y * S + s0);
+        u64x2* p64 = reinterpret_cast<u64x2*>(a.part64 + (size_t)biy * S + s0);
         p64[0] = (u64x2){(unsigned long long)totaldp[0], (unsigned long long)totaldp[1]};
         p64[1] = (u64x2){(unsigned long long)totaldp[2], (unsigned long long)totaldp[3]};
     } else if (s0 < S && !(a.dbg & 1)) {
@@ -3481,6 +3484,18 @@ __global__ __launch_bounds__(256) void k_planarize(const uint32_t* __restrict__ 
         for (int k = 0; k < ncol; ++k) dst[(int64_t)k * n_cells + c] = src[c * ncol + k];
 }
 
+// rows of row_words 4-byte words -> rows of row_words + pad_words, the pad filled with `fill` (trk_pad_rows)
+__global__ __launch_bounds__(256) void k_pad_rows(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                 int64_t n_rows, int row_words, int pad_words, uint32_t fill) {
+    const int drow = row_words + pad_words;
+    const int64_t n = n_rows * drow, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / drow;
+        const int c = (int)(i - r * drow);
+        dst[i] = c < row_words ? src[r * row_words + c] : fill;
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -4073,7 +4088,8 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
                     v.part64 = reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + b16);
                 }
             }
-            dim3 grid(gx, gy), block(CF_THREADS);
+            v.xy = getenv("TRK_CF_XY") ? atoi(getenv("TRK_CF_XY")) : 0;
+            dim3 grid(v.xy ? gy : gx, v.xy ? gx : gy), block(CF_THREADS);
             hipLaunchKernelGGL(kv2, grid, block, lds2, stream, v);
             if (v.part16) {
                 hipError_t e1 = hipGetLastError();
@@ -4400,6 +4416,16 @@ hipError_t launch_stream_probe(const void* const* in, int n_in, void* const* out
     if (lpb2 >= 1 && lpb2 < lpb) lpb = lpb2;
     const int gy = (L + lpb - 1) / lpb;
     hipLaunchKernelGGL((k_stream_probe<3, 2>), dim3(gx, gy), dim3(256), 30 * 1024, stream, a, L, S4, lpb);
+    return hipGetLastError();
+}
+
+hipError_t launch_pad_rows(const void* src, void* dst, int64_t n_rows, int row_words, int pad_words, uint32_t fill,
+                           int n_cu, hipStream_t stream) {
+    const int64_t n = n_rows * ((int64_t)row_words + pad_words);
+    const int64_t want = (n + 255) / 256;
+    const unsigned grid = (unsigned)(want < (int64_t)n_cu * 32 ? want : (int64_t)n_cu * 32);
+    hipLaunchKernelGGL(k_pad_rows, dim3(grid ? grid : 1), dim3(256), 0, stream, static_cast<const uint32_t*>(src),
+                       static_cast<uint32_t*>(dst), n_rows, row_words, pad_words, fill);
     return hipGetLastError();
 }
 

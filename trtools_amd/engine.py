@@ -528,15 +528,16 @@ class Engine:
         """The selected queue waits for the mark last recorded under ``slot`` (trk_event_wait)."""
         self._chk(self.lib.trk_event_wait(self.ctx, int(slot)))
 
-    def upload_plane(self, arr):
-        """Upload a FORMAT plane [L, S] or [L, S, k] (int32 / float32) as it is.  Planes of up to four columns stay
+    def upload_plane(self, arr, n_pad=0):
+        """Upload a FORMAT plane [L, S] or [L, S, k] (int32 / float32) as it is (n_pad: padding samples of missing
+        values appended on the device, pad_samples).  Planes of up to four columns stay
         interleaved, as cyvcf2 hands them: the call-filter kernel fetches a thread's k 16-byte chunks and picks the
         columns out of its registers (5.45 against 3.8 ms on the GangSTR nine-filter set at 50k x 5k), which is
         cheaper than transposing them first (the transposition moves every byte twice: 5.5 ms for the same planes).
         Wider planes are made planar on the device ([k, L, S], TRK_DT_PLANAR: every column streams as 16-byte
         vectors; a host transpose of a 160 MB plane costs ~0.3 s).  TRK_CF_PLANARIZE=1 / 0 forces either."""
         arr = np.asarray(arr)
-        d = self.upload(np.ascontiguousarray(arr))
+        d = self.pad_samples(self.upload(np.ascontiguousarray(arr)), n_pad)
         if arr.ndim == 3 and arr.shape[2] > 1:
             force = os.environ.get('TRK_CF_PLANARIZE')
             if force == '1' or (force is None and arr.shape[2] > 4):
@@ -544,6 +545,23 @@ class Engine:
                 d.free()
                 return p
         return d
+
+    PAD_FILL = {'i2': 0xffffffff, 'i4': 0x80000000, 'f4': 0x7fc00000}    # -1 genotypes / missing int32 / nan
+
+    def pad_samples(self, d, n_pad):
+        """Device [L, S, ...] (int16 pairs, int32 or float32) -> new device array [L, S + n_pad, ...] whose padding
+        columns are missing values (trk_pad_rows); ``d`` is freed.  n_pad == 0: ``d`` itself."""
+        if not n_pad:
+            return d
+        Lc, S = d.shape[0], d.shape[1]
+        inner = int(np.prod(d.shape[2:], dtype=np.int64)) * d.dtype.itemsize
+        if inner % 4:
+            raise ValueError("pad_samples: %d bytes per sample" % inner)
+        out = self.empty((Lc, S + n_pad) + tuple(d.shape[2:]), d.dtype)
+        fill = self.PAD_FILL[d.dtype.str[1:]]
+        self._chk(self.lib.trk_pad_rows(self.ctx, d.ptr, out.ptr, Lc, S * inner // 4, n_pad * inner // 4, fill))
+        d.free()
+        return out
 
     def planarize(self, plane):
         """Device [L, S, k] -> new device array [k, L, S] marked planar (trk_planarize)."""

@@ -376,6 +376,7 @@ class SynthBatch:
                  pure_repeats=False):
         self.eng = eng
         self.n_loci, self.n_samples, self.seed = n_loci, n_samples, seed
+        self.n_pad, self.n_dev = 0, n_samples
         self.locus_base = locus_base
         self.loci = loci if loci is not None else make_loci(n_loci, n_samples, seed,
                                                             pure_repeats=pure_repeats)
@@ -394,9 +395,41 @@ class SynthBatch:
         self.batch = eng.make_batch(self.dev['gt'], self.d_off, lc, sc, cv,
                                     max_alleles=int(np.max(np.diff(off))) if n_loci else 0)
 
+    def pad_rows(self, align=32):
+        """Append padding samples (no-call genotypes, missing FORMAT values; trk_batch.n_pad_samples) to every plane
+        generated so far so that the rows are a multiple of ``align`` samples -- what compute.DeviceCompute does with
+        a cohort it uploads (trk_pad_rows: every row starts on a 128-byte boundary).  n_samples stays the number of
+        real samples; n_dev is the row length on the device."""
+        n_pad = (-self.n_samples) % align if align else 0
+        if n_pad and not self.n_pad:
+            for k in list(self.dev):
+                self.dev[k] = self.eng.pad_samples(self.dev[k], n_pad)
+            self.n_pad = n_pad
+            self.n_dev = self.n_samples + n_pad
+            off, lc, sc, cv = self.tables
+            old = self.batch
+            self.batch = self.eng.make_batch(self.dev['gt'], self.d_off, lc, sc, cv, n_pad=n_pad,
+                                             max_alleles=int(np.max(np.diff(off))) if self.n_loci else 0)
+            for k, a in old.arrays.items():
+                if k not in ('gt', 'allele_off'):
+                    a.free()
+        return self.n_pad
+
     def host_rows(self, locus_idx):
         """CPU regeneration of selected loci (for spot-check parity at full size)."""
-        return cells_numpy(self.seed, self.loci, locus_idx, self.n_samples, self.locus_base)
+        rows = cells_numpy(self.seed, self.loci, locus_idx, self.n_samples, self.locus_base)
+        return self._pad_host(rows)
+
+    def _pad_host(self, rows):
+        """The padding samples of pad_rows on regenerated host rows (no-call genotypes, missing values)."""
+        if not self.n_pad:
+            return rows
+        out = {}
+        for k, a in rows.items():
+            fill = -1 if a.dtype == np.int16 else (np.nan if a.dtype.kind == 'f' else INT_MISSING)
+            pad = np.full((a.shape[0], self.n_pad) + a.shape[2:], fill, dtype=a.dtype)
+            out[k] = np.concatenate([a, pad], axis=1)
+        return out
 
     def add_gangstr_planes(self):
         """Generate QEXP / REPCN / RC / REPCI on the device for this call set (GangSTR shape)."""
@@ -410,8 +443,9 @@ class SynthBatch:
 
     def host_gangstr_rows(self, locus_idx, base_rows=None):
         h = base_rows if base_rows is not None else self.host_rows(locus_idx)
-        return gangstr_planes_numpy(self.seed, self.loci, locus_idx, self.n_samples, h['gt'], h['dp'],
-                                    self.locus_base)
+        S = self.n_samples
+        return self._pad_host(gangstr_planes_numpy(self.seed, self.loci, locus_idx, S, h['gt'][:, :S], h['dp'][:, :S],
+                                                   self.locus_base))
 
 
 # ---------------------------------------------------------------------------
