@@ -342,7 +342,7 @@ def assoc_extra(wl, seed, no_check, no_cpu, iters=5, group=None, total_loci=None
     scan_ms = ms / max(n, 1)
     cells = n_loci * wl.n_real
     out = {"workload": "associaTR linear-regression scan, %d loci x %d samples x 1 trait (BASELINE configs[4] on %s)"
-                       % (total_loci, n_samples,
+                       % (total_loci, wl.n_real,
                           "one GPU" if world == 1 else "%d GPUs, %d loci per GPU, no exchange step" % (world, n_loci)),
            "n_gpus": world, "loci_per_s": total_loci / wall, "ms_per_pass": wall * 1e3,
            "kernels_ms": {"k_assoc_scan": scan_ms, "k_assoc_finalize": msf / max(nf, 1)},

@@ -1,0 +1,8 @@
+#!/bin/bash
+# per-kernel durations of the associaTR scan (tools/assoc_probe.py) under rocprofv3; usage: assoc_profile.sh "15,31"
+repo=$(cd "$(dirname "$0")/.." && pwd)
+out=$repo/gpurun_out/r03/assoc_prof
+mkdir -p "$out"; cd /tmp; export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d "$out/stats" -o stats -- python "$repo/tools/assoc_probe.py" --vecs "${1:-15,31}" ${2:+$2} > "$out/under_rocprof.log" 2>&1
+db=$(find "$out/stats" -name '*.db' | head -1)
+if [ -n "$db" ]; then ( cd "$repo" && python tools/rocprof_summary.py stats "$db" | head -14 | cut -c1-220 ); else tail -5 "$out/under_rocprof.log"; fi

@@ -78,15 +78,32 @@ struct AssocArgs {
     int kshift;
     int n_cu;
     uint8_t pa[AS_MAXNC], pb[AS_MAXNC];  // Gram entry e = row pa[e] x row pb[e]; row M = ones
+    // MFMA kernel: the missing calls of the regression set, one bit per sample, for k_assoc_gram_miss
+    unsigned long long* missbits;   // [L][nsteps][4]: word (step, j), bit `lane` <-> sample 256 step + 4 lane + j
+    double* vect;                   // [S][16 RT] sample-major copy of the vector block (+ the row of ones, zero rows)
+    int nsteps;
 };
 
 // -------------------------------------------------------------------------------------------
 // Gram matrix of the sample vectors (+ ones) over the regression set: one thread per entry
 // -------------------------------------------------------------------------------------------
+template <bool WIDE>   // WIDE: more entries than the pa / pb tables hold (M > 31): the pair is derived from e
 __global__ __launch_bounds__(256) void k_assoc_gram(AssocArgs a, double* __restrict__ full) {
     const int e = blockIdx.x;
     const int S = a.b.n_samples;
-    const int ra = a.pa[e], rb = a.pb[e];
+    int ra, rb;
+    if (WIDE) {
+        int r = 0, q = e;
+        while (q >= a.M + 1 - r) {
+            q -= a.M + 1 - r;
+            ++r;
+        }
+        ra = r;
+        rb = r + q;
+    } else {
+        ra = a.pa[e];
+        rb = a.pb[e];
+    }
     double acc = 0.0;
     for (int s = threadIdx.x; s < S; s += 256) {
         if (a.sample_in && !a.sample_in[s]) continue;
@@ -853,37 +870,27 @@ template <int RT, bool MASK>
 __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan_mfma(const AssocArgs a) {
     extern __shared__ double lds_d[];
     constexpr int ROWS = 16 * RT;
-    constexpr int NP = RT * (RT + 1) / 2;  // tile pairs of the symmetric Gram matrix
     __shared__ int tile_sh;
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wid = tid >> 6;
     const int S = a.b.n_samples, M = a.M, L = a.b.n_loci;
-    double* Vb = lds_d;                 // [ROWS][MF_SBR]  rows 0..M-1 vectors, row M ones, rest zero
-    double* Gt = Vb + ROWS * MF_SBR;    // [16][MF_SBR]    summed lengths of the 16 loci (0 where not tested)
-    unsigned char* wave_area = reinterpret_cast<unsigned char*>(Gt + 16 * MF_SBR) + (size_t)wid * a.wave_bytes;
-    uint16_t* xs = reinterpret_cast<uint16_t*>(wave_area);  // [MF_SB + 8] missing samples of this step
-    wave_area += (MF_SB + 8) * sizeof(uint16_t);
+    double* Gt2 = lds_d;                // [2][16][MF_SBR]  summed lengths of the 16 loci (0 where not tested), two steps
+    unsigned char* wave_area = reinterpret_cast<unsigned char*>(Gt2 + 2 * 16 * MF_SBR) + (size_t)wid * a.wave_bytes;
     const int K = 1 << a.kshift;
-    const int nsteps = (S + MF_SB - 1) / MF_SB;
-    // staging role of this thread: row vr (+16 per tile), 4 consecutive samples at column vc
-    const int vr = tid >> 6, vc = (tid & 63) * 4;
-    for (int r = tid; r < ROWS; r += AS_THREADS) Vb[r * MF_SBR + MF_SB] = 0.0;
-
-    auto load_v = [&](int step, double (*out)[4]) {
-        const int s = step * MF_SB + vc;
-        uint32_t mk = 0x01010101u;
-        if (MASK && s < S) mk = *reinterpret_cast<const uint32_t*>(a.sample_in + s);
+    const int nsteps = a.nsteps;
+    // B operand of this lane: row (lane & 15) of a tile, the sample behind column 16 wid + 4 ks + lane / 16 of the
+    // step (column j * 64 + c holds sample 4 c + j): straight from the sample-major vector block, 128 contiguous
+    // bytes per sample and tile.  a.vect has nsteps * 256 rows (zero beyond S).
+    const int bj = wid >> 2;
+    const double* vrow = a.vect + (lane & 15);
+    auto load_b = [&](int step, double (*out)[4]) {
 #pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            const int r = vr + 16 * t;
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = ((16 * wid + 4 * ks) & 63) + (lane >> 4);
+            const size_t s = (size_t)step * MF_SB + 4 * c + bj;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool in = s < S && ((mk >> (8 * j)) & 0xffu) != 0;   // S % 4 == 0: all four or none
-                double x = 0.0;
-                if (in) x = r < M ? a.vec[(size_t)r * S + s + j] : (r == M ? 1.0 : 0.0);
-                out[t][j] = x;
-            }
+            for (int t = 0; t < RT; ++t) out[t][ks] = vrow[s * ROWS + 16 * t];
         }
     };
 
@@ -914,11 +921,9 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan_mfma(const AssocArgs 
         const int kslot = lane & (K - 1);
         const u32x4* row = reinterpret_cast<const u32x4*>(a.b.gt + (int64_t)(has ? l : 0) * S * 2);
 
-        d4 C[RT], Gc[NP];
+        d4 C[RT];
 #pragma unroll
         for (int t = 0; t < RT; ++t) C[t] = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int p = 0; p < NP; ++p) Gc[p] = (d4){0.0, 0.0, 0.0, 0.0};
         double sgg = 0.0;
         double a_def[4] = {0.0, 0.0, 0.0, 0.0}, b_def[RT][4];
 #pragma unroll
@@ -929,20 +934,14 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan_mfma(const AssocArgs 
         const u32x4 dead = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
         u32x4 vnext = dead;
         uint32_t mnext = 0x01010101u;
-        double vbn[RT][4];
         if (has && 4 * lane < S) {
             vnext = __builtin_nontemporal_load(&row[lane]);
             if (MASK) mnext = *reinterpret_cast<const uint32_t*>(a.sample_in + 4 * lane);
         }
-        load_v(0, vbn);
 
         for (int step = 0; step < nsteps; ++step) {
             const int s0 = step * MF_SB;
-            // ---- this step's vector block -> LDS; this wave's genotype chunk -> G tile -----------
-#pragma unroll
-            for (int t = 0; t < RT; ++t)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) Vb[(vr + 16 * t) * MF_SBR + j * 64 + (tid & 63)] = vbn[t][j];
+            double* Gt = Gt2 + (step & 1) * 16 * MF_SBR;
             const u32x4 v = vnext;
             const uint32_t mk = mnext;
             const bool live = has && s0 + 4 * lane < S;
@@ -974,7 +973,8 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan_mfma(const AssocArgs 
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) Gt[wid * MF_SBR + j * 64 + lane] = g4[j];
-            // ---- next step's operands into registers (they arrive during the MFMA phase) ---------
+            // ---- next step's genotype chunk and this step's B operands (they arrive during the decode of the
+            //      next step, where they are multiplied) ----------------------------------------------------
             vnext = dead;
             mnext = 0x01010101u;
             if (step + 1 < nsteps) {
@@ -983,48 +983,23 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan_mfma(const AssocArgs 
                     vnext = __builtin_nontemporal_load(&row[(sn >> 2)]);
                     if (MASK) mnext = *reinterpret_cast<const uint32_t*>(a.sample_in + sn);
                 }
-                load_v(step + 1, vbn);
             }
-            // ---- this wave's missing samples of the step, compacted (order: cell, then lane) ------
-            int cnt = 0;
+            load_b(step, b_def);
+            // ---- this wave's missing samples of the step: four ballots, for k_assoc_gram_miss ---------
+            {
+                unsigned long long mine = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool bit = (rare >> j) & 1u;
-                const uint64_t mm = __ballot(bit);
-                if (mm) {
-                    const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32),
-                                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-                    if (bit) xs[pos] = (uint16_t)(j * 64 + lane);
-                    cnt += __popcll(mm);
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned long long mm = __ballot((rare >> j) & 1u);
+                    if (lane == j) mine = mm;
                 }
+                if (has && lane < 4) a.missbits[((size_t)l * nsteps + step) * 4 + lane] = mine;
             }
-            if (lane < 4) xs[cnt + lane] = (uint16_t)MF_SB;  // pad the last batch with the zero column
-            __syncthreads();
-            // ---- operands of this wave's share of the tile product, columns [16 wid, 16 wid + 16):
-            //      into registers now, multiplied during the next step's decode ---------------------
+            __syncthreads();     // the G tile of this step is complete (the other buffer is free: its readers are past
+                                 // the previous barrier)
+            // ---- A operands of this wave's share of the tile product, columns [16 wid, 16 wid + 16) ----
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int col = 16 * wid + 4 * ks + (lane >> 4);
-                a_def[ks] = Gt[(lane & 15) * MF_SBR + col];
-#pragma unroll
-                for (int t = 0; t < RT; ++t) b_def[t][ks] = Vb[(16 * t + (lane & 15)) * MF_SBR + col];
-            }
-            // ---- Gram matrix of this locus's missing samples, four at a time ---------------------
-            for (int b0 = 0; b0 < cnt; b0 += 4) {
-                const int sx = xs[b0 + (lane >> 4)];
-                double z[RT];
-#pragma unroll
-                for (int t = 0; t < RT; ++t) z[t] = Vb[(16 * t + (lane & 15)) * MF_SBR + sx];
-                int p = 0;
-#pragma unroll
-                for (int ti = 0; ti < RT; ++ti)
-#pragma unroll
-                    for (int tj = ti; tj < RT; ++tj) {
-                        Gc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(z[ti], z[tj], Gc[p], 0, 0, 0);
-                        ++p;
-                    }
-            }
-            __syncthreads();
+            for (int ks = 0; ks < 4; ++ks) a_def[ks] = Gt[(lane & 15) * MF_SBR + 16 * wid + 4 * ks + (lane >> 4)];
         }
 
         // ---- end of the row --------------------------------------------------------------------
@@ -1033,7 +1008,8 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan_mfma(const AssocArgs 
 #pragma unroll
             for (int t = 0; t < RT; ++t) C[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_def[ks], b_def[t][ks], C[t], 0, 0, 0);
         double* rec = a.partial + (size_t)(has ? l : 0) * a.NS;
-        double* red = Gt;  // [16 waves][256]
+        __syncthreads();            // every wave has read its last A operands: the G tile buffers become the reduction area
+        double* red = Gt2;  // [16 waves][256]
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
 #pragma unroll
@@ -1043,10 +1019,10 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan_mfma(const AssocArgs 
                 // locus wid = 4*reg + lane/16  ->  reg = wid / 4, lane group wid % 4; vector row 16 t + lane
                 double sum = 0.0;
                 for (int w2 = 0; w2 < AS_WAVES; ++w2) sum += red[w2 * 256 + (16 * (wid & 3) + lane) * 4 + (wid >> 2)];
-                const int vrow = 16 * t + lane;
+                const int vrow_i = 16 * t + lane;
                 if (has) {
-                    if (vrow < M) rec[3 + vrow] = sum;
-                    else if (vrow == M) rec[1] = sum;   // the row of ones: sum g
+                    if (vrow_i < M) rec[3 + vrow_i] = sum;
+                    else if (vrow_i == M) rec[1] = sum;   // the row of ones: sum g
                 }
             }
             __syncthreads();
@@ -1054,18 +1030,6 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan_mfma(const AssocArgs 
         const double sgg_w = wave_sum_f64(sgg);
         if (has) {
             if (lane == 0) rec[2] = sgg_w;
-            int p = 0;
-#pragma unroll
-            for (int ti = 0; ti < RT; ++ti)
-#pragma unroll
-                for (int tj = ti; tj < RT; ++tj) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int ra = 16 * ti + 4 * r + (lane >> 4), rb = 16 * tj + (lane & 15);
-                        if (ra <= rb && rb <= M) rec[3 + M + ra * (M + 1) - ra * (ra - 1) / 2 + (rb - ra)] = Gc[p][r];
-                    }
-                    ++p;
-                }
             for (int bin = lane; bin < A + 3; bin += WAVE) {
                 uint32_t sum = 0;
                 for (int k = 0; k < K; ++k) sum += hist[(bin << a.kshift) + ((k + lane) & (K - 1))];
@@ -1076,6 +1040,163 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan_mfma(const AssocArgs 
         }
         wave_fence();
     }
+}
+
+// -------------------------------------------------------------------------------------------
+// Gram correction of the MFMA scan: sum over the MISSING calls of a locus (regression-set samples whose call is not
+// made) of z z^T, z = the sample's column of [vectors..., 1] -- what the finaliser subtracts from the Gram matrix of
+// the whole regression set.  The scan leaves one bit per sample (AssocArgs.missbits); here one wave per locus walks
+// the bits, gathers the samples' columns from the sample-major copy of the vector block (AssocArgs.vect: a column is
+// 128 contiguous bytes per 16-row tile) four samples at a time, A = B = Z (16 rows x 4 samples) per tile pair, and
+// writes the NC entries of the record.  (Inside the scan's step loop this cost 1.0 ms of 3.1 at M = 15 and 2.3 ms
+// of 5.3 at M = 31, 100k x 10k: the accumulators of the tile pairs pushed the scan into scratch.)
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_assoc_vect(const AssocArgs a, int rows) {
+    const int S = a.b.n_samples, M = a.M;
+    const int64_t n = (int64_t)a.nsteps * MF_SB * rows;      // whole steps: zero columns beyond S
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int s = (int)(i / rows), r = (int)(i - (int64_t)s * rows);
+        a.vect[i] = s >= S ? 0.0 : (r < M ? a.vec[(size_t)r * S + s] : (r == M ? 1.0 : 0.0));
+    }
+}
+
+constexpr int GM_WAVES = 4;     // loci per workgroup
+constexpr int GM_LIST = 1032;   // pending sample indices of one wave: a quarter round (16 words) always fits behind the < 4 left over
+template <int RT> struct GmCfg {
+    static constexpr int GROUP = RT >= 3 ? 4 : 8;   // batches of four samples per software-pipeline stage
+    static constexpr bool TWO = RT == 1;            // a second accumulator set (one tile pair: consecutive products
+};                                                  // would wait for each other)
+template <int RT>
+__global__ __launch_bounds__(WAVE* GM_WAVES) void k_assoc_gram_miss(const AssocArgs a) {
+    extern __shared__ unsigned long long gm_lds[];
+    constexpr int ROWS = 16 * RT;
+    constexpr int NP = RT * (RT + 1) / 2;
+    constexpr int GM_GROUP = GmCfg<RT>::GROUP;
+    constexpr bool TWO = GmCfg<RT>::TWO;
+    const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x >> 6;
+    const int l = blockIdx.x * GM_WAVES + wid;
+    const int M = a.M, nw = a.nsteps * 4;
+    if (l >= a.b.n_loci) return;
+    uint32_t* list = reinterpret_cast<uint32_t*>(gm_lds) + wid * GM_LIST;
+    const unsigned long long* mb = a.missbits + (size_t)l * nw;
+    d4 Gc[NP], Gd[NP];     // two accumulator sets, alternating: consecutive products do not wait for each other
+#pragma unroll
+    for (int p = 0; p < NP; ++p) Gc[p] = Gd[p] = (d4){0.0, 0.0, 0.0, 0.0};
+    const double* zbase = a.vect + (lane & 15);
+    int cnt = 0;
+    // the columns of GM_GROUP batches (four samples each, lane group lane / 16 takes one) starting at entry e0;
+    // entries at or beyond `end` are zero columns
+    auto fetch = [&](double (*z)[RT], int e0, int end) {
+#pragma unroll
+        for (int u = 0; u < GM_GROUP; ++u) {
+            const int e = e0 + 4 * u + (lane >> 4);
+            const bool ok = e < end;
+            const uint32_t sx = ok ? list[e] : 0u;
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+#if defined(TRK_GM_ABL) && TRK_GM_ABL == 1
+                z[u][t] = ok ? (double)sx : 0.0;                       // timing only: no gather
+#else
+                z[u][t] = ok ? zbase[(size_t)sx * ROWS + 16 * t] : 0.0;
+#endif
+            }
+        }
+    };
+    auto multiply = [&](double (*z)[RT]) {
+#pragma unroll
+        for (int u = 0; u < GM_GROUP; ++u) {
+            int p = 0;
+#pragma unroll
+            for (int ti = 0; ti < RT; ++ti)
+#pragma unroll
+                for (int tj = ti; tj < RT; ++tj) {
+#if defined(TRK_GM_ABL) && TRK_GM_ABL == 2
+                    Gc[p][0] += z[u][ti] * z[u][tj];                   // timing only: no matrix instruction
+                    ++p;
+                    continue;
+#endif
+                    if (TWO && (u & 1)) Gd[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(z[u][ti], z[u][tj], Gd[p], 0, 0, 0);
+                    else Gc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(z[u][ti], z[u][tj], Gc[p], 0, 0, 0);
+                    ++p;
+                }
+        }
+    };
+    // consumes the list (all of it when `flush`, else whole batches of four; the rest moves to the front): the
+    // columns of the next GM_GROUP batches are requested while the matrix pipe works on the current ones
+    auto consume = [&](bool flush) {
+        const int end = flush ? cnt : (cnt & ~3);
+        constexpr int STRIDE = 4 * GM_GROUP;
+        double za[GM_GROUP][RT], zb[GM_GROUP][RT];
+        if (end > 0) fetch(za, 0, end);
+        for (int e0 = 0; e0 < end; e0 += 2 * STRIDE) {
+            if (e0 + STRIDE < end) fetch(zb, e0 + STRIDE, end);
+            multiply(za);
+            if (e0 + STRIDE < end) {
+                if (e0 + 2 * STRIDE < end) fetch(za, e0 + 2 * STRIDE, end);
+                multiply(zb);
+            }
+        }
+        wave_fence();
+        if (!flush) {
+            const int rest = cnt - end;
+            uint32_t keep = 0;
+            if (lane < rest) keep = list[end + lane];
+            wave_fence();
+            if (lane < rest) list[lane] = keep;
+            cnt = rest;
+            wave_fence();
+        }
+    };
+    // the set bits of `mm` (this lane's word w = 4 step + j: bit b <-> sample 256 step + 4 b + j) appended to the list
+    auto append = [&](unsigned long long mm, int w) {
+        const int c = __popcll(mm);
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const int t = __shfl_up(incl, o, WAVE);
+            if (lane >= o) incl += t;
+        }
+        const int total = __shfl(incl, WAVE - 1, WAVE);
+        if (total == 0) return;
+        if (cnt + total > GM_LIST) {
+            wave_fence();
+            consume(false);
+        }
+        int pos = cnt + incl - c;
+        const uint32_t base = (uint32_t)(w >> 2) * MF_SB + (uint32_t)(w & 3);
+        while (mm) {
+            const int b = __ffsll((unsigned long long)mm) - 1;
+            mm &= mm - 1;
+            list[pos++] = base + 4u * (uint32_t)b;
+        }
+        cnt += total;
+    };
+    for (int w0 = 0; w0 < nw; w0 += WAVE) {
+        const int w = w0 + lane;
+        const unsigned long long mm = w < nw ? mb[w] : 0ull;
+        if (wave_sum_i32(__popcll(mm)) <= GM_LIST - 4) {
+            append(mm, w);
+        } else {                                  // a round of mostly missing calls: a quarter of the lanes at a time
+            for (int q = 0; q < 4; ++q) append((lane >> 4) == q ? mm : 0ull, w);
+        }
+    }
+    wave_fence();
+    consume(true);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) Gc[p] += Gd[p];
+    double* rec = a.partial + (size_t)l * a.NS;
+    int p = 0;
+#pragma unroll
+    for (int ti = 0; ti < RT; ++ti)
+#pragma unroll
+        for (int tj = ti; tj < RT; ++tj) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ra = 16 * ti + 4 * r + (lane >> 4), rb = 16 * tj + (lane & 15);
+                if (ra <= rb && rb <= M) rec[3 + M + ra * (M + 1) - ra * (ra - 1) / 2 + (rb - ra)] = Gc[p][r];
+            }
+            ++p;
+        }
 }
 
 // -------------------------------------------------------------------------------------------
@@ -2112,10 +2233,10 @@ static AssocPlan assoc_plan(const trk_batch& b, int M) {
     {
         int mfma_min = 5;
         if (const char* e = getenv("TRK_AS_MFMA_MIN")) mfma_min = atoi(e);
-        if (M >= mfma_min && M + 1 <= 32) {
-            p.mfma_rt = M + 1 <= 16 ? 1 : 2;
-            p.wave_bytes = (((MF_SB + 8) * 2 + 15) & ~15) + (((Amax + 3) * (8 + (4 << kshift)) + 15) & ~15);
-            p.lds_bytes = (size_t)(16 * p.mfma_rt + 16) * MF_SBR * 8 + (size_t)AS_WAVES * p.wave_bytes;
+        if (M >= mfma_min && M + 1 <= 64 && !(M > AS_MAXV && getenv("TRK_AS_WIDE_PAIRS"))) {
+            p.mfma_rt = (M + 1 + 15) / 16;      // 16-row tiles of [vectors..., 1]: up to four (62 trait columns + ones)
+            p.wave_bytes = (((Amax + 3) * (8 + (4 << kshift)) + 15) & ~15);
+            p.lds_bytes = (size_t)(2 * 16) * MF_SBR * 8 + (size_t)AS_WAVES * p.wave_bytes;
             p.nchunks = 1;
             p.chunk = 0;
             p.loci_per_wg = 0;
@@ -2177,6 +2298,12 @@ static size_t assoc_ws_one(const trk_batch& b, int M) {
     size_t bytes = 1024 + (size_t)NC * 8;                             // work counters, full Gram
     bytes += (size_t)p.nchunks * b.n_loci * NS * 8;                   // partial records
     bytes += ((size_t)b.n_alleles_total * 4 + 7) & ~(size_t)7;        // class counts
+    if (p.fast && p.mfma_rt) {                                        // missing-call bits, sample-major vector block
+        const size_t nsteps = ((size_t)b.n_samples + MF_SB - 1) / MF_SB;
+        bytes = (bytes + 255) & ~(size_t)255;
+        bytes += (size_t)b.n_loci * nsteps * 4 * 8 + 256;
+        bytes += nsteps * MF_SB * 16 * p.mfma_rt * 8;
+    }
     return bytes + 64;
 }
 
@@ -2261,6 +2388,16 @@ static void assoc_build(const trk_batch& b, const trk_assoc_params& prm, const t
     f.full = full;
     f.allele_count = out.allele_count;
     f.cc = reinterpret_cast<int32_t*>(ws + (size_t)a.NC * 8 + (size_t)p.nchunks * b.n_loci * a.NS * 8);
+    if (p.fast && p.mfma_rt) {
+        a.nsteps = (b.n_samples + MF_SB - 1) / MF_SB;
+        size_t o = (size_t)(reinterpret_cast<unsigned char*>(f.cc) - static_cast<unsigned char*>(workspace)) +
+                   (((size_t)b.n_alleles_total * 4 + 7) & ~(size_t)7);
+        o = (o + 255) & ~(size_t)255;
+        a.missbits = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(workspace) + o);
+        o += (size_t)b.n_loci * a.nsteps * 4 * 8 + 256;
+        o &= ~(size_t)255;
+        a.vect = reinterpret_cast<double*>(static_cast<unsigned char*>(workspace) + o);
+    }
     f.rlen_class = prm.rlen_class;
     f.allele_len = prm.allele_len;
     f.locus_int = out.locus_int;
@@ -2285,13 +2422,17 @@ hipError_t launch_assoc_prepare(const trk_batch& b, const trk_assoc_params& prm,
     if ((err = hipMemsetAsync(a.work_counter, 0, 1024, stream)) != hipSuccess) return err;
     if (b.n_alleles_total > 0) {
         if ((err = hipMemsetAsync(f.cc, 0, (size_t)b.n_alleles_total * 4, stream)) != hipSuccess) return err;
-        if (prm.n_vec > AS_MAXV) return hipSuccess;   // wide design: the pair scans prepare themselves
+        if (prm.n_vec > AS_MAXV && !(p.fast && p.mfma_rt)) return hipSuccess;   // pairs of row groups prepare themselves
         if (!p.fast || p.nchunks > 1)
             if ((err = hipMemsetAsync(out.allele_count, 0, (size_t)b.n_alleles_total * 4, stream)) != hipSuccess)
                 return err;
     }
-    if (prm.n_vec > AS_MAXV) return hipSuccess;
-    hipLaunchKernelGGL(k_assoc_gram, dim3(a.NC), dim3(256), 0, stream, a, full);
+    if (prm.n_vec > AS_MAXV) {
+        if (!(p.fast && p.mfma_rt)) return hipSuccess;
+        hipLaunchKernelGGL(k_assoc_gram<true>, dim3(a.NC), dim3(256), 0, stream, a, full);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_assoc_gram<false>, dim3(a.NC), dim3(256), 0, stream, a, full);
     return hipGetLastError();
 }
 
@@ -2368,8 +2509,11 @@ hipError_t launch_assoc_scan(const trk_batch& b, const trk_assoc_params& prm, co
     AssocArgs a;
     FinArgs f;
     double* full;
-    if (prm.n_vec > AS_MAXV) return b.n_loci ? launch_assoc_scan_wide(b, prm, out, workspace, n_cu, stream) : hipSuccess;
     assoc_build(b, prm, out, workspace, p, a, f, full);
+    // wide designs (32-62 trait columns): three or four 16-row tiles in ONE pass of the MFMA kernel; batches outside
+    // the streaming conditions (and TRK_AS_WIDE_PAIRS=1) go pair of row groups by pair of row groups
+    if (prm.n_vec > AS_MAXV && !(p.fast && p.mfma_rt))
+        return b.n_loci ? launch_assoc_scan_wide(b, prm, out, workspace, n_cu, stream) : hipSuccess;
     a.n_cu = n_cu > 0 ? n_cu : 256;
     if (b.n_loci == 0) return hipSuccess;
     if (p.fast && p.mfma_rt) {
@@ -2382,12 +2526,25 @@ hipError_t launch_assoc_scan(const trk_batch& b, const trk_assoc_params& prm, co
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);                       \
     if (e != hipSuccess) return e;                                                                               \
     hipLaunchKernelGGL((k_assoc_scan_mfma<RT_, MASK_>), dim3(gx), dim3(AS_THREADS), p.lds_bytes, stream, a);
+        hipLaunchKernelGGL(k_assoc_vect, dim3(a.n_cu * 4), dim3(256), 0, stream, a, 16 * p.mfma_rt);
         if (p.mfma_rt == 1) {
             if (a.sample_in) { TRK_MFMA_LAUNCH(1, true) } else { TRK_MFMA_LAUNCH(1, false) }
-        } else {
+        } else if (p.mfma_rt == 2) {
             if (a.sample_in) { TRK_MFMA_LAUNCH(2, true) } else { TRK_MFMA_LAUNCH(2, false) }
+        } else if (p.mfma_rt == 3) {
+            if (a.sample_in) { TRK_MFMA_LAUNCH(3, true) } else { TRK_MFMA_LAUNCH(3, false) }
+        } else {
+            if (a.sample_in) { TRK_MFMA_LAUNCH(4, true) } else { TRK_MFMA_LAUNCH(4, false) }
         }
 #undef TRK_MFMA_LAUNCH
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        // the Gram correction of every locus's missing calls, from the bits the scan left
+        const size_t gm_lds = (size_t)GM_WAVES * GM_LIST * 4;
+        const unsigned gm_grid = (unsigned)((b.n_loci + GM_WAVES - 1) / GM_WAVES);
+        if (p.mfma_rt == 1) hipLaunchKernelGGL(k_assoc_gram_miss<1>, dim3(gm_grid), dim3(WAVE * GM_WAVES), gm_lds, stream, a);
+        else if (p.mfma_rt == 2) hipLaunchKernelGGL(k_assoc_gram_miss<2>, dim3(gm_grid), dim3(WAVE * GM_WAVES), gm_lds, stream, a);
+        else if (p.mfma_rt == 3) hipLaunchKernelGGL(k_assoc_gram_miss<3>, dim3(gm_grid), dim3(WAVE * GM_WAVES), gm_lds, stream, a);
+        else hipLaunchKernelGGL(k_assoc_gram_miss<4>, dim3(gm_grid), dim3(WAVE * GM_WAVES), gm_lds, stream, a);
         return hipGetLastError();
     }
     if (p.fast) {
@@ -2445,7 +2602,7 @@ hipError_t launch_assoc_dosage(const trk_batch& b, const trk_assoc_params& prm, 
             return err;
     }
     if (b.n_loci == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_assoc_gram, dim3(a.NC), dim3(256), 0, stream, a, full);
+    hipLaunchKernelGGL(k_assoc_gram<false>, dim3(a.NC), dim3(256), 0, stream, a, full);
     DosArgs q{dos, class_sums, locus_sums};
     // few alleles everywhere (and diploid, which Beagle output is): the single-pass kernel
     if (b.max_alleles > 0 && b.max_alleles <= DQ_A && b.ploidy == 2 && !b.locus_ploidy && !getenv("TRK_AS_DOSAGE_GENERIC"))
