@@ -400,10 +400,11 @@ int trk_locus_filters(trk_ctx* ctx, int32_t n_loci, const trk_stats_out* stats,
  * The outcome / covariates are the caller's standardised columns (associaTR.py:198-202),
  * row-major by VECTOR: vec[0] = outcome, vec[1..] = covariates, each [S] (entries of
  * samples with sample_in == 0 are ignored).  The intercept is implicit.
- * Up to TRK_ASSOC_MAX_VEC rows are scanned in ONE pass over the genotype tensor; trk_assoc_scan
- * takes up to TRK_ASSOC_MAX_VEC_WIDE rows (associaTR.py:138-204 has no bound: any number of
- * --same-file-covars / .npy columns) by scanning every pair of 15-row groups as a design of its
- * own -- g(g-1)/2 passes for g = ceil(M / 15) groups -- and solving the whole design per locus.
+ * trk_assoc_scan takes up to TRK_ASSOC_MAX_VEC_WIDE rows (associaTR.py:138-204 has no bound: any number of
+ * --same-file-covars / .npy columns), in ONE pass over the genotype tensor for diploid batches whose rows are whole
+ * 16-byte chunks (up to four 16-row tiles of [vectors..., 1] per 16 loci on the matrix pipe); other batches with more
+ * than TRK_ASSOC_MAX_VEC rows are scanned pair of 15-row groups by pair -- g(g-1)/2 passes for g = ceil(M / 15)
+ * groups -- and the whole design solved per locus.  trk_assoc_scan_dosage takes up to TRK_ASSOC_MAX_VEC rows.
  */
 #define TRK_ASSOC_MAX_VEC 31
 #define TRK_ASSOC_MAX_VEC_WIDE 62
