@@ -1062,8 +1062,11 @@ __global__ __launch_bounds__(256) void k_assoc_vect(const AssocArgs a, int rows)
 
 constexpr int GM_WAVES = 4;     // loci per workgroup
 constexpr int GM_LIST = 1032;   // pending sample indices of one wave: a quarter round (16 words) always fits behind the < 4 left over
+#ifndef GM_GROUP_ALL
+#define GM_GROUP_ALL (RT >= 3 ? 4 : 8)
+#endif
 template <int RT> struct GmCfg {
-    static constexpr int GROUP = RT >= 3 ? 4 : 8;   // batches of four samples per software-pipeline stage
+    static constexpr int GROUP = GM_GROUP_ALL;    // batches of four samples per software-pipeline stage
     static constexpr bool TWO = RT == 1;            // a second accumulator set (one tile pair: consecutive products
 };                                                  // would wait for each other)
 template <int RT>
