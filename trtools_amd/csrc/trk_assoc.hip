@@ -2074,38 +2074,61 @@ __global__ __launch_bounds__(WAVE* RW_WAVES) void k_assoc_regress_wave(const Fin
     double* lf = a.locus_f64 + (size_t)l * TRK_AF_COLS;
     if (li[TRK_AI_STATUS] != TRK_AS_OK || li[TRK_AI_RANK] != -1) return;  // filtered, or already regressed
     const int M = a.M, L = a.b.n_loci, P = M + 1;
-    const int ld = P + 1;                       // row stride (odd or even, rows are lane-private)
-    double* A = rw_lds + (size_t)wid * (P + 1) * ld;   // rows 0..P-1 matrix, row P rhs
-    const double* rec0 = a.partial + (size_t)l * a.NS;
+    // rows packed as a lower triangle (row i: columns 0..i at i (i + 1) / 2; row P = the right-hand side): half the LDS
+    // of a square tile -- twice the waves per CU at 63 rows -- and no common row stride (a stride of 64 doubles put
+    // all 64 lanes on one bank)
+    double* A = rw_lds + (size_t)wid * ((P + 1) * (P + 2) / 2);
+#define AT(i, k) A[(i) * ((i) + 1) / 2 + (k)]
     auto psum = [&](int col) {
         double v = 0.0;
         for (int ch = 0; ch < a.nchunks; ++ch) v += a.partial[((size_t)ch * L + l) * a.NS + col];
         return v;
     };
-    (void)rec0;
     auto G = [&](int r, int c) {
         if (r > c) { const int t = r; r = c; c = t; }
         const int e = gidx(r, c, M);
         return a.full[e] - psum(3 + M + e);
     };
-    auto row_of = [&](int j) { return j == 0 ? M : j; };
     const double n_d = (double)li[TRK_AI_N_TESTED];
     const double mean = lf[TRK_AF_COLS - 1], sd = lf[TRK_AF_GT_STD];
     const double sg = psum(1);
     const double sy = G(0, M), yy = G(0, 0);
-    // ---- build: lane i < M row of Z'Z, lane M the genotype row, lane P the right-hand side ------
-    if (lane < M) {
-        for (int j = 0; j <= lane; ++j) A[lane * ld + j] = G(row_of(lane), row_of(j));
-    } else if (lane == M) {
-        for (int j = 0; j < M; ++j) {
-            const double sgc = j == 0 ? sg : psum(3 + j);
-            const double sc = j == 0 ? n_d : G(j, M);
-            A[M * ld + j] = (sgc - mean * sc) / sd;
+    // ---- build.  Tile row i < M: row [ones, covariates 1..M-1][i] of Z'Z; row M the genotype row; row P the
+    //      right-hand side.  The Gram entries (vector rows r <= c, row M = ones -> tile index 0, row 0 = outcome ->
+    //      the right-hand side) are read in record order, 64 consecutive entries per step ------------------------
+    {
+        int r = 0, pos = lane;                 // entry e = lane, lane + 64, ...: row r, column r + pos
+        while (r <= M && pos >= M + 1 - r) {
+            pos -= M + 1 - r;
+            ++r;
         }
-        A[M * ld + M] = n_d;
+        for (int e = lane; e < a.NC; e += WAVE) {
+            const int c = r + pos;
+            const double val = a.full[e] - psum(3 + M + e);
+            const int ic = c == M ? 0 : c;
+            if (r == 0) {
+                if (c != 0) AT(P, ic) = val;   // (0, 0) is y'y
+            } else {
+                const int ir = r == M ? 0 : r;
+                const int hi = ir > ic ? ir : ic, lo = ir > ic ? ic : ir;
+                AT(hi, lo) = val;
+            }
+            pos += WAVE;
+            while (r <= M && pos >= M + 1 - r) {
+                pos -= M + 1 - r;
+                ++r;
+            }
+        }
+    }
+    wave_fence();
+    if (lane < M) {
+        const double sgc = lane == 0 ? sg : psum(3 + lane);
+        const double sc = lane == 0 ? n_d : AT(lane, 0);      // G(lane, M): the ones column of row `lane`
+        AT(M, lane) = (sgc - mean * sc) / sd;
+    } else if (lane == M) {
+        AT(M, M) = n_d;
     } else if (lane == P) {
-        for (int j = 0; j < M; ++j) A[P * ld + j] = j == 0 ? sy : G(0, j);
-        A[P * ld + M] = (psum(3) - mean * sy) / sd;
+        AT(P, M) = (psum(3) - mean * sy) / sd;
     }
     wave_fence();
     // ---- left-looking Cholesky; rows j..P (row P = rhs) are updated for column j ---------------
@@ -2115,19 +2138,19 @@ __global__ __launch_bounds__(WAVE* RW_WAVES) void k_assoc_regress_wave(const Fin
     for (int j = 0; j < P; ++j) {
         double v = 0.0;
         if (lane >= j && lane <= P) {
-            v = A[lane * ld + j];
-            for (int k = 0; k < j; ++k) v -= A[lane * ld + k] * A[j * ld + k];
+            v = AT(lane, j);
+            for (int k = 0; k < j; ++k) v -= AT(lane, k) * AT(j, k);
         }
-        const double ajj = A[j * ld + j];  // still the original diagonal entry
+        const double ajj = AT(j, j);  // still the original diagonal entry
         const double d = __shfl(v, j, WAVE);
         wave_fence();
         if (!(d > 1e-11 * ajj)) {  // column in the span of the previous ones: dropped (pinv semantics)
-            if (lane >= j && lane <= P) A[lane * ld + j] = 0.0;
+            if (lane >= j && lane <= P) AT(lane, j) = 0.0;
             if (j == P - 1) last_dependent = true;
         } else {
             const double ljj = sqrt(d);
-            if (lane == j) A[lane * ld + j] = ljj;
-            else if (lane > j && lane <= P) A[lane * ld + j] = v / ljj;
+            if (lane == j) AT(lane, j) = ljj;
+            else if (lane > j && lane <= P) AT(lane, j) = v / ljj;
             ++rank;
         }
         wave_fence();
@@ -2138,10 +2161,10 @@ __global__ __launch_bounds__(WAVE* RW_WAVES) void k_assoc_regress_wave(const Fin
             li[TRK_AI_STATUS] = TRK_AS_COLLINEAR;
         } else {
             for (int j = 0; j < P; ++j) {
-                const double z = A[P * ld + j];
+                const double z = AT(P, j);
                 zz += z * z;
             }
-            const double lpp = A[M * ld + M], zp = A[P * ld + M];
+            const double lpp = AT(M, M), zp = AT(P, M);
             const double df = n_d - (double)rank;
             const double ssr = yy - zz;
             const double scale = ssr / df;
@@ -2158,6 +2181,7 @@ __global__ __launch_bounds__(WAVE* RW_WAVES) void k_assoc_regress_wave(const Fin
         }
         lf[TRK_AF_COLS - 1] = NAN;
     }
+#undef AT
 }
 
 
@@ -2339,14 +2363,14 @@ static hipError_t launch_scan_t(const AssocArgs& a, const AssocPlan& p, hipStrea
 }
 
 static bool use_wave_regress(int M) {
-    int min_m = 18;  // below, the thread-per-locus solve is faster (M = 16: 1.05 vs 1.12 ms; M = 20: 1.62 vs 1.31 ms)
+    int min_m = 16;  // below, the thread-per-locus solve is faster (round 3: M = 15: 0.64 vs 0.69 ms; M = 16: 1.08 vs 0.71)
     if (const char* e = getenv("TRK_AS_WAVE_REGRESS_MIN")) min_m = atoi(e);
     return M >= min_m && M + 2 <= WAVE;
 }
 
 static hipError_t launch_regress_wave(const FinArgs& f, hipStream_t stream) {
     const int P = f.M + 1;
-    const size_t lds = (size_t)RW_WAVES * (P + 1) * (P + 1) * 8;
+    const size_t lds = (size_t)RW_WAVES * ((P + 1) * (P + 2) / 2) * 8;
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assoc_regress_wave),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) return err;
