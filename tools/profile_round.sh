@@ -24,6 +24,9 @@ run3 qc python "$repo/tools/qc_probe.py" --iters 3
 # statSTR --samples (sample groups): kernel trace only
 rocprofv3 --kernel-trace --stats -d "$out/groups_stats" -o stats -- python "$repo/tools/groups_probe.py" > "$out/groups_under_rocprof.log" 2>&1
 ( cd "$repo" && python tools/rocprof_summary.py stats "$(db groups_stats)" > "$out/${tag}_groups_kernel_stats.csv" )
+# associaTR with 1 ... 62 trait columns (MFMA scan, Gram correction, per-locus solve): kernel trace only
+rocprofv3 --kernel-trace --stats -d "$out/assoc_stats" -o stats -- python "$repo/tools/assoc_wide_probe.py" --m 1 15 31 45 62 > "$out/assoc_under_rocprof.log" 2>&1
+( cd "$repo" && python tools/rocprof_summary.py stats "$(db assoc_stats)" > "$out/${tag}_assoc_kernel_stats.csv" )
 cd "$repo"
 python tools/pmc_traffic.py "$out/${tag}_bench_pmc_fetch_write.csv" "$out/${tag}_configs_pmc_fetch_write.csv" "$tag" > "$out/${tag}_pmc_traffic.json"
 grep -h "^{" "$out/bench_under_rocprof.log" | tail -1 | cut -c1-300
