@@ -205,7 +205,9 @@ int64_t trk_vcf_statstr_rows(const trk_vcf_batch* b, const trk_vcf_harmonized* h
  *                      columns col_a + col_a2 of plane_a (GangSTR QEXP[1] + QEXP[2] as a float32 sum, filters.py:668-
  *                      672; RC[1] + RC[3], filters.py:717-721), kind 3 GangSTR's bad confidence interval: plane_a the
  *                      REPCN columns, plane_b the pre-parsed REPCI (lo, hi per haplotype), the value is REPCN of the
- *                      first haplotype whose interval excludes it (filters.py:744-756)
+ *                      first haplotype whose interval excludes it (filters.py:744-756), kind 4 PopSTR's
+ *                      require-support: plane_a the AD columns (one per allele), col_a the threshold, the value is
+ *                      the read support of the last haplotype whose allele has fewer reads (filters.py:858-867)
  *   format_keys/kinds  the header's FORMAT IDs and how each is decoded (TRK_VCF_COL_INT / _FLOAT / _UCS4); IDs not
  *                      listed decode as strings
  * Returns the bytes written; -(bytes needed) when cap is too small; INT64_MIN for bad arguments; INT64_MIN + 1 when

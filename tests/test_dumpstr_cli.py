@@ -139,6 +139,26 @@ def test_output_vcf_matches_reference_golden_cpu(tmp_path):
     _check_vcf(run_case(tmp_path, OracleCompute(), 'longtr_filters'), 'longtr_filters')
 
 
+def test_popstr_require_support_runs_through_the_batch_pipeline_cpu(tmp_path):
+    """--popstr-require-support (filters.py:835-867; AD is Number=R) no longer sends a PopSTR run to the per-record
+    loop: AD is decoded into a fixed number of columns, the native writer computes the reported read support
+    (trk_vcf_cf_value kind 4).  Logs and VCF equal the reference's goldens; with a narrower AD plane than the
+    records' allele lists the batches fall back to the per-record loop and the outputs stay the same."""
+    from oracle_compute import OracleCompute
+    from trtools_amd.dumpSTR import dumpSTR
+    _check_vcf(run_case(tmp_path, OracleCompute(), 'popstr_filters'), 'popstr_filters')
+    assert dumpSTR.LAST_RUN['path'] == 'batch' and dumpSTR.LAST_RUN['fallback_batches'] == 0
+    old = dumpSTR._Run.AD_COLUMNS
+    dumpSTR._Run.AD_COLUMNS = 2
+    try:
+        sub = tmp_path / 'narrow'
+        sub.mkdir()
+        _check_vcf(run_case(sub, OracleCompute(), 'popstr_filters'), 'popstr_filters')
+        assert dumpSTR.LAST_RUN['fallback_batches'] > 0
+    finally:
+        dumpSTR._Run.AD_COLUMNS = old
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(VCF_GOLD))
 def test_output_vcf_matches_reference_golden_gpu(tmp_path, name):

@@ -2066,6 +2066,21 @@ int64_t trk_vcf_dumpstr_lines(const trk_vcf_batch* b, const trk_vcf_dumpstr* in,
                             }
                         v[(size_t)s] = x;
                     }
+                } else if (fv.kind == 4) {
+                    // PopSTR's require-support (filters.py:858-867): the read support (plane a: AD, one column per
+                    // allele) of the LAST haplotype whose allele has fewer than col_a reads
+                    for (int s = 0; s < S; ++s) {
+                        const int32_t* ad = static_cast<const int32_t*>(fv.plane_a) + ((size_t)l * S + s) * fv.ncol_a;
+                        const int16_t* g = in->gt + ((size_t)l * S + s) * in->ploidy;
+                        double x = NAN;
+                        for (int j = 0; j < in->ploidy; ++j) {
+                            int a = g[j];
+                            if (a < 0) a += fv.ncol_a;
+                            if (a < 0 || a >= fv.ncol_a) continue;
+                            if ((double)ad[a] < (double)fv.col_a) x = (double)ad[a];
+                        }
+                        v[(size_t)s] = x;
+                    }
                 } else {
                     for (int s = 0; s < S; ++s) {
                         const double a = elem(fv.plane_a, fv.dtype_a, fv.ncol_a, fv.col_a, s);

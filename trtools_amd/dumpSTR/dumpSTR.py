@@ -328,7 +328,7 @@ class _Planes:
 def _filter_values(f, planes, hb, l):
     """float64[S]: what the reference writes after '<filter name>_' for a fired call."""
     if isinstance(f, filters.PopSTRCallRequireSupport):
-        ad = planes.get('AD')[l]
+        ad = planes.get('__ad')[l]
         out = np.full(ad.shape[0], np.nan)
         rows = np.arange(ad.shape[0])
         for j in range(int(hb.locus_ploidy[l])):          # last offending haplotype wins
@@ -479,7 +479,9 @@ class _Run:
     # ---- the batch pipeline: no Python object per record -------------------------------------------------------
     _SIMPLE_VALUES = (filters.CallFilterMinValue, filters._HipSTRRatio, filters.HipSTRCallMinSuppReads,
                       filters._GangSTRQexp, filters.GangSTRCallSpanOnly, filters.GangSTRCallSpanBoundOnly,
-                      filters.GangSTRCallBadCI)
+                      filters.GangSTRCallBadCI, filters.PopSTRCallRequireSupport)
+    AD_COLUMNS = 16     # PopSTR's AD (Number=R) is decoded into this many columns; a batch with a record of more
+                        # alleles takes the per-record loop
 
     def batch_path_ok(self, vcftype):
         """The batch pipeline (native reader -> native batch harmoniser -> device -> native record writer) covers
@@ -510,7 +512,7 @@ class _Run:
         # a record lacks the key) and all records must agree on the depth field (DP, else LC: dumpSTR.py:688-695 is
         # judged per record) -- otherwise the per-record loop takes the batch and behaves as the reference does.
         formats = rb.format_columns()
-        real = {'__minsupp': ('ALLREADS', 'GB'), '__rc': ('RC',), '__repci': ('REPCI',)}
+        real = {'__minsupp': ('ALLREADS', 'GB'), '__rc': ('RC',), '__repci': ('REPCI',), '__ad': ('AD',)}
         dp_keys = set()
         for fmt in formats:
             for k in keys:
@@ -524,6 +526,15 @@ class _Run:
             keys.append(dp_key)
         if any(k not in rb.planes for k in keys):
             return False
+        if any(isinstance(f, filters.PopSTRCallRequireSupport) for f in self.call_filters):
+            # filters.py:858-867 indexes AD by the genotype index, negative ones from the END of the record's own
+            # list: the batch's fixed-width plane answers alike where every allele has a column, every record is of
+            # the tensor's ploidy and no call is half missing
+            g = rb.gt
+            if (int(np.max(np.diff(hz.allele_off), initial=0)) > self.AD_COLUMNS or
+                    bool(np.any(np.asarray(rb.locus_ploidy) != g.shape[2])) or
+                    bool(np.any((g < 0).any(axis=2) & (g >= 0).any(axis=2)))):
+                return False
         index = {k: i for i, k in enumerate(keys)}
         arrays = [rb.planes[k] for k in keys]
         specs = [f.spec(index) for f in self.call_filters]
@@ -577,6 +588,8 @@ class _Run:
                 cfv.append((f.name, 2, (rb.planes['__rc'], 1, 3), None))
             elif isinstance(f, filters.GangSTRCallBadCI):
                 cfv.append((f.name, 3, (rb.planes['REPCN'], 0), (rb.planes['__repci'], 0)))
+            elif isinstance(f, filters.PopSTRCallRequireSupport):
+                cfv.append((f.name, 4, (rb.planes['__ad'], int(f.threshold)), None))
             else:
                 key = f.planes()[0][0]
                 cfv.append((f.name, 0, (rb.planes[key], 0), None))
@@ -897,6 +910,9 @@ def main(args):
                 invcf.select_format('RC', vcfnative.KIND_INT, 4, alias='__rc')
             elif key == '__repci':
                 invcf.select_format('REPCI', vcfnative.KIND_INT_RANGES, 4, alias='__repci')
+            elif key == '__ad':      # Number=R: one column per allele, up to AD_COLUMNS of them
+                if 'AD' in format_fields and format_fields['AD']['Type'] == 'Integer':
+                    invcf.select_format('AD', vcfnative.KIND_INT, _Run.AD_COLUMNS, alias='__ad')
             elif key in format_fields and format_fields[key]['Type'] in ('Integer', 'Float') \
                     and format_fields[key]['Number'].isdigit():
                 invcf.select_format(key, ncol=int(format_fields[key]['Number']))

@@ -541,10 +541,12 @@ class PopSTRCallRequireSupport(Reason):
         self.name += str(threshold)
 
     def planes(self):
-        return [_field('AD')]
+        # '__ad': the batch pipeline's fixed-width native decode of AD (Number=R); the per-record loop parses the
+        # record's own list, as wide as its allele list
+        return [('__ad', lambda record: record.format['AD'])]
 
     def spec(self, ix):
-        return dict(op=L.F_AD_SUPPORT_LT, plane_a=ix['AD'], thr=self.threshold)
+        return dict(op=L.F_AD_SUPPORT_LT, plane_a=ix['__ad'], thr=self.threshold)
 
     def value(self, get, l):
         raise NotImplementedError  # needs the genotype indices: handled in dumpSTR.evaluate_call_filters
