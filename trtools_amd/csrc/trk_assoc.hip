@@ -946,7 +946,6 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan_mfma(const AssocArgs 
             const uint32_t mk = mnext;
             const bool live = has && s0 + 4 * lane < S;
             uint32_t rare = 0;
-            double g4[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 // the PREVIOUS step's tile product, from registers: the matrix pipe works while this
@@ -964,15 +963,13 @@ __global__ __launch_bounds__(AS_THREADS) void k_assoc_scan_mfma(const AssocArgs 
                 const bool ok = called & in & live;
                 rare |= (uint32_t)(in & !called & live) << j;
                 g = ok ? g : 0.0;
-                g4[j] = g;
+                Gt[wid * MF_SBR + j * 64 + lane] = g;      // (this step's buffer: its last readers are behind the previous barrier)
                 sgg = __builtin_fma(g, g, sgg);
                 if (live) {
                     atomicAdd(&hist[((ok ? lo : 1u) << a.kshift) + kslot], 1u);
                     atomicAdd(&hist[((ok ? hi : 1u) << a.kshift) + kslot], 1u);
                 }
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) Gt[wid * MF_SBR + j * 64 + lane] = g4[j];
             // ---- next step's genotype chunk and this step's B operands (they arrive during the decode of the
             //      next step, where they are multiplied) ----------------------------------------------------
             vnext = dead;
