@@ -910,30 +910,42 @@ __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v3(
 // ---------------------------------------------------------------------------
 constexpr int V2G_EXTRA = 10;
 
+// (round 3: LDS byte addresses straight from the packed 16-bit bins, as in v2m_cell -- one multiply-add for the class's
+// histogram, one v_mad_u32_u16 per half; the rare rows as predicated adds on precomputed bin addresses.  The first form
+// indexed `hist + cls * cstride + kslot` by words and shifted every bin by kshift: ~30 vector instructions per cell.)
+struct V2gBase {
+    uint32_t hist_b;     // LDS byte address of hist + 4 * kslot
+    uint32_t kbytes;     // bytes from one bin to the next (4 << kshift)
+    uint32_t cstride_b;  // bytes from one class's histogram to the next
+    uint32_t pairs_b;    // byte offset of bin A + 3 (the four sentinel pairs)
+    uint32_t eq_b;       // byte offset of bin A + 7 ('both bins equal'; A + 8 / A + 9: same length / sequence class)
+    uint32_t lut_b;      // LDS byte address of the class LUT
+};
+__device__ __forceinline__ void lds_inc(uint32_t addr_b) {
+    __hip_atomic_fetch_add((lds_u32p)(uintptr_t)addr_b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 template <bool DUP>
-__device__ __forceinline__ void v2g_cell(uint32_t w, uint32_t cls, uint32_t amax2, uint32_t* hist,
-                                         const uint32_t* lut, int kshift, int kslot, int cstride, int A) {
+__device__ __forceinline__ void v2g_cell(uint32_t w, uint32_t cls, uint32_t amax2, const V2gBase& g) {
     u16x2 u = __builtin_bit_cast(u16x2, w) + (u16x2){2, 2};
     u16x2 t2 = __builtin_elementwise_min(u, __builtin_bit_cast(u16x2, amax2));
     const uint32_t t = __builtin_bit_cast(uint32_t, t2);
-    const uint32_t lo = t & 0xffffu, hi = t >> 16;
-    uint32_t* h = hist + cls * cstride + kslot;
-    atomicAdd(&h[lo << kshift], 1u);
-    atomicAdd(&h[hi << kshift], 1u);
-    if ((t & 0xfffefffeu) == 0u) atomicAdd(&h[(A + 3 + (int)(lo + 2u * hi)) << kshift], 1u);
+    const uint32_t base = cls * g.cstride_b + g.hist_b;
+    lds_inc(mad16_lo(t, g.kbytes, base));
+    lds_inc(mad16_hi(t, g.kbytes, base));
+    if ((t & 0xfffefffeu) == 0u)    // both haplotypes sentinels: pair lo + 2 * hi
+        lds_inc(((t | (t >> 15)) & 3u) * g.kbytes + (base + g.pairs_b));
     if (DUP) {
-        const uint32_t x = lut[lo] ^ lut[hi];
-        if ((x & 0xffffu) == 0u) atomicAdd(&h[(A + 8) << kshift], 1u);
-        if ((x >> 16) == 0u) atomicAdd(&h[(A + 9) << kshift], 1u);
-    } else if (lo == hi) {
-        atomicAdd(&h[(A + 7) << kshift], 1u);
+        const uint32_t x = *(lds_cu32p)(uintptr_t)mad16_lo(t, 4u, g.lut_b) ^ *(lds_cu32p)(uintptr_t)mad16_hi(t, 4u, g.lut_b);
+        if ((x & 0xffffu) == 0u) lds_inc(base + g.eq_b + g.kbytes);
+        if (x < 0x10000u) lds_inc(base + g.eq_b + 2u * g.kbytes);
+    } else if ((t & 0xffffu) == (t >> 16)) {
+        lds_inc(base + g.eq_b);
     }
 }
 
 template <bool DUP>
 __device__ __forceinline__ void v2g_row(const u32x4* __restrict__ row, const uint32_t* __restrict__ gbits4,
-                                        int nchunks, int lane, uint32_t amax2, uint32_t* hist, const uint32_t* lut,
-                                        int kshift, int kslot, int cstride, int A, uint32_t cmask) {
+                                        int nchunks, int lane, uint32_t amax2, const V2gBase& g, uint32_t cmask) {
     constexpr int U = 2;
     int c = lane;
     for (; c + (U - 1) * WAVE < nchunks; c += U * WAVE) {
@@ -947,15 +959,13 @@ __device__ __forceinline__ void v2g_row(const u32x4* __restrict__ row, const uin
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                v2g_cell<DUP>(v[u][j], (gb[u] >> (8 * j)) & cmask, amax2, hist, lut, kshift, kslot, cstride, A);
+            for (int j = 0; j < 4; ++j) v2g_cell<DUP>(v[u][j], (gb[u] >> (8 * j)) & cmask, amax2, g);
     }
     for (; c < nchunks; c += WAVE) {
         const u32x4 v = __builtin_nontemporal_load(&row[c]);
         const uint32_t gb = gbits4[c];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            v2g_cell<DUP>(v[j], (gb >> (8 * j)) & cmask, amax2, hist, lut, kshift, kslot, cstride, A);
+        for (int j = 0; j < 4; ++j) v2g_cell<DUP>(v[j], (gb >> (8 * j)) & cmask, amax2, g);
     }
 }
 
@@ -998,10 +1008,17 @@ __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v2g(
     const u32x4* row = reinterpret_cast<const u32x4*>(b.gt) + (((int64_t)l * S) >> 2);
     const uint32_t* gbits4 = reinterpret_cast<const uint32_t*>(b.group_bits);
     const uint32_t amax2 = (uint32_t)(A + 2) * 0x00010001u;
+    V2gBase gb;
+    gb.kbytes = 4u << kshift;
+    gb.hist_b = (uint32_t)(uintptr_t)(lds_u32p)hist + 4u * (uint32_t)kslot;
+    gb.cstride_b = 4u * (uint32_t)cstride;
+    gb.pairs_b = (uint32_t)(A + 3) * gb.kbytes;
+    gb.eq_b = (uint32_t)(A + 7) * gb.kbytes;
+    gb.lut_b = (uint32_t)(uintptr_t)(lds_u32p)lut;
     if (dup)
-        v2g_row<true>(row, gbits4, S >> 2, lane, amax2, hist, lut, kshift, kslot, cstride, A, (uint32_t)ncls - 1u);
+        v2g_row<true>(row, gbits4, S >> 2, lane, amax2, gb, (uint32_t)ncls - 1u);
     else
-        v2g_row<false>(row, gbits4, S >> 2, lane, amax2, hist, lut, kshift, kslot, cstride, A, (uint32_t)ncls - 1u);
+        v2g_row<false>(row, gbits4, S >> 2, lane, amax2, gb, (uint32_t)ncls - 1u);
     wave_lds_fence();
     // fold: per bin the K copies of every class, then per group the classes that contain it.  Group g's total of
     // a bin is parked in copy 0 of class g's bin (only this lane touches the bin's words).
