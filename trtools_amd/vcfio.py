@@ -792,11 +792,19 @@ class VCFWriter:
         self.path = path
         self._tmpl = template
         self._wrote_header = False
+        self._pool = None        # one background thread for write_bytes (TRK_ASYNC_WRITE=0: none)
+        self._pending = None
         if path.endswith('.gz'):
             from .bgzf import BgzfWriter
             self._fh = BgzfWriter(path)      # --zip output is real bgzip (dumpSTR.py:1241-1245)
         else:
             self._fh = open(path, 'w')
+
+    def _drain(self):
+        """Wait for the block the writer thread holds (order of the output; its exception, if any, is raised here)."""
+        f, self._pending = self._pending, None
+        if f is not None:
+            f.result()
 
     def _header(self):
         t = self._tmpl
@@ -810,29 +818,47 @@ class VCFWriter:
         self._wrote_header = True
 
     def write_record(self, variant):
+        self._drain()
         if not self._wrote_header:
             self._header()
         self._fh.write(str(variant))
 
     def write_text(self, text):
         """Already formatted record lines (merged shards of a multi-process run)."""
+        self._drain()
         if not self._wrote_header:
             self._header()
         self._fh.write(text)
 
     def write_bytes(self, data):
         """Already formatted record lines as bytes / a memoryview (the batch record writer): no decode - encode
-        round trip through the text layer."""
+        round trip through the text layer.  The block is written (and, for --zip, compressed) by a background thread
+        while the caller goes on to its next batch; at most one block is in flight, so the order of the output and the
+        memory held are those of the synchronous writer."""
+        self._drain()
         if not self._wrote_header:
             self._header()
         raw = getattr(self._fh, 'buffer', None)
         if raw is not None:                      # text file: flush what the text layer holds, then the raw bytes
             self._fh.flush()
-            raw.write(data)
+            job = lambda: raw.write(data)
         else:
-            self._fh.write(bytes(data))          # BgzfWriter takes bytes
+            job = lambda: self._fh.write(bytes(data))          # BgzfWriter takes bytes
+        if os.environ.get('TRK_ASYNC_WRITE', '1') == '0':
+            job()
+            return
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(1)
+        self._pending = self._pool.submit(job)
 
     def close(self):
+        try:
+            self._drain()
+        finally:
+            if self._pool is not None:
+                self._pool.shutdown(wait=True)
+                self._pool = None
         if not self._wrote_header:
             self._header()
         self._fh.close()
