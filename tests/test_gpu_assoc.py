@@ -151,9 +151,19 @@ def test_mfma_path_many_covariates(eng):
     assert run_case(eng, 25, 20, 516, M=20, cutoff=0.0, miss=0.5) > 3      # half the calls missing
 
 
+def test_gram_correction_of_mostly_missing_loci_on_long_rows(eng):
+    """k_assoc_gram_miss: a round of 64 bit words covers 4096 samples; with 90 % of the calls missing it holds more
+    sample indices than the wave's list (1032), so the round is taken a quarter of the lanes at a time and the list is
+    consumed in between -- on rows of 8192 samples, one to three 16-row tiles, against the oracle."""
+    assert run_case(eng, 61, 24, 8192, M=6, miss=0.9) > 10
+    assert run_case(eng, 62, 20, 8192, M=20, subset=True, miss=0.85) > 8
+    assert run_case(eng, 63, 18, 4100, M=36, miss=0.8) > 8                   # (S not a multiple of 256 either)
+
+
 def test_wide_designs_pairs_of_row_groups(eng):
-    """More than 31 trait columns (the reference has no bound, associaTR.py:138-204): pairs of 15-row groups
-    through the same scan kernels, the whole design solved by a wave per locus.  Up to 62 rows."""
+    """More than 31 trait columns (the reference has no bound, associaTR.py:138-204): ONE pass of three or four
+    16-row tiles for diploid batches whose rows are whole 16-byte chunks (round 3), pairs of 15-row groups through
+    the same scan kernels otherwise; the whole design solved by a wave per locus.  Up to 62 rows."""
     assert run_case(eng, 41, 50, 1024, M=32, subset=True) > 20               # groups of 15, 15, 2
     assert run_case(eng, 42, 37, 772, M=45, subset=True, miss=0.1) > 15      # three full groups; loci % 16, S % 256
     assert run_case(eng, 43, 40, 1280, M=62, cutoff=0.0, miss=0.3) > 15      # five groups, ten pairs, 64 lanes
