@@ -203,6 +203,33 @@ __global__ __launch_bounds__(256) void k_cfr(Streams s, int L, int C4, int RS4, 
     if (dummy && lpb < 0) dummy[threadIdx.x] = 0;
 }
 
+// the column-owner walk with the STORES' cache policy spelled out (loads: nontemporal as in the product).
+// POL 0: nt (the product's), 1: plain, 2: sc1, 3: sc0 sc1, 4: nt sc1, 5: nt sc0 sc1
+template <int POL>
+__device__ __forceinline__ void st_pol(u32x4* p, u32x4 v) {
+    if (POL == 0) __builtin_nontemporal_store(v, p);
+    else if (POL == 1) *p = v;
+    else if (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else if (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else if (POL == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+template <int POL>
+__global__ __launch_bounds__(256) void k_cfp(Streams s, int L, int S4, int lpb) {
+    extern __shared__ uint32_t dummy[];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= S4) return;
+    const int l0 = blockIdx.y * lpb, l1 = min(L, l0 + lpb);
+    for (int l = l0; l < l1; ++l) {
+        const size_t o = (size_t)l * S4 + c;
+        u32x4 r = {(uint32_t)l, 1u, 2u, 3u};
+        r |= __builtin_nontemporal_load(s.in[0] + o) | __builtin_nontemporal_load(s.in[1] + o) | __builtin_nontemporal_load(s.in[2] + o);
+        st_pol<POL>(s.out[0] + o, r);
+        st_pol<POL>(s.out[1] + o, r + 1u);
+    }
+    if (dummy && lpb < 0) dummy[threadIdx.x] = 0;
+}
+
 // one wave per locus row, 4 waves per workgroup, U chunks in flight per lane
 template <int U, int NIN, int NOUT, bool NT>
 __global__ __launch_bounds__(256) void k_row(Streams s, int L, int S4, uint32_t* sink) {
@@ -379,6 +406,17 @@ int main(int argc, char** argv) {
             printf("%s{\"name\": \"%s\", \"min_ms\": %.4f, \"avg_ms\": %.4f, \"tbps\": %.3f}", i ? ", " : "",
                    results[i].name.c_str(), results[i].mn, results[i].avg, results[i].bytes / results[i].avg * 1e-9);
         printf("]\n");
+        return 0;
+    }
+    if (argc > 4 && !strcmp(argv[4], "policy")) {
+        // cache policy of the two output streams (the guide: plain / sc0 / nt stores KEEP the line in the XCD's L2,
+        // sc1 / sc0 sc1 DROP it): does writing through help a stream that never reads its output again?
+        const int lpb = lpb_for(5), gy = (L + lpb - 1) / lpb;
+        for (int round = 0; round < 2; ++round) {
+#define PL(P, NAME) run("policy: stores " NAME, b5, [&] { hipLaunchKernelGGL((k_cfp<P>), dim3(gx, gy), dim3(256), 30 * 1024, 0, s, L, S4, lpb); });
+            PL(0, "nt (product)") PL(1, "plain") PL(2, "sc1") PL(3, "sc0 sc1") PL(4, "sc1 nt") PL(5, "sc0 sc1 nt")
+#undef PL
+        }
         return 0;
     }
     if (argc > 4 && !strcmp(argv[4], "stride")) {
