@@ -214,7 +214,7 @@ __device__ __forceinline__ void st_pol(u32x4* p, u32x4 v) {
     else if (POL == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
     else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
-template <int POL>
+template <int POL, bool LNT = true>
 __global__ __launch_bounds__(256) void k_cfp(Streams s, int L, int S4, int lpb) {
     extern __shared__ uint32_t dummy[];
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_cfp(Streams s, int L, int S4, int lpb) 
     for (int l = l0; l < l1; ++l) {
         const size_t o = (size_t)l * S4 + c;
         u32x4 r = {(uint32_t)l, 1u, 2u, 3u};
-        r |= __builtin_nontemporal_load(s.in[0] + o) | __builtin_nontemporal_load(s.in[1] + o) | __builtin_nontemporal_load(s.in[2] + o);
+        r |= ld<LNT>(s.in[0] + o) | ld<LNT>(s.in[1] + o) | ld<LNT>(s.in[2] + o);
         st_pol<POL>(s.out[0] + o, r);
         st_pol<POL>(s.out[1] + o, r + 1u);
     }
@@ -416,6 +416,7 @@ int main(int argc, char** argv) {
 #define PL(P, NAME) run("policy: stores " NAME, b5, [&] { hipLaunchKernelGGL((k_cfp<P>), dim3(gx, gy), dim3(256), 30 * 1024, 0, s, L, S4, lpb); });
             PL(0, "nt (product)") PL(1, "plain") PL(2, "sc1") PL(3, "sc0 sc1") PL(4, "sc1 nt") PL(5, "sc0 sc1 nt")
 #undef PL
+            run("policy: loads plain, stores nt", b5, [&] { hipLaunchKernelGGL((k_cfp<0, false>), dim3(gx, gy), dim3(256), 30 * 1024, 0, s, L, S4, lpb); });
         }
         return 0;
     }
