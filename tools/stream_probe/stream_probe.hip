@@ -350,8 +350,13 @@ int main(int argc, char** argv) {
     Streams s;
     void* buf[5];
     for (int k = 0; k < 5; ++k) {
-        CK(hipMalloc(&buf[k], plane));
-        CK(hipMemset(buf[k], k + 1, plane));
+        // SKEW=<bytes>: stream k starts k * SKEW bytes into its allocation (do the five streams, walked at the same
+        // offset, meet on the same channels?)
+        const size_t skew = getenv("SKEW") ? (size_t)atoll(getenv("SKEW")) * k : 0;
+        CK(hipMalloc(&buf[k], plane + skew + 256));
+        CK(hipMemset(buf[k], k + 1, plane + skew));
+        buf[k] = (char*)buf[k] + skew;
+        if (k == 0 && getenv("SKEW")) printf("# SKEW %s bytes per stream\n", getenv("SKEW"));
     }
     for (int k = 0; k < 3; ++k) s.in[k] = (const u32x4*)buf[k];
     s.out[0] = (u32x4*)buf[3];
@@ -406,6 +411,29 @@ int main(int argc, char** argv) {
             printf("%s{\"name\": \"%s\", \"min_ms\": %.4f, \"avg_ms\": %.4f, \"tbps\": %.3f}", i ? ", " : "",
                    results[i].name.c_str(), results[i].mn, results[i].avg, results[i].bytes / results[i].avg * 1e-9);
         printf("]\n");
+        return 0;
+    }
+    if (argc > 4 && !strcmp(argv[4], "arena")) {
+        // ONE allocation holding the five streams, stream k at k * (plane rounded up to 2 MB + skew): is the relative
+        // placement of the streams (which channels the same offset of each stream falls on) worth anything, and is it
+        // reproducible from run to run?  (Separately allocated planes: 3.22 ... 3.83 ms from process to process.)
+        const size_t slot = (plane + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        const size_t max_skew = (size_t)48 << 20;
+        char* arena;
+        CK(hipMalloc(&arena, 5 * (slot + max_skew) + 4096));
+        CK(hipMemset(arena, 1, 5 * (slot + max_skew)));
+        const int lpb = lpb_for(5), gy = (L + lpb - 1) / lpb;
+        const size_t skews[] = {0, 256, 4096, 65536, 131072, 262144, 524288, 1048576, 1064960, 1310720, 2097152, 3145728,
+                                4194304, 5242880, 8388608, 12582912, 16777216, 25165824, 33554432, 0};
+        for (size_t sk : skews) {
+            Streams a;
+            for (int k = 0; k < 3; ++k) a.in[k] = (const u32x4*)(arena + k * (slot + sk));
+            a.out[0] = (u32x4*)(arena + 3 * (slot + sk));
+            a.out[1] = (u32x4*)(arena + 4 * (slot + sk));
+            char nm[128];
+            snprintf(nm, sizeof nm, "arena: streams %zu MB + %zu bytes apart", slot >> 20, sk);
+            run(nm, b5, [&] { hipLaunchKernelGGL((k_cfp<0>), dim3(gx, gy), dim3(256), 30 * 1024, 0, a, L, S4, lpb); });
+        }
         return 0;
     }
     if (argc > 4 && !strcmp(argv[4], "policy")) {
