@@ -608,6 +608,15 @@ def config1_extra(eng, no_check, iters=50):
     Lc, S = 10000, 1000
     sb = SynthBatch(eng, Lc, S, seed=20260928 + 1, planes=())
     res = eng.alloc_stats(sb.batch)
+    # the pass as a command line runs it (no event brackets between its launches) ...
+    for it in range(iters + 3):
+        if it == 3:
+            eng.sync()
+            t0 = time.perf_counter()
+        eng.locus_stats(sb.batch, out=res)
+    eng.sync()
+    w = (time.perf_counter() - t0) / iters
+    # ... and once more with HIP events around each launch for the per-kernel figures (the brackets cost a few us)
     eng.profile(True)
     for it in range(iters + 3):
         if it == 3:
@@ -616,21 +625,26 @@ def config1_extra(eng, no_check, iters=50):
             t0 = time.perf_counter()
         eng.locus_stats(sb.batch, out=res)
     eng.sync()
-    w = (time.perf_counter() - t0) / iters
+    w_prof = (time.perf_counter() - t0) / iters
     pg = eng.profile_get()
     eng.profile(False)
     cnt_ms = pg['k_locus_count'][1] / pg['k_locus_count'][0]
     fin_ms = pg['k_locus_finalize'][1] / pg['k_locus_finalize'][0]
+    fused = os.environ.get('TRK_FUSED_STATS') != '0'
     out = {"workload": "statSTR full statistics, HipSTR shape, %d loci x %d samples (BASELINE configs[1])" % (Lc, S),
            "ms_per_pass": w * 1e3, "loci_per_s": Lc / w, "calls_per_s": Lc * S / w,
-           "kernels_ms": {"k_locus_count": cnt_ms, "k_locus_finalize+k_hwe_test": fin_ms},
+           "ms_per_pass_with_event_brackets": w_prof * 1e3,
+           "launches_per_pass": ("2: k_locus_count_v3<4,4,true> (count + finaliser), k_hwe_test_slots" if fused else
+                                 "5: count, counter reset, finaliser, HWE tests, HWE serial remainder"),
+           "kernels_ms": ({"k_locus_count_v3<fin>": cnt_ms, "k_hwe_test_slots": fin_ms} if fused else
+                          {"k_locus_count": cnt_ms, "k_locus_finalize+k_hwe_test": fin_ms}),
            "roofline": {"bound": "hbm", "kernel": "k_locus_count", "bytes_per_cell": 4,
                         "achieved": Lc * S * 4 / (cnt_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": Lc * S * 4 / (cnt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "note": "40 MB per launch: 5 us at the HBM peak -- launch-latency regime; the long-stream "
                                 "figure for this row length is extras.short_rows"}}
-    # THROUGHPUT of the same pass when a command line keeps several batches in flight: the pass is a chain of three
-    # short latency-bound kernels (count 18 us, finaliser 29, HWE tests 20-28) that leave most of the chip idle;
+    # THROUGHPUT of the same pass when a command line keeps several batches in flight: the pass is a chain of
+    # short latency-bound kernels (count + finaliser 26 us, HWE tests 20-23) that leave most of the chip idle;
     # four independent batches round-robin over the context's four in-order queues overlap them
     NQ = 4
     sets = [res] + [eng.alloc_stats(sb.batch) for _ in range(NQ - 1)]

@@ -1,0 +1,107 @@
+"""The small-batch statSTR pass in two launches (k_locus_count_v3<4,4,true>: the finaliser as the count kernel's
+epilogue; k_hwe_test_slots) against the five-launch chain (count, counter reset, k_locus_finalize, k_hwe_test,
+k_hwe_test_serial): every output bit for bit, and the chain itself against the oracle.
+
+Reference: the per-record statistics of statSTR.py:575-639 through tr_harmonizer.py:1420-1560 and utils.py:139-338."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from trtools_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _fetch(res):
+    return res.allele_count.get().copy(), res.locus_int.get().copy(), res.locus_f64.get().copy()
+
+
+def _both(eng, b, thresh):
+    os.environ['TRK_FUSED_STATS'] = '0'
+    try:
+        chain = _fetch(eng.locus_stats(b, nalleles_thresh=thresh))
+    finally:
+        del os.environ['TRK_FUSED_STATS']
+    fused = _fetch(eng.locus_stats(b, nalleles_thresh=thresh))
+    return chain, fused
+
+
+def _same(chain, fused):
+    assert np.array_equal(chain[0], fused[0])
+    assert np.array_equal(chain[1], fused[1]), np.argwhere(chain[1] != fused[1])[:5]
+    a, c = chain[2].view(np.uint64), fused[2].view(np.uint64)
+    nan_both = np.isnan(chain[2]) & np.isnan(fused[2])
+    bad = (a != c) & ~nan_both
+    assert not bad.any(), (np.argwhere(bad)[:5], chain[2][bad][:5], fused[2][bad][:5])
+
+
+@pytest.mark.parametrize("S", [4, 60, 64, 252, 1000, 2048])
+@pytest.mark.parametrize("max_alt", [0, 3, 14, 40])
+def test_fused_pass_equals_the_chain(eng, S, max_alt):
+    from test_gpu_stats import _random_batch, check_against_oracle
+    from oracle import trtools_oracle as orc
+    from trtools_amd import _lib as L
+    rng = np.random.default_rng(1000 * max_alt + S)
+    n_loci = 45          # the last wave of four loci holds one
+    gt, lens, strs, _, (off, lc, sc, cv) = _random_batch(rng, n_loci, S, 2, max_alt)
+    for l in range(n_loci):
+        r = rng.random(S)
+        if l % 3 == 0:
+            gt[l][r < 0.05, 1] = -2
+            gt[l][(r >= 0.10) & (r < 0.12)] = -2
+        gt[l][(r >= 0.05) & (r < 0.08)] = (-1, -2)
+        gt[l][(r >= 0.12) & (r < 0.16)] = -1
+        gt[l][(r >= 0.16) & (r < 0.19), 1] = -1
+    gt[3] = -1                 # nothing called: ValueError status
+    gt[4] = -2
+    gt[7] = 0                  # one allele, everybody homozygous
+    if S >= 60:
+        gt[8][:, 0] = 0        # every call heterozygous or 0/0
+    b = eng.make_batch(gt, off, lc, sc, cv)
+    chain, fused = _both(eng, b, 0.02)
+    _same(chain, fused)
+    check_against_oracle(orc, L, *fused, off, gt, lens, strs, [None], 0.02)
+
+
+def test_fused_pass_on_a_synthetic_cohort_and_padding(eng):
+    """configs[1]'s shape at a tenth of its loci, rows padded with no-call samples (trk_batch.n_pad_samples)."""
+    from trtools_amd.synth import SynthBatch
+    sb = SynthBatch(eng, 1000, 1000, seed=77, planes=())
+    chain, fused = _both(eng, sb.batch, 0.01)
+    _same(chain, fused)
+    sb.pad_rows(32)
+    chain_p, fused_p = _both(eng, sb.batch, 0.01)
+    _same(chain_p, fused_p)
+    _same(chain, fused_p)      # the padding leaves every statistic alone
+
+
+def test_out_of_range_indices_and_negative_threshold(eng):
+    from test_gpu_stats import _random_batch
+    rng = np.random.default_rng(5)
+    gt, lens, strs, _, (off, lc, sc, cv) = _random_batch(rng, 17, 128, 2, 6)
+    gt[2][5] = (30, 0)
+    gt[9][7] = (1, 99)
+    b = eng.make_batch(gt, off, lc, sc, cv)
+    for thresh in (0.0, -1.0, 0.5, 1.0):
+        _same(*_both(eng, b, thresh))
+
+
+def test_larger_batches_stay_on_the_chain_unless_asked(eng):
+    """Above 32768 loci the statistics come from the chain (the finaliser overlaps other passes there);
+    TRK_FUSED_STATS=<loci> moves the limit: the same bits either way."""
+    from trtools_amd.synth import SynthBatch
+    sb = SynthBatch(eng, 40000, 256, seed=3, planes=())
+    ref = _fetch(eng.locus_stats(sb.batch))
+    os.environ['TRK_FUSED_STATS'] = '100000'
+    try:
+        got = _fetch(eng.locus_stats(sb.batch))
+    finally:
+        del os.environ['TRK_FUSED_STATS']
+    _same(ref, got)

@@ -3,4 +3,4 @@ import bench, json
 from trtools_amd.engine import Engine
 eng = Engine(0)
 r = bench.config1_extra(eng, False)
-print(json.dumps({k: r[k] for k in ('ms_per_pass','loci_per_s','kernels_ms','four_queues','parity_rows_checked')}))
+print(json.dumps({k: r[k] for k in r if k not in ("roofline", "workload")}))

@@ -471,6 +471,24 @@ int trk_locus_stats(trk_ctx* ctx, const trk_batch* in, const trk_stats_params* p
     if (in->n_class_runs > 0)   // (grown before the bracket: a growth synchronises this queue; null -> per-call kernels)
         class_ws = static_cast<int32_t*>(workspace_for_queue(
             ctx, (size_t)in->n_class_runs * ((size_t)sumA + (size_t)in->n_loci * TRK_LI_COLS) * sizeof(int32_t)));
+    if (!count_only && !(prm && (prm->flags & TRK_STATS_TWIN))) {
+        // small batches: the finaliser is the count kernel's epilogue (two launches per pass instead of five)
+        rc = ensure_fin_buffers(ctx, G, sumA, in->n_loci);
+        if (rc) return rc;
+        if (trk::launch_locus_stats_fused(*in, nullptr, nullptr, nullptr, nullptr, 0.0, nullptr, nullptr, 0)) {
+            const double thr = prm ? prm->nalleles_thresh : 0.01;
+            ProfScope ps(ctx, TRK_K_LOCUS_COUNT);
+            hipError_t fe = hipSuccess;
+            (void)trk::launch_locus_stats_fused(*in, out->allele_count, out->locus_int, out->locus_f64,
+                                                ctx->worklist_[ctx->cur], thr, ctx->s(), &fe, 1);
+            HIPCHK(ctx, fe);
+            ps.split(TRK_K_LOCUS_FINALIZE);
+            (void)trk::launch_locus_stats_fused(*in, out->allele_count, out->locus_int, out->locus_f64,
+                                                ctx->worklist_[ctx->cur], thr, ctx->s(), &fe, 2);
+            HIPCHK(ctx, fe);
+            return TRK_OK;
+        }
+    }
     {
         ProfScope ps(ctx, TRK_K_LOCUS_COUNT);
         HIPCHK(ctx, trk::launch_locus_count(*in, in->max_alleles, out->allele_count, out->locus_int,

@@ -15,6 +15,8 @@ hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* alle
                               int n_cu, hipStream_t stream, bool twin, int32_t* class_ws);
 hipError_t launch_permute_columns(const int16_t* src, int16_t* dst, const int32_t* col, int64_t n_loci, int n_src,
                                   int n_dst, int ploidy, int n_cu, hipStream_t stream);
+bool launch_locus_stats_fused(const trk_batch& b, int32_t* allele_count, int32_t* locus_int, double* locus_f64,
+                              void* worklist, double nalleles_thresh, hipStream_t stream, hipError_t* err, int stage);
 hipError_t launch_locus_finalize(const trk_batch& b, const int32_t* allele_count, int32_t* locus_int,
                                  double* locus_f64, int32_t* scratch, void* worklist, double nalleles_thresh,
                                  hipStream_t stream);

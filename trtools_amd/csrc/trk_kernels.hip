@@ -747,6 +747,16 @@ __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v2(
 // 32-lane group share rows and own 16 columns each (a ds_add_u32 is served in lane groups {0-31}, {32-63}).
 // bins as in v2: 0 '-2', 1 '-1', 2..A+1 alleles, A+2 out of range, A+3..A+6 sentinel pairs.
 // ---------------------------------------------------------------------------
+// one deferred HWE test (k_hwe_test): homogeneous work items, so the lanes of a wave
+// differ only in loop trip counts, and loci whose two allele partitions coincide are
+// tested once
+struct HweItem {
+    int32_t slot;   // g * L + l
+    int32_t modes;  // bit 0: write HWEP_LEN, bit 1: write HWEP_STR
+    int32_t k, n;
+    double p;
+};
+
 template <int LPL>
 __device__ __forceinline__ int seg_sum(int v) {
 #pragma unroll
@@ -787,10 +797,29 @@ __device__ __forceinline__ void v3_cell(uint32_t w, uint32_t amax2, uint32_t hco
     }
 }
 
-template <int R, int U>
+// ---------------------------------------------------------------------------
+// The finaliser as the count kernel's epilogue (small batches: BASELINE configs[1] is a latency chain of launches,
+// the 40 MB stream itself is 5 us).  The LPL lanes of a locus share the work that k_locus_finalize does in one
+// thread: the divisions and logarithms of the classes go side by side (class c on lane c mod LPL), and only the
+// float64 SUMS -- whose order is the reference's (utils.py:139-296 iterate the sorted allele dict) -- stay serial:
+// every sum is a chain  acc += X[c], c ascending,  over an LDS array X filled in parallel (an empty class holds +0.0:
+// acc + 0.0 == acc), up to four chains side by side on the locus's first lanes.  Same operations on the same operands
+// in the same order as mode_stats / k_locus_finalize: the results are the same bits.
+// HWE tests go to FIXED slots (items[l] by length, items[L + l] by sequence; modes == 0: none) -- no counter to zero,
+// no compaction: k_hwe_test_slots walks 2 L slots.
+// ---------------------------------------------------------------------------
+struct V3Fin {
+    double* locus_f64;
+    HweItem* items;
+    double nalleles_thresh;
+    int amax4;          // max_alleles rounded up to a multiple of four
+    int fin_words;      // 32-bit words of one locus's scratch: 2 * amax4 (class counts) + 10 * amax4 (five f64 arrays)
+};
+
+template <int R, int U, bool FIN = false>
 __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v3(
     trk_batch b, int32_t* __restrict__ allele_count, int32_t* __restrict__ locus_int, int nbmax,
-    int wave_lds_words, int64_t twin_ac, int64_t twin_li) {
+    int wave_lds_words, int64_t twin_ac, int64_t twin_li, V3Fin fin) {
     static_assert(R == 2 || R == 4, "loci per wave");
     constexpr int LPL = WAVE / R;                 // lanes per locus
     constexpr int KC = R == 4 ? 16 : 32;          // histogram columns of one locus
@@ -867,7 +896,10 @@ __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v3(
             allele_count[off + bin - 2] = (int32_t)s;
             if (twin_ac) allele_count[twin_ac + off + bin - 2] = (int32_t)s;
         }
-        hrow[(bin << 5) + cbase] = s;
+        if (FIN)   // (the histogram rows become the finaliser's scratch: the totals go to a row of their own)
+            wbase[2 * nbmax * 32 + (R + sub) * nbmax + bin] = s;
+        else
+            hrow[(bin << 5) + cbase] = s;
     }
     wave_lds_fence();
     n_eq = (uint32_t)seg_sum<LPL>((int)n_eq);
@@ -875,7 +907,206 @@ __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v3(
         n_hl = (uint32_t)seg_sum<LPL>((int)n_hl);
         n_hs = (uint32_t)seg_sum<LPL>((int)n_hs);
     }
-    if (sl == 0 && live) {
+    if (FIN) {
+        const uint32_t* h = wbase + 2 * nbmax * 32 + (R + sub) * nbmax;     // the locus's bin totals
+        const int h_m2 = (int)h[0], h_m1 = (int)h[1];
+        const int n_bad = (int)h[A + 2];
+        const int c00 = (int)h[A + 3], c10 = (int)h[A + 4], c01 = (int)h[A + 5], c11 = (int)h[A + 6];
+        const int hom_idx = (int)n_eq - c11 - c00;
+        const int n_called = S - (h_m1 - c11), n_low = h_m2 - c00 - c10 - c01;
+        const int n_homl = dup ? (int)n_hl - c11 - c00 : hom_idx, n_homs = dup ? (int)n_hs - c11 - c00 : hom_idx;
+        const int A4 = (A + 3) & ~3, M4 = fin.amax4;
+        const int lane0 = sub * LPL;
+        int32_t* ccl = reinterpret_cast<int32_t*>(wbase + sub * fin.fin_words);   // (over the folded histogram rows)
+        int32_t* ccs = ccl + M4;
+        double* Fl = reinterpret_cast<double*>(ccs + M4);   // f = n / total by class, alleles by length
+        double* T1 = Fl + M4;                               // f^2, then -(pk ln pk), then f (v - mean)^2
+        double* Fs = T1 + M4;                               // by sequence: f, then -(pk ln pk)
+        double* T3 = Fs + M4;                               // by sequence f^2, then v f (the mean's terms)
+        double* CV = T3 + M4;                               // class values (lengths)
+        for (int a = sl; a < A4; a += LPL) {
+            ccl[a] = 0;
+            ccs[a] = 0;
+        }
+        wave_lds_fence();
+        int tot = 0;
+        for (int a = sl; a < A; a += LPL) {
+            const int n = (int)h[a + 2];
+            const uint32_t cls = lut[a + 2];
+            __hip_atomic_fetch_add(&ccl[cls & 0xffffu], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&ccs[cls >> 16], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            tot += n;
+        }
+        const int total = seg_sum<LPL>(tot);
+        wave_lds_fence();
+        const double nan = __builtin_nan("");
+        const double ft = (double)total;      // float(sum(counts))   (tr_harmonizer.py:1539)
+        const double* cvg = b.len_class_value + off;
+        // pass 1 (parallel): f and f^2 per class; nalleles, last non-empty class, first most frequent class
+        // the two partitions give the same class counts in the same order at most loci (then one set of sums serves
+        // both, as in k_locus_finalize); equal only as multisets -- alleles sorted by sequence against by length --
+        // means another summation order: both sets are taken
+        int mism = n_homl != n_homs;
+        for (int c = sl; c < A; c += LPL) mism |= ccl[c] != ccs[c];
+        const bool same = seg_max<LPL>(mism) == 0;
+        const bool both = __ballot(!same) != 0ull;
+        int na_l = 0, na_s = 0, last = -1, bestn = 0;
+        for (int c = sl; c < A4; c += LPL) {
+            const int nl = c < A ? ccl[c] : 0, ns = c < A ? ccs[c] : 0;
+            const double fl = nl ? (double)nl / ft : 0.0;
+            Fl[c] = fl;
+            T1[c] = fl * fl;
+            CV[c] = c < A ? cvg[c] : 0.0;
+            na_l += (nl != 0) & (fl >= fin.nalleles_thresh);     // statSTR.py:207
+            if (nl) last = c;
+            bestn = nl > bestn ? nl : bestn;
+            if (both) {
+                const double fs = ns ? (double)ns / ft : 0.0;
+                Fs[c] = fs;
+                T3[c] = fs * fs;
+                na_s += (ns != 0) & (fs >= fin.nalleles_thresh);
+            }
+        }
+        na_l = seg_sum<LPL>(na_l);
+        last = seg_max<LPL>(last);
+        bestn = seg_max<LPL>(bestn);
+        int best = 0x7fffffff;    // first maximum == min over ties (utils.py:263-271)
+        for (int c = sl; c < A; c += LPL)
+            if (ccl[c] == bestn) { best = c; break; }
+        best = -seg_max<LPL>(-best);
+        na_s = both ? seg_sum<LPL>(na_s) : na_l;
+        wave_lds_fence();
+        // chains 1: sum f, sum f^2 (both partitions)
+        const int j = sl & 3;
+        const double* base1 = j == 0 ? Fl : j == 1 ? T1 : j == 2 ? Fs : T3;
+        double fsum_l, sq_l, fsum_s, sq_s;
+        {
+            double acc = 0.0;
+            if (sl < (both ? 4 : 2))
+                for (int c = 0; c < A4; c += 4) {
+                    const double x0 = base1[c], x1 = base1[c + 1], x2 = base1[c + 2], x3 = base1[c + 3];
+                    acc += x0;
+                    acc += x1;
+                    acc += x2;
+                    acc += x3;
+                }
+            fsum_l = __shfl(acc, lane0, WAVE);
+            sq_l = __shfl(acc, lane0 + 1, WAVE);
+            fsum_s = both ? __shfl(acc, lane0 + 2, WAVE) : fsum_l;
+            sq_s = both ? __shfl(acc, lane0 + 3, WAVE) : sq_l;
+        }
+        wave_lds_fence();
+        // pass 2 (parallel): -(pk ln pk) with pk = f / sum f (scipy.stats.entropy normalises), v f
+        for (int c = sl; c < A4; c += LPL) {
+            const double fl = Fl[c];
+            double e = 0.0;
+            if (fl != 0.0) {
+                const double pk = fl / fsum_l;
+                e = -(pk * log(pk));
+            }
+            T1[c] = e;
+            T3[c] = CV[c] * fl;           // utils.py:236
+            if (both) {
+                const double fs = Fs[c];
+                double es = 0.0;
+                if (fs != 0.0) {
+                    const double pk = fs / fsum_s;
+                    es = -(pk * log(pk));
+                }
+                Fs[c] = es;
+            }
+        }
+        wave_lds_fence();
+        const double* base2 = j == 0 ? T1 : j == 1 ? T3 : Fs;
+        double ent_l, ent_s, mean;
+        {
+            double acc = 0.0;
+            if (sl < (both ? 3 : 2))
+                for (int c = 0; c < A4; c += 4) {
+                    const double x0 = base2[c], x1 = base2[c + 1], x2 = base2[c + 2], x3 = base2[c + 3];
+                    acc += x0;
+                    acc += x1;
+                    acc += x2;
+                    acc += x3;
+                }
+            ent_l = __shfl(acc, lane0, WAVE);
+            mean = __shfl(acc, lane0 + 1, WAVE);
+            ent_s = both ? __shfl(acc, lane0 + 2, WAVE) : ent_l;
+        }
+        wave_lds_fence();
+        // pass 3: the variance's terms, f (v - mean)^2   (utils.py:296)
+        for (int c = sl; c < A4; c += LPL) {
+            const double d = CV[c] - mean;
+            T1[c] = Fl[c] * (d * d);
+        }
+        wave_lds_fence();
+        double var;
+        {
+            double acc = 0.0;
+            if (sl == 0)
+                for (int c = 0; c < A4; c += 4) {
+                    const double x0 = T1[c], x1 = T1[c + 1], x2 = T1[c + 2], x3 = T1[c + 3];
+                    acc += x0;
+                    acc += x1;
+                    acc += x2;
+                    acc += x3;
+                }
+            var = __shfl(acc, lane0, WAVE);
+        }
+        // the rows (mode_stats / k_locus_finalize)
+        const bool have = total > 0;
+        const bool ok_l = have && fabs(1.0 - fsum_l) <= 0.001, ok_s = have && fabs(1.0 - fsum_s) <= 0.001;   // utils.py:140
+        ent_l /= 0.693147180559945309417232;
+        ent_s /= 0.693147180559945309417232;
+        ent_l = ent_l == 0.0 ? 0.0 : ent_l;
+        ent_s = ent_s == 0.0 ? 0.0 : ent_s;
+        const int st_base = n_called == 0 ? TRK_HWE_VALUE_ERROR : n_low > 0 ? TRK_HWE_NAN : TRK_HWE_OK;   // (ploidy 2 here)
+        const int st_l = ok_l ? st_base : TRK_HWE_NAN, st_s = ok_s ? st_base : TRK_HWE_NAN;
+        if (live) {
+            const int ns_real = S - b.n_pad_samples;
+            double fv;
+            switch (sl) {
+                case TRK_LF_THRESH: fv = have && last >= 0 ? CV[last < 0 ? 0 : last] : nan; break;
+                case TRK_LF_MEAN: fv = ok_l ? mean : nan; break;
+                case TRK_LF_MODE: fv = ok_l ? CV[best >= A ? 0 : best] : nan; break;
+                case TRK_LF_VAR: fv = ok_l ? var : nan; break;
+                case TRK_LF_HET_LEN: fv = ok_l ? 1.0 - sq_l : nan; break;       // utils.py:175
+                case TRK_LF_HET_STR: fv = ok_s ? 1.0 - sq_s : nan; break;
+                case TRK_LF_ENTROPY_LEN: fv = ok_l ? ent_l : nan; break;
+                case TRK_LF_ENTROPY_STR: fv = ok_s ? ent_s : nan; break;
+                case TRK_LF_CALLRATE: fv = ns_real > 0 ? (double)n_called / (double)ns_real : nan; break;   // tr_harmonizer.py:946
+                case 11: fv = 0.0; break;
+                default: fv = nan; break;      // the two HWE p-values: k_hwe_test_slots
+            }
+            int iv;
+            switch (sl) {
+                case TRK_LI_N_CALLED: iv = n_called; break;
+                case TRK_LI_N_LOWPLOIDY: iv = n_low; break;
+                case TRK_LI_N_HOM_LEN: iv = n_homl; break;
+                case TRK_LI_N_HOM_STR: iv = n_homs; break;
+                case TRK_LI_N_ALLELES: iv = total; break;
+                case TRK_LI_N_BAD: iv = n_bad; break;
+                case TRK_LI_HWE_STATUS_LEN: iv = st_l; break;
+                case TRK_LI_HWE_STATUS_STR: iv = st_s; break;
+                case TRK_LI_N_SAMPLES: iv = ns_real; break;
+                case TRK_LI_NALLELES_LEN: iv = have ? na_l : 0; break;
+                case TRK_LI_NALLELES_STR: iv = have ? na_s : 0; break;
+                default: iv = 0; break;
+            }
+            if (sl < TRK_LF_COLS) {
+                fin.locus_f64[(int64_t)l * TRK_LF_COLS + sl] = fv;
+                locus_int[(int64_t)l * TRK_LI_COLS + sl] = iv;
+            }
+            if (sl == 12) {
+                const HweItem it = {l, st_l == TRK_HWE_OK ? (same ? 3 : 1) : 0, n_homl, n_called, sq_l};
+                fin.items[l] = it;
+            }
+            if (sl == 13) {
+                const HweItem it = {l, (!same && st_s == TRK_HWE_OK) ? 2 : 0, n_homs, n_called, sq_s};
+                fin.items[b.n_loci + l] = it;
+            }
+        }
+    } else if (sl == 0 && live) {
         const uint32_t* h = hrow + cbase;
         const int h_m2 = (int)h[0 << 5], h_m1 = (int)h[1 << 5];
         const int n_bad = (int)h[(A + 2) << 5];
@@ -1149,16 +1380,6 @@ struct ModeStats {
     int nalleles, status;
 };
 
-// one deferred HWE test (k_hwe_test): homogeneous work items, so the lanes of a wave
-// differ only in loop trip counts, and loci whose two allele partitions coincide are
-// tested once
-struct HweItem {
-    int32_t slot;   // g * L + l
-    int32_t modes;  // bit 0: write HWEP_LEN, bit 1: write HWEP_STR
-    int32_t k, n;
-    double p;
-};
-
 // class counts are in cc[0..ncls), ascending class order == the dict order the
 // reference iterates in (np.unique sorts keys; tr_harmonizer.py:1495-1499)
 __device__ __forceinline__ void mode_stats(const int32_t* cc, int cstride, int ncls, int64_t total,
@@ -1379,6 +1600,24 @@ __global__ __launch_bounds__(FIN_THREADS, 7) void k_hwe_test_serial(const unsign
         if (it.modes & 1) lf[TRK_LF_HWEP_LEN] = pv;
         if (it.modes & 2) lf[TRK_LF_HWEP_STR] = pv;
     }
+}
+
+// the fused small-batch pass's tests: fixed slots (k_locus_count_v3<.., FIN>), two lanes per test, the few tests the
+// pair routine hands back finished in place by the serial routine
+__global__ __launch_bounds__(FIN_THREADS) void k_hwe_test_slots(const HweItem* __restrict__ items, unsigned int n_slots,
+                                                                double* __restrict__ locus_f64) {
+    const unsigned int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned int t = tid >> 1;
+    if (t >= n_slots) return;
+    const HweItem it = items[t];
+    if (it.modes == 0) return;
+    bool ok;
+    double pv = trkmath::binomtest_two_sided_pair(it.k, it.n, it.p, (int)(tid & 1), &ok);  // utils.py:334-338
+    if (tid & 1) return;
+    if (!ok) [[clang::always_inline]] pv = trkmath::binomtest_two_sided(it.k, it.n, it.p);
+    double* lf = locus_f64 + (int64_t)it.slot * TRK_LF_COLS;
+    if (it.modes & 1) lf[TRK_LF_HWEP_LEN] = pv;
+    if (it.modes & 2) lf[TRK_LF_HWEP_STR] = pv;
 }
 
 // the lane-pair test on caller-supplied triples (trk_binomtest_batch: parity tests of the routine itself)
@@ -3586,13 +3825,13 @@ static bool launch_count_streaming(const trk_batch& b, int max_alleles, int32_t*
                 dim3 g3((b.n_loci + per_wg - 1) / per_wg);
                 const size_t lds3 = (size_t)COUNT_WAVES_PER_WG * words3 * sizeof(uint32_t);
                 if (rr == 4 && cnt_u == 4)
-                    hipLaunchKernelGGL((k_locus_count_v3<4, 4>), g3, block, lds3, stream, b, allele_count, locus_int, nbmax, words3, twin_ac, twin_li);
+                    hipLaunchKernelGGL((k_locus_count_v3<4, 4>), g3, block, lds3, stream, b, allele_count, locus_int, nbmax, words3, twin_ac, twin_li, V3Fin{});
                 else if (rr == 4)
-                    hipLaunchKernelGGL((k_locus_count_v3<4, 2>), g3, block, lds3, stream, b, allele_count, locus_int, nbmax, words3, twin_ac, twin_li);
+                    hipLaunchKernelGGL((k_locus_count_v3<4, 2>), g3, block, lds3, stream, b, allele_count, locus_int, nbmax, words3, twin_ac, twin_li, V3Fin{});
                 else if (cnt_u == 4)
-                    hipLaunchKernelGGL((k_locus_count_v3<2, 4>), g3, block, lds3, stream, b, allele_count, locus_int, nbmax, words3, twin_ac, twin_li);
+                    hipLaunchKernelGGL((k_locus_count_v3<2, 4>), g3, block, lds3, stream, b, allele_count, locus_int, nbmax, words3, twin_ac, twin_li, V3Fin{});
                 else
-                    hipLaunchKernelGGL((k_locus_count_v3<2, 2>), g3, block, lds3, stream, b, allele_count, locus_int, nbmax, words3, twin_ac, twin_li);
+                    hipLaunchKernelGGL((k_locus_count_v3<2, 2>), g3, block, lds3, stream, b, allele_count, locus_int, nbmax, words3, twin_ac, twin_li, V3Fin{});
                 // (only N_ALLELES / HWE status / NALLELES columns, written by the finaliser, are left untouched)
                 { *err = hipGetLastError(); return true; }
             }
@@ -3737,6 +3976,45 @@ hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* alle
         hipLaunchKernelGGL(k_locus_count<false>, dim3(wgs), dim3(WAVE * COUNT_WAVES_PER_WG), lds, stream, b,
                            allele_count, locus_int, hist_entries, lut_entries);
     return copy_twin();
+}
+
+// count + finaliser in one launch, the HWE tests in a second (small ungrouped diploid batches of short rows).
+// false: outside what the fused kernel covers -- the caller takes launch_locus_count + launch_locus_finalize.
+bool launch_locus_stats_fused(const trk_batch& b, int32_t* allele_count, int32_t* locus_int, double* locus_f64,
+                              void* worklist, double nalleles_thresh, hipStream_t stream, hipError_t* err, int stage) {
+    // stage 0: only answer whether the batch is covered; 1: count + finaliser; 2: the HWE tests
+    const char* env = getenv("TRK_FUSED_STATS");      // 0: never; N > 1: up to N loci (default 32768)
+    const int64_t limit = env ? atoll(env) : 32768;
+    const int max_alleles = b.max_alleles;
+    if (limit <= 0 || b.n_loci > limit) return false;
+    if (b.ploidy != 2 || b.group_bits || b.locus_ploidy || b.row_stride || b.n_class_runs > 0) return false;
+    if (max_alleles <= 0 || max_alleles + 2 >= 65535 || (b.n_samples % 4) != 0 || b.n_samples <= 0 || b.n_samples > 2048)
+        return false;
+    if (getenv("TRK_CNT_VER") || getenv("TRK_CNT_R") || getenv("TRK_CNT_U")) return false;   // A/B knobs of the count kernels
+    const int nbmax = max_alleles + 7;
+    V3Fin fin;
+    fin.locus_f64 = locus_f64;
+    fin.items = reinterpret_cast<HweItem*>(reinterpret_cast<char*>(worklist) + 16);
+    fin.nalleles_thresh = nalleles_thresh;
+    fin.amax4 = (max_alleles + 3) & ~3;
+    fin.fin_words = 12 * fin.amax4;
+    const int words3 = (2 * nbmax * 32 + 8 * nbmax + 3) & ~3;   // histogram rows (later the scratch), LUTs, bin totals
+    const size_t lds3 = (size_t)COUNT_WAVES_PER_WG * words3 * sizeof(uint32_t);
+    if (lds3 > 80 * 1024) return false;
+    if (stage == 0) return true;
+    const unsigned int n_slots = 2u * (unsigned int)b.n_loci;
+    if (stage == 2) {
+        hipLaunchKernelGGL(k_hwe_test_slots, dim3((2 * n_slots + FIN_THREADS - 1) / FIN_THREADS), dim3(FIN_THREADS), 0, stream,
+                           fin.items, n_slots, locus_f64);
+        *err = hipGetLastError();
+        return true;
+    }
+    sync_gt_temporal();
+    const int per_wg = COUNT_WAVES_PER_WG * 4;
+    hipLaunchKernelGGL((k_locus_count_v3<4, 4, true>), dim3((b.n_loci + per_wg - 1) / per_wg), dim3(WAVE * COUNT_WAVES_PER_WG),
+                       lds3, stream, b, allele_count, locus_int, nbmax, words3, (int64_t)0, (int64_t)0, fin);
+    *err = hipGetLastError();
+    return true;
 }
 
 hipError_t launch_locus_finalize(const trk_batch& b, const int32_t* allele_count, int32_t* locus_int,
