@@ -992,9 +992,33 @@ def main():
     if use_dist:
         group = SocketGroup(rank, world)     # rendezvous / barrier / small host reductions over TCP: no torch
     eng = Engine(0 if share_device else local_rank)
+    comm_note = None
     if use_dist and comm_mode != 'host':
-        uid = group.broadcast_bytes(eng.comm_unique_id() if rank == 0 else b'')
-        eng.comm_init(rank, world, uid)
+        # RCCL, one rank per GPU.  If the communicator cannot be built on ANY rank (the ranks agree over the socket
+        # group), the run goes on with the step's exchange through host copies and says so in the line -- a scaling
+        # figure with the wire named is worth more than none.
+        err, uid = '', b''
+        if rank == 0:
+            try:
+                uid = eng.comm_unique_id()
+            except Exception as e:
+                err = "%s: %s" % (type(e).__name__, e)
+        uid = group.broadcast_bytes(uid)     # (every rank takes part whatever happened on rank 0)
+        if uid:
+            try:
+                eng.comm_init(rank, world, uid)
+            except Exception as e:
+                err = "%s: %s" % (type(e).__name__, e)
+        elif not err:
+            err = "no communicator id from rank 0"
+        n_bad = int(group.allreduce_sum_i64(np.array([1 if err else 0], dtype=np.int64))[0])
+        if n_bad:
+            errs = group.allgather_bytes(np.frombuffer(err.encode()[:400], dtype=np.uint8))
+            first = next((bytes(b.tobytes()).decode(errors='replace') for b in errs if len(b)), '')
+            comm_mode = 'host'
+            comm_note = "RCCL communicator not built on %d of %d ranks (%s): exchange through host copies" % (
+                n_bad, world, first)
+            print(comm_note, file=sys.stderr)
     # the cohort's per-locus tables (every rank builds the same ones from the seed)
     loci = make_loci(args.loci, args.samples, args.seed)
     if args.scaling == 'strong':
@@ -1079,7 +1103,9 @@ def main():
                        "max_alleles": int(np.max(np.diff(wl.sb.tables[0]))),
                        "sharding": ("contiguous locus shards by rank; per step ONE grouped RCCL launch: all-reduce of "
                                     "the packed sample_info / totaldp / loc_info counters + all-gather of the "
-                                    "per-locus filter decisions") if world > 1 else "single GPU"},
+                                    "per-locus filter decisions" if comm_mode != 'host' else
+                                    "contiguous locus shards by rank; the step's exchange through HOST copies over the "
+                                    "socket group (%s)" % (comm_note or "TRK_BENCH_COMM=host")) if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_call_filter_v2 (HIP events around that kernel alone; the 0.06 ms "
                                                    "k_cf_reduce that follows it is kernels_ms.k_cf_reduce)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -93,15 +93,15 @@ def test_out_of_range_indices_and_negative_threshold(eng):
         _same(*_both(eng, b, thresh))
 
 
-def test_larger_batches_stay_on_the_chain_unless_asked(eng):
-    """Above 32768 loci the statistics come from the chain (the finaliser overlaps other passes there);
-    TRK_FUSED_STATS=<loci> moves the limit: the same bits either way."""
+def test_large_batches_and_the_limit_knob(eng):
+    """The fused pass serves every batch of short rows; TRK_FUSED_STATS=<loci> caps it (0: never): same bits."""
     from trtools_amd.synth import SynthBatch
     sb = SynthBatch(eng, 40000, 256, seed=3, planes=())
-    ref = _fetch(eng.locus_stats(sb.batch))
-    os.environ['TRK_FUSED_STATS'] = '100000'
+    chain, fused = _both(eng, sb.batch, 0.01)
+    _same(chain, fused)
+    os.environ['TRK_FUSED_STATS'] = '1000'
     try:
-        got = _fetch(eng.locus_stats(sb.batch))
+        capped = _fetch(eng.locus_stats(sb.batch))
     finally:
         del os.environ['TRK_FUSED_STATS']
-    _same(ref, got)
+    _same(chain, capped)
