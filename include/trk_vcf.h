@@ -74,7 +74,8 @@ typedef struct {
     /* the record lines themselves (for the fixed columns and anything not decoded above):
      * text[line_off[i] .. line_end[i]) is record i (no newline);
      * field_off[i*10 + k] is the offset inside the line of column k (k = 0..8: CHROM..FORMAT,
-     * k = 9: first sample column).  Owned by the reader, valid until the next call.        */
+     * k = 9: first sample column).  Owned by the reader; valid during the NEXT trk_vcf_read_batch
+     * call too (a thread may read batch n + 1 while batch n is in use), gone with the one after. */
     const char* text;
     const int64_t* line_off;
     const int64_t* line_end;

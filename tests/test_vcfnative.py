@@ -254,3 +254,72 @@ def test_wide_genotypes_widen_one_batch_only_and_nine_haplotypes_are_named(tmp_p
         r.read_raw_batch(4)
     r.close()
     assert 'nine.vcf' in str(ei.value) and '7:123' in str(ei.value) and '8 haplotypes' in str(ei.value)
+
+
+def _batch_digest(rb):
+    """Everything a batch hands out: arrays, the record lines (through the reader-owned text), harmonised tables."""
+    import ctypes as C
+    lines = [C.string_at(rb.b.text + rb.b.line_off[l], rb.b.line_end[l] - rb.b.line_off[l]) for l in range(rb.n)]
+    return (rb.gt.copy(), rb.phased.copy(), rb.locus_ploidy.copy(), {k: v.copy() for k, v in rb.planes.items()}, lines)
+
+
+@pytest.mark.parametrize("ring", [0, 2])
+def test_read_ahead_hands_out_the_same_batches_and_keeps_the_previous_one_valid(ring):
+    """NativeVCFReader.read_ahead: batch n + 1 is read on a worker thread while batch n is in use -- libtrk keeps
+    the text and line tables of a batch valid during the next trk_vcf_read_batch.  The batches equal those of a
+    plain reader, although batch n is looked at only after the worker has read batch n + 1."""
+    import time
+    from trtools_amd import vcfnative
+    path = os.path.join(D, 'many_samples.vcf.gz')
+
+    def batches(ahead):
+        r = vcfnative.NativeVCFReader(path, batch_records=7)
+        r.select_format('DP')
+        if ring:
+            r.use_buffers(None, ring=ring)
+        if ahead:
+            r.read_ahead()
+        out = []
+        while True:
+            rb = r.read_raw_batch(7)
+            if rb.n == 0:
+                break
+            if ahead:
+                time.sleep(0.01)             # the worker reads (and finishes) the batch after this one meanwhile
+            hz = rb.harmonize('hipstr')      # the reader's harmoniser on this batch's text
+            out.append(_batch_digest(rb) + (hz.pos.copy(), hz.allele_off.copy()))
+        r.close()
+        return out
+
+    plain, ahead = batches(False), batches(True)
+    assert len(plain) == len(ahead) > 3
+    for a, b in zip(plain, ahead):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert a[3].keys() == b[3].keys() and all(np.array_equal(a[3][k], b[3][k]) for k in a[3])
+        assert a[4] == b[4]
+        assert np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6])
+
+
+def test_read_ahead_errors_surface_in_order_and_a_seek_drops_the_batch_in_flight(tmp_path):
+    from trtools_amd import vcfnative
+    head = ('##fileformat=VCFv4.1\n##FORMAT=<ID=GT,Number=1,Type=String,Description="g">\n'
+            '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tA\tB\n')
+    recs = ['1\t%d\t.\tA\tAA\t.\t.\t.\tGT\t0/1\t0/0\n' % (10 + i) for i in range(6)]
+    recs[4] = '1\t14\t.\tA\tAA\t.\t.\t.\tGT\t0/1\n'            # a record without its second sample column
+    p = tmp_path / 'short.vcf'
+    p.write_text(head + ''.join(recs))
+    r = vcfnative.NativeVCFReader(str(p)).read_ahead()
+    assert r.read_raw_batch(2).n == 2                          # (the worker is already on records 3-4)
+    assert r.read_raw_batch(2).n == 2
+    with pytest.raises(ValueError) as ei:                      # the bad batch fails when it is asked for, not before
+        r.read_raw_batch(2)
+    assert 'fewer sample columns' in str(ei.value)
+    r.close()
+    # a region query (seek) while a read is in flight: the batch in flight is dropped, the query's records come back
+    path = os.path.join(D, 'many_samples.vcf.gz')
+    want = [v.POS for v in vcfnative.NativeVCFReader(path)('1:1000000-2000000')]
+    r = vcfnative.NativeVCFReader(path, batch_records=5).read_ahead()
+    assert r.read_raw_batch(5).n == 5
+    got = [v.POS for v in r('1:1000000-2000000')]
+    r.close()
+    assert got == want and len(want) > 0

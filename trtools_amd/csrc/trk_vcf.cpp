@@ -90,6 +90,11 @@ public:
         return c ? c : (have < m ? -1 : (have > m ? 1 : 0));
     }
     std::string substr(size_t pos, size_t n) const { return std::string(p_ + pos, std::min(n, n_ - pos)); }
+    void swap(TextBuf& o) {
+        std::swap(p_, o.p_);
+        std::swap(n_, o.n_);
+        std::swap(cap_, o.cap_);
+    }
 };
 
 // libdeflate (2-3x zlib's inflate rate) is in the image as a runtime library without its header: bound by hand at
@@ -362,8 +367,17 @@ struct trk_vcf {
     std::vector<PlaneSel> planes;
     TextBuf buf;         // decompressed text: [consumed .. pending)
     size_t pos = 0;      // start of unconsumed text in buf
-    std::vector<int64_t> line_off, line_end;
+    std::vector<int64_t> line_off, line_end;     // of the batch being read
     std::vector<int32_t> field_off;
+    // A batch stays valid during the NEXT trk_vcf_read_batch call (a caller's thread reads batch n + 1 while batch n
+    // is harmonised, filtered and written): its text is left in `prev_text` when the unconsumed tail moves on, its
+    // line tables in one of two kept sets.
+    TextBuf prev_text;
+    struct Kept {
+        std::vector<int64_t> line_off, line_end;
+        std::vector<int32_t> field_off;
+    } kept[2];
+    int kept_i = 0;
     int n_threads = 1;
     // contiguous shard of the file (trk_vcf_shard)
     bool sharded = false, skip_partial = false, shard_done = false;
@@ -915,7 +929,11 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
     out->max_ploidy = max_ploidy;
     // drop what the previous call handed out
     if (v->pos > 0) {
-        v->buf.erase(0, v->pos);
+        // (the handed-out text is not moved: the tail is copied to the other buffer and the two change places)
+        const size_t tail = v->buf.size() - v->pos;
+        v->prev_text.resize(tail);
+        if (tail) memcpy(v->prev_text.data(), v->buf.data() + v->pos, tail);
+        v->buf.swap(v->prev_text);
         if (v->src.limit_pos != SIZE_MAX) v->src.limit_pos = v->src.limit_pos > v->pos ? v->src.limit_pos - v->pos : 0;
         v->pos = 0;
     }
@@ -1012,11 +1030,16 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
         fprintf(stderr, "[trk_vcf] batch of %d records: scan %.1f ms (of which inflate/read %.1f), parse %.1f ms, %d threads\n", n,
                 (t1 - t0) * 1e3, t_fill * 1e3, (now() - t1) * 1e3, nt);
     v->pos = scan;
+    v->kept_i ^= 1;
+    trk_vcf::Kept& kp = v->kept[v->kept_i];
+    kp.line_off.swap(v->line_off);
+    kp.line_end.swap(v->line_end);
+    kp.field_off.swap(v->field_off);
     out->n_records = n;
     out->text = v->buf.data();
-    out->line_off = v->line_off.data();
-    out->line_end = v->line_end.data();
-    out->field_off = v->field_off.data();
+    out->line_off = kp.line_off.data();
+    out->line_end = kp.line_end.data();
+    out->field_off = kp.field_off.data();
     return 0;
 }
 

@@ -937,6 +937,8 @@ def main(args):
         kinds = {k: (1 if h['Type'] == 'Integer' else 2 if h['Type'] == 'Float' else 4) for k, h in format_fields.items()}
         invcf.use_buffers(getattr(runtime.get_compute(), 'host_buffer', None), ring=2,
                           release=getattr(runtime.get_compute(), 'host_release', None))
+        if args.num_records is None:              # (--num-records shortens the last batch: no read beyond it)
+            invcf.read_ahead()
     LAST_RUN.clear()
     LAST_RUN.update(path='batch' if use_batches else 'per-record', batches=0, fallback_batches=0)
     while use_batches:

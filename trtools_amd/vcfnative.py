@@ -367,8 +367,50 @@ class NativeVCFReader(vcfio.VCFReader):
             raise ValueError("cannot select FORMAT field %s" % key)
         self._selected.append((name, kind, ncol, np.float32 if kind == KIND_FLOAT else np.int32))
 
+    def read_ahead(self, on=True):
+        """Read batch n + 1 on a worker thread while the caller works on batch n (the native call releases the GIL;
+        libtrk keeps a batch's text and line tables valid during the next read).  With a ring of array sets
+        (``use_buffers``) the ring must hold two sets.  ``TRK_VCF_READ_AHEAD=0`` turns it off."""
+        self._drop_pending()
+        self._ahead = bool(on) and os.environ.get('TRK_VCF_READ_AHEAD', '1') != '0'
+        return self
+
+    def _drop_pending(self):
+        """Wait for a read in flight and forget its batch (before a seek / shard / close)."""
+        pend, self._pending = getattr(self, '_pending', None), None
+        if pend is not None:
+            pend[0].join()
+
     def read_raw_batch(self, n_records=None):
         """Decode the next batch of records into arrays (RawBatch); ``.n == 0`` at the end of the file."""
+        if not getattr(self, '_ahead', False):
+            return self._read_raw_batch(n_records)
+        import threading
+
+        def start():
+            box = {}
+
+            def work():
+                try:
+                    box['rb'] = self._read_raw_batch(n_records)
+                except BaseException as e:      # re-raised on the caller's thread
+                    box['err'] = e
+            t = threading.Thread(target=work, name='trk-vcf-read-ahead', daemon=True)
+            t.start()
+            return t, box
+        if getattr(self, '_pending', None) is None:
+            self._pending = start()
+        t, box = self._pending
+        t.join()
+        self._pending = None
+        if 'err' in box:
+            raise box['err']
+        rb = box['rb']
+        if rb.n:
+            self._pending = start()
+        return rb
+
+    def _read_raw_batch(self, n_records=None):
         S = self.n_samples
         P = self._max_ploidy
         n = n_records or self._batch_records or max(1, min(4096, (1 << 22) // max(S, 1)))
@@ -405,6 +447,7 @@ class NativeVCFReader(vcfio.VCFReader):
         and the callers deal batches out round-robin)."""
         if world <= 1:
             return True
+        self._drop_pending()
         b, e = C.c_uint64(), C.c_uint64()
         if self._lib.trk_vcf_shard(self._h, int(rank), int(world), C.byref(b), C.byref(e)) != 0:
             return False
@@ -514,6 +557,7 @@ class NativeVCFReader(vcfio.VCFReader):
         seeks to the first 16 kb window the region touches (the index's linear table) and stops at
         the first record past the region; without one it scans the whole file."""
         vcfio.VCFReader.__call__(self, region)
+        self._drop_pending()
         self._indexed_region = False
         tbi = self.path + '.tbi'
         if os.path.isfile(tbi) and os.environ.get('TRK_TABIX', '1') != '0':
@@ -566,6 +610,7 @@ class NativeVCFReader(vcfio.VCFReader):
 
     def close(self):
         if self._h is not None:
+            self._drop_pending()
             self._lib.trk_vcf_close(self._h)
             self._h = None
         slabs, self._slabs, self._ring = getattr(self, '_slabs', []), [], []
