@@ -266,3 +266,17 @@ def test_dumpstr_depth_field_is_judged_per_record(tmp_path):
     finally:
         runtime.set_compute(old)
     assert a == b
+
+
+def test_read_ahead_leaves_both_command_lines_outputs_alone(tmp_path, monkeypatch):
+    """TRK_VCF_READ_AHEAD=1: the reader's worker thread reads batch n + 1 while batch n is processed (small batches
+    here, so that several are in flight over the file); outputs equal the per-record loops' as without it."""
+    from oracle_compute import OracleCompute
+    from trtools_amd.statSTR import statSTR
+    from trtools_amd.dumpSTR import dumpSTR
+    monkeypatch.setenv('TRK_VCF_READ_AHEAD', '1')
+    monkeypatch.setattr(statSTR, 'BATCH_CELLS', 40 * 7, raising=False)
+    monkeypatch.setattr(dumpSTR, 'BATCH_CELLS', 40 * 7, raising=False)
+    _run_stat(tmp_path, OracleCompute(), os.path.join(SYN, 'synth_hipstr.vcf'), 'hipstr', hwep=True)
+    name = sorted(set(DUMP_CASES) - BIG_CASES - FALLBACK_CASES)[0]
+    _run_dump(tmp_path, OracleCompute(), name)

@@ -1,0 +1,14 @@
+"""dumpSTR's command line on the file tools/e2e_probe.py generated (/tmp/e2e), three runs: seconds and phases."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from trtools_amd.dumpSTR import dumpSTR
+path = sys.argv[1]
+old = sys.argv
+sys.argv = ['dumpSTR', '--vcf', path, '--out', '/tmp/e2e/dump', '--vcftype', 'hipstr',
+            '--hipstr-min-call-DP', '10', '--hipstr-max-call-DP', '55', '--hipstr-min-call-Q', '0.9',
+            '--min-locus-callrate', '0.8', '--min-locus-hwep', '0.001', '--min-locus-het', '0.05', '--max-locus-het', '0.9']
+dargs = dumpSTR.getargs()
+sys.argv = old
+for i in range(3):
+    t = time.time(); rc = dumpSTR.main(dargs); dt = time.time() - t
+    print("run %d: %.3f s  phases %s" % (i, dt, {p: round(x, 3) for p, x in dumpSTR.LAST_RUN['seconds'].items()}), flush=True)

@@ -611,6 +611,8 @@ int trk_vcf_open(const char* path, int n_threads, trk_vcf** out) {
     trk_vcf* v = new trk_vcf();
     // all cores, but not more than 64 threads: the workers are started per batch, and beyond that their start-up
     // costs more than the extra hands bring (a 50 MB batch parses in ~3 ms on 64 threads)
+    if (n_threads <= 0)
+        if (const char* e = getenv("TRK_VCF_THREADS")) n_threads = atoi(e);     // inflate / parse threads of a reader
     if (n_threads <= 0) n_threads = std::min(64, (int)std::thread::hardware_concurrency());
     if (n_threads < 1) n_threads = 1;
     v->n_threads = n_threads;

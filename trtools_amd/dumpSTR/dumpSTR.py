@@ -937,7 +937,11 @@ def main(args):
         kinds = {k: (1 if h['Type'] == 'Integer' else 2 if h['Type'] == 'Float' else 4) for k, h in format_fields.items()}
         invcf.use_buffers(getattr(runtime.get_compute(), 'host_buffer', None), ring=2,
                           release=getattr(runtime.get_compute(), 'host_release', None))
-        if args.num_records is None:              # (--num-records shortens the last batch: no read beyond it)
+        # TRK_VCF_READ_AHEAD=1: batch n + 1 is read while batch n is filtered and written.  Off by default: measured on
+        # 1 GB of text the read leaves the critical path (0.33 -> 0.05 s) and the phases it runs beside slow down by
+        # as much (record heads 0.12 -> 0.24 s, record text 0.35 -> 0.52 s): 1.13-1.25 s either way
+        # (profiles/r03_notes.md section 15).  (--num-records shortens the last batch: no read beyond it.)
+        if args.num_records is None and os.environ.get('TRK_VCF_READ_AHEAD', '0') == '1':
             invcf.read_ahead()
     LAST_RUN.clear()
     LAST_RUN.update(path='batch' if use_batches else 'per-record', batches=0, fallback_batches=0)

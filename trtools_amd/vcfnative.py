@@ -370,9 +370,9 @@ class NativeVCFReader(vcfio.VCFReader):
     def read_ahead(self, on=True):
         """Read batch n + 1 on a worker thread while the caller works on batch n (the native call releases the GIL;
         libtrk keeps a batch's text and line tables valid during the next read).  With a ring of array sets
-        (``use_buffers``) the ring must hold two sets.  ``TRK_VCF_READ_AHEAD=0`` turns it off."""
+        (``use_buffers``) the ring must hold two sets."""
         self._drop_pending()
-        self._ahead = bool(on) and os.environ.get('TRK_VCF_READ_AHEAD', '1') != '0'
+        self._ahead = bool(on)
         return self
 
     def _drop_pending(self):
