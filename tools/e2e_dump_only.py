@@ -12,3 +12,7 @@ sys.argv = old
 for i in range(3):
     t = time.time(); rc = dumpSTR.main(dargs); dt = time.time() - t
     print("run %d: %.3f s  phases %s" % (i, dt, {p: round(x, 3) for p, x in dumpSTR.LAST_RUN['seconds'].items()}), flush=True)
+if os.environ.get('E2E_PROFILE'):
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable(); dumpSTR.main(dargs); pr.disable()
+    pstats.Stats(pr).sort_stats('tottime').print_stats(22)

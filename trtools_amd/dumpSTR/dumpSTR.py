@@ -629,7 +629,9 @@ class _Run:
             heads.append('\t'.join(f))
         t_lines = time.perf_counter()
         _tick('record_heads_python', t_lines - t_heads)
-        text = rb.dumpstr_lines(heads, ch.mask, cfv, format_kinds)
+        if not hasattr(self, '_out_ring'):
+            self._out_ring = {}          # two output buffers for the run, taken in turn (one block is with the writer)
+        text = rb.dumpstr_lines(heads, ch.mask, cfv, format_kinds, out_ring=self._out_ring)
         _tick('record_text_native', time.perf_counter() - t_lines)
         if text is None:
             return self._undo_batch()

@@ -207,10 +207,14 @@ class RawBatch:
         end = f9 - 1 if 0 < f9 < n_line else n_line
         return C.string_at(b.text + b.line_off[l], end).decode().split('\t')
 
-    def dumpstr_lines(self, heads, mask, cf_values, format_kinds, n_threads=0):
+    def dumpstr_lines(self, heads, mask, cf_values, format_kinds, n_threads=0, out_ring=None):
         """trk_vcf_dumpstr_lines: the output records of the batch.  heads: list of str / None; mask: uint8 or uint32
         [n, S]; cf_values: list of (name, kind, (plane, col), (plane, col) | None); format_kinds: {FORMAT ID: 1 int /
-        2 float / 4 string}.  Returns bytes, or None when a record is outside what the native writer covers."""
+        2 float / 4 string}.  Returns bytes, or None when a record is outside what the native writer covers.
+        ``out_ring``: a dict the caller keeps for the run -- the output lands in one of TWO buffers held there, taken in
+        turn, instead of a fresh array per batch (a fresh 100 MB array is 25 000 page faults inside the formatter's
+        threads, which serialise in the kernel).  The caller must be done with a result before the call after the
+        next one (dumpSTR's writer holds at most one block in flight)."""
         S, P = self.gt.shape[1], self.gt.shape[2]
         gt = np.ascontiguousarray(self.gt)
         ph = np.ascontiguousarray(self.phased)
@@ -247,8 +251,16 @@ class RawBatch:
         # tight one (x 1.3 alone) made the writer run twice on every batch whose calls mostly pass.
         cap = (int((int(self.b.line_end[self.n - 1]) - int(self.b.line_off[0])) * 1.35) + self.n * S * 12 + (1 << 16)
                if self.n else 16)
+        slot = None
+        if out_ring is not None:
+            slot = out_ring['i'] = (out_ring.get('i', -1) + 1) % 2
         while True:
-            buf = np.empty(cap, dtype=np.uint8)          # not zero-filled; handed to the writer as a memoryview
+            if slot is None:
+                buf = np.empty(cap, dtype=np.uint8)      # not zero-filled; handed to the writer as a memoryview
+            else:
+                buf = out_ring.get(slot)
+                if buf is None or buf.size < cap:
+                    buf = out_ring[slot] = np.empty(cap + cap // 8, dtype=np.uint8)
             n = lib.trk_vcf_dumpstr_lines(C.byref(self.b), C.byref(prm), buf.ctypes.data, cap, C.byref(err))
             if n >= 0:
                 return memoryview(buf)[:n]
