@@ -638,7 +638,9 @@ def config1_extra(eng, no_check, iters=50):
                                  "5: count, counter reset, finaliser, HWE tests, HWE serial remainder"),
            "kernels_ms": ({"k_locus_count_v3<fin>": cnt_ms, "k_hwe_test_slots": fin_ms} if fused else
                           {"k_locus_count": cnt_ms, "k_locus_finalize+k_hwe_test": fin_ms}),
-           "roofline": {"bound": "hbm", "kernel": "k_locus_count", "bytes_per_cell": 4,
+           "roofline": {"bound": "hbm", "kernel": ("k_locus_count_v3<4,4,true> (the finaliser is its epilogue: the time "
+                                                   "is count + finaliser)" if fused else "k_locus_count"),
+                        "bytes_per_cell": 4,
                         "achieved": Lc * S * 4 / (cnt_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": Lc * S * 4 / (cnt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "note": "40 MB per launch: 5 us at the HBM peak -- launch-latency regime; the long-stream "
