@@ -280,3 +280,26 @@ def test_read_ahead_leaves_both_command_lines_outputs_alone(tmp_path, monkeypatc
     _run_stat(tmp_path, OracleCompute(), os.path.join(SYN, 'synth_hipstr.vcf'), 'hipstr', hwep=True)
     name = sorted(set(DUMP_CASES) - BIG_CASES - FALLBACK_CASES)[0]
     _run_dump(tmp_path, OracleCompute(), name)
+
+
+def test_plot_afreq_keeps_the_table_on_the_batch_pipeline(tmp_path):
+    """--plot-afreq (statSTR.py:603-607): the first eleven reported records are plotted from a short read of their
+    own; the table comes from the batch pipeline and equals the one of a run without plots."""
+    pytest.importorskip('matplotlib')
+    import glob
+    from oracle_compute import OracleCompute
+    from trtools_amd import runtime
+    from trtools_amd.statSTR import statSTR
+    path = os.path.join(SYN, 'synth_hipstr.vcf')
+    old = runtime.set_compute(OracleCompute())
+    try:
+        plain = str(tmp_path / 'plain')
+        assert statSTR.main(_stat_args(path, plain, 'hipstr')) == 0
+        out = str(tmp_path / 'plots')
+        assert statSTR.main(_stat_args(path, out, 'hipstr', plot_afreq=True)) == 0
+        assert statSTR.LAST_RUN['path'] == 'batch'
+    finally:
+        runtime.set_compute(old)
+    assert open(out + '.tab').read() == open(plain + '.tab').read()
+    n_records = open(plain + '.tab').read().count('\n') - 1
+    assert len(glob.glob(out + '-*.pdf')) == min(11, n_records) > 0

@@ -240,11 +240,35 @@ def _flush(batch, group_masks, fmt, outf, nalleles_thresh):
 def _batch_path_ok(args, invcf, vcftype):
     """The batch pipeline (native reader -> native batch harmoniser -> device -> native row formatter: no Python
     object per record) covers the callers whose records carry allele SEQUENCES, with or without a --region query
-    (index seek, then batches cut at the region's end); everything else and plots take the per-record loop below.
+    (index seek, then batches cut at the region's end); everything else takes the per-record loop below.
+    --plot-afreq does not change the path: its eleven plots come from a short read of their own (_plot_first).
     TRK_STATSTR_BATCH=0 forces the per-record loop."""
     from ..vcfnative import NativeVCFReader, VT_CODES
     return (isinstance(invcf, NativeVCFReader) and vcftype.name in VT_CODES and
-            not args.plot_afreq and len(invcf.samples) > 0 and os.environ.get('TRK_STATSTR_BATCH', '1') != '0')
+            len(invcf.samples) > 0 and os.environ.get('TRK_STATSTR_BATCH', '1') != '0')
+
+
+def _plot_first(args, vcftype, group_masks, sample_prefixes):
+    """--plot-afreq (statSTR.py:603-607): allele-frequency plots of the first eleven records the run reports
+    (``num_plotted <= 10``), from a reader of their own -- the table itself stays on the batch pipeline instead of
+    sending the whole file through record objects for the sake of eleven plots."""
+    from .plots import PlotAlleleFreqs
+    rd = utils.LoadSingleReader(args.vcf, checkgz=args.region is not None)
+    if rd is None:
+        return
+    try:
+        num_plotted = 0
+        for record in (rd(args.region) if args.region else rd):
+            trrecord = trh.HarmonizeRecord(vcftype, record)
+            if args.only_passing and record.FILTER is not None:
+                continue
+            PlotAlleleFreqs(trrecord, args.out, sample_indexes=group_masks, sampleprefixes=sample_prefixes)
+            num_plotted += 1
+            if num_plotted > 10:
+                break
+    finally:
+        if hasattr(rd, 'close'):
+            rd.close()
 
 
 # what the last main() call ran through (bench.py's end-to-end extra and the tests read it): 'batch' = the batch
@@ -405,14 +429,14 @@ def main(args):
         shard = _ShardedOut(outf)
         if shard.rank == 0:
             outf.write("\t".join(header) + "\n")
-        if not args.plot_afreq:
-            shard.attach(invcf, args.region)
+        shard.attach(invcf, args.region)
+        if args.plot_afreq and shard.rank == 0:
+            _plot_first(args, vcftype, group_masks, sample_prefixes)
         region = invcf(args.region) if args.region else invcf
         n_samples = max(len(invcf.samples), 1)
         batch_loci = max(1, min(4096, BATCH_CELLS // n_samples))
         start_time = time.time()
         nrecords = 0
-        num_plotted = 0
         batch = []
         LAST_RUN.clear()
         LAST_RUN.update(path='per-record', batches=0, fallback_batches=0)
@@ -426,10 +450,6 @@ def main(args):
             trrecord = trh.HarmonizeRecord(vcftype, record)
             if args.only_passing and record.FILTER is not None:
                 continue
-            if args.plot_afreq and num_plotted <= 10:
-                from .plots import PlotAlleleFreqs
-                PlotAlleleFreqs(trrecord, args.out, sample_indexes=group_masks, sampleprefixes=sample_prefixes)
-                num_plotted += 1
             batch.append((record, trrecord))
             if len(batch) >= batch_loci:
                 if shard.next_batch():
