@@ -242,7 +242,11 @@ typedef struct {
 } trk_stats_out;
 
 /* (a3)(a5)-(a9) of SURVEY.md section 8: for every locus and sample group the
- * allele histogram and every statSTR statistic.                                  */
+ * allele histogram and every statSTR statistic.
+ * Ungrouped diploid batches of rows <= 2048 samples take two launches (the finaliser is
+ * the count kernel's epilogue, the HWE tests a second kernel; same bits as the general
+ * sequence count / finaliser / tests -- TRK_FUSED_STATS=0 in the environment selects the
+ * latter); every other batch the general sequence.                                      */
 int trk_locus_stats(trk_ctx* ctx, const trk_batch* in, const trk_stats_params* prm,
                     trk_stats_out* out);
 
