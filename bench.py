@@ -744,6 +744,10 @@ def config2_extra(eng, no_check, iters=5):
     Lc, S = 50000, 5000
     sb = SynthBatch(eng, Lc, S, seed=20260928 + 2, planes=('dp', 'q'), pure_repeats=True)
     sb.add_gangstr_planes()
+    # rows on 128-byte boundaries (24 no-call padding samples: 5024 per device row), as compute.DeviceCompute uploads
+    # a cohort -- a 5000-sample row is 20 000 bytes, three rows of four start inside a cache line (planar pass
+    # 3.16 -> 2.91 ms, same box); every rate counts the 5000 real samples
+    sb.pad_rows(max(4, int(os.environ.get('TRK_ROW_ALIGN', '32')) & ~3))
     names = ['dp', 'q', 'qexp', 'rc', 'repcn', 'repci']
     inter = [sb.dev[n] for n in names]
     planes = [eng.planarize(p) for p in inter]
@@ -772,10 +776,10 @@ def config2_extra(eng, no_check, iters=5):
     cf = pg['k_call_filter'][1] / pg['k_call_filter'][0]
     moved = 4 + 4 + 4 + 8 + 8 + 8 + 16 + 8   # GT, DP, Q, QEXP[1:3], RC[1], RC[3], REPCN, REPCI; GT' + mask
     out = {"workload": "dumpSTR, GangSTR shape, 9 call filters + 4 locus filters, %d loci x %d samples "
-                       "(BASELINE configs[2]), FORMAT planes planar" % (Lc, S),
+                       "(BASELINE configs[2]), FORMAT planes planar, %d samples per device row" % (Lc, S, sb.n_dev),
            "ms_per_pass": w * 1e3, "loci_per_s": Lc / w, "calls_per_s": Lc * S / w,
            "kernels_ms": {k: (v[1] / v[0]) for k, v in pg.items() if v[0]},
-           "roofline": {"bound": "hbm", "kernel": "k_call_filter_fast", "bytes_per_cell_moved": moved,
+           "roofline": {"bound": "hbm", "kernel": "k_call_filter_gs<true,true,511>", "bytes_per_cell_moved": moved,
                         "bytes_per_cell_nominal": 72,
                         "achieved": Lc * S * moved / (cf * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": Lc * S * moved / (cf * 1e-3) / 1e9 / HBM_PEAK_GBS}}
@@ -793,7 +797,8 @@ def config2_extra(eng, no_check, iters=5):
             return out_c.gt_out.get_rows(lo, hi), out_c.filter_mask.get_rows(lo, hi)
 
         t0 = time.perf_counter()
-        r = fullsize.check_step(fetch_inputs, fetch_outputs, Lc, S, sb.tables, filters, 0, locus_args, dev, block=2048)
+        r = fullsize.check_step(fetch_inputs, fetch_outputs, Lc, sb.n_dev, sb.tables, filters, 0, locus_args, dev,
+                                block=2048, n_pad=sb.n_pad)
         out["parity_rows_checked"] = r['loci']
         out["parity_calls_bit_for_bit"] = r['calls_bit_for_bit']
         out["parity_worst_float_rel"] = r['worst_float_rel']

@@ -24,6 +24,8 @@ print("configs[1] statSTR 10k x 1k: %.3f ms/pass = %.2e loci/s (%.2e calls/s); c
 Lc, S = 50000, 5000
 sb = SynthBatch(eng, Lc, S, seed=20260928 + 2, planes=('dp', 'q'), pure_repeats=True)
 sb.add_gangstr_planes()
+if os.environ.get('TRK_C2_PAD', '1') != '0':    # rows on 128-byte boundaries, as compute.DeviceCompute uploads a cohort
+    sb.pad_rows(32)
 planes = [sb.dev['dp'], sb.dev['q'], sb.dev['qexp'], sb.dev['rc'], sb.dev['repcn'], sb.dev['repci']]
 filters = [dict(op=L.F_LT, plane_a=0, thr=10), dict(op=L.F_GT, plane_a=0, thr=60), dict(op=L.F_LT, plane_a=1, thr=0.9),
            dict(op=L.F_CALLED_LT, plane_a=2, col_a=1, thr=0.05), dict(op=L.F_CALLED_LT, plane_a=2, col_a=2, thr=0.05),
@@ -50,7 +52,7 @@ for layout in ('interleaved', 'planar'):
     cf = pg['k_call_filter'][1] / pg['k_call_filter'][0]
     print("configs[2] dumpSTR GangSTR 50k x 5k [%s]: %.3f ms/pass = %.2e loci/s (%.2e calls/s); call filter %.3f ms = %.0f GB/s "
           "(%d B/call), count %.3f ms, finalize+hwe %.3f ms" % (layout, w * 1e3, Lc / w, Lc * S / w, cf,
-          Lc * S * bpc / (cf * 1e-3) / 1e9, bpc, pg['k_locus_count'][1] / pg['k_locus_count'][0],
+          Lc * S * (bpc if layout == 'interleaved' else 60) / (cf * 1e-3) / 1e9, bpc if layout == 'interleaved' else 60, pg['k_locus_count'][1] / pg['k_locus_count'][0],
           pg['k_locus_finalize'][1] / pg['k_locus_finalize'][0]))
     got = [out.sample_counters.get(), out.filter_mask.get(), out.gt_out.get(), st.locus_int.get()]
     if ref_bits is None:

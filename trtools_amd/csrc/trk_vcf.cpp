@@ -2154,7 +2154,10 @@ int64_t trk_vcf_dumpstr_lines(const trk_vcf_batch* b, const trk_vcf_dumpstr* in,
             o.push_back('\n');
         }
     };
-    const int nt = std::max(1, std::min({in->n_threads > 0 ? in->n_threads : 32, 64, n}));
+    int want = in->n_threads > 0 ? in->n_threads : 32;
+    if (in->n_threads <= 0)
+        if (const char* e = getenv("TRK_FMT_THREADS")) want = std::max(1, atoi(e));    // formatter threads (default 32)
+    const int nt = std::max(1, std::min({want, 128, n}));
     std::vector<std::thread> th;
     for (int t = 1; t < nt; ++t) th.emplace_back(runner);
     runner();
