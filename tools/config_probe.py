@@ -63,6 +63,8 @@ for layout in ('interleaved', 'planar'):
 del sb, planes, st, out
 Lc, S = 100000, 10000
 sb = SynthBatch(eng, Lc, S, seed=20260928 + 3, planes=('dp', 'q', 'dstutter', 'dflankindel'))
+if os.environ.get('TRK_C2_PAD', '1') != '0':
+    sb.pad_rows(32)
 planes = [sb.dev['dp'], sb.dev['q'], sb.dev['dstutter'], sb.dev['dflankindel']]
 filters = [dict(op=L.F_RATIO_GT, plane_a=3, plane_b=0, thr=0.15), dict(op=L.F_RATIO_GT, plane_a=2, plane_b=0, thr=0.15),
            dict(op=L.F_LT, plane_a=0, thr=10), dict(op=L.F_GT, plane_a=0, thr=55), dict(op=L.F_LT, plane_a=1, thr=0.9)]

@@ -8,6 +8,8 @@ from trtools_amd.synth import SynthBatch
 eng = Engine(0)
 for L, S in ((1000, 1000), (10000, 1000), (30000, 2000), (100000, 1000), (400000, 1000), (100000, 2048)):
     sb = SynthBatch(eng, L, S, seed=5, planes=())
+    if os.environ.get('PAD') == '1':
+        sb.pad_rows(32)
     res = eng.alloc_stats(sb.batch)
     row = []
     for mode in ('0', '100000000'):
