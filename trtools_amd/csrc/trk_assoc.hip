@@ -1757,24 +1757,25 @@ __global__ __launch_bounds__(256) void k_dosages(trk_batch b, const double* __re
 // classes of equal length were merged as integer counts; classes whose rounded lengths
 // coincide are merged as float frequencies, added in ascending order.
 struct AfStream {
-    const int32_t* cc;          // class counts of this locus
+    const int32_t* cc;          // class counts of this locus (entry c at cc[c * cs])
     const uint16_t* rcls;       // rounded class of each length class
     int ncls, c;
     double total;
+    int cs = 1;
     __device__ void reset() { c = 0; }
     __device__ bool next(double& f) {
-        while (c < ncls && cc[c] == 0) ++c;
+        while (c < ncls && cc[c * cs] == 0) ++c;
         if (c >= ncls) return false;
         const int r = rcls[c];
-        f = (double)cc[c] / total;
+        f = (double)cc[c * cs] / total;
         ++c;
         while (c < ncls) {
-            if (cc[c] == 0) {
+            if (cc[c * cs] == 0) {
                 ++c;
                 continue;
             }
             if (rcls[c] != r) break;
-            f += (double)cc[c] / total;
+            f += (double)cc[c * cs] / total;
             ++c;
         }
         return true;
@@ -1810,6 +1811,7 @@ struct PwSum {
         return res;
     }
     __device__ double sum(int n) {
+        if (n <= 128) return leaf(n);   // (every locus with <= 128 alleles: the explicit stack below -- scratch -- is not touched)
         int fn[24], stage[24];
         double left[24];
         int sp = 0;
@@ -1857,6 +1859,8 @@ struct FinArgs {
     double* locus_f64;
     double cutoff;
     int M, NS, NC, nchunks;
+    int cc_lds, cc_lds_off;      // cc_lds: class counts in thread-private LDS columns ([class][thread] int32), which start
+                                 // cc_lds_off doubles x blockDim.x into the block's dynamic LDS; else the global scratch `cc`
     int dosage;                  // 1: no allele-frequency filters here (the caller applies them)
     int wave_regress;            // 1: the regression is left to k_assoc_regress_wave (wide designs)
 };
@@ -1892,17 +1896,24 @@ __global__ __launch_bounds__(FIN_T) void k_assoc_finalize(const FinArgs a) {
     // ---- allele frequencies and the locus filters --------------------------------------------
     const int off = a.b.allele_off[l];
     const int A = a.b.allele_off[l + 1] - off;
-    int32_t* cc = a.cc + off;
+    // (LDS columns: the read-add-write of a class count is an LDS round trip, not a global one -- this kernel is a
+    // chain of latencies, one thread per locus at 1.5 waves per SIMD)
+    const bool cc_lds = a.cc_lds && A <= a.b.max_alleles;   // (a locus beyond the stated maximum keeps the global scratch)
+    int32_t* cc = cc_lds ? reinterpret_cast<int32_t*>(fin_lds + (size_t)a.cc_lds_off * blockDim.x) + threadIdx.x
+                         : a.cc + off;
+    const int cs = cc_lds ? (int)blockDim.x : 1;
+    if (cc_lds)
+        for (int i = 0; i < A; ++i) cc[i * cs] = 0;
     int64_t total = 0;
     for (int i = 0; i < A; ++i) {
         const int cnt = a.allele_count[off + i];
         if (cnt) {
-            cc[a.b.len_class[off + i]] += cnt;
+            cc[a.b.len_class[off + i] * cs] += cnt;
             total += cnt;
         }
     }
     li[TRK_AI_N_HAPS] = (int)total;
-    AfStream st{cc, a.rlen_class + off, A, 0, (double)total};
+    AfStream st{cc, a.rlen_class + off, A, 0, (double)total, cs};
     int R = 0, argmax = 0;
     double fmax = -1.0, f;
     st.reset();
@@ -2596,7 +2607,13 @@ hipError_t launch_assoc_finalize(const trk_batch& b, const trk_assoc_params& prm
     const int P = prm.n_vec + 1;
     int fin_t = FIN_T;
     while (fin_t > 8 && !f.wave_regress && (size_t)(P * (P + 1) / 2 + P) * fin_t * 8 > 150 * 1024) fin_t >>= 1;
-    const size_t fin_lds = f.wave_regress ? 0 : (size_t)(P * (P + 1) / 2 + P) * fin_t * 8;   // the normal matrix lives in k_assoc_regress_wave
+    size_t fin_lds = f.wave_regress ? 0 : (size_t)(P * (P + 1) / 2 + P) * fin_t * 8;   // the normal matrix lives in k_assoc_regress_wave
+    f.cc_lds = f.cc_lds_off = 0;
+    if (b.max_alleles > 0 && fin_lds + (size_t)b.max_alleles * fin_t * 4 <= 64 * 1024) {   // class counts in LDS columns
+        f.cc_lds = 1;
+        f.cc_lds_off = f.wave_regress ? 0 : P * (P + 1) / 2 + P;
+        fin_lds += (size_t)b.max_alleles * fin_t * 4;
+    }
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assoc_finalize),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds);
     if (err != hipSuccess) return err;
@@ -2639,6 +2656,7 @@ hipError_t launch_assoc_dosage(const trk_batch& b, const trk_assoc_params& prm, 
         hipLaunchKernelGGL(k_assoc_dosage, dim3((b.n_loci + 3) / 4), dim3(256), 0, stream, a, q);
     if ((err = hipGetLastError()) != hipSuccess) return err;
     f.dosage = 1;
+    f.cc_lds = f.cc_lds_off = 0;
     const int P = prm.n_vec + 1;
     int fin_t = FIN_T;
     while (fin_t > 8 && (size_t)(P * (P + 1) / 2 + P) * fin_t * 8 > 150 * 1024) fin_t >>= 1;
