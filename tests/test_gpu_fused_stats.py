@@ -105,3 +105,33 @@ def test_large_batches_and_the_limit_knob(eng):
     finally:
         del os.environ['TRK_FUSED_STATS']
     _same(chain, capped)
+
+
+@pytest.mark.parametrize("ploidy,n_groups,S", [(2, 0, 5000), (2, 3, 1000), (1, 0, 257), (3, 2, 300), (2, 8, 64), (4, 0, 90)])
+def test_cooperative_finaliser_equals_the_one_thread_finaliser(eng, ploidy, n_groups, S):
+    """k_locus_finalize_coop (sixteen lanes per (group, locus), what batches of up to 4096 rows and <= 64 alleles per
+    locus take after the general count kernels) against k_locus_finalize (TRK_FIN_COOP=0): every output bit for bit --
+    ploidy 1-4 with a ploidy table, sample groups, the wave-per-locus count kernel's long rows."""
+    from test_gpu_stats import _random_batch
+    rng = np.random.default_rng(31 * ploidy + 7 * n_groups + S)
+    n_loci = 37
+    gt, lens, strs, lp, (off, lc, sc, cv) = _random_batch(rng, n_loci, S, ploidy, 11, with_low=(ploidy > 2))
+    gt[2] = -1
+    gb = None
+    if n_groups:
+        gb = np.zeros(S, dtype=np.uint8)
+        for g in range(n_groups):
+            gb |= (rng.random(S) < 0.4).astype(np.uint8) << g
+    b = eng.make_batch(gt, off, lc, sc, cv, locus_ploidy=lp if ploidy != 2 else None, group_bits=gb,
+                       n_groups=max(n_groups, 1))
+    os.environ['TRK_FUSED_STATS'] = '0'
+    try:
+        os.environ['TRK_FIN_COOP'] = '0'
+        try:
+            one = _fetch(eng.locus_stats(b, nalleles_thresh=0.03))
+        finally:
+            del os.environ['TRK_FIN_COOP']
+        coop = _fetch(eng.locus_stats(b, nalleles_thresh=0.03))
+    finally:
+        del os.environ['TRK_FUSED_STATS']
+    _same(one, coop)

@@ -816,6 +816,230 @@ struct V3Fin {
     int fin_words;      // 32-bit words of one locus's scratch: 2 * amax4 (class counts) + 10 * amax4 (five f64 arrays)
 };
 
+// What one locus's lanes need for the cooperative finaliser (coop_finalize): counts by allele index and the
+// alleles' classes (LDS or global), 12 * amax4 words of LDS scratch, the row predicates of the count pass.
+struct CoopFin {
+    const uint32_t* cnt;        // [A] called haplotypes per allele index
+    const uint32_t* cls;        // [A] length class | sequence class << 16
+    const double* cv;           // [A] class values (lengths), global
+    uint32_t* scratch;          // LDS, 12 * amax4 words, 8-byte aligned, this locus's own
+    int amax4;
+    int row, n_rows;            // output row (g * L + l) and rows in all (slot addressing)
+    int pl, ns_real;            // ploidy of the locus; samples of the group
+    double nalleles_thresh;
+    int32_t* locus_int;
+    double* locus_f64;
+    unsigned int* hwe_count;    // compact work list when not null, else fixed slots
+    HweItem* items;
+};
+
+template <int LPL>
+__device__ __forceinline__ void coop_finalize(const CoopFin& fa, bool live, bool any_dup, int sl, int lane0, int A,
+                                              int n_called, int n_low, int n_homl, int n_homs, int n_bad) {
+    const int A4 = (A + 3) & ~3, M4 = fa.amax4;
+    int32_t* ccl = reinterpret_cast<int32_t*>(fa.scratch);
+    int32_t* ccs = ccl + M4;
+    double* Fl = reinterpret_cast<double*>(ccs + M4);   // f = n / total by class, alleles by length
+    double* T1 = Fl + M4;                               // f^2, then -(pk ln pk), then f (v - mean)^2
+    double* Fs = T1 + M4;                               // by sequence: f, then -(pk ln pk)
+    double* T3 = Fs + M4;                               // by sequence f^2, then v f (the mean's terms)
+    double* CV = T3 + M4;                               // class values (lengths)
+    for (int a = sl; a < A4; a += LPL) {
+        ccl[a] = 0;
+        ccs[a] = 0;
+    }
+    wave_lds_fence();
+    int tot = 0;
+    for (int a = sl; a < A; a += LPL) {
+        const int n = (int)fa.cnt[a];
+        const uint32_t cls = fa.cls[a];
+        __hip_atomic_fetch_add(&ccl[cls & 0xffffu], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&ccs[cls >> 16], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        tot += n;
+    }
+    const int total = seg_sum<LPL>(tot);
+    wave_lds_fence();
+    const double nan = __builtin_nan("");
+    const double ft = (double)total;      // float(sum(counts))   (tr_harmonizer.py:1539)
+    const double* cvg = fa.cv;
+    // pass 1 (parallel): f and f^2 per class; nalleles, last non-empty class, first most frequent class
+    // the two partitions give the same class counts in the same order at most loci (then one set of sums serves
+    // both, as in k_locus_finalize); equal only as multisets -- alleles sorted by sequence against by length --
+    // means another summation order: both sets are taken
+    int mism = n_homl != n_homs;
+    for (int c = sl; c < A; c += LPL) mism |= ccl[c] != ccs[c];
+    const bool same = seg_max<LPL>(mism) == 0;
+    const bool both = __ballot(!same) != 0ull;
+    int na_l = 0, na_s = 0, last = -1, bestn = 0;
+    for (int c = sl; c < A4; c += LPL) {
+        const int nl = c < A ? ccl[c] : 0, ns = c < A ? ccs[c] : 0;
+        const double fl = nl ? (double)nl / ft : 0.0;
+        Fl[c] = fl;
+        T1[c] = fl * fl;
+        CV[c] = c < A ? cvg[c] : 0.0;
+        na_l += (nl != 0) & (fl >= fa.nalleles_thresh);     // statSTR.py:207
+        if (nl) last = c;
+        bestn = nl > bestn ? nl : bestn;
+        if (both) {
+            const double fs = ns ? (double)ns / ft : 0.0;
+            Fs[c] = fs;
+            T3[c] = fs * fs;
+            na_s += (ns != 0) & (fs >= fa.nalleles_thresh);
+        }
+    }
+    na_l = seg_sum<LPL>(na_l);
+    last = seg_max<LPL>(last);
+    bestn = seg_max<LPL>(bestn);
+    int best = 0x7fffffff;    // first maximum == min over ties (utils.py:263-271)
+    for (int c = sl; c < A; c += LPL)
+        if (ccl[c] == bestn) { best = c; break; }
+    best = -seg_max<LPL>(-best);
+    na_s = both ? seg_sum<LPL>(na_s) : na_l;
+    wave_lds_fence();
+    // chains 1: sum f, sum f^2 (both partitions)
+    const int j = sl & 3;
+    const double* base1 = j == 0 ? Fl : j == 1 ? T1 : j == 2 ? Fs : T3;
+    double fsum_l, sq_l, fsum_s, sq_s;
+    {
+        double acc = 0.0;
+        if (sl < (both ? 4 : 2))
+            for (int c = 0; c < A4; c += 4) {
+                const double x0 = base1[c], x1 = base1[c + 1], x2 = base1[c + 2], x3 = base1[c + 3];
+                acc += x0;
+                acc += x1;
+                acc += x2;
+                acc += x3;
+            }
+        fsum_l = __shfl(acc, lane0, WAVE);
+        sq_l = __shfl(acc, lane0 + 1, WAVE);
+        fsum_s = both ? __shfl(acc, lane0 + 2, WAVE) : fsum_l;
+        sq_s = both ? __shfl(acc, lane0 + 3, WAVE) : sq_l;
+    }
+    wave_lds_fence();
+    // pass 2 (parallel): -(pk ln pk) with pk = f / sum f (scipy.stats.entropy normalises), v f
+    for (int c = sl; c < A4; c += LPL) {
+        const double fl = Fl[c];
+        double e = 0.0;
+        if (fl != 0.0) {
+            const double pk = fl / fsum_l;
+            e = -(pk * log(pk));
+        }
+        T1[c] = e;
+        T3[c] = CV[c] * fl;           // utils.py:236
+        if (both) {
+            const double fs = Fs[c];
+            double es = 0.0;
+            if (fs != 0.0) {
+                const double pk = fs / fsum_s;
+                es = -(pk * log(pk));
+            }
+            Fs[c] = es;
+        }
+    }
+    wave_lds_fence();
+    const double* base2 = j == 0 ? T1 : j == 1 ? T3 : Fs;
+    double ent_l, ent_s, mean;
+    {
+        double acc = 0.0;
+        if (sl < (both ? 3 : 2))
+            for (int c = 0; c < A4; c += 4) {
+                const double x0 = base2[c], x1 = base2[c + 1], x2 = base2[c + 2], x3 = base2[c + 3];
+                acc += x0;
+                acc += x1;
+                acc += x2;
+                acc += x3;
+            }
+        ent_l = __shfl(acc, lane0, WAVE);
+        mean = __shfl(acc, lane0 + 1, WAVE);
+        ent_s = both ? __shfl(acc, lane0 + 2, WAVE) : ent_l;
+    }
+    wave_lds_fence();
+    // pass 3: the variance's terms, f (v - mean)^2   (utils.py:296)
+    for (int c = sl; c < A4; c += LPL) {
+        const double d = CV[c] - mean;
+        T1[c] = Fl[c] * (d * d);
+    }
+    wave_lds_fence();
+    double var;
+    {
+        double acc = 0.0;
+        if (sl == 0)
+            for (int c = 0; c < A4; c += 4) {
+                const double x0 = T1[c], x1 = T1[c + 1], x2 = T1[c + 2], x3 = T1[c + 3];
+                acc += x0;
+                acc += x1;
+                acc += x2;
+                acc += x3;
+            }
+        var = __shfl(acc, lane0, WAVE);
+    }
+    // the rows (mode_stats / k_locus_finalize)
+    const bool have = total > 0;
+    const bool ok_l = have && fabs(1.0 - fsum_l) <= 0.001, ok_s = have && fabs(1.0 - fsum_s) <= 0.001;   // utils.py:140
+    ent_l /= 0.693147180559945309417232;
+    ent_s /= 0.693147180559945309417232;
+    ent_l = ent_l == 0.0 ? 0.0 : ent_l;
+    ent_s = ent_s == 0.0 ? 0.0 : ent_s;
+    const int st_base = n_called == 0 ? TRK_HWE_VALUE_ERROR : fa.pl < 2 ? TRK_HWE_INDEX_ERROR : n_low > 0 ? TRK_HWE_NAN : TRK_HWE_OK;
+    const int st_l = ok_l ? st_base : TRK_HWE_NAN, st_s = ok_s ? st_base : TRK_HWE_NAN;
+    if (live) {
+        const int ns_real = fa.ns_real;
+        double fv;
+        switch (sl) {
+            case TRK_LF_THRESH: fv = have && last >= 0 ? CV[last < 0 ? 0 : last] : nan; break;
+            case TRK_LF_MEAN: fv = ok_l ? mean : nan; break;
+            case TRK_LF_MODE: fv = ok_l ? CV[best >= A ? 0 : best] : nan; break;
+            case TRK_LF_VAR: fv = ok_l ? var : nan; break;
+            case TRK_LF_HET_LEN: fv = ok_l ? 1.0 - sq_l : nan; break;       // utils.py:175
+            case TRK_LF_HET_STR: fv = ok_s ? 1.0 - sq_s : nan; break;
+            case TRK_LF_ENTROPY_LEN: fv = ok_l ? ent_l : nan; break;
+            case TRK_LF_ENTROPY_STR: fv = ok_s ? ent_s : nan; break;
+            case TRK_LF_CALLRATE: fv = ns_real > 0 ? (double)n_called / (double)ns_real : nan; break;   // tr_harmonizer.py:946
+            case 11: fv = 0.0; break;
+            default: fv = nan; break;      // the two HWE p-values: k_hwe_test_slots
+        }
+        int iv;
+        switch (sl) {
+            case TRK_LI_N_CALLED: iv = n_called; break;
+            case TRK_LI_N_LOWPLOIDY: iv = n_low; break;
+            case TRK_LI_N_HOM_LEN: iv = n_homl; break;
+            case TRK_LI_N_HOM_STR: iv = n_homs; break;
+            case TRK_LI_N_ALLELES: iv = total; break;
+            case TRK_LI_N_BAD: iv = n_bad; break;
+            case TRK_LI_HWE_STATUS_LEN: iv = st_l; break;
+            case TRK_LI_HWE_STATUS_STR: iv = st_s; break;
+            case TRK_LI_N_SAMPLES: iv = ns_real; break;
+            case TRK_LI_NALLELES_LEN: iv = have ? na_l : 0; break;
+            case TRK_LI_NALLELES_STR: iv = have ? na_s : 0; break;
+            default: iv = 0; break;
+        }
+        if (sl < TRK_LF_COLS) {
+            fa.locus_f64[(int64_t)fa.row * TRK_LF_COLS + sl] = fv;
+            fa.locus_int[(int64_t)fa.row * TRK_LI_COLS + sl] = iv;
+        }
+        if (fa.hwe_count) {   // compact work list (k_hwe_test<W>), as k_locus_finalize pushes it
+            if (sl == 12 && st_l == TRK_HWE_OK) {
+                const HweItem it = {fa.row, same ? 3 : 1, n_homl, n_called, sq_l};
+                fa.items[atomicAdd(fa.hwe_count, 1u)] = it;
+            }
+            if (sl == 13 && !same && st_s == TRK_HWE_OK) {
+                const HweItem it = {fa.row, 2, n_homs, n_called, sq_s};
+                fa.items[atomicAdd(fa.hwe_count, 1u)] = it;
+            }
+        } else {              // fixed slots (k_hwe_test_slots)
+            if (sl == 12) {
+                const HweItem it = {fa.row, st_l == TRK_HWE_OK ? (same ? 3 : 1) : 0, n_homl, n_called, sq_l};
+                fa.items[fa.row] = it;
+            }
+            if (sl == 13) {
+                const HweItem it = {fa.row, (!same && st_s == TRK_HWE_OK) ? 2 : 0, n_homs, n_called, sq_s};
+                fa.items[fa.n_rows + fa.row] = it;
+            }
+        }
+    }
+}
+
+
 template <int R, int U, bool FIN = false>
 __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v3(
     trk_batch b, int32_t* __restrict__ allele_count, int32_t* __restrict__ locus_int, int nbmax,
@@ -915,197 +1139,22 @@ __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v3(
         const int hom_idx = (int)n_eq - c11 - c00;
         const int n_called = S - (h_m1 - c11), n_low = h_m2 - c00 - c10 - c01;
         const int n_homl = dup ? (int)n_hl - c11 - c00 : hom_idx, n_homs = dup ? (int)n_hs - c11 - c00 : hom_idx;
-        const int A4 = (A + 3) & ~3, M4 = fin.amax4;
-        const int lane0 = sub * LPL;
-        int32_t* ccl = reinterpret_cast<int32_t*>(wbase + sub * fin.fin_words);   // (over the folded histogram rows)
-        int32_t* ccs = ccl + M4;
-        double* Fl = reinterpret_cast<double*>(ccs + M4);   // f = n / total by class, alleles by length
-        double* T1 = Fl + M4;                               // f^2, then -(pk ln pk), then f (v - mean)^2
-        double* Fs = T1 + M4;                               // by sequence: f, then -(pk ln pk)
-        double* T3 = Fs + M4;                               // by sequence f^2, then v f (the mean's terms)
-        double* CV = T3 + M4;                               // class values (lengths)
-        for (int a = sl; a < A4; a += LPL) {
-            ccl[a] = 0;
-            ccs[a] = 0;
-        }
-        wave_lds_fence();
-        int tot = 0;
-        for (int a = sl; a < A; a += LPL) {
-            const int n = (int)h[a + 2];
-            const uint32_t cls = lut[a + 2];
-            __hip_atomic_fetch_add(&ccl[cls & 0xffffu], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&ccs[cls >> 16], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            tot += n;
-        }
-        const int total = seg_sum<LPL>(tot);
-        wave_lds_fence();
-        const double nan = __builtin_nan("");
-        const double ft = (double)total;      // float(sum(counts))   (tr_harmonizer.py:1539)
-        const double* cvg = b.len_class_value + off;
-        // pass 1 (parallel): f and f^2 per class; nalleles, last non-empty class, first most frequent class
-        // the two partitions give the same class counts in the same order at most loci (then one set of sums serves
-        // both, as in k_locus_finalize); equal only as multisets -- alleles sorted by sequence against by length --
-        // means another summation order: both sets are taken
-        int mism = n_homl != n_homs;
-        for (int c = sl; c < A; c += LPL) mism |= ccl[c] != ccs[c];
-        const bool same = seg_max<LPL>(mism) == 0;
-        const bool both = __ballot(!same) != 0ull;
-        int na_l = 0, na_s = 0, last = -1, bestn = 0;
-        for (int c = sl; c < A4; c += LPL) {
-            const int nl = c < A ? ccl[c] : 0, ns = c < A ? ccs[c] : 0;
-            const double fl = nl ? (double)nl / ft : 0.0;
-            Fl[c] = fl;
-            T1[c] = fl * fl;
-            CV[c] = c < A ? cvg[c] : 0.0;
-            na_l += (nl != 0) & (fl >= fin.nalleles_thresh);     // statSTR.py:207
-            if (nl) last = c;
-            bestn = nl > bestn ? nl : bestn;
-            if (both) {
-                const double fs = ns ? (double)ns / ft : 0.0;
-                Fs[c] = fs;
-                T3[c] = fs * fs;
-                na_s += (ns != 0) & (fs >= fin.nalleles_thresh);
-            }
-        }
-        na_l = seg_sum<LPL>(na_l);
-        last = seg_max<LPL>(last);
-        bestn = seg_max<LPL>(bestn);
-        int best = 0x7fffffff;    // first maximum == min over ties (utils.py:263-271)
-        for (int c = sl; c < A; c += LPL)
-            if (ccl[c] == bestn) { best = c; break; }
-        best = -seg_max<LPL>(-best);
-        na_s = both ? seg_sum<LPL>(na_s) : na_l;
-        wave_lds_fence();
-        // chains 1: sum f, sum f^2 (both partitions)
-        const int j = sl & 3;
-        const double* base1 = j == 0 ? Fl : j == 1 ? T1 : j == 2 ? Fs : T3;
-        double fsum_l, sq_l, fsum_s, sq_s;
-        {
-            double acc = 0.0;
-            if (sl < (both ? 4 : 2))
-                for (int c = 0; c < A4; c += 4) {
-                    const double x0 = base1[c], x1 = base1[c + 1], x2 = base1[c + 2], x3 = base1[c + 3];
-                    acc += x0;
-                    acc += x1;
-                    acc += x2;
-                    acc += x3;
-                }
-            fsum_l = __shfl(acc, lane0, WAVE);
-            sq_l = __shfl(acc, lane0 + 1, WAVE);
-            fsum_s = both ? __shfl(acc, lane0 + 2, WAVE) : fsum_l;
-            sq_s = both ? __shfl(acc, lane0 + 3, WAVE) : sq_l;
-        }
-        wave_lds_fence();
-        // pass 2 (parallel): -(pk ln pk) with pk = f / sum f (scipy.stats.entropy normalises), v f
-        for (int c = sl; c < A4; c += LPL) {
-            const double fl = Fl[c];
-            double e = 0.0;
-            if (fl != 0.0) {
-                const double pk = fl / fsum_l;
-                e = -(pk * log(pk));
-            }
-            T1[c] = e;
-            T3[c] = CV[c] * fl;           // utils.py:236
-            if (both) {
-                const double fs = Fs[c];
-                double es = 0.0;
-                if (fs != 0.0) {
-                    const double pk = fs / fsum_s;
-                    es = -(pk * log(pk));
-                }
-                Fs[c] = es;
-            }
-        }
-        wave_lds_fence();
-        const double* base2 = j == 0 ? T1 : j == 1 ? T3 : Fs;
-        double ent_l, ent_s, mean;
-        {
-            double acc = 0.0;
-            if (sl < (both ? 3 : 2))
-                for (int c = 0; c < A4; c += 4) {
-                    const double x0 = base2[c], x1 = base2[c + 1], x2 = base2[c + 2], x3 = base2[c + 3];
-                    acc += x0;
-                    acc += x1;
-                    acc += x2;
-                    acc += x3;
-                }
-            ent_l = __shfl(acc, lane0, WAVE);
-            mean = __shfl(acc, lane0 + 1, WAVE);
-            ent_s = both ? __shfl(acc, lane0 + 2, WAVE) : ent_l;
-        }
-        wave_lds_fence();
-        // pass 3: the variance's terms, f (v - mean)^2   (utils.py:296)
-        for (int c = sl; c < A4; c += LPL) {
-            const double d = CV[c] - mean;
-            T1[c] = Fl[c] * (d * d);
-        }
-        wave_lds_fence();
-        double var;
-        {
-            double acc = 0.0;
-            if (sl == 0)
-                for (int c = 0; c < A4; c += 4) {
-                    const double x0 = T1[c], x1 = T1[c + 1], x2 = T1[c + 2], x3 = T1[c + 3];
-                    acc += x0;
-                    acc += x1;
-                    acc += x2;
-                    acc += x3;
-                }
-            var = __shfl(acc, lane0, WAVE);
-        }
-        // the rows (mode_stats / k_locus_finalize)
-        const bool have = total > 0;
-        const bool ok_l = have && fabs(1.0 - fsum_l) <= 0.001, ok_s = have && fabs(1.0 - fsum_s) <= 0.001;   // utils.py:140
-        ent_l /= 0.693147180559945309417232;
-        ent_s /= 0.693147180559945309417232;
-        ent_l = ent_l == 0.0 ? 0.0 : ent_l;
-        ent_s = ent_s == 0.0 ? 0.0 : ent_s;
-        const int st_base = n_called == 0 ? TRK_HWE_VALUE_ERROR : n_low > 0 ? TRK_HWE_NAN : TRK_HWE_OK;   // (ploidy 2 here)
-        const int st_l = ok_l ? st_base : TRK_HWE_NAN, st_s = ok_s ? st_base : TRK_HWE_NAN;
-        if (live) {
-            const int ns_real = S - b.n_pad_samples;
-            double fv;
-            switch (sl) {
-                case TRK_LF_THRESH: fv = have && last >= 0 ? CV[last < 0 ? 0 : last] : nan; break;
-                case TRK_LF_MEAN: fv = ok_l ? mean : nan; break;
-                case TRK_LF_MODE: fv = ok_l ? CV[best >= A ? 0 : best] : nan; break;
-                case TRK_LF_VAR: fv = ok_l ? var : nan; break;
-                case TRK_LF_HET_LEN: fv = ok_l ? 1.0 - sq_l : nan; break;       // utils.py:175
-                case TRK_LF_HET_STR: fv = ok_s ? 1.0 - sq_s : nan; break;
-                case TRK_LF_ENTROPY_LEN: fv = ok_l ? ent_l : nan; break;
-                case TRK_LF_ENTROPY_STR: fv = ok_s ? ent_s : nan; break;
-                case TRK_LF_CALLRATE: fv = ns_real > 0 ? (double)n_called / (double)ns_real : nan; break;   // tr_harmonizer.py:946
-                case 11: fv = 0.0; break;
-                default: fv = nan; break;      // the two HWE p-values: k_hwe_test_slots
-            }
-            int iv;
-            switch (sl) {
-                case TRK_LI_N_CALLED: iv = n_called; break;
-                case TRK_LI_N_LOWPLOIDY: iv = n_low; break;
-                case TRK_LI_N_HOM_LEN: iv = n_homl; break;
-                case TRK_LI_N_HOM_STR: iv = n_homs; break;
-                case TRK_LI_N_ALLELES: iv = total; break;
-                case TRK_LI_N_BAD: iv = n_bad; break;
-                case TRK_LI_HWE_STATUS_LEN: iv = st_l; break;
-                case TRK_LI_HWE_STATUS_STR: iv = st_s; break;
-                case TRK_LI_N_SAMPLES: iv = ns_real; break;
-                case TRK_LI_NALLELES_LEN: iv = have ? na_l : 0; break;
-                case TRK_LI_NALLELES_STR: iv = have ? na_s : 0; break;
-                default: iv = 0; break;
-            }
-            if (sl < TRK_LF_COLS) {
-                fin.locus_f64[(int64_t)l * TRK_LF_COLS + sl] = fv;
-                locus_int[(int64_t)l * TRK_LI_COLS + sl] = iv;
-            }
-            if (sl == 12) {
-                const HweItem it = {l, st_l == TRK_HWE_OK ? (same ? 3 : 1) : 0, n_homl, n_called, sq_l};
-                fin.items[l] = it;
-            }
-            if (sl == 13) {
-                const HweItem it = {l, (!same && st_s == TRK_HWE_OK) ? 2 : 0, n_homs, n_called, sq_s};
-                fin.items[b.n_loci + l] = it;
-            }
-        }
+        CoopFin fa;
+        fa.cnt = h + 2;
+        fa.cls = lut + 2;
+        fa.cv = b.len_class_value + off;
+        fa.scratch = wbase + sub * fin.fin_words;       // (over the folded histogram rows)
+        fa.amax4 = fin.amax4;
+        fa.row = l;
+        fa.n_rows = b.n_loci;
+        fa.pl = 2;
+        fa.ns_real = S - b.n_pad_samples;
+        fa.nalleles_thresh = fin.nalleles_thresh;
+        fa.locus_int = locus_int;
+        fa.locus_f64 = fin.locus_f64;
+        fa.hwe_count = nullptr;
+        fa.items = fin.items;
+        coop_finalize<LPL>(fa, live, any_dup, sl, sub * LPL, A, n_called, n_low, n_homl, n_homs, n_bad);
     } else if (sl == 0 && live) {
         const uint32_t* h = hrow + cbase;
         const int h_m2 = (int)h[0 << 5], h_m1 = (int)h[1 << 5];
@@ -1557,6 +1606,64 @@ __global__ __launch_bounds__(FIN_THREADS) void k_locus_finalize(trk_batch b, con
     int ns = li[TRK_LI_N_SAMPLES];
     lf[TRK_LF_CALLRATE] = ns > 0 ? (double)n_called / (double)ns : nan;  // tr_harmonizer.py:946
     lf[11] = 0.0;
+}
+
+// ---------------------------------------------------------------------------
+// k_locus_finalize_coop : k_locus_finalize by SIXTEEN lanes per (group, locus) -- coop_finalize, the epilogue of the fused
+// small-batch pass, on counts that are already in memory (after any count kernel, after the call filters' delta
+// outputs).  Same bits as the one-thread kernel (same operations in the same order); the HWE tests go to the same
+// compact work list.  One thread per locus walks ~37 classes with a float64 division and a logarithm each, serially;
+// here the classes go side by side -- a shorter chain for a small batch (command-line batches of large cohorts are
+// 800-4000 loci), more instructions in all: launch_locus_finalize takes it up to 4096 rows.
+// ---------------------------------------------------------------------------
+constexpr int FC_LPL = 16, FC_THREADS = 256;
+__global__ __launch_bounds__(FC_THREADS) void k_locus_finalize_coop(trk_batch b, const int32_t* __restrict__ allele_count,
+                                                                    int32_t* __restrict__ locus_int,
+                                                                    double* __restrict__ locus_f64,
+                                                                    double nalleles_thresh, int amax4,
+                                                                    unsigned int* __restrict__ hwe_count,
+                                                                    HweItem* __restrict__ hwe_items) {
+    extern __shared__ uint32_t fc_lds[];
+    const int L = b.n_loci;
+    const int G = b.group_bits ? b.n_groups : 1;
+    const int64_t n_units = (int64_t)G * L;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int sl = lane % FC_LPL, sub = lane / FC_LPL;
+    const int64_t wave_unit0 = ((int64_t)blockIdx.x * FC_THREADS + (threadIdx.x & ~(WAVE - 1))) / FC_LPL;
+    if (wave_unit0 >= n_units) return;     // whole wave beyond the batch
+    const int64_t unit = wave_unit0 + sub;
+    const bool live = unit < n_units;
+    const int t = (int)(live ? unit : n_units - 1);
+    const int g = t / L, l = t - g * L;
+    const int off = b.allele_off[l];
+    const int A = b.allele_off[l + 1] - off;
+    uint32_t* cnt = fc_lds + (size_t)(threadIdx.x / FC_LPL) * 14 * amax4;
+    uint32_t* cls = cnt + amax4;
+    const int32_t* ac = allele_count + (int64_t)g * b.n_alleles_total + off;
+    for (int a = sl; a < A; a += FC_LPL) {
+        cnt[a] = (uint32_t)ac[a];
+        cls[a] = (uint32_t)b.len_class[off + a] | ((uint32_t)b.str_class[off + a] << 16);
+    }
+    const int32_t* li = locus_int + (int64_t)t * TRK_LI_COLS;
+    const int n_called = li[TRK_LI_N_CALLED], n_low = li[TRK_LI_N_LOWPLOIDY], n_homl = li[TRK_LI_N_HOM_LEN],
+              n_homs = li[TRK_LI_N_HOM_STR], n_bad = li[TRK_LI_N_BAD], ns = li[TRK_LI_N_SAMPLES];
+    wave_lds_fence();
+    CoopFin fa;
+    fa.cnt = cnt;
+    fa.cls = cls;
+    fa.cv = b.len_class_value + off;
+    fa.scratch = cls + amax4;
+    fa.amax4 = amax4;
+    fa.row = t;
+    fa.n_rows = (int)n_units;
+    fa.pl = b.locus_ploidy ? (int)b.locus_ploidy[l] : b.ploidy;
+    fa.ns_real = ns;
+    fa.nalleles_thresh = nalleles_thresh;
+    fa.locus_int = locus_int;
+    fa.locus_f64 = locus_f64;
+    fa.hwe_count = hwe_count;
+    fa.items = hwe_items;
+    coop_finalize<FC_LPL>(fa, live, true, sl, sub * FC_LPL, A, n_called, n_low, n_homl, n_homs, n_bad);
 }
 
 // Two neighbouring lanes per test: the kernel lasts as long as its slowest test, and a test is a chain of pmf
@@ -4031,7 +4138,18 @@ hipError_t launch_locus_finalize(const trk_batch& b, const int32_t* allele_count
     HweItem* items = reinterpret_cast<HweItem*>(reinterpret_cast<char*>(worklist) + 16);
     hipError_t e = hipMemsetAsync(count, 0, 16, stream);
     if (e != hipSuccess) return e;
-    if (maxA > 0 && maxA <= 96) {
+    // Sixteen lanes per locus shorten the LATENCY of a small batch (800 loci: 78 -> 51 us incl. the tests, 1677: 78 ->
+    // 58, 3355: 78 -> 67) and cost throughput on a large one (6000: 70 -> 75 us, 100k: 0.20 -> 0.70 ms -- the serial
+    // sums idle fifteen lanes): up to 4096 rows.  TRK_FIN_COOP = 0 never, N: up to N rows (tools/fin_coop_probe.py).
+    const char* coop_env = getenv("TRK_FIN_COOP");
+    const int64_t coop_max = coop_env ? atoll(coop_env) : 4096;
+    if (maxA > 0 && maxA <= 64 && n <= coop_max) {
+        const int amax4 = (maxA + 3) & ~3;
+        const size_t lds = (size_t)(FC_THREADS / FC_LPL) * 14 * amax4 * sizeof(uint32_t);
+        const int64_t per_wg = FC_THREADS / FC_LPL;
+        hipLaunchKernelGGL(k_locus_finalize_coop, dim3((unsigned)((n + per_wg - 1) / per_wg)), dim3(FC_THREADS), lds, stream, b,
+                           allele_count, locus_int, locus_f64, nalleles_thresh, amax4, count, items);
+    } else if (maxA > 0 && maxA <= 96) {
         size_t lds = (size_t)2 * maxA * FIN_THREADS * sizeof(int32_t);
         hipLaunchKernelGGL(k_locus_finalize<true>, dim3(blocks), dim3(FIN_THREADS), lds, stream, b, allele_count,
                            locus_int, locus_f64, scratch, nalleles_thresh, maxA, count, items);
