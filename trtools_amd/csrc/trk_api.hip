@@ -97,8 +97,8 @@ struct trk_ctx {
     size_t worklist_bytes_[TRK_N_STREAMS] = {};
     void* cf_ws_[TRK_N_STREAMS] = {};       // call-filter partial sample counters (per queue)
     size_t cf_ws_bytes_[TRK_N_STREAMS] = {};
-    void* assoc_ws = nullptr;    // associaTR scan workspace (Gram, partial records, class counts)
-    size_t assoc_ws_bytes = 0;
+    void* assoc_ws_[TRK_N_STREAMS] = {};   // per queue: scans on different queues run side by side    // associaTR scan workspace (Gram, partial records, class counts)
+    size_t assoc_ws_bytes_[TRK_N_STREAMS] = {};
     ncclComm_t comm = nullptr;
     int rank = 0, n_ranks = 1;
 };
@@ -241,7 +241,8 @@ void trk_free(trk_ctx* ctx) {
         if (ctx->join_event[i]) (void)hipEventDestroy(ctx->join_event[i]);
         if (ctx->streams[i]) (void)hipStreamDestroy(ctx->streams[i]);
     }
-    if (ctx->assoc_ws) (void)hipFree(ctx->assoc_ws);
+    for (int i = 0; i < TRK_N_STREAMS; ++i)
+        if (ctx->assoc_ws_[i]) (void)hipFree(ctx->assoc_ws_[i]);
     delete ctx;
 }
 
@@ -727,23 +728,23 @@ int trk_assoc_scan(trk_ctx* ctx, const trk_batch* in, const trk_assoc_params* pr
         return fail(ctx, TRK_ERR_ARG, "assoc outputs are NULL");
     (void)hipSetDevice(ctx->device);
     const size_t need = trk::assoc_workspace_bytes(*in, prm->n_vec);
-    if (need > ctx->assoc_ws_bytes) {
+    if (need > ctx->assoc_ws_bytes_[ctx->cur]) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->s()));
-        if (ctx->assoc_ws) (void)hipFree(ctx->assoc_ws);
-        ctx->assoc_ws = nullptr;
-        ctx->assoc_ws_bytes = 0;
-        hipError_t e = hipMalloc(&ctx->assoc_ws, need);
+        if (ctx->assoc_ws_[ctx->cur]) (void)hipFree(ctx->assoc_ws_[ctx->cur]);
+        ctx->assoc_ws_[ctx->cur] = nullptr;
+        ctx->assoc_ws_bytes_[ctx->cur] = 0;
+        hipError_t e = hipMalloc(&ctx->assoc_ws_[ctx->cur], need);
         if (e != hipSuccess) return fail(ctx, TRK_ERR_NOMEM, "assoc workspace hipMalloc(%zu): %s", need, hipGetErrorString(e));
-        ctx->assoc_ws_bytes = need;
+        ctx->assoc_ws_bytes_[ctx->cur] = need;
     }
-    HIPCHK(ctx, trk::launch_assoc_prepare(*in, *prm, *out, ctx->assoc_ws, ctx->s()));
+    HIPCHK(ctx, trk::launch_assoc_prepare(*in, *prm, *out, ctx->assoc_ws_[ctx->cur], ctx->s()));
     {
         ProfScope ps(ctx, TRK_K_ASSOC_SCAN);
-        HIPCHK(ctx, trk::launch_assoc_scan(*in, *prm, *out, ctx->assoc_ws, ctx->n_cu, ctx->s()));
+        HIPCHK(ctx, trk::launch_assoc_scan(*in, *prm, *out, ctx->assoc_ws_[ctx->cur], ctx->n_cu, ctx->s()));
     }
     {
         ProfScope ps(ctx, TRK_K_ASSOC_FINALIZE);
-        HIPCHK(ctx, trk::launch_assoc_finalize(*in, *prm, *out, ctx->assoc_ws, ctx->s()));
+        HIPCHK(ctx, trk::launch_assoc_finalize(*in, *prm, *out, ctx->assoc_ws_[ctx->cur], ctx->s()));
     }
     return TRK_OK;
 }
@@ -767,17 +768,17 @@ int trk_assoc_scan_dosage(trk_ctx* ctx, const trk_batch* in, const trk_assoc_par
     trk_batch bb = *in;
     bb.max_alleles = 0;
     const size_t need = trk::assoc_workspace_bytes(bb, prm->n_vec);
-    if (need > ctx->assoc_ws_bytes) {
+    if (need > ctx->assoc_ws_bytes_[ctx->cur]) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->s()));
-        if (ctx->assoc_ws) (void)hipFree(ctx->assoc_ws);
-        ctx->assoc_ws = nullptr;
-        ctx->assoc_ws_bytes = 0;
-        hipError_t e = hipMalloc(&ctx->assoc_ws, need);
+        if (ctx->assoc_ws_[ctx->cur]) (void)hipFree(ctx->assoc_ws_[ctx->cur]);
+        ctx->assoc_ws_[ctx->cur] = nullptr;
+        ctx->assoc_ws_bytes_[ctx->cur] = 0;
+        hipError_t e = hipMalloc(&ctx->assoc_ws_[ctx->cur], need);
         if (e != hipSuccess) return fail(ctx, TRK_ERR_NOMEM, "assoc workspace hipMalloc(%zu): %s", need, hipGetErrorString(e));
-        ctx->assoc_ws_bytes = need;
+        ctx->assoc_ws_bytes_[ctx->cur] = need;
     }
     ProfScope ps(ctx, TRK_K_ASSOC_SCAN);
-    HIPCHK(ctx, trk::launch_assoc_dosage(*in, *prm, *dos, *out, class_sums, locus_sums, ctx->assoc_ws, ctx->s()));
+    HIPCHK(ctx, trk::launch_assoc_dosage(*in, *prm, *dos, *out, class_sums, locus_sums, ctx->assoc_ws_[ctx->cur], ctx->s()));
     return TRK_OK;
 }
 
