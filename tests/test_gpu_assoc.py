@@ -262,3 +262,30 @@ def test_dosage_scan_against_oracle(eng):
     numpy's blocked float32 row sum), rounding collisions between alleles, sample subset, missing calls."""
     for seed, (L_, S, M, amax) in enumerate([(30, 300, 2, 4), (24, 257, 5, 14), (12, 128, 20, 3)]):
         run_dosage_case(eng, seed, L_, S, M, amax, min_ok=L_ // 3)
+
+
+def test_scans_on_two_queues_run_side_by_side(eng):
+    """The scan's workspace (Gram, partial records, class counts, work counter) is per queue: two different cohorts
+    scanned concurrently on queues 0 and 1, several rounds, return what each returns alone."""
+    from trtools_amd.synth import SynthBatch, pack_assoc_tables
+    cases = []
+    for k, (Lc, S) in enumerate(((3000, 2000), (2500, 1000))):
+        sb = SynthBatch(eng, Lc, S, seed=500 + k, planes=())
+        alen, rcls = pack_assoc_tables(sb.loci.allele_lens, 2)
+        y = np.random.default_rng(9 + k).normal(size=S)
+        y = (y - y.mean()) / y.std()
+        cases.append((sb, eng.upload(y[None, :].copy(), np.float64), eng.upload(alen, np.float64),
+                      eng.upload(rcls, np.uint16)))
+    alone = []
+    for sb, v, al, rc in cases:
+        r = eng.assoc_scan(sb.batch, v, al, rc, non_major_cutoff=5.0)
+        alone.append((r.locus_int.get().copy(), r.locus_f64.get().copy()))
+    outs = [None, None]
+    for _ in range(6):
+        for q, (sb, v, al, rc) in enumerate(cases):
+            with eng.on_queue(q):
+                outs[q] = eng.assoc_scan(sb.batch, v, al, rc, non_major_cutoff=5.0, out=outs[q])
+    eng.sync()
+    for q in range(2):
+        assert np.array_equal(outs[q].locus_int.get(), alone[q][0]), q
+        assert np.array_equal(outs[q].locus_f64.get(), alone[q][1], equal_nan=True), q
