@@ -356,8 +356,6 @@ def assoc_extra(wl, seed, no_check, no_cpu, iters=5, group=None, total_loci=None
         for it in range(2 * iters + 2):
             if it == 2:
                 eng.sync()
-                if group is not None:
-                    group.barrier()
                 t0 = time.perf_counter()
             with eng.on_queue(it % 2):
                 if it % 2:
@@ -365,12 +363,11 @@ def assoc_extra(wl, seed, no_check, no_cpu, iters=5, group=None, total_loci=None
                 else:
                     res = eng.assoc_scan(wl.sb.batch, vec_d, alen_d, rcls_d, non_major_cutoff=20.0, out=res)
         eng.sync()
-        w2 = (time.perf_counter() - t0) / (2 * iters)
-        if group is not None:
-            w2 = float(group.allreduce_max_f64(np.array([w2]))[0])
+        w2 = (time.perf_counter() - t0) / (2 * iters)      # (this rank's; no collective inside an optional extra)
         same = (np.array_equal(res2.locus_int.get(), res.locus_int.get()) and
                 np.array_equal(res2.locus_f64.get(), res.locus_f64.get(), equal_nan=True))
-        out["two_queues"] = {"what": "the same pass, two batches in flight on two queues (throughput, not latency)",
+        out["two_queues"] = {"what": "the same pass, two batches in flight on two queues (throughput, not latency; rank 0's "
+                                     "time, every rank scanning its shard)",
                              "ms_per_pass": w2 * 1e3, "loci_per_s": total_loci / w2, "identical_outputs": bool(same)}
         for d in (res2.locus_int, res2.locus_f64, res2.allele_count):
             d.free()
