@@ -1,0 +1,18 @@
+"""statSTR's command line on the file tools/e2e_probe.py generated: wall time of three runs, then one run with the
+reader's per-batch timing (TRK_VCF_TIMING) and a cProfile of the Python side."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from trtools_amd.statSTR import statSTR
+path = sys.argv[1]
+ns = argparse.Namespace(vcf=path, out='/tmp/e2e/stat', vcftype='hipstr', samples=None, sample_prefixes=None,
+                        plot_afreq=False, region=None, thresh=True, afreq=True, acount=True, hwep=True, het=True,
+                        entropy=True, mean=True, mode=True, var=True, numcalled=True, use_length=False, precision=4,
+                        nalleles=True, nalleles_thresh=0.01, only_passing=False)
+for i in range(3):
+    t = time.time(); statSTR.main(ns); print("run %d: %.3f s" % (i, time.time() - t), flush=True)
+os.environ['TRK_VCF_TIMING'] = '1'
+t = time.time(); statSTR.main(ns); print("timed run: %.3f s" % (time.time() - t), flush=True)
+del os.environ['TRK_VCF_TIMING']
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable(); statSTR.main(ns); pr.disable()
+pstats.Stats(pr).sort_stats('tottime').print_stats(14)

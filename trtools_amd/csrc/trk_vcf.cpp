@@ -123,12 +123,88 @@ const Deflater& deflater() {
 // ---------------------------------------------------------------------------------------
 // input: plain text, gzip stream, or BGZF (block-parallel inflate)
 // ---------------------------------------------------------------------------------------
+// A fixed set of worker threads that run one job at a time together with the caller: fill_bgzf inflates ~50 MB of text
+// per call, twenty calls per GB -- spawning and joining 63 threads each time was about half of the inflate time
+// (1 GB of text: 102 ms at 64 threads).
+class WorkerPool {
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void()>* job_ = nullptr;
+    uint64_t gen_ = 0;
+    int pending_ = 0;
+    bool stop_ = false;
+
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void()>* job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+                job = job_;
+            }
+            (*job)();
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+
+public:
+    WorkerPool() = default;
+    WorkerPool(const WorkerPool&) = delete;
+    WorkerPool& operator=(const WorkerPool&) = delete;
+    ~WorkerPool() { shutdown(); }
+    void shutdown() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+        th_.clear();
+        stop_ = false;
+    }
+    // runs `job` on up to n - 1 pool threads and on the caller; returns when every one of them has returned
+    void run(int n, const std::function<void()>& job) {
+        const int want = std::max(0, n - 1);
+        while ((int)th_.size() < want) th_.emplace_back([this] { loop(); });
+        if (!th_.empty()) {
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                job_ = &job;
+                pending_ = (int)th_.size();
+                ++gen_;
+            }
+            cv_.notify_all();
+        }
+        job();
+        if (!th_.empty()) {
+            std::unique_lock<std::mutex> lk(m_);
+            done_.wait(lk, [&] { return pending_ == 0; });
+        }
+    }
+};
+
 struct Source {
     FILE* fp = nullptr;
     gzFile gz = nullptr;
     bool bgzf = false, plain = false, eof = false;
     int n_threads = 1;
-    std::vector<unsigned char> cbuf;  // compressed bytes not yet consumed (BGZF)
+    // compressed bytes not yet consumed (BGZF).  Not a std::vector: resize() must not zero 8 MB that fread overwrites.
+    struct CBuf {
+        TextBuf b;
+        size_t size() const { return b.size(); }
+        unsigned char* data() { return reinterpret_cast<unsigned char*>(b.data()); }
+        const unsigned char* data() const { return reinterpret_cast<const unsigned char*>(b.data()); }
+        void clear() { b.clear(); }
+        void resize(size_t n) { b.resize(n); }
+        void drop_front(size_t n) { b.erase(0, n); }
+    } cbuf;
     size_t cpos = 0;
     // contiguous shards (trk_vcf_shard): the blocks from file offset end_coff on belong to the next rank.  The first of
     // them is still inflated (the last line this rank owns may end in it), one more per call after that; limit_pos is
@@ -197,7 +273,11 @@ struct Source {
         return true;
     }
 
+    WorkerPool pool;                   // the inflater threads (created with the first BGZF fill, kept until close)
+    double t_fread = 0, t_resize = 0, t_inflate = 0;   // TRK_VCF_TIMING: where fill_bgzf's time goes (seconds, cumulative)
     bool fill_bgzf(TextBuf& out, size_t want, std::string& err) {
+        auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double tf0 = now();
         // top up the compressed buffer
         if (cpos > 0 && cpos == cbuf.size()) {
             cbuf_foff += cbuf.size();
@@ -214,7 +294,7 @@ struct Source {
         }
         if (cbuf.size() - cpos < target) {
             if (cpos > 0) {
-                cbuf.erase(cbuf.begin(), cbuf.begin() + (long)cpos);
+                cbuf.drop_front(cpos);
                 cbuf_foff += cpos;
                 cpos = 0;
             }
@@ -223,6 +303,7 @@ struct Source {
             size_t got = fread(cbuf.data() + old, 1, target, fp);
             cbuf.resize(old + got);
         }
+        t_fread += now() - tf0;
         // index complete blocks
         struct Blk { size_t off, csize, isize, dst; };
         std::vector<Blk> blks;
@@ -286,7 +367,10 @@ struct Source {
             return false;
         }
         size_t base = out.size();
+        const double tr0 = now();
         out.resize(base + total);
+        const double ti0 = now();
+        t_resize += ti0 - tr0;
         std::atomic<size_t> next{0};
         std::atomic<bool> bad{false};
         auto work = [&]() {
@@ -327,10 +411,8 @@ struct Source {
             }
         };
         int nt = std::max(1, std::min<int>(n_threads, (int)blks.size()));
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(work);
-        work();
-        for (auto& t : th) t.join();
+        pool.run(nt, work);
+        t_inflate += now() - ti0;
         if (bad) {
             err = "BGZF inflate failed";
             return false;
@@ -1029,8 +1111,10 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
         return 5;
     }
     if (timing)
-        fprintf(stderr, "[trk_vcf] batch of %d records: scan %.1f ms (of which inflate/read %.1f), parse %.1f ms, %d threads\n", n,
-                (t1 - t0) * 1e3, t_fill * 1e3, (now() - t1) * 1e3, nt);
+        fprintf(stderr, "[trk_vcf] batch of %d records: scan %.1f ms (of which inflate/read %.1f), parse %.1f ms, %d threads; "
+                        "cumulative fread %.1f ms, buffer growth %.1f ms, inflate %.1f ms\n", n,
+                (t1 - t0) * 1e3, t_fill * 1e3, (now() - t1) * 1e3, nt, v->src.t_fread * 1e3, v->src.t_resize * 1e3,
+                v->src.t_inflate * 1e3);
     v->pos = scan;
     v->kept_i ^= 1;
     trk_vcf::Kept& kp = v->kept[v->kept_i];
