@@ -988,17 +988,6 @@ extern "C" void trk_vcf_counters(trk_vcf* v, uint64_t out[3]) {
 void trk_vcf_close(trk_vcf* v) {
     if (!v) return;
     v->src.close();
-    // The text buffers of a large file are hundreds of megabytes of huge pages: unmapping them takes ~25 ms each
-    // (statSTR on 1 GB of text: 59 ms of a 0.30 s run inside close).  The whole reader is torn down on a detached
-    // thread -- nothing reads it any more; piecemeal would not do: the caller's own unmaps queue behind the big ones
-    // on the address-space lock -- and the caller gets its answer now.
-    if (v->buf.capacity() + v->prev_text.capacity() > ((size_t)32 << 20)) {
-        try {
-            std::thread([v] { delete v; }).detach();
-            return;
-        } catch (...) {
-        }
-    }
     delete v;
 }
 
