@@ -138,8 +138,15 @@ class Workload:
         S, nf = n_samples, len(self.filters)
         S2 = (S + 1) & ~1                                         # 16-byte aligned segments
         self.sums_, self.call_outs, self.loc_counters_ = [], [], []
-        gt_out = eng.empty((self.n_loci, S, 2), np.int16)
-        mask = eng.empty((self.n_loci, S), np.uint32)
+        # the two output planes of the call-filter pass: placed by the engine's tuner (Engine.placed_output_pair: on
+        # this part the pass's stream runs at one of two speeds depending on where its output planes landed)
+        self.placement = None
+        if self.n_loci * S * 4 >= (1 << 28) and os.environ.get('TRK_TUNE_PLACEMENT', '6') not in ('0', '1'):
+            gt_out, mask = eng.placed_output_pair(b, [self.sb.dev['gt'], self.sb.dev['dp'], self.sb.dev['q']])
+            self.placement = list(type(eng).last_placement or [])
+        else:
+            gt_out = eng.empty((self.n_loci, S, 2), np.int16)
+            mask = eng.empty((self.n_loci, S), np.uint32)
         for _ in range(NB):
             sums = eng.zeros(((1 + nf) * S2 + 2 * S2 + L.TRK_LC_COLS,), np.int64)
             sc = sums.view(0, (1 + nf, S), np.int64) if S2 == S else None
@@ -778,7 +785,7 @@ def config2_extra(eng, no_check, iters=5):
     filters = gangstr_filters()
     locus_args = dict(min_callrate=0.8, min_hwep=1e-3, min_het=0.05, max_het=0.9, use_length=False)
     st = eng.alloc_stats(sb.batch)
-    out_c = eng.alloc_call_out(sb.batch, len(filters))
+    out_c = eng.alloc_call_out(sb.batch, len(filters), tune_against=[sb.dev['gt'], sb.dev['dp'], sb.dev['q']])
     bits = eng.empty((Lc,), np.uint32)
     loc = eng.zeros((L.TRK_LC_COLS,), np.int64)
     eng.profile(True)
@@ -1143,7 +1150,11 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "bytes_per_cell": BYTES_PER_CELL_CALL_FILTER, "avg_launch_ms": avg_cf,
-                         "launches": kn, "box_stream_probe": None, "frac_of_box_stream": None},
+                         "launches": kn, "box_stream_probe": None, "frac_of_box_stream": None,
+                         "output_placement": ({"what": "Engine.placed_output_pair: candidate allocations of the two output "
+                                                       "planes, bare-stream probe of each (ms, fastest first = the one in "
+                                                       "use); TRK_TUNE_PLACEMENT=0 for a plain allocation",
+                                               "probe_ms": wl.placement} if wl.placement else None)},
             "kernels_ms": {k: (v[1] / v[0] if v[0] else None) for k, v in prof.items()},
             "k_locus_count_roofline": {"achieved": cells * BYTES_PER_CELL_COUNT / (avg_cnt * 1e-3) / 1e9 if cn else 0.0,
                                        "unit": "GB/s", "bytes_per_cell": BYTES_PER_CELL_COUNT,

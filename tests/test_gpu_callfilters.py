@@ -439,3 +439,25 @@ def test_compact_mask_output(eng, n_samples, n_filters):
     assert np.array_equal(out.sample_totaldp.get(), full.sample_totaldp.get())
     assert np.array_equal(st2.allele_count.get(), st.allele_count.get())
     assert np.array_equal(st2.locus_int.get()[..., :6], st.locus_int.get()[..., :6])
+
+
+def test_placed_output_planes_hold_the_same_results(eng):
+    """Engine.alloc_call_out(tune_against=...): the two big output planes come from the best of several candidate
+    allocations (bare-stream probe of the pass's shape through each); the pass writes into them what it writes into
+    plainly allocated ones, and the losers are given back."""
+    from trtools_amd import _lib as L
+    from trtools_amd.engine import Engine
+    from trtools_amd.synth import SynthBatch
+    sb = SynthBatch(eng, 8192, 8192, seed=11, planes=('dp', 'q'))
+    planes = [sb.dev['dp'], sb.dev['q']]
+    filters = [dict(op=L.F_LT, plane_a=0, thr=10), dict(op=L.F_GT, plane_a=0, thr=55), dict(op=L.F_LT, plane_a=1, thr=0.9)]
+    plain = eng.call_filters(sb.batch, planes, filters, dp_plane=0)
+    live_before = len(eng._live)
+    out = eng.alloc_call_out(sb.batch, len(filters), tune_against=[sb.dev['gt'], sb.dev['dp'], sb.dev['q']])
+    seen = Engine.last_placement
+    assert seen and 1 <= len(seen) <= 6 and seen == sorted(seen)
+    assert len(eng._live) - live_before == 7          # the seven arrays of one CallResult: the other candidates are gone
+    tuned = eng.call_filters(sb.batch, planes, filters, dp_plane=0, out=out)
+    assert np.array_equal(tuned.gt_out.get(), plain.gt_out.get())
+    assert np.array_equal(tuned.filter_mask.get(), plain.filter_mask.get())
+    assert np.array_equal(tuned.sample_counters.get(), plain.sample_counters.get())

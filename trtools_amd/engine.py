@@ -462,8 +462,51 @@ class Engine:
         self._chk(self.lib.trk_locus_stats(self.ctx, C.byref(batch.struct), C.byref(prm), C.byref(out.struct)))
         return out
 
-    def alloc_call_out(self, batch, n_filters, want_gt=True, want_mask=True, want_mask8=False):
+    # What the placement tuner saw last (bench.py reports it): probe times of the candidate output pairs, ms
+    last_placement = None
+
+    def placed_output_pair(self, batch, ins, tries=None):
+        """The two big output planes of a call-filter pass (masked genotypes, filter mask) in the best of up to
+        ``tries`` allocations.  On MI355X the time of a 12 B-in / 8 B-out stream depends on WHERE its two output
+        planes landed: with the inputs fixed, fresh output allocations give 3.21 or 3.80 ms at 100k x 10k -- two
+        levels, nothing between, the same for an allocation as long as it lives, invisible to a write-only stream
+        over it (memset 0.61-0.64 ms either way) and indifferent to where the inputs are
+        (tools/placement_probe2.py, profiles/r03_notes.md section 22).  So: allocate a candidate pair, time the bare
+        stream of the pass's shape through it (trk_stream_probe, ~10 ms), keep the candidates alive so that the next
+        one gets other memory, stop once both levels have been seen, keep the fastest, give the rest back."""
+        Lc, S = batch.n_loci, batch.n_samples
+        tries = int(os.environ.get('TRK_TUNE_PLACEMENT', '6')) if tries is None else int(tries)
+        cands = []
+        for _ in range(max(1, tries)):
+            g = self.empty((Lc, S, 2), np.int16)
+            m = self.empty((Lc, S), np.uint32)
+            ms = self.stream_probe(ins[0], ins[1], ins[2], g, m, Lc, S, reps=3)
+            cands.append((ms, g, m))
+            lo, hi = min(c[0] for c in cands), max(c[0] for c in cands)
+            if hi >= 1.06 * lo:          # both levels seen: the low one is the fast placement
+                break
+        cands.sort(key=lambda c: c[0])
+        for _, g, m in cands[1:]:
+            g.free()
+            m.free()
+        if len(cands) > 1:
+            self.sync()
+            self.trim()                  # the losers go back to the driver, not into the pool for the next caller
+        Engine.last_placement = [round(c[0], 3) for c in cands]
+        return cands[0][1], cands[0][2]
+
+    def alloc_call_out(self, batch, n_filters, want_gt=True, want_mask=True, want_mask8=False, tune_against=None):
+        """``tune_against``: the three resident input planes ([L, S] of 4-byte elements: the genotype tensor and two
+        FORMAT planes) of the pass these outputs are for.  Output planes of 256 MB and more are then placed by
+        ``placed_output_pair`` (TRK_TUNE_PLACEMENT=0: plain allocation; =N: up to N candidates, default 6)."""
         S = batch.n_samples
+        tries = int(os.environ.get('TRK_TUNE_PLACEMENT', '6'))
+        if (tune_against is not None and tries > 1 and want_gt and want_mask and batch.ploidy == 2 and
+                batch.n_loci * S * 4 >= (1 << 28)):
+            g, m = self.placed_output_pair(batch, tune_against, tries)
+            return CallResult(g, m, self.zeros((1 + n_filters, S), np.int64), self.zeros((S,), np.int64),
+                              self.zeros((S,), np.int64), self.zeros((4,), np.int32), self.zeros((S,), np.float64),
+                              self.empty((batch.n_loci, S), np.uint8) if want_mask8 else None)
         return CallResult(
             self.empty((batch.n_loci, S, batch.ploidy), np.int16) if want_gt else None,
             self.empty((batch.n_loci, S), np.uint32) if want_mask else None,
