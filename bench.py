@@ -1151,9 +1151,10 @@ def main():
                          "traffic_source": traffic_src,
                          "bytes_per_cell": BYTES_PER_CELL_CALL_FILTER, "avg_launch_ms": avg_cf,
                          "launches": kn, "box_stream_probe": None, "frac_of_box_stream": None,
-                         "output_placement": ({"what": "Engine.placed_output_pair: candidate allocations of the two output "
-                                                       "planes, bare-stream probe of each (ms, fastest first = the one in "
-                                                       "use); TRK_TUNE_PLACEMENT=0 for a plain allocation",
+                         "output_placement": ({"what": "Engine.placed_output_pair: candidate planes allocated one at a time, "
+                                                       "the bare-stream probe of every pair of them as the pass's two output "
+                                                       "planes (ms, fastest first = the pair in use); "
+                                                       "TRK_TUNE_PLACEMENT=0 for a plain allocation",
                                                "probe_ms": wl.placement} if wl.placement else None)},
             "kernels_ms": {k: (v[1] / v[0] if v[0] else None) for k, v in prof.items()},
             "k_locus_count_roofline": {"achieved": cells * BYTES_PER_CELL_COUNT / (avg_cnt * 1e-3) / 1e9 if cn else 0.0,

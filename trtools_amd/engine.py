@@ -466,34 +466,36 @@ class Engine:
     last_placement = None
 
     def placed_output_pair(self, batch, ins, tries=None):
-        """The two big output planes of a call-filter pass (masked genotypes, filter mask) in the best of up to
-        ``tries`` allocations.  On MI355X the time of a 12 B-in / 8 B-out stream depends on WHERE its two output
-        planes landed: with the inputs fixed, fresh output allocations give 3.21 or 3.80 ms at 100k x 10k -- two
-        levels, nothing between, the same for an allocation as long as it lives, invisible to a write-only stream
-        over it (memset 0.61-0.64 ms either way) and indifferent to where the inputs are
-        (tools/placement_probe2.py, profiles/r03_notes.md section 22).  So: allocate a candidate pair, time the bare
-        stream of the pass's shape through it (trk_stream_probe, ~10 ms), keep the candidates alive so that the next
-        one gets other memory, stop once both levels have been seen, keep the fastest, give the rest back."""
+        """The two big output planes of a call-filter pass (masked genotypes, filter mask) chosen among up to
+        ``tries`` candidate allocations.  On MI355X the 12 B-in / 8 B-out stream runs at one of two speeds, 18 % apart
+        (3.2 / 3.8 ms at 100k x 10k), and which one is decided by the two output planes alone: every 4 GB allocation
+        belongs to one of a few classes (the driver rotates through them), a pair from the SAME class is slow, a pair
+        from two classes is fast -- whatever the offsets inside the allocations (128 B ... 192 MB: no change), wherever
+        the inputs are, and invisible to a write-only stream over one plane (tools/placement_probe*.py,
+        profiles/r03_notes.md section 22).  So: allocate one candidate plane at a time, time the bare stream of the
+        pass's shape (trk_stream_probe, ~10 ms) with it and each plane held so far, stop at the first pair that is
+        clearly faster than another (both levels seen), keep the fastest pair, give the rest back to the driver."""
         Lc, S = batch.n_loci, batch.n_samples
         tries = int(os.environ.get('TRK_TUNE_PLACEMENT', '6')) if tries is None else int(tries)
-        cands = []
-        for _ in range(max(1, tries)):
-            g = self.empty((Lc, S, 2), np.int16)
-            m = self.empty((Lc, S), np.uint32)
-            ms = self.stream_probe(ins[0], ins[1], ins[2], g, m, Lc, S, reps=3)
-            cands.append((ms, g, m))
-            lo, hi = min(c[0] for c in cands), max(c[0] for c in cands)
-            if hi >= 1.06 * lo:          # both levels seen: the low one is the fast placement
-                break
-        cands.sort(key=lambda c: c[0])
-        for _, g, m in cands[1:]:
-            g.free()
-            m.free()
-        if len(cands) > 1:
+        planes, pairs = [], []
+        for _ in range(max(2, tries)):
+            p = self.empty((Lc, S), np.uint32)
+            for q in planes:
+                pairs.append((self.stream_probe(ins[0], ins[1], ins[2], q, p, Lc, S, reps=3), q, p))
+            planes.append(p)
+            if pairs and max(t for t, _, _ in pairs) >= 1.06 * min(t for t, _, _ in pairs):
+                break                    # both levels seen: the low one is the fast placement
+        pairs.sort(key=lambda c: c[0])
+        _, g, m = pairs[0]
+        for p in planes:
+            if p is not g and p is not m:
+                p.free()
+        if len(planes) > 2:
             self.sync()
-            self.trim()                  # the losers go back to the driver, not into the pool for the next caller
-        Engine.last_placement = [round(c[0], 3) for c in cands]
-        return cands[0][1], cands[0][2]
+            self.trim()                  # the others go back to the driver, not into the pool for the next caller
+        g.shape, g.dtype = (Lc, S, 2), np.dtype(np.int16)      # (same bytes: the masked genotypes are int16 pairs)
+        Engine.last_placement = [round(c[0], 3) for c in pairs]
+        return g, m
 
     def alloc_call_out(self, batch, n_filters, want_gt=True, want_mask=True, want_mask8=False, tune_against=None):
         """``tune_against``: the three resident input planes ([L, S] of 4-byte elements: the genotype tensor and two
