@@ -141,7 +141,7 @@ class Workload:
         # the two output planes of the call-filter pass: placed by the engine's tuner (Engine.placed_output_pair: on
         # this part the pass's stream runs at one of two speeds depending on where its output planes landed)
         self.placement = None
-        if self.n_loci * S * 4 >= (1 << 28) and os.environ.get('TRK_TUNE_PLACEMENT', '6') not in ('0', '1'):
+        if self.n_loci * S * 4 >= (1 << 28) and os.environ.get('TRK_TUNE_PLACEMENT', '10') not in ('0', '1'):
             gt_out, mask = eng.placed_output_pair(b, [self.sb.dev['gt'], self.sb.dev['dp'], self.sb.dev['q']])
             self.placement = list(type(eng).last_placement or [])
         else:
@@ -1152,8 +1152,8 @@ def main():
                          "bytes_per_cell": BYTES_PER_CELL_CALL_FILTER, "avg_launch_ms": avg_cf,
                          "launches": kn, "box_stream_probe": None, "frac_of_box_stream": None,
                          "output_placement": ({"what": "Engine.placed_output_pair: candidate planes allocated one at a time, "
-                                                       "the bare-stream probe of every pair of them as the pass's two output "
-                                                       "planes (ms, fastest first = the pair in use); "
+                                                       "the bare-stream probe of each with the first plane as the pass's two "
+                                                       "output planes (ms, fastest first = the pair in use); "
                                                        "TRK_TUNE_PLACEMENT=0 for a plain allocation",
                                                "probe_ms": wl.placement} if wl.placement else None)},
             "kernels_ms": {k: (v[1] / v[0] if v[0] else None) for k, v in prof.items()},

@@ -473,24 +473,28 @@ class Engine:
         from two classes is fast -- whatever the offsets inside the allocations (128 B ... 192 MB: no change), wherever
         the inputs are, and invisible to a write-only stream over one plane (tools/placement_probe*.py,
         profiles/r03_notes.md section 22).  So: allocate one candidate plane at a time, time the bare stream of the
-        pass's shape (trk_stream_probe, ~10 ms) with it and each plane held so far, stop at the first pair that is
-        clearly faster than another (both levels seen), keep the fastest pair, give the rest back to the driver."""
+        pass's shape (trk_stream_probe, ~10 ms) with it and the first plane, stop at the first pair that is clearly
+        faster than another (both levels seen), keep the fastest pair, give the rest back to the driver."""
         Lc, S = batch.n_loci, batch.n_samples
-        tries = int(os.environ.get('TRK_TUNE_PLACEMENT', '6')) if tries is None else int(tries)
-        planes, pairs = [], []
-        for _ in range(max(2, tries)):
+        tries = int(os.environ.get('TRK_TUNE_PLACEMENT', '10')) if tries is None else int(tries)
+        # (pairs inside a class are all slow, pairs across classes all fast: it is enough to time every new plane
+        # with the FIRST one; the driver changes class every 20-30 GB of allocations, so ten planes of a 4 GB shape
+        # reach another class even when a previous process has just returned one large region)
+        g = self.empty((Lc, S), np.uint32)
+        pairs, spacers = [], []
+        step = 4 << 30                   # memory to move on by per candidate: smaller planes get a spacer behind them
+        for _ in range(max(1, tries - 1)):
             p = self.empty((Lc, S), np.uint32)
-            for q in planes:
-                pairs.append((self.stream_probe(ins[0], ins[1], ins[2], q, p, Lc, S, reps=3), q, p))
-            planes.append(p)
-            if pairs and max(t for t, _, _ in pairs) >= 1.06 * min(t for t, _, _ in pairs):
+            pairs.append((self.stream_probe(ins[0], ins[1], ins[2], g, p, Lc, S, reps=3), p))
+            if max(t for t, _ in pairs) >= 1.06 * min(t for t, _ in pairs):
                 break                    # both levels seen: the low one is the fast placement
+            if p.nbytes < step:
+                spacers.append(self.empty((step - p.nbytes,), np.uint8))
         pairs.sort(key=lambda c: c[0])
-        _, g, m = pairs[0]
-        for p in planes:
-            if p is not g and p is not m:
-                p.free()
-        if len(planes) > 2:
+        m = pairs[0][1]
+        for p in [q for _, q in pairs[1:]] + spacers:
+            p.free()
+        if len(pairs) > 1:
             self.sync()
             self.trim()                  # the others go back to the driver, not into the pool for the next caller
         g.shape, g.dtype = (Lc, S, 2), np.dtype(np.int16)      # (same bytes: the masked genotypes are int16 pairs)
@@ -500,9 +504,9 @@ class Engine:
     def alloc_call_out(self, batch, n_filters, want_gt=True, want_mask=True, want_mask8=False, tune_against=None):
         """``tune_against``: the three resident input planes ([L, S] of 4-byte elements: the genotype tensor and two
         FORMAT planes) of the pass these outputs are for.  Output planes of 256 MB and more are then placed by
-        ``placed_output_pair`` (TRK_TUNE_PLACEMENT=0: plain allocation; =N: up to N candidates, default 6)."""
+        ``placed_output_pair`` (TRK_TUNE_PLACEMENT=0: plain allocation; =N: up to N candidate planes, default 10)."""
         S = batch.n_samples
-        tries = int(os.environ.get('TRK_TUNE_PLACEMENT', '6'))
+        tries = int(os.environ.get('TRK_TUNE_PLACEMENT', '10'))
         if (tune_against is not None and tries > 1 and want_gt and want_mask and batch.ploidy == 2 and
                 batch.n_loci * S * 4 >= (1 << 28)):
             g, m = self.placed_output_pair(batch, tune_against, tries)
