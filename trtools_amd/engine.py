@@ -490,6 +490,11 @@ class Engine:
                 break                    # both levels seen: the low one is the fast placement
             if p.nbytes < step:
                 spacers.append(self.empty((step - p.nbytes,), np.uint8))
+            if 3 <= len(pairs) <= 6:     # still one level: jump further (four spacers of 16 GB at most)
+                try:
+                    spacers.append(self.empty((16 << 30,), np.uint8))
+                except Exception:
+                    pass
         pairs.sort(key=lambda c: c[0])
         m = pairs[0][1]
         for p in [q for _, q in pairs[1:]] + spacers:
