@@ -175,6 +175,7 @@ typedef struct {
     const int32_t* n_len_classes;  /* [n]                                                                 */
     const int32_t* hrun;           /* [n] longest homopolymer run of REF (utils.GetHomopolymerRun)        */
     const int32_t* period;         /* [n] INFO PERIOD as an integer, INT32_MIN where the record has none  */
+    const int64_t* tr_pos;         /* [n] TRRecord.pos: INFO START for HipSTR (tr_harmonizer.py:407), else POS */
 } trk_vcf_harmonized;
 int trk_vcf_harmonize(trk_vcf* v, const trk_vcf_batch* b, int vcftype, trk_vcf_harmonized* out);
 

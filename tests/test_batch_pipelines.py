@@ -303,3 +303,74 @@ def test_plot_afreq_keeps_the_table_on_the_batch_pipeline(tmp_path):
     assert open(out + '.tab').read() == open(plain + '.tab').read()
     n_records = open(plain + '.tab').read().count('\n') - 1
     assert len(glob.glob(out + '-*.pdf')) == min(11, n_records) > 0
+
+
+def _flank_subset(tmp_path, n_flank=12, n_plain=12):
+    """A text VCF with the header of the HipSTR trio file, ``n_flank`` of its records whose alleles carry flanking
+    bases (INFO START != POS) and ``n_plain`` without, in file order; and a bgzipped + indexed BED file holding, for
+    every flank record with START > POS, exactly the bases [POS, START) -- left of the harmonised record."""
+    import gzip
+    from trtools_amd import bgzf, tabix
+    src = os.path.join(DD, 'trio_chr21_hipstr.sorted.vcf.gz')
+    vcf = str(tmp_path / 'flanks.vcf')
+    bed = str(tmp_path / 'flanks.bed.gz')
+    flank_pos, iv, nf, npl = [], [], 0, 0
+    with gzip.open(src, 'rt') as fin, open(vcf, 'w') as fout:
+        for line in fin:
+            if line.startswith('#'):
+                fout.write(line)
+                continue
+            f = line.split('\t', 8)
+            pos = int(f[1])
+            start = int([t for t in f[7].split(';') if t.startswith('START=')][0][6:])
+            if start > pos and nf < n_flank:
+                nf += 1
+                flank_pos.append(start)
+                iv.append((f[0], pos - 1, start - 1))
+                fout.write(line)
+            elif start == pos and npl < n_plain:
+                npl += 1
+                fout.write(line)
+            if nf == n_flank and npl == n_plain:
+                break
+    assert nf >= 4, "the fixture lost its flank-carrying records"
+    with bgzf.BgzfWriter(bed) as w:
+        w.write(''.join('%s\t%d\t%d\n' % t for t in iv).encode())
+    open(bed + '.tbi', 'wb').close()       # the filter only requires the index to exist (filters.py:206-217)
+    return vcf, bed, flank_pos
+
+
+def _check_flank_regions(tmp_path, compute):
+    from trtools_amd import runtime
+    from trtools_amd.dumpSTR import dumpSTR
+    vcf, bed, flank_pos = _flank_subset(tmp_path)
+    old = runtime.set_compute(compute)
+    try:
+        def go(mode):
+            out = str(tmp_path / ('r' + mode))
+            assert dumpSTR.main(dump_args(out, vcf, vcftype='hipstr', filter_regions=bed, filter_regions_names='flank',
+                                          hipstr_min_call_DP=5)) == 0
+            assert (dumpSTR.LAST_RUN['path'] == 'batch') == (mode == '1')
+            return tuple(open(out + ext).read() for ext in ('.vcf', '.samplog.tab', '.loclog.tab'))
+        a, b = _both(go, 'TRK_DUMPSTR_BATCH')
+    finally:
+        runtime.set_compute(old)
+    assert a == b
+    # TRRecord.pos is INFO START for these records (tr_harmonizer.py:407): the bases left of START are not the record
+    recs = [l.split('\t', 8) for l in a[0].split('\n') if l and not l.startswith('#')]
+    hit = [r for r in recs if 'flank' in r[6]]
+    starts = {int([t for t in r[7].split(';') if t.startswith('START=')][0][6:]): r for r in recs}
+    assert all('flank' not in starts[p][6] for p in flank_pos if p in starts), [r[:7] for r in hit]
+
+
+def test_dumpstr_region_filter_reads_the_harmonised_position(tmp_path):
+    """--filter-regions in the batch pipeline tested [POS, POS + ref_len) where the reference and
+    the per-record loop test [TRRecord.pos, ...) = INFO START for HipSTR records with flanking bases."""
+    from oracle_compute import OracleCompute
+    _check_flank_regions(tmp_path, OracleCompute())
+
+
+@pytest.mark.gpu
+def test_dumpstr_region_filter_reads_the_harmonised_position_gpu(tmp_path):
+    from trtools_amd import runtime
+    _check_flank_regions(tmp_path, runtime.get_compute())

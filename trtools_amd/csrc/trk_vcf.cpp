@@ -434,7 +434,7 @@ struct HzStore {
     std::vector<int32_t> allele_off, n_str_classes, n_len_classes, hrun, period;
     std::vector<uint16_t> len_class, str_class;
     std::vector<double> len_class_value, allele_len;
-    std::vector<int64_t> pos, end, key_off;
+    std::vector<int64_t> pos, tr_pos, end, key_off;
     std::vector<uint8_t> passing, status;
     std::string keys;
 };
@@ -1550,6 +1550,7 @@ struct HzRecord {  // one record's harmonised alleles (views into the line; uppe
     std::vector<std::pair<const char*, long>> alleles;  // trimmed [ptr, len)
     double unit = 1.0;                                   // len(motif)
     int64_t pos = 0, end = 0;
+    int64_t tr_pos = 0;                                  // TRRecord.pos: INFO START for HipSTR (tr_harmonizer.py:407), else POS
     int32_t hrun = 0;
     int32_t period = INT32_MIN;                          // INFO PERIOD (an integer), INT32_MIN when absent
     bool ok = false, passing = false;
@@ -1589,6 +1590,7 @@ void harmonize_one(const char* line, const int32_t* fo, int64_t line_len, int vc
     long pos;
     if (!parse_long(col[1], cole[1], pos)) return;
     r.pos = pos;
+    r.tr_pos = pos;
     const char* ref = col[3];
     const long ref_len = (long)(cole[3] - col[3]);
     const char* flt = col[6];
@@ -1704,6 +1706,7 @@ void harmonize_one(const char* line, const int32_t* fo, int64_t line_len, int vc
             r.alleles.emplace_back(al.first + b, e - b);
         }
         r.unit = (double)period;
+        r.tr_pos = start;
     } else {
         if (!info_get(info, infoe, "RU", 2, vb, ve, hv) || !hv || ve == vb) return;
         const long rul = (long)(ve - vb);
@@ -1776,6 +1779,7 @@ int trk_vcf_harmonize(trk_vcf* v, const trk_vcf_batch* b, int vcftype, trk_vcf_h
     }
     st.allele_off.assign((size_t)n + 1, 0);
     st.pos.assign((size_t)n, 0);
+    st.tr_pos.assign((size_t)n, 0);
     st.end.assign((size_t)n, 0);
     st.passing.assign((size_t)n, 0);
     st.status.assign((size_t)n, 0);
@@ -1789,6 +1793,7 @@ int trk_vcf_harmonize(trk_vcf* v, const trk_vcf_batch* b, int vcftype, trk_vcf_h
         st.status[(size_t)i] = r.ok ? 0 : 1;
         n_python += !r.ok;
         st.pos[(size_t)i] = r.pos;
+        st.tr_pos[(size_t)i] = r.tr_pos;
         st.end[(size_t)i] = r.end;
         st.passing[(size_t)i] = r.passing;
         st.hrun[(size_t)i] = r.hrun;
@@ -1869,6 +1874,7 @@ int trk_vcf_harmonize(trk_vcf* v, const trk_vcf_batch* b, int vcftype, trk_vcf_h
     out->n_len_classes = st.n_len_classes.data();
     out->hrun = st.hrun.data();
     out->period = st.period.data();
+    out->tr_pos = st.tr_pos.data();
     return 0;
 }
 

@@ -564,7 +564,9 @@ class _Run:
                     if chroms is None:
                         chroms = rb.chrom_column()
                     ref_len = hz.allele_len[hz.allele_off[:-1]]          # record.ref_allele_length (repeat units)
-                    fire = f.overlaps_batch(chroms, hz.pos, hz.pos + ref_len)
+                    # record.pos is the HARMONISED position (INFO START for HipSTR records with flanking bases,
+                    # tr_harmonizer.py:407), as the per-record Filter_Regions.__call__ reads it
+                    fire = f.overlaps_batch(chroms, hz.tr_pos, hz.tr_pos + ref_len)
                 ext |= fire.astype(np.uint32) << np.uint32(j)
         t_dev = time.perf_counter()
         ch, st, bits, lc = compute.dumpstr_batch(hb, arrays, specs, -1 if dp_key is None else index[dp_key],

@@ -215,7 +215,11 @@ class _QueueScope:
         self.eng._chk(self.eng.lib.trk_stream_select(self.eng.ctx, self.queue))
         self.eng._queue = self.queue
         if self.queue != 0:
+            # buffers freed while only queue 0 ran were pooled as idle: queue 0 may still be working on them when
+            # another queue takes one, so from here on none of them is
             self.eng._multi_queue = True
+            for rest in self.eng._pool.values():
+                rest[:] = [(p, False) for p, _ in rest]
         return self
 
     def __exit__(self, *exc):
@@ -284,7 +288,8 @@ class Engine:
         self._pool_bytes -= cap
         if not safe:
             self.sync()
-            self._multi_queue = False
+            # still inside an on_queue(k != 0) scope: later frees are not idle either
+            self._multi_queue = self._queue != 0
             for rest in self._pool.values():
                 rest[:] = [(p, True) for p, _ in rest]
         return ptr
@@ -292,7 +297,7 @@ class Engine:
     def _pool_give(self, cap, ptr):
         if self._pool_limit <= 0 or self._pool_bytes + cap > self._pool_limit:
             return False
-        self._pool.setdefault(cap, []).append((ptr, not self._multi_queue))
+        self._pool.setdefault(cap, []).append((ptr, not self._multi_queue and self._queue == 0))
         self._pool_bytes += cap
         return True
 

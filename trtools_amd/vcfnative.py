@@ -35,7 +35,7 @@ class _Harmonized(C.Structure):
                 ('passing', C.POINTER(C.c_uint8)), ('status', C.POINTER(C.c_uint8)), ('keys', C.c_void_p),
                 ('key_off', C.POINTER(C.c_int64)), ('n_str_classes', C.POINTER(C.c_int32)),
                 ('n_len_classes', C.POINTER(C.c_int32)), ('hrun', C.POINTER(C.c_int32)),
-                ('period', C.POINTER(C.c_int32))]
+                ('period', C.POINTER(C.c_int32)), ('tr_pos', C.POINTER(C.c_int64))]
 
 
 class _StatRows(C.Structure):
@@ -72,6 +72,7 @@ class HarmonizedBatch:
         self.key_off = _np(hz.key_off, sa + 1, np.int64)
         self.hrun = _np(hz.hrun, n, np.int32)
         self.period = _np(hz.period, n, np.int32)
+        self.tr_pos = _np(hz.tr_pos, n, np.int64)
         self.status = _np(hz.status, n, np.uint8)
 
     def lists(self):
