@@ -138,15 +138,16 @@ class Workload:
         S, nf = n_samples, len(self.filters)
         S2 = (S + 1) & ~1                                         # 16-byte aligned segments
         self.sums_, self.call_outs, self.loc_counters_ = [], [], []
-        # the two output planes of the call-filter pass: placed by the engine's tuner (Engine.placed_output_pair: on
-        # this part the pass's stream runs at one of two speeds depending on where its output planes landed)
+        # the two output planes of the call-filter pass, placed as every caller of Engine.alloc_call_out gets them
+        # (trk_dev_alloc_pair: on this part the pass's two write streams run on one of two levels depending on where the
+        # two planes landed; at most two spare planes during the search, TRK_PLACE_OUTPUTS=0: plain allocations)
         self.placement = None
-        if self.n_loci * S * 4 >= (1 << 28) and os.environ.get('TRK_TUNE_PLACEMENT', '10') not in ('0', '1'):
-            gt_out, mask = eng.placed_output_pair(b, [self.sb.dev['gt'], self.sb.dev['dp'], self.sb.dev['q']])
-            self.placement = list(type(eng).last_placement or [])
-        else:
-            gt_out = eng.empty((self.n_loci, S, 2), np.int16)
-            mask = eng.empty((self.n_loci, S), np.uint32)
+        co0 = eng.alloc_call_out(b, len(self.filters))
+        gt_out, mask = co0.gt_out, co0.filter_mask
+        for x in (co0.sample_counters, co0.sample_totaldp, co0.sample_dp_missing, co0.error, co0.sample_totaldp_f64):
+            x.free()
+        if self.n_loci * S * 4 >= eng.PLACE_MIN_BYTES and os.environ.get('TRK_PLACE_OUTPUTS', '1') != '0':
+            self.placement = dict(type(eng).last_placement or {})
         for _ in range(NB):
             sums = eng.zeros(((1 + nf) * S2 + 2 * S2 + L.TRK_LC_COLS,), np.int64)
             sc = sums.view(0, (1 + nf, S), np.int64) if S2 == S else None
@@ -785,7 +786,7 @@ def config2_extra(eng, no_check, iters=5):
     filters = gangstr_filters()
     locus_args = dict(min_callrate=0.8, min_hwep=1e-3, min_het=0.05, max_het=0.9, use_length=False)
     st = eng.alloc_stats(sb.batch)
-    out_c = eng.alloc_call_out(sb.batch, len(filters), tune_against=[sb.dev['gt'], sb.dev['dp'], sb.dev['q']])
+    out_c = eng.alloc_call_out(sb.batch, len(filters))
     bits = eng.empty((Lc,), np.uint32)
     loc = eng.zeros((L.TRK_LC_COLS,), np.int64)
     eng.profile(True)
@@ -994,7 +995,7 @@ def box_stream_probe(eng, wl):
         pms = eng.stream_probe(wl.sb.dev['gt'], wl.sb.dev['dp'], wl.sb.dev['q'], wl.call_out.gt_out,
                                wl.call_out.filter_mask, wl.n_loci, wl.n_samples, reps=5)
         box_probe = {"what": "k_stream_probe<3,2>: three 16 B/lane nontemporal input streams, two output streams, "
-                             "the call-filter pass's tiling and grid rule, no arithmetic (profiles/r03_notes.md)",
+                             "the call-filter pass's tiling and launch geometry (cf_geometry), no arithmetic",
                      "avg_launch_ms": pms,
                      "achieved": wl.n_loci * wl.n_real * BYTES_PER_CELL_CALL_FILTER / (pms * 1e-3) / 1e9,
                      "unit": "GB/s"}
@@ -1144,18 +1145,21 @@ def main():
                                     "per-locus filter decisions" if comm_mode != 'host' else
                                     "contiguous locus shards by rank; the step's exchange through HOST copies over the "
                                     "socket group (%s)" % (comm_note or "TRK_BENCH_COMM=host")) if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "k_call_filter_v2 (HIP events around that kernel alone; the 0.06 ms "
+            "roofline": {"bound": "hbm", "kernel": "k_call_filter_v4 (HIP events around that kernel alone; the 0.015 ms "
                                                    "k_cf_reduce that follows it is kernels_ms.k_cf_reduce)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "bytes_per_cell": BYTES_PER_CELL_CALL_FILTER, "avg_launch_ms": avg_cf,
                          "launches": kn, "box_stream_probe": None, "frac_of_box_stream": None,
-                         "output_placement": ({"what": "Engine.placed_output_pair: candidate planes allocated one at a time, "
-                                                       "the bare-stream probe of each with the first plane as the pass's two "
-                                                       "output planes (ms, fastest first = the pair in use); "
-                                                       "TRK_TUNE_PLACEMENT=0 for a plain allocation",
-                                               "probe_ms": wl.placement} if wl.placement else None)},
+                         # flat keys (the driver's parser drops nested objects of this one)
+                         "placement_probe_ms": (wl.placement or {}).get('probe_ms'),
+                         "placement_placed": (wl.placement or {}).get('placed'),
+                         "placement_seconds": (wl.placement or {}).get('seconds'),
+                         "placement_peak_extra_bytes": (wl.placement or {}).get('peak_extra_bytes'),
+                         "placement_note": "trk_dev_alloc_pair: write-only probe (ms) of the masked-genotype plane with "
+                                           "each candidate mask plane, at most two spare planes; the fastest pair is in "
+                                           "use.  The command lines' outputs go through the same call from 256 MB planes on"},
             "kernels_ms": {k: (v[1] / v[0] if v[0] else None) for k, v in prof.items()},
             "k_locus_count_roofline": {"achieved": cells * BYTES_PER_CELL_COUNT / (avg_cnt * 1e-3) / 1e9 if cn else 0.0,
                                        "unit": "GB/s", "bytes_per_cell": BYTES_PER_CELL_COUNT,
@@ -1206,6 +1210,9 @@ def main():
         out["roofline"]["box_stream_probe"] = probe
         if probe.get("achieved"):
             out["roofline"]["frac_of_box_stream"] = out["roofline"]["achieved"] / probe["achieved"]
+            # flat copies (the driver's parser keeps scalars of this object, not nested ones)
+            out["roofline"]["box_stream_ms"] = probe.get("avg_launch_ms")
+            out["roofline"]["box_stream_frac_of_peak"] = probe.get("frac")
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if group is not None:
         group.barrier()

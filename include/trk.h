@@ -296,6 +296,31 @@ int trk_stream_probe(trk_ctx* ctx, const void* in0, const void* in1, const void*
                      int64_t n_loci, int64_t n_samples, int32_t reps, float* avg_ms);
 int trk_device_clocks(trk_ctx* ctx, int32_t* sclk_khz, int32_t* mclk_khz, int32_t* mem_bus_bits);
 
+/* ---- the two output planes of a call-filter pass, placed -----------------------------------------
+ * dumpSTR.py:613-774 (ApplyCallFilters) writes a masked genotype and a FILTER value per call: here two [n_loci,
+ * n_samples] 4-byte planes written in lock step.  On MI355X that pair of write streams runs on one of two levels,
+ * 10-18 % apart, decided by WHICH allocations the two planes are (profiles/r03_notes.md section 22, r04_notes.md
+ * section 1: not by offsets, launch geometry or the inputs), stable while the allocations live.  trk_dev_alloc_pair
+ * allocates the first plane, then candidates for the second one at a time, times the write-only half of the pass's
+ * stream over (first, candidate) -- ~3 launches, 1-2 ms each at 4 GB planes -- and stops at the first pair that is
+ * clearly fast (>= 6 % faster than another candidate, or >= TRK_PAIR_FAST_TBPS of write rate); the best pair is
+ * returned, the other candidates freed.  max_spare = planes that may exist beyond the two returned (0: plain
+ * allocation + one probe; trk_call_filters' callers use 2): the transient never exceeds max_spare x bytes_each.
+ * Both planes are plain device allocations (trk_dev_free); their contents are undefined. */
+#define TRK_PAIR_MAX_PROBES 8
+#define TRK_PAIR_FAST_TBPS 6.5
+typedef struct {
+    int32_t n_probed;              /* candidates timed                                                      */
+    int32_t placed;                /* 1: the kept pair is on the fast level by one of the two criteria      */
+    float probe_ms[TRK_PAIR_MAX_PROBES];  /* write-only probe of (a, candidate k)                           */
+    float kept_ms;                 /* the kept pair's                                                        */
+    float reserved;
+    double seconds;                /* host time the call took (allocations + probes)                        */
+    uint64_t peak_extra_bytes;     /* allocated beyond the two returned planes, at the peak                 */
+} trk_pair_info;
+int trk_dev_alloc_pair(trk_ctx* ctx, size_t bytes_each, int64_t n_loci, int64_t n_samples, int32_t max_spare,
+                       void** a, void** b, trk_pair_info* info);
+
 /* Filter opcodes: one per distinct arithmetic in dumpSTR/filters.py.           */
 enum {
     TRK_F_LT = 1,          /* CallFilterMinValue :363-367  value < thr (in the plane's dtype) */

@@ -57,11 +57,13 @@ def _run_shard(lo, hi):
 def _worker(rank, world, port, outfile):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from trtools_amd import dist as tdist
+    from torch_comm import TorchComm
     dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
     lo, hi = tdist.locus_shard(24, rank, world)
     info, loc, rows = _run_shard(lo, hi)
-    comm = tdist.TorchComm()
+    comm = TorchComm()
     info = tdist.reduce_sample_info(info, comm)
     loc = tdist.reduce_loc_info(loc, comm)
     allrows = tdist.gather_rows(rows, comm)
@@ -101,14 +103,16 @@ def test_two_rank_sharded_dumpstr_matches_single_process(tmp_path):
 def _float_worker(rank, world, port, outfile):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from trtools_amd import dist as tdist
+    from torch_comm import TorchComm
     dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
     info = collections.OrderedDict()
     info['numcalls'] = np.array([3, 4, 5, 0]) * (rank + 1)
     # ExpansionHunter's LC is a Float field: per-shard depth sums carry fractions (and one sample is poisoned on rank 1)
     info['totaldp'] = np.array([10.25, 0.5, 7.125, 0.0]) + rank * np.array([0.5, 0.25, np.nan if rank else 0.0, 0.0])
     info['f0'] = np.array([1, 0, 2, 0])
-    red = tdist.reduce_sample_info(info, tdist.TorchComm())
+    red = tdist.reduce_sample_info(info, TorchComm())
     if rank == 0:
         with open(outfile, 'wb') as fh:
             pickle.dump(dict(red), fh)

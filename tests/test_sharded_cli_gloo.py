@@ -31,9 +31,10 @@ def _worker(rank, world, port, outdir):
     from trtools_amd.statSTR import statSTR
     from trtools_amd.dumpSTR import dumpSTR
     from oracle_compute import OracleCompute
+    from torch_comm import TorchComm
     import gen_golden_dumpstr as gg
     runtime.set_compute(OracleCompute())
-    tdist.set_comm(tdist.TorchComm())
+    tdist.set_comm(TorchComm())
     statSTR.BATCH_CELLS = 50 * 64       # many small batches so that both ranks get work
     dumpSTR.BATCH_CELLS = 24 * 7
     sys.argv = ['dumpSTR', '--synthetic-golden', 'hipstr_all']

@@ -82,6 +82,47 @@ __global__ __launch_bounds__(256) void k_walk(Streams s, int L, int S4, int lpb)
     if (dummy && lpb < 0) dummy[threadIdx.x] = 0;
 }
 
+// XCD-aware 1-D launch (block b runs on XCD b % 8, observed): the gx column tiles of one locus range get consecutive
+// slots of ONE XCD, so that an XCD streams whole rows of a few ranges instead of 4 KB pieces of every range.
+// range = xcd + 8 * (slot / gx), column tile = slot % gx; n_ranges is rounded up to a multiple of 8 by the launcher.
+template <int OUT>
+__global__ __launch_bounds__(256) void k_walk_xcd(Streams s, int L, int S4, int lpb, int gx_) {
+    extern __shared__ uint32_t dummy[];
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int by = xcd + 8 * (slot / gx_), bx = slot % gx_;
+    const int c = bx * 256 + threadIdx.x;
+    if (c >= S4) return;
+    const int l0 = by * lpb, l1 = min(L, l0 + lpb);
+    for (int l = l0; l < l1; ++l) {
+        const size_t o = (size_t)l * S4 + c;
+        u32x4 r = {(uint32_t)l, 1u, 2u, 3u};
+        r |= __builtin_nontemporal_load(s.in[0] + o) | __builtin_nontemporal_load(s.in[1] + o) | __builtin_nontemporal_load(s.in[2] + o);
+        put<OUT>(s, l, c, S4, r, r + 1u);
+    }
+    if (dummy && lpb < 0) dummy[threadIdx.x] = 0;
+}
+
+// XCD-aware, K walkers per range: the K workgroups of a (range, tile) take loci l0 + k, l0 + k + K, ... -- the range's
+// window is K adjacent rows per stream instead of one, and there are K times fewer ranges (distinct places in memory
+// that are streamed at the same time) for the same number of resident workgroups.
+__global__ __launch_bounds__(256) void k_walk_xcdk(Streams s, int L, int S4, int lpr, int gx_, int K) {
+    extern __shared__ uint32_t dummy[];
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int per = gx_ * K;
+    const int range = xcd + 8 * (slot / per), rem = slot % per, k = rem / gx_, bx = rem % gx_;
+    const int c = bx * 256 + threadIdx.x;
+    if (c >= S4) return;
+    const int l0 = range * lpr, l1 = min(L, l0 + lpr);
+    for (int l = l0 + k; l < l1; l += K) {
+        const size_t o = (size_t)l * S4 + c;
+        u32x4 r = {(uint32_t)l, 1u, 2u, 3u};
+        r |= __builtin_nontemporal_load(s.in[0] + o) | __builtin_nontemporal_load(s.in[1] + o) | __builtin_nontemporal_load(s.in[2] + o);
+        __builtin_nontemporal_store(r, s.out[0] + o);
+        __builtin_nontemporal_store(r + 1u, s.out[1] + o);
+    }
+    if (dummy && lpr < 0) dummy[threadIdx.x] = 0;
+}
+
 // store policy per output stream: P 0 nt, 1 plain, 2 sc1, 3 sc0 sc1
 template <int P>
 __device__ __forceinline__ void st_pol(u32x4* p, u32x4 v) {
@@ -220,6 +261,24 @@ static void geometry(const Streams& s, const char* tag) {
         const int gy = std::max(1, 2 * wgcu * ncu / gx), lpb = (L + gy - 1) / gy;
         snprintf(nm, sizeof nm, "[%s] two rounds of %d WG/CU contiguous (gy %d, %d loci/WG)", tag, wgcu, gy, lpb);
         run(nm, [&] { hipLaunchKernelGGL((k_walk<0, 0, 0>), dim3(gx, gy), dim3(256), lds_for(wgcu), 0, s, L, S4, lpb); });
+    }
+    for (int wgcu : {2, 3, 4, 5, 8}) {
+        const int ny = std::max(8, wgcu * ncu / gx / 8 * 8), lpb = (L + ny - 1) / ny;
+        snprintf(nm, sizeof nm, "[%s] XCD-aware persistent %d WG/CU (%d ranges of %d loci)", tag, wgcu, ny, lpb);
+        run(nm, [&] { hipLaunchKernelGGL((k_walk_xcd<0>), dim3(ny * gx), dim3(256), lds_for(wgcu), 0, s, L, S4, lpb, gx); });
+    }
+    for (int wgcu : {4, 5, 8})
+        for (int K : {2, 4, 8, 16}) {
+            int nr = wgcu * ncu / (gx * K) / 8 * 8;
+            if (nr < 8) nr = 8;
+            const int lpr = (L + nr - 1) / nr;
+            snprintf(nm, sizeof nm, "[%s] XCD-aware persistent %d WG/CU, %d walkers per range (%d ranges of %d loci)", tag, wgcu, K, nr, lpr);
+            run(nm, [&] { hipLaunchKernelGGL(k_walk_xcdk, dim3(nr * gx * K), dim3(256), lds_for(wgcu), 0, s, L, S4, lpr, gx, K); });
+        }
+    for (int lpb : {56, 112, 250, 500}) {
+        const int ny = ((L + lpb - 1) / lpb + 7) / 8 * 8;
+        snprintf(nm, sizeof nm, "[%s] XCD-aware %d loci/block, <= 5 WG/CU (%d ranges = %.2f rounds)", tag, lpb, ny, (double)gx * ny / (ncu * 5.0));
+        run(nm, [&] { hipLaunchKernelGGL((k_walk_xcd<0>), dim3(ny * gx), dim3(256), lds_for(5), 0, s, L, S4, lpb, gx); });
     }
     for (int lpb : {32, 112}) {
         const int gy = (L + lpb - 1) / lpb;

@@ -122,6 +122,15 @@ AF_COLS = 10
 (AS_OK, AS_NO_CALLED, AS_ONE_ALLELE, AS_NON_MAJOR, AS_N_COVARS, AS_ZERO_VARIANCE, AS_COLLINEAR) = range(7)
 
 
+PAIR_MAX_PROBES = 8
+
+
+class PairInfo(C.Structure):
+    _fields_ = [('n_probed', C.c_int32), ('placed', C.c_int32), ('probe_ms', C.c_float * PAIR_MAX_PROBES),
+                ('kept_ms', C.c_float), ('reserved', C.c_float), ('seconds', C.c_double),
+                ('peak_extra_bytes', C.c_uint64)]
+
+
 class SynthSpec(C.Structure):
     _fields_ = [('seed', C.c_uint64), ('n_loci', C.c_int32), ('n_samples', C.c_int32),
                 ('allele_off', C.c_void_p), ('allele_cdf24', C.c_void_p), ('miss_thr16', C.c_void_p),
@@ -131,7 +140,7 @@ class SynthSpec(C.Structure):
 # every symbol include/trk.h declares (tests check that the library exports them)
 EXPORTS = [
     'trk_init', 'trk_free', 'trk_last_error', 'trk_backend', 'trk_device_count', 'trk_device_info',
-    'trk_dev_alloc', 'trk_dev_free', 'trk_memcpy_h2d', 'trk_memcpy_d2h', 'trk_memcpy_d2d', 'trk_memset', 'trk_sync',
+    'trk_dev_alloc', 'trk_dev_alloc_pair', 'trk_dev_free', 'trk_memcpy_h2d', 'trk_memcpy_d2h', 'trk_memcpy_d2d', 'trk_memset', 'trk_sync',
     'trk_timer_start', 'trk_timer_stop', 'trk_timer_elapsed_ms',
     'trk_profile_enable', 'trk_profile_get', 'trk_profile_reset',
     'trk_locus_stats', 'trk_locus_finalize', 'trk_call_filters', 'trk_locus_filters',
@@ -224,6 +233,7 @@ def load():
     lib.trk_device_info.argtypes = [vp, C.c_char_p, C.c_int, P(C.c_int), P(u64), C.c_char_p, C.c_int]
     lib.trk_dev_alloc.argtypes = [vp, C.c_size_t, P(vp)]
     lib.trk_dev_free.argtypes = [vp, vp]
+    lib.trk_dev_alloc_pair.argtypes = [vp, C.c_size_t, i64, i64, i32, P(vp), P(vp), P(PairInfo)]
     lib.trk_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
     lib.trk_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
     lib.trk_memcpy_d2d.argtypes = [vp, vp, vp, C.c_size_t]

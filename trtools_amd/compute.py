@@ -76,7 +76,7 @@ class DeviceCompute:
         shape[axis] = n_pad
         return np.concatenate([arr, np.full(shape, value, dtype=arr.dtype)], axis=axis)
 
-    def _upload(self, hb, pad=True, rows=False):
+    def _upload(self, hb, pad=True, rows=False, allow_class_sort=False):
         # a per-locus ploidy table only when some locus really is of lower ploidy than the tensor
         # (the kernels' streaming paths need every column to be live)
         lp = hb.locus_ploidy
@@ -89,7 +89,9 @@ class DeviceCompute:
         # (DeviceBatch.sorted_by_class; the per-call group kernel takes 19-23 ms at 100k x 10k where this takes ~2).
         # Up to three groups keep the one-pass grouped kernel (k_locus_count_v2g), which needs no gather.
         mode = os.environ.get('TRK_CLASS_SORT', '')
-        class_sort = (gb is not None and hb.gt.shape[2] == 2 and lp is None and hb.n_loci > 0 and mode != '0' and
+        # (only trk_locus_stats reads a class-ordered batch: every other entry point needs the samples in their
+        # own order and number, so the gather is an opt-in of locus_stats -- ADVICE r03)
+        class_sort = (allow_class_sort and gb is not None and hb.gt.shape[2] == 2 and lp is None and hb.n_loci > 0 and mode != '0' and
                       (hb.n_groups >= 4 or mode == '1'))
         if class_sort:
             base = self.eng.make_batch(hb.gt, hb.allele_off, hb.len_class, hb.str_class, hb.len_class_value,
@@ -118,7 +120,7 @@ class DeviceCompute:
                 o.free()
 
     def locus_stats(self, hb, nalleles_thresh=0.01):
-        b = self._upload(hb, rows=True)
+        b = self._upload(hb, rows=True, allow_class_sort=True)
         res = self.eng.locus_stats(b, nalleles_thresh=nalleles_thresh)
         out = StatsHost(res.allele_count.get(), res.locus_int.get(), res.locus_f64.get())
         self._free(b, res.allele_count, res.locus_int, res.locus_f64)

@@ -3,6 +3,7 @@
 // so that the library loads on machines without it.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -441,6 +442,8 @@ static int check_batch(trk_ctx* ctx, const trk_batch* b, bool count_entry = fals
                                       "four samples apart and at least n_samples long", b->row_stride);
     if (b->n_class_runs < 0 || (b->n_class_runs > 0 && (!b->class_runs || !b->group_bits)))
         return fail(ctx, TRK_ERR_ARG, "class_runs needs the run table and group_bits");
+    if (b->n_class_runs > 0 && !count_entry)   // class-ordered columns are not the cohort's sample order
+        return fail(ctx, TRK_ERR_ARG, "a class-ordered batch (class_runs) is for trk_locus_stats only");
     if (b->n_loci < 0 || b->n_samples < 0) return fail(ctx, TRK_ERR_ARG, "negative batch dimensions");
     if (b->ploidy < 1 || b->ploidy > TRK_MAX_PLOIDY)
         return fail(ctx, TRK_ERR_ARG, "ploidy %d outside [1,%d]", b->ploidy, TRK_MAX_PLOIDY);
@@ -532,7 +535,7 @@ static int ensure_fin_buffers(trk_ctx* ctx, int G, int64_t sumA, int n_loci) {
 
 int trk_locus_finalize(trk_ctx* ctx, const trk_batch* in, const trk_stats_params* prm, trk_stats_out* out) {
     if (!ctx) return TRK_ERR_ARG;
-    int rc = check_batch(ctx, in);
+    int rc = check_batch(ctx, in, true);   // (reads the allele tables and the counts only: any column layout)
     if (rc) return rc;
     if (!out || !out->allele_count || !out->locus_int || !out->locus_f64)
         return fail(ctx, TRK_ERR_ARG, "stats outputs are NULL");
@@ -880,6 +883,91 @@ int trk_stream_probe(trk_ctx* ctx, const void* in0, const void* in1, const void*
     if (e != hipSuccess) return fail(ctx, TRK_ERR_HIP, "trk_stream_probe: %s", hipGetErrorString(e));
     *avg_ms = ms / (float)reps;
     return TRK_OK;
+}
+
+// write-only probe of a pair of output planes (the two-output half of the call-filter pass's stream): ms per launch
+static hipError_t probe_pair_ms(trk_ctx* ctx, void* a, void* b, int64_t n_loci, int64_t n_samples, float* ms_out) {
+    void* out[2] = {a, b};
+    hipEvent_t e0, e1;
+    hipError_t e = hipEventCreate(&e0);
+    if (e != hipSuccess) return e;
+    e = hipEventCreate(&e1);
+    if (e != hipSuccess) { (void)hipEventDestroy(e0); return e; }
+    const int reps = 2;
+    e = trk::launch_stream_probe(nullptr, 0, out, 2, n_loci, n_samples, ctx->n_cu, ctx->s());   // warm-up (first touch)
+    if (e == hipSuccess) e = hipEventRecord(e0, ctx->s());
+    for (int r = 0; r < reps && e == hipSuccess; ++r)
+        e = trk::launch_stream_probe(nullptr, 0, out, 2, n_loci, n_samples, ctx->n_cu, ctx->s());
+    if (e == hipSuccess) e = hipEventRecord(e1, ctx->s());
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_out = ms / (float)reps;
+    return e;
+}
+
+int trk_dev_alloc_pair(trk_ctx* ctx, size_t bytes_each, int64_t n_loci, int64_t n_samples, int32_t max_spare,
+                       void** a, void** b, trk_pair_info* info) {
+    if (!ctx || !a || !b) return TRK_ERR_ARG;
+    *a = *b = nullptr;
+    trk_pair_info pi = {};
+    if (n_loci < 1 || n_samples < 4 || n_samples % 4 || bytes_each < (size_t)n_loci * (size_t)n_samples * 4u)
+        return fail(ctx, TRK_ERR_ARG, "trk_dev_alloc_pair: planes of [n_loci, n_samples] 4-byte cells, n_samples %% 4 == 0");
+    if (max_spare < 0) max_spare = 0;
+    if (max_spare > TRK_PAIR_MAX_PROBES - 1) max_spare = TRK_PAIR_MAX_PROBES - 1;
+    (void)hipSetDevice(ctx->device);
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t e = hipMalloc(a, bytes_each);
+    if (e != hipSuccess) return fail(ctx, TRK_ERR_NOMEM, "hipMalloc(%zu): %s", bytes_each, hipGetErrorString(e));
+    // Candidates for the second plane, one at a time, each timed together with the first (a pair of planes is on one
+    // of two levels for as long as the allocations live -- profiles/r03_notes.md section 22 -- and the level shows in
+    // the write-only half of the stream: 7.0 against 5.4-5.9 TB/s).  At most `max_spare` planes beyond the two that
+    // are returned exist at any time; the search stops at the first pair that is clearly on the fast level.
+    void* cand[TRK_PAIR_MAX_PROBES] = {};
+    float ms[TRK_PAIR_MAX_PROBES] = {};
+    int n = 0, best = -1;
+    const double gbytes = 2.0 * (double)n_loci * (double)n_samples * 4.0 * 1e-9;
+    int rc = TRK_OK;
+    while (n < 1 + max_spare) {
+        void* p = nullptr;
+        e = hipMalloc(&p, bytes_each);
+        if (e != hipSuccess) {                    // out of memory for a spare: keep what there is
+            (void)hipGetLastError();
+            if (n == 0) rc = fail(ctx, TRK_ERR_NOMEM, "hipMalloc(%zu): %s", bytes_each, hipGetErrorString(e));
+            break;
+        }
+        cand[n] = p;
+        e = probe_pair_ms(ctx, *a, p, n_loci, n_samples, &ms[n]);
+        if (e != hipSuccess) { rc = fail(ctx, TRK_ERR_HIP, "trk_dev_alloc_pair probe: %s", hipGetErrorString(e)); ++n; break; }
+        if (best < 0 || ms[n] < ms[best]) best = n;
+        ++n;
+        float worst = ms[0];
+        for (int k = 1; k < n; ++k) worst = ms[k] > worst ? ms[k] : worst;
+        const double tbps = gbytes / (double)ms[best];            // GB / ms = TB/s
+        if (worst >= 1.06f * ms[best] || tbps >= TRK_PAIR_FAST_TBPS) { pi.placed = 1; break; }
+        // (a candidate handed back to the driver comes back as the next allocation: every candidate is held until the
+        // search ends, which is why their number is the memory bound)
+    }
+    pi.peak_extra_bytes = (uint64_t)(n > 1 ? n - 1 : 0) * (uint64_t)bytes_each;
+    if (rc == TRK_OK && best >= 0) {
+        *b = cand[best];
+        cand[best] = nullptr;
+        pi.kept_ms = ms[best];
+    }
+    for (int k = 0; k < n; ++k)
+        if (cand[k]) (void)hipFree(cand[k]);
+    if (rc != TRK_OK) {
+        if (*b) (void)hipFree(*b);
+        (void)hipFree(*a);
+        *a = *b = nullptr;
+    }
+    pi.n_probed = n;
+    for (int k = 0; k < n; ++k) pi.probe_ms[k] = ms[k];
+    pi.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (info) *info = pi;
+    return rc;
 }
 
 int trk_device_clocks(trk_ctx* ctx, int32_t* sclk_khz, int32_t* mclk_khz, int32_t* mem_bus_bits) {

@@ -27,7 +27,9 @@
 //   k_synth            counter-based synthetic genotype / FORMAT generator.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "../../include/trk.h"
 #include "trk_binom.h"
@@ -2115,6 +2117,8 @@ __device__ __forceinline__ void cf_gather(const CfLocus<NS>& d, int idx, uint32_
 // delta outputs, profiles/r02_notes.md]
 constexpr int CF_LINFO = 3;
 constexpr int CF_LUT_UNROLL = 8;
+template <bool STORE = true>   // STORE = false: only linfo (k_call_filter_v4 reads the classes of its rare duplicate-class
+                                // loci from global memory when it drains its queue; lutb is not touched)
 __device__ __forceinline__ void cf_build_lut(const trk_batch& b, int l_begin, int nl, int nal, int tid,
                                              uint32_t* lutb, int32_t* linfo) {
     for (int li = tid; li < nl; li += CF_THREADS) {
@@ -2145,7 +2149,7 @@ __device__ __forceinline__ void cf_build_lut(const trk_batch& b, int l_begin, in
                 // uniform over the lane group, and a group never straddles a wave: the shuffles below are safe
                 if (li >= nl) break;
                 const int A = linfo[CF_LINFO * li];
-                if (q < nal) lutb[li * nal + q] = cls[u];
+                if (STORE && q < nal) lutb[li * nal + q] = cls[u];
                 u16x2 m = __builtin_bit_cast(u16x2, cls[u]);
                 for (int o = gsz >> 1; o > 0; o >>= 1) {
                     const uint32_t t = (uint32_t)__shfl_xor((int)__builtin_bit_cast(uint32_t, m), o, WAVE);
@@ -2157,19 +2161,22 @@ __device__ __forceinline__ void cf_build_lut(const trk_batch& b, int l_begin, in
         __syncthreads();
         return;
     }
-    for (int i = tid; i < nl * nal; i += CF_THREADS) {     // allele sets beyond a wave: one entry at a time
-        const int li = i / nal, q = i - li * nal;
-        if (q >= linfo[CF_LINFO * li]) continue;
-        const int e = linfo[CF_LINFO * li + 2] + q;
-        lutb[i] = (uint32_t)b.len_class[e] | ((uint32_t)b.str_class[e] << 16);
+    if (STORE) {
+        for (int i = tid; i < nl * nal; i += CF_THREADS) {     // allele sets beyond a wave: one entry at a time
+            const int li = i / nal, q = i - li * nal;
+            if (q >= linfo[CF_LINFO * li]) continue;
+            const int e = linfo[CF_LINFO * li + 2] + q;
+            lutb[i] = (uint32_t)b.len_class[e] | ((uint32_t)b.str_class[e] << 16);
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // dense ranks: a duplicate exists iff the largest rank + 1 < A, i.e. iff no allele has rank A - 1
     for (int li = tid; li < nl; li += CF_THREADS) {
         const int A = linfo[CF_LINFO * li];
         bool top_l = false, top_s = false;
         for (int q = 0; q < A; ++q) {
-            const uint32_t v = lutb[li * nal + q];
+            const int e = linfo[CF_LINFO * li + 2] + q;
+            const uint32_t v = STORE ? lutb[li * nal + q] : ((uint32_t)b.len_class[e] | ((uint32_t)b.str_class[e] << 16));
             top_l |= (int)(v & 0xffffu) == A - 1;
             top_s |= (int)(v >> 16) == A - 1;
         }
@@ -2193,7 +2200,7 @@ struct CfDelta {
 enum { V2_TRASH = 0, V2_W0 = 1, V2_W1 = 2, V2_EXTRA = 3 };
 
 // a called genotype that a filter masks to no-call: what it removes from the locus counts.  (The packed,
-// branch-free form of k_call_filter_v2 costs this kernel five more VGPRs and a wave of occupancy.)
+// branch-free form of k_call_filter_v4 costs this kernel five more VGPRs and a wave of occupancy.)
 __device__ __forceinline__ void cf_delta_call(const CfDelta& c, uint32_t w, int pl) {
     const int a0 = (int)(int16_t)(w & 0xffffu);
     const int a1 = pl > 1 ? (int)(int16_t)(w >> 16) : -3;
@@ -2221,7 +2228,7 @@ __device__ __forceinline__ void cf_delta_call(const CfDelta& c, uint32_t w, int 
 // picks its operands with a wave-uniform DYNAMIC index, which the compiler turns into one indexed v_mov each
 // (s_set_gpr_idx).  The select chain of cf_gather costs 4 x NS instructions per operand; with nine filters the
 // GangSTR set spent ~250 vector instructions per call on 60 bytes (SQ counters, profiles/r02_notes.md section 8).
-// Decisions are wave-wide lane masks in scalar registers as in k_call_filter_v2.
+// Decisions are wave-wide lane masks in scalar registers as in k_call_filter_v4.
 template <int NS, bool GEN>
 struct CfRegs {
     static constexpr int NLO = (NS < 8 ? NS : 8) * 4, NHI = (NS > 8 ? NS - 8 : 1) * 4;
@@ -2766,86 +2773,128 @@ __global__ __launch_bounds__(CF_THREADS, (NS == 12 && ALLREG) ? 4 : 1) void k_ca
 }
 
 // ---------------------------------------------------------------------------
-// k_call_filter_v2 : the issue-lean streaming kernel for the common dumpSTR filter
-// sets (every filter a plain threshold on a single-column plane: min/max DP, min Q,
-// pre-parsed min supporting reads ...), diploid records, S % 4 == 0.
-// Profiling showed the generic streaming kernel to be instruction-issue bound
-// (~2300 issue cycles per wave per locus), not HBM bound.  Here
-//   * integer planes compare against pre-rounded int32 thresholds (one v_cmp),
-//     float planes against the float32 threshold (numpy's semantics);
-//   * per-sample filter counters live in registers (NF x 4, add-with-carry);
-//   * the only data-dependent branch is "this call is filtered" (a few %), whose
-//     body is four LDS atomics into the block's delta table (alleles to their bin
-//     or a trash slot, {called, low-ploidy} and {hom-by-length, hom-by-sequence}
-//     as two packed 16+16-bit words).
+// Launch geometry of the column-owner call-filter kernels (k_call_filter_v4 / _gs): a workgroup owns one column tile
+// (CF_THREADS x CF_V samples) and ONE contiguous range of `walk` locus blocks (sub-blocks of loci_per_block loci: the
+// LDS delta table is rebuilt block by block while the per-sample counters stay in registers over the whole range).
+//   map 0   grid (gx, n_ranges): column tiles are neighbours in launch order
+//   map 1   grid (n_ranges, gx): locus-major launch order
+//   map 2   1-D grid, XCD-aware: block b runs on XCD b % 8 (observed, MI355X_MICROARCH.md "Workgroup dispatch"), so
+//           range = b % 8 + 8 * ((b / 8) / gx), tile = (b / 8) % gx puts the gx tiles of a range -- whole rows -- on
+//           ONE XCD and gives each XCD every eighth range.
+// What the round-4 sweeps with the output planes' placement pinned say (profiles/r04_notes.md section 1): the bare
+// stream of this shape is worth 3.3-3.45 ms at 100k x 10k whatever the map, the block size or the occupancy (+-3 %);
+// persistent ranges save k_cf_reduce its rows (0.075 -> 0.015 ms) and the product kernel 1-3 %; the 10-18 % between
+// a fast and a slow PAIR of output planes (r03_notes section 22) is not a matter of geometry.
+// A speed choice only: every workgroup computes the same thing wherever it runs.
 // ---------------------------------------------------------------------------
-struct V2Filter {
+struct CfGeom {
+    int gx, n_ranges, walk, map;
+};
+__device__ __forceinline__ bool cf_place(const CfGeom& g, int& tile, int& range) {
+    if (g.map == 2) {
+        const int slot = (int)blockIdx.x >> 3;
+        range = ((int)blockIdx.x & 7) + 8 * (slot / g.gx);
+        tile = slot % g.gx;
+    } else if (g.map == 1) {
+        range = blockIdx.x;
+        tile = blockIdx.y;
+    } else {
+        tile = blockIdx.x;
+        range = blockIdx.y;
+    }
+    return range < g.n_ranges;
+}
+
+constexpr int V2_MAX_FILTERS = 6;
+// ---------------------------------------------------------------------------
+// k_call_filter_v4 : the streaming kernel for the common dumpSTR filter sets -- every filter a plain threshold on a
+// single-column plane (min / max DP, min Q, pre-parsed min supporting reads ...) or a HipSTR ratio over the depth
+// plane; diploid records, S % 4 == 0.  Column-owner tiling: a thread owns four consecutive samples and walks the loci
+// of its workgroup's range, the per-sample counters of dumpSTR's sample_info in registers (add-with-carry, the
+// wave-wide decision mask as the carry), decisions as 64-bit lane masks in scalar registers.
+// Round 4 rewrote the round-2/3 kernel (k_call_filter_v2, git history) for a third of its instructions: the v2 loop issued 246 vector + 358 scalar instructions per wave and locus (tools/loop_census.py): the filter
+// kind was a run-time switch (57 branches, four duplicated compare arms per filter), the kernel arguments were
+// re-read from the constant cache every iteration (14 s_load), twelve scalars lived in vector lanes, and the delta
+// block -- what a FILTERED call removes from its locus's counts -- ran its ~20 vector instructions and two LDS
+// atomics per call slot for the two or three lanes of a wave that have a filtered call.  Here:
+//   * the compare TYPE is static: the host orders the filters integer planes first, float planes last, and NFLT
+//     (the number of trailing float filters) is a template argument; LT / GT is folded into the operands --
+//     integers: x > t <=> !(x < t + 1), the inversion applied to the wave-wide lane mask (one s_xor); floats:
+//     x > t <=> -x < -t, the sign flipped on the value (exact, NaN stays false);
+//   * everything about call j is finished before call j + 1 starts, so only a handful of 64-bit lane masks are live
+//     at any time (no spills, no argument re-loads);
+//   * FILTERED CALLS ARE QUEUED, not handled where they are met (the trick of k_assoc_scan_few's missing-call
+//     queue): a wave appends {genotype word, locus} to its own LDS queue (ballot rank = v_mbcnt, one masked
+//     ds_write_b64 per call slot) and drains the queue in bulk -- lane = queued call, 64 at a time, the allele /
+//     called / homozygosity updates of the block's delta table as before -- when it runs full and at the end of
+//     the block.  The drain's instructions serve 64 calls instead of two.
+// 184 vector + 167 scalar instructions per wave and locus (v2: 246 + 358); same-process A/B at 100k x 10k: 3.58 ->
+// 3.46 ms, every locus and 1.2e8 calls bit for bit against the compiled oracle under both (profiles/r04_notes.md).
+// ---------------------------------------------------------------------------
+struct V4Filter {
     const void* plane;    // [L,S] int32 or float32
-    int32_t kind;         // 0: int LT, 1: int GT, 2: float LT, 3: float GT, 4: int / depth > dthr (RATIO_GT)
+    int32_t thr;          // integer: fires when (x < thr) != invert; float: bits of the (sign-flipped) threshold
+    uint32_t flip;        // float: 0x80000000 for GT (the value's sign is flipped), else 0
+    int32_t invert;       // integer GT: thr = t + 1 and the lane mask is inverted
     int32_t need_called;  // TRK_F_CALLED_LT
-    int32_t ithr;
-    float fthr;
     int32_t bit;          // bit of this filter in the mask / row of sample_counters - 1
+    int32_t ratio;        // 1: HipSTR-style ratio over the depth plane: (double)x / (double)depth > dthr
+    int32_t is_float;     // the plane's type (read by the NFLT = -1 builds only: there the type is a run-time flag)
     int32_t pad;
     double dthr;
 };
-constexpr int V2_MAX_FILTERS = 6;
-// -DTRK_V2_WRED=0 builds the per-lane form for A/B runs (profiles/r01_notes.md: 4.35 -> 4.19 ms)
-#ifndef TRK_V2_WRED
-#define TRK_V2_WRED 1
-#endif
-constexpr bool V2_WRED = TRK_V2_WRED != 0;
-// -DTRK_V2_ABL=<bits>: timing-only ablation builds of k_call_filter_v2 (wrong results; tools/v2_ablation.sh):
-// 1 no filter compares, 2 no per-sample counter adds, 4 no depth statistics, 8 no per-locus delta block,
-// 16 no decision logic at all (outputs are copies of the inputs), 32 no block prologue / delta flush,
-// 64 everything is computed but the stored words do not depend on it (GT' = GT, mask = 0)
-#ifndef TRK_V2_ABL
-#define TRK_V2_ABL 0
-#endif
-constexpr int V2_ABL = TRK_V2_ABL;
-// -DTRK_V2_HIST=<K>: TIMING EXPERIMENT -- the call-filter pass also histograms every call (K bank-spread copies per
-// bin, the count kernel's sentinel / equal-halves popcounts) into a scratch LDS table that nobody reads
-#ifndef TRK_V2_HIST
-#define TRK_V2_HIST 0
-#endif
-constexpr int V2_HIST = TRK_V2_HIST;
-struct V2Args {
+constexpr int V4_QCAP = 320;            // queue entries per wave: drained when fewer than 4 x 64 are free
+struct V4Args {
     trk_batch b;
-    V2Filter f[V2_MAX_FILTERS];
-    const int32_t* dp;    // DP/LC plane or nullptr
+    V4Filter f[V2_MAX_FILTERS];
+    const int32_t* dp;
     int loci_per_block;
-    int delta_nal;        // max_alleles when the delta outputs are requested, else 0
-    int dbg;              // TRK_CF_DBG (timing experiments only): 1 no per-sample counter flush, 2 no delta flush
-    int xy;               // 1: launched locus-major (blockIdx.x walks the locus blocks, blockIdx.y the column tiles)
-    // per-workgroup partial sample counters (plain coalesced stores, summed by k_cf_reduce) instead of one
-    // device-scope atomic per counter, sample and workgroup; nullptr: atomics
-    uint16_t* part16;     // [gridDim.y][2 + NF][S]: numcalls, dp-missing, filter k
-    unsigned long long* part64;  // [gridDim.y][S]: totaldp
+    int delta_nal;
+    int dbg;
+    CfGeom geom;
+    uint16_t* part16;
+    unsigned long long* part64;
     trk_call_out out;
 };
 
-// RATIO: some filter is a HipSTR-style ratio over the depth plane (float64 division, filters.py:415-484)
-// ALIAS: static sharing of plane registers -- bit 0: the depth statistics read filter 0's plane (a.dp == f[0].plane),
-//        bit k (k >= 1): filter k reads the plane of filter k - 1 (the host orders the filters so; min-DP / max-DP /
-//        depth sums are ONE 16-byte load per locus instead of three)
-// PF:    the planes of locus l + 1 are requested before locus l is evaluated (second register set)
-template <int NF, bool DELTA, bool RATIO, int ALIAS = 0, int PF = 0>
-__global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
+// one queued call: what it removes from its locus's counts (dumpSTR.py:715-727 masks it to a no-call)
+__device__ __forceinline__ void v4_drain_one(uint32_t w, uint32_t li, uint32_t* dtab, const trk_batch& b,
+                                             const int32_t* linfo, int nal, int dstride) {
+    uint32_t* tab = dtab + li * dstride;
+    const uint32_t A = (uint32_t)linfo[CF_LINFO * li];
+    const uint32_t a0 = w & 0xffffu, a1 = w >> 16;   // unsigned halves: -1 = 0xffff, -2 = 0xfffe
+    const bool v0 = a0 < A, v1 = a1 < A;             // (-2 / out of range: not below A)
+    atomicAdd(&tab[v0 ? (int)a0 : nal + V2_TRASH], 1u);
+    atomicAdd(&tab[v1 ? (int)a1 : nal + V2_TRASH], 1u);
+    const bool low = (a0 == 0xfffeu) | (a1 == 0xfffeu);
+    // homozygous by index (same allele twice); by length / sequence class only where the locus has alleles that
+    // share a class (rare): then the LUT decides for a0 != a1
+    bool hl = (a0 == a1) & v0, hs = hl;
+    if (v0 && v1 && !hl && cf_lut_needed(linfo, (int)li)) {
+        const int o = linfo[CF_LINFO * li + 2];   // (rare: the classes come from global memory, not from an LDS copy)
+        hl = b.len_class[o + a0] == b.len_class[o + a1];
+        hs = b.str_class[o + a0] == b.str_class[o + a1];
+    }
+    atomicAdd(&tab[nal + V2_W0], 1u + (low ? 0x10000u : 0u));
+    const uint32_t w1 = (hl ? 1u : 0u) + (hs ? 0x10000u : 0u);
+    if (w1) atomicAdd(&tab[nal + V2_W1], w1);
+}
+
+template <int NF, int NFLT, bool DELTA, bool RATIO, int ALIAS>
+__global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
     extern __shared__ uint32_t v2lds[];
     const int tid = threadIdx.x;
     const int S = a.b.n_samples, L = a.b.n_loci;
-    const int bix = a.xy ? blockIdx.y : blockIdx.x, biy = a.xy ? blockIdx.x : blockIdx.y;
-    const int gdy = a.xy ? gridDim.x : gridDim.y;
+    int bix, biy;
+    if (!cf_place(a.geom, bix, biy)) return;
     const int64_t s0 = ((int64_t)bix * CF_THREADS + tid) * CF_V;
     const int nal = a.delta_nal;
     const int dstride = nal + V2_EXTRA;
     uint32_t* dtab = v2lds;                                        // [loci][nal + 3]
-    uint32_t* lutb = dtab + (size_t)a.loci_per_block * dstride;    // [loci][nal]
-    int32_t* linfo = reinterpret_cast<int32_t*>(lutb + (size_t)a.loci_per_block * nal);  // [loci][2]
-    uint32_t* hist = reinterpret_cast<uint32_t*>(linfo + (size_t)a.loci_per_block * CF_LINFO);  // V2_HIST: [loci][(nal + 3) * K]
-    const int hstride = (nal + 3) * V2_HIST;
-    // per-sample counters live in registers across ALL the locus blocks this workgroup walks
-    // (blockIdx.y, + gridDim.y, ...) and are flushed once
+    int32_t* linfo = reinterpret_cast<int32_t*>(dtab + (size_t)a.loci_per_block * dstride);  // [loci][3]
+    // this wave's queue [V4_QCAP] of {genotype word, locus of the block}, behind the tables on an 8-byte boundary
+    uint2* queue = reinterpret_cast<uint2*>(v2lds + ((((size_t)a.loci_per_block * (dstride + CF_LINFO)) + 1) & ~(size_t)1)) +
+                   (size_t)(tid >> 6) * V4_QCAP;
     uint32_t numcalls[CF_V] = {0, 0, 0, 0}, dpmiss[CF_V] = {0, 0, 0, 0};
     uint32_t fc[NF][CF_V];
     int64_t totaldp[CF_V] = {0, 0, 0, 0};
@@ -2853,129 +2902,101 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
     for (int k = 0; k < NF; ++k)
 #pragma unroll
         for (int j = 0; j < CF_V; ++j) fc[k][j] = 0;
-    uint64_t nn[NF];      // all lanes when the filter also applies to calls that are not made
-    uint32_t bitv[NF];    // the filter's bit of the mask word
+    uint64_t nn[NF], inv[NF];   // all lanes when the filter also applies to calls that are not made / when inverted
+    uint32_t bitv[NF];          // the filter's bit of the mask word, in a vector register (a select's constant)
 #pragma unroll
     for (int k = 0; k < NF; ++k) {
         nn[k] = a.f[k].need_called == 0 ? ~0ull : 0ull;
+        inv[k] = a.f[k].invert ? ~0ull : 0ull;
         bitv[k] = 1u << a.f[k].bit;
+        asm volatile("" : "+v"(bitv[k]));
     }
+    uint32_t qtail = 0;         // wave-uniform
+    const bool live = s0 < S;
+    const bool has_dp = (ALIAS & 1) || a.dp != nullptr;
+    // (the last wave of a row may be partly beyond S: its live lanes share the queue among themselves)
+    const uint64_t exm = __ballot(live);
+    const uint32_t n_lanes = (uint32_t)__popcll(exm);
+    const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(exm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)exm, 0u));
+    auto drain = [&]() {
+        if (!DELTA) return;
+        wave_lds_fence();
+        for (uint32_t i = my_rank; i < qtail; i += n_lanes) {
+            const uint2 r = queue[i];
+            v4_drain_one(r.x, r.y, dtab, a.b, linfo, nal, dstride);
+        }
+        wave_lds_fence();
+        qtail = 0;
+    };
     const int n_blocks = (L + a.loci_per_block - 1) / a.loci_per_block;
-    for (int by = biy; by < n_blocks; by += gdy) {
-    const int l_begin = by * a.loci_per_block;
-    const int l_end = min(L, l_begin + a.loci_per_block);
-    const int nl = l_end - l_begin;
-    if (DELTA && !(V2_ABL & 32)) {
-        if (V2_HIST)
-            for (int i = tid; i < nl * hstride; i += CF_THREADS) hist[i] = 0;
-        for (int i = tid; i < nl * dstride; i += CF_THREADS) dtab[i] = 0;
-        cf_build_lut(a.b, l_begin, nl, nal, tid, lutb, linfo);
-    }
-    if (s0 < S) {
-        const bool leader = (tid & 63) == __ffsll((unsigned long long)__ballot(1)) - 1;  // first live lane of the wave
-        struct Set { u32x4 g; u32x4 pv[NF]; u32x4 dv; };
-        auto load_set = [&](Set& d, int l) {
-            const int64_t c4 = ((int64_t)l * S + s0) >> 2;
-            const u32x4* gp = reinterpret_cast<const u32x4*>(a.b.gt) + c4;
-            if (ALIAS == 0 && PF == 0) d.g = g_gt_temporal ? *gp : __builtin_nontemporal_load(gp);
-            else d.g = __builtin_nontemporal_load(gp);
-#pragma unroll
-            for (int k = 0; k < NF; ++k) {
-                if (k > 0 && ((ALIAS >> k) & 1)) d.pv[k] = d.pv[k - 1];
-                else d.pv[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.f[k].plane) + c4);
-            }
-            d.dv = (u32x4){0, 0, 0, 0};
-            if (ALIAS & 1) d.dv = d.pv[0];
-            else if (a.dp) d.dv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.dp) + c4);
-        };
-        Set cur;
-        if (PF) load_set(cur, l_begin);
-        for (int l = l_begin; l < l_end; ++l) {
-            const int64_t c4 = ((int64_t)l * S + s0) >> 2;
-            Set nxt;
-            if (PF) {
-                if (l + 1 < l_end) load_set(nxt, l + 1);
-                else nxt = cur;
-            } else {
-                load_set(cur, l);
-            }
-            const u32x4 g = cur.g;
-            u32x4 pv[NF];
-#pragma unroll
-            for (int k = 0; k < NF; ++k) pv[k] = cur.pv[k];
-            const u32x4 dv = cur.dv;
-            u32x4 wout, mout;
-            uint32_t w0acc = 0, w1acc = 0;
-            // The decisions are kept as wave-wide 64-bit lane masks in scalar registers (ballots) and combined by
-            // scalar instructions; the vector side only compares, builds the mask word, and bumps the counters with
-            // the mask as carry-in.  The filter's kind is tested ONCE per filter and locus (four plain compares per
-            // arm).  (Written call-major with per-lane booleans and the kind tested inside, the compiler emitted the
-            // four-way test per call and filter, merged the booleans with three scalar instructions each and ran out
-            // of scalar registers -- SGPR spills are v_readlane / v_writelane, vector instructions: 98 VALU + 100
-            // SALU instructions per call, the SIMDs 67 % VALU-busy; profiles/r02_notes.md section 8.)
-            uint64_t hm[NF][CF_V];
-#pragma unroll
-            for (int k = 0; k < NF; ++k) {
-                const V2Filter& f = a.f[k];
-                if (V2_ABL & 1) {
-#pragma unroll
-                    for (int j = 0; j < CF_V; ++j) hm[k][j] = 0;
-                } else if (RATIO && f.kind == 4) {
-                    // (deciding from x - thr * y and dividing only near ties was measured: 7.41 vs 7.19 ms, the
-                    // kernel has the issue slots for the division; profiles/r01_notes.md)
-#pragma unroll
-                    for (int j = 0; j < CF_V; ++j)
-                        hm[k][j] = __ballot(((double)(int32_t)pv[k][j] / (double)(int32_t)dv[j]) > f.dthr);
-                } else if (f.kind == 0) {
-#pragma unroll
-                    for (int j = 0; j < CF_V; ++j) hm[k][j] = __ballot((int32_t)pv[k][j] < f.ithr);
-                } else if (f.kind == 1) {
-#pragma unroll
-                    for (int j = 0; j < CF_V; ++j) hm[k][j] = __ballot((int32_t)pv[k][j] > f.ithr);
-                } else if (f.kind == 2) {
-#pragma unroll
-                    for (int j = 0; j < CF_V; ++j) hm[k][j] = __ballot(__uint_as_float(pv[k][j]) < f.fthr);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < CF_V; ++j) hm[k][j] = __ballot(__uint_as_float(pv[k][j]) > f.fthr);
-                }
-            }
-            uint64_t passm[CF_V], filtm[CF_V];
-#pragma unroll
-            for (int j = 0; j < CF_V; ++j) {
-                const uint32_t w = g[j];
-                // (one ballot per compare: the ballot of a combined condition goes through a 0/1 register)
-                const uint64_t calledm = __ballot((w & 0xffffu) != 0xffffu) & __ballot(w < 0xffff0000u);
-                uint32_t m = __builtin_amdgcn_inverse_ballot_w64(calledm) ? 0u : TRK_MASK_NOCALL;
-                uint64_t anyhit = 0;
+    const int by_end = min(n_blocks, (biy + 1) * a.geom.walk);
+    for (int by = biy * a.geom.walk; by < by_end; ++by) {
+        const int l_begin = by * a.loci_per_block;
+        const int l_end = min(L, l_begin + a.loci_per_block);
+        const int nl = l_end - l_begin;
+        if (DELTA) {
+            for (int i = tid; i < nl * dstride; i += CF_THREADS) dtab[i] = 0;
+            cf_build_lut<false>(a.b, l_begin, nl, nal, tid, nullptr, linfo);
+        }
+        if (live) {
+            for (int l = l_begin; l < l_end; ++l) {
+                const int64_t c4 = ((int64_t)l * S + s0) >> 2;
+                const u32x4 g = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.b.gt) + c4);
+                u32x4 pv[NF];
 #pragma unroll
                 for (int k = 0; k < NF; ++k) {
-                    const uint64_t h = hm[k][j] & (calledm | nn[k]);
-                    m |= __builtin_amdgcn_inverse_ballot_w64(h) ? bitv[k] : 0u;
-                    if (!(V2_ABL & 2)) add_mask(fc[k][j], h & calledm);  // dumpSTR.py:661
-                    anyhit |= h;
+                    if (k > 0 && ((ALIAS >> k) & 1)) pv[k] = pv[k - 1];
+                    else pv[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.f[k].plane) + c4);
                 }
-                passm[j] = calledm & ~anyhit;   // mask word == 0: dumpSTR.py:686
-                filtm[j] = calledm & anyhit;    // called and not passing: dumpSTR.py:715-727
-                if (!(V2_ABL & 2)) add_mask(numcalls[j], passm[j]);
-                wout[j] = __builtin_amdgcn_inverse_ballot_w64(filtm[j]) ? 0xffffffffu : w;
-                mout[j] = m;
-            }
-            if (V2_ABL & 16) {
-#pragma unroll
-                for (int j = 0; j < CF_V; ++j) { wout[j] = g[j]; mout[j] = pv[0][j] ^ pv[NF - 1][j]; }
-            }
-            if (!(V2_ABL & 4) && ((ALIAS & 1) || a.dp)) {
+                u32x4 dv = {0, 0, 0, 0};
+                if (ALIAS & 1) dv = pv[0];
+                else if (a.dp) dv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.dp) + c4);
+                u32x4 wout, mout;
                 uint64_t bad = 0;
+                const uint32_t li = (uint32_t)(l - l_begin);
 #pragma unroll
                 for (int j = 0; j < CF_V; ++j) {
-                    const int32_t d = (int32_t)dv[j];
-                    add_mask(dpmiss[j], passm[j] & __ballot(d == INT32_MIN));
-                    const int32_t dpos = d > 0 ? d : 0;
-                    totaldp[j] += __builtin_amdgcn_inverse_ballot_w64(passm[j]) ? dpos : 0;
-                    bad |= passm[j] & __ballot((uint32_t)d > 0x80000000u);   // negative, not the missing marker
+                    const uint32_t w = g[j];
+                    // called: neither half is the missing marker (one ballot per compare: the ballot of a combined
+                    // condition goes through a 0/1 register)
+                    const uint64_t calledm = __ballot((w & 0xffffu) != 0xffffu) & __ballot(w < 0xffff0000u);
+                    uint32_t m = __builtin_amdgcn_inverse_ballot_w64(calledm) ? 0u : TRK_MASK_NOCALL;
+                    uint64_t anyhit = 0;
+#pragma unroll
+                    for (int k = 0; k < NF; ++k) {
+                        const V4Filter& f = a.f[k];
+                        uint64_t c;
+                        if (RATIO && f.ratio)
+                            c = __ballot(((double)(int32_t)pv[k][j] / (double)(int32_t)dv[j]) > f.dthr);
+                        else if (NFLT < 0 ? f.is_float != 0 : k >= NF - NFLT)
+                            c = __ballot(__uint_as_float(pv[k][j] ^ f.flip) < __uint_as_float((uint32_t)f.thr));
+                        else
+                            c = __ballot((int32_t)pv[k][j] < f.thr) ^ inv[k];
+                        const uint64_t h = c & (calledm | nn[k]);
+                        m |= __builtin_amdgcn_inverse_ballot_w64(h) ? bitv[k] : 0u;
+                        add_mask(fc[k][j], h & calledm);   // dumpSTR.py:661
+                        anyhit |= h;
+                    }
+                    const uint64_t passm = calledm & ~anyhit;   // mask word == 0: dumpSTR.py:686
+                    const uint64_t filtm = calledm & anyhit;    // called and not passing: dumpSTR.py:715-727
+                    add_mask(numcalls[j], passm);
+                    wout[j] = __builtin_amdgcn_inverse_ballot_w64(filtm) ? 0xffffffffu : w;
+                    mout[j] = m;
+                    if (has_dp) {
+                        const int32_t d = (int32_t)dv[j];
+                        add_mask(dpmiss[j], passm & __ballot(d == INT32_MIN));
+                        const int32_t dpos = d > 0 ? d : 0;
+                        totaldp[j] += __builtin_amdgcn_inverse_ballot_w64(passm) ? dpos : 0;
+                        bad |= passm & __ballot((uint32_t)d > 0x80000000u);   // negative, not the missing marker
+                    }
+                    if (DELTA && filtm) {   // (wave-uniform test) queue the filtered calls of slot j
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(filtm >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)filtm, 0u));
+                        if (__builtin_amdgcn_inverse_ballot_w64(filtm)) queue[qtail + rank] = make_uint2(w, li);
+                        qtail += (uint32_t)__popcll(filtm);
+                    }
                 }
-                if (bad) {   // a negative depth on a call that passes (cold): dumpSTR.py:698-706
+                if (has_dp && bad) {   // a negative depth on a call that passes (cold): dumpSTR.py:698-706
 #pragma unroll
                     for (int j = CF_V - 1; j >= 0; --j) {
                         const int32_t d = (int32_t)dv[j];
@@ -2987,142 +3008,43 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
                         }
                     }
                 }
+                if (a.out.gt_out) __builtin_nontemporal_store(wout, reinterpret_cast<u32x4*>(a.out.gt_out) + c4);
+                if (a.out.filter_mask) __builtin_nontemporal_store(mout, reinterpret_cast<u32x4*>(a.out.filter_mask) + c4);
+                if (a.out.filter_mask8) {   // one byte per call: bit 7 = no-call
+                    uint32_t m8 = 0;
+#pragma unroll
+                    for (int j = 0; j < CF_V; ++j) m8 |= ((mout[j] & 0x7fu) | ((mout[j] >> 24) & 0x80u)) << (8 * j);
+                    __builtin_nontemporal_store(m8, reinterpret_cast<uint32_t*>(a.out.filter_mask8) + c4);
+                }
+                if (DELTA && qtail > (uint32_t)(V4_QCAP - CF_V * WAVE)) drain();
             }
-            if (V2_HIST && DELTA) {
-                const int li = l - l_begin;
-                const uint32_t A2 = (uint32_t)linfo[CF_LINFO * li] + 2u;
-                const uint32_t amax2 = A2 | (A2 << 16);
-                const uint32_t hb = (uint32_t)(uintptr_t)(lds_u32p)(hist + li * hstride + (tid & (V2_HIST - 1)));
-                const uint32_t kbytes = 4u * V2_HIST;
-                uint32_t e0 = 0, e1 = 0, e2 = 0;
-#pragma unroll
-                for (int j = 0; j < CF_V; ++j) {
-                    u16x2 u = __builtin_bit_cast(u16x2, g[j]) + (u16x2){2, 2};
-                    u16x2 t2 = __builtin_elementwise_min(u, __builtin_bit_cast(u16x2, amax2));
-                    const uint32_t t = __builtin_bit_cast(uint32_t, t2);
-                    __hip_atomic_fetch_add((lds_u32p)(uintptr_t)mad16_lo(t, kbytes, hb), 1u, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add((lds_u32p)(uintptr_t)mad16_hi(t, kbytes, hb), 1u, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
-                    e0 += (uint32_t)__popcll(halves_equal(t)) + ((uint32_t)__popcll(__ballot(t == 0x00000000u)) << 16);
-                    e1 += (uint32_t)__popcll(__ballot(t == 0x00000001u)) + ((uint32_t)__popcll(__ballot(t == 0x00010000u)) << 16);
-                    e2 += (uint32_t)__popcll(__ballot(t == 0x00010001u));
-                }
-                if (leader) {
-                    uint32_t* tl = hist + li * hstride + (nal + 2) * V2_HIST;
-                    atomicAdd(&tl[0], e0);
-                    atomicAdd(&tl[1], e1);
-                    atomicAdd(&tl[2], e2);
-                }
-            }
-            uint32_t* tab = dtab;
-            if (V2_ABL & 8) {
-            } else if (DELTA && V2_WRED) {
-                // the per-locus words are sums of lane flags: count them from the masks, one LDS atomic per wave
-                const int li = l - l_begin;
-                tab = dtab + li * dstride;
-                const uint32_t A = (uint32_t)linfo[CF_LINFO * li];
-                const bool lut_needed = cf_lut_needed(linfo, li);
-                const uint32_t* lutl = lutb + li * nal;
-#pragma unroll
-                for (int j = 0; j < CF_V; ++j) {
-                    const uint32_t w = g[j];
-                    const uint32_t a0 = w & 0xffffu, a1 = w >> 16;   // unsigned halves: -1 = 0xffff, -2 = 0xfffe
-                    const bool filtered = __builtin_amdgcn_inverse_ballot_w64(filtm[j]);
-                    const bool v0 = a0 < A, v1 = a1 < A;             // (-2 / out of range: not below A)
-                    const uint64_t lowm = filtm[j] & (__ballot(a0 == 0xfffeu) | __ballot(a1 == 0xfffeu));
-                    // homozygous by index (same allele twice); by length / sequence class only where the locus has
-                    // alleles that share a class (uniform per locus, rare): then the LUT decides for a0 != a1
-                    uint64_t hlm = filtm[j] & __ballot(a0 == a1) & __ballot(v0), hsm = hlm;
-                    if (filtered) {
-                        atomicAdd(&tab[v0 ? (int)a0 : nal + V2_TRASH], 1u);
-                        atomicAdd(&tab[v1 ? (int)a1 : nal + V2_TRASH], 1u);
-                    }
-                    if (lut_needed) {
-                        const bool need = filtered & v0 & v1 & (a0 != a1);
-                        uint32_t q = 0xffffffffu;
-                        if (need) q = lutl[a0] ^ lutl[a1];
-                        hlm |= __ballot((q & 0xffffu) == 0u);
-                        hsm |= __ballot((q >> 16) == 0u);
-                    }
-                    w0acc += (uint32_t)__popcll(filtm[j]) + ((uint32_t)__popcll(lowm) << 16);
-                    w1acc += (uint32_t)__popcll(hlm) + ((uint32_t)__popcll(hsm) << 16);
-                }
-            } else if (DELTA) {
-                const int li = l - l_begin;
-                tab = dtab + li * dstride;
-                const int A = linfo[CF_LINFO * li];
-                const bool lut_needed = cf_lut_needed(linfo, li);
-#pragma unroll
-                for (int j = 0; j < CF_V; ++j) {
-                    if (__builtin_amdgcn_inverse_ballot_w64(filtm[j])) {
-                        const uint32_t w = g[j];
-                        const int sa0 = (int)(int16_t)(w & 0xffffu), sa1 = (int)(int16_t)(w >> 16);
-                        const bool v0 = (unsigned)sa0 < (unsigned)A, v1 = (unsigned)sa1 < (unsigned)A;
-                        atomicAdd(&tab[v0 ? sa0 : nal + V2_TRASH], 1u);
-                        atomicAdd(&tab[v1 ? sa1 : nal + V2_TRASH], 1u);
-                        const bool low = (sa0 == -2) | (sa1 == -2);
-                        bool hl = (sa0 == sa1) & v0, hs = hl;
-                        if (v0 && v1 && !hl && lut_needed) {
-                            const uint32_t* lutl = lutb + li * nal;
-                            const uint32_t q = lutl[sa0] ^ lutl[sa1];
-                            hl = (q & 0xffffu) == 0u;
-                            hs = (q >> 16) == 0u;
-                        }
-                        atomicAdd(&tab[nal + V2_W0], 1u + (low ? 0x10000u : 0u));
-                        const uint32_t w1 = (hl ? 1u : 0u) + (hs ? 0x10000u : 0u);
-                        if (w1) atomicAdd(&tab[nal + V2_W1], w1);
-                    }
+            drain();
+        }
+        if (DELTA) {  // one global atomic per non-zero entry of the block's delta table
+            __syncthreads();
+            const uint32_t rcp = (uint32_t)((0x100000000ull + (uint32_t)dstride - 1u) / (uint32_t)dstride);  // i / dstride
+            for (int i = tid; i < nl * dstride; i += CF_THREADS) {
+                const uint32_t v = dtab[i];
+                if (!v || (a.dbg & 2)) continue;
+                const int li = (int)__umulhi((uint32_t)i, rcp);
+                const int r = i - li * dstride;
+                const int l = l_begin + li;
+                if (r < nal) {
+                    atomicSub(&a.out.delta_allele_count[linfo[CF_LINFO * li + 2] + r], (int)v);
+                } else if (r == nal + V2_W0) {
+                    int32_t* li_ = a.out.delta_locus_int + (int64_t)l * TRK_LI_COLS;
+                    atomicSub(&li_[TRK_LI_N_CALLED], (int)(v & 0xffffu));
+                    if (v >> 16) atomicSub(&li_[TRK_LI_N_LOWPLOIDY], (int)(v >> 16));
+                } else if (r == nal + V2_W1) {
+                    int32_t* li_ = a.out.delta_locus_int + (int64_t)l * TRK_LI_COLS;
+                    if (v & 0xffffu) atomicSub(&li_[TRK_LI_N_HOM_LEN], (int)(v & 0xffffu));
+                    if (v >> 16) atomicSub(&li_[TRK_LI_N_HOM_STR], (int)(v >> 16));
                 }
             }
-            if (DELTA && V2_WRED && leader && !(V2_ABL & 8)) {
-                if (w0acc) atomicAdd(&tab[nal + V2_W0], w0acc);
-                if (w1acc) atomicAdd(&tab[nal + V2_W1], w1acc);
-            }
-            if (V2_ABL & 64) {   // the decisions are made (they feed the counters), but what is stored does not depend on them
-#pragma unroll
-                for (int j = 0; j < CF_V; ++j) {
-                    numcalls[j] += (wout[j] != g[j]) + (mout[j] != 0u);
-                    wout[j] = g[j];
-                    mout[j] = 0u;
-                }
-            }
-            if (a.out.gt_out) __builtin_nontemporal_store(wout, reinterpret_cast<u32x4*>(a.out.gt_out) + c4);
-            if (a.out.filter_mask) __builtin_nontemporal_store(mout, reinterpret_cast<u32x4*>(a.out.filter_mask) + c4);
-            if (a.out.filter_mask8) {   // one byte per call: bit 7 = no-call
-                uint32_t m8 = 0;
-#pragma unroll
-                for (int j = 0; j < CF_V; ++j) m8 |= ((mout[j] & 0x7fu) | ((mout[j] >> 24) & 0x80u)) << (8 * j);
-                __builtin_nontemporal_store(m8, reinterpret_cast<uint32_t*>(a.out.filter_mask8) + c4);
-            }
-            if (PF) cur = nxt;
+            __syncthreads();   // the table is re-initialised for the next block
         }
     }
-    if (DELTA && !(V2_ABL & 32)) {  // one global atomic per non-zero entry of the block's delta table
-        __syncthreads();
-        const uint32_t rcp = (uint32_t)((0x100000000ull + (uint32_t)dstride - 1u) / (uint32_t)dstride);  // i / dstride
-        for (int i = tid; i < nl * dstride; i += CF_THREADS) {
-            const uint32_t v = dtab[i];
-            if (!v || (a.dbg & 2)) continue;
-            const int li = (int)__umulhi((uint32_t)i, rcp);
-            const int r = i - li * dstride;
-            const int l = l_begin + li;
-            if (r < nal) {
-                atomicSub(&a.out.delta_allele_count[linfo[CF_LINFO * li + 2] + r], (int)v);
-            } else if (r == nal + V2_W0) {
-                int32_t* li_ = a.out.delta_locus_int + (int64_t)l * TRK_LI_COLS;
-                atomicSub(&li_[TRK_LI_N_CALLED], (int)(v & 0xffffu));
-                if (v >> 16) atomicSub(&li_[TRK_LI_N_LOWPLOIDY], (int)(v >> 16));
-            } else if (r == nal + V2_W1) {
-                int32_t* li_ = a.out.delta_locus_int + (int64_t)l * TRK_LI_COLS;
-                if (v & 0xffffu) atomicSub(&li_[TRK_LI_N_HOM_LEN], (int)(v & 0xffffu));
-                if (v >> 16) atomicSub(&li_[TRK_LI_N_HOM_STR], (int)(v >> 16));
-            }
-        }
-        __syncthreads();   // the table is re-initialised for the next block
-    }
-    }  // locus blocks of this workgroup
-    if (s0 < S && a.part16 && !(a.dbg & 1)) {
+    if (live && a.part16 && !(a.dbg & 1)) {
         // this workgroup's counters of its 4 samples: one 8-byte store per counter row, 32 bytes of depth sums
         typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
         typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
@@ -3139,7 +3061,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
         u64x2* p64 = reinterpret_cast<u64x2*>(a.part64 + (size_t)biy * S + s0);
         p64[0] = (u64x2){(unsigned long long)totaldp[0], (unsigned long long)totaldp[1]};
         p64[1] = (u64x2){(unsigned long long)totaldp[2], (unsigned long long)totaldp[3]};
-    } else if (s0 < S && !(a.dbg & 1)) {
+    } else if (live && !(a.dbg & 1)) {
 #pragma unroll
         for (int j = 0; j < CF_V; ++j) {
             const int64_t s = s0 + j;
@@ -3160,7 +3082,6 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
                               (unsigned long long)fc[k][j]);
         }
     }
-
 }
 
 // ---------------------------------------------------------------------------
@@ -3172,7 +3093,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v2(const V2Args a) {
 //   2 min Q    Q < t (float32)        (every call)          7 span+bound  RC[1] + RC[3] == DP (int64 sum; called)
 //   3 QEXP het QEXP[1] < t            (called)              8 bad CI      REPCN[j] outside REPCI[2j .. 2j+1], j = 0, 1
 //   4 QEXP hom QEXP[2] < t            (called)
-// Same tiling, counters, delta table and outputs as k_call_filter_v2 (column-owner: thread = 4 samples x the loci of
+// Same tiling, counters, delta table and outputs as k_call_filter_v4 (column-owner: thread = 4 samples x the loci of
 // its workgroup).  PLANAR: every column its own [L, S] array (13 16-byte loads per locus, unused columns never
 // read); otherwise the planes as cyvcf2 / Engine.upload_plane hands them, [L, S, k]: the k vectors of a thread's
 // four calls are loaded whole and the columns picked out of the registers with compile-time indices (16 loads).
@@ -3194,8 +3115,9 @@ struct GsArgs {
     const void* p[12];
     int use_qexp, use_rc, use_ci, has_dp;
     int loci_per_block, delta_nal;
-    uint16_t* part16;            // [gridDim.y][2 + GS_NF][S]
-    unsigned long long* part64;  // [gridDim.y][S]
+    uint16_t* part16;            // [n_ranges][2 + GS_NF][S]
+    unsigned long long* part64;  // [n_ranges][S]
+    CfGeom geom;                 // workgroup -> (column tile, range of locus blocks), as in k_call_filter_v4
     trk_call_out out;
 };
 
@@ -3207,7 +3129,9 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_gs(const GsArgs a) {
     extern __shared__ uint32_t v2lds[];
     const int tid = threadIdx.x;
     const int S = a.b.n_samples, L = a.b.n_loci;
-    const int64_t s0 = ((int64_t)blockIdx.x * CF_THREADS + tid) * CF_V;
+    int bix, biy;
+    if (!cf_place(a.geom, bix, biy)) return;
+    const int64_t s0 = ((int64_t)bix * CF_THREADS + tid) * CF_V;
     const int nal = a.delta_nal;
     const int dstride = nal + V2_EXTRA;
     uint32_t* dtab = v2lds;
@@ -3233,7 +3157,8 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_gs(const GsArgs a) {
             add_mask(c[j >> 1], mask);
     };
     const int n_blocks = (L + a.loci_per_block - 1) / a.loci_per_block;
-    for (int by = blockIdx.y; by < n_blocks; by += gridDim.y) {
+    const int by_end = min(n_blocks, (biy + 1) * a.geom.walk);
+    for (int by = biy * a.geom.walk; by < by_end; ++by) {
     const int l_begin = by * a.loci_per_block;
     const int l_end = min(L, l_begin + a.loci_per_block);
     const int nl = l_end - l_begin;
@@ -3356,7 +3281,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_gs(const GsArgs a) {
                     }
                 }
             }
-            if (DELTA) {    // what the filtered calls remove from the locus counts (as k_call_filter_v2)
+            if (DELTA) {    // what the filtered calls remove from the locus counts (k_call_filter_v4 queues them instead)
                 const int li = l - l_begin;
                 uint32_t* tab = dtab + li * dstride;
                 const uint32_t A = (uint32_t)linfo[CF_LINFO * li];
@@ -3427,7 +3352,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_gs(const GsArgs a) {
     if (s0 < S) {
         typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
         typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-        u16x4* p16 = reinterpret_cast<u16x4*>(a.part16 + ((size_t)blockIdx.y * (2 + GS_NF)) * S + s0);
+        u16x4* p16 = reinterpret_cast<u16x4*>(a.part16 + ((size_t)biy * (2 + GS_NF)) * S + s0);
         const size_t rs = (size_t)S / 4;
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         // (the pairs are already in the partial rows' layout: four 16-bit counters = two registers = one 8-byte store)
@@ -3435,14 +3360,14 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_gs(const GsArgs a) {
         reinterpret_cast<u32x2*>(p16 + rs)[0] = (u32x2){dpmiss[0], dpmiss[1]};
 #pragma unroll
         for (int k = 0; k < GS_NF; ++k) reinterpret_cast<u32x2*>(p16 + (2 + k) * rs)[0] = (u32x2){fc[k][0], fc[k][1]};
-        u64x2* p64 = reinterpret_cast<u64x2*>(a.part64 + (size_t)blockIdx.y * S + s0);
+        u64x2* p64 = reinterpret_cast<u64x2*>(a.part64 + (size_t)biy * S + s0);
         p64[0] = (u64x2){(unsigned long long)totaldp[0], (unsigned long long)totaldp[1]};
         p64[1] = (u64x2){(unsigned long long)totaldp[2], (unsigned long long)totaldp[3]};
     }
 }
 
 // ---------------------------------------------------------------------------
-// k_cf_reduce : sums the per-workgroup partial sample counters of k_call_filter_v2 into the int64 outputs.
+// k_cf_reduce : sums the per-workgroup partial sample counters of k_call_filter_v4 / _gs into the int64 outputs.
 // Thread (quad of 4 samples, slice): walks the locus blocks by = slice, slice + NSL, ...; the NSL slices of a quad are
 // added up through LDS and one thread per quad does the (non-atomic) += on the outputs.  12.5k loci x 10k samples:
 // 1280 workgroups x 60k counters = 7.7 M device-scope atomics (58 us, all at the end of the single round of
@@ -3674,11 +3599,13 @@ struct ProbeArgs {
     u32x4* out[4];
 };
 template <int NIN, int NOUT>
-__global__ __launch_bounds__(256) void k_stream_probe(ProbeArgs s, int L, int S4, int lpb) {
+__global__ __launch_bounds__(256) void k_stream_probe(ProbeArgs s, int L, int S4, int lpb, CfGeom geom) {
     extern __shared__ uint32_t probe_lds[];   // sized by the launcher to cap the resident workgroups per CU
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    int bix, biy;
+    if (!cf_place(geom, bix, biy)) return;     // the call-filter kernels' own workgroup -> (tile, range) map
+    const int c = bix * 256 + threadIdx.x;
     if (c >= S4) return;
-    const int l0 = blockIdx.y * lpb, l1 = min(L, l0 + lpb);
+    const int l0 = biy * geom.walk * lpb, l1 = min(L, l0 + geom.walk * lpb);
     for (int l = l0; l < l1; ++l) {
         const size_t o = (size_t)l * S4 + c;
         u32x4 r = {(uint32_t)l, 1u, 2u, 3u};
@@ -3866,6 +3793,74 @@ __global__ __launch_bounds__(256) void k_pad_rows(const uint32_t* __restrict__ s
 // ---------------------------------------------------------------------------
 namespace trk {
 
+// Geometry of a column-owner call-filter launch (CfGeom): L loci, gx column tiles, at most lpb_cap loci per LDS block,
+// `occ` resident workgroups per CU.
+//   * PERSISTENT when the batch is long enough (every workgroup gets at least two LDS blocks): W workgroups per CU
+//     (TRK_CF_WGCU; default min(occ, 5)), each walking ONE contiguous range of loci block by block with its per-sample
+//     counters in registers -- n_ranges partial-counter rows for k_cf_reduce instead of one per block.
+//   * otherwise (a strong-scaling shard, a command-line batch): one block per workgroup, whole rounds of resident
+//     workgroups and at least TRK_CF_MIN_ROUNDS (2) of them.  All workgroups of ONE round run their prologue (class
+//     LUT), their stream and their flush at the same time, so the memory system idles twice; from two rounds on the
+//     phases of different workgroups overlap (12.5k loci x 10k samples: 1070 workgroups of 117 loci = 0.84 rounds
+//     0.77 ms; 2560 of 49 loci 0.63 ms).
+//   * map (TRK_CF_MAP, default 2): the XCD-aware 1-D launch -- see CfGeom.
+struct CfLaunch {
+    CfGeom geom;
+    int lpb;
+    dim3 grid;
+};
+static CfLaunch cf_geometry(int L, int gx, int lpb_cap, int n_cu, int occ) {
+    CfLaunch r;
+    if (lpb_cap < 1) lpb_cap = 1;
+    if (const char* e = getenv("TRK_CF_LPB")) {
+        const int q = atoi(e);
+        if (q > 0 && q < lpb_cap) lpb_cap = q;
+    }
+    int map = 2;
+    if (const char* e = getenv("TRK_CF_MAP")) map = atoi(e);
+    if (map < 0 || map > 2) map = 2;
+    if (occ < 1) occ = 4;
+    // one workgroup slot per CU stays free when five fit: same-process A/B at 100k x 10k (r04_notes section 2) -- four
+    // per CU 3.53 + 0.014 ms (kernel + k_cf_reduce), five 3.46 + 0.13, and the step's small kernels on the other
+    // queues (finalisers, HWE tests) find room: 4.29 against 4.36 ms per step
+    int wgcu = occ >= 5 ? 4 : occ;
+    if (const char* e = getenv("TRK_CF_WGCU")) wgcu = atoi(e) > 0 ? atoi(e) : wgcu;
+    long pr = (long)wgcu * n_cu / gx;             // ranges of a persistent launch
+    if (map == 2) pr = pr / 8 * 8;
+    if (pr < 1) pr = 1;
+    const long lpr = (L + pr - 1) / pr;             // loci per range
+    int lpb, walk;
+    if (lpr >= 2L * lpb_cap && !getenv("TRK_CF_NO_PERSIST")) {
+        walk = (int)((lpr + lpb_cap - 1) / lpb_cap);
+        lpb = (int)((lpr + walk - 1) / walk);
+    } else {
+        int min_rounds = 2;
+        if (const char* e = getenv("TRK_CF_MIN_ROUNDS")) min_rounds = atoi(e) > 0 ? atoi(e) : 2;
+        const long slots = (long)n_cu * occ;
+        lpb = lpb_cap;
+        long k = ((long)gx * ((L + lpb - 1) / lpb) + slots - 1) / slots;
+        if (k < min_rounds) k = min_rounds;
+        long gyr = (k * slots) / gx;
+        if (gyr > L) gyr = L;
+        if (gyr >= 1) {
+            int lpb2 = (int)((L + gyr - 1) / gyr);
+            if (lpb2 < 8) lpb2 = L < 8 ? (L > 0 ? L : 1) : 8;   // a block's fixed cost needs some loci to spread over
+            if (lpb2 < lpb) lpb = lpb2;
+        }
+        walk = 1;
+    }
+    const int n_blocks = (L + lpb - 1) / lpb;
+    r.lpb = lpb;
+    r.geom.gx = gx;
+    r.geom.walk = walk;
+    r.geom.n_ranges = (n_blocks + walk - 1) / walk;
+    r.geom.map = map;
+    if (map == 2) r.grid = dim3((unsigned)((r.geom.n_ranges + 7) / 8 * 8) * (unsigned)gx);
+    else if (map == 1) r.grid = dim3((unsigned)r.geom.n_ranges, (unsigned)gx);
+    else r.grid = dim3((unsigned)gx, (unsigned)r.geom.n_ranges);
+    return r;
+}
+
 static int next_pow2(int v) {
     int p = 1;
     while (p < v) p <<= 1;
@@ -3978,7 +3973,6 @@ hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* alle
     const int G = b.group_bits ? b.n_groups : 1;
     const bool fast2 = (b.ploidy == 2) && !b.group_bits;
     const size_t ac_elems = (size_t)G * (size_t)b.n_alleles_total, li_elems = (size_t)G * b.n_loci * TRK_LI_COLS;
-    const int64_t twin_ac = twin ? (int64_t)ac_elems : 0, twin_li = twin ? (int64_t)li_elems : 0;
     auto zero_outputs = [&]() -> hipError_t {
         hipError_t e = hipMemsetAsync(allele_count, 0, ac_elems * sizeof(int32_t), stream);
         if (e != hipSuccess) return e;
@@ -4337,27 +4331,29 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             a.delta_stride = stride;
         }
     }
-    // ---- issue-lean kernel: every filter a plain threshold on a single-column plane ----
+    // ---- k_call_filter_v4: every filter a plain threshold on a single-column plane (or a HipSTR ratio over the
+    // depth plane); static compare types, queued delta updates ----
     if (vec && !b.locus_ploidy && n_filters >= 1 && n_filters <= V2_MAX_FILTERS && !getenv("TRK_CF_GENERIC")) {
-        V2Args v;
+        V4Args v = {};
+        V4Filter raw[V2_MAX_FILTERS];
+        bool is_f32[V2_MAX_FILTERS];
         bool ok = true, ratio = false;
         for (int k = 0; k < n_filters && ok; ++k) {
             const trk_call_filter& f = filters[k];
             const trk_plane& pl = planes[f.plane_a];
-            V2Filter& o = v.f[k];
+            V4Filter& o = raw[k];
+            o = V4Filter{};
             o.need_called = f.op == TRK_F_CALLED_LT;
             o.bit = k;
-            o.pad = 0;
-            o.ithr = 0;
-            o.fthr = 0.f;
             o.dthr = f.thr;
+            is_f32[k] = false;
             if (f.op == TRK_F_RATIO_GT) {
                 // numerator an int32 source, denominator the depth vector the kernel loads anyway
                 ok = a.f_src_a[k] >= 0 && a.src_ptr[a.f_src_a[k]] && a.dp_src >= 0 && a.f_src_b[k] == a.dp_src &&
                      !((a.src_f32_mask >> a.f_src_a[k]) & 1u) && !((a.src_f32_mask >> a.dp_src) & 1u);
                 if (!ok) break;
                 o.plane = a.src_ptr[a.f_src_a[k]];
-                o.kind = 4;
+                o.ratio = 1;
                 ratio = true;
                 continue;
             }
@@ -4367,14 +4363,20 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             o.plane = a.src_ptr[a.f_src_a[k]];
             const bool gt_op = f.op == TRK_F_GT;
             if ((pl.dtype & 0xff) == TRK_DT_F32) {
-                o.kind = 2 | (gt_op ? 1 : 0);
-                o.fthr = (float)f.thr;
+                // x > t  <=>  -x < -t  (exact; a NaN on either side compares false both ways)
+                is_f32[k] = true;
+                o.is_float = 1;
+                const float t = (float)f.thr;
+                uint32_t tb;
+                memcpy(&tb, &t, 4);
+                o.flip = gt_op ? 0x80000000u : 0u;
+                o.thr = (int32_t)(tb ^ o.flip);
             } else {
-                // (double)v < thr  <=>  v < ceil(thr);   (double)v > thr  <=>  v > floor(thr)
+                // (double)v < thr  <=>  v < ceil(thr);   (double)v > thr  <=>  v > floor(thr)  <=>  !(v < floor(thr) + 1)
                 const double t = gt_op ? floor(f.thr) : ceil(f.thr);
                 if (!(t > -2147483647.0 && t < 2147483647.0)) ok = false;
-                o.kind = gt_op ? 1 : 0;
-                o.ithr = (int32_t)t;
+                o.thr = (int32_t)t + (gt_op ? 1 : 0);
+                o.invert = gt_op ? 1 : 0;
             }
         }
         if (ok && dp_plane >= 0 && a.dp_src < 0) ok = false;
@@ -4386,116 +4388,76 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             v.out = a.out;
             v.delta_nal = delta ? b.max_alleles : 0;
             v.dbg = a.dbg;
-            size_t lds2 = 0;
-            if (delta) {
-                const size_t per_locus = ((size_t)2 * b.max_alleles + V2_EXTRA + CF_LINFO + (size_t)(b.max_alleles + 3) * V2_HIST) * sizeof(uint32_t);
-                int max_lpb = (int)(((V2_HIST ? 30 : 32) * 1024) / per_locus);
-                if (lpb > max_lpb) lpb = max_lpb;
-                lds2 = (size_t)lpb * per_locus;
-            }
-            if (const char* e = getenv("TRK_CF_LPB")) {
-                int q = atoi(e);
-                if (q > 0 && (!delta || q <= lpb)) lpb = q;
-                if (delta) lds2 = (size_t)lpb * ((size_t)2 * b.max_alleles + V2_EXTRA + CF_LINFO + (size_t)(b.max_alleles + 3) * V2_HIST) * sizeof(uint32_t);
-            }
-            void (*kv2)(V2Args) = nullptr;
-#define TRK_V2(NFV)                                                                                   \
-    kv2 = (delta && ratio) ? k_call_filter_v2<NFV, true, true>                                        \
-          : delta          ? k_call_filter_v2<NFV, true, false>                                       \
-          : ratio          ? k_call_filter_v2<NFV, false, true>                                       \
-                           : k_call_filter_v2<NFV, false, false>
-            if (n_filters == 1) { TRK_V2(1); }
-            else if (n_filters == 2) { TRK_V2(2); }
-            else if (n_filters == 3) { TRK_V2(3); }
-            else if (n_filters == 4) { TRK_V2(4); }
-            else if (n_filters == 5) { TRK_V2(5); }
-            else { TRK_V2(6); }
-            // Static plane sharing (template ALIAS): the filters of one plane are made neighbours, the depth plane's
-            // first, and the instantiation whose alias pattern matches reads each plane ONCE per locus (min-DP /
-            // max-DP / depth sums: one 16-byte load instead of three; same-box A/B 3.85 -> 3.70 ms on a fast box,
-            // 4.34 -> 4.28 on a slow one, profiles/r03_notes.md).  TRK_V2_MODE=0 keeps one load per filter;
-            // bit 1 of TRK_V2_MODE adds the next-locus prefetch (measured: no gain, kept for A/B runs at NF = 3).
-            {
-                const int mode = getenv("TRK_V2_MODE") ? atoi(getenv("TRK_V2_MODE")) : 1;
-                if (mode && delta) {
-                    V2Filter tmp[V2_MAX_FILTERS];
-                    int n = 0;
-                    bool used[V2_MAX_FILTERS] = {false};
-                    for (int pass = 0; pass < 2; ++pass)
-                        for (int k = 0; k < n_filters; ++k) {
-                            if (used[k]) continue;
-                            if (pass == 0 && v.f[k].plane != (const void*)v.dp) continue;
-                            const void* pl = v.f[k].plane;
-                            for (int q = k; q < n_filters; ++q)
-                                if (!used[q] && v.f[q].plane == pl) { tmp[n++] = v.f[q]; used[q] = true; }
+            // order: the filters of one plane neighbours (one load per plane where the instantiation shares it), the
+            // depth plane's first, integer planes before float planes
+            int n = 0, nflt = 0;
+            bool used[V2_MAX_FILTERS] = {false};
+            for (int pass = 0; pass < 3; ++pass)
+                for (int k = 0; k < n_filters; ++k) {
+                    if (used[k]) continue;
+                    if (pass == 0 && raw[k].plane != (const void*)v.dp) continue;
+                    if (pass <= 1 && is_f32[k]) continue;
+                    const void* pl = raw[k].plane;
+                    for (int q = k; q < n_filters; ++q)
+                        if (!used[q] && raw[q].plane == pl && is_f32[q] == is_f32[k]) {
+                            v.f[n++] = raw[q];
+                            used[q] = true;
+                            nflt += is_f32[q] ? 1 : 0;
                         }
-                    int alias = (v.dp && tmp[0].plane == (const void*)v.dp) ? 1 : 0;
-                    if (n_filters >= 2 && tmp[1].plane == tmp[0].plane) alias |= 2;
-                    // (further pairs of one plane keep their own loads: only bit 0 / bit 1 patterns are instantiated)
-                    void (*ka)(V2Args) = nullptr;
-#define TRK_V2A(NFV, RT)                                                                          \
-    ka = alias == 3 ? (NFV >= 2 ? k_call_filter_v2<NFV, true, RT, (NFV >= 2 ? 3 : 1), 0> : nullptr) \
-       : alias == 1 ? k_call_filter_v2<NFV, true, RT, 1, 0> : nullptr
-                    if (!ratio) {
-                        if (n_filters == 1) { TRK_V2A(1, false); }
-                        else if (n_filters == 2) { TRK_V2A(2, false); }
-                        else if (n_filters == 3) { TRK_V2A(3, false); }
-                        else if (n_filters == 4) { TRK_V2A(4, false); }
-                    } else {
-                        if (n_filters == 3) { TRK_V2A(3, true); }
-                        else if (n_filters == 4) { TRK_V2A(4, true); }
-                        else if (n_filters == 5) { TRK_V2A(5, true); }
-                        else if (n_filters == 6) { TRK_V2A(6, true); }
-                    }
-#undef TRK_V2A
-                    if ((mode & 2) && n_filters == 3 && !ratio)
-                        ka = alias == 3 ? k_call_filter_v2<3, true, false, 3, 1> : k_call_filter_v2<3, true, false, 0, 1>;
-                    if (ka) {
-                        if (!((mode & 2) && alias != 3))
-                            for (int k = 0; k < n_filters; ++k) v.f[k] = tmp[k];
-                        kv2 = ka;
-                    }
                 }
+            int alias = (v.dp && v.f[0].plane == (const void*)v.dp) ? 1 : 0;
+            if (alias && n_filters >= 2 && v.f[1].plane == v.f[0].plane) alias = 3;
+            if (!delta) alias = 0;                 // (only the dumpSTR shape -- delta outputs -- has the sharing builds)
+            int tflt = nflt <= 1 ? nflt : -1;      // -1: the compare type is a run-time flag per filter
+            if (!delta) tflt = -1;
+            if (tflt < 0 && alias) alias = 0;
+            void (*k4)(V4Args) = nullptr;
+#define TRK_V4_PICK(NFV)                                                                                              \
+    if (!delta) k4 = ratio ? k_call_filter_v4<NFV, -1, false, true, 0> : k_call_filter_v4<NFV, -1, false, false, 0>;  \
+    else if (tflt < 0) k4 = ratio ? k_call_filter_v4<NFV, -1, true, true, 0> : k_call_filter_v4<NFV, -1, true, false, 0>; \
+    else if (tflt == 0)                                                                                               \
+        k4 = alias == 3   ? (ratio ? k_call_filter_v4<NFV, 0, true, true, (NFV >= 2 ? 3 : 1)> : k_call_filter_v4<NFV, 0, true, false, (NFV >= 2 ? 3 : 1)>) \
+             : alias == 1 ? (ratio ? k_call_filter_v4<NFV, 0, true, true, 1> : k_call_filter_v4<NFV, 0, true, false, 1>) \
+                          : (ratio ? k_call_filter_v4<NFV, 0, true, true, 0> : k_call_filter_v4<NFV, 0, true, false, 0>); \
+    else                                                                                                              \
+        k4 = alias == 3   ? (ratio ? k_call_filter_v4<NFV, 1, true, true, (NFV >= 2 ? 3 : 1)> : k_call_filter_v4<NFV, 1, true, false, (NFV >= 2 ? 3 : 1)>) \
+             : alias == 1 ? (ratio ? k_call_filter_v4<NFV, 1, true, true, 1> : k_call_filter_v4<NFV, 1, true, false, 1>) \
+                          : (ratio ? k_call_filter_v4<NFV, 1, true, true, 0> : k_call_filter_v4<NFV, 1, true, false, 0>)
+            switch (n_filters) {
+                case 1: TRK_V4_PICK(1); break;
+                case 2: TRK_V4_PICK(2); break;
+                case 3: TRK_V4_PICK(3); break;
+                case 4: TRK_V4_PICK(4); break;
+                case 5: TRK_V4_PICK(5); break;
+                default: TRK_V4_PICK(6); break;
             }
-            // Grid: whole rounds of resident workgroups, and at least TRK_CF_MIN_ROUNDS (2) of them.  All workgroups
-            // of ONE round run their prologue (class LUT), their stream and their flush at the same time, so the
-            // memory system idles twice; from two rounds on the phases of different workgroups overlap.  Matters
-            // for a strong-scaling shard (12.5k loci x 10k samples: 1070 workgroups of 117 loci = 0.84 rounds
-            // 0.77 ms; 2560 of 49 loci 0.63 ms); at 100k loci the rule changes 6.7 rounds into 7.
-            if (!getenv("TRK_CF_LPB")) {
-                int occ = 0;
-                const size_t lds_max = delta ? (size_t)lpb * ((size_t)2 * b.max_alleles + V2_EXTRA + CF_LINFO + (size_t)(b.max_alleles + 3) * V2_HIST) * 4 : 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kv2, CF_THREADS, lds_max) != hipSuccess || occ < 1)
-                    occ = 4;
-                int min_rounds = 2;
-                if (const char* e = getenv("TRK_CF_MIN_ROUNDS")) min_rounds = atoi(e) > 0 ? atoi(e) : 2;
-                const long slots = (long)n_cu * occ;
-                const long min_wgs = (long)gx * ((L + lpb - 1) / lpb);
-                long k = (min_wgs + slots - 1) / slots;
-                if (k < min_rounds) k = min_rounds;
-                long gyr = (k * slots) / gx;
-                if (gyr > L) gyr = L;
-                if (gyr >= 1) {
-                    int lpb2 = (int)((L + gyr - 1) / gyr);
-                    if (lpb2 < 8) lpb2 = L < 8 ? L : 8;      // a block's fixed cost needs some loci to spread over
-                    if (lpb2 < lpb) lpb = lpb2;
-                }
-                if (delta) lds2 = (size_t)lpb * ((size_t)2 * b.max_alleles + V2_EXTRA + CF_LINFO + (size_t)(b.max_alleles + 3) * V2_HIST) * sizeof(uint32_t);
+#undef TRK_V4_PICK
+            // LDS: the block's delta table + class LUT + locus info, and one queue per wave -- within 32 KiB, so that
+            // five workgroups fit a CU
+            const size_t qbytes = delta ? (size_t)(CF_THREADS / WAVE) * V4_QCAP * sizeof(uint2) : 0;
+            const size_t per_locus4 = delta ? ((size_t)b.max_alleles + V2_EXTRA + CF_LINFO) * sizeof(uint32_t) : 0;
+            if (delta) {
+                // (a workgroup's LDS stays well below 160 KiB / 5: at 32 360 bytes the occupancy query still says five
+                // workgroups per CU and four are resident -- a persistent launch then runs a second round)
+                size_t budget = 26 * 1024;
+                if (const char* e = getenv("TRK_CF_LDS_KB")) budget = (size_t)(atoi(e) > 12 ? atoi(e) : 12) * 1024;
+                const int max_lpb = (int)((budget - qbytes - 8) / per_locus4);
+                if (lpb > max_lpb) lpb = max_lpb;
+                if (lpb > 255) lpb = 255;
+                if (lpb < 1) lpb = 1;
             }
-            gy = (L + lpb - 1) / lpb;
+            int occ = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k4, CF_THREADS, (size_t)lpb * per_locus4 + qbytes + 8) != hipSuccess || occ < 1)
+                occ = 4;
+            const CfLaunch cl = cf_geometry(L, gx, lpb, n_cu, occ);
+            lpb = cl.lpb;
+            const size_t lds4 = delta ? (((size_t)lpb * per_locus4 + 7) & ~(size_t)7) + qbytes : 0;
             v.loci_per_block = lpb;
-            // workgroups walk blocks blockIdx.y, + gridDim.y, ... with the per-sample counters in registers;
-            // TRK_CF_GY caps gridDim.y (default: one block per workgroup)
-            if (const char* e = getenv("TRK_CF_GY")) {
-                int q = atoi(e);
-                if (q > 0 && q < gy) gy = q;
-            }
-            // per-workgroup partial counters + k_cf_reduce instead of atomics (u16 partials: a workgroup's loci
-            // must stay below 65536; TRK_CF_ATOMICS=1 keeps the atomics for A/B runs)
+            v.geom = cl.geom;
+            gy = cl.geom.n_ranges;
             v.part16 = nullptr;
             v.part64 = nullptr;
-            const long walks = ((L + lpb - 1) / lpb + gy - 1) / gy;
-            if (walks * lpb < 65536 && !getenv("TRK_CF_ATOMICS")) {
+            if ((long)cl.geom.walk * lpb < 65536 && !getenv("TRK_CF_ATOMICS")) {
                 const size_t b16 = (((size_t)gy * (2 + n_filters) * S * sizeof(uint16_t)) + 255) & ~(size_t)255;
                 const size_t b64 = (size_t)gy * S * sizeof(unsigned long long);
                 if (void* ws = scratch.get(scratch.user, b16 + b64)) {
@@ -4503,20 +4465,20 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
                     v.part64 = reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + b16);
                 }
             }
-            v.xy = getenv("TRK_CF_XY") ? atoi(getenv("TRK_CF_XY")) : 0;
-            dim3 grid(v.xy ? gy : gx, v.xy ? gx : gy), block(CF_THREADS);
-            hipLaunchKernelGGL(kv2, grid, block, lds2, stream, v);
+            if (getenv("TRK_CF_VERBOSE"))
+                fprintf(stderr, "k_call_filter_v4<%d,%d,%d,%d,%d>: L %d gx %d lpb %d walk %d ranges %d map %d grid %u x %u, lds %zu B, "
+                                "occupancy %d WG/CU\n", n_filters, tflt, (int)delta, (int)ratio, alias, L, gx, lpb, cl.geom.walk,
+                        cl.geom.n_ranges, cl.geom.map, cl.grid.x, cl.grid.y, lds4, occ);
+            hipLaunchKernelGGL(k4, cl.grid, dim3(CF_THREADS), lds4, stream, v);
             if (v.part16) {
                 hipError_t e1 = hipGetLastError();
                 if (e1 != hipSuccess) return e1;
                 if (scratch.next_kernel) scratch.next_kernel(scratch.user);
-                const int quads = S / 4;
                 CfrBits fb = {};
                 for (int k = 0; k < n_filters; ++k) fb.bit[k] = v.f[k].bit;
-                hipLaunchKernelGGL(k_cf_reduce, dim3((quads + CFR_QPB - 1) / CFR_QPB), dim3(CFR_NSL * CFR_QPB), 0, stream,
+                hipLaunchKernelGGL(k_cf_reduce, dim3((S / 4 + CFR_QPB - 1) / CFR_QPB), dim3(CFR_NSL * CFR_QPB), 0, stream,
                                    v.part16, v.part64, gy, S, 2 + n_filters, fb, out);
             }
-#undef TRK_V2
             return hipGetLastError();
         }
     }
@@ -4646,36 +4608,25 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
                 canonical ? (delta ? k_call_filter_gs<true, true, 0x1ff> : k_call_filter_gs<true, false, 0x1ff>)
                           : (planar ? (delta ? k_call_filter_gs<true, true, -1> : k_call_filter_gs<true, false, -1>)
                                     : (delta ? k_call_filter_gs<false, true, -1> : k_call_filter_gs<false, false, -1>));
-            // geometry as for k_call_filter_v2: whole rounds of resident workgroups, the delta table within 32 KiB
+            // geometry as for k_call_filter_v4 (cf_geometry), the delta table within 32 KiB
             const size_t per_locus = delta ? ((size_t)2 * b.max_alleles + V2_EXTRA + CF_LINFO) * sizeof(uint32_t) : 0;
             int lpb2 = lpb;
             if (delta) lpb2 = std::min<int>(lpb2, (int)((32 * 1024) / per_locus));
             int occ = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kg, CF_THREADS, (size_t)lpb2 * per_locus) != hipSuccess || occ < 1)
                 occ = 3;
-            const long slots = (long)n_cu * occ;
-            long rounds = ((long)gx * ((L + lpb2 - 1) / lpb2) + slots - 1) / slots;
-            if (rounds < 2) rounds = 2;
-            long gyr = rounds * slots / gx;
-            if (gyr > L) gyr = L;
-            if (gyr >= 1) {
-                int q = (int)((L + gyr - 1) / gyr);
-                if (q < 8) q = L < 8 ? L : 8;
-                if (q < lpb2) lpb2 = q;
-            }
-            if (const char* e = getenv("TRK_CF_LPB")) {
-                const int q = atoi(e);
-                if (q > 0 && q <= lpb2) lpb2 = q;
-            }
-            const int gy2 = (L + lpb2 - 1) / lpb2;
+            const CfLaunch cl = cf_geometry(L, gx, lpb2, n_cu, occ);
+            lpb2 = cl.lpb;
+            const int gy2 = cl.geom.n_ranges;
             g.loci_per_block = lpb2;
+            g.geom = cl.geom;
             const size_t b16 = (((size_t)gy2 * (2 + GS_NF) * S * sizeof(uint16_t)) + 255) & ~(size_t)255;
             const size_t b64 = (size_t)gy2 * S * sizeof(unsigned long long);
-            void* ws = lpb2 < 65536 ? scratch.get(scratch.user, b16 + b64) : nullptr;
+            void* ws = (long)cl.geom.walk * lpb2 < 65536 ? scratch.get(scratch.user, b16 + b64) : nullptr;
             if (ws) {
                 g.part16 = static_cast<uint16_t*>(ws);
                 g.part64 = reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + b16);
-                hipLaunchKernelGGL(kg, dim3(gx, gy2), dim3(CF_THREADS), (size_t)lpb2 * per_locus, stream, g);
+                hipLaunchKernelGGL(kg, cl.grid, dim3(CF_THREADS), (size_t)lpb2 * per_locus, stream, g);
                 hipError_t e1 = hipGetLastError();
                 if (e1 != hipSuccess) return e1;
                 if (scratch.next_kernel) scratch.next_kernel(scratch.user);
@@ -4814,23 +4765,18 @@ hipError_t launch_permute_columns(const int16_t* src, int16_t* dst, const int32_
 
 hipError_t launch_stream_probe(const void* const* in, int n_in, void* const* out, int n_out, int64_t n_loci,
                                int64_t n_samples, int n_cu, hipStream_t stream) {
-    if (n_in != 3 || n_out != 2 || n_samples % 4) return hipErrorInvalidValue;
+    if (!((n_in == 3 && n_out == 2) || (n_in == 0 && n_out == 2)) || n_samples % 4) return hipErrorInvalidValue;
     ProbeArgs a = {};
     for (int k = 0; k < n_in; ++k) a.in[k] = static_cast<const u32x4*>(in[k]);
     for (int k = 0; k < n_out; ++k) a.out[k] = static_cast<u32x4*>(out[k]);
     const int S4 = (int)(n_samples / 4), L = (int)n_loci;
     const int gx = (S4 + 255) / 256;
-    // the call-filter pass's geometry: 5 workgroups per CU (capped here by 30 KiB of dynamic LDS), whole rounds
-    const long slots = (long)n_cu * 5;
-    int lpb = 117;
-    long rounds = ((long)gx * ((L + lpb - 1) / lpb) + slots - 1) / slots;
-    if (rounds < 2) rounds = 2;
-    long gyr = rounds * slots / gx;
-    if (gyr < 1) gyr = 1;
-    const int lpb2 = (int)((L + gyr - 1) / gyr);
-    if (lpb2 >= 1 && lpb2 < lpb) lpb = lpb2;
-    const int gy = (L + lpb - 1) / lpb;
-    hipLaunchKernelGGL((k_stream_probe<3, 2>), dim3(gx, gy), dim3(256), 30 * 1024, stream, a, L, S4, lpb);
+    // the call-filter pass's own geometry (cf_geometry: persistent ranges, XCD-aware map; the same TRK_CF_* knobs),
+    // five workgroups per CU admitted (capped here by 30 KiB of dynamic LDS), blocks of 80 loci as the kernel's
+    const CfLaunch cl = cf_geometry(L, gx, 80, n_cu, 5);
+    const int lpb = cl.lpb;
+    if (n_in == 0) hipLaunchKernelGGL((k_stream_probe<0, 2>), cl.grid, dim3(256), 30 * 1024, stream, a, L, S4, lpb, cl.geom);
+    else hipLaunchKernelGGL((k_stream_probe<3, 2>), cl.grid, dim3(256), 30 * 1024, stream, a, L, S4, lpb, cl.geom);
     return hipGetLastError();
 }
 

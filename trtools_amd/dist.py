@@ -10,8 +10,11 @@ only data that crosses ranks:
   the rank that writes the output                          -> all-gather in rank order.
 
 ``RcclComm`` runs both on device buffers through libtrk (RCCL over xGMI);
-``TorchComm`` does the same on host arrays through an initialised
-``torch.distributed`` group (gloo on CPU in the tests)."""
+``SocketGroup`` does the same on host arrays over plain TCP (rendezvous, barrier,
+the small reductions of the sharded command lines).  No torch in the package: the
+gloo tests bring their own communicator (tests/torch_comm.py)."""
+import struct
+
 import numpy as np
 
 
@@ -22,40 +25,12 @@ def locus_shard(n_loci, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
-class TorchComm:
-    """Host-array collectives over torch.distributed (any backend that handles CPU tensors)."""
-
-    def __init__(self):
-        import torch.distributed as dist
-        self.dist = dist
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
-
-    def allreduce_sum_i64(self, arr):
-        import torch
-        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64).copy())
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return t.numpy()
-
-    def allgather_bytes(self, arr):
-        """Gather variable-length uint8 payloads; returns the list in rank order."""
-        import torch
-        n = torch.tensor([arr.size], dtype=torch.int64)
-        sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
-        self.dist.all_gather(sizes, n)
-        m = int(max(int(s[0]) for s in sizes))
-        buf = torch.zeros(m, dtype=torch.uint8)
-        buf[:arr.size] = torch.from_numpy(np.array(arr, dtype=np.uint8).reshape(-1))
-        outs = [torch.zeros(m, dtype=torch.uint8) for _ in range(self.world)]
-        self.dist.all_gather(outs, buf)
-        return [o.numpy()[:int(s[0])] for o, s in zip(outs, sizes)]
-
-
 class SocketGroup:
     """Process group over plain TCP sockets -- rendezvous, barrier and small host-array collectives without torch.
     Rank 0 listens on (addr, port) and is the hub: a collective is a gather of every rank's payload to rank 0 and a
     broadcast of the result.  What crosses it is small (the 128-byte RCCL id, a few timings, dumpSTR's per-sample
-    counters: < 1 MB); bulk data goes through RCCL (``RcclComm``).  Same surface as ``TorchComm`` so the sharded
-    command lines and the tests can run on either."""
+    counters: < 1 MB); bulk data goes through RCCL (``RcclComm``).  Same surface as ``RcclComm`` (and the tests' gloo
+    communicator) so the sharded command lines run on any of them."""
 
     def __init__(self, rank=None, world=None, addr=None, port=None, timeout=300.0):
         import os
@@ -146,11 +121,10 @@ class SocketGroup:
         self._bcast(b'')
 
     def allgather_bytes(self, arr):
-        import pickle
         mine = np.ascontiguousarray(arr, dtype=np.uint8).reshape(-1).tobytes()
         parts = self._gather(mine)
-        blob = self._bcast(pickle.dumps(parts) if parts is not None else b'')
-        return [np.frombuffer(p, dtype=np.uint8) for p in pickle.loads(blob)]
+        blob = self._bcast(pack_frames(parts) if parts is not None else b'')
+        return [np.frombuffer(p, dtype=np.uint8) for p in unpack_frames(blob)]
 
     def _allreduce(self, arr, dtype, fold):
         a = np.ascontiguousarray(arr, dtype=dtype)
@@ -175,6 +149,32 @@ class SocketGroup:
             except OSError:
                 pass
         self._peers, self._hub = {}, None
+
+
+def pack_frames(parts):
+    """A list of byte strings as one blob: count, the sizes (int64 each), then the raw bytes.  Plain framing --
+    nothing a peer sends is ever unpickled."""
+    parts = [bytes(p) for p in parts]
+    return struct.pack('<q', len(parts)) + struct.pack('<%dq' % len(parts), *[len(p) for p in parts]) + b''.join(parts)
+
+
+def unpack_frames(blob):
+    blob = bytes(blob)
+    if len(blob) < 8:
+        raise ValueError("truncated frame list")
+    n = struct.unpack_from('<q', blob, 0)[0]
+    if n < 0 or 8 + 8 * n > len(blob):
+        raise ValueError("bad frame count %d" % n)
+    sizes = struct.unpack_from('<%dq' % n, blob, 8)
+    at, out = 8 + 8 * n, []
+    for sz in sizes:
+        if sz < 0 or at + sz > len(blob):
+            raise ValueError("bad frame size %d" % sz)
+        out.append(blob[at:at + sz])
+        at += sz
+    if at != len(blob):
+        raise ValueError("trailing bytes after the frames")
+    return out
 
 
 class RcclComm:
@@ -251,7 +251,7 @@ _comm = None
 
 
 def set_comm(comm):
-    """Install the communicator the sharded CLIs use (tests: TorchComm over gloo)."""
+    """Install the communicator the sharded CLIs use (tests: tests/torch_comm.TorchComm over gloo)."""
     global _comm
     old = _comm
     _comm = comm
@@ -292,10 +292,11 @@ def get_comm():
 def merge_parts(parts, comm):
     """``parts``: this rank's list of (batch_index, bytes).  Returns, on every rank, the
     concatenation of all ranks' parts in batch order (== record order of the input)."""
-    import pickle
-    blobs = comm.allgather_bytes(np.frombuffer(pickle.dumps(parts), dtype=np.uint8))
+    mine = pack_frames([struct.pack('<q', int(i)) + bytes(p) for i, p in parts])
+    blobs = comm.allgather_bytes(np.frombuffer(mine, dtype=np.uint8))
     allparts = []
     for b in blobs:
-        allparts.extend(pickle.loads(b.tobytes()))
+        for fr in unpack_frames(b.tobytes()):
+            allparts.append((struct.unpack_from('<q', fr, 0)[0], fr[8:]))
     allparts.sort(key=lambda t: t[0])
     return b''.join(p for _, p in allparts)

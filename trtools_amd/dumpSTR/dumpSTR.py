@@ -442,10 +442,11 @@ class _Run:
             self.sample_info['totaldp'][:] = np.nan
         self.loc_info = dist.reduce_loc_info(self.loc_info, self.comm)
         # contigs the header does not declare: every rank's, in rank order (== file order for contiguous shards)
-        import pickle
         seen = []
-        for blob in self.comm.allgather_bytes(np.frombuffer(pickle.dumps(list(self.invcf.contigs_seen)), dtype=np.uint8)):
-            for c in pickle.loads(blob.tobytes()):
+        mine = dist.pack_frames([str(c).encode() for c in self.invcf.contigs_seen])
+        for blob in self.comm.allgather_bytes(np.frombuffer(mine, dtype=np.uint8)):
+            for c in dist.unpack_frames(blob.tobytes()):
+                c = c.decode()
                 if c not in seen:
                     seen.append(c)
         self.invcf.contigs_seen[:] = seen

@@ -33,6 +33,23 @@ class DeviceArray:
             self.ptr = ptr.value
         eng._live.add(self)
 
+    @classmethod
+    def adopt(cls, eng, shape, dtype, ptr, cap):
+        """An owning array over a device allocation of ``cap`` bytes made elsewhere (trk_dev_alloc_pair); ``cap`` must
+        be the engine's size class of the array, so that ``free`` can pool it like any other buffer."""
+        self = cls.__new__(cls)
+        self.eng = eng
+        self.shape = tuple(int(x) for x in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self.parent = None
+        self.cap = int(cap)
+        if self.cap < self.nbytes:
+            raise ValueError("allocation smaller than the array")
+        self.ptr = int(ptr)
+        eng._live.add(self)
+        return self
+
     def view(self, offset_bytes, shape, dtype):
         """A typed window [offset_bytes, ...) of this array's memory; the parent keeps ownership.  Lets a caller lay
         several result arrays out back to back in one allocation (one RCCL all-reduce over all of them)."""
@@ -99,6 +116,14 @@ class DeviceBatch:
         self.ploidy = struct.ploidy
         self.n_groups = n_groups
         self.sum_alleles = sum_alleles
+        self._class_runs = None      # host table behind struct.class_runs (sorted_by_class): must outlive the struct
+        self.class_sorted = False
+
+    def _derived(self, s, arrays, n_groups):
+        """A batch made from a copy of this one's struct: whatever host memory the struct points at stays alive."""
+        out = DeviceBatch(s, arrays, n_groups, self.sum_alleles)
+        out._class_runs, out.class_sorted = self._class_runs, self.class_sorted
+        return out
 
     def with_gt(self, gt_dev):
         """Same allele tables, different genotype tensor (e.g. dumpSTR's masked GT)."""
@@ -107,7 +132,7 @@ class DeviceBatch:
         s.gt = gt_dev.ptr
         arrays = dict(self.arrays)
         arrays['gt'] = gt_dev
-        return DeviceBatch(s, arrays, self.n_groups, self.sum_alleles)
+        return self._derived(s, arrays, self.n_groups)
 
     def with_groups(self, eng, group_bits, n_groups):
         """Same tensors, sample groups attached (bit g of group_bits[s]: sample s is in group g)."""
@@ -118,7 +143,7 @@ class DeviceBatch:
         s.n_groups = int(n_groups)
         arrays = dict(self.arrays)
         arrays['group_bits'] = gb
-        return DeviceBatch(s, arrays, int(n_groups), self.sum_alleles)
+        return self._derived(s, arrays, int(n_groups))
 
 
     def sorted_by_class(self, eng, group_bits, n_groups):
@@ -467,68 +492,50 @@ class Engine:
         self._chk(self.lib.trk_locus_stats(self.ctx, C.byref(batch.struct), C.byref(prm), C.byref(out.struct)))
         return out
 
-    # What the placement tuner saw last (bench.py reports it): probe times of the candidate output pairs, ms
+    # What the last placed allocation saw (bench.py reports it): trk_pair_info as a dict
     last_placement = None
+    PLACE_MIN_BYTES = 1 << 28      # planes from 256 MB on are placed (at 67 MB no levels can be told apart)
 
-    def placed_output_pair(self, batch, ins, tries=None):
-        """The two big output planes of a call-filter pass (masked genotypes, filter mask) chosen among up to
-        ``tries`` candidate allocations.  On MI355X the 12 B-in / 8 B-out stream runs at one of two speeds, 18 % apart
-        (3.2 / 3.8 ms at 100k x 10k), and which one is decided by the two output planes alone: every 4 GB allocation
-        belongs to one of a few classes (the driver rotates through them), a pair from the SAME class is slow, a pair
-        from two classes is fast -- whatever the offsets inside the allocations (128 B ... 192 MB: no change), wherever
-        the inputs are, and invisible to a write-only stream over one plane (tools/placement_probe*.py,
-        profiles/r03_notes.md section 22).  So: allocate one candidate plane at a time, time the bare stream of the
-        pass's shape (trk_stream_probe, ~10 ms) with it and the first plane, stop at the first pair that is clearly
-        faster than another (both levels seen), keep the fastest pair, give the rest back to the driver."""
+    def placed_output_pair(self, batch, max_spare=None):
+        """The two big output planes of a call-filter pass (masked genotypes [L, S, 2] int16, filter mask [L, S]
+        uint32) through trk_dev_alloc_pair: on MI355X the pass's two write streams run on one of two levels, 10-18 %
+        apart, decided by which allocations the two planes are (profiles/r03_notes.md section 22); the library times
+        the write-only half of the stream over the first plane and up to 1 + ``max_spare`` candidates for the second
+        (default 2 spare planes: TRK_PLACE_SPARE) and keeps the fastest pair.  Pooled buffers are used as they come
+        (no probe) when the engine's pool holds a pair of this size class."""
         Lc, S = batch.n_loci, batch.n_samples
-        tries = int(os.environ.get('TRK_TUNE_PLACEMENT', '10')) if tries is None else int(tries)
-        # (pairs inside a class are all slow, pairs across classes all fast: it is enough to time every new plane
-        # with the FIRST one; the driver changes class every 20-30 GB of allocations, so ten planes of a 4 GB shape
-        # reach another class even when a previous process has just returned one large region)
-        g = self.empty((Lc, S), np.uint32)
-        pairs, spacers = [], []
-        step = 4 << 30                   # memory to move on by per candidate: smaller planes get a spacer behind them
-        for _ in range(max(1, tries - 1)):
-            p = self.empty((Lc, S), np.uint32)
-            pairs.append((self.stream_probe(ins[0], ins[1], ins[2], g, p, Lc, S, reps=3), p))
-            if max(t for t, _ in pairs) >= 1.06 * min(t for t, _ in pairs):
-                break                    # both levels seen: the low one is the fast placement
-            if p.nbytes < step:
-                spacers.append(self.empty((step - p.nbytes,), np.uint8))
-            if 3 <= len(pairs) <= 6:     # still one level: jump further (four spacers of 16 GB at most)
-                try:
-                    spacers.append(self.empty((16 << 30,), np.uint8))
-                except Exception:
-                    pass
-        pairs.sort(key=lambda c: c[0])
-        m = pairs[0][1]
-        for p in [q for _, q in pairs[1:]] + spacers:
-            p.free()
-        if len(pairs) > 1:
-            self.sync()
-            self.trim()                  # the others go back to the driver, not into the pool for the next caller
-        g.shape, g.dtype = (Lc, S, 2), np.dtype(np.int16)      # (same bytes: the masked genotypes are int16 pairs)
-        Engine.last_placement = [round(c[0], 3) for c in pairs]
+        nbytes = Lc * S * 4
+        cap = self._size_class(max(nbytes, 16))
+        if max_spare is None:
+            max_spare = int(os.environ.get('TRK_PLACE_SPARE', '2'))
+        a, b, info = C.c_void_p(), C.c_void_p(), L.PairInfo()
+        self._chk(self.lib.trk_dev_alloc_pair(self.ctx, cap, Lc, S, int(max_spare), C.byref(a), C.byref(b),
+                                              C.byref(info)))
+        Engine.last_placement = dict(probe_ms=[round(float(info.probe_ms[k]), 3) for k in range(info.n_probed)],
+                                     kept_ms=round(float(info.kept_ms), 3), placed=bool(info.placed),
+                                     seconds=round(float(info.seconds), 4), peak_extra_bytes=int(info.peak_extra_bytes),
+                                     plane_bytes=int(cap))
+        g = DeviceArray.adopt(self, (Lc, S, 2), np.int16, a.value, cap)
+        m = DeviceArray.adopt(self, (Lc, S), np.uint32, b.value, cap)
         return g, m
 
-    def alloc_call_out(self, batch, n_filters, want_gt=True, want_mask=True, want_mask8=False, tune_against=None):
-        """``tune_against``: the three resident input planes ([L, S] of 4-byte elements: the genotype tensor and two
-        FORMAT planes) of the pass these outputs are for.  Output planes of 256 MB and more are then placed by
-        ``placed_output_pair`` (TRK_TUNE_PLACEMENT=0: plain allocation; =N: up to N candidate planes, default 10)."""
+    def alloc_call_out(self, batch, n_filters, want_gt=True, want_mask=True, want_mask8=False, place=None):
+        """Outputs of trk_call_filters for ``batch``.  The two big planes (masked genotypes, mask) of a diploid batch
+        are PLACED from 256 MB each on (``placed_output_pair``; ``place=False`` or TRK_PLACE_OUTPUTS=0: plain
+        allocations) -- the command lines' per-batch outputs, a strong-scaling shard's and the bench's alike."""
         S = batch.n_samples
-        tries = int(os.environ.get('TRK_TUNE_PLACEMENT', '10'))
-        if (tune_against is not None and tries > 1 and want_gt and want_mask and batch.ploidy == 2 and
-                batch.n_loci * S * 4 >= (1 << 28)):
-            g, m = self.placed_output_pair(batch, tune_against, tries)
-            return CallResult(g, m, self.zeros((1 + n_filters, S), np.int64), self.zeros((S,), np.int64),
-                              self.zeros((S,), np.int64), self.zeros((4,), np.int32), self.zeros((S,), np.float64),
-                              self.empty((batch.n_loci, S), np.uint8) if want_mask8 else None)
-        return CallResult(
-            self.empty((batch.n_loci, S, batch.ploidy), np.int16) if want_gt else None,
-            self.empty((batch.n_loci, S), np.uint32) if want_mask else None,
-            self.zeros((1 + n_filters, S), np.int64), self.zeros((S,), np.int64),
-            self.zeros((S,), np.int64), self.zeros((4,), np.int32), self.zeros((S,), np.float64),
-            self.empty((batch.n_loci, S), np.uint8) if want_mask8 else None)
+        if place is None:
+            place = os.environ.get('TRK_PLACE_OUTPUTS', '1') != '0'
+        g = m = None
+        if (place and want_gt and want_mask and batch.ploidy == 2 and batch.n_loci * S * 4 >= self.PLACE_MIN_BYTES and
+                S % 4 == 0 and not self._pool.get(self._size_class(batch.n_loci * S * 4))):
+            g, m = self.placed_output_pair(batch)
+        else:
+            g = self.empty((batch.n_loci, S, batch.ploidy), np.int16) if want_gt else None
+            m = self.empty((batch.n_loci, S), np.uint32) if want_mask else None
+        return CallResult(g, m, self.zeros((1 + n_filters, S), np.int64), self.zeros((S,), np.int64),
+                          self.zeros((S,), np.int64), self.zeros((4,), np.int32), self.zeros((S,), np.float64),
+                          self.empty((batch.n_loci, S), np.uint8) if want_mask8 else None)
 
     def locus_finalize(self, batch, stats, nalleles_thresh=0.01):
         """Float statistics + HWE test from counts already in ``stats`` (trk_locus_finalize)."""
