@@ -238,6 +238,40 @@ typedef struct {
 int64_t trk_vcf_dumpstr_lines(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, char* out, int64_t cap,
                               int32_t* err_record);
 
+/* trk_vcf_dumpstr_records (round 4): the same records with NOTHING per record from the caller.
+ *   heads      base.heads may be NULL (or hold NULL entries): the nine leading columns are then built here -- columns
+ *              0-5 as read, FILTER = filter_text[l] (NULL: as read), INFO rewritten as vcfio.rewrite_info /
+ *              _rewrite_info_general do (every declared Integer / Float value re-serialised the way htslib writes it
+ *              back, a Flag as its bare key, the updates HRUN, HET, HWEP, AC, REFAC of dumpSTR.py:1304-1336 in place
+ *              or appended in that order), FORMAT + ':FILTER'.  keep[l] == 0: the record is not written
+ *              (--drop-filtered).  An INFO column this rewrite does not cover (a key twice, a number only Python's
+ *              int() / float() take) sets need_head[l] = 1 and the call returns INT64_MIN + 2: the caller supplies
+ *              those heads in base.heads and calls again.
+ *   samples    fast_path != 0: the sample columns are first tried WITHOUT decoding (fast_samples in trk_vcf.cpp:
+ *              tokens that '%g' / integer formatting would print back unchanged are copied as bytes, the others
+ *              re-serialised one by one, filtered calls nulled as dumpSTR.py:721-746 does); a record the pass cannot
+ *              prove equal to the decode -> null -> format path takes that path.  TRK_FMT_FAST=0 disables it. */
+typedef struct {
+    trk_vcf_dumpstr base;
+    const uint8_t* keep;                 /* [n] or NULL (all records are written)                              */
+    const char* const* filter_text;      /* [n] or NULL; NULL entries keep the column as read                   */
+    const int32_t* hrun;                 /* [n] INFO HRUN                                                       */
+    const uint8_t* have_stats;           /* [n] the locus has called samples left: HET / HWEP / AC / REFAC from
+                                            the arrays below, otherwise -1 / -1 / zeros / 0                     */
+    const double* het;                   /* [n]                                                                 */
+    const double* hwep;                  /* [n]                                                                 */
+    const int32_t* allele_count;         /* counts of the masked genotypes by allele index, [allele_off[n]]     */
+    const int32_t* allele_off;           /* [n + 1]                                                             */
+    int32_t n_info_keys, fast_path;
+    const char* const* info_keys;        /* the header's INFO IDs ...                                           */
+    const int32_t* info_kinds;           /* ... 0 String, 1 Integer, 2 Float, 3 Flag                            */
+    uint8_t* need_head;                  /* [n] out (zeroed by the caller), or NULL                             */
+} trk_vcf_dumpstr2;
+int64_t trk_vcf_dumpstr_records(const trk_vcf_batch* b, const trk_vcf_dumpstr2* in, char* out, int64_t cap,
+                                int32_t* err_record);
+/* records written so far by this process: without decoding / through the decode path / with a caller-built head */
+void trk_vcf_dumpstr_stats(int64_t* fast, int64_t* decoded, int64_t* caller_heads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -374,3 +374,131 @@ def test_dumpstr_region_filter_reads_the_harmonised_position(tmp_path):
 def test_dumpstr_region_filter_reads_the_harmonised_position_gpu(tmp_path):
     from trtools_amd import runtime
     _check_flank_regions(tmp_path, runtime.get_compute())
+
+
+# ---- round 4: native record heads + the sample columns written without decoding (trk_vcf_dumpstr_records) ----------
+def _dump_variants(tmp_path, name, envs):
+    """dumpSTR's batch pipeline on DUMP_CASES[name] under each environment of ``envs``: outputs + writer statistics."""
+    from oracle_compute import OracleCompute
+    from trtools_amd import runtime, vcfnative
+    from trtools_amd.dumpSTR import dumpSTR
+    path, kw = DUMP_CASES[name]
+    old = runtime.set_compute(OracleCompute())
+    outs = []
+    try:
+        for i, env in enumerate(envs):
+            for k, v in env.items():
+                os.environ[k] = v
+            try:
+                before = vcfnative.dumpstr_writer_stats()
+                out = str(tmp_path / ('v%d' % i))
+                assert dumpSTR.main(dump_args(out, path, **kw)) == 0
+                after = vcfnative.dumpstr_writer_stats()
+                outs.append((tuple(open(out + ext).read() for ext in ('.vcf', '.samplog.tab', '.loclog.tab')),
+                             {k: after[k] - before[k] for k in after}, dumpSTR.LAST_RUN['path']))
+            finally:
+                for k in env:
+                    del os.environ[k]
+    finally:
+        runtime.set_compute(old)
+    return outs
+
+
+@pytest.mark.parametrize('name', ['synth_hipstr_all', 'synth_gangstr_all', 'hipstr_drop_filtered', 'no_call_filters'])
+def test_dumpstr_native_heads_and_undecoded_samples_equal_the_decode_path(tmp_path, name):
+    """The three writers of the batch pipeline give the same bytes: (a) heads built natively + sample columns copied
+    token by token (the default), (b) native heads + decode -> null -> format (TRK_FMT_FAST=0), (c) heads from Python
+    (round 3's path, TRK_DUMPSTR_NATIVE_HEADS=0) -- and (a) really writes its records without decoding them."""
+    a, b, c = _dump_variants(tmp_path, name, [{}, {'TRK_FMT_FAST': '0'}, {'TRK_DUMPSTR_NATIVE_HEADS': '0'}])
+    assert a[2] == b[2] == c[2] == 'batch'
+    assert a[0] == b[0] == c[0]
+    n_out = sum(1 for ln in a[0][0].split('\n') if ln and not ln.startswith('#'))
+    assert a[1]['fast'] == n_out and a[1]['decoded'] == 0, a[1]
+    if name != 'hipstr_drop_filtered':
+        assert n_out > 20
+    assert b[1]['fast'] == 0 and b[1]['decoded'] == a[1]['fast']
+    assert a[1]['caller_heads'] == 0 and c[1]['fast'] == 0
+
+
+def _mutated_hipstr(tmp_path, seed):
+    """synth_hipstr.vcf with its sample columns rewritten at random: numbers spelled the ways a decoder normalises
+    ('007', '+5', '1.00', '0.50', '1e-3', seven digits), vector fields of equal and of ragged length, missing values,
+    samples that stop early, a string field; plus INFO values of every declared type."""
+    import random
+    rnd = random.Random(seed)
+    src = os.path.join(SYN, 'synth_hipstr.vcf')
+    dst = str(tmp_path / ('mut%d.vcf' % seed))
+    ints = ['7', '007', '12', '0', '-3', '-0', '123456789', '2147483000', '.', '31']   # ('+5': the per-record path's)
+    floats = ['0.99', '1.00', '0.50', '1', '0.5', '1e-3', '0.0001', '0.00012345', '123456.7', '0.1234567', '-0', '0.0', '.', '12.5',
+              '1E2', '999999', '1000000', '0.95']
+    extra_hdr = ['##FORMAT=<ID=PQ2,Number=2,Type=Float,Description="x">\n', '##FORMAT=<ID=AL,Number=.,Type=Integer,Description="x">\n',
+                 '##FORMAT=<ID=TAG,Number=1,Type=String,Description="x">\n',
+                 '##INFO=<ID=FQ,Number=1,Type=Float,Description="x">\n', '##INFO=<ID=FLG,Number=0,Type=Flag,Description="x">\n',
+                 '##INFO=<ID=NV,Number=.,Type=Integer,Description="x">\n']
+    with open(src) as fin, open(dst, 'w') as fout:
+        for line in fin:
+            if line.startswith('#CHROM'):
+                fout.write(''.join(extra_hdr))
+            if line.startswith('#'):
+                fout.write(line)
+                continue
+            f = line.rstrip('\n').split('\t')
+            f[7] += ';FQ=%s;NV=%s%s;OTHER=x,y' % (rnd.choice(['0.50', '1.25', '3', '1e-2', '.']),
+                                                rnd.choice(['1,2', '007', '+4,.', '5']), rnd.choice(['', ';FLG', ';FLG=1']))
+            keys = f[8].split(':')
+            ragged_al, ragged_pq = rnd.random() < 0.3, rnd.random() < 0.2
+            f[8] = ':'.join(keys + ['PQ2', 'AL', 'TAG'])
+            for i in range(9, len(f)):
+                t = f[i].split(':')
+                if len(t) == len(keys) and t[0] not in ('.', './.', '.|.'):
+                    if rnd.random() < 0.5:
+                        t[keys.index('DP')] = rnd.choice(['11', '22', '45', '007', '033', '60'])
+                    if rnd.random() < 0.5:
+                        t[keys.index('Q')] = rnd.choice(['0.99', '1.00', '0.90', '0.5', '1', '0.951', '0.9512345'])
+                pq = ','.join(rnd.choice(floats) for _ in range(rnd.choice([1, 2]) if ragged_pq else 2))
+                al = ','.join(rnd.choice(ints) for _ in range(rnd.choice([1, 2, 3]) if ragged_al else 2))
+                t += [pq, al, rnd.choice(['a', 'bc', '.', 'x|y;z'])]
+                if rnd.random() < 0.08:
+                    t = t[:rnd.randint(max(1, len(keys)), len(t))]         # trailing fields dropped
+                f[i] = ':'.join(t)
+            fout.write('\t'.join(f) + '\n')
+    return dst
+
+
+@pytest.mark.parametrize('seed', [1, 2, 3, 4])
+def test_undecoded_sample_columns_on_rewritten_text(tmp_path, seed):
+    """The span writer (fast_samples) against decode -> null -> format on text it has to work for: every record comes
+    out the same bytes whichever writer took it, and the native INFO rewrite equals vcfio.rewrite_info."""
+    from oracle_compute import OracleCompute
+    from trtools_amd import runtime, vcfnative
+    from trtools_amd.dumpSTR import dumpSTR
+    vcf = _mutated_hipstr(tmp_path, seed)
+    old = runtime.set_compute(OracleCompute())
+    outs, stats = [], []
+    try:
+        for i, env in enumerate([{}, {'TRK_FMT_FAST': '0'}, {'TRK_DUMPSTR_NATIVE_HEADS': '0'}]):
+            for k, v in env.items():
+                os.environ[k] = v
+            try:
+                before = vcfnative.dumpstr_writer_stats()
+                out = str(tmp_path / ('w%d' % i))
+                assert dumpSTR.main(dump_args(out, vcf, vcftype='hipstr', hipstr_min_call_DP=20, hipstr_max_call_DP=50,
+                                              hipstr_min_call_Q=0.9, min_locus_callrate=0.2)) == 0
+                assert dumpSTR.LAST_RUN['path'] == 'batch'
+                after = vcfnative.dumpstr_writer_stats()
+                outs.append(open(out + '.vcf').read())
+                stats.append({k: after[k] - before[k] for k in after})
+            finally:
+                for k in env:
+                    del os.environ[k]
+    finally:
+        runtime.set_compute(old)
+    for x, what in ((outs[1], 'decode path'), (outs[2], 'Python heads')):
+        if x != outs[0]:
+            la, lb = outs[0].split('\n'), x.split('\n')
+            i = next(i for i, (p, q) in enumerate(zip(la, lb)) if p != q)
+            fa, fb = la[i].split('\t'), lb[i].split('\t')
+            j = next(j for j, (p, q) in enumerate(zip(fa, fb)) if p != q)
+            raise AssertionError("line %d column %d differs from the %s:\n%s\n%s" % (i, j, what, fa[j][:200], fb[j][:200]))
+    assert stats[0]['fast'] > 0, stats        # some records are taken by the span writer, the ragged ones by the decoder
+    assert stats[0]['fast'] + stats[0]['decoded'] == stats[1]['decoded']

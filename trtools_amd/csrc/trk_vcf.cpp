@@ -2023,14 +2023,395 @@ int64_t trk_vcf_statstr_rows(const trk_vcf_batch* b, const trk_vcf_harmonized* h
 // =====================================================================================================
 extern "C" {
 
-int64_t trk_vcf_dumpstr_lines(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, char* out, int64_t cap,
-                              int32_t* err_record) {
-    if (!b || !in || !in->heads || !in->gt || !in->locus_ploidy || (!in->mask8 && !in->mask32)) return INT64_MIN;
+}  // extern "C"
+
+namespace {
+
+// ---- dumpSTR's record heads, natively (round 4) ---------------------------------------------------------------
+// What trtools_amd/dumpSTR/dumpSTR.py builds per record in Python: the eight leading columns with FILTER replaced
+// and INFO rewritten (vcfio.rewrite_info / _rewrite_info_general: every value re-serialised the way htslib writes it
+// back -- Integer from the parsed int, Float from float32 by '%g', a Flag as its bare key, String as it is), the
+// updates HRUN / HET / HWEP / AC / REFAC in place or appended in that order (dumpSTR.py:1304-1336), FORMAT + ':FILTER'.
+// Returns false where the Python code must build the head (a key twice, a number Python's int() / float() takes and
+// this parser does not).
+inline bool info_int_token(const char* p, const char* e, std::string& o) {
+    // Python's int(): here only [+-]?digits (<= 18); anything else is left to Python
+    if (e - p == 1 && *p == '.') { o.push_back('.'); return true; }
+    const char* q = p;
+    bool neg = false;
+    if (q < e && (*q == '+' || *q == '-')) { neg = *q == '-'; ++q; }
+    if (q == e || e - q > 18) return false;
+    long long v = 0;
+    for (const char* c = q; c < e; ++c) {
+        if (*c < '0' || *c > '9') return false;
+        v = v * 10 + (*c - '0');
+    }
+    char tmp[24];
+    auto r = std::to_chars(tmp, tmp + sizeof tmp, neg ? -v : v);
+    o.append(tmp, (size_t)(r.ptr - tmp));
+    return true;
+}
+inline bool info_float_token(const char* p, const char* e, std::string& o) {
+    if (e - p == 1 && *p == '.') { o.push_back('.'); return true; }
+    if (p == e) return false;
+    for (const char* c = p; c < e; ++c)
+        if (!((*c >= '0' && *c <= '9') || *c == '.' || *c == 'e' || *c == 'E' || *c == '+' || *c == '-')) return false;
+    double d = 0;
+    const char* q = (*p == '+') ? p + 1 : p;      // from_chars takes no leading '+', Python's float() does
+    auto r = std::from_chars(q, e, d);
+    if (r.ptr != e) return false;
+    if (r.ec == std::errc::result_out_of_range) d = strtod(std::string(p, e).c_str(), nullptr);
+    else if (r.ec != std::errc()) return false;
+    const float f = (float)d;                      // float(np.float32(x))
+    if (!std::isfinite(f)) return false;
+    char tmp[48];
+    const int len = snprintf(tmp, sizeof tmp, "%g", (double)f);
+    o.append(tmp, (size_t)len);
+    return true;
+}
+struct InfoUpdates {
+    int32_t hrun;
+    bool have_stats;
+    double het, hwep;
+    const int32_t* ac;     // counts by allele index: ac[0] the reference's
+    int n_alt;
+};
+inline void put_update(std::string& o, int which, const InfoUpdates& u) {
+    char tmp[48];
+    switch (which) {
+        case 0: { auto r = std::to_chars(tmp, tmp + sizeof tmp, u.hrun); o.append("HRUN=").append(tmp, (size_t)(r.ptr - tmp)); break; }
+        case 1:
+        case 2: {
+            o.append(which == 1 ? "HET=" : "HWEP=");
+            if (!u.have_stats) { o.append("-1"); break; }
+            const int len = snprintf(tmp, sizeof tmp, "%g", which == 1 ? u.het : u.hwep);
+            o.append(tmp, (size_t)len);
+            break;
+        }
+        case 3: {
+            o.append("AC=");
+            if (u.n_alt == 0) { o.push_back('0'); break; }
+            for (int j = 1; j <= u.n_alt; ++j) {
+                if (j > 1) o.push_back(',');
+                auto r = std::to_chars(tmp, tmp + sizeof tmp, u.have_stats ? u.ac[j] : 0);
+                o.append(tmp, (size_t)(r.ptr - tmp));
+            }
+            break;
+        }
+        default: {
+            auto r = std::to_chars(tmp, tmp + sizeof tmp, u.have_stats ? u.ac[0] : 0);
+            o.append("REFAC=").append(tmp, (size_t)(r.ptr - tmp));
+        }
+    }
+}
+bool rewrite_info_native(const char* p, const char* e, const trk_vcf_dumpstr2* x, const InfoUpdates& u, std::string& o) {
+    static const char* const UPD[5] = {"HRUN", "HET", "HWEP", "AC", "REFAC"};
+    static const size_t UPDL[5] = {4, 3, 4, 2, 5};
+    bool done[5] = {false, false, false, false, false};
+    const size_t o0 = o.size();
+    bool first = true;
+    // keys seen so far (a key twice: Python's dict keeps the last value for both places)
+    const char* seen_b[64];
+    size_t seen_l[64];
+    int n_seen = 0;
+    if (!(e - p == 1 && *p == '.')) {
+        while (p < e) {
+            const char* te = find_ch(p, e, ';');
+            if (te > p) {
+                const char* eq = find_ch(p, te, '=');
+                const size_t kl = (size_t)(eq - p);
+                for (int i = 0; i < n_seen; ++i)
+                    if (seen_l[i] == kl && memcmp(seen_b[i], p, kl) == 0) return false;
+                if (n_seen == 64) return false;
+                seen_b[n_seen] = p;
+                seen_l[n_seen++] = kl;
+                if (!first) o.push_back(';');
+                first = false;
+                int up = -1;
+                for (int i = 0; i < 5; ++i)
+                    if (UPDL[i] == kl && memcmp(UPD[i], p, kl) == 0) up = i;
+                if (up >= 0) {
+                    put_update(o, up, u);
+                    done[up] = true;
+                } else if (eq == te) {
+                    o.append(p, kl);                 // a bare key, whatever its declared type
+                } else {
+                    int kind = 0;                    // String when the header does not declare the key
+                    for (int t = 0; t < x->n_info_keys; ++t)
+                        if (strlen(x->info_keys[t]) == kl && memcmp(x->info_keys[t], p, kl) == 0) { kind = x->info_kinds[t]; break; }
+                    if (kind == 3) {
+                        o.append(p, kl);             // a Flag with a value is written back as the flag
+                    } else if (kind == 1 || kind == 2) {
+                        o.append(p, kl + 1);
+                        const char* v = eq + 1;
+                        while (true) {
+                            const char* ve = find_ch(v, te, ',');
+                            if (!(kind == 1 ? info_int_token(v, ve, o) : info_float_token(v, ve, o))) return false;
+                            if (ve == te) break;
+                            o.push_back(',');
+                            v = ve + 1;
+                        }
+                    } else {
+                        o.append(p, (size_t)(te - p));
+                    }
+                }
+            }
+            if (te == e) break;
+            p = te + 1;
+        }
+    }
+    for (int i = 0; i < 5; ++i)
+        if (!done[i]) {
+            if (!first) o.push_back(';');
+            first = false;
+            put_update(o, i, u);
+        }
+    if (o.size() == o0) o.push_back('.');
+    return true;
+}
+
+// ---- the sample columns of an output record without decoding them (round 4) ----------------------------------------
+// trk_vcf_decode_formats -> nulling -> format_range turns every FORMAT value into a typed array element and back into
+// text (44 ns per value on 32 threads, 0.33 s per GB).  Almost every value comes back as the bytes it was read from:
+// an integer without leading zeros or sign, a decimal of at most six significant digits without trailing zeros
+// between 1e-4 and 1e6 (float32 holds it, '%g' prints it back), a string, a '.'.  This pass walks the sample columns
+// once, copies such tokens as they are, re-serialises the others one by one (the same parse and '%g' the decoder and
+// the formatter use), writes the filtered calls as the reference nulls them (dumpSTR.py:721-746: every allele '.',
+// unphased, every other field '.') and appends the FILTER value.  It declines (returns false: the record takes the
+// decode / format path) whatever it cannot prove equal to that path's output: mixed phase separators, non-ASCII
+// strings, vector fields whose length differs between samples, numbers from_chars does not take whole.
+inline bool canon_uint(const char* p, const char* e) {      // digits without a leading zero, at most nine
+    const ptrdiff_t n = e - p;
+    if (n < 1 || n > 9) return false;
+    if (*p == '0') return n == 1;
+    for (; p < e; ++p)
+        if (*p < '0' || *p > '9') return false;
+    return true;
+}
+inline bool canon_int(const char* p, const char* e) {
+    if (p < e && *p == '-') return e - p > 1 && p[1] != '0' && canon_uint(p + 1, e);
+    return canon_uint(p, e);
+}
+// a decimal '%g' of its float32 value prints back unchanged: -?(0|[1-9]d*)(.d*[1-9])?, <= 6 significant digits,
+// 1e-4 <= |x| < 1e6 or an integer below 1e6 (0 included)
+inline bool canon_float(const char* p, const char* e) {
+    if (p < e && *p == '-') ++p;
+    if (p == e) return false;
+    const char* ip = p;
+    while (p < e && *p >= '0' && *p <= '9') ++p;
+    const ptrdiff_t ni = p - ip;
+    if (ni < 1 || (ni > 1 && *ip == '0') || ni > 6) return false;
+    if (p == e) return true;                                // an integer of at most six digits
+    if (*p != '.') return false;
+    const char* fp = ++p;
+    while (p < e && *p >= '0' && *p <= '9') ++p;
+    const ptrdiff_t nf = p - fp;
+    if (p != e || nf < 1 || e[-1] == '0') return false;
+    if (*ip != '0') return ni + nf <= 6;
+    // 0.000ddd: significant digits start at the first non-zero; at most three zeros behind the point (>= 1e-4)
+    const char* z = fp;
+    while (z < e && *z == '0') ++z;
+    return (z - fp) <= 3 && (e - z) <= 6;
+}
+inline void put_callfilter(OutBuf& o, uint32_t m, int n_filters, const char* const* names, const double* const* values,
+                           int64_t s) {
+    char tmp[48];
+    if (m & 0x80000000u) {
+        o.put("NOCALL", 6);
+    } else if (m == 0) {
+        o.put("PASS", 4);
+    } else {
+        int n = 0;
+        for (int b = 0; b < n_filters && b < 31; ++b) {
+            if (!((m >> b) & 1u)) continue;
+            if (n++) o.put(',');
+            o.put(names[b], strlen(names[b]));
+            o.put('_');
+            const double x = values[b] ? values[b][s] : NAN;
+            const int len = snprintf(tmp, sizeof tmp, "%g", x);
+            o.put(tmp, (size_t)len);
+        }
+        if (!n) o.put('.');
+    }
+}
+// kinds[f]: -1 GT, TRK_VCF_COL_INT / _FLOAT / _UCS4.  m32 / filtered: the record's mask row.
+bool fast_samples(const char* smp, const char* end, int S, int pl, int nf, const int* kinds, const uint32_t* m32,
+                  const uint8_t* filtered, int n_filters, const char* const* names, const double* const* values,
+                  OutBuf& o) {
+    while (end > smp && (end[-1] == '\n' || end[-1] == '\r')) --end;
+    int fcount[64], imax[64], iused[64];
+    if (nf > 64) return false;
+    for (int f = 0; f < nf; ++f) {
+        fcount[f] = 0;          // values per token of a float vector field (0: not seen yet)
+        imax[f] = 1;            // integer field: the widest token so far = the columns of the decoder's array
+        iused[f] = INT32_MAX;   // ... and the narrowest width a filtered call of the record was written with
+    }
+    const char* p = smp;
+    char tmp[48];
+    for (int s = 0; s < S; ++s) {
+        if (p > end) return false;
+        const char* se = find_ch(p, end, '\t');
+        o.put('\t');
+        const bool flt = filtered[s] != 0;
+        const char* q = p;
+        bool exhausted = q == se && false;
+        for (int f = 0; f < nf; ++f) {
+            if (f) o.put(':');
+            const char* tb = q;
+            const char* te = se;
+            if (exhausted) {
+                tb = te = nullptr;
+            } else {
+                te = find_ch(q, se, ':');
+                if (te == se) exhausted = true;
+                else q = te + 1;
+            }
+            const int kind = kinds[f];
+            if (flt) {
+                // the reference nulls the call: every allele missing and unphased, every other field missing; what the
+                // token held only matters for the shape of a vector field (checked on the calls that are kept)
+                if (kind < 0) {
+                    for (int j = 0; j < pl; ++j) {
+                        if (j) o.put('/');
+                        o.put('.');
+                    }
+                    if (pl == 0) o.put('.');
+                } else if (kind == TRK_VCF_COL_INT) {
+                    // one '.' per column of the record's widest integer vector (the decoder's array width; this
+                    // call's own token counts): written with the width known so far, checked at the end
+                    int cnt = 1;
+                    if (tb)
+                        for (const char* c = tb; c < te; ++c) cnt += *c == ',';
+                    if (cnt > imax[f]) imax[f] = cnt;
+                    for (int j = 0; j < imax[f]; ++j) {
+                        if (j) o.put(',');
+                        o.put('.');
+                    }
+                    if (imax[f] < iused[f]) iused[f] = imax[f];
+                } else {
+                    o.put('.');
+                }
+                continue;
+            }
+            if (!tb || (te - tb == 1 && *tb == '.')) {     // missing (or a column the sample does not have)
+                if (tb == nullptr && kind < 0) return false;
+                o.put('.');
+                continue;
+            }
+            if (te == tb) return false;                    // an empty token: the decoder's business
+            if (kind < 0) {
+                // alleles: '.' or canonical integers, one separator throughout, at most pl of them
+                char sep = 0;
+                int na = 0;
+                const char* a = tb;
+                while (true) {
+                    const char* ae = a;
+                    while (ae < te && *ae != '/' && *ae != '|') ++ae;
+                    if (!((ae - a == 1 && *a == '.') || canon_uint(a, ae))) return false;
+                    ++na;
+                    if (ae == te) break;
+                    if (sep && *ae != sep) return false;
+                    sep = *ae;
+                    a = ae + 1;
+                }
+                if (na > pl) return false;
+                o.put(tb, (size_t)(te - tb));
+            } else if (kind == TRK_VCF_COL_INT) {
+                const char* v = tb;
+                int nv = 0;
+                while (true) {
+                    const char* ve = find_ch(v, te, ',');
+                    if (nv++) o.put(',');
+                    if (ve - v == 1 && *v == '.') {
+                        o.put('.');
+                    } else if (canon_int(v, ve)) {
+                        o.put(v, (size_t)(ve - v));
+                    } else {
+                        int32_t x;
+                        auto r = std::from_chars(v, ve, x);
+                        if (r.ec != std::errc() || r.ptr != ve || x == INT32_MIN || x == INT32_MIN + 1) return false;
+                        o.put_int(x);
+                    }
+                    if (ve == te) break;
+                    v = ve + 1;
+                }
+                if (nv > imax[f]) imax[f] = nv;
+            } else if (kind == TRK_VCF_COL_FLOAT) {
+                const char* v = tb;
+                int nv = 0;
+                bool all_missing = true;
+                const int64_t mark = o.n;
+                while (true) {
+                    const char* ve = find_ch(v, te, ',');
+                    if (nv++) o.put(',');
+                    if (ve - v == 1 && *v == '.') {
+                        o.put('.');
+                    } else if (canon_float(v, ve)) {
+                        o.put(v, (size_t)(ve - v));
+                        all_missing = false;
+                    } else {
+                        double x;
+                        auto r = std::from_chars(v, ve, x);
+                        if (r.ec != std::errc() || r.ptr != ve) return false;
+                        const float fl = (float)x;
+                        if (std::isnan(fl)) {
+                            o.put('.');
+                        } else {
+                            auto w = std::to_chars(tmp, tmp + sizeof tmp, (double)fl, std::chars_format::general, 6);
+                            o.put(tmp, (size_t)(w.ptr - tmp));
+                            all_missing = false;
+                        }
+                    }
+                    if (ve == te) break;
+                    v = ve + 1;
+                }
+                if (nv > 1) {
+                    // a vector: every sample must carry the same number of values (a shorter one is padded with
+                    // missing values by the decoder and printed with them); all missing prints one '.'
+                    if (fcount[f] == 0) fcount[f] = nv;
+                    else if (fcount[f] != nv) return false;
+                    if (all_missing) { o.n = mark; o.put('.'); }
+                } else if (fcount[f] > 1) {
+                    return false;
+                } else if (fcount[f] == 0) {
+                    fcount[f] = 1;
+                }
+            } else {
+                for (const char* c = tb; c < te; ++c)
+                    if ((unsigned char)*c >= 0x80 || *c == 0) return false;
+                o.put(tb, (size_t)(te - tb));
+            }
+        }
+        if (!exhausted) return false;                       // more tokens than FORMAT keys
+        o.put(':');
+        put_callfilter(o, m32[s], n_filters, names, values, s);
+        if (se == end) {
+            if (s != S - 1) return false;
+            p = end + 1;
+        } else {
+            p = se + 1;
+        }
+    }
+    if (p <= end) return false;                             // more columns than samples
+    // a filtered call written before the record's widest integer vector was met has too few '.': the decode path's job
+    for (int f = 0; f < nf; ++f)
+        if (iused[f] != INT32_MAX && iused[f] != imax[f]) return false;
+    return true;
+}
+
+// records written without decoding / through the decode path / with a caller-built head, since the process started
+std::atomic<int64_t> g_fmt_fast{0}, g_fmt_slow{0}, g_fmt_py_heads{0};
+
+int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const trk_vcf_dumpstr2* ext, char* out,
+                     int64_t cap, int32_t* err_record) {
+    if (!b || !in || (!in->heads && !ext) || !in->gt || !in->locus_ploidy || (!in->mask8 && !in->mask32)) return INT64_MIN;
     const int n = b->n_records, S = in->n_samples, P = in->ploidy;
     if (err_record) *err_record = -1;
     std::vector<std::string> lines((size_t)n);
     std::atomic<int> next{0};
     std::atomic<int> bad{INT32_MAX};
+    std::atomic<int> need_heads{0};
+    const bool fast_ok = ext && ext->fast_path && !(getenv("TRK_FMT_FAST") && atoi(getenv("TRK_FMT_FAST")) == 0);
     auto fail = [&](int l) {
         int cur = bad.load();
         while (l < cur && !bad.compare_exchange_weak(cur, l)) {}
@@ -2048,13 +2429,116 @@ int64_t trk_vcf_dumpstr_lines(const trk_vcf_batch* b, const trk_vcf_dumpstr* in,
         for (int k = 0; k < in->n_filters; ++k) names[(size_t)k] = in->filters[k].name;
         std::unique_ptr<char[]> scratch;
         size_t scratch_cap = 0;
+        // the numbers behind '<filter name>_<value>' of the filters that fired somewhere in record l
+        auto fire_values = [&](int l, uint32_t any_bits) {
+        for (int k = 0; k < in->n_filters; ++k) {
+            vptr[(size_t)k] = nullptr;
+            if (!((any_bits >> k) & 1u)) continue;
+            const trk_vcf_cf_value& fv = in->filters[k];
+            std::vector<double>& v = vals[(size_t)k];
+            v.resize((size_t)S);
+            auto elem = [&](const void* plane, int dtype, int ncol, int col, int s) -> double {
+                const size_t i = ((size_t)l * S + s) * ncol + col;
+                return dtype == 1 ? (double)static_cast<const float*>(plane)[i] : (double)static_cast<const int32_t*>(plane)[i];
+            };
+            if (fv.kind == 2) {
+                // sum of two columns of one plane: GangSTR's QEXP[1] + QEXP[2] (a float32 sum, as numpy adds two
+                // float32 arrays) and RC[1] + RC[3] (integers)
+                for (int s = 0; s < S; ++s) {
+                    const size_t i = ((size_t)l * S + s) * fv.ncol_a;
+                    if (fv.dtype_a == 1) {
+                        const float* pa = static_cast<const float*>(fv.plane_a) + i;
+                        const volatile float f = pa[fv.col_a] + pa[fv.col_a2];
+                        v[(size_t)s] = (double)f;
+                    } else {
+                        const int32_t* pa = static_cast<const int32_t*>(fv.plane_a) + i;
+                        v[(size_t)s] = (double)((int64_t)pa[fv.col_a] + (int64_t)pa[fv.col_a2]);
+                    }
+                }
+            } else if (fv.kind == 3) {
+                // GangSTR's bad confidence interval: the maximum-likelihood copy number (plane a, one column per
+                // haplotype) of the FIRST haplotype whose interval (plane b: lo, hi per haplotype) excludes it
+                for (int s = 0; s < S; ++s) {
+                    const int32_t* ml = static_cast<const int32_t*>(fv.plane_a) + ((size_t)l * S + s) * fv.ncol_a;
+                    const int32_t* ci = static_cast<const int32_t*>(fv.plane_b) + ((size_t)l * S + s) * fv.ncol_b;
+                    double x = NAN;
+                    for (int j = 0; j < fv.ncol_a && 2 * j + 1 < fv.ncol_b; ++j)
+                        if (ml[j] < ci[2 * j] || ci[2 * j + 1] < ml[j]) {
+                            x = (double)ml[j];
+                            break;
+                        }
+                    v[(size_t)s] = x;
+                }
+            } else if (fv.kind == 4) {
+                // PopSTR's require-support (filters.py:858-867): the read support (plane a: AD, one column per
+                // allele) of the LAST haplotype whose allele has fewer than col_a reads
+                for (int s = 0; s < S; ++s) {
+                    const int32_t* ad = static_cast<const int32_t*>(fv.plane_a) + ((size_t)l * S + s) * fv.ncol_a;
+                    const int16_t* g = in->gt + ((size_t)l * S + s) * in->ploidy;
+                    double x = NAN;
+                    for (int j = 0; j < in->ploidy; ++j) {
+                        int a = g[j];
+                        if (a < 0) a += fv.ncol_a;
+                        if (a < 0 || a >= fv.ncol_a) continue;
+                        if ((double)ad[a] < (double)fv.col_a) x = (double)ad[a];
+                    }
+                    v[(size_t)s] = x;
+                }
+            } else {
+                for (int s = 0; s < S; ++s) {
+                    const double a = elem(fv.plane_a, fv.dtype_a, fv.ncol_a, fv.col_a, s);
+                    v[(size_t)s] = fv.kind == 1 ? a / elem(fv.plane_b, fv.dtype_b, fv.ncol_b, fv.col_b, s) : a;
+                }
+            }
+            vptr[(size_t)k] = v.data();
+        }
+        };
+        std::string head_store;
+        std::vector<int> kinds;
         for (;;) {
             const int l = next.fetch_add(1);
             if (l >= n) break;
-            if (!in->heads[l]) continue;     // record dropped by the caller (--drop-filtered)
             const char* line = b->text + b->line_off[l];
             const int32_t* fo = b->field_off + (size_t)l * 10;
             const int64_t line_len = b->line_end[l] - b->line_off[l];
+            const char* head = in->heads ? in->heads[l] : nullptr;
+            size_t hl = 0;
+            if (ext) {
+                if (ext->keep && !ext->keep[l]) continue;     // record dropped by the caller (--drop-filtered)
+                if (!head) {
+                    // the nine leading columns: 0-5 as read, FILTER, INFO rewritten, FORMAT + ':FILTER'
+                    if (fo[9] <= fo[8] || fo[9] >= line_len) { fail(l); continue; }
+                    head_store.clear();
+                    head_store.append(line, (size_t)fo[6]);
+                    const char* ft = ext->filter_text ? ext->filter_text[l] : nullptr;
+                    if (ft) head_store.append(ft);
+                    else head_store.append(line + fo[6], (size_t)(fo[7] - 1 - fo[6]));
+                    head_store.push_back('\t');
+                    InfoUpdates u;
+                    u.hrun = ext->hrun[l];
+                    u.have_stats = ext->have_stats[l] != 0;
+                    u.het = ext->het[l];
+                    u.hwep = ext->hwep[l];
+                    u.ac = ext->allele_count + ext->allele_off[l];
+                    u.n_alt = ext->allele_off[l + 1] - ext->allele_off[l] - 1;
+                    if (!rewrite_info_native(line + fo[7], line + fo[8] - 1, ext, u, head_store)) {
+                        if (ext->need_head) ext->need_head[l] = 1;
+                        need_heads.fetch_add(1);
+                        continue;
+                    }
+                    head_store.push_back('\t');
+                    head_store.append(line + fo[8], (size_t)(fo[9] - 1 - fo[8]));
+                    head_store.append(":FILTER");
+                    head = head_store.data();
+                    hl = head_store.size();
+                } else {
+                    hl = strlen(head);
+                    g_fmt_py_heads.fetch_add(1, std::memory_order_relaxed);
+                }
+            } else {
+                if (!head) continue;     // record dropped by the caller (--drop-filtered)
+                hl = strlen(head);
+            }
             if (fo[9] <= fo[8] || fo[9] >= line_len) { fail(l); continue; }
             // FORMAT keys of the record -> decode kinds from the header table
             const char* f = line + fo[8];
@@ -2086,16 +2570,7 @@ int64_t trk_vcf_dumpstr_lines(const trk_vcf_batch* b, const trk_vcf_dumpstr* in,
             const int nf = (int)dec.size();
             const char* smp = line + fo[9];
             const int64_t smp_len = line_len - fo[9];
-            if (trk_vcf_decode_formats(smp, smp_len, S, nf, dec.data(), 0) != 0) { fail(l); continue; }
-            store.resize((size_t)nf);
-            for (int i = 0; i < nf; ++i) {
-                if (dec[(size_t)i].kind < 0) continue;
-                const size_t bytes = (size_t)S * (size_t)std::max(dec[(size_t)i].ncol, 1) * 4;
-                if (store[(size_t)i].size() < bytes) store[(size_t)i].resize(bytes);
-                if (dec[(size_t)i].kind == TRK_VCF_COL_UCS4) memset(store[(size_t)i].data(), 0, bytes);   // NUL padded
-                dec[(size_t)i].out = store[(size_t)i].data();
-            }
-            if (trk_vcf_decode_formats(smp, smp_len, S, nf, dec.data(), 1) != 0) { fail(l); continue; }
+            const int pl = in->locus_ploidy[l];
             // the mask of this record as 32 bits; filtered = some filter fired on a called sample (dumpSTR.py:715-717)
             uint32_t any_bits = 0;
             for (int s = 0; s < S; ++s) {
@@ -2110,8 +2585,42 @@ int64_t trk_vcf_dumpstr_lines(const trk_vcf_batch* b, const trk_vcf_dumpstr* in,
                 filtered[(size_t)s] = (m & 0x7fffffffu) != 0 && !(m & 0x80000000u);
                 any_bits |= m & 0x7fffffffu;
             }
+            fire_values(l, any_bits);
+            if (fast_ok) {
+                // the span transducer first (fast_samples): no typed arrays at all
+                kinds.resize((size_t)nf);
+                for (int i = 0; i < nf; ++i) kinds[(size_t)i] = dec[(size_t)i].kind;
+                int64_t cfw = 8;
+                for (int k = 0; k < in->n_filters; ++k) cfw += (int64_t)strlen(names[(size_t)k]) + 26;
+                const int64_t need = smp_len * 2 + (int64_t)S * (cfw + 4 * (pl + 1) + 2 * nf) + 64;
+                if ((int64_t)scratch_cap < need) {
+                    scratch.reset(new char[(size_t)need]);
+                    scratch_cap = (size_t)need;
+                }
+                OutBuf ob{scratch.get(), need, 0};
+                if (fast_samples(smp, smp + smp_len, S, pl, nf, kinds.data(), m32.data(), filtered.data(), in->n_filters,
+                                 names.data(), vptr.data(), ob) && ob.n <= need) {
+                    std::string& o = lines[(size_t)l];
+                    o.reserve(hl + (size_t)ob.n + 1);
+                    o.assign(head, hl);
+                    o.append(scratch.get(), (size_t)ob.n);
+                    o.push_back('\n');
+                    g_fmt_fast.fetch_add(1, std::memory_order_relaxed);
+                    continue;
+                }
+            }
+            g_fmt_slow.fetch_add(1, std::memory_order_relaxed);
+            if (trk_vcf_decode_formats(smp, smp_len, S, nf, dec.data(), 0) != 0) { fail(l); continue; }
+            store.resize((size_t)nf);
+            for (int i = 0; i < nf; ++i) {
+                if (dec[(size_t)i].kind < 0) continue;
+                const size_t bytes = (size_t)S * (size_t)std::max(dec[(size_t)i].ncol, 1) * 4;
+                if (store[(size_t)i].size() < bytes) store[(size_t)i].resize(bytes);
+                if (dec[(size_t)i].kind == TRK_VCF_COL_UCS4) memset(store[(size_t)i].data(), 0, bytes);   // NUL padded
+                dec[(size_t)i].out = store[(size_t)i].data();
+            }
+            if (trk_vcf_decode_formats(smp, smp_len, S, nf, dec.data(), 1) != 0) { fail(l); continue; }
             // genotypes: [S, pl + 1] with the phase column; a filtered call is all '.' and unphased (:721-727)
-            const int pl = in->locus_ploidy[l];
             gtrow.assign((size_t)S * (pl + 1), 0);
             for (int s = 0; s < S; ++s) {
                 int16_t* g = &gtrow[(size_t)s * (pl + 1)];
@@ -2142,68 +2651,6 @@ int64_t trk_vcf_dumpstr_lines(const trk_vcf_batch* b, const trk_vcf_dumpstr* in,
                         for (int j = 1; j < d.ncol; ++j) o[j] = 0;
                     }
                 }
-            }
-            // the numbers behind '<filter name>_<value>' of the filters that fired somewhere in this record
-            for (int k = 0; k < in->n_filters; ++k) {
-                vptr[(size_t)k] = nullptr;
-                if (!((any_bits >> k) & 1u)) continue;
-                const trk_vcf_cf_value& fv = in->filters[k];
-                std::vector<double>& v = vals[(size_t)k];
-                v.resize((size_t)S);
-                auto elem = [&](const void* plane, int dtype, int ncol, int col, int s) -> double {
-                    const size_t i = ((size_t)l * S + s) * ncol + col;
-                    return dtype == 1 ? (double)static_cast<const float*>(plane)[i] : (double)static_cast<const int32_t*>(plane)[i];
-                };
-                if (fv.kind == 2) {
-                    // sum of two columns of one plane: GangSTR's QEXP[1] + QEXP[2] (a float32 sum, as numpy adds two
-                    // float32 arrays) and RC[1] + RC[3] (integers)
-                    for (int s = 0; s < S; ++s) {
-                        const size_t i = ((size_t)l * S + s) * fv.ncol_a;
-                        if (fv.dtype_a == 1) {
-                            const float* pa = static_cast<const float*>(fv.plane_a) + i;
-                            const volatile float f = pa[fv.col_a] + pa[fv.col_a2];
-                            v[(size_t)s] = (double)f;
-                        } else {
-                            const int32_t* pa = static_cast<const int32_t*>(fv.plane_a) + i;
-                            v[(size_t)s] = (double)((int64_t)pa[fv.col_a] + (int64_t)pa[fv.col_a2]);
-                        }
-                    }
-                } else if (fv.kind == 3) {
-                    // GangSTR's bad confidence interval: the maximum-likelihood copy number (plane a, one column per
-                    // haplotype) of the FIRST haplotype whose interval (plane b: lo, hi per haplotype) excludes it
-                    for (int s = 0; s < S; ++s) {
-                        const int32_t* ml = static_cast<const int32_t*>(fv.plane_a) + ((size_t)l * S + s) * fv.ncol_a;
-                        const int32_t* ci = static_cast<const int32_t*>(fv.plane_b) + ((size_t)l * S + s) * fv.ncol_b;
-                        double x = NAN;
-                        for (int j = 0; j < fv.ncol_a && 2 * j + 1 < fv.ncol_b; ++j)
-                            if (ml[j] < ci[2 * j] || ci[2 * j + 1] < ml[j]) {
-                                x = (double)ml[j];
-                                break;
-                            }
-                        v[(size_t)s] = x;
-                    }
-                } else if (fv.kind == 4) {
-                    // PopSTR's require-support (filters.py:858-867): the read support (plane a: AD, one column per
-                    // allele) of the LAST haplotype whose allele has fewer than col_a reads
-                    for (int s = 0; s < S; ++s) {
-                        const int32_t* ad = static_cast<const int32_t*>(fv.plane_a) + ((size_t)l * S + s) * fv.ncol_a;
-                        const int16_t* g = in->gt + ((size_t)l * S + s) * in->ploidy;
-                        double x = NAN;
-                        for (int j = 0; j < in->ploidy; ++j) {
-                            int a = g[j];
-                            if (a < 0) a += fv.ncol_a;
-                            if (a < 0 || a >= fv.ncol_a) continue;
-                            if ((double)ad[a] < (double)fv.col_a) x = (double)ad[a];
-                        }
-                        v[(size_t)s] = x;
-                    }
-                } else {
-                    for (int s = 0; s < S; ++s) {
-                        const double a = elem(fv.plane_a, fv.dtype_a, fv.ncol_a, fv.col_a, s);
-                        v[(size_t)s] = fv.kind == 1 ? a / elem(fv.plane_b, fv.dtype_b, fv.ncol_b, fv.col_b, s) : a;
-                    }
-                }
-                vptr[(size_t)k] = v.data();
             }
             trk_vcf_callfilter cf{m32.data(), in->n_filters, 0, names.data(), vptr.data()};
             cols.clear();
@@ -2238,9 +2685,8 @@ int64_t trk_vcf_dumpstr_lines(const trk_vcf_batch* b, const trk_vcf_dumpstr* in,
             const int64_t w = ob.n;
             if (w > need) { fail(l); continue; }
             std::string& o = lines[(size_t)l];
-            const size_t hl = strlen(in->heads[l]);
             o.reserve(hl + (size_t)w + 1);
-            o.assign(in->heads[l], hl);
+            o.assign(head, hl);
             o.append(scratch.get(), (size_t)w);
             o.push_back('\n');
         }
@@ -2257,6 +2703,7 @@ int64_t trk_vcf_dumpstr_lines(const trk_vcf_batch* b, const trk_vcf_dumpstr* in,
         if (err_record) *err_record = bad.load();
         return INT64_MIN + 1;
     }
+    if (need_heads.load() > 0) return INT64_MIN + 2;   // ext->need_head says which records want their head from the caller
     int64_t total = 0;
     for (auto& s : lines) total += (int64_t)s.size();
     if (!out || total > cap) return -total;
@@ -2278,6 +2725,30 @@ int64_t trk_vcf_dumpstr_lines(const trk_vcf_batch* b, const trk_vcf_dumpstr* in,
         for (auto& t : tc) t.join();
     }
     return total;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t trk_vcf_dumpstr_lines(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, char* out, int64_t cap,
+                              int32_t* err_record) {
+    if (!in || !in->heads) return INT64_MIN;
+    return dumpstr_impl(b, in, nullptr, out, cap, err_record);
+}
+
+void trk_vcf_dumpstr_stats(int64_t* fast, int64_t* decoded, int64_t* caller_heads) {
+    if (fast) *fast = g_fmt_fast.load();
+    if (decoded) *decoded = g_fmt_slow.load();
+    if (caller_heads) *caller_heads = g_fmt_py_heads.load();
+}
+
+int64_t trk_vcf_dumpstr_records(const trk_vcf_batch* b, const trk_vcf_dumpstr2* in, char* out, int64_t cap,
+                                int32_t* err_record) {
+    if (!in || !in->hrun || !in->have_stats || !in->het || !in->hwep || !in->allele_count || !in->allele_off ||
+        (in->n_info_keys > 0 && (!in->info_keys || !in->info_kinds)))
+        return INT64_MIN;
+    return dumpstr_impl(b, &in->base, in, out, cap, err_record);
 }
 
 }  // extern "C"

@@ -597,29 +597,31 @@ class _Run:
                 key = f.planes()[0][0]
                 cfv.append((f.name, 0, (rb.planes[key], 0), None))
         ul = bool(args.use_length)
-        heads = []
-        for l in range(rb.n):
-            b = int(bits[l])
-            fired_names = [f.filter_name() for f in self.locus_filters if (b >> self.bit_of[id(f)]) & 1]
+        I0, F0 = st.locus_int[0], st.locus_f64[0]
+        have = I0[:, L.LI_N_CALLED] > 0
+        status = I0[:, L.LI_HWE_STATUS_LEN if ul else L.LI_HWE_STATUS_STR]
+        if np.any(have & (status == L.HWE_INDEX_ERROR)) and not args.drop_filtered:
+            raise IndexError("tuple index out of range (haploid genotypes have no HWE test)")
+
+        def fired_names_of(b):
+            names_ = [f.filter_name() for f in self.locus_filters if (b >> self.bit_of[id(f)]) & 1]
             if (b >> L.LOCF_NO_CALLS) & 1:
-                fired_names.append('NO_CALLS_REMAINING')
-            if args.drop_filtered and fired_names:
-                heads.append(None)
-                continue
+                names_.append('NO_CALLS_REMAINING')
+            return names_
+
+        def py_head(l):
+            """The nine leading columns of output record l, in Python (vcfio.rewrite_info): what the native writer
+            does for every record whose INFO column it covers."""
+            fired_names = fired_names_of(int(bits[l]))
             f = rb.head_fields(l)
-            if len(f) < 9:
-                return self._undo_batch()
             if not args.drop_filtered:
                 f[6] = ';'.join(fired_names) if fired_names else 'PASS'
-            elif f[6] == '.':
-                pass                      # an unset FILTER stays '.', 'PASS' stays 'PASS' (Variant.to_text)
             upd = [('HRUN', int(hz.hrun[l]))]
-            I, Fv = st.locus_int[0, l], st.locus_f64[0, l]
+            I, Fv = I0[l], F0[l]
             o = int(hz.allele_off[l])
             n_alt = int(hz.allele_off[l + 1]) - o - 1
             if I[L.LI_N_CALLED] > 0:
-                status = I[L.LI_HWE_STATUS_LEN if ul else L.LI_HWE_STATUS_STR]
-                if status == L.HWE_INDEX_ERROR:
+                if I[L.LI_HWE_STATUS_LEN if ul else L.LI_HWE_STATUS_STR] == L.HWE_INDEX_ERROR:
                     raise IndexError("tuple index out of range (haploid genotypes have no HWE test)")
                 ac = st.allele_count[0, o:o + n_alt + 1].tolist()
                 upd += [('HET', float(Fv[L.LF_HET_LEN if ul else L.LF_HET_STR])),
@@ -629,12 +631,42 @@ class _Run:
                 upd += [('HET', -1), ('HWEP', -1), ('AC', 0 if n_alt == 0 else ','.join(['0'] * n_alt)), ('REFAC', 0)]
             f[7] = vcfio.rewrite_info(self.invcf, f[7], upd)
             f[8] = f[8] + ':FILTER'
-            heads.append('\t'.join(f))
+            return '\t'.join(f)
+
+        heads, native = None, None
+        if os.environ.get('TRK_DUMPSTR_NATIVE_HEADS', '1') != '0':
+            # the heads are built by the native writer (trk_vcf_dumpstr_records): per record only the FILTER text, one
+            # string per distinct pattern of fired locus filters
+            ub, inv = np.unique(bits, return_inverse=True)
+            texts, dropped = [], []
+            for b in ub.tolist():
+                fn = fired_names_of(int(b))
+                dropped.append(bool(args.drop_filtered and fn))
+                texts.append(None if args.drop_filtered else (';'.join(fn) if fn else 'PASS').encode())
+            keep_rec = None
+            if args.drop_filtered:
+                keep_rec = (~np.asarray(dropped, dtype=bool)[inv]).astype(np.uint8)
+                if np.any(have & (status == L.HWE_INDEX_ERROR) & (keep_rec != 0)):
+                    raise IndexError("tuple index out of range (haploid genotypes have no HWE test)")
+            ftext = None if args.drop_filtered else [texts[i] for i in inv.tolist()]
+            native = dict(keep=keep_rec, filter_text=ftext, hrun=hz.hrun, have_stats=have.astype(np.uint8),
+                          het=F0[:, L.LF_HET_LEN if ul else L.LF_HET_STR], hwep=F0[:, L.LF_HWEP_LEN if ul else L.LF_HWEP_STR],
+                          allele_count=st.allele_count[0], allele_off=hz.allele_off, info_types=self.invcf.info_types,
+                          py_head=py_head)
+        else:
+            heads = []
+            for l in range(rb.n):
+                if args.drop_filtered and fired_names_of(int(bits[l])):
+                    heads.append(None)
+                    continue
+                if len(rb.head_fields(l)) < 9:
+                    return self._undo_batch()
+                heads.append(py_head(l))
         t_lines = time.perf_counter()
-        _tick('record_heads_python', t_lines - t_heads)
+        _tick('record_heads_python' if native is None else 'record_heads_setup', t_lines - t_heads)
         if not hasattr(self, '_out_ring'):
             self._out_ring = {}          # two output buffers for the run, taken in turn (one block is with the writer)
-        text = rb.dumpstr_lines(heads, ch.mask, cfv, format_kinds, out_ring=self._out_ring)
+        text = rb.dumpstr_lines(heads, ch.mask, cfv, format_kinds, out_ring=self._out_ring, native=native)
         _tick('record_text_native', time.perf_counter() - t_lines)
         if text is None:
             return self._undo_batch()

@@ -101,6 +101,14 @@ class _DumpLines(C.Structure):
                 ('format_keys', C.POINTER(C.c_char_p)), ('format_kinds', C.POINTER(C.c_int32))]
 
 
+class _DumpRecords(C.Structure):
+    _fields_ = [('base', _DumpLines), ('keep', C.c_void_p), ('filter_text', C.POINTER(C.c_char_p)),
+                ('hrun', C.c_void_p), ('have_stats', C.c_void_p), ('het', C.c_void_p), ('hwep', C.c_void_p),
+                ('allele_count', C.c_void_p), ('allele_off', C.c_void_p), ('n_info_keys', C.c_int32),
+                ('fast_path', C.c_int32), ('info_keys', C.POINTER(C.c_char_p)), ('info_kinds', C.POINTER(C.c_int32)),
+                ('need_head', C.c_void_p)]
+
+
 class RawBatch:
     """One batch of records as the native reader decoded it: the genotype tensor and FORMAT planes as arrays, the
     record text still inside the reader.  No Python object per record unless ``records()`` is asked for."""
@@ -208,14 +216,19 @@ class RawBatch:
         end = f9 - 1 if 0 < f9 < n_line else n_line
         return C.string_at(b.text + b.line_off[l], end).decode().split('\t')
 
-    def dumpstr_lines(self, heads, mask, cf_values, format_kinds, n_threads=0, out_ring=None):
+    def dumpstr_lines(self, heads, mask, cf_values, format_kinds, n_threads=0, out_ring=None, native=None):
         """trk_vcf_dumpstr_lines: the output records of the batch.  heads: list of str / None; mask: uint8 or uint32
         [n, S]; cf_values: list of (name, kind, (plane, col), (plane, col) | None); format_kinds: {FORMAT ID: 1 int /
         2 float / 4 string}.  Returns bytes, or None when a record is outside what the native writer covers.
         ``out_ring``: a dict the caller keeps for the run -- the output lands in one of TWO buffers held there, taken in
         turn, instead of a fresh array per batch (a fresh 100 MB array is 25 000 page faults inside the formatter's
         threads, which serialise in the kernel).  The caller must be done with a result before the call after the
-        next one (dumpSTR's writer holds at most one block in flight)."""
+        next one (dumpSTR's writer holds at most one block in flight).
+        ``native`` (trk_vcf_dumpstr_records): the record heads are built by the library -- a dict with keep (uint8 [n]
+        or None), filter_text (list of bytes / None per record, or None), hrun (int32 [n]), have_stats (uint8 [n]),
+        het / hwep (float64 [n]), allele_count (int32), allele_off (int32 [n + 1]), info_types ({ID: (Type, Number)}),
+        py_head (callable l -> str: the head of a record whose INFO column the native rewrite declines); ``heads`` is
+        then ignored."""
         S, P = self.gt.shape[1], self.gt.shape[2]
         gt = np.ascontiguousarray(self.gt)
         ph = np.ascontiguousarray(self.phased)
@@ -237,7 +250,10 @@ class RawBatch:
                 keep.append(pb)
                 fv[k].plane_b, fv[k].dtype_b = pb.ctypes.data, 1 if pb.dtype == np.float32 else 0
                 fv[k].ncol_b, fv[k].col_b = (pb.shape[2] if pb.ndim == 3 else 1), int(bsrc[1])
-        harr = (C.c_char_p * max(self.n, 1))(*[None if h is None else h.encode() for h in heads])
+        if native is None:
+            harr = (C.c_char_p * max(self.n, 1))(*[None if h is None else h.encode() for h in heads])
+        else:
+            harr = None
         fk = list(format_kinds.items())
         karr = (C.c_char_p * max(len(fk), 1))(*[k.encode() for k, _ in fk])
         kk = (C.c_int32 * max(len(fk), 1))(*[int(v) for _, v in fk])
@@ -246,6 +262,24 @@ class RawBatch:
                          mask.ctypes.data if mask.dtype == np.uint32 else None, fv, harr, karr, kk)
         lib = self.reader._lib
         err = C.c_int32()
+        ext = None
+        if native is not None:
+            arrs = {k: (None if native.get(k) is None else np.ascontiguousarray(native[k], dtype=dt))
+                    for k, dt in (('keep', np.uint8), ('hrun', np.int32), ('have_stats', np.uint8), ('het', np.float64),
+                                  ('hwep', np.float64), ('allele_count', np.int32), ('allele_off', np.int32))}
+            keep.extend(arrs.values())
+            ft = native.get('filter_text')
+            ftarr = None if ft is None else (C.c_char_p * max(self.n, 1))(*ft)
+            ik = list((native.get('info_types') or {}).items())
+            kind_of = {'Integer': 1, 'Float': 2, 'Flag': 3}
+            ikeys = (C.c_char_p * max(len(ik), 1))(*[k.encode() for k, _ in ik])
+            ikinds = (C.c_int32 * max(len(ik), 1))(*[kind_of.get(t[0], 0) for _, t in ik])
+            need = np.zeros(max(self.n, 1), dtype=np.uint8)
+            ext = _DumpRecords(prm, None if arrs['keep'] is None else arrs['keep'].ctypes.data, ftarr,
+                               arrs['hrun'].ctypes.data, arrs['have_stats'].ctypes.data, arrs['het'].ctypes.data,
+                               arrs['hwep'].ctypes.data, arrs['allele_count'].ctypes.data, arrs['allele_off'].ctypes.data,
+                               len(ik), 1, ikeys, ikinds, need.ctypes.data)
+            keep.extend([ftarr, ikeys, ikinds, need])
         # output bound: the input text, a third more for re-serialised numbers, and per call the FILTER column this
         # pass appends (':PASS' / ':NOCALL'; the longer '<name>_<value>' strings of the few filtered calls fit in
         # the slack).  The buffer is not touched beyond what is written, so a generous bound costs nothing -- a
@@ -262,9 +296,25 @@ class RawBatch:
                 buf = out_ring.get(slot)
                 if buf is None or buf.size < cap:
                     buf = out_ring[slot] = np.empty(cap + cap // 8, dtype=np.uint8)
-            n = lib.trk_vcf_dumpstr_lines(C.byref(self.b), C.byref(prm), buf.ctypes.data, cap, C.byref(err))
+            if ext is None:
+                n = lib.trk_vcf_dumpstr_lines(C.byref(self.b), C.byref(prm), buf.ctypes.data, cap, C.byref(err))
+            else:
+                n = lib.trk_vcf_dumpstr_records(C.byref(self.b), C.byref(ext), buf.ctypes.data, cap, C.byref(err))
             if n >= 0:
                 return memoryview(buf)[:n]
+            if ext is not None and n == -(1 << 63) + 2:
+                # INFO columns the native rewrite leaves to Python: those heads come from the caller, once
+                if ext.base.heads:
+                    return None
+                todo = np.flatnonzero(need[:self.n])
+                hl = [None] * max(self.n, 1)
+                for l in todo:
+                    hl[int(l)] = native['py_head'](int(l)).encode()
+                harr = (C.c_char_p * max(self.n, 1))(*hl)
+                keep.append(harr)
+                ext.base.heads = harr
+                need[:] = 0
+                continue
             if n <= -(1 << 63) + 1:
                 return None
             cap = -n + 64
@@ -288,6 +338,15 @@ class RawBatch:
             if v.CHROM not in r.contigs_declared and v.CHROM not in r.contigs_seen:
                 r.contigs_seen.append(v.CHROM)
         return out
+
+
+def dumpstr_writer_stats():
+    """{'fast', 'decoded', 'caller_heads'}: output records written so far without decoding their sample columns / through
+    the decode path / with a head built in Python (trk_vcf_dumpstr_stats)."""
+    lib = _api()
+    a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+    lib.trk_vcf_dumpstr_stats(C.byref(a), C.byref(b), C.byref(c))
+    return dict(fast=a.value, decoded=b.value, caller_heads=c.value)
 
 
 def _api():
@@ -317,6 +376,11 @@ def _api():
         lib.trk_vcf_dumpstr_lines.argtypes = [C.POINTER(_Batch), C.POINTER(_DumpLines), vp, C.c_int64,
                                               C.POINTER(C.c_int32)]
         lib.trk_vcf_dumpstr_lines.restype = C.c_int64
+        lib.trk_vcf_dumpstr_records.argtypes = [C.POINTER(_Batch), C.POINTER(_DumpRecords), vp, C.c_int64,
+                                                C.POINTER(C.c_int32)]
+        lib.trk_vcf_dumpstr_records.restype = C.c_int64
+        lib.trk_vcf_dumpstr_stats.argtypes = [C.POINTER(C.c_int64)] * 3
+        lib.trk_vcf_dumpstr_stats.restype = None
         lib._vcf_ready = True
     return lib
 
