@@ -8,7 +8,7 @@ ns = argparse.Namespace(vcf=path, out='/tmp/e2e/stat', vcftype='hipstr', samples
                         plot_afreq=False, region=None, thresh=True, afreq=True, acount=True, hwep=True, het=True,
                         entropy=True, mean=True, mode=True, var=True, numcalled=True, use_length=False, precision=4,
                         nalleles=True, nalleles_thresh=0.01, only_passing=False)
-for i in range(3):
+for i in range(4):
     t = time.time(); statSTR.main(ns); print("run %d: %.3f s" % (i, time.time() - t), flush=True)
 os.environ['TRK_VCF_TIMING'] = '1'
 t = time.time(); statSTR.main(ns); print("timed run: %.3f s" % (time.time() - t), flush=True)

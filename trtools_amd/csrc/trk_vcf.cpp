@@ -40,12 +40,41 @@ class TextBuf {
     char* p_ = nullptr;
     size_t n_ = 0, cap_ = 0;
 
+    // Big buffers are kept for the next reader of the process instead of going back to the C library: giving ~500 MB
+    // of huge-page text back is 50 ms of trk_vcf_close after a 1 GB file (and the next reader faults the same pages
+    // in again).  At most TRK_VCF_BUF_CACHE_MB (default 4096; 0: off) are held; a one-shot command line never frees
+    // them before it exits.
+    struct Cache {
+        std::mutex m;
+        std::vector<std::pair<char*, size_t>> free_list;
+        size_t bytes = 0, limit = (size_t)4096 << 20;
+        Cache() {
+            if (const char* e = getenv("TRK_VCF_BUF_CACHE_MB")) limit = (size_t)std::max(0L, atol(e)) << 20;
+        }
+    };
+    static Cache& cache() {
+        static Cache* c = new Cache;     // never destroyed: buffers may be handed back during static destruction
+        return *c;
+    }
+    static constexpr size_t kCacheMin = (size_t)16 << 20;
+
 public:
     static constexpr size_t npos = std::string::npos;
     TextBuf() = default;
     TextBuf(const TextBuf&) = delete;
     TextBuf& operator=(const TextBuf&) = delete;
-    ~TextBuf() { free(p_); }
+    ~TextBuf() {
+        if (p_ && cap_ >= kCacheMin) {
+            Cache& c = cache();
+            std::lock_guard<std::mutex> g(c.m);
+            if (c.bytes + cap_ <= c.limit) {
+                c.free_list.emplace_back(p_, cap_);
+                c.bytes += cap_;
+                return;
+            }
+        }
+        free(p_);
+    }
     size_t size() const { return n_; }
     size_t capacity() const { return cap_; }
     const char* data() const { return p_; }
@@ -54,8 +83,26 @@ public:
     const char& operator[](size_t i) const { return p_[i]; }
     void reserve(size_t c) {
         if (c <= cap_) return;
+        if (!p_ && c >= kCacheMin) {      // a buffer a closed reader left behind, the largest one
+            Cache& ch = cache();
+            std::lock_guard<std::mutex> g(ch.m);
+            size_t best = SIZE_MAX;
+            for (size_t i = 0; i < ch.free_list.size(); ++i)
+                if (best == SIZE_MAX || ch.free_list[i].second > ch.free_list[best].second) best = i;
+            if (best != SIZE_MAX) {
+                p_ = ch.free_list[best].first;
+                cap_ = ch.free_list[best].second;
+                ch.bytes -= cap_;
+                ch.free_list.erase(ch.free_list.begin() + (long)best);
+                if (c <= cap_) return;
+            }
+        }
         size_t nc = std::max<size_t>(c, cap_ + cap_ / 2);
         nc = (nc + ((size_t)1 << 21) - 1) & ~(((size_t)1 << 21) - 1);
+        if (p_ && n_ == 0) {              // nothing to keep: no copy of the old bytes
+            free(p_);
+            p_ = nullptr;
+        }
         char* q = static_cast<char*>(realloc(p_, nc));
         if (!q) throw std::bad_alloc();
         p_ = q;
@@ -195,6 +242,7 @@ struct Source {
     FILE* fp = nullptr;
     gzFile gz = nullptr;
     bool bgzf = false, plain = false, eof = false;
+    bool src_eof = false;             // the last read of compressed bytes came back short (end of file)
     int n_threads = 1;
     // compressed bytes not yet consumed (BGZF).  Not a std::vector: resize() must not zero 8 MB that fread overwrites.
     struct CBuf {
@@ -301,7 +349,42 @@ struct Source {
             }
             size_t old = cbuf.size();
             cbuf.resize(old + target);
-            size_t got = fread(cbuf.data() + old, 1, target, fp);
+            size_t got = 0;
+            const off_t foff = ftello(fp);
+            if (target >= ((size_t)4 << 20) && n_threads > 1 && foff >= 0) {
+                // the compressed bytes by several threads (pread of 1 MB-aligned slices): a single fread copies the
+                // page cache at ~8 GB/s, 40 ms per GB of text that the inflaters wait for
+                const int fd = fileno(fp);
+                const int nt = std::min(n_threads, 16);
+                const size_t slice = (((target + (size_t)nt - 1) / (size_t)nt) + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+                const int n_sl = (int)((target + slice - 1) / slice);
+                std::vector<size_t> got_k((size_t)n_sl, 0);
+                std::atomic<int> nx{0};
+                unsigned char* dst = cbuf.data() + old;
+                auto rd = [&]() {
+                    for (;;) {
+                        const int k = nx.fetch_add(1);
+                        if (k >= n_sl) break;
+                        const size_t b0 = (size_t)k * slice, len = std::min(slice, target - b0);
+                        size_t g = 0;
+                        while (g < len) {
+                            const ssize_t r = pread(fd, dst + b0 + g, len - g, foff + (off_t)(b0 + g));
+                            if (r <= 0) break;
+                            g += (size_t)r;
+                        }
+                        got_k[(size_t)k] = g;
+                    }
+                };
+                pool.run(std::min(nt, n_sl), rd);
+                for (int k = 0; k < n_sl; ++k) {
+                    got += got_k[(size_t)k];
+                    if (got_k[(size_t)k] < std::min(slice, target - (size_t)k * slice)) break;
+                }
+                (void)fseeko(fp, foff + (off_t)got, SEEK_SET);
+            } else {
+                got = fread(cbuf.data() + old, 1, target, fp);
+            }
+            src_eof = got < target;
             cbuf.resize(old + got);
         }
         t_fread += now() - tf0;
@@ -360,7 +443,7 @@ struct Source {
             p += bsize;
         }
         if (blks.empty()) {
-            if (cbuf.size() - cpos == 0 || feof(fp)) {
+            if (cbuf.size() - cpos == 0 || src_eof) {
                 eof = true;
                 return true;
             }
@@ -419,7 +502,7 @@ struct Source {
             return false;
         }
         cpos = p;
-        if (cpos == cbuf.size() && feof(fp)) eof = true;
+        if (cpos == cbuf.size() && src_eof) eof = true;
         return true;
     }
 };
@@ -784,7 +867,7 @@ int trk_vcf_seek(trk_vcf* v, uint64_t voffset) {
     v->src.end_coff = UINT64_MAX;
     v->src.limit_pos = SIZE_MAX;
     v->sharded = v->skip_partial = v->shard_done = false;
-    v->src.eof = false;
+    v->src.eof = v->src.src_eof = false;
     v->buf.clear();
     v->pos = 0;
     v->line_off.clear();
@@ -957,7 +1040,7 @@ extern "C" int trk_vcf_shard(trk_vcf* v, int rank, int world, uint64_t* begin_of
     v->src.cbuf.clear();
     v->src.cpos = 0;
     v->src.cbuf_foff = b0;
-    v->src.eof = false;
+    v->src.eof = v->src.src_eof = false;
     v->src.limit_pos = SIZE_MAX;
     v->src.n_inflated = v->src.n_compressed = v->src.n_blocks = 0;
     v->buf.clear();
@@ -1892,7 +1975,7 @@ int64_t trk_vcf_statstr_rows(const trk_vcf_batch* b, const trk_vcf_harmonized* h
     const bool ul = in->use_length != 0;
     const int prec = in->precision;
     // rows are independent: formatted by a few threads into per-chunk strings, concatenated in order
-    const int chunk = 256;
+    const int chunk = 64;
     const int n_chunks = (n + chunk - 1) / chunk;
     std::vector<std::string> parts((size_t)n_chunks);
     std::atomic<int> next{0};
@@ -1992,7 +2075,9 @@ int64_t trk_vcf_statstr_rows(const trk_vcf_batch* b, const trk_vcf_harmonized* h
             }
         }
     };
-    const int nt = std::max(1, std::min(8, n_chunks));
+    // (a row is ~25 us of number formatting: 17 000 rows on eight threads were 67 ms of statSTR's 0.34 s per GB of text)
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int nt = std::max(1, std::min({32, hw > 0 ? hw : 8, n_chunks}));
     std::vector<std::thread> th;
     for (int t = 1; t < nt; ++t) th.emplace_back(runner);
     runner();
@@ -2399,6 +2484,47 @@ bool fast_samples(const char* smp, const char* end, int S, int pl, int nf, const
     return true;
 }
 
+// output chunks of the record writer, kept between calls (at most 1 GB of them)
+struct FmtChunk {
+    char* p = nullptr;
+    size_t cap = 0;
+};
+struct FmtChunkPool {
+    std::mutex m;
+    std::vector<FmtChunk> free_list;
+    size_t bytes = 0;
+    FmtChunk take(size_t need) {
+        {
+            std::lock_guard<std::mutex> g(m);
+            for (size_t i = 0; i < free_list.size(); ++i)
+                if (free_list[i].cap >= need) {
+                    FmtChunk c = free_list[i];
+                    free_list.erase(free_list.begin() + (long)i);
+                    bytes -= c.cap;
+                    return c;
+                }
+        }
+        FmtChunk c;
+        c.cap = std::max<size_t>(need, (size_t)8 << 20);
+        c.p = static_cast<char*>(malloc(c.cap));
+        if (!c.p) throw std::bad_alloc();
+        return c;
+    }
+    void give(const FmtChunk& c) {
+        std::lock_guard<std::mutex> g(m);
+        if (bytes + c.cap <= ((size_t)1 << 30)) {
+            free_list.push_back(c);
+            bytes += c.cap;
+        } else {
+            free(c.p);
+        }
+    }
+};
+FmtChunkPool& fmt_chunks() {
+    static FmtChunkPool* p = new FmtChunkPool;
+    return *p;
+}
+
 // records written without decoding / through the decode path / with a caller-built head, since the process started
 std::atomic<int64_t> g_fmt_fast{0}, g_fmt_slow{0}, g_fmt_py_heads{0};
 
@@ -2407,7 +2533,12 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
     if (!b || !in || (!in->heads && !ext) || !in->gt || !in->locus_ploidy || (!in->mask8 && !in->mask32)) return INT64_MIN;
     const int n = b->n_records, S = in->n_samples, P = in->ploidy;
     if (err_record) *err_record = -1;
-    std::vector<std::string> lines((size_t)n);
+    // a record is formatted straight into a chunk of its thread (head, sample columns, newline); rptr / rlen say where
+    // it lies.  Chunks come from a process-wide pool and go back to it: no allocation, no page fault per batch
+    std::vector<const char*> rptr((size_t)n, nullptr);
+    std::vector<size_t> rlen((size_t)n, 0);
+    std::vector<FmtChunk> used_chunks;
+    std::mutex used_mu;
     std::atomic<int> next{0};
     std::atomic<int> bad{INT32_MAX};
     std::atomic<int> need_heads{0};
@@ -2427,8 +2558,6 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
         std::vector<const double*> vptr((size_t)std::max(in->n_filters, 1));
         std::vector<const char*> names((size_t)std::max(in->n_filters, 1));
         for (int k = 0; k < in->n_filters; ++k) names[(size_t)k] = in->filters[k].name;
-        std::unique_ptr<char[]> scratch;
-        size_t scratch_cap = 0;
         // the numbers behind '<filter name>_<value>' of the filters that fired somewhere in record l
         auto fire_values = [&](int l, uint32_t any_bits) {
         for (int k = 0; k < in->n_filters; ++k) {
@@ -2495,6 +2624,17 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
         };
         std::string head_store;
         std::vector<int> kinds;
+        FmtChunk cur;
+        size_t cur_n = 0;
+        auto room = [&](size_t need) -> char* {
+            if (!cur.p || cur_n + need > cur.cap) {
+                cur = fmt_chunks().take(need);
+                cur_n = 0;
+                std::lock_guard<std::mutex> g(used_mu);
+                used_chunks.push_back(cur);
+            }
+            return cur.p + cur_n;
+        };
         for (;;) {
             const int l = next.fetch_add(1);
             if (l >= n) break;
@@ -2593,18 +2733,15 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
                 int64_t cfw = 8;
                 for (int k = 0; k < in->n_filters; ++k) cfw += (int64_t)strlen(names[(size_t)k]) + 26;
                 const int64_t need = smp_len * 2 + (int64_t)S * (cfw + 4 * (pl + 1) + 2 * nf) + 64;
-                if ((int64_t)scratch_cap < need) {
-                    scratch.reset(new char[(size_t)need]);
-                    scratch_cap = (size_t)need;
-                }
-                OutBuf ob{scratch.get(), need, 0};
+                char* dst = room(hl + (size_t)need + 1);
+                OutBuf ob{dst + hl, need, 0};
                 if (fast_samples(smp, smp + smp_len, S, pl, nf, kinds.data(), m32.data(), filtered.data(), in->n_filters,
                                  names.data(), vptr.data(), ob) && ob.n <= need) {
-                    std::string& o = lines[(size_t)l];
-                    o.reserve(hl + (size_t)ob.n + 1);
-                    o.assign(head, hl);
-                    o.append(scratch.get(), (size_t)ob.n);
-                    o.push_back('\n');
+                    memcpy(dst, head, hl);
+                    dst[hl + (size_t)ob.n] = '\n';
+                    rptr[(size_t)l] = dst;
+                    rlen[(size_t)l] = hl + (size_t)ob.n + 1;
+                    cur_n += rlen[(size_t)l];
                     g_fmt_fast.fetch_add(1, std::memory_order_relaxed);
                     continue;
                 }
@@ -2672,25 +2809,25 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
             int64_t cfw = 8;
             for (int k = 0; k < in->n_filters; ++k) cfw += (int64_t)strlen(names[(size_t)k]) + 26;
             need += (int64_t)S * cfw;
-            // formatted into this thread's scratch (sized by a generous bound, never value-initialised), then
-            // copied at its real length
-            if ((int64_t)scratch_cap < need) {
-                scratch.reset(new char[(size_t)need]);
-                scratch_cap = (size_t)need;
-            }
+            // formatted into this thread's chunk behind the head (sized by a generous bound, never value-initialised)
             // (format_range directly: trk_vcf_format_samples would hand the record to its sample-range thread pool,
             // and thirty-two callers queueing on that one pool serialise -- here the records are the parallel axis)
-            OutBuf ob{scratch.get(), need, 0};
+            char* dst = room(hl + (size_t)need + 1);
+            OutBuf ob{dst + hl, need, 0};
             format_range(0, S, (int)cols.size(), cols.data(), ob);
             const int64_t w = ob.n;
             if (w > need) { fail(l); continue; }
-            std::string& o = lines[(size_t)l];
-            o.reserve(hl + (size_t)w + 1);
-            o.assign(head, hl);
-            o.append(scratch.get(), (size_t)w);
-            o.push_back('\n');
+            memcpy(dst, head, hl);
+            dst[hl + (size_t)w] = '\n';
+            rptr[(size_t)l] = dst;
+            rlen[(size_t)l] = hl + (size_t)w + 1;
+            cur_n += rlen[(size_t)l];
         }
     };
+    struct GiveBack {      // the chunks return to the pool however the call ends
+        std::vector<FmtChunk>& v;
+        ~GiveBack() { for (auto& c : v) fmt_chunks().give(c); }
+    } give_back{used_chunks};
     int want = in->n_threads > 0 ? in->n_threads : 32;
     if (in->n_threads <= 0)
         if (const char* e = getenv("TRK_FMT_THREADS")) want = std::max(1, atoi(e));    // formatter threads (default 32)
@@ -2705,18 +2842,18 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
     }
     if (need_heads.load() > 0) return INT64_MIN + 2;   // ext->need_head says which records want their head from the caller
     int64_t total = 0;
-    for (auto& s : lines) total += (int64_t)s.size();
+    for (size_t i = 0; i < (size_t)n; ++i) total += (int64_t)rlen[i];
     if (!out || total > cap) return -total;
     {   // the lines land at their prefix offsets, copied by the same number of threads
         std::vector<int64_t> at((size_t)n + 1, 0);
-        for (int i = 0; i < n; ++i) at[(size_t)i + 1] = at[(size_t)i] + (int64_t)lines[(size_t)i].size();
+        for (int i = 0; i < n; ++i) at[(size_t)i + 1] = at[(size_t)i] + (int64_t)rlen[(size_t)i];
         std::atomic<int> nx{0};
         auto copier = [&]() {
             for (;;) {
                 const int i0 = nx.fetch_add(16);
                 if (i0 >= n) break;
                 for (int i = i0; i < std::min(n, i0 + 16); ++i)
-                    memcpy(out + at[(size_t)i], lines[(size_t)i].data(), lines[(size_t)i].size());
+                    if (rlen[(size_t)i]) memcpy(out + at[(size_t)i], rptr[(size_t)i], rlen[(size_t)i]);
             }
         };
         std::vector<std::thread> tc;
