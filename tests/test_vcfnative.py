@@ -323,3 +323,39 @@ def test_read_ahead_errors_surface_in_order_and_a_seek_drops_the_batch_in_flight
     got = [v.POS for v in r('1:1000000-2000000')]
     r.close()
     assert got == want and len(want) > 0
+
+
+def test_pool_that_grows_between_jobs_and_parallel_reads(tmp_path):
+    """A file whose compressed bytes are read by several threads (>= 4 MB per fill) with MORE inflater threads than
+    read slices: the reader's pool grows between the two jobs of one fill (round 4: threads created then took the
+    finished job for a new one and the reader hung).  Same records as with one thread."""
+    import numpy as np
+    from trtools_amd import vcfnative
+    from trtools_amd.bgzf import BgzfWriter
+    rng = np.random.default_rng(3)
+    S, n = 2000, 900
+    path = str(tmp_path / 'big.vcf.gz')
+    with BgzfWriter(path, level=1) as fh:
+        fh.write('##fileformat=VCFv4.1\n##FORMAT=<ID=GT,Number=1,Type=String,Description="GT">\n'
+                 '##FORMAT=<ID=DP,Number=1,Type=Integer,Description="DP">\n')
+        fh.write('#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t' + '\t'.join('S%d' % i for i in range(S)) + '\n')
+        for l in range(n):
+            g = rng.integers(0, 3, size=(S, 2)).astype(str)
+            dp = rng.integers(0, 10 ** 6, size=S).astype(str)
+            cols = np.char.add(np.char.add(np.char.add(g[:, 0], '/'), g[:, 1]), np.char.add(':', dp))
+            fh.write('chr1\t%d\t.\tA\tC,G\t.\t.\t.\tGT:DP\t%s\n' % (100 + l, '\t'.join(cols)))
+    assert os.path.getsize(path) > (5 << 20)
+    sums = []
+    for nt in (1, 48):
+        r = vcfnative.NativeVCFReader(path, n_threads=nt)
+        r.select_format('DP')
+        tot, recs = 0, 0
+        while True:
+            rb = r.read_raw_batch()
+            if not rb.n:
+                break
+            tot += int(rb.gt.astype(np.int64).sum()) + int(np.asarray(rb.planes['DP'], dtype=np.int64).sum())
+            recs += rb.n
+        r.close()
+        sums.append((recs, tot))
+    assert sums[0][0] == n and sums[0] == sums[1]

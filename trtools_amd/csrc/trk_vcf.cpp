@@ -183,8 +183,7 @@ class WorkerPool {
     int pending_ = 0;
     bool stop_ = false;
 
-    void loop() {
-        uint64_t seen = 0;
+    void loop(uint64_t seen) {   // seen: the generation at the time the thread was created (earlier jobs are not its)
         for (;;) {
             const std::function<void()>* job;
             {
@@ -220,7 +219,15 @@ public:
     // runs `job` on up to n - 1 pool threads and on the caller; returns when every one of them has returned
     void run(int n, const std::function<void()>& job) {
         const int want = std::max(0, n - 1);
-        while ((int)th_.size() < want) th_.emplace_back([this] { loop(); });
+        if ((int)th_.size() < want) {
+            // a pool that grows between two jobs: the new threads must not take the finished job for a new one
+            uint64_t g0;
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                g0 = gen_;
+            }
+            while ((int)th_.size() < want) th_.emplace_back([this, g0] { loop(g0); });
+        }
         if (!th_.empty()) {
             {
                 std::lock_guard<std::mutex> lk(m_);
