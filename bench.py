@@ -844,7 +844,7 @@ def config2_extra(eng, no_check, iters=5):
 
 def end_to_end_extra(eng, seed):
     """SURVEY.md 8(d) "report both kernel-only and end-to-end": (a) statSTR's command line from a bgzipped text VCF
-    (2000 loci x 5000 samples, GT:DP:Q, written here) to its table of 11 statistics -- native reader, native batch
+    (17 000 loci x 5000 samples = 1.02 GB of text, GT:DP:Q, written here) to its table of 11 statistics -- native reader, native batch
     harmoniser, upload from pinned staging, kernels, download, native row formatter; (b) a packed host batch
     (4096 loci x 10000 samples) through upload + statistics + download, i.e. the device path with PCIe included,
     from pageable and from pinned host memory.  Never part of `value`."""
@@ -858,10 +858,27 @@ def end_to_end_extra(eng, seed):
     comp = DeviceCompute(engine=eng)
     old = runtime.set_compute(comp)
     try:
-        Lc, S = 2000, 5000
+        # 17 000 loci x 5 000 samples = 1.02 GB of text (the end-to-end rows at >= 1 GB): 1000 distinct
+        # records are rendered (the sample columns of a record are ~60 KB of text) and written 17 times over with their
+        # own POS / ID / START / END -- the command lines read, harmonise, count and write every record as any other
+        L0, TILES, S = 1000, int(os.environ.get('TRK_E2E_TILES', '17')), 5000
+        Lc = L0 * TILES
         tmp = tempfile.mkdtemp(prefix='trk_e2e_')
         path = os.path.join(tmp, 'synth.vcf.gz')
-        loci = synth.make_loci(Lc, S, seed=5)
+        loci = synth.make_loci(L0, S, seed=5)
+        recs = []
+        for l0 in range(0, L0, 64):
+            idx = np.arange(l0, min(L0, l0 + 64))
+            rows = synth.cells_numpy(5, loci, idx, S)
+            for r, l in enumerate(idx):
+                strs = loci.allele_strs[l]
+                g0 = np.where(rows['gt'][r, :, 0] < 0, '.', rows['gt'][r, :, 0].astype(str))
+                g1 = np.where(rows['gt'][r, :, 1] < 0, '.', rows['gt'][r, :, 1].astype(str))
+                dp = np.where(rows['dp'][r] == -2147483648, '.', rows['dp'][r].astype(str))
+                q = np.where(np.isnan(rows['q'][r]), '.', np.char.mod('%g', rows['q'][r]))
+                cols = np.char.add(np.char.add(np.char.add(np.char.add(g0, '|'), g1), ':'),
+                                   np.char.add(np.char.add(dp, ':'), q))
+                recs.append((strs[0], ','.join(strs[1:]) or '.', len(loci.motifs[l]), '\tGT:DP:Q\t' + '\t'.join(cols) + '\n'))
         with BgzfWriter(path, level=1) as fh:
             fh.write('##fileformat=VCFv4.1\n##command=HipSTR-v0.6.2 --synthetic\n')
             for k in ('START', 'END', 'PERIOD'):
@@ -869,21 +886,21 @@ def end_to_end_extra(eng, seed):
             for k, t in (('GT', 'String'), ('DP', 'Integer'), ('Q', 'Float')):
                 fh.write('##FORMAT=<ID=%s,Number=1,Type=%s,Description="%s">\n' % (k, t, k))
             fh.write('#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t' + '\t'.join('S%05d' % i for i in range(S)) + '\n')
-            for l0 in range(0, Lc, 64):
-                idx = np.arange(l0, min(Lc, l0 + 64))
-                rows = synth.cells_numpy(5, loci, idx, S)
-                for r, l in enumerate(idx):
-                    strs = loci.allele_strs[l]
-                    pos = 1000 + 500 * int(l)
-                    g0 = np.where(rows['gt'][r, :, 0] < 0, '.', rows['gt'][r, :, 0].astype(str))
-                    g1 = np.where(rows['gt'][r, :, 1] < 0, '.', rows['gt'][r, :, 1].astype(str))
-                    dp = np.where(rows['dp'][r] == -2147483648, '.', rows['dp'][r].astype(str))
-                    q = np.where(np.isnan(rows['q'][r]), '.', np.char.mod('%g', rows['q'][r]))
-                    cols = np.char.add(np.char.add(np.char.add(np.char.add(g0, '|'), g1), ':'),
-                                       np.char.add(np.char.add(dp, ':'), q))
-                    fh.write('\t'.join(['chr1', str(pos), 'STR_%d' % l, strs[0], ','.join(strs[1:]) or '.', '.', '.',
-                                        'START=%d;END=%d;PERIOD=%d' % (pos, pos + len(strs[0]) - 1, len(loci.motifs[l])),
-                                        'GT:DP:Q']) + '\t' + '\t'.join(cols) + '\n')
+            for t in range(TILES):
+                block = []
+                for l, (ref, alts, period, tail) in enumerate(recs):
+                    gl = t * L0 + l
+                    pos = 1000 + 500 * gl
+                    block.append('chr1\t%d\tSTR_%d\t%s\t%s\t.\t.\tSTART=%d;END=%d;PERIOD=%d%s'
+                                 % (pos, gl, ref, alts, pos, pos + len(ref) - 1, period, tail))
+                fh.write(''.join(block))
+        del recs
+
+        def clear_outputs(prefix):
+            # (truncating the previous run's 1.5 GB output is 0.15 s of open(): not the command line's time)
+            for f in os.listdir(tmp):
+                if f.startswith(prefix + '.'):
+                    os.remove(os.path.join(tmp, f))
         ns = argparse.Namespace(vcf=path, out=os.path.join(tmp, 'stat'), vcftype='hipstr', samples=None,
                                 sample_prefixes=None, plot_afreq=False, region=None, thresh=True, afreq=True,
                                 acount=True, hwep=True, het=True, entropy=True, mean=True, mode=True, var=True,
@@ -891,6 +908,7 @@ def end_to_end_extra(eng, seed):
                                 only_passing=False)
         best = None
         for _ in range(3):
+            clear_outputs('stat')
             t0 = time.perf_counter()
             rc = statSTR.main(ns)
             el = time.perf_counter() - t0
@@ -914,6 +932,7 @@ def end_to_end_extra(eng, seed):
             sys.argv = argv
         best = None
         for _ in range(3):
+            clear_outputs('dump')
             t0 = time.perf_counter()
             rc = dumpSTR.main(dargs)
             el = time.perf_counter() - t0

@@ -304,7 +304,7 @@ int trk_device_clocks(trk_ctx* ctx, int32_t* sclk_khz, int32_t* mclk_khz, int32_
  * allocates the first plane, then candidates for the second one at a time, times the write-only half of the pass's
  * stream over (first, candidate) -- ~3 launches, 1-2 ms each at 4 GB planes -- and stops at the first pair that is
  * clearly fast (>= 6 % faster than another candidate, or >= TRK_PAIR_FAST_TBPS of write rate); the best pair is
- * returned, the other candidates freed.  max_spare = planes that may exist beyond the two returned (0: plain
+ * returned, the other candidates freed.  max_spare = FRESH planes that may exist beyond the two returned (0: plain
  * allocation + one probe; trk_call_filters' callers use 2): the transient never exceeds max_spare x bytes_each.
  * Both planes are plain device allocations (trk_dev_free); their contents are undefined. */
 #define TRK_PAIR_MAX_PROBES 8
@@ -314,12 +314,15 @@ typedef struct {
     int32_t placed;                /* 1: the kept pair is on the fast level by one of the two criteria      */
     float probe_ms[TRK_PAIR_MAX_PROBES];  /* write-only probe of (a, candidate k)                           */
     float kept_ms;                 /* the kept pair's                                                        */
-    float reserved;
+    int32_t have_a, have_b;        /* index in have[] of the plane returned as *a / *b, -1: a fresh allocation */
+    int32_t reserved;
     double seconds;                /* host time the call took (allocations + probes)                        */
-    uint64_t peak_extra_bytes;     /* allocated beyond the two returned planes, at the peak                 */
+    uint64_t peak_extra_bytes;     /* freshly allocated beyond the two returned planes, at the peak         */
 } trk_pair_info;
+/* have[0 .. n_have): planes of bytes_each the caller already holds (an allocator's pooled buffers): have[0] becomes the
+ * first plane, the others are the first candidates for the second; the ones not returned stay the caller's. */
 int trk_dev_alloc_pair(trk_ctx* ctx, size_t bytes_each, int64_t n_loci, int64_t n_samples, int32_t max_spare,
-                       void** a, void** b, trk_pair_info* info);
+                       void* const* have, int32_t n_have, void** a, void** b, trk_pair_info* info);
 
 /* Filter opcodes: one per distinct arithmetic in dumpSTR/filters.py.           */
 enum {

@@ -127,7 +127,8 @@ PAIR_MAX_PROBES = 8
 
 class PairInfo(C.Structure):
     _fields_ = [('n_probed', C.c_int32), ('placed', C.c_int32), ('probe_ms', C.c_float * PAIR_MAX_PROBES),
-                ('kept_ms', C.c_float), ('reserved', C.c_float), ('seconds', C.c_double),
+                ('kept_ms', C.c_float), ('have_a', C.c_int32), ('have_b', C.c_int32), ('reserved', C.c_int32),
+                ('seconds', C.c_double),
                 ('peak_extra_bytes', C.c_uint64)]
 
 
@@ -233,7 +234,7 @@ def load():
     lib.trk_device_info.argtypes = [vp, C.c_char_p, C.c_int, P(C.c_int), P(u64), C.c_char_p, C.c_int]
     lib.trk_dev_alloc.argtypes = [vp, C.c_size_t, P(vp)]
     lib.trk_dev_free.argtypes = [vp, vp]
-    lib.trk_dev_alloc_pair.argtypes = [vp, C.c_size_t, i64, i64, i32, P(vp), P(vp), P(PairInfo)]
+    lib.trk_dev_alloc_pair.argtypes = [vp, C.c_size_t, i64, i64, i32, P(vp), i32, P(vp), P(vp), P(PairInfo)]
     lib.trk_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
     lib.trk_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
     lib.trk_memcpy_d2d.argtypes = [vp, vp, vp, C.c_size_t]

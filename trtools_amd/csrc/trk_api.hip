@@ -909,59 +909,78 @@ static hipError_t probe_pair_ms(trk_ctx* ctx, void* a, void* b, int64_t n_loci, 
 }
 
 int trk_dev_alloc_pair(trk_ctx* ctx, size_t bytes_each, int64_t n_loci, int64_t n_samples, int32_t max_spare,
-                       void** a, void** b, trk_pair_info* info) {
-    if (!ctx || !a || !b) return TRK_ERR_ARG;
+                       void* const* have, int32_t n_have, void** a, void** b, trk_pair_info* info) {
+    if (!ctx || !a || !b || n_have < 0 || (n_have > 0 && !have)) return TRK_ERR_ARG;
     *a = *b = nullptr;
     trk_pair_info pi = {};
+    pi.have_a = pi.have_b = -1;
     if (n_loci < 1 || n_samples < 4 || n_samples % 4 || bytes_each < (size_t)n_loci * (size_t)n_samples * 4u)
         return fail(ctx, TRK_ERR_ARG, "trk_dev_alloc_pair: planes of [n_loci, n_samples] 4-byte cells, n_samples %% 4 == 0");
     if (max_spare < 0) max_spare = 0;
-    if (max_spare > TRK_PAIR_MAX_PROBES - 1) max_spare = TRK_PAIR_MAX_PROBES - 1;
     (void)hipSetDevice(ctx->device);
     const auto t0 = std::chrono::steady_clock::now();
-    hipError_t e = hipMalloc(a, bytes_each);
-    if (e != hipSuccess) return fail(ctx, TRK_ERR_NOMEM, "hipMalloc(%zu): %s", bytes_each, hipGetErrorString(e));
+    hipError_t e = hipSuccess;
+    // the first plane: one the caller holds already (a pooled buffer), else a fresh allocation
+    if (n_have > 0) {
+        *a = have[0];
+        pi.have_a = 0;
+    } else {
+        e = hipMalloc(a, bytes_each);
+        if (e != hipSuccess) return fail(ctx, TRK_ERR_NOMEM, "hipMalloc(%zu): %s", bytes_each, hipGetErrorString(e));
+    }
     // Candidates for the second plane, one at a time, each timed together with the first (a pair of planes is on one
     // of two levels for as long as the allocations live -- profiles/r03_notes.md section 22 -- and the level shows in
-    // the write-only half of the stream: 7.0 against 5.4-5.9 TB/s).  At most `max_spare` planes beyond the two that
-    // are returned exist at any time; the search stops at the first pair that is clearly on the fast level.
-    void* cand[TRK_PAIR_MAX_PROBES] = {};
+    // the write-only half of the stream: 7.0 against 5.4-5.9 TB/s): first the other planes the caller holds, then
+    // fresh allocations.  At most `max_spare` fresh planes beyond the ones returned exist at any time; the search stops
+    // at the first pair that is clearly on the fast level.  (A candidate handed back to the driver comes back as the
+    // next allocation: every candidate is held until the search ends, which is why their number is the memory bound.)
+    struct Cand { void* p; int have; };
+    Cand cand[TRK_PAIR_MAX_PROBES] = {};
     float ms[TRK_PAIR_MAX_PROBES] = {};
-    int n = 0, best = -1;
+    int n = 0, best = -1, n_fresh = 0;
+    const int fresh_cap = 1 + max_spare;
     const double gbytes = 2.0 * (double)n_loci * (double)n_samples * 4.0 * 1e-9;
     int rc = TRK_OK;
-    while (n < 1 + max_spare) {
-        void* p = nullptr;
-        e = hipMalloc(&p, bytes_each);
-        if (e != hipSuccess) {                    // out of memory for a spare: keep what there is
-            (void)hipGetLastError();
-            if (n == 0) rc = fail(ctx, TRK_ERR_NOMEM, "hipMalloc(%zu): %s", bytes_each, hipGetErrorString(e));
+    while (n < TRK_PAIR_MAX_PROBES) {
+        Cand c = {nullptr, -1};
+        if (1 + n < n_have) {
+            c.p = have[1 + n];
+            c.have = 1 + n;
+        } else if (n_fresh < fresh_cap) {
+            e = hipMalloc(&c.p, bytes_each);
+            if (e != hipSuccess) {                    // out of memory for a spare: keep what there is
+                (void)hipGetLastError();
+                if (n == 0) rc = fail(ctx, TRK_ERR_NOMEM, "hipMalloc(%zu): %s", bytes_each, hipGetErrorString(e));
+                break;
+            }
+            ++n_fresh;
+        } else {
             break;
         }
-        cand[n] = p;
-        e = probe_pair_ms(ctx, *a, p, n_loci, n_samples, &ms[n]);
-        if (e != hipSuccess) { rc = fail(ctx, TRK_ERR_HIP, "trk_dev_alloc_pair probe: %s", hipGetErrorString(e)); ++n; break; }
-        if (best < 0 || ms[n] < ms[best]) best = n;
+        cand[n] = c;
+        e = probe_pair_ms(ctx, *a, c.p, n_loci, n_samples, &ms[n]);
         ++n;
+        if (e != hipSuccess) { rc = fail(ctx, TRK_ERR_HIP, "trk_dev_alloc_pair probe: %s", hipGetErrorString(e)); break; }
+        if (best < 0 || ms[n - 1] < ms[best]) best = n - 1;
         float worst = ms[0];
         for (int k = 1; k < n; ++k) worst = ms[k] > worst ? ms[k] : worst;
         const double tbps = gbytes / (double)ms[best];            // GB / ms = TB/s
         if (worst >= 1.06f * ms[best] || tbps >= TRK_PAIR_FAST_TBPS) { pi.placed = 1; break; }
-        // (a candidate handed back to the driver comes back as the next allocation: every candidate is held until the
-        // search ends, which is why their number is the memory bound)
     }
-    pi.peak_extra_bytes = (uint64_t)(n > 1 ? n - 1 : 0) * (uint64_t)bytes_each;
+    pi.peak_extra_bytes = (uint64_t)(n_fresh > 1 ? n_fresh - 1 : 0) * (uint64_t)bytes_each;
     if (rc == TRK_OK && best >= 0) {
-        *b = cand[best];
-        cand[best] = nullptr;
+        *b = cand[best].p;
+        pi.have_b = cand[best].have;
         pi.kept_ms = ms[best];
+        cand[best].p = nullptr;
     }
     for (int k = 0; k < n; ++k)
-        if (cand[k]) (void)hipFree(cand[k]);
+        if (cand[k].p && cand[k].have < 0) (void)hipFree(cand[k].p);      // (the caller's own planes stay the caller's)
     if (rc != TRK_OK) {
-        if (*b) (void)hipFree(*b);
-        (void)hipFree(*a);
+        if (*b && pi.have_b < 0) (void)hipFree(*b);
+        if (pi.have_a < 0) (void)hipFree(*a);
         *a = *b = nullptr;
+        pi.have_a = pi.have_b = -1;
     }
     pi.n_probed = n;
     for (int k = 0; k < n; ++k) pi.probe_ms[k] = ms[k];

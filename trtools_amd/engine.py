@@ -501,16 +501,34 @@ class Engine:
         uint32) through trk_dev_alloc_pair: on MI355X the pass's two write streams run on one of two levels, 10-18 %
         apart, decided by which allocations the two planes are (profiles/r03_notes.md section 22); the library times
         the write-only half of the stream over the first plane and up to 1 + ``max_spare`` candidates for the second
-        (default 2 spare planes: TRK_PLACE_SPARE) and keeps the fastest pair.  Pooled buffers are used as they come
-        (no probe) when the engine's pool holds a pair of this size class."""
+        (default 2 spare planes: TRK_PLACE_SPARE) and keeps the fastest pair.  Buffers of the size class that the engine's
+        pool holds are the first candidates; the ones not taken go back to the pool."""
         Lc, S = batch.n_loci, batch.n_samples
         nbytes = Lc * S * 4
         cap = self._size_class(max(nbytes, 16))
         if max_spare is None:
             max_spare = int(os.environ.get('TRK_PLACE_SPARE', '2'))
         a, b, info = C.c_void_p(), C.c_void_p(), L.PairInfo()
-        self._chk(self.lib.trk_dev_alloc_pair(self.ctx, cap, Lc, S, int(max_spare), C.byref(a), C.byref(b),
-                                              C.byref(info)))
+        # buffers of this size class the pool holds are the first candidates (idle ones only: a probe writes them)
+        have = []
+        while len(have) < 4:
+            lst = self._pool.get(cap)
+            if not lst:
+                break
+            p_ = self._pool_take(cap)
+            if p_ is None:
+                break
+            have.append(p_)
+        harr = (C.c_void_p * max(len(have), 1))(*have)
+        try:
+            self._chk(self.lib.trk_dev_alloc_pair(self.ctx, cap, Lc, S, int(max_spare), harr, len(have), C.byref(a),
+                                                  C.byref(b), C.byref(info)))
+        finally:
+            used = {info.have_a, info.have_b}
+            for k, p_ in enumerate(have):
+                if k not in used:
+                    if not self._pool_give(cap, p_):
+                        self.lib.trk_dev_free(self.ctx, p_)
         Engine.last_placement = dict(probe_ms=[round(float(info.probe_ms[k]), 3) for k in range(info.n_probed)],
                                      kept_ms=round(float(info.kept_ms), 3), placed=bool(info.placed),
                                      seconds=round(float(info.seconds), 4), peak_extra_bytes=int(info.peak_extra_bytes),
@@ -528,7 +546,7 @@ class Engine:
             place = os.environ.get('TRK_PLACE_OUTPUTS', '1') != '0'
         g = m = None
         if (place and want_gt and want_mask and batch.ploidy == 2 and batch.n_loci * S * 4 >= self.PLACE_MIN_BYTES and
-                S % 4 == 0 and not self._pool.get(self._size_class(batch.n_loci * S * 4))):
+                S % 4 == 0):
             g, m = self.placed_output_pair(batch)
         else:
             g = self.empty((batch.n_loci, S, batch.ploidy), np.int16) if want_gt else None
