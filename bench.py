@@ -1174,6 +1174,7 @@ def main():
                          # flat keys (the driver's parser drops nested objects of this one)
                          "placement_probe_ms": (wl.placement or {}).get('probe_ms'),
                          "placement_placed": (wl.placement or {}).get('placed'),
+                         "placement_jumps": (wl.placement or {}).get('jumps'),
                          "placement_seconds": (wl.placement or {}).get('seconds'),
                          "placement_peak_extra_bytes": (wl.placement or {}).get('peak_extra_bytes'),
                          "placement_note": "trk_dev_alloc_pair: write-only probe (ms) of the masked-genotype plane with "

@@ -304,7 +304,9 @@ int trk_device_clocks(trk_ctx* ctx, int32_t* sclk_khz, int32_t* mclk_khz, int32_
  * allocates the first plane, then candidates for the second one at a time, times the write-only half of the pass's
  * stream over (first, candidate) -- ~3 launches, 1-2 ms each at 4 GB planes -- and stops at the first pair that is
  * clearly fast (>= 6 % faster than another candidate, or >= TRK_PAIR_FAST_TBPS of write rate); the best pair is
- * returned, the other candidates freed.  max_spare = FRESH planes that may exist beyond the two returned (0: plain
+ * returned, the other candidates freed.  When every neighbour is slow the search steps ahead: the spares are freed, a
+ * spacer of TRK_PLACE_JUMP_GB (16) GB is allocated -- never touched --, one candidate is taken behind it, the spacer
+ * freed (at most two such jumps; transient = spacer + one plane, reported in peak_extra_bytes).  max_spare = FRESH planes that may exist beyond the two returned (0: plain
  * allocation + one probe; trk_call_filters' callers use 2): the transient never exceeds max_spare x bytes_each.
  * Both planes are plain device allocations (trk_dev_free); their contents are undefined. */
 #define TRK_PAIR_MAX_PROBES 8
@@ -315,7 +317,7 @@ typedef struct {
     float probe_ms[TRK_PAIR_MAX_PROBES];  /* write-only probe of (a, candidate k)                           */
     float kept_ms;                 /* the kept pair's                                                        */
     int32_t have_a, have_b;        /* index in have[] of the plane returned as *a / *b, -1: a fresh allocation */
-    int32_t reserved;
+    int32_t n_jumps;               /* candidates taken behind a spacer (TRK_PLACE_JUMP_GB, default 16 GB, at most 2)  */
     double seconds;                /* host time the call took (allocations + probes)                        */
     uint64_t peak_extra_bytes;     /* freshly allocated beyond the two returned planes, at the peak         */
 } trk_pair_info;

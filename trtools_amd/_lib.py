@@ -127,7 +127,7 @@ PAIR_MAX_PROBES = 8
 
 class PairInfo(C.Structure):
     _fields_ = [('n_probed', C.c_int32), ('placed', C.c_int32), ('probe_ms', C.c_float * PAIR_MAX_PROBES),
-                ('kept_ms', C.c_float), ('have_a', C.c_int32), ('have_b', C.c_int32), ('reserved', C.c_int32),
+                ('kept_ms', C.c_float), ('have_a', C.c_int32), ('have_b', C.c_int32), ('n_jumps', C.c_int32),
                 ('seconds', C.c_double),
                 ('peak_extra_bytes', C.c_uint64)]
 

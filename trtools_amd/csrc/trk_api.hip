@@ -937,8 +937,12 @@ int trk_dev_alloc_pair(trk_ctx* ctx, size_t bytes_each, int64_t n_loci, int64_t 
     struct Cand { void* p; int have; };
     Cand cand[TRK_PAIR_MAX_PROBES] = {};
     float ms[TRK_PAIR_MAX_PROBES] = {};
-    int n = 0, best = -1, n_fresh = 0;
+    int n = 0, best = -1, n_fresh = 0, n_jumps = 0;
     const int fresh_cap = 1 + max_spare;
+    // TRK_PLACE_JUMP_GB (default 16, 0: no jumps): how far a jump steps; at most two of them
+    size_t jump_bytes = (size_t)16 << 30, peak_jump = 0;
+    if (const char* ev = getenv("TRK_PLACE_JUMP_GB")) jump_bytes = (size_t)(atof(ev) > 0 ? atof(ev) * 1073741824.0 : 0);
+    const int max_jumps = 2;
     const double gbytes = 2.0 * (double)n_loci * (double)n_samples * 4.0 * 1e-9;
     int rc = TRK_OK;
     while (n < TRK_PAIR_MAX_PROBES) {
@@ -954,6 +958,28 @@ int trk_dev_alloc_pair(trk_ctx* ctx, size_t bytes_each, int64_t n_loci, int64_t 
                 break;
             }
             ++n_fresh;
+        } else if (n_jumps < max_jumps && jump_bytes > 0) {
+            // every neighbour is on the slow level (the driver hands a whole region out plane by plane): give the
+            // losing spares back, step `jump_bytes` ahead behind a spacer that is never touched, take ONE candidate
+            // there, return the spacer.  Transient: the spacer + that plane.
+            for (int k = 0; k < n; ++k)
+                if (k != best && cand[k].p && cand[k].have < 0) {
+                    (void)hipFree(cand[k].p);
+                    cand[k].p = nullptr;
+                }
+            void* spacer = nullptr;
+            if (hipMalloc(&spacer, jump_bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                break;
+            }
+            e = hipMalloc(&c.p, bytes_each);
+            (void)hipFree(spacer);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                break;
+            }
+            ++n_jumps;
+            if (jump_bytes + bytes_each > peak_jump) peak_jump = jump_bytes + bytes_each;
         } else {
             break;
         }
@@ -968,6 +994,8 @@ int trk_dev_alloc_pair(trk_ctx* ctx, size_t bytes_each, int64_t n_loci, int64_t 
         if (worst >= 1.06f * ms[best] || tbps >= TRK_PAIR_FAST_TBPS) { pi.placed = 1; break; }
     }
     pi.peak_extra_bytes = (uint64_t)(n_fresh > 1 ? n_fresh - 1 : 0) * (uint64_t)bytes_each;
+    if (peak_jump > pi.peak_extra_bytes) pi.peak_extra_bytes = peak_jump;
+    pi.n_jumps = n_jumps;
     if (rc == TRK_OK && best >= 0) {
         *b = cand[best].p;
         pi.have_b = cand[best].have;

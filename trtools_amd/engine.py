@@ -530,7 +530,7 @@ class Engine:
                     if not self._pool_give(cap, p_):
                         self.lib.trk_dev_free(self.ctx, p_)
         Engine.last_placement = dict(probe_ms=[round(float(info.probe_ms[k]), 3) for k in range(info.n_probed)],
-                                     kept_ms=round(float(info.kept_ms), 3), placed=bool(info.placed),
+                                     kept_ms=round(float(info.kept_ms), 3), placed=bool(info.placed), jumps=int(info.n_jumps),
                                      seconds=round(float(info.seconds), 4), peak_extra_bytes=int(info.peak_extra_bytes),
                                      plane_bytes=int(cap))
         g = DeviceArray.adopt(self, (Lc, S, 2), np.int16, a.value, cap)
