@@ -43,7 +43,7 @@ def main():
         return {"kernel": k, "fetch_kib_raw": v['FETCH_SIZE'][0], "write_kib_raw": v.get('WRITE_SIZE', (0.0,))[0],
                 "fetch_bytes": f, "write_bytes": w, "bytes_per_launch": f + w, "algorithmic_bytes_per_launch": algo,
                 "ratio": (f + w) / algo if algo else None}
-    res["k_call_filter"] = entry(bench, 'k_call_filter_v2<3, true, false', 20.0e9)
+    res["k_call_filter"] = entry(bench, 'k_call_filter_v4<3, 1, true, false', 20.0e9) or entry(bench, 'k_call_filter_v2<3, true, false', 20.0e9)
     res["k_stream_probe"] = entry(bench, 'k_stream_probe<3, 2>', 20.0e9)
     res["k_cf_reduce"] = entry(bench, 'k_cf_reduce', None)
     res["k_locus_count"] = entry(bench, 'k_locus_count_v2<', 4.0e9)
