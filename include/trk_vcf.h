@@ -80,7 +80,16 @@ typedef struct {
     const int64_t* line_off;
     const int64_t* line_end;
     const int32_t* field_off;
+    int16_t* gt_mapped;      /* [max_records, n_out, P] caller-owned or NULL: the genotypes once more, sample s in
+                                column map[s] (trk_vcf_set_sample_map), unmapped columns no-calls             */
 } trk_vcf_batch;
+
+/* statSTR.py:520-542 (--samples): group membership belongs to the SAMPLE, so the columns can be laid out by sample class
+ * while the record is parsed -- for free -- and every class becomes a column range the ungrouped count kernels read
+ * (trk_batch.class_runs).  map[s] = output column of the file's sample s, or -1 (the sample is in no group: never
+ * written); n_out = columns of a gt_mapped row (class ranges padded to 16-byte boundaries, the row to 128).  NULL map:
+ * off.  The reader keeps filling trk_vcf_batch.gt in file order as well (the per-record paths read that one). */
+int trk_vcf_set_sample_map(trk_vcf* v, const int32_t* map, int32_t n_out);
 
 /* Decode up to max_records records.  Returns 0, or a non-zero code with trk_vcf_last_error(). */
 int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batch* out);

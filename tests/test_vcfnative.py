@@ -359,3 +359,33 @@ def test_pool_that_grows_between_jobs_and_parallel_reads(tmp_path):
         r.close()
         sums.append((recs, tot))
     assert sums[0][0] == n and sums[0] == sums[1]
+
+
+def test_sample_map_lays_the_columns_out_while_parsing():
+    """trk_vcf_set_sample_map (statSTR --samples, round 4): gt_mapped is the file-order tensor gathered by the
+    engine's class layout -- every class a run of columns on a multiple of four, padding columns no-calls, samples
+    in no group dropped -- and the file-order tensor is still there."""
+    import numpy as np
+    from trtools_amd import vcfnative
+    from trtools_amd.engine import class_layout
+    path = os.path.join(GOLDEN, 'data', 'many_samples.vcf.gz')
+    r = vcfnative.NativeVCFReader(path)
+    S = r.n_samples
+    rng = np.random.default_rng(5)
+    gb = rng.integers(0, 8, size=S).astype(np.uint8)          # three overlapping groups, some samples in none
+    lay = class_layout(gb, 3, row_align=32)
+    assert lay['n_out'] % 32 == 0 and np.all(lay['runs'].reshape(-1, 4)[:, 0] % 4 == 0)
+    r.set_sample_map(lay['col_of'], lay['n_out'])
+    n = 0
+    while True:
+        rb = r.read_raw_batch(40)
+        if not rb.n:
+            break
+        want = np.full((rb.n, lay['n_out'], rb.gt.shape[2]), -1, dtype=np.int16)
+        real = lay['cols'] >= 0
+        want[:, real] = rb.gt[:, lay['cols'][real]]
+        assert np.array_equal(rb.gt_mapped, want)
+        assert np.array_equal(lay['bits'][real], gb[lay['cols'][real]])
+        n += rb.n
+    assert n > 100
+    r.close()

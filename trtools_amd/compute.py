@@ -88,6 +88,13 @@ class DeviceCompute:
         # gathered on the device into class order and counted range by range with the ungrouped streaming kernel
         # (DeviceBatch.sorted_by_class; the per-call group kernel takes 19-23 ms at 100k x 10k where this takes ~2).
         # Up to three groups keep the one-pass grouped kernel (k_locus_count_v2g), which needs no gather.
+        lay = getattr(hb, 'class_layout', None)
+        if lay is not None and allow_class_sort:
+            # the columns arrive in class order already (the reader laid them out while it parsed the records,
+            # trk_vcf_set_sample_map): no gather, the ungrouped streaming kernel per class range
+            base = self.eng.make_batch(hb.gt, hb.allele_off, hb.len_class, hb.str_class, hb.len_class_value,
+                                       max_alleles=hb.max_alleles)
+            return base.with_class_layout(self.eng, lay, hb.n_groups)
         mode = os.environ.get('TRK_CLASS_SORT', '')
         # (only trk_locus_stats reads a class-ordered batch: every other entry point needs the samples in their
         # own order and number, so the gather is an opt-in of locus_stats -- ADVICE r03)
@@ -127,6 +134,7 @@ class DeviceCompute:
         return out
 
     supports_compact = True
+    supports_class_layout = True      # locus_stats takes a HostBatch whose columns are in engine.class_layout order
 
     def dumpstr_batch(self, hb, planes, filters, dp_plane, locus_spec, nalleles_thresh=0.01, compact=False):
         """Call filters -> masked genotypes -> locus statistics -> locus filters, all on the device.

@@ -555,6 +555,9 @@ struct trk_vcf {
     // contiguous shard of the file (trk_vcf_shard)
     bool sharded = false, skip_partial = false, shard_done = false;
     uint64_t plain_end = UINT64_MAX;   // plain text: file offset where the next rank's lines begin
+    // trk_vcf_set_sample_map: sample s of the file -> column sample_map[s] of trk_vcf_batch.gt_mapped (-1: dropped)
+    std::vector<int32_t> sample_map;
+    int map_out = 0;
 };
 
 namespace {
@@ -674,6 +677,12 @@ void parse_record(RecordJob& job, int rec) {
     int16_t* gt = job.out->gt + (size_t)rec * S * P;
     uint8_t* ph = job.out->phased ? job.out->phased + (size_t)rec * S : nullptr;
     for (size_t i = 0; i < (size_t)S * P; ++i) gt[i] = -2;
+    // the same genotypes a second time with the samples in the caller's column order (trk_vcf_set_sample_map):
+    // columns no sample maps to are no-calls
+    const int32_t* smap = (job.out->gt_mapped && !v->sample_map.empty()) ? v->sample_map.data() : nullptr;
+    int16_t* gtm = smap ? job.out->gt_mapped + (size_t)rec * v->map_out * P : nullptr;
+    if (gtm)
+        for (size_t i = 0; i < (size_t)v->map_out * P; ++i) gtm[i] = -1;
     if (ph) memset(ph, 0, (size_t)S);
     const int np = (int)v->planes.size();
     // FORMAT keys -> subfield index of GT and of every selected plane's inputs
@@ -744,6 +753,8 @@ void parse_record(RecordJob& job, int rec) {
             if (ph) ph[s] = phased ? 1 : 0;
             maxpl = std::max(maxpl, j);
         }
+        if (gtm && smap[s] >= 0)
+            for (int j = 0; j < P; ++j) gtm[(size_t)smap[s] * P + j] = gt[(size_t)s * P + j];
         for (int i = 0; i < np; ++i) {
             const PlaneSel& ps = v->planes[i];
             char* base = static_cast<char*>(job.out->planes[i]);
@@ -1086,6 +1097,25 @@ const char* trk_vcf_header(trk_vcf* v, size_t* len) {
     return v->header.c_str();
 }
 int trk_vcf_n_samples(trk_vcf* v) { return (int)v->samples.size(); }
+int trk_vcf_set_sample_map(trk_vcf* v, const int32_t* map, int32_t n_out) {
+    if (!v) return 2;
+    v->sample_map.clear();
+    v->map_out = 0;
+    if (!map) return 0;
+    const int S = (int)v->samples.size();
+    if (n_out < 1) { v->err = "sample map: n_out must be positive"; return 1; }
+    std::vector<uint8_t> seen((size_t)n_out, 0);
+    for (int s = 0; s < S; ++s) {
+        if (map[s] < -1 || map[s] >= n_out) { v->err = "sample map: column out of range"; return 1; }
+        if (map[s] >= 0) {
+            if (seen[(size_t)map[s]]) { v->err = "sample map: two samples on one column"; return 1; }
+            seen[(size_t)map[s]] = 1;
+        }
+    }
+    v->sample_map.assign(map, map + S);
+    v->map_out = n_out;
+    return 0;
+}
 const char* trk_vcf_sample_name(trk_vcf* v, int i) {
     return (i >= 0 && i < (int)v->samples.size()) ? v->samples[(size_t)i].c_str() : "";
 }

@@ -153,44 +153,74 @@ class DeviceBatch:
         batch carries the run table; trk_locus_stats then counts each range with the ungrouped kernel and adds the
         classes into their groups.  ``group_bits``: host uint8[S] of THIS batch's columns (padding columns 0).
         Returns a new DeviceBatch that owns the gathered tensor (free its arrays['gt'] / ['group_bits'] when done);
-        diploid batches only -- others get ``with_groups``."""
+        diploid batches only -- others get ``with_groups``.  (The command line lays its columns out by class while the
+        reader parses them -- ``class_layout`` / ``with_class_layout`` -- and needs no gather.)"""
         gb = np.ascontiguousarray(group_bits, dtype=np.uint8) & np.uint8((1 << int(n_groups)) - 1)
         S = self.n_samples
         if gb.shape != (S,):
             raise ValueError("group_bits must have one entry per sample column")
         if self.ploidy != 2 or self.n_loci == 0:
             return self.with_groups(eng, gb, n_groups)
-        cols, bits, runs, at = [], [], [], 0
-        for c in np.unique(gb):
-            if c == 0:
-                continue
-            idx = np.flatnonzero(gb == c).astype(np.int32)
-            pad = (-idx.size) % 4
-            runs.append((at, idx.size + pad, idx.size, int(c)))
-            at += idx.size + pad
-            cols.append(np.concatenate([idx, np.full(pad, -1, dtype=np.int32)]))
-            bits.append(np.concatenate([np.full(idx.size, c, dtype=np.uint8), np.zeros(pad, dtype=np.uint8)]))
-        if not runs:
+        lay = class_layout(gb, n_groups, row_align=4)
+        if lay is None:
             return self.with_groups(eng, gb, n_groups)
-        col = np.concatenate(cols)
-        S2 = int(col.size)
-        col_d = eng.upload(col)
+        S2 = lay['n_out']
+        col_d = eng.upload(lay['cols'])
         gt2 = eng.empty((self.n_loci, S2, 2), np.int16)
         eng._chk(eng.lib.trk_permute_columns(eng.ctx, self.arrays['gt'].ptr, gt2.ptr, col_d.ptr, self.n_loci, S, S2, 2))
         col_d.free()
+        return self.with_class_layout(eng, lay, n_groups, gt2)
+
+    def with_class_layout(self, eng, lay, n_groups, gt_sorted=None):
+        """This batch's tables over a genotype tensor whose columns are in ``class_layout`` order (``gt_sorted``: a
+        DeviceArray [L, n_out, 2]; None: this batch's own tensor already is)."""
         s = L.Batch()
         C.memmove(C.byref(s), C.byref(self.struct), C.sizeof(L.Batch))
-        gbd = eng.upload(np.concatenate(bits))
-        table = np.ascontiguousarray(np.array(runs, dtype=np.int32).reshape(-1))
-        s.gt, s.n_samples, s.n_pad_samples = gt2.ptr, S2, 0
-        s.group_bits, s.n_groups = gbd.ptr, int(n_groups)
-        s.n_class_runs, s.class_runs = len(runs), table.ctypes.data
+        gbd = eng.upload(lay['bits'])
+        table = lay['runs']
         arrays = dict(self.arrays)
-        arrays['gt'], arrays['group_bits'] = gt2, gbd
+        if gt_sorted is not None:
+            arrays['gt'] = gt_sorted
+        s.gt, s.n_samples, s.n_pad_samples = arrays['gt'].ptr, int(lay['n_out']), 0
+        s.group_bits, s.n_groups = gbd.ptr, int(n_groups)
+        s.n_class_runs, s.class_runs = len(table) // 4, table.ctypes.data
+        arrays['group_bits'] = gbd
         out = DeviceBatch(s, arrays, int(n_groups), self.sum_alleles)
         out._class_runs = table          # host memory the struct points at
         out.class_sorted = True
         return out
+
+
+def class_layout(group_bits, n_groups, row_align=32):
+    """Column order of a cohort by sample CLASS (pattern of group bits, statSTR.py:520-542): every class a run of
+    columns starting on a multiple of four (16 bytes of diploid genotypes), padded with no-call columns; samples in no
+    group are left out; the row padded to a multiple of ``row_align`` columns.  Returns None when no sample is in a group,
+    else {'cols': int32 [n_out] file column of each output column (-1: a padding column), 'col_of': int32 [S] output
+    column of each file column (-1: dropped), 'bits': uint8 [n_out], 'runs': int32 table of (start, padded length,
+    samples, class bits) per run, 'n_out'}."""
+    gb = np.ascontiguousarray(group_bits, dtype=np.uint8) & np.uint8((1 << int(n_groups)) - 1)
+    cols, bits, runs, at = [], [], [], 0
+    for c in np.unique(gb):
+        if c == 0:
+            continue
+        idx = np.flatnonzero(gb == c).astype(np.int32)
+        pad = (-idx.size) % 4
+        runs.append((at, idx.size + pad, idx.size, int(c)))
+        at += idx.size + pad
+        cols.append(np.concatenate([idx, np.full(pad, -1, dtype=np.int32)]))
+        bits.append(np.concatenate([np.full(idx.size, c, dtype=np.uint8), np.zeros(pad, dtype=np.uint8)]))
+    if not runs:
+        return None
+    tail = (-at) % max(4, int(row_align))
+    if tail:
+        cols.append(np.full(tail, -1, dtype=np.int32))
+        bits.append(np.zeros(tail, dtype=np.uint8))
+    col = np.ascontiguousarray(np.concatenate(cols))
+    col_of = np.full(gb.shape[0], -1, dtype=np.int32)
+    real = col >= 0
+    col_of[col[real]] = np.flatnonzero(real).astype(np.int32)
+    return dict(cols=col, col_of=col_of, bits=np.ascontiguousarray(np.concatenate(bits)),
+                runs=np.ascontiguousarray(np.array(runs, dtype=np.int32).reshape(-1)), n_out=int(col.size))
 
 
 class StatsResult:

@@ -296,6 +296,16 @@ def _run_batches(args, invcf, vcftype, group_masks, fmt, shard, batch_loci, star
             for g, m in enumerate(part):
                 gb |= (np.asarray(m, dtype=bool).astype(np.uint8) << g)
             passes.append((gb, len(part)))
+    # Sample groups (one pass of <= 8): the reader lays the genotype columns out by sample CLASS while it parses them
+    # (trk_vcf_set_sample_map) -- every class a column range the ungrouped count kernel streams, no gather on the
+    # device, no per-call group look-ups (TRK_CLASS_SORT=0: the grouped kernel on file-order columns)
+    layout = None
+    if (masks is not None and len(passes) == 1 and hasattr(invcf, 'set_sample_map') and
+            os.environ.get('TRK_CLASS_SORT', '1') != '0' and getattr(compute, 'supports_class_layout', False)):
+        from ..engine import class_layout
+        layout = class_layout(passes[0][0], passes[0][1], row_align=32 if len(invcf.samples) >= 512 else 4)
+        if layout is not None:
+            invcf.set_sample_map(layout['col_of'], layout['n_out'])
     invcf.use_buffers(getattr(compute, 'host_buffer', None), ring=2, release=getattr(compute, 'host_release', None))
     # (TRK_VCF_READ_AHEAD=1: batch n + 1 is read and parsed while batch n is counted and written.  Off by default: this
     # command line is its reader -- 0.29 of 0.32 s per GB of text -- and has nothing to hide the read behind)
@@ -338,8 +348,13 @@ def _run_batches(args, invcf, vcftype, group_masks, fmt, shard, batch_loci, star
             continue
         parts = []
         for gb, ng in passes:
-            hb = HostBatch.from_tables(rb.gt, rb.locus_ploidy, hz.allele_off, hz.len_class, hz.str_class,
-                                       hz.len_class_value, gb, ng, lists=hz.lists)
+            sorted_ok = (layout is not None and rb.gt_mapped is not None and rb.gt.shape[2] == 2 and
+                         bool(np.all(np.asarray(rb.locus_ploidy) == 2)))
+            hb = HostBatch.from_tables(rb.gt_mapped if sorted_ok else rb.gt, rb.locus_ploidy, hz.allele_off, hz.len_class,
+                                       hz.str_class, hz.len_class_value, layout['bits'] if sorted_ok else gb, ng,
+                                       lists=hz.lists)
+            if sorted_ok:
+                hb.class_layout = layout
             parts.append(compute.locus_stats(hb, nalleles_thresh=args.nalleles_thresh))
         st = parts[0]
         if len(parts) > 1:                   # more than eight strata: the passes' rows side by side

@@ -24,7 +24,7 @@ class _Batch(C.Structure):
     _fields_ = [('n_records', C.c_int32), ('max_ploidy', C.c_int32), ('gt', C.c_void_p),
                 ('phased', C.c_void_p), ('locus_ploidy', C.c_void_p), ('planes', C.POINTER(C.c_void_p)),
                 ('text', C.c_void_p), ('line_off', C.POINTER(C.c_int64)), ('line_end', C.POINTER(C.c_int64)),
-                ('field_off', C.POINTER(C.c_int32))]
+                ('field_off', C.POINTER(C.c_int32)), ('gt_mapped', C.c_void_p)]
 
 
 class _Harmonized(C.Structure):
@@ -113,10 +113,12 @@ class RawBatch:
     """One batch of records as the native reader decoded it: the genotype tensor and FORMAT planes as arrays, the
     record text still inside the reader.  No Python object per record unless ``records()`` is asked for."""
 
-    def __init__(self, reader, b, gt, ph, lp, planes):
+    def __init__(self, reader, b, gt, ph, lp, planes, gt_mapped=None):
         self.reader, self.b = reader, b
         self.n = b.n_records
         self.gt, self.phased, self.locus_ploidy = gt[:self.n], ph[:self.n], lp[:self.n]
+        # the genotypes once more in the column order of set_sample_map (None without a map)
+        self.gt_mapped = None if gt_mapped is None else gt_mapped[:self.n]
         self.planes = {k: planes[j][:self.n] for j, (k, _, _, _) in enumerate(reader._selected)}
         self._hz = None
 
@@ -360,6 +362,7 @@ def _api():
         lib.trk_vcf_last_error.restype = C.c_char_p
         lib.trk_vcf_header.argtypes = [vp, C.POINTER(C.c_size_t)]
         lib.trk_vcf_header.restype = C.c_void_p
+        lib.trk_vcf_set_sample_map.argtypes = [vp, vp, C.c_int32]
         lib.trk_vcf_n_samples.argtypes = [vp]
         lib.trk_vcf_sample_name.argtypes = [vp, C.c_int]
         lib.trk_vcf_sample_name.restype = C.c_char_p
@@ -493,10 +496,11 @@ class NativeVCFReader(vcfio.VCFReader):
         n = n_records or self._batch_records or max(1, min(4096, (1 << 22) // max(S, 1)))
         while True:
             # (a batch retried with a wider tensor gets arrays of its own: the ring keeps the file's usual shape)
-            gt, ph, lp, planes = self._arrays(n, S, P, ring=(P == self._max_ploidy))
+            gt, ph, lp, planes, gtm = self._arrays(n, S, P, ring=(P == self._max_ploidy))
             parr = (C.c_void_p * max(len(planes), 1))(*[p.ctypes.data for p in planes])
             b = _Batch()
             b.gt, b.phased, b.locus_ploidy = gt.ctypes.data, ph.ctypes.data, lp.ctypes.data
+            b.gt_mapped = None if gtm is None else gtm.ctypes.data
             b.planes = C.cast(parr, C.POINTER(C.c_void_p))
             rc = self._lib.trk_vcf_read_batch(self._h, n, P, C.byref(b))
             if rc == 5 and b'haplotypes' in self._lib.trk_vcf_last_error(self._h):
@@ -513,7 +517,7 @@ class NativeVCFReader(vcfio.VCFReader):
             if rc != 0:
                 raise ValueError(self._lib.trk_vcf_last_error(self._h).decode())
             break
-        rb = RawBatch(self, b, gt, ph, lp, planes)
+        rb = RawBatch(self, b, gt, ph, lp, planes, gtm)
         rb._keep = parr
         return rb
 
@@ -547,15 +551,32 @@ class NativeVCFReader(vcfio.VCFReader):
         self._ring, self._ring_i, self._ring_n, self._alloc = [], 0, int(ring), allocator
         self._release, self._slabs = release, []     # ``release(slab)``: called for every slab when the reader closes
 
+    def set_sample_map(self, col_of_sample, n_out):
+        """trk_vcf_set_sample_map: every batch also carries ``gt_mapped`` [n, n_out, P] -- sample s of the file in
+        column ``col_of_sample[s]`` (-1: left out), unmapped columns no-calls.  ``None``: off."""
+        if col_of_sample is None:
+            self._lib.trk_vcf_set_sample_map(self._h, None, 0)
+            self._map_out = 0
+            return self
+        m = np.ascontiguousarray(col_of_sample, dtype=np.int32)
+        if m.shape != (self.n_samples,):
+            raise ValueError("one column per sample of the file")
+        if self._lib.trk_vcf_set_sample_map(self._h, m.ctypes.data, int(n_out)) != 0:
+            raise ValueError(self._lib.trk_vcf_last_error(self._h).decode())
+        self._map_out = int(n_out)
+        return self
+
     def _arrays(self, n, S, P, ring=True):
+        M = getattr(self, '_map_out', 0)
         if getattr(self, '_ring_n', 0) <= 0 or not ring:
             return (np.empty((n, S, P), dtype=np.int16), np.empty((n, S), dtype=np.uint8), np.empty(n, dtype=np.uint8),
-                    [np.empty((n, S, nc), dtype=dt) for _, _, nc, dt in self._selected])
-        key = (n, S, P, tuple((nc, np.dtype(dt).str) for _, _, nc, dt in self._selected))
+                    [np.empty((n, S, nc), dtype=dt) for _, _, nc, dt in self._selected],
+                    np.empty((n, M, P), dtype=np.int16) if M else None)
+        key = (n, S, P, M, tuple((nc, np.dtype(dt).str) for _, _, nc, dt in self._selected))
         if len(self._ring) < self._ring_n or self._ring[self._ring_i % self._ring_n][0] != key:
             # one slab per ring slot (a pinned allocation costs milliseconds whatever its size), carved 64-byte aligned
             shapes = [((n, S, P), np.int16), ((n, S), np.uint8), ((n,), np.uint8)] + \
-                     [((n, S, nc), dt) for _, _, nc, dt in self._selected]
+                     [((n, S, nc), dt) for _, _, nc, dt in self._selected] + ([((n, M, P), np.int16)] if M else [])
             sizes = [(int(np.prod(sh, dtype=np.int64)) * np.dtype(dt).itemsize + 63) & ~63 for sh, dt in shapes]
             total = max(sum(sizes), 64)
             if self._alloc is not None:
@@ -572,7 +593,8 @@ class NativeVCFReader(vcfio.VCFReader):
                 cursor[0] += (nb + 63) & ~63
                 return a
             slot = (key, (take((n, S, P), np.int16), take((n, S), np.uint8), take((n,), np.uint8),
-                          [take((n, S, nc), dt) for _, _, nc, dt in self._selected]))
+                          [take((n, S, nc), dt) for _, _, nc, dt in self._selected],
+                          take((n, M, P), np.int16) if M else None))
             if len(self._ring) < self._ring_n:
                 self._ring.append(slot)
                 self._ring_i = len(self._ring) - 1
