@@ -21,7 +21,7 @@ def _lib():
 
 def test_library_exports_every_declared_symbol():
     L, lib = _lib()
-    hdr = open(os.path.join(ROOT, 'include', 'trk.h')).read()
+    hdr = open(os.path.join(ROOT, 'include', 'trk.h')).read() + open(os.path.join(ROOT, 'include', 'trk_test.h')).read()
     hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
     declared = sorted(set(re.findall(r'\b(trk_[a-z0-9_]+)\s*\(', hdr)))
     assert declared, "no declarations parsed"
@@ -94,3 +94,14 @@ def test_binomtest_host_entry_random_cases_match_scipy():
         got = lib.trk_binomtest_two_sided(k, n, p)
         want = st.binomtest(k, n, p).pvalue
         assert abs(got - want) <= 1e-9 * max(want, 1e-300) or abs(got - want) < 1e-300, (k, n, p, got, want)
+
+
+def test_library_exports_every_symbol_of_the_reader_header():
+    """include/trk_vcf.h (native reader, batch harmoniser, row / record writers): every declared entry point is exported."""
+    _, lib = _lib()
+    hdr = open(os.path.join(ROOT, 'include', 'trk_vcf.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = sorted(set(re.findall(r'\b(trk_vcf_[a-z0-9_]+)\s*\(', hdr)))
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), "libtrk.so does not export %s" % name

@@ -138,7 +138,7 @@ class SynthSpec(C.Structure):
                 ('inbreed_thr16', C.c_void_p), ('locus_base', C.c_int32), ('reserved', C.c_int32)]
 
 
-# every symbol include/trk.h declares (tests check that the library exports them)
+# every symbol include/trk.h and include/trk_test.h declare (tests check that the library exports them)
 EXPORTS = [
     'trk_init', 'trk_free', 'trk_last_error', 'trk_backend', 'trk_device_count', 'trk_device_info',
     'trk_dev_alloc', 'trk_dev_alloc_pair', 'trk_dev_free', 'trk_memcpy_h2d', 'trk_memcpy_d2h', 'trk_memcpy_d2d', 'trk_memset', 'trk_sync',
@@ -160,7 +160,7 @@ class TrkError(RuntimeError):
 
 # the sources libtrk.so is built from, in the order csrc/Makefile hashes them
 _SOURCES = ['csrc/trk_api.hip', 'csrc/trk_assoc.hip', 'csrc/trk_binom.h', 'csrc/trk_internal.h', 'csrc/trk_kernels.hip',
-            'csrc/trk_qc.hip', 'csrc/trk_student.h', 'csrc/trk_vcf.cpp', '../include/trk.h', '../include/trk_vcf.h']
+            'csrc/trk_qc.hip', 'csrc/trk_student.h', 'csrc/trk_vcf.cpp', '../include/trk.h', '../include/trk_test.h', '../include/trk_vcf.h']
 
 
 def source_digest():

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/trk.h"
+#include "../../include/trk_test.h"
 #include "trk_binom.h"
 #include "trk_student.h"
 #include "trk_internal.h"

@@ -29,6 +29,7 @@
 #include <stdlib.h>
 
 #include "../../include/trk.h"
+#include "../../include/trk_test.h"
 #include "trk_internal.h"
 #include "trk_student.h"
 

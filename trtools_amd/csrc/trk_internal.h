@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/trk.h"
+#include "../../include/trk_test.h"
 
 #define TRK_MAX_PLOIDY 8
 

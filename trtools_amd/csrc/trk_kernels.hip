@@ -32,6 +32,7 @@
 #include <string.h>
 
 #include "../../include/trk.h"
+#include "../../include/trk_test.h"
 #include "trk_binom.h"
 #include "trk_internal.h"
 

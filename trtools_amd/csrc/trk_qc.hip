@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include "../../include/trk.h"
+#include "../../include/trk_test.h"
 #include "trk_internal.h"
 
 namespace {
