@@ -4167,8 +4167,13 @@ hipError_t launch_locus_finalize(const trk_batch& b, const int32_t* allele_count
     // forces one or the other.
     static const char* hwe_env = getenv("TRK_HWE_WIDE");
     const bool hwe_wide = hwe_env ? atoi(hwe_env) != 0 : n <= 32768;
+    // (TRK_HWE_WAVES=4: the 128-register build -- 108 B of scratch instead of 332 -- which still fits beside the four
+    // call-filter waves of a SIMD that the round-4 launch geometry leaves room for)
+    static const int hwe_waves = getenv("TRK_HWE_WAVES") ? atoi(getenv("TRK_HWE_WAVES")) : 7;
     if (hwe_wide)
         hipLaunchKernelGGL(k_hwe_test<1>, dim3(tblocks), dim3(FIN_THREADS), 0, stream, count, items, locus_f64, overflow);
+    else if (hwe_waves == 4)
+        hipLaunchKernelGGL(k_hwe_test<4>, dim3(tblocks), dim3(FIN_THREADS), 0, stream, count, items, locus_f64, overflow);
     else
         hipLaunchKernelGGL(k_hwe_test<7>, dim3(tblocks), dim3(FIN_THREADS), 0, stream, count, items, locus_f64, overflow);
     if ((e = hipGetLastError()) != hipSuccess) return e;
