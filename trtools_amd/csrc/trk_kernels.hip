@@ -4169,7 +4169,7 @@ hipError_t launch_locus_finalize(const trk_batch& b, const int32_t* allele_count
     const bool hwe_wide = hwe_env ? atoi(hwe_env) != 0 : n <= 32768;
     // (TRK_HWE_WAVES=4: the 128-register build -- 108 B of scratch instead of 332 -- which still fits beside the four
     // call-filter waves of a SIMD that the round-4 launch geometry leaves room for)
-    static const int hwe_waves = getenv("TRK_HWE_WAVES") ? atoi(getenv("TRK_HWE_WAVES")) : 7;
+    static const int hwe_waves = getenv("TRK_HWE_WAVES") ? atoi(getenv("TRK_HWE_WAVES")) : 4;   // (same-box A/B of the bench step: 4.15 ms against 4.22 with the 72-register build)
     if (hwe_wide)
         hipLaunchKernelGGL(k_hwe_test<1>, dim3(tblocks), dim3(FIN_THREADS), 0, stream, count, items, locus_f64, overflow);
     else if (hwe_waves == 4)
