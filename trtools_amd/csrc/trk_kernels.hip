@@ -3136,8 +3136,24 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_gs(const GsArgs a) {
     const int nal = a.delta_nal;
     const int dstride = nal + V2_EXTRA;
     uint32_t* dtab = v2lds;
-    uint32_t* lutb = dtab + (size_t)a.loci_per_block * dstride;
-    int32_t* linfo = reinterpret_cast<int32_t*>(lutb + (size_t)a.loci_per_block * nal);
+    int32_t* linfo = reinterpret_cast<int32_t*>(dtab + (size_t)a.loci_per_block * dstride);
+    // this wave's queue of filtered calls {genotype word, locus of the block}, behind the tables (k_call_filter_v4)
+    uint2* queue = reinterpret_cast<uint2*>(v2lds + ((((size_t)a.loci_per_block * (dstride + CF_LINFO)) + 1) & ~(size_t)1)) +
+                   (size_t)(tid >> 6) * V4_QCAP;
+    uint32_t qtail = 0;
+    const uint64_t exm = __ballot(s0 < S);
+    const uint32_t n_lanes = (uint32_t)__popcll(exm);
+    const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(exm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)exm, 0u));
+    auto drain = [&]() {
+        if (!DELTA) return;
+        wave_lds_fence();
+        for (uint32_t i = my_rank; i < qtail; i += n_lanes) {
+            const uint2 r = queue[i];
+            v4_drain_one(r.x, r.y, dtab, a.b, linfo, nal, dstride);
+        }
+        wave_lds_fence();
+        qtail = 0;
+    };
     // per-sample counters as 16-bit pairs (samples 2 i and 2 i + 1 share a register: a workgroup's loci stay below
     // 65536): half the registers of one counter per sample -- 22 instead of 44 VGPRs, the difference between three
     // and four waves per SIMD.  The low half takes the mask as the carry of an add, the high half through the SDWA
@@ -3165,10 +3181,9 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_gs(const GsArgs a) {
     const int nl = l_end - l_begin;
     if (DELTA) {
         for (int i = tid; i < nl * dstride; i += CF_THREADS) dtab[i] = 0;
-        cf_build_lut(a.b, l_begin, nl, nal, tid, lutb, linfo);
+        cf_build_lut<false>(a.b, l_begin, nl, nal, tid, nullptr, linfo);
     }
     if (s0 < S) {
-        const bool leader = (tid & 63) == __ffsll((unsigned long long)__ballot(1)) - 1;
         for (int l = l_begin; l < l_end; ++l) {
             const int64_t c4 = ((int64_t)l * S + s0) >> 2;
             // (interleaved planes: a lane's k vectors are k x 16 consecutive bytes, so every load instruction of the
@@ -3282,38 +3297,15 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_gs(const GsArgs a) {
                     }
                 }
             }
-            if (DELTA) {    // what the filtered calls remove from the locus counts (k_call_filter_v4 queues them instead)
-                const int li = l - l_begin;
-                uint32_t* tab = dtab + li * dstride;
-                const uint32_t A = (uint32_t)linfo[CF_LINFO * li];
-                const bool lut_needed = cf_lut_needed(linfo, li);
-                const uint32_t* lutl = lutb + li * nal;
-                uint32_t w0acc = 0, w1acc = 0;
+            if (DELTA) {    // the filtered calls are queued (as in k_call_filter_v4) and drained in bulk
+                const uint32_t li = (uint32_t)(l - l_begin);
 #pragma unroll
                 for (int j = 0; j < CF_V; ++j) {
-                    const uint32_t w = g[j];
-                    const uint32_t a0 = w & 0xffffu, a1 = w >> 16;
-                    const bool filtered = __builtin_amdgcn_inverse_ballot_w64(filtm[j]);
-                    const bool v0 = a0 < A, v1 = a1 < A;
-                    const uint64_t lowm = filtm[j] & (__ballot(a0 == 0xfffeu) | __ballot(a1 == 0xfffeu));
-                    uint64_t hlm = filtm[j] & __ballot(a0 == a1) & __ballot(v0), hsm = hlm;
-                    if (filtered) {
-                        atomicAdd(&tab[v0 ? (int)a0 : nal + V2_TRASH], 1u);
-                        atomicAdd(&tab[v1 ? (int)a1 : nal + V2_TRASH], 1u);
-                    }
-                    if (lut_needed) {
-                        const bool need = filtered & v0 & v1 & (a0 != a1);
-                        uint32_t q = 0xffffffffu;
-                        if (need) q = lutl[a0] ^ lutl[a1];
-                        hlm |= __ballot((q & 0xffffu) == 0u);
-                        hsm |= __ballot((q >> 16) == 0u);
-                    }
-                    w0acc += (uint32_t)__popcll(filtm[j]) + ((uint32_t)__popcll(lowm) << 16);
-                    w1acc += (uint32_t)__popcll(hlm) + ((uint32_t)__popcll(hsm) << 16);
-                }
-                if (leader) {
-                    if (w0acc) atomicAdd(&tab[nal + V2_W0], w0acc);
-                    if (w1acc) atomicAdd(&tab[nal + V2_W1], w1acc);
+                    if (!filtm[j]) continue;
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(filtm[j] >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)filtm[j], 0u));
+                    if (__builtin_amdgcn_inverse_ballot_w64(filtm[j])) queue[qtail + rank] = make_uint2(g[j], li);
+                    qtail += (uint32_t)__popcll(filtm[j]);
                 }
             }
             if (a.out.gt_out) __builtin_nontemporal_store(wout, reinterpret_cast<u32x4*>(a.out.gt_out) + c4);
@@ -3324,7 +3316,9 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_gs(const GsArgs a) {
                 for (int j = 0; j < CF_V; ++j) m8 |= ((mout[j] & 0x7fu) | ((mout[j] >> 24) & 0x80u)) << (8 * j);
                 __builtin_nontemporal_store(m8, reinterpret_cast<uint32_t*>(a.out.filter_mask8) + c4);
             }
+            if (DELTA && qtail > (uint32_t)(V4_QCAP - CF_V * WAVE)) drain();
         }
+        drain();
     }
     if (DELTA) {
         __syncthreads();
@@ -4615,11 +4609,12 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
                           : (planar ? (delta ? k_call_filter_gs<true, true, -1> : k_call_filter_gs<true, false, -1>)
                                     : (delta ? k_call_filter_gs<false, true, -1> : k_call_filter_gs<false, false, -1>));
             // geometry as for k_call_filter_v4 (cf_geometry), the delta table within 32 KiB
-            const size_t per_locus = delta ? ((size_t)2 * b.max_alleles + V2_EXTRA + CF_LINFO) * sizeof(uint32_t) : 0;
+            const size_t per_locus = delta ? ((size_t)b.max_alleles + V2_EXTRA + CF_LINFO) * sizeof(uint32_t) : 0;
+            const size_t gq = delta ? (size_t)(CF_THREADS / WAVE) * V4_QCAP * sizeof(uint2) + 8 : 0;   // the waves' queues
             int lpb2 = lpb;
-            if (delta) lpb2 = std::min<int>(lpb2, (int)((32 * 1024) / per_locus));
+            if (delta) lpb2 = std::max(1, std::min<int>({lpb2, 255, (int)((30 * 1024 - gq) / per_locus)}));
             int occ = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kg, CF_THREADS, (size_t)lpb2 * per_locus) != hipSuccess || occ < 1)
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kg, CF_THREADS, (size_t)lpb2 * per_locus + gq) != hipSuccess || occ < 1)
                 occ = 3;
             const CfLaunch cl = cf_geometry(L, gx, lpb2, n_cu, occ);
             lpb2 = cl.lpb;
@@ -4632,7 +4627,7 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             if (ws) {
                 g.part16 = static_cast<uint16_t*>(ws);
                 g.part64 = reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + b16);
-                hipLaunchKernelGGL(kg, cl.grid, dim3(CF_THREADS), (size_t)lpb2 * per_locus, stream, g);
+                hipLaunchKernelGGL(kg, cl.grid, dim3(CF_THREADS), delta ? ((((size_t)lpb2 * per_locus) + 7) & ~(size_t)7) + gq : 0, stream, g);
                 hipError_t e1 = hipGetLastError();
                 if (e1 != hipSuccess) return e1;
                 if (scratch.next_kernel) scratch.next_kernel(scratch.user);
