@@ -138,7 +138,7 @@ DUMP_CASES = {
 
 # inputs the native pieces decline (records without the mandatory INFO fields, a FORMAT/FILTER field from an earlier
 # dumpSTR round): the batch goes through the record objects -- same outputs, just not through the batch pipeline
-FALLBACK_CASES = {'longtr'}
+FALLBACK_CASES = set()      # (round 4: LongTR's symbolic '<DEL>' alleles are harmonised natively too)
 BIG_CASES = {'hipstr_thresholds', 'hipstr_ratios_minsupp', 'gangstr_thresholds', 'gangstr_all_trio'}     # trio files: GPU legs only
 
 

@@ -1739,7 +1739,9 @@ void harmonize_one(const char* line, const int32_t* fo, int64_t line_len, int vc
         }
     }
     const bool by_length = vcftype == TRK_VT_EH || vcftype == TRK_VT_POPSTR;
-    if (!by_length)
+    // (HipSTR / LongTR: the reference slices and upper-cases a symbolic '<DEL>' like any other allele string --
+    // tr_harmonizer.py:336-408 -- so it is an allele here too; the other sequence callers leave such records to Python)
+    if (!by_length && vcftype != TRK_VT_HIPSTR)
         for (auto& al : raw)
             for (long i = 0; i < al.second; ++i)
                 if (al.first[i] == '<' || al.first[i] == '[' || al.first[i] == ']' || al.first[i] == '*') return;  // symbolic
@@ -2356,7 +2358,8 @@ inline void put_callfilter(OutBuf& o, uint32_t m, int n_filters, const char* con
         if (!n) o.put('.');
     }
 }
-// kinds[f]: -1 GT, TRK_VCF_COL_INT / _FLOAT / _UCS4.  m32 / filtered: the record's mask row.
+// kinds[f]: -1 GT, -2 the record's own FILTER field (replaced in place), TRK_VCF_COL_INT / _FLOAT / _UCS4.
+// m32 / filtered: the record's mask row.
 bool fast_samples(const char* smp, const char* end, int S, int pl, int nf, const int* kinds, const uint32_t* m32,
                   const uint8_t* filtered, int n_filters, const char* const* names, const double* const* values,
                   OutBuf& o) {
@@ -2370,6 +2373,7 @@ bool fast_samples(const char* smp, const char* end, int S, int pl, int nf, const
     }
     const char* p = smp;
     char tmp[48];
+    bool has_filter = false;
     for (int s = 0; s < S; ++s) {
         if (p > end) return false;
         const char* se = find_ch(p, end, '\t');
@@ -2389,6 +2393,11 @@ bool fast_samples(const char* smp, const char* end, int S, int pl, int nf, const
                 else q = te + 1;
             }
             const int kind = kinds[f];
+            if (kind == -2) {                              // the record's own FORMAT/FILTER field: replaced in place
+                put_callfilter(o, m32[s], n_filters, names, values, s);
+                has_filter = true;
+                continue;
+            }
             if (flt) {
                 // the reference nulls the call: every allele missing and unphased, every other field missing; what the
                 // token held only matters for the shape of a vector field (checked on the calls that are kept)
@@ -2505,8 +2514,10 @@ bool fast_samples(const char* smp, const char* end, int S, int pl, int nf, const
             }
         }
         if (!exhausted) return false;                       // more tokens than FORMAT keys
-        o.put(':');
-        put_callfilter(o, m32[s], n_filters, names, values, s);
+        if (!has_filter) {
+            o.put(':');
+            put_callfilter(o, m32[s], n_filters, names, values, s);
+        }
         if (se == end) {
             if (s != S - 1) return false;
             p = end + 1;
@@ -2705,7 +2716,18 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
                     }
                     head_store.push_back('\t');
                     head_store.append(line + fo[8], (size_t)(fo[9] - 1 - fo[8]));
-                    head_store.append(":FILTER");
+                    {   // FORMAT + ':FILTER' -- unless the record carries the key already (a second dumpSTR round)
+                        bool has = false;
+                        const char* fb = line + fo[8];
+                        const char* fe2 = line + fo[9] - 1;
+                        while (fb <= fe2) {
+                            const char* c = find_ch(fb, fe2, ':');
+                            if (c - fb == 6 && memcmp(fb, "FILTER", 6) == 0) has = true;
+                            if (c >= fe2) break;
+                            fb = c + 1;
+                        }
+                        if (!has) head_store.append(":FILTER");
+                    }
                     head = head_store.data();
                     hl = head_store.size();
                 } else {
@@ -2721,7 +2743,7 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
             const char* f = line + fo[8];
             const char* fe = line + fo[9] - 1;
             dec.clear();
-            int gt_idx = -1;
+            int gt_idx = -1, filter_idx = -1;
             bool ok = true;
             for (const char* a = f; a <= fe;) {
                 const char* c = find_ch(a, fe, ':');
@@ -2731,7 +2753,10 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
                     gt_idx = (int)dec.size();
                     kind = -1;
                 } else if (kl == 6 && memcmp(a, "FILTER", 6) == 0) {
-                    ok = false;              // a second dumpSTR round: the per-record path knows what to do
+                    // a second dumpSTR round: the field's values are replaced where they stand (Variant.set_format of
+                    // an existing key, dumpSTR.py:648-683), nothing is appended
+                    if (filter_idx >= 0 || !ext) ok = false;
+                    filter_idx = (int)dec.size();
                 } else {
                     for (int t = 0; t < in->n_format_keys; ++t)
                         if (strlen(in->format_keys[t]) == kl && memcmp(in->format_keys[t], a, kl) == 0) {
@@ -2766,7 +2791,7 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
             if (fast_ok) {
                 // the span transducer first (fast_samples): no typed arrays at all
                 kinds.resize((size_t)nf);
-                for (int i = 0; i < nf; ++i) kinds[(size_t)i] = dec[(size_t)i].kind;
+                for (int i = 0; i < nf; ++i) kinds[(size_t)i] = i == filter_idx ? -2 : dec[(size_t)i].kind;
                 int64_t cfw = 8;
                 for (int k = 0; k < in->n_filters; ++k) cfw += (int64_t)strlen(names[(size_t)k]) + 26;
                 const int64_t need = smp_len * 2 + (int64_t)S * (cfw + 4 * (pl + 1) + 2 * nf) + 64;
@@ -2831,7 +2856,9 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
             int64_t need = 0;
             for (int i = 0; i < nf; ++i) {
                 const trk_vcf_decode& d = dec[(size_t)i];
-                if (d.kind < 0) {
+                if (i == filter_idx) {
+                    cols.push_back({TRK_VCF_COL_CALLFILTER, 1, 0, 0, &cf});
+                } else if (d.kind < 0) {
                     cols.push_back({TRK_VCF_COL_GT, pl + 1, 0, 0, gtrow.data()});
                     need += (int64_t)S * (7 * (pl + 1) + 1);
                 } else if (d.kind == TRK_VCF_COL_UCS4) {
@@ -2842,7 +2869,7 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
                     need += (int64_t)S * (17 * d.ncol + 1);
                 }
             }
-            cols.push_back({TRK_VCF_COL_CALLFILTER, 1, 0, 0, &cf});
+            if (filter_idx < 0) cols.push_back({TRK_VCF_COL_CALLFILTER, 1, 0, 0, &cf});
             int64_t cfw = 8;
             for (int k = 0; k < in->n_filters; ++k) cfw += (int64_t)strlen(names[(size_t)k]) + 26;
             need += (int64_t)S * cfw;

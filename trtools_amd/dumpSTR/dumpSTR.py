@@ -630,7 +630,8 @@ class _Run:
             else:
                 upd += [('HET', -1), ('HWEP', -1), ('AC', 0 if n_alt == 0 else ','.join(['0'] * n_alt)), ('REFAC', 0)]
             f[7] = vcfio.rewrite_info(self.invcf, f[7], upd)
-            f[8] = f[8] + ':FILTER'
+            if 'FILTER' not in f[8].split(':'):
+                f[8] = f[8] + ':FILTER'
             return '\t'.join(f)
 
         heads, native = None, None
