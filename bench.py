@@ -142,6 +142,10 @@ class Workload:
         # (trk_dev_alloc_pair: on this part the pass's two write streams run on one of two levels depending on where the
         # two planes landed; at most two spare planes during the search, TRK_PLACE_OUTPUTS=0: plain allocations)
         self.placement = None
+        # (the placement classes are regions of the device's memory the driver fills in turn: a process whose first
+        # 50 GB are ONE class -- one in four on this pool, profiles/r04_notes.md section 4 -- needs a long step to reach
+        # another; the search's time and transient bytes are in the line: roofline.placement_*)
+        os.environ.setdefault('TRK_PLACE_JUMP_GB', '16,64,150')
         co0 = eng.alloc_call_out(b, len(self.filters))
         gt_out, mask = co0.gt_out, co0.filter_mask
         for x in (co0.sample_counters, co0.sample_totaldp, co0.sample_dp_missing, co0.error, co0.sample_totaldp_f64):

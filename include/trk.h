@@ -289,8 +289,8 @@ int trk_permute_columns(trk_ctx* ctx, const int16_t* src, int16_t* dst, const in
  * stream over (first, candidate) -- ~3 launches, 1-2 ms each at 4 GB planes -- and stops at the first pair that is
  * clearly fast (>= 6 % faster than another candidate, or >= TRK_PAIR_FAST_TBPS of write rate); the best pair is
  * returned, the other candidates freed.  When every neighbour is slow the search steps ahead: the spares are freed, a
- * spacer of TRK_PLACE_JUMP_GB (16) GB is allocated -- never touched --, one candidate is taken behind it, the spacer
- * freed (at most two such jumps; transient = spacer + one plane, reported in peak_extra_bytes).  max_spare = FRESH planes that may exist beyond the two returned (0: plain
+ * spacer is allocated -- never touched --, one candidate is taken behind it, the spacer freed (TRK_PLACE_JUMP_GB: the
+ * spacer sizes, default two jumps of 16 GB; transient = spacer + one plane, reported in peak_extra_bytes).  max_spare = FRESH planes that may exist beyond the two returned (0: plain
  * allocation + one probe; trk_call_filters' callers use 2): the transient never exceeds max_spare x bytes_each.
  * Both planes are plain device allocations (trk_dev_free); their contents are undefined. */
 #define TRK_PAIR_MAX_PROBES 8
@@ -301,7 +301,7 @@ typedef struct {
     float probe_ms[TRK_PAIR_MAX_PROBES];  /* write-only probe of (a, candidate k)                           */
     float kept_ms;                 /* the kept pair's                                                        */
     int32_t have_a, have_b;        /* index in have[] of the plane returned as *a / *b, -1: a fresh allocation */
-    int32_t n_jumps;               /* candidates taken behind a spacer (TRK_PLACE_JUMP_GB, default 16 GB, at most 2)  */
+    int32_t n_jumps;               /* candidates taken behind a spacer (TRK_PLACE_JUMP_GB: sizes in GB, default "16,16") */
     double seconds;                /* host time the call took (allocations + probes)                        */
     uint64_t peak_extra_bytes;     /* freshly allocated beyond the two returned planes, at the peak         */
 } trk_pair_info;

@@ -458,7 +458,7 @@ def test_placed_output_planes_hold_the_same_results(eng):
     Engine.last_placement = None
     out = eng.alloc_call_out(sb.batch, len(filters))
     seen = Engine.last_placement
-    assert seen and 1 <= len(seen['probe_ms']) <= 5 and seen['kept_ms'] == min(seen['probe_ms'])
+    assert seen and 1 <= len(seen["probe_ms"]) <= 7 and seen['kept_ms'] == min(seen['probe_ms'])
     assert seen['peak_extra_bytes'] <= max(2 * seen['plane_bytes'], (16 << 30) + seen['plane_bytes']) and seen['seconds'] < 5.0
     assert len(eng._live) - live_before == 7          # the seven arrays of one CallResult: the other candidates are gone
     tuned = eng.call_filters(sb.batch, planes, filters, dp_plane=0, out=out)

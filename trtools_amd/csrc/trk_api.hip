@@ -940,10 +940,22 @@ int trk_dev_alloc_pair(trk_ctx* ctx, size_t bytes_each, int64_t n_loci, int64_t 
     float ms[TRK_PAIR_MAX_PROBES] = {};
     int n = 0, best = -1, n_fresh = 0, n_jumps = 0;
     const int fresh_cap = 1 + max_spare;
-    // TRK_PLACE_JUMP_GB (default 16, 0: no jumps): how far a jump steps; at most two of them
-    size_t jump_bytes = (size_t)16 << 30, peak_jump = 0;
-    if (const char* ev = getenv("TRK_PLACE_JUMP_GB")) jump_bytes = (size_t)(atof(ev) > 0 ? atof(ev) * 1073741824.0 : 0);
-    const int max_jumps = 2;
+    // TRK_PLACE_JUMP_GB: the spacer sizes of the jumps, a comma-separated list (default "16,16"; "0": no jumps; at
+    // most four).  The classes are regions of the device's memory that the driver fills in turn (r04_notes section 4):
+    // a process whose first 50 GB are one class needs a long step -- bench.py asks for "16,64,150" and reports what the
+    // search took.
+    size_t jumps[4] = {(size_t)16 << 30, (size_t)16 << 30, 0, 0}, peak_jump = 0;
+    int max_jumps = 2;
+    if (const char* ev = getenv("TRK_PLACE_JUMP_GB")) {
+        max_jumps = 0;
+        for (const char* q = ev; *q && max_jumps < 4;) {
+            const double gb = atof(q);
+            if (gb > 0) jumps[max_jumps++] = (size_t)(gb * 1073741824.0);
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+    }
+    size_t jump_bytes = max_jumps > 0 ? jumps[0] : 0;
     const double gbytes = 2.0 * (double)n_loci * (double)n_samples * 4.0 * 1e-9;
     int rc = TRK_OK;
     while (n < TRK_PAIR_MAX_PROBES) {
@@ -968,6 +980,7 @@ int trk_dev_alloc_pair(trk_ctx* ctx, size_t bytes_each, int64_t n_loci, int64_t 
                     (void)hipFree(cand[k].p);
                     cand[k].p = nullptr;
                 }
+            jump_bytes = jumps[n_jumps];
             void* spacer = nullptr;
             if (hipMalloc(&spacer, jump_bytes) != hipSuccess) {
                 (void)hipGetLastError();
