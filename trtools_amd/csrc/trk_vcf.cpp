@@ -2896,10 +2896,13 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
     if (in->n_threads <= 0)
         if (const char* e = getenv("TRK_FMT_THREADS")) want = std::max(1, atoi(e));    // formatter threads (default 32)
     const int nt = std::max(1, std::min({want, 128, n}));
+    const bool timing = getenv("TRK_FMT_TIMING") != nullptr;
+    const auto tf0 = std::chrono::steady_clock::now();
     std::vector<std::thread> th;
     for (int t = 1; t < nt; ++t) th.emplace_back(runner);
     runner();
     for (auto& t : th) t.join();
+    const auto tf1 = std::chrono::steady_clock::now();
     if (bad.load() != INT32_MAX) {
         if (err_record) *err_record = bad.load();
         return INT64_MIN + 1;
@@ -2925,6 +2928,10 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
         copier();
         for (auto& t : tc) t.join();
     }
+    if (timing)
+        fprintf(stderr, "[trk_vcf] %d records written: format %.1f ms, gather %.1f ms, %d threads, %.0f MB\n", n,
+                std::chrono::duration<double, std::milli>(tf1 - tf0).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf1).count(), nt, total * 1e-6);
     return total;
 }
 
