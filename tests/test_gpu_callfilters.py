@@ -465,3 +465,54 @@ def test_placed_output_planes_hold_the_same_results(eng):
     assert np.array_equal(tuned.gt_out.get(), plain.gt_out.get())
     assert np.array_equal(tuned.filter_mask.get(), plain.filter_mask.get())
     assert np.array_equal(tuned.sample_counters.get(), plain.sample_counters.get())
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_streaming_kernel_equals_the_per_call_kernel_on_random_filter_sets(eng, seed):
+    """k_call_filter_v4 (round 4: static compare types, LT / GT folded into the operands, filters reordered by plane and
+    type, queued delta updates) against the per-call kernel (TRK_CF_GENERIC=1, pinned to the oracle elsewhere) on filter
+    sets it has to get right: 1-6 filters over two integer and two float planes in any order, LT / GT / called-only LT,
+    fractional, negative and extreme thresholds, missing values and NaNs, with and without the delta outputs."""
+    import os
+    from trtools_amd import _lib as L
+    from trtools_amd.synth import SynthBatch
+    rng = np.random.default_rng(1000 + seed)
+    n_loci, S = int(rng.integers(40, 400)), int(rng.choice([256, 1000, 1024, 2052]))
+    sb = SynthBatch(eng, n_loci, S, seed=50 + seed, planes=('dp', 'q'))
+    dp = sb.dev['dp'].get()
+    i2 = rng.integers(-5, 60, size=(n_loci, S)).astype(np.int32)
+    i2[rng.random((n_loci, S)) < 0.04] = -2147483648
+    f2 = (rng.normal(size=(n_loci, S)) * 3).astype(np.float32)
+    f2[rng.random((n_loci, S)) < 0.04] = np.nan
+    f2[rng.random((n_loci, S)) < 0.01] = -0.0
+    planes = [sb.dev['dp'], sb.dev['q'], eng.upload(i2), eng.upload(f2)]
+    thr_int = [0.0, 10.0, 10.5, -3.0, 54.999, 2147483000.0, -2147483000.0, 30.0]
+    thr_flt = [0.9, 0.0, -0.0, 1.0, -1.5, 0.3333333, 1e30, -1e30]
+    nf = int(rng.integers(1, 7))
+    filters = []
+    for _ in range(nf):
+        p = int(rng.integers(0, 4))
+        op = int(rng.choice([L.F_LT, L.F_GT, L.F_CALLED_LT]))
+        filters.append(dict(op=op, plane_a=p, thr=float(rng.choice(thr_flt if p in (1, 3) else thr_int))))
+    use_dp = bool(rng.integers(0, 2)) or np.any(dp < 0) is False
+    outs = []
+    for generic in (False, True):
+        if generic:
+            os.environ['TRK_CF_GENERIC'] = '1'
+        try:
+            st = eng.locus_stats(sb.batch, count_only=True) if seed % 3 else None
+            res = eng.call_filters(sb.batch, planes, filters, dp_plane=0 if use_dp else -1,
+                                   out=eng.alloc_call_out(sb.batch, nf, place=False), delta_stats=st)
+            outs.append((res.gt_out.get(), res.filter_mask.get(), res.sample_counters.get(), res.sample_totaldp.get(),
+                         res.sample_dp_missing.get(), res.error.get()[0] != 0,
+                         None if st is None else (st.allele_count.get(), st.locus_int.get()[..., :6])))
+        finally:
+            os.environ.pop('TRK_CF_GENERIC', None)
+    a, b = outs
+    assert a[5] == b[5]
+    if a[5]:
+        return                      # a negative depth on a passing call: both kernels report it, outputs are void
+    for x, y, what in zip(a[:5], b[:5], ('gt_out', 'mask', 'counters', 'totaldp', 'dp_missing')):
+        assert np.array_equal(x, y), (what, filters)
+    if a[6] is not None:
+        assert np.array_equal(a[6][0], b[6][0]) and np.array_equal(a[6][1], b[6][1]), filters
