@@ -172,8 +172,6 @@ class Workload:
         self._pending = None
         self.overlap = overlap
         self.pipeline_count = pipeline_count
-        # TRK_BENCH_SINGLE_READ=0: the round-3 step (count pass, then the call filters with the delta outputs)
-        self.single_read = os.environ.get('TRK_BENCH_SINGLE_READ', '0') != '0'
         # TRK_BENCH_COMM=host (rehearsal of the N > 1 control flow with several ranks on ONE device, where RCCL
         # refuses to build a communicator): the step's exchange goes through host copies over the socket group
         self.host_group = host_group
@@ -202,26 +200,6 @@ class Workload:
         b = self.sb.batch
         out = self.call_outs[i]
         q1, q2, qc = (1, 2, 3 if self.pipeline_count else 0) if self.overlap else (0, 0, 0)
-        if self.single_read:
-            # Round 4: ONE read of the genotype tensor per step.  The call-filter pass counts the unfiltered genotypes
-            # (statSTR's counts, stats_a) beside the masked ones (dumpSTR's, stats_b): trk_call_out.count_*.  statSTR's
-            # finaliser of this step and dumpSTR's tail of the previous one run beside the pass on queues 2 and 1.
-            with eng.on_queue(q1):
-                self._tail()                                                       # dumpSTR tail of the previous step
-            eng.event_wait(self.EV_TAIL + i)
-            eng.event_wait(self.EV_FINA + i)
-            self.sums_[i].zero()
-            eng.call_filters(b, self.planes, self.filters, dp_plane=0, out=out, delta_stats=self.stats_b[i],
-                             count_stats=self.stats_a[i])
-            eng.event_record(self.EV_CF + i)
-            with eng.on_queue(q2):
-                eng.event_wait(self.EV_CF + i)
-                eng.locus_finalize(b, self.stats_a[i])                             # statSTR: 11 statistics per locus
-                eng.event_record(self.EV_FINA + i)
-            self._pending = i
-            if not self.overlap:
-                self._tail()
-            return
         with eng.on_queue(qc):
             eng.event_wait(self.EV_TAIL + i)       # tail(n - NB) has consumed sums / stats_b of this buffer set
             eng.event_wait(self.EV_FINA + i)       # fin_a(n - NB) has consumed stats_a of this buffer set

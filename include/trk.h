@@ -362,15 +362,6 @@ typedef struct {
                                    filtered call's genotype is '.') asks for this and neither gt_out nor filter_mask:
                                    12 B read + 1 B written per call instead of 12 + 8 (the per-sample counters and the
                                    delta outputs are unchanged).  NULL, or more than 7 filters: not written.        */
-    /* Round 4, optional (both or neither; they need the delta outputs): the SINGLE-READ step.  When set, the caller has NOT
-     * counted the batch: the call zeroes count_* and delta_*, counts the unfiltered genotypes into count_allele_count
-     * [sumA] / count_locus_int [L, TRK_LI_COLS] (what trk_locus_stats(TRK_STATS_COUNT_ONLY) writes for group 0) and
-     * leaves the counts of gt_out in delta_* -- from the one pass over the genotype tensor that the filters make anyway
-     * (statSTR.py:575-639 and dumpSTR.py:1270-1338 read a record once).  count_* may equal delta_*: only the masked
-     * genotypes' counts are wanted (dumpSTR alone).  Filter sets or shapes the streaming kernel does not take are
-     * counted by the count kernel first, inside the same call: the outputs are the same either way.                */
-    int32_t* count_allele_count;
-    int32_t* count_locus_int;
 } trk_call_out;
 #define TRK_MASK8_NOCALL 0x80u
 

@@ -516,111 +516,3 @@ def test_streaming_kernel_equals_the_per_call_kernel_on_random_filter_sets(eng, 
         assert np.array_equal(x, y), (what, filters)
     if a[6] is not None:
         assert np.array_equal(a[6][0], b[6][0]) and np.array_equal(a[6][1], b[6][1]), filters
-
-
-def _single_read_case(eng, seed):
-    """A diploid batch that exercises every branch of the count: duplicated length classes, a few low-ploidy loci
-    (second slot absent), half calls, no-calls, allele indices outside the locus' table, padding samples."""
-    from trtools_amd.synth import pack_alleles
-    rng = np.random.default_rng(7000 + seed)
-    Lc = int(rng.integers(30, 500))
-    S = int(rng.choice([256, 1000, 1024, 2052]))
-    n_pad = int(rng.choice([0, 0, 4, 28]))
-    nal = rng.integers(1, [4, 12, 40, 64][seed % 4] + 1, size=Lc)
-    lens, strs = [], []
-    for l in range(Lc):
-        n = int(nal[l])
-        # lengths with repeats: several alleles of one length (distinct sequences) share a length class
-        ln = np.round(rng.integers(4, 4 + max(2, n // 2 + 1), size=n) * (1.0 if l % 3 else 0.5), 1)
-        lens.append([float(x) for x in ln])
-        strs.append(['A' * (3 + i) + 'C' * (i % 3) for i in range(n)])
-    off, lc, sc, cv = pack_alleles(lens, strs)
-    gt = np.empty((Lc, S + n_pad, 2), np.int16)
-    for l in range(Lc):
-        gt[l] = rng.integers(0, int(nal[l]), size=(S + n_pad, 2))
-    r = rng.random((Lc, S + n_pad))
-    gt[r < 0.05] = -1                                   # no-calls
-    gt[(r >= 0.05) & (r < 0.07), 1] = -1                # half calls
-    gt[(r >= 0.07) & (r < 0.075), 0] = 200              # indices outside the table
-    lp = None
-    if seed % 2:
-        lp = np.full(Lc, 2, np.uint8)
-        lp[rng.random(Lc) < 0.2] = 1
-        gt[lp == 1, :, 1] = -2
-    if n_pad:
-        gt[:, S:, :] = -1
-    dp = rng.integers(0, 60, size=(Lc, S + n_pad)).astype(np.int32)
-    dp[rng.random((Lc, S + n_pad)) < 0.03] = INT_MIN
-    q = rng.random((Lc, S + n_pad)).astype(np.float32)
-    q[rng.random((Lc, S + n_pad)) < 0.03] = np.nan
-    if n_pad:
-        dp[:, S:] = INT_MIN
-        q[:, S:] = np.nan
-    b = eng.make_batch(gt, off, lc, sc, cv, locus_ploidy=lp, n_pad=n_pad)
-    return b, [eng.upload(dp), eng.upload(q)], Lc
-
-
-@pytest.mark.parametrize("seed", range(8))
-@pytest.mark.parametrize("same", [False, True])
-def test_single_read_step_equals_count_then_filter(eng, seed, same):
-    """trk_call_out.count_*: the call-filter pass that also counts the unfiltered genotypes (k_call_filter_v4<...,COUNT>,
-    one read of the genotype tensor for dumpSTR's and statSTR's counts) leaves, bit for bit, what the count kernel
-    followed by the call-filter pass leaves: counts(GT) in count_*, counts(GT') in delta_*, and every other output.
-    ``same``: count_* == delta_* (dumpSTR alone: only the masked genotypes' counts are kept)."""
-    from trtools_amd import _lib as L
-    b, planes, Lc = _single_read_case(eng, seed)
-    sets = [[dict(op=L.F_LT, plane_a=0, thr=20), dict(op=L.F_GT, plane_a=0, thr=50), dict(op=L.F_LT, plane_a=1, thr=0.9)],
-            [dict(op=L.F_LT, plane_a=0, thr=25)],
-            [dict(op=L.F_LT, plane_a=1, thr=0.5), dict(op=L.F_CALLED_LT, plane_a=0, thr=10)],
-            [dict(op=L.F_GT, plane_a=0, thr=30.5), dict(op=L.F_LT, plane_a=0, thr=5)]]
-    filters = sets[seed % len(sets)]
-    nf = len(filters)
-    # reference: count, then filter with the delta outputs
-    st_gt = eng.locus_stats(b, count_only=True)
-    st_ref = eng.locus_stats(b, count_only=True)
-    ref = eng.call_filters(b, planes, filters, dp_plane=0, out=eng.alloc_call_out(b, nf, place=False), delta_stats=st_ref)
-    # single read
-    st_cnt = eng.alloc_stats(b)
-    st_dl = st_cnt if same else eng.alloc_stats(b)
-    for st in {id(st_cnt): st_cnt, id(st_dl): st_dl}.values():      # stale contents must not leak into the result
-        for arr in (st.allele_count, st.locus_int):
-            eng._chk(eng.lib.trk_memset(eng.ctx, arr.ptr, 0x5a, arr.nbytes))
-    res = eng.call_filters(b, planes, filters, dp_plane=0, out=eng.alloc_call_out(b, nf, place=False), delta_stats=st_dl,
-                           count_stats=st_cnt)
-    if res.error.get()[0] or ref.error.get()[0]:
-        assert res.error.get()[0] == ref.error.get()[0]
-    for what in ('gt_out', 'filter_mask', 'sample_counters', 'sample_totaldp', 'sample_dp_missing'):
-        assert np.array_equal(getattr(res, what).get(), getattr(ref, what).get()), what
-    assert np.array_equal(st_dl.allele_count.get(), st_ref.allele_count.get())
-    assert np.array_equal(st_dl.locus_int.get(), st_ref.locus_int.get())
-    if not same:
-        assert np.array_equal(st_cnt.allele_count.get(), st_gt.allele_count.get())
-        assert np.array_equal(st_cnt.locus_int.get(), st_gt.locus_int.get())
-    # and the statistics that follow are those of a recount of gt_out
-    # (N_BAD aside: a filtered call's out-of-range index stays counted -- the reference raises IndexError on such a
-    # record, dumpSTR.py never gets as far as masking it; every caller treats N_BAD > 0 as that error)
-    eng.locus_finalize(b, st_dl)
-    rec = eng.locus_stats(b.with_gt(res.gt_out))
-    cols = [c for c in range(L.TRK_LI_COLS) if c != L.LI_N_BAD]
-    assert np.array_equal(st_dl.locus_int.get()[..., cols], rec.locus_int.get()[..., cols])
-    assert np.array_equal(np.nan_to_num(st_dl.locus_f64.get(), nan=-7.0), np.nan_to_num(rec.locus_f64.get(), nan=-7.0))
-
-
-def test_single_read_step_outside_the_streaming_kernel(eng):
-    """count_* with shapes the streaming kernel declines (odd cohort, sample groups, a ratio filter): the call counts
-    with the count kernel first; the outputs are the same."""
-    from trtools_amd import _lib as L
-    from trtools_amd.synth import SynthBatch
-    sb = SynthBatch(eng, 120, 1003, seed=77)
-    filters = [dict(op=L.F_LT, plane_a=0, thr=25), dict(op=L.F_LT, plane_a=1, thr=0.95)]
-    planes = [sb.dev['dp'], sb.dev['q']]
-    st_gt = eng.locus_stats(sb.batch, count_only=True)
-    st_ref = eng.locus_stats(sb.batch, count_only=True)
-    ref = eng.call_filters(sb.batch, planes, filters, dp_plane=0, delta_stats=st_ref)
-    st_cnt, st_dl = eng.alloc_stats(sb.batch), eng.alloc_stats(sb.batch)
-    res = eng.call_filters(sb.batch, planes, filters, dp_plane=0, delta_stats=st_dl, count_stats=st_cnt)
-    assert np.array_equal(res.gt_out.get(), ref.gt_out.get())
-    assert np.array_equal(st_cnt.allele_count.get(), st_gt.allele_count.get())
-    assert np.array_equal(st_cnt.locus_int.get(), st_gt.locus_int.get())
-    assert np.array_equal(st_dl.allele_count.get(), st_ref.allele_count.get())
-    assert np.array_equal(st_dl.locus_int.get(), st_ref.locus_int.get())

@@ -73,8 +73,7 @@ class CallOut(C.Structure):
                 ('sample_counters', C.c_void_p), ('sample_totaldp', C.c_void_p),
                 ('sample_dp_missing', C.c_void_p), ('error', C.c_void_p),
                 ('delta_allele_count', C.c_void_p), ('delta_locus_int', C.c_void_p),
-                ('sample_totaldp_f64', C.c_void_p), ('filter_mask8', C.c_void_p),
-                ('count_allele_count', C.c_void_p), ('count_locus_int', C.c_void_p)]
+                ('sample_totaldp_f64', C.c_void_p), ('filter_mask8', C.c_void_p)]
 
 
 class LocusFilterSpec(C.Structure):

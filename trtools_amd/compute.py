@@ -150,11 +150,9 @@ class DeviceCompute:
         # counts of the unfiltered genotypes, corrected by the call-filter kernel for every call it
         # masks (dumpSTR.py:721-774 rebuilds the record; here no second pass over the tensor), then
         # the finaliser
-        # (round 4: the call-filter pass counts too -- one read of the genotype tensor, trk_call_out.count_*; only the
-        # masked genotypes' counts are kept here, so count_* == delta_*)
-        st = eng.alloc_stats(b)
+        st = eng.locus_stats(b, nalleles_thresh=nalleles_thresh, count_only=True)
         cout = eng.alloc_call_out(b, len(filters), want_gt=not compact, want_mask=not compact, want_mask8=compact)
-        call = eng.call_filters(b, dplanes, filters, dp_plane=dp_plane, out=cout, delta_stats=st, count_stats=st)
+        call = eng.call_filters(b, dplanes, filters, dp_plane=dp_plane, out=cout, delta_stats=st)
         eng.locus_finalize(b, st, nalleles_thresh=nalleles_thresh)
         ext = None
         spec = dict(locus_spec)

@@ -2121,8 +2121,7 @@ constexpr int CF_LUT_UNROLL = 8;
 template <bool STORE = true>   // STORE = false: only linfo (k_call_filter_v4 reads the classes of its rare duplicate-class
                                 // loci from global memory when it drains its queue; lutb is not touched)
 __device__ __forceinline__ void cf_build_lut(const trk_batch& b, int l_begin, int nl, int nal, int tid,
-                                             uint32_t* lutb, int32_t* linfo, int lstride = 0) {
-    if (lstride == 0) lstride = nal;      // words between two loci's LUT rows
+                                             uint32_t* lutb, int32_t* linfo) {
     for (int li = tid; li < nl; li += CF_THREADS) {
         const int o0 = b.allele_off[l_begin + li], o1 = b.allele_off[l_begin + li + 1];
         linfo[CF_LINFO * li] = o1 - o0;
@@ -2151,7 +2150,7 @@ __device__ __forceinline__ void cf_build_lut(const trk_batch& b, int l_begin, in
                 // uniform over the lane group, and a group never straddles a wave: the shuffles below are safe
                 if (li >= nl) break;
                 const int A = linfo[CF_LINFO * li];
-                if (STORE && q < nal) lutb[li * lstride + q] = cls[u];
+                if (STORE && q < nal) lutb[li * nal + q] = cls[u];
                 u16x2 m = __builtin_bit_cast(u16x2, cls[u]);
                 for (int o = gsz >> 1; o > 0; o >>= 1) {
                     const uint32_t t = (uint32_t)__shfl_xor((int)__builtin_bit_cast(uint32_t, m), o, WAVE);
@@ -2168,7 +2167,7 @@ __device__ __forceinline__ void cf_build_lut(const trk_batch& b, int l_begin, in
             const int li = i / nal, q = i - li * nal;
             if (q >= linfo[CF_LINFO * li]) continue;
             const int e = linfo[CF_LINFO * li + 2] + q;
-            lutb[li * lstride + q] = (uint32_t)b.len_class[e] | ((uint32_t)b.str_class[e] << 16);
+            lutb[i] = (uint32_t)b.len_class[e] | ((uint32_t)b.str_class[e] << 16);
         }
         __syncthreads();
     }
@@ -2178,7 +2177,7 @@ __device__ __forceinline__ void cf_build_lut(const trk_batch& b, int l_begin, in
         bool top_l = false, top_s = false;
         for (int q = 0; q < A; ++q) {
             const int e = linfo[CF_LINFO * li + 2] + q;
-            const uint32_t v = STORE ? lutb[li * lstride + q] : ((uint32_t)b.len_class[e] | ((uint32_t)b.str_class[e] << 16));
+            const uint32_t v = STORE ? lutb[li * nal + q] : ((uint32_t)b.len_class[e] | ((uint32_t)b.str_class[e] << 16));
             top_l |= (int)(v & 0xffffu) == A - 1;
             top_s |= (int)(v >> 16) == A - 1;
         }
@@ -2882,33 +2881,7 @@ __device__ __forceinline__ void v4_drain_one(uint32_t w, uint32_t li, uint32_t* 
     if (w1) atomicAdd(&tab[nal + V2_W1], w1);
 }
 
-// COUNT (round 4, the single-read step): the pass also counts the UNFILTERED genotypes -- what k_locus_count_v2 reads the
-// tensor a second time for.  Every call slot adds its two haplotypes to the block's table htab [loci][bins][K = 8 copies]
-// with two LDS atomics, as the count kernel's cell does (v2m_cell: sentinels mapped to bins 0 / 1, indices outside the
-// locus's alleles to bin A + 2, byte addresses straight from the packed 16-bit bins) -- but straight into the BLOCK's
-// table, so nothing is folded per locus (the first form of this path kept a histogram of the current locus per wave and
-// folded it every iteration: 525 vector + 430 scalar instructions per wave and locus, 10.6 ms at 100k x 10k against
-// 3.5 without the count).  The row predicates ride on the same atomics: the first one adds 1 | 1 << 12 when the two
-// bins are equal, so a bin's word is {haplotypes : 12, equal pairs : 20} (a copy of a bin sees at most 256 haplotypes
-// of a block's 1024 samples) -- bins 0 and 1 give the (-2,-2) and (-1,-1) pairs, the sum over the bins the pairs equal
-// by index.  What is left are the pairs of one -1 and one -2 (a popcount per slot, added by the wave's first lane when
-// there are any) and, at a locus whose alleles share a length or sequence class, the pairs equal by class (two LUT
-// reads per slot from the block's LUT by bin, popcounts).  At the end of the block every bin's copies are folded and
-// every non-zero entry goes to count_* with one global atomic; the delta table's entries are subtracted from delta_*
-// as without COUNT, and when the two are different arrays k_add_counts adds count_* to delta_* after the pass.
-// The constants of a row (N_CALLED starts at S, N_SAMPLES) are added by the workgroup of column tile 0.
-enum { V4R_M2 = 0, V4R_C00, V4R_M1, V4R_C11, V4R_BAD, V4R_EQ, V4R_MIX, V4R_HLHS, V4R_N };
-constexpr int V4_HK = 8, V4_HKSHIFT = 3;     // copies per bin
-// sum of the two 16-bit halves (bins): 1 <=> one haplotype -1, the other -2
-__device__ __forceinline__ uint32_t halves_sum(uint32_t t) {
-    uint32_t r;
-    asm("v_sad_u16 %0, %1, 0, 0" : "=v"(r) : "v"(t));
-    return r;
-}
-__global__ __launch_bounds__(256) void k_add_counts(int32_t* __restrict__ dst, const int32_t* __restrict__ src, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] += src[i];
-}
-template <int NF, int NFLT, bool DELTA, bool RATIO, int ALIAS, bool COUNT = false>
+template <int NF, int NFLT, bool DELTA, bool RATIO, int ALIAS>
 __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
     extern __shared__ uint32_t v2lds[];
     const int tid = threadIdx.x;
@@ -2923,14 +2896,6 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
     // this wave's queue [V4_QCAP] of {genotype word, locus of the block}, behind the tables on an 8-byte boundary
     uint2* queue = reinterpret_cast<uint2*>(v2lds + ((((size_t)a.loci_per_block * (dstride + CF_LINFO)) + 1) & ~(size_t)1)) +
                    (size_t)(tid >> 6) * V4_QCAP;
-    // COUNT: the block's table of the unfiltered genotypes' counts [loci][(bins << 3) + V4R_N], 16-byte aligned, then
-    // the block's class LUT by bin [loci][bins]
-    const int nb = nal + 3;                                   // bins: -2, -1, alleles, out of range
-    const int hstride = (nb << V4_HKSHIFT) + V4R_N;
-    uint32_t* htab = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(reinterpret_cast<uint2*>(v2lds + ((((size_t)a.loci_per_block * (dstride + CF_LINFO)) + 1) & ~(size_t)1)) +
-                                                                               (size_t)(CF_THREADS / WAVE) * V4_QCAP) + 15) & ~(uintptr_t)15);
-    uint32_t* lutc = htab + (size_t)a.loci_per_block * hstride;
-    const uint32_t htab_lane_b = (uint32_t)(uintptr_t)(lds_u32p)htab + 4u * ((uint32_t)tid & (V4_HK - 1));
     uint32_t numcalls[CF_V] = {0, 0, 0, 0}, dpmiss[CF_V] = {0, 0, 0, 0};
     uint32_t fc[NF][CF_V];
     int64_t totaldp[CF_V] = {0, 0, 0, 0};
@@ -2972,20 +2937,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
         const int nl = l_end - l_begin;
         if (DELTA) {
             for (int i = tid; i < nl * dstride; i += CF_THREADS) dtab[i] = 0;
-            if (COUNT) {
-                const u32x4 z4 = {0u, 0u, 0u, 0u};
-                for (int i = tid; i < (nl * hstride) >> 2; i += CF_THREADS) reinterpret_cast<u32x4*>(htab)[i] = z4;
-                cf_build_lut<true>(a.b, l_begin, nl, nal, tid, lutc + 2, linfo, nb);     // allele q at bin q + 2
-                for (int li = tid; li < nl; li += CF_THREADS) {   // sentinel bins: classes no allele has, distinct from each other
-                    uint32_t* lr = lutc + li * nb;
-                    lr[0] = 0xffffffffu;
-                    lr[1] = 0xfffefffeu;
-                    lr[linfo[CF_LINFO * li] + 2] = 0xfffdfffdu;
-                }
-                __syncthreads();
-            } else {
-                cf_build_lut<false>(a.b, l_begin, nl, nal, tid, nullptr, linfo);
-            }
+            cf_build_lut<false>(a.b, l_begin, nl, nal, tid, nullptr, linfo);
         }
         if (live) {
             for (int l = l_begin; l < l_end; ++l) {
@@ -3057,41 +3009,6 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
                         }
                     }
                 }
-                if (COUNT && !(a.dbg & 4)) {
-                    // the four call slots into the block's table of this locus
-                    const uint32_t A = (uint32_t)__builtin_amdgcn_readfirstlane(linfo[CF_LINFO * li]);
-                    const uint32_t amax2 = (A + 2u) * 0x00010001u;
-                    const uint32_t hist_b = htab_lane_b + li * (uint32_t)(hstride * 4);
-                    uint32_t tb[CF_V], n_mix = 0;
-#pragma unroll
-                    for (int j = 0; j < CF_V; ++j) {
-                        const uint32_t w = g[j];   // (a copy: __builtin_bit_cast of the vector ELEMENT read element 0 four times)
-                        const u16x2 u = __builtin_bit_cast(u16x2, w) + (u16x2){2, 2};
-                        const uint32_t t = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(u, __builtin_bit_cast(u16x2, amax2)));
-                        tb[j] = t;
-                        const uint32_t v1 = __builtin_amdgcn_inverse_ballot_w64(halves_equal(t)) ? 0x1001u : 1u;
-                        if (!(a.dbg & 16)) {
-                        __hip_atomic_fetch_add((lds_u32p)(uintptr_t)mad16_lo(t, 4u << V4_HKSHIFT, hist_b), v1, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add((lds_u32p)(uintptr_t)mad16_hi(t, 4u << V4_HKSHIFT, hist_b), 1u, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                        n_mix += (uint32_t)__popcll(__ballot(halves_sum(t) == 1u));
-                    }
-                    uint32_t* racc = htab + li * hstride + (nb << V4_HKSHIFT);
-                    if (n_mix && my_rank == 0) atomicAdd(&racc[V4R_MIX], n_mix);
-                    if (cf_lut_needed(linfo, (int)li)) {   // alleles that share a class: the pairs equal by class
-                        const uint32_t lut_b = (uint32_t)(uintptr_t)(lds_u32p)lutc + li * (uint32_t)(nb * 4);
-                        uint32_t n_hl = 0, n_hs = 0;
-#pragma unroll
-                        for (int j = 0; j < CF_V; ++j) {
-                            const uint32_t x = *(lds_cu32p)(uintptr_t)mad16_lo(tb[j], 4u, lut_b) ^ *(lds_cu32p)(uintptr_t)mad16_hi(tb[j], 4u, lut_b);
-                            n_hl += (uint32_t)__popcll(__ballot((x & 0xffffu) == 0u));
-                            n_hs += (uint32_t)__popcll(__ballot(x < 0x10000u));
-                        }
-                        if (my_rank == 0) atomicAdd(&racc[V4R_HLHS], n_hl | (n_hs << 16));
-                    }
-                }
                 if (a.out.gt_out) __builtin_nontemporal_store(wout, reinterpret_cast<u32x4*>(a.out.gt_out) + c4);
                 if (a.out.filter_mask) __builtin_nontemporal_store(mout, reinterpret_cast<u32x4*>(a.out.filter_mask) + c4);
                 if (a.out.filter_mask8) {   // one byte per call: bit 7 = no-call
@@ -3123,60 +3040,6 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
                     int32_t* li_ = a.out.delta_locus_int + (int64_t)l * TRK_LI_COLS;
                     if (v & 0xffffu) atomicSub(&li_[TRK_LI_N_HOM_LEN], (int)(v & 0xffffu));
                     if (v >> 16) atomicSub(&li_[TRK_LI_N_HOM_STR], (int)(v >> 16));
-                }
-            }
-            if (COUNT && !(a.dbg & 8)) {
-                // the unfiltered counts of this workgroup's 1024 samples: every bin's copies folded, the allele bins one
-                // global atomic per non-zero entry, the row predicates per locus (k_locus_count_v2's formulas, which are
-                // sums over samples; the constants of a row come from column tile 0)
-                const uint32_t rcph = (uint32_t)((0x100000000ull + (uint32_t)nb - 1u) / (uint32_t)nb);
-                for (int i = tid; i < nl * nb; i += CF_THREADS) {
-                    const int li = (int)__umulhi((uint32_t)i, rcph);
-                    const int bin = i - li * nb;
-                    const int A = linfo[CF_LINFO * li];
-                    if (bin > A + 2) continue;
-                    uint32_t* hrow = htab + li * hstride;
-                    const u32x4* hp = reinterpret_cast<const u32x4*>(hrow + (bin << V4_HKSHIFT));
-                    uint32_t cnt = 0, eq = 0;
-#pragma unroll
-                    for (int k = 0; k < V4_HK / 4; ++k) {
-                        const u32x4 h = hp[k];
-                        cnt += ((h.x & 0xfffu) + (h.y & 0xfffu)) + ((h.z & 0xfffu) + (h.w & 0xfffu));
-                        eq += ((h.x >> 12) + (h.y >> 12)) + ((h.z >> 12) + (h.w >> 12));
-                    }
-                    uint32_t* racc = hrow + (nb << V4_HKSHIFT);
-                    if (eq) atomicAdd(&racc[V4R_EQ], eq);
-                    if (bin == 0) {
-                        racc[V4R_M2] = cnt;
-                        racc[V4R_C00] = eq;
-                    } else if (bin == 1) {
-                        racc[V4R_M1] = cnt;
-                        racc[V4R_C11] = eq;
-                    } else if (bin == A + 2) {
-                        racc[V4R_BAD] = cnt;
-                    } else if (cnt) {
-                        atomicAdd(&a.out.count_allele_count[linfo[CF_LINFO * li + 2] + bin - 2], (int)cnt);
-                    }
-                }
-                __syncthreads();
-                for (int li = tid; li < nl; li += CF_THREADS) {
-                    const uint32_t* x = htab + li * hstride + (nb << V4_HKSHIFT);
-                    const int c00 = (int)x[V4R_C00], c11 = (int)x[V4R_C11];
-                    const int miss_rows = (int)x[V4R_M1] - c11;
-                    const int low_rows = (int)x[V4R_M2] - c00 - (int)x[V4R_MIX];
-                    const int hom_idx = (int)x[V4R_EQ] - c11 - c00;
-                    const bool dupl = cf_lut_needed(linfo, li);
-                    const int hl = dupl ? (int)(x[V4R_HLHS] & 0xffffu) - c11 - c00 : hom_idx;
-                    const int hs = dupl ? (int)(x[V4R_HLHS] >> 16) - c11 - c00 : hom_idx;
-                    const int n_called = (bix == 0 ? S : 0) - miss_rows;
-                    const int n_smp = bix == 0 ? S - a.b.n_pad_samples : 0;
-                    int32_t* li_ = a.out.count_locus_int + (int64_t)(l_begin + li) * TRK_LI_COLS;
-                    if (n_called) atomicAdd(&li_[TRK_LI_N_CALLED], n_called);
-                    if (low_rows) atomicAdd(&li_[TRK_LI_N_LOWPLOIDY], low_rows);
-                    if (hl) atomicAdd(&li_[TRK_LI_N_HOM_LEN], hl);
-                    if (hs) atomicAdd(&li_[TRK_LI_N_HOM_STR], hs);
-                    if (x[V4R_BAD]) atomicAdd(&li_[TRK_LI_N_BAD], (int)x[V4R_BAD]);
-                    if (n_smp) atomicAdd(&li_[TRK_LI_N_SAMPLES], n_smp);
                 }
             }
             __syncthreads();   // the table is re-initialised for the next block
@@ -4339,23 +4202,6 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
     if (n_filters > 7) a.out.filter_mask8 = nullptr;
     const int S = b.n_samples, L = b.n_loci;
     if (S == 0 || L == 0) return hipSuccess;
-    // trk_call_out.count_*: the caller has not counted the batch.  The streaming kernel counts inside its own pass where
-    // it can (k_call_filter_v4<..., COUNT>); every other path counts first, here, with the count kernel -- into count_*
-    // and, as the starting point of the delta outputs, into delta_*.
-    const bool want_count = out.count_allele_count != nullptr;
-    if (want_count && (!out.count_locus_int || !out.delta_allele_count || !out.delta_locus_int)) return hipErrorInvalidValue;
-    bool counted = false;
-    auto count_first = [&]() -> hipError_t {
-        if (!want_count || counted) return hipSuccess;
-        counted = true;
-        hipError_t e = launch_locus_count(b, b.max_alleles, out.delta_allele_count, out.delta_locus_int, n_cu, stream, false, nullptr);
-        if (e != hipSuccess || out.count_allele_count == out.delta_allele_count) return e;
-        e = hipMemcpyAsync(out.count_allele_count, out.delta_allele_count, (size_t)b.n_alleles_total * sizeof(int32_t),
-                           hipMemcpyDeviceToDevice, stream);
-        if (e != hipSuccess) return e;
-        return hipMemcpyAsync(out.count_locus_int, out.delta_locus_int, (size_t)L * TRK_LI_COLS * sizeof(int32_t),
-                              hipMemcpyDeviceToDevice, stream);
-    };
     int gx = (S + CF_THREADS * CF_V - 1) / (CF_THREADS * CF_V);
     // enough blocks to fill the chip (>= 8 per CU) while keeping the per-block
     // counter flush (one atomic per sample per counter) small next to the stream
@@ -4586,41 +4432,14 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
                 default: TRK_V4_PICK(6); break;
             }
 #undef TRK_V4_PICK
-            // the single-read step: the instantiations that also count (threshold filters, delta outputs, static types)
-            // (up to 64 alleles a locus: four wave histograms and the block's count table share the LDS with the queues)
-            bool fuse = want_count && delta && !ratio && tflt >= 0 && b.group_bits == nullptr && b.row_stride == 0 &&
-                        b.max_alleles <= 64 &&
-                        (getenv("TRK_CF_FUSE") && atoi(getenv("TRK_CF_FUSE")) != 0);   // opt-in: measured slower (r04_notes section 10)
-            if (fuse) {
-                void (*kc)(V4Args) = nullptr;
-#define TRK_V4_CNT(NFV)                                                                                               \
-    kc = tflt == 0 ? (alias == 3   ? k_call_filter_v4<NFV, 0, true, false, (NFV >= 2 ? 3 : 1), true>                  \
-                      : alias == 1 ? k_call_filter_v4<NFV, 0, true, false, 1, true>                                   \
-                                   : k_call_filter_v4<NFV, 0, true, false, 0, true>)                                  \
-                   : (alias == 3   ? k_call_filter_v4<NFV, 1, true, false, (NFV >= 2 ? 3 : 1), true>                  \
-                      : alias == 1 ? k_call_filter_v4<NFV, 1, true, false, 1, true>                                   \
-                                   : k_call_filter_v4<NFV, 1, true, false, 0, true>)
-                switch (n_filters) {
-                    case 1: TRK_V4_CNT(1); break;
-                    case 2: TRK_V4_CNT(2); break;
-                    case 3: TRK_V4_CNT(3); break;
-                    case 4: TRK_V4_CNT(4); break;
-                    case 5: TRK_V4_CNT(5); break;
-                    default: TRK_V4_CNT(6); break;
-                }
-#undef TRK_V4_CNT
-                k4 = kc;
-            }
             // LDS: the block's delta table + class LUT + locus info, and one queue per wave -- within 32 KiB, so that
             // five workgroups fit a CU
-            // (fused: + the block's count table [bins][8 copies] + row words, and its class LUT by bin, per locus)
-            const size_t nb4 = (size_t)b.max_alleles + 3;
-            const size_t qbytes = delta ? (size_t)(CF_THREADS / WAVE) * V4_QCAP * sizeof(uint2) + (fuse ? 16 : 0) : 0;
-            const size_t per_locus4 = delta ? ((size_t)b.max_alleles + V2_EXTRA + CF_LINFO + (fuse ? (nb4 << V4_HKSHIFT) + V4R_N + nb4 : 0)) * sizeof(uint32_t) : 0;
+            const size_t qbytes = delta ? (size_t)(CF_THREADS / WAVE) * V4_QCAP * sizeof(uint2) : 0;
+            const size_t per_locus4 = delta ? ((size_t)b.max_alleles + V2_EXTRA + CF_LINFO) * sizeof(uint32_t) : 0;
             if (delta) {
                 // (a workgroup's LDS stays well below 160 KiB / 5: at 32 360 bytes the occupancy query still says five
                 // workgroups per CU and four are resident -- a persistent launch then runs a second round)
-                size_t budget = fuse ? 38 * 1024 : 26 * 1024;      // fused: four workgroups per CU (160 KiB / 4)
+                size_t budget = 26 * 1024;
                 if (const char* e = getenv("TRK_CF_LDS_KB")) budget = (size_t)(atoi(e) > 12 ? atoi(e) : 12) * 1024;
                 const int max_lpb = (int)((budget - qbytes - 8) / per_locus4);
                 if (lpb > max_lpb) lpb = max_lpb;
@@ -4632,20 +4451,7 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
                 occ = 4;
             const CfLaunch cl = cf_geometry(L, gx, lpb, n_cu, occ);
             lpb = cl.lpb;
-            const size_t lds4 = delta ? (((size_t)lpb * per_locus4 + 7) & ~(size_t)7) + qbytes + 16 : 0;
-            if (!fuse) {
-                hipError_t ec = count_first();
-                if (ec != hipSuccess) return ec;
-            } else {
-                counted = true;
-                hipError_t ec = hipMemsetAsync(out.delta_allele_count, 0, (size_t)b.n_alleles_total * sizeof(int32_t), stream);
-                if (ec == hipSuccess) ec = hipMemsetAsync(out.delta_locus_int, 0, (size_t)L * TRK_LI_COLS * sizeof(int32_t), stream);
-                if (ec == hipSuccess && out.count_allele_count != out.delta_allele_count) {
-                    ec = hipMemsetAsync(out.count_allele_count, 0, (size_t)b.n_alleles_total * sizeof(int32_t), stream);
-                    if (ec == hipSuccess) ec = hipMemsetAsync(out.count_locus_int, 0, (size_t)L * TRK_LI_COLS * sizeof(int32_t), stream);
-                }
-                if (ec != hipSuccess) return ec;
-            }
+            const size_t lds4 = delta ? (((size_t)lpb * per_locus4 + 7) & ~(size_t)7) + qbytes : 0;
             v.loci_per_block = lpb;
             v.geom = cl.geom;
             gy = cl.geom.n_ranges;
@@ -4660,8 +4466,8 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
                 }
             }
             if (getenv("TRK_CF_VERBOSE"))
-                fprintf(stderr, "k_call_filter_v4<%d,%d,%d,%d,%d%s>: L %d gx %d lpb %d walk %d ranges %d map %d grid %u x %u, lds %zu B, "
-                                "occupancy %d WG/CU\n", n_filters, tflt, (int)delta, (int)ratio, alias, fuse ? ",count" : "", L, gx, lpb, cl.geom.walk,
+                fprintf(stderr, "k_call_filter_v4<%d,%d,%d,%d,%d>: L %d gx %d lpb %d walk %d ranges %d map %d grid %u x %u, lds %zu B, "
+                                "occupancy %d WG/CU\n", n_filters, tflt, (int)delta, (int)ratio, alias, L, gx, lpb, cl.geom.walk,
                         cl.geom.n_ranges, cl.geom.map, cl.grid.x, cl.grid.y, lds4, occ);
             hipLaunchKernelGGL(k4, cl.grid, dim3(CF_THREADS), lds4, stream, v);
             if (v.part16) {
@@ -4672,13 +4478,6 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
                 for (int k = 0; k < n_filters; ++k) fb.bit[k] = v.f[k].bit;
                 hipLaunchKernelGGL(k_cf_reduce, dim3((S / 4 + CFR_QPB - 1) / CFR_QPB), dim3(CFR_NSL * CFR_QPB), 0, stream,
                                    v.part16, v.part64, gy, S, 2 + n_filters, fb, out);
-            }
-            if (fuse && out.count_allele_count != out.delta_allele_count) {
-                // delta_* holds minus what the filtered calls remove: + the counts of the unfiltered genotypes
-                hipLaunchKernelGGL(k_add_counts, dim3(n_cu * 4), dim3(256), 0, stream, out.delta_allele_count,
-                                   out.count_allele_count, (int64_t)b.n_alleles_total);
-                hipLaunchKernelGGL(k_add_counts, dim3(n_cu * 4), dim3(256), 0, stream, out.delta_locus_int,
-                                   out.count_locus_int, (int64_t)L * TRK_LI_COLS);
             }
             return hipGetLastError();
         }
@@ -4828,7 +4627,6 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             if (ws) {
                 g.part16 = static_cast<uint16_t*>(ws);
                 g.part64 = reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + b16);
-                { hipError_t ec = count_first(); if (ec != hipSuccess) return ec; }
                 hipLaunchKernelGGL(kg, cl.grid, dim3(CF_THREADS), delta ? ((((size_t)lpb2 * per_locus) + 7) & ~(size_t)7) + gq : 0, stream, g);
                 hipError_t e1 = hipGetLastError();
                 if (e1 != hipSuccess) return e1;
@@ -4844,7 +4642,6 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
     if (vec) {
         if (out.delta_allele_count && !lds_delta) {
             // no room for an LDS table (huge allele sets): per-call evaluation with global atomics
-            { hipError_t ec = count_first(); if (ec != hipSuccess) return ec; }
             hipLaunchKernelGGL(k_call_filter<false>, dim3(gx, gy), dim3(CF_THREADS), lds, stream, a);
             return hipGetLastError();
         }
@@ -4916,10 +4713,8 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
         }
         a.loci_per_wg = lpw;
         a.loci_per_block = sub;
-        { hipError_t ec = count_first(); if (ec != hipSuccess) return ec; }
         hipLaunchKernelGGL(kfn, dim3(gx, gyf), dim3(CF_THREADS), lds, stream, a);
     } else {
-        { hipError_t ec = count_first(); if (ec != hipSuccess) return ec; }
         hipLaunchKernelGGL(k_call_filter<false>, dim3(gx, gy), dim3(CF_THREADS), lds, stream, a);
     }
     return hipGetLastError();

@@ -253,16 +253,12 @@ class CallResult:
                                 None, None, sample_totaldp_f64.ptr if sample_totaldp_f64 is not None else None,
                                 filter_mask8.ptr if filter_mask8 is not None else None)
 
-    def with_delta(self, stats, count=None):
-        """trk_call_out whose delta outputs point at ``stats`` (counts of the unfiltered genotypes; with ``count``,
-        the call itself counts them into ``count`` first -- the single-read step, trk.h trk_call_out)."""
+    def with_delta(self, stats):
+        """trk_call_out whose delta outputs point at ``stats`` (counts of the unfiltered genotypes)."""
         s = L.CallOut()
         C.memmove(C.byref(s), C.byref(self.struct), C.sizeof(L.CallOut))
         s.delta_allele_count = stats.allele_count.ptr
         s.delta_locus_int = stats.locus_int.ptr
-        if count is not None:
-            s.count_allele_count = count.allele_count.ptr
-            s.count_locus_int = count.locus_int.ptr
         return s
 
 
@@ -595,14 +591,11 @@ class Engine:
         self._chk(self.lib.trk_locus_finalize(self.ctx, C.byref(batch.struct), C.byref(prm), C.byref(stats.struct)))
         return stats
 
-    def call_filters(self, batch, planes, filters, dp_plane=-1, out=None, delta_stats=None, count_stats=None):
+    def call_filters(self, batch, planes, filters, dp_plane=-1, out=None, delta_stats=None):
         """planes: list of DeviceArray ([L,S] or [L,S,k], int32/float32);
         filters: list of dicts(op, plane_a, col_a=0, plane_b=-1, col_b=0, col_a2=0, thr=0.0);
         delta_stats: StatsResult holding the counts of the unfiltered genotypes, corrected in place
-        to the counts of the masked genotypes (no second pass over the tensor);
-        count_stats: StatsResult NOT counted yet -- the call leaves the counts of the unfiltered genotypes in it
-        and those of the masked genotypes in ``delta_stats`` (may be the same object), reading the genotype
-        tensor once for both (trk.h trk_call_out.count_*)."""
+        to the counts of the masked genotypes (no second pass over the tensor)."""
         np_ = len(planes)
         nf = len(filters)
         if np_ > L.TRK_MAX_PLANES or nf > L.TRK_MAX_FILTERS:
@@ -627,9 +620,7 @@ class Engine:
                                    int(f.get('col_a2', 0)), float(f.get('thr', 0.0)))
         if out is None:
             out = self.alloc_call_out(batch, nf)
-        if count_stats is not None and delta_stats is None:
-            raise ValueError("count_stats needs delta_stats")
-        ostruct = out.struct if delta_stats is None else out.with_delta(delta_stats, count_stats)
+        ostruct = out.struct if delta_stats is None else out.with_delta(delta_stats)
         self._chk(self.lib.trk_call_filters(self.ctx, C.byref(batch.struct), parr, np_, farr, nf,
                                             int(dp_plane), C.byref(ostruct)))
         return out
