@@ -562,13 +562,17 @@ __device__ __forceinline__ uint32_t scan_quad(const QuadCtx& q, const u32x4 v, u
         double g = gl[j] + gh[j];   // NaN when either haplotype is '-1'
         const bool called = g == g;
         bool ok = called;
+        // the flag: rare = 2 rare + (this call), the wave-wide mask of the test as the carry of ONE add (a select and
+        // an OR before; the kernel is bound by vector issue, profiles/r04_notes.md section 12) -- call j ends at bit 3 - j
         if (MASK) {
             const bool in = (mk >> (8 * j)) & 1u;
             ok = called & in;
-            rare |= (in & !called) ? (1u << j) : 0u;
+            const uint64_t mm = __ballot(in & !called);
+            asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(rare) : "s"(mm) : "vcc");
             g = ok ? g : 0.0;
         } else {
-            rare |= called ? 0u : (1u << j);
+            const uint64_t mm = __ballot(!called);
+            asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(rare) : "s"(mm) : "vcc");
             // the NaN is the LUT's (payload 0, and NaN + x keeps it): without its high word it is +0.0
             const uint64_t gb = __builtin_bit_cast(uint64_t, g);
             const uint32_t hi = called ? (uint32_t)(gb >> 32) : 0u;
@@ -612,7 +616,7 @@ __device__ __forceinline__ void drain_few(const QuadCtx& q, const uint32_t* queu
         while (bits) {
             const int b = __ffs((int)bits) - 1;
             bits &= bits - 1;
-            const int s = ((c0 + (b >> 2) * WAVE) << 2) + (b & 3);
+            const int s = ((c0 + (b >> 2) * WAVE) << 2) + (3 - (b & 3));   // (scan_quad: call j of a chunk at bit 3 - j)
             double z[MV + 1];
 #pragma unroll
             for (int k = 0; k < MV; ++k) z[k] = q.vec[(size_t)k * q.Sr + s];
