@@ -420,12 +420,14 @@ int trk_locus_filters(trk_ctx* ctx, int32_t n_loci, const trk_stats_out* stats,
  * samples with sample_in == 0 are ignored).  The intercept is implicit.
  * trk_assoc_scan takes up to TRK_ASSOC_MAX_VEC_WIDE rows (associaTR.py:138-204 has no bound: any number of
  * --same-file-covars / .npy columns), in ONE pass over the genotype tensor for diploid batches whose rows are whole
- * 16-byte chunks (up to four 16-row tiles of [vectors..., 1] per 16 loci on the matrix pipe); other batches with more
- * than TRK_ASSOC_MAX_VEC rows are scanned pair of 15-row groups by pair -- g(g-1)/2 passes for g = ceil(M / 15)
- * groups -- and the whole design solved per locus.  trk_assoc_scan_dosage takes up to TRK_ASSOC_MAX_VEC rows.
+ * 16-byte chunks and up to 62 rows (up to four 16-row tiles of [vectors..., 1] per 16 loci on the matrix pipe); other
+ * batches with more than TRK_ASSOC_MAX_VEC rows, and every design of 63 rows and more, are scanned pair of 15-row groups
+ * by pair -- g(g-1)/2 passes for g = ceil(M / 15) groups -- and the whole design solved per locus by one wavefront
+ * (two rows of the normal matrix per lane from 63 rows on; the bound is that tile's size in LDS).
+ * trk_assoc_scan_dosage takes up to TRK_ASSOC_MAX_VEC rows.
  */
 #define TRK_ASSOC_MAX_VEC 31
-#define TRK_ASSOC_MAX_VEC_WIDE 62
+#define TRK_ASSOC_MAX_VEC_WIDE 126
 typedef struct {
     int32_t n_vec;              /* M >= 1: outcome + (M-1) covariates                        */
     int32_t flags;              /* 0                                                         */

@@ -98,14 +98,14 @@ def _wide_traits(tmp_path, n_cols, seed=9):
 
 
 def test_wide_design_limits_of_the_host_layer(tmp_path, oracle_compute):
-    """More than 31 trait columns (no bound in the reference, associaTR.py:138-204): accepted up to 62 for the
+    """More than 31 trait columns (no bound in the reference, associaTR.py:138-204): accepted up to 126 for the
     GT-based scan, refused above, and above 31 with --beagle-dosages."""
     out = str(tmp_path / 'w.tsv')
     run_cli(out, dict(same_samples=True, tr_vcf=assoc_cases.HIPSTR, traits=[_wide_traits(tmp_path, 40)]), 2, 2)
     rows = open(out).readlines()
     assert len(rows) > 10 and sum('n covars >= n samples' not in r for r in rows[1:]) > 5
     with pytest.raises(ValueError):
-        run_cli(out, dict(same_samples=True, tr_vcf=assoc_cases.HIPSTR, traits=[_wide_traits(tmp_path, 63)]), 2, 2)
+        run_cli(out, dict(same_samples=True, tr_vcf=assoc_cases.HIPSTR, traits=[_wide_traits(tmp_path, 127)]), 2, 2)
     with pytest.raises(ValueError):
         run_cli(out, dict(same_samples=True, beagle_dosages=True, traits=[_wide_traits(tmp_path, 32)]), 2, 2)
 

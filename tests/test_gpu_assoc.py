@@ -163,7 +163,7 @@ def test_gram_correction_of_mostly_missing_loci_on_long_rows(eng):
 def test_wide_designs_pairs_of_row_groups(eng):
     """More than 31 trait columns (the reference has no bound, associaTR.py:138-204): ONE pass of three or four
     16-row tiles for diploid batches whose rows are whole 16-byte chunks (round 3), pairs of 15-row groups through
-    the same scan kernels otherwise; the whole design solved by a wave per locus.  Up to 62 rows."""
+    the same scan kernels otherwise; the whole design solved by a wave per locus."""
     assert run_case(eng, 41, 50, 1024, M=32, subset=True) > 20               # groups of 15, 15, 2
     assert run_case(eng, 42, 37, 772, M=45, subset=True, miss=0.1) > 15      # three full groups; loci % 16, S % 256
     assert run_case(eng, 43, 40, 1280, M=62, cutoff=0.0, miss=0.3) > 15      # five groups, ten pairs, 64 lanes
@@ -171,7 +171,17 @@ def test_wide_designs_pairs_of_row_groups(eng):
     assert run_case(eng, 45, 30, 300, P=3, M=33) > 10                        # triploid: the generic scan kernel
     from trtools_amd._lib import TrkError
     with pytest.raises(TrkError):
-        run_case(eng, 46, 10, 256, M=63)
+        run_case(eng, 46, 10, 256, M=127)
+
+
+def test_designs_beyond_one_pass_of_the_matrix_pipe(eng):
+    """63 to 126 trait columns (round 4): always pairs of 15-row groups (up to nine groups, 36 passes), the whole design
+    solved by one wavefront per locus with TWO rows of the normal matrix per lane (k_assoc_regress_wave<2>; the first
+    size is the one where row 64 appears)."""
+    assert run_case(eng, 47, 24, 512, M=63, miss=0.1) > 10
+    assert run_case(eng, 48, 20, 1024, M=100, subset=True) > 8
+    assert run_case(eng, 49, 16, 772, M=126, cutoff=0.0, miss=0.2) > 6
+    assert run_case(eng, 50, 12, 300, P=3, M=70) > 4                          # triploid: the generic scan kernel
 
 
 def test_wave_parallel_regression_for_narrow_designs_too(eng):

@@ -115,7 +115,7 @@ class AssocOut(C.Structure):
 
 # associaTR scan: trk_assoc_out columns / status codes (include/trk.h)
 ASSOC_MAX_VEC = 31        # one pass over the genotype tensor
-ASSOC_MAX_VEC_WIDE = 62   # trk_assoc_scan: pairs of 15-row groups (TRK_ASSOC_MAX_VEC_WIDE)
+ASSOC_MAX_VEC_WIDE = 126  # trk_assoc_scan: one MFMA pass up to 62 rows, pairs of 15-row groups beyond (TRK_ASSOC_MAX_VEC_WIDE)
 AI_N_TESTED, AI_STATUS, AI_N_RALLELES, AI_RANK, AI_N_BAD, AI_N_HAPS, AI_COLS = 0, 1, 2, 3, 4, 5, 8
 (AF_PVAL, AF_COEF, AF_SE, AF_RSQUARED, AF_GT_STD, AF_GT_MEAN, AF_TVALUE, AF_DF_RESID, AF_NONMAJOR) = range(9)
 AF_COLS = 10

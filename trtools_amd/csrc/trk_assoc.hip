@@ -2077,11 +2077,14 @@ __global__ __launch_bounds__(FIN_T) void k_assoc_finalize(const FinArgs a) {
 // substitution for free).  Left-looking: column j needs row j (broadcast reads) and each lane's
 // own row.  Same arithmetic and the same dropped-column rule as the thread-per-locus finaliser.
 // -------------------------------------------------------------------------------------------
+// R rows per lane (rows lane, lane + 64, ...): R = 1 up to 62 trait columns, R = 2 up to 126 (round 4; the triangle of a
+// 128-row tile is 66 KB: two waves per workgroup then, blockDim.x / 64 says how many).
 constexpr int RW_WAVES = 4;
+template <int R>
 __global__ __launch_bounds__(WAVE* RW_WAVES) void k_assoc_regress_wave(const FinArgs a) {
     extern __shared__ double rw_lds[];
     const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x >> 6;
-    const int l = blockIdx.x * RW_WAVES + wid;
+    const int l = blockIdx.x * (int)(blockDim.x >> 6) + wid;
     if (l >= a.b.n_loci) return;
     int32_t* li = a.locus_int + (size_t)l * TRK_AI_COLS;
     double* lf = a.locus_f64 + (size_t)l * TRK_AF_COLS;
@@ -2134,14 +2137,18 @@ __global__ __launch_bounds__(WAVE* RW_WAVES) void k_assoc_regress_wave(const Fin
         }
     }
     wave_fence();
-    if (lane < M) {
-        const double sgc = lane == 0 ? sg : psum(3 + lane);
-        const double sc = lane == 0 ? n_d : AT(lane, 0);      // G(lane, M): the ones column of row `lane`
-        AT(M, lane) = (sgc - mean * sc) / sd;
-    } else if (lane == M) {
-        AT(M, M) = n_d;
-    } else if (lane == P) {
-        AT(P, M) = (psum(3) - mean * sy) / sd;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const int i = lane + q * WAVE;
+        if (i < M) {
+            const double sgc = i == 0 ? sg : psum(3 + i);
+            const double sc = i == 0 ? n_d : AT(i, 0);      // G(i, M): the ones column of row i
+            AT(M, i) = (sgc - mean * sc) / sd;
+        } else if (i == M) {
+            AT(M, M) = n_d;
+        } else if (i == P) {
+            AT(P, M) = (psum(3) - mean * sy) / sd;
+        }
     }
     wave_fence();
     // ---- left-looking Cholesky; rows j..P (row P = rhs) are updated for column j ---------------
@@ -2149,21 +2156,39 @@ __global__ __launch_bounds__(WAVE* RW_WAVES) void k_assoc_regress_wave(const Fin
     bool last_dependent = false;
     double zz = 0.0;
     for (int j = 0; j < P; ++j) {
-        double v = 0.0;
-        if (lane >= j && lane <= P) {
-            v = AT(lane, j);
-            for (int k = 0; k < j; ++k) v -= AT(lane, k) * AT(j, k);
+        double v[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int i = lane + q * WAVE;
+            v[q] = 0.0;
+            if (i >= j && i <= P) {
+                v[q] = AT(i, j);
+                for (int k = 0; k < j; ++k) v[q] -= AT(i, k) * AT(j, k);
+            }
         }
         const double ajj = AT(j, j);  // still the original diagonal entry
-        const double d = __shfl(v, j, WAVE);
+        double d = 0.0;               // row j's value: lane j % 64, slot j / 64
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const double t = __shfl(v[q], j & (WAVE - 1), WAVE);
+            if ((j >> 6) == q) d = t;
+        }
         wave_fence();
         if (!(d > 1e-11 * ajj)) {  // column in the span of the previous ones: dropped (pinv semantics)
-            if (lane >= j && lane <= P) AT(lane, j) = 0.0;
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const int i = lane + q * WAVE;
+                if (i >= j && i <= P) AT(i, j) = 0.0;
+            }
             if (j == P - 1) last_dependent = true;
         } else {
             const double ljj = sqrt(d);
-            if (lane == j) AT(lane, j) = ljj;
-            else if (lane > j && lane <= P) AT(lane, j) = v / ljj;
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const int i = lane + q * WAVE;
+                if (i == j) AT(i, j) = ljj;
+                else if (i > j && i <= P) AT(i, j) = v[q] / ljj;
+            }
             ++rank;
         }
         wave_fence();
@@ -2199,7 +2224,8 @@ __global__ __launch_bounds__(WAVE* RW_WAVES) void k_assoc_regress_wave(const Fin
 
 
 // -------------------------------------------------------------------------------------------
-// wide designs (32..62 vector rows): the rows are cut into groups of <= 15 and every PAIR of groups
+// wide designs (32..126 vector rows; 63 and more always, 32..62 outside the one-pass MFMA kernel's conditions): the
+// rows are cut into groups of <= 15 and every PAIR of groups
 // is scanned as a design of <= 30 rows by the kernels above; this kernel moves one pair's records
 // (chunks summed) and its full Gram matrix to their places in the records of the whole design.
 // Block l < L: locus l; block L: the full Gram matrix.
@@ -2378,17 +2404,20 @@ static hipError_t launch_scan_t(const AssocArgs& a, const AssocPlan& p, hipStrea
 static bool use_wave_regress(int M) {
     int min_m = 16;  // below, the thread-per-locus solve is faster (round 3: M = 15: 0.64 vs 0.69 ms; M = 16: 1.08 vs 0.71)
     if (const char* e = getenv("TRK_AS_WAVE_REGRESS_MIN")) min_m = atoi(e);
-    return M >= min_m && M + 2 <= WAVE;
+    return M >= min_m && M + 2 <= 2 * WAVE;
 }
 
 static hipError_t launch_regress_wave(const FinArgs& f, hipStream_t stream) {
     const int P = f.M + 1;
-    const size_t lds = (size_t)RW_WAVES * ((P + 1) * (P + 2) / 2) * 8;
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assoc_regress_wave),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (P + 1 > 2 * WAVE) return hipErrorInvalidValue;
+    const size_t tri = (size_t)((P + 1) * (P + 2) / 2) * 8;     // one locus's tile: lower triangle + the right-hand side
+    int waves = RW_WAVES;
+    while (waves > 1 && waves * tri > 144 * 1024) waves >>= 1;
+    const size_t lds = (size_t)waves * tri;
+    void (*kern)(FinArgs) = P + 1 <= WAVE ? k_assoc_regress_wave<1> : k_assoc_regress_wave<2>;
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(k_assoc_regress_wave, dim3((f.b.n_loci + RW_WAVES - 1) / RW_WAVES), dim3(WAVE * RW_WAVES), lds,
-                       stream, f);
+    hipLaunchKernelGGL(kern, dim3((f.b.n_loci + waves - 1) / waves), dim3(WAVE * waves), lds, stream, f);
     return hipGetLastError();
 }
 
