@@ -550,7 +550,13 @@ def strong_shard_extra(eng, args, loci, t_full_ms, steps):
                            "k_call_filter_frac": cells * BYTES_PER_CELL_CALL_FILTER / (cf * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "kernels_ms": {k: (v[1] / v[0] if v[0] else None) for k, v in prof.items() if v[0]},
                            "predicted_efficiency": (t_full_ms / n) / ms,
-                           "predicted_loci_per_s_at_N": args.loci / (ms * 1e-3)}
+                           "predicted_loci_per_s_at_N": args.loci / (ms * 1e-3),
+                           # the shard's two output planes (hi x S x 4 B each): placed from 256 MB on (Engine.PLACE_MIN_BYTES)
+                           "output_planes_bytes_each": hi * wl.n_samples * 4,
+                           "output_planes_placed": (wl.placement or {}).get('placed') if wl.placement is not None else
+                                                   "not searched (planes below 256 MB: no placement classes to tell apart)",
+                           "placement_probe_ms": (wl.placement or {}).get('probe_ms'),
+                           "placement_peak_extra_bytes": (wl.placement or {}).get('peak_extra_bytes')}
         wl.free()
     out["note"] = ("one GPU, 1-rank RCCL communicator: every kernel and collective launch of a rank of the N-GPU "
                    "strong-scaled run, without the xGMI wire time (< 1 MB per step)")

@@ -72,7 +72,8 @@ typedef struct {
     uint8_t* locus_ploidy;   /* [max_records]        caller-owned                            */
     void** planes;           /* [n_selected] caller-owned buffers [max_records, S, ncol]    */
     /* the record lines themselves (for the fixed columns and anything not decoded above):
-     * text[line_off[i] .. line_end[i]) is record i (no newline);
+     * text[line_off[i] .. line_end[i]) is record i (no newline; text[line_end[i]] itself is the line's '\n' or '\r' and
+     * readable -- the reader appends a newline to a last line without one -- which trk_vcf_dumpstr_records relies on);
      * field_off[i*10 + k] is the offset inside the line of column k (k = 0..8: CHROM..FORMAT,
      * k = 9: first sample column).  Owned by the reader; valid during the NEXT trk_vcf_read_batch
      * call too (a thread may read batch n + 1 while batch n is in use), gone with the one after. */

@@ -420,14 +420,48 @@ def test_dumpstr_native_heads_and_undecoded_samples_equal_the_decode_path(tmp_pa
     assert a[1]['caller_heads'] == 0 and c[1]['fast'] == 0
 
 
-def _mutated_hipstr(tmp_path, seed):
+def _mutated_hipstr(tmp_path, seed, scalar=False):
     """synth_hipstr.vcf with its sample columns rewritten at random: numbers spelled the ways a decoder normalises
     ('007', '+5', '1.00', '0.50', '1e-3', seven digits), vector fields of equal and of ragged length, missing values,
-    samples that stop early, a string field; plus INFO values of every declared type."""
+    samples that stop early, a string field; plus INFO values of every declared type.  ``scalar``: no vector fields
+    (the records the span writer's scalar tier takes, round 4): most records keep canonical numbers only, one in
+    three gets the other spellings, tokens stop early or are a lone '.'."""
     import random
     rnd = random.Random(seed)
     src = os.path.join(SYN, 'synth_hipstr.vcf')
-    dst = str(tmp_path / ('mut%d.vcf' % seed))
+    dst = str(tmp_path / ('mut%d%s.vcf' % (seed, 's' if scalar else '')))
+    if scalar:
+        canon_i, canon_f = ['7', '12', '0', '-3', '31', '123456789', '.'], ['0.99', '1', '0.5', '0.0001', '0.00012345', '12.5', '999999', '-0', '.', '0.95', '123.456']
+        odd_i, odd_f = ['007', '-0', '2147483000', '1234567890'], ['1.00', '0.50', '1e-3', '123456.7', '0.1234567', '0.0', '1E2', '1000000', '.5', '0.00001']
+        with open(src) as fin, open(dst, 'w') as fout:
+            for line in fin:
+                if line.startswith('#'):
+                    fout.write(line)
+                    continue
+                f = line.rstrip('\n').split('\t')
+                keys = f[8].split(':')
+                odd = rnd.random() < 0.33
+                for i in range(9, len(f)):
+                    t = f[i].split(':')
+                    if len(t) != len(keys) or t[0] in ('.', './.', '.|.'):
+                        continue
+                    for k in ('DP', 'DSTUTTER', 'DFLANKINDEL'):
+                        if rnd.random() < 0.4:
+                            t[keys.index(k)] = rnd.choice(canon_i + (odd_i if odd and k != 'DP' else []))
+                    if rnd.random() < 0.3:
+                        t[keys.index('DP')] = rnd.choice(['11', '22', '45', '60'] + (['007', '033'] if odd else []))
+                    if rnd.random() < 0.5:
+                        t[keys.index('Q')] = rnd.choice(['0.99', '0.9', '0.5', '1', '0.951'] + (odd_f if odd else []))
+                    r = rnd.random()
+                    if r < 0.05:
+                        t = t[:rnd.randint(1, len(t))]                  # trailing fields dropped
+                    elif r < 0.08:
+                        t = ['.']                                       # HipSTR's sample without a call
+                    elif r < 0.09 and odd:
+                        t = t + ['extra']                               # more fields than keys
+                    f[i] = ':'.join(t)
+                fout.write('\t'.join(f) + '\n')
+        return dst
     ints = ['7', '007', '12', '0', '-3', '-0', '123456789', '2147483000', '.', '31']   # ('+5': the per-record path's)
     floats = ['0.99', '1.00', '0.50', '1', '0.5', '1e-3', '0.0001', '0.00012345', '123456.7', '0.1234567', '-0', '0.0', '.', '12.5',
               '1E2', '999999', '1000000', '0.95']
@@ -465,18 +499,20 @@ def _mutated_hipstr(tmp_path, seed):
     return dst
 
 
-@pytest.mark.parametrize('seed', [1, 2, 3, 4])
-def test_undecoded_sample_columns_on_rewritten_text(tmp_path, seed):
-    """The span writer (fast_samples) against decode -> null -> format on text it has to work for: every record comes
-    out the same bytes whichever writer took it, and the native INFO rewrite equals vcfio.rewrite_info."""
+@pytest.mark.parametrize('seed,scalar', [(1, False), (2, False), (3, False), (4, False), (5, True), (6, True), (7, True), (8, True)])
+def test_undecoded_sample_columns_on_rewritten_text(tmp_path, seed, scalar):
+    """The span writer (fast_samples, and its scalar tier fast_samples_scalar on the records without vector fields)
+    against decode -> null -> format on text it has to work for: every record comes out the same bytes whichever
+    writer took it (scalar tier, general transducer alone, decode path, Python heads), and the native INFO rewrite
+    equals vcfio.rewrite_info."""
     from oracle_compute import OracleCompute
     from trtools_amd import runtime, vcfnative
     from trtools_amd.dumpSTR import dumpSTR
-    vcf = _mutated_hipstr(tmp_path, seed)
+    vcf = _mutated_hipstr(tmp_path, seed, scalar)
     old = runtime.set_compute(OracleCompute())
     outs, stats = [], []
     try:
-        for i, env in enumerate([{}, {'TRK_FMT_FAST': '0'}, {'TRK_DUMPSTR_NATIVE_HEADS': '0'}]):
+        for i, env in enumerate([{}, {'TRK_FMT_FAST': '0'}, {'TRK_DUMPSTR_NATIVE_HEADS': '0'}, {'TRK_FMT_SCALAR': '0'}]):
             for k, v in env.items():
                 os.environ[k] = v
             try:
@@ -493,7 +529,7 @@ def test_undecoded_sample_columns_on_rewritten_text(tmp_path, seed):
                     del os.environ[k]
     finally:
         runtime.set_compute(old)
-    for x, what in ((outs[1], 'decode path'), (outs[2], 'Python heads')):
+    for x, what in ((outs[1], 'decode path'), (outs[2], 'Python heads'), (outs[3], 'general transducer')):
         if x != outs[0]:
             la, lb = outs[0].split('\n'), x.split('\n')
             i = next(i for i, (p, q) in enumerate(zip(la, lb)) if p != q)

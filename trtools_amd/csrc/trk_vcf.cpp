@@ -2337,6 +2337,19 @@ inline bool canon_float(const char* p, const char* e) {
     while (z < e && *z == '0') ++z;
     return (z - fp) <= 3 && (e - z) <= 6;
 }
+// "%g" of x: small integers by hand, other finite values through to_chars (general, 6 = printf's %g by definition,
+// without the format parsing and the locale of snprintf), non-finite values through snprintf itself
+inline int fmt_g6(char* tmp, size_t cap, double x) {
+    if (x == (double)(int32_t)x && x > -1e6 && x < 1e6 && !(x == 0.0 && std::signbit(x))) {
+        auto r = std::to_chars(tmp, tmp + cap, (int32_t)x);
+        return (int)(r.ptr - tmp);
+    }
+    if (std::isfinite(x)) {
+        auto r = std::to_chars(tmp, tmp + cap, x, std::chars_format::general, 6);
+        if (r.ec == std::errc()) return (int)(r.ptr - tmp);
+    }
+    return snprintf(tmp, cap, "%g", x);
+}
 inline void put_callfilter(OutBuf& o, uint32_t m, int n_filters, const char* const* names, const double* const* values,
                            int64_t s) {
     char tmp[48];
@@ -2352,12 +2365,186 @@ inline void put_callfilter(OutBuf& o, uint32_t m, int n_filters, const char* con
             o.put(names[b], strlen(names[b]));
             o.put('_');
             const double x = values[b] ? values[b][s] : NAN;
-            const int len = snprintf(tmp, sizeof tmp, "%g", x);
+            const int len = fmt_g6(tmp, sizeof tmp, x);
             o.put(tmp, (size_t)len);
         }
         if (!n) o.put('.');
     }
 }
+// The span transducer's first tier (round 4): records whose FORMAT fields are the genotype, scalar Integer / Float
+// fields and strings, every sample's token followed by a tab (the last one by the line's newline).  A call that is kept is checked
+// in ONE forward scan of its bytes (the canonical forms of canon_uint / canon_int / canon_float, inlined; no memchr
+// per token and per field, no bounds-checked put per piece) and copied whole; a filtered call is one prepared string.
+// Anything else about a record -- vectors, a token with more fields than keys, a number that is not canonical -- returns
+// false before anything is kept and fast_samples below takes the record.  `end` must point at a readable byte (the
+// newline).  53 -> ~20 ns per call on the 1 GB probe (profiles/r04_notes.md section 13).
+bool fast_samples_scalar(const char* smp, const char* end, int S, int pl, int nf, const int* kinds, const uint32_t* m32,
+                         const uint8_t* filtered, int n_filters, const char* const* names, const double* const* values,
+                         OutBuf& o) {
+    if (nf < 1 || nf > 16 || pl < 1) return false;
+    for (int f = 0; f < nf; ++f)
+        if (kinds[f] != -1 && kinds[f] != TRK_VCF_COL_INT && kinds[f] != TRK_VCF_COL_FLOAT && kinds[f] != TRK_VCF_COL_UCS4)
+            return false;
+    // a filtered call: alleles missing and unphased, every other field missing
+    char nulltok[64];
+    int nl = 0;
+    for (int f = 0; f < nf; ++f) {
+        if (f) nulltok[nl++] = ':';
+        if (kinds[f] < 0) {
+            if (nl + 2 * pl + 2 > (int)sizeof nulltok) return false;
+            for (int j = 0; j < pl; ++j) {
+                if (j) nulltok[nl++] = '/';
+                nulltok[nl++] = '.';
+            }
+        } else {
+            nulltok[nl++] = '.';
+        }
+    }
+    char* const w0 = o.p + o.n;
+    char* w = w0;
+    const char* c = smp;
+    char tmp[48];
+#define TRK_DIGIT(ch) ((unsigned)((ch) - '0') <= 9u)
+    for (int s = 0; s < S; ++s) {
+        const char* const tok = c;
+        const bool flt = filtered[s] != 0;
+        int pad = 0;            // fields a kept call does not hold (HipSTR writes '.' for a sample without a call): '.' each
+        for (int f = 0; f < nf; ++f) {
+            const int kind = kinds[f];
+            if (flt) {
+                // only the shape matters: a scalar (no comma), at most nf fields
+                while (*c != ':' && *c != '\t' && *c != ',' && *c != '\n' && *c != '\r' && *c != 0) ++c;
+                if (*c == ',') return false;
+                if (c == tok && f == 0) return false;             // an empty token
+            } else if (kind < 0) {
+                int na = 0;
+                char sep = 0;
+                for (;;) {
+                    if (*c == '.') {
+                        ++c;
+                    } else if (*c == '0') {
+                        ++c;
+                        if (TRK_DIGIT(*c)) return false;
+                    } else if (TRK_DIGIT(*c)) {
+                        const char* a = c;
+                        do ++c; while (TRK_DIGIT(*c));
+                        if (c - a > 9) return false;
+                    } else {
+                        return false;
+                    }
+                    ++na;
+                    if (*c != '/' && *c != '|') break;
+                    if (sep && *c != sep) return false;
+                    sep = *c++;
+                }
+                if (na > pl) return false;
+            } else if (kind == TRK_VCF_COL_INT) {
+                if (*c == '.') {
+                    ++c;
+                } else {
+                    if (*c == '-') {
+                        ++c;
+                        if (*c == '0') return false;
+                    }
+                    if (*c == '0') {
+                        ++c;
+                        if (TRK_DIGIT(*c)) return false;
+                    } else if (TRK_DIGIT(*c)) {
+                        const char* a = c;
+                        do ++c; while (TRK_DIGIT(*c));
+                        if (c - a > 9) return false;
+                    } else {
+                        return false;
+                    }
+                }
+            } else if (kind == TRK_VCF_COL_UCS4) {   // a string: ASCII, not empty, copied as it stands
+                const char* a = c;
+                while (*c != ':' && *c != '\t' && *c != '\n' && *c != '\r') {
+                    if ((unsigned char)*c >= 0x80 || *c == 0) return false;
+                    ++c;
+                }
+                if (c == a) return false;
+            } else {   // Float: '.', or -?(0|[1-9]d*)(.d*[1-9])? with at most six significant digits, 1e-4 <= |x| < 1e6
+                if (*c == '.' && !TRK_DIGIT(c[1])) {
+                    ++c;
+                } else {
+                    if (*c == '-') ++c;
+                    const char* ip = c;
+                    while (TRK_DIGIT(*c)) ++c;
+                    const ptrdiff_t ni = c - ip;
+                    if (ni < 1 || (ni > 1 && *ip == '0') || ni > 6) return false;
+                    if (*c == '.') {
+                        const char* fp = ++c;
+                        while (TRK_DIGIT(*c)) ++c;
+                        const ptrdiff_t nfr = c - fp;
+                        if (nfr < 1 || c[-1] == '0') return false;
+                        if (*ip != '0') {
+                            if (ni + nfr > 6) return false;
+                        } else {
+                            const char* z = fp;
+                            while (*z == '0') ++z;
+                            if (z - fp > 3 || c - z > 6) return false;
+                        }
+                    }
+                }
+            }
+            if (f + 1 < nf) {
+                if (*c == ':') { ++c; continue; }
+                if (*c == '\t' || c == end) {                     // fewer fields than keys
+                    pad = flt ? 0 : nf - 1 - f;
+                    break;
+                }
+                return false;
+            }
+        }
+        // the token ends here: a tab, or the line's end for the last sample
+        if (s + 1 < S) {
+            if (*c != '\t') return false;
+        } else if (c != end) {
+            return false;
+        }
+        *w++ = '\t';
+        const uint32_t m = m32[s];
+        if (flt) {
+            memcpy(w, nulltok, (size_t)nl);
+            w += nl;
+            *w++ = ':';
+            int n = 0;
+            for (int b = 0; b < n_filters && b < 31; ++b) {
+                if (!((m >> b) & 1u)) continue;
+                if (n++) *w++ = ',';
+                const size_t ln = strlen(names[b]);
+                memcpy(w, names[b], ln);
+                w += ln;
+                *w++ = '_';
+                const int len = fmt_g6(tmp, sizeof tmp, values[b] ? values[b][s] : NAN);
+                memcpy(w, tmp, (size_t)len);
+                w += len;
+            }
+            if (!n) *w++ = '.';
+        } else {
+            const size_t tl = (size_t)(c - tok);
+            memcpy(w, tok, tl);
+            w += tl;
+            for (int k = 0; k < pad; ++k) {
+                *w++ = ':';
+                *w++ = '.';
+            }
+            if (m & 0x80000000u) {
+                memcpy(w, ":NOCALL", 7);
+                w += 7;
+            } else {
+                memcpy(w, ":PASS", 5);
+                w += 5;
+            }
+        }
+        ++c;   // past the tab (or the newline: not read again)
+    }
+#undef TRK_DIGIT
+    o.n += (int64_t)(w - w0);
+    return true;
+}
+
 // kinds[f]: -1 GT, -2 the record's own FILTER field (replaced in place), TRK_VCF_COL_INT / _FLOAT / _UCS4.
 // m32 / filtered: the record's mask row.
 bool fast_samples(const char* smp, const char* end, int S, int pl, int nf, const int* kinds, const uint32_t* m32,
@@ -2574,7 +2761,7 @@ FmtChunkPool& fmt_chunks() {
 }
 
 // records written without decoding / through the decode path / with a caller-built head, since the process started
-std::atomic<int64_t> g_fmt_fast{0}, g_fmt_slow{0}, g_fmt_py_heads{0};
+std::atomic<int64_t> g_fmt_fast{0}, g_fmt_slow{0}, g_fmt_py_heads{0}, g_fmt_scalar{0};   // (scalar: of the fast ones, the scalar tier's)
 
 int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const trk_vcf_dumpstr2* ext, char* out,
                      int64_t cap, int32_t* err_record) {
@@ -2591,6 +2778,7 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
     std::atomic<int> bad{INT32_MAX};
     std::atomic<int> need_heads{0};
     const bool fast_ok = ext && ext->fast_path && !(getenv("TRK_FMT_FAST") && atoi(getenv("TRK_FMT_FAST")) == 0);
+    const bool scalar_tier = !(getenv("TRK_FMT_SCALAR") && atoi(getenv("TRK_FMT_SCALAR")) == 0);   // (0: the general transducer only)
     auto fail = [&](int l) {
         int cur = bad.load();
         while (l < cur && !bad.compare_exchange_weak(cur, l)) {}
@@ -2797,14 +2985,23 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
                 const int64_t need = smp_len * 2 + (int64_t)S * (cfw + 4 * (pl + 1) + 2 * nf) + 64;
                 char* dst = room(hl + (size_t)need + 1);
                 OutBuf ob{dst + hl, need, 0};
-                if (fast_samples(smp, smp + smp_len, S, pl, nf, kinds.data(), m32.data(), filtered.data(), in->n_filters,
-                                 names.data(), vptr.data(), ob) && ob.n <= need) {
+                // (the scalar tier reads the byte behind the last token: text[line_end[l]] is the line's '\n' or '\r' in the
+                // reader's buffer -- read_batch appends one to a last line without -- see trk_vcf.h)
+                const char* send = smp + smp_len;
+                while (send > smp && (send[-1] == '\n' || send[-1] == '\r')) --send;
+                const bool scalar_ok = (*send == '\n' || *send == '\r') && filter_idx < 0 && scalar_tier &&
+                                       fast_samples_scalar(smp, send, S, pl, nf, kinds.data(), m32.data(), filtered.data(),
+                                                           in->n_filters, names.data(), vptr.data(), ob);
+                if (!scalar_ok) ob.n = 0;
+                if ((scalar_ok || fast_samples(smp, smp + smp_len, S, pl, nf, kinds.data(), m32.data(), filtered.data(), in->n_filters,
+                                               names.data(), vptr.data(), ob)) && ob.n <= need) {
                     memcpy(dst, head, hl);
                     dst[hl + (size_t)ob.n] = '\n';
                     rptr[(size_t)l] = dst;
                     rlen[(size_t)l] = hl + (size_t)ob.n + 1;
                     cur_n += rlen[(size_t)l];
                     g_fmt_fast.fetch_add(1, std::memory_order_relaxed);
+                    if (scalar_ok) g_fmt_scalar.fetch_add(1, std::memory_order_relaxed);
                     continue;
                 }
             }
@@ -2929,9 +3126,11 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
         for (auto& t : tc) t.join();
     }
     if (timing)
-        fprintf(stderr, "[trk_vcf] %d records written: format %.1f ms, gather %.1f ms, %d threads, %.0f MB\n", n,
+        fprintf(stderr, "[trk_vcf] %d records written: format %.1f ms, gather %.1f ms, %d threads, %.0f MB; since the process "
+                        "started %ld records by the span writer (%ld its scalar tier), %ld decoded\n", n,
                 std::chrono::duration<double, std::milli>(tf1 - tf0).count(),
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf1).count(), nt, total * 1e-6);
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf1).count(), nt, total * 1e-6,
+                (long)g_fmt_fast.load(), (long)g_fmt_scalar.load(), (long)g_fmt_slow.load());
     return total;
 }
 
