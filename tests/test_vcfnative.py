@@ -23,11 +23,13 @@ def _same(a, b):
     return np.array_equal(a, b)
 
 
-def _compare(path, batch_records=None, max_ploidy=2):
+def _compare(path, batch_records=None, max_ploidy=2, only=None):
+    """``only``: the FORMAT fields to decode into planes (default: every Integer / Float field; scalar fields alone
+    put the reader on the fast form of parse_record)."""
     from trtools_amd import vcfio, vcfnative
     py = list(vcfio.VCFReader(path))
     r = vcfnative.NativeVCFReader(path, batch_records=batch_records, max_ploidy=max_ploidy)
-    num = [k for k, (t, n) in r.format_types.items() if t in ('Integer', 'Float') and k != 'GT']
+    num = [k for k, (t, n) in r.format_types.items() if t in ('Integer', 'Float') and k != 'GT' and (only is None or k in only)]
     ncols = {}
     for v in py:
         for k in num:
@@ -54,7 +56,8 @@ def _compare(path, batch_records=None, max_ploidy=2):
         # undecoded fields are still reachable through the record text
         for k in x.FORMAT:
             if k not in num and k != 'GT':
-                assert np.array_equal(x.format(k), y.format(k))
+                xa, ya = x.format(k), y.format(k)
+                assert (_same(xa, ya) if xa.dtype.kind in 'fi' and xa.shape == ya.shape else np.array_equal(xa, ya)), (x.POS, k)
         assert str(x) == str(y)
     return len(py)
 
@@ -389,3 +392,66 @@ def test_sample_map_lays_the_columns_out_while_parsing():
         n += rb.n
     assert n > 100
     r.close()
+
+
+def test_fast_sample_scan_on_every_spelling(tmp_path):
+    """parse_record's one-scan form of a sample (round 4: alleles, scalar Integer / Float planes) against the Python
+    decoder and against the general code (TRK_VCF_PARSE_GENERIC=1) on the spellings it takes itself and the ones it
+    hands over: leading zeros, signs, '.5', '5.', fifteen and sixteen digits, exponents, inf / nan, vectors in a scalar
+    field, empty alleles and subfields, long allele indices, more alleles than the tensor holds, tokens that stop early."""
+    from trtools_amd import vcfnative
+    ints = ['7', '007', '-3', '-0', '0', '123456789', '1234567890', '.', '', '+5', '1,2', '12x', '-', '2147483647']
+    floats = ['0.97', '1', '.5', '5.', '-.5', '-0', '0.000123', '123456789012345', '1234567890123456', '0.1234567890123456789',
+              '1e-3', '1E2', 'inf', '-inf', 'nan', '.', '', '0.5,0.6', '00.25', '-12.75', '3.', '1e', '0x10']
+    gts = ['0|1', '1/0', '.', './.', '.|1', '0|', '|1', '', '10|2', '1234|0', '12345|0', '-1|0', '0/1/2', '0', '1|1']
+    rng = np.random.default_rng(3)
+    S = 60
+    lines = ['##fileformat=VCFv4.2', '##command=HipSTR-v0.6.2 x', '##INFO=<ID=START,Number=1,Type=Integer,Description="s">',
+             '##INFO=<ID=END,Number=1,Type=Integer,Description="e">', '##INFO=<ID=PERIOD,Number=1,Type=Integer,Description="p">',
+             '##FORMAT=<ID=GT,Number=1,Type=String,Description="g">', '##FORMAT=<ID=GB,Number=1,Type=String,Description="b">',
+             '##FORMAT=<ID=DP,Number=1,Type=Integer,Description="d">', '##FORMAT=<ID=Q,Number=1,Type=Float,Description="q">',
+             '##FORMAT=<ID=XX,Number=1,Type=String,Description="x">',
+             '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t' + '\t'.join('s%d' % i for i in range(S))]
+    for r in range(40):
+        fmt = [['GT', 'GB', 'DP', 'Q', 'XX'], ['GT', 'DP', 'Q'], ['GT', 'Q', 'XX', 'DP'], ['DP', 'GT', 'Q']][r % 4]
+        cols = []
+        for s in range(S):
+            t = []
+            for k in fmt:
+                pool = {'GT': gts, 'DP': ints, 'Q': floats, 'GB': ['0|0', '.', 'a'], 'XX': ['x', 'y|z', '.']}[k]
+                easy = {'GT': ['0|1', '1|1', '.|.'], 'DP': ['12', '30', '.'], 'Q': ['0.9', '1', '0.55']}.get(k, pool)
+                t.append(str(rng.choice(pool if rng.random() < 0.25 else easy)))
+            if rng.random() < 0.1:
+                t = t[:int(rng.integers(1, len(t) + 1))]
+            tok = ':'.join(t)
+            cols.append(tok if tok else '.')
+        lines.append('\t'.join(['chr1', str(100 + 50 * r), '.', 'ACAC', 'ACACAC,AC', '.', '.', 'START=%d;END=%d;PERIOD=2' % (100 + 50 * r, 103 + 50 * r),
+                                ':'.join(fmt)] + cols))
+    path = str(tmp_path / 'spell.vcf')
+    open(path, 'w').write('\n'.join(lines) + '\n')
+
+    def arrays(generic):
+        if generic:
+            os.environ['TRK_VCF_PARSE_GENERIC'] = '1'
+        try:
+            out = []
+            for P in (2, 3):
+                r = vcfnative.NativeVCFReader(path, batch_records=16, max_ploidy=P)
+                r.select_format('DP')
+                r.select_format('Q')
+                try:
+                    for rec in r:
+                        out.append((rec.genotype.array().copy(), rec.format('DP').copy(), rec.format('Q').copy(), rec.ploidy))
+                except Exception as e:          # more alleles than the tensor holds: both forms must say so
+                    out.append(('error', type(e).__name__, str(e)))
+            return out
+        finally:
+            os.environ.pop('TRK_VCF_PARSE_GENERIC', None)
+    a, b = arrays(False), arrays(True)
+    assert len(a) == len(b) and len(a) > 20
+    for x, y in zip(a, b):
+        if isinstance(x[0], str) or isinstance(y[0], str):
+            assert x == y
+            continue
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[3] == y[3]
+        assert np.array_equal(x[2].view(np.uint32), y[2].view(np.uint32))          # floats bit for bit (signed zeros, NaN)

@@ -102,6 +102,8 @@ def test_random_vcf_text(tmp_path_factory, seed, n_rec, S, max_ploidy, container
     # (a Float plane wider than a record's own vectors cannot tell padding from '.': PL is written with its
     # declared three values or a single '.', as the fixed-Number fields the CLIs select are)
     assert _compare(path, batch_records=int(rng.integers(1, 8)), max_ploidy=max_ploidy) == n_rec
+    # and with the scalar planes alone: the one-scan form of a sample (parse_record, round 4)
+    assert _compare(path, batch_records=int(rng.integers(1, 8)), max_ploidy=max_ploidy, only=('DP', 'Q')) == n_rec
     os.remove(path)
 
 

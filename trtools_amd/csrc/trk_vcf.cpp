@@ -168,6 +168,41 @@ const Deflater& deflater() {
     return d;
 }
 
+// CPUs' worth of time the container's cgroup grants per scheduling period (cpu.max of cgroup v2, cfs_quota_us / cfs_period_us
+// of v1); 0: no quota.  The GPU boxes of this project show 256 hardware threads and grant 16 (cpu.max "1600000 100000"):
+// 64 reader threads burn the period's budget in bursts and the whole process is throttled until the next period
+// (profiles/r04_notes.md section 13), so the default thread counts follow the quota, not the visible CPUs.
+static int cpu_quota() {
+    static const int q = [] {
+        long quota = -1, period = 0;
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char a[32] = {0};
+            if (fscanf(f, "%31s %ld", a, &period) == 2 && strcmp(a, "max") != 0) quota = atol(a);
+            fclose(f);
+        } else {
+            if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+                if (fscanf(g, "%ld", &quota) != 1) quota = -1;
+                fclose(g);
+            }
+            if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (fscanf(g, "%ld", &period) != 1) period = 0;
+                fclose(g);
+            }
+        }
+        return (quota > 0 && period > 0) ? (int)std::max(1L, (quota + period - 1) / period) : 0;
+    }();
+    return q;
+}
+// default number of worker threads for a phase that would like `want`: the visible CPUs, and twice the quota when
+// there is one (bursts above the quota pay while the other phases of the command line idle; far above it they stall)
+static int default_threads(int want) {
+    const int hw = (int)std::thread::hardware_concurrency();
+    int n = std::min(want, hw > 0 ? hw : 8);
+    const int q = cpu_quota();
+    if (q > 0) n = std::min(n, std::max(8, 2 * q));
+    return std::max(1, n);
+}
+
 // ---------------------------------------------------------------------------------------
 // input: plain text, gzip stream, or BGZF (block-parallel inflate)
 // ---------------------------------------------------------------------------------------
@@ -716,7 +751,137 @@ void parse_record(RecordJob& job, int rec) {
     int maxpl = 1;
     const char* sp = line + foff[9];
     std::vector<const char*> sub_b((size_t)max_needed + 2), sub_e((size_t)max_needed + 2);
+    // The fast form of a sample (round 4): ONE forward scan of the token up to the last subfield that is needed --
+    // alleles of at most five digits, scalar Integer planes of at most nine, scalar Float planes as digits[.digits] of
+    // at most fifteen (w / 10^k in float64 is the correctly rounded double of such a decimal, Clinger's fast path: the
+    // same double from_chars gives, then the same cast) -- no memchr per token and subfield, no from_chars.  Anything
+    // else about a token (exponents, signs on alleles, vectors, inf / nan, more alleles than the tensor holds) sends
+    // THAT sample through the general code below.  Needs the byte at `end` readable: the line's newline.
+    static const double kP10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                    1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    int8_t plane_at[32];
+    bool fast_rec = np <= 32 && max_needed >= 0 && max_needed < 32 && (*end == '\n' || *end == '\r') && !(getenv("TRK_VCF_PARSE_GENERIC") && atoi(getenv("TRK_VCF_PARSE_GENERIC")) != 0);
+    if (fast_rec) {
+        for (int k = 0; k < 32; ++k) plane_at[k] = -1;
+        for (int i = 0; i < np && fast_rec; ++i) {
+            const PlaneSel& ps = v->planes[i];
+            if ((ps.kind != TRK_VCF_INT && ps.kind != TRK_VCF_FLOAT) || ps.ncol != 1) fast_rec = false;
+            else if (pidx[i] >= 0) {
+                if (plane_at[pidx[i]] >= 0 || pidx[i] == gt_idx) fast_rec = false;    // two planes of one subfield
+                else plane_at[pidx[i]] = (int8_t)i;
+            }
+        }
+    }
+#define TRK_DIGIT(ch) ((unsigned)((ch) - '0') <= 9u)
     for (int s = 0; s < S; ++s) {
+        if (fast_rec) {
+            const char* c = sp;
+            int k = 0, j = 0;
+            bool phased = false, ok = true;
+            uint32_t got = 0;                    // planes parsed from this token
+            for (;;) {
+                if (k == gt_idx) {
+                    for (;;) {
+                        int a;
+                        if (*c == '.') {
+                            a = -1;
+                            ++c;
+                        } else if (TRK_DIGIT(*c)) {
+                            const char* a0 = c;
+                            a = 0;
+                            do a = a * 10 + (*c++ - '0'); while (TRK_DIGIT(*c));
+                            if (c - a0 > 4) { ok = false; break; }
+                        } else if (*c == '/' || *c == '|' || *c == ':' || *c == '\t' || c == end) {
+                            a = -1;              // an empty allele
+                        } else {
+                            ok = false;
+                            break;
+                        }
+                        if (j >= P) { ok = false; break; }
+                        gt[(size_t)s * P + j++] = (int16_t)a;
+                        if (*c == '|') phased = true;
+                        else if (*c != '/') break;
+                        ++c;
+                    }
+                    if (!ok) break;
+                } else if (plane_at[k] >= 0) {
+                    const int i = plane_at[k];
+                    char* base = static_cast<char*>(job.out->planes[i]);
+                    if (v->planes[i].kind == TRK_VCF_INT) {
+                        int32_t x;
+                        if (*c == '.' && (c[1] == ':' || c[1] == '\t' || c + 1 == end)) {
+                            x = INT_MISSING;
+                            ++c;
+                        } else {
+                            const bool neg = *c == '-';
+                            if (neg) ++c;
+                            if (!TRK_DIGIT(*c)) { ok = false; break; }
+                            const char* a0 = c;
+                            uint32_t u = 0;
+                            do u = u * 10 + (uint32_t)(*c++ - '0'); while (TRK_DIGIT(*c));
+                            if (c - a0 > 9) { ok = false; break; }
+                            x = neg ? -(int32_t)u : (int32_t)u;
+                        }
+                        reinterpret_cast<int32_t*>(base)[(size_t)rec * S + s] = x;
+                    } else {
+                        float x;
+                        if (*c == '.' && (c[1] == ':' || c[1] == '\t' || c + 1 == end)) {
+                            x = NAN;
+                            ++c;
+                        } else {
+                            const bool neg = *c == '-';
+                            if (neg) ++c;
+                            const char* a0 = c;
+                            uint64_t w = 0;
+                            while (TRK_DIGIT(*c)) w = w * 10 + (uint64_t)(*c++ - '0');
+                            int nd = (int)(c - a0), kf = 0;
+                            if (*c == '.') {
+                                const char* f0 = ++c;
+                                while (TRK_DIGIT(*c)) w = w * 10 + (uint64_t)(*c++ - '0');
+                                kf = (int)(c - f0);
+                                nd += kf;
+                            }
+                            if (nd < 1 || nd > 15) { ok = false; break; }     // ('.' alone, or more digits than a double holds)
+                            const double d = (double)w / kP10[kf];
+                            x = (float)(neg ? -d : d);
+                        }
+                        reinterpret_cast<float*>(base)[(size_t)rec * S + s] = x;
+                    }
+                    got |= 1u << i;
+                } else {
+                    while (*c != ':' && *c != '\t' && *c != '\n' && *c != '\r') ++c;
+                }
+                if (*c == ':') {
+                    if (k == max_needed) break;          // the rest of the token is not needed
+                    ++c;
+                    ++k;
+                    continue;
+                }
+                if (*c == '\t' || c == end) break;
+                ok = false;                              // something the scan does not know (an exponent, a comma ...)
+                break;
+            }
+            if (ok) {
+                if (ph) ph[s] = phased ? 1 : 0;
+                maxpl = std::max(maxpl, j);
+                if (gtm && smap[s] >= 0)
+                    for (int jj = 0; jj < P; ++jj) gtm[(size_t)smap[s] * P + jj] = gt[(size_t)s * P + jj];
+                for (int i = 0; i < np; ++i)
+                    if (!((got >> i) & 1u)) {            // absent from FORMAT, or dropped at the end of the token
+                        char* base = static_cast<char*>(job.out->planes[i]);
+                        if (v->planes[i].kind == TRK_VCF_INT) reinterpret_cast<int32_t*>(base)[(size_t)rec * S + s] = INT_MISSING;
+                        else reinterpret_cast<float*>(base)[(size_t)rec * S + s] = NAN;
+                    }
+                const char* se = (*c == '\t' || c == end) ? c : find_ch(c, end, '\t');
+                if (se == end) {
+                    if (s + 1 < S) { job.error = 3; job.error_rec = rec; }
+                    break;
+                }
+                sp = se + 1;
+                continue;
+            }
+            for (int jj = 0; jj < P; ++jj) gt[(size_t)s * P + jj] = -2;      // the general code starts from padding
+        }
         const char* se = find_ch(sp, end, '\t');
         // subfield boundaries up to the last one we need
         int nsub = 0;
@@ -780,6 +945,7 @@ void parse_record(RecordJob& job, int rec) {
         }
         sp = se + 1;
     }
+#undef TRK_DIGIT
     job.out->locus_ploidy[rec] = (uint8_t)maxpl;
 }
 
@@ -797,7 +963,7 @@ int trk_vcf_open(const char* path, int n_threads, trk_vcf** out) {
     // costs more than the extra hands bring (a 50 MB batch parses in ~3 ms on 64 threads)
     if (n_threads <= 0)
         if (const char* e = getenv("TRK_VCF_THREADS")) n_threads = atoi(e);     // inflate / parse threads of a reader
-    if (n_threads <= 0) n_threads = std::min(64, (int)std::thread::hardware_concurrency());
+    if (n_threads <= 0) n_threads = default_threads(64);
     if (n_threads < 1) n_threads = 1;
     v->n_threads = n_threads;
     if (!v->src.open(path, n_threads, g_open_error)) {
@@ -1847,7 +2013,12 @@ void harmonize_one(const char* line, const int32_t* fo, int64_t line_len, int vc
 // Python's '{:.<p>}'.format(float): '%.<p>g' plus '.0' when the result looks like an integer
 inline void put_py_float(std::string& o, double v, int prec) {
     char tmp[64];
-    int n = snprintf(tmp, sizeof tmp, "%.*g", prec, v);
+    int n;
+    // "%.*g": to_chars(general, precision) is printf's %g by definition, without the format parsing and the locale
+    auto tr = std::isfinite(v) && prec > 0 && prec < 40 ? std::to_chars(tmp, tmp + sizeof tmp, v, std::chars_format::general, prec)
+                                                       : std::to_chars_result{tmp, std::errc::invalid_argument};
+    if (tr.ec == std::errc()) n = (int)(tr.ptr - tmp);
+    else n = snprintf(tmp, sizeof tmp, "%.*g", prec, v);
     o.append(tmp, (size_t)n);
     bool plain = true;
     for (int i = 0; i < n; ++i)
@@ -2073,10 +2244,11 @@ int64_t trk_vcf_statstr_rows(const trk_vcf_batch* b, const trk_vcf_harmonized* h
                         if (ul) put_np_float(o, h->len_class_value[off + k]);
                         else o.append(h->keys + h->key_off[off + k], (size_t)(h->key_off[off + k + 1] - h->key_off[off + k]));
                         o.push_back(':');
-                        int m;
-                        if (count) m = snprintf(tmp, sizeof tmp, "%lld", (long long)cc[(size_t)k]);
-                        else m = snprintf(tmp, sizeof tmp, "%.3f", (double)cc[(size_t)k] / (double)total);
-                        o.append(tmp, (size_t)m);
+                        // ('%.3f' and '%d' of the reference's format strings: to_chars(fixed, 3) is printf's %.3f)
+                        std::to_chars_result m = count ? std::to_chars(tmp, tmp + sizeof tmp, (long long)cc[(size_t)k])
+                                                       : std::to_chars(tmp, tmp + sizeof tmp, (double)cc[(size_t)k] / (double)total,
+                                                                       std::chars_format::fixed, 3);
+                        o.append(tmp, (size_t)(m.ptr - tmp));
                     }
                     if (!any) o.push_back('.');
                 };
@@ -2115,8 +2287,7 @@ int64_t trk_vcf_statstr_rows(const trk_vcf_batch* b, const trk_vcf_harmonized* h
         }
     };
     // (a row is ~25 us of number formatting: 17 000 rows on eight threads were 67 ms of statSTR's 0.34 s per GB of text)
-    const int hw = (int)std::thread::hardware_concurrency();
-    const int nt = std::max(1, std::min({32, hw > 0 ? hw : 8, n_chunks}));
+    const int nt = std::max(1, std::min(default_threads(32), n_chunks));
     std::vector<std::thread> th;
     for (int t = 1; t < nt; ++t) th.emplace_back(runner);
     runner();
@@ -3089,7 +3260,7 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
         std::vector<FmtChunk>& v;
         ~GiveBack() { for (auto& c : v) fmt_chunks().give(c); }
     } give_back{used_chunks};
-    int want = in->n_threads > 0 ? in->n_threads : 32;
+    int want = in->n_threads > 0 ? in->n_threads : default_threads(32);
     if (in->n_threads <= 0)
         if (const char* e = getenv("TRK_FMT_THREADS")) want = std::max(1, atoi(e));    // formatter threads (default 32)
     const int nt = std::max(1, std::min({want, 128, n}));
