@@ -424,7 +424,7 @@ int trk_locus_filters(trk_ctx* ctx, int32_t n_loci, const trk_stats_out* stats,
  * batches with more than TRK_ASSOC_MAX_VEC rows, and every design of 63 rows and more, are scanned pair of 15-row groups
  * by pair -- g(g-1)/2 passes for g = ceil(M / 15) groups -- and the whole design solved per locus by one wavefront
  * (two rows of the normal matrix per lane from 63 rows on; the bound is that tile's size in LDS).
- * trk_assoc_scan_dosage takes up to TRK_ASSOC_MAX_VEC rows.
+ * trk_assoc_scan_dosage takes up to TRK_ASSOC_MAX_VEC rows in one pass and up to TRK_ASSOC_MAX_VEC_WIDE pair of groups by pair.
  */
 #define TRK_ASSOC_MAX_VEC 31
 #define TRK_ASSOC_MAX_VEC_WIDE 126

@@ -272,6 +272,9 @@ def test_dosage_scan_against_oracle(eng):
     numpy's blocked float32 row sum), rounding collisions between alleles, sample subset, missing calls."""
     for seed, (L_, S, M, amax) in enumerate([(30, 300, 2, 4), (24, 257, 5, 14), (12, 128, 20, 3)]):
         run_dosage_case(eng, seed, L_, S, M, amax, min_ok=L_ // 3)
+    # more than 31 columns (round 4): pairs of 15-row groups through the same kernels, two rows per lane from 63 on
+    run_dosage_case(eng, 7, 16, 320, 40, 4, min_ok=4)
+    run_dosage_case(eng, 8, 12, 512, 70, 3, min_ok=3)
 
 
 def test_scans_on_two_queues_run_side_by_side(eng):

@@ -123,9 +123,10 @@ def _load_design(all_samples, trait_fnames, same_samples, sample_fname):
 def _device_vectors(sample_filter, covars, outcome, beagle_dosages=False):
     """[M, S] float64 for trk_assoc_params.vec: row 0 the outcome, rows 1.. the covariates; samples
     outside the regression set hold zeros (ignored on the device).  Up to 62 rows are scanned in one
-    pass, up to 126 as pairs of row groups (trk.h TRK_ASSOC_MAX_VEC_WIDE); --beagle-dosages: 31."""
+    pass, up to 126 as pairs of row groups (trk.h TRK_ASSOC_MAX_VEC_WIDE); --beagle-dosages: pairs of row groups
+    from 32 rows on."""
     S, M = len(sample_filter), covars.shape[1] - 1
-    limit = L.ASSOC_MAX_VEC if beagle_dosages else L.ASSOC_MAX_VEC_WIDE
+    limit = L.ASSOC_MAX_VEC_WIDE
     if M > limit:
         raise ValueError("associaTR: %d trait columns (phenotype + covariates); this build scans at most %d"
                          % (M, limit))

@@ -759,8 +759,8 @@ int trk_assoc_scan_dosage(trk_ctx* ctx, const trk_batch* in, const trk_assoc_par
     int rc = check_batch(ctx, in);
     if (rc) return rc;
     if (!prm || !out || !dos) return fail(ctx, TRK_ERR_ARG, "assoc params/outputs are NULL");
-    if (prm->n_vec < 1 || prm->n_vec > TRK_ASSOC_MAX_VEC)
-        return fail(ctx, TRK_ERR_ARG, "n_vec %d outside [1,%d]", prm->n_vec, TRK_ASSOC_MAX_VEC);
+    if (prm->n_vec < 1 || prm->n_vec > TRK_ASSOC_MAX_VEC_WIDE)
+        return fail(ctx, TRK_ERR_ARG, "n_vec %d outside [1,%d]", prm->n_vec, TRK_ASSOC_MAX_VEC_WIDE);
     if (in->n_loci == 0) return TRK_OK;
     if (!prm->vec || !prm->allele_len || !prm->rlen_class) return fail(ctx, TRK_ERR_ARG, "assoc inputs are NULL");
     if (!dos->ap1 || !dos->ap2 || !dos->perm || !dos->dclass || !dos->dclass_value || !dos->best_class)

@@ -2656,18 +2656,16 @@ hipError_t launch_assoc_finalize(const trk_batch& b, const trk_assoc_params& prm
     return f.wave_regress ? launch_regress_wave(f, stream) : hipSuccess;
 }
 
-hipError_t launch_assoc_dosage(const trk_batch& b, const trk_assoc_params& prm, const trk_assoc_dosage& dos,
-                               const trk_assoc_out& out, double* class_sums, double* locus_sums, void* workspace,
-                               hipStream_t stream) {
+// one pass of the dosage kernels over the batch for the design `prm` (at most AS_MAXV rows): records into `workspace`
+static hipError_t dosage_pass(const trk_batch& b, const trk_batch& bb, const trk_assoc_params& prm, const trk_assoc_dosage& dos,
+                              const trk_assoc_out& out, double* class_sums, double* locus_sums, void* workspace,
+                              hipStream_t stream) {
     AssocPlan p;
     AssocArgs a;
     FinArgs f;
     double* full;
-    trk_batch bb = b;
-    bb.max_alleles = 0;  // plan: the generic record layout (one chunk, no LDS-resident vectors)
     assoc_build(bb, prm, out, workspace, p, a, f, full);
     a.b = b;
-    f.b = b;
     hipError_t err;
     if ((err = hipMemsetAsync(a.work_counter, 0, 1024, stream)) != hipSuccess) return err;
     if (b.n_alleles_total > 0) {
@@ -2688,13 +2686,87 @@ hipError_t launch_assoc_dosage(const trk_batch& b, const trk_assoc_params& prm, 
     }
     else
         hipLaunchKernelGGL(k_assoc_dosage, dim3((b.n_loci + 3) / 4), dim3(256), 0, stream, a, q);
-    if ((err = hipGetLastError()) != hipSuccess) return err;
+    return hipGetLastError();
+}
+
+hipError_t launch_assoc_dosage(const trk_batch& b, const trk_assoc_params& prm, const trk_assoc_dosage& dos,
+                               const trk_assoc_out& out, double* class_sums, double* locus_sums, void* workspace,
+                               hipStream_t stream) {
+    AssocPlan p;
+    AssocArgs a;
+    FinArgs f;
+    double* full;
+    trk_batch bb = b;
+    bb.max_alleles = 0;  // plan: the generic record layout (one chunk, no LDS-resident vectors)
+    assoc_build(bb, prm, out, workspace, p, a, f, full);
+    f.b = b;
+    hipError_t err;
+    const int M = prm.n_vec, S = b.n_samples;
+    if (M <= AS_MAXV) {
+        if ((err = dosage_pass(b, bb, prm, dos, out, class_sums, locus_sums, workspace, stream)) != hipSuccess) return err;
+    } else {
+        // wide designs (round 4): pair of 15-row groups by pair through the same kernels, as launch_assoc_scan_wide
+        // does for the genotype scan (the dosages, the class and locus sums are the same in every pass)
+        unsigned char* sub_ws = static_cast<unsigned char*>(workspace) + ((assoc_ws_one(bb, M) + 255) & ~(size_t)255);
+        double* sub_vec = reinterpret_cast<double*>(sub_ws + ((assoc_ws_one(bb, 2 * AW_GROUP) + 255) & ~(size_t)255));
+        int32_t* sub_cnt = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(sub_vec) + wide_vec_bytes(bb));
+        const int ng = (M + AW_GROUP - 1) / AW_GROUP;
+        bool first = true;
+        for (int ga = 0; ga < ng; ++ga)
+            for (int gb = ga + 1; gb < ng; ++gb) {
+                const int a0 = ga * AW_GROUP, na = AW_GROUP;
+                const int b0 = gb * AW_GROUP, nb = (M - b0 < AW_GROUP) ? M - b0 : AW_GROUP;
+                const int m = na + nb;
+                if ((err = hipMemcpyAsync(sub_vec, prm.vec + (size_t)a0 * S, (size_t)na * S * 8, hipMemcpyDeviceToDevice,
+                                          stream)) != hipSuccess)
+                    return err;
+                if ((err = hipMemcpyAsync(sub_vec + (size_t)na * S, prm.vec + (size_t)b0 * S, (size_t)nb * S * 8,
+                                          hipMemcpyDeviceToDevice, stream)) != hipSuccess)
+                    return err;
+                trk_assoc_params sp = prm;
+                sp.n_vec = m;
+                sp.vec = sub_vec;
+                trk_assoc_out so = out;
+                if (!first) so.allele_count = sub_cnt;
+                if ((err = dosage_pass(b, bb, sp, dos, so, class_sums, locus_sums, sub_ws, stream)) != hipSuccess) return err;
+                if (b.n_loci == 0) continue;
+                AssocPlan q;
+                AssocArgs sa;
+                FinArgs sf;
+                double* sfull;
+                assoc_build(bb, sp, so, sub_ws, q, sa, sf, sfull);
+                WideArgs w{};
+                w.sub_partial = sa.partial;
+                w.sub_full = sfull;
+                w.partial = a.partial;
+                w.full = full;
+                w.L = b.n_loci;
+                w.m = m;
+                w.ns = sa.NS;
+                w.nc = sa.NC;
+                w.nchunks = q.nchunks;
+                w.M = M;
+                w.NS = a.NS;
+                w.first = first ? 1 : 0;
+                for (int r = 0; r < na; ++r) w.row[r] = (uint8_t)(a0 + r);
+                for (int r = 0; r < nb; ++r) w.row[na + r] = (uint8_t)(b0 + r);
+                w.row[m] = (uint8_t)M;
+                for (int e = 0; e < sa.NC; ++e) {
+                    w.pa[e] = sa.pa[e];
+                    w.pb[e] = sa.pb[e];
+                }
+                hipLaunchKernelGGL(k_assoc_wide_gather, dim3(b.n_loci + 1), dim3(256), 0, stream, w);
+                if ((err = hipGetLastError()) != hipSuccess) return err;
+                first = false;
+            }
+    }
+    if (b.n_loci == 0) return hipSuccess;
     f.dosage = 1;
     f.cc_lds = f.cc_lds_off = 0;
-    const int P = prm.n_vec + 1;
+    const int P = M + 1;
     int fin_t = FIN_T;
-    while (fin_t > 8 && (size_t)(P * (P + 1) / 2 + P) * fin_t * 8 > 150 * 1024) fin_t >>= 1;
-    const size_t fin_lds = (size_t)(P * (P + 1) / 2 + P) * fin_t * 8;
+    while (fin_t > 8 && !f.wave_regress && (size_t)(P * (P + 1) / 2 + P) * fin_t * 8 > 150 * 1024) fin_t >>= 1;
+    const size_t fin_lds = f.wave_regress ? 0 : (size_t)(P * (P + 1) / 2 + P) * fin_t * 8;   // (the normal matrix lives in k_assoc_regress_wave)
     if ((err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assoc_finalize),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds)) != hipSuccess)
         return err;
