@@ -3825,7 +3825,13 @@ static CfLaunch cf_geometry(int L, int gx, int lpb_cap, int n_cu, int occ) {
     if (pr < 1) pr = 1;
     const long lpr = (L + pr - 1) / pr;             // loci per range
     int lpb, walk;
-    if (lpr >= 2L * lpb_cap && !getenv("TRK_CF_NO_PERSIST")) {
+    // persistent ranges from 24 loci per range on (round 4, second half: was two full blocks).  A strong-scaling shard of
+    // 12.5k loci used to launch 2560 workgroups of one block each and filled every slot of the chip; 960 persistent ones
+    // run the pass in the same time and leave the step's finalisers and HWE tests on the other queues a slot per CU:
+    // 0.66 -> 0.58 ms per step at 12.5k x 10k (tools/shard_probe.py, r04_notes section 14).  TRK_CF_PERSIST_MIN moves it.
+    long persist_min = 24;
+    if (const char* e = getenv("TRK_CF_PERSIST_MIN")) persist_min = atol(e) > 0 ? atol(e) : persist_min;
+    if (lpr >= persist_min && !getenv("TRK_CF_NO_PERSIST")) {
         walk = (int)((lpr + lpb_cap - 1) / lpb_cap);
         lpb = (int)((lpr + walk - 1) / walk);
     } else {
