@@ -955,6 +955,10 @@ int trk_dev_alloc_pair(trk_ctx* ctx, size_t bytes_each, int64_t n_loci, int64_t 
             if (*q == ',') ++q;
         }
     }
+    // planes below 1 GB (a strong-scaling shard's): the neighbouring candidates only.  At 0.5 GB the candidates of one
+    // process came out within 4 % of each other six times out of six (profiles/r04_bench_final.json, extras.strong_shard)
+    // and a jump's spacers are 300 times the plane
+    if (bytes_each < ((size_t)1 << 30) && !getenv("TRK_PLACE_JUMP_SMALL")) max_jumps = 0;
     size_t jump_bytes = max_jumps > 0 ? jumps[0] : 0;
     const double gbytes = 2.0 * (double)n_loci * (double)n_samples * 4.0 * 1e-9;
     int rc = TRK_OK;
