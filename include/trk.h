@@ -524,6 +524,43 @@ enum { TRK_DOS_BESTGUESS = 0, TRK_DOS_BEAGLEAP = 1, TRK_DOS_BESTGUESS_NORM = 2, 
 int trk_dosages(trk_ctx* ctx, const trk_batch* in, const double* allele_len, int dosage_type, const float* ap1,
                 const float* ap2, int n_alt_cols, float* out, int32_t* locus_err);
 
+/* ---- the sample columns of a batch of VCF records, parsed on the device (round 4; SURVEY.md section 8(f1) widened) ----
+ * Replaces the per-sample half of the native reader's parse (trk_vcf_read_batch: cyvcf2's genotype.array() and
+ * format(key) of the reference's record loop, tr_harmonizer.py:1420-1499 / dumpSTR.py:613-700) for callers that bring
+ * the batch's TEXT to the device instead of its decoded arrays: the genotype tensor and up to four scalar FORMAT planes
+ * come into being in HBM.  The host still finds the lines, the nine fixed columns and the FORMAT keys (trk_vcf.h).
+ * Grammar per token: alleles '.' or at most four digits separated by '/' or '|'; Integer planes -?d{1,9} or '.';
+ * Float planes -?d*(.d*)? of at most fifteen digits or '.', value = the correctly rounded float64 of the decimal cast to
+ * float32 (what strtod + a cast give).  Anything else -- exponents, vectors, inf / nan, signs on alleles -- sets
+ * TRK_PARSE_HOST in the record's flag: the rows of that record are undefined and the caller parses it with the host
+ * code.  Subfields a token does not hold are missing values (INT32_MIN / NaN), alleles beyond a call's own are -2.     */
+#define TRK_PARSE_MAX_PLANES 4
+enum { TRK_PARSE_INT = 0, TRK_PARSE_FLOAT = 1 };
+enum {
+    TRK_PARSE_HOST = 1,    /* a token outside the device grammar: parse this record on the host              */
+    TRK_PARSE_COLUMNS = 2, /* not n_samples sample columns (the reader's error 3)                            */
+    TRK_PARSE_PLOIDY = 4   /* a call with more alleles than `ploidy` (the reader's error 2)                  */
+};
+typedef struct {
+    const uint8_t* text;     /* device, 16-byte aligned; readable up to the 16-byte chunk that holds the last line_end */
+    int64_t n_bytes;
+    int32_t n_records, n_samples, ploidy;
+    int32_t n_planes;        /* <= TRK_PARSE_MAX_PLANES */
+    const int64_t* smp_off;  /* device [n_records]: offset in text of the record's first sample token (field_off[9])      */
+    const int64_t* line_end; /* device [n_records]: offset of the record's newline ('\n' or '\r': it must be there)       */
+    const int8_t* gt_idx;    /* device [n_records]: index of GT among the record's FORMAT keys, -1: none                 */
+    const int8_t* plane_idx[TRK_PARSE_MAX_PLANES];   /* device [n_records] each: index of plane k's key, -1: absent      */
+    int32_t plane_kind[TRK_PARSE_MAX_PLANES];        /* TRK_PARSE_INT / TRK_PARSE_FLOAT                                   */
+} trk_parse_in;
+typedef struct {
+    int16_t* gt;           /* device [n_records, n_samples, ploidy]                       */
+    uint8_t* phased;       /* optional device [n_records, n_samples]: some '|' in the call */
+    void* planes[TRK_PARSE_MAX_PLANES];   /* device [n_records, n_samples] int32 / float32 */
+    uint8_t* locus_ploidy; /* device [n_records]: the most alleles a call of the record holds (>= 1) */
+    uint8_t* flags;        /* device [n_records]: 0 or TRK_PARSE_* bits                    */
+} trk_parse_out;
+int trk_parse_samples(trk_ctx* ctx, const trk_parse_in* in, trk_parse_out* out);
+
 /* ---- qcSTR's reductions (trtools/qcSTR/qcSTR.py:529-561, 619-621) ----------------
  * One pass over the genotype tensor and (optionally) the FORMAT quality plane of a batch:
  *   a sample's entry at a locus is a CALL unless every haplotype index of the record is -1 (qcSTR.py:533-535 --

@@ -95,6 +95,22 @@ int trk_vcf_set_sample_map(trk_vcf* v, const int32_t* map, int32_t n_out);
 /* Decode up to max_records records.  Returns 0, or a non-zero code with trk_vcf_last_error(). */
 int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batch* out);
 
+/* Round 4: the sample columns left to the caller.  With trk_vcf_skip_samples(v, 1) trk_vcf_read_batch finds the lines,
+ * the fixed columns and the FORMAT keys of every record and stops there: gt / phased / locus_ploidy / planes / gt_mapped
+ * are NOT written.  trk_vcf_format_idx returns [n_records][stride] int8, stride = 1 + selected planes: the index of GT,
+ * then of every selected plane's key, among the record's FORMAT keys (-1: absent) -- what trk_parse_samples
+ * (include/trk.h) needs beside the text and the offsets to parse the sample columns on the device; valid as long as the
+ * batch's line tables.  trk_vcf_parse_samples fills the arrays of the batch just read on the host after all (the
+ * fallback for records the device flags; errors as trk_vcf_read_batch's). */
+int trk_vcf_skip_samples(trk_vcf* v, int on);
+/* The reader's two text buffers continue in the caller's memory, `cap_each` bytes each (pinned pages, so that the upload
+ * of a batch's text is a plain DMA).  Between two batches only: the text of the batch read last moves (its pointers go
+ * stale).  The memory stays the caller's: never freed or reallocated here; a batch that outgrows it moves the reader back
+ * to memory of its own.  0: done (or already so); 1: the bytes held now do not fit. */
+int trk_vcf_set_text_buffers(trk_vcf* v, void* a, void* b, size_t cap_each);
+const int8_t* trk_vcf_format_idx(trk_vcf* v, int32_t* stride);
+int trk_vcf_parse_samples(trk_vcf* v, trk_vcf_batch* b);
+
 /* ---- record serialisation ---------------------------------------------------------------
  * what the reference gets from cyvcf2.Writer.write_record (htslib's
  * vcf_format) for the records dumpSTR rewrites (dumpSTR.py:684, 721-746, 1338).  The per-sample

@@ -455,3 +455,41 @@ def test_fast_sample_scan_on_every_spelling(tmp_path):
             continue
         assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[3] == y[3]
         assert np.array_equal(x[2].view(np.uint32), y[2].view(np.uint32))          # floats bit for bit (signed zeros, NaN)
+
+
+def test_text_buffers_in_the_callers_memory(tmp_path):
+    """trk_vcf_set_text_buffers (round 4: pinned pages for the upload of a batch's text): the reader moves into the
+    caller's memory between two batches and reads on -- same records; buffers too small for the bytes held are refused,
+    a later batch that outgrows them moves the reader back to memory of its own."""
+    import ctypes as C
+    from trtools_amd import vcfnative
+    src = os.path.join(GOLDEN, 'dumpstr_synth', 'synth_hipstr.vcf')
+
+    def lines_of(r, hook=None):
+        out = []
+        k = 0
+        while True:
+            rb = r.read_raw_batch(7)
+            if rb.n == 0:
+                break
+            out += [C.string_at(rb.b.text + rb.b.line_off[l], rb.b.line_end[l] - rb.b.line_off[l]) for l in range(rb.n)]
+            out.append(rb.gt.copy().tobytes())
+            k += 1
+            if hook:
+                hook(r, k)
+        return out
+    want = lines_of(vcfnative.NativeVCFReader(src))
+    for cap in (1 << 20, 1 << 14):          # roomy; smaller than the file's later needs (the reader moves out again)
+        bufs = [np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)]
+        rcs = []
+
+        def hook(r, k):
+            if k == 2:
+                rcs.append(r._lib.trk_vcf_set_text_buffers(r._h, bufs[0].ctypes.data, bufs[1].ctypes.data, cap))
+        got = lines_of(vcfnative.NativeVCFReader(src), hook)
+        assert got == want and rcs and rcs[0] in (0, 1)
+    tiny = [np.zeros(16, np.uint8), np.zeros(16, np.uint8)]
+    r = vcfnative.NativeVCFReader(src)
+    r.read_raw_batch(3)
+    assert r._lib.trk_vcf_set_text_buffers(r._h, tiny[0].ctypes.data, tiny[1].ctypes.data, 16) == 1
+    assert r.read_raw_batch(3).n == 3

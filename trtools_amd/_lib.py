@@ -113,6 +113,23 @@ class AssocOut(C.Structure):
     _fields_ = [('locus_int', C.c_void_p), ('locus_f64', C.c_void_p), ('allele_count', C.c_void_p)]
 
 
+# trk_parse_samples (include/trk.h): the sample columns of a batch of records parsed on the device
+PARSE_MAX_PLANES = 4
+PARSE_INT, PARSE_FLOAT = 0, 1
+PARSE_HOST, PARSE_COLUMNS, PARSE_PLOIDY = 1, 2, 4
+
+
+class ParseIn(C.Structure):
+    _fields_ = [('text', C.c_void_p), ('n_bytes', C.c_int64), ('n_records', C.c_int32), ('n_samples', C.c_int32),
+                ('ploidy', C.c_int32), ('n_planes', C.c_int32), ('smp_off', C.c_void_p), ('line_end', C.c_void_p),
+                ('gt_idx', C.c_void_p), ('plane_idx', C.c_void_p * PARSE_MAX_PLANES), ('plane_kind', C.c_int32 * PARSE_MAX_PLANES)]
+
+
+class ParseOut(C.Structure):
+    _fields_ = [('gt', C.c_void_p), ('phased', C.c_void_p), ('planes', C.c_void_p * PARSE_MAX_PLANES),
+                ('locus_ploidy', C.c_void_p), ('flags', C.c_void_p)]
+
+
 # associaTR scan: trk_assoc_out columns / status codes (include/trk.h)
 ASSOC_MAX_VEC = 31        # one pass over the genotype tensor
 ASSOC_MAX_VEC_WIDE = 126  # trk_assoc_scan: one MFMA pass up to 62 rows, pairs of 15-row groups beyond (TRK_ASSOC_MAX_VEC_WIDE)
@@ -147,7 +164,7 @@ EXPORTS = [
     'trk_locus_stats', 'trk_locus_finalize', 'trk_call_filters', 'trk_locus_filters',
     'trk_comm_unique_id', 'trk_comm_init', 'trk_allreduce_sum_i64', 'trk_allgather',
     'trk_binomtest_two_sided', 'trk_binom_pmf', 'trk_binomtest_batch', 'trk_synth_fill', 'trk_synth_fill_gangstr',
-    'trk_assoc_scan', 'trk_assoc_scan_dosage', 'trk_student_t_two_sided', 'trk_dosages', 'trk_qc_reduce', 'trk_planarize', 'trk_pad_rows', 'trk_permute_columns', 'trk_stream_probe', 'trk_device_clocks', 'trk_stream_select', 'trk_stream_wait',
+    'trk_assoc_scan', 'trk_assoc_scan_dosage', 'trk_student_t_two_sided', 'trk_dosages', 'trk_qc_reduce', 'trk_parse_samples', 'trk_planarize', 'trk_pad_rows', 'trk_permute_columns', 'trk_stream_probe', 'trk_device_clocks', 'trk_stream_select', 'trk_stream_wait',
     'trk_host_alloc', 'trk_host_free', 'trk_memcpy_h2d_async', 'trk_memcpy_d2h_async', 'trk_queue_sync', 'trk_exchange', 'trk_event_record', 'trk_event_wait',
 ]
 
@@ -160,7 +177,7 @@ class TrkError(RuntimeError):
 
 # the sources libtrk.so is built from, in the order csrc/Makefile hashes them
 _SOURCES = ['csrc/trk_api.hip', 'csrc/trk_assoc.hip', 'csrc/trk_binom.h', 'csrc/trk_internal.h', 'csrc/trk_kernels.hip',
-            'csrc/trk_qc.hip', 'csrc/trk_student.h', 'csrc/trk_vcf.cpp', '../include/trk.h', '../include/trk_test.h', '../include/trk_vcf.h']
+            'csrc/trk_parse.hip', 'csrc/trk_qc.hip', 'csrc/trk_student.h', 'csrc/trk_vcf.cpp', '../include/trk.h', '../include/trk_test.h', '../include/trk_vcf.h']
 
 
 def source_digest():
@@ -279,6 +296,7 @@ def load():
     lib.trk_stream_wait.argtypes = [vp, C.c_int, C.c_int]
     lib.trk_dosages.argtypes = [vp, P(Batch), vp, C.c_int, vp, vp, C.c_int, vp, vp]
     lib.trk_qc_reduce.argtypes = [vp, P(Batch), P(QcParams), P(QcOut)]
+    lib.trk_parse_samples.argtypes = [vp, P(ParseIn), P(ParseOut)]
     lib.trk_student_t_two_sided.argtypes = [dbl, dbl]
     lib.trk_student_t_two_sided.restype = dbl
     lib.trk_synth_fill.argtypes = [vp, P(SynthSpec), vp, vp, vp, vp, vp]

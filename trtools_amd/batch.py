@@ -34,7 +34,10 @@ class HostBatch:
         (allele_lens, allele_strs) for the few users that want the per-locus Python lists (the oracle-backed
         compute stand-in of the tests)."""
         hb = cls.__new__(cls)
-        hb.gt = gt if (gt.dtype == np.int16 and gt.flags['C_CONTIGUOUS']) else np.ascontiguousarray(gt, dtype=np.int16)
+        if not isinstance(gt, np.ndarray) and hasattr(gt, 'ptr'):
+            hb.gt = gt                        # an engine.DeviceArray: the tensor was parsed on the device (trk_parse_samples)
+        else:
+            hb.gt = gt if (gt.dtype == np.int16 and gt.flags['C_CONTIGUOUS']) else np.ascontiguousarray(gt, dtype=np.int16)
         hb.n_loci, hb.n_samples, hb.ploidy = hb.gt.shape
         hb.locus_ploidy = np.ascontiguousarray(locus_ploidy, dtype=np.uint8)
         hb.allele_off, hb.len_class, hb.str_class, hb.len_class_value = allele_off, len_class, str_class, len_class_value

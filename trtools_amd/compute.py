@@ -110,7 +110,9 @@ class DeviceCompute:
         if n_pad and gb is not None:
             gb = self._pad(gb, n_pad, 0, 0)          # padding samples belong to no group
         # (the padding columns are appended on the device: no host copy of the tensor)
-        gt_d = self.eng.pad_samples(self.eng.upload(hb.gt, np.int16), n_pad)
+        # (a genotype tensor that is on the device already -- parsed there, trk_parse_samples -- is taken over as it is)
+        from .engine import DeviceArray
+        gt_d = self.eng.pad_samples(hb.gt if isinstance(hb.gt, DeviceArray) else self.eng.upload(hb.gt, np.int16), n_pad)
         return self.eng.make_batch(gt_d, hb.allele_off, hb.len_class, hb.str_class,
                                    hb.len_class_value, locus_ploidy=lp, group_bits=gb,
                                    n_groups=hb.n_groups, max_alleles=hb.max_alleles, n_pad=n_pad)
@@ -146,7 +148,9 @@ class DeviceCompute:
         b = self._upload(hb, rows=True)
         S = hb.gt.shape[1]
         n_pad = b.struct.n_samples - S      # the padding samples' FORMAT values are missing like their genotypes
-        dplanes = [eng.upload_plane(p, n_pad=n_pad) for p in planes]
+        # (planes that are on the device already -- parsed there, trk_parse_samples -- are taken over, padded on the device)
+        from .engine import DeviceArray
+        dplanes = [eng.pad_samples(p, n_pad) if isinstance(p, DeviceArray) else eng.upload_plane(p, n_pad=n_pad) for p in planes]
         # counts of the unfiltered genotypes, corrected by the call-filter kernel for every call it
         # masks (dumpSTR.py:721-774 rebuilds the record; here no second pass over the tensor), then
         # the finaliser
@@ -161,7 +165,7 @@ class DeviceCompute:
             ext = eng.upload(np.ascontiguousarray(ext_host, dtype=np.uint32))
         bits, counters = eng.locus_filters(hb.n_loci, st, extern_bits=ext, **spec)
         totaldp = call.sample_totaldp.get()
-        if dp_plane >= 0 and np.asarray(planes[dp_plane]).dtype.kind == 'f':
+        if dp_plane >= 0 and np.dtype(planes[dp_plane].dtype).kind == 'f':
             totaldp = call.sample_totaldp_f64.get()      # Float depth plane (ExpansionHunter's LC)
         ch = CallHost(None if compact else call.gt_out.get()[:, :S],
                       call.filter_mask8.get()[:, :S] if compact else call.filter_mask.get()[:, :S],

@@ -828,6 +828,26 @@ int trk_qc_reduce(trk_ctx* ctx, const trk_batch* in, const trk_qc_params* prm, t
     return TRK_OK;
 }
 
+int trk_parse_samples(trk_ctx* ctx, const trk_parse_in* in, trk_parse_out* out) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (!in || !out) return fail(ctx, TRK_ERR_ARG, "parse_samples: arguments are NULL");
+    if (in->n_records < 0 || in->n_samples < 0 || in->ploidy < 1 || in->n_planes < 0 || in->n_planes > TRK_PARSE_MAX_PLANES)
+        return fail(ctx, TRK_ERR_ARG, "parse_samples: records %d, samples %d, ploidy %d, planes %d", in->n_records, in->n_samples,
+                    in->ploidy, in->n_planes);
+    if (in->n_records == 0 || in->n_samples == 0) return TRK_OK;
+    if (!in->text || ((uintptr_t)in->text & 15u) || !in->smp_off || !in->line_end || !out->gt || !out->locus_ploidy || !out->flags)
+        return fail(ctx, TRK_ERR_ARG, "parse_samples: text (16-byte aligned), offsets, gt, locus_ploidy and flags are required");
+    for (int i = 0; i < in->n_planes; ++i) {
+        if (!in->plane_idx[i] || !out->planes[i]) return fail(ctx, TRK_ERR_ARG, "parse_samples: plane %d is NULL", i);
+        if (in->plane_kind[i] != TRK_PARSE_INT && in->plane_kind[i] != TRK_PARSE_FLOAT)
+            return fail(ctx, TRK_ERR_ARG, "parse_samples: plane %d kind %d", i, in->plane_kind[i]);
+    }
+    (void)hipSetDevice(ctx->device);
+    ProfScope ps(ctx, TRK_K_SYNTH);      // (the "generate the inputs" slot of the profile)
+    HIPCHK(ctx, trk::launch_parse_samples(*in, *out, ctx->s()));
+    return TRK_OK;
+}
+
 int trk_planarize(trk_ctx* ctx, const void* src, void* dst, int64_t n_cells, int32_t ncol) {
     if (!ctx) return TRK_ERR_ARG;
     if (!src || !dst || n_cells < 0 || ncol < 1) return fail(ctx, TRK_ERR_ARG, "planarize arguments");

@@ -64,5 +64,6 @@ size_t qc_workspace_bytes(const trk_batch& b, const float* quality, int n_cu);
 hipError_t launch_qc_reduce(const trk_batch& b, const trk_qc_params& prm, const trk_qc_out& out, void* workspace,
                             int n_cu, hipStream_t stream);
 
+hipError_t launch_parse_samples(const trk_parse_in& in, const trk_parse_out& out, hipStream_t stream);
 }  // namespace trk
 #endif

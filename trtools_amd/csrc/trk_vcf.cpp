@@ -39,6 +39,28 @@ std::string g_open_error;
 class TextBuf {
     char* p_ = nullptr;
     size_t n_ = 0, cap_ = 0;
+    bool ext_ = false;      // the memory is the caller's (adopt(): pinned pages for the upload of the text): never freed,
+                            // never reallocated, never cached here; growing beyond it moves the bytes to memory of our own
+    void drop() {           // let go of the current memory
+        if (ext_ || !p_) {
+            p_ = nullptr;
+        } else if (cap_ >= kCacheMin) {
+            Cache& c = cache();
+            std::lock_guard<std::mutex> g(c.m);
+            if (c.bytes + cap_ <= c.limit) {
+                c.free_list.emplace_back(p_, cap_);
+                c.bytes += cap_;
+            } else {
+                free(p_);
+            }
+            p_ = nullptr;
+        } else {
+            free(p_);
+            p_ = nullptr;
+        }
+        cap_ = 0;
+        ext_ = false;
+    }
 
     // Big buffers are kept for the next reader of the process instead of going back to the C library: giving ~500 MB
     // of huge-page text back is 50 ms of trk_vcf_close after a 1 GB file (and the next reader faults the same pages
@@ -63,18 +85,20 @@ public:
     TextBuf() = default;
     TextBuf(const TextBuf&) = delete;
     TextBuf& operator=(const TextBuf&) = delete;
-    ~TextBuf() {
-        if (p_ && cap_ >= kCacheMin) {
-            Cache& c = cache();
-            std::lock_guard<std::mutex> g(c.m);
-            if (c.bytes + cap_ <= c.limit) {
-                c.free_list.emplace_back(p_, cap_);
-                c.bytes += cap_;
-                return;
-            }
-        }
-        free(p_);
+    ~TextBuf() { drop(); }
+    // continue in the caller's memory [q, q + cap): the bytes held now are copied over (false, nothing changed: they do not fit)
+    bool adopt(char* q, size_t cap) {
+        if (!q || n_ > cap) return false;
+        if (n_) memcpy(q, p_, n_);
+        const size_t n = n_;
+        drop();
+        p_ = q;
+        cap_ = cap;
+        n_ = n;
+        ext_ = true;
+        return true;
     }
+    bool external() const { return ext_; }
     size_t size() const { return n_; }
     size_t capacity() const { return cap_; }
     const char* data() const { return p_; }
@@ -83,6 +107,18 @@ public:
     const char& operator[](size_t i) const { return p_[i]; }
     void reserve(size_t c) {
         if (c <= cap_) return;
+        if (ext_) {                       // the caller's memory is too small after all: move to memory of our own
+            char* old = p_;
+            const size_t n = n_;
+            p_ = nullptr;
+            cap_ = 0;
+            ext_ = false;
+            n_ = 0;
+            reserve(c);
+            if (n) memcpy(p_, old, n);
+            n_ = n;
+            return;
+        }
         if (!p_ && c >= kCacheMin) {      // a buffer a closed reader left behind, the largest one
             Cache& ch = cache();
             std::lock_guard<std::mutex> g(ch.m);
@@ -142,6 +178,7 @@ public:
         std::swap(p_, o.p_);
         std::swap(n_, o.n_);
         std::swap(cap_, o.cap_);
+        std::swap(ext_, o.ext_);
     }
 };
 
@@ -584,7 +621,13 @@ struct trk_vcf {
     struct Kept {
         std::vector<int64_t> line_off, line_end;
         std::vector<int32_t> field_off;
+        std::vector<int8_t> fmt_idx;
     } kept[2];
+    // trk_vcf_skip_samples: read_batch stops a record at its FORMAT keys -- the caller parses the sample columns itself
+    // (on the device: trk_parse_samples, include/trk.h) or asks for them later (trk_vcf_parse_samples).  fmt_idx
+    // [n_records][1 + planes]: index of GT, then of every selected plane's key, among the record's FORMAT keys.
+    bool skip_samples = false;
+    std::vector<int8_t> fmt_idx;
     int kept_i = 0;
     int n_threads = 1;
     // contiguous shard of the file (trk_vcf_shard)
@@ -688,6 +731,11 @@ struct RecordJob {
     const char* text;
     int S, P;
     trk_vcf_batch* out;
+    const int64_t* line_off;
+    const int64_t* line_end;
+    int32_t* field_off;
+    int8_t* fmt_idx = nullptr;     // [n][1 + planes] (skip_samples)
+    bool samples = true;           // false: stop at the FORMAT keys
     std::atomic<int> error{0};
     std::atomic<int> error_rec{-1};   // a record the error was met in
 };
@@ -695,9 +743,9 @@ struct RecordJob {
 void parse_record(RecordJob& job, int rec) {
     trk_vcf* v = job.v;
     const int S = job.S, P = job.P;
-    const char* line = job.text + v->line_off[rec];
-    const char* end = job.text + v->line_end[rec];
-    int32_t* foff = &v->field_off[(size_t)rec * 10];
+    const char* line = job.text + job.line_off[rec];
+    const char* end = job.text + job.line_end[rec];
+    int32_t* foff = &job.field_off[(size_t)rec * 10];
     const char* p = line;
     for (int k = 0; k < 10; ++k) {
         foff[k] = (int32_t)(p - line);
@@ -711,14 +759,15 @@ void parse_record(RecordJob& job, int rec) {
     }
     int16_t* gt = job.out->gt + (size_t)rec * S * P;
     uint8_t* ph = job.out->phased ? job.out->phased + (size_t)rec * S : nullptr;
-    for (size_t i = 0; i < (size_t)S * P; ++i) gt[i] = -2;
+    if (job.samples)
+        for (size_t i = 0; i < (size_t)S * P; ++i) gt[i] = -2;
     // the same genotypes a second time with the samples in the caller's column order (trk_vcf_set_sample_map):
     // columns no sample maps to are no-calls
     const int32_t* smap = (job.out->gt_mapped && !v->sample_map.empty()) ? v->sample_map.data() : nullptr;
     int16_t* gtm = smap ? job.out->gt_mapped + (size_t)rec * v->map_out * P : nullptr;
-    if (gtm)
+    if (gtm && job.samples)
         for (size_t i = 0; i < (size_t)v->map_out * P; ++i) gtm[i] = -1;
-    if (ph) memset(ph, 0, (size_t)S);
+    if (ph && job.samples) memset(ph, 0, (size_t)S);
     const int np = (int)v->planes.size();
     // FORMAT keys -> subfield index of GT and of every selected plane's inputs
     const char* fmt = line + foff[8];
@@ -746,6 +795,12 @@ void parse_record(RecordJob& job, int rec) {
             a = b + 1;
         }
     }
+    if (job.fmt_idx) {
+        int8_t* fi = job.fmt_idx + (size_t)rec * (size_t)(1 + np);
+        fi[0] = (int8_t)(gt_idx > 126 ? -1 : gt_idx);
+        for (int i = 0; i < np; ++i) fi[1 + i] = (int8_t)(pidx[i] > 126 ? -1 : pidx[i]);
+    }
+    if (!job.samples) return;
     int max_needed = gt_idx;
     for (int i = 0; i < np; ++i) max_needed = std::max(max_needed, std::max(pidx[i], pidx2[i]));
     int maxpl = 1;
@@ -1368,6 +1423,12 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
     job.S = S;
     job.P = max_ploidy;
     job.out = out;
+    job.line_off = v->line_off.data();
+    job.line_end = v->line_end.data();
+    job.field_off = v->field_off.data();
+    job.samples = !v->skip_samples;
+    v->fmt_idx.assign(v->skip_samples ? (size_t)n * (1 + v->planes.size()) : 0, (int8_t)-1);
+    job.fmt_idx = v->skip_samples ? v->fmt_idx.data() : nullptr;
     std::atomic<int> next{0};
     auto runner = [&]() {
         for (;;) {
@@ -1408,11 +1469,76 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
     kp.line_off.swap(v->line_off);
     kp.line_end.swap(v->line_end);
     kp.field_off.swap(v->field_off);
+    kp.fmt_idx.swap(v->fmt_idx);
     out->n_records = n;
     out->text = v->buf.data();
     out->line_off = kp.line_off.data();
     out->line_end = kp.line_end.data();
     out->field_off = kp.field_off.data();
+    return 0;
+}
+
+// The reader's two text buffers continue in the caller's memory (pinned pages: the batch's text is uploaded by plain DMA).
+// Call between two batches, when the previous batch's text is no longer needed: its bytes move.
+int trk_vcf_set_text_buffers(trk_vcf* v, void* a, void* b, size_t cap_each) {
+    if (!v || !a || !b || cap_each == 0) return 2;
+    if (v->buf.external() || v->prev_text.external()) return 0;
+    if (v->buf.size() > cap_each || v->prev_text.size() > cap_each) return 1;
+    v->buf.adopt(static_cast<char*>(a), cap_each);
+    v->prev_text.adopt(static_cast<char*>(b), cap_each);
+    return 0;
+}
+
+int trk_vcf_skip_samples(trk_vcf* v, int on) {
+    if (!v) return 2;
+    v->skip_samples = on != 0;
+    return 0;
+}
+
+const int8_t* trk_vcf_format_idx(trk_vcf* v, int32_t* stride) {
+    if (!v) return nullptr;
+    if (stride) *stride = 1 + (int32_t)v->planes.size();
+    const trk_vcf::Kept& kp = v->kept[v->kept_i];
+    return kp.fmt_idx.empty() ? nullptr : kp.fmt_idx.data();
+}
+
+// the half of the last batch that trk_vcf_skip_samples left out: genotypes, phasing, planes, ploidies of every record
+int trk_vcf_parse_samples(trk_vcf* v, trk_vcf_batch* b) {
+    if (!v || !b) return 2;
+    const int n = b->n_records;
+    if (n <= 0) return 0;
+    trk_vcf::Kept& kp = v->kept[v->kept_i];
+    if ((int)kp.line_off.size() < n || b->text == nullptr) {
+        v->err = "trk_vcf_parse_samples: not the batch of the last trk_vcf_read_batch";
+        return 2;
+    }
+    RecordJob job;
+    job.v = v;
+    job.text = b->text;
+    job.S = (int)v->samples.size();
+    job.P = b->max_ploidy;
+    job.out = b;
+    job.line_off = kp.line_off.data();
+    job.line_end = kp.line_end.data();
+    job.field_off = kp.field_off.data();
+    std::atomic<int> next{0};
+    auto runner = [&]() {
+        for (;;) {
+            int i = next.fetch_add(1);
+            if (i >= n) break;
+            parse_record(job, i);
+        }
+    };
+    const int nt = std::max(1, std::min(v->n_threads, n));
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(runner);
+    runner();
+    for (auto& t : th) t.join();
+    if (job.error) {
+        v->err = job.error == 2 ? "a genotype has more haplotypes than max_ploidy"
+                                : "a record has fewer sample columns than the header";
+        return 5;
+    }
     return 0;
 }
 

@@ -547,9 +547,23 @@ class _Run:
                 self.invcf.contigs_seen.append(chrom)
         if not self._mine():
             return True
-        hb = HostBatch.from_tables(rb.gt, rb.locus_ploidy, hz.allele_off, hz.len_class, hz.str_class,
-                                   hz.len_class_value, lists=hz.lists)
         compute = runtime.get_compute()
+        dev = getattr(rb, 'dev', None)
+        if dev is not None and getattr(compute, 'eng', None) is not None:
+            # the sample columns were parsed on the device (TRK_DEVICE_PARSE=1): the tensor and the planes are there already;
+            # the host copies (the record writer reads the values of fired filters, the decode path the genotypes) come
+            # back by DMA into the reader's pinned arrays first -- the device arrays are the batch's from here on
+            rb._host()
+            hb = HostBatch.from_tables(dev['gt'], rb.locus_ploidy, hz.allele_off, hz.len_class, hz.str_class,
+                                       hz.len_class_value, lists=hz.lists)
+            arrays = [dev['planes'][k] for k in keys]
+            dev['gt'] = None
+            for k in keys:
+                dev['planes'][k] = None
+            rb.release_device()
+        else:
+            hb = HostBatch.from_tables(rb.gt, rb.locus_ploidy, hz.allele_off, hz.len_class, hz.str_class,
+                                       hz.len_class_value, lists=hz.lists)
         kw = dict(compact=True) if getattr(compute, 'supports_compact', False) else {}
         # the string-only locus filters (HRUN, BED regions: filters.py:190-300) for the whole batch at once, from the
         # harmoniser's per-record tables: extern bits of the locus-filter kernel
@@ -975,22 +989,34 @@ def main(args):
         kinds = {k: (1 if h['Type'] == 'Integer' else 2 if h['Type'] == 'Float' else 4) for k, h in format_fields.items()}
         invcf.use_buffers(getattr(runtime.get_compute(), 'host_buffer', None), ring=2,
                           release=getattr(runtime.get_compute(), 'host_release', None))
-        # TRK_VCF_READ_AHEAD=1: batch n + 1 is read while batch n is filtered and written.  Off by default: measured on
-        # 1 GB of text the read leaves the critical path (0.33 -> 0.05 s) and the phases it runs beside slow down by
-        # as much (record heads 0.12 -> 0.24 s, record text 0.35 -> 0.52 s): 1.13-1.25 s either way
-        # (profiles/r03_notes.md section 15).  (--num-records shortens the last batch: no read beyond it.)
-        if args.num_records is None and os.environ.get('TRK_VCF_READ_AHEAD', '0') == '1':
+        # Batch n + 1 is read while batch n is filtered and written (TRK_VCF_READ_AHEAD=0: off).  Rounds 3 and 4 (first half)
+        # kept it off -- the phases it ran beside slowed down by what it hid: on the GPU boxes the container is granted
+        # 16 CPUs' worth of time and the command line was bound by CPU seconds.  With the parse on the device the read is
+        # the inflate alone and the overlap is real: 0.37 -> 0.30 s per GB (profiles/r04_notes.md section 15).
+        # (--num-records shortens the last batch: no read beyond it.)
+        if args.num_records is None and os.environ.get('TRK_VCF_READ_AHEAD', '1') == '1':
             invcf.read_ahead()
+        # The sample columns are parsed on the device (trk_parse_samples, round 4; TRK_DEVICE_PARSE=0: on the host) -- scalar
+        # Integer / Float planes only, so HipSTR's filter sets; the reader refuses otherwise and parses on the host as before
+        device_parse = (os.environ.get('TRK_DEVICE_PARSE', '1') == '1' and hasattr(invcf, 'device_parse') and
+                        getattr(runtime.get_compute(), 'eng', None) is not None and
+                        invcf.device_parse(runtime.get_compute().eng))
     LAST_RUN.clear()
     LAST_RUN.update(path='batch' if use_batches else 'per-record', batches=0, fallback_batches=0)
+    if use_batches:
+        LAST_RUN['device_parse'] = bool(device_parse)
+    last_rb = None
     while use_batches:
+        if last_rb is not None:
+            last_rb.release_device()
+            last_rb = None
         want = batch_loci
         if args.num_records is not None:          # dumpSTR.py:1292-1293: the first num_records records
             want = min(batch_loci, args.num_records - record_counter)
             if want <= 0:
                 break
         t0 = time.perf_counter()
-        rb = invcf.read_raw_batch(want)
+        rb = last_rb = invcf.read_raw_batch(want)
         t1 = time.perf_counter()
         _tick('read_parse', t1 - t0)
         if rb.n == 0:
@@ -1031,6 +1057,8 @@ def main(args):
                 common.WARNING("Could not parse VCF.\n" + ve.args[0])
                 return 1
             raise ve
+    if use_batches and last_rb is not None:
+        last_rb.release_device()
     while not use_batches:
         try:
             record = next(harmonizer)

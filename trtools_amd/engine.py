@@ -289,6 +289,8 @@ class Engine:
         self.ctx = None
         self._live = set()
         self._pool = {}              # size class -> [(device pointer, idle: no queue can still be using it)]
+        import threading
+        self._pool_lock = threading.RLock()
         self._pool_bytes = 0
         self._queue = 0              # the selected queue (on_queue)
         self._multi_queue = False    # another queue than 0 has been used since the last full synchronisation
@@ -336,25 +338,28 @@ class Engine:
         buffer can be handed straight back out; once other queues have been used (bench.py's pipelined step) nobody
         knows which queue touched a buffer last, and the first reuse waits for the whole device (trk_sync) -- after
         which every pooled buffer is idle again."""
-        lst = self._pool.get(cap)
-        if not lst:
-            return None
-        ptr, safe = lst.pop()
-        self._pool_bytes -= cap
-        if not safe:
-            self.sync()
-            # still inside an on_queue(k != 0) scope: later frees are not idle either
-            self._multi_queue = self._queue != 0
-            for rest in self._pool.values():
-                rest[:] = [(p, True) for p, _ in rest]
-        return ptr
+        # (the pool is shared with the reader's read-ahead thread when it parses on the device: one lock around its books)
+        with self._pool_lock:
+            lst = self._pool.get(cap)
+            if not lst:
+                return None
+            ptr, safe = lst.pop()
+            self._pool_bytes -= cap
+            if not safe:
+                self.sync()
+                # still inside an on_queue(k != 0) scope: later frees are not idle either
+                self._multi_queue = self._queue != 0
+                for rest in self._pool.values():
+                    rest[:] = [(p, True) for p, _ in rest]
+            return ptr
 
     def _pool_give(self, cap, ptr):
-        if self._pool_limit <= 0 or self._pool_bytes + cap > self._pool_limit:
-            return False
-        self._pool.setdefault(cap, []).append((ptr, not self._multi_queue and self._queue == 0))
-        self._pool_bytes += cap
-        return True
+        with self._pool_lock:
+            if self._pool_limit <= 0 or self._pool_bytes + cap > self._pool_limit:
+                return False
+            self._pool.setdefault(cap, []).append((ptr, not self._multi_queue and self._queue == 0))
+            self._pool_bytes += cap
+            return True
 
     def trim(self):
         """Return every pooled device buffer to the driver."""
@@ -521,6 +526,9 @@ class Engine:
         prm = L.StatsParams(float(nalleles_thresh), flags, 0)
         self._chk(self.lib.trk_locus_stats(self.ctx, C.byref(batch.struct), C.byref(prm), C.byref(out.struct)))
         return out
+
+    import threading as _threading
+    _pool_lock = _threading.RLock()      # (class-level default; every engine gets its own in __init__)
 
     # What the last placed allocation saw (bench.py reports it): trk_pair_info as a dict
     last_placement = None
@@ -777,6 +785,60 @@ class Engine:
                                        a2.ptr if a2 is not None else None, a1.shape[2] if a1 is not None else 0,
                                        out.ptr, err.ptr))
         return out, err
+
+    def parse_samples(self, text, smp_off, line_end, n_samples, ploidy, gt_idx, planes=(), want_phased=False):
+        """trk_parse_samples (include/trk.h): the sample columns of L records parsed on the device.
+        text: the batch's text (bytes / uint8 array on the host, or a DeviceArray that is 16-byte aligned and padded by
+        16 bytes); smp_off / line_end: int64 [L] offsets INTO text of every record's first sample token and of its
+        newline; gt_idx: int8 [L] index of GT among the record's FORMAT keys; planes: [(idx int8 [L], 'i' | 'f'), ...]
+        (at most four scalar Integer / Float fields).  Returns a dict of DeviceArrays: gt int16 [L, S, P], planes
+        (int32 / float32 [L, S]), locus_ploidy uint8 [L], flags uint8 [L] (0, or _lib.PARSE_* bits: the rows of a
+        flagged record are undefined -- parse it with the host reader), phased uint8 [L, S] when asked for."""
+        if isinstance(text, DeviceArray):
+            text_d, own_text = text, False
+        else:
+            host = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else text.view(np.uint8).reshape(-1)
+            text_d = self.empty((host.shape[0] + 32,), np.uint8)
+            if host.shape[0]:
+                self._chk(self.lib.trk_memcpy_h2d(self.ctx, text_d.ptr, host.ctypes.data, host.shape[0]))
+            own_text = True
+        n_rec = int(np.asarray(smp_off).shape[0]) if not isinstance(smp_off, DeviceArray) else smp_off.shape[0]
+
+        def dev(x, dt):
+            return x if isinstance(x, DeviceArray) else self.upload(np.ascontiguousarray(x, dtype=dt), dt)
+        tmp = []
+        so, le, gi = dev(smp_off, np.int64), dev(line_end, np.int64), dev(gt_idx, np.int8)
+        tmp += [x for x, src in ((so, smp_off), (le, line_end), (gi, gt_idx)) if not isinstance(src, DeviceArray)]
+        if len(planes) > L.PARSE_MAX_PLANES:
+            raise ValueError("at most %d planes" % L.PARSE_MAX_PLANES)
+        pin = L.ParseIn()
+        pin.text, pin.n_bytes = text_d.ptr, text_d.nbytes
+        pin.n_records, pin.n_samples, pin.ploidy, pin.n_planes = n_rec, int(n_samples), int(ploidy), len(planes)
+        pin.smp_off, pin.line_end, pin.gt_idx = so.ptr, le.ptr, gi.ptr
+        out = dict(gt=self.empty((n_rec, n_samples, ploidy), np.int16), locus_ploidy=self.empty((n_rec,), np.uint8),
+                   flags=self.empty((n_rec,), np.uint8), planes=[])
+        pout = L.ParseOut()
+        for i, (idx, kind) in enumerate(planes):
+            d = dev(idx, np.int8)
+            if not isinstance(idx, DeviceArray):
+                tmp.append(d)
+            pin.plane_idx[i] = d.ptr
+            pin.plane_kind[i] = L.PARSE_FLOAT if kind == 'f' else L.PARSE_INT
+            arr = self.empty((n_rec, n_samples), np.float32 if kind == 'f' else np.int32)
+            out['planes'].append(arr)
+            pout.planes[i] = arr.ptr
+        pout.gt, pout.locus_ploidy, pout.flags = out['gt'].ptr, out['locus_ploidy'].ptr, out['flags'].ptr
+        if want_phased:
+            out['phased'] = self.empty((n_rec, n_samples), np.uint8)
+            pout.phased = out['phased'].ptr
+        self._chk(self.lib.trk_parse_samples(self.ctx, C.byref(pin), C.byref(pout)))
+        if tmp or own_text:
+            self.sync()                       # (the temporaries go back to the pool: the kernel must be done with them)
+        for t in tmp:
+            t.free()
+        if own_text:
+            text_d.free()
+        return out
 
     def qc_reduce(self, batch, quality=None, sample_in=None, ignore_no_call=False):
         """trk_qc_reduce (qcSTR's reductions, include/trk.h): per-sample and per-locus call counts, and with a

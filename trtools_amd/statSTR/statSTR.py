@@ -307,16 +307,26 @@ def _run_batches(args, invcf, vcftype, group_masks, fmt, shard, batch_loci, star
         if layout is not None:
             invcf.set_sample_map(layout['col_of'], layout['n_out'])
     invcf.use_buffers(getattr(compute, 'host_buffer', None), ring=2, release=getattr(compute, 'host_release', None))
-    # (TRK_VCF_READ_AHEAD=1: batch n + 1 is read and parsed while batch n is counted and written.  Off by default: this
-    # command line is its reader -- 0.29 of 0.32 s per GB of text -- and has nothing to hide the read behind)
-    invcf.read_ahead(os.environ.get('TRK_VCF_READ_AHEAD', '0') == '1')
+    # The sample columns are parsed on the device (trk_parse_samples, round 4; TRK_DEVICE_PARSE=0: on the host): the reader
+    # stops at the FORMAT keys, the batch's text goes over PCIe instead of the genotype tensor.  Ungrouped runs on the
+    # device engine only.
+    device_parse = (masks is None and os.environ.get('TRK_DEVICE_PARSE', '1') == '1' and hasattr(invcf, 'device_parse') and
+                    getattr(compute, 'eng', None) is not None and invcf.device_parse(compute.eng))
+    LAST_RUN['device_parse'] = bool(device_parse)
+    # Batch n + 1 is read while batch n is counted and written (TRK_VCF_READ_AHEAD=0: off; it was off while the command line
+    # was bound by CPU seconds on the 16-CPU grant of the GPU boxes: with the parse on the device 0.18 -> 0.125 s per GB,
+    # profiles/r04_notes.md section 15)
+    invcf.read_ahead(os.environ.get('TRK_VCF_READ_AHEAD', '1') == '1')
     nrecords = 0
     region_done = False
     LAST_RUN.update(path='batch', batches=0, fallback_batches=0)
     if args.region:
         invcf(args.region)                   # statSTR.py:568-570: seek to the region's first index window
+    last_rb = None
     while not region_done:
-        rb = invcf.read_raw_batch(batch_loci)
+        if last_rb is not None:
+            last_rb.release_device()         # (a device-parsed batch that went another way than the device's)
+        rb = last_rb = invcf.read_raw_batch(batch_loci)
         if rb.n == 0:
             break
         hz = rb.harmonize(vcftype.name)
@@ -350,12 +360,16 @@ def _run_batches(args, invcf, vcftype, group_masks, fmt, shard, batch_loci, star
         for gb, ng in passes:
             sorted_ok = (layout is not None and rb.gt_mapped is not None and rb.gt.shape[2] == 2 and
                          bool(np.all(np.asarray(rb.locus_ploidy) == 2)))
-            hb = HostBatch.from_tables(rb.gt_mapped if sorted_ok else rb.gt, rb.locus_ploidy, hz.allele_off, hz.len_class,
+            gt_in = rb.gt_mapped if sorted_ok else (rb.dev['gt'] if rb.dev is not None else rb.gt)
+            hb = HostBatch.from_tables(gt_in, rb.locus_ploidy, hz.allele_off, hz.len_class,
                                        hz.str_class, hz.len_class_value, layout['bits'] if sorted_ok else gb, ng,
                                        lists=hz.lists)
             if sorted_ok:
                 hb.class_layout = layout
             parts.append(compute.locus_stats(hb, nalleles_thresh=args.nalleles_thresh))
+            if rb.dev is not None and gt_in is rb.dev['gt']:
+                rb.dev['gt'] = None           # (the batch built from it freed the tensor with its other arrays)
+                rb.release_device()
         st = parts[0]
         if len(parts) > 1:                   # more than eight strata: the passes' rows side by side
             from ..compute import StatsHost
@@ -380,6 +394,8 @@ def _run_batches(args, invcf, vcftype, group_masks, fmt, shard, batch_loci, star
         if args.out != "stdout" and shard.rank == 0:
             print("Finished {} records, time/record={:.5}sec".format(
                 nrecords, (time.time() - start_time) / nrecords), flush=True, end="\r")
+    if last_rb is not None:
+        last_rb.release_device()
     return nrecords
 
 

@@ -116,11 +116,41 @@ class RawBatch:
     def __init__(self, reader, b, gt, ph, lp, planes, gt_mapped=None):
         self.reader, self.b = reader, b
         self.n = b.n_records
-        self.gt, self.phased, self.locus_ploidy = gt[:self.n], ph[:self.n], lp[:self.n]
+        self._gt, self._phased, self.locus_ploidy = gt[:self.n], ph[:self.n], lp[:self.n]
         # the genotypes once more in the column order of set_sample_map (None without a map)
         self.gt_mapped = None if gt_mapped is None else gt_mapped[:self.n]
-        self.planes = {k: planes[j][:self.n] for j, (k, _, _, _) in enumerate(reader._selected)}
+        self._planes = {k: planes[j][:self.n] for j, (k, _, _, _) in enumerate(reader._selected)}
         self._hz = None
+        self.dev = None          # device-parsed batch (NativeVCFReader.device_parse): dict(gt=, planes={key: DeviceArray})
+
+    # In device-parse mode the sample columns were parsed by trk_parse_samples and live in HBM (``dev``); the host
+    # arrays are filled from them the first time somebody asks (the record writer's decode path, the per-record loop).
+    def _host(self):
+        d = self.dev
+        if d is not None and not d.get('on_host'):
+            d['on_host'] = True
+            if self.n:
+                eng = d['gt'].eng
+                # straight into the reader's (pinned) arrays: the views are the contiguous leading records of them
+                for dst, src in [(self._gt, d['gt']), (self._phased, d['phased'])] + \
+                                [(self._planes[k], a) for k, a in d['planes'].items()]:
+                    if dst.flags['C_CONTIGUOUS'] and dst.nbytes == src.nbytes:
+                        eng._chk(eng.lib.trk_memcpy_d2h(eng.ctx, dst.ctypes.data, src.ptr, src.nbytes))
+                    else:
+                        dst[...] = src.get().reshape(dst.shape)
+        return self
+
+    gt = property(lambda self: self._host()._gt)
+    phased = property(lambda self: self._host()._phased)
+    planes = property(lambda self: self._host()._planes)
+
+    def release_device(self):
+        """Give the device-parsed arrays back (the caller took what it needs, or handed them to a DeviceBatch)."""
+        d, self.dev = self.dev, None
+        if d is not None:
+            for a in [d.get('gt'), d.get('phased')] + list(d.get('planes', {}).values()):
+                if a is not None and a.ptr is not None:
+                    a.free()
 
     def harmonize(self, vcftype):
         hz = _Harmonized()
@@ -368,6 +398,11 @@ def _api():
         lib.trk_vcf_sample_name.restype = C.c_char_p
         lib.trk_vcf_select_format.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
         lib.trk_vcf_read_batch.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_Batch)]
+        lib.trk_vcf_skip_samples.argtypes = [vp, C.c_int]
+        lib.trk_vcf_set_text_buffers.argtypes = [vp, vp, vp, C.c_size_t]
+        lib.trk_vcf_format_idx.argtypes = [vp, C.POINTER(C.c_int32)]
+        lib.trk_vcf_format_idx.restype = C.c_void_p
+        lib.trk_vcf_parse_samples.argtypes = [vp, C.POINTER(_Batch)]
         lib.trk_vcf_seek.argtypes = [vp, C.c_uint64]
         lib.trk_vcf_shard.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         lib.trk_vcf_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -490,9 +525,27 @@ class NativeVCFReader(vcfio.VCFReader):
             self._pending = start()
         return rb
 
+    def _pin_text(self):
+        """Device-parse mode, from the second batch on: the reader's two text buffers continue in pinned memory of the
+        engine's (trk_vcf_set_text_buffers), so that the upload of a batch's text is a plain DMA.  Sized from the first
+        batch; a later batch that outgrows them moves the reader back to its own memory (and the copy to a staged one)."""
+        need = getattr(self, '_text_seen', 0)
+        if not need or getattr(self, '_text_pinned', False) or getattr(self, '_alloc', None) is None or getattr(self, '_ahead', False):
+            return
+        self._text_pinned = True
+        cap = (int(need * 1.25) + (64 << 20) + 4095) & ~4095
+        try:
+            a, b = self._alloc(cap), self._alloc(cap)
+        except Exception:
+            return
+        self._slabs = getattr(self, '_slabs', []) + [a, b]
+        self._lib.trk_vcf_set_text_buffers(self._h, a.ctypes.data, b.ctypes.data, cap)
+
     def _read_raw_batch(self, n_records=None):
         S = self.n_samples
         P = self._max_ploidy
+        if getattr(self, '_dev_eng', None) is not None:
+            self._pin_text()
         n = n_records or self._batch_records or max(1, min(4096, (1 << 22) // max(S, 1)))
         while True:
             # (a batch retried with a wider tensor gets arrays of its own: the ring keeps the file's usual shape)
@@ -517,9 +570,78 @@ class NativeVCFReader(vcfio.VCFReader):
             if rc != 0:
                 raise ValueError(self._lib.trk_vcf_last_error(self._h).decode())
             break
+        dev = None
+        if getattr(self, '_dev_eng', None) is not None and b.n_records:
+            dev, gt, ph, lp, planes, gtm, parr = self._parse_on_device(b, P, (gt, ph, lp, planes, gtm, parr))
         rb = RawBatch(self, b, gt, ph, lp, planes, gtm)
         rb._keep = parr
+        rb.dev = dev
         return rb
+
+    def device_parse(self, engine):
+        """The sample columns of every batch parsed ON THE DEVICE (trk_parse_samples, include/trk.h; round 4): the native
+        reader stops at the FORMAT keys (trk_vcf_skip_samples), the batch's text goes to the device once, the genotype
+        tensor and the selected scalar planes come into being there (``RawBatch.dev``).  A batch in which the device
+        flags any record is parsed by the host after all (trk_vcf_parse_samples): same arrays either way.  Needs
+        scalar Integer / Float planes (at most four) and no sample map; ``None`` turns it off."""
+        ok = engine is not None and not getattr(self, '_map_out', 0) and len(self._selected) <= _lib.PARSE_MAX_PLANES and \
+            all(nc == 1 and kd in (KIND_INT, KIND_FLOAT) for _, kd, nc, _ in self._selected)
+        self._dev_eng = engine if ok else None
+        self._lib.trk_vcf_skip_samples(self._h, 1 if ok else 0)
+        return bool(ok)
+
+    def _parse_on_device(self, b, P, arrays):
+        """The sample columns of the batch just read, on the device; returns (dev dict or None, the host arrays)."""
+        gt, ph, lp, planes, gtm, parr = arrays
+        eng, n, S = self._dev_eng, b.n_records, self.n_samples
+        lo = np.ctypeslib.as_array(b.line_off, shape=(n,))
+        le = np.ctypeslib.as_array(b.line_end, shape=(n,))
+        fo9 = np.ctypeslib.as_array(b.field_off, shape=(n * 10,))[9::10]
+        base = int(lo[0]) & ~15                         # the upload starts on a 16-byte boundary of the reader's buffer
+        nbytes = int(le[-1]) + 1 - base
+        self._text_seen = max(getattr(self, '_text_seen', 0), int(le[-1]) + 1)
+        stride = C.c_int32()
+        fptr = self._lib.trk_vcf_format_idx(self._h, C.byref(stride))
+        fi = np.ctypeslib.as_array(C.cast(fptr, C.POINTER(C.c_int8)), shape=(n, stride.value)) if fptr else None
+        out = None
+        if fi is not None and nbytes > 0 and S > 0:
+            td = eng.empty((nbytes + 32,), np.uint8)
+            eng._chk(eng.lib.trk_memcpy_h2d(eng.ctx, td.ptr, b.text + base, nbytes))
+            kinds = ['f' if kd == KIND_FLOAT else 'i' for _, kd, _, _ in self._selected]
+            out = eng.parse_samples(td, (lo + fo9 - base).astype(np.int64), (le - base).astype(np.int64), S, P,
+                                    np.ascontiguousarray(fi[:, 0]),
+                                    planes=[(np.ascontiguousarray(fi[:, 1 + j]), k) for j, k in enumerate(kinds)],
+                                    want_phased=True)
+            flags = out['flags'].get()
+            td.free()
+            if flags.any():
+                for a in [out['gt'], out['phased'], out['locus_ploidy'], out['flags']] + out['planes']:
+                    a.free()
+                out = None
+        if out is None:
+            # something the device grammar does not cover (or an error the host reports in its own words): the host parses
+            # the batch after all -- with a wider tensor when a call holds more alleles than this one has columns
+            self.device_fallbacks = getattr(self, 'device_fallbacks', 0) + 1
+            while True:
+                rc = self._lib.trk_vcf_parse_samples(self._h, C.byref(b))
+                if rc == 5 and b'haplotypes' in self._lib.trk_vcf_last_error(self._h) and P < 8:
+                    P = min(8, 2 * P)
+                    gt, ph, lp, planes, gtm = self._arrays(max(n, 1), S, P, ring=False)
+                    parr = (C.c_void_p * max(len(planes), 1))(*[p.ctypes.data for p in planes])
+                    b.gt, b.phased, b.locus_ploidy = gt.ctypes.data, ph.ctypes.data, lp.ctypes.data
+                    b.gt_mapped = None if gtm is None else gtm.ctypes.data
+                    b.planes = C.cast(parr, C.POINTER(C.c_void_p))
+                    b.max_ploidy = P
+                    continue
+                if rc != 0:
+                    raise ValueError(self._lib.trk_vcf_last_error(self._h).decode())
+                break
+            return None, gt, ph, lp, planes, gtm, parr
+        lp[:n] = out['locus_ploidy'].get()
+        out['locus_ploidy'].free()
+        out['flags'].free()
+        dev = dict(gt=out['gt'], phased=out['phased'], planes={k: a for (k, _, _, _), a in zip(self._selected, out['planes'])})
+        return dev, gt, ph, lp, planes, gtm, parr
 
     def shard(self, rank, world):
         """Keep only this rank's contiguous share of the records (trk_vcf_shard: the compressed file cut at BGZF block
