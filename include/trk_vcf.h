@@ -203,6 +203,7 @@ typedef struct {
     const int32_t* period;         /* [n] INFO PERIOD as an integer, INT32_MIN where the record has none  */
     const int64_t* tr_pos;         /* [n] TRRecord.pos: INFO START for HipSTR (tr_harmonizer.py:407), else POS */
 } trk_vcf_harmonized;
+/* (the tables are the reader's: valid during the NEXT trk_vcf_harmonize call too, gone with the one after -- as a batch's text) */
 int trk_vcf_harmonize(trk_vcf* v, const trk_vcf_batch* b, int vcftype, trk_vcf_harmonized* out);
 
 enum { TRK_SS_THRESH = 1, TRK_SS_AFREQ = 2, TRK_SS_ACOUNT = 4, TRK_SS_NALLELES = 8, TRK_SS_HWEP = 16, TRK_SS_HET = 32,

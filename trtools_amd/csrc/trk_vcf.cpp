@@ -605,7 +605,8 @@ struct HzStore {
 
 struct trk_vcf {
     Source src;
-    HzStore hz;
+    HzStore hz2[2];      // results of trk_vcf_harmonize, two sets taken in turn: a batch's tables stay valid during the NEXT
+    int hz_i = 0;        // call too (the read-ahead thread harmonises batch n + 1 while batch n's tables are in use)
     std::string err;
     std::string header;
     std::vector<std::string> samples;
@@ -2176,7 +2177,8 @@ extern "C" {
 
 int trk_vcf_harmonize(trk_vcf* v, const trk_vcf_batch* b, int vcftype, trk_vcf_harmonized* out) {
     if (!v || !b || !out || vcftype < 0 || vcftype > TRK_VT_POPSTR) return 2;
-    HzStore& st = v->hz;
+    v->hz_i ^= 1;
+    HzStore& st = v->hz2[v->hz_i];
     const int n = b->n_records;
     std::vector<HzRecord> recs((size_t)n);
     {
