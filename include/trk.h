@@ -561,6 +561,39 @@ typedef struct {
 } trk_parse_out;
 int trk_parse_samples(trk_ctx* ctx, const trk_parse_in* in, trk_parse_out* out);
 
+/* ---- dumpSTR's sample columns written on the device (round 4; the host form is trk_vcf_dumpstr_records' span writer) ----
+ * Per sample: a tab, then the token as it stands (+ ':.' per FORMAT key it lacks) + ':PASS' / ':NOCALL', or for a filtered
+ * call the nulled token + ':' + '<filter>_<value>,...' (dumpSTR.py:648-683, 715-746).  A kept token is copied only when
+ * decode -> format would print it back unchanged (canonical numbers, one separator in GT, ASCII strings, no vectors); a
+ * record with anything else -- or a value whose '%g' needs an exponent or sits on a rounding tie -- gets TRK_PARSE_HOST in
+ * its flag and is left to the host writer.  Pass 1 leaves rec_len / flags; the caller lays the records out (out_off) and
+ * pass 2 writes the bytes of every unflagged record.  text / smp_off / line_end as for trk_parse_samples.            */
+#define TRK_FORMAT_MAX_FIELDS 16
+#define TRK_FORMAT_MAX_FILTERS 7
+enum { TRK_FORMAT_GT = 1, TRK_FORMAT_INT = 2, TRK_FORMAT_FLOAT = 3, TRK_FORMAT_STRING = 4 };
+typedef struct {
+    const uint8_t* text;
+    int64_t n_bytes;
+    int32_t n_records, n_samples, mask_stride, plane_stride;
+    const int64_t* smp_off;
+    const int64_t* line_end;
+    const uint8_t* field_kind;   /* device [n_records][TRK_FORMAT_MAX_FIELDS]: TRK_FORMAT_* of the record's FORMAT keys   */
+    const uint8_t* n_fields;     /* device [n_records]: FORMAT keys of the record; 0: not for the device                 */
+    const uint8_t* ploidy;       /* device [n_records]: alleles of a nulled call ('./.')                                 */
+    const uint8_t* mask8;        /* device [n_records, mask_stride]: trk_call_out.filter_mask8                           */
+    int32_t n_filters, reserved; /* <= TRK_FORMAT_MAX_FILTERS                                                            */
+    char filter_name[TRK_FORMAT_MAX_FILTERS][32];
+    const void* filter_plane[TRK_FORMAT_MAX_FILTERS];   /* device [n_records, plane_stride]: the value behind '<name>_<value>' */
+    int32_t filter_dtype[TRK_FORMAT_MAX_FILTERS];       /* 0 int32, 1 float32                                            */
+} trk_format_in;
+typedef struct {
+    uint32_t* rec_len;       /* device [n_records] (pass 1): bytes of the record's sample columns, 0 when flagged        */
+    uint8_t* flags;          /* device [n_records] (pass 1 writes, pass 2 reads)                                         */
+    uint8_t* out;            /* device (pass 2)                                                                          */
+    const int64_t* out_off;  /* device [n_records] (pass 2): where every record's columns go in `out`                    */
+} trk_format_out;
+int trk_format_samples(trk_ctx* ctx, const trk_format_in* in, trk_format_out* out, int pass);
+
 /* ---- qcSTR's reductions (trtools/qcSTR/qcSTR.py:529-561, 619-621) ----------------
  * One pass over the genotype tensor and (optionally) the FORMAT quality plane of a batch:
  *   a sample's entry at a locus is a CALL unless every haplotype index of the record is -1 (qcSTR.py:533-535 --

@@ -293,7 +293,18 @@ typedef struct {
     const char* const* info_keys;        /* the header's INFO IDs ...                                           */
     const int32_t* info_kinds;           /* ... 0 String, 1 Integer, 2 Float, 3 Flag                            */
     uint8_t* need_head;                  /* [n] out (zeroed by the caller), or NULL                             */
+    /* Round 4, optional (all four or none): the sample columns of the records as trk_format_samples (include/trk.h) wrote
+     * them on the device, copied to the host -- record l's columns are dev_regions[dev_region_off[l] .. + dev_region_len[l]);
+     * dev_flags[l] != 0: the device left the record to this writer.  The head is built here either way.            */
+    const char* dev_regions;
+    const int64_t* dev_region_off;
+    const uint32_t* dev_region_len;
+    const uint8_t* dev_flags;
 } trk_vcf_dumpstr2;
+/* The FORMAT keys of every record of the batch as trk_format_samples wants them: kinds16 [n][16] (1 GT, 2 Integer,
+ * 3 Float, 4 String, by in->format_keys / format_kinds; unlisted keys are strings), n_fields [n] -- 0 for a record the
+ * device must not format (no GT, a FILTER field of its own, more than 16 keys, a vector-typed kind).                 */
+int trk_vcf_format_kinds(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, uint8_t* kinds16, uint8_t* n_fields);
 int64_t trk_vcf_dumpstr_records(const trk_vcf_batch* b, const trk_vcf_dumpstr2* in, char* out, int64_t cap,
                                 int32_t* err_record);
 /* records written so far by this process: without decoding / through the decode path / with a caller-built head */

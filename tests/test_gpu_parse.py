@@ -270,3 +270,41 @@ def test_dumpstr_command_line_with_the_sample_columns_parsed_on_the_device(tmp_p
         a[0] = '\n'.join(x for x in a[0].split('\n') if not x.startswith('##command-DumpSTR'))
         b[0] = '\n'.join(x for x in b[0].split('\n') if not x.startswith('##command-DumpSTR'))
         assert a == b and a[0].count('\n') > 30
+
+
+@pytest.mark.parametrize('seed', [5, 6, 7, 8])
+def test_dumpstr_sample_columns_written_on_the_device(tmp_path, seed):
+    """trk_format_samples behind dumpSTR's command line (TRK_DEVICE_FORMAT=1; opt-in): on the
+    HipSTR fixture and on its rewritten-text variants (numbers spelled every way, tokens that stop early, a lone '.', a
+    field too many -- tests/test_batch_pipelines.py's generator) the output VCF is byte for byte the host writer's; the
+    device takes the regular records and leaves the others."""
+    from test_dumpstr_cli import make_args as dump_args
+    from test_batch_pipelines import _mutated_hipstr
+    from trtools_amd import vcfnative
+    from trtools_amd.dumpSTR import dumpSTR
+    src = os.path.join(GOLDEN, 'dumpstr_synth', 'synth_hipstr.vcf') if seed == 5 else _mutated_hipstr(tmp_path, seed, scalar=True)
+    if seed != 5:
+        # (exponents are outside the device PARSE grammar and would send every batch to the host reader: spelled out
+        # here, as numbers that parse on the device and are not canonical for the writer)
+        text = open(src).read().replace(':1e-3', ':0.001000').replace(':1E2', ':100.0')
+        open(src, 'w').write(text)
+    kw = dict(hipstr_min_call_DP=20, hipstr_max_call_DP=50, hipstr_min_call_Q=0.9, min_locus_callrate=0.2)
+    outs, took = [], []
+    for dev in ('0', '1'):
+        os.environ['TRK_DEVICE_FORMAT'] = dev
+        before = dict(vcfnative.DEVICE_FORMAT)
+        try:
+            out = str(tmp_path / ('f%s' % dev))
+            assert dumpSTR.main(dump_args(out, src, vcftype='hipstr', **kw)) == 0
+            assert dumpSTR.LAST_RUN['path'] == 'batch'
+            outs.append('\n'.join(x for x in open(out + '.vcf').read().split('\n') if not x.startswith('##command-DumpSTR')))
+            took.append(vcfnative.DEVICE_FORMAT['records'] - before['records'])
+        finally:
+            os.environ.pop('TRK_DEVICE_FORMAT', None)
+    if outs[0] != outs[1]:
+        la, lb = outs[0].split('\n'), outs[1].split('\n')
+        i = next(i for i, (p, q) in enumerate(zip(la, lb)) if p != q)
+        fa, fb = la[i].split('\t'), lb[i].split('\t')
+        j = next((j for j, (p, q) in enumerate(zip(fa, fb)) if p != q), -1)
+        raise AssertionError("line %d column %d: host %r device %r" % (i, j, fa[j][:80] if j >= 0 else len(fa), fb[j][:80] if j >= 0 else len(fb)))
+    assert took[0] == 0 and took[1] > (20 if seed == 5 else 0), took

@@ -125,6 +125,21 @@ class ParseIn(C.Structure):
                 ('gt_idx', C.c_void_p), ('plane_idx', C.c_void_p * PARSE_MAX_PLANES), ('plane_kind', C.c_int32 * PARSE_MAX_PLANES)]
 
 
+FORMAT_MAX_FIELDS, FORMAT_MAX_FILTERS = 16, 7
+
+
+class FormatIn(C.Structure):
+    _fields_ = [('text', C.c_void_p), ('n_bytes', C.c_int64), ('n_records', C.c_int32), ('n_samples', C.c_int32),
+                ('mask_stride', C.c_int32), ('plane_stride', C.c_int32), ('smp_off', C.c_void_p), ('line_end', C.c_void_p),
+                ('field_kind', C.c_void_p), ('n_fields', C.c_void_p), ('ploidy', C.c_void_p), ('mask8', C.c_void_p),
+                ('n_filters', C.c_int32), ('reserved', C.c_int32), ('filter_name', (C.c_char * 32) * FORMAT_MAX_FILTERS),
+                ('filter_plane', C.c_void_p * FORMAT_MAX_FILTERS), ('filter_dtype', C.c_int32 * FORMAT_MAX_FILTERS)]
+
+
+class FormatOut(C.Structure):
+    _fields_ = [('rec_len', C.c_void_p), ('flags', C.c_void_p), ('out', C.c_void_p), ('out_off', C.c_void_p)]
+
+
 class ParseOut(C.Structure):
     _fields_ = [('gt', C.c_void_p), ('phased', C.c_void_p), ('planes', C.c_void_p * PARSE_MAX_PLANES),
                 ('locus_ploidy', C.c_void_p), ('flags', C.c_void_p)]
@@ -164,7 +179,7 @@ EXPORTS = [
     'trk_locus_stats', 'trk_locus_finalize', 'trk_call_filters', 'trk_locus_filters',
     'trk_comm_unique_id', 'trk_comm_init', 'trk_allreduce_sum_i64', 'trk_allgather',
     'trk_binomtest_two_sided', 'trk_binom_pmf', 'trk_binomtest_batch', 'trk_synth_fill', 'trk_synth_fill_gangstr',
-    'trk_assoc_scan', 'trk_assoc_scan_dosage', 'trk_student_t_two_sided', 'trk_dosages', 'trk_qc_reduce', 'trk_parse_samples', 'trk_planarize', 'trk_pad_rows', 'trk_permute_columns', 'trk_stream_probe', 'trk_device_clocks', 'trk_stream_select', 'trk_stream_wait',
+    'trk_assoc_scan', 'trk_assoc_scan_dosage', 'trk_student_t_two_sided', 'trk_dosages', 'trk_qc_reduce', 'trk_parse_samples', 'trk_format_samples', 'trk_planarize', 'trk_pad_rows', 'trk_permute_columns', 'trk_stream_probe', 'trk_device_clocks', 'trk_stream_select', 'trk_stream_wait',
     'trk_host_alloc', 'trk_host_free', 'trk_memcpy_h2d_async', 'trk_memcpy_d2h_async', 'trk_queue_sync', 'trk_exchange', 'trk_event_record', 'trk_event_wait',
 ]
 
@@ -297,6 +312,7 @@ def load():
     lib.trk_dosages.argtypes = [vp, P(Batch), vp, C.c_int, vp, vp, C.c_int, vp, vp]
     lib.trk_qc_reduce.argtypes = [vp, P(Batch), P(QcParams), P(QcOut)]
     lib.trk_parse_samples.argtypes = [vp, P(ParseIn), P(ParseOut)]
+    lib.trk_format_samples.argtypes = [vp, P(FormatIn), P(FormatOut), C.c_int]
     lib.trk_student_t_two_sided.argtypes = [dbl, dbl]
     lib.trk_student_t_two_sided.restype = dbl
     lib.trk_synth_fill.argtypes = [vp, P(SynthSpec), vp, vp, vp, vp, vp]

@@ -848,6 +848,25 @@ int trk_parse_samples(trk_ctx* ctx, const trk_parse_in* in, trk_parse_out* out) 
     return TRK_OK;
 }
 
+int trk_format_samples(trk_ctx* ctx, const trk_format_in* in, trk_format_out* out, int pass) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (!in || !out || (pass != 1 && pass != 2)) return fail(ctx, TRK_ERR_ARG, "format_samples: arguments");
+    if (in->n_records < 0 || in->n_samples < 0 || in->n_filters < 0 || in->n_filters > TRK_FORMAT_MAX_FILTERS)
+        return fail(ctx, TRK_ERR_ARG, "format_samples: records %d, samples %d, filters %d", in->n_records, in->n_samples, in->n_filters);
+    if (in->n_records == 0 || in->n_samples == 0) return TRK_OK;
+    if (!in->text || ((uintptr_t)in->text & 15u) || !in->smp_off || !in->line_end || !in->field_kind || !in->n_fields ||
+        !in->ploidy || !in->mask8 || !out->rec_len || !out->flags || in->mask_stride < in->n_samples ||
+        in->plane_stride < in->n_samples)
+        return fail(ctx, TRK_ERR_ARG, "format_samples: inputs / outputs are NULL or too narrow");
+    for (int i = 0; i < in->n_filters; ++i)
+        if (!in->filter_plane[i] || !memchr(in->filter_name[i], 0, sizeof in->filter_name[i]))
+            return fail(ctx, TRK_ERR_ARG, "format_samples: filter %d", i);
+    if (pass == 2 && (!out->out || !out->out_off)) return fail(ctx, TRK_ERR_ARG, "format_samples: pass 2 needs out and out_off");
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, trk::launch_format_samples(*in, *out, pass, ctx->s()));
+    return TRK_OK;
+}
+
 int trk_planarize(trk_ctx* ctx, const void* src, void* dst, int64_t n_cells, int32_t ncol) {
     if (!ctx) return TRK_ERR_ARG;
     if (!src || !dst || n_cells < 0 || ncol < 1) return fail(ctx, TRK_ERR_ARG, "planarize arguments");

@@ -65,5 +65,6 @@ hipError_t launch_qc_reduce(const trk_batch& b, const trk_qc_params& prm, const 
                             int n_cu, hipStream_t stream);
 
 hipError_t launch_parse_samples(const trk_parse_in& in, const trk_parse_out& out, hipStream_t stream);
+hipError_t launch_format_samples(const trk_format_in& in, const trk_format_out& out, int pass, hipStream_t stream);
 }  // namespace trk
 #endif

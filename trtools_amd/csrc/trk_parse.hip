@@ -293,6 +293,401 @@ __global__ __launch_bounds__(PS_THREADS) void k_parse_samples(const ParseArgs a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_format_samples : dumpSTR's sample columns WRITTEN on the device (round 4; the host form is fast_samples_scalar in
+// trk_vcf.cpp, dumpSTR.py:648-683 and 715-746 in the reference): per sample a tab, then either the token as it stands
+// (+ ':.' per FORMAT key it does not hold) + ':PASS' / ':NOCALL', or -- a filtered call -- the nulled token
+// ('./.:.:.') + ':' + '<filter>_<value>,...'.  A kept token is copied only if decode -> format would print it back
+// unchanged (the canonical-number rules of the host tier, checked in one forward scan); anything else flags the
+// record and the host writer takes it.  Same tiling as k_parse_samples, but a lane owns CONSECUTIVE tokens of the tile
+// so that its output is one contiguous span: pass 1 (EMIT = false) leaves the record's length and flag, the caller
+// turns lengths into offsets, pass 2 writes.
+// ---------------------------------------------------------------------------------------------------------------------
+struct FormatArgs {
+    trk_format_in in;
+    trk_format_out out;
+};
+
+// "%g" of x into buf: the length, or -1 when the host has to print it (exponent forms, non-finite, a rounding tie)
+__device__ int g6(char* buf, double x) {
+    int n = 0;
+    if (!(x == x) || x - x != 0.0) return -1;
+    if (x == 0.0) {
+        if (__builtin_signbit(x)) return -1;
+        buf[0] = '0';
+        return 1;
+    }
+    if (x < 0) {
+        buf[n++] = '-';
+        x = -x;
+    }
+    if (x < 1e-4 || x >= 1e6) return -1;
+    int e = x >= 1e5 ? 5 : x >= 1e4 ? 4 : x >= 1e3 ? 3 : x >= 1e2 ? 2 : x >= 1e1 ? 1 : x >= 1e0 ? 0 : x >= 1e-1 ? -1 : x >= 1e-2 ? -2 : x >= 1e-3 ? -3 : -4;
+    const double y = x * c_p10[5 - e];                  // six significant digits before the point (5 - e in 0 .. 9)
+    const double fl = floor(y), fr = y - fl;
+    if (fabs(fr - 0.5) < 1e-6) return -1;               // too close to a tie for one rounded product to decide
+    uint32_t d = (uint32_t)fl + (fr > 0.5 ? 1u : 0u);
+    if (d >= 1000000u) {                                // 999999.6 -> 1000000: one more digit before the point
+        d = 100000u;
+        ++e;
+        if (e > 5) return -1;
+    }
+    char dig[6];
+    for (int i = 5; i >= 0; --i) {
+        dig[i] = (char)('0' + d % 10u);
+        d /= 10u;
+    }
+    int last = 5;
+    while (last > 0 && dig[last] == '0') --last;        // significant digits dig[0 .. last]
+    if (e >= 0) {
+        for (int i = 0; i <= e; ++i) buf[n++] = dig[i];
+        if (last > e) {
+            buf[n++] = '.';
+            for (int i = e + 1; i <= last; ++i) buf[n++] = dig[i];
+        }
+    } else {
+        buf[n++] = '0';
+        buf[n++] = '.';
+        for (int i = 0; i < -e - 1; ++i) buf[n++] = '0';
+        for (int i = 0; i <= last; ++i) buf[n++] = dig[i];
+    }
+    return n;
+}
+
+// one token: its length, the fields a kept call lacks, false when the host has to write the record
+__device__ __forceinline__ bool tok_check(const unsigned char* tok, const unsigned char* tok_end, const uint8_t* kinds, int nf,
+                                          int pl, bool flt, int& pad) {
+    const unsigned char* c = tok;
+    pad = 0;
+    for (int f = 0; f < nf; ++f) {
+        const int kind = kinds[f];
+        if (flt) {
+            while (*c != ':' && *c != '\t' && *c != ',' && *c != '\n' && *c != '\r' && *c != 0) ++c;
+            if (*c == ',') return false;
+            if (c == tok && f == 0) return false;
+        } else if (kind == 1) {
+            int na = 0;
+            unsigned char sep = 0;
+            for (;;) {
+                if (*c == '.') {
+                    ++c;
+                } else if (*c == '0') {
+                    ++c;
+                    if (is_digit(*c)) return false;
+                } else if (is_digit(*c)) {
+                    const unsigned char* a = c;
+                    do ++c; while (is_digit(*c));
+                    if (c - a > 9) return false;
+                } else {
+                    return false;
+                }
+                ++na;
+                if (*c != '/' && *c != '|') break;
+                if (sep && *c != sep) return false;
+                sep = *c++;
+            }
+            if (na > pl) return false;
+        } else if (kind == 2) {
+            if (*c == '.') {
+                ++c;
+            } else {
+                if (*c == '-') {
+                    ++c;
+                    if (*c == '0') return false;
+                }
+                if (*c == '0') {
+                    ++c;
+                    if (is_digit(*c)) return false;
+                } else if (is_digit(*c)) {
+                    const unsigned char* a = c;
+                    do ++c; while (is_digit(*c));
+                    if (c - a > 9) return false;
+                } else {
+                    return false;
+                }
+            }
+        } else if (kind == 4) {
+            const unsigned char* a = c;
+            while (*c != ':' && *c != '\t' && *c != '\n' && *c != '\r') {
+                if (*c >= 0x80 || *c == 0) return false;
+                ++c;
+            }
+            if (c == a) return false;
+        } else {
+            if (*c == '.' && !is_digit(c[1])) {
+                ++c;
+            } else {
+                if (*c == '-') ++c;
+                const unsigned char* ip = c;
+                while (is_digit(*c)) ++c;
+                const long ni = c - ip;
+                if (ni < 1 || (ni > 1 && *ip == '0') || ni > 6) return false;
+                if (*c == '.') {
+                    const unsigned char* fp = ++c;
+                    while (is_digit(*c)) ++c;
+                    const long nfr = c - fp;
+                    if (nfr < 1 || c[-1] == '0') return false;
+                    if (*ip != '0') {
+                        if (ni + nfr > 6) return false;
+                    } else {
+                        const unsigned char* z = fp;
+                        while (*z == '0') ++z;
+                        if (z - fp > 3 || c - z > 6) return false;
+                    }
+                }
+            }
+        }
+        if (f + 1 < nf) {
+            if (*c == ':') { ++c; continue; }
+            if (c == tok_end) {
+                pad = flt ? 0 : nf - 1 - f;
+                break;
+            }
+            return false;
+        }
+    }
+    return c == tok_end;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(PS_THREADS) void k_format_samples(const FormatArgs a) {
+    __shared__ uint16_t s_cnt[PS_CHUNKS];
+    __shared__ uint32_t s_tok[PS_MAXTOK];
+    __shared__ uint32_t s_wsum[PS_THREADS / 64];
+    __shared__ uint32_t s_flags, s_base, s_obase;
+    __shared__ uint8_t s_kinds[TRK_FORMAT_MAX_FIELDS];
+    __shared__ char s_null[64];
+    __shared__ int s_nl;
+    const int rec = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int S = a.in.n_samples;
+    const int nf = a.in.n_fields[rec], pl = a.in.ploidy[rec];
+    if (EMIT && a.out.flags[rec]) return;                  // the host writes this record
+    const int64_t r0 = a.in.smp_off[rec], r1 = a.in.line_end[rec];
+    if (tid == 0) {
+        s_flags = (nf < 1 || nf > TRK_FORMAT_MAX_FIELDS || pl < 1 || pl > 8 || r1 <= r0) ? TRK_PARSE_HOST : 0u;
+        s_base = 0;
+        s_obase = 0;
+        int nl = 0;
+        for (int f = 0; f < nf && f < TRK_FORMAT_MAX_FIELDS; ++f) {
+            const uint8_t k = a.in.field_kind[(int64_t)rec * TRK_FORMAT_MAX_FIELDS + f];
+            s_kinds[f] = k;
+            if (k < 1 || k > 4) s_flags = TRK_PARSE_HOST;
+            if (f) s_null[nl++] = ':';
+            if (k == 1) {
+                for (int j = 0; j < pl && j < 8; ++j) {
+                    if (j) s_null[nl++] = '/';
+                    s_null[nl++] = '.';
+                }
+            } else {
+                s_null[nl++] = '.';
+            }
+        }
+        s_nl = nl;
+    }
+    __syncthreads();
+    if (s_flags) {
+        if (!EMIT && tid == 0) {
+            a.out.flags[rec] = (uint8_t)s_flags;
+            a.out.rec_len[rec] = 0;
+        }
+        return;
+    }
+    const unsigned char* reg = a.in.text + r0;
+    const int64_t n = r1 - r0;
+    const int64_t lead = (int64_t)((uintptr_t)reg & 15u);
+    const int64_t span = n + lead;
+    const uint8_t* mrow = a.in.mask8 + (int64_t)rec * a.in.mask_stride;
+    unsigned char* obuf = EMIT ? a.out.out + a.out.out_off[rec] : nullptr;
+    for (int64_t t0 = 0; t0 < span; t0 += PS_TILE) {
+        uint32_t mk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = tid + q * PS_THREADS;
+            const int64_t o = t0 + (int64_t)c * 16 - lead;
+            uint32_t m = 0;
+            if (o < n && o + 16 > 0) {
+                const uint4 v = *reinterpret_cast<const uint4*>(reg + o);
+                m = tab_mask(v);
+                if (o < 0) m &= ~((1u << (int)(-o)) - 1u);
+                if (o + 16 > n) m &= (1u << (int)(n - o)) - 1u;
+            }
+            mk[q] = m;
+            s_cnt[c] = (uint16_t)__popc(m);
+        }
+        __syncthreads();
+        uint32_t own[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            own[q] = s_cnt[4 * tid + q];
+            sum += own[q];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)incl, o, 64);
+            if ((tid & 63) >= o) incl += y;
+        }
+        if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (int w = 0; w < (tid >> 6); ++w) wbase += s_wsum[w];
+        const uint32_t tile_tabs = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        uint32_t run = wbase + incl - sum;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            s_cnt[4 * tid + q] = (uint16_t)run;
+            run += own[q];
+        }
+        __syncthreads();
+        const uint32_t first = t0 == 0 ? 1u : 0u;
+        if (t0 == 0 && tid == 0) s_tok[0] = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = tid + q * PS_THREADS;
+            uint32_t m = mk[q];
+            uint32_t k = first + s_cnt[c];
+            const int64_t o = t0 + (int64_t)c * 16 - lead;
+            while (m) {
+                const int b = __ffs((int)m) - 1;
+                m &= m - 1;
+                if (k < (uint32_t)PS_MAXTOK) s_tok[k] = (uint32_t)(o + b + 1);
+                ++k;
+            }
+        }
+        __syncthreads();
+        const uint32_t base = s_base, obase = s_obase;
+        const uint32_t ntok = first + tile_tabs;
+        if (ntok > (uint32_t)PS_MAXTOK || (int64_t)base + ntok > S) {     // (uniform) too many columns, or degenerate text
+            if (tid == 0) s_flags |= TRK_PARSE_HOST;
+            __syncthreads();
+            break;
+        }
+        // ---- lane t owns tokens [t per, (t + 1) per) of the tile: lengths, then (EMIT) the bytes at its running offset ----
+        const uint32_t per = (ntok + PS_THREADS - 1) / PS_THREADS;
+        const uint32_t k0 = min(ntok, (uint32_t)tid * per), k1 = min(ntok, k0 + per);
+        uint32_t lflags = 0;
+        // pass over my tokens twice when emitting: lengths first (for the scan), bytes second
+        uint32_t mylen = 0;
+        for (uint32_t k = k0; k < k1; ++k) {
+            const int64_t s = (int64_t)base + k;
+            const unsigned char* tok = reg + s_tok[k];
+            // the token ends at the next token's tab -- the next start minus one -- or at the line's end
+            const unsigned char* tok_end = (k + 1 < ntok) ? reg + s_tok[k + 1] - 1 : nullptr;
+            if (!tok_end) {
+                // the last token of the tile: up to the next tab, or the end of the region
+                const unsigned char* e = tok;
+                while (e < reg + n && *e != '\t') ++e;
+                tok_end = e;
+            }
+            const uint8_t mb = mrow[s];
+            const bool flt = (mb & 0x7f) != 0 && !(mb & 0x80);
+            int pad;
+            if (!tok_check(tok, tok_end, s_kinds, nf, pl, flt, pad)) {
+                lflags |= TRK_PARSE_HOST;
+                continue;
+            }
+            uint32_t len = 1;
+            if (flt) {
+                len += (uint32_t)s_nl + 1;
+                int cnt = 0;
+                for (int b = 0; b < a.in.n_filters; ++b) {
+                    if (!((mb >> b) & 1)) continue;
+                    if (cnt++) ++len;
+                    int ln = 0;
+                    while (a.in.filter_name[b][ln]) ++ln;
+                    char tmp[24];
+                    const double x = a.in.filter_dtype[b] ? (double)static_cast<const float*>(a.in.filter_plane[b])[(int64_t)rec * a.in.plane_stride + s]
+                                                          : (double)static_cast<const int32_t*>(a.in.filter_plane[b])[(int64_t)rec * a.in.plane_stride + s];
+                    const int gl = g6(tmp, x);
+                    if (gl < 0) { lflags |= TRK_PARSE_HOST; break; }
+                    len += (uint32_t)ln + 1 + (uint32_t)gl;
+                }
+                if (!cnt) ++len;
+            } else {
+                len += (uint32_t)(tok_end - tok) + 2u * (uint32_t)pad + ((mb & 0x80) ? 7u : 5u);
+            }
+            mylen += len;
+        }
+        // exclusive scan of the lanes' lengths over the workgroup
+        uint32_t li = mylen;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)li, o, 64);
+            if ((tid & 63) >= o) li += y;
+        }
+        __syncthreads();
+        if ((tid & 63) == 63) s_wsum[tid >> 6] = li;
+        __syncthreads();
+        uint32_t lbase = 0;
+        for (int w = 0; w < (tid >> 6); ++w) lbase += s_wsum[w];
+        const uint32_t tile_len = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        if (EMIT) {
+            unsigned char* w = obuf + obase + lbase + li - mylen;
+            for (uint32_t k = k0; k < k1; ++k) {
+                const int64_t s = (int64_t)base + k;
+                const unsigned char* tok = reg + s_tok[k];
+                const unsigned char* tok_end = (k + 1 < ntok) ? reg + s_tok[k + 1] - 1 : nullptr;
+                if (!tok_end) {
+                    const unsigned char* e = tok;
+                    while (e < reg + n && *e != '\t') ++e;
+                    tok_end = e;
+                }
+                const uint8_t mb = mrow[s];
+                const bool flt = (mb & 0x7f) != 0 && !(mb & 0x80);
+                *w++ = '\t';
+                if (flt) {
+                    for (int i = 0; i < s_nl; ++i) *w++ = (unsigned char)s_null[i];
+                    *w++ = ':';
+                    int cnt = 0;
+                    for (int b = 0; b < a.in.n_filters; ++b) {
+                        if (!((mb >> b) & 1)) continue;
+                        if (cnt++) *w++ = ',';
+                        for (int i = 0; a.in.filter_name[b][i]; ++i) *w++ = (unsigned char)a.in.filter_name[b][i];
+                        *w++ = '_';
+                        char tmp[24];
+                        const double x = a.in.filter_dtype[b] ? (double)static_cast<const float*>(a.in.filter_plane[b])[(int64_t)rec * a.in.plane_stride + s]
+                                                              : (double)static_cast<const int32_t*>(a.in.filter_plane[b])[(int64_t)rec * a.in.plane_stride + s];
+                        const int gl = g6(tmp, x);
+                        for (int i = 0; i < gl; ++i) *w++ = (unsigned char)tmp[i];
+                    }
+                    if (!cnt) *w++ = '.';
+                } else {
+                    int pad = 0;
+                    {   // fields the token lacks: its colons against the record's keys
+                        int colons = 0;
+                        for (const unsigned char* c = tok; c < tok_end; ++c) colons += *c == ':';
+                        pad = nf - 1 - colons;
+                        if (pad < 0) pad = 0;
+                    }
+                    for (const unsigned char* c = tok; c < tok_end; ++c) *w++ = *c;
+                    for (int i = 0; i < pad; ++i) {
+                        *w++ = ':';
+                        *w++ = '.';
+                    }
+                    const char* tag = (mb & 0x80) ? ":NOCALL" : ":PASS";
+                    for (int i = 0; tag[i]; ++i) *w++ = (unsigned char)tag[i];
+                }
+            }
+        }
+        if (lflags) atomicOr(&s_flags, lflags);
+        __syncthreads();
+        if (tid == 0) {
+            s_base = base + ntok;
+            s_obase = obase + tile_len;
+        }
+        __syncthreads();
+        if (s_flags) break;                 // (uniform) the host writes this record: no need to go on
+    }
+    if (!EMIT && tid == 0) {
+        uint32_t f = s_flags;
+        if (!f && (int64_t)s_base != S) f |= TRK_PARSE_HOST;
+        a.out.flags[rec] = (uint8_t)f;
+        a.out.rec_len[rec] = f ? 0u : s_obase;
+    }
+}
+
 }  // namespace
 
 namespace trk {
@@ -301,6 +696,14 @@ hipError_t launch_parse_samples(const trk_parse_in& in, const trk_parse_out& out
     if (in.n_records <= 0) return hipSuccess;
     ParseArgs a{in, out};
     hipLaunchKernelGGL(k_parse_samples, dim3((unsigned)in.n_records), dim3(PS_THREADS), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_format_samples(const trk_format_in& in, const trk_format_out& out, int pass, hipStream_t stream) {
+    if (in.n_records <= 0) return hipSuccess;
+    FormatArgs a{in, out};
+    if (pass == 1) hipLaunchKernelGGL(k_format_samples<false>, dim3((unsigned)in.n_records), dim3(PS_THREADS), 0, stream, a);
+    else hipLaunchKernelGGL(k_format_samples<true>, dim3((unsigned)in.n_records), dim3(PS_THREADS), 0, stream, a);
     return hipGetLastError();
 }
 

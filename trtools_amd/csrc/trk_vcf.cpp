@@ -3060,7 +3060,7 @@ FmtChunkPool& fmt_chunks() {
 }
 
 // records written without decoding / through the decode path / with a caller-built head, since the process started
-std::atomic<int64_t> g_fmt_fast{0}, g_fmt_slow{0}, g_fmt_py_heads{0}, g_fmt_scalar{0};   // (scalar: of the fast ones, the scalar tier's)
+std::atomic<int64_t> g_fmt_fast{0}, g_fmt_slow{0}, g_fmt_py_heads{0}, g_fmt_scalar{0}, g_fmt_device{0};   // (scalar / device: of the fast ones, the scalar tier's / the device's)
 
 int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const trk_vcf_dumpstr2* ext, char* out,
                      int64_t cap, int32_t* err_record) {
@@ -3260,6 +3260,20 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
             const char* smp = line + fo[9];
             const int64_t smp_len = line_len - fo[9];
             const int pl = in->locus_ploidy[l];
+            if (fast_ok && ext->dev_regions && ext->dev_flags && !ext->dev_flags[l] && filter_idx < 0) {
+                // the device wrote this record's sample columns (trk_format_samples): head + those bytes + newline
+                const size_t rl = ext->dev_region_len[l];
+                char* dst = room(hl + rl + 1);
+                memcpy(dst, head, hl);
+                memcpy(dst + hl, ext->dev_regions + ext->dev_region_off[l], rl);
+                dst[hl + rl] = '\n';
+                rptr[(size_t)l] = dst;
+                rlen[(size_t)l] = hl + rl + 1;
+                cur_n += rlen[(size_t)l];
+                g_fmt_fast.fetch_add(1, std::memory_order_relaxed);
+                g_fmt_device.fetch_add(1, std::memory_order_relaxed);
+                continue;
+            }
             // the mask of this record as 32 bits; filtered = some filter fired on a called sample (dumpSTR.py:715-717)
             uint32_t any_bits = 0;
             for (int s = 0; s < S; ++s) {
@@ -3447,6 +3461,49 @@ void trk_vcf_dumpstr_stats(int64_t* fast, int64_t* decoded, int64_t* caller_head
     if (fast) *fast = g_fmt_fast.load();
     if (decoded) *decoded = g_fmt_slow.load();
     if (caller_heads) *caller_heads = g_fmt_py_heads.load();
+}
+
+int trk_vcf_format_kinds(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, uint8_t* kinds16, uint8_t* n_fields) {
+    if (!b || !in || !kinds16 || !n_fields) return 2;
+    const int n = b->n_records;
+    for (int l = 0; l < n; ++l) {
+        uint8_t* k16 = kinds16 + (size_t)l * 16;
+        memset(k16, 0, 16);
+        n_fields[l] = 0;
+        const char* line = b->text + b->line_off[l];
+        const int32_t* fo = b->field_off + (size_t)l * 10;
+        const int64_t line_len = b->line_end[l] - b->line_off[l];
+        if (fo[9] <= fo[8] || fo[9] >= line_len) continue;
+        const char* f = line + fo[8];
+        const char* fe = line + fo[9] - 1;
+        int nf = 0;
+        bool ok = true, have_gt = false;
+        for (const char* a = f; a <= fe;) {
+            const char* c = find_ch(a, fe, ':');
+            const size_t kl = (size_t)(c - a);
+            int kind = 4;
+            if (kl == 2 && a[0] == 'G' && a[1] == 'T') {
+                kind = 1;
+                if (have_gt) ok = false;
+                have_gt = true;
+            } else if (kl == 6 && memcmp(a, "FILTER", 6) == 0) {
+                ok = false;
+            } else {
+                for (int t = 0; t < in->n_format_keys; ++t)
+                    if (strlen(in->format_keys[t]) == kl && memcmp(in->format_keys[t], a, kl) == 0) {
+                        const int fk = in->format_kinds[t];
+                        kind = fk == TRK_VCF_COL_INT ? 2 : fk == TRK_VCF_COL_FLOAT ? 3 : fk == TRK_VCF_COL_UCS4 ? 4 : 0;
+                        break;
+                    }
+            }
+            if (kind == 0 || nf >= 16) { ok = false; break; }
+            k16[nf++] = (uint8_t)kind;
+            if (c >= fe) break;
+            a = c + 1;
+        }
+        if (ok && have_gt) n_fields[l] = (uint8_t)nf;
+    }
+    return 0;
 }
 
 int64_t trk_vcf_dumpstr_records(const trk_vcf_batch* b, const trk_vcf_dumpstr2* in, char* out, int64_t cap,

@@ -560,7 +560,7 @@ class _Run:
             dev['gt'] = None
             for k in keys:
                 dev['planes'][k] = None
-            rb.release_device()
+            # (the text and the offsets stay on the device for the record writer's device half; released with the batch)
         else:
             hb = HostBatch.from_tables(rb.gt, rb.locus_ploidy, hz.allele_off, hz.len_class, hz.str_class,
                                        hz.len_class_value, lists=hz.lists)

@@ -106,7 +106,11 @@ class _DumpRecords(C.Structure):
                 ('hrun', C.c_void_p), ('have_stats', C.c_void_p), ('het', C.c_void_p), ('hwep', C.c_void_p),
                 ('allele_count', C.c_void_p), ('allele_off', C.c_void_p), ('n_info_keys', C.c_int32),
                 ('fast_path', C.c_int32), ('info_keys', C.POINTER(C.c_char_p)), ('info_kinds', C.POINTER(C.c_int32)),
-                ('need_head', C.c_void_p)]
+                ('need_head', C.c_void_p), ('dev_regions', C.c_void_p), ('dev_region_off', C.c_void_p),
+                ('dev_region_len', C.c_void_p), ('dev_flags', C.c_void_p)]
+
+
+DEVICE_FORMAT = dict(records=0, left_to_host=0)     # records whose sample columns the device wrote / left to the host writer
 
 
 class RawBatch:
@@ -148,7 +152,7 @@ class RawBatch:
         """Give the device-parsed arrays back (the caller took what it needs, or handed them to a DeviceBatch)."""
         d, self.dev = self.dev, None
         if d is not None:
-            for a in [d.get('gt'), d.get('phased')] + list(d.get('planes', {}).values()):
+            for a in [d.get('gt'), d.get('phased'), d.get('text'), d.get('smp_off'), d.get('line_end')] + list(d.get('planes', {}).values()):
                 if a is not None and a.ptr is not None:
                     a.free()
 
@@ -315,6 +319,11 @@ class RawBatch:
                                arrs['hwep'].ctypes.data, arrs['allele_count'].ctypes.data, arrs['allele_off'].ctypes.data,
                                len(ik), 1, ikeys, ikinds, need.ctypes.data)
             keep.extend([ftarr, ikeys, ikinds, need])
+            regions = self._device_regions(prm, mask, cf_values, S, out_ring)
+            if regions is not None:
+                ext.dev_regions, ext.dev_region_off = regions['buf'].ctypes.data, regions['off'].ctypes.data
+                ext.dev_region_len, ext.dev_flags = regions['len'].ctypes.data, regions['flags'].ctypes.data
+                keep.append(regions)
         # output bound: the input text, a third more for re-serialised numbers, and per call the FILTER column this
         # pass appends (':PASS' / ':NOCALL'; the longer '<name>_<value>' strings of the few filtered calls fit in
         # the slack).  The buffer is not touched beyond what is written, so a generous bound costs nothing -- a
@@ -353,6 +362,76 @@ class RawBatch:
             if n <= -(1 << 63) + 1:
                 return None
             cap = -n + 64
+
+    def _device_regions(self, prm, mask, cf_values, S, out_ring):
+        """The sample columns of the batch's output records written ON THE DEVICE (trk_format_samples; round 4): needs the
+        batch's text there (device-parse mode), the one-byte mask and plain-value filters.  Returns host arrays
+        (buf, off, len, flags) for trk_vcf_dumpstr2.dev_*, or None (the host writer does everything).
+        Opt-in (TRK_DEVICE_FORMAT=1): byte-identical output, and measured NEUTRAL on the 1 GB command line (0.28-0.30 s either
+        way: what the 32 host threads spend on the text, the device path spends on moving mask / planes up and 1.5 GB of
+        columns down on the caller's thread -- profiles/r04_notes.md section 16)."""
+        d = self.dev
+        if (d is None or d.get('text') is None or os.environ.get('TRK_DEVICE_FORMAT', '0') != '1' or self.n == 0 or
+                mask.dtype != np.uint8 or len(cf_values) > _lib.FORMAT_MAX_FILTERS or
+                any(kind != 0 or bsrc is not None or int(a[1]) != 0 or len(name.encode()) > 31 or
+                    (np.asarray(a[0]).ndim == 3 and np.asarray(a[0]).shape[2] != 1) for name, kind, a, bsrc in cf_values)):
+            return None
+        eng, n, lib = d['eng'], self.n, self.reader._lib
+        kinds16, nf = np.zeros((n, 16), np.uint8), np.zeros(n, np.uint8)
+        if lib.trk_vcf_format_kinds(C.byref(self.b), C.byref(prm), kinds16.ctypes.data, nf.ctypes.data) != 0 or not nf.any():
+            return None
+        tmp = []
+
+        def up(x, dt):
+            a = eng.upload(np.ascontiguousarray(x, dtype=dt), dt)
+            tmp.append(a)
+            return a
+        fin = _lib.FormatIn()
+        fin.text, fin.n_bytes = d['text'].ptr, d['text'].nbytes
+        fin.n_records, fin.n_samples, fin.mask_stride, fin.plane_stride = n, S, S, S
+        fin.smp_off, fin.line_end = d['smp_off'].ptr, d['line_end'].ptr
+        fin.field_kind, fin.n_fields = up(kinds16, np.uint8).ptr, up(nf, np.uint8).ptr
+        fin.ploidy, fin.mask8 = up(self.locus_ploidy, np.uint8).ptr, up(mask, np.uint8).ptr
+        fin.n_filters = len(cf_values)
+        for k, (name, kind, a, bsrc) in enumerate(cf_values):
+            pa = np.asarray(a[0])
+            fin.filter_name[k].value = name.encode()
+            fin.filter_plane[k] = up(pa.reshape(n, S), pa.dtype).ptr
+            fin.filter_dtype[k] = 1 if pa.dtype == np.float32 else 0
+        rec_len, flags = eng.empty((n,), np.uint32), eng.empty((n,), np.uint8)
+        tmp += [rec_len, flags]
+        fout = _lib.FormatOut()
+        fout.rec_len, fout.flags = rec_len.ptr, flags.ptr
+        try:
+            eng._chk(eng.lib.trk_format_samples(eng.ctx, C.byref(fin), C.byref(fout), 1))
+            ln, fl = rec_len.get(), flags.get()
+            off = np.zeros(n, np.int64)
+            np.cumsum(ln[:-1], out=off[1:])
+            total = int(off[-1] + ln[-1])
+            if total == 0:
+                return None
+            out_d = eng.empty((total + 16,), np.uint8)
+            tmp.append(out_d)
+            fout.out, fout.out_off = out_d.ptr, up(off, np.int64).ptr
+            eng._chk(eng.lib.trk_format_samples(eng.ctx, C.byref(fin), C.byref(fout), 2))
+            # back into one of two pinned buffers kept for the run (the writer reads them before the batch after the next)
+            ring = out_ring if out_ring is not None else {}
+            key = ('dev', ring.get('i', 0))
+            buf = ring.get(key)
+            if buf is None or buf.size < total:
+                alloc = getattr(self.reader, '_alloc', None)
+                buf = alloc(int(total * 1.25) + (1 << 20)) if alloc is not None else np.empty(int(total * 1.25) + (1 << 20), np.uint8)
+                if alloc is not None:
+                    self.reader._slabs = getattr(self.reader, '_slabs', []) + [buf]
+                ring[key] = buf
+            eng._chk(eng.lib.trk_memcpy_d2h(eng.ctx, buf.ctypes.data, out_d.ptr, total))
+        finally:
+            eng.sync()
+            for a in tmp:
+                a.free()
+        DEVICE_FORMAT['records'] += int((fl == 0).sum())
+        DEVICE_FORMAT['left_to_host'] += int((fl != 0).sum())
+        return dict(buf=buf, off=off, len=np.ascontiguousarray(ln, dtype=np.uint32), flags=np.ascontiguousarray(fl, dtype=np.uint8))
 
     def iter_variants(self):
         """The batch's vcfio.Variant objects one at a time (a malformed line raises at ITS turn, as the per-record
@@ -401,6 +480,7 @@ def _api():
         lib.trk_vcf_sample_name.restype = C.c_char_p
         lib.trk_vcf_select_format.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
         lib.trk_vcf_read_batch.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_Batch)]
+        lib.trk_vcf_format_kinds.argtypes = [C.POINTER(_Batch), C.POINTER(_DumpLines), vp, vp]
         lib.trk_vcf_skip_samples.argtypes = [vp, C.c_int]
         lib.trk_vcf_set_text_buffers.argtypes = [vp, vp, vp, C.c_size_t]
         lib.trk_vcf_format_idx.argtypes = [vp, C.POINTER(C.c_int32)]
@@ -624,14 +704,15 @@ class NativeVCFReader(vcfio.VCFReader):
             td = eng.empty((nbytes + 32,), np.uint8)
             eng._chk(eng.lib.trk_memcpy_h2d(eng.ctx, td.ptr, b.text + base, nbytes))
             kinds = ['f' if kd == KIND_FLOAT else 'i' for _, kd, _, _ in self._selected]
-            out = eng.parse_samples(td, (lo + fo9 - base).astype(np.int64), (le - base).astype(np.int64), S, P,
+            so_d = eng.upload((lo + fo9 - base).astype(np.int64), np.int64)
+            le_d = eng.upload((le - base).astype(np.int64), np.int64)
+            out = eng.parse_samples(td, so_d, le_d, S, P,
                                     np.ascontiguousarray(fi[:, 0]),
                                     planes=[(np.ascontiguousarray(fi[:, 1 + j]), k) for j, k in enumerate(kinds)],
                                     want_phased=True)
             flags = out['flags'].get()
-            td.free()
             if flags.any():
-                for a in [out['gt'], out['phased'], out['locus_ploidy'], out['flags']] + out['planes']:
+                for a in [out['gt'], out['phased'], out['locus_ploidy'], out['flags'], td, so_d, le_d] + out['planes']:
                     a.free()
                 out = None
         if out is None:
@@ -656,7 +737,8 @@ class NativeVCFReader(vcfio.VCFReader):
         lp[:n] = out['locus_ploidy'].get()
         out['locus_ploidy'].free()
         out['flags'].free()
-        dev = dict(gt=out['gt'], phased=out['phased'], planes={k: a for (k, _, _, _), a in zip(self._selected, out['planes'])})
+        dev = dict(gt=out['gt'], phased=out['phased'], planes={k: a for (k, _, _, _), a in zip(self._selected, out['planes'])},
+                   text=td, smp_off=so_d, line_end=le_d, eng=eng)     # (text and offsets stay: the record writer's device half)
         return dev, gt, ph, lp, planes, gtm, parr
 
     def shard(self, rank, world):
