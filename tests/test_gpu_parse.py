@@ -274,7 +274,7 @@ def test_dumpstr_command_line_with_the_sample_columns_parsed_on_the_device(tmp_p
 
 @pytest.mark.parametrize('seed', [5, 6, 7, 8])
 def test_dumpstr_sample_columns_written_on_the_device(tmp_path, seed):
-    """trk_format_samples behind dumpSTR's command line (TRK_DEVICE_FORMAT=1; opt-in): on the
+    """trk_format_samples behind dumpSTR's command line (on by default with the device parse; TRK_DEVICE_FORMAT=0: the host writer): on the
     HipSTR fixture and on its rewritten-text variants (numbers spelled every way, tokens that stop early, a lone '.', a
     field too many -- tests/test_batch_pipelines.py's generator) the output VCF is byte for byte the host writer's; the
     device takes the regular records and leaves the others."""

@@ -28,6 +28,14 @@ class CallHost:
         self.totaldp = totaldp
         self.dp_missing = dp_missing
         self.error = error
+        self.dev = None          # dumpstr_batch(keep_device=True): dict(mask8=, planes=[...], stride=) of DeviceArrays
+
+    def release_device(self):
+        d, self.dev = self.dev, None
+        if d is not None:
+            for a in [d.get('mask8')] + list(d.get('planes', [])):
+                if a is not None and a.ptr is not None:
+                    a.free()
 
 
 class AssocHost:
@@ -138,7 +146,7 @@ class DeviceCompute:
     supports_compact = True
     supports_class_layout = True      # locus_stats takes a HostBatch whose columns are in engine.class_layout order
 
-    def dumpstr_batch(self, hb, planes, filters, dp_plane, locus_spec, nalleles_thresh=0.01, compact=False):
+    def dumpstr_batch(self, hb, planes, filters, dp_plane, locus_spec, nalleles_thresh=0.01, compact=False, keep_device=False):
         """Call filters -> masked genotypes -> locus statistics -> locus filters, all on the device.
         Returns (CallHost, StatsHost, locus_bits uint32[L], loc_counters int64[32]).  ``compact``: the caller
         rebuilds its records from the mask -- only the one-byte mask comes back (trk_call_out.filter_mask8; CallHost.mask
@@ -172,6 +180,11 @@ class DeviceCompute:
                       call.sample_counters.get()[:, :S], totaldp[:S], call.sample_dp_missing.get()[:S], call.error.get())
         sh = StatsHost(st.allele_count.get(), st.locus_int.get(), st.locus_f64.get())
         out = (ch, sh, bits.get(), counters.get())
+        if keep_device and compact:
+            # the one-byte mask and the planes stay on the device for the record writer's device half (trk_format_samples);
+            # the caller gives them back (CallHost.release_device)
+            ch.dev = dict(mask8=call.filter_mask8, planes=list(dplanes), stride=int(b.struct.n_samples))
+            call.filter_mask8, dplanes = None, []
         self._free(b, *dplanes, call.gt_out, call.filter_mask, call.filter_mask8, call.sample_counters, call.sample_totaldp,
                    call.sample_totaldp_f64,
                    call.sample_dp_missing, call.error, st.allele_count, st.locus_int, st.locus_f64,

@@ -584,6 +584,8 @@ class _Run:
                     fire = f.overlaps_batch(chroms, hz.tr_pos, hz.tr_pos + ref_len)
                 ext |= fire.astype(np.uint32) << np.uint32(j)
         t_dev = time.perf_counter()
+        if dev is not None and kw.get('compact') and os.environ.get('TRK_DEVICE_FORMAT', '1') == '1':
+            kw['keep_device'] = True         # (the mask and the planes stay on the device for trk_format_samples)
         ch, st, bits, lc = compute.dumpstr_batch(hb, arrays, specs, -1 if dp_key is None else index[dp_key],
                                                  dict(self.spec, extern_bits=ext), **kw)
         t_heads = time.perf_counter()
@@ -591,6 +593,7 @@ class _Run:
         # the native writer first: if it declines, the batch has left no trace
         names = [f.name for f in self.call_filters]
         cfv = []
+        cf_plane_idx = []            # plain-value filters: which of the uploaded planes holds the value
         for f in self.call_filters:
             if isinstance(f, filters._HipSTRRatio):
                 cfv.append((f.name, 1, (rb.planes[f.numerator], 0), (rb.planes['DP'], 0)))
@@ -610,6 +613,7 @@ class _Run:
             else:
                 key = f.planes()[0][0]
                 cfv.append((f.name, 0, (rb.planes[key], 0), None))
+                cf_plane_idx.append(index[key])
         ul = bool(args.use_length)
         I0, F0 = st.locus_int[0], st.locus_f64[0]
         have = I0[:, L.LI_N_CALLED] > 0
@@ -667,7 +671,9 @@ class _Run:
             native = dict(keep=keep_rec, filter_text=ftext, hrun=hz.hrun, have_stats=have.astype(np.uint8),
                           het=F0[:, L.LF_HET_LEN if ul else L.LF_HET_STR], hwep=F0[:, L.LF_HWEP_LEN if ul else L.LF_HWEP_STR],
                           allele_count=st.allele_count[0], allele_off=hz.allele_off, info_types=self.invcf.info_types,
-                          py_head=py_head)
+                          py_head=py_head,
+                          dev_call=getattr(ch, 'dev', None) if len(cf_plane_idx) == len(cfv) else None,
+                          cf_plane_idx=cf_plane_idx)
         else:
             heads = []
             for l in range(rb.n):
@@ -682,6 +688,8 @@ class _Run:
         if not hasattr(self, '_out_ring'):
             self._out_ring = {}          # two output buffers for the run, taken in turn (one block is with the writer)
         text = rb.dumpstr_lines(heads, ch.mask, cfv, format_kinds, out_ring=self._out_ring, native=native)
+        if getattr(ch, 'dev', None) is not None:
+            ch.release_device()
         _tick('record_text_native', time.perf_counter() - t_lines)
         if text is None:
             return self._undo_batch()

@@ -8,6 +8,7 @@ selected FORMAT arrays are views into those batch arrays; other FORMAT fields ar
 available (decoded lazily in Python from the record text)."""
 import ctypes as C
 import os
+import sys
 
 from struct import error as struct_error
 
@@ -319,7 +320,7 @@ class RawBatch:
                                arrs['hwep'].ctypes.data, arrs['allele_count'].ctypes.data, arrs['allele_off'].ctypes.data,
                                len(ik), 1, ikeys, ikinds, need.ctypes.data)
             keep.extend([ftarr, ikeys, ikinds, need])
-            regions = self._device_regions(prm, mask, cf_values, S, out_ring)
+            regions = self._device_regions(prm, mask, cf_values, S, out_ring, native.get('dev_call'), native.get('cf_plane_idx'))
             if regions is not None:
                 ext.dev_regions, ext.dev_region_off = regions['buf'].ctypes.data, regions['off'].ctypes.data
                 ext.dev_region_len, ext.dev_flags = regions['len'].ctypes.data, regions['flags'].ctypes.data
@@ -363,20 +364,22 @@ class RawBatch:
                 return None
             cap = -n + 64
 
-    def _device_regions(self, prm, mask, cf_values, S, out_ring):
+    def _device_regions(self, prm, mask, cf_values, S, out_ring, dev_call=None, cf_plane_idx=None):
         """The sample columns of the batch's output records written ON THE DEVICE (trk_format_samples; round 4): needs the
         batch's text there (device-parse mode), the one-byte mask and plain-value filters.  Returns host arrays
         (buf, off, len, flags) for trk_vcf_dumpstr2.dev_*, or None (the host writer does everything).
-        Opt-in (TRK_DEVICE_FORMAT=1): byte-identical output, and measured NEUTRAL on the 1 GB command line (0.28-0.30 s either
-        way: what the 32 host threads spend on the text, the device path spends on moving mask / planes up and 1.5 GB of
-        columns down on the caller's thread -- profiles/r04_notes.md section 16)."""
+        On by default where the batch was parsed on the device (TRK_DEVICE_FORMAT=0: off): byte-identical output; with the
+        call-filter pass's mask and planes kept on the device 0.245-0.28 s against 0.28-0.30 on the 1 GB command line
+        (profiles/r04_notes.md section 16)."""
         d = self.dev
-        if (d is None or d.get('text') is None or os.environ.get('TRK_DEVICE_FORMAT', '0') != '1' or self.n == 0 or
+        if (d is None or d.get('text') is None or os.environ.get('TRK_DEVICE_FORMAT', '1') != '1' or self.n == 0 or
                 mask.dtype != np.uint8 or len(cf_values) > _lib.FORMAT_MAX_FILTERS or
                 any(kind != 0 or bsrc is not None or int(a[1]) != 0 or len(name.encode()) > 31 or
                     (np.asarray(a[0]).ndim == 3 and np.asarray(a[0]).shape[2] != 1) for name, kind, a, bsrc in cf_values)):
             return None
         eng, n, lib = d['eng'], self.n, self.reader._lib
+        import time as _t
+        _tm = [_t.perf_counter()]
         kinds16, nf = np.zeros((n, 16), np.uint8), np.zeros(n, np.uint8)
         if lib.trk_vcf_format_kinds(C.byref(self.b), C.byref(prm), kinds16.ctypes.data, nf.ctypes.data) != 0 or not nf.any():
             return None
@@ -388,23 +391,30 @@ class RawBatch:
             return a
         fin = _lib.FormatIn()
         fin.text, fin.n_bytes = d['text'].ptr, d['text'].nbytes
-        fin.n_records, fin.n_samples, fin.mask_stride, fin.plane_stride = n, S, S, S
+        # the mask and the value planes: the call-filter pass's own device arrays when the caller kept them (rows padded
+        # to `stride` samples), else uploaded again
+        on_dev = dev_call is not None and cf_plane_idx is not None and len(cf_plane_idx) == len(cf_values)
+        stride = int(dev_call['stride']) if on_dev else S
+        fin.n_records, fin.n_samples, fin.mask_stride, fin.plane_stride = n, S, stride, stride
         fin.smp_off, fin.line_end = d['smp_off'].ptr, d['line_end'].ptr
         fin.field_kind, fin.n_fields = up(kinds16, np.uint8).ptr, up(nf, np.uint8).ptr
-        fin.ploidy, fin.mask8 = up(self.locus_ploidy, np.uint8).ptr, up(mask, np.uint8).ptr
+        fin.ploidy = up(self.locus_ploidy, np.uint8).ptr
+        fin.mask8 = dev_call['mask8'].ptr if on_dev else up(mask, np.uint8).ptr
         fin.n_filters = len(cf_values)
         for k, (name, kind, a, bsrc) in enumerate(cf_values):
             pa = np.asarray(a[0])
             fin.filter_name[k].value = name.encode()
-            fin.filter_plane[k] = up(pa.reshape(n, S), pa.dtype).ptr
+            fin.filter_plane[k] = dev_call['planes'][cf_plane_idx[k]].ptr if on_dev else up(pa.reshape(n, S), pa.dtype).ptr
             fin.filter_dtype[k] = 1 if pa.dtype == np.float32 else 0
         rec_len, flags = eng.empty((n,), np.uint32), eng.empty((n,), np.uint8)
         tmp += [rec_len, flags]
         fout = _lib.FormatOut()
         fout.rec_len, fout.flags = rec_len.ptr, flags.ptr
         try:
+            _tm.append(_t.perf_counter())
             eng._chk(eng.lib.trk_format_samples(eng.ctx, C.byref(fin), C.byref(fout), 1))
             ln, fl = rec_len.get(), flags.get()
+            _tm.append(_t.perf_counter())
             off = np.zeros(n, np.int64)
             np.cumsum(ln[:-1], out=off[1:])
             total = int(off[-1] + ln[-1])
@@ -414,6 +424,7 @@ class RawBatch:
             tmp.append(out_d)
             fout.out, fout.out_off = out_d.ptr, up(off, np.int64).ptr
             eng._chk(eng.lib.trk_format_samples(eng.ctx, C.byref(fin), C.byref(fout), 2))
+            eng.sync(); _tm.append(_t.perf_counter())
             # back into one of two pinned buffers kept for the run (the writer reads them before the batch after the next)
             ring = out_ring if out_ring is not None else {}
             key = ('dev', ring.get('i', 0))
@@ -425,6 +436,10 @@ class RawBatch:
                     self.reader._slabs = getattr(self.reader, '_slabs', []) + [buf]
                 ring[key] = buf
             eng._chk(eng.lib.trk_memcpy_d2h(eng.ctx, buf.ctypes.data, out_d.ptr, total))
+            _tm.append(_t.perf_counter())
+            if os.environ.get('TRK_FMT_TIMING'):
+                print('[device format] setup %.1f ms, pass 1 %.1f, alloc + pass 2 %.1f, download of %.0f MB %.1f' % tuple(
+                    [(b_ - a_) * 1e3 for a_, b_ in zip(_tm[:3], _tm[1:4])] + [total / 1e6, (_tm[4] - _tm[3]) * 1e3]), file=sys.stderr)
         finally:
             eng.sync()
             for a in tmp:
