@@ -3071,6 +3071,10 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
     // it lies.  Chunks come from a process-wide pool and go back to it: no allocation, no page fault per batch
     std::vector<const char*> rptr((size_t)n, nullptr);
     std::vector<size_t> rlen((size_t)n, 0);
+    // a record whose sample columns the device wrote: the head sits in a chunk (rptr / rlen), the columns stay where the
+    // download put them (gptr / glen) until the gather copies both, and the newline, into the output block
+    std::vector<const char*> gptr((size_t)n, nullptr);
+    std::vector<size_t> glen((size_t)n, 0);
     std::vector<FmtChunk> used_chunks;
     std::mutex used_mu;
     std::atomic<int> next{0};
@@ -3263,13 +3267,13 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
             if (fast_ok && ext->dev_regions && ext->dev_flags && !ext->dev_flags[l] && filter_idx < 0) {
                 // the device wrote this record's sample columns (trk_format_samples): head + those bytes + newline
                 const size_t rl = ext->dev_region_len[l];
-                char* dst = room(hl + rl + 1);
+                char* dst = room(hl);
                 memcpy(dst, head, hl);
-                memcpy(dst + hl, ext->dev_regions + ext->dev_region_off[l], rl);
-                dst[hl + rl] = '\n';
                 rptr[(size_t)l] = dst;
-                rlen[(size_t)l] = hl + rl + 1;
-                cur_n += rlen[(size_t)l];
+                rlen[(size_t)l] = hl;
+                gptr[(size_t)l] = ext->dev_regions + ext->dev_region_off[l];
+                glen[(size_t)l] = rl + 1;        // (+ the newline, written by the gather)
+                cur_n += hl;
                 g_fmt_fast.fetch_add(1, std::memory_order_relaxed);
                 g_fmt_device.fetch_add(1, std::memory_order_relaxed);
                 continue;
@@ -3419,11 +3423,11 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
     }
     if (need_heads.load() > 0) return INT64_MIN + 2;   // ext->need_head says which records want their head from the caller
     int64_t total = 0;
-    for (size_t i = 0; i < (size_t)n; ++i) total += (int64_t)rlen[i];
+    for (size_t i = 0; i < (size_t)n; ++i) total += (int64_t)(rlen[i] + glen[i]);
     if (!out || total > cap) return -total;
     {   // the lines land at their prefix offsets, copied by the same number of threads
         std::vector<int64_t> at((size_t)n + 1, 0);
-        for (int i = 0; i < n; ++i) at[(size_t)i + 1] = at[(size_t)i] + (int64_t)rlen[(size_t)i];
+        for (int i = 0; i < n; ++i) at[(size_t)i + 1] = at[(size_t)i] + (int64_t)(rlen[(size_t)i] + glen[(size_t)i]);
         std::atomic<int> nx{0};
         auto copier = [&]() {
             for (;;) {
@@ -3431,6 +3435,12 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
                 if (i0 >= n) break;
                 for (int i = i0; i < std::min(n, i0 + 16); ++i)
                     if (rlen[(size_t)i]) memcpy(out + at[(size_t)i], rptr[(size_t)i], rlen[(size_t)i]);
+                for (int i = i0; i < std::min(n, i0 + 16); ++i)
+                    if (glen[(size_t)i]) {
+                        char* d = out + at[(size_t)i] + rlen[(size_t)i];
+                        memcpy(d, gptr[(size_t)i], glen[(size_t)i] - 1);
+                        d[glen[(size_t)i] - 1] = '\n';
+                    }
             }
         };
         std::vector<std::thread> tc;
