@@ -28,6 +28,7 @@ constexpr int PS_TILE = 16384;                 // bytes of text per tile
 constexpr int PS_CHUNKS = PS_TILE / 16;        // 1024 chunks, four per lane
 constexpr int PS_MAXTOK = PS_TILE / 2 + 2;     // tokens that can START in a tile (one byte + a tab each)
 constexpr int32_t PS_INT_MISSING = INT32_MIN;
+constexpr int FS_STAGE = 28672;                // bytes of a tile's output staged in LDS by k_format_samples<true>
 
 struct ParseArgs {
     trk_parse_in in;
@@ -453,7 +454,10 @@ __device__ __forceinline__ bool tok_check(const unsigned char* tok, const unsign
 template <bool EMIT>
 __global__ __launch_bounds__(PS_THREADS) void k_format_samples(const FormatArgs a) {
     __shared__ uint16_t s_cnt[PS_CHUNKS];
-    __shared__ uint32_t s_tok[PS_MAXTOK];
+    __shared__ uint16_t s_tok[PS_MAXTOK];          // token starts of the tile, relative to the tile's first byte (t0 - lead)
+    // EMIT: the tile's output is assembled in LDS (every lane writes its tokens' bytes there) and leaves for global
+    // memory four bytes per lane, coalesced; a tile whose output does not fit is written byte by byte as before
+    __shared__ uint32_t s_stage[EMIT ? FS_STAGE / 4 + 2 : 1];
     __shared__ uint32_t s_wsum[PS_THREADS / 64];
     __shared__ uint32_t s_flags, s_base, s_obase;
     __shared__ uint8_t s_kinds[TRK_FORMAT_MAX_FIELDS];
@@ -542,7 +546,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_format_samples(const FormatArgs 
         }
         __syncthreads();
         const uint32_t first = t0 == 0 ? 1u : 0u;
-        if (t0 == 0 && tid == 0) s_tok[0] = 0u;
+        if (t0 == 0 && tid == 0) s_tok[0] = (uint16_t)lead;      // (the region's first byte, relative to t0 - lead = -lead)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int c = tid + q * PS_THREADS;
@@ -552,7 +556,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_format_samples(const FormatArgs 
             while (m) {
                 const int b = __ffs((int)m) - 1;
                 m &= m - 1;
-                if (k < (uint32_t)PS_MAXTOK) s_tok[k] = (uint32_t)(o + b + 1);
+                if (k < (uint32_t)PS_MAXTOK) s_tok[k] = (uint16_t)(o + b + 1 - (t0 - lead));
                 ++k;
             }
         }
@@ -572,9 +576,9 @@ __global__ __launch_bounds__(PS_THREADS) void k_format_samples(const FormatArgs 
         uint32_t mylen = 0;
         for (uint32_t k = k0; k < k1; ++k) {
             const int64_t s = (int64_t)base + k;
-            const unsigned char* tok = reg + s_tok[k];
+            const unsigned char* tok = reg + (t0 - lead) + s_tok[k];
             // the token ends at the next token's tab -- the next start minus one -- or at the line's end
-            const unsigned char* tok_end = (k + 1 < ntok) ? reg + s_tok[k + 1] - 1 : nullptr;
+            const unsigned char* tok_end = (k + 1 < ntok) ? reg + (t0 - lead) + s_tok[k + 1] - 1 : nullptr;
             if (!tok_end) {
                 // the last token of the tile: up to the next tab, or the end of the region
                 const unsigned char* e = tok;
@@ -624,11 +628,12 @@ __global__ __launch_bounds__(PS_THREADS) void k_format_samples(const FormatArgs 
         for (int w = 0; w < (tid >> 6); ++w) lbase += s_wsum[w];
         const uint32_t tile_len = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
         if (EMIT) {
-            unsigned char* w = obuf + obase + lbase + li - mylen;
+            const bool staged = tile_len <= (uint32_t)FS_STAGE;      // (uniform)
+            unsigned char* w = (staged ? reinterpret_cast<unsigned char*>(s_stage) : obuf + obase) + lbase + li - mylen;
             for (uint32_t k = k0; k < k1; ++k) {
                 const int64_t s = (int64_t)base + k;
-                const unsigned char* tok = reg + s_tok[k];
-                const unsigned char* tok_end = (k + 1 < ntok) ? reg + s_tok[k + 1] - 1 : nullptr;
+                const unsigned char* tok = reg + (t0 - lead) + s_tok[k];
+                const unsigned char* tok_end = (k + 1 < ntok) ? reg + (t0 - lead) + s_tok[k + 1] - 1 : nullptr;
                 if (!tok_end) {
                     const unsigned char* e = tok;
                     while (e < reg + n && *e != '\t') ++e;
@@ -670,6 +675,23 @@ __global__ __launch_bounds__(PS_THREADS) void k_format_samples(const FormatArgs 
                     for (int i = 0; tag[i]; ++i) *w++ = (unsigned char)tag[i];
                 }
             }
+        }
+        if (EMIT && tile_len <= (uint32_t)FS_STAGE) {
+            __syncthreads();
+            unsigned char* dst = obuf + obase;
+            const unsigned char* st8 = reinterpret_cast<const unsigned char*>(s_stage);
+            const uint32_t head = min(tile_len, (uint32_t)((4u - (uint32_t)((uintptr_t)dst & 3u)) & 3u));
+            if ((uint32_t)tid < head) dst[tid] = st8[tid];
+            const uint32_t nd = (tile_len - head) >> 2;
+            uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + head);
+            const uint32_t sh = 8u * (head & 3u);
+            for (uint32_t i = tid; i < nd; i += PS_THREADS) {
+                const uint32_t sb = head + 4u * i;
+                const uint32_t lo = s_stage[sb >> 2], hi = s_stage[(sb >> 2) + 1];
+                d32[i] = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
+            }
+            const uint32_t done = head + 4u * nd;
+            if ((uint32_t)tid < tile_len - done) dst[done + tid] = st8[done + tid];
         }
         if (lflags) atomicOr(&s_flags, lflags);
         __syncthreads();
