@@ -191,7 +191,7 @@ class TrkError(RuntimeError):
 
 
 # the sources libtrk.so is built from, in the order csrc/Makefile hashes them
-_SOURCES = ['csrc/trk_api.hip', 'csrc/trk_assoc.hip', 'csrc/trk_binom.h', 'csrc/trk_internal.h', 'csrc/trk_kernels.hip',
+_SOURCES = ['csrc/trk_api.hip', 'csrc/trk_assoc.hip', 'csrc/trk_binom.h', 'csrc/trk_hwe.hip', 'csrc/trk_internal.h', 'csrc/trk_kernels.hip',
             'csrc/trk_parse.hip', 'csrc/trk_qc.hip', 'csrc/trk_student.h', 'csrc/trk_vcf.cpp', '../include/trk.h', '../include/trk_test.h', '../include/trk_vcf.h']
 
 

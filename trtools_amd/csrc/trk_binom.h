@@ -196,11 +196,15 @@ TRK_HD inline double binom_upper_tail(int64_t k, int64_t n, double p) {
 }
 
 // scipy _binary_search_for_binom_tst on a(x) = sign * pmf(x)
+// (a LEAF function on the device: ONE inlined pmf evaluation serves the loop and the final test -- a call from here
+// would cost a stack frame for the return address in every kernel that can reach the bisection)
 TRK_HD TRK_COLD inline int64_t binom_bsearch(double sign, double d, int64_t lo, int64_t hi, int64_t n,
                                     double p) {
-    while (lo < hi) {
-        int64_t mid = lo + (hi - lo) / 2;
-        double midval = sign * binom_pmf_cold(mid, n, p);
+    for (;;) {
+        const bool last = !(lo < hi);
+        const int64_t mid = last ? lo : lo + (hi - lo) / 2;
+        const double midval = sign * binom_pmf(mid, n, p);
+        if (last) return midval <= d ? lo : lo - 1;
         if (midval < d) {
             lo = mid + 1;
         } else if (midval > d) {
@@ -209,8 +213,6 @@ TRK_HD TRK_COLD inline int64_t binom_bsearch(double sign, double d, int64_t lo, 
             return mid;
         }
     }
-    if (sign * binom_pmf_cold(lo, n, p) <= d) return lo;
-    return lo - 1;
 }
 
 // The index scipy's bisection returns -- the largest i in [lo, hi] with sign * pmf(i) <= d, lo - 1 if there is none
@@ -221,7 +223,7 @@ TRK_HD TRK_COLD inline int64_t binom_bsearch(double sign, double d, int64_t lo, 
 // when the walk does not arrive.
 // *pmf_next = pmf(ix + 1) when ix < hi: both values start a tail sum of the test, which therefore needs no further
 // evaluation.
-TRK_HD inline int64_t binom_boundary(double sign, double d, int64_t lo, int64_t hi, int64_t n, double p, int64_t guess,
+TRK_HD TRK_HOT inline int64_t binom_boundary(double sign, double d, int64_t lo, int64_t hi, int64_t n, double p, int64_t guess,
                                      double* pmf_ix, double* pmf_next) {
     if (lo > hi) {                       // (the bisection's final test alone)
         const int64_t ix = sign * binom_pmf_cold(lo, n, p) <= d ? lo : lo - 1;

@@ -1,4 +1,4 @@
-// trk_internal.h -- declarations shared by trk_kernels.hip and trk_api.hip
+// trk_internal.h -- declarations shared by the translation units of libtrk.so
 #ifndef TRK_INTERNAL_H
 #define TRK_INTERNAL_H
 #include <hip/hip_runtime.h>
@@ -22,6 +22,20 @@ hipError_t launch_locus_finalize(const trk_batch& b, const int32_t* allele_count
                                  double* locus_f64, int32_t* scratch, void* worklist, double nalleles_thresh,
                                  hipStream_t stream);
 size_t finalize_worklist_bytes(int64_t n_group_loci);
+// one deferred HWE test: homogeneous work items, so the lanes of a wave differ only in loop trip counts, and loci
+// whose two allele partitions coincide are tested once.  Written by the finalisers (trk_kernels.hip), read by the
+// test kernels (trk_hwe.hip).
+struct HweItem {
+    int32_t slot;   // g * L + l
+    int32_t modes;  // bit 0: write HWEP_LEN, bit 1: write HWEP_STR
+    int32_t k, n;
+    double p;
+};
+// the tests of a compact work list (header word 0 items; `overflow`: room for one index per item) and of fixed slots
+// (modes == 0: none) -- trk_hwe.hip
+hipError_t launch_hwe_tests(unsigned int* count, const HweItem* items, double* locus_f64, unsigned int* overflow,
+                            int64_t n_group_loci, hipStream_t stream);
+hipError_t launch_hwe_slots(const HweItem* items, unsigned int n_slots, double* locus_f64, hipStream_t stream);
 // device scratch owned by the context, handed out (and grown) on request; nullptr when it cannot be had
 struct Scratch {
     void* user;

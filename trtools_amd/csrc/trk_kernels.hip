@@ -36,6 +36,8 @@
 #include "trk_binom.h"
 #include "trk_internal.h"
 
+using trk::HweItem;
+
 namespace {
 
 constexpr int WAVE = 64;
@@ -750,16 +752,6 @@ __global__ __launch_bounds__(WAVE* COUNT_WAVES_PER_WG) void k_locus_count_v2(
 // 32-lane group share rows and own 16 columns each (a ds_add_u32 is served in lane groups {0-31}, {32-63}).
 // bins as in v2: 0 '-2', 1 '-1', 2..A+1 alleles, A+2 out of range, A+3..A+6 sentinel pairs.
 // ---------------------------------------------------------------------------
-// one deferred HWE test (k_hwe_test): homogeneous work items, so the lanes of a wave
-// differ only in loop trip counts, and loci whose two allele partitions coincide are
-// tested once
-struct HweItem {
-    int32_t slot;   // g * L + l
-    int32_t modes;  // bit 0: write HWEP_LEN, bit 1: write HWEP_STR
-    int32_t k, n;
-    double p;
-};
-
 template <int LPL>
 __device__ __forceinline__ int seg_sum(int v) {
 #pragma unroll
@@ -1667,82 +1659,6 @@ __global__ __launch_bounds__(FC_THREADS) void k_locus_finalize_coop(trk_batch b,
     fa.hwe_count = hwe_count;
     fa.items = hwe_items;
     coop_finalize<FC_LPL>(fa, live, true, sl, sub * FC_LPL, A, n_called, n_low, n_homl, n_homs, n_bad);
-}
-
-// Two neighbouring lanes per test: the kernel lasts as long as its slowest test, and a test is a chain of pmf
-// evaluations that go two at a time this way (trk_binom.h).  The kernel runs beside the call-filter kernel of the
-// step, in the registers that one leaves free: it holds the pair routine alone -- the few tests the pair hands back
-// (worklist header word 1 counts them) are done by k_hwe_test_serial right after.
-template <int WAVES>   // waves per SIMD the kernel is compiled for: 7 -> 72 registers, what five call-filter waves leave free
-__global__ __launch_bounds__(FIN_THREADS, WAVES) void k_hwe_test(unsigned int* __restrict__ hwe_count,
-                                                         const HweItem* __restrict__ items,
-                                                         double* __restrict__ locus_f64,
-                                                         unsigned int* __restrict__ overflow) {
-    const unsigned int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned int t = tid >> 1;
-    if (t >= hwe_count[0]) return;
-    const HweItem it = items[t];
-    bool ok;
-    const double pv = trkmath::binomtest_two_sided_pair(it.k, it.n, it.p, (int)(tid & 1), &ok);  // utils.py:334-338
-    if (tid & 1) return;
-    if (!ok) {
-        overflow[atomicAdd(&hwe_count[1], 1u)] = t;
-        return;
-    }
-    double* lf = locus_f64 + (int64_t)it.slot * TRK_LF_COLS;
-    if (it.modes & 1) lf[TRK_LF_HWEP_LEN] = pv;
-    if (it.modes & 2) lf[TRK_LF_HWEP_STR] = pv;
-}
-
-// one lane per test: the items of `list` (header word 1 entries), or every item (list == nullptr, TRK_HWE_SERIAL=1)
-// (compiled for the registers the call-filter waves leave free, like the pair kernel: a launch that needs more waits
-// for the whole call-filter kernel to retire, with nothing to do)
-__global__ __launch_bounds__(FIN_THREADS, 7) void k_hwe_test_serial(const unsigned int* __restrict__ hwe_count,
-                                                                const HweItem* __restrict__ items,
-                                                                double* __restrict__ locus_f64,
-                                                                const unsigned int* __restrict__ list) {
-    const unsigned int total = list ? hwe_count[1] : hwe_count[0];
-    for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-        const HweItem it = items[list ? list[t] : t];
-        double pv;
-        [[clang::always_inline]] pv = trkmath::binomtest_two_sided(it.k, it.n, it.p);
-        double* lf = locus_f64 + (int64_t)it.slot * TRK_LF_COLS;
-        if (it.modes & 1) lf[TRK_LF_HWEP_LEN] = pv;
-        if (it.modes & 2) lf[TRK_LF_HWEP_STR] = pv;
-    }
-}
-
-// the fused small-batch pass's tests: fixed slots (k_locus_count_v3<.., FIN>), two lanes per test, the few tests the
-// pair routine hands back finished in place by the serial routine
-__global__ __launch_bounds__(FIN_THREADS) void k_hwe_test_slots(const HweItem* __restrict__ items, unsigned int n_slots,
-                                                                double* __restrict__ locus_f64) {
-    const unsigned int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned int t = tid >> 1;
-    if (t >= n_slots) return;
-    const HweItem it = items[t];
-    if (it.modes == 0) return;
-    bool ok;
-    double pv = trkmath::binomtest_two_sided_pair(it.k, it.n, it.p, (int)(tid & 1), &ok);  // utils.py:334-338
-    if (tid & 1) return;
-    if (!ok) [[clang::always_inline]] pv = trkmath::binomtest_two_sided(it.k, it.n, it.p);
-    double* lf = locus_f64 + (int64_t)it.slot * TRK_LF_COLS;
-    if (it.modes & 1) lf[TRK_LF_HWEP_LEN] = pv;
-    if (it.modes & 2) lf[TRK_LF_HWEP_STR] = pv;
-}
-
-// the lane-pair test on caller-supplied triples (trk_binomtest_batch: parity tests of the routine itself)
-__global__ __launch_bounds__(FIN_THREADS) void k_binomtest_batch(const int64_t* __restrict__ k, const int64_t* __restrict__ n,
-                                                                const double* __restrict__ p, int64_t count,
-                                                                double* __restrict__ out, int lanes) {
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t t = lanes == 2 ? tid >> 1 : tid;
-    if (t >= count) return;
-    const int64_t kk = k[t], nn = n[t];
-    const double pp = p[t];
-    const bool valid = nn >= 1 && kk >= 0 && kk <= nn && pp >= 0.0 && pp <= 1.0;
-    double pv = __builtin_nan("");
-    if (valid) pv = lanes == 2 ? trkmath::binomtest_two_sided_pair_or_serial(kk, nn, pp, (int)(tid & 1)) : trkmath::binomtest_two_sided(kk, nn, pp);
-    if (lanes != 2 || !(tid & 1)) out[t] = pv;
 }
 
 // ---------------------------------------------------------------------------
@@ -4108,9 +4024,7 @@ bool launch_locus_stats_fused(const trk_batch& b, int32_t* allele_count, int32_t
     if (stage == 0) return true;
     const unsigned int n_slots = 2u * (unsigned int)b.n_loci;
     if (stage == 2) {
-        hipLaunchKernelGGL(k_hwe_test_slots, dim3((2 * n_slots + FIN_THREADS - 1) / FIN_THREADS), dim3(FIN_THREADS), 0, stream,
-                           fin.items, n_slots, locus_f64);
-        *err = hipGetLastError();
+        *err = launch_hwe_slots(fin.items, n_slots, locus_f64, stream);
         return true;
     }
     sync_gt_temporal();
@@ -4154,40 +4068,7 @@ hipError_t launch_locus_finalize(const trk_batch& b, const int32_t* allele_count
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    unsigned int* overflow = reinterpret_cast<unsigned int*>(items + 2 * n);
-    static const int hwe_serial = getenv("TRK_HWE_SERIAL") ? 1 : 0;   // one lane per test, for A/B timing
-    if (hwe_serial) {
-        hipLaunchKernelGGL(k_hwe_test_serial, dim3((unsigned)((2 * n + FIN_THREADS - 1) / FIN_THREADS)), dim3(FIN_THREADS), 0,
-                           stream, count, items, locus_f64, (const unsigned int*)nullptr);
-        return hipGetLastError();
-    }
-    int tblocks = (int)((4 * n + FIN_THREADS - 1) / FIN_THREADS);   // up to two tests per locus, two lanes per test
-    // small batches are a latency chain (configs[1]: count 18 us, finaliser 29, these tests 20): the uncapped build,
-    // 155 registers and no scratch; large ones run beside the call filters: the 72-register build.  TRK_HWE_WIDE=1/0
-    // forces one or the other.
-    static const char* hwe_env = getenv("TRK_HWE_WIDE");
-    const bool hwe_wide = hwe_env ? atoi(hwe_env) != 0 : n <= 32768;
-    // (TRK_HWE_WAVES=4: the 128-register build -- 108 B of scratch instead of 332 -- which still fits beside the four
-    // call-filter waves of a SIMD that the round-4 launch geometry leaves room for)
-    static const int hwe_waves = getenv("TRK_HWE_WAVES") ? atoi(getenv("TRK_HWE_WAVES")) : 4;   // (same-box A/B of the bench step: 4.15 ms against 4.22 with the 72-register build)
-    if (hwe_wide)
-        hipLaunchKernelGGL(k_hwe_test<1>, dim3(tblocks), dim3(FIN_THREADS), 0, stream, count, items, locus_f64, overflow);
-    else if (hwe_waves == 4)
-        hipLaunchKernelGGL(k_hwe_test<4>, dim3(tblocks), dim3(FIN_THREADS), 0, stream, count, items, locus_f64, overflow);
-    else
-        hipLaunchKernelGGL(k_hwe_test<7>, dim3(tblocks), dim3(FIN_THREADS), 0, stream, count, items, locus_f64, overflow);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_hwe_test_serial, dim3(256), dim3(FIN_THREADS), 0, stream, count, items, locus_f64,
-                       (const unsigned int*)overflow);
-    return hipGetLastError();
-}
-
-hipError_t launch_binomtest_batch(const int64_t* k, const int64_t* n, const double* p, int64_t count, double* out,
-                                  int lanes, hipStream_t stream) {
-    if (count <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_binomtest_batch, dim3((unsigned)((lanes * count + FIN_THREADS - 1) / FIN_THREADS)), dim3(FIN_THREADS), 0,
-                       stream, k, n, p, count, out, lanes);
-    return hipGetLastError();
+    return launch_hwe_tests(count, items, locus_f64, reinterpret_cast<unsigned int*>(items + 2 * n), n, stream);
 }
 
 size_t finalize_worklist_bytes(int64_t n_group_loci) {
