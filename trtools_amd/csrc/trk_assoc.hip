@@ -1815,36 +1815,47 @@ struct PwSum {
         for (; i < n; ++i) res += take();
         return res;
     }
+    // numpy's recursion as a loop with NO arrays (an indexed stack would be scratch memory in every launch, touched or
+    // not): the path to the current node is two bits per level (1: in the left child, 2: in the right one) from which
+    // the node's size is replayed, the left halves' sums wait in twelve named registers.  Classes are 16-bit
+    // (rlen_class), so n <= 65536 = 128 * 2^9: ten levels at most.
+    static constexpr int PW_LEVELS = 12;
     __device__ double sum(int n) {
-        if (n <= 128) return leaf(n);   // (every locus with <= 128 alleles: the explicit stack below -- scratch -- is not touched)
-        int fn[24], stage[24];
-        double left[24];
+        if (n <= 128) return leaf(n);
+        double left[PW_LEVELS];
+#pragma unroll
+        for (int k = 0; k < PW_LEVELS; ++k) left[k] = 0.0;
+        uint32_t path = 0;   // stage of level d: (path >> 2 d) & 3
         int sp = 0;
-        fn[0] = n;
-        stage[0] = 0;
         double ret = 0.0;
         while (sp >= 0) {
-            const int m = fn[sp];
-            if (m <= 128) {
+            int m = n;
+            for (int d = 0; d < sp; ++d) {
+                int h = m / 2;
+                h -= h % 8;
+                m = ((path >> (2 * d)) & 3u) == 1u ? h : m - h;
+            }
+            if (m <= 128 || sp >= PW_LEVELS - 1) {   // (the second condition cannot hold for n <= 65536)
                 ret = leaf(m);
                 --sp;
                 continue;
             }
-            int n2 = m / 2;
-            n2 -= n2 % 8;
-            if (stage[sp] == 0) {
-                stage[sp] = 1;
-                fn[sp + 1] = n2;
-                stage[sp + 1] = 0;
+            const uint32_t stage = (path >> (2 * sp)) & 3u;
+            if (stage == 0u) {
+                path |= 1u << (2 * sp);
                 ++sp;
-            } else if (stage[sp] == 1) {
-                left[sp] = ret;
-                stage[sp] = 2;
-                fn[sp + 1] = m - n2;
-                stage[sp + 1] = 0;
+                path &= ~(3u << (2 * sp));
+            } else if (stage == 1u) {
+#pragma unroll
+                for (int k = 0; k < PW_LEVELS; ++k) left[k] = k == sp ? ret : left[k];
+                path += 1u << (2 * sp);
                 ++sp;
+                path &= ~(3u << (2 * sp));
             } else {
-                ret = left[sp] + ret;
+                double lv = 0.0;
+#pragma unroll
+                for (int k = 0; k < PW_LEVELS; ++k) lv = k == sp ? left[k] : lv;
+                ret = lv + ret;
                 --sp;
             }
         }
