@@ -28,7 +28,14 @@ constexpr int PS_TILE = 16384;                 // bytes of text per tile
 constexpr int PS_CHUNKS = PS_TILE / 16;        // 1024 chunks, four per lane
 constexpr int PS_MAXTOK = PS_TILE / 2 + 2;     // tokens that can START in a tile (one byte + a tab each)
 constexpr int32_t PS_INT_MISSING = INT32_MIN;
-constexpr int FS_STAGE = 28672;                // bytes of a tile's output staged in LDS by k_format_samples<true>
+// k_format_samples: tiles of 8 KB (two chunks per lane) -- text, token list and the staged output of a tile together stay
+// under 40 KB of LDS, four workgroups per CU
+constexpr int FS_TILE = 8192;
+constexpr int FS_CHUNKS = FS_TILE / 16;        // 512 chunks, two per lane
+constexpr int FS_Q = FS_CHUNKS / PS_THREADS;
+constexpr int FS_MAXTOK = FS_TILE / 2 + 2;
+constexpr int FS_OVER = 256;                   // text staged beyond the tile: the tile's last token ends there, or the host writes the record
+constexpr int FS_STAGE = 20480;                // bytes of a tile's output staged in LDS by k_format_samples<true>
 
 struct ParseArgs {
     trk_parse_in in;
@@ -451,12 +458,68 @@ __device__ __forceinline__ bool tok_check(const unsigned char* tok, const unsign
     return c == tok_end;
 }
 
+// the bytes of the lane's tokens k0 .. k1 - 1 at w (LDS stage or global memory: one inlined copy per address space)
+struct EmitCtx {
+    const unsigned char* tb;      // the tile's text in LDS
+    const uint16_t* tokv;         // token starts (LDS), tokv[ntok] = the end of the tile's last token + 1
+    const uint8_t* mrow;
+    const char* nullv;
+    int nl, nf;
+    int64_t base;
+    int64_t prow;                 // rec * plane_stride
+};
+
+template <typename W>
+__device__ __forceinline__ void emit_tokens(W w, const EmitCtx& e, const trk_format_in& in, uint32_t k0, uint32_t k1) {
+    for (uint32_t k = k0; k < k1; ++k) {
+        const int64_t s = e.base + k;
+        const unsigned char* tok = e.tb + e.tokv[k];
+        const unsigned char* tok_end = e.tb + e.tokv[k + 1] - 1;
+        const uint8_t mb = e.mrow[s];
+        const bool flt = (mb & 0x7f) != 0 && !(mb & 0x80);
+        *w++ = '\t';
+        if (flt) {
+            for (int i = 0; i < e.nl; ++i) *w++ = (unsigned char)e.nullv[i];
+            *w++ = ':';
+            int cnt = 0;
+            for (int b = 0; b < in.n_filters; ++b) {
+                if (!((mb >> b) & 1)) continue;
+                if (cnt++) *w++ = ',';
+                for (int i = 0; in.filter_name[b][i]; ++i) *w++ = (unsigned char)in.filter_name[b][i];
+                *w++ = '_';
+                char tmp[24];
+                const double x = in.filter_dtype[b] ? (double)static_cast<const float*>(in.filter_plane[b])[e.prow + s]
+                                                    : (double)static_cast<const int32_t*>(in.filter_plane[b])[e.prow + s];
+                const int gl = g6(tmp, x);
+                for (int i = 0; i < gl; ++i) *w++ = (unsigned char)tmp[i];
+            }
+            if (!cnt) *w++ = '.';
+        } else {
+            int colons = 0;
+            for (const unsigned char* c = tok; c < tok_end; ++c) {
+                const unsigned char ch = *c;
+                colons += ch == ':';
+                *w++ = ch;
+            }
+            int pad = e.nf - 1 - colons;    // fields the token lacks: its colons against the record's keys
+            for (int i = 0; i < pad; ++i) {
+                *w++ = ':';
+                *w++ = '.';
+            }
+            const char* tag = (mb & 0x80) ? ":NOCALL" : ":PASS";
+            for (int i = 0; tag[i]; ++i) *w++ = (unsigned char)tag[i];
+        }
+    }
+}
+
 template <bool EMIT>
 __global__ __launch_bounds__(PS_THREADS) void k_format_samples(const FormatArgs a) {
-    __shared__ uint16_t s_cnt[PS_CHUNKS];
-    __shared__ uint16_t s_tok[PS_MAXTOK];          // token starts of the tile, relative to the tile's first byte (t0 - lead)
+    __shared__ uint16_t s_cnt[FS_CHUNKS];
+    __shared__ uint16_t s_tok[FS_MAXTOK + 1];      // token starts of the tile, relative to the tile's first byte (t0 - lead)
+    // the tile's TEXT (+ FS_OVER bytes beyond it): the lanes walk their tokens byte by byte, from LDS
+    __shared__ uint4 s_text[FS_CHUNKS + FS_OVER / 16];
     // EMIT: the tile's output is assembled in LDS (every lane writes its tokens' bytes there) and leaves for global
-    // memory four bytes per lane, coalesced; a tile whose output does not fit is written byte by byte as before
+    // memory four bytes per lane, coalesced; a tile whose output does not fit is written byte by byte
     __shared__ uint32_t s_stage[EMIT ? FS_STAGE / 4 + 2 : 1];
     __shared__ uint32_t s_wsum[PS_THREADS / 64];
     __shared__ uint32_t s_flags, s_base, s_obase;
@@ -499,20 +562,22 @@ __global__ __launch_bounds__(PS_THREADS) void k_format_samples(const FormatArgs 
         return;
     }
     const unsigned char* reg = a.in.text + r0;
-    const int64_t n = r1 - r0;
+    const int64_t n = r1 - r0;                              // reg[n] is the newline
     const int64_t lead = (int64_t)((uintptr_t)reg & 15u);
     const int64_t span = n + lead;
     const uint8_t* mrow = a.in.mask8 + (int64_t)rec * a.in.mask_stride;
     unsigned char* obuf = EMIT ? a.out.out + a.out.out_off[rec] : nullptr;
-    for (int64_t t0 = 0; t0 < span; t0 += PS_TILE) {
-        uint32_t mk[4];
+    const unsigned char* tb = reinterpret_cast<const unsigned char*>(s_text);
+    for (int64_t t0 = 0; t0 < span; t0 += FS_TILE) {
+        uint32_t mk[FS_Q];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < FS_Q; ++q) {
             const int c = tid + q * PS_THREADS;
             const int64_t o = t0 + (int64_t)c * 16 - lead;
             uint32_t m = 0;
-            if (o < n && o + 16 > 0) {
+            if (o <= n && o + 16 > 0) {                     // (the chunk that holds the newline too: the last token ends on it)
                 const uint4 v = *reinterpret_cast<const uint4*>(reg + o);
+                s_text[c] = v;
                 m = tab_mask(v);
                 if (o < 0) m &= ~((1u << (int)(-o)) - 1u);
                 if (o + 16 > n) m &= (1u << (int)(n - o)) - 1u;
@@ -520,11 +585,16 @@ __global__ __launch_bounds__(PS_THREADS) void k_format_samples(const FormatArgs 
             mk[q] = m;
             s_cnt[c] = (uint16_t)__popc(m);
         }
+        if (tid < FS_OVER / 16) {
+            const int c = FS_CHUNKS + tid;
+            const int64_t o = t0 + (int64_t)c * 16 - lead;
+            if (o <= n) s_text[c] = *reinterpret_cast<const uint4*>(reg + o);
+        }
         __syncthreads();
-        uint32_t own[4], sum = 0;
+        uint32_t own[FS_Q], sum = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            own[q] = s_cnt[4 * tid + q];
+        for (int q = 0; q < FS_Q; ++q) {
+            own[q] = s_cnt[FS_Q * tid + q];
             sum += own[q];
         }
         uint32_t incl = sum;
@@ -540,51 +610,52 @@ __global__ __launch_bounds__(PS_THREADS) void k_format_samples(const FormatArgs 
         const uint32_t tile_tabs = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
         uint32_t run = wbase + incl - sum;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            s_cnt[4 * tid + q] = (uint16_t)run;
+        for (int q = 0; q < FS_Q; ++q) {
+            s_cnt[FS_Q * tid + q] = (uint16_t)run;
             run += own[q];
         }
         __syncthreads();
         const uint32_t first = t0 == 0 ? 1u : 0u;
         if (t0 == 0 && tid == 0) s_tok[0] = (uint16_t)lead;      // (the region's first byte, relative to t0 - lead = -lead)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < FS_Q; ++q) {
             const int c = tid + q * PS_THREADS;
             uint32_t m = mk[q];
             uint32_t k = first + s_cnt[c];
-            const int64_t o = t0 + (int64_t)c * 16 - lead;
             while (m) {
                 const int b = __ffs((int)m) - 1;
                 m &= m - 1;
-                if (k < (uint32_t)PS_MAXTOK) s_tok[k] = (uint16_t)(o + b + 1 - (t0 - lead));
+                if (k < (uint32_t)FS_MAXTOK) s_tok[k] = (uint16_t)(c * 16 + b + 1);
                 ++k;
             }
         }
         __syncthreads();
         const uint32_t base = s_base, obase = s_obase;
         const uint32_t ntok = first + tile_tabs;
-        if (ntok > (uint32_t)PS_MAXTOK || (int64_t)base + ntok > S) {     // (uniform) too many columns, or degenerate text
+        if (ntok > (uint32_t)FS_MAXTOK || (int64_t)base + ntok > S) {     // (uniform) too many columns, or degenerate text
             if (tid == 0) s_flags |= TRK_PARSE_HOST;
             __syncthreads();
             break;
         }
+        // the tile's last token ends at the next tab or at the newline, within the staged text -- or the host writes the record
+        if (tid == 0 && ntok) {
+            const int64_t lim = min((int64_t)(FS_TILE + FS_OVER), span - t0);   // staged bytes; span - t0: the newline's offset
+            int64_t e = s_tok[ntok - 1];
+            while (e < lim && tb[e] != '\t') ++e;
+            if (e >= lim && lim != span - t0) s_flags |= TRK_PARSE_HOST;
+            s_tok[ntok] = (uint16_t)(e + 1);
+        }
+        __syncthreads();
+        if (s_flags) break;                 // (uniform)
         // ---- lane t owns tokens [t per, (t + 1) per) of the tile: lengths, then (EMIT) the bytes at its running offset ----
         const uint32_t per = (ntok + PS_THREADS - 1) / PS_THREADS;
         const uint32_t k0 = min(ntok, (uint32_t)tid * per), k1 = min(ntok, k0 + per);
         uint32_t lflags = 0;
-        // pass over my tokens twice when emitting: lengths first (for the scan), bytes second
         uint32_t mylen = 0;
         for (uint32_t k = k0; k < k1; ++k) {
             const int64_t s = (int64_t)base + k;
-            const unsigned char* tok = reg + (t0 - lead) + s_tok[k];
-            // the token ends at the next token's tab -- the next start minus one -- or at the line's end
-            const unsigned char* tok_end = (k + 1 < ntok) ? reg + (t0 - lead) + s_tok[k + 1] - 1 : nullptr;
-            if (!tok_end) {
-                // the last token of the tile: up to the next tab, or the end of the region
-                const unsigned char* e = tok;
-                while (e < reg + n && *e != '\t') ++e;
-                tok_end = e;
-            }
+            const unsigned char* tok = tb + s_tok[k];
+            const unsigned char* tok_end = tb + s_tok[k + 1] - 1;     // the next token's tab, or the newline
             const uint8_t mb = mrow[s];
             const bool flt = (mb & 0x7f) != 0 && !(mb & 0x80);
             int pad;
@@ -628,70 +699,28 @@ __global__ __launch_bounds__(PS_THREADS) void k_format_samples(const FormatArgs 
         for (int w = 0; w < (tid >> 6); ++w) lbase += s_wsum[w];
         const uint32_t tile_len = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
         if (EMIT) {
-            const bool staged = tile_len <= (uint32_t)FS_STAGE;      // (uniform)
-            unsigned char* w = (staged ? reinterpret_cast<unsigned char*>(s_stage) : obuf + obase) + lbase + li - mylen;
-            for (uint32_t k = k0; k < k1; ++k) {
-                const int64_t s = (int64_t)base + k;
-                const unsigned char* tok = reg + (t0 - lead) + s_tok[k];
-                const unsigned char* tok_end = (k + 1 < ntok) ? reg + (t0 - lead) + s_tok[k + 1] - 1 : nullptr;
-                if (!tok_end) {
-                    const unsigned char* e = tok;
-                    while (e < reg + n && *e != '\t') ++e;
-                    tok_end = e;
+            const EmitCtx ec{tb, s_tok, mrow, s_null, s_nl, nf, (int64_t)base, (int64_t)rec * a.in.plane_stride};
+            const uint32_t woff = lbase + li - mylen;
+            if (tile_len <= (uint32_t)FS_STAGE) {       // (uniform)
+                emit_tokens(reinterpret_cast<unsigned char*>(s_stage) + woff, ec, a.in, k0, k1);
+                __syncthreads();
+                unsigned char* dst = obuf + obase;
+                const unsigned char* st8 = reinterpret_cast<const unsigned char*>(s_stage);
+                const uint32_t head = min(tile_len, (uint32_t)((4u - (uint32_t)((uintptr_t)dst & 3u)) & 3u));
+                if ((uint32_t)tid < head) dst[tid] = st8[tid];
+                const uint32_t nd = (tile_len - head) >> 2;
+                uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + head);
+                const uint32_t sh = 8u * (head & 3u);
+                for (uint32_t i = tid; i < nd; i += PS_THREADS) {
+                    const uint32_t sb = head + 4u * i;
+                    const uint32_t lo = s_stage[sb >> 2], hi = s_stage[(sb >> 2) + 1];
+                    d32[i] = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
                 }
-                const uint8_t mb = mrow[s];
-                const bool flt = (mb & 0x7f) != 0 && !(mb & 0x80);
-                *w++ = '\t';
-                if (flt) {
-                    for (int i = 0; i < s_nl; ++i) *w++ = (unsigned char)s_null[i];
-                    *w++ = ':';
-                    int cnt = 0;
-                    for (int b = 0; b < a.in.n_filters; ++b) {
-                        if (!((mb >> b) & 1)) continue;
-                        if (cnt++) *w++ = ',';
-                        for (int i = 0; a.in.filter_name[b][i]; ++i) *w++ = (unsigned char)a.in.filter_name[b][i];
-                        *w++ = '_';
-                        char tmp[24];
-                        const double x = a.in.filter_dtype[b] ? (double)static_cast<const float*>(a.in.filter_plane[b])[(int64_t)rec * a.in.plane_stride + s]
-                                                              : (double)static_cast<const int32_t*>(a.in.filter_plane[b])[(int64_t)rec * a.in.plane_stride + s];
-                        const int gl = g6(tmp, x);
-                        for (int i = 0; i < gl; ++i) *w++ = (unsigned char)tmp[i];
-                    }
-                    if (!cnt) *w++ = '.';
-                } else {
-                    int pad = 0;
-                    {   // fields the token lacks: its colons against the record's keys
-                        int colons = 0;
-                        for (const unsigned char* c = tok; c < tok_end; ++c) colons += *c == ':';
-                        pad = nf - 1 - colons;
-                        if (pad < 0) pad = 0;
-                    }
-                    for (const unsigned char* c = tok; c < tok_end; ++c) *w++ = *c;
-                    for (int i = 0; i < pad; ++i) {
-                        *w++ = ':';
-                        *w++ = '.';
-                    }
-                    const char* tag = (mb & 0x80) ? ":NOCALL" : ":PASS";
-                    for (int i = 0; tag[i]; ++i) *w++ = (unsigned char)tag[i];
-                }
+                const uint32_t done = head + 4u * nd;
+                if ((uint32_t)tid < tile_len - done) dst[done + tid] = st8[done + tid];
+            } else {
+                emit_tokens(obuf + obase + woff, ec, a.in, k0, k1);
             }
-        }
-        if (EMIT && tile_len <= (uint32_t)FS_STAGE) {
-            __syncthreads();
-            unsigned char* dst = obuf + obase;
-            const unsigned char* st8 = reinterpret_cast<const unsigned char*>(s_stage);
-            const uint32_t head = min(tile_len, (uint32_t)((4u - (uint32_t)((uintptr_t)dst & 3u)) & 3u));
-            if ((uint32_t)tid < head) dst[tid] = st8[tid];
-            const uint32_t nd = (tile_len - head) >> 2;
-            uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + head);
-            const uint32_t sh = 8u * (head & 3u);
-            for (uint32_t i = tid; i < nd; i += PS_THREADS) {
-                const uint32_t sb = head + 4u * i;
-                const uint32_t lo = s_stage[sb >> 2], hi = s_stage[(sb >> 2) + 1];
-                d32[i] = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
-            }
-            const uint32_t done = head + 4u * nd;
-            if ((uint32_t)tid < tile_len - done) dst[done + tid] = st8[done + tid];
         }
         if (lflags) atomicOr(&s_flags, lflags);
         __syncthreads();
