@@ -300,6 +300,11 @@ typedef struct {
     const int64_t* dev_region_off;
     const uint32_t* dev_region_len;
     const uint8_t* dev_flags;
+    /* optional: the copy of dev_regions to the host may still be in flight when the call starts -- the writer builds the
+     * heads first and calls dev_wait(dev_wait_arg) (e.g. trk_sync with its context; non-zero: the call fails with
+     * INT64_MIN + 1, err_record -1) before it reads the first byte of dev_regions                                        */
+    int (*dev_wait)(void* arg);
+    void* dev_wait_arg;
 } trk_vcf_dumpstr2;
 /* The FORMAT keys of every record of the batch as trk_format_samples wants them: kinds16 [n][16] (1 GT, 2 Integer,
  * 3 Float, 4 String, by in->format_keys / format_kinds; unlisted keys are strings), n_fields [n] -- 0 for a record the

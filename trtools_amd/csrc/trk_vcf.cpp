@@ -3425,6 +3425,10 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
     int64_t total = 0;
     for (size_t i = 0; i < (size_t)n; ++i) total += (int64_t)(rlen[i] + glen[i]);
     if (!out || total > cap) return -total;
+    if (ext && ext->dev_regions && ext->dev_wait && ext->dev_wait(ext->dev_wait_arg) != 0) {   // the columns' download
+        if (err_record) *err_record = -1;
+        return INT64_MIN + 1;
+    }
     {   // the lines land at their prefix offsets, copied by the same number of threads
         std::vector<int64_t> at((size_t)n + 1, 0);
         for (int i = 0; i < n; ++i) at[(size_t)i + 1] = at[(size_t)i] + (int64_t)(rlen[(size_t)i] + glen[(size_t)i]);

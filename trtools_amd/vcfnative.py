@@ -108,7 +108,8 @@ class _DumpRecords(C.Structure):
                 ('allele_count', C.c_void_p), ('allele_off', C.c_void_p), ('n_info_keys', C.c_int32),
                 ('fast_path', C.c_int32), ('info_keys', C.POINTER(C.c_char_p)), ('info_kinds', C.POINTER(C.c_int32)),
                 ('need_head', C.c_void_p), ('dev_regions', C.c_void_p), ('dev_region_off', C.c_void_p),
-                ('dev_region_len', C.c_void_p), ('dev_flags', C.c_void_p)]
+                ('dev_region_len', C.c_void_p), ('dev_flags', C.c_void_p),
+                ('dev_wait', C.c_void_p), ('dev_wait_arg', C.c_void_p)]
 
 
 DEVICE_FORMAT = dict(records=0, left_to_host=0)     # records whose sample columns the device wrote / left to the host writer
@@ -302,7 +303,7 @@ class RawBatch:
                          mask.ctypes.data if mask.dtype == np.uint32 else None, fv, harr, karr, kk)
         lib = self.reader._lib
         err = C.c_int32()
-        ext = None
+        ext = regions = None
         if native is not None:
             arrs = {k: (None if native.get(k) is None else np.ascontiguousarray(native[k], dtype=dt))
                     for k, dt in (('keep', np.uint8), ('hrun', np.int32), ('have_stats', np.uint8), ('het', np.float64),
@@ -324,6 +325,8 @@ class RawBatch:
             if regions is not None:
                 ext.dev_regions, ext.dev_region_off = regions['buf'].ctypes.data, regions['off'].ctypes.data
                 ext.dev_region_len, ext.dev_flags = regions['len'].ctypes.data, regions['flags'].ctypes.data
+                if regions.get('wait') is not None:     # the download is in flight: the writer waits after the heads
+                    ext.dev_wait, ext.dev_wait_arg = regions['wait']
                 keep.append(regions)
         # output bound: the input text, a third more for re-serialised numbers, and per call the FILTER column this
         # pass appends (':PASS' / ':NOCALL'; the longer '<name>_<value>' strings of the few filtered calls fit in
@@ -334,35 +337,38 @@ class RawBatch:
         slot = None
         if out_ring is not None:
             slot = out_ring['i'] = (out_ring.get('i', -1) + 1) % 2
-        while True:
-            if slot is None:
-                buf = np.empty(cap, dtype=np.uint8)      # not zero-filled; handed to the writer as a memoryview
-            else:
-                buf = out_ring.get(slot)
-                if buf is None or buf.size < cap:
-                    buf = out_ring[slot] = np.empty(cap + cap // 8, dtype=np.uint8)
-            if ext is None:
-                n = lib.trk_vcf_dumpstr_lines(C.byref(self.b), C.byref(prm), buf.ctypes.data, cap, C.byref(err))
-            else:
-                n = lib.trk_vcf_dumpstr_records(C.byref(self.b), C.byref(ext), buf.ctypes.data, cap, C.byref(err))
-            if n >= 0:
-                return memoryview(buf)[:n]
-            if ext is not None and n == -(1 << 63) + 2:
-                # INFO columns the native rewrite leaves to Python: those heads come from the caller, once
-                if ext.base.heads:
+        try:
+            while True:
+                if slot is None:
+                    buf = np.empty(cap, dtype=np.uint8)      # not zero-filled; handed to the writer as a memoryview
+                else:
+                    buf = out_ring.get(slot)
+                    if buf is None or buf.size < cap:
+                        buf = out_ring[slot] = np.empty(cap + cap // 8, dtype=np.uint8)
+                if ext is None:
+                    n = lib.trk_vcf_dumpstr_lines(C.byref(self.b), C.byref(prm), buf.ctypes.data, cap, C.byref(err))
+                else:
+                    n = lib.trk_vcf_dumpstr_records(C.byref(self.b), C.byref(ext), buf.ctypes.data, cap, C.byref(err))
+                if n >= 0:
+                    return memoryview(buf)[:n]
+                if ext is not None and n == -(1 << 63) + 2:
+                    # INFO columns the native rewrite leaves to Python: those heads come from the caller, once
+                    if ext.base.heads:
+                        return None
+                    todo = np.flatnonzero(need[:self.n])
+                    hl = [None] * max(self.n, 1)
+                    for l in todo:
+                        hl[int(l)] = native['py_head'](int(l)).encode()
+                    harr = (C.c_char_p * max(self.n, 1))(*hl)
+                    keep.append(harr)
+                    ext.base.heads = harr
+                    need[:] = 0
+                    continue
+                if n <= -(1 << 63) + 1:
                     return None
-                todo = np.flatnonzero(need[:self.n])
-                hl = [None] * max(self.n, 1)
-                for l in todo:
-                    hl[int(l)] = native['py_head'](int(l)).encode()
-                harr = (C.c_char_p * max(self.n, 1))(*hl)
-                keep.append(harr)
-                ext.base.heads = harr
-                need[:] = 0
-                continue
-            if n <= -(1 << 63) + 1:
-                return None
-            cap = -n + 64
+                cap = -n + 64
+        finally:
+            self._release_regions(regions)     # (the columns' download has completed; device buffers back)
 
     def _device_regions(self, prm, mask, cf_values, S, out_ring, dev_call=None, cf_plane_idx=None):
         """The sample columns of the batch's output records written ON THE DEVICE (trk_format_samples; round 4): needs the
@@ -435,18 +441,40 @@ class RawBatch:
                 if alloc is not None:
                     self.reader._slabs = getattr(self.reader, '_slabs', []) + [buf]
                 ring[key] = buf
-            eng._chk(eng.lib.trk_memcpy_d2h(eng.ctx, buf.ctypes.data, out_d.ptr, total))
+            wait = held = None
+            if os.environ.get('TRK_FMT_ASYNC', '1') == '1' and getattr(self.reader, '_alloc', None) is not None:
+                # (pinned destination: the copy runs beside the writer's head building; the writer waits through
+                # dev_wait before it reads the columns, the device buffers are released after the writer's call)
+                eng._chk(eng.lib.trk_memcpy_d2h_async(eng.ctx, buf.ctypes.data, out_d.ptr, total))
+                wait = (C.cast(eng.lib.trk_sync, C.c_void_p).value, eng.ctx)
+                held, tmp = (eng, tmp), []
+            else:
+                eng._chk(eng.lib.trk_memcpy_d2h(eng.ctx, buf.ctypes.data, out_d.ptr, total))
             _tm.append(_t.perf_counter())
             if os.environ.get('TRK_FMT_TIMING'):
-                print('[device format] setup %.1f ms, pass 1 %.1f, alloc + pass 2 %.1f, download of %.0f MB %.1f' % tuple(
-                    [(b_ - a_) * 1e3 for a_, b_ in zip(_tm[:3], _tm[1:4])] + [total / 1e6, (_tm[4] - _tm[3]) * 1e3]), file=sys.stderr)
+                print('[device format] setup %.1f ms, pass 1 %.1f, alloc + pass 2 %.1f, download of %.0f MB %.1f%s' % tuple(
+                    [(b_ - a_) * 1e3 for a_, b_ in zip(_tm[:3], _tm[1:4])] + [total / 1e6, (_tm[4] - _tm[3]) * 1e3,
+                                                                          ' (enqueued)' if wait else '']), file=sys.stderr)
         finally:
-            eng.sync()
-            for a in tmp:
-                a.free()
+            if tmp:
+                eng.sync()
+                for a in tmp:
+                    a.free()
         DEVICE_FORMAT['records'] += int((fl == 0).sum())
         DEVICE_FORMAT['left_to_host'] += int((fl != 0).sum())
-        return dict(buf=buf, off=off, len=np.ascontiguousarray(ln, dtype=np.uint32), flags=np.ascontiguousarray(fl, dtype=np.uint8))
+        return dict(buf=buf, off=off, len=np.ascontiguousarray(ln, dtype=np.uint32), flags=np.ascontiguousarray(fl, dtype=np.uint8),
+                    wait=wait, held=held)
+
+    @staticmethod
+    def _release_regions(regions):
+        """After the writer's call (however it ended): the download has completed, the device buffers go back."""
+        held = regions.get('held') if regions else None
+        if held:
+            regions['held'] = None
+            eng, arrs = held
+            eng.sync()
+            for a in arrs:
+                a.free()
 
     def iter_variants(self):
         """The batch's vcfio.Variant objects one at a time (a malformed line raises at ITS turn, as the per-record
