@@ -538,3 +538,58 @@ def test_undecoded_sample_columns_on_rewritten_text(tmp_path, seed, scalar):
             raise AssertionError("line %d column %d differs from the %s:\n%s\n%s" % (i, j, what, fa[j][:200], fb[j][:200]))
     assert stats[0]['fast'] > 0, stats        # some records are taken by the span writer, the ragged ones by the decoder
     assert stats[0]['fast'] + stats[0]['decoded'] == stats[1]['decoded']
+
+
+def test_writer_takes_the_sample_columns_from_the_caller_and_waits_for_them(tmp_path, monkeypatch):
+    """trk_vcf_dumpstr2.dev_regions / dev_wait without a GPU: the columns of every output record are handed to the native
+    writer as the device path would (here cut from a first run's own output), one record in five left to the writer
+    (dev_flags), and the copy 'completes' inside dev_wait -- the buffer holds garbage until the writer calls it, which it
+    must do after the heads and before the first byte is read.  Same bytes as the first run; a failing wait fails the
+    batch (the pipeline falls back to its other writer)."""
+    import ctypes as C
+    import numpy as np
+    from trtools_amd import vcfnative
+    (ref, stats, path), = _dump_variants(tmp_path, 'synth_hipstr_all', [{}])
+    cols = {}
+    for ln in ref[0].split('\n'):
+        if ln and not ln.startswith('#'):
+            f = ln.split('\t')
+            cols[(f[0], f[1])] = ('\t' + '\t'.join(f[9:])).encode()
+    assert len(cols) > 20
+    state = {'calls': 0, 'pending': [], 'fail': False, 'taken': 0}
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p)
+    def wait(_arg):
+        state['calls'] += 1
+        for buf, good in state['pending']:
+            buf[:good.size] = good
+        state['pending'] = []
+        return 1 if state['fail'] else 0
+
+    def fake_regions(self, prm, mask, cf_values, S, out_ring, dev_call=None, cf_plane_idx=None):
+        n = self.n
+        lo = np.ctypeslib.as_array(self.b.line_off, shape=(n,))
+        le = np.ctypeslib.as_array(self.b.line_end, shape=(n,))
+        parts, off, ln, fl = [], np.zeros(n, np.int64), np.zeros(n, np.uint32), np.ones(n, np.uint8)
+        at = 0
+        for l in range(n):
+            head = C.string_at(self.b.text + int(lo[l]), min(int(le[l] - lo[l]), 200)).split(b'\t')
+            c = cols.get((head[0].decode(), head[1].decode()))
+            off[l] = at
+            if c is not None and l % 5 != 4:
+                parts.append(c)
+                ln[l], fl[l] = len(c), 0
+                at += len(c)
+                state['taken'] += 1
+        good = np.frombuffer(b''.join(parts) + b'\0', dtype=np.uint8).copy()
+        buf = np.full(good.size, ord('#'), dtype=np.uint8)          # not there yet
+        state['pending'].append((buf, good))
+        return dict(buf=buf, off=off, len=ln, flags=fl, wait=(C.cast(wait, C.c_void_p).value, None), held=None)
+
+    monkeypatch.setattr(vcfnative.RawBatch, '_device_regions', fake_regions)
+    (got, stats2, path2), = _dump_variants(tmp_path, 'synth_hipstr_all', [{}])
+    assert path2 == 'batch' and got == ref
+    assert state['calls'] >= 1 and state['taken'] > 20 and not state['pending']
+    state['fail'] = True
+    (got3, _, path3), = _dump_variants(tmp_path, 'synth_hipstr_all', [{}])
+    assert got3 == ref           # (the batch went to the writer that needs no columns)
