@@ -90,6 +90,13 @@ int trk_queue_sync(trk_ctx* ctx, int queue);
  * workspace: use them from one queue at a time.                                                        */
 #define TRK_N_STREAMS 4
 int trk_stream_select(trk_ctx* ctx, int queue);
+/* A queue for the CALLING thread alone: from now on this thread's copies and kernels (the entry points that take no
+ * per-queue scratch: trk_memcpy_*, trk_parse_samples, trk_format_samples) go to `queue` whatever trk_stream_select says;
+ * -1 returns the thread to the selected queue.  For a helper thread that feeds the device beside the caller's thread
+ * (the command lines' reader uploads and parses batch n + 1 while batch n is counted, filtered and written): its 80 MB
+ * uploads no longer sit in front of the caller's kernels.  Hand-over is the caller's business (the helper synchronises
+ * its queue -- trk_queue_sync, or any blocking copy -- before the other thread touches what it made).                */
+int trk_thread_queue(trk_ctx* ctx, int queue);
 int trk_stream_wait(trk_ctx* ctx, int waiter, int signal);
 /* Named ordering points for pipelines that run several batches deep: trk_event_record marks "everything enqueued so
  * far on the SELECTED queue"; trk_event_wait makes the selected queue wait for the mark of `slot` as last recorded

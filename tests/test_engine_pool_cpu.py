@@ -16,12 +16,22 @@ class _Lib:
         self.calls.append(('select', q))
         return 0
 
+    def trk_thread_queue(self, ctx, q):
+        self.calls.append(('thread_queue', q))
+        return 0
+
+    def trk_queue_sync(self, ctx, q):
+        self.calls.append(('queue_sync', q))
+        return 0
+
 
 def _engine():
     e = Engine.__new__(Engine)
     e.lib, e.ctx = _Lib(), 1
     e._pool, e._pool_bytes, e._pool_limit = {}, 0, 1 << 30
     e._queue, e._multi_queue = 0, False
+    import threading
+    e._tls, e._pool_lock, e._thread_queues = threading.local(), threading.RLock(), False
     return e
 
 
@@ -52,3 +62,37 @@ def test_sync_inside_a_scope_does_not_clear_the_flag():
     assert e.lib.calls.count('sync') == n
     assert e._pool_take(4096) == 222        # back on queue 0: must wait for queue 1
     assert e.lib.calls.count('sync') == n + 1
+
+
+def test_a_helper_thread_with_a_queue_of_its_own():
+    """Round 4 (trk_thread_queue): the reader's thread works on queue 3 beside the caller's queue 0.  A buffer goes back
+    to the pool tagged with the queue of the thread that frees it; the same thread takes it back without waiting, the
+    other one waits for THAT queue only (not for the device); frees under idle_frees() are idle for everybody; buffers
+    pooled before the helper appeared count as queue 0's."""
+    import threading
+    e = _engine()
+    e._pool_give(4096, 100)                       # before any helper: "in order on queue 0"
+    seen = {}
+
+    def helper():
+        e.thread_queue(3)
+        seen['old'] = e._pool_take(4096)          # pooled by queue 0 before the helper existed: waits for queue 0
+        seen['calls_old'] = list(e.lib.calls)
+        e._pool_give(4096, 333)                   # freed by the helper: tagged 3
+        n = len(e.lib.calls)
+        seen['own'] = e._pool_take(4096)          # its own buffer back: no wait
+        seen['own_waited'] = len(e.lib.calls) != n
+        e._pool_give(4096, 333)
+        with e.idle_frees():
+            e._pool_give(8192, 444)               # freed after the helper waited for everything
+    t = threading.Thread(target=helper)
+    t.start()
+    t.join()
+    assert seen['old'] == 100 and ('queue_sync', 0) in seen['calls_old'] and 'sync' not in seen['calls_old']
+    assert seen['own'] == 333 and not seen['own_waited']
+    e.lib.calls.clear()
+    assert e._pool_take(8192) == 444 and e.lib.calls == []          # idle: nobody waits
+    assert e._pool_take(4096) == 333 and e.lib.calls == [('queue_sync', 3)]
+    e.lib.calls.clear()
+    e._pool_give(4096, 555)                       # the caller's own free (queue 0) and take
+    assert e._pool_take(4096) == 555 and e.lib.calls == []

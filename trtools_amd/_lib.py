@@ -180,7 +180,7 @@ EXPORTS = [
     'trk_comm_unique_id', 'trk_comm_init', 'trk_allreduce_sum_i64', 'trk_allgather',
     'trk_binomtest_two_sided', 'trk_binom_pmf', 'trk_binomtest_batch', 'trk_synth_fill', 'trk_synth_fill_gangstr',
     'trk_assoc_scan', 'trk_assoc_scan_dosage', 'trk_student_t_two_sided', 'trk_dosages', 'trk_qc_reduce', 'trk_parse_samples', 'trk_format_samples', 'trk_planarize', 'trk_pad_rows', 'trk_permute_columns', 'trk_stream_probe', 'trk_device_clocks', 'trk_stream_select', 'trk_stream_wait',
-    'trk_host_alloc', 'trk_host_free', 'trk_memcpy_h2d_async', 'trk_memcpy_d2h_async', 'trk_queue_sync', 'trk_exchange', 'trk_event_record', 'trk_event_wait',
+    'trk_host_alloc', 'trk_host_free', 'trk_memcpy_h2d_async', 'trk_memcpy_d2h_async', 'trk_queue_sync', 'trk_thread_queue', 'trk_exchange', 'trk_event_record', 'trk_event_wait',
 ]
 
 _lib = None
@@ -292,6 +292,7 @@ def load():
     lib.trk_host_free.argtypes = [vp, vp]
     lib.trk_memcpy_h2d_async.argtypes = [vp, vp, vp, C.c_size_t]
     lib.trk_memcpy_d2h_async.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.trk_thread_queue.argtypes = [vp, C.c_int]
     lib.trk_queue_sync.argtypes = [vp, C.c_int]
     lib.trk_event_record.argtypes = [vp, C.c_int]
     lib.trk_event_wait.argtypes = [vp, C.c_int]

@@ -74,6 +74,9 @@ struct ProfRec {
     hipEvent_t start, stop;
 };
 
+// trk_thread_queue: the queue of the CALLING thread, when it has asked for one of its own (-1: the selected queue)
+static thread_local int t_queue = -1;
+
 struct trk_ctx {
     int device = 0;
     int n_cu = 256;
@@ -84,7 +87,7 @@ struct trk_ctx {
     hipEvent_t user_event[TRK_N_EVENTS] = {};
     bool user_event_set[TRK_N_EVENTS] = {};
     int cur = 0;
-    hipStream_t s() const { return streams[cur]; }
+    hipStream_t s() const { return streams[t_queue >= 0 ? t_queue : cur]; }
     std::string err;
     hipEvent_t t_start[TRK_N_TIMERS] = {};
     hipEvent_t t_stop[TRK_N_TIMERS] = {};
@@ -349,6 +352,12 @@ int trk_stream_select(trk_ctx* ctx, int queue) {
     if (!ctx) return TRK_ERR_ARG;
     if (queue < 0 || queue >= TRK_N_STREAMS) return fail(ctx, TRK_ERR_ARG, "queue %d outside [0, %d)", queue, TRK_N_STREAMS);
     ctx->cur = queue;
+    return TRK_OK;
+}
+int trk_thread_queue(trk_ctx* ctx, int queue) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (queue < -1 || queue >= TRK_N_STREAMS) return fail(ctx, TRK_ERR_ARG, "queue %d outside [-1, %d)", queue, TRK_N_STREAMS);
+    t_queue = queue;
     return TRK_OK;
 }
 int trk_stream_wait(trk_ctx* ctx, int waiter, int signal) {

@@ -291,6 +291,8 @@ class Engine:
         self._pool = {}              # size class -> [(device pointer, idle: no queue can still be using it)]
         import threading
         self._pool_lock = threading.RLock()
+        self._tls = threading.local()
+        self._thread_queues = False  # a thread has asked for a queue of its own (thread_queue): frees carry their queue
         self._pool_bytes = 0
         self._queue = 0              # the selected queue (on_queue)
         self._multi_queue = False    # another queue than 0 has been used since the last full synchronisation
@@ -332,32 +334,81 @@ class Engine:
         step = 1 << (int(nbytes - 1).bit_length() - 3)
         return (nbytes + step - 1) // step * step
 
+    def thread_queue(self, queue):
+        """trk_thread_queue: the CALLING thread's copies and kernels go to ``queue`` from now on (-1: back to the selected
+        queue).  For a helper thread that uploads and parses the next batch beside the caller's thread; buffers it frees
+        are tagged with its queue, and whoever takes one on another queue waits for that queue first."""
+        self._chk(self.lib.trk_thread_queue(self.ctx, int(queue)))
+        self._tls.q = int(queue)
+        if queue >= 0:
+            with self._pool_lock:
+                if not self._thread_queues:
+                    self._thread_queues = True
+                    for rest in self._pool.values():       # pooled as "in order on queue 0": say so
+                        rest[:] = [(p, 0 if t is True else t) for p, t in rest]
+
+    def _my_queue(self):
+        q = getattr(self._tls, 'q', -1)
+        return q if q >= 0 else self._queue
+
+    class _IdleFrees:
+        def __init__(self, eng):
+            self.eng = eng
+
+        def __enter__(self):
+            self.eng._tls.idle = getattr(self.eng._tls, 'idle', 0) + 1
+
+        def __exit__(self, *exc):
+            self.eng._tls.idle -= 1
+            return False
+
+    def idle_frees(self):
+        """``with eng.idle_frees(): a.free()`` -- the caller has waited for every queue that touched the buffers it frees
+        inside (they go back to the pool as idle for everybody)."""
+        return Engine._IdleFrees(self)
+
     def _pool_take(self, cap):
         """A pooled buffer of this size class.  free() is NOT a synchronisation point (hipFree was): work enqueued
-        earlier may still read or write a freed buffer.  Queues are in-order, so while only queue 0 is in use a
-        buffer can be handed straight back out; once other queues have been used (bench.py's pipelined step) nobody
-        knows which queue touched a buffer last, and the first reuse waits for the whole device (trk_sync) -- after
-        which every pooled buffer is idle again."""
+        earlier may still read or write a freed buffer.  A pooled buffer carries a tag: True (idle), a queue number
+        (freed by a thread working on that queue: in order there, anybody else waits for that queue first), or False
+        (queues were switched with on_queue -- bench.py's pipelined step -- and nobody knows which one touched it
+        last: the first reuse waits for the whole device, after which every pooled buffer is idle again)."""
         # (the pool is shared with the reader's read-ahead thread when it parses on the device: one lock around its books)
+        wait_for = None
         with self._pool_lock:
             lst = self._pool.get(cap)
             if not lst:
                 return None
-            ptr, safe = lst.pop()
+            ptr, tag = lst.pop()
             self._pool_bytes -= cap
-            if not safe:
+            if tag is True:
+                return ptr
+            if tag is False:
                 self.sync()
                 # still inside an on_queue(k != 0) scope: later frees are not idle either
                 self._multi_queue = self._queue != 0
                 for rest in self._pool.values():
                     rest[:] = [(p, True) for p, _ in rest]
-            return ptr
+                return ptr
+            if tag != self._my_queue():
+                wait_for = tag
+        if wait_for is not None:
+            self._chk(self.lib.trk_queue_sync(self.ctx, wait_for))     # (outside the lock: the other thread goes on)
+        return ptr
 
     def _pool_give(self, cap, ptr):
         with self._pool_lock:
             if self._pool_limit <= 0 or self._pool_bytes + cap > self._pool_limit:
                 return False
-            self._pool.setdefault(cap, []).append((ptr, not self._multi_queue and self._queue == 0))
+            if getattr(self._tls, 'idle', 0) > 0:
+                tag = True
+            elif self._multi_queue or (self._queue != 0 and getattr(self._tls, 'q', -1) < 0):
+                tag = False
+            elif self._thread_queues:
+                tag = self._my_queue()
+            else:
+                tag = True
+            self._pool.setdefault(cap, []).append((ptr, tag))
             self._pool_bytes += cap
             return True
 
@@ -529,6 +580,8 @@ class Engine:
 
     import threading as _threading
     _pool_lock = _threading.RLock()      # (class-level default; every engine gets its own in __init__)
+    _tls = _threading.local()
+    _thread_queues = False
 
     # What the last placed allocation saw (bench.py reports it): trk_pair_info as a dict
     last_placement = None
@@ -834,10 +887,11 @@ class Engine:
         self._chk(self.lib.trk_parse_samples(self.ctx, C.byref(pin), C.byref(pout)))
         if tmp or own_text:
             self.sync()                       # (the temporaries go back to the pool: the kernel must be done with them)
-        for t in tmp:
-            t.free()
-        if own_text:
-            text_d.free()
+        with self.idle_frees():
+            for t in tmp:
+                t.free()
+            if own_text:
+                text_d.free()
         return out
 
     def qc_reduce(self, batch, quality=None, sample_in=None, ignore_no_call=False):

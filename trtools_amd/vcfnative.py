@@ -112,6 +112,7 @@ class _DumpRecords(C.Structure):
                 ('dev_wait', C.c_void_p), ('dev_wait_arg', C.c_void_p)]
 
 
+READER_QUEUE = 3       # the read-ahead thread's queue in device-parse mode (trk_thread_queue)
 DEVICE_FORMAT = dict(records=0, left_to_host=0)     # records whose sample columns the device wrote / left to the host writer
 
 
@@ -640,6 +641,11 @@ class NativeVCFReader(vcfio.VCFReader):
 
             def work():
                 try:
+                    eng = getattr(self, '_dev_eng', None)
+                    if eng is not None and os.environ.get('TRK_READER_QUEUE', '1') != '0':
+                        # this thread's uploads and parse kernel on a queue of its own: they no longer sit in front of
+                        # the caller's kernels (every batch is handed over after a blocking copy on that queue)
+                        eng.thread_queue(READER_QUEUE)
                     rb = self._read_raw_batch(n_records)
                     if rb.n and getattr(self, '_prefetch_hz', None):
                         try:
@@ -755,8 +761,9 @@ class NativeVCFReader(vcfio.VCFReader):
                                     want_phased=True)
             flags = out['flags'].get()
             if flags.any():
-                for a in [out['gt'], out['phased'], out['locus_ploidy'], out['flags'], td, so_d, le_d] + out['planes']:
-                    a.free()
+                with eng.idle_frees():            # (parse_samples waited for the device; .get() for this thread's queue)
+                    for a in [out['gt'], out['phased'], out['locus_ploidy'], out['flags'], td, so_d, le_d] + out['planes']:
+                        a.free()
                 out = None
         if out is None:
             # something the device grammar does not cover (or an error the host reports in its own words): the host parses
@@ -778,8 +785,9 @@ class NativeVCFReader(vcfio.VCFReader):
                 break
             return None, gt, ph, lp, planes, gtm, parr
         lp[:n] = out['locus_ploidy'].get()
-        out['locus_ploidy'].free()
-        out['flags'].free()
+        with eng.idle_frees():
+            out['locus_ploidy'].free()
+            out['flags'].free()
         dev = dict(gt=out['gt'], phased=out['phased'], planes={k: a for (k, _, _, _), a in zip(self._selected, out['planes'])},
                    text=td, smp_off=so_d, line_end=le_d, eng=eng)     # (text and offsets stay: the record writer's device half)
         return dev, gt, ph, lp, planes, gtm, parr
