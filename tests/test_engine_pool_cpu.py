@@ -96,3 +96,23 @@ def test_a_helper_thread_with_a_queue_of_its_own():
     e.lib.calls.clear()
     e._pool_give(4096, 555)                       # the caller's own free (queue 0) and take
     assert e._pool_take(4096) == 555 and e.lib.calls == []
+
+
+def test_held_array_goes_back_to_the_pool_only_after_unhold():
+    """DeviceArray.hold(): somebody who is not the owner may still want the array's bytes -- the owner's free() is
+    carried out by unhold()."""
+    from trtools_amd.engine import DeviceArray
+    e = _engine()
+    e._live = set()
+    a = DeviceArray.adopt(e, (1024,), 'u1', 777, 4096)
+    a.hold()
+    a.free()
+    assert a.ptr is None and e._pool_take(4096) is None      # not in the pool yet
+    a.unhold()
+    assert e._pool_take(4096) == 777
+    b = DeviceArray.adopt(e, (1024,), 'u1', 888, 4096)
+    b.hold()
+    b.unhold()                                               # nobody freed it in between: still the owner's
+    assert b.ptr == 888 and e._pool_take(4096) is None
+    b.free()
+    assert e._pool_take(4096) == 888

@@ -525,7 +525,7 @@ class _Run:
         dp_key = dp_keys.pop() if dp_keys else None
         if dp_key is not None and dp_key not in keys:
             keys.append(dp_key)
-        if any(k not in rb.planes for k in keys):
+        if any(k not in rb.plane_arrays() for k in keys):
             return False
         if any(isinstance(f, filters.PopSTRCallRequireSupport) for f in self.call_filters):
             # filters.py:858-867 indexes AD by the genotype index, negative ones from the END of the record's own
@@ -537,7 +537,7 @@ class _Run:
                     bool(np.any((g < 0).any(axis=2) & (g >= 0).any(axis=2)))):
                 return False
         index = {k: i for i, k in enumerate(keys)}
-        arrays = [rb.planes[k] for k in keys]
+        arrays = [rb.plane_arrays()[k] for k in keys]
         specs = [f.spec(index) for f in self.call_filters]
         self.batch_no += 1
         # contigs the header does not declare are registered for EVERY record of the batch, on every rank, before the
@@ -551,9 +551,11 @@ class _Run:
         dev = getattr(rb, 'dev', None)
         if dev is not None and getattr(compute, 'eng', None) is not None:
             # the sample columns were parsed on the device (TRK_DEVICE_PARSE=1): the tensor and the planes are there already;
-            # the host copies (the record writer reads the values of fired filters, the decode path the genotypes) come
-            # back by DMA into the reader's pinned arrays first -- the device arrays are the batch's from here on
-            rb._host()
+            # the device arrays are the batch's from here on.  The host copies (the record writer's host tiers read the
+            # values of fired filters, its decode path the genotypes) are made only if somebody asks: the arrays' memory
+            # is held until the batch is released (RawBatch.host_defer)
+            if not rb.host_defer():
+                rb._host()
             hb = HostBatch.from_tables(dev['gt'], rb.locus_ploidy, hz.allele_off, hz.len_class, hz.str_class,
                                        hz.len_class_value, lists=hz.lists)
             arrays = [dev['planes'][k] for k in keys]
@@ -596,23 +598,23 @@ class _Run:
         cf_plane_idx = []            # plain-value filters: which of the uploaded planes holds the value
         for f in self.call_filters:
             if isinstance(f, filters._HipSTRRatio):
-                cfv.append((f.name, 1, (rb.planes[f.numerator], 0), (rb.planes['DP'], 0)))
+                cfv.append((f.name, 1, (rb.plane_arrays()[f.numerator], 0), (rb.plane_arrays()['DP'], 0)))
             elif isinstance(f, filters._GangSTRQexp):
                 if len(f.cols) == 1:
-                    cfv.append((f.name, 0, (rb.planes['QEXP'], f.cols[0]), None))
+                    cfv.append((f.name, 0, (rb.plane_arrays()['QEXP'], f.cols[0]), None))
                 else:
-                    cfv.append((f.name, 2, (rb.planes['QEXP'], f.cols[0], f.cols[1]), None))
+                    cfv.append((f.name, 2, (rb.plane_arrays()['QEXP'], f.cols[0], f.cols[1]), None))
             elif isinstance(f, filters.GangSTRCallSpanOnly):
-                cfv.append((f.name, 0, (rb.planes['__rc'], 1), None))
+                cfv.append((f.name, 0, (rb.plane_arrays()['__rc'], 1), None))
             elif isinstance(f, filters.GangSTRCallSpanBoundOnly):
-                cfv.append((f.name, 2, (rb.planes['__rc'], 1, 3), None))
+                cfv.append((f.name, 2, (rb.plane_arrays()['__rc'], 1, 3), None))
             elif isinstance(f, filters.GangSTRCallBadCI):
-                cfv.append((f.name, 3, (rb.planes['REPCN'], 0), (rb.planes['__repci'], 0)))
+                cfv.append((f.name, 3, (rb.plane_arrays()['REPCN'], 0), (rb.plane_arrays()['__repci'], 0)))
             elif isinstance(f, filters.PopSTRCallRequireSupport):
-                cfv.append((f.name, 4, (rb.planes['__ad'], int(f.threshold)), None))
+                cfv.append((f.name, 4, (rb.plane_arrays()['__ad'], int(f.threshold)), None))
             else:
                 key = f.planes()[0][0]
-                cfv.append((f.name, 0, (rb.planes[key], 0), None))
+                cfv.append((f.name, 0, (rb.plane_arrays()[key], 0), None))
                 cf_plane_idx.append(index[key])
         ul = bool(args.use_length)
         I0, F0 = st.locus_int[0], st.locus_f64[0]

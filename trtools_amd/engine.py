@@ -98,11 +98,30 @@ class DeviceArray:
         """Give the memory back: to the engine's pool of device buffers (reused by the next array of the same size
         class -- a CLI run allocates the same dozen buffers for every batch, and hipMalloc / hipFree each
         synchronise the device), or to the driver when pooling is off or the pool is full."""
+        if getattr(self, '_holds', 0) > 0 and self.parent is None and self.ptr is not None:
+            self._late, self.ptr = self.ptr, None       # (somebody may still want its bytes: unhold() gives it back)
+            self.eng._live.discard(self)
+            return
         if self.parent is None and self.ptr is not None and self.eng.ctx is not None:
             if not self.eng._pool_give(self.cap, self.ptr):
                 self.eng.lib.trk_dev_free(self.eng.ctx, self.ptr)
         self.ptr = None
         self.eng._live.discard(self)
+
+    def hold(self):
+        """Keep the MEMORY (not the array) until ``unhold``: a free() in between -- by an owner that is done with the
+        array -- is carried out then.  For a reader of the bytes that is not the owner (RawBatch: the host copies of a
+        device-parsed batch are made only if somebody asks for them)."""
+        self._holds = getattr(self, '_holds', 0) + 1
+        return self
+
+    def unhold(self):
+        self._holds -= 1
+        late = getattr(self, '_late', None)
+        if self._holds == 0 and late is not None:
+            self._late = None
+            if self.eng.ctx is not None and not self.eng._pool_give(self.cap, late):
+                self.eng.lib.trk_dev_free(self.eng.ctx, late)
 
 
 class DeviceBatch:

@@ -132,9 +132,31 @@ class RawBatch:
 
     # In device-parse mode the sample columns were parsed by trk_parse_samples and live in HBM (``dev``); the host
     # arrays are filled from them the first time somebody asks (the record writer's decode path, the per-record loop).
+    def host_defer(self):
+        """The device arrays are about to change hands (dumpSTR gives them to its device batch, which frees them when it is
+        done): their MEMORY is held until this batch is released, so that the host copies can still be made if somebody
+        asks -- 160 MB per batch at 17 000 x 5000 that only the records the device leaves to the host writer need.
+        Returns False (nothing held) when the copies could not be plain ones: the caller copies now (``_host``)."""
+        d = self.dev
+        if d is None or d.get('on_host') or d.get('deferred') is not None:
+            return d is not None and d.get('deferred') is not None
+        pairs = [(self._gt, d['gt']), (self._phased, d['phased'])] + [(self._planes[k], a) for k, a in d['planes'].items()]
+        if os.environ.get('TRK_HOST_DEFER', '1') == '0' or not self.n or \
+                not all(src is not None and src.ptr is not None and dst.flags['C_CONTIGUOUS'] and dst.nbytes == src.nbytes
+                        for dst, src in pairs):
+            return False
+        d['deferred'] = (d['gt'].eng, [(dst, src.hold(), src.ptr, src.nbytes) for dst, src in pairs])
+        return True
+
     def _host(self):
         d = self.dev
-        if d is not None and not d.get('on_host'):
+        if d is not None and d.get('deferred') is not None:
+            eng, items = d['deferred']
+            d['deferred'], d['on_host'] = None, True
+            for dst, src, ptr, nbytes in items:
+                eng._chk(eng.lib.trk_memcpy_d2h(eng.ctx, dst.ctypes.data, ptr, nbytes))
+                src.unhold()
+        elif d is not None and not d.get('on_host'):
             d['on_host'] = True
             if self.n:
                 eng = d['gt'].eng
@@ -151,8 +173,17 @@ class RawBatch:
     phased = property(lambda self: self._host()._phased)
     planes = property(lambda self: self._host()._planes)
 
+    def plane_arrays(self):
+        """The host planes as OBJECTS (keys, shapes, addresses): in device-parse mode their contents may not have been
+        copied yet (``host_defer``) -- reading values goes through ``planes``."""
+        return self._planes
+
     def release_device(self):
         """Give the device-parsed arrays back (the caller took what it needs, or handed them to a DeviceBatch)."""
+        if self.dev is not None and self.dev.get('deferred') is not None:
+            for _dst, src, _ptr, _n in self.dev['deferred'][1]:      # nobody asked for the host copies
+                src.unhold()
+            self.dev['deferred'] = None
         d, self.dev = self.dev, None
         if d is not None:
             for a in [d.get('gt'), d.get('phased'), d.get('text'), d.get('smp_off'), d.get('line_end')] + list(d.get('planes', {}).values()):
@@ -271,9 +302,11 @@ class RawBatch:
         het / hwep (float64 [n]), allele_count (int32), allele_off (int32 [n + 1]), info_types ({ID: (Type, Number)}),
         py_head (callable l -> str: the head of a record whose INFO column the native rewrite declines); ``heads`` is
         then ignored."""
-        S, P = self.gt.shape[1], self.gt.shape[2]
-        gt = np.ascontiguousarray(self.gt)
-        ph = np.ascontiguousarray(self.phased)
+        # (device-parse mode: the host copies may have been deferred -- host_defer; only the arrays' addresses are taken
+        # here, and the copies are made below unless the device writes the columns of every record)
+        S, P = self._gt.shape[1], self._gt.shape[2]
+        gt = np.ascontiguousarray(self._gt)
+        ph = np.ascontiguousarray(self._phased)
         lp = np.ascontiguousarray(self.locus_ploidy)
         mask = np.ascontiguousarray(mask)
         keep = [gt, ph, lp, mask]
@@ -329,6 +362,8 @@ class RawBatch:
                 if regions.get('wait') is not None:     # the download is in flight: the writer waits after the heads
                     ext.dev_wait, ext.dev_wait_arg = regions['wait']
                 keep.append(regions)
+        if regions is None or regions['flags'].any() or os.environ.get('TRK_FMT_FAST', '1') == '0':
+            self._host()        # the writer reads genotypes / values of some record: they have to be here
         # output bound: the input text, a third more for re-serialised numbers, and per call the FILTER column this
         # pass appends (':PASS' / ':NOCALL'; the longer '<name>_<value>' strings of the few filtered calls fit in
         # the slack).  The buffer is not touched beyond what is written, so a generous bound costs nothing -- a
