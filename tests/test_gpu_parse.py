@@ -308,3 +308,61 @@ def test_dumpstr_sample_columns_written_on_the_device(tmp_path, seed):
         j = next((j for j, (p, q) in enumerate(zip(fa, fb)) if p != q), -1)
         raise AssertionError("line %d column %d: host %r device %r" % (i, j, fa[j][:80] if j >= 0 else len(fa), fb[j][:80] if j >= 0 else len(fb)))
     assert took[0] == 0 and took[1] > (20 if seed == 5 else 0), took
+
+
+def test_dumpstr_device_format_long_rows_and_tile_boundaries(tmp_path):
+    """k_format_samples beyond one tile: rows of 3000 samples (~45 KB of sample text: six 8 KB tiles), tokens of every
+    length so that starts and ends fall on every byte of a chunk and across tile ends, calls every filter fires on, a
+    record whose tokens are longer than the text staged beyond a tile (the host writer's) and CRLF line ends.  dumpSTR's output with the device writer is byte for byte the host writer's."""
+    from test_dumpstr_cli import make_args as dump_args
+    from trtools_amd import vcfnative
+    from trtools_amd.dumpSTR import dumpSTR
+    rng = np.random.default_rng(31)
+    S = 3000
+    hdr = ['##fileformat=VCFv4.2', '##command=HipSTR-v0.6.2 x', '##INFO=<ID=START,Number=1,Type=Integer,Description="s">',
+           '##INFO=<ID=END,Number=1,Type=Integer,Description="e">', '##INFO=<ID=PERIOD,Number=1,Type=Integer,Description="p">',
+           '##FORMAT=<ID=GT,Number=1,Type=String,Description="g">', '##FORMAT=<ID=DP,Number=1,Type=Integer,Description="d">',
+           '##FORMAT=<ID=Q,Number=1,Type=Float,Description="q">', '##FORMAT=<ID=TAG,Number=1,Type=String,Description="t">',
+           '##contig=<ID=chr1,length=100000>',
+           '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t' + '\t'.join('s%d' % i for i in range(S))]
+    # (no Q below 1e-4: '%g' prints those with an exponent, which is the host writer's business -- the record would be its)
+    qs = ['0.99', '1', '0.5', '0.93', '0.912345', '0.001', '0.85', '.']
+    for nl, name in (('\n', 'lf'), ('\r\n', 'crlf')):
+        lines = list(hdr)
+        for r in range(14):
+            cols = []
+            for s in range(S):
+                u = rng.random()
+                if u < 0.03:
+                    cols.append('.')
+                    continue
+                gt = '%d|%d' % (rng.integers(0, 3), rng.integers(0, 3))
+                tag = 'x' * (400 if r == 9 else int(rng.integers(1, 24)))
+                t = [gt, str(int(rng.integers(0, 90))), qs[int(rng.integers(0, len(qs)))], tag]
+                cols.append(':'.join(t[:int(rng.integers(2, 5))] if u < 0.1 else t))
+            lines.append('\t'.join(['chr1', str(100 + 50 * r), '.', 'ACAC', 'ACACAC,AC', '.', '.',
+                                    'START=%d;END=%d;PERIOD=2' % (100 + 50 * r, 103 + 50 * r), 'GT:DP:Q:TAG'] + cols))
+        src = str(tmp_path / (name + '.vcf'))
+        open(src, 'wb').write((nl.join(lines) + nl).encode())
+        kw = dict(hipstr_min_call_DP=20, hipstr_max_call_DP=70, hipstr_min_call_Q=0.9)
+        outs, took = [], []
+        for dev in ('0', '1'):
+            os.environ['TRK_DEVICE_FORMAT'] = dev
+            before = dict(vcfnative.DEVICE_FORMAT)
+            try:
+                out = str(tmp_path / ('%s_f%s' % (name, dev)))
+                assert dumpSTR.main(dump_args(out, src, vcftype='hipstr', **kw)) == 0
+                assert dumpSTR.LAST_RUN['path'] == 'batch'
+                outs.append([x for x in open(out + '.vcf', 'rb').read().split(b'\n') if not x.startswith(b'##command-DumpSTR')])
+                took.append((vcfnative.DEVICE_FORMAT['records'] - before['records'],
+                             vcfnative.DEVICE_FORMAT['left_to_host'] - before['left_to_host']))
+            finally:
+                os.environ.pop('TRK_DEVICE_FORMAT', None)
+        assert len(outs[0]) == len(outs[1])
+        for i, (p, q) in enumerate(zip(outs[0], outs[1])):
+            if p != q:
+                fa, fb = p.split(b'\t'), q.split(b'\t')
+                j = next((j for j, (x, y) in enumerate(zip(fa, fb)) if x != y), -1)
+                raise AssertionError("%s line %d column %d: host %r device %r" % (name, i, j, fa[j][:80], fb[j][:80]))
+        if name == 'lf':
+            assert took[0] == (0, 0) and took[1][0] >= 12 and took[1][1] >= 1, took     # (record 9: tokens beyond the staged text)
