@@ -325,8 +325,9 @@ def test_dumpstr_device_format_long_rows_and_tile_boundaries(tmp_path):
            '##FORMAT=<ID=Q,Number=1,Type=Float,Description="q">', '##FORMAT=<ID=TAG,Number=1,Type=String,Description="t">',
            '##contig=<ID=chr1,length=100000>',
            '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t' + '\t'.join('s%d' % i for i in range(S))]
-    # (no Q below 1e-4: '%g' prints those with an exponent, which is the host writer's business -- the record would be its)
-    qs = ['0.99', '1', '0.5', '0.93', '0.912345', '0.001', '0.85', '.']
+    # (depths of seven digits and more among the values: the writer prints those with an exponent.  No Q below 1e-4: spelled
+    # without an exponent such a token is not canonical -- decode -> format would rewrite it -- and the record is the host's)
+    qs = ['0.99', '1', '0.5', '0.93', '0.912345', '0.0001', '0.85', '.', '0.001', '0.00012']
     for nl, name in (('\n', 'lf'), ('\r\n', 'crlf')):
         lines = list(hdr)
         for r in range(14):
@@ -338,7 +339,8 @@ def test_dumpstr_device_format_long_rows_and_tile_boundaries(tmp_path):
                     continue
                 gt = '%d|%d' % (rng.integers(0, 3), rng.integers(0, 3))
                 tag = 'x' * (400 if r == 9 else int(rng.integers(1, 24)))
-                t = [gt, str(int(rng.integers(0, 90))), qs[int(rng.integers(0, len(qs)))], tag]
+                dp = int(rng.integers(0, 90)) if rng.random() < 0.97 else int(rng.choice([1234567, 20000000, 999999, 1000000, 214748364]))
+                t = [gt, str(dp), qs[int(rng.integers(0, len(qs)))], tag]
                 cols.append(':'.join(t[:int(rng.integers(2, 5))] if u < 0.1 else t))
             lines.append('\t'.join(['chr1', str(100 + 50 * r), '.', 'ACAC', 'ACACAC,AC', '.', '.',
                                     'START=%d;END=%d;PERIOD=2' % (100 + 50 * r, 103 + 50 * r), 'GT:DP:Q:TAG'] + cols))

@@ -317,7 +317,9 @@ struct FormatArgs {
     trk_format_out out;
 };
 
-// "%g" of x into buf: the length, or -1 when the host has to print it (exponent forms, non-finite, a rounding tie)
+// "%g" of x into buf: the length, or -1 when the host has to print it (non-finite, a rounding tie, an exponent beyond
+// the table).  Six significant digits by ONE rounded product / quotient with a power of ten; fixed notation for decimal
+// exponents -4 .. 5, d[.ddddd]e+XX from 10^6 on (depths of seven digits), trailing zeros dropped -- printf's rules.
 __device__ int g6(char* buf, double x) {
     int n = 0;
     if (!(x == x) || x - x != 0.0) return -1;
@@ -330,17 +332,28 @@ __device__ int g6(char* buf, double x) {
         buf[n++] = '-';
         x = -x;
     }
-    if (x < 1e-4 || x >= 1e6) return -1;
-    int e = x >= 1e5 ? 5 : x >= 1e4 ? 4 : x >= 1e3 ? 3 : x >= 1e2 ? 2 : x >= 1e1 ? 1 : x >= 1e0 ? 0 : x >= 1e-1 ? -1 : x >= 1e-2 ? -2 : x >= 1e-3 ? -3 : -4;
-    const double y = x * c_p10[5 - e];                  // six significant digits before the point (5 - e in 0 .. 9)
+    // (below 1e-4 printf writes an exponent too, but no such value gets here: a token that spells one without an exponent is
+    // not canonical -- the record is the host's -- and one with an exponent is outside the device parser's grammar)
+    // (-- except the values a hair below 1e-4 that round up to it: float32 0.0001 is 9.99999975e-05)
+    if (x < 9.99999e-5 || x >= 1e15) return -1;
+    int e;                                               // decimal exponent of the first significant digit
+    if (x >= 1.0) {
+        e = 0;
+        while (e < 14 && x >= c_p10[e + 1]) ++e;
+    } else {
+        e = x >= 1e-1 ? -1 : x >= 1e-2 ? -2 : x >= 1e-3 ? -3 : x >= 1e-4 ? -4 : -5;
+    }
+    const double y = e <= 5 ? x * c_p10[5 - e] : x / c_p10[e - 5];   // six significant digits before the point
     const double fl = floor(y), fr = y - fl;
     if (fabs(fr - 0.5) < 1e-6) return -1;               // too close to a tie for one rounded product to decide
     uint32_t d = (uint32_t)fl + (fr > 0.5 ? 1u : 0u);
     if (d >= 1000000u) {                                // 999999.6 -> 1000000: one more digit before the point
         d = 100000u;
         ++e;
-        if (e > 5) return -1;
+    } else if (d < 100000u) {                           // the exponent guessed one too high (x a hair below a power of ten)
+        return -1;
     }
+    if (e < -4) return -1;                              // (stayed below 1e-4 after rounding: an exponent form, the host's)
     char dig[6];
     for (int i = 5; i >= 0; --i) {
         dig[i] = (char)('0' + d % 10u);
@@ -348,6 +361,24 @@ __device__ int g6(char* buf, double x) {
     }
     int last = 5;
     while (last > 0 && dig[last] == '0') --last;        // significant digits dig[0 .. last]
+    if (e < -4 || e >= 6) {                             // d[.ddddd]e[+-]XX
+        buf[n++] = dig[0];
+        if (last > 0) {
+            buf[n++] = '.';
+            for (int i = 1; i <= last; ++i) buf[n++] = dig[i];
+        }
+        buf[n++] = 'e';
+        int ae = e;
+        if (ae < 0) {
+            buf[n++] = '-';
+            ae = -ae;
+        } else {
+            buf[n++] = '+';
+        }
+        buf[n++] = (char)('0' + ae / 10);
+        buf[n++] = (char)('0' + ae % 10);
+        return n;
+    }
     if (e >= 0) {
         for (int i = 0; i <= e; ++i) buf[n++] = dig[i];
         if (last > e) {
