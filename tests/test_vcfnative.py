@@ -493,3 +493,56 @@ def test_text_buffers_in_the_callers_memory(tmp_path):
     r.read_raw_batch(3)
     assert r._lib.trk_vcf_set_text_buffers(r._h, tiny[0].ctypes.data, tiny[1].ctypes.data, 16) == 1
     assert r.read_raw_batch(3).n == 3
+
+
+@pytest.mark.parametrize('container', ['plain', 'bgzf', 'plain_no_final_newline', 'plain_crlf'])
+def test_line_index_over_many_megabytes(tmp_path, container):
+    """The newlines of a batch's text are found by the inflater pool a megabyte per task once a fill brings more than two
+    (round 4): 12 MB of text in lines of 40 bytes to 300 KB, blank lines, line ends on and next to the megabyte
+    boundaries -- the records (position, id, sample columns) are the file's, in order, in batches of 7 and of 1000."""
+    import gzip
+    from trtools_amd import bgzf, vcfnative
+    rng = np.random.default_rng(77)
+    S = 5
+    hdr = ('##fileformat=VCFv4.2\n##contig=<ID=chr1>\n##FORMAT=<ID=GT,Number=1,Type=String,Description="g">\n'
+           '##INFO=<ID=X,Number=1,Type=String,Description="x">\n'
+           '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t' + '\t'.join('s%d' % i for i in range(S)) + '\n')
+    nl = '\r\n' if container == 'plain_crlf' else '\n'
+    recs, body, size = [], [], len(hdr)
+    i = 0
+    while size < 12 << 20:
+        pad = int(rng.choice([0, 3, 40, 700, 9000, 70000, 300000]))
+        # (every so often a line that ends exactly on, one before and one after a multiple of 1 MB of the TEXT)
+        gts = ['%d/%d' % (rng.integers(0, 2), rng.integers(0, 2)) for _ in range(S)]
+        line = 'chr1\t%d\tr%d\tACAC\tAC\t.\t.\tX=%s\tGT\t%s' % (1000 + 5 * i, i, 'a' * pad, '\t'.join(gts))
+        if i % 5 == 0:
+            want = ((size >> 20) + 1) << 20
+            need = want - size - len(line) - len(nl) + int(rng.integers(-1, 2))
+            if 0 < need < 400000:
+                line = line.replace('X=', 'X=' + 'b' * need, 1)
+        recs.append((1000 + 5 * i, 'r%d' % i, gts))
+        body.append(line)
+        size += len(line) + len(nl)
+        if i % 11 == 3 and container != 'plain_crlf':
+            body.append('')                      # a blank line
+            size += len(nl)
+        i += 1
+    text = hdr.replace('\n', nl) + nl.join(body) + ('' if container == 'plain_no_final_newline' else nl)
+    path = str(tmp_path / ('big.vcf' + ('.gz' if container == 'bgzf' else '')))
+    if container == 'bgzf':
+        with bgzf.BgzfWriter(path) as fh:
+            fh.write(text)
+    else:
+        open(path, 'w', newline='').write(text)
+    for batch in (7, 1000):
+        r = vcfnative.NativeVCFReader(path, batch_records=batch, n_threads=8)
+        got = []
+        while True:
+            rb = r.read_raw_batch(batch)
+            if not rb.n:
+                break
+            for l in range(rb.n):
+                f = rb.head_fields(l)
+                got.append((int(f[1]), f[2], ['%d/%d' % tuple(rb.gt[l, s]) for s in range(S)]))
+        assert len(got) == len(recs)
+        assert got == recs
