@@ -368,3 +368,45 @@ def test_dumpstr_device_format_long_rows_and_tile_boundaries(tmp_path):
                 raise AssertionError("%s line %d column %d: host %r device %r" % (name, i, j, fa[j][:80], fb[j][:80]))
         if name == 'lf':
             assert took[0] == (0, 0) and took[1][0] >= 12 and took[1][1] >= 1, took     # (record 9: tokens beyond the staged text)
+
+
+def test_device_parse_tokens_longer_than_the_staged_text(eng, tmp_path):
+    """k_parse_samples walks its tokens in an LDS copy of the tile that reaches 256 bytes beyond it.  FORMAT GT:TAG:DP:Q with
+    string fields of 20 ... 900 bytes IN FRONT of the numbers: a token that starts near a tile's end and needs bytes beyond
+    the staged text flags its record (the host's); every record the device takes equals the host reader's arrays, and the
+    records with short strings are all taken."""
+    rng = np.random.default_rng(123)
+    S = 1500
+    hdr = ['##fileformat=VCFv4.2', '##FORMAT=<ID=GT,Number=1,Type=String,Description="g">',
+           '##FORMAT=<ID=TAG,Number=1,Type=String,Description="t">', '##FORMAT=<ID=DP,Number=1,Type=Integer,Description="d">',
+           '##FORMAT=<ID=Q,Number=1,Type=Float,Description="q">',
+           '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t' + '\t'.join('s%d' % i for i in range(S))]
+    lines = list(hdr)
+    long_rec = []
+    for r in range(10):
+        big = r % 2 == 1
+        long_rec.append(big)
+        cols = []
+        for s in range(S):
+            ln = int(rng.integers(300, 900)) if big else int(rng.integers(1, 20))
+            cols.append('%d/%d:%s:%d:%.3f' % (rng.integers(0, 3), rng.integers(0, 3), 'y' * ln, rng.integers(0, 99), rng.random()))
+        lines.append('\t'.join(['chr1', str(100 + 10 * r), '.', 'ACAC', 'AC,ACACAC', '.', '.', '.', 'GT:TAG:DP:Q'] + cols))
+    path = str(tmp_path / 'longtags.vcf')
+    open(path, 'w').write('\n'.join(lines) + '\n')
+    from trtools_amd import vcfnative
+    r = vcfnative.NativeVCFReader(path, batch_records=10, max_ploidy=2)
+    for k in ('DP', 'Q'):
+        r.select_format(k)
+    rb = r.read_raw_batch(10)
+    text, so, le, gi, pidx = device_inputs(rb, ['DP', 'Q'])
+    out = eng.parse_samples(text, so, le, S, 2, gi, planes=list(zip(pidx, ['i', 'f'])), want_phased=True)
+    flags = out['flags'].get()
+    take = flags == 0
+    assert take[[i for i, b in enumerate(long_rec) if not b]].all()            # short strings: all the device's
+    assert not take[[i for i, b in enumerate(long_rec) if b]].any()            # 1500 tokens of 300+ bytes: some tile end hits one
+    assert np.array_equal(out['gt'].get()[take], rb.gt[take])
+    assert np.array_equal(out['planes'][0].get()[take], rb.planes['DP'][:, :, 0][take])
+    assert np.array_equal(out['planes'][1].get()[take].view(np.uint32), rb.planes['Q'][:, :, 0][take].view(np.uint32))
+    # and through the reader's own device mode: the batch falls back to the host parser, same arrays
+    n, taken = compare_file(eng, path, batch_records=10)
+    assert n == 10 and taken == 5

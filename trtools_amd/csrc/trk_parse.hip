@@ -13,7 +13,8 @@
 // One workgroup per record.  The sample region is walked in tiles of 16 KB: every lane loads four 16-byte chunks
 // (coalesced), the tabs of a chunk are a 16-bit mask, their number goes to LDS, a workgroup scan turns the counts into
 // the index of each chunk's first token, the lanes scatter their chunks' token starts into an LDS list, and then lane t
-// parses tokens t, t + 256, ... of the tile straight from global memory (the bytes are in L2: the tile was just read).
+// parses tokens t, t + 256, ... of the tile from an LDS copy of it (the chunks are stored there as they arrive, with
+// 256 bytes beyond the tile and a closing tab: a token whose needed fields reach that tab is the host's).
 // HBM traffic: the text once + the arrays once.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,6 +29,7 @@ constexpr int PS_TILE = 16384;                 // bytes of text per tile
 constexpr int PS_CHUNKS = PS_TILE / 16;        // 1024 chunks, four per lane
 constexpr int PS_MAXTOK = PS_TILE / 2 + 2;     // tokens that can START in a tile (one byte + a tab each)
 constexpr int32_t PS_INT_MISSING = INT32_MIN;
+constexpr int PS_OVER = 256;                   // k_parse_samples: text staged beyond a tile (its last token's needed fields end there)
 // k_format_samples: tiles of 8 KB (two chunks per lane) -- text, token list and the staged output of a tile together stay
 // under 40 KB of LDS, four workgroups per CU
 constexpr int FS_TILE = 8192;
@@ -63,7 +65,10 @@ __device__ __forceinline__ uint32_t tab_mask(const uint4 v) {
 
 __global__ __launch_bounds__(PS_THREADS) void k_parse_samples(const ParseArgs a) {
     __shared__ uint16_t s_cnt[PS_CHUNKS];          // tabs per chunk, then the index of the chunk's first token in the tile
-    __shared__ uint32_t s_tok[PS_MAXTOK];          // start offsets (from the region's start) of the tokens of this tile
+    __shared__ uint16_t s_tok[PS_MAXTOK];          // start offsets of the tokens of this tile, from the tile's first chunk
+    // the tile's TEXT and PS_OVER bytes beyond it, closed by a tab: the lanes walk their tokens from LDS; a token whose
+    // needed fields reach the closing tab is the host's
+    __shared__ uint4 s_text[PS_CHUNKS + PS_OVER / 16 + 1];
     __shared__ uint32_t s_wsum[PS_THREADS / 64];
     __shared__ uint32_t s_flags, s_maxpl, s_base;
     const int rec = blockIdx.x;
@@ -114,14 +119,22 @@ __global__ __launch_bounds__(PS_THREADS) void k_parse_samples(const ParseArgs a)
             const int c = tid + q * PS_THREADS;              // chunk of the tile
             const int64_t o = t0 + (int64_t)c * 16 - lead;   // offset of the chunk's first byte from the region's start
             uint32_t m = 0;
-            if (o < n && o + 16 > 0) {
+            if (o <= n && o + 16 > 0) {                        // (the chunk that holds the newline too)
                 const uint4 v = *reinterpret_cast<const uint4*>(reg + o);
+                s_text[c] = v;
                 m = tab_mask(v);
                 if (o < 0) m &= ~((1u << (int)(-o)) - 1u);                    // bytes before the region
                 if (o + 16 > n) m &= (1u << (int)(n - o)) - 1u;               // bytes from the newline on
             }
             mk[q] = m;
             s_cnt[c] = (uint16_t)__popc(m);
+        }
+        if (tid <= PS_OVER / 16) {
+            const int c = PS_CHUNKS + tid;
+            const int64_t o = t0 + (int64_t)c * 16 - lead;
+            uint4 v = {0x09090909u, 0x09090909u, 0x09090909u, 0x09090909u};      // beyond the staged text: tabs
+            if (tid < PS_OVER / 16 && o <= n) v = *reinterpret_cast<const uint4*>(reg + o);
+            s_text[c] = v;
         }
         __syncthreads();
         // ---- exclusive scan of the 1024 counts: lane t owns chunks 4t .. 4t + 3 -----------------------------------
@@ -151,17 +164,16 @@ __global__ __launch_bounds__(PS_THREADS) void k_parse_samples(const ParseArgs a)
         __syncthreads();
         // ---- token starts of the tile: the byte after every tab (+ the region's first token in the first tile) -----
         const uint32_t first = t0 == 0 ? 1u : 0u;
-        if (t0 == 0 && tid == 0) s_tok[0] = 0u;
+        if (t0 == 0 && tid == 0) s_tok[0] = (uint16_t)lead;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int c = tid + q * PS_THREADS;
             uint32_t m = mk[q];
             uint32_t k = first + s_cnt[c];
-            const int64_t o = t0 + (int64_t)c * 16 - lead;
             while (m) {
                 const int b = __ffs((int)m) - 1;
                 m &= m - 1;
-                if (k < (uint32_t)PS_MAXTOK) s_tok[k] = (uint32_t)(o + b + 1);
+                if (k < (uint32_t)PS_MAXTOK) s_tok[k] = (uint16_t)(c * 16 + b + 1);
                 ++k;
             }
         }
@@ -181,8 +193,12 @@ __global__ __launch_bounds__(PS_THREADS) void k_parse_samples(const ParseArgs a)
                 lflags |= TRK_PARSE_COLUMNS;
                 continue;
             }
-            const unsigned char* c = reg + s_tok[k];
-            const unsigned char* const end = reg + n;
+            const unsigned char* const tb = reinterpret_cast<const unsigned char*>(s_text);
+            const unsigned char* c = tb + s_tok[k];
+            // the region's end (the newline) and the end of the staged text, as addresses in the tile's LDS copy
+            const int64_t rel_end = span - t0;
+            const unsigned char* const end = tb + (rel_end < (int64_t)(PS_TILE + PS_OVER) ? rel_end : (int64_t)(PS_TILE + PS_OVER + 16));
+            const unsigned char* const lim = tb + PS_TILE + PS_OVER;
             int16_t* g = a.out.gt + ((int64_t)rec * S + s) * P;
             int j = 0;
             bool phased = false, ok = true;
@@ -274,7 +290,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_parse_samples(const ParseArgs a)
                 ok = false;
                 break;
             }
-            if (!ok) {
+            if (!ok || (c >= lim && c != end)) {       // (the walk ran into the end of the staged text: a token that long is the host's)
                 lflags |= TRK_PARSE_HOST;
                 continue;
             }
