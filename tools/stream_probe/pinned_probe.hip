@@ -184,6 +184,95 @@ __global__ __launch_bounds__(256) void k_flat(Streams s, int L, int S4) {
     }
 }
 
+
+// ---- round 5: temporal decoupling of the two write streams ----
+// XCD-aware persistent column-owner walk (the product's map 2); the outputs of K loci are held in registers and leave as
+// bursts.  MODE 0: A at once, B held K loci (A A A A | B B B B interleaved only at burst boundaries); 1: both held, K
+// stores to A then K stores to B; 2: as 1 with an s_waitcnt vmcnt(0) between the two bursts (A's stores have left the
+// wave before B's start).
+template <int K, int MODE>
+__global__ __launch_bounds__(256) void k_walk_burst(Streams s, int L, int S4, int lpb, int gx_) {
+    extern __shared__ uint32_t dummy[];
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int by = xcd + 8 * (slot / gx_), bx = slot % gx_;
+    const int c = bx * 256 + threadIdx.x;
+    if (c >= S4) return;
+    const int l0 = by * lpb, l1 = min(L, l0 + lpb);
+    for (int lb = l0; lb < l1; lb += K) {
+        u32x4 ha[K], hb[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int l = lb + i;
+            if (l < l1) {
+                const size_t o = (size_t)l * S4 + c;
+                u32x4 r = {(uint32_t)l, 1u, 2u, 3u};
+                r |= __builtin_nontemporal_load(s.in[0] + o) | __builtin_nontemporal_load(s.in[1] + o) | __builtin_nontemporal_load(s.in[2] + o);
+                if (MODE == 0) __builtin_nontemporal_store(r, s.out[0] + o);
+                else ha[i] = r;
+                hb[i] = r + 1u;
+            }
+        }
+        if (MODE != 0) {
+#pragma unroll
+            for (int i = 0; i < K; ++i)
+                if (lb + i < l1) __builtin_nontemporal_store(ha[i], s.out[0] + (size_t)(lb + i) * S4 + c);
+            if (MODE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+            if (lb + i < l1) __builtin_nontemporal_store(hb[i], s.out[1] + (size_t)(lb + i) * S4 + c);
+    }
+    if (dummy && lpb < 0) dummy[threadIdx.x] = 0;
+}
+
+// row-owner walk: a workgroup of T threads covers WHOLE rows (CH chunks per thread, chunk = tid + i * T) and walks a
+// contiguous range of loci: 40 KB contiguous per locus and plane leave one workgroup.  ORDER 0: A, B per chunk;
+// 1: the row's A stores, then its B stores; 2: K rows of A, then K rows of B (K = 2).
+template <int T, int CH, int ORDER>
+__global__ __launch_bounds__(T) void k_row(Streams s, int L, int S4, int lpw) {
+    const int l0 = blockIdx.x * lpw, l1 = min(L, l0 + lpw);
+    for (int l = l0; l < l1; ++l) {
+        u32x4 r[CH];
+        const size_t ro = (size_t)l * S4;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = threadIdx.x + i * T;
+            r[i] = (u32x4){(uint32_t)l, 1u, 2u, 3u};
+            if (c < S4) r[i] |= __builtin_nontemporal_load(s.in[0] + ro + c) | __builtin_nontemporal_load(s.in[1] + ro + c) | __builtin_nontemporal_load(s.in[2] + ro + c);
+        }
+        if (ORDER == 0) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int c = threadIdx.x + i * T;
+                if (c < S4) { __builtin_nontemporal_store(r[i], s.out[0] + ro + c); __builtin_nontemporal_store(r[i] + 1u, s.out[1] + ro + c); }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int c = threadIdx.x + i * T;
+                if (c < S4) __builtin_nontemporal_store(r[i], s.out[0] + ro + c);
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int c = threadIdx.x + i * T;
+                if (c < S4) __builtin_nontemporal_store(r[i] + 1u, s.out[1] + ro + c);
+            }
+        }
+    }
+}
+
+// write-only, ONE plane per kernel (two of them run on two queues at the same time: is the pair effect a matter of two
+// streams of one WAVE, or of any two streams into the same class at the same time?)
+__global__ __launch_bounds__(256) void k_fill_walk(u32x4* out, int L, int S4, int lpb) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= S4) return;
+    const int l0 = blockIdx.y * lpb, l1 = min(L, l0 + lpb);
+    for (int l = l0; l < l1; ++l) {
+        u32x4 r = {(uint32_t)l, 1u, 2u, 3u};
+        __builtin_nontemporal_store(r, out + (size_t)l * S4 + c);
+    }
+}
+
 struct Result { std::string name; double mn, avg; };
 static std::vector<Result> results;
 static hipEvent_t e0, e1;
@@ -302,6 +391,53 @@ static void geometry(const Streams& s, const char* tag) {
     run(nm, [&] { hipLaunchKernelGGL((k_pol<P0, P1>), dim3(gx, gy), dim3(256), lds_for(5), 0, s, L, S4, lpb); });
     PL(0, 0, "nt / nt") PL(0, 1, "nt / plain") PL(1, 0, "plain / nt") PL(0, 2, "nt / sc1") PL(0, 3, "nt / sc0 sc1") PL(1, 1, "plain / plain")
 #undef PL
+}
+
+
+static void burst(const Streams& s, const char* tag) {
+    char nm[200];
+    const int wgcu = 4;
+    const int ny = std::max(8, wgcu * ncu / gx / 8 * 8), lpb = (L + ny - 1) / ny;
+    snprintf(nm, sizeof nm, "[%s] XCD-aware persistent 4 WG/CU, no burst (reference)", tag);
+    run(nm, [&] { hipLaunchKernelGGL((k_walk_xcd<0>), dim3(ny * gx), dim3(256), lds_for(wgcu), 0, s, L, S4, lpb, gx); });
+#define BU(K, M, NAME)                                                                                                     \
+    snprintf(nm, sizeof nm, "[%s] burst K = %d, %s", tag, K, NAME);                                                        \
+    run(nm, [&] { hipLaunchKernelGGL((k_walk_burst<K, M>), dim3(ny * gx), dim3(256), lds_for(wgcu), 0, s, L, S4, lpb, gx); });
+    BU(2, 0, "A at once, B held") BU(4, 0, "A at once, B held") BU(8, 0, "A at once, B held") BU(16, 0, "A at once, B held")
+    BU(2, 1, "K x A then K x B") BU(4, 1, "K x A then K x B") BU(8, 1, "K x A then K x B")
+    BU(4, 2, "K x A, wait, K x B") BU(8, 2, "K x A, wait, K x B")
+#undef BU
+#define RO(T, CH, O, NAME)                                                                                                 \
+    if ((T) * (CH) >= S4) for (int per : {1, 2, 4}) {                                                                      \
+        const int nw = per * ncu, lpw = (L + nw - 1) / nw;                                                                 \
+        snprintf(nm, sizeof nm, "[%s] row-owner %d threads x %d chunks, %d WG/CU, %s", tag, T, CH, per, NAME);             \
+        run(nm, [&] { hipLaunchKernelGGL((k_row<T, CH, O>), dim3(nw), dim3(T), 0, 0, s, L, S4, lpw); });                   \
+    }
+    RO(1024, 3, 0, "A B per chunk") RO(1024, 3, 1, "row of A then row of B")
+    RO(512, 5, 0, "A B per chunk") RO(512, 5, 1, "row of A then row of B")
+    RO(256, 10, 0, "A B per chunk") RO(256, 10, 1, "row of A then row of B")
+#undef RO
+    // two write-only kernels, one plane each, at the same time on two queues; and one after the other
+    static hipStream_t q1 = nullptr;
+    static hipEvent_t ef = nullptr, eb = nullptr;
+    if (!q1) { CK(hipStreamCreateWithFlags(&q1, hipStreamNonBlocking)); CK(hipEventCreate(&ef)); CK(hipEventCreate(&eb)); }
+    const int lpbp = lpb_product(), gyp = (L + lpbp - 1) / lpbp;
+    snprintf(nm, sizeof nm, "[%s] write only, plane A then plane B (two launches, one queue)", tag);
+    run(nm, [&] {
+        hipLaunchKernelGGL(k_fill_walk, dim3(gx, gyp), dim3(256), 0, 0, s.out[0], L, S4, lpbp);
+        hipLaunchKernelGGL(k_fill_walk, dim3(gx, gyp), dim3(256), 0, 0, s.out[1], L, S4, lpbp);
+    });
+    snprintf(nm, sizeof nm, "[%s] write only, plane A and plane B at the same time (two queues)", tag);
+    run(nm, [&] {
+        CK(hipEventRecord(ef, 0));
+        CK(hipStreamWaitEvent(q1, ef, 0));
+        hipLaunchKernelGGL(k_fill_walk, dim3(gx, gyp), dim3(256), 0, 0, s.out[0], L, S4, lpbp);
+        hipLaunchKernelGGL(k_fill_walk, dim3(gx, gyp), dim3(256), 0, q1, s.out[1], L, S4, lpbp);
+        CK(hipEventRecord(eb, q1));
+        CK(hipStreamWaitEvent(0, eb, 0));
+    });
+    snprintf(nm, sizeof nm, "[%s] write only, both planes from one kernel (product grid)", tag);
+    run(nm, [&] { hipLaunchKernelGGL((k_mix<0, 2>), dim3(gx, gyp), dim3(256), lds_for(5), 0, s, L, S4, lpbp, sink); });
 }
 
 template <int OUT>
@@ -429,6 +565,90 @@ int main(int argc, char** argv) {
     if (want("geometry")) {
         geometry(sf, "fast pair");
         if (two_levels) geometry(ss, "slow pair");
+    }
+    if (want("burst")) {
+        burst(sf, "fast pair");
+        if (two_levels) burst(ss, "slow pair");
+    }
+    if (want("memtype")) {   // the mask plane in memory of another type: does the pair effect follow the cache policy?
+        for (unsigned fl : {(unsigned)hipDeviceMallocUncached, (unsigned)hipDeviceMallocFinegrained}) {
+            for (int t = 0; t < 3; ++t) {
+                void* p = nullptr;
+                if (hipExtMallocWithFlags(&p, plane + 256, fl) != hipSuccess) { printf("# hipExtMallocWithFlags(%u) failed\n", fl); (void)hipGetLastError(); break; }
+                CK(hipMemset(p, 7, plane));
+                Streams o = s;
+                o.out[0] = (u32x4*)cand[0];
+                o.out[1] = (u32x4*)p;
+                char nm[200];
+                snprintf(nm, sizeof nm, "memtype: plane 0 + %s plane #%d (%p), product shape", fl == hipDeviceMallocUncached ? "UNCACHED" : "FINE-GRAINED", t, p);
+                product_shape(o, nm);
+                o.out[0] = (u32x4*)cand[slow_b];
+                snprintf(nm, sizeof nm, "memtype: plane %d + %s plane #%d, product shape", slow_b, fl == hipDeviceMallocUncached ? "UNCACHED" : "FINE-GRAINED", t);
+                product_shape(o, nm);
+            }
+        }
+    }
+    if (want("uc2")) {   // uncached planes among themselves, as inputs, as the masked-genotype plane; their read rate
+        std::vector<void*> uc;
+        for (int t = 0; t < 6; ++t) {
+            void* p = nullptr;
+            if (hipExtMallocWithFlags(&p, plane + 256, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); break; }
+            CK(hipMemset(p, 7, plane));
+            uc.push_back(p);
+        }
+        const int n = (int)uc.size();
+        printf("# uc2: %d uncached planes; pair matrix (ms), rows = out0, columns = out1, product shape\n", n);
+        for (int i = 0; i < n; ++i) {
+            printf("#  ");
+            for (int j = 0; j < n; ++j) {
+                if (i == j) { printf("   -   "); continue; }
+                Streams o = s;
+                o.out[0] = (u32x4*)uc[i];
+                o.out[1] = (u32x4*)uc[j];
+                printf(" %6.3f", product_shape(o, "", true));
+            }
+            printf("\n");
+        }
+        printf("# uc2: out0 = cached candidate k, out1 = uncached plane 0 / 1\n#  ");
+        for (size_t k = 0; k < cand.size(); ++k) {
+            Streams o = s;
+            o.out[0] = (u32x4*)cand[k];
+            o.out[1] = (u32x4*)uc[0];
+            printf(" %6.3f", product_shape(o, "", true));
+            o.out[1] = (u32x4*)uc[1 % n];
+            printf("/%6.3f", product_shape(o, "", true));
+        }
+        printf("\n# uc2: out0 = uncached plane 0, out1 = cached candidate k\n#  ");
+        for (size_t k = 0; k < cand.size(); ++k) {
+            Streams o = s;
+            o.out[0] = (u32x4*)uc[0];
+            o.out[1] = (u32x4*)cand[k];
+            printf(" %6.3f", product_shape(o, "", true));
+        }
+        printf("\n");
+        if (n >= 5) {
+            char nm[200];
+            Streams o = s;
+            o.out[0] = (u32x4*)uc[0]; o.out[1] = (u32x4*)uc[1];
+            const int lpb = lpb_product(), gy = (L + lpb - 1) / lpb;
+            run("uc2: cached inputs, both outputs uncached, product shape", [&] { hipLaunchKernelGGL((k_walk<0, 0, 0>), dim3(gx, gy), dim3(256), lds_for(5), 0, o, L, S4, lpb); });
+            run("uc2: same, write only", [&] { hipLaunchKernelGGL((k_mix<0, 2>), dim3(gx, gy), dim3(256), lds_for(5), 0, o, L, S4, lpb, sink); });
+            const int ny = std::max(8, 4 * ncu / gx / 8 * 8), lpx = (L + ny - 1) / ny;
+            run("uc2: same, XCD-aware persistent 4 WG/CU", [&] { hipLaunchKernelGGL((k_walk_xcd<0>), dim3(ny * gx), dim3(256), lds_for(4), 0, o, L, S4, lpx, gx); });
+            const unsigned gflat = (unsigned)(((size_t)L * S4 + 255) / 256);
+            run("uc2: same, flat", [&] { hipLaunchKernelGGL((k_flat<0>), dim3(gflat), dim3(256), 0, 0, o, L, S4); });
+            Streams u = o;
+            for (int k = 0; k < 3; ++k) u.in[k] = (const u32x4*)uc[2 + k];
+            run("uc2: UNCACHED inputs too (5 uncached planes), product shape", [&] { hipLaunchKernelGGL((k_walk<0, 0, 0>), dim3(gx, gy), dim3(256), lds_for(5), 0, u, L, S4, lpb); });
+            run("uc2: read only, 3 uncached inputs, product grid", [&] { hipLaunchKernelGGL((k_mix<3, 0>), dim3(gx, gy), dim3(256), lds_for(5), 0, u, L, S4, lpb, sink); });
+            run("uc2: read only, 3 cached inputs, product grid", [&] { hipLaunchKernelGGL((k_mix<3, 0>), dim3(gx, gy), dim3(256), lds_for(5), 0, s, L, S4, lpb, sink); });
+            Streams v = s;
+            v.out[0] = (u32x4*)cand[0]; v.out[1] = (u32x4*)cand[slow_b];
+            v.in[0] = (const u32x4*)uc[2];
+            run("uc2: slow cached pair as outputs, input 0 uncached", [&] { hipLaunchKernelGGL((k_walk<0, 0, 0>), dim3(gx, gy), dim3(256), lds_for(5), 0, v, L, S4, lpb); });
+            (void)nm;
+        }
+        for (void* p : uc) hipFree(p);
     }
     // free every candidate but the two pairs' planes before the big single allocations
     for (size_t k = 1; k < cand.size(); ++k)
