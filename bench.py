@@ -46,6 +46,7 @@ Extras (N = 1 only, each outside the timed region of the headline metric):
   config1         BASELINE configs[1]: statSTR full statistics, 10k loci x 1k samples
   config2         BASELINE configs[2]: dumpSTR, GangSTR shape, nine call + four locus filters, 50k x 5k
   compact_outputs the call-filter pass with the opt-in one-byte mask and no masked-genotype plane (13 B per call)
+  in_place_gt     the call-filter pass with the masked genotypes written into the batch's own tensor (sparse stores)
   end_to_end      statSTR's command line from a bgzipped text VCF to its table; a packed host batch through
                   upload + kernels + download (PCIe included)
   associatr_scan  BASELINE configs[4] on one GPU
@@ -142,10 +143,8 @@ class Workload:
         # (trk_dev_alloc_pair: on this part the pass's two write streams run on one of two levels depending on where the
         # two planes landed; at most two spare planes during the search, TRK_PLACE_OUTPUTS=0: plain allocations)
         self.placement = None
-        # (the placement classes are regions of the device's memory the driver fills in turn: a process whose first
-        # 50 GB are ONE class -- one in four on this pool, profiles/r04_notes.md section 4 -- needs a long step to reach
-        # another; the search's time and transient bytes are in the line: roofline.placement_*)
-        os.environ.setdefault('TRK_PLACE_JUMP_GB', '16,64,150')
+        # (the product's own search, no private settings: at most two spare planes and two 16 GB steps, i.e. never more
+        # than the working set again in transient memory; what it saw and took is in the line: roofline.placement_*)
         co0 = eng.alloc_call_out(b, len(self.filters))
         gt_out, mask = co0.gt_out, co0.filter_mask
         for x in (co0.sample_counters, co0.sample_totaldp, co0.sample_dp_missing, co0.error, co0.sample_totaldp_f64):
@@ -556,6 +555,7 @@ def strong_shard_extra(eng, args, loci, t_full_ms, steps):
                            "output_planes_placed": (wl.placement or {}).get('placed') if wl.placement is not None else
                                                    "not searched (planes below 256 MB: no placement classes to tell apart)",
                            "placement_probe_ms": (wl.placement or {}).get('probe_ms'),
+                           "placement_reserved": (wl.placement or {}).get('reserved'),
                            "placement_peak_extra_bytes": (wl.placement or {}).get('peak_extra_bytes')}
         wl.free()
     out["note"] = ("one GPU, 1-rank RCCL communicator: every kernel and collective launch of a rank of the N-GPU "
@@ -600,6 +600,65 @@ def compact_outputs_extra(wl, iters=8):
            "achieved_GBs": cells * 13 / (ms * 1e-3) / 1e9, "frac": cells * 13 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "checked": "mask bytes of 2048 loci, every sample counter and every allele count equal the 20 B run's"}
     for a in (out.filter_mask8, out.sample_counters, out.sample_totaldp, out.sample_dp_missing, out.error,
+              out.sample_totaldp_f64, st.allele_count, st.locus_int, st.locus_f64):
+        a.free()
+    return res
+
+
+def in_place_extra(wl, iters=6):
+    """The call-filter pass of the headline step with the masked genotypes written IN PLACE (trk_call_out.gt_out ==
+    trk_batch.gt, as dumpSTR.py:721-727 updates its record): 12 B read + the 4 B mask + only the 16-byte chunks that hold
+    a filtered call.  One big write stream: the pass no longer depends on which allocations its two output planes are
+    (profiles/r03_notes.md section 22).  Opt-in; the headline keeps SURVEY.md 8d's two full output planes (20 B)."""
+    eng = wl.eng
+    b = wl.sb.batch
+    i = wl.last
+    gt = b.arrays['gt']
+    keep = eng.empty(gt.shape, gt.dtype)
+    keep.copy_from(gt)
+    ref_rows = 2048
+    ref_mask = wl.call_out.filter_mask.get_rows(0, ref_rows)
+    ref_gt = wl.call_out.gt_out.get_rows(0, ref_rows)
+    ref_counters = wl.call_out.sample_counters.get()
+    out = eng.alloc_call_out(b, len(wl.filters), in_place=True)
+    st = eng.alloc_stats(b)
+    eng.profile(True)
+    try:
+        for it in range(iters + 2):
+            if it == 2:
+                eng.sync()
+                eng.profile_reset()
+            gt.copy_from(keep)
+            for a in (out.sample_counters, out.sample_totaldp, out.sample_dp_missing):
+                a.zero()
+            st.allele_count.copy_from(wl.stats_a[i].allele_count)
+            st.locus_int.copy_from(wl.stats_a[i].locus_int)
+            eng.call_filters(b, wl.planes, wl.filters, dp_plane=0, out=out, delta_stats=st)
+        eng.sync()
+        n, ms = eng.profile_get()['k_call_filter']
+        eng.profile(False)
+        ms /= n
+        got_gt = gt.get_rows(0, ref_rows)
+        assert np.array_equal(got_gt, ref_gt), "in-place genotypes differ from the two-plane run's masked genotypes"
+        assert np.array_equal(out.filter_mask.get_rows(0, ref_rows), ref_mask), "mask differs with in-place genotypes"
+        assert np.array_equal(out.sample_counters.get(), ref_counters), "counters differ with in-place genotypes"
+        assert np.array_equal(st.allele_count.get(), wl.stats_b[i].allele_count.get())
+    finally:
+        gt.copy_from(keep)
+        eng.sync()
+    # chunks (4 calls) that hold a call which is made and filtered: the ones the pass stores
+    filt = ((ref_mask & np.uint32(0x7fffffff)) != 0) & ((ref_mask >> np.uint32(31)) == 0)
+    S4 = filt.shape[1] // 4 * 4
+    touched = float(filt[:, :S4].reshape(filt.shape[0], -1, 4).any(axis=2).mean())
+    bpc = 12 + 4 + 4 * touched
+    cells = wl.n_loci * wl.n_real
+    res = {"workload": "the call-filter pass of the headline step with gt_out == gt (in place): 12 B read, the 4 B mask "
+                       "and %.1f %% of the genotype chunks written" % (100 * touched),
+           "k_call_filter_ms": ms, "bytes_per_cell": round(bpc, 3), "chunks_written_frac": touched,
+           "achieved_GBs": cells * bpc / (ms * 1e-3) / 1e9, "frac": cells * bpc / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "checked": "genotypes and mask words of %d loci, every sample counter and every allele count equal the 20 B run's"
+                      % ref_rows}
+    for a in (keep, out.filter_mask, out.sample_counters, out.sample_totaldp, out.sample_dp_missing, out.error,
               out.sample_totaldp_f64, st.allele_count, st.locus_int, st.locus_f64):
         a.free()
     return res
@@ -1187,9 +1246,13 @@ def main():
                          "placement_jumps": (wl.placement or {}).get('jumps'),
                          "placement_seconds": (wl.placement or {}).get('seconds'),
                          "placement_peak_extra_bytes": (wl.placement or {}).get('peak_extra_bytes'),
-                         "placement_note": "trk_dev_alloc_pair: write-only probe (ms) of the masked-genotype plane with "
-                                           "each candidate mask plane, at most two spare planes; the fastest pair is in "
-                                           "use.  The command lines' outputs go through the same call from 256 MB planes on"},
+                         "placement_reserved": (wl.placement or {}).get('reserved'),
+                         "reservation": type(eng).last_reservation,
+                         "placement_note": "Engine() reserves the pair as the process's first two device allocations "
+                                           "(trk_reserve_pair, the product default: 2 x 4 GiB; 'reservation' = what that "
+                                           "saw) and trk_dev_alloc_pair lends it out (placement_reserved); without a "
+                                           "reservation the call times the masked-genotype plane with each candidate "
+                                           "mask plane (write-only probe, ms), at most two spare planes"},
             "kernels_ms": {k: (v[1] / v[0] if v[0] else None) for k, v in prof.items()},
             "k_locus_count_roofline": {"achieved": cells * BYTES_PER_CELL_COUNT / (avg_cnt * 1e-3) / 1e9 if cn else 0.0,
                                        "unit": "GB/s", "bytes_per_cell": BYTES_PER_CELL_COUNT,
@@ -1223,6 +1286,7 @@ def main():
                 extras["cpu_baseline_c"] = {"error": str(e)[:200]}
         if not args.no_extras:
             extras["compact_outputs"] = compact_outputs_extra(wl)
+            extras["in_place_gt"] = in_place_extra(wl)
             extras["qc_reduce"] = qc_reduce_extra(wl, args.no_check)
             probe = box_stream_probe(eng, wl)
             wl.free()

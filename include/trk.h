@@ -311,7 +311,19 @@ typedef struct {
     int32_t n_jumps;               /* candidates taken behind a spacer (TRK_PLACE_JUMP_GB: sizes in GB, default "16,16") */
     double seconds;                /* host time the call took (allocations + probes)                        */
     uint64_t peak_extra_bytes;     /* freshly allocated beyond the two returned planes, at the peak         */
+    int32_t reserved;              /* 1: the planes are the context's reserved pair (trk_reserve_pair)      */
+    int32_t pad_;
 } trk_pair_info;
+/* RESERVING the pair.  Which level a pair of planes is on follows from where the two allocations lie in the device's
+ * memory -- three classes of regions, a pair inside one class is slow, a pair across two is fast (the 16-plane matrix
+ * in profiles/r05_class_probe.txt) -- and a process's FIRST two allocations lie in two different classes: 8 of 8 fresh
+ * processes at 4 GB planes, against 2 of 8 once 12 GB of inputs had been allocated first (same file).
+ * trk_reserve_pair, called right after trk_init and before any other device allocation, takes two planes of bytes_each
+ * then and there (timed once; if that pair is slow after all, a third plane is tried and the best two stay).  The
+ * context owns them for its lifetime: trk_dev_alloc_pair lends them out whenever both are free and bytes_each fits
+ * (trk_pair_info.reserved = 1) -- a sub-plane lies in its plane's region, so smaller shapes are served alike -- and
+ * trk_dev_free on either pointer hands it back instead of freeing it. */
+int trk_reserve_pair(trk_ctx* ctx, size_t bytes_each, trk_pair_info* info);
 /* have[0 .. n_have): planes of bytes_each the caller already holds (an allocator's pooled buffers): have[0] becomes the
  * first plane, the others are the first candidates for the second; the ones not returned stay the caller's. */
 int trk_dev_alloc_pair(trk_ctx* ctx, size_t bytes_each, int64_t n_loci, int64_t n_samples, int32_t max_spare,
@@ -345,7 +357,12 @@ typedef struct {
 
 typedef struct {
     int16_t* gt_out;          /* [L,S,P] genotypes with filtered calls set to -1
-                                 (dumpSTR.py:721-727); may be NULL                 */
+                                 (dumpSTR.py:721-727); may be NULL.  May be the batch's own
+                                 tensor (gt_out == trk_batch.gt, IN PLACE -- what the reference
+                                 does with its record): every kernel reads a cell before it
+                                 writes it, and the streaming kernels then store only the
+                                 16-byte chunks that hold a filtered call (one big write stream
+                                 instead of two: no pair of output planes to place)           */
     uint32_t* filter_mask;    /* [L,S] bit k = filter k fired, bit 31 = sample was a
                                  no-call (dumpSTR.py:651); 0 == 'PASS'; may be NULL */
     int64_t* sample_counters; /* [(1+nf), S] += : row 0 numcalls (:686-687),

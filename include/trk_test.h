@@ -61,6 +61,16 @@ int trk_synth_fill_gangstr(trk_ctx* ctx, const trk_synth_spec* spec, const int16
                            const int32_t* allele_repcn, float* qexp, int32_t* repcn, int32_t* rc,
                            int32_t* repci);
 
+/* ---- options: forced code paths of the parity tests, A/B switches of tools/ -------------------
+ * The product reads a handful of documented settings from the environment (README.md "Environment") and nothing
+ * else.  Every other switch of the library -- "take the per-call kernel although the streaming one applies", "launch
+ * geometry x", "print the reader's timing" -- is an OPTION by name (the names are the ones the tools have always used:
+ * TRK_CF_GENERIC, TRK_FUSED_STATS, TRK_VCF_PARSE_GENERIC ...): set here, process-wide, value NULL = unset; read by the
+ * library at every launch.  Only the lab build of the library (`make lab`: -DTRK_LAB, trtools_amd/libtrk_lab.so, what
+ * tools/ load through TRK_LIBTRK) also takes options from the environment. */
+int trk_test_set_option(const char* name, const char* value);
+const char* trk_test_get_option(const char* name);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+# the suite forces code paths and compares them: the package's lab knobs are honoured (trtools_amd/_knobs.py); the
+# library's own switches are set through helpers.lab_env / _lib.set_option (include/trk_test.h)
+os.environ.setdefault('TRK_LAB', '1')
 
 
 def pytest_configure(config):

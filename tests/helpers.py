@@ -29,3 +29,29 @@ def close(a, b, rtol=1e-9, atol=1e-12):
     if math.isinf(a) or math.isinf(b):
         return a == b
     return abs(a - b) <= atol + rtol * max(abs(a), abs(b))
+
+
+class lab_env:
+    """``with lab_env(TRK_FMT_FAST='0', ...):`` -- switches for the block, in BOTH places a switch can live: the
+    package's lab knobs (environment, honoured under TRK_LAB=1: tests/conftest.py) and the library's options
+    (include/trk_test.h: trk_test_set_option).  Restored afterwards."""
+
+    def __init__(self, **kv):
+        self.kv = {k: str(v) for k, v in kv.items()}
+
+    def __enter__(self):
+        from trtools_amd import _lib as L
+        self.old_env = {k: os.environ.get(k) for k in self.kv}
+        self.opt = L.options(**self.kv)
+        self.opt.__enter__()
+        os.environ.update(self.kv)
+        return self
+
+    def __exit__(self, *exc):
+        self.opt.__exit__(*exc)
+        for k, v in self.old_env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        return False

@@ -9,7 +9,7 @@ import os
 
 import pytest
 
-from helpers import GOLDEN
+from helpers import GOLDEN, lab_env
 from test_dumpstr_cli import make_args as dump_args
 
 D = os.path.join(GOLDEN, 'data')
@@ -387,18 +387,13 @@ def _dump_variants(tmp_path, name, envs):
     outs = []
     try:
         for i, env in enumerate(envs):
-            for k, v in env.items():
-                os.environ[k] = v
-            try:
+            with lab_env(**env):
                 before = vcfnative.dumpstr_writer_stats()
                 out = str(tmp_path / ('v%d' % i))
                 assert dumpSTR.main(dump_args(out, path, **kw)) == 0
                 after = vcfnative.dumpstr_writer_stats()
                 outs.append((tuple(open(out + ext).read() for ext in ('.vcf', '.samplog.tab', '.loclog.tab')),
                              {k: after[k] - before[k] for k in after}, dumpSTR.LAST_RUN['path']))
-            finally:
-                for k in env:
-                    del os.environ[k]
     finally:
         runtime.set_compute(old)
     return outs
@@ -513,9 +508,7 @@ def test_undecoded_sample_columns_on_rewritten_text(tmp_path, seed, scalar):
     outs, stats = [], []
     try:
         for i, env in enumerate([{}, {'TRK_FMT_FAST': '0'}, {'TRK_DUMPSTR_NATIVE_HEADS': '0'}, {'TRK_FMT_SCALAR': '0'}]):
-            for k, v in env.items():
-                os.environ[k] = v
-            try:
+            with lab_env(**env):
                 before = vcfnative.dumpstr_writer_stats()
                 out = str(tmp_path / ('w%d' % i))
                 assert dumpSTR.main(dump_args(out, vcf, vcftype='hipstr', hipstr_min_call_DP=20, hipstr_max_call_DP=50,
@@ -524,9 +517,6 @@ def test_undecoded_sample_columns_on_rewritten_text(tmp_path, seed, scalar):
                 after = vcfnative.dumpstr_writer_stats()
                 outs.append(open(out + '.vcf').read())
                 stats.append({k: after[k] - before[k] for k in after})
-            finally:
-                for k in env:
-                    del os.environ[k]
     finally:
         runtime.set_compute(old)
     for x, what in ((outs[1], 'decode path'), (outs[2], 'Python heads'), (outs[3], 'general transducer')):

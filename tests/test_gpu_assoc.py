@@ -6,6 +6,8 @@ import sys
 import numpy as np
 import pytest
 
+from trtools_amd import _lib as L
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -185,22 +187,22 @@ def test_designs_beyond_one_pass_of_the_matrix_pipe(eng):
 
 
 def test_wave_parallel_regression_for_narrow_designs_too(eng):
-    os.environ['TRK_AS_WAVE_REGRESS_MIN'] = '2'
+    L.set_option('TRK_AS_WAVE_REGRESS_MIN', '2')
     try:
         assert run_case(eng, 31, 60, 512, M=2, subset=True) > 25
         assert run_case(eng, 32, 40, 640, M=9, subset=True) > 15
     finally:
-        del os.environ['TRK_AS_WAVE_REGRESS_MIN']
+        L.set_option('TRK_AS_WAVE_REGRESS_MIN', None)
 
 
 def test_lds_resident_kernels_for_more_than_two_vectors(eng):
-    os.environ['TRK_AS_MFMA_MIN'] = '99'
+    L.set_option('TRK_AS_MFMA_MIN', '99')
     try:
         assert run_case(eng, 2, 90, 1000, M=4, subset=True) > 40
         assert run_case(eng, 3, 60, 768, M=10, subset=True, cutoff=0.0) > 30
         assert run_case(eng, 4, 40, 4096, M=16, subset=True, miss=0.02) > 20
     finally:
-        del os.environ['TRK_AS_MFMA_MIN']
+        L.set_option('TRK_AS_MFMA_MIN', None)
 
 
 def test_many_alleles_and_rounding(eng):

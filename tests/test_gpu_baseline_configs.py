@@ -20,7 +20,7 @@ import math
 import numpy as np
 import pytest
 
-from helpers import close
+from helpers import close, lab_env
 
 pytestmark = pytest.mark.gpu
 
@@ -215,23 +215,13 @@ def test_config4_associatr_100k_x_10k(eng):
     y = (y - y.mean()) / y.std()
 
     def scan(vec, sample_in=None, env=None):
-        old = {}
-        for k, v in (env or {}).items():
-            old[k] = os.environ.get(k)
-            os.environ[k] = v
-        try:
+        with lab_env(**(env or {})):
             r = eng.assoc_scan(sb.batch, np.ascontiguousarray(vec), alen_d, rcls_d, sample_in=sample_in,
                                non_major_cutoff=20.0)
             out = (r.locus_int.get(), r.locus_f64.get(), r.allele_count.get())
             for d in (r.locus_int, r.locus_f64, r.allele_count):
                 d.free()
             return out
-        finally:
-            for k, v in old.items():
-                if v is None:
-                    del os.environ[k]
-                else:
-                    os.environ[k] = v
 
     li, lf, cnt = scan(y[None, :])
     ok = li[:, TL.AI_STATUS] == TL.AS_OK

@@ -352,14 +352,22 @@ def test_ratio_filters_decide_like_the_float64_division(eng):
     gt = rng.integers(0, 2, size=(Lc, S, 2)).astype(np.int16)
     off, lc, sc, cv = pack_alleles([[2.0, 3.0]] * Lc, [['ACAC', 'ACACAC']] * Lc)
     b = eng.make_batch(gt, off, lc, sc, cv)
-    for thr in (0.15, 0.2, 1.0 / 3.0, 0.0, -0.5, 1.0, 1e-300, 3.0, float('inf'), 0.15000000000000002):
+    # (round 5: the streaming kernel decides by the sign of x - t |d| and divides only inside one ulp above the threshold:
+    # thresholds ON the rounded quotient of a ratio the data is full of, and one ulp either side of it)
+    cases = [(t, 3, 20) for t in (0.15, 0.2, 1.0 / 3.0, 0.0, -0.5, 1.0, 1e-300, 3.0, float('inf'), float('-inf'),
+                                  0.15000000000000002, float('nan'))]
+    for n_, d_ in ((7, 13), (1, 3), (33, 97), (5, 7), (1, 10), (-4, 9), (0, 5)):
+        q = n_ / d_
+        cases += [(q, n_, d_), (float(np.nextafter(q, np.inf)), n_, d_), (float(np.nextafter(q, -np.inf)), n_, d_)]
+    for thr, n_, d_ in cases:
         dp = rng.integers(1, 200, size=(Lc, S)).astype(np.int32)
         num = rng.integers(0, 40, size=(Lc, S)).astype(np.int32)
         # exact ties and near ties of the threshold
         k = rng.integers(1, 9, size=(Lc, S))
+        k[rng.random((Lc, S)) < 0.2] *= -1               # (-n) / (-d): the same quotient through a negative depth
         tie = rng.random((Lc, S)) < 0.3
-        dp[tie] = (20 * k)[tie]
-        num[tie] = (3 * k)[tie]
+        dp[tie] = (d_ * k)[tie]
+        num[tie] = (n_ * k)[tie]
         dp[rng.random((Lc, S)) < 0.02] = 0
         dp[rng.random((Lc, S)) < 0.02] = INT_MIN
         num[rng.random((Lc, S)) < 0.02] = INT_MIN
@@ -370,7 +378,7 @@ def test_ratio_filters_decide_like_the_float64_division(eng):
         filters = [dict(op=L.F_RATIO_GT, plane_a=1, plane_b=0, thr=thr), dict(op=L.F_LT, plane_a=0, thr=-1e9)]
         res = eng.call_filters(b, [eng.upload(dp), eng.upload(num)], filters, dp_plane=0)
         got = (res.filter_mask.get() & np.uint32(1)).astype(bool)
-        assert np.array_equal(got, want), thr
+        assert np.array_equal(got, want), (thr, n_, d_)
 
 
 @pytest.mark.parametrize("max_alt,S", [(130, 512), (900, 256), (3000, 64)])
@@ -441,6 +449,53 @@ def test_compact_mask_output(eng, n_samples, n_filters):
     assert np.array_equal(st2.locus_int.get()[..., :6], st.locus_int.get()[..., :6])
 
 
+@pytest.mark.parametrize("shape", ["hipstr3", "hipstr5", "gangstr", "percall"])
+def test_in_place_masked_genotypes(eng, shape):
+    """gt_out == trk_batch.gt: the genotype tensor is updated where it lies (the reference sets the filtered calls of
+    its record to no-call, dumpSTR.py:721-727).  The streaming kernels store only the chunks that hold a filtered call;
+    every cell, the mask, the counters and the delta counts equal the two-plane run's -- at every locus."""
+    from trtools_amd import _lib as L
+    from trtools_amd.synth import SynthBatch
+    S = 1003 if shape == "percall" else 2052
+    n_loci = 300
+    if shape == "gangstr":
+        sb = SynthBatch(eng, n_loci, S, seed=5, planes=('dp', 'q'), pure_repeats=True)
+        sb.add_gangstr_planes()
+        planes = [eng.planarize(sb.dev[n]) for n in ('dp', 'q', 'qexp', 'rc', 'repcn', 'repci')]
+        filters = [dict(op=L.F_LT, plane_a=0, thr=12), dict(op=L.F_GT, plane_a=0, thr=55), dict(op=L.F_LT, plane_a=1, thr=0.9),
+                   dict(op=L.F_CALLED_LT, plane_a=2, col_a=1, thr=0.05), dict(op=L.F_CALLED_EQ, plane_a=3, col_a=1, plane_b=0, col_b=0),
+                   dict(op=L.F_CALLED_OUTSIDE_CI, plane_a=4, plane_b=5)]
+    else:
+        sb = SynthBatch(eng, n_loci, S, seed=5, planes=('dp', 'q', 'dstutter', 'dflankindel'))
+        planes = [sb.dev['dp'], sb.dev['q'], sb.dev['dstutter'], sb.dev['dflankindel']]
+        filters = [dict(op=L.F_LT, plane_a=0, thr=12), dict(op=L.F_GT, plane_a=0, thr=55), dict(op=L.F_LT, plane_a=1, thr=0.9)]
+        if shape == "hipstr5":
+            filters += [dict(op=L.F_RATIO_GT, plane_a=2, plane_b=0, thr=0.12), dict(op=L.F_RATIO_GT, plane_a=3, plane_b=0, thr=0.08)]
+    st = eng.locus_stats(sb.batch, count_only=True)
+    two = eng.call_filters(sb.batch, planes, filters, dp_plane=0, out=eng.alloc_call_out(sb.batch, len(filters), place=False),
+                           delta_stats=st)
+    want_gt, want_mask = two.gt_out.get(), two.filter_mask.get()
+    before = sb.batch.arrays['gt'].get()
+    assert (want_gt != before).any()
+    st2 = eng.locus_stats(sb.batch, count_only=True)
+    out = eng.alloc_call_out(sb.batch, len(filters), in_place=True)
+    assert out.gt_out.ptr == sb.batch.arrays['gt'].ptr
+    eng.call_filters(sb.batch, planes, filters, dp_plane=0, out=out, delta_stats=st2)
+    assert np.array_equal(sb.batch.arrays['gt'].get(), want_gt)
+    assert np.array_equal(out.filter_mask.get(), want_mask)
+    assert np.array_equal(out.sample_counters.get(), two.sample_counters.get())
+    assert np.array_equal(out.sample_totaldp.get(), two.sample_totaldp.get())
+    assert np.array_equal(st2.allele_count.get(), st.allele_count.get())
+    assert np.array_equal(st2.locus_int.get()[..., :6], st.locus_int.get()[..., :6])
+    # the counts of the updated tensor are the delta-corrected counts (dumpSTR.py:748-774 rebuilds its record)
+    recount = eng.locus_stats(sb.batch, count_only=True)
+    assert np.array_equal(recount.allele_count.get(), st2.allele_count.get())
+    # a second pass over the updated tensor filters nothing further among the calls that are left
+    out3 = eng.alloc_call_out(sb.batch, len(filters), in_place=True)
+    eng.call_filters(sb.batch, planes, filters, dp_plane=0, out=out3)
+    assert np.array_equal(sb.batch.arrays['gt'].get(), want_gt)
+
+
 def test_placed_output_planes_hold_the_same_results(eng):
     """Engine.alloc_call_out from 256 MB planes on (trk_dev_alloc_pair): the second big output plane is the best of at
     most three candidates (write-only probe of the pass's stream shape with the first plane), at most two spare planes
@@ -465,6 +520,43 @@ def test_placed_output_planes_hold_the_same_results(eng):
     assert np.array_equal(tuned.gt_out.get(), plain.gt_out.get())
     assert np.array_equal(tuned.filter_mask.get(), plain.filter_mask.get())
     assert np.array_equal(tuned.sample_counters.get(), plain.sample_counters.get())
+
+
+def test_reserved_pair_is_lent_and_handed_back():
+    """trk_reserve_pair (Engine(reserve_pair_gb=...)): the context takes the two output planes as its first device
+    allocations and trk_dev_alloc_pair lends them to whoever asks for a pair that fits; a freed plane goes back to the
+    context (not to the driver, not to the engine's pool), a second pair while the first is out is searched as before;
+    the pass writes into the lent planes what it writes into plain ones."""
+    from trtools_amd import _lib as L
+    from trtools_amd.engine import Engine
+    from trtools_amd.synth import SynthBatch
+    e2 = Engine(0, reserve_pair_gb=0.375)
+    try:
+        assert e2.reserved_pair_bytes == 384 << 20 and Engine.last_reservation['plane_bytes'] == 384 << 20
+        assert len(Engine.last_reservation['probe_ms']) in (1, 3)
+        sb = SynthBatch(e2, 8192, 8192, seed=11, planes=('dp', 'q'))
+        planes = [sb.dev['dp'], sb.dev['q']]
+        filters = [dict(op=L.F_LT, plane_a=0, thr=10), dict(op=L.F_GT, plane_a=0, thr=55), dict(op=L.F_LT, plane_a=1, thr=0.9)]
+        plain = e2.call_filters(sb.batch, planes, filters, dp_plane=0, out=e2.alloc_call_out(sb.batch, len(filters), place=False))
+        out = e2.alloc_call_out(sb.batch, len(filters))
+        assert Engine.last_placement['reserved'] and len(Engine.last_placement['probe_ms']) == 1
+        ptrs = (out.gt_out.ptr, out.filter_mask.ptr)
+        lent = e2.call_filters(sb.batch, planes, filters, dp_plane=0, out=out)
+        assert np.array_equal(lent.gt_out.get(), plain.gt_out.get())
+        assert np.array_equal(lent.filter_mask.get(), plain.filter_mask.get())
+        other = e2.alloc_call_out(sb.batch, len(filters))          # the pair is out: a searched pair
+        assert not Engine.last_placement['reserved'] and other.gt_out.ptr not in ptrs
+        pool_before = e2._pool_bytes
+        out.gt_out.free()
+        out.filter_mask.free()
+        assert e2._pool_bytes == pool_before                       # handed back to the context, not pooled
+        again = e2.alloc_call_out(sb.batch, len(filters))
+        assert Engine.last_placement['reserved'] and (again.gt_out.ptr, again.filter_mask.ptr) == ptrs
+        small = SynthBatch(e2, 64, 512, seed=3, planes=('dp', 'q'))  # below 256 MB: plain allocations, pair untouched
+        o3 = e2.alloc_call_out(small.batch, 3)
+        assert o3.gt_out.ptr not in ptrs
+    finally:
+        e2.close()
 
 
 @pytest.mark.parametrize("seed", range(12))
@@ -498,7 +590,7 @@ def test_streaming_kernel_equals_the_per_call_kernel_on_random_filter_sets(eng, 
     outs = []
     for generic in (False, True):
         if generic:
-            os.environ['TRK_CF_GENERIC'] = '1'
+            L.set_option('TRK_CF_GENERIC', '1')
         try:
             st = eng.locus_stats(sb.batch, count_only=True) if seed % 3 else None
             res = eng.call_filters(sb.batch, planes, filters, dp_plane=0 if use_dp else -1,
@@ -507,7 +599,7 @@ def test_streaming_kernel_equals_the_per_call_kernel_on_random_filter_sets(eng, 
                          res.sample_dp_missing.get(), res.error.get()[0] != 0,
                          None if st is None else (st.allele_count.get(), st.locus_int.get()[..., :6])))
         finally:
-            os.environ.pop('TRK_CF_GENERIC', None)
+            L.set_option('TRK_CF_GENERIC', None)
     a, b = outs
     assert a[5] == b[5]
     if a[5]:

@@ -8,6 +8,8 @@ import os
 import numpy as np
 import pytest
 
+from helpers import lab_env
+
 pytestmark = pytest.mark.gpu
 
 
@@ -24,11 +26,8 @@ def _fetch(res):
 
 
 def _both(eng, b, thresh):
-    os.environ['TRK_FUSED_STATS'] = '0'
-    try:
+    with lab_env(TRK_FUSED_STATS='0'):
         chain = _fetch(eng.locus_stats(b, nalleles_thresh=thresh))
-    finally:
-        del os.environ['TRK_FUSED_STATS']
     fused = _fetch(eng.locus_stats(b, nalleles_thresh=thresh))
     return chain, fused
 
@@ -99,11 +98,8 @@ def test_large_batches_and_the_limit_knob(eng):
     sb = SynthBatch(eng, 40000, 256, seed=3, planes=())
     chain, fused = _both(eng, sb.batch, 0.01)
     _same(chain, fused)
-    os.environ['TRK_FUSED_STATS'] = '1000'
-    try:
+    with lab_env(TRK_FUSED_STATS='1000'):
         capped = _fetch(eng.locus_stats(sb.batch))
-    finally:
-        del os.environ['TRK_FUSED_STATS']
     _same(chain, capped)
 
 
@@ -124,14 +120,8 @@ def test_cooperative_finaliser_equals_the_one_thread_finaliser(eng, ploidy, n_gr
             gb |= (rng.random(S) < 0.4).astype(np.uint8) << g
     b = eng.make_batch(gt, off, lc, sc, cv, locus_ploidy=lp if ploidy != 2 else None, group_bits=gb,
                        n_groups=max(n_groups, 1))
-    os.environ['TRK_FUSED_STATS'] = '0'
-    try:
-        os.environ['TRK_FIN_COOP'] = '0'
-        try:
+    with lab_env(TRK_FUSED_STATS='0'):
+        with lab_env(TRK_FIN_COOP='0'):
             one = _fetch(eng.locus_stats(b, nalleles_thresh=0.03))
-        finally:
-            del os.environ['TRK_FIN_COOP']
         coop = _fetch(eng.locus_stats(b, nalleles_thresh=0.03))
-    finally:
-        del os.environ['TRK_FUSED_STATS']
     _same(one, coop)

@@ -284,11 +284,11 @@ def test_loci_per_wave_variants_agree(eng, S):
     b = eng.make_batch(gt, off, lc, sc, cv)
     got = {}
     for rr in ('1', '2', '4'):
-        os.environ['TRK_CNT_R'] = rr
+        L.set_option('TRK_CNT_R', rr)
         try:
             got[rr] = _fetch(eng.locus_stats(b, nalleles_thresh=0.02))
         finally:
-            del os.environ['TRK_CNT_R']
+            L.set_option('TRK_CNT_R', None)
     check_against_oracle(orc, L, *got['1'], off, gt, lens, strs, [None], 0.02)
     for rr in ('2', '4'):
         assert np.array_equal(got[rr][0], got['1'][0]), rr
@@ -381,11 +381,11 @@ def test_sample_groups_on_the_streaming_kernel(eng, n_groups, S, layout):
         assert np.all(li[g][:, L.LI_N_SAMPLES] == int(groups[g].sum()))
     # the per-call kernel (TRK_CNT_NOGROUPFAST) gives the same integers
     import os
-    os.environ['TRK_CNT_NOGROUPFAST'] = '1'
+    L.set_option('TRK_CNT_NOGROUPFAST', '1')
     try:
         ref = eng.locus_stats(b, nalleles_thresh=0.05)
     finally:
-        del os.environ['TRK_CNT_NOGROUPFAST']
+        L.set_option('TRK_CNT_NOGROUPFAST', None)
     cols = [L.LI_N_CALLED, L.LI_N_LOWPLOIDY, L.LI_N_HOM_LEN, L.LI_N_HOM_STR, L.LI_N_SAMPLES]
     assert np.array_equal(ref.allele_count.get(), res.allele_count.get())
     assert np.array_equal(ref.locus_int.get()[:, :, cols], res.locus_int.get()[:, :, cols])

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from helpers import GOLDEN
+from trtools_amd import _lib as L_
 
 D = os.path.join(GOLDEN, 'data')
 FILES = [os.path.join(D, 'many_samples.vcf.gz')] + sorted(glob.glob(os.path.join(D, 'dumpSTR', '*.sorted.vcf.gz'))) + \
@@ -432,7 +433,7 @@ def test_fast_sample_scan_on_every_spelling(tmp_path):
 
     def arrays(generic):
         if generic:
-            os.environ['TRK_VCF_PARSE_GENERIC'] = '1'
+            L_.set_option('TRK_VCF_PARSE_GENERIC', '1')
         try:
             out = []
             for P in (2, 3):
@@ -446,7 +447,7 @@ def test_fast_sample_scan_on_every_spelling(tmp_path):
                     out.append(('error', type(e).__name__, str(e)))
             return out
         finally:
-            os.environ.pop('TRK_VCF_PARSE_GENERIC', None)
+            L_.set_option('TRK_VCF_PARSE_GENERIC', None)
     a, b = arrays(False), arrays(True)
     assert len(a) == len(b) and len(a) > 20
     for x, y in zip(a, b):

@@ -1,4 +1,5 @@
 #!/bin/bash
+export TRK_LAB=1   # tools are lab runs: lab knobs are honoured (trtools_amd/_knobs.py)
 # A/B of two library builds on ONE GPU box (box-to-box variance is +-5 %): build the variant next to the product
 # library, e.g.
 #   hipcc ... -DTRK_V2_WRED=0 -c trk_kernels.hip -o /tmp/k.o && hipcc -shared ... -o trtools_amd/libtrk_w0.so

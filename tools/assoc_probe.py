@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Ad-hoc timing of the associaTR scan on the GPU box (not the bench contract):
 100k loci x 10k samples (BASELINE configs[4] shape), M = 1 outcome + covariates."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,4 +1,5 @@
 #!/bin/bash
+export TRK_LAB=1   # tools are lab runs: lab knobs are honoured (trtools_amd/_knobs.py)
 # per-kernel durations of the associaTR scan (tools/assoc_probe.py) under rocprofv3; usage: assoc_profile.sh "15,31"
 repo=$(cd "$(dirname "$0")/.." && pwd)
 out=$repo/gpurun_out/r03/assoc_prof

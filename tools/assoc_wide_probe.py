@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Timing of trk_assoc_scan for growing designs on the GPU box (100k loci x 10k samples resident): one pass up to
 31 trait columns, pairs of 15-row groups above (TRK_ASSOC_MAX_VEC_WIDE)."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

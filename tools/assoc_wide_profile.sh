@@ -1,4 +1,5 @@
 #!/bin/bash
+export TRK_LAB=1   # tools are lab runs: lab knobs are honoured (trtools_amd/_knobs.py)
 # per-kernel durations of tools/assoc_wide_probe.py under rocprofv3; usage: assoc_wide_profile.sh 32 62
 repo=$(cd "$(dirname "$0")/.." && pwd)
 out=$repo/gpurun_out/r03/assoc_wide_prof

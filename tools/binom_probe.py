@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Kernel time of the exact binomial test on the device, one lane per test against the lane pair, by input class
 (run under rocprofv3 --kernel-trace; tools/binom_probe.py prints the call order, the trace holds the durations)."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -6,6 +6,7 @@ Settings are environment assignments the dispatch reads at every launch (TRK_CF_
 TRK_CF_NO_PERSIST / TRK_V2_MODE), given as comma-separated groups:
     python tools/cf_geometry_probe.py "TRK_CF_MAP=0,TRK_CF_NO_PERSIST=1" "TRK_CF_MAP=2,TRK_CF_WGCU=3" ...
 --check: every locus of the step against the compiled oracle under the FIRST and the LAST setting."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ['TRK_PLACE_OUTPUTS'] = '0'

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """cProfile of the statSTR command line on the synthetic file of tools/e2e_probe.py (host-side hot spots)."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import argparse, cProfile, os, pstats, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser()

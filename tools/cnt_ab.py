@@ -1,5 +1,6 @@
 """k_locus_count on three shapes (100k x 10k, 12.5k x 10k, 400k x 1k at 1 and 4 loci per wave); run once per build with
 TRK_LIBTRK=<other libtrk.so> for a same-box A/B.  `gpurun -- python tools/cnt_ab.py`."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import os, sys
 sys.path.insert(0, '/root/repo')
 import numpy as np

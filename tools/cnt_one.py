@@ -1,5 +1,6 @@
 """k_locus_count on one shape: `python tools/cnt_one.py [loci samples]` (TRK_CNT_U / TRK_CNT_R / TRK_LIBTRK select
 variants); also the command tools/sq_counters.sh wraps for the count kernel's instruction counters."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from trtools_amd.engine import Engine

@@ -2,6 +2,7 @@
 """BASELINE configs[0]: statSTR --afreq --het --mean on the real trio HipSTR file (9532 loci x 3 samples), and dumpSTR
 with the HipSTR call filters + four locus filters on the same file, end to end through the CLIs.  The reference's
 own time for the statSTR command in the build container was 3.93 s."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 vcf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'data', 'dumpSTR',

@@ -1,3 +1,4 @@
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import sys; sys.path.insert(0,'/root/repo')
 import bench, json
 from trtools_amd.engine import Engine

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Timing of BASELINE configs[1] (statSTR, 10k x 1k) and configs[2] (dumpSTR, GangSTR shape, 50k x 5k, nine call
 filters + four locus filters) on the GPU box, inputs resident; kernel times from the library's HIP-event brackets."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

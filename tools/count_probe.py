@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """k_locus_count across row lengths x loci-per-wave (TRK_CNT_R) x loads in flight (TRK_CNT_U), inputs resident;
 kernel time from the library's HIP-event brackets.  `gpurun -- python tools/count_probe.py`."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import copy, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

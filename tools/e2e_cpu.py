@@ -1,5 +1,6 @@
 """Wall and CPU seconds (user + sys, all threads) of the two 1 GB command lines per reader / formatter thread count.
 usage: e2e_cpu.py file.vcf.gz [threads ...]"""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import argparse, os, resource, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from trtools_amd.statSTR import statSTR

@@ -1,6 +1,7 @@
 """statSTR's 1 GB command line with the sample columns parsed on the host (default) and on the device
 (TRK_DEVICE_PARSE=1): wall / CPU seconds, best of three, and the two tables compared.
 usage: e2e_device_parse.py /tmp/e2e/synth_17000x5000.vcf.gz"""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import argparse, hashlib, os, resource, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from trtools_amd.statSTR import statSTR

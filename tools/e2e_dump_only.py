@@ -1,4 +1,5 @@
 """dumpSTR's command line on the file tools/e2e_probe.py generated (/tmp/e2e), three runs: seconds and phases."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from trtools_amd.dumpSTR import dumpSTR

@@ -1,5 +1,6 @@
 """Per-batch seconds and minor page faults of the reader's and the record writer's native calls in one dumpSTR run of
 tools/e2e_dump_only.py's command line (who re-faults 150 MB every other batch?)."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import os, sys, time, resource, glob
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from trtools_amd import vcfnative

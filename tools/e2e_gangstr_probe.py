@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configs[2] end to end through text at reduced scale: a synthetic GangSTR VCF (GT:DP:Q:REPCN:REPCI:RC:QEXP)
 -> native reader (RC / REPCI pre-parsed) -> packed batch -> GPU (nine call filters, four locus filters) -> output VCF."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

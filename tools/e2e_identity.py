@@ -2,6 +2,7 @@
 file: byte for byte (VERDICT r03 item 2's closing criterion).  The per-record loop takes a minute per GB; the file
 is tools/e2e_probe.py's, cut to --loci records so that the slow side stays bounded.
 usage: e2e_identity.py /tmp/e2e/synth_17000x5000.vcf.gz [--loci 3000]"""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import argparse, hashlib, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ap = argparse.ArgumentParser()

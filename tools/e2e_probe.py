@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end probe: text VCF -> native reader -> packed batch -> GPU -> statSTR table.
 Generates a synthetic HipSTR-shape bgzip VCF (GT:DP:Q), then times the readers and the CLI."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

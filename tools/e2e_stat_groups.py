@@ -1,6 +1,7 @@
 """statSTR --samples a,b on the file tools/e2e_probe.py generated: the class-ordered columns the reader lays out while
 parsing (default) against the grouped kernel on file-order columns (TRK_CLASS_SORT=0): wall time, count-kernel time,
 and the two tables must be equal."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,5 +1,6 @@
 """statSTR's command line on the file tools/e2e_probe.py generated: wall time of three runs, then one run with the
 reader's per-batch timing (TRK_VCF_TIMING) and a cProfile of the Python side."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from trtools_amd.statSTR import statSTR

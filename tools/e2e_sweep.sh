@@ -1,4 +1,5 @@
 #!/bin/bash
+export TRK_LAB=1   # tools are lab runs: lab knobs are honoured (trtools_amd/_knobs.py)
 # Host-side knobs of the 1 GB end-to-end runs (tools/e2e_dump_only.py, e2e_stat_only.py) on the GPU box: reader threads,
 # formatter threads, read-ahead.  usage: tools/e2e_sweep.sh  (writes gpurun_out/e2e_sweep.txt)
 cd "$(dirname "$0")/.."

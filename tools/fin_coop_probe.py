@@ -1,5 +1,6 @@
 """The finaliser after the count pass of a big batch: sixteen lanes per locus (k_locus_finalize_coop) against one
 thread per locus (TRK_FIN_COOP=0); HIP-event brackets of the library."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from trtools_amd.engine import Engine

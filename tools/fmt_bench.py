@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Record serialiser microbenchmark (trk_vcf_format_samples): one S-sample record, columns GT / +DP / +Q; run with
 TRK_FMT_THREADS=1 for the serial path."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import sys, time, numpy as np, ctypes, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from trtools_amd import vcfio

@@ -1,5 +1,6 @@
 """statSTR pass, fused (count + finaliser in one launch, HWE slots) against the chain, at several batch sizes.
 TRK_FUSED_STATS=<max loci> moves the limit of the fused pass (0: never)."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -15,6 +15,7 @@ Each case is written twice: ``<case>.tsv`` with the reference's default text pre
 ``<case>.precise.tsv`` with allele_len_precision=10 / pval_precision=15 (the reference tests
 raise the precisions in the same way).
 """
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import argparse
 import contextlib
 import io

@@ -2,6 +2,7 @@
 synthetic VCFs (text rendering of trtools_amd.synth).  For every case the input VCF and the
 reference's three outputs (.vcf through this repo's VCF writer, .samplog.tab, .loclog.tab)
 are stored under tests/golden/dumpstr_synth/."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import argparse
 import os
 import sys

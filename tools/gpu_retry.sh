@@ -1,4 +1,5 @@
 #!/bin/bash
+export TRK_LAB=1   # tools are lab runs: lab knobs are honoured (trtools_amd/_knobs.py)
 # gpurun with retries while the pool is busy (exit code 3 / status transient: nothing charged).
 # usage: tools/gpu_retry.sh <timeout-seconds> '<command>'
 T=$1; shift

@@ -2,6 +2,7 @@
 """statSTR --samples a,b (sample groups, SURVEY 8d "stratified variant") at 100k x 10k: time of the count and
 finalise kernels with G = 1, 2, 3 group masks (2: disjoint 40 % / 60 %; 3: the reference's layout for two sample
 lists = the two lists plus everything)."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Experiment: the headline step on one GPU as two 50k-locus halves run alternately (count pass of one half beside the
 call filters of the other), against one 100k-locus pass.  Not the bench contract."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench

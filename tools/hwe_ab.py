@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """configs[1] (statSTR 10k x 1k) finaliser + HWE test time; run once with TRK_HWE_SERIAL=1 and once without."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from trtools_amd.engine import Engine

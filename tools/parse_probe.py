@@ -2,6 +2,7 @@
 """trk_parse_samples on the 1 GB probe file (tools/e2e_probe.py): per batch of the native reader the batch's text goes
 to the device, the kernel is timed with HIP events, its arrays are compared with the reader's for the whole batch.
 usage: parse_probe.py /tmp/e2e/synth_17000x5000.vcf.gz [--planes DP Q] [--iters 5]"""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))

@@ -2,6 +2,7 @@
 """Are the 'classes' of the output-plane pair effect (r03_notes section 22) large contiguous regions of the device's
 address space?  Planes of 4 GB with GAP GB of untouched spacer between them (the driver hands memory out in order), the
 bare 3-in / 2-out stream over every pair: a block structure in the matrix would say yes."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,6 +1,7 @@
 """Does the bare call-filter stream depend on WHICH allocation the planes landed in?  One process: five 4 GB planes
 allocated, probed, then (mode free) freed and allocated again or (mode keep) kept while the next set is allocated.
 TRK_POOL_GB=0 so that a free really returns the memory."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import os, sys
 os.environ['TRK_POOL_GB'] = '0'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

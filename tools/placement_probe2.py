@@ -1,5 +1,6 @@
 """Which planes' placement decides the bare stream's time?  (a) inputs fixed, outputs re-allocated; (b) outputs fixed,
 inputs re-allocated; with each allocation's memset time (a write-only stream over it) beside the probe."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import os, sys
 os.environ['TRK_POOL_GB'] = '0'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

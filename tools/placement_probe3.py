@@ -1,4 +1,5 @@
 """Is the slow level a property of ONE output plane or of the PAIR?  Six planes, every ordered pair as (gt_out, mask)."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import os, sys
 os.environ['TRK_POOL_GB'] = '0'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,7 @@
 """A slow and a fast pair of output planes; the mask plane moved SKEW bytes into its (larger) allocation: which skews
 turn a slow pair fast, which a fast pair slow?  (The period and the width of the bad window of whatever the two
 lock-step write streams collide on.)"""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import os, sys
 os.environ['TRK_POOL_GB'] = '0'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,7 @@
 """After another process has just released its memory, do fresh allocations all land in one class -- and does a large
 spacer allocation move the next ones elsewhere?  Planes allocated one at a time; for each, its probe time paired with
 every earlier plane ('s' = slow pair, 'f' = fast pair); after plane 5 a spacer of SPACER_GB is allocated and held."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import os, sys
 os.environ['TRK_POOL_GB'] = '0'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

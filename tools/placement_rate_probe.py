@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """How often does trk_dev_alloc_pair end on the fast level?  One fresh process per trial (the driver's allocation state
 is per process): three 4 GB input planes as the bench holds them, then the placed pair; prints trk_pair_info."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import os, subprocess, sys
 if len(sys.argv) > 1 and sys.argv[1] == 'child':
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

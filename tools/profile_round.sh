@@ -1,4 +1,5 @@
 #!/bin/bash
+export TRK_LAB=1   # tools are lab runs: lab knobs are honoured (trtools_amd/_knobs.py)
 # The rocprofv3 passes behind profiles/<tag>_*: kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in their own runs
 # (never combined with another trace domain), around (a) the bench command -- headline step + the associaTR extra --
 # (b) tools/config_probe.py (BASELINE configs[1] and configs[2], HipSTR five-filter set) and (c) tools/qc_probe.py.  Run on the GPU box:

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Timing of trk_qc_reduce (qcSTR's reductions) on the GPU box: 100k loci x 10k samples, genotypes + quality plane
 resident (8 B per call)."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,4 +1,5 @@
 #!/bin/bash
+export TRK_LAB=1   # tools are lab runs: lab knobs are honoured (trtools_amd/_knobs.py)
 # The native reader / writer tests under AddressSanitizer + UBSan, then under ThreadSanitizer.
 #   tools/sanitize_tests.sh [asan|tsan|both]      (default both; CPU only, ~10 min)
 # Builds trtools_amd/libtrk_{asan,tsan}.so (csrc/Makefile), preloads the sanitizer runtime into python and points

@@ -1,4 +1,5 @@
 #!/bin/bash
+export TRK_LAB=1   # tools are lab runs: lab knobs are honoured (trtools_amd/_knobs.py)
 # Kernels of libtrk.so that use scratch memory, per translation unit, from the compiler's own resource remarks
 # (`-Rpass-analysis=kernel-resource-usage`): name, VGPRs, scratch bytes per lane.  Run from anywhere; no GPU needed.
 cd "$(dirname "$0")/../trtools_amd/csrc" || exit 1

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The strong-scaling shard regime on one GPU: the bench step at --loci loci under launch-geometry knobs
 (TRK_CF_LPB ...), kernel times from the library's HIP-event brackets.  `gpurun -- python tools/shard_probe.py`."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

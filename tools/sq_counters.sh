@@ -1,4 +1,5 @@
 #!/bin/bash
+export TRK_LAB=1   # tools are lab runs: lab knobs are honoured (trtools_amd/_knobs.py)
 # SQ instruction-mix counters of every kernel of a command (one rocprofv3 --pmc pass per counter group; no other
 # trace domains).  usage: tools/sq_counters.sh <out.txt> <command...>
 out=$1; shift

@@ -1,4 +1,5 @@
 #!/bin/bash
+export TRK_LAB=1   # tools are lab runs: lab knobs are honoured (trtools_amd/_knobs.py)
 # what the GPU box lets a process see about the placement of its device memory (round 5: the output-pair effect)
 echo "== debugfs"; ls /sys/kernel/debug 2>&1 | head; mount | grep -i debug
 ls /sys/kernel/debug/dri 2>&1 | head

@@ -2,6 +2,7 @@
 """Kernel timeline of the 12.5k-locus shard step (what one of eight ranks runs): `rocprofv3 --kernel-trace -d DIR --
 python tools/timeline_probe.py run`, then `python tools/timeline_probe.py show DIR` prints, for the last steps, every
 kernel's start / end relative to the step's call-filter kernel and the idle gap of the call-filter queue."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import glob, os, sqlite3, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if sys.argv[1] == 'run':

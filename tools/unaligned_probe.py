@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Cohort sizes that are not a multiple of four samples (rows not 16-byte aligned): time of the statSTR pass, the dumpSTR
 call-filter pass and the one-trait association scan at S = 10000 vs S = 9999 / 10001 / 10002."""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

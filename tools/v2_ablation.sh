@@ -1,4 +1,5 @@
 #!/bin/bash
+export TRK_LAB=1   # tools are lab runs: lab knobs are honoured (trtools_amd/_knobs.py)
 # Timing-only ablation builds of the call-filter kernel (-DTRK_V2_ABL=<bits>, see trk_kernels.hip), built here (no GPU
 # needed) into trtools_amd/abl/; `gpurun -- bash tools/v2_ablation.sh run` times each on the headline step.
 cd "$(dirname "$0")/.."

@@ -2,6 +2,7 @@
 """Same-box A/B of the call-filter kernel's build variants on the headline step (bench.Workload):
 TRK_V2_MODE values given on the command line (the dispatch reads the variable at every launch), alternating rounds.
 usage: python tools/v2_mode_probe.py [--loci L] [--rounds R] mode [mode ...]"""
+import os as _os; _os.environ.setdefault('TRK_LAB', '1')   # a tool: lab knobs are honoured (trtools_amd/_knobs.py)
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,5 +1,6 @@
 """ctypes binding of libtrk.so (include/trk.h).  No torch, no fallback: if the
 HIP library is missing or no MI355X is visible this module raises."""
+from . import _knobs
 import ctypes as C
 import os
 
@@ -161,7 +162,7 @@ class PairInfo(C.Structure):
     _fields_ = [('n_probed', C.c_int32), ('placed', C.c_int32), ('probe_ms', C.c_float * PAIR_MAX_PROBES),
                 ('kept_ms', C.c_float), ('have_a', C.c_int32), ('have_b', C.c_int32), ('n_jumps', C.c_int32),
                 ('seconds', C.c_double),
-                ('peak_extra_bytes', C.c_uint64)]
+                ('peak_extra_bytes', C.c_uint64), ('reserved', C.c_int32), ('pad_', C.c_int32)]
 
 
 class SynthSpec(C.Structure):
@@ -173,12 +174,12 @@ class SynthSpec(C.Structure):
 # every symbol include/trk.h and include/trk_test.h declare (tests check that the library exports them)
 EXPORTS = [
     'trk_init', 'trk_free', 'trk_last_error', 'trk_backend', 'trk_device_count', 'trk_device_info',
-    'trk_dev_alloc', 'trk_dev_alloc_pair', 'trk_dev_free', 'trk_memcpy_h2d', 'trk_memcpy_d2h', 'trk_memcpy_d2d', 'trk_memset', 'trk_sync',
+    'trk_dev_alloc', 'trk_dev_alloc_pair', 'trk_reserve_pair', 'trk_dev_free', 'trk_memcpy_h2d', 'trk_memcpy_d2h', 'trk_memcpy_d2d', 'trk_memset', 'trk_sync',
     'trk_timer_start', 'trk_timer_stop', 'trk_timer_elapsed_ms',
     'trk_profile_enable', 'trk_profile_get', 'trk_profile_reset',
     'trk_locus_stats', 'trk_locus_finalize', 'trk_call_filters', 'trk_locus_filters',
     'trk_comm_unique_id', 'trk_comm_init', 'trk_allreduce_sum_i64', 'trk_allgather',
-    'trk_binomtest_two_sided', 'trk_binom_pmf', 'trk_binomtest_batch', 'trk_synth_fill', 'trk_synth_fill_gangstr',
+    'trk_binomtest_two_sided', 'trk_binom_pmf', 'trk_binomtest_batch', 'trk_synth_fill', 'trk_synth_fill_gangstr', 'trk_test_set_option', 'trk_test_get_option',
     'trk_assoc_scan', 'trk_assoc_scan_dosage', 'trk_student_t_two_sided', 'trk_dosages', 'trk_qc_reduce', 'trk_parse_samples', 'trk_format_samples', 'trk_planarize', 'trk_pad_rows', 'trk_permute_columns', 'trk_stream_probe', 'trk_device_clocks', 'trk_stream_select', 'trk_stream_wait',
     'trk_host_alloc', 'trk_host_free', 'trk_memcpy_h2d_async', 'trk_memcpy_d2h_async', 'trk_queue_sync', 'trk_thread_queue', 'trk_exchange', 'trk_event_record', 'trk_event_wait',
 ]
@@ -208,7 +209,7 @@ def _ensure_current():
     """A prebuilt libtrk.so must come from the sources next to it: the build leaves their SHA-256 in
     libtrk.so.srchash.  On a mismatch the library is rebuilt (hipcc cross-compiles anywhere); if that is not
     possible this raises rather than run a stale binary.  TRK_SKIP_STALE_CHECK=1 skips the check."""
-    if os.environ.get('TRK_SKIP_STALE_CHECK'):
+    if _knobs.lab('TRK_SKIP_STALE_CHECK'):
         return
     try:
         want = source_digest()
@@ -239,6 +240,31 @@ def _ensure_current():
                 raise TrkError("libtrk.so is stale and the rebuild failed:\n%s" % r.stdout.decode()[-2000:])
 
 
+def set_option(name, value):
+    """An option of include/trk_test.h (forced code paths of the parity tests, A/B switches of tools/): ``value`` None
+    unsets it.  Process-wide; the product itself sets none."""
+    load().trk_test_set_option(name.encode(), None if value is None else str(value).encode())
+
+
+class options:
+    """``with options(TRK_CF_GENERIC=1): ...`` -- library options set for the block, restored after it."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        lib = load()
+        self.old = {k: lib.trk_test_get_option(k.encode()) for k in self.kv}
+        for k, v in self.kv.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, None if v is None else v.decode())
+        return False
+
+
 def load():
     """dlopen libtrk.so and declare signatures.  Raises if it was not built."""
     global _lib
@@ -248,7 +274,7 @@ def load():
         raise TrkError("libtrk.so is not built (%s). Run `make -C trtools_amd/csrc` or "
                        "`python -c 'import __graft_entry__ as g; g.build()'`. "
                        "There is no CPU fallback." % LIB_PATH)
-    alt = os.environ.get('TRK_LIBTRK')          # A/B runs of two builds on one box (tools/ab_bench.sh)
+    alt = _knobs.lab('TRK_LIBTRK')          # A/B runs of two builds on one box (tools/ab_bench.sh)
     if alt:
         lib = C.CDLL(alt)
     else:
@@ -267,6 +293,10 @@ def load():
     lib.trk_dev_alloc.argtypes = [vp, C.c_size_t, P(vp)]
     lib.trk_dev_free.argtypes = [vp, vp]
     lib.trk_dev_alloc_pair.argtypes = [vp, C.c_size_t, i64, i64, i32, P(vp), i32, P(vp), P(vp), P(PairInfo)]
+    lib.trk_reserve_pair.argtypes = [vp, C.c_size_t, P(PairInfo)]
+    lib.trk_test_set_option.argtypes = [C.c_char_p, C.c_char_p]
+    lib.trk_test_get_option.argtypes = [C.c_char_p]
+    lib.trk_test_get_option.restype = C.c_char_p
     lib.trk_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
     lib.trk_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
     lib.trk_memcpy_d2d.argtypes = [vp, vp, vp, C.c_size_t]

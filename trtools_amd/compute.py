@@ -6,6 +6,7 @@ The host layer (tr_harmonizer / statSTR / dumpSTR mirrors) only talks to this
 interface; the tests substitute an oracle-backed object with the same methods
 to exercise the host logic on machines without a GPU -- the product itself has
 no CPU implementation."""
+from . import _knobs
 import os
 
 import numpy as np
@@ -48,9 +49,9 @@ class AssocHost:
 
 
 class DeviceCompute:
-    def __init__(self, engine=None, device=0):
+    def __init__(self, engine=None, device=0, reserve_pair_gb=None):
         from .engine import Engine
-        self.eng = engine if engine is not None else Engine(device)
+        self.eng = engine if engine is not None else Engine(device, reserve_pair_gb=reserve_pair_gb)
 
     def host_buffer(self, nbytes):
         """Pinned staging memory for the native reader's batch arrays (Engine.host_buffer)."""
@@ -68,11 +69,11 @@ class DeviceCompute:
         samples (default 32 = 128 bytes) from 512 samples on, so that every row of the tensor and of the FORMAT
         planes starts on a cache-line boundary (include/trk.h, trk_pad_rows: 3-4 % of the call-filter pass)."""
         S = hb.gt.shape[1]
-        if not (hb.gt.shape[2] == 2 and S > 0 and os.environ.get('TRK_PAD_SAMPLES', '1') != '0'):
+        if not (hb.gt.shape[2] == 2 and S > 0 and _knobs.lab('TRK_PAD_SAMPLES', '1') != '0'):
             return 0
         align = 4
         if rows and S >= 512:
-            align = max(4, int(os.environ.get('TRK_ROW_ALIGN', '32')) & ~3)
+            align = max(4, int(_knobs.lab('TRK_ROW_ALIGN', '32')) & ~3)
         return (-S) % align
 
     @staticmethod
@@ -103,7 +104,7 @@ class DeviceCompute:
             base = self.eng.make_batch(hb.gt, hb.allele_off, hb.len_class, hb.str_class, hb.len_class_value,
                                        max_alleles=hb.max_alleles)
             return base.with_class_layout(self.eng, lay, hb.n_groups)
-        mode = os.environ.get('TRK_CLASS_SORT', '')
+        mode = _knobs.lab('TRK_CLASS_SORT', '')
         # (only trk_locus_stats reads a class-ordered batch: every other entry point needs the samples in their
         # own order and number, so the gather is an opt-in of locus_stats -- ADVICE r03)
         class_sort = (allow_class_sort and gb is not None and hb.gt.shape[2] == 2 and lp is None and hb.n_loci > 0 and mode != '0' and

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <cmath>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -89,6 +90,9 @@ struct trk_ctx {
     int cur = 0;
     hipStream_t s() const { return streams[t_queue >= 0 ? t_queue : cur]; }
     std::string err;
+    // entry points may be called from two threads at once (the reader's helper thread on its own queue, trk_thread_queue):
+    // the profile bookkeeping (event pool, pending brackets) and the error string are shared and go through this lock
+    std::mutex book_m;
     hipEvent_t t_start[TRK_N_TIMERS] = {};
     hipEvent_t t_stop[TRK_N_TIMERS] = {};
     bool profiling = false;
@@ -106,6 +110,11 @@ struct trk_ctx {
     size_t assoc_ws_bytes_[TRK_N_STREAMS] = {};
     ncclComm_t comm = nullptr;
     int rank = 0, n_ranks = 1;
+    // the reserved pair of output planes (trk_reserve_pair): owned by the context, lent out by trk_dev_alloc_pair
+    void* res_plane[2] = {nullptr, nullptr};
+    size_t res_bytes = 0;
+    bool res_lent[2] = {false, false};
+    float res_tbps = 0.f;
 };
 
 static int fail(trk_ctx* ctx, int code, const char* fmt, ...) {
@@ -114,10 +123,12 @@ static int fail(trk_ctx* ctx, int code, const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (ctx)
+    if (ctx) {
+        std::lock_guard<std::mutex> g(ctx->book_m);
         ctx->err = buf;
-    else
+    } else {
         g_init_error = buf;
+    }
     return code;
 }
 
@@ -128,10 +139,13 @@ static int fail(trk_ctx* ctx, int code, const char* fmt, ...) {
     } while (0)
 
 static hipEvent_t get_event(trk_ctx* ctx) {
-    if (!ctx->event_pool.empty()) {
-        hipEvent_t e = ctx->event_pool.back();
-        ctx->event_pool.pop_back();
-        return e;
+    {
+        std::lock_guard<std::mutex> g(ctx->book_m);
+        if (!ctx->event_pool.empty()) {
+            hipEvent_t e = ctx->event_pool.back();
+            ctx->event_pool.pop_back();
+            return e;
+        }
     }
     hipEvent_t e = nullptr;
     (void)hipEventCreate(&e);
@@ -154,13 +168,17 @@ struct ProfScope {
     ~ProfScope() {
         if (!on) return;
         (void)hipEventRecord(rec.stop, st);
+        std::lock_guard<std::mutex> g(ctx->book_m);
         ctx->prof_pending.push_back(rec);
     }
     // ends the bracket of the first kernel of a launch sequence here and opens one for the next kernel
     void split(int kernel2) {
         if (!on) return;
         (void)hipEventRecord(rec.stop, st);
-        ctx->prof_pending.push_back(rec);
+        {
+            std::lock_guard<std::mutex> g(ctx->book_m);
+            ctx->prof_pending.push_back(rec);
+        }
         rec.kernel = kernel2;
         rec.start = get_event(ctx);
         rec.stop = get_event(ctx);
@@ -169,17 +187,24 @@ struct ProfScope {
 };
 
 static void drain_profile(trk_ctx* ctx) {
-    for (auto& r : ctx->prof_pending) {
+    std::vector<ProfRec> pend;
+    {
+        std::lock_guard<std::mutex> g(ctx->book_m);
+        pend.swap(ctx->prof_pending);
+    }
+    std::vector<hipEvent_t> back;
+    for (auto& r : pend) {
         (void)hipEventSynchronize(r.stop);
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
             ctx->prof_n[r.kernel] += 1;
             ctx->prof_ms[r.kernel] += ms;
         }
-        ctx->event_pool.push_back(r.start);
-        ctx->event_pool.push_back(r.stop);
+        back.push_back(r.start);
+        back.push_back(r.stop);
     }
-    ctx->prof_pending.clear();
+    std::lock_guard<std::mutex> g(ctx->book_m);
+    ctx->event_pool.insert(ctx->event_pool.end(), back.begin(), back.end());
 }
 
 extern "C" {
@@ -232,6 +257,8 @@ void trk_free(trk_ctx* ctx) {
     for (int i = 0; i < TRK_N_STREAMS; ++i) (void)hipStreamSynchronize(ctx->streams[i]);
     drain_profile(ctx);
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+    for (int k = 0; k < 2; ++k)
+        if (ctx->res_plane[k]) (void)hipFree(ctx->res_plane[k]);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < TRK_N_TIMERS; ++i) {
         (void)hipEventDestroy(ctx->t_start[i]);
@@ -281,6 +308,11 @@ int trk_dev_free(trk_ctx* ctx, void* dptr) {
     if (!ctx) return TRK_ERR_ARG;
     if (!dptr) return TRK_OK;
     for (int i = 0; i < TRK_N_STREAMS; ++i) HIPCHK(ctx, hipStreamSynchronize(ctx->streams[i]));
+    for (int k = 0; k < 2; ++k)
+        if (dptr == ctx->res_plane[k]) {   // a plane of the reserved pair goes back to the context, not to the driver
+            ctx->res_lent[k] = false;
+            return TRK_OK;
+        }
     HIPCHK(ctx, hipFree(dptr));
     return TRK_OK;
 }
@@ -957,6 +989,64 @@ static hipError_t probe_pair_ms(trk_ctx* ctx, void* a, void* b, int64_t n_loci, 
     return e;
 }
 
+int trk_reserve_pair(trk_ctx* ctx, size_t bytes_each, trk_pair_info* info) {
+    if (!ctx) return TRK_ERR_ARG;
+    trk_pair_info pi = {};
+    pi.have_a = pi.have_b = -1;
+    if (ctx->res_plane[0]) return fail(ctx, TRK_ERR_ARG, "trk_reserve_pair: a pair is reserved already");
+    bytes_each = (bytes_each + 4095) & ~(size_t)4095;
+    if (bytes_each < ((size_t)1 << 20)) return fail(ctx, TRK_ERR_ARG, "trk_reserve_pair: at least 1 MB per plane");
+    (void)hipSetDevice(ctx->device);
+    const auto t0 = std::chrono::steady_clock::now();
+    void* p[3] = {nullptr, nullptr, nullptr};
+    for (int k = 0; k < 2; ++k) {
+        hipError_t e = hipMalloc(&p[k], bytes_each);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (p[0]) (void)hipFree(p[0]);
+            return fail(ctx, TRK_ERR_NOMEM, "trk_reserve_pair: hipMalloc(%zu): %s", bytes_each, hipGetErrorString(e));
+        }
+    }
+    // the probe's shape: rows of 8192 samples over the whole plane
+    const int64_t S = 8192, Lp = (int64_t)(bytes_each / ((size_t)S * 4u));
+    const double gbytes = 2.0 * (double)Lp * (double)S * 4.0 * 1e-9;
+    int n = 0;
+    hipError_t e = Lp >= 1 ? probe_pair_ms(ctx, p[0], p[1], Lp, S, &pi.probe_ms[n]) : hipSuccess;
+    ++n;
+    int keep_a = 0, keep_b = 1;
+    float best = pi.probe_ms[0];
+    if (e == hipSuccess && Lp >= 1 && gbytes / (double)best < TRK_PAIR_FAST_TBPS && bytes_each >= ((size_t)1 << 28)) {
+        // (rare at the start of a process: one more plane, the best of the three pairs stays)
+        if (hipMalloc(&p[2], bytes_each) == hipSuccess) {
+            for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+                e = probe_pair_ms(ctx, p[k], p[2], Lp, S, &pi.probe_ms[n]);
+                if (e == hipSuccess && pi.probe_ms[n] < best) { best = pi.probe_ms[n]; keep_a = k; keep_b = 2; }
+                ++n;
+            }
+            pi.peak_extra_bytes = bytes_each;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    if (e != hipSuccess) {
+        for (int k = 0; k < 3; ++k) if (p[k]) (void)hipFree(p[k]);
+        return fail(ctx, TRK_ERR_HIP, "trk_reserve_pair probe: %s", hipGetErrorString(e));
+    }
+    for (int k = 0; k < 3; ++k)
+        if (p[k] && k != keep_a && k != keep_b) (void)hipFree(p[k]);
+    ctx->res_plane[0] = p[keep_a];
+    ctx->res_plane[1] = p[keep_b];
+    ctx->res_bytes = bytes_each;
+    ctx->res_lent[0] = ctx->res_lent[1] = false;
+    ctx->res_tbps = Lp >= 1 ? (float)(gbytes / (double)best) : 0.f;
+    pi.n_probed = n;
+    pi.kept_ms = best;
+    pi.placed = ctx->res_tbps >= (float)TRK_PAIR_FAST_TBPS ? 1 : 0;
+    pi.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (info) *info = pi;
+    return TRK_OK;
+}
+
 int trk_dev_alloc_pair(trk_ctx* ctx, size_t bytes_each, int64_t n_loci, int64_t n_samples, int32_t max_spare,
                        void* const* have, int32_t n_have, void** a, void** b, trk_pair_info* info) {
     if (!ctx || !a || !b || n_have < 0 || (n_have > 0 && !have)) return TRK_ERR_ARG;
@@ -969,6 +1059,27 @@ int trk_dev_alloc_pair(trk_ctx* ctx, size_t bytes_each, int64_t n_loci, int64_t 
     (void)hipSetDevice(ctx->device);
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipSuccess;
+    // the reserved pair (trk_reserve_pair: the process's first two allocations), when it is free and large enough:
+    // lent out as it is, timed once with the caller's shape for the record
+    if (ctx->res_plane[0] && !ctx->res_lent[0] && !ctx->res_lent[1] && bytes_each <= ctx->res_bytes) {
+        *a = ctx->res_plane[0];
+        *b = ctx->res_plane[1];
+        ctx->res_lent[0] = ctx->res_lent[1] = true;
+        e = probe_pair_ms(ctx, *a, *b, n_loci, n_samples, &pi.probe_ms[0]);
+        if (e != hipSuccess) {
+            ctx->res_lent[0] = ctx->res_lent[1] = false;
+            *a = *b = nullptr;
+            return fail(ctx, TRK_ERR_HIP, "trk_dev_alloc_pair probe: %s", hipGetErrorString(e));
+        }
+        pi.n_probed = 1;
+        pi.kept_ms = pi.probe_ms[0];
+        pi.reserved = 1;
+        const double gb = 2.0 * (double)n_loci * (double)n_samples * 4.0 * 1e-9;
+        pi.placed = (gb / (double)pi.kept_ms >= TRK_PAIR_FAST_TBPS || ctx->res_tbps >= (float)TRK_PAIR_FAST_TBPS) ? 1 : 0;
+        pi.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (info) *info = pi;
+        return TRK_OK;
+    }
     // the first plane: one the caller holds already (a pooled buffer), else a fresh allocation
     if (n_have > 0) {
         *a = have[0];
@@ -994,7 +1105,7 @@ int trk_dev_alloc_pair(trk_ctx* ctx, size_t bytes_each, int64_t n_loci, int64_t 
     // search took.
     size_t jumps[4] = {(size_t)16 << 30, (size_t)16 << 30, 0, 0}, peak_jump = 0;
     int max_jumps = 2;
-    if (const char* ev = getenv("TRK_PLACE_JUMP_GB")) {
+    if (const char* ev = trk_opt("TRK_PLACE_JUMP_GB")) {
         max_jumps = 0;
         for (const char* q = ev; *q && max_jumps < 4;) {
             const double gb = atof(q);
@@ -1006,7 +1117,7 @@ int trk_dev_alloc_pair(trk_ctx* ctx, size_t bytes_each, int64_t n_loci, int64_t 
     // planes below 1 GB (a strong-scaling shard's): the neighbouring candidates only.  At 0.5 GB the candidates of one
     // process came out within 4 % of each other six times out of six (profiles/r04_bench_final.json, extras.strong_shard)
     // and a jump's spacers are 300 times the plane
-    if (bytes_each < ((size_t)1 << 30) && !getenv("TRK_PLACE_JUMP_SMALL")) max_jumps = 0;
+    if (bytes_each < ((size_t)1 << 30) && !trk_opt("TRK_PLACE_JUMP_SMALL")) max_jumps = 0;
     size_t jump_bytes = max_jumps > 0 ? jumps[0] : 0;
     const double gbytes = 2.0 * (double)n_loci * (double)n_samples * 4.0 * 1e-9;
     int rc = TRK_OK;

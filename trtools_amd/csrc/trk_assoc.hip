@@ -1099,11 +1099,7 @@ __global__ __launch_bounds__(WAVE* GM_WAVES) void k_assoc_gram_miss(const AssocA
             const uint32_t sx = ok ? list[e] : 0u;
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
-#if defined(TRK_GM_ABL) && TRK_GM_ABL == 1
-                z[u][t] = ok ? (double)sx : 0.0;                       // timing only: no gather
-#else
                 z[u][t] = ok ? zbase[(size_t)sx * ROWS + 16 * t] : 0.0;
-#endif
             }
         }
     };
@@ -1115,11 +1111,6 @@ __global__ __launch_bounds__(WAVE* GM_WAVES) void k_assoc_gram_miss(const AssocA
             for (int ti = 0; ti < RT; ++ti)
 #pragma unroll
                 for (int tj = ti; tj < RT; ++tj) {
-#if defined(TRK_GM_ABL) && TRK_GM_ABL == 2
-                    Gc[p][0] += z[u][ti] * z[u][tj];                   // timing only: no matrix instruction
-                    ++p;
-                    continue;
-#endif
                     if (TWO && (u & 1)) Gd[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(z[u][ti], z[u][tj], Gd[p], 0, 0, 0);
                     else Gc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(z[u][ti], z[u][tj], Gc[p], 0, 0, 0);
                     ++p;
@@ -2296,7 +2287,7 @@ static AssocPlan assoc_plan(const trk_batch& b, int M) {
     p.nchunks = 1;
     const int S = b.n_samples, Amax = b.max_alleles;
     p.mv = M <= 1 ? 1 : M <= 2 ? 2 : M <= 4 ? 4 : M <= 8 ? 8 : 16;
-    if (getenv("TRK_AS_GENERIC")) return p;
+    if (trk_opt("TRK_AS_GENERIC")) return p;
     if (b.ploidy != 2 || b.locus_ploidy || S <= 0 || (S % 4) != 0 || Amax <= 0 || Amax + 3 >= 65535 ||
         (reinterpret_cast<uintptr_t>(b.gt) & 15))
         return p;
@@ -2309,8 +2300,8 @@ static AssocPlan assoc_plan(const trk_batch& b, int M) {
     // many covariates: the MFMA kernel (16 loci per workgroup step); TRK_AS_MFMA_MIN moves the threshold
     {
         int mfma_min = 5;
-        if (const char* e = getenv("TRK_AS_MFMA_MIN")) mfma_min = atoi(e);
-        if (M >= mfma_min && M + 1 <= 64 && !(M > AS_MAXV && getenv("TRK_AS_WIDE_PAIRS"))) {
+        if (const char* e = trk_opt("TRK_AS_MFMA_MIN")) mfma_min = atoi(e);
+        if (M >= mfma_min && M + 1 <= 64 && !(M > AS_MAXV && trk_opt("TRK_AS_WIDE_PAIRS"))) {
             p.mfma_rt = (M + 1 + 15) / 16;      // 16-row tiles of [vectors..., 1]: up to four (62 trait columns + ones)
             p.wave_bytes = (((Amax + 3) * (8 + (4 << kshift)) + 15) & ~15);
             p.lds_bytes = (size_t)(2 * 16) * MF_SBR * 8 + (size_t)AS_WAVES * p.wave_bytes;
@@ -2352,7 +2343,7 @@ static AssocPlan assoc_plan(const trk_batch& b, int M) {
         if (p.loci_per_wg < 1) p.loci_per_wg = 1;
     }
     p.loci_per_wg = 0;  // persistent workgroups by default; TRK_AS_LB=n restores static blocks of n loci
-    if (const char* e = getenv("TRK_AS_LB")) p.loci_per_wg = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char* e = trk_opt("TRK_AS_LB")) p.loci_per_wg = atoi(e) > 0 ? atoi(e) : 0;
     p.fast = true;
     return p;
 }
@@ -2387,10 +2378,7 @@ static size_t assoc_ws_one(const trk_batch& b, int M) {
 template <int MV, bool MASK>
 static hipError_t launch_scan_tm(const AssocArgs& a, const AssocPlan& p, hipStream_t stream) {
     void (*kern)(const AssocArgs) = &k_assoc_scan<MV, MASK>;
-    if constexpr (MV <= 2) {   // TRK_AS_OLD_SCAN=1: the per-call kernel, for A/B timing
-        static const bool old_scan = getenv("TRK_AS_OLD_SCAN") != nullptr;
-        if (!old_scan) kern = &k_assoc_scan_few<MV, MASK>;
-    }
+    if constexpr (MV <= 2) kern = &k_assoc_scan_few<MV, MASK>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     if (e != hipSuccess) return e;
@@ -2414,7 +2402,7 @@ static hipError_t launch_scan_t(const AssocArgs& a, const AssocPlan& p, hipStrea
 
 static bool use_wave_regress(int M) {
     int min_m = 16;  // below, the thread-per-locus solve is faster (round 3: M = 15: 0.64 vs 0.69 ms; M = 16: 1.08 vs 0.71)
-    if (const char* e = getenv("TRK_AS_WAVE_REGRESS_MIN")) min_m = atoi(e);
+    if (const char* e = trk_opt("TRK_AS_WAVE_REGRESS_MIN")) min_m = atoi(e);
     return M >= min_m && M + 2 <= 2 * WAVE;
 }
 
@@ -2689,7 +2677,7 @@ static hipError_t dosage_pass(const trk_batch& b, const trk_batch& bb, const trk
     hipLaunchKernelGGL(k_assoc_gram<false>, dim3(a.NC), dim3(256), 0, stream, a, full);
     DosArgs q{dos, class_sums, locus_sums};
     // few alleles everywhere (and diploid, which Beagle output is): the single-pass kernel
-    if (b.max_alleles > 0 && b.max_alleles <= DQ_A && b.ploidy == 2 && !b.locus_ploidy && !getenv("TRK_AS_DOSAGE_GENERIC"))
+    if (b.max_alleles > 0 && b.max_alleles <= DQ_A && b.ploidy == 2 && !b.locus_ploidy && !trk_opt("TRK_AS_DOSAGE_GENERIC"))
     {
         const int cmax = b.max_alleles;   // classes <= alleles
         hipLaunchKernelGGL(k_assoc_dosage_small, dim3((b.n_loci + 3) / 4), dim3(256), (size_t)4 * cmax * 4 * WAVE * 8, stream, a,

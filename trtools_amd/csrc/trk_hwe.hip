@@ -100,7 +100,7 @@ __global__ __launch_bounds__(HWE_THREADS) void k_binomtest_batch(const int64_t* 
 namespace trk {
 hipError_t launch_hwe_tests(unsigned int* count, const HweItem* items, double* locus_f64, unsigned int* overflow,
                             int64_t n, hipStream_t stream) {
-    static const int hwe_serial = getenv("TRK_HWE_SERIAL") ? 1 : 0;   // one lane per test, for A/B timing
+    const int hwe_serial = trk_opt("TRK_HWE_SERIAL") ? 1 : 0;   // one lane per test, for A/B timing
     if (hwe_serial) {
         hipLaunchKernelGGL(k_hwe_test_serial, dim3((unsigned)((2 * n + HWE_THREADS - 1) / HWE_THREADS)), dim3(HWE_THREADS), 0,
                            stream, count, items, locus_f64, (const unsigned int*)nullptr);

@@ -9,6 +9,9 @@
 
 #define TRK_MAX_PLOIDY 8
 
+// an option of include/trk_test.h (nullptr: unset); defined in trk_vcf.cpp, which the sanitizer builds recompile
+extern "C" __attribute__((visibility("hidden"))) const char* trk_opt(const char* name);
+
 namespace trk {
 // class_ws: device scratch of n_class_runs x (sumA + L x TRK_LI_COLS) int32 for the class passes of a batch whose
 // columns are ordered by sample class (trk_batch.class_runs); nullptr: the per-call group kernels

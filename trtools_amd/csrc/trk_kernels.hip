@@ -1779,7 +1779,6 @@ struct CallArgs {
     uint32_t int_thr_mask;      // LT/GT on an int32 source with the threshold folded to an integer (f_ithr)
     int32_t f_ithr[TRK_MAX_FILTERS];
     int32_t delta_stride;       // LDS words per locus of the delta table (max_alleles + 4), 0 = no delta
-    int32_t dbg;
     trk_call_out out;
 };
 
@@ -2366,7 +2365,7 @@ __device__ __forceinline__ void cf_process_r(const CallArgs& a, int l, int64_t c
             }
         }
     }
-    if (has_delta && !(a.dbg & 1)) {
+    if (has_delta) {
         // what the filtered calls remove from the locus counts: allele bins per call, the four per-locus counters
         // from the masks -- one LDS atomic each per wave and locus
         uint32_t n_filt = 0, n_low = 0, n_hl = 0, n_hs = 0;
@@ -2560,7 +2559,7 @@ __device__ __forceinline__ void cf_process(const CallArgs& a, int l, int64_t cel
                 }
             }
         } else if (called[j]) {  // dumpSTR.py:715-727
-            if (has_delta && !(a.dbg & 1)) cf_delta_call(dc, w[j], pl);
+            if (has_delta) cf_delta_call(dc, w[j], pl);
             w[j] = pl > 1 ? 0xffffffffu : (w[j] | 0xffffu);
         }
     }
@@ -2645,8 +2644,7 @@ __global__ __launch_bounds__(CF_THREADS, (NS == 12 && ALLREG) ? 4 : 1) void k_ca
         }
         if (dstride) {  // flush the sub-block's delta table: one global atomic per non-zero entry
             __syncthreads();
-            if (!(a.dbg & 2))
-                for (int i = tid; i < nl * dstride; i += CF_THREADS) {
+            for (int i = tid; i < nl * dstride; i += CF_THREADS) {
                     const int v = dbase[i];
                     if (!v) continue;
                     const int li_f = i / dstride;
@@ -2759,15 +2757,16 @@ struct V4Filter {
     int32_t is_float;     // the plane's type (read by the NFLT = -1 builds only: there the type is a run-time flag)
     int32_t pad;
     double dthr;
+    double dthr_up;       // ratio: the next double above dthr (x / d above it rounds to a quotient above dthr)
 };
 constexpr int V4_QCAP = 320;            // queue entries per wave: drained when fewer than 4 x 64 are free
+constexpr int V4_PD = 3;                // input sets of the compact build's prefetch ring (k_call_filter_v4, OUT == 2)
 struct V4Args {
     trk_batch b;
     V4Filter f[V2_MAX_FILTERS];
     const int32_t* dp;
     int loci_per_block;
     int delta_nal;
-    int dbg;
     CfGeom geom;
     uint16_t* part16;
     unsigned long long* part64;
@@ -2797,7 +2796,16 @@ __device__ __forceinline__ void v4_drain_one(uint32_t w, uint32_t li, uint32_t* 
     if (w1) atomicAdd(&tab[nal + V2_W1], w1);
 }
 
-template <int NF, int NFLT, bool DELTA, bool RATIO, int ALIAS>
+// OUT: the output set as a template argument.  0: whichever of gt_out / filter_mask / filter_mask8 the caller set (run-time
+// pointer tests, wave-uniform); 2: filter_mask8 ALONE -- what dumpSTR's command line asks for (compute.dumpstr_batch): no
+// masked-genotype words, no 32-bit mask, the four bytes of a chunk assembled directly, and the NEXT locus's loads in
+// flight while this one is worked on.  With 13 B per call instead of 20 the pass is no longer bound by the memory
+// system but by how many bytes four waves per SIMD keep in flight (one locus each: the loop waited for its loads
+// before it started on them); the 20 B builds gain nothing from the prefetch (r04_notes section 2) and do not carry it.
+// gt_out == b.gt (IN PLACE, OUT == 0): the genotype tensor is updated where it lies, as the reference does with its
+// record (dumpSTR.py:721-727) -- only the 16-byte chunks that hold a filtered call are written, the second write stream
+// of the pass nearly vanishes (and with it the output-pair effect of profiles/r03_notes.md section 22).
+template <int NF, int NFLT, bool DELTA, bool RATIO, int ALIAS, int OUT = 0>
 __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
     extern __shared__ uint32_t v2lds[];
     const int tid = threadIdx.x;
@@ -2809,9 +2817,11 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
     const int dstride = nal + V2_EXTRA;
     uint32_t* dtab = v2lds;                                        // [loci][nal + 3]
     int32_t* linfo = reinterpret_cast<int32_t*>(dtab + (size_t)a.loci_per_block * dstride);  // [loci][3]
-    // this wave's queue [V4_QCAP] of {genotype word, locus of the block}, behind the tables on an 8-byte boundary
-    uint2* queue = reinterpret_cast<uint2*>(v2lds + ((((size_t)a.loci_per_block * (dstride + CF_LINFO)) + 1) & ~(size_t)1)) +
-                   (size_t)(tid >> 6) * V4_QCAP;
+    // this wave's queue [V4_QCAP] of {genotype word, locus of the block}, behind the tables on an 8-byte boundary (the
+    // wave's base as a scalar: a push's address is one shift-and-add on the lane's rank)
+    const uint32_t qbase_w = (uint32_t)(((((size_t)a.loci_per_block * (dstride + CF_LINFO)) + 1) & ~(size_t)1)) +
+                             (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6) * (uint32_t)(2 * V4_QCAP);
+    uint2* queue = reinterpret_cast<uint2*>(v2lds + qbase_w);
     uint32_t numcalls[CF_V] = {0, 0, 0, 0}, dpmiss[CF_V] = {0, 0, 0, 0};
     uint32_t fc[NF][CF_V];
     int64_t totaldp[CF_V] = {0, 0, 0, 0};
@@ -2828,9 +2838,13 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
         bitv[k] = 1u << a.f[k].bit;
         asm volatile("" : "+v"(bitv[k]));
     }
+    // the no-call flag: bit 31 of the mask word, bit 7 of the mask byte
+    uint32_t nocallv = OUT == 2 ? 0x80u : TRK_MASK_NOCALL;
+    asm volatile("" : "+v"(nocallv));
     uint32_t qtail = 0;         // wave-uniform
     const bool live = s0 < S;
     const bool has_dp = (ALIAS & 1) || a.dp != nullptr;
+    const bool in_place = OUT == 0 && a.out.gt_out != nullptr && a.out.gt_out == a.b.gt;
     // (the last wave of a row may be partly beyond S: its live lanes share the queue among themselves)
     const uint64_t exm = __ballot(live);
     const uint32_t n_lanes = (uint32_t)__popcll(exm);
@@ -2845,8 +2859,141 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
         wave_lds_fence();
         qtail = 0;
     };
+    struct In {
+        u32x4 g, dv;
+        u32x4 pv[NF];
+    };
+    // (plane sharing -- ALIAS bit 0: the depth vector is filter 0's plane; bit 1: filter 1 reads filter 0's plane -- is
+    // resolved where a value is USED: a copy made at the load would wait for the load)
+    auto fetch = [&](int l, In& in) {
+        const int64_t c4 = ((int64_t)l * S + s0) >> 2;
+        in.g = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.b.gt) + c4);
+#pragma unroll
+        for (int k = 0; k < NF; ++k)
+            if (!(k > 0 && ((ALIAS >> k) & 1)))
+                in.pv[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.f[k].plane) + c4);
+        if (!(ALIAS & 1) && a.dp) in.dv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.dp) + c4);
+    };
+    auto process = [&](int l, int l_begin, const In& in) {
+        const int64_t c4 = ((int64_t)l * S + s0) >> 2;
+        const u32x4& g = in.g;
+        const u32x4& dv = (ALIAS & 1) ? in.pv[0] : in.dv;
+#define TRK_PV(k) in.pv[((k) > 0 && ((ALIAS >> (k)) & 1)) ? (k) - 1 : (k)]
+        u32x4 wout, mout;
+        uint64_t bad = 0, touched = 0;
+        const uint32_t li = (uint32_t)(l - l_begin);
+#pragma unroll
+        for (int j = 0; j < CF_V; ++j) {
+            const uint32_t w = g[j];
+            // called: neither half is the missing marker (one ballot per compare: the ballot of a combined
+            // condition goes through a 0/1 register)
+            const uint64_t calledm = __ballot((w & 0xffffu) != 0xffffu) & __ballot(w < 0xffff0000u);
+            uint32_t m = __builtin_amdgcn_inverse_ballot_w64(calledm) ? 0u : nocallv;
+            uint64_t anyhit = 0;
+#pragma unroll
+            for (int k = 0; k < NF; ++k) {
+                const V4Filter& f = a.f[k];
+                uint64_t c;
+                if (RATIO && f.ratio) {
+                    // RN(x / d) > t without the division (filters.py:415-484 divides two int32 columns in float64
+                    // for every call; the decision is almost never close).  With the sign of d moved onto x the
+                    // sign of x - t |d| -- one fused multiply-add, exact in sign -- says on which side of t the
+                    // exact quotient lies: at or below t the rounded quotient is not above it either; above the
+                    // NEXT double after t it is.  Only a quotient in between (an exact tie of the threshold such as
+                    // 3/20 against 0.15, which rounds DOWN to t) and d == 0 (inf / nan) take the division, in a
+                    // wave-uniform branch.
+                    const int32_t xi = (int32_t)TRK_PV(k)[j], di = (int32_t)dv[j];
+                    const double ad = __builtin_fabs((double)di);
+                    const double xs = __longlong_as_double(__double_as_longlong((double)xi) ^
+                                                           ((long long)((uint32_t)di & 0x80000000u) << 32));
+                    const uint64_t yes = __ballot(__builtin_fma(-f.dthr_up, ad, xs) > 0.0);
+                    const uint64_t no = __ballot(__builtin_fma(-f.dthr, ad, xs) <= 0.0);
+                    const uint64_t unsure = (~(yes | no) | __ballot(di == 0)) & exm;
+                    c = yes & ~unsure;
+                    if (unsure) c |= unsure & __ballot(((double)xi / (double)di) > f.dthr);
+                } else if (NFLT < 0 ? f.is_float != 0 : k >= NF - NFLT)
+                    c = __ballot(__uint_as_float(TRK_PV(k)[j] ^ f.flip) < __uint_as_float((uint32_t)f.thr));
+                else
+                    c = __ballot((int32_t)TRK_PV(k)[j] < f.thr) ^ inv[k];
+                const uint64_t h = c & (calledm | nn[k]);
+                m |= __builtin_amdgcn_inverse_ballot_w64(h) ? bitv[k] : 0u;
+                add_mask(fc[k][j], h & calledm);   // dumpSTR.py:661
+                anyhit |= h;
+            }
+            const uint64_t passm = calledm & ~anyhit;   // mask word == 0: dumpSTR.py:686
+            const uint64_t filtm = calledm & anyhit;    // called and not passing: dumpSTR.py:715-727
+            add_mask(numcalls[j], passm);
+            if (OUT != 2) wout[j] = __builtin_amdgcn_inverse_ballot_w64(filtm) ? 0xffffffffu : w;
+            mout[j] = m;
+            touched |= filtm;
+            if (has_dp) {
+                // a passing call's depth is added when it is not negative; a negative one is the missing marker
+                // (counted) or an error -- both rare, decided off the stream (dumpSTR.py:696-713)
+                const int32_t d = (int32_t)dv[j];
+                const uint64_t pneg = passm & __ballot(d < 0);
+                totaldp[j] += __builtin_amdgcn_inverse_ballot_w64(passm & ~pneg) ? d : 0;
+                if (pneg) {   // (wave-uniform test)
+                    const uint64_t missm = __ballot(d == INT32_MIN);
+                    add_mask(dpmiss[j], pneg & missm);
+                    bad |= pneg & ~missm;
+                }
+            }
+            if (DELTA && filtm) {   // (wave-uniform test) queue the filtered calls of slot j
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(filtm >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)filtm, 0u));
+                if (__builtin_amdgcn_inverse_ballot_w64(filtm)) queue[qtail + rank] = make_uint2(w, li);
+                qtail += (uint32_t)__popcll(filtm);
+            }
+        }
+        if (has_dp && bad) {   // a negative depth on a call that passes (cold): dumpSTR.py:698-706
+#pragma unroll
+            for (int j = CF_V - 1; j >= 0; --j) {
+                const int32_t d = (int32_t)dv[j];
+                if ((mout[j] == 0u) & (d < 0) & (d != INT32_MIN)) {
+                    if (atomicCAS(&a.out.error[0], 0, 1) == 0) {
+                        a.out.error[1] = l;
+                        a.out.error[2] = (int32_t)(s0 + j);
+                    }
+                }
+            }
+        }
+        if (OUT == 2) {   // one byte per call, bit 7 = no-call
+            const uint32_t m8 = mout[0] | (mout[1] << 8) | (mout[2] << 16) | (mout[3] << 24);
+            __builtin_nontemporal_store(m8, reinterpret_cast<uint32_t*>(a.out.filter_mask8) + c4);
+        } else {
+            if (in_place) {   // only the chunks with a filtered call change
+                if (__builtin_amdgcn_inverse_ballot_w64(touched))
+                    __builtin_nontemporal_store(wout, reinterpret_cast<u32x4*>(a.out.gt_out) + c4);
+            } else if (a.out.gt_out) {
+                __builtin_nontemporal_store(wout, reinterpret_cast<u32x4*>(a.out.gt_out) + c4);
+            }
+            if (a.out.filter_mask) __builtin_nontemporal_store(mout, reinterpret_cast<u32x4*>(a.out.filter_mask) + c4);
+            if (a.out.filter_mask8) {   // one byte per call: bit 7 = no-call
+                uint32_t m8 = 0;
+#pragma unroll
+                for (int j = 0; j < CF_V; ++j) m8 |= ((mout[j] & 0x7fu) | ((mout[j] >> 24) & 0x80u)) << (8 * j);
+                __builtin_nontemporal_store(m8, reinterpret_cast<uint32_t*>(a.out.filter_mask8) + c4);
+            }
+        }
+        if (DELTA && qtail > (uint32_t)(V4_QCAP - CF_V * WAVE)) drain();
+#undef TRK_PV
+    };
     const int n_blocks = (L + a.loci_per_block - 1) / a.loci_per_block;
     const int by_end = min(n_blocks, (biy + 1) * a.geom.walk);
+    const int l_last = min(L, by_end * a.loci_per_block);   // end of this workgroup's range
+    // OUT == 2: a ring of V4_PD input sets; set k holds locus (range start + k) mod V4_PD.  The loop is unrolled V4_PD
+    // times so that every set is a fixed group of registers; a set is refilled -- with the locus V4_PD further on,
+    // across the blocks of the range -- as soon as its locus has been worked on, so V4_PD - 1 loci are in flight while
+    // one is worked on.  The host makes the block length a multiple of V4_PD (only the last block of the batch may be
+    // shorter: its tail runs without refills).  Refills are UNCONDITIONAL (beyond the range's end the last locus is
+    // fetched again): a branch around a fetch would turn the wait for a set's loads into a wait for everything (the
+    // counter of outstanding loads is merged pessimistically where two paths meet).
+    In ring[V4_PD] = {};
+    const int r_begin = biy * a.geom.walk * a.loci_per_block;
+    if (OUT == 2 && live && r_begin < l_last) {
+#pragma unroll
+        for (int k = 0; k < V4_PD; ++k) fetch(min(r_begin + k, l_last - 1), ring[k]);
+    }
     for (int by = biy * a.geom.walk; by < by_end; ++by) {
         const int l_begin = by * a.loci_per_block;
         const int l_end = min(L, l_begin + a.loci_per_block);
@@ -2856,84 +3003,23 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
             cf_build_lut<false>(a.b, l_begin, nl, nal, tid, nullptr, linfo);
         }
         if (live) {
-            for (int l = l_begin; l < l_end; ++l) {
-                const int64_t c4 = ((int64_t)l * S + s0) >> 2;
-                const u32x4 g = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.b.gt) + c4);
-                u32x4 pv[NF];
+            if (OUT == 2) {
+                int l = l_begin;
+                for (; l + V4_PD <= l_end; l += V4_PD) {
 #pragma unroll
-                for (int k = 0; k < NF; ++k) {
-                    if (k > 0 && ((ALIAS >> k) & 1)) pv[k] = pv[k - 1];
-                    else pv[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.f[k].plane) + c4);
-                }
-                u32x4 dv = {0, 0, 0, 0};
-                if (ALIAS & 1) dv = pv[0];
-                else if (a.dp) dv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.dp) + c4);
-                u32x4 wout, mout;
-                uint64_t bad = 0;
-                const uint32_t li = (uint32_t)(l - l_begin);
-#pragma unroll
-                for (int j = 0; j < CF_V; ++j) {
-                    const uint32_t w = g[j];
-                    // called: neither half is the missing marker (one ballot per compare: the ballot of a combined
-                    // condition goes through a 0/1 register)
-                    const uint64_t calledm = __ballot((w & 0xffffu) != 0xffffu) & __ballot(w < 0xffff0000u);
-                    uint32_t m = __builtin_amdgcn_inverse_ballot_w64(calledm) ? 0u : TRK_MASK_NOCALL;
-                    uint64_t anyhit = 0;
-#pragma unroll
-                    for (int k = 0; k < NF; ++k) {
-                        const V4Filter& f = a.f[k];
-                        uint64_t c;
-                        if (RATIO && f.ratio)
-                            c = __ballot(((double)(int32_t)pv[k][j] / (double)(int32_t)dv[j]) > f.dthr);
-                        else if (NFLT < 0 ? f.is_float != 0 : k >= NF - NFLT)
-                            c = __ballot(__uint_as_float(pv[k][j] ^ f.flip) < __uint_as_float((uint32_t)f.thr));
-                        else
-                            c = __ballot((int32_t)pv[k][j] < f.thr) ^ inv[k];
-                        const uint64_t h = c & (calledm | nn[k]);
-                        m |= __builtin_amdgcn_inverse_ballot_w64(h) ? bitv[k] : 0u;
-                        add_mask(fc[k][j], h & calledm);   // dumpSTR.py:661
-                        anyhit |= h;
-                    }
-                    const uint64_t passm = calledm & ~anyhit;   // mask word == 0: dumpSTR.py:686
-                    const uint64_t filtm = calledm & anyhit;    // called and not passing: dumpSTR.py:715-727
-                    add_mask(numcalls[j], passm);
-                    wout[j] = __builtin_amdgcn_inverse_ballot_w64(filtm) ? 0xffffffffu : w;
-                    mout[j] = m;
-                    if (has_dp) {
-                        const int32_t d = (int32_t)dv[j];
-                        add_mask(dpmiss[j], passm & __ballot(d == INT32_MIN));
-                        const int32_t dpos = d > 0 ? d : 0;
-                        totaldp[j] += __builtin_amdgcn_inverse_ballot_w64(passm) ? dpos : 0;
-                        bad |= passm & __ballot((uint32_t)d > 0x80000000u);   // negative, not the missing marker
-                    }
-                    if (DELTA && filtm) {   // (wave-uniform test) queue the filtered calls of slot j
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(filtm >> 32),
-                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)filtm, 0u));
-                        if (__builtin_amdgcn_inverse_ballot_w64(filtm)) queue[qtail + rank] = make_uint2(w, li);
-                        qtail += (uint32_t)__popcll(filtm);
+                    for (int k = 0; k < V4_PD; ++k) {
+                        process(l + k, l_begin, ring[k]);
+                        fetch(min(l + k + V4_PD, l_last - 1), ring[k]);
                     }
                 }
-                if (has_dp && bad) {   // a negative depth on a call that passes (cold): dumpSTR.py:698-706
 #pragma unroll
-                    for (int j = CF_V - 1; j >= 0; --j) {
-                        const int32_t d = (int32_t)dv[j];
-                        if ((mout[j] == 0u) & (d < 0) & (d != INT32_MIN)) {
-                            if (atomicCAS(&a.out.error[0], 0, 1) == 0) {
-                                a.out.error[1] = l;
-                                a.out.error[2] = (int32_t)(s0 + j);
-                            }
-                        }
-                    }
+                for (int k = 0; k < V4_PD - 1; ++k)     // (the batch's last block: fewer than V4_PD loci left)
+                    if (l + k < l_end) process(l + k, l_begin, ring[k]);
+            } else {
+                for (int l = l_begin; l < l_end; ++l) {
+                    fetch(l, ring[0]);
+                    process(l, l_begin, ring[0]);
                 }
-                if (a.out.gt_out) __builtin_nontemporal_store(wout, reinterpret_cast<u32x4*>(a.out.gt_out) + c4);
-                if (a.out.filter_mask) __builtin_nontemporal_store(mout, reinterpret_cast<u32x4*>(a.out.filter_mask) + c4);
-                if (a.out.filter_mask8) {   // one byte per call: bit 7 = no-call
-                    uint32_t m8 = 0;
-#pragma unroll
-                    for (int j = 0; j < CF_V; ++j) m8 |= ((mout[j] & 0x7fu) | ((mout[j] >> 24) & 0x80u)) << (8 * j);
-                    __builtin_nontemporal_store(m8, reinterpret_cast<uint32_t*>(a.out.filter_mask8) + c4);
-                }
-                if (DELTA && qtail > (uint32_t)(V4_QCAP - CF_V * WAVE)) drain();
             }
             drain();
         }
@@ -2942,7 +3028,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
             const uint32_t rcp = (uint32_t)((0x100000000ull + (uint32_t)dstride - 1u) / (uint32_t)dstride);  // i / dstride
             for (int i = tid; i < nl * dstride; i += CF_THREADS) {
                 const uint32_t v = dtab[i];
-                if (!v || (a.dbg & 2)) continue;
+                if (!v) continue;
                 const int li = (int)__umulhi((uint32_t)i, rcp);
                 const int r = i - li * dstride;
                 const int l = l_begin + li;
@@ -2961,7 +3047,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
             __syncthreads();   // the table is re-initialised for the next block
         }
     }
-    if (live && a.part16 && !(a.dbg & 1)) {
+    if (live && a.part16) {
         // this workgroup's counters of its 4 samples: one 8-byte store per counter row, 32 bytes of depth sums
         typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
         typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
@@ -2978,7 +3064,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
         u64x2* p64 = reinterpret_cast<u64x2*>(a.part64 + (size_t)biy * S + s0);
         p64[0] = (u64x2){(unsigned long long)totaldp[0], (unsigned long long)totaldp[1]};
         p64[1] = (u64x2){(unsigned long long)totaldp[2], (unsigned long long)totaldp[3]};
-    } else if (live && !(a.dbg & 1)) {
+    } else if (live) {
 #pragma unroll
         for (int j = 0; j < CF_V; ++j) {
             const int64_t s = s0 + j;
@@ -3016,10 +3102,6 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
 // four calls are loaded whole and the columns picked out of the registers with compile-time indices (16 loads).
 // ---------------------------------------------------------------------------
 constexpr int GS_NF = 9;
-#ifndef TRK_GS_NT_INTERLEAVED
-#define TRK_GS_NT_INTERLEAVED 0
-#endif
-constexpr bool GS_NT_INTERLEAVED = TRK_GS_NT_INTERLEAVED != 0;
 struct GsFilter {
     int32_t on, bit, ithr;
     float fthr;
@@ -3104,10 +3186,10 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_gs(const GsArgs a) {
             const int64_t c4 = ((int64_t)l * S + s0) >> 2;
             // (interleaved planes: a lane's k vectors are k x 16 consecutive bytes, so every load instruction of the
             // group touches every cache line of the wave's 64 k x 16 bytes -- plain loads, which the L1 may keep
-            // between them, instead of the streaming hint; TRK_GS_NT_INTERLEAVED for A/B runs)
+            // between them, instead of the streaming hint: r03_ab_gangstr_interleaved_loads.txt)
             auto ld = [&](int slot, int64_t idx) {
                 const u32x4* q = reinterpret_cast<const u32x4*>(a.p[slot]) + idx;
-                return (PLANAR || slot < 2 || GS_NT_INTERLEAVED) ? __builtin_nontemporal_load(q) : *q;
+                return (PLANAR || slot < 2) ? __builtin_nontemporal_load(q) : *q;
             };
             const u32x4 g = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.b.gt) + c4);
             u32x4 dv = {0, 0, 0, 0}, qv = {0, 0, 0, 0};
@@ -3224,7 +3306,12 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_gs(const GsArgs a) {
                     qtail += (uint32_t)__popcll(filtm[j]);
                 }
             }
-            if (a.out.gt_out) __builtin_nontemporal_store(wout, reinterpret_cast<u32x4*>(a.out.gt_out) + c4);
+            if (a.out.gt_out == a.b.gt) {   // in place (k_call_filter_v4's header): only the chunks with a filtered call
+                if (a.out.gt_out && __builtin_amdgcn_inverse_ballot_w64(filtm[0] | filtm[1] | filtm[2] | filtm[3]))
+                    __builtin_nontemporal_store(wout, reinterpret_cast<u32x4*>(a.out.gt_out) + c4);
+            } else if (a.out.gt_out) {
+                __builtin_nontemporal_store(wout, reinterpret_cast<u32x4*>(a.out.gt_out) + c4);
+            }
             if (a.out.filter_mask) __builtin_nontemporal_store(mout, reinterpret_cast<u32x4*>(a.out.filter_mask) + c4);
             if (a.out.filter_mask8) {
                 uint32_t m8 = 0;
@@ -3720,22 +3807,23 @@ struct CfLaunch {
     int lpb;
     dim3 grid;
 };
-static CfLaunch cf_geometry(int L, int gx, int lpb_cap, int n_cu, int occ) {
+static CfLaunch cf_geometry(int L, int gx, int lpb_cap, int n_cu, int occ, int mult = 1) {
     CfLaunch r;
     if (lpb_cap < 1) lpb_cap = 1;
-    if (const char* e = getenv("TRK_CF_LPB")) {
+    if (mult > 1) lpb_cap = lpb_cap >= mult ? lpb_cap / mult * mult : mult;   // blocks of whole multiples of `mult` loci
+    if (const char* e = trk_opt("TRK_CF_LPB")) {
         const int q = atoi(e);
         if (q > 0 && q < lpb_cap) lpb_cap = q;
     }
     int map = 2;
-    if (const char* e = getenv("TRK_CF_MAP")) map = atoi(e);
+    if (const char* e = trk_opt("TRK_CF_MAP")) map = atoi(e);
     if (map < 0 || map > 2) map = 2;
     if (occ < 1) occ = 4;
     // one workgroup slot per CU stays free when five fit: same-process A/B at 100k x 10k (r04_notes section 2) -- four
     // per CU 3.53 + 0.014 ms (kernel + k_cf_reduce), five 3.46 + 0.13, and the step's small kernels on the other
     // queues (finalisers, HWE tests) find room: 4.29 against 4.36 ms per step
     int wgcu = occ >= 5 ? 4 : occ;
-    if (const char* e = getenv("TRK_CF_WGCU")) wgcu = atoi(e) > 0 ? atoi(e) : wgcu;
+    if (const char* e = trk_opt("TRK_CF_WGCU")) wgcu = atoi(e) > 0 ? atoi(e) : wgcu;
     long pr = (long)wgcu * n_cu / gx;             // ranges of a persistent launch
     if (map == 2) pr = pr / 8 * 8;
     if (pr < 1) pr = 1;
@@ -3746,13 +3834,13 @@ static CfLaunch cf_geometry(int L, int gx, int lpb_cap, int n_cu, int occ) {
     // run the pass in the same time and leave the step's finalisers and HWE tests on the other queues a slot per CU:
     // 0.66 -> 0.58 ms per step at 12.5k x 10k (tools/shard_probe.py, r04_notes section 14).  TRK_CF_PERSIST_MIN moves it.
     long persist_min = 24;
-    if (const char* e = getenv("TRK_CF_PERSIST_MIN")) persist_min = atol(e) > 0 ? atol(e) : persist_min;
-    if (lpr >= persist_min && !getenv("TRK_CF_NO_PERSIST")) {
+    if (const char* e = trk_opt("TRK_CF_PERSIST_MIN")) persist_min = atol(e) > 0 ? atol(e) : persist_min;
+    if (lpr >= persist_min && !trk_opt("TRK_CF_NO_PERSIST")) {
         walk = (int)((lpr + lpb_cap - 1) / lpb_cap);
         lpb = (int)((lpr + walk - 1) / walk);
     } else {
         int min_rounds = 2;
-        if (const char* e = getenv("TRK_CF_MIN_ROUNDS")) min_rounds = atoi(e) > 0 ? atoi(e) : 2;
+        if (const char* e = trk_opt("TRK_CF_MIN_ROUNDS")) min_rounds = atoi(e) > 0 ? atoi(e) : 2;
         const long slots = (long)n_cu * occ;
         lpb = lpb_cap;
         long k = ((long)gx * ((L + lpb - 1) / lpb) + slots - 1) / slots;
@@ -3765,6 +3853,10 @@ static CfLaunch cf_geometry(int L, int gx, int lpb_cap, int n_cu, int occ) {
             if (lpb2 < lpb) lpb = lpb2;
         }
         walk = 1;
+    }
+    if (mult > 1) {
+        const int up = (lpb + mult - 1) / mult * mult;
+        lpb = up <= lpb_cap ? up : lpb_cap;
     }
     const int n_blocks = (L + lpb - 1) / lpb;
     r.lpb = lpb;
@@ -3789,7 +3881,7 @@ static int next_pow2(int v) {
 // paths accumulate with atomics into zeroed arrays and are followed by two device-to-device copies.
 static void sync_gt_temporal() {
     static int last = -1;
-    const int want = getenv("TRK_GT_TEMPORAL") ? atoi(getenv("TRK_GT_TEMPORAL")) : 0;
+    const int want = trk_opt("TRK_GT_TEMPORAL") ? atoi(trk_opt("TRK_GT_TEMPORAL")) : 0;
     if (want != last) {
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gt_temporal), &want, sizeof want);
         last = want;
@@ -3816,7 +3908,7 @@ static bool launch_count_streaming(const trk_batch& b, int max_alleles, int32_t*
         return hipMemcpyAsync(locus_int + li_elems, locus_int, li_elems * sizeof(int32_t), hipMemcpyDeviceToDevice, stream);
     };
     if (fast2 && max_alleles > 0 && (b.n_samples % 4) == 0 && b.n_samples > 0) {
-        const char* ver_env = getenv("TRK_CNT_VER");
+        const char* ver_env = trk_opt("TRK_CNT_VER");
         const bool use_v2 = !b.locus_ploidy && max_alleles + 2 < 65535 && !(ver_env && atoi(ver_env) == 1);
         if (!use_v2 && b.row_stride) return false;   // (the older kernel knows no views)
         const int extra = use_v2 ? 7 : 1;  // bins besides the alleles
@@ -3829,14 +3921,14 @@ static bool launch_count_streaming(const trk_batch& b, int max_alleles, int32_t*
             size_t lds_fast = (size_t)COUNT_WAVES_PER_WG * words * sizeof(uint32_t);
             int wgs_fast = (b.n_loci + COUNT_WAVES_PER_WG - 1) / COUNT_WAVES_PER_WG;
             int cnt_u = 4;   // with the double-buffered streamer four chunks in flight beat two (tools/count_probe.py)
-            if (const char* e = getenv("TRK_CNT_U")) cnt_u = atoi(e);
+            if (const char* e = trk_opt("TRK_CNT_U")) cnt_u = atoi(e);
             dim3 grid(wgs_fast), block(WAVE * COUNT_WAVES_PER_WG);
             // short rows: R loci per wave (k_locus_count_v3) while the wider per-wave histogram still lets >= 2
             // workgroups share a CU.  TRK_CNT_R = 1 / 2 / 4 overrides the row-length rule (tools/perf_sweep.py).
             // four loci per wave for rows of up to 2048 samples (400k x 1k: R = 4 0.38 ms, R = 1 0.46; 200k x 2k: 0.37 / 0.37;
             // 100k x 4k: 0.37 / 0.29; 100k x 10k: 0.76 / 0.62)
             int rr = b.n_samples <= 2048 ? 4 : 1;
-            if (const char* e = getenv("TRK_CNT_R")) rr = atoi(e);
+            if (const char* e = trk_opt("TRK_CNT_R")) rr = atoi(e);
             const int nbmax = max_alleles + 7;
             const int words3 = (2 * nbmax * 32 + 4 * nbmax + 3) & ~3;
             if (use_v2 && (rr == 2 || rr == 4) && (size_t)COUNT_WAVES_PER_WG * words3 * 4 <= 72 * 1024) {
@@ -3857,7 +3949,7 @@ static bool launch_count_streaming(const trk_batch& b, int max_alleles, int32_t*
             if (use_v2) {
                 // wave-per-locus kernel: two chunks per register set (83 VGPRs, five waves per SIMD) beat four (100
                 // VGPRs, four waves) since the streamer swaps its two sets instead of copying: 0.70 vs 0.79 ms
-                const int v2_u = getenv("TRK_CNT_U") ? cnt_u : 2;
+                const int v2_u = trk_opt("TRK_CNT_U") ? cnt_u : 2;
                 if (v2_u == 4)
                     hipLaunchKernelGGL(k_locus_count_v2<4>, grid, block, lds_fast, stream, b, allele_count, locus_int,
                                        kshift, words, twin_ac, twin_li);
@@ -3956,7 +4048,7 @@ hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* alle
     // sample groups (statSTR --samples): the streaming kernel with one histogram per class of group bits
     if (b.group_bits && G >= 1 && G <= 3 && b.ploidy == 2 && !b.locus_ploidy && max_alleles > 0 &&
         max_alleles + 2 < 65535 && b.n_samples > 0 && (b.n_samples % 4) == 0 &&
-        ((uintptr_t)b.group_bits & 3u) == 0 && !getenv("TRK_CNT_NOGROUPFAST")) {
+        ((uintptr_t)b.group_bits & 3u) == 0 && !trk_opt("TRK_CNT_NOGROUPFAST")) {
         const int ncls = 1 << G, nb = max_alleles + V2G_EXTRA;
         int kshift = 5;
         while (kshift > 2 && ncls * (nb << kshift) + nb > 3072) --kshift;   // <= 12 KiB per wave
@@ -4003,14 +4095,14 @@ bool launch_locus_stats_fused(const trk_batch& b, int32_t* allele_count, int32_t
     // stage 0: only answer whether the batch is covered; 1: count + finaliser; 2: the HWE tests
     // TRK_FUSED_STATS = 0: never; N: up to N loci.  Default: every batch of short rows (tools/fused_probe.py: 0.037 vs
     // 0.067 ms at 1k loci, 0.045 / 0.075 at 10k, 0.21 / 0.24 at 100k, 0.72 / 0.79 at 400k x 1k samples)
-    const char* env = getenv("TRK_FUSED_STATS");
+    const char* env = trk_opt("TRK_FUSED_STATS");
     const int64_t limit = env ? atoll(env) : (int64_t)1 << 30;
     const int max_alleles = b.max_alleles;
     if (limit <= 0 || b.n_loci > limit) return false;
     if (b.ploidy != 2 || b.group_bits || b.locus_ploidy || b.row_stride || b.n_class_runs > 0) return false;
     if (max_alleles <= 0 || max_alleles + 2 >= 65535 || (b.n_samples % 4) != 0 || b.n_samples <= 0 || b.n_samples > 2048)
         return false;
-    if (getenv("TRK_CNT_VER") || getenv("TRK_CNT_R") || getenv("TRK_CNT_U")) return false;   // A/B knobs of the count kernels
+    if (trk_opt("TRK_CNT_VER") || trk_opt("TRK_CNT_R") || trk_opt("TRK_CNT_U")) return false;   // A/B knobs of the count kernels
     const int nbmax = max_alleles + 7;
     V3Fin fin;
     fin.locus_f64 = locus_f64;
@@ -4050,7 +4142,7 @@ hipError_t launch_locus_finalize(const trk_batch& b, const int32_t* allele_count
     // Sixteen lanes per locus shorten the LATENCY of a small batch (800 loci: 78 -> 51 us incl. the tests, 1677: 78 ->
     // 58, 3355: 78 -> 67) and cost throughput on a large one (6000: 70 -> 75 us, 100k: 0.20 -> 0.70 ms -- the serial
     // sums idle fifteen lanes): up to 4096 rows.  TRK_FIN_COOP = 0 never, N: up to N rows (tools/fin_coop_probe.py).
-    const char* coop_env = getenv("TRK_FIN_COOP");
+    const char* coop_env = trk_opt("TRK_FIN_COOP");
     const int64_t coop_max = coop_env ? atoll(coop_env) : 4096;
     if (maxA > 0 && maxA <= 64 && n <= coop_max) {
         const int amax4 = (maxA + 3) & ~3;
@@ -4119,12 +4211,12 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
         a.f_ci_n[k] = 0;
     }
     auto source_of = [&](int p, int col) -> int {
-        if (!vec || p < 0 || p >= n_planes || getenv("TRK_CF_NOSRC")) return -1;
+        if (!vec || p < 0 || p >= n_planes || trk_opt("TRK_CF_NOSRC")) return -1;
         const trk_plane& pl = planes[p];
         const bool planar = (pl.dtype & TRK_DT_PLANAR) != 0;
         if (col < 0 || col >= pl.ncol) return -1;
         if (pl.ncol > 1 && !planar) {   // interleaved: all k columns become sources together
-            if (pl.ncol > 4 || ((uintptr_t)pl.data & 15u) || getenv("TRK_CF_NOGROUPS")) return -1;
+            if (pl.ncol > 4 || ((uintptr_t)pl.data & 15u) || trk_opt("TRK_CF_NOGROUPS")) return -1;
             for (int g = 0; g < a.grp_n; ++g)
                 if (grp_plane[g] == p) return a.grp_base[g] + col;
             if (a.grp_n >= CF_MAX_GROUPS || a.n_src + pl.ncol > CF_NSRC) return -1;
@@ -4200,7 +4292,6 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
         }
     }
     a.delta_stride = 0;
-    a.dbg = getenv("TRK_CF_DBG") ? atoi(getenv("TRK_CF_DBG")) : 0;
     bool lds_delta = false;
     if (out.delta_allele_count && vec && b.max_alleles > 0) {
         // the delta table must fit next to the filter counters: shrink the locus block if needed
@@ -4220,7 +4311,7 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
     }
     // ---- k_call_filter_v4: every filter a plain threshold on a single-column plane (or a HipSTR ratio over the
     // depth plane); static compare types, queued delta updates ----
-    if (vec && !b.locus_ploidy && n_filters >= 1 && n_filters <= V2_MAX_FILTERS && !getenv("TRK_CF_GENERIC")) {
+    if (vec && !b.locus_ploidy && n_filters >= 1 && n_filters <= V2_MAX_FILTERS && !trk_opt("TRK_CF_GENERIC")) {
         V4Args v = {};
         V4Filter raw[V2_MAX_FILTERS];
         bool is_f32[V2_MAX_FILTERS];
@@ -4241,6 +4332,7 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
                 if (!ok) break;
                 o.plane = a.src_ptr[a.f_src_a[k]];
                 o.ratio = 1;
+                o.dthr_up = nextafter(f.thr, INFINITY);
                 ratio = true;
                 continue;
             }
@@ -4274,7 +4366,6 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             v.dp = dp_plane >= 0 ? reinterpret_cast<const int32_t*>(a.src_ptr[a.dp_src]) : nullptr;
             v.out = a.out;
             v.delta_nal = delta ? b.max_alleles : 0;
-            v.dbg = a.dbg;
             // order: the filters of one plane neighbours (one load per plane where the instantiation shares it), the
             // depth plane's first, integer planes before float planes
             int n = 0, nflt = 0;
@@ -4299,8 +4390,26 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             if (!delta) tflt = -1;
             if (tflt < 0 && alias) alias = 0;
             void (*k4)(V4Args) = nullptr;
+            // the output set as a template argument where it pays: filter_mask8 alone with delta outputs and static
+            // compare types -- dumpSTR's command line (compute.dumpstr_batch)
+            const size_t qbytes = delta ? (size_t)(CF_THREADS / WAVE) * V4_QCAP * sizeof(uint2) : 0;
+            const size_t per_locus4 = delta ? ((size_t)b.max_alleles + V2_EXTRA + CF_LINFO) * sizeof(uint32_t) : 0;
+            size_t lds_budget = 26 * 1024;
+            if (const char* e = trk_opt("TRK_CF_LDS_KB")) lds_budget = (size_t)(atoi(e) > 12 ? atoi(e) : 12) * 1024;
+            const int max_lpb4 = delta ? (int)((lds_budget - qbytes - 8) / per_locus4) : 255;
+            const bool compact = delta && tflt >= 0 && out.filter_mask8 && !out.gt_out && !out.filter_mask && max_lpb4 >= V4_PD &&
+                                 lpb >= V4_PD;
 #define TRK_V4_PICK(NFV)                                                                                              \
-    if (!delta) k4 = ratio ? k_call_filter_v4<NFV, -1, false, true, 0> : k_call_filter_v4<NFV, -1, false, false, 0>;  \
+    if (compact) {                                                                                                    \
+        if (tflt == 0)                                                                                                \
+            k4 = alias == 3   ? (ratio ? k_call_filter_v4<NFV, 0, true, true, (NFV >= 2 ? 3 : 1), 2> : k_call_filter_v4<NFV, 0, true, false, (NFV >= 2 ? 3 : 1), 2>) \
+                 : alias == 1 ? (ratio ? k_call_filter_v4<NFV, 0, true, true, 1, 2> : k_call_filter_v4<NFV, 0, true, false, 1, 2>) \
+                              : (ratio ? k_call_filter_v4<NFV, 0, true, true, 0, 2> : k_call_filter_v4<NFV, 0, true, false, 0, 2>); \
+        else                                                                                                          \
+            k4 = alias == 3   ? (ratio ? k_call_filter_v4<NFV, 1, true, true, (NFV >= 2 ? 3 : 1), 2> : k_call_filter_v4<NFV, 1, true, false, (NFV >= 2 ? 3 : 1), 2>) \
+                 : alias == 1 ? (ratio ? k_call_filter_v4<NFV, 1, true, true, 1, 2> : k_call_filter_v4<NFV, 1, true, false, 1, 2>) \
+                              : (ratio ? k_call_filter_v4<NFV, 1, true, true, 0, 2> : k_call_filter_v4<NFV, 1, true, false, 0, 2>); \
+    } else if (!delta) k4 = ratio ? k_call_filter_v4<NFV, -1, false, true, 0> : k_call_filter_v4<NFV, -1, false, false, 0>;  \
     else if (tflt < 0) k4 = ratio ? k_call_filter_v4<NFV, -1, true, true, 0> : k_call_filter_v4<NFV, -1, true, false, 0>; \
     else if (tflt == 0)                                                                                               \
         k4 = alias == 3   ? (ratio ? k_call_filter_v4<NFV, 0, true, true, (NFV >= 2 ? 3 : 1)> : k_call_filter_v4<NFV, 0, true, false, (NFV >= 2 ? 3 : 1)>) \
@@ -4321,14 +4430,10 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
 #undef TRK_V4_PICK
             // LDS: the block's delta table + class LUT + locus info, and one queue per wave -- within 32 KiB, so that
             // five workgroups fit a CU
-            const size_t qbytes = delta ? (size_t)(CF_THREADS / WAVE) * V4_QCAP * sizeof(uint2) : 0;
-            const size_t per_locus4 = delta ? ((size_t)b.max_alleles + V2_EXTRA + CF_LINFO) * sizeof(uint32_t) : 0;
             if (delta) {
                 // (a workgroup's LDS stays well below 160 KiB / 5: at 32 360 bytes the occupancy query still says five
                 // workgroups per CU and four are resident -- a persistent launch then runs a second round)
-                size_t budget = 26 * 1024;
-                if (const char* e = getenv("TRK_CF_LDS_KB")) budget = (size_t)(atoi(e) > 12 ? atoi(e) : 12) * 1024;
-                const int max_lpb = (int)((budget - qbytes - 8) / per_locus4);
+                const int max_lpb = max_lpb4;
                 if (lpb > max_lpb) lpb = max_lpb;
                 if (lpb > 255) lpb = 255;
                 if (lpb < 1) lpb = 1;
@@ -4336,7 +4441,7 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             int occ = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k4, CF_THREADS, (size_t)lpb * per_locus4 + qbytes + 8) != hipSuccess || occ < 1)
                 occ = 4;
-            const CfLaunch cl = cf_geometry(L, gx, lpb, n_cu, occ);
+            const CfLaunch cl = cf_geometry(L, gx, lpb, n_cu, occ, compact ? V4_PD : 1);   // (the prefetch ring: whole turns)
             lpb = cl.lpb;
             const size_t lds4 = delta ? (((size_t)lpb * per_locus4 + 7) & ~(size_t)7) + qbytes : 0;
             v.loci_per_block = lpb;
@@ -4344,7 +4449,7 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             gy = cl.geom.n_ranges;
             v.part16 = nullptr;
             v.part64 = nullptr;
-            if ((long)cl.geom.walk * lpb < 65536 && !getenv("TRK_CF_ATOMICS")) {
+            if ((long)cl.geom.walk * lpb < 65536 && !trk_opt("TRK_CF_ATOMICS")) {
                 const size_t b16 = (((size_t)gy * (2 + n_filters) * S * sizeof(uint16_t)) + 255) & ~(size_t)255;
                 const size_t b64 = (size_t)gy * S * sizeof(unsigned long long);
                 if (void* ws = scratch.get(scratch.user, b16 + b64)) {
@@ -4352,9 +4457,9 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
                     v.part64 = reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + b16);
                 }
             }
-            if (getenv("TRK_CF_VERBOSE"))
-                fprintf(stderr, "k_call_filter_v4<%d,%d,%d,%d,%d>: L %d gx %d lpb %d walk %d ranges %d map %d grid %u x %u, lds %zu B, "
-                                "occupancy %d WG/CU\n", n_filters, tflt, (int)delta, (int)ratio, alias, L, gx, lpb, cl.geom.walk,
+            if (trk_opt("TRK_CF_VERBOSE"))
+                fprintf(stderr, "k_call_filter_v4<%d,%d,%d,%d,%d,%d>: L %d gx %d lpb %d walk %d ranges %d map %d grid %u x %u, lds %zu B, "
+                                "occupancy %d WG/CU\n", n_filters, tflt, (int)delta, (int)ratio, alias, compact ? 2 : 0, L, gx, lpb, cl.geom.walk,
                         cl.geom.n_ranges, cl.geom.map, cl.grid.x, cl.grid.y, lds4, occ);
             hipLaunchKernelGGL(k4, cl.grid, dim3(CF_THREADS), lds4, stream, v);
             if (v.part16) {
@@ -4371,8 +4476,8 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
     }
     // ---- dumpSTR's closed GangSTR list (k_call_filter_gs): every filter one of the nine roles, the depth plane the
     // DP operand, multi-column planes all planar or all interleaved.  TRK_CF_NOGS=1: the interpreter kernel. ----
-    if (vec && !b.locus_ploidy && n_filters >= 1 && n_filters <= GS_NF && !getenv("TRK_CF_NOGS") &&
-        !getenv("TRK_CF_GENERIC") && (!out.delta_allele_count || (b.max_alleles > 0 && b.max_alleles <= 120))) {
+    if (vec && !b.locus_ploidy && n_filters >= 1 && n_filters <= GS_NF && !trk_opt("TRK_CF_NOGS") &&
+        !trk_opt("TRK_CF_GENERIC") && (!out.delta_allele_count || (b.max_alleles > 0 && b.max_alleles <= 120))) {
         GsArgs g = {};
         bool ok = true;
         int qexp_pl = -1, rc_pl = -1, cn_pl = -1, ci_pl = -1, q_pl = -1;
@@ -4490,7 +4595,7 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             for (int r = 0; r < GS_NF; ++r) canonical = canonical && g.f[r].on && g.f[r].bit == r;
             // (interleaved planes: the build with run-time flags is the faster one -- 3.44 against 3.6-3.8 ms at 50k x
             // 5k on one box, profiles/r03_notes.md -- so the compile-time set serves the planar layout only)
-            canonical = canonical && planar && !getenv("TRK_GS_RUNTIME_FLAGS");
+            canonical = canonical && planar && !trk_opt("TRK_GS_RUNTIME_FLAGS");
             void (*kg)(GsArgs) =
                 canonical ? (delta ? k_call_filter_gs<true, true, 0x1ff> : k_call_filter_gs<true, false, 0x1ff>)
                           : (planar ? (delta ? k_call_filter_gs<true, true, -1> : k_call_filter_gs<true, false, -1>)
@@ -4534,9 +4639,9 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
         }
         // knobs for tools/perf_sweep.py: TRK_CF_ROUNDS / TRK_CF_WPC workgroups per CU, TRK_CF_DELTA_KB table budget
         int rounds = 1, wpc = 0, delta_kb = 8;
-        if (const char* e = getenv("TRK_CF_ROUNDS")) rounds = atoi(e) > 0 ? atoi(e) : rounds;
-        if (const char* e = getenv("TRK_CF_WPC")) wpc = atoi(e);
-        if (const char* e = getenv("TRK_CF_DELTA_KB")) delta_kb = atoi(e) > 0 ? atoi(e) : delta_kb;
+        if (const char* e = trk_opt("TRK_CF_ROUNDS")) rounds = atoi(e) > 0 ? atoi(e) : rounds;
+        if (const char* e = trk_opt("TRK_CF_WPC")) wpc = atoi(e);
+        if (const char* e = trk_opt("TRK_CF_DELTA_KB")) delta_kb = atoi(e) > 0 ? atoi(e) : delta_kb;
         // load slots / element offsets of the register-vector path (CallArgs: slot_*, src_off, src_stride)
         for (int q = 0; q < 16; ++q) {
             a.slot_ptr[q] = b.gt;
@@ -4557,10 +4662,10 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
                 a.src_stride[q] = a.grp_k[g];
             }
         const bool allreg = a.reg_filter_mask == (n_filters >= 32 ? ~0u : (1u << n_filters) - 1u) &&
-                            (dp_plane < 0 || a.dp_src >= 0) && !getenv("TRK_CF_NOALLREG");
+                            (dp_plane < 0 || a.dp_src >= 0) && !trk_opt("TRK_CF_NOALLREG");
         void (*kfn)(CallArgs) = nullptr;
         // TRK_CF_NOREGVEC=1: the select-chain form also for planar sources (A/B timing)
-        const bool regvec = allreg && !getenv("TRK_CF_NOREGVEC");
+        const bool regvec = allreg && !trk_opt("TRK_CF_NOREGVEC");
 #define TRK_FAST(NS)                                                                                          \
     kfn = regvec ? (a.grp_n == 0 ? k_call_filter_fast<NS, true, 1> : k_call_filter_fast<NS, true, 2>)         \
                  : allreg ? k_call_filter_fast<NS, true, 0> : k_call_filter_fast<NS, false, 0>
@@ -4645,7 +4750,7 @@ hipError_t launch_permute_columns(const int16_t* src, int16_t* dst, const int32_
     const int64_t cap = (int64_t)n_cu * 32;
     if (wgs > cap) wgs = cap;
     // rows of up to 16k diploid samples are staged in LDS (64 KiB); longer ones are gathered from global memory
-    const bool lds_ok = ploidy == 2 && (n_dst & 3) == 0 && (size_t)n_src * 4 <= 64 * 1024 && !getenv("TRK_PERMUTE_NOLDS");
+    const bool lds_ok = ploidy == 2 && (n_dst & 3) == 0 && (size_t)n_src * 4 <= 64 * 1024 && !trk_opt("TRK_PERMUTE_NOLDS");
     hipLaunchKernelGGL(k_permute_columns, dim3((unsigned)wgs), dim3(256), lds_ok ? (size_t)n_src * 4 : 0, stream, src, dst, col,
                        n_loci, n_src, n_dst, ploidy, lds_ok ? 1 : 0);
     return hipGetLastError();

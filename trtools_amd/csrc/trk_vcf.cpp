@@ -24,6 +24,48 @@
 
 #include "../../include/trk_vcf.h"
 
+// ---- options (include/trk_test.h): a process-wide table of name -> value, set by trk_test_set_option ----
+// Values are never freed (a reader of an option may still hold the pointer): tests set a handful.
+namespace {
+struct OptTable {
+    std::mutex m;
+    std::vector<std::pair<std::string, const char*>> kv;
+    std::atomic<int> n_set{0};
+};
+OptTable& opt_table() {
+    static OptTable* t = new OptTable;
+    return *t;
+}
+}  // namespace
+extern "C" __attribute__((visibility("hidden"))) const char* trk_opt(const char* name) {
+    OptTable& t = opt_table();
+    if (t.n_set.load(std::memory_order_acquire) > 0) {
+        std::lock_guard<std::mutex> g(t.m);
+        for (auto& e : t.kv)
+            if (e.first == name) return e.second;
+    }
+#ifdef TRK_LAB
+    return getenv(name);   // the lab build (tools/): options from the environment too
+#else
+    return nullptr;
+#endif
+}
+extern "C" int trk_test_set_option(const char* name, const char* value) {
+    if (!name || !*name) return 2;
+    OptTable& t = opt_table();
+    std::lock_guard<std::mutex> g(t.m);
+    const char* v = value ? strdup(value) : nullptr;
+    for (auto& e : t.kv)
+        if (e.first == name) {
+            e.second = v;
+            return 0;
+        }
+    t.kv.emplace_back(name, v);
+    t.n_set.fetch_add(1, std::memory_order_release);
+    return 0;
+}
+extern "C" const char* trk_test_get_option(const char* name) { return name ? trk_opt(name) : nullptr; }
+
 namespace {
 
 constexpr int32_t INT_MISSING = INT32_MIN;
@@ -190,7 +232,7 @@ struct Deflater {
     int (*decompress)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
     void (*release)(void*) = nullptr;
     Deflater() {
-        if (getenv("TRK_VCF_ZLIB")) return;
+        if (trk_opt("TRK_VCF_ZLIB")) return;
         handle = dlopen("libdeflate.so.0", RTLD_NOW);
         if (!handle) return;
         alloc = reinterpret_cast<void* (*)()>(dlsym(handle, "libdeflate_alloc_decompressor"));
@@ -816,7 +858,7 @@ void parse_record(RecordJob& job, int rec) {
     static const double kP10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
                                     1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
     int8_t plane_at[32];
-    bool fast_rec = np <= 32 && max_needed >= 0 && max_needed < 32 && (*end == '\n' || *end == '\r') && !(getenv("TRK_VCF_PARSE_GENERIC") && atoi(getenv("TRK_VCF_PARSE_GENERIC")) != 0);
+    bool fast_rec = np <= 32 && max_needed >= 0 && max_needed < 32 && (*end == '\n' || *end == '\r') && !(trk_opt("TRK_VCF_PARSE_GENERIC") && atoi(trk_opt("TRK_VCF_PARSE_GENERIC")) != 0);
     if (fast_rec) {
         for (int k = 0; k < 32; ++k) plane_at[k] = -1;
         for (int i = 0; i < np && fast_rec; ++i) {
@@ -1384,7 +1426,7 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
         }
         v->skip_partial = false;
     }
-    const bool timing = getenv("TRK_VCF_TIMING") != nullptr;
+    const bool timing = trk_opt("TRK_VCF_TIMING") != nullptr;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = timing ? now() : 0.0;
     double t_fill = 0.0;
@@ -3123,8 +3165,8 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
     std::atomic<int> next{0};
     std::atomic<int> bad{INT32_MAX};
     std::atomic<int> need_heads{0};
-    const bool fast_ok = ext && ext->fast_path && !(getenv("TRK_FMT_FAST") && atoi(getenv("TRK_FMT_FAST")) == 0);
-    const bool scalar_tier = !(getenv("TRK_FMT_SCALAR") && atoi(getenv("TRK_FMT_SCALAR")) == 0);   // (0: the general transducer only)
+    const bool fast_ok = ext && ext->fast_path && !(trk_opt("TRK_FMT_FAST") && atoi(trk_opt("TRK_FMT_FAST")) == 0);
+    const bool scalar_tier = !(trk_opt("TRK_FMT_SCALAR") && atoi(trk_opt("TRK_FMT_SCALAR")) == 0);   // (0: the general transducer only)
     auto fail = [&](int l) {
         int cur = bad.load();
         while (l < cur && !bad.compare_exchange_weak(cur, l)) {}
@@ -3453,7 +3495,7 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
     if (in->n_threads <= 0)
         if (const char* e = getenv("TRK_FMT_THREADS")) want = std::max(1, atoi(e));    // formatter threads (default 32)
     const int nt = std::max(1, std::min({want, 128, n}));
-    const bool timing = getenv("TRK_FMT_TIMING") != nullptr;
+    const bool timing = trk_opt("TRK_FMT_TIMING") != nullptr;
     const auto tf0 = std::chrono::steady_clock::now();
     std::vector<std::thread> th;
     for (int t = 1; t < nt; ++t) th.emplace_back(runner);

@@ -11,6 +11,7 @@ the reference (trtools/dumpSTR/dumpSTR.py), with the per-record loop
 Host Python parses / harmonises records, pre-parses string FORMAT fields,
 evaluates the string-only locus filters (HRUN, BED regions) and writes text.
 """
+from .. import _knobs
 import argparse
 import collections
 import itertools
@@ -494,7 +495,7 @@ class _Run:
         return (isinstance(self.invcf, NativeVCFReader) and vcftype.name in VT_CODES and
                 all(isinstance(f, self._SIMPLE_VALUES) for f in self.call_filters) and
                 len(self.invcf.samples) > 0 and
-                os.environ.get('TRK_DUMPSTR_BATCH', '1') != '0')
+                _knobs.lab('TRK_DUMPSTR_BATCH', '1') != '0')
 
     def process_raw(self, rb, hz, format_kinds):
         """One batch through the batch pipeline.  False: a record is outside what it covers (nothing has been
@@ -586,7 +587,7 @@ class _Run:
                     fire = f.overlaps_batch(chroms, hz.tr_pos, hz.tr_pos + ref_len)
                 ext |= fire.astype(np.uint32) << np.uint32(j)
         t_dev = time.perf_counter()
-        if dev is not None and kw.get('compact') and os.environ.get('TRK_DEVICE_FORMAT', '1') == '1':
+        if dev is not None and kw.get('compact') and _knobs.env('TRK_DEVICE_FORMAT', '1') == '1':
             kw['keep_device'] = True         # (the mask and the planes stay on the device for trk_format_samples)
         ch, st, bits, lc = compute.dumpstr_batch(hb, arrays, specs, -1 if dp_key is None else index[dp_key],
                                                  dict(self.spec, extern_bits=ext), **kw)
@@ -655,7 +656,7 @@ class _Run:
             return '\t'.join(f)
 
         heads, native = None, None
-        if os.environ.get('TRK_DUMPSTR_NATIVE_HEADS', '1') != '0':
+        if _knobs.lab('TRK_DUMPSTR_NATIVE_HEADS', '1') != '0':
             # the heads are built by the native writer (trk_vcf_dumpstr_records): per record only the FILTER text, one
             # string per distinct pattern of fired locus filters
             ub, inv = np.unique(bits, return_inverse=True)
@@ -1004,11 +1005,11 @@ def main(args):
         # 16 CPUs' worth of time and the command line was bound by CPU seconds.  With the parse on the device the read is
         # the inflate alone and the overlap is real: 0.37 -> 0.30 s per GB (profiles/r04_notes.md section 15).
         # (--num-records shortens the last batch: no read beyond it.)
-        if args.num_records is None and os.environ.get('TRK_VCF_READ_AHEAD', '1') == '1':
+        if args.num_records is None and _knobs.env('TRK_VCF_READ_AHEAD', '1') == '1':
             invcf.read_ahead()
         # The sample columns are parsed on the device (trk_parse_samples, round 4; TRK_DEVICE_PARSE=0: on the host) -- scalar
         # Integer / Float planes only, so HipSTR's filter sets; the reader refuses otherwise and parses on the host as before
-        device_parse = (os.environ.get('TRK_DEVICE_PARSE', '1') == '1' and hasattr(invcf, 'device_parse') and
+        device_parse = (_knobs.env('TRK_DEVICE_PARSE', '1') == '1' and hasattr(invcf, 'device_parse') and
                         getattr(runtime.get_compute(), 'eng', None) is not None and
                         invcf.device_parse(runtime.get_compute().eng))
     LAST_RUN.clear()

@@ -5,6 +5,7 @@ runs in the HIP kernels of libtrk.so.  Arrays handed to the engine are numpy
 arrays with the documented dtypes; ``upload`` makes the PCIe copy explicit and
 returns a ``DeviceArray``; results stay on the device until ``.get()``.
 """
+from . import _knobs
 import ctypes as C
 import os
 
@@ -34,10 +35,12 @@ class DeviceArray:
         eng._live.add(self)
 
     @classmethod
-    def adopt(cls, eng, shape, dtype, ptr, cap):
+    def adopt(cls, eng, shape, dtype, ptr, cap, reserved=False):
         """An owning array over a device allocation of ``cap`` bytes made elsewhere (trk_dev_alloc_pair); ``cap`` must
-        be the engine's size class of the array, so that ``free`` can pool it like any other buffer."""
+        be the engine's size class of the array, so that ``free`` can pool it like any other buffer.  ``reserved``:
+        a plane of the context's reserved pair -- ``free`` hands it back to the context, never to the pool."""
         self = cls.__new__(cls)
+        self._reserved = bool(reserved)
         self.eng = eng
         self.shape = tuple(int(x) for x in shape)
         self.dtype = np.dtype(dtype)
@@ -103,7 +106,7 @@ class DeviceArray:
             self.eng._live.discard(self)
             return
         if self.parent is None and self.ptr is not None and self.eng.ctx is not None:
-            if not self.eng._pool_give(self.cap, self.ptr):
+            if getattr(self, '_reserved', False) or not self.eng._pool_give(self.cap, self.ptr):
                 self.eng.lib.trk_dev_free(self.eng.ctx, self.ptr)
         self.ptr = None
         self.eng._live.discard(self)
@@ -303,7 +306,14 @@ class _QueueScope:
 
 
 class Engine:
-    def __init__(self, device=0):
+    # Planes the context reserves for the call-filter pass's two outputs as the process's FIRST device allocations
+    # (trk_reserve_pair; include/trk.h: a process's first two allocations lie in two different placement classes, 8 of
+    # 8 fresh processes, profiles/r05_class_probe.txt).  ``reserve_pair_gb``: GiB per plane; None: TRK_RESERVE_PAIR_GB,
+    # else 4 on a device with at least 64 GB (a 100 000 x 10 000 cohort's planes are 4.0 GB), else nothing; 0: nothing
+    # (the command lines: their per-batch planes are far below the 256 MB from which placement shows at all).
+    last_reservation = None
+
+    def __init__(self, device=0, reserve_pair_gb=None):
         self.lib = L.load()
         self.ctx = None
         self._live = set()
@@ -316,7 +326,7 @@ class Engine:
         self._queue = 0              # the selected queue (on_queue)
         self._multi_queue = False    # another queue than 0 has been used since the last full synchronisation
         # the pool holds at most TRK_POOL_GB of freed buffers until close() / trim() (0 = no pooling)
-        self._pool_limit = int(float(os.environ.get('TRK_POOL_GB', '8')) * (1 << 30))
+        self._pool_limit = int(float(_knobs.env('TRK_POOL_GB', '8')) * (1 << 30))
         self._pinned = []            # pointers of hipHostMalloc'ed staging buffers
         self._pinned_cls = {}        # pointer -> size class of the buffers handed out
         self._pinned_free = {}       # size class -> released pointers
@@ -336,6 +346,18 @@ class Engine:
         self.arch = arch.value.decode()
         self.n_cu = ncu.value
         self.hbm_bytes = hbm.value
+        if reserve_pair_gb is None:
+            env = _knobs.env('TRK_RESERVE_PAIR_GB')
+            reserve_pair_gb = float(env) if env else (4.0 if self.hbm_bytes >= (64 << 30) else 0.0)
+        self.reserved_pair_bytes = 0
+        if reserve_pair_gb and reserve_pair_gb > 0:
+            info = L.PairInfo()
+            nbytes = int(float(reserve_pair_gb) * (1 << 30))
+            if self.lib.trk_reserve_pair(self.ctx, nbytes, C.byref(info)) == 0:    # (out of memory: no reservation)
+                self.reserved_pair_bytes = nbytes
+                Engine.last_reservation = dict(probe_ms=[round(float(info.probe_ms[k]), 3) for k in range(info.n_probed)],
+                                               kept_ms=round(float(info.kept_ms), 3), fast=bool(info.placed),
+                                               seconds=round(float(info.seconds), 4), plane_bytes=nbytes)
 
     # ---- plumbing ----
     def _chk(self, rc):
@@ -617,7 +639,7 @@ class Engine:
         nbytes = Lc * S * 4
         cap = self._size_class(max(nbytes, 16))
         if max_spare is None:
-            max_spare = int(os.environ.get('TRK_PLACE_SPARE', '2'))
+            max_spare = int(_knobs.lab('TRK_PLACE_SPARE', '2'))
         a, b, info = C.c_void_p(), C.c_void_p(), L.PairInfo()
         # buffers of this size class the pool holds are the first candidates (idle ones only: a probe writes them)
         have = []
@@ -630,6 +652,7 @@ class Engine:
                 break
             have.append(p_)
         harr = (C.c_void_p * max(len(have), 1))(*have)
+        info.have_a = info.have_b = -1       # (a call that fails before it writes *info has taken none of them)
         try:
             self._chk(self.lib.trk_dev_alloc_pair(self.ctx, cap, Lc, S, int(max_spare), harr, len(have), C.byref(a),
                                                   C.byref(b), C.byref(info)))
@@ -642,20 +665,28 @@ class Engine:
         Engine.last_placement = dict(probe_ms=[round(float(info.probe_ms[k]), 3) for k in range(info.n_probed)],
                                      kept_ms=round(float(info.kept_ms), 3), placed=bool(info.placed), jumps=int(info.n_jumps),
                                      seconds=round(float(info.seconds), 4), peak_extra_bytes=int(info.peak_extra_bytes),
-                                     plane_bytes=int(cap))
-        g = DeviceArray.adopt(self, (Lc, S, 2), np.int16, a.value, cap)
-        m = DeviceArray.adopt(self, (Lc, S), np.uint32, b.value, cap)
+                                     plane_bytes=int(cap), reserved=bool(info.reserved))
+        res = bool(info.reserved)
+        g = DeviceArray.adopt(self, (Lc, S, 2), np.int16, a.value, cap, reserved=res)
+        m = DeviceArray.adopt(self, (Lc, S), np.uint32, b.value, cap, reserved=res)
         return g, m
 
-    def alloc_call_out(self, batch, n_filters, want_gt=True, want_mask=True, want_mask8=False, place=None):
+    def alloc_call_out(self, batch, n_filters, want_gt=True, want_mask=True, want_mask8=False, place=None,
+                       in_place=False):
         """Outputs of trk_call_filters for ``batch``.  The two big planes (masked genotypes, mask) of a diploid batch
         are PLACED from 256 MB each on (``placed_output_pair``; ``place=False`` or TRK_PLACE_OUTPUTS=0: plain
-        allocations) -- the command lines' per-batch outputs, a strong-scaling shard's and the bench's alike."""
+        allocations) -- the command lines' per-batch outputs, a strong-scaling shard's and the bench's alike.
+        ``in_place=True``: the masked genotypes are written into the batch's own tensor (``gt_out`` IS ``batch.gt``,
+        as dumpSTR.py:721-727 updates its record): the pass stores only the 16-byte chunks that hold a filtered call
+        and has ONE big write stream, so there is no pair to place."""
         S = batch.n_samples
         if place is None:
-            place = os.environ.get('TRK_PLACE_OUTPUTS', '1') != '0'
+            place = _knobs.env('TRK_PLACE_OUTPUTS', '1') != '0'
         g = m = None
-        if (place and want_gt and want_mask and batch.ploidy == 2 and batch.n_loci * S * 4 >= self.PLACE_MIN_BYTES and
+        if in_place and want_gt:
+            g = batch.arrays['gt']
+            m = self.empty((batch.n_loci, S), np.uint32) if want_mask else None
+        elif (place and want_gt and want_mask and batch.ploidy == 2 and batch.n_loci * S * 4 >= self.PLACE_MIN_BYTES and
                 S % 4 == 0):
             g, m = self.placed_output_pair(batch)
         else:
@@ -733,7 +764,7 @@ class Engine:
         arr = np.asarray(arr)
         d = self.pad_samples(self.upload(np.ascontiguousarray(arr)), n_pad)
         if arr.ndim == 3 and arr.shape[2] > 1:
-            force = os.environ.get('TRK_CF_PLANARIZE')
+            force = _knobs.lab('TRK_CF_PLANARIZE')
             if force == '1' or (force is None and arr.shape[2] > 4):
                 p = self.planarize(d)
                 d.free()

@@ -1,4 +1,5 @@
 """Process-wide compute object (one Engine per process per GPU)."""
+from . import _knobs
 import os
 
 _compute = None
@@ -10,7 +11,11 @@ def get_compute():
     global _compute
     if _compute is None:
         from .compute import DeviceCompute
-        _compute = DeviceCompute(device=int(os.environ.get('TRK_DEVICE', os.environ.get('LOCAL_RANK', '0'))))
+        # (the command lines and the TRRecord API work batch by batch: output planes far below the size at which their
+        # placement shows -- no reserved pair, unless TRK_RESERVE_PAIR_GB asks for one)
+        env = _knobs.env('TRK_RESERVE_PAIR_GB')
+        _compute = DeviceCompute(device=int(_knobs.env('TRK_DEVICE', os.environ.get('LOCAL_RANK', '0'))),
+                                 reserve_pair_gb=float(env) if env else 0.0)
     return _compute
 
 

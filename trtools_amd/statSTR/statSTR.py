@@ -7,6 +7,7 @@ Host Python parses / harmonises records and formats text; every statistic in
 the table comes from the device (allele histograms + finaliser), for all sample
 groups of a batch in one kernel pass.
 """
+from .. import _knobs
 import argparse
 import os
 import sys
@@ -245,7 +246,7 @@ def _batch_path_ok(args, invcf, vcftype):
     TRK_STATSTR_BATCH=0 forces the per-record loop."""
     from ..vcfnative import NativeVCFReader, VT_CODES
     return (isinstance(invcf, NativeVCFReader) and vcftype.name in VT_CODES and
-            len(invcf.samples) > 0 and os.environ.get('TRK_STATSTR_BATCH', '1') != '0')
+            len(invcf.samples) > 0 and _knobs.lab('TRK_STATSTR_BATCH', '1') != '0')
 
 
 def _plot_first(args, vcftype, group_masks, sample_prefixes):
@@ -301,7 +302,7 @@ def _run_batches(args, invcf, vcftype, group_masks, fmt, shard, batch_loci, star
     # device, no per-call group look-ups (TRK_CLASS_SORT=0: the grouped kernel on file-order columns)
     layout = None
     if (masks is not None and len(passes) == 1 and hasattr(invcf, 'set_sample_map') and
-            os.environ.get('TRK_CLASS_SORT', '1') != '0' and getattr(compute, 'supports_class_layout', False)):
+            _knobs.lab('TRK_CLASS_SORT', '1') != '0' and getattr(compute, 'supports_class_layout', False)):
         from ..engine import class_layout
         layout = class_layout(passes[0][0], passes[0][1], row_align=32 if len(invcf.samples) >= 512 else 4)
         if layout is not None:
@@ -310,13 +311,13 @@ def _run_batches(args, invcf, vcftype, group_masks, fmt, shard, batch_loci, star
     # The sample columns are parsed on the device (trk_parse_samples, round 4; TRK_DEVICE_PARSE=0: on the host): the reader
     # stops at the FORMAT keys, the batch's text goes over PCIe instead of the genotype tensor.  Ungrouped runs on the
     # device engine only.
-    device_parse = (masks is None and os.environ.get('TRK_DEVICE_PARSE', '1') == '1' and hasattr(invcf, 'device_parse') and
+    device_parse = (masks is None and _knobs.env('TRK_DEVICE_PARSE', '1') == '1' and hasattr(invcf, 'device_parse') and
                     getattr(compute, 'eng', None) is not None and invcf.device_parse(compute.eng))
     LAST_RUN['device_parse'] = bool(device_parse)
     # Batch n + 1 is read while batch n is counted and written (TRK_VCF_READ_AHEAD=0: off; it was off while the command line
     # was bound by CPU seconds on the 16-CPU grant of the GPU boxes: with the parse on the device 0.18 -> 0.125 s per GB,
     # profiles/r04_notes.md section 15)
-    invcf.read_ahead(os.environ.get('TRK_VCF_READ_AHEAD', '1') == '1')
+    invcf.read_ahead(_knobs.env('TRK_VCF_READ_AHEAD', '1') == '1')
     nrecords = 0
     region_done = False
     LAST_RUN.update(path='batch', batches=0, fallback_batches=0)

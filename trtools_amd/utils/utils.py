@@ -5,6 +5,7 @@ The per-sample reductions of the hot path never come through here: they run on
 the GPU (libtrk).  These functions are the dict-level API the reference exposes
 (utils.py:118-338) plus the O(allele length) host-side string helpers used
 while harmonising a record (utils.py:340-602)."""
+from .. import _knobs
 import argparse
 import math
 import os
@@ -40,7 +41,7 @@ def LoadSingleReader(vcf_loc, checkgz=True, lazy=False, samples=None):
             common.WARNING("Samples cannot be loaded in a particular order. Order will be ignored")
         samples = list(samples)
     try:
-        if os.environ.get('TRK_NATIVE_VCF', '1') != '0':
+        if _knobs.lab('TRK_NATIVE_VCF', '1') != '0':
             from .. import vcfnative
             return vcfnative.NativeVCFReader(vcf_loc, lazy=lazy, samples=samples)
         return vcfio.VCFReader(vcf_loc, lazy=lazy, samples=samples)

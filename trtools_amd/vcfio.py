@@ -21,6 +21,7 @@ batch packer and the TRRecord facade see what they would see from cyvcf2:
 It is host plumbing (a native block-parallel parser is SURVEY.md section 8f
 row 1), not part of the device hot path.
 """
+from . import _knobs
 import ctypes
 import gzip
 import os
@@ -162,7 +163,7 @@ def _serializer():
     global _SERIALIZER
     if _SERIALIZER is False:
         _SERIALIZER = None
-        if os.environ.get('TRK_NATIVE_WRITER', '1') != '0':
+        if _knobs.lab('TRK_NATIVE_WRITER', '1') != '0':
             try:
                 from . import _lib
                 lib = _lib.load()
@@ -844,7 +845,7 @@ class VCFWriter:
             job = lambda: raw.write(data)
         else:
             job = lambda: self._fh.write(bytes(data))          # BgzfWriter takes bytes
-        if os.environ.get('TRK_ASYNC_WRITE', '1') == '0':
+        if _knobs.lab('TRK_ASYNC_WRITE', '1') == '0':
             job()
             return
         if self._pool is None:

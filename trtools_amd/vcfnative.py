@@ -6,6 +6,7 @@ numpy arrays: the genotype tensor, the phase bits and any FORMAT field selected 
 ``select_format``.  Records come out as ``vcfio.Variant`` objects whose genotype matrix and
 selected FORMAT arrays are views into those batch arrays; other FORMAT fields are still
 available (decoded lazily in Python from the record text)."""
+from . import _knobs
 import ctypes as C
 import os
 import sys
@@ -141,7 +142,7 @@ class RawBatch:
         if d is None or d.get('on_host') or d.get('deferred') is not None:
             return d is not None and d.get('deferred') is not None
         pairs = [(self._gt, d['gt']), (self._phased, d['phased'])] + [(self._planes[k], a) for k, a in d['planes'].items()]
-        if os.environ.get('TRK_HOST_DEFER', '1') == '0' or not self.n or \
+        if _knobs.lab('TRK_HOST_DEFER', '1') == '0' or not self.n or \
                 not all(src is not None and src.ptr is not None and dst.flags['C_CONTIGUOUS'] and dst.nbytes == src.nbytes
                         for dst, src in pairs):
             return False
@@ -362,7 +363,7 @@ class RawBatch:
                 if regions.get('wait') is not None:     # the download is in flight: the writer waits after the heads
                     ext.dev_wait, ext.dev_wait_arg = regions['wait']
                 keep.append(regions)
-        if regions is None or regions['flags'].any() or os.environ.get('TRK_FMT_FAST', '1') == '0':
+        if regions is None or regions['flags'].any() or _knobs.lab('TRK_FMT_FAST', '1') == '0':
             self._host()        # the writer reads genotypes / values of some record: they have to be here
         # output bound: the input text, a third more for re-serialised numbers, and per call the FILTER column this
         # pass appends (':PASS' / ':NOCALL'; the longer '<name>_<value>' strings of the few filtered calls fit in
@@ -414,7 +415,7 @@ class RawBatch:
         call-filter pass's mask and planes kept on the device 0.245-0.28 s against 0.28-0.30 on the 1 GB command line
         (profiles/r04_notes.md section 16)."""
         d = self.dev
-        if (d is None or d.get('text') is None or os.environ.get('TRK_DEVICE_FORMAT', '1') != '1' or self.n == 0 or
+        if (d is None or d.get('text') is None or _knobs.env('TRK_DEVICE_FORMAT', '1') != '1' or self.n == 0 or
                 mask.dtype != np.uint8 or len(cf_values) > _lib.FORMAT_MAX_FILTERS or
                 any(kind != 0 or bsrc is not None or int(a[1]) != 0 or len(name.encode()) > 31 or
                     (np.asarray(a[0]).ndim == 3 and np.asarray(a[0]).shape[2] != 1) for name, kind, a, bsrc in cf_values)):
@@ -469,7 +470,7 @@ class RawBatch:
             eng.sync(); _tm.append(_t.perf_counter())
             # back into one of two pinned buffers kept for the run (the writer reads them before the batch after the next)
             ring = out_ring if out_ring is not None else {}
-            key = ('dev', ring.get('i', 0))
+            key = ('dev', (ring.get('i', -1) + 1) % 2)      # (the slot dumpstr_lines moves to for THIS batch)
             buf = ring.get(key)
             if buf is None or buf.size < total:
                 alloc = getattr(self.reader, '_alloc', None)
@@ -478,7 +479,7 @@ class RawBatch:
                     self.reader._slabs = getattr(self.reader, '_slabs', []) + [buf]
                 ring[key] = buf
             wait = held = None
-            if os.environ.get('TRK_FMT_ASYNC', '1') == '1' and getattr(self.reader, '_alloc', None) is not None:
+            if _knobs.lab('TRK_FMT_ASYNC', '1') == '1' and getattr(self.reader, '_alloc', None) is not None:
                 # (pinned destination: the copy runs beside the writer's head building; the writer waits through
                 # dev_wait before it reads the columns, the device buffers are released after the writer's call)
                 eng._chk(eng.lib.trk_memcpy_d2h_async(eng.ctx, buf.ctypes.data, out_d.ptr, total))
@@ -487,7 +488,7 @@ class RawBatch:
             else:
                 eng._chk(eng.lib.trk_memcpy_d2h(eng.ctx, buf.ctypes.data, out_d.ptr, total))
             _tm.append(_t.perf_counter())
-            if os.environ.get('TRK_FMT_TIMING'):
+            if _knobs.lab('TRK_FMT_TIMING'):
                 print('[device format] setup %.1f ms, pass 1 %.1f, alloc + pass 2 %.1f, download of %.0f MB %.1f%s' % tuple(
                     [(b_ - a_) * 1e3 for a_, b_ in zip(_tm[:3], _tm[1:4])] + [total / 1e6, (_tm[4] - _tm[3]) * 1e3,
                                                                           ' (enqueued)' if wait else '']), file=sys.stderr)
@@ -664,6 +665,9 @@ class NativeVCFReader(vcfio.VCFReader):
         pend, self._pending = getattr(self, '_pending', None), None
         if pend is not None:
             pend[0].join()
+            rb = pend[1].get('rb')
+            if rb is not None:           # the batch nobody will take: its device-parsed arrays go back to the engine
+                rb.release_device()
 
     def read_raw_batch(self, n_records=None):
         """Decode the next batch of records into arrays (RawBatch); ``.n == 0`` at the end of the file."""
@@ -677,7 +681,7 @@ class NativeVCFReader(vcfio.VCFReader):
             def work():
                 try:
                     eng = getattr(self, '_dev_eng', None)
-                    if eng is not None and os.environ.get('TRK_READER_QUEUE', '1') != '0':
+                    if eng is not None and _knobs.lab('TRK_READER_QUEUE', '1') != '0':
                         # this thread's uploads and parse kernel on a queue of its own: they no longer sit in front of
                         # the caller's kernels (every batch is handed over after a blocking copy on that queue)
                         eng.thread_queue(READER_QUEUE)
@@ -965,7 +969,7 @@ class NativeVCFReader(vcfio.VCFReader):
         self._drop_pending()
         self._indexed_region = False
         tbi = self.path + '.tbi'
-        if os.path.isfile(tbi) and os.environ.get('TRK_TABIX', '1') != '0':
+        if os.path.isfile(tbi) and _knobs.lab('TRK_TABIX', '1') != '0':
             from . import tabix
             try:
                 idx = tabix.TabixIndex.load(tbi)
