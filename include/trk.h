@@ -585,6 +585,36 @@ typedef struct {
 } trk_parse_out;
 int trk_parse_samples(trk_ctx* ctx, const trk_parse_in* in, trk_parse_out* out);
 
+/* ---- BGZF members inflated on the device (round 5; SURVEY.md section 8(f1): the reader row's "BGZF block inflate") ----
+ * Replaces the inflate step of the native reader (trk_vcf.cpp's pool of libdeflate / zlib workers -- what htslib does
+ * for the reference, /root/reference/trtools/utils/utils.py:19-67) for callers that bring a batch's COMPRESSED bytes to
+ * the device: a bgzip'ed file is a chain of independent gzip members of at most 64 KiB of text (RFC 1952 / 1951, no
+ * preset dictionary); the host finds the members (sizes are in their headers) and names each one's raw DEFLATE payload;
+ * one wave inflates one member (stored, fixed and dynamic blocks) straight into the text buffer the parse kernels
+ * read.  The text equals zlib's byte for byte; a member the kernel cannot finish gets a flag and is the host's
+ * (nothing is written beyond out_off + out_len of any member).  comp must be readable for 8 bytes beyond the last
+ * payload (the member's own CRC32 / ISIZE trailer is there in a BGZF file). */
+enum {
+    TRK_INFLATE_STREAM = 1,   /* not a valid DEFLATE stream (or it reads beyond the payload)                */
+    TRK_INFLATE_OVERRUN = 2,  /* the stream holds more, or less, text than out_len                           */
+    TRK_INFLATE_INPUT = 4     /* offsets / lengths outside the buffers                                       */
+};
+typedef struct {
+    const uint8_t* comp;      /* device: the compressed bytes                                                */
+    int64_t n_comp_bytes;
+    int32_t n_blocks;
+    int32_t pad_;
+    const int64_t* in_off;    /* device [n_blocks]: offset in comp of the member's DEFLATE payload           */
+    const int32_t* in_len;    /* device [n_blocks]: payload bytes (BSIZE + 1 - header - 8)                   */
+    const int64_t* out_off;   /* device [n_blocks]: offset in text of the member's first byte                */
+    const int32_t* out_len;   /* device [n_blocks]: the member's ISIZE (<= 65536)                            */
+} trk_inflate_in;
+typedef struct {
+    uint8_t* text;            /* device                                                                      */
+    uint8_t* flags;           /* device [n_blocks]: 0 or TRK_INFLATE_* bits                                  */
+} trk_inflate_out;
+int trk_inflate_blocks(trk_ctx* ctx, const trk_inflate_in* in, const trk_inflate_out* out);
+
 /* ---- dumpSTR's sample columns written on the device (round 4; the host form is trk_vcf_dumpstr_records' span writer) ----
  * Per sample: a tab, then the token as it stands (+ ':.' per FORMAT key it lacks) + ':PASS' / ':NOCALL', or for a filtered
  * call the nulled token + ':' + '<filter>_<value>,...' (dumpSTR.py:648-683, 715-746).  A kept token is copied only when

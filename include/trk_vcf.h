@@ -111,6 +111,37 @@ int trk_vcf_set_text_buffers(trk_vcf* v, void* a, void* b, size_t cap_each);
 const int8_t* trk_vcf_format_idx(trk_vcf* v, int32_t* stride);
 int trk_vcf_parse_samples(trk_vcf* v, trk_vcf_batch* b);
 
+/* ---- BGZF members inflated by the caller (round 5: on the device, trk_inflate_blocks of include/trk.h) --------------
+ * With a hook installed trk_vcf_read_batch no longer inflates: for every run of complete BGZF members it has read it
+ * calls hook->inflate with the compressed bytes and the members' payloads; the hook inflates them wherever it likes (the
+ * text of the run is bytes [abs_base, abs_base + total) of the file's text, counted from the byte `seed` was given
+ * first) and gives back ONLY what the host side of a batch reads:
+ *   - the newlines: *nl = offsets relative to abs_base, ascending, bit 63 set when the byte before is '\r' (the array
+ *     stays the hook's, valid until its next call);
+ *   - the HEADS of the lines -- every byte from a line's start up to and including its ninth tab (CHROM ... FORMAT)
+ *     -- copied to their places in `out` (out[i] = text byte abs_base + i); the sample columns are NOT written: in
+ *     this mode trk_vcf_batch.text is valid in the heads only (trk_vcf_skip_samples must be on);
+ *   - *line_state (in / out): the tabs seen so far (0 ... 9) in the line that is unfinished at the end of the text.
+ * seed(text, n) is called once, when the hook is installed, with the text the reader has already inflated itself
+ * (what trk_vcf_open read beyond the header).  Returns: 0, else the read fails with that code in the error text.
+ * Whoever needs a batch's sample columns on the host (trk_vcf_parse_samples, the record writers' host paths) must put
+ * them there first: trk_vcf_text_abs says where trk_vcf_batch.text[0] lies in the stream.  Not with trk_vcf_seek /
+ * trk_vcf_shard (both return an error while a hook is installed). */
+typedef struct {
+    uint64_t payload_off;   /* of the member's raw DEFLATE stream in `comp`          */
+    uint32_t payload_len;
+    uint32_t isize;         /* bytes of text the member holds (<= 65536)              */
+    uint64_t dst;           /* where that text goes, relative to abs_base             */
+} trk_vcf_iblock;
+typedef struct {
+    void* user;
+    int (*seed)(void* user, const char* text, size_t n_bytes);
+    int (*inflate)(void* user, const unsigned char* comp, size_t comp_bytes, const trk_vcf_iblock* blocks, int n_blocks,
+                   uint64_t abs_base, size_t total, char* out, int* line_state, const uint64_t** nl, size_t* n_nl);
+} trk_vcf_inflate_hook;
+int trk_vcf_set_inflate_hook(trk_vcf* v, const trk_vcf_inflate_hook* hook);
+uint64_t trk_vcf_text_abs(trk_vcf* v);
+
 /* ---- record serialisation ---------------------------------------------------------------
  * what the reference gets from cyvcf2.Writer.write_record (htslib's
  * vcf_format) for the records dumpSTR rewrites (dumpSTR.py:684, 721-746, 1338).  The per-sample

@@ -18,7 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--loci', type=int, default=100000)
 ap.add_argument('--samples', type=int, default=10000)
 ap.add_argument('--iters', type=int, default=4)
-ap.add_argument('which', nargs='*', default=['full', 'compact', 'hipstr5', 'hipstr5c'])
+ap.add_argument('which', nargs='*', default=['full', 'compact', 'compact_cv1', 'compact', 'compact_cv1', 'hipstr5', 'hipstr5c'])
 a = ap.parse_args()
 eng = Engine(0)
 sb = SynthBatch(eng, a.loci, a.samples, seed=20260931, planes=('dp', 'q', 'dstutter', 'dflankindel'))
@@ -29,9 +29,15 @@ f5 = f3 + [dict(op=L.F_RATIO_GT, plane_a=2, plane_b=0, thr=0.15), dict(op=L.F_RA
 st0 = eng.locus_stats(sb.batch, count_only=True)
 st = eng.alloc_stats(sb.batch)
 cells = a.loci * a.samples
+_o = eng.alloc_call_out(sb.batch, 3)
+print("bare stream of the full pass on this box (k_stream_probe, reserved pair %s): %.3f ms" % (
+    (type(eng).last_placement or {}).get('reserved'),
+    eng.stream_probe(sb.dev['gt'], sb.dev['dp'], sb.dev['q'], _o.gt_out, _o.filter_mask, a.loci, sb.batch.n_samples, reps=3)), flush=True)
+_o.gt_out.free(); _o.filter_mask.free()
 for w in a.which:
     filters = f5 if w.startswith('hipstr5') else f3
-    compact = w in ('compact', 'hipstr5c')
+    compact = w in ('compact', 'hipstr5c', 'compact_cv1')
+    L.set_option('TRK_CF_CV1', '1' if w == 'compact_cv1' else None)
     out = eng.alloc_call_out(sb.batch, len(filters), want_gt=not compact, want_mask=not compact, want_mask8=compact)
     eng.profile(True)
     for it in range(a.iters + 1):
@@ -44,8 +50,9 @@ for w in a.which:
     n, ms = eng.profile_get()['k_call_filter']
     eng.profile(False)
     bpc = 4 + 4 * (2 if len(filters) == 3 else 4) + (1 if compact else 8)
-    print("%-9s %d filters, %2d B per call: %.3f ms = %.0f GB/s = %.3f of 8 TB/s" %
-          (w, len(filters), bpc, ms / n, cells * bpc / (ms / n * 1e-3) / 1e9, cells * bpc / (ms / n * 1e-3) / 8e12), flush=True)
+    print("%-11s %d filters, %2d B per call: %.3f ms = %.0f GB/s = %.3f of 8 TB/s%s" %
+          (w, len(filters), bpc, ms / n, cells * bpc / (ms / n * 1e-3) / 1e9, cells * bpc / (ms / n * 1e-3) / 8e12,
+           '' if compact else '   placement %s' % (type(eng).last_placement,)), flush=True)
     for x in (out.gt_out, out.filter_mask, out.filter_mask8):
         if x is not None:
             x.free()

@@ -273,6 +273,59 @@ __global__ __launch_bounds__(256) void k_fill_walk(u32x4* out, int L, int S4, in
     }
 }
 
+// ---- round 5: the compact pass's stream (3 x 16 B/lane in, ONE byte per call out: 4 B per lane and locus) ----
+// MODE 0: the 4-byte store as it is (nt); 1: plain store; 2: the bytes of 4 loci exchanged inside the workgroup through
+// LDS so that a wave stores 16 B per lane (one kilobyte row segment per wave instruction) every fourth locus;
+// 3: no output at all (the read-only walk, same loop)
+template <int MODE, int DEPTH>
+__global__ __launch_bounds__(256) void k_compact(Streams s, uint32_t* out8, int L, int S4, int lpb, int gx_, uint32_t* sink) {
+    __shared__ uint32_t stage[4][256];
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int by = xcd + 8 * (slot / gx_), bx = slot % gx_;
+    const int c = bx * 256 + threadIdx.x;
+    const bool live = c < S4;
+    const int l0 = by * lpb, l1 = min(L, l0 + lpb);
+    u32x4 acc = {0, 0, 0, 0};
+    u32x4 ring[DEPTH][3];
+    auto fetch = [&](int l, u32x4 (&r)[3]) {
+        const size_t o = (size_t)min(l, l1 - 1) * S4 + (live ? c : 0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) r[k] = __builtin_nontemporal_load(s.in[k] + o);
+    };
+    if (l0 >= l1) return;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) fetch(l0 + d, ring[d]);
+    for (int l = l0; l < l1; l += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (l + d >= l1) break;
+            const u32x4 r = ring[d][0] | ring[d][1] | ring[d][2];
+            fetch(l + d + DEPTH, ring[d]);
+            const uint32_t m8 = (r.x & 0xff) | ((r.y & 0xff) << 8) | ((r.z & 0xff) << 16) | (r.w << 24);
+            const size_t o = (size_t)(l + d) * S4 + c;
+            if (MODE == 0) { if (live) __builtin_nontemporal_store(m8, out8 + o); }
+            else if (MODE == 1) { if (live) out8[o] = m8; }
+            else if (MODE == 2) {
+                const int q = (l + d - l0) & 3;
+                stage[q][threadIdx.x] = m8;
+                if (q == 3 || l + d == l1 - 1) {
+                    __syncthreads();
+                    // wave w stores locus (l + d - q + w)'s kilobyte: lane i the 16 bytes of threads 4i .. 4i + 3
+                    const int w = threadIdx.x >> 6, i = threadIdx.x & 63;
+                    if (w <= q) {
+                        const u32x4 v = {stage[w][4 * i], stage[w][4 * i + 1], stage[w][4 * i + 2], stage[w][4 * i + 3]};
+                        const int cc = bx * 256 + 4 * i;
+                        if (cc + 3 < S4) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out8 + (size_t)(l + d - q + w) * S4 + cc));
+                        else for (int k = 0; k < 4; ++k) if (cc + k < S4) out8[(size_t)(l + d - q + w) * S4 + cc + k] = v[k];
+                    }
+                    __syncthreads();
+                }
+            } else acc ^= r;
+        }
+    }
+    if (MODE == 3 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[0] = 1;
+}
+
 struct Result { std::string name; double mn, avg; };
 static std::vector<Result> results;
 static hipEvent_t e0, e1;
@@ -440,6 +493,19 @@ static void burst(const Streams& s, const char* tag) {
     run(nm, [&] { hipLaunchKernelGGL((k_mix<0, 2>), dim3(gx, gyp), dim3(256), lds_for(5), 0, s, L, S4, lpbp, sink); });
 }
 
+static void compact(const Streams& s, uint32_t* out8) {
+    char nm[200];
+    for (int wgcu : {4, 5, 8}) {
+        const int ny = std::max(8, wgcu * ncu / gx / 8 * 8), lpb = (L + ny - 1) / ny;
+#define CO(M, D, NAME)                                                                                                     \
+        snprintf(nm, sizeof nm, "[compact] %d WG/CU, %d loci in flight, %s", wgcu, D, NAME);                               \
+        run(nm, [&] { hipLaunchKernelGGL((k_compact<M, D>), dim3(ny * gx), dim3(256), 0, 0, s, out8, L, S4, lpb, gx, sink); });
+        CO(3, 1, "read only") CO(3, 3, "read only") CO(0, 1, "4 B nt store") CO(0, 2, "4 B nt store") CO(0, 3, "4 B nt store")
+        CO(1, 1, "4 B plain store") CO(1, 3, "4 B plain store") CO(2, 1, "16 B stores through LDS every 4th locus") CO(2, 3, "16 B stores through LDS every 4th locus")
+#undef CO
+    }
+}
+
 template <int OUT>
 static void one_stream_runs(const Streams& s, const char* tag, const char* layout) {
     char nm[200];
@@ -565,6 +631,12 @@ int main(int argc, char** argv) {
     if (want("geometry")) {
         geometry(sf, "fast pair");
         if (two_levels) geometry(ss, "slow pair");
+    }
+    if (want("compact")) {
+        uint32_t* out8 = nullptr;
+        CK(hipMalloc((void**)&out8, plane / 4 + 256));
+        compact(s, out8);
+        hipFree(out8);
     }
     if (want("burst")) {
         burst(sf, "fast pair");

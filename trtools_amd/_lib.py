@@ -114,6 +114,19 @@ class AssocOut(C.Structure):
     _fields_ = [('locus_int', C.c_void_p), ('locus_f64', C.c_void_p), ('allele_count', C.c_void_p)]
 
 
+# trk_inflate_blocks (include/trk.h): BGZF members inflated on the device
+INFLATE_STREAM, INFLATE_OVERRUN, INFLATE_INPUT = 1, 2, 4
+
+
+class InflateIn(C.Structure):
+    _fields_ = [('comp', C.c_void_p), ('n_comp_bytes', C.c_int64), ('n_blocks', C.c_int32), ('pad_', C.c_int32),
+                ('in_off', C.c_void_p), ('in_len', C.c_void_p), ('out_off', C.c_void_p), ('out_len', C.c_void_p)]
+
+
+class InflateOut(C.Structure):
+    _fields_ = [('text', C.c_void_p), ('flags', C.c_void_p)]
+
+
 # trk_parse_samples (include/trk.h): the sample columns of a batch of records parsed on the device
 PARSE_MAX_PLANES = 4
 PARSE_INT, PARSE_FLOAT = 0, 1
@@ -180,7 +193,7 @@ EXPORTS = [
     'trk_locus_stats', 'trk_locus_finalize', 'trk_call_filters', 'trk_locus_filters',
     'trk_comm_unique_id', 'trk_comm_init', 'trk_allreduce_sum_i64', 'trk_allgather',
     'trk_binomtest_two_sided', 'trk_binom_pmf', 'trk_binomtest_batch', 'trk_synth_fill', 'trk_synth_fill_gangstr', 'trk_test_set_option', 'trk_test_get_option',
-    'trk_assoc_scan', 'trk_assoc_scan_dosage', 'trk_student_t_two_sided', 'trk_dosages', 'trk_qc_reduce', 'trk_parse_samples', 'trk_format_samples', 'trk_planarize', 'trk_pad_rows', 'trk_permute_columns', 'trk_stream_probe', 'trk_device_clocks', 'trk_stream_select', 'trk_stream_wait',
+    'trk_assoc_scan', 'trk_assoc_scan_dosage', 'trk_student_t_two_sided', 'trk_dosages', 'trk_qc_reduce', 'trk_parse_samples', 'trk_format_samples', 'trk_inflate_blocks', 'trk_planarize', 'trk_pad_rows', 'trk_permute_columns', 'trk_stream_probe', 'trk_device_clocks', 'trk_stream_select', 'trk_stream_wait',
     'trk_host_alloc', 'trk_host_free', 'trk_memcpy_h2d_async', 'trk_memcpy_d2h_async', 'trk_queue_sync', 'trk_thread_queue', 'trk_exchange', 'trk_event_record', 'trk_event_wait',
 ]
 
@@ -192,7 +205,7 @@ class TrkError(RuntimeError):
 
 
 # the sources libtrk.so is built from, in the order csrc/Makefile hashes them
-_SOURCES = ['csrc/trk_api.hip', 'csrc/trk_assoc.hip', 'csrc/trk_binom.h', 'csrc/trk_hwe.hip', 'csrc/trk_internal.h', 'csrc/trk_kernels.hip',
+_SOURCES = ['csrc/trk_api.hip', 'csrc/trk_assoc.hip', 'csrc/trk_binom.h', 'csrc/trk_hwe.hip', 'csrc/trk_inflate.hip', 'csrc/trk_internal.h', 'csrc/trk_kernels.hip',
             'csrc/trk_parse.hip', 'csrc/trk_qc.hip', 'csrc/trk_student.h', 'csrc/trk_vcf.cpp', '../include/trk.h', '../include/trk_test.h', '../include/trk_vcf.h']
 
 
@@ -343,6 +356,7 @@ def load():
     lib.trk_dosages.argtypes = [vp, P(Batch), vp, C.c_int, vp, vp, C.c_int, vp, vp]
     lib.trk_qc_reduce.argtypes = [vp, P(Batch), P(QcParams), P(QcOut)]
     lib.trk_parse_samples.argtypes = [vp, P(ParseIn), P(ParseOut)]
+    lib.trk_inflate_blocks.argtypes = [vp, P(InflateIn), P(InflateOut)]
     lib.trk_format_samples.argtypes = [vp, P(FormatIn), P(FormatOut), C.c_int]
     lib.trk_student_t_two_sided.argtypes = [dbl, dbl]
     lib.trk_student_t_two_sided.restype = dbl

@@ -889,6 +889,19 @@ int trk_parse_samples(trk_ctx* ctx, const trk_parse_in* in, trk_parse_out* out) 
     return TRK_OK;
 }
 
+int trk_inflate_blocks(trk_ctx* ctx, const trk_inflate_in* in, const trk_inflate_out* out) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (!in || !out) return fail(ctx, TRK_ERR_ARG, "inflate_blocks: arguments are NULL");
+    if (in->n_blocks < 0 || in->n_comp_bytes < 0) return fail(ctx, TRK_ERR_ARG, "inflate_blocks: %d blocks, %lld bytes", in->n_blocks, (long long)in->n_comp_bytes);
+    if (in->n_blocks == 0) return TRK_OK;
+    if (!in->comp || !in->in_off || !in->in_len || !in->out_off || !in->out_len || !out->text || !out->flags)
+        return fail(ctx, TRK_ERR_ARG, "inflate_blocks: comp, the four block tables, text and flags are required");
+    (void)hipSetDevice(ctx->device);
+    ProfScope ps(ctx, TRK_K_SYNTH);      // (the "generate the inputs" slot of the profile)
+    HIPCHK(ctx, trk::launch_inflate(*in, *out, ctx->n_cu, ctx->s()));
+    return TRK_OK;
+}
+
 int trk_format_samples(trk_ctx* ctx, const trk_format_in* in, trk_format_out* out, int pass) {
     if (!ctx) return TRK_ERR_ARG;
     if (!in || !out || (pass != 1 && pass != 2)) return fail(ctx, TRK_ERR_ARG, "format_samples: arguments");

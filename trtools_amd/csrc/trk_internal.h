@@ -17,6 +17,7 @@ namespace trk {
 // columns are ordered by sample class (trk_batch.class_runs); nullptr: the per-call group kernels
 hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* allele_count, int32_t* locus_int,
                               int n_cu, hipStream_t stream, bool twin, int32_t* class_ws);
+hipError_t launch_inflate(const trk_inflate_in& in, const trk_inflate_out& out, int n_cu, hipStream_t stream);
 hipError_t launch_permute_columns(const int16_t* src, int16_t* dst, const int32_t* col, int64_t n_loci, int n_src,
                                   int n_dst, int ploidy, int n_cu, hipStream_t stream);
 bool launch_locus_stats_fused(const trk_batch& b, int32_t* allele_count, int32_t* locus_int, double* locus_f64,

@@ -2760,7 +2760,8 @@ struct V4Filter {
     double dthr_up;       // ratio: the next double above dthr (x / d above it rounds to a quotient above dthr)
 };
 constexpr int V4_QCAP = 320;            // queue entries per wave: drained when fewer than 4 x 64 are free
-constexpr int V4_PD = 3;                // input sets of the compact build's prefetch ring (k_call_filter_v4, OUT == 2)
+constexpr int V4_PD = 2;                // input sets of the compact build's prefetch ring (k_call_filter_v4, OUT == 2)
+constexpr int V4_CV_MAXNF = 3;          // up to this many filters the compact build takes two chunks per thread (registers)
 struct V4Args {
     trk_batch b;
     V4Filter f[V2_MAX_FILTERS];
@@ -2805,14 +2806,30 @@ __device__ __forceinline__ void v4_drain_one(uint32_t w, uint32_t li, uint32_t* 
 // gt_out == b.gt (IN PLACE, OUT == 0): the genotype tensor is updated where it lies, as the reference does with its
 // record (dumpSTR.py:721-727) -- only the 16-byte chunks that hold a filtered call are written, the second write stream
 // of the pass nearly vanishes (and with it the output-pair effect of profiles/r03_notes.md section 22).
-template <int NF, int NFLT, bool DELTA, bool RATIO, int ALIAS, int OUT = 0>
+// CV: 16-byte chunks (four samples each) a thread owns -- chunk c of thread t is chunk c * CF_THREADS + t of the tile, so
+// that every load and store instruction of a wave stays one contiguous kilobyte.  The compact build takes two: the ONE
+// BYTE per call it writes is a 4-byte store per lane and locus, and what a write stream costs this memory system is a
+// fixed ~100 ns of a channel per contiguous SEGMENT, whatever the segment's size up to 4 KB (tools/stream_probe
+// pinned_probe `compact`, profiles/r05_pinned_compact.txt: three input planes alone 1.79 ms, with a million one-kilobyte
+// row segments of mask bytes 2.62 -- eight per cent more bytes, 46 % more time).  Two chunks per thread halve the segments.
+template <int NF, int NFLT, bool DELTA, bool RATIO, int ALIAS, int OUT = 0, int CV = (OUT == 2 && NF <= V4_CV_MAXNF ? 2 : 1)>
 __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
     extern __shared__ uint32_t v2lds[];
     const int tid = threadIdx.x;
     const int S = a.b.n_samples, L = a.b.n_loci;
     int bix, biy;
     if (!cf_place(a.geom, bix, biy)) return;
-    const int64_t s0 = ((int64_t)bix * CF_THREADS + tid) * CF_V;
+    // first sample of chunk c; a chunk beyond the row's end (the last tile's tail) reads chunk 0's cells and has no effect
+    int64_t s0c[CV];
+    uint64_t lm[CV];
+    bool livec[CV];
+#pragma unroll
+    for (int c = 0; c < CV; ++c) {
+        const int64_t sc = (((int64_t)bix * CV + c) * CF_THREADS + tid) * CF_V;
+        livec[c] = sc < S;
+        s0c[c] = livec[c] ? sc : ((int64_t)bix * CV * CF_THREADS + tid) * CF_V;
+    }
+    const int64_t s0 = s0c[0];
     const int nal = a.delta_nal;
     const int dstride = nal + V2_EXTRA;
     uint32_t* dtab = v2lds;                                        // [loci][nal + 3]
@@ -2822,13 +2839,12 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
     const uint32_t qbase_w = (uint32_t)(((((size_t)a.loci_per_block * (dstride + CF_LINFO)) + 1) & ~(size_t)1)) +
                              (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6) * (uint32_t)(2 * V4_QCAP);
     uint2* queue = reinterpret_cast<uint2*>(v2lds + qbase_w);
-    uint32_t numcalls[CF_V] = {0, 0, 0, 0}, dpmiss[CF_V] = {0, 0, 0, 0};
-    uint32_t fc[NF][CF_V];
-    int64_t totaldp[CF_V] = {0, 0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < NF; ++k)
-#pragma unroll
-        for (int j = 0; j < CF_V; ++j) fc[k][j] = 0;
+    struct Acc {
+        uint32_t numcalls[CF_V], dpmiss[CF_V];
+        uint32_t fc[NF][CF_V];
+        int64_t totaldp[CF_V];
+    };
+    Acc acc[CV] = {};
     uint64_t nn[NF], inv[NF];   // all lanes when the filter also applies to calls that are not made / when inverted
     uint32_t bitv[NF];          // the filter's bit of the mask word, in a vector register (a select's constant)
 #pragma unroll
@@ -2842,11 +2858,13 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
     uint32_t nocallv = OUT == 2 ? 0x80u : TRK_MASK_NOCALL;
     asm volatile("" : "+v"(nocallv));
     uint32_t qtail = 0;         // wave-uniform
-    const bool live = s0 < S;
+    const bool live = livec[0];
     const bool has_dp = (ALIAS & 1) || a.dp != nullptr;
     const bool in_place = OUT == 0 && a.out.gt_out != nullptr && a.out.gt_out == a.b.gt;
     // (the last wave of a row may be partly beyond S: its live lanes share the queue among themselves)
     const uint64_t exm = __ballot(live);
+#pragma unroll
+    for (int c = 0; c < CV; ++c) lm[c] = __ballot(livec[c]);
     const uint32_t n_lanes = (uint32_t)__popcll(exm);
     const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(exm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)exm, 0u));
     auto drain = [&]() {
@@ -2865,8 +2883,8 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
     };
     // (plane sharing -- ALIAS bit 0: the depth vector is filter 0's plane; bit 1: filter 1 reads filter 0's plane -- is
     // resolved where a value is USED: a copy made at the load would wait for the load)
-    auto fetch = [&](int l, In& in) {
-        const int64_t c4 = ((int64_t)l * S + s0) >> 2;
+    auto fetch = [&](int l, In& in, int cv) {
+        const int64_t c4 = ((int64_t)l * S + s0c[cv]) >> 2;
         in.g = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.b.gt) + c4);
 #pragma unroll
         for (int k = 0; k < NF; ++k)
@@ -2874,8 +2892,9 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
                 in.pv[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.f[k].plane) + c4);
         if (!(ALIAS & 1) && a.dp) in.dv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.dp) + c4);
     };
-    auto process = [&](int l, int l_begin, const In& in) {
-        const int64_t c4 = ((int64_t)l * S + s0) >> 2;
+    auto process = [&](int l, int l_begin, const In& in, int cv) {
+        const int64_t c4 = ((int64_t)l * S + s0c[cv]) >> 2;
+        Acc& ac = acc[cv];
         const u32x4& g = in.g;
         const u32x4& dv = (ALIAS & 1) ? in.pv[0] : in.dv;
 #define TRK_PV(k) in.pv[((k) > 0 && ((ALIAS >> (k)) & 1)) ? (k) - 1 : (k)]
@@ -2887,7 +2906,8 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
             const uint32_t w = g[j];
             // called: neither half is the missing marker (one ballot per compare: the ballot of a combined
             // condition goes through a 0/1 register)
-            const uint64_t calledm = __ballot((w & 0xffffu) != 0xffffu) & __ballot(w < 0xffff0000u);
+            uint64_t calledm = __ballot((w & 0xffffu) != 0xffffu) & __ballot(w < 0xffff0000u);
+            if (cv > 0) calledm &= lm[cv];     // (a chunk beyond the row's end: its lanes are no calls, filtered by nothing)
             uint32_t m = __builtin_amdgcn_inverse_ballot_w64(calledm) ? 0u : nocallv;
             uint64_t anyhit = 0;
 #pragma unroll
@@ -2917,12 +2937,12 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
                     c = __ballot((int32_t)TRK_PV(k)[j] < f.thr) ^ inv[k];
                 const uint64_t h = c & (calledm | nn[k]);
                 m |= __builtin_amdgcn_inverse_ballot_w64(h) ? bitv[k] : 0u;
-                add_mask(fc[k][j], h & calledm);   // dumpSTR.py:661
+                add_mask(ac.fc[k][j], h & calledm);   // dumpSTR.py:661
                 anyhit |= h;
             }
             const uint64_t passm = calledm & ~anyhit;   // mask word == 0: dumpSTR.py:686
             const uint64_t filtm = calledm & anyhit;    // called and not passing: dumpSTR.py:715-727
-            add_mask(numcalls[j], passm);
+            add_mask(ac.numcalls[j], passm);
             if (OUT != 2) wout[j] = __builtin_amdgcn_inverse_ballot_w64(filtm) ? 0xffffffffu : w;
             mout[j] = m;
             touched |= filtm;
@@ -2931,10 +2951,10 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
                 // (counted) or an error -- both rare, decided off the stream (dumpSTR.py:696-713)
                 const int32_t d = (int32_t)dv[j];
                 const uint64_t pneg = passm & __ballot(d < 0);
-                totaldp[j] += __builtin_amdgcn_inverse_ballot_w64(passm & ~pneg) ? d : 0;
+                ac.totaldp[j] += __builtin_amdgcn_inverse_ballot_w64(passm & ~pneg) ? d : 0;
                 if (pneg) {   // (wave-uniform test)
                     const uint64_t missm = __ballot(d == INT32_MIN);
-                    add_mask(dpmiss[j], pneg & missm);
+                    add_mask(ac.dpmiss[j], pneg & missm);
                     bad |= pneg & ~missm;
                 }
             }
@@ -2952,14 +2972,14 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
                 if ((mout[j] == 0u) & (d < 0) & (d != INT32_MIN)) {
                     if (atomicCAS(&a.out.error[0], 0, 1) == 0) {
                         a.out.error[1] = l;
-                        a.out.error[2] = (int32_t)(s0 + j);
+                        a.out.error[2] = (int32_t)(s0c[cv] + j);
                     }
                 }
             }
         }
         if (OUT == 2) {   // one byte per call, bit 7 = no-call
             const uint32_t m8 = mout[0] | (mout[1] << 8) | (mout[2] << 16) | (mout[3] << 24);
-            __builtin_nontemporal_store(m8, reinterpret_cast<uint32_t*>(a.out.filter_mask8) + c4);
+            if (cv == 0 || livec[cv]) __builtin_nontemporal_store(m8, reinterpret_cast<uint32_t*>(a.out.filter_mask8) + c4);
         } else {
             if (in_place) {   // only the chunks with a filtered call change
                 if (__builtin_amdgcn_inverse_ballot_w64(touched))
@@ -2988,11 +3008,13 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
     // shorter: its tail runs without refills).  Refills are UNCONDITIONAL (beyond the range's end the last locus is
     // fetched again): a branch around a fetch would turn the wait for a set's loads into a wait for everything (the
     // counter of outstanding loads is merged pessimistically where two paths meet).
-    In ring[V4_PD] = {};
+    In ring[V4_PD][CV] = {};
     const int r_begin = biy * a.geom.walk * a.loci_per_block;
     if (OUT == 2 && live && r_begin < l_last) {
 #pragma unroll
-        for (int k = 0; k < V4_PD; ++k) fetch(min(r_begin + k, l_last - 1), ring[k]);
+        for (int k = 0; k < V4_PD; ++k)
+#pragma unroll
+            for (int c = 0; c < CV; ++c) fetch(min(r_begin + k, l_last - 1), ring[k][c], c);
     }
     for (int by = biy * a.geom.walk; by < by_end; ++by) {
         const int l_begin = by * a.loci_per_block;
@@ -3007,18 +3029,26 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
                 int l = l_begin;
                 for (; l + V4_PD <= l_end; l += V4_PD) {
 #pragma unroll
-                    for (int k = 0; k < V4_PD; ++k) {
-                        process(l + k, l_begin, ring[k]);
-                        fetch(min(l + k + V4_PD, l_last - 1), ring[k]);
-                    }
+                    for (int k = 0; k < V4_PD; ++k)
+#pragma unroll
+                        for (int c = 0; c < CV; ++c) {
+                            process(l + k, l_begin, ring[k][c], c);
+                            fetch(min(l + k + V4_PD, l_last - 1), ring[k][c], c);
+                        }
                 }
 #pragma unroll
                 for (int k = 0; k < V4_PD - 1; ++k)     // (the batch's last block: fewer than V4_PD loci left)
-                    if (l + k < l_end) process(l + k, l_begin, ring[k]);
+                    if (l + k < l_end) {
+#pragma unroll
+                        for (int c = 0; c < CV; ++c) process(l + k, l_begin, ring[k][c], c);
+                    }
             } else {
                 for (int l = l_begin; l < l_end; ++l) {
-                    fetch(l, ring[0]);
-                    process(l, l_begin, ring[0]);
+#pragma unroll
+                    for (int c = 0; c < CV; ++c) {
+                        fetch(l, ring[0][c], c);
+                        process(l, l_begin, ring[0][c], c);
+                    }
                 }
             }
             drain();
@@ -3047,42 +3077,48 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
             __syncthreads();   // the table is re-initialised for the next block
         }
     }
-    if (live && a.part16) {
-        // this workgroup's counters of its 4 samples: one 8-byte store per counter row, 32 bytes of depth sums
-        typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
-        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-        u16x4* p16 = reinterpret_cast<u16x4*>(a.part16 + ((size_t)biy * (2 + NF)) * S + s0);
-        const size_t rs = (size_t)S / 4;   // row stride in u16x4
-        p16[0] = (u16x4){(unsigned short)numcalls[0], (unsigned short)numcalls[1], (unsigned short)numcalls[2],
-                         (unsigned short)numcalls[3]};
-        p16[rs] = (u16x4){(unsigned short)dpmiss[0], (unsigned short)dpmiss[1], (unsigned short)dpmiss[2],
-                          (unsigned short)dpmiss[3]};
 #pragma unroll
-        for (int k = 0; k < NF; ++k)
-            p16[(2 + k) * rs] = (u16x4){(unsigned short)fc[k][0], (unsigned short)fc[k][1], (unsigned short)fc[k][2],
-                                        (unsigned short)fc[k][3]};
-        u64x2* p64 = reinterpret_cast<u64x2*>(a.part64 + (size_t)biy * S + s0);
-        p64[0] = (u64x2){(unsigned long long)totaldp[0], (unsigned long long)totaldp[1]};
-        p64[1] = (u64x2){(unsigned long long)totaldp[2], (unsigned long long)totaldp[3]};
-    } else if (live) {
-#pragma unroll
-        for (int j = 0; j < CF_V; ++j) {
-            const int64_t s = s0 + j;
-            if (numcalls[j])
-                atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_counters + s),
-                          (unsigned long long)numcalls[j]);
-            if (totaldp[j])
-                atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_totaldp + s),
-                          (unsigned long long)totaldp[j]);
-            if (dpmiss[j])
-                atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_dp_missing + s),
-                          (unsigned long long)dpmiss[j]);
+    for (int cv = 0; cv < CV; ++cv) {
+        if (!livec[cv]) continue;
+        const Acc& ac = acc[cv];
+        const int64_t sc = s0c[cv];
+        if (a.part16) {
+            // this workgroup's counters of the chunk's 4 samples: one 8-byte store per counter row, 32 bytes of depth sums
+            typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            u16x4* p16 = reinterpret_cast<u16x4*>(a.part16 + ((size_t)biy * (2 + NF)) * S + sc);
+            const size_t rs = (size_t)S / 4;   // row stride in u16x4
+            p16[0] = (u16x4){(unsigned short)ac.numcalls[0], (unsigned short)ac.numcalls[1], (unsigned short)ac.numcalls[2],
+                             (unsigned short)ac.numcalls[3]};
+            p16[rs] = (u16x4){(unsigned short)ac.dpmiss[0], (unsigned short)ac.dpmiss[1], (unsigned short)ac.dpmiss[2],
+                              (unsigned short)ac.dpmiss[3]};
 #pragma unroll
             for (int k = 0; k < NF; ++k)
-                if (fc[k][j])
-                    atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_counters +
-                                                                    (int64_t)(1 + a.f[k].bit) * S + s),
-                              (unsigned long long)fc[k][j]);
+                p16[(2 + k) * rs] = (u16x4){(unsigned short)ac.fc[k][0], (unsigned short)ac.fc[k][1], (unsigned short)ac.fc[k][2],
+                                            (unsigned short)ac.fc[k][3]};
+            u64x2* p64 = reinterpret_cast<u64x2*>(a.part64 + (size_t)biy * S + sc);
+            p64[0] = (u64x2){(unsigned long long)ac.totaldp[0], (unsigned long long)ac.totaldp[1]};
+            p64[1] = (u64x2){(unsigned long long)ac.totaldp[2], (unsigned long long)ac.totaldp[3]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < CF_V; ++j) {
+                const int64_t s = sc + j;
+                if (ac.numcalls[j])
+                    atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_counters + s),
+                              (unsigned long long)ac.numcalls[j]);
+                if (ac.totaldp[j])
+                    atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_totaldp + s),
+                              (unsigned long long)ac.totaldp[j]);
+                if (ac.dpmiss[j])
+                    atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_dp_missing + s),
+                              (unsigned long long)ac.dpmiss[j]);
+#pragma unroll
+                for (int k = 0; k < NF; ++k)
+                    if (ac.fc[k][j])
+                        atomicAdd(reinterpret_cast<unsigned long long*>(a.out.sample_counters +
+                                                                        (int64_t)(1 + a.f[k].bit) * S + s),
+                                  (unsigned long long)ac.fc[k][j]);
+            }
         }
     }
 }
@@ -4419,6 +4455,7 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
         k4 = alias == 3   ? (ratio ? k_call_filter_v4<NFV, 1, true, true, (NFV >= 2 ? 3 : 1)> : k_call_filter_v4<NFV, 1, true, false, (NFV >= 2 ? 3 : 1)>) \
              : alias == 1 ? (ratio ? k_call_filter_v4<NFV, 1, true, true, 1> : k_call_filter_v4<NFV, 1, true, false, 1>) \
                           : (ratio ? k_call_filter_v4<NFV, 1, true, true, 0> : k_call_filter_v4<NFV, 1, true, false, 0>)
+            bool cv1 = false;      // (A/B of the two-chunk tile against one chunk per thread: the headline's instantiation only)
             switch (n_filters) {
                 case 1: TRK_V4_PICK(1); break;
                 case 2: TRK_V4_PICK(2); break;
@@ -4428,6 +4465,10 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
                 default: TRK_V4_PICK(6); break;
             }
 #undef TRK_V4_PICK
+            if (compact && n_filters == 3 && tflt == 1 && alias == 3 && !ratio && trk_opt("TRK_CF_CV1")) {
+                k4 = k_call_filter_v4<3, 1, true, false, 3, 2, 1>;
+                cv1 = true;
+            }
             // LDS: the block's delta table + class LUT + locus info, and one queue per wave -- within 32 KiB, so that
             // five workgroups fit a CU
             if (delta) {
@@ -4441,7 +4482,9 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             int occ = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k4, CF_THREADS, (size_t)lpb * per_locus4 + qbytes + 8) != hipSuccess || occ < 1)
                 occ = 4;
-            const CfLaunch cl = cf_geometry(L, gx, lpb, n_cu, occ, compact ? V4_PD : 1);   // (the prefetch ring: whole turns)
+            // (the compact build: two chunks per thread, i.e. column tiles of 2048 samples; blocks of whole ring turns)
+            const int gxl = (compact && n_filters <= V4_CV_MAXNF && !cv1) ? (S + 2 * CF_THREADS * CF_V - 1) / (2 * CF_THREADS * CF_V) : gx;
+            const CfLaunch cl = cf_geometry(L, gxl, lpb, n_cu, occ, compact ? V4_PD : 1);
             lpb = cl.lpb;
             const size_t lds4 = delta ? (((size_t)lpb * per_locus4 + 7) & ~(size_t)7) + qbytes : 0;
             v.loci_per_block = lpb;
@@ -4459,7 +4502,7 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             }
             if (trk_opt("TRK_CF_VERBOSE"))
                 fprintf(stderr, "k_call_filter_v4<%d,%d,%d,%d,%d,%d>: L %d gx %d lpb %d walk %d ranges %d map %d grid %u x %u, lds %zu B, "
-                                "occupancy %d WG/CU\n", n_filters, tflt, (int)delta, (int)ratio, alias, compact ? 2 : 0, L, gx, lpb, cl.geom.walk,
+                                "occupancy %d WG/CU\n", n_filters, tflt, (int)delta, (int)ratio, alias, compact ? 2 : 0, L, gxl, lpb, cl.geom.walk,
                         cl.geom.n_ranges, cl.geom.map, cl.grid.x, cl.grid.y, lds4, occ);
             hipLaunchKernelGGL(k4, cl.grid, dim3(CF_THREADS), lds4, stream, v);
             if (v.part16) {

@@ -383,6 +383,12 @@ struct Source {
     uint64_t end_coff = UINT64_MAX;
     size_t limit_pos = SIZE_MAX;
     uint64_t n_inflated = 0, n_compressed = 0, n_blocks = 0;   // counters: bytes out / in, blocks
+    // trk_vcf_set_inflate_hook: the members are inflated by the caller (on the device); the text buffer then holds the
+    // heads of the lines only and the newlines come from the hook
+    trk_vcf_inflate_hook hook = {nullptr, nullptr, nullptr};
+    uint64_t abs_end = 0;             // stream offset of the end of the text handed to the reader so far
+    int line_state = 0;               // tabs seen in the unfinished last line (the hook's carry)
+    std::vector<uint64_t> dev_nls;    // newlines reported and not yet behind the reader: stream offsets | bit 63 = after '\r'
 
     bool open(const char* path, int threads, std::string& err) {
         n_threads = threads;
@@ -576,6 +582,32 @@ struct Source {
         out.resize(base + total);
         const double ti0 = now();
         t_resize += ti0 - tr0;
+        if (hook.inflate) {
+            std::vector<trk_vcf_iblock> ib(blks.size());
+            const size_t c0 = blks[0].off;
+            for (size_t i = 0; i < blks.size(); ++i) {
+                const unsigned char* h = cbuf.data() + blks[i].off;
+                const size_t xlen = (size_t)h[10] | ((size_t)h[11] << 8);
+                ib[i].payload_off = blks[i].off - c0 + 12 + xlen;
+                ib[i].payload_len = (uint32_t)(blks[i].csize - 12 - xlen - 8);
+                ib[i].isize = (uint32_t)blks[i].isize;
+                ib[i].dst = blks[i].dst;
+            }
+            const uint64_t* nl = nullptr;
+            size_t n_nl = 0;
+            const int rc = hook.inflate(hook.user, cbuf.data() + c0, p - c0, ib.data(), (int)ib.size(), abs_end, total,
+                                        total ? &out[base] : nullptr, &line_state, &nl, &n_nl);
+            t_inflate += now() - ti0;
+            if (rc != 0) {
+                err = "the inflate hook failed (" + std::to_string(rc) + ")";
+                return false;
+            }
+            for (size_t i = 0; i < n_nl; ++i) dev_nls.push_back(((nl[i] & ~(1ull << 63)) + abs_end) | (nl[i] & (1ull << 63)));
+            abs_end += total;
+            cpos = p;
+            if (cpos == cbuf.size() && src_eof) eof = true;
+            return true;
+        }
         std::atomic<size_t> next{0};
         std::atomic<bool> bad{false};
         auto work = [&]() {
@@ -679,6 +711,7 @@ struct trk_vcf {
     // trk_vcf_set_sample_map: sample s of the file -> column sample_map[s] of trk_vcf_batch.gt_mapped (-1: dropped)
     std::vector<int32_t> sample_map;
     int map_out = 0;
+    uint64_t abs0 = 0;                 // inflate hook: stream offset of buf[0]
 };
 
 namespace {
@@ -1121,6 +1154,10 @@ int trk_vcf_open(const char* path, int n_threads, trk_vcf** out) {
 
 int trk_vcf_seek(trk_vcf* v, uint64_t voffset) {
     if (!v) return 2;
+    if (v->src.hook.inflate) {
+        v->err = "no seek while an inflate hook is installed";
+        return 1;
+    }
     if (!v->src.bgzf || !v->src.fp) {
         v->err = "seek needs a BGZF (bgzip) file";
         return 1;
@@ -1291,6 +1328,10 @@ int last_byte_before(FILE* fp, uint64_t b, uint64_t fsize) {
 extern "C" int trk_vcf_shard(trk_vcf* v, int rank, int world, uint64_t* begin_off, uint64_t* end_off) {
     if (!v || world < 1 || rank < 0 || rank >= world) return 2;
     if (world == 1) return 0;
+    if (v->src.hook.inflate) {
+        v->err = "no shard while an inflate hook is installed";
+        return 1;
+    }
     if (!v->src.fp || !(v->src.bgzf || v->src.plain)) {
         v->err = "contiguous shards need a BGZF (bgzip) or plain-text file";
         return 1;
@@ -1404,7 +1445,14 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
         if (tail) memcpy(v->prev_text.data(), v->buf.data() + v->pos, tail);
         v->buf.swap(v->prev_text);
         if (v->src.limit_pos != SIZE_MAX) v->src.limit_pos = v->src.limit_pos > v->pos ? v->src.limit_pos - v->pos : 0;
+        v->abs0 += v->pos;
         v->pos = 0;
+    }
+    const bool hooked = v->src.hook.inflate != nullptr;
+    if (hooked) {   // newlines behind the reader are done with
+        size_t k = 0;
+        while (k < v->src.dev_nls.size() && (v->src.dev_nls[k] & ~(1ull << 63)) < v->abs0) ++k;
+        if (k) v->src.dev_nls.erase(v->src.dev_nls.begin(), v->src.dev_nls.begin() + (ptrdiff_t)k);
     }
     v->line_off.clear();
     v->line_end.clear();
@@ -1434,12 +1482,22 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
     // of indexed text (a 60 KB record is one memchr over 60 KB: 200 MB per batch of 3355 records at 5000 samples was
     // 5-7 ms on the reader's one thread, next to 9 ms of inflate on 32).  Nothing is kept between calls: the text that
     // stays behind the batch's last line (at most one fill) is indexed again by the next call.
-    std::vector<size_t> nls;
-    size_t nls_i = 0, nls_to = scan;
+    std::vector<size_t> nls;          // (inflate hook: bit 63 of an entry = the byte before the newline is '\r')
+    constexpr size_t CR_BIT = (size_t)1 << 63;
+    size_t nls_i = 0, nls_to = scan, hook_i = 0;
     auto index_more = [&]() {
         const size_t a = nls_to, b = v->buf.size();
         nls_to = b;
         if (b <= a) return;
+        if (hooked) {    // the text holds line heads only: the newlines are the hook's
+            for (; hook_i < v->src.dev_nls.size(); ++hook_i) {
+                const uint64_t e = v->src.dev_nls[hook_i];
+                const uint64_t off = (e & ~(1ull << 63)) - v->abs0;
+                if (off >= b) break;
+                if (off >= a) nls.push_back((size_t)off | ((e >> 63) ? CR_BIT : 0));
+            }
+            return;
+        }
         const char* base = v->buf.data();
         constexpr size_t CH = 1u << 20;
         const size_t nch = (b - a + CH - 1) / CH;
@@ -1467,7 +1525,7 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
     };
     auto next_nl = [&](size_t from) -> size_t {
         for (;;) {
-            while (nls_i < nls.size() && nls[nls_i] < from) ++nls_i;
+            while (nls_i < nls.size() && (nls[nls_i] & ~CR_BIT) < from) ++nls_i;
             if (nls_i < nls.size()) return nls[nls_i];
             if (nls_to >= v->buf.size()) return std::string::npos;
             index_more();
@@ -1483,6 +1541,10 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
             if (v->src.eof) {
                 if (scan < v->buf.size()) {  // last line without a newline
                     v->buf.push_back('\n');
+                    if (hooked) {
+                        v->src.dev_nls.push_back(v->abs0 + v->buf.size() - 1);
+                        v->src.abs_end += 1;
+                    }
                     continue;
                 }
                 break;
@@ -1492,8 +1554,10 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
             if (timing) t_fill += now() - tf;
             continue;
         }
+        const bool cr_flag = (nl & CR_BIT) != 0;
+        nl &= ~CR_BIT;
         size_t e = nl;
-        if (e > scan && v->buf[e - 1] == '\r') --e;
+        if (e > scan && (hooked ? cr_flag : v->buf[e - 1] == '\r')) --e;
         if (e > scan && !(v->sharded && v->buf[scan] == '#')) {  // skip blank lines (and, in a shard, the header)
             v->line_off.push_back((int64_t)scan);
             v->line_end.push_back((int64_t)e);
@@ -1563,6 +1627,56 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
     out->field_off = kp.field_off.data();
     return 0;
 }
+
+int trk_vcf_set_inflate_hook(trk_vcf* v, const trk_vcf_inflate_hook* hook) {
+    if (!v) return 2;
+    if (!hook || !hook->inflate) {
+        if (v->src.hook.inflate) {
+            v->err = "the inflate hook cannot be taken away again: the text holds line heads only";
+            return 2;
+        }
+        return 0;
+    }
+    if (!v->src.bgzf || !v->src.fp || v->sharded || v->src.end_coff != UINT64_MAX) {
+        v->err = "the inflate hook needs a BGZF file read from its start to its end (no shard, no seek)";
+        return 2;
+    }
+    if (!v->skip_samples) {
+        v->err = "the inflate hook needs trk_vcf_skip_samples: only the heads of the lines reach the host";
+        return 2;
+    }
+    // what has been inflated so far (the rest of trk_vcf_open's last fill) is real text: drop what is consumed, index its
+    // newlines and the tabs of its unfinished last line here, and hand it to the hook as the start of the stream
+    if (v->pos > 0) {
+        v->buf.erase(0, v->pos);
+        v->pos = 0;
+    }
+    v->abs0 = 0;
+    v->src.dev_nls.clear();
+    const char* b = v->buf.data();
+    const size_t n = v->buf.size();
+    size_t last = 0;
+    for (const char* q = b; (q = static_cast<const char*>(memchr(q, '\n', (size_t)(b + n - q)))) != nullptr; ++q) {
+        const size_t o = (size_t)(q - b);
+        v->src.dev_nls.push_back((uint64_t)o | ((o > 0 && q[-1] == '\r') ? (1ull << 63) : 0));
+        last = o + 1;
+    }
+    int tabs = 0;
+    for (size_t i = last; i < n && tabs < 9; ++i) tabs += b[i] == '\t';
+    v->src.line_state = tabs;
+    v->src.abs_end = n;
+    if (hook->seed) {
+        const int rc = hook->seed(hook->user, b, n);
+        if (rc != 0) {
+            v->err = "the inflate hook's seed failed (" + std::to_string(rc) + ")";
+            return 2;
+        }
+    }
+    v->src.hook = *hook;
+    return 0;
+}
+
+uint64_t trk_vcf_text_abs(trk_vcf* v) { return v ? v->abs0 : 0; }
 
 // The reader's two text buffers continue in the caller's memory (pinned pages: the batch's text is uploaded by plain DMA).
 // Call between two batches, when the previous batch's text is no longer needed: its bytes move.

@@ -889,6 +889,38 @@ class Engine:
                                        out.ptr, err.ptr))
         return out, err
 
+    def inflate_blocks(self, comp, in_off, in_len, out_off, out_len, text=None, text_bytes=None):
+        """trk_inflate_blocks (include/trk.h): BGZF members inflated on the device.  comp: the compressed bytes (host
+        bytes / uint8 array, or a DeviceArray); in_off / in_len: where each member's raw DEFLATE payload lies in comp;
+        out_off / out_len: where its text goes and how long it is (the member's ISIZE).  Returns (text DeviceArray uint8,
+        flags uint8 array on the host: 0 or _lib.INFLATE_* bits per member)."""
+        n = int(np.asarray(in_off).shape[0])
+        if isinstance(comp, DeviceArray):
+            comp_d, own = comp, False
+            n_comp = comp.nbytes
+        else:
+            host = np.frombuffer(comp, dtype=np.uint8) if not isinstance(comp, np.ndarray) else comp.view(np.uint8).reshape(-1)
+            n_comp = int(host.shape[0])
+            comp_d = self.empty((n_comp + 64,), np.uint8)
+            if n_comp:
+                self._chk(self.lib.trk_memcpy_h2d(self.ctx, comp_d.ptr, host.ctypes.data, n_comp))
+            own = True
+        oo = np.ascontiguousarray(out_off, dtype=np.int64)
+        ol = np.ascontiguousarray(out_len, dtype=np.int32)
+        if text is None:
+            need = int((oo + ol).max()) if n else 0
+            text = self.empty((max(need if text_bytes is None else int(text_bytes), 16) + 32,), np.uint8)
+        io, il = self.upload(np.ascontiguousarray(in_off, dtype=np.int64), np.int64), self.upload(np.ascontiguousarray(in_len, dtype=np.int32), np.int32)
+        oo_d, ol_d = self.upload(oo, np.int64), self.upload(ol, np.int32)
+        flags = self.empty((max(n, 1),), np.uint8)
+        pin = L.InflateIn(comp_d.ptr, n_comp, n, 0, io.ptr, il.ptr, oo_d.ptr, ol_d.ptr)
+        pout = L.InflateOut(text.ptr, flags.ptr)
+        self._chk(self.lib.trk_inflate_blocks(self.ctx, C.byref(pin), C.byref(pout)))
+        fl = flags.get()[:n]
+        for a in [io, il, oo_d, ol_d, flags] + ([comp_d] if own else []):
+            a.free()
+        return text, fl
+
     def parse_samples(self, text, smp_off, line_end, n_samples, ploidy, gt_idx, planes=(), want_phased=False):
         """trk_parse_samples (include/trk.h): the sample columns of L records parsed on the device.
         text: the batch's text (bytes / uint8 array on the host, or a DeviceArray that is 16-byte aligned and padded by
