@@ -615,6 +615,19 @@ typedef struct {
 } trk_inflate_out;
 int trk_inflate_blocks(trk_ctx* ctx, const trk_inflate_in* in, const trk_inflate_out* out);
 
+/* The native reader's inflate hook (include/trk_vcf.h: trk_vcf_set_inflate_hook) served by this context's device: every
+ * run of BGZF members the reader reads goes to the device compressed, is inflated there into a segment of text that
+ * STAYS in HBM, is indexed there (newlines; the ninth tab of every line) and only the newlines and the heads of the lines
+ * go back to the host.  trk_inflate_hook hands out the three values of a trk_vcf_inflate_hook {user, seed, inflate};
+ * trk_inflate_text copies bytes [abs_from, abs_from + n_bytes) of the file's text (trk_vcf_text_abs + an offset into
+ * trk_vcf_batch.text) from the segments to dst (device) -- the text trk_parse_samples / trk_format_samples read -- and
+ * lets go of the segments that end at or before release_before.  A member the kernel flags is inflated by zlib inside
+ * the hook.  trk_inflate_stats: {members, of which flagged, bytes of text, compressed bytes, hook calls}.  The hook runs
+ * on the queue of the thread that reads (trk_thread_queue); one reader per context at a time. */
+int trk_inflate_hook(trk_ctx* ctx, void** user, void** seed_fn, void** inflate_fn);
+int trk_inflate_text(trk_ctx* ctx, uint64_t abs_from, int64_t n_bytes, void* dst, uint64_t release_before);
+int trk_inflate_stats(trk_ctx* ctx, uint64_t out[5]);
+
 /* ---- dumpSTR's sample columns written on the device (round 4; the host form is trk_vcf_dumpstr_records' span writer) ----
  * Per sample: a tab, then the token as it stands (+ ':.' per FORMAT key it lacks) + ':PASS' / ':NOCALL', or for a filtered
  * call the nulled token + ':' + '<filter>_<value>,...' (dumpSTR.py:648-683, 715-746).  A kept token is copied only when

@@ -1,0 +1,206 @@
+"""The native reader's inflate hook (include/trk_vcf.h: trk_vcf_set_inflate_hook) with a hook written in Python: the
+members are inflated by zlib HERE, the hook hands back the newlines and copies only the HEADS of the lines into the
+reader's text buffer -- every other byte of it is poisoned -- exactly what the device hook of trk_api.hip does.  The
+batches the reader then returns (lines, field offsets, FORMAT key indices, harmonised alleles) must equal the ones of
+a plain read of the same file, whatever the fill boundaries cut through (heads, CRLF pairs, the last line without a
+newline).  CPU only: this pins the reader's half of the device-inflate path."""
+import ctypes as C
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN
+
+SEED_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class IBlock(C.Structure):
+    _fields_ = [('payload_off', C.c_uint64), ('payload_len', C.c_uint32), ('isize', C.c_uint32), ('dst', C.c_uint64)]
+
+
+INFLATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(IBlock), C.c_int, C.c_uint64, C.c_size_t,
+                         C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_size_t))
+
+
+class PyHook:
+    """zlib inflate + line index + heads, with the carry of the unfinished line between calls."""
+
+    def __init__(self):
+        self.text = bytearray()          # the whole stream (what a device keeps in its segments)
+        self.keep = []
+        self.calls = 0
+
+        def seed(user, text, n):
+            self.text += C.string_at(text, n)
+            return 0
+
+        def inflate(user, comp, comp_bytes, blocks, n_blocks, abs_base, total, out, line_state, nl, n_nl):
+            self.calls += 1
+            assert abs_base == len(self.text)
+            raw = C.string_at(comp, comp_bytes)
+            seg = bytearray(total)
+            for i in range(n_blocks):
+                b = blocks[i]
+                d = zlib.decompress(raw[b.payload_off:b.payload_off + b.payload_len], -15)
+                assert len(d) == b.isize
+                seg[b.dst:b.dst + b.isize] = d
+            self.text += seg
+            # poison the reader's buffer, then put the heads where they belong
+            if total:
+                C.memset(out, 0xEE, total)
+            tabs = line_state[0]
+            pos, nls = 0, []
+            seg_b = bytes(seg)
+            while True:
+                e = seg_b.find(b'\n', pos)
+                end = e if e >= 0 else total
+                # head of [pos, end): up to and including tab number 9 - tabs
+                k, he = pos, None
+                need = 9 - tabs
+                if need <= 0:
+                    he = pos
+                else:
+                    found = 0
+                    while found < need:
+                        t = seg_b.find(b'\t', k, end)
+                        if t < 0:
+                            break
+                        found += 1
+                        k = t + 1
+                    he = k if found == need else end
+                    tabs_now = min(9, tabs + found)
+                if he > pos:
+                    C.memmove(out + pos, seg_b[pos:he], he - pos)
+                if e < 0:
+                    line_state[0] = 9 if need <= 0 else tabs_now
+                    break
+                nls.append(e | ((1 << 63) if e > 0 and seg_b[e - 1:e] == b'\r' else 0))
+                tabs = 0
+                pos = e + 1
+            arr = (C.c_uint64 * max(len(nls), 1))(*nls)
+            self.keep = [arr]
+            nl[0] = C.cast(arr, C.POINTER(C.c_uint64))
+            n_nl[0] = len(nls)
+            return 0
+        self._seed, self._inflate = SEED_FN(seed), INFLATE_FN(inflate)
+
+    def struct(self):
+        from trtools_amd.vcfnative import _InflateHook
+        return _InflateHook(None, C.cast(self._seed, C.c_void_p).value, C.cast(self._inflate, C.c_void_p).value)
+
+
+def _batches(path, hooked, batch_records, keys=('DP', 'Q')):
+    """(per record: head text, line length, field offsets, fmt idx), harmonised lists -- read with or without a hook."""
+    from trtools_amd import vcfnative
+    r = vcfnative.NativeVCFReader(path, batch_records=batch_records)
+    for k in keys:
+        if k in r.format_types:
+            r.select_format(k)
+    r._lib.trk_vcf_skip_samples(r._h, 1)
+    hook = None
+    if hooked:
+        hook = PyHook()
+        hs = hook.struct()
+        assert r._lib.trk_vcf_set_inflate_hook(r._h, C.byref(hs)) == 0, r._lib.trk_vcf_last_error(r._h)
+        r._keep_hook = (hook, hs)
+    out, absolute = [], []
+    while True:
+        rb = r._read_raw_batch(batch_records)
+        if rb.n == 0:
+            break
+        b = rb.b
+        stride = C.c_int32()
+        fptr = r._lib.trk_vcf_format_idx(r._h, C.byref(stride))
+        fi = np.ctypeslib.as_array(C.cast(fptr, C.POINTER(C.c_int8)), shape=(rb.n, stride.value)).copy()
+        abs0 = int(r._lib.trk_vcf_text_abs(r._h))
+        for l in range(rb.n):
+            fo = [int(b.field_off[l * 10 + k]) for k in range(10)]
+            head = C.string_at(b.text + b.line_off[l], fo[9] if fo[9] > 0 else b.line_end[l] - b.line_off[l])
+            out.append((head, int(b.line_end[l] - b.line_off[l]), tuple(fo), tuple(fi[l])))
+            absolute.append((abs0 + int(b.line_off[l]), abs0 + int(b.line_end[l])))
+        hz = rb.harmonize('hipstr') if 'hipstr' in os.path.basename(path) else None
+        if hz is not None:
+            out.append(('hz', tuple(map(str, hz.lists()[:3]))))
+    r.close()
+    return out, absolute, hook
+
+
+FILES = [os.path.join(GOLDEN, 'dumpstr_synth', f) for f in ('synth_hipstr.vcf.gz', 'synth_gangstr.vcf.gz')
+         if os.path.exists(os.path.join(GOLDEN, 'dumpstr_synth', f))]
+
+
+def _bgzip(tmp_path, name, text, level=6):
+    from trtools_amd.bgzf import BgzfWriter
+    p = str(tmp_path / name)
+    with BgzfWriter(p, threads=1) as fh:
+        fh.write(text)
+    return p
+
+
+def _synthetic(n_rec, S, crlf=False, last_newline=True, seed=0):
+    rng = np.random.default_rng(seed)
+    nl = '\r\n' if crlf else '\n'
+    hdr = ['##fileformat=VCFv4.2', '##command=HipSTR-v0.6.2 x', '##INFO=<ID=START,Number=1,Type=Integer,Description="s">',
+           '##INFO=<ID=END,Number=1,Type=Integer,Description="e">', '##INFO=<ID=PERIOD,Number=1,Type=Integer,Description="p">',
+           '##FORMAT=<ID=GT,Number=1,Type=String,Description="g">', '##FORMAT=<ID=DP,Number=1,Type=Integer,Description="d">',
+           '##FORMAT=<ID=Q,Number=1,Type=Float,Description="q">',
+           '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t' + '\t'.join('s%d' % i for i in range(S))]
+    lines = []
+    for r in range(n_rec):
+        cols = ['%d|%d:%d:0.%02d' % (rng.integers(0, 3), rng.integers(0, 3), rng.integers(0, 90), rng.integers(0, 100)) for _ in range(S)]
+        alt = ','.join('AC' * int(k) for k in rng.integers(1, 40, size=int(rng.integers(1, 5))))
+        lines.append('\t'.join(['chr1', str(1000 + 37 * r), 'id%d' % r, 'ACAC', alt, '.', '.', 'START=%d;END=%d;PERIOD=2' % (1000 + 37 * r, 1003 + 37 * r),
+                                'GT:DP:Q'] + cols))
+    text = nl.join(hdr + lines) + (nl if last_newline else '')
+    return text.encode()
+
+
+@pytest.mark.parametrize("case", ["long rows", "short rows", "crlf", "no last newline", "one record"])
+def test_hooked_read_equals_the_plain_read(tmp_path, case):
+    text = {"long rows": lambda: _synthetic(40, 6000, seed=1), "short rows": lambda: _synthetic(3000, 3, seed=2),
+            "crlf": lambda: _synthetic(60, 900, crlf=True, seed=3), "no last newline": lambda: _synthetic(25, 700, last_newline=False, seed=4),
+            "one record": lambda: _synthetic(1, 5, seed=5)}[case]()
+    path = _bgzip(tmp_path, 'f.vcf.gz', text)
+    from trtools_amd import _lib as L
+    for br, min_read in ((7, 70000), (64, 300000), (16, 8 << 20)):
+        # (small reads of the compressed file, so that a file of a few megabytes takes many fills: members, heads and
+        # CRLF pairs cut by the fill boundaries)
+        with L.options(TRK_VCF_READ_BYTES=min_read):
+            plain, abs_p, _ = _batches(path, False, br)
+            hooked, abs_h, hook = _batches(path, True, br)
+        assert len(plain) == len(hooked) and len(plain) > 0
+        for a, b in zip(plain, hooked):
+            assert a == b
+        # the absolute offsets the hooked reader reports point at the lines in the hook's copy of the stream
+        full = bytes(hook.text)
+        recs = [x for x in hooked if x[0] != 'hz']
+        for (lo, le), rec in zip(abs_h, recs):
+            assert full[lo:lo + len(rec[0])] == rec[0] and (le == len(full) or full[le:le + 1] in (b'\n', b'\r'))
+        assert hook.calls >= (1 if min_read < (1 << 20) and len(text) > 2000000 else 0)
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_hooked_read_of_the_fixtures(path):
+    from trtools_amd import _lib as L
+    with L.options(TRK_VCF_READ_BYTES=20000):
+        plain, _, _ = _batches(path, False, 16)
+        hooked, _, hook = _batches(path, True, 16)
+    assert plain == hooked and len(plain) > 10
+
+
+def test_hook_is_refused_where_it_cannot_work(tmp_path):
+    from trtools_amd import vcfnative
+    text = _synthetic(10, 5)
+    plain = str(tmp_path / 'p.vcf')
+    open(plain, 'wb').write(text)
+    r = vcfnative.NativeVCFReader(plain)
+    r._lib.trk_vcf_skip_samples(r._h, 1)
+    hs = PyHook().struct()
+    assert r._lib.trk_vcf_set_inflate_hook(r._h, C.byref(hs)) != 0          # not BGZF
+    r.close()
+    path = _bgzip(tmp_path, 'g.vcf.gz', text)
+    r = vcfnative.NativeVCFReader(path)
+    assert r._lib.trk_vcf_set_inflate_hook(r._h, C.byref(hs)) != 0          # the samples are not skipped
+    r.close()

@@ -18,7 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--loci', type=int, default=100000)
 ap.add_argument('--samples', type=int, default=10000)
 ap.add_argument('--iters', type=int, default=4)
-ap.add_argument('which', nargs='*', default=['full', 'compact', 'compact_cv1', 'compact', 'compact_cv1', 'hipstr5', 'hipstr5c'])
+ap.add_argument('which', nargs='*', default=['full', 'compact', 'compact_cv2', 'compact', 'compact_cv2', 'hipstr5', 'hipstr5c'])
 a = ap.parse_args()
 eng = Engine(0)
 sb = SynthBatch(eng, a.loci, a.samples, seed=20260931, planes=('dp', 'q', 'dstutter', 'dflankindel'))
@@ -36,8 +36,8 @@ print("bare stream of the full pass on this box (k_stream_probe, reserved pair %
 _o.gt_out.free(); _o.filter_mask.free()
 for w in a.which:
     filters = f5 if w.startswith('hipstr5') else f3
-    compact = w in ('compact', 'hipstr5c', 'compact_cv1')
-    L.set_option('TRK_CF_CV1', '1' if w == 'compact_cv1' else None)
+    compact = w in ('compact', 'hipstr5c', 'compact_cv2')
+    L.set_option('TRK_CF_CV2', '1' if w == 'compact_cv2' else None)
     out = eng.alloc_call_out(sb.batch, len(filters), want_gt=not compact, want_mask=not compact, want_mask8=compact)
     eng.profile(True)
     for it in range(a.iters + 1):

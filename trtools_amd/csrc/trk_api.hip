@@ -8,13 +8,16 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <zlib.h>
 #include <cmath>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/trk.h"
 #include "../../include/trk_test.h"
+#include "../../include/trk_vcf.h"
 #include "trk_binom.h"
 #include "trk_student.h"
 #include "trk_internal.h"
@@ -78,6 +81,9 @@ struct ProfRec {
 // trk_thread_queue: the queue of the CALLING thread, when it has asked for one of its own (-1: the selected queue)
 static thread_local int t_queue = -1;
 
+struct InflateState;
+static void inflate_state_free(InflateState* st);
+
 struct trk_ctx {
     int device = 0;
     int n_cu = 256;
@@ -111,6 +117,7 @@ struct trk_ctx {
     ncclComm_t comm = nullptr;
     int rank = 0, n_ranks = 1;
     // the reserved pair of output planes (trk_reserve_pair): owned by the context, lent out by trk_dev_alloc_pair
+    struct InflateState* inflate = nullptr;   // the reader's inflate hook served by this context (trk_inflate_hook)
     void* res_plane[2] = {nullptr, nullptr};
     size_t res_bytes = 0;
     bool res_lent[2] = {false, false};
@@ -259,6 +266,7 @@ void trk_free(trk_ctx* ctx) {
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
     for (int k = 0; k < 2; ++k)
         if (ctx->res_plane[k]) (void)hipFree(ctx->res_plane[k]);
+    if (ctx->inflate) inflate_state_free(ctx->inflate);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < TRK_N_TIMERS; ++i) {
         (void)hipEventDestroy(ctx->t_start[i]);
@@ -899,6 +907,286 @@ int trk_inflate_blocks(trk_ctx* ctx, const trk_inflate_in* in, const trk_inflate
     (void)hipSetDevice(ctx->device);
     ProfScope ps(ctx, TRK_K_SYNTH);      // (the "generate the inputs" slot of the profile)
     HIPCHK(ctx, trk::launch_inflate(*in, *out, ctx->n_cu, ctx->s()));
+    return TRK_OK;
+}
+
+// ---- the native reader's inflate hook, served by the device (include/trk_vcf.h: trk_vcf_set_inflate_hook) ----------
+// A run of BGZF members goes to the device compressed, is inflated there (trk_inflate.hip) into a SEGMENT of text that
+// stays in HBM, and the host gets back what it reads of a batch: the newlines and the heads of the lines.  The sample
+// columns are never text on the host; trk_inflate_text copies a batch's span of the stream out of the segments for the
+// parse / format kernels.  Called from the reader's thread (its own queue through trk_thread_queue); one reader per
+// context at a time.
+struct InfSeg {
+    uint64_t abs;      // stream offset of the segment's first byte
+    size_t n;          // bytes of text
+    uint8_t* d;
+    size_t cap;
+};
+struct InflateState {
+    trk_ctx* ctx = nullptr;
+    std::deque<InfSeg> segs;
+    std::vector<std::pair<uint8_t*, size_t>> spare;     // segment buffers to use again
+    uint8_t* d_comp = nullptr;
+    size_t comp_cap = 0;
+    uint8_t* d_tab = nullptr;
+    size_t tab_cap = 0;
+    uint8_t* d_ws = nullptr;       // line-index workspace
+    size_t ws_cap = 0;
+    uint8_t* h_stage = nullptr;    // pinned: tables up, results down
+    size_t h_cap = 0;
+    std::vector<uint64_t> nl_host;
+    uint64_t n_blocks = 0, n_flagged = 0, n_text = 0, n_comp = 0, n_calls = 0;
+};
+static void inflate_state_free(InflateState* st) {
+    for (auto& sg : st->segs) (void)hipFree(sg.d);
+    for (auto& sp : st->spare) (void)hipFree(sp.first);
+    if (st->d_comp) (void)hipFree(st->d_comp);
+    if (st->d_tab) (void)hipFree(st->d_tab);
+    if (st->d_ws) (void)hipFree(st->d_ws);
+    if (st->h_stage) (void)hipHostFree(st->h_stage);
+    delete st;
+}
+static bool inf_grow_dev(uint8_t*& p, size_t& cap, size_t need) {
+    if (cap >= need) return true;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = need + need / 4 + 4096;
+    if (hipMalloc((void**)&p, want) != hipSuccess) { (void)hipGetLastError(); return false; }
+    cap = want;
+    return true;
+}
+static bool inf_grow_host(InflateState* st, size_t need) {
+    if (st->h_cap >= need) return true;
+    if (st->h_stage) (void)hipHostFree(st->h_stage);
+    st->h_stage = nullptr;
+    st->h_cap = 0;
+    const size_t want = need + need / 4 + 65536;
+    if (hipHostMalloc((void**)&st->h_stage, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+    st->h_cap = want;
+    return true;
+}
+static uint8_t* inf_segment(InflateState* st, size_t need, size_t& cap) {
+    size_t best = SIZE_MAX;
+    for (size_t i = 0; i < st->spare.size(); ++i)
+        if (st->spare[i].second >= need && (best == SIZE_MAX || st->spare[i].second < st->spare[best].second)) best = i;
+    if (best != SIZE_MAX) {
+        uint8_t* p = st->spare[best].first;
+        cap = st->spare[best].second;
+        st->spare.erase(st->spare.begin() + (long)best);
+        return p;
+    }
+    uint8_t* p = nullptr;
+    const size_t want = need + need / 8 + 4096;
+    if (hipMalloc((void**)&p, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    cap = want;
+    return p;
+}
+static void inf_release(InflateState* st, const InfSeg& sg) {
+    if (st->spare.size() < 8) st->spare.emplace_back(sg.d, sg.cap);
+    else (void)hipFree(sg.d);
+}
+
+static int inf_seed(void* user, const char* text, size_t n) {
+    InflateState* st = static_cast<InflateState*>(user);
+    trk_ctx* ctx = st->ctx;
+    (void)hipSetDevice(ctx->device);
+    for (auto& sg : st->segs) inf_release(st, sg);
+    st->segs.clear();
+    if (n == 0) return 0;
+    size_t cap = 0;
+    uint8_t* d = inf_segment(st, n + 2048, cap);
+    if (!d) return TRK_ERR_NOMEM;
+    if (hipMemcpyAsync(d, text, n, hipMemcpyHostToDevice, ctx->s()) != hipSuccess || hipStreamSynchronize(ctx->s()) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(d);
+        return TRK_ERR_HIP;
+    }
+    st->segs.push_back({0, n, d, cap});
+    return 0;
+}
+
+static int inf_inflate(void* user, const unsigned char* comp, size_t comp_bytes, const trk_vcf_iblock* blocks, int n_blocks,
+                       uint64_t abs_base, size_t total, char* out, int* line_state, const uint64_t** nl, size_t* n_nl) {
+    InflateState* st = static_cast<InflateState*>(user);
+    trk_ctx* ctx = st->ctx;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t q = ctx->s();
+    *nl = nullptr;
+    *n_nl = 0;
+    ++st->n_calls;
+    if (total == 0 || n_blocks <= 0) return 0;            // (members without text: the end-of-file marker)
+    const size_t nb = (size_t)n_blocks;
+    // tables: in_off, out_off (int64), in_len, out_len (int32), then the flags
+    const size_t tab_bytes = nb * 24, flag_off = (tab_bytes + 15) & ~(size_t)15;
+    if (!inf_grow_dev(st->d_comp, st->comp_cap, comp_bytes + 64) || !inf_grow_dev(st->d_tab, st->tab_cap, flag_off + nb + 16)) return TRK_ERR_NOMEM;
+    const size_t n_tiles = (total + 16383) / 16384;
+    const size_t nl_cap = total / 16 + 1024;
+    // workspace: counts, scalars (n_nl, head_total, state), nl, head_off, head_len, pack_off, packed
+    size_t o_counts = 0, o_scal = (o_counts + (n_tiles + 1) * 4 + 15) & ~(size_t)15, o_nl = o_scal + 64, o_hoff = o_nl + nl_cap * 8,
+           o_hlen = o_hoff + (nl_cap + 1) * 8, o_poff = (o_hlen + (nl_cap + 1) * 4 + 15) & ~(size_t)15,
+           o_pack = (o_poff + (nl_cap + 1) * 4 + 15) & ~(size_t)15, ws_bytes = o_pack + total + 64;
+    if (!inf_grow_dev(st->d_ws, st->ws_cap, ws_bytes)) return TRK_ERR_NOMEM;
+    if (!inf_grow_host(st, std::max(flag_off + nb + 64, (size_t)4096))) return TRK_ERR_NOMEM;
+    size_t seg_cap = 0;
+    uint8_t* seg = inf_segment(st, total + 2048, seg_cap);
+    if (!seg) return TRK_ERR_NOMEM;
+    auto bail = [&](int code) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(q);
+        st->spare.emplace_back(seg, seg_cap);
+        return code;
+    };
+    int64_t* t_in_off = reinterpret_cast<int64_t*>(st->h_stage);
+    int64_t* t_out_off = t_in_off + nb;
+    int32_t* t_in_len = reinterpret_cast<int32_t*>(t_out_off + nb);
+    int32_t* t_out_len = t_in_len + nb;
+    for (size_t i = 0; i < nb; ++i) {
+        if (blocks[i].payload_off + blocks[i].payload_len > comp_bytes || blocks[i].dst + blocks[i].isize > total) return bail(TRK_ERR_ARG);
+        t_in_off[i] = (int64_t)blocks[i].payload_off;
+        t_out_off[i] = (int64_t)blocks[i].dst;
+        t_in_len[i] = (int32_t)blocks[i].payload_len;
+        t_out_len[i] = (int32_t)blocks[i].isize;
+    }
+    if (hipMemcpyAsync(st->d_comp, comp, comp_bytes, hipMemcpyHostToDevice, q) != hipSuccess) return bail(TRK_ERR_HIP);
+    if (hipMemcpyAsync(st->d_tab, st->h_stage, tab_bytes, hipMemcpyHostToDevice, q) != hipSuccess) return bail(TRK_ERR_HIP);
+    trk_inflate_in in = {};
+    in.comp = st->d_comp;
+    in.n_comp_bytes = (int64_t)comp_bytes;
+    in.n_blocks = n_blocks;
+    in.in_off = reinterpret_cast<const int64_t*>(st->d_tab);
+    in.out_off = in.in_off + nb;
+    in.in_len = reinterpret_cast<const int32_t*>(in.out_off + nb);
+    in.out_len = in.in_len + nb;
+    trk_inflate_out io = {seg, st->d_tab + flag_off};
+    if (trk::launch_inflate(in, io, ctx->n_cu, q) != hipSuccess) return bail(TRK_ERR_HIP);
+    uint8_t* h_flags = st->h_stage + flag_off;
+    if (hipMemcpyAsync(h_flags, st->d_tab + flag_off, nb, hipMemcpyDeviceToHost, q) != hipSuccess || hipStreamSynchronize(q) != hipSuccess)
+        return bail(TRK_ERR_HIP);
+    // members the kernel left: inflated here (zlib), their text copied in
+    for (size_t i = 0; i < nb; ++i) {
+        if (!h_flags[i]) continue;
+        ++st->n_flagged;
+        std::vector<unsigned char> tmp(blocks[i].isize ? blocks[i].isize : 1);
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) return bail(TRK_ERR_HIP);
+        zs.next_in = const_cast<unsigned char*>(comp + blocks[i].payload_off);
+        zs.avail_in = blocks[i].payload_len;
+        zs.next_out = tmp.data();
+        zs.avail_out = blocks[i].isize;
+        const int rc = inflate(&zs, Z_FINISH);
+        const bool okz = rc == Z_STREAM_END && zs.total_out == blocks[i].isize;
+        inflateEnd(&zs);
+        if (!okz) return bail(TRK_ERR_ARG);                 // a member nobody can inflate: the file is corrupt
+        if (blocks[i].isize && hipMemcpy(seg + blocks[i].dst, tmp.data(), blocks[i].isize, hipMemcpyHostToDevice) != hipSuccess)
+            return bail(TRK_ERR_HIP);
+    }
+    // the line index and the heads
+    trk::LineIndexWs ws;
+    ws.counts = reinterpret_cast<uint32_t*>(st->d_ws + o_counts);
+    uint32_t* scal = reinterpret_cast<uint32_t*>(st->d_ws + o_scal);
+    ws.n_nl = scal;
+    ws.head_total = scal + 1;
+    ws.state = reinterpret_cast<int32_t*>(scal + 2);
+    ws.nl = reinterpret_cast<uint64_t*>(st->d_ws + o_nl);
+    ws.nl_cap = (uint32_t)nl_cap;
+    ws.head_off = reinterpret_cast<uint64_t*>(st->d_ws + o_hoff);
+    ws.head_len = reinterpret_cast<uint32_t*>(st->d_ws + o_hlen);
+    ws.pack_off = reinterpret_cast<uint32_t*>(st->d_ws + o_poff);
+    ws.packed = st->d_ws + o_pack;
+    ws.packed_cap = (uint32_t)std::min<size_t>(total + 64, 0xffffffffu);
+    if (hipMemsetAsync(seg + total, '\n', 2048, q) != hipSuccess) return bail(TRK_ERR_HIP);     // (readable padding)
+    if (trk::launch_line_index(seg, (int64_t)total, *line_state, ws, q) != hipSuccess) return bail(TRK_ERR_HIP);
+    uint32_t* h_scal = reinterpret_cast<uint32_t*>(st->h_stage);
+    if (hipMemcpyAsync(h_scal, scal, 16, hipMemcpyDeviceToHost, q) != hipSuccess || hipStreamSynchronize(q) != hipSuccess) return bail(TRK_ERR_HIP);
+    const uint32_t n_found = h_scal[0], head_total = h_scal[1];
+    const int state = (int)h_scal[2];
+    if (n_found > nl_cap || head_total > ws.packed_cap) return bail(TRK_ERR_ARG);       // (lines of fewer than 16 bytes on average: not a VCF)
+    const size_t n_lines = (size_t)n_found + 1;
+    const size_t r_nl = 0, r_hoff = r_nl + (size_t)n_found * 8, r_hlen = r_hoff + n_lines * 8, r_pack = (r_hlen + n_lines * 4 + 15) & ~(size_t)15,
+                 r_bytes = r_pack + head_total;
+    if (!inf_grow_host(st, r_bytes + 64)) return bail(TRK_ERR_NOMEM);
+    hipError_t e = hipSuccess;
+    if (n_found) e = hipMemcpyAsync(st->h_stage + r_nl, ws.nl, (size_t)n_found * 8, hipMemcpyDeviceToHost, q);
+    if (e == hipSuccess) e = hipMemcpyAsync(st->h_stage + r_hoff, ws.head_off, n_lines * 8, hipMemcpyDeviceToHost, q);
+    if (e == hipSuccess) e = hipMemcpyAsync(st->h_stage + r_hlen, ws.head_len, n_lines * 4, hipMemcpyDeviceToHost, q);
+    if (e == hipSuccess && head_total) e = hipMemcpyAsync(st->h_stage + r_pack, ws.packed, head_total, hipMemcpyDeviceToHost, q);
+    if (e == hipSuccess) e = hipStreamSynchronize(q);
+    if (e != hipSuccess) return bail(TRK_ERR_HIP);
+    const uint64_t* h_nl = reinterpret_cast<const uint64_t*>(st->h_stage + r_nl);
+    const uint64_t* h_hoff = reinterpret_cast<const uint64_t*>(st->h_stage + r_hoff);
+    const uint32_t* h_hlen = reinterpret_cast<const uint32_t*>(st->h_stage + r_hlen);
+    const uint8_t* h_pack = st->h_stage + r_pack;
+    size_t at = 0;
+    for (size_t i = 0; i < n_lines; ++i) {
+        const size_t len = h_hlen[i];
+        if (h_hoff[i] + len > total || at + len > head_total) return bail(TRK_ERR_ARG);
+        if (len) memcpy(out + h_hoff[i], h_pack + at, len);
+        at += len;
+    }
+    st->nl_host.assign(h_nl, h_nl + n_found);
+    *nl = st->nl_host.data();
+    *n_nl = n_found;
+    *line_state = state;
+    st->segs.push_back({abs_base, total, seg, seg_cap});
+    st->n_blocks += nb;
+    st->n_text += total;
+    st->n_comp += comp_bytes;
+    return 0;
+}
+
+int trk_inflate_hook(trk_ctx* ctx, void** user, void** seed_fn, void** inflate_fn) {
+    if (!ctx || !user || !seed_fn || !inflate_fn) return TRK_ERR_ARG;
+    if (!ctx->inflate) {
+        ctx->inflate = new InflateState();
+        ctx->inflate->ctx = ctx;
+    }
+    *user = ctx->inflate;
+    *seed_fn = reinterpret_cast<void*>(&inf_seed);
+    *inflate_fn = reinterpret_cast<void*>(&inf_inflate);
+    return TRK_OK;
+}
+
+int trk_inflate_text(trk_ctx* ctx, uint64_t abs_from, int64_t n_bytes, void* dst, uint64_t release_before) {
+    if (!ctx || !ctx->inflate) return TRK_ERR_ARG;
+    if (n_bytes < 0 || (n_bytes > 0 && !dst)) return fail(ctx, TRK_ERR_ARG, "inflate_text: %lld bytes", (long long)n_bytes);
+    InflateState* st = ctx->inflate;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t q = ctx->s();
+    const uint64_t to = abs_from + (uint64_t)n_bytes;
+    uint64_t covered = abs_from;          // the segments are consecutive: everything below `covered` has been copied
+    for (const InfSeg& sg : st->segs) {
+        const uint64_t a = std::max<uint64_t>(sg.abs, abs_from), b = std::min<uint64_t>(sg.abs + sg.n, to);
+        if (a >= b) continue;
+        if (a != covered) return fail(ctx, TRK_ERR_ARG, "inflate_text: bytes %llu .. %llu of the stream are no longer (or not yet) on the device",
+                                      (unsigned long long)covered, (unsigned long long)a);
+        HIPCHK(ctx, hipMemcpyAsync(static_cast<uint8_t*>(dst) + (a - abs_from), sg.d + (a - sg.abs), (size_t)(b - a), hipMemcpyDeviceToDevice, q));
+        covered = b;
+    }
+    if (covered < to) {
+        // beyond the inflated text: the newline the reader appends to a last line without one
+        if (to - covered > 16) return fail(ctx, TRK_ERR_ARG, "inflate_text: %llu bytes beyond the inflated text", (unsigned long long)(to - covered));
+        HIPCHK(ctx, hipMemsetAsync(static_cast<uint8_t*>(dst) + (covered - abs_from), '\n', (size_t)(to - covered), q));
+    }
+    while (!st->segs.empty() && st->segs.front().abs + st->segs.front().n <= release_before) {
+        HIPCHK(ctx, hipStreamSynchronize(q));          // (its bytes may still be on their way out)
+        inf_release(st, st->segs.front());
+        st->segs.pop_front();
+    }
+    return TRK_OK;
+}
+
+int trk_inflate_stats(trk_ctx* ctx, uint64_t out[5]) {
+    if (!ctx || !out) return TRK_ERR_ARG;
+    for (int i = 0; i < 5; ++i) out[i] = 0;
+    if (ctx->inflate) {
+        out[0] = ctx->inflate->n_blocks;
+        out[1] = ctx->inflate->n_flagged;
+        out[2] = ctx->inflate->n_text;
+        out[3] = ctx->inflate->n_comp;
+        out[4] = ctx->inflate->n_calls;
+    }
     return TRK_OK;
 }
 

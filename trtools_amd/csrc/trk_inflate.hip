@@ -443,6 +443,217 @@ __global__ __launch_bounds__(64) void k_inflate_bgzf(const InfArgs a) {
     }
 }
 
+
+// ---- the line index of inflated text, and the heads of its lines (the reader's inflate hook, trk_api.hip) ----------
+// What the host side of a batch reads of a 60 KB record is its first hundred bytes: CHROM ... FORMAT.  With the text
+// inflated in HBM the host gets (a) where the newlines are and (b) those heads, packed; the sample columns never cross
+// PCIe as text.  Three steps over a segment of text: newlines counted per 16 KB tile, scanned, scattered in order
+// (k_nl_*); one wave per line looks for the line's ninth tab (k_line_heads); head lengths scanned, heads gathered.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int NL_TILE = 16384;     // bytes per workgroup of the newline passes: thread t owns 64 consecutive bytes
+
+__device__ __forceinline__ uint32_t eq_bytes(uint32_t x, uint32_t pattern) {   // 0x80 in every byte of x equal to the pattern's
+    const uint32_t t = x ^ pattern;
+    return ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t | 0x7f7f7f7fu);
+}
+
+// the 64 bytes of thread `tid` of tile `tile` as sixteen words, bytes at or beyond n zeroed
+__device__ __forceinline__ void load_slice(const uint8_t* text, int64_t n, int64_t at, uint32_t (&w)[16]) {
+    const u32x4* p = reinterpret_cast<const u32x4*>(text + at);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        u32x4 v = {0, 0, 0, 0};
+        if (at + 16 * k < n) v = p[k];      // (the segment is padded: a vector that starts inside it is readable)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t b = at + 16 * k + 4 * j;
+            uint32_t x = v[j];
+            if (b + 4 > n) x = b >= n ? 0u : (x & (0xffffffffu >> (8 * (int)(b + 4 - n))));
+            w[4 * k + j] = x;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nl_count(const uint8_t* text, int64_t n, uint32_t* counts) {
+    __shared__ uint32_t part[4];
+    const int64_t at = (int64_t)blockIdx.x * NL_TILE + threadIdx.x * 64;
+    uint32_t c = 0;
+    if (at < n) {
+        uint32_t w[16];
+        load_slice(text, n, at, w);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) c += __popc(eq_bytes(w[k], 0x0a0a0a0au));
+    }
+    for (int o = 32; o; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+// exclusive scan of counts[0 .. n) in place by ONE workgroup; total to *total
+__global__ __launch_bounds__(1024) void k_scan_u32(uint32_t* counts, int n, uint32_t* total) {
+    __shared__ uint32_t tot[1024];
+    const int per = (n + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(n, lo + per);
+    uint32_t sum = 0;
+    for (int i = lo; i < hi; ++i) sum += counts[i];
+    tot[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const uint32_t v = threadIdx.x >= (unsigned)o ? tot[threadIdx.x - o] : 0u;
+        __syncthreads();
+        tot[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = threadIdx.x ? tot[threadIdx.x - 1] : 0u;
+    for (int i = lo; i < hi; ++i) {
+        const uint32_t c = counts[i];
+        counts[i] = run;
+        run += c;
+    }
+    if (threadIdx.x == 1023) *total = tot[1023];
+}
+
+__global__ __launch_bounds__(256) void k_nl_scatter(const uint8_t* text, int64_t n, const uint32_t* offs, uint64_t* nl, uint32_t cap) {
+    __shared__ uint32_t cnt[256];
+    const int64_t at = (int64_t)blockIdx.x * NL_TILE + threadIdx.x * 64;
+    uint32_t w[16];
+    uint32_t c = 0;
+    if (at < n) {
+        load_slice(text, n, at, w);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) c += __popc(eq_bytes(w[k], 0x0a0a0a0au));
+    }
+    cnt[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const uint32_t v = threadIdx.x >= (unsigned)o ? cnt[threadIdx.x - o] : 0u;
+        __syncthreads();
+        cnt[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (!c) return;
+    uint32_t at_out = offs[blockIdx.x] + cnt[threadIdx.x] - c;
+#pragma unroll 1
+    for (int k = 0; k < 16; ++k) {
+        uint32_t z = eq_bytes(w[k], 0x0a0a0a0au);
+        while (z) {
+            const int b = (__ffs(z) - 1) >> 3;
+            z &= z - 1;
+            const int64_t pos = at + 4 * k + b;
+            if (at_out < cap) nl[at_out] = (uint64_t)pos | ((pos > 0 && text[pos - 1] == '\r') ? (1ull << 63) : 0ull);
+            ++at_out;
+        }
+    }
+}
+
+// One wave per line.  Line i = [start, end): start = 0 / nl[i - 1] + 1, end = nl[i] / n (the last, unfinished one).
+// The head of a line ends behind its ninth tab (the first line: behind tab 9 - tabs_in of what this segment holds of
+// it); a line with fewer tabs is all head.  head_len[i] bytes from head_off[i]; *state_out: the tabs (0 ... 9) seen
+// in the unfinished last line.
+__global__ __launch_bounds__(64) void k_line_heads(const uint8_t* text, int64_t n, const uint64_t* nl, const uint32_t* n_nl_p,
+                                                   int tabs_in, uint64_t* head_off, uint32_t* head_len, int32_t* state_out) {
+    const uint32_t n_nl = *n_nl_p;
+    const int lane = threadIdx.x;
+    for (uint32_t i = blockIdx.x; i <= n_nl; i += gridDim.x) {
+        const int64_t start = i == 0 ? 0 : (int64_t)(nl[i - 1] & ~(1ull << 63)) + 1;
+        const int64_t end = i < n_nl ? (int64_t)(nl[i] & ~(1ull << 63)) : n;
+        const int carried = i == 0 ? tabs_in : 0;
+        const int need = 9 - carried;
+        int found = 0;
+        int64_t head_end = end;
+        if (need <= 0) {
+            head_end = start;
+        } else {
+            for (int64_t base = start & ~(int64_t)15; base < end && found < need; base += 1024) {
+                const int64_t at = base + 16 * lane;
+                uint32_t m = 0;                                  // bit b: byte at + b is a tab inside [start, end)
+                if (at < end) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(text + at);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        uint32_t z = eq_bytes(v[j], 0x09090909u);
+                        m |= (((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u)) << (4 * j);
+                    }
+                    if (at < start) m &= 0xffffu << (int)(start - at);
+                    if (at + 16 > end) m &= 0xffffu >> (int)(at + 16 - end);
+                    m &= 0xffffu;
+                }
+                int c = __popc(m), inc = c;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v2 = __shfl_up(inc, o);
+                    if (lane >= o) inc += v2;
+                }
+                const int total = __shfl(inc, 63);
+                if (found + total >= need) {
+                    // the lane that holds tab number `need`: the k-th set bit of its mask
+                    const bool mine = found + inc >= need && found + inc - c < need;
+                    int64_t he = 0;
+                    if (mine) {
+                        int k = need - (found + inc - c);        // 1-based among this lane's tabs
+                        uint32_t mm = m;
+                        while (--k) mm &= mm - 1;
+                        he = at + (__ffs(mm) - 1) + 1;
+                    }
+                    const uint64_t who = __ballot(mine);
+                    const int src = __ffsll((unsigned long long)who) - 1;
+                    head_end = __shfl(he, src);
+                    found = need;
+                } else {
+                    found += total;
+                }
+            }
+        }
+        if (lane == 0) {
+            head_off[i] = (uint64_t)start;
+            head_len[i] = (uint32_t)(head_end - start);
+            if (i == n_nl) *state_out = min(9, carried + found);
+        }
+    }
+}
+
+// heads gathered back to back: pack_off = exclusive scan of head_len
+__global__ __launch_bounds__(64) void k_head_gather(const uint8_t* text, const uint64_t* head_off, const uint32_t* head_len,
+                                                    const uint32_t* pack_off, const uint32_t* n_nl_p, uint8_t* packed, uint32_t cap) {
+    const uint32_t n_lines = *n_nl_p + 1;
+    for (uint32_t i = blockIdx.x; i < n_lines; i += gridDim.x) {
+        const uint8_t* src = text + head_off[i];
+        const uint32_t len = head_len[i], o = pack_off[i];
+        for (uint32_t k = threadIdx.x; k < len; k += 64)
+            if (o + k < cap) packed[o + k] = src[k];
+    }
+}
+
+// exclusive scan of v[0 .. *n_nl_p] in place (one workgroup), total to *total
+__global__ __launch_bounds__(1024) void k_scan_lines(uint32_t* v, const uint32_t* n_nl_p, uint32_t* total) {
+    __shared__ uint32_t tot[1024];
+    const int n = (int)*n_nl_p + 1;
+    const int per = (n + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(n, lo + per);
+    uint32_t sum = 0;
+    for (int i = lo; i < hi; ++i) sum += v[i];
+    tot[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const uint32_t x = threadIdx.x >= (unsigned)o ? tot[threadIdx.x - o] : 0u;
+        __syncthreads();
+        tot[threadIdx.x] += x;
+        __syncthreads();
+    }
+    uint32_t run = threadIdx.x ? tot[threadIdx.x - 1] : 0u;
+    for (int i = lo; i < hi; ++i) {
+        const uint32_t c = v[i];
+        v[i] = run;
+        run += c;
+    }
+    if (threadIdx.x == 1023) *total = tot[1023];
+}
+
+__global__ void k_copy_u32(const uint32_t* src, uint32_t* dst, const uint32_t* n_nl_p) {   // dst[i] = src[i], i <= n_nl
+    const uint32_t n = *n_nl_p + 1;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 }  // namespace
 
 namespace trk {
@@ -451,6 +662,26 @@ hipError_t launch_inflate(const trk_inflate_in& in, const trk_inflate_out& out, 
     InfArgs a{in, out};
     const int grid = in.n_blocks < n_cu * 4 ? in.n_blocks : n_cu * 4;
     hipLaunchKernelGGL(k_inflate_bgzf, dim3(grid), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
+// The line index of text[0 .. n) and the heads of its lines (see k_line_heads).  All results stay on the device:
+//   ws.counts [n_tiles + 1] scratch, ws.n_nl (one word), ws.nl [nl_cap], ws.head_off / head_len / pack_off [nl_cap + 1],
+//   ws.head_total (one word), ws.state (one word), ws.packed [packed_cap]
+hipError_t launch_line_index(const uint8_t* text, int64_t n, int tabs_in, const LineIndexWs& ws, hipStream_t stream) {
+    const int n_tiles = (int)((n + NL_TILE - 1) / NL_TILE);
+    if (n_tiles < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_nl_count, dim3(n_tiles), dim3(256), 0, stream, text, n, ws.counts);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, stream, ws.counts, n_tiles, ws.n_nl);
+    hipLaunchKernelGGL(k_nl_scatter, dim3(n_tiles), dim3(256), 0, stream, text, n, ws.counts, ws.nl, ws.nl_cap);
+    const int lines_grid = 4096;
+    hipLaunchKernelGGL(k_line_heads, dim3(lines_grid), dim3(64), 0, stream, text, n, ws.nl, ws.n_nl, tabs_in, ws.head_off,
+                       ws.head_len, ws.state);
+    // pack_off = exclusive scan of head_len (a copy, scanned in place by one workgroup)
+    hipLaunchKernelGGL(k_copy_u32, dim3(256), dim3(256), 0, stream, ws.head_len, ws.pack_off, ws.n_nl);
+    hipLaunchKernelGGL(k_scan_lines, dim3(1), dim3(1024), 0, stream, ws.pack_off, ws.n_nl, ws.head_total);
+    hipLaunchKernelGGL(k_head_gather, dim3(lines_grid), dim3(64), 0, stream, text, ws.head_off, ws.head_len, ws.pack_off, ws.n_nl,
+                       ws.packed, ws.packed_cap);
     return hipGetLastError();
 }
 }  // namespace trk

@@ -18,6 +18,20 @@ namespace trk {
 hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* allele_count, int32_t* locus_int,
                               int n_cu, hipStream_t stream, bool twin, int32_t* class_ws);
 hipError_t launch_inflate(const trk_inflate_in& in, const trk_inflate_out& out, int n_cu, hipStream_t stream);
+struct LineIndexWs {     // device results / scratch of launch_line_index (trk_inflate.hip)
+    uint32_t* counts;    // [tiles of 16 KB + 1]
+    uint32_t* n_nl;      // newlines found
+    uint64_t* nl;        // [nl_cap] their offsets, bit 63: after a '\r'
+    uint32_t nl_cap;
+    uint64_t* head_off;  // [nl_cap + 1] per line (the last: the unfinished one)
+    uint32_t* head_len;
+    uint32_t* pack_off;
+    uint32_t* head_total;
+    int32_t* state;      // tabs seen in the unfinished last line
+    uint8_t* packed;     // the heads back to back
+    uint32_t packed_cap;
+};
+hipError_t launch_line_index(const uint8_t* text, int64_t n, int tabs_in, const LineIndexWs& ws, hipStream_t stream);
 hipError_t launch_permute_columns(const int16_t* src, int16_t* dst, const int32_t* col, int64_t n_loci, int n_src,
                                   int n_dst, int ploidy, int n_cu, hipStream_t stream);
 bool launch_locus_stats_fused(const trk_batch& b, int32_t* allele_count, int32_t* locus_int, double* locus_f64,

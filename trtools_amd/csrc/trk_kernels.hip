@@ -2761,7 +2761,7 @@ struct V4Filter {
 };
 constexpr int V4_QCAP = 320;            // queue entries per wave: drained when fewer than 4 x 64 are free
 constexpr int V4_PD = 2;                // input sets of the compact build's prefetch ring (k_call_filter_v4, OUT == 2)
-constexpr int V4_CV_MAXNF = 3;          // up to this many filters the compact build takes two chunks per thread (registers)
+constexpr int V4_CV_MAXNF = 0;          // filters up to which the compact build takes two chunks per thread: none (see the kernel's header)
 struct V4Args {
     trk_batch b;
     V4Filter f[V2_MAX_FILTERS];
@@ -2807,11 +2807,14 @@ __device__ __forceinline__ void v4_drain_one(uint32_t w, uint32_t li, uint32_t* 
 // record (dumpSTR.py:721-727) -- only the 16-byte chunks that hold a filtered call are written, the second write stream
 // of the pass nearly vanishes (and with it the output-pair effect of profiles/r03_notes.md section 22).
 // CV: 16-byte chunks (four samples each) a thread owns -- chunk c of thread t is chunk c * CF_THREADS + t of the tile, so
-// that every load and store instruction of a wave stays one contiguous kilobyte.  The compact build takes two: the ONE
-// BYTE per call it writes is a 4-byte store per lane and locus, and what a write stream costs this memory system is a
-// fixed ~100 ns of a channel per contiguous SEGMENT, whatever the segment's size up to 4 KB (tools/stream_probe
-// pinned_probe `compact`, profiles/r05_pinned_compact.txt: three input planes alone 1.79 ms, with a million one-kilobyte
-// row segments of mask bytes 2.62 -- eight per cent more bytes, 46 % more time).  Two chunks per thread halve the segments.
+// that every load and store instruction of a wave stays one contiguous kilobyte.  ONE in every build that is launched.
+// Why it exists: the compact build's one byte per call is a 4-byte store per lane and locus, and the bare stream of that
+// shape -- three input planes and a million one-kilobyte row segments of mask bytes -- takes 2.62 ms where the three
+// planes alone take 1.79 (tools/stream_probe pinned_probe `compact`, profiles/r05_pinned_compact.txt: eight per cent more
+// bytes, 46 % more time; 16-byte stores exchanged through LDS 2.52, deeper prefetch nothing).  Two chunks per thread
+// halve the number of segments; same-process A/B of the product kernel (tools/cf_variants_probe.py, TRK_CF_CV2):
+// 3.15 ms against 2.74 with one chunk -- twice the counters and inputs in registers cost the occupancy more than the
+// wider segments bring.  The compact pass runs at 0.95 of its own stream; the stream's shape is the bound.
 template <int NF, int NFLT, bool DELTA, bool RATIO, int ALIAS, int OUT = 0, int CV = (OUT == 2 && NF <= V4_CV_MAXNF ? 2 : 1)>
 __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
     extern __shared__ uint32_t v2lds[];
@@ -4455,7 +4458,7 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
         k4 = alias == 3   ? (ratio ? k_call_filter_v4<NFV, 1, true, true, (NFV >= 2 ? 3 : 1)> : k_call_filter_v4<NFV, 1, true, false, (NFV >= 2 ? 3 : 1)>) \
              : alias == 1 ? (ratio ? k_call_filter_v4<NFV, 1, true, true, 1> : k_call_filter_v4<NFV, 1, true, false, 1>) \
                           : (ratio ? k_call_filter_v4<NFV, 1, true, true, 0> : k_call_filter_v4<NFV, 1, true, false, 0>)
-            bool cv1 = false;      // (A/B of the two-chunk tile against one chunk per thread: the headline's instantiation only)
+            bool cv1 = true;       // one chunk per thread (TRK_CF_CV2: the two-chunk tile, for A/B runs of the headline's set)
             switch (n_filters) {
                 case 1: TRK_V4_PICK(1); break;
                 case 2: TRK_V4_PICK(2); break;
@@ -4465,9 +4468,9 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
                 default: TRK_V4_PICK(6); break;
             }
 #undef TRK_V4_PICK
-            if (compact && n_filters == 3 && tflt == 1 && alias == 3 && !ratio && trk_opt("TRK_CF_CV1")) {
-                k4 = k_call_filter_v4<3, 1, true, false, 3, 2, 1>;
-                cv1 = true;
+            if (compact && n_filters == 3 && tflt == 1 && alias == 3 && !ratio && trk_opt("TRK_CF_CV2")) {
+                k4 = k_call_filter_v4<3, 1, true, false, 3, 2, 2>;     // (A/B: the two-chunk tile, the headline's filter set)
+                cv1 = false;
             }
             // LDS: the block's delta table + class LUT + locus info, and one queue per wave -- within 32 KiB, so that
             // five workgroups fit a CU
@@ -4483,7 +4486,7 @@ hipError_t launch_call_filter(const trk_batch& b, const trk_plane* planes, int n
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k4, CF_THREADS, (size_t)lpb * per_locus4 + qbytes + 8) != hipSuccess || occ < 1)
                 occ = 4;
             // (the compact build: two chunks per thread, i.e. column tiles of 2048 samples; blocks of whole ring turns)
-            const int gxl = (compact && n_filters <= V4_CV_MAXNF && !cv1) ? (S + 2 * CF_THREADS * CF_V - 1) / (2 * CF_THREADS * CF_V) : gx;
+            const int gxl = (compact && !cv1) ? (S + 2 * CF_THREADS * CF_V - 1) / (2 * CF_THREADS * CF_V) : gx;
             const CfLaunch cl = cf_geometry(L, gxl, lpb, n_cu, occ, compact ? V4_PD : 1);
             lpb = cl.lpb;
             const size_t lds4 = delta ? (((size_t)lpb * per_locus4 + 7) & ~(size_t)7) + qbytes : 0;

@@ -294,7 +294,11 @@ __global__ __launch_bounds__(PS_THREADS) void k_parse_samples(const ParseArgs a)
                 lflags |= TRK_PARSE_HOST;
                 continue;
             }
-            for (int jj = j; jj < P; ++jj) g[jj] = -2;
+            // (a token that ends before the record's GT key -- GT not the first key, trailing fields dropped -- is a
+            // missing call, '.', as htslib fills a dropped field: tests/test_gpu_text_fuzz.py)
+            const int j0 = (gt_idx >= 0 && j == 0) ? 1 : j;
+            if (j0 > j) g[0] = -1;
+            for (int jj = j0; jj < P; ++jj) g[jj] = -2;
             if (a.out.phased) a.out.phased[(int64_t)rec * S + s] = phased ? 1 : 0;
             lmaxpl = (uint32_t)j > lmaxpl ? (uint32_t)j : lmaxpl;
             for (int i = 0; i < a.in.n_planes; ++i)

@@ -461,6 +461,8 @@ struct Source {
             cpos = 0;
         }
         size_t target = std::max<size_t>(want / 3, 8u << 20);
+        // (TRK_VCF_READ_BYTES: an option of the tests -- many small fills on files of a few megabytes)
+        if (const char* e = trk_opt("TRK_VCF_READ_BYTES")) target = (size_t)std::max(1L, atol(e));
         if (end_coff != UINT64_MAX) {
             // a shard reads up to its end plus one block; once there, one more block's worth per call
             const uint64_t have_to = cbuf_foff + cbuf.size();
@@ -722,6 +724,7 @@ inline const char* find_ch(const char* p, const char* e, char c) {
 }
 
 inline int32_t parse_int(const char* p, const char* e) {
+    if (e - p >= 2 && *p == '+' && (unsigned)(p[1] - '0') <= 9u) ++p;      // an explicit plus sign (strtol takes it)
     if (p == e || (e - p == 1 && *p == '.')) return INT_MISSING;
     long long v = 0;
     auto r = std::from_chars(p, e, v);
@@ -993,6 +996,7 @@ void parse_record(RecordJob& job, int rec) {
                 break;
             }
             if (ok) {
+                if (gt_idx >= 0 && j == 0) gt[(size_t)s * P] = -1;     // the token ends before its GT: a missing call (see below)
                 if (ph) ph[s] = phased ? 1 : 0;
                 maxpl = std::max(maxpl, j);
                 if (gtm && smap[s] >= 0)
@@ -1048,6 +1052,11 @@ void parse_record(RecordJob& job, int rec) {
             }
             if (ph) ph[s] = phased ? 1 : 0;
             maxpl = std::max(maxpl, j);
+        } else if (gt_idx >= 0) {
+            // the record has a GT key and this sample's token ends before it (GT is not the first key and the trailing
+            // fields are dropped): a missing call, '.', as htslib fills a dropped field
+            gt[(size_t)s * P] = -1;
+            if (ph) ph[s] = 0;
         }
         if (gtm && smap[s] >= 0)
             for (int j = 0; j < P; ++j) gtm[(size_t)smap[s] * P + j] = gt[(size_t)s * P + j];

@@ -1016,6 +1016,10 @@ def main(args):
     LAST_RUN.update(path='batch' if use_batches else 'per-record', batches=0, fallback_batches=0)
     if use_batches:
         LAST_RUN['device_parse'] = bool(device_parse)
+        # ... and the BGZF members are inflated there too (trk_inflate_blocks, round 5; TRK_DEVICE_INFLATE=0: by the reader's
+        # threads): the compressed bytes cross PCIe, the host sees the newlines and the heads of the lines
+        LAST_RUN['device_inflate'] = bool(device_parse and _knobs.env('TRK_DEVICE_INFLATE', '1') == '1' and
+                                          hasattr(invcf, 'device_inflate') and invcf.device_inflate(runtime.get_compute().eng))
     last_rb = None
     while use_batches:
         if last_rb is not None:

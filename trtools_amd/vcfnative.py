@@ -29,6 +29,10 @@ class _Batch(C.Structure):
                 ('field_off', C.POINTER(C.c_int32)), ('gt_mapped', C.c_void_p)]
 
 
+class _InflateHook(C.Structure):          # trk_vcf_inflate_hook (include/trk_vcf.h)
+    _fields_ = [('user', C.c_void_p), ('seed', C.c_void_p), ('inflate', C.c_void_p)]
+
+
 class _Harmonized(C.Structure):
     _fields_ = [('n_records', C.c_int32), ('n_python', C.c_int32), ('n_alleles_total', C.c_int64),
                 ('allele_off', C.POINTER(C.c_int32)), ('len_class', C.POINTER(C.c_uint16)),
@@ -149,7 +153,21 @@ class RawBatch:
         d['deferred'] = (d['gt'].eng, [(dst, src.hold(), src.ptr, src.nbytes) for dst, src in pairs])
         return True
 
+    def fetch_text(self):
+        """Device-inflate mode (NativeVCFReader.device_inflate): the host's copy of the batch's text holds the heads of the
+        lines only.  Whoever reads sample columns on the host -- the host parse of a batch the device flags, the record
+        writers' host paths, the per-record objects -- brings the text over first (once): one copy out of the batch's
+        text in HBM into the reader's buffer."""
+        d = self.dev
+        if d is None or not d.get('sparse_text') or d.get('text_on_host') or d.get('text') is None or d['text'].ptr is None:
+            return self
+        d['text_on_host'] = True
+        eng = d['eng']
+        eng._chk(eng.lib.trk_memcpy_d2h(eng.ctx, self.b.text + d['text_base'], d['text'].ptr, d['text_nbytes']))
+        return self
+
     def _host(self):
+        self.fetch_text()
         d = self.dev
         if d is not None and d.get('deferred') is not None:
             eng, items = d['deferred']
@@ -562,6 +580,9 @@ def _api():
         lib.trk_vcf_read_batch.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_Batch)]
         lib.trk_vcf_format_kinds.argtypes = [C.POINTER(_Batch), C.POINTER(_DumpLines), vp, vp]
         lib.trk_vcf_skip_samples.argtypes = [vp, C.c_int]
+        lib.trk_vcf_set_inflate_hook.argtypes = [vp, C.POINTER(_InflateHook)]
+        lib.trk_vcf_text_abs.argtypes = [vp]
+        lib.trk_vcf_text_abs.restype = C.c_uint64
         lib.trk_vcf_set_text_buffers.argtypes = [vp, vp, vp, C.c_size_t]
         lib.trk_vcf_format_idx.argtypes = [vp, C.POINTER(C.c_int32)]
         lib.trk_vcf_format_idx.restype = C.c_void_p
@@ -774,6 +795,24 @@ class NativeVCFReader(vcfio.VCFReader):
         self._lib.trk_vcf_skip_samples(self._h, 1 if ok else 0)
         return bool(ok)
 
+    def device_inflate(self, engine):
+        """The file's BGZF members inflated ON THE DEVICE (round 5; trk_inflate_blocks / trk_inflate_hook, include/trk.h):
+        the compressed bytes cross PCIe, the text comes into being in HBM where trk_parse_samples reads it, and the host
+        gets the newlines and the heads of the lines (CHROM ... FORMAT) -- all it reads of a batch.  Needs ``device_parse``
+        on, a bgzip'ed file read from start to end (no region, no shard).  Returns whether it is on."""
+        if engine is None or getattr(self, '_dev_eng', None) is not engine or getattr(self, '_inflate_on', False):
+            return bool(getattr(self, '_inflate_on', False))
+        self._drop_pending()
+        user, seed, infl = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        if engine.lib.trk_inflate_hook(engine.ctx, C.byref(user), C.byref(seed), C.byref(infl)) != 0:
+            return False
+        hook = _InflateHook(user.value, seed.value, infl.value)
+        if self._lib.trk_vcf_set_inflate_hook(self._h, C.byref(hook)) != 0:
+            return False                     # (plain gzip / text, a shard, a region: the host inflates)
+        self._inflate_hook = hook
+        self._inflate_on = True
+        return True
+
     def _parse_on_device(self, b, P, arrays):
         """The sample columns of the batch just read, on the device; returns (dev dict or None, the host arrays)."""
         gt, ph, lp, planes, gtm, parr = arrays
@@ -788,9 +827,17 @@ class NativeVCFReader(vcfio.VCFReader):
         fptr = self._lib.trk_vcf_format_idx(self._h, C.byref(stride))
         fi = np.ctypeslib.as_array(C.cast(fptr, C.POINTER(C.c_int8)), shape=(n, stride.value)) if fptr else None
         out = None
+        sparse = bool(getattr(self, '_inflate_on', False))
+        if sparse and not (fi is not None and nbytes > 0 and S > 0):
+            raise ValueError("%s: a batch without sample columns in device-inflate mode" % self.path)
         if fi is not None and nbytes > 0 and S > 0:
             td = eng.empty((nbytes + 32,), np.uint8)
-            eng._chk(eng.lib.trk_memcpy_h2d(eng.ctx, td.ptr, b.text + base, nbytes))
+            if sparse:
+                # the text is in HBM already (the inflate hook's segments): the batch's span of it, device to device
+                abs0 = int(self._lib.trk_vcf_text_abs(self._h))
+                eng._chk(eng.lib.trk_inflate_text(eng.ctx, abs0 + base, nbytes, td.ptr, abs0 + base))
+            else:
+                eng._chk(eng.lib.trk_memcpy_h2d(eng.ctx, td.ptr, b.text + base, nbytes))
             kinds = ['f' if kd == KIND_FLOAT else 'i' for _, kd, _, _ in self._selected]
             so_d = eng.upload((lo + fo9 - base).astype(np.int64), np.int64)
             le_d = eng.upload((le - base).astype(np.int64), np.int64)
@@ -800,6 +847,8 @@ class NativeVCFReader(vcfio.VCFReader):
                                     want_phased=True)
             flags = out['flags'].get()
             if flags.any():
+                if sparse:                        # the host parses this batch: its sample columns have to be there
+                    eng._chk(eng.lib.trk_memcpy_d2h(eng.ctx, b.text + base, td.ptr, nbytes))
                 with eng.idle_frees():            # (parse_samples waited for the device; .get() for this thread's queue)
                     for a in [out['gt'], out['phased'], out['locus_ploidy'], out['flags'], td, so_d, le_d] + out['planes']:
                         a.free()
@@ -828,7 +877,8 @@ class NativeVCFReader(vcfio.VCFReader):
             out['locus_ploidy'].free()
             out['flags'].free()
         dev = dict(gt=out['gt'], phased=out['phased'], planes={k: a for (k, _, _, _), a in zip(self._selected, out['planes'])},
-                   text=td, smp_off=so_d, line_end=le_d, eng=eng)     # (text and offsets stay: the record writer's device half)
+                   text=td, smp_off=so_d, line_end=le_d, eng=eng,     # (text and offsets stay: the record writer's device half)
+                   sparse_text=sparse, text_base=base, text_nbytes=nbytes)
         return dev, gt, ph, lp, planes, gtm, parr
 
     def shard(self, rank, world):
@@ -916,6 +966,7 @@ class NativeVCFReader(vcfio.VCFReader):
 
     def _rows_of(self, rb):
         b, S = rb.b, self.n_samples
+        rb.fetch_text()
         rows = []
         for i in range(rb.n):
             # the nine fixed columns as text now; the sample columns (most of the line) stay bytes until a field
