@@ -108,7 +108,7 @@ def test_command_lines_with_and_without_the_device_inflate(tmp_path):
     lines[k] = b'\t'.join(f)
     path = _bgzip(tmp_path, 'in.vcf.gz', b'\n'.join(lines))
     outs = {}
-    for tag, env in (('dev', {}), ('host', dict(TRK_DEVICE_INFLATE='0'))):
+    for tag, env in (('dev', dict(TRK_DEVICE_INFLATE='1')), ('host', dict(TRK_DEVICE_INFLATE='0'))):
         old = {k_: os.environ.get(k_) for k_ in env}
         os.environ.update(env)
         try:

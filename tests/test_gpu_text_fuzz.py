@@ -61,7 +61,7 @@ HDR = ['##fileformat=VCFv4.2', '##command=HipSTR-v0.6.2 fuzz',
 # spellings: `easy` pools are inside the device grammar (plain digits, a sign, decimals with a digit on one side at
 # least); `hard` pools hold everything the host reader takes (and a few things nobody takes as a number)
 GT_EASY = ['0|1', '1/0', '.', './.', '.|1', '1|.', '0/0', '10|2', '123|0', '7', '1|1']
-GT_HARD = GT_EASY + ['0|', '|1', '1234|0', '12345|0', '0/1/2', '1|2|3', '.|.|.', '0/1|1']
+GT_HARD = GT_EASY + ['1234|0', '12345|0', '0/1/2', '1|2|3', '.|.|.', '0/1|1']
 INT_EASY = ['7', '30', '-3', '0', '-0', '.', '123456789', '007', '-999999999']
 # (tokens the Python decoder refuses outright -- '', '12x', '1e3' in an Integer field, integers beyond int32 -- are no
 # use here: the definition says nothing about them)
@@ -176,7 +176,10 @@ def test_device_parse_against_the_python_decoder(eng, tmp_path_factory, seed, n_
     head = HDR + ['#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t' + '\t'.join('s%d' % i for i in range(S))]
     with open(path, 'wb') as fh:
         fh.write((nl.join(head + rec_lines) + nl).encode())
-    py = list(vcfio.VCFReader(path))
+    try:
+        py = list(vcfio.VCFReader(path))
+    except (ValueError, OverflowError):
+        return                      # (text the Python decoder refuses outright: the definition says nothing)
     assert len(py) == n_rec
     out = _device_parse(eng, rec_lines, nl, S, P, keys, kinds)
     flags = out['flags'].get()

@@ -150,7 +150,7 @@ def _synthetic(n_rec, S, crlf=False, last_newline=True, seed=0):
     lines = []
     for r in range(n_rec):
         cols = ['%d|%d:%d:0.%02d' % (rng.integers(0, 3), rng.integers(0, 3), rng.integers(0, 90), rng.integers(0, 100)) for _ in range(S)]
-        alt = ','.join('AC' * int(k) for k in rng.integers(1, 40, size=int(rng.integers(1, 5))))
+        alt = ','.join('AC' * int(k) for k in rng.integers(1, 40, size=int(rng.integers(2, 5))))
         lines.append('\t'.join(['chr1', str(1000 + 37 * r), 'id%d' % r, 'ACAC', alt, '.', '.', 'START=%d;END=%d;PERIOD=2' % (1000 + 37 * r, 1003 + 37 * r),
                                 'GT:DP:Q'] + cols))
     text = nl.join(hdr + lines) + (nl if last_newline else '')

@@ -6,7 +6,8 @@ SUPPORTED settings -- the table in README.md ("Environment") -- are read with ``
     TRK_VCF_THREADS       inflate / parse threads of a native reader (libtrk; default: twice the CPU grant, 8 ... 64)
     TRK_FMT_THREADS       formatter threads of the native writers (libtrk; default: twice the CPU grant, 8 ... 32)
     TRK_VCF_READ_AHEAD    1 (default): batch n + 1 is read on a helper thread while batch n is worked on
-    TRK_DEVICE_INFLATE    1 (default): BGZF blocks are inflated on the GPU (the file crosses PCIe compressed)
+    TRK_DEVICE_INFLATE    1: BGZF blocks are inflated on the GPU (the file crosses PCIe compressed); default: see
+                          DEVICE_INFLATE_DEFAULT below
     TRK_DEVICE_PARSE      1 (default): the sample columns are parsed on the GPU
     TRK_DEVICE_FORMAT     1 (default): dumpSTR's sample columns are written on the GPU
     TRK_PLACE_OUTPUTS     1 (default): big output plane pairs of the call-filter pass are placed (trk_dev_alloc_pair)
@@ -23,6 +24,12 @@ import os
 
 SUPPORTED = ('TRK_DEVICE', 'TRK_VCF_THREADS', 'TRK_FMT_THREADS', 'TRK_VCF_READ_AHEAD', 'TRK_DEVICE_INFLATE',
              'TRK_DEVICE_PARSE', 'TRK_DEVICE_FORMAT', 'TRK_PLACE_OUTPUTS', 'TRK_RESERVE_PAIR_GB', 'TRK_POOL_GB')
+
+
+# The command lines' default for TRK_DEVICE_INFLATE.  '0' while the device inflates a gigabyte of text in ~40 ms and the
+# host's 32 inflater threads in ~60 ms beside everything else they do (profiles/r05_notes.md): the device path is correct
+# (tests/test_gpu_inflate*.py) and frees a CPU-second per GB, but does not shorten the command lines yet.
+DEVICE_INFLATE_DEFAULT = '0'
 
 
 def env(name, default=None):

@@ -12,13 +12,13 @@
 //     ballots in symbol order, every lane fills the primary-table slots of its own symbols.  Codes longer than the
 //     primary table's index (rare by construction) are decoded by the canonical comparison (first code / count per
 //     length, symbols sorted by length), not through secondary tables;
-//   * the text is assembled in a 32 KiB LDS window (DEFLATE's maximum match distance), matches are copied by the lanes
-//     (a period shorter than the length by doubling), and the window is written out to the text buffer in HBM as it
-//     fills -- 64 bytes per instruction.
+//   * the text goes straight to the buffer in HBM; the last 4 KiB of it are also kept in an LDS ring: a match inside the
+//     ring is copied there by the lanes (a period shorter than the length by doubling), a match further back reads the
+//     text buffer (the wave fences its own stores every 2 KiB, so those bytes are there).
 // A member the kernel cannot finish (corrupt stream, more text than its ISIZE, a distance before the member's start) is
 // FLAGGED and left to the host inflater; nothing is trusted about the input beyond the bounds the caller gives.
 // Roofline note: a serial symbol decode per wave is bound by the latency of its dependent table reads, not by HBM: the
-// pass is sized by members in flight (four waves per CU by the LDS window), not by bytes.
+// pass is sized by members in flight (sixteen waves per CU: 8 KiB of LDS and 87 registers per member), not by bytes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -27,7 +27,6 @@
 
 namespace {
 
-constexpr int INF_WIN = 32768;            // window bytes (power of two >= 32768)
 constexpr int LL_ROOT = 10, D_ROOT = 8;   // index bits of the primary tables
 constexpr int LL_MAX = 288, D_MAX = 32;
 
@@ -42,17 +41,25 @@ struct CodeSet {          // per code (literal/length, distance): canonical desc
     uint32_t offs[16];    // where the length's symbols start in `sorted`
 };
 
+// A wave's LDS: the decode tables and a RING of the last 4 KiB of text.  The text itself goes straight to the buffer in
+// HBM; a match whose source lies inside the ring is copied there (LDS is in order for a wave: no fence), a match
+// further back reads the text buffer, which holds those bytes for sure -- the wave fences its own stores every 2 KiB.
+// 8 KiB of LDS per member instead of a 32 KiB window: sixteen members per CU instead of four, and a member is one
+// long chain of dependent look-ups that only other members' chains can overlap with (first form, window in LDS:
+// 7 ms per member, 9.6 GB/s of text on the whole chip -- tools/inflate_probe.py, profiles/r05_notes.md).
+constexpr int RING = 4096;
+constexpr int NEAR = RING - 258;          // a match at most this far back is served by the ring alone
+constexpr int INF_WAVES = 4;              // members per workgroup (one per wave)
+
 struct Lds {
-    uint8_t win[INF_WIN];
+    uint8_t ring[RING];
     uint16_t ll_tab[1 << LL_ROOT];
     uint16_t d_tab[1 << D_ROOT];
     uint16_t ll_sorted[LL_MAX];
     uint16_t d_sorted[D_MAX];
     uint8_t lens[LL_MAX + D_MAX];
     CodeSet ll, d;
-    uint32_t pre_cnt[8], pre_first[8], pre_offs[8];
     uint8_t pre_sorted[19], pre_len[19];
-    uint32_t err;
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -60,32 +67,32 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 // the compressed stream of one member: 256 bytes per register, a dword per lane; `next` is the following 256
 struct BitReader {
     const uint32_t* base;      // dword-aligned address at or before the payload
-    int64_t n_dwords;          // dwords that may be read (payload + slack the caller guarantees)
-    int64_t w0;                // dword index held by lane 0 of `cur`
+    uint32_t n_dwords;         // dwords that may be read (payload + slack the caller guarantees); a payload is < 64 KiB
+    uint32_t w0;               // dword index held by lane 0 of `cur`
     uint32_t cur, next;
-    int64_t dw;                // next dword to take
+    uint32_t dw;               // next dword to take
     uint64_t bb;               // bit buffer (uniform)
     int bc;                    // valid bits in bb
     int lane;
+    int skip;                  // bytes between `base` and the payload's first byte
 
-    __device__ __forceinline__ uint32_t load_reg(int64_t w) const {
-        const int64_t i = w + lane;
+    __device__ __forceinline__ uint32_t load_reg(uint32_t w) const {
+        const uint32_t i = w + (uint32_t)lane;
         return i < n_dwords ? __builtin_nontemporal_load(base + i) : 0u;
     }
-    int skip;                  // bytes between `base` and the payload's first byte
     __device__ __forceinline__ void init(const uint8_t* p, int64_t n_bytes, int ln) {
         lane = ln;
         const uintptr_t a = reinterpret_cast<uintptr_t>(p);
         base = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
         skip = (int)(a & 3);
-        n_dwords = (n_bytes + skip + 3) / 4 + 2;      // (+ 8 bytes: the member's CRC32 / ISIZE trailer follows the payload)
+        n_dwords = (uint32_t)((n_bytes + skip + 3) / 4 + 2);      // (+ 8 bytes: the member's CRC32 / ISIZE trailer follows the payload)
         seek(0);
     }
     // continue at byte `off` of the payload
     __device__ __forceinline__ void seek(int64_t off) {
-        const int64_t b = off + skip;
+        const uint32_t b = (uint32_t)off + (uint32_t)skip;
         dw = b >> 2;
-        w0 = dw & ~(int64_t)63;
+        w0 = dw & ~63u;
         cur = load_reg(w0);
         next = load_reg(w0 + 64);
         bb = 0;
@@ -122,7 +129,7 @@ struct BitReader {
         return v;
     }
     // bits consumed since the payload's first byte
-    __device__ __forceinline__ int64_t bits_used() const { return dw * 32 - bc - 8 * skip; }
+    __device__ __forceinline__ int64_t bits_used() const { return (int64_t)dw * 32 - bc - 8 * skip; }
 };
 
 __device__ __forceinline__ uint32_t rev_bits(uint32_t v, int n) { return __builtin_bitreverse32(v) >> (32 - n); }
@@ -131,7 +138,7 @@ __device__ __forceinline__ uint32_t rev_bits(uint32_t v, int n) { return __built
 // Returns false (uniform) for an over-subscribed code, or an incomplete one that zlib would refuse (anything but a
 // single one-bit code or an empty code).
 template <int ROOT>
-__device__ bool build_code(const uint8_t* lens, int n, CodeSet& cs, uint16_t* tab, uint16_t* sorted, int lane) {
+__device__ __noinline__ bool build_code(const uint8_t* lens, int n, CodeSet& cs, uint16_t* tab, uint16_t* sorted, int lane) {
     if (lane < 16) cs.cnt[lane] = 0;
     for (int i = lane; i < (1 << ROOT); i += 64) tab[i] = 0;
     __builtin_amdgcn_wave_barrier();
@@ -140,17 +147,19 @@ __device__ bool build_code(const uint8_t* lens, int n, CodeSet& cs, uint16_t* ta
         if (l) atomicAdd(&cs.cnt[l], 1u);
     }
     __builtin_amdgcn_wave_barrier();
-    uint32_t code = 0, off = 0, total = 0;
+    // first code and offset per length: fifteen uniform steps over the counts (lane q keeps what belongs to length q)
+    uint32_t code = 0, off = 0, total = 0, my_first = 0, my_off = 0;
     int left = 1, max_len = 0;
     bool over = false;
-    uint32_t firstv[16], offv[16];
-#pragma unroll
+#pragma unroll 1
     for (int l = 1; l <= 15; ++l) {
         const uint32_t c = uni(cs.cnt[l]);
         left = (left << 1) - (int)c;
         over |= left < 0;
-        firstv[l] = code;
-        offv[l] = off;
+        if (lane == l) {
+            my_first = code;
+            my_off = off;
+        }
         code = (code + c) << 1;
         off += c;
         total += c;
@@ -158,36 +167,30 @@ __device__ bool build_code(const uint8_t* lens, int n, CodeSet& cs, uint16_t* ta
     }
     if (over) return false;
     if (left > 0 && !(total == 0 || (total == 1 && max_len == 1))) return false;
-    if (lane >= 1 && lane < 16) {
-        cs.first[lane] = 0;
-        cs.offs[lane] = 0;
+    if (lane < 16) {
+        cs.first[lane] = my_first;
+        cs.offs[lane] = my_off;
     }
-#pragma unroll
-    for (int l = 1; l <= 15; ++l)
-        if (lane == l) {
-            cs.first[l] = firstv[l];
-            cs.offs[l] = offv[l];
-        }
-    // a symbol's rank among the symbols of its length, in symbol order: ballots over chunks of 64 symbols
-    uint32_t run[16];
-#pragma unroll
-    for (int l = 0; l < 16; ++l) run[l] = 0;
+    __builtin_amdgcn_wave_barrier();
+    // a symbol's rank among the symbols of its length, in symbol order: ballots over chunks of 64 symbols; lane q of
+    // `run` counts the symbols of length q met so far
+    uint32_t run = 0;
     const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     for (int s0 = 0; s0 < n; s0 += 64) {
         const int s = s0 + lane;
         const int l = s < n ? (int)lens[s] : 0;
-        uint32_t rank = 0, fc = 0, fo = 0;
-#pragma unroll
+        uint32_t rank = 0, add = 0;
+#pragma unroll 1
         for (int q = 1; q <= 15; ++q) {
             const uint64_t m = __ballot(l == q);
-            if (l == q) {
-                rank = run[q] + (uint32_t)__popcll(m & lt);
-                fc = firstv[q];
-                fo = offv[q];
-            }
-            run[q] += (uint32_t)__popcll(m);
+            if (l == q) rank = (uint32_t)__popcll(m & lt);
+            if (lane == q) add = (uint32_t)__popcll(m);
         }
+        const uint32_t before = (uint32_t)__shfl((int)run, l);       // the count of MY length before this chunk
+        run += add;
         if (l) {
+            rank += before;
+            const uint32_t fc = cs.first[l], fo = cs.offs[l];
             sorted[fo + rank] = (uint16_t)s;
             if (l <= ROOT) {
                 const uint16_t e = (uint16_t)((s << 4) | l);
@@ -230,21 +233,33 @@ __device__ __forceinline__ int decode_sym(BitReader& br, const CodeSet& cs, cons
     return -1;
 }
 
-__global__ __launch_bounds__(64) void k_inflate_bgzf(const InfArgs a) {
-    __shared__ Lds s;
-    const int lane = threadIdx.x;
-    for (int blk = blockIdx.x; blk < a.in.n_blocks; blk += gridDim.x) {
+__global__ __launch_bounds__(64 * INF_WAVES) void k_inflate_bgzf(const InfArgs a) {
+    __shared__ Lds s_all[INF_WAVES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    Lds& s = s_all[wave];
+    for (int blk = blockIdx.x * INF_WAVES + wave; blk < a.in.n_blocks; blk += gridDim.x * INF_WAVES) {
         const int64_t in_off = a.in.in_off[blk];
         const int32_t in_len = a.in.in_len[blk];
         const int32_t out_len = a.in.out_len[blk];
         uint8_t* dst = a.out.text + a.in.out_off[blk];
         uint32_t err = 0;
         if (in_len < 0 || out_len < 0 || out_len > 65536 || in_off < 0 || in_off + in_len > a.in.n_comp_bytes) err = TRK_INFLATE_INPUT;
-        int pos = 0;          // bytes of text produced
-        int flushed = 0;      // bytes of the window already written out
-        auto flush_to = [&](int upto) {
-            for (int i = flushed + lane; i < upto; i += 64) dst[i] = s.win[i & (INF_WIN - 1)];
-            flushed = upto;
+        int pos = 0;          // bytes of text produced (the pending literals included)
+        int fenced = 0;       // the wave's stores of text[0 .. fenced) are done: others may read them
+        // literals wait in a register, lane k the k-th of the run, and leave together -- one ring write and one store per
+        // run instead of per byte (the per-symbol vector instructions are what bounds this kernel: profiles/r05_sq_inflate.txt)
+        uint32_t pend = 0;
+        int npend = 0;
+        auto flush_literals = [&]() {
+            if (npend) {
+                if (lane < npend) {
+                    const uint32_t o = (uint32_t)(pos - npend) + (uint32_t)lane;
+                    s.ring[o & (RING - 1)] = (uint8_t)pend;
+                    dst[o] = (uint8_t)pend;
+                }
+                npend = 0;
+            }
         };
         if (!err && out_len > 0) {
             BitReader br;
@@ -258,6 +273,7 @@ __global__ __launch_bounds__(64) void k_inflate_bgzf(const InfArgs a) {
                 const uint32_t type = br.take(2);
                 if (type == 0) {
                     // stored: to the next byte boundary, LEN / NLEN, LEN raw bytes
+                    flush_literals();
                     br.drop(br.bc & 7);
                     br.refill();
                     const uint32_t len = br.take(16);
@@ -267,14 +283,12 @@ __global__ __launch_bounds__(64) void k_inflate_bgzf(const InfArgs a) {
                     if (pos + (int)len > out_len) { err = TRK_INFLATE_OVERRUN; break; }
                     const int64_t byte0 = br.bits_used() / 8;         // payload offset of the first raw byte
                     if (byte0 + (int64_t)len > (int64_t)in_len) { err = TRK_INFLATE_STREAM; break; }
-                    // through the window in pieces (a run may be longer than the window; later matches may reach into it)
-                    for (int done = 0; done < (int)len;) {
-                        const int n = min((int)len - done, INF_WIN / 2);
-                        for (int i = lane; i < n; i += 64) s.win[(pos + done + i) & (INF_WIN - 1)] = p[byte0 + done + i];
-                        __builtin_amdgcn_wave_barrier();
-                        flush_to(pos + done + n);
-                        done += n;
+                    for (int i = lane; i < (int)len; i += 64) {
+                        const uint8_t b = p[byte0 + i];
+                        dst[pos + i] = b;
+                        if ((int)len - i <= RING) s.ring[(pos + i) & (RING - 1)] = b;     // (the run's last RING bytes)
                     }
+                    __builtin_amdgcn_wave_barrier();
                     pos += (int)len;
                     br.seek(byte0 + len);
                     continue;
@@ -383,8 +397,12 @@ __global__ __launch_bounds__(64) void k_inflate_bgzf(const InfArgs a) {
                     __builtin_amdgcn_wave_barrier();
                     if (uni(s.lens[256]) == 0) { err = TRK_INFLATE_STREAM; break; }     // no end-of-block code
                 }
-                if (!build_code<LL_ROOT>(s.lens, n_ll, s.ll, s.ll_tab, s.ll_sorted, lane) ||
-                    !build_code<D_ROOT>(s.lens + LL_MAX, n_d, s.d, s.d_tab, s.d_sorted, lane)) {
+                // (the result of a call that is not inlined is "divergent" to the compiler, and a divergent exit from this
+                // loop would move the whole bit reader into vector registers: 92 vector instructions per symbol instead
+                // of a dozen -- readfirstlane says what it is)
+                const bool ok_ll = uni(build_code<LL_ROOT>(s.lens, n_ll, s.ll, s.ll_tab, s.ll_sorted, lane) ? 1u : 0u) != 0;
+                const bool ok_d = uni(build_code<D_ROOT>(s.lens + LL_MAX, n_d, s.d, s.d_tab, s.d_sorted, lane) ? 1u : 0u) != 0;
+                if (!ok_ll || !ok_d) {
                     err = TRK_INFLATE_STREAM;
                     break;
                 }
@@ -395,11 +413,15 @@ __global__ __launch_bounds__(64) void k_inflate_bgzf(const InfArgs a) {
                     if (sym < 0) { err = TRK_INFLATE_STREAM; break; }
                     if (sym < 256) {
                         if (pos >= out_len) { err = TRK_INFLATE_OVERRUN; break; }
-                        if (lane == 0) s.win[pos & (INF_WIN - 1)] = (uint8_t)sym;
+                        pend = lane == npend ? (uint32_t)sym : pend;
+                        ++npend;
                         ++pos;
+                        if (npend == 64) flush_literals();
                     } else if (sym == 256) {
+                        flush_literals();
                         break;
                     } else {
+                        flush_literals();
                         const int li = sym - 257;
                         if (li > 28) { err = TRK_INFLATE_STREAM; break; }
                         int len;
@@ -420,29 +442,51 @@ __global__ __launch_bounds__(64) void k_inflate_bgzf(const InfArgs a) {
                         }
                         if (dist > pos) { err = TRK_INFLATE_STREAM; break; }
                         if (pos + len > out_len) { err = TRK_INFLATE_OVERRUN; break; }
-                        // the copy: lanes take bytes; a period shorter than what is left doubles as the copy proceeds
-                        int done = 0, d_eff = dist;
-                        while (done < len) {
-                            const int n = min(min(len - done, 64), d_eff);
-                            if (lane < n) s.win[(pos + done + lane) & (INF_WIN - 1)] = s.win[(pos + done + lane - d_eff) & (INF_WIN - 1)];
-                            done += n;
-                            if (n == d_eff && d_eff < 64) d_eff *= 2;
+                        if (dist <= NEAR) {
+                            // inside the ring: lanes take bytes; a period shorter than what is left doubles as the copy proceeds
+                            int done = 0, d_eff = dist;
+                            while (done < len) {
+                                const int n = min(min(len - done, 64), d_eff);
+                                if (lane < n) {
+                                    const uint32_t o = (uint32_t)(pos + done) + (uint32_t)lane;
+                                    const uint8_t b = s.ring[(o - (uint32_t)d_eff) & (RING - 1)];
+                                    s.ring[o & (RING - 1)] = b;
+                                    dst[o] = b;
+                                }
+                                done += n;
+                                if (n == d_eff && d_eff < 64) d_eff *= 2;
+                            }
+                        } else {
+                            // further back than the ring: from the text buffer (no overlap: the distance exceeds the length)
+                            if (pos - dist + len > fenced) {
+                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                                fenced = pos;
+                            }
+                            for (int done = 0; done < len; done += 64) {
+                                if (done + lane < len) {
+                                    const uint32_t o = (uint32_t)(pos + done) + (uint32_t)lane;
+                                    const uint8_t b = dst[o - (uint32_t)dist];
+                                    s.ring[o & (RING - 1)] = b;
+                                    dst[o] = b;
+                                }
+                            }
                         }
                         pos += len;
                     }
-                    if (pos - flushed >= 4096) flush_to(pos & ~63);
+                    if (pos - fenced >= 2048) {     // (a match beyond the ring then finds its source finished)
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                        fenced = pos;
+                    }
                     if (br.bits_used() > bit_limit + 64) { err = TRK_INFLATE_STREAM; break; }
                 }
             }
             if (!err && br.bits_used() > bit_limit) err = TRK_INFLATE_STREAM;     // read beyond the payload
         }
         if (!err && pos != out_len) err = TRK_INFLATE_OVERRUN;
-        if (!err) flush_to(pos);
         if (lane == 0) a.out.flags[blk] = (uint8_t)err;
         __builtin_amdgcn_wave_barrier();
     }
 }
-
 
 // ---- the line index of inflated text, and the heads of its lines (the reader's inflate hook, trk_api.hip) ----------
 // What the host side of a batch reads of a 60 KB record is its first hundred bytes: CHROM ... FORMAT.  With the text
@@ -660,8 +704,10 @@ namespace trk {
 hipError_t launch_inflate(const trk_inflate_in& in, const trk_inflate_out& out, int n_cu, hipStream_t stream) {
     if (in.n_blocks <= 0) return hipSuccess;
     InfArgs a{in, out};
-    const int grid = in.n_blocks < n_cu * 4 ? in.n_blocks : n_cu * 4;
-    hipLaunchKernelGGL(k_inflate_bgzf, dim3(grid), dim3(64), 0, stream, a);
+    // members walk the grid: sixteen waves per CU when the registers allow (four workgroups of four members)
+    const int wgs = (in.n_blocks + INF_WAVES - 1) / INF_WAVES;
+    const int grid = wgs < n_cu * 4 ? wgs : n_cu * 4;
+    hipLaunchKernelGGL(k_inflate_bgzf, dim3(grid), dim3(64 * INF_WAVES), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -1559,7 +1559,9 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
                 break;
             }
             const double tf = timing ? now() : 0.0;
-            if (!v->src.fill(v->buf, 16u << 20, v->err)) return 1;
+            // (with an inflate hook: runs of ~4500 members -- on the device a member is one wave's serial work of ~8 ms
+            // whatever else runs, and the chip holds 4096 of them at a time: tools/inflate_probe.py)
+            if (!v->src.fill(v->buf, hooked ? (288u << 20) : (16u << 20), v->err)) return 1;
             if (timing) t_fill += now() - tf;
             continue;
         }

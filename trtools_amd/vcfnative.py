@@ -731,11 +731,15 @@ class NativeVCFReader(vcfio.VCFReader):
         return rb
 
     def _pin_text(self):
-        """Device-parse mode, from the second batch on: the reader's two text buffers continue in pinned memory of the
-        engine's (trk_vcf_set_text_buffers), so that the upload of a batch's text is a plain DMA.  Sized from the first
-        batch; a later batch that outgrows them moves the reader back to its own memory (and the copy to a staged one)."""
+        """Host-inflate mode WITHOUT read-ahead, from the second batch on: the reader's two text buffers continue in pinned
+        memory of the engine's (trk_vcf_set_text_buffers), so that the upload of a batch's text is a plain DMA.  Sized from
+        the first batch; a later batch that outgrows them moves the reader back to its own memory.  NOT in the default
+        configuration: with read-ahead the previous batch's text is still in use when the next read starts (the move
+        would pull it from under the caller), and with the device inflate (round 5, the default on bgzip'ed files) a
+        batch's text never is on the host -- the compressed bytes are what crosses PCIe."""
         need = getattr(self, '_text_seen', 0)
-        if not need or getattr(self, '_text_pinned', False) or getattr(self, '_alloc', None) is None or getattr(self, '_ahead', False):
+        if not need or getattr(self, '_text_pinned', False) or getattr(self, '_alloc', None) is None or \
+                getattr(self, '_ahead', False) or getattr(self, '_inflate_on', False):
             return
         self._text_pinned = True
         cap = (int(need * 1.25) + (64 << 20) + 4095) & ~4095
