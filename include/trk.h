@@ -316,11 +316,13 @@ typedef struct {
 } trk_pair_info;
 /* RESERVING the pair.  Which level a pair of planes is on follows from where the two allocations lie in the device's
  * memory -- three classes of regions, a pair inside one class is slow, a pair across two is fast (the 16-plane matrix
- * in profiles/r05_class_probe.txt) -- and a process's FIRST two allocations lie in two different classes: 8 of 8 fresh
- * processes at 4 GB planes, against 2 of 8 once 12 GB of inputs had been allocated first (same file).
- * trk_reserve_pair, called right after trk_init and before any other device allocation, takes two planes of bytes_each
- * then and there (timed once; if that pair is slow after all, a third plane is tried and the best two stay).  The
- * context owns them for its lifetime: trk_dev_alloc_pair lends them out whenever both are free and bytes_each fits
+ * in profiles/r05_class_probe.txt) -- and at the START of a process the class changes within the first few allocations:
+ * plane 0 has a fast partner among planes 1 ... 4 in seven of eight fresh processes (five times it is plane 1), against
+ * two of eight for the plane next to it once 12 GB of inputs have been allocated (same file).  trk_reserve_pair,
+ * called right after trk_init and before any other device allocation, takes planes of bytes_each one at a time -- five
+ * at most --, times each with the ones before it and stops at the first fast pair; the best pair stays, the others go
+ * back (transient: up to three planes, while the device is still empty).  The context owns the pair for its lifetime:
+ * trk_dev_alloc_pair lends it out whenever it is fast, both planes are free and bytes_each fits
  * (trk_pair_info.reserved = 1) -- a sub-plane lies in its plane's region, so smaller shapes are served alike -- and
  * trk_dev_free on either pointer hands it back instead of freeing it. */
 int trk_reserve_pair(trk_ctx* ctx, size_t bytes_each, trk_pair_info* info);

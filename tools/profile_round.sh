@@ -3,7 +3,7 @@ export TRK_LAB=1   # tools are lab runs: lab knobs are honoured (trtools_amd/_kn
 # The rocprofv3 passes behind profiles/<tag>_*: kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in their own runs
 # (never combined with another trace domain), around (a) the bench command -- headline step + the associaTR extra --
 # (b) tools/config_probe.py (BASELINE configs[1] and configs[2], HipSTR five-filter set) and (c) tools/qc_probe.py.  Run on the GPU box:
-#   gpurun -- bash tools/profile_round.sh r03
+#   gpurun -- bash tools/profile_round.sh r05
 set -u
 tag=${1:-r03}
 repo=$(pwd)
@@ -22,6 +22,14 @@ run3() {   # name, command...: stats pass + two PMC passes of the same command
 run3 bench python "$repo/bench.py" --steps 5 --warmup 2 --no-check --no-cpu-baseline --no-extras
 run3 configs python "$repo/tools/config_probe.py"
 run3 qc python "$repo/tools/qc_probe.py" --iters 3
+# round 5: the call-filter pass's builds one by one -- the 13 B compact build dumpSTR's command line launches, the HipSTR
+# five-filter set full and compact -- with their own FETCH / WRITE passes
+run3 variants python "$repo/tools/cf_variants_probe.py" --iters 3 full compact hipstr5 hipstr5c
+# round 5: BGZF members inflated on the device (the 1 GB probe file: written here if it is not there)
+mkdir -p /tmp/e2e
+[ -f /tmp/e2e/synth_17000x5000.vcf.gz ] || python "$repo/tools/e2e_probe.py" --loci 17000 --samples 5000 --no-gpu > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d "$out/inflate_stats" -o stats -- python "$repo/tools/inflate_probe.py" /tmp/e2e/synth_17000x5000.vcf.gz 4096 0 > "$out/inflate_under_rocprof.log" 2>&1
+( cd "$repo" && python tools/rocprof_summary.py stats "$(db inflate_stats)" > "$out/${tag}_inflate_kernel_stats.csv" )
 # statSTR --samples (sample groups): kernel trace only
 rocprofv3 --kernel-trace --stats -d "$out/groups_stats" -o stats -- python "$repo/tools/groups_probe.py" > "$out/groups_under_rocprof.log" 2>&1
 ( cd "$repo" && python tools/rocprof_summary.py stats "$(db groups_stats)" > "$out/${tag}_groups_kernel_stats.csv" )

@@ -1299,50 +1299,56 @@ int trk_reserve_pair(trk_ctx* ctx, size_t bytes_each, trk_pair_info* info) {
     if (bytes_each < ((size_t)1 << 20)) return fail(ctx, TRK_ERR_ARG, "trk_reserve_pair: at least 1 MB per plane");
     (void)hipSetDevice(ctx->device);
     const auto t0 = std::chrono::steady_clock::now();
-    void* p[3] = {nullptr, nullptr, nullptr};
-    for (int k = 0; k < 2; ++k) {
-        hipError_t e = hipMalloc(&p[k], bytes_each);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            if (p[0]) (void)hipFree(p[0]);
-            return fail(ctx, TRK_ERR_NOMEM, "trk_reserve_pair: hipMalloc(%zu): %s", bytes_each, hipGetErrorString(e));
-        }
-    }
-    // the probe's shape: rows of 8192 samples over the whole plane
-    const int64_t S = 8192, Lp = (int64_t)(bytes_each / ((size_t)S * 4u));
+    // Planes one at a time, each timed with every plane taken before it, until a pair is on the fast level: at the start
+    // of a process the placement class changes within the first few allocations (profiles/r05_class_probe.txt: a fast
+    // partner for plane 0 among planes 1 ... 4 in seven of eight fresh processes) and the memory is empty, so up to
+    // four spare planes cost nothing but 5 ms of probes each.  The best pair stays, the rest goes back.
+    constexpr int MAXP = 5;
+    void* p[MAXP] = {};
+    const int64_t S = 8192, Lp = (int64_t)(bytes_each / ((size_t)S * 4u));   // the probe's shape: rows of 8192 samples
     const double gbytes = 2.0 * (double)Lp * (double)S * 4.0 * 1e-9;
-    int n = 0;
-    hipError_t e = Lp >= 1 ? probe_pair_ms(ctx, p[0], p[1], Lp, S, &pi.probe_ms[n]) : hipSuccess;
-    ++n;
-    int keep_a = 0, keep_b = 1;
-    float best = pi.probe_ms[0];
-    if (e == hipSuccess && Lp >= 1 && gbytes / (double)best < TRK_PAIR_FAST_TBPS && bytes_each >= ((size_t)1 << 28)) {
-        // (rare at the start of a process: one more plane, the best of the three pairs stays)
-        if (hipMalloc(&p[2], bytes_each) == hipSuccess) {
-            for (int k = 0; k < 2 && e == hipSuccess; ++k) {
-                e = probe_pair_ms(ctx, p[k], p[2], Lp, S, &pi.probe_ms[n]);
-                if (e == hipSuccess && pi.probe_ms[n] < best) { best = pi.probe_ms[n]; keep_a = k; keep_b = 2; }
-                ++n;
-            }
-            pi.peak_extra_bytes = bytes_each;
-        } else {
+    int n = 0, n_probes = 0, keep_a = 0, keep_b = 1;
+    float best = 0.f;
+    hipError_t e = hipSuccess;
+    const bool can_probe = Lp >= 1 && bytes_each >= ((size_t)1 << 28);      // (below 256 MB no levels can be told apart)
+    while (n < MAXP) {
+        if (hipMalloc(&p[n], bytes_each) != hipSuccess) {
             (void)hipGetLastError();
+            p[n] = nullptr;
+            break;
         }
+        ++n;
+        if (n < 2) continue;
+        if (!can_probe) break;
+        bool fast = false;
+        for (int j = 0; j < n - 1 && e == hipSuccess; ++j) {
+            float ms = 0.f;
+            e = probe_pair_ms(ctx, p[j], p[n - 1], Lp, S, &ms);
+            if (e != hipSuccess) break;
+            if (n_probes < TRK_PAIR_MAX_PROBES) pi.probe_ms[n_probes] = ms;
+            ++n_probes;
+            if (best == 0.f || ms < best) { best = ms; keep_a = j; keep_b = n - 1; }
+        }
+        if (e != hipSuccess) break;
+        fast = gbytes / (double)best >= TRK_PAIR_FAST_TBPS;
+        if (fast) break;
     }
-    if (e != hipSuccess) {
-        for (int k = 0; k < 3; ++k) if (p[k]) (void)hipFree(p[k]);
-        return fail(ctx, TRK_ERR_HIP, "trk_reserve_pair probe: %s", hipGetErrorString(e));
+    if (e != hipSuccess || n < 2) {
+        for (int k = 0; k < MAXP; ++k) if (p[k]) (void)hipFree(p[k]);
+        if (e != hipSuccess) return fail(ctx, TRK_ERR_HIP, "trk_reserve_pair probe: %s", hipGetErrorString(e));
+        return fail(ctx, TRK_ERR_NOMEM, "trk_reserve_pair: hipMalloc(%zu)", bytes_each);
     }
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < MAXP; ++k)
         if (p[k] && k != keep_a && k != keep_b) (void)hipFree(p[k]);
     ctx->res_plane[0] = p[keep_a];
     ctx->res_plane[1] = p[keep_b];
     ctx->res_bytes = bytes_each;
     ctx->res_lent[0] = ctx->res_lent[1] = false;
-    ctx->res_tbps = Lp >= 1 ? (float)(gbytes / (double)best) : 0.f;
-    pi.n_probed = n;
+    ctx->res_tbps = (can_probe && best > 0.f) ? (float)(gbytes / (double)best) : 0.f;
+    pi.n_probed = n_probes < TRK_PAIR_MAX_PROBES ? n_probes : TRK_PAIR_MAX_PROBES;
     pi.kept_ms = best;
     pi.placed = ctx->res_tbps >= (float)TRK_PAIR_FAST_TBPS ? 1 : 0;
+    pi.peak_extra_bytes = (uint64_t)(n > 2 ? n - 2 : 0) * (uint64_t)bytes_each;
     pi.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (info) *info = pi;
     return TRK_OK;
@@ -1362,7 +1368,8 @@ int trk_dev_alloc_pair(trk_ctx* ctx, size_t bytes_each, int64_t n_loci, int64_t 
     hipError_t e = hipSuccess;
     // the reserved pair (trk_reserve_pair: the process's first two allocations), when it is free and large enough:
     // lent out as it is, timed once with the caller's shape for the record
-    if (ctx->res_plane[0] && !ctx->res_lent[0] && !ctx->res_lent[1] && bytes_each <= ctx->res_bytes) {
+    if (ctx->res_plane[0] && !ctx->res_lent[0] && !ctx->res_lent[1] && bytes_each <= ctx->res_bytes &&
+        (ctx->res_tbps >= (float)TRK_PAIR_FAST_TBPS || ctx->res_bytes < ((size_t)1 << 28))) {    // (a pair that is not fast is not lent: the search below)
         *a = ctx->res_plane[0];
         *b = ctx->res_plane[1];
         ctx->res_lent[0] = ctx->res_lent[1] = true;
