@@ -319,9 +319,9 @@ typedef struct {
  * in profiles/r05_class_probe.txt) -- and at the START of a process the class changes within the first few allocations:
  * plane 0 has a fast partner among planes 1 ... 4 in seven of eight fresh processes (five times it is plane 1), against
  * two of eight for the plane next to it once 12 GB of inputs have been allocated (same file).  trk_reserve_pair,
- * called right after trk_init and before any other device allocation, takes planes of bytes_each one at a time -- five
+ * called right after trk_init and before any other device allocation, takes planes of bytes_each one at a time -- eight
  * at most --, times each with the ones before it and stops at the first fast pair; the best pair stays, the others go
- * back (transient: up to three planes, while the device is still empty).  The context owns the pair for its lifetime:
+ * back (transient: up to six planes, while the device is still empty).  The context owns the pair for its lifetime:
  * trk_dev_alloc_pair lends it out whenever it is fast, both planes are free and bytes_each fits
  * (trk_pair_info.reserved = 1) -- a sub-plane lies in its plane's region, so smaller shapes are served alike -- and
  * trk_dev_free on either pointer hands it back instead of freeing it. */

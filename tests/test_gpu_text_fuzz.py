@@ -111,6 +111,7 @@ def _render(rng, n_rec, S, hard_p, crlf, ploidy_max):
                     t = ','.join(str(int(rng.integers(0, 50))) for _ in range(int(rng.integers(1, 4))))
                 else:
                     t = str(rng.choice(['0|0', '.', '-2|4', 'x', 'a;b|c', 'long_' * int(rng.integers(1, 30))]))
+                    easy_only &= len(t) <= 40      # (a token whose needed fields lie beyond the text staged behind a tile is the host's)
                 toks.append(t)
             if rng.random() < 0.12 and len(toks) > 1:
                 toks = toks[:int(rng.integers(1, len(toks)))]        # trailing fields dropped

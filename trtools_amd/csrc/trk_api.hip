@@ -1303,7 +1303,7 @@ int trk_reserve_pair(trk_ctx* ctx, size_t bytes_each, trk_pair_info* info) {
     // of a process the placement class changes within the first few allocations (profiles/r05_class_probe.txt: a fast
     // partner for plane 0 among planes 1 ... 4 in seven of eight fresh processes) and the memory is empty, so up to
     // four spare planes cost nothing but 5 ms of probes each.  The best pair stays, the rest goes back.
-    constexpr int MAXP = 5;
+    constexpr int MAXP = 8;
     void* p[MAXP] = {};
     const int64_t S = 8192, Lp = (int64_t)(bytes_each / ((size_t)S * 4u));   // the probe's shape: rows of 8192 samples
     const double gbytes = 2.0 * (double)Lp * (double)S * 4.0 * 1e-9;
