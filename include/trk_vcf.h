@@ -138,6 +138,8 @@ typedef struct {
     int (*seed)(void* user, const char* text, size_t n_bytes);
     int (*inflate)(void* user, const unsigned char* comp, size_t comp_bytes, const trk_vcf_iblock* blocks, int n_blocks,
                    uint64_t abs_base, size_t total, char* out, int* line_state, const uint64_t** nl, size_t* n_nl);
+    int32_t max_members;    /* > 0: at most this many members per call (a device inflates a member per wave: the run that
+                               fills it once, no more, is the fastest -- 16 x the CUs on gfx950); 0: whatever was read */
 } trk_vcf_inflate_hook;
 int trk_vcf_set_inflate_hook(trk_vcf* v, const trk_vcf_inflate_hook* hook);
 uint64_t trk_vcf_text_abs(trk_vcf* v);

@@ -31,6 +31,7 @@ class PyHook:
         self.text = bytearray()          # the whole stream (what a device keeps in its segments)
         self.keep = []
         self.calls = 0
+        self.max_seen = 0
 
         def seed(user, text, n):
             self.text += C.string_at(text, n)
@@ -38,6 +39,7 @@ class PyHook:
 
         def inflate(user, comp, comp_bytes, blocks, n_blocks, abs_base, total, out, line_state, nl, n_nl):
             self.calls += 1
+            self.max_seen = max(getattr(self, 'max_seen', 0), n_blocks)
             assert abs_base == len(self.text)
             raw = C.string_at(comp, comp_bytes)
             seg = bytearray(total)
@@ -86,12 +88,12 @@ class PyHook:
             return 0
         self._seed, self._inflate = SEED_FN(seed), INFLATE_FN(inflate)
 
-    def struct(self):
+    def struct(self, max_members=0):
         from trtools_amd.vcfnative import _InflateHook
-        return _InflateHook(None, C.cast(self._seed, C.c_void_p).value, C.cast(self._inflate, C.c_void_p).value)
+        return _InflateHook(None, C.cast(self._seed, C.c_void_p).value, C.cast(self._inflate, C.c_void_p).value, max_members)
 
 
-def _batches(path, hooked, batch_records, keys=('DP', 'Q')):
+def _batches(path, hooked, batch_records, keys=('DP', 'Q'), max_members=0):
     """(per record: head text, line length, field offsets, fmt idx), harmonised lists -- read with or without a hook."""
     from trtools_amd import vcfnative
     r = vcfnative.NativeVCFReader(path, batch_records=batch_records)
@@ -102,7 +104,7 @@ def _batches(path, hooked, batch_records, keys=('DP', 'Q')):
     hook = None
     if hooked:
         hook = PyHook()
-        hs = hook.struct()
+        hs = hook.struct(max_members)
         assert r._lib.trk_vcf_set_inflate_hook(r._h, C.byref(hs)) == 0, r._lib.trk_vcf_last_error(r._h)
         r._keep_hook = (hook, hs)
     out, absolute = [], []
@@ -164,12 +166,12 @@ def test_hooked_read_equals_the_plain_read(tmp_path, case):
             "one record": lambda: _synthetic(1, 5, seed=5)}[case]()
     path = _bgzip(tmp_path, 'f.vcf.gz', text)
     from trtools_amd import _lib as L
-    for br, min_read in ((7, 70000), (64, 300000), (16, 8 << 20)):
+    for br, min_read, mm in ((7, 70000, 0), (64, 300000, 0), (16, 8 << 20, 0), (16, 8 << 20, 3), (7, 70000, 1)):
         # (small reads of the compressed file, so that a file of a few megabytes takes many fills: members, heads and
-        # CRLF pairs cut by the fill boundaries)
+        # CRLF pairs cut by the fill boundaries; mm: the hook's max_members -- runs of at most so many members)
         with L.options(TRK_VCF_READ_BYTES=min_read):
             plain, abs_p, _ = _batches(path, False, br)
-            hooked, abs_h, hook = _batches(path, True, br)
+            hooked, abs_h, hook = _batches(path, True, br, max_members=mm)
         assert len(plain) == len(hooked) and len(plain) > 0
         for a, b in zip(plain, hooked):
             assert a == b
@@ -179,6 +181,7 @@ def test_hooked_read_equals_the_plain_read(tmp_path, case):
         for (lo, le), rec in zip(abs_h, recs):
             assert full[lo:lo + len(rec[0])] == rec[0] and (le == len(full) or full[le:le + 1] in (b'\n', b'\r'))
         assert hook.calls >= (1 if min_read < (1 << 20) and len(text) > 2000000 else 0)
+        assert mm == 0 or hook.max_seen <= mm
 
 
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])

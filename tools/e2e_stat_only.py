@@ -11,9 +11,10 @@ ns = argparse.Namespace(vcf=path, out='/tmp/e2e/stat', vcftype='hipstr', samples
                         nalleles=True, nalleles_thresh=0.01, only_passing=False)
 for i in range(4):
     t = time.time(); statSTR.main(ns); print("run %d: %.3f s" % (i, time.time() - t), flush=True)
-os.environ['TRK_VCF_TIMING'] = '1'
+from trtools_amd import _lib as _L
+_L.set_option('TRK_VCF_TIMING', 1); _L.set_option('TRK_INFLATE_TIMING', 1)
 t = time.time(); statSTR.main(ns); print("timed run: %.3f s" % (time.time() - t), flush=True)
-del os.environ['TRK_VCF_TIMING']
+_L.set_option('TRK_VCF_TIMING', None); _L.set_option('TRK_INFLATE_TIMING', None)
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable(); statSTR.main(ns); pr.disable()
 pstats.Stats(pr).sort_stats('tottime').print_stats(14)

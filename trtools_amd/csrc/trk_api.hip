@@ -1016,6 +1016,12 @@ static int inf_inflate(void* user, const unsigned char* comp, size_t comp_bytes,
     *n_nl = 0;
     ++st->n_calls;
     if (total == 0 || n_blocks <= 0) return 0;            // (members without text: the end-of-file marker)
+    const bool timing = trk_opt("TRK_INFLATE_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t0 = now();
     const size_t nb = (size_t)n_blocks;
     // tables: in_off, out_off (int64), in_len, out_len (int32), then the flags
     const size_t tab_bytes = nb * 24, flag_off = (tab_bytes + 15) & ~(size_t)15;
@@ -1050,6 +1056,8 @@ static int inf_inflate(void* user, const unsigned char* comp, size_t comp_bytes,
     }
     if (hipMemcpyAsync(st->d_comp, comp, comp_bytes, hipMemcpyHostToDevice, q) != hipSuccess) return bail(TRK_ERR_HIP);
     if (hipMemcpyAsync(st->d_tab, st->h_stage, tab_bytes, hipMemcpyHostToDevice, q) != hipSuccess) return bail(TRK_ERR_HIP);
+    if (timing) (void)hipStreamSynchronize(q);
+    const auto t1 = now();
     trk_inflate_in in = {};
     in.comp = st->d_comp;
     in.n_comp_bytes = (int64_t)comp_bytes;
@@ -1063,6 +1071,7 @@ static int inf_inflate(void* user, const unsigned char* comp, size_t comp_bytes,
     uint8_t* h_flags = st->h_stage + flag_off;
     if (hipMemcpyAsync(h_flags, st->d_tab + flag_off, nb, hipMemcpyDeviceToHost, q) != hipSuccess || hipStreamSynchronize(q) != hipSuccess)
         return bail(TRK_ERR_HIP);
+    const auto t2 = now();
     // members the kernel left: inflated here (zlib), their text copied in
     for (size_t i = 0; i < nb; ++i) {
         if (!h_flags[i]) continue;
@@ -1100,6 +1109,7 @@ static int inf_inflate(void* user, const unsigned char* comp, size_t comp_bytes,
     if (trk::launch_line_index(seg, (int64_t)total, *line_state, ws, q) != hipSuccess) return bail(TRK_ERR_HIP);
     uint32_t* h_scal = reinterpret_cast<uint32_t*>(st->h_stage);
     if (hipMemcpyAsync(h_scal, scal, 16, hipMemcpyDeviceToHost, q) != hipSuccess || hipStreamSynchronize(q) != hipSuccess) return bail(TRK_ERR_HIP);
+    const auto t3 = now();
     const uint32_t n_found = h_scal[0], head_total = h_scal[1];
     const int state = (int)h_scal[2];
     if (n_found > nl_cap || head_total > ws.packed_cap) return bail(TRK_ERR_ARG);       // (lines of fewer than 16 bytes on average: not a VCF)
@@ -1114,6 +1124,7 @@ static int inf_inflate(void* user, const unsigned char* comp, size_t comp_bytes,
     if (e == hipSuccess && head_total) e = hipMemcpyAsync(st->h_stage + r_pack, ws.packed, head_total, hipMemcpyDeviceToHost, q);
     if (e == hipSuccess) e = hipStreamSynchronize(q);
     if (e != hipSuccess) return bail(TRK_ERR_HIP);
+    const auto t4 = now();
     const uint64_t* h_nl = reinterpret_cast<const uint64_t*>(st->h_stage + r_nl);
     const uint64_t* h_hoff = reinterpret_cast<const uint64_t*>(st->h_stage + r_hoff);
     const uint32_t* h_hlen = reinterpret_cast<const uint32_t*>(st->h_stage + r_hlen);
@@ -1133,6 +1144,9 @@ static int inf_inflate(void* user, const unsigned char* comp, size_t comp_bytes,
     st->n_blocks += nb;
     st->n_text += total;
     st->n_comp += comp_bytes;
+    if (timing)
+        fprintf(stderr, "[trk inflate] %d members, %.1f MB -> %.1f MB: prepare+upload %.2f ms, kernel+flags %.2f, index %.2f, results down %.2f, heads %.2f\n", n_blocks,
+                comp_bytes / 1e6, total / 1e6, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, now()));
     return 0;
 }
 

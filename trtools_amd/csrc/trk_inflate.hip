@@ -6,7 +6,7 @@
 // headers give sizes; include/trk_vcf.h) and hands the raw DEFLATE payloads over; one WAVE inflates one member:
 //   * the bit reader, the Huffman decode and the control flow are wave-uniform (every lane computes the same thing: on
 //     this machine that is the scalar unit plus broadcast LDS reads -- there is nothing to hand out inside one symbol);
-//   * the compressed bytes are read 256 at a time, a dword per lane, the next 256 already in flight; a dword of the
+//   * the compressed bytes are read 256 at a time, a dword per lane (loaded when the reader gets there); a dword of the
 //     stream is one v_readlane;
 //   * the code tables are built by all lanes: counts by LDS atomics, a symbol's rank among the symbols of its length by
 //     ballots in symbol order, every lane fills the primary-table slots of its own symbols.  Codes longer than the
@@ -14,7 +14,7 @@
 //     length, symbols sorted by length), not through secondary tables;
 //   * the text goes straight to the buffer in HBM; the last 4 KiB of it are also kept in an LDS ring: a match inside the
 //     ring is copied there by the lanes (a period shorter than the length by doubling), a match further back reads the
-//     text buffer (the wave fences its own stores every 2 KiB, so those bytes are there).
+//     text buffer behind a workgroup-scope fence (the wave's own stores have completed: lanes read other lanes' bytes).
 // A member the kernel cannot finish (corrupt stream, more text than its ISIZE, a distance before the member's start) is
 // FLAGGED and left to the host inflater; nothing is trusted about the input beyond the bounds the caller gives.
 // Roofline note: a serial symbol decode per wave is bound by the latency of its dependent table reads, not by HBM: the
@@ -27,7 +27,7 @@
 
 namespace {
 
-constexpr int LL_ROOT = 10, D_ROOT = 8;   // index bits of the primary tables
+constexpr int LL_ROOT = 9, D_ROOT = 8;    // index bits of the primary tables
 constexpr int LL_MAX = 288, D_MAX = 32;
 
 struct InfArgs {
@@ -43,7 +43,7 @@ struct CodeSet {          // per code (literal/length, distance): canonical desc
 
 // A wave's LDS: the decode tables and a RING of the last 4 KiB of text.  The text itself goes straight to the buffer in
 // HBM; a match whose source lies inside the ring is copied there (LDS is in order for a wave: no fence), a match
-// further back reads the text buffer, which holds those bytes for sure -- the wave fences its own stores every 2 KiB.
+// further back reads the text buffer once the wave's own stores up to there have completed (a workgroup-scope fence).
 // 8 KiB of LDS per member instead of a 32 KiB window: sixteen members per CU instead of four, and a member is one
 // long chain of dependent look-ups that only other members' chains can overlap with (first form, window in LDS:
 // 7 ms per member, 9.6 GB/s of text on the whole chip -- tools/inflate_probe.py, profiles/r05_notes.md).
@@ -53,8 +53,8 @@ constexpr int INF_WAVES = 4;              // members per workgroup (one per wave
 
 struct Lds {
     uint8_t ring[RING];
-    uint16_t ll_tab[1 << LL_ROOT];
-    uint16_t d_tab[1 << D_ROOT];
+    uint32_t ll_tab[1 << LL_ROOT];
+    uint32_t d_tab[1 << D_ROOT];
     uint16_t ll_sorted[LL_MAX];
     uint16_t d_sorted[D_MAX];
     uint8_t lens[LL_MAX + D_MAX];
@@ -64,12 +64,36 @@ struct Lds {
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
+// What a symbol MEANS, ready for the decode loop -- the primary tables hold this beside the code's length, so that a
+// symbol costs one look-up and no arithmetic on its number:
+//   bits 0-3  length of the code word (0: the word is longer than the table's index, or no code word at all)
+//   bits 4-7  extra bits that follow it
+//   bits 8-9  0 a literal, 1 a length / a distance, 2 end of block, 3 a symbol no valid stream holds
+//   bits 16+  the literal, or the base of the length (3 ... 258) / of the distance (1 ... 24577)
+constexpr uint32_t E_KIND = 0x300u, E_BASE = 0x100u, E_EOB = 0x200u, E_BAD = 0x300u;
+__device__ __forceinline__ uint32_t ll_entry(int sym) {
+    if (sym < 256) return (uint32_t)sym << 16;
+    if (sym == 256) return E_EOB;
+    const int li = sym - 257;
+    if (li > 28) return E_BAD;
+    if (li < 8) return ((uint32_t)(li + 3) << 16) | E_BASE;
+    if (li == 28) return (258u << 16) | E_BASE;
+    const int eb = (li >> 2) - 1;
+    return ((uint32_t)(((4 + (li & 3)) << eb) + 3) << 16) | E_BASE | ((uint32_t)eb << 4);
+}
+__device__ __forceinline__ uint32_t d_entry(int ds) {
+    if (ds > 29) return E_BAD;
+    if (ds < 4) return ((uint32_t)(ds + 1) << 16) | E_BASE;
+    const int eb = (ds >> 1) - 1;
+    return ((uint32_t)(((2 + (ds & 1)) << eb) + 1) << 16) | E_BASE | ((uint32_t)eb << 4);
+}
+
 // the compressed stream of one member: 256 bytes per register, a dword per lane; `next` is the following 256
 struct BitReader {
     const uint32_t* base;      // dword-aligned address at or before the payload
     uint32_t n_dwords;         // dwords that may be read (payload + slack the caller guarantees); a payload is < 64 KiB
     uint32_t w0;               // dword index held by lane 0 of `cur`
-    uint32_t cur, next;
+    uint32_t cur;              // 256 bytes of the stream, a dword per lane
     uint32_t dw;               // next dword to take
     uint64_t bb;               // bit buffer (uniform)
     int bc;                    // valid bits in bb
@@ -78,7 +102,8 @@ struct BitReader {
 
     __device__ __forceinline__ uint32_t load_reg(uint32_t w) const {
         const uint32_t i = w + (uint32_t)lane;
-        return i < n_dwords ? __builtin_nontemporal_load(base + i) : 0u;
+        typedef const __attribute__((address_space(1))) uint32_t* gptr;
+        return i < n_dwords ? __builtin_nontemporal_load((gptr)(uintptr_t)base + i) : 0u;
     }
     __device__ __forceinline__ void init(const uint8_t* p, int64_t n_bytes, int ln) {
         lane = ln;
@@ -94,7 +119,6 @@ struct BitReader {
         dw = b >> 2;
         w0 = dw & ~63u;
         cur = load_reg(w0);
-        next = load_reg(w0 + 64);
         bb = 0;
         bc = 0;
         refill();
@@ -103,10 +127,13 @@ struct BitReader {
         bc -= sk;
     }
     __device__ __forceinline__ uint32_t take_dword() {
-        if (dw >= w0 + 64) {           // (uniform) the next register becomes the current one
-            cur = next;
+        // (uniform) the next 256 bytes.  Loaded when needed, not ahead: a register that is in flight across the symbol
+        // loop makes every use of the reader wait for ALL the wave's memory operations -- its stores of text included --
+        // at every dword (one counter, vmcnt, for loads and stores); this way the wave waits once per 256 bytes
+        if (dw >= w0 + 64) {
             w0 += 64;
-            next = load_reg(w0 + 64);
+            cur = load_reg(w0);
+            asm volatile("" : "+v"(cur));      // (a use HERE: the wait for the load stays on this path, not on every dword's)
         }
         const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(dw - w0));
         ++dw;
@@ -114,6 +141,13 @@ struct BitReader {
     }
     __device__ __forceinline__ void refill() {     // at least 33 valid bits afterwards
         while (bc <= 32) {
+            bb |= (uint64_t)take_dword() << bc;
+            bc += 32;
+        }
+    }
+    // the same where bc >= 0 is known (everywhere but after seek): one dword is enough
+    __device__ __forceinline__ void refill1() {
+        if (bc <= 32) {
             bb |= (uint64_t)take_dword() << bc;
             bc += 32;
         }
@@ -137,8 +171,8 @@ __device__ __forceinline__ uint32_t rev_bits(uint32_t v, int n) { return __built
 // Build the decode structures of one code from lens[0 .. n): counts, first codes, sorted symbols, primary table.
 // Returns false (uniform) for an over-subscribed code, or an incomplete one that zlib would refuse (anything but a
 // single one-bit code or an empty code).
-template <int ROOT>
-__device__ __noinline__ bool build_code(const uint8_t* lens, int n, CodeSet& cs, uint16_t* tab, uint16_t* sorted, int lane) {
+template <int ROOT, bool DIST>
+__device__ __noinline__ bool build_code(const uint8_t* lens, int n, CodeSet& cs, uint32_t* tab, uint16_t* sorted, int lane) {
     if (lane < 16) cs.cnt[lane] = 0;
     for (int i = lane; i < (1 << ROOT); i += 64) tab[i] = 0;
     __builtin_amdgcn_wave_barrier();
@@ -193,7 +227,7 @@ __device__ __noinline__ bool build_code(const uint8_t* lens, int n, CodeSet& cs,
             const uint32_t fc = cs.first[l], fo = cs.offs[l];
             sorted[fo + rank] = (uint16_t)s;
             if (l <= ROOT) {
-                const uint16_t e = (uint16_t)((s << 4) | l);
+                const uint32_t e = (DIST ? d_entry(s) : ll_entry(s)) | (uint32_t)l;
                 for (uint32_t k = rev_bits(fc + rank, l); k < (1u << ROOT); k += 1u << l) tab[k] = e;
             }
         }
@@ -202,33 +236,19 @@ __device__ __noinline__ bool build_code(const uint8_t* lens, int n, CodeSet& cs,
     return true;
 }
 
-// one symbol of a code (uniform).  Returns the symbol, or -1 for bits that are no code word.  `br` holds >= 15 bits.
+// A code word the primary table does not hold (uniform; the rare path): longer than ROOT bits, or -- in an incomplete
+// code -- a word of at most ROOT bits that is unused.  By the canonical comparison: first code / count per length,
+// symbols sorted by length.  `bits` = the stream's next 15 bits or more.  Returns (symbol << 4) | length of the word, or
+// -1 for bits that are no code word.
 template <int ROOT>
-__device__ __forceinline__ int decode_sym(BitReader& br, const CodeSet& cs, const uint16_t* tab, const uint16_t* sorted) {
-    const uint32_t e = uni(tab[br.peek(ROOT)]);
-    if (e) {
-        br.drop((int)(e & 15u));
-        return (int)(e >> 4);
-    }
-    const uint32_t r = __builtin_bitreverse32((uint32_t)br.bb);    // the stream's next bits, first bit on top
+__device__ __noinline__ int decode_long(uint32_t bits, const CodeSet& cs, const uint16_t* sorted) {
+    const uint32_t r = __builtin_bitreverse32(bits);    // first bit on top
 #pragma unroll 1
-    for (int l = ROOT + 1; l <= 15; ++l) {
+    for (int k = 0; k < 15; ++k) {
+        const int l = k < 15 - ROOT ? ROOT + 1 + k : k - (15 - ROOT) + 1;      // ROOT + 1 ... 15, then 1 ... ROOT
         const uint32_t c = r >> (32 - l);
         const uint32_t idx = c - uni(cs.first[l]);
-        if (idx < uni(cs.cnt[l])) {
-            br.drop(l);
-            return (int)uni(sorted[uni(cs.offs[l]) + idx]);
-        }
-    }
-    // codes of at most ROOT bits that the table does not hold: an incomplete code's unused words
-#pragma unroll 1
-    for (int l = 1; l <= ROOT; ++l) {
-        const uint32_t c = r >> (32 - l);
-        const uint32_t idx = c - uni(cs.first[l]);
-        if (idx < uni(cs.cnt[l])) {
-            br.drop(l);
-            return (int)uni(sorted[uni(cs.offs[l]) + idx]);
-        }
+        if (idx < uni(cs.cnt[l])) return ((int)uni(sorted[uni(cs.offs[l]) + idx]) << 4) | l;
     }
     return -1;
 }
@@ -251,9 +271,11 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate_bgzf(const InfArgs a
         // run instead of per byte (the per-symbol vector instructions are what bounds this kernel: profiles/r05_sq_inflate.txt)
         uint32_t pend = 0;
         int npend = 0;
+        // (pos may run past out_len by the literals that wait: they are not stored then, and the member is flagged)
         auto flush_literals = [&]() {
             if (npend) {
-                if (lane < npend) {
+                if (pos > out_len) err = TRK_INFLATE_OVERRUN;
+                else if (lane < npend) {
                     const uint32_t o = (uint32_t)(pos - npend) + (uint32_t)lane;
                     s.ring[o & (RING - 1)] = (uint8_t)pend;
                     dst[o] = (uint8_t)pend;
@@ -266,6 +288,9 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate_bgzf(const InfArgs a
             const uint8_t* p = a.in.comp + in_off;
             br.init(p, in_len, lane);
             const int64_t bit_limit = (int64_t)in_len * 8;
+            // the symbol loop looks at the dword counter only (the exact test follows the last block): a stream that runs
+            // past its payload reads zeros, and zeros end in an error or at out_len whatever they decode to
+            const uint32_t dw_limit = ((uint32_t)br.skip + (uint32_t)in_len + 3u) / 4u + 4u;
             bool last = false;
             while (!last && !err) {
                 br.refill();
@@ -400,46 +425,53 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate_bgzf(const InfArgs a
                 // (the result of a call that is not inlined is "divergent" to the compiler, and a divergent exit from this
                 // loop would move the whole bit reader into vector registers: 92 vector instructions per symbol instead
                 // of a dozen -- readfirstlane says what it is)
-                const bool ok_ll = uni(build_code<LL_ROOT>(s.lens, n_ll, s.ll, s.ll_tab, s.ll_sorted, lane) ? 1u : 0u) != 0;
-                const bool ok_d = uni(build_code<D_ROOT>(s.lens + LL_MAX, n_d, s.d, s.d_tab, s.d_sorted, lane) ? 1u : 0u) != 0;
+                const bool ok_ll = uni(build_code<LL_ROOT, false>(s.lens, n_ll, s.ll, s.ll_tab, s.ll_sorted, lane) ? 1u : 0u) != 0;
+                const bool ok_d = uni(build_code<D_ROOT, true>(s.lens + LL_MAX, n_d, s.d, s.d_tab, s.d_sorted, lane) ? 1u : 0u) != 0;
                 if (!ok_ll || !ok_d) {
                     err = TRK_INFLATE_STREAM;
                     break;
                 }
                 // ---- the symbols of this block ----
+                // One look-up per symbol: the table's entry says what the symbol means (ll_entry / d_entry).  At the top
+                // the reader holds >= 33 bits: a literal / length word and its extra bits take at most 20, a distance
+                // word and its extra bits at most 28 after one more dword.
                 for (;;) {
-                    br.refill();
-                    const int sym = decode_sym<LL_ROOT>(br, s.ll, s.ll_tab, s.ll_sorted);
-                    if (sym < 0) { err = TRK_INFLATE_STREAM; break; }
-                    if (sym < 256) {
-                        if (pos >= out_len) { err = TRK_INFLATE_OVERRUN; break; }
-                        pend = lane == npend ? (uint32_t)sym : pend;
+                    br.refill1();
+                    uint32_t e = uni(s.ll_tab[(uint32_t)br.bb & ((1u << LL_ROOT) - 1u)]);
+                    if (!(e & 15u)) {
+                        const int sl = (int)uni((uint32_t)decode_long<LL_ROOT>((uint32_t)br.bb, s.ll, s.ll_sorted));
+                        if (sl < 0) { err = TRK_INFLATE_STREAM; break; }
+                        e = ll_entry(sl >> 4) | (uint32_t)(sl & 15);
+                    }
+                    br.drop((int)(e & 15u));
+                    if (!(e & E_KIND)) {
+                        pend = lane == npend ? e >> 16 : pend;
                         ++npend;
                         ++pos;
-                        if (npend == 64) flush_literals();
-                    } else if (sym == 256) {
-                        flush_literals();
-                        break;
+                        if (npend == 64) {
+                            flush_literals();
+                            if (err || br.dw > dw_limit) { err = err ? err : TRK_INFLATE_STREAM; break; }
+                        }
                     } else {
                         flush_literals();
-                        const int li = sym - 257;
-                        if (li > 28) { err = TRK_INFLATE_STREAM; break; }
-                        int len;
-                        if (li < 8) len = li + 3;
-                        else if (li == 28) len = 258;
-                        else {
-                            const int eb = (li >> 2) - 1;
-                            len = ((4 + (li & 3)) << eb) + 3 + (int)br.take(eb);
+                        if (err) break;
+                        if (e & E_EOB) {              // end of block, or a symbol that is none
+                            if ((e & E_KIND) == E_BAD) err = TRK_INFLATE_STREAM;
+                            break;
                         }
-                        br.refill();
-                        const int ds = decode_sym<D_ROOT>(br, s.d, s.d_tab, s.d_sorted);
-                        if (ds < 0 || ds > 29) { err = TRK_INFLATE_STREAM; break; }
-                        int dist;
-                        if (ds < 4) dist = ds + 1;
-                        else {
-                            const int eb = (ds >> 1) - 1;
-                            dist = ((2 + (ds & 1)) << eb) + 1 + (int)br.take(eb);
+                        const int leb = (int)((e >> 4) & 15u);
+                        const int len = (int)(e >> 16) + (int)br.take(leb);
+                        br.refill1();
+                        uint32_t d = uni(s.d_tab[(uint32_t)br.bb & ((1u << D_ROOT) - 1u)]);
+                        if (!(d & 15u)) {
+                            const int sl = (int)uni((uint32_t)decode_long<D_ROOT>((uint32_t)br.bb, s.d, s.d_sorted));
+                            if (sl < 0) { err = TRK_INFLATE_STREAM; break; }
+                            d = d_entry(sl >> 4) | (uint32_t)(sl & 15);
                         }
+                        br.drop((int)(d & 15u));
+                        if ((d & E_KIND) != E_BASE) { err = TRK_INFLATE_STREAM; break; }
+                        const int deb = (int)((d >> 4) & 15u);
+                        const int dist = (int)(d >> 16) + (int)br.take(deb);
                         if (dist > pos) { err = TRK_INFLATE_STREAM; break; }
                         if (pos + len > out_len) { err = TRK_INFLATE_OVERRUN; break; }
                         if (dist <= NEAR) {
@@ -458,8 +490,11 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate_bgzf(const InfArgs a
                             }
                         } else {
                             // further back than the ring: from the text buffer (no overlap: the distance exceeds the length)
+                            // Lanes read what OTHER lanes of this wave stored: a fence of workgroup scope -- the wave's
+                            // stores have reached the CU's L1 / the L2 it reads through (s_waitcnt vmcnt(0)); nothing
+                            // leaves this CU.  (Agent scope here wrote the whole L2 back, `buffer_wbl2`, per fence.)
                             if (pos - dist + len > fenced) {
-                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                                 fenced = pos;
                             }
                             for (int done = 0; done < len; done += 64) {
@@ -472,12 +507,8 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate_bgzf(const InfArgs a
                             }
                         }
                         pos += len;
+                        if (br.dw > dw_limit) { err = TRK_INFLATE_STREAM; break; }
                     }
-                    if (pos - fenced >= 2048) {     // (a match beyond the ring then finds its source finished)
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-                        fenced = pos;
-                    }
-                    if (br.bits_used() > bit_limit + 64) { err = TRK_INFLATE_STREAM; break; }
                 }
             }
             if (!err && br.bits_used() > bit_limit) err = TRK_INFLATE_STREAM;     // read beyond the payload

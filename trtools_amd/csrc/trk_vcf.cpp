@@ -430,7 +430,9 @@ struct Source {
         size_t start = out.size();
         // (a shard that has reached the next rank's blocks takes one block per call: the caller only needs the end of
         // its last line)
-        while (!eof && out.size() - start < want && !(limit_pos != SIZE_MAX && out.size() > start)) {
+        // (with an inflate hook: one run of members per call -- the hook says how many it likes at a time)
+        while (!eof && out.size() - start < want && !(limit_pos != SIZE_MAX && out.size() > start) &&
+               !(hook.inflate && hook.max_members > 0 && out.size() > start)) {
             if (plain || gz) {
                 size_t chunk = std::max<size_t>(want, 1 << 22);
                 size_t old = out.size();
@@ -564,6 +566,7 @@ struct Source {
                 err = "corrupt BGZF block (inflated size above 64 KiB)";
                 return false;
             }
+            if (hook.inflate && hook.max_members > 0 && (int64_t)blks.size() >= (int64_t)hook.max_members) break;
             blks.push_back({p, bsize, isize, total});
             total += isize;
             n_inflated += isize;

@@ -30,7 +30,7 @@ class _Batch(C.Structure):
 
 
 class _InflateHook(C.Structure):          # trk_vcf_inflate_hook (include/trk_vcf.h)
-    _fields_ = [('user', C.c_void_p), ('seed', C.c_void_p), ('inflate', C.c_void_p)]
+    _fields_ = [('user', C.c_void_p), ('seed', C.c_void_p), ('inflate', C.c_void_p), ('max_members', C.c_int32)]
 
 
 class _Harmonized(C.Structure):
@@ -810,7 +810,9 @@ class NativeVCFReader(vcfio.VCFReader):
         user, seed, infl = C.c_void_p(), C.c_void_p(), C.c_void_p()
         if engine.lib.trk_inflate_hook(engine.ctx, C.byref(user), C.byref(seed), C.byref(infl)) != 0:
             return False
-        hook = _InflateHook(user.value, seed.value, infl.value)
+        # (a member is one wave's serial work of ~7 ms whatever else runs, and a CU holds sixteen of them: a run that fills
+        # the chip exactly once is inflated at the best rate -- tools/inflate_probe.py)
+        hook = _InflateHook(user.value, seed.value, infl.value, 16 * int(getattr(engine, 'n_cu', 256)))
         if self._lib.trk_vcf_set_inflate_hook(self._h, C.byref(hook)) != 0:
             return False                     # (plain gzip / text, a shard, a region: the host inflates)
         self._inflate_hook = hook
