@@ -14,8 +14,12 @@ ap.add_argument('--samples', type=int, default=10000)
 ap.add_argument('--iters', type=int, default=5)
 ap.add_argument('--vecs', type=str, default='1,2,4,8')
 ap.add_argument('--subset', action='store_true')
+ap.add_argument('--opt', action='append', default=[], help='library option KEY=VALUE (include/trk_test.h)')
 a = ap.parse_args()
 eng = Engine(0)
+from trtools_amd import _lib as _L
+for kv in a.opt:
+    _L.set_option(*kv.split('=', 1))
 sb = SynthBatch(eng, a.loci, a.samples, seed=20260928 + 5, planes=())
 alen, rcls = pack_assoc_tables(sb.loci.allele_lens, 2)
 alen_d, rcls_d = eng.upload(alen, np.float64), eng.upload(rcls, np.uint16)
