@@ -338,6 +338,17 @@ typedef struct {
      * INT64_MIN + 1, err_record -1) before it reads the first byte of dev_regions                                        */
     int (*dev_wait)(void* arg);
     void* dev_wait_arg;
+    /* Round 5, optional -- WHOLE-RECORD EMIT: instead of columns that were copied to the host somewhere (dev_regions) and
+     * are gathered behind their heads here, the device puts them where they belong in `out`.  With dev_emit set
+     * (dev_regions may be NULL; dev_region_len / dev_flags as above) the writer builds the heads and the records the device
+     * left to it, lays the batch out -- record l at out[at[l]], its head of head_len[l] bytes first -- and calls
+     *   dev_emit(dev_emit_arg, rec_off, total, out)
+     * once: rec_off[l] = at[l] + head_len[l] for a record whose columns the device holds, -1 for the others; the callee
+     * writes the dev_region_len[l] bytes of those columns at out[rec_off[l]] and may write ANY byte of out[0, total)
+     * besides (one copy of a device buffer laid out the same way is the intended use): the heads, the newlines and the
+     * records written here are put in afterwards.  Non-zero: the call fails with INT64_MIN + 1, err_record -1.          */
+    int (*dev_emit)(void* arg, const int64_t* rec_off, int64_t total, char* out);
+    void* dev_emit_arg;
 } trk_vcf_dumpstr2;
 /* The FORMAT keys of every record of the batch as trk_format_samples wants them: kinds16 [n][16] (1 GT, 2 Integer,
  * 3 Float, 4 String, by in->format_keys / format_kinds; unlisted keys are strings), n_fields [n] -- 0 for a record the

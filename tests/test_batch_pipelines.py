@@ -583,3 +583,65 @@ def test_writer_takes_the_sample_columns_from_the_caller_and_waits_for_them(tmp_
     state['fail'] = True
     (got3, _, path3), = _dump_variants(tmp_path, 'synth_hipstr_all', [{}])
     assert got3 == ref           # (the batch went to the writer that needs no columns)
+
+
+def test_writer_lays_the_batch_out_and_the_caller_puts_the_columns_in_place(tmp_path, monkeypatch):
+    """trk_vcf_dumpstr2.dev_emit (whole-record emit) without a GPU: the writer builds the heads, lays the batch out and
+    calls back with every record's column offset; the callee here scribbles over the WHOLE block first (as one copy of a
+    device buffer would) and then puts the columns (cut from a first run's own output) at the offsets it was given; one
+    record in five is left to the writer (dev_flags).  Same bytes as the first run; a block that is too small is asked
+    for again; a failing callback fails the batch (the pipeline falls back to its other writer)."""
+    import ctypes as C
+    import numpy as np
+    from trtools_amd import vcfnative
+    (ref, stats, path), = _dump_variants(tmp_path, 'synth_hipstr_all', [{}])
+    cols = {}
+    for ln in ref[0].split('\n'):
+        if ln and not ln.startswith('#'):
+            f = ln.split('\t')
+            cols[(f[0], f[1])] = ('\t' + '\t'.join(f[9:])).encode()
+    state = {'calls': 0, 'fail': False, 'taken': 0, 'cap': None, 'totals': []}
+
+    def fake_regions(self, prm, mask, cf_values, S, out_ring, dev_call=None, cf_plane_idx=None):
+        n = self.n
+        lo = np.ctypeslib.as_array(self.b.line_off, shape=(n,))
+        le = np.ctypeslib.as_array(self.b.line_end, shape=(n,))
+        mine, ln, fl = {}, np.zeros(n, np.uint32), np.ones(n, np.uint8)
+        for l in range(n):
+            head = C.string_at(self.b.text + int(lo[l]), min(int(le[l] - lo[l]), 200)).split(b'\t')
+            c = cols.get((head[0].decode(), head[1].decode()))
+            if c is not None and l % 5 != 4:
+                mine[l] = c
+                ln[l], fl[l] = len(c), 0
+                state['taken'] += 1
+
+        def emit(_arg, rec_off, total, out):
+            state['calls'] += 1
+            state['totals'].append(int(total))
+            if state['fail']:
+                return 1
+            C.memset(out, ord('#'), total)
+            for l in range(n):
+                if l in mine:
+                    assert rec_off[l] > 0
+                    C.memmove(out + rec_off[l], mine[l], len(mine[l]))
+                else:
+                    assert rec_off[l] == -1
+            return 0
+        cb = vcfnative._EMIT_FN(emit)
+        cap = state['cap'] if state['cap'] is not None else int(le[n - 1] - lo[0]) * 2 + (1 << 16)
+        return dict(buf=None, off=None, len=ln, flags=fl, wait=None, held=None, emit=cb, cap=cap, error=None)
+
+    monkeypatch.setattr(vcfnative.RawBatch, '_device_regions', fake_regions)
+    (got, stats2, path2), = _dump_variants(tmp_path, 'synth_hipstr_all', [{}])
+    assert path2 == 'batch' and got == ref
+    assert state['calls'] >= 1 and state['taken'] > 20
+    # a block that is too small: the writer says how much it needs and is called again
+    calls0 = state['calls']
+    state['cap'] = 1000
+    (got2, _, path2b), = _dump_variants(tmp_path, 'synth_hipstr_all', [{}])
+    assert got2 == ref and path2b == 'batch' and state['calls'] > calls0
+    state['cap'] = None
+    state['fail'] = True
+    (got3, _, path3), = _dump_variants(tmp_path, 'synth_hipstr_all', [{}])
+    assert got3 == ref           # (the batch went to the writer that needs no columns)

@@ -289,18 +289,24 @@ def test_dumpstr_sample_columns_written_on_the_device(tmp_path, seed):
         text = open(src).read().replace(':1e-3', ':0.001000').replace(':1E2', ':100.0')
         open(src, 'w').write(text)
     kw = dict(hipstr_min_call_DP=20, hipstr_max_call_DP=50, hipstr_min_call_Q=0.9, min_locus_callrate=0.2)
-    outs, took = [], []
-    for dev in ('0', '1'):
+    outs, took, emitted = [], [], []
+    # (host writer; device columns put in place in the output block -- whole-record emit, the default; device columns
+    # downloaded and gathered behind their heads by the writer, round 4's form)
+    for dev, emit in (('0', '1'), ('1', '1'), ('1', '0')):
         os.environ['TRK_DEVICE_FORMAT'] = dev
+        os.environ['TRK_FMT_EMIT'] = emit
         before = dict(vcfnative.DEVICE_FORMAT)
         try:
-            out = str(tmp_path / ('f%s' % dev))
+            out = str(tmp_path / ('f%s%s' % (dev, emit)))
             assert dumpSTR.main(dump_args(out, src, vcftype='hipstr', **kw)) == 0
             assert dumpSTR.LAST_RUN['path'] == 'batch'
             outs.append('\n'.join(x for x in open(out + '.vcf').read().split('\n') if not x.startswith('##command-DumpSTR')))
             took.append(vcfnative.DEVICE_FORMAT['records'] - before['records'])
+            emitted.append(vcfnative.DEVICE_FORMAT.get('emitted', 0) - before.get('emitted', 0))
         finally:
             os.environ.pop('TRK_DEVICE_FORMAT', None)
+            os.environ.pop('TRK_FMT_EMIT', None)
+    assert outs[2] == outs[1] and took[2] == took[1] and emitted == [0, took[1], 0], (took, emitted)
     if outs[0] != outs[1]:
         la, lb = outs[0].split('\n'), outs[1].split('\n')
         i = next(i for i, (p, q) in enumerate(zip(la, lb)) if p != q)

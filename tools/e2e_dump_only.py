@@ -16,6 +16,11 @@ for i in range(3):
         os.remove(f)        # (truncating last run's 1.5 GB output is 0.15 s of open(): not the command line's time)
     t = time.time(); rc = dumpSTR.main(dargs); dt = time.time() - t
     print("run %d: %.3f s  phases %s" % (i, dt, {p: round(x, 3) for p, x in dumpSTR.LAST_RUN['seconds'].items()}), flush=True)
+if os.environ.get('E2E_FMT_TIMING'):
+    from trtools_amd import _lib as _L
+    _L.set_option('TRK_FMT_TIMING', 1)
+    t = time.time(); rc = dumpSTR.main(dargs); print("timed run: %.3f s" % (time.time() - t), flush=True)
+    _L.set_option('TRK_FMT_TIMING', None)
 if os.environ.get('E2E_PROFILE'):
     import cProfile, pstats
     pr = cProfile.Profile(); pr.enable(); dumpSTR.main(dargs); pr.disable()

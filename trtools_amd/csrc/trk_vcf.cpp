@@ -3288,6 +3288,7 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
     // download put them (gptr / glen) until the gather copies both, and the newline, into the output block
     std::vector<const char*> gptr((size_t)n, nullptr);
     std::vector<size_t> glen((size_t)n, 0);
+    std::vector<uint8_t> on_device((size_t)n, 0);     // the device holds the record's sample columns
     std::vector<FmtChunk> used_chunks;
     std::mutex used_mu;
     std::atomic<int> next{0};
@@ -3477,15 +3478,17 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
             const char* smp = line + fo[9];
             const int64_t smp_len = line_len - fo[9];
             const int pl = in->locus_ploidy[l];
-            if (fast_ok && ext->dev_regions && ext->dev_flags && !ext->dev_flags[l] && filter_idx < 0) {
+            if (fast_ok && (ext->dev_regions || ext->dev_emit) && ext->dev_flags && !ext->dev_flags[l] && filter_idx < 0) {
                 // the device wrote this record's sample columns (trk_format_samples): head + those bytes + newline
                 const size_t rl = ext->dev_region_len[l];
                 char* dst = room(hl);
                 memcpy(dst, head, hl);
                 rptr[(size_t)l] = dst;
                 rlen[(size_t)l] = hl;
-                gptr[(size_t)l] = ext->dev_regions + ext->dev_region_off[l];
+                // (whole-record emit: the columns are put into `out` by dev_emit, gptr stays NULL)
+                gptr[(size_t)l] = ext->dev_emit ? nullptr : ext->dev_regions + ext->dev_region_off[l];
                 glen[(size_t)l] = rl + 1;        // (+ the newline, written by the gather)
+                on_device[(size_t)l] = 1;
                 cur_n += hl;
                 g_fmt_fast.fetch_add(1, std::memory_order_relaxed);
                 g_fmt_device.fetch_add(1, std::memory_order_relaxed);
@@ -3638,13 +3641,25 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
     int64_t total = 0;
     for (size_t i = 0; i < (size_t)n; ++i) total += (int64_t)(rlen[i] + glen[i]);
     if (!out || total > cap) return -total;
-    if (ext && ext->dev_regions && ext->dev_wait && ext->dev_wait(ext->dev_wait_arg) != 0) {   // the columns' download
+    const bool emit = ext && ext->dev_emit;
+    if (ext && !emit && ext->dev_regions && ext->dev_wait && ext->dev_wait(ext->dev_wait_arg) != 0) {   // the columns' download
         if (err_record) *err_record = -1;
         return INT64_MIN + 1;
     }
     {   // the lines land at their prefix offsets, copied by the same number of threads
         std::vector<int64_t> at((size_t)n + 1, 0);
         for (int i = 0; i < n; ++i) at[(size_t)i + 1] = at[(size_t)i] + (int64_t)(rlen[(size_t)i] + glen[(size_t)i]);
+        if (emit) {
+            // whole-record emit: the device's columns come straight to their places (the callee may scribble over the rest
+            // of out[0, total): heads and host-written records go in after it)
+            std::vector<int64_t> rec_off((size_t)n, -1);
+            for (int i = 0; i < n; ++i)
+                if (on_device[(size_t)i]) rec_off[(size_t)i] = at[(size_t)i] + (int64_t)rlen[(size_t)i];
+            if (ext->dev_emit(ext->dev_emit_arg, rec_off.data(), total, out) != 0) {
+                if (err_record) *err_record = -1;
+                return INT64_MIN + 1;
+            }
+        }
         std::atomic<int> nx{0};
         auto copier = [&]() {
             for (;;) {
@@ -3655,7 +3670,7 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
                 for (int i = i0; i < std::min(n, i0 + 16); ++i)
                     if (glen[(size_t)i]) {
                         char* d = out + at[(size_t)i] + rlen[(size_t)i];
-                        memcpy(d, gptr[(size_t)i], glen[(size_t)i] - 1);
+                        if (gptr[(size_t)i]) memcpy(d, gptr[(size_t)i], glen[(size_t)i] - 1);     // (NULL: dev_emit put them there)
                         d[glen[(size_t)i] - 1] = '\n';
                     }
             }

@@ -114,7 +114,11 @@ class _DumpRecords(C.Structure):
                 ('fast_path', C.c_int32), ('info_keys', C.POINTER(C.c_char_p)), ('info_kinds', C.POINTER(C.c_int32)),
                 ('need_head', C.c_void_p), ('dev_regions', C.c_void_p), ('dev_region_off', C.c_void_p),
                 ('dev_region_len', C.c_void_p), ('dev_flags', C.c_void_p),
-                ('dev_wait', C.c_void_p), ('dev_wait_arg', C.c_void_p)]
+                ('dev_wait', C.c_void_p), ('dev_wait_arg', C.c_void_p),
+                ('dev_emit', C.c_void_p), ('dev_emit_arg', C.c_void_p)]
+
+
+_EMIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.c_void_p)     # trk_vcf_dumpstr2.dev_emit
 
 
 READER_QUEUE = 3       # the read-ahead thread's queue in device-parse mode (trk_thread_queue)
@@ -375,7 +379,12 @@ class RawBatch:
                                len(ik), 1, ikeys, ikinds, need.ctypes.data)
             keep.extend([ftarr, ikeys, ikinds, need])
             regions = self._device_regions(prm, mask, cf_values, S, out_ring, native.get('dev_call'), native.get('cf_plane_idx'))
-            if regions is not None:
+            if regions is not None and regions.get('emit') is not None:
+                # whole-record emit: the writer lays the batch out and calls back; the device puts the columns in place
+                ext.dev_region_len, ext.dev_flags = regions['len'].ctypes.data, regions['flags'].ctypes.data
+                ext.dev_emit = C.cast(regions['emit'], C.c_void_p).value
+                keep.append(regions)
+            elif regions is not None:
                 ext.dev_regions, ext.dev_region_off = regions['buf'].ctypes.data, regions['off'].ctypes.data
                 ext.dev_region_len, ext.dev_flags = regions['len'].ctypes.data, regions['flags'].ctypes.data
                 if regions.get('wait') is not None:     # the download is in flight: the writer waits after the heads
@@ -392,9 +401,21 @@ class RawBatch:
         slot = None
         if out_ring is not None:
             slot = out_ring['i'] = (out_ring.get('i', -1) + 1) % 2
+        emit = regions is not None and regions.get('emit') is not None
+        if emit:
+            cap = int(regions['cap'])      # (a tight bound: the block is pinned memory, the copy's destination)
         try:
             while True:
-                if slot is None:
+                if emit:
+                    ring, key = (out_ring if out_ring is not None else {}), ('emit', slot)
+                    buf = ring.get(key)
+                    if buf is None or buf.size < cap:
+                        alloc = getattr(self.reader, '_alloc', None)     # (pinned where the reader has an engine's allocator)
+                        buf = ring[key] = (alloc(cap + cap // 16 + (1 << 20)) if alloc is not None
+                                           else np.empty(cap + cap // 16 + (1 << 20), dtype=np.uint8))
+                        if alloc is not None:
+                            self.reader._slabs = getattr(self.reader, '_slabs', []) + [buf]
+                elif slot is None:
                     buf = np.empty(cap, dtype=np.uint8)      # not zero-filled; handed to the writer as a memoryview
                 else:
                     buf = out_ring.get(slot)
@@ -406,6 +427,8 @@ class RawBatch:
                     n = lib.trk_vcf_dumpstr_records(C.byref(self.b), C.byref(ext), buf.ctypes.data, cap, C.byref(err))
                 if n >= 0:
                     return memoryview(buf)[:n]
+                if emit and regions.get('error') is not None:
+                    raise regions['error']
                 if ext is not None and n == -(1 << 63) + 2:
                     # INFO columns the native rewrite leaves to Python: those heads come from the caller, once
                     if ext.base.heads:
@@ -481,6 +504,42 @@ class RawBatch:
             total = int(off[-1] + ln[-1])
             if total == 0:
                 return None
+            if (out_ring is not None and getattr(self.reader, '_alloc', None) is not None and
+                    _knobs.lab('TRK_FMT_EMIT', '1') == '1'):
+                # WHOLE-RECORD EMIT (round 5): pass 2 waits until the writer has built the heads and laid the batch out
+                # (trk_vcf_dumpstr2.dev_emit); it then writes every record's columns at their FINAL offsets and one copy
+                # brings the block to the pinned output buffer -- no gather of heads and columns on the host
+                res = dict(buf=None, off=None, len=np.ascontiguousarray(ln, dtype=np.uint32),
+                           flags=np.ascontiguousarray(fl, dtype=np.uint8), wait=None, held=(eng, tmp), error=None)
+                held_tmp, tmp = tmp, []
+
+                def emit_cb(_arg, rec_off_p, total_out, out_p):
+                    try:
+                        ro = np.ctypeslib.as_array(rec_off_p, shape=(n,)).copy()
+                        ro[ro < 0] = 0
+                        ro_d = eng.upload(ro, np.int64)
+                        out_dd = eng.empty((int(total_out) + 16,), np.uint8)
+                        held_tmp.extend([ro_d, out_dd])
+                        fout.out, fout.out_off = out_dd.ptr, ro_d.ptr
+                        eng._chk(eng.lib.trk_format_samples(eng.ctx, C.byref(fin), C.byref(fout), 2))
+                        eng._chk(eng.lib.trk_memcpy_d2h(eng.ctx, out_p, out_dd.ptr, int(total_out)))
+                        return 0
+                    except Exception as e:      # (a ctypes callback must not raise: kept for the caller)
+                        res['error'] = e
+                        return 1
+                res['emit'] = _EMIT_FN(emit_cb)
+                res['keep'] = (fin, fout)
+                # bound of the block: the columns, the heads (as read, doubled, + the INFO updates) and what the host
+                # writer may make of the records the device left to it
+                fo9 = np.ctypeslib.as_array(self.b.field_off, shape=(n, 10))[:, 9].astype(np.int64)
+                ll = (np.ctypeslib.as_array(self.b.line_end, shape=(n,)) - np.ctypeslib.as_array(self.b.line_off, shape=(n,))).astype(np.int64)
+                host = fl != 0
+                res['cap'] = (int(ln[~host].sum()) + 2 * int(fo9.sum()) + 768 * n + int((ll[host] * 1.35).sum()) +
+                              int(host.sum()) * (12 * S + 64) + (1 << 16))
+                DEVICE_FORMAT['records'] += int((fl == 0).sum())
+                DEVICE_FORMAT['left_to_host'] += int((fl != 0).sum())
+                DEVICE_FORMAT['emitted'] = DEVICE_FORMAT.get('emitted', 0) + int((fl == 0).sum())
+                return res
             out_d = eng.empty((total + 16,), np.uint8)
             tmp.append(out_d)
             fout.out, fout.out_off = out_d.ptr, up(off, np.int64).ptr
