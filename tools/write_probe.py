@@ -1,57 +1,67 @@
-"""How fast does the box take 1.5 GB into a file?  One writer (write), N writers (pwrite at disjoint offsets), and a
-memory-mapped file filled by N threads.  usage: write_probe.py [dir]"""
-import mmap, os, sys, threading, time
-d = sys.argv[1] if len(sys.argv) > 1 else '/tmp/e2e'
-os.makedirs(d, exist_ok=True)
-total = 1536 << 20
-chunk = 4 << 20
-buf = (b'0123456789abcdef' * (chunk // 16))
-path = os.path.join(d, 'write_probe.bin')
+"""How fast does a 150 MB block reach a file on this box: one write(), pwrite() by several threads, memcpy into an mmap of
+the file by several threads.  (dumpSTR's writer thread: profiles/r05_notes.md section 8.)"""
+import ctypes as C
+import mmap
+import os
+import sys
+import threading
+import time
 
-def fresh():
+import numpy as np
+
+path = sys.argv[1] if len(sys.argv) > 1 else '/tmp/e2e/wprobe.bin'
+N, B = 150_000_000, 8
+blk = np.random.randint(32, 120, N, dtype=np.uint8)
+mv = memoryview(blk)
+
+
+def run(name, fn):
     if os.path.exists(path):
         os.remove(path)
-
-def one_writer():
-    fresh()
-    t = time.time()
-    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
-    for _ in range(total // chunk):
-        os.write(fd, buf)
-    os.close(fd)
-    return time.time() - t
-
-def n_pwriters(n):
-    fresh()
-    t = time.time()
-    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
-    def work(k):
-        for i in range(k, total // chunk, n):
-            os.pwrite(fd, buf, i * chunk)
-    th = [threading.Thread(target=work, args=(k,)) for k in range(n)]
-    [x.start() for x in th]; [x.join() for x in th]
-    os.close(fd)
-    return time.time() - t
-
-def n_mmap(n):
-    fresh()
-    t = time.time()
     fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
-    os.ftruncate(fd, total)
-    mm = mmap.mmap(fd, total)
-    mv = memoryview(mm)
-    def work(k):
-        for i in range(k, total // chunk, n):
-            mv[i * chunk:(i + 1) * chunk] = buf
-    th = [threading.Thread(target=work, args=(k,)) for k in range(n)]
-    [x.start() for x in th]; [x.join() for x in th]
-    mv.release(); mm.close(); os.close(fd)
-    return time.time() - t
+    ts = []
+    for i in range(B):
+        t = time.perf_counter()
+        fn(fd, i * N)
+        ts.append((time.perf_counter() - t) * 1e3)
+    t = time.perf_counter()
+    os.close(fd)
+    print('%-28s per block ms: %s  (close %.1f)' % (name, ' '.join('%.1f' % x for x in ts), (time.perf_counter() - t) * 1e3), flush=True)
+    os.remove(path)
 
-for rep in range(2):
-    print("write, one thread        : %.3f s = %.2f GB/s" % ((lambda s: (s, total / s / 1e9))(one_writer())), flush=True)
-    for n in (2, 4, 8):
-        s = n_pwriters(n); print("pwrite, %d threads        : %.3f s = %.2f GB/s" % (n, s, total / s / 1e9), flush=True)
-    for n in (1, 4, 8):
-        s = n_mmap(n); print("mmap + copy, %d threads   : %.3f s = %.2f GB/s" % (n, s, total / s / 1e9), flush=True)
-fresh()
+
+def one_write(fd, off):
+    os.pwrite(fd, mv, off)
+
+
+def par_pwrite(nt):
+    def fn(fd, off):
+        step = (N + nt - 1) // nt
+        th = [threading.Thread(target=lambda k=k: os.pwrite(fd, mv[k * step:min(N, (k + 1) * step)], off + k * step)) for k in range(nt)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    return fn
+
+
+def par_mmap(nt):
+    def fn(fd, off):
+        os.ftruncate(fd, off + N)
+        pg = off - off % mmap.ALLOCATIONGRANULARITY
+        m = mmap.mmap(fd, off + N - pg, offset=pg)
+        base = C.addressof(C.c_char.from_buffer(m)) + (off - pg)
+        step = (N + nt - 1) // nt
+        src = blk.ctypes.data
+        th = [threading.Thread(target=lambda k=k: C.memmove(base + k * step, src + k * step, min(step, N - k * step))) for k in range(nt)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        del base
+        m.close()
+    return fn
+
+
+run('one write', one_write)
+for nt in (2, 4, 8):
+    run('pwrite x %d threads' % nt, par_pwrite(nt))
+for nt in (1, 4, 8, 16):
+    run('mmap + memcpy x %d threads' % nt, par_mmap(nt))
+run('one write', one_write)

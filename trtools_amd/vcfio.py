@@ -845,6 +845,15 @@ class VCFWriter:
             job = lambda: raw.write(data)
         else:
             job = lambda: self._fh.write(bytes(data))          # BgzfWriter takes bytes
+        if _knobs.lab('TRK_WRITE_TIMING'):
+            import sys
+            import time
+            inner = job
+
+            def job():
+                t = time.perf_counter()
+                inner()
+                print('[writer] block of %.0f MB written in %.1f ms' % (len(data) / 1e6, (time.perf_counter() - t) * 1e3), file=sys.stderr)
         if _knobs.lab('TRK_ASYNC_WRITE', '1') == '0':
             job()
             return
