@@ -627,6 +627,9 @@ int trk_inflate_blocks(trk_ctx* ctx, const trk_inflate_in* in, const trk_inflate
  * the hook.  trk_inflate_stats: {members, of which flagged, bytes of text, compressed bytes, hook calls}.  The hook runs
  * on the queue of the thread that reads (trk_thread_queue); one reader per context at a time. */
 int trk_inflate_hook(trk_ctx* ctx, void** user, void** seed_fn, void** inflate_fn);
+/* the hook's `inflate` in two halves (trk_vcf_inflate_hook.submit / .collect): the reader keeps two runs in flight, the
+ * kernels run on a queue of the hook's own, the file read and the upload of run k + 1 go on behind the kernel of run k */
+int trk_inflate_hook_async(trk_ctx* ctx, void** submit_fn, void** collect_fn);
 int trk_inflate_text(trk_ctx* ctx, uint64_t abs_from, int64_t n_bytes, void* dst, uint64_t release_before);
 int trk_inflate_stats(trk_ctx* ctx, uint64_t out[5]);
 

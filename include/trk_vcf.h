@@ -140,6 +140,13 @@ typedef struct {
                    uint64_t abs_base, size_t total, char* out, int* line_state, const uint64_t** nl, size_t* n_nl);
     int32_t max_members;    /* > 0: at most this many members per call (a device inflates a member per wave: the run that
                                fills it once, no more, is the fastest -- 16 x the CUs on gfx950); 0: whatever was read */
+    /* Optional, both or neither: `inflate` in two halves, so that the reader can keep TWO runs in flight -- it reads run
+     * k + 1 from the file and submits it (the hook copies `comp` before it returns and starts inflating) BEFORE it
+     * collects run k, whose results are what `inflate` returns.  Runs are collected in the order they were submitted;
+     * abs_base counts on from run to run.  With these set, `inflate` is not called.                                  */
+    int (*submit)(void* user, const unsigned char* comp, size_t comp_bytes, const trk_vcf_iblock* blocks, int n_blocks,
+                  uint64_t abs_base, size_t total);
+    int (*collect)(void* user, char* out, int* line_state, const uint64_t** nl, size_t* n_nl);
 } trk_vcf_inflate_hook;
 int trk_vcf_set_inflate_hook(trk_vcf* v, const trk_vcf_inflate_hook* hook);
 uint64_t trk_vcf_text_abs(trk_vcf* v);

@@ -27,13 +27,20 @@ def eng():
     e.close()
 
 
-def _read(eng, path, batch_records, device_inflate):
+def _read(eng, path, batch_records, device_inflate, pipeline=True):
     from trtools_amd import vcfnative
     r = vcfnative.NativeVCFReader(path, batch_records=batch_records)
     r.select_format('DP')
     r.select_format('Q')
     assert r.device_parse(eng)
-    assert r.device_inflate(eng) if device_inflate else True
+    if device_inflate:
+        # (two runs in flight -- trk_inflate_hook_async, the default -- or the hook's one synchronous call per run)
+        os.environ['TRK_INFLATE_PIPELINE'] = '1' if pipeline else '0'
+        try:
+            assert r.device_inflate(eng)
+        finally:
+            os.environ.pop('TRK_INFLATE_PIPELINE', None)
+        assert bool(r._inflate_hook.submit) == pipeline
     out = []
     while True:
         rb = r._read_raw_batch(batch_records)
@@ -75,12 +82,14 @@ def test_device_inflated_batches_equal_host_inflated_ones(eng, tmp_path, case):
         with L.options(**opts):
             host, _ = _read(eng, path, br, False)
             dev, fb = _read(eng, path, br, True)
-        assert len(host) == len(dev) and len(host) > 0 and fb == 0
-        for (h1, l1, g1, p1, pl1, lp1), (h2, l2, g2, p2, pl2, lp2) in zip(host, dev):
-            assert h1 == h2 and l1 == l2
-            assert np.array_equal(g1, g2) and np.array_equal(p1, p2) and np.array_equal(lp1, lp2)
-            for k in pl1:
-                assert np.array_equal(pl1[k].view(np.uint32), pl2[k].view(np.uint32)), k
+            dev1, fb1 = _read(eng, path, br, True, pipeline=False)
+        for dev, fb in ((dev, fb), (dev1, fb1)):
+            assert len(host) == len(dev) and len(host) > 0 and fb == 0
+            for (h1, l1, g1, p1, pl1, lp1), (h2, l2, g2, p2, pl2, lp2) in zip(host, dev):
+                assert h1 == h2 and l1 == l2
+                assert np.array_equal(g1, g2) and np.array_equal(p1, p2) and np.array_equal(lp1, lp2)
+                for k in pl1:
+                    assert np.array_equal(pl1[k].view(np.uint32), pl2[k].view(np.uint32)), k
     st = (C.c_uint64 * 5)()
     eng.lib.trk_inflate_stats(eng.ctx, st)
     assert st[0] > 0 and st[1] == 0 and st[2] > 0      # members inflated on the device, none left to zlib

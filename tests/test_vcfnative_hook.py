@@ -24,6 +24,10 @@ INFLATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(
                          C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_size_t))
 
 
+SUBMIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(IBlock), C.c_int, C.c_uint64, C.c_size_t)
+COLLECT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_size_t))
+
+
 class PyHook:
     """zlib inflate + line index + heads, with the carry of the unfinished line between calls."""
 
@@ -32,22 +36,37 @@ class PyHook:
         self.keep = []
         self.calls = 0
         self.max_seen = 0
+        self.queue, self.max_in_flight = [], 0
 
         def seed(user, text, n):
             self.text += C.string_at(text, n)
             return 0
 
         def inflate(user, comp, comp_bytes, blocks, n_blocks, abs_base, total, out, line_state, nl, n_nl):
-            self.calls += 1
-            self.max_seen = max(getattr(self, 'max_seen', 0), n_blocks)
-            assert abs_base == len(self.text)
             raw = C.string_at(comp, comp_bytes)
+            blks = [(blocks[i].payload_off, blocks[i].payload_len, blocks[i].isize, blocks[i].dst) for i in range(n_blocks)]
+            return work(raw, blks, abs_base, total, out, line_state, nl, n_nl)
+
+        # the two halves (trk_vcf_inflate_hook.submit / collect): the reader hands run k + 1 over before it collects run k
+        def submit(user, comp, comp_bytes, blocks, n_blocks, abs_base, total):
+            blks = [(blocks[i].payload_off, blocks[i].payload_len, blocks[i].isize, blocks[i].dst) for i in range(n_blocks)]
+            self.queue.append((C.string_at(comp, comp_bytes), blks, abs_base, total))
+            self.max_in_flight = max(self.max_in_flight, len(self.queue))
+            return 0
+
+        def collect(user, out, line_state, nl, n_nl):
+            raw, blks, abs_base, total = self.queue.pop(0)
+            return work(raw, blks, abs_base, total, out, line_state, nl, n_nl)
+
+        def work(raw, blks, abs_base, total, out, line_state, nl, n_nl):
+            self.calls += 1
+            self.max_seen = max(getattr(self, 'max_seen', 0), len(blks))
+            assert abs_base == len(self.text)
             seg = bytearray(total)
-            for i in range(n_blocks):
-                b = blocks[i]
-                d = zlib.decompress(raw[b.payload_off:b.payload_off + b.payload_len], -15)
-                assert len(d) == b.isize
-                seg[b.dst:b.dst + b.isize] = d
+            for off, ln, isize, dst in blks:
+                d = zlib.decompress(raw[off:off + ln], -15)
+                assert len(d) == isize
+                seg[dst:dst + isize] = d
             self.text += seg
             # poison the reader's buffer, then put the heads where they belong
             if total:
@@ -87,13 +106,17 @@ class PyHook:
             n_nl[0] = len(nls)
             return 0
         self._seed, self._inflate = SEED_FN(seed), INFLATE_FN(inflate)
+        self._submit, self._collect = SUBMIT_FN(submit), COLLECT_FN(collect)
 
-    def struct(self, max_members=0):
+    def struct(self, max_members=0, pipelined=False):
         from trtools_amd.vcfnative import _InflateHook
-        return _InflateHook(None, C.cast(self._seed, C.c_void_p).value, C.cast(self._inflate, C.c_void_p).value, max_members)
+        h = _InflateHook(None, C.cast(self._seed, C.c_void_p).value, C.cast(self._inflate, C.c_void_p).value, max_members)
+        if pipelined:
+            h.submit, h.collect = C.cast(self._submit, C.c_void_p).value, C.cast(self._collect, C.c_void_p).value
+        return h
 
 
-def _batches(path, hooked, batch_records, keys=('DP', 'Q'), max_members=0):
+def _batches(path, hooked, batch_records, keys=('DP', 'Q'), max_members=0, pipelined=False):
     """(per record: head text, line length, field offsets, fmt idx), harmonised lists -- read with or without a hook."""
     from trtools_amd import vcfnative
     r = vcfnative.NativeVCFReader(path, batch_records=batch_records)
@@ -104,7 +127,7 @@ def _batches(path, hooked, batch_records, keys=('DP', 'Q'), max_members=0):
     hook = None
     if hooked:
         hook = PyHook()
-        hs = hook.struct(max_members)
+        hs = hook.struct(max_members, pipelined)
         assert r._lib.trk_vcf_set_inflate_hook(r._h, C.byref(hs)) == 0, r._lib.trk_vcf_last_error(r._h)
         r._keep_hook = (hook, hs)
     out, absolute = [], []
@@ -166,12 +189,14 @@ def test_hooked_read_equals_the_plain_read(tmp_path, case):
             "one record": lambda: _synthetic(1, 5, seed=5)}[case]()
     path = _bgzip(tmp_path, 'f.vcf.gz', text)
     from trtools_amd import _lib as L
-    for br, min_read, mm in ((7, 70000, 0), (64, 300000, 0), (16, 8 << 20, 0), (16, 8 << 20, 3), (7, 70000, 1)):
+    for br, min_read, mm, pl in ((7, 70000, 0, False), (64, 300000, 0, False), (16, 8 << 20, 0, False), (16, 8 << 20, 3, False),
+                                 (7, 70000, 1, False), (7, 70000, 0, True), (16, 8 << 20, 3, True), (64, 300000, 1, True)):
         # (small reads of the compressed file, so that a file of a few megabytes takes many fills: members, heads and
-        # CRLF pairs cut by the fill boundaries; mm: the hook's max_members -- runs of at most so many members)
+        # CRLF pairs cut by the fill boundaries; mm: the hook's max_members -- runs of at most so many members; pl: the
+        # hook's submit / collect halves -- two runs in flight)
         with L.options(TRK_VCF_READ_BYTES=min_read):
             plain, abs_p, _ = _batches(path, False, br)
-            hooked, abs_h, hook = _batches(path, True, br, max_members=mm)
+            hooked, abs_h, hook = _batches(path, True, br, max_members=mm, pipelined=pl)
         assert len(plain) == len(hooked) and len(plain) > 0
         for a, b in zip(plain, hooked):
             assert a == b
@@ -182,6 +207,7 @@ def test_hooked_read_equals_the_plain_read(tmp_path, case):
             assert full[lo:lo + len(rec[0])] == rec[0] and (le == len(full) or full[le:le + 1] in (b'\n', b'\r'))
         assert hook.calls >= (1 if min_read < (1 << 20) and len(text) > 2000000 else 0)
         assert mm == 0 or hook.max_seen <= mm
+        assert not hook.queue and (not pl or hook.max_in_flight <= 2)
 
 
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
@@ -190,7 +216,8 @@ def test_hooked_read_of_the_fixtures(path):
     with L.options(TRK_VCF_READ_BYTES=20000):
         plain, _, _ = _batches(path, False, 16)
         hooked, _, hook = _batches(path, True, 16)
-    assert plain == hooked and len(plain) > 10
+        piped, _, hook2 = _batches(path, True, 16, max_members=2, pipelined=True)
+    assert plain == hooked and plain == piped and len(plain) > 10 and hook2.max_in_flight == 2
 
 
 def test_hook_is_refused_where_it_cannot_work(tmp_path):

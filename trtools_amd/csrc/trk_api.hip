@@ -922,14 +922,41 @@ struct InfSeg {
     uint8_t* d;
     size_t cap;
 };
-struct InflateState {
-    trk_ctx* ctx = nullptr;
-    std::deque<InfSeg> segs;
-    std::vector<std::pair<uint8_t*, size_t>> spare;     // segment buffers to use again
+// One run of members on its way through the device: submitted (compressed bytes and tables up, kernel launched on the
+// hook's own queue, flags on their way down) and not yet collected.
+struct InfRun {
     uint8_t* d_comp = nullptr;
     size_t comp_cap = 0;
     uint8_t* d_tab = nullptr;
     size_t tab_cap = 0;
+    uint8_t* h_tab = nullptr;      // pinned: tables up, flags down
+    size_t h_cap = 0;
+    uint8_t* seg = nullptr;
+    size_t seg_cap = 0;
+    size_t nb = 0, total = 0, comp_bytes = 0, flag_off = 0;
+    uint64_t abs_base = 0;
+    std::vector<trk_vcf_iblock> blocks;
+    hipEvent_t done = nullptr;
+    double t_up = 0.0;
+    std::chrono::steady_clock::time_point t_submit;
+};
+static void inf_run_free(InfRun& r) {
+    if (r.d_comp) (void)hipFree(r.d_comp);
+    if (r.d_tab) (void)hipFree(r.d_tab);
+    if (r.h_tab) (void)hipHostFree(r.h_tab);
+    if (r.done) (void)hipEventDestroy(r.done);
+    r = InfRun{};
+}
+
+struct InflateState {
+    trk_ctx* ctx = nullptr;
+    std::deque<InfRun> runs;            // submitted, not collected (in order)
+    std::vector<InfRun> run_pool;       // their buffers, to use again
+    hipStream_t q_inf = nullptr;        // the inflate kernels' queue
+    hipStream_t q_up = nullptr;         // the uploads'
+
+    std::deque<InfSeg> segs;
+    std::vector<std::pair<uint8_t*, size_t>> spare;     // segment buffers to use again
     uint8_t* d_ws = nullptr;       // line-index workspace
     size_t ws_cap = 0;
     uint8_t* h_stage = nullptr;    // pinned: tables up, results down
@@ -940,8 +967,14 @@ struct InflateState {
 static void inflate_state_free(InflateState* st) {
     for (auto& sg : st->segs) (void)hipFree(sg.d);
     for (auto& sp : st->spare) (void)hipFree(sp.first);
-    if (st->d_comp) (void)hipFree(st->d_comp);
-    if (st->d_tab) (void)hipFree(st->d_tab);
+    if (st->q_inf) (void)hipStreamSynchronize(st->q_inf);
+    for (auto& r : st->runs) {
+        if (r.seg) (void)hipFree(r.seg);
+        inf_run_free(r);
+    }
+    for (auto& r : st->run_pool) inf_run_free(r);
+    if (st->q_inf) (void)hipStreamDestroy(st->q_inf);
+    if (st->q_up) (void)hipStreamDestroy(st->q_up);
     if (st->d_ws) (void)hipFree(st->d_ws);
     if (st->h_stage) (void)hipHostFree(st->h_stage);
     delete st;
@@ -993,6 +1026,14 @@ static int inf_seed(void* user, const char* text, size_t n) {
     (void)hipSetDevice(ctx->device);
     for (auto& sg : st->segs) inf_release(st, sg);
     st->segs.clear();
+    if (st->q_inf) (void)hipStreamSynchronize(st->q_inf);
+    while (!st->runs.empty()) {            // (a reader that went away with runs in flight)
+        InfRun r = std::move(st->runs.front());
+        st->runs.pop_front();
+        if (r.seg) st->spare.emplace_back(r.seg, r.seg_cap);
+        r.seg = nullptr;
+        st->run_pool.push_back(std::move(r));
+    }
     if (n == 0) return 0;
     size_t cap = 0;
     uint8_t* d = inf_segment(st, n + 2048, cap);
@@ -1006,44 +1047,66 @@ static int inf_seed(void* user, const char* text, size_t n) {
     return 0;
 }
 
-static int inf_inflate(void* user, const unsigned char* comp, size_t comp_bytes, const trk_vcf_iblock* blocks, int n_blocks,
-                       uint64_t abs_base, size_t total, char* out, int* line_state, const uint64_t** nl, size_t* n_nl) {
+// submit: the run's compressed bytes are copied before the call returns (the reader moves its buffer on), the kernel
+// runs on the hook's own queue -- behind the kernel of the run before, beside whatever the reader's and the caller's
+// queues do.
+static int inf_submit(void* user, const unsigned char* comp, size_t comp_bytes, const trk_vcf_iblock* blocks, int n_blocks,
+                      uint64_t abs_base, size_t total) {
     InflateState* st = static_cast<InflateState*>(user);
     trk_ctx* ctx = st->ctx;
     (void)hipSetDevice(ctx->device);
-    hipStream_t q = ctx->s();
-    *nl = nullptr;
-    *n_nl = 0;
     ++st->n_calls;
-    if (total == 0 || n_blocks <= 0) return 0;            // (members without text: the end-of-file marker)
-    const bool timing = trk_opt("TRK_INFLATE_TIMING") != nullptr;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-        return std::chrono::duration<double, std::milli>(b - a).count();
-    };
-    const auto t0 = now();
-    const size_t nb = (size_t)n_blocks;
-    // tables: in_off, out_off (int64), in_len, out_len (int32), then the flags
-    const size_t tab_bytes = nb * 24, flag_off = (tab_bytes + 15) & ~(size_t)15;
-    if (!inf_grow_dev(st->d_comp, st->comp_cap, comp_bytes + 64) || !inf_grow_dev(st->d_tab, st->tab_cap, flag_off + nb + 16)) return TRK_ERR_NOMEM;
-    const size_t n_tiles = (total + 16383) / 16384;
-    const size_t nl_cap = total / 16 + 1024;
-    // workspace: counts, scalars (n_nl, head_total, state), nl, head_off, head_len, pack_off, packed
-    size_t o_counts = 0, o_scal = (o_counts + (n_tiles + 1) * 4 + 15) & ~(size_t)15, o_nl = o_scal + 64, o_hoff = o_nl + nl_cap * 8,
-           o_hlen = o_hoff + (nl_cap + 1) * 8, o_poff = (o_hlen + (nl_cap + 1) * 4 + 15) & ~(size_t)15,
-           o_pack = (o_poff + (nl_cap + 1) * 4 + 15) & ~(size_t)15, ws_bytes = o_pack + total + 64;
-    if (!inf_grow_dev(st->d_ws, st->ws_cap, ws_bytes)) return TRK_ERR_NOMEM;
-    if (!inf_grow_host(st, std::max(flag_off + nb + 64, (size_t)4096))) return TRK_ERR_NOMEM;
-    size_t seg_cap = 0;
-    uint8_t* seg = inf_segment(st, total + 2048, seg_cap);
-    if (!seg) return TRK_ERR_NOMEM;
+    InfRun r;
+    if (!st->run_pool.empty()) {
+        r = std::move(st->run_pool.back());
+        st->run_pool.pop_back();
+    }
     auto bail = [&](int code) {
         (void)hipGetLastError();
-        (void)hipStreamSynchronize(q);
-        st->spare.emplace_back(seg, seg_cap);
+        if (st->q_inf) (void)hipStreamSynchronize(st->q_inf);
+        if (r.seg) st->spare.emplace_back(r.seg, r.seg_cap);
+        r.seg = nullptr;
+        st->run_pool.push_back(std::move(r));
         return code;
     };
-    int64_t* t_in_off = reinterpret_cast<int64_t*>(st->h_stage);
+    r.nb = n_blocks > 0 ? (size_t)n_blocks : 0;
+    r.total = total;
+    r.comp_bytes = comp_bytes;
+    r.abs_base = abs_base;
+    r.t_submit = std::chrono::steady_clock::now();
+    if (total == 0 || r.nb == 0) {                  // (members without text: the end-of-file marker)
+        r.nb = 0;
+        r.total = 0;
+        st->runs.push_back(std::move(r));
+        return 0;
+    }
+    if (!st->q_inf) {
+        // the kernels' queue at the LOWEST priority: a hardware queue of its own (queues of one priority share a few, in
+        // order -- the index kernels of run k then sat behind the kernel of run k + 1 for its 11 ms), and whatever the
+        // reader's and the caller's queues launch is dispatched ahead of members that still wait for a CU
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&st->q_inf, hipStreamNonBlocking, least) != hipSuccess ||
+            hipStreamCreateWithFlags(&st->q_up, hipStreamNonBlocking) != hipSuccess)
+            return bail(TRK_ERR_HIP);
+    }
+    if (!r.done && hipEventCreateWithFlags(&r.done, hipEventDisableTiming) != hipSuccess) return bail(TRK_ERR_HIP);
+    const size_t nb = r.nb;
+    // tables: in_off, out_off (int64), in_len, out_len (int32), then the flags
+    const size_t tab_bytes = nb * 24;
+    r.flag_off = (tab_bytes + 15) & ~(size_t)15;
+    if (!inf_grow_dev(r.d_comp, r.comp_cap, comp_bytes + 64) || !inf_grow_dev(r.d_tab, r.tab_cap, r.flag_off + nb + 16)) return bail(TRK_ERR_NOMEM);
+    if (r.h_cap < r.flag_off + nb + 64) {
+        if (r.h_tab) (void)hipHostFree(r.h_tab);
+        r.h_tab = nullptr;
+        r.h_cap = 0;
+        const size_t want = (r.flag_off + nb + 64) * 5 / 4 + 4096;
+        if (hipHostMalloc((void**)&r.h_tab, want, hipHostMallocDefault) != hipSuccess) return bail(TRK_ERR_NOMEM);
+        r.h_cap = want;
+    }
+    r.seg = inf_segment(st, total + 2048, r.seg_cap);
+    if (!r.seg) return bail(TRK_ERR_NOMEM);
+    int64_t* t_in_off = reinterpret_cast<int64_t*>(r.h_tab);
     int64_t* t_out_off = t_in_off + nb;
     int32_t* t_in_len = reinterpret_cast<int32_t*>(t_out_off + nb);
     int32_t* t_out_len = t_in_len + nb;
@@ -1054,44 +1117,96 @@ static int inf_inflate(void* user, const unsigned char* comp, size_t comp_bytes,
         t_in_len[i] = (int32_t)blocks[i].payload_len;
         t_out_len[i] = (int32_t)blocks[i].isize;
     }
-    if (hipMemcpyAsync(st->d_comp, comp, comp_bytes, hipMemcpyHostToDevice, q) != hipSuccess) return bail(TRK_ERR_HIP);
-    if (hipMemcpyAsync(st->d_tab, st->h_stage, tab_bytes, hipMemcpyHostToDevice, q) != hipSuccess) return bail(TRK_ERR_HIP);
-    if (timing) (void)hipStreamSynchronize(q);
-    const auto t1 = now();
+    r.blocks.assign(blocks, blocks + nb);
+    // (the upload on a queue of its own, waited for here: `comp` is the reader's to reuse when this returns, and waiting on
+    // the kernels' queue would wait for the run before)
+    if (hipMemcpyAsync(r.d_comp, comp, comp_bytes, hipMemcpyHostToDevice, st->q_up) != hipSuccess) return bail(TRK_ERR_HIP);
+    if (hipMemcpyAsync(r.d_tab, r.h_tab, tab_bytes, hipMemcpyHostToDevice, st->q_up) != hipSuccess) return bail(TRK_ERR_HIP);
+    if (hipStreamSynchronize(st->q_up) != hipSuccess) return bail(TRK_ERR_HIP);
+    r.t_up = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r.t_submit).count();
     trk_inflate_in in = {};
-    in.comp = st->d_comp;
+    in.comp = r.d_comp;
     in.n_comp_bytes = (int64_t)comp_bytes;
     in.n_blocks = n_blocks;
-    in.in_off = reinterpret_cast<const int64_t*>(st->d_tab);
+    in.in_off = reinterpret_cast<const int64_t*>(r.d_tab);
     in.out_off = in.in_off + nb;
     in.in_len = reinterpret_cast<const int32_t*>(in.out_off + nb);
     in.out_len = in.in_len + nb;
-    trk_inflate_out io = {seg, st->d_tab + flag_off};
-    if (trk::launch_inflate(in, io, ctx->n_cu, q) != hipSuccess) return bail(TRK_ERR_HIP);
-    uint8_t* h_flags = st->h_stage + flag_off;
-    if (hipMemcpyAsync(h_flags, st->d_tab + flag_off, nb, hipMemcpyDeviceToHost, q) != hipSuccess || hipStreamSynchronize(q) != hipSuccess)
-        return bail(TRK_ERR_HIP);
+    trk_inflate_out io = {r.seg, r.d_tab + r.flag_off};
+    if (trk::launch_inflate(in, io, ctx->n_cu, st->q_inf) != hipSuccess) return bail(TRK_ERR_HIP);
+    if (hipMemsetAsync(r.seg + total, '\n', 2048, st->q_inf) != hipSuccess) return bail(TRK_ERR_HIP);     // (readable padding)
+    if (hipMemcpyAsync(r.h_tab + r.flag_off, r.d_tab + r.flag_off, nb, hipMemcpyDeviceToHost, st->q_inf) != hipSuccess) return bail(TRK_ERR_HIP);
+    if (hipEventRecord(r.done, st->q_inf) != hipSuccess) return bail(TRK_ERR_HIP);
+    st->runs.push_back(std::move(r));
+    return 0;
+}
+
+// collect: the oldest run submitted -- wait for its kernel, inflate what it flagged here, index the text and bring the
+// newlines and the heads back (on the calling thread's queue)
+static int inf_collect(void* user, char* out, int* line_state, const uint64_t** nl, size_t* n_nl) {
+    InflateState* st = static_cast<InflateState*>(user);
+    trk_ctx* ctx = st->ctx;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t q = ctx->s();
+    *nl = nullptr;
+    *n_nl = 0;
+    if (st->runs.empty()) return TRK_ERR_ARG;
+    InfRun r = std::move(st->runs.front());
+    st->runs.pop_front();
+    const size_t nb = r.nb, total = r.total;
+    if (total == 0 || nb == 0) {
+        st->run_pool.push_back(std::move(r));
+        return 0;
+    }
+    const bool timing = trk_opt("TRK_INFLATE_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    uint8_t* seg = r.seg;
+    const size_t seg_cap = r.seg_cap;
+    auto bail = [&](int code) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(q);
+        st->spare.emplace_back(seg, seg_cap);
+        r.seg = nullptr;
+        st->run_pool.push_back(std::move(r));
+        return code;
+    };
+    const auto t1 = now();
+    if (hipEventSynchronize(r.done) != hipSuccess) return bail(TRK_ERR_HIP);
     const auto t2 = now();
-    // members the kernel left: inflated here (zlib), their text copied in
+    const uint8_t* h_flags = r.h_tab + r.flag_off;
+    // members the kernel left: inflated here (zlib; their compressed bytes come back from the device), their text copied in
     for (size_t i = 0; i < nb; ++i) {
         if (!h_flags[i]) continue;
         ++st->n_flagged;
-        std::vector<unsigned char> tmp(blocks[i].isize ? blocks[i].isize : 1);
+        const trk_vcf_iblock& b = r.blocks[i];
+        std::vector<unsigned char> cin(b.payload_len ? b.payload_len : 1), tmp(b.isize ? b.isize : 1);
+        if (b.payload_len && hipMemcpy(cin.data(), r.d_comp + b.payload_off, b.payload_len, hipMemcpyDeviceToHost) != hipSuccess)
+            return bail(TRK_ERR_HIP);
         z_stream zs;
         memset(&zs, 0, sizeof zs);
         if (inflateInit2(&zs, -15) != Z_OK) return bail(TRK_ERR_HIP);
-        zs.next_in = const_cast<unsigned char*>(comp + blocks[i].payload_off);
-        zs.avail_in = blocks[i].payload_len;
+        zs.next_in = cin.data();
+        zs.avail_in = b.payload_len;
         zs.next_out = tmp.data();
-        zs.avail_out = blocks[i].isize;
+        zs.avail_out = b.isize;
         const int rc = inflate(&zs, Z_FINISH);
-        const bool okz = rc == Z_STREAM_END && zs.total_out == blocks[i].isize;
+        const bool okz = rc == Z_STREAM_END && zs.total_out == b.isize;
         inflateEnd(&zs);
         if (!okz) return bail(TRK_ERR_ARG);                 // a member nobody can inflate: the file is corrupt
-        if (blocks[i].isize && hipMemcpy(seg + blocks[i].dst, tmp.data(), blocks[i].isize, hipMemcpyHostToDevice) != hipSuccess)
-            return bail(TRK_ERR_HIP);
+        if (b.isize && hipMemcpy(seg + b.dst, tmp.data(), b.isize, hipMemcpyHostToDevice) != hipSuccess) return bail(TRK_ERR_HIP);
     }
     // the line index and the heads
+    const size_t n_tiles = (total + 16383) / 16384;
+    const size_t nl_cap = total / 16 + 1024;
+    // workspace: counts, scalars (n_nl, head_total, state), nl, head_off, head_len, pack_off, packed
+    size_t o_counts = 0, o_scal = (o_counts + (n_tiles + 1) * 4 + 15) & ~(size_t)15, o_nl = o_scal + 64, o_hoff = o_nl + nl_cap * 8,
+           o_hlen = o_hoff + (nl_cap + 1) * 8, o_poff = (o_hlen + (nl_cap + 1) * 4 + 15) & ~(size_t)15,
+           o_pack = (o_poff + (nl_cap + 1) * 4 + 15) & ~(size_t)15, ws_bytes = o_pack + total + 64;
+    if (!inf_grow_dev(st->d_ws, st->ws_cap, ws_bytes)) return bail(TRK_ERR_NOMEM);
+    if (!inf_grow_host(st, 4096)) return bail(TRK_ERR_NOMEM);
     trk::LineIndexWs ws;
     ws.counts = reinterpret_cast<uint32_t*>(st->d_ws + o_counts);
     uint32_t* scal = reinterpret_cast<uint32_t*>(st->d_ws + o_scal);
@@ -1105,7 +1220,6 @@ static int inf_inflate(void* user, const unsigned char* comp, size_t comp_bytes,
     ws.pack_off = reinterpret_cast<uint32_t*>(st->d_ws + o_poff);
     ws.packed = st->d_ws + o_pack;
     ws.packed_cap = (uint32_t)std::min<size_t>(total + 64, 0xffffffffu);
-    if (hipMemsetAsync(seg + total, '\n', 2048, q) != hipSuccess) return bail(TRK_ERR_HIP);     // (readable padding)
     if (trk::launch_line_index(seg, (int64_t)total, *line_state, ws, q) != hipSuccess) return bail(TRK_ERR_HIP);
     uint32_t* h_scal = reinterpret_cast<uint32_t*>(st->h_stage);
     if (hipMemcpyAsync(h_scal, scal, 16, hipMemcpyDeviceToHost, q) != hipSuccess || hipStreamSynchronize(q) != hipSuccess) return bail(TRK_ERR_HIP);
@@ -1140,14 +1254,25 @@ static int inf_inflate(void* user, const unsigned char* comp, size_t comp_bytes,
     *nl = st->nl_host.data();
     *n_nl = n_found;
     *line_state = state;
-    st->segs.push_back({abs_base, total, seg, seg_cap});
+    st->segs.push_back({r.abs_base, total, seg, seg_cap});
     st->n_blocks += nb;
     st->n_text += total;
-    st->n_comp += comp_bytes;
+    st->n_comp += r.comp_bytes;
     if (timing)
-        fprintf(stderr, "[trk inflate] %d members, %.1f MB -> %.1f MB: prepare+upload %.2f ms, kernel+flags %.2f, index %.2f, results down %.2f, heads %.2f\n", n_blocks,
-                comp_bytes / 1e6, total / 1e6, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, now()));
+        fprintf(stderr, "[trk inflate] %zu members, %.1f MB -> %.1f MB: upload %.2f ms, submitted %.2f ms ago, waited %.2f for the kernel, "
+                        "index %.2f, results down %.2f, heads %.2f\n", nb, r.comp_bytes / 1e6, total / 1e6, r.t_up, ms(r.t_submit, t1),
+                ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, now()));
+    r.seg = nullptr;
+    st->run_pool.push_back(std::move(r));
     return 0;
+}
+
+// the two halves in one call (a reader that keeps one run in flight)
+static int inf_inflate(void* user, const unsigned char* comp, size_t comp_bytes, const trk_vcf_iblock* blocks, int n_blocks,
+                       uint64_t abs_base, size_t total, char* out, int* line_state, const uint64_t** nl, size_t* n_nl) {
+    const int rc = inf_submit(user, comp, comp_bytes, blocks, n_blocks, abs_base, total);
+    if (rc != 0) return rc;
+    return inf_collect(user, out, line_state, nl, n_nl);
 }
 
 int trk_inflate_hook(trk_ctx* ctx, void** user, void** seed_fn, void** inflate_fn) {
@@ -1159,6 +1284,13 @@ int trk_inflate_hook(trk_ctx* ctx, void** user, void** seed_fn, void** inflate_f
     *user = ctx->inflate;
     *seed_fn = reinterpret_cast<void*>(&inf_seed);
     *inflate_fn = reinterpret_cast<void*>(&inf_inflate);
+    return TRK_OK;
+}
+
+int trk_inflate_hook_async(trk_ctx* ctx, void** submit_fn, void** collect_fn) {
+    if (!ctx || !submit_fn || !collect_fn) return TRK_ERR_ARG;
+    *submit_fn = reinterpret_cast<void*>(&inf_submit);
+    *collect_fn = reinterpret_cast<void*>(&inf_collect);
     return TRK_OK;
 }
 

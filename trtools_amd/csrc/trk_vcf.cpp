@@ -11,6 +11,7 @@
 #include <charconv>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -453,7 +454,11 @@ struct Source {
 
     WorkerPool pool;                   // the inflater threads (created with the first BGZF fill, kept until close)
     double t_fread = 0, t_resize = 0, t_inflate = 0;   // TRK_VCF_TIMING: where fill_bgzf's time goes (seconds, cumulative)
-    bool fill_bgzf(TextBuf& out, size_t want, std::string& err) {
+    struct Blk { size_t off, csize, isize, dst; };
+    // Top up the compressed buffer and find the complete members that follow cpos (at most hook.max_members with a hook):
+    // blks, their end p in cbuf and the bytes of text they hold.  `out_size`: where that text will start in the reader's
+    // buffer (a shard's limit_pos).  false: an error (err).
+    bool scan_run(size_t want, size_t out_size, std::vector<Blk>& blks, size_t& p, size_t& total, std::string& err) {
         auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double tf0 = now();
         // top up the compressed buffer
@@ -520,13 +525,13 @@ struct Source {
         }
         t_fread += now() - tf0;
         // index complete blocks
-        struct Blk { size_t off, csize, isize, dst; };
-        std::vector<Blk> blks;
-        size_t p = cpos, total = 0;
+        blks.clear();
+        p = cpos;
+        total = 0;
         int beyond = 0;                   // blocks of the next shard taken by this call
         while (p + 18 <= cbuf.size()) {
             if (cbuf_foff + p >= end_coff) {
-                if (limit_pos == SIZE_MAX) limit_pos = out.size() + total;
+                if (limit_pos == SIZE_MAX) limit_pos = out_size + total;
                 if (beyond++ >= 1) break;
             }
             const unsigned char* h = cbuf.data() + p;
@@ -574,6 +579,79 @@ struct Source {
             ++n_blocks;
             p += bsize;
         }
+        return true;
+    }
+    void hook_blocks(const std::vector<Blk>& blks, std::vector<trk_vcf_iblock>& ib) const {
+        ib.resize(blks.size());
+        const size_t c0 = blks[0].off;
+        for (size_t i = 0; i < blks.size(); ++i) {
+            const unsigned char* h = cbuf.data() + blks[i].off;
+            const size_t xlen = (size_t)h[10] | ((size_t)h[11] << 8);
+            ib[i].payload_off = blks[i].off - c0 + 12 + xlen;
+            ib[i].payload_len = (uint32_t)(blks[i].csize - 12 - xlen - 8);
+            ib[i].isize = (uint32_t)blks[i].isize;
+            ib[i].dst = blks[i].dst;
+        }
+    }
+    // A hook with submit / collect: TWO runs of members in flight -- run k + 1 is read and handed over (its upload, its
+    // kernel's launch) before run k is waited for, so the file read and the upload go on behind run k's inflate.
+    std::deque<size_t> inflight;       // bytes of text of the runs submitted and not collected
+    uint64_t abs_submit = 0;           // stream offset behind the last submitted run
+    bool src_done = false;             // no complete member is left in the file
+    bool fill_bgzf_pipelined(TextBuf& out, size_t want, std::string& err) {
+        auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double ti0 = now();
+        std::vector<Blk> blks;
+        std::vector<trk_vcf_iblock> ib;
+        while (inflight.size() < 2 && !src_done) {
+            size_t p = 0, total = 0;
+            if (!scan_run(want, 0, blks, p, total, err)) return false;
+            if (blks.empty()) {
+                if (cbuf.size() - cpos == 0 || src_eof) {
+                    src_done = true;
+                    break;
+                }
+                err = "truncated BGZF block";
+                return false;
+            }
+            hook_blocks(blks, ib);
+            const size_t c0 = blks[0].off;
+            const int rc = hook.submit(hook.user, cbuf.data() + c0, p - c0, ib.data(), (int)ib.size(), abs_submit, total);
+            if (rc != 0) {
+                err = "the inflate hook failed (" + std::to_string(rc) + ")";
+                return false;
+            }
+            abs_submit += total;
+            inflight.push_back(total);
+            cpos = p;
+        }
+        if (inflight.empty()) {
+            eof = true;
+            return true;
+        }
+        const size_t total = inflight.front();
+        inflight.pop_front();
+        const size_t base = out.size();
+        out.resize(base + total);
+        const uint64_t* nl = nullptr;
+        size_t n_nl = 0;
+        const int rc = hook.collect(hook.user, total ? &out[base] : nullptr, &line_state, &nl, &n_nl);
+        t_inflate += now() - ti0;
+        if (rc != 0) {
+            err = "the inflate hook failed (" + std::to_string(rc) + ")";
+            return false;
+        }
+        for (size_t i = 0; i < n_nl; ++i) dev_nls.push_back(((nl[i] & ~(1ull << 63)) + abs_end) | (nl[i] & (1ull << 63)));
+        abs_end += total;
+        if (inflight.empty() && (src_done || (cpos == cbuf.size() && src_eof))) eof = true;
+        return true;
+    }
+    bool fill_bgzf(TextBuf& out, size_t want, std::string& err) {
+        if (hook.inflate && hook.submit && hook.collect) return fill_bgzf_pipelined(out, want, err);
+        auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        std::vector<Blk> blks;
+        size_t p = 0, total = 0;
+        if (!scan_run(want, out.size(), blks, p, total, err)) return false;
         if (blks.empty()) {
             if (cbuf.size() - cpos == 0 || src_eof) {
                 eof = true;
@@ -588,16 +666,9 @@ struct Source {
         const double ti0 = now();
         t_resize += ti0 - tr0;
         if (hook.inflate) {
-            std::vector<trk_vcf_iblock> ib(blks.size());
+            std::vector<trk_vcf_iblock> ib;
+            hook_blocks(blks, ib);
             const size_t c0 = blks[0].off;
-            for (size_t i = 0; i < blks.size(); ++i) {
-                const unsigned char* h = cbuf.data() + blks[i].off;
-                const size_t xlen = (size_t)h[10] | ((size_t)h[11] << 8);
-                ib[i].payload_off = blks[i].off - c0 + 12 + xlen;
-                ib[i].payload_len = (uint32_t)(blks[i].csize - 12 - xlen - 8);
-                ib[i].isize = (uint32_t)blks[i].isize;
-                ib[i].dst = blks[i].dst;
-            }
             const uint64_t* nl = nullptr;
             size_t n_nl = 0;
             const int rc = hook.inflate(hook.user, cbuf.data() + c0, p - c0, ib.data(), (int)ib.size(), abs_end, total,
@@ -1679,6 +1750,9 @@ int trk_vcf_set_inflate_hook(trk_vcf* v, const trk_vcf_inflate_hook* hook) {
     for (size_t i = last; i < n && tabs < 9; ++i) tabs += b[i] == '\t';
     v->src.line_state = tabs;
     v->src.abs_end = n;
+    v->src.abs_submit = n;
+    v->src.inflight.clear();
+    v->src.src_done = false;
     if (hook->seed) {
         const int rc = hook->seed(hook->user, b, n);
         if (rc != 0) {

@@ -30,7 +30,8 @@ class _Batch(C.Structure):
 
 
 class _InflateHook(C.Structure):          # trk_vcf_inflate_hook (include/trk_vcf.h)
-    _fields_ = [('user', C.c_void_p), ('seed', C.c_void_p), ('inflate', C.c_void_p), ('max_members', C.c_int32)]
+    _fields_ = [('user', C.c_void_p), ('seed', C.c_void_p), ('inflate', C.c_void_p), ('max_members', C.c_int32),
+                ('submit', C.c_void_p), ('collect', C.c_void_p)]
 
 
 class _Harmonized(C.Structure):
@@ -872,6 +873,11 @@ class NativeVCFReader(vcfio.VCFReader):
         # (a member is one wave's serial work of ~7 ms whatever else runs, and a CU holds sixteen of them: a run that fills
         # the chip exactly once is inflated at the best rate -- tools/inflate_probe.py)
         hook = _InflateHook(user.value, seed.value, infl.value, 16 * int(getattr(engine, 'n_cu', 256)))
+        if _knobs.lab('TRK_INFLATE_PIPELINE', '1') == '1':
+            # two runs in flight: run k + 1 is read and uploaded behind the kernel of run k (trk_inflate_hook_async)
+            sub, col = C.c_void_p(), C.c_void_p()
+            if engine.lib.trk_inflate_hook_async(engine.ctx, C.byref(sub), C.byref(col)) == 0:
+                hook.submit, hook.collect = sub.value, col.value
         if self._lib.trk_vcf_set_inflate_hook(self._h, C.byref(hook)) != 0:
             return False                     # (plain gzip / text, a shard, a region: the host inflates)
         self._inflate_hook = hook
