@@ -6,8 +6,8 @@ SUPPORTED settings -- the table in README.md ("Environment") -- are read with ``
     TRK_VCF_THREADS       inflate / parse threads of a native reader (libtrk; default: twice the CPU grant, 8 ... 64)
     TRK_FMT_THREADS       formatter threads of the native writers (libtrk; default: twice the CPU grant, 8 ... 32)
     TRK_VCF_READ_AHEAD    1 (default): batch n + 1 is read on a helper thread while batch n is worked on
-    TRK_DEVICE_INFLATE    1: BGZF blocks are inflated on the GPU (the file crosses PCIe compressed); default: see
-                          DEVICE_INFLATE_DEFAULT below
+    TRK_DEVICE_INFLATE    1: BGZF blocks are inflated on the GPU (the file crosses PCIe compressed); default: 1 for statSTR,
+                          0 for dumpSTR (DEVICE_INFLATE_DEFAULT below)
     TRK_DEVICE_PARSE      1 (default): the sample columns are parsed on the GPU
     TRK_DEVICE_FORMAT     1 (default): dumpSTR's sample columns are written on the GPU
     TRK_PLACE_OUTPUTS     1 (default): big output plane pairs of the call-filter pass are placed (trk_dev_alloc_pair)
@@ -26,10 +26,12 @@ SUPPORTED = ('TRK_DEVICE', 'TRK_VCF_THREADS', 'TRK_FMT_THREADS', 'TRK_VCF_READ_A
              'TRK_DEVICE_PARSE', 'TRK_DEVICE_FORMAT', 'TRK_PLACE_OUTPUTS', 'TRK_RESERVE_PAIR_GB', 'TRK_POOL_GB')
 
 
-# The command lines' default for TRK_DEVICE_INFLATE.  '0' while the device inflates a gigabyte of text in ~40 ms and the
-# host's 32 inflater threads in ~60 ms beside everything else they do (profiles/r05_notes.md): the device path is correct
-# (tests/test_gpu_inflate*.py) and frees a CPU-second per GB, but does not shorten the command lines yet.
-DEVICE_INFLATE_DEFAULT = '0'
+# The command lines' defaults for TRK_DEVICE_INFLATE (profiles/r05_notes.md section 6, r05_e2e_cpu_seconds.txt; 1.02 GB):
+#   statSTR  '1': 0.103-0.111 s against 0.111-0.127 with the host's inflater threads on the same boxes, at 0.5 CPU-seconds
+#                 instead of 1.6-1.7 (two runs of 4096 members in flight behind the reader, kernels on a lowest-priority queue);
+#   dumpSTR  '0': its own kernels and copies share the device with the inflate kernel -- 0.22-0.23 s against 0.18-0.19,
+#                 although at 0.76 CPU-seconds instead of 1.8-2.0: TRK_DEVICE_INFLATE=1 where host cores are the scarce thing.
+DEVICE_INFLATE_DEFAULT = {'statSTR': '1', 'dumpSTR': '0'}
 
 
 def env(name, default=None):

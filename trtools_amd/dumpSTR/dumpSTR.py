@@ -1019,7 +1019,7 @@ def main(args):
         LAST_RUN['device_parse'] = bool(device_parse)
         # ... and the BGZF members are inflated there too (trk_inflate_blocks, round 5; TRK_DEVICE_INFLATE=0: by the reader's
         # threads): the compressed bytes cross PCIe, the host sees the newlines and the heads of the lines
-        LAST_RUN['device_inflate'] = bool(device_parse and _knobs.env('TRK_DEVICE_INFLATE', DEVICE_INFLATE_DEFAULT) == '1' and
+        LAST_RUN['device_inflate'] = bool(device_parse and _knobs.env('TRK_DEVICE_INFLATE', DEVICE_INFLATE_DEFAULT['dumpSTR']) == '1' and
                                           hasattr(invcf, 'device_inflate') and invcf.device_inflate(runtime.get_compute().eng))
     last_rb = None
     while use_batches:

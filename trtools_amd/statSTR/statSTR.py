@@ -318,7 +318,7 @@ def _run_batches(args, invcf, vcftype, group_masks, fmt, shard, batch_loci, star
     # ... and the file's BGZF members are inflated there too (trk_inflate_blocks, round 5; TRK_DEVICE_INFLATE=0: by the
     # reader's threads): the compressed bytes cross PCIe, the host sees the newlines and the heads of the lines.  Whole-file
     # runs only (a region seeks).
-    LAST_RUN['device_inflate'] = bool(device_parse and not args.region and _knobs.env('TRK_DEVICE_INFLATE', DEVICE_INFLATE_DEFAULT) == '1' and
+    LAST_RUN['device_inflate'] = bool(device_parse and not args.region and _knobs.env('TRK_DEVICE_INFLATE', DEVICE_INFLATE_DEFAULT['statSTR']) == '1' and
                                       hasattr(invcf, 'device_inflate') and invcf.device_inflate(compute.eng))
     # Batch n + 1 is read while batch n is counted and written (TRK_VCF_READ_AHEAD=0: off; it was off while the command line
     # was bound by CPU seconds on the 16-CPU grant of the GPU boxes: with the parse on the device 0.18 -> 0.125 s per GB,
