@@ -737,7 +737,9 @@ class NativeVCFReader(vcfio.VCFReader):
     def prefetch_harmonize(self, vcftype):
         """With read-ahead on, the reader's thread also harmonises the batch it read (trk_vcf_harmonize keeps two result
         sets: batch n's tables stay valid while batch n + 1 is harmonised).  Measured neutral on the 1 GB command lines
-        (the reader's thread becomes the longer one: dumpSTR 0.30, statSTR 0.15-0.16 s either way): not switched on."""
+        (the reader's thread becomes the longer one: dumpSTR 0.30, statSTR 0.15-0.16 s either way) and, in round 5 with the
+        inflate on the device and that thread the short one, slower (statSTR 0.115-0.123 against 0.103-0.117 s): not
+        switched on."""
         self._prefetch_hz = vcftype
         return self
 
