@@ -360,6 +360,20 @@ public:
     }
 };
 
+// The caller-side phases (harmonise, statSTR's rows, the record writers) run their per-chunk jobs on ONE process-wide pool
+// instead of threads made and joined per call (16-32 threads, twice per batch in the writers: ~1-2 ms per batch of
+// creation alone).  One job at a time (the lock): two callers at once take turns.
+static void run_on_caller_pool(int nt, const std::function<void()>& job) {
+    static WorkerPool* pool = new WorkerPool;      // (never destroyed: no join of parked threads at process exit)
+    static std::mutex* mu = new std::mutex;
+    if (nt <= 1) {
+        job();
+        return;
+    }
+    std::lock_guard<std::mutex> g(*mu);
+    pool->run(nt, job);
+}
+
 struct Source {
     FILE* fp = nullptr;
     gzFile gz = nullptr;
@@ -1673,10 +1687,7 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
         }
     };
     int nt = std::max(1, std::min(v->n_threads, n));
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back(runner);
-    runner();
-    for (auto& t : th) t.join();
+    v->src.pool.run(nt, runner);     // (the reader's own pool: this is the thread that fills)
     if (job.error) {
         // nothing is consumed: the same lines are decoded again by the next call (the caller retries a ploidy
         // overflow with a wider genotype tensor, vcfnative.py)
@@ -2480,10 +2491,7 @@ int trk_vcf_harmonize(trk_vcf* v, const trk_vcf_batch* b, int vcftype, trk_vcf_h
             }
         };
         const int nt = std::max(1, std::min({v->n_threads, 16, (n + 63) / 64}));
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(runner);
-        runner();
-        for (auto& t : th) t.join();
+        run_on_caller_pool(nt, runner);
     }
     st.allele_off.assign((size_t)n + 1, 0);
     st.pos.assign((size_t)n, 0);
@@ -2517,51 +2525,83 @@ int trk_vcf_harmonize(trk_vcf* v, const trk_vcf_batch* b, int vcftype, trk_vcf_h
     st.allele_len.assign(sumA, 0.0);
     st.key_off.assign(sumA + 1, 0);
     st.keys.clear();
-    std::vector<int> order;
-    std::vector<std::string> up;
-    for (int i = 0; i < n; ++i) {
-        const size_t o = (size_t)st.allele_off[(size_t)i];
-        const size_t A = (size_t)st.allele_off[(size_t)i + 1] - o;
-        if (st.status[(size_t)i]) {
-            for (size_t q = 0; q <= A; ++q) st.key_off[o + q] = (int64_t)st.keys.size();
-            continue;
-        }
-        const HzRecord& r = recs[(size_t)i];
-        up.resize(A);
-        for (size_t q = 0; q < A; ++q) {
-            up[q].assign(r.alleles[q].first, (size_t)r.alleles[q].second);
-            for (auto& c : up[q])
-                if (c >= 'a' && c <= 'z') c = (char)(c - 32);
-            st.allele_len[o + q] = r.lengths.empty() ? (double)r.alleles[q].second / r.unit   // len(allele) / len(motif)
-                                                     : r.lengths[q];                          // the stated length
-        }
-        // sequence classes: dense rank in sorted order of the distinct sequences (python str order == byte order)
-        order.resize(A);
-        for (size_t q = 0; q < A; ++q) order[q] = (int)q;
-        std::sort(order.begin(), order.end(), [&](int x, int y) { return up[(size_t)x] < up[(size_t)y]; });
-        int rank = -1;
-        for (size_t k = 0; k < A; ++k) {
-            if (k == 0 || up[(size_t)order[k]] != up[(size_t)order[k - 1]]) {
-                ++rank;
-                st.key_off[o + (size_t)rank] = (int64_t)st.keys.size();
-                st.keys.append(up[(size_t)order[k]]);
+    // The classes of a record's alleles are its own business: chunks of 64 records by the same threads, every chunk with
+    // the sorted distinct sequences of its records in a string of its own (key_off relative to it); the strings are
+    // joined in order afterwards.  (This loop was serial: 3 of the call's 5 ms on a batch of 3355 HipSTR records.)
+    constexpr int HZ_CHUNK = 64;
+    const int n_chunks = (n + HZ_CHUNK - 1) / HZ_CHUNK;
+    std::vector<std::string> chunk_keys((size_t)n_chunks);
+    {
+        std::atomic<int> next{0};
+        auto runner = [&]() {
+            std::vector<int> order;
+            std::vector<std::string> up;
+            for (;;) {
+                const int c = next.fetch_add(1);
+                if (c >= n_chunks) break;
+                std::string& keys = chunk_keys[(size_t)c];
+                for (int i = c * HZ_CHUNK; i < std::min(n, (c + 1) * HZ_CHUNK); ++i) {
+                    const size_t o = (size_t)st.allele_off[(size_t)i];
+                    const size_t A = (size_t)st.allele_off[(size_t)i + 1] - o;
+                    if (st.status[(size_t)i]) {
+                        for (size_t q = 0; q < A; ++q) st.key_off[o + q] = (int64_t)keys.size();
+                        continue;
+                    }
+                    const HzRecord& r = recs[(size_t)i];
+                    up.resize(A);
+                    for (size_t q = 0; q < A; ++q) {
+                        up[q].assign(r.alleles[q].first, (size_t)r.alleles[q].second);
+                        for (auto& ch : up[q])
+                            if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 32);
+                        st.allele_len[o + q] = r.lengths.empty() ? (double)r.alleles[q].second / r.unit   // len(allele) / len(motif)
+                                                                 : r.lengths[q];                          // the stated length
+                    }
+                    // sequence classes: dense rank in sorted order of the distinct sequences (python str order == byte order)
+                    order.resize(A);
+                    for (size_t q = 0; q < A; ++q) order[q] = (int)q;
+                    std::sort(order.begin(), order.end(), [&](int x, int y) { return up[(size_t)x] < up[(size_t)y]; });
+                    int rank = -1;
+                    for (size_t k = 0; k < A; ++k) {
+                        if (k == 0 || up[(size_t)order[k]] != up[(size_t)order[k - 1]]) {
+                            ++rank;
+                            st.key_off[o + (size_t)rank] = (int64_t)keys.size();
+                            keys.append(up[(size_t)order[k]]);
+                        }
+                        st.str_class[o + (size_t)order[k]] = (uint16_t)rank;
+                    }
+                    st.n_str_classes[(size_t)i] = rank + 1;
+                    for (size_t q = (size_t)rank + 1; q < A; ++q) st.key_off[o + q] = (int64_t)keys.size();
+                    // length classes: dense rank of the distinct lengths, ascending
+                    std::sort(order.begin(), order.end(),
+                              [&](int x, int y) { return st.allele_len[o + (size_t)x] < st.allele_len[o + (size_t)y]; });
+                    rank = -1;
+                    for (size_t k = 0; k < A; ++k) {
+                        const double lv = st.allele_len[o + (size_t)order[k]];
+                        if (k == 0 || lv != st.allele_len[o + (size_t)order[k - 1]]) {
+                            ++rank;
+                            st.len_class_value[o + (size_t)rank] = lv;
+                        }
+                        st.len_class[o + (size_t)order[k]] = (uint16_t)rank;
+                    }
+                    st.n_len_classes[(size_t)i] = rank + 1;
+                }
             }
-            st.str_class[o + (size_t)order[k]] = (uint16_t)rank;
+        };
+        const int nt = std::max(1, std::min({v->n_threads, 16, n_chunks}));
+        run_on_caller_pool(nt, runner);
+    }
+    {   // join the chunks' strings; the offsets become absolute
+        size_t total = 0;
+        for (const auto& k : chunk_keys) total += k.size();
+        st.keys.reserve(total);
+        for (int c = 0; c < n_chunks; ++c) {
+            const int64_t base = (int64_t)st.keys.size();
+            const size_t o0 = (size_t)st.allele_off[(size_t)c * HZ_CHUNK];
+            const size_t o1 = (size_t)st.allele_off[(size_t)std::min(n, (c + 1) * HZ_CHUNK)];
+            if (base)
+                for (size_t q = o0; q < o1; ++q) st.key_off[q] += base;
+            st.keys.append(chunk_keys[(size_t)c]);
         }
-        st.n_str_classes[(size_t)i] = rank + 1;
-        for (size_t q = (size_t)rank + 1; q <= A; ++q) st.key_off[o + q] = (int64_t)st.keys.size();
-        // length classes: dense rank of the distinct lengths, ascending
-        std::sort(order.begin(), order.end(), [&](int x, int y) { return st.allele_len[o + (size_t)x] < st.allele_len[o + (size_t)y]; });
-        rank = -1;
-        for (size_t k = 0; k < A; ++k) {
-            const double lv = st.allele_len[o + (size_t)order[k]];
-            if (k == 0 || lv != st.allele_len[o + (size_t)order[k - 1]]) {
-                ++rank;
-                st.len_class_value[o + (size_t)rank] = lv;
-            }
-            st.len_class[o + (size_t)order[k]] = (uint16_t)rank;
-        }
-        st.n_len_classes[(size_t)i] = rank + 1;
     }
     st.key_off[sumA] = (int64_t)st.keys.size();
     out->n_records = n;
@@ -2703,10 +2743,7 @@ int64_t trk_vcf_statstr_rows(const trk_vcf_batch* b, const trk_vcf_harmonized* h
     };
     // (a row is ~25 us of number formatting: 17 000 rows on eight threads were 67 ms of statSTR's 0.34 s per GB of text)
     const int nt = std::max(1, std::min(default_threads(32), n_chunks));
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back(runner);
-    runner();
-    for (auto& t : th) t.join();
+    run_on_caller_pool(nt, runner);
     if (bad_locus.load() != INT32_MAX) {
         if (err_locus) *err_locus = bad_locus.load();
         if (err_kind) *err_kind = bad_kind.load();
@@ -3702,10 +3739,7 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
     const int nt = std::max(1, std::min({want, 128, n}));
     const bool timing = trk_opt("TRK_FMT_TIMING") != nullptr;
     const auto tf0 = std::chrono::steady_clock::now();
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back(runner);
-    runner();
-    for (auto& t : th) t.join();
+    run_on_caller_pool(nt, runner);
     const auto tf1 = std::chrono::steady_clock::now();
     if (bad.load() != INT32_MAX) {
         if (err_record) *err_record = bad.load();
@@ -3749,10 +3783,7 @@ int64_t dumpstr_impl(const trk_vcf_batch* b, const trk_vcf_dumpstr* in, const tr
                     }
             }
         };
-        std::vector<std::thread> tc;
-        for (int t = 1; t < nt; ++t) tc.emplace_back(copier);
-        copier();
-        for (auto& t : tc) t.join();
+        run_on_caller_pool(nt, copier);
     }
     if (timing)
         fprintf(stderr, "[trk_vcf] %d records written: format %.1f ms, gather %.1f ms, %d threads, %.0f MB; since the process "
