@@ -139,3 +139,39 @@ def test_command_lines_with_and_without_the_device_inflate(tmp_path):
                     os.environ[k_] = v
     assert outs['dev'] == outs['host']
     assert len(outs['dev'][1]) > 1000000
+
+
+@pytest.mark.gpu
+def test_a_member_nobody_can_inflate_fails_the_read_and_the_next_reader_works(eng, tmp_path):
+    """A bgzip'ed file with one member's DEFLATE stream broken (its ISIZE and CRC left alone): the kernel flags the member,
+    zlib refuses it too, and the read fails with an error -- with two runs in flight at that moment.  The context's hook is
+    usable again afterwards: the next reader on the same engine reads a good file to its end."""
+    from trtools_amd import vcfnative, _lib as L
+    text = _synthetic(3000, 400, seed=11)
+    good = _bgzip(tmp_path, 'good.vcf.gz', text)
+    raw = bytearray(open(good, 'rb').read())
+    # walk the members; break the payload of one in the middle of the file
+    offs, p = [], 0
+    while p + 18 <= len(raw):
+        bsize = (raw[p + 16] | (raw[p + 17] << 8)) + 1
+        offs.append((p, bsize))
+        p += bsize
+    assert len(offs) > 12
+    p, bsize = offs[len(offs) // 2]
+    for k in range(p + 18 + 40, p + 18 + 60):
+        raw[k] ^= 0x5a
+    bad = str(tmp_path / 'bad.vcf.gz')
+    open(bad, 'wb').write(bytes(raw))
+    with L.options(TRK_VCF_READ_BYTES=200000):       # (runs of a few members: the broken one is met with another run behind it)
+        r = vcfnative.NativeVCFReader(bad, batch_records=64)
+        r.select_format('DP')
+        assert r.device_parse(eng) and r.device_inflate(eng) and r._inflate_hook.submit
+        with pytest.raises(ValueError, match='inflate'):
+            while True:
+                rb = r._read_raw_batch(64)
+                if rb.n == 0:
+                    break
+                rb.release_device()
+        r.close()
+        out, fb = _read(eng, good, 64, True)
+    assert sum(len(h) for h, *_ in out) == 3000 and fb == 0
