@@ -366,9 +366,15 @@ public:
 static void run_on_caller_pool(int nt, const std::function<void()>& job) {
     static WorkerPool* pool = new WorkerPool;      // (never destroyed: no join of parked threads at process exit)
     static std::mutex* mu = new std::mutex;
+    static pid_t owner = getpid();
     if (nt <= 1) {
         job();
         return;
+    }
+    if (getpid() != owner) {     // a forked child: the parent's threads do not exist here -- a pool and a lock of its own
+        pool = new WorkerPool;
+        mu = new std::mutex;
+        owner = getpid();
     }
     std::lock_guard<std::mutex> g(*mu);
     pool->run(nt, job);
