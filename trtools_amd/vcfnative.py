@@ -1012,7 +1012,12 @@ class NativeVCFReader(vcfio.VCFReader):
                      [((n, S, nc), dt) for _, _, nc, dt in self._selected] + ([((n, M, P), np.int16)] if M else [])
             sizes = [(int(np.prod(sh, dtype=np.int64)) * np.dtype(dt).itemsize + 63) & ~63 for sh, dt in shapes]
             total = max(sum(sizes), 64)
-            if self._alloc is not None:
+            if getattr(self, '_dev_eng', None) is not None:
+                # device parse: these arrays are filled only if somebody asks for the host copies (RawBatch._host) or the
+                # host has to parse a batch the device flags -- address space, no pinned pages, nothing touched (two
+                # pinned slabs of ~220 MB were 40-80 ms of a fresh process's first batches for nothing)
+                slab = np.empty(total, dtype=np.uint8)
+            elif self._alloc is not None:
                 slab = self._alloc(total)
                 self._slabs.append(slab)
             else:
