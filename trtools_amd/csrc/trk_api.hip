@@ -953,7 +953,6 @@ struct InflateState {
     std::deque<InfRun> runs;            // submitted, not collected (in order)
     std::vector<InfRun> run_pool;       // their buffers, to use again
     hipStream_t q_inf = nullptr;        // the inflate kernels' queue
-    hipStream_t q_up = nullptr;         // the uploads'
 
     std::deque<InfSeg> segs;
     std::vector<std::pair<uint8_t*, size_t>> spare;     // segment buffers to use again
@@ -974,7 +973,6 @@ static void inflate_state_free(InflateState* st) {
     }
     for (auto& r : st->run_pool) inf_run_free(r);
     if (st->q_inf) (void)hipStreamDestroy(st->q_inf);
-    if (st->q_up) (void)hipStreamDestroy(st->q_up);
     if (st->d_ws) (void)hipFree(st->d_ws);
     if (st->h_stage) (void)hipHostFree(st->h_stage);
     delete st;
@@ -1086,9 +1084,7 @@ static int inf_submit(void* user, const unsigned char* comp, size_t comp_bytes, 
         // reader's and the caller's queues launch is dispatched ahead of members that still wait for a CU
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (hipStreamCreateWithPriority(&st->q_inf, hipStreamNonBlocking, least) != hipSuccess ||
-            hipStreamCreateWithFlags(&st->q_up, hipStreamNonBlocking) != hipSuccess)
-            return bail(TRK_ERR_HIP);
+        if (hipStreamCreateWithPriority(&st->q_inf, hipStreamNonBlocking, least) != hipSuccess) return bail(TRK_ERR_HIP);
     }
     if (!r.done && hipEventCreateWithFlags(&r.done, hipEventDisableTiming) != hipSuccess) return bail(TRK_ERR_HIP);
     const size_t nb = r.nb;
@@ -1118,11 +1114,12 @@ static int inf_submit(void* user, const unsigned char* comp, size_t comp_bytes, 
         t_out_len[i] = (int32_t)blocks[i].isize;
     }
     r.blocks.assign(blocks, blocks + nb);
-    // (the upload on a queue of its own, waited for here: `comp` is the reader's to reuse when this returns, and waiting on
-    // the kernels' queue would wait for the run before)
-    if (hipMemcpyAsync(r.d_comp, comp, comp_bytes, hipMemcpyHostToDevice, st->q_up) != hipSuccess) return bail(TRK_ERR_HIP);
-    if (hipMemcpyAsync(r.d_tab, r.h_tab, tab_bytes, hipMemcpyHostToDevice, st->q_up) != hipSuccess) return bail(TRK_ERR_HIP);
-    if (hipStreamSynchronize(st->q_up) != hipSuccess) return bail(TRK_ERR_HIP);
+    // (the upload on the calling thread's queue -- idle: collect waits for what it puts there -- and waited for here:
+    // `comp` is the reader's to reuse when this returns, and waiting on the kernels' queue would wait for the run before)
+    hipStream_t q_up = ctx->s();
+    if (hipMemcpyAsync(r.d_comp, comp, comp_bytes, hipMemcpyHostToDevice, q_up) != hipSuccess) return bail(TRK_ERR_HIP);
+    if (hipMemcpyAsync(r.d_tab, r.h_tab, tab_bytes, hipMemcpyHostToDevice, q_up) != hipSuccess) return bail(TRK_ERR_HIP);
+    if (hipStreamSynchronize(q_up) != hipSuccess) return bail(TRK_ERR_HIP);
     r.t_up = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r.t_submit).count();
     trk_inflate_in in = {};
     in.comp = r.d_comp;
