@@ -99,6 +99,7 @@ struct trk_ctx {
     // entry points may be called from two threads at once (the reader's helper thread on its own queue, trk_thread_queue):
     // the profile bookkeeping (event pool, pending brackets) and the error string are shared and go through this lock
     std::mutex book_m;
+    std::mutex queue_m;       // creation of a queue on its first use (ensure_queue)
     hipEvent_t t_start[TRK_N_TIMERS] = {};
     hipEvent_t t_stop[TRK_N_TIMERS] = {};
     bool profiling = false;
@@ -227,6 +228,22 @@ int trk_device_count(int* n) {
     return TRK_OK;
 }
 
+static int ensure_queue(trk_ctx* ctx, int i) {
+    if (ctx->streams[i]) return TRK_OK;
+    std::lock_guard<std::mutex> g(ctx->queue_m);
+    if (ctx->streams[i]) return TRK_OK;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t q = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&q, hipStreamNonBlocking);
+    if (e == hipSuccess && !ctx->join_event[i]) e = hipEventCreateWithFlags(&ctx->join_event[i], hipEventDisableTiming);
+    if (e != hipSuccess) {
+        if (q) (void)hipStreamDestroy(q);
+        return fail(ctx, TRK_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    ctx->streams[i] = q;
+    return TRK_OK;
+}
+
 int trk_init(int device, trk_ctx** out) {
     if (!out) return fail(nullptr, TRK_ERR_ARG, "trk_init: out is NULL");
     *out = nullptr;
@@ -241,13 +258,12 @@ int trk_init(int device, trk_ctx** out) {
     ctx->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
-    for (int i = 0; i < TRK_N_STREAMS; ++i) {
-        e = hipStreamCreateWithFlags(&ctx->streams[i], hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_event[i], hipEventDisableTiming);
-        if (e != hipSuccess) {
-            delete ctx;
-            return fail(nullptr, TRK_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
-        }
+    // queue 0 now, the others when they are first selected (trk_stream_select / trk_thread_queue / trk_stream_wait): a
+    // queue costs ~10 ms to create, and a command line uses two of the four
+    if (ensure_queue(ctx, 0) != TRK_OK) {
+        std::string msg = ctx->err;
+        delete ctx;
+        return fail(nullptr, TRK_ERR_HIP, "%s", msg.c_str());
     }
     for (int i = 0; i < TRK_N_TIMERS; ++i) {
         (void)hipEventCreate(&ctx->t_start[i]);
@@ -261,7 +277,8 @@ int trk_init(int device, trk_ctx** out) {
 void trk_free(trk_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (int i = 0; i < TRK_N_STREAMS; ++i) (void)hipStreamSynchronize(ctx->streams[i]);
+    for (int i = 0; i < TRK_N_STREAMS; ++i)
+        if (ctx->streams[i]) (void)hipStreamSynchronize(ctx->streams[i]);
     drain_profile(ctx);
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
     for (int k = 0; k < 2; ++k)
@@ -315,7 +332,8 @@ int trk_dev_alloc(trk_ctx* ctx, size_t bytes, void** dptr) {
 int trk_dev_free(trk_ctx* ctx, void* dptr) {
     if (!ctx) return TRK_ERR_ARG;
     if (!dptr) return TRK_OK;
-    for (int i = 0; i < TRK_N_STREAMS; ++i) HIPCHK(ctx, hipStreamSynchronize(ctx->streams[i]));
+    for (int i = 0; i < TRK_N_STREAMS; ++i)
+        if (ctx->streams[i]) HIPCHK(ctx, hipStreamSynchronize(ctx->streams[i]));
     for (int k = 0; k < 2; ++k)
         if (dptr == ctx->res_plane[k]) {   // a plane of the reserved pair goes back to the context, not to the driver
             ctx->res_lent[k] = false;
@@ -352,7 +370,8 @@ int trk_memset(trk_ctx* ctx, void* d, int v, size_t n) {
 }
 int trk_sync(trk_ctx* ctx) {
     if (!ctx) return TRK_ERR_ARG;
-    for (int i = 0; i < TRK_N_STREAMS; ++i) HIPCHK(ctx, hipStreamSynchronize(ctx->streams[i]));
+    for (int i = 0; i < TRK_N_STREAMS; ++i)
+        if (ctx->streams[i]) HIPCHK(ctx, hipStreamSynchronize(ctx->streams[i]));
     return TRK_OK;
 }
 int trk_host_alloc(trk_ctx* ctx, size_t bytes, void** hptr) {
@@ -385,18 +404,21 @@ int trk_memcpy_d2h_async(trk_ctx* ctx, void* h, const void* d, size_t n) {
 int trk_queue_sync(trk_ctx* ctx, int queue) {
     if (!ctx) return TRK_ERR_ARG;
     if (queue < 0 || queue >= TRK_N_STREAMS) return fail(ctx, TRK_ERR_ARG, "queue %d outside [0, %d)", queue, TRK_N_STREAMS);
-    HIPCHK(ctx, hipStreamSynchronize(ctx->streams[queue]));
+    if (ctx->streams[queue]) HIPCHK(ctx, hipStreamSynchronize(ctx->streams[queue]));
     return TRK_OK;
 }
 int trk_stream_select(trk_ctx* ctx, int queue) {
     if (!ctx) return TRK_ERR_ARG;
     if (queue < 0 || queue >= TRK_N_STREAMS) return fail(ctx, TRK_ERR_ARG, "queue %d outside [0, %d)", queue, TRK_N_STREAMS);
+    if (const int rc = ensure_queue(ctx, queue)) return rc;
     ctx->cur = queue;
     return TRK_OK;
 }
 int trk_thread_queue(trk_ctx* ctx, int queue) {
     if (!ctx) return TRK_ERR_ARG;
     if (queue < -1 || queue >= TRK_N_STREAMS) return fail(ctx, TRK_ERR_ARG, "queue %d outside [-1, %d)", queue, TRK_N_STREAMS);
+    if (queue >= 0)
+        if (const int rc = ensure_queue(ctx, queue)) return rc;
     t_queue = queue;
     return TRK_OK;
 }
@@ -406,6 +428,8 @@ int trk_stream_wait(trk_ctx* ctx, int waiter, int signal) {
         return fail(ctx, TRK_ERR_ARG, "queue outside [0, %d)", TRK_N_STREAMS);
     if (waiter == signal) return TRK_OK;
     (void)hipSetDevice(ctx->device);
+    if (!ctx->streams[signal]) return TRK_OK;            // nothing was ever put on that queue
+    if (const int rc = ensure_queue(ctx, waiter)) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->join_event[signal], ctx->streams[signal]));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->streams[waiter], ctx->join_event[signal], 0));
     return TRK_OK;
