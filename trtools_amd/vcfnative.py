@@ -251,28 +251,40 @@ class RawBatch:
             cap = -n + 64
         return buf.raw[:n], el.value, ek.value
 
+    def _chrom_runs(self):
+        """(first record of every run of records with one CHROM, that CHROM as str) -- by array operations on the text (a
+        Python loop over the records was 1.4 ms per batch on dumpSTR's caller thread)."""
+        n = self.n
+        if n == 0:
+            return np.zeros(0, np.int64), []
+        fo = np.ctypeslib.as_array(self.b.field_off, shape=(n * 10,))
+        lo = np.ctypeslib.as_array(self.b.line_off, shape=(n,))
+        start = lo.astype(np.int64) + fo[0::10]
+        ln = (fo[1::10] - 1 - fo[0::10]).astype(np.int64)
+        L = max(int(ln.max()), 1)
+        size = int((start + ln).max()) + 1
+        text = np.frombuffer((C.c_uint8 * size).from_address(int(self.b.text)), dtype=np.uint8)
+        col = np.arange(L, dtype=np.int64)[None, :]
+        by = np.where(col < ln[:, None], text[np.minimum(start[:, None] + col, size - 1)], 0)
+        change = np.ones(n, dtype=bool)
+        change[1:] = (ln[1:] != ln[:-1]) | (by[1:] != by[:-1]).any(axis=1)
+        first = np.flatnonzero(change)
+        return first, [bytes(by[l, :ln[l]]).decode() for l in first]
+
     def chroms(self):
         """The distinct CHROM values of the batch, in order of first appearance."""
-        out, last = [], None
-        for l in range(self.n):
-            f0, f1 = int(self.b.field_off[l * 10]), int(self.b.field_off[l * 10 + 1])
-            c = C.string_at(self.b.text + self.b.line_off[l] + f0, f1 - 1 - f0)
-            if c != last:
-                last = c
-                d = c.decode()
-                if d not in out:
-                    out.append(d)
+        out = []
+        for d in self._chrom_runs()[1]:
+            if d not in out:
+                out.append(d)
         return out
 
     def chrom_column(self):
         """CHROM of every record of the batch (list of str)."""
-        out, last, lastd = [], None, None
-        for l in range(self.n):
-            f0, f1 = int(self.b.field_off[l * 10]), int(self.b.field_off[l * 10 + 1])
-            c = C.string_at(self.b.text + self.b.line_off[l] + f0, f1 - 1 - f0)
-            if c != last:
-                last, lastd = c, c.decode()
-            out.append(lastd)
+        first, names = self._chrom_runs()
+        out = []
+        for k, d in enumerate(names):
+            out.extend([d] * (int(first[k + 1] if k + 1 < len(first) else self.n) - int(first[k])))
         return out
 
     def format_columns(self):
