@@ -63,6 +63,9 @@ struct Lds {
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// A branch the common symbol does not take must not cost it a TAKEN branch (a jump over the rare block): the rare blocks go
+// out of line.  The time of a symbol is its taken branches more than its instructions (tools/inflate_symbol_probe.py).
+#define RARE(x) __builtin_expect(!!(x), 0)
 
 // What a symbol MEANS, ready for the decode loop -- the primary tables hold this beside the code's length, so that a
 // symbol costs one look-up and no arithmetic on its number:
@@ -92,7 +95,6 @@ __device__ __forceinline__ uint32_t d_entry(int ds) {
 struct BitReader {
     const uint32_t* base;      // dword-aligned address at or before the payload
     uint32_t n_dwords;         // dwords that may be read (payload + slack the caller guarantees); a payload is < 64 KiB
-    uint32_t w0;               // dword index held by lane 0 of `cur`
     uint32_t cur;              // 256 bytes of the stream, a dword per lane
     uint32_t dw;               // next dword to take
     uint64_t bb;               // bit buffer (uniform)
@@ -117,8 +119,7 @@ struct BitReader {
     __device__ __forceinline__ void seek(int64_t off) {
         const uint32_t b = (uint32_t)off + (uint32_t)skip;
         dw = b >> 2;
-        w0 = dw & ~63u;
-        cur = load_reg(w0);
+        cur = (dw & 63u) ? load_reg(dw & ~63u) : 0u;     // (lane k holds dword (dw & ~63) + k; at a window's start take_dword loads it)
         bb = 0;
         bc = 0;
         refill();
@@ -130,12 +131,11 @@ struct BitReader {
         // (uniform) the next 256 bytes.  Loaded when needed, not ahead: a register that is in flight across the symbol
         // loop makes every use of the reader wait for ALL the wave's memory operations -- its stores of text included --
         // at every dword (one counter, vmcnt, for loads and stores); this way the wave waits once per 256 bytes
-        if (dw >= w0 + 64) {
-            w0 += 64;
-            cur = load_reg(w0);
+        if (RARE((dw & 63u) == 0u)) {
+            cur = load_reg(dw);
             asm volatile("" : "+v"(cur));      // (a use HERE: the wait for the load stays on this path, not on every dword's)
         }
-        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(dw - w0));
+        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(dw & 63u));
         ++dw;
         return v;
     }
@@ -266,7 +266,6 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate_bgzf(const InfArgs a
         uint32_t err = 0;
         if (in_len < 0 || out_len < 0 || out_len > 65536 || in_off < 0 || in_off + in_len > a.in.n_comp_bytes) err = TRK_INFLATE_INPUT;
         int pos = 0;          // bytes of text produced (the pending literals included)
-        int fenced = 0;       // the wave's stores of text[0 .. fenced) are done: others may read them
         // literals wait in a register, lane k the k-th of the run, and leave together -- one ring write and one store per
         // run instead of per byte (the per-symbol vector instructions are what bounds this kernel: profiles/r05_sq_inflate.txt)
         uint32_t pend = 0;
@@ -438,9 +437,9 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate_bgzf(const InfArgs a
                 for (;;) {
                     br.refill1();
                     uint32_t e = uni(s.ll_tab[(uint32_t)br.bb & ((1u << LL_ROOT) - 1u)]);
-                    if (!(e & 15u)) {
+                    if (RARE(!(e & 15u))) {
                         const int sl = (int)uni((uint32_t)decode_long<LL_ROOT>((uint32_t)br.bb, s.ll, s.ll_sorted));
-                        if (sl < 0) { err = TRK_INFLATE_STREAM; break; }
+                        if (RARE(sl < 0)) { err = TRK_INFLATE_STREAM; break; }
                         e = ll_entry(sl >> 4) | (uint32_t)(sl & 15);
                     }
                     br.drop((int)(e & 15u));
@@ -448,14 +447,14 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate_bgzf(const InfArgs a
                         pend = lane == npend ? e >> 16 : pend;
                         ++npend;
                         ++pos;
-                        if (npend == 64) {
+                        if (RARE(npend == 64)) {
                             flush_literals();
                             if (err || br.dw > dw_limit) { err = err ? err : TRK_INFLATE_STREAM; break; }
                         }
                     } else {
                         flush_literals();
-                        if (err) break;
-                        if (e & E_EOB) {              // end of block, or a symbol that is none
+                        if (RARE(err != 0)) break;
+                        if (RARE((e & E_EOB) != 0)) {              // end of block, or a symbol that is none
                             if ((e & E_KIND) == E_BAD) err = TRK_INFLATE_STREAM;
                             break;
                         }
@@ -463,20 +462,29 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate_bgzf(const InfArgs a
                         const int len = (int)(e >> 16) + (int)br.take(leb);
                         br.refill1();
                         uint32_t d = uni(s.d_tab[(uint32_t)br.bb & ((1u << D_ROOT) - 1u)]);
-                        if (!(d & 15u)) {
+                        if (RARE(!(d & 15u))) {
                             const int sl = (int)uni((uint32_t)decode_long<D_ROOT>((uint32_t)br.bb, s.d, s.d_sorted));
-                            if (sl < 0) { err = TRK_INFLATE_STREAM; break; }
+                            if (RARE(sl < 0)) { err = TRK_INFLATE_STREAM; break; }
                             d = d_entry(sl >> 4) | (uint32_t)(sl & 15);
                         }
                         br.drop((int)(d & 15u));
-                        if ((d & E_KIND) != E_BASE) { err = TRK_INFLATE_STREAM; break; }
+                        if (RARE((d & E_KIND) != E_BASE)) { err = TRK_INFLATE_STREAM; break; }
                         const int deb = (int)((d >> 4) & 15u);
                         const int dist = (int)(d >> 16) + (int)br.take(deb);
-                        if (dist > pos) { err = TRK_INFLATE_STREAM; break; }
-                        if (pos + len > out_len) { err = TRK_INFLATE_OVERRUN; break; }
-                        if (dist <= NEAR) {
+                        if (RARE(dist > pos)) { err = TRK_INFLATE_STREAM; break; }
+                        if (RARE(pos + len > out_len)) { err = TRK_INFLATE_OVERRUN; break; }
+                        if (!RARE(dist > NEAR)) {
                             // inside the ring: lanes take bytes; a period shorter than what is left doubles as the copy proceeds
                             int done = 0, d_eff = dist;
+                            if (len <= 64 && dist >= len) {     // (most matches: one step, source and destination apart)
+                                if (lane < len) {
+                                    const uint32_t o = (uint32_t)pos + (uint32_t)lane;
+                                    const uint8_t b = s.ring[(o - (uint32_t)dist) & (RING - 1)];
+                                    s.ring[o & (RING - 1)] = b;
+                                    dst[o] = b;
+                                }
+                                done = len;
+                            }
                             while (done < len) {
                                 const int n = min(min(len - done, 64), d_eff);
                                 if (lane < n) {
@@ -493,10 +501,9 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate_bgzf(const InfArgs a
                             // Lanes read what OTHER lanes of this wave stored: a fence of workgroup scope -- the wave's
                             // stores have reached the CU's L1 / the L2 it reads through (s_waitcnt vmcnt(0)); nothing
                             // leaves this CU.  (Agent scope here wrote the whole L2 back, `buffer_wbl2`, per fence.)
-                            if (pos - dist + len > fenced) {
-                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                                fenced = pos;
-                            }
+                            // (every far match: they are few -- a VCF's repeats lie within the ring -- and keeping track
+                            // of what is fenced was one more value carried around the symbol loop)
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                             for (int done = 0; done < len; done += 64) {
                                 if (done + lane < len) {
                                     const uint32_t o = (uint32_t)(pos + done) + (uint32_t)lane;
@@ -507,7 +514,7 @@ __global__ __launch_bounds__(64 * INF_WAVES) void k_inflate_bgzf(const InfArgs a
                             }
                         }
                         pos += len;
-                        if (br.dw > dw_limit) { err = TRK_INFLATE_STREAM; break; }
+                        if (RARE(br.dw > dw_limit)) { err = TRK_INFLATE_STREAM; break; }
                     }
                 }
             }
