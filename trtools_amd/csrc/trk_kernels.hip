@@ -2933,7 +2933,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
                     const uint64_t no = __ballot(__builtin_fma(-f.dthr, ad, xs) <= 0.0);
                     const uint64_t unsure = (~(yes | no) | __ballot(di == 0)) & exm;
                     c = yes & ~unsure;
-                    if (unsure) c |= unsure & __ballot(((double)xi / (double)di) > f.dthr);
+                    if (__builtin_expect(unsure != 0, 0)) c |= unsure & __ballot(((double)xi / (double)di) > f.dthr);
                 } else if (NFLT < 0 ? f.is_float != 0 : k >= NF - NFLT)
                     c = __ballot(__uint_as_float(TRK_PV(k)[j] ^ f.flip) < __uint_as_float((uint32_t)f.thr));
                 else
@@ -2955,7 +2955,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
                 const int32_t d = (int32_t)dv[j];
                 const uint64_t pneg = passm & __ballot(d < 0);
                 ac.totaldp[j] += __builtin_amdgcn_inverse_ballot_w64(passm & ~pneg) ? d : 0;
-                if (pneg) {   // (wave-uniform test)
+                if (__builtin_expect(pneg != 0, 0)) {   // (wave-uniform test; rare: out of line)
                     const uint64_t missm = __ballot(d == INT32_MIN);
                     add_mask(ac.dpmiss[j], pneg & missm);
                     bad |= pneg & ~missm;
@@ -2968,7 +2968,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
                 qtail += (uint32_t)__popcll(filtm);
             }
         }
-        if (has_dp && bad) {   // a negative depth on a call that passes (cold): dumpSTR.py:698-706
+        if (__builtin_expect(has_dp && bad, 0)) {   // a negative depth on a call that passes (cold): dumpSTR.py:698-706
 #pragma unroll
             for (int j = CF_V - 1; j >= 0; --j) {
                 const int32_t d = (int32_t)dv[j];
@@ -2998,7 +2998,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_v4(const V4Args a) {
                 __builtin_nontemporal_store(m8, reinterpret_cast<uint32_t*>(a.out.filter_mask8) + c4);
             }
         }
-        if (DELTA && qtail > (uint32_t)(V4_QCAP - CF_V * WAVE)) drain();
+        if (DELTA && __builtin_expect(qtail > (uint32_t)(V4_QCAP - CF_V * WAVE), 0)) drain();
 #undef TRK_PV
     };
     const int n_blocks = (L + a.loci_per_block - 1) / a.loci_per_block;
@@ -3358,7 +3358,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_gs(const GsArgs a) {
                 for (int j = 0; j < CF_V; ++j) m8 |= ((mout[j] & 0x7fu) | ((mout[j] >> 24) & 0x80u)) << (8 * j);
                 __builtin_nontemporal_store(m8, reinterpret_cast<uint32_t*>(a.out.filter_mask8) + c4);
             }
-            if (DELTA && qtail > (uint32_t)(V4_QCAP - CF_V * WAVE)) drain();
+            if (DELTA && __builtin_expect(qtail > (uint32_t)(V4_QCAP - CF_V * WAVE), 0)) drain();
         }
         drain();
     }
