@@ -3321,7 +3321,7 @@ __global__ __launch_bounds__(CF_THREADS) void k_call_filter_gs(const GsArgs a) {
                     totaldp[j] += __builtin_amdgcn_inverse_ballot_w64(passm[j]) ? dpos : 0;
                     bad |= passm[j] & __ballot((uint32_t)d > 0x80000000u);
                 }
-                if (bad) {   // a negative depth on a call that passes (cold): dumpSTR.py:698-706
+                if (__builtin_expect(bad != 0, 0)) {   // a negative depth on a call that passes (cold): dumpSTR.py:698-706
 #pragma unroll
                     for (int j = CF_V - 1; j >= 0; --j) {
                         const int32_t d = (int32_t)dv[j];
