@@ -234,3 +234,35 @@ def test_hook_is_refused_where_it_cannot_work(tmp_path):
     r = vcfnative.NativeVCFReader(path)
     assert r._lib.trk_vcf_set_inflate_hook(r._h, C.byref(hs)) != 0          # the samples are not skipped
     r.close()
+
+
+def test_chrom_runs_of_a_batch(tmp_path):
+    """RawBatch.chroms / chrom_column (array operations on the text) against a per-record reading: contig names of
+    different lengths, runs of one record, a contig that comes back."""
+    from trtools_amd import vcfnative
+    names = ['chr1'] * 5 + ['chr10'] * 3 + ['chr1'] + ['X'] * 4 + ['chrUn_gl000220'] + ['X'] + ['chr2'] * 6
+    hdr = ['##fileformat=VCFv4.2', '##command=HipSTR-v0.6.2 x', '##INFO=<ID=START,Number=1,Type=Integer,Description="s">',
+           '##INFO=<ID=END,Number=1,Type=Integer,Description="e">', '##INFO=<ID=PERIOD,Number=1,Type=Integer,Description="p">',
+           '##FORMAT=<ID=GT,Number=1,Type=String,Description="g">', '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts0\ts1']
+    lines = ['%s\t%d\t.\tACAC\tACACAC\t.\t.\tSTART=%d;END=%d;PERIOD=2\tGT\t0|1\t1|1' % (c, 100 + 10 * i, 100 + 10 * i, 103 + 10 * i)
+             for i, c in enumerate(names)]
+    path = str(tmp_path / 'c.vcf')
+    open(path, 'w').write('\n'.join(hdr + lines) + '\n')
+    for br in (len(names), 4, 1):
+        r = vcfnative.NativeVCFReader(path, batch_records=br)
+        got_col, got_distinct, at = [], [], 0
+        while True:
+            rb = r._read_raw_batch(br)
+            if rb.n == 0:
+                break
+            col = rb.chrom_column()
+            assert col == names[at:at + rb.n]
+            want = []
+            for c in col:
+                if c not in want:
+                    want.append(c)
+            assert rb.chroms() == want
+            got_col += col
+            at += rb.n
+        r.close()
+        assert got_col == names
