@@ -1154,7 +1154,10 @@ static int inf_submit(void* user, const unsigned char* comp, size_t comp_bytes, 
     in.in_len = reinterpret_cast<const int32_t*>(in.out_off + nb);
     in.out_len = in.in_len + nb;
     trk_inflate_out io = {r.seg, r.d_tab + r.flag_off};
-    if (trk::launch_inflate(in, io, ctx->n_cu, st->q_inf) != hipSuccess) return bail(TRK_ERR_HIP);
+    // three workgroups per CU, not the four that fit: a CU full of members (134 KB of its LDS, for the 5 ms a member takes)
+    // has no room for a workgroup of the parse kernel (35 KB) or of the count kernels -- the batch before waited for members
+    // to retire: statSTR 0.082-0.089 -> 0.076-0.084 s at 1 GB (profiles/r05_notes.md section 6)
+    if (trk::launch_inflate(in, io, ctx->n_cu, st->q_inf, 3) != hipSuccess) return bail(TRK_ERR_HIP);
     if (hipMemsetAsync(r.seg + total, '\n', 2048, st->q_inf) != hipSuccess) return bail(TRK_ERR_HIP);     // (readable padding)
     if (hipMemcpyAsync(r.h_tab + r.flag_off, r.d_tab + r.flag_off, nb, hipMemcpyDeviceToHost, st->q_inf) != hipSuccess) return bail(TRK_ERR_HIP);
     if (hipEventRecord(r.done, st->q_inf) != hipSuccess) return bail(TRK_ERR_HIP);

@@ -21,6 +21,7 @@
 // pass is sized by members in flight (sixteen waves per CU: 8 KiB of LDS and 87 registers per member), not by bytes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/trk.h"
 #include "trk_internal.h"
@@ -739,12 +740,14 @@ __global__ void k_copy_u32(const uint32_t* src, uint32_t* dst, const uint32_t* n
 }  // namespace
 
 namespace trk {
-hipError_t launch_inflate(const trk_inflate_in& in, const trk_inflate_out& out, int n_cu, hipStream_t stream) {
+hipError_t launch_inflate(const trk_inflate_in& in, const trk_inflate_out& out, int n_cu, hipStream_t stream, int wgs_per_cu) {
     if (in.n_blocks <= 0) return hipSuccess;
     InfArgs a{in, out};
     // members walk the grid: sixteen waves per CU when the registers allow (four workgroups of four members)
     const int wgs = (in.n_blocks + INF_WAVES - 1) / INF_WAVES;
-    const int grid = wgs < n_cu * 4 ? wgs : n_cu * 4;
+    int per_cu = wgs_per_cu >= 1 && wgs_per_cu <= 4 ? wgs_per_cu : 4;
+    if (const char* o = trk_opt("TRK_INFLATE_WGS_PER_CU")) per_cu = atoi(o) > 0 ? atoi(o) : per_cu;
+    const int grid = wgs < n_cu * per_cu ? wgs : n_cu * per_cu;
     hipLaunchKernelGGL(k_inflate_bgzf, dim3(grid), dim3(64 * INF_WAVES), 0, stream, a);
     return hipGetLastError();
 }

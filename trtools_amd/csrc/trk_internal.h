@@ -17,7 +17,9 @@ namespace trk {
 // columns are ordered by sample class (trk_batch.class_runs); nullptr: the per-call group kernels
 hipError_t launch_locus_count(const trk_batch& b, int max_alleles, int32_t* allele_count, int32_t* locus_int,
                               int n_cu, hipStream_t stream, bool twin, int32_t* class_ws);
-hipError_t launch_inflate(const trk_inflate_in& in, const trk_inflate_out& out, int n_cu, hipStream_t stream);
+// wgs_per_cu: resident workgroups (of four members) per CU: 4 = all the kernel's LDS allows, the best rate of the kernel
+// alone; 3 leaves 59 KB of a CU's LDS to whatever else runs (the hook: the parse and count kernels of the batch before)
+hipError_t launch_inflate(const trk_inflate_in& in, const trk_inflate_out& out, int n_cu, hipStream_t stream, int wgs_per_cu = 4);
 struct LineIndexWs {     // device results / scratch of launch_line_index (trk_inflate.hip)
     uint32_t* counts;    // [tiles of 16 KB + 1]
     uint32_t* n_nl;      // newlines found

@@ -884,9 +884,11 @@ class NativeVCFReader(vcfio.VCFReader):
         user, seed, infl = C.c_void_p(), C.c_void_p(), C.c_void_p()
         if engine.lib.trk_inflate_hook(engine.ctx, C.byref(user), C.byref(seed), C.byref(infl)) != 0:
             return False
-        # (a member is one wave's serial work of ~7 ms whatever else runs, and a CU holds sixteen of them: a run that fills
-        # the chip exactly once is inflated at the best rate -- tools/inflate_probe.py)
-        hook = _InflateHook(user.value, seed.value, infl.value, 16 * int(getattr(engine, 'n_cu', 256)))
+        # (runs of 16 x the CUs members: a member is one wave's serial work of ~5 ms whatever else runs; the hook keeps
+        # twelve of them on a CU at a time -- three workgroups, room for the other kernels' LDS -- and the reader never waits
+        # for a run's kernel anyway; runs of 12 x the CUs measured the same: tools/inflate_probe.py, r05 notes section 6)
+        hook = _InflateHook(user.value, seed.value, infl.value,
+                            int(_knobs.lab('TRK_INFLATE_RUN_PER_CU', '16')) * int(getattr(engine, 'n_cu', 256)))
         if _knobs.lab('TRK_INFLATE_PIPELINE', '1') == '1':
             # two runs in flight: run k + 1 is read and uploaded behind the kernel of run k (trk_inflate_hook_async)
             sub, col = C.c_void_p(), C.c_void_p()
