@@ -27,7 +27,7 @@ SUPPORTED = ('TRK_DEVICE', 'TRK_VCF_THREADS', 'TRK_FMT_THREADS', 'TRK_VCF_READ_A
 
 
 # The command lines' defaults for TRK_DEVICE_INFLATE (profiles/r05_notes.md section 6, r05_e2e_cpu_seconds.txt; 1.02 GB):
-#   statSTR  '1': 0.086-0.088 s against 0.095-0.105 with the host's inflater threads on the same box, at 0.5 CPU-seconds
+#   statSTR  '1': 0.076-0.088 s against 0.095-0.105 with the host's inflater threads on the same box, at 0.5 CPU-seconds
 #                 instead of 1.6-1.7 (two runs of 4096 members in flight behind the reader, kernels on a lowest-priority queue);
 #   dumpSTR  '0': its own kernels and copies share the device with the inflate kernel -- 0.22-0.24 s against 0.173,
 #                 although at 0.76 CPU-seconds instead of 1.8-2.0: TRK_DEVICE_INFLATE=1 where host cores are the scarce thing.
