@@ -324,7 +324,11 @@ typedef struct {
  * back (transient: up to six planes, while the device is still empty).  The context owns the pair for its lifetime:
  * trk_dev_alloc_pair lends it out whenever it is fast, both planes are free and bytes_each fits
  * (trk_pair_info.reserved = 1) -- a sub-plane lies in its plane's region, so smaller shapes are served alike -- and
- * trk_dev_free on either pointer hands it back instead of freeing it. */
+ * trk_dev_free on either pointer hands it back instead of freeing it.  When none of the eight planes makes a fast pair
+ * (planes of at least 256 MB: below that no levels can be told apart and the first two are kept as they are) NOTHING stays
+ * reserved: every plane goes back, the call returns TRK_OK with info->placed = 0 and trk_dev_alloc_pair searches as if
+ * the call had not been made.  Cost: 2 x bytes_each of device memory for the life of the context when it succeeds, up
+ * to 8 x bytes_each transiently and ~5 ms per probe at start-up (one probe in most processes). */
 int trk_reserve_pair(trk_ctx* ctx, size_t bytes_each, trk_pair_info* info);
 /* have[0 .. n_have): planes of bytes_each the caller already holds (an allocator's pooled buffers): have[0] becomes the
  * first plane, the others are the first candidates for the second; the ones not returned stay the caller's. */

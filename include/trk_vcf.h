@@ -116,8 +116,9 @@ int trk_vcf_parse_samples(trk_vcf* v, trk_vcf_batch* b);
  * calls hook->inflate with the compressed bytes and the members' payloads; the hook inflates them wherever it likes (the
  * text of the run is bytes [abs_base, abs_base + total) of the file's text, counted from the byte `seed` was given
  * first) and gives back ONLY what the host side of a batch reads:
- *   - the newlines: *nl = offsets relative to abs_base, ascending, bit 63 set when the byte before is '\r' (the array
- *     stays the hook's, valid until its next call);
+ *   - the newlines: *nl = offsets relative to abs_base, ascending, bit 63 set when the byte before is '\r' -- for a
+ *     newline at offset 0 that byte is the LAST byte of the text handed over before (the run before's, or the seed's:
+ *     a CRLF pair cut by a run's boundary); the array stays the hook's, valid until its next call;
  *   - the HEADS of the lines -- every byte from a line's start up to and including its ninth tab (CHROM ... FORMAT)
  *     -- copied to their places in `out` (out[i] = text byte abs_base + i); the sample columns are NOT written: in
  *     this mode trk_vcf_batch.text is valid in the heads only (trk_vcf_skip_samples must be on);

@@ -116,3 +116,24 @@ def test_held_array_goes_back_to_the_pool_only_after_unhold():
     assert b.ptr == 888 and e._pool_take(4096) is None
     b.free()
     assert e._pool_take(4096) == 888
+
+
+def test_held_plane_of_the_reserved_pair_goes_back_to_the_context():
+    """unhold()'s late free must not put a plane of the reserved pair (DeviceArray._reserved: lent by
+    trk_dev_alloc_pair) into the buffer pool -- it is handed back through trk_dev_free, as free() does."""
+    from trtools_amd.engine import DeviceArray
+    e = _engine()
+    e._live = set()
+    freed = []
+    e.lib.trk_dev_free = lambda ctx, p: freed.append(p) or 0
+    for held in (True, False):
+        a = DeviceArray.adopt(e, (1024,), 'u1', 4242, 4096)
+        a._reserved = True
+        if held:
+            a.hold()
+        a.free()
+        if held:
+            assert freed == []                                # somebody still reads it
+            a.unhold()
+        assert freed == [4242] and e._pool_take(4096) is None and e._pool_bytes == 0
+        freed.clear()

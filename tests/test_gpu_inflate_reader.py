@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 from helpers import lab_env
-from test_vcfnative_hook import _synthetic, _bgzip
+from test_vcfnative_hook import _synthetic, _bgzip, _bgzip_members, _crlf_cut_members, _blank_runs_text
 
 pytestmark = pytest.mark.gpu
 
@@ -71,13 +71,25 @@ def _read(eng, path, batch_records, device_inflate, pipeline=True):
     return out, fallbacks
 
 
-@pytest.mark.parametrize("case", ["long rows", "short rows", "crlf", "no last newline"])
+@pytest.mark.parametrize("case", ["long rows", "short rows", "crlf", "no last newline", "crlf cut by the runs", "runs of blank lines"])
 def test_device_inflated_batches_equal_host_inflated_ones(eng, tmp_path, case):
-    text = {"long rows": lambda: _synthetic(300, 6000, seed=1), "short rows": lambda: _synthetic(20000, 3, seed=2),
-            "crlf": lambda: _synthetic(400, 900, crlf=True, seed=3), "no last newline": lambda: _synthetic(250, 700, last_newline=False, seed=4)}[case]()
-    path = _bgzip(tmp_path, 'f.vcf.gz', text)
+    sizes = ((64, 500000), (37, 3 << 20), (128, None))
+    if case == "crlf cut by the runs":
+        # every member ends with a line's '\r' and begins with its '\n': each run boundary cuts a pair, and the flag of
+        # a newline at offset 0 of a run comes from the run before
+        _, parts = _crlf_cut_members(n_rec=900, S=60)
+        path = _bgzip_members(tmp_path, 'f.vcf.gz', parts)
+        sizes = ((64, 3000), (37, 40000), (128, None))
+    elif case == "runs of blank lines":
+        # lines of fewer than 16 bytes on average: the line tables are sized from the count (they were
+        # total / 16 + 1024 entries, overrun on the device before the host refused the read)
+        path = _bgzip(tmp_path, 'f.vcf.gz', _blank_runs_text(n_rec=300, S=200, run=1500000))
+    else:
+        text = {"long rows": lambda: _synthetic(300, 6000, seed=1), "short rows": lambda: _synthetic(20000, 3, seed=2),
+                "crlf": lambda: _synthetic(400, 900, crlf=True, seed=3), "no last newline": lambda: _synthetic(250, 700, last_newline=False, seed=4)}[case]()
+        path = _bgzip(tmp_path, 'f.vcf.gz', text)
     from trtools_amd import _lib as L
-    for br, read_bytes in ((64, 500000), (37, 3 << 20), (128, None)):
+    for br, read_bytes in sizes:
         opts = {} if read_bytes is None else dict(TRK_VCF_READ_BYTES=read_bytes)
         with L.options(**opts):
             host, _ = _read(eng, path, br, False)

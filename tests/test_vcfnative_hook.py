@@ -62,6 +62,7 @@ class PyHook:
             self.calls += 1
             self.max_seen = max(getattr(self, 'max_seen', 0), len(blks))
             assert abs_base == len(self.text)
+            before = bytes(self.text[-1:])      # (a '\r' there belongs to a newline that opens this run)
             seg = bytearray(total)
             for off, ln, isize, dst in blks:
                 d = zlib.decompress(raw[off:off + ln], -15)
@@ -97,7 +98,7 @@ class PyHook:
                 if e < 0:
                     line_state[0] = 9 if need <= 0 else tabs_now
                     break
-                nls.append(e | ((1 << 63) if e > 0 and seg_b[e - 1:e] == b'\r' else 0))
+                nls.append(e | ((1 << 63) if (seg_b[e - 1:e] if e > 0 else before) == b'\r' else 0))
                 tabs = 0
                 pos = e + 1
             arr = (C.c_uint64 * max(len(nls), 1))(*nls)
@@ -152,7 +153,7 @@ def _batches(path, hooked, batch_records, keys=('DP', 'Q'), max_members=0, pipel
     return out, absolute, hook
 
 
-FILES = [os.path.join(GOLDEN, 'dumpstr_synth', f) for f in ('synth_hipstr.vcf.gz', 'synth_gangstr.vcf.gz')
+FILES = [os.path.join(GOLDEN, 'dumpstr_synth', f) for f in ('synth_hipstr.vcf', 'synth_gangstr.vcf')
          if os.path.exists(os.path.join(GOLDEN, 'dumpstr_synth', f))]
 
 
@@ -161,6 +162,18 @@ def _bgzip(tmp_path, name, text, level=6):
     p = str(tmp_path / name)
     with BgzfWriter(p, threads=1) as fh:
         fh.write(text)
+    return p
+
+
+def _bgzip_members(tmp_path, name, parts, level=6):
+    """A BGZF file whose members hold exactly `parts` (bytes each, <= 65280): the test decides what a member boundary cuts."""
+    from trtools_amd.bgzf import _compress_block, _EOF
+    p = str(tmp_path / name)
+    with open(p, 'wb') as fh:
+        for part in parts:
+            assert 0 < len(part) <= 0xff00
+            fh.write(_compress_block((bytes(part), level)))
+        fh.write(_EOF)
     return p
 
 
@@ -210,14 +223,77 @@ def test_hooked_read_equals_the_plain_read(tmp_path, case):
         assert not hook.queue and (not pl or hook.max_in_flight <= 2)
 
 
-@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
-def test_hooked_read_of_the_fixtures(path):
+def _crlf_cut_members(n_rec=700, S=40, seed=11):
+    """CRLF text in members that END with a line's '\r' and BEGIN with its '\n': whatever run of members a hook is given,
+    its boundary cuts a CRLF pair (the flag of a newline at offset 0 of a run comes from the run before)."""
+    text = _synthetic(n_rec, S, crlf=True, seed=seed)
+    lines = text.split(b'\r\n')
+    assert lines[-1] == b''
+    lines = lines[:-1]
+    k = next(i for i, ln in enumerate(lines) if ln.startswith(b'#CHROM'))
+    parts = [b'\r\n'.join(lines[:k + 1]) + b'\r']              # the header and the first '\r'
+    for ln in lines[k + 1:]:
+        parts.append(b'\n' + ln + b'\r')
+    parts.append(b'\n')
+    return text, parts
+
+
+def _blank_runs_text(n_rec=300, S=30, seed=12, run=200000):
+    """Records between long runs of blank lines (lines of fewer than 16 bytes on average: ADVICE r05 -- the device's
+    line tables were sized total / 16; the host's path skips blank lines)."""
+    text = _synthetic(n_rec, S, seed=seed)
+    lines = text.split(b'\n')[:-1]
+    k = next(i for i, ln in enumerate(lines) if ln.startswith(b'#CHROM'))
+    out = lines[:k + 1]
+    for i, ln in enumerate(lines[k + 1:]):
+        if i in (0, 100, 299):
+            out.append(b'\n' * run)                       # (joined below: run + 1 blank lines)
+        elif i % 7 == 0:
+            out.append(b'')
+        out.append(ln)
+    return b'\n'.join(out) + b'\n' * 5000
+
+
+@pytest.mark.parametrize("mm,pl", [(1, False), (1, True), (3, True), (0, False)])
+def test_crlf_pair_cut_by_every_run_boundary(tmp_path, mm, pl):
+    text, parts = _crlf_cut_members()
+    path = _bgzip_members(tmp_path, 'cut.vcf.gz', parts)
+    import gzip
+    assert gzip.open(path).read() == text
     from trtools_amd import _lib as L
+    for br, min_read in ((5, 4000), (64, 1 << 20)):
+        with L.options(TRK_VCF_READ_BYTES=min_read):
+            plain, _, _ = _batches(path, False, br)
+            hooked, abs_h, hook = _batches(path, True, br, max_members=mm, pipelined=pl)
+        assert plain == hooked and len(plain) == 700
+        full = bytes(hook.text)
+        for (lo, le), rec in zip(abs_h, hooked):
+            assert full[le:le + 2] == b'\r\n'               # the line ends IN FRONT of its '\r'
+
+
+def test_runs_of_blank_lines(tmp_path):
+    text = _blank_runs_text()
+    path = _bgzip(tmp_path, 'blank.vcf.gz', text)
+    from trtools_amd import _lib as L
+    with L.options(TRK_VCF_READ_BYTES=300000):
+        plain, _, _ = _batches(path, False, 64)
+        hooked, _, _ = _batches(path, True, 64, max_members=2, pipelined=True)
+    assert plain == hooked and len(plain) == 300
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_hooked_read_of_the_fixtures(path, tmp_path):
+    from trtools_amd import _lib as L
+    # (the fixtures are plain text of ~50 KB: their records thirty times over, so that the reader has something to fill)
+    lines = open(path, 'rb').read().split(b'\n')
+    k = next(i for i, ln in enumerate(lines) if ln.startswith(b'#CHROM'))
+    text = b'\n'.join(lines[:k + 1] + [ln for _ in range(30) for ln in lines[k + 1:] if ln]) + b'\n'
+    path = _bgzip(tmp_path, os.path.basename(path) + '.gz', text)
     with L.options(TRK_VCF_READ_BYTES=20000):
         plain, _, _ = _batches(path, False, 16)
         hooked, _, hook = _batches(path, True, 16)
         piped, _, hook2 = _batches(path, True, 16, max_members=2, pipelined=True)
-    assert plain == hooked and plain == piped and len(plain) > 10 and hook2.max_in_flight == 2
+    assert plain == hooked and plain == piped and len(plain) > 300 and hook.calls >= 2 and hook2.max_in_flight == 2
 
 
 def test_hook_is_refused_where_it_cannot_work(tmp_path):

@@ -320,6 +320,25 @@ __global__ __launch_bounds__(256) void k_compact(Streams s, uint32_t* out8, int 
                     }
                     __syncthreads();
                 }
+            } else if (MODE == 4) {
+                // round 6: TILED mask layout [column tile][locus][256 lanes]: a workgroup's kilobytes of consecutive
+                // loci lie back to back (one contiguous ~1 MB stream per workgroup instead of a kilobyte per 10 KB row)
+                if (live) __builtin_nontemporal_store(m8, out8 + ((size_t)bx * L + (l + d)) * 256 + threadIdx.x);
+            } else if (MODE == 5) {
+                // tiled per WAVE: [column tile][wave][locus][64 lanes] -- each wave's 256 B of consecutive loci back to back
+                if (live) __builtin_nontemporal_store(m8, out8 + (((size_t)bx * 4 + (threadIdx.x >> 6)) * L + (l + d)) * 64 + (threadIdx.x & 63));
+            } else if (MODE == 6) {
+                // tiled per wave + the bytes of 4 loci exchanged inside the WAVE (no barrier): lane i stores 16 B = the dwords
+                // of lanes 4(i & 15) .. + 3 of locus (i >> 4): one contiguous kilobyte per wave every fourth locus
+                const int q = (l + d - l0) & 3;
+                const int w = threadIdx.x >> 6, i = threadIdx.x & 63;
+                stage[q][threadIdx.x] = m8;
+                if (q == 3 || l + d == l1 - 1) {
+                    const int qq = i >> 4, r4 = 4 * (i & 15);
+                    const u32x4 v = {stage[qq][64 * w + r4], stage[qq][64 * w + r4 + 1], stage[qq][64 * w + r4 + 2], stage[qq][64 * w + r4 + 3]};
+                    if (qq <= q)
+                        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out8 + (((size_t)bx * 4 + w) * L + (l + d - q + qq)) * 64 + r4));
+                }
             } else acc ^= r;
         }
     }
@@ -502,6 +521,9 @@ static void compact(const Streams& s, uint32_t* out8) {
         run(nm, [&] { hipLaunchKernelGGL((k_compact<M, D>), dim3(ny * gx), dim3(256), 0, 0, s, out8, L, S4, lpb, gx, sink); });
         CO(3, 1, "read only") CO(3, 3, "read only") CO(0, 1, "4 B nt store") CO(0, 2, "4 B nt store") CO(0, 3, "4 B nt store")
         CO(1, 1, "4 B plain store") CO(1, 3, "4 B plain store") CO(2, 1, "16 B stores through LDS every 4th locus") CO(2, 3, "16 B stores through LDS every 4th locus")
+        CO(4, 1, "TILED [tile][locus][256], 4 B nt store") CO(4, 2, "TILED [tile][locus][256], 4 B nt store") CO(4, 3, "TILED [tile][locus][256], 4 B nt store")
+        CO(5, 1, "TILED per wave [tile][wave][locus][64], 4 B nt store") CO(5, 3, "TILED per wave [tile][wave][locus][64], 4 B nt store")
+        CO(6, 1, "TILED per wave, 16 B stores (4 loci exchanged inside the wave)") CO(6, 3, "TILED per wave, 16 B stores (4 loci exchanged inside the wave)")
 #undef CO
     }
 }
@@ -634,7 +656,7 @@ int main(int argc, char** argv) {
     }
     if (want("compact")) {
         uint32_t* out8 = nullptr;
-        CK(hipMalloc((void**)&out8, plane / 4 + 256));
+        CK(hipMalloc((void**)&out8, (size_t)gx * L * 1024 + 4096));     // (the tiled layouts: whole 256-lane tiles)
         compact(s, out8);
         hipFree(out8);
     }

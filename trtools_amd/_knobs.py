@@ -15,6 +15,10 @@ SUPPORTED settings -- the table in README.md ("Environment") -- are read with ``
                           for API engines, 0 for the command lines)
     TRK_POOL_GB           device memory the engine's buffer pool may hold (default 8)
 
+libtrk itself reads three of them with getenv -- TRK_VCF_THREADS, TRK_FMT_THREADS and TRK_VCF_BUF_CACHE_MB (megabytes of
+text buffers a process keeps for its next reader, default 4096, 0: none; read once, when the first reader opens) -- and
+nothing else.
+
 Everything else the package ever looked up in the environment -- forced code paths of the parity tests, A/B switches of
 tools/ -- is a LAB knob: read with ``lab`` and honoured only when TRK_LAB=1 is set (tests/conftest.py and the tools
 set it).  The library's own switches are options of include/trk_test.h (``_lib.set_option``); its lab build

@@ -221,7 +221,9 @@ def source_digest():
 def _ensure_current():
     """A prebuilt libtrk.so must come from the sources next to it: the build leaves their SHA-256 in
     libtrk.so.srchash.  On a mismatch the library is rebuilt (hipcc cross-compiles anywhere); if that is not
-    possible this raises rather than run a stale binary.  TRK_SKIP_STALE_CHECK=1 skips the check."""
+    possible this raises rather than run a stale binary.  The check is skipped only in a lab process
+    (TRK_LAB=1 TRK_SKIP_STALE_CHECK=1: tools/ running one build against another); a binary-only install -- no
+    sources next to the library -- has nothing to compare and loads as it is."""
     if _knobs.lab('TRK_SKIP_STALE_CHECK'):
         return
     try:

@@ -985,7 +985,8 @@ struct InflateState {
     uint8_t* h_stage = nullptr;    // pinned: tables up, results down
     size_t h_cap = 0;
     std::vector<uint64_t> nl_host;
-    uint64_t n_blocks = 0, n_flagged = 0, n_text = 0, n_comp = 0, n_calls = 0;
+    uint64_t n_blocks = 0, n_flagged = 0, n_text = 0, n_comp = 0, n_calls = 0, n_regrown = 0;
+    int tail_byte = -1;            // the last byte of the text handed over so far (a '\r' there flags the next run's first newline)
 };
 static void inflate_state_free(InflateState* st) {
     for (auto& sg : st->segs) (void)hipFree(sg.d);
@@ -1056,6 +1057,7 @@ static int inf_seed(void* user, const char* text, size_t n) {
         r.seg = nullptr;
         st->run_pool.push_back(std::move(r));
     }
+    st->tail_byte = n ? (int)(unsigned char)text[n - 1] : -1;
     if (n == 0) return 0;
     size_t cap = 0;
     uint8_t* d = inf_segment(st, n + 2048, cap);
@@ -1222,35 +1224,53 @@ static int inf_collect(void* user, char* out, int* line_state, const uint64_t** 
         if (!okz) return bail(TRK_ERR_ARG);                 // a member nobody can inflate: the file is corrupt
         if (b.isize && hipMemcpy(seg + b.dst, tmp.data(), b.isize, hipMemcpyHostToDevice) != hipSuccess) return bail(TRK_ERR_HIP);
     }
-    // the line index and the heads
+    // the line index and the heads.  Two steps: the newlines are COUNTED first and the tables sized from the count (a
+    // guess -- a line per sixteen bytes -- only sizes the first try: text with shorter lines, blank lines or no VCF at
+    // all, is indexed like any other, as the host's path reads it)
     const size_t n_tiles = (total + 16383) / 16384;
-    const size_t nl_cap = total / 16 + 1024;
-    // workspace: counts, scalars (n_nl, head_total, state), nl, head_off, head_len, pack_off, packed
-    size_t o_counts = 0, o_scal = (o_counts + (n_tiles + 1) * 4 + 15) & ~(size_t)15, o_nl = o_scal + 64, o_hoff = o_nl + nl_cap * 8,
-           o_hlen = o_hoff + (nl_cap + 1) * 8, o_poff = (o_hlen + (nl_cap + 1) * 4 + 15) & ~(size_t)15,
-           o_pack = (o_poff + (nl_cap + 1) * 4 + 15) & ~(size_t)15, ws_bytes = o_pack + total + 64;
-    if (!inf_grow_dev(st->d_ws, st->ws_cap, ws_bytes)) return bail(TRK_ERR_NOMEM);
-    if (!inf_grow_host(st, 4096)) return bail(TRK_ERR_NOMEM);
+    size_t nl_cap = total / 16 + 1024;
     trk::LineIndexWs ws;
-    ws.counts = reinterpret_cast<uint32_t*>(st->d_ws + o_counts);
-    uint32_t* scal = reinterpret_cast<uint32_t*>(st->d_ws + o_scal);
-    ws.n_nl = scal;
-    ws.head_total = scal + 1;
-    ws.state = reinterpret_cast<int32_t*>(scal + 2);
-    ws.nl = reinterpret_cast<uint64_t*>(st->d_ws + o_nl);
-    ws.nl_cap = (uint32_t)nl_cap;
-    ws.head_off = reinterpret_cast<uint64_t*>(st->d_ws + o_hoff);
-    ws.head_len = reinterpret_cast<uint32_t*>(st->d_ws + o_hlen);
-    ws.pack_off = reinterpret_cast<uint32_t*>(st->d_ws + o_poff);
-    ws.packed = st->d_ws + o_pack;
-    ws.packed_cap = (uint32_t)std::min<size_t>(total + 64, 0xffffffffu);
-    if (trk::launch_line_index(seg, (int64_t)total, *line_state, ws, q) != hipSuccess) return bail(TRK_ERR_HIP);
+    uint32_t* scal = nullptr;
+    // workspace: counts, scalars (n_nl, head_total, state, last byte), nl, head_off, head_len, pack_off, packed
+    auto lay_out = [&]() -> bool {
+        size_t o_counts = 0, o_scal = (o_counts + (n_tiles + 1) * 4 + 15) & ~(size_t)15, o_nl = o_scal + 64, o_hoff = o_nl + nl_cap * 8,
+               o_hlen = o_hoff + (nl_cap + 1) * 8, o_poff = (o_hlen + (nl_cap + 1) * 4 + 15) & ~(size_t)15,
+               o_pack = (o_poff + (nl_cap + 1) * 4 + 15) & ~(size_t)15, ws_bytes = o_pack + total + 64;
+        if (!inf_grow_dev(st->d_ws, st->ws_cap, ws_bytes)) return false;
+        ws.counts = reinterpret_cast<uint32_t*>(st->d_ws + o_counts);
+        scal = reinterpret_cast<uint32_t*>(st->d_ws + o_scal);
+        ws.n_nl = scal;
+        ws.head_total = scal + 1;
+        ws.state = reinterpret_cast<int32_t*>(scal + 2);
+        ws.nl = reinterpret_cast<uint64_t*>(st->d_ws + o_nl);
+        ws.nl_cap = (uint32_t)nl_cap;
+        ws.head_off = reinterpret_cast<uint64_t*>(st->d_ws + o_hoff);
+        ws.head_len = reinterpret_cast<uint32_t*>(st->d_ws + o_hlen);
+        ws.pack_off = reinterpret_cast<uint32_t*>(st->d_ws + o_poff);
+        ws.packed = st->d_ws + o_pack;
+        ws.packed_cap = (uint32_t)std::min<size_t>(total + 64, 0xffffffffu);
+        return true;
+    };
+    if (total >= 0xfffffff0u) return bail(TRK_ERR_ARG);             // (32-bit line tables; a run is a few hundred megabytes)
+    if (!lay_out()) return bail(TRK_ERR_NOMEM);
+    if (!inf_grow_host(st, 4096)) return bail(TRK_ERR_NOMEM);
     uint32_t* h_scal = reinterpret_cast<uint32_t*>(st->h_stage);
+    for (int attempt = 0;; ++attempt) {
+        if (trk::launch_line_count(seg, (int64_t)total, ws, q) != hipSuccess) return bail(TRK_ERR_HIP);
+        if (hipMemcpyAsync(h_scal, scal, 4, hipMemcpyDeviceToHost, q) != hipSuccess || hipStreamSynchronize(q) != hipSuccess) return bail(TRK_ERR_HIP);
+        if (h_scal[0] <= nl_cap) break;
+        if (attempt) return bail(TRK_ERR_HIP);                       // (the count of one text cannot change)
+        nl_cap = (size_t)h_scal[0] + 1024;                           // the workspace moves: counted again in the new one
+        ++st->n_regrown;
+        if (!lay_out()) return bail(TRK_ERR_NOMEM);
+    }
+    if (trk::launch_line_index(seg, (int64_t)total, *line_state, ws, q) != hipSuccess) return bail(TRK_ERR_HIP);
     if (hipMemcpyAsync(h_scal, scal, 16, hipMemcpyDeviceToHost, q) != hipSuccess || hipStreamSynchronize(q) != hipSuccess) return bail(TRK_ERR_HIP);
     const auto t3 = now();
     const uint32_t n_found = h_scal[0], head_total = h_scal[1];
     const int state = (int)h_scal[2];
-    if (n_found > nl_cap || head_total > ws.packed_cap) return bail(TRK_ERR_ARG);       // (lines of fewer than 16 bytes on average: not a VCF)
+    const int tail_now = (int)(int32_t)h_scal[3];      // (read here: the staging buffer may move below)
+    if (n_found > nl_cap || head_total > ws.packed_cap) return bail(TRK_ERR_ARG);       // (cannot happen: sized from the count above)
     const size_t n_lines = (size_t)n_found + 1;
     const size_t r_nl = 0, r_hoff = r_nl + (size_t)n_found * 8, r_hlen = r_hoff + n_lines * 8, r_pack = (r_hlen + n_lines * 4 + 15) & ~(size_t)15,
                  r_bytes = r_pack + head_total;
@@ -1275,6 +1295,9 @@ static int inf_collect(void* user, char* out, int* line_state, const uint64_t** 
         at += len;
     }
     st->nl_host.assign(h_nl, h_nl + n_found);
+    // a CRLF pair cut by the run's boundary: the '\r' was the last byte of the text before (the run before's, or the seed's)
+    if (n_found && (st->nl_host[0] & ~(1ull << 63)) == 0 && st->tail_byte == '\r') st->nl_host[0] |= 1ull << 63;
+    st->tail_byte = tail_now;
     *nl = st->nl_host.data();
     *n_nl = n_found;
     *line_state = state;
@@ -1508,13 +1531,26 @@ int trk_reserve_pair(trk_ctx* ctx, size_t bytes_each, trk_pair_info* info) {
         if (e != hipSuccess) return fail(ctx, TRK_ERR_HIP, "trk_reserve_pair probe: %s", hipGetErrorString(e));
         return fail(ctx, TRK_ERR_NOMEM, "trk_reserve_pair: hipMalloc(%zu)", bytes_each);
     }
+    const float tbps = (can_probe && best > 0.f) ? (float)(gbytes / (double)best) : 0.f;
+    if (can_probe && tbps < (float)TRK_PAIR_FAST_TBPS) {
+        // no fast pair among MAXP planes: a pair that trk_dev_alloc_pair would never lend is not kept either (ADVICE r05:
+        // 2 x bytes_each held for the life of the context for nothing) -- everything goes back, the caller is told
+        for (int k = 0; k < MAXP; ++k) if (p[k]) (void)hipFree(p[k]);
+        pi.n_probed = n_probes < TRK_PAIR_MAX_PROBES ? n_probes : TRK_PAIR_MAX_PROBES;
+        pi.kept_ms = best;
+        pi.placed = 0;
+        pi.peak_extra_bytes = (uint64_t)n * (uint64_t)bytes_each;
+        pi.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (info) *info = pi;
+        return TRK_OK;
+    }
     for (int k = 0; k < MAXP; ++k)
         if (p[k] && k != keep_a && k != keep_b) (void)hipFree(p[k]);
     ctx->res_plane[0] = p[keep_a];
     ctx->res_plane[1] = p[keep_b];
     ctx->res_bytes = bytes_each;
     ctx->res_lent[0] = ctx->res_lent[1] = false;
-    ctx->res_tbps = (can_probe && best > 0.f) ? (float)(gbytes / (double)best) : 0.f;
+    ctx->res_tbps = tbps;
     pi.n_probed = n_probes < TRK_PAIR_MAX_PROBES ? n_probes : TRK_PAIR_MAX_PROBES;
     pi.kept_ms = best;
     pi.placed = ctx->res_tbps >= (float)TRK_PAIR_FAST_TBPS ? 1 : 0;

@@ -635,9 +635,10 @@ __global__ __launch_bounds__(256) void k_nl_scatter(const uint8_t* text, int64_t
 // it); a line with fewer tabs is all head.  head_len[i] bytes from head_off[i]; *state_out: the tabs (0 ... 9) seen
 // in the unfinished last line.
 __global__ __launch_bounds__(64) void k_line_heads(const uint8_t* text, int64_t n, const uint64_t* nl, const uint32_t* n_nl_p,
-                                                   int tabs_in, uint64_t* head_off, uint32_t* head_len, int32_t* state_out) {
-    const uint32_t n_nl = *n_nl_p;
-    const int lane = threadIdx.x;
+                                                   int tabs_in, uint64_t* head_off, uint32_t* head_len, int32_t* state_out,
+                                                   uint32_t cap) {
+    const uint32_t n_nl = min(*n_nl_p, cap);     // (the tables hold cap + 1 lines; the host sizes them from the count and
+    const int lane = threadIdx.x;                //  launches this after it has read it -- the clamp is the belt to that)
     for (uint32_t i = blockIdx.x; i <= n_nl; i += gridDim.x) {
         const int64_t start = i == 0 ? 0 : (int64_t)(nl[i - 1] & ~(1ull << 63)) + 1;
         const int64_t end = i < n_nl ? (int64_t)(nl[i] & ~(1ull << 63)) : n;
@@ -690,15 +691,19 @@ __global__ __launch_bounds__(64) void k_line_heads(const uint8_t* text, int64_t 
         if (lane == 0) {
             head_off[i] = (uint64_t)start;
             head_len[i] = (uint32_t)(head_end - start);
-            if (i == n_nl) *state_out = min(9, carried + found);
+            if (i == n_nl) {
+                state_out[0] = min(9, carried + found);
+                state_out[1] = n > 0 ? (int32_t)text[n - 1] : -1;     // the run's last byte: a '\r' there belongs to the
+            }                                                          // newline that opens the next run
         }
     }
 }
 
 // heads gathered back to back: pack_off = exclusive scan of head_len
 __global__ __launch_bounds__(64) void k_head_gather(const uint8_t* text, const uint64_t* head_off, const uint32_t* head_len,
-                                                    const uint32_t* pack_off, const uint32_t* n_nl_p, uint8_t* packed, uint32_t cap) {
-    const uint32_t n_lines = *n_nl_p + 1;
+                                                    const uint32_t* pack_off, const uint32_t* n_nl_p, uint8_t* packed, uint32_t cap,
+                                                    uint32_t nl_cap) {
+    const uint32_t n_lines = min(*n_nl_p, nl_cap) + 1;
     for (uint32_t i = blockIdx.x; i < n_lines; i += gridDim.x) {
         const uint8_t* src = text + head_off[i];
         const uint32_t len = head_len[i], o = pack_off[i];
@@ -708,9 +713,9 @@ __global__ __launch_bounds__(64) void k_head_gather(const uint8_t* text, const u
 }
 
 // exclusive scan of v[0 .. *n_nl_p] in place (one workgroup), total to *total
-__global__ __launch_bounds__(1024) void k_scan_lines(uint32_t* v, const uint32_t* n_nl_p, uint32_t* total) {
+__global__ __launch_bounds__(1024) void k_scan_lines(uint32_t* v, const uint32_t* n_nl_p, uint32_t* total, uint32_t nl_cap) {
     __shared__ uint32_t tot[1024];
-    const int n = (int)*n_nl_p + 1;
+    const int n = (int)min(*n_nl_p, nl_cap) + 1;
     const int per = (n + 1023) / 1024;
     const int lo = threadIdx.x * per, hi = min(n, lo + per);
     uint32_t sum = 0;
@@ -732,8 +737,8 @@ __global__ __launch_bounds__(1024) void k_scan_lines(uint32_t* v, const uint32_t
     if (threadIdx.x == 1023) *total = tot[1023];
 }
 
-__global__ void k_copy_u32(const uint32_t* src, uint32_t* dst, const uint32_t* n_nl_p) {   // dst[i] = src[i], i <= n_nl
-    const uint32_t n = *n_nl_p + 1;
+__global__ void k_copy_u32(const uint32_t* src, uint32_t* dst, const uint32_t* n_nl_p, uint32_t nl_cap) {   // dst[i] = src[i], i <= n_nl
+    const uint32_t n = min(*n_nl_p, nl_cap) + 1;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
@@ -752,23 +757,33 @@ hipError_t launch_inflate(const trk_inflate_in& in, const trk_inflate_out& out, 
     return hipGetLastError();
 }
 
-// The line index of text[0 .. n) and the heads of its lines (see k_line_heads).  All results stay on the device:
+// The line index of text[0 .. n) and the heads of its lines (see k_line_heads), in two steps so that the tables are
+// sized from the COUNT and not from a guess about the text (lines of fewer than 16 bytes -- blank lines, text that is
+// no VCF -- used to overrun a workspace sized total / 16: ADVICE r05).  All results stay on the device:
 //   ws.counts [n_tiles + 1] scratch, ws.n_nl (one word), ws.nl [nl_cap], ws.head_off / head_len / pack_off [nl_cap + 1],
-//   ws.head_total (one word), ws.state (one word), ws.packed [packed_cap]
-hipError_t launch_line_index(const uint8_t* text, int64_t n, int tabs_in, const LineIndexWs& ws, hipStream_t stream) {
+//   ws.head_total (one word), ws.state (two words: tabs of the unfinished last line, the text's last byte),
+//   ws.packed [packed_cap]
+// Step 1: the newlines per 16 KB tile and their total in *ws.n_nl (the caller reads it and makes sure nl_cap >= it).
+hipError_t launch_line_count(const uint8_t* text, int64_t n, const LineIndexWs& ws, hipStream_t stream) {
     const int n_tiles = (int)((n + NL_TILE - 1) / NL_TILE);
     if (n_tiles < 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_nl_count, dim3(n_tiles), dim3(256), 0, stream, text, n, ws.counts);
     hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, stream, ws.counts, n_tiles, ws.n_nl);
+    return hipGetLastError();
+}
+// Step 2: everything else.  Every kernel clamps the line count to ws.nl_cap.
+hipError_t launch_line_index(const uint8_t* text, int64_t n, int tabs_in, const LineIndexWs& ws, hipStream_t stream) {
+    const int n_tiles = (int)((n + NL_TILE - 1) / NL_TILE);
+    if (n_tiles < 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_nl_scatter, dim3(n_tiles), dim3(256), 0, stream, text, n, ws.counts, ws.nl, ws.nl_cap);
     const int lines_grid = 4096;
     hipLaunchKernelGGL(k_line_heads, dim3(lines_grid), dim3(64), 0, stream, text, n, ws.nl, ws.n_nl, tabs_in, ws.head_off,
-                       ws.head_len, ws.state);
+                       ws.head_len, ws.state, ws.nl_cap);
     // pack_off = exclusive scan of head_len (a copy, scanned in place by one workgroup)
-    hipLaunchKernelGGL(k_copy_u32, dim3(256), dim3(256), 0, stream, ws.head_len, ws.pack_off, ws.n_nl);
-    hipLaunchKernelGGL(k_scan_lines, dim3(1), dim3(1024), 0, stream, ws.pack_off, ws.n_nl, ws.head_total);
+    hipLaunchKernelGGL(k_copy_u32, dim3(256), dim3(256), 0, stream, ws.head_len, ws.pack_off, ws.n_nl, ws.nl_cap);
+    hipLaunchKernelGGL(k_scan_lines, dim3(1), dim3(1024), 0, stream, ws.pack_off, ws.n_nl, ws.head_total, ws.nl_cap);
     hipLaunchKernelGGL(k_head_gather, dim3(lines_grid), dim3(64), 0, stream, text, ws.head_off, ws.head_len, ws.pack_off, ws.n_nl,
-                       ws.packed, ws.packed_cap);
+                       ws.packed, ws.packed_cap, ws.nl_cap);
     return hipGetLastError();
 }
 }  // namespace trk

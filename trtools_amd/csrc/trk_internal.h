@@ -29,10 +29,11 @@ struct LineIndexWs {     // device results / scratch of launch_line_index (trk_i
     uint32_t* head_len;
     uint32_t* pack_off;
     uint32_t* head_total;
-    int32_t* state;      // tabs seen in the unfinished last line
+    int32_t* state;      // [2] tabs seen in the unfinished last line; the text's last byte
     uint8_t* packed;     // the heads back to back
     uint32_t packed_cap;
 };
+hipError_t launch_line_count(const uint8_t* text, int64_t n, const LineIndexWs& ws, hipStream_t stream);   // step 1: *ws.n_nl
 hipError_t launch_line_index(const uint8_t* text, int64_t n, int tabs_in, const LineIndexWs& ws, hipStream_t stream);
 hipError_t launch_permute_columns(const int16_t* src, int16_t* dst, const int32_t* col, int64_t n_loci, int n_src,
                                   int n_dst, int ploidy, int n_cu, hipStream_t stream);

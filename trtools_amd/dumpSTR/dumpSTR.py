@@ -133,6 +133,24 @@ def _check_caller(format_fields, args, rules, pairs):
     return True
 
 
+def _caller_check(key, lines):
+    def check(format_fields, args):
+        _, _, rules, pairs = _CALLER_RULES[key]
+        return _check_caller(format_fields, args, rules, pairs)
+    check.__doc__ = ("Are the %s call-level options in range, and does the VCF carry the FORMAT fields they read?  "
+                     "False after a WARNING otherwise (dumpSTR.py:%s)." % (_CALLER_RULES[key][1], lines))
+    return check
+
+
+# the reference's per-caller validators under their own names (CheckFilters below walks the same table)
+CheckHipSTRFilters = _caller_check('hipstr', '101-151')
+CheckLongTRFilters = _caller_check('longtr', '153-198')
+CheckGangSTRFilters = _caller_check('gangstr', '200-263')
+CheckAdVNTRFilters = _caller_check('advntr', '265-310')
+CheckEHFilters = _caller_check('eh', '312-357')
+CheckPopSTRFilters = _caller_check('popstr', '359-394')
+
+
 def CheckFilters(format_fields, args, vcftype, is_beagle):
     """Validate the user's filters against the VCF's caller (dumpSTR.py:396-521)."""
     if not CheckLocusFilters(args, vcftype, is_beagle):
@@ -380,6 +398,72 @@ def _null_filtered(vcfrecord, filtered, ploidy):
         else:
             raise ValueError("Found an unexpected format dtype for format field " + field)
         vcfrecord.set_format(field, vals)
+
+
+def ApplyCallFilters(record, call_filters, sample_info, sample_names):
+    """The reference's per-record entry (dumpSTR.py:613-774) with its arguments, side effects and return value: the
+    FORMAT/FILTER text of every sample is set on ``record.vcfrecord``, ``sample_info`` (filter name -> int[S],
+    'numcalls', 'totaldp') is updated, filtered calls lose their genotype and every other FORMAT value, and a TRRecord
+    over the modified variant comes back.  main() does not call it -- a batch of records is one pass of the
+    call-filter kernel (_Run) -- but the decisions here come from that same kernel: the record is a one-locus batch."""
+    from .. import runtime
+    hb = pack_records([record])
+    planes = _Planes([record], call_filters)
+    specs = [f.spec(planes.index) for f in call_filters]
+    nothing = dict(min_callrate=None, min_hwep=None, min_het=None, max_het=None, use_length=False, n_extern=0,
+                   extern_bits=None)
+    ch, _, _, _ = runtime.get_compute().dumpstr_batch(hb, planes.arrays, specs, planes.dp_plane, nothing)
+    if ch.error[0]:
+        bad = np.zeros(record.GetNumSamples(), dtype=bool)
+        bad[int(ch.error[2])] = True
+        raise ValueError("The following samples have calls but negative DP values at chromosome {} pos {}: {}"
+                         .format(record.chrom, record.pos, str(np.asarray(sample_names)[bad])))
+    sample_info['numcalls'] += ch.sample_counters[0]
+    for k, f in enumerate(call_filters):
+        sample_info[f.name] += ch.sample_counters[1 + k]
+    if planes.dp_plane >= 0:
+        sample_info['totaldp'] += ch.totaldp
+        sample_info['totaldp'][ch.dp_missing > 0] = np.nan
+    else:
+        sample_info['totaldp'][:] = np.nan
+    v, mrow = record.vcfrecord, ch.mask[0]
+    vals = [_filter_values(f, planes, hb, 0) if np.any((mrow >> np.uint32(k)) & 1) else None
+            for k, f in enumerate(call_filters)]
+    v.set_format('FILTER', vcfio.CallFilterColumn(mrow, [f.name for f in call_filters], vals))
+    filtered = ((mrow & np.uint32(0x7fffffff)) != 0) & ((mrow & np.uint32(L.TRK_MASK_NOCALL)) == 0)
+    if not np.any(filtered):
+        return record
+    _null_filtered(v, filtered, record.GetMaxPloidy())
+    # a record of its own over the modified variant; alleles that were given by length stay so (dumpSTR.py:748-773)
+    by_len_alt, by_len_ref = record.HasFabricatedAltAlleles(), record.HasFabricatedRefAllele()
+    return trh.TRRecord(v, None if by_len_ref else record.ref_allele, None if by_len_alt else record.alt_alleles,
+                        record.motif, record.record_id, record.quality_field, harmonized_pos=record.pos,
+                        full_alleles=record.full_alleles,
+                        ref_allele_length=record.ref_allele_length if by_len_ref else None,
+                        alt_allele_lengths=record.alt_allele_lengths if by_len_alt else None,
+                        quality_score_transform=record.quality_score_transform)
+
+
+def ApplyLocusFilters(record, locus_filters, loc_info, drop_filtered):
+    """The reference's per-record entry (dumpSTR.py:917-973): every filter is asked about the record, ``loc_info``
+    counts the ones that fire (and 'NO_CALLS_REMAINING', 'PASS', 'totalcalls'), the variant's FILTER column is set
+    unless filtered records are dropped; True when the locus is filtered.  ``record`` is a TRRecord (statistics from the
+    device) or anything that offers the methods the filters read."""
+    fired = []
+    for filt in locus_filters:
+        if filt(record) is not None:
+            loc_info[filt.filter_name()] += 1
+            fired.append(filt.filter_name())
+    n_called = np.sum(record.GetCalledSamples())
+    if n_called == 0:
+        loc_info['NO_CALLS_REMAINING'] += 1
+        fired.append('NO_CALLS_REMAINING')
+    if not drop_filtered:
+        record.vcfrecord.FILTER = ';'.join(fired) if fired else 'PASS'
+    if not fired:
+        loc_info['PASS'] += 1
+        loc_info['totalcalls'] += n_called
+    return bool(fired)
 
 
 class _Run:

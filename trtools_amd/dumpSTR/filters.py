@@ -44,7 +44,17 @@ def _record_stats(record):
     return st.locus_int[0, 0], st.locus_f64[0, 0]
 
 
+def _on_device(record):
+    """A TRRecord of this package has its statistics on the device; anything else that merely offers the TRRecord methods
+    a filter reads (the duck-typed records of the reference's own filter tests, dumpSTR/tests/test_filters.py:68-84) is
+    asked through those methods, as the reference's filters ask (filters.py:96-100, 138-142, 179-183)."""
+    return hasattr(record, '_device_stats')
+
+
 def _hwep_of(record, uselength):
+    if not _on_device(record):
+        return utils.GetHardyWeinbergBinomialTest(record.GetAlleleFreqs(uselength=uselength),
+                                                  record.GetGenotypeCounts(uselength=uselength))
     I, F = _record_stats(record)
     status = I[L.LI_HWE_STATUS_LEN if uselength else L.LI_HWE_STATUS_STR]
     if status == L.HWE_VALUE_ERROR:
@@ -52,6 +62,13 @@ def _hwep_of(record, uselength):
     if status == L.HWE_INDEX_ERROR:
         raise IndexError("tuple index out of range")
     return F[L.LF_HWEP_LEN if uselength else L.LF_HWEP_STR]
+
+
+def _het_of(record, uselength):
+    if not _on_device(record):
+        return utils.GetHeterozygosity(record.GetAlleleFreqs(uselength=uselength))
+    _, F = _record_stats(record)
+    return F[L.LF_HET_LEN if uselength else L.LF_HET_STR]
 
 
 class Filter_MinLocusCallrate(FilterBase):
@@ -97,8 +114,7 @@ class Filter_MinLocusHet(FilterBase):
         self.uselength = uselength
 
     def __call__(self, record):
-        _, F = _record_stats(record)
-        het = F[L.LF_HET_LEN if self.uselength else L.LF_HET_STR]
+        het = _het_of(record, self.uselength)
         return het if het < self.threshold else None
 
     def filter_name(self):
@@ -115,8 +131,7 @@ class Filter_MaxLocusHet(FilterBase):
         self.uselength = uselength
 
     def __call__(self, record):
-        _, F = _record_stats(record)
-        het = F[L.LF_HET_LEN if self.uselength else L.LF_HET_STR]
+        het = _het_of(record, self.uselength)
         return het if het > self.threshold else None
 
     def filter_name(self):

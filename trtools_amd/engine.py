@@ -123,7 +123,8 @@ class DeviceArray:
         late = getattr(self, '_late', None)
         if self._holds == 0 and late is not None:
             self._late = None
-            if self.eng.ctx is not None and not self.eng._pool_give(self.cap, late):
+            # (as free(): a plane of the reserved pair goes back to the context, never into the buffer pool)
+            if self.eng.ctx is not None and (getattr(self, '_reserved', False) or not self.eng._pool_give(self.cap, late)):
                 self.eng.lib.trk_dev_free(self.eng.ctx, late)
 
 
@@ -354,7 +355,9 @@ class Engine:
             info = L.PairInfo()
             nbytes = int(float(reserve_pair_gb) * (1 << 30))
             if self.lib.trk_reserve_pair(self.ctx, nbytes, C.byref(info)) == 0:    # (out of memory: no reservation)
-                self.reserved_pair_bytes = nbytes
+                # (planes large enough to be probed are kept only when the pair is fast: one that would never be lent
+                # is given back by trk_reserve_pair itself)
+                self.reserved_pair_bytes = nbytes if (info.placed or nbytes < (1 << 28)) else 0
                 Engine.last_reservation = dict(probe_ms=[round(float(info.probe_ms[k]), 3) for k in range(info.n_probed)],
                                                kept_ms=round(float(info.kept_ms), 3), fast=bool(info.placed),
                                                seconds=round(float(info.seconds), 4), plane_bytes=nbytes)

@@ -33,6 +33,91 @@ def GetHeader(header, sample_prefixes):
     return [header + "-" + sp for sp in sample_prefixes]
 
 
+# ---- the reference's per-record statistic functions (statSTR.py:31-80, 104-426) -----------------------------------------
+# main() never calls them -- a batch of loci and every sample group is one kernel pass (_flush) -- but they are part of
+# the module's surface: ``statSTR.GetHet(trrecord, sample_indexes=[...], uselength=...)`` answers for ONE record, one
+# value per entry of ``sample_indexes`` (None: every sample).  Each is the reference's composition of TRRecord methods
+# and utils functions; the record's histogram comes from the device (TRRecord._device_stats: a one-locus batch).
+MAXPLOTS = 10
+
+
+def _per_group(sample_indexes, fn):
+    return [fn(si) for si in sample_indexes]
+
+
+def PlotAlleleFreqs(trrecord, outprefix, sample_indexes=[None], sampleprefixes=None):
+    """statSTR.py:31-80."""
+    from . import plots
+    if sample_indexes == [None]:
+        sampleprefixes = ["sample"]
+    plots.PlotAlleleFreqs(trrecord, outprefix, sample_indexes=sample_indexes, sampleprefixes=sampleprefixes)
+
+
+def GetThresh(trrecord, sample_indexes=[None]):
+    """Largest called allele length per sample group, nan without calls (statSTR.py:104-127)."""
+    return _per_group(sample_indexes, lambda si: trrecord.GetMaxAllele(sample_index=si))
+
+
+def GetAFreq(trrecord, sample_indexes=[None], count=False, uselength=True):
+    """'allele:freq,...' (three decimals) or 'allele:count,...' per sample group, alleles ascending; '.' for a group
+    without calls (statSTR.py:129-173)."""
+    def one(si):
+        table = (trrecord.GetAlleleCounts if count else trrecord.GetAlleleFreqs)(uselength=uselength, sample_index=si)
+        if not table:
+            return "."
+        item = "%s:%i" if count else "%s:%.3f"
+        return ",".join(item % (allele, table[allele]) for allele in sorted(table))
+    return _per_group(sample_indexes, one)
+
+
+def GetNAlleles(trrecord, sample_indexes=[None], nalleles_thresh=0.01, uselength=True):
+    """Alleles whose frequency reaches ``nalleles_thresh`` (statSTR.py:175-209)."""
+    def one(si):
+        freqs = trrecord.GetAlleleFreqs(uselength=uselength, sample_index=si)
+        return sum(1 for f in freqs.values() if f >= nalleles_thresh)
+    return _per_group(sample_indexes, one)
+
+
+def GetHWEP(trrecord, sample_indexes=[None], uselength=True):
+    """Two-sided binomial test of the homozygote count against Hardy-Weinberg expectation (statSTR.py:211-252)."""
+    def one(si):
+        return utils.GetHardyWeinbergBinomialTest(trrecord.GetAlleleFreqs(sample_index=si, uselength=uselength),
+                                                  trrecord.GetGenotypeCounts(sample_index=si, uselength=uselength))
+    return _per_group(sample_indexes, one)
+
+
+def GetHet(trrecord, sample_indexes=[None], uselength=True):
+    """1 - sum p^2 (statSTR.py:254-291)."""
+    return _per_group(sample_indexes, lambda si: utils.GetHeterozygosity(
+        trrecord.GetAlleleFreqs(sample_index=si, uselength=uselength)))
+
+
+def GetEntropy(trrecord, sample_indexes=[None], uselength=True):
+    """Bit entropy of the allele distribution (statSTR.py:293-332)."""
+    return _per_group(sample_indexes, lambda si: utils.GetEntropy(
+        trrecord.GetAlleleFreqs(sample_index=si, uselength=uselength)))
+
+
+def GetMean(trrecord, sample_indexes=[None], uselength=True):
+    """Mean allele length -- by length whatever ``uselength`` says, as the reference (statSTR.py:334-358)."""
+    return _per_group(sample_indexes, lambda si: utils.GetMean(trrecord.GetAlleleFreqs(sample_index=si, uselength=True)))
+
+
+def GetMode(trrecord, sample_indexes=[None], uselength=True):
+    """statSTR.py:360-383."""
+    return _per_group(sample_indexes, lambda si: utils.GetMode(trrecord.GetAlleleFreqs(sample_index=si, uselength=True)))
+
+
+def GetVariance(trrecord, sample_indexes=[None], uselength=True):
+    """statSTR.py:385-409."""
+    return _per_group(sample_indexes, lambda si: utils.GetVariance(trrecord.GetAlleleFreqs(sample_index=si, uselength=True)))
+
+
+def GetNumSamples(trrecord, sample_indexes=[None]):
+    """Samples with a full genotype: the genotype counts summed (statSTR.py:411-431)."""
+    return _per_group(sample_indexes, lambda si: sum(trrecord.GetGenotypeCounts(sample_index=si).values()))
+
+
 def format_nan_precision(precision_format, val):
     """statSTR.py:490-494."""
     if np.isnan(val):
