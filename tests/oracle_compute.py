@@ -61,6 +61,13 @@ def _eval_filter(f, planes, l, g):
     pa = planes[f['plane_a']][l]
     pa = pa.reshape(pa.shape[0], -1)
     ca = f.get('col_a', 0)
+    # what trk_call_filters refuses (TRK_ERR_ARG "col_a out of range"), the stand-in refuses too: a plane narrower than
+    # the columns a filter names must not pass on the CPU and fail on the device
+    for key, plane_key in (('col_a', 'plane_a'), ('col_a2', 'plane_a'), ('col_b', 'plane_b')):
+        if key in f and f.get(plane_key, -1) >= 0:
+            width = int(np.prod(planes[f[plane_key]].shape[2:], dtype=np.int64)) if planes[f[plane_key]].ndim > 2 else 1
+            if not 0 <= f[key] < width:
+                raise ValueError("filter spec: %s = %d out of range for a plane of %d columns" % (key, f[key], width))
     thr = f.get('thr', 0.0)
     if pa.dtype == np.int32 and float(thr) == int(thr):
         thr = int(thr)
@@ -97,6 +104,8 @@ def _eval_filter(f, planes, l, g):
         out[np.nonzero(called)[0][hit]] = v[hit]
         return out
     if op == L.F_CALLED_OUTSIDE_CI:
+        if pb.shape[1] != 2 * pa.shape[1]:       # (trk_call_filters: "REPCI plane needs 2 columns per REPCN column")
+            raise ValueError("filter spec: a REPCI plane of %d columns for a REPCN plane of %d" % (pb.shape[1], pa.shape[1]))
         cis = np.array(['%d-%d,%d-%d' % tuple(r[:4]) for r in pb])
         return orc.filt_gangstr_bad_ci(g, pa, cis)
     if op == L.F_AD_SUPPORT_LT:

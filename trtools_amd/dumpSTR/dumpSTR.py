@@ -306,6 +306,7 @@ def _tick(phase, seconds):
 
 class _Planes:
     """FORMAT planes a set of call filters needs, stacked over a batch of records."""
+    MIN_WIDTH = {'QEXP': 3, 'REPCN': 2, '__repci': 4, '__rc': 4}      # columns the GangSTR filters index (filters.py:573-757)
 
     def __init__(self, records, call_filters, want_dp=True):
         self.keys, builders = [], {}
@@ -331,11 +332,22 @@ class _Planes:
             per = [a.reshape(a.shape[0], -1) for a in per]
             kind = per[0].dtype.kind if per else 'i'
             if kind == 'f':
-                self.arrays.append(stack_plane([a.astype(np.float32) for a in per], np.float32))
+                plane = stack_plane([a.astype(np.float32) for a in per], np.float32)
             elif kind in 'iu':
-                self.arrays.append(stack_plane([a.astype(np.int32) for a in per], np.int32))
+                plane = stack_plane([a.astype(np.int32) for a in per], np.int32)
             else:
                 raise ValueError("Found an unexpected format dtype for format field " + k)
+            # a record without a single call carries ONE missing value per sample whatever the field's Number (htslib,
+            # cyvcf2, vcfio alike); the reference's filters return before they index such an array (filters.py:598-600).
+            # A batch of nothing but such records -- the per-record API's one-record batches -- still gets a plane of the
+            # field's width: missing values in the columns the filters name
+            need = self.MIN_WIDTH.get(k, 1)
+            if plane.shape[2] < need:
+                wide = np.full(plane.shape[:2] + (need,), np.nan if plane.dtype.kind == 'f' else _NOCALL_INT_FORMAT_VAL,
+                               dtype=plane.dtype)
+                wide[:, :, :plane.shape[2]] = plane
+                plane = wide
+            self.arrays.append(plane)
 
     def get(self, key):
         return self.arrays[self.index[key]]
