@@ -367,6 +367,19 @@ int64_t trk_vcf_dumpstr_records(const trk_vcf_batch* b, const trk_vcf_dumpstr2* 
 /* records written so far by this process: without decoding / through the decode path / with a caller-built head */
 void trk_vcf_dumpstr_stats(int64_t* fast, int64_t* decoded, int64_t* caller_heads);
 
+/* ---- BGZF output (round 6): dumpSTR --zip, reference dumpSTR.py:1241-1245 + 1347-1352 (`bgzip -f`, then `tabix`) ----
+ * n bytes of text as consecutive BGZF members of at most 0xff00 bytes of text each (SAM specification section 4.1: gzip
+ * members with the 'BC' extra field; every member is a DEFLATE stream of its own, CRC-32 and ISIZE behind it), compressed on
+ * the caller-side worker pool (n_threads <= 0: the FMT_THREADS default) by libdeflate where the image has it, zlib else.
+ * level 1 ... 9 (0: stored members).  No end-of-file member is written: the caller appends it when the file ends
+ * (trk_bgzf_eof).  The members of [data, data + n) depend on the text and the level alone -- not on the thread count, not on
+ * how a stream was cut into calls as long as every call but the last hands over a multiple of 0xff00 bytes.
+ * Returns 0 and *out_bytes; 1: out_cap below trk_bgzf_bound(n); 2: the compressor failed. */
+size_t trk_bgzf_bound(size_t n);
+int trk_bgzf_compress(const void* data, size_t n, int level, int n_threads, void* out, size_t out_cap, size_t* out_bytes);
+/* the 28-byte end-of-file member; returns its length */
+size_t trk_bgzf_eof(void* out28);
+
 #ifdef __cplusplus
 }
 #endif

@@ -122,6 +122,70 @@ def test_dumpstr_zip_writes_an_index(tmp_path):
     idx = tabix.TabixIndex.load(out + '.tbi')
     n = sum(1 for s, e, l in tabix._lines(out) if l and l[:1] != b'#')
     assert sum(idx.bins[r][tabix.META_BIN][1][0] for r in range(len(idx.names))) == n > 0
+    # round 6: the index comes from the places the writer noted while it wrote (VCFWriter.write_index) -- it must be the
+    # index a scan of the finished file gives
+    scan = tabix.build(out, str(tmp_path / 'scan.tbi'))
+    assert (idx.names, idx.bins, idx.linear, idx.meta) == (scan.names, scan.bins, scan.linear, scan.meta)
+
+
+@pytest.mark.parametrize('native', [True, False])
+def test_writer_index_equals_the_scan_of_the_file(tmp_path, native):
+    """VCFWriter (--zip) notes where its records lie and writes the .tbi itself: records written one by one, as text and as
+    blocks of bytes on the writer thread; lines longer than a BGZF member, a line that ends with its member, several
+    contigs -- against tabix.build's scan of the finished file, with libtrk's members and with the interpreter's."""
+    from trtools_amd import bgzf, tabix, vcfio
+    os.environ['TRK_BGZF_PYTHON'] = '0' if native else '1'
+    bgzf._native = False
+    try:
+        rng = np.random.default_rng(5)
+        hdr = ['##fileformat=VCFv4.2', '##FORMAT=<ID=GT,Number=1,Type=String,Description="g">',
+               '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t' + '\t'.join('s%d' % i for i in range(30000))]
+
+        class _Tmpl:
+            _header_lines, _chrom_line = hdr[:-1], hdr[-1]
+            has_pass_filter, contigs_seen = True, []
+        recs, pos = [], 100
+        for chrom in ('chr1', 'chr2', 'chrX'):
+            for i in range(60):
+                pos += int(rng.integers(1, 40000))
+                nsamp = int(rng.choice([3, 50, 30000]))
+                ref = 'AC' * int(rng.integers(1, 30))
+                info = 'END=%d;PERIOD=2' % (pos + len(ref) + int(rng.integers(0, 50))) if rng.random() < 0.5 else '.'
+                recs.append('\t'.join([chrom, str(pos), '.', ref, 'ACAC', '.', '.', info, 'GT'] + ['0/1'] * nsamp) + '\n')
+            pos = 50
+        path = str(tmp_path / 'w.vcf.gz')
+        w = vcfio.VCFWriter(path, _Tmpl())
+        assert bool(w._fh._lib) == native
+        k = 0
+        while k < len(recs):
+            how, n = int(rng.integers(0, 3)), int(rng.integers(1, 25))
+            chunk = recs[k:k + n]
+            k += n
+            if how == 0:
+                for r in chunk:
+                    w.write_record(r)
+            elif how == 1:
+                w.write_text(''.join(chunk))
+            else:
+                w.write_bytes(''.join(chunk).encode())
+        w.close()
+        mine = w.write_index()
+        scan = tabix.build(path, str(tmp_path / 'scan.tbi'))
+        assert (mine.names, mine.bins, mine.linear) == (scan.names, scan.bins, scan.linear)
+        back = tabix.TabixIndex.load(path + '.tbi')
+        assert (back.names, back.bins, back.linear, back.meta) == (scan.names, scan.bins, scan.linear, scan.meta)
+        import gzip
+        assert gzip.open(path).read().decode().split('\n')[len(hdr):-1] == [r[:-1] for r in recs]
+        # unsorted records: what `tabix` refuses
+        w2 = vcfio.VCFWriter(str(tmp_path / 'u.vcf.gz'), _Tmpl())
+        w2.write_record(recs[5])
+        w2.write_record(recs[2])
+        w2.close()
+        with pytest.raises(ValueError):
+            w2.write_index()
+    finally:
+        del os.environ['TRK_BGZF_PYTHON']
+        bgzf._native = False
 
 
 def test_stale_index_falls_back_to_a_scan():

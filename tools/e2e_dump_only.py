@@ -8,6 +8,8 @@ old = sys.argv
 sys.argv = ['dumpSTR', '--vcf', path, '--out', '/tmp/e2e/dump', '--vcftype', 'hipstr',
             '--hipstr-min-call-DP', '10', '--hipstr-max-call-DP', '55', '--hipstr-min-call-Q', '0.9',
             '--min-locus-callrate', '0.8', '--min-locus-hwep', '0.001', '--min-locus-het', '0.05', '--max-locus-het', '0.9']
+if os.environ.get('E2E_ZIP'):          # round 6: --zip (libtrk's BGZF members, the index from the places the writer noted)
+    sys.argv.append('--zip')
 dargs = dumpSTR.getargs()
 sys.argv = old
 import glob
@@ -16,6 +18,8 @@ for i in range(3):
         os.remove(f)        # (truncating last run's 1.5 GB output is 0.15 s of open(): not the command line's time)
     t = time.time(); rc = dumpSTR.main(dargs); dt = time.time() - t
     print("run %d: %.3f s  phases %s" % (i, dt, {p: round(x, 3) for p, x in dumpSTR.LAST_RUN['seconds'].items()}), flush=True)
+    if os.environ.get('E2E_ZIP'):
+        print("   output %.0f MB + index %.0f KB" % (os.path.getsize('/tmp/e2e/dump.vcf.gz') / 1e6, os.path.getsize('/tmp/e2e/dump.vcf.gz.tbi') / 1e3), flush=True)
 if os.environ.get('E2E_FMT_TIMING'):
     from trtools_amd import _lib as _L
     _L.set_option('TRK_FMT_TIMING', 1)

@@ -1211,7 +1211,10 @@ def main(args):
         # the reference shells out to `tabix` (dumpSTR.py:1347-1352); the index is written here
         from .. import tabix
         try:
-            tabix.build(args.out + suffix)
+            if getattr(outvcf, '_recs', None) is not None:
+                outvcf.write_index()      # from the places the writer noted: the output is not read back
+            else:
+                tabix.build(args.out + suffix)
         except (OSError, ValueError) as e:
             common.WARNING("Tabix failed with returncode 1 (%s)" % e)
             return 1

@@ -174,56 +174,84 @@ def _lines(path):
         yield carry_voff, carry_voff, carry
 
 
-def build(vcf_gz_path, out_path=None):
-    """Write ``<vcf>.tbi`` for a position-sorted bgzipped VCF.  Returns the TabixIndex."""
-    names, runs, linear, stats = [], [], [], []
-    last = None          # (sequence index, begin) of the previous record
-    for start, after, line in _lines(vcf_gz_path):
-        if not line or line[:1] == b'#':
-            continue
-        f = line.split(b'\t', 8)
-        chrom = f[0].decode()
-        beg, end = vcf_interval([x.decode() for x in f[:8]])
-        if chrom not in names:
-            names.append(chrom)
-            runs.append([])       # [bin, first start, last end] of consecutive same-bin records
-            linear.append([])
-            stats.append([start, after, 0])
-        r = names.index(chrom)
+class TabixBuilder:
+    """The index of a position-sorted VCF from its records in file order: ``add`` takes a record's sequence, its 0-based
+    half-open interval and the virtual offsets of its line's first byte and of the byte behind its newline; ``finish``
+    returns the TabixIndex.  ``build`` feeds it from a file; a writer that knows where its lines lie feeds it as it
+    writes (vcfio.VCFWriter: dumpSTR --zip indexes its output without reading it back)."""
+
+    def __init__(self, what='the file'):
+        self.what = what
+        self.names, self.runs, self.linear, self.stats = [], [], [], []
+        self._of = {}
+        self._last = None          # (sequence index, begin) of the previous record
+
+    def add(self, chrom, beg, end, start, after):
+        r = self._of.get(chrom)
+        if r is None:
+            r = self._of[chrom] = len(self.names)
+            self.names.append(chrom)
+            self.runs.append([])       # [bin, first start, last end] of consecutive same-bin records
+            self.linear.append([])
+            self.stats.append([start, after, 0])
+        last = self._last
         if last is not None and (r < last[0] or (r == last[0] and beg < last[1])):
-            raise ValueError("%s is not sorted by position (record %s:%d)" % (vcf_gz_path, chrom, beg + 1))
-        last = (r, beg)
+            raise ValueError("%s is not sorted by position (record %s:%d)" % (self.what, chrom, beg + 1))
+        self._last = (r, beg)
         b = reg2bin(beg, end)
-        if runs[r] and runs[r][-1][0] == b:
-            runs[r][-1][2] = after
+        runs = self.runs[r]
+        if runs and runs[-1][0] == b:
+            runs[-1][2] = after
         else:
-            runs[r].append([b, start, after])
-        lin = linear[r]
+            runs.append([b, start, after])
+        lin = self.linear[r]
         for w in range(beg >> _SHIFT, ((end - 1) >> _SHIFT) + 1):
             while len(lin) <= w:
                 lin.append(0)
             if lin[w] == 0:
                 lin[w] = start
-        stats[r][1] = after
-        stats[r][2] += 1
-    bins = []
-    for r in range(len(names)):
-        by_bin = {}
-        for b, u, v in runs[r]:
-            chunks = by_bin.setdefault(b, [])
-            if chunks and chunks[-1][1] >> 16 >= u >> 16:   # continues in the same block: one chunk
-                chunks[-1][1] = v
-            else:
-                chunks.append([u, v])
-        by_bin = {b: [tuple(c) for c in chunks] for b, chunks in by_bin.items()}
-        by_bin[META_BIN] = [(stats[r][0], stats[r][1]), (stats[r][2], 0)]
-        bins.append(by_bin)
-        lin = linear[r]   # empty windows: leading ones take the first record's offset, the others
-        first = next((v for v in lin if v), 0)   # inherit the previous window (as htslib writes them)
-        for w in range(len(lin)):
-            if lin[w] == 0:
-                lin[w] = lin[w - 1] if w and lin[w - 1] else first
-    idx = TabixIndex(names, bins, linear, dict(format=2, col_seq=1, col_beg=2, col_end=0, meta=ord('#'), skip=0))
+        self.stats[r][1] = after
+        self.stats[r][2] += 1
+
+    def finish(self):
+        bins = []
+        for r in range(len(self.names)):
+            by_bin = {}
+            for b, u, v in self.runs[r]:
+                chunks = by_bin.setdefault(b, [])
+                if chunks and chunks[-1][1] >> 16 >= u >> 16:   # continues in the same block: one chunk
+                    chunks[-1][1] = v
+                else:
+                    chunks.append([u, v])
+            by_bin = {b: [tuple(c) for c in chunks] for b, chunks in by_bin.items()}
+            by_bin[META_BIN] = [(self.stats[r][0], self.stats[r][1]), (self.stats[r][2], 0)]
+            bins.append(by_bin)
+            lin = self.linear[r]   # empty windows: leading ones take the first record's offset, the others
+            first = next((v for v in lin if v), 0)   # inherit the previous window (as htslib writes them)
+            for w in range(len(lin)):
+                if lin[w] == 0:
+                    lin[w] = lin[w - 1] if w and lin[w - 1] else first
+        return TabixIndex(self.names, bins, self.linear,
+                          dict(format=2, col_seq=1, col_beg=2, col_end=0, meta=ord('#'), skip=0))
+
+
+def record_interval(line, limit=None):
+    """(sequence name, beg, end) of a VCF record given as bytes (its first eight columns are read, the sample columns
+    are not touched)."""
+    f = line.split(b'\t', 8) if limit is None else line[:limit].split(b'\t', 8)
+    beg, end = vcf_interval([x.decode() for x in f[:8]])
+    return f[0].decode(), beg, end
+
+
+def build(vcf_gz_path, out_path=None):
+    """Write ``<vcf>.tbi`` for a position-sorted bgzipped VCF.  Returns the TabixIndex."""
+    tb = TabixBuilder(vcf_gz_path)
+    for start, after, line in _lines(vcf_gz_path):
+        if not line or line[:1] == b'#':
+            continue
+        chrom, beg, end = record_interval(line)
+        tb.add(chrom, beg, end, start, after)
+    idx = tb.finish()
     write(idx, out_path or vcf_gz_path + '.tbi')
     return idx
 

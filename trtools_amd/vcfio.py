@@ -795,9 +795,15 @@ class VCFWriter:
         self._wrote_header = False
         self._pool = None        # one background thread for write_bytes (TRK_ASYNC_WRITE=0: none)
         self._pending = None
+        # --zip: the records' places in the text are noted as they are written -- (sequence, interval, first byte, byte
+        # behind the newline) -- and close() turns them into the tabix index (write_index): the reference runs `tabix`
+        # over the finished file (dumpSTR.py:1347-1352), rounds 1-5 read it back and inflated it once more in Python
+        self._recs = None
+        self.wrote_index = False
         if path.endswith('.gz'):
             from .bgzf import BgzfWriter
             self._fh = BgzfWriter(path)      # --zip output is real bgzip (dumpSTR.py:1241-1245)
+            self._recs = []
         else:
             self._fh = open(path, 'w')
 
@@ -818,17 +824,45 @@ class VCFWriter:
         self._fh.write('\n'.join(lines + [t._chrom_line]) + '\n')
         self._wrote_header = True
 
+    def _note(self, data, at):
+        """The record lines of ``data`` (bytes-like, whole lines), which will lie at byte ``at`` of the text."""
+        from .tabix import record_interval
+        recs, n, pos = self._recs, len(data), 0
+        find = data.find
+        while pos < n:
+            nl = find(b'\n', pos)
+            if nl < 0:
+                nl = n
+            if nl > pos and data[pos:pos + 1] != b'#':
+                # the first eight columns lie in front of the eighth tab: no copy of a 60 KB line for them
+                t = pos
+                for _ in range(8):
+                    t = find(b'\t', t, nl) + 1
+                    if t == 0:
+                        t = nl + 1
+                        break
+                chrom, beg, end = record_interval(bytes(data[pos:t - 1]))
+                recs.append((chrom, beg, end, at + pos, at + min(nl + 1, n)))
+            pos = nl + 1
+
     def write_record(self, variant):
         self._drain()
         if not self._wrote_header:
             self._header()
-        self._fh.write(str(variant))
+        text = str(variant)
+        if self._recs is not None:
+            text = text.encode()
+            self._note(text, self._fh.text_bytes)
+        self._fh.write(text)
 
     def write_text(self, text):
         """Already formatted record lines (merged shards of a multi-process run)."""
         self._drain()
         if not self._wrote_header:
             self._header()
+        if self._recs is not None:
+            text = text.encode() if isinstance(text, str) else text
+            self._note(text, self._fh.text_bytes)
         self._fh.write(text)
 
     def write_bytes(self, data):
@@ -844,7 +878,12 @@ class VCFWriter:
             self._fh.flush()
             job = lambda: raw.write(data)
         else:
-            job = lambda: self._fh.write(bytes(data))          # BgzfWriter takes bytes
+            block = data if isinstance(data, (bytes, bytearray)) else bytes(data)      # BgzfWriter takes bytes
+            at = self._fh.text_bytes
+
+            def job():
+                self._note(block, at)           # (on the writer thread, beside the caller's next batch)
+                self._fh.write(block)
         if _knobs.lab('TRK_WRITE_TIMING'):
             import sys
             import time
@@ -872,3 +911,16 @@ class VCFWriter:
         if not self._wrote_header:
             self._header()
         self._fh.close()
+
+    def write_index(self):
+        """``<path>.tbi`` from the places noted while writing (after close(); --zip only).  ValueError when the records
+        were not sorted by position -- what `tabix` refuses."""
+        from . import tabix
+        tb = tabix.TabixBuilder(self.path)
+        vo = self._fh.voffset
+        for chrom, beg, end, a, b in self._recs:
+            tb.add(chrom, beg, end, vo(a), vo(b))
+        idx = tb.finish()
+        tabix.write(idx, self.path + '.tbi')
+        self.wrote_index = True
+        return idx
