@@ -39,6 +39,10 @@ def check_case(name, tmp_path):
     out = str(tmp_path / 'a.tsv')
     log = run_cli(out, kw, 10, 15)
     assert 'samples in the VCF' in log and 'Done.' in log
+    from trtools_amd.associaTR import associaTR as at
+    # (round 6) GT-based runs go through the batch pipeline -- native reader, native batch harmoniser, one scan per batch,
+    # rows without an object per record; --beagle-dosages keeps the per-record loop
+    assert at.LAST_RUN['path'] == ('per-record' if kw.get('beagle_dosages') else 'batch'), at.LAST_RUN
     compare_tables(out, os.path.join(GOLD, name + '.precise.tsv'), rtol=1e-9)
     if plink:
         assert compare_to_plink(out, os.path.join(assoc_cases.DATA, plink), 'test_pheno', skip_filtered=skip) > 100
@@ -67,6 +71,22 @@ def test_cli_on_device(name, tmp_path):
     from trtools_amd import runtime
     runtime.set_compute(None)
     check_case(name, tmp_path)
+
+
+@pytest.mark.parametrize('name', ['hipstr_covars', 'multiallelic', 'region', 'sample_subset'])
+def test_per_record_loop_writes_the_batch_pipelines_table(name, tmp_path, oracle_compute):
+    """The two ways through perform_gwas -- record objects one by one (TRK_ASSOC_BATCH=0) and the batch pipeline -- write the
+    same bytes."""
+    from helpers import lab_env
+    from trtools_amd.associaTR import associaTR as at
+    kw, _, _ = assoc_cases.CASES[name]
+    a, b = str(tmp_path / 'a.tsv'), str(tmp_path / 'b.tsv')
+    run_cli(a, kw, 10, 15)
+    assert at.LAST_RUN['path'] == 'batch'
+    with lab_env(TRK_ASSOC_BATCH='0'):
+        run_cli(b, kw, 10, 15)
+    assert at.LAST_RUN['path'] == 'per-record'
+    assert open(a).read() == open(b).read() and open(a).read().count('\n') > 1
 
 
 def test_refused_options(tmp_path, oracle_compute):

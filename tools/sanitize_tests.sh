@@ -7,7 +7,7 @@ export TRK_LAB=1   # tools are lab runs: lab knobs are honoured (trtools_amd/_kn
 set -u
 cd "$(dirname "$0")/.."
 which=${1:-both}
-TESTS="tests/test_vcfnative.py tests/test_vcfnative_hook.py tests/test_vcfnative_fuzz.py tests/test_vcf_writer_native.py tests/test_vcf_shards.py tests/test_tabix.py tests/test_batch_pipelines.py tests/test_harmonizer_and_flags.py"
+TESTS="tests/test_vcfnative.py tests/test_vcfnative_hook.py tests/test_vcfnative_fuzz.py tests/test_vcf_writer_native.py tests/test_vcf_shards.py tests/test_tabix.py tests/test_batch_pipelines.py tests/test_harmonizer_and_flags.py tests/test_bgzf_native.py"
 rc=0
 run() {   # $1 = asan|tsan, $2 = runtime library name
   make -C trtools_amd/csrc "$1" || exit 2

@@ -171,47 +171,121 @@ def _dosage_details(rec, n, cs, ls):
     return allele_frequency, extra
 
 
-def _flush(records, outfile, vec, sample_filter, pheno_std, non_major_cutoff, beagle_dosages=False):
-    """One device batch -> output rows (associaTR.py:246-293)."""
-    if not records:
-        return
+class _Facts:
+    """What a row reads of a record: the harmonised position, the motif and the allele lengths (the batch pipeline builds
+    these from the native harmoniser's tables; a TRRecord offers the same attributes)."""
+    __slots__ = ('chrom', 'pos', 'motif', 'ref_allele_length', 'alt_allele_lengths')
+
+    def __init__(self, chrom, pos, motif, lens):
+        self.chrom, self.pos, self.motif = chrom, pos, motif
+        self.ref_allele_length, self.alt_allele_lengths = lens[0], lens[1:]
+
+
+# Memo tables of the row writer: the same few hundred allele lengths come back in every batch, and what the reference does
+# with one of them -- python's round on a python float, numpy's on a numpy scalar, numpy's text of a float64 -- is done
+# ONCE per distinct value, by the very call the per-record code makes (exact by construction), instead of per row.
+_py_round, _np_round, _np_text = {}, {}, {}
+
+
+def _rounded_py(x, precision):
+    key = (x, precision)
+    r = _py_round.get(key)
+    if r is None:
+        r = _py_round[key] = round(float(x), precision)
+    return r
+
+
+def _rounded_np(x, precision):
+    key = (x, precision)
+    r = _np_round.get(key)
+    if r is None:
+        r = _np_round[key] = round(np.float64(x), precision)
+    return r
+
+
+def _text_np(x):
+    t = _np_text.get(x)
+    if t is None:
+        t = _np_text[x] = str(np.array([x], dtype=np.float64).astype(str)[0])
+    return t
+
+
+_key_text = {}
+
+
+def _text_key(k):
+    """str() of a rounded-length key (a numpy scalar), once per distinct value."""
+    t = _key_text.get(k)
+    if t is None:
+        t = _key_text[k] = str(k)
+    return t
+
+
+def _gt_row_parts(rec, counts, lens):
+    """(alleles column, allele_frequency dict, detail columns) of a GT-mode row: what np.unique(rounded lengths).astype(str),
+    load_and_filter_genotypes.allele_frequency_from_counts and locus_details give for the record, without an array per
+    record (reference load_and_filter_genotypes.py:157-227 through the per-record functions of this package, which the
+    tests compare with this one)."""
     lf_mod = load_and_filter_genotypes
-    hb = pack_records(records)
-    if beagle_dosages:
-        from ..batch import stack_plane
-        ap1 = stack_plane([np.asarray(r.format['AP1'], dtype=np.float32) for r in records], np.float32)
-        ap2 = stack_plane([np.asarray(r.format['AP2'], dtype=np.float32) for r in records], np.float32)
-        res, class_sums, locus_sums, _ = runtime.get_compute().assoc_dosage_batch(
-            hb, vec, sample_filter, ap1, ap2, precision=lf_mod.allele_len_precision)
+    prec = lf_mod.allele_len_precision
+    alleles = ','.join(_text_np(v) for v in sorted({_rounded_py(x, prec) for x in lens}))
+    # GetAlleleFreqs by length (ascending keys) over the tested samples' counts, then clean_len_alleles
+    by_len = {}
+    for x, c in zip(lens, counts):
+        if c > 0:
+            by_len[x] = by_len.get(x, 0) + c
+    total = float(sum(by_len.values()))
+    freq = {}
+    for k in sorted(by_len):
+        nk = _rounded_np(k, prec)
+        v = by_len[k] / total
+        freq[nk] = freq[nk] + v if nk in freq else v
+    # dict_str of {rounded length: '{:.2g}' of its frequency}: keys ascending already, text of a key memoised; the general
+    # function (quotes, brackets, NaN rewritten) only when a value could need it
+    vals = ['{:.2g}'.format(val) for val in freq.values()]
+    if any('n' in v for v in vals):                      # (nan / inf: never for counted alleles)
+        afreq = lf_mod.dict_str(dict(zip(freq.keys(), vals)))
     else:
-        res = runtime.get_compute().assoc_batch(hb, vec, sample_filter, non_major_cutoff,
-                                                precision=lf_mod.allele_len_precision)
+        afreq = '{' + ', '.join(['"%s": "%s"' % (_text_key(k), v) for k, v in zip(freq.keys(), vals)]) + '}'
+    details = [rec.motif, str(len(rec.motif)), str(_rounded_py(rec.ref_allele_length, prec)), afreq]
+    return alleles, freq, details
+
+
+def _write_rows(outfile, recs, allele_off, allele_lens, res, pheno_std, non_major_cutoff, dosage=None):
+    """The output rows of one device batch (associaTR.py:246-293).  ``recs``: TRRecords or _Facts; ``dosage``:
+    (class_sums, locus_sums) of a --beagle-dosages batch."""
+    lf_mod = load_and_filter_genotypes
     fmt = "{:." + str(pval_precision) + "e}\t{}\t{}\t{}\t"
-    for l, rec in enumerate(records):
-        li, lf = res.locus_int[l], res.locus_f64[l]
-        o, e = int(hb.allele_off[l]), int(hb.allele_off[l + 1])
-        status = int(li[L.AI_STATUS])
-        if beagle_dosages:
-            n = int(li[L.AI_N_TESTED])
-            allele_frequency, extra = _dosage_details(rec, n, class_sums[o:e], locus_sums[l])
+    LI = res.locus_int
+    # python floats from here on: the same IEEE arithmetic and the same shortest-digits text as numpy scalars, without a
+    # numpy scalar object per number
+    LF = np.asarray(res.locus_f64, dtype=np.float64).tolist()
+    pheno_std = float(pheno_std)
+    status_col, ntest_col = LI[:, L.AI_STATUS].tolist(), LI[:, L.AI_N_TESTED].tolist()
+    counts_all = None if dosage is not None else res.allele_count.tolist()
+    offs = [int(x) for x in allele_off]
+    out = []
+    for l, rec in enumerate(recs):
+        o, e = offs[l], offs[l + 1]
+        status = status_col[l]
+        if dosage is not None:
+            n = ntest_col[l]
+            allele_frequency, extra = _dosage_details(rec, n, dosage[0][o:e], dosage[1][l])
             details = lf_mod.locus_details(rec, allele_frequency, extra)
             reason = lf_mod.filter_reason(allele_frequency, n, non_major_cutoff, True)
             if reason:                       # load_trs's filters come before the regression's own
                 status = -1
+            alleles = ','.join(list(np.unique(lf_mod.rounded_allele_lengths(rec)).astype(str)))
         else:
-            allele_frequency = lf_mod.allele_frequency_from_counts(res.allele_count[o:e], hb.allele_lens[l])
-            details = lf_mod.locus_details(rec, allele_frequency)
+            alleles, _, details = _gt_row_parts(rec, counts_all[o:e], allele_lens[l])
             reason = None
-        unique_alleles = np.unique(lf_mod.rounded_allele_lengths(rec))
-        outfile.write("{}\t{}\t{}\t{}\t".format(rec.chrom, rec.pos, ','.join(list(unique_alleles.astype(str))),
-                                                int(li[L.AI_N_TESTED])))
+        head = "{}\t{}\t{}\t{}\t".format(rec.chrom, rec.pos, alleles, ntest_col[l])
         if status == L.AS_OK:
+            lf = LF[l]
             std = lf[L.AF_GT_STD]
-            outfile.write('False\t')
-            outfile.write(fmt.format(lf[L.AF_PVAL], lf[L.AF_COEF] / std * pheno_std, lf[L.AF_SE] / std * pheno_std,
-                                     lf[L.AF_RSQUARED]))
-            outfile.write('\t'.join(details))
-            outfile.write('\n')
+            out.append(head + 'False\t' + fmt.format(lf[L.AF_PVAL], lf[L.AF_COEF] / std * pheno_std,
+                                                     lf[L.AF_SE] / std * pheno_std, lf[L.AF_RSQUARED]) +
+                       '\t'.join(details) + '\n')
         else:
             if status == -1:
                 pass
@@ -225,11 +299,141 @@ def _flush(records, outfile, vec, sample_filter, pheno_std, non_major_cutoff, be
                                  % (rec.chrom, rec.pos))
             else:
                 raise ValueError("locus %s:%s: genotype collinear with the covariates" % (rec.chrom, rec.pos))
-            outfile.write('{}\tnan\tnan\tnan\tnan\t'.format(reason))
-            outfile.write('\t'.join(details))
-            outfile.write('\n')
+            out.append(head + '{}\tnan\tnan\tnan\tnan\t'.format(reason) + '\t'.join(details) + '\n')
+    outfile.write(''.join(out))
     if hasattr(outfile, 'flush'):
         outfile.flush()
+
+
+def _flush(records, outfile, vec, sample_filter, pheno_std, non_major_cutoff, beagle_dosages=False):
+    """One device batch of record objects -> output rows."""
+    if not records:
+        return
+    lf_mod = load_and_filter_genotypes
+    hb = pack_records(records)
+    if beagle_dosages:
+        from ..batch import stack_plane
+        ap1 = stack_plane([np.asarray(r.format['AP1'], dtype=np.float32) for r in records], np.float32)
+        ap2 = stack_plane([np.asarray(r.format['AP2'], dtype=np.float32) for r in records], np.float32)
+        res, class_sums, locus_sums, _ = runtime.get_compute().assoc_dosage_batch(
+            hb, vec, sample_filter, ap1, ap2, precision=lf_mod.allele_len_precision)
+        _write_rows(outfile, records, hb.allele_off, hb.allele_lens, res, pheno_std, non_major_cutoff,
+                    dosage=(class_sums, locus_sums))
+    else:
+        res = runtime.get_compute().assoc_batch(hb, vec, sample_filter, non_major_cutoff,
+                                                precision=lf_mod.allele_len_precision)
+        _write_rows(outfile, records, hb.allele_off, hb.allele_lens, res, pheno_std, non_major_cutoff)
+
+
+# ---- the batch pipeline (round 6): native reader -> native batch harmoniser -> device scan -> rows, no object per record ----
+# what the last perform_gwas call ran through (the tests and tools/e2e_assoc_only.py read it): 'batch', 'mixed' (some
+# batches went through the record objects) or 'per-record'
+LAST_RUN = {}
+_MOTIF_KEY = {'gangstr': 'RU', 'advntr': 'RU', 'eh': 'RU', 'popstr': 'Motif'}
+
+
+def _batch_path_ok(reader, vcftype, region, beagle_dosages, period_check):
+    """GT-based runs over a file the native reader reads, of a caller the native harmoniser covers; --beagle-dosages (AP
+    planes per record) and the hidden PERIOD check keep the per-record loop.  TRK_ASSOC_BATCH=0 (lab) forces it."""
+    from .. import _knobs
+    from ..vcfnative import NativeVCFReader, VT_CODES
+    return (isinstance(reader, NativeVCFReader) and vcftype.name in VT_CODES and not beagle_dosages and not period_check and
+            len(reader.samples) > 0 and _knobs.lab('TRK_ASSOC_BATCH', '1') != '0')
+
+
+def _batch_motifs(rb, hz, vcftype):
+    """TRRecord.motif of every record of the batch, as the harmonisers derive it (utils/tr_harmonizer.py): HipSTR / LongTR
+    infer it from the trimmed reference allele -- sliced by the leading flank once more, as the reference does
+    (tr_harmonizer.py:397) -- and INFO/PERIOD; the other callers carry it in INFO."""
+    if vcftype.name in ('hipstr', 'longtr'):
+        lead = (hz.tr_pos - hz.pos).tolist()
+        per = hz.period.tolist()
+        return [utils.InferRepeatSequence(ref[ld:], p) for ref, ld, p in zip(hz.ref_keys(), lead, per)]
+    key = _MOTIF_KEY[vcftype.name] + '='
+    out = []
+    for l in range(rb.n):
+        info = rb.head_fields(l)[7]
+        val = next(item[len(key):] for item in info.split(';') if item.startswith(key))
+        out.append(val.upper())
+    return out
+
+
+def _run_batches(reader, vcftype, region, shard, vec, sample_filter, pheno_std, non_major_cutoff, batch_loci):
+    """perform_gwas_helper's loop (associaTR.py:246-293) a batch of records at a time.  Returns the number of loci."""
+    from .. import _knobs
+    from ..batch import HostBatch
+    from ..synth import assoc_tables_from_classes
+    compute = runtime.get_compute()
+    lf_mod = load_and_filter_genotypes
+    reader.use_buffers(getattr(compute, 'host_buffer', None), ring=2, release=getattr(compute, 'host_release', None))
+    # the sample columns are parsed on the device (trk_parse_samples) and, for whole-file runs, the BGZF members inflated
+    # there (statSTR's settings: the scan reads the genotype tensor where the parse kernel left it)
+    device_parse = (_knobs.env('TRK_DEVICE_PARSE', '1') == '1' and hasattr(reader, 'device_parse') and
+                    getattr(compute, 'eng', None) is not None and reader.device_parse(compute.eng))
+    LAST_RUN['device_parse'] = bool(device_parse)
+    LAST_RUN['device_inflate'] = bool(device_parse and not region and shard.world == 1 and
+                                      _knobs.env('TRK_DEVICE_INFLATE', _knobs.DEVICE_INFLATE_DEFAULT['statSTR']) == '1' and
+                                      hasattr(reader, 'device_inflate') and reader.device_inflate(compute.eng))
+    reader.read_ahead(_knobs.env('TRK_VCF_READ_AHEAD', '1') == '1')
+    region_start, region_done = None, False
+    if region is not None:
+        region_start = int(region.split(':')[1].split('-')[0]) if ':' in region else None
+        reader(region)
+    n_loci = 0
+    last_rb = None
+    while not region_done:
+        if last_rb is not None:
+            last_rb.release_device()
+        rb = last_rb = reader.read_raw_batch(batch_loci)
+        if rb.n == 0:
+            break
+        hz = rb.harmonize(vcftype.name)
+        keep = None
+        if region is not None:
+            keep, region_done = reader.region_keep(rb, hz)
+            if region_start is not None:
+                keep = keep & (hz.pos >= region_start)       # load_trs skips the records that start before the region
+            if not keep.any():
+                continue
+        LAST_RUN['batches'] += 1
+        if hz.n_python or (keep is not None and not keep.all()):
+            # something the native harmoniser does not cover, or a batch the region cuts: through the record objects
+            if hz.n_python:
+                LAST_RUN['fallback_batches'] += 1
+                LAST_RUN['path'] = 'mixed'
+            recs = [trh.HarmonizeRecord(vcftype, record) for l, record in enumerate(rb.records())
+                    if keep is None or keep[l]]
+            n_loci += len(recs)
+            if shard.next_batch():
+                _flush(recs, shard, vec, sample_filter, pheno_std, non_major_cutoff)
+                shard.end_batch()
+            continue
+        n_loci += rb.n
+        if not shard.next_batch():
+            continue
+        gt_in = rb.dev['gt'] if rb.dev is not None else rb.gt
+        hb = HostBatch.from_tables(gt_in, rb.locus_ploidy, hz.allele_off, hz.len_class, hz.str_class,
+                                   hz.len_class_value, lists=hz.lists)
+        tables = assoc_tables_from_classes(hz.allele_off, hz.allele_len, hz.len_class_value, hz.n_len_classes,
+                                           lf_mod.allele_len_precision)
+        if getattr(compute, 'eng', None) is not None:
+            res = compute.assoc_batch(hb, vec, sample_filter, non_major_cutoff, precision=lf_mod.allele_len_precision,
+                                      tables=tables)
+        else:                                     # (the tests' stand-in computes from the per-locus lists)
+            res = compute.assoc_batch(hb, vec, sample_filter, non_major_cutoff, precision=lf_mod.allele_len_precision)
+        if rb.dev is not None and gt_in is rb.dev['gt']:
+            rb.dev['gt'] = None               # (the batch built from it freed the tensor with its other arrays)
+            rb.release_device()
+        off = hz.allele_off.tolist()
+        alen = hz.allele_len.tolist()
+        chroms, poss, motifs = rb.chrom_column(), hz.tr_pos.tolist(), _batch_motifs(rb, hz, vcftype)
+        lens = [alen[off[l]:off[l + 1]] for l in range(rb.n)]
+        facts = [_Facts(chroms[l], poss[l], motifs[l], lens[l]) for l in range(rb.n)]
+        _write_rows(shard, facts, off, lens, res, pheno_std, non_major_cutoff)
+        shard.end_batch()
+    if last_rb is not None:
+        last_rb.release_device()
+    return n_loci
 
 
 def perform_gwas_helper(outfile, all_samples, record_iter, phenotype_name, trait_fnames, same_samples, sample_fname,
@@ -265,13 +469,21 @@ def perform_gwas_helper(outfile, all_samples, record_iter, phenotype_name, trait
             _flush(recs, shard, vec, sample_filter, pheno_std, non_major_cutoff, beagle_dosages)
             shard.end_batch()
 
-    for trrecord in record_iter:
-        records.append(trrecord)
-        n_loci += 1
-        if len(records) >= batch_loci:
-            emit(records)
-            records = []
-    emit(records)
+    batch = attach.get('batch') if attach is not None else None
+    LAST_RUN.clear()
+    LAST_RUN.update(path='batch' if batch else 'per-record', batches=0, fallback_batches=0)
+    if batch:
+        reader, vcftype, region = batch
+        shard.attach(reader, region)
+        n_loci = _run_batches(reader, vcftype, region, shard, vec, sample_filter, pheno_std, non_major_cutoff, batch_loci)
+    else:
+        for trrecord in record_iter:
+            records.append(trrecord)
+            n_loci += 1
+            if len(records) >= batch_loci:
+                emit(records)
+                records = []
+        emit(records)
     shard.finish()
     total_time = time.time() - start_time
     if n_loci > 0:
@@ -292,8 +504,13 @@ def perform_gwas(outfname, tr_vcf, phenotype_name, traits_fnames, vcftype, same_
         raise ValueError("could not open %s" % tr_vcf)
     all_samples = reader.samples
     attach = {}
-    record_iter = load_and_filter_genotypes.iter_records(
-        tr_vcf, region, vcftype, beagle_dosages, imputed_ukb_strs_paper_period_check, attach=attach)
+    inferred = trh.InferVCFType(reader, vcftype if vcftype else 'auto')
+    if _batch_path_ok(reader, inferred, region, beagle_dosages, imputed_ukb_strs_paper_period_check):
+        attach['batch'] = (reader, inferred, region)          # the batch pipeline reads `reader` itself
+        record_iter = None
+    else:
+        record_iter = load_and_filter_genotypes.iter_records(
+            tr_vcf, region, vcftype, beagle_dosages, imputed_ukb_strs_paper_period_check, attach=attach)
     from .. import dist
     rank = dist.get_comm()[0]
     temp = outfname + '.temp' if rank == 0 else outfname + '.rank%d.temp' % rank

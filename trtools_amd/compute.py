@@ -192,13 +192,14 @@ class DeviceCompute:
                    bits, counters, ext)
         return out
 
-    def assoc_batch(self, hb, vec, sample_in, non_major_cutoff, precision=2):
+    def assoc_batch(self, hb, vec, sample_in, non_major_cutoff, precision=2, tables=None):
         """associaTR scan of one batch (trk_assoc_scan): vec [M, S] float64 (outcome, covariates),
-        sample_in bool[S] or None.  Returns AssocHost."""
+        sample_in bool[S] or None; ``tables``: (allele_len, rlen_class) already made for the batch
+        (synth.assoc_tables_from_classes: the batch pipeline has no per-locus Python lists).  Returns AssocHost."""
         from .synth import pack_assoc_tables
         eng = self.eng
         b = self._upload(hb)
-        alen, rcls = pack_assoc_tables(hb.allele_lens, precision)
+        alen, rcls = tables if tables is not None else pack_assoc_tables(hb.allele_lens, precision)
         sin = None
         if sample_in is not None and not bool(np.all(sample_in)):
             sin = np.ascontiguousarray(sample_in, dtype=np.uint8)

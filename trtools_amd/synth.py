@@ -88,6 +88,29 @@ def pack_assoc_tables(allele_lens, precision=2):
     return alen, rcls
 
 
+def assoc_tables_from_classes(allele_off, allele_len, len_class_value, n_len_classes, precision=2):
+    """``pack_assoc_tables`` for a whole batch from the harmoniser's arrays, no Python loop over loci: allele_len [sumA] (by
+    allele index) as it is; rlen_class[allele_off[l] + c] = dense rank of ``round(np.float64(length of class c), precision)``
+    among locus l's distinct rounded lengths.  The classes of a locus ascend by length and rounding is monotone, so the
+    rounded values ascend too: the rank of class c is the number of changes of value before it."""
+    off = np.asarray(allele_off, dtype=np.int64)
+    sa = int(off[-1]) if len(off) else 0
+    rcls = np.zeros(sa, dtype=np.uint16)
+    if sa:
+        n = np.diff(off)
+        loc = np.repeat(np.arange(len(n)), n)
+        c = np.arange(sa) - off[loc]
+        valid = c < np.asarray(n_len_classes, dtype=np.int64)[loc]
+        rv = np.round(np.asarray(len_class_value, dtype=np.float64), precision)   # (== round(np.float64(v), precision))
+        new = np.ones(sa, dtype=bool)
+        new[1:] = (rv[1:] != rv[:-1]) | (loc[1:] != loc[:-1])
+        new &= valid
+        run = np.cumsum(new)
+        rank = run - run[off[loc]]          # the locus's first class is new: run[first] counts it
+        rcls[valid] = rank[valid].astype(np.uint16)
+    return np.ascontiguousarray(allele_len, dtype=np.float64).copy(), rcls
+
+
 def pack_dosage_tables(allele_lens, precision=2):
     """Per-locus length lists -> the per-allele tables of ``trk_assoc_dosage`` (include/trk.h):
     perm int32 (allele indices ordered by (class, index)), dclass uint16 (by allele index: rank of

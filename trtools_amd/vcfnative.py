@@ -81,6 +81,14 @@ class HarmonizedBatch:
         self.period = _np(hz.period, n, np.int32)
         self.tr_pos = _np(hz.tr_pos, n, np.int64)
         self.status = _np(hz.status, n, np.uint8)
+        self.n_len_classes = _np(hz.n_len_classes, n, np.int32)
+
+    def ref_keys(self):
+        """The harmonised (trimmed, upper-cased) reference allele of every record, as str."""
+        keys = C.string_at(self.struct.keys, int(self.key_off[-1])) if len(self.key_off) else b''
+        at = self.allele_off[:-1].astype(np.int64) + self.str_class[self.allele_off[:-1]] if self.n else np.zeros(0, np.int64)
+        lo, hi = self.key_off[at].tolist(), self.key_off[at + 1].tolist()
+        return [keys[a:b].decode() for a, b in zip(lo, hi)]
 
     def lists(self):
         """(allele_lens, allele_strs) per locus as Python lists (tests' oracle stand-in only)."""
