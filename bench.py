@@ -57,6 +57,7 @@ import json
 import os
 import sys
 import time
+import warnings
 
 import numpy as np
 
@@ -1011,6 +1012,49 @@ def end_to_end_extra(eng, seed):
             "workload": "dumpSTR (min/max call DP, min call Q; call rate, HWE, het low/high) on the same file, to an "
                         "output VCF of %.0f MB + sample and locus logs" % (os.path.getsize(os.path.join(tmp, 'dump.vcf')) / 1e6),
             "seconds": best, "loci_per_s": Lc / best, "calls_per_s": Lc * S / best, "path": dict(dumpSTR.LAST_RUN)}
+        # round 6: the same command line with --zip -- the output as BGZF members made by libtrk (trk_bgzf_compress) and the
+        # tabix index from the places the writer noted (rounds 1-5: zlib members on a thread pool of the interpreter and a
+        # scan of the finished file: 7.7 s)
+        zargs = argparse.Namespace(**vars(dargs))
+        zargs.zip, zargs.out = True, os.path.join(tmp, 'zdump')
+        best = None
+        for _ in range(2):
+            clear_outputs('zdump')
+            t0 = time.perf_counter()
+            rc = dumpSTR.main(zargs)
+            el = time.perf_counter() - t0
+            assert rc == 0
+            best = el if best is None else min(best, el)
+        out["dumpstr_cli_zip"] = {
+            "workload": "the same dumpSTR run with --zip: a bgzipped output VCF of %.0f MB + its .tbi"
+                        % (os.path.getsize(zargs.out + '.vcf.gz') / 1e6),
+            "seconds": best, "loci_per_s": Lc / best, "calls_per_s": Lc * S / best,
+            "index_bytes": os.path.getsize(zargs.out + '.vcf.gz.tbi')}
+        clear_outputs('zdump')
+        # round 6: associaTR's command line (BASELINE configs[4]'s caller) on the same file, one trait: the batch pipeline
+        # (native reader -> batch harmoniser -> device parse / inflate -> one scan per batch -> rows)
+        from trtools_amd.associaTR import associaTR
+        import contextlib
+        import io
+        tr_path = os.path.join(tmp, 'traits.npy')
+        np.save(tr_path, np.random.default_rng(5).normal(size=(S, 2)))
+        sys.argv = ['associaTR', os.path.join(tmp, 'assoc.tsv'), path, 'pheno', tr_path, '--same-samples', '--vcftype', 'hipstr']
+        try:
+            aargs = associaTR.getargs()
+        finally:
+            sys.argv = argv
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                associaTR.main(aargs)
+            el = time.perf_counter() - t0
+            best = el if best is None else min(best, el)
+        out["associatr_cli_text_vcf_to_table"] = {
+            "workload": "associaTR (one trait, no covariates) on the same file, to its table",
+            "seconds": best, "loci_per_s": Lc / best, "calls_per_s": Lc * S / best,
+            "rows": sum(1 for _ in open(os.path.join(tmp, 'assoc.tsv'))) - 1, "path": dict(associaTR.LAST_RUN)}
         # BASELINE configs[2] through text at reduced scale: a GangSTR-shape file (GT:DP:Q:REPCN:REPCI:RC:QEXP), the
         # nine GangSTR call filters + four locus filters, output VCF + logs
         Lg, Sg = 400, 2000
