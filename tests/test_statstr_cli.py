@@ -69,8 +69,17 @@ def test_golden_all_stats_gpu(tmp_path):
 
 @pytest.mark.gpu
 def test_golden_stratified_gpu(tmp_path):
+    """The reference's stratified table three ways: sample columns parsed on the device and counted by the grouped kernel
+    in file order (round 6, the default), and the host parse with / without the class-ordered columns."""
+    from helpers import lab_env
     from trtools_amd.compute import DeviceCompute
+    from trtools_amd.statSTR import statSTR
     _run(tmp_path, DeviceCompute(), 'many_samples_all_strat.tab', **_strat())
+    assert statSTR.LAST_RUN['device_parse'] and statSTR.LAST_RUN['path'] == 'batch'
+    for sort in ('1', '0'):
+        with lab_env(TRK_GROUPS_DEVICE_PARSE='0', TRK_CLASS_SORT=sort):
+            _run(tmp_path, DeviceCompute(), 'many_samples_all_strat.tab', **_strat())
+            assert not statSTR.LAST_RUN['device_parse']
 
 
 def test_bad_inputs_return_1(tmp_path):

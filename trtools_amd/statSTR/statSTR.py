@@ -387,7 +387,14 @@ def _run_batches(args, invcf, vcftype, group_masks, fmt, shard, batch_loci, star
     # (trk_vcf_set_sample_map) -- every class a column range the ungrouped count kernel streams, no gather on the
     # device, no per-call group look-ups (TRK_CLASS_SORT=0: the grouped kernel on file-order columns)
     layout = None
-    if (masks is not None and len(passes) == 1 and hasattr(invcf, 'set_sample_map') and
+    # (round 6) ... unless the sample columns are parsed on the device: with one pass of groups the grouped count kernel
+    # reads the tensor where the parse kernel left it, in file order (a command line's batches are a few thousand records
+    # -- launch latency either way -- and the host parse it replaces is most of the run: 0.17-0.18 -> 0.08 s per GB with two
+    # groups, tools/e2e_stat_groups.py); more than eight groups (several passes over one tensor) keep the host parse
+    groups_on_device = (masks is not None and len(passes) == 1 and _knobs.env('TRK_DEVICE_PARSE', '1') == '1' and
+                        hasattr(invcf, 'device_parse') and getattr(compute, 'eng', None) is not None and
+                        _knobs.lab('TRK_GROUPS_DEVICE_PARSE', '1') != '0')
+    if (masks is not None and len(passes) == 1 and not groups_on_device and hasattr(invcf, 'set_sample_map') and
             _knobs.lab('TRK_CLASS_SORT', '1') != '0' and getattr(compute, 'supports_class_layout', False)):
         from ..engine import class_layout
         layout = class_layout(passes[0][0], passes[0][1], row_align=32 if len(invcf.samples) >= 512 else 4)
@@ -397,8 +404,9 @@ def _run_batches(args, invcf, vcftype, group_masks, fmt, shard, batch_loci, star
     # The sample columns are parsed on the device (trk_parse_samples, round 4; TRK_DEVICE_PARSE=0: on the host): the reader
     # stops at the FORMAT keys, the batch's text goes over PCIe instead of the genotype tensor.  Ungrouped runs on the
     # device engine only.
-    device_parse = (masks is None and _knobs.env('TRK_DEVICE_PARSE', '1') == '1' and hasattr(invcf, 'device_parse') and
-                    getattr(compute, 'eng', None) is not None and invcf.device_parse(compute.eng))
+    device_parse = ((masks is None or groups_on_device) and _knobs.env('TRK_DEVICE_PARSE', '1') == '1' and
+                    hasattr(invcf, 'device_parse') and getattr(compute, 'eng', None) is not None and
+                    invcf.device_parse(compute.eng))
     LAST_RUN['device_parse'] = bool(device_parse)
     # ... and the file's BGZF members are inflated there too (trk_inflate_blocks, round 5; TRK_DEVICE_INFLATE=0: by the
     # reader's threads): the compressed bytes cross PCIe, the host sees the newlines and the heads of the lines.  Whole-file
