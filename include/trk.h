@@ -637,6 +637,19 @@ int trk_inflate_hook_async(trk_ctx* ctx, void** submit_fn, void** collect_fn);
 int trk_inflate_text(trk_ctx* ctx, uint64_t abs_from, int64_t n_bytes, void* dst, uint64_t release_before);
 int trk_inflate_stats(trk_ctx* ctx, uint64_t out[5]);
 
+/* ---- BGZF members DEFLATED on the device (round 6; the mirror of trk_inflate_blocks) -------------------------------------
+ * What it replaces: `bgzip -f` over dumpSTR's finished output (the reference shells out, dumpSTR.py:1241-1245, 1347-1352).
+ * n bytes of text in HOST memory (pinned or not) -> consecutive BGZF members of TRK_DEFLATE_MEMBER bytes of text each in host_out: the
+ * text goes up, one wave per member makes the member's DEFLATE stream (greedy LZ77 with one hash probe per position, one
+ * dynamic-Huffman block; a member that would not get smaller is stored), the members are laid out back to back on the device
+ * and come down in one copy; the CRC-32 of every member is computed on the host meanwhile (the text is there) and put in.
+ * Any stream that inflates to the text is a right answer: the bytes differ from trk_bgzf_compress's (libdeflate / zlib), the
+ * text they hold does not.  No end-of-file member (trk_bgzf_eof).  out_cap >= trk_deflate_bound(n).  Returns TRK_OK and
+ * *out_bytes; TRK_ERR_ARG: out_cap too small; one call per context at a time. */
+#define TRK_DEFLATE_MEMBER 16384      /* bytes of text per member trk_deflate_bgzf makes (bgzip's: 0xff00; any size <= 64 KB is BGZF) */
+size_t trk_deflate_bound(size_t n);
+int trk_deflate_bgzf(trk_ctx* ctx, const void* host_text, size_t n, void* host_out, size_t out_cap, size_t* out_bytes);
+
 /* ---- dumpSTR's sample columns written on the device (round 4; the host form is trk_vcf_dumpstr_records' span writer) ----
  * Per sample: a tab, then the token as it stands (+ ':.' per FORMAT key it lacks) + ':PASS' / ':NOCALL', or for a filtered
  * call the nulled token + ':' + '<filter>_<value>,...' (dumpSTR.py:648-683, 715-746).  A kept token is copied only when

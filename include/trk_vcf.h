@@ -379,6 +379,10 @@ size_t trk_bgzf_bound(size_t n);
 int trk_bgzf_compress(const void* data, size_t n, int level, int n_threads, void* out, size_t out_cap, size_t* out_bytes);
 /* the 28-byte end-of-file member; returns its length */
 size_t trk_bgzf_eof(void* out28);
+/* the offsets of the newlines of text[0 .. n), ascending, into out[0 .. cap) (memchr on the worker pool: a writer that notes
+ * where its records lie scans a 150 MB block in a couple of milliseconds); returns how many there are (more than cap: only
+ * the first cap were written) */
+int64_t trk_text_newlines(const void* text, size_t n, int64_t* out, size_t cap);
 
 #ifdef __cplusplus
 }

@@ -16,10 +16,14 @@ import glob
 for i in range(3):
     for f in glob.glob('/tmp/e2e/dump.*'):
         os.remove(f)        # (truncating last run's 1.5 GB output is 0.15 s of open(): not the command line's time)
+    import resource
+    r0 = resource.getrusage(resource.RUSAGE_SELF)
     t = time.time(); rc = dumpSTR.main(dargs); dt = time.time() - t
-    print("run %d: %.3f s  phases %s" % (i, dt, {p: round(x, 3) for p, x in dumpSTR.LAST_RUN['seconds'].items()}), flush=True)
+    r1 = resource.getrusage(resource.RUSAGE_SELF)
+    print("run %d: %.3f s  (CPU %.2f s)  phases %s" % (i, dt, (r1.ru_utime + r1.ru_stime) - (r0.ru_utime + r0.ru_stime),
+                                                     {p: round(x, 3) for p, x in dumpSTR.LAST_RUN['seconds'].items()}), flush=True)
     if os.environ.get('E2E_ZIP'):
-        print("   output %.0f MB + index %.0f KB" % (os.path.getsize('/tmp/e2e/dump.vcf.gz') / 1e6, os.path.getsize('/tmp/e2e/dump.vcf.gz.tbi') / 1e3), flush=True)
+        print("   output %.0f MB + index %.0f KB  (TRK_ZIP_LEVEL %s, TRK_DEVICE_DEFLATE %s)" % (os.path.getsize('/tmp/e2e/dump.vcf.gz') / 1e6, os.path.getsize('/tmp/e2e/dump.vcf.gz.tbi') / 1e3, os.environ.get('TRK_ZIP_LEVEL', '6'), os.environ.get('TRK_DEVICE_DEFLATE', '0')), flush=True)
 if os.environ.get('E2E_FMT_TIMING'):
     from trtools_amd import _lib as _L
     _L.set_option('TRK_FMT_TIMING', 1)

@@ -14,6 +14,8 @@ SUPPORTED settings -- the table in README.md ("Environment") -- are read with ``
     TRK_RESERVE_PAIR_GB   GiB per plane an Engine reserves for that pair at start-up (default 4 on >= 64 GB devices
                           for API engines, 0 for the command lines)
     TRK_POOL_GB           device memory the engine's buffer pool may hold (default 8)
+    TRK_ZIP_LEVEL         level of dumpSTR --zip's host compressor (libdeflate 1 ... 9, 0: stored; default 6)
+    TRK_DEVICE_DEFLATE    1: dumpSTR --zip's blocks are deflated on the GPU (trk_deflate_bgzf); default 0
 
 libtrk itself reads three of them with getenv -- TRK_VCF_THREADS, TRK_FMT_THREADS and TRK_VCF_BUF_CACHE_MB (megabytes of
 text buffers a process keeps for its next reader, default 4096, 0: none; read once, when the first reader opens) -- and
@@ -27,7 +29,8 @@ set it).  The library's own switches are options of include/trk_test.h (``_lib.s
 import os
 
 SUPPORTED = ('TRK_DEVICE', 'TRK_VCF_THREADS', 'TRK_FMT_THREADS', 'TRK_VCF_READ_AHEAD', 'TRK_DEVICE_INFLATE',
-             'TRK_DEVICE_PARSE', 'TRK_DEVICE_FORMAT', 'TRK_PLACE_OUTPUTS', 'TRK_RESERVE_PAIR_GB', 'TRK_POOL_GB')
+             'TRK_DEVICE_PARSE', 'TRK_DEVICE_FORMAT', 'TRK_PLACE_OUTPUTS', 'TRK_RESERVE_PAIR_GB', 'TRK_POOL_GB',
+             'TRK_ZIP_LEVEL', 'TRK_DEVICE_DEFLATE')
 
 
 # The command lines' defaults for TRK_DEVICE_INFLATE (profiles/r05_notes.md section 6, r05_e2e_cpu_seconds.txt; 1.02 GB):

@@ -193,7 +193,7 @@ EXPORTS = [
     'trk_locus_stats', 'trk_locus_finalize', 'trk_call_filters', 'trk_locus_filters',
     'trk_comm_unique_id', 'trk_comm_init', 'trk_allreduce_sum_i64', 'trk_allgather',
     'trk_binomtest_two_sided', 'trk_binom_pmf', 'trk_binomtest_batch', 'trk_synth_fill', 'trk_synth_fill_gangstr', 'trk_test_set_option', 'trk_test_get_option',
-    'trk_assoc_scan', 'trk_assoc_scan_dosage', 'trk_student_t_two_sided', 'trk_dosages', 'trk_qc_reduce', 'trk_parse_samples', 'trk_format_samples', 'trk_inflate_blocks', 'trk_inflate_hook', 'trk_inflate_hook_async', 'trk_inflate_text', 'trk_inflate_stats', 'trk_planarize', 'trk_pad_rows', 'trk_permute_columns', 'trk_stream_probe', 'trk_device_clocks', 'trk_stream_select', 'trk_stream_wait',
+    'trk_assoc_scan', 'trk_assoc_scan_dosage', 'trk_student_t_two_sided', 'trk_dosages', 'trk_qc_reduce', 'trk_parse_samples', 'trk_format_samples', 'trk_inflate_blocks', 'trk_inflate_hook', 'trk_inflate_hook_async', 'trk_inflate_text', 'trk_inflate_stats', 'trk_deflate_bgzf', 'trk_deflate_bound', 'trk_planarize', 'trk_pad_rows', 'trk_permute_columns', 'trk_stream_probe', 'trk_device_clocks', 'trk_stream_select', 'trk_stream_wait',
     'trk_host_alloc', 'trk_host_free', 'trk_memcpy_h2d_async', 'trk_memcpy_d2h_async', 'trk_queue_sync', 'trk_thread_queue', 'trk_exchange', 'trk_event_record', 'trk_event_wait',
 ]
 
@@ -205,7 +205,7 @@ class TrkError(RuntimeError):
 
 
 # the sources libtrk.so is built from, in the order csrc/Makefile hashes them
-_SOURCES = ['csrc/trk_api.hip', 'csrc/trk_assoc.hip', 'csrc/trk_binom.h', 'csrc/trk_hwe.hip', 'csrc/trk_inflate.hip', 'csrc/trk_internal.h', 'csrc/trk_kernels.hip',
+_SOURCES = ['csrc/trk_api.hip', 'csrc/trk_assoc.hip', 'csrc/trk_binom.h', 'csrc/trk_deflate.hip', 'csrc/trk_hwe.hip', 'csrc/trk_inflate.hip', 'csrc/trk_internal.h', 'csrc/trk_kernels.hip',
             'csrc/trk_parse.hip', 'csrc/trk_qc.hip', 'csrc/trk_student.h', 'csrc/trk_vcf.cpp', '../include/trk.h', '../include/trk_test.h', '../include/trk_vcf.h']
 
 
@@ -363,6 +363,9 @@ def load():
     lib.trk_inflate_text.argtypes = [vp, u64, i64, vp, u64]
     lib.trk_inflate_stats.argtypes = [vp, P(u64)]
     lib.trk_inflate_hook_async.argtypes = [vp, P(vp), P(vp)]
+    lib.trk_deflate_bound.argtypes = [C.c_size_t]
+    lib.trk_deflate_bound.restype = C.c_size_t
+    lib.trk_deflate_bgzf.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, P(C.c_size_t)]
     lib.trk_format_samples.argtypes = [vp, P(FormatIn), P(FormatOut), C.c_int]
     lib.trk_student_t_two_sided.argtypes = [dbl, dbl]
     lib.trk_student_t_two_sided.restype = dbl

@@ -13,6 +13,7 @@ import zlib
 
 _EOF = bytes.fromhex('1f8b08040000000000ff0600424302001b0003000000000000000000')
 BLOCK = 0xff00
+DEVICE_MEMBER = 16384     # bytes of text per member the device makes (include/trk.h: TRK_DEFLATE_MEMBER)
 
 
 def _compress_block(args):
@@ -48,6 +49,13 @@ def _native_lib():
     return _native
 
 
+def _address(data):
+    """(object that keeps the buffer alive, address of its first byte) of bytes / bytearray / a memoryview."""
+    import numpy as np
+    arr = np.frombuffer(data, dtype=np.uint8)
+    return arr, arr.ctypes.data
+
+
 class BgzfWriter:
     """``write`` collects text; whole members leave ``CHUNK`` bytes at a time -- one native call that compresses its
     members on the library's worker pool (ctypes drops the GIL), or ``BATCH`` zlib members on a thread pool of the
@@ -55,7 +63,11 @@ class BgzfWriter:
     BATCH = 64
     CHUNK = 256 * BLOCK            # ~16 MB of text per native call
 
-    def __init__(self, path, level=6, threads=None):
+    def __init__(self, path, level=6, threads=None, engine=None):
+        """``engine``: a device engine -- blocks of at least DEVICE_MIN bytes are deflated on the GPU (trk_deflate_bgzf:
+        the text goes up, the members come down; the host computes the CRCs), smaller writes and the stream's tail by the
+        host compressor.  The members hold 0xff00 bytes of text either way."""
+        self._engine = engine
         self._fh = open(path, 'wb')
         self._buf = bytearray()
         self._level = level
@@ -64,6 +76,8 @@ class BgzfWriter:
         self._lib = _native_lib()
         self._out = None           # the native path's output buffer, reused
         self._coff = [0]           # compressed offset of member k; the last entry: behind the members written so far
+        self._toff = [0]           # ... and the offset in the TEXT of its first byte (members need not be of one size:
+                                   # the device's hold DEVICE_MEMBER bytes, the host's BLOCK)
         self.text_bytes = 0        # bytes of text handed to write() so far
         n = threads if threads is not None else min(16, os.cpu_count() or 1)
         self._pool = None
@@ -79,30 +93,50 @@ class BgzfWriter:
         need = lib.trk_bgzf_bound(n)
         if self._out is None or len(self._out) < need:
             self._out = bytearray(need)
-        hold = (C.c_char * len(data)).from_buffer(data) if isinstance(data, bytearray) else C.c_char_p(data)
-        base = C.addressof(hold) if isinstance(data, bytearray) else C.cast(hold, C.c_void_p).value
+        hold, base = _address(data)
         dst = (C.c_char * len(self._out)).from_buffer(self._out)
         got = C.c_size_t(0)
         try:
             rc = lib.trk_bgzf_compress(C.c_void_p(base + at), n, int(self._level), int(self._threads or 0), dst,
                                        len(self._out), C.byref(got))
         finally:
-            del hold, dst          # (a bytearray cannot be resized while a ctypes view of it lives)
+            del hold, dst          # (a bytearray cannot be resized while a view of it lives)
         if rc != 0:
             raise OSError("trk_bgzf_compress failed (%d)" % rc)
-        out, end, pos, coff = self._out, got.value, 0, self._coff
-        base = coff[-1]
+        self._members(self._out, got.value, n, BLOCK)
+        self._fh.write(memoryview(self._out)[:got.value])
+
+    def _members(self, out, end, n_text, member):
+        """The members of out[0 : end) -- ``n_text`` bytes of text, ``member`` per member -- join the offset tables."""
+        pos, coff, toff = 0, self._coff, self._toff
+        base, tbase, k = coff[-1], toff[-1], 0
         while pos < end:           # the members' sizes (BSIZE at byte 16 of each): where member k + 1 begins
             pos += (out[pos + 16] | (out[pos + 17] << 8)) + 1
+            k += 1
             coff.append(base + pos)
-        self._fh.write(memoryview(out)[:end])
+            toff.append(tbase + min(k * member, n_text))
+
+    DEVICE_MIN = 8 << 20
+
+    def _device_emit(self, data, at, n):
+        """Members of data[at : at + n] made on the device (DEVICE_MEMBER bytes of text each)."""
+        hold, base = _address(data)
+        try:
+            out = self._engine.deflate_bgzf(None, address=base + at, nbytes=n)
+        finally:
+            del hold
+        self._members(out, len(out), n, DEVICE_MEMBER)
+        self._fh.write(out)
 
     def _emit_chunks(self, data, at, n):
+        if self._engine is not None and n >= self.DEVICE_MIN:      # (any length: a call's last member is as long as what is left)
+            self._device_emit(data, at, n)
+            return
         for o in range(0, n, self.CHUNK):
             self._native_emit(data, at + o, min(self.CHUNK, n - o))
 
     def _native_write(self, data):
-        if not isinstance(data, (bytes, bytearray)):
+        if not isinstance(data, (bytes, bytearray, memoryview)):
             data = bytes(data)
         if len(data) >= self.CHUNK:
             # a block of a batch writer (150 MB): what is kept of the text before it is topped up to whole members and
@@ -130,8 +164,9 @@ class BgzfWriter:
         a member is the START of the next one.  After close() only (every member has been written)."""
         if text_off >= self.text_bytes:
             return self._coff[-1] << 16
-        k, w = divmod(text_off, BLOCK)
-        return (self._coff[k] << 16) | w
+        import bisect
+        k = bisect.bisect_right(self._toff, text_off) - 1
+        return (self._coff[k] << 16) | (text_off - self._toff[k])
 
     def write(self, data):
         if isinstance(data, str):
@@ -154,9 +189,10 @@ class BgzfWriter:
         jobs = [(raw, self._level) for raw in self._pending]
         self._pending = []
         out = self._pool.map(_compress_block, jobs) if self._pool is not None else map(_compress_block, jobs)
-        for blk in out:
+        for blk, (raw, _) in zip(out, jobs):
             self._fh.write(blk)
             self._coff.append(self._coff[-1] + len(blk))
+            self._toff.append(self._toff[-1] + len(raw))
 
     def close(self):
         if self._lib is not None:

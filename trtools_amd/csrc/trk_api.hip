@@ -83,6 +83,16 @@ static thread_local int t_queue = -1;
 
 struct InflateState;
 static void inflate_state_free(InflateState* st);
+struct DeflateState {          // trk_deflate_bgzf's device buffers and pinned staging, grown on demand, kept for the next call
+    uint8_t* d_text = nullptr; size_t text_cap = 0;
+    uint8_t* d_slots = nullptr; size_t slots_cap = 0;
+    uint8_t* d_out = nullptr; size_t out_cap = 0;
+    uint8_t* d_tok = nullptr; size_t tok_cap = 0;
+    uint8_t* d_tab = nullptr; size_t tab_cap = 0;      // sizes (u32) + offsets (u64)
+    uint64_t* h_off = nullptr; size_t h_cap = 0;       // pinned
+    std::vector<uint32_t> crc;
+    hipStream_t q = nullptr;       // a queue of its own: the call comes from a writer thread beside the caller's kernels
+};
 
 struct trk_ctx {
     int device = 0;
@@ -119,6 +129,7 @@ struct trk_ctx {
     int rank = 0, n_ranks = 1;
     // the reserved pair of output planes (trk_reserve_pair): owned by the context, lent out by trk_dev_alloc_pair
     struct InflateState* inflate = nullptr;   // the reader's inflate hook served by this context (trk_inflate_hook)
+    DeflateState* deflate = nullptr;          // trk_deflate_bgzf
     void* res_plane[2] = {nullptr, nullptr};
     size_t res_bytes = 0;
     bool res_lent[2] = {false, false};
@@ -284,6 +295,14 @@ void trk_free(trk_ctx* ctx) {
     for (int k = 0; k < 2; ++k)
         if (ctx->res_plane[k]) (void)hipFree(ctx->res_plane[k]);
     if (ctx->inflate) inflate_state_free(ctx->inflate);
+    if (ctx->deflate) {
+        DeflateState* d = ctx->deflate;
+        for (uint8_t* p : {d->d_text, d->d_slots, d->d_out, d->d_tok, d->d_tab})
+            if (p) (void)hipFree(p);
+        if (d->h_off) (void)hipHostFree(d->h_off);
+        if (d->q) (void)hipStreamDestroy(d->q);
+        delete d;
+    }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < TRK_N_TIMERS; ++i) {
         (void)hipEventDestroy(ctx->t_start[i]);
@@ -1380,6 +1399,68 @@ int trk_inflate_stats(trk_ctx* ctx, uint64_t out[5]) {
         out[3] = ctx->inflate->n_comp;
         out[4] = ctx->inflate->n_calls;
     }
+    return TRK_OK;
+}
+
+// ---- BGZF members deflated on the device (include/trk.h) ----
+size_t trk_deflate_bound(size_t n) { return ((n + TRK_DEFLATE_MEMBER - 1) / TRK_DEFLATE_MEMBER + 1) * (size_t)(TRK_DEFLATE_MEMBER + 64 + 26); }
+
+int trk_deflate_bgzf(trk_ctx* ctx, const void* host_text, size_t n, void* host_out, size_t out_cap, size_t* out_bytes) {
+    if (!ctx) return TRK_ERR_ARG;
+    if (out_bytes) *out_bytes = 0;
+    if ((!host_text && n) || !host_out || !out_bytes) return fail(ctx, TRK_ERR_ARG, "deflate_bgzf: arguments");
+    if (out_cap < trk_deflate_bound(n)) return fail(ctx, TRK_ERR_ARG, "deflate_bgzf: out_cap below trk_deflate_bound(%zu)", n);
+    if (n == 0) return TRK_OK;
+    (void)hipSetDevice(ctx->device);
+    if (!ctx->deflate) ctx->deflate = new DeflateState();
+    DeflateState* d = ctx->deflate;
+    if (!d->q && hipStreamCreateWithFlags(&d->q, hipStreamNonBlocking) != hipSuccess) return fail(ctx, TRK_ERR_HIP, "deflate_bgzf: queue");
+    hipStream_t q = d->q;
+    const size_t nm = (n + TRK_DEFLATE_MEMBER - 1) / TRK_DEFLATE_MEMBER;
+    auto grow = [&](uint8_t*& p, size_t& cap, size_t need) {
+        if (cap >= need) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = need + need / 4 + 4096;
+        if (hipMalloc((void**)&p, want) != hipSuccess) { (void)hipGetLastError(); return false; }
+        cap = want;
+        return true;
+    };
+    const size_t tab_bytes = ((nm * 4 + 15) & ~(size_t)15) + (nm + 1) * 8;
+    if (!grow(d->d_text, d->text_cap, n + 512) || !grow(d->d_slots, d->slots_cap, nm * trk::deflate_slot_bytes()) ||
+        !grow(d->d_out, d->out_cap, nm * (trk::deflate_slot_bytes() + 26)) || !grow(d->d_tok, d->tok_cap, trk::deflate_tok_bytes(ctx->n_cu, (int)nm)) ||
+        !grow(d->d_tab, d->tab_cap, tab_bytes))
+        return fail(ctx, TRK_ERR_NOMEM, "deflate_bgzf: device buffers for %zu members", nm);
+    if (d->h_cap < (nm + 1) * 8) {
+        if (d->h_off) (void)hipHostFree(d->h_off);
+        d->h_off = nullptr;
+        d->h_cap = 0;
+        const size_t want = (nm + 1) * 8 * 2 + 4096;
+        if (hipHostMalloc((void**)&d->h_off, want, hipHostMallocDefault) != hipSuccess) return fail(ctx, TRK_ERR_NOMEM, "deflate_bgzf: staging");
+        d->h_cap = want;
+    }
+    uint32_t* d_sizes = reinterpret_cast<uint32_t*>(d->d_tab);
+    uint64_t* d_off = reinterpret_cast<uint64_t*>(d->d_tab + ((nm * 4 + 15) & ~(size_t)15));
+    HIPCHK(ctx, hipMemcpyAsync(d->d_text, host_text, n, hipMemcpyHostToDevice, q));
+    HIPCHK(ctx, trk::launch_deflate(d->d_text, (int64_t)n, d->d_slots, d_sizes, reinterpret_cast<uint16_t*>(d->d_tok), d_off, d->d_out,
+                                    ctx->n_cu, q));
+    HIPCHK(ctx, hipMemcpyAsync(d->h_off, d_off, (nm + 1) * 8, hipMemcpyDeviceToHost, q));
+    // the members' checksums while the device works (the text is the host's)
+    d->crc.resize(nm);
+    trk_member_crc32(host_text, n, TRK_DEFLATE_MEMBER, d->crc.data());
+    HIPCHK(ctx, hipStreamSynchronize(q));
+    const uint64_t total = d->h_off[nm];
+    if (total > out_cap) return fail(ctx, TRK_ERR_ARG, "deflate_bgzf: %llu bytes of members for a buffer of %zu", (unsigned long long)total, out_cap);
+    HIPCHK(ctx, hipMemcpyAsync(host_out, d->d_out, total, hipMemcpyDeviceToHost, q));
+    HIPCHK(ctx, hipStreamSynchronize(q));
+    unsigned char* o = static_cast<unsigned char*>(host_out);
+    for (size_t m = 0; m < nm; ++m) {
+        unsigned char* t = o + d->h_off[m + 1] - 8;
+        const uint32_t c = d->crc[m];
+        t[0] = (unsigned char)c; t[1] = (unsigned char)(c >> 8); t[2] = (unsigned char)(c >> 16); t[3] = (unsigned char)(c >> 24);
+    }
+    *out_bytes = (size_t)total;
     return TRK_OK;
 }
 

@@ -11,6 +11,9 @@
 
 // an option of include/trk_test.h (nullptr: unset); defined in trk_vcf.cpp, which the sanitizer builds recompile
 extern "C" __attribute__((visibility("hidden"))) const char* trk_opt(const char* name);
+// CRC-32 of every `member`-byte piece of text[0 .. n) on the caller-side worker pool (trk_vcf.cpp: libdeflate's where the
+// image has it, zlib's else): crc[m] for m < ceil(n / member)
+extern "C" __attribute__((visibility("hidden"))) void trk_member_crc32(const void* text, size_t n, size_t member, uint32_t* crc);
 
 namespace trk {
 // class_ws: device scratch of n_class_runs x (sumA + L x TRK_LI_COLS) int32 for the class passes of a batch whose
@@ -33,6 +36,10 @@ struct LineIndexWs {     // device results / scratch of launch_line_index (trk_i
     uint8_t* packed;     // the heads back to back
     uint32_t packed_cap;
 };
+size_t deflate_slot_bytes();
+size_t deflate_tok_bytes(int n_cu, int n_members);
+hipError_t launch_deflate(const uint8_t* text, int64_t n, uint8_t* slots, uint32_t* sizes, uint16_t* tok, uint64_t* off, uint8_t* out,
+                          int n_cu, hipStream_t stream);
 hipError_t launch_line_count(const uint8_t* text, int64_t n, const LineIndexWs& ws, hipStream_t stream);   // step 1: *ws.n_nl
 hipError_t launch_line_index(const uint8_t* text, int64_t n, int tabs_in, const LineIndexWs& ws, hipStream_t stream);
 hipError_t launch_permute_columns(const int16_t* src, int16_t* dst, const int32_t* col, int64_t n_loci, int n_src,

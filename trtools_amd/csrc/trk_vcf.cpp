@@ -3938,7 +3938,61 @@ size_t bgzf_member(const unsigned char* text, size_t n, int level, void* ld_comp
 }
 }  // namespace
 
+// the CRC-32 of every member of a text (trk_deflate_bgzf, trk_api.hip: the device makes the DEFLATE streams, the text's
+// checksums are computed here while it does)
+extern "C" __attribute__((visibility("hidden"))) void trk_member_crc32(const void* text, size_t n, size_t member, uint32_t* crc) {
+    const size_t nb = (n + member - 1) / member;
+    if (!nb) return;
+    const unsigned char* t = static_cast<const unsigned char*>(text);
+    const Deflater& d = deflater();
+    int want = default_threads(32);
+    if (const char* e = getenv("TRK_FMT_THREADS")) want = std::max(1, atoi(e));
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::min(want, 128), (nb + 15) / 16));
+    std::atomic<size_t> next{0};
+    const std::function<void()> job = [&]() {
+        for (;;) {
+            const size_t b0 = next.fetch_add(16);
+            if (b0 >= nb) break;
+            for (size_t b = b0; b < std::min(nb, b0 + 16); ++b) {
+                const size_t at = b * member, m = std::min(member, n - at);
+                crc[b] = d.c_crc32 ? d.c_crc32(0, t + at, m) : (uint32_t)crc32(crc32(0L, Z_NULL, 0), t + at, (uInt)m);
+            }
+        }
+    };
+    run_on_caller_pool(nt, job);
+}
+
 extern "C" {
+
+int64_t trk_text_newlines(const void* text, size_t n, int64_t* out, size_t cap) {
+    if (!text || !n) return 0;
+    const char* base = static_cast<const char*>(text);
+    constexpr size_t CH = (size_t)1 << 20;
+    const size_t nch = (n + CH - 1) / CH;
+    std::vector<std::vector<int64_t>> part(nch);
+    std::atomic<size_t> nx{0};
+    const std::function<void()> job = [&]() {
+        for (;;) {
+            const size_t c = nx.fetch_add(1);
+            if (c >= nch) break;
+            const char* q = base + c * CH;
+            const char* const qe = base + std::min(n, (c + 1) * CH);
+            while ((q = static_cast<const char*>(memchr(q, '\n', (size_t)(qe - q)))) != nullptr) {
+                part[c].push_back((int64_t)(q - base));
+                ++q;
+            }
+        }
+    };
+    run_on_caller_pool((int)std::min<size_t>((size_t)default_threads(32), nch), job);
+    int64_t total = 0;
+    for (const auto& pc : part) {
+        for (int64_t v : pc) {
+            if ((size_t)total < cap && out) out[total] = v;
+            ++total;
+        }
+    }
+    return total;
+}
 
 size_t trk_bgzf_bound(size_t n) { return ((n + BGZF_TEXT - 1) / BGZF_TEXT + 1) * BGZF_SLOT; }
 

@@ -892,6 +892,28 @@ class Engine:
                                        out.ptr, err.ptr))
         return out, err
 
+    def deflate_bgzf(self, data, address=None, nbytes=None, out=None):
+        """trk_deflate_bgzf (include/trk.h): text in host memory -> its BGZF members (0xff00 bytes of text each, no end-of-file
+        member), made on the device.  ``data``: bytes / bytearray, or None with ``address`` / ``nbytes`` of a host buffer
+        (a pinned output block: no copy on the way up).  Returns a memoryview of the members in ``out`` (a bytearray kept
+        and regrown by the engine when None: valid until the next call)."""
+        if data is not None:
+            nbytes = len(data)
+            hold = (C.c_char * nbytes).from_buffer(data) if isinstance(data, bytearray) else C.c_char_p(bytes(data) if not isinstance(data, bytes) else data)
+            address = C.addressof(hold) if isinstance(data, bytearray) else C.cast(hold, C.c_void_p).value
+        need = int(self.lib.trk_deflate_bound(int(nbytes)))
+        if out is None:
+            out = getattr(self, '_deflate_out', None)
+            if out is None or len(out) < need:
+                out = self._deflate_out = bytearray(need)
+        dst = (C.c_char * len(out)).from_buffer(out)
+        got = C.c_size_t(0)
+        try:
+            self._chk(self.lib.trk_deflate_bgzf(self.ctx, C.c_void_p(address), int(nbytes), dst, len(out), C.byref(got)))
+        finally:
+            del dst
+        return memoryview(out)[:got.value]
+
     def inflate_blocks(self, comp, in_off, in_len, out_off, out_len, text=None, text_bytes=None):
         """trk_inflate_blocks (include/trk.h): BGZF members inflated on the device.  comp: the compressed bytes (host
         bytes / uint8 array, or a DeviceArray); in_off / in_len: where each member's raw DEFLATE payload lies in comp;

@@ -802,7 +802,17 @@ class VCFWriter:
         self.wrote_index = False
         if path.endswith('.gz'):
             from .bgzf import BgzfWriter
-            self._fh = BgzfWriter(path)      # --zip output is real bgzip (dumpSTR.py:1241-1245)
+            # --zip output is real bgzip (dumpSTR.py:1241-1245).  TRK_ZIP_LEVEL: the level of the host compressor
+            # (libdeflate; default 6, what `bgzip` gives); TRK_DEVICE_DEFLATE=1: the record writer's blocks are deflated on
+            # the GPU (trk_deflate_bgzf) when the process has a device engine
+            eng = None
+            if _knobs.env('TRK_DEVICE_DEFLATE', '0') == '1':
+                from . import runtime
+                try:
+                    eng = getattr(runtime.get_compute(), 'eng', None)
+                except Exception:
+                    eng = None
+            self._fh = BgzfWriter(path, level=int(_knobs.env('TRK_ZIP_LEVEL', '6')), engine=eng)
             self._recs = []
         else:
             self._fh = open(path, 'w')
@@ -823,6 +833,50 @@ class VCFWriter:
             lines.append('##contig=<ID=%s>' % c)
         self._fh.write('\n'.join(lines + [t._chrom_line]) + '\n')
         self._wrote_header = True
+
+    def _note_block(self, data, at):
+        """``_note`` for a block of the batch writer (a memoryview of ~150 MB): the newlines by libtrk (memchr on its worker
+        pool), then the first eight columns of every line -- a slice of the line's head, never the sample columns."""
+        import numpy as np
+        from .bgzf import _native_lib
+        from .tabix import record_interval
+        lib = _native_lib()
+        n = len(data)
+        if lib is None or n < (1 << 20):
+            return self._note(bytes(data), at)
+        lib.trk_text_newlines.restype = ctypes.c_int64
+        lib.trk_text_newlines.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+        arr = np.frombuffer(data, dtype=np.uint8)
+        cap = max(1024, n // 64)
+        while True:
+            nl = np.empty(cap, dtype=np.int64)
+            got = int(lib.trk_text_newlines(arr.ctypes.data, n, nl.ctypes.data, cap))
+            if got <= cap:
+                break
+            cap = got
+        ends = nl[:got].tolist()
+        if not ends or ends[-1] != n - 1:
+            ends.append(n)                       # (a last line without its newline)
+        recs, pos = self._recs, 0
+        mv = memoryview(data)
+        for e in ends:
+            if e > pos and mv[pos] != 35:        # '#'
+                head = bytes(mv[pos:min(e, pos + 1024)])
+                t = 0
+                for _ in range(8):
+                    t = head.find(b'\t', t) + 1
+                    if t == 0:
+                        break
+                if t == 0 and e - pos > len(head):          # the eight columns are longer than a kilobyte
+                    head = bytes(mv[pos:e])
+                    t = 0
+                    for _ in range(8):
+                        t = head.find(b'\t', t) + 1
+                        if t == 0:
+                            break
+                chrom, beg, end = record_interval(head[:t - 1] if t else head)
+                recs.append((chrom, beg, end, at + pos, at + min(e + 1, n)))
+            pos = e + 1
 
     def _note(self, data, at):
         """The record lines of ``data`` (bytes-like, whole lines), which will lie at byte ``at`` of the text."""
@@ -878,11 +932,11 @@ class VCFWriter:
             self._fh.flush()
             job = lambda: raw.write(data)
         else:
-            block = data if isinstance(data, (bytes, bytearray)) else bytes(data)      # BgzfWriter takes bytes
+            block = data            # (bytes, a bytearray or a memoryview of the record writer's block: no copy)
             at = self._fh.text_bytes
 
             def job():
-                self._note(block, at)           # (on the writer thread, beside the caller's next batch)
+                self._note_block(block, at)     # (on the writer thread, beside the caller's next batch)
                 self._fh.write(block)
         if _knobs.lab('TRK_WRITE_TIMING'):
             import sys
