@@ -30,6 +30,9 @@ mkdir -p /tmp/e2e
 [ -f /tmp/e2e/synth_17000x5000.vcf.gz ] || python "$repo/tools/e2e_probe.py" --loci 17000 --samples 5000 --no-gpu > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d "$out/inflate_stats" -o stats -- python "$repo/tools/inflate_probe.py" /tmp/e2e/synth_17000x5000.vcf.gz 4096 0 > "$out/inflate_under_rocprof.log" 2>&1
 ( cd "$repo" && python tools/rocprof_summary.py stats "$(db inflate_stats)" > "$out/${tag}_inflate_kernel_stats.csv" )
+# round 6: BGZF members deflated on the device (150 MB of dumpSTR-like text per call)
+rocprofv3 --kernel-trace --stats -d "$out/deflate_stats" -o stats -- python "$repo/tools/deflate_probe.py" 150 > "$out/deflate_under_rocprof.log" 2>&1
+( cd "$repo" && python tools/rocprof_summary.py stats "$(db deflate_stats)" > "$out/${tag}_deflate_kernel_stats.csv" )
 # statSTR --samples (sample groups): kernel trace only
 rocprofv3 --kernel-trace --stats -d "$out/groups_stats" -o stats -- python "$repo/tools/groups_probe.py" > "$out/groups_under_rocprof.log" 2>&1
 ( cd "$repo" && python tools/rocprof_summary.py stats "$(db groups_stats)" > "$out/${tag}_groups_kernel_stats.csv" )

@@ -1443,7 +1443,7 @@ int trk_deflate_bgzf(trk_ctx* ctx, const void* host_text, size_t n, void* host_o
     uint32_t* d_sizes = reinterpret_cast<uint32_t*>(d->d_tab);
     uint64_t* d_off = reinterpret_cast<uint64_t*>(d->d_tab + ((nm * 4 + 15) & ~(size_t)15));
     HIPCHK(ctx, hipMemcpyAsync(d->d_text, host_text, n, hipMemcpyHostToDevice, q));
-    HIPCHK(ctx, trk::launch_deflate(d->d_text, (int64_t)n, d->d_slots, d_sizes, reinterpret_cast<uint16_t*>(d->d_tok), d_off, d->d_out,
+    HIPCHK(ctx, trk::launch_deflate(d->d_text, (int64_t)n, d->d_slots, d_sizes, reinterpret_cast<uint32_t*>(d->d_tok), d_off, d->d_out,
                                     ctx->n_cu, q));
     HIPCHK(ctx, hipMemcpyAsync(d->h_off, d_off, (nm + 1) * 8, hipMemcpyDeviceToHost, q));
     // the members' checksums while the device works (the text is the host's)

@@ -9,11 +9,12 @@
 // chain and the parallelism is ACROSS members (a 1.5 GB output is 23 000 of them).
 //   stage A  greedy LZ77, one hash probe per position (2048-entry table of the last token start with the same hash of four
 //            bytes, in LDS); the candidate is compared 64 bytes at a time by the lanes (ballot); tokens go to a
-//            per-wave stream in global memory (16-bit units), symbol frequencies to LDS;
+//            per-wave stream in global memory (32 bits each), symbol frequencies to LDS;
 //   stage B  code lengths of the three alphabets by the two-queue Huffman construction (leaves ranked by all lanes, the
 //            merge by one), frequencies halved while a code is longer than its limit; canonical codes;
-//   stage C  the block header (code-length runs) and the tokens, one lane writing bits; a member that would not get
-//            smaller is STORED.
+//   stage C  the block header (code-length runs) by one lane, then the tokens sixty-four at a time: every lane makes one
+//            token's bits, a scan places them, the lanes OR them into a window of the stream in LDS; a member that would
+//            not get smaller is STORED.
 // The payload of member m goes to slots + m * SLOT, its length to sizes[m]; k_deflate_pack lays the members out back to
 // back with their BGZF headers and trailers (the CRC-32 is the host's: the text came from there).
 #include <hip/hip_runtime.h>
@@ -33,7 +34,7 @@ constexpr int DF_HB = 11;                     // hash bits
 constexpr int DF_MIN = 4, DF_MAX = 258, DF_DIST = 32768;
 constexpr int DF_NLL = 288, DF_NDL = 32, DF_NCL = 32;     // alphabet array sizes (286 / 30 / 19 used)
 constexpr uint32_t DF_SLOT = DF_MEMBER + 64;  // bytes of a member's payload slot (a stored member: text + 5)
-constexpr uint32_t DF_TOKCAP = DF_MEMBER + 64;   // 16-bit units of a wave's token stream
+constexpr uint32_t DF_TOKCAP = DF_MEMBER + 64;   // tokens (32 bits each) of a wave's stream
 constexpr int DF_WGS_PER_CU = 6;              // 6.4 KB of LDS per member: twenty-four members per CU
 
 __constant__ uint16_t c_lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
@@ -69,7 +70,7 @@ struct DeflArgs {
     int32_t n_members;
     uint8_t* slots;        // [n_members][DF_SLOT]
     uint32_t* sizes;       // [n_members] payload bytes
-    uint16_t* tok;         // [gridDim.x * DF_WAVES][DF_TOKCAP]
+    uint32_t* tok;         // [gridDim.x * DF_WAVES][DF_TOKCAP]: a literal's byte, or 0x80000000 | (length - 3) << 16 | distance - 1
 };
 
 // per-wave LDS (6.4 KB): the hash table of stage A is the scratch of stage B.  Sixteen-bit counters throughout: a member
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(WAVE* DF_WAVES) void k_deflate_bgzf(const DeflArgs 
     const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x >> 6;
     WaveLds& w = lds[wid];
     const int wave_slot = blockIdx.x * DF_WAVES + wid, n_slots = gridDim.x * DF_WAVES;
-    uint16_t* tok = a.tok + (size_t)wave_slot * DF_TOKCAP;
+    uint32_t* tok = a.tok + (size_t)wave_slot * DF_TOKCAP;
     for (int m = wave_slot; m < a.n_members; m += n_slots) {
         const uint8_t* text = a.text + (int64_t)m * DF_MEMBER;
         const int n = (int)min<int64_t>(DF_MEMBER, a.n_total - (int64_t)m * DF_MEMBER);
@@ -263,17 +264,16 @@ __global__ __launch_bounds__(WAVE* DF_WAVES) void k_deflate_bgzf(const DeflArgs 
             dist = __builtin_amdgcn_readfirstlane(dist);
             if (best) {
                 if (lane == 0) {
-                    tok[tc] = (uint16_t)(0x8000u | (uint32_t)(best - 3));
-                    tok[tc + 1] = (uint16_t)(dist - 1);
+                    tok[tc] = 0x80000000u | ((uint32_t)(best - 3) << 16) | (uint32_t)(dist - 1);
                     ++w.lf[257 + len_sym(best)];
                     ++w.df[dist_sym(dist)];
                 }
-                tc += 2;
+                tc += 1;
                 p += best;
             } else {
                 const uint32_t b = v & 0xffu;
                 if (lane == 0) {
-                    tok[tc] = (uint16_t)b;
+                    tok[tc] = b;
                     ++w.lf[b];
                 }
                 tc += 1;
@@ -348,7 +348,9 @@ __global__ __launch_bounds__(WAVE* DF_WAVES) void k_deflate_bgzf(const DeflArgs 
         n_runs = __builtin_amdgcn_readfirstlane(n_runs);
         wave_sync();
         huffman_lengths(w, w.cf, 19, 7, w.cl, lane);
-        // ---- stage C: the bits (one lane) -----------------------------------------------------------------------------
+        // ---- stage C: the bits ------------------------------------------------------------------------------------------
+        uint32_t hdr_words = 0, hdr_acc = 0;
+        int hdr_n = 0, dynamic = 0;
         if (lane == 0) {
             canonical_codes(w.ll, 286, w.lc);
             canonical_codes(w.dl, 30, w.dc);
@@ -379,27 +381,85 @@ __global__ __launch_bounds__(WAVE* DF_WAVES) void k_deflate_bgzf(const DeflArgs 
                     else if (s == 17) bo.put(w.run_ext[k], 3);
                     else if (s == 18) bo.put(w.run_ext[k], 7);
                 }
-                for (uint32_t t = 0; t < tc;) {
-                    const uint32_t u = tok[t];
-                    if (u & 0x8000u) {
-                        const int l = (int)(u & 0x7fffu) + 3, d = (int)tok[t + 1] + 1;
-                        t += 2;
-                        const int ls = len_sym(l);
-                        bo.put(w.lc[257 + ls], w.ll[257 + ls]);
-                        const int le = len_extra(ls);
-                        if (le) bo.put((uint32_t)(l - c_lbase[ls]), le);
-                        const int ds = dist_sym(d);
-                        bo.put(w.dc[ds], w.dl[ds]);
-                        const int de = dist_extra(ds);
-                        if (de) bo.put((uint32_t)(d - c_dbase[ds]), de);
-                    } else {
-                        t += 1;
-                        bo.put(w.lc[u], w.ll[u]);
-                    }
-                }
-                bo.put(w.lc[256], w.ll[256]);
-                payload_bytes = bo.finish();
+                // the header is written; the tokens follow from bit `hdr_bits` on (all lanes, below)
+                hdr_words = bo.words;
+                hdr_acc = (uint32_t)bo.acc;
+                hdr_n = bo.n;
+                dynamic = 1;
             }
+        }
+        dynamic = __builtin_amdgcn_readfirstlane(dynamic);
+        if (dynamic) {
+            // ---- the tokens, SIXTY-FOUR AT A TIME: every lane makes the bits of one token (at most 48), a scan of the lengths
+            // says where they go, the lanes OR them into a window of the stream in LDS and the window's full dwords leave for
+            // the payload.  (One lane walking the token stream took a dependent global load per token: half of the member's
+            // time.)  The end-of-block symbol is token number tc.
+            uint32_t* stage = reinterpret_cast<uint32_t*>(w.u.htab);         // (stage B's scratch is done with: 100 dwords)
+            uint32_t out_word = __builtin_amdgcn_readfirstlane(hdr_words);   // dwords of the payload already complete
+            uint32_t carry_bits = (uint32_t)__builtin_amdgcn_readfirstlane(hdr_n);      // bits of the open dword
+            uint32_t carry = __builtin_amdgcn_readfirstlane(hdr_acc);
+            // (the token stream was written by lane 0: its stores have completed before the other lanes read it -- one L1 per
+            // CU, so workgroup scope is enough)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            for (uint32_t t0 = 0; t0 <= tc; t0 += WAVE) {
+                const uint32_t t = t0 + (uint32_t)lane;
+                uint64_t v = 0;
+                int nb = 0;
+                if (t < tc) {
+                    const uint32_t u = tok[t];
+                    if (u & 0x80000000u) {
+                        const int l = (int)((u >> 16) & 0x7fffu) + 3, d = (int)(u & 0xffffu) + 1;
+                        const int ls = len_sym(l);
+                        v = w.lc[257 + ls];
+                        nb = w.ll[257 + ls];
+                        const int le = len_extra(ls);
+                        v |= (uint64_t)(uint32_t)(l - c_lbase[ls]) << nb;
+                        nb += le;
+                        const int ds = dist_sym(d);
+                        v |= (uint64_t)w.dc[ds] << nb;
+                        nb += w.dl[ds];
+                        const int de = dist_extra(ds);
+                        v |= (uint64_t)(uint32_t)(d - c_dbase[ds]) << nb;
+                        nb += de;
+                    } else {
+                        v = w.lc[u];
+                        nb = w.ll[u];
+                    }
+                } else if (t == tc) {
+                    v = w.lc[256];
+                    nb = w.ll[256];
+                }
+                // where this token's bits start, counted from the open dword's first bit
+                int incl = nb;
+                for (int o = 1; o < WAVE; o <<= 1) {
+                    const int x = __shfl_up(incl, o, WAVE);
+                    if (lane >= o) incl += x;
+                }
+                const uint32_t total = (uint32_t)__shfl(incl, WAVE - 1, WAVE);
+                const uint32_t at = carry_bits + (uint32_t)(incl - nb);
+                // the window: the open dword, then what 64 tokens can fill (64 x 48 bits = 96 dwords)
+                for (int i = lane; i < 100; i += WAVE) stage[i] = i == 0 ? carry : 0u;
+                wave_sync();
+                if (nb) {
+                    const uint32_t wd = at >> 5, sh = at & 31u;
+                    atomicOr(&stage[wd], (uint32_t)(v << sh));
+                    const uint64_t rest = sh ? (v >> (32 - sh)) : (v >> 32);      // the bits beyond the first dword
+                    if (sh + (uint32_t)nb > 32u) atomicOr(&stage[wd + 1], (uint32_t)rest);
+                    if (sh + (uint32_t)nb > 64u) atomicOr(&stage[wd + 2], (uint32_t)(rest >> 32));
+                }
+                wave_sync();
+                const uint32_t bits_now = carry_bits + total;
+                const uint32_t full = bits_now >> 5;
+                for (uint32_t i = (uint32_t)lane; i < full; i += WAVE) payload[out_word + i] = stage[i];
+                carry = stage[full];
+                carry_bits = bits_now & 31u;
+                out_word += full;
+                wave_sync();
+            }
+            if (lane == 0 && carry_bits) payload[out_word] = carry;
+            payload_bytes = out_word * 4u + ((carry_bits + 7u) >> 3);
         }
         payload_bytes = __builtin_amdgcn_readfirstlane(payload_bytes);
         if (payload_bytes == 0) {
@@ -468,13 +528,13 @@ namespace trk {
 size_t deflate_slot_bytes() { return DF_SLOT; }
 size_t deflate_tok_bytes(int n_cu, int n_members) {
     const int wgs = min((n_members + DF_WAVES - 1) / DF_WAVES, n_cu * DF_WGS_PER_CU);
-    return (size_t)max(wgs, 1) * DF_WAVES * DF_TOKCAP * sizeof(uint16_t);
+    return (size_t)max(wgs, 1) * DF_WAVES * DF_TOKCAP * sizeof(uint32_t);
 }
 
 // text[0 .. n) on the device -> the BGZF members back to back in `out` (capacity: n_members * (DF_SLOT + 26); slots:
 // n_members * deflate_slot_bytes()), their
 // offsets in off[0 .. n_members] (off[n_members] = total bytes), the CRC-32 fields zero.  slots / sizes / tok: workspace.
-hipError_t launch_deflate(const uint8_t* text, int64_t n, uint8_t* slots, uint32_t* sizes, uint16_t* tok, uint64_t* off, uint8_t* out,
+hipError_t launch_deflate(const uint8_t* text, int64_t n, uint8_t* slots, uint32_t* sizes, uint32_t* tok, uint64_t* off, uint8_t* out,
                           int n_cu, hipStream_t stream) {
     const int n_members = (int)((n + DF_MEMBER - 1) / DF_MEMBER);
     if (n_members < 1) return hipSuccess;

@@ -38,7 +38,7 @@ struct LineIndexWs {     // device results / scratch of launch_line_index (trk_i
 };
 size_t deflate_slot_bytes();
 size_t deflate_tok_bytes(int n_cu, int n_members);
-hipError_t launch_deflate(const uint8_t* text, int64_t n, uint8_t* slots, uint32_t* sizes, uint16_t* tok, uint64_t* off, uint8_t* out,
+hipError_t launch_deflate(const uint8_t* text, int64_t n, uint8_t* slots, uint32_t* sizes, uint32_t* tok, uint64_t* off, uint8_t* out,
                           int n_cu, hipStream_t stream);
 hipError_t launch_line_count(const uint8_t* text, int64_t n, const LineIndexWs& ws, hipStream_t stream);   // step 1: *ws.n_nl
 hipError_t launch_line_index(const uint8_t* text, int64_t n, int tabs_in, const LineIndexWs& ws, hipStream_t stream);
