@@ -21,7 +21,7 @@ import sys
 
 import numpy as np
 import pytest
-from hypothesis import HealthCheck, given, settings, strategies as st
+from hypothesis import example, HealthCheck, given, settings, strategies as st
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -166,6 +166,7 @@ def _vcfio_arrays(x, S, P, keys, kinds):
 @_cfg(2000)
 @given(seed=st.integers(0, 2**31 - 1), n_rec=st.integers(1, 10), S=st.integers(1, 48), P=st.integers(1, 3),
        hard=st.sampled_from([0.0, 0.0, 0.03, 0.3]), crlf=st.booleans())
+@example(seed=9611089, n_rec=2, S=5, P=2, hard=0.0, crlf=False)      # (round-6 campaign: a FORMAT column with none of the asked keys)
 def test_device_parse_against_the_python_decoder(eng, tmp_path_factory, seed, n_rec, S, P, hard, crlf):
     from trtools_amd import vcfio, vcfnative, _lib as L
     rng = np.random.default_rng(seed)
@@ -221,7 +222,10 @@ def test_device_parse_against_the_python_decoder(eng, tmp_path_factory, seed, n_
             if want is None:                  # a call with more alleles than the tensor holds
                 assert flags[i] & (L.PARSE_PLOIDY | L.PARSE_HOST), (seed, i, int(flags[i]))
                 continue
-            assert not easy_only, ("a record of in-grammar spellings was flagged", seed, i, int(flags[i]), rec_lines[i][:300])
+            # (a record whose FORMAT holds neither GT nor any of the asked keys is the host's by the kernel's own rule -- nothing
+            # for the device to parse, "the host has the last word": trk_parse.hip; met by the round-6 campaign, seed 9611089)
+            nothing_asked = 'GT' not in x.FORMAT and not any(k in x.FORMAT for k in keys)
+            assert not easy_only or nothing_asked, ("a record of in-grammar spellings was flagged", seed, i, int(flags[i]), rec_lines[i][:300])
             # the product parses this record on the host: that result must be vcfio's
             if host is None:
                 try:
