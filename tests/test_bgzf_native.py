@@ -122,3 +122,30 @@ def test_writer_feeds_change_nothing_and_the_reader_reads_it(tmp_path):
     n = sum(1 for _ in r)
     r.close()
     assert n == 400
+
+
+def test_a_failing_device_deflate_hands_over_to_the_host(tmp_path):
+    """BgzfWriter(engine=...): blocks go to the engine's deflate_bgzf; when that raises, the host compressor makes the
+    members from there on and the file is whole (no GPU needed: the engine is a stand-in)."""
+    from trtools_amd import bgzf
+    bgzf._native = False
+    calls = []
+
+    class Failing:
+        def deflate_bgzf(self, data, address=None, nbytes=None, out=None):
+            calls.append(nbytes)
+            raise RuntimeError("no device")
+
+    text = os.urandom(4000) + b'chr1\t100\tabc\n' * (3 << 20)
+    path = str(tmp_path / 'f.gz')
+    w = bgzf.BgzfWriter(path, engine=Failing())
+    w.write(text)
+    w.write(text[:100000])
+    w.close()
+    assert calls and w._engine is None
+    assert gzip.open(path).read() == text + text[:100000]
+    # the offsets the index is built from are those of the file that was written
+    raw = open(path, 'rb').read()
+    for k in (0, 1, len(w._coff) // 2, len(w._coff) - 2):
+        assert raw[w._coff[k]:w._coff[k] + 4] == b'\x1f\x8b\x08\x04'
+    assert w._coff[-1] == len(raw) - 28 and w._toff[-1] == len(text) + 100000

@@ -130,8 +130,13 @@ class BgzfWriter:
 
     def _emit_chunks(self, data, at, n):
         if self._engine is not None and n >= self.DEVICE_MIN:      # (any length: a call's last member is as long as what is left)
-            self._device_emit(data, at, n)
-            return
+            try:
+                self._device_emit(data, at, n)
+                return
+            except Exception as e:        # (out of device memory, a context that went away): the host makes the members from here on
+                import sys
+                sys.stderr.write("BgzfWriter: the device deflate failed (%s); the host compressor takes over\n" % e)
+                self._engine = None
         for o in range(0, n, self.CHUNK):
             self._native_emit(data, at + o, min(self.CHUNK, n - o))
 
