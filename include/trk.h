@@ -645,7 +645,8 @@ int trk_inflate_stats(trk_ctx* ctx, uint64_t out[5]);
  * and come down in one copy; the CRC-32 of every member is computed on the host meanwhile (the text is there) and put in.
  * Any stream that inflates to the text is a right answer: the bytes differ from trk_bgzf_compress's (libdeflate / zlib), the
  * text they hold does not.  No end-of-file member (trk_bgzf_eof).  out_cap >= trk_deflate_bound(n).  Returns TRK_OK and
- * *out_bytes; TRK_ERR_ARG: out_cap too small; one call per context at a time. */
+ * *out_bytes; TRK_ERR_ARG: out_cap too small.  Calls on one context take turns (a lock); the call has a queue of its own, so a
+ * writer thread may make it beside the caller's kernels. */
 #define TRK_DEFLATE_MEMBER 16384      /* bytes of text per member trk_deflate_bgzf makes (bgzip's: 0xff00; any size <= 64 KB is BGZF) */
 size_t trk_deflate_bound(size_t n);
 int trk_deflate_bgzf(trk_ctx* ctx, const void* host_text, size_t n, void* host_out, size_t out_cap, size_t* out_bytes);

@@ -92,6 +92,7 @@ struct DeflateState {          // trk_deflate_bgzf's device buffers and pinned s
     uint64_t* h_off = nullptr; size_t h_cap = 0;       // pinned
     std::vector<uint32_t> crc;
     hipStream_t q = nullptr;       // a queue of its own: the call comes from a writer thread beside the caller's kernels
+    std::mutex m;                  // one call at a time (the buffers are the state's)
 };
 
 struct trk_ctx {
@@ -1412,8 +1413,12 @@ int trk_deflate_bgzf(trk_ctx* ctx, const void* host_text, size_t n, void* host_o
     if (out_cap < trk_deflate_bound(n)) return fail(ctx, TRK_ERR_ARG, "deflate_bgzf: out_cap below trk_deflate_bound(%zu)", n);
     if (n == 0) return TRK_OK;
     (void)hipSetDevice(ctx->device);
-    if (!ctx->deflate) ctx->deflate = new DeflateState();
+    {
+        std::lock_guard<std::mutex> g0(ctx->queue_m);
+        if (!ctx->deflate) ctx->deflate = new DeflateState();
+    }
     DeflateState* d = ctx->deflate;
+    std::lock_guard<std::mutex> g(d->m);
     if (!d->q && hipStreamCreateWithFlags(&d->q, hipStreamNonBlocking) != hipSuccess) return fail(ctx, TRK_ERR_HIP, "deflate_bgzf: queue");
     hipStream_t q = d->q;
     const size_t nm = (n + TRK_DEFLATE_MEMBER - 1) / TRK_DEFLATE_MEMBER;
