@@ -1,12 +1,15 @@
 """A line-by-line model of k_deflate_bgzf (trtools_amd/csrc/trk_deflate.hip): the DEFLATE stream the device makes of one
-BGZF member's text -- greedy LZ77 with one hash probe per position, one dynamic-Huffman block per member.  TEST
+BGZF member's text -- greedy LZ77 over a table of eight candidates per hash, one dynamic-Huffman block per member.  TEST
 INFRASTRUCTURE: the checker of the device's bytes is zlib's inflate (any valid stream that gives the text back is right);
 this model additionally says which valid stream the kernel is meant to produce, so that a difference points at the step
 that went wrong.  Nothing here is imported by the product."""
 
-HASH_BITS = 11
+HASH_BITS = 8             # buckets of the candidate table ...
+WAYS = 8                  # ... of eight places each: position q goes to place q % 8 of its bucket
 MEMBER = 16384            # bytes of text per member (include/trk.h: TRK_DEFLATE_MEMBER)
 MIN_MATCH, MAX_MATCH, MAX_DIST = 4, 258, 32768
+FIRST = 32                # bytes of every candidate compared side by side; only the winner is followed beyond them
+INSERT = 64               # positions of a match that enter the table (its first ones)
 LBASE = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258]
 LEXT = [0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0]
 DBASE = [1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145,
@@ -32,24 +35,39 @@ def hash4(text, i):
     return ((v * 2654435761) & 0xffffffff) >> (32 - HASH_BITS)
 
 
+def _common(text, c, p, start, limit):
+    l = start
+    while l < limit and text[c + l] == text[p + l]:
+        l += 1
+    return l
+
+
 def lz_tokens(text):
-    """[(byte, 0) | (length, distance)]: at every position ONE candidate -- the last position with the same hash of four
-    bytes at which a token started -- is tried; a match of at least four bytes is taken greedily."""
-    n, table, toks, p = len(text), [0] * (1 << HASH_BITS), [], 0
+    """[(byte, 0) | (length, distance)].  The table holds, per hash of four bytes, the last position of each residue
+    modulo WAYS that was entered.  At a position the (up to) eight candidates of its bucket are compared over their first
+    FIRST bytes; the longest wins, the nearest among equals, and only the winner is followed beyond FIRST bytes; a match
+    of at least four bytes is taken greedily.  Then the token's positions -- the first INSERT of a match -- enter the
+    table (later positions over earlier ones)."""
+    n, table, toks, p = len(text), [0] * (WAYS << HASH_BITS), [], 0
     while p < n:
         best = dist = 0
         if p + 4 <= n:
             h = hash4(text, p)
-            c = table[h]            # position + 1, 0: none
-            table[h] = p + 1
-            if c and p + 1 - c <= MAX_DIST:
-                c -= 1
-                limit = min(MAX_MATCH, n - p)
-                l = 0
-                while l < limit and text[c + l] == text[p + l]:
-                    l += 1
-                if l >= MIN_MATCH:
-                    best, dist = l, p - c
+            limit = min(MAX_MATCH, n - p)
+            for w in range(WAYS):
+                c = table[h * WAYS + w]            # position + 1, 0: none
+                if c and p + 1 - c <= MAX_DIST:
+                    c -= 1
+                    l = _common(text, c, p, 0, min(FIRST, limit))
+                    if l > best or (l == best and l and p - c < dist):
+                        best, dist = l, p - c
+            if best == FIRST and limit > FIRST:
+                best = _common(text, p - dist, p, FIRST, limit)
+            if best < MIN_MATCH:
+                best = dist = 0
+        for q in range(p, p + min(max(best, 1), INSERT)):
+            if q + 4 <= n:
+                table[hash4(text, q) * WAYS + (q & (WAYS - 1))] = q + 1
         if best:
             toks.append((best, dist))
             p += best

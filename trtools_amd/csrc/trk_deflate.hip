@@ -5,11 +5,14 @@
 // made here is defined by tests/deflate_model.py (a line-by-line model, test infrastructure), and the tests check the bytes
 // against that model and -- the actual requirement -- through zlib's inflate.
 //
-// One WAVE per member of 16 KB of text, twenty-four members per CU, thousands in flight: as in k_inflate_bgzf the work of a member is a serial
-// chain and the parallelism is ACROSS members (a 1.5 GB output is 23 000 of them).
-//   stage A  greedy LZ77, one hash probe per position (2048-entry table of the last token start with the same hash of four
-//            bytes, in LDS); the candidate is compared 64 bytes at a time by the lanes (ballot); tokens go to a
-//            per-wave stream in global memory (32 bits each), symbol frequencies to LDS;
+// One WAVE per member of 16 KB of text, twenty members per CU, thousands in flight: as in k_inflate_bgzf the work of a member is a serial
+// chain and the parallelism is ACROSS members (a 1.5 GB output is 92 000 of them).
+//   stage A  greedy LZ77.  The candidate table (LDS, 4 KB): 256 buckets by the hash of four bytes, eight places each, position q
+//            in place q % 8 -- the last eight residues seen.  At a position the bucket's eight candidates are compared SIDE BY
+//            SIDE, eight lanes and 32 bytes each, in one round trip to the text (the longest wins, the nearest among equals;
+//            only the winner is followed further); every position of a token enters the table, the lanes in parallel.
+//            Tokens go to a per-wave stream in global memory (32 bits each), symbol frequencies to LDS.  (Until the end of
+//            round 6: one candidate per position, token starts only -- files 12-15 % larger.)
 //   stage B  code lengths of the three alphabets by the two-queue Huffman construction (leaves ranked by all lanes, the
 //            merge by one), frequencies halved while a code is longer than its limit; canonical codes;
 //   stage C  the block header (code-length runs) by one lane, then the tokens sixty-four at a time: every lane makes one
@@ -30,12 +33,18 @@ constexpr int DF_WAVES = 4;                   // members per workgroup
 constexpr int DF_MEMBER = TRK_DEFLATE_MEMBER; // bytes of text per member (include/trk.h): 16 KB, a quarter of bgzip's -- a
                                               // member is ONE wave's serial work, and a 150 MB block of dumpSTR's output is
                                               // 9 000 of these against 2 300 of bgzip's size: the chip has 6 000 wave slots
-constexpr int DF_HB = 11;                     // hash bits
+constexpr int DF_HB = 8, DF_WAYS = 8;          // the candidate table: 256 buckets (hash of four bytes) of eight places
+constexpr int DF_FIRST = 32, DF_INSERT = 64;  // bytes of every candidate compared at once; positions of a match that enter the table
 constexpr int DF_MIN = 4, DF_MAX = 258, DF_DIST = 32768;
+static_assert(DF_MEMBER <= DF_DIST, "every earlier position of a member is within reach of a distance code");
 constexpr int DF_NLL = 288, DF_NDL = 32, DF_NCL = 32;     // alphabet array sizes (286 / 30 / 19 used)
 constexpr uint32_t DF_SLOT = DF_MEMBER + 64;  // bytes of a member's payload slot (a stored member: text + 5)
 constexpr uint32_t DF_TOKCAP = DF_MEMBER + 64;   // tokens (32 bits each) of a wave's stream
-constexpr int DF_WGS_PER_CU = 6;              // 6.4 KB of LDS per member: twenty-four members per CU
+#ifndef DF_OCC
+#define DF_OCC 5
+#endif
+constexpr int DF_WGS_PER_CU = DF_OCC;         // workgroups (of one wave per SIMD) resident per CU: the kernel is held to 96
+                                              // registers for it (it took 129, three waves per SIMD, while the LDS had room for six)
 
 __constant__ uint16_t c_lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __constant__ uint16_t c_dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537,
@@ -58,6 +67,17 @@ __device__ __forceinline__ int dist_sym(int d) {           // 1 ... 32768 -> 0 .
 }
 __device__ __forceinline__ int dist_extra(int sym) { return sym < 4 ? 0 : (sym >> 1) - 1; }
 
+__device__ __forceinline__ uint32_t load_u32(const uint8_t* p) {      // any alignment (one global_load_dword)
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ int grp8_min(int x) {       // the minimum over the eight lanes of a group, in every one of them
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false));      // quad_perm [1,0,3,2]
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false));      // quad_perm [2,3,0,1]
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false));     // row_half_mirror
+    return x;
+}
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -77,7 +97,7 @@ struct DeflArgs {
 // holds at most 16 385 symbols.
 struct __attribute__((aligned(16))) WaveLds {
     union {
-        uint16_t htab[1 << DF_HB];                                   // 4096 B
+        uint16_t htab[DF_WAYS << DF_HB];                             // 4096 B
         struct {
             uint16_t order[DF_NLL];     // leaves in (frequency, symbol) order
             uint16_t weight[2 * DF_NLL];
@@ -85,6 +105,9 @@ struct __attribute__((aligned(16))) WaveLds {
             uint8_t depth[2 * DF_NLL];
             uint16_t fcopy[DF_NLL];     // the frequencies the tree is built from (halved while a code is too long)
         } hb;
+        struct {
+            uint16_t count[16], next[16];      // canonical_codes: codes per length, the next code of a length
+        } cn;
     } u;
     uint16_t lf[DF_NLL], df[DF_NDL], cf[DF_NCL];                     // frequencies as counted
     uint8_t ll[DF_NLL], dl[DF_NDL], cl[DF_NCL];                      // code lengths
@@ -105,6 +128,7 @@ __device__ void huffman_lengths(WaveLds& w, const uint16_t* f0, int n, int limit
             if (!fs) continue;
             ++used_here;
             int rank = 0;
+#pragma unroll 4
             for (int t = 0; t < n; ++t) {
                 const uint32_t ft = f[t];
                 rank += (ft != 0u) & ((ft < fs) | ((ft == fs) & (t < s)));
@@ -156,16 +180,19 @@ __device__ void huffman_lengths(WaveLds& w, const uint16_t* f0, int n, int limit
     }
 }
 
-// canonical codes, bit-reversed (one lane; n <= 288)
-__device__ void canonical_codes(const uint8_t* len, int n, uint16_t* code) {
-    uint32_t count[16] = {0}, nxt[16];
+// canonical codes, bit-reversed (one lane; n <= 288).  The two small tables are indexed by a code LENGTH: in the LDS (the
+// tree's scratch is free by now), not in thirty-two registers behind select chains.
+__device__ void canonical_codes(WaveLds& w, const uint8_t* len, int n, uint16_t* code) {
+    uint16_t* count = w.u.cn.count;
+    uint16_t* nxt = w.u.cn.next;
+    for (int b = 0; b < 16; ++b) count[b] = 0;
     for (int s = 0; s < n; ++s) ++count[len[s] & 15];
     count[0] = 0;
     uint32_t c = 0;
     nxt[0] = 0;
     for (int b = 1; b < 16; ++b) {
         c = (c + count[b - 1]) << 1;
-        nxt[b] = c;
+        nxt[b] = (uint16_t)c;
     }
     for (int s = 0; s < n; ++s) {
         const int l = len[s];
@@ -199,7 +226,7 @@ struct BitOut {
     }
 };
 
-__global__ __launch_bounds__(WAVE* DF_WAVES) void k_deflate_bgzf(const DeflArgs a) {
+__global__ __launch_bounds__(WAVE* DF_WAVES) __attribute__((amdgpu_waves_per_eu(DF_OCC, DF_OCC))) void k_deflate_bgzf(const DeflArgs a) {
     __shared__ WaveLds lds[DF_WAVES];
     const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x >> 6;
     WaveLds& w = lds[wid];
@@ -236,33 +263,66 @@ __global__ __launch_bounds__(WAVE* DF_WAVES) void k_deflate_bgzf(const DeflArgs 
             }
             const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)win, wi), hi = (uint32_t)__builtin_amdgcn_readlane((int)win, wi + 1);
             const uint32_t v = (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (p & 3)));      // the four bytes at p
-            if (p + 4 <= n) {
+            const bool can = p + 4 <= n;
+            uint32_t tq = v;                               // the four bytes at p + lane (loaded when a match may be found)
+            if (can) {
+                // The bucket's eight candidates side by side: eight lanes each, a dword per lane -- their first 32 bytes
+                // in ONE round trip to the text.
                 const uint32_t h = (v * 2654435761u) >> (32 - DF_HB);
-                const int c = (int)w.u.htab[h];          // position + 1, 0: none
-                w.u.htab[h] = (uint16_t)(p + 1);
-                if (c && p + 1 - c <= DF_DIST) {
-                    const int cp = c - 1;
+                const int c = (int)w.u.htab[h * DF_WAYS + (lane >> 3)];      // position + 1, 0: none
+                if (__ballot(c != 0)) {
                     const int limit = min(DF_MAX, n - p);
-                    int l = 0;
-                    for (;;) {
-                        const int j = l + lane;
-                        const bool differ = j >= limit || text[cp + j] != text[p + j];
-                        const uint64_t mm = __ballot(differ);
+                    const int j4 = (lane & 7) * 4;
+                    tq = load_u32(text + p + lane);
+                    const uint32_t mine = load_u32(text + p + j4);
+                    int lj = 999;
+                    if (c) {
+                        const uint32_t x = mine ^ load_u32(text + (c - 1) + j4);
+                        if (x) lj = j4 + (__builtin_ctz(x) >> 3);
+                    }
+                    lj = grp8_min(lj);
+                    const int l = min(min(lj, DF_FIRST), limit);
+                    const uint32_t key = c ? ((uint32_t)l << 16) | (uint32_t)(0xffff - (p - (c - 1))) : 0u;   // longest, then nearest
+                    uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, 0);
+                    k = max(k, (uint32_t)__builtin_amdgcn_readlane((int)key, 8));
+                    k = max(k, (uint32_t)__builtin_amdgcn_readlane((int)key, 16));
+                    k = max(k, (uint32_t)__builtin_amdgcn_readlane((int)key, 24));
+                    k = max(k, (uint32_t)__builtin_amdgcn_readlane((int)key, 32));
+                    k = max(k, (uint32_t)__builtin_amdgcn_readlane((int)key, 40));
+                    k = max(k, (uint32_t)__builtin_amdgcn_readlane((int)key, 48));
+                    k = max(k, (uint32_t)__builtin_amdgcn_readlane((int)key, 56));
+                    best = (int)(k >> 16);
+                    dist = 0xffff - (int)(k & 0xffffu);
+                    if (best == DF_FIRST && limit > DF_FIRST) {          // only the winner is followed beyond its first 32 bytes
+                        const uint8_t* cand = text + p - dist;
+                        const int o = DF_FIRST + 4 * lane;               // (one step reaches 288 bytes: the limit is 258)
+                        const uint32_t x = load_u32(cand + o) ^ load_u32(text + p + o);
+                        const int ml = x ? (__builtin_ctz(x) >> 3) : 4;
+                        const uint64_t mm = __ballot(ml < 4);
+                        int l2 = DF_FIRST + 4 * WAVE;
                         if (mm) {
-                            l += __ffsll((unsigned long long)mm) - 1;
-                            break;
+                            const int t = __ffsll((unsigned long long)mm) - 1;
+                            l2 = DF_FIRST + 4 * t + __builtin_amdgcn_readlane(ml, t);
                         }
-                        l += WAVE;
+                        best = min(l2, limit);
                     }
-                    if (l >= DF_MIN) {
-                        best = l;
-                        dist = p - cp;
-                    }
+                    if (best < DF_MIN) best = dist = 0;
                 }
             }
-            best = __builtin_amdgcn_readfirstlane(best);
-            dist = __builtin_amdgcn_readfirstlane(dist);
+            // the token's positions enter the table (a match's first 64): place q % 8 of the bucket of the four bytes at q
             if (best) {
+                const int q = p + lane;
+                const bool act = lane < min(best, DF_INSERT) && q + 4 <= n;
+                uint16_t* slot = &w.u.htab[((tq * 2654435761u) >> (32 - DF_HB)) * DF_WAYS + (q & (DF_WAYS - 1))];
+                const uint16_t val = (uint16_t)(q + 1);
+                // two positions of one token may share a place (a period of 8 in the text): the LATER one stays.  Which lane's
+                // store the LDS keeps is not promised, so the lanes look and the ones that lost to an earlier position store again.
+                bool pend = act;
+                do {
+                    if (pend) *slot = val;
+                    wave_sync();
+                    pend = act && *slot < val;
+                } while (__ballot(pend));
                 if (lane == 0) {
                     tok[tc] = 0x80000000u | ((uint32_t)(best - 3) << 16) | (uint32_t)(dist - 1);
                     ++w.lf[257 + len_sym(best)];
@@ -273,9 +333,11 @@ __global__ __launch_bounds__(WAVE* DF_WAVES) void k_deflate_bgzf(const DeflArgs 
             } else {
                 const uint32_t b = v & 0xffu;
                 if (lane == 0) {
+                    if (can) w.u.htab[((v * 2654435761u) >> (32 - DF_HB)) * DF_WAYS + (p & (DF_WAYS - 1))] = (uint16_t)(p + 1);
                     tok[tc] = b;
                     ++w.lf[b];
                 }
+                wave_sync();
                 tc += 1;
                 p += 1;
             }
@@ -295,7 +357,9 @@ __global__ __launch_bounds__(WAVE* DF_WAVES) void k_deflate_bgzf(const DeflArgs 
         wave_sync();
         int hlit = 286, hdist = 30, n_runs = 0;
         if (lane == 0) {
+#pragma nounroll
             while (hlit > 257 && w.ll[hlit - 1] == 0) --hlit;
+#pragma nounroll
             while (hdist > 1 && w.dl[hdist - 1] == 0) --hdist;
             // the code-length sequence, run-length coded (tests/deflate_model.py: code_length_runs)
             for (int s = 0; s < DF_NCL; ++s) w.cf[s] = 0;
@@ -352,9 +416,9 @@ __global__ __launch_bounds__(WAVE* DF_WAVES) void k_deflate_bgzf(const DeflArgs 
         uint32_t hdr_words = 0, hdr_acc = 0;
         int hdr_n = 0, dynamic = 0;
         if (lane == 0) {
-            canonical_codes(w.ll, 286, w.lc);
-            canonical_codes(w.dl, 30, w.dc);
-            canonical_codes(w.cl, 19, w.cc);
+            canonical_codes(w, w.ll, 286, w.lc);
+            canonical_codes(w, w.dl, 30, w.dc);
+            canonical_codes(w, w.cl, 19, w.cc);
             int hclen = 19;
             while (hclen > 4 && w.cl[c_clord[hclen - 1]] == 0) --hclen;
             // size of the dynamic block, in bits, from the frequencies as counted
@@ -363,7 +427,9 @@ __global__ __launch_bounds__(WAVE* DF_WAVES) void k_deflate_bgzf(const DeflArgs 
                 const int s = w.run_sym[k];
                 bits += w.cl[s] + (s == 16 ? 2 : s == 17 ? 3 : s == 18 ? 7 : 0);
             }
+#pragma unroll 2
             for (int s = 0; s < 286; ++s) bits += (uint64_t)w.lf[s] * (w.ll[s] + (s >= 257 ? len_extra(s - 257) : 0));
+#pragma unroll 2
             for (int s = 0; s < 30; ++s) bits += (uint64_t)w.df[s] * (w.dl[s] + dist_extra(s));
             const uint32_t dyn_bytes = (uint32_t)((bits + 7) >> 3);
             if (dyn_bytes <= (uint32_t)n + 5u) {
