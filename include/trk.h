@@ -640,7 +640,7 @@ int trk_inflate_stats(trk_ctx* ctx, uint64_t out[5]);
 /* ---- BGZF members DEFLATED on the device (round 6; the mirror of trk_inflate_blocks) -------------------------------------
  * What it replaces: `bgzip -f` over dumpSTR's finished output (the reference shells out, dumpSTR.py:1241-1245, 1347-1352).
  * n bytes of text in HOST memory (pinned or not) -> consecutive BGZF members of TRK_DEFLATE_MEMBER bytes of text each in host_out: the
- * text goes up, one wave per member makes the member's DEFLATE stream (greedy LZ77 with one hash probe per position, one
+ * text goes up, one wave per member makes the member's DEFLATE stream (greedy LZ77, sixteen candidates compared side by side per step, one
  * dynamic-Huffman block; a member that would not get smaller is stored), the members are laid out back to back on the device
  * and come down in one copy; the CRC-32 of every member is computed on the host meanwhile (the text is there) and put in.
  * Any stream that inflates to the text is a right answer: the bytes differ from trk_bgzf_compress's (libdeflate / zlib), the

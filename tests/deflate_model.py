@@ -8,7 +8,7 @@ HASH_BITS = 8             # buckets of the candidate table ...
 WAYS = 8                  # ... of eight places each: position q goes to place q % 8 of its bucket
 MEMBER = 16384            # bytes of text per member (include/trk.h: TRK_DEFLATE_MEMBER)
 MIN_MATCH, MAX_MATCH, MAX_DIST = 4, 258, 32768
-FIRST = 32                # bytes of every candidate compared side by side; only the winner is followed beyond them
+FIRST = 16                # bytes of every candidate compared side by side; only the winner is followed beyond them
 INSERT = 64               # positions of a match that enter the table (its first ones)
 LBASE = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258]
 LEXT = [0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0]
@@ -42,38 +42,59 @@ def _common(text, c, p, start, limit):
     return l
 
 
+def _find(text, table, p):
+    """(length over the first FIRST bytes, distance) of the best candidate of p's bucket: the longest, the nearest among
+    equals; (0, 0) when that is not a match."""
+    n, best, dist = len(text), 0, 0
+    if p + 4 <= n:
+        h = hash4(text, p)
+        lim = min(FIRST, MAX_MATCH, n - p)
+        for w in range(WAYS):
+            c = table[h * WAYS + w]            # position + 1, 0: none
+            if c and p + 1 - c <= MAX_DIST:
+                c -= 1
+                l = _common(text, c, p, 0, lim)
+                if l > best or (l == best and l and p - c < dist):
+                    best, dist = l, p - c
+    return (best, dist) if best >= MIN_MATCH else (0, 0)
+
+
 def lz_tokens(text):
     """[(byte, 0) | (length, distance)].  The table holds, per hash of four bytes, the last position of each residue
-    modulo WAYS that was entered.  At a position the (up to) eight candidates of its bucket are compared over their first
-    FIRST bytes; the longest wins, the nearest among equals, and only the winner is followed beyond FIRST bytes; a match
-    of at least four bytes is taken greedily.  Then the token's positions -- the first INSERT of a match -- enter the
-    table (later positions over earlier ones)."""
+    modulo WAYS that was entered.  A step looks at TWO positions, p and p + 1, against the table as it is (the kernel: sixteen
+    candidates side by side): the better match over the first FIRST bytes wins -- p on a tie -- and only the winner is
+    followed beyond FIRST bytes; when it is p + 1's, the byte at p goes out as a literal first; when neither has one, two
+    literals go out.  A token's positions -- the first INSERT of a match -- enter the table, later ones over earlier ones."""
     n, table, toks, p = len(text), [0] * (WAYS << HASH_BITS), [], 0
+
+    def enter(q):
+        if q + 4 <= n:
+            table[hash4(text, q) * WAYS + (q & (WAYS - 1))] = q + 1
+
+    def literal(q):
+        toks.append((text[q], 0))
+        enter(q)
+
     while p < n:
-        best = dist = 0
-        if p + 4 <= n:
-            h = hash4(text, p)
+        b0, d0 = _find(text, table, p)
+        b1, d1 = _find(text, table, p + 1)
+        if b1 > b0:
+            literal(p)
+            p, b0, d0 = p + 1, b1, d1
+        if b0:
             limit = min(MAX_MATCH, n - p)
-            for w in range(WAYS):
-                c = table[h * WAYS + w]            # position + 1, 0: none
-                if c and p + 1 - c <= MAX_DIST:
-                    c -= 1
-                    l = _common(text, c, p, 0, min(FIRST, limit))
-                    if l > best or (l == best and l and p - c < dist):
-                        best, dist = l, p - c
-            if best == FIRST and limit > FIRST:
-                best = _common(text, p - dist, p, FIRST, limit)
-            if best < MIN_MATCH:
-                best = dist = 0
-        for q in range(p, p + min(max(best, 1), INSERT)):
-            if q + 4 <= n:
-                table[hash4(text, q) * WAYS + (q & (WAYS - 1))] = q + 1
-        if best:
-            toks.append((best, dist))
-            p += best
+            if b0 == FIRST and limit > FIRST:
+                b0 = _common(text, p - d0, p, FIRST, limit)
+            for q in range(p, p + min(b0, INSERT)):
+                enter(q)
+            toks.append((b0, d0))
+            p += b0
         else:
-            toks.append((text[p], 0))
+            literal(p)
             p += 1
+            if p < n:
+                literal(p)             # (its bucket had no match for it either)
+                p += 1
     return toks
 
 

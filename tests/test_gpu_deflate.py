@@ -48,7 +48,9 @@ def _texts():
     rand = bytes(rng.integers(0, 256, size=70000, dtype=np.uint8))
     return {'vcf': vcf, 'fixture': fixture * 3, 'random': rand, 'newlines': b'\n' * 140000, 'ab': b'ab' * 40000,
             'one byte': b'x', 'four': b'abcd', 'long runs': b'A' * 300 + b'C' * 70000 + b'ACGT' * 500,
-            'text + noise': vcf[:100000] + rand[:3000] + vcf[:50000], 'every byte': bytes(range(256)) * 300}
+            'text + noise': vcf[:100000] + rand[:3000] + vcf[:50000], 'every byte': bytes(range(256)) * 300,
+            # positions of one token that share a place of a bucket (periods of 8 and 16), and buckets that overflow (three letters)
+            'periods': b'ATCGATCC' * 3000 + bytes(rng.integers(65, 68, size=40000, dtype=np.uint8)) + b'0123456789abcdef' * 1500}
 
 
 @pytest.mark.parametrize('name', sorted(_texts()))
@@ -64,7 +66,7 @@ def test_members_inflate_to_the_text(eng, name):
         assert payload == dm.deflate_member(t), (name, k)
     if name == 'random':
         assert all(len(p) == len(t) + 5 and p[0] == 1 for t, p in ms)          # stored
-    if name in ('vcf', 'fixture', 'newlines', 'ab', 'long runs'):
+    if name in ('vcf', 'fixture', 'newlines', 'ab', 'long runs', 'periods'):
         assert len(raw) < 0.5 * len(text)
 
 

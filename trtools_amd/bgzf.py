@@ -66,7 +66,7 @@ class BgzfWriter:
     def __init__(self, path, level=6, threads=None, engine=None):
         """``engine``: a device engine -- blocks of at least DEVICE_MIN bytes are deflated on the GPU (trk_deflate_bgzf:
         the text goes up, the members come down; the host computes the CRCs), smaller writes and the stream's tail by the
-        host compressor.  The members hold 0xff00 bytes of text either way."""
+        host compressor (whose members hold 0xff00 bytes of text; the device's hold DEVICE_MEMBER)."""
         self._engine = engine
         self._fh = open(path, 'wb')
         self._buf = bytearray()

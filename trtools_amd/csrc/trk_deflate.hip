@@ -34,7 +34,7 @@ constexpr int DF_MEMBER = TRK_DEFLATE_MEMBER; // bytes of text per member (inclu
                                               // member is ONE wave's serial work, and a 150 MB block of dumpSTR's output is
                                               // 9 000 of these against 2 300 of bgzip's size: the chip has 6 000 wave slots
 constexpr int DF_HB = 8, DF_WAYS = 8;          // the candidate table: 256 buckets (hash of four bytes) of eight places
-constexpr int DF_FIRST = 32, DF_INSERT = 64;  // bytes of every candidate compared at once; positions of a match that enter the table
+constexpr int DF_FIRST = 16, DF_INSERT = 64;  // bytes of every candidate compared at once; positions of a match that enter the table
 constexpr int DF_MIN = 4, DF_MAX = 258, DF_DIST = 32768;
 static_assert(DF_MEMBER <= DF_DIST, "every earlier position of a member is within reach of a distance code");
 constexpr int DF_NLL = 288, DF_NDL = 32, DF_NCL = 32;     // alphabet array sizes (286 / 30 / 19 used)
@@ -72,10 +72,14 @@ __device__ __forceinline__ uint32_t load_u32(const uint8_t* p) {      // any ali
     __builtin_memcpy(&v, p, 4);
     return v;
 }
-__device__ __forceinline__ int grp8_min(int x) {       // the minimum over the eight lanes of a group, in every one of them
+__device__ __forceinline__ int grp4_min(int x) {       // the minimum over the four lanes of a group, in every one of them
     x = min(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false));      // quad_perm [1,0,3,2]
     x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false));      // quad_perm [2,3,0,1]
-    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false));     // row_half_mirror
+    return x;
+}
+__device__ __forceinline__ uint32_t row_max(uint32_t x) {      // the maximum over a row of sixteen lanes whose groups of four agree
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x124, 0xf, 0xf, false));     // row_ror:4
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x128, 0xf, 0xf, false));     // row_ror:8
     return x;
 }
 __device__ __forceinline__ void wave_sync() {
@@ -253,8 +257,9 @@ __global__ __launch_bounds__(WAVE* DF_WAVES) __attribute__((amdgpu_waves_per_eu(
         uint32_t win = text32[lane];                       // (the buffer is padded: reads beyond the text's end stay inside it)
         int p = 0;
         uint32_t tc = 0;
+        const int grp = lane >> 2, j4 = (lane & 3) * 4;    // sixteen groups of four lanes: a candidate each, 16 bytes of it
+        const int second = grp >> 3;                       // groups 8 ... 15 look at p + 1
         while (p < n) {
-            int best = 0, dist = 0;
             int wi = (p >> 2) - wb;
             if (wi >= WAVE - 1) {
                 wb = p >> 2;
@@ -262,58 +267,72 @@ __global__ __launch_bounds__(WAVE* DF_WAVES) __attribute__((amdgpu_waves_per_eu(
                 wi = 0;
             }
             const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)win, wi), hi = (uint32_t)__builtin_amdgcn_readlane((int)win, wi + 1);
-            const uint32_t v = (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (p & 3)));      // the four bytes at p
-            const bool can = p + 4 <= n;
-            uint32_t tq = v;                               // the four bytes at p + lane (loaded when a match may be found)
-            if (can) {
-                // The bucket's eight candidates side by side: eight lanes each, a dword per lane -- their first 32 bytes
-                // in ONE round trip to the text.
-                const uint32_t h = (v * 2654435761u) >> (32 - DF_HB);
-                const int c = (int)w.u.htab[h * DF_WAYS + (lane >> 3)];      // position + 1, 0: none
+            const uint64_t v8 = (((uint64_t)hi << 32) | lo) >> (8 * (p & 3));
+            const uint32_t v0 = (uint32_t)v8, v1 = (uint32_t)(v8 >> 8);      // the four bytes at p, at p + 1
+            // ---- the match: TWO positions against the table as it is, their sixteen candidates side by side, sixteen bytes
+            // ---- each, in ONE round trip to the text; the better one wins (p on a tie), only the winner is followed further
+            int b0 = 0, d0 = 0, b1 = 0, d1 = 0;
+            uint32_t tq0 = v0, tq1 = v1;                   // the four bytes at p + lane, p + 1 + lane (loaded when a match may be found)
+            {
+                const int pos = p + second;
+                const uint32_t h = ((second ? v1 : v0) * 2654435761u) >> (32 - DF_HB);
+                const int c = pos + 4 <= n ? (int)w.u.htab[h * DF_WAYS + (grp & 7)] : 0;      // position + 1, 0: none
                 if (__ballot(c != 0)) {
-                    const int limit = min(DF_MAX, n - p);
-                    const int j4 = (lane & 7) * 4;
-                    tq = load_u32(text + p + lane);
-                    const uint32_t mine = load_u32(text + p + j4);
+                    tq0 = load_u32(text + p + lane);
+                    tq1 = load_u32(text + p + 1 + lane);
                     int lj = 999;
                     if (c) {
-                        const uint32_t x = mine ^ load_u32(text + (c - 1) + j4);
+                        const uint32_t x = load_u32(text + pos + j4) ^ load_u32(text + (c - 1) + j4);
                         if (x) lj = j4 + (__builtin_ctz(x) >> 3);
                     }
-                    lj = grp8_min(lj);
-                    const int l = min(min(lj, DF_FIRST), limit);
-                    const uint32_t key = c ? ((uint32_t)l << 16) | (uint32_t)(0xffff - (p - (c - 1))) : 0u;   // longest, then nearest
-                    uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, 0);
-                    k = max(k, (uint32_t)__builtin_amdgcn_readlane((int)key, 8));
-                    k = max(k, (uint32_t)__builtin_amdgcn_readlane((int)key, 16));
-                    k = max(k, (uint32_t)__builtin_amdgcn_readlane((int)key, 24));
-                    k = max(k, (uint32_t)__builtin_amdgcn_readlane((int)key, 32));
-                    k = max(k, (uint32_t)__builtin_amdgcn_readlane((int)key, 40));
-                    k = max(k, (uint32_t)__builtin_amdgcn_readlane((int)key, 48));
-                    k = max(k, (uint32_t)__builtin_amdgcn_readlane((int)key, 56));
-                    best = (int)(k >> 16);
-                    dist = 0xffff - (int)(k & 0xffffu);
-                    if (best == DF_FIRST && limit > DF_FIRST) {          // only the winner is followed beyond its first 32 bytes
-                        const uint8_t* cand = text + p - dist;
-                        const int o = DF_FIRST + 4 * lane;               // (one step reaches 288 bytes: the limit is 258)
-                        const uint32_t x = load_u32(cand + o) ^ load_u32(text + p + o);
-                        const int ml = x ? (__builtin_ctz(x) >> 3) : 4;
-                        const uint64_t mm = __ballot(ml < 4);
-                        int l2 = DF_FIRST + 4 * WAVE;
-                        if (mm) {
-                            const int t = __ffsll((unsigned long long)mm) - 1;
-                            l2 = DF_FIRST + 4 * t + __builtin_amdgcn_readlane(ml, t);
-                        }
-                        best = min(l2, limit);
+                    lj = grp4_min(lj);
+                    const int l = min(min(lj, DF_FIRST), n - pos);
+                    uint32_t key = c ? ((uint32_t)l << 16) | (uint32_t)(0xffff - (pos - (c - 1))) : 0u;      // longest, then nearest
+                    key = row_max(key);                    // (a row of sixteen lanes = four candidates)
+                    const uint32_t k0 = max((uint32_t)__builtin_amdgcn_readlane((int)key, 0), (uint32_t)__builtin_amdgcn_readlane((int)key, 16));
+                    const uint32_t k1 = max((uint32_t)__builtin_amdgcn_readlane((int)key, 32), (uint32_t)__builtin_amdgcn_readlane((int)key, 48));
+                    if ((int)(k0 >> 16) >= DF_MIN) {
+                        b0 = (int)(k0 >> 16);
+                        d0 = 0xffff - (int)(k0 & 0xffffu);
                     }
-                    if (best < DF_MIN) best = dist = 0;
+                    if ((int)(k1 >> 16) >= DF_MIN) {
+                        b1 = (int)(k1 >> 16);
+                        d1 = 0xffff - (int)(k1 & 0xffffu);
+                    }
                 }
             }
-            // the token's positions enter the table (a match's first 64): place q % 8 of the bucket of the four bytes at q
-            if (best) {
+            if (b1 > b0) {                                 // p + 1 has the better match: the byte at p is a literal
+                if (lane == 0) {
+                    if (p + 4 <= n) w.u.htab[((v0 * 2654435761u) >> (32 - DF_HB)) * DF_WAYS + (p & (DF_WAYS - 1))] = (uint16_t)(p + 1);
+                    tok[tc] = v0 & 0xffu;
+                    ++w.lf[v0 & 0xffu];
+                }
+                wave_sync();
+                tc += 1;
+                p += 1;
+                b0 = b1;
+                d0 = d1;
+                tq0 = tq1;
+            }
+            if (b0) {
+                int best = b0;
+                const int limit = min(DF_MAX, n - p);
+                if (best == DF_FIRST && limit > DF_FIRST) {
+                    const int o = DF_FIRST + 4 * lane;     // (one step reaches 272 bytes: the limit is 258)
+                    const uint32_t x = load_u32(text + p - d0 + o) ^ load_u32(text + p + o);
+                    const int ml = x ? (__builtin_ctz(x) >> 3) : 4;
+                    const uint64_t mm = __ballot(ml < 4);
+                    int l2 = DF_FIRST + 4 * WAVE;
+                    if (mm) {
+                        const int t = __ffsll((unsigned long long)mm) - 1;
+                        l2 = DF_FIRST + 4 * t + __builtin_amdgcn_readlane(ml, t);
+                    }
+                    best = min(l2, limit);
+                }
+                // the token's positions enter the table (a match's first 64): place q % 8 of the bucket of the four bytes at q
                 const int q = p + lane;
                 const bool act = lane < min(best, DF_INSERT) && q + 4 <= n;
-                uint16_t* slot = &w.u.htab[((tq * 2654435761u) >> (32 - DF_HB)) * DF_WAYS + (q & (DF_WAYS - 1))];
+                uint16_t* slot = &w.u.htab[((tq0 * 2654435761u) >> (32 - DF_HB)) * DF_WAYS + (q & (DF_WAYS - 1))];
                 const uint16_t val = (uint16_t)(q + 1);
                 // two positions of one token may share a place (a period of 8 in the text): the LATER one stays.  Which lane's
                 // store the LDS keeps is not promised, so the lanes look and the ones that lost to an earlier position store again.
@@ -324,22 +343,28 @@ __global__ __launch_bounds__(WAVE* DF_WAVES) __attribute__((amdgpu_waves_per_eu(
                     pend = act && *slot < val;
                 } while (__ballot(pend));
                 if (lane == 0) {
-                    tok[tc] = 0x80000000u | ((uint32_t)(best - 3) << 16) | (uint32_t)(dist - 1);
+                    tok[tc] = 0x80000000u | ((uint32_t)(best - 3) << 16) | (uint32_t)(d0 - 1);
                     ++w.lf[257 + len_sym(best)];
-                    ++w.df[dist_sym(dist)];
+                    ++w.df[dist_sym(d0)];
                 }
                 tc += 1;
                 p += best;
             } else {
-                const uint32_t b = v & 0xffu;
+                // no match at p and none at p + 1: two literals
+                const int two = p + 1 < n;
+                if (lane < 1 + two) {
+                    const uint32_t vq = lane ? v1 : v0;
+                    const int q = p + lane;
+                    if (q + 4 <= n) w.u.htab[((vq * 2654435761u) >> (32 - DF_HB)) * DF_WAYS + (q & (DF_WAYS - 1))] = (uint16_t)(q + 1);
+                    tok[tc + lane] = vq & 0xffu;
+                }
                 if (lane == 0) {
-                    if (can) w.u.htab[((v * 2654435761u) >> (32 - DF_HB)) * DF_WAYS + (p & (DF_WAYS - 1))] = (uint16_t)(p + 1);
-                    tok[tc] = b;
-                    ++w.lf[b];
+                    ++w.lf[v0 & 0xffu];
+                    if (two) ++w.lf[v1 & 0xffu];
                 }
                 wave_sync();
-                tc += 1;
-                p += 1;
+                tc += 1 + two;
+                p += 1 + two;
             }
         }
         wave_sync();
