@@ -383,6 +383,20 @@ size_t trk_bgzf_eof(void* out28);
  * where its records lie scans a 150 MB block in a couple of milliseconds); returns how many there are (more than cap: only
  * the first cap were written) */
 int64_t trk_text_newlines(const void* text, size_t n, int64_t* out, size_t cap);
+/* The record lines among the lines of text[0 .. n) whose newlines are nl[0 .. n_nl) (trk_text_newlines; a last line without
+ * one ends at n), for a writer that builds the tabix index of what it writes: row k of out[cap][8] =
+ *   { offset of the line, offset behind its newline, beg, end, offset of CHROM, its length, new, odd }
+ * with [beg, end) the interval htslib's tabix gives a VCF line -- POS - 1 ... POS - 1 + len(REF), INFO/END when it lies beyond
+ * beg --, new = 1 when CHROM differs from the record before (in this call), odd = 1 when the line's head is not what this
+ * scanner reads (fewer than four columns, a POS or END that is not plain digits, a REF beyond ASCII): beg and end are then
+ * unset and the caller reads that head itself.  Lines that are empty or begin with '#' are no records.  Returns the number of
+ * records (more than cap: only the first cap rows were written). */
+int64_t trk_text_record_places(const void* text, size_t n, const int64_t* nl, size_t n_nl, int64_t* out, size_t cap);
+/* where the BGZF members of data[0 .. n) begin: out[k] = the offset of member k, k < cap, by the chain of their BSIZE fields
+ * (what a writer that keeps virtual offsets walks after every block of members it made -- 9 000 steps per block on the device's
+ * path: not a loop for an interpreter that holds its lock meanwhile).  Returns the number of members (more than cap: only
+ * the first cap were written); -1: the chain leaves the buffer or meets something that is not a BGZF header. */
+int64_t trk_bgzf_member_offsets(const void* data, size_t n, uint64_t* out, size_t cap);
 
 #ifdef __cplusplus
 }

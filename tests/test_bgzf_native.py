@@ -149,3 +149,23 @@ def test_a_failing_device_deflate_hands_over_to_the_host(tmp_path):
     for k in (0, 1, len(w._coff) // 2, len(w._coff) - 2):
         assert raw[w._coff[k]:w._coff[k] + 4] == b'\x1f\x8b\x08\x04'
     assert w._coff[-1] == len(raw) - 28 and w._toff[-1] == len(text) + 100000
+
+
+def test_member_offsets_follow_the_chain():
+    """trk_bgzf_member_offsets: where the members of a buffer begin (what BgzfWriter's virtual offsets are made of), against a
+    walk of the BSIZE fields here; a buffer that is not whole members is refused, a short table is said to be short."""
+    lib = _lib()
+    text = _synthetic(60, 700, seed=4)
+    raw = _compress(lib, text, 1, 4) + bytes.fromhex('1f8b08040000000000ff0600424302001b0003000000000000000000')
+    want, pos = [], 0
+    while pos < len(raw):
+        want.append(pos)
+        pos += struct.unpack_from('<H', raw, pos + 16)[0] + 1
+    assert len(want) == (len(text) + 0xfeff) // 0xff00 + 1
+    out = np.zeros(len(want) + 3, dtype=np.uint64)
+    walk = lambda buf, cap: int(lib.trk_bgzf_member_offsets(C.c_char_p(buf), len(buf), out.ctypes.data, cap))
+    assert walk(raw, len(out)) == len(want) and out[:len(want)].tolist() == want and out[len(want):].tolist() == [0, 0, 0]
+    out[:] = 0
+    assert walk(raw, 2) == len(want) and out[:3].tolist() == want[:2] + [0]          # (the count, the first two places)
+    assert walk(raw[:-1], len(out)) == -1 and walk(raw[:want[1] + 5], len(out)) == -1
+    assert walk(b'x' + raw, len(out)) == -1 and walk(b'', len(out)) == 0

@@ -245,3 +245,51 @@ def test_random_files_index_seek_equals_scan(tmp_path_factory, seed, n_rec, n_ch
         got = _records(vcfnative.NativeVCFReader(path), reg)
         want = _records(vcfio.VCFReader(path), reg)
         assert got == want, reg
+
+
+def test_native_record_places_equal_the_python_scan(tmp_path):
+    """trk_text_record_places (what VCFWriter notes of a block of the batch writer) against the writer's own per-line scan:
+    INFO/END before, behind and without other items, END spellings python's int() reads and this scanner leaves to it, a
+    name that is not END, heads of four columns, names beyond ASCII, comment and empty lines, a last line without newline."""
+    from trtools_amd import vcfio
+    rng = np.random.default_rng(9)
+    lines = ['#comment\n', '\n']
+    pos = 10
+    infos = ['.', 'END=%d', 'PERIOD=2;END=%d', 'END=%d;X=1', 'XEND=%d', 'END=+%d', 'END= %d', 'END=', 'END=1_0', 'END=abc;END=%d',
+             'A=1;END=%d;END=7', 'END=0', '']
+    for chrom in ('chr1', 'chrü', 'c'):
+        for i in range(80):
+            pos += int(rng.integers(1, 500))
+            ref = 'ACG' * int(rng.integers(1, 9))
+            info = infos[int(rng.integers(0, len(infos)))]
+            if '%d' in info:
+                info = info % (pos + int(rng.integers(-5, 60)))
+            cols = [chrom, str(pos) if rng.random() < 0.9 else ' %d' % pos, '.', ref, 'A', '.', '.', info, 'GT', '0/1', '1/1']
+            if rng.random() < 0.1:
+                cols = cols[:int(rng.integers(4, 9))]
+            lines.append('\t'.join(cols) + '\n')
+            if rng.random() < 0.05:
+                lines.append('#in between\n')
+        pos = 5
+    lines[-1] = lines[-1][:-1]                     # (no newline at the very end)
+    text = ''.join(lines).encode()
+
+    class _Tmpl:
+        _header_lines, _chrom_line = ['##fileformat=VCFv4.2'], '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ta\tb'
+        has_pass_filter, contigs_seen = True, []
+
+    def noted(native_min):
+        w = vcfio.VCFWriter(str(tmp_path / ('n%d.vcf.gz' % native_min)), _Tmpl())
+        assert w._fh._lib is not None
+        w.NOTE_NATIVE_MIN = native_min
+        w._note_block(memoryview(np.frombuffer(text, dtype=np.uint8).copy()), 1000)
+        out = []
+        for rec in w._recs:
+            if len(rec) == 2:
+                out += [(rec[0][a], b, c, d, e) for a, b, c, d, e in rec[1].tolist()]
+            else:
+                out.append(rec)
+        w.close()
+        return out
+    native, python = noted(0), noted(1 << 40)
+    assert len(python) == 240 and native == python

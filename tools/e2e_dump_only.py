@@ -13,6 +13,8 @@ if os.environ.get('E2E_ZIP'):          # round 6: --zip (libtrk's BGZF members, 
 dargs = dumpSTR.getargs()
 sys.argv = old
 import glob
+if os.environ.get('E2E_SWITCH'):       # the interpreter's thread switch interval (default 5 ms): what a thread that wants the GIL waits for
+    sys.setswitchinterval(float(os.environ['E2E_SWITCH']))
 for i in range(3):
     for f in glob.glob('/tmp/e2e/dump.*'):
         os.remove(f)        # (truncating last run's 1.5 GB output is 0.15 s of open(): not the command line's time)

@@ -43,6 +43,8 @@ def _native_lib():
                 lib.trk_bgzf_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                                   C.POINTER(C.c_size_t)]
                 lib.trk_bgzf_compress.restype = C.c_int
+                lib.trk_bgzf_member_offsets.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+                lib.trk_bgzf_member_offsets.restype = C.c_int64
                 _native = lib
         except Exception:          # (no libtrk.so here: the Python members)
             _native = None
@@ -68,6 +70,8 @@ class BgzfWriter:
         the text goes up, the members come down; the host computes the CRCs), smaller writes and the stream's tail by the
         host compressor (whose members hold 0xff00 bytes of text; the device's hold DEVICE_MEMBER)."""
         self._engine = engine
+        from . import _knobs
+        self._timing = bool(_knobs.lab('TRK_WRITE_TIMING'))
         self._fh = open(path, 'wb')
         self._buf = bytearray()
         self._level = level
@@ -107,9 +111,29 @@ class BgzfWriter:
         self._fh.write(memoryview(self._out)[:got.value])
 
     def _members(self, out, end, n_text, member):
-        """The members of out[0 : end) -- ``n_text`` bytes of text, ``member`` per member -- join the offset tables."""
-        pos, coff, toff = 0, self._coff, self._toff
-        base, tbase, k = coff[-1], toff[-1], 0
+        """The members of out[0 : end) -- ``n_text`` bytes of text, ``member`` per member -- join the offset tables.  Where
+        they begin: libtrk walks the chain of their BSIZE fields (a block of the device's has 9 000 members: not a loop for
+        the interpreter, whose lock the caller's thread waits for meanwhile)."""
+        import numpy as np
+        coff, toff = self._coff, self._toff
+        base, tbase = coff[-1], toff[-1]
+        lib = self._lib
+        if lib is not None and end:
+            cap = n_text // member + 2
+            offs = np.empty(cap, dtype=np.uint64)
+            hold, addr = _address(out)
+            try:
+                k = int(lib.trk_bgzf_member_offsets(C.c_void_p(addr), end, offs.ctypes.data, cap))
+            finally:
+                del hold
+            if k < 0 or k > cap:
+                raise OSError("BgzfWriter: the members made do not form a chain")
+            starts = offs[:k].astype(np.int64)
+            coff.extend((base + starts[1:]).tolist())
+            coff.append(base + end)
+            toff.extend((tbase + np.minimum(np.arange(1, k + 1, dtype=np.int64) * member, n_text)).tolist())
+            return
+        pos, k = 0, 0
         while pos < end:           # the members' sizes (BSIZE at byte 16 of each): where member k + 1 begins
             pos += (out[pos + 16] | (out[pos + 17] << 8)) + 1
             k += 1
@@ -120,13 +144,21 @@ class BgzfWriter:
 
     def _device_emit(self, data, at, n):
         """Members of data[at : at + n] made on the device (DEVICE_MEMBER bytes of text each)."""
+        import time
+        t0 = time.perf_counter()
         hold, base = _address(data)
         try:
             out = self._engine.deflate_bgzf(None, address=base + at, nbytes=n)
         finally:
             del hold
+        t1 = time.perf_counter()
         self._members(out, len(out), n, DEVICE_MEMBER)
+        t2 = time.perf_counter()
         self._fh.write(out)
+        if self._timing:
+            import sys
+            print('[bgzf] %.0f MB: device deflate %.1f ms, member table %.1f ms, write of %.0f MB %.1f ms' % (
+                n / 1e6, (t1 - t0) * 1e3, (t2 - t1) * 1e3, len(out) / 1e6, (time.perf_counter() - t2) * 1e3), file=sys.stderr)
 
     def _emit_chunks(self, data, at, n):
         if self._engine is not None and n >= self.DEVICE_MIN:      # (any length: a call's last member is as long as what is left)

@@ -372,22 +372,29 @@ public:
 
 // The caller-side phases (harmonise, statSTR's rows, the record writers) run their per-chunk jobs on ONE process-wide pool
 // instead of threads made and joined per call (16-32 threads, twice per batch in the writers: ~1-2 ms per batch of
-// creation alone).  One job at a time (the lock): two callers at once take turns.
+// creation alone).  One job at a time (the lock): two callers at once take turns -- a writer thread's members, CRCs and
+// newline scans among them (a pool of their own was measured in round 6: dumpSTR --zip no faster, level 1 5 % slower).
+struct SharedPool {
+    WorkerPool* pool = new WorkerPool;      // (never destroyed: no join of parked threads at process exit)
+    std::mutex* mu = new std::mutex;
+    pid_t owner = getpid();
+    void run(int nt, const std::function<void()>& job) {
+        if (nt <= 1) {
+            job();
+            return;
+        }
+        if (getpid() != owner) {     // a forked child: the parent's threads do not exist here -- a pool and a lock of its own
+            pool = new WorkerPool;
+            mu = new std::mutex;
+            owner = getpid();
+        }
+        std::lock_guard<std::mutex> g(*mu);
+        pool->run(nt, job);
+    }
+};
 static void run_on_caller_pool(int nt, const std::function<void()>& job) {
-    static WorkerPool* pool = new WorkerPool;      // (never destroyed: no join of parked threads at process exit)
-    static std::mutex* mu = new std::mutex;
-    static pid_t owner = getpid();
-    if (nt <= 1) {
-        job();
-        return;
-    }
-    if (getpid() != owner) {     // a forked child: the parent's threads do not exist here -- a pool and a lock of its own
-        pool = new WorkerPool;
-        mu = new std::mutex;
-        owner = getpid();
-    }
-    std::lock_guard<std::mutex> g(*mu);
-    pool->run(nt, job);
+    static SharedPool* sp = new SharedPool;
+    sp->run(nt, job);
 }
 
 struct Source {
@@ -3963,6 +3970,106 @@ extern "C" __attribute__((visibility("hidden"))) void trk_member_crc32(const voi
 }
 
 extern "C" {
+
+static bool plain_digits(const char* p, const char* e, int64_t* v) {
+    if (p == e || e - p > 18) return false;
+    int64_t x = 0;
+    for (; p < e; ++p) {
+        if (*p < '0' || *p > '9') return false;
+        x = x * 10 + (*p - '0');
+    }
+    *v = x;
+    return true;
+}
+
+int64_t trk_text_record_places(const void* text, size_t n, const int64_t* nl, size_t n_nl, int64_t* out, size_t cap) {
+    const char* t = static_cast<const char*>(text);
+    int64_t k = 0;
+    size_t pos = 0;
+    const char* prev = nullptr;
+    size_t prev_len = 0;
+    for (size_t i = 0; i <= n_nl && pos < n; ++i) {
+        const size_t e = i < n_nl ? (size_t)nl[i] : n;          // the line is [pos, e)
+        if (e > pos && t[pos] != '#') {
+            if ((size_t)k < cap) {
+                int64_t* row = out + (size_t)k * 8;
+                // the first eight columns: col[c] begins at b[c] and ends at b[c + 1] - 1
+                const char* b[9];
+                int nc = 0;
+                const char* q = t + pos;
+                const char* const le = t + e;
+                b[0] = q;
+                while (nc < 8) {
+                    const char* tab = static_cast<const char*>(memchr(q, '\t', (size_t)(le - q)));
+                    ++nc;
+                    if (!tab) {
+                        b[nc] = le + 1;
+                        break;
+                    }
+                    b[nc] = tab + 1;
+                    q = tab + 1;
+                }
+                const size_t clen = (size_t)(b[1] - 1 - b[0]);
+                row[0] = (int64_t)pos;
+                row[1] = (int64_t)std::min(e + 1, n);
+                row[2] = row[3] = -1;
+                row[4] = (int64_t)(b[0] - t);
+                row[5] = (int64_t)clen;
+                row[6] = !(prev && prev_len == clen && memcmp(prev, b[0], clen) == 0);
+                prev = b[0];
+                prev_len = clen;
+                int64_t p1 = 0;
+                bool odd = nc < 4 || !plain_digits(b[1], b[2] - 1, &p1);
+                if (!odd) {
+                    for (const char* r = b[3]; r < b[4] - 1; ++r) odd |= (unsigned char)*r >= 0x80;
+                }
+                if (!odd) {
+                    const int64_t beg = p1 - 1;
+                    int64_t end = beg + (int64_t)(b[4] - 1 - b[3]);
+                    if (nc >= 8) {                 // INFO: the first item that begins with END=
+                        const char* it = b[7];
+                        const char* const ie = b[8] - 1;
+                        while (it <= ie) {
+                            const char* semi = static_cast<const char*>(memchr(it, ';', (size_t)(ie - it)));
+                            const char* const item_end = semi ? semi : ie;
+                            if (item_end - it >= 4 && memcmp(it, "END=", 4) == 0) {
+                                int64_t ev = 0;
+                                if (plain_digits(it + 4, item_end, &ev)) {
+                                    if (ev > beg) end = ev;
+                                } else {
+                                    odd = true;    // (whatever python's int() makes of it: the caller's)
+                                }
+                                break;
+                            }
+                            if (!semi) break;
+                            it = semi + 1;
+                        }
+                    }
+                    row[2] = beg;
+                    row[3] = std::max(end, beg + 1);
+                }
+                row[7] = odd;
+                if (odd) row[2] = row[3] = -1;
+            }
+            ++k;
+        }
+        pos = e + 1;
+    }
+    return k;
+}
+
+int64_t trk_bgzf_member_offsets(const void* data, size_t n, uint64_t* out, size_t cap) {
+    const uint8_t* d = static_cast<const uint8_t*>(data);
+    size_t pos = 0;
+    int64_t k = 0;
+    while (pos < n) {
+        if (n - pos < 18 || d[pos] != 0x1f || d[pos + 1] != 0x8b || d[pos + 12] != 'B' || d[pos + 13] != 'C') return -1;
+        if ((size_t)k < cap) out[k] = pos;
+        ++k;
+        pos += ((size_t)d[pos + 16] | ((size_t)d[pos + 17] << 8)) + 1;
+    }
+    return pos == n ? k : -1;
+}
 
 int64_t trk_text_newlines(const void* text, size_t n, int64_t* out, size_t cap) {
     if (!text || !n) return 0;

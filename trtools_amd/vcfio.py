@@ -834,6 +834,8 @@ class VCFWriter:
         self._fh.write('\n'.join(lines + [t._chrom_line]) + '\n')
         self._wrote_header = True
 
+    NOTE_NATIVE_MIN = 1 << 20     # bytes of a block from which its record places are found by libtrk
+
     def _note_block(self, data, at):
         """``_note`` for a block of the batch writer (a memoryview of ~150 MB): the newlines by libtrk (memchr on its worker
         pool), then the first eight columns of every line -- a slice of the line's head, never the sample columns."""
@@ -842,7 +844,7 @@ class VCFWriter:
         from .tabix import record_interval
         lib = _native_lib()
         n = len(data)
-        if lib is None or n < (1 << 20):
+        if lib is None or n < self.NOTE_NATIVE_MIN:
             return self._note(bytes(data), at)
         lib.trk_text_newlines.restype = ctypes.c_int64
         lib.trk_text_newlines.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
@@ -854,29 +856,29 @@ class VCFWriter:
             if got <= cap:
                 break
             cap = got
-        ends = nl[:got].tolist()
-        if not ends or ends[-1] != n - 1:
-            ends.append(n)                       # (a last line without its newline)
-        recs, pos = self._recs, 0
+        # ... then the places and intervals of the record lines, by libtrk as well (a loop over a block's 1 700 lines here
+        # held the interpreter's lock for 8 ms per block -- a third of the writer thread's time with the members made on the
+        # device, and time the caller's thread waited for the lock)
+        lib.trk_text_record_places.restype = ctypes.c_int64
+        lib.trk_text_record_places.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                               ctypes.c_void_p, ctypes.c_size_t]
+        cap = got + 1
+        rows = np.empty((cap, 8), dtype=np.int64)
+        k = int(lib.trk_text_record_places(arr.ctypes.data, n, nl.ctypes.data, got, rows.ctypes.data, cap))
+        rows = rows[:k]
         mv = memoryview(data)
-        for e in ends:
-            if e > pos and mv[pos] != 35:        # '#'
-                head = bytes(mv[pos:min(e, pos + 1024)])
-                t = 0
-                for _ in range(8):
-                    t = head.find(b'\t', t) + 1
-                    if t == 0:
-                        break
-                if t == 0 and e - pos > len(head):          # the eight columns are longer than a kilobyte
-                    head = bytes(mv[pos:e])
-                    t = 0
-                    for _ in range(8):
-                        t = head.find(b'\t', t) + 1
-                        if t == 0:
-                            break
-                chrom, beg, end = record_interval(head[:t - 1] if t else head)
-                recs.append((chrom, beg, end, at + pos, at + min(e + 1, n)))
-            pos = e + 1
+        names = []
+        for r in np.flatnonzero(rows[:, 6]).tolist():              # where the sequence changes: its name
+            names.append(bytes(mv[rows[r, 4]:rows[r, 4] + rows[r, 5]]).decode())
+        for r in np.flatnonzero(rows[:, 7]).tolist():              # a head the scanner leaves to this side
+            e = int(rows[r, 1])
+            if e > int(rows[r, 0]) and mv[e - 1] == 10:
+                e -= 1
+            _, rows[r, 2], rows[r, 3] = record_interval(bytes(mv[rows[r, 0]:e]))
+        which = np.cumsum(rows[:, 6]) - 1                          # index into names
+        rows[:, 0] += at
+        rows[:, 1] += at
+        self._recs.append((names, np.column_stack((which, rows[:, 2], rows[:, 3], rows[:, 0], rows[:, 1]))))
 
     def _note(self, data, at):
         """The record lines of ``data`` (bytes-like, whole lines), which will lie at byte ``at`` of the text."""
@@ -927,6 +929,9 @@ class VCFWriter:
         self._drain()
         if not self._wrote_header:
             self._header()
+        import sys
+        import time
+        timing = bool(_knobs.lab('TRK_WRITE_TIMING'))
         raw = getattr(self._fh, 'buffer', None)
         if raw is not None:                      # text file: flush what the text layer holds, then the raw bytes
             self._fh.flush()
@@ -936,11 +941,13 @@ class VCFWriter:
             at = self._fh.text_bytes
 
             def job():
+                t0 = time.perf_counter()
                 self._note_block(block, at)     # (on the writer thread, beside the caller's next batch)
+                t1 = time.perf_counter()
                 self._fh.write(block)
-        if _knobs.lab('TRK_WRITE_TIMING'):
-            import sys
-            import time
+                if timing:
+                    print('[writer] places noted in %.1f ms, members made and written in %.1f ms' % ((t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3), file=sys.stderr)
+        if timing:
             inner = job
 
             def job():
@@ -972,8 +979,14 @@ class VCFWriter:
         from . import tabix
         tb = tabix.TabixBuilder(self.path)
         vo = self._fh.voffset
-        for chrom, beg, end, a, b in self._recs:
-            tb.add(chrom, beg, end, vo(a), vo(b))
+        for rec in self._recs:
+            if len(rec) == 2:                    # a block of the batch writer: (sequence names, rows)
+                names, rows = rec
+                for w, beg, end, a, b in rows.tolist():
+                    tb.add(names[w], beg, end, vo(a), vo(b))
+            else:
+                chrom, beg, end, a, b = rec
+                tb.add(chrom, beg, end, vo(a), vo(b))
         idx = tb.finish()
         tabix.write(idx, self.path + '.tbi')
         self.wrote_index = True
