@@ -1,5 +1,5 @@
 """trk_deflate_bgzf (include/trk.h; round 6): BGZF members DEFLATED on the device.  The requirement: every member is a gzip
-member with the 'BC' field whose stream zlib inflates to the member's 0xff00 bytes of text, with the right CRC-32 and
+member with the 'BC' field whose stream zlib inflates to the member's text (16 KB: TRK_DEFLATE_MEMBER), with the right CRC-32 and
 ISIZE -- checked on VCF text, runs, random bytes (stored members), every length around the member size, and through the
 native reader.  Beyond it: the payload equals tests/deflate_model.py's stream byte for byte (the kernel's line-by-line
 model), so that a difference names the stage that went wrong."""
@@ -16,6 +16,7 @@ from helpers import GOLDEN
 from test_vcfnative_hook import _synthetic
 
 pytestmark = pytest.mark.gpu
+COUNTS = {'cases': 0, 'members': 0, 'bytes': 0, 'model': 0}
 
 
 @pytest.fixture(scope='module')
@@ -24,6 +25,9 @@ def eng():
     e = Engine(0, reserve_pair_gb=0)
     yield e
     e.close()
+    if COUNTS['cases']:
+        print("\n[device deflate fuzz] %(cases)d texts, %(members)d members, %(bytes)d bytes: every member inflated by zlib, "
+              "%(model)d compared with the model byte for byte" % COUNTS)
 
 
 def _members(raw):
@@ -137,3 +141,48 @@ def test_dumpstr_zip_with_the_members_made_on_the_device(tmp_path):
     idx = tabix.TabixIndex.load(dev + '.tbi')
     scan = tabix.build(dev, str(tmp_path / 'scan.tbi'))
     assert (idx.names, idx.bins, idx.linear, idx.meta) == (scan.names, scan.bins, scan.linear, scan.meta)
+
+
+# ---- random texts (hypothesis): whatever the text, zlib gives it back and the first members equal the model's -----------
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+_SCALE = int(os.environ.get('TRK_PROPERTY_SCALE', '0'))       # k: a one-off campaign, k times the examples, fresh seeds
+
+
+def _random_text(seed, pieces, alphabet, n_words, around):
+    """Text made of a small vocabulary of random words (so that matches of every length and distance occur), runs of one
+    byte, periodic stretches and noise; cut to a length around a multiple of the member size."""
+    rng = np.random.default_rng(seed)
+    words = [bytes(rng.integers(0, alphabet, size=int(rng.integers(1, 40)), dtype=np.uint8) + (48 if alphabet <= 64 else 0))
+             for _ in range(n_words)]
+    out = bytearray()
+    want = around * dm.MEMBER + int(rng.integers(-70, 70))
+    while len(out) < max(want, 1):
+        kind = int(rng.integers(0, pieces))
+        if kind == 0:
+            out += bytes([int(rng.integers(0, 256))]) * int(rng.integers(1, 700))                    # a run
+        elif kind == 1:
+            out += words[int(rng.integers(0, n_words))][:int(rng.integers(1, 17))] * int(rng.integers(2, 60))   # a period
+        elif kind == 2:
+            out += bytes(rng.integers(0, 256, size=int(rng.integers(1, 300)), dtype=np.uint8))       # noise
+        else:
+            for _ in range(int(rng.integers(1, 200))):
+                out += words[int(rng.integers(0, n_words))]
+    return bytes(out[:max(want, 1)])
+
+
+@settings(max_examples=40 * max(_SCALE, 1), deadline=None, derandomize=_SCALE == 0, database=None, suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(0, 2 ** 31), pieces=st.integers(3, 8), alphabet=st.sampled_from([2, 4, 10, 64, 256]),
+       n_words=st.integers(1, 400), around=st.integers(0, 5))
+def test_random_texts(eng, seed, pieces, alphabet, n_words, around):
+    text = _random_text(seed, pieces, alphabet, n_words, around)
+    raw = bytes(eng.deflate_bgzf(text))
+    ms = _members(raw)                                      # (inflates every member, checks CRC-32 and ISIZE)
+    assert b''.join(t for t, _ in ms) == text
+    assert all(len(t) == dm.MEMBER for t, _ in ms[:-1])
+    for k in {0, len(ms) - 1}:                              # the first and the last (short) member against the model
+        assert ms[k][1] == dm.deflate_member(ms[k][0]), (seed, pieces, alphabet, n_words, around, k)
+        COUNTS['model'] += 1
+    COUNTS['cases'] += 1
+    COUNTS['members'] += len(ms)
+    COUNTS['bytes'] += len(text)
