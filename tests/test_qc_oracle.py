@@ -96,3 +96,43 @@ def test_product_host_logic_with_the_oracle_behind_the_compute_seam(case):
     assert got['n_alleles'] == want['diffref_hist']['n']
     np.testing.assert_allclose(got['sum_diff_unit'], want['diffref_hist']['sum'], rtol=1e-9, atol=1e-6)
     np.testing.assert_allclose(got['sum_diff_bp'], want['diffref_bias']['sum_diffs'], rtol=1e-9, atol=1e-6)
+
+
+def _same(a, b):
+    assert a.keys() == b.keys()
+    for k in a:
+        x, y = a[k], b[k]
+        if isinstance(x, np.ndarray) or isinstance(y, np.ndarray) or (isinstance(x, list) and x and isinstance(x[0], float)):
+            assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True), k
+        else:
+            assert x == y, k
+
+
+@pytest.mark.parametrize('case', [c for c in CASES if c['name'] in ('many_samples_subset_ignore', 'multi_chrom', 'gangstr_ignore',
+                                                                     'few_samples', 'popstr_no_quality')],
+                         ids=lambda c: c['name'])
+@pytest.mark.parametrize('extra', [dict(), dict(period=2), dict(numrecords=7), dict(period=4, numrecords=3)],
+                         ids=['all', 'period 2', 'seven records', 'period 4, three records'])
+def test_the_batch_road_equals_the_record_objects(case, extra):
+    """qc_reductions a batch at a time (native reader -> native batch harmoniser -> the device passes over the batch's
+    tables) against the loop over record objects it replaced (TRK_QC_BATCH=0): every accumulator the same, bit for bit --
+    with --period (batches it cuts go through the record objects) and --numrecords (nothing read beyond them)."""
+    from helpers import lab_env
+    from oracle_compute import OracleCompute
+    from trtools_amd import runtime
+    from trtools_amd.qcSTR import reductions
+    kw = dict(vcftype=case['vcftype'], samples=os.path.join(GOLD, case['samples']) if case['samples'] else None,
+              quality=case['quality'], quality_ignore_no_call=case['ignore_no_call'], batch_loci=5, **extra)
+    old = runtime.set_compute(OracleCompute())
+    try:
+        got = reductions.qc_reductions(os.path.join(GOLD, case['vcf']), **kw)
+        road = dict(reductions.LAST_RUN)
+        with lab_env(TRK_QC_BATCH='0'):
+            want = reductions.qc_reductions(os.path.join(GOLD, case['vcf']), **kw)
+            assert reductions.LAST_RUN['path'] == 'per-record'
+    finally:
+        runtime.set_compute(old)
+    assert road['path'] in ('batch', 'mixed') and road['batches'] > 0, road
+    if 'period' not in extra:
+        assert road['path'] == 'batch' and road['fallback_batches'] == 0, road
+    _same(got, want)
