@@ -630,7 +630,7 @@ hipError_t launch_deflate(const uint8_t* text, int64_t n, uint8_t* slots, uint32
     const int n_members = (int)((n + DF_MEMBER - 1) / DF_MEMBER);
     if (n_members < 1) return hipSuccess;
     DeflArgs a{text, n, n_members, slots, sizes, tok};
-    // six workgroups of four members per CU
+    // five workgroups of four members per CU (DF_OCC)
     const int wgs = min((n_members + DF_WAVES - 1) / DF_WAVES, n_cu * DF_WGS_PER_CU);
     hipLaunchKernelGGL(k_deflate_bgzf, dim3(wgs), dim3(WAVE * DF_WAVES), 0, stream, a);
     hipLaunchKernelGGL(k_deflate_scan, dim3(1), dim3(1024), 0, stream, sizes, n_members, off);
