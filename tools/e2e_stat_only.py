@@ -9,6 +9,11 @@ ns = argparse.Namespace(vcf=path, out='/tmp/e2e/stat', vcftype='hipstr', samples
                         plot_afreq=False, region=None, thresh=True, afreq=True, acount=True, hwep=True, het=True,
                         entropy=True, mean=True, mode=True, var=True, numcalled=True, use_length=False, precision=4,
                         nalleles=True, nalleles_thresh=0.01, only_passing=False)
+if os.environ.get('E2E_BATCH_CELLS'):        # experiment: smaller batches (and, E2E_HOOK_RUN_MB, smaller runs of members)
+    statSTR.BATCH_CELLS = int(os.environ['E2E_BATCH_CELLS'])
+if os.environ.get('E2E_HOOK_RUN_MB'):
+    from trtools_amd import _lib as _L1
+    _L1.set_option('TRK_VCF_HOOK_RUN_MB', int(os.environ['E2E_HOOK_RUN_MB']))
 for i in range(4):
     t = time.time(); statSTR.main(ns); print("run %d: %.3f s" % (i, time.time() - t), flush=True)
 from trtools_amd import _lib as _L

@@ -1672,7 +1672,9 @@ int trk_vcf_read_batch(trk_vcf* v, int max_records, int max_ploidy, trk_vcf_batc
             const double tf = timing ? now() : 0.0;
             // (with an inflate hook: runs of ~4500 members -- on the device a member is one wave's serial work of ~8 ms
             // whatever else runs, and the chip holds 4096 of them at a time: tools/inflate_probe.py)
-            if (!v->src.fill(v->buf, hooked ? (288u << 20) : (16u << 20), v->err)) return 1;
+            size_t hook_run = 288u << 20;
+            if (const char* e = trk_opt("TRK_VCF_HOOK_RUN_MB")) hook_run = (size_t)std::max(1L, atol(e)) << 20;      // (lab: the run's size)
+            if (!v->src.fill(v->buf, hooked ? hook_run : (16u << 20), v->err)) return 1;
             if (timing) t_fill += now() - tf;
             continue;
         }
