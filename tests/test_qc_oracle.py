@@ -108,11 +108,14 @@ def _same(a, b):
             assert x == y, k
 
 
-@pytest.mark.parametrize('case', [c for c in CASES if c['name'] in ('many_samples_subset_ignore', 'multi_chrom', 'gangstr_ignore',
-                                                                     'few_samples', 'popstr_no_quality')],
-                         ids=lambda c: c['name'])
-@pytest.mark.parametrize('extra', [dict(), dict(period=2), dict(numrecords=7), dict(period=4, numrecords=3)],
-                         ids=['all', 'period 2', 'seven records', 'period 4, three records'])
+_ROADS = [('many_samples_subset_ignore', dict()), ('many_samples_subset_ignore', dict(period=2)),
+          ('many_samples_subset_ignore', dict(period=4, numrecords=3)), ('multi_chrom', dict()), ('multi_chrom', dict(numrecords=7)),
+          ('gangstr_ignore', dict(numrecords=60)), ('gangstr_ignore', dict(period=2)), ('few_samples', dict(numrecords=7)),
+          ('popstr_no_quality', dict(numrecords=40))]
+
+
+@pytest.mark.parametrize('case, extra', [(next(c for c in CASES if c['name'] == n), e) for n, e in _ROADS],
+                         ids=['%s %s' % (n, ' '.join('%s=%s' % kv for kv in e.items()) or 'all') for n, e in _ROADS])
 def test_the_batch_road_equals_the_record_objects(case, extra):
     """qc_reductions a batch at a time (native reader -> native batch harmoniser -> the device passes over the batch's
     tables) against the loop over record objects it replaced (TRK_QC_BATCH=0): every accumulator the same, bit for bit --
