@@ -329,7 +329,6 @@ def _flush(records, outfile, vec, sample_filter, pheno_std, non_major_cutoff, be
 # what the last perform_gwas call ran through (the tests and tools/e2e_assoc_only.py read it): 'batch', 'mixed' (some
 # batches went through the record objects) or 'per-record'
 LAST_RUN = {}
-_MOTIF_KEY = {'gangstr': 'RU', 'advntr': 'RU', 'eh': 'RU', 'popstr': 'Motif'}
 
 
 def _batch_path_ok(reader, vcftype, region, beagle_dosages, period_check):
@@ -339,23 +338,6 @@ def _batch_path_ok(reader, vcftype, region, beagle_dosages, period_check):
     from ..vcfnative import NativeVCFReader, VT_CODES
     return (isinstance(reader, NativeVCFReader) and vcftype.name in VT_CODES and not beagle_dosages and not period_check and
             len(reader.samples) > 0 and _knobs.lab('TRK_ASSOC_BATCH', '1') != '0')
-
-
-def _batch_motifs(rb, hz, vcftype):
-    """TRRecord.motif of every record of the batch, as the harmonisers derive it (utils/tr_harmonizer.py): HipSTR / LongTR
-    infer it from the trimmed reference allele -- sliced by the leading flank once more, as the reference does
-    (tr_harmonizer.py:397) -- and INFO/PERIOD; the other callers carry it in INFO."""
-    if vcftype.name in ('hipstr', 'longtr'):
-        lead = (hz.tr_pos - hz.pos).tolist()
-        per = hz.period.tolist()
-        return [utils.InferRepeatSequence(ref[ld:], p) for ref, ld, p in zip(hz.ref_keys(), lead, per)]
-    key = _MOTIF_KEY[vcftype.name] + '='
-    out = []
-    for l in range(rb.n):
-        info = rb.head_fields(l)[7]
-        val = next(item[len(key):] for item in info.split(';') if item.startswith(key))
-        out.append(val.upper())
-    return out
 
 
 def _run_batches(reader, vcftype, region, shard, vec, sample_filter, pheno_std, non_major_cutoff, batch_loci):
@@ -426,7 +408,7 @@ def _run_batches(reader, vcftype, region, shard, vec, sample_filter, pheno_std, 
             rb.release_device()
         off = hz.allele_off.tolist()
         alen = hz.allele_len.tolist()
-        chroms, poss, motifs = rb.chrom_column(), hz.tr_pos.tolist(), _batch_motifs(rb, hz, vcftype)
+        chroms, poss, motifs = rb.chrom_column(), hz.tr_pos.tolist(), rb.motifs(hz, vcftype.name)
         lens = [alen[off[l]:off[l + 1]] for l in range(rb.n)]
         facts = [_Facts(chroms[l], poss[l], motifs[l], lens[l]) for l in range(rb.n)]
         _write_rows(shard, facts, off, lens, res, pheno_std, non_major_cutoff)

@@ -108,7 +108,6 @@ def _run_batches(compute, invcf, vcftype, sample_index, use_q, ignore, period, n
     """The main loop a batch of records at a time: native reader -> native batch harmoniser -> the device passes.  A batch
     the harmoniser leaves records of to this side, one that --period cuts, or one with a record whose FORMAT lacks the
     quality field goes through the record objects (``_flush``).  Returns the number of records taken."""
-    from ..associaTR.associaTR import _batch_motifs
     qkey = _QUALITY_KEY.get(vcftype.name) if use_q else None
     if qkey is not None:
         invcf.select_format(qkey)
@@ -121,7 +120,7 @@ def _run_batches(compute, invcf, vcftype, sample_index, use_q, ignore, period, n
             break
         hz = rb.harmonize(vcftype.name)
         LAST_RUN['batches'] += 1
-        motifs = None if hz.n_python else _batch_motifs(rb, hz, vcftype)
+        motifs = None if hz.n_python else rb.motifs(hz, vcftype.name)
         whole = (not hz.n_python and (period is None or all(len(m) == period for m in motifs)) and
                  (qkey is None or all(qkey in cols for cols in rb.format_columns())))
         if not whole:

@@ -325,6 +325,26 @@ class RawBatch:
                 out.append(t.decode().split(':') if t else [])
         return out
 
+    _MOTIF_KEY = {'gangstr': 'RU', 'advntr': 'RU', 'eh': 'RU', 'popstr': 'Motif'}
+
+    def motifs(self, hz, vcftype):
+        """TRRecord.motif of every record of the batch, as the harmonisers derive it (utils/tr_harmonizer.py): HipSTR / LongTR
+        infer it from the trimmed reference allele -- sliced by the leading flank once more, as the reference does
+        (tr_harmonizer.py:397) -- and INFO/PERIOD; the other callers carry it in INFO.  ``hz``: this batch's harmonised
+        tables, ``vcftype``: the caller's name."""
+        from .utils import utils
+        if vcftype in ('hipstr', 'longtr'):
+            lead = (hz.tr_pos - hz.pos).tolist()
+            per = hz.period.tolist()
+            return [utils.InferRepeatSequence(ref[ld:], p) for ref, ld, p in zip(hz.ref_keys(), lead, per)]
+        key = self._MOTIF_KEY[vcftype] + '='
+        out = []
+        for l in range(self.n):
+            info = self.head_fields(l)[7]
+            val = next(item[len(key):] for item in info.split(';') if item.startswith(key))
+            out.append(val.upper())
+        return out
+
     def head_fields(self, l):
         """The eight leading columns and the FORMAT column of record l as text."""
         b = self.b
